@@ -1,0 +1,623 @@
+"""CPU oracle (NumPy) for the cd_dynamax CDNLGSSM EKF / UKF / EKF-smoother hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``cd_dynamax_amd/`` may import this module; it is
+used by ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py``
+as the checker the HIP kernels are compared with.
+
+This is a restatement, batched over a leading trajectory axis N, of the reference algorithm
+(all paths relative to /root/reference):
+
+* ``src/continuous_discrete_nonlinear_gaussian_ssm/inference_ekf.py:46-148``  (_predict)
+* ``.../inference_ekf.py:153-199``  (_condition_on), ``:202-326`` (extended_kalman_filter)
+* ``.../inference_ekf.py:363-448``  (_smooth), ``:450-539`` (extended_kalman_smoother)
+* ``.../inference_ukf.py:45-89, 93-159, 162-203, 206-308``  (UKF)
+* ``src/utils/diffrax_utils.py:40-165``  (diffeqsolve wrapper: Dopri5, ConstantStepSize, dt0=0.01)
+* ``dynamax/utils/utils.py:202-211``  (psd_solve, symmetrize)
+* ``.../cdnlgssm_utils.py:38-83``  (LearnableLinear / LearnableLorenz63 drifts)
+
+Third-party arithmetic that is NOT under /root/reference and is restated from its published
+algorithm (pinned versions from ``hduq_cd_dynamax_requirements.txt``):
+
+* diffrax 0.4.0 -- ``Dopri5`` Butcher tableau (Dormand & Prince 1980), ``ConstantStepSize``
+  (next step = previous end + dt0), the integration loop's ``tnext = min(t0 + dt0, t1)`` start,
+  ``tprev = min(tprev, t1)`` and ``_clip_to_end`` (clip when ``tnext > t1 - tol``, tol = 1e-10 in
+  float64 / 1e-6 in float32), loop condition ``tprev < t1``.
+* jax 0.4.13 -- ``jnp.linalg.cholesky`` / ``cho_factor`` (lower, NaN on a non-positive pivot),
+  ``jnp.trace`` on a rank-3 array (traces axes 0 and 1).
+* tensorflow-probability 0.20.1 -- ``MultivariateNormalFullCovariance.log_prob``:
+  ``L = chol(S)`` (no jitter), ``-0.5*|L^-1 (y-mu)|^2 - sum(log diag L) - 0.5*m*log(2*pi)``.
+
+PARITY PINNING.  The JAX reference cannot be imported in the build container (no jax / diffrax /
+tfp).  The oracle is pinned by (tests/test_oracle.py):
+  1. the reference's own known-answer constants for the Dopri5 push-forward,
+     ``src/test_scripts/cdlgssm_test_filter_TRegular.py:59-60`` (reproduced in float32);
+  2. the reference's test equalities EKF(first, second) == UKF == CD Kalman filter on linear
+     models (``src/test_scripts/cdnlgssm_test_filter_linear_TRegular.py:314-324, 414-424``), checked
+     here against an independent closed-form (matrix-exponential / Van Loan) Kalman filter;
+  3. EKF smoother == closed-form RTS smoother on linear models
+     (``src/test_scripts/cdnlgssm_test_smoother_linear_TRegular.py:222-232``, soft in the reference).
+Nonlinear (Lorenz / MLP) outputs are NOT pinned by anything the reference ships ("parity unpinned"
+for those beyond the three items above); they are pinned to this fp64 restatement.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import numpy as np
+
+# --------------------------------------------------------------------------------------
+# Dormand-Prince 5(4) tableau (diffrax 0.4.0 ``Dopri5``; only the 5th-order solution is used
+# because the step-size controller is ``ConstantStepSize`` -- diffrax_utils.py:47)
+# --------------------------------------------------------------------------------------
+DOPRI5_A = (
+    (),
+    (1 / 5,),
+    (3 / 40, 9 / 40),
+    (44 / 45, -56 / 15, 32 / 9),
+    (19372 / 6561, -25360 / 2187, 64448 / 6561, -212 / 729),
+    (9017 / 3168, -355 / 33, 46732 / 5247, 49 / 176, -5103 / 18656),
+)
+DOPRI5_B = (35 / 384, 0.0, 500 / 1113, 125 / 192, -2187 / 6784, 11 / 84)
+
+
+# --------------------------------------------------------------------------------------
+# Drift registry.  f: [N,d] -> [N,d]; jac: [N,d] -> [N,d,d] (dF_i/dx_j);
+# divgrad: [N,d] -> [N,d], the vector  g_l = sum_i d^2 f_i / (dx_i dx_l)  that the reference's
+# "second order" mean term 0.5*jnp.trace(H_t @ P) reduces to (0.5 * P @ g), SURVEY.md section 0.5.
+# --------------------------------------------------------------------------------------
+class LinearDrift:
+    """f(x) = W x + b   (cdnlgssm_utils.py:50-61)."""
+
+    kind = "linear"
+
+    def __init__(self, weights, bias):
+        self.W = np.asarray(weights)
+        self.b = np.asarray(bias)
+
+    def cast(self, dtype):
+        return LinearDrift(self.W.astype(dtype), self.b.astype(dtype))
+
+    def f(self, x):
+        return x @ self.W.T + self.b
+
+    def jac(self, x):
+        return np.broadcast_to(self.W, x.shape[:-1] + self.W.shape).copy()
+
+    def divgrad(self, x):
+        return np.zeros_like(x)
+
+    def theta(self):
+        return np.concatenate([self.W.ravel(), self.b.ravel()]).astype(np.float64)
+
+
+class Lorenz63Drift:
+    """cdnlgssm_utils.py:63-83."""
+
+    kind = "lorenz63"
+
+    def __init__(self, sigma=10.0, rho=28.0, beta=8.0 / 3.0, dtype=np.float64):
+        self.dtype = dtype
+        self.sigma, self.rho, self.beta = (dtype(sigma), dtype(rho), dtype(beta))
+
+    def cast(self, dtype):
+        return Lorenz63Drift(self.sigma, self.rho, self.beta, dtype=dtype)
+
+    def f(self, x):
+        s, r, b = self.sigma, self.rho, self.beta
+        return np.stack(
+            [s * (x[..., 1] - x[..., 0]), x[..., 0] * (r - x[..., 2]) - x[..., 1], x[..., 0] * x[..., 1] - b * x[..., 2]],
+            axis=-1,
+        )
+
+    def jac(self, x):
+        s, r, b = self.sigma, self.rho, self.beta
+        F = np.zeros(x.shape + (3,), dtype=x.dtype)
+        F[..., 0, 0] = -s
+        F[..., 0, 1] = s
+        F[..., 1, 0] = r - x[..., 2]
+        F[..., 1, 1] = -1
+        F[..., 1, 2] = -x[..., 0]
+        F[..., 2, 0] = x[..., 1]
+        F[..., 2, 1] = x[..., 0]
+        F[..., 2, 2] = -b
+        return F
+
+    def divgrad(self, x):
+        return np.zeros_like(x)  # dF_ii/dx is constant
+
+    def theta(self):
+        return np.array([self.sigma, self.rho, self.beta], dtype=np.float64)
+
+
+class Lorenz96Drift:
+    """f_i = (x_{i+1} - x_{i-2}) x_{i-1} - x_i + F  (build-defined; not in the reference)."""
+
+    kind = "lorenz96"
+
+    def __init__(self, forcing=8.0, dtype=np.float64):
+        self.dtype = dtype
+        self.F = dtype(forcing)
+
+    def cast(self, dtype):
+        return Lorenz96Drift(self.F, dtype=dtype)
+
+    def f(self, x):
+        xp1 = np.roll(x, -1, axis=-1)
+        xm1 = np.roll(x, 1, axis=-1)
+        xm2 = np.roll(x, 2, axis=-1)
+        return (xp1 - xm2) * xm1 - x + self.F
+
+    def jac(self, x):
+        d = x.shape[-1]
+        J = np.zeros(x.shape + (d,), dtype=x.dtype)
+        for i in range(d):  # indices may coincide for tiny d, hence +=
+            J[..., i, (i + 1) % d] += x[..., (i - 1) % d]
+            J[..., i, (i - 2) % d] -= x[..., (i - 1) % d]
+            J[..., i, (i - 1) % d] += x[..., (i + 1) % d] - x[..., (i - 2) % d]
+            J[..., i, i] -= 1
+        return J
+
+    def divgrad(self, x):
+        return np.zeros_like(x)  # needs d >= 4; dF_ii/dx = 0
+
+    def theta(self):
+        return np.array([self.F], dtype=np.float64)
+
+
+class MLPDrift:
+    """f(x) = W3 tanh(W2 tanh(W1 x + b1) + b2) + b3 (2 hidden layers; build-defined stand-in for the
+    reference's NeuralNetDrift tutorial class, whose notebooks are absent from the mount)."""
+
+    kind = "mlp"
+
+    def __init__(self, W1, b1, W2, b2, W3, b3):
+        self.W1, self.b1, self.W2, self.b2, self.W3, self.b3 = (np.asarray(a) for a in (W1, b1, W2, b2, W3, b3))
+
+    def cast(self, dtype):
+        return MLPDrift(*(a.astype(dtype) for a in (self.W1, self.b1, self.W2, self.b2, self.W3, self.b3)))
+
+    def _fwd(self, x):
+        a1 = np.tanh(x @ self.W1.T + self.b1)
+        a2 = np.tanh(a1 @ self.W2.T + self.b2)
+        return a1, a2
+
+    def f(self, x):
+        _, a2 = self._fwd(x)
+        return a2 @ self.W3.T + self.b3
+
+    def jac(self, x):
+        a1, a2 = self._fwd(x)
+        d1 = 1 - a1 * a1  # [N,h1]
+        d2 = 1 - a2 * a2  # [N,h2]
+        # J = W3 diag(d2) W2 diag(d1) W1
+        B = self.W2[None] * d1[:, None, :]  # [N,h2,h1]
+        B = d2[:, :, None] * B
+        C = np.einsum("oh,nhk->nok", self.W3, B)  # [N,d,h1]
+        return np.einsum("nok,kj->noj", C, self.W1)
+
+    def divgrad(self, x):
+        # g_l = d/dx_l  sum_i J_ii(x); analytic: differentiate tr(W3 D2 W2 D1 W1).
+        a1, a2 = self._fwd(x)
+        d1 = 1 - a1 * a1
+        d2 = 1 - a2 * a2
+        dd1 = -2 * a1 * d1  # d(d1)/d(z1)
+        dd2 = -2 * a2 * d2
+        W1, W2, W3 = self.W1, self.W2, self.W3
+        # tr(J) = sum_{p,q} (W1 W3)_{q p}... write  tr = sum_{p,q} M_pq d2_p W2_pq d1_q,  M = (W1 @ W3).T -> M_pq = sum_i W3_ip W1_qi
+        M = (W1 @ W3).T  # [h2,h1]
+        G = M * W2  # [h2,h1]
+        # d tr / d z1_q (direct)  = sum_p G_pq d2_p dd1_q
+        # d tr / d z2_p = sum_q G_pq dd2_p d1_q ; z2 = W2 a1 + b2 -> dz2_p/dz1_q = W2_pq d1_q
+        t_direct = (d2 @ G) * dd1  # [N,h1]
+        s2 = dd2 * (d1 @ G.T)  # [N,h2]
+        t_chain = (s2 @ W2) * d1  # [N,h1]
+        return (t_direct + t_chain) @ W1  # [N,d]
+
+    def theta(self):
+        return np.concatenate([a.ravel() for a in (self.W1, self.b1, self.W2, self.b2, self.W3, self.b3)]).astype(np.float64)
+
+
+class Model:
+    """The pieces of ParamsCDNLGSSM the hot path touches (cdnlgssm_utils.py:88-209): drift, L, Qc,
+    linear emission h(x) = H x + bias (LearnableLinear), R, initial mean / covariance."""
+
+    def __init__(self, drift, L, Qc, H, bias, R, m0, P0):
+        self.drift = drift
+        self.L, self.Qc, self.H, self.bias, self.R, self.m0, self.P0 = (
+            np.asarray(a, dtype=np.float64) for a in (L, Qc, H, bias, R, m0, P0)
+        )
+        self.d = self.m0.shape[0]
+        self.m = self.H.shape[0]
+
+    def cast(self, dtype):
+        mdl = Model.__new__(Model)
+        mdl.drift = self.drift.cast(dtype)
+        for k in ("L", "Qc", "H", "bias", "R", "m0", "P0"):
+            setattr(mdl, k, getattr(self, k).astype(dtype))
+        mdl.d, mdl.m = self.d, self.m
+        return mdl
+
+
+# --------------------------------------------------------------------------------------
+# small dense linear algebra, batched over the leading axis, NaN-propagating like jax/LAPACK-on-XLA
+# --------------------------------------------------------------------------------------
+def symmetrize(A):
+    """dynamax/utils/utils.py:209-211."""
+    return 0.5 * (A + np.swapaxes(A, -1, -2))
+
+
+def cholesky_lower(A):
+    """Lower Cholesky, batched; a non-positive pivot yields NaN (jnp.linalg.cholesky semantics)."""
+    A = np.asarray(A)
+    n = A.shape[-1]
+    Lm = np.zeros_like(A)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        for j in range(n):
+            s = A[..., j, j] - np.sum(Lm[..., j, :j] ** 2, axis=-1)
+            piv = np.sqrt(s)  # NaN if s < 0
+            Lm[..., j, j] = piv
+            for i in range(j + 1, n):
+                s = A[..., i, j] - np.sum(Lm[..., i, :j] * Lm[..., j, :j], axis=-1)
+                Lm[..., i, j] = s / piv
+    return Lm
+
+
+def solve_lower(Lm, B):
+    """Solve L X = B (B: [..., n, k])."""
+    n = Lm.shape[-1]
+    X = np.zeros_like(B)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        for i in range(n):
+            s = B[..., i, :] - np.einsum("...j,...jk->...k", Lm[..., i, :i], X[..., :i, :])
+            X[..., i, :] = s / Lm[..., i, i][..., None]
+    return X
+
+
+def solve_upper_from_lower(Lm, B):
+    """Solve L^T X = B."""
+    n = Lm.shape[-1]
+    X = np.zeros_like(B)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        for i in range(n - 1, -1, -1):
+            s = B[..., i, :] - np.einsum("...j,...jk->...k", Lm[..., i + 1 :, i], X[..., i + 1 :, :])
+            X[..., i, :] = s / Lm[..., i, i][..., None]
+    return X
+
+
+def psd_solve(A, B, diagonal_boost=1e-9):
+    """dynamax/utils/utils.py:202-207: symmetrize + boost*I, Cholesky (lower), cho_solve."""
+    dtype = A.dtype
+    n = A.shape[-1]
+    A = symmetrize(A) + dtype.type(diagonal_boost) * np.eye(n, dtype=dtype)
+    Lm = cholesky_lower(A)
+    return solve_upper_from_lower(Lm, solve_lower(Lm, B))
+
+
+def mvn_logpdf(y, mu, S):
+    """TFP MultivariateNormalFullCovariance(mu, S).log_prob(y) (inference_ekf.py:286, inference_ukf.py:197)."""
+    dtype = S.dtype
+    m = S.shape[-1]
+    Lm = cholesky_lower(S)
+    z = solve_lower(Lm, (y - mu)[..., None])[..., 0]
+    with np.errstate(invalid="ignore", divide="ignore"):
+        logdet_half = np.sum(np.log(np.diagonal(Lm, axis1=-2, axis2=-1)), axis=-1)
+    return dtype.type(-0.5) * np.sum(z * z, axis=-1) - logdet_half - dtype.type(0.5 * m * math.log(2 * math.pi))
+
+
+# --------------------------------------------------------------------------------------
+# diffeqsolve (diffrax_utils.py:40-165, ODE branch; diffrax 0.4.0 integrate loop)
+# --------------------------------------------------------------------------------------
+def _tree_axpy(y0, ks, coefs, dtype):
+    """y0 + sum_j coefs[j] * ks[j]: the increment is summed first and added to y0 once (diffrax's
+    ``y0 + a_lower[i] @ ks`` form), which is what keeps the float32 push-forward within 1-2 ulp of exact."""
+    out = []
+    for c, comp0 in enumerate(y0):
+        acc = None
+        for kj, a in zip(ks, coefs):
+            if a != 0.0:
+                term = dtype.type(a) * kj[c]
+                acc = term if acc is None else acc + term
+        out.append(comp0 + acc)
+    return tuple(out)
+
+
+def dopri5_step(rhs, y, dt):
+    """One Dopri5 step of size dt (dt: [N]); k_j = dt * f(stage_j) (diffrax ODETerm.vf_prod)."""
+    dtype = y[0].dtype
+    ks = []
+    for i in range(6):
+        yi = y if i == 0 else _tree_axpy(y, ks, DOPRI5_A[i], dtype)
+        fi = rhs(yi)
+        ks.append(tuple(dt.reshape((-1,) + (1,) * (c.ndim - 1)) * c for c in fi))
+    return _tree_axpy(y, ks, DOPRI5_B, dtype)
+
+
+def diffeqsolve(rhs, t0, t1, y0, dt0=0.01, max_steps=100000, count_steps=None):
+    """Integrate the autonomous ODE y' = rhs(y) from t0 to t1 (both [N]) with fixed-step Dopri5.
+
+    Mirrors diffrax 0.4.0: tprev=t0, tnext=min(t0+dt0, t1); while tprev < t1: step(tprev->tnext);
+    tprev=min(tnext, t1); tnext=clip_to_end(tprev + dt0).  Under vmap the reference runs until every
+    lane has finished with finished lanes masked; same here.  ``reverse=True`` solves in the
+    reference integrate s from 0 to t1-t0 with rhs negated (diffrax_utils.py:13-25,131-135); for the
+    autonomous right-hand sides of this path the caller passes t0=0, t1=t1-t0 and the negated rhs.
+    """
+    dtype = y0[0].dtype
+    tol = dtype.type(1e-10 if dtype == np.float64 else 1e-6)
+    t0 = np.asarray(t0, dtype=dtype)
+    t1 = np.asarray(t1, dtype=dtype)
+    dt0 = dtype.type(dt0)
+    tprev = t0.copy()
+    tnext = np.minimum(t0 + dt0, t1)
+    y = tuple(c.copy() for c in y0)
+    nsteps = np.zeros(t0.shape, dtype=np.int64)
+    for _ in range(int(max_steps)):
+        active = tprev < t1
+        if not active.any():
+            break
+        dt = np.where(active, tnext - tprev, dtype.type(0))
+        ynew = dopri5_step(rhs, y, dt)
+        y = tuple(np.where(active.reshape((-1,) + (1,) * (c.ndim - 1)), cn, c) for cn, c in zip(ynew, y))
+        nsteps += active
+        tprev_new = np.minimum(tnext, t1)
+        tnext_new = tnext + dt0
+        tnext_new = np.where(tnext_new > t1 - tol, t1, tnext_new)
+        tprev = np.where(active, tprev_new, tprev)
+        tnext = np.where(active, tnext_new, tnext)
+    if count_steps is not None:
+        count_steps.append(nsteps)
+    return y
+
+
+# --------------------------------------------------------------------------------------
+# EKF
+# --------------------------------------------------------------------------------------
+def _LQL(mdl):
+    return mdl.L @ mdl.Qc @ mdl.L.T
+
+
+def ekf_predict(mdl, m, P, t0, t1, state_order="second", dt0=0.01, max_steps=100000, cov_rescaling=1.0):
+    """inference_ekf.py:46-148."""
+    dtype = m.dtype
+    LQL = _LQL(mdl)
+    drift = mdl.drift
+
+    if state_order == "zeroth":
+        (m1,) = diffeqsolve(lambda y: (drift.f(y[0]),), t0, t1, (m,), dt0, max_steps)
+        dt = (np.asarray(t1, dtype=dtype) - np.asarray(t0, dtype=dtype))[:, None, None]
+        Lr = mdl.L * dtype.type(cov_rescaling)
+        return m1, P + np.sqrt(dt) * (Lr @ mdl.Qc @ Lr.T)
+
+    def rhs(y):
+        mm, PP = y
+        F = drift.jac(mm)
+        dm = drift.f(mm)
+        if state_order == "second":
+            # 0.5*jnp.trace(H_t @ P) with H_t[i,j,k] -> 0.5 * sum_k g_k P[k,:]   (inference_ekf.py:111-114)
+            dm = dm + dtype.type(0.5) * np.einsum("nk,nkl->nl", drift.divgrad(mm), PP)
+        elif state_order != "first":
+            raise ValueError(f"EKF hyperparams.state_order = {state_order} not implemented yet")
+        dP = F @ PP + PP @ np.swapaxes(F, -1, -2) + LQL
+        return dm, dP
+
+    return diffeqsolve(rhs, t0, t1, (m, P), dt0, max_steps)
+
+
+def ekf_condition_on(mdl, m, P, y, num_iter=1):
+    """inference_ekf.py:153-199 with a linear emission h(x) = H x + bias."""
+    H, R, bias = mdl.H, mdl.R, mdl.bias
+    for _ in range(num_iter):
+        S = R + H @ P @ H.T
+        K = np.swapaxes(psd_solve(S, H @ P), -1, -2)
+        Pn = P - K @ S @ np.swapaxes(K, -1, -2)
+        mn = m + np.einsum("nij,nj->ni", K, y - (m @ H.T + bias))
+        m, P = mn, Pn
+    return m, symmetrize(P)
+
+
+def _t0_t1(t, dt_final, dtype):
+    """inference_ekf.py:235-250: t1 = [t[1:], t[-1] + dt_final]."""
+    t = np.asarray(t, dtype=dtype)
+    t1 = np.concatenate([t[:, 1:], t[:, -1:] + dtype.type(dt_final)], axis=1)
+    return t, t1
+
+
+def ekf_filter(
+    mdl: Model,
+    t,
+    y,
+    state_order: str = "second",
+    num_iter: int = 1,
+    dt0: float = 0.01,
+    dt_final: float = 1e-10,
+    max_steps: int = 100000,
+    cov_rescaling: float = 1.0,
+    dtype=np.float64,
+):
+    """extended_kalman_filter (inference_ekf.py:202-326), batched: t [N,T], y [N,T,m]."""
+    dtype = np.dtype(dtype)
+    mdl = mdl.cast(dtype)
+    y = np.asarray(y, dtype=dtype)
+    N, T, _ = y.shape
+    d = mdl.d
+    t0s, t1s = _t0_t1(t, dt_final, dtype)
+    ll = np.zeros(N, dtype=dtype)
+    pm = np.broadcast_to(mdl.m0, (N, d)).copy()
+    pP = np.broadcast_to(mdl.P0, (N, d, d)).copy()
+    out = {
+        "filtered_means": np.zeros((N, T, d), dtype),
+        "filtered_covariances": np.zeros((N, T, d, d), dtype),
+        "predicted_means": np.zeros((N, T, d), dtype),
+        "predicted_covariances": np.zeros((N, T, d, d), dtype),
+    }
+    for k in range(T):
+        yk = y[:, k]
+        S = mdl.H @ pP @ mdl.H.T + mdl.R
+        ll = ll + mvn_logpdf(yk, pm @ mdl.H.T + mdl.bias, S)
+        fm, fP = ekf_condition_on(mdl, pm, pP, yk, num_iter)
+        pm, pP = ekf_predict(mdl, fm, fP, t0s[:, k], t1s[:, k], state_order, dt0, max_steps, cov_rescaling)
+        out["filtered_means"][:, k] = fm
+        out["filtered_covariances"][:, k] = fP
+        out["predicted_means"][:, k] = pm
+        out["predicted_covariances"][:, k] = pP
+    out["marginal_loglik"] = ll
+    return out
+
+
+def ekf_smoother(mdl: Model, t, y, state_order="second", dt0=0.01, dt_final=1e-10, max_steps=100000, dtype=np.float64,
+                 filtered: Optional[dict] = None):
+    """extended_kalman_smoother (inference_ekf.py:450-539) + _smooth (:363-448), smooth_order='first'.
+
+    The filter inside the smoother runs with num_iter=1 (inference_ekf.py:489-495).
+    """
+    dtype = np.dtype(dtype)
+    if filtered is None:
+        filtered = ekf_filter(mdl, t, y, state_order, 1, dt0, dt_final, max_steps, dtype=dtype)
+    mdl = mdl.cast(dtype)
+    t = np.asarray(t, dtype=dtype)
+    fm, fP = filtered["filtered_means"], filtered["filtered_covariances"]
+    N, T, d = fm.shape
+    LQL = _LQL(mdl)
+    sm = np.zeros_like(fm)
+    sP = np.zeros_like(fP)
+    sm[:, -1] = fm[:, -1]
+    sP[:, -1] = fP[:, -1]
+    ms, Ps = fm[:, -1].copy(), fP[:, -1].copy()
+    drift = mdl.drift
+    for k in range(T - 2, -1, -1):
+        mf, Pf = fm[:, k], fP[:, k]
+
+        def rhs(yv, mf=mf, Pf=Pf):
+            m_s, P_s = yv
+            F = drift.jac(mf)
+            aux = np.swapaxes(psd_solve(Pf, np.broadcast_to(LQL, Pf.shape).copy()), -1, -2)
+            G = F + aux
+            dm = drift.f(mf) + np.einsum("nij,nj->ni", G, m_s - mf)
+            dP = G @ P_s + P_s @ np.swapaxes(G, -1, -2) - LQL
+            return -dm, -dP  # reverse_rhs (diffrax_utils.py:13-25)
+
+        t0, t1 = t[:, k], t[:, k + 1]
+        ms, Ps = diffeqsolve(rhs, np.zeros_like(t0), t1 - t0, (ms, Ps), dt0, max_steps)
+        sm[:, k] = ms
+        sP[:, k] = Ps
+    return {
+        "marginal_loglik": filtered["marginal_loglik"],
+        "filtered_means": fm,
+        "filtered_covariances": fP,
+        "smoothed_means": sm,
+        "smoothed_covariances": sP,
+    }
+
+
+# --------------------------------------------------------------------------------------
+# UKF (inference_ukf.py)
+# --------------------------------------------------------------------------------------
+def ukf_weights(n, alpha, beta, kappa, dtype):
+    """_compute_lambda / _compute_weights (inference_ukf.py:42, 63-89)."""
+    dtype = np.dtype(dtype)
+    alpha = dtype.type(alpha)
+    lamb = alpha**2 * dtype.type(n + kappa) - dtype.type(n)
+    factor = dtype.type(1) / (dtype.type(2) * (dtype.type(n) + lamb))
+    w_mean = np.concatenate([[lamb / (n + lamb)], np.ones(2 * n, dtype) * factor]).astype(dtype)
+    w_cov = np.concatenate([[lamb / (n + lamb) + (1 - alpha**2 + beta)], np.ones(2 * n, dtype) * factor]).astype(dtype)
+    I_w = np.eye(2 * n + 1, dtype=dtype) - w_mean[:, None]
+    W = (I_w @ np.diag(w_cov) @ I_w.T).astype(dtype)
+    return dtype.type(lamb), w_mean, w_cov, W
+
+
+def ukf_sigmas(m, P, lamb):
+    """_compute_sigmas (inference_ukf.py:45-60): m, m + c*chol(P)[:,i], m - c*chol(P)[:,i]; returns [N,2n+1,n]."""
+    n = m.shape[-1]
+    dist = np.sqrt(m.dtype.type(n) + lamb) * cholesky_lower(P)
+    cols = np.swapaxes(dist, -1, -2)  # cols[:, i, :] = dist[:, :, i]
+    return np.concatenate([m[:, None, :], m[:, None, :] + cols, m[:, None, :] - cols], axis=1)
+
+
+def ukf_filter(mdl: Model, t, y, alpha=math.sqrt(3), beta=2, kappa=1, dt0=0.01, dt_final=1e-10, max_steps=100000,
+               dtype=np.float64):
+    """unscented_kalman_filter (inference_ukf.py:206-308), batched."""
+    dtype = np.dtype(dtype)
+    mdl = mdl.cast(dtype)
+    y = np.asarray(y, dtype=dtype)
+    N, T, _ = y.shape
+    d = mdl.d
+    lamb, w_mean, w_cov, W = ukf_weights(d, alpha, beta, kappa, dtype)
+    LQL = _LQL(mdl)
+    drift = mdl.drift
+    t0s, t1s = _t0_t1(t, dt_final, dtype)
+    ll = np.zeros(N, dtype=dtype)
+    pm = np.broadcast_to(mdl.m0, (N, d)).copy()
+    pP = np.broadcast_to(mdl.P0, (N, d, d)).copy()
+    out = {
+        "filtered_means": np.zeros((N, T, d), dtype),
+        "filtered_covariances": np.zeros((N, T, d, d), dtype),
+        "predicted_means": np.zeros((N, T, d), dtype),
+        "predicted_covariances": np.zeros((N, T, d, d), dtype),
+    }
+
+    def rhs(yv):
+        m_t, P_t = yv
+        X = ukf_sigmas(m_t, P_t, lamb)  # [N,2n+1,n]
+        fX = drift.f(X.reshape(-1, d)).reshape(X.shape)
+        dm = np.einsum("nsi,s->ni", fX, w_mean)
+        foo = np.einsum("nsi,st,ntj->nij", fX, W, X)
+        return dm, foo + np.swapaxes(foo, -1, -2) + LQL
+
+    for k in range(T):
+        yk = y[:, k]
+        # _condition_on (inference_ukf.py:162-203)
+        X = ukf_sigmas(pm, pP, lamb)
+        Y = X @ mdl.H.T + mdl.bias
+        ymean = np.einsum("s,nsj->nj", w_mean, Y)
+        dY = Y - ymean[:, None, :]
+        dX = X - pm[:, None, :]
+        S = np.einsum("s,nsi,nsj->nij", w_cov, dY, dY) + mdl.R
+        C = np.einsum("s,nsi,nsj->nij", w_cov, dX, dY)
+        ll = ll + mvn_logpdf(yk, ymean, S)
+        K = np.swapaxes(psd_solve(S, np.swapaxes(C, -1, -2)), -1, -2)
+        fm = pm + np.einsum("nij,nj->ni", K, yk - ymean)
+        fP = pP - K @ S @ np.swapaxes(K, -1, -2)  # NB: no symmetrize in the UKF
+        pm, pP = diffeqsolve(rhs, t0s[:, k], t1s[:, k], (fm, fP), dt0, max_steps)
+        out["filtered_means"][:, k] = fm
+        out["filtered_covariances"][:, k] = fP
+        out["predicted_means"][:, k] = pm
+        out["predicted_covariances"][:, k] = pP
+    out["marginal_loglik"] = ll
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# synthetic data (time-grid recipe of simulation_utils.py:46-49)
+# --------------------------------------------------------------------------------------
+def irregular_times(rng, N, T, T_total):
+    u = rng.uniform(0.0, 1.0, size=(N, T))
+    s = np.cumsum(u, axis=1)
+    return s / s[:, -1:] * T_total
+
+
+def simulate(mdl: Model, t, rng, h=1e-3):
+    """Euler-Maruyama states at step h from x0 ~ N(m0,P0); y = H x + bias + N(0,R).  Data realism only."""
+    N, T = t.shape
+    d, m = mdl.d, mdl.m
+    Lc = mdl.L @ np.linalg.cholesky(mdl.Qc)
+    x = mdl.m0 + rng.standard_normal((N, d)) @ np.linalg.cholesky(mdl.P0).T
+    cur = t[:, 0].copy()
+    ys = np.zeros((N, T, m))
+    Rc = np.linalg.cholesky(mdl.R)
+    for k in range(T):
+        gap = t[:, k] - cur
+        nsub = int(max(1, math.ceil(gap.max() / h))) if gap.max() > 0 else 0
+        if nsub:
+            hh = (gap / nsub)[:, None]
+            for _ in range(nsub):
+                x = x + hh * mdl.drift.f(x) + np.sqrt(hh) * (rng.standard_normal((N, d)) @ Lc.T)
+        cur = t[:, k].copy()
+        ys[:, k] = x @ mdl.H.T + mdl.bias + rng.standard_normal((N, m)) @ Rc.T
+    return ys
+
+
+def lorenz63_model(m_obs=3, P0_scale=5.0):
+    """C2/C3 of SURVEY.md section 8d: sigma=10, rho=28, beta=8/3, L=Qc=I, H=I3 (or first rows), R=I, m0=0, P0=5I."""
+    d = 3
+    return Model(Lorenz63Drift(), np.eye(d), np.eye(d), np.eye(d)[:m_obs], np.zeros(m_obs), np.eye(m_obs), np.zeros(d),
+                 P0_scale * np.eye(d))
