@@ -1,0 +1,18 @@
+"""cd_dynamax_amd -- MI355X-native continuous-discrete Gaussian filtering engine (host surface).
+
+Same public names as /root/reference/src/continuous_discrete_nonlinear_gaussian_ssm/__init__.py for the
+filtering / smoothing hot path; the arithmetic lives in hand-written HIP kernels behind the C ABI of
+``include/cdkf.h``.
+"""
+from .models import ContDiscreteNonlinearGaussianSSM, cdnlgssm_filter, cdnlgssm_smoother
+from .params import (EKFHyperParams, EnKFHyperParams, LearnableLinear, LearnableLorenz63, LearnableLorenz96,
+                     LearnableMatrix, LearnableMLP, LearnableVector, ParameterProperties, ParamsCDNLGSSM,
+                     ParamsCDNLGSSMDynamics, ParamsCDNLGSSMEmissions, ParamsLGSSMInitial, PosteriorGSSMFiltered,
+                     PosteriorGSSMSmoothed, UKFHyperParams)
+
+__all__ = [
+    "ContDiscreteNonlinearGaussianSSM", "cdnlgssm_filter", "cdnlgssm_smoother", "EKFHyperParams", "UKFHyperParams",
+    "EnKFHyperParams", "LearnableVector", "LearnableMatrix", "LearnableLinear", "LearnableLorenz63",
+    "LearnableLorenz96", "LearnableMLP", "ParameterProperties", "ParamsLGSSMInitial", "ParamsCDNLGSSMDynamics",
+    "ParamsCDNLGSSMEmissions", "ParamsCDNLGSSM", "PosteriorGSSMFiltered", "PosteriorGSSMSmoothed",
+]

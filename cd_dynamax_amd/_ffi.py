@@ -1,0 +1,196 @@
+"""ctypes binding of the C ABI declared in ``include/cdkf.h`` (libcdkf_hip.so).
+
+There is deliberately NO fallback: if the HIP library is missing or a call fails, this raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcdkf_hip.so")
+
+CDKF_OK = 0
+CDKF_EINVAL = -1
+CDKF_EUNSUPPORTED = -2
+CDKF_EHIP = -3
+
+STATUS_NOT_PD = 1
+STATUS_NAN = 2
+STATUS_MAX_STEPS = 4
+
+DRIFT_LINEAR = 0
+DRIFT_LORENZ63 = 1
+DRIFT_LORENZ96 = 2
+DRIFT_MLP_TANH = 3
+
+LAYOUT_NT = 0
+LAYOUT_TN = 1
+
+ORDER = {"zeroth": 0, "first": 1, "second": 2}
+
+_dp = C.POINTER(C.c_double)
+
+
+class CdkfModel(C.Structure):
+    _fields_ = [
+        ("drift_kind", C.c_int32),
+        ("state_dim", C.c_int32),
+        ("emission_dim", C.c_int32),
+        ("hidden1", C.c_int32),
+        ("hidden2", C.c_int32),
+        ("reserved", C.c_int32),
+        ("n_theta", C.c_int64),
+        ("theta", _dp),
+        ("L", _dp),
+        ("Qc", _dp),
+        ("H", _dp),
+        ("h_bias", _dp),
+        ("R", _dp),
+        ("m0", _dp),
+        ("P0", _dp),
+    ]
+
+
+class CdkfOpts(C.Structure):
+    _fields_ = [
+        ("state_order", C.c_int32),
+        ("num_iter", C.c_int32),
+        ("t_shared", C.c_int32),
+        ("device", C.c_int32),
+        ("layout", C.c_int32),
+        ("reserved", C.c_int32),
+        ("max_steps", C.c_int64),
+        ("dt0", C.c_double),
+        ("dt_final", C.c_double),
+        ("cov_rescaling", C.c_double),
+        ("ukf_alpha", C.c_double),
+        ("ukf_beta", C.c_double),
+        ("ukf_kappa", C.c_double),
+    ]
+
+
+class CdkfError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"cdkf error {code}: {msg}")
+        self.code = code
+
+
+# every symbol include/cdkf.h declares (tests/test_abi.py checks this list against the header)
+_ALGOS = ("ekf_filter", "ukf_filter", "ekf_smoother")
+SYMBOLS = (
+    ["cdkf_default_opts", "cdkf_version", "cdkf_last_error", "cdkf_device_count", "cdkf_supported", "cdkf_malloc",
+     "cdkf_free", "cdkf_memcpy_h2d", "cdkf_memcpy_d2h", "cdkf_memset", "cdkf_synchronize", "cdkf_ll_sum_f64_dev",
+     "cdkf_ll_sum_f32_dev"]
+    + [f"cdkf_{a}_{p}{s}" for a in _ALGOS for p in ("f64", "f32") for s in ("", "_dev")]
+)
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    """Load libcdkf_hip.so (once).  Fails loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"HIP library {LIB_PATH} is missing; build it with `make -C cd_dynamax_amd/csrc` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback."
+        )
+    L = C.CDLL(LIB_PATH)
+    L.cdkf_last_error.restype = C.c_char_p
+    L.cdkf_version.restype = C.c_int
+    L.cdkf_device_count.restype = C.c_int
+    L.cdkf_default_opts.argtypes = [C.POINTER(CdkfOpts)]
+    L.cdkf_default_opts.restype = None
+    L.cdkf_supported.argtypes = [C.POINTER(CdkfModel), C.POINTER(CdkfOpts), C.c_int, C.c_int]
+    L.cdkf_supported.restype = C.c_int
+    L.cdkf_malloc.argtypes = [C.POINTER(C.c_void_p), C.c_int64]
+    L.cdkf_free.argtypes = [C.c_void_p]
+    L.cdkf_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    L.cdkf_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    L.cdkf_memset.argtypes = [C.c_void_p, C.c_int, C.c_int64]
+    L.cdkf_synchronize.argtypes = [C.c_void_p]
+    for name in ("cdkf_ll_sum_f64_dev", "cdkf_ll_sum_f32_dev"):
+        getattr(L, name).argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        getattr(L, name).restype = C.c_int
+    for a in _ALGOS:
+        for p in ("f64", "f32"):
+            base = [C.POINTER(CdkfModel), C.POINTER(CdkfOpts), C.c_int64, C.c_int64] + [C.c_void_p] * 8
+            f = getattr(L, f"cdkf_{a}_{p}")
+            f.argtypes = base
+            f.restype = C.c_int
+            f = getattr(L, f"cdkf_{a}_{p}_dev")
+            f.argtypes = base + [C.c_void_p]
+            f.restype = C.c_int
+    _lib = L
+    return L
+
+
+def check(rc: int) -> None:
+    if rc != CDKF_OK:
+        raise CdkfError(rc, lib().cdkf_last_error().decode("utf-8", "replace"))
+
+
+def default_opts() -> CdkfOpts:
+    o = CdkfOpts()
+    lib().cdkf_default_opts(C.byref(o))
+    return o
+
+
+class ModelBlock:
+    """Owns the double-precision host arrays a ``cdkf_model`` points to."""
+
+    def __init__(self, drift_kind, theta, L, Qc, H, h_bias, R, m0, P0, hidden=(0, 0)):
+        f64 = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+        self.theta, self.L, self.Qc, self.H, self.h_bias, self.R, self.m0, self.P0 = map(
+            f64, (theta, L, Qc, H, h_bias, R, m0, P0))
+        d = self.m0.shape[0]
+        m = self.h_bias.shape[0]
+        if self.L.shape != (d, d) or self.Qc.shape != (d, d) or self.P0.shape != (d, d):
+            raise ValueError("L, Qc and P0 must be [state_dim, state_dim]")
+        if self.H.shape != (m, d) or self.R.shape != (m, m):
+            raise ValueError("H must be [emission_dim, state_dim] and R [emission_dim, emission_dim]")
+        self.state_dim, self.emission_dim = d, m
+        ptr = lambda a: a.ctypes.data_as(_dp)
+        self.c = CdkfModel(
+            drift_kind=int(drift_kind), state_dim=d, emission_dim=m, hidden1=int(hidden[0]), hidden2=int(hidden[1]),
+            reserved=0, n_theta=self.theta.size, theta=ptr(self.theta), L=ptr(self.L), Qc=ptr(self.Qc), H=ptr(self.H),
+            h_bias=ptr(self.h_bias), R=ptr(self.R), m0=ptr(self.m0), P0=ptr(self.P0))
+
+
+def _vp(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def run_host(algo: str, mdl: ModelBlock, opts: CdkfOpts, t: np.ndarray, y: np.ndarray, want: dict, dtype):
+    """Call cdkf_<algo>_<f32|f64> on host (NumPy) buffers.
+
+    t: [N,T] or [T] (opts.t_shared), y: [N,T,m] in the reference layout.  ``want``: four booleans for
+    the four optional output arrays in ABI order.  Returns (ll, [4 arrays or None], status); the
+    arrays have the reference shapes [N,T,...].
+
+    The device side always runs in the engine's time-major layout (CDKF_LAYOUT_TN): inputs are
+    transposed on the host before upload and the outputs come back as transposed VIEWS of the
+    time-major buffers (same shapes and values as the reference's arrays, no extra copy).
+    """
+    dtype = np.dtype(dtype)
+    suffix = {np.dtype(np.float32): "f32", np.dtype(np.float64): "f64"}[dtype]
+    N, T, m = y.shape
+    d = mdl.state_dim
+    opts.layout = LAYOUT_TN
+    t = np.asarray(t, dtype=dtype)
+    t = np.ascontiguousarray(t if opts.t_shared else t.T)
+    y = np.ascontiguousarray(np.asarray(y, dtype=dtype).transpose(1, 0, 2))
+    ll = np.empty((N,), dtype)
+    status = np.zeros((N,), np.int32)
+    shapes = [(T, N, d), (T, N, d, d), (T, N, d), (T, N, d, d)]
+    outs = [np.empty(s, dtype) if w else None for s, w in zip(shapes, want)]
+    fn = getattr(lib(), f"cdkf_{algo}_{suffix}")
+    check(fn(C.byref(mdl.c), C.byref(opts), N, T, _vp(t), _vp(y), _vp(ll), *[_vp(o) for o in outs], _vp(status)))
+    outs = [None if o is None else np.swapaxes(o, 0, 1) for o in outs]
+    return ll, outs, status

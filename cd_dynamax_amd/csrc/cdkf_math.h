@@ -1,0 +1,166 @@
+// cdkf_math.h -- register-resident small dense linear algebra + Dormand-Prince stepper for the
+// lane-per-trajectory ("reg") kernels.  Everything is compile-time sized and fully unrolled so that
+// the mean, covariance and the six RK slopes of one trajectory live in the VGPRs of one lane.
+//
+// Reference arithmetic being restated (paths relative to /root/reference):
+//   psd_solve / symmetrize            dynamax/utils/utils.py:202-211
+//   MVN(...).log_prob                 inference_ekf.py:286 (TFP MultivariateNormalFullCovariance)
+//   diffeqsolve -> Dopri5, const dt0  src/utils/diffrax_utils.py:40-165 (diffrax 0.4.0)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define CDKF_DEV __device__ __forceinline__
+
+namespace cdkf {
+
+// ---- packed upper-triangular index of a symmetric D x D matrix -----------------------------
+template <int D>
+CDKF_DEV constexpr int sidx(int i, int j) {
+  return (i <= j) ? (i * D - (i * (i - 1)) / 2 + (j - i)) : (j * D - (j * (j - 1)) / 2 + (i - j));
+}
+template <int D>
+struct Dims {
+  static constexpr int NP = D * (D + 1) / 2;  // packed covariance entries
+  static constexpr int NS = D + NP;           // ODE state: [mean, packed covariance]
+};
+
+// ---- scalar helpers ------------------------------------------------------------------------
+CDKF_DEV float rfma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+CDKF_DEV double rfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+CDKF_DEV float rrsqrt(float x) { return rsqrtf(x); }
+CDKF_DEV double rrsqrt(double x) { return rsqrt(x); }
+CDKF_DEV float rsqrt_(float x) { return sqrtf(x); }
+CDKF_DEV double rsqrt_(double x) { return sqrt(x); }
+CDKF_DEV float rmin(float a, float b) { return fminf(a, b); }
+CDKF_DEV double rmin(double a, double b) { return fmin(a, b); }
+
+template <typename R>
+struct Tol;  // diffrax _clip_to_end tolerance
+template <>
+struct Tol<double> {
+  static constexpr double v = 1e-10;
+};
+template <>
+struct Tol<float> {
+  static constexpr float v = 1e-6f;
+};
+
+// ---- Cholesky of an M x M matrix given by its lower triangle (full storage S[a][b], a >= b read) --
+// Returns the factor in Lc (lower) and the reciprocal pivots in inv.  A non-positive pivot gives
+// NaN downstream (rsqrt of a negative), as jnp.linalg.cholesky does; `bad` is set for status.
+template <typename R, int M>
+CDKF_DEV void chol_lower(const R (&S)[M][M], R (&Lc)[M][M], R (&inv)[M], bool& bad) {
+#pragma unroll
+  for (int j = 0; j < M; ++j) {
+    R s = S[j][j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) s = rfma(-Lc[j][k], Lc[j][k], s);
+    bad = bad || !(s > R(0));
+    R r = rrsqrt(s);
+    inv[j] = r;
+    Lc[j][j] = s * r;
+#pragma unroll
+    for (int i = j + 1; i < M; ++i) {
+      R v = S[i][j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) v = rfma(-Lc[i][k], Lc[j][k], v);
+      Lc[i][j] = v * r;
+    }
+  }
+}
+
+// Solve (Lc Lc^T) X = B for X, B: [M][K] (cho_solve).  In place on B.
+template <typename R, int M, int K>
+CDKF_DEV void chol_solve(const R (&Lc)[M][M], const R (&inv)[M], R (&B)[M][K]) {
+#pragma unroll
+  for (int c = 0; c < K; ++c) {
+#pragma unroll
+    for (int i = 0; i < M; ++i) {  // forward
+      R v = B[i][c];
+#pragma unroll
+      for (int k = 0; k < i; ++k) v = rfma(-Lc[i][k], B[k][c], v);
+      B[i][c] = v * inv[i];
+    }
+#pragma unroll
+    for (int i = M - 1; i >= 0; --i) {  // backward with Lc^T
+      R v = B[i][c];
+#pragma unroll
+      for (int k = i + 1; k < M; ++k) v = rfma(-Lc[k][i], B[k][c], v);
+      B[i][c] = v * inv[i];
+    }
+  }
+}
+
+// ---- Dormand-Prince 5(4), fixed step (diffrax Dopri5 + ConstantStepSize) ---------------------
+// Stage values are formed as y0 + dt * (sum_j a_ij f_j): the increment is summed first and added to
+// y0 once, the same association as diffrax's `y0 + a_lower[i] @ ks` (this is what keeps float32
+// within 1-2 ulp of the reference's known-answer constants).  The ODEs of this path are autonomous,
+// so FSAL's 7th evaluation equals the next step's first and is simply not computed.
+template <typename R>
+struct Dp5 {
+  static constexpr R a21 = R(1.0 / 5.0);
+  static constexpr R a31 = R(3.0 / 40.0), a32 = R(9.0 / 40.0);
+  static constexpr R a41 = R(44.0 / 45.0), a42 = R(-56.0 / 15.0), a43 = R(32.0 / 9.0);
+  static constexpr R a51 = R(19372.0 / 6561.0), a52 = R(-25360.0 / 2187.0), a53 = R(64448.0 / 6561.0),
+                     a54 = R(-212.0 / 729.0);
+  static constexpr R a61 = R(9017.0 / 3168.0), a62 = R(-355.0 / 33.0), a63 = R(46732.0 / 5247.0),
+                     a64 = R(49.0 / 176.0), a65 = R(-5103.0 / 18656.0);
+  static constexpr R b1 = R(35.0 / 384.0), b3 = R(500.0 / 1113.0), b4 = R(125.0 / 192.0),
+                     b5 = R(-2187.0 / 6784.0), b6 = R(11.0 / 84.0);
+};
+
+template <typename R, int NS, typename Rhs>
+CDKF_DEV void dopri5_step(R (&y)[NS], R dt, const Rhs& rhs) {
+  using C = Dp5<R>;
+  R k1[NS], k2[NS], k3[NS], k4[NS], k5[NS], k6[NS], ys[NS];
+  rhs(y, k1);
+#pragma unroll
+  for (int e = 0; e < NS; ++e) ys[e] = rfma(dt, C::a21 * k1[e], y[e]);
+  rhs(ys, k2);
+#pragma unroll
+  for (int e = 0; e < NS; ++e) ys[e] = rfma(dt, rfma(C::a32, k2[e], C::a31 * k1[e]), y[e]);
+  rhs(ys, k3);
+#pragma unroll
+  for (int e = 0; e < NS; ++e)
+    ys[e] = rfma(dt, rfma(C::a43, k3[e], rfma(C::a42, k2[e], C::a41 * k1[e])), y[e]);
+  rhs(ys, k4);
+#pragma unroll
+  for (int e = 0; e < NS; ++e)
+    ys[e] = rfma(dt, rfma(C::a54, k4[e], rfma(C::a53, k3[e], rfma(C::a52, k2[e], C::a51 * k1[e]))), y[e]);
+  rhs(ys, k5);
+#pragma unroll
+  for (int e = 0; e < NS; ++e)
+    ys[e] = rfma(
+        dt, rfma(C::a65, k5[e], rfma(C::a64, k4[e], rfma(C::a63, k3[e], rfma(C::a62, k2[e], C::a61 * k1[e])))),
+        y[e]);
+  rhs(ys, k6);
+#pragma unroll
+  for (int e = 0; e < NS; ++e)
+    y[e] = rfma(dt, rfma(C::b6, k6[e], rfma(C::b5, k5[e], rfma(C::b4, k4[e], rfma(C::b3, k3[e], C::b1 * k1[e])))),
+                y[e]);
+}
+
+// Integrate y from t0 to t1 with the diffrax 0.4.0 loop: tprev = t0, tnext = min(t0 + dt0, t1);
+// while tprev < t1: step; tprev = min(tnext, t1); tnext = clip_to_end(tnext + dt0).
+// Returns true if max_steps was hit.
+template <typename R, int NS, typename Rhs>
+CDKF_DEV bool integrate(R (&y)[NS], R t0, R t1, R dt0, long max_steps, const Rhs& rhs) {
+  R tprev = t0;
+  R tnext = rmin(t0 + dt0, t1);
+  long steps = 0;
+  bool capped = false;
+  while (tprev < t1) {
+    if (steps >= max_steps) {
+      capped = true;
+      break;
+    }
+    dopri5_step<R, NS>(y, tnext - tprev, rhs);
+    tprev = rmin(tnext, t1);
+    R tn = tnext + dt0;
+    tnext = (tn > t1 - Tol<R>::v) ? t1 : tn;
+    ++steps;
+  }
+  return capped;
+}
+
+}  // namespace cdkf

@@ -1,0 +1,637 @@
+// cdkf_reg_kernels.h -- lane-per-trajectory ("reg") sweep kernels for small state dimensions.
+//
+// Mapping: one LANE owns one trajectory for the whole time scan; mean, packed
+// symmetric covariance and the six Dormand-Prince slopes live in that lane's VGPRs, model
+// parameters arrive as kernel arguments (SGPRs).  At d <= 4 this beats a wave-per-trajectory
+// mapping: the symmetric/sparse arithmetic is minimal, there is no cross-lane traffic, and a wave
+// issues a 64-lane fp64 instruction in the same 4 cycles whether 9 or 64 lanes carry work.
+//
+// Reference functions restated (paths relative to /root/reference/src/continuous_discrete_nonlinear_gaussian_ssm):
+//   extended_kalman_filter  inference_ekf.py:202-326     _predict :46-148     _condition_on :153-199
+//   extended_kalman_smoother inference_ekf.py:450-539    _smooth  :363-448
+//   unscented_kalman_filter inference_ukf.py:206-308     _predict :93-159     _condition_on :162-203
+#pragma once
+#include "cdkf_drifts.h"
+
+namespace cdkf {
+
+constexpr int kStatusNotPd = 1, kStatusNan = 2, kStatusMaxSteps = 4;
+
+template <typename R, int D, int M, typename Drift>
+struct RegArgs {
+  static constexpr int NP = Dims<D>::NP;
+  Drift drift;
+  R LQL[NP];   // packed upper triangle of L Qc L^T
+  R LQLz[NP];  // zeroth order: (L c) Qc (L c)^T, c = cov_rescaling
+  R H[M][D];
+  R hb[M];
+  R Rm[M][M];
+  R m0[D];
+  R P0[NP];
+  R dt0, dt_final;
+  // UKF weights (inference_ukf.py:63-89): sigma scale sqrt(n + lambda), w_mean[0], w_cov[0], w_i
+  R ukf_c, ukf_wm0, ukf_wc0, ukf_wi;
+  long max_steps;
+  int order, num_iter;
+  long N, T;
+  // element (n, k, i) of an array lives at  n * sn + k * sk + i.  Reference layout [N,T,w]:
+  // (sn, sk) = (T*w, w); time-major layout [T,N,w]: (sn, sk) = (w, N*w); shared t: sn = 0.
+  long t_sn, t_sk, y_sn, y_sk, m_sn, m_sk, P_sn, P_sk;
+  const R* t;
+  const R* y;
+  R* ll;
+  R* fm;
+  R* fP;
+  R* pm;
+  R* pP;
+  int* status;
+};
+
+// ---- EKF moment ODE right-hand side (inference_ekf.py:76-123) --------------------------------
+template <typename R, int D, typename Drift>
+struct EkfRhs {
+  static constexpr int NS = Dims<D>::NS;
+  const Drift& drift;
+  const R* LQL;
+  int order;
+  CDKF_DEV void operator()(const R (&y)[NS], R (&dy)[NS]) const {
+    R F[D][D], f[D];
+    drift.f(y, f);
+    drift.jac(y, F);
+    R A[D][D];  // A = F P
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        R acc = R(0);
+        bool first = true;
+#pragma unroll
+        for (int k = 0; k < D; ++k)
+          if (Drift::nz(i, k)) {
+            R p = y[D + sidx<D>(k, j)];
+            acc = first ? F[i][k] * p : rfma(F[i][k], p, acc);
+            first = false;
+          }
+        A[i][j] = acc;
+      }
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int j = i; j < D; ++j) dy[D + sidx<D>(i, j)] = (A[i][j] + A[j][i]) + LQL[sidx<D>(i, j)];
+#pragma unroll
+    for (int i = 0; i < D; ++i) dy[i] = f[i];
+    if (Drift::HAS_G && order == 2) {
+      R g[D];
+      drift.divgrad(y, g);
+#pragma unroll
+      for (int l = 0; l < D; ++l) {
+        R s = R(0);
+#pragma unroll
+        for (int k = 0; k < D; ++k) s = rfma(g[k], y[D + sidx<D>(k, l)], s);
+        dy[l] = rfma(R(0.5), s, dy[l]);
+      }
+    }
+  }
+};
+
+// mean-only ODE for state_order == 'zeroth' (inference_ekf.py:97-99,126-138)
+template <typename R, int D, typename Drift>
+struct MeanRhs {
+  const Drift& drift;
+  CDKF_DEV void operator()(const R (&y)[D], R (&dy)[D]) const { drift.f(y, dy); }
+};
+
+// ---- EKF measurement update + log-likelihood term ---------------------------------------------
+// ll term: MVN(H m + b, H P H^T + R).log_prob(y)                       inference_ekf.py:285-286
+// update : S = R + H P H^T; K = psd_solve(S, H P)^T; P+ = P - K S K^T; m+ = m + K (y - h(m)),
+//          repeated num_iter times, then symmetrize                     inference_ekf.py:183-199
+template <typename R, int D, int M, typename Args>
+CDKF_DEV void ekf_update(const Args& a, R (&ys)[Dims<D>::NS], const R (&yobs)[M], double& ll, int& st) {
+  bool bad = false;
+  for (int it = 0; it < a.num_iter; ++it) {
+    R HP[M][D];
+#pragma unroll
+    for (int r = 0; r < M; ++r)
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        R s = a.H[r][0] * ys[D + sidx<D>(0, j)];
+#pragma unroll
+        for (int k = 1; k < D; ++k) s = rfma(a.H[r][k], ys[D + sidx<D>(k, j)], s);
+        HP[r][j] = s;
+      }
+    R S[M][M];
+#pragma unroll
+    for (int r = 0; r < M; ++r)
+#pragma unroll
+      for (int c = 0; c < M; ++c) {
+        R s = HP[r][0] * a.H[c][0];
+#pragma unroll
+        for (int k = 1; k < D; ++k) s = rfma(HP[r][k], a.H[c][k], s);
+        S[r][c] = s + a.Rm[r][c];
+      }
+    R v[M];  // innovation
+#pragma unroll
+    for (int r = 0; r < M; ++r) {
+      R s = a.H[r][0] * ys[0];
+#pragma unroll
+      for (int k = 1; k < D; ++k) s = rfma(a.H[r][k], ys[k], s);
+      v[r] = yobs[r] - (s + a.hb[r]);
+    }
+    if (it == 0) {
+      // TFP log_prob: Cholesky of S as given (lower triangle, no jitter)
+      R Lc[M][M], inv[M];
+      chol_lower<R, M>(S, Lc, inv, bad);
+      R q = R(0), pinv = R(1);
+      R z[M];
+#pragma unroll
+      for (int i = 0; i < M; ++i) {
+        R w = v[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) w = rfma(-Lc[i][k], z[k], w);
+        z[i] = w * inv[i];
+        q = rfma(z[i], z[i], q);
+        pinv *= inv[i];
+      }
+      // -0.5 q - sum log L_ii - 0.5 M log(2 pi);   sum log L_ii = -log(prod inv_i)
+      ll += -0.5 * (double)q + log((double)pinv) - 0.5 * M * 1.8378770664093454835606594728112;
+    }
+    // psd_solve: symmetrize + 1e-9 I, Cholesky, cho_solve           dynamax/utils/utils.py:202-207
+    R Sb[M][M];
+#pragma unroll
+    for (int r = 0; r < M; ++r)
+#pragma unroll
+      for (int c = 0; c <= r; ++c) {
+        R s = R(0.5) * (S[r][c] + S[c][r]);
+        if (r == c) s += R(1e-9);
+        Sb[r][c] = s;
+      }
+    R Lb[M][M], invb[M];
+    chol_lower<R, M>(Sb, Lb, invb, bad);
+    R X[M][D];  // X = Sb^{-1} (H P);  K = X^T
+#pragma unroll
+    for (int r = 0; r < M; ++r)
+#pragma unroll
+      for (int j = 0; j < D; ++j) X[r][j] = HP[r][j];
+    chol_solve<R, M, D>(Lb, invb, X);
+    R KS[D][M];  // K S
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int c = 0; c < M; ++c) {
+        R s = X[0][i] * S[0][c];
+#pragma unroll
+        for (int r = 1; r < M; ++r) s = rfma(X[r][i], S[r][c], s);
+        KS[i][c] = s;
+      }
+    // P+ = P - (K S) K^T, then symmetrize (applied every iteration here; the reference symmetrizes
+    // once after the loop -- identical for num_iter == 1, rounding-level otherwise)
+    R Pn[Dims<D>::NP];
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int j = i; j < D; ++j) {
+        R tij = KS[i][0] * X[0][j], tji = KS[j][0] * X[0][i];
+#pragma unroll
+        for (int c = 1; c < M; ++c) {
+          tij = rfma(KS[i][c], X[c][j], tij);
+          tji = rfma(KS[j][c], X[c][i], tji);
+        }
+        R p = ys[D + sidx<D>(i, j)];
+        Pn[sidx<D>(i, j)] = R(0.5) * ((p - tij) + (p - tji));
+      }
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      R s = ys[i];
+#pragma unroll
+      for (int r = 0; r < M; ++r) s = rfma(X[r][i], v[r], s);
+      ys[i] = s;
+    }
+#pragma unroll
+    for (int e = 0; e < Dims<D>::NP; ++e) ys[D + e] = Pn[e];
+  }
+  if (bad) st |= kStatusNotPd;
+}
+
+// store helpers: mean [D] and full symmetric covariance [D,D] in the reference layout
+template <typename R, int D>
+CDKF_DEV void store_moments(R* __restrict__ mean_out, R* __restrict__ cov_out, long moff, long poff,
+                            const R (&ys)[Dims<D>::NS]) {
+  if (mean_out) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) mean_out[moff + i] = ys[i];
+  }
+  if (cov_out) {
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int j = 0; j < D; ++j) cov_out[poff + i * D + j] = ys[D + sidx<D>(i, j)];
+  }
+}
+
+// ---- EKF filter sweep -------------------------------------------------------------------------
+template <typename R, int D, int M, typename Drift>
+__global__ __launch_bounds__(64) void ekf_filter_reg_kernel(const RegArgs<R, D, M, Drift> a) {
+  constexpr int NS = Dims<D>::NS;
+  constexpr int NP = Dims<D>::NP;
+  const long gid = (long)blockIdx.x * 64 + threadIdx.x;
+  const bool live = gid < a.N;
+  const long n = live ? gid : a.N - 1;  // idle lanes shadow the last trajectory and store nothing
+
+  const R* __restrict__ tp = a.t + n * a.t_sn;
+  const R* __restrict__ yp = a.y + n * a.y_sn;
+
+  R ys[NS];
+#pragma unroll
+  for (int i = 0; i < D; ++i) ys[i] = a.m0[i];
+#pragma unroll
+  for (int e = 0; e < NP; ++e) ys[D + e] = a.P0[e];
+
+  double ll = 0.0;
+  int st = 0;
+  EkfRhs<R, D, Drift> rhs{a.drift, a.LQL, a.order};
+  MeanRhs<R, D, Drift> mrhs{a.drift};
+
+  R tcur = tp[0];
+  R ycur[M];
+#pragma unroll
+  for (int r = 0; r < M; ++r) ycur[r] = yp[r];
+
+  for (long k = 0; k < a.T; ++k) {
+    // prefetch next step's observation and interval end before the arithmetic of this step
+    const long kn = (k + 1 < a.T) ? k + 1 : k;
+    R tnext_obs = tp[kn * a.t_sk];
+    R ynext[M];
+#pragma unroll
+    for (int r = 0; r < M; ++r) ynext[r] = yp[kn * a.y_sk + r];
+
+    ekf_update<R, D, M>(a, ys, ycur, ll, st);
+    if (ys[0] != ys[0]) st |= kStatusNan;
+    const long moff = n * a.m_sn + k * a.m_sk, poff = n * a.P_sn + k * a.P_sk;
+    if (live) store_moments<R, D>(a.fm, a.fP, moff, poff, ys);
+
+    const R t1 = (k + 1 < a.T) ? tnext_obs : tcur + a.dt_final;
+    bool capped;
+    if (a.order == 0) {
+      R mm[D];
+#pragma unroll
+      for (int i = 0; i < D; ++i) mm[i] = ys[i];
+      capped = integrate<R, D>(mm, tcur, t1, a.dt0, a.max_steps, mrhs);
+      const R sq = rsqrt_(t1 - tcur);
+#pragma unroll
+      for (int i = 0; i < D; ++i) ys[i] = mm[i];
+#pragma unroll
+      for (int e = 0; e < NP; ++e) ys[D + e] = rfma(sq, a.LQLz[e], ys[D + e]);
+    } else {
+      capped = integrate<R, NS>(ys, tcur, t1, a.dt0, a.max_steps, rhs);
+    }
+    if (capped) st |= kStatusMaxSteps;
+    if (live) store_moments<R, D>(a.pm, a.pP, moff, poff, ys);
+
+    tcur = tnext_obs;
+#pragma unroll
+    for (int r = 0; r < M; ++r) ycur[r] = ynext[r];
+  }
+  if (live) {
+    a.ll[n] = (R)ll;
+    if (a.status) a.status[n] = st;
+  }
+}
+
+
+// ---- unpack a full symmetric D x D matrix from the packed state (for Cholesky: lower triangle) ----
+template <typename R, int D>
+CDKF_DEV void unpack_sym(const R* packed, R (&A)[D][D]) {
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j < D; ++j) A[i][j] = packed[sidx<D>(i, j)];
+}
+
+// ---- UKF: sigma points m, m +- c * chol(P)[:, i]  (inference_ukf.py:45-60) ---------------------
+// X[0] = m, X[1+i] = m + c L[:,i], X[1+D+i] = m - c L[:,i]
+template <typename R, int D>
+CDKF_DEV void ukf_sigmas(const R (&ys)[Dims<D>::NS], R c, R (&X)[2 * D + 1][D], bool& bad) {
+  R P[D][D], Lc[D][D], inv[D];
+  unpack_sym<R, D>(ys + D, P);
+  chol_lower<R, D>(P, Lc, inv, bad);
+#pragma unroll
+  for (int j = 0; j < D; ++j) X[0][j] = ys[j];
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      const R dlt = (j >= i) ? c * Lc[j][i] : R(0);
+      X[1 + i][j] = ys[j] + dlt;
+      X[1 + D + i][j] = ys[j] - dlt;
+    }
+}
+
+// UKF moment ODE (inference_ukf.py:128-152):  dm = fX^T w_m,  dP = fX^T W X + (.)^T + L Qc L^T with
+// W = (I - w_m 1^T) diag(w_c) (I - w_m 1^T)^T, evaluated in its factored form
+// fX^T W X = sum_s w_c[s] (fX_s - fbar)(X_s - xbar)^T,  fbar = sum w_m fX,  xbar = sum w_m X.
+template <typename R, int D, typename Args>
+struct UkfRhs {
+  static constexpr int NS = Dims<D>::NS;
+  static constexpr int S = 2 * D + 1;
+  const Args& a;
+  bool* bad;
+  CDKF_DEV void operator()(const R (&y)[NS], R (&dy)[NS]) const {
+    R X[S][D], fX[S][D];
+    ukf_sigmas<R, D>(y, a.ukf_c, X, *bad);
+#pragma unroll
+    for (int s = 0; s < S; ++s) a.drift.f(X[s], fX[s]);
+    R fbar[D], xbar[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      R sf = fX[1][j], sx = X[1][j];
+#pragma unroll
+      for (int s = 2; s < S; ++s) {
+        sf += fX[s][j];
+        sx += X[s][j];
+      }
+      fbar[j] = rfma(a.ukf_wm0, fX[0][j], a.ukf_wi * sf);
+      xbar[j] = rfma(a.ukf_wm0, X[0][j], a.ukf_wi * sx);
+      dy[j] = fbar[j];
+    }
+    R foo[D][D];
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        R acc = R(0);
+#pragma unroll
+        for (int s = 1; s < S; ++s) acc = rfma(fX[s][i] - fbar[i], X[s][j] - xbar[j], acc);
+        foo[i][j] = rfma(a.ukf_wc0, (fX[0][i] - fbar[i]) * (X[0][j] - xbar[j]), a.ukf_wi * acc);
+      }
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int j = i; j < D; ++j) dy[D + sidx<D>(i, j)] = (foo[i][j] + foo[j][i]) + a.LQL[sidx<D>(i, j)];
+  }
+};
+
+// UKF measurement update (inference_ukf.py:162-203)
+template <typename R, int D, int M, typename Args>
+CDKF_DEV void ukf_update(const Args& a, R (&ys)[Dims<D>::NS], const R (&yobs)[M], double& ll, int& st) {
+  constexpr int S = 2 * D + 1;
+  bool bad = false;
+  R X[S][D], Y[S][M];
+  ukf_sigmas<R, D>(ys, a.ukf_c, X, bad);
+#pragma unroll
+  for (int s = 0; s < S; ++s)
+#pragma unroll
+    for (int r = 0; r < M; ++r) {
+      R v = a.H[r][0] * X[s][0];
+#pragma unroll
+      for (int k = 1; k < D; ++k) v = rfma(a.H[r][k], X[s][k], v);
+      Y[s][r] = v + a.hb[r];
+    }
+  R ybar[M];
+#pragma unroll
+  for (int r = 0; r < M; ++r) {
+    R sy = Y[1][r];
+#pragma unroll
+    for (int s = 2; s < S; ++s) sy += Y[s][r];
+    ybar[r] = rfma(a.ukf_wm0, Y[0][r], a.ukf_wi * sy);
+  }
+  R Sm[M][M], C[D][M];
+#pragma unroll
+  for (int r = 0; r < M; ++r)
+#pragma unroll
+    for (int c = 0; c < M; ++c) {
+      R acc = R(0);
+#pragma unroll
+      for (int s = 1; s < S; ++s) acc = rfma(Y[s][r] - ybar[r], Y[s][c] - ybar[c], acc);
+      Sm[r][c] = rfma(a.ukf_wc0, (Y[0][r] - ybar[r]) * (Y[0][c] - ybar[c]), a.ukf_wi * acc) + a.Rm[r][c];
+    }
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int c = 0; c < M; ++c) {
+      R acc = R(0);
+#pragma unroll
+      for (int s = 1; s < S; ++s) acc = rfma(X[s][i] - ys[i], Y[s][c] - ybar[c], acc);
+      C[i][c] = a.ukf_wi * acc;  // the s = 0 term is (m - m) * (.) = 0
+    }
+  R v[M];
+#pragma unroll
+  for (int r = 0; r < M; ++r) v[r] = yobs[r] - ybar[r];
+  {
+    R Lc[M][M], inv[M];
+    chol_lower<R, M>(Sm, Lc, inv, bad);
+    R q = R(0), pinv = R(1), z[M];
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+      R w = v[i];
+#pragma unroll
+      for (int k = 0; k < i; ++k) w = rfma(-Lc[i][k], z[k], w);
+      z[i] = w * inv[i];
+      q = rfma(z[i], z[i], q);
+      pinv *= inv[i];
+    }
+    ll += -0.5 * (double)q + log((double)pinv) - 0.5 * M * 1.8378770664093454835606594728112;
+  }
+  R Sb[M][M];
+#pragma unroll
+  for (int r = 0; r < M; ++r)
+#pragma unroll
+    for (int c = 0; c <= r; ++c) {
+      R s = R(0.5) * (Sm[r][c] + Sm[c][r]);
+      if (r == c) s += R(1e-9);
+      Sb[r][c] = s;
+    }
+  R Lb[M][M], invb[M];
+  chol_lower<R, M>(Sb, Lb, invb, bad);
+  R Xs[M][D];  // Sb^{-1} C^T ;  K = Xs^T
+#pragma unroll
+  for (int r = 0; r < M; ++r)
+#pragma unroll
+    for (int j = 0; j < D; ++j) Xs[r][j] = C[j][r];
+  chol_solve<R, M, D>(Lb, invb, Xs);
+  R KS[D][M];
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int c = 0; c < M; ++c) {
+      R s = Xs[0][i] * Sm[0][c];
+#pragma unroll
+      for (int r = 1; r < M; ++r) s = rfma(Xs[r][i], Sm[r][c], s);
+      KS[i][c] = s;
+    }
+  // P+ = P - K S K^T (no symmetrize in the UKF); the packed entry (i,j), i<=j, takes the LOWER
+  // element (j,i) of the reference's result, which is what the next Cholesky reads.
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = i; j < D; ++j) {
+      R tji = KS[j][0] * Xs[0][i];
+#pragma unroll
+      for (int c = 1; c < M; ++c) tji = rfma(KS[j][c], Xs[c][i], tji);
+      ys[D + sidx<D>(i, j)] -= tji;
+    }
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    R s = ys[i];
+#pragma unroll
+    for (int r = 0; r < M; ++r) s = rfma(Xs[r][i], v[r], s);
+    ys[i] = s;
+  }
+  if (bad) st |= kStatusNotPd;
+}
+
+template <typename R, int D, int M, typename Drift>
+__global__ __launch_bounds__(64) void ukf_filter_reg_kernel(const RegArgs<R, D, M, Drift> a) {
+  constexpr int NS = Dims<D>::NS;
+  constexpr int NP = Dims<D>::NP;
+  const long gid = (long)blockIdx.x * 64 + threadIdx.x;
+  const bool live = gid < a.N;
+  const long n = live ? gid : a.N - 1;
+  const R* __restrict__ tp = a.t + n * a.t_sn;
+  const R* __restrict__ yp = a.y + n * a.y_sn;
+
+  R ys[NS];
+#pragma unroll
+  for (int i = 0; i < D; ++i) ys[i] = a.m0[i];
+#pragma unroll
+  for (int e = 0; e < NP; ++e) ys[D + e] = a.P0[e];
+  double ll = 0.0;
+  int st = 0;
+  bool bad_rhs = false;
+  UkfRhs<R, D, RegArgs<R, D, M, Drift>> rhs{a, &bad_rhs};
+
+  R tcur = tp[0];
+  R ycur[M];
+#pragma unroll
+  for (int r = 0; r < M; ++r) ycur[r] = yp[r];
+  for (long k = 0; k < a.T; ++k) {
+    const long kn = (k + 1 < a.T) ? k + 1 : k;
+    R tnext_obs = tp[kn * a.t_sk];
+    R ynext[M];
+#pragma unroll
+    for (int r = 0; r < M; ++r) ynext[r] = yp[kn * a.y_sk + r];
+
+    ukf_update<R, D, M>(a, ys, ycur, ll, st);
+    if (ys[0] != ys[0]) st |= kStatusNan;
+    const long moff = n * a.m_sn + k * a.m_sk, poff = n * a.P_sn + k * a.P_sk;
+    if (live) store_moments<R, D>(a.fm, a.fP, moff, poff, ys);
+    const R t1 = (k + 1 < a.T) ? tnext_obs : tcur + a.dt_final;
+    if (integrate<R, NS>(ys, tcur, t1, a.dt0, a.max_steps, rhs)) st |= kStatusMaxSteps;
+    if (live) store_moments<R, D>(a.pm, a.pP, moff, poff, ys);
+    tcur = tnext_obs;
+#pragma unroll
+    for (int r = 0; r < M; ++r) ycur[r] = ynext[r];
+  }
+  if (bad_rhs) st |= kStatusNotPd;
+  if (live) {
+    a.ll[n] = (R)ll;
+    if (a.status) a.status[n] = st;
+  }
+}
+
+// ---- EKF (RTS) smoother backward sweep (inference_ekf.py:363-448, 503-531) ----------------------
+// Over the interval [t_k, t_{k+1}] the filtered moments (m_f, P_f) at t_k are constants, so
+// G = F(m_f) + psd_solve(P_f, L Qc L^T)^T and f(m_f) are hoisted out of the RK stages (the reference
+// re-factorises P_f in every stage and gets the same numbers).
+template <typename R, int D>
+struct SmoothRhs {
+  static constexpr int NS = Dims<D>::NS;
+  R G[D][D];
+  R fmf[D];
+  R mf[D];
+  const R* LQL;
+  // reverse-time: the reference integrates -rhs(t1 - s) over s in [0, t1 - t0] (diffrax_utils.py:13-25)
+  CDKF_DEV void operator()(const R (&y)[NS], R (&dy)[NS]) const {
+    R dm[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) dm[i] = y[i] - mf[i];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      R s = G[i][0] * dm[0];
+#pragma unroll
+      for (int k = 1; k < D; ++k) s = rfma(G[i][k], dm[k], s);
+      dy[i] = -(fmf[i] + s);
+    }
+    R A[D][D];
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        R s = G[i][0] * y[D + sidx<D>(0, j)];
+#pragma unroll
+        for (int k = 1; k < D; ++k) s = rfma(G[i][k], y[D + sidx<D>(k, j)], s);
+        A[i][j] = s;
+      }
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int j = i; j < D; ++j) dy[D + sidx<D>(i, j)] = -((A[i][j] + A[j][i]) - LQL[sidx<D>(i, j)]);
+  }
+};
+
+template <typename R, int D, int M, typename Drift>
+__global__ __launch_bounds__(64) void ekf_smoother_reg_kernel(const RegArgs<R, D, M, Drift> a, R* __restrict__ sm,
+                                                              R* __restrict__ sP) {
+  constexpr int NS = Dims<D>::NS;
+  const long gid = (long)blockIdx.x * 64 + threadIdx.x;
+  const bool live = gid < a.N;
+  const long n = live ? gid : a.N - 1;
+  const R* __restrict__ tp = a.t + n * a.t_sn;
+  const R* __restrict__ fm = a.fm + n * a.m_sn;
+  const R* __restrict__ fP = a.fP + n * a.P_sn;
+  int st = 0;
+  bool bad = false;
+
+  R ys[NS];  // smoothed moments at t_{k+1}
+  {
+    const long k = a.T - 1;
+#pragma unroll
+    for (int i = 0; i < D; ++i) ys[i] = fm[k * a.m_sk + i];
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int j = i; j < D; ++j) ys[D + sidx<D>(i, j)] = fP[k * a.P_sk + i * D + j];
+    if (live) store_moments<R, D>(sm, sP, n * a.m_sn + k * a.m_sk, n * a.P_sn + k * a.P_sk, ys);
+  }
+  R t1 = tp[(a.T - 1) * a.t_sk];
+  for (long k = a.T - 2; k >= 0; --k) {
+    SmoothRhs<R, D> rhs;
+    rhs.LQL = a.LQL;
+    R Pf[D][D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) rhs.mf[i] = fm[k * a.m_sk + i];
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int j = 0; j < D; ++j) Pf[i][j] = fP[k * a.P_sk + i * D + j];
+    const R t0 = tp[k * a.t_sk];
+    a.drift.f(rhs.mf, rhs.fmf);
+    a.drift.jac(rhs.mf, rhs.G);
+    // aux = psd_solve(P_f, LQL)^T
+    R Sb[D][D], Lb[D][D], invb[D], X[D][D];
+#pragma unroll
+    for (int r = 0; r < D; ++r)
+#pragma unroll
+      for (int c = 0; c <= r; ++c) {
+        R s = R(0.5) * (Pf[r][c] + Pf[c][r]);
+        if (r == c) s += R(1e-9);
+        Sb[r][c] = s;
+      }
+    chol_lower<R, D>(Sb, Lb, invb, bad);
+#pragma unroll
+    for (int r = 0; r < D; ++r)
+#pragma unroll
+      for (int c = 0; c < D; ++c) X[r][c] = a.LQL[sidx<D>(r, c)];
+    chol_solve<R, D, D>(Lb, invb, X);
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int j = 0; j < D; ++j) rhs.G[i][j] += X[j][i];
+    if (integrate<R, NS>(ys, R(0), t1 - t0, a.dt0, a.max_steps, rhs)) st |= kStatusMaxSteps;
+    if (live) store_moments<R, D>(sm, sP, n * a.m_sn + k * a.m_sk, n * a.P_sn + k * a.P_sk, ys);
+    t1 = t0;
+  }
+  if (bad) st |= kStatusNotPd;
+  if (live && a.status && st) atomicOr(&a.status[n], st);
+}
+
+}  // namespace cdkf

@@ -1,0 +1,36 @@
+// launch_ekf.hip -- EKF filter sweep: kernel selection and launch.
+#include "cdkf_launch.h"
+
+namespace cdkf {
+
+template <typename R, int D, int M, typename Drift>
+static int run_ekf_reg(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll,
+                       R* fm, R* fP, R* pm, R* pP, int32_t* status, hipStream_t stream) {
+  RegArgs<R, D, M, Drift> a;
+  fill_reg_args(a, mdl, o, N, T, t, y, ll, fm, fP, pm, pP, status);
+  const unsigned blocks = (unsigned)((N + 63) / 64);
+  hipLaunchKernelGGL((ekf_filter_reg_kernel<R, D, M, Drift>), dim3(blocks), dim3(64), 0, stream, a);
+  CDKF_HIP_CHECK(hipGetLastError());
+  return CDKF_OK;
+}
+
+template <typename R>
+int launch_ekf_filter(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll,
+                      R* fm, R* fP, R* pm, R* pP, int32_t* status, hipStream_t stream) {
+#define X(KIND, DRIFT, D_, M_)                                                           \
+  if (mdl->drift_kind == KIND && mdl->state_dim == D_ && mdl->emission_dim == M_)        \
+    return run_ekf_reg<R, D_, M_, DRIFT<R, D_>>(mdl, o, N, T, t, y, ll, fm, fP, pm, pP, status, stream);
+  CDKF_REG_SHAPES(X)
+#undef X
+  set_error("EKF filter: no kernel for drift_kind=%d state_dim=%d emission_dim=%d", mdl->drift_kind, mdl->state_dim,
+            mdl->emission_dim);
+  return CDKF_EUNSUPPORTED;
+}
+
+template int launch_ekf_filter<float>(const cdkf_model*, const cdkf_opts*, int64_t, int64_t, const float*, const float*,
+                                      float*, float*, float*, float*, float*, int32_t*, hipStream_t);
+template int launch_ekf_filter<double>(const cdkf_model*, const cdkf_opts*, int64_t, int64_t, const double*,
+                                       const double*, double*, double*, double*, double*, double*, int32_t*,
+                                       hipStream_t);
+
+}  // namespace cdkf

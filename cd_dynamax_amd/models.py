@@ -1,0 +1,263 @@
+"""Drop-in host surface of the CDNLGSSM filtering / smoothing hot path.
+
+Mirrors /root/reference/src/continuous_discrete_nonlinear_gaussian_ssm/models.py:
+``cdnlgssm_filter`` (:658-718), ``cdnlgssm_smoother`` (:720-764),
+``ContDiscreteNonlinearGaussianSSM.marginal_log_prob`` (:393-408) and ``initialize`` (:169-291); the
+``filter`` / ``smoother`` methods have the signature of ``SSM.filter/smoother``
+(/root/reference/src/ssm_temissions.py:344-386, which only raise NotImplementedError there).
+
+All arithmetic happens in the HIP library (``_ffi.py`` -> libcdkf_hip.so).  Inputs may carry a
+leading trajectory axis: ``emissions [N,T,m]`` and ``t_emissions [N,T,1]`` (or a shared ``[T,1]``)
+replace the reference's user-side ``jax.vmap`` (ssm_temissions.py:555-566); outputs then carry the
+same leading axis and ``marginal_loglik`` has shape ``[N]``.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple, Union
+
+import numpy as np
+
+from . import _ffi
+from .params import (EKFHyperParams, EnKFHyperParams, LearnableLinear, LearnableLorenz63, LearnableLorenz96,
+                     LearnableMatrix, LearnableMLP, LearnableVector, ParameterProperties, ParamsCDNLGSSM,
+                     ParamsCDNLGSSMDynamics, ParamsCDNLGSSMEmissions, ParamsLGSSMInitial, PosteriorGSSMFiltered,
+                     PosteriorGSSMSmoothed, UKFHyperParams)
+
+_FILTER_FIELDS = ["filtered_means", "filtered_covariances", "predicted_means", "predicted_covariances"]
+
+
+def _model_block(params: ParamsCDNLGSSM) -> _ffi.ModelBlock:
+    """ParamsCDNLGSSM -> cdkf_model.  Python callables cannot cross a C ABI, so the drift and the
+    emission function must be instances of the registry classes; anything else is refused loudly."""
+    drift = params.dynamics.drift
+    hidden = (0, 0)
+    if isinstance(drift, LearnableLinear):
+        W = np.asarray(drift.weights, dtype=np.float64)
+        kind, theta = _ffi.DRIFT_LINEAR, np.concatenate([W.ravel(), np.asarray(drift.bias, np.float64).ravel()])
+    elif isinstance(drift, LearnableLorenz63):
+        kind, theta = _ffi.DRIFT_LORENZ63, np.array([drift.sigma, drift.rho, drift.beta], dtype=np.float64)
+    elif isinstance(drift, LearnableLorenz96):
+        kind, theta = _ffi.DRIFT_LORENZ96, np.array([drift.forcing], dtype=np.float64)
+    elif isinstance(drift, LearnableMLP):
+        kind = _ffi.DRIFT_MLP_TANH
+        hidden = (np.asarray(drift.W1).shape[0], np.asarray(drift.W2).shape[0])
+        theta = np.concatenate([np.asarray(a, np.float64).ravel() for a in drift])
+    else:
+        raise NotImplementedError(
+            f"drift of type {type(drift).__name__} is not in the HIP drift registry "
+            "(LearnableLinear, LearnableLorenz63, LearnableLorenz96, LearnableMLP)")
+    h = params.emissions.emission_function
+    if not isinstance(h, LearnableLinear):
+        raise NotImplementedError(
+            f"emission_function of type {type(h).__name__} is not supported: the HIP path implements the "
+            "reference's LearnableLinear emission h(x) = weights @ x + bias")
+    return _ffi.ModelBlock(
+        kind, theta, params.dynamics.diffusion_coefficient.f(), params.dynamics.diffusion_cov.f(), h.weights, h.bias,
+        params.emissions.emission_cov.f(), params.initial.mean.f(), params.initial.cov.f(), hidden)
+
+
+def _opts(hyperparams, num_iter: int = 1):
+    o = _ffi.default_opts()
+    settings = dict(getattr(hyperparams, "diffeqsolve_settings", {}) or {})
+    unknown = set(settings) - {"dt0", "max_steps"}
+    if unknown:
+        raise NotImplementedError(
+            f"diffeqsolve_settings {sorted(unknown)} are not supported by the HIP path (Dopri5 with constant "
+            "step dt0 only, the default of src/utils/diffrax_utils.py:40-52)")
+    o.dt0 = float(settings.get("dt0", 0.01))
+    o.max_steps = int(settings.get("max_steps", 100000))
+    o.dt_final = float(hyperparams.dt_final)
+    o.num_iter = int(num_iter)
+    if isinstance(hyperparams, EKFHyperParams):
+        if hyperparams.state_order not in _ffi.ORDER:
+            raise ValueError(f"EKF hyperparams.state_order = {hyperparams.state_order} not implemented yet")
+        o.state_order = _ffi.ORDER[hyperparams.state_order]
+        o.cov_rescaling = float(hyperparams.cov_rescaling)
+    else:
+        o.ukf_alpha, o.ukf_beta, o.ukf_kappa = float(hyperparams.alpha), float(hyperparams.beta), float(hyperparams.kappa)
+    return o
+
+
+def _prepare(emissions, t_emissions, hyperparams, opts, dtype):
+    """Normalise (emissions, t_emissions) to y [N,T,m], t [N,T] or [T]; returns (y, t, batched)."""
+    y = np.asarray(emissions)
+    if dtype is None:
+        dtype = np.float32 if y.dtype == np.float32 else np.float64
+    dtype = np.dtype(dtype)
+    if y.ndim == 1:
+        y = y[:, None]
+    batched = y.ndim == 3
+    if not batched:
+        y = y[None]
+    N, T, _ = y.shape
+    if t_emissions is None:
+        # t0 = arange(T), t1 = arange(1, T+1): the last interval has length 1 (inference_ekf.py:247-250)
+        t = np.arange(T, dtype=dtype)
+        opts.dt_final = 1.0
+        opts.t_shared = 1
+    else:
+        t = np.asarray(t_emissions, dtype=dtype)
+        if t.ndim == 3 or (t.ndim == 2 and t.shape[-1] != 1 and batched):
+            t = t.reshape(N, T)
+            opts.t_shared = 0
+        else:
+            t = t.reshape(-1)
+            if t.shape[0] != T:
+                raise ValueError(f"t_emissions has {t.shape[0]} time points but emissions has {T}")
+            opts.t_shared = 1
+    return np.ascontiguousarray(y, dtype=dtype), np.ascontiguousarray(t), batched, dtype
+
+
+def _squeeze(a, batched):
+    return a if (batched or a is None) else a[0]
+
+
+def cdnlgssm_filter(
+    params: ParamsCDNLGSSM,
+    emissions,
+    t_emissions=None,
+    hyperparams: Optional[Union[EKFHyperParams, EnKFHyperParams, UKFHyperParams]] = EKFHyperParams(),
+    inputs=None,
+    num_iter: Optional[int] = 1,
+    output_fields: Optional[List[str]] = _FILTER_FIELDS,
+    dtype=None,
+) -> PosteriorGSSMFiltered:
+    """Continuous-discrete nonlinear filter; EKF or UKF by the class of ``hyperparams``
+    (reference dispatch: models.py:689-716).  ``inputs`` are ignored by every drift in the registry,
+    exactly as the reference's shipped Learnable* classes ignore ``u``."""
+    if isinstance(hyperparams, EKFHyperParams):
+        algo = "ekf_filter"
+    elif isinstance(hyperparams, UKFHyperParams):
+        algo = "ukf_filter"
+    elif isinstance(hyperparams, EnKFHyperParams):
+        raise NotImplementedError("the ensemble Kalman filter is stochastic and not part of the HIP hot path")
+    else:
+        raise TypeError(f"unknown filter hyperparams {type(hyperparams).__name__}")
+    mdl = _model_block(params)
+    opts = _opts(hyperparams, num_iter if algo == "ekf_filter" else 1)
+    y, t, batched, dtype = _prepare(emissions, t_emissions, hyperparams, opts, dtype)
+    fields = list(output_fields) if output_fields is not None else []
+    want = [f in fields for f in _FILTER_FIELDS]
+    ll, outs, _ = _ffi.run_host(algo, mdl, opts, t, y, want, dtype)
+    out = {name: _squeeze(arr, batched) for name, arr in zip(_FILTER_FIELDS, outs) if arr is not None}
+    return PosteriorGSSMFiltered(marginal_loglik=ll if batched else ll[0], **out)
+
+
+def cdnlgssm_smoother(
+    params: ParamsCDNLGSSM,
+    emissions,
+    t_emissions=None,
+    hyperparams: Optional[Union[EKFHyperParams, EnKFHyperParams, UKFHyperParams]] = EKFHyperParams(),
+    inputs=None,
+    num_iter: Optional[int] = 1,
+    dtype=None,
+) -> PosteriorGSSMSmoothed:
+    """Continuous-discrete EKF (RTS) smoother (reference: models.py:720-764; one pass,
+    inference_ekf.py:578-586)."""
+    if isinstance(hyperparams, EnKFHyperParams):
+        raise ValueError("EnKS not implemented yet")
+    if isinstance(hyperparams, UKFHyperParams):
+        raise ValueError("UKS not implemented yet")
+    if not isinstance(hyperparams, EKFHyperParams):
+        raise TypeError(f"unknown smoother hyperparams {type(hyperparams).__name__}")
+    if hyperparams.smooth_order != "first":
+        raise ValueError(f"EKF hyperparams.smooth_order = {hyperparams.smooth_order} not implemented yet")
+    mdl = _model_block(params)
+    opts = _opts(hyperparams, 1)
+    y, t, batched, dtype = _prepare(emissions, t_emissions, hyperparams, opts, dtype)
+    ll, outs, _ = _ffi.run_host("ekf_smoother", mdl, opts, t, y, [True] * 4, dtype)
+    fm, fP, sm, sP = (_squeeze(a, batched) for a in outs)
+    return PosteriorGSSMSmoothed(marginal_loglik=ll if batched else ll[0], filtered_means=fm, filtered_covariances=fP,
+                                 smoothed_means=sm, smoothed_covariances=sP)
+
+
+class ContDiscreteNonlinearGaussianSSM:
+    """Continuous-discrete nonlinear Gaussian SSM (reference: models.py:117-408), restricted to the
+    inference surface of the hot path: ``initialize``, ``marginal_log_prob``, ``filter``, ``smoother``."""
+
+    def __init__(self, state_dim: int, emission_dim: int, input_dim: int = 0, diffeqsolve_settings: dict = {}):
+        self.state_dim = state_dim
+        self.emission_dim = emission_dim
+        self.input_dim = 0
+        self._diffeqsolve_settings = diffeqsolve_settings
+
+    @property
+    def emission_shape(self):
+        return (self.emission_dim,)
+
+    @property
+    def inputs_shape(self):
+        return (self.input_dim,) if self.input_dim > 0 else None
+
+    @property
+    def diffeqsolve_settings(self):
+        return self._diffeqsolve_settings
+
+    def initialize(
+        self,
+        key=None,
+        initial_mean: dict = None,
+        initial_cov: dict = None,
+        dynamics_drift: dict = None,
+        dynamics_diffusion_coefficient: dict = None,
+        dynamics_diffusion_cov: dict = None,
+        dynamics_approx_order: Optional[float] = 2.0,
+        emission_function: dict = None,
+        emission_cov: dict = None,
+    ) -> Tuple[ParamsCDNLGSSM, ParamsCDNLGSSM]:
+        """Same dict-based interface and defaults as models.py:169-291 (``key`` seeds the default
+        emission weights through NumPy instead of jax.random)."""
+        d, m = self.state_dim, self.emission_dim
+        rng = np.random.default_rng(0 if key is None else key)
+        _initial_mean = {"params": LearnableVector(np.zeros(d)), "props": LearnableVector(ParameterProperties(False))}
+        _initial_cov = {"params": LearnableMatrix(np.eye(d)), "props": LearnableMatrix(ParameterProperties(False))}
+        _drift = {"params": LearnableLinear(weights=-0.1 * np.eye(d), bias=np.zeros(d)),
+                  "props": LearnableLinear(weights=ParameterProperties(False), bias=ParameterProperties(False))}
+        _L = {"params": LearnableMatrix(0.1 * np.eye(d)), "props": LearnableMatrix(ParameterProperties(False))}
+        _Q = {"params": LearnableMatrix(0.1 * np.eye(d)), "props": LearnableMatrix(ParameterProperties(False))}
+        _h = {"params": LearnableLinear(weights=rng.standard_normal((m, d)), bias=np.zeros(m)),
+              "props": LearnableLinear(weights=ParameterProperties(False), bias=ParameterProperties(False))}
+        _R = {"params": LearnableMatrix(0.1 * np.eye(m)), "props": LearnableMatrix(ParameterProperties(False))}
+
+        def wrap(x, x0, cls):
+            if x is None:
+                return x0
+            # the reference also accepts raw arrays for the initial mean / cov in older call sites
+            if not hasattr(x["params"], "f"):
+                return {"params": cls(x["params"]), "props": cls(x["props"])}
+            return x
+
+        initial_mean = wrap(initial_mean, _initial_mean, LearnableVector)
+        initial_cov = wrap(initial_cov, _initial_cov, LearnableMatrix)
+        dynamics_drift = dynamics_drift if dynamics_drift is not None else _drift
+        dynamics_diffusion_coefficient = wrap(dynamics_diffusion_coefficient, _L, LearnableMatrix)
+        dynamics_diffusion_cov = wrap(dynamics_diffusion_cov, _Q, LearnableMatrix)
+        approx = {"params": dynamics_approx_order if dynamics_approx_order is not None else 2.0,
+                  "props": ParameterProperties(False)}
+        emission_function = emission_function if emission_function is not None else _h
+        emission_cov = wrap(emission_cov, _R, LearnableMatrix)
+        out = {}
+        for k in ("params", "props"):
+            out[k] = ParamsCDNLGSSM(
+                initial=ParamsLGSSMInitial(mean=initial_mean[k], cov=initial_cov[k]),
+                dynamics=ParamsCDNLGSSMDynamics(drift=dynamics_drift[k],
+                                                diffusion_coefficient=dynamics_diffusion_coefficient[k],
+                                                diffusion_cov=dynamics_diffusion_cov[k], approx_order=approx[k]),
+                emissions=ParamsCDNLGSSMEmissions(emission_function=emission_function[k], emission_cov=emission_cov[k]),
+            )
+        return out["params"], out["props"]
+
+    def marginal_log_prob(self, params, emissions, t_emissions=None, filter_hyperparams=EKFHyperParams(), inputs=None,
+                          dtype=None):
+        """models.py:393-408: the filter's marginal log-likelihood (``[N]`` for batched emissions)."""
+        post = cdnlgssm_filter(params=params, emissions=emissions, t_emissions=t_emissions,
+                               hyperparams=filter_hyperparams, inputs=inputs, output_fields=[], dtype=dtype)
+        return post.marginal_loglik
+
+    def filter(self, params, emissions, t_emissions=None, filter_hyperparams=EKFHyperParams(), inputs=None,
+               dtype=None) -> PosteriorGSSMFiltered:
+        return cdnlgssm_filter(params, emissions, t_emissions, filter_hyperparams, inputs, dtype=dtype)
+
+    def smoother(self, params, emissions, t_emissions=None, filter_hyperparams=EKFHyperParams(), inputs=None,
+                 dtype=None) -> PosteriorGSSMSmoothed:
+        return cdnlgssm_smoother(params, emissions, t_emissions, filter_hyperparams, inputs, dtype=dtype)

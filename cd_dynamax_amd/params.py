@@ -1,0 +1,151 @@
+"""Parameter / hyper-parameter / posterior containers of the CDNLGSSM hot path.
+
+Same names, fields and ``.f(x, u, t)`` accessors as the reference, so that code written against
+cd_dynamax builds these objects unchanged (NumPy arrays instead of jax arrays):
+
+* ``LearnableVector / LearnableMatrix / LearnableLinear / LearnableLorenz63`` and
+  ``ParamsCDNLGSSM{,Dynamics,Emissions}``:
+  /root/reference/src/continuous_discrete_nonlinear_gaussian_ssm/cdnlgssm_utils.py:38-209
+* ``ParamsLGSSMInitial, PosteriorGSSMFiltered, PosteriorGSSMSmoothed``:
+  /root/reference/dynamax/linear_gaussian_ssm/inference.py:19-33, 112-143
+* ``EKFHyperParams`` inference_ekf.py:34-44, ``UKFHyperParams`` inference_ukf.py:25-33
+* ``ParameterProperties``: /root/reference/dynamax/parameters.py:25 (metadata only here)
+
+``LearnableLorenz96`` and ``LearnableMLP`` are build-defined drift families (BASELINE.json configs 4, 5;
+the reference's NeuralNetDrift notebooks are absent from the mount).
+"""
+from __future__ import annotations
+
+import math
+from typing import Any, NamedTuple, Optional
+
+import numpy as np
+
+
+class ParameterProperties(NamedTuple):
+    trainable: bool = True
+    constrainer: Any = None
+
+
+class LearnableVector(NamedTuple):
+    params: Any
+
+    def f(self, x=None, u=None, t=None):
+        return self.params
+
+
+class LearnableMatrix(NamedTuple):
+    params: Any
+
+    def f(self, x=None, u=None, t=None):
+        return self.params
+
+
+class LearnableLinear(NamedTuple):
+    """f(x) = weights @ x + bias"""
+    weights: Any
+    bias: Any
+
+    def f(self, x, u=None, t=None):
+        return np.asarray(self.weights) @ np.asarray(x) + np.asarray(self.bias)
+
+
+class LearnableLorenz63(NamedTuple):
+    sigma: Any
+    rho: Any
+    beta: Any
+
+    def f(self, x, u=None, t=None):
+        return np.array([
+            self.sigma * (x[1] - x[0]),
+            x[0] * (self.rho - x[2]) - x[1],
+            x[0] * x[1] - self.beta * x[2],
+        ])
+
+
+class LearnableLorenz96(NamedTuple):
+    """f_i = (x_{i+1} - x_{i-2}) x_{i-1} - x_i + forcing (cyclic)."""
+    forcing: Any
+
+    def f(self, x, u=None, t=None):
+        x = np.asarray(x)
+        return (np.roll(x, -1) - np.roll(x, 2)) * np.roll(x, 1) - x + self.forcing
+
+
+class LearnableMLP(NamedTuple):
+    """f(x) = W3 tanh(W2 tanh(W1 x + b1) + b2) + b3."""
+    W1: Any
+    b1: Any
+    W2: Any
+    b2: Any
+    W3: Any
+    b3: Any
+
+    def f(self, x, u=None, t=None):
+        a1 = np.tanh(np.asarray(self.W1) @ np.asarray(x) + np.asarray(self.b1))
+        a2 = np.tanh(np.asarray(self.W2) @ a1 + np.asarray(self.b2))
+        return np.asarray(self.W3) @ a2 + np.asarray(self.b3)
+
+
+class ParamsLGSSMInitial(NamedTuple):
+    mean: Any
+    cov: Any
+
+
+class ParamsCDNLGSSMDynamics(NamedTuple):
+    drift: Any
+    diffusion_coefficient: Any
+    diffusion_cov: Any
+    approx_order: Any = 2.0
+
+
+class ParamsCDNLGSSMEmissions(NamedTuple):
+    emission_function: Any
+    emission_cov: Any
+
+
+class ParamsCDNLGSSM(NamedTuple):
+    initial: ParamsLGSSMInitial
+    dynamics: ParamsCDNLGSSMDynamics
+    emissions: ParamsCDNLGSSMEmissions
+
+
+class PosteriorGSSMFiltered(NamedTuple):
+    marginal_loglik: Any
+    filtered_means: Optional[Any] = None
+    filtered_covariances: Optional[Any] = None
+    predicted_means: Optional[Any] = None
+    predicted_covariances: Optional[Any] = None
+
+
+class PosteriorGSSMSmoothed(NamedTuple):
+    marginal_loglik: Any
+    filtered_means: Any
+    filtered_covariances: Any
+    smoothed_means: Any
+    smoothed_covariances: Any
+    smoothed_cross_covariances: Optional[Any] = None
+
+
+class EKFHyperParams(NamedTuple):
+    dt_final: float = 1e-10
+    state_order: str = "second"
+    emission_order: str = "first"
+    smooth_order: str = "first"
+    cov_rescaling: float = 1.0
+    diffeqsolve_settings: dict = {}
+
+
+class UKFHyperParams(NamedTuple):
+    dt_final: float = 1e-10
+    alpha: float = math.sqrt(3)
+    beta: int = 2
+    kappa: int = 1
+    diffeqsolve_settings: dict = {}
+
+
+class EnKFHyperParams(NamedTuple):
+    """Present only so that ``isinstance`` dispatch can reject it explicitly: the ensemble filter is
+    stochastic (JAX PRNG / Brownian tree) and out of scope."""
+    dt_final: float = 1e-10
+    N_particles: int = 100

@@ -1,0 +1,194 @@
+/*
+ * cdkf.h -- C ABI of the MI355X-native continuous-discrete Gaussian filtering engine.
+ *
+ * This is the drop-in boundary for the batched-trajectory hot path of hd-UQ/cd_dynamax.  The
+ * reference is pure Python/JAX and has no FFI of its own, so each entry
+ * point below names the reference *function* it replaces (paths relative to /root/reference).
+ * Only plain pointers, sizes and PODs cross this boundary: no torch / numpy / HIP types.
+ *
+ * Conventions
+ *  - All matrices are dense row-major.  N = trajectories, T = observations per trajectory,
+ *    d = state_dim, m = emission_dim.
+ *  - Reference layout, opts.layout = CDKF_LAYOUT_NT (what `jax.vmap` over the trajectory axis produces):
+ *      t  [N,T]   (or [T] when opts.t_shared != 0; the reference's t_emissions[:,0])
+ *      y  [N,T,m]
+ *      means [N,T,d], covariances [N,T,d,d], ll [N], status [N]
+ *    Time-major layout, opts.layout = CDKF_LAYOUT_TN: the same arrays with the first two axes swapped.
+ *  - Output pointers may be NULL: that field is then not produced (the reference's
+ *    `output_fields` filter, inference_ekf.py:209,315).
+ *  - Functions return 0 on success or a negative CDKF_E* code; cdkf_last_error() returns a
+ *    thread-local message.  Numerical failures are NOT errors: they are flagged in status[n]
+ *    and the outputs go NaN from that step on, like the reference's silent NaN propagation.
+ *  - `_dev` variants take DEVICE pointers (hipMalloc'ed / torch tensors' data_ptr) and a
+ *    hipStream_t passed as void* (NULL = the default stream); they enqueue work and return without
+ *    synchronising.  The host variants allocate, copy, run, copy back and free.
+ *  - The model parameter block is always given in double on the host and converted to the
+ *    compute type inside the library.
+ */
+#ifndef CDKF_H
+#define CDKF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CDKF_VERSION 100 /* 0.1.0 */
+
+/* error codes */
+#define CDKF_OK 0
+#define CDKF_EINVAL (-1)      /* bad argument (NULL pointer, negative size, ...) */
+#define CDKF_EUNSUPPORTED (-2) /* no kernel for this (drift, d, m, option) combination */
+#define CDKF_EHIP (-3)        /* a HIP runtime call failed (no device, out of memory, ...) */
+
+/* status[n] bit flags */
+#define CDKF_STATUS_NOT_PD 1    /* a Cholesky pivot was <= 0 (S, or P in the UKF / smoother) */
+#define CDKF_STATUS_NAN 2       /* a NaN reached the filtered mean */
+#define CDKF_STATUS_MAX_STEPS 4 /* an observation interval needed more than max_steps RK steps */
+
+/* drift registry: the reference's `params.dynamics.drift` Learnable* classes
+ * (src/continuous_discrete_nonlinear_gaussian_ssm/cdnlgssm_utils.py:50-83) plus two build-defined
+ * families for BASELINE.json configs 4 and 5.  theta layouts: */
+#define CDKF_DRIFT_LINEAR 0   /* LearnableLinear: theta = [W (d*d), b (d)]; f = W x + b */
+#define CDKF_DRIFT_LORENZ63 1 /* LearnableLorenz63: theta = [sigma, rho, beta]; d = 3 */
+#define CDKF_DRIFT_LORENZ96 2 /* theta = [F]; f_i = (x_{i+1} - x_{i-2}) x_{i-1} - x_i + F; d >= 4 */
+#define CDKF_DRIFT_MLP_TANH 3 /* theta = [W1 (h1*d), b1 (h1), W2 (h2*h1), b2 (h2), W3 (d*h2), b3 (d)];
+                                 f = W3 tanh(W2 tanh(W1 x + b1) + b2) + b3 */
+
+/* array layouts (opts.layout).  NT is what jax.vmap over trajectories produces in the reference;
+ * TN is the engine's native time-major layout: at step k the 64 trajectories of a wavefront touch
+ * one contiguous run of memory, so every load and store coalesces. */
+#define CDKF_LAYOUT_NT 0 /* t [N,T], y [N,T,m], means [N,T,d], covariances [N,T,d,d] */
+#define CDKF_LAYOUT_TN 1 /* t [T,N], y [T,N,m], means [T,N,d], covariances [T,N,d,d] */
+
+/* state_order of EKFHyperParams (inference_ekf.py:40) */
+#define CDKF_ORDER_ZEROTH 0
+#define CDKF_ORDER_FIRST 1
+#define CDKF_ORDER_SECOND 2
+
+/* ParamsCDNLGSSM (cdnlgssm_utils.py:191-209) restricted to what the hot path reads.  The
+ * emission function is the reference's LearnableLinear: h(x) = H x + h_bias. */
+typedef struct cdkf_model {
+  int32_t drift_kind;   /* CDKF_DRIFT_* */
+  int32_t state_dim;    /* d */
+  int32_t emission_dim; /* m */
+  int32_t hidden1;      /* MLP only */
+  int32_t hidden2;      /* MLP only */
+  int32_t reserved;
+  int64_t n_theta;
+  const double* theta; /* [n_theta] drift parameters */
+  const double* L;     /* [d,d] diffusion coefficient  (params.dynamics.diffusion_coefficient) */
+  const double* Qc;    /* [d,d] diffusion covariance   (params.dynamics.diffusion_cov) */
+  const double* H;     /* [m,d] emission weights */
+  const double* h_bias;/* [m]   emission bias */
+  const double* R;     /* [m,m] emission covariance */
+  const double* m0;    /* [d]   initial mean */
+  const double* P0;    /* [d,d] initial covariance */
+} cdkf_model;
+
+/* EKFHyperParams / UKFHyperParams (inference_ekf.py:34-44, inference_ukf.py:25-33) and the
+ * defaults of src/utils/diffrax_utils.py:40-52 (Dopri5, ConstantStepSize, dt0 = 0.01). */
+typedef struct cdkf_opts {
+  int32_t state_order;  /* CDKF_ORDER_*; default SECOND */
+  int32_t num_iter;     /* EKF update re-linearisations; default 1 */
+  int32_t t_shared;     /* 0: t is [N,T]; 1: t is [T], shared by all trajectories */
+  int32_t device;       /* HIP device ordinal; -1 = current device */
+  int32_t layout;       /* CDKF_LAYOUT_NT (default) or CDKF_LAYOUT_TN; applies to t (unless shared), y and
+                           every mean / covariance array.  ll and status are always [N]. */
+  int32_t reserved;
+  int64_t max_steps;    /* RK steps per observation interval; default 100000 */
+  double dt0;           /* default 0.01 */
+  double dt_final;      /* default 1e-10 (inference_ekf.py:39) */
+  double cov_rescaling; /* zeroth-order only; default 1.0 */
+  double ukf_alpha;     /* default sqrt(3) */
+  double ukf_beta;      /* default 2 */
+  double ukf_kappa;     /* default 1 */
+} cdkf_opts;
+
+/* Fill *opts with the reference defaults listed above. */
+void cdkf_default_opts(cdkf_opts* opts);
+
+int cdkf_version(void);
+const char* cdkf_last_error(void);
+/* Number of HIP devices visible, or a negative error code. */
+int cdkf_device_count(void);
+/* 1 if a kernel exists for this model/algorithm/precision, else 0.  algo: 0 EKF filter,
+ * 1 UKF filter, 2 EKF smoother.  bytes_per_real: 4 or 8. */
+int cdkf_supported(const cdkf_model* mdl, const cdkf_opts* opts, int algo, int bytes_per_real);
+
+/* ---- device memory helpers (so that host code needs no other GPU runtime) ------------------- */
+int cdkf_malloc(void** dev_ptr, int64_t bytes);
+int cdkf_free(void* dev_ptr);
+int cdkf_memcpy_h2d(void* dev_dst, const void* host_src, int64_t bytes);
+int cdkf_memcpy_d2h(void* host_dst, const void* dev_src, int64_t bytes);
+int cdkf_memset(void* dev_ptr, int value, int64_t bytes);
+int cdkf_synchronize(void* stream);
+
+/* ---- EKF filter: replaces extended_kalman_filter / iterated_extended_kalman_filter
+ *      (src/continuous_discrete_nonlinear_gaussian_ssm/inference_ekf.py:202-361) under
+ *      jax.vmap over trajectories (src/ssm_temissions.py:555-566). ------------------------------ */
+int cdkf_ekf_filter_f64(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T,
+                        const double* t, const double* y, double* ll, double* filtered_means,
+                        double* filtered_covs, double* predicted_means, double* predicted_covs,
+                        int32_t* status);
+int cdkf_ekf_filter_f32(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T,
+                        const float* t, const float* y, float* ll, float* filtered_means,
+                        float* filtered_covs, float* predicted_means, float* predicted_covs,
+                        int32_t* status);
+int cdkf_ekf_filter_f64_dev(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T,
+                            const double* t, const double* y, double* ll, double* filtered_means,
+                            double* filtered_covs, double* predicted_means, double* predicted_covs,
+                            int32_t* status, void* stream);
+int cdkf_ekf_filter_f32_dev(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T,
+                            const float* t, const float* y, float* ll, float* filtered_means,
+                            float* filtered_covs, float* predicted_means, float* predicted_covs,
+                            int32_t* status, void* stream);
+
+/* ---- UKF filter: replaces unscented_kalman_filter (inference_ukf.py:206-308). ---------------- */
+int cdkf_ukf_filter_f64(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T,
+                        const double* t, const double* y, double* ll, double* filtered_means,
+                        double* filtered_covs, double* predicted_means, double* predicted_covs,
+                        int32_t* status);
+int cdkf_ukf_filter_f32(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T,
+                        const float* t, const float* y, float* ll, float* filtered_means,
+                        float* filtered_covs, float* predicted_means, float* predicted_covs,
+                        int32_t* status);
+int cdkf_ukf_filter_f64_dev(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T,
+                            const double* t, const double* y, double* ll, double* filtered_means,
+                            double* filtered_covs, double* predicted_means, double* predicted_covs,
+                            int32_t* status, void* stream);
+int cdkf_ukf_filter_f32_dev(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T,
+                            const float* t, const float* y, float* ll, float* filtered_means,
+                            float* filtered_covs, float* predicted_means, float* predicted_covs,
+                            int32_t* status, void* stream);
+
+/* ---- EKF (RTS) smoother: replaces extended_kalman_smoother / iterated_extended_kalman_smoother
+ *      (inference_ekf.py:450-593): runs the filter (num_iter = 1) and then the backward sweep
+ *      of _smooth (inference_ekf.py:363-448).  filtered_* and smoothed_* are all required. ----- */
+int cdkf_ekf_smoother_f64(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T,
+                          const double* t, const double* y, double* ll, double* filtered_means,
+                          double* filtered_covs, double* smoothed_means, double* smoothed_covs,
+                          int32_t* status);
+int cdkf_ekf_smoother_f32(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T,
+                          const float* t, const float* y, float* ll, float* filtered_means,
+                          float* filtered_covs, float* smoothed_means, float* smoothed_covs,
+                          int32_t* status);
+int cdkf_ekf_smoother_f64_dev(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T,
+                              const double* t, const double* y, double* ll, double* filtered_means,
+                              double* filtered_covs, double* smoothed_means, double* smoothed_covs,
+                              int32_t* status, void* stream);
+int cdkf_ekf_smoother_f32_dev(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T,
+                              const float* t, const float* y, float* ll, float* filtered_means,
+                              float* filtered_covs, float* smoothed_means, float* smoothed_covs,
+                              int32_t* status, void* stream);
+
+/* ---- sum_n ll[n]: the reduction of src/ssm_temissions.py:567 (`vmap(...)(...).sum()`), done on
+ *      the device so that the multi-GPU caller can all-reduce ONE scalar over RCCL. ------------- */
+int cdkf_ll_sum_f64_dev(const double* ll, int64_t N, double* out_sum, void* stream);
+int cdkf_ll_sum_f32_dev(const float* ll, int64_t N, double* out_sum, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CDKF_H */

@@ -97,8 +97,8 @@ class Lorenz63Drift:
     kind = "lorenz63"
 
     def __init__(self, sigma=10.0, rho=28.0, beta=8.0 / 3.0, dtype=np.float64):
-        self.dtype = dtype
-        self.sigma, self.rho, self.beta = (dtype(sigma), dtype(rho), dtype(beta))
+        self.dtype = np.dtype(dtype).type
+        self.sigma, self.rho, self.beta = (self.dtype(sigma), self.dtype(rho), self.dtype(beta))
 
     def cast(self, dtype):
         return Lorenz63Drift(self.sigma, self.rho, self.beta, dtype=dtype)
@@ -136,8 +136,8 @@ class Lorenz96Drift:
     kind = "lorenz96"
 
     def __init__(self, forcing=8.0, dtype=np.float64):
-        self.dtype = dtype
-        self.F = dtype(forcing)
+        self.dtype = np.dtype(dtype).type
+        self.F = self.dtype(forcing)
 
     def cast(self, dtype):
         return Lorenz96Drift(self.F, dtype=dtype)

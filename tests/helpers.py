@@ -1,0 +1,127 @@
+"""Shared test helpers: oracle-model -> drop-in params, closed-form linear Kalman filter / RTS smoother
+(an oracle-independent cross-check), comparison utilities in the style of the reference's
+src/utils/test_utils.py:160-179 (compare_structs tolerance ladder)."""
+import numpy as np
+import scipy.linalg as sla
+
+import cd_dynamax_amd as cd
+import cdkf_oracle as o
+
+
+def params_from(mdl: o.Model) -> cd.ParamsCDNLGSSM:
+    dr = mdl.drift
+    if dr.kind == "lorenz63":
+        drift = cd.LearnableLorenz63(float(dr.sigma), float(dr.rho), float(dr.beta))
+    elif dr.kind == "linear":
+        drift = cd.LearnableLinear(dr.W, dr.b)
+    elif dr.kind == "lorenz96":
+        drift = cd.LearnableLorenz96(float(dr.F))
+    elif dr.kind == "mlp":
+        drift = cd.LearnableMLP(dr.W1, dr.b1, dr.W2, dr.b2, dr.W3, dr.b3)
+    else:
+        raise ValueError(dr.kind)
+    return cd.ParamsCDNLGSSM(
+        initial=cd.ParamsLGSSMInitial(cd.LearnableVector(mdl.m0), cd.LearnableMatrix(mdl.P0)),
+        dynamics=cd.ParamsCDNLGSSMDynamics(drift, cd.LearnableMatrix(mdl.L), cd.LearnableMatrix(mdl.Qc), 2.0),
+        emissions=cd.ParamsCDNLGSSMEmissions(cd.LearnableLinear(mdl.H, mdl.bias), cd.LearnableMatrix(mdl.R)))
+
+
+def relerr(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-300))
+
+
+def assert_close_structs(got: dict, ref: dict, rtol, names=None):
+    for k in names or ref.keys():
+        if k in got and got[k] is not None:
+            e = relerr(got[k], ref[k])
+            assert e <= rtol, f"{k}: max-relative error {e:.3e} > {rtol:.1e}"
+
+
+def linear_model(rng, d, m, stable=True):
+    W = -0.5 * np.eye(d) + 0.3 * rng.standard_normal((d, d)) / np.sqrt(d)
+    b = 0.2 * rng.standard_normal(d)
+    L = np.eye(d) + 0.1 * rng.standard_normal((d, d))
+    A = rng.standard_normal((d, d))
+    Qc = 0.3 * (A @ A.T / d + np.eye(d))
+    H = rng.standard_normal((m, d))
+    hb = 0.1 * rng.standard_normal(m)
+    B = rng.standard_normal((m, m))
+    R = 0.2 * (B @ B.T / m + np.eye(m))
+    m0 = rng.standard_normal(d)
+    C = rng.standard_normal((d, d))
+    P0 = C @ C.T / d + 0.5 * np.eye(d)
+    return o.Model(o.LinearDrift(W, b), L, Qc, H, hb, R, m0, P0)
+
+
+def van_loan(F, LQL, b, dt):
+    """Exact discretisation of dx = (F x + b) dt + L dW over dt: x' = A x + c + N(0, Q)."""
+    d = F.shape[0]
+    Mx = np.zeros((2 * d, 2 * d))
+    Mx[:d, :d] = -F
+    Mx[:d, d:] = LQL
+    Mx[d:, d:] = F.T
+    E = sla.expm(Mx * dt)
+    A = E[d:, d:].T
+    Q = A @ E[:d, d:]
+    Ma = np.zeros((d + 1, d + 1))
+    Ma[:d, :d] = F
+    Ma[:d, d] = b
+    c = sla.expm(Ma * dt)[:d, d]
+    return A, 0.5 * (Q + Q.T), c
+
+
+def closed_form_kf(mdl: o.Model, t, y, dt_final=1e-10):
+    """Exact continuous-discrete Kalman filter + RTS smoother for ONE trajectory with a linear drift."""
+    F, b = mdl.drift.W.astype(np.float64), mdl.drift.b.astype(np.float64)
+    LQL = mdl.L @ mdl.Qc @ mdl.L.T
+    T, d = len(t), mdl.d
+    fm, fP, pm, pP = np.zeros((T, d)), np.zeros((T, d, d)), np.zeros((T, d)), np.zeros((T, d, d))
+    As = np.zeros((T, d, d))
+    m, P, ll = mdl.m0.copy(), mdl.P0.copy(), 0.0
+    for k in range(T):
+        S = mdl.H @ P @ mdl.H.T + mdl.R
+        v = y[k] - (mdl.H @ m + mdl.bias)
+        ll += -0.5 * v @ np.linalg.solve(S, v) - 0.5 * np.linalg.slogdet(S)[1] - 0.5 * mdl.m * np.log(2 * np.pi)
+        K = np.linalg.solve(S, mdl.H @ P).T
+        m = m + K @ v
+        P = P - K @ S @ K.T
+        P = 0.5 * (P + P.T)
+        fm[k], fP[k] = m, P
+        dt = (t[k + 1] - t[k]) if k + 1 < T else dt_final
+        A, Q, c = van_loan(F, LQL, b, dt)
+        As[k] = A
+        m = A @ m + c
+        P = A @ P @ A.T + Q
+        pm[k], pP[k] = m, P
+    sm, sP = fm.copy(), fP.copy()
+    for k in range(T - 2, -1, -1):
+        G = np.linalg.solve(pP[k], As[k] @ fP[k]).T
+        sm[k] = fm[k] + G @ (sm[k + 1] - pm[k])
+        sP[k] = fP[k] + G @ (sP[k + 1] - pP[k]) @ G.T
+    return dict(marginal_loglik=ll, filtered_means=fm, filtered_covariances=fP, predicted_means=pm,
+                predicted_covariances=pP, smoothed_means=sm, smoothed_covariances=sP)
+
+
+def model_from_fixture(g) -> o.Model:
+    kind = str(g["drift_kind"])
+    th = g["theta"]
+    d = g["m0"].shape[0]
+    if kind == "linear":
+        drift = o.LinearDrift(th[: d * d].reshape(d, d), th[d * d:])
+    elif kind == "lorenz63":
+        drift = o.Lorenz63Drift(*th)
+    elif kind == "lorenz96":
+        drift = o.Lorenz96Drift(th[0])
+    else:
+        raise ValueError(kind)
+    return o.Model(drift, g["L"], g["Qc"], g["H"], g["bias"], g["R"], g["m0"], g["P0"])
+
+
+GOLDEN = ["linear_d2_m6_regular", "tracking_d4_m2_regular", "lorenz63_m3_irregular", "lorenz63_m1_irregular"]
+FILTER_KEYS = ["filtered_means", "filtered_covariances", "predicted_means", "predicted_covariances"]
+
+
+def load_golden(name):
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))

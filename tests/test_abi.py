@@ -1,0 +1,86 @@
+"""The C-ABI library builds, loads, and exports every symbol include/cdkf.h declares; struct layouts match;
+without a GPU every compute entry point fails loudly (no silent fallback).  CPU only."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from cd_dynamax_amd import _ffi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "cdkf.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(cdkf_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol(hip_lib):
+    syms = header_symbols()
+    assert len(syms) >= 25
+    for s in syms:
+        assert hasattr(hip_lib, s), f"libcdkf_hip.so does not export {s}"
+    assert sorted(_ffi.SYMBOLS) == syms, "cd_dynamax_amd/_ffi.py SYMBOLS out of sync with include/cdkf.h"
+
+
+def test_version_and_default_opts(hip_lib):
+    assert hip_lib.cdkf_version() == 100
+    o = _ffi.default_opts()
+    assert (o.state_order, o.num_iter, o.t_shared, o.device, o.layout) == (2, 1, 0, -1, 0)
+    assert o.max_steps == 100000 and o.dt0 == 0.01 and o.dt_final == 1e-10 and o.cov_rescaling == 1.0
+    assert abs(o.ukf_alpha - np.sqrt(3)) < 1e-15 and o.ukf_beta == 2 and o.ukf_kappa == 1
+    # struct sizes the header implies (LP64): guards against silent ABI drift
+    assert C.sizeof(_ffi.CdkfOpts) == 6 * 4 + 8 + 6 * 8
+    assert C.sizeof(_ffi.CdkfModel) == 6 * 4 + 8 + 8 * 8
+
+
+def _l63_block():
+    return _ffi.ModelBlock(_ffi.DRIFT_LORENZ63, [10, 28, 8 / 3], np.eye(3), np.eye(3), np.eye(3), np.zeros(3), np.eye(3),
+                           np.zeros(3), 5 * np.eye(3))
+
+
+def test_supported_shapes(hip_lib):
+    o = _ffi.default_opts()
+    blk = _l63_block()
+    for algo in (0, 1, 2):
+        assert hip_lib.cdkf_supported(C.byref(blk.c), C.byref(o), algo, 8) == 1
+        assert hip_lib.cdkf_supported(C.byref(blk.c), C.byref(o), algo, 4) == 1
+    assert hip_lib.cdkf_supported(C.byref(blk.c), C.byref(o), 0, 2) == 0
+    assert hip_lib.cdkf_supported(None, C.byref(o), 0, 8) == 0
+
+
+def test_argument_errors_are_reported(hip_lib):
+    o = _ffi.default_opts()
+    blk = _l63_block()
+    t = np.zeros((2, 4))
+    y = np.zeros((2, 4, 3))
+    ll = np.zeros(2)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    f = hip_lib.cdkf_ekf_filter_f64
+    assert f(C.byref(blk.c), C.byref(o), 2, 0, vp(t), vp(y), vp(ll), None, None, None, None, None) == _ffi.CDKF_EINVAL
+    assert b"T >= 1" in hip_lib.cdkf_last_error()
+    assert f(C.byref(blk.c), C.byref(o), 2, 4, None, vp(y), vp(ll), None, None, None, None, None) == _ffi.CDKF_EINVAL
+    o.state_order = 7
+    assert f(C.byref(blk.c), C.byref(o), 2, 4, vp(t), vp(y), vp(ll), None, None, None, None, None) == _ffi.CDKF_EINVAL
+    assert b"state_order" in hip_lib.cdkf_last_error()
+    o = _ffi.default_opts()
+    o.layout = 5
+    assert f(C.byref(blk.c), C.byref(o), 2, 4, vp(t), vp(y), vp(ll), None, None, None, None, None) == _ffi.CDKF_EINVAL
+    # N = 0 is a valid empty batch
+    o = _ffi.default_opts()
+    assert f(C.byref(blk.c), C.byref(o), 0, 4, vp(t), vp(y), vp(ll), None, None, None, None, None) == _ffi.CDKF_OK
+
+
+def test_no_gpu_means_loud_failure(hip_lib):
+    """On a box without a GPU the product path must raise, never fall back to a CPU computation."""
+    if hip_lib.cdkf_device_count() > 0:
+        pytest.skip("a GPU is present")
+    import cd_dynamax_amd as cd
+    from helpers import params_from
+    import cdkf_oracle as orc
+    with pytest.raises(_ffi.CdkfError) as ei:
+        cd.cdnlgssm_filter(params_from(orc.lorenz63_model(3)), np.zeros((5, 3)), np.arange(5.0)[:, None])
+    assert ei.value.code == _ffi.CDKF_EHIP

@@ -1,0 +1,198 @@
+"""Pins the CPU oracle (oracle/cdkf_oracle.py) to everything the reference's own tests hold for the
+hot path.  CPU only."""
+import numpy as np
+import pytest
+
+import cdkf_oracle as o
+from helpers import closed_form_kf, linear_model, relerr
+
+
+def test_dopri5_known_answer_constants_fp32():
+    """/root/reference/src/test_scripts/cdlgssm_test_filter_TRegular.py:59-60: the float32 Dopri5
+    (dt0 = 0.01) push-forward of F = -0.1 I, L = Qc = 0.5 I over dt = 1 -- bit-exact."""
+    dt = np.float32
+    mdl = o.Model(o.LinearDrift(-0.1 * np.eye(2), np.zeros(2)), 0.5 * np.eye(2), 0.5 * np.eye(2), np.eye(2),
+                  np.zeros(2), np.eye(2), np.zeros(2), np.eye(2)).cast(np.dtype(dt))
+    m = np.array([[1, 0], [0, 1]], dtype=dt)
+    P = np.zeros((2, 2, 2), dtype=dt)
+    m1, P1 = o.ekf_predict(mdl, m, P, np.zeros(2), np.ones(2), "first")
+    assert m1.dtype == np.float32 and P1.dtype == np.float32
+    A_ref = np.float32(0.9048373699188232421875)
+    Q_ref = np.float32(0.11329327523708343505859375)
+    assert m1[0, 0] == A_ref and m1[1, 1] == A_ref and m1[0, 1] == 0
+    assert P1[0, 0, 0] == Q_ref and P1[0, 1, 1] == Q_ref and P1[0, 0, 1] == 0
+
+
+def test_dopri5_fp64_matches_closed_form():
+    mdl = o.Model(o.LinearDrift(-0.1 * np.eye(2), np.zeros(2)), 0.5 * np.eye(2), 0.5 * np.eye(2), np.eye(2),
+                  np.zeros(2), np.eye(2), np.zeros(2), np.eye(2))
+    m1, P1 = o.ekf_predict(mdl, np.array([[1.0, 0.0]]), np.zeros((1, 2, 2)), np.zeros(1), np.ones(1), "first")
+    assert abs(m1[0, 0] - np.exp(-0.1)) < 1e-14
+    assert abs(P1[0, 0, 0] - 0.125 * (1 - np.exp(-0.2)) / 0.2) < 1e-14
+
+
+def test_step_counts_and_end_clipping():
+    """diffrax 0.4.0 loop: n = ceil(gap/dt0) steps, the last clipped to t1; zero-length interval = no step;
+    a gap within 1e-10 of a multiple of dt0 does not spawn a sliver step after the first."""
+    counts = []
+    gaps = np.array([0.0, 1e-10, 0.004, 0.01, 0.0100001, 0.025, 0.03, 0.03 - 1e-12, 0.1])
+    y0 = (np.ones((len(gaps), 1)),)
+    o.diffeqsolve(lambda y: (-y[0],), np.zeros(len(gaps)), gaps, y0, count_steps=counts)
+    assert counts[0].tolist() == [0, 1, 1, 1, 2, 3, 3, 3, 10]
+    (y1,) = o.diffeqsolve(lambda y: (-y[0],), np.zeros(len(gaps)), gaps, y0)
+    np.testing.assert_allclose(y1[:, 0], np.exp(-gaps), rtol=1e-12)
+
+
+@pytest.mark.parametrize("regular", [True, False])
+@pytest.mark.parametrize("d,m", [(2, 6), (4, 2), (3, 3)])
+def test_linear_filters_equal_closed_form_kf(regular, d, m):
+    """cdnlgssm_test_filter_linear_TRegular.py:314-324 (EKF first & second) and :414-424 (UKF) assert
+    equality with the CD Kalman filter at rtol 1e-5; here against an exact expm Kalman filter, also
+    on irregular grids.  (2,6) is the test script's STATE_DIM/EMISSION_DIM."""
+    rng = np.random.default_rng(10 * d + m)
+    T = 100
+    mdl = linear_model(rng, d, m)
+    t = (np.arange(T, dtype=float) if regular else o.irregular_times(rng, 1, T, 30.0)[0])[None]
+    y = o.simulate(mdl, t, rng)
+    dtf = 1.0 if regular else 1e-10
+    ref = closed_form_kf(mdl, t[0], y[0], dt_final=dtf)
+    names = ["filtered_means", "filtered_covariances", "predicted_means", "predicted_covariances"]
+    for order in ("first", "second"):
+        got = o.ekf_filter(mdl, t, y, state_order=order, dt_final=dtf)
+        for k in names:
+            assert relerr(got[k][0], ref[k]) < 1e-7, (order, k)
+        assert abs(got["marginal_loglik"][0] - ref["marginal_loglik"]) < 1e-6 * abs(ref["marginal_loglik"])
+    got = o.ukf_filter(mdl, t, y, dt_final=dtf)
+    for k in names:
+        assert relerr(got[k][0], ref[k]) < 1e-7, ("ukf", k)
+    assert abs(got["marginal_loglik"][0] - ref["marginal_loglik"]) < 1e-6 * abs(ref["marginal_loglik"])
+    # float32 runs (the reference's precision) meet the reference's rtol = 1e-5 ... 1e-4 ladder
+    got32 = o.ekf_filter(mdl, t, y, dtype=np.float32, dt_final=dtf)
+    assert got32["filtered_means"].dtype == np.float32
+    for k in names:
+        assert relerr(got32[k][0], ref[k]) < 2e-4, ("fp32", k)
+
+
+def test_t_emissions_none_equals_arange():
+    """cdnlgssm_test_filter_linear_TRegular.py:136-139: t_emissions=None == t_emissions=arange(T) with the last
+    interval of length 1 (inference_ekf.py:247-250)."""
+    rng = np.random.default_rng(3)
+    mdl = linear_model(rng, 2, 3)
+    T = 20
+    t = np.arange(T, dtype=float)[None]
+    y = o.simulate(mdl, t, rng)
+    a = o.ekf_filter(mdl, t, y, dt_final=1.0)
+    ref = closed_form_kf(mdl, t[0], y[0], dt_final=1.0)
+    assert relerr(a["predicted_covariances"][0, -1], ref["predicted_covariances"][-1]) < 1e-8
+
+
+@pytest.mark.parametrize("d,m", [(2, 6), (3, 2)])
+def test_linear_smoother_equals_cd_smoother_type2(d, m):
+    """cdnlgssm_test_smoother_linear_TRegular.py:222-232 + src/test_scripts/README.md: on a linear model the
+    EKF smoother equals the CD Kalman smoother "type 2", whose backward ODE
+    (continuous_discrete_linear_gaussian_ssm/inference.py:636-690) holds the filtered (m_f, P_f) of the left
+    end of each interval fixed: dm_s = F m_s + aux (m_s - m_f), dP_s = (F+aux) P_s + P_s (F+aux)^T - LQL^T,
+    aux = psd_solve(P_f, LQL)^T.  Integrated here independently with scipy's adaptive solve_ivp."""
+    from scipy.integrate import solve_ivp
+    rng = np.random.default_rng(7 + d)
+    T = 40
+    mdl = linear_model(rng, d, m)
+    mdl.drift.b[:] = 0  # the linear type-2 smoother has no bias term
+    t = o.irregular_times(rng, 1, T, 6.0)
+    y = o.simulate(mdl, t, rng)
+    got = o.ekf_smoother(mdl, t, y)
+    fm, fP = got["filtered_means"][0], got["filtered_covariances"][0]
+    F = mdl.drift.W
+    LQL = mdl.L @ mdl.Qc @ mdl.L.T
+    ms, Ps = fm[-1].copy(), fP[-1].copy()
+    for k in range(T - 2, -1, -1):
+        aux = np.linalg.solve(0.5 * (fP[k] + fP[k].T) + 1e-9 * np.eye(d), LQL).T
+        G = F + aux
+
+        def rhs(_, v, G=G, k=k, aux=aux):
+            mm, PP = v[:d], v[d:].reshape(d, d)
+            return np.concatenate([F @ mm + aux @ (mm - fm[k]), (G @ PP + PP @ G.T - LQL).ravel()])
+
+        # restart every interval from the oracle's own value at t_{k+1}: isolates one interval's integration
+        ms, Ps = got["smoothed_means"][0, k + 1], got["smoothed_covariances"][0, k + 1]
+        sol = solve_ivp(rhs, (t[0, k + 1], t[0, k]), np.concatenate([ms, Ps.ravel()]), rtol=1e-12, atol=1e-14)
+        ms, Ps = sol.y[:d, -1], sol.y[d:, -1].reshape(d, d)
+        assert relerr(got["smoothed_means"][0, k], ms) < 1e-5, k  # Dopri5(dt0=0.01) truncation at |G| dt0 ~ 0.5
+        assert relerr(got["smoothed_covariances"][0, k], Ps) < 1e-5, k
+    np.testing.assert_array_equal(got["smoothed_means"][0, -1], got["filtered_means"][0, -1])
+
+
+def test_smoother_tends_to_exact_rts_for_dense_observations():
+    """The fixed-(m_f, P_f) backward ODE is an O(gap) approximation of the exact RTS recursion (the reference
+    accepts the mismatch with its type-1 smoother, `accept_failure=True`); the two agree as gaps shrink."""
+    errs = []
+    for T_total in (3.0, 0.03):
+        rng = np.random.default_rng(9)
+        mdl = linear_model(rng, 3, 2)
+        t = o.irregular_times(rng, 1, 60, T_total)
+        y = o.simulate(mdl, t, rng)
+        ref = closed_form_kf(mdl, t[0], y[0])
+        got = o.ekf_smoother(mdl, t, y)
+        errs.append(relerr(got["smoothed_covariances"][0], ref["smoothed_covariances"]))
+    assert errs[1] < 2e-3 and errs[1] < errs[0] / 10
+
+
+def test_second_order_term_is_reference_trace_quirk():
+    """0.5*jnp.trace(H_t @ P) on a (d,d,d) Hessian traces axes (0,1), i.e.
+    0.5 * sum_{i,k} d2f_i/dx_i dx_k P[k,:].  Checked against a finite-difference Hessian of the MLP drift."""
+    rng = np.random.default_rng(5)
+    d, h = 3, 5
+    drift = o.MLPDrift(rng.normal(size=(h, d)), rng.normal(size=h), rng.normal(size=(h, h)), rng.normal(size=h),
+                       rng.normal(size=(d, h)), rng.normal(size=d))
+    x = rng.normal(size=(1, d))
+    A = rng.normal(size=(d, d))
+    P = A @ A.T
+    eps = 1e-5
+    Hs = np.zeros((d, d, d))  # Hs[i,j,k] = d2 f_i / dx_j dx_k
+    for k in range(d):
+        e = np.zeros(d)
+        e[k] = eps
+        Hs[:, :, k] = (drift.jac(x + e)[0] - drift.jac(x - e)[0]) / (2 * eps)
+    ref = 0.5 * np.trace(Hs @ P)  # numpy trace on a 3-D array also uses axes (0,1)
+    got = 0.5 * drift.divgrad(x)[0] @ P
+    np.testing.assert_allclose(got, ref, rtol=1e-6, atol=1e-8)
+    for drf in (o.Lorenz63Drift(), o.Lorenz96Drift()):
+        assert np.all(drf.divgrad(rng.normal(size=(2, 6 if drf.kind == "lorenz96" else 3))) == 0)
+
+
+def test_jacobians_match_finite_differences():
+    rng = np.random.default_rng(0)
+    drifts = [(o.Lorenz63Drift(), 3), (o.Lorenz96Drift(), 7),
+              (o.MLPDrift(rng.normal(size=(5, 4)), rng.normal(size=5), rng.normal(size=(6, 5)), rng.normal(size=6),
+                          rng.normal(size=(4, 6)), rng.normal(size=4)), 4)]
+    for drift, d in drifts:
+        x = rng.normal(size=(2, d))
+        J = drift.jac(x)
+        eps = 1e-6
+        for j in range(d):
+            e = np.zeros(d)
+            e[j] = eps
+            np.testing.assert_allclose(J[:, :, j], (drift.f(x + e) - drift.f(x - e)) / (2 * eps), atol=1e-7)
+
+
+def test_psd_solve_and_mvn_against_scipy():
+    import scipy.stats as st
+    rng = np.random.default_rng(1)
+    A = rng.normal(size=(3, 4, 4))
+    S = A @ np.swapaxes(A, -1, -2) + np.eye(4)
+    B = rng.normal(size=(3, 4, 2))
+    X = o.psd_solve(S, B)
+    np.testing.assert_allclose(X, np.linalg.solve(S + 1e-9 * np.eye(4), B), rtol=1e-10)
+    y, mu = rng.normal(size=(3, 4)), rng.normal(size=(3, 4))
+    lp = o.mvn_logpdf(y, mu, S)
+    for i in range(3):
+        np.testing.assert_allclose(lp[i], st.multivariate_normal(mu[i], S[i]).logpdf(y[i]), rtol=1e-12)
+    # non-PD -> NaN, no exception (jnp.linalg.cholesky semantics)
+    assert np.isnan(o.cholesky_lower(np.array([[[1.0, 2.0], [2.0, 1.0]]]))).any()
+
+
+def test_ukf_weights_match_sarkka():
+    lamb, wm, wc, W = o.ukf_weights(3, np.sqrt(3), 2, 1, np.float64)
+    assert abs(lamb - 9) < 1e-12 and abs(wm[0] - 0.75) < 1e-12 and abs(wm[1] - 1 / 24) < 1e-12
+    assert abs(wc[0] - 0.75) < 1e-12 and abs(wm.sum() - 1) < 1e-12
+    np.testing.assert_allclose(W, W.T, atol=1e-15)
