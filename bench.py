@@ -87,15 +87,15 @@ def main():
         emissions=cd.ParamsCDNLGSSMEmissions(cd.LearnableLinear(np.eye(3), np.zeros(3)), cd.LearnableMatrix(np.eye(3))))
     blk = _model_block(params)
     opts = _ffi.default_opts()
-    opts.layout = _ffi.LAYOUT_TN  # engine-native time-major layout
+    opts.layout = _ffi.LAYOUT_TCN  # engine-native layout [T, component, N]: every access coalesces
     N, T = N_PER_GPU, T_STEPS
 
     t_h, y_h = make_batch(rank, N, T)
     t_d = torch.from_numpy(np.ascontiguousarray(t_h.T)).to(dev)                   # [T,N]
-    y_d = torch.from_numpy(np.ascontiguousarray(y_h.transpose(1, 0, 2))).to(dev)  # [T,N,m]
+    y_d = torch.from_numpy(np.ascontiguousarray(y_h.transpose(1, 2, 0))).to(dev)  # [T,m,N]
     ll = torch.empty(N, dtype=torch.float64, device=dev)
-    fm = torch.empty(T, N, D, dtype=torch.float64, device=dev)
-    fP = torch.empty(T, N, D, D, dtype=torch.float64, device=dev)
+    fm = torch.empty(T, D, N, dtype=torch.float64, device=dev)
+    fP = torch.empty(T, D, D, N, dtype=torch.float64, device=dev)
     pm = torch.empty_like(fm)
     pP = torch.empty_like(fP)
     status = torch.zeros(N, dtype=torch.int32, device=dev)
@@ -150,7 +150,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "Lorenz-63 CDNLGSSM EKF (state_order=second), d_x=3, d_y=3, 4096 trajectories x 1000 "
-                                   "irregular obs per GPU, fp64, 4 output fields, time-major layout, Dopri5 dt0=0.01",
+                                   "irregular obs per GPU, fp64, 4 output fields, native [T,comp,N] layout, Dopri5 dt0=0.01",
                        "trajectories_per_gpu": N, "num_timesteps": T, "parallelism": f"dp{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "ekf_filter_reg_kernel<double,3,3,Lorenz63>",
@@ -180,7 +180,7 @@ def cpu_baseline_and_error(t_h, y_h, ll_dev, fm_dev):
     reps = int(max(2, min(200, np.ceil(3.0 / max(ref["_seconds"], 1e-4)))))
     el = sum(oc.ekf_filter(mdl, t_h[:ns], y_h[:ns], nthreads=cores)["_seconds"] for _ in range(reps)) / reps
     ll = ll_dev[:ns].cpu().numpy()
-    fm = fm_dev[:, :ns].cpu().numpy().transpose(1, 0, 2)
+    fm = fm_dev[:, :, :ns].cpu().numpy().transpose(2, 0, 1)
     return {
         "cpu_baseline": {"value": ns / el, "unit": "trajectories/s", "cores": cores, "kind": "port",
                          "sample": f"the same {ns} trajectories x 1000 steps batch, fp64, all four outputs written, C/OpenMP "

@@ -29,6 +29,7 @@ DRIFT_MLP_TANH = 3
 
 LAYOUT_NT = 0
 LAYOUT_TN = 1
+LAYOUT_TCN = 2
 
 ORDER = {"zeroth": 0, "first": 1, "second": 2}
 
@@ -174,23 +175,23 @@ def run_host(algo: str, mdl: ModelBlock, opts: CdkfOpts, t: np.ndarray, y: np.nd
     the four optional output arrays in ABI order.  Returns (ll, [4 arrays or None], status); the
     arrays have the reference shapes [N,T,...].
 
-    The device side always runs in the engine's time-major layout (CDKF_LAYOUT_TN): inputs are
-    transposed on the host before upload and the outputs come back as transposed VIEWS of the
-    time-major buffers (same shapes and values as the reference's arrays, no extra copy).
+    The device side always runs in the engine's native layout (CDKF_LAYOUT_TCN: time, component,
+    trajectory): inputs are transposed on the host before upload and the outputs come back as
+    transposed VIEWS of the native buffers (same shapes and values as the reference's arrays, no copy).
     """
     dtype = np.dtype(dtype)
     suffix = {np.dtype(np.float32): "f32", np.dtype(np.float64): "f64"}[dtype]
     N, T, m = y.shape
     d = mdl.state_dim
-    opts.layout = LAYOUT_TN
+    opts.layout = LAYOUT_TCN
     t = np.asarray(t, dtype=dtype)
     t = np.ascontiguousarray(t if opts.t_shared else t.T)
-    y = np.ascontiguousarray(np.asarray(y, dtype=dtype).transpose(1, 0, 2))
+    y = np.ascontiguousarray(np.asarray(y, dtype=dtype).transpose(1, 2, 0))  # [T,m,N]
     ll = np.empty((N,), dtype)
     status = np.zeros((N,), np.int32)
-    shapes = [(T, N, d), (T, N, d, d), (T, N, d), (T, N, d, d)]
+    shapes = [(T, d, N), (T, d, d, N), (T, d, N), (T, d, d, N)]
     outs = [np.empty(s, dtype) if w else None for s, w in zip(shapes, want)]
     fn = getattr(lib(), f"cdkf_{algo}_{suffix}")
     check(fn(C.byref(mdl.c), C.byref(opts), N, T, _vp(t), _vp(y), _vp(ll), *[_vp(o) for o in outs], _vp(status)))
-    outs = [None if o is None else np.swapaxes(o, 0, 1) for o in outs]
+    outs = [None if o is None else np.moveaxis(o, -1, 0) for o in outs]  # [N,T,d(,d)] views
     return ll, outs, status

@@ -39,8 +39,8 @@ int check_common(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T
     set_error("EKF hyperparams.state_order = %d not implemented yet", o->state_order);
     return CDKF_EINVAL;
   }
-  if (o->layout != CDKF_LAYOUT_NT && o->layout != CDKF_LAYOUT_TN) {
-    set_error("opts.layout must be CDKF_LAYOUT_NT or CDKF_LAYOUT_TN");
+  if (o->layout != CDKF_LAYOUT_NT && o->layout != CDKF_LAYOUT_TN && o->layout != CDKF_LAYOUT_TCN) {
+    set_error("opts.layout must be CDKF_LAYOUT_NT, CDKF_LAYOUT_TN or CDKF_LAYOUT_TCN");
     return CDKF_EINVAL;
   }
   if (o->num_iter < 1 || !(o->dt0 > 0) || o->max_steps < 1) {

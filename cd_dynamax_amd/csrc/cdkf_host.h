@@ -96,7 +96,16 @@ void fill_reg_args(RegArgs<R, D, M, Drift>& a, const cdkf_model* mdl, const cdkf
   a.num_iter = o->num_iter;
   a.N = N;
   a.T = T;
-  if (o->layout == CDKF_LAYOUT_TN) {  // time-major [T,N,w]
+  a.y_si = a.m_si = a.P_si = 1;
+  if (o->layout == CDKF_LAYOUT_TCN) {  // [T,w,N]: component-major inside a time step
+    a.t_sn = o->t_shared ? 0 : 1;
+    a.t_sk = o->t_shared ? 1 : N;
+    a.y_sn = a.m_sn = a.P_sn = 1;
+    a.y_sk = N * M;
+    a.m_sk = N * D;
+    a.P_sk = N * D * D;
+    a.y_si = a.m_si = a.P_si = N;
+  } else if (o->layout == CDKF_LAYOUT_TN) {  // time-major [T,N,w]
     a.t_sn = o->t_shared ? 0 : 1;
     a.t_sk = o->t_shared ? 1 : N;
     a.y_sn = M;

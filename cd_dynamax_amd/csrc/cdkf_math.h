@@ -109,42 +109,94 @@ struct Dp5 {
                      b5 = R(-2187.0 / 6784.0), b6 = R(11.0 / 84.0);
 };
 
+// The 21 non-zero tableau entries held in VGPRs.  `pin()` hides the value from the optimiser, which
+// otherwise re-materialises every 64-bit constant with two s_mov_b32 at each entry of the RK loop (42+
+// scalar moves per observation step) and spills SGPRs around them; a lone wave issues one instruction
+// per ~4 cycles whatever its type, so those moves cost as much as the fp64 FMAs they feed.
+template <typename R>
+CDKF_DEV R pin(R x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+template <typename R>
+struct Dp5V {
+  R a21, a31, a32, a41, a42, a43, a51, a52, a53, a54, a61, a62, a63, a64, a65, b1, b3, b4, b5, b6;
+  CDKF_DEV void init() {
+    using C = Dp5<R>;
+    a21 = pin(C::a21);
+    a31 = pin(C::a31); a32 = pin(C::a32);
+    a41 = pin(C::a41); a42 = pin(C::a42); a43 = pin(C::a43);
+    a51 = pin(C::a51); a52 = pin(C::a52); a53 = pin(C::a53); a54 = pin(C::a54);
+    a61 = pin(C::a61); a62 = pin(C::a62); a63 = pin(C::a63); a64 = pin(C::a64); a65 = pin(C::a65);
+    b1 = pin(C::b1); b3 = pin(C::b3); b4 = pin(C::b4); b5 = pin(C::b5); b6 = pin(C::b6);
+  }
+};
+
+// One Dormand-Prince step.  Two associations of the stage combination:
+//  * float:  y0 + dt * (sum_j a_ij f_j)  -- the increment is summed first and added to y0 once, like
+//    diffrax's `y0 + a_lower[i] @ ks`; this keeps float32 within 1-2 ulp of the reference's constants.
+//  * double: ((y0 + c_i1 f_1) + c_i2 f_2) + ...  with c_ij = dt a_ij formed once per step: one FMA per
+//    term (20 per state entry instead of 26).  The extra roundings are at 1e-16 relative.
 template <typename R, int NS, typename Rhs>
-CDKF_DEV void dopri5_step(R (&y)[NS], R dt, const Rhs& rhs) {
-  using C = Dp5<R>;
+CDKF_DEV void dopri5_step(R (&y)[NS], R dt, const Rhs& rhs, const Dp5V<R>& C) {
   R k1[NS], k2[NS], k3[NS], k4[NS], k5[NS], k6[NS], ys[NS];
-  rhs(y, k1);
+  if constexpr (sizeof(R) == 8) {
+    const R c21 = dt * C.a21, c31 = dt * C.a31, c32 = dt * C.a32, c41 = dt * C.a41, c42 = dt * C.a42,
+            c43 = dt * C.a43, c51 = dt * C.a51, c52 = dt * C.a52, c53 = dt * C.a53, c54 = dt * C.a54,
+            c61 = dt * C.a61, c62 = dt * C.a62, c63 = dt * C.a63, c64 = dt * C.a64, c65 = dt * C.a65,
+            d1 = dt * C.b1, d3 = dt * C.b3, d4 = dt * C.b4, d5 = dt * C.b5, d6 = dt * C.b6;
+    rhs(y, k1);
 #pragma unroll
-  for (int e = 0; e < NS; ++e) ys[e] = rfma(dt, C::a21 * k1[e], y[e]);
-  rhs(ys, k2);
+    for (int e = 0; e < NS; ++e) ys[e] = rfma(c21, k1[e], y[e]);
+    rhs(ys, k2);
 #pragma unroll
-  for (int e = 0; e < NS; ++e) ys[e] = rfma(dt, rfma(C::a32, k2[e], C::a31 * k1[e]), y[e]);
-  rhs(ys, k3);
+    for (int e = 0; e < NS; ++e) ys[e] = rfma(c32, k2[e], rfma(c31, k1[e], y[e]));
+    rhs(ys, k3);
 #pragma unroll
-  for (int e = 0; e < NS; ++e)
-    ys[e] = rfma(dt, rfma(C::a43, k3[e], rfma(C::a42, k2[e], C::a41 * k1[e])), y[e]);
-  rhs(ys, k4);
+    for (int e = 0; e < NS; ++e) ys[e] = rfma(c43, k3[e], rfma(c42, k2[e], rfma(c41, k1[e], y[e])));
+    rhs(ys, k4);
 #pragma unroll
-  for (int e = 0; e < NS; ++e)
-    ys[e] = rfma(dt, rfma(C::a54, k4[e], rfma(C::a53, k3[e], rfma(C::a52, k2[e], C::a51 * k1[e]))), y[e]);
-  rhs(ys, k5);
+    for (int e = 0; e < NS; ++e)
+      ys[e] = rfma(c54, k4[e], rfma(c53, k3[e], rfma(c52, k2[e], rfma(c51, k1[e], y[e]))));
+    rhs(ys, k5);
 #pragma unroll
-  for (int e = 0; e < NS; ++e)
-    ys[e] = rfma(
-        dt, rfma(C::a65, k5[e], rfma(C::a64, k4[e], rfma(C::a63, k3[e], rfma(C::a62, k2[e], C::a61 * k1[e])))),
-        y[e]);
-  rhs(ys, k6);
+    for (int e = 0; e < NS; ++e)
+      ys[e] = rfma(c65, k5[e], rfma(c64, k4[e], rfma(c63, k3[e], rfma(c62, k2[e], rfma(c61, k1[e], y[e])))));
+    rhs(ys, k6);
 #pragma unroll
-  for (int e = 0; e < NS; ++e)
-    y[e] = rfma(dt, rfma(C::b6, k6[e], rfma(C::b5, k5[e], rfma(C::b4, k4[e], rfma(C::b3, k3[e], C::b1 * k1[e])))),
-                y[e]);
+    for (int e = 0; e < NS; ++e)
+      y[e] = rfma(d6, k6[e], rfma(d5, k5[e], rfma(d4, k4[e], rfma(d3, k3[e], rfma(d1, k1[e], y[e])))));
+  } else {
+    rhs(y, k1);
+#pragma unroll
+    for (int e = 0; e < NS; ++e) ys[e] = rfma(dt, C.a21 * k1[e], y[e]);
+    rhs(ys, k2);
+#pragma unroll
+    for (int e = 0; e < NS; ++e) ys[e] = rfma(dt, rfma(C.a32, k2[e], C.a31 * k1[e]), y[e]);
+    rhs(ys, k3);
+#pragma unroll
+    for (int e = 0; e < NS; ++e) ys[e] = rfma(dt, rfma(C.a43, k3[e], rfma(C.a42, k2[e], C.a41 * k1[e])), y[e]);
+    rhs(ys, k4);
+#pragma unroll
+    for (int e = 0; e < NS; ++e)
+      ys[e] = rfma(dt, rfma(C.a54, k4[e], rfma(C.a53, k3[e], rfma(C.a52, k2[e], C.a51 * k1[e]))), y[e]);
+    rhs(ys, k5);
+#pragma unroll
+    for (int e = 0; e < NS; ++e)
+      ys[e] = rfma(dt, rfma(C.a65, k5[e], rfma(C.a64, k4[e], rfma(C.a63, k3[e], rfma(C.a62, k2[e], C.a61 * k1[e])))),
+                   y[e]);
+    rhs(ys, k6);
+#pragma unroll
+    for (int e = 0; e < NS; ++e)
+      y[e] = rfma(dt, rfma(C.b6, k6[e], rfma(C.b5, k5[e], rfma(C.b4, k4[e], rfma(C.b3, k3[e], C.b1 * k1[e])))), y[e]);
+  }
 }
 
 // Integrate y from t0 to t1 with the diffrax 0.4.0 loop: tprev = t0, tnext = min(t0 + dt0, t1);
 // while tprev < t1: step; tprev = min(tnext, t1); tnext = clip_to_end(tnext + dt0).
 // Returns true if max_steps was hit.
 template <typename R, int NS, typename Rhs>
-CDKF_DEV bool integrate(R (&y)[NS], R t0, R t1, R dt0, long max_steps, const Rhs& rhs) {
+CDKF_DEV bool integrate(R (&y)[NS], R t0, R t1, R dt0, long max_steps, const Rhs& rhs, const Dp5V<R>& C) {
   R tprev = t0;
   R tnext = rmin(t0 + dt0, t1);
   long steps = 0;
@@ -154,7 +206,7 @@ CDKF_DEV bool integrate(R (&y)[NS], R t0, R t1, R dt0, long max_steps, const Rhs
       capped = true;
       break;
     }
-    dopri5_step<R, NS>(y, tnext - tprev, rhs);
+    dopri5_step<R, NS>(y, tnext - tprev, rhs, C);
     tprev = rmin(tnext, t1);
     R tn = tnext + dt0;
     tnext = (tn > t1 - Tol<R>::v) ? t1 : tn;

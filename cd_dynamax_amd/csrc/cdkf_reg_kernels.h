@@ -36,7 +36,8 @@ struct RegArgs {
   long N, T;
   // element (n, k, i) of an array lives at  n * sn + k * sk + i.  Reference layout [N,T,w]:
   // (sn, sk) = (T*w, w); time-major layout [T,N,w]: (sn, sk) = (w, N*w); shared t: sn = 0.
-  long t_sn, t_sk, y_sn, y_sk, m_sn, m_sk, P_sn, P_sk;
+  // component stride si: 1 for the array-of-structures layouts, N for CDKF_LAYOUT_TCN ([T,w,N]).
+  long t_sn, t_sk, y_sn, y_sk, y_si, m_sn, m_sk, m_si, P_sn, P_sk, P_si;
   const R* t;
   const R* y;
   R* ll;
@@ -101,41 +102,73 @@ struct MeanRhs {
   CDKF_DEV void operator()(const R (&y)[D], R (&dy)[D]) const { drift.f(y, dy); }
 };
 
+// ---- log-likelihood accumulator ------------------------------------------------------------------
+// sum_k [-0.5 q_k - sum_i log L_ii - 0.5 M log 2pi] with sum_i log L_ii = -log prod_i (1 / L_ii): the
+// reciprocal pivots are multiplied into a running product and ONE fp64 log is taken every 8 steps (or
+// earlier if the product leaves [1e-150, 1e150]) instead of M logs per step.
+struct LlAcc {
+  double ll = 0.0, prod = 1.0;
+  int cnt = 0;
+  CDKF_DEV void add(double q, double pinv, int M) {
+    ll += -0.5 * q - 0.5 * M * 1.8378770664093454835606594728112;
+    prod *= pinv;
+    ++cnt;
+    const double ap = fabs(prod);
+    if (cnt == 8 || !(ap > 1e-150 && ap < 1e150)) flush();
+  }
+  CDKF_DEV void flush() {
+    ll += log(prod);
+    prod = 1.0;
+    cnt = 0;
+  }
+};
+
 // ---- EKF measurement update + log-likelihood term ---------------------------------------------
 // ll term: MVN(H m + b, H P H^T + R).log_prob(y)                       inference_ekf.py:285-286
 // update : S = R + H P H^T; K = psd_solve(S, H P)^T; P+ = P - K S K^T; m+ = m + K (y - h(m)),
 //          repeated num_iter times, then symmetrize                     inference_ekf.py:183-199
-template <typename R, int D, int M, typename Args>
-CDKF_DEV void ekf_update(const Args& a, R (&ys)[Dims<D>::NS], const R (&yobs)[M], double& ll, int& st) {
+// HSEL: the emission picks the first M state coordinates (H = I[:M], bias = 0 -- the tutorials' H = I_3 and
+// H = [1,0,0]); then H P = P[:M,:], H P H^T = P[:M,:M] and the products with H disappear.
+template <typename R, int D, int M, bool HSEL, typename Args>
+CDKF_DEV void ekf_update(const Args& a, R (&ys)[Dims<D>::NS], const R (&yobs)[M], LlAcc& ll, int& st) {
   bool bad = false;
   for (int it = 0; it < a.num_iter; ++it) {
-    R HP[M][D];
+    R HP[M][D], S[M][M], v[M];
+    if constexpr (HSEL) {
 #pragma unroll
-    for (int r = 0; r < M; ++r)
+      for (int r = 0; r < M; ++r) {
 #pragma unroll
-      for (int j = 0; j < D; ++j) {
-        R s = a.H[r][0] * ys[D + sidx<D>(0, j)];
+        for (int j = 0; j < D; ++j) HP[r][j] = ys[D + sidx<D>(r, j)];
 #pragma unroll
-        for (int k = 1; k < D; ++k) s = rfma(a.H[r][k], ys[D + sidx<D>(k, j)], s);
-        HP[r][j] = s;
+        for (int c = 0; c < M; ++c) S[r][c] = ys[D + sidx<D>(r, c)] + a.Rm[r][c];
+        v[r] = yobs[r] - ys[r];
       }
-    R S[M][M];
+    } else {
 #pragma unroll
-    for (int r = 0; r < M; ++r)
+      for (int r = 0; r < M; ++r)
 #pragma unroll
-      for (int c = 0; c < M; ++c) {
-        R s = HP[r][0] * a.H[c][0];
+        for (int j = 0; j < D; ++j) {
+          R s = a.H[r][0] * ys[D + sidx<D>(0, j)];
 #pragma unroll
-        for (int k = 1; k < D; ++k) s = rfma(HP[r][k], a.H[c][k], s);
-        S[r][c] = s + a.Rm[r][c];
+          for (int k = 1; k < D; ++k) s = rfma(a.H[r][k], ys[D + sidx<D>(k, j)], s);
+          HP[r][j] = s;
+        }
+#pragma unroll
+      for (int r = 0; r < M; ++r)
+#pragma unroll
+        for (int c = 0; c < M; ++c) {
+          R s = HP[r][0] * a.H[c][0];
+#pragma unroll
+          for (int k = 1; k < D; ++k) s = rfma(HP[r][k], a.H[c][k], s);
+          S[r][c] = s + a.Rm[r][c];
+        }
+#pragma unroll
+      for (int r = 0; r < M; ++r) {
+        R s = a.H[r][0] * ys[0];
+#pragma unroll
+        for (int k = 1; k < D; ++k) s = rfma(a.H[r][k], ys[k], s);
+        v[r] = yobs[r] - (s + a.hb[r]);
       }
-    R v[M];  // innovation
-#pragma unroll
-    for (int r = 0; r < M; ++r) {
-      R s = a.H[r][0] * ys[0];
-#pragma unroll
-      for (int k = 1; k < D; ++k) s = rfma(a.H[r][k], ys[k], s);
-      v[r] = yobs[r] - (s + a.hb[r]);
     }
     if (it == 0) {
       // TFP log_prob: Cholesky of S as given (lower triangle, no jitter)
@@ -152,8 +185,7 @@ CDKF_DEV void ekf_update(const Args& a, R (&ys)[Dims<D>::NS], const R (&yobs)[M]
         q = rfma(z[i], z[i], q);
         pinv *= inv[i];
       }
-      // -0.5 q - sum log L_ii - 0.5 M log(2 pi);   sum log L_ii = -log(prod inv_i)
-      ll += -0.5 * (double)q + log((double)pinv) - 0.5 * M * 1.8378770664093454835606594728112;
+      ll.add((double)q, (double)pinv, M);
     }
     // psd_solve: symmetrize + 1e-9 I, Cholesky, cho_solve           dynamax/utils/utils.py:202-207
     R Sb[M][M];
@@ -173,31 +205,35 @@ CDKF_DEV void ekf_update(const Args& a, R (&ys)[Dims<D>::NS], const R (&yobs)[M]
 #pragma unroll
       for (int j = 0; j < D; ++j) X[r][j] = HP[r][j];
     chol_solve<R, M, D>(Lb, invb, X);
-    R KS[D][M];  // K S
+    R SX[M][D];  // S X  (so that K S K^T = X^T (S X))
 #pragma unroll
-    for (int i = 0; i < D; ++i)
+    for (int r = 0; r < M; ++r)
 #pragma unroll
-      for (int c = 0; c < M; ++c) {
-        R s = X[0][i] * S[0][c];
+      for (int j = 0; j < D; ++j) {
+        R s = S[r][0] * X[0][j];
 #pragma unroll
-        for (int r = 1; r < M; ++r) s = rfma(X[r][i], S[r][c], s);
-        KS[i][c] = s;
+        for (int c = 1; c < M; ++c) s = rfma(S[r][c], X[c][j], s);
+        SX[r][j] = s;
       }
-    // P+ = P - (K S) K^T, then symmetrize (applied every iteration here; the reference symmetrizes
-    // once after the loop -- identical for num_iter == 1, rounding-level otherwise)
+    // P+ = P - K S K^T, then symmetrize (applied every iteration here; the reference symmetrizes once
+    // after the loop -- identical for num_iter == 1, rounding-level otherwise)
     R Pn[Dims<D>::NP];
 #pragma unroll
     for (int i = 0; i < D; ++i)
 #pragma unroll
       for (int j = i; j < D; ++j) {
-        R tij = KS[i][0] * X[0][j], tji = KS[j][0] * X[0][i];
+        R tij = X[0][i] * SX[0][j];
 #pragma unroll
-        for (int c = 1; c < M; ++c) {
-          tij = rfma(KS[i][c], X[c][j], tij);
-          tji = rfma(KS[j][c], X[c][i], tji);
+        for (int c = 1; c < M; ++c) tij = rfma(X[c][i], SX[c][j], tij);
+        const R p = ys[D + sidx<D>(i, j)];
+        if (i == j) {
+          Pn[sidx<D>(i, j)] = p - tij;
+        } else {
+          R tji = X[0][j] * SX[0][i];
+#pragma unroll
+          for (int c = 1; c < M; ++c) tji = rfma(X[c][j], SX[c][i], tji);
+          Pn[sidx<D>(i, j)] = R(0.5) * ((p - tij) + (p - tji));
         }
-        R p = ys[D + sidx<D>(i, j)];
-        Pn[sidx<D>(i, j)] = R(0.5) * ((p - tij) + (p - tji));
       }
 #pragma unroll
     for (int i = 0; i < D; ++i) {
@@ -214,23 +250,60 @@ CDKF_DEV void ekf_update(const Args& a, R (&ys)[Dims<D>::NS], const R (&yobs)[M]
 
 // store helpers: mean [D] and full symmetric covariance [D,D] in the reference layout
 template <typename R, int D>
-CDKF_DEV void store_moments(R* __restrict__ mean_out, R* __restrict__ cov_out, long moff, long poff,
-                            const R (&ys)[Dims<D>::NS]) {
+CDKF_DEV void store_moments(R* __restrict__ mean_out, R* __restrict__ cov_out, long moff, long poff, long m_si,
+                            long P_si, const R (&ys)[Dims<D>::NS]) {
   if (mean_out) {
+    R* p = mean_out + moff;
 #pragma unroll
-    for (int i = 0; i < D; ++i) mean_out[moff + i] = ys[i];
+    for (int i = 0; i < D; ++i) {
+      *p = ys[i];
+      p += m_si;
+    }
   }
   if (cov_out) {
+    R* p = cov_out + poff;
 #pragma unroll
     for (int i = 0; i < D; ++i)
 #pragma unroll
-      for (int j = 0; j < D; ++j) cov_out[poff + i * D + j] = ys[D + sidx<D>(i, j)];
+      for (int j = 0; j < D; ++j) {
+        *p = ys[D + sidx<D>(i, j)];
+        p += P_si;
+      }
   }
 }
 
+template <typename R, int D>
+CDKF_DEV void store_moments_all(R* __restrict__ mean_out, R* __restrict__ cov_out, long moff, long poff, long m_si,
+                                long P_si, const R (&ys)[Dims<D>::NS]) {
+  R* p = mean_out + moff;
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    *p = ys[i];
+    p += m_si;
+  }
+  R* q = cov_out + poff;
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      *q = ys[D + sidx<D>(i, j)];
+      q += P_si;
+    }
+}
+
 // ---- EKF filter sweep -------------------------------------------------------------------------
-template <typename R, int D, int M, typename Drift>
-__global__ __launch_bounds__(64) void ekf_filter_reg_kernel(const RegArgs<R, D, M, Drift> a) {
+// ZEROTH: state_order == 'zeroth' (mean-only ODE + sqrt(dt) L Qc L^T, inference_ekf.py:126-138);
+// HSEL:   emission = first M coordinates (see ekf_update);
+// OUT:    kOutNone (log-likelihood only), kOutAll (all four moment arrays, stored UNCONDITIONALLY) or
+//         kOutSome (each pointer checked at run time).  The unconditional form matters: gfx950 has one
+//         in-order vmcnt for loads and stores, and with stores under a branch the compiler must assume
+//         none were issued, so every wait for a prefetched observation degenerates to "drain all
+//         stores" (~300 cycles twice per step).  Idle lanes of the last wavefront shadow trajectory
+//         N-1 and store the same values to the same addresses, so no lane predicate is needed either.
+constexpr int kOutNone = 0, kOutAll = 1, kOutSome = 2;
+
+template <typename R, int D, int M, typename Drift, bool ZEROTH, bool HSEL, int OUT>
+__global__ __launch_bounds__(64, 1) void ekf_filter_reg_kernel(const RegArgs<R, D, M, Drift> a) {
   constexpr int NS = Dims<D>::NS;
   constexpr int NP = Dims<D>::NP;
   const long gid = (long)blockIdx.x * 64 + threadIdx.x;
@@ -239,6 +312,7 @@ __global__ __launch_bounds__(64) void ekf_filter_reg_kernel(const RegArgs<R, D, 
 
   const R* __restrict__ tp = a.t + n * a.t_sn;
   const R* __restrict__ yp = a.y + n * a.y_sn;
+  long moff = n * a.m_sn, poff = n * a.P_sn;
 
   R ys[NS];
 #pragma unroll
@@ -246,57 +320,67 @@ __global__ __launch_bounds__(64) void ekf_filter_reg_kernel(const RegArgs<R, D, 
 #pragma unroll
   for (int e = 0; e < NP; ++e) ys[D + e] = a.P0[e];
 
-  double ll = 0.0;
+  LlAcc ll;
   int st = 0;
+  Dp5V<R> C;
+  C.init();
   EkfRhs<R, D, Drift> rhs{a.drift, a.LQL, a.order};
   MeanRhs<R, D, Drift> mrhs{a.drift};
 
   R tcur = tp[0];
+  if (a.T > 1) tp += a.t_sk;
+  R tnext_obs = tp[0];  // t_{k+1}
   R ycur[M];
 #pragma unroll
-  for (int r = 0; r < M; ++r) ycur[r] = yp[r];
+  for (int r = 0; r < M; ++r) ycur[r] = yp[r * a.y_si];
 
   for (long k = 0; k < a.T; ++k) {
-    // prefetch next step's observation and interval end before the arithmetic of this step
-    const long kn = (k + 1 < a.T) ? k + 1 : k;
-    R tnext_obs = tp[kn * a.t_sk];
-    R ynext[M];
-#pragma unroll
-    for (int r = 0; r < M; ++r) ynext[r] = yp[kn * a.y_sk + r];
-
-    ekf_update<R, D, M>(a, ys, ycur, ll, st);
+    ekf_update<R, D, M, HSEL>(a, ys, ycur, ll, st);
     if (ys[0] != ys[0]) st |= kStatusNan;
-    const long moff = n * a.m_sn + k * a.m_sk, poff = n * a.P_sn + k * a.P_sk;
-    if (live) store_moments<R, D>(a.fm, a.fP, moff, poff, ys);
+    if constexpr (OUT == kOutAll) store_moments_all<R, D>(a.fm, a.fP, moff, poff, a.m_si, a.P_si, ys);
+    if constexpr (OUT == kOutSome) store_moments<R, D>(a.fm, a.fP, moff, poff, a.m_si, a.P_si, ys);
 
     const R t1 = (k + 1 < a.T) ? tnext_obs : tcur + a.dt_final;
+    // software prefetch of y_{k+1} and t_{k+2}: issued before the RK stages so that the loads (which
+    // return in order behind this step's stores) have a whole predict + update to land
+    if (k + 1 < a.T) yp += a.y_sk;
+    if (k + 2 < a.T) tp += a.t_sk;
+    R ynext[M];
+#pragma unroll
+    for (int r = 0; r < M; ++r) ynext[r] = yp[r * a.y_si];
+    const R tnn = tp[0];
+
     bool capped;
-    if (a.order == 0) {
+    if constexpr (ZEROTH) {
       R mm[D];
 #pragma unroll
       for (int i = 0; i < D; ++i) mm[i] = ys[i];
-      capped = integrate<R, D>(mm, tcur, t1, a.dt0, a.max_steps, mrhs);
+      capped = integrate<R, D>(mm, tcur, t1, a.dt0, a.max_steps, mrhs, C);
       const R sq = rsqrt_(t1 - tcur);
 #pragma unroll
       for (int i = 0; i < D; ++i) ys[i] = mm[i];
 #pragma unroll
       for (int e = 0; e < NP; ++e) ys[D + e] = rfma(sq, a.LQLz[e], ys[D + e]);
     } else {
-      capped = integrate<R, NS>(ys, tcur, t1, a.dt0, a.max_steps, rhs);
+      capped = integrate<R, NS>(ys, tcur, t1, a.dt0, a.max_steps, rhs, C);
     }
     if (capped) st |= kStatusMaxSteps;
-    if (live) store_moments<R, D>(a.pm, a.pP, moff, poff, ys);
+    if constexpr (OUT == kOutAll) store_moments_all<R, D>(a.pm, a.pP, moff, poff, a.m_si, a.P_si, ys);
+    if constexpr (OUT == kOutSome) store_moments<R, D>(a.pm, a.pP, moff, poff, a.m_si, a.P_si, ys);
+    moff += a.m_sk;
+    poff += a.P_sk;
 
     tcur = tnext_obs;
+    tnext_obs = tnn;
 #pragma unroll
     for (int r = 0; r < M; ++r) ycur[r] = ynext[r];
   }
+  ll.flush();
   if (live) {
-    a.ll[n] = (R)ll;
+    a.ll[n] = (R)ll.ll;
     if (a.status) a.status[n] = st;
   }
 }
-
 
 // ---- unpack a full symmetric D x D matrix from the packed state (for Cholesky: lower triangle) ----
 template <typename R, int D>
@@ -372,7 +456,7 @@ struct UkfRhs {
 
 // UKF measurement update (inference_ukf.py:162-203)
 template <typename R, int D, int M, typename Args>
-CDKF_DEV void ukf_update(const Args& a, R (&ys)[Dims<D>::NS], const R (&yobs)[M], double& ll, int& st) {
+CDKF_DEV void ukf_update(const Args& a, R (&ys)[Dims<D>::NS], const R (&yobs)[M], LlAcc& ll, int& st) {
   constexpr int S = 2 * D + 1;
   bool bad = false;
   R X[S][D], Y[S][M];
@@ -429,7 +513,7 @@ CDKF_DEV void ukf_update(const Args& a, R (&ys)[Dims<D>::NS], const R (&yobs)[M]
       q = rfma(z[i], z[i], q);
       pinv *= inv[i];
     }
-    ll += -0.5 * (double)q + log((double)pinv) - 0.5 * M * 1.8378770664093454835606594728112;
+    ll.add((double)q, (double)pinv, M);
   }
   R Sb[M][M];
 #pragma unroll
@@ -494,36 +578,39 @@ __global__ __launch_bounds__(64) void ukf_filter_reg_kernel(const RegArgs<R, D, 
   for (int i = 0; i < D; ++i) ys[i] = a.m0[i];
 #pragma unroll
   for (int e = 0; e < NP; ++e) ys[D + e] = a.P0[e];
-  double ll = 0.0;
+  LlAcc ll;
   int st = 0;
   bool bad_rhs = false;
+  Dp5V<R> C;
+  C.init();
   UkfRhs<R, D, RegArgs<R, D, M, Drift>> rhs{a, &bad_rhs};
 
   R tcur = tp[0];
   R ycur[M];
 #pragma unroll
-  for (int r = 0; r < M; ++r) ycur[r] = yp[r];
+  for (int r = 0; r < M; ++r) ycur[r] = yp[r * a.y_si];
   for (long k = 0; k < a.T; ++k) {
     const long kn = (k + 1 < a.T) ? k + 1 : k;
     R tnext_obs = tp[kn * a.t_sk];
     R ynext[M];
 #pragma unroll
-    for (int r = 0; r < M; ++r) ynext[r] = yp[kn * a.y_sk + r];
+    for (int r = 0; r < M; ++r) ynext[r] = yp[kn * a.y_sk + r * a.y_si];
 
     ukf_update<R, D, M>(a, ys, ycur, ll, st);
     if (ys[0] != ys[0]) st |= kStatusNan;
     const long moff = n * a.m_sn + k * a.m_sk, poff = n * a.P_sn + k * a.P_sk;
-    if (live) store_moments<R, D>(a.fm, a.fP, moff, poff, ys);
+    if (live) store_moments<R, D>(a.fm, a.fP, moff, poff, a.m_si, a.P_si, ys);
     const R t1 = (k + 1 < a.T) ? tnext_obs : tcur + a.dt_final;
-    if (integrate<R, NS>(ys, tcur, t1, a.dt0, a.max_steps, rhs)) st |= kStatusMaxSteps;
-    if (live) store_moments<R, D>(a.pm, a.pP, moff, poff, ys);
+    if (integrate<R, NS>(ys, tcur, t1, a.dt0, a.max_steps, rhs, C)) st |= kStatusMaxSteps;
+    if (live) store_moments<R, D>(a.pm, a.pP, moff, poff, a.m_si, a.P_si, ys);
     tcur = tnext_obs;
 #pragma unroll
     for (int r = 0; r < M; ++r) ycur[r] = ynext[r];
   }
   if (bad_rhs) st |= kStatusNotPd;
+  ll.flush();
   if (live) {
-    a.ll[n] = (R)ll;
+    a.ll[n] = (R)ll.ll;
     if (a.status) a.status[n] = st;
   }
 }
@@ -580,17 +667,19 @@ __global__ __launch_bounds__(64) void ekf_smoother_reg_kernel(const RegArgs<R, D
   const R* __restrict__ fP = a.fP + n * a.P_sn;
   int st = 0;
   bool bad = false;
+  Dp5V<R> C;
+  C.init();
 
   R ys[NS];  // smoothed moments at t_{k+1}
   {
     const long k = a.T - 1;
 #pragma unroll
-    for (int i = 0; i < D; ++i) ys[i] = fm[k * a.m_sk + i];
+    for (int i = 0; i < D; ++i) ys[i] = fm[k * a.m_sk + i * a.m_si];
 #pragma unroll
     for (int i = 0; i < D; ++i)
 #pragma unroll
-      for (int j = i; j < D; ++j) ys[D + sidx<D>(i, j)] = fP[k * a.P_sk + i * D + j];
-    if (live) store_moments<R, D>(sm, sP, n * a.m_sn + k * a.m_sk, n * a.P_sn + k * a.P_sk, ys);
+      for (int j = i; j < D; ++j) ys[D + sidx<D>(i, j)] = fP[k * a.P_sk + (i * D + j) * a.P_si];
+    if (live) store_moments<R, D>(sm, sP, n * a.m_sn + k * a.m_sk, n * a.P_sn + k * a.P_sk, a.m_si, a.P_si, ys);
   }
   R t1 = tp[(a.T - 1) * a.t_sk];
   for (long k = a.T - 2; k >= 0; --k) {
@@ -598,11 +687,11 @@ __global__ __launch_bounds__(64) void ekf_smoother_reg_kernel(const RegArgs<R, D
     rhs.LQL = a.LQL;
     R Pf[D][D];
 #pragma unroll
-    for (int i = 0; i < D; ++i) rhs.mf[i] = fm[k * a.m_sk + i];
+    for (int i = 0; i < D; ++i) rhs.mf[i] = fm[k * a.m_sk + i * a.m_si];
 #pragma unroll
     for (int i = 0; i < D; ++i)
 #pragma unroll
-      for (int j = 0; j < D; ++j) Pf[i][j] = fP[k * a.P_sk + i * D + j];
+      for (int j = 0; j < D; ++j) Pf[i][j] = fP[k * a.P_sk + (i * D + j) * a.P_si];
     const R t0 = tp[k * a.t_sk];
     a.drift.f(rhs.mf, rhs.fmf);
     a.drift.jac(rhs.mf, rhs.G);
@@ -626,8 +715,8 @@ __global__ __launch_bounds__(64) void ekf_smoother_reg_kernel(const RegArgs<R, D
     for (int i = 0; i < D; ++i)
 #pragma unroll
       for (int j = 0; j < D; ++j) rhs.G[i][j] += X[j][i];
-    if (integrate<R, NS>(ys, R(0), t1 - t0, a.dt0, a.max_steps, rhs)) st |= kStatusMaxSteps;
-    if (live) store_moments<R, D>(sm, sP, n * a.m_sn + k * a.m_sk, n * a.P_sn + k * a.P_sk, ys);
+    if (integrate<R, NS>(ys, R(0), t1 - t0, a.dt0, a.max_steps, rhs, C)) st |= kStatusMaxSteps;
+    if (live) store_moments<R, D>(sm, sP, n * a.m_sn + k * a.m_sk, n * a.P_sn + k * a.P_sk, a.m_si, a.P_si, ys);
     t1 = t0;
   }
   if (bad) st |= kStatusNotPd;

@@ -13,7 +13,7 @@
  *      t  [N,T]   (or [T] when opts.t_shared != 0; the reference's t_emissions[:,0])
  *      y  [N,T,m]
  *      means [N,T,d], covariances [N,T,d,d], ll [N], status [N]
- *    Time-major layout, opts.layout = CDKF_LAYOUT_TN: the same arrays with the first two axes swapped.
+ *    Time-major layouts, opts.layout = CDKF_LAYOUT_TN / CDKF_LAYOUT_TCN: see the CDKF_LAYOUT_* defines.
  *  - Output pointers may be NULL: that field is then not produced (the reference's
  *    `output_fields` filter, inference_ekf.py:209,315).
  *  - Functions return 0 on success or a negative CDKF_E* code; cdkf_last_error() returns a
@@ -57,10 +57,13 @@ extern "C" {
                                  f = W3 tanh(W2 tanh(W1 x + b1) + b2) + b3 */
 
 /* array layouts (opts.layout).  NT is what jax.vmap over trajectories produces in the reference;
- * TN is the engine's native time-major layout: at step k the 64 trajectories of a wavefront touch
- * one contiguous run of memory, so every load and store coalesces. */
+ * TN / TCN are time-major: at step k the 64 trajectories of a wavefront touch one contiguous run of
+ * memory. */
 #define CDKF_LAYOUT_NT 0 /* t [N,T], y [N,T,m], means [N,T,d], covariances [N,T,d,d] */
 #define CDKF_LAYOUT_TN 1 /* t [T,N], y [T,N,m], means [T,N,d], covariances [T,N,d,d] */
+#define CDKF_LAYOUT_TCN 2 /* t [T,N], y [T,m,N], means [T,d,N], covariances [T,d,d,N]: trajectory index
+                             fastest, so that lane n of a wavefront touches element n of a contiguous run in
+                             EVERY load and store instruction (fully coalesced; the engine's native layout) */
 
 /* state_order of EKFHyperParams (inference_ekf.py:40) */
 #define CDKF_ORDER_ZEROTH 0
@@ -94,8 +97,8 @@ typedef struct cdkf_opts {
   int32_t num_iter;     /* EKF update re-linearisations; default 1 */
   int32_t t_shared;     /* 0: t is [N,T]; 1: t is [T], shared by all trajectories */
   int32_t device;       /* HIP device ordinal; -1 = current device */
-  int32_t layout;       /* CDKF_LAYOUT_NT (default) or CDKF_LAYOUT_TN; applies to t (unless shared), y and
-                           every mean / covariance array.  ll and status are always [N]. */
+  int32_t layout;       /* CDKF_LAYOUT_NT (default), _TN or _TCN; applies to t (unless shared), y and every
+                           mean / covariance array.  ll and status are always [N]. */
   int32_t reserved;
   int64_t max_steps;    /* RK steps per observation interval; default 100000 */
   double dt0;           /* default 0.01 */

@@ -162,9 +162,10 @@ def _run_dev(lib, algo, blk, opts, t, y, dtype, layout, outputs=True):
     d = blk.state_dim
     suf = "f64" if dtype == np.float64 else "f32"
     opts.layout = layout
-    tn = layout == _ffi.LAYOUT_TN
+    tn = layout != _ffi.LAYOUT_NT
+    tcn = layout == _ffi.LAYOUT_TCN
     th = np.ascontiguousarray((t.T if tn else t).astype(dtype))
-    yh = np.ascontiguousarray((y.transpose(1, 0, 2) if tn else y).astype(dtype))
+    yh = np.ascontiguousarray((y.transpose(1, 2, 0) if tcn else y.transpose(1, 0, 2) if tn else y).astype(dtype))
     sz = np.dtype(dtype).itemsize
     td, yd = _dev(lib, th), _dev(lib, yh)
     ll, st, llsum = _dev(lib, nbytes=N * sz), _dev(lib, nbytes=N * 4), _dev(lib, nbytes=8)
@@ -173,9 +174,11 @@ def _run_dev(lib, algo, blk, opts, t, y, dtype, layout, outputs=True):
     _ffi.check(fn(C.byref(blk.c), C.byref(opts), N, T, td, yd, ll, *bufs, st, None))
     _ffi.check(getattr(lib, f"cdkf_ll_sum_{suf}_dev")(ll, N, llsum, None))
     _ffi.check(lib.cdkf_synchronize(None))
-    lead = (T, N) if tn else (N, T)
-    outs = [None if b is None else _to_host(lib, b, lead + w, dtype) for b, w in zip(bufs, ((d,), (d, d), (d,), (d, d)))]
-    if tn:
+    shp = lambda w: (T,) + w + (N,) if tcn else ((T, N) + w if tn else (N, T) + w)
+    outs = [None if b is None else _to_host(lib, b, shp(w), dtype) for b, w in zip(bufs, ((d,), (d, d), (d,), (d, d)))]
+    if tcn:
+        outs = [None if a is None else np.moveaxis(a, -1, 0) for a in outs]
+    elif tn:
         outs = [None if a is None else np.swapaxes(a, 0, 1) for a in outs]
     res = (_to_host(lib, ll, (N,), dtype), outs, _to_host(lib, st, (N,), np.int32), _to_host(lib, llsum, (1,), np.float64)[0])
     for p in [td, yd, ll, st, llsum] + [b for b in bufs if b is not None]:
@@ -193,10 +196,11 @@ def test_layouts_are_bitwise_identical_and_ll_sum(hip_lib):
     for algo in ("ekf_filter", "ukf_filter", "ekf_smoother"):
         for dtype in (np.float64, np.float32):
             a = _run_dev(hip_lib, algo, blk, _ffi.default_opts(), t, y, dtype, _ffi.LAYOUT_NT)
-            b = _run_dev(hip_lib, algo, blk, _ffi.default_opts(), t, y, dtype, _ffi.LAYOUT_TN)
-            np.testing.assert_array_equal(a[0], b[0])
-            for x, z in zip(a[1], b[1]):
-                np.testing.assert_array_equal(x, z)
+            for lay in (_ffi.LAYOUT_TN, _ffi.LAYOUT_TCN):
+                b = _run_dev(hip_lib, algo, blk, _ffi.default_opts(), t, y, dtype, lay)
+                np.testing.assert_array_equal(a[0], b[0])
+                for x, z in zip(a[1], b[1]):
+                    np.testing.assert_array_equal(x, z)
             assert abs(a[3] - a[0].astype(np.float64).sum()) <= 1e-12 * abs(a[3])
             assert (a[2] == 0).all()
 
@@ -234,7 +238,7 @@ def test_c2_full_size_properties(hip_lib):
     sub = rng.choice(N, size=6, replace=False)
     y[sub] = o.simulate(mdl, t[sub], rng)
     blk = models._model_block(params_from(mdl))
-    ll, outs, st, llsum = _run_dev(hip_lib, "ekf_filter", blk, _ffi.default_opts(), t, y, np.float64, _ffi.LAYOUT_TN)
+    ll, outs, st, llsum = _run_dev(hip_lib, "ekf_filter", blk, _ffi.default_opts(), t, y, np.float64, _ffi.LAYOUT_TCN)
     assert (st == 0).all() and np.isfinite(ll).all()
     assert abs(llsum - ll.sum()) < 1e-10 * abs(llsum)
     ref = o.ekf_filter(mdl, t[sub], y[sub])
@@ -242,6 +246,6 @@ def test_c2_full_size_properties(hip_lib):
     for a, k in zip(outs, FILTER_KEYS):
         assert relerr(a[sub], ref[k]) < 1e-9, k
     # fp32 engine on the same batch stays within the north-star 1e-5 of the fp64 engine on the filtered moments
-    ll32, outs32, st32, _ = _run_dev(hip_lib, "ekf_filter", blk, _ffi.default_opts(), t, y, np.float32, _ffi.LAYOUT_TN)
+    ll32, outs32, st32, _ = _run_dev(hip_lib, "ekf_filter", blk, _ffi.default_opts(), t, y, np.float32, _ffi.LAYOUT_TCN)
     assert (st32 == 0).all()
     assert relerr(outs32[0][sub], ref["filtered_means"]) < 1e-4

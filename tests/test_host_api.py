@@ -207,6 +207,6 @@ def test_run_host_transposes_to_time_major(monkeypatch):
     opts = _default()
     ll, outs, st = _ffi.run_host("ekf_filter", blk, opts, np.zeros((5, 7)), np.zeros((5, 7, 3)), [True, True, False, False],
                                  np.float64)
-    assert seen == {"layout": _ffi.LAYOUT_TN, "N": 5, "T": 7}
+    assert seen == {"layout": _ffi.LAYOUT_TCN, "N": 5, "T": 7}
     assert outs[0].shape == (5, 7, 3) and outs[1].shape == (5, 7, 3, 3) and outs[2] is None
-    assert outs[0].base is not None and outs[0].base.shape == (7, 5, 3)  # a view of the time-major buffer
+    assert outs[0].base is not None and outs[0].base.shape == (7, 3, 5)  # a view of the native [T,d,N] buffer
