@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-saturation", action="store_true", help="skip the extra N=65536 (HBM-bound regime) measurement")
     args = ap.parse_args()
 
     import torch
@@ -159,10 +160,45 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             out.update(cpu_baseline_and_error(t_h, y_h, ll, fm))
+        if not args.no_saturation and world == 1:
+            del fm, fP, pm, pP
+            out["saturated_regime"] = saturated(lib, blk, opts, dev, torch)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def saturated(lib, blk, opts, dev, torch, n=65536, reps=5):
+    """Same kernel, same per-trajectory workload, 16x the trajectories (1024 wavefronts = one per SIMD): the
+    regime where the sweep is bounded by HBM rather than by the T-long dependency chain of 64 wavefronts.
+    Reported beside the headline number, never instead of it."""
+    from cd_dynamax_amd import _ffi
+    T = T_STEPS
+    t_h, y_h = make_batch(99, 4096, T)
+    reps_n = n // 4096
+    t_d = torch.from_numpy(np.ascontiguousarray(t_h.T)).to(dev).repeat(1, reps_n)
+    y_d = torch.from_numpy(np.ascontiguousarray(y_h.transpose(1, 2, 0))).to(dev).repeat(1, 1, reps_n)
+    f64 = dict(dtype=torch.float64, device=dev)
+    ll, st = torch.empty(n, **f64), torch.zeros(n, dtype=torch.int32, device=dev)
+    fm, fP = torch.empty(T, D, n, **f64), torch.empty(T, D, D, n, **f64)
+    pm, pP = torch.empty_like(fm), torch.empty_like(fP)
+    p = lambda x: C.c_void_p(x.data_ptr())
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    run = lambda: _ffi.check(lib.cdkf_ekf_filter_f64_dev(C.byref(blk.c), C.byref(opts), n, T, p(t_d), p(y_d), p(ll), p(fm),
+                                                         p(fP), p(pm), p(pP), p(st), stream))
+    run()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in evs:
+        a.record()
+        run()
+        b.record()
+    torch.cuda.synchronize()
+    ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    gbs = n * T * 224 / (ms * 1e-3) / 1e9
+    return {"trajectories": n, "num_timesteps": T, "kernel_ms": ms, "trajectories_per_sec": n / (ms * 1e-3),
+            "achieved_GBps": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS}
 
 
 def cpu_baseline_and_error(t_h, y_h, ll_dev, fm_dev):
@@ -175,6 +211,10 @@ def cpu_baseline_and_error(t_h, y_h, ll_dev, fm_dev):
     ns = t_h.shape[0]
     mdl = o.lorenz63_model(3)
     oc.ekf_filter(mdl, t_h[:8], y_h[:8], nthreads=cores)  # build / warm-up
+    # pick the thread count that serves the CPU best (containers often expose more CPUs than their quota)
+    cand = sorted({c for c in (cores, cores // 2, cores // 4, 64, 32, 16, 8) if 1 <= c <= cores}, reverse=True)
+    best = min(cand, key=lambda c: min(oc.ekf_filter(mdl, t_h[:ns], y_h[:ns], nthreads=c)["_seconds"] for _ in range(2)))
+    cores = best
     ref = oc.ekf_filter(mdl, t_h[:ns], y_h[:ns], nthreads=cores)
     # bounded sample: repeat the 4096 x 1000 batch until ~3 s of wall time have been spent (>= 2 passes)
     reps = int(max(2, min(200, np.ceil(3.0 / max(ref["_seconds"], 1e-4)))))

@@ -32,6 +32,31 @@ int launch_ekf_smoother(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, in
 
 bool kernel_available(const cdkf_model* mdl, const cdkf_opts* o, int algo);
 
+// true if the emission picks the first M state coordinates: H = I[:M], bias = 0
+inline bool emission_is_selection(const cdkf_model* mdl) {
+  const int d = mdl->state_dim, m = mdl->emission_dim;
+  if (m > d) return false;
+  for (int r = 0; r < m; ++r) {
+    if (mdl->h_bias[r] != 0.0) return false;
+    for (int j = 0; j < d; ++j)
+      if (mdl->H[r * d + j] != (r == j ? 1.0 : 0.0)) return false;
+  }
+  return true;
+}
+
+// launch filter_reg_kernel with the OUT specialisation matching the requested output pointers
+template <typename R, int D, int M, typename Drift, bool UKF, bool ZEROTH, bool HSEL>
+inline void launch_filter_reg(const RegArgs<R, D, M, Drift>& a, hipStream_t stream) {
+  const dim3 grid((unsigned)((a.N + 63) / 64)), block(64);
+  const bool all = a.fm && a.fP && a.pm && a.pP, none = !a.fm && !a.fP && !a.pm && !a.pP;
+  if (all)
+    hipLaunchKernelGGL((filter_reg_kernel<R, D, M, Drift, UKF, ZEROTH, HSEL, kOutAll>), grid, block, 0, stream, a);
+  else if (none)
+    hipLaunchKernelGGL((filter_reg_kernel<R, D, M, Drift, UKF, ZEROTH, HSEL, kOutNone>), grid, block, 0, stream, a);
+  else
+    hipLaunchKernelGGL((filter_reg_kernel<R, D, M, Drift, UKF, ZEROTH, HSEL, kOutSome>), grid, block, 0, stream, a);
+}
+
 inline bool reg_shape_available(const cdkf_model* mdl) {
 #define X(KIND, DRIFT, D_, M_) \
   if (mdl->drift_kind == KIND && mdl->state_dim == D_ && mdl->emission_dim == M_) return true;

@@ -8,8 +8,7 @@ static int run_ukf_reg(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int
                        R* fm, R* fP, R* pm, R* pP, int32_t* status, hipStream_t stream) {
   RegArgs<R, D, M, Drift> a;
   fill_reg_args(a, mdl, o, N, T, t, y, ll, fm, fP, pm, pP, status);
-  const unsigned blocks = (unsigned)((N + 63) / 64);
-  hipLaunchKernelGGL((ukf_filter_reg_kernel<R, D, M, Drift>), dim3(blocks), dim3(64), 0, stream, a);
+  launch_filter_reg<R, D, M, Drift, true, false, false>(a, stream);
   CDKF_HIP_CHECK(hipGetLastError());
   return CDKF_OK;
 }

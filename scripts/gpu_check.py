@@ -51,7 +51,7 @@ for mobs in (3, 1):
 
 # ---- timing at C2: N=4096, T=1000 ----
 L = _ffi.lib()
-for N in (4096, 65536):
+for N in (4096, 65536, 262144):
     T = 1000
     mdl = o.lorenz63_model(3)
     t = o.irregular_times(rng, N, T, 0.005 * T)
@@ -66,11 +66,12 @@ for N in (4096, 65536):
             if arr is not None:
                 _ffi.check(L.cdkf_memcpy_h2d(p, arr.ctypes.data_as(C.c_void_p), nb))
             return p
-        td, yd = dev(np.ascontiguousarray(t, dt)), dev(np.ascontiguousarray(y, dt))
+        td, yd = dev(np.ascontiguousarray(t.T, dt)), dev(np.ascontiguousarray(y.transpose(1, 2, 0), dt))  # TCN
         ll, st = dev(nbytes=N * sz), dev(nbytes=N * 4)
         fm, pm = dev(nbytes=N * T * 3 * sz), dev(nbytes=N * T * 3 * sz)
         fP, pP = dev(nbytes=N * T * 9 * sz), dev(nbytes=N * T * 9 * sz)
         opts = _ffi.default_opts()
+        opts.layout = _ffi.LAYOUT_TCN
         for algo in ("ekf_filter", "ukf_filter"):
             fn = getattr(L, f"cdkf_{algo}_{suf}_dev")
             for full in (True, False):
