@@ -152,7 +152,7 @@ int cdkf_device_count(void) {
 
 int cdkf_supported(const cdkf_model* mdl, const cdkf_opts* o, int algo, int bytes_per_real) {
   if (!mdl || !o || (bytes_per_real != 4 && bytes_per_real != 8) || algo < 0 || algo > 2) return 0;
-  return kernel_available(mdl, o, algo) ? 1 : 0;
+  return kernel_available(mdl, o, algo, bytes_per_real) ? 1 : 0;
 }
 
 int cdkf_malloc(void** p, int64_t bytes) {

@@ -30,7 +30,16 @@ template <typename R>
 int launch_ekf_smoother(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y,
                         R* ll, R* fm, R* fP, R* sm, R* sP, int32_t* status, hipStream_t stream);
 
-bool kernel_available(const cdkf_model* mdl, const cdkf_opts* o, int algo);
+bool kernel_available(const cdkf_model* mdl, const cdkf_opts* o, int algo, int bytes_per_real);
+
+// workgroup-per-trajectory kernels (launch_wg.hip): any registry drift, d and m up to what fits 160 KB of LDS
+bool wg_shape_available(const cdkf_model* mdl, int bytes_per_real);
+template <typename R>
+int launch_ekf_filter_wg(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll,
+                         R* fm, R* fP, R* pm, R* pP, int32_t* status, hipStream_t stream);
+template <typename R>
+int launch_ekf_smoother_wg(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y,
+                           R* ll, R* fm, R* fP, R* sm, R* sP, int32_t* status, hipStream_t stream);
 
 // true if the emission picks the first M state coordinates: H = I[:M], bias = 0
 inline bool emission_is_selection(const cdkf_model* mdl) {

@@ -34,9 +34,7 @@ int launch_ekf_smoother(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, in
     return run_eks_reg<R, D_, M_, DRIFT<R, D_>>(mdl, o, N, T, t, y, ll, fm, fP, sm, sP, status, stream);
   CDKF_REG_SHAPES(X)
 #undef X
-  set_error("EKF smoother: no kernel for drift_kind=%d state_dim=%d emission_dim=%d", mdl->drift_kind, mdl->state_dim,
-            mdl->emission_dim);
-  return CDKF_EUNSUPPORTED;
+  return launch_ekf_smoother_wg<R>(mdl, o, N, T, t, y, ll, fm, fP, sm, sP, status, stream);
 }
 
 template int launch_ekf_smoother<float>(const cdkf_model*, const cdkf_opts*, int64_t, int64_t, const float*,
@@ -45,6 +43,9 @@ template int launch_ekf_smoother<double>(const cdkf_model*, const cdkf_opts*, in
                                          const double*, double*, double*, double*, double*, double*, int32_t*,
                                          hipStream_t);
 
-bool kernel_available(const cdkf_model* mdl, const cdkf_opts*, int) { return reg_shape_available(mdl); }
+bool kernel_available(const cdkf_model* mdl, const cdkf_opts*, int algo, int bytes_per_real) {
+  if (reg_shape_available(mdl)) return true;
+  return algo != 1 && wg_shape_available(mdl, bytes_per_real);  // no workgroup UKF yet
+}
 
 }  // namespace cdkf

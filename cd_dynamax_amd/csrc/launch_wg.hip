@@ -1,0 +1,237 @@
+// launch_wg.hip -- workgroup-per-trajectory kernels: parameter block upload, LDS sizing, launch.
+#include "cdkf_launch.h"
+#include "cdkf_wg_kernels.h"
+
+#include <mutex>
+
+namespace cdkf {
+
+static constexpr size_t kLdsLimit = 160 * 1024;
+
+template <typename R>
+static size_t wg_lds_bytes(const cdkf_model* mdl) {
+  const int q = mdl->state_dim > mdl->emission_dim ? mdl->state_dim : mdl->emission_dim;
+  const int lq = (q + 3) & ~3;
+  return WgLds<R>::bytes(q, lq, wg_extra_reals(mdl->drift_kind, mdl->state_dim, mdl->hidden1, mdl->hidden2)) + 64;
+}
+
+static long expected_theta(const cdkf_model* mdl) {
+  const long d = mdl->state_dim, h1 = mdl->hidden1, h2 = mdl->hidden2;
+  switch (mdl->drift_kind) {
+    case CDKF_DRIFT_LINEAR: return d * d + d;
+    case CDKF_DRIFT_LORENZ63: return 3;
+    case CDKF_DRIFT_LORENZ96: return 1;
+    case CDKF_DRIFT_MLP_TANH: return h1 * d + h1 + h2 * h1 + h2 + d * h2 + d;
+    default: return -1;
+  }
+}
+
+bool wg_shape_available(const cdkf_model* mdl, int bytes_per_real) {
+  const int d = mdl->state_dim, m = mdl->emission_dim;
+  if (d < 1 || m < 1 || d > 64 || m > 64) return false;
+  if (expected_theta(mdl) < 0 || expected_theta(mdl) != mdl->n_theta) return false;
+  if (mdl->drift_kind == CDKF_DRIFT_LORENZ63 && d != 3) return false;
+  if (mdl->drift_kind == CDKF_DRIFT_LORENZ96 && d < 4) return false;
+  const size_t lds = bytes_per_real == 8 ? wg_lds_bytes<double>(mdl) : wg_lds_bytes<float>(mdl);
+  return lds <= kLdsLimit - 256;
+}
+
+// Parameter blocks (up to ~70 KB for d = 40) go through a small ring of persistent device buffers, each paired
+// with a pinned host staging buffer and an event recorded behind the kernels that read it.  The asynchronous
+// _dev entry points therefore neither allocate nor synchronise in the steady state.  (hipMallocAsync +
+// hipMemcpyAsync from pageable memory was tried first and delivered stale parameter blocks on ROCm 7.2.)
+struct ParamSlot {
+  void* dev = nullptr;
+  void* host = nullptr;
+  size_t cap = 0;
+  int device = -1;
+  hipEvent_t done = nullptr;
+  bool in_flight = false;
+};
+static constexpr int kParamSlots = 8;
+static ParamSlot g_slots[kParamSlots];
+static int g_next_slot = 0;
+static std::mutex g_slot_mutex;
+
+static int param_pool_acquire(size_t bytes, ParamSlot** out) {
+  std::lock_guard<std::mutex> lock(g_slot_mutex);
+  int dev = 0;
+  CDKF_HIP_CHECK(hipGetDevice(&dev));
+  ParamSlot& s = g_slots[g_next_slot];
+  g_next_slot = (g_next_slot + 1) % kParamSlots;
+  if (s.in_flight) {
+    CDKF_HIP_CHECK(hipEventSynchronize(s.done));
+    s.in_flight = false;
+  }
+  if (s.cap < bytes || s.device != dev) {
+    if (s.dev) (void)hipFree(s.dev);
+    if (s.host) (void)hipHostFree(s.host);
+    if (s.done) (void)hipEventDestroy(s.done);
+    s = ParamSlot();
+    const size_t cap = bytes < 4096 ? 4096 : bytes;
+    CDKF_HIP_CHECK(hipMalloc(&s.dev, cap));
+    CDKF_HIP_CHECK(hipHostMalloc(&s.host, cap, hipHostMallocDefault));
+    CDKF_HIP_CHECK(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+    s.cap = cap;
+    s.device = dev;
+  }
+  *out = &s;
+  return CDKF_OK;
+}
+
+static int param_pool_release(ParamSlot* s, hipStream_t stream) {
+  std::lock_guard<std::mutex> lock(g_slot_mutex);
+  CDKF_HIP_CHECK(hipEventRecord(s->done, stream));
+  s->in_flight = true;
+  return CDKF_OK;
+}
+
+// Builds the parameter block in the compute type and uploads it through the ring above.
+template <typename R>
+static int wg_prepare(WgArgs<R>& a, R** dev_block, ParamSlot** slot_out, const cdkf_model* mdl, const cdkf_opts* o,
+                      int64_t N, int64_t T, hipStream_t stream) {
+  const int d = mdl->state_dim, m = mdl->emission_dim;
+  if (!wg_shape_available(mdl, sizeof(R))) {
+    set_error("no kernel for drift_kind=%d state_dim=%d emission_dim=%d n_theta=%lld (fp%d)", mdl->drift_kind, d, m,
+              (long long)mdl->n_theta, (int)sizeof(R) * 8);
+    return CDKF_EUNSUPPORTED;
+  }
+  std::vector<R> h;
+  auto push = [&](const double* src, long n) {
+    const long off = (long)h.size();
+    for (long i = 0; i < n; ++i) h.push_back(R(src[i]));
+    return off;
+  };
+  a.o_theta = push(mdl->theta, mdl->n_theta);
+  std::vector<R> full(d * d), packed(d * (d + 1) / 2);
+  auto push_lql = [&](double scale) {
+    lql_packed<R>(mdl->L, mdl->Qc, d, scale, packed.data());
+    int e = 0;
+    for (int i = 0; i < d; ++i)
+      for (int j = i; j < d; ++j) full[i * d + j] = full[j * d + i] = packed[e++];
+    const long off = (long)h.size();
+    h.insert(h.end(), full.begin(), full.end());
+    return off;
+  };
+  a.o_LQL = push_lql(1.0);
+  a.o_LQLz = push_lql(o->cov_rescaling);
+  a.o_H = push(mdl->H, (long)m * d);
+  a.o_hb = push(mdl->h_bias, m);
+  a.o_R = push(mdl->R, (long)m * m);
+  a.o_m0 = push(mdl->m0, d);
+  a.o_P0 = push(mdl->P0, (long)d * d);
+  ParamSlot* slot = nullptr;
+  int prc = param_pool_acquire(h.size() * sizeof(R), &slot);
+  if (prc) return prc;
+  std::memcpy(slot->host, h.data(), h.size() * sizeof(R));
+  CDKF_HIP_CHECK(hipMemcpyAsync(slot->dev, slot->host, h.size() * sizeof(R), hipMemcpyHostToDevice, stream));
+  *dev_block = (R*)slot->dev;
+  *slot_out = slot;
+  a.par = *dev_block;
+  a.kind = mdl->drift_kind;
+  a.d = d;
+  a.m = m;
+  a.h1 = mdl->hidden1;
+  a.h2 = mdl->hidden2;
+  a.q = d > m ? d : m;
+  a.lq = (a.q + 3) & ~3;
+  a.order = o->state_order;
+  a.num_iter = o->num_iter;
+  a.max_steps = (long)o->max_steps;
+  a.dt0 = R(o->dt0);
+  a.dt_final = R(o->dt_final);
+  a.N = N;
+  a.T = T;
+  a.y_si = a.m_si = a.P_si = 1;
+  const long M = m, D = d;
+  if (o->layout == CDKF_LAYOUT_TCN) {
+    a.t_sn = o->t_shared ? 0 : 1;
+    a.t_sk = o->t_shared ? 1 : N;
+    a.y_sn = a.m_sn = a.P_sn = 1;
+    a.y_sk = N * M;
+    a.m_sk = N * D;
+    a.P_sk = N * D * D;
+    a.y_si = a.m_si = a.P_si = N;
+  } else if (o->layout == CDKF_LAYOUT_TN) {
+    a.t_sn = o->t_shared ? 0 : 1;
+    a.t_sk = o->t_shared ? 1 : N;
+    a.y_sn = M;
+    a.y_sk = N * M;
+    a.m_sn = D;
+    a.m_sk = N * D;
+    a.P_sn = D * D;
+    a.P_sk = N * D * D;
+  } else {
+    a.t_sn = o->t_shared ? 0 : T;
+    a.t_sk = 1;
+    a.y_sn = T * M;
+    a.y_sk = M;
+    a.m_sn = T * D;
+    a.m_sk = D;
+    a.P_sn = T * D * D;
+    a.P_sk = D * D;
+  }
+  return CDKF_OK;
+}
+
+// Raise the dynamic-LDS cap of a kernel ONCE to the whole CU (minus the kernels' few static bytes).  Re-setting the
+// attribute to the exact size before every launch misbehaved on ROCm 7.2: the first launch after the size grew
+// ran with the stale, smaller cap and produced garbage.
+template <typename K>
+static int wg_raise_lds_cap(K kernel) {
+  CDKF_HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLdsLimit - 256)));
+  return CDKF_OK;
+}
+
+static int wg_threads(int d) {
+  if (const char* e = getenv("CDKF_WG_THREADS")) return atoi(e);  // debugging aid
+  return d * d >= 1024 ? 256 : (d * d >= 256 ? 128 : 64);
+}
+
+template <typename R>
+int launch_ekf_filter_wg(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll,
+                         R* fm, R* fP, R* pm, R* pP, int32_t* status, hipStream_t stream) {
+  WgArgs<R> a{};
+  R* blk = nullptr;
+  ParamSlot* slot = nullptr;
+  int rc = wg_prepare(a, &blk, &slot, mdl, o, N, T, stream);
+  if (rc) return rc;
+  a.t = t; a.y = y; a.ll = ll; a.fm = fm; a.fP = fP; a.pm = pm; a.pP = pP; a.status = status;
+  const size_t lds = wg_lds_bytes<R>(mdl);
+  static const int cap_rc = wg_raise_lds_cap(ekf_filter_wg_kernel<R>);
+  if (cap_rc) return cap_rc;
+  hipLaunchKernelGGL(ekf_filter_wg_kernel<R>, dim3((unsigned)N), dim3(wg_threads(a.d)), lds, stream, a);
+  CDKF_HIP_CHECK(hipGetLastError());
+  return param_pool_release(slot, stream);
+}
+
+template <typename R>
+int launch_ekf_smoother_wg(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y,
+                           R* ll, R* fm, R* fP, R* sm, R* sP, int32_t* status, hipStream_t stream) {
+  cdkf_opts of = *o;
+  of.num_iter = 1;
+  WgArgs<R> a{};
+  R* blk = nullptr;
+  ParamSlot* slot = nullptr;
+  int rc = wg_prepare(a, &blk, &slot, mdl, &of, N, T, stream);
+  if (rc) return rc;
+  a.t = t; a.y = y; a.ll = ll; a.fm = fm; a.fP = fP; a.pm = nullptr; a.pP = nullptr; a.sm = sm; a.sP = sP; a.status = status;
+  const size_t lds = wg_lds_bytes<R>(mdl);
+  static const int cap_rc = wg_raise_lds_cap(ekf_filter_wg_kernel<R>) | wg_raise_lds_cap(ekf_smoother_wg_kernel<R>);
+  if (cap_rc) return CDKF_EHIP;
+  hipLaunchKernelGGL(ekf_filter_wg_kernel<R>, dim3((unsigned)N), dim3(wg_threads(a.d)), lds, stream, a);
+  CDKF_HIP_CHECK(hipGetLastError());
+  hipLaunchKernelGGL(ekf_smoother_wg_kernel<R>, dim3((unsigned)N), dim3(wg_threads(a.d)), lds, stream, a);
+  CDKF_HIP_CHECK(hipGetLastError());
+  return param_pool_release(slot, stream);
+}
+
+#define INST(R)                                                                                                        \
+  template int launch_ekf_filter_wg<R>(const cdkf_model*, const cdkf_opts*, int64_t, int64_t, const R*, const R*, R*,  \
+                                       R*, R*, R*, R*, int32_t*, hipStream_t);                                         \
+  template int launch_ekf_smoother_wg<R>(const cdkf_model*, const cdkf_opts*, int64_t, int64_t, const R*, const R*,    \
+                                         R*, R*, R*, R*, R*, int32_t*, hipStream_t);
+INST(float)
+INST(double)
+
+}  // namespace cdkf

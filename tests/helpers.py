@@ -125,3 +125,22 @@ FILTER_KEYS = ["filtered_means", "filtered_covariances", "predicted_means", "pre
 def load_golden(name):
     import os
     return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
+
+
+def lorenz96_model(d, m_obs=None, forcing=8.0):
+    """SURVEY.md section 8d config C4: f_i = (x_{i+1} - x_{i-2}) x_{i-1} - x_i + F, L = Qc = I, R = I, m0 = F 1, P0 = I;
+    m_obs < d observes every (d // m_obs)-th coordinate."""
+    m_obs = d if m_obs is None else m_obs
+    H = np.eye(d)[:: max(1, d // m_obs)][:m_obs]
+    return o.Model(o.Lorenz96Drift(forcing), np.eye(d), np.eye(d), H, np.zeros(m_obs), np.eye(m_obs),
+                   forcing * np.ones(d), np.eye(d))
+
+
+def mlp_model(rng, d=8, m_obs=4, h=64):
+    """MLP(d -> h -> h -> d, tanh), weights N(0, 1/fan_in), H = first m rows of I."""
+    W1 = rng.standard_normal((h, d)) / np.sqrt(d)
+    W2 = rng.standard_normal((h, h)) / np.sqrt(h)
+    W3 = rng.standard_normal((d, h)) / np.sqrt(h)
+    b1, b2, b3 = (0.1 * rng.standard_normal(k) for k in (h, h, d))
+    return o.Model(o.MLPDrift(W1, b1, W2, b2, W3, b3), np.eye(d), 0.5 * np.eye(d), np.eye(d)[:m_obs], np.zeros(m_obs),
+                   0.5 * np.eye(m_obs), np.zeros(d), np.eye(d))
