@@ -83,7 +83,8 @@ class CdkfError(RuntimeError):
 # every symbol include/cdkf.h declares (tests/test_abi.py checks this list against the header)
 _ALGOS = ("ekf_filter", "ukf_filter", "ekf_smoother")
 SYMBOLS = (
-    ["cdkf_default_opts", "cdkf_version", "cdkf_last_error", "cdkf_device_count", "cdkf_supported", "cdkf_malloc",
+    ["cdkf_default_opts", "cdkf_version", "cdkf_last_error", "cdkf_device_count", "cdkf_supported",
+     "cdkf_preferred_layout", "cdkf_malloc",
      "cdkf_free", "cdkf_memcpy_h2d", "cdkf_memcpy_d2h", "cdkf_memset", "cdkf_synchronize", "cdkf_ll_sum_f64_dev",
      "cdkf_ll_sum_f32_dev"]
     + [f"cdkf_{a}_{p}{s}" for a in _ALGOS for p in ("f64", "f32") for s in ("", "_dev")]
@@ -110,6 +111,8 @@ def lib() -> C.CDLL:
     L.cdkf_default_opts.restype = None
     L.cdkf_supported.argtypes = [C.POINTER(CdkfModel), C.POINTER(CdkfOpts), C.c_int, C.c_int]
     L.cdkf_supported.restype = C.c_int
+    L.cdkf_preferred_layout.argtypes = [C.POINTER(CdkfModel)]
+    L.cdkf_preferred_layout.restype = C.c_int
     L.cdkf_malloc.argtypes = [C.POINTER(C.c_void_p), C.c_int64]
     L.cdkf_free.argtypes = [C.c_void_p]
     L.cdkf_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
@@ -175,23 +178,25 @@ def run_host(algo: str, mdl: ModelBlock, opts: CdkfOpts, t: np.ndarray, y: np.nd
     the four optional output arrays in ABI order.  Returns (ll, [4 arrays or None], status); the
     arrays have the reference shapes [N,T,...].
 
-    The device side always runs in the engine's native layout (CDKF_LAYOUT_TCN: time, component,
-    trajectory): inputs are transposed on the host before upload and the outputs come back as
-    transposed VIEWS of the native buffers (same shapes and values as the reference's arrays, no copy).
+    The device side runs in the layout the library prefers for this model (cdkf_preferred_layout:
+    CDKF_LAYOUT_TCN = [T,w,N] for the lane-per-trajectory kernels, CDKF_LAYOUT_TN = [T,N,w] for the
+    workgroup-per-trajectory ones): inputs are transposed on the host before upload and the outputs
+    come back as transposed VIEWS of those buffers (same shapes and values as the reference's arrays).
     """
     dtype = np.dtype(dtype)
     suffix = {np.dtype(np.float32): "f32", np.dtype(np.float64): "f64"}[dtype]
     N, T, m = y.shape
     d = mdl.state_dim
-    opts.layout = LAYOUT_TCN
+    opts.layout = lib().cdkf_preferred_layout(C.byref(mdl.c))
+    tcn = opts.layout == LAYOUT_TCN
     t = np.asarray(t, dtype=dtype)
     t = np.ascontiguousarray(t if opts.t_shared else t.T)
-    y = np.ascontiguousarray(np.asarray(y, dtype=dtype).transpose(1, 2, 0))  # [T,m,N]
+    y = np.ascontiguousarray(np.asarray(y, dtype=dtype).transpose((1, 2, 0) if tcn else (1, 0, 2)))
     ll = np.empty((N,), dtype)
     status = np.zeros((N,), np.int32)
-    shapes = [(T, d, N), (T, d, d, N), (T, d, N), (T, d, d, N)]
+    shapes = [(T, d, N), (T, d, d, N), (T, d, N), (T, d, d, N)] if tcn else [(T, N, d), (T, N, d, d)] * 2
     outs = [np.empty(s, dtype) if w else None for s, w in zip(shapes, want)]
     fn = getattr(lib(), f"cdkf_{algo}_{suffix}")
     check(fn(C.byref(mdl.c), C.byref(opts), N, T, _vp(t), _vp(y), _vp(ll), *[_vp(o) for o in outs], _vp(status)))
-    outs = [None if o is None else np.moveaxis(o, -1, 0) for o in outs]  # [N,T,d(,d)] views
+    outs = [None if o is None else (np.moveaxis(o, -1, 0) if tcn else np.swapaxes(o, 0, 1)) for o in outs]  # views
     return ll, outs, status

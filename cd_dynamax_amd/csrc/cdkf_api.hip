@@ -155,6 +155,10 @@ int cdkf_supported(const cdkf_model* mdl, const cdkf_opts* o, int algo, int byte
   return kernel_available(mdl, o, algo, bytes_per_real) ? 1 : 0;
 }
 
+int cdkf_preferred_layout(const cdkf_model* mdl) {
+  return (mdl && reg_shape_available(mdl)) ? CDKF_LAYOUT_TCN : CDKF_LAYOUT_TN;
+}
+
 int cdkf_malloc(void** p, int64_t bytes) {
   if (!p || bytes < 0) {
     set_error("cdkf_malloc: bad arguments");

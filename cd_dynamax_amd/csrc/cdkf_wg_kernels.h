@@ -21,7 +21,7 @@ constexpr int kDriftLinear = 0, kDriftLorenz63 = 1, kDriftLorenz96 = 2, kDriftMl
 template <typename R>
 struct WgArgs {
   int kind, d, m, h1, h2;
-  int q, lq;       // q = max(d, m); lq = q rounded up to a multiple of 4 (leading dimension of every LDS matrix)
+  int q, lq;       // q = max(d, m); lq = (q rounded up to a multiple of 4) + 1: leading dimension of every LDS matrix
   int order, num_iter;
   long max_steps;
   R dt0, dt_final;
@@ -57,6 +57,16 @@ struct WgLds {
   __device__ R* extra() const { return base + 10L * msz + 14L * vsz; }
 };
 
+// Integer division by a run-time divisor costs ~40 instructions on CDNA; every entry loop needs (row, col) from a
+// flat index, so use a float reciprocal with a +-1 correction (exact for 0 <= e < 2^23, 0 < n < 2^12).
+__device__ __forceinline__ int fdiv(int e, int n) {
+  int q = (int)((float)e * __frcp_rn((float)n));
+  const int r = e - q * n;
+  q += (r >= n) - (r < 0);
+  return q;
+}
+__device__ __forceinline__ int fmod_(int e, int n) { return e - fdiv(e, n) * n; }
+
 #define CDKF_WG_FOR(idx, n) for (int idx = threadIdx.x; idx < (n); idx += blockDim.x)
 
 // C[r x c] = A[r x k] * B[k x c]   (all in LDS, leading dimension lq); 1x4 strips per lane
@@ -65,7 +75,7 @@ __device__ __forceinline__ void wg_matmul(R* __restrict__ C, const R* __restrict
                                           int k, int c, int lq) {
   const int c4 = (c + 3) >> 2;
   CDKF_WG_FOR(e, r * c4) {
-    const int i = e / c4, j = (e - i * c4) << 2;
+    const int i = fdiv(e, c4), j = (e - i * c4) << 2;
     R a0 = 0, a1 = 0, a2 = 0, a3 = 0;
     const R* Ai = A + i * lq;
     const R* Bj = B + j;
@@ -90,7 +100,7 @@ template <typename R>
 __device__ __forceinline__ void wg_matmul_nt(R* __restrict__ C, const R* __restrict__ A, const R* __restrict__ B, int r,
                                              int k, int c, int lq) {
   CDKF_WG_FOR(e, r * c) {
-    const int i = e / c, j = e - i * c;
+    const int i = fdiv(e, c), j = e - i * c;
     R acc = 0;
     for (int kk = 0; kk < k; ++kk) acc = rfma(A[i * lq + kk], B[j * lq + kk], acc);
     C[i * lq + j] = acc;
@@ -102,7 +112,7 @@ template <typename R>
 __device__ __forceinline__ void wg_matmul_tn(R* __restrict__ C, const R* __restrict__ A, const R* __restrict__ B, int r,
                                              int k, int c, int lq) {
   CDKF_WG_FOR(e, r * c) {
-    const int i = e / c, j = e - i * c;
+    const int i = fdiv(e, c), j = e - i * c;
     R acc = 0;
     for (int kk = 0; kk < k; ++kk) acc = rfma(A[kk * lq + i], B[kk * lq + j], acc);
     C[i * lq + j] = acc;
@@ -129,7 +139,7 @@ __device__ __forceinline__ void wg_cholesky(R* S, R* inv, int n, int lq, int* ba
     // trailing update of the lower triangle: S[a][b] -= L[a][j] L[b][j], j < b <= a
     const int rem = n - j - 1;
     CDKF_WG_FOR(e, rem * rem) {
-      const int a = j + 1 + e / rem, b = j + 1 + e % rem;
+      const int a = j + 1 + fdiv(e, rem), b = j + 1 + fmod_(e, rem);
       if (b <= a) S[a * lq + b] = rfma(-S[a * lq + j], S[b * lq + j], S[a * lq + b]);
     }
   }
@@ -145,7 +155,7 @@ __device__ __forceinline__ void wg_chol_solve(const R* L, const R* inv, R* B, in
     __syncthreads();
     const int rem = n - i - 1;
     CDKF_WG_FOR(e, rem * c) {
-      const int r = i + 1 + e / c, j = e % c;
+      const int r = i + 1 + fdiv(e, c), j = fmod_(e, c);
       B[r * lq + j] = rfma(-L[r * lq + i], B[i * lq + j], B[r * lq + j]);
     }
   }
@@ -154,11 +164,19 @@ __device__ __forceinline__ void wg_chol_solve(const R* L, const R* inv, R* B, in
     CDKF_WG_FOR(j, c) B[i * lq + j] *= inv[i];
     __syncthreads();
     CDKF_WG_FOR(e, i * c) {
-      const int r = e / c, j = e % c;
+      const int r = fdiv(e, c), j = fmod_(e, c);
       B[r * lq + j] = rfma(-L[i * lq + r], B[i * lq + j], B[r * lq + j]);
     }
   }
   __syncthreads();
+}
+
+// MLP scratch in LDS behind the matrices: a1[h1] a2[h2] s2[h2] tq[h1] Cm[d*h1] Gm[h2*h1], then the weights
+__host__ __device__ inline int wg_extra_reals(int kind, int d, int h1, int h2) {
+  return kind == kDriftMlp ? (2 * h1 + 2 * h2 + d * h1 + h2 * h1) : 0;
+}
+__host__ __device__ inline int wg_mlp_theta_reals(int kind, int d, int h1, int h2) {
+  return kind == kDriftMlp ? (h1 * d + h1 + h2 * h1 + h2 + d * h2 + d) : 0;
 }
 
 // ---- drift: f(x) -> fv, Jacobian -> F (dense, LDS), g = grad(div f) -> gv (MLP only) ------------------------
@@ -176,14 +194,16 @@ template <typename R>
 __device__ void wg_drift(const WgArgs<R>& a, const WgLds<R>& L, const R* __restrict__ x, R* __restrict__ fv,
                          R* __restrict__ F, R* __restrict__ gv, bool want_jac) {
   const int d = a.d, lq = a.lq;
-  const R* th = a.par + a.o_theta;
+  // MLP: the weights were copied behind the scratch by wg_mlp_prepare (LDS); other drifts read the few
+  // parameters they need from the L2-resident parameter block
+  const R* th = (a.kind == kDriftMlp) ? L.extra() + wg_extra_reals(kDriftMlp, a.d, a.h1, a.h2) : a.par + a.o_theta;
   if (a.kind == kDriftLinear) {
     CDKF_WG_FOR(i, d) {
       R s = 0;
       for (int j = 0; j < d; ++j) s = rfma(th[i * d + j], x[j], s);
       fv[i] = s + th[d * d + i];
     }
-    if (want_jac) CDKF_WG_FOR(e, d * d) F[(e / d) * lq + (e % d)] = th[e];
+    if (want_jac) CDKF_WG_FOR(e, d * d) F[(fdiv(e, d)) * lq + (fmod_(e, d))] = th[e];
   } else if (a.kind == kDriftLorenz63) {
     if (threadIdx.x == 0) {
       fv[0] = th[0] * (x[1] - x[0]);
@@ -201,7 +221,7 @@ __device__ void wg_drift(const WgArgs<R>& a, const WgLds<R>& L, const R* __restr
       fv[i] = rfma(xp1 - xm2, xm1, th[0] - x[i]);
     }
     if (want_jac) {
-      CDKF_WG_FOR(e, d * d) F[(e / d) * lq + (e % d)] = 0;
+      CDKF_WG_FOR(e, d * d) F[(fdiv(e, d)) * lq + (fmod_(e, d))] = 0;
       __syncthreads();
       CDKF_WG_FOR(i, d) {
         const R xp1 = x[(i + 1) % d], xm1 = x[(i + d - 1) % d], xm2 = x[(i + d - 2) % d];
@@ -245,14 +265,14 @@ __device__ void wg_drift(const WgArgs<R>& a, const WgLds<R>& L, const R* __restr
     if (want_jac) {
       // C = W3 diag(1 - a2^2) W2 diag(1 - a1^2)   [d x h1];   J = C W1
       CDKF_WG_FOR(e, d * h1) {
-        const int i = e / h1, qq = e % h1;
+        const int i = fdiv(e, h1), qq = fmod_(e, h1);
         R s = 0;
         for (int p = 0; p < h2; ++p) s = rfma(W3[i * h2 + p] * (R(1) - a2[p] * a2[p]), W2[p * h1 + qq], s);
         Cm[e] = s * (R(1) - a1[qq] * a1[qq]);
       }
       __syncthreads();
       CDKF_WG_FOR(e, d * d) {
-        const int i = e / d, j = e % d;
+        const int i = fdiv(e, d), j = fmod_(e, d);
         R s = 0;
         for (int qq = 0; qq < h1; ++qq) s = rfma(Cm[i * h1 + qq], W1[qq * d + j], s);
         F[i * lq + j] = s;
@@ -286,23 +306,21 @@ __device__ void wg_drift(const WgArgs<R>& a, const WgLds<R>& L, const R* __restr
   __syncthreads();
 }
 
-// MLP scratch in LDS behind the matrices: a1[h1] a2[h2] s2[h2] tq[h1] Cm[d*h1] Gm[h2*h1]
-inline int wg_extra_reals(int kind, int d, int h1, int h2) {
-  return kind == kDriftMlp ? (2 * h1 + 2 * h2 + d * h1 + h2 * h1) : 0;
-}
-
 // G_pq = (sum_i W3_ip W1_qi) * W2_pq : constant of the MLP, built once per workgroup
 template <typename R>
 __device__ void wg_mlp_prepare(const WgArgs<R>& a, const WgLds<R>& L) {
   if (a.kind != kDriftMlp) return;
   const int d = a.d, h1 = a.h1, h2 = a.h2;
-  const R* th = a.par + a.o_theta;
+  R* thl = L.extra() + wg_extra_reals(kDriftMlp, d, h1, h2);
+  CDKF_WG_FOR(e, wg_mlp_theta_reals(kDriftMlp, d, h1, h2)) thl[e] = (a.par + a.o_theta)[e];
+  __syncthreads();
+  const R* th = thl;
   const R* W1 = th;
   const R* W2 = W1 + h1 * d + h1;
   const R* W3 = W2 + h2 * h1 + h2;
   R* Gm = L.extra() + (2 * h1 + 2 * h2 + d * h1);
   CDKF_WG_FOR(e, h2 * h1) {
-    const int p = e / h1, qq = e % h1;
+    const int p = fdiv(e, h1), qq = fmod_(e, h1);
     R s = 0;
     for (int i = 0; i < d; ++i) s = rfma(W3[i * h2 + p], W1[qq * d + i], s);
     Gm[e] = s * W2[e];
@@ -323,7 +341,7 @@ __device__ void wg_rhs_ekf(const WgArgs<R>& a, const WgLds<R>& L, const R* ms, c
   if (mean_only) return;
   if (a.kind == kDriftLorenz96) {  // banded Jacobian: 4 terms per entry
     CDKF_WG_FOR(e, d * d) {
-      const int i = e / d, j = e % d;
+      const int i = fdiv(e, d), j = fmod_(e, d);
       const int k1 = (i + 1) % d, k2 = (i + d - 2) % d, k3 = (i + d - 1) % d;
       R s = F[i * lq + k2] * Ps[k2 * lq + j];
       s = rfma(F[i * lq + k3], Ps[k3 * lq + j], s);
@@ -337,7 +355,7 @@ __device__ void wg_rhs_ekf(const WgArgs<R>& a, const WgLds<R>& L, const R* ms, c
   __syncthreads();
   const R* LQL = a.par + a.o_LQL;
   CDKF_WG_FOR(e, d * d) {
-    const int j = e / d, i = e % d;  // i fastest: A[j][i] row reads are contiguous, A[i][j] strided
+    const int j = fdiv(e, d), i = fmod_(e, d);  // i fastest: A[j][i] row reads are contiguous, A[i][j] strided
     kP[i * lq + j] = (A[i * lq + j] + A[j * lq + i]) + LQL[i * d + j];
   }
   if (second) {
@@ -432,7 +450,7 @@ __device__ void wg_ekf_update(const WgArgs<R>& a, const WgLds<R>& L, const R* __
   R* v = L.vec(2);
   R* z = L.vec(3);
   R* inv = L.vec(4);
-  CDKF_WG_FOR(e, m * d) Hl[(e / d) * lq + (e % d)] = H[e];
+  CDKF_WG_FOR(e, m * d) Hl[(fdiv(e, d)) * lq + (fmod_(e, d))] = H[e];
   __syncthreads();
   for (int it = 0; it < a.num_iter; ++it) {
     wg_matmul(HP, Hl, P, m, d, d, lq);
@@ -444,10 +462,10 @@ __device__ void wg_ekf_update(const WgArgs<R>& a, const WgLds<R>& L, const R* __
       v[r] = yobs_lds[r] - (s + hb[r]);
     }
     __syncthreads();
-    CDKF_WG_FOR(e, m * m) S[(e / m) * lq + (e % m)] += Rm[e];
+    CDKF_WG_FOR(e, m * m) S[(fdiv(e, m)) * lq + (fmod_(e, m))] += Rm[e];
     __syncthreads();
     if (it == 0) {  // TFP log_prob with the un-jittered S
-      CDKF_WG_FOR(e, m * m) Lc[(e / m) * lq + (e % m)] = S[(e / m) * lq + (e % m)];
+      CDKF_WG_FOR(e, m * m) Lc[(fdiv(e, m)) * lq + (fmod_(e, m))] = S[(fdiv(e, m)) * lq + (fmod_(e, m))];
       CDKF_WG_FOR(r, m) z[r] = v[r];
       wg_cholesky(Lc, inv, m, lq, bad);
       for (int i = 0; i < m; ++i) {  // forward substitution z = L^-1 v, one barrier per row
@@ -467,12 +485,12 @@ __device__ void wg_ekf_update(const WgArgs<R>& a, const WgLds<R>& L, const R* __
     }
     // psd_solve(S, HP): symmetrize + 1e-9 I, Cholesky, solve
     CDKF_WG_FOR(e, m * m) {
-      const int r = e / m, c = e % m;
+      const int r = fdiv(e, m), c = fmod_(e, m);
       R s = R(0.5) * (S[r * lq + c] + S[c * lq + r]);
       if (r == c) s += R(1e-9);
       Lc[r * lq + c] = s;
     }
-    CDKF_WG_FOR(e, m * d) X[(e / d) * lq + (e % d)] = HP[(e / d) * lq + (e % d)];
+    CDKF_WG_FOR(e, m * d) X[(fdiv(e, d)) * lq + (fmod_(e, d))] = HP[(fdiv(e, d)) * lq + (fmod_(e, d))];
     wg_cholesky(Lc, inv, m, lq, bad);
     wg_chol_solve(Lc, inv, X, m, d, lq);
     wg_matmul(SX, S, X, m, m, d, lq);  // S X
@@ -486,14 +504,14 @@ __device__ void wg_ekf_update(const WgArgs<R>& a, const WgLds<R>& L, const R* __
     __syncthreads();
     CDKF_WG_FOR(i, d) mm[i] = z[i];
     CDKF_WG_FOR(e, d * d) {
-      const int i = e / d, j = e % d;
+      const int i = fdiv(e, d), j = fmod_(e, d);
       P[i * lq + j] -= Tm[i * lq + j];
     }
     __syncthreads();
   }
   // symmetrize (dynamax/utils/utils.py:209-211)
   CDKF_WG_FOR(e, d * d) {
-    const int i = e / d, j = e % d;
+    const int i = fdiv(e, d), j = fmod_(e, d);
     if (i < j) {
       const R s = R(0.5) * (P[i * lq + j] + P[j * lq + i]);
       P[i * lq + j] = s;
@@ -514,7 +532,7 @@ __device__ __forceinline__ void wg_store(const WgArgs<R>& a, const WgLds<R>& L, 
   if (Po) {
     R* p = Po + n * a.P_sn + k * a.P_sk;
     const R* P = L.mat(0);
-    CDKF_WG_FOR(e, d * d) p[e * a.P_si] = P[(e / d) * lq + (e % d)];
+    CDKF_WG_FOR(e, d * d) p[e * a.P_si] = P[(fdiv(e, d)) * lq + (fmod_(e, d))];
   }
 }
 
@@ -535,7 +553,7 @@ __global__ void ekf_filter_wg_kernel(const WgArgs<R> a) {
   __syncthreads();
   CDKF_WG_FOR(i, d) L.vec(0)[i] = (a.par + a.o_m0)[i];
   CDKF_WG_FOR(e, d * d) {
-    const int i = e / d, j = e % d;
+    const int i = fdiv(e, d), j = fmod_(e, d);
     L.mat(0)[i * lq + j] = R(0.5) * ((a.par + a.o_P0)[i * d + j] + (a.par + a.o_P0)[j * d + i]);
   }
   wg_mlp_prepare(a, L);
@@ -558,7 +576,7 @@ __global__ void ekf_filter_wg_kernel(const WgArgs<R> a) {
     if (zeroth) {
       const R sq = rsqrt_(t1 - t0);
       const R* Qz = a.par + a.o_LQLz;
-      CDKF_WG_FOR(e, d * d) L.mat(0)[(e / d) * lq + (e % d)] = rfma(sq, Qz[e], L.mat(0)[(e / d) * lq + (e % d)]);
+      CDKF_WG_FOR(e, d * d) L.mat(0)[(fdiv(e, d)) * lq + (fmod_(e, d))] = rfma(sq, Qz[e], L.mat(0)[(fdiv(e, d)) * lq + (fmod_(e, d))]);
       __syncthreads();
     }
     wg_store(a, L, a.pm, a.pP, n, k);
@@ -594,7 +612,7 @@ __global__ void ekf_smoother_wg_kernel(const WgArgs<R> a) {
   {
     const long k = a.T - 1;
     CDKF_WG_FOR(i, d) L.vec(0)[i] = fm[k * a.m_sk + i * a.m_si];
-    CDKF_WG_FOR(e, d * d) L.mat(0)[(e / d) * lq + (e % d)] = fP[k * a.P_sk + e * a.P_si];
+    CDKF_WG_FOR(e, d * d) L.mat(0)[(fdiv(e, d)) * lq + (fmod_(e, d))] = fP[k * a.P_sk + e * a.P_si];
     __syncthreads();
     wg_store(a, L, a.sm, a.sP, n, k);
     __syncthreads();
@@ -614,7 +632,7 @@ __global__ void ekf_smoother_wg_kernel(const WgArgs<R> a) {
     }
     __syncthreads();
     CDKF_WG_FOR(e, d * d) {
-      const int j = e / d, i = e % d;
+      const int j = fdiv(e, d), i = fmod_(e, d);
       kP[i * lq + j] = -((A[i * lq + j] + A[j * lq + i]) - LQL[i * d + j]);
     }
     __syncthreads();
@@ -625,10 +643,10 @@ __global__ void ekf_smoother_wg_kernel(const WgArgs<R> a) {
     R* Lc = L.mat(9);
     R* X = L.mat(1);
     CDKF_WG_FOR(i, d) mf[i] = fm[k * a.m_sk + i * a.m_si];
-    CDKF_WG_FOR(e, d * d) L.mat(2)[(e / d) * lq + (e % d)] = fP[k * a.P_sk + e * a.P_si];
+    CDKF_WG_FOR(e, d * d) L.mat(2)[(fdiv(e, d)) * lq + (fmod_(e, d))] = fP[k * a.P_sk + e * a.P_si];
     __syncthreads();
     CDKF_WG_FOR(e, d * d) {
-      const int r = e / d, c = e % d;
+      const int r = fdiv(e, d), c = fmod_(e, d);
       R s = R(0.5) * (L.mat(2)[r * lq + c] + L.mat(2)[c * lq + r]);
       if (r == c) s += R(1e-9);
       Lc[r * lq + c] = s;
@@ -638,7 +656,7 @@ __global__ void ekf_smoother_wg_kernel(const WgArgs<R> a) {
     wg_chol_solve(Lc, inv, X, d, d, lq);  // X = P_f^{-1} LQL
     wg_drift(a, L, mf, fmf, G, (R*)nullptr, true);
     CDKF_WG_FOR(e, d * d) {
-      const int i = e / d, j = e % d;
+      const int i = fdiv(e, d), j = fmod_(e, d);
       G[i * lq + j] += X[j * lq + i];
     }
     __syncthreads();

@@ -11,8 +11,9 @@ static constexpr size_t kLdsLimit = 160 * 1024;
 template <typename R>
 static size_t wg_lds_bytes(const cdkf_model* mdl) {
   const int q = mdl->state_dim > mdl->emission_dim ? mdl->state_dim : mdl->emission_dim;
-  const int lq = (q + 3) & ~3;
-  return WgLds<R>::bytes(q, lq, wg_extra_reals(mdl->drift_kind, mdl->state_dim, mdl->hidden1, mdl->hidden2)) + 64;
+  const int lq = ((q + 3) & ~3) + 1;
+  return WgLds<R>::bytes(q, lq, wg_extra_reals(mdl->drift_kind, mdl->state_dim, mdl->hidden1, mdl->hidden2) +
+                                    wg_mlp_theta_reals(mdl->drift_kind, mdl->state_dim, mdl->hidden1, mdl->hidden2)) + 64;
 }
 
 static long expected_theta(const cdkf_model* mdl) {
@@ -134,7 +135,7 @@ static int wg_prepare(WgArgs<R>& a, R** dev_block, ParamSlot** slot_out, const c
   a.h1 = mdl->hidden1;
   a.h2 = mdl->hidden2;
   a.q = d > m ? d : m;
-  a.lq = (a.q + 3) & ~3;
+  a.lq = ((a.q + 3) & ~3) + 1;  // multiple of 4 (1x4 strips stay inside a row) plus 1 (odd: column walks hit 32 different LDS banks)
   a.order = o->state_order;
   a.num_iter = o->num_iter;
   a.max_steps = (long)o->max_steps;
@@ -187,6 +188,11 @@ static int wg_threads(int d) {
   if (const char* e = getenv("CDKF_WG_THREADS")) return atoi(e);  // debugging aid
   return d * d >= 1024 ? 256 : (d * d >= 256 ? 128 : 64);
 }
+// the MLP's hidden layers give every phase of the right-hand side >= h1*d independent entries
+static int wg_threads(const cdkf_model* mdl) {
+  const int t = wg_threads(mdl->state_dim);
+  return (mdl->drift_kind == CDKF_DRIFT_MLP_TANH && t < 256) ? 256 : t;
+}
 
 template <typename R>
 int launch_ekf_filter_wg(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll,
@@ -200,7 +206,7 @@ int launch_ekf_filter_wg(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, i
   const size_t lds = wg_lds_bytes<R>(mdl);
   static const int cap_rc = wg_raise_lds_cap(ekf_filter_wg_kernel<R>);
   if (cap_rc) return cap_rc;
-  hipLaunchKernelGGL(ekf_filter_wg_kernel<R>, dim3((unsigned)N), dim3(wg_threads(a.d)), lds, stream, a);
+  hipLaunchKernelGGL(ekf_filter_wg_kernel<R>, dim3((unsigned)N), dim3(wg_threads(mdl)), lds, stream, a);
   CDKF_HIP_CHECK(hipGetLastError());
   return param_pool_release(slot, stream);
 }
@@ -219,9 +225,9 @@ int launch_ekf_smoother_wg(const cdkf_model* mdl, const cdkf_opts* o, int64_t N,
   const size_t lds = wg_lds_bytes<R>(mdl);
   static const int cap_rc = wg_raise_lds_cap(ekf_filter_wg_kernel<R>) | wg_raise_lds_cap(ekf_smoother_wg_kernel<R>);
   if (cap_rc) return CDKF_EHIP;
-  hipLaunchKernelGGL(ekf_filter_wg_kernel<R>, dim3((unsigned)N), dim3(wg_threads(a.d)), lds, stream, a);
+  hipLaunchKernelGGL(ekf_filter_wg_kernel<R>, dim3((unsigned)N), dim3(wg_threads(mdl)), lds, stream, a);
   CDKF_HIP_CHECK(hipGetLastError());
-  hipLaunchKernelGGL(ekf_smoother_wg_kernel<R>, dim3((unsigned)N), dim3(wg_threads(a.d)), lds, stream, a);
+  hipLaunchKernelGGL(ekf_smoother_wg_kernel<R>, dim3((unsigned)N), dim3(wg_threads(mdl)), lds, stream, a);
   CDKF_HIP_CHECK(hipGetLastError());
   return param_pool_release(slot, stream);
 }

@@ -120,6 +120,10 @@ int cdkf_device_count(void);
  * 1 UKF filter, 2 EKF smoother.  bytes_per_real: 4 or 8. */
 int cdkf_supported(const cdkf_model* mdl, const cdkf_opts* opts, int algo, int bytes_per_real);
 
+/* The layout (CDKF_LAYOUT_*) in which this model's kernels move data fastest: _TCN for the lane-per-trajectory
+ * kernels (small state_dim), _TN for the workgroup-per-trajectory kernels (a trajectory's d x d block contiguous). */
+int cdkf_preferred_layout(const cdkf_model* mdl);
+
 /* ---- device memory helpers (so that host code needs no other GPU runtime) ------------------- */
 int cdkf_malloc(void** dev_ptr, int64_t bytes);
 int cdkf_free(void* dev_ptr);

@@ -48,8 +48,28 @@ def case(name, mdl, t, y, dt_final, orders=("first", "second"), ukf=True, eks=Tr
     print(name, os.path.getsize(path) // 1024, "KiB")
 
 
+def case_wide(name, mdl, t, y, orders):
+    """Large-state fixtures (Lorenz-96 d=40, MLP d=8): inputs, log-likelihoods, all filtered / smoothed means,
+    and the covariances of the LAST step only (a d x d block per step would not be a small fixture)."""
+    out = dict(model_arrays(mdl), t=t, y=y, dt_final=1e-10)
+    if mdl.drift.kind == "mlp":
+        out["hidden"] = np.array([mdl.drift.W1.shape[0], mdl.drift.W2.shape[0]])
+    for order in orders:
+        r = o.ekf_filter(mdl, t, y, state_order=order)
+        out[f"ekf_{order}_ll"] = r["marginal_loglik"]
+        out[f"ekf_{order}_filtered_means"] = r["filtered_means"]
+        out[f"ekf_{order}_filtered_cov_last"] = r["filtered_covariances"][:, -1]
+        out[f"ekf_{order}_predicted_cov_last"] = r["predicted_covariances"][:, -1]
+    r = o.ekf_smoother(mdl, t, y, state_order=orders[-1])
+    out["eks_smoothed_means"] = r["smoothed_means"]
+    out["eks_smoothed_cov_first"] = r["smoothed_covariances"][:, 0]
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(name, os.path.getsize(path) // 1024, "KiB")
+
+
 def main():
-    from helpers import linear_model
+    from helpers import linear_model, lorenz96_model, mlp_model
     # 1. the reference test scripts' shape: STATE_DIM=2, EMISSION_DIM=6, T=100 regular integer times, dt_final=1
     rng = np.random.default_rng(100)
     mdl = linear_model(rng, 2, 6)
@@ -73,6 +93,17 @@ def main():
         t[1, 40] = t[1, 39]  # zero-length interval
         y = o.simulate(mdl, t, rng)
         case(f"lorenz63_m{m_obs}_irregular", mdl, t, y, 1e-10, orders=("second",))
+    # 5. BASELINE config 4 shape: Lorenz-96, d = 40, fully observed (N=2, T=20)
+    rng = np.random.default_rng(104)
+    mdl = lorenz96_model(40, 40)
+    t = o.irregular_times(rng, 2, 20, 0.012 * 20)
+    case_wide("lorenz96_d40_m40", mdl, t, o.simulate(mdl, t, rng), orders=("second",))
+    # 6. BASELINE config 5 shape: MLP(8 -> 64 -> 64 -> 8, tanh) drift, d = 8, m = 4 (N=4, T=50); 'second' carries the
+    #    reference's 0.5*trace(H_t @ P) quirk (non-zero here), 'first' does not
+    rng = np.random.default_rng(105)
+    mdl = mlp_model(rng, 8, 4, 64)
+    t = o.irregular_times(rng, 4, 50, 0.02 * 50)
+    case_wide("mlp_d8_m4", mdl, t, o.simulate(mdl, t, rng), orders=("first", "second"))
 
 
 if __name__ == "__main__":

@@ -113,12 +113,22 @@ def model_from_fixture(g) -> o.Model:
         drift = o.Lorenz63Drift(*th)
     elif kind == "lorenz96":
         drift = o.Lorenz96Drift(th[0])
+    elif kind == "mlp":
+        h1, h2 = (int(v) for v in g["hidden"])
+        sizes = [(h1, d), (h1,), (h2, h1), (h2,), (d, h2), (d,)]
+        parts, off = [], 0
+        for shp in sizes:
+            n = int(np.prod(shp))
+            parts.append(th[off:off + n].reshape(shp))
+            off += n
+        drift = o.MLPDrift(*parts)
     else:
         raise ValueError(kind)
     return o.Model(drift, g["L"], g["Qc"], g["H"], g["bias"], g["R"], g["m0"], g["P0"])
 
 
 GOLDEN = ["linear_d2_m6_regular", "tracking_d4_m2_regular", "lorenz63_m3_irregular", "lorenz63_m1_irregular"]
+GOLDEN_WIDE = ["lorenz96_d40_m40", "mlp_d8_m4"]
 FILTER_KEYS = ["filtered_means", "filtered_covariances", "predicted_means", "predicted_covariances"]
 
 

@@ -5,7 +5,8 @@ import pytest
 
 import cd_dynamax_amd as cd
 import cdkf_oracle as o
-from helpers import FILTER_KEYS, linear_model, lorenz96_model, mlp_model, params_from, relerr
+from helpers import (FILTER_KEYS, GOLDEN_WIDE, linear_model, load_golden, lorenz96_model, mlp_model, model_from_fixture,
+                     params_from, relerr)
 
 pytestmark = pytest.mark.gpu
 
@@ -92,3 +93,22 @@ def test_wg_and_reg_kernels_agree_on_shared_shape(hip_lib):
     t = o.irregular_times(rng, 3, 20, 0.3)
     y = o.simulate(mdl, t, rng)
     _check(cd.cdnlgssm_filter(params_from(mdl), y, t[..., None]), o.ekf_filter(mdl, t, y), 1e-9)
+
+
+@pytest.mark.parametrize("name", GOLDEN_WIDE)
+def test_wide_golden_vectors(hip_lib, name):
+    """Committed fixtures at the BASELINE config 4 / 5 shapes (Lorenz-96 d=40; MLP d=8, first and second order)."""
+    g = load_golden(name)
+    mdl = model_from_fixture(g)
+    P = params_from(mdl)
+    y, t = g["y"], g["t"][..., None]
+    orders = [k[4:-3] for k in g.files if k.startswith("ekf_") and k.endswith("_ll")]
+    for order in orders:
+        post = cd.cdnlgssm_filter(P, y, t, cd.EKFHyperParams(state_order=order))
+        assert relerr(post.marginal_loglik, g[f"ekf_{order}_ll"]) < 1e-9
+        assert relerr(post.filtered_means, g[f"ekf_{order}_filtered_means"]) < 1e-9
+        assert relerr(post.filtered_covariances[:, -1], g[f"ekf_{order}_filtered_cov_last"]) < 1e-9
+        assert relerr(post.predicted_covariances[:, -1], g[f"ekf_{order}_predicted_cov_last"]) < 1e-9
+    sm = cd.cdnlgssm_smoother(P, y, t, cd.EKFHyperParams(state_order=orders[-1]))
+    assert relerr(sm.smoothed_means, g["eks_smoothed_means"]) < 1e-8
+    assert relerr(sm.smoothed_covariances[:, 0], g["eks_smoothed_cov_first"]) < 1e-8

@@ -195,6 +195,9 @@ def test_run_host_transposes_to_time_major(monkeypatch):
         def cdkf_last_error(self):
             return b""
 
+        def cdkf_preferred_layout(self, mdl):
+            return _ffi.LAYOUT_TCN
+
         def __getattr__(self, name):
             def fn(mdl, opts, N, T, t, y, ll, a1, a2, a3, a4, st):
                 seen["layout"], seen["N"], seen["T"] = opts._obj.layout, N, T
