@@ -300,61 +300,64 @@ CDKF_DEV void unpack_sym(const R* packed, R (&A)[D][D]) {
     for (int j = 0; j < D; ++j) A[i][j] = packed[sidx<D>(i, j)];
 }
 
-// ---- UKF: sigma points m, m +- c * chol(P)[:, i]  (inference_ukf.py:45-60) ---------------------
-// X[0] = m, X[1+i] = m + c L[:,i], X[1+D+i] = m - c L[:,i]
+// ---- UKF -----------------------------------------------------------------------------------------
+// Sigma points (inference_ukf.py:45-60): X_0 = m, X_{i+-} = m +- o_i with o_i = c * chol(P)[:, i] (lower
+// triangular: o_i[j] = 0 for j < i).  The reference's weighted sums are evaluated in antisymmetric form:
+// with xbar = sum_s w_m[s] X_s = m (the weights sum to one) the pair (i+, i-) contributes
+//   (g(X_i+) - gbar) o_i^T + (g(X_i-) - gbar) (-o_i)^T = (g(X_i+) - g(X_i-)) o_i^T,
+// and the s = 0 term carries the factor (m - xbar) = 0.  Same numbers as the literal
+// fX^T W X / tensordot forms up to rounding, at a third of the arithmetic.
 template <typename R, int D>
-CDKF_DEV void ukf_sigmas(const R (&ys)[Dims<D>::NS], R c, R (&X)[2 * D + 1][D], bool& bad) {
+CDKF_DEV void ukf_offsets(const R (&ys)[Dims<D>::NS], R c, R (&o)[D][D], bool& bad) {
   R P[D][D], Lc[D][D], inv[D];
   unpack_sym<R, D>(ys + D, P);
   chol_lower<R, D>(P, Lc, inv, bad);
 #pragma unroll
-  for (int j = 0; j < D; ++j) X[0][j] = ys[j];
-#pragma unroll
   for (int i = 0; i < D; ++i)
 #pragma unroll
-    for (int j = 0; j < D; ++j) {
-      const R dlt = (j >= i) ? c * Lc[j][i] : R(0);
-      X[1 + i][j] = ys[j] + dlt;
-      X[1 + D + i][j] = ys[j] - dlt;
-    }
+    for (int j = 0; j < D; ++j) o[i][j] = (j >= i) ? c * Lc[j][i] : R(0);
 }
 
-// UKF moment ODE (inference_ukf.py:128-152):  dm = fX^T w_m,  dP = fX^T W X + (.)^T + L Qc L^T with
-// W = (I - w_m 1^T) diag(w_c) (I - w_m 1^T)^T, evaluated in its factored form
-// fX^T W X = sum_s w_c[s] (fX_s - fbar)(X_s - xbar)^T,  fbar = sum w_m fX,  xbar = sum w_m X.
+// UKF moment ODE (inference_ukf.py:128-152):  dm = fX^T w_m,  dP = fX^T W X + (.)^T + L Qc L^T.
 template <typename R, int D, typename Args>
 struct UkfRhs {
   static constexpr int NS = Dims<D>::NS;
-  static constexpr int S = 2 * D + 1;
   const Args& a;
   bool* bad;
   CDKF_DEV void operator()(const R (&y)[NS], R (&dy)[NS]) const {
-    R X[S][D], fX[S][D];
-    ukf_sigmas<R, D>(y, a.ukf_c, X, *bad);
+    R o[D][D];
+    ukf_offsets<R, D>(y, a.ukf_c, o, *bad);
+    R f0[D], sum[D], df[D][D];
+    a.drift.f(y, f0);
 #pragma unroll
-    for (int s = 0; s < S; ++s) a.drift.f(X[s], fX[s]);
-    R fbar[D], xbar[D];
+    for (int j = 0; j < D; ++j) sum[j] = R(0);
 #pragma unroll
-    for (int j = 0; j < D; ++j) {
-      R sf = fX[1][j], sx = X[1][j];
-#pragma unroll
-      for (int s = 2; s < S; ++s) {
-        sf += fX[s][j];
-        sx += X[s][j];
-      }
-      fbar[j] = rfma(a.ukf_wm0, fX[0][j], a.ukf_wi * sf);
-      xbar[j] = rfma(a.ukf_wm0, X[0][j], a.ukf_wi * sx);
-      dy[j] = fbar[j];
-    }
-    R foo[D][D];
-#pragma unroll
-    for (int i = 0; i < D; ++i)
+    for (int i = 0; i < D; ++i) {
+      R xp[D], xm[D], fp[D], fm[D];
 #pragma unroll
       for (int j = 0; j < D; ++j) {
-        R acc = R(0);
+        xp[j] = (j >= i) ? y[j] + o[i][j] : y[j];
+        xm[j] = (j >= i) ? y[j] - o[i][j] : y[j];
+      }
+      a.drift.f(xp, fp);
+      a.drift.f(xm, fm);
 #pragma unroll
-        for (int s = 1; s < S; ++s) acc = rfma(fX[s][i] - fbar[i], X[s][j] - xbar[j], acc);
-        foo[i][j] = rfma(a.ukf_wc0, (fX[0][i] - fbar[i]) * (X[0][j] - xbar[j]), a.ukf_wi * acc);
+      for (int j = 0; j < D; ++j) {
+        sum[j] += fp[j] + fm[j];
+        df[i][j] = fp[j] - fm[j];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < D; ++j) dy[j] = rfma(a.ukf_wm0, f0[j], a.ukf_wi * sum[j]);
+    R foo[D][D];  // foo[r][b] = w_i sum_{i <= b} df_i[r] o_i[b]
+#pragma unroll
+    for (int r = 0; r < D; ++r)
+#pragma unroll
+      for (int b = 0; b < D; ++b) {
+        R acc = df[0][r] * o[0][b];
+#pragma unroll
+        for (int i = 1; i <= b; ++i) acc = rfma(df[i][r], o[i][b], acc);
+        foo[r][b] = a.ukf_wi * acc;
       }
 #pragma unroll
     for (int i = 0; i < D; ++i)
@@ -363,52 +366,51 @@ struct UkfRhs {
   }
 };
 
-// UKF measurement update (inference_ukf.py:162-203)
+// UKF measurement update (inference_ukf.py:162-203) for the linear emission h(x) = H x + b:
+// ybar = H m + b,  dY_i = H o_i,  S = 2 w_i sum_i dY_i dY_i^T + R,  C = 2 w_i sum_i o_i dY_i^T.
 template <typename R, int D, int M, typename Args>
 CDKF_DEV void ukf_update(const Args& a, R (&ys)[Dims<D>::NS], const R (&yobs)[M], LlAcc& ll, int& st) {
-  constexpr int S = 2 * D + 1;
   bool bad = false;
-  R X[S][D], Y[S][M];
-  ukf_sigmas<R, D>(ys, a.ukf_c, X, bad);
+  R o[D][D];
+  ukf_offsets<R, D>(ys, a.ukf_c, o, bad);
+  R dY[D][M];
 #pragma unroll
-  for (int s = 0; s < S; ++s)
+  for (int i = 0; i < D; ++i)
 #pragma unroll
     for (int r = 0; r < M; ++r) {
-      R v = a.H[r][0] * X[s][0];
+      R v = R(0);
 #pragma unroll
-      for (int k = 1; k < D; ++k) v = rfma(a.H[r][k], X[s][k], v);
-      Y[s][r] = v + a.hb[r];
+      for (int k = i; k < D; ++k) v = rfma(a.H[r][k], o[i][k], v);
+      dY[i][r] = v;
     }
-  R ybar[M];
+  R v[M];
 #pragma unroll
   for (int r = 0; r < M; ++r) {
-    R sy = Y[1][r];
+    R s = a.H[r][0] * ys[0];
 #pragma unroll
-    for (int s = 2; s < S; ++s) sy += Y[s][r];
-    ybar[r] = rfma(a.ukf_wm0, Y[0][r], a.ukf_wi * sy);
+    for (int k = 1; k < D; ++k) s = rfma(a.H[r][k], ys[k], s);
+    v[r] = yobs[r] - (s + a.hb[r]);
   }
+  const R w2 = a.ukf_wi + a.ukf_wi;
   R Sm[M][M], C[D][M];
 #pragma unroll
   for (int r = 0; r < M; ++r)
 #pragma unroll
     for (int c = 0; c < M; ++c) {
-      R acc = R(0);
+      R acc = dY[0][r] * dY[0][c];
 #pragma unroll
-      for (int s = 1; s < S; ++s) acc = rfma(Y[s][r] - ybar[r], Y[s][c] - ybar[c], acc);
-      Sm[r][c] = rfma(a.ukf_wc0, (Y[0][r] - ybar[r]) * (Y[0][c] - ybar[c]), a.ukf_wi * acc) + a.Rm[r][c];
+      for (int i = 1; i < D; ++i) acc = rfma(dY[i][r], dY[i][c], acc);
+      Sm[r][c] = rfma(w2, acc, a.Rm[r][c]);
     }
 #pragma unroll
-  for (int i = 0; i < D; ++i)
+  for (int k = 0; k < D; ++k)
 #pragma unroll
     for (int c = 0; c < M; ++c) {
-      R acc = R(0);
+      R acc = o[0][k] * dY[0][c];
 #pragma unroll
-      for (int s = 1; s < S; ++s) acc = rfma(X[s][i] - ys[i], Y[s][c] - ybar[c], acc);
-      C[i][c] = a.ukf_wi * acc;  // the s = 0 term is (m - m) * (.) = 0
+      for (int i = 1; i <= k; ++i) acc = rfma(o[i][k], dY[i][c], acc);
+      C[k][c] = w2 * acc;
     }
-  R v[M];
-#pragma unroll
-  for (int r = 0; r < M; ++r) v[r] = yobs[r] - ybar[r];
   {
     R Lc[M][M], inv[M];
     chol_lower<R, M>(Sm, Lc, inv, bad);
@@ -441,25 +443,25 @@ CDKF_DEV void ukf_update(const Args& a, R (&ys)[Dims<D>::NS], const R (&yobs)[M]
 #pragma unroll
     for (int j = 0; j < D; ++j) Xs[r][j] = C[j][r];
   chol_solve<R, M, D>(Lb, invb, Xs);
-  R KS[D][M];
+  R SX[M][D];
 #pragma unroll
-  for (int i = 0; i < D; ++i)
+  for (int r = 0; r < M; ++r)
 #pragma unroll
-    for (int c = 0; c < M; ++c) {
-      R s = Xs[0][i] * Sm[0][c];
+    for (int j = 0; j < D; ++j) {
+      R s = Sm[r][0] * Xs[0][j];
 #pragma unroll
-      for (int r = 1; r < M; ++r) s = rfma(Xs[r][i], Sm[r][c], s);
-      KS[i][c] = s;
+      for (int c = 1; c < M; ++c) s = rfma(Sm[r][c], Xs[c][j], s);
+      SX[r][j] = s;
     }
-  // P+ = P - K S K^T (no symmetrize in the UKF); the packed entry (i,j), i<=j, takes the LOWER
-  // element (j,i) of the reference's result, which is what the next Cholesky reads.
+  // P+ = P - K S K^T (no symmetrize in the UKF); the packed entry (i,j), i<=j, takes the LOWER element (j,i)
+  // of the reference's result, which is what the next Cholesky reads.
 #pragma unroll
   for (int i = 0; i < D; ++i)
 #pragma unroll
     for (int j = i; j < D; ++j) {
-      R tji = KS[j][0] * Xs[0][i];
+      R tji = Xs[0][j] * SX[0][i];
 #pragma unroll
-      for (int c = 1; c < M; ++c) tji = rfma(KS[j][c], Xs[c][i], tji);
+      for (int c = 1; c < M; ++c) tji = rfma(Xs[c][j], SX[c][i], tji);
       ys[D + sidx<D>(i, j)] -= tji;
     }
 #pragma unroll
