@@ -1,0 +1,899 @@
+// cdkf_wg2_kernels.h -- workgroup-per-trajectory sweep kernels, second generation.
+//
+// Mapping: one WORKGROUP owns one trajectory for the whole time scan.
+//  * Every thread OWNS up to EPT fixed entries (i,j) of the d x d covariance for the whole sweep; the six
+//    Dormand-Prince slopes of those entries (and of the mean, threads 0..d-1) live in its REGISTERS.  LDS holds only
+//    what other threads must see: the covariance P, the current stage value Ps, the stage mean and -- for drifts with
+//    a dense Jacobian -- F and F Ps.  Two barriers per RK stage.
+//  * The measurement update uses blocked (8-wide) right-looking Cholesky factorisations and blocked triangular
+//    solves over all threads: ~45 barriers per update at m = 40 instead of one or two per row.
+//  * Lorenz-96's Jacobian has 4 entries per row: its rows are evaluated on the fly from the stage mean, no F matrix.
+//  * The RK step count of an interval is uniform over the workgroup: no lane waits for another trajectory.
+// Reference functions restated: as in cdkf_reg_kernels.h.
+#pragma once
+#include "cdkf_math.h"
+
+namespace cdkf {
+
+constexpr int kDriftLinear = 0, kDriftLorenz63 = 1, kDriftLorenz96 = 2, kDriftMlp = 3;
+constexpr int kWgBlock = 8;  // panel width of the blocked factorisations
+
+template <typename R>
+struct WgArgs {
+  int kind, d, m, h1, h2;
+  int q, lq;  // q = max(d, m); lq = (q rounded up to a multiple of 4) + 1: leading dimension of every LDS matrix
+  int order, num_iter, hsel;
+  long max_steps;
+  R dt0, dt_final;
+  const R* par;  // device block: theta | LQL[d*d] | LQLz[d*d] | H[m*d] | hb[m] | Rm[m*m] | m0[d] | P0[d*d]
+  long o_theta, o_LQL, o_LQLz, o_H, o_hb, o_R, o_m0, o_P0;
+  long N, T;
+  long t_sn, t_sk, y_sn, y_sk, y_si, m_sn, m_sk, m_si, P_sn, P_sk, P_si;
+  const R* t;
+  const R* y;
+  R* ll;
+  R* fm;
+  R* fP;
+  R* pm;
+  R* pP;
+  R* sm;
+  R* sP;
+  int* status;
+};
+
+// Integer division by a run-time divisor costs ~40 instructions on CDNA: float reciprocal with +-1 correction
+// (exact for 0 <= e < 2^23, 0 < n < 2^12).
+__device__ __forceinline__ int fdiv(int e, int n) {
+  int q = (int)((float)e * __frcp_rn((float)n));
+  const int r = e - q * n;
+  q += (r >= n) - (r < 0);
+  return q;
+}
+
+#define CDKF_WG_FOR(idx, n) for (int idx = threadIdx.x; idx < (n); idx += blockDim.x)
+
+// ---- LDS carve-up ---------------------------------------------------------------------------------------------
+// matrices (q x lq each): 0 P, 1 Ps (= X in the update), 2 S, 3 L1 (= S X once the log-likelihood is done), 4 L2,
+// [5 F, 6 A if dense Jacobian], [next 2: HP, Hl if !hsel]
+// vectors (lq each): 0 m, 1 ms, 2 f, 3 g, 4 v, 5 z, 6 inv1, 7 inv2, 8 y, 9 m_f, 10 f(m_f), 11 tmp
+struct WgPlan {
+  int nmat, nvec, i_F, i_A, i_HP, i_Hl, extra;
+};
+__host__ __device__ inline int wg_mlp_scratch(int kind, int d, int h1, int h2) {
+  return kind == kDriftMlp ? (2 * h1 + 2 * h2 + d * h1 + h2 * h1 + h1 * d + 4) : 0;  // a1 a2 s2 tq T[h2*d] Gm[h2*h1] U[h1*d]
+}
+__host__ __device__ inline int wg_mlp_theta(int kind, int d, int h1, int h2) {
+  return kind == kDriftMlp ? (h1 * d + h1 + h2 * h1 + h2 + d * h2 + d) : 0;
+}
+__host__ __device__ inline WgPlan wg_plan(int kind, int d, int h1, int h2, int hsel, bool smoother) {
+  WgPlan p;
+  int n = 5;
+  const bool dense = (kind != kDriftLorenz96) || smoother;  // the smoother's G = F + aux is dense for every drift
+  p.i_F = dense ? n++ : -1;
+  p.i_A = dense ? n++ : -1;
+  p.i_HP = hsel ? -1 : n++;
+  p.i_Hl = hsel ? -1 : n++;
+  p.nmat = n;
+  p.nvec = 12;
+  p.extra = wg_mlp_scratch(kind, d, h1, h2) + wg_mlp_theta(kind, d, h1, h2);
+  return p;
+}
+__host__ __device__ inline long wg_lds_reals(const WgPlan& p, int q, int lq) {
+  return (long)p.nmat * q * lq + (long)p.nvec * lq + p.extra;
+}
+
+template <typename R>
+struct WgLds {
+  R* base;
+  int msz, lq;
+  WgPlan plan;
+  __device__ WgLds(R* b, int q, int lq_, const WgPlan& pl) : base(b), msz(q * lq_), lq(lq_), plan(pl) {}
+  __device__ R* mat(int i) const { return base + (long)i * msz; }
+  __device__ R* vec(int i) const { return base + (long)plan.nmat * msz + (long)i * lq; }
+  __device__ R* extra() const { return base + (long)plan.nmat * msz + (long)plan.nvec * lq; }
+};
+
+// ---- dense helpers (all operands in LDS, leading dimension lq) ---------------------------------------------------
+// C[r x c] = A[r x k] * B[k x c]; 1x4 strips per thread
+template <typename R>
+__device__ __forceinline__ void wg_matmul(R* __restrict__ C, const R* __restrict__ A, const R* __restrict__ B, int r,
+                                          int k, int c, int lq) {
+  const int c4 = (c + 3) >> 2;
+  CDKF_WG_FOR(e, r * c4) {
+    const int i = fdiv(e, c4), j = (e - i * c4) << 2;
+    R a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    const R* Ai = A + i * lq;
+    const R* Bj = B + j;
+#pragma unroll 4
+    for (int kk = 0; kk < k; ++kk) {
+      const R f = Ai[kk];
+      const R* b = Bj + kk * lq;
+      a0 = rfma(f, b[0], a0);
+      a1 = rfma(f, b[1], a1);
+      a2 = rfma(f, b[2], a2);
+      a3 = rfma(f, b[3], a3);
+    }
+    R* cij = C + i * lq + j;
+    cij[0] = a0;
+    cij[1] = a1;
+    cij[2] = a2;
+    cij[3] = a3;  // strip columns >= c land in the row padding (lq >= roundup4(c) + 1) and are never read as data
+  }
+}
+// C[r x c] = A[r x k] * B^T, B is [c x k]
+template <typename R>
+__device__ __forceinline__ void wg_matmul_nt(R* __restrict__ C, const R* __restrict__ A, const R* __restrict__ B, int r,
+                                             int k, int c, int lq) {
+  CDKF_WG_FOR(e, r * c) {
+    const int i = fdiv(e, c), j = e - i * c;
+    R acc = 0;
+#pragma unroll 4
+    for (int kk = 0; kk < k; ++kk) acc = rfma(A[i * lq + kk], B[j * lq + kk], acc);
+    C[i * lq + j] = acc;
+  }
+}
+// C[r x c] = A^T * B, A is [k x r], B is [k x c]; 1x4 strips
+template <typename R>
+__device__ __forceinline__ void wg_matmul_tn(R* __restrict__ C, const R* __restrict__ A, const R* __restrict__ B, int r,
+                                             int k, int c, int lq) {
+  const int c4 = (c + 3) >> 2;
+  CDKF_WG_FOR(e, r * c4) {
+    const int i = fdiv(e, c4), j = (e - i * c4) << 2;
+    R a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll 4
+    for (int kk = 0; kk < k; ++kk) {
+      const R f = A[kk * lq + i];
+      const R* b = B + kk * lq + j;
+      a0 = rfma(f, b[0], a0);
+      a1 = rfma(f, b[1], a1);
+      a2 = rfma(f, b[2], a2);
+      a3 = rfma(f, b[3], a3);
+    }
+    R* cij = C + i * lq + j;
+    cij[0] = a0;
+    cij[1] = a1;
+    cij[2] = a2;
+    cij[3] = a3;
+  }
+}
+
+// Blocked right-looking Cholesky (lower, in place) of up to TWO n x n matrices at once (S2 may be null): the LL
+// factor and the boosted gain factor of one update are independent.  inv*[j] = 1 / L[j][j].  3 barriers per
+// 8-wide panel.  Non-positive pivots give NaN (jnp.linalg.cholesky semantics) and raise *bad.
+template <typename R>
+__device__ void wg_cholesky2(R* S1, R* inv1, R* S2, R* inv2, int n, int lq, int* bad) {
+  const int nmat = S2 ? 2 : 1;
+  for (int kb = 0; kb < n; kb += kWgBlock) {
+    const int nb = (n - kb < kWgBlock) ? n - kb : kWgBlock;
+    __syncthreads();
+    // (a) diagonal block: one thread per matrix (thread 0 and thread 64 sit on different wavefronts when there are any)
+    const int who = (blockDim.x > 64) ? 64 : 1;
+    if (threadIdx.x == 0 || (nmat == 2 && threadIdx.x == who)) {
+      R* S = (threadIdx.x == 0) ? S1 : S2;
+      R* inv = (threadIdx.x == 0) ? inv1 : inv2;
+      for (int j = kb; j < kb + nb; ++j) {
+        R s = S[j * lq + j];
+        for (int k = kb; k < j; ++k) s = rfma(-S[j * lq + k], S[j * lq + k], s);
+        if (!(s > R(0))) *bad = 1;
+        const R r = rrsqrt(s);
+        inv[j] = r;
+        S[j * lq + j] = s * r;
+        for (int i = j + 1; i < kb + nb; ++i) {
+          R v = S[i * lq + j];
+          for (int k = kb; k < j; ++k) v = rfma(-S[i * lq + k], S[j * lq + k], v);
+          S[i * lq + j] = v * r;
+        }
+      }
+    }
+    __syncthreads();
+    // (b) panel below the block: row r solves  X L_blk^T = S[r][kb:kb+nb]
+    const int rest = n - kb - nb;
+    CDKF_WG_FOR(e, rest * nmat) {
+      const int w = (e >= rest) ? 1 : 0;
+      const int r = kb + nb + (e - w * rest);
+      R* S = w ? S2 : S1;
+      const R* inv = w ? inv2 : inv1;
+      for (int j = kb; j < kb + nb; ++j) {
+        R v = S[r * lq + j];
+        for (int k = kb; k < j; ++k) v = rfma(-S[r * lq + k], S[j * lq + k], v);
+        S[r * lq + j] = v * inv[j];
+      }
+    }
+    __syncthreads();
+    // (c) trailing update of the lower triangle: S[a][b] -= sum_k L[a][k] L[b][k]
+    CDKF_WG_FOR(e, rest * rest * nmat) {
+      const int w = (e >= rest * rest) ? 1 : 0;
+      const int e2 = e - w * rest * rest;
+      const int ar = fdiv(e2, rest), br = e2 - ar * rest;
+      if (br <= ar) {
+        R* S = w ? S2 : S1;
+        const int a = kb + nb + ar, b = kb + nb + br;
+        R v = S[a * lq + b];
+#pragma unroll 8
+        for (int k = kb; k < kb + nb; ++k) v = rfma(-S[a * lq + k], S[b * lq + k], v);
+        S[a * lq + b] = v;
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// Solve (L L^T) X = B in place, B is [n x c]; blocked substitution, 2 barriers per panel and direction.
+template <typename R>
+__device__ void wg_chol_solve(const R* L, const R* inv, R* B, int n, int c, int lq) {
+  for (int kb = 0; kb < n; kb += kWgBlock) {  // forward: L Y = B
+    const int nb = (n - kb < kWgBlock) ? n - kb : kWgBlock;
+    __syncthreads();
+    CDKF_WG_FOR(j, c) {
+      for (int i = kb; i < kb + nb; ++i) {
+        R v = B[i * lq + j];
+        for (int k = kb; k < i; ++k) v = rfma(-L[i * lq + k], B[k * lq + j], v);
+        B[i * lq + j] = v * inv[i];
+      }
+    }
+    __syncthreads();
+    const int rest = n - kb - nb;
+    CDKF_WG_FOR(e, rest * c) {
+      const int rr = fdiv(e, c), j = e - rr * c, r = kb + nb + rr;
+      R v = B[r * lq + j];
+#pragma unroll 8
+      for (int k = kb; k < kb + nb; ++k) v = rfma(-L[r * lq + k], B[k * lq + j], v);
+      B[r * lq + j] = v;
+    }
+  }
+  const int nblk = (n + kWgBlock - 1) / kWgBlock;
+  for (int bi = nblk - 1; bi >= 0; --bi) {  // backward: L^T X = Y
+    const int kb = bi * kWgBlock;
+    const int nb = (n - kb < kWgBlock) ? n - kb : kWgBlock;
+    __syncthreads();
+    CDKF_WG_FOR(j, c) {
+      for (int i = kb + nb - 1; i >= kb; --i) {
+        R v = B[i * lq + j];
+        for (int k = i + 1; k < kb + nb; ++k) v = rfma(-L[k * lq + i], B[k * lq + j], v);
+        B[i * lq + j] = v * inv[i];
+      }
+    }
+    __syncthreads();
+    CDKF_WG_FOR(e, kb * c) {
+      const int r = fdiv(e, c), j = e - r * c;
+      R v = B[r * lq + j];
+#pragma unroll 8
+      for (int k = kb; k < kb + nb; ++k) v = rfma(-L[k * lq + r], B[k * lq + j], v);
+      B[r * lq + j] = v;
+    }
+  }
+  __syncthreads();
+}
+
+// ---- drifts ------------------------------------------------------------------------------------------------------
+template <typename R>
+__device__ __forceinline__ R rtanh(R x) {
+  return (R)tanh((double)x);
+}
+template <>
+__device__ __forceinline__ float rtanh<float>(float x) {
+  return tanhf(x);
+}
+
+// MLP constants in LDS (once per workgroup): the weights, and G_pq = (sum_i W3_ip W1_qi) W2_pq for grad(div f)
+template <typename R>
+__device__ void wg_mlp_prepare(const WgArgs<R>& a, const WgLds<R>& L) {
+  if (a.kind != kDriftMlp) return;
+  const int d = a.d, h1 = a.h1, h2 = a.h2;
+  R* thl = L.extra() + wg_mlp_scratch(kDriftMlp, d, h1, h2);
+  CDKF_WG_FOR(e, wg_mlp_theta(kDriftMlp, d, h1, h2)) thl[e] = (a.par + a.o_theta)[e];
+  __syncthreads();
+  const R* W1 = thl;
+  const R* W2 = W1 + h1 * d + h1;
+  const R* W3 = W2 + h2 * h1 + h2;
+  R* Gm = L.extra() + (2 * h1 + 2 * h2 + h2 * d);
+  CDKF_WG_FOR(e, h2 * h1) {
+    const int p = fdiv(e, h1), qq = e - p * h1;
+    R s = 0;
+    for (int i = 0; i < d; ++i) s = rfma(W3[i * h2 + p], W1[qq * d + i], s);
+    Gm[e] = s * W2[e];
+  }
+  __syncthreads();
+}
+
+// f(x) -> fv; dense Jacobian -> F (if F != null); g = grad(div f) -> gv (MLP only, if gv != null).  Ends with a
+// barrier.  Lorenz-96 callers that only need f and use the banded product pass F = null.
+template <typename R>
+__device__ void wg_drift(const WgArgs<R>& a, const WgLds<R>& L, const R* __restrict__ x, R* __restrict__ fv,
+                         R* __restrict__ F, R* __restrict__ gv) {
+  const int d = a.d, lq = a.lq;
+  if (a.kind == kDriftLinear) {
+    const R* th = a.par + a.o_theta;
+    CDKF_WG_FOR(i, d) {
+      R s = 0;
+      for (int j = 0; j < d; ++j) s = rfma(th[i * d + j], x[j], s);
+      fv[i] = s + th[d * d + i];
+    }
+    if (F) CDKF_WG_FOR(e, d * d) {
+        const int i = fdiv(e, d);
+        F[i * lq + (e - i * d)] = th[e];
+      }
+  } else if (a.kind == kDriftLorenz63) {
+    const R* th = a.par + a.o_theta;
+    if (threadIdx.x == 0) {
+      fv[0] = th[0] * (x[1] - x[0]);
+      fv[1] = x[0] * (th[1] - x[2]) - x[1];
+      fv[2] = x[0] * x[1] - th[2] * x[2];
+      if (F) {
+        F[0] = -th[0]; F[1] = th[0]; F[2] = 0;
+        F[lq] = th[1] - x[2]; F[lq + 1] = -1; F[lq + 2] = -x[0];
+        F[2 * lq] = x[1]; F[2 * lq + 1] = x[0]; F[2 * lq + 2] = -th[2];
+      }
+    }
+  } else if (a.kind == kDriftLorenz96) {
+    const R forcing = (a.par + a.o_theta)[0];
+    CDKF_WG_FOR(i, d) {
+      const int ip1 = (i + 1 == d) ? 0 : i + 1, im1 = (i == 0) ? d - 1 : i - 1, im2 = (im1 == 0) ? d - 1 : im1 - 1;
+      fv[i] = rfma(x[ip1] - x[im2], x[im1], forcing - x[i]);
+    }
+    if (F) {
+      CDKF_WG_FOR(e, d * d) {
+        const int i = fdiv(e, d), j = e - i * d;
+        const int ip1 = (i + 1 == d) ? 0 : i + 1, im1 = (i == 0) ? d - 1 : i - 1, im2 = (im1 == 0) ? d - 1 : im1 - 1;
+        R v = 0;
+        if (j == ip1) v = x[im1];
+        if (j == im2) v = -x[im1];
+        if (j == im1) v = x[ip1] - x[im2];
+        if (j == i) v = R(-1);
+        F[i * lq + j] = v;
+      }
+    }
+  } else {  // MLP: f = W3 tanh(W2 tanh(W1 x + b1) + b2) + b3;  J = W3 D2 W2 D1 W1 via the tangent T = D2 W2 D1 W1
+    const int h1 = a.h1, h2 = a.h2;
+    const R* W1 = L.extra() + wg_mlp_scratch(kDriftMlp, d, h1, h2);
+    const R* b1 = W1 + h1 * d;
+    const R* W2 = b1 + h1;
+    const R* b2 = W2 + h2 * h1;
+    const R* W3 = b2 + h2;
+    const R* b3 = W3 + d * h2;
+    R* a1 = L.extra();   // [h1]
+    R* a2 = a1 + h1;     // [h2]
+    R* s2 = a2 + h2;     // [h2]
+    R* tq = s2 + h2;     // [h1]
+    R* Tm = tq + h1;     // [h2 x d] tangent of the second layer (stored as h2 rows of d)
+    R* Gm = Tm + h2 * d; // [h2 x h1]
+    // layer 1: a1 = tanh(W1 x + b1) and, for the Jacobian, U[q][:] = (1 - a1_q^2) W1[q][:]   (U lives in Tm's tail)
+    R* Um = Gm + h2 * h1;  // [h1 x d]
+    CDKF_WG_FOR(p, h1) {
+      R s = b1[p];
+      for (int j = 0; j < d; ++j) s = rfma(W1[p * d + j], x[j], s);
+      const R t = rtanh(s);
+      a1[p] = t;
+      if (F) {
+        const R d1 = R(1) - t * t;
+        for (int j = 0; j < d; ++j) Um[p * d + j] = d1 * W1[p * d + j];
+      }
+    }
+    __syncthreads();
+    // layer 2, one row p and one 4-column strip per thread: z2_p = W2[p] . a1 + b2_p (every strip recomputes it),
+    // T[p][j..j+3] = W2[p] . U[:, j..j+3]; stored already scaled by d2_p = 1 - tanh(z2_p)^2
+    {
+      const int d4 = F ? ((d + 3) >> 2) : 1;
+      CDKF_WG_FOR(e, h2 * d4) {
+        const int p = fdiv(e, d4), j = (e - p * d4) << 2;
+        R z = b2[p], t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+        const R* w = W2 + p * h1;
+        if (F) {
+#pragma unroll 4
+          for (int qq = 0; qq < h1; ++qq) {
+            const R wq = w[qq];
+            const R* u = Um + qq * d + j;
+            z = rfma(wq, a1[qq], z);
+            t0 = rfma(wq, u[0], t0);
+            t1 = rfma(wq, u[1], t1);
+            t2 = rfma(wq, u[2], t2);
+            t3 = rfma(wq, u[3], t3);
+          }
+        } else {
+#pragma unroll 4
+          for (int qq = 0; qq < h1; ++qq) z = rfma(w[qq], a1[qq], z);
+        }
+        const R av = rtanh(z);
+        if (j == 0) a2[p] = av;
+        if (F) {
+          const R d2 = R(1) - av * av;
+          R* tp = Tm + p * d + j;
+          tp[0] = d2 * t0;
+          if (j + 1 < d) tp[1] = d2 * t1;
+          if (j + 2 < d) tp[2] = d2 * t2;
+          if (j + 3 < d) tp[3] = d2 * t3;
+        }
+      }
+    }
+    __syncthreads();
+    // layer 3: f = W3 a2 + b3;  J = W3 (D2 T)
+    CDKF_WG_FOR(e, d * (d + 1)) {
+      const int i = fdiv(e, d + 1), j = e - i * (d + 1);
+      if (j == d) {
+        R s = b3[i];
+#pragma unroll 4
+        for (int p = 0; p < h2; ++p) s = rfma(W3[i * h2 + p], a2[p], s);
+        fv[i] = s;
+      } else if (F) {
+        R s = 0;
+#pragma unroll 4
+        for (int p = 0; p < h2; ++p) s = rfma(W3[i * h2 + p], Tm[p * d + j], s);
+        F[i * lq + j] = s;
+      }
+    }
+    if (gv) {
+      // g = d tr(J)/dx, tr(J) = sum_pq G_pq d2_p d1_q
+      CDKF_WG_FOR(p, h2) {
+        R s = 0;
+        for (int qq = 0; qq < h1; ++qq) s = rfma(Gm[p * h1 + qq], R(1) - a1[qq] * a1[qq], s);
+        s2[p] = R(-2) * a2[p] * (R(1) - a2[p] * a2[p]) * s;
+      }
+      __syncthreads();
+      CDKF_WG_FOR(qq, h1) {
+        const R d1 = R(1) - a1[qq] * a1[qq];
+        R td = 0, tc = 0;
+        for (int p = 0; p < h2; ++p) {
+          td = rfma(R(1) - a2[p] * a2[p], Gm[p * h1 + qq], td);
+          tc = rfma(s2[p], W2[p * h1 + qq], tc);
+        }
+        tq[qq] = td * (R(-2) * a1[qq] * d1) + tc * d1;
+      }
+      __syncthreads();
+      CDKF_WG_FOR(l, d) {
+        R s = 0;
+        for (int qq = 0; qq < h1; ++qq) s = rfma(tq[qq], W1[qq * d + l], s);
+        gv[l] = s;
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// ---- per-thread ownership of covariance entries ------------------------------------------------------------------
+template <typename R, int EPT>
+struct Own {
+  int n;            // number of owned entries (<= EPT)
+  int off[EPT];     // LDS offset i*lq + j
+  int ei[EPT], ej[EPT];
+  R lql[EPT];       // (L Qc L^T)[i][j]
+  __device__ void init(int d, int lq, const R* LQL) {
+    n = 0;
+#pragma unroll
+    for (int u = 0; u < EPT; ++u) {
+      const int e = threadIdx.x + u * blockDim.x;
+      const bool ok = e < d * d;
+      const int i = ok ? fdiv(e, d) : 0, j = ok ? e - i * d : 0;
+      ei[u] = i;
+      ej[u] = j;
+      off[u] = i * lq + j;
+      lql[u] = ok ? LQL[i * d + j] : R(0);
+      n += ok;
+    }
+  }
+};
+
+// One Dormand-Prince step with register-resident slopes.  `rhs(msrc, Psrc, s, km, kP)` must fill this thread's slopes
+// for stage s from the LDS stage value and END with a barrier-free state (it may use barriers inside).
+template <typename R, int EPT, typename RhsFn>
+__device__ __forceinline__ void wg_dopri5_step(const WgLds<R>& L, const Own<R, EPT>& own, int d, R dt, bool with_P,
+                                               RhsFn rhs) {
+  using C = Dp5<R>;
+  R* mcur = L.vec(0);
+  R* Pm = L.mat(0);
+  R* ms = L.vec(1);
+  R* Ps = L.mat(1);
+  R kM[6];
+  R kP[6][EPT];
+  const bool has_m = threadIdx.x < d;
+  const R A_[6][5] = {{0, 0, 0, 0, 0},
+                      {C::a21, 0, 0, 0, 0},
+                      {C::a31, C::a32, 0, 0, 0},
+                      {C::a41, C::a42, C::a43, 0, 0},
+                      {C::a51, C::a52, C::a53, C::a54, 0},
+                      {C::a61, C::a62, C::a63, C::a64, C::a65}};
+#pragma unroll
+  for (int s = 0; s < 6; ++s) {
+    if (s == 0) {
+      rhs(mcur, Pm, kM[0], kP[0]);
+    } else {
+      if (has_m) {
+        R acc = A_[s][0] * kM[0];
+#pragma unroll
+        for (int j = 1; j < s; ++j) acc = rfma(A_[s][j], kM[j], acc);
+        ms[threadIdx.x] = rfma(dt, acc, mcur[threadIdx.x]);
+      }
+      if (with_P) {
+#pragma unroll
+        for (int u = 0; u < EPT; ++u)
+          if (u < own.n) {
+            R acc = A_[s][0] * kP[0][u];
+#pragma unroll
+            for (int j = 1; j < s; ++j) acc = rfma(A_[s][j], kP[j][u], acc);
+            Ps[own.off[u]] = rfma(dt, acc, Pm[own.off[u]]);
+          }
+      }
+      __syncthreads();
+      rhs(ms, Ps, kM[s], kP[s]);
+    }
+    __syncthreads();  // every thread is done reading the stage value before it is overwritten
+  }
+  if (has_m) {
+    const R acc = rfma(C::b6, kM[5], rfma(C::b5, kM[4], rfma(C::b4, kM[3], rfma(C::b3, kM[2], C::b1 * kM[0]))));
+    mcur[threadIdx.x] = rfma(dt, acc, mcur[threadIdx.x]);
+  }
+  if (with_P) {
+#pragma unroll
+    for (int u = 0; u < EPT; ++u)
+      if (u < own.n) {
+        const R acc =
+            rfma(C::b6, kP[5][u], rfma(C::b5, kP[4][u], rfma(C::b4, kP[3][u], rfma(C::b3, kP[2][u], C::b1 * kP[0][u]))));
+        Pm[own.off[u]] = rfma(dt, acc, Pm[own.off[u]]);
+      }
+  }
+  __syncthreads();
+}
+
+template <typename R, int EPT, typename RhsFn>
+__device__ __forceinline__ bool wg_integrate(const WgLds<R>& L, const Own<R, EPT>& own, int d, R t0, R t1, R dt0,
+                                             long max_steps, bool with_P, RhsFn rhs) {
+  R tprev = t0;
+  R tnext = rmin(t0 + dt0, t1);
+  long steps = 0;
+  while (tprev < t1) {  // uniform over the workgroup
+    if (steps >= max_steps) return true;
+    wg_dopri5_step<R, EPT>(L, own, d, tnext - tprev, with_P, rhs);
+    tprev = rmin(tnext, t1);
+    const R tn = tnext + dt0;
+    tnext = (tn > t1 - Tol<R>::v) ? t1 : tn;
+    ++steps;
+  }
+  return false;
+}
+
+// EKF moment right-hand side for this thread's entries (inference_ekf.py:76-123):
+//   kP_ij = sum_k F_ik Ps_kj + sum_k F_jk Ps_ki + LQL_ij;   kM_i = f_i (+ 0.5 sum_k g_k Ps_ki)
+template <typename R, int EPT>
+__device__ __forceinline__ void wg_rhs_ekf(const WgArgs<R>& a, const WgLds<R>& L, const Own<R, EPT>& own, const R* ms,
+                                           const R* Ps, R& kM, R (&kP)[EPT], bool mean_only) {
+  const int d = a.d, lq = a.lq;
+  R* fv = L.vec(2);
+  R* gv = L.vec(3);
+  const bool second = (a.order == 2) && (a.kind == kDriftMlp);
+  if (a.kind == kDriftLorenz96) {
+    const R forcing = (a.par + a.o_theta)[0];
+    if (threadIdx.x < d) {
+      const int i = threadIdx.x;
+      const int ip1 = (i + 1 == d) ? 0 : i + 1, im1 = (i == 0) ? d - 1 : i - 1, im2 = (im1 == 0) ? d - 1 : im1 - 1;
+      kM = rfma(ms[ip1] - ms[im2], ms[im1], forcing - ms[i]);
+    }
+    if (mean_only) return;
+    // banded Jacobian rows evaluated on the fly: F_i,i+1 = x_{i-1}, F_i,i-2 = -x_{i-1}, F_i,i-1 = x_{i+1} - x_{i-2}, F_ii = -1
+#pragma unroll
+    for (int u = 0; u < EPT; ++u)
+      if (u < own.n) {
+        const int i = own.ei[u], j = own.ej[u];
+        const int ip1 = (i + 1 == d) ? 0 : i + 1, im1 = (i == 0) ? d - 1 : i - 1, im2 = (im1 == 0) ? d - 1 : im1 - 1;
+        const int jp1 = (j + 1 == d) ? 0 : j + 1, jm1 = (j == 0) ? d - 1 : j - 1, jm2 = (jm1 == 0) ? d - 1 : jm1 - 1;
+        const R xi1 = ms[im1], xj1 = ms[jm1];
+        R s = -xi1 * Ps[im2 * lq + j];
+        s = rfma(ms[ip1] - ms[im2], Ps[im1 * lq + j], s);
+        s -= Ps[i * lq + j];
+        s = rfma(xi1, Ps[ip1 * lq + j], s);
+        R w = -xj1 * Ps[jm2 * lq + i];
+        w = rfma(ms[jp1] - ms[jm2], Ps[jm1 * lq + i], w);
+        w -= Ps[j * lq + i];
+        w = rfma(xj1, Ps[jp1 * lq + i], w);
+        kP[u] = (s + w) + own.lql[u];
+      }
+    return;
+  }
+  R* F = L.mat(L.plan.i_F);
+  R* A = L.mat(L.plan.i_A);
+  wg_drift(a, L, ms, fv, mean_only ? (R*)nullptr : F, second ? gv : (R*)nullptr);
+  if (threadIdx.x < d) kM = fv[threadIdx.x];
+  if (mean_only) return;
+  wg_matmul(A, F, Ps, d, d, d, lq);
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < EPT; ++u)
+    if (u < own.n) kP[u] = (A[own.off[u]] + A[own.ej[u] * lq + own.ei[u]]) + own.lql[u];
+  if (second && threadIdx.x < d) {
+    R s = 0;
+    for (int k = 0; k < d; ++k) s = rfma(gv[k], Ps[k * lq + threadIdx.x], s);
+    kM = rfma(R(0.5), s, kM);
+  }
+}
+
+// ---- EKF update on the LDS state (inference_ekf.py:153-199, 285-286) --------------------------------------------
+template <typename R>
+__device__ void wg_ekf_update(const WgArgs<R>& a, const WgLds<R>& L, const R* __restrict__ yl, double* ll, int* bad) {
+  const int d = a.d, m = a.m, lq = a.lq;
+  const R* hb = a.par + a.o_hb;
+  const R* Rm = a.par + a.o_R;
+  R* mm = L.vec(0);
+  R* P = L.mat(0);
+  R* X = L.mat(1);   // stage matrix is free during the update
+  R* S = L.mat(2);
+  R* L1 = L.mat(3);
+  R* L2 = L.mat(4);
+  R* SX = L.mat(3);  // aliases L1: the TFP factor is dead once z and the log-determinant are taken
+  R* v = L.vec(4);
+  R* z = L.vec(5);
+  R* inv1 = L.vec(6);
+  R* inv2 = L.vec(7);
+  R* tmp = L.vec(11);
+  const bool hsel = a.hsel != 0;
+  R* HP = hsel ? P : L.mat(L.plan.i_HP);  // with H = I[:m] the first m rows of P ARE H P
+  R* Hl = hsel ? (R*)nullptr : L.mat(L.plan.i_Hl);
+  if (!hsel) {
+    const R* H = a.par + a.o_H;
+    CDKF_WG_FOR(e, m * d) {
+      const int r = fdiv(e, d);
+      Hl[r * lq + (e - r * d)] = H[e];
+    }
+    __syncthreads();
+  }
+  for (int it = 0; it < a.num_iter; ++it) {
+    if (hsel) {
+      CDKF_WG_FOR(e, m * m) {
+        const int r = fdiv(e, m), c = e - r * m;
+        S[r * lq + c] = P[r * lq + c] + Rm[e];
+      }
+      CDKF_WG_FOR(r, m) v[r] = yl[r] - mm[r];
+    } else {
+      wg_matmul(HP, Hl, P, m, d, d, lq);
+      __syncthreads();
+      CDKF_WG_FOR(e, m * m) {
+        const int r = fdiv(e, m), c = e - r * m;
+        R acc = 0;
+        for (int k = 0; k < d; ++k) acc = rfma(HP[r * lq + k], Hl[c * lq + k], acc);
+        S[r * lq + c] = acc + Rm[e];
+      }
+      CDKF_WG_FOR(r, m) {
+        R s = 0;
+        for (int k = 0; k < d; ++k) s = rfma(Hl[r * lq + k], mm[k], s);
+        v[r] = yl[r] - (s + hb[r]);
+      }
+    }
+    __syncthreads();
+    // L1 <- S (TFP log_prob, no jitter; only on the first iteration), L2 <- symmetrize(S) + 1e-9 I (psd_solve), X <- H P
+    CDKF_WG_FOR(e, m * m) {
+      const int r = fdiv(e, m), c = e - r * m;
+      L1[r * lq + c] = S[r * lq + c];
+      R s = R(0.5) * (S[r * lq + c] + S[c * lq + r]);
+      if (r == c) s += R(1e-9);
+      L2[r * lq + c] = s;
+    }
+    CDKF_WG_FOR(e, m * d) {
+      const int r = fdiv(e, d), c = e - r * d;
+      X[r * lq + c] = HP[r * lq + c];
+    }
+    wg_cholesky2(it == 0 ? L1 : (R*)L2, it == 0 ? inv1 : inv2, it == 0 ? L2 : (R*)nullptr, inv2, m, lq, bad);
+    if (it == 0) {
+      // z = L1^-1 v and the log-likelihood term: one wavefront, lane r keeps v_r in a register
+      if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        double qd = 0.0, ld = 0.0;
+        for (int base = 0; base < m; base += 64) {  // m <= 64 in practice: a single pass
+          R vr = (base + lane < m) ? v[base + lane] : R(0);
+          for (int j = 0; j < m - base && j < 64; ++j) {
+            const R zj = __shfl(vr, j, 64) * inv1[base + j];
+            if (lane > j && base + lane < m) vr = rfma(-L1[(base + lane) * lq + base + j], zj, vr);
+            qd += (double)zj * (double)zj;
+            ld += log((double)inv1[base + j]);
+          }
+        }
+        if (lane == 0) *ll += -0.5 * qd + ld - 0.5 * m * 1.8378770664093454835606594728112;
+      }
+    }
+    wg_chol_solve(L2, inv2, X, m, d, lq);            // X = Sb^-1 (H P);   K = X^T
+    wg_matmul(SX, S, X, m, m, d, lq);                // S X
+    CDKF_WG_FOR(i, d) {                              // m+ = m + K v (staged: v is still being read)
+      R s = mm[i];
+      for (int r = 0; r < m; ++r) s = rfma(X[r * lq + i], v[r], s);
+      tmp[i] = s;
+    }
+    __syncthreads();
+    // P <- P - X^T (S X)   (1x4 strips)
+    {
+      const int c4 = (d + 3) >> 2;
+      CDKF_WG_FOR(e, d * c4) {
+        const int i = fdiv(e, c4), j = (e - i * c4) << 2;
+        R a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll 4
+        for (int kk = 0; kk < m; ++kk) {
+          const R f = X[kk * lq + i];
+          const R* b = SX + kk * lq + j;
+          a0 = rfma(f, b[0], a0);
+          a1 = rfma(f, b[1], a1);
+          a2 = rfma(f, b[2], a2);
+          a3 = rfma(f, b[3], a3);
+        }
+        R* p = P + i * lq + j;
+        p[0] -= a0;
+        if (j + 1 < d) p[1] -= a1;
+        if (j + 2 < d) p[2] -= a2;
+        if (j + 3 < d) p[3] -= a3;
+      }
+    }
+    CDKF_WG_FOR(i, d) mm[i] = tmp[i];
+    __syncthreads();
+  }
+  // symmetrize (dynamax/utils/utils.py:209-211)
+  CDKF_WG_FOR(e, d * d) {
+    const int i = fdiv(e, d), j = e - i * d;
+    if (i < j) {
+      const R s = R(0.5) * (P[i * lq + j] + P[j * lq + i]);
+      P[i * lq + j] = s;
+      P[j * lq + i] = s;
+    }
+  }
+  __syncthreads();
+}
+
+template <typename R>
+__device__ __forceinline__ void wg_store(const WgArgs<R>& a, const WgLds<R>& L, R* mo, R* Po, long n, long k) {
+  const int d = a.d, lq = a.lq;
+  if (mo) {
+    R* p = mo + n * a.m_sn + k * a.m_sk;
+    const R* mm = L.vec(0);
+    CDKF_WG_FOR(i, d) p[i * a.m_si] = mm[i];
+  }
+  if (Po) {
+    R* p = Po + n * a.P_sn + k * a.P_sk;
+    const R* P = L.mat(0);
+    CDKF_WG_FOR(e, d * d) {
+      const int i = fdiv(e, d);
+      p[e * a.P_si] = P[i * lq + (e - i * d)];
+    }
+  }
+}
+
+// ---- EKF filter sweep ----------------------------------------------------------------------------------------------
+template <typename R, int EPT>
+__global__ __launch_bounds__(256, 2) void ekf_filter_wg_kernel(const WgArgs<R> a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const WgPlan plan = wg_plan(a.kind, a.d, a.h1, a.h2, a.hsel, false);
+  WgLds<R> L(reinterpret_cast<R*>(smem_raw), a.q, a.lq, plan);
+  __shared__ int bad;
+  __shared__ double ll;
+  const long n = blockIdx.x;
+  const int d = a.d, m = a.m, lq = a.lq;
+  if (threadIdx.x == 0) {
+    bad = 0;
+    ll = 0.0;
+  }
+  CDKF_WG_FOR(e, (int)((long)plan.nmat * a.q * lq + (long)plan.nvec * lq)) L.base[e] = 0;
+  __syncthreads();
+  CDKF_WG_FOR(i, d) L.vec(0)[i] = (a.par + a.o_m0)[i];
+  CDKF_WG_FOR(e, d * d) {
+    const int i = fdiv(e, d), j = e - i * d;
+    L.mat(0)[i * lq + j] = R(0.5) * ((a.par + a.o_P0)[i * d + j] + (a.par + a.o_P0)[j * d + i]);
+  }
+  wg_mlp_prepare(a, L);
+  Own<R, EPT> own;
+  own.init(d, lq, a.par + a.o_LQL);
+  __syncthreads();
+  const R* tp = a.t + n * a.t_sn;
+  const R* yp = a.y + n * a.y_sn;
+  R* yl = L.vec(8);
+  int st = 0;
+  const bool zeroth = a.order == 0;
+  auto rhs = [&](const R* ms, const R* Ps, R& kM, R (&kP)[EPT]) { wg_rhs_ekf<R, EPT>(a, L, own, ms, Ps, kM, kP, zeroth); };
+  for (long k = 0; k < a.T; ++k) {
+    CDKF_WG_FOR(r, m) yl[r] = yp[k * a.y_sk + r * a.y_si];
+    const R t0 = tp[k * a.t_sk];
+    const R t1 = (k + 1 < a.T) ? tp[(k + 1) * a.t_sk] : t0 + a.dt_final;
+    __syncthreads();
+    wg_ekf_update(a, L, yl, &ll, &bad);
+    wg_store(a, L, a.fm, a.fP, n, k);
+    __syncthreads();
+    if (wg_integrate<R, EPT>(L, own, d, t0, t1, a.dt0, a.max_steps, !zeroth, rhs)) st |= kStatusMaxSteps;
+    if (zeroth) {
+      const R sq = rsqrt_(t1 - t0);
+      const R* Qz = a.par + a.o_LQLz;
+      CDKF_WG_FOR(e, d * d) {
+        const int i = fdiv(e, d), j = e - i * d;
+        L.mat(0)[i * lq + j] = rfma(sq, Qz[e], L.mat(0)[i * lq + j]);
+      }
+      __syncthreads();
+    }
+    wg_store(a, L, a.pm, a.pP, n, k);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    if (bad) st |= kStatusNotPd;
+    if (ll != ll) st |= kStatusNan;
+    a.ll[n] = (R)ll;
+    if (a.status) a.status[n] = st;
+  }
+}
+
+// ---- EKF smoother backward sweep (inference_ekf.py:363-448, 503-531) ---------------------------------------------
+// Per interval the filtered (m_f, P_f) at t_k are constants: G = F(m_f) + psd_solve(P_f, LQL)^T and f(m_f) are formed
+// once; the reverse-time right-hand side is  dm = -[f(m_f) + G (m_s - m_f)],  dP = -[G P_s + (G P_s)^T - LQL].
+template <typename R, int EPT>
+__global__ __launch_bounds__(256, 2) void ekf_smoother_wg_kernel(const WgArgs<R> a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const WgPlan plan = wg_plan(a.kind, a.d, a.h1, a.h2, a.hsel, true);
+  WgLds<R> L(reinterpret_cast<R*>(smem_raw), a.q, a.lq, plan);
+  __shared__ int bad;
+  const long n = blockIdx.x;
+  const int d = a.d, lq = a.lq;
+  if (threadIdx.x == 0) bad = 0;
+  CDKF_WG_FOR(e, (int)((long)plan.nmat * a.q * lq + (long)plan.nvec * lq)) L.base[e] = 0;
+  __syncthreads();
+  wg_mlp_prepare(a, L);
+  Own<R, EPT> own;
+  own.init(d, lq, a.par + a.o_LQL);
+  const R* tp = a.t + n * a.t_sn;
+  const R* fm = a.fm + n * a.m_sn;
+  const R* fP = a.fP + n * a.P_sn;
+  int st = 0;
+  {
+    const long k = a.T - 1;
+    CDKF_WG_FOR(i, d) L.vec(0)[i] = fm[k * a.m_sk + i * a.m_si];
+    CDKF_WG_FOR(e, d * d) {
+      const int i = fdiv(e, d);
+      L.mat(0)[i * lq + (e - i * d)] = fP[k * a.P_sk + e * a.P_si];
+    }
+    __syncthreads();
+    wg_store(a, L, a.sm, a.sP, n, k);
+    __syncthreads();
+  }
+  R* G = L.mat(plan.i_F);
+  R* A = L.mat(plan.i_A);
+  R* Lc = L.mat(3);
+  R* X = L.mat(4);
+  R* inv = L.vec(6);
+  R* mf = L.vec(9);
+  R* fmf = L.vec(10);
+  const R* LQL = a.par + a.o_LQL;
+  auto rhs = [&](const R* ms, const R* Ps, R& kM, R (&kP)[EPT]) {
+    wg_matmul(A, G, Ps, d, d, d, lq);
+    if (threadIdx.x < d) {
+      R s = 0;
+      for (int k = 0; k < d; ++k) s = rfma(G[threadIdx.x * lq + k], ms[k] - mf[k], s);
+      kM = -(fmf[threadIdx.x] + s);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < EPT; ++u)
+      if (u < own.n) kP[u] = -((A[own.off[u]] + A[own.ej[u] * lq + own.ei[u]]) - own.lql[u]);
+  };
+  R t1 = tp[(a.T - 1) * a.t_sk];
+  for (long k = a.T - 2; k >= 0; --k) {
+    const R t0 = tp[k * a.t_sk];
+    CDKF_WG_FOR(i, d) mf[i] = fm[k * a.m_sk + i * a.m_si];
+    CDKF_WG_FOR(e, d * d) {
+      const int i = fdiv(e, d);
+      L.mat(2)[i * lq + (e - i * d)] = fP[k * a.P_sk + e * a.P_si];
+    }
+    __syncthreads();
+    CDKF_WG_FOR(e, d * d) {
+      const int r = fdiv(e, d), c = e - r * d;
+      R s = R(0.5) * (L.mat(2)[r * lq + c] + L.mat(2)[c * lq + r]);
+      if (r == c) s += R(1e-9);
+      Lc[r * lq + c] = s;
+      X[r * lq + c] = LQL[e];
+    }
+    wg_cholesky2(Lc, inv, (R*)nullptr, (R*)nullptr, d, lq, &bad);
+    wg_chol_solve(Lc, inv, X, d, d, lq);  // X = P_f^{-1} LQL
+    wg_drift(a, L, mf, fmf, G, (R*)nullptr);
+    CDKF_WG_FOR(e, d * d) {
+      const int i = fdiv(e, d), j = e - i * d;
+      G[i * lq + j] += X[j * lq + i];
+    }
+    __syncthreads();
+    if (wg_integrate<R, EPT>(L, own, d, R(0), t1 - t0, a.dt0, a.max_steps, true, rhs)) st |= kStatusMaxSteps;
+    wg_store(a, L, a.sm, a.sP, n, k);
+    __syncthreads();
+    t1 = t0;
+  }
+  if (threadIdx.x == 0 && a.status) {
+    if (bad) st |= kStatusNotPd;
+    if (st) atomicOr(&a.status[n], st);
+  }
+}
+
+}  // namespace cdkf

@@ -1,6 +1,6 @@
 // launch_wg.hip -- workgroup-per-trajectory kernels: parameter block upload, LDS sizing, launch.
 #include "cdkf_launch.h"
-#include "cdkf_wg_kernels.h"
+#include "cdkf_wg2_kernels.h"
 
 #include <mutex>
 
@@ -8,12 +8,14 @@ namespace cdkf {
 
 static constexpr size_t kLdsLimit = 160 * 1024;
 
+static int wg_hsel(const cdkf_model* mdl) { return emission_is_selection(mdl) ? 1 : 0; }
+
 template <typename R>
-static size_t wg_lds_bytes(const cdkf_model* mdl) {
+static size_t wg_lds_bytes(const cdkf_model* mdl, bool smoother) {
   const int q = mdl->state_dim > mdl->emission_dim ? mdl->state_dim : mdl->emission_dim;
   const int lq = ((q + 3) & ~3) + 1;
-  return WgLds<R>::bytes(q, lq, wg_extra_reals(mdl->drift_kind, mdl->state_dim, mdl->hidden1, mdl->hidden2) +
-                                    wg_mlp_theta_reals(mdl->drift_kind, mdl->state_dim, mdl->hidden1, mdl->hidden2)) + 64;
+  const WgPlan plan = wg_plan(mdl->drift_kind, mdl->state_dim, mdl->hidden1, mdl->hidden2, wg_hsel(mdl), smoother);
+  return sizeof(R) * (size_t)wg_lds_reals(plan, q, lq) + 64;
 }
 
 static long expected_theta(const cdkf_model* mdl) {
@@ -33,7 +35,7 @@ bool wg_shape_available(const cdkf_model* mdl, int bytes_per_real) {
   if (expected_theta(mdl) < 0 || expected_theta(mdl) != mdl->n_theta) return false;
   if (mdl->drift_kind == CDKF_DRIFT_LORENZ63 && d != 3) return false;
   if (mdl->drift_kind == CDKF_DRIFT_LORENZ96 && d < 4) return false;
-  const size_t lds = bytes_per_real == 8 ? wg_lds_bytes<double>(mdl) : wg_lds_bytes<float>(mdl);
+  const size_t lds = bytes_per_real == 8 ? wg_lds_bytes<double>(mdl, true) : wg_lds_bytes<float>(mdl, true);
   return lds <= kLdsLimit - 256;
 }
 
@@ -134,6 +136,7 @@ static int wg_prepare(WgArgs<R>& a, R** dev_block, ParamSlot** slot_out, const c
   a.m = m;
   a.h1 = mdl->hidden1;
   a.h2 = mdl->hidden2;
+  a.hsel = wg_hsel(mdl);
   a.q = d > m ? d : m;
   a.lq = ((a.q + 3) & ~3) + 1;  // multiple of 4 (1x4 strips stay inside a row) plus 1 (odd: column walks hit 32 different LDS banks)
   a.order = o->state_order;
@@ -194,6 +197,44 @@ static int wg_threads(const cdkf_model* mdl) {
   return (mdl->drift_kind == CDKF_DRIFT_MLP_TANH && t < 256) ? 256 : t;
 }
 
+// entries of the d x d covariance owned by one thread
+static int wg_ept(int d, int threads) {
+  const int need = (d * d + threads - 1) / threads;
+  for (int e : {1, 2, 4, 8, 16})
+    if (need <= e) return e;
+  return -1;
+}
+
+template <typename R, int EPT>
+static int launch_wg_pair(const WgArgs<R>& a, bool filter, bool smoother, int threads, size_t lds_f, size_t lds_s,
+                          hipStream_t stream) {
+  static const int cap_rc = wg_raise_lds_cap(ekf_filter_wg_kernel<R, EPT>) | wg_raise_lds_cap(ekf_smoother_wg_kernel<R, EPT>);
+  if (cap_rc) return CDKF_EHIP;
+  if (filter) {
+    hipLaunchKernelGGL((ekf_filter_wg_kernel<R, EPT>), dim3((unsigned)a.N), dim3(threads), lds_f, stream, a);
+    CDKF_HIP_CHECK(hipGetLastError());
+  }
+  if (smoother) {
+    hipLaunchKernelGGL((ekf_smoother_wg_kernel<R, EPT>), dim3((unsigned)a.N), dim3(threads), lds_s, stream, a);
+    CDKF_HIP_CHECK(hipGetLastError());
+  }
+  return CDKF_OK;
+}
+
+template <typename R>
+static int launch_wg_dispatch(const WgArgs<R>& a, const cdkf_model* mdl, bool smoother, hipStream_t stream) {
+  const int threads = wg_threads(mdl);
+  const size_t lds_f = wg_lds_bytes<R>(mdl, false), lds_s = wg_lds_bytes<R>(mdl, true);
+  switch (wg_ept(a.d, threads)) {
+    case 1: return launch_wg_pair<R, 1>(a, true, smoother, threads, lds_f, lds_s, stream);
+    case 2: return launch_wg_pair<R, 2>(a, true, smoother, threads, lds_f, lds_s, stream);
+    case 4: return launch_wg_pair<R, 4>(a, true, smoother, threads, lds_f, lds_s, stream);
+    case 8: return launch_wg_pair<R, 8>(a, true, smoother, threads, lds_f, lds_s, stream);
+    case 16: return launch_wg_pair<R, 16>(a, true, smoother, threads, lds_f, lds_s, stream);
+    default: set_error("state_dim %d too large for the workgroup kernels", a.d); return CDKF_EUNSUPPORTED;
+  }
+}
+
 template <typename R>
 int launch_ekf_filter_wg(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll,
                          R* fm, R* fP, R* pm, R* pP, int32_t* status, hipStream_t stream) {
@@ -203,12 +244,9 @@ int launch_ekf_filter_wg(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, i
   int rc = wg_prepare(a, &blk, &slot, mdl, o, N, T, stream);
   if (rc) return rc;
   a.t = t; a.y = y; a.ll = ll; a.fm = fm; a.fP = fP; a.pm = pm; a.pP = pP; a.status = status;
-  const size_t lds = wg_lds_bytes<R>(mdl);
-  static const int cap_rc = wg_raise_lds_cap(ekf_filter_wg_kernel<R>);
-  if (cap_rc) return cap_rc;
-  hipLaunchKernelGGL(ekf_filter_wg_kernel<R>, dim3((unsigned)N), dim3(wg_threads(mdl)), lds, stream, a);
-  CDKF_HIP_CHECK(hipGetLastError());
-  return param_pool_release(slot, stream);
+  rc = launch_wg_dispatch<R>(a, mdl, false, stream);
+  const int rc2 = param_pool_release(slot, stream);
+  return rc ? rc : rc2;
 }
 
 template <typename R>
@@ -222,14 +260,9 @@ int launch_ekf_smoother_wg(const cdkf_model* mdl, const cdkf_opts* o, int64_t N,
   int rc = wg_prepare(a, &blk, &slot, mdl, &of, N, T, stream);
   if (rc) return rc;
   a.t = t; a.y = y; a.ll = ll; a.fm = fm; a.fP = fP; a.pm = nullptr; a.pP = nullptr; a.sm = sm; a.sP = sP; a.status = status;
-  const size_t lds = wg_lds_bytes<R>(mdl);
-  static const int cap_rc = wg_raise_lds_cap(ekf_filter_wg_kernel<R>) | wg_raise_lds_cap(ekf_smoother_wg_kernel<R>);
-  if (cap_rc) return CDKF_EHIP;
-  hipLaunchKernelGGL(ekf_filter_wg_kernel<R>, dim3((unsigned)N), dim3(wg_threads(mdl)), lds, stream, a);
-  CDKF_HIP_CHECK(hipGetLastError());
-  hipLaunchKernelGGL(ekf_smoother_wg_kernel<R>, dim3((unsigned)N), dim3(wg_threads(mdl)), lds, stream, a);
-  CDKF_HIP_CHECK(hipGetLastError());
-  return param_pool_release(slot, stream);
+  rc = launch_wg_dispatch<R>(a, mdl, true, stream);
+  const int rc2 = param_pool_release(slot, stream);
+  return rc ? rc : rc2;
 }
 
 #define INST(R)                                                                                                        \
