@@ -145,6 +145,7 @@ def main():
 
     if rank == 0:
         bytes_per_launch = N * T * 8 * ((1 + M) + 2 * (D + D * D))  # 224 B per trajectory-step
+        traffic, traffic_src = pmc_traffic(bytes_per_launch)
         achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
         out = {
             "metric": "trajectories_per_sec", "value": world * N * args.steps / elapsed, "unit": "trajectories/s",
@@ -154,7 +155,8 @@ def main():
                                    "irregular obs per GPU, fp64, 4 output fields, native [T,comp,N] layout, Dopri5 dt0=0.01",
                        "trajectories_per_gpu": N, "num_timesteps": T, "parallelism": f"dp{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "ekf_filter_reg_kernel<double,3,3,Lorenz63>",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": "filter_reg_kernel<double,3,3,DriftLorenz63,UKF=0,ZEROTH=0,HSEL=1,OUT=all>",
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_per_launch},
             "marginal_loglik_sum": total_ll, "status_flags_raised": n_bad,
         }
@@ -167,6 +169,23 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic(algorithmic_bytes):
+    """HBM bytes per launch of the sweep kernel from the committed rocprofv3 PMC passes of THIS command
+    (profiles/*_pmc_summary.json: FETCH_SIZE x2 per MI355X_MICROARCH.md + WRITE_SIZE, separate --pmc runs).
+    Counters cannot be read from inside an un-profiled run, so the number is the latest committed measurement
+    for the same workload; null if there is none."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json"))):
+        try:
+            rec = json.load(open(path))
+        except Exception:
+            continue
+        if rec.get("algorithmic_bytes_per_launch") == algorithmic_bytes:
+            best = (rec["hbm_traffic_bytes_per_launch"], os.path.relpath(path, ROOT))
+    return best if best else (None, None)
 
 
 def saturated(lib, blk, opts, dev, torch, n=65536, reps=5):
