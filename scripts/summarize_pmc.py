@@ -9,11 +9,11 @@ tag = sys.argv[1]
 kernel_sub = sys.argv[2] if len(sys.argv) > 2 else "ekf_filter"
 N, T, bytes_per_step = 4096, 1000, 224
 out = {"round": 1, "tag": tag,
-       "command": "rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline",
-       "workload": "N=4096, T=1000, fp64, 4 outputs, time-major"}
+       "command": "rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-saturation",
+       "workload": "N=4096, T=1000, fp64, 4 outputs, native [T,comp,N] layout"}
 for kind, name in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
     f = glob.glob(f"gpurun_out/prof_{tag}/pmc_{kind}/runc/*_counter_collection.csv")[0]
-    rows = [r for r in csv.DictReader(open(f)) if kernel_sub in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(f)) if kernel_sub in r["Kernel_Name"] and int(r["Grid_Size"]) == N]
     out["kernel"] = rows[0]["Kernel_Name"][:120]
     vals = [float(r["Counter_Value"]) for r in rows][1:]
     out[name + "_KB_per_launch_raw"] = sum(vals) / len(vals)
