@@ -249,3 +249,49 @@ def test_c2_full_size_properties(hip_lib):
     ll32, outs32, st32, _ = _run_dev(hip_lib, "ekf_filter", blk, _ffi.default_opts(), t, y, np.float32, _ffi.LAYOUT_TCN)
     assert (st32 == 0).all()
     assert relerr(outs32[0][sub], ref["filtered_means"]) < 1e-4
+
+
+def test_reference_known_answer_constants_through_the_hip_kernels(hip_lib):
+    """The reference's Dopri5 push-forward constants (src/test_scripts/cdlgssm_test_filter_TRegular.py:59-60) through
+    the fp32 HIP EKF itself: F = -0.1 I, L = Qc = 0.5 I, unit interval, R huge so that the update is a no-op; the
+    predicted mean / covariance after the first interval are A m0 and Q.  FMA contraction on the GPU changes
+    individual roundings, so the bar is 2 ulp (the NumPy and C oracles reproduce the constants bit-exactly)."""
+    mdl = o.Model(o.LinearDrift(-0.1 * np.eye(2), np.zeros(2)), 0.5 * np.eye(2), 0.5 * np.eye(2), np.eye(2),
+                  np.zeros(2), 1e30 * np.eye(2), np.array([1.0, 0.0]), np.zeros((2, 2)))
+    P = params_from(mdl)
+    y = np.zeros((2, 2), np.float32)
+    t = np.array([[0.0], [1.0]], np.float32)
+    A_ref, Q_ref = np.float32(0.9048373699188232421875), np.float32(0.11329327523708343505859375)
+    # (the UKF cannot start from P0 = 0: its sigma points need chol(P0))
+    for hp in (cd.EKFHyperParams(dt_final=1.0, state_order="first"), cd.EKFHyperParams(dt_final=1.0)):
+        post = cd.cdnlgssm_filter(P, y, t, hp)
+        assert post.predicted_means.dtype == np.float32
+        assert abs(float(post.predicted_means[0, 0]) - float(A_ref)) <= 2 * np.spacing(A_ref), type(hp).__name__
+        assert abs(float(post.predicted_covariances[0, 0, 0]) - float(Q_ref)) <= 2 * np.spacing(Q_ref), type(hp).__name__
+    post = cd.cdnlgssm_filter(P, y.astype(np.float64), t.astype(np.float64), cd.EKFHyperParams(dt_final=1.0))
+    assert abs(post.predicted_means[0, 0] - np.exp(-0.1)) < 1e-14
+    assert abs(post.predicted_covariances[0, 0, 0] - 0.125 * (1 - np.exp(-0.2)) / 0.2) < 1e-14
+
+
+def test_linear_model_filters_agree_with_closed_form_kalman_filter(hip_lib):
+    """The reference's own assertion (cdnlgssm_test_filter_linear_TRegular.py:314-324, 414-424: EKF first/second and UKF
+    equal the CD Kalman filter on a linear model, rtol 1e-5), with the HIP kernels on one side and an exact
+    matrix-exponential Kalman filter -- independent of the oracle -- on the other; fp32 run at the reference's
+    precision, fp64 run far below its tolerance."""
+    from helpers import closed_form_kf
+    rng = np.random.default_rng(2026)
+    mdl = linear_model(rng, 2, 6)  # the test script's STATE_DIM, EMISSION_DIM
+    T = 100
+    t = np.arange(T, dtype=float)
+    y = o.simulate(mdl, t[None], rng)[0]
+    ref = closed_form_kf(mdl, t, y, dt_final=1.0)
+    P = params_from(mdl)
+    for hp in (cd.EKFHyperParams(dt_final=1.0, state_order="first"), cd.EKFHyperParams(dt_final=1.0, state_order="second"),
+               cd.UKFHyperParams(dt_final=1.0)):
+        for dtype, tol in ((np.float64, 1e-7), (np.float32, 1e-4)):
+            post = cd.cdnlgssm_filter(P, y.astype(dtype), t[:, None], hp)
+            for k in FILTER_KEYS:
+                assert relerr(getattr(post, k), ref[k]) < tol, (type(hp).__name__, dtype.__name__, k)
+            assert abs(post.marginal_loglik - ref["marginal_loglik"]) < tol * abs(ref["marginal_loglik"]) * 10
+    sm = cd.cdnlgssm_smoother(P, y, t[:, None], cd.EKFHyperParams(dt_final=1.0))
+    np.testing.assert_array_equal(sm.smoothed_means[-1], sm.filtered_means[-1])
