@@ -1,0 +1,469 @@
+// cdkf_wave8_kernels.h -- wavefront-per-trajectory EKF sweep for state_dim <= 8 (the MLP-drift configuration).
+//
+// Mapping: one WAVEFRONT owns one trajectory for the whole time scan; four wavefronts (four
+// trajectories) share a workgroup only to share the drift's weights in LDS.  Lane l = (i, j) = (l >> 3, l & 7) owns
+// covariance entry P_ij and its six Dormand-Prince slopes in registers; lanes 0..7 also own the mean.  The 8 x 8
+// products (F P, H P H^T, the Cholesky updates, X^T S X) exchange operands through a per-wavefront LDS tile with
+// wavefront-scope fences only -- there is no workgroup barrier inside the time loop, so the four trajectories of
+// a workgroup never wait for each other's RK step counts.
+// MLP drift (d -> h1 -> h2 -> d, tanh, h1, h2 <= 64): lane p is hidden unit p; its rows of W2 and of
+// G = ((W1 W3)^T o W2) stay in registers, the row-major copies in LDS serve the column-wise uses; the Jacobian is the
+// forward-mode tangent  W3 D2 (W2 (D1 W1)).
+//
+// Reference functions restated: extended_kalman_filter and helpers, inference_ekf.py:46-148, 153-199, 202-326.
+#pragma once
+#include "cdkf_wg2_kernels.h"
+
+namespace cdkf {
+
+constexpr int kW8 = 8;        // lane grid is 8 x 8
+constexpr int kHid = 64;      // hidden units padded to the wavefront width
+constexpr int kW8Waves = 4;   // trajectories per workgroup
+
+CDKF_DEV void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// per-wavefront LDS tile (in reals)
+struct W8Off {
+  static constexpr int P = 0, A = 64, F = 128, X = 192, SX = 256, S1 = 320, S2 = 384, HP = 448;
+  static constexpr int x = 512, f = 520, g = 528, v = 536, z = 544, y = 552, tmp = 560;
+  static constexpr int base_end = 568;
+  // MLP only
+  static constexpr int a1 = 568, d1 = 632, a2 = 696, d2 = 760, s2 = 824, tq = 888, U = 952, V = 952 + 512;
+  static constexpr int mlp_end = 952 + 1024;
+};
+// shared (per workgroup) MLP weights, all padded to kHid: W1[64][8] b1[64] W2[64][64] b2[64] W3[8][65] b3[8] Gm[64][64]
+struct W8Sh {
+  static constexpr int W1 = 0, b1 = 512, W2 = 576, b2 = 576 + 4096, W3 = 4736, b3 = 4736 + 8 * 65, Gm = 5264;
+  static constexpr int end = 5264 + 4096;
+};
+__host__ __device__ inline long wave8_lds_reals(int kind) {
+  return (kind == kDriftMlp) ? (long)W8Sh::end + kW8Waves * W8Off::mlp_end : (long)kW8Waves * W8Off::base_end;
+}
+
+template <typename R>
+__global__ __launch_bounds__(256, 1) void ekf_filter_wave8_kernel(const WgArgs<R> a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  R* smem = reinterpret_cast<R*>(smem_raw);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i = lane >> 3, j = lane & 7;
+  const int d = a.d, m = a.m;
+  const bool mlp = a.kind == kDriftMlp;
+  const int h1 = a.h1, h2 = a.h2;
+  R* Sh = smem;
+  R* W = smem + (mlp ? W8Sh::end : 0) + wave * (mlp ? W8Off::mlp_end : W8Off::base_end);
+  const R* th = a.par + a.o_theta;
+
+  // ---- shared MLP weights (zero-padded), built by the whole workgroup --------------------------------------------
+  if (mlp) {
+    for (int e = threadIdx.x; e < W8Sh::end; e += blockDim.x) Sh[e] = 0;
+    __syncthreads();
+    const R* gW1 = th;
+    const R* gb1 = gW1 + h1 * d;
+    const R* gW2 = gb1 + h1;
+    const R* gb2 = gW2 + h2 * h1;
+    const R* gW3 = gb2 + h2;
+    const R* gb3 = gW3 + d * h2;
+    for (int e = threadIdx.x; e < h1 * d; e += blockDim.x) Sh[W8Sh::W1 + fdiv(e, d) * kW8 + (e - fdiv(e, d) * d)] = gW1[e];
+    for (int e = threadIdx.x; e < h1; e += blockDim.x) Sh[W8Sh::b1 + e] = gb1[e];
+    for (int e = threadIdx.x; e < h2 * h1; e += blockDim.x) Sh[W8Sh::W2 + fdiv(e, h1) * kHid + (e - fdiv(e, h1) * h1)] = gW2[e];
+    for (int e = threadIdx.x; e < h2; e += blockDim.x) Sh[W8Sh::b2 + e] = gb2[e];
+    for (int e = threadIdx.x; e < d * h2; e += blockDim.x) Sh[W8Sh::W3 + fdiv(e, h2) * 65 + (e - fdiv(e, h2) * h2)] = gW3[e];
+    for (int e = threadIdx.x; e < d; e += blockDim.x) Sh[W8Sh::b3 + e] = gb3[e];
+    __syncthreads();
+    // Gm[p][q] = (sum_i W3[i][p] W1[q][i]) * W2[p][q]
+    for (int e = threadIdx.x; e < kHid * kHid; e += blockDim.x) {
+      const int p = e >> 6, q = e & 63;
+      R s = 0;
+      for (int ii = 0; ii < d; ++ii) s = rfma(Sh[W8Sh::W3 + ii * 65 + p], Sh[W8Sh::W1 + q * kW8 + ii], s);
+      Sh[W8Sh::Gm + e] = s * Sh[W8Sh::W2 + e];
+    }
+    __syncthreads();
+  }
+  const long n = (long)blockIdx.x * kW8Waves + wave;
+  if (n >= a.N) return;  // whole wavefront; no workgroup barrier follows
+
+  // ---- per-lane constants ---------------------------------------------------------------------------------------
+  const bool inP = (i < d) && (j < d);
+  const R lql = inP ? (a.par + a.o_LQL)[i * d + j] : R(0);
+  const R lqlz = inP ? (a.par + a.o_LQLz)[i * d + j] : R(0);
+  const bool hsel = a.hsel != 0;
+  const R Hij = (i < m && j < d) ? (a.par + a.o_H)[i * d + j] : R(0);       // lane (r=i, k=j) holds H[r][k]
+  const R Rij = (i < m && j < m) ? (a.par + a.o_R)[i * m + j] : R(0);       // lane (r, c) holds R[r][c]
+  const R hbj = (lane < m) ? (a.par + a.o_hb)[lane] : R(0);
+  const R Wlin = (a.kind == kDriftLinear && inP) ? th[i * d + j] : R(0);    // linear drift: lane (i,k) holds W[i][k]
+  const R blin = (a.kind == kDriftLinear && lane < d) ? th[d * d + lane] : R(0);
+  R w1row[kW8], w2row[kHid], gmrow[kHid];
+  R b1l = 0, b2l = 0;
+  const bool second = (a.order == 2) && mlp;
+  if (mlp) {
+#pragma unroll
+    for (int jj = 0; jj < kW8; ++jj) w1row[jj] = pin(Sh[W8Sh::W1 + lane * kW8 + jj]);
+    // pin(): the rows must stay in VGPRs -- re-reading them from LDS inside the loops would be a 64-way bank
+    // conflict (lane p reads row p: stride 64 elements)
+#pragma unroll
+    for (int q = 0; q < kHid; ++q) w2row[q] = pin(Sh[W8Sh::W2 + lane * kHid + q]);
+    if (second) {
+#pragma unroll
+      for (int q = 0; q < kHid; ++q) gmrow[q] = pin(Sh[W8Sh::Gm + lane * kHid + q]);
+    }
+    b1l = Sh[W8Sh::b1 + lane];
+    b2l = Sh[W8Sh::b2 + lane];
+  }
+
+  // ---- state ---------------------------------------------------------------------------------------------------------
+  R Pij = inP ? R(0.5) * ((a.par + a.o_P0)[i * d + j] + (a.par + a.o_P0)[j * d + i]) : R(0);
+  R mj = (lane < d) ? (a.par + a.o_m0)[lane] : R(0);  // lanes 0..d-1 own the mean
+  double ll = 0.0;
+  int st = 0;
+  bool bad = false;
+  const bool zeroth = a.order == 0;
+
+  // right-hand side of the moment ODEs for the stage value (xs: mean on lanes < d, Ps: this lane's covariance entry)
+  auto rhs = [&](R xs, R Ps, R& kM, R& kP) {
+    W[W8Off::P + lane] = Ps;
+    if (lane < kW8) W[W8Off::x + lane] = xs;
+    wave_sync();
+    R xk[kW8];
+#pragma unroll
+    for (int k = 0; k < kW8; ++k) xk[k] = W[W8Off::x + k];
+    R Fij = 0;  // lane (i, k=j) computes F[i][k]
+    R fi = 0;   // lanes < d: f_lane
+    if (a.kind == kDriftLinear) {
+      Fij = Wlin;
+      // f_i = sum_k W[i][k] x_k + b_i : every lane forms its product, row sums through the tile
+      W[W8Off::A + lane] = Wlin * xk[j];
+      wave_sync();
+      if (lane < kW8) {
+        R s = blin;
+#pragma unroll
+        for (int k = 0; k < kW8; ++k) s += W[W8Off::A + lane * kW8 + k];
+        fi = s;
+      }
+      wave_sync();
+    } else if (a.kind == kDriftLorenz63) {
+      const R sg = th[0], rho = th[1], bt = th[2];
+      if (i == 0) Fij = (j == 0) ? -sg : (j == 1 ? sg : R(0));
+      if (i == 1) Fij = (j == 0) ? rho - xk[2] : (j == 1 ? R(-1) : (j == 2 ? -xk[0] : R(0)));
+      if (i == 2) Fij = (j == 0) ? xk[1] : (j == 1 ? xk[0] : (j == 2 ? -bt : R(0)));
+      if (!inP) Fij = 0;
+      if (lane == 0) fi = sg * (xk[1] - xk[0]);
+      if (lane == 1) fi = xk[0] * (rho - xk[2]) - xk[1];
+      if (lane == 2) fi = xk[0] * xk[1] - bt * xk[2];
+    } else if (a.kind == kDriftLorenz96) {
+      auto X = [&](int q) { return W[W8Off::x + q]; };
+      const int ip1 = (i + 1 >= d) ? 0 : i + 1, im1 = (i == 0) ? d - 1 : i - 1, im2 = (im1 == 0) ? d - 1 : im1 - 1;
+      if (inP) {
+        if (j == ip1) Fij = X(im1);
+        if (j == im2) Fij = -X(im1);
+        if (j == im1) Fij = X(ip1) - X(im2);
+        if (j == i) Fij = R(-1);
+      }
+      if (lane < d) {
+        const int l = lane;
+        const int lp1 = (l + 1 >= d) ? 0 : l + 1, lm1 = (l == 0) ? d - 1 : l - 1, lm2 = (lm1 == 0) ? d - 1 : lm1 - 1;
+        fi = rfma(X(lp1) - X(lm2), X(lm1), th[0] - X(l));
+      }
+    } else {  // MLP
+      // layer 1: lane = hidden unit q
+      R z1 = b1l;
+#pragma unroll
+      for (int k = 0; k < kW8; ++k) z1 = rfma(w1row[k], xk[k], z1);
+      const R a1 = rtanh(z1);
+      const R d1 = R(1) - a1 * a1;
+      W[W8Off::a1 + lane] = a1;
+      W[W8Off::d1 + lane] = d1;
+      if (!zeroth) {
+#pragma unroll
+        for (int k = 0; k < kW8; ++k) W[W8Off::U + lane * kW8 + k] = d1 * w1row[k];
+      }
+      wave_sync();
+      // layer 2: lane = hidden unit p; z2 and the tangent T[p][:] = sum_q W2[p][q] U[q][:]
+      R z2 = b2l;
+      R T[kW8];
+#pragma unroll
+      for (int k = 0; k < kW8; ++k) T[k] = 0;
+      if (!zeroth) {
+#pragma unroll
+        for (int q = 0; q < kHid; ++q) {
+          const R w = w2row[q];
+          z2 = rfma(w, W[W8Off::a1 + q], z2);
+#pragma unroll
+          for (int k = 0; k < kW8; ++k) T[k] = rfma(w, W[W8Off::U + q * kW8 + k], T[k]);
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < kHid; ++q) z2 = rfma(w2row[q], W[W8Off::a1 + q], z2);
+      }
+      const R a2 = rtanh(z2);
+      const R d2 = R(1) - a2 * a2;
+      W[W8Off::a2 + lane] = a2;
+      W[W8Off::d2 + lane] = d2;
+      if (!zeroth) {
+#pragma unroll
+        for (int k = 0; k < kW8; ++k) W[W8Off::V + lane * kW8 + k] = d2 * T[k];
+      }
+      wave_sync();
+      // layer 3: lane (i, j): F[i][j] = sum_p W3[i][p] V[p][j]; row sums of W3 a2 give f_i (kept by lanes with j == 0)
+      R fs = 0;
+      if (!zeroth) {
+#pragma unroll 8
+        for (int p = 0; p < kHid; ++p) {
+          const R w3 = Sh[W8Sh::W3 + i * 65 + p];
+          Fij = rfma(w3, W[W8Off::V + p * kW8 + j], Fij);
+          fs = rfma(w3, W[W8Off::a2 + p], fs);
+        }
+      } else {
+#pragma unroll 8
+        for (int p = 0; p < kHid; ++p) fs = rfma(Sh[W8Sh::W3 + i * 65 + p], W[W8Off::a2 + p], fs);
+      }
+      if (!inP) Fij = 0;
+      // f_i sits on lanes (i, *); move it to lane i
+      if (j == 0) W[W8Off::f + i] = fs + Sh[W8Sh::b3 + i];
+      R gl = 0;
+      if (second) {
+        // g = grad(div f):  s2_p = dd2_p sum_q G[p][q] d1_q ;  tq_q = dd1_q sum_p d2_p G[p][q] + d1_q sum_p s2_p W2[p][q]
+        R s = 0;
+#pragma unroll
+        for (int q = 0; q < kHid; ++q) s = rfma(gmrow[q], W[W8Off::d1 + q], s);
+        W[W8Off::s2 + lane] = R(-2) * a2 * d2 * s;
+        wave_sync();
+        R td = 0, tc = 0;
+#pragma unroll 8
+        for (int p = 0; p < kHid; ++p) {
+          td = rfma(W[W8Off::d2 + p], Sh[W8Sh::Gm + p * kHid + lane], td);
+          tc = rfma(W[W8Off::s2 + p], Sh[W8Sh::W2 + p * kHid + lane], tc);
+        }
+        W[W8Off::tq + lane] = td * (R(-2) * a1 * d1) + tc * d1;
+        wave_sync();
+        if (lane < kW8) {
+#pragma unroll 8
+          for (int q = 0; q < kHid; ++q) gl = rfma(W[W8Off::tq + q], Sh[W8Sh::W1 + q * kW8 + lane], gl);
+        }
+      }
+      wave_sync();
+      if (lane < kW8) {
+        fi = W[W8Off::f + lane];
+        if (second) W[W8Off::g + lane] = gl;
+      }
+      wave_sync();
+    }
+    if (lane < kW8) kM = (lane < d) ? fi : R(0);
+    if (zeroth) return;
+    // A = F Ps ; kP = A_ij + A_ji + LQL_ij
+    W[W8Off::F + lane] = Fij;
+    wave_sync();
+    R acc = 0;
+#pragma unroll
+    for (int k = 0; k < kW8; ++k) acc = rfma(W[W8Off::F + i * kW8 + k], W[W8Off::P + k * kW8 + j], acc);
+    W[W8Off::A + lane] = acc;
+    wave_sync();
+    kP = (acc + W[W8Off::A + j * kW8 + i]) + lql;
+    if (second && lane < kW8) {
+      R s = 0;
+#pragma unroll
+      for (int k = 0; k < kW8; ++k) s = rfma(W[W8Off::g + k], W[W8Off::P + k * kW8 + lane], s);
+      kM = rfma(R(0.5), s, kM);
+    }
+    wave_sync();
+  };
+
+  const R* tp = a.t + n * a.t_sn;
+  const R* yp = a.y + n * a.y_sn;
+  using C = Dp5<R>;
+  for (long k = 0; k < a.T; ++k) {
+    // ---------------- update (inference_ekf.py:153-199, 285-286) ----------------
+    const R yl = (lane < m) ? yp[k * a.y_sk + lane * a.y_si] : R(0);
+    for (int it = 0; it < a.num_iter; ++it) {
+      W[W8Off::P + lane] = Pij;
+      if (lane < kW8) W[W8Off::x + lane] = mj;
+      wave_sync();
+      // HP[r][c] (lane (r=i, c=j)) = sum_k H[r][k] P[k][c];  H row r lives on lanes (r, *)
+      R hp;
+      if (hsel) {
+        hp = (i < m) ? Pij : R(0);
+      } else {
+        W[W8Off::F + lane] = Hij;  // borrow the F tile for H
+        wave_sync();
+        hp = 0;
+#pragma unroll
+        for (int kk = 0; kk < kW8; ++kk) hp = rfma(W[W8Off::F + i * kW8 + kk], W[W8Off::P + kk * kW8 + j], hp);
+      }
+      W[W8Off::HP + lane] = hp;
+      wave_sync();
+      // S[r][c] = sum_k HP[r][k] H[c][k] + R[r][c]
+      R s;
+      if (hsel) {
+        s = (i < m && j < m) ? Pij + Rij : R(0);
+      } else {
+        s = 0;
+#pragma unroll
+        for (int kk = 0; kk < kW8; ++kk) s = rfma(W[W8Off::HP + i * kW8 + kk], W[W8Off::F + j * kW8 + kk], s);
+        s = (i < m && j < m) ? s + Rij : R(0);
+      }
+      // innovation on lanes < m
+      R vv = 0;
+      if (lane < kW8) {
+        if (hsel) {
+          vv = (lane < m) ? yl - mj : R(0);
+        } else {
+          R hm = 0;
+#pragma unroll
+          for (int kk = 0; kk < kW8; ++kk) hm = rfma(W[W8Off::F + lane * kW8 + kk], W[W8Off::x + kk], hm);
+          vv = (lane < m) ? yl - (hm + hbj) : R(0);
+        }
+        W[W8Off::v + lane] = vv;
+      }
+      // two factorisations side by side: S1 = S (TFP), S2 = symmetrize(S) + 1e-9 I (psd_solve); pad with identity
+      W[W8Off::S1 + lane] = s;
+      wave_sync();
+      R s1 = (i < m && j < m) ? s : (i == j ? R(1) : R(0));
+      R s2v = (i < m && j < m) ? R(0.5) * (s + W[W8Off::S1 + j * kW8 + i]) + (i == j ? R(1e-9) : R(0)) : (i == j ? R(1) : R(0));
+      wave_sync();
+      R inv1[kW8], inv2[kW8];
+#pragma unroll
+      for (int p = 0; p < kW8; ++p) {
+        W[W8Off::S1 + lane] = s1;
+        W[W8Off::S2 + lane] = s2v;
+        wave_sync();
+        const R p1 = W[W8Off::S1 + p * kW8 + p], p2 = W[W8Off::S2 + p * kW8 + p];
+        if (p < m && (!(p1 > R(0)) || !(p2 > R(0)))) bad = true;
+        const R r1 = rrsqrt(p1), r2 = rrsqrt(p2);
+        inv1[p] = r1;
+        inv2[p] = r2;
+        // column p below the pivot, scaled; then the trailing update of the lower triangle
+        const R l1i = W[W8Off::S1 + i * kW8 + p] * r1, l1j = W[W8Off::S1 + j * kW8 + p] * r1;
+        const R l2i = W[W8Off::S2 + i * kW8 + p] * r2, l2j = W[W8Off::S2 + j * kW8 + p] * r2;
+        wave_sync();
+        if (j == p && i >= p) {
+          s1 = (i == p) ? p1 * r1 : l1i;
+          s2v = (i == p) ? p2 * r2 : l2i;
+        } else if (i > p && j > p && j <= i) {
+          s1 = rfma(-l1i, l1j, s1);
+          s2v = rfma(-l2i, l2j, s2v);
+        }
+      }
+      // now s1 / s2v hold L1 / L2 (lower triangles)
+      W[W8Off::S1 + lane] = s1;
+      W[W8Off::S2 + lane] = s2v;
+      wave_sync();
+      if (it == 0) {
+        // z = L1^-1 v (forward substitution on every lane redundantly), log-likelihood term
+        R z[kW8];
+        double qd = 0.0, pinv = 1.0;
+#pragma unroll
+        for (int r = 0; r < kW8; ++r) {
+          R w = W[W8Off::v + r];
+#pragma unroll
+          for (int c = 0; c < r; ++c) w = rfma(-W[W8Off::S1 + r * kW8 + c], z[c], w);
+          z[r] = w * inv1[r];
+          if (r < m) {
+            qd += (double)z[r] * (double)z[r];
+            pinv *= (double)inv1[r];
+          }
+        }
+        ll += -0.5 * qd + log(pinv) - 0.5 * m * 1.8378770664093454835606594728112;
+      }
+      // X = Sb^-1 HP : column c = j solved by the 8 lanes (*, j); every lane walks its own column redundantly
+      R xcol[kW8];
+#pragma unroll
+      for (int r = 0; r < kW8; ++r) {
+        R w = W[W8Off::HP + r * kW8 + j];
+#pragma unroll
+        for (int c = 0; c < r; ++c) w = rfma(-W[W8Off::S2 + r * kW8 + c], xcol[c], w);
+        xcol[r] = w * inv2[r];
+      }
+#pragma unroll
+      for (int r = kW8 - 1; r >= 0; --r) {
+        R w = xcol[r];
+#pragma unroll
+        for (int c = r + 1; c < kW8; ++c) w = rfma(-W[W8Off::S2 + c * kW8 + r], xcol[c], w);
+        xcol[r] = w * inv2[r];
+      }
+      R xij = 0;  // X[r=i][c=j] (select instead of a run-time register index)
+#pragma unroll
+      for (int r = 0; r < kW8; ++r)
+        if (r == i && r < m) xij = xcol[r];
+      W[W8Off::X + lane] = xij;
+      wave_sync();
+      // SX[r][c] = sum_q S[r][q] X[q][c]   (S re-read from the original tile: recompute from s saved in HP slot order)
+      // the original S was overwritten by its factor; keep a copy in SX's slot first
+      W[W8Off::SX + lane] = s;
+      wave_sync();
+      R sx = 0;
+#pragma unroll
+      for (int q = 0; q < kW8; ++q) sx = rfma(W[W8Off::SX + i * kW8 + q], xcol[q] * ((q < m) ? R(1) : R(0)), sx);
+      wave_sync();
+      W[W8Off::SX + lane] = (i < m) ? sx : R(0);
+      wave_sync();
+      // T[a][b] = sum_r X[r][a] SX[r][b];  P <- P - T;  m <- m + X^T v
+      R tt = 0;
+#pragma unroll
+      for (int r = 0; r < kW8; ++r) tt = rfma(W[W8Off::X + r * kW8 + i], W[W8Off::SX + r * kW8 + j], tt);
+      if (inP) Pij -= tt;
+      if (lane < kW8) {
+        R dm = 0;
+#pragma unroll
+        for (int r = 0; r < kW8; ++r) dm = rfma(W[W8Off::X + r * kW8 + lane], W[W8Off::v + r], dm);
+        if (lane < d) mj += dm;
+      }
+      wave_sync();
+    }
+    // symmetrize
+    W[W8Off::P + lane] = Pij;
+    wave_sync();
+    Pij = R(0.5) * (Pij + W[W8Off::P + j * kW8 + i]);
+    wave_sync();
+    if (mj != mj) st |= kStatusNan;
+    // ---------------- store filtered ----------------
+    if (a.fm && lane < d) a.fm[n * a.m_sn + k * a.m_sk + lane * a.m_si] = mj;
+    if (a.fP && inP) a.fP[n * a.P_sn + k * a.P_sk + (i * d + j) * a.P_si] = Pij;
+    // ---------------- predict ----------------
+    const R t0 = tp[k * a.t_sk];
+    const R t1 = (k + 1 < a.T) ? tp[(k + 1) * a.t_sk] : t0 + a.dt_final;
+    {
+      R tprev = t0;
+      R tnext = rmin(t0 + a.dt0, t1);
+      long steps = 0;
+      while (tprev < t1) {  // uniform over the wavefront
+        if (steps >= a.max_steps) {
+          st |= kStatusMaxSteps;
+          break;
+        }
+        const R dt = tnext - tprev;
+        R kM1 = 0, kM2 = 0, kM3 = 0, kM4 = 0, kM5 = 0, kM6 = 0, kP1 = 0, kP2 = 0, kP3 = 0, kP4 = 0, kP5 = 0, kP6 = 0;
+        rhs(mj, Pij, kM1, kP1);
+        rhs(rfma(dt, C::a21 * kM1, mj), rfma(dt, C::a21 * kP1, Pij), kM2, kP2);
+        rhs(rfma(dt, rfma(C::a32, kM2, C::a31 * kM1), mj), rfma(dt, rfma(C::a32, kP2, C::a31 * kP1), Pij), kM3, kP3);
+        rhs(rfma(dt, rfma(C::a43, kM3, rfma(C::a42, kM2, C::a41 * kM1)), mj),
+            rfma(dt, rfma(C::a43, kP3, rfma(C::a42, kP2, C::a41 * kP1)), Pij), kM4, kP4);
+        rhs(rfma(dt, rfma(C::a54, kM4, rfma(C::a53, kM3, rfma(C::a52, kM2, C::a51 * kM1))), mj),
+            rfma(dt, rfma(C::a54, kP4, rfma(C::a53, kP3, rfma(C::a52, kP2, C::a51 * kP1))), Pij), kM5, kP5);
+        rhs(rfma(dt, rfma(C::a65, kM5, rfma(C::a64, kM4, rfma(C::a63, kM3, rfma(C::a62, kM2, C::a61 * kM1)))), mj),
+            rfma(dt, rfma(C::a65, kP5, rfma(C::a64, kP4, rfma(C::a63, kP3, rfma(C::a62, kP2, C::a61 * kP1)))), Pij), kM6,
+            kP6);
+        mj = rfma(dt, rfma(C::b6, kM6, rfma(C::b5, kM5, rfma(C::b4, kM4, rfma(C::b3, kM3, C::b1 * kM1)))), mj);
+        if (!zeroth)
+          Pij = rfma(dt, rfma(C::b6, kP6, rfma(C::b5, kP5, rfma(C::b4, kP4, rfma(C::b3, kP3, C::b1 * kP1)))), Pij);
+        tprev = rmin(tnext, t1);
+        const R tn = tnext + a.dt0;
+        tnext = (tn > t1 - Tol<R>::v) ? t1 : tn;
+        ++steps;
+      }
+    }
+    if (zeroth) Pij = rfma(rsqrt_(t1 - t0), lqlz, Pij);
+    if (a.pm && lane < d) a.pm[n * a.m_sn + k * a.m_sk + lane * a.m_si] = mj;
+    if (a.pP && inP) a.pP[n * a.P_sn + k * a.P_sk + (i * d + j) * a.P_si] = Pij;
+  }
+  if (lane == 0) {
+    if (bad) st |= kStatusNotPd;
+    if (ll != ll) st |= kStatusNan;
+    a.ll[n] = (R)ll;
+    if (a.status) a.status[n] = st;
+  }
+}
+
+}  // namespace cdkf

@@ -1,6 +1,7 @@
 // launch_wg.hip -- workgroup-per-trajectory kernels: parameter block upload, LDS sizing, launch.
 #include "cdkf_launch.h"
 #include "cdkf_wg2_kernels.h"
+#include "cdkf_wave8_kernels.h"
 
 #include <mutex>
 
@@ -235,6 +236,25 @@ static int launch_wg_dispatch(const WgArgs<R>& a, const cdkf_model* mdl, bool sm
   }
 }
 
+// wavefront-per-trajectory kernel: state and emission dimensions up to 8, MLP hidden layers up to 64
+static bool wave8_shape(const cdkf_model* mdl) {
+  if (getenv("CDKF_NO_WAVE8")) return false;  // debugging aid: force the workgroup kernels
+  if (mdl->state_dim > 8 || mdl->emission_dim > 8) return false;
+  if (mdl->drift_kind == CDKF_DRIFT_MLP_TANH && (mdl->hidden1 > 64 || mdl->hidden2 > 64)) return false;
+  return true;
+}
+
+template <typename R>
+static int launch_wave8(const WgArgs<R>& a, hipStream_t stream) {
+  static const int cap_rc = wg_raise_lds_cap(ekf_filter_wave8_kernel<R>);
+  if (cap_rc) return CDKF_EHIP;
+  const size_t lds = sizeof(R) * (size_t)wave8_lds_reals(a.kind) + 64;
+  const unsigned blocks = (unsigned)((a.N + kW8Waves - 1) / kW8Waves);
+  hipLaunchKernelGGL(ekf_filter_wave8_kernel<R>, dim3(blocks), dim3(64 * kW8Waves), lds, stream, a);
+  CDKF_HIP_CHECK(hipGetLastError());
+  return CDKF_OK;
+}
+
 template <typename R>
 int launch_ekf_filter_wg(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll,
                          R* fm, R* fP, R* pm, R* pP, int32_t* status, hipStream_t stream) {
@@ -244,7 +264,7 @@ int launch_ekf_filter_wg(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, i
   int rc = wg_prepare(a, &blk, &slot, mdl, o, N, T, stream);
   if (rc) return rc;
   a.t = t; a.y = y; a.ll = ll; a.fm = fm; a.fP = fP; a.pm = pm; a.pP = pP; a.status = status;
-  rc = launch_wg_dispatch<R>(a, mdl, false, stream);
+  rc = wave8_shape(mdl) ? launch_wave8<R>(a, stream) : launch_wg_dispatch<R>(a, mdl, false, stream);
   const int rc2 = param_pool_release(slot, stream);
   return rc ? rc : rc2;
 }
