@@ -4,6 +4,8 @@ Same public names as /root/reference/src/continuous_discrete_nonlinear_gaussian_
 filtering / smoothing hot path; the arithmetic lives in hand-written HIP kernels behind the C ABI of
 ``include/cdkf.h``.
 """
+from .linear import (ContDiscreteLinearGaussianSSM, KFHyperParams, ParamsCDLGSSM, ParamsCDLGSSMDynamics,
+                     ParamsLGSSMEmissions, cdlgssm_filter, cdlgssm_smoother)
 from .models import ContDiscreteNonlinearGaussianSSM, cdnlgssm_filter, cdnlgssm_smoother
 from .params import (EKFHyperParams, EnKFHyperParams, LearnableLinear, LearnableLorenz63, LearnableLorenz96,
                      LearnableMatrix, LearnableMLP, LearnableVector, ParameterProperties, ParamsCDNLGSSM,
@@ -15,4 +17,6 @@ __all__ = [
     "EnKFHyperParams", "LearnableVector", "LearnableMatrix", "LearnableLinear", "LearnableLorenz63",
     "LearnableLorenz96", "LearnableMLP", "ParameterProperties", "ParamsLGSSMInitial", "ParamsCDNLGSSMDynamics",
     "ParamsCDNLGSSMEmissions", "ParamsCDNLGSSM", "PosteriorGSSMFiltered", "PosteriorGSSMSmoothed",
+    "ContDiscreteLinearGaussianSSM", "KFHyperParams", "ParamsCDLGSSM", "ParamsCDLGSSMDynamics", "ParamsLGSSMEmissions",
+    "cdlgssm_filter", "cdlgssm_smoother",
 ]

@@ -295,3 +295,39 @@ def test_linear_model_filters_agree_with_closed_form_kalman_filter(hip_lib):
             assert abs(post.marginal_loglik - ref["marginal_loglik"]) < tol * abs(ref["marginal_loglik"]) * 10
     sm = cd.cdnlgssm_smoother(P, y, t[:, None], cd.EKFHyperParams(dt_final=1.0))
     np.testing.assert_array_equal(sm.smoothed_means[-1], sm.filtered_means[-1])
+
+
+def test_baseline_config1_linear_tracking_front_end(hip_lib):
+    """BASELINE.json config 1: CD linear-Gaussian tracking model (d_x=4, d_y=2), 1 trajectory, 500 regular steps, through
+    the reference's linear-model surface (ContDiscreteLinearGaussianSSM.filter / .smoother), against the exact
+    matrix-exponential Kalman filter and the oracle's smoother."""
+    from helpers import closed_form_kf
+    F = np.zeros((4, 4))
+    F[0, 2] = F[1, 3] = 1.0
+    H = np.eye(4)[:2]
+    mdl = o.Model(o.LinearDrift(F, np.zeros(4)), np.eye(4), 0.1 * np.eye(4), H, np.zeros(2), 0.5 * np.eye(2),
+                  np.array([8.0, 10.0, 1.0, 0.0]), np.eye(4))
+    T = 500
+    t = np.arange(T, dtype=float)
+    rng = np.random.default_rng(1)
+    y = o.simulate(mdl, t[None], rng)[0]
+    model = cd.ContDiscreteLinearGaussianSSM(state_dim=4, emission_dim=2)
+    pp = cd.ParameterProperties()
+    params, _ = model.initialize(
+        initial_mean={"params": mdl.m0, "props": pp}, initial_cov={"params": mdl.P0, "props": pp},
+        dynamics_weights={"params": F, "props": pp}, dynamics_diffusion_coefficient={"params": mdl.L, "props": pp},
+        dynamics_diffusion_cov={"params": mdl.Qc, "props": pp}, emission_weights={"params": H, "props": pp},
+        emission_cov={"params": mdl.R, "props": pp})
+    ref = closed_form_kf(mdl, t, y, dt_final=1.0)
+    post = model.filter(params, y, filter_hyperparams=cd.KFHyperParams(dt_final=1.0))  # t_emissions=None: regular grid
+    for k in FILTER_KEYS:
+        assert relerr(getattr(post, k), ref[k]) < 1e-7, k
+    assert abs(post.marginal_loglik - ref["marginal_loglik"]) < 1e-7 * abs(ref["marginal_loglik"])
+    ll = model.marginal_log_prob(params, y, t[:, None], cd.KFHyperParams(dt_final=1.0))
+    assert abs(ll - post.marginal_loglik) < 1e-10 * abs(ll)
+    sm = model.smoother(params, y, t[:, None], smoother_type="cd_smoother_2")
+    oref = o.ekf_smoother(mdl, t[None], y[None], state_order="first")
+    assert relerr(sm.smoothed_means, oref["smoothed_means"][0]) < 1e-9
+    assert relerr(sm.smoothed_covariances, oref["smoothed_covariances"][0]) < 1e-9
+    post32 = model.filter(params, y.astype(np.float32), filter_hyperparams=cd.KFHyperParams(dt_final=1.0))
+    assert relerr(post32.filtered_means, ref["filtered_means"]) < 1e-4

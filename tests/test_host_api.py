@@ -213,3 +213,38 @@ def test_run_host_transposes_to_time_major(monkeypatch):
     assert seen == {"layout": _ffi.LAYOUT_TCN, "N": 5, "T": 7}
     assert outs[0].shape == (5, 7, 3) and outs[1].shape == (5, 7, 3, 3) and outs[2] is None
     assert outs[0].base is not None and outs[0].base.shape == (7, 3, 5)  # a view of the native [T,d,N] buffer
+
+
+def test_linear_model_front_end(oracle_backend):
+    """BASELINE config 1 surface: ContDiscreteLinearGaussianSSM.filter / smoother / marginal_log_prob map onto the EKF
+    with a LearnableLinear drift (state_order='first'); unsupported reference features are refused, not approximated."""
+    from helpers import closed_form_kf
+    model = cd.ContDiscreteLinearGaussianSSM(state_dim=4, emission_dim=2)
+    F = np.zeros((4, 4))
+    F[0, 2] = F[1, 3] = 1.0
+    params, props = model.initialize(
+        initial_mean={"params": np.array([8.0, 10.0, 1.0, 0.0]), "props": cd.ParameterProperties()},
+        dynamics_weights={"params": F, "props": cd.ParameterProperties()},
+        dynamics_diffusion_coefficient={"params": np.eye(4), "props": cd.ParameterProperties()},
+        emission_weights={"params": np.eye(4)[:2], "props": cd.ParameterProperties()},
+        emission_cov={"params": 0.5 * np.eye(2), "props": cd.ParameterProperties()})
+    assert isinstance(params, cd.ParamsCDLGSSM) and params.dynamics.bias is None
+    rng = np.random.default_rng(0)
+    T = 30
+    y = rng.standard_normal((T, 2))
+    post = model.filter(params, y, filter_hyperparams=cd.KFHyperParams(dt_final=1.0))
+    assert oracle_backend[-1][0] == "ekf_filter" and oracle_backend[-1][1:3] == (1, 1.0)
+    mdl = o.Model(o.LinearDrift(F, np.zeros(4)), np.eye(4), 0.1 * np.eye(4), np.eye(4)[:2], np.zeros(2), 0.5 * np.eye(2),
+                  np.array([8.0, 10.0, 1.0, 0.0]), np.eye(4))
+    ref = closed_form_kf(mdl, np.arange(T, dtype=float), y, dt_final=1.0)
+    np.testing.assert_allclose(post.filtered_means, ref["filtered_means"], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(model.marginal_log_prob(params, y, filter_hyperparams=cd.KFHyperParams(dt_final=1.0)),
+                               ref["marginal_loglik"], rtol=1e-8)
+    sm = model.smoother(params, y, smoother_type="cd_smoother_2")
+    assert oracle_backend[-1][0] == "ekf_smoother" and sm.smoothed_means.shape == (T, 4)
+    with pytest.raises(NotImplementedError, match="cd_smoother_1"):
+        model.smoother(params, y)  # the reference's default type needs the transition matrices
+    with pytest.raises(NotImplementedError, match="bias"):
+        cd.cdlgssm_filter(params._replace(dynamics=params.dynamics._replace(bias=np.ones(4))), y)
+    with pytest.raises(NotImplementedError, match="inputs"):
+        cd.cdlgssm_filter(params, y, inputs=np.ones((T, 1)))
