@@ -157,6 +157,18 @@ __device__ __forceinline__ void wg_matmul_tn(R* __restrict__ C, const R* __restr
   }
 }
 
+// Register copy of an 8 x 8 diagonal block (lower triangle) of an LDS matrix, padded with the identity beyond nb:
+// all loads are independent, so their LDS latency overlaps -- the serial parts of the blocked algorithms below then
+// run out of registers instead of chasing ~100-cycle ds_read round trips.
+template <typename R>
+__device__ __forceinline__ void wg_load_block(const R* S, int kb, int nb, int lq, R (&Lr)[kWgBlock][kWgBlock]) {
+#pragma unroll
+  for (int i = 0; i < kWgBlock; ++i)
+#pragma unroll
+    for (int k = 0; k <= i; ++k)
+      Lr[i][k] = (i < nb) ? S[(kb + i) * lq + kb + k] : (i == k ? R(1) : R(0));
+}
+
 // Blocked right-looking Cholesky (lower, in place) of up to TWO n x n matrices at once (S2 may be null): the LL
 // factor and the boosted gain factor of one update are independent.  inv*[j] = 1 / L[j][j].  3 barriers per
 // 8-wide panel.  Non-positive pivots give NaN (jnp.linalg.cholesky semantics) and raise *bad.
@@ -166,38 +178,65 @@ __device__ void wg_cholesky2(R* S1, R* inv1, R* S2, R* inv2, int n, int lq, int*
   for (int kb = 0; kb < n; kb += kWgBlock) {
     const int nb = (n - kb < kWgBlock) ? n - kb : kWgBlock;
     __syncthreads();
-    // (a) diagonal block: one thread per matrix (thread 0 and thread 64 sit on different wavefronts when there are any)
+    // (a) diagonal block, factored in the registers of one thread per matrix (threads 0 and 64: different wavefronts)
     const int who = (blockDim.x > 64) ? 64 : 1;
     if (threadIdx.x == 0 || (nmat == 2 && threadIdx.x == who)) {
       R* S = (threadIdx.x == 0) ? S1 : S2;
       R* inv = (threadIdx.x == 0) ? inv1 : inv2;
-      for (int j = kb; j < kb + nb; ++j) {
-        R s = S[j * lq + j];
-        for (int k = kb; k < j; ++k) s = rfma(-S[j * lq + k], S[j * lq + k], s);
-        if (!(s > R(0))) *bad = 1;
-        const R r = rrsqrt(s);
-        inv[j] = r;
-        S[j * lq + j] = s * r;
-        for (int i = j + 1; i < kb + nb; ++i) {
-          R v = S[i * lq + j];
-          for (int k = kb; k < j; ++k) v = rfma(-S[i * lq + k], S[j * lq + k], v);
-          S[i * lq + j] = v * r;
+      R Lr[kWgBlock][kWgBlock], rv[kWgBlock];
+      wg_load_block(S, kb, nb, lq, Lr);
+      bool nonpd = false;
+#pragma unroll
+      for (int j = 0; j < kWgBlock; ++j) {
+        R sj = Lr[j][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) sj = rfma(-Lr[j][k], Lr[j][k], sj);
+        nonpd = nonpd || !(sj > R(0));
+        const R r = rrsqrt(sj);
+        rv[j] = r;
+        Lr[j][j] = sj * r;
+#pragma unroll
+        for (int i2 = j + 1; i2 < kWgBlock; ++i2) {
+          R v = Lr[i2][j];
+#pragma unroll
+          for (int k = 0; k < j; ++k) v = rfma(-Lr[i2][k], Lr[j][k], v);
+          Lr[i2][j] = v * r;
         }
       }
+      if (nonpd) *bad = 1;
+#pragma unroll
+      for (int i2 = 0; i2 < kWgBlock; ++i2)
+        if (i2 < nb) {
+          inv[kb + i2] = rv[i2];
+#pragma unroll
+          for (int k = 0; k <= i2; ++k) S[(kb + i2) * lq + kb + k] = Lr[i2][k];
+        }
     }
     __syncthreads();
-    // (b) panel below the block: row r solves  X L_blk^T = S[r][kb:kb+nb]
+    // (b) panel below the block: row r solves  X L_blk^T = S[r][kb:kb+nb], out of registers
     const int rest = n - kb - nb;
     CDKF_WG_FOR(e, rest * nmat) {
       const int w = (e >= rest) ? 1 : 0;
       const int r = kb + nb + (e - w * rest);
       R* S = w ? S2 : S1;
       const R* inv = w ? inv2 : inv1;
-      for (int j = kb; j < kb + nb; ++j) {
-        R v = S[r * lq + j];
-        for (int k = kb; k < j; ++k) v = rfma(-S[r * lq + k], S[j * lq + k], v);
-        S[r * lq + j] = v * inv[j];
+      R Lr[kWgBlock][kWgBlock], row[kWgBlock], rv[kWgBlock];
+      wg_load_block(S, kb, nb, lq, Lr);
+#pragma unroll
+      for (int j = 0; j < kWgBlock; ++j) {
+        row[j] = (j < nb) ? S[r * lq + kb + j] : R(0);
+        rv[j] = (j < nb) ? inv[kb + j] : R(1);
       }
+#pragma unroll
+      for (int j = 0; j < kWgBlock; ++j) {
+        R v = row[j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) v = rfma(-row[k], Lr[j][k], v);
+        row[j] = v * rv[j];
+      }
+#pragma unroll
+      for (int j = 0; j < kWgBlock; ++j)
+        if (j < nb) S[r * lq + kb + j] = row[j];
     }
     __syncthreads();
     // (c) trailing update of the lower triangle: S[a][b] -= sum_k L[a][k] L[b][k]
@@ -218,18 +257,31 @@ __device__ void wg_cholesky2(R* S1, R* inv1, R* S2, R* inv2, int n, int lq, int*
   __syncthreads();
 }
 
-// Solve (L L^T) X = B in place, B is [n x c]; blocked substitution, 2 barriers per panel and direction.
+// Solve (L L^T) X = B in place, B is [n x c]; blocked substitution, 2 barriers per panel and direction; the
+// 8 x 8 triangular solves run out of registers.
 template <typename R>
 __device__ void wg_chol_solve(const R* L, const R* inv, R* B, int n, int c, int lq) {
   for (int kb = 0; kb < n; kb += kWgBlock) {  // forward: L Y = B
     const int nb = (n - kb < kWgBlock) ? n - kb : kWgBlock;
     __syncthreads();
     CDKF_WG_FOR(j, c) {
-      for (int i = kb; i < kb + nb; ++i) {
-        R v = B[i * lq + j];
-        for (int k = kb; k < i; ++k) v = rfma(-L[i * lq + k], B[k * lq + j], v);
-        B[i * lq + j] = v * inv[i];
+      R Lr[kWgBlock][kWgBlock], col[kWgBlock], rv[kWgBlock];
+      wg_load_block(L, kb, nb, lq, Lr);
+#pragma unroll
+      for (int i = 0; i < kWgBlock; ++i) {
+        col[i] = (i < nb) ? B[(kb + i) * lq + j] : R(0);
+        rv[i] = (i < nb) ? inv[kb + i] : R(1);
       }
+#pragma unroll
+      for (int i = 0; i < kWgBlock; ++i) {
+        R v = col[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) v = rfma(-Lr[i][k], col[k], v);
+        col[i] = v * rv[i];
+      }
+#pragma unroll
+      for (int i = 0; i < kWgBlock; ++i)
+        if (i < nb) B[(kb + i) * lq + j] = col[i];
     }
     __syncthreads();
     const int rest = n - kb - nb;
@@ -247,11 +299,23 @@ __device__ void wg_chol_solve(const R* L, const R* inv, R* B, int n, int c, int 
     const int nb = (n - kb < kWgBlock) ? n - kb : kWgBlock;
     __syncthreads();
     CDKF_WG_FOR(j, c) {
-      for (int i = kb + nb - 1; i >= kb; --i) {
-        R v = B[i * lq + j];
-        for (int k = i + 1; k < kb + nb; ++k) v = rfma(-L[k * lq + i], B[k * lq + j], v);
-        B[i * lq + j] = v * inv[i];
+      R Lr[kWgBlock][kWgBlock], col[kWgBlock], rv[kWgBlock];
+      wg_load_block(L, kb, nb, lq, Lr);
+#pragma unroll
+      for (int i = 0; i < kWgBlock; ++i) {
+        col[i] = (i < nb) ? B[(kb + i) * lq + j] : R(0);
+        rv[i] = (i < nb) ? inv[kb + i] : R(1);
       }
+#pragma unroll
+      for (int i = kWgBlock - 1; i >= 0; --i) {
+        R v = col[i];
+#pragma unroll
+        for (int k = i + 1; k < kWgBlock; ++k) v = rfma(-Lr[k][i], col[k], v);
+        col[i] = v * rv[i];
+      }
+#pragma unroll
+      for (int i = 0; i < kWgBlock; ++i)
+        if (i < nb) B[(kb + i) * lq + j] = col[i];
     }
     __syncthreads();
     CDKF_WG_FOR(e, kb * c) {
@@ -751,7 +815,7 @@ __device__ __forceinline__ void wg_store(const WgArgs<R>& a, const WgLds<R>& L, 
 
 // ---- EKF filter sweep ----------------------------------------------------------------------------------------------
 template <typename R, int EPT>
-__global__ __launch_bounds__(256, 2) void ekf_filter_wg_kernel(const WgArgs<R> a) {
+__global__ __launch_bounds__(512) void ekf_filter_wg_kernel(const WgArgs<R> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const WgPlan plan = wg_plan(a.kind, a.d, a.h1, a.h2, a.hsel, false);
   WgLds<R> L(reinterpret_cast<R*>(smem_raw), a.q, a.lq, plan);
@@ -813,7 +877,7 @@ __global__ __launch_bounds__(256, 2) void ekf_filter_wg_kernel(const WgArgs<R> a
 // Per interval the filtered (m_f, P_f) at t_k are constants: G = F(m_f) + psd_solve(P_f, LQL)^T and f(m_f) are formed
 // once; the reverse-time right-hand side is  dm = -[f(m_f) + G (m_s - m_f)],  dP = -[G P_s + (G P_s)^T - LQL].
 template <typename R, int EPT>
-__global__ __launch_bounds__(256, 2) void ekf_smoother_wg_kernel(const WgArgs<R> a) {
+__global__ __launch_bounds__(512) void ekf_smoother_wg_kernel(const WgArgs<R> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const WgPlan plan = wg_plan(a.kind, a.d, a.h1, a.h2, a.hsel, true);
   WgLds<R> L(reinterpret_cast<R*>(smem_raw), a.q, a.lq, plan);

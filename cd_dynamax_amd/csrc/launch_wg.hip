@@ -190,7 +190,9 @@ static int wg_raise_lds_cap(K kernel) {
 
 static int wg_threads(int d) {
   if (const char* e = getenv("CDKF_WG_THREADS")) return atoi(e);  // debugging aid
-  return d * d >= 1024 ? 256 : (d * d >= 256 ? 128 : 64);
+  // d >= 32: 512 threads (two wavefronts per SIMD hide each other's LDS latency, and 4 owned entries per thread
+  // keep the six RK slopes inside the 256 architectural VGPRs)
+  return d * d >= 1024 ? 512 : (d * d >= 256 ? 128 : 64);
 }
 // the MLP's hidden layers give every phase of the right-hand side >= h1*d independent entries
 static int wg_threads(const cdkf_model* mdl) {
