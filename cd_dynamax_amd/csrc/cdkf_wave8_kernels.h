@@ -121,6 +121,9 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave8_kernel(const WgArgs<R
   int st = 0;
   bool bad = false;
   const bool zeroth = a.order == 0;
+  // explicit double-buffering of LDS reads pays in fp32; in fp64 the pinned weight rows already fill the register
+  // file and a second buffer spills to scratch (measured 2.7x slower), so fp64 loads each chunk right before use
+  constexpr bool kPrefetch = sizeof(R) == 4;
 
   // right-hand side of the moment ODEs for the stage value (xs: mean on lanes < d, Ps: this lane's covariance entry)
   auto rhs = [&](R xs, R Ps, R& kM, R& kP) {
@@ -168,6 +171,198 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave8_kernel(const WgArgs<R
         fi = rfma(X(lp1) - X(lm2), X(lm1), th[0] - X(l));
       }
     } else {  // MLP
+      if constexpr (kPrefetch) {  // fp32: explicitly double-buffered LDS reads
+      // layer 1: lane = hidden unit q
+      R z1 = b1l;
+#pragma unroll
+      for (int k = 0; k < kW8; ++k) z1 = rfma(w1row[k], xk[k], z1);
+      const R a1 = rtanh(z1);
+      const R d1 = R(1) - a1 * a1;
+      W[W8Off::a1 + lane] = a1;
+      W[W8Off::d1 + lane] = d1;
+      if (!zeroth) {
+#pragma unroll
+        for (int k = 0; k < kW8; ++k) W[W8Off::U + lane * kW8 + k] = d1 * w1row[k];
+      }
+      wave_sync();
+      // layer 2: lane = hidden unit p; z2 and the tangent T[p][:] = sum_q W2[p][q] U[q][:]
+      R z2 = b2l;
+      R T[kW8];
+#pragma unroll
+      for (int k = 0; k < kW8; ++k) T[k] = 0;
+      // (explicitly double-buffered in chunks of 4 hidden units: a lone wavefront has no other wave to hide the
+      //  ~100-cycle LDS round trip, so the next chunk's loads are in flight while this chunk's FMAs issue)
+      if (!zeroth) {
+        constexpr int CQ = (sizeof(R) == 8) ? 2 : 4;  // fp64: the pinned rows already fill the register file
+        R ub[2][CQ][kW8], ab[2][CQ];
+        auto ld = [&](int b, int q0) {
+#pragma unroll
+          for (int qq = 0; qq < CQ; ++qq) {
+            ab[b][qq] = W[W8Off::a1 + q0 + qq];
+#pragma unroll
+            for (int k = 0; k < kW8; ++k) ub[b][qq][k] = W[W8Off::U + (q0 + qq) * kW8 + k];
+          }
+        };
+        if (kPrefetch) ld(0, 0);
+#pragma unroll
+        for (int c = 0; c < kHid / CQ; ++c) {
+          const int b = kPrefetch ? (c & 1) : 0;
+          if (kPrefetch) {
+            if (c + 1 < kHid / CQ) ld(b ^ 1, CQ * (c + 1));
+          } else {
+            __builtin_amdgcn_sched_barrier(0);  // keep this chunk's loads behind the previous chunk's FMAs
+            ld(0, CQ * c);
+          }
+#pragma unroll
+          for (int qq = 0; qq < CQ; ++qq) {
+            const R w = w2row[CQ * c + qq];
+            z2 = rfma(w, ab[b][qq], z2);
+#pragma unroll
+            for (int k = 0; k < kW8; ++k) T[k] = rfma(w, ub[b][qq][k], T[k]);
+          }
+        }
+      } else {
+        R ab[2][16];
+        auto ld = [&](int b, int q0) {
+#pragma unroll
+          for (int qq = 0; qq < 16; ++qq) ab[b][qq] = W[W8Off::a1 + q0 + qq];
+        };
+        if (kPrefetch) ld(0, 0);
+#pragma unroll
+        for (int c = 0; c < kHid / 16; ++c) {
+          const int b = kPrefetch ? (c & 1) : 0;
+          if (kPrefetch) {
+            if (c + 1 < kHid / 16) ld(b ^ 1, 16 * (c + 1));
+          } else {
+            __builtin_amdgcn_sched_barrier(0);  // keep this chunk's loads behind the previous chunk's FMAs
+            ld(0, 16 * c);
+          }
+#pragma unroll
+          for (int qq = 0; qq < 16; ++qq) z2 = rfma(w2row[16 * c + qq], ab[b][qq], z2);
+        }
+      }
+      const R a2 = rtanh(z2);
+      const R d2 = R(1) - a2 * a2;
+      W[W8Off::a2 + lane] = a2;
+      W[W8Off::d2 + lane] = d2;
+      if (!zeroth) {
+#pragma unroll
+        for (int k = 0; k < kW8; ++k) W[W8Off::V + lane * kW8 + k] = d2 * T[k];
+      }
+      wave_sync();
+      // layer 3: lane (i, j): F[i][j] = sum_p W3[i][p] V[p][j]; row sums of W3 a2 give f_i (kept by lanes with j == 0)
+      R fs = 0;
+      {
+        constexpr int CP = (sizeof(R) == 8) ? 4 : 8;
+        R w3b[2][CP], vb[2][CP], a2b[2][CP];
+        auto ld = [&](int b, int p0) {
+#pragma unroll
+          for (int pp = 0; pp < CP; ++pp) {
+            w3b[b][pp] = Sh[W8Sh::W3 + i * 65 + p0 + pp];
+            a2b[b][pp] = W[W8Off::a2 + p0 + pp];
+            if (!zeroth) vb[b][pp] = W[W8Off::V + (p0 + pp) * kW8 + j];
+          }
+        };
+        if (kPrefetch) ld(0, 0);
+#pragma unroll
+        for (int c = 0; c < kHid / CP; ++c) {
+          const int b = kPrefetch ? (c & 1) : 0;
+          if (kPrefetch) {
+            if (c + 1 < kHid / CP) ld(b ^ 1, CP * (c + 1));
+          } else {
+            __builtin_amdgcn_sched_barrier(0);  // keep this chunk's loads behind the previous chunk's FMAs
+            ld(0, CP * c);
+          }
+#pragma unroll
+          for (int pp = 0; pp < CP; ++pp) {
+            fs = rfma(w3b[b][pp], a2b[b][pp], fs);
+            if (!zeroth) Fij = rfma(w3b[b][pp], vb[b][pp], Fij);
+          }
+        }
+      }
+      if (!inP) Fij = 0;
+      // f_i sits on lanes (i, *); move it to lane i
+      if (j == 0) W[W8Off::f + i] = fs + Sh[W8Sh::b3 + i];
+      R gl = 0;
+      if (second) {
+        // g = grad(div f):  s2_p = dd2_p sum_q G[p][q] d1_q ;  tq_q = dd1_q sum_p d2_p G[p][q] + d1_q sum_p s2_p W2[p][q]
+        R s = 0;
+        {
+          constexpr int CD = (sizeof(R) == 8) ? 8 : 16;
+          R db[2][CD];
+          auto ld = [&](int b, int q0) {
+#pragma unroll
+            for (int qq = 0; qq < CD; ++qq) db[b][qq] = W[W8Off::d1 + q0 + qq];
+          };
+          if (kPrefetch) ld(0, 0);
+#pragma unroll
+          for (int c = 0; c < kHid / CD; ++c) {
+            const int b = kPrefetch ? (c & 1) : 0;
+            if (kPrefetch) {
+              if (c + 1 < kHid / CD) ld(b ^ 1, CD * (c + 1));
+            } else {
+              __builtin_amdgcn_sched_barrier(0);  // keep this chunk's loads behind the previous chunk's FMAs
+              ld(0, CD * c);
+            }
+#pragma unroll
+            for (int qq = 0; qq < CD; ++qq) s = rfma(gmrow[CD * c + qq], db[b][qq], s);
+          }
+        }
+        W[W8Off::s2 + lane] = R(-2) * a2 * d2 * s;
+        wave_sync();
+        R td = 0, tc = 0;
+        {
+          constexpr int CT = (sizeof(R) == 8) ? 4 : 8;
+          R d2b[2][CT], gb[2][CT], s2b[2][CT], wb[2][CT];
+          auto ld = [&](int b, int p0) {
+#pragma unroll
+            for (int pp = 0; pp < CT; ++pp) {
+              d2b[b][pp] = W[W8Off::d2 + p0 + pp];
+              gb[b][pp] = Sh[W8Sh::Gm + (p0 + pp) * kHid + lane];
+              s2b[b][pp] = W[W8Off::s2 + p0 + pp];
+              wb[b][pp] = Sh[W8Sh::W2 + (p0 + pp) * kHid + lane];
+            }
+          };
+          if (kPrefetch) ld(0, 0);
+#pragma unroll
+          for (int c = 0; c < kHid / CT; ++c) {
+            const int b = kPrefetch ? (c & 1) : 0;
+            if (kPrefetch) {
+              if (c + 1 < kHid / CT) ld(b ^ 1, CT * (c + 1));
+            } else {
+              __builtin_amdgcn_sched_barrier(0);  // keep this chunk's loads behind the previous chunk's FMAs
+              ld(0, CT * c);
+            }
+#pragma unroll
+            for (int pp = 0; pp < CT; ++pp) {
+              td = rfma(d2b[b][pp], gb[b][pp], td);
+              tc = rfma(s2b[b][pp], wb[b][pp], tc);
+            }
+          }
+        }
+        W[W8Off::tq + lane] = td * (R(-2) * a1 * d1) + tc * d1;
+        wave_sync();
+        {
+          // g_l = sum_q tq[q] W1[q][l] for l < 8: every lane (i, j) sums the 8 hidden units q = 8 c + i of column j,
+          // the 8 partial sums of a column meet in the tile
+          R part = 0;
+#pragma unroll
+          for (int c = 0; c < kHid / 8; ++c) part = rfma(W[W8Off::tq + 8 * c + i], Sh[W8Sh::W1 + (8 * c + i) * kW8 + j], part);
+          W[W8Off::A + lane] = part;
+          wave_sync();
+          if (lane < kW8) {
+#pragma unroll
+            for (int r = 0; r < kW8; ++r) gl += W[W8Off::A + r * kW8 + lane];
+          }
+        }
+      }
+      wave_sync();
+      if (lane < kW8) {
+        fi = W[W8Off::f + lane];
+        if (second) W[W8Off::g + lane] = gl;
+      }
+      wave_sync();
+      } else {  // fp64: plain loops (a second buffer would spill the pinned weight rows)
       // layer 1: lane = hidden unit q
       R z1 = b1l;
 #pragma unroll
@@ -250,6 +445,7 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave8_kernel(const WgArgs<R
         if (second) W[W8Off::g + lane] = gl;
       }
       wave_sync();
+      }
     }
     if (lane < kW8) kM = (lane < d) ? fi : R(0);
     if (zeroth) return;
