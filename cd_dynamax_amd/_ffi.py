@@ -63,7 +63,7 @@ class CdkfOpts(C.Structure):
         ("t_shared", C.c_int32),
         ("device", C.c_int32),
         ("layout", C.c_int32),
-        ("reserved", C.c_int32),
+        ("forecast", C.c_int32),
         ("max_steps", C.c_int64),
         ("dt0", C.c_double),
         ("dt_final", C.c_double),

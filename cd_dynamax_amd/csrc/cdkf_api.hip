@@ -23,8 +23,8 @@ int check_common(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T
     set_error("need N >= 0 and T >= 1 (got N=%lld T=%lld)", (long long)N, (long long)T);
     return CDKF_EINVAL;
   }
-  if (!t || !y || !ll) {
-    set_error("t, y and ll must not be NULL");
+  if (!t || !ll || (!y && !(o && o->forecast))) {
+    set_error("t, y and ll must not be NULL (y may be NULL only in forecast mode)");
     return CDKF_EINVAL;
   }
   if (mdl->state_dim < 1 || mdl->emission_dim < 1) {
@@ -76,7 +76,7 @@ int run_with_host_buffers(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, 
   if (o2m && (rc = d2m.alloc(nm * sizeof(R)))) return rc;
   if (o2P && (rc = d2P.alloc(nP * sizeof(R)))) return rc;
   CDKF_HIP_CHECK(hipMemcpy(dt.p, t, nt * sizeof(R), hipMemcpyHostToDevice));
-  CDKF_HIP_CHECK(hipMemcpy(dy.p, y, (size_t)N * T * m * sizeof(R), hipMemcpyHostToDevice));
+  if (y) CDKF_HIP_CHECK(hipMemcpy(dy.p, y, (size_t)N * T * m * sizeof(R), hipMemcpyHostToDevice));
   rc = fn(mdl, o, N, T, (const R*)dt.p, (const R*)dy.p, (R*)dll.p, (R*)d1m.p, (R*)d1P.p, (R*)d2m.p, (R*)d2P.p,
           (int32_t*)dst.p, (void*)nullptr);
   if (rc) return rc;
@@ -128,6 +128,7 @@ void cdkf_default_opts(cdkf_opts* o) {
   o->t_shared = 0;
   o->device = -1;
   o->layout = CDKF_LAYOUT_NT;
+  o->forecast = 0;
   o->max_steps = 100000;
   o->dt0 = 0.01;
   o->dt_final = 1e-10;

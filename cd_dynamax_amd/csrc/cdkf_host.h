@@ -94,9 +94,11 @@ void fill_reg_args(RegArgs<R, D, M, Drift>& a, const cdkf_model* mdl, const cdkf
   a.max_steps = (long)o->max_steps;
   a.order = o->state_order;
   a.num_iter = o->num_iter;
+  a.forecast = o->forecast;
   a.N = N;
   a.T = T;
   a.y_si = a.m_si = a.P_si = 1;
+  const bool no_y = (y == nullptr);
   if (o->layout == CDKF_LAYOUT_TCN) {  // [T,w,N]: component-major inside a time step
     a.t_sn = o->t_shared ? 0 : 1;
     a.t_sk = o->t_shared ? 1 : N;
@@ -124,8 +126,9 @@ void fill_reg_args(RegArgs<R, D, M, Drift>& a, const cdkf_model* mdl, const cdkf
     a.P_sn = T * D * D;
     a.P_sk = D * D;
   }
+  if (no_y) a.y_sn = a.y_sk = a.y_si = 0;  // every 'observation' load hits t[0]
   a.t = t;
-  a.y = y;
+  a.y = y ? y : t;  // forecast mode ignores the observations; keep the prefetch loads on valid memory
   a.ll = ll;
   a.fm = fm;
   a.fP = fP;

@@ -32,7 +32,7 @@ struct RegArgs {
   // UKF weights (inference_ukf.py:63-89): sigma scale sqrt(n + lambda), w_mean[0], w_cov[0], w_i
   R ukf_c, ukf_wm0, ukf_wc0, ukf_wi;
   long max_steps;
-  int order, num_iter;
+  int order, num_iter, forecast;
   long N, T;
   // element (n, k, i) of an array lives at  n * sn + k * sk + i.  Reference layout [N,T,w]:
   // (sn, sk) = (T*w, w); time-major layout [T,N,w]: (sn, sk) = (w, N*w); shared t: sn = 0.
@@ -521,10 +521,12 @@ __global__ __launch_bounds__(64, 1) void filter_reg_kernel(const RegArgs<R, D, M
   for (int r = 0; r < M; ++r) ycur[r] = yp[r * a.y_si];
 
   for (long k = 0; k < a.T; ++k) {
-    if constexpr (UKF)
-      ukf_update<R, D, M>(a, ys, ycur, ll, st);
-    else
-      ekf_update<R, D, M, HSEL>(a, ys, ycur, ll, st);
+    if (!a.forecast) {  // forecast mode (forecast_*_kalman_filter): no measurement update, no log-likelihood
+      if constexpr (UKF)
+        ukf_update<R, D, M>(a, ys, ycur, ll, st);
+      else
+        ekf_update<R, D, M, HSEL>(a, ys, ycur, ll, st);
+    }
     if (ys[0] != ys[0]) st |= kStatusNan;
     if constexpr (OUT == kOutAll) store_moments_all<R, D>(a.fm, a.fP, moff, poff, a.m_si, a.P_si, ys);
     if constexpr (OUT == kOutSome) store_moments<R, D>(a.fm, a.fP, moff, poff, a.m_si, a.P_si, ys);

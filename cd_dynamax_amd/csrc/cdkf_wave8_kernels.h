@@ -473,7 +473,7 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave8_kernel(const WgArgs<R
   for (long k = 0; k < a.T; ++k) {
     // ---------------- update (inference_ekf.py:153-199, 285-286) ----------------
     const R yl = (lane < m) ? yp[k * a.y_sk + lane * a.y_si] : R(0);
-    for (int it = 0; it < a.num_iter; ++it) {
+    for (int it = 0; it < (a.forecast ? 0 : a.num_iter); ++it) {
       W[W8Off::P + lane] = Pij;
       if (lane < kW8) W[W8Off::x + lane] = mj;
       wave_sync();

@@ -22,7 +22,7 @@ template <typename R>
 struct WgArgs {
   int kind, d, m, h1, h2;
   int q, lq;  // q = max(d, m); lq = (q rounded up to a multiple of 4) + 1: leading dimension of every LDS matrix
-  int order, num_iter, hsel;
+  int order, num_iter, hsel, forecast;
   long max_steps;
   R dt0, dt_final;
   const R* par;  // device block: theta | LQL[d*d] | LQLz[d*d] | H[m*d] | hb[m] | Rm[m*m] | m0[d] | P0[d*d]
@@ -849,7 +849,7 @@ __global__ __launch_bounds__(512) void ekf_filter_wg_kernel(const WgArgs<R> a) {
     const R t0 = tp[k * a.t_sk];
     const R t1 = (k + 1 < a.T) ? tp[(k + 1) * a.t_sk] : t0 + a.dt_final;
     __syncthreads();
-    wg_ekf_update(a, L, yl, &ll, &bad);
+    if (!a.forecast) wg_ekf_update(a, L, yl, &ll, &bad);
     wg_store(a, L, a.fm, a.fP, n, k);
     __syncthreads();
     if (wg_integrate<R, EPT>(L, own, d, t0, t1, a.dt0, a.max_steps, !zeroth, rhs)) st |= kStatusMaxSteps;

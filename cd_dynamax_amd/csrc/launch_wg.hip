@@ -138,6 +138,7 @@ static int wg_prepare(WgArgs<R>& a, R** dev_block, ParamSlot** slot_out, const c
   a.h1 = mdl->hidden1;
   a.h2 = mdl->hidden2;
   a.hsel = wg_hsel(mdl);
+  a.forecast = o->forecast;
   a.q = d > m ? d : m;
   a.lq = ((a.q + 3) & ~3) + 1;  // multiple of 4 (1x4 strips stay inside a row) plus 1 (odd: column walks hit 32 different LDS banks)
   a.order = o->state_order;
@@ -266,6 +267,7 @@ int launch_ekf_filter_wg(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, i
   int rc = wg_prepare(a, &blk, &slot, mdl, o, N, T, stream);
   if (rc) return rc;
   a.t = t; a.y = y; a.ll = ll; a.fm = fm; a.fP = fP; a.pm = pm; a.pP = pP; a.status = status;
+  if (!y) { a.y = t; a.y_sn = a.y_sk = a.y_si = 0; }  // forecast mode: observations are ignored
   rc = wave8_shape(mdl) ? launch_wave8<R>(a, stream) : launch_wg_dispatch<R>(a, mdl, false, stream);
   const int rc2 = param_pool_release(slot, stream);
   return rc ? rc : rc2;

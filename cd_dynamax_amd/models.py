@@ -18,7 +18,7 @@ from typing import List, Optional, Tuple, Union
 import numpy as np
 
 from . import _ffi
-from .params import (EKFHyperParams, EnKFHyperParams, LearnableLinear, LearnableLorenz63, LearnableLorenz96,
+from .params import (EKFHyperParams, EnKFHyperParams, GSSMForecast, LearnableLinear, LearnableLorenz63, LearnableLorenz96,
                      LearnableMatrix, LearnableMLP, LearnableVector, ParameterProperties, ParamsCDNLGSSM,
                      ParamsCDNLGSSMDynamics, ParamsCDNLGSSMEmissions, ParamsLGSSMInitial, PosteriorGSSMFiltered,
                      PosteriorGSSMSmoothed, UKFHyperParams)
@@ -169,6 +169,62 @@ def cdnlgssm_smoother(
     fm, fP, sm, sP = (_squeeze(a, batched) for a in outs)
     return PosteriorGSSMSmoothed(marginal_loglik=ll if batched else ll[0], filtered_means=fm, filtered_covariances=fP,
                                  smoothed_means=sm, smoothed_covariances=sP)
+
+
+def cdnlgssm_forecast(
+    params: ParamsCDNLGSSM,
+    init_forecast,
+    t_init,
+    t_forecast=None,
+    hyperparams: Optional[Union[EKFHyperParams, EnKFHyperParams, UKFHyperParams]] = EKFHyperParams(),
+    inputs=None,
+    output_fields: Optional[List[str]] = ["forecasted_state_means", "forecasted_state_covariances"],
+    dtype=None,
+) -> GSSMForecast:
+    """Forecast the Gaussian state distribution over ``t_forecast`` from ``init_forecast`` at ``t_init``: repeated
+    ``_predict`` without measurement updates (reference: models.py:767-936 -> forecast_extended_kalman_filter,
+    inference_ekf.py:679-766 / forecast_unscented_kalman_filter, inference_ukf.py:409-505).
+
+    ``init_forecast`` is a ``(mean, covariance)`` pair or any object with ``.mean()`` / ``.covariance()`` (the reference
+    passes a TFP MultivariateNormalFullCovariance); a leading trajectory axis on it and on ``t_init`` / ``t_forecast``
+    forecasts a batch.  Only the distribution forecast is on the HIP path; path (SDE sample) forecasts and emission
+    moments are not.
+    """
+    if t_forecast is None:
+        raise ValueError("t_forecast must be provided for forecasting")
+    if isinstance(hyperparams, EKFHyperParams):
+        algo = "ekf_filter"
+    elif isinstance(hyperparams, UKFHyperParams):
+        algo = "ukf_filter"
+    else:
+        raise NotImplementedError("only EKF / UKF distribution forecasts are on the HIP path")
+    if hasattr(init_forecast, "mean") and callable(init_forecast.mean):
+        m_init, P_init = np.asarray(init_forecast.mean()), np.asarray(init_forecast.covariance())
+    else:
+        m_init, P_init = (np.asarray(a) for a in init_forecast)
+    if m_init.ndim > 1:
+        raise NotImplementedError("one initial distribution per call (the model block holds a single (m0, P0))")
+    fields = list(output_fields) if output_fields is not None else []
+    unknown = set(fields) - {"forecasted_state_means", "forecasted_state_covariances"}
+    if unknown:
+        raise NotImplementedError(f"forecast fields {sorted(unknown)} are not produced by the HIP path")
+    start = params._replace(initial=ParamsLGSSMInitial(LearnableVector(m_init), LearnableMatrix(P_init)))
+    mdl = _model_block(start)
+    opts = _opts(hyperparams, 1)
+    opts.forecast = 1
+    tf = np.asarray(t_forecast, dtype=np.float64)
+    batched = tf.ndim == 3
+    tf = tf.reshape(tf.shape[0], -1) if batched else tf.reshape(1, -1)
+    ti = np.broadcast_to(np.asarray(t_init, dtype=np.float64).reshape(-1, 1), (tf.shape[0], 1))
+    t = np.concatenate([ti, tf], axis=1)  # [N, 1 + n]: t0 = [t_init, t_forecast[:-1]], t1 = t_forecast
+    dtype = np.dtype(np.float64 if dtype is None else dtype)
+    y = np.zeros((t.shape[0], t.shape[1], mdl.emission_dim), dtype)  # ignored in forecast mode
+    opts.t_shared = 0
+    want = [False, False, "forecasted_state_means" in fields, "forecasted_state_covariances" in fields]
+    _, outs, _ = _ffi.run_host(algo, mdl, opts, t.astype(dtype), y, want, dtype)
+    fm = None if outs[2] is None else _squeeze(outs[2][:, :-1], batched)
+    fP = None if outs[3] is None else _squeeze(outs[3][:, :-1], batched)
+    return GSSMForecast(forecasted_state_means=fm, forecasted_state_covariances=fP)
 
 
 class ContDiscreteNonlinearGaussianSSM:

@@ -127,6 +127,16 @@ class PosteriorGSSMSmoothed(NamedTuple):
     smoothed_cross_covariances: Optional[Any] = None
 
 
+class GSSMForecast(NamedTuple):
+    """cdnlgssm_utils.py:227-248 (only the Gaussian-forecast fields are produced by the HIP path)."""
+    forecasted_state_means: Optional[Any] = None
+    forecasted_state_covariances: Optional[Any] = None
+    forecasted_emission_means: Optional[Any] = None
+    forecasted_emission_covariances: Optional[Any] = None
+    forecasted_state_path: Optional[Any] = None
+    forecasted_emission_path: Optional[Any] = None
+
+
 class EKFHyperParams(NamedTuple):
     dt_final: float = 1e-10
     state_order: str = "second"

@@ -99,7 +99,11 @@ typedef struct cdkf_opts {
   int32_t device;       /* HIP device ordinal; -1 = current device */
   int32_t layout;       /* CDKF_LAYOUT_NT (default), _TN or _TCN; applies to t (unless shared), y and every
                            mean / covariance array.  ll and status are always [N]. */
-  int32_t reserved;
+  int32_t forecast;     /* 0 (default): filter.  1: forecast mode -- the measurement update and the log-likelihood are
+                           skipped, so predicted_means[k] / predicted_covs[k] are the moments pushed from (m0, P0) at
+                           t[0] to t[k+1]; y is ignored (may be NULL) and ll is set to 0.  Replaces
+                           forecast_extended_kalman_filter / forecast_unscented_kalman_filter
+                           (inference_ekf.py:679-766, inference_ukf.py:409-505). */
   int64_t max_steps;    /* RK steps per observation interval; default 100000 */
   double dt0;           /* default 0.01 */
   double dt_final;      /* default 1e-10 (inference_ekf.py:39) */

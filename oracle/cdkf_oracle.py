@@ -586,6 +586,39 @@ def ukf_filter(mdl: Model, t, y, alpha=math.sqrt(3), beta=2, kappa=1, dt0=0.01, 
     return out
 
 
+def forecast(mdl: Model, m_init, P_init, t_init, t_forecast, method="ekf", state_order="second", alpha=math.sqrt(3), beta=2,
+             kappa=1, dt0=0.01, max_steps=100000, dtype=np.float64):
+    """forecast_extended_kalman_filter (inference_ekf.py:679-766) / forecast_unscented_kalman_filter
+    (inference_ukf.py:409-505): repeated _predict over t0 = [t_init, t_forecast[:-1]], t1 = t_forecast, no updates.
+    t_init [N], t_forecast [N,n]; returns (means [N,n,d], covs [N,n,d,d])."""
+    dtype = np.dtype(dtype)
+    mdl = mdl.cast(dtype)
+    tf = np.asarray(t_forecast, dtype=dtype)
+    N, n = tf.shape
+    d = mdl.d
+    m = np.broadcast_to(np.asarray(m_init, dtype), (N, d)).copy()
+    P = np.broadcast_to(np.asarray(P_init, dtype), (N, d, d)).copy()
+    t0 = np.asarray(t_init, dtype=dtype).reshape(N).copy()
+    means, covs = np.zeros((N, n, d), dtype), np.zeros((N, n, d, d), dtype)
+    if method == "ukf":
+        lamb, w_mean, w_cov, W = ukf_weights(d, alpha, beta, kappa, dtype)
+        LQL = _LQL(mdl)
+
+        def rhs(yv):
+            X = ukf_sigmas(yv[0], yv[1], lamb)
+            fX = mdl.drift.f(X.reshape(-1, d)).reshape(X.shape)
+            foo = np.einsum("nsi,st,ntj->nij", fX, W, X)
+            return np.einsum("nsi,s->ni", fX, w_mean), foo + np.swapaxes(foo, -1, -2) + LQL
+    for k in range(n):
+        if method == "ukf":
+            m, P = diffeqsolve(rhs, t0, tf[:, k], (m, P), dt0, max_steps)
+        else:
+            m, P = ekf_predict(mdl, m, P, t0, tf[:, k], state_order, dt0, max_steps)
+        means[:, k], covs[:, k] = m, P
+        t0 = tf[:, k]
+    return means, covs
+
+
 # --------------------------------------------------------------------------------------
 # synthetic data (SURVEY.md section 8d; time-grid recipe of simulation_utils.py:46-49)
 # --------------------------------------------------------------------------------------

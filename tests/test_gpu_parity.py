@@ -331,3 +331,32 @@ def test_baseline_config1_linear_tracking_front_end(hip_lib):
     assert relerr(sm.smoothed_covariances, oref["smoothed_covariances"][0]) < 1e-9
     post32 = model.filter(params, y.astype(np.float32), filter_hyperparams=cd.KFHyperParams(dt_final=1.0))
     assert relerr(post32.filtered_means, ref["filtered_means"]) < 1e-4
+
+
+def test_forecast_matches_repeated_predict(hip_lib):
+    """cdnlgssm_forecast (reference: models.py:767-936 -> forecast_extended/unscented_kalman_filter): the moments pushed
+    from an initial Gaussian over a forecast grid without updates, EKF and UKF, register and wavefront kernels."""
+    from helpers import lorenz96_model
+    rng = np.random.default_rng(11)
+    for mdl in (o.lorenz63_model(1), lorenz96_model(6, 3)):
+        d = mdl.d
+        A = rng.standard_normal((d, d))
+        m_init, P_init = rng.standard_normal(d) + 2.0, A @ A.T / d + 0.5 * np.eye(d)
+        t_init = 0.37
+        t_forecast = t_init + np.cumsum(rng.uniform(0.001, 0.03, size=25))
+        P = params_from(mdl)
+        ref_m, ref_P = o.forecast(mdl, m_init, P_init, np.array([t_init]), t_forecast[None], method="ekf")
+        fc = cd.cdnlgssm_forecast(P, (m_init, P_init), np.array([[t_init]]), t_forecast[:, None])
+        assert isinstance(fc, cd.GSSMForecast) and fc.forecasted_state_means.shape == (25, d)
+        assert relerr(fc.forecasted_state_means, ref_m[0]) < 1e-9
+        assert relerr(fc.forecasted_state_covariances, ref_P[0]) < 1e-9
+        fc = cd.cdnlgssm_forecast(P, (m_init, P_init), np.array([[t_init]]), t_forecast[:, None],
+                                  output_fields=["forecasted_state_means"])
+        assert fc.forecasted_state_covariances is None
+        if d == 3:  # UKF forecast (register kernels only)
+            ref_m, ref_P = o.forecast(mdl, m_init, P_init, np.array([t_init]), t_forecast[None], method="ukf")
+            fc = cd.cdnlgssm_forecast(P, (m_init, P_init), np.array([[t_init]]), t_forecast[:, None], cd.UKFHyperParams())
+            assert relerr(fc.forecasted_state_means, ref_m[0]) < 1e-8
+            assert relerr(fc.forecasted_state_covariances, ref_P[0]) < 1e-8
+    with pytest.raises(ValueError, match="t_forecast"):
+        cd.cdnlgssm_forecast(P, (m_init, P_init), np.array([[t_init]]))
