@@ -58,7 +58,9 @@ template <typename R, int D, int M, typename Drift, bool UKF, bool ZEROTH, bool 
 inline void launch_filter_reg(const RegArgs<R, D, M, Drift>& a, hipStream_t stream) {
   const dim3 grid((unsigned)((a.N + 63) / 64)), block(64);
   const bool all = a.fm && a.fP && a.pm && a.pP, none = !a.fm && !a.fP && !a.pm && !a.pP;
-  if (all)
+  if (a.forecast)  // rare path: one generic instantiation (run-time output checks, general emission)
+    hipLaunchKernelGGL((filter_reg_kernel<R, D, M, Drift, UKF, ZEROTH, false, kOutSome, true>), grid, block, 0, stream, a);
+  else if (all)
     hipLaunchKernelGGL((filter_reg_kernel<R, D, M, Drift, UKF, ZEROTH, HSEL, kOutAll>), grid, block, 0, stream, a);
   else if (none)
     hipLaunchKernelGGL((filter_reg_kernel<R, D, M, Drift, UKF, ZEROTH, HSEL, kOutNone>), grid, block, 0, stream, a);

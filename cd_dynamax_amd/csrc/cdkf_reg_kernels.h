@@ -486,7 +486,7 @@ CDKF_DEV void ukf_update(const Args& a, R (&ys)[Dims<D>::NS], const R (&yobs)[M]
 //         N-1 and store the same values to the same addresses, so no lane predicate is needed either.
 constexpr int kOutNone = 0, kOutAll = 1, kOutSome = 2;
 
-template <typename R, int D, int M, typename Drift, bool UKF, bool ZEROTH, bool HSEL, int OUT>
+template <typename R, int D, int M, typename Drift, bool UKF, bool ZEROTH, bool HSEL, int OUT, bool FORECAST = false>
 __global__ __launch_bounds__(64, 1) void filter_reg_kernel(const RegArgs<R, D, M, Drift> a) {
   constexpr int NS = Dims<D>::NS;
   constexpr int NP = Dims<D>::NP;
@@ -521,7 +521,7 @@ __global__ __launch_bounds__(64, 1) void filter_reg_kernel(const RegArgs<R, D, M
   for (int r = 0; r < M; ++r) ycur[r] = yp[r * a.y_si];
 
   for (long k = 0; k < a.T; ++k) {
-    if (!a.forecast) {  // forecast mode (forecast_*_kalman_filter): no measurement update, no log-likelihood
+    if constexpr (!FORECAST) {  // forecast mode (forecast_*_kalman_filter): no measurement update, no log-likelihood
       if constexpr (UKF)
         ukf_update<R, D, M>(a, ys, ycur, ll, st);
       else

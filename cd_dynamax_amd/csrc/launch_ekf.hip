@@ -10,7 +10,12 @@ static int run_ekf_reg(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int
   fill_reg_args(a, mdl, o, N, T, t, y, ll, fm, fP, pm, pP, status);
   if (o->state_order == CDKF_ORDER_ZEROTH) {
     const dim3 grid((unsigned)((N + 63) / 64)), block(64);
-    hipLaunchKernelGGL((filter_reg_kernel<R, D, M, Drift, false, true, false, kOutSome>), grid, block, 0, stream, a);
+    if (o->forecast)
+      hipLaunchKernelGGL((filter_reg_kernel<R, D, M, Drift, false, true, false, kOutSome, true>), grid, block, 0, stream, a);
+    else
+      hipLaunchKernelGGL((filter_reg_kernel<R, D, M, Drift, false, true, false, kOutSome>), grid, block, 0, stream, a);
+  } else if (o->forecast) {
+    launch_filter_reg<R, D, M, Drift, false, false, false>(a, stream);
   } else if (M <= D && emission_is_selection(mdl)) {
     launch_filter_reg<R, D, M, Drift, false, false, (M <= D)>(a, stream);
   } else {
