@@ -38,6 +38,9 @@ template <typename R>
 int launch_ekf_filter_wg(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll,
                          R* fm, R* fP, R* pm, R* pP, int32_t* status, hipStream_t stream);
 template <typename R>
+int launch_ukf_filter_wg(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll,
+                         R* fm, R* fP, R* pm, R* pP, int32_t* status, hipStream_t stream);
+template <typename R>
 int launch_ekf_smoother_wg(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y,
                            R* ll, R* fm, R* fP, R* sm, R* sP, int32_t* status, hipStream_t stream);
 

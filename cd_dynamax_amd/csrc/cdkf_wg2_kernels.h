@@ -22,7 +22,8 @@ template <typename R>
 struct WgArgs {
   int kind, d, m, h1, h2;
   int q, lq;  // q = max(d, m); lq = (q rounded up to a multiple of 4) + 1: leading dimension of every LDS matrix
-  int order, num_iter, hsel, forecast;
+  int order, num_iter, hsel, forecast, ukf;
+  R ukf_c, ukf_wm0, ukf_wi;  // sigma scale sqrt(n + lambda), w_mean[0], 1 / (2 (n + lambda))   (inference_ukf.py:63-89)
   long max_steps;
   R dt0, dt_final;
   const R* par;  // device block: theta | LQL[d*d] | LQLz[d*d] | H[m*d] | hb[m] | Rm[m*m] | m0[d] | P0[d*d]
@@ -65,10 +66,10 @@ __host__ __device__ inline int wg_mlp_scratch(int kind, int d, int h1, int h2) {
 __host__ __device__ inline int wg_mlp_theta(int kind, int d, int h1, int h2) {
   return kind == kDriftMlp ? (h1 * d + h1 + h2 * h1 + h2 + d * h2 + d) : 0;
 }
-__host__ __device__ inline WgPlan wg_plan(int kind, int d, int h1, int h2, int hsel, bool smoother) {
+__host__ __device__ inline WgPlan wg_plan(int kind, int d, int h1, int h2, int hsel, bool smoother, bool ukf = false) {
   WgPlan p;
   int n = 5;
-  const bool dense = (kind != kDriftLorenz96) || smoother;  // the smoother's G = F + aux is dense for every drift
+  const bool dense = (kind != kDriftLorenz96) || smoother || ukf;  // smoother: G = F + aux is dense; UKF: O = c chol(P)
   p.i_F = dense ? n++ : -1;
   p.i_A = dense ? n++ : -1;
   p.i_HP = hsel ? -1 : n++;
@@ -668,6 +669,98 @@ __device__ __forceinline__ void wg_rhs_ekf(const WgArgs<R>& a, const WgLds<R>& L
   }
 }
 
+// UKF moment right-hand side (inference_ukf.py:128-152) in the antisymmetric form of cdkf_reg_kernels.h:
+//   O = c chol(Ps);  dm = w_m0 f(m) + w_i sum_i [f(m + o_i) + f(m - o_i)];
+//   dP = foo + foo^T + LQL,  foo = w_i DF O^T,  DF[:, i] = f(m + o_i) - f(m - o_i).
+// LDS use during the RK stages: O in the F slot, DF in the A slot, foo in the S slot (free between updates).
+template <typename R, int EPT>
+__device__ __forceinline__ void wg_rhs_ukf(const WgArgs<R>& a, const WgLds<R>& L, const Own<R, EPT>& own, const R* ms,
+                                           const R* Ps, R& kM, R (&kP)[EPT], int* bad) {
+  const int d = a.d, lq = a.lq;
+  R* O = L.mat(L.plan.i_F);
+  R* DF = L.mat(L.plan.i_A);
+  R* foo = L.mat(2);
+  R* f0 = L.vec(2);
+  R* sum = L.vec(3);
+  R* xs = L.vec(4);   // a sigma point
+  R* fx = L.vec(5);   // its drift
+  R* inv = L.vec(6);
+  CDKF_WG_FOR(e, d * d) {
+    const int i = fdiv(e, d), j = e - i * d;
+    O[i * lq + j] = Ps[i * lq + j];
+  }
+  wg_cholesky2(O, inv, (R*)nullptr, (R*)nullptr, d, lq, bad);
+  CDKF_WG_FOR(e, d * d) {
+    const int i = fdiv(e, d), j = e - i * d;
+    O[i * lq + j] = (j <= i) ? a.ukf_c * O[i * lq + j] : R(0);
+  }
+  __syncthreads();
+  if (a.kind == kDriftLinear) {
+    // f(m +- o) = W (m +- o) + b:  DF = 2 W O,  sum = 2 d f(m)
+    const R* th = a.par + a.o_theta;
+    wg_drift(a, L, ms, f0, (R*)nullptr, (R*)nullptr);
+    CDKF_WG_FOR(e, d * d) {
+      const int r = fdiv(e, d), i = e - r * d;
+      R acc = 0;
+      for (int k = i; k < d; ++k) acc = rfma(th[r * d + k], O[k * lq + i], acc);
+      DF[r * lq + i] = acc + acc;
+    }
+    CDKF_WG_FOR(r, d) sum[r] = R(2 * d) * f0[r];
+    __syncthreads();
+  } else if (a.kind == kDriftLorenz96) {
+    const R forcing = (a.par + a.o_theta)[0];
+    CDKF_WG_FOR(r, d) {
+      const int rp1 = (r + 1 == d) ? 0 : r + 1, rm1 = (r == 0) ? d - 1 : r - 1, rm2 = (rm1 == 0) ? d - 1 : rm1 - 1;
+      f0[r] = rfma(ms[rp1] - ms[rm2], ms[rm1], forcing - ms[r]);
+      sum[r] = 0;
+    }
+    CDKF_WG_FOR(e, d * d) {
+      const int r = fdiv(e, d), i = e - r * d;
+      const int rp1 = (r + 1 == d) ? 0 : r + 1, rm1 = (r == 0) ? d - 1 : r - 1, rm2 = (rm1 == 0) ? d - 1 : rm1 - 1;
+      const R op1 = O[rp1 * lq + i], om1 = O[rm1 * lq + i], om2 = O[rm2 * lq + i], o0 = O[r * lq + i];
+      const R fp = rfma((ms[rp1] + op1) - (ms[rm2] + om2), ms[rm1] + om1, forcing - (ms[r] + o0));
+      const R fm = rfma((ms[rp1] - op1) - (ms[rm2] - om2), ms[rm1] - om1, forcing - (ms[r] - o0));
+      DF[r * lq + i] = fp - fm;
+      foo[r * lq + i] = fp + fm;  // summed over i below
+    }
+    __syncthreads();
+    CDKF_WG_FOR(r, d) {
+      R acc = 0;
+      for (int i = 0; i < d; ++i) acc += foo[r * lq + i];
+      sum[r] = acc;
+    }
+    __syncthreads();
+  } else {  // generic (Lorenz-63, MLP): one drift evaluation per sigma point
+    wg_drift(a, L, ms, f0, (R*)nullptr, (R*)nullptr);
+    CDKF_WG_FOR(r, d) sum[r] = 0;
+    __syncthreads();
+    for (int i = 0; i < d; ++i) {
+      for (int sgn = 0; sgn < 2; ++sgn) {
+        CDKF_WG_FOR(r, d) xs[r] = sgn ? ms[r] - O[r * lq + i] : ms[r] + O[r * lq + i];
+        __syncthreads();
+        wg_drift(a, L, xs, fx, (R*)nullptr, (R*)nullptr);
+        CDKF_WG_FOR(r, d) {
+          sum[r] += fx[r];
+          DF[r * lq + i] = sgn ? DF[r * lq + i] - fx[r] : fx[r];
+        }
+        __syncthreads();
+      }
+    }
+  }
+  if (threadIdx.x < d) kM = rfma(a.ukf_wm0, f0[threadIdx.x], a.ukf_wi * sum[threadIdx.x]);
+  // foo[r][b] = w_i sum_{i <= b} DF[r][i] O[b][i]
+  CDKF_WG_FOR(e, d * d) {
+    const int r = fdiv(e, d), b = e - r * d;
+    R acc = 0;
+    for (int i = 0; i <= b; ++i) acc = rfma(DF[r * lq + i], O[b * lq + i], acc);
+    foo[r * lq + b] = a.ukf_wi * acc;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < EPT; ++u)
+    if (u < own.n) kP[u] = (foo[own.off[u]] + foo[own.ej[u] * lq + own.ei[u]]) + own.lql[u];
+}
+
 // ---- EKF update on the LDS state (inference_ekf.py:153-199, 285-286) --------------------------------------------
 template <typename R>
 __device__ void wg_ekf_update(const WgArgs<R>& a, const WgLds<R>& L, const R* __restrict__ yl, double* ll, int* bad) {
@@ -697,8 +790,51 @@ __device__ void wg_ekf_update(const WgArgs<R>& a, const WgLds<R>& L, const R* __
     }
     __syncthreads();
   }
-  for (int it = 0; it < a.num_iter; ++it) {
-    if (hsel) {
+  const bool ukf = a.ukf != 0;
+  R* O = ukf ? L.mat(L.plan.i_F) : (R*)nullptr;   // UKF: O = c chol(P), columns are the sigma offsets o_i
+  R* HO = ukf ? (hsel ? O : L.mat(L.plan.i_A)) : (R*)nullptr;
+  for (int it = 0; it < (ukf ? 1 : a.num_iter); ++it) {
+    if (ukf) {
+      // unscented update for the linear emission (inference_ukf.py:162-203), antisymmetric form (cdkf_reg_kernels.h):
+      // dY_i = H o_i,  S = 2 w_i sum_i dY_i dY_i^T + R,  C = 2 w_i sum_i o_i dY_i^T,  ybar = H m + b
+      CDKF_WG_FOR(e, d * d) {
+        const int i = fdiv(e, d), j = e - i * d;
+        O[i * lq + j] = P[i * lq + j];
+      }
+      wg_cholesky2(O, inv1, (R*)nullptr, (R*)nullptr, d, lq, bad);
+      CDKF_WG_FOR(e, d * d) {
+        const int i = fdiv(e, d), j = e - i * d;
+        O[i * lq + j] = (j <= i) ? a.ukf_c * O[i * lq + j] : R(0);
+      }
+      __syncthreads();
+      if (!hsel) {
+        wg_matmul(HO, Hl, O, m, d, d, lq);
+        __syncthreads();
+      }
+      const R w2 = a.ukf_wi + a.ukf_wi;
+      CDKF_WG_FOR(e, m * m) {
+        const int r = fdiv(e, m), c = e - r * m;
+        R acc = 0;
+        for (int k = 0; k < d; ++k) acc = rfma(HO[r * lq + k], HO[c * lq + k], acc);
+        S[r * lq + c] = rfma(w2, acc, Rm[e]);
+      }
+      CDKF_WG_FOR(e, m * d) {  // X0 = C^T = 2 w_i HO O^T, kept in the HP slot semantics below via X directly
+        const int r = fdiv(e, d), c = e - r * d;
+        R acc = 0;
+        for (int k = 0; k <= c; ++k) acc = rfma(HO[r * lq + k], O[c * lq + k], acc);
+        X[r * lq + c] = w2 * acc;
+      }
+      CDKF_WG_FOR(r, m) {
+        R sv = 0;
+        if (hsel) {
+          sv = mm[r];
+        } else {
+          for (int k = 0; k < d; ++k) sv = rfma(Hl[r * lq + k], mm[k], sv);
+          sv += hb[r];
+        }
+        v[r] = yl[r] - sv;
+      }
+    } else if (hsel) {
       CDKF_WG_FOR(e, m * m) {
         const int r = fdiv(e, m), c = e - r * m;
         S[r * lq + c] = P[r * lq + c] + Rm[e];
@@ -728,10 +864,10 @@ __device__ void wg_ekf_update(const WgArgs<R>& a, const WgLds<R>& L, const R* __
       if (r == c) s += R(1e-9);
       L2[r * lq + c] = s;
     }
-    CDKF_WG_FOR(e, m * d) {
-      const int r = fdiv(e, d), c = e - r * d;
-      X[r * lq + c] = HP[r * lq + c];
-    }
+    if (!ukf) CDKF_WG_FOR(e, m * d) {
+        const int r = fdiv(e, d), c = e - r * d;
+        X[r * lq + c] = HP[r * lq + c];
+      }
     wg_cholesky2(it == 0 ? L1 : (R*)L2, it == 0 ? inv1 : inv2, it == 0 ? L2 : (R*)nullptr, inv2, m, lq, bad);
     if (it == 0) {
       // z = L1^-1 v and the log-likelihood term: one wavefront, lane r keeps v_r in a register
@@ -783,8 +919,8 @@ __device__ void wg_ekf_update(const WgArgs<R>& a, const WgLds<R>& L, const R* __
     CDKF_WG_FOR(i, d) mm[i] = tmp[i];
     __syncthreads();
   }
-  // symmetrize (dynamax/utils/utils.py:209-211)
-  CDKF_WG_FOR(e, d * d) {
+  // symmetrize (dynamax/utils/utils.py:209-211); the reference's UKF does not
+  if (!ukf) CDKF_WG_FOR(e, d * d) {
     const int i = fdiv(e, d), j = e - i * d;
     if (i < j) {
       const R s = R(0.5) * (P[i * lq + j] + P[j * lq + i]);
@@ -817,7 +953,7 @@ __device__ __forceinline__ void wg_store(const WgArgs<R>& a, const WgLds<R>& L, 
 template <typename R, int EPT>
 __global__ __launch_bounds__(512) void ekf_filter_wg_kernel(const WgArgs<R> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const WgPlan plan = wg_plan(a.kind, a.d, a.h1, a.h2, a.hsel, false);
+  const WgPlan plan = wg_plan(a.kind, a.d, a.h1, a.h2, a.hsel, false, a.ukf != 0);
   WgLds<R> L(reinterpret_cast<R*>(smem_raw), a.q, a.lq, plan);
   __shared__ int bad;
   __shared__ double ll;
@@ -842,8 +978,13 @@ __global__ __launch_bounds__(512) void ekf_filter_wg_kernel(const WgArgs<R> a) {
   const R* yp = a.y + n * a.y_sn;
   R* yl = L.vec(8);
   int st = 0;
-  const bool zeroth = a.order == 0;
-  auto rhs = [&](const R* ms, const R* Ps, R& kM, R (&kP)[EPT]) { wg_rhs_ekf<R, EPT>(a, L, own, ms, Ps, kM, kP, zeroth); };
+  const bool zeroth = (a.order == 0) && !a.ukf;
+  auto rhs = [&](const R* ms, const R* Ps, R& kM, R (&kP)[EPT]) {
+    if (a.ukf)
+      wg_rhs_ukf<R, EPT>(a, L, own, ms, Ps, kM, kP, &bad);
+    else
+      wg_rhs_ekf<R, EPT>(a, L, own, ms, Ps, kM, kP, zeroth);
+  };
   for (long k = 0; k < a.T; ++k) {
     CDKF_WG_FOR(r, m) yl[r] = yp[k * a.y_sk + r * a.y_si];
     const R t0 = tp[k * a.t_sk];

@@ -45,7 +45,7 @@ template int launch_ekf_smoother<double>(const cdkf_model*, const cdkf_opts*, in
 
 bool kernel_available(const cdkf_model* mdl, const cdkf_opts*, int algo, int bytes_per_real) {
   if (reg_shape_available(mdl)) return true;
-  return algo != 1 && wg_shape_available(mdl, bytes_per_real);  // no workgroup UKF yet
+  return wg_shape_available(mdl, bytes_per_real);
 }
 
 }  // namespace cdkf

@@ -21,9 +21,7 @@ int launch_ukf_filter(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int6
     return run_ukf_reg<R, D_, M_, DRIFT<R, D_>>(mdl, o, N, T, t, y, ll, fm, fP, pm, pP, status, stream);
   CDKF_REG_SHAPES(X)
 #undef X
-  set_error("UKF filter: no kernel for drift_kind=%d state_dim=%d emission_dim=%d", mdl->drift_kind, mdl->state_dim,
-            mdl->emission_dim);
-  return CDKF_EUNSUPPORTED;
+  return launch_ukf_filter_wg<R>(mdl, o, N, T, t, y, ll, fm, fP, pm, pP, status, stream);
 }
 
 template int launch_ukf_filter<float>(const cdkf_model*, const cdkf_opts*, int64_t, int64_t, const float*, const float*,

@@ -12,10 +12,10 @@ static constexpr size_t kLdsLimit = 160 * 1024;
 static int wg_hsel(const cdkf_model* mdl) { return emission_is_selection(mdl) ? 1 : 0; }
 
 template <typename R>
-static size_t wg_lds_bytes(const cdkf_model* mdl, bool smoother) {
+static size_t wg_lds_bytes(const cdkf_model* mdl, bool smoother, bool ukf = false) {
   const int q = mdl->state_dim > mdl->emission_dim ? mdl->state_dim : mdl->emission_dim;
   const int lq = ((q + 3) & ~3) + 1;
-  const WgPlan plan = wg_plan(mdl->drift_kind, mdl->state_dim, mdl->hidden1, mdl->hidden2, wg_hsel(mdl), smoother);
+  const WgPlan plan = wg_plan(mdl->drift_kind, mdl->state_dim, mdl->hidden1, mdl->hidden2, wg_hsel(mdl), smoother, ukf);
   return sizeof(R) * (size_t)wg_lds_reals(plan, q, lq) + 64;
 }
 
@@ -139,6 +139,14 @@ static int wg_prepare(WgArgs<R>& a, R** dev_block, ParamSlot** slot_out, const c
   a.h2 = mdl->hidden2;
   a.hsel = wg_hsel(mdl);
   a.forecast = o->forecast;
+  a.ukf = 0;
+  {  // UKF weights in the compute type (inference_ukf.py:42, 63-89)
+    const R alpha = R(o->ukf_alpha), nn = R(d);
+    const R lamb = alpha * alpha * (nn + R(o->ukf_kappa)) - nn;
+    a.ukf_c = std::sqrt(nn + lamb);
+    a.ukf_wm0 = lamb / (nn + lamb);
+    a.ukf_wi = R(1) / (R(2) * (nn + lamb));
+  }
   a.q = d > m ? d : m;
   a.lq = ((a.q + 3) & ~3) + 1;  // multiple of 4 (1x4 strips stay inside a row) plus 1 (odd: column walks hit 32 different LDS banks)
   a.order = o->state_order;
@@ -228,7 +236,7 @@ static int launch_wg_pair(const WgArgs<R>& a, bool filter, bool smoother, int th
 template <typename R>
 static int launch_wg_dispatch(const WgArgs<R>& a, const cdkf_model* mdl, bool smoother, hipStream_t stream) {
   const int threads = wg_threads(mdl);
-  const size_t lds_f = wg_lds_bytes<R>(mdl, false), lds_s = wg_lds_bytes<R>(mdl, true);
+  const size_t lds_f = wg_lds_bytes<R>(mdl, false, a.ukf != 0), lds_s = wg_lds_bytes<R>(mdl, true);
   switch (wg_ept(a.d, threads)) {
     case 1: return launch_wg_pair<R, 1>(a, true, smoother, threads, lds_f, lds_s, stream);
     case 2: return launch_wg_pair<R, 2>(a, true, smoother, threads, lds_f, lds_s, stream);
@@ -289,8 +297,31 @@ int launch_ekf_smoother_wg(const cdkf_model* mdl, const cdkf_opts* o, int64_t N,
   return rc ? rc : rc2;
 }
 
+template <typename R>
+int launch_ukf_filter_wg(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll,
+                         R* fm, R* fP, R* pm, R* pP, int32_t* status, hipStream_t stream) {
+  if (wg_lds_bytes<R>(mdl, false, true) > kLdsLimit - 256) {
+    set_error("UKF: state_dim %d does not fit the workgroup kernel's LDS plan", mdl->state_dim);
+    return CDKF_EUNSUPPORTED;
+  }
+  WgArgs<R> a{};
+  R* blk = nullptr;
+  ParamSlot* slot = nullptr;
+  int rc = wg_prepare(a, &blk, &slot, mdl, o, N, T, stream);
+  if (rc) return rc;
+  a.ukf = 1;
+  a.num_iter = 1;
+  a.t = t; a.y = y; a.ll = ll; a.fm = fm; a.fP = fP; a.pm = pm; a.pP = pP; a.status = status;
+  if (!y) { a.y = t; a.y_sn = a.y_sk = a.y_si = 0; }
+  rc = launch_wg_dispatch<R>(a, mdl, false, stream);
+  const int rc2 = param_pool_release(slot, stream);
+  return rc ? rc : rc2;
+}
+
 #define INST(R)                                                                                                        \
   template int launch_ekf_filter_wg<R>(const cdkf_model*, const cdkf_opts*, int64_t, int64_t, const R*, const R*, R*,  \
+                                       R*, R*, R*, R*, int32_t*, hipStream_t);                                         \
+  template int launch_ukf_filter_wg<R>(const cdkf_model*, const cdkf_opts*, int64_t, int64_t, const R*, const R*, R*,  \
                                        R*, R*, R*, R*, int32_t*, hipStream_t);                                         \
   template int launch_ekf_smoother_wg<R>(const cdkf_model*, const cdkf_opts*, int64_t, int64_t, const R*, const R*,    \
                                          R*, R*, R*, R*, R*, int32_t*, hipStream_t);

@@ -81,8 +81,7 @@ def test_linear_models_beyond_register_shapes(hip_lib, d, m):
     _check(cd.cdnlgssm_filter(P, y, t[..., None]), o.ekf_filter(mdl, t, y), 1e-9)
     ref = o.ekf_smoother(mdl, t, y)
     assert relerr(cd.cdnlgssm_smoother(P, y, t[..., None]).smoothed_covariances, ref["smoothed_covariances"]) < 1e-8
-    with pytest.raises(Exception):  # no workgroup UKF yet: refused loudly, not approximated
-        cd.cdnlgssm_filter(P, y, t[..., None], cd.UKFHyperParams())
+    _check(cd.cdnlgssm_filter(P, y, t[..., None], cd.UKFHyperParams()), o.ukf_filter(mdl, t, y), 1e-8)
 
 
 def test_wg_and_reg_kernels_agree_on_shared_shape(hip_lib):
@@ -112,3 +111,26 @@ def test_wide_golden_vectors(hip_lib, name):
     sm = cd.cdnlgssm_smoother(P, y, t, cd.EKFHyperParams(state_order=orders[-1]))
     assert relerr(sm.smoothed_means, g["eks_smoothed_means"]) < 1e-8
     assert relerr(sm.smoothed_covariances[:, 0], g["eks_smoothed_cov_first"]) < 1e-8
+
+
+@pytest.mark.parametrize("case", ["l96_6_3", "l96_12_12", "l96_40_40", "mlp_8_4"])
+def test_unscented_filter_on_workgroup_kernels(hip_lib, case):
+    """unscented_kalman_filter (inference_ukf.py:206-308) beyond the register shapes: banded Lorenz-96 fast path, the
+    generic one-drift-per-sigma-point path (MLP), general and selection emissions, fp64 and fp32."""
+    rng = np.random.default_rng(abs(hash(case)) % 997)
+    if case.startswith("l96"):
+        _, d, m = case.split("_")
+        mdl = lorenz96_model(int(d), int(m))
+        N, T = (2, 12) if int(d) == 40 else (4, 25)
+    else:
+        mdl = mlp_model(rng, 8, 4, 16)
+        N, T = 3, 15
+    t = o.irregular_times(rng, N, T, 0.012 * T)
+    y = o.simulate(mdl, t, rng)
+    P = params_from(mdl)
+    ref = o.ukf_filter(mdl, t, y)
+    _check(cd.cdnlgssm_filter(P, y, t[..., None], cd.UKFHyperParams()), ref, 1e-8)
+    ref2 = o.ukf_filter(mdl, t, y, alpha=1.1, beta=1.0, kappa=0.5)
+    _check(cd.cdnlgssm_filter(P, y, t[..., None], cd.UKFHyperParams(alpha=1.1, beta=1.0, kappa=0.5)), ref2, 1e-8)
+    post32 = cd.cdnlgssm_filter(P, y.astype(np.float32), t[..., None], cd.UKFHyperParams())
+    assert relerr(post32.filtered_means, ref["filtered_means"]) < 5e-4
