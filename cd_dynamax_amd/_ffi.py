@@ -86,7 +86,8 @@ SYMBOLS = (
     ["cdkf_default_opts", "cdkf_version", "cdkf_last_error", "cdkf_device_count", "cdkf_supported",
      "cdkf_preferred_layout", "cdkf_malloc",
      "cdkf_free", "cdkf_memcpy_h2d", "cdkf_memcpy_d2h", "cdkf_memset", "cdkf_synchronize", "cdkf_ll_sum_f64_dev",
-     "cdkf_ll_sum_f32_dev"]
+     "cdkf_ll_sum_f32_dev", "cdkf_emission_moments_f64", "cdkf_emission_moments_f32", "cdkf_emission_moments_f64_dev",
+     "cdkf_emission_moments_f32_dev"]
     + [f"cdkf_{a}_{p}{s}" for a in _ALGOS for p in ("f64", "f32") for s in ("", "_dev")]
 )
 
@@ -122,6 +123,13 @@ def lib() -> C.CDLL:
     for name in ("cdkf_ll_sum_f64_dev", "cdkf_ll_sum_f32_dev"):
         getattr(L, name).argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
         getattr(L, name).restype = C.c_int
+    for p in ("f64", "f32"):
+        f = getattr(L, f"cdkf_emission_moments_{p}")
+        f.argtypes = [C.POINTER(CdkfModel), C.c_int64] + [C.c_void_p] * 4
+        f.restype = C.c_int
+        f = getattr(L, f"cdkf_emission_moments_{p}_dev")
+        f.argtypes = [C.POINTER(CdkfModel), C.c_int64] + [C.c_void_p] * 5
+        f.restype = C.c_int
     for a in _ALGOS:
         for p in ("f64", "f32"):
             base = [C.POINTER(CdkfModel), C.POINTER(CdkfOpts), C.c_int64, C.c_int64] + [C.c_void_p] * 8
@@ -200,3 +208,18 @@ def run_host(algo: str, mdl: ModelBlock, opts: CdkfOpts, t: np.ndarray, y: np.nd
     check(fn(C.byref(mdl.c), C.byref(opts), N, T, _vp(t), _vp(y), _vp(ll), *[_vp(o) for o in outs], _vp(status)))
     outs = [None if o is None else (np.moveaxis(o, -1, 0) if tcn else np.swapaxes(o, 0, 1)) for o in outs]  # views
     return ll, outs, status
+
+
+def emission_moments(mdl: ModelBlock, means: np.ndarray, covs: Optional[np.ndarray], dtype):
+    """cdkf_emission_moments_<f32|f64> on host buffers: means [..., d], covs [..., d, d] or None."""
+    dtype = np.dtype(dtype)
+    suffix = {np.dtype(np.float32): "f32", np.dtype(np.float64): "f64"}[dtype]
+    d, m = mdl.state_dim, mdl.emission_dim
+    lead = means.shape[:-1]
+    mu = np.ascontiguousarray(means, dtype).reshape(-1, d)
+    rows = mu.shape[0]
+    P = None if covs is None else np.ascontiguousarray(covs, dtype).reshape(rows, d, d)
+    om = np.empty((rows, m), dtype)
+    oc = None if P is None else np.empty((rows, m, m), dtype)
+    check(getattr(lib(), f"cdkf_emission_moments_{suffix}")(C.byref(mdl.c), rows, _vp(mu), _vp(P), _vp(om), _vp(oc)))
+    return om.reshape(lead + (m,)), None if oc is None else oc.reshape(lead + (m, m))

@@ -114,6 +114,110 @@ int ll_sum_dev(const R* ll, int64_t N, double* out, void* stream) {
   return CDKF_OK;
 }
 
+// ---- emission moments: one workgroup (64 threads) per state marginal, H and the d x d covariance staged in LDS ----
+template <typename R>
+__global__ __launch_bounds__(64) void emission_moments_kernel(int d, int m, const R* __restrict__ par, long rows,
+                                                              const R* __restrict__ means, const R* __restrict__ covs,
+                                                              R* __restrict__ out_mean, R* __restrict__ out_cov) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  R* P = reinterpret_cast<R*>(smem_raw);  // [d*d]
+  R* HP = P + d * d;                      // [m*d]
+  const R* H = par;                       // [m*d]
+  const R* hb = par + m * d;              // [m]
+  const R* Rm = hb + m;                   // [m*m]
+  for (long row = blockIdx.x; row < rows; row += gridDim.x) {
+    const R* mu = means + row * d;
+    for (int r = threadIdx.x; r < m; r += 64) {
+      R s = hb[r];
+      for (int k = 0; k < d; ++k) s = rfma(H[r * d + k], mu[k], s);
+      out_mean[row * m + r] = s;
+    }
+    if (covs && out_cov) {
+      for (int e = threadIdx.x; e < d * d; e += 64) P[e] = covs[row * d * d + e];
+      __syncthreads();
+      for (int e = threadIdx.x; e < m * d; e += 64) {
+        const int r = e / d, j = e - r * d;
+        R s = 0;
+        for (int k = 0; k < d; ++k) s = rfma(H[r * d + k], P[k * d + j], s);
+        HP[e] = s;
+      }
+      __syncthreads();
+      for (int e = threadIdx.x; e < m * m; e += 64) {
+        const int r = e / m, c = e - r * m;
+        R s = 0;
+        for (int k = 0; k < d; ++k) s = rfma(HP[r * d + k], H[c * d + k], s);
+        out_cov[row * m * m + e] = s + Rm[e];
+      }
+      __syncthreads();
+    }
+  }
+}
+
+template <typename R>
+int emission_moments_dev(const cdkf_model* mdl, int64_t rows, const R* means, const R* covs, R* out_mean, R* out_cov,
+                         hipStream_t stream) {
+  if (!mdl || !mdl->H || !mdl->h_bias || !mdl->R || rows < 0 || (rows > 0 && (!means || !out_mean))) {
+    set_error("emission_moments: bad arguments");
+    return CDKF_EINVAL;
+  }
+  if (rows == 0) return CDKF_OK;
+  const int d = mdl->state_dim, m = mdl->emission_dim;
+  if (d < 1 || m < 1 || (size_t)(d * d + m * d) * sizeof(R) > 150 * 1024) {
+    set_error("emission_moments: unsupported dimensions d=%d m=%d", d, m);
+    return CDKF_EUNSUPPORTED;
+  }
+  std::vector<R> h;
+  for (int i = 0; i < m * d; ++i) h.push_back(R(mdl->H[i]));
+  for (int i = 0; i < m; ++i) h.push_back(R(mdl->h_bias[i]));
+  for (int i = 0; i < m * m; ++i) h.push_back(R(mdl->R[i]));
+  R* par = nullptr;  // small, synchronous upload: this entry point is not on the sweep path
+  CDKF_HIP_CHECK(hipMalloc((void**)&par, h.size() * sizeof(R)));
+  hipError_t e = hipMemcpy(par, h.data(), h.size() * sizeof(R), hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    const size_t lds = (size_t)(d * d + m * d) * sizeof(R);
+    if (lds > 48 * 1024)
+      e = hipFuncSetAttribute((const void*)emission_moments_kernel<R>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+    if (e == hipSuccess) {
+      const unsigned blocks = (unsigned)(rows < 65536 ? rows : 65536);
+      hipLaunchKernelGGL(emission_moments_kernel<R>, dim3(blocks), dim3(64), lds, stream, d, m, (const R*)par, (long)rows, means,
+                         covs, out_mean, out_cov);
+      e = hipGetLastError();
+      if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    }
+  }
+  (void)hipFree(par);
+  if (e != hipSuccess) {
+    set_error("emission_moments failed: %s", hipGetErrorString(e));
+    return CDKF_EHIP;
+  }
+  return CDKF_OK;
+}
+
+template <typename R>
+int emission_moments_host(const cdkf_model* mdl, int64_t rows, const R* means, const R* covs, R* out_mean, R* out_cov) {
+  if (!mdl || rows < 0 || (rows > 0 && (!means || !out_mean))) {
+    set_error("emission_moments: bad arguments");
+    return CDKF_EINVAL;
+  }
+  if (rows == 0) return CDKF_OK;
+  const size_t d = mdl->state_dim, m = mdl->emission_dim;
+  DevBuf dm, dP, om, oP;
+  int rc;
+  if ((rc = dm.alloc(rows * d * sizeof(R))) || (rc = om.alloc(rows * m * sizeof(R)))) return rc;
+  CDKF_HIP_CHECK(hipMemcpy(dm.p, means, rows * d * sizeof(R), hipMemcpyHostToDevice));
+  const bool with_cov = covs && out_cov;
+  if (with_cov) {
+    if ((rc = dP.alloc(rows * d * d * sizeof(R))) || (rc = oP.alloc(rows * m * m * sizeof(R)))) return rc;
+    CDKF_HIP_CHECK(hipMemcpy(dP.p, covs, rows * d * d * sizeof(R), hipMemcpyHostToDevice));
+  }
+  rc = emission_moments_dev<R>(mdl, rows, (const R*)dm.p, with_cov ? (const R*)dP.p : nullptr, (R*)om.p,
+                               with_cov ? (R*)oP.p : nullptr, nullptr);
+  if (rc) return rc;
+  CDKF_HIP_CHECK(hipMemcpy(out_mean, om.p, rows * m * sizeof(R), hipMemcpyDeviceToHost));
+  if (with_cov) CDKF_HIP_CHECK(hipMemcpy(out_cov, oP.p, rows * m * m * sizeof(R), hipMemcpyDeviceToHost));
+  return CDKF_OK;
+}
+
 }  // namespace cdkf
 
 using namespace cdkf;
@@ -224,6 +328,23 @@ CDKF_DEFINE_ALGO(ukf_filter, f64, double, launch_ukf_filter)
 CDKF_DEFINE_ALGO(ukf_filter, f32, float, launch_ukf_filter)
 CDKF_DEFINE_ALGO(ekf_smoother, f64, double, launch_ekf_smoother)
 CDKF_DEFINE_ALGO(ekf_smoother, f32, float, launch_ekf_smoother)
+
+int cdkf_emission_moments_f64(const cdkf_model* mdl, int64_t rows, const double* means, const double* covs, double* om,
+                              double* oc) {
+  return emission_moments_host<double>(mdl, rows, means, covs, om, oc);
+}
+int cdkf_emission_moments_f32(const cdkf_model* mdl, int64_t rows, const float* means, const float* covs, float* om,
+                              float* oc) {
+  return emission_moments_host<float>(mdl, rows, means, covs, om, oc);
+}
+int cdkf_emission_moments_f64_dev(const cdkf_model* mdl, int64_t rows, const double* means, const double* covs,
+                                  double* om, double* oc, void* stream) {
+  return emission_moments_dev<double>(mdl, rows, means, covs, om, oc, (hipStream_t)stream);
+}
+int cdkf_emission_moments_f32_dev(const cdkf_model* mdl, int64_t rows, const float* means, const float* covs, float* om,
+                                  float* oc, void* stream) {
+  return emission_moments_dev<float>(mdl, rows, means, covs, om, oc, (hipStream_t)stream);
+}
 
 int cdkf_ll_sum_f64_dev(const double* ll, int64_t N, double* out, void* stream) {
   return ll_sum_dev<double>(ll, N, out, stream);

@@ -227,6 +227,24 @@ def cdnlgssm_forecast(
     return GSSMForecast(forecasted_state_means=fm, forecasted_state_covariances=fP)
 
 
+def cdnlgssm_emissions(params: ParamsCDNLGSSM, t_states, state_means, state_covs=None, inputs=None, hyperparams=None,
+                       key=None, dtype=None):
+    """Emission moments of Gaussian state marginals (reference: models.py:939-1047 ->
+    emissions_extended_kalman_filter inference_ekf.py:768-855 / emissions_unscented_kalman_filter
+    inference_ukf.py:507-612): ``(H m + b, H P H^T + R)`` per time point; with ``state_covs=None`` the states are point
+    estimates and only the means are returned (second element None).  For the registry's linear emission the EKF and
+    UKF versions coincide, so ``hyperparams`` only selects nothing; ``t_states`` is accepted for signature parity."""
+    if t_states is None:
+        raise ValueError("t_states must be provided for forecasting")
+    if isinstance(hyperparams, EnKFHyperParams):
+        raise NotImplementedError("ensemble emissions are stochastic and not part of the HIP path")
+    mu = np.asarray(state_means)
+    if dtype is None:
+        dtype = np.float32 if mu.dtype == np.float32 else np.float64
+    mdl = _model_block(params)
+    return _ffi.emission_moments(mdl, mu, None if state_covs is None else np.asarray(state_covs), dtype)
+
+
 class ContDiscreteNonlinearGaussianSSM:
     """Continuous-discrete nonlinear Gaussian SSM (reference: models.py:117-408), restricted to the
     inference surface of the hot path: ``initialize``, ``marginal_log_prob``, ``filter``, ``smoother``."""

@@ -194,6 +194,20 @@ int cdkf_ekf_smoother_f32_dev(const cdkf_model* mdl, const cdkf_opts* opts, int6
                               float* filtered_covs, float* smoothed_means, float* smoothed_covs,
                               int32_t* status, void* stream);
 
+/* ---- emission moments of Gaussian state marginals: replaces emissions_extended_kalman_filter /
+ *      emissions_unscented_kalman_filter (inference_ekf.py:768-855, inference_ukf.py:507-612; identical for the
+ *      linear emission of the registry): out_mean[r] = H mean[r] + h_bias, out_cov[r] = H cov[r] H^T + R.
+ *      `rows` state marginals stored contiguously: means [rows,d], covs [rows,d,d] (NULL: point estimates, out_cov is
+ *      then not written), out_mean [rows,m], out_cov [rows,m,m]. ---------------------------------------------- */
+int cdkf_emission_moments_f64(const cdkf_model* mdl, int64_t rows, const double* means, const double* covs,
+                              double* out_mean, double* out_cov);
+int cdkf_emission_moments_f32(const cdkf_model* mdl, int64_t rows, const float* means, const float* covs,
+                              float* out_mean, float* out_cov);
+int cdkf_emission_moments_f64_dev(const cdkf_model* mdl, int64_t rows, const double* means, const double* covs,
+                                  double* out_mean, double* out_cov, void* stream);
+int cdkf_emission_moments_f32_dev(const cdkf_model* mdl, int64_t rows, const float* means, const float* covs,
+                                  float* out_mean, float* out_cov, void* stream);
+
 /* ---- sum_n ll[n]: the reduction of src/ssm_temissions.py:567 (`vmap(...)(...).sum()`), done on
  *      the device so that the multi-GPU caller can all-reduce ONE scalar over RCCL. ------------- */
 int cdkf_ll_sum_f64_dev(const double* ll, int64_t N, double* out_sum, void* stream);

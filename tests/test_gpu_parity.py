@@ -360,3 +360,23 @@ def test_forecast_matches_repeated_predict(hip_lib):
             assert relerr(fc.forecasted_state_covariances, ref_P[0]) < 1e-8
     with pytest.raises(ValueError, match="t_forecast"):
         cd.cdnlgssm_forecast(P, (m_init, P_init), np.array([[t_init]]))
+
+
+def test_emission_moments(hip_lib):
+    """cdnlgssm_emissions (reference: models.py:939-1047 -> emissions_extended_kalman_filter, inference_ekf.py:768-855):
+    (H m + b, H P H^T + R) for every state marginal, small and large dimensions, with and without covariances."""
+    rng = np.random.default_rng(21)
+    for d, m in ((3, 1), (4, 2), (40, 17)):
+        mdl = linear_model(rng, d, m)
+        P = params_from(mdl)
+        mu = rng.standard_normal((5, 7, d))
+        A = rng.standard_normal((5, 7, d, d))
+        cov = A @ np.swapaxes(A, -1, -2)
+        em, ec = cd.cdnlgssm_emissions(P, np.zeros((7, 1)), mu, cov)
+        np.testing.assert_allclose(em, mu @ mdl.H.T + mdl.bias, rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(ec, mdl.H @ cov @ mdl.H.T + mdl.R, rtol=1e-11, atol=1e-11)
+        em2, ec2 = cd.cdnlgssm_emissions(P, np.zeros((7, 1)), mu[0])
+        assert ec2 is None
+        np.testing.assert_allclose(em2, em[0], rtol=1e-12, atol=1e-12)
+        em32, ec32 = cd.cdnlgssm_emissions(P, np.zeros((7, 1)), mu.astype(np.float32), cov.astype(np.float32))
+        assert em32.dtype == np.float32 and relerr(ec32, ec) < 1e-5
