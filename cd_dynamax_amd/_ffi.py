@@ -87,7 +87,9 @@ SYMBOLS = (
      "cdkf_preferred_layout", "cdkf_malloc",
      "cdkf_free", "cdkf_memcpy_h2d", "cdkf_memcpy_d2h", "cdkf_memset", "cdkf_synchronize", "cdkf_ll_sum_f64_dev",
      "cdkf_ll_sum_f32_dev", "cdkf_emission_moments_f64", "cdkf_emission_moments_f32", "cdkf_emission_moments_f64_dev",
-     "cdkf_emission_moments_f32_dev"]
+     "cdkf_emission_moments_f32_dev", "cdkf_ekf_loglik_grad_f64", "cdkf_ekf_loglik_grad_f32",
+     "cdkf_ekf_loglik_grad_f64_dev", "cdkf_ekf_loglik_grad_f32_dev", "cdkf_grad_supported", "cdkf_grad_sum_f64_dev",
+     "cdkf_grad_sum_f32_dev"]
     + [f"cdkf_{a}_{p}{s}" for a in _ALGOS for p in ("f64", "f32") for s in ("", "_dev")]
 )
 
@@ -129,6 +131,19 @@ def lib() -> C.CDLL:
         f.restype = C.c_int
         f = getattr(L, f"cdkf_emission_moments_{p}_dev")
         f.argtypes = [C.POINTER(CdkfModel), C.c_int64] + [C.c_void_p] * 5
+        f.restype = C.c_int
+    L.cdkf_grad_supported.argtypes = [C.POINTER(CdkfModel), C.POINTER(CdkfOpts)]
+    L.cdkf_grad_supported.restype = C.c_int
+    for p in ("f64", "f32"):
+        base = [C.POINTER(CdkfModel), C.POINTER(CdkfOpts), C.c_int64, C.c_int64] + [C.c_void_p] * 5
+        f = getattr(L, f"cdkf_ekf_loglik_grad_{p}")
+        f.argtypes = base
+        f.restype = C.c_int
+        f = getattr(L, f"cdkf_ekf_loglik_grad_{p}_dev")
+        f.argtypes = base + [C.c_void_p]
+        f.restype = C.c_int
+        f = getattr(L, f"cdkf_grad_sum_{p}_dev")
+        f.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
         f.restype = C.c_int
     for a in _ALGOS:
         for p in ("f64", "f32"):
@@ -208,6 +223,23 @@ def run_host(algo: str, mdl: ModelBlock, opts: CdkfOpts, t: np.ndarray, y: np.nd
     check(fn(C.byref(mdl.c), C.byref(opts), N, T, _vp(t), _vp(y), _vp(ll), *[_vp(o) for o in outs], _vp(status)))
     outs = [None if o is None else (np.moveaxis(o, -1, 0) if tcn else np.swapaxes(o, 0, 1)) for o in outs]  # views
     return ll, outs, status
+
+
+def loglik_grad(mdl: ModelBlock, opts: CdkfOpts, t: np.ndarray, y: np.ndarray, dtype):
+    """cdkf_ekf_loglik_grad_<f32|f64> on host buffers (t [N,T] or [T], y [N,T,m]): returns (ll [N], grad [N, n_theta], status)."""
+    dtype = np.dtype(dtype)
+    suffix = {np.dtype(np.float32): "f32", np.dtype(np.float64): "f64"}[dtype]
+    N, T, m = y.shape
+    opts.layout = LAYOUT_TCN  # the gradient kernels are lane-per-(trajectory, parameter): coalesced in [T,w,N]
+    t = np.asarray(t, dtype=dtype)
+    t = np.ascontiguousarray(t if opts.t_shared else t.T)
+    y = np.ascontiguousarray(np.asarray(y, dtype=dtype).transpose(1, 2, 0))
+    ll = np.empty((N,), dtype)
+    grad = np.empty((N, mdl.theta.size), dtype)
+    status = np.zeros((N,), np.int32)
+    fn = getattr(lib(), f"cdkf_ekf_loglik_grad_{suffix}")
+    check(fn(C.byref(mdl.c), C.byref(opts), N, T, _vp(t), _vp(y), _vp(ll), _vp(grad), _vp(status)))
+    return ll, grad, status
 
 
 def emission_moments(mdl: ModelBlock, means: np.ndarray, covs: Optional[np.ndarray], dtype):

@@ -114,6 +114,73 @@ int ll_sum_dev(const R* ll, int64_t N, double* out, void* stream) {
   return CDKF_OK;
 }
 
+// ---- column sums of the per-trajectory gradient [N, P]: one workgroup per parameter ---------------------------
+template <typename R>
+__global__ __launch_bounds__(256) void grad_sum_kernel(const R* __restrict__ g, long N, int P, double* __restrict__ out) {
+  __shared__ double part[4];
+  const int p = blockIdx.x;
+  double s = 0.0;
+  for (long i = threadIdx.x; i < N; i += 256) s += (double)g[i * P + p];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[p] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
+template <typename R>
+int grad_sum_dev(const R* g, int64_t N, int64_t P, double* out, void* stream) {
+  if (!g || !out || N < 0 || P < 1) {
+    set_error("grad_sum: bad arguments");
+    return CDKF_EINVAL;
+  }
+  hipLaunchKernelGGL(grad_sum_kernel<R>, dim3((unsigned)P), dim3(256), 0, (hipStream_t)stream, g, (long)N, (int)P, out);
+  CDKF_HIP_CHECK(hipGetLastError());
+  return CDKF_OK;
+}
+
+template <typename R>
+int loglik_grad_dev(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll,
+                    R* grad, int32_t* status, void* stream) {
+  int rc = check_common(mdl, o, N, T, t, y, ll);
+  if (rc) return rc;
+  if (!grad) {
+    set_error("loglik_grad: grad must not be NULL");
+    return CDKF_EINVAL;
+  }
+  if (N == 0) return CDKF_OK;
+  if ((rc = select_device(o))) return rc;
+  return launch_ekf_grad<R>(mdl, o, N, T, t, y, ll, grad, status, (hipStream_t)stream);
+}
+
+template <typename R>
+int loglik_grad_host(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll,
+                     R* grad, int32_t* status) {
+  int rc = check_common(mdl, o, N, T, t, y, ll);
+  if (rc) return rc;
+  if (!grad) {
+    set_error("loglik_grad: grad must not be NULL");
+    return CDKF_EINVAL;
+  }
+  if (N == 0) return CDKF_OK;
+  if ((rc = select_device(o))) return rc;
+  const size_t nt = (size_t)(o->t_shared ? T : N * T), ny = (size_t)N * T * mdl->emission_dim;
+  const size_t ng = (size_t)N * (size_t)mdl->n_theta;
+  DevBuf dt, dy, dll, dg, dst;
+  if ((rc = dt.alloc(nt * sizeof(R))) || (rc = dy.alloc(ny * sizeof(R))) || (rc = dll.alloc(N * sizeof(R))) ||
+      (rc = dg.alloc(ng * sizeof(R))) || (rc = dst.alloc(N * sizeof(int32_t))))
+    return rc;
+  CDKF_HIP_CHECK(hipMemcpy(dt.p, t, nt * sizeof(R), hipMemcpyHostToDevice));
+  CDKF_HIP_CHECK(hipMemcpy(dy.p, y, ny * sizeof(R), hipMemcpyHostToDevice));
+  rc = launch_ekf_grad<R>(mdl, o, N, T, (const R*)dt.p, (const R*)dy.p, (R*)dll.p, (R*)dg.p, (int32_t*)dst.p, nullptr);
+  if (rc) return rc;
+  CDKF_HIP_CHECK(hipDeviceSynchronize());
+  CDKF_HIP_CHECK(hipMemcpy(ll, dll.p, N * sizeof(R), hipMemcpyDeviceToHost));
+  CDKF_HIP_CHECK(hipMemcpy(grad, dg.p, ng * sizeof(R), hipMemcpyDeviceToHost));
+  if (status) CDKF_HIP_CHECK(hipMemcpy(status, dst.p, N * sizeof(int32_t), hipMemcpyDeviceToHost));
+  return CDKF_OK;
+}
+
 // ---- emission moments: one workgroup (64 threads) per state marginal, H and the d x d covariance staged in LDS ----
 template <typename R>
 __global__ __launch_bounds__(64) void emission_moments_kernel(int d, int m, const R* __restrict__ par, long rows,
@@ -344,6 +411,32 @@ int cdkf_emission_moments_f64_dev(const cdkf_model* mdl, int64_t rows, const dou
 int cdkf_emission_moments_f32_dev(const cdkf_model* mdl, int64_t rows, const float* means, const float* covs, float* om,
                                   float* oc, void* stream) {
   return emission_moments_dev<float>(mdl, rows, means, covs, om, oc, (hipStream_t)stream);
+}
+
+int cdkf_ekf_loglik_grad_f64(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const double* t,
+                             const double* y, double* ll, double* grad, int32_t* status) {
+  return loglik_grad_host<double>(mdl, o, N, T, t, y, ll, grad, status);
+}
+int cdkf_ekf_loglik_grad_f32(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const float* t,
+                             const float* y, float* ll, float* grad, int32_t* status) {
+  return loglik_grad_host<float>(mdl, o, N, T, t, y, ll, grad, status);
+}
+int cdkf_ekf_loglik_grad_f64_dev(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const double* t,
+                                 const double* y, double* ll, double* grad, int32_t* status, void* stream) {
+  return loglik_grad_dev<double>(mdl, o, N, T, t, y, ll, grad, status, stream);
+}
+int cdkf_ekf_loglik_grad_f32_dev(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const float* t,
+                                 const float* y, float* ll, float* grad, int32_t* status, void* stream) {
+  return loglik_grad_dev<float>(mdl, o, N, T, t, y, ll, grad, status, stream);
+}
+int cdkf_grad_supported(const cdkf_model* mdl, const cdkf_opts* o) {
+  return (mdl && o && grad_shape_available(mdl, o)) ? 1 : 0;
+}
+int cdkf_grad_sum_f64_dev(const double* grad, int64_t N, int64_t n_theta, double* out, void* stream) {
+  return grad_sum_dev<double>(grad, N, n_theta, out, stream);
+}
+int cdkf_grad_sum_f32_dev(const float* grad, int64_t N, int64_t n_theta, double* out, void* stream) {
+  return grad_sum_dev<float>(grad, N, n_theta, out, stream);
 }
 
 int cdkf_ll_sum_f64_dev(const double* ll, int64_t N, double* out, void* stream) {

@@ -30,6 +30,12 @@ template <typename R>
 int launch_ekf_smoother(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y,
                         R* ll, R* fm, R* fP, R* sm, R* sP, int32_t* status, hipStream_t stream);
 
+// log-likelihood + gradient w.r.t. the drift parameters (launch_grad.hip); grad [N, n_theta]
+template <typename R>
+int launch_ekf_grad(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll,
+                    R* grad, int32_t* status, hipStream_t stream);
+bool grad_shape_available(const cdkf_model* mdl, const cdkf_opts* o);
+
 bool kernel_available(const cdkf_model* mdl, const cdkf_opts* o, int algo, int bytes_per_real);
 
 // workgroup-per-trajectory kernels (launch_wg.hip): any registry drift, d and m up to what fits 160 KB of LDS

@@ -1,0 +1,60 @@
+// launch_grad.hip -- log-likelihood + gradient w.r.t. the drift parameters (cdkf_grad_kernels.h): shape registry and launch.
+#include "cdkf_grad_kernels.h"
+#include "cdkf_launch.h"
+
+// X(drift_kind, DriftTemplate, D, M)
+#define CDKF_GRAD_SHAPES(X)                   \
+  X(CDKF_DRIFT_LORENZ63, DriftLorenz63, 3, 1) \
+  X(CDKF_DRIFT_LORENZ63, DriftLorenz63, 3, 2) \
+  X(CDKF_DRIFT_LORENZ63, DriftLorenz63, 3, 3) \
+  X(CDKF_DRIFT_LINEAR, DriftLinear, 1, 1)     \
+  X(CDKF_DRIFT_LINEAR, DriftLinear, 2, 1)     \
+  X(CDKF_DRIFT_LINEAR, DriftLinear, 2, 2)     \
+  X(CDKF_DRIFT_LINEAR, DriftLinear, 3, 3)
+
+namespace cdkf {
+
+bool grad_shape_available(const cdkf_model* mdl, const cdkf_opts* o) {
+  if (o->state_order == CDKF_ORDER_ZEROTH || o->num_iter != 1 || o->forecast) return false;
+#define X(KIND, DRIFT, D_, M_) \
+  if (mdl->drift_kind == KIND && mdl->state_dim == D_ && mdl->emission_dim == M_) return true;
+  CDKF_GRAD_SHAPES(X)
+#undef X
+  return false;
+}
+
+template <typename R, int D, int M, typename Drift>
+static int run_grad(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll,
+                    R* grad, int32_t* status, hipStream_t stream) {
+  GradArgs<R, D, M, Drift> ga;
+  fill_reg_args(ga.a, mdl, o, N, T, t, y, ll, (R*)nullptr, (R*)nullptr, (R*)nullptr, (R*)nullptr, status);
+  ga.grad = grad;
+  const long lanes = (long)N * DriftGrad<R, D, Drift>::NPAR;
+  hipLaunchKernelGGL((ekf_grad_reg_kernel<R, D, M, Drift>), dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, stream, ga);
+  CDKF_HIP_CHECK(hipGetLastError());
+  return CDKF_OK;
+}
+
+template <typename R>
+int launch_ekf_grad(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll,
+                    R* grad, int32_t* status, hipStream_t stream) {
+  if (!grad_shape_available(mdl, o)) {
+    set_error("loglik_grad: no kernel for drift_kind=%d state_dim=%d emission_dim=%d state_order=%d num_iter=%d "
+              "(gradients cover the register-resident Lorenz-63 / linear shapes, state_order first|second, num_iter 1)",
+              mdl->drift_kind, mdl->state_dim, mdl->emission_dim, o->state_order, o->num_iter);
+    return CDKF_EUNSUPPORTED;
+  }
+#define X(KIND, DRIFT, D_, M_)                                                    \
+  if (mdl->drift_kind == KIND && mdl->state_dim == D_ && mdl->emission_dim == M_) \
+    return run_grad<R, D_, M_, DRIFT<R, D_>>(mdl, o, N, T, t, y, ll, grad, status, stream);
+  CDKF_GRAD_SHAPES(X)
+#undef X
+  return CDKF_EUNSUPPORTED;
+}
+
+template int launch_ekf_grad<float>(const cdkf_model*, const cdkf_opts*, int64_t, int64_t, const float*, const float*,
+                                    float*, float*, int32_t*, hipStream_t);
+template int launch_ekf_grad<double>(const cdkf_model*, const cdkf_opts*, int64_t, int64_t, const double*, const double*,
+                                     double*, double*, int32_t*, hipStream_t);
+
+}  // namespace cdkf

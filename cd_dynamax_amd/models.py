@@ -171,6 +171,45 @@ def cdnlgssm_smoother(
                                  smoothed_means=sm, smoothed_covariances=sP)
 
 
+def _drift_like(drift, theta_grad):
+    """Pack a gradient array [..., n_theta] into the drift's own NamedTuple (the pytree jax.grad would return)."""
+    if isinstance(drift, LearnableLorenz63):
+        return LearnableLorenz63(sigma=theta_grad[..., 0], rho=theta_grad[..., 1], beta=theta_grad[..., 2])
+    d = np.asarray(drift.weights).shape[0]
+    return LearnableLinear(weights=theta_grad[..., : d * d].reshape(theta_grad.shape[:-1] + (d, d)),
+                           bias=theta_grad[..., d * d:])
+
+
+def cdnlgssm_loglik_and_grad(
+    params: ParamsCDNLGSSM,
+    emissions,
+    t_emissions=None,
+    hyperparams: EKFHyperParams = EKFHyperParams(),
+    inputs=None,
+    dtype=None,
+):
+    """EKF marginal log-likelihood and its gradient w.r.t. the drift parameters -- the drift block of what
+    ``jax.value_and_grad(_loss_fn)`` returns in the reference's fit_sgd (ssm_temissions.py:550-568), per trajectory and
+    un-negated / un-normalised.  Returns ``(ll, grad)``: ``ll`` as ``marginal_log_prob`` (``[N]`` for batched emissions),
+    ``grad`` an instance of the drift's class whose fields hold d ll / d field (leading ``[N]`` when batched).
+
+    Forward sensitivities inside the HIP sweep (cdkf_ekf_loglik_grad_*); drifts LearnableLorenz63 / LearnableLinear at the
+    register-resident shapes, ``state_order`` first or second.  Anything else raises (no finite-difference fallback)."""
+    if not isinstance(hyperparams, EKFHyperParams):
+        raise NotImplementedError("gradients are provided for the EKF marginal log-likelihood only")
+    mdl = _model_block(params)
+    opts = _opts(hyperparams, 1)
+    y, t, batched, dtype = _prepare(emissions, t_emissions, hyperparams, opts, dtype)
+    if not _ffi.lib().cdkf_grad_supported(_ffi.C.byref(mdl.c), _ffi.C.byref(opts)):
+        raise NotImplementedError(
+            f"no gradient kernel for drift {type(params.dynamics.drift).__name__} with state_dim={mdl.state_dim}, "
+            f"emission_dim={mdl.emission_dim}, state_order={hyperparams.state_order}")
+    ll, grad, _ = _ffi.loglik_grad(mdl, opts, t, y, dtype)
+    if not batched:
+        ll, grad = ll[0], grad[0]
+    return ll, _drift_like(params.dynamics.drift, grad)
+
+
 def cdnlgssm_forecast(
     params: ParamsCDNLGSSM,
     init_forecast,
@@ -327,6 +366,11 @@ class ContDiscreteNonlinearGaussianSSM:
         post = cdnlgssm_filter(params=params, emissions=emissions, t_emissions=t_emissions,
                                hyperparams=filter_hyperparams, inputs=inputs, output_fields=[], dtype=dtype)
         return post.marginal_loglik
+
+    def marginal_log_prob_and_grad(self, params, emissions, t_emissions=None, filter_hyperparams=EKFHyperParams(),
+                                   inputs=None, dtype=None):
+        """(marginal_log_prob, d marginal_log_prob / d drift parameters): see ``cdnlgssm_loglik_and_grad``."""
+        return cdnlgssm_loglik_and_grad(params, emissions, t_emissions, filter_hyperparams, inputs, dtype=dtype)
 
     def filter(self, params, emissions, t_emissions=None, filter_hyperparams=EKFHyperParams(), inputs=None,
                dtype=None) -> PosteriorGSSMFiltered:

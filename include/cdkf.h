@@ -208,6 +208,26 @@ int cdkf_emission_moments_f64_dev(const cdkf_model* mdl, int64_t rows, const dou
 int cdkf_emission_moments_f32_dev(const cdkf_model* mdl, int64_t rows, const float* means, const float* covs,
                                   float* out_mean, float* out_cov, void* stream);
 
+/* ---- marginal log-likelihood AND its gradient w.r.t. the drift parameters theta (ordering of cdkf_model.theta):
+ *      replaces jax.value_and_grad of the fit_sgd loss, src/ssm_temissions.py:550-568, for the drift block of
+ *      the parameters (what the Lorenz-63 parameter-estimation tutorials learn).  EKF, state_order first/second,
+ *      num_iter 1; shapes: cdkf_grad_supported().  ll [N], grad [N, n_theta] row-major whatever opts.layout is
+ *      (t and y follow opts.layout).  Exact derivative of the discretised recursion (forward sensitivities). -- */
+int cdkf_ekf_loglik_grad_f64(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T, const double* t,
+                             const double* y, double* ll, double* grad, int32_t* status);
+int cdkf_ekf_loglik_grad_f32(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T, const float* t,
+                             const float* y, float* ll, float* grad, int32_t* status);
+int cdkf_ekf_loglik_grad_f64_dev(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T, const double* t,
+                                 const double* y, double* ll, double* grad, int32_t* status, void* stream);
+int cdkf_ekf_loglik_grad_f32_dev(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T, const float* t,
+                                 const float* y, float* ll, float* grad, int32_t* status, void* stream);
+/* 1 if cdkf_ekf_loglik_grad_* has a kernel for this model/options, else 0 */
+int cdkf_grad_supported(const cdkf_model* mdl, const cdkf_opts* opts);
+/* out[p] = sum_n grad[n, p] on the device (the `.sum()` of ssm_temissions.py:567 applied to the gradient), so a
+ * multi-GPU caller all-reduces n_theta scalars */
+int cdkf_grad_sum_f64_dev(const double* grad, int64_t N, int64_t n_theta, double* out_sum, void* stream);
+int cdkf_grad_sum_f32_dev(const float* grad, int64_t N, int64_t n_theta, double* out_sum, void* stream);
+
 /* ---- sum_n ll[n]: the reduction of src/ssm_temissions.py:567 (`vmap(...)(...).sum()`), done on
  *      the device so that the multi-GPU caller can all-reduce ONE scalar over RCCL. ------------- */
 int cdkf_ll_sum_f64_dev(const double* ll, int64_t N, double* out_sum, void* stream);

@@ -620,6 +620,113 @@ def forecast(mdl: Model, m_init, P_init, t_init, t_forecast, method="ekf", state
 
 
 # --------------------------------------------------------------------------------------
+# d(marginal log-likelihood)/d(drift parameters): forward-mode sensitivities of the EKF recursion
+# --------------------------------------------------------------------------------------
+# The reference obtains this gradient by JAX reverse-mode AD through the same computation
+# (ssm_temissions.py:550-568 `value_and_grad(_loss_fn)`); the exact derivative of the discretised
+# algorithm is unique, so differentiating the recursion forward gives the same numbers.  Restated
+# here as the checker for cdkf_ekf_loglik_grad_*; itself checked against central finite differences
+# of ekf_filter's log-likelihood (tests/test_oracle.py).
+def _drift_param_derivs(drift, x):
+    """Returns (dfdth [N,P,d], dFdth [N,P,d,d], dFdx [N,d(i),d,d]) for the drift at x [N,d]."""
+    N, d = x.shape
+    if drift.kind == "lorenz63":
+        dfdth = np.zeros((N, 3, 3), x.dtype)
+        dfdth[:, 0, 0] = x[:, 1] - x[:, 0]
+        dfdth[:, 1, 1] = x[:, 0]
+        dfdth[:, 2, 2] = -x[:, 2]
+        dFdth = np.zeros((N, 3, 3, 3), x.dtype)
+        dFdth[:, 0, 0, 0], dFdth[:, 0, 0, 1] = -1, 1
+        dFdth[:, 1, 1, 0] = 1
+        dFdth[:, 2, 2, 2] = -1
+        dFdx = np.zeros((N, 3, 3, 3), x.dtype)
+        dFdx[:, 0, 1, 2], dFdx[:, 0, 2, 1] = -1, 1   # d/dx
+        dFdx[:, 1, 2, 0] = 1                          # d/dy
+        dFdx[:, 2, 1, 0] = -1                         # d/dz
+        return dfdth, dFdth, dFdx
+    if drift.kind == "linear":
+        P = d * d + d
+        dfdth = np.zeros((N, P, d), x.dtype)
+        dFdth = np.zeros((N, P, d, d), x.dtype)
+        for i in range(d):
+            for j in range(d):
+                dfdth[:, i * d + j, i] = x[:, j]
+                dFdth[:, i * d + j, i, j] = 1
+            dfdth[:, d * d + i, i] = 1
+        return dfdth, dFdth, np.zeros((N, d, d, d), x.dtype)
+    raise NotImplementedError(drift.kind)
+
+
+def ekf_loglik_grad(mdl: Model, t, y, dt0=0.01, dt_final=1e-10, max_steps=100000, dtype=np.float64):
+    """Returns (ll [N], grad [N, n_theta]) for the EKF with state_order first/second (identical for the drifts
+    supported here), num_iter = 1.  theta ordering = drift.theta()."""
+    dtype = np.dtype(dtype)
+    mdl = mdl.cast(dtype)
+    y = np.asarray(y, dtype=dtype)
+    N, T, _ = y.shape
+    d, mm = mdl.d, mdl.m
+    drift = mdl.drift
+    npar = drift.theta().size
+    H, R, bias = mdl.H, mdl.R, mdl.bias
+    LQL = _LQL(mdl)
+    t0s, t1s = _t0_t1(t, dt_final, dtype)
+    m = np.broadcast_to(mdl.m0, (N, d)).copy()
+    P = np.broadcast_to(mdl.P0, (N, d, d)).copy()
+    dm = np.zeros((N, npar, d), dtype)
+    dP = np.zeros((N, npar, d, d), dtype)
+    ll = np.zeros(N, dtype)
+    g = np.zeros((N, npar), dtype)
+    eye = np.eye(mm, dtype=dtype)
+    T_ = lambda A: np.swapaxes(A, -1, -2)
+    for k in range(T):
+        # ---- update with sensitivities ----
+        HP = H @ P
+        S = HP @ H.T + R
+        v = y[:, k] - (m @ H.T + bias)
+        dHP = H @ dP                                    # [N,P,m,d]
+        dS = dHP @ H.T                                  # [N,P,m,m]
+        dv = -dm @ H.T                                  # [N,P,m]
+        Lc = cholesky_lower(S)
+        Sinv = solve_upper_from_lower(Lc, solve_lower(Lc, np.broadcast_to(eye, S.shape).copy()))
+        w = np.einsum("nij,nj->ni", Sinv, v)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            logdet_half = np.sum(np.log(np.diagonal(Lc, axis1=-2, axis2=-1)), axis=-1)
+        ll = ll + (-0.5 * np.einsum("ni,ni->n", v, w) - logdet_half - 0.5 * mm * math.log(2 * math.pi))
+        g = g + (-np.einsum("ni,npi->np", w, dv) + 0.5 * np.einsum("ni,npij,nj->np", w, dS, w)
+                 - 0.5 * np.einsum("nij,npji->np", Sinv, dS))
+        Sb = symmetrize(S) + dtype.type(1e-9) * eye
+        Lb = cholesky_lower(Sb)
+        X = solve_upper_from_lower(Lb, solve_lower(Lb, HP))          # [N,m,d]
+        dSb = symmetrize(dS)
+        rhs = dHP - dSb @ X[:, None]
+        Lbp = np.broadcast_to(Lb[:, None], dSb.shape).copy().reshape(-1, mm, mm)
+        dX = solve_upper_from_lower(Lbp, solve_lower(Lbp, rhs.reshape(-1, mm, d))).reshape(rhs.shape)
+        m_new = m + np.einsum("nri,nr->ni", X, v)
+        dm_new = dm + np.einsum("npri,nr->npi", dX, v) + np.einsum("nri,npr->npi", X, dv)
+        SX = S @ X
+        Tm = T_(X) @ SX
+        dT = T_(dX) @ SX[:, None] + T_(X)[:, None] @ (dS @ X[:, None]) + T_(X)[:, None] @ (S[:, None] @ dX)
+        P = symmetrize(P - Tm)
+        dP = symmetrize(dP - dT)
+        m, dm = m_new, dm_new
+        # ---- predict with sensitivities (same Dormand-Prince steps as the primal) ----
+
+        def rhs_all(yv):
+            mm_, PP, dmm, dPP = yv
+            F = drift.jac(mm_)
+            dfdth, dFdth, dFdx = _drift_param_derivs(drift, mm_)
+            dmdt = drift.f(mm_)
+            dPdt = F @ PP + PP @ T_(F) + LQL
+            ddm = np.einsum("nij,npj->npi", F, dmm) + dfdth
+            dF = np.einsum("nkij,npk->npij", dFdx, dmm) + dFdth
+            B = dF @ PP[:, None] + F[:, None] @ dPP
+            return dmdt, dPdt, ddm, B + T_(B)
+
+        m, P, dm, dP = diffeqsolve(rhs_all, t0s[:, k], t1s[:, k], (m, P, dm, dP), dt0, max_steps)
+    return ll, g
+
+
+# --------------------------------------------------------------------------------------
 # synthetic data (SURVEY.md section 8d; time-grid recipe of simulation_utils.py:46-49)
 # --------------------------------------------------------------------------------------
 def irregular_times(rng, N, T, T_total):

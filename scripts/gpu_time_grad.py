@@ -1,0 +1,29 @@
+"""Time the C2-sized log-likelihood + gradient sweep (dev helper)."""
+import ctypes as C, sys, time
+import numpy as np
+sys.path.insert(0, "."); sys.path.insert(0, "oracle"); sys.path.insert(0, "tests")
+import cdkf_oracle as o
+from cd_dynamax_amd import _ffi
+from cd_dynamax_amd.models import _model_block, _opts
+import cd_dynamax_amd as cd
+from helpers import params_from
+
+L = _ffi.lib()
+for dtype, sfx in ((np.float64, "f64"), (np.float32, "f32")):
+    rng = np.random.default_rng(0)
+    N, T = 4096, 1000
+    mdl = o.lorenz63_model(3)
+    t = o.irregular_times(rng, N, T, 0.01).astype(dtype)
+    y = rng.standard_normal((N, T, 3)).astype(dtype) * 5
+    mb = _model_block(params_from(mdl)); opts = _opts(cd.EKFHyperParams(), 1); opts.layout = _ffi.LAYOUT_TCN
+    tt = np.ascontiguousarray(t.T); yy = np.ascontiguousarray(y.transpose(1, 2, 0))
+    def dev(a):
+        p = C.c_void_p(); _ffi.check(L.cdkf_malloc(C.byref(p), a.nbytes)); _ffi.check(L.cdkf_memcpy_h2d(p, a.ctypes.data_as(C.c_void_p), a.nbytes)); return p
+    dt_, dy_ = dev(tt), dev(yy)
+    dll, dg, dst = dev(np.zeros(N, dtype)), dev(np.zeros((N, 3), dtype)), dev(np.zeros(N, np.int32))
+    fn = getattr(L, f"cdkf_ekf_loglik_grad_{sfx}_dev")
+    for rep in range(4):
+        t0 = time.perf_counter()
+        _ffi.check(fn(C.byref(mb.c), C.byref(opts), N, T, dt_, dy_, dll, dg, dst, None)); _ffi.check(L.cdkf_synchronize(None))
+        el = time.perf_counter() - t0
+    print(f"grad {sfx} N={N} T={T}: {el*1e3:.2f} ms")

@@ -11,7 +11,7 @@ import pytest
 import cd_dynamax_amd as cd
 import cdkf_oracle as o
 from cd_dynamax_amd import _ffi, models
-from helpers import FILTER_KEYS, GOLDEN, linear_model, load_golden, model_from_fixture, params_from, relerr
+from helpers import FILTER_KEYS, GOLDEN, linear_model, load_golden, lorenz96_model, model_from_fixture, params_from, relerr
 
 pytestmark = pytest.mark.gpu
 
@@ -380,3 +380,48 @@ def test_emission_moments(hip_lib):
         np.testing.assert_allclose(em2, em[0], rtol=1e-12, atol=1e-12)
         em32, ec32 = cd.cdnlgssm_emissions(P, np.zeros((7, 1)), mu.astype(np.float32), cov.astype(np.float32))
         assert em32.dtype == np.float32 and relerr(ec32, ec) < 1e-5
+
+
+@pytest.mark.parametrize("kind,d,m", [("lorenz63", 3, 3), ("lorenz63", 3, 1), ("lorenz63", 3, 2), ("linear", 2, 2),
+                                      ("linear", 2, 1), ("linear", 1, 1), ("linear", 3, 3)])
+def test_loglik_gradient(hip_lib, kind, d, m):
+    """cdnlgssm_loglik_and_grad (the drift block of jax.value_and_grad(_loss_fn), ssm_temissions.py:550-568) against the
+    oracle's forward-sensitivity gradient (itself pinned to finite differences in tests/test_oracle.py), irregular
+    per-trajectory times, N not a multiple of the wavefront, and the log-likelihood against the plain filter."""
+    rng = np.random.default_rng(77)
+    mdl = o.lorenz63_model(m) if kind == "lorenz63" else linear_model(rng, d, m)
+    N, T = 70, 40
+    t = o.irregular_times(rng, N, T, 0.2)
+    y = o.simulate(mdl, t, rng)
+    P = params_from(mdl)
+    ll_ref, g_ref = o.ekf_loglik_grad(mdl, t, y)
+    ll, g = cd.cdnlgssm_loglik_and_grad(P, y, t[..., None])
+    gflat = np.stack([g.sigma, g.rho, g.beta], -1) if kind == "lorenz63" else np.concatenate(
+        [g.weights.reshape(N, -1), g.bias], -1)
+    assert gflat.shape == g_ref.shape
+    np.testing.assert_allclose(ll, ll_ref, rtol=1e-11)
+    scale = np.abs(g_ref).max(axis=0, keepdims=True) + 1e-30
+    assert np.max(np.abs(gflat - g_ref) / scale) < 1e-9
+    post = cd.cdnlgssm_filter(P, y, t[..., None], output_fields=[])
+    np.testing.assert_allclose(ll, post.marginal_loglik, rtol=1e-13)
+    # one trajectory, unbatched call
+    ll1, g1 = cd.cdnlgssm_loglik_and_grad(P, y[3], t[3][:, None])
+    assert np.ndim(ll1) == 0 and abs(ll1 - ll[3]) <= 1e-12 * abs(ll[3])
+    # fp32 kernels: same recursion in single precision
+    ll32, g32 = cd.cdnlgssm_loglik_and_grad(P, y.astype(np.float32), t[..., None].astype(np.float32))
+    g32 = np.stack([g32.sigma, g32.rho, g32.beta], -1) if kind == "lorenz63" else np.concatenate(
+        [g32.weights.reshape(N, -1), g32.bias], -1)
+    assert g32.dtype == np.float32
+    assert np.max(np.abs(g32 - g_ref) / scale) < 5e-3
+
+
+def test_loglik_gradient_unsupported_raises(hip_lib):
+    rng = np.random.default_rng(5)
+    mdl = lorenz96_model(8, 4)
+    t = o.irregular_times(rng, 2, 5, 0.1)
+    y = o.simulate(mdl, t, rng)
+    with pytest.raises(NotImplementedError, match="no gradient kernel"):
+        cd.cdnlgssm_loglik_and_grad(params_from(mdl), y, t[..., None])
+    with pytest.raises(NotImplementedError, match="no gradient kernel"):
+        cd.cdnlgssm_loglik_and_grad(params_from(o.lorenz63_model(3)), y[..., :3], t[..., None],
+                                    cd.EKFHyperParams(state_order="zeroth"))

@@ -196,3 +196,32 @@ def test_ukf_weights_match_sarkka():
     assert abs(lamb - 9) < 1e-12 and abs(wm[0] - 0.75) < 1e-12 and abs(wm[1] - 1 / 24) < 1e-12
     assert abs(wc[0] - 0.75) < 1e-12 and abs(wm.sum() - 1) < 1e-12
     np.testing.assert_allclose(W, W.T, atol=1e-15)
+
+
+@pytest.mark.parametrize("kind", ["lorenz63", "linear"])
+def test_loglik_gradient_matches_finite_differences(kind):
+    """The forward-sensitivity gradient of the EKF marginal log-likelihood w.r.t. the drift parameters (what the
+    reference gets from jax.value_and_grad, ssm_temissions.py:550-568) against central finite differences of
+    ekf_filter's own log-likelihood."""
+    rng = np.random.default_rng(31)
+    if kind == "lorenz63":
+        mdl = o.lorenz63_model(2)
+        rebuild = lambda th: o.Model(o.Lorenz63Drift(*th), mdl.L, mdl.Qc, mdl.H, mdl.bias, mdl.R, mdl.m0, mdl.P0)
+    else:
+        mdl = linear_model(rng, 2, 3)
+        rebuild = lambda th: o.Model(o.LinearDrift(th[:4].reshape(2, 2), th[4:]), mdl.L, mdl.Qc, mdl.H, mdl.bias, mdl.R,
+                                     mdl.m0, mdl.P0)
+    N, T = 3, 25
+    t = o.irregular_times(rng, N, T, 0.3)
+    y = o.simulate(mdl, t, rng)
+    ll, g = o.ekf_loglik_grad(mdl, t, y)
+    ref = o.ekf_filter(mdl, t, y)["marginal_loglik"]
+    np.testing.assert_allclose(ll, ref, rtol=1e-12)
+    th0 = mdl.drift.theta()
+    for p in range(th0.size):
+        h = 1e-6 * max(1.0, abs(th0[p]))
+        tp, tm = th0.copy(), th0.copy()
+        tp[p] += h
+        tm[p] -= h
+        fd = (o.ekf_filter(rebuild(tp), t, y)["marginal_loglik"] - o.ekf_filter(rebuild(tm), t, y)["marginal_loglik"]) / (2 * h)
+        np.testing.assert_allclose(g[:, p], fd, rtol=2e-6, atol=1e-6)
