@@ -190,6 +190,39 @@ class ModelBlock:
             h_bias=ptr(self.h_bias), R=ptr(self.R), m0=ptr(self.m0), P0=ptr(self.P0))
 
 
+class DeviceArray:
+    """A device allocation owned by the library's allocator (cdkf_malloc / cdkf_free), with NumPy upload / download."""
+
+    def __init__(self, shape, dtype):
+        self.shape, self.dtype = tuple(shape), np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        self.ptr = C.c_void_p()
+        check(lib().cdkf_malloc(C.byref(self.ptr), self.nbytes))
+
+    @classmethod
+    def from_numpy(cls, a: np.ndarray) -> "DeviceArray":
+        a = np.ascontiguousarray(a)
+        d = cls(a.shape, a.dtype)
+        check(lib().cdkf_memcpy_h2d(d.ptr, a.ctypes.data_as(C.c_void_p), d.nbytes))
+        return d
+
+    def numpy(self) -> np.ndarray:
+        out = np.empty(self.shape, self.dtype)
+        check(lib().cdkf_memcpy_d2h(out.ctypes.data_as(C.c_void_p), self.ptr, self.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            lib().cdkf_free(self.ptr)
+            self.ptr = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 def _vp(a: Optional[np.ndarray]):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 

@@ -69,3 +69,36 @@ def sharded_marginal_log_prob(local_ll_fn: Callable[[int, int], np.ndarray], n_t
     lo, hi = shard_bounds(n_total, rank, world)
     local = float(np.sum(np.asarray(local_ll_fn(lo, hi), dtype=np.float64))) if hi > lo else 0.0
     return allreduce_sum(local)
+
+
+def allreduce_sum_array(values, device=None) -> np.ndarray:
+    """Element-wise sum of a small float64 array over all ranks (one collective)."""
+    import torch
+    import torch.distributed as dist
+    arr = np.ascontiguousarray(values, dtype=np.float64)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return arr.copy()
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else "cpu"
+    buf = torch.from_numpy(arr.reshape(-1).copy()).to(device)
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+    return buf.cpu().numpy().reshape(arr.shape)
+
+
+def sharded_loglik_and_grad(local_fn: Callable[[int, int], Tuple[np.ndarray, np.ndarray]], n_total: int, n_theta: int):
+    """(sum_n ll_n, sum_n d ll_n / d theta): every rank evaluates ``local_fn(lo, hi) -> (ll [B], grad [B, n_theta])`` on
+    its block (cdkf_ekf_loglik_grad_*), and the 1 + n_theta block sums cross the fabric in ONE all-reduce -- the data-
+    parallel form of ``value_and_grad`` of the fit_sgd loss (ssm_temissions.py:550-568)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        rank, world = dist.get_rank(), dist.get_world_size()
+    else:
+        rank, world = 0, 1
+    lo, hi = shard_bounds(n_total, rank, world)
+    packed = np.zeros(1 + n_theta)
+    if hi > lo:
+        ll, grad = local_fn(lo, hi)
+        packed[0] = np.sum(np.asarray(ll, dtype=np.float64))
+        packed[1:] = np.sum(np.asarray(grad, dtype=np.float64).reshape(hi - lo, n_theta), axis=0)
+    packed = allreduce_sum_array(packed)
+    return float(packed[0]), packed[1:]

@@ -372,6 +372,14 @@ class ContDiscreteNonlinearGaussianSSM:
         """(marginal_log_prob, d marginal_log_prob / d drift parameters): see ``cdnlgssm_loglik_and_grad``."""
         return cdnlgssm_loglik_and_grad(params, emissions, t_emissions, filter_hyperparams, inputs, dtype=dtype)
 
+    def fit_sgd(self, params, props, emissions, t_emissions=None, filter_hyperparams=None, inputs=None, optimizer=None,
+                batch_size: int = 1, num_epochs: int = 50, shuffle: bool = False, return_param_history: bool = False,
+                return_grad_history: bool = False, key=0, dtype=None, allreduce=None):
+        """ssm_temissions.py:492-600 for the trainable drift parameters; see ``cd_dynamax_amd.fit.fit_sgd``."""
+        from .fit import fit_sgd
+        return fit_sgd(self, params, props, emissions, t_emissions, filter_hyperparams, inputs, optimizer, batch_size,
+                       num_epochs, shuffle, return_param_history, return_grad_history, key, dtype, allreduce)
+
     def filter(self, params, emissions, t_emissions=None, filter_hyperparams=EKFHyperParams(), inputs=None,
                dtype=None) -> PosteriorGSSMFiltered:
         return cdnlgssm_filter(params, emissions, t_emissions, filter_hyperparams, inputs, dtype=dtype)

@@ -36,6 +36,11 @@ full = o.ekf_filter(mdl, t, y)["marginal_loglik"].sum()
 assert calls == [D.shard_bounds(N, rank, world)], calls
 assert abs(total - full) < 1e-9 * abs(full), (total, full)
 assert abs(D.allreduce_sum(float(rank + 1)) - 3.0) < 1e-12
+# value-and-gradient: 1 + n_theta sums in one collective
+tot, g = D.sharded_loglik_and_grad(lambda lo, hi: o.ekf_loglik_grad(mdl, t[lo:hi], y[lo:hi]), N, 3)
+ll_full, g_full = o.ekf_loglik_grad(mdl, t, y)
+assert abs(tot - ll_full.sum()) < 1e-9 * abs(ll_full.sum())
+assert np.allclose(g, g_full.sum(axis=0), rtol=1e-9, atol=1e-9), (g, g_full.sum(axis=0))
 dist.barrier()
 dist.destroy_process_group()
 sys.stdout.write("RANK_OK_%d\n" % rank); sys.stdout.flush()

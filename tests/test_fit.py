@@ -1,0 +1,111 @@
+"""fit_sgd (reference: ssm_temissions.py:492-600, utils/optimize_utils.py:48-140): host logic on CPU, the value-and-gradient
+path on the GPU against the oracle."""
+import numpy as np
+import pytest
+
+import cd_dynamax_amd as cd
+import cdkf_oracle as o
+from cd_dynamax_amd import fit
+from cd_dynamax_amd.params import ParameterProperties as PP
+from helpers import params_from
+
+
+def _l63_problem(m=3):
+    """The set-up of the reference's SGD timer (test_scripts/timers/timer_sgd.py:38-80): Lorenz-63 drift trainable,
+    everything else frozen."""
+    model = cd.ContDiscreteNonlinearGaussianSSM(3, m)
+    frozen = PP(trainable=False)
+    params, props = model.initialize(
+        key=0,
+        initial_mean={"params": np.zeros(3), "props": frozen},
+        initial_cov={"params": 100 * np.eye(3), "props": frozen},
+        dynamics_drift={"params": cd.LearnableLorenz63(10.0, 28.0, 8 / 3), "props": cd.LearnableLorenz63(PP(), PP(), PP())},
+        dynamics_diffusion_coefficient={"params": cd.LearnableMatrix(np.eye(3)), "props": cd.LearnableMatrix(frozen)},
+        dynamics_diffusion_cov={"params": cd.LearnableMatrix(np.eye(3)), "props": cd.LearnableMatrix(frozen)},
+        emission_function={"params": cd.LearnableLinear(np.eye(m, 3), np.zeros(m)), "props": cd.LearnableLinear(frozen, frozen)},
+        emission_cov={"params": cd.LearnableMatrix(np.eye(m)), "props": cd.LearnableMatrix(frozen)},
+    )
+    return model, params, props
+
+
+def test_adam_matches_optax_formula():
+    """optax.adam: mu = b1 mu + (1-b1) g; nu = b2 nu + (1-b2) g^2; update = -lr mu_hat / (sqrt(nu_hat) + eps)."""
+    opt = fit.Adam(0.1)
+    th = np.array([1.0, -2.0])
+    st = opt.init(th)
+    g1 = np.array([0.5, -4.0])
+    u1, st = opt.update(g1, st)
+    np.testing.assert_allclose(u1, -0.1 * g1 / (np.abs(g1) + 1e-8), rtol=1e-12)  # first step: -lr * sign(g)
+    g2 = np.array([0.25, 1.0])
+    u2, st = opt.update(g2, st)
+    mu = 0.9 * 0.1 * g1 + 0.1 * g2
+    nu = 0.999 * 0.001 * g1 ** 2 + 0.001 * g2 ** 2
+    np.testing.assert_allclose(u2, -0.1 * (mu / (1 - 0.81)) / (np.sqrt(nu / (1 - 0.999 ** 2)) + 1e-8), rtol=1e-12)
+    u, _ = fit.SGD(0.5).update(g1, None)
+    np.testing.assert_allclose(u, -0.5 * g1)
+
+
+def test_trainable_mask_and_refusals():
+    model, params, props = _l63_problem()
+    np.testing.assert_array_equal(fit._trainable_mask(params, props), [True, True, True])
+    p2 = props._replace(dynamics=props.dynamics._replace(drift=cd.LearnableLorenz63(PP(), PP(False), PP())))
+    np.testing.assert_array_equal(fit._trainable_mask(params, p2), [True, False, True])
+    p3 = props._replace(emissions=props.emissions._replace(emission_cov=cd.LearnableMatrix(PP())))
+    with pytest.raises(NotImplementedError, match="emissions.emission_cov"):
+        fit._trainable_mask(params, p3)
+    p4 = props._replace(dynamics=props.dynamics._replace(drift=cd.LearnableLorenz63(PP(constrainer=object()), PP(), PP())))
+    with pytest.raises(NotImplementedError, match="constrainer"):
+        fit._trainable_mask(params, p4)
+    th = fit._drift_theta(params.dynamics.drift)
+    assert fit._drift_from_theta(params.dynamics.drift, th) == params.dynamics.drift
+
+
+@pytest.mark.gpu
+def test_fit_sgd_first_step_matches_oracle_gradient(hip_lib):
+    """One epoch, two minibatches of plain SGD: losses and parameter updates from the oracle's value-and-gradient."""
+    model, params, props = _l63_problem(m=1)
+    rng = np.random.default_rng(3)
+    mdl = o.lorenz63_model(1)
+    mdl = o.Model(mdl.drift, np.eye(3), np.eye(3), np.eye(1, 3), np.zeros(1), np.eye(1), np.zeros(3), 100 * np.eye(3))
+    N, T, lr, bs = 6, 30, 0.05, 4
+    t = o.irregular_times(rng, N, T, 0.05)
+    y = o.simulate(mdl, t, rng)
+    new, losses, ph, gh = model.fit_sgd(params, props, y, t[..., None], cd.EKFHyperParams(), optimizer=fit.SGD(lr),
+                                        batch_size=bs, num_epochs=1, return_param_history=True, return_grad_history=True)
+    th = mdl.drift.theta().copy()
+    exp_losses = []
+    for lo, hi in ((0, 4), (4, 6)):
+        cur = o.Model(o.Lorenz63Drift(*th), mdl.L, mdl.Qc, mdl.H, mdl.bias, mdl.R, mdl.m0, mdl.P0)
+        ll, g = o.ekf_loglik_grad(cur, t[lo:hi], y[lo:hi])
+        scale = N / (hi - lo)
+        exp_losses.append(-(ll.sum() * scale) / y.size)
+        gl = -(g.sum(0) * scale) / y.size
+        th = th - lr * gl
+    np.testing.assert_allclose(losses, [np.mean(exp_losses)], rtol=1e-10)
+    np.testing.assert_allclose([new.dynamics.drift.sigma, new.dynamics.drift.rho, new.dynamics.drift.beta], th, rtol=1e-10)
+    np.testing.assert_allclose([gh[0].sigma, gh[0].rho, gh[0].beta], gl, rtol=1e-8)
+    assert ph[0] == new.dynamics.drift
+
+
+@pytest.mark.gpu
+def test_fit_sgd_recovers_lorenz63_parameters(hip_lib):
+    """Parameter estimation as in the reference's Lorenz-63 tutorials: start from perturbed (sigma, rho, beta), Adam on
+    the EKF marginal log-likelihood; the loss falls and every parameter ends closer to the truth."""
+    model, params, props = _l63_problem(m=3)
+    rng = np.random.default_rng(11)
+    true = o.lorenz63_model(3)
+    true = o.Model(true.drift, np.eye(3), np.eye(3), np.eye(3), np.zeros(3), np.eye(3), np.zeros(3), 100 * np.eye(3))
+    N, T = 64, 150
+    t = o.irregular_times(rng, N, T, 0.02)
+    y = o.simulate(true, t, rng)
+    start = params._replace(dynamics=params.dynamics._replace(drift=cd.LearnableLorenz63(8.0, 25.0, 2.0)))
+    new, losses = model.fit_sgd(start, props, y, t[..., None], cd.EKFHyperParams(), optimizer=fit.Adam(0.05), batch_size=N,
+                                num_epochs=150)
+    assert losses[-1] < losses[0] and np.all(np.isfinite(losses))
+    got = np.array([new.dynamics.drift.sigma, new.dynamics.drift.rho, new.dynamics.drift.beta])
+    truth, init = np.array([10.0, 28.0, 8 / 3]), np.array([8.0, 25.0, 2.0])
+    assert np.all(np.abs(got - truth) < 0.5 * np.abs(init - truth)), got
+    ll_true = model.marginal_log_prob(params, y, t[..., None]).sum()
+    ll_fit = model.marginal_log_prob(new, y, t[..., None]).sum()
+    assert ll_fit > model.marginal_log_prob(start, y, t[..., None]).sum()
+    assert ll_fit > ll_true - 0.01 * abs(ll_true)
