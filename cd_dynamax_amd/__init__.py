@@ -4,6 +4,7 @@ Same public names as /root/reference/src/continuous_discrete_nonlinear_gaussian_
 filtering / smoothing hot path; the arithmetic lives in hand-written HIP kernels behind the C ABI of
 ``include/cdkf.h``.
 """
+from . import fit
 from .linear import (ContDiscreteLinearGaussianSSM, KFHyperParams, ParamsCDLGSSM, ParamsCDLGSSMDynamics,
                      ParamsLGSSMEmissions, cdlgssm_filter, cdlgssm_smoother)
 from .models import (ContDiscreteNonlinearGaussianSSM, cdnlgssm_emissions, cdnlgssm_filter, cdnlgssm_forecast,
