@@ -727,6 +727,184 @@ def ekf_loglik_grad(mdl: Model, t, y, dt0=0.01, dt_final=1e-10, max_steps=100000
 
 
 # --------------------------------------------------------------------------------------
+# the same gradient by the discrete adjoint (reverse mode) -- all drift parameters, any registry drift
+# --------------------------------------------------------------------------------------
+# What jax.value_and_grad does in the reference (reverse mode through update + Dormand-Prince steps,
+# diffrax_utils.py:49 RecursiveCheckpointAdjoint), written out: checker for the reverse-sweep HIP kernel
+# (cdkf_ekf_loglik_grad_* with the MLP drift).  state_order 'first' (for drifts with a non-zero grad(div f) the
+# 'second' mean term would need third derivatives of the drift); one trajectory at a time, plain loops.
+_DP_A = [[], [1 / 5], [3 / 40, 9 / 40], [44 / 45, -56 / 15, 32 / 9], [19372 / 6561, -25360 / 2187, 64448 / 6561, -212 / 729],
+         [9017 / 3168, -355 / 33, 46732 / 5247, 49 / 176, -5103 / 18656]]
+_DP_B = [35 / 384, 0.0, 500 / 1113, 125 / 192, -2187 / 6784, 11 / 84]
+
+
+def drift_vjp(drift, x, lam, G):
+    """Gradient of  s(x, theta) = lam . f(x) + <G, F(x)>  w.r.t. (x, theta);  x [d], lam [d], G [d,d]."""
+    d = x.shape[0]
+    if drift.kind == "mlp":
+        W1, W2, W3 = drift.W1, drift.W2, drift.W3
+        z1 = W1 @ x + drift.b1
+        a1 = np.tanh(z1)
+        d1 = 1 - a1 * a1
+        U = d1[:, None] * W1                      # tangent of a1 for the d unit directions  [h1,d]
+        Tz = W2 @ U                               # tangent of z2                           [h2,d]
+        a2 = np.tanh(W2 @ a1 + drift.b2)
+        d2 = 1 - a2 * a2
+        V = d2[:, None] * Tz                      # tangent of a2                           [h2,d]
+        # reverse
+        c2 = W3.T @ G                             # cotangent of V                          [h2,d]
+        gW3 = np.outer(lam, a2) + G @ V.T
+        gb3 = lam.copy()
+        a2b = W3.T @ lam + np.sum(-2 * a2[:, None] * Tz * c2, axis=1)
+        zt2 = d2[:, None] * c2                    # cotangent of Tz
+        z2b = d2 * a2b
+        gW2 = np.outer(z2b, a1) + zt2 @ U.T
+        gb2 = z2b
+        c1 = W2.T @ zt2                           # cotangent of U                          [h1,d]
+        a1b = W2.T @ z2b + np.sum(-2 * a1[:, None] * W1 * c1, axis=1)
+        z1b = d1 * a1b
+        gW1 = np.outer(z1b, x) + d1[:, None] * c1
+        gb1 = z1b
+        xb = W1.T @ z1b
+        return xb, np.concatenate([g.ravel() for g in (gW1, gb1, gW2, gb2, gW3, gb3)])
+    F = drift.jac(x[None])[0]
+    xb = F.T @ lam
+    if drift.kind == "lorenz63":
+        th = np.array([lam[0] * (x[1] - x[0]) - G[0, 0] + G[0, 1], lam[1] * x[0] + G[1, 0], -lam[2] * x[2] - G[2, 2]])
+        xb = xb + np.array([-G[1, 2] + G[2, 1], G[2, 0], -G[1, 0]])
+        return xb, th
+    if drift.kind == "linear":
+        return xb, np.concatenate([(np.outer(lam, x) + G).ravel(), lam])
+    if drift.kind == "lorenz96":
+        for i in range(d):
+            ip1, im1, im2 = (i + 1) % d, (i - 1) % d, (i - 2) % d
+            xb[im1] += G[i, ip1] - G[i, im2]
+            xb[ip1] += G[i, im1]
+            xb[im2] -= G[i, im1]
+        return xb, np.array([lam.sum()])
+    raise NotImplementedError(drift.kind)
+
+
+def _step_sizes(t0, t1, dt0, tol, max_steps):
+    """The dt sequence of the diffeqsolve loop above for one interval."""
+    out = []
+    tprev, tnext = t0, min(t0 + dt0, t1)
+    while tprev < t1 and len(out) < max_steps:
+        out.append(tnext - tprev)
+        tprev = min(tnext, t1)
+        tn = tnext + dt0
+        tnext = t1 if tn > t1 - tol else tn
+    return out
+
+
+def ekf_loglik_grad_adjoint(mdl: Model, t, y, dt0=0.01, dt_final=1e-10, max_steps=100000):
+    """Returns (ll [N], grad [N, n_theta]): EKF, state_order 'first', num_iter 1; float64."""
+    mdl = mdl.cast(np.float64)
+    y = np.asarray(y, np.float64)
+    t = np.asarray(t, np.float64)
+    N, T, _ = y.shape
+    d, mm = mdl.d, mdl.m
+    drift = mdl.drift
+    H, R, bias = mdl.H, mdl.R, mdl.bias
+    LQL = _LQL(mdl)
+    npar = drift.theta().size
+    eye_m = np.eye(mm)
+    sym = lambda A: 0.5 * (A + A.T)
+    f = lambda x: drift.f(x[None])[0]
+    jac = lambda x: drift.jac(x[None])[0]
+
+    def rhs(x, P):
+        F = jac(x)
+        A = F @ P
+        return f(x), A + A.T + LQL
+
+    def stages(x, P, dt):
+        ks = []
+        for i in range(6):
+            xs = x + dt * sum((_DP_A[i][j] * ks[j][0] for j in range(i)), np.zeros(d))
+            Ps = P + dt * sum((_DP_A[i][j] * ks[j][1] for j in range(i)), np.zeros((d, d)))
+            ks.append(rhs(xs, Ps))
+        return ks
+
+    def stage_in(x, P, dt, ks, i):
+        return (x + dt * sum((_DP_A[i][j] * ks[j][0] for j in range(i)), np.zeros(d)),
+                P + dt * sum((_DP_A[i][j] * ks[j][1] for j in range(i)), np.zeros((d, d))))
+
+    ll_out, g_out = np.zeros(N), np.zeros((N, npar))
+    for n in range(N):
+        tn = t if t.ndim == 1 else t[n]
+        # ---- forward sweep, keeping predicted and filtered moments ----
+        mp, Pp, mf, Pf = [mdl.m0.copy()], [sym(mdl.P0)], [], []
+        ll = 0.0
+        for k in range(T):
+            m_, P_ = mp[k], Pp[k]
+            S = H @ P_ @ H.T + R
+            v = y[n, k] - (H @ m_ + bias)
+            Lc = np.linalg.cholesky(S)
+            w = np.linalg.solve(S, v)
+            ll += -0.5 * v @ w - np.log(np.diag(Lc)).sum() - 0.5 * mm * math.log(2 * math.pi)
+            Sb = sym(S) + 1e-9 * eye_m
+            X = np.linalg.solve(Sb, H @ P_)
+            mf.append(m_ + X.T @ v)
+            Pf.append(sym(P_ - X.T @ S @ X))
+            if k + 1 < T:
+                x, P = mf[k], Pf[k]
+                for dt in _step_sizes(tn[k], tn[k + 1], dt0, 1e-10, max_steps):
+                    ks = stages(x, P, dt)
+                    x = x + dt * sum(_DP_B[i] * ks[i][0] for i in range(6))
+                    P = P + dt * sum(_DP_B[i] * ks[i][1] for i in range(6))
+                mp.append(x)
+                Pp.append(P)
+        # ---- backward sweep ----
+        thb = np.zeros(npar)
+        mb, Pb = np.zeros(d), np.zeros((d, d))          # adjoint of the filtered moments at k
+        for k in range(T - 1, -1, -1):
+            m_, P_ = mp[k], Pp[k]
+            HP = H @ P_
+            S = HP @ H.T + R
+            v = y[n, k] - (H @ m_ + bias)
+            Sinv = np.linalg.inv(S)
+            w = Sinv @ v
+            Sb = sym(S) + 1e-9 * eye_m
+            X = np.linalg.solve(Sb, HP)
+            Pb = sym(Pb)
+            vb = X @ mb - w
+            Kb = np.outer(v, mb) - 2 * S @ X @ Pb                  # cotangent of K^T  [m,d]
+            Sbar = -X @ Pb @ X.T + 0.5 * np.outer(w, w) - 0.5 * Sinv
+            Ub = np.linalg.solve(Sb, Kb)                           # [m,d]
+            Sbar = Sbar + sym(-X @ Ub.T)
+            Pb = Pb + sym(Ub.T @ H) + H.T @ Sbar @ H
+            mb = mb - H.T @ vb
+            if k == 0:
+                break
+            # predict k-1 -> k: reverse the Dormand-Prince steps
+            dts = _step_sizes(tn[k - 1], tn[k], dt0, 1e-10, max_steps)
+            starts = [(mf[k - 1], Pf[k - 1])]
+            for dt in dts[:-1]:
+                x, P = starts[-1]
+                ks = stages(x, P, dt)
+                starts.append((x + dt * sum(_DP_B[i] * ks[i][0] for i in range(6)),
+                               P + dt * sum(_DP_B[i] * ks[i][1] for i in range(6))))
+            for (x, P), dt in zip(reversed(starts), reversed(dts)):
+                ks = stages(x, P, dt)
+                Yb = [None] * 6
+                for i in range(5, -1, -1):
+                    lam = dt * (_DP_B[i] * mb + sum((_DP_A[j][i] * Yb[j][0] for j in range(i + 1, 6)), np.zeros(d)))
+                    Lam = dt * (_DP_B[i] * Pb + sum((_DP_A[j][i] * Yb[j][1] for j in range(i + 1, 6)), np.zeros((d, d))))
+                    Lam = sym(Lam)
+                    xs, Ps = stage_in(x, P, dt, ks, i)
+                    F = jac(xs)
+                    xb, tb = drift_vjp(drift, xs, lam, 2 * Lam @ Ps)
+                    thb += tb
+                    Yb[i] = (xb, F.T @ Lam + Lam @ F)
+                mb = mb + sum(Yb[i][0] for i in range(6))
+                Pb = sym(Pb + sum(Yb[i][1] for i in range(6)))
+        ll_out[n] = ll
+        g_out[n] = thb
+    return ll_out, g_out
+
+
+# --------------------------------------------------------------------------------------
 # synthetic data (SURVEY.md section 8d; time-grid recipe of simulation_utils.py:46-49)
 # --------------------------------------------------------------------------------------
 def irregular_times(rng, N, T, T_total):

@@ -147,10 +147,12 @@ def lorenz96_model(d, m_obs=None, forcing=8.0):
 
 
 def mlp_model(rng, d=8, m_obs=4, h=64):
-    """MLP(d -> h -> h -> d, tanh), weights N(0, 1/fan_in), H = first m rows of I."""
-    W1 = rng.standard_normal((h, d)) / np.sqrt(d)
-    W2 = rng.standard_normal((h, h)) / np.sqrt(h)
-    W3 = rng.standard_normal((d, h)) / np.sqrt(h)
-    b1, b2, b3 = (0.1 * rng.standard_normal(k) for k in (h, h, d))
+    """MLP(d -> h -> h -> d, tanh), weights N(0, 1/fan_in), H = first m rows of I.
+    ``h``: one hidden width or a pair (h1, h2)."""
+    h1, h2 = (h, h) if np.isscalar(h) else h
+    W1 = rng.standard_normal((h1, d)) / np.sqrt(d)
+    W2 = rng.standard_normal((h2, h1)) / np.sqrt(h1)
+    W3 = rng.standard_normal((d, h2)) / np.sqrt(h2)
+    b1, b2, b3 = (0.1 * rng.standard_normal(k) for k in (h1, h2, d))
     return o.Model(o.MLPDrift(W1, b1, W2, b2, W3, b3), np.eye(d), 0.5 * np.eye(d), np.eye(d)[:m_obs], np.zeros(m_obs),
                    0.5 * np.eye(m_obs), np.zeros(d), np.eye(d))

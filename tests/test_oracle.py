@@ -225,3 +225,51 @@ def test_loglik_gradient_matches_finite_differences(kind):
         tm[p] -= h
         fd = (o.ekf_filter(rebuild(tp), t, y)["marginal_loglik"] - o.ekf_filter(rebuild(tm), t, y)["marginal_loglik"]) / (2 * h)
         np.testing.assert_allclose(g[:, p], fd, rtol=2e-6, atol=1e-6)
+
+
+def _rebuild_drift(mdl, th):
+    dr = mdl.drift
+    if dr.kind == "mlp":
+        parts, off = [], 0
+        for a in (dr.W1, dr.b1, dr.W2, dr.b2, dr.W3, dr.b3):
+            parts.append(th[off:off + a.size].reshape(a.shape))
+            off += a.size
+        nd = o.MLPDrift(*parts)
+    elif dr.kind == "lorenz96":
+        nd = o.Lorenz96Drift(th[0])
+    else:
+        raise NotImplementedError
+    return o.Model(nd, mdl.L, mdl.Qc, mdl.H, mdl.bias, mdl.R, mdl.m0, mdl.P0)
+
+
+def test_adjoint_gradient_equals_forward_sensitivities():
+    """Two independent derivations of the same gradient (reverse sweep vs forward sensitivities) agree to rounding."""
+    rng = np.random.default_rng(1)
+    for mdl in (o.lorenz63_model(2), linear_model(rng, 2, 3)):
+        t = o.irregular_times(rng, 2, 12, 0.025)
+        y = o.simulate(mdl, t, rng)
+        ll1, g1 = o.ekf_loglik_grad(mdl, t, y)
+        ll2, g2 = o.ekf_loglik_grad_adjoint(mdl, t, y)
+        np.testing.assert_allclose(ll2, ll1, rtol=1e-13)
+        assert np.abs(g1 - g2).max() < 1e-12 * np.abs(g1).max()
+
+
+@pytest.mark.parametrize("kind", ["mlp", "lorenz96"])
+def test_adjoint_gradient_matches_finite_differences(kind):
+    """Reverse-sweep gradient (all drift parameters; MLP: second-order backprop through the Jacobian) against central
+    differences of ekf_filter's log-likelihood along random directions in parameter space."""
+    from helpers import lorenz96_model, mlp_model
+    rng = np.random.default_rng(2)
+    mdl = mlp_model(rng, 4, 2, (7, 5)) if kind == "mlp" else lorenz96_model(6, 3)
+    t = o.irregular_times(rng, 2, 10, 0.025)
+    y = o.simulate(mdl, t, rng)
+    ll, g = o.ekf_loglik_grad_adjoint(mdl, t, y)
+    np.testing.assert_allclose(ll, o.ekf_filter(mdl, t, y, state_order="first")["marginal_loglik"], rtol=1e-12)
+    th0 = mdl.drift.theta()
+    for _ in range(3):
+        u = rng.standard_normal(th0.size)
+        u /= np.linalg.norm(u)
+        h = 1e-5
+        fd = (o.ekf_filter(_rebuild_drift(mdl, th0 + h * u), t, y, state_order="first")["marginal_loglik"]
+              - o.ekf_filter(_rebuild_drift(mdl, th0 - h * u), t, y, state_order="first")["marginal_loglik"]) / (2 * h)
+        np.testing.assert_allclose(g @ u, fd, rtol=1e-5, atol=1e-8)
