@@ -1,0 +1,579 @@
+// cdkf_adjoint_kernels.h -- reverse sweep (discrete adjoint) of the EKF log-likelihood for the MLP drift:
+// d ll / d theta for ALL drift parameters (h1 d + h1 + h2 h1 + h2 + d h2 + d of them) in one backward pass.
+//
+// The reference gets this from jax.value_and_grad through the filter (ssm_temissions.py:550-568; reverse mode
+// through diffrax with RecursiveCheckpointAdjoint, diffrax_utils.py:49).  Same quantity here, written out:
+//   forward  : the wave8 filter sweep stores the predicted and filtered moments at every observation (these
+//              are the adjoint's checkpoints -- the filter outputs the reference returns anyway);
+//   backward : k = T-1 .. 0:  (1) adjoint of the measurement update + log-likelihood term at k,
+//                             (2) adjoint of the Dormand-Prince steps over [t_{k-1}, t_k], re-integrating the interval
+//                                 from the filtered moments at k-1 (step starts kept in LDS, stages recomputed),
+//              each right-hand-side adjoint back-propagates through f AND through the Jacobian F = W3 D2 W2 D1 W1
+//              (second-order backprop: reverse over the forward tangent pass).
+// state_order 'first' only: the reference's 'second' mean term 0.5 P grad(div f) would need third derivatives.
+//
+// Mapping: one wavefront per trajectory as in cdkf_wave8_kernels.h -- lane (i, j) owns entry (i, j) of every 8 x 8 tile
+// (P, its adjoint, the stage slopes and their adjoints stay in registers), lane p is hidden unit p in the MLP passes and
+// accumulates row p of dW2 (64 registers), row p of dW1, column p of dW3 and its bias entries for the whole sweep: the
+// parameter gradient never leaves registers until the final store.  W2 is read from LDS in both orientations
+// (W2T[q][p] for the forward matvec, W2[p][q] for the transposed one) so that lanes always hit consecutive banks.
+#pragma once
+#include "cdkf_wave8_kernels.h"
+
+namespace cdkf {
+
+struct AdjSh {  // per workgroup, in reals; hidden sizes padded to 64, state to 8
+  static constexpr int W1 = 0;             // [64][8]
+  static constexpr int b1 = 512;           // [64]
+  static constexpr int W2 = 576;           // [64][64]   W2[p][q]
+  static constexpr int W2T = 576 + 4096;   // [64][64]   W2T[q][p] = W2[p][q]
+  static constexpr int b2 = 576 + 8192;    // [64]
+  static constexpr int W3 = 8832;          // [8][65]
+  static constexpr int b3 = 8832 + 520;    // [8]
+  static constexpr int end = 9360;
+};
+constexpr int kAdjCk = 8;  // Dormand-Prince step starts kept per replay chunk
+struct AdjOff {  // per wavefront, in reals
+  static constexpr int P = 0, F = 64, Lam = 128, G = 192, A = 256, B = 320, X = 384, S = 448, S1 = 512, S2 = 576, HP = 640,
+                       H = 704, Pb = 768, Kb = 832, Ub = 896, Si = 960, XP = 1024;
+  static constexpr int x = 1088, lam = 1096, f = 1104, v = 1112, w = 1120, mb = 1128, vb = 1136;
+  static constexpr int a1 = 1168, a2 = 1232, zb2 = 1296, U = 1360, V = 1872, ZT2 = 2384, RED = 2896;
+  static constexpr int ck = 3408;  // kAdjCk x (64 P + 8 m), then kAdjCk step sizes
+  static constexpr int end = 3408 + kAdjCk * 72 + kAdjCk;
+};
+template <typename R>
+constexpr int adj_waves() {
+  return sizeof(R) == 8 ? 2 : 4;
+}
+template <typename R>
+constexpr size_t adj_lds_bytes() {
+  return sizeof(R) * (size_t)(AdjSh::end + adj_waves<R>() * AdjOff::end) + 64;
+}
+
+// Dormand-Prince tableau as arrays (static indices after unrolling)
+template <typename R>
+struct Dp5T {
+  static constexpr R a[6][5] = {{0, 0, 0, 0, 0},
+                                {Dp5<R>::a21, 0, 0, 0, 0},
+                                {Dp5<R>::a31, Dp5<R>::a32, 0, 0, 0},
+                                {Dp5<R>::a41, Dp5<R>::a42, Dp5<R>::a43, 0, 0},
+                                {Dp5<R>::a51, Dp5<R>::a52, Dp5<R>::a53, Dp5<R>::a54, 0},
+                                {Dp5<R>::a61, Dp5<R>::a62, Dp5<R>::a63, Dp5<R>::a64, Dp5<R>::a65}};
+  static constexpr R b[6] = {Dp5<R>::b1, 0, Dp5<R>::b3, Dp5<R>::b4, Dp5<R>::b5, Dp5<R>::b6};
+};
+
+template <typename R>
+__global__ __launch_bounds__(64 * adj_waves<R>(), 1) void ekf_adjoint_wave8_kernel(const WgArgs<R> a, R* __restrict__ grad) {
+  constexpr int WAVES = adj_waves<R>();
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  R* Sh = reinterpret_cast<R*>(smem_raw);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i = lane >> 3, j = lane & 7;
+  const int d = a.d, m = a.m, h1 = a.h1, h2 = a.h2;
+  R* W = Sh + AdjSh::end + wave * AdjOff::end;
+  const R* th = a.par + a.o_theta;
+  const long oW1 = 0, ob1 = oW1 + (long)h1 * d, oW2 = ob1 + h1, ob2 = oW2 + (long)h2 * h1, oW3 = ob2 + h2, ob3 = oW3 + (long)d * h2;
+
+  // ---- shared weights, zero-padded -------------------------------------------------------------------------------
+  for (int e = threadIdx.x; e < AdjSh::end; e += blockDim.x) Sh[e] = 0;
+  __syncthreads();
+  for (int e = threadIdx.x; e < h1 * d; e += blockDim.x) {
+    const int q = fdiv(e, d);
+    Sh[AdjSh::W1 + q * 8 + (e - q * d)] = th[oW1 + e];
+  }
+  for (int e = threadIdx.x; e < h1; e += blockDim.x) Sh[AdjSh::b1 + e] = th[ob1 + e];
+  for (int e = threadIdx.x; e < h2 * h1; e += blockDim.x) {
+    const int p = fdiv(e, h1), q = e - p * h1;
+    const R w = th[oW2 + e];
+    Sh[AdjSh::W2 + p * 64 + q] = w;
+    Sh[AdjSh::W2T + q * 64 + p] = w;
+  }
+  for (int e = threadIdx.x; e < h2; e += blockDim.x) Sh[AdjSh::b2 + e] = th[ob2 + e];
+  for (int e = threadIdx.x; e < d * h2; e += blockDim.x) {
+    const int r = fdiv(e, h2);
+    Sh[AdjSh::W3 + r * 65 + (e - r * h2)] = th[oW3 + e];
+  }
+  for (int e = threadIdx.x; e < d; e += blockDim.x) Sh[AdjSh::b3 + e] = th[ob3 + e];
+  __syncthreads();
+  const long n = (long)blockIdx.x * WAVES + wave;
+  if (n >= a.N) return;  // whole wavefront; no workgroup barrier follows
+
+  // ---- per-lane constants ---------------------------------------------------------------------------------------
+  const bool inP = (i < d) && (j < d);
+  const R lql = inP ? (a.par + a.o_LQL)[i * d + j] : R(0);
+  const R Hij = (i < m && j < d) ? (a.par + a.o_H)[i * d + j] : R(0);  // lane (r=i, k=j) holds H[r][k]
+  const R Rij = (i < m && j < m) ? (a.par + a.o_R)[i * m + j] : R(0);
+  const R hbj = (lane < m) ? (a.par + a.o_hb)[lane] : R(0);
+  R w1row[8], w3col[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    w1row[k] = Sh[AdjSh::W1 + lane * 8 + k];
+    w3col[k] = Sh[AdjSh::W3 + k * 65 + lane];
+  }
+  const R b1l = Sh[AdjSh::b1 + lane], b2l = Sh[AdjSh::b2 + lane];
+
+  // ---- parameter-gradient accumulators (registers for the whole sweep) -------------------------------------------
+  R gW2[64], gW1[8], gW3[8];
+  R gb1 = 0, gb2 = 0, gb3 = 0;
+#pragma unroll
+  for (int q = 0; q < 64; ++q) gW2[q] = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) gW1[k] = gW3[k] = 0;
+
+  // ---- 8 x 8 tile products: lane (i, j) gets one entry ----------------------------------------------------------
+  auto mm = [&](int TA, int TB) {  // (A B)_ij
+    R s = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s = rfma(W[TA + i * 8 + k], W[TB + k * 8 + j], s);
+    return s;
+  };
+  auto mm_tn = [&](int TA, int TB) {  // (A^T B)_ij
+    R s = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s = rfma(W[TA + k * 8 + i], W[TB + k * 8 + j], s);
+    return s;
+  };
+  auto mm_nt = [&](int TA, int TB) {  // (A B^T)_ij
+    R s = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s = rfma(W[TA + i * 8 + k], W[TB + j * 8 + k], s);
+    return s;
+  };
+
+  // ---- MLP forward with the tangent of the 8 unit directions; needs W[x] = stage mean (synced) ---------------------
+  // lane = hidden unit: returns a1, d1 (layer 1), a2, d2, T = W2 (D1 W1) row (layer 2); leaves a1, U = D1 W1, a2,
+  // V = D2 T in LDS and the Jacobian entry F_ij / the drift f in registers of lane (i, j) / LDS vector f.
+  auto mlp_fwd = [&](R (&xk)[8], R& a1, R& d1, R& a2, R& d2, R (&T)[8], R& Fij) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) xk[k] = W[AdjOff::x + k];
+    R z1 = b1l;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) z1 = rfma(w1row[k], xk[k], z1);
+    a1 = rtanh(z1);
+    d1 = R(1) - a1 * a1;
+    W[AdjOff::a1 + lane] = a1;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) W[AdjOff::U + lane * 8 + k] = d1 * w1row[k];
+    wave_sync();
+    R z2 = b2l;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) T[k] = 0;
+#pragma unroll 8
+    for (int q = 0; q < 64; ++q) {
+      const R w = Sh[AdjSh::W2T + q * 64 + lane];
+      z2 = rfma(w, W[AdjOff::a1 + q], z2);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) T[k] = rfma(w, W[AdjOff::U + q * 8 + k], T[k]);
+    }
+    a2 = rtanh(z2);
+    d2 = R(1) - a2 * a2;
+    W[AdjOff::a2 + lane] = a2;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) W[AdjOff::V + lane * 8 + k] = d2 * T[k];
+    wave_sync();
+    R fs = 0;
+    Fij = 0;
+#pragma unroll 8
+    for (int p = 0; p < 64; ++p) {
+      const R w3 = Sh[AdjSh::W3 + i * 65 + p];
+      Fij = rfma(w3, W[AdjOff::V + p * 8 + j], Fij);
+      fs = rfma(w3, W[AdjOff::a2 + p], fs);
+    }
+    if (!inP) Fij = 0;
+    if (j == 0) W[AdjOff::f + i] = (i < d) ? fs + Sh[AdjSh::b3 + i] : R(0);
+  };
+
+  // ---- right-hand side of the moment ODEs (state_order 'first') --------------------------------------------------
+  auto rhs_fwd = [&](R xs, R Ps, R& kM, R& kP) {
+    W[AdjOff::P + lane] = Ps;
+    if (lane < 8) W[AdjOff::x + lane] = xs;
+    wave_sync();
+    R xk[8], a1, d1, a2, d2, T[8], Fij;
+    mlp_fwd(xk, a1, d1, a2, d2, T, Fij);
+    W[AdjOff::F + lane] = Fij;
+    wave_sync();
+    const R acc = mm(AdjOff::F, AdjOff::P);
+    W[AdjOff::A + lane] = acc;
+    wave_sync();
+    kP = (acc + W[AdjOff::A + j * 8 + i]) + lql;
+    if (lane < 8) kM = W[AdjOff::f + lane];
+    wave_sync();
+  };
+
+  // ---- its adjoint: given the cotangent (lam, Lam) of the slope at the stage value (xs, Ps) -----------------------
+  //   Ybar_P = F^T Lam + Lam F;   Ybar_m, dtheta += gradient of  lam . f(x) + <G, F(x)>,  G = 2 Lam P
+  auto rhs_adj = [&](R xs, R Ps, R lam, R Lam, R& YM, R& YP) {
+    W[AdjOff::P + lane] = Ps;
+    W[AdjOff::Lam + lane] = Lam;
+    if (lane < 8) {
+      W[AdjOff::x + lane] = xs;
+      W[AdjOff::lam + lane] = lam;
+    }
+    wave_sync();
+    R xk[8], a1, d1, a2, d2, T[8], Fij;
+    mlp_fwd(xk, a1, d1, a2, d2, T, Fij);
+    W[AdjOff::F + lane] = Fij;
+    W[AdjOff::G + lane] = R(2) * mm(AdjOff::Lam, AdjOff::P);
+    wave_sync();
+    YP = mm_tn(AdjOff::F, AdjOff::Lam) + mm(AdjOff::Lam, AdjOff::F);
+    // layer 3, lane p: c2_j = sum_i W3[i][p] G[i][j] is the cotangent of V[p][j]
+    R c2[8], lamv[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      c2[k] = 0;
+      lamv[k] = W[AdjOff::lam + k];
+    }
+    R a2b = 0;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      R gv = 0;  // sum_j G[r][j] V[p][j]
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const R g = W[AdjOff::G + r * 8 + k];
+        c2[k] = rfma(w3col[r], g, c2[k]);
+        gv = rfma(g, T[k], gv);
+      }
+      gW3[r] = rfma(lamv[r], a2, rfma(d2, gv, gW3[r]));
+      a2b = rfma(w3col[r], lamv[r], a2b);
+    }
+    R zt2[8];
+    {
+      R s = 0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s = rfma(T[k], c2[k], s);
+      a2b = rfma(R(-2) * a2, s, a2b);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) zt2[k] = d2 * c2[k];
+    }
+    const R z2b = d2 * a2b;
+    gb2 += z2b;
+    W[AdjOff::zb2 + lane] = z2b;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) W[AdjOff::ZT2 + lane * 8 + k] = zt2[k];
+    // layer 2 weights: dW2[p][q] += z2b a1[q] + sum_j zt2[j] U[q][j]
+#pragma unroll
+    for (int q = 0; q < 64; ++q) {
+      R s = rfma(z2b, W[AdjOff::a1 + q], gW2[q]);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s = rfma(zt2[k], W[AdjOff::U + q * 8 + k], s);
+      gW2[q] = s;
+    }
+    wave_sync();
+    // layer 1, lane q: c1_j = sum_p W2[p][q] zt2_p[j] is the cotangent of U[q][j]
+    R c1[8], s1 = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) c1[k] = 0;
+#pragma unroll 8
+    for (int p = 0; p < 64; ++p) {
+      const R w = Sh[AdjSh::W2 + p * 64 + lane];
+      s1 = rfma(w, W[AdjOff::zb2 + p], s1);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) c1[k] = rfma(w, W[AdjOff::ZT2 + p * 8 + k], c1[k]);
+    }
+    {
+      R s = 0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s = rfma(w1row[k], c1[k], s);
+      s1 = rfma(R(-2) * a1, s, s1);
+    }
+    const R z1b = d1 * s1;
+    gb1 += z1b;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      gW1[k] = rfma(z1b, xk[k], rfma(d1, c1[k], gW1[k]));
+      W[AdjOff::RED + lane * 8 + k] = w1row[k] * z1b;
+    }
+    if (lane < 8) gb3 += lam;
+    wave_sync();
+    // Ybar_m[j] = sum_q W1[q][j] z1b[q]: lane (i, j) sums the hidden units q = 8 c + i, the partial sums meet in a tile
+    R part = 0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) part += W[AdjOff::RED + (8 * c + i) * 8 + j];
+    W[AdjOff::A + lane] = part;
+    wave_sync();
+    if (lane < 8) {
+      R s = 0;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) s += W[AdjOff::A + r * 8 + lane];
+      YM = s;
+    }
+    wave_sync();
+  };
+
+  using TB = Dp5T<R>;
+  // stage value i from the step start and the slopes k_0 .. k_{i-1}
+  auto stage_in = [&](int si, R y0, const R (&ks)[6], R dt) {
+    R s = 0;
+#pragma unroll
+    for (int jj = 0; jj < 5; ++jj)
+      if (jj < si) s = rfma(TB::a[si][jj], ks[jj], s);
+    return rfma(dt, s, y0);
+  };
+  // one Dormand-Prince step forward (as the filter takes it)
+  auto step_fwd = [&](R& mj, R& Pij, R dt) {
+    R kM[6] = {0, 0, 0, 0, 0, 0}, kP[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < 6; ++s) rhs_fwd(stage_in(s, mj, kM, dt), stage_in(s, Pij, kP, dt), kM[s], kP[s]);
+    R sm = 0, sp = 0;
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+      sm = rfma(TB::b[s], kM[s], sm);
+      sp = rfma(TB::b[s], kP[s], sp);
+    }
+    mj = rfma(dt, sm, mj);
+    Pij = rfma(dt, sp, Pij);
+  };
+  // ... and its adjoint: (mb, Pb) cotangent of the step's result -> cotangent of its start; dtheta accumulated
+  auto step_adj = [&](R mj, R Pij, R dt, R& mb, R& Pb) {
+    R kM[6] = {0, 0, 0, 0, 0, 0}, kP[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < 6; ++s) rhs_fwd(stage_in(s, mj, kM, dt), stage_in(s, Pij, kP, dt), kM[s], kP[s]);
+    R yM[6] = {0, 0, 0, 0, 0, 0}, yP[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int s = 5; s >= 0; --s) {
+      R lm = TB::b[s] * mb, lp = TB::b[s] * Pb;
+#pragma unroll
+      for (int r = 5; r > 0; --r)
+        if (r > s) {
+          lm = rfma(TB::a[r][s], yM[r], lm);
+          lp = rfma(TB::a[r][s], yP[r], lp);
+        }
+      rhs_adj(stage_in(s, mj, kM, dt), stage_in(s, Pij, kP, dt), dt * lm, dt * lp, yM[s], yP[s]);
+    }
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+      mb += yM[s];
+      Pb += yP[s];
+    }
+  };
+
+  // ---- backward sweep ------------------------------------------------------------------------------------------------
+  const R* tp = a.t + n * a.t_sn;
+  const R* yp = a.y + n * a.y_sn;
+  R mb = 0, Pb = 0;  // cotangent of the filtered moments at k (mean on lanes < 8)
+  for (long k = a.T - 1; k >= 0; --k) {
+    // (1) measurement update + log-likelihood term at k, from the predicted moments
+    R mp, Pp;
+    if (k == 0) {
+      mp = (lane < d) ? (a.par + a.o_m0)[lane] : R(0);
+      Pp = inP ? R(0.5) * ((a.par + a.o_P0)[i * d + j] + (a.par + a.o_P0)[j * d + i]) : R(0);
+    } else {
+      mp = (lane < d) ? a.pm[n * a.m_sn + (k - 1) * a.m_sk + lane * a.m_si] : R(0);
+      Pp = inP ? a.pP[n * a.P_sn + (k - 1) * a.P_sk + (i * d + j) * a.P_si] : R(0);
+    }
+    const R yl = (lane < m) ? yp[k * a.y_sk + lane * a.y_si] : R(0);
+    W[AdjOff::P + lane] = Pp;
+    W[AdjOff::H + lane] = Hij;
+    W[AdjOff::Pb + lane] = Pb;
+    if (lane < 8) {
+      W[AdjOff::x + lane] = mp;
+      W[AdjOff::mb + lane] = mb;
+    }
+    wave_sync();
+    const R hp = mm(AdjOff::H, AdjOff::P);
+    const R Pbs = R(0.5) * (Pb + W[AdjOff::Pb + j * 8 + i]);
+    W[AdjOff::HP + lane] = hp;
+    R vv = 0;
+    if (lane < 8) {
+      R hm = 0;
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) hm = rfma(W[AdjOff::H + lane * 8 + kk], W[AdjOff::x + kk], hm);
+      vv = (lane < m) ? yl - (hm + hbj) : R(0);
+      W[AdjOff::v + lane] = vv;
+    }
+    wave_sync();
+    const R s = (i < m && j < m) ? mm_nt(AdjOff::HP, AdjOff::H) + Rij : R(0);
+    W[AdjOff::S + lane] = s;
+    W[AdjOff::Pb + lane] = Pbs;
+    wave_sync();
+    // factorise S (log-likelihood) and Sb = sym(S) + 1e-9 I (psd_solve), both padded with the identity
+    R s1 = (i < m && j < m) ? s : (i == j ? R(1) : R(0));
+    R s2 = (i < m && j < m) ? R(0.5) * (s + W[AdjOff::S + j * 8 + i]) + (i == j ? R(1e-9) : R(0)) : (i == j ? R(1) : R(0));
+    R inv1[8], inv2[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      W[AdjOff::S1 + lane] = s1;
+      W[AdjOff::S2 + lane] = s2;
+      wave_sync();
+      const R p1 = W[AdjOff::S1 + p * 8 + p], p2 = W[AdjOff::S2 + p * 8 + p];
+      const R r1 = rrsqrt(p1), r2 = rrsqrt(p2);
+      inv1[p] = r1;
+      inv2[p] = r2;
+      const R l1i = W[AdjOff::S1 + i * 8 + p] * r1, l1j = W[AdjOff::S1 + j * 8 + p] * r1;
+      const R l2i = W[AdjOff::S2 + i * 8 + p] * r2, l2j = W[AdjOff::S2 + j * 8 + p] * r2;
+      wave_sync();
+      if (j == p && i >= p) {
+        s1 = (i == p) ? p1 * r1 : l1i;
+        s2 = (i == p) ? p2 * r2 : l2i;
+      } else if (i > p && j > p && j <= i) {
+        s1 = rfma(-l1i, l1j, s1);
+        s2 = rfma(-l2i, l2j, s2);
+      }
+    }
+    W[AdjOff::S1 + lane] = s1;
+    W[AdjOff::S2 + lane] = s2;
+    wave_sync();
+    // column solves with a factor tile: col <- (L L^T)^-1 col
+    auto chol_solve_col = [&](int TL, const R (&inv)[8], R (&col)[8]) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        R w = col[r];
+#pragma unroll
+        for (int c = 0; c < r; ++c) w = rfma(-W[TL + r * 8 + c], col[c], w);
+        col[r] = w * inv[r];
+      }
+#pragma unroll
+      for (int r = 7; r >= 0; --r) {
+        R w = col[r];
+#pragma unroll
+        for (int c = r + 1; c < 8; ++c) w = rfma(-W[TL + c * 8 + r], col[c], w);
+        col[r] = w * inv[r];
+      }
+    };
+    auto pick = [&](const R (&col)[8]) {  // col[i] without a run-time register index
+      R out = 0;
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+        if (r == i) out = col[r];
+      return out;
+    };
+    R col[8];
+    // w = S^-1 v (every lane, redundantly)
+    R wv[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) wv[r] = W[AdjOff::v + r];
+    chol_solve_col(AdjOff::S1, inv1, wv);
+    // S^-1 (column j), masked to the m x m block
+#pragma unroll
+    for (int r = 0; r < 8; ++r) col[r] = (r == j) ? R(1) : R(0);
+    chol_solve_col(AdjOff::S1, inv1, col);
+    const R sinv = (i < m && j < m) ? pick(col) : R(0);
+    // X = Sb^-1 (H P) (column j)
+#pragma unroll
+    for (int r = 0; r < 8; ++r) col[r] = W[AdjOff::HP + r * 8 + j];
+    chol_solve_col(AdjOff::S2, inv2, col);
+    const R xij = (i < m) ? pick(col) : R(0);
+    W[AdjOff::X + lane] = xij;
+    wave_sync();
+    // XP = X Pbar;  vbar = X mbar - w
+    const R xp = mm(AdjOff::X, AdjOff::Pb);
+    W[AdjOff::XP + lane] = xp;
+    R vb = 0;
+    if (lane < 8) {
+      R sacc = 0;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) sacc = rfma(W[AdjOff::X + lane * 8 + c], W[AdjOff::mb + c], sacc);
+      R wl = 0;
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+        if (r == lane) wl = wv[r];
+      vb = (lane < m) ? sacc - wl : R(0);
+      W[AdjOff::vb + lane] = vb;
+    }
+    wave_sync();
+    // Kb = v mbar^T - 2 S (X Pbar)      (cotangent of K^T)
+    const R kb = rfma(R(-2), mm(AdjOff::S, AdjOff::XP), W[AdjOff::v + i] * W[AdjOff::mb + j]);
+    W[AdjOff::Kb + lane] = (i < m) ? kb : R(0);
+    wave_sync();
+    // Ub = Sb^-1 Kb (column j)
+#pragma unroll
+    for (int r = 0; r < 8; ++r) col[r] = W[AdjOff::Kb + r * 8 + j];
+    chol_solve_col(AdjOff::S2, inv2, col);
+    W[AdjOff::Ub + lane] = (i < m) ? pick(col) : R(0);
+    wave_sync();
+    // Sbar = -(X Pbar) X^T + w w^T / 2 - S^-1 / 2 - sym(X Ub^T)
+    R wi = 0, wj = 0;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      if (r == i) wi = wv[r];
+      if (r == j) wj = wv[r];
+    }
+    const R xu = mm_nt(AdjOff::X, AdjOff::Ub);
+    W[AdjOff::A + lane] = xu;
+    wave_sync();
+    R sbar = -mm_nt(AdjOff::XP, AdjOff::X) + R(0.5) * wi * wj - R(0.5) * sinv - R(0.5) * (xu + W[AdjOff::A + j * 8 + i]);
+    if (!(i < m && j < m)) sbar = 0;
+    W[AdjOff::B + lane] = sbar;
+    wave_sync();
+    // Pbar <- Pbar + sym(Ub^T H) + H^T Sbar H;   mbar <- mbar - H^T vbar
+    const R uh = mm_tn(AdjOff::Ub, AdjOff::H);
+    const R sh = mm(AdjOff::B, AdjOff::H);
+    wave_sync();
+    W[AdjOff::A + lane] = uh;
+    W[AdjOff::B + lane] = sh;
+    wave_sync();
+    Pb = Pbs + R(0.5) * (uh + W[AdjOff::A + j * 8 + i]) + mm_tn(AdjOff::H, AdjOff::B);
+    if (!inP) Pb = 0;
+    if (lane < 8) {
+      R sacc = 0;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) sacc = rfma(W[AdjOff::H + r * 8 + lane], W[AdjOff::vb + r], sacc);
+      mb = (lane < d) ? mb - sacc : R(0);
+    }
+    wave_sync();
+    if (k == 0) break;
+
+    // (2) predict k-1 -> k: reverse the Dormand-Prince steps, replaying the interval in chunks of kAdjCk steps
+    const R t0 = tp[(k - 1) * a.t_sk], t1 = tp[k * a.t_sk];
+    long S = 0;
+    {
+      R tprev = t0, tnext = rmin(t0 + a.dt0, t1);
+      while (tprev < t1 && S < a.max_steps) {
+        tprev = rmin(tnext, t1);
+        const R tn = tnext + a.dt0;
+        tnext = (tn > t1 - Tol<R>::v) ? t1 : tn;
+        ++S;
+      }
+    }
+    const R mf = (lane < d) ? a.fm[n * a.m_sn + (k - 1) * a.m_sk + lane * a.m_si] : R(0);
+    const R Pf = inP ? a.fP[n * a.P_sn + (k - 1) * a.P_sk + (i * d + j) * a.P_si] : R(0);
+    for (long cs = ((S - 1) / kAdjCk) * kAdjCk; cs >= 0; cs -= kAdjCk) {
+      const long ce = (cs + kAdjCk < S) ? cs + kAdjCk : S;
+      R mj = mf, Pij = Pf;
+      R tprev = t0, tnext = rmin(t0 + a.dt0, t1);
+      for (long s = 0; s < ce; ++s) {
+        const R dt = tnext - tprev;
+        if (s >= cs) {
+          const int slot = (int)(s - cs);
+          W[AdjOff::ck + slot * 72 + lane] = Pij;
+          if (lane < 8) W[AdjOff::ck + slot * 72 + 64 + lane] = mj;
+          if (lane == 0) W[AdjOff::ck + kAdjCk * 72 + slot] = dt;
+        }
+        if (s + 1 < ce) step_fwd(mj, Pij, dt);
+        tprev = rmin(tnext, t1);
+        const R tn = tnext + a.dt0;
+        tnext = (tn > t1 - Tol<R>::v) ? t1 : tn;
+      }
+      wave_sync();
+      for (long s = ce - 1; s >= cs; --s) {
+        const int slot = (int)(s - cs);
+        const R Ps = W[AdjOff::ck + slot * 72 + lane];
+        const R ms = (lane < 8) ? W[AdjOff::ck + slot * 72 + 64 + lane] : R(0);
+        const R dt = W[AdjOff::ck + kAdjCk * 72 + slot];
+        step_adj(ms, Ps, dt, mb, Pb);
+      }
+      wave_sync();
+    }
+  }
+
+  // ---- store this trajectory's gradient (theta ordering: W1, b1, W2, b2, W3, b3) ----------------------------------
+  R* g = grad + n * (ob3 + d);
+  if (lane < h1) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (k < d) g[oW1 + (long)lane * d + k] = gW1[k];
+    g[ob1 + lane] = gb1;
+  }
+  if (lane < h2) {
+#pragma unroll
+    for (int q = 0; q < 64; ++q)
+      if (q < h1) g[oW2 + (long)lane * h1 + q] = gW2[q];
+    g[ob2 + lane] = gb2;
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+      if (r < d) g[oW3 + (long)r * h2 + lane] = gW3[r];
+  }
+  if (lane < d) g[ob3 + lane] = gb3;
+}
+
+}  // namespace cdkf

@@ -35,6 +35,11 @@ template <typename R>
 int launch_ekf_grad(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll,
                     R* grad, int32_t* status, hipStream_t stream);
 bool grad_shape_available(const cdkf_model* mdl, const cdkf_opts* o);
+// reverse sweep for the MLP drift (launch_wg.hip, cdkf_adjoint_kernels.h)
+template <typename R>
+int launch_ekf_grad_adjoint(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll,
+                            R* grad, int32_t* status, hipStream_t stream);
+bool adjoint_shape_available(const cdkf_model* mdl, const cdkf_opts* o);
 
 bool kernel_available(const cdkf_model* mdl, const cdkf_opts* o, int algo, int bytes_per_real);
 

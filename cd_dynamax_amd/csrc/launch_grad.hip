@@ -15,6 +15,7 @@
 namespace cdkf {
 
 bool grad_shape_available(const cdkf_model* mdl, const cdkf_opts* o) {
+  if (adjoint_shape_available(mdl, o)) return true;
   if (o->state_order == CDKF_ORDER_ZEROTH || o->num_iter != 1 || o->forecast) return false;
 #define X(KIND, DRIFT, D_, M_) \
   if (mdl->drift_kind == KIND && mdl->state_dim == D_ && mdl->emission_dim == M_) return true;
@@ -38,9 +39,11 @@ static int run_grad(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_
 template <typename R>
 int launch_ekf_grad(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll,
                     R* grad, int32_t* status, hipStream_t stream) {
+  if (adjoint_shape_available(mdl, o)) return launch_ekf_grad_adjoint<R>(mdl, o, N, T, t, y, ll, grad, status, stream);
   if (!grad_shape_available(mdl, o)) {
     set_error("loglik_grad: no kernel for drift_kind=%d state_dim=%d emission_dim=%d state_order=%d num_iter=%d "
-              "(gradients cover the register-resident Lorenz-63 / linear shapes, state_order first|second, num_iter 1)",
+              "(forward sensitivities: register-resident Lorenz-63 / linear shapes, state_order first|second; reverse "
+              "sweep: MLP drift with state_dim, emission_dim <= 8, hidden <= 64, state_order first; num_iter 1)",
               mdl->drift_kind, mdl->state_dim, mdl->emission_dim, o->state_order, o->num_iter);
     return CDKF_EUNSUPPORTED;
   }

@@ -2,6 +2,7 @@
 #include "cdkf_launch.h"
 #include "cdkf_wg2_kernels.h"
 #include "cdkf_wave8_kernels.h"
+#include "cdkf_adjoint_kernels.h"
 
 #include <mutex>
 
@@ -317,6 +318,74 @@ int launch_ukf_filter_wg(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, i
   const int rc2 = param_pool_release(slot, stream);
   return rc ? rc : rc2;
 }
+
+// ---- reverse-sweep gradient (cdkf_adjoint_kernels.h) ------------------------------------------------------------------
+// The forward sweep's moments (the adjoint's checkpoints) live in a grow-only per-process workspace; an event recorded
+// behind the backward kernel orders its reuse across streams.
+struct AdjWorkspace {
+  void* p = nullptr;
+  size_t cap = 0;
+  int device = -1;
+  hipEvent_t done = nullptr;
+  bool in_flight = false;
+};
+static AdjWorkspace g_adj_ws;
+static std::mutex g_adj_mutex;
+
+bool adjoint_shape_available(const cdkf_model* mdl, const cdkf_opts* o) {
+  return mdl->drift_kind == CDKF_DRIFT_MLP_TANH && wave8_shape(mdl) && o->state_order == CDKF_ORDER_FIRST &&
+         o->num_iter == 1 && !o->forecast && expected_theta(mdl) == mdl->n_theta;
+}
+
+template <typename R>
+int launch_ekf_grad_adjoint(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll,
+                            R* grad, int32_t* status, hipStream_t stream) {
+  static const int cap_rc = wg_raise_lds_cap(ekf_adjoint_wave8_kernel<R>);
+  if (cap_rc) return CDKF_EHIP;
+  WgArgs<R> a{};
+  R* blk = nullptr;
+  ParamSlot* slot = nullptr;
+  int rc = wg_prepare(a, &blk, &slot, mdl, o, N, T, stream);
+  if (rc) return rc;
+  const size_t nm = (size_t)N * T * mdl->state_dim, nP = nm * mdl->state_dim, bytes = 2 * (nm + nP) * sizeof(R);
+  std::lock_guard<std::mutex> lock(g_adj_mutex);
+  int dev = 0;
+  CDKF_HIP_CHECK(hipGetDevice(&dev));
+  AdjWorkspace& ws = g_adj_ws;
+  if (ws.cap < bytes || ws.device != dev) {
+    if (ws.in_flight) CDKF_HIP_CHECK(hipEventSynchronize(ws.done));
+    if (ws.p) (void)hipFree(ws.p);
+    if (ws.done) (void)hipEventDestroy(ws.done);
+    ws = AdjWorkspace();
+    CDKF_HIP_CHECK(hipMalloc(&ws.p, bytes));
+    CDKF_HIP_CHECK(hipEventCreateWithFlags(&ws.done, hipEventDisableTiming));
+    ws.cap = bytes;
+    ws.device = dev;
+  } else if (ws.in_flight) {
+    CDKF_HIP_CHECK(hipStreamWaitEvent(stream, ws.done, 0));
+  }
+  R* w = (R*)ws.p;
+  a.t = t; a.y = y; a.ll = ll; a.status = status;
+  a.fm = w; a.fP = w + nm; a.pm = w + nm + nP; a.pP = w + 2 * nm + nP;
+  rc = launch_wave8<R>(a, stream);
+  if (!rc) {
+    constexpr int WAVES = adj_waves<R>();
+    hipLaunchKernelGGL(ekf_adjoint_wave8_kernel<R>, dim3((unsigned)((N + WAVES - 1) / WAVES)), dim3(64 * WAVES),
+                       adj_lds_bytes<R>(), stream, a, grad);
+    if (hipGetLastError() != hipSuccess) {
+      set_error("adjoint kernel launch failed");
+      rc = CDKF_EHIP;
+    }
+  }
+  CDKF_HIP_CHECK(hipEventRecord(ws.done, stream));
+  ws.in_flight = true;
+  const int rc2 = param_pool_release(slot, stream);
+  return rc ? rc : rc2;
+}
+template int launch_ekf_grad_adjoint<float>(const cdkf_model*, const cdkf_opts*, int64_t, int64_t, const float*, const float*,
+                                            float*, float*, int32_t*, hipStream_t);
+template int launch_ekf_grad_adjoint<double>(const cdkf_model*, const cdkf_opts*, int64_t, int64_t, const double*,
+                                             const double*, double*, double*, int32_t*, hipStream_t);
 
 #define INST(R)                                                                                                        \
   template int launch_ekf_filter_wg<R>(const cdkf_model*, const cdkf_opts*, int64_t, int64_t, const R*, const R*, R*,  \

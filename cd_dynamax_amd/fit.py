@@ -2,7 +2,7 @@
 :550-568, loop utils/optimize_utils.py:48-140 / dynamax run_sgd) with the value-and-gradient of the loss computed by
 the HIP sweep ``cdkf_ekf_loglik_grad_*`` instead of ``jax.value_and_grad`` through the filter.
 
-Scope: the trainable leaves must be fields of ``params.dynamics.drift`` (LearnableLorenz63 / LearnableLinear -- the
+Scope: the trainable leaves must be fields of ``params.dynamics.drift`` (LearnableLorenz63 / LearnableLinear / LearnableMLP -- the
 set-up of the reference's own SGD timer, test_scripts/timers/timer_sgd.py:38-66, which freezes everything else) and
 carry no constrainer.  Any other trainable leaf raises NotImplementedError: there is no gradient for it here, and
 silently freezing it would change the optimisation problem.
@@ -19,7 +19,7 @@ from typing import Any, List, Optional
 import numpy as np
 
 from . import _ffi
-from .params import EKFHyperParams, LearnableLinear, LearnableLorenz63, ParameterProperties
+from .params import EKFHyperParams, LearnableLinear, LearnableLorenz63, LearnableMLP, ParameterProperties
 
 
 class Adam:
@@ -72,12 +72,21 @@ def _drift_theta(drift) -> np.ndarray:
         return np.array([drift.sigma, drift.rho, drift.beta], dtype=np.float64)
     if isinstance(drift, LearnableLinear):
         return np.concatenate([np.asarray(drift.weights, np.float64).ravel(), np.asarray(drift.bias, np.float64).ravel()])
+    if isinstance(drift, LearnableMLP):
+        return np.concatenate([np.asarray(a, np.float64).ravel() for a in drift])
     raise NotImplementedError(f"fit_sgd: no gradient kernel for a drift of type {type(drift).__name__}")
 
 
 def _drift_from_theta(drift, theta: np.ndarray):
     if isinstance(drift, LearnableLorenz63):
         return LearnableLorenz63(sigma=float(theta[0]), rho=float(theta[1]), beta=float(theta[2]))
+    if isinstance(drift, LearnableMLP):
+        parts, off = [], 0
+        for a in drift:
+            shp = np.asarray(a).shape
+            parts.append(theta[off:off + int(np.prod(shp))].reshape(shp).copy())
+            off += int(np.prod(shp))
+        return LearnableMLP(*parts)
     d = np.asarray(drift.weights).shape[0]
     return LearnableLinear(weights=theta[: d * d].reshape(d, d).copy(), bias=theta[d * d:].copy())
 
@@ -101,6 +110,8 @@ def _trainable_mask(params, props) -> np.ndarray:
     if isinstance(drift, LearnableLinear):
         d = np.asarray(drift.weights).shape[0]
         return np.concatenate([np.full(d * d, masks.get("weights", False)), np.full(d, masks.get("bias", False))])
+    if isinstance(drift, LearnableMLP):
+        return np.concatenate([np.full(np.asarray(getattr(drift, f)).size, masks.get(f, False)) for f in drift._fields])
     raise NotImplementedError(f"fit_sgd: no gradient kernel for a drift of type {type(drift).__name__}")
 
 

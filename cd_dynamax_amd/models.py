@@ -175,6 +175,13 @@ def _drift_like(drift, theta_grad):
     """Pack a gradient array [..., n_theta] into the drift's own NamedTuple (the pytree jax.grad would return)."""
     if isinstance(drift, LearnableLorenz63):
         return LearnableLorenz63(sigma=theta_grad[..., 0], rho=theta_grad[..., 1], beta=theta_grad[..., 2])
+    if isinstance(drift, LearnableMLP):
+        lead, parts, off = theta_grad.shape[:-1], [], 0
+        for a in drift:
+            shp = np.asarray(a).shape
+            parts.append(theta_grad[..., off:off + int(np.prod(shp))].reshape(lead + shp))
+            off += int(np.prod(shp))
+        return LearnableMLP(*parts)
     d = np.asarray(drift.weights).shape[0]
     return LearnableLinear(weights=theta_grad[..., : d * d].reshape(theta_grad.shape[:-1] + (d, d)),
                            bias=theta_grad[..., d * d:])
@@ -193,8 +200,9 @@ def cdnlgssm_loglik_and_grad(
     un-negated / un-normalised.  Returns ``(ll, grad)``: ``ll`` as ``marginal_log_prob`` (``[N]`` for batched emissions),
     ``grad`` an instance of the drift's class whose fields hold d ll / d field (leading ``[N]`` when batched).
 
-    Forward sensitivities inside the HIP sweep (cdkf_ekf_loglik_grad_*); drifts LearnableLorenz63 / LearnableLinear at the
-    register-resident shapes, ``state_order`` first or second.  Anything else raises (no finite-difference fallback)."""
+    LearnableLorenz63 / LearnableLinear at the register-resident shapes: forward sensitivities inside the sweep,
+    ``state_order`` first or second.  LearnableMLP (state_dim, emission_dim <= 8, hidden <= 64): reverse sweep (discrete
+    adjoint) for all weights and biases, ``state_order='first'``.  Anything else raises (no finite-difference fallback)."""
     if not isinstance(hyperparams, EKFHyperParams):
         raise NotImplementedError("gradients are provided for the EKF marginal log-likelihood only")
     mdl = _model_block(params)

@@ -134,3 +134,33 @@ def test_unscented_filter_on_workgroup_kernels(hip_lib, case):
     _check(cd.cdnlgssm_filter(P, y, t[..., None], cd.UKFHyperParams(alpha=1.1, beta=1.0, kappa=0.5)), ref2, 1e-8)
     post32 = cd.cdnlgssm_filter(P, y.astype(np.float32), t[..., None], cd.UKFHyperParams())
     assert relerr(post32.filtered_means, ref["filtered_means"]) < 5e-4
+
+
+@pytest.mark.parametrize("d,m,h", [(8, 4, (64, 64)), (4, 2, (7, 5)), (8, 8, (32, 16)), (3, 1, (64, 9))])
+def test_mlp_loglik_gradient_reverse_sweep(hip_lib, d, m, h):
+    """Reverse-sweep gradient w.r.t. every weight and bias of the MLP drift (BASELINE config 5's SGD objective; reference:
+    jax.value_and_grad of the fit_sgd loss, ssm_temissions.py:550-568) against the oracle's discrete adjoint (pinned to
+    finite differences in tests/test_oracle.py).  Intervals of 1..30 Dormand-Prince steps exercise the chunked replay."""
+    rng = np.random.default_rng(9)
+    mdl = mlp_model(rng, d, m, h)
+    N, T = 5, 9
+    t = o.irregular_times(rng, N, T, 0.02)
+    t[:, 5:] += 0.25        # one long interval (more steps than one replay chunk holds)
+    y = o.simulate(mdl, t, rng)
+    P = params_from(mdl)
+    hyp = cd.EKFHyperParams(state_order="first")
+    ll_ref, g_ref = o.ekf_loglik_grad_adjoint(mdl, t, y)
+    ll, g = cd.cdnlgssm_loglik_and_grad(P, y, t[..., None], hyp)
+    np.testing.assert_allclose(ll, ll_ref, rtol=1e-10)
+    flat = np.concatenate([np.asarray(a).reshape(N, -1) for a in g], axis=-1)
+    assert flat.shape == g_ref.shape
+    scale = np.abs(g_ref).max()
+    assert np.abs(flat - g_ref).max() < 1e-8 * scale, np.abs(flat - g_ref).max() / scale
+    assert g.W2.shape == (N,) + mdl.drift.W2.shape and g.b3.shape == (N, d)
+    # fp32 kernels
+    ll32, g32 = cd.cdnlgssm_loglik_and_grad(P, y.astype(np.float32), t[..., None].astype(np.float32), hyp)
+    flat32 = np.concatenate([np.asarray(a).reshape(N, -1) for a in g32], axis=-1)
+    assert flat32.dtype == np.float32 and np.abs(flat32 - g_ref).max() < 2e-2 * scale
+    # the default state_order='second' needs third derivatives of the drift: refused, not approximated
+    with pytest.raises(NotImplementedError, match="no gradient kernel"):
+        cd.cdnlgssm_loglik_and_grad(P, y, t[..., None])
