@@ -109,3 +109,39 @@ def test_fit_sgd_recovers_lorenz63_parameters(hip_lib):
     ll_fit = model.marginal_log_prob(new, y, t[..., None]).sum()
     assert ll_fit > model.marginal_log_prob(start, y, t[..., None]).sum()
     assert ll_fit > ll_true - 0.01 * abs(ll_true)
+
+
+@pytest.mark.gpu
+def test_fit_sgd_mlp_drift(hip_lib):
+    """BASELINE config 5 in miniature: SGD over the marginal log-likelihood of an MLP-drift model (partial observations).
+    First step against the oracle's adjoint gradient, then Adam lowers the loss."""
+    from helpers import mlp_model
+    rng = np.random.default_rng(4)
+    d, m = 4, 2
+    true = mlp_model(rng, d, m, (16, 16))
+    N, T = 12, 30
+    t = o.irregular_times(rng, N, T, 0.03)
+    y = o.simulate(true, t, rng)
+    start = mlp_model(np.random.default_rng(5), d, m, (16, 16))          # different weights, same everything else
+    P0 = params_from(start)
+    frozen = PP(trainable=False)
+    props = P0._replace(
+        initial=P0.initial._replace(mean=cd.LearnableVector(frozen), cov=cd.LearnableMatrix(frozen)),
+        dynamics=P0.dynamics._replace(drift=cd.LearnableMLP(*([PP()] * 6)), diffusion_coefficient=cd.LearnableMatrix(frozen),
+                                      diffusion_cov=cd.LearnableMatrix(frozen), approx_order=frozen),
+        emissions=P0.emissions._replace(emission_function=cd.LearnableLinear(frozen, frozen),
+                                        emission_cov=cd.LearnableMatrix(frozen)))
+    model = cd.ContDiscreteNonlinearGaussianSSM(d, m)
+    hyp = cd.EKFHyperParams(state_order="first")
+    lr = 0.1
+    new, losses = model.fit_sgd(P0, props, y, t[..., None], hyp, optimizer=fit.SGD(lr), batch_size=N, num_epochs=1)
+    ll, g = o.ekf_loglik_grad_adjoint(start, t, y)
+    np.testing.assert_allclose(losses[0], -ll.sum() / y.size, rtol=1e-10)
+    th1 = start.drift.theta() + lr * g.sum(0) / y.size
+    got = np.concatenate([np.asarray(a).ravel() for a in new.dynamics.drift])
+    np.testing.assert_allclose(got, th1, rtol=1e-8, atol=1e-10)
+    new, losses = model.fit_sgd(P0, props, y, t[..., None], hyp, optimizer=fit.Adam(0.01), batch_size=4, num_epochs=25,
+                                shuffle=True, key=1)
+    assert np.all(np.isfinite(losses)) and losses[-1] < losses[0] and losses[-5:].mean() < losses[:5].mean()
+    with pytest.raises(NotImplementedError, match="no gradient kernel"):
+        model.fit_sgd(P0, props, y, t[..., None], cd.EKFHyperParams(), num_epochs=1)   # state_order='second'
