@@ -797,8 +797,13 @@ def _step_sizes(t0, t1, dt0, tol, max_steps):
     return out
 
 
-def ekf_loglik_grad_adjoint(mdl: Model, t, y, dt0=0.01, dt_final=1e-10, max_steps=100000):
-    """Returns (ll [N], grad [N, n_theta]): EKF, state_order 'first', num_iter 1; float64."""
+def ekf_loglik_grad_adjoint(mdl: Model, t, y, dt0=0.01, dt_final=1e-10, max_steps=100000, full=False):
+    """Returns (ll [N], grad [N, n_theta]): EKF, state_order 'first', num_iter 1; float64.
+
+    ``full=True`` adds a dict with the gradients w.r.t. every other parameter of the model, each with a leading [N]:
+    m0, P0, L, Qc, H, bias, R and LQL (= the cotangent of L Qc L^T the first two are chained from).  Cotangents of the
+    symmetric matrices (P0, LQL, R; Qc through LQL) are symmetric: they pair with symmetric perturbations, which is
+    what every symmetric parametrisation (the reference's RealToPSDBijector) produces."""
     mdl = mdl.cast(np.float64)
     y = np.asarray(y, np.float64)
     t = np.asarray(t, np.float64)
@@ -831,6 +836,8 @@ def ekf_loglik_grad_adjoint(mdl: Model, t, y, dt0=0.01, dt_final=1e-10, max_step
                 P + dt * sum((_DP_A[i][j] * ks[j][1] for j in range(i)), np.zeros((d, d))))
 
     ll_out, g_out = np.zeros(N), np.zeros((N, npar))
+    extra = {"m0": np.zeros((N, d)), "P0": np.zeros((N, d, d)), "LQL": np.zeros((N, d, d)), "H": np.zeros((N, mm, d)),
+             "bias": np.zeros((N, mm)), "R": np.zeros((N, mm, mm))}
     for n in range(N):
         tn = t if t.ndim == 1 else t[n]
         # ---- forward sweep, keeping predicted and filtered moments ----
@@ -873,9 +880,13 @@ def ekf_loglik_grad_adjoint(mdl: Model, t, y, dt0=0.01, dt_final=1e-10, max_step
             Sbar = -X @ Pb @ X.T + 0.5 * np.outer(w, w) - 0.5 * Sinv
             Ub = np.linalg.solve(Sb, Kb)                           # [m,d]
             Sbar = Sbar + sym(-X @ Ub.T)
+            extra["R"][n] += Sbar
+            extra["H"][n] += 2 * Sbar @ HP - np.outer(vb, m_) + Ub @ P_
+            extra["bias"][n] -= vb
             Pb = Pb + sym(Ub.T @ H) + H.T @ Sbar @ H
             mb = mb - H.T @ vb
             if k == 0:
+                extra["m0"][n], extra["P0"][n] = mb, sym(Pb)
                 break
             # predict k-1 -> k: reverse the Dormand-Prince steps
             dts = _step_sizes(tn[k - 1], tn[k], dt0, 1e-10, max_steps)
@@ -896,12 +907,17 @@ def ekf_loglik_grad_adjoint(mdl: Model, t, y, dt0=0.01, dt_final=1e-10, max_step
                     F = jac(xs)
                     xb, tb = drift_vjp(drift, xs, lam, 2 * Lam @ Ps)
                     thb += tb
+                    extra["LQL"][n] += Lam
                     Yb[i] = (xb, F.T @ Lam + Lam @ F)
                 mb = mb + sum(Yb[i][0] for i in range(6))
                 Pb = sym(Pb + sum(Yb[i][1] for i in range(6)))
         ll_out[n] = ll
         g_out[n] = thb
-    return ll_out, g_out
+    if not full:
+        return ll_out, g_out
+    extra["L"] = extra["LQL"] @ mdl.L @ mdl.Qc.T + np.swapaxes(extra["LQL"], -1, -2) @ mdl.L @ mdl.Qc
+    extra["Qc"] = mdl.L.T @ extra["LQL"] @ mdl.L
+    return ll_out, g_out, extra
 
 
 # --------------------------------------------------------------------------------------

@@ -273,3 +273,35 @@ def test_adjoint_gradient_matches_finite_differences(kind):
         fd = (o.ekf_filter(_rebuild_drift(mdl, th0 + h * u), t, y, state_order="first")["marginal_loglik"]
               - o.ekf_filter(_rebuild_drift(mdl, th0 - h * u), t, y, state_order="first")["marginal_loglik"]) / (2 * h)
         np.testing.assert_allclose(g @ u, fd, rtol=1e-5, atol=1e-8)
+
+
+def test_adjoint_gradient_all_parameters_matches_finite_differences():
+    """full=True: gradients w.r.t. m0, P0, L, Qc, H, bias, R (general, non-diagonal values) along random directions."""
+    from helpers import mlp_model
+    rng = np.random.default_rng(3)
+    d, m = 4, 2
+    drift = mlp_model(rng, d, m, (6, 5)).drift
+    A, B, C = rng.standard_normal((d, d)), rng.standard_normal((m, m)), rng.standard_normal((d, d))
+    mdl = o.Model(drift, np.eye(d) + 0.2 * rng.standard_normal((d, d)), A @ A.T / d + 0.3 * np.eye(d), rng.standard_normal((m, d)),
+                  0.1 * rng.standard_normal(m), B @ B.T / m + 0.2 * np.eye(m), rng.standard_normal(d), C @ C.T / d + 0.5 * np.eye(d))
+    N, T = 2, 8
+    t = o.irregular_times(rng, N, T, 0.03)
+    y = o.simulate(mdl, t, rng)
+    _, _, ex = o.ekf_loglik_grad_adjoint(mdl, t, y, full=True)
+
+    def LL(**kw):
+        a = dict(L=mdl.L, Qc=mdl.Qc, H=mdl.H, bias=mdl.bias, R=mdl.R, m0=mdl.m0, P0=mdl.P0)
+        a.update(kw)
+        return o.ekf_filter(o.Model(drift, a["L"], a["Qc"], a["H"], a["bias"], a["R"], a["m0"], a["P0"]), t, y,
+                            state_order="first")["marginal_loglik"]
+
+    h = 1e-6
+    for name, symmetric in (("m0", False), ("P0", True), ("L", False), ("Qc", True), ("H", False), ("bias", False), ("R", True)):
+        base = getattr(mdl, name)
+        for _ in range(2):
+            u = rng.standard_normal(base.shape)
+            if symmetric:
+                u = 0.5 * (u + u.T)
+            fd = (LL(**{name: base + h * u}) - LL(**{name: base - h * u})) / (2 * h)
+            an = (ex[name] * u).reshape(N, -1).sum(1)
+            assert np.abs(fd - an).max() < 2e-5 * np.abs(fd).max(), name
