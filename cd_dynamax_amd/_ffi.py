@@ -88,7 +88,8 @@ SYMBOLS = (
      "cdkf_free", "cdkf_memcpy_h2d", "cdkf_memcpy_d2h", "cdkf_memset", "cdkf_synchronize", "cdkf_ll_sum_f64_dev",
      "cdkf_ll_sum_f32_dev", "cdkf_emission_moments_f64", "cdkf_emission_moments_f32", "cdkf_emission_moments_f64_dev",
      "cdkf_emission_moments_f32_dev", "cdkf_ekf_loglik_grad_f64", "cdkf_ekf_loglik_grad_f32",
-     "cdkf_ekf_loglik_grad_f64_dev", "cdkf_ekf_loglik_grad_f32_dev", "cdkf_grad_supported", "cdkf_grad_sum_f64_dev",
+     "cdkf_ekf_loglik_grad_f64_dev", "cdkf_ekf_loglik_grad_f32_dev", "cdkf_grad_supported", "cdkf_grad_all_supported", "cdkf_ekf_loglik_grad_all_f64",
+     "cdkf_ekf_loglik_grad_all_f32", "cdkf_ekf_loglik_grad_all_f64_dev", "cdkf_ekf_loglik_grad_all_f32_dev", "cdkf_grad_sum_f64_dev",
      "cdkf_grad_sum_f32_dev"]
     + [f"cdkf_{a}_{p}{s}" for a in _ALGOS for p in ("f64", "f32") for s in ("", "_dev")]
 )
@@ -134,6 +135,16 @@ def lib() -> C.CDLL:
         f.restype = C.c_int
     L.cdkf_grad_supported.argtypes = [C.POINTER(CdkfModel), C.POINTER(CdkfOpts)]
     L.cdkf_grad_supported.restype = C.c_int
+    L.cdkf_grad_all_supported.argtypes = [C.POINTER(CdkfModel), C.POINTER(CdkfOpts)]
+    L.cdkf_grad_all_supported.restype = C.c_int
+    for p in ("f64", "f32"):
+        base = [C.POINTER(CdkfModel), C.POINTER(CdkfOpts), C.c_int64, C.c_int64] + [C.c_void_p] * 6
+        f = getattr(L, f"cdkf_ekf_loglik_grad_all_{p}")
+        f.argtypes = base
+        f.restype = C.c_int
+        f = getattr(L, f"cdkf_ekf_loglik_grad_all_{p}_dev")
+        f.argtypes = base + [C.c_void_p]
+        f.restype = C.c_int
     for p in ("f64", "f32"):
         base = [C.POINTER(CdkfModel), C.POINTER(CdkfOpts), C.c_int64, C.c_int64] + [C.c_void_p] * 5
         f = getattr(L, f"cdkf_ekf_loglik_grad_{p}")
@@ -258,8 +269,13 @@ def run_host(algo: str, mdl: ModelBlock, opts: CdkfOpts, t: np.ndarray, y: np.nd
     return ll, outs, status
 
 
-def loglik_grad(mdl: ModelBlock, opts: CdkfOpts, t: np.ndarray, y: np.ndarray, dtype):
-    """cdkf_ekf_loglik_grad_<f32|f64> on host buffers (t [N,T] or [T], y [N,T,m]): returns (ll [N], grad [N, n_theta], status)."""
+def model_grad_size(d: int, m: int) -> int:
+    return d + 2 * d * d + m * d + m + m * m
+
+
+def loglik_grad(mdl: ModelBlock, opts: CdkfOpts, t: np.ndarray, y: np.ndarray, dtype, with_model: bool = False):
+    """cdkf_ekf_loglik_grad[_all]_<f32|f64> on host buffers (t [N,T] or [T], y [N,T,m]): returns (ll [N], grad [N, n_theta],
+    status) and, ``with_model``, the model block [N, d + 2 d^2 + m d + m + m^2] as a fourth item."""
     dtype = np.dtype(dtype)
     suffix = {np.dtype(np.float32): "f32", np.dtype(np.float64): "f64"}[dtype]
     N, T, m = y.shape
@@ -270,6 +286,11 @@ def loglik_grad(mdl: ModelBlock, opts: CdkfOpts, t: np.ndarray, y: np.ndarray, d
     ll = np.empty((N,), dtype)
     grad = np.empty((N, mdl.theta.size), dtype)
     status = np.zeros((N,), np.int32)
+    if with_model:
+        gm = np.empty((N, model_grad_size(mdl.state_dim, mdl.emission_dim)), dtype)
+        fn = getattr(lib(), f"cdkf_ekf_loglik_grad_all_{suffix}")
+        check(fn(C.byref(mdl.c), C.byref(opts), N, T, _vp(t), _vp(y), _vp(ll), _vp(grad), _vp(gm), _vp(status)))
+        return ll, grad, status, gm
     fn = getattr(lib(), f"cdkf_ekf_loglik_grad_{suffix}")
     check(fn(C.byref(mdl.c), C.byref(opts), N, T, _vp(t), _vp(y), _vp(ll), _vp(grad), _vp(status)))
     return ll, grad, status

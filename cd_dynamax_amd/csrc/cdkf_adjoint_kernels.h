@@ -1,5 +1,6 @@
-// cdkf_adjoint_kernels.h -- reverse sweep (discrete adjoint) of the EKF log-likelihood for the MLP drift:
-// d ll / d theta for ALL drift parameters (h1 d + h1 + h2 h1 + h2 + d h2 + d of them) in one backward pass.
+// cdkf_adjoint_kernels.h -- reverse sweep (discrete adjoint) of the EKF log-likelihood, state_dim <= 8:
+// d ll / d theta for ALL drift parameters (MLP: h1 d + h1 + h2 h1 + h2 + d h2 + d of them) and, on request, for every
+// other parameter of the model (m0, P0, L Qc L^T, H, bias, R) in one backward pass.
 //
 // The reference gets this from jax.value_and_grad through the filter (ssm_temissions.py:550-568; reverse mode
 // through diffrax with RecursiveCheckpointAdjoint, diffrax_utils.py:49).  Same quantity here, written out:
@@ -41,14 +42,16 @@ struct AdjOff {  // per wavefront, in reals
   static constexpr int ck = 3408;  // kAdjCk x (64 P + 8 m), then kAdjCk step sizes
   static constexpr int end = 3408 + kAdjCk * 72 + kAdjCk;
 };
-template <typename R>
+template <typename R, bool MLP>
 constexpr int adj_waves() {
-  return sizeof(R) == 8 ? 2 : 4;
+  return (MLP && sizeof(R) == 8) ? 2 : 4;
 }
-template <typename R>
+template <typename R, bool MLP>
 constexpr size_t adj_lds_bytes() {
-  return sizeof(R) * (size_t)(AdjSh::end + adj_waves<R>() * AdjOff::end) + 64;
+  return sizeof(R) * (size_t)((MLP ? AdjSh::end : 0) + adj_waves<R, MLP>() * AdjOff::end) + 64;
 }
+// layout of the optional model-gradient block (per trajectory): m0 [d] | P0 [d,d] | LQL [d,d] | H [m,d] | bias [m] | R [m,m]
+__host__ __device__ inline long adj_model_grad_size(int d, int m) { return (long)d + 2L * d * d + (long)m * d + m + (long)m * m; }
 
 // Dormand-Prince tableau as arrays (static indices after unrolling)
 template <typename R>
@@ -62,19 +65,21 @@ struct Dp5T {
   static constexpr R b[6] = {Dp5<R>::b1, 0, Dp5<R>::b3, Dp5<R>::b4, Dp5<R>::b5, Dp5<R>::b6};
 };
 
-template <typename R>
-__global__ __launch_bounds__(64 * adj_waves<R>(), 1) void ekf_adjoint_wave8_kernel(const WgArgs<R> a, R* __restrict__ grad) {
-  constexpr int WAVES = adj_waves<R>();
+template <typename R, bool MLP>
+__global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wave8_kernel(const WgArgs<R> a, R* __restrict__ grad,
+                                                                                       R* __restrict__ grad_model) {
+  constexpr int WAVES = adj_waves<R, MLP>();
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   R* Sh = reinterpret_cast<R*>(smem_raw);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int i = lane >> 3, j = lane & 7;
   const int d = a.d, m = a.m, h1 = a.h1, h2 = a.h2;
-  R* W = Sh + AdjSh::end + wave * AdjOff::end;
+  R* W = Sh + (MLP ? AdjSh::end : 0) + wave * AdjOff::end;
   const R* th = a.par + a.o_theta;
   const long oW1 = 0, ob1 = oW1 + (long)h1 * d, oW2 = ob1 + h1, ob2 = oW2 + (long)h2 * h1, oW3 = ob2 + h2, ob3 = oW3 + (long)d * h2;
 
   // ---- shared weights, zero-padded -------------------------------------------------------------------------------
+  if constexpr (MLP) {
   for (int e = threadIdx.x; e < AdjSh::end; e += blockDim.x) Sh[e] = 0;
   __syncthreads();
   for (int e = threadIdx.x; e < h1 * d; e += blockDim.x) {
@@ -95,6 +100,7 @@ __global__ __launch_bounds__(64 * adj_waves<R>(), 1) void ekf_adjoint_wave8_kern
   }
   for (int e = threadIdx.x; e < d; e += blockDim.x) Sh[AdjSh::b3 + e] = th[ob3 + e];
   __syncthreads();
+  }
   const long n = (long)blockIdx.x * WAVES + wave;
   if (n >= a.N) return;  // whole wavefront; no workgroup barrier follows
 
@@ -105,20 +111,28 @@ __global__ __launch_bounds__(64 * adj_waves<R>(), 1) void ekf_adjoint_wave8_kern
   const R Rij = (i < m && j < m) ? (a.par + a.o_R)[i * m + j] : R(0);
   const R hbj = (lane < m) ? (a.par + a.o_hb)[lane] : R(0);
   R w1row[8], w3col[8];
+  R b1l = 0, b2l = 0;
+  if constexpr (MLP) {
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    w1row[k] = Sh[AdjSh::W1 + lane * 8 + k];
-    w3col[k] = Sh[AdjSh::W3 + k * 65 + lane];
+    for (int k = 0; k < 8; ++k) {
+      w1row[k] = Sh[AdjSh::W1 + lane * 8 + k];
+      w3col[k] = Sh[AdjSh::W3 + k * 65 + lane];
+    }
+    b1l = Sh[AdjSh::b1 + lane];
+    b2l = Sh[AdjSh::b2 + lane];
   }
-  const R b1l = Sh[AdjSh::b1 + lane], b2l = Sh[AdjSh::b2 + lane];
+  const R Wlin = (a.kind == kDriftLinear && inP) ? th[i * d + j] : R(0);  // linear drift: lane (i,k) holds W[i][k]
+  const R blin = (a.kind == kDriftLinear && lane < d) ? th[d * d + lane] : R(0);
 
   // ---- parameter-gradient accumulators (registers for the whole sweep) -------------------------------------------
-  R gW2[64], gW1[8], gW3[8];
+  R gW2[MLP ? 64 : 1], gW1[8], gW3[8];
   R gb1 = 0, gb2 = 0, gb3 = 0;
 #pragma unroll
-  for (int q = 0; q < 64; ++q) gW2[q] = 0;
+  for (int q = 0; q < (MLP ? 64 : 1); ++q) gW2[q] = 0;
 #pragma unroll
   for (int k = 0; k < 8; ++k) gW1[k] = gW3[k] = 0;
+  R gTile = 0, gVec = 0;                 // non-MLP drifts: linear dW[i][j] on lane (i, j); bias / Lorenz parameters on lanes < 8
+  R gQ = 0, gR = 0, gH = 0, gBias = 0;   // model block: d/d(L Qc L^T), d/dR, d/dH on lane (i, j); d/d bias on lanes < 8
 
   // ---- 8 x 8 tile products: lane (i, j) gets one entry ----------------------------------------------------------
   auto mm = [&](int TA, int TB) {  // (A B)_ij
@@ -183,13 +197,60 @@ __global__ __launch_bounds__(64 * adj_waves<R>(), 1) void ekf_adjoint_wave8_kern
     if (j == 0) W[AdjOff::f + i] = (i < d) ? fs + Sh[AdjSh::b3 + i] : R(0);
   };
 
+  // ---- registry drifts other than the MLP: Jacobian entry on lane (i, j), f in the LDS vector; needs W[x] (synced) ----
+  auto drift_fwd = [&](R& Fij) {
+    R xk[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) xk[k] = W[AdjOff::x + k];
+    Fij = 0;
+    R fi = 0;
+    if (a.kind == kDriftLinear) {
+      Fij = Wlin;
+      if (lane < 8) {
+        fi = blin;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (k < d) fi = rfma(th[lane < d ? lane * d + k : 0], xk[k], fi);
+      }
+    } else if (a.kind == kDriftLorenz63) {
+      const R sg = th[0], rho = th[1], bt = th[2];
+      if (i == 0) Fij = (j == 0) ? -sg : (j == 1 ? sg : R(0));
+      if (i == 1) Fij = (j == 0) ? rho - xk[2] : (j == 1 ? R(-1) : (j == 2 ? -xk[0] : R(0)));
+      if (i == 2) Fij = (j == 0) ? xk[1] : (j == 1 ? xk[0] : (j == 2 ? -bt : R(0)));
+      if (lane == 0) fi = sg * (xk[1] - xk[0]);
+      if (lane == 1) fi = xk[0] * (rho - xk[2]) - xk[1];
+      if (lane == 2) fi = xk[0] * xk[1] - bt * xk[2];
+    } else {  // Lorenz-96
+      auto X = [&](int q) { return W[AdjOff::x + q]; };
+      const int ip1 = (i + 1 >= d) ? 0 : i + 1, im1 = (i == 0) ? d - 1 : i - 1, im2 = (im1 == 0) ? d - 1 : im1 - 1;
+      if (inP) {
+        if (j == ip1) Fij = X(im1);
+        if (j == im2) Fij = -X(im1);
+        if (j == im1) Fij = X(ip1) - X(im2);
+        if (j == i) Fij = R(-1);
+      }
+      if (lane < d) {
+        const int l = lane;
+        const int lp1 = (l + 1 >= d) ? 0 : l + 1, lm1 = (l == 0) ? d - 1 : l - 1, lm2 = (lm1 == 0) ? d - 1 : lm1 - 1;
+        fi = rfma(X(lp1) - X(lm2), X(lm1), th[0] - X(l));
+      }
+    }
+    if (!inP) Fij = 0;
+    if (lane < 8) W[AdjOff::f + lane] = (lane < d) ? fi : R(0);
+  };
+
   // ---- right-hand side of the moment ODEs (state_order 'first') --------------------------------------------------
   auto rhs_fwd = [&](R xs, R Ps, R& kM, R& kP) {
     W[AdjOff::P + lane] = Ps;
     if (lane < 8) W[AdjOff::x + lane] = xs;
     wave_sync();
-    R xk[8], a1, d1, a2, d2, T[8], Fij;
-    mlp_fwd(xk, a1, d1, a2, d2, T, Fij);
+    R Fij;
+    if constexpr (MLP) {
+      R xk[8], a1, d1, a2, d2, T[8];
+      mlp_fwd(xk, a1, d1, a2, d2, T, Fij);
+    } else {
+      drift_fwd(Fij);
+    }
     W[AdjOff::F + lane] = Fij;
     wave_sync();
     const R acc = mm(AdjOff::F, AdjOff::P);
@@ -210,6 +271,54 @@ __global__ __launch_bounds__(64 * adj_waves<R>(), 1) void ekf_adjoint_wave8_kern
       W[AdjOff::lam + lane] = lam;
     }
     wave_sync();
+    gQ += Lam;
+    if constexpr (!MLP) {
+      R Fij;
+      drift_fwd(Fij);
+      W[AdjOff::F + lane] = Fij;
+      const R Gij = R(2) * mm(AdjOff::Lam, AdjOff::P);
+      W[AdjOff::G + lane] = Gij;
+      wave_sync();
+      YP = mm_tn(AdjOff::F, AdjOff::Lam) + mm(AdjOff::Lam, AdjOff::F);
+      auto G = [&](int r, int c) { return W[AdjOff::G + r * 8 + c]; };
+      if (a.kind == kDriftLinear) gTile = rfma(W[AdjOff::lam + i], W[AdjOff::x + j], gTile + Gij);
+      if (lane < 8) {
+        R s = 0;  // (F^T lam)_lane
+#pragma unroll
+        for (int r = 0; r < 8; ++r) s = rfma(W[AdjOff::F + r * 8 + lane], W[AdjOff::lam + r], s);
+        if (a.kind == kDriftLinear) {
+          gVec += lam;
+        } else if (a.kind == kDriftLorenz63) {
+          const R x0 = W[AdjOff::x + 0], x1 = W[AdjOff::x + 1], x2 = W[AdjOff::x + 2];
+          if (lane == 0) {
+            gVec += lam * (x1 - x0) - G(0, 0) + G(0, 1);
+            s += -G(1, 2) + G(2, 1);
+          } else if (lane == 1) {
+            gVec += lam * x0 + G(1, 0);
+            s += G(2, 0);
+          } else if (lane == 2) {
+            gVec += -lam * x2 - G(2, 2);
+            s += -G(1, 0);
+          }
+        } else {  // Lorenz-96: dF[i][i+1]/dx_{i-1} = 1, dF[i][i-2]/dx_{i-1} = -1, dF[i][i-1]/dx_{i+1} = 1, dF[i][i-1]/dx_{i-2} = -1
+          if (lane < d) {
+            auto wrap = [&](int q) { return q < 0 ? q + d : (q >= d ? q - d : q); };
+            const int c = lane;
+            const int c1 = wrap(c + 1), c2 = wrap(c + 2), cm1 = wrap(c - 1), cm2 = wrap(c - 2);
+            s += G(c1, c2) - G(c1, cm1) + G(cm1, cm2) - G(c2, c1);
+          }
+          if (lane == 0) {
+            R sl = 0;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) sl += W[AdjOff::lam + r];
+            gVec += sl;
+          }
+        }
+        YM = (lane < d) ? s : R(0);
+      }
+      wave_sync();
+      return;
+    } else {
     R xk[8], a1, d1, a2, d2, T[8], Fij;
     mlp_fwd(xk, a1, d1, a2, d2, T, Fij);
     W[AdjOff::F + lane] = Fij;
@@ -298,6 +407,7 @@ __global__ __launch_bounds__(64 * adj_waves<R>(), 1) void ekf_adjoint_wave8_kern
       YM = s;
     }
     wave_sync();
+    }
   };
 
   using TB = Dp5T<R>;
@@ -495,6 +605,10 @@ __global__ __launch_bounds__(64 * adj_waves<R>(), 1) void ekf_adjoint_wave8_kern
     if (!(i < m && j < m)) sbar = 0;
     W[AdjOff::B + lane] = sbar;
     wave_sync();
+    // model block: dR += Sbar; dH += 2 Sbar (H P) - vbar m^T + Ub P; dbias -= vbar
+    gR += sbar;
+    gH += R(2) * mm(AdjOff::B, AdjOff::HP) - W[AdjOff::vb + i] * W[AdjOff::x + j] + mm(AdjOff::Ub, AdjOff::P);
+    if (lane < 8) gBias -= vb;
     // Pbar <- Pbar + sym(Ub^T H) + H^T Sbar H;   mbar <- mbar - H^T vbar
     const R uh = mm_tn(AdjOff::Ub, AdjOff::H);
     const R sh = mm(AdjOff::B, AdjOff::H);
@@ -556,7 +670,32 @@ __global__ __launch_bounds__(64 * adj_waves<R>(), 1) void ekf_adjoint_wave8_kern
     }
   }
 
-  // ---- store this trajectory's gradient (theta ordering: W1, b1, W2, b2, W3, b3) ----------------------------------
+  // ---- model block: m0 | P0 | LQL | H | bias | R ------------------------------------------------------------------------
+  if (grad_model) {
+    R* gm = grad_model + n * adj_model_grad_size(d, m);
+    if (lane < d) gm[lane] = mb;
+    if (inP) {
+      gm[d + i * d + j] = Pb;
+      gm[d + d * d + i * d + j] = gQ;
+    }
+    R* gh = gm + d + 2 * d * d;
+    if (i < m && j < d) gh[i * d + j] = gH;
+    if (lane < m) gh[m * d + lane] = gBias;
+    if (i < m && j < m) gh[m * d + m + i * m + j] = gR;
+  }
+  // ---- drift block --------------------------------------------------------------------------------------------------------
+  if constexpr (!MLP) {
+    if (a.kind == kDriftLinear) {
+      R* g = grad + n * (long)(d * d + d);
+      if (inP) g[i * d + j] = gTile;
+      if (lane < d) g[d * d + lane] = gVec;
+    } else if (a.kind == kDriftLorenz63) {
+      if (lane < 3) grad[n * 3 + lane] = gVec;
+    } else {
+      if (lane == 0) grad[n] = gVec;
+    }
+  } else {
+  // MLP (theta ordering: W1, b1, W2, b2, W3, b3)
   R* g = grad + n * (ob3 + d);
   if (lane < h1) {
 #pragma unroll
@@ -574,6 +713,7 @@ __global__ __launch_bounds__(64 * adj_waves<R>(), 1) void ekf_adjoint_wave8_kern
       if (r < d) g[oW3 + (long)r * h2 + lane] = gW3[r];
   }
   if (lane < d) g[ob3 + lane] = gb3;
+  }
 }
 
 }  // namespace cdkf

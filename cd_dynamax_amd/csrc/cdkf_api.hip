@@ -141,7 +141,7 @@ int grad_sum_dev(const R* g, int64_t N, int64_t P, double* out, void* stream) {
 
 template <typename R>
 int loglik_grad_dev(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll,
-                    R* grad, int32_t* status, void* stream) {
+                    R* grad, R* grad_model, int32_t* status, void* stream) {
   int rc = check_common(mdl, o, N, T, t, y, ll);
   if (rc) return rc;
   if (!grad) {
@@ -150,12 +150,12 @@ int loglik_grad_dev(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_
   }
   if (N == 0) return CDKF_OK;
   if ((rc = select_device(o))) return rc;
-  return launch_ekf_grad<R>(mdl, o, N, T, t, y, ll, grad, status, (hipStream_t)stream);
+  return launch_ekf_grad<R>(mdl, o, N, T, t, y, ll, grad, grad_model, status, (hipStream_t)stream);
 }
 
 template <typename R>
 int loglik_grad_host(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll,
-                     R* grad, int32_t* status) {
+                     R* grad, R* grad_model, int32_t* status) {
   int rc = check_common(mdl, o, N, T, t, y, ll);
   if (rc) return rc;
   if (!grad) {
@@ -166,17 +166,22 @@ int loglik_grad_host(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64
   if ((rc = select_device(o))) return rc;
   const size_t nt = (size_t)(o->t_shared ? T : N * T), ny = (size_t)N * T * mdl->emission_dim;
   const size_t ng = (size_t)N * (size_t)mdl->n_theta;
-  DevBuf dt, dy, dll, dg, dst;
+  const size_t dd = mdl->state_dim, mm = mdl->emission_dim;
+  const size_t ngm = (size_t)N * (dd + 2 * dd * dd + mm * dd + mm + mm * mm);
+  DevBuf dt, dy, dll, dg, dst, dgm;
+  if (grad_model && (rc = dgm.alloc(ngm * sizeof(R)))) return rc;
   if ((rc = dt.alloc(nt * sizeof(R))) || (rc = dy.alloc(ny * sizeof(R))) || (rc = dll.alloc(N * sizeof(R))) ||
       (rc = dg.alloc(ng * sizeof(R))) || (rc = dst.alloc(N * sizeof(int32_t))))
     return rc;
   CDKF_HIP_CHECK(hipMemcpy(dt.p, t, nt * sizeof(R), hipMemcpyHostToDevice));
   CDKF_HIP_CHECK(hipMemcpy(dy.p, y, ny * sizeof(R), hipMemcpyHostToDevice));
-  rc = launch_ekf_grad<R>(mdl, o, N, T, (const R*)dt.p, (const R*)dy.p, (R*)dll.p, (R*)dg.p, (int32_t*)dst.p, nullptr);
+  rc = launch_ekf_grad<R>(mdl, o, N, T, (const R*)dt.p, (const R*)dy.p, (R*)dll.p, (R*)dg.p, (R*)dgm.p, (int32_t*)dst.p,
+                          nullptr);
   if (rc) return rc;
   CDKF_HIP_CHECK(hipDeviceSynchronize());
   CDKF_HIP_CHECK(hipMemcpy(ll, dll.p, N * sizeof(R), hipMemcpyDeviceToHost));
   CDKF_HIP_CHECK(hipMemcpy(grad, dg.p, ng * sizeof(R), hipMemcpyDeviceToHost));
+  if (grad_model) CDKF_HIP_CHECK(hipMemcpy(grad_model, dgm.p, ngm * sizeof(R), hipMemcpyDeviceToHost));
   if (status) CDKF_HIP_CHECK(hipMemcpy(status, dst.p, N * sizeof(int32_t), hipMemcpyDeviceToHost));
   return CDKF_OK;
 }
@@ -415,19 +420,49 @@ int cdkf_emission_moments_f32_dev(const cdkf_model* mdl, int64_t rows, const flo
 
 int cdkf_ekf_loglik_grad_f64(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const double* t,
                              const double* y, double* ll, double* grad, int32_t* status) {
-  return loglik_grad_host<double>(mdl, o, N, T, t, y, ll, grad, status);
+  return loglik_grad_host<double>(mdl, o, N, T, t, y, ll, grad, nullptr, status);
 }
 int cdkf_ekf_loglik_grad_f32(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const float* t,
                              const float* y, float* ll, float* grad, int32_t* status) {
-  return loglik_grad_host<float>(mdl, o, N, T, t, y, ll, grad, status);
+  return loglik_grad_host<float>(mdl, o, N, T, t, y, ll, grad, nullptr, status);
 }
 int cdkf_ekf_loglik_grad_f64_dev(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const double* t,
                                  const double* y, double* ll, double* grad, int32_t* status, void* stream) {
-  return loglik_grad_dev<double>(mdl, o, N, T, t, y, ll, grad, status, stream);
+  return loglik_grad_dev<double>(mdl, o, N, T, t, y, ll, grad, nullptr, status, stream);
 }
 int cdkf_ekf_loglik_grad_f32_dev(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const float* t,
                                  const float* y, float* ll, float* grad, int32_t* status, void* stream) {
-  return loglik_grad_dev<float>(mdl, o, N, T, t, y, ll, grad, status, stream);
+  return loglik_grad_dev<float>(mdl, o, N, T, t, y, ll, grad, nullptr, status, stream);
+}
+static int need_model_grad(const void* gm) {
+  if (gm) return CDKF_OK;
+  set_error("loglik_grad_all: grad_model must not be NULL");
+  return CDKF_EINVAL;
+}
+int cdkf_ekf_loglik_grad_all_f64(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const double* t,
+                                 const double* y, double* ll, double* grad, double* grad_model, int32_t* status) {
+  if (int rc = need_model_grad(grad_model)) return rc;
+  return loglik_grad_host<double>(mdl, o, N, T, t, y, ll, grad, grad_model, status);
+}
+int cdkf_ekf_loglik_grad_all_f32(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const float* t,
+                                 const float* y, float* ll, float* grad, float* grad_model, int32_t* status) {
+  if (int rc = need_model_grad(grad_model)) return rc;
+  return loglik_grad_host<float>(mdl, o, N, T, t, y, ll, grad, grad_model, status);
+}
+int cdkf_ekf_loglik_grad_all_f64_dev(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const double* t,
+                                     const double* y, double* ll, double* grad, double* grad_model, int32_t* status,
+                                     void* stream) {
+  if (int rc = need_model_grad(grad_model)) return rc;
+  return loglik_grad_dev<double>(mdl, o, N, T, t, y, ll, grad, grad_model, status, stream);
+}
+int cdkf_ekf_loglik_grad_all_f32_dev(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const float* t,
+                                     const float* y, float* ll, float* grad, float* grad_model, int32_t* status,
+                                     void* stream) {
+  if (int rc = need_model_grad(grad_model)) return rc;
+  return loglik_grad_dev<float>(mdl, o, N, T, t, y, ll, grad, grad_model, status, stream);
+}
+int cdkf_grad_all_supported(const cdkf_model* mdl, const cdkf_opts* o) {
+  return (mdl && o && adjoint_shape_available(mdl, o)) ? 1 : 0;
 }
 int cdkf_grad_supported(const cdkf_model* mdl, const cdkf_opts* o) {
   return (mdl && o && grad_shape_available(mdl, o)) ? 1 : 0;

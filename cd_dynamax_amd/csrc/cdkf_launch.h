@@ -33,12 +33,12 @@ int launch_ekf_smoother(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, in
 // log-likelihood + gradient w.r.t. the drift parameters (launch_grad.hip); grad [N, n_theta]
 template <typename R>
 int launch_ekf_grad(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll,
-                    R* grad, int32_t* status, hipStream_t stream);
+                    R* grad, R* grad_model, int32_t* status, hipStream_t stream);
 bool grad_shape_available(const cdkf_model* mdl, const cdkf_opts* o);
-// reverse sweep for the MLP drift (launch_wg.hip, cdkf_adjoint_kernels.h)
+// reverse sweep, state_dim <= 8 (launch_wg.hip, cdkf_adjoint_kernels.h); grad_model (optional): [N, d + 2 d^2 + m d + m + m^2]
 template <typename R>
 int launch_ekf_grad_adjoint(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll,
-                            R* grad, int32_t* status, hipStream_t stream);
+                            R* grad, R* grad_model, int32_t* status, hipStream_t stream);
 bool adjoint_shape_available(const cdkf_model* mdl, const cdkf_opts* o);
 
 bool kernel_available(const cdkf_model* mdl, const cdkf_opts* o, int algo, int bytes_per_real);

@@ -14,14 +14,17 @@
 
 namespace cdkf {
 
-bool grad_shape_available(const cdkf_model* mdl, const cdkf_opts* o) {
-  if (adjoint_shape_available(mdl, o)) return true;
+static bool sens_shape_available(const cdkf_model* mdl, const cdkf_opts* o) {
   if (o->state_order == CDKF_ORDER_ZEROTH || o->num_iter != 1 || o->forecast) return false;
 #define X(KIND, DRIFT, D_, M_) \
   if (mdl->drift_kind == KIND && mdl->state_dim == D_ && mdl->emission_dim == M_) return true;
   CDKF_GRAD_SHAPES(X)
 #undef X
   return false;
+}
+
+bool grad_shape_available(const cdkf_model* mdl, const cdkf_opts* o) {
+  return sens_shape_available(mdl, o) || adjoint_shape_available(mdl, o);
 }
 
 template <typename R, int D, int M, typename Drift>
@@ -38,12 +41,16 @@ static int run_grad(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_
 
 template <typename R>
 int launch_ekf_grad(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll,
-                    R* grad, int32_t* status, hipStream_t stream) {
-  if (adjoint_shape_available(mdl, o)) return launch_ekf_grad_adjoint<R>(mdl, o, N, T, t, y, ll, grad, status, stream);
-  if (!grad_shape_available(mdl, o)) {
+                    R* grad, R* grad_model, int32_t* status, hipStream_t stream) {
+  // drift parameters only: forward sensitivities where a register-resident kernel exists (one sweep, no workspace);
+  // otherwise, and whenever the model block is requested, the forward + reverse sweep pair
+  const bool sens = !grad_model && sens_shape_available(mdl, o);
+  if (!sens && adjoint_shape_available(mdl, o))
+    return launch_ekf_grad_adjoint<R>(mdl, o, N, T, t, y, ll, grad, grad_model, status, stream);
+  if (!sens) {
     set_error("loglik_grad: no kernel for drift_kind=%d state_dim=%d emission_dim=%d state_order=%d num_iter=%d "
-              "(forward sensitivities: register-resident Lorenz-63 / linear shapes, state_order first|second; reverse "
-              "sweep: MLP drift with state_dim, emission_dim <= 8, hidden <= 64, state_order first; num_iter 1)",
+              "(forward sensitivities: register-resident Lorenz-63 / linear shapes; reverse sweep: state_dim, emission_dim "
+              "<= 8, MLP hidden <= 64 with state_order first; num_iter 1, state_order first|second)",
               mdl->drift_kind, mdl->state_dim, mdl->emission_dim, o->state_order, o->num_iter);
     return CDKF_EUNSUPPORTED;
   }
@@ -56,8 +63,8 @@ int launch_ekf_grad(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_
 }
 
 template int launch_ekf_grad<float>(const cdkf_model*, const cdkf_opts*, int64_t, int64_t, const float*, const float*,
-                                    float*, float*, int32_t*, hipStream_t);
+                                    float*, float*, float*, int32_t*, hipStream_t);
 template int launch_ekf_grad<double>(const cdkf_model*, const cdkf_opts*, int64_t, int64_t, const double*, const double*,
-                                     double*, double*, int32_t*, hipStream_t);
+                                     double*, double*, double*, int32_t*, hipStream_t);
 
 }  // namespace cdkf

@@ -333,15 +333,29 @@ static AdjWorkspace g_adj_ws;
 static std::mutex g_adj_mutex;
 
 bool adjoint_shape_available(const cdkf_model* mdl, const cdkf_opts* o) {
-  return mdl->drift_kind == CDKF_DRIFT_MLP_TANH && wave8_shape(mdl) && o->state_order == CDKF_ORDER_FIRST &&
-         o->num_iter == 1 && !o->forecast && expected_theta(mdl) == mdl->n_theta;
+  if (!wave8_shape(mdl) || !wg_shape_available(mdl, 8) || o->num_iter != 1 || o->forecast) return false;
+  if (o->state_order == CDKF_ORDER_ZEROTH) return false;
+  // the MLP has a non-zero grad(div f): its 'second' mean term would need third derivatives of the drift
+  if (mdl->drift_kind == CDKF_DRIFT_MLP_TANH && o->state_order != CDKF_ORDER_FIRST) return false;
+  return true;
+}
+
+template <typename R, bool MLP>
+static int launch_adjoint_kernel(const WgArgs<R>& a, R* grad, R* grad_model, hipStream_t stream) {
+  static const int cap_rc = wg_raise_lds_cap(&ekf_adjoint_wave8_kernel<R, MLP>);
+  if (cap_rc) return CDKF_EHIP;
+  constexpr int WAVES = adj_waves<R, MLP>();
+  constexpr size_t lds = adj_lds_bytes<R, MLP>();
+  const dim3 grid((unsigned)((a.N + WAVES - 1) / WAVES)), block(64 * WAVES);
+  auto kernel = ekf_adjoint_wave8_kernel<R, MLP>;
+  hipLaunchKernelGGL(kernel, grid, block, lds, stream, a, grad, grad_model);
+  CDKF_HIP_CHECK(hipGetLastError());
+  return CDKF_OK;
 }
 
 template <typename R>
 int launch_ekf_grad_adjoint(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll,
-                            R* grad, int32_t* status, hipStream_t stream) {
-  static const int cap_rc = wg_raise_lds_cap(ekf_adjoint_wave8_kernel<R>);
-  if (cap_rc) return CDKF_EHIP;
+                            R* grad, R* grad_model, int32_t* status, hipStream_t stream) {
   WgArgs<R> a{};
   R* blk = nullptr;
   ParamSlot* slot = nullptr;
@@ -368,24 +382,18 @@ int launch_ekf_grad_adjoint(const cdkf_model* mdl, const cdkf_opts* o, int64_t N
   a.t = t; a.y = y; a.ll = ll; a.status = status;
   a.fm = w; a.fP = w + nm; a.pm = w + nm + nP; a.pP = w + 2 * nm + nP;
   rc = launch_wave8<R>(a, stream);
-  if (!rc) {
-    constexpr int WAVES = adj_waves<R>();
-    hipLaunchKernelGGL(ekf_adjoint_wave8_kernel<R>, dim3((unsigned)((N + WAVES - 1) / WAVES)), dim3(64 * WAVES),
-                       adj_lds_bytes<R>(), stream, a, grad);
-    if (hipGetLastError() != hipSuccess) {
-      set_error("adjoint kernel launch failed");
-      rc = CDKF_EHIP;
-    }
-  }
+  if (!rc)
+    rc = (mdl->drift_kind == CDKF_DRIFT_MLP_TANH) ? launch_adjoint_kernel<R, true>(a, grad, grad_model, stream)
+                                                   : launch_adjoint_kernel<R, false>(a, grad, grad_model, stream);
   CDKF_HIP_CHECK(hipEventRecord(ws.done, stream));
   ws.in_flight = true;
   const int rc2 = param_pool_release(slot, stream);
   return rc ? rc : rc2;
 }
 template int launch_ekf_grad_adjoint<float>(const cdkf_model*, const cdkf_opts*, int64_t, int64_t, const float*, const float*,
-                                            float*, float*, int32_t*, hipStream_t);
+                                            float*, float*, float*, int32_t*, hipStream_t);
 template int launch_ekf_grad_adjoint<double>(const cdkf_model*, const cdkf_opts*, int64_t, int64_t, const double*,
-                                             const double*, double*, double*, int32_t*, hipStream_t);
+                                             const double*, double*, double*, double*, int32_t*, hipStream_t);
 
 #define INST(R)                                                                                                        \
   template int launch_ekf_filter_wg<R>(const cdkf_model*, const cdkf_opts*, int64_t, int64_t, const R*, const R*, R*,  \

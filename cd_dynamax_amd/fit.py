@@ -2,10 +2,13 @@
 :550-568, loop utils/optimize_utils.py:48-140 / dynamax run_sgd) with the value-and-gradient of the loss computed by
 the HIP sweep ``cdkf_ekf_loglik_grad_*`` instead of ``jax.value_and_grad`` through the filter.
 
-Scope: the trainable leaves must be fields of ``params.dynamics.drift`` (LearnableLorenz63 / LearnableLinear / LearnableMLP -- the
-set-up of the reference's own SGD timer, test_scripts/timers/timer_sgd.py:38-66, which freezes everything else) and
-carry no constrainer.  Any other trainable leaf raises NotImplementedError: there is no gradient for it here, and
-silently freezing it would change the optimisation problem.
+Scope.  Trainable drift leaves only (the set-up of the reference's own SGD timer, test_scripts/timers/timer_sgd.py:38-66):
+the drift-gradient entry point -- forward sensitivities for the register-resident Lorenz-63 / linear shapes, the reverse
+sweep otherwise.  Any other trainable leaf (initial mean / covariance, diffusion coefficient / covariance, emission
+weights / bias / covariance): the all-parameter reverse sweep (state and emission dimension <= 8).  Constrainers: ``None``
+or ``bijectors.RealToPSDBijector`` (the reference's choice for covariances); optimisation runs in the unconstrained space
+as in the reference (to_unconstrained / from_unconstrained, dynamax/parameters.py:53-90).  What the kernels cannot
+differentiate raises NotImplementedError -- silently freezing a leaf would change the optimisation problem.
 
 Data stay resident: every minibatch is uploaded once (time-major [T,w,B], the layout the gradient kernels coalesce
 on), the per-trajectory log-likelihoods and gradients are reduced on the device, and 1 + n_theta doubles come back
@@ -19,7 +22,7 @@ from typing import Any, List, Optional
 import numpy as np
 
 from . import _ffi
-from .params import EKFHyperParams, LearnableLinear, LearnableLorenz63, LearnableMLP, ParameterProperties
+from .params import EKFHyperParams, ParameterProperties
 
 
 class Adam:
@@ -55,127 +58,161 @@ class SGD:
 
 
 def _leaves(tree, prefix=""):
-    """(path, leaf) pairs of a props tree: NamedTuples are interior nodes, ParameterProperties are leaves."""
+    """(path, leaf) pairs of a props tree: NamedTuples are interior nodes, ParameterProperties are leaves; anything else
+    (e.g. the float ``approx_order``) is not a parameter."""
     if isinstance(tree, ParameterProperties):
         yield prefix, tree
     elif isinstance(tree, tuple) and hasattr(tree, "_fields"):
         for f in tree._fields:
             yield from _leaves(getattr(tree, f), f"{prefix}.{f}" if prefix else f)
-    elif tree is None:
-        return
-    else:
-        raise TypeError(f"unexpected entry of type {type(tree).__name__} at props.{prefix}")
+
+
+def _get(tree, path: str):
+    for f in path.split("."):
+        tree = getattr(tree, f)
+    return tree
+
+
+def _set(tree, path: str, value):
+    head, _, rest = path.partition(".")
+    return tree._replace(**{head: _set(getattr(tree, head), rest, value) if rest else value})
 
 
 def _drift_theta(drift) -> np.ndarray:
-    if isinstance(drift, LearnableLorenz63):
-        return np.array([drift.sigma, drift.rho, drift.beta], dtype=np.float64)
-    if isinstance(drift, LearnableLinear):
-        return np.concatenate([np.asarray(drift.weights, np.float64).ravel(), np.asarray(drift.bias, np.float64).ravel()])
-    if isinstance(drift, LearnableMLP):
-        return np.concatenate([np.asarray(a, np.float64).ravel() for a in drift])
-    raise NotImplementedError(f"fit_sgd: no gradient kernel for a drift of type {type(drift).__name__}")
+    return np.concatenate([np.asarray(a, np.float64).ravel() for a in drift])
 
 
 def _drift_from_theta(drift, theta: np.ndarray):
-    if isinstance(drift, LearnableLorenz63):
-        return LearnableLorenz63(sigma=float(theta[0]), rho=float(theta[1]), beta=float(theta[2]))
-    if isinstance(drift, LearnableMLP):
-        parts, off = [], 0
-        for a in drift:
-            shp = np.asarray(a).shape
-            parts.append(theta[off:off + int(np.prod(shp))].reshape(shp).copy())
-            off += int(np.prod(shp))
-        return LearnableMLP(*parts)
-    d = np.asarray(drift.weights).shape[0]
-    return LearnableLinear(weights=theta[: d * d].reshape(d, d).copy(), bias=theta[d * d:].copy())
+    parts, off = [], 0
+    for a in drift:
+        shp = np.asarray(a).shape
+        v = theta[off:off + int(np.prod(shp, dtype=np.int64))].reshape(shp)
+        parts.append(float(v) if shp == () else v.copy())
+        off += int(np.prod(shp, dtype=np.int64))
+    return type(drift)(*parts)
 
 
-def _trainable_mask(params, props) -> np.ndarray:
-    """Boolean mask over theta; raises for trainable leaves outside the drift or with a constrainer."""
-    drift = params.dynamics.drift
-    masks = {}
-    for path, leaf in _leaves(props):
-        if not leaf.trainable:
-            continue
-        if not path.startswith("dynamics.drift."):
-            raise NotImplementedError(
-                f"fit_sgd: props.{path} is trainable, but the HIP path differentiates the log-likelihood w.r.t. the drift "
-                "parameters only; set trainable=False on it (as test_scripts/timers/timer_sgd.py does)")
-        if leaf.constrainer is not None:
-            raise NotImplementedError(f"fit_sgd: constrainer on props.{path} is not supported")
-        masks[path.split(".")[-1]] = True
-    if isinstance(drift, LearnableLorenz63):
-        return np.array([masks.get(k, False) for k in ("sigma", "rho", "beta")])
-    if isinstance(drift, LearnableLinear):
-        d = np.asarray(drift.weights).shape[0]
-        return np.concatenate([np.full(d * d, masks.get("weights", False)), np.full(d, masks.get("bias", False))])
-    if isinstance(drift, LearnableMLP):
-        return np.concatenate([np.full(np.asarray(getattr(drift, f)).size, masks.get(f, False)) for f in drift._fields])
-    raise NotImplementedError(f"fit_sgd: no gradient kernel for a drift of type {type(drift).__name__}")
+class _Trainable:
+    """The trainable leaves of (params, props), flattened to one unconstrained vector."""
+
+    def __init__(self, params, props):
+        self.items = []  # (path, constrainer, shape, slice into the unconstrained vector)
+        off = 0
+        for path, leaf in _leaves(props):
+            if not leaf.trainable:
+                continue
+            value = np.asarray(_get(params, path), np.float64)
+            c = leaf.constrainer
+            if c is not None and not (hasattr(c, "forward") and hasattr(c, "inverse") and hasattr(c, "forward_vjp")):
+                raise NotImplementedError(
+                    f"fit_sgd: constrainer {type(c).__name__} on props.{path} is not supported (use None or "
+                    "cd_dynamax_amd.bijectors.RealToPSDBijector)")
+            n = value.size if c is None else np.asarray(c.inverse(value)).size
+            self.items.append((path, c, value.shape, slice(off, off + n)))
+            off += n
+        if not self.items:
+            raise ValueError("fit_sgd: no trainable parameters")
+        self.size = off
+        self.drift_only = all(p.startswith("dynamics.drift.") and c is None for p, c, _, _ in self.items)
+
+    def to_unconstrained(self, params) -> np.ndarray:
+        u = np.zeros(self.size)
+        for path, c, _, sl in self.items:
+            value = np.asarray(_get(params, path), np.float64)
+            u[sl] = value.ravel() if c is None else c.inverse(value)
+        return u
+
+    def from_unconstrained(self, params, u: np.ndarray):
+        for path, c, shape, sl in self.items:
+            value = u[sl].reshape(shape) if c is None else c.forward(u[sl])
+            params = _set(params, path, float(value) if np.ndim(value) == 0 else np.array(value))
+        return params
+
+    def pull_back(self, grads, u: np.ndarray) -> np.ndarray:
+        """Gradient tree (same structure as params) -> gradient w.r.t. the unconstrained vector."""
+        g = np.zeros(self.size)
+        for path, c, _, sl in self.items:
+            leaf = np.asarray(_get(grads, path), np.float64)
+            g[sl] = leaf.ravel() if c is None else c.forward_vjp(u[sl], leaf)
+        return g
 
 
 class _ResidentBatch:
     """One minibatch on the device: t [T,B] (or [T] shared), y [T,m,B], and the output buffers."""
 
-    def __init__(self, y: np.ndarray, t: np.ndarray, t_shared: bool, n_theta: int, dtype):
+    def __init__(self, y: np.ndarray, t: np.ndarray, t_shared: bool, n_theta: int, n_model: int, dtype):
         B, T, m = y.shape
-        self.B, self.T = B, T
+        self.B, self.T, self.n_theta, self.n_model = B, T, n_theta, n_model
         self.t = _ffi.DeviceArray.from_numpy(np.ascontiguousarray(t if t_shared else t.T, dtype=dtype))
         self.y = _ffi.DeviceArray.from_numpy(np.ascontiguousarray(y.transpose(1, 2, 0), dtype=dtype))
         self.ll = _ffi.DeviceArray((B,), dtype)
         self.grad = _ffi.DeviceArray((B, n_theta), dtype)
+        self.gmodel = _ffi.DeviceArray((B, n_model), dtype) if n_model else None
         self.status = _ffi.DeviceArray((B,), np.int32)
-        self.sums = _ffi.DeviceArray((1 + n_theta,), np.float64)
+        self.sums = _ffi.DeviceArray((1 + n_theta + n_model,), np.float64)
 
     def value_and_grad(self, mdl: _ffi.ModelBlock, opts, suffix: str):
+        """(sum ll, sum d ll/d theta [n_theta], sum d ll/d model block [n_model]) over the minibatch, reduced on the device."""
         L = _ffi.lib()
-        n_theta = mdl.theta.size
-        _ffi.check(getattr(L, f"cdkf_ekf_loglik_grad_{suffix}_dev")(
-            C.byref(mdl.c), C.byref(opts), self.B, self.T, self.t.ptr, self.y.ptr, self.ll.ptr, self.grad.ptr,
-            self.status.ptr, None))
+        if self.n_model:
+            _ffi.check(getattr(L, f"cdkf_ekf_loglik_grad_all_{suffix}_dev")(
+                C.byref(mdl.c), C.byref(opts), self.B, self.T, self.t.ptr, self.y.ptr, self.ll.ptr, self.grad.ptr,
+                self.gmodel.ptr, self.status.ptr, None))
+        else:
+            _ffi.check(getattr(L, f"cdkf_ekf_loglik_grad_{suffix}_dev")(
+                C.byref(mdl.c), C.byref(opts), self.B, self.T, self.t.ptr, self.y.ptr, self.ll.ptr, self.grad.ptr,
+                self.status.ptr, None))
         sums = self.sums.ptr.value
         _ffi.check(getattr(L, f"cdkf_ll_sum_{suffix}_dev")(self.ll.ptr, self.B, C.c_void_p(sums), None))
-        _ffi.check(getattr(L, f"cdkf_grad_sum_{suffix}_dev")(self.grad.ptr, self.B, n_theta, C.c_void_p(sums + 8), None))
+        _ffi.check(getattr(L, f"cdkf_grad_sum_{suffix}_dev")(self.grad.ptr, self.B, self.n_theta, C.c_void_p(sums + 8), None))
+        if self.n_model:
+            _ffi.check(getattr(L, f"cdkf_grad_sum_{suffix}_dev")(self.gmodel.ptr, self.B, self.n_model,
+                                                                C.c_void_p(sums + 8 * (1 + self.n_theta)), None))
         _ffi.check(L.cdkf_synchronize(None))
         out = self.sums.numpy()
-        return float(out[0]), out[1:]
+        return float(out[0]), out[1:1 + self.n_theta], out[1 + self.n_theta:]
 
     def free(self):
-        for a in (self.t, self.y, self.ll, self.grad, self.status, self.sums):
-            a.free()
+        for a in (self.t, self.y, self.ll, self.grad, self.gmodel, self.status, self.sums):
+            if a is not None:
+                a.free()
 
 
 def fit_sgd(model, params, props, emissions, t_emissions=None, filter_hyperparams: Optional[Any] = None, inputs=None,
             optimizer=None, batch_size: int = 1, num_epochs: int = 50, shuffle: bool = False,
             return_param_history: bool = False, return_grad_history: bool = False, key=0, dtype=None,
             allreduce=None):
-    """Minimise ``-(log_prior + sum_n ll_n * scale) / emissions.size`` over the trainable drift parameters
-    (ssm_temissions.py:550-568).  Returns ``(params, losses)`` (+ parameter / gradient histories when requested, one
-    entry per epoch as the reference's scan returns them, optimize_utils.py:128-131).
+    """Minimise ``-(log_prior + sum_n ll_n * scale) / emissions.size`` over the trainable parameters, in the unconstrained
+    space (ssm_temissions.py:548-583).  Returns ``(params, losses)`` (+ parameter / gradient histories when requested, one
+    entry per epoch as the reference's scan returns them, optimize_utils.py:128-131; gradients are those of the loss
+    w.r.t. the unconstrained parameters, packed like ``params`` for unconstrained leaves).
 
     ``key``: seed of the NumPy generator that permutes the sequences when ``shuffle`` (JAX's PRNG stream is not
     reproduced).  ``allreduce``: optional callable summing a float64 array over data-parallel ranks
     (``distributed.allreduce_sum_array``) -- each rank then passes its own block of sequences and every rank applies the
     same update."""
-    from .models import _model_block, _opts, _prepare
+    from .models import _grads_tree, _model_block, _opts, _prepare
     hyper = EKFHyperParams() if filter_hyperparams is None else filter_hyperparams
     if not isinstance(hyper, EKFHyperParams):
         raise NotImplementedError("fit_sgd: gradients are provided for the EKF marginal log-likelihood only")
     optimizer = Adam(1e-3) if optimizer is None else optimizer
-    mask = _trainable_mask(params, props)
+    tr = _Trainable(params, props)
     opts = _opts(hyper, 1)
     y, t, batched, dtype = _prepare(emissions, t_emissions, hyper, opts, dtype)
     opts.layout = _ffi.LAYOUT_TCN
     suffix = "f32" if dtype == np.float32 else "f64"
     mdl0 = _model_block(params)
-    if not _ffi.lib().cdkf_grad_supported(C.byref(mdl0.c), C.byref(opts)):
+    check = _ffi.lib().cdkf_grad_supported if tr.drift_only else _ffi.lib().cdkf_grad_all_supported
+    if not check(C.byref(mdl0.c), C.byref(opts)):
+        what = "drift gradient" if tr.drift_only else "all-parameter reverse-sweep"
         raise NotImplementedError(
-            f"fit_sgd: no gradient kernel for drift {type(params.dynamics.drift).__name__} with state_dim="
-            f"{mdl0.state_dim}, emission_dim={mdl0.emission_dim}, state_order={hyper.state_order}")
+            f"fit_sgd: no {what} kernel for drift {type(params.dynamics.drift).__name__} with state_dim={mdl0.state_dim}, "
+            f"emission_dim={mdl0.emission_dim}, state_order={hyper.state_order}"
+            + ("" if tr.drift_only else f"; trainable: {[p for p, _, _, _ in tr.items]}"))
     N = y.shape[0]
     size = float(y.size)
     n_theta = mdl0.theta.size
+    n_model = 0 if tr.drift_only else _ffi.model_grad_size(mdl0.state_dim, mdl0.emission_dim)
     t_shared = bool(opts.t_shared)
     num_batches = -(-N // batch_size)
     if batch_size >= N:
@@ -183,16 +220,16 @@ def fit_sgd(model, params, props, emissions, t_emissions=None, filter_hyperparam
     rng = np.random.default_rng(key if isinstance(key, (int, np.integer)) else 0)
 
     def build(idx):
-        return _ResidentBatch(y[idx], t if t_shared else t[idx], t_shared, n_theta, dtype)
+        return _ResidentBatch(y[idx], t if t_shared else t[idx], t_shared, n_theta, n_model, dtype)
 
     order = np.arange(N)
     resident: List[_ResidentBatch] = []
     if not shuffle:
         resident = [build(order[b * batch_size:(b + 1) * batch_size]) for b in range(num_batches)]
 
-    theta = _drift_theta(params.dynamics.drift)
-    state = optimizer.init(theta)
-    losses, theta_hist, grad_hist = [], [], []
+    u = tr.to_unconstrained(params)
+    state = optimizer.init(u)
+    losses, param_hist, grad_hist = [], [], []
     cur = params
     try:
         for _ in range(num_epochs):
@@ -202,30 +239,32 @@ def fit_sgd(model, params, props, emissions, t_emissions=None, filter_hyperparam
                     b.free()
                 resident = [build(perm[b * batch_size:(b + 1) * batch_size]) for b in range(num_batches)]
             avg = 0.0
-            g_loss = np.zeros(n_theta)
+            g_u = np.zeros(tr.size)
             for itr, batch in enumerate(resident):
-                cur = params._replace(dynamics=params.dynamics._replace(drift=_drift_from_theta(params.dynamics.drift, theta)))
-                ll_sum, g_sum = batch.value_and_grad(_model_block(cur), opts, suffix)
+                cur = tr.from_unconstrained(params, u)
+                mdl = _model_block(cur)
+                ll_sum, g_th, g_md = batch.value_and_grad(mdl, opts, suffix)
                 if allreduce is not None:
-                    red = allreduce(np.concatenate([[ll_sum], g_sum]))
-                    ll_sum, g_sum = float(red[0]), red[1:]
+                    red = allreduce(np.concatenate([[ll_sum], g_th, g_md]))
+                    ll_sum, g_th, g_md = float(red[0]), red[1:1 + n_theta], red[1 + n_theta:]
+                grads = _grads_tree(cur, mdl, g_th, g_md if n_model else None)
                 scale = N / batch.B
                 loss = -(ll_sum * scale) / size
-                g_loss = np.where(mask, -(g_sum * scale) / size, 0.0)
-                upd, state = optimizer.update(g_loss, state)
-                theta = theta + np.where(mask, upd, 0.0)
+                g_u = -(tr.pull_back(grads, u) * scale) / size
+                upd, state = optimizer.update(g_u, state)
+                u = u + upd
                 avg = (avg * itr + loss) / (itr + 1)
             losses.append(avg)
-            theta_hist.append(theta.copy())
-            grad_hist.append(g_loss.copy())
+            if return_param_history:
+                param_hist.append(tr.from_unconstrained(params, u))
+            if return_grad_history:
+                grad_hist.append(g_u.copy())
     finally:
         for b in resident:
             b.free()
-    drift0 = params.dynamics.drift
-    final = params._replace(dynamics=params.dynamics._replace(drift=_drift_from_theta(drift0, theta)))
-    out = [final, np.asarray(losses)]
+    out = [tr.from_unconstrained(params, u), np.asarray(losses)]
     if return_param_history:
-        out.append([_drift_from_theta(drift0, th) for th in theta_hist])
+        out.append(param_hist)
     if return_grad_history:
-        out.append([_drift_from_theta(drift0, g) for g in grad_hist])
+        out.append(grad_hist)
     return tuple(out)

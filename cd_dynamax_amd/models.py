@@ -175,6 +175,8 @@ def _drift_like(drift, theta_grad):
     """Pack a gradient array [..., n_theta] into the drift's own NamedTuple (the pytree jax.grad would return)."""
     if isinstance(drift, LearnableLorenz63):
         return LearnableLorenz63(sigma=theta_grad[..., 0], rho=theta_grad[..., 1], beta=theta_grad[..., 2])
+    if isinstance(drift, LearnableLorenz96):
+        return LearnableLorenz96(forcing=theta_grad[..., 0])
     if isinstance(drift, LearnableMLP):
         lead, parts, off = theta_grad.shape[:-1], [], 0
         for a in drift:
@@ -185,6 +187,36 @@ def _drift_like(drift, theta_grad):
     d = np.asarray(drift.weights).shape[0]
     return LearnableLinear(weights=theta_grad[..., : d * d].reshape(theta_grad.shape[:-1] + (d, d)),
                            bias=theta_grad[..., d * d:])
+
+
+def _grads_tree(params: ParamsCDNLGSSM, mdl: _ffi.ModelBlock, g_theta, g_model=None) -> ParamsCDNLGSSM:
+    """Device gradient blocks ([..., n_theta] and [..., d + 2 d^2 + m d + m + m^2]) -> a ParamsCDNLGSSM of gradients.
+    Without the model block the non-drift leaves are zeros."""
+    d, m = mdl.state_dim, mdl.emission_dim
+    g_theta = np.asarray(g_theta)
+    lead = g_theta.shape[:-1]
+    if g_model is None:
+        g_model = np.zeros(lead + (_ffi.model_grad_size(d, m),), g_theta.dtype)
+    off = 0
+
+    def take(*shape):
+        nonlocal off
+        n = int(np.prod(shape))
+        out = g_model[..., off:off + n].reshape(lead + shape)
+        off += n
+        return out
+
+    g_m0, g_P0, g_LQL, g_H, g_b, g_R = take(d), take(d, d), take(d, d), take(m, d), take(m), take(m, m)
+    L, Qc = mdl.L.astype(g_model.dtype), mdl.Qc.astype(g_model.dtype)
+    g_L = g_LQL @ L @ Qc.T + np.swapaxes(g_LQL, -1, -2) @ L @ Qc      # LQL = L Qc L^T
+    g_Qc = L.T @ g_LQL @ L
+    return ParamsCDNLGSSM(
+        initial=ParamsLGSSMInitial(mean=LearnableVector(g_m0), cov=LearnableMatrix(g_P0)),
+        dynamics=ParamsCDNLGSSMDynamics(drift=_drift_like(params.dynamics.drift, g_theta),
+                                        diffusion_coefficient=LearnableMatrix(g_L), diffusion_cov=LearnableMatrix(g_Qc),
+                                        approx_order=0.0),
+        emissions=ParamsCDNLGSSMEmissions(emission_function=LearnableLinear(weights=g_H, bias=g_b),
+                                          emission_cov=LearnableMatrix(g_R)))
 
 
 def cdnlgssm_loglik_and_grad(
@@ -201,8 +233,9 @@ def cdnlgssm_loglik_and_grad(
     ``grad`` an instance of the drift's class whose fields hold d ll / d field (leading ``[N]`` when batched).
 
     LearnableLorenz63 / LearnableLinear at the register-resident shapes: forward sensitivities inside the sweep,
-    ``state_order`` first or second.  LearnableMLP (state_dim, emission_dim <= 8, hidden <= 64): reverse sweep (discrete
-    adjoint) for all weights and biases, ``state_order='first'``.  Anything else raises (no finite-difference fallback)."""
+    ``state_order`` first or second.  Any registry drift with state_dim, emission_dim <= 8 (LearnableMLP: hidden <= 64 and
+    ``state_order='first'``): forward + reverse sweep (discrete adjoint).  Anything else raises (no finite-difference
+    fallback)."""
     if not isinstance(hyperparams, EKFHyperParams):
         raise NotImplementedError("gradients are provided for the EKF marginal log-likelihood only")
     mdl = _model_block(params)
@@ -216,6 +249,38 @@ def cdnlgssm_loglik_and_grad(
     if not batched:
         ll, grad = ll[0], grad[0]
     return ll, _drift_like(params.dynamics.drift, grad)
+
+
+def cdnlgssm_loglik_and_grad_all(
+    params: ParamsCDNLGSSM,
+    emissions,
+    t_emissions=None,
+    hyperparams: EKFHyperParams = EKFHyperParams(),
+    inputs=None,
+    dtype=None,
+):
+    """EKF marginal log-likelihood and its gradient w.r.t. EVERY parameter: returns ``(ll, grads)`` with ``grads`` a
+    ``ParamsCDNLGSSM`` of the same structure as ``params`` (what ``jax.grad`` of ``marginal_log_prob`` returns in the
+    reference, ssm_temissions.py:550-568), leaves carrying a leading ``[N]`` for batched emissions.
+
+    One forward and one reverse sweep on the device (cdkf_ekf_loglik_grad_all_*): state and emission dimension <= 8, any
+    registry drift (MLP: ``state_order='first'``).  Gradients of the symmetric matrices (initial covariance, diffusion
+    covariance, emission covariance) are symmetric cotangents: exact for symmetric perturbations, i.e. for any symmetric
+    parametrisation such as the reference's ``RealToPSDBijector``."""
+    if not isinstance(hyperparams, EKFHyperParams):
+        raise NotImplementedError("gradients are provided for the EKF marginal log-likelihood only")
+    mdl = _model_block(params)
+    opts = _opts(hyperparams, 1)
+    y, t, batched, dtype = _prepare(emissions, t_emissions, hyperparams, opts, dtype)
+    if not _ffi.lib().cdkf_grad_all_supported(_ffi.C.byref(mdl.c), _ffi.C.byref(opts)):
+        raise NotImplementedError(
+            f"no reverse-sweep kernel for drift {type(params.dynamics.drift).__name__} with state_dim={mdl.state_dim}, "
+            f"emission_dim={mdl.emission_dim}, state_order={hyperparams.state_order} (needs dimensions <= 8; MLP drift: "
+            "state_order='first')")
+    ll, gth, _, gm = _ffi.loglik_grad(mdl, opts, t, y, dtype, with_model=True)
+    if not batched:
+        ll, gth, gm = ll[0], gth[0], gm[0]
+    return ll, _grads_tree(params, mdl, gth, gm)
 
 
 def cdnlgssm_forecast(

@@ -210,8 +210,9 @@ int cdkf_emission_moments_f32_dev(const cdkf_model* mdl, int64_t rows, const flo
 
 /* ---- marginal log-likelihood AND its gradient w.r.t. the drift parameters theta (ordering of cdkf_model.theta):
  *      replaces jax.value_and_grad of the fit_sgd loss, src/ssm_temissions.py:550-568, for the drift block of
- *      the parameters (what the Lorenz-63 parameter-estimation tutorials learn).  EKF, state_order first/second,
- *      num_iter 1; shapes: cdkf_grad_supported().  ll [N], grad [N, n_theta] row-major whatever opts.layout is
+ *      the parameters (what the Lorenz-63 parameter-estimation tutorials learn).  EKF, num_iter 1; state_order
+ *      first/second (MLP drift: first only -- its 'second' mean term needs third derivatives); shapes:
+ *      cdkf_grad_supported().  ll [N], grad [N, n_theta] row-major whatever opts.layout is
  *      (t and y follow opts.layout).  Exact derivative of the discretised recursion (forward sensitivities). -- */
 int cdkf_ekf_loglik_grad_f64(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T, const double* t,
                              const double* y, double* ll, double* grad, int32_t* status);
@@ -221,6 +222,24 @@ int cdkf_ekf_loglik_grad_f64_dev(const cdkf_model* mdl, const cdkf_opts* opts, i
                                  const double* y, double* ll, double* grad, int32_t* status, void* stream);
 int cdkf_ekf_loglik_grad_f32_dev(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T, const float* t,
                                  const float* y, float* ll, float* grad, int32_t* status, void* stream);
+/* ---- the same plus the gradient w.r.t. every other model parameter (the remaining leaves of the pytree jax.grad returns
+ *      for ParamsCDNLGSSM): grad_model [N, d + 2 d^2 + m d + m + m^2] row-major, per trajectory
+ *          m0 [d] | P0 [d,d] | LQL [d,d] | H [m,d] | h_bias [m] | R [m,m]
+ *      LQL is the cotangent of L Qc L^T: dL = 2 LQL L Qc and dQc = L^T LQL L for symmetric Qc (the caller chains these;
+ *      the Python host does).  Cotangents of the symmetric matrices (P0, LQL, R) are symmetric: they pair with
+ *      symmetric perturbations, which is what a symmetric parametrisation (dynamax RealToPSDBijector) produces.
+ *      Reverse sweep (discrete adjoint), state_dim and emission_dim <= 8: cdkf_grad_all_supported(). ------------------- */
+int cdkf_ekf_loglik_grad_all_f64(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T, const double* t,
+                                 const double* y, double* ll, double* grad, double* grad_model, int32_t* status);
+int cdkf_ekf_loglik_grad_all_f32(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T, const float* t,
+                                 const float* y, float* ll, float* grad, float* grad_model, int32_t* status);
+int cdkf_ekf_loglik_grad_all_f64_dev(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T, const double* t,
+                                     const double* y, double* ll, double* grad, double* grad_model, int32_t* status,
+                                     void* stream);
+int cdkf_ekf_loglik_grad_all_f32_dev(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T, const float* t,
+                                     const float* y, float* ll, float* grad, float* grad_model, int32_t* status,
+                                     void* stream);
+int cdkf_grad_all_supported(const cdkf_model* mdl, const cdkf_opts* opts);
 /* 1 if cdkf_ekf_loglik_grad_* has a kernel for this model/options, else 0 */
 int cdkf_grad_supported(const cdkf_model* mdl, const cdkf_opts* opts);
 /* out[p] = sum_n grad[n, p] on the device (the `.sum()` of ssm_temissions.py:567 applied to the gradient), so a

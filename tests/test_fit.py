@@ -45,19 +45,52 @@ def test_adam_matches_optax_formula():
     np.testing.assert_allclose(u, -0.5 * g1)
 
 
-def test_trainable_mask_and_refusals():
+def test_trainable_leaves_flatten_and_refusals():
+    from cd_dynamax_amd.bijectors import RealToPSDBijector
     model, params, props = _l63_problem()
-    np.testing.assert_array_equal(fit._trainable_mask(params, props), [True, True, True])
-    p2 = props._replace(dynamics=props.dynamics._replace(drift=cd.LearnableLorenz63(PP(), PP(False), PP())))
-    np.testing.assert_array_equal(fit._trainable_mask(params, p2), [True, False, True])
-    p3 = props._replace(emissions=props.emissions._replace(emission_cov=cd.LearnableMatrix(PP())))
-    with pytest.raises(NotImplementedError, match="emissions.emission_cov"):
-        fit._trainable_mask(params, p3)
+    tr = fit._Trainable(params, props)
+    assert [p for p, _, _, _ in tr.items] == ["dynamics.drift.sigma", "dynamics.drift.rho", "dynamics.drift.beta"]
+    assert tr.drift_only and tr.size == 3
+    u = tr.to_unconstrained(params)
+    np.testing.assert_allclose(u, [10.0, 28.0, 8 / 3])
+    assert tr.from_unconstrained(params, u + 1.0).dynamics.drift == cd.LearnableLorenz63(11.0, 29.0, 8 / 3 + 1.0)
+    # a frozen drift leaf drops out; a trainable covariance with the PSD bijector joins in unconstrained form
+    p2 = props._replace(dynamics=props.dynamics._replace(drift=cd.LearnableLorenz63(PP(), PP(False), PP())),
+                        emissions=props.emissions._replace(emission_cov=cd.LearnableMatrix(PP(constrainer=RealToPSDBijector()))))
+    tr2 = fit._Trainable(params, p2)
+    assert not tr2.drift_only and tr2.size == 2 + 6
+    u2 = tr2.to_unconstrained(params)
+    back = tr2.from_unconstrained(params, u2)
+    np.testing.assert_allclose(back.emissions.emission_cov.params, params.emissions.emission_cov.params, atol=1e-14)
+    assert back.dynamics.drift.rho == params.dynamics.drift.rho
     p4 = props._replace(dynamics=props.dynamics._replace(drift=cd.LearnableLorenz63(PP(constrainer=object()), PP(), PP())))
     with pytest.raises(NotImplementedError, match="constrainer"):
-        fit._trainable_mask(params, p4)
+        fit._Trainable(params, p4)
+    frozen = PP(False)
+    with pytest.raises(ValueError, match="no trainable"):
+        fit._Trainable(params, props._replace(dynamics=props.dynamics._replace(drift=cd.LearnableLorenz63(frozen, frozen, frozen))))
     th = fit._drift_theta(params.dynamics.drift)
     assert fit._drift_from_theta(params.dynamics.drift, th) == params.dynamics.drift
+
+
+def test_psd_bijector_restates_tfp_chain():
+    """dynamax RealToPSDBijector = CholeskyOuterProduct o TransformDiagonal(Exp) o FillTriangular (bijectors.py:21-35).
+    fill_triangular against the example in TFP's documentation; inverse and vector-Jacobian product against the forward."""
+    from cd_dynamax_amd.bijectors import RealToPSDBijector, fill_triangular, fill_triangular_inverse
+    np.testing.assert_array_equal(fill_triangular(np.arange(1.0, 7.0)), [[4, 0, 0], [6, 5, 0], [3, 2, 1]])
+    np.testing.assert_array_equal(fill_triangular_inverse(fill_triangular(np.arange(1.0, 11.0))), np.arange(1.0, 11.0))
+    b = RealToPSDBijector()
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal(10)
+    P = b.forward(x)
+    assert np.allclose(P, P.T) and np.linalg.eigvalsh(P).min() > 0
+    np.testing.assert_allclose(b.inverse(P), x, atol=1e-12)
+    L = fill_triangular(x)
+    L[np.arange(4), np.arange(4)] = np.exp(np.diag(L))
+    np.testing.assert_allclose(P, L @ L.T, rtol=1e-14)
+    G = rng.standard_normal((4, 4))
+    fd = np.array([((b.forward(x + 1e-6 * e) - b.forward(x - 1e-6 * e)) / 2e-6 * G).sum() for e in np.eye(10)])
+    np.testing.assert_allclose(b.forward_vjp(x, G), fd, rtol=1e-7, atol=1e-8)
 
 
 @pytest.mark.gpu
@@ -83,8 +116,8 @@ def test_fit_sgd_first_step_matches_oracle_gradient(hip_lib):
         th = th - lr * gl
     np.testing.assert_allclose(losses, [np.mean(exp_losses)], rtol=1e-10)
     np.testing.assert_allclose([new.dynamics.drift.sigma, new.dynamics.drift.rho, new.dynamics.drift.beta], th, rtol=1e-10)
-    np.testing.assert_allclose([gh[0].sigma, gh[0].rho, gh[0].beta], gl, rtol=1e-8)
-    assert ph[0] == new.dynamics.drift
+    np.testing.assert_allclose(gh[0], gl, rtol=1e-8)
+    assert ph[0].dynamics.drift == new.dynamics.drift
 
 
 @pytest.mark.gpu
@@ -143,5 +176,52 @@ def test_fit_sgd_mlp_drift(hip_lib):
     new, losses = model.fit_sgd(P0, props, y, t[..., None], hyp, optimizer=fit.Adam(0.01), batch_size=4, num_epochs=25,
                                 shuffle=True, key=1)
     assert np.all(np.isfinite(losses)) and losses[-1] < losses[0] and losses[-5:].mean() < losses[:5].mean()
-    with pytest.raises(NotImplementedError, match="no gradient kernel"):
+    with pytest.raises(NotImplementedError, match="no drift gradient kernel"):
         model.fit_sgd(P0, props, y, t[..., None], cd.EKFHyperParams(), num_epochs=1)   # state_order='second'
+
+
+@pytest.mark.gpu
+def test_fit_sgd_all_parameters_first_step_and_descent(hip_lib):
+    """Every leaf trainable -- drift, initial mean, diffusion coefficient, emission weights / bias unconstrained, the three
+    covariances through RealToPSDBijector as in the reference's default props -- on a linear model (the cdlgssm
+    learn-parameters notebooks' set-up, d = 4, m = 2).  The first plain-SGD step must equal the step computed from the
+    oracle's all-parameter adjoint pulled back through the bijectors; Adam then lowers the loss."""
+    from cd_dynamax_amd.bijectors import RealToPSDBijector
+    from helpers import linear_model
+    rng = np.random.default_rng(8)
+    d, m = 4, 2
+    mdl = linear_model(rng, d, m)
+    N, T = 10, 25
+    t = o.irregular_times(rng, N, T, 0.05)
+    y = o.simulate(mdl, t, rng)
+    P0 = params_from(mdl)
+    psd, free = PP(constrainer=RealToPSDBijector()), PP()
+    props = P0._replace(
+        initial=P0.initial._replace(mean=cd.LearnableVector(free), cov=cd.LearnableMatrix(psd)),
+        dynamics=P0.dynamics._replace(drift=cd.LearnableLinear(free, free), diffusion_coefficient=cd.LearnableMatrix(free),
+                                      diffusion_cov=cd.LearnableMatrix(psd), approx_order=PP(False)),
+        emissions=P0.emissions._replace(emission_function=cd.LearnableLinear(free, free), emission_cov=cd.LearnableMatrix(psd)))
+    model = cd.ContDiscreteNonlinearGaussianSSM(d, m)
+    hyp = cd.EKFHyperParams(state_order="first")
+    lr = 0.05
+    new, losses = model.fit_sgd(P0, props, y, t[..., None], hyp, optimizer=fit.SGD(lr), batch_size=N, num_epochs=1)
+    ll, g, ex = o.ekf_loglik_grad_adjoint(mdl, t, y, full=True)
+    np.testing.assert_allclose(losses[0], -ll.sum() / y.size, rtol=1e-10)
+    b = RealToPSDBijector()
+    sz = y.size
+    # unconstrained leaves: theta <- theta + lr * grad / size
+    np.testing.assert_allclose(new.dynamics.drift.weights, mdl.drift.W + lr * g.sum(0)[:d * d].reshape(d, d) / sz, rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(new.initial.mean.params, mdl.m0 + lr * ex["m0"].sum(0) / sz, rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(new.dynamics.diffusion_coefficient.params, mdl.L + lr * ex["L"].sum(0) / sz, rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(new.emissions.emission_function.weights, mdl.H + lr * ex["H"].sum(0) / sz, rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(new.emissions.emission_function.bias, mdl.bias + lr * ex["bias"].sum(0) / sz, rtol=1e-8, atol=1e-11)
+    # PSD leaves: the step is taken on the unconstrained vector
+    for got, base, key in ((new.emissions.emission_cov.params, mdl.R, "R"), (new.initial.cov.params, mdl.P0, "P0"),
+                           (new.dynamics.diffusion_cov.params, mdl.Qc, "Qc")):
+        u = b.inverse(base)
+        np.testing.assert_allclose(got, b.forward(u + lr * b.forward_vjp(u, ex[key].sum(0)) / sz), rtol=1e-8, atol=1e-11)
+    new, losses = model.fit_sgd(P0, props, y, t[..., None], hyp, optimizer=fit.Adam(0.02), batch_size=5, num_epochs=30)
+    assert np.all(np.isfinite(losses)) and losses[-1] < losses[0]
+    assert np.linalg.eigvalsh(new.emissions.emission_cov.params).min() > 0
+    ll_new = model.marginal_log_prob(new, y, t[..., None], hyp).sum()
+    assert ll_new > ll.sum()

@@ -417,7 +417,7 @@ def test_loglik_gradient(hip_lib, kind, d, m):
 
 def test_loglik_gradient_unsupported_raises(hip_lib):
     rng = np.random.default_rng(5)
-    mdl = lorenz96_model(8, 4)
+    mdl = lorenz96_model(12, 4)           # state_dim > 8: neither the sensitivity kernels nor the reverse sweep
     t = o.irregular_times(rng, 2, 5, 0.1)
     y = o.simulate(mdl, t, rng)
     with pytest.raises(NotImplementedError, match="no gradient kernel"):

@@ -164,3 +164,55 @@ def test_mlp_loglik_gradient_reverse_sweep(hip_lib, d, m, h):
     # the default state_order='second' needs third derivatives of the drift: refused, not approximated
     with pytest.raises(NotImplementedError, match="no gradient kernel"):
         cd.cdnlgssm_loglik_and_grad(P, y, t[..., None])
+
+
+def _general_model(rng, drift, d, m):
+    """Non-diagonal L, Qc, R, P0, a dense H with bias: every parameter of the model carries a non-trivial gradient."""
+    A, B, C = rng.standard_normal((d, d)), rng.standard_normal((m, m)), rng.standard_normal((d, d))
+    return o.Model(drift, np.eye(d) + 0.2 * rng.standard_normal((d, d)), A @ A.T / d + 0.3 * np.eye(d),
+                   rng.standard_normal((m, d)), 0.1 * rng.standard_normal(m), B @ B.T / m + 0.2 * np.eye(m),
+                   rng.standard_normal(d), C @ C.T / d + 0.5 * np.eye(d))
+
+
+@pytest.mark.parametrize("kind,d,m", [("mlp", 8, 4), ("mlp", 5, 3), ("linear", 4, 2), ("lorenz63", 3, 2), ("lorenz96", 6, 3),
+                                      ("lorenz96", 8, 8), ("linear", 1, 1)])
+def test_loglik_gradient_all_parameters(hip_lib, kind, d, m):
+    """cdnlgssm_loglik_and_grad_all: one forward + one reverse sweep gives d ll / d(every parameter) -- the full pytree
+    jax.grad(marginal_log_prob) returns in the reference -- against the oracle's discrete adjoint (FD-pinned)."""
+    rng = np.random.default_rng(13)
+    if kind == "mlp":
+        drift = mlp_model(rng, d, m, (24, 40)).drift
+    elif kind == "linear":
+        drift = linear_model(rng, d, m).drift
+    elif kind == "lorenz63":
+        drift = o.lorenz63_model(m).drift
+    else:
+        drift = lorenz96_model(d, m).drift
+    mdl = _general_model(rng, drift, d, m)
+    N, T = 6, 12
+    t = o.irregular_times(rng, N, T, 0.02)
+    t[:, 7:] += 0.12
+    y = o.simulate(mdl, t, rng)
+    hyp = cd.EKFHyperParams(state_order="first")
+    ll_ref, g_ref, ex = o.ekf_loglik_grad_adjoint(mdl, t, y, full=True)
+    ll, g = cd.cdnlgssm_loglik_and_grad_all(params_from(mdl), y, t[..., None], hyp)
+    np.testing.assert_allclose(ll, ll_ref, rtol=1e-10)
+
+    def close(a, b, name):
+        scale = np.abs(b).max() + 1e-300
+        assert np.abs(np.asarray(a) - b).max() < 1e-8 * scale, (name, np.abs(np.asarray(a) - b).max() / scale)
+
+    dr = g.dynamics.drift
+    flat = np.concatenate([np.asarray(a).reshape(N, -1) for a in dr], axis=-1)
+    close(flat, g_ref, "drift")
+    close(g.initial.mean.params, ex["m0"], "m0")
+    close(g.initial.cov.params, ex["P0"], "P0")
+    close(g.dynamics.diffusion_coefficient.params, ex["L"], "L")
+    close(g.dynamics.diffusion_cov.params, ex["Qc"], "Qc")
+    close(g.emissions.emission_function.weights, ex["H"], "H")
+    close(g.emissions.emission_function.bias, ex["bias"], "bias")
+    close(g.emissions.emission_cov.params, ex["R"], "R")
+    # unbatched call: same numbers without the leading axis
+    ll1, g1 = cd.cdnlgssm_loglik_and_grad_all(params_from(mdl), y[2], t[2][:, None], hyp)
+    assert np.ndim(ll1) == 0 and g1.emissions.emission_cov.params.shape == (m, m)
+    close(g1.emissions.emission_cov.params, ex["R"][2], "R[2]")
