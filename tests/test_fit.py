@@ -225,3 +225,54 @@ def test_fit_sgd_all_parameters_first_step_and_descent(hip_lib):
     assert np.linalg.eigvalsh(new.emissions.emission_cov.params).min() > 0
     ll_new = model.marginal_log_prob(new, y, t[..., None], hyp).sum()
     assert ll_new > ll.sum()
+
+
+@pytest.mark.gpu
+def test_linear_model_gradient_against_exact_kalman_filter(hip_lib):
+    """BASELINE config 1 (tracking model, d_x = 4, d_y = 2, regular grid: 100 Dormand-Prince steps per interval) through
+    ContDiscreteLinearGaussianSSM.marginal_log_prob_and_grad: directional derivatives of the EXACT (matrix-exponential)
+    Kalman filter's log-likelihood by central differences -- an implementation that shares nothing with the kernels or
+    the oracle -- and then fit_sgd on the linear surface."""
+    from cd_dynamax_amd.bijectors import RealToPSDBijector
+    from helpers import closed_form_kf
+    F = np.zeros((4, 4))
+    F[0, 2] = F[1, 3] = 1.0
+    H = np.eye(4)[:2]
+    m0 = np.array([8.0, 10.0, 1.0, 0.0])
+    rng = np.random.default_rng(1)
+    T = 60
+    t = np.arange(T, dtype=float)
+
+    def mk(F_=F, R_=0.5 * np.eye(2), Qc_=0.1 * np.eye(4), H_=H, m0_=m0):
+        return o.Model(o.LinearDrift(F_, np.zeros(4)), np.eye(4), Qc_, H_, np.zeros(2), R_, m0_, np.eye(4))
+
+    mdl = mk()
+    y = o.simulate(mdl, t[None], rng)[0]
+    model = cd.ContDiscreteLinearGaussianSSM(state_dim=4, emission_dim=2)
+    free, psd, frozen = PP(), PP(constrainer=RealToPSDBijector()), PP(False)
+    params, props = model.initialize(
+        initial_mean={"params": m0, "props": free}, initial_cov={"params": np.eye(4), "props": frozen},
+        dynamics_weights={"params": F, "props": free}, dynamics_diffusion_coefficient={"params": np.eye(4), "props": frozen},
+        dynamics_diffusion_cov={"params": 0.1 * np.eye(4), "props": psd}, emission_weights={"params": H, "props": free},
+        emission_cov={"params": 0.5 * np.eye(2), "props": psd})
+    hyp = cd.KFHyperParams(dt_final=1.0)
+    ll, g = model.marginal_log_prob_and_grad(params, y, t[:, None], hyp)
+    assert abs(ll - closed_form_kf(mdl, t, y, 1.0)["marginal_loglik"]) < 1e-7 * abs(ll)
+    h = 1e-5
+    for name, leaf, sym in (("F_", g.dynamics.weights, False), ("R_", g.emissions.cov, True), ("Qc_", g.dynamics.diffusion_cov, True),
+                            ("H_", g.emissions.weights, False), ("m0_", g.initial.mean, False)):
+        base = {"F_": F, "R_": 0.5 * np.eye(2), "Qc_": 0.1 * np.eye(4), "H_": H, "m0_": m0}[name]
+        u = rng.standard_normal(base.shape)
+        if sym:
+            u = 0.5 * (u + u.T)
+        fd = (closed_form_kf(mk(**{name: base + h * u}), t, y, 1.0)["marginal_loglik"]
+              - closed_form_kf(mk(**{name: base - h * u}), t, y, 1.0)["marginal_loglik"]) / (2 * h)
+        assert abs((np.asarray(leaf) * u).sum() - fd) < 1e-5 * abs(fd) + 1e-7, name
+    start = params._replace(emissions=params.emissions._replace(cov=1.5 * np.eye(2)),
+                            dynamics=params.dynamics._replace(diffusion_cov=0.3 * np.eye(4)))
+    new, losses = model.fit_sgd(start, props, y, t[:, None], hyp, optimizer=fit.Adam(0.003), num_epochs=40)
+    assert np.all(np.isfinite(losses)) and losses[-1] < losses[0] and losses[-5:].mean() < losses[:5].mean()
+    assert isinstance(new, cd.ParamsCDLGSSM) and np.linalg.eigvalsh(new.emissions.cov).min() > 0
+    np.testing.assert_array_equal(new.initial.cov, params.initial.cov)        # frozen leaf untouched
+    with pytest.raises(NotImplementedError, match="dynamics bias"):
+        model.fit_sgd(params._replace(dynamics=params.dynamics._replace(bias=np.zeros(4))), props, y, t[:, None], hyp, num_epochs=1)
