@@ -163,6 +163,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out.update(cpu_baseline_and_error(t_h, y_h, ll, fm))
         if not args.no_saturation and world == 1:
+            out["value_and_grad"] = value_and_grad(lib, blk, opts, N, T, t_d, y_d, ll, dev, torch, stream)
             del fm, fP, pm, pP
             out["saturated_regime"] = saturated(lib, blk, opts, dev, torch)
         print(json.dumps(out), flush=True)
@@ -186,6 +187,30 @@ def pmc_traffic(algorithmic_bytes):
         if rec.get("algorithmic_bytes_per_launch") == algorithmic_bytes:
             best = (rec["hbm_traffic_bytes_per_launch"], os.path.relpath(path, ROOT))
     return best if best else (None, None)
+
+
+def value_and_grad(lib, blk, opts, N, T, t_d, y_d, ll, dev, torch, stream, reps=5):
+    """The SGD objective on the same resident batch: log-likelihood and its gradient w.r.t. (sigma, rho, beta) in one
+    sweep (cdkf_ekf_loglik_grad_f64_dev: forward sensitivities, a lane per (trajectory, parameter)).  Informational --
+    the headline metric stays the filter sweep."""
+    from cd_dynamax_amd import _ffi
+    grad = torch.empty(N, 3, dtype=torch.float64, device=dev)
+    st = torch.zeros(N, dtype=torch.int32, device=dev)
+    p = lambda x: C.c_void_p(x.data_ptr())
+    run = lambda: _ffi.check(lib.cdkf_ekf_loglik_grad_f64_dev(C.byref(blk.c), C.byref(opts), N, T, p(t_d), p(y_d), p(ll),
+                                                              p(grad), p(st), stream))
+    run()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in evs:
+        a.record()
+        run()
+        b.record()
+    torch.cuda.synchronize()
+    ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    return {"workload": "same batch: marginal log-likelihood + d/d(sigma, rho, beta) per trajectory, fp64",
+            "kernel": "ekf_grad_reg_kernel<double,3,3,DriftLorenz63>", "kernel_ms": ms,
+            "trajectories_per_sec": N / (ms * 1e-3), "grad_sum": [float(v) for v in grad.sum(0).tolist()]}
 
 
 def saturated(lib, blk, opts, dev, torch, n=65536, reps=5):

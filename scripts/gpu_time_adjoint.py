@@ -1,7 +1,9 @@
 """Time the C5-slice value-and-gradient (MLP drift d=8, m=4, 2x64; dev helper)."""
 import ctypes as C, sys, time
 import numpy as np
-sys.path.insert(0, "."); sys.path.insert(0, "oracle"); sys.path.insert(0, "tests")
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
 import cdkf_oracle as o
 from cd_dynamax_amd import _ffi
 from cd_dynamax_amd.models import _model_block, _opts
