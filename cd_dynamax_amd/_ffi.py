@@ -88,7 +88,8 @@ SYMBOLS = (
      "cdkf_free", "cdkf_memcpy_h2d", "cdkf_memcpy_d2h", "cdkf_memset", "cdkf_synchronize", "cdkf_ll_sum_f64_dev",
      "cdkf_ll_sum_f32_dev", "cdkf_emission_moments_f64", "cdkf_emission_moments_f32", "cdkf_emission_moments_f64_dev",
      "cdkf_emission_moments_f32_dev", "cdkf_ekf_loglik_grad_f64", "cdkf_ekf_loglik_grad_f32",
-     "cdkf_ekf_loglik_grad_f64_dev", "cdkf_ekf_loglik_grad_f32_dev", "cdkf_grad_supported", "cdkf_grad_all_supported", "cdkf_ekf_loglik_grad_all_f64",
+     "cdkf_ekf_loglik_grad_f64_dev", "cdkf_ekf_loglik_grad_f32_dev", "cdkf_kf_smoother1_f64", "cdkf_kf_smoother1_f32", "cdkf_kf_smoother1_f64_dev", "cdkf_kf_smoother1_f32_dev",
+     "cdkf_kf_smoother1_supported", "cdkf_grad_supported", "cdkf_grad_all_supported", "cdkf_ekf_loglik_grad_all_f64",
      "cdkf_ekf_loglik_grad_all_f32", "cdkf_ekf_loglik_grad_all_f64_dev", "cdkf_ekf_loglik_grad_all_f32_dev", "cdkf_grad_sum_f64_dev",
      "cdkf_grad_sum_f32_dev"]
     + [f"cdkf_{a}_{p}{s}" for a in _ALGOS for p in ("f64", "f32") for s in ("", "_dev")]
@@ -132,6 +133,16 @@ def lib() -> C.CDLL:
         f.restype = C.c_int
         f = getattr(L, f"cdkf_emission_moments_{p}_dev")
         f.argtypes = [C.POINTER(CdkfModel), C.c_int64] + [C.c_void_p] * 5
+        f.restype = C.c_int
+    L.cdkf_kf_smoother1_supported.argtypes = [C.POINTER(CdkfModel)]
+    L.cdkf_kf_smoother1_supported.restype = C.c_int
+    for p in ("f64", "f32"):
+        base = [C.POINTER(CdkfModel), C.POINTER(CdkfOpts), C.c_int64, C.c_int64] + [C.c_void_p] * 9
+        f = getattr(L, f"cdkf_kf_smoother1_{p}")
+        f.argtypes = base
+        f.restype = C.c_int
+        f = getattr(L, f"cdkf_kf_smoother1_{p}_dev")
+        f.argtypes = base + [C.c_void_p]
         f.restype = C.c_int
     L.cdkf_grad_supported.argtypes = [C.POINTER(CdkfModel), C.POINTER(CdkfOpts)]
     L.cdkf_grad_supported.restype = C.c_int
@@ -267,6 +278,28 @@ def run_host(algo: str, mdl: ModelBlock, opts: CdkfOpts, t: np.ndarray, y: np.nd
     check(fn(C.byref(mdl.c), C.byref(opts), N, T, _vp(t), _vp(y), _vp(ll), *[_vp(o) for o in outs], _vp(status)))
     outs = [None if o is None else (np.moveaxis(o, -1, 0) if tcn else np.swapaxes(o, 0, 1)) for o in outs]  # views
     return ll, outs, status
+
+
+def kf_smoother1(mdl: ModelBlock, opts: CdkfOpts, t: np.ndarray, y: np.ndarray, dtype):
+    """cdkf_kf_smoother1_<f32|f64> on host buffers: returns (ll, fm, fP, sm, sP, cross [N,T-1,d,d], status) in the
+    reference shapes (views of [T,N,...] buffers)."""
+    dtype = np.dtype(dtype)
+    suffix = {np.dtype(np.float32): "f32", np.dtype(np.float64): "f64"}[dtype]
+    N, T, m = y.shape
+    d = mdl.state_dim
+    opts.layout = LAYOUT_TN
+    t = np.asarray(t, dtype=dtype)
+    t = np.ascontiguousarray(t if opts.t_shared else t.T)
+    y = np.ascontiguousarray(np.asarray(y, dtype=dtype).transpose(1, 0, 2))
+    ll = np.empty((N,), dtype)
+    status = np.zeros((N,), np.int32)
+    fm, sm = (np.empty((T, N, d), dtype) for _ in range(2))
+    fP, sP, cr = (np.empty((T, N, d, d), dtype) for _ in range(3))
+    fn = getattr(lib(), f"cdkf_kf_smoother1_{suffix}")
+    check(fn(C.byref(mdl.c), C.byref(opts), N, T, _vp(t), _vp(y), _vp(ll), _vp(fm), _vp(fP), _vp(sm), _vp(sP), _vp(cr),
+             _vp(status)))
+    sw = lambda a: np.swapaxes(a, 0, 1)
+    return ll, sw(fm), sw(fP), sw(sm), sw(sP), sw(cr)[:, :T - 1], status
 
 
 def model_grad_size(d: int, m: int) -> int:

@@ -186,6 +186,53 @@ int loglik_grad_host(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64
   return CDKF_OK;
 }
 
+// ---- linear model, smoother type 1 -------------------------------------------------------------------------------------
+template <typename R>
+int kf_smoother1_dev(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll, R* fm,
+                     R* fP, R* sm, R* sP, R* cross, int32_t* status, void* stream) {
+  int rc = check_common(mdl, o, N, T, t, y, ll);
+  if (rc) return rc;
+  if (N == 0) return CDKF_OK;
+  if ((rc = select_device(o))) return rc;
+  return launch_kf_smoother1<R>(mdl, o, N, T, t, y, ll, fm, fP, sm, sP, cross, status, (hipStream_t)stream);
+}
+
+template <typename R>
+int kf_smoother1_host(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll, R* fm,
+                      R* fP, R* sm, R* sP, R* cross, int32_t* status) {
+  int rc = check_common(mdl, o, N, T, t, y, ll);
+  if (rc) return rc;
+  if (!fm || !fP || !sm || !sP) {
+    set_error("kf_smoother1: filtered and smoothed output arrays must not be NULL");
+    return CDKF_EINVAL;
+  }
+  if (N == 0) return CDKF_OK;
+  if ((rc = select_device(o))) return rc;
+  const size_t d = mdl->state_dim, m = mdl->emission_dim;
+  const size_t nt = (size_t)(o->t_shared ? T : N * T), ny = (size_t)N * T * m, nm = (size_t)N * T * d, nP = nm * d;
+  DevBuf dt, dy, dll, dst, dfm, dfP, dsm, dsP, dcr;
+  if ((rc = dt.alloc(nt * sizeof(R))) || (rc = dy.alloc(ny * sizeof(R))) || (rc = dll.alloc(N * sizeof(R))) ||
+      (rc = dst.alloc(N * sizeof(int32_t))) || (rc = dfm.alloc(nm * sizeof(R))) || (rc = dfP.alloc(nP * sizeof(R))) ||
+      (rc = dsm.alloc(nm * sizeof(R))) || (rc = dsP.alloc(nP * sizeof(R))))
+    return rc;
+  if (cross && (rc = dcr.alloc(nP * sizeof(R)))) return rc;
+  CDKF_HIP_CHECK(hipMemcpy(dt.p, t, nt * sizeof(R), hipMemcpyHostToDevice));
+  CDKF_HIP_CHECK(hipMemcpy(dy.p, y, ny * sizeof(R), hipMemcpyHostToDevice));
+  if (cross) CDKF_HIP_CHECK(hipMemset(dcr.p, 0, nP * sizeof(R)));
+  rc = launch_kf_smoother1<R>(mdl, o, N, T, (const R*)dt.p, (const R*)dy.p, (R*)dll.p, (R*)dfm.p, (R*)dfP.p, (R*)dsm.p,
+                              (R*)dsP.p, (R*)dcr.p, (int32_t*)dst.p, nullptr);
+  if (rc) return rc;
+  CDKF_HIP_CHECK(hipDeviceSynchronize());
+  CDKF_HIP_CHECK(hipMemcpy(ll, dll.p, N * sizeof(R), hipMemcpyDeviceToHost));
+  if (status) CDKF_HIP_CHECK(hipMemcpy(status, dst.p, N * sizeof(int32_t), hipMemcpyDeviceToHost));
+  CDKF_HIP_CHECK(hipMemcpy(fm, dfm.p, nm * sizeof(R), hipMemcpyDeviceToHost));
+  CDKF_HIP_CHECK(hipMemcpy(fP, dfP.p, nP * sizeof(R), hipMemcpyDeviceToHost));
+  CDKF_HIP_CHECK(hipMemcpy(sm, dsm.p, nm * sizeof(R), hipMemcpyDeviceToHost));
+  CDKF_HIP_CHECK(hipMemcpy(sP, dsP.p, nP * sizeof(R), hipMemcpyDeviceToHost));
+  if (cross) CDKF_HIP_CHECK(hipMemcpy(cross, dcr.p, nP * sizeof(R), hipMemcpyDeviceToHost));
+  return CDKF_OK;
+}
+
 // ---- emission moments: one workgroup (64 threads) per state marginal, H and the d x d covariance staged in LDS ----
 template <typename R>
 __global__ __launch_bounds__(64) void emission_moments_kernel(int d, int m, const R* __restrict__ par, long rows,
@@ -434,6 +481,26 @@ int cdkf_ekf_loglik_grad_f32_dev(const cdkf_model* mdl, const cdkf_opts* o, int6
                                  const float* y, float* ll, float* grad, int32_t* status, void* stream) {
   return loglik_grad_dev<float>(mdl, o, N, T, t, y, ll, grad, nullptr, status, stream);
 }
+int cdkf_kf_smoother1_f64(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const double* t, const double* y,
+                          double* ll, double* fm, double* fP, double* sm, double* sP, double* cross, int32_t* status) {
+  return kf_smoother1_host<double>(mdl, o, N, T, t, y, ll, fm, fP, sm, sP, cross, status);
+}
+int cdkf_kf_smoother1_f32(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const float* t, const float* y,
+                          float* ll, float* fm, float* fP, float* sm, float* sP, float* cross, int32_t* status) {
+  return kf_smoother1_host<float>(mdl, o, N, T, t, y, ll, fm, fP, sm, sP, cross, status);
+}
+int cdkf_kf_smoother1_f64_dev(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const double* t,
+                              const double* y, double* ll, double* fm, double* fP, double* sm, double* sP, double* cross,
+                              int32_t* status, void* stream) {
+  return kf_smoother1_dev<double>(mdl, o, N, T, t, y, ll, fm, fP, sm, sP, cross, status, stream);
+}
+int cdkf_kf_smoother1_f32_dev(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const float* t,
+                              const float* y, float* ll, float* fm, float* fP, float* sm, float* sP, float* cross,
+                              int32_t* status, void* stream) {
+  return kf_smoother1_dev<float>(mdl, o, N, T, t, y, ll, fm, fP, sm, sP, cross, status, stream);
+}
+int cdkf_kf_smoother1_supported(const cdkf_model* mdl) { return (mdl && smoother1_shape_available(mdl)) ? 1 : 0; }
+
 static int need_model_grad(const void* gm) {
   if (gm) return CDKF_OK;
   set_error("loglik_grad_all: grad_model must not be NULL");

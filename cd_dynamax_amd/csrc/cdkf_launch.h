@@ -41,6 +41,12 @@ int launch_ekf_grad_adjoint(const cdkf_model* mdl, const cdkf_opts* o, int64_t N
                             R* grad, R* grad_model, int32_t* status, hipStream_t stream);
 bool adjoint_shape_available(const cdkf_model* mdl, const cdkf_opts* o);
 
+// linear model, smoother type 1 (launch_wg.hip, cdkf_rts1_kernels.h); cross (optional) has the strides of sP, entries 0..T-2
+template <typename R>
+int launch_kf_smoother1(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll,
+                        R* fm, R* fP, R* sm, R* sP, R* cross, int32_t* status, hipStream_t stream);
+bool smoother1_shape_available(const cdkf_model* mdl);
+
 bool kernel_available(const cdkf_model* mdl, const cdkf_opts* o, int algo, int bytes_per_real);
 
 // workgroup-per-trajectory kernels (launch_wg.hip): any registry drift, d and m up to what fits 160 KB of LDS

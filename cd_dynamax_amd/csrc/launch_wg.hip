@@ -3,6 +3,7 @@
 #include "cdkf_wg2_kernels.h"
 #include "cdkf_wave8_kernels.h"
 #include "cdkf_adjoint_kernels.h"
+#include "cdkf_rts1_kernels.h"
 
 #include <mutex>
 
@@ -394,6 +395,76 @@ template int launch_ekf_grad_adjoint<float>(const cdkf_model*, const cdkf_opts*,
                                             float*, float*, float*, int32_t*, hipStream_t);
 template int launch_ekf_grad_adjoint<double>(const cdkf_model*, const cdkf_opts*, int64_t, int64_t, const double*,
                                              const double*, double*, double*, double*, int32_t*, hipStream_t);
+
+// ---- linear model, smoother type 1 (cdkf_rts1_kernels.h): filter sweep, pushed-forward (A, Q) per interval, discrete RTS ----
+bool smoother1_shape_available(const cdkf_model* mdl) {
+  if (mdl->drift_kind != CDKF_DRIFT_LINEAR || mdl->state_dim > 8 || !wg_shape_available(mdl, 8)) return false;
+  const int d = mdl->state_dim;
+  for (int i = 0; i < d; ++i)
+    if (mdl->theta[d * d + i] != 0.0) return false;  // the reference adds the bias un-integrated; only b = 0 is the same model
+  return true;
+}
+
+template <typename R>
+int launch_kf_smoother1(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll,
+                        R* fm, R* fP, R* sm, R* sP, R* cross, int32_t* status, hipStream_t stream) {
+  if (!smoother1_shape_available(mdl)) {
+    set_error("kf_smoother1: needs a linear drift with zero bias and state_dim <= 8 (got drift_kind=%d state_dim=%d)",
+              mdl->drift_kind, mdl->state_dim);
+    return CDKF_EUNSUPPORTED;
+  }
+  if (!fm || !fP || !sm || !sP) {
+    set_error("kf_smoother1: filtered and smoothed output arrays must not be NULL");
+    return CDKF_EINVAL;
+  }
+  cdkf_opts of = *o;
+  of.state_order = CDKF_ORDER_FIRST;
+  of.num_iter = 1;
+  of.forecast = 0;
+  int rc = launch_ekf_filter<R>(mdl, &of, N, T, t, y, ll, fm, fP, nullptr, nullptr, status, stream);
+  if (rc) return rc;
+  static const int cap_rc = wg_raise_lds_cap(pushforward_wave8_kernel<R>) | wg_raise_lds_cap(rts1_wave8_kernel<R>);
+  if (cap_rc) return CDKF_EHIP;
+  WgArgs<R> a{};
+  R* blk = nullptr;
+  ParamSlot* slot = nullptr;
+  rc = wg_prepare(a, &blk, &slot, mdl, &of, N, T, stream);
+  if (rc) return rc;
+  a.t = t; a.y = y; a.ll = ll; a.fm = fm; a.fP = fP; a.sm = sm; a.sP = sP; a.status = status;
+  const size_t d = mdl->state_dim, items = (size_t)N * (size_t)(T - 1), bytes = (items ? items : 1) * 2 * d * d * sizeof(R);
+  std::lock_guard<std::mutex> lock(g_adj_mutex);
+  int dev = 0;
+  CDKF_HIP_CHECK(hipGetDevice(&dev));
+  AdjWorkspace& ws = g_adj_ws;
+  if (ws.cap < bytes || ws.device != dev) {
+    if (ws.in_flight) CDKF_HIP_CHECK(hipEventSynchronize(ws.done));
+    if (ws.p) (void)hipFree(ws.p);
+    if (ws.done) (void)hipEventDestroy(ws.done);
+    ws = AdjWorkspace();
+    CDKF_HIP_CHECK(hipMalloc(&ws.p, bytes));
+    CDKF_HIP_CHECK(hipEventCreateWithFlags(&ws.done, hipEventDisableTiming));
+    ws.cap = bytes;
+    ws.device = dev;
+  } else if (ws.in_flight) {
+    CDKF_HIP_CHECK(hipStreamWaitEvent(stream, ws.done, 0));
+  }
+  const size_t lds = sizeof(R) * (size_t)kRts1Waves * Rts1Off::end + 64;
+  if (items) {
+    hipLaunchKernelGGL(pushforward_wave8_kernel<R>, dim3((unsigned)((items + kRts1Waves - 1) / kRts1Waves)),
+                       dim3(64 * kRts1Waves), lds, stream, a, (R*)ws.p);
+    CDKF_HIP_CHECK(hipGetLastError());
+  }
+  hipLaunchKernelGGL(rts1_wave8_kernel<R>, dim3((unsigned)((N + kRts1Waves - 1) / kRts1Waves)), dim3(64 * kRts1Waves), lds,
+                     stream, a, (const R*)ws.p, cross);
+  CDKF_HIP_CHECK(hipGetLastError());
+  CDKF_HIP_CHECK(hipEventRecord(ws.done, stream));
+  ws.in_flight = true;
+  return param_pool_release(slot, stream);
+}
+template int launch_kf_smoother1<float>(const cdkf_model*, const cdkf_opts*, int64_t, int64_t, const float*, const float*,
+                                        float*, float*, float*, float*, float*, float*, int32_t*, hipStream_t);
+template int launch_kf_smoother1<double>(const cdkf_model*, const cdkf_opts*, int64_t, int64_t, const double*, const double*,
+                                         double*, double*, double*, double*, double*, double*, int32_t*, hipStream_t);
 
 #define INST(R)                                                                                                        \
   template int launch_ekf_filter_wg<R>(const cdkf_model*, const cdkf_opts*, int64_t, int64_t, const R*, const R*, R*,  \

@@ -14,8 +14,8 @@ Differences, all refused loudly rather than approximated:
   * the moments are integrated directly (dP/dt = F P + P F^T + L Qc L^T) instead of pushing (A, Q) forward and
     forming A P A^T + Q: identical up to the O(dt0^6) difference of two 5th-order solutions (~1e-12 relative).
   * ``smoother_type='cd_smoother_2'`` (Sarkka Alg. 3.18, inference.py:636-690) is the EKF smoother of the hot path;
-    the reference's default ``'cd_smoother_1'`` (discrete RTS on the pushed-forward (A, Q)) needs the transition
-    matrices, which the moment kernels do not produce -- not implemented.
+    the reference's default ``'cd_smoother_1'`` (discrete RTS on the pushed-forward (A, Q)) has its own two kernels
+    (cdkf_rts1_kernels.h) for state_dim <= 8; its forward pass is the moment-integrating filter above.
 """
 from __future__ import annotations
 
@@ -122,11 +122,25 @@ def cdlgssm_filter(params: ParamsCDLGSSM, emissions, t_emissions=None, filter_hy
 
 def cdlgssm_smoother(params: ParamsCDLGSSM, emissions, t_emissions=None, filter_hyperparams: Optional[KFHyperParams] = None,
                      inputs=None, smoother_type: Optional[str] = "cd_smoother_1", dtype=None) -> PosteriorGSSMSmoothed:
-    """Continuous-discrete Kalman smoother (reference: inference.py:694-800); only ``cd_smoother_2``."""
+    """Continuous-discrete Kalman smoother (reference: inference.py:694-823): ``cd_smoother_1`` (the default; discrete RTS
+    on the pushed-forward (A, Q), Sarkka Alg. 3.17, with ``smoothed_cross_covariances``; state_dim <= 8 on the HIP path)
+    or ``cd_smoother_2`` (Alg. 3.18, the continuous-time backward ODE = the EKF smoother of the hot path)."""
     if smoother_type == "cd_smoother_1":
-        raise NotImplementedError(
-            "smoother_type='cd_smoother_1' (discrete RTS on the pushed-forward (A, Q), Sarkka Alg. 3.17) is not implemented "
-            "on the HIP path; pass smoother_type='cd_smoother_2' (Alg. 3.18, the continuous-time backward ODE)")
+        from . import _ffi
+        from .models import _model_block, _opts, _prepare, _squeeze
+        nl = _as_nonlinear(params, inputs)
+        mdl = _model_block(nl)
+        hyper = _hyper(filter_hyperparams)
+        opts = _opts(hyper, 1)
+        y, t, batched, dtype = _prepare(emissions, t_emissions, hyper, opts, dtype)
+        if not _ffi.lib().cdkf_kf_smoother1_supported(_ffi.C.byref(mdl.c)):
+            raise NotImplementedError(
+                f"smoother_type='cd_smoother_1' runs on the HIP path for state_dim <= 8 (got {mdl.state_dim}); pass "
+                "smoother_type='cd_smoother_2' (Sarkka Alg. 3.18)")
+        ll, fm, fP, sm, sP, cr, _ = _ffi.kf_smoother1(mdl, opts, t, y, dtype)
+        sq = lambda a: _squeeze(a, batched)
+        return PosteriorGSSMSmoothed(marginal_loglik=ll if batched else ll[0], filtered_means=sq(fm), filtered_covariances=sq(fP),
+                                     smoothed_means=sq(sm), smoothed_covariances=sq(sP), smoothed_cross_covariances=sq(cr))
     if smoother_type != "cd_smoother_2":
         raise ValueError(f"unknown smoother_type {smoother_type!r}")
     return cdnlgssm_smoother(_as_nonlinear(params, inputs), emissions, t_emissions, _hyper(filter_hyperparams), dtype=dtype)

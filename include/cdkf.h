@@ -208,6 +208,27 @@ int cdkf_emission_moments_f64_dev(const cdkf_model* mdl, int64_t rows, const dou
 int cdkf_emission_moments_f32_dev(const cdkf_model* mdl, int64_t rows, const float* means, const float* covs,
                                   float* out_mean, float* out_cov, void* stream);
 
+/* ---- linear model, smoother type 1: replaces cdlgssm_smoother(..., smoother_type='cd_smoother_1') -- the reference's default --
+ *      src/continuous_discrete_linear_gaussian_ssm/inference.py:694-823 (_step_1 :746-773, compute_pushforward :105-143):
+ *      filter sweep, the pushed-forward (A, Q) of every interval (Dopri5, dt0), discrete RTS (Sarkka Alg. 3.17).
+ *      drift_kind LINEAR with zero bias, state_dim <= 8: cdkf_kf_smoother1_supported().  Arrays follow opts.layout;
+ *      smoothed_cross (optional, NULL to skip) has the shape and strides of smoothed_covs, entries k = 0 .. T-2 written
+ *      (cross[k] = C_k P_s[k+1] + m_s[k] m_s[k+1]^T, inference.py:769). --------------------------------------------------- */
+int cdkf_kf_smoother1_f64(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T, const double* t, const double* y,
+                          double* ll, double* filtered_means, double* filtered_covs, double* smoothed_means,
+                          double* smoothed_covs, double* smoothed_cross, int32_t* status);
+int cdkf_kf_smoother1_f32(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T, const float* t, const float* y,
+                          float* ll, float* filtered_means, float* filtered_covs, float* smoothed_means, float* smoothed_covs,
+                          float* smoothed_cross, int32_t* status);
+int cdkf_kf_smoother1_f64_dev(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T, const double* t,
+                              const double* y, double* ll, double* filtered_means, double* filtered_covs,
+                              double* smoothed_means, double* smoothed_covs, double* smoothed_cross, int32_t* status,
+                              void* stream);
+int cdkf_kf_smoother1_f32_dev(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T, const float* t,
+                              const float* y, float* ll, float* filtered_means, float* filtered_covs, float* smoothed_means,
+                              float* smoothed_covs, float* smoothed_cross, int32_t* status, void* stream);
+int cdkf_kf_smoother1_supported(const cdkf_model* mdl);
+
 /* ---- marginal log-likelihood AND its gradient w.r.t. the drift parameters theta (ordering of cdkf_model.theta):
  *      replaces jax.value_and_grad of the fit_sgd loss, src/ssm_temissions.py:550-568, for the drift block of
  *      the parameters (what the Lorenz-63 parameter-estimation tutorials learn).  EKF, num_iter 1; state_order

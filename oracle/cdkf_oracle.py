@@ -620,6 +620,56 @@ def forecast(mdl: Model, m_init, P_init, t_init, t_forecast, method="ekf", state
 
 
 # --------------------------------------------------------------------------------------
+# linear model: smoother type 1 (discrete RTS on the pushed-forward (A, Q))
+# --------------------------------------------------------------------------------------
+def kf_pushforward(mdl: Model, t0, t1, dt0=0.01, max_steps=100000, dtype=np.float64):
+    """compute_pushforward (continuous_discrete_linear_gaussian_ssm/inference.py:105-143): A' = F A, Q' = F Q + Q F^T +
+    L Qc L^T from (I, 0) over [t0, t1] with the same Dopri5 loop.  t0, t1: [B]; returns A, Q: [B, d, d]."""
+    dtype = np.dtype(dtype)
+    mdl = mdl.cast(dtype)
+    F = mdl.drift.W
+    LQL = _LQL(mdl)
+    B = np.asarray(t0).shape[0]
+    d = mdl.d
+    A0 = np.broadcast_to(np.eye(d, dtype=dtype), (B, d, d)).copy()
+    Q0 = np.zeros((B, d, d), dtype)
+    rhs = lambda yv: (F @ yv[0], F @ yv[1] + yv[1] @ F.T + LQL)
+    return diffeqsolve(rhs, np.asarray(t0, dtype), np.asarray(t1, dtype), (A0, Q0), dt0, max_steps)
+
+
+def kf_smoother_type1(mdl: Model, t, y, dt0=0.01, dt_final=1e-10, max_steps=100000, dtype=np.float64,
+                      filtered: Optional[dict] = None):
+    """cdlgssm_smoother(..., smoother_type='cd_smoother_1') (inference.py:694-823, _step_1 :746-773; Sarkka Alg. 3.17):
+    C = psd_solve(Q + A P_f A^T, A P_f)^T;  m_s = m_f + C (m_s' - A m_f);  P_s = P_f + C (P_s' - A P_f A^T - Q) C^T;
+    cross = C P_s' + m_s m_s'^T.  Linear drift with zero bias, no inputs.  The forward pass is this build's filter (moments
+    integrated directly)."""
+    dtype = np.dtype(dtype)
+    if mdl.drift.kind != "linear" or np.any(mdl.drift.b != 0):
+        raise NotImplementedError("type-1 smoother: linear drift with zero bias")
+    if filtered is None:
+        filtered = ekf_filter(mdl, t, y, "first", 1, dt0, dt_final, max_steps, dtype=dtype)
+    mdlc = mdl.cast(dtype)
+    t = np.asarray(t, dtype=dtype)
+    fm, fP = filtered["filtered_means"], filtered["filtered_covariances"]
+    N, T, d = fm.shape
+    tt = np.broadcast_to(t, (N, T)) if t.ndim == 1 else t
+    sm, sP = fm.copy(), fP.copy()
+    cross = np.zeros((N, max(T - 1, 0), d, d), dtype)
+    eye = np.eye(d, dtype=dtype)
+    for k in range(T - 2, -1, -1):
+        A, Q = kf_pushforward(mdlc, tt[:, k], tt[:, k + 1], dt0, max_steps, dtype)
+        AP = A @ fP[:, k]
+        Ppred = AP @ np.swapaxes(A, -1, -2) + Q
+        C = np.swapaxes(psd_solve(Ppred, AP), -1, -2)
+        sm[:, k] = fm[:, k] + np.einsum("nij,nj->ni", C, sm[:, k + 1] - np.einsum("nij,nj->ni", A, fm[:, k]))
+        sP[:, k] = fP[:, k] + C @ (sP[:, k + 1] - Ppred) @ np.swapaxes(C, -1, -2)
+        cross[:, k] = C @ sP[:, k + 1] + sm[:, k][:, :, None] * sm[:, k + 1][:, None, :]
+    out = dict(filtered)
+    out.update(smoothed_means=sm, smoothed_covariances=sP, smoothed_cross_covariances=cross)
+    return out
+
+
+# --------------------------------------------------------------------------------------
 # d(marginal log-likelihood)/d(drift parameters): forward-mode sensitivities of the EKF recursion
 # --------------------------------------------------------------------------------------
 # The reference obtains this gradient by JAX reverse-mode AD through the same computation

@@ -425,3 +425,54 @@ def test_loglik_gradient_unsupported_raises(hip_lib):
     with pytest.raises(NotImplementedError, match="no gradient kernel"):
         cd.cdnlgssm_loglik_and_grad(params_from(o.lorenz63_model(3)), y[..., :3], t[..., None],
                                     cd.EKFHyperParams(state_order="zeroth"))
+
+
+@pytest.mark.parametrize("d,m", [(4, 2), (2, 6), (8, 3), (1, 1)])
+def test_linear_smoother_type1(hip_lib, d, m):
+    """cdlgssm_smoother(..., smoother_type='cd_smoother_1') -- the reference's default (inference.py:694-823): discrete RTS
+    on the Dopri5-pushed-forward (A, Q), with smoothed_cross_covariances.  Against the oracle restatement (itself pinned to
+    the exact matrix-exponential RTS smoother in tests/test_oracle.py); batched irregular times, then one trajectory on
+    the regular grid (t_emissions=None: 100 Dormand-Prince steps per interval)."""
+    rng = np.random.default_rng(40 + d)
+    base = linear_model(rng, d, m)
+    mdl = o.Model(o.LinearDrift(base.drift.W, np.zeros(d)), base.L, base.Qc, base.H, base.bias, base.R, base.m0, base.P0)
+    N, T = 5, 25
+    t = o.irregular_times(rng, N, T, 0.15)
+    y = o.simulate(mdl, t, rng)
+    model = cd.ContDiscreteLinearGaussianSSM(state_dim=d, emission_dim=m, has_emissions_bias=True)
+    pp = cd.ParameterProperties()
+    params, _ = model.initialize(
+        initial_mean={"params": mdl.m0, "props": pp}, initial_cov={"params": mdl.P0, "props": pp},
+        dynamics_weights={"params": mdl.drift.W, "props": pp}, dynamics_diffusion_coefficient={"params": mdl.L, "props": pp},
+        dynamics_diffusion_cov={"params": mdl.Qc, "props": pp}, emission_weights={"params": mdl.H, "props": pp},
+        emission_bias={"params": mdl.bias, "props": pp}, emission_cov={"params": mdl.R, "props": pp})
+    ref = o.kf_smoother_type1(mdl, t, y)
+    post = model.smoother(params, y, t[..., None])          # default smoother_type
+    assert post.smoothed_cross_covariances.shape == (N, T - 1, d, d)
+    for k in ("filtered_means", "filtered_covariances", "smoothed_means", "smoothed_covariances", "smoothed_cross_covariances"):
+        assert relerr(getattr(post, k), ref[k]) < 1e-9, k
+    np.testing.assert_allclose(post.marginal_loglik, ref["marginal_loglik"], rtol=1e-11)
+    # type 2 (the reference freezes the filtered moments over each interval) approximates the same smoother
+    post2 = model.smoother(params, y, t[..., None], smoother_type="cd_smoother_2")
+    assert relerr(post.smoothed_means, post2.smoothed_means) < 5e-2
+    # one trajectory, regular grid, single precision
+    y1 = y[0]
+    ref1 = o.kf_smoother_type1(mdl, np.arange(T, dtype=float)[None], y1[None], dt_final=1.0)
+    p1 = model.smoother(params, y1, filter_hyperparams=cd.KFHyperParams(dt_final=1.0))
+    assert p1.smoothed_means.shape == (T, d) and relerr(p1.smoothed_covariances, ref1["smoothed_covariances"][0]) < 1e-8
+    p32 = model.smoother(params, y1.astype(np.float32), filter_hyperparams=cd.KFHyperParams(dt_final=1.0))
+    assert p32.smoothed_means.dtype == np.float32 and relerr(p32.smoothed_means, ref1["smoothed_means"][0]) < 2e-3
+
+
+def test_linear_smoother_type1_refusals(hip_lib):
+    rng = np.random.default_rng(3)
+    mdl = linear_model(rng, 12, 3)
+    model = cd.ContDiscreteLinearGaussianSSM(state_dim=12, emission_dim=3)
+    pp = cd.ParameterProperties()
+    params, _ = model.initialize(dynamics_weights={"params": mdl.drift.W, "props": pp})
+    y = rng.standard_normal((6, 3))
+    with pytest.raises(NotImplementedError, match="state_dim <= 8"):
+        model.smoother(params, y)
+    assert model.smoother(params, y, smoother_type="cd_smoother_2").smoothed_means.shape == (6, 12)
+    with pytest.raises(ValueError, match="unknown smoother_type"):
+        model.smoother(params, y, smoother_type="cd_smoother_3")

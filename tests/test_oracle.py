@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 import cdkf_oracle as o
-from helpers import closed_form_kf, linear_model, relerr
+from helpers import closed_form_kf, linear_model, relerr, van_loan
 
 
 def test_dopri5_known_answer_constants_fp32():
@@ -305,3 +305,25 @@ def test_adjoint_gradient_all_parameters_matches_finite_differences():
             fd = (LL(**{name: base + h * u}) - LL(**{name: base - h * u})) / (2 * h)
             an = (ex[name] * u).reshape(N, -1).sum(1)
             assert np.abs(fd - an).max() < 2e-5 * np.abs(fd).max(), name
+
+
+def test_type1_smoother_matches_exact_rts():
+    """kf_smoother_type1 (reference cd_smoother_1: discrete RTS on the Dopri5-pushed-forward (A, Q)) against the exact
+    matrix-exponential RTS smoother; the cross term against its definition with the exact gain."""
+    rng = np.random.default_rng(12)
+    mdl = linear_model(rng, 3, 2)
+    mdl = o.Model(o.LinearDrift(mdl.drift.W, np.zeros(3)), mdl.L, mdl.Qc, mdl.H, mdl.bias, mdl.R, mdl.m0, mdl.P0)
+    T = 30
+    t = o.irregular_times(rng, 1, T, 0.2)
+    y = o.simulate(mdl, t, rng)
+    out = o.kf_smoother_type1(mdl, t, y)
+    ref = closed_form_kf(mdl, t[0], y[0])
+    # 1e-6: the reference's psd_solve adds 1e-9 to the diagonal of A P_f A^T + Q (here ~1e-2), the exact smoother does not
+    assert relerr(out["smoothed_means"][0], ref["smoothed_means"]) < 1e-6
+    assert relerr(out["smoothed_covariances"][0], ref["smoothed_covariances"]) < 1e-6
+    A, Q, _ = van_loan(mdl.drift.W, mdl.L @ mdl.Qc @ mdl.L.T, np.zeros(3), t[0, 6] - t[0, 5])
+    A_o, Q_o = o.kf_pushforward(mdl, t[:, 5], t[:, 6])
+    assert relerr(A_o[0], A) < 1e-10 and relerr(Q_o[0], Q) < 1e-10
+    C = np.linalg.solve(A @ ref["filtered_covariances"][5] @ A.T + Q, A @ ref["filtered_covariances"][5]).T
+    cross = C @ ref["smoothed_covariances"][6] + np.outer(ref["smoothed_means"][5], ref["smoothed_means"][6])
+    assert relerr(out["smoothed_cross_covariances"][0, 5], cross) < 1e-6
