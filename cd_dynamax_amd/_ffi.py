@@ -88,7 +88,8 @@ SYMBOLS = (
      "cdkf_free", "cdkf_memcpy_h2d", "cdkf_memcpy_d2h", "cdkf_memset", "cdkf_synchronize", "cdkf_ll_sum_f64_dev",
      "cdkf_ll_sum_f32_dev", "cdkf_emission_moments_f64", "cdkf_emission_moments_f32", "cdkf_emission_moments_f64_dev",
      "cdkf_emission_moments_f32_dev", "cdkf_ekf_loglik_grad_f64", "cdkf_ekf_loglik_grad_f32",
-     "cdkf_ekf_loglik_grad_f64_dev", "cdkf_ekf_loglik_grad_f32_dev", "cdkf_kf_smoother1_f64", "cdkf_kf_smoother1_f32", "cdkf_kf_smoother1_f64_dev", "cdkf_kf_smoother1_f32_dev",
+     "cdkf_ekf_loglik_grad_f64_dev", "cdkf_ekf_loglik_grad_f32_dev", "cdkf_custom_drift_register", "cdkf_custom_drift_compile", "cdkf_set_kernel_source_dir",
+     "cdkf_kf_smoother1_f64", "cdkf_kf_smoother1_f32", "cdkf_kf_smoother1_f64_dev", "cdkf_kf_smoother1_f32_dev",
      "cdkf_kf_smoother1_supported", "cdkf_grad_supported", "cdkf_grad_all_supported", "cdkf_ekf_loglik_grad_all_f64",
      "cdkf_ekf_loglik_grad_all_f32", "cdkf_ekf_loglik_grad_all_f64_dev", "cdkf_ekf_loglik_grad_all_f32_dev", "cdkf_grad_sum_f64_dev",
      "cdkf_grad_sum_f32_dev"]
@@ -134,6 +135,13 @@ def lib() -> C.CDLL:
         f = getattr(L, f"cdkf_emission_moments_{p}_dev")
         f.argtypes = [C.POINTER(CdkfModel), C.c_int64] + [C.c_void_p] * 5
         f.restype = C.c_int
+    L.cdkf_custom_drift_register.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p]
+    L.cdkf_custom_drift_register.restype = C.c_int
+    L.cdkf_custom_drift_compile.argtypes = [C.c_int] * 5
+    L.cdkf_custom_drift_compile.restype = C.c_int
+    L.cdkf_set_kernel_source_dir.argtypes = [C.c_char_p]
+    L.cdkf_set_kernel_source_dir.restype = None
+    L.cdkf_set_kernel_source_dir(os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc").encode())
     L.cdkf_kf_smoother1_supported.argtypes = [C.POINTER(CdkfModel)]
     L.cdkf_kf_smoother1_supported.restype = C.c_int
     for p in ("f64", "f32"):
@@ -278,6 +286,18 @@ def run_host(algo: str, mdl: ModelBlock, opts: CdkfOpts, t: np.ndarray, y: np.nd
     check(fn(C.byref(mdl.c), C.byref(opts), N, T, _vp(t), _vp(y), _vp(ll), *[_vp(o) for o in outs], _vp(status)))
     outs = [None if o is None else (np.moveaxis(o, -1, 0) if tcn else np.swapaxes(o, 0, 1)) for o in outs]  # views
     return ll, outs, status
+
+
+DRIFT_CUSTOM_BASE = 1000
+
+
+def register_custom_drift(state_dim: int, n_theta: int, f_src: str, jac_src: str, divgrad_src: Optional[str]) -> int:
+    """cdkf_custom_drift_register: returns the drift_kind (same sources -> same kind)."""
+    kind = lib().cdkf_custom_drift_register(int(state_dim), int(n_theta), f_src.encode(), jac_src.encode(),
+                                            None if divgrad_src is None else divgrad_src.encode())
+    if kind < 0:
+        check(kind)
+    return kind
 
 
 def kf_smoother1(mdl: ModelBlock, opts: CdkfOpts, t: np.ndarray, y: np.ndarray, dtype):

@@ -380,8 +380,16 @@ int cdkf_supported(const cdkf_model* mdl, const cdkf_opts* o, int algo, int byte
 }
 
 int cdkf_preferred_layout(const cdkf_model* mdl) {
-  return (mdl && reg_shape_available(mdl)) ? CDKF_LAYOUT_TCN : CDKF_LAYOUT_TN;
+  return (mdl && (reg_shape_available(mdl) || custom_kind(mdl->drift_kind))) ? CDKF_LAYOUT_TCN : CDKF_LAYOUT_TN;
 }
+
+int cdkf_custom_drift_register(int state_dim, int n_theta, const char* f_src, const char* jac_src, const char* divgrad_src) {
+  return custom_register(state_dim, n_theta, f_src, jac_src, divgrad_src);
+}
+int cdkf_custom_drift_compile(int drift_kind, int bytes_per_real, int emission_dim, int algo, int state_order) {
+  return custom_compile_check(drift_kind, bytes_per_real, emission_dim, algo, state_order);
+}
+void cdkf_set_kernel_source_dir(const char* dir) { custom_set_source_dir(dir); }
 
 int cdkf_malloc(void** p, int64_t bytes) {
   if (!p || bytes < 0) {

@@ -47,6 +47,28 @@ int launch_kf_smoother1(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, in
                         R* fm, R* fP, R* sm, R* sP, R* cross, int32_t* status, hipStream_t stream);
 bool smoother1_shape_available(const cdkf_model* mdl);
 
+// ring of persistent parameter buffers (launch_wg.hip): device block + pinned staging + an event behind the readers
+struct ParamSlot {
+  void* dev = nullptr;
+  void* host = nullptr;
+  size_t cap = 0;
+  int device = -1;
+  hipEvent_t done = nullptr;
+  bool in_flight = false;
+};
+int param_pool_acquire(size_t bytes, ParamSlot** out);
+int param_pool_release(ParamSlot* s, hipStream_t stream);
+
+// user-supplied drifts compiled at run time (launch_custom.hip); algo: 0 EKF filter, 1 UKF filter, 2 EKF smoother
+bool custom_kind(int kind);
+bool custom_shape_available(const cdkf_model* mdl, const cdkf_opts* o);
+template <typename R>
+int launch_custom(int algo, const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll,
+                  R* a1, R* a2, R* a3, R* a4, int32_t* status, hipStream_t stream);
+int custom_register(int state_dim, int n_theta, const char* f_src, const char* jac_src, const char* divgrad_src);
+int custom_compile_check(int kind, int bytes_per_real, int emission_dim, int algo, int state_order);
+void custom_set_source_dir(const char* dir);
+
 bool kernel_available(const cdkf_model* mdl, const cdkf_opts* o, int algo, int bytes_per_real);
 
 // workgroup-per-trajectory kernels (launch_wg.hip): any registry drift, d and m up to what fits 160 KB of LDS

@@ -7,7 +7,9 @@
 //   MVN(...).log_prob                 inference_ekf.py:286 (TFP MultivariateNormalFullCovariance)
 //   diffeqsolve -> Dopri5, const dt0  src/utils/diffrax_utils.py:40-165 (diffrax 0.4.0)
 #pragma once
+#ifndef __HIPCC_RTC__  // hipRTC (launch_custom.hip) provides the runtime declarations itself
 #include <hip/hip_runtime.h>
+#endif
 
 #define CDKF_DEV __device__ __forceinline__
 

@@ -486,8 +486,9 @@ CDKF_DEV void ukf_update(const Args& a, R (&ys)[Dims<D>::NS], const R (&yobs)[M]
 //         N-1 and store the same values to the same addresses, so no lane predicate is needed either.
 constexpr int kOutNone = 0, kOutAll = 1, kOutSome = 2;
 
+// (body as a device function so that run-time compiled kernels -- user-supplied drifts, launch_custom.hip -- share it)
 template <typename R, int D, int M, typename Drift, bool UKF, bool ZEROTH, bool HSEL, int OUT, bool FORECAST = false>
-__global__ __launch_bounds__(64, 1) void filter_reg_kernel(const RegArgs<R, D, M, Drift> a) {
+CDKF_DEV void filter_reg_body(const RegArgs<R, D, M, Drift>& a) {
   constexpr int NS = Dims<D>::NS;
   constexpr int NP = Dims<D>::NP;
   const long gid = (long)blockIdx.x * 64 + threadIdx.x;
@@ -576,6 +577,11 @@ __global__ __launch_bounds__(64, 1) void filter_reg_kernel(const RegArgs<R, D, M
   }
 }
 
+template <typename R, int D, int M, typename Drift, bool UKF, bool ZEROTH, bool HSEL, int OUT, bool FORECAST = false>
+__global__ __launch_bounds__(64, 1) void filter_reg_kernel(const RegArgs<R, D, M, Drift> a) {
+  filter_reg_body<R, D, M, Drift, UKF, ZEROTH, HSEL, OUT, FORECAST>(a);
+}
+
 // ---- EKF (RTS) smoother backward sweep (inference_ekf.py:363-448, 503-531) ----------------------
 // Over the interval [t_k, t_{k+1}] the filtered moments (m_f, P_f) at t_k are constants, so
 // G = F(m_f) + psd_solve(P_f, L Qc L^T)^T and f(m_f) are hoisted out of the RK stages (the reference
@@ -617,8 +623,7 @@ struct SmoothRhs {
 };
 
 template <typename R, int D, int M, typename Drift>
-__global__ __launch_bounds__(64) void ekf_smoother_reg_kernel(const RegArgs<R, D, M, Drift> a, R* __restrict__ sm,
-                                                              R* __restrict__ sP) {
+CDKF_DEV void ekf_smoother_reg_body(const RegArgs<R, D, M, Drift>& a, R* __restrict__ sm, R* __restrict__ sP) {
   constexpr int NS = Dims<D>::NS;
   const long gid = (long)blockIdx.x * 64 + threadIdx.x;
   const bool live = gid < a.N;
@@ -682,6 +687,12 @@ __global__ __launch_bounds__(64) void ekf_smoother_reg_kernel(const RegArgs<R, D
   }
   if (bad) st |= kStatusNotPd;
   if (live && a.status && st) atomicOr(&a.status[n], st);
+}
+
+template <typename R, int D, int M, typename Drift>
+__global__ __launch_bounds__(64) void ekf_smoother_reg_kernel(const RegArgs<R, D, M, Drift> a, R* __restrict__ sm,
+                                                              R* __restrict__ sP) {
+  ekf_smoother_reg_body<R, D, M, Drift>(a, sm, sP);
 }
 
 }  // namespace cdkf

@@ -1,0 +1,359 @@
+// launch_custom.hip -- user-supplied drifts: the reference takes any Python callable as the drift
+// (ParamsCDNLGSSMDynamics.drift, cdnlgssm_utils.py:38-61); a callable cannot cross a C ABI, so the counterpart here is
+// a drift given as C source for f(x, theta), its Jacobian and (optionally) grad(div f), compiled at run time with
+// hipRTC into the SAME lane-per-trajectory sweep bodies (filter_reg_body / ekf_smoother_reg_body of
+// cdkf_reg_kernels.h) the built-in drifts use.  One module per (drift, precision, emission_dim, algorithm variant),
+// compiled on first use and cached for the life of the process.
+#include <dlfcn.h>
+#include <hip/hiprtc.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <tuple>
+
+#include "cdkf_launch.h"
+
+namespace cdkf {
+
+namespace {
+
+struct CustomDrift {
+  int d, n_theta;
+  std::string f_src, jac_src, g_src;
+  bool has_g;
+};
+std::vector<CustomDrift> g_drifts;
+std::mutex g_mutex;
+std::string g_src_dir;
+
+// kind, bytes per real, emission_dim, ukf, zeroth, forecast, smoother
+using Key = std::tuple<int, int, int, int, int, int, int>;
+struct Compiled {
+  hipModule_t module = nullptr;
+  hipFunction_t fn = nullptr;
+};
+std::map<Key, Compiled> g_modules;
+
+std::string source_dir() {
+  if (!g_src_dir.empty()) return g_src_dir;
+  Dl_info info;
+  if (dladdr((const void*)&source_dir, &info) && info.dli_fname) {
+    std::string p(info.dli_fname);
+    const size_t slash = p.find_last_of('/');
+    g_src_dir = (slash == std::string::npos ? std::string(".") : p.substr(0, slash)) + "/../csrc";
+  } else {
+    g_src_dir = ".";
+  }
+  return g_src_dir;
+}
+
+std::string generate_source(const CustomDrift& c, int bytes, int m, int ukf, int zeroth, int forecast, int smoother) {
+  std::string s;
+  s += "#include \"cdkf_reg_kernels.h\"\n";
+  s += "namespace cdkf {\n";
+  s += "template <typename R, int D>\nstruct DriftCustom {\n";
+  s += "  static constexpr int NTHETA = " + std::to_string(c.n_theta) + ";\n";
+  s += "  static constexpr bool HAS_G = " + std::string(c.has_g ? "true" : "false") + ";\n";
+  s += "  static constexpr bool CONST_JAC = false;\n";
+  s += "  R th[" + std::to_string(c.n_theta > 0 ? c.n_theta : 1) + "];\n";
+  s += "  static constexpr bool nz(int, int) { return true; }\n";
+  s += "  CDKF_DEV void f(const R* x, R (&fx)[D]) const {\n    const R* theta = th; (void)theta;\n";
+  s += "#line 1 \"drift_f\"\n" + c.f_src + "\n  }\n";
+  s += "  CDKF_DEV void jac(const R* x, R (&F)[D][D]) const {\n    const R* theta = th; (void)theta;\n";
+  s += "    for (int i_ = 0; i_ < D; ++i_) for (int j_ = 0; j_ < D; ++j_) F[i_][j_] = R(0);\n";
+  s += "#line 1 \"drift_jacobian\"\n" + c.jac_src + "\n  }\n";
+  s += "  CDKF_DEV void divgrad(const R* x, R (&g)[D]) const {\n    const R* theta = th; (void)theta;\n";
+  s += "    for (int i_ = 0; i_ < D; ++i_) g[i_] = R(0);\n";
+  s += "#line 1 \"drift_divgrad\"\n" + c.g_src + "\n  }\n};\n}  // namespace cdkf\n";
+  s += "using R = " + std::string(bytes == 8 ? "double" : "float") + ";\n";
+  s += "constexpr int DD = " + std::to_string(c.d) + ", MM = " + std::to_string(m) + ";\n";
+  s += "using Drift = cdkf::DriftCustom<R, DD>;\nusing Args = cdkf::RegArgs<R, DD, MM, Drift>;\n";
+  // parameter blob (reals): theta | LQL | LQLz | H | hb | Rm | m0 | P0 | dt0 dt_final ukf_c ukf_wm0 ukf_wc0 ukf_wi
+  // integer blob (longs) : max_steps order num_iter forecast N T t_sn t_sk y_sn y_sk y_si m_sn m_sk m_si P_sn P_sk P_si
+  s += R"(
+__device__ __forceinline__ void unpack(Args& a, const R* __restrict__ par, const long* __restrict__ ip, const R* t, const R* y,
+                                       R* ll, R* fm, R* fP, R* pm, R* pP, int* status) {
+  constexpr int NP = cdkf::Dims<DD>::NP;
+  int o = 0;
+  for (int k = 0; k < Drift::NTHETA; ++k) a.drift.th[k] = par[o + k];
+  o += Drift::NTHETA;
+  for (int k = 0; k < NP; ++k) a.LQL[k] = par[o + k];
+  o += NP;
+  for (int k = 0; k < NP; ++k) a.LQLz[k] = par[o + k];
+  o += NP;
+  for (int r = 0; r < MM; ++r) for (int k = 0; k < DD; ++k) a.H[r][k] = par[o + r * DD + k];
+  o += MM * DD;
+  for (int r = 0; r < MM; ++r) a.hb[r] = par[o + r];
+  o += MM;
+  for (int r = 0; r < MM; ++r) for (int c = 0; c < MM; ++c) a.Rm[r][c] = par[o + r * MM + c];
+  o += MM * MM;
+  for (int k = 0; k < DD; ++k) a.m0[k] = par[o + k];
+  o += DD;
+  for (int k = 0; k < NP; ++k) a.P0[k] = par[o + k];
+  o += NP;
+  a.dt0 = par[o]; a.dt_final = par[o + 1]; a.ukf_c = par[o + 2]; a.ukf_wm0 = par[o + 3]; a.ukf_wc0 = par[o + 4];
+  a.ukf_wi = par[o + 5];
+  a.max_steps = ip[0]; a.order = (int)ip[1]; a.num_iter = (int)ip[2]; a.forecast = (int)ip[3]; a.N = ip[4]; a.T = ip[5];
+  a.t_sn = ip[6]; a.t_sk = ip[7]; a.y_sn = ip[8]; a.y_sk = ip[9]; a.y_si = ip[10]; a.m_sn = ip[11]; a.m_sk = ip[12];
+  a.m_si = ip[13]; a.P_sn = ip[14]; a.P_sk = ip[15]; a.P_si = ip[16];
+  a.t = t; a.y = y; a.ll = ll; a.fm = fm; a.fP = fP; a.pm = pm; a.pP = pP; a.status = status;
+}
+)";
+  if (!smoother) {
+    s += "extern \"C\" __global__ __launch_bounds__(64, 1) void cdkf_custom_kernel(const R* par, const long* ip, const R* t, "
+         "const R* y, R* ll, R* fm, R* fP, R* pm, R* pP, int* status, R* sm, R* sP) {\n  Args a;\n"
+         "  unpack(a, par, ip, t, y, ll, fm, fP, pm, pP, status);\n";
+    s += "  cdkf::filter_reg_body<R, DD, MM, Drift, " + std::string(ukf ? "true" : "false") + ", " +
+         std::string(zeroth ? "true" : "false") + ", false, cdkf::kOutSome, " + std::string(forecast ? "true" : "false") +
+         ">(a);\n}\n";
+  } else {
+    s += "extern \"C\" __global__ __launch_bounds__(64) void cdkf_custom_kernel(const R* par, const long* ip, const R* t, "
+         "const R* y, R* ll, R* fm, R* fP, R* pm, R* pP, int* status, R* sm, R* sP) {\n  Args a;\n"
+         "  unpack(a, par, ip, t, y, ll, fm, fP, pm, pP, status);\n"
+         "  cdkf::ekf_smoother_reg_body<R, DD, MM, Drift>(a, sm, sP);\n}\n";
+  }
+  return s;
+}
+
+// compile one variant; `code` receives the code object.  No GPU needed (the target is named explicitly).
+int compile_variant(const CustomDrift& c, const Key& key, const std::string& arch, std::vector<char>& code) {
+  const std::string src = generate_source(c, std::get<1>(key), std::get<2>(key), std::get<3>(key), std::get<4>(key),
+                                          std::get<5>(key), std::get<6>(key));
+  hiprtcProgram prog = nullptr;
+  if (hiprtcCreateProgram(&prog, src.c_str(), "cdkf_custom_drift.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
+    set_error("custom drift: hiprtcCreateProgram failed");
+    return CDKF_EHIP;
+  }
+  const std::string inc = "-I" + source_dir(), off = "--offload-arch=" + arch;
+  const char* opts[] = {off.c_str(), "-O3", "-std=c++17", inc.c_str(), "-Wno-pass-failed"};
+  const hiprtcResult res = hiprtcCompileProgram(prog, 5, opts);
+  if (res != HIPRTC_SUCCESS) {
+    size_t n = 0;
+    hiprtcGetProgramLogSize(prog, &n);
+    std::string log(n ? n : 1, '\0');
+    if (n) hiprtcGetProgramLog(prog, &log[0]);
+    // keep the diagnostics, drop the include-chain preamble
+    std::string brief;
+    size_t pos = 0;
+    while (pos < log.size()) {
+      size_t eol = log.find('\n', pos);
+      if (eol == std::string::npos) eol = log.size();
+      if (log.compare(pos, 21, "In file included from") != 0) brief.append(log, pos, eol - pos + 1);
+      pos = eol + 1;
+    }
+    set_error("custom drift: compilation failed (%s): %.400s", hiprtcGetErrorString(res), brief.c_str());
+    hiprtcDestroyProgram(&prog);
+    return CDKF_EINVAL;
+  }
+  size_t sz = 0;
+  hiprtcGetCodeSize(prog, &sz);
+  code.resize(sz);
+  hiprtcGetCode(prog, code.data());
+  hiprtcDestroyProgram(&prog);
+  return CDKF_OK;
+}
+
+int get_function(int kind, const Key& key, hipFunction_t* fn) {
+  std::lock_guard<std::mutex> lock(g_mutex);
+  auto it = g_modules.find(key);
+  if (it != g_modules.end()) {
+    *fn = it->second.fn;
+    return CDKF_OK;
+  }
+  const CustomDrift& c = g_drifts[kind - CDKF_DRIFT_CUSTOM_BASE];
+  int dev = 0;
+  CDKF_HIP_CHECK(hipGetDevice(&dev));
+  hipDeviceProp_t prop;
+  CDKF_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+  std::vector<char> code;
+  int rc = compile_variant(c, key, prop.gcnArchName, code);
+  if (rc) return rc;
+  Compiled m;
+  CDKF_HIP_CHECK(hipModuleLoadData(&m.module, code.data()));
+  CDKF_HIP_CHECK(hipModuleGetFunction(&m.fn, m.module, "cdkf_custom_kernel"));
+  g_modules[key] = m;
+  *fn = m.fn;
+  return CDKF_OK;
+}
+
+}  // namespace
+
+bool custom_kind(int kind) {
+  std::lock_guard<std::mutex> lock(g_mutex);
+  return kind >= CDKF_DRIFT_CUSTOM_BASE && kind - CDKF_DRIFT_CUSTOM_BASE < (int)g_drifts.size();
+}
+
+bool custom_shape_available(const cdkf_model* mdl, const cdkf_opts* o) {
+  if (!custom_kind(mdl->drift_kind)) return false;
+  std::lock_guard<std::mutex> lock(g_mutex);
+  const CustomDrift& c = g_drifts[mdl->drift_kind - CDKF_DRIFT_CUSTOM_BASE];
+  if (c.d != mdl->state_dim || c.n_theta != mdl->n_theta || mdl->emission_dim > 6) return false;
+  if (o && o->state_order == CDKF_ORDER_SECOND && !c.has_g) return false;
+  return true;
+}
+
+// algo: 0 EKF filter, 1 UKF filter, 2 EKF smoother (filter + backward sweep)
+template <typename R>
+int launch_custom(int algo, const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll,
+                  R* a1, R* a2, R* a3, R* a4, int32_t* status, hipStream_t stream) {
+  if (!custom_kind(mdl->drift_kind)) {
+    set_error("unknown drift_kind %d", mdl->drift_kind);
+    return CDKF_EUNSUPPORTED;
+  }
+  CustomDrift c;
+  {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    c = g_drifts[mdl->drift_kind - CDKF_DRIFT_CUSTOM_BASE];
+  }
+  const int d = mdl->state_dim, m = mdl->emission_dim;
+  if (c.d != d || c.n_theta != mdl->n_theta) {
+    set_error("custom drift %d was registered for state_dim=%d, n_theta=%d (model has %d, %lld)", mdl->drift_kind, c.d,
+              c.n_theta, d, (long long)mdl->n_theta);
+    return CDKF_EINVAL;
+  }
+  if (m > 6) {
+    set_error("custom drifts run on the register-resident kernels: emission_dim <= 6 (got %d)", m);
+    return CDKF_EUNSUPPORTED;
+  }
+  if (algo != 1 && o->state_order == CDKF_ORDER_SECOND && !c.has_g) {
+    set_error("custom drift without grad(div f) source: state_order 'second' needs it (the reference differentiates the "
+              "drift twice, inference_ekf.py:108-116); register divgrad_src or use state_order 'first'");
+    return CDKF_EUNSUPPORTED;
+  }
+  const bool smoother = algo == 2;
+  if (smoother && (!a1 || !a2 || !a3 || !a4)) {
+    set_error("EKF smoother: filtered and smoothed output pointers must not be NULL");
+    return CDKF_EINVAL;
+  }
+  // ---- parameter blobs -----------------------------------------------------------------------------------------------
+  const int np = d * (d + 1) / 2;
+  std::vector<R> par;
+  for (long k = 0; k < mdl->n_theta; ++k) par.push_back(R(mdl->theta[k]));
+  std::vector<R> packed(np);
+  lql_packed<R>(mdl->L, mdl->Qc, d, 1.0, packed.data());
+  par.insert(par.end(), packed.begin(), packed.end());
+  lql_packed<R>(mdl->L, mdl->Qc, d, o->cov_rescaling, packed.data());
+  par.insert(par.end(), packed.begin(), packed.end());
+  for (int k = 0; k < m * d; ++k) par.push_back(R(mdl->H[k]));
+  for (int k = 0; k < m; ++k) par.push_back(R(mdl->h_bias[k]));
+  for (int k = 0; k < m * m; ++k) par.push_back(R(mdl->R[k]));
+  for (int k = 0; k < d; ++k) par.push_back(R(mdl->m0[k]));
+  for (int i = 0; i < d; ++i)
+    for (int j = i; j < d; ++j) par.push_back(R(0.5) * (R(mdl->P0[i * d + j]) + R(mdl->P0[j * d + i])));
+  {
+    const R alpha = R(o->ukf_alpha), n = R(d);
+    const R lamb = alpha * alpha * (n + R(o->ukf_kappa)) - n;
+    par.push_back(R(o->dt0));
+    par.push_back(R(o->dt_final));
+    par.push_back(std::sqrt(n + lamb));
+    par.push_back(lamb / (n + lamb));
+    par.push_back(lamb / (n + lamb) + (R(1) - alpha * alpha + R(o->ukf_beta)));
+    par.push_back(R(1) / (R(2) * (n + lamb)));
+  }
+  long ip[17];
+  ip[0] = (long)o->max_steps;
+  ip[1] = o->state_order;
+  ip[2] = smoother ? 1 : o->num_iter;
+  ip[3] = smoother ? 0 : o->forecast;
+  ip[4] = N;
+  ip[5] = T;
+  const long M = m, D = d;
+  long* st = ip + 6;  // t_sn t_sk y_sn y_sk y_si m_sn m_sk m_si P_sn P_sk P_si
+  st[4] = st[7] = st[10] = 1;
+  if (o->layout == CDKF_LAYOUT_TCN) {
+    st[0] = o->t_shared ? 0 : 1; st[1] = o->t_shared ? 1 : N;
+    st[2] = st[5] = st[8] = 1;
+    st[3] = N * M; st[6] = N * D; st[9] = N * D * D;
+    st[4] = st[7] = st[10] = N;
+  } else if (o->layout == CDKF_LAYOUT_TN) {
+    st[0] = o->t_shared ? 0 : 1; st[1] = o->t_shared ? 1 : N;
+    st[2] = M; st[3] = N * M; st[5] = D; st[6] = N * D; st[8] = D * D; st[9] = N * D * D;
+  } else {
+    st[0] = o->t_shared ? 0 : T; st[1] = 1;
+    st[2] = T * M; st[3] = M; st[5] = T * D; st[6] = D; st[8] = T * D * D; st[9] = D * D;
+  }
+  const R* yy = y;
+  if (!y) {  // forecast mode ignores the observations; keep the prefetch loads on valid memory
+    yy = t;
+    st[2] = st[3] = st[4] = 0;
+  }
+  const size_t par_bytes = par.size() * sizeof(R), blob = ((par_bytes + 15) & ~size_t(15)) + sizeof(ip);
+  ParamSlot* slot = nullptr;
+  int rc = param_pool_acquire(blob, &slot);
+  if (rc) return rc;
+  std::memcpy(slot->host, par.data(), par_bytes);
+  std::memcpy((char*)slot->host + ((par_bytes + 15) & ~size_t(15)), ip, sizeof(ip));
+  CDKF_HIP_CHECK(hipMemcpyAsync(slot->dev, slot->host, blob, hipMemcpyHostToDevice, stream));
+  const R* dpar = (const R*)slot->dev;
+  const long* dip = (const long*)((char*)slot->dev + ((par_bytes + 15) & ~size_t(15)));
+
+  // ---- kernels ---------------------------------------------------------------------------------------------------------
+  const unsigned blocks = (unsigned)((N + 63) / 64);
+  R* null_r = nullptr;
+  auto run = [&](const Key& key, R* o1, R* o2, R* o3, R* o4, R* sm, R* sP) -> int {
+    hipFunction_t fn = nullptr;
+    int r = get_function(mdl->drift_kind, key, &fn);
+    if (r) return r;
+    void* args[] = {(void*)&dpar, (void*)&dip, (void*)&t, (void*)&yy, (void*)&ll, (void*)&o1, (void*)&o2,
+                    (void*)&o3,   (void*)&o4,  (void*)&status, (void*)&sm, (void*)&sP};
+    CDKF_HIP_CHECK(hipModuleLaunchKernel(fn, blocks, 1, 1, 64, 1, 1, 0, stream, args, nullptr));
+    return CDKF_OK;
+  };
+  const int zeroth = (algo != 1 && o->state_order == CDKF_ORDER_ZEROTH) ? 1 : 0;
+  if (!smoother) {
+    rc = run(Key(mdl->drift_kind, (int)sizeof(R), m, algo == 1, zeroth, o->forecast ? 1 : 0, 0), a1, a2, a3, a4, null_r, null_r);
+  } else {
+    rc = run(Key(mdl->drift_kind, (int)sizeof(R), m, 0, zeroth, 0, 0), a1, a2, null_r, null_r, null_r, null_r);
+    if (!rc) rc = run(Key(mdl->drift_kind, (int)sizeof(R), m, 0, 0, 0, 1), a1, a2, null_r, null_r, a3, a4);
+  }
+  const int rc2 = param_pool_release(slot, stream);
+  return rc ? rc : rc2;
+}
+
+template int launch_custom<float>(int, const cdkf_model*, const cdkf_opts*, int64_t, int64_t, const float*, const float*, float*,
+                                  float*, float*, float*, float*, int32_t*, hipStream_t);
+template int launch_custom<double>(int, const cdkf_model*, const cdkf_opts*, int64_t, int64_t, const double*, const double*,
+                                   double*, double*, double*, double*, double*, int32_t*, hipStream_t);
+
+int custom_register(int state_dim, int n_theta, const char* f_src, const char* jac_src, const char* divgrad_src) {
+  if (state_dim < 1 || state_dim > 6 || n_theta < 0 || !f_src || !jac_src) {
+    set_error("custom drift: need 1 <= state_dim <= 6, n_theta >= 0 and sources for f and its Jacobian");
+    return CDKF_EINVAL;
+  }
+  std::lock_guard<std::mutex> lock(g_mutex);
+  CustomDrift c{state_dim, n_theta, f_src, jac_src, divgrad_src ? divgrad_src : "", divgrad_src != nullptr};
+  for (size_t k = 0; k < g_drifts.size(); ++k) {
+    const CustomDrift& e = g_drifts[k];
+    if (e.d == c.d && e.n_theta == c.n_theta && e.f_src == c.f_src && e.jac_src == c.jac_src && e.g_src == c.g_src &&
+        e.has_g == c.has_g)
+      return CDKF_DRIFT_CUSTOM_BASE + (int)k;
+  }
+  g_drifts.push_back(c);
+  return CDKF_DRIFT_CUSTOM_BASE + (int)g_drifts.size() - 1;
+}
+
+int custom_compile_check(int kind, int bytes_per_real, int emission_dim, int algo, int state_order) {
+  if (!custom_kind(kind) || (bytes_per_real != 4 && bytes_per_real != 8) || emission_dim < 1 || emission_dim > 6 || algo < 0 ||
+      algo > 2) {
+    set_error("custom drift compile check: bad arguments");
+    return CDKF_EINVAL;
+  }
+  CustomDrift c;
+  {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    c = g_drifts[kind - CDKF_DRIFT_CUSTOM_BASE];
+  }
+  std::vector<char> code;
+  const int zeroth = (algo != 1 && state_order == CDKF_ORDER_ZEROTH) ? 1 : 0;
+  int rc = compile_variant(c, Key(kind, bytes_per_real, emission_dim, algo == 1, zeroth, 0, 0), "gfx950", code);
+  if (!rc && algo == 2) rc = compile_variant(c, Key(kind, bytes_per_real, emission_dim, 0, 0, 0, 1), "gfx950", code);
+  return rc;
+}
+
+void custom_set_source_dir(const char* dir) {
+  std::lock_guard<std::mutex> lock(g_mutex);
+  g_src_dir = dir ? dir : "";
+}
+
+}  // namespace cdkf

@@ -25,6 +25,7 @@ int launch_ekf_smoother(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, in
     set_error("EKF smoother: filtered and smoothed output pointers must not be NULL");
     return CDKF_EINVAL;
   }
+  if (custom_kind(mdl->drift_kind)) return launch_custom<R>(2, mdl, o, N, T, t, y, ll, fm, fP, sm, sP, status, stream);
   if (o->state_order == CDKF_ORDER_ZEROTH) {
     // the reference's filter accepts it; kept for parity with extended_kalman_smoother, which simply
     // forwards hyperparams to the filter and always smooths with smooth_order = 'first'
@@ -43,7 +44,8 @@ template int launch_ekf_smoother<double>(const cdkf_model*, const cdkf_opts*, in
                                          const double*, double*, double*, double*, double*, double*, int32_t*,
                                          hipStream_t);
 
-bool kernel_available(const cdkf_model* mdl, const cdkf_opts*, int algo, int bytes_per_real) {
+bool kernel_available(const cdkf_model* mdl, const cdkf_opts* o, int algo, int bytes_per_real) {
+  if (custom_kind(mdl->drift_kind)) return custom_shape_available(mdl, algo == 1 ? nullptr : o);
   if (reg_shape_available(mdl)) return true;
   return wg_shape_available(mdl, bytes_per_real);
 }

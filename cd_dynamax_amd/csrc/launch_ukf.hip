@@ -16,6 +16,7 @@ static int run_ukf_reg(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int
 template <typename R>
 int launch_ukf_filter(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll,
                       R* fm, R* fP, R* pm, R* pP, int32_t* status, hipStream_t stream) {
+  if (custom_kind(mdl->drift_kind)) return launch_custom<R>(1, mdl, o, N, T, t, y, ll, fm, fP, pm, pP, status, stream);
 #define X(KIND, DRIFT, D_, M_)                                                           \
   if (mdl->drift_kind == KIND && mdl->state_dim == D_ && mdl->emission_dim == M_)        \
     return run_ukf_reg<R, D_, M_, DRIFT<R, D_>>(mdl, o, N, T, t, y, ll, fm, fP, pm, pP, status, stream);

@@ -46,20 +46,12 @@ bool wg_shape_available(const cdkf_model* mdl, int bytes_per_real) {
 // with a pinned host staging buffer and an event recorded behind the kernels that read it.  The asynchronous
 // _dev entry points therefore neither allocate nor synchronise in the steady state.  (hipMallocAsync +
 // hipMemcpyAsync from pageable memory was tried first and delivered stale parameter blocks on ROCm 7.2.)
-struct ParamSlot {
-  void* dev = nullptr;
-  void* host = nullptr;
-  size_t cap = 0;
-  int device = -1;
-  hipEvent_t done = nullptr;
-  bool in_flight = false;
-};
 static constexpr int kParamSlots = 8;
 static ParamSlot g_slots[kParamSlots];
 static int g_next_slot = 0;
 static std::mutex g_slot_mutex;
 
-static int param_pool_acquire(size_t bytes, ParamSlot** out) {
+int param_pool_acquire(size_t bytes, ParamSlot** out) {
   std::lock_guard<std::mutex> lock(g_slot_mutex);
   int dev = 0;
   CDKF_HIP_CHECK(hipGetDevice(&dev));
@@ -85,7 +77,7 @@ static int param_pool_acquire(size_t bytes, ParamSlot** out) {
   return CDKF_OK;
 }
 
-static int param_pool_release(ParamSlot* s, hipStream_t stream) {
+int param_pool_release(ParamSlot* s, hipStream_t stream) {
   std::lock_guard<std::mutex> lock(g_slot_mutex);
   CDKF_HIP_CHECK(hipEventRecord(s->done, stream));
   s->in_flight = true;

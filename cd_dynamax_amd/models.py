@@ -18,7 +18,8 @@ from typing import List, Optional, Tuple, Union
 import numpy as np
 
 from . import _ffi
-from .params import (EKFHyperParams, EnKFHyperParams, GSSMForecast, LearnableLinear, LearnableLorenz63, LearnableLorenz96,
+from .params import (EKFHyperParams, EnKFHyperParams, GSSMForecast, LearnableCustomDrift, LearnableLinear, LearnableLorenz63,
+                     LearnableLorenz96,
                      LearnableMatrix, LearnableMLP, LearnableVector, ParameterProperties, ParamsCDNLGSSM,
                      ParamsCDNLGSSMDynamics, ParamsCDNLGSSMEmissions, ParamsLGSSMInitial, PosteriorGSSMFiltered,
                      PosteriorGSSMSmoothed, UKFHyperParams)
@@ -42,10 +43,15 @@ def _model_block(params: ParamsCDNLGSSM) -> _ffi.ModelBlock:
         kind = _ffi.DRIFT_MLP_TANH
         hidden = (np.asarray(drift.W1).shape[0], np.asarray(drift.W2).shape[0])
         theta = np.concatenate([np.asarray(a, np.float64).ravel() for a in drift])
+    elif isinstance(drift, LearnableCustomDrift):
+        theta = np.atleast_1d(np.asarray(drift.theta, dtype=np.float64)).ravel()
+        d = int(np.asarray(params.initial.mean.f()).shape[0])
+        kind = _ffi.register_custom_drift(d, theta.size, drift.f_src, drift.jac_src, drift.divgrad_src)
     else:
         raise NotImplementedError(
             f"drift of type {type(drift).__name__} is not in the HIP drift registry "
-            "(LearnableLinear, LearnableLorenz63, LearnableLorenz96, LearnableMLP)")
+            "(LearnableLinear, LearnableLorenz63, LearnableLorenz96, LearnableMLP) and is not a LearnableCustomDrift "
+            "(C source compiled at run time; Python callables cannot cross the C ABI)")
     h = params.emissions.emission_function
     if not isinstance(h, LearnableLinear):
         raise NotImplementedError(

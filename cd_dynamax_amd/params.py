@@ -87,6 +87,30 @@ class LearnableMLP(NamedTuple):
         return np.asarray(self.W3) @ a2 + np.asarray(self.b3)
 
 
+class LearnableCustomDrift(NamedTuple):
+    """A user-defined drift for the HIP path.  The reference takes any callable (cdnlgssm_utils.py:38-61); here the drift
+    is C source compiled at run time into the register-resident sweep kernels (include/cdkf.h,
+    cdkf_custom_drift_register):
+
+      f_src        statements computing ``fx[i]`` from ``x[j]`` and ``theta[k]``         e.g. "fx[0] = x[1]; fx[1] = -theta[0]*sin(x[0]);"
+      jac_src      statements assigning the non-zero ``F[i][j]`` = d f_i / d x_j        e.g. "F[0][1] = R(1); F[1][0] = -theta[0]*cos(x[0]);"
+      divgrad_src  statements assigning ``g[i]`` = d/dx_i sum_j d f_j / d x_j, or None (EKF ``state_order='second'`` is
+                   then refused -- the reference obtains this term by differentiating the drift twice)
+
+    ``R`` is the compute type (float or double); state_dim <= 6.  ``py_f`` (optional) is the same function as a Python
+    callable ``f(x, u, t)`` for host-side use; it is never called by the filter."""
+    theta: Any
+    f_src: str
+    jac_src: str
+    divgrad_src: Optional[str] = None
+    py_f: Optional[Any] = None
+
+    def f(self, x, u=None, t=None):
+        if self.py_f is None:
+            raise NotImplementedError("LearnableCustomDrift: no Python callable was given (py_f)")
+        return self.py_f(x, u, t)
+
+
 class ParamsLGSSMInitial(NamedTuple):
     mean: Any
     cov: Any

@@ -53,6 +53,7 @@ extern "C" {
 #define CDKF_DRIFT_LINEAR 0   /* LearnableLinear: theta = [W (d*d), b (d)]; f = W x + b */
 #define CDKF_DRIFT_LORENZ63 1 /* LearnableLorenz63: theta = [sigma, rho, beta]; d = 3 */
 #define CDKF_DRIFT_LORENZ96 2 /* theta = [F]; f_i = (x_{i+1} - x_{i-2}) x_{i-1} - x_i + F; d >= 4 */
+#define CDKF_DRIFT_CUSTOM_BASE 1000 /* kinds >= this come from cdkf_custom_drift_register() */
 #define CDKF_DRIFT_MLP_TANH 3 /* theta = [W1 (h1*d), b1 (h1), W2 (h2*h1), b2 (h2), W3 (d*h2), b3 (d)];
                                  f = W3 tanh(W2 tanh(W1 x + b1) + b2) + b3 */
 
@@ -207,6 +208,28 @@ int cdkf_emission_moments_f64_dev(const cdkf_model* mdl, int64_t rows, const dou
                                   double* out_mean, double* out_cov, void* stream);
 int cdkf_emission_moments_f32_dev(const cdkf_model* mdl, int64_t rows, const float* means, const float* covs,
                                   float* out_mean, float* out_cov, void* stream);
+
+/* ---- user-supplied drifts.  The reference accepts any Python callable as ParamsCDNLGSSMDynamics.drift
+ *      (src/continuous_discrete_nonlinear_gaussian_ssm/cdnlgssm_utils.py:38-61); across a C ABI the drift is C source,
+ *      compiled at run time (hipRTC) into the same register-resident sweep kernels the built-in drifts use.
+ *        f_src       body computing  fx[i] = f_i(x, theta)         (x: const R*, theta: const R*, R = float or double)
+ *        jac_src     body assigning the NON-ZERO entries F[i][j] = d f_i / d x_j   (F is zeroed first)
+ *        divgrad_src body assigning g[i] = d/dx_i sum_j d f_j/d x_j, or NULL: then EKF state_order 'second' is refused
+ *                    (the reference's second-order mean term 0.5 P grad(div f), inference_ekf.py:108-116)
+ *      e.g. a pendulum:  f_src "fx[0] = x[1]; fx[1] = -theta[0] * sin(x[0]);"
+ *                        jac_src "F[0][1] = R(1); F[1][0] = -theta[0] * cos(x[0]);"
+ *      state_dim <= 6, emission_dim <= 6.  Returns the drift_kind to put in cdkf_model (>= CDKF_DRIFT_CUSTOM_BASE; the
+ *      same sources give the same kind) or a negative CDKF_E* code.  Filters (EKF all orders, UKF), EKF smoother and
+ *      forecast mode are available for custom kinds; kernels compile on first use (seconds) and are cached.  Compile
+ *      errors in the snippets surface through cdkf_last_error(). */
+int cdkf_custom_drift_register(int state_dim, int n_theta, const char* f_src, const char* jac_src,
+                               const char* divgrad_src);
+/* compile (without loading: no GPU needed) the kernel for one variant -- algo 0 EKF filter, 1 UKF filter, 2 EKF
+ * smoother -- to check the snippets early; 0 or a negative CDKF_E* code with the compiler log in cdkf_last_error() */
+int cdkf_custom_drift_compile(int drift_kind, int bytes_per_real, int emission_dim, int algo, int state_order);
+/* directory holding the kernel headers (cdkf_reg_kernels.h ...) for run-time compilation; default: <dir of this
+ * library>/../csrc */
+void cdkf_set_kernel_source_dir(const char* dir);
 
 /* ---- linear model, smoother type 1: replaces cdlgssm_smoother(..., smoother_type='cd_smoother_1') -- the reference's default --
  *      src/continuous_discrete_linear_gaussian_ssm/inference.py:694-823 (_step_1 :746-773, compute_pushforward :105-143):

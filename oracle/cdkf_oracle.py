@@ -218,6 +218,36 @@ class MLPDrift:
         return np.concatenate([a.ravel() for a in (self.W1, self.b1, self.W2, self.b2, self.W3, self.b3)]).astype(np.float64)
 
 
+class CallableDrift:
+    """A drift given by vectorised callables -- the oracle-side twin of a run-time compiled custom drift
+    (cdkf_custom_drift_register): f(x, theta) -> [N,d], jac(x, theta) -> [N,d,d], divgrad(x, theta) -> [N,d] (or None
+    when grad(div f) = 0 is not claimed: state_order 'second' is then unavailable)."""
+
+    kind = "custom"
+
+    def __init__(self, theta, f, jac, divgrad=None, dtype=np.float64):
+        self.dtype = np.dtype(dtype)
+        self.th = np.asarray(theta, dtype=self.dtype)
+        self._f, self._jac, self._g = f, jac, divgrad
+
+    def cast(self, dtype):
+        return CallableDrift(self.th, self._f, self._jac, self._g, dtype=dtype)
+
+    def f(self, x):
+        return np.asarray(self._f(x, self.th), dtype=x.dtype)
+
+    def jac(self, x):
+        return np.asarray(self._jac(x, self.th), dtype=x.dtype)
+
+    def divgrad(self, x):
+        if self._g is None:
+            raise NotImplementedError("custom drift without grad(div f): state_order 'second' is unavailable")
+        return np.asarray(self._g(x, self.th), dtype=x.dtype)
+
+    def theta(self):
+        return self.th.astype(np.float64)
+
+
 class Model:
     """The pieces of ParamsCDNLGSSM the hot path touches (cdnlgssm_utils.py:88-209): drift, L, Qc,
     linear emission h(x) = H x + bias (LearnableLinear), R, initial mean / covariance."""
