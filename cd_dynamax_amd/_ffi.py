@@ -11,7 +11,8 @@ from typing import Optional
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcdkf_hip.so")
+# CDKF_LIB_PATH: development aid (A/B timing of two builds); the default is the in-tree library
+LIB_PATH = os.environ.get("CDKF_LIB_PATH") or os.path.join(_HERE, "lib", "libcdkf_hip.so")
 
 CDKF_OK = 0
 CDKF_EINVAL = -1

@@ -486,100 +486,15 @@ CDKF_DEV void ukf_update(const Args& a, R (&ys)[Dims<D>::NS], const R (&yobs)[M]
 //         N-1 and store the same values to the same addresses, so no lane predicate is needed either.
 constexpr int kOutNone = 0, kOutAll = 1, kOutSome = 2;
 
-// (body as a device function so that run-time compiled kernels -- user-supplied drifts, launch_custom.hip -- share it)
-template <typename R, int D, int M, typename Drift, bool UKF, bool ZEROTH, bool HSEL, int OUT, bool FORECAST = false>
-CDKF_DEV void filter_reg_body(const RegArgs<R, D, M, Drift>& a) {
-  constexpr int NS = Dims<D>::NS;
-  constexpr int NP = Dims<D>::NP;
-  const long gid = (long)blockIdx.x * 64 + threadIdx.x;
-  const bool live = gid < a.N;
-  const long n = live ? gid : a.N - 1;  // idle lanes shadow the last trajectory
-
-  const R* __restrict__ tp = a.t + n * a.t_sn;
-  const R* __restrict__ yp = a.y + n * a.y_sn;
-  long moff = n * a.m_sn, poff = n * a.P_sn;
-
-  R ys[NS];
-#pragma unroll
-  for (int i = 0; i < D; ++i) ys[i] = a.m0[i];
-#pragma unroll
-  for (int e = 0; e < NP; ++e) ys[D + e] = a.P0[e];
-
-  LlAcc ll;
-  int st = 0;
-  bool bad_rhs = false;
-  Dp5V<R> C;
-  C.init();
-  EkfRhs<R, D, Drift> rhs{a.drift, a.LQL, a.order};
-  MeanRhs<R, D, Drift> mrhs{a.drift};
-  UkfRhs<R, D, RegArgs<R, D, M, Drift>> urhs{a, &bad_rhs};
-
-  R tcur = tp[0];
-  if (a.T > 1) tp += a.t_sk;
-  R tnext_obs = tp[0];  // t_{k+1}
-  R ycur[M];
-#pragma unroll
-  for (int r = 0; r < M; ++r) ycur[r] = yp[r * a.y_si];
-
-  for (long k = 0; k < a.T; ++k) {
-    if constexpr (!FORECAST) {  // forecast mode (forecast_*_kalman_filter): no measurement update, no log-likelihood
-      if constexpr (UKF)
-        ukf_update<R, D, M>(a, ys, ycur, ll, st);
-      else
-        ekf_update<R, D, M, HSEL>(a, ys, ycur, ll, st);
-    }
-    if (ys[0] != ys[0]) st |= kStatusNan;
-    if constexpr (OUT == kOutAll) store_moments_all<R, D>(a.fm, a.fP, moff, poff, a.m_si, a.P_si, ys);
-    if constexpr (OUT == kOutSome) store_moments<R, D>(a.fm, a.fP, moff, poff, a.m_si, a.P_si, ys);
-
-    const R t1 = (k + 1 < a.T) ? tnext_obs : tcur + a.dt_final;
-    // software prefetch of y_{k+1} and t_{k+2}: issued before the RK stages so that the loads (which
-    // return in order behind this step's stores) have a whole predict + update to land
-    if (k + 1 < a.T) yp += a.y_sk;
-    if (k + 2 < a.T) tp += a.t_sk;
-    R ynext[M];
-#pragma unroll
-    for (int r = 0; r < M; ++r) ynext[r] = yp[r * a.y_si];
-    const R tnn = tp[0];
-
-    bool capped;
-    if constexpr (UKF) {
-      capped = integrate<R, NS>(ys, tcur, t1, a.dt0, a.max_steps, urhs, C);
-    } else if constexpr (ZEROTH) {
-      R mm[D];
-#pragma unroll
-      for (int i = 0; i < D; ++i) mm[i] = ys[i];
-      capped = integrate<R, D>(mm, tcur, t1, a.dt0, a.max_steps, mrhs, C);
-      const R sq = rsqrt_(t1 - tcur);
-#pragma unroll
-      for (int i = 0; i < D; ++i) ys[i] = mm[i];
-#pragma unroll
-      for (int e = 0; e < NP; ++e) ys[D + e] = rfma(sq, a.LQLz[e], ys[D + e]);
-    } else {
-      capped = integrate<R, NS>(ys, tcur, t1, a.dt0, a.max_steps, rhs, C);
-    }
-    if (capped) st |= kStatusMaxSteps;
-    if constexpr (OUT == kOutAll) store_moments_all<R, D>(a.pm, a.pP, moff, poff, a.m_si, a.P_si, ys);
-    if constexpr (OUT == kOutSome) store_moments<R, D>(a.pm, a.pP, moff, poff, a.m_si, a.P_si, ys);
-    moff += a.m_sk;
-    poff += a.P_sk;
-
-    tcur = tnext_obs;
-    tnext_obs = tnn;
-#pragma unroll
-    for (int r = 0; r < M; ++r) ycur[r] = ynext[r];
-  }
-  if (bad_rhs) st |= kStatusNotPd;
-  ll.flush();
-  if (live) {
-    a.ll[n] = (R)ll.ll;
-    if (a.status) a.status[n] = st;
-  }
-}
-
 template <typename R, int D, int M, typename Drift, bool UKF, bool ZEROTH, bool HSEL, int OUT, bool FORECAST = false>
 __global__ __launch_bounds__(64, 1) void filter_reg_kernel(const RegArgs<R, D, M, Drift> a) {
-  filter_reg_body<R, D, M, Drift, UKF, ZEROTH, HSEL, OUT, FORECAST>(a);
+#include "cdkf_filter_reg_body.inc"
+}
+
+// the same sweep as a device function, for the run-time compiled kernels of user-supplied drifts (launch_custom.hip)
+template <typename R, int D, int M, typename Drift, bool UKF, bool ZEROTH, bool HSEL, int OUT, bool FORECAST = false>
+CDKF_DEV void filter_reg_body(const RegArgs<R, D, M, Drift>& a) {
+#include "cdkf_filter_reg_body.inc"
 }
 
 // ---- EKF (RTS) smoother backward sweep (inference_ekf.py:363-448, 503-531) ----------------------
