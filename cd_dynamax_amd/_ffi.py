@@ -65,6 +65,8 @@ class CdkfOpts(C.Structure):
         ("device", C.c_int32),
         ("layout", C.c_int32),
         ("forecast", C.c_int32),
+        ("solver", C.c_int32),
+        ("reserved", C.c_int32),
         ("max_steps", C.c_int64),
         ("dt0", C.c_double),
         ("dt_final", C.c_double),
@@ -290,6 +292,7 @@ def run_host(algo: str, mdl: ModelBlock, opts: CdkfOpts, t: np.ndarray, y: np.nd
 
 
 DRIFT_CUSTOM_BASE = 1000
+SOLVERS = {"dopri5": 0, "tsit5": 1, "bosh3": 2, "heun": 3, "midpoint": 4, "ralston": 5, "euler": 6}
 
 
 def register_custom_drift(state_dim: int, n_theta: int, f_src: str, jac_src: str, divgrad_src: Optional[str]) -> int:

@@ -43,6 +43,10 @@ int check_common(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T
     set_error("opts.layout must be CDKF_LAYOUT_NT, CDKF_LAYOUT_TN or CDKF_LAYOUT_TCN");
     return CDKF_EINVAL;
   }
+  if (o->solver < CDKF_SOLVER_DOPRI5 || o->solver > CDKF_SOLVER_EULER || o->reserved != 0) {
+    set_error("opts.solver must be one of CDKF_SOLVER_* (got %d) and opts.reserved 0", o->solver);
+    return CDKF_EINVAL;
+  }
   if (o->num_iter < 1 || !(o->dt0 > 0) || o->max_steps < 1) {
     set_error("need num_iter >= 1, dt0 > 0, max_steps >= 1");
     return CDKF_EINVAL;
@@ -352,6 +356,8 @@ void cdkf_default_opts(cdkf_opts* o) {
   o->device = -1;
   o->layout = CDKF_LAYOUT_NT;
   o->forecast = 0;
+  o->solver = CDKF_SOLVER_DOPRI5;
+  o->reserved = 0;
   o->max_steps = 100000;
   o->dt0 = 0.01;
   o->dt_final = 1e-10;

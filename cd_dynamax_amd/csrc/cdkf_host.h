@@ -64,6 +64,41 @@ void lql_packed(const double* L, const double* Qc, int d, double scale, R* out_p
     for (int j = i; j < d; ++j) out_packed[e++] = R(0.5) * (full[i * d + j] + full[j * d + i]);
 }
 
+// Runge-Kutta tableaus selectable through opts.solver (CDKF_SOLVER_*); published coefficients (Euler; explicit trapezoid =
+// diffrax.Heun; explicit midpoint; Ralston; Bogacki-Shampine 3(2) = diffrax.Bosh3; Tsitouras 5(4) = diffrax.Tsit5)
+template <typename R>
+inline bool fill_rk_tab(int solver, RkTab<R>& tb) {
+  static const double dp5[6][5] = {{0}, {1.0 / 5}, {3.0 / 40, 9.0 / 40}, {44.0 / 45, -56.0 / 15, 32.0 / 9},
+                                   {19372.0 / 6561, -25360.0 / 2187, 64448.0 / 6561, -212.0 / 729},
+                                   {9017.0 / 3168, -355.0 / 33, 46732.0 / 5247, 49.0 / 176, -5103.0 / 18656}};
+  static const double dp5b[6] = {35.0 / 384, 0, 500.0 / 1113, 125.0 / 192, -2187.0 / 6784, 11.0 / 84};
+  static const double ts5[6][5] = {{0}, {0.161}, {-0.008480655492356989, 0.335480655492357},
+                                   {2.8971530571054935, -6.359448489975075, 4.3622954328695815},
+                                   {5.325864828439257, -11.748883564062828, 7.4955393428898365, -0.09249506636175525},
+                                   {5.86145544294642, -12.92096931784711, 8.159367898576159, -0.071584973281401,
+                                    -0.028269050394068383}};
+  static const double ts5b[6] = {0.09646076681806523, 0.01, 0.4798896504144996, 1.379008574103742, -3.290069515436081,
+                                 2.324710524099774};
+  double a[6][5] = {{0}}, b[6] = {0};
+  int stages = 0;
+  switch (solver) {
+    case CDKF_SOLVER_DOPRI5: stages = 6; std::memcpy(a, dp5, sizeof(a)); std::memcpy(b, dp5b, sizeof(b)); break;
+    case CDKF_SOLVER_TSIT5: stages = 6; std::memcpy(a, ts5, sizeof(a)); std::memcpy(b, ts5b, sizeof(b)); break;
+    case CDKF_SOLVER_EULER: stages = 1; b[0] = 1; break;
+    case CDKF_SOLVER_HEUN: stages = 2; a[1][0] = 1; b[0] = b[1] = 0.5; break;
+    case CDKF_SOLVER_MIDPOINT: stages = 2; a[1][0] = 0.5; b[1] = 1; break;
+    case CDKF_SOLVER_RALSTON: stages = 2; a[1][0] = 2.0 / 3; b[0] = 0.25; b[1] = 0.75; break;
+    case CDKF_SOLVER_BOSH3: stages = 3; a[1][0] = 0.5; a[2][1] = 0.75; b[0] = 2.0 / 9; b[1] = 1.0 / 3; b[2] = 4.0 / 9; break;
+    default: return false;
+  }
+  tb.stages = stages;
+  for (int i = 0; i < 6; ++i) {
+    tb.b[i] = R(b[i]);
+    for (int j = 0; j < 5; ++j) tb.a[i][j] = R(a[i][j]);
+  }
+  return true;
+}
+
 template <typename R, int D, int M, typename Drift>
 void fill_reg_args(RegArgs<R, D, M, Drift>& a, const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T,
                    const R* t, const R* y, R* ll, R* fm, R* fP, R* pm, R* pP, int32_t* status) {
@@ -95,6 +130,8 @@ void fill_reg_args(RegArgs<R, D, M, Drift>& a, const cdkf_model* mdl, const cdkf
   a.order = o->state_order;
   a.num_iter = o->num_iter;
   a.forecast = o->forecast;
+  a.solver = o->solver;
+  fill_rk_tab<R>(o->solver, a.rk);  // opts.solver was validated by check_common
   a.N = N;
   a.T = T;
   a.y_si = a.m_si = a.P_si = 1;

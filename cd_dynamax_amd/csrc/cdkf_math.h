@@ -197,6 +197,65 @@ CDKF_DEV void dopri5_step(R (&y)[NS], R dt, const Rhs& rhs, const Dp5V<R>& C) {
 // Integrate y from t0 to t1 with the diffrax 0.4.0 loop: tprev = t0, tnext = min(t0 + dt0, t1);
 // while tprev < t1: step; tprev = min(tnext, t1); tnext = clip_to_end(tnext + dt0).
 // Returns true if max_steps was hit.
+// ---- any explicit Runge-Kutta method with up to six stages, coefficients at run time (opts.solver; the reference forwards
+// a diffrax solver object through diffeqsolve_settings, src/utils/diffrax_utils.py:40-57).  Fixed steps: only the solution
+// weights b are used.  Stage loop fully unrolled with uniform guards so that the slopes keep static register indices.
+template <typename R>
+struct RkTab {
+  int stages;
+  R a[6][5];
+  R b[6];
+};
+
+template <typename R, int NS, typename Rhs>
+CDKF_DEV void rk_step(R (&y)[NS], R dt, const Rhs& rhs, const RkTab<R>& tb) {
+  R k[6][NS], ys[NS];
+#pragma unroll
+  for (int s = 0; s < 6; ++s) {
+    if (s < tb.stages) {
+#pragma unroll
+      for (int e = 0; e < NS; ++e) {
+        R acc = R(0);
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+          if (j < s) acc = rfma(tb.a[s][j], k[j][e], acc);
+        ys[e] = rfma(dt, acc, y[e]);
+      }
+      rhs(ys, k[s]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < NS; ++e) k[s][e] = R(0);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < NS; ++e) {
+    R acc = R(0);
+#pragma unroll
+    for (int s = 0; s < 6; ++s) acc = rfma(tb.b[s], k[s][e], acc);
+    y[e] = rfma(dt, acc, y[e]);
+  }
+}
+
+template <typename R, int NS, typename Rhs>
+CDKF_DEV bool integrate(R (&y)[NS], R t0, R t1, R dt0, long max_steps, const Rhs& rhs, const RkTab<R>& tb) {
+  R tprev = t0;
+  R tnext = rmin(t0 + dt0, t1);
+  long steps = 0;
+  bool capped = false;
+  while (tprev < t1) {
+    if (steps >= max_steps) {
+      capped = true;
+      break;
+    }
+    rk_step<R, NS>(y, tnext - tprev, rhs, tb);
+    tprev = rmin(tnext, t1);
+    R tn = tnext + dt0;
+    tnext = (tn > t1 - Tol<R>::v) ? t1 : tn;
+    ++steps;
+  }
+  return capped;
+}
+
 template <typename R, int NS, typename Rhs>
 CDKF_DEV bool integrate(R (&y)[NS], R t0, R t1, R dt0, long max_steps, const Rhs& rhs, const Dp5V<R>& C) {
   R tprev = t0;

@@ -33,6 +33,8 @@ struct RegArgs {
   R ukf_c, ukf_wm0, ukf_wc0, ukf_wi;
   long max_steps;
   int order, num_iter, forecast;
+  int solver;   // CDKF_SOLVER_*
+  RkTab<R> rk;  // used by the GENERIC instantiations only (solver != CDKF_SOLVER_DOPRI5)
   long N, T;
   // element (n, k, i) of an array lives at  n * sn + k * sk + i.  Reference layout [N,T,w]:
   // (sn, sk) = (T*w, w); time-major layout [T,N,w]: (sn, sk) = (w, N*w); shared t: sn = 0.
@@ -46,6 +48,24 @@ struct RegArgs {
   R* pm;
   R* pP;
   int* status;
+};
+
+// tableau the sweep integrates with: the VGPR-pinned Dormand-Prince constants, or the run-time tableau of the arguments
+template <typename R, bool GENERIC>
+struct TabSel {
+  template <typename Args>
+  static CDKF_DEV Dp5V<R> get(const Args&) {
+    Dp5V<R> c;
+    c.init();
+    return c;
+  }
+};
+template <typename R>
+struct TabSel<R, true> {
+  template <typename Args>
+  static CDKF_DEV const RkTab<R>& get(const Args& a) {
+    return a.rk;
+  }
 };
 
 // ---- EKF moment ODE right-hand side (inference_ekf.py:76-123) --------------------------------
@@ -486,13 +506,15 @@ CDKF_DEV void ukf_update(const Args& a, R (&ys)[Dims<D>::NS], const R (&yobs)[M]
 //         N-1 and store the same values to the same addresses, so no lane predicate is needed either.
 constexpr int kOutNone = 0, kOutAll = 1, kOutSome = 2;
 
-template <typename R, int D, int M, typename Drift, bool UKF, bool ZEROTH, bool HSEL, int OUT, bool FORECAST = false>
+template <typename R, int D, int M, typename Drift, bool UKF, bool ZEROTH, bool HSEL, int OUT, bool FORECAST = false,
+          bool GENERIC = false>
 __global__ __launch_bounds__(64, 1) void filter_reg_kernel(const RegArgs<R, D, M, Drift> a) {
 #include "cdkf_filter_reg_body.inc"
 }
 
 // the same sweep as a device function, for the run-time compiled kernels of user-supplied drifts (launch_custom.hip)
-template <typename R, int D, int M, typename Drift, bool UKF, bool ZEROTH, bool HSEL, int OUT, bool FORECAST = false>
+template <typename R, int D, int M, typename Drift, bool UKF, bool ZEROTH, bool HSEL, int OUT, bool FORECAST = false,
+          bool GENERIC = false>
 CDKF_DEV void filter_reg_body(const RegArgs<R, D, M, Drift>& a) {
 #include "cdkf_filter_reg_body.inc"
 }
@@ -537,7 +559,7 @@ struct SmoothRhs {
   }
 };
 
-template <typename R, int D, int M, typename Drift>
+template <typename R, int D, int M, typename Drift, bool GENERIC = false>
 CDKF_DEV void ekf_smoother_reg_body(const RegArgs<R, D, M, Drift>& a, R* __restrict__ sm, R* __restrict__ sP) {
   constexpr int NS = Dims<D>::NS;
   const long gid = (long)blockIdx.x * 64 + threadIdx.x;
@@ -548,8 +570,7 @@ CDKF_DEV void ekf_smoother_reg_body(const RegArgs<R, D, M, Drift>& a, R* __restr
   const R* __restrict__ fP = a.fP + n * a.P_sn;
   int st = 0;
   bool bad = false;
-  Dp5V<R> C;
-  C.init();
+  const auto C = TabSel<R, GENERIC>::get(a);
 
   R ys[NS];  // smoothed moments at t_{k+1}
   {
@@ -604,10 +625,10 @@ CDKF_DEV void ekf_smoother_reg_body(const RegArgs<R, D, M, Drift>& a, R* __restr
   if (live && a.status && st) atomicOr(&a.status[n], st);
 }
 
-template <typename R, int D, int M, typename Drift>
+template <typename R, int D, int M, typename Drift, bool GENERIC = false>
 __global__ __launch_bounds__(64) void ekf_smoother_reg_kernel(const RegArgs<R, D, M, Drift> a, R* __restrict__ sm,
                                                               R* __restrict__ sP) {
-  ekf_smoother_reg_body<R, D, M, Drift>(a, sm, sP);
+  ekf_smoother_reg_body<R, D, M, Drift, GENERIC>(a, sm, sP);
 }
 
 }  // namespace cdkf

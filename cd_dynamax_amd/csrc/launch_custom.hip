@@ -27,8 +27,8 @@ std::vector<CustomDrift> g_drifts;
 std::mutex g_mutex;
 std::string g_src_dir;
 
-// kind, bytes per real, emission_dim, ukf, zeroth, forecast, smoother
-using Key = std::tuple<int, int, int, int, int, int, int>;
+// kind, bytes per real, emission_dim, ukf, zeroth, forecast, smoother, generic Runge-Kutta tableau
+using Key = std::tuple<int, int, int, int, int, int, int, int>;
 struct Compiled {
   hipModule_t module = nullptr;
   hipFunction_t fn = nullptr;
@@ -48,7 +48,8 @@ std::string source_dir() {
   return g_src_dir;
 }
 
-std::string generate_source(const CustomDrift& c, int bytes, int m, int ukf, int zeroth, int forecast, int smoother) {
+std::string generate_source(const CustomDrift& c, int bytes, int m, int ukf, int zeroth, int forecast, int smoother,
+                            int generic) {
   std::string s;
   s += "#include \"cdkf_reg_kernels.h\"\n";
   s += "namespace cdkf {\n";
@@ -69,7 +70,7 @@ std::string generate_source(const CustomDrift& c, int bytes, int m, int ukf, int
   s += "using R = " + std::string(bytes == 8 ? "double" : "float") + ";\n";
   s += "constexpr int DD = " + std::to_string(c.d) + ", MM = " + std::to_string(m) + ";\n";
   s += "using Drift = cdkf::DriftCustom<R, DD>;\nusing Args = cdkf::RegArgs<R, DD, MM, Drift>;\n";
-  // parameter blob (reals): theta | LQL | LQLz | H | hb | Rm | m0 | P0 | dt0 dt_final ukf_c ukf_wm0 ukf_wc0 ukf_wi
+  // parameter blob (reals): theta | LQL | LQLz | H | hb | Rm | m0 | P0 | dt0 dt_final ukf_c ukf_wm0 ukf_wc0 ukf_wi | rk.a[30] rk.b[6]
   // integer blob (longs) : max_steps order num_iter forecast N T t_sn t_sk y_sn y_sk y_si m_sn m_sk m_si P_sn P_sk P_si
   s += R"(
 __device__ __forceinline__ void unpack(Args& a, const R* __restrict__ par, const long* __restrict__ ip, const R* t, const R* y,
@@ -94,6 +95,11 @@ __device__ __forceinline__ void unpack(Args& a, const R* __restrict__ par, const
   o += NP;
   a.dt0 = par[o]; a.dt_final = par[o + 1]; a.ukf_c = par[o + 2]; a.ukf_wm0 = par[o + 3]; a.ukf_wc0 = par[o + 4];
   a.ukf_wi = par[o + 5];
+  o += 6;
+  for (int s = 0; s < 6; ++s) for (int j = 0; j < 5; ++j) a.rk.a[s][j] = par[o + s * 5 + j];
+  o += 30;
+  for (int s = 0; s < 6; ++s) a.rk.b[s] = par[o + s];
+  a.rk.stages = (int)ip[17]; a.solver = (int)ip[18];
   a.max_steps = ip[0]; a.order = (int)ip[1]; a.num_iter = (int)ip[2]; a.forecast = (int)ip[3]; a.N = ip[4]; a.T = ip[5];
   a.t_sn = ip[6]; a.t_sk = ip[7]; a.y_sn = ip[8]; a.y_sk = ip[9]; a.y_si = ip[10]; a.m_sn = ip[11]; a.m_sk = ip[12];
   a.m_si = ip[13]; a.P_sn = ip[14]; a.P_sk = ip[15]; a.P_si = ip[16];
@@ -105,13 +111,13 @@ __device__ __forceinline__ void unpack(Args& a, const R* __restrict__ par, const
          "const R* y, R* ll, R* fm, R* fP, R* pm, R* pP, int* status, R* sm, R* sP) {\n  Args a;\n"
          "  unpack(a, par, ip, t, y, ll, fm, fP, pm, pP, status);\n";
     s += "  cdkf::filter_reg_body<R, DD, MM, Drift, " + std::string(ukf ? "true" : "false") + ", " +
-         std::string(zeroth ? "true" : "false") + ", false, cdkf::kOutSome, " + std::string(forecast ? "true" : "false") +
-         ">(a);\n}\n";
+         std::string(zeroth ? "true" : "false") + ", false, cdkf::kOutSome, " + std::string(forecast ? "true" : "false") + ", " +
+         std::string(generic ? "true" : "false") + ">(a);\n}\n";
   } else {
     s += "extern \"C\" __global__ __launch_bounds__(64) void cdkf_custom_kernel(const R* par, const long* ip, const R* t, "
          "const R* y, R* ll, R* fm, R* fP, R* pm, R* pP, int* status, R* sm, R* sP) {\n  Args a;\n"
          "  unpack(a, par, ip, t, y, ll, fm, fP, pm, pP, status);\n"
-         "  cdkf::ekf_smoother_reg_body<R, DD, MM, Drift>(a, sm, sP);\n}\n";
+         "  cdkf::ekf_smoother_reg_body<R, DD, MM, Drift, " + std::string(generic ? "true" : "false") + ">(a, sm, sP);\n}\n";
   }
   return s;
 }
@@ -119,7 +125,7 @@ __device__ __forceinline__ void unpack(Args& a, const R* __restrict__ par, const
 // compile one variant; `code` receives the code object.  No GPU needed (the target is named explicitly).
 int compile_variant(const CustomDrift& c, const Key& key, const std::string& arch, std::vector<char>& code) {
   const std::string src = generate_source(c, std::get<1>(key), std::get<2>(key), std::get<3>(key), std::get<4>(key),
-                                          std::get<5>(key), std::get<6>(key));
+                                          std::get<5>(key), std::get<6>(key), std::get<7>(key));
   hiprtcProgram prog = nullptr;
   if (hiprtcCreateProgram(&prog, src.c_str(), "cdkf_custom_drift.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
     set_error("custom drift: hiprtcCreateProgram failed");
@@ -251,7 +257,15 @@ int launch_custom(int algo, const cdkf_model* mdl, const cdkf_opts* o, int64_t N
     par.push_back(lamb / (n + lamb) + (R(1) - alpha * alpha + R(o->ukf_beta)));
     par.push_back(R(1) / (R(2) * (n + lamb)));
   }
-  long ip[17];
+  RkTab<R> tb;
+  fill_rk_tab<R>(o->solver, tb);
+  for (int s = 0; s < 6; ++s)
+    for (int j = 0; j < 5; ++j) par.push_back(tb.a[s][j]);
+  for (int s = 0; s < 6; ++s) par.push_back(tb.b[s]);
+  const int generic = o->solver != CDKF_SOLVER_DOPRI5;
+  long ip[19];
+  ip[17] = tb.stages;
+  ip[18] = o->solver;
   ip[0] = (long)o->max_steps;
   ip[1] = o->state_order;
   ip[2] = smoother ? 1 : o->num_iter;
@@ -302,10 +316,10 @@ int launch_custom(int algo, const cdkf_model* mdl, const cdkf_opts* o, int64_t N
   };
   const int zeroth = (algo != 1 && o->state_order == CDKF_ORDER_ZEROTH) ? 1 : 0;
   if (!smoother) {
-    rc = run(Key(mdl->drift_kind, (int)sizeof(R), m, algo == 1, zeroth, o->forecast ? 1 : 0, 0), a1, a2, a3, a4, null_r, null_r);
+    rc = run(Key(mdl->drift_kind, (int)sizeof(R), m, algo == 1, zeroth, o->forecast ? 1 : 0, 0, generic), a1, a2, a3, a4, null_r, null_r);
   } else {
-    rc = run(Key(mdl->drift_kind, (int)sizeof(R), m, 0, zeroth, 0, 0), a1, a2, null_r, null_r, null_r, null_r);
-    if (!rc) rc = run(Key(mdl->drift_kind, (int)sizeof(R), m, 0, 0, 0, 1), a1, a2, null_r, null_r, a3, a4);
+    rc = run(Key(mdl->drift_kind, (int)sizeof(R), m, 0, zeroth, 0, 0, generic), a1, a2, null_r, null_r, null_r, null_r);
+    if (!rc) rc = run(Key(mdl->drift_kind, (int)sizeof(R), m, 0, 0, 0, 1, generic), a1, a2, null_r, null_r, a3, a4);
   }
   const int rc2 = param_pool_release(slot, stream);
   return rc ? rc : rc2;
@@ -346,8 +360,8 @@ int custom_compile_check(int kind, int bytes_per_real, int emission_dim, int alg
   }
   std::vector<char> code;
   const int zeroth = (algo != 1 && state_order == CDKF_ORDER_ZEROTH) ? 1 : 0;
-  int rc = compile_variant(c, Key(kind, bytes_per_real, emission_dim, algo == 1, zeroth, 0, 0), "gfx950", code);
-  if (!rc && algo == 2) rc = compile_variant(c, Key(kind, bytes_per_real, emission_dim, 0, 0, 0, 1), "gfx950", code);
+  int rc = compile_variant(c, Key(kind, bytes_per_real, emission_dim, algo == 1, zeroth, 0, 0, 0), "gfx950", code);
+  if (!rc && algo == 2) rc = compile_variant(c, Key(kind, bytes_per_real, emission_dim, 0, 0, 0, 1, 0), "gfx950", code);
   return rc;
 }
 

@@ -65,11 +65,16 @@ def _model_block(params: ParamsCDNLGSSM) -> _ffi.ModelBlock:
 def _opts(hyperparams, num_iter: int = 1):
     o = _ffi.default_opts()
     settings = dict(getattr(hyperparams, "diffeqsolve_settings", {}) or {})
-    unknown = set(settings) - {"dt0", "max_steps"}
+    unknown = set(settings) - {"dt0", "max_steps", "solver"}
     if unknown:
         raise NotImplementedError(
-            f"diffeqsolve_settings {sorted(unknown)} are not supported by the HIP path (Dopri5 with constant "
-            "step dt0 only, the default of src/utils/diffrax_utils.py:40-52)")
+            f"diffeqsolve_settings {sorted(unknown)} are not supported by the HIP path (explicit Runge-Kutta methods with the "
+            "constant step dt0, the default controller of src/utils/diffrax_utils.py:40-52; no adaptive stepping)")
+    solver = settings.get("solver", "dopri5")
+    name = solver.lower() if isinstance(solver, str) else type(solver).__name__.lower()   # 'tsit5' or a diffrax.Tsit5() object
+    if name not in _ffi.SOLVERS:
+        raise NotImplementedError(f"diffeqsolve_settings['solver'] = {solver!r}: choose from {sorted(_ffi.SOLVERS)}")
+    o.solver = _ffi.SOLVERS[name]
     o.dt0 = float(settings.get("dt0", 0.01))
     o.max_steps = int(settings.get("max_steps", 100000))
     o.dt_final = float(hyperparams.dt_final)

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define CDKF_VERSION 100 /* 0.1.0 */
+#define CDKF_VERSION 101 /* 0.1.0 */
 
 /* error codes */
 #define CDKF_OK 0
@@ -53,6 +53,14 @@ extern "C" {
 #define CDKF_DRIFT_LINEAR 0   /* LearnableLinear: theta = [W (d*d), b (d)]; f = W x + b */
 #define CDKF_DRIFT_LORENZ63 1 /* LearnableLorenz63: theta = [sigma, rho, beta]; d = 3 */
 #define CDKF_DRIFT_LORENZ96 2 /* theta = [F]; f_i = (x_{i+1} - x_{i-2}) x_{i-1} - x_i + F; d >= 4 */
+#define CDKF_SOLVER_DOPRI5 0   /* Dormand-Prince 5(4): diffrax.Dopri5, the reference's default */
+#define CDKF_SOLVER_TSIT5 1    /* Tsitouras 5(4): diffrax.Tsit5 */
+#define CDKF_SOLVER_BOSH3 2    /* Bogacki-Shampine 3(2): diffrax.Bosh3 */
+#define CDKF_SOLVER_HEUN 3     /* explicit trapezoid: diffrax.Heun */
+#define CDKF_SOLVER_MIDPOINT 4 /* explicit midpoint: diffrax.Midpoint */
+#define CDKF_SOLVER_RALSTON 5  /* Ralston's 2nd-order method: diffrax.Ralston */
+#define CDKF_SOLVER_EULER 6    /* diffrax.Euler */
+
 #define CDKF_DRIFT_CUSTOM_BASE 1000 /* kinds >= this come from cdkf_custom_drift_register() */
 #define CDKF_DRIFT_MLP_TANH 3 /* theta = [W1 (h1*d), b1 (h1), W2 (h2*h1), b2 (h2), W3 (d*h2), b3 (d)];
                                  f = W3 tanh(W2 tanh(W1 x + b1) + b2) + b3 */
@@ -105,6 +113,11 @@ typedef struct cdkf_opts {
                            t[0] to t[k+1]; y is ignored (may be NULL) and ll is set to 0.  Replaces
                            forecast_extended_kalman_filter / forecast_unscented_kalman_filter
                            (inference_ekf.py:679-766, inference_ukf.py:409-505). */
+  int32_t solver;       /* CDKF_SOLVER_*: the explicit Runge-Kutta method of the predict step, fixed steps of dt0 (the
+                           reference forwards diffeqsolve_settings['solver'] to diffrax, src/utils/diffrax_utils.py:40-57).
+                           Default DOPRI5 (diffrax_utils.py:120-123).  The other methods run on the register-resident
+                           kernels (incl. custom drifts); larger models and the gradient entry points take DOPRI5 only. */
+  int32_t reserved;     /* must be 0 */
   int64_t max_steps;    /* RK steps per observation interval; default 100000 */
   double dt0;           /* default 0.01 */
   double dt_final;      /* default 1e-10 (inference_ekf.py:39) */

@@ -60,6 +60,41 @@ DOPRI5_A = (
 )
 DOPRI5_B = (35 / 384, 0.0, 500 / 1113, 125 / 192, -2187 / 6784, 11 / 84)
 
+# Other explicit Runge-Kutta methods a caller can select through diffeqsolve_settings['solver'] (the reference forwards the
+# diffrax solver object to dfx.diffeqsolve, src/utils/diffrax_utils.py:40-57, 150-163).  With ConstantStepSize only the
+# solution weights matter (the embedded error estimate is unused); diffrax 0.4.0 is not in the mount, so these are the
+# published tableaus: Euler; Heun = explicit trapezoid (diffrax.Heun); explicit midpoint; Ralston (2nd order, minimal error
+# bound); Bogacki-Shampine 3(2) (diffrax.Bosh3); Tsitouras 5(4) (diffrax.Tsit5; Tsitouras 2011, Table 1).
+TABLEAUS = {
+    "dopri5": (DOPRI5_A, DOPRI5_B),
+    "euler": (((),), (1.0,)),
+    "heun": (((), (1.0,)), (0.5, 0.5)),
+    "midpoint": (((), (0.5,)), (0.0, 1.0)),
+    "ralston": (((), (2 / 3,)), (0.25, 0.75)),
+    "bosh3": (((), (0.5,), (0.0, 0.75)), (2 / 9, 1 / 3, 4 / 9)),
+    "tsit5": (((), (0.161,), (-0.008480655492356989, 0.335480655492357),
+               (2.8971530571054935, -6.359448489975075, 4.3622954328695815),
+               (5.325864828439257, -11.748883564062828, 7.4955393428898365, -0.09249506636175525),
+               (5.86145544294642, -12.92096931784711, 8.159367898576159, -0.071584973281401, -0.028269050394068383)),
+              (0.09646076681806523, 0.01, 0.4798896504144996, 1.379008574103742, -3.290069515436081, 2.324710524099774)),
+}
+_ACTIVE = ["dopri5"]
+
+
+class use_solver:
+    """``with use_solver('tsit5'): ...`` -- every diffeqsolve call inside integrates with that tableau (fixed steps)."""
+
+    def __init__(self, name):
+        if name not in TABLEAUS:
+            raise ValueError(f"unknown solver {name!r}")
+        self.name = name
+
+    def __enter__(self):
+        _ACTIVE.append(self.name)
+
+    def __exit__(self, *exc):
+        _ACTIVE.pop()
+
 
 # --------------------------------------------------------------------------------------
 # Drift registry.  f: [N,d] -> [N,d]; jac: [N,d] -> [N,d,d] (dF_i/dx_j);
@@ -355,12 +390,13 @@ def _tree_axpy(y0, ks, coefs, dtype):
 def dopri5_step(rhs, y, dt):
     """One Dopri5 step of size dt (dt: [N]); k_j = dt * f(stage_j) (diffrax ODETerm.vf_prod)."""
     dtype = y[0].dtype
+    A, B = TABLEAUS[_ACTIVE[-1]]
     ks = []
-    for i in range(6):
-        yi = y if i == 0 else _tree_axpy(y, ks, DOPRI5_A[i], dtype)
+    for i in range(len(B)):
+        yi = y if i == 0 else _tree_axpy(y, ks, A[i], dtype)
         fi = rhs(yi)
         ks.append(tuple(dt.reshape((-1,) + (1,) * (c.ndim - 1)) * c for c in fi))
-    return _tree_axpy(y, ks, DOPRI5_B, dtype)
+    return _tree_axpy(y, ks, B, dtype)
 
 
 def diffeqsolve(rhs, t0, t1, y0, dt0=0.01, max_steps=100000, count_steps=None):

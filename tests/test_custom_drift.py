@@ -136,3 +136,12 @@ def test_custom_drift_second_order_with_divgrad(hip_lib):
         assert relerr(ref1["filtered_means"], ref["filtered_means"]) > 1e-6       # the second-order term is not a no-op here
     with pytest.raises(NotImplementedError, match="no gradient kernel"):
         cd.cdnlgssm_loglik_and_grad(P, y, t[..., None])
+    # another Runge-Kutta method through the same run-time compiled kernels
+    hyp = cd.EKFHyperParams(diffeqsolve_settings={"solver": "tsit5"})
+    with o.use_solver("tsit5"):
+        ref = o.ekf_filter(mdl, t, y, state_order="second")
+        refs = o.ekf_smoother(mdl, t, y, state_order="second")
+    post = cd.cdnlgssm_filter(P, y, t[..., None], hyp)
+    assert relerr(post.filtered_covariances, ref["filtered_covariances"]) < 1e-11
+    sm = cd.cdnlgssm_smoother(P, y, t[..., None], hyp)
+    assert relerr(sm.smoothed_means, refs["smoothed_means"]) < 1e-10

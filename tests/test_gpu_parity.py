@@ -476,3 +476,61 @@ def test_linear_smoother_type1_refusals(hip_lib):
     assert model.smoother(params, y, smoother_type="cd_smoother_2").smoothed_means.shape == (6, 12)
     with pytest.raises(ValueError, match="unknown smoother_type"):
         model.smoother(params, y, smoother_type="cd_smoother_3")
+
+
+@pytest.mark.parametrize("solver", ["tsit5", "bosh3", "heun", "midpoint", "ralston", "euler"])
+def test_runge_kutta_solver_choice(hip_lib, solver):
+    """diffeqsolve_settings={'solver': ...} (the reference forwards a diffrax solver object to dfx.diffeqsolve,
+    src/utils/diffrax_utils.py:40-57, 150-163; fixed steps of dt0): EKF second / zeroth order, UKF, EKF smoother and
+    forecast on Lorenz-63, EKF on a linear model, against the oracle integrating with the same tableau."""
+    rng = np.random.default_rng(90)
+    settings = {"solver": solver, "dt0": 0.01}
+    for mdl, name in ((o.lorenz63_model(2), "l63"), (linear_model(rng, 2, 2), "lin")):
+        N, T = 9, 25
+        t = o.irregular_times(rng, N, T, 0.04)
+        y = o.simulate(mdl, t, rng)
+        P = params_from(mdl)
+        with o.use_solver(solver):
+            ref = o.ekf_filter(mdl, t, y)
+            ref0 = o.ekf_filter(mdl, t, y, state_order="zeroth")
+            refu = o.ukf_filter(mdl, t, y)
+            refs = o.ekf_smoother(mdl, t, y)
+        post = cd.cdnlgssm_filter(P, y, t[..., None], cd.EKFHyperParams(diffeqsolve_settings=settings))
+        for k in FILTER_KEYS:
+            assert relerr(getattr(post, k), ref[k]) < 1e-11, (name, k)
+        np.testing.assert_allclose(post.marginal_loglik, ref["marginal_loglik"], rtol=1e-11)
+        post0 = cd.cdnlgssm_filter(P, y, t[..., None], cd.EKFHyperParams(state_order="zeroth", diffeqsolve_settings=settings))
+        assert relerr(post0.filtered_means, ref0["filtered_means"]) < 1e-11
+        postu = cd.cdnlgssm_filter(P, y, t[..., None], cd.UKFHyperParams(diffeqsolve_settings=settings))
+        assert relerr(postu.filtered_covariances, refu["filtered_covariances"]) < 1e-10
+        sm = cd.cdnlgssm_smoother(P, y, t[..., None], cd.EKFHyperParams(diffeqsolve_settings=settings))
+        assert relerr(sm.smoothed_means, refs["smoothed_means"]) < 1e-10
+        assert relerr(sm.smoothed_covariances, refs["smoothed_covariances"]) < 1e-10
+        if name == "l63":  # the method matters (this is not the default tableau under another name)
+            dflt = cd.cdnlgssm_filter(P, y, t[..., None], cd.EKFHyperParams())
+            diff = relerr(post.filtered_covariances, dflt.filtered_covariances)
+            assert 1e-14 < diff < 1e-6 if solver == "tsit5" else diff > 1e-10, diff
+    p32 = cd.cdnlgssm_filter(P, y.astype(np.float32), t[..., None].astype(np.float32), cd.EKFHyperParams(diffeqsolve_settings=settings))
+    assert relerr(p32.filtered_means, ref["filtered_means"]) < 1e-3
+    fc = cd.cdnlgssm_forecast(P, (mdl.m0, mdl.P0), np.array([[0.0]]), np.linspace(0.05, 0.5, 5)[:, None],
+                              cd.EKFHyperParams(diffeqsolve_settings=settings))
+    with o.use_solver(solver):
+        rm, rP = o.forecast(mdl, mdl.m0[None], mdl.P0[None], np.array([0.0]), np.linspace(0.05, 0.5, 5)[None], "ekf")
+    assert relerr(fc.forecasted_state_means, rm[0]) < 1e-11
+
+
+def test_solver_choice_refusals(hip_lib):
+    rng = np.random.default_rng(1)
+    mdl = lorenz96_model(8, 4)
+    t = o.irregular_times(rng, 2, 5, 0.1)
+    y = o.simulate(mdl, t, rng)
+    with pytest.raises(_ffi.CdkfError, match="Dormand-Prince only"):
+        cd.cdnlgssm_filter(params_from(mdl), y, t[..., None], cd.EKFHyperParams(diffeqsolve_settings={"solver": "tsit5"}))
+    with pytest.raises(NotImplementedError, match="choose from"):
+        cd.cdnlgssm_filter(params_from(mdl), y, t[..., None], cd.EKFHyperParams(diffeqsolve_settings={"solver": "kvaerno5"}))
+    with pytest.raises(NotImplementedError, match="stepsize_controller"):
+        cd.cdnlgssm_filter(params_from(mdl), y, t[..., None], cd.EKFHyperParams(diffeqsolve_settings={"stepsize_controller": object()}))
+    l63 = o.lorenz63_model(3)
+    y3 = o.simulate(l63, t, rng)
+    with pytest.raises(NotImplementedError, match="no gradient kernel"):
+        cd.cdnlgssm_loglik_and_grad(params_from(l63), y3, t[..., None], cd.EKFHyperParams(diffeqsolve_settings={"solver": "heun"}))

@@ -42,7 +42,17 @@ def oracle_backend(monkeypatch):
             keys = ["filtered_means", "filtered_covariances", "smoothed_means", "smoothed_covariances"]
         return r["marginal_loglik"], [r[k] if w else None for k, w in zip(keys, want)], np.zeros(N, np.int32)
 
+    def fake_smoother1(blk, opts, t, y, dtype):
+        calls.append(("kf_smoother1", opts.t_shared, opts.dt_final, opts.num_iter, (), np.dtype(dtype)))
+        mdl = _mdl_from_block(blk)
+        N, T, _ = y.shape
+        tt = np.broadcast_to(t, (N, T)) if opts.t_shared else t
+        r = o.kf_smoother_type1(mdl, tt, y, dt0=opts.dt0, dt_final=opts.dt_final, max_steps=opts.max_steps, dtype=dtype)
+        return (r["marginal_loglik"], r["filtered_means"], r["filtered_covariances"], r["smoothed_means"],
+                r["smoothed_covariances"], r["smoothed_cross_covariances"], np.zeros(N, np.int32))
+
     monkeypatch.setattr(_ffi, "run_host", fake)
+    monkeypatch.setattr(_ffi, "kf_smoother1", fake_smoother1)
     monkeypatch.setattr(_ffi, "default_opts", lambda: _default())
     return calls
 
@@ -129,7 +139,9 @@ def test_dispatch_by_hyperparams_class(oracle_backend):
     with pytest.raises(ValueError, match="state_order"):
         cd.cdnlgssm_filter(P, y[0], t[0][:, None], cd.EKFHyperParams(state_order="third"))
     with pytest.raises(NotImplementedError, match="diffeqsolve_settings"):
-        cd.cdnlgssm_filter(P, y[0], t[0][:, None], cd.EKFHyperParams(diffeqsolve_settings={"solver": "Tsit5"}))
+        cd.cdnlgssm_filter(P, y[0], t[0][:, None], cd.EKFHyperParams(diffeqsolve_settings={"stepsize_controller": "PIDController"}))
+    with pytest.raises(NotImplementedError, match="choose from"):
+        cd.cdnlgssm_filter(P, y[0], t[0][:, None], cd.EKFHyperParams(diffeqsolve_settings={"solver": "Kvaerno5"}))
 
 
 def test_dtype_follows_emissions(oracle_backend):
@@ -242,8 +254,9 @@ def test_linear_model_front_end(oracle_backend):
                                ref["marginal_loglik"], rtol=1e-8)
     sm = model.smoother(params, y, smoother_type="cd_smoother_2")
     assert oracle_backend[-1][0] == "ekf_smoother" and sm.smoothed_means.shape == (T, 4)
-    with pytest.raises(NotImplementedError, match="cd_smoother_1"):
-        model.smoother(params, y)  # the reference's default type needs the transition matrices
+    sm1 = model.smoother(params, y)  # the reference's default: smoother type 1 (discrete RTS on the pushed-forward (A, Q))
+    assert oracle_backend[-1][0] == "kf_smoother1" and sm1.smoothed_cross_covariances.shape == (T - 1, 4, 4)
+    assert sm1.smoothed_means.shape == (T, 4) and np.ndim(sm1.marginal_loglik) == 0
     with pytest.raises(NotImplementedError, match="bias"):
         cd.cdlgssm_filter(params._replace(dynamics=params.dynamics._replace(bias=np.ones(4))), y)
     with pytest.raises(NotImplementedError, match="inputs"):

@@ -327,3 +327,25 @@ def test_type1_smoother_matches_exact_rts():
     C = np.linalg.solve(A @ ref["filtered_covariances"][5] @ A.T + Q, A @ ref["filtered_covariances"][5]).T
     cross = C @ ref["smoothed_covariances"][6] + np.outer(ref["smoothed_means"][5], ref["smoothed_means"][6])
     assert relerr(out["smoothed_cross_covariances"][0, 5], cross) < 1e-6
+
+
+@pytest.mark.parametrize("name,order", [("euler", 1), ("heun", 2), ("midpoint", 2), ("ralston", 2), ("bosh3", 3), ("tsit5", 5),
+                                        ("dopri5", 5)])
+def test_tableaus_have_their_published_order(name, order):
+    """The selectable Runge-Kutta tableaus (diffrax is not in the mount: published coefficients): consistency (row sums of A
+    equal the nodes implied by quadrature of polynomials) and the observed order of convergence on a nonlinear system with
+    a closed-form solution -- a wrong digit in any coefficient lowers the order."""
+    A, B = o.TABLEAUS[name]
+    assert abs(sum(B) - 1.0) < 1e-14
+    c = [sum(row) for row in A]
+    for k in range(1, min(order, 4) + 1):          # sum_i b_i c_i^(k-1) = 1/k
+        assert abs(sum(b * ci ** (k - 1) for b, ci in zip(B, c)) - 1.0 / k) < 1e-12, k
+    # logistic equation y' = y (1 - y), y(0) = 0.2 (closed form); errors at two step sizes
+    exact = lambda tt: 0.2 * np.exp(tt) / (1 + 0.2 * (np.exp(tt) - 1))
+    errs = []
+    with o.use_solver(name):
+        for dt0 in (0.1, 0.05):
+            (yv,) = o.diffeqsolve(lambda yv: (yv[0] * (1 - yv[0]),), np.zeros(1), np.ones(1), (np.full((1, 1), 0.2),), dt0=dt0)
+            errs.append(abs(yv[0, 0] - exact(1.0)))
+    observed = np.log2(errs[0] / errs[1])
+    assert observed > order - 0.35, (name, observed, errs)
