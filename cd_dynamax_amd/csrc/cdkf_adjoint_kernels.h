@@ -53,18 +53,6 @@ constexpr size_t adj_lds_bytes() {
 // layout of the optional model-gradient block (per trajectory): m0 [d] | P0 [d,d] | LQL [d,d] | H [m,d] | bias [m] | R [m,m]
 __host__ __device__ inline long adj_model_grad_size(int d, int m) { return (long)d + 2L * d * d + (long)m * d + m + (long)m * m; }
 
-// Dormand-Prince tableau as arrays (static indices after unrolling)
-template <typename R>
-struct Dp5T {
-  static constexpr R a[6][5] = {{0, 0, 0, 0, 0},
-                                {Dp5<R>::a21, 0, 0, 0, 0},
-                                {Dp5<R>::a31, Dp5<R>::a32, 0, 0, 0},
-                                {Dp5<R>::a41, Dp5<R>::a42, Dp5<R>::a43, 0, 0},
-                                {Dp5<R>::a51, Dp5<R>::a52, Dp5<R>::a53, Dp5<R>::a54, 0},
-                                {Dp5<R>::a61, Dp5<R>::a62, Dp5<R>::a63, Dp5<R>::a64, Dp5<R>::a65}};
-  static constexpr R b[6] = {Dp5<R>::b1, 0, Dp5<R>::b3, Dp5<R>::b4, Dp5<R>::b5, Dp5<R>::b6};
-};
-
 template <typename R, bool MLP>
 __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wave8_kernel(const WgArgs<R> a, R* __restrict__ grad,
                                                                                        R* __restrict__ grad_model) {

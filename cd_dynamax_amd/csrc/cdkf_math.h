@@ -111,6 +111,18 @@ struct Dp5 {
                      b5 = R(-2187.0 / 6784.0), b6 = R(11.0 / 84.0);
 };
 
+// Dormand-Prince tableau as arrays (static indices after unrolling)
+template <typename R>
+struct Dp5T {
+  static constexpr R a[6][5] = {{0, 0, 0, 0, 0},
+                                {Dp5<R>::a21, 0, 0, 0, 0},
+                                {Dp5<R>::a31, Dp5<R>::a32, 0, 0, 0},
+                                {Dp5<R>::a41, Dp5<R>::a42, Dp5<R>::a43, 0, 0},
+                                {Dp5<R>::a51, Dp5<R>::a52, Dp5<R>::a53, Dp5<R>::a54, 0},
+                                {Dp5<R>::a61, Dp5<R>::a62, Dp5<R>::a63, Dp5<R>::a64, Dp5<R>::a65}};
+  static constexpr R b[6] = {Dp5<R>::b1, 0, Dp5<R>::b3, Dp5<R>::b4, Dp5<R>::b5, Dp5<R>::b6};
+};
+
 // The 21 non-zero tableau entries held in VGPRs.  `pin()` hides the value from the optimiser, which
 // otherwise re-materialises every 64-bit constant with two s_mov_b32 at each entry of the RK loop (42+
 // scalar moves per observation step) and spills SGPRs around them; a lone wave issues one instruction

@@ -14,6 +14,11 @@
 #include "cdkf_math.h"
 
 namespace cdkf {
+#ifdef CDKF_PHASE_PROFILE
+#define CDKF_TICK(i) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x == 0) prof_t[i] = wall_clock64(); } while (0)
+#else
+#define CDKF_TICK(i) do {} while (0)
+#endif
 
 constexpr int kDriftLinear = 0, kDriftLorenz63 = 1, kDriftLorenz96 = 2, kDriftMlp = 3;
 constexpr int kWgBlock = 8;  // panel width of the blocked factorisations
@@ -158,6 +163,61 @@ __device__ __forceinline__ void wg_matmul_tn(R* __restrict__ C, const R* __restr
   }
 }
 
+// ---- matrix-core products: C (op)= op(A) op(B) on 16 x 16 output tiles, one tile per wavefront at a time ---------------
+// v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32 (exact f64 / f32 arithmetic).  On MI355X the f64 MFMA rate equals the
+// vector FMA rate; the gain is operand traffic: a k-step of a tile (1024 FMAs) takes two LDS reads per lane, where the
+// 1 x 4 register strips above take five per four FMAs and were LDS-bound.  Lane l feeds A[l & 15][k0 + (l >> 4)] and
+// B[k0 + (l >> 4)][l & 15]; results: column l & 15, rows (l >> 4) + 4 r (f64) or 4 (l >> 4) + r (f32), r = 0..3
+// (cdna_hip_programming.md, "Fragment layout").  Out-of-range rows / columns / k are fed zeros.
+typedef double wg_f64x4 __attribute__((ext_vector_type(4)));
+typedef float wg_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ wg_f64x4 wg_mfma(double a, double b, wg_f64x4 c) {
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ wg_f32x4 wg_mfma(float a, float b, wg_f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+template <typename R>
+struct WgAcc;
+template <>
+struct WgAcc<double> {
+  typedef wg_f64x4 type;
+  static __device__ __forceinline__ int row(int lane, int r) { return (lane >> 4) + 4 * r; }
+};
+template <>
+struct WgAcc<float> {
+  typedef wg_f32x4 type;
+  static __device__ __forceinline__ int row(int lane, int r) { return 4 * (lane >> 4) + r; }
+};
+// TA: A is stored transposed (A'(i,k) = A[k][i]); TB: B is stored transposed (B'(k,j) = B[j][k]); SUB: C -= product
+template <typename R, bool TA, bool TB, bool SUB>
+__device__ __forceinline__ void wg_mm(R* __restrict__ C, const R* __restrict__ A, const R* __restrict__ B, int r, int kdim,
+                                      int c, int lq) {
+  const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6, lane = threadIdx.x & 63;
+  const int tc = (c + 15) >> 4, ntile = ((r + 15) >> 4) * tc;
+  for (int tile = wave; tile < ntile; tile += nw) {
+    const int ti = fdiv(tile, tc), tj = tile - ti * tc;
+    const int ai = ti * 16 + (lane & 15), bj = tj * 16 + (lane & 15), kq = lane >> 4;
+    const bool aok = ai < r, bok = bj < c;
+    typename WgAcc<R>::type acc = {0, 0, 0, 0};
+    for (int k0 = 0; k0 < kdim; k0 += 4) {
+      const int k = k0 + kq;
+      const bool kok = k < kdim;
+      const R av = (aok && kok) ? (TA ? A[k * lq + ai] : A[ai * lq + k]) : R(0);
+      const R bv = (bok && kok) ? (TB ? B[bj * lq + k] : B[k * lq + bj]) : R(0);
+      acc = wg_mfma(av, bv, acc);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = ti * 16 + WgAcc<R>::row(lane, q);
+      if (row < r && bok) {
+        R* p = C + row * lq + bj;
+        *p = SUB ? *p - acc[q] : acc[q];
+      }
+    }
+  }
+}
+
 // Register copy of an 8 x 8 diagonal block (lower triangle) of an LDS matrix, padded with the identity beyond nb:
 // all loads are independent, so their LDS latency overlaps -- the serial parts of the blocked algorithms below then
 // run out of registers instead of chasing ~100-cycle ds_read round trips.
@@ -256,6 +316,28 @@ __device__ void wg_cholesky2(R* S1, R* inv1, R* S2, R* inv2, int n, int lq, int*
     }
   }
   __syncthreads();
+}
+
+// ---- wavefront helpers ----------------------------------------------------------------------------------------------------
+// (A single-wavefront Cholesky / substitution with the matrix in LDS was tried for the 40 x 40 update: no workgroup
+//  barriers, but one wavefront cannot issue LDS reads fast enough -- 84 us against 58 us for the blocked versions below.)
+template <typename R>
+__device__ __forceinline__ R wave_bcast(R x, int src);
+template <>
+__device__ __forceinline__ float wave_bcast<float>(float x, int src) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), src));
+}
+template <>
+__device__ __forceinline__ double wave_bcast<double>(double x, int src) {
+  const long long b = __double_as_longlong(x);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), src);
+  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
 // Solve (L L^T) X = B in place, B is [n x c]; blocked substitution, 2 barriers per panel and direction; the
@@ -517,72 +599,93 @@ __device__ void wg_drift(const WgArgs<R>& a, const WgLds<R>& L, const R* __restr
 // ---- per-thread ownership of covariance entries ------------------------------------------------------------------
 template <typename R, int EPT>
 struct Own {
-  int n;            // number of owned entries (<= EPT)
-  int off[EPT];     // LDS offset i*lq + j
-  int ei[EPT], ej[EPT];
-  R lql[EPT];       // (L Qc L^T)[i][j]
+  int n;         // number of owned entries (<= EPT): entry u is e = threadIdx.x + u * blockDim.x < d * d
+  int d_, lq_;   // uniform
+  R lql[EPT];    // (L Qc L^T)[i][j]
+  // row / column / LDS offset of entry u, re-derived at each use (a handful of integer instructions): kept in registers
+  // they were the values the allocator spilled, and every Runge-Kutta stage re-loaded them from scratch
+  __device__ __forceinline__ void at(int u, int& i, int& j) const {
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));  // opaque: keeps the optimiser from hoisting these few integer ops out of the Runge-Kutta
+                                 // loops, where their results (and everything derived from them) were spilled to scratch
+    const int e = t + u * blockDim.x;
+    i = fdiv(e, d_);
+    j = e - i * d_;
+  }
+  __device__ __forceinline__ int off(int u) const {
+    int i, j;
+    at(u, i, j);
+    return i * lq_ + j;
+  }
   __device__ void init(int d, int lq, const R* LQL) {
     n = 0;
+    d_ = d;
+    lq_ = lq;
 #pragma unroll
     for (int u = 0; u < EPT; ++u) {
       const int e = threadIdx.x + u * blockDim.x;
       const bool ok = e < d * d;
-      const int i = ok ? fdiv(e, d) : 0, j = ok ? e - i * d : 0;
-      ei[u] = i;
-      ej[u] = j;
-      off[u] = i * lq + j;
-      lql[u] = ok ? LQL[i * d + j] : R(0);
+      lql[u] = ok ? LQL[e] : R(0);
       n += ok;
     }
   }
 };
 
-// One Dormand-Prince step with register-resident slopes.  `rhs(msrc, Psrc, s, km, kP)` must fill this thread's slopes
-// for stage s from the LDS stage value and END with a barrier-free state (it may use barriers inside).
+// One Dormand-Prince step with register-resident slopes.  `rhs(msrc, Psrc, km, kP)` must fill this thread's slopes from
+// the LDS stage value and END with a barrier-free state (it may use barriers inside).  The six stages are separate
+// instantiations (wg_stage<S>) rather than an unrolled loop: when the optimiser declined to unroll the loop around the
+// inlined right-hand side, the slope arrays were indexed dynamically and moved to scratch memory (5x slower sweeps).
+template <int S, typename R, int EPT, typename RhsFn>
+__device__ __forceinline__ void wg_stage(const WgLds<R>& L, const Own<R, EPT>& own, int d, R dt, bool with_P, RhsFn& rhs,
+                                         R (&kM)[6], R (&kP)[6][EPT]) {
+  using TB = Dp5T<R>;
+  R* mcur = L.vec(0);
+  R* Pm = L.mat(0);
+  R* ms = L.vec(1);
+  R* Ps = L.mat(1);
+  if constexpr (S == 0) {
+    rhs(mcur, Pm, kM[0], kP[0]);
+  } else {
+    if (threadIdx.x < d) {
+      R acc = TB::a[S][0] * kM[0];
+#pragma unroll
+      for (int j = 1; j < S; ++j) acc = rfma(TB::a[S][j], kM[j], acc);
+      ms[threadIdx.x] = rfma(dt, acc, mcur[threadIdx.x]);
+    }
+    if (with_P) {
+#pragma unroll
+      for (int u = 0; u < EPT; ++u)
+        if (u < own.n) {
+          R acc = TB::a[S][0] * kP[0][u];
+#pragma unroll
+          for (int j = 1; j < S; ++j) acc = rfma(TB::a[S][j], kP[j][u], acc);
+          {
+            const int o_ = own.off(u);
+            Ps[o_] = rfma(dt, acc, Pm[o_]);
+          }
+        }
+    }
+    __syncthreads();
+    rhs(ms, Ps, kM[S], kP[S]);
+  }
+  __syncthreads();  // every thread is done reading the stage value before it is overwritten
+}
+
 template <typename R, int EPT, typename RhsFn>
 __device__ __forceinline__ void wg_dopri5_step(const WgLds<R>& L, const Own<R, EPT>& own, int d, R dt, bool with_P,
                                                RhsFn rhs) {
   using C = Dp5<R>;
   R* mcur = L.vec(0);
   R* Pm = L.mat(0);
-  R* ms = L.vec(1);
-  R* Ps = L.mat(1);
   R kM[6];
   R kP[6][EPT];
-  const bool has_m = threadIdx.x < d;
-  const R A_[6][5] = {{0, 0, 0, 0, 0},
-                      {C::a21, 0, 0, 0, 0},
-                      {C::a31, C::a32, 0, 0, 0},
-                      {C::a41, C::a42, C::a43, 0, 0},
-                      {C::a51, C::a52, C::a53, C::a54, 0},
-                      {C::a61, C::a62, C::a63, C::a64, C::a65}};
-#pragma unroll
-  for (int s = 0; s < 6; ++s) {
-    if (s == 0) {
-      rhs(mcur, Pm, kM[0], kP[0]);
-    } else {
-      if (has_m) {
-        R acc = A_[s][0] * kM[0];
-#pragma unroll
-        for (int j = 1; j < s; ++j) acc = rfma(A_[s][j], kM[j], acc);
-        ms[threadIdx.x] = rfma(dt, acc, mcur[threadIdx.x]);
-      }
-      if (with_P) {
-#pragma unroll
-        for (int u = 0; u < EPT; ++u)
-          if (u < own.n) {
-            R acc = A_[s][0] * kP[0][u];
-#pragma unroll
-            for (int j = 1; j < s; ++j) acc = rfma(A_[s][j], kP[j][u], acc);
-            Ps[own.off[u]] = rfma(dt, acc, Pm[own.off[u]]);
-          }
-      }
-      __syncthreads();
-      rhs(ms, Ps, kM[s], kP[s]);
-    }
-    __syncthreads();  // every thread is done reading the stage value before it is overwritten
-  }
-  if (has_m) {
+  wg_stage<0>(L, own, d, dt, with_P, rhs, kM, kP);
+  wg_stage<1>(L, own, d, dt, with_P, rhs, kM, kP);
+  wg_stage<2>(L, own, d, dt, with_P, rhs, kM, kP);
+  wg_stage<3>(L, own, d, dt, with_P, rhs, kM, kP);
+  wg_stage<4>(L, own, d, dt, with_P, rhs, kM, kP);
+  wg_stage<5>(L, own, d, dt, with_P, rhs, kM, kP);
+  if (threadIdx.x < d) {
     const R acc = rfma(C::b6, kM[5], rfma(C::b5, kM[4], rfma(C::b4, kM[3], rfma(C::b3, kM[2], C::b1 * kM[0]))));
     mcur[threadIdx.x] = rfma(dt, acc, mcur[threadIdx.x]);
   }
@@ -592,7 +695,10 @@ __device__ __forceinline__ void wg_dopri5_step(const WgLds<R>& L, const Own<R, E
       if (u < own.n) {
         const R acc =
             rfma(C::b6, kP[5][u], rfma(C::b5, kP[4][u], rfma(C::b4, kP[3][u], rfma(C::b3, kP[2][u], C::b1 * kP[0][u]))));
-        Pm[own.off[u]] = rfma(dt, acc, Pm[own.off[u]]);
+        {
+          const int o_ = own.off(u);
+          Pm[o_] = rfma(dt, acc, Pm[o_]);
+        }
       }
   }
   __syncthreads();
@@ -636,7 +742,8 @@ __device__ __forceinline__ void wg_rhs_ekf(const WgArgs<R>& a, const WgLds<R>& L
 #pragma unroll
     for (int u = 0; u < EPT; ++u)
       if (u < own.n) {
-        const int i = own.ei[u], j = own.ej[u];
+        int i, j;
+        own.at(u, i, j);
         const int ip1 = (i + 1 == d) ? 0 : i + 1, im1 = (i == 0) ? d - 1 : i - 1, im2 = (im1 == 0) ? d - 1 : im1 - 1;
         const int jp1 = (j + 1 == d) ? 0 : j + 1, jm1 = (j == 0) ? d - 1 : j - 1, jm2 = (jm1 == 0) ? d - 1 : jm1 - 1;
         const R xi1 = ms[im1], xj1 = ms[jm1];
@@ -657,11 +764,15 @@ __device__ __forceinline__ void wg_rhs_ekf(const WgArgs<R>& a, const WgLds<R>& L
   wg_drift(a, L, ms, fv, mean_only ? (R*)nullptr : F, second ? gv : (R*)nullptr);
   if (threadIdx.x < d) kM = fv[threadIdx.x];
   if (mean_only) return;
-  wg_matmul(A, F, Ps, d, d, d, lq);
+  wg_mm<R, false, false, false>(A, F, Ps, d, d, d, lq);
   __syncthreads();
 #pragma unroll
   for (int u = 0; u < EPT; ++u)
-    if (u < own.n) kP[u] = (A[own.off[u]] + A[own.ej[u] * lq + own.ei[u]]) + own.lql[u];
+    if (u < own.n) {
+      int i, j;
+      own.at(u, i, j);
+      kP[u] = (A[i * lq + j] + A[j * lq + i]) + own.lql[u];
+    }
   if (second && threadIdx.x < d) {
     R s = 0;
     for (int k = 0; k < d; ++k) s = rfma(gv[k], Ps[k * lq + threadIdx.x], s);
@@ -758,12 +869,20 @@ __device__ __forceinline__ void wg_rhs_ukf(const WgArgs<R>& a, const WgLds<R>& L
   __syncthreads();
 #pragma unroll
   for (int u = 0; u < EPT; ++u)
-    if (u < own.n) kP[u] = (foo[own.off[u]] + foo[own.ej[u] * lq + own.ei[u]]) + own.lql[u];
+    if (u < own.n) {
+      int i, j;
+      own.at(u, i, j);
+      kP[u] = (foo[i * lq + j] + foo[j * lq + i]) + own.lql[u];
+    }
 }
 
 // ---- EKF update on the LDS state (inference_ekf.py:153-199, 285-286) --------------------------------------------
 template <typename R>
 __device__ void wg_ekf_update(const WgArgs<R>& a, const WgLds<R>& L, const R* __restrict__ yl, double* ll, int* bad) {
+#ifdef CDKF_PHASE_PROFILE
+  __shared__ long long prof_t[8];
+#endif
+  CDKF_TICK(0);
   const int d = a.d, m = a.m, lq = a.lq;
   const R* hb = a.par + a.o_hb;
   const R* Rm = a.par + a.o_R;
@@ -808,7 +927,7 @@ __device__ void wg_ekf_update(const WgArgs<R>& a, const WgLds<R>& L, const R* __
       }
       __syncthreads();
       if (!hsel) {
-        wg_matmul(HO, Hl, O, m, d, d, lq);
+        wg_mm<R, false, false, false>(HO, Hl, O, m, d, d, lq);
         __syncthreads();
       }
       const R w2 = a.ukf_wi + a.ukf_wi;
@@ -841,7 +960,7 @@ __device__ void wg_ekf_update(const WgArgs<R>& a, const WgLds<R>& L, const R* __
       }
       CDKF_WG_FOR(r, m) v[r] = yl[r] - mm[r];
     } else {
-      wg_matmul(HP, Hl, P, m, d, d, lq);
+      wg_mm<R, false, false, false>(HP, Hl, P, m, d, d, lq);
       __syncthreads();
       CDKF_WG_FOR(e, m * m) {
         const int r = fdiv(e, m), c = e - r * m;
@@ -868,56 +987,54 @@ __device__ void wg_ekf_update(const WgArgs<R>& a, const WgLds<R>& L, const R* __
         const int r = fdiv(e, d), c = e - r * d;
         X[r * lq + c] = HP[r * lq + c];
       }
+    CDKF_TICK(1);
     wg_cholesky2(it == 0 ? L1 : (R*)L2, it == 0 ? inv1 : inv2, it == 0 ? L2 : (R*)nullptr, inv2, m, lq, bad);
-    if (it == 0) {
-      // z = L1^-1 v and the log-likelihood term: one wavefront, lane r keeps v_r in a register
-      if (threadIdx.x < 64) {
-        const int lane = threadIdx.x;
-        double qd = 0.0, ld = 0.0;
-        for (int base = 0; base < m; base += 64) {  // m <= 64 in practice: a single pass
-          R vr = (base + lane < m) ? v[base + lane] : R(0);
-          for (int j = 0; j < m - base && j < 64; ++j) {
-            const R zj = __shfl(vr, j, 64) * inv1[base + j];
-            if (lane > j && base + lane < m) vr = rfma(-L1[(base + lane) * lq + base + j], zj, vr);
+    CDKF_TICK(2);
+    if (it == 0 && threadIdx.x < 64) {
+      // z = L1^-1 v and the log-likelihood term on one wavefront (the others go on to the gain solve and meet it at that
+      // routine's first barrier): lane r carries v_r, pivots of the step broadcast with v_readlane, the column entries and
+      // reciprocal pivots of four steps in flight per LDS round trip; log-determinant from the reciprocal pivots in parallel
+      const int lane = threadIdx.x;
+      R vr = (lane < m) ? v[lane] : R(0);
+      double qd = 0.0;
+      const R* lrow = L1 + ((lane < m) ? lane : m - 1) * lq;
+      for (int j0 = 0; j0 < m; j0 += 4) {
+        R lj[4], ij[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int jj = (j0 + q < m) ? j0 + q : m - 1;
+          lj[q] = lrow[jj];
+          ij[q] = inv1[jj];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int j = j0 + q;
+          if (j < m) {
+            const R zj = wave_bcast<R>(vr, j) * ij[q];
+            if (lane > j && lane < m) vr = rfma(-lj[q], zj, vr);
             qd += (double)zj * (double)zj;
-            ld += log((double)inv1[base + j]);
           }
         }
-        if (lane == 0) *ll += -0.5 * qd + ld - 0.5 * m * 1.8378770664093454835606594728112;
       }
+      double ld = (lane < m) ? log((double)inv1[lane]) : 0.0;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) ld += __shfl_down(ld, off, 64);
+      if (lane == 0) *ll += -0.5 * qd + ld - 0.5 * m * 1.8378770664093454835606594728112;
     }
+    CDKF_TICK(3);
     wg_chol_solve(L2, inv2, X, m, d, lq);            // X = Sb^-1 (H P);   K = X^T
-    wg_matmul(SX, S, X, m, m, d, lq);                // S X
+    CDKF_TICK(4);
+    wg_mm<R, false, false, false>(SX, S, X, m, m, d, lq);  // S X
     CDKF_WG_FOR(i, d) {                              // m+ = m + K v (staged: v is still being read)
       R s = mm[i];
       for (int r = 0; r < m; ++r) s = rfma(X[r * lq + i], v[r], s);
       tmp[i] = s;
     }
     __syncthreads();
-    // P <- P - X^T (S X)   (1x4 strips)
-    {
-      const int c4 = (d + 3) >> 2;
-      CDKF_WG_FOR(e, d * c4) {
-        const int i = fdiv(e, c4), j = (e - i * c4) << 2;
-        R a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-#pragma unroll 4
-        for (int kk = 0; kk < m; ++kk) {
-          const R f = X[kk * lq + i];
-          const R* b = SX + kk * lq + j;
-          a0 = rfma(f, b[0], a0);
-          a1 = rfma(f, b[1], a1);
-          a2 = rfma(f, b[2], a2);
-          a3 = rfma(f, b[3], a3);
-        }
-        R* p = P + i * lq + j;
-        p[0] -= a0;
-        if (j + 1 < d) p[1] -= a1;
-        if (j + 2 < d) p[2] -= a2;
-        if (j + 3 < d) p[3] -= a3;
-      }
-    }
+    wg_mm<R, true, false, true>(P, X, SX, d, m, d, lq);  // P <- P - X^T (S X)
     CDKF_WG_FOR(i, d) mm[i] = tmp[i];
     __syncthreads();
+    CDKF_TICK(5);
   }
   // symmetrize (dynamax/utils/utils.py:209-211); the reference's UKF does not
   if (!ukf) CDKF_WG_FOR(e, d * d) {
@@ -929,6 +1046,12 @@ __device__ void wg_ekf_update(const WgArgs<R>& a, const WgLds<R>& L, const R* __
     }
   }
   __syncthreads();
+#ifdef CDKF_PHASE_PROFILE
+  CDKF_TICK(6);
+  if (threadIdx.x == 0 && blockIdx.x == 0 && a.T > 20)
+    printf("update phases (x10ns): setup %lld chol %lld ll %lld solve %lld SX+P %lld sym %lld\n", prof_t[1] - prof_t[0],
+           prof_t[2] - prof_t[1], prof_t[3] - prof_t[2], prof_t[4] - prof_t[3], prof_t[5] - prof_t[4], prof_t[6] - prof_t[5]);
+#endif
 }
 
 template <typename R>
@@ -950,8 +1073,14 @@ __device__ __forceinline__ void wg_store(const WgArgs<R>& a, const WgLds<R>& L, 
 }
 
 // ---- EKF filter sweep ----------------------------------------------------------------------------------------------
-template <typename R, int EPT>
-__global__ __launch_bounds__(512) void ekf_filter_wg_kernel(const WgArgs<R> a) {
+// UKF: unscented instead of extended filter.  KIND: kDriftAny (drift chosen at run time) or one drift kind -- a specialised
+// instantiation does not carry the register pressure of the code paths it cannot take (the union spilled to scratch).
+constexpr int kDriftAny = -1;
+template <typename R, int EPT, bool UKF, int KIND>
+__global__ __launch_bounds__(512) void ekf_filter_wg_kernel(const WgArgs<R> a_in) {
+  WgArgs<R> a = a_in;
+  if constexpr (KIND != kDriftAny) a.kind = KIND;
+  a.ukf = UKF ? 1 : 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const WgPlan plan = wg_plan(a.kind, a.d, a.h1, a.h2, a.hsel, false, a.ukf != 0);
   WgLds<R> L(reinterpret_cast<R*>(smem_raw), a.q, a.lq, plan);
@@ -980,7 +1109,7 @@ __global__ __launch_bounds__(512) void ekf_filter_wg_kernel(const WgArgs<R> a) {
   int st = 0;
   const bool zeroth = (a.order == 0) && !a.ukf;
   auto rhs = [&](const R* ms, const R* Ps, R& kM, R (&kP)[EPT]) {
-    if (a.ukf)
+    if constexpr (UKF)
       wg_rhs_ukf<R, EPT>(a, L, own, ms, Ps, kM, kP, &bad);
     else
       wg_rhs_ekf<R, EPT>(a, L, own, ms, Ps, kM, kP, zeroth);
@@ -993,6 +1122,9 @@ __global__ __launch_bounds__(512) void ekf_filter_wg_kernel(const WgArgs<R> a) {
     if (!a.forecast) wg_ekf_update(a, L, yl, &ll, &bad);
     wg_store(a, L, a.fm, a.fP, n, k);
     __syncthreads();
+    // (re)derive this thread's entry indices here: values that live across the measurement update would be spilled to
+    // scratch by its register pressure and re-loaded inside every Runge-Kutta stage (measured: 3.4x on the d = 40 sweep)
+    own.init(d, lq, a.par + a.o_LQL);
     if (wg_integrate<R, EPT>(L, own, d, t0, t1, a.dt0, a.max_steps, !zeroth, rhs)) st |= kStatusMaxSteps;
     if (zeroth) {
       const R sq = rsqrt_(t1 - t0);
@@ -1055,7 +1187,7 @@ __global__ __launch_bounds__(512) void ekf_smoother_wg_kernel(const WgArgs<R> a)
   R* fmf = L.vec(10);
   const R* LQL = a.par + a.o_LQL;
   auto rhs = [&](const R* ms, const R* Ps, R& kM, R (&kP)[EPT]) {
-    wg_matmul(A, G, Ps, d, d, d, lq);
+    wg_mm<R, false, false, false>(A, G, Ps, d, d, d, lq);
     if (threadIdx.x < d) {
       R s = 0;
       for (int k = 0; k < d; ++k) s = rfma(G[threadIdx.x * lq + k], ms[k] - mf[k], s);
@@ -1064,7 +1196,11 @@ __global__ __launch_bounds__(512) void ekf_smoother_wg_kernel(const WgArgs<R> a)
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < EPT; ++u)
-      if (u < own.n) kP[u] = -((A[own.off[u]] + A[own.ej[u] * lq + own.ei[u]]) - own.lql[u]);
+      if (u < own.n) {
+        int i, j;
+        own.at(u, i, j);
+        kP[u] = -((A[i * lq + j] + A[j * lq + i]) - own.lql[u]);
+      }
   };
   R t1 = tp[(a.T - 1) * a.t_sk];
   for (long k = a.T - 2; k >= 0; --k) {
@@ -1090,6 +1226,7 @@ __global__ __launch_bounds__(512) void ekf_smoother_wg_kernel(const WgArgs<R> a)
       G[i * lq + j] += X[j * lq + i];
     }
     __syncthreads();
+    own.init(d, lq, a.par + a.o_LQL);  // see the filter kernel
     if (wg_integrate<R, EPT>(L, own, d, R(0), t1 - t0, a.dt0, a.max_steps, true, rhs)) st |= kStatusMaxSteps;
     wg_store(a, L, a.sm, a.sP, n, k);
     __syncthreads();

@@ -219,10 +219,19 @@ static int wg_ept(int d, int threads) {
 template <typename R, int EPT>
 static int launch_wg_pair(const WgArgs<R>& a, bool filter, bool smoother, int threads, size_t lds_f, size_t lds_s,
                           hipStream_t stream) {
-  static const int cap_rc = wg_raise_lds_cap(ekf_filter_wg_kernel<R, EPT>) | wg_raise_lds_cap(ekf_smoother_wg_kernel<R, EPT>);
+  static const int cap_rc = wg_raise_lds_cap(ekf_filter_wg_kernel<R, EPT, false, kDriftAny>) |
+                            wg_raise_lds_cap(ekf_filter_wg_kernel<R, EPT, true, kDriftAny>) |
+                            wg_raise_lds_cap(ekf_filter_wg_kernel<R, EPT, false, kDriftLorenz96>) |
+                            wg_raise_lds_cap(ekf_smoother_wg_kernel<R, EPT>);
   if (cap_rc) return CDKF_EHIP;
   if (filter) {
-    hipLaunchKernelGGL((ekf_filter_wg_kernel<R, EPT>), dim3((unsigned)a.N), dim3(threads), lds_f, stream, a);
+    const dim3 grid((unsigned)a.N), block(threads);
+    if (a.ukf)
+      hipLaunchKernelGGL((ekf_filter_wg_kernel<R, EPT, true, kDriftAny>), grid, block, lds_f, stream, a);
+    else if (a.kind == kDriftLorenz96)
+      hipLaunchKernelGGL((ekf_filter_wg_kernel<R, EPT, false, kDriftLorenz96>), grid, block, lds_f, stream, a);
+    else
+      hipLaunchKernelGGL((ekf_filter_wg_kernel<R, EPT, false, kDriftAny>), grid, block, lds_f, stream, a);
     CDKF_HIP_CHECK(hipGetLastError());
   }
   if (smoother) {
