@@ -300,18 +300,14 @@ __device__ void wg_cholesky2(R* S1, R* inv1, R* S2, R* inv2, int n, int lq, int*
         if (j < nb) S[r * lq + kb + j] = row[j];
     }
     __syncthreads();
-    // (c) trailing update of the lower triangle: S[a][b] -= sum_k L[a][k] L[b][k]
-    CDKF_WG_FOR(e, rest * rest * nmat) {
-      const int w = (e >= rest * rest) ? 1 : 0;
-      const int e2 = e - w * rest * rest;
-      const int ar = fdiv(e2, rest), br = e2 - ar * rest;
-      if (br <= ar) {
-        R* S = w ? S2 : S1;
-        const int a = kb + nb + ar, b = kb + nb + br;
-        R v = S[a * lq + b];
-#pragma unroll 8
-        for (int k = kb; k < kb + nb; ++k) v = rfma(-S[a * lq + k], S[b * lq + k], v);
-        S[a * lq + b] = v;
+    // (c) trailing update S[a][b] -= sum_k L[a][k] L[b][k] as a rank-nb matrix-core product over the whole trailing square
+    //     (the upper triangle receives values nobody reads: every consumer takes the lower one)
+    if (rest > 0) {
+      R* T1 = S1 + (kb + nb) * lq;
+      wg_mm<R, false, true, true>(T1 + kb + nb, T1 + kb, T1 + kb, rest, nb, rest, lq);
+      if (nmat == 2) {
+        R* T2 = S2 + (kb + nb) * lq;
+        wg_mm<R, false, true, true>(T2 + kb + nb, T2 + kb, T2 + kb, rest, nb, rest, lq);
       }
     }
   }
@@ -368,13 +364,7 @@ __device__ void wg_chol_solve(const R* L, const R* inv, R* B, int n, int c, int 
     }
     __syncthreads();
     const int rest = n - kb - nb;
-    CDKF_WG_FOR(e, rest * c) {
-      const int rr = fdiv(e, c), j = e - rr * c, r = kb + nb + rr;
-      R v = B[r * lq + j];
-#pragma unroll 8
-      for (int k = kb; k < kb + nb; ++k) v = rfma(-L[r * lq + k], B[k * lq + j], v);
-      B[r * lq + j] = v;
-    }
+    if (rest > 0) wg_mm<R, false, false, true>(B + (kb + nb) * lq, L + (kb + nb) * lq + kb, B + kb * lq, rest, nb, c, lq);
   }
   const int nblk = (n + kWgBlock - 1) / kWgBlock;
   for (int bi = nblk - 1; bi >= 0; --bi) {  // backward: L^T X = Y
@@ -401,13 +391,7 @@ __device__ void wg_chol_solve(const R* L, const R* inv, R* B, int n, int c, int 
         if (i < nb) B[(kb + i) * lq + j] = col[i];
     }
     __syncthreads();
-    CDKF_WG_FOR(e, kb * c) {
-      const int r = fdiv(e, c), j = e - r * c;
-      R v = B[r * lq + j];
-#pragma unroll 8
-      for (int k = kb; k < kb + nb; ++k) v = rfma(-L[k * lq + r], B[k * lq + j], v);
-      B[r * lq + j] = v;
-    }
+    if (kb > 0) wg_mm<R, true, false, true>(B, L + kb * lq, B + kb * lq, kb, nb, c, lq);
   }
   __syncthreads();
 }
