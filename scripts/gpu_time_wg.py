@@ -1,6 +1,7 @@
 """Timing of the per-GPU slices of BASELINE configs 4 (Lorenz-96 d=40 EKF + smoother) and 5 (MLP drift, LL only)."""
 import ctypes as C, sys, os, time
-sys.path[:0] = [os.path.join(os.path.dirname(__file__), ".."), os.path.join(os.path.dirname(__file__), "..", "oracle"), os.path.join(os.path.dirname(__file__), "..", "tests")]
+_R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [_R, os.path.join(_R, "oracle"), os.path.join(_R, "tests")]
 import numpy as np
 import cdkf_oracle as o
 from cd_dynamax_amd import _ffi, models
