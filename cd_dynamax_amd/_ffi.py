@@ -44,7 +44,7 @@ class CdkfModel(C.Structure):
         ("emission_dim", C.c_int32),
         ("hidden1", C.c_int32),
         ("hidden2", C.c_int32),
-        ("reserved", C.c_int32),
+        ("emission_kind", C.c_int32),
         ("n_theta", C.c_int64),
         ("theta", _dp),
         ("L", _dp),
@@ -91,7 +91,7 @@ SYMBOLS = (
      "cdkf_free", "cdkf_memcpy_h2d", "cdkf_memcpy_d2h", "cdkf_memset", "cdkf_synchronize", "cdkf_ll_sum_f64_dev",
      "cdkf_ll_sum_f32_dev", "cdkf_emission_moments_f64", "cdkf_emission_moments_f32", "cdkf_emission_moments_f64_dev",
      "cdkf_emission_moments_f32_dev", "cdkf_ekf_loglik_grad_f64", "cdkf_ekf_loglik_grad_f32",
-     "cdkf_ekf_loglik_grad_f64_dev", "cdkf_ekf_loglik_grad_f32_dev", "cdkf_custom_drift_register", "cdkf_custom_drift_compile", "cdkf_set_kernel_source_dir",
+     "cdkf_ekf_loglik_grad_f64_dev", "cdkf_ekf_loglik_grad_f32_dev", "cdkf_custom_drift_register", "cdkf_custom_drift_compile", "cdkf_custom_emission_register", "cdkf_set_kernel_source_dir",
      "cdkf_kf_smoother1_f64", "cdkf_kf_smoother1_f32", "cdkf_kf_smoother1_f64_dev", "cdkf_kf_smoother1_f32_dev",
      "cdkf_kf_smoother1_supported", "cdkf_grad_supported", "cdkf_grad_all_supported", "cdkf_ekf_loglik_grad_all_f64",
      "cdkf_ekf_loglik_grad_all_f32", "cdkf_ekf_loglik_grad_all_f64_dev", "cdkf_ekf_loglik_grad_all_f32_dev", "cdkf_grad_sum_f64_dev",
@@ -140,7 +140,9 @@ def lib() -> C.CDLL:
         f.restype = C.c_int
     L.cdkf_custom_drift_register.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p]
     L.cdkf_custom_drift_register.restype = C.c_int
-    L.cdkf_custom_drift_compile.argtypes = [C.c_int] * 5
+    L.cdkf_custom_drift_compile.argtypes = [C.c_int] * 6
+    L.cdkf_custom_emission_register.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_char_p]
+    L.cdkf_custom_emission_register.restype = C.c_int
     L.cdkf_custom_drift_compile.restype = C.c_int
     L.cdkf_set_kernel_source_dir.argtypes = [C.c_char_p]
     L.cdkf_set_kernel_source_dir.restype = None
@@ -205,7 +207,7 @@ def default_opts() -> CdkfOpts:
 class ModelBlock:
     """Owns the double-precision host arrays a ``cdkf_model`` points to."""
 
-    def __init__(self, drift_kind, theta, L, Qc, H, h_bias, R, m0, P0, hidden=(0, 0)):
+    def __init__(self, drift_kind, theta, L, Qc, H, h_bias, R, m0, P0, hidden=(0, 0), emission_kind=0):
         f64 = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.float64))
         self.theta, self.L, self.Qc, self.H, self.h_bias, self.R, self.m0, self.P0 = map(
             f64, (theta, L, Qc, H, h_bias, R, m0, P0))
@@ -219,7 +221,7 @@ class ModelBlock:
         ptr = lambda a: a.ctypes.data_as(_dp)
         self.c = CdkfModel(
             drift_kind=int(drift_kind), state_dim=d, emission_dim=m, hidden1=int(hidden[0]), hidden2=int(hidden[1]),
-            reserved=0, n_theta=self.theta.size, theta=ptr(self.theta), L=ptr(self.L), Qc=ptr(self.Qc), H=ptr(self.H),
+            emission_kind=int(emission_kind), n_theta=self.theta.size, theta=ptr(self.theta), L=ptr(self.L), Qc=ptr(self.Qc), H=ptr(self.H),
             h_bias=ptr(self.h_bias), R=ptr(self.R), m0=ptr(self.m0), P0=ptr(self.P0))
 
 
@@ -299,6 +301,14 @@ def register_custom_drift(state_dim: int, n_theta: int, f_src: str, jac_src: str
     """cdkf_custom_drift_register: returns the drift_kind (same sources -> same kind)."""
     kind = lib().cdkf_custom_drift_register(int(state_dim), int(n_theta), f_src.encode(), jac_src.encode(),
                                             None if divgrad_src is None else divgrad_src.encode())
+    if kind < 0:
+        check(kind)
+    return kind
+
+
+def register_custom_emission(state_dim: int, emission_dim: int, h_src: str, hjac_src: str) -> int:
+    """cdkf_custom_emission_register: returns the emission_kind (same sources -> same kind)."""
+    kind = lib().cdkf_custom_emission_register(int(state_dim), int(emission_dim), h_src.encode(), hjac_src.encode())
     if kind < 0:
         check(kind)
     return kind

@@ -35,6 +35,11 @@ int check_common(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T
     set_error("model parameter pointers must not be NULL");
     return CDKF_EINVAL;
   }
+  if (mdl->emission_kind != 0 && !custom_kind(mdl->drift_kind)) {
+    set_error("emission_kind %d: a custom emission runs on the run-time compiled kernels, which need the drift as source too "
+              "(cdkf_custom_drift_register; the Python host converts the built-in drifts)", mdl->emission_kind);
+    return CDKF_EUNSUPPORTED;
+  }
   if (o->state_order < 0 || o->state_order > 2) {
     set_error("EKF hyperparams.state_order = %d not implemented yet", o->state_order);
     return CDKF_EINVAL;
@@ -322,6 +327,10 @@ int emission_moments_host(const cdkf_model* mdl, int64_t rows, const R* means, c
     set_error("emission_moments: bad arguments");
     return CDKF_EINVAL;
   }
+  if (mdl->emission_kind != 0) {
+    set_error("emission_moments: linear emission only (emission_kind %d)", mdl->emission_kind);
+    return CDKF_EUNSUPPORTED;
+  }
   if (rows == 0) return CDKF_OK;
   const size_t d = mdl->state_dim, m = mdl->emission_dim;
   DevBuf dm, dP, om, oP;
@@ -392,8 +401,12 @@ int cdkf_preferred_layout(const cdkf_model* mdl) {
 int cdkf_custom_drift_register(int state_dim, int n_theta, const char* f_src, const char* jac_src, const char* divgrad_src) {
   return custom_register(state_dim, n_theta, f_src, jac_src, divgrad_src);
 }
-int cdkf_custom_drift_compile(int drift_kind, int bytes_per_real, int emission_dim, int algo, int state_order) {
-  return custom_compile_check(drift_kind, bytes_per_real, emission_dim, algo, state_order);
+int cdkf_custom_drift_compile(int drift_kind, int bytes_per_real, int emission_dim, int algo, int state_order,
+                              int emission_kind) {
+  return custom_compile_check(drift_kind, bytes_per_real, emission_dim, algo, state_order, emission_kind);
+}
+int cdkf_custom_emission_register(int state_dim, int emission_dim, const char* h_src, const char* hjac_src) {
+  return custom_emission_register(state_dim, emission_dim, h_src, hjac_src);
 }
 void cdkf_set_kernel_source_dir(const char* dir) { custom_set_source_dir(dir); }
 

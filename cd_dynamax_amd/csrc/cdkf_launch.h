@@ -66,7 +66,9 @@ template <typename R>
 int launch_custom(int algo, const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll,
                   R* a1, R* a2, R* a3, R* a4, int32_t* status, hipStream_t stream);
 int custom_register(int state_dim, int n_theta, const char* f_src, const char* jac_src, const char* divgrad_src);
-int custom_compile_check(int kind, int bytes_per_real, int emission_dim, int algo, int state_order);
+int custom_compile_check(int kind, int bytes_per_real, int emission_dim, int algo, int state_order, int emission_kind);
+int custom_emission_register(int state_dim, int emission_dim, const char* h_src, const char* hjac_src);
+bool custom_emission_kind(int emission_kind, int d, int m);
 void custom_set_source_dir(const char* dir);
 
 bool kernel_available(const cdkf_model* mdl, const cdkf_opts* o, int algo, int bytes_per_real);

@@ -386,51 +386,11 @@ struct UkfRhs {
   }
 };
 
-// UKF measurement update (inference_ukf.py:162-203) for the linear emission h(x) = H x + b:
-// ybar = H m + b,  dY_i = H o_i,  S = 2 w_i sum_i dY_i dY_i^T + R,  C = 2 w_i sum_i o_i dY_i^T.
-template <typename R, int D, int M, typename Args>
-CDKF_DEV void ukf_update(const Args& a, R (&ys)[Dims<D>::NS], const R (&yobs)[M], LlAcc& ll, int& st) {
-  bool bad = false;
-  R o[D][D];
-  ukf_offsets<R, D>(ys, a.ukf_c, o, bad);
-  R dY[D][M];
-#pragma unroll
-  for (int i = 0; i < D; ++i)
-#pragma unroll
-    for (int r = 0; r < M; ++r) {
-      R v = R(0);
-#pragma unroll
-      for (int k = i; k < D; ++k) v = rfma(a.H[r][k], o[i][k], v);
-      dY[i][r] = v;
-    }
-  R v[M];
-#pragma unroll
-  for (int r = 0; r < M; ++r) {
-    R s = a.H[r][0] * ys[0];
-#pragma unroll
-    for (int k = 1; k < D; ++k) s = rfma(a.H[r][k], ys[k], s);
-    v[r] = yobs[r] - (s + a.hb[r]);
-  }
-  const R w2 = a.ukf_wi + a.ukf_wi;
-  R Sm[M][M], C[D][M];
-#pragma unroll
-  for (int r = 0; r < M; ++r)
-#pragma unroll
-    for (int c = 0; c < M; ++c) {
-      R acc = dY[0][r] * dY[0][c];
-#pragma unroll
-      for (int i = 1; i < D; ++i) acc = rfma(dY[i][r], dY[i][c], acc);
-      Sm[r][c] = rfma(w2, acc, a.Rm[r][c]);
-    }
-#pragma unroll
-  for (int k = 0; k < D; ++k)
-#pragma unroll
-    for (int c = 0; c < M; ++c) {
-      R acc = o[0][k] * dY[0][c];
-#pragma unroll
-      for (int i = 1; i <= k; ++i) acc = rfma(o[i][k], dY[i][c], acc);
-      C[k][c] = w2 * acc;
-    }
+// Shared tail of the unscented update: log-likelihood term MVN(ybar, S).log_prob(y), gain K = psd_solve(S, C^T)^T,
+// m+ = m + K v, P+ = P - K S K^T  (inference_ukf.py:196-203).  v = y - ybar, Sm = S, C = cross-covariance [D][M].
+template <typename R, int D, int M>
+CDKF_DEV void ukf_finish(R (&ys)[Dims<D>::NS], const R (&v)[M], const R (&Sm)[M][M], const R (&C)[D][M], LlAcc& ll, int& st,
+                         bool bad) {
   {
     R Lc[M][M], inv[M];
     chol_lower<R, M>(Sm, Lc, inv, bad);
@@ -494,6 +454,213 @@ CDKF_DEV void ukf_update(const Args& a, R (&ys)[Dims<D>::NS], const R (&yobs)[M]
   if (bad) st |= kStatusNotPd;
 }
 
+// UKF measurement update (inference_ukf.py:162-203) for the linear emission h(x) = H x + b:
+// ybar = H m + b,  dY_i = H o_i,  S = 2 w_i sum_i dY_i dY_i^T + R,  C = 2 w_i sum_i o_i dY_i^T.
+template <typename R, int D, int M, typename Args>
+CDKF_DEV void ukf_update(const Args& a, R (&ys)[Dims<D>::NS], const R (&yobs)[M], LlAcc& ll, int& st) {
+  bool bad = false;
+  R o[D][D];
+  ukf_offsets<R, D>(ys, a.ukf_c, o, bad);
+  R dY[D][M];
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int r = 0; r < M; ++r) {
+      R v = R(0);
+#pragma unroll
+      for (int k = i; k < D; ++k) v = rfma(a.H[r][k], o[i][k], v);
+      dY[i][r] = v;
+    }
+  R v[M];
+#pragma unroll
+  for (int r = 0; r < M; ++r) {
+    R s = a.H[r][0] * ys[0];
+#pragma unroll
+    for (int k = 1; k < D; ++k) s = rfma(a.H[r][k], ys[k], s);
+    v[r] = yobs[r] - (s + a.hb[r]);
+  }
+  const R w2 = a.ukf_wi + a.ukf_wi;
+  R Sm[M][M], C[D][M];
+#pragma unroll
+  for (int r = 0; r < M; ++r)
+#pragma unroll
+    for (int c = 0; c < M; ++c) {
+      R acc = dY[0][r] * dY[0][c];
+#pragma unroll
+      for (int i = 1; i < D; ++i) acc = rfma(dY[i][r], dY[i][c], acc);
+      Sm[r][c] = rfma(w2, acc, a.Rm[r][c]);
+    }
+#pragma unroll
+  for (int k = 0; k < D; ++k)
+#pragma unroll
+    for (int c = 0; c < M; ++c) {
+      R acc = o[0][k] * dY[0][c];
+#pragma unroll
+      for (int i = 1; i <= k; ++i) acc = rfma(o[i][k], dY[i][c], acc);
+      C[k][c] = w2 * acc;
+    }
+  ukf_finish<R, D, M>(ys, v, Sm, C, ll, st, bad);
+}
+
+// ---- user-supplied emission functions (run-time compiled kernels, launch_custom.hip) -----------------------------------
+// The reference accepts any callable h and linearises it with jacfwd (inference_ekf.py:258-259, 183-199) or pushes the
+// sigma points through it (inference_ukf.py:162-203).  An emission type provides  h(x, hx[M])  and  jac(x, H[M][D]).
+struct EmisLinearTag {  // the built-in kernels: linear emission from the argument block, code paths above
+  static constexpr bool kCustom = false;
+};
+
+template <typename R, int D, int M, typename Emis, typename Args>
+CDKF_DEV void ekf_update_custom(const Args& a, const Emis& em, R (&ys)[Dims<D>::NS], const R (&yobs)[M], LlAcc& ll, int& st) {
+  bool bad = false;
+  for (int it = 0; it < a.num_iter; ++it) {
+    R H[M][D], hx[M];
+    em.jac(ys, H);  // re-linearised at the current mean in every iteration
+    em.h(ys, hx);
+    R HP[M][D], S[M][M], v[M];
+#pragma unroll
+    for (int r = 0; r < M; ++r)
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        R s = H[r][0] * ys[D + sidx<D>(0, j)];
+#pragma unroll
+        for (int k = 1; k < D; ++k) s = rfma(H[r][k], ys[D + sidx<D>(k, j)], s);
+        HP[r][j] = s;
+      }
+#pragma unroll
+    for (int r = 0; r < M; ++r) {
+#pragma unroll
+      for (int c = 0; c < M; ++c) {
+        R s = HP[r][0] * H[c][0];
+#pragma unroll
+        for (int k = 1; k < D; ++k) s = rfma(HP[r][k], H[c][k], s);
+        S[r][c] = s + a.Rm[r][c];
+      }
+      v[r] = yobs[r] - hx[r];
+    }
+    if (it == 0) {
+      R Lc[M][M], inv[M];
+      chol_lower<R, M>(S, Lc, inv, bad);
+      R q = R(0), pinv = R(1);
+      R z[M];
+#pragma unroll
+      for (int i = 0; i < M; ++i) {
+        R w = v[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) w = rfma(-Lc[i][k], z[k], w);
+        z[i] = w * inv[i];
+        q = rfma(z[i], z[i], q);
+        pinv *= inv[i];
+      }
+      ll.add((double)q, (double)pinv, M);
+    }
+    R Sb[M][M];
+#pragma unroll
+    for (int r = 0; r < M; ++r)
+#pragma unroll
+      for (int c = 0; c <= r; ++c) {
+        R s = R(0.5) * (S[r][c] + S[c][r]);
+        if (r == c) s += R(1e-9);
+        Sb[r][c] = s;
+      }
+    R Lb[M][M], invb[M];
+    chol_lower<R, M>(Sb, Lb, invb, bad);
+    R X[M][D];
+#pragma unroll
+    for (int r = 0; r < M; ++r)
+#pragma unroll
+      for (int j = 0; j < D; ++j) X[r][j] = HP[r][j];
+    chol_solve<R, M, D>(Lb, invb, X);
+    R SX[M][D];
+#pragma unroll
+    for (int r = 0; r < M; ++r)
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        R s = S[r][0] * X[0][j];
+#pragma unroll
+        for (int c = 1; c < M; ++c) s = rfma(S[r][c], X[c][j], s);
+        SX[r][j] = s;
+      }
+    R Pn[Dims<D>::NP];
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int j = i; j < D; ++j) {
+        R tij = X[0][i] * SX[0][j], tji = X[0][j] * SX[0][i];
+#pragma unroll
+        for (int c = 1; c < M; ++c) {
+          tij = rfma(X[c][i], SX[c][j], tij);
+          tji = rfma(X[c][j], SX[c][i], tji);
+        }
+        const R p = ys[D + sidx<D>(i, j)];
+        Pn[sidx<D>(i, j)] = (i == j) ? p - tij : R(0.5) * ((p - tij) + (p - tji));
+      }
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      R s = ys[i];
+#pragma unroll
+      for (int r = 0; r < M; ++r) s = rfma(X[r][i], v[r], s);
+      ys[i] = s;
+    }
+#pragma unroll
+    for (int e = 0; e < Dims<D>::NP; ++e) ys[D + e] = Pn[e];
+  }
+  if (bad) st |= kStatusNotPd;
+}
+
+// unscented update through a general emission: Y_s = h(X_s), ybar = sum w_m Y, S = sum w_c (Y - ybar)(Y - ybar)^T + R,
+// C = sum w_c (X - m)(Y - ybar)^T  (the s = 0 term of C vanishes; the pairs share the offset o_i)
+template <typename R, int D, int M, typename Emis, typename Args>
+CDKF_DEV void ukf_update_custom(const Args& a, const Emis& em, R (&ys)[Dims<D>::NS], const R (&yobs)[M], LlAcc& ll, int& st) {
+  bool bad = false;
+  R o[D][D];
+  ukf_offsets<R, D>(ys, a.ukf_c, o, bad);
+  R Y0[M], Yp[D][M], Ym[D][M], ybar[M];
+  em.h(ys, Y0);
+#pragma unroll
+  for (int r = 0; r < M; ++r) ybar[r] = R(0);
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    R xp[D], xm[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      xp[j] = (j >= i) ? ys[j] + o[i][j] : ys[j];
+      xm[j] = (j >= i) ? ys[j] - o[i][j] : ys[j];
+    }
+    em.h(xp, Yp[i]);
+    em.h(xm, Ym[i]);
+#pragma unroll
+    for (int r = 0; r < M; ++r) ybar[r] += Yp[i][r] + Ym[i][r];
+  }
+  R v[M], Sm[M][M], C[D][M];
+#pragma unroll
+  for (int r = 0; r < M; ++r) {
+    ybar[r] = rfma(a.ukf_wm0, Y0[r], a.ukf_wi * ybar[r]);
+    v[r] = yobs[r] - ybar[r];
+  }
+#pragma unroll
+  for (int r = 0; r < M; ++r)
+#pragma unroll
+    for (int c = 0; c < M; ++c) {
+      R acc = R(0);
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        acc = rfma(Yp[i][r] - ybar[r], Yp[i][c] - ybar[c], acc);
+        acc = rfma(Ym[i][r] - ybar[r], Ym[i][c] - ybar[c], acc);
+      }
+      Sm[r][c] = rfma(a.ukf_wc0 * (Y0[r] - ybar[r]), Y0[c] - ybar[c], rfma(a.ukf_wi, acc, a.Rm[r][c]));
+    }
+#pragma unroll
+  for (int k = 0; k < D; ++k)
+#pragma unroll
+    for (int c = 0; c < M; ++c) {
+      R acc = R(0);
+#pragma unroll
+      for (int i = 0; i <= k; ++i) acc = rfma(o[i][k], Yp[i][c] - Ym[i][c], acc);
+      C[k][c] = a.ukf_wi * acc;
+    }
+  ukf_finish<R, D, M>(ys, v, Sm, C, ll, st, bad);
+}
+
 // ---- filter sweep (EKF and UKF) -------------------------------------------------------------------
 // UKF:    unscented filter (inference_ukf.py:206-308) instead of the extended one (inference_ekf.py:202-326);
 // ZEROTH: EKF state_order == 'zeroth' (mean-only ODE + sqrt(dt) L Qc L^T, inference_ekf.py:126-138);
@@ -507,14 +674,14 @@ CDKF_DEV void ukf_update(const Args& a, R (&ys)[Dims<D>::NS], const R (&yobs)[M]
 constexpr int kOutNone = 0, kOutAll = 1, kOutSome = 2;
 
 template <typename R, int D, int M, typename Drift, bool UKF, bool ZEROTH, bool HSEL, int OUT, bool FORECAST = false,
-          bool GENERIC = false>
+          bool GENERIC = false, typename Emis = EmisLinearTag>
 __global__ __launch_bounds__(64, 1) void filter_reg_kernel(const RegArgs<R, D, M, Drift> a) {
 #include "cdkf_filter_reg_body.inc"
 }
 
 // the same sweep as a device function, for the run-time compiled kernels of user-supplied drifts (launch_custom.hip)
 template <typename R, int D, int M, typename Drift, bool UKF, bool ZEROTH, bool HSEL, int OUT, bool FORECAST = false,
-          bool GENERIC = false>
+          bool GENERIC = false, typename Emis = EmisLinearTag>
 CDKF_DEV void filter_reg_body(const RegArgs<R, D, M, Drift>& a) {
 #include "cdkf_filter_reg_body.inc"
 }

@@ -23,17 +23,27 @@ struct CustomDrift {
   std::string f_src, jac_src, g_src;
   bool has_g;
 };
+struct CustomEmission {
+  int d, m;
+  std::string h_src, jac_src;
+};
 std::vector<CustomDrift> g_drifts;
+std::vector<CustomEmission> g_emis;  // emission_kind = CDKF_EMISSION_CUSTOM_BASE + index
 std::mutex g_mutex;
 std::string g_src_dir;
 
-// kind, bytes per real, emission_dim, ukf, zeroth, forecast, smoother, generic Runge-Kutta tableau
-using Key = std::tuple<int, int, int, int, int, int, int, int>;
+// kind, bytes per real, emission_dim, ukf, zeroth, forecast, smoother, generic Runge-Kutta tableau, emission kind (0: linear)
+using Key = std::tuple<int, int, int, int, int, int, int, int, int>;
 struct Compiled {
   hipModule_t module = nullptr;
   hipFunction_t fn = nullptr;
 };
 std::map<Key, Compiled> g_modules;
+
+std::mutex& g_mutex_emis() {
+  static std::mutex m;
+  return m;
+}
 
 std::string source_dir() {
   if (!g_src_dir.empty()) return g_src_dir;
@@ -49,7 +59,7 @@ std::string source_dir() {
 }
 
 std::string generate_source(const CustomDrift& c, int bytes, int m, int ukf, int zeroth, int forecast, int smoother,
-                            int generic) {
+                            int generic, const CustomEmission* em) {
   std::string s;
   s += "#include \"cdkf_reg_kernels.h\"\n";
   s += "namespace cdkf {\n";
@@ -67,6 +77,18 @@ std::string generate_source(const CustomDrift& c, int bytes, int m, int ukf, int
   s += "  CDKF_DEV void divgrad(const R* x, R (&g)[D]) const {\n    const R* theta = th; (void)theta;\n";
   s += "    for (int i_ = 0; i_ < D; ++i_) g[i_] = R(0);\n";
   s += "#line 1 \"drift_divgrad\"\n" + c.g_src + "\n  }\n};\n}  // namespace cdkf\n";
+  if (em) {
+    // emission parameters eta = [the model's H block (m x d, row-major) | h_bias (m)], read from the argument block
+    s += "namespace cdkf {\ntemplate <typename R, int D, int M>\nstruct EmisCustom {\n";
+    s += "  static constexpr bool kCustom = true;\n  R eta_[M * D + M];\n";
+    s += "  template <typename Args> CDKF_DEV void load(const Args& a) {\n";
+    s += "    for (int r = 0; r < M; ++r) { for (int k = 0; k < D; ++k) eta_[r * D + k] = a.H[r][k]; eta_[M * D + r] = a.hb[r]; }\n  }\n";
+    s += "  CDKF_DEV void h(const R* x, R (&hx)[M]) const {\n    const R* eta = eta_; (void)eta;\n";
+    s += "#line 1 \"emission_h\"\n" + em->h_src + "\n  }\n";
+    s += "  CDKF_DEV void jac(const R* x, R (&H)[M][D]) const {\n    const R* eta = eta_; (void)eta;\n";
+    s += "    for (int r_ = 0; r_ < M; ++r_) for (int k_ = 0; k_ < D; ++k_) H[r_][k_] = R(0);\n";
+    s += "#line 1 \"emission_jacobian\"\n" + em->jac_src + "\n  }\n};\n}  // namespace cdkf\n";
+  }
   s += "using R = " + std::string(bytes == 8 ? "double" : "float") + ";\n";
   s += "constexpr int DD = " + std::to_string(c.d) + ", MM = " + std::to_string(m) + ";\n";
   s += "using Drift = cdkf::DriftCustom<R, DD>;\nusing Args = cdkf::RegArgs<R, DD, MM, Drift>;\n";
@@ -112,7 +134,7 @@ __device__ __forceinline__ void unpack(Args& a, const R* __restrict__ par, const
          "  unpack(a, par, ip, t, y, ll, fm, fP, pm, pP, status);\n";
     s += "  cdkf::filter_reg_body<R, DD, MM, Drift, " + std::string(ukf ? "true" : "false") + ", " +
          std::string(zeroth ? "true" : "false") + ", false, cdkf::kOutSome, " + std::string(forecast ? "true" : "false") + ", " +
-         std::string(generic ? "true" : "false") + ">(a);\n}\n";
+         std::string(generic ? "true" : "false") + (em ? ", cdkf::EmisCustom<R, DD, MM>" : "") + ">(a);\n}\n";
   } else {
     s += "extern \"C\" __global__ __launch_bounds__(64) void cdkf_custom_kernel(const R* par, const long* ip, const R* t, "
          "const R* y, R* ll, R* fm, R* fP, R* pm, R* pP, int* status, R* sm, R* sP) {\n  Args a;\n"
@@ -124,8 +146,14 @@ __device__ __forceinline__ void unpack(Args& a, const R* __restrict__ par, const
 
 // compile one variant; `code` receives the code object.  No GPU needed (the target is named explicitly).
 int compile_variant(const CustomDrift& c, const Key& key, const std::string& arch, std::vector<char>& code) {
+  CustomEmission em;
+  const int ek = std::get<8>(key);
+  if (ek) {
+    std::lock_guard<std::mutex> lock(g_mutex_emis());
+    em = g_emis[ek - CDKF_EMISSION_CUSTOM_BASE];
+  }
   const std::string src = generate_source(c, std::get<1>(key), std::get<2>(key), std::get<3>(key), std::get<4>(key),
-                                          std::get<5>(key), std::get<6>(key), std::get<7>(key));
+                                          std::get<5>(key), std::get<6>(key), std::get<7>(key), ek ? &em : nullptr);
   hiprtcProgram prog = nullptr;
   if (hiprtcCreateProgram(&prog, src.c_str(), "cdkf_custom_drift.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
     set_error("custom drift: hiprtcCreateProgram failed");
@@ -185,6 +213,31 @@ int get_function(int kind, const Key& key, hipFunction_t* fn) {
 
 }  // namespace
 
+bool custom_emission_kind(int ek, int d, int m) {
+  std::lock_guard<std::mutex> lock(g_mutex_emis());
+  const int idx = ek - CDKF_EMISSION_CUSTOM_BASE;
+  return idx >= 0 && idx < (int)g_emis.size() && g_emis[idx].d == d && g_emis[idx].m == m;
+}
+
+static int c_dim(int kind) {
+  std::lock_guard<std::mutex> lock(g_mutex);
+  const int idx = kind - CDKF_DRIFT_CUSTOM_BASE;
+  return (idx >= 0 && idx < (int)g_drifts.size()) ? g_drifts[idx].d : -1;
+}
+
+int custom_emission_register(int state_dim, int emission_dim, const char* h_src, const char* hjac_src) {
+  if (state_dim < 1 || state_dim > 6 || emission_dim < 1 || emission_dim > 6 || !h_src || !hjac_src) {
+    set_error("custom emission: need 1 <= state_dim, emission_dim <= 6 and sources for h and its Jacobian");
+    return CDKF_EINVAL;
+  }
+  std::lock_guard<std::mutex> lock(g_mutex_emis());
+  for (size_t k = 0; k < g_emis.size(); ++k)
+    if (g_emis[k].d == state_dim && g_emis[k].m == emission_dim && g_emis[k].h_src == h_src && g_emis[k].jac_src == hjac_src)
+      return CDKF_EMISSION_CUSTOM_BASE + (int)k;
+  g_emis.push_back(CustomEmission{state_dim, emission_dim, h_src, hjac_src});
+  return CDKF_EMISSION_CUSTOM_BASE + (int)g_emis.size() - 1;
+}
+
 bool custom_kind(int kind) {
   std::lock_guard<std::mutex> lock(g_mutex);
   return kind >= CDKF_DRIFT_CUSTOM_BASE && kind - CDKF_DRIFT_CUSTOM_BASE < (int)g_drifts.size();
@@ -221,6 +274,11 @@ int launch_custom(int algo, const cdkf_model* mdl, const cdkf_opts* o, int64_t N
   if (m > 6) {
     set_error("custom drifts run on the register-resident kernels: emission_dim <= 6 (got %d)", m);
     return CDKF_EUNSUPPORTED;
+  }
+  const int ek = mdl->emission_kind;
+  if (ek && !custom_emission_kind(ek, d, m)) {
+    set_error("emission_kind %d is not a custom emission registered for state_dim=%d, emission_dim=%d", ek, d, m);
+    return CDKF_EINVAL;
   }
   if (algo != 1 && o->state_order == CDKF_ORDER_SECOND && !c.has_g) {
     set_error("custom drift without grad(div f) source: state_order 'second' needs it (the reference differentiates the "
@@ -316,10 +374,10 @@ int launch_custom(int algo, const cdkf_model* mdl, const cdkf_opts* o, int64_t N
   };
   const int zeroth = (algo != 1 && o->state_order == CDKF_ORDER_ZEROTH) ? 1 : 0;
   if (!smoother) {
-    rc = run(Key(mdl->drift_kind, (int)sizeof(R), m, algo == 1, zeroth, o->forecast ? 1 : 0, 0, generic), a1, a2, a3, a4, null_r, null_r);
+    rc = run(Key(mdl->drift_kind, (int)sizeof(R), m, algo == 1, zeroth, o->forecast ? 1 : 0, 0, generic, ek), a1, a2, a3, a4, null_r, null_r);
   } else {
-    rc = run(Key(mdl->drift_kind, (int)sizeof(R), m, 0, zeroth, 0, 0, generic), a1, a2, null_r, null_r, null_r, null_r);
-    if (!rc) rc = run(Key(mdl->drift_kind, (int)sizeof(R), m, 0, 0, 0, 1, generic), a1, a2, null_r, null_r, a3, a4);
+    rc = run(Key(mdl->drift_kind, (int)sizeof(R), m, 0, zeroth, 0, 0, generic, ek), a1, a2, null_r, null_r, null_r, null_r);
+    if (!rc) rc = run(Key(mdl->drift_kind, (int)sizeof(R), m, 0, 0, 0, 1, generic, 0), a1, a2, null_r, null_r, a3, a4);
   }
   const int rc2 = param_pool_release(slot, stream);
   return rc ? rc : rc2;
@@ -347,7 +405,11 @@ int custom_register(int state_dim, int n_theta, const char* f_src, const char* j
   return CDKF_DRIFT_CUSTOM_BASE + (int)g_drifts.size() - 1;
 }
 
-int custom_compile_check(int kind, int bytes_per_real, int emission_dim, int algo, int state_order) {
+int custom_compile_check(int kind, int bytes_per_real, int emission_dim, int algo, int state_order, int emission_kind) {
+  if (emission_kind && !custom_emission_kind(emission_kind, c_dim(kind), emission_dim)) {
+    set_error("custom emission %d is not registered for this state / emission dimension", emission_kind);
+    return CDKF_EINVAL;
+  }
   if (!custom_kind(kind) || (bytes_per_real != 4 && bytes_per_real != 8) || emission_dim < 1 || emission_dim > 6 || algo < 0 ||
       algo > 2) {
     set_error("custom drift compile check: bad arguments");
@@ -360,8 +422,8 @@ int custom_compile_check(int kind, int bytes_per_real, int emission_dim, int alg
   }
   std::vector<char> code;
   const int zeroth = (algo != 1 && state_order == CDKF_ORDER_ZEROTH) ? 1 : 0;
-  int rc = compile_variant(c, Key(kind, bytes_per_real, emission_dim, algo == 1, zeroth, 0, 0, 0), "gfx950", code);
-  if (!rc && algo == 2) rc = compile_variant(c, Key(kind, bytes_per_real, emission_dim, 0, 0, 0, 1, 0), "gfx950", code);
+  int rc = compile_variant(c, Key(kind, bytes_per_real, emission_dim, algo == 1, zeroth, 0, 0, 0, emission_kind), "gfx950", code);
+  if (!rc && algo == 2) rc = compile_variant(c, Key(kind, bytes_per_real, emission_dim, 0, 0, 0, 1, 0, 0), "gfx950", code);
   return rc;
 }
 

@@ -18,7 +18,8 @@ from typing import List, Optional, Tuple, Union
 import numpy as np
 
 from . import _ffi
-from .params import (EKFHyperParams, EnKFHyperParams, GSSMForecast, LearnableCustomDrift, LearnableLinear, LearnableLorenz63,
+from .params import (EKFHyperParams, EnKFHyperParams, GSSMForecast, LearnableCustomDrift, LearnableCustomEmission, LearnableLinear,
+                     LearnableLorenz63,
                      LearnableLorenz96,
                      LearnableMatrix, LearnableMLP, LearnableVector, ParameterProperties, ParamsCDNLGSSM,
                      ParamsCDNLGSSMDynamics, ParamsCDNLGSSMEmissions, ParamsLGSSMInitial, PosteriorGSSMFiltered,
@@ -53,13 +54,50 @@ def _model_block(params: ParamsCDNLGSSM) -> _ffi.ModelBlock:
             "(LearnableLinear, LearnableLorenz63, LearnableLorenz96, LearnableMLP) and is not a LearnableCustomDrift "
             "(C source compiled at run time; Python callables cannot cross the C ABI)")
     h = params.emissions.emission_function
+    if isinstance(h, LearnableCustomEmission):
+        # a custom emission runs on the run-time compiled kernels: the drift has to be source as well
+        d = int(np.asarray(params.initial.mean.f()).shape[0])
+        m = int(np.asarray(params.emissions.emission_cov.f()).shape[0])
+        if kind < _ffi.DRIFT_CUSTOM_BASE:
+            src = _builtin_drift_source(drift, d)
+            kind = _ffi.register_custom_drift(d, theta.size, *src)
+            hidden = (0, 0)
+        eta = np.atleast_1d(np.asarray(h.eta, dtype=np.float64)).ravel()
+        if eta.size > m * d + m:
+            raise ValueError(f"LearnableCustomEmission.eta has {eta.size} entries; at most emission_dim * (state_dim + 1) = {m * d + m}")
+        eta = np.concatenate([eta, np.zeros(m * d + m - eta.size)])
+        ek = _ffi.register_custom_emission(d, m, h.h_src, h.hjac_src)
+        return _ffi.ModelBlock(
+            kind, theta, params.dynamics.diffusion_coefficient.f(), params.dynamics.diffusion_cov.f(), eta[:m * d].reshape(m, d),
+            eta[m * d:], params.emissions.emission_cov.f(), params.initial.mean.f(), params.initial.cov.f(), hidden, emission_kind=ek)
     if not isinstance(h, LearnableLinear):
         raise NotImplementedError(
-            f"emission_function of type {type(h).__name__} is not supported: the HIP path implements the "
-            "reference's LearnableLinear emission h(x) = weights @ x + bias")
+            f"emission_function of type {type(h).__name__} is not supported: the HIP path implements the reference's "
+            "LearnableLinear emission h(x) = weights @ x + bias, or a LearnableCustomEmission (C source compiled at run time)")
     return _ffi.ModelBlock(
         kind, theta, params.dynamics.diffusion_coefficient.f(), params.dynamics.diffusion_cov.f(), h.weights, h.bias,
         params.emissions.emission_cov.f(), params.initial.mean.f(), params.initial.cov.f(), hidden)
+
+
+def _builtin_drift_source(drift, d: int):
+    """(f_src, jac_src, divgrad_src) of a registry drift, for the run-time compiled kernels (needed when the EMISSION is
+    user-defined: those kernels take the whole model as source)."""
+    if isinstance(drift, LearnableLorenz63):
+        return ("fx[0] = theta[0] * (x[1] - x[0]); fx[1] = x[0] * (theta[1] - x[2]) - x[1]; fx[2] = x[0] * x[1] - theta[2] * x[2];",
+                "F[0][0] = -theta[0]; F[0][1] = theta[0]; F[1][0] = theta[1] - x[2]; F[1][1] = R(-1); F[1][2] = -x[0]; "
+                "F[2][0] = x[1]; F[2][1] = x[0]; F[2][2] = -theta[2];", "")
+    if isinstance(drift, LearnableLinear):
+        f = " ".join(f"fx[{i}] = theta[{d * d + i}]" + "".join(f" + theta[{i * d + j}] * x[{j}]" for j in range(d)) + ";" for i in range(d))
+        jac = " ".join(f"F[{i}][{j}] = theta[{i * d + j}];" for i in range(d) for j in range(d))
+        return f, jac, ""
+    if isinstance(drift, LearnableLorenz96):
+        f = " ".join(f"fx[{i}] = (x[{(i + 1) % d}] - x[{(i - 2) % d}]) * x[{(i - 1) % d}] - x[{i}] + theta[0];" for i in range(d))
+        jac = " ".join(f"F[{i}][{(i + 1) % d}] = x[{(i - 1) % d}]; F[{i}][{(i - 2) % d}] = -x[{(i - 1) % d}]; "
+                       f"F[{i}][{(i - 1) % d}] = x[{(i + 1) % d}] - x[{(i - 2) % d}]; F[{i}][{i}] = R(-1);" for i in range(d))
+        return f, jac, ""
+    raise NotImplementedError(
+        f"a LearnableCustomEmission needs the drift as source: {type(drift).__name__} has no source form here (use "
+        "LearnableCustomDrift, LearnableLorenz63, LearnableLinear or LearnableLorenz96 with state_dim <= 6)")
 
 
 def _opts(hyperparams, num_iter: int = 1):
@@ -364,6 +402,8 @@ def cdnlgssm_emissions(params: ParamsCDNLGSSM, t_states, state_means, state_covs
     mu = np.asarray(state_means)
     if dtype is None:
         dtype = np.float32 if mu.dtype == np.float32 else np.float64
+    if isinstance(params.emissions.emission_function, LearnableCustomEmission):
+        raise NotImplementedError("emission moments are implemented for the linear emission only")
     mdl = _model_block(params)
     return _ffi.emission_moments(mdl, mu, None if state_covs is None else np.asarray(state_covs), dtype)
 

@@ -111,6 +111,27 @@ class LearnableCustomDrift(NamedTuple):
         return self.py_f(x, u, t)
 
 
+class LearnableCustomEmission(NamedTuple):
+    """A user-defined (non-linear) emission function for the HIP path -- the counterpart of passing any callable as
+    ``ParamsCDNLGSSMEmissions.emission_function`` in the reference (linearised by the EKF with jacfwd, inference_ekf.py:258-259;
+    evaluated at the sigma points by the UKF, inference_ukf.py:162-203):
+
+      h_src     statements computing ``hx[r]`` from ``x[k]`` and ``eta[j]``            e.g. "hx[0] = eta[0] * sin(x[0]);"
+      hjac_src  statements assigning the non-zero ``H[r][k]`` = d h_r / d x_k          e.g. "H[0][0] = eta[0] * cos(x[0]);"
+
+    ``eta``: the emission's parameter vector, at most emission_dim * (state_dim + 1) entries (it travels in the H / bias
+    block of the C model).  state_dim, emission_dim <= 6.  ``py_h`` (optional): the same function as a Python callable."""
+    eta: Any
+    h_src: str
+    hjac_src: str
+    py_h: Optional[Any] = None
+
+    def f(self, x, u=None, t=None):
+        if self.py_h is None:
+            raise NotImplementedError("LearnableCustomEmission: no Python callable was given (py_h)")
+        return self.py_h(x, u, t)
+
+
 class ParamsLGSSMInitial(NamedTuple):
     mean: Any
     cov: Any

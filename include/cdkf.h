@@ -62,6 +62,7 @@ extern "C" {
 #define CDKF_SOLVER_EULER 6    /* diffrax.Euler */
 
 #define CDKF_DRIFT_CUSTOM_BASE 1000 /* kinds >= this come from cdkf_custom_drift_register() */
+#define CDKF_EMISSION_CUSTOM_BASE 1000 /* emission kinds >= this come from cdkf_custom_emission_register() */
 #define CDKF_DRIFT_MLP_TANH 3 /* theta = [W1 (h1*d), b1 (h1), W2 (h2*h1), b2 (h2), W3 (d*h2), b3 (d)];
                                  f = W3 tanh(W2 tanh(W1 x + b1) + b2) + b3 */
 
@@ -87,7 +88,8 @@ typedef struct cdkf_model {
   int32_t emission_dim; /* m */
   int32_t hidden1;      /* MLP only */
   int32_t hidden2;      /* MLP only */
-  int32_t reserved;
+  int32_t emission_kind; /* 0: linear emission h(x) = H x + h_bias; >= CDKF_EMISSION_CUSTOM_BASE: a registered custom emission,
+                            whose parameter vector eta is [H (m*d, row-major) | h_bias (m)] (custom drift kinds only) */
   int64_t n_theta;
   const double* theta; /* [n_theta] drift parameters */
   const double* L;     /* [d,d] diffusion coefficient  (params.dynamics.diffusion_coefficient) */
@@ -237,9 +239,21 @@ int cdkf_emission_moments_f32_dev(const cdkf_model* mdl, int64_t rows, const flo
  *      errors in the snippets surface through cdkf_last_error(). */
 int cdkf_custom_drift_register(int state_dim, int n_theta, const char* f_src, const char* jac_src,
                                const char* divgrad_src);
+/* A user-supplied EMISSION function (the reference accepts any callable h and linearises it with jacfwd,
+ * inference_ekf.py:258-259, or pushes the sigma points through it, inference_ukf.py:162-203):
+ *   h_src     body computing  hx[r] = h_r(x, eta)                 (x: const R*, eta: const R*, R = float or double)
+ *   hjac_src  body assigning the NON-ZERO entries H[r][k] = d h_r / d x_k   (H is zeroed first)
+ * eta is the model's emission block read as a flat vector: eta[r*d + k] = cdkf_model.H[r][k], eta[m*d + r] = h_bias[r].
+ * e.g. observing the sine of a pendulum angle: h_src "hx[0] = eta[0] * sin(x[0]);"  hjac_src "H[0][0] = eta[0] * cos(x[0]);"
+ * Returns the value for cdkf_model.emission_kind (>= CDKF_EMISSION_CUSTOM_BASE) or a negative CDKF_E* code.  Runs on the
+ * run-time compiled kernels: the drift must be a custom kind too.  EKF (re-linearised in every update iteration) and UKF
+ * filters, EKF smoother; not the gradient or emission-moment entry points. */
+int cdkf_custom_emission_register(int state_dim, int emission_dim, const char* h_src, const char* hjac_src);
 /* compile (without loading: no GPU needed) the kernel for one variant -- algo 0 EKF filter, 1 UKF filter, 2 EKF
- * smoother -- to check the snippets early; 0 or a negative CDKF_E* code with the compiler log in cdkf_last_error() */
-int cdkf_custom_drift_compile(int drift_kind, int bytes_per_real, int emission_dim, int algo, int state_order);
+ * smoother; emission_kind 0 or a registered custom emission -- to check the snippets early; 0 or a negative CDKF_E* code
+ * with the compiler log in cdkf_last_error() */
+int cdkf_custom_drift_compile(int drift_kind, int bytes_per_real, int emission_dim, int algo, int state_order,
+                              int emission_kind);
 /* directory holding the kernel headers (cdkf_reg_kernels.h ...) for run-time compilation; default: <dir of this
  * library>/../csrc */
 void cdkf_set_kernel_source_dir(const char* dir);

@@ -287,13 +287,18 @@ class Model:
     """The pieces of ParamsCDNLGSSM the hot path touches (cdnlgssm_utils.py:88-209): drift, L, Qc,
     linear emission h(x) = H x + bias (LearnableLinear), R, initial mean / covariance."""
 
-    def __init__(self, drift, L, Qc, H, bias, R, m0, P0):
+    def __init__(self, drift, L, Qc, H, bias, R, m0, P0, emission=None):
+        """``emission``: optional pair of vectorised callables (h(x, eta) -> [N,m], jac(x, eta) -> [N,m,d]) for a
+        non-linear emission function (the reference accepts any callable, cdnlgssm_utils.py:38-61, and linearises it with
+        jacfwd, inference_ekf.py:258); its parameter vector eta is concat(H.ravel(), bias) -- the storage a run-time
+        compiled custom emission (cdkf_custom_emission_register) reads."""
         self.drift = drift
         self.L, self.Qc, self.H, self.bias, self.R, self.m0, self.P0 = (
             np.asarray(a, dtype=np.float64) for a in (L, Qc, H, bias, R, m0, P0)
         )
         self.d = self.m0.shape[0]
         self.m = self.H.shape[0]
+        self.emission = emission
 
     def cast(self, dtype):
         mdl = Model.__new__(Model)
@@ -301,7 +306,22 @@ class Model:
         for k in ("L", "Qc", "H", "bias", "R", "m0", "P0"):
             setattr(mdl, k, getattr(self, k).astype(dtype))
         mdl.d, mdl.m = self.d, self.m
+        mdl.emission = self.emission
         return mdl
+
+    def h(self, x):
+        """Emission mean at x [..., d] -> [..., m]."""
+        if self.emission is None:
+            return x @ self.H.T + self.bias
+        eta = np.concatenate([self.H.ravel(), self.bias])
+        return np.asarray(self.emission[0](x, eta), dtype=x.dtype)
+
+    def Hjac(self, x):
+        """Emission Jacobian at x [N, d] -> [N, m, d]."""
+        if self.emission is None:
+            return np.broadcast_to(self.H, x.shape[:-1] + self.H.shape)
+        eta = np.concatenate([self.H.ravel(), self.bias])
+        return np.asarray(self.emission[1](x, eta), dtype=x.dtype)
 
 
 # --------------------------------------------------------------------------------------
@@ -470,13 +490,14 @@ def ekf_predict(mdl, m, P, t0, t1, state_order="second", dt0=0.01, max_steps=100
 
 
 def ekf_condition_on(mdl, m, P, y, num_iter=1):
-    """inference_ekf.py:153-199 with a linear emission h(x) = H x + bias."""
-    H, R, bias = mdl.H, mdl.R, mdl.bias
+    """inference_ekf.py:153-199: the emission is re-linearised at the current mean in every iteration."""
+    R = mdl.R
     for _ in range(num_iter):
-        S = R + H @ P @ H.T
+        H = mdl.Hjac(m)
+        S = R + H @ P @ np.swapaxes(H, -1, -2)
         K = np.swapaxes(psd_solve(S, H @ P), -1, -2)
         Pn = P - K @ S @ np.swapaxes(K, -1, -2)
-        mn = m + np.einsum("nij,nj->ni", K, y - (m @ H.T + bias))
+        mn = m + np.einsum("nij,nj->ni", K, y - mdl.h(m))
         m, P = mn, Pn
     return m, symmetrize(P)
 
@@ -518,8 +539,9 @@ def ekf_filter(
     }
     for k in range(T):
         yk = y[:, k]
-        S = mdl.H @ pP @ mdl.H.T + mdl.R
-        ll = ll + mvn_logpdf(yk, pm @ mdl.H.T + mdl.bias, S)
+        Hk = mdl.Hjac(pm)
+        S = Hk @ pP @ np.swapaxes(Hk, -1, -2) + mdl.R
+        ll = ll + mvn_logpdf(yk, mdl.h(pm), S)
         fm, fP = ekf_condition_on(mdl, pm, pP, yk, num_iter)
         pm, pP = ekf_predict(mdl, fm, fP, t0s[:, k], t1s[:, k], state_order, dt0, max_steps, cov_rescaling)
         out["filtered_means"][:, k] = fm
@@ -633,7 +655,7 @@ def ukf_filter(mdl: Model, t, y, alpha=math.sqrt(3), beta=2, kappa=1, dt0=0.01, 
         yk = y[:, k]
         # _condition_on (inference_ukf.py:162-203)
         X = ukf_sigmas(pm, pP, lamb)
-        Y = X @ mdl.H.T + mdl.bias
+        Y = mdl.h(X.reshape(-1, d)).reshape(X.shape[:2] + (mdl.m,))
         ymean = np.einsum("s,nsj->nj", w_mean, Y)
         dY = Y - ymean[:, None, :]
         dX = X - pm[:, None, :]

@@ -64,17 +64,17 @@ def test_register_and_compile_all_variants():
     for kind in (k1, k2):
         for nbytes in (8, 4):
             for algo in (0, 1, 2):
-                assert L.cdkf_custom_drift_compile(kind, nbytes, 1, algo, 1) == 0, L.cdkf_last_error().decode()
-    assert L.cdkf_custom_drift_compile(k2, 8, 3, 0, 0) == 0                # zeroth order, emission_dim 3
+                assert L.cdkf_custom_drift_compile(kind, nbytes, 1, algo, 1, 0) == 0, L.cdkf_last_error().decode()
+    assert L.cdkf_custom_drift_compile(k2, 8, 3, 0, 0, 0) == 0                # zeroth order, emission_dim 3
     with pytest.raises(_ffi.CdkfError):
         _ffi.register_custom_drift(9, 1, PEND_F, PEND_J, None)             # state_dim > 6
-    assert L.cdkf_custom_drift_compile(12345, 8, 1, 0, 1) != 0
+    assert L.cdkf_custom_drift_compile(12345, 8, 1, 0, 1, 0) != 0
 
 
 def test_broken_snippet_reports_the_compiler_diagnostic():
     kind = _ffi.register_custom_drift(2, 1, "fx[0] = x[1]; fx[1] = -theta[0] * sine(x[0]);", "F[0][1] = R(1);", None)
     L = _ffi.lib()
-    assert L.cdkf_custom_drift_compile(kind, 8, 1, 0, 1) != 0
+    assert L.cdkf_custom_drift_compile(kind, 8, 1, 0, 1, 0) != 0
     msg = L.cdkf_last_error().decode()
     assert "drift_f:1" in msg and "sine" in msg
 
@@ -145,3 +145,109 @@ def test_custom_drift_second_order_with_divgrad(hip_lib):
     assert relerr(post.filtered_covariances, ref["filtered_covariances"]) < 1e-11
     sm = cd.cdnlgssm_smoother(P, y, t[..., None], hyp)
     assert relerr(sm.smoothed_means, refs["smoothed_means"]) < 1e-10
+
+
+# ---- user-supplied emission functions ---------------------------------------------------------------------------------------
+SIN_H = "hx[0] = eta[0] * sin(x[0]) + eta[1];"
+SIN_J = "H[0][0] = eta[0] * cos(x[0]);"
+QUAD_H = "hx[0] = eta[0] * x[0] * x[0] + x[2]; hx[1] = eta[1] * x[1] + eta[2] * tanh(x[2]);"
+QUAD_J = "H[0][0] = R(2) * eta[0] * x[0]; H[0][2] = R(1); H[1][1] = eta[1]; H[1][2] = eta[2] * (R(1) - tanh(x[2]) * tanh(x[2]));"
+
+
+def sin_emission():
+    h = lambda x, eta: (eta[0] * np.sin(x[..., 0]) + eta[1])[..., None]
+
+    def jac(x, eta):
+        H = np.zeros(x.shape[:-1] + (1, 2), x.dtype)
+        H[..., 0, 0] = eta[0] * np.cos(x[..., 0])
+        return H
+    return h, jac
+
+
+def quad_emission():
+    h = lambda x, eta: np.stack([eta[0] * x[..., 0] ** 2 + x[..., 2], eta[1] * x[..., 1] + eta[2] * np.tanh(x[..., 2])], -1)
+
+    def jac(x, eta):
+        H = np.zeros(x.shape[:-1] + (2, 3), x.dtype)
+        H[..., 0, 0] = 2 * eta[0] * x[..., 0]
+        H[..., 0, 2] = 1
+        H[..., 1, 1] = eta[1]
+        H[..., 1, 2] = eta[2] * (1 - np.tanh(x[..., 2]) ** 2)
+        return H
+    return h, jac
+
+
+def test_custom_emission_compiles_without_gpu():
+    kd = _ffi.register_custom_drift(2, 2, PEND_F, PEND_J, None)
+    ke = _ffi.register_custom_emission(2, 1, SIN_H, SIN_J)
+    assert ke >= 1000 and _ffi.register_custom_emission(2, 1, SIN_H, SIN_J) == ke
+    L = _ffi.lib()
+    for algo in (0, 1, 2):
+        assert L.cdkf_custom_drift_compile(kd, 8, 1, algo, 1, ke) == 0, L.cdkf_last_error().decode()
+    assert L.cdkf_custom_drift_compile(kd, 8, 2, 0, 1, ke) != 0          # registered for emission_dim 1
+    bad = _ffi.register_custom_emission(2, 1, "hx[0] = sinus(x[0]);", SIN_J)
+    assert L.cdkf_custom_drift_compile(kd, 4, 1, 0, 1, bad) != 0 and "emission_h:1" in L.cdkf_last_error().decode()
+
+
+@pytest.mark.gpu
+def test_custom_emission_pendulum_sine(hip_lib):
+    """The classic non-linear-observation pendulum (angle observed through its sine): EKF with 1 and 3 re-linearisations
+    (iterated EKF, inference_ekf.py:183-199), UKF with the sigma points pushed through h (inference_ukf.py:162-203),
+    EKF smoother -- against the oracle evaluating the same h and its Jacobian as NumPy callables."""
+    rng = np.random.default_rng(81)
+    theta, eta = np.array([2.0, 0.3]), np.array([1.5, 0.2])
+    mdl = o.Model(pendulum_oracle(theta), np.eye(2), np.array([[0.05, 0.01], [0.01, 0.1]]), eta[None, :], np.zeros(1),
+                  0.1 * np.eye(1), np.array([0.7, 0.0]), 0.3 * np.eye(2), emission=sin_emission())
+    # eta travels as [H.ravel() | bias]: H = [[1.5, 0.2]], bias = [0]  ->  eta = (1.5, 0.2, 0)
+    N, T = 40, 30
+    t = o.irregular_times(rng, N, T, 0.08)
+    y = o.simulate(mdl, t, rng) if False else (mdl.h(np.cumsum(rng.standard_normal((N, T, 2)) * 0.05, axis=1) + mdl.m0)
+                                               + 0.3 * rng.standard_normal((N, T, 1)))
+    P = cd.ParamsCDNLGSSM(
+        initial=cd.ParamsLGSSMInitial(cd.LearnableVector(mdl.m0), cd.LearnableMatrix(mdl.P0)),
+        dynamics=cd.ParamsCDNLGSSMDynamics(cd.LearnableCustomDrift(theta, PEND_F, PEND_J), cd.LearnableMatrix(mdl.L),
+                                           cd.LearnableMatrix(mdl.Qc), 2.0),
+        emissions=cd.ParamsCDNLGSSMEmissions(cd.LearnableCustomEmission(eta, SIN_H, SIN_J), cd.LearnableMatrix(mdl.R)))
+    for num_iter in (1, 3):
+        ref = o.ekf_filter(mdl, t, y, state_order="first", num_iter=num_iter)
+        post = cd.cdnlgssm_filter(P, y, t[..., None], cd.EKFHyperParams(state_order="first"), num_iter=num_iter)
+        for k in FILTER_KEYS:
+            assert relerr(getattr(post, k), ref[k]) < 1e-11, (num_iter, k)
+        np.testing.assert_allclose(post.marginal_loglik, ref["marginal_loglik"], rtol=1e-11)
+    refu = o.ukf_filter(mdl, t, y)
+    postu = cd.cdnlgssm_filter(P, y, t[..., None], cd.UKFHyperParams())
+    for k in FILTER_KEYS:
+        assert relerr(getattr(postu, k), refu[k]) < 1e-10, k
+    np.testing.assert_allclose(postu.marginal_loglik, refu["marginal_loglik"], rtol=1e-10)
+    refs = o.ekf_smoother(mdl, t, y, state_order="first")
+    sm = cd.cdnlgssm_smoother(P, y, t[..., None], cd.EKFHyperParams(state_order="first"))
+    assert relerr(sm.smoothed_means, refs["smoothed_means"]) < 1e-10
+    p32 = cd.cdnlgssm_filter(P, y.astype(np.float32), t[..., None].astype(np.float32), cd.EKFHyperParams(state_order="first"))
+    assert relerr(p32.filtered_means, o.ekf_filter(mdl, t, y, state_order="first")["filtered_means"]) < 5e-4
+    with pytest.raises(NotImplementedError):
+        cd.cdnlgssm_emissions(P, t[0][:, None], post.filtered_means[0], post.filtered_covariances[0])
+
+
+@pytest.mark.gpu
+def test_custom_emission_with_builtin_drift(hip_lib):
+    """A registry drift (Lorenz-63) under a user-defined two-component emission: the host turns the drift into source so
+    that the whole model goes through the run-time compiled kernel; default state_order='second'."""
+    rng = np.random.default_rng(82)
+    eta = np.array([0.05, 1.2, 3.0])
+    base = o.lorenz63_model(2)
+    Hblk = np.concatenate([eta, np.zeros(3)]).reshape(2, 3)          # eta padded into the [m, d] block, bias = 0
+    mdl = o.Model(base.drift, base.L, base.Qc, Hblk, np.zeros(2), base.R, base.m0, base.P0, emission=quad_emission())
+    N, T = 20, 25
+    t = o.irregular_times(rng, N, T, 0.03)
+    y = mdl.h(base.m0 + np.cumsum(rng.standard_normal((N, T, 3)) * 0.3, axis=1)) + rng.standard_normal((N, T, 2))
+    P = params_for(base, cd.LearnableLorenz63(10.0, 28.0, 8 / 3))
+    P = P._replace(emissions=cd.ParamsCDNLGSSMEmissions(cd.LearnableCustomEmission(eta, QUAD_H, QUAD_J), cd.LearnableMatrix(base.R)))
+    ref = o.ekf_filter(mdl, t, y)
+    post = cd.cdnlgssm_filter(P, y, t[..., None])
+    for k in FILTER_KEYS:
+        assert relerr(getattr(post, k), ref[k]) < 1e-10, k
+    refu = o.ukf_filter(mdl, t, y)
+    postu = cd.cdnlgssm_filter(P, y, t[..., None], cd.UKFHyperParams())
+    assert relerr(postu.filtered_covariances, refu["filtered_covariances"]) < 1e-9
+    with pytest.raises(NotImplementedError, match="no gradient kernel"):
+        cd.cdnlgssm_loglik_and_grad(P, y, t[..., None])
