@@ -9,7 +9,7 @@ from .linear import (ContDiscreteLinearGaussianSSM, KFHyperParams, ParamsCDLGSSM
                      ParamsLGSSMEmissions, cdlgssm_filter, cdlgssm_smoother)
 from .models import (ContDiscreteNonlinearGaussianSSM, cdnlgssm_emissions, cdnlgssm_filter, cdnlgssm_forecast,
                      cdnlgssm_loglik_and_grad, cdnlgssm_loglik_and_grad_all, cdnlgssm_smoother)
-from .params import (EKFHyperParams, EnKFHyperParams, GSSMForecast, LearnableCustomDrift, LearnableCustomEmission, LearnableLinear, LearnableLorenz63, LearnableLorenz96,
+from .params import (ConstantStepSize, PIDController, EKFHyperParams, EnKFHyperParams, GSSMForecast, LearnableCustomDrift, LearnableCustomEmission, LearnableLinear, LearnableLorenz63, LearnableLorenz96,
                      LearnableMatrix, LearnableMLP, LearnableVector, ParameterProperties, ParamsCDNLGSSM,
                      ParamsCDNLGSSMDynamics, ParamsCDNLGSSMEmissions, ParamsLGSSMInitial, PosteriorGSSMFiltered,
                      PosteriorGSSMSmoothed, UKFHyperParams)
@@ -21,5 +21,5 @@ __all__ = [
     "ParamsCDNLGSSMEmissions", "ParamsCDNLGSSM", "PosteriorGSSMFiltered", "PosteriorGSSMSmoothed",
     "ContDiscreteLinearGaussianSSM", "KFHyperParams", "ParamsCDLGSSM", "ParamsCDLGSSMDynamics", "ParamsLGSSMEmissions",
     "cdlgssm_filter", "cdlgssm_smoother", "cdnlgssm_forecast", "cdnlgssm_emissions", "GSSMForecast",
-    "cdnlgssm_loglik_and_grad", "cdnlgssm_loglik_and_grad_all", "LearnableCustomDrift", "LearnableCustomEmission",
+    "cdnlgssm_loglik_and_grad", "cdnlgssm_loglik_and_grad_all", "LearnableCustomDrift", "LearnableCustomEmission", "PIDController", "ConstantStepSize",
 ]

@@ -66,7 +66,7 @@ class CdkfOpts(C.Structure):
         ("layout", C.c_int32),
         ("forecast", C.c_int32),
         ("solver", C.c_int32),
-        ("reserved", C.c_int32),
+        ("adaptive", C.c_int32),
         ("max_steps", C.c_int64),
         ("dt0", C.c_double),
         ("dt_final", C.c_double),
@@ -74,6 +74,11 @@ class CdkfOpts(C.Structure):
         ("ukf_alpha", C.c_double),
         ("ukf_beta", C.c_double),
         ("ukf_kappa", C.c_double),
+        ("rtol", C.c_double),
+        ("atol", C.c_double),
+        ("pid_p", C.c_double),
+        ("pid_i", C.c_double),
+        ("pid_d", C.c_double),
     ]
 
 

@@ -48,9 +48,18 @@ int check_common(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T
     set_error("opts.layout must be CDKF_LAYOUT_NT, CDKF_LAYOUT_TN or CDKF_LAYOUT_TCN");
     return CDKF_EINVAL;
   }
-  if (o->solver < CDKF_SOLVER_DOPRI5 || o->solver > CDKF_SOLVER_EULER || o->reserved != 0) {
-    set_error("opts.solver must be one of CDKF_SOLVER_* (got %d) and opts.reserved 0", o->solver);
+  if (o->solver < CDKF_SOLVER_DOPRI5 || o->solver > CDKF_SOLVER_EULER || (o->adaptive != 0 && o->adaptive != 1)) {
+    set_error("opts.solver must be one of CDKF_SOLVER_* (got %d) and opts.adaptive 0 or 1 (got %d)", o->solver, o->adaptive);
     return CDKF_EINVAL;
+  }
+  if (o->adaptive) {
+    const bool has_estimate = o->solver == CDKF_SOLVER_DOPRI5 || o->solver == CDKF_SOLVER_TSIT5 || o->solver == CDKF_SOLVER_BOSH3 ||
+                              o->solver == CDKF_SOLVER_HEUN;
+    if (!has_estimate || !(o->rtol >= 0) || !(o->atol >= 0) || !(o->rtol + o->atol > 0)) {
+      set_error("adaptive stepping needs a method with an embedded error estimate (DOPRI5, TSIT5, BOSH3, HEUN) and rtol, atol >= 0 "
+                "not both zero (solver %d, rtol %g, atol %g)", o->solver, o->rtol, o->atol);
+      return CDKF_EINVAL;
+    }
   }
   if (o->num_iter < 1 || !(o->dt0 > 0) || o->max_steps < 1) {
     set_error("need num_iter >= 1, dt0 > 0, max_steps >= 1");
@@ -366,7 +375,12 @@ void cdkf_default_opts(cdkf_opts* o) {
   o->layout = CDKF_LAYOUT_NT;
   o->forecast = 0;
   o->solver = CDKF_SOLVER_DOPRI5;
-  o->reserved = 0;
+  o->adaptive = 0;
+  o->rtol = 1e-3;
+  o->atol = 1e-6;
+  o->pid_p = 0.0;
+  o->pid_i = 1.0;
+  o->pid_d = 0.0;
   o->max_steps = 100000;
   o->dt0 = 0.01;
   o->dt_final = 1e-10;

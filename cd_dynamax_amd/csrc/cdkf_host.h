@@ -67,7 +67,8 @@ void lql_packed(const double* L, const double* Qc, int d, double scale, R* out_p
 // Runge-Kutta tableaus selectable through opts.solver (CDKF_SOLVER_*); published coefficients (Euler; explicit trapezoid =
 // diffrax.Heun; explicit midpoint; Ralston; Bogacki-Shampine 3(2) = diffrax.Bosh3; Tsitouras 5(4) = diffrax.Tsit5)
 template <typename R>
-inline bool fill_rk_tab(int solver, RkTab<R>& tb) {
+inline bool fill_rk_tab(const cdkf_opts* o, RkTab<R>& tb) {
+  const int solver = o->solver;
   static const double dp5[6][5] = {{0}, {1.0 / 5}, {3.0 / 40, 9.0 / 40}, {44.0 / 45, -56.0 / 15, 32.0 / 9},
                                    {19372.0 / 6561, -25360.0 / 2187, 64448.0 / 6561, -212.0 / 729},
                                    {9017.0 / 3168, -355.0 / 33, 46732.0 / 5247, 49.0 / 176, -5103.0 / 18656}};
@@ -79,16 +80,34 @@ inline bool fill_rk_tab(int solver, RkTab<R>& tb) {
                                     -0.028269050394068383}};
   static const double ts5b[6] = {0.09646076681806523, 0.01, 0.4798896504144996, 1.379008574103742, -3.290069515436081,
                                  2.324710524099774};
-  double a[6][5] = {{0}}, b[6] = {0};
-  int stages = 0;
+  double a[6][5] = {{0}}, b[6] = {0}, be[7] = {0};
+  int stages = 0, order = 0, fsal = 0;
   switch (solver) {
-    case CDKF_SOLVER_DOPRI5: stages = 6; std::memcpy(a, dp5, sizeof(a)); std::memcpy(b, dp5b, sizeof(b)); break;
-    case CDKF_SOLVER_TSIT5: stages = 6; std::memcpy(a, ts5, sizeof(a)); std::memcpy(b, ts5b, sizeof(b)); break;
+    case CDKF_SOLVER_DOPRI5: {
+      stages = 6; order = 5; fsal = 1;
+      std::memcpy(a, dp5, sizeof(a)); std::memcpy(b, dp5b, sizeof(b));
+      const double e[7] = {35.0 / 384 - 5179.0 / 57600, 0, 500.0 / 1113 - 7571.0 / 16695, 125.0 / 192 - 393.0 / 640,
+                           -2187.0 / 6784 + 92097.0 / 339200, 11.0 / 84 - 187.0 / 2100, -1.0 / 40};
+      std::memcpy(be, e, sizeof(be));
+      break;
+    }
+    case CDKF_SOLVER_TSIT5: {
+      stages = 6; order = 5; fsal = 1;
+      std::memcpy(a, ts5, sizeof(a)); std::memcpy(b, ts5b, sizeof(b));
+      const double e[7] = {-0.00178001105222577714, -0.0008164344596567469, 0.007880878010261995, -0.1447110071732629,
+                           0.5823571654525552, -0.45808210592918697, 0.015151515151515152};
+      std::memcpy(be, e, sizeof(be));
+      break;
+    }
     case CDKF_SOLVER_EULER: stages = 1; b[0] = 1; break;
-    case CDKF_SOLVER_HEUN: stages = 2; a[1][0] = 1; b[0] = b[1] = 0.5; break;
+    case CDKF_SOLVER_HEUN: stages = 2; order = 2; a[1][0] = 1; b[0] = b[1] = 0.5; be[0] = 0.5; be[1] = -0.5; break;
     case CDKF_SOLVER_MIDPOINT: stages = 2; a[1][0] = 0.5; b[1] = 1; break;
     case CDKF_SOLVER_RALSTON: stages = 2; a[1][0] = 2.0 / 3; b[0] = 0.25; b[1] = 0.75; break;
-    case CDKF_SOLVER_BOSH3: stages = 3; a[1][0] = 0.5; a[2][1] = 0.75; b[0] = 2.0 / 9; b[1] = 1.0 / 3; b[2] = 4.0 / 9; break;
+    case CDKF_SOLVER_BOSH3:
+      stages = 3; order = 3; fsal = 1;
+      a[1][0] = 0.5; a[2][1] = 0.75; b[0] = 2.0 / 9; b[1] = 1.0 / 3; b[2] = 4.0 / 9;
+      be[0] = 2.0 / 9 - 7.0 / 24; be[1] = 1.0 / 3 - 1.0 / 4; be[2] = 4.0 / 9 - 1.0 / 3; be[6] = -1.0 / 8;  // FSAL weight in slot 6
+      break;
     default: return false;
   }
   tb.stages = stages;
@@ -96,6 +115,16 @@ inline bool fill_rk_tab(int solver, RkTab<R>& tb) {
     tb.b[i] = R(b[i]);
     for (int j = 0; j < 5; ++j) tb.a[i][j] = R(a[i][j]);
   }
+  for (int i = 0; i < 7; ++i) tb.berr[i] = R(be[i]);
+  tb.fsal = fsal;
+  tb.adaptive = o->adaptive ? 1 : 0;
+  if (tb.adaptive && order == 0) return false;  // no embedded error estimate
+  const double ord = order ? order : 1;
+  tb.rtol = R(o->rtol);
+  tb.atol = R(o->atol);
+  tb.c1 = R((o->pid_i + o->pid_p + o->pid_d) / ord);
+  tb.c2 = R(-(o->pid_p + 2 * o->pid_d) / ord);
+  tb.c3 = R(o->pid_d / ord);
   return true;
 }
 
@@ -131,7 +160,7 @@ void fill_reg_args(RegArgs<R, D, M, Drift>& a, const cdkf_model* mdl, const cdkf
   a.num_iter = o->num_iter;
   a.forecast = o->forecast;
   a.solver = o->solver;
-  fill_rk_tab<R>(o->solver, a.rk);  // opts.solver was validated by check_common
+  fill_rk_tab<R>(o, a.rk);  // opts.solver / adaptive were validated by check_common
   a.N = N;
   a.T = T;
   a.y_si = a.m_si = a.P_si = 1;

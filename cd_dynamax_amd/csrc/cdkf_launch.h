@@ -102,7 +102,7 @@ template <typename R, int D, int M, typename Drift, bool UKF, bool ZEROTH, bool 
 inline void launch_filter_reg(const RegArgs<R, D, M, Drift>& a, hipStream_t stream) {
   const dim3 grid((unsigned)((a.N + 63) / 64)), block(64);
   const bool all = a.fm && a.fP && a.pm && a.pP, none = !a.fm && !a.fP && !a.pm && !a.pP;
-  if (a.rk.stages && a.solver != CDKF_SOLVER_DOPRI5) {  // non-default Runge-Kutta method: run-time tableau
+  if (a.rk.stages && (a.solver != CDKF_SOLVER_DOPRI5 || a.rk.adaptive)) {  // non-default method or adaptive steps: run-time tableau
     if (a.forecast)
       hipLaunchKernelGGL((filter_reg_kernel<R, D, M, Drift, UKF, ZEROTH, false, kOutSome, true, true>), grid, block, 0, stream, a);
     else

@@ -217,6 +217,12 @@ struct RkTab {
   int stages;
   R a[6][5];
   R b[6];
+  // adaptive stepping (diffrax.PIDController around the embedded pair): error weights b_sol - b_hat, the 7th entry
+  // belonging to the first-same-as-last stage f(y_new) (evaluated when fsal != 0); c1, c2, c3 = the controller's
+  // exponents (i + p + d) / order, -(p + 2 d) / order, d / order
+  int adaptive, fsal;
+  R berr[7];
+  R rtol, atol, c1, c2, c3;
 };
 
 template <typename R, int NS, typename Rhs>
@@ -248,8 +254,112 @@ CDKF_DEV void rk_step(R (&y)[NS], R dt, const Rhs& rhs, const RkTab<R>& tb) {
   }
 }
 
-template <typename R, int NS, typename Rhs>
+CDKF_DEV float rpow(float a, float b) { return powf(a, b); }
+CDKF_DEV double rpow(double a, double b) { return pow(a, b); }
+CDKF_DEV float rabs(float a) { return fabsf(a); }
+CDKF_DEV double rabs(double a) { return fabs(a); }
+CDKF_DEV float rmax(float a, float b) { return fmaxf(a, b); }
+CDKF_DEV double rmax(double a, double b) { return fmax(a, b); }
+
+// Adaptive solve: the step-size controller of diffrax.PIDController (restated from its published algorithm; oracle:
+// _diffeqsolve_adaptive).  Per step: the embedded error estimate, its RMS over ALL entries of the state pytree -- the mean
+// and the FULL d x d covariance, so the packed off-diagonal entries count twice -- scaled by atol + max(|y|, |y_new|) rtol;
+// accept iff < 1; next size = attempted size * clip(0.9 e^-c1 e1^-c2 e2^-c3, [1 if accepted else 0.2, 10]); a rejected step
+// that would cross the end goes half-way.  max_steps counts attempts.  Each lane adapts on its own.
+template <typename R, int NS, int MEAN_ONLY, typename Rhs>
+CDKF_DEV bool integrate_adaptive(R (&y)[NS], R t0, R t1, R dt0, long max_steps, const Rhs& rhs, const RkTab<R>& tb) {
+  // state dimension behind the packed layout NS = D + D (D + 1) / 2
+  constexpr int D = MEAN_ONLY ? NS : (NS == 2 ? 1 : NS == 5 ? 2 : NS == 9 ? 3 : NS == 14 ? 4 : NS == 20 ? 5 : NS == 27 ? 6 : -1);
+  static_assert(D > 0, "integrate_adaptive: unexpected state size");
+  constexpr int COUNT = MEAN_ONLY ? NS : D + D * D;
+  R tprev = t0;
+  R tnext = rmin(t0 + dt0, t1);
+  R inv1 = R(1), inv2 = R(1);
+  long steps = 0;
+  bool capped = false;
+  while (tprev < t1) {
+    if (steps >= max_steps) {
+      capped = true;
+      break;
+    }
+    const R dt = tnext - tprev;
+    R k[7][NS], ys[NS], yn[NS];
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+      if (s < tb.stages) {
+#pragma unroll
+        for (int e = 0; e < NS; ++e) {
+          R acc = R(0);
+#pragma unroll
+          for (int j = 0; j < 5; ++j)
+            if (j < s) acc = rfma(tb.a[s][j], k[j][e], acc);
+          ys[e] = rfma(dt, acc, y[e]);
+        }
+        rhs(ys, k[s]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < NS; ++e) k[s][e] = R(0);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < NS; ++e) {
+      R acc = R(0);
+#pragma unroll
+      for (int s = 0; s < 6; ++s) acc = rfma(tb.b[s], k[s][e], acc);
+      yn[e] = rfma(dt, acc, y[e]);
+    }
+    if (tb.fsal) {
+      rhs(yn, k[6]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < NS; ++e) k[6][e] = R(0);
+    }
+    R sq = R(0);
+#pragma unroll
+    for (int e = 0; e < NS; ++e) {
+      R err = R(0);
+#pragma unroll
+      for (int s = 0; s < 7; ++s) err = rfma(tb.berr[s], k[s][e], err);
+      const R sc = (dt * err) / rfma(rmax(rabs(y[e]), rabs(yn[e])), tb.rtol, tb.atol);
+      // weight of the packed entry in the full pytree: mean and diagonal once, off-diagonal twice
+      R w = R(1);
+      if (!MEAN_ONLY && e >= D) {
+        int idx = e - D, row = 0;
+        while (idx >= D - row) {
+          idx -= D - row;
+          ++row;
+        }
+        w = idx == 0 ? R(1) : R(2);
+      }
+      sq = rfma(w * sc, sc, sq);
+    }
+    const R scaled = rsqrt_(sq / R(COUNT));
+    const bool keep = scaled < R(1);
+    const R inv = (scaled == R(0)) ? R(__builtin_huge_val()) : R(1) / scaled;
+    R factor = R(0.9) * rpow(inv, tb.c1);
+    if (tb.c2 != R(0)) factor *= rpow(inv1, tb.c2);
+    if (tb.c3 != R(0)) factor *= rpow(inv2, tb.c3);
+    // fmax / fmin semantics: a NaN estimate (a stage that left the domain because the attempted step was far too long)
+    // rejects the step and shrinks it by factormin; diffrax's clip would propagate the NaN and end in its max_steps error
+    factor = rmin(rmax(factor, keep ? R(1) : R(0.2)), R(10));
+    const R nt0 = keep ? tnext : tprev;
+    const R nt1 = nt0 + dt * factor;
+    if (keep) {
+#pragma unroll
+      for (int e = 0; e < NS; ++e) y[e] = yn[e];
+      inv2 = inv1;
+      inv1 = inv;
+    }
+    tprev = rmin(nt0, t1);
+    tnext = (nt1 > t1 - Tol<R>::v) ? (keep ? t1 : rfma(R(0.5), t1 - tprev, tprev)) : nt1;
+    ++steps;
+  }
+  return capped;
+}
+
+template <typename R, int NS, int MEAN_ONLY = 0, typename Rhs>
 CDKF_DEV bool integrate(R (&y)[NS], R t0, R t1, R dt0, long max_steps, const Rhs& rhs, const RkTab<R>& tb) {
+  if (tb.adaptive) return integrate_adaptive<R, NS, MEAN_ONLY>(y, t0, t1, dt0, max_steps, rhs, tb);
   R tprev = t0;
   R tnext = rmin(t0 + dt0, t1);
   long steps = 0;
@@ -268,7 +378,7 @@ CDKF_DEV bool integrate(R (&y)[NS], R t0, R t1, R dt0, long max_steps, const Rhs
   return capped;
 }
 
-template <typename R, int NS, typename Rhs>
+template <typename R, int NS, int MEAN_ONLY = 0, typename Rhs>
 CDKF_DEV bool integrate(R (&y)[NS], R t0, R t1, R dt0, long max_steps, const Rhs& rhs, const Dp5V<R>& C) {
   R tprev = t0;
   R tnext = rmin(t0 + dt0, t1);

@@ -92,7 +92,7 @@ std::string generate_source(const CustomDrift& c, int bytes, int m, int ukf, int
   s += "using R = " + std::string(bytes == 8 ? "double" : "float") + ";\n";
   s += "constexpr int DD = " + std::to_string(c.d) + ", MM = " + std::to_string(m) + ";\n";
   s += "using Drift = cdkf::DriftCustom<R, DD>;\nusing Args = cdkf::RegArgs<R, DD, MM, Drift>;\n";
-  // parameter blob (reals): theta | LQL | LQLz | H | hb | Rm | m0 | P0 | dt0 dt_final ukf_c ukf_wm0 ukf_wc0 ukf_wi | rk.a[30] rk.b[6]
+  // parameter blob (reals): theta | LQL | LQLz | H | hb | Rm | m0 | P0 | dt0 dt_final ukf_c ukf_wm0 ukf_wc0 ukf_wi | rk.a[30] rk.b[6] rk.berr[7] rtol atol c1 c2 c3
   // integer blob (longs) : max_steps order num_iter forecast N T t_sn t_sk y_sn y_sk y_si m_sn m_sk m_si P_sn P_sk P_si
   s += R"(
 __device__ __forceinline__ void unpack(Args& a, const R* __restrict__ par, const long* __restrict__ ip, const R* t, const R* y,
@@ -121,7 +121,11 @@ __device__ __forceinline__ void unpack(Args& a, const R* __restrict__ par, const
   for (int s = 0; s < 6; ++s) for (int j = 0; j < 5; ++j) a.rk.a[s][j] = par[o + s * 5 + j];
   o += 30;
   for (int s = 0; s < 6; ++s) a.rk.b[s] = par[o + s];
-  a.rk.stages = (int)ip[17]; a.solver = (int)ip[18];
+  o += 6;
+  for (int s = 0; s < 7; ++s) a.rk.berr[s] = par[o + s];
+  o += 7;
+  a.rk.rtol = par[o]; a.rk.atol = par[o + 1]; a.rk.c1 = par[o + 2]; a.rk.c2 = par[o + 3]; a.rk.c3 = par[o + 4];
+  a.rk.stages = (int)ip[17]; a.solver = (int)ip[18]; a.rk.adaptive = (int)ip[19]; a.rk.fsal = (int)ip[20];
   a.max_steps = ip[0]; a.order = (int)ip[1]; a.num_iter = (int)ip[2]; a.forecast = (int)ip[3]; a.N = ip[4]; a.T = ip[5];
   a.t_sn = ip[6]; a.t_sk = ip[7]; a.y_sn = ip[8]; a.y_sk = ip[9]; a.y_si = ip[10]; a.m_sn = ip[11]; a.m_sk = ip[12];
   a.m_si = ip[13]; a.P_sn = ip[14]; a.P_sk = ip[15]; a.P_si = ip[16];
@@ -316,14 +320,18 @@ int launch_custom(int algo, const cdkf_model* mdl, const cdkf_opts* o, int64_t N
     par.push_back(R(1) / (R(2) * (n + lamb)));
   }
   RkTab<R> tb;
-  fill_rk_tab<R>(o->solver, tb);
+  fill_rk_tab<R>(o, tb);
   for (int s = 0; s < 6; ++s)
     for (int j = 0; j < 5; ++j) par.push_back(tb.a[s][j]);
   for (int s = 0; s < 6; ++s) par.push_back(tb.b[s]);
-  const int generic = o->solver != CDKF_SOLVER_DOPRI5;
-  long ip[19];
+  for (int s = 0; s < 7; ++s) par.push_back(tb.berr[s]);
+  par.push_back(tb.rtol); par.push_back(tb.atol); par.push_back(tb.c1); par.push_back(tb.c2); par.push_back(tb.c3);
+  const int generic = o->solver != CDKF_SOLVER_DOPRI5 || o->adaptive;
+  long ip[21];
   ip[17] = tb.stages;
   ip[18] = o->solver;
+  ip[19] = tb.adaptive;
+  ip[20] = tb.fsal;
   ip[0] = (long)o->max_steps;
   ip[1] = o->state_order;
   ip[2] = smoother ? 1 : o->num_iter;

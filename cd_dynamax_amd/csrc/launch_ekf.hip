@@ -8,7 +8,7 @@ static int run_ekf_reg(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int
                        R* fm, R* fP, R* pm, R* pP, int32_t* status, hipStream_t stream) {
   RegArgs<R, D, M, Drift> a;
   fill_reg_args(a, mdl, o, N, T, t, y, ll, fm, fP, pm, pP, status);
-  if (o->state_order == CDKF_ORDER_ZEROTH && o->solver != CDKF_SOLVER_DOPRI5) {
+  if (o->state_order == CDKF_ORDER_ZEROTH && (o->solver != CDKF_SOLVER_DOPRI5 || o->adaptive)) {
     launch_filter_reg<R, D, M, Drift, false, true, false>(a, stream);
   } else if (o->state_order == CDKF_ORDER_ZEROTH) {
     const dim3 grid((unsigned)((N + 63) / 64)), block(64);

@@ -11,7 +11,7 @@ static int run_eks_reg(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int
   RegArgs<R, D, M, Drift> a;
   fill_reg_args(a, mdl, &of, N, T, t, y, ll, fm, fP, (R*)nullptr, (R*)nullptr, status);
   const unsigned blocks = (unsigned)((N + 63) / 64);
-  if (of.solver != CDKF_SOLVER_DOPRI5) {
+  if (of.solver != CDKF_SOLVER_DOPRI5 || of.adaptive) {
     if (of.state_order == CDKF_ORDER_ZEROTH)
       hipLaunchKernelGGL((filter_reg_kernel<R, D, M, Drift, false, true, false, kOutSome, false, true>), dim3(blocks), dim3(64), 0, stream, a);
     else

@@ -15,7 +15,7 @@
 namespace cdkf {
 
 static bool sens_shape_available(const cdkf_model* mdl, const cdkf_opts* o) {
-  if (o->solver != CDKF_SOLVER_DOPRI5) return false;
+  if (o->solver != CDKF_SOLVER_DOPRI5 || o->adaptive) return false;
   if (o->state_order == CDKF_ORDER_ZEROTH || o->num_iter != 1 || o->forecast) return false;
 #define X(KIND, DRIFT, D_, M_) \
   if (mdl->drift_kind == KIND && mdl->state_dim == D_ && mdl->emission_dim == M_) return true;

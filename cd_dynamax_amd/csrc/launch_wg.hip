@@ -89,9 +89,10 @@ template <typename R>
 static int wg_prepare(WgArgs<R>& a, R** dev_block, ParamSlot** slot_out, const cdkf_model* mdl, const cdkf_opts* o,
                       int64_t N, int64_t T, hipStream_t stream) {
   const int d = mdl->state_dim, m = mdl->emission_dim;
-  if (o->solver != CDKF_SOLVER_DOPRI5) {
-    set_error("opts.solver = %d: the workgroup / wavefront kernels (state_dim %d, emission_dim %d) integrate with Dormand-Prince "
-              "only; the other Runge-Kutta methods run on the register-resident shapes", o->solver, d, m);
+  if (o->solver != CDKF_SOLVER_DOPRI5 || o->adaptive) {
+    set_error("opts.solver = %d, adaptive = %d: the workgroup / wavefront kernels (state_dim %d, emission_dim %d) integrate with Dormand-Prince "
+              "in fixed steps only; the other Runge-Kutta methods and adaptive stepping run on the register-resident shapes", o->solver,
+              o->adaptive, d, m);
     return CDKF_EUNSUPPORTED;
   }
   if (!wg_shape_available(mdl, sizeof(R))) {
@@ -340,7 +341,7 @@ static AdjWorkspace g_adj_ws;
 static std::mutex g_adj_mutex;
 
 bool adjoint_shape_available(const cdkf_model* mdl, const cdkf_opts* o) {
-  if (o->solver != CDKF_SOLVER_DOPRI5) return false;
+  if (o->solver != CDKF_SOLVER_DOPRI5 || o->adaptive) return false;
   if (!wave8_shape(mdl) || !wg_shape_available(mdl, 8) || o->num_iter != 1 || o->forecast) return false;
   if (o->state_order == CDKF_ORDER_ZEROTH) return false;
   // the MLP has a non-zero grad(div f): its 'second' mean term would need third derivatives of the drift

@@ -103,16 +103,33 @@ def _builtin_drift_source(drift, d: int):
 def _opts(hyperparams, num_iter: int = 1):
     o = _ffi.default_opts()
     settings = dict(getattr(hyperparams, "diffeqsolve_settings", {}) or {})
-    unknown = set(settings) - {"dt0", "max_steps", "solver"}
+    # keys that only matter for SDE solves / JAX autodiff in the reference and have no effect on this path
+    for k in ("tol_vbt", "adjoint", "key", "debug"):
+        settings.pop(k, None)
+    unknown = set(settings) - {"dt0", "max_steps", "solver", "stepsize_controller"}
     if unknown:
         raise NotImplementedError(
-            f"diffeqsolve_settings {sorted(unknown)} are not supported by the HIP path (explicit Runge-Kutta methods with the "
-            "constant step dt0, the default controller of src/utils/diffrax_utils.py:40-52; no adaptive stepping)")
+            f"diffeqsolve_settings {sorted(unknown)} are not supported by the HIP path (explicit Runge-Kutta methods, fixed "
+            "steps or PIDController; src/utils/diffrax_utils.py:40-57)")
+    ctrl = settings.get("stepsize_controller")
+    if ctrl is not None and type(ctrl).__name__ != "ConstantStepSize" and ctrl != "ConstantStepSize":
+        if not (hasattr(ctrl, "rtol") and hasattr(ctrl, "atol")):
+            raise NotImplementedError(f"diffeqsolve_settings['stepsize_controller'] = {ctrl!r}: ConstantStepSize or PIDController")
+        defaults = dict(dtmin=None, dtmax=None, step_ts=None, jump_ts=None, safety=0.9, factormin=0.2, factormax=10.0,
+                        force_dtmin=True, error_order=None)
+        for k, v in defaults.items():
+            if hasattr(ctrl, k) and getattr(ctrl, k) is not None and getattr(ctrl, k) != v:
+                raise NotImplementedError(f"PIDController.{k} = {getattr(ctrl, k)!r}: only the default ({v!r}) is implemented")
+        o.adaptive = 1
+        o.rtol, o.atol = float(ctrl.rtol), float(ctrl.atol)
+        o.pid_p, o.pid_i, o.pid_d = (float(getattr(ctrl, k, v)) for k, v in (("pcoeff", 0.0), ("icoeff", 1.0), ("dcoeff", 0.0)))
     solver = settings.get("solver", "dopri5")
     name = solver.lower() if isinstance(solver, str) else type(solver).__name__.lower()   # 'tsit5' or a diffrax.Tsit5() object
     if name not in _ffi.SOLVERS:
         raise NotImplementedError(f"diffeqsolve_settings['solver'] = {solver!r}: choose from {sorted(_ffi.SOLVERS)}")
     o.solver = _ffi.SOLVERS[name]
+    if o.adaptive and name not in ("dopri5", "tsit5", "bosh3", "heun"):
+        raise NotImplementedError(f"adaptive stepping needs an embedded error estimate: dopri5, tsit5, bosh3 or heun (got {name})")
     o.dt0 = float(settings.get("dt0", 0.01))
     o.max_steps = int(settings.get("max_steps", 100000))
     o.dt_final = float(hyperparams.dt_final)

@@ -87,6 +87,21 @@ class LearnableMLP(NamedTuple):
         return np.asarray(self.W3) @ a2 + np.asarray(self.b3)
 
 
+class ConstantStepSize(NamedTuple):
+    """diffrax.ConstantStepSize(): fixed steps of dt0 -- the default of the reference (src/utils/diffrax_utils.py:47)."""
+
+
+class PIDController(NamedTuple):
+    """diffrax.PIDController(rtol, atol, pcoeff, icoeff, dcoeff) for ``diffeqsolve_settings['stepsize_controller']``; the
+    remaining diffrax options are at their defaults (safety 0.9, factormin 0.2, factormax 10, RMS norm, no dtmin / dtmax).
+    A diffrax controller object with the same attributes is accepted as well."""
+    rtol: float
+    atol: float
+    pcoeff: float = 0.0
+    icoeff: float = 1.0
+    dcoeff: float = 0.0
+
+
 class LearnableCustomDrift(NamedTuple):
     """A user-defined drift for the HIP path.  The reference takes any callable (cdnlgssm_utils.py:38-61); here the drift
     is C source compiled at run time into the register-resident sweep kernels (include/cdkf.h,

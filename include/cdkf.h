@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define CDKF_VERSION 101 /* 0.1.0 */
+#define CDKF_VERSION 102 /* 0.1.0 */
 
 /* error codes */
 #define CDKF_OK 0
@@ -119,7 +119,10 @@ typedef struct cdkf_opts {
                            reference forwards diffeqsolve_settings['solver'] to diffrax, src/utils/diffrax_utils.py:40-57).
                            Default DOPRI5 (diffrax_utils.py:120-123).  The other methods run on the register-resident
                            kernels (incl. custom drifts); larger models and the gradient entry points take DOPRI5 only. */
-  int32_t reserved;     /* must be 0 */
+  int32_t adaptive;     /* 0 (default): fixed steps of dt0 (diffrax.ConstantStepSize).  1: diffrax.PIDController(rtol, atol, pcoeff,
+                           icoeff, dcoeff) around the method's embedded error estimate (DOPRI5, TSIT5, BOSH3, HEUN), first step
+                           dt0, every trajectory adapting on its own; max_steps then counts accepted and rejected steps.
+                           Register-resident kernels and custom drifts, like the non-default solvers. */
   int64_t max_steps;    /* RK steps per observation interval; default 100000 */
   double dt0;           /* default 0.01 */
   double dt_final;      /* default 1e-10 (inference_ekf.py:39) */
@@ -127,6 +130,11 @@ typedef struct cdkf_opts {
   double ukf_alpha;     /* default sqrt(3) */
   double ukf_beta;      /* default 2 */
   double ukf_kappa;     /* default 1 */
+  double rtol;          /* adaptive only; defaults 1e-3 / 1e-6 (the values of the reference's tutorial notebook) */
+  double atol;
+  double pid_p;         /* PIDController pcoeff / icoeff / dcoeff; defaults 0 / 1 / 0 (an I-controller, diffrax's default) */
+  double pid_i;
+  double pid_d;
 } cdkf_opts;
 
 /* Fill *opts with the reference defaults listed above. */

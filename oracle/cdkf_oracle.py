@@ -78,19 +78,33 @@ TABLEAUS = {
                (5.86145544294642, -12.92096931784711, 8.159367898576159, -0.071584973281401, -0.028269050394068383)),
               (0.09646076681806523, 0.01, 0.4798896504144996, 1.379008574103742, -3.290069515436081, 2.324710524099774)),
 }
-_ACTIVE = ["dopri5"]
+# Embedded error weights b_sol - b_hat (last entry: the first-same-as-last stage f(y_new)) and the order used by the step-size
+# controller (diffrax: error_order = solver.order for ODEs), for the methods that carry an error estimate.
+ERROR_WEIGHTS = {
+    "dopri5": ((35 / 384 - 5179 / 57600, 0.0, 500 / 1113 - 7571 / 16695, 125 / 192 - 393 / 640, -2187 / 6784 + 92097 / 339200,
+                11 / 84 - 187 / 2100, -1 / 40), 5),
+    "tsit5": ((-0.00178001105222577714, -0.0008164344596567469, 0.007880878010261995, -0.1447110071732629, 0.5823571654525552,
+               -0.45808210592918697, 0.015151515151515152), 5),
+    "bosh3": ((2 / 9 - 7 / 24, 1 / 3 - 1 / 4, 4 / 9 - 1 / 3, -1 / 8), 3),
+    "heun": ((0.5, -0.5, 0.0), 2),
+}
+_ACTIVE = [("dopri5", None)]
 
 
 class use_solver:
-    """``with use_solver('tsit5'): ...`` -- every diffeqsolve call inside integrates with that tableau (fixed steps)."""
+    """``with use_solver('tsit5'): ...`` -- every diffeqsolve call inside integrates with that tableau.  ``adaptive``: None
+    (fixed steps of dt0, diffrax.ConstantStepSize) or a dict(rtol, atol[, pcoeff=0, icoeff=1, dcoeff=0]) for
+    diffrax.PIDController."""
 
-    def __init__(self, name):
+    def __init__(self, name, adaptive=None):
         if name not in TABLEAUS:
             raise ValueError(f"unknown solver {name!r}")
-        self.name = name
+        if adaptive is not None and name not in ERROR_WEIGHTS:
+            raise ValueError(f"solver {name!r} has no embedded error estimate")
+        self.name, self.adaptive = name, adaptive
 
     def __enter__(self):
-        _ACTIVE.append(self.name)
+        _ACTIVE.append((self.name, self.adaptive))
 
     def __exit__(self, *exc):
         _ACTIVE.pop()
@@ -410,7 +424,7 @@ def _tree_axpy(y0, ks, coefs, dtype):
 def dopri5_step(rhs, y, dt):
     """One Dopri5 step of size dt (dt: [N]); k_j = dt * f(stage_j) (diffrax ODETerm.vf_prod)."""
     dtype = y[0].dtype
-    A, B = TABLEAUS[_ACTIVE[-1]]
+    A, B = TABLEAUS[_ACTIVE[-1][0]]
     ks = []
     for i in range(len(B)):
         yi = y if i == 0 else _tree_axpy(y, ks, A[i], dtype)
@@ -428,6 +442,8 @@ def diffeqsolve(rhs, t0, t1, y0, dt0=0.01, max_steps=100000, count_steps=None):
     reference integrate s from 0 to t1-t0 with rhs negated (diffrax_utils.py:13-25,131-135); for the
     autonomous right-hand sides of this path the caller passes t0=0, t1=t1-t0 and the negated rhs.
     """
+    if _ACTIVE[-1][1] is not None:
+        return _diffeqsolve_adaptive(rhs, t0, t1, y0, dt0, max_steps, count_steps)
     dtype = y0[0].dtype
     tol = dtype.type(1e-10 if dtype == np.float64 else 1e-6)
     t0 = np.asarray(t0, dtype=dtype)
@@ -448,6 +464,85 @@ def diffeqsolve(rhs, t0, t1, y0, dt0=0.01, max_steps=100000, count_steps=None):
         tprev_new = np.minimum(tnext, t1)
         tnext_new = tnext + dt0
         tnext_new = np.where(tnext_new > t1 - tol, t1, tnext_new)
+        tprev = np.where(active, tprev_new, tprev)
+        tnext = np.where(active, tnext_new, tnext)
+    if count_steps is not None:
+        count_steps.append(nsteps)
+    return y
+
+
+def _diffeqsolve_adaptive(rhs, t0, t1, y0, dt0, max_steps, count_steps):
+    """diffrax.PIDController around the embedded pair (diffrax 0.4.0 is not in the mount; restated from its published
+    algorithm -- step_size_controller/adaptive.py and the integrate loop):
+      y_error      = dt * sum_i (b_sol - b_hat)_i k_i, the last stage being f(y_candidate) (FSAL methods)
+      scaled_error = rms over ALL entries of the state pytree (mean and full d x d covariance) of
+                     y_error / (atol + max(|y0|, |y_candidate|) rtol);   keep the step iff scaled_error < 1
+      factor       = clip(safety * e^-(i+p+d)/order * e_prev^(p+2d)/order * e_prevprev^-d/order, [1 if kept else factormin, factormax])
+                     with e the scaled error (history updated on accepted steps only), safety 0.9, factormin 0.2, factormax 10
+      next step    = previous attempted size * factor, from t1 (kept) or again from t0 (rejected); the end is clipped as in
+                     the fixed-step loop, a REJECTED step that would cross the end is sent half-way there
+    max_steps counts accepted and rejected steps."""
+    name, ad = _ACTIVE[-1]
+    A, B = TABLEAUS[name]
+    Berr, order = ERROR_WEIGHTS[name]
+    dtype = y0[0].dtype
+    tol = dtype.type(1e-10 if dtype == np.float64 else 1e-6)
+    rtol, atol = dtype.type(ad["rtol"]), dtype.type(ad["atol"])
+    pc, ic, dc = (dtype.type(ad.get(k, v)) for k, v in (("pcoeff", 0.0), ("icoeff", 1.0), ("dcoeff", 0.0)))
+    c1, c2, c3 = (ic + pc + dc) / order, -(pc + 2 * dc) / order, dc / order
+    safety, fmin, fmax = dtype.type(0.9), dtype.type(0.2), dtype.type(10.0)
+    t0 = np.asarray(t0, dtype=dtype)
+    t1 = np.asarray(t1, dtype=dtype)
+    N = t0.shape[0]
+    tprev = t0.copy()
+    tnext = np.minimum(t0 + dtype.type(dt0), t1)
+    y = tuple(c.copy() for c in y0)
+    inv1 = np.ones(N, dtype)
+    inv2 = np.ones(N, dtype)
+    nsteps = np.zeros(N, dtype=np.int64)
+    bc = lambda v, c: v.reshape((-1,) + (1,) * (c.ndim - 1))
+    size = sum(int(np.prod(c.shape[1:])) for c in y0)
+    for _ in range(int(max_steps)):
+        active = tprev < t1
+        if not active.any():
+            break
+        dt = np.where(active, tnext - tprev, dtype.type(0))
+        ks = []
+        for i in range(len(B)):
+            yi = y if i == 0 else _tree_axpy(y, ks, A[i], dtype)
+            ks.append(tuple(bc(dt, c) * c for c in rhs(yi)))
+        ynew = _tree_axpy(y, ks, B, dtype)
+        if len(Berr) > len(B) and Berr[len(B)] != 0.0:
+            ks.append(tuple(bc(dt, c) * c for c in rhs(ynew)))
+        yerr = tuple(sum(dtype.type(Berr[i]) * ks[i][c] for i in range(len(ks)) if Berr[i] != 0.0) for c in range(len(y)))
+        sq = np.zeros(N, dtype)
+        for c in range(len(y)):
+            sc = yerr[c] / (atol + np.maximum(np.abs(y[c]), np.abs(ynew[c])) * rtol)
+            sq = sq + np.sum((sc * sc).reshape(N, -1), axis=1)
+        scaled = np.sqrt(sq / dtype.type(size))
+        keep = scaled < 1
+        with np.errstate(divide="ignore", over="ignore", invalid="ignore"):
+            inv = np.where(scaled == 0, dtype.type(np.inf), dtype.type(1) / scaled)
+            factor = safety * inv ** c1
+            if c2 != 0:
+                factor = factor * inv1 ** c2
+            if c3 != 0:
+                factor = factor * inv2 ** c3
+        # fmax / fmin: a NaN error estimate (e.g. a UKF stage covariance that lost positive definiteness because the attempted
+        # step was far too long) rejects the step with factor = factormin.  diffrax's clip would propagate the NaN into the
+        # step size and the solve would end in its max_steps error; the engine retries with a shorter step instead.
+        factor = np.fmin(np.fmax(factor, np.where(keep, dtype.type(1), fmin)), fmax)
+        dtn = dt * factor
+        nt0 = np.where(keep, tnext, tprev)
+        nt1 = nt0 + dtn
+        upd = active & keep
+        y = tuple(np.where(bc(upd, c), cn, c) for cn, c in zip(ynew, y))
+        inv2 = np.where(upd, inv1, inv2)
+        inv1 = np.where(upd, inv, inv1)
+        nsteps += active
+        tprev_new = np.minimum(nt0, t1)
+        tclip = np.where(keep, t1, tprev_new + dtype.type(0.5) * (t1 - tprev_new))
+        tnext_new = np.where(nt1 > t1 - tol, tclip, nt1)
         tprev = np.where(active, tprev_new, tprev)
         tnext = np.where(active, tnext_new, tnext)
     if count_steps is not None:

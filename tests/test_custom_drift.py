@@ -145,6 +145,13 @@ def test_custom_drift_second_order_with_divgrad(hip_lib):
     assert relerr(post.filtered_covariances, ref["filtered_covariances"]) < 1e-11
     sm = cd.cdnlgssm_smoother(P, y, t[..., None], hyp)
     assert relerr(sm.smoothed_means, refs["smoothed_means"]) < 1e-10
+    # ... and adaptive step-size control
+    ctrl = dict(rtol=1e-6, atol=1e-8)
+    hyp = cd.EKFHyperParams(diffeqsolve_settings={"solver": "dopri5", "dt0": 0.02, "stepsize_controller": cd.PIDController(**ctrl)})
+    with o.use_solver("dopri5", adaptive=ctrl):
+        ref = o.ekf_filter(mdl, t, y, state_order="second", dt0=0.02)
+    post = cd.cdnlgssm_filter(P, y, t[..., None], hyp)
+    assert relerr(post.filtered_covariances, ref["filtered_covariances"]) < 1e-10
 
 
 # ---- user-supplied emission functions ---------------------------------------------------------------------------------------

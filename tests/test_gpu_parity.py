@@ -524,7 +524,7 @@ def test_solver_choice_refusals(hip_lib):
     mdl = lorenz96_model(8, 4)
     t = o.irregular_times(rng, 2, 5, 0.1)
     y = o.simulate(mdl, t, rng)
-    with pytest.raises(_ffi.CdkfError, match="Dormand-Prince only"):
+    with pytest.raises(_ffi.CdkfError, match="fixed steps only"):
         cd.cdnlgssm_filter(params_from(mdl), y, t[..., None], cd.EKFHyperParams(diffeqsolve_settings={"solver": "tsit5"}))
     with pytest.raises(NotImplementedError, match="choose from"):
         cd.cdnlgssm_filter(params_from(mdl), y, t[..., None], cd.EKFHyperParams(diffeqsolve_settings={"solver": "kvaerno5"}))
@@ -534,3 +534,60 @@ def test_solver_choice_refusals(hip_lib):
     y3 = o.simulate(l63, t, rng)
     with pytest.raises(NotImplementedError, match="no gradient kernel"):
         cd.cdnlgssm_loglik_and_grad(params_from(l63), y3, t[..., None], cd.EKFHyperParams(diffeqsolve_settings={"solver": "heun"}))
+
+
+@pytest.mark.parametrize("solver,ctrl", [("tsit5", dict(rtol=1e-6, atol=1e-8)), ("dopri5", dict(rtol=1e-5, atol=1e-7, pcoeff=0.1, icoeff=0.3)),
+                                         ("bosh3", dict(rtol=1e-4, atol=1e-6)), ("heun", dict(rtol=1e-3, atol=1e-5, dcoeff=0.05))])
+def test_adaptive_step_size_control(hip_lib, solver, ctrl):
+    """diffeqsolve_settings={'solver': ..., 'stepsize_controller': PIDController(rtol, atol, ...)} (the reference's tutorial
+    uses Tsit5 + PIDController for its high-fidelity log-likelihood): every trajectory adapts on its own.  Against the oracle's
+    restatement of the controller -- identical accept / reject decisions give agreement to rounding; intervals of very
+    different lengths, first step dt0 = 0.05 far above what the tolerance allows (forces rejections)."""
+    rng = np.random.default_rng(100)
+    mdl = o.lorenz63_model(2)
+    N, T = 9, 20
+    t = o.irregular_times(rng, N, T, 0.05)
+    t[:, 10:] += 0.4
+    y = o.simulate(mdl, t, rng)
+    P = params_from(mdl)
+    settings = {"solver": solver, "dt0": 0.05, "stepsize_controller": cd.PIDController(**ctrl)}
+    with o.use_solver(solver, adaptive=ctrl):
+        ref = o.ekf_filter(mdl, t, y, dt0=0.05)
+        refu = o.ukf_filter(mdl, t, y, dt0=0.05)
+        refs = o.ekf_smoother(mdl, t, y, dt0=0.05)
+        ref0 = o.ekf_filter(mdl, t, y, dt0=0.05, state_order="zeroth")
+    post = cd.cdnlgssm_filter(P, y, t[..., None], cd.EKFHyperParams(diffeqsolve_settings=settings))
+    for k in FILTER_KEYS:
+        assert relerr(getattr(post, k), ref[k]) < 1e-10, k
+    np.testing.assert_allclose(post.marginal_loglik, ref["marginal_loglik"], rtol=1e-10)
+    postu = cd.cdnlgssm_filter(P, y, t[..., None], cd.UKFHyperParams(diffeqsolve_settings=settings))
+    assert relerr(postu.filtered_means, refu["filtered_means"]) < 1e-9
+    sm = cd.cdnlgssm_smoother(P, y, t[..., None], cd.EKFHyperParams(diffeqsolve_settings=settings))
+    assert relerr(sm.smoothed_covariances, refs["smoothed_covariances"]) < 1e-9
+    post0 = cd.cdnlgssm_filter(P, y, t[..., None], cd.EKFHyperParams(state_order="zeroth", diffeqsolve_settings=settings))
+    assert relerr(post0.filtered_means, ref0["filtered_means"]) < 1e-10
+    # the adaptive solve tracks the fixed-step reference solution to about its tolerance
+    fine = cd.cdnlgssm_filter(P, y, t[..., None], cd.EKFHyperParams(diffeqsolve_settings={"dt0": 0.001}))
+    assert relerr(post.filtered_means, fine.filtered_means) < 300 * ctrl["rtol"]
+    # a step budget that cannot be met raises the MAX_STEPS status, as diffrax raises on max_steps
+    tight = dict(settings, max_steps=3)
+    mb = models._model_block(P)
+    op = models._opts(cd.EKFHyperParams(diffeqsolve_settings=tight), 1)
+    _, _, status = _ffi.run_host("ekf_filter", mb, op, t, y, [False] * 4, np.float64)
+    assert (status & 4).any()
+
+
+def test_adaptive_refusals(hip_lib):
+    rng = np.random.default_rng(1)
+    l63 = o.lorenz63_model(3)
+    t = o.irregular_times(rng, 2, 5, 0.1)
+    y = o.simulate(l63, t, rng)
+    pid = cd.PIDController(1e-3, 1e-6)
+    with pytest.raises(NotImplementedError, match="embedded error estimate"):
+        cd.cdnlgssm_filter(params_from(l63), y, t[..., None], cd.EKFHyperParams(diffeqsolve_settings={"solver": "euler", "stepsize_controller": pid}))
+    mdl = lorenz96_model(8, 4)
+    y8 = o.simulate(mdl, t, rng)
+    with pytest.raises(_ffi.CdkfError, match="fixed steps only"):
+        cd.cdnlgssm_filter(params_from(mdl), y8, t[..., None], cd.EKFHyperParams(diffeqsolve_settings={"stepsize_controller": pid}))
+    assert cd.cdnlgssm_filter(params_from(l63), y, t[..., None], cd.EKFHyperParams(
+        diffeqsolve_settings={"stepsize_controller": cd.ConstantStepSize(), "tol_vbt": 1e-5})).filtered_means.shape == (2, 5, 3)

@@ -349,3 +349,34 @@ def test_tableaus_have_their_published_order(name, order):
             errs.append(abs(yv[0, 0] - exact(1.0)))
     observed = np.log2(errs[0] / errs[1])
     assert observed > order - 0.35, (name, observed, errs)
+
+
+@pytest.mark.parametrize("name", ["dopri5", "tsit5", "bosh3", "heun"])
+def test_adaptive_controller_meets_tolerance_and_adapts(name):
+    """The PID step-size controller around the embedded pairs: embedded weights sum to zero (both methods consistent), the
+    error of the adaptive solve tracks rtol, tightening rtol costs more steps, and a stiff-ish start forces rejections
+    (more attempted steps than a solve that starts with a good step size)."""
+    werr, order = o.ERROR_WEIGHTS[name]
+    assert abs(sum(werr)) < 1e-12
+    # the embedded method b_hat = b_sol - b_err (last stage: f(y_new), node 1) satisfies the quadrature order conditions up
+    # to order - 1 -- a wrong digit in an embedded weight breaks them
+    A, B = o.TABLEAUS[name]
+    nodes = [sum(row) for row in A] + [1.0]
+    bhat = [(B[i] if i < len(B) else 0.0) - werr[i] for i in range(len(werr))]
+    for k in range(1, order):
+        assert abs(sum(b * c ** (k - 1) for b, c in zip(bhat, nodes)) - 1.0 / k) < 1e-9, (name, k)
+    exact = lambda tt: 0.2 * np.exp(tt) / (1 + 0.2 * (np.exp(tt) - 1))
+    rhs = lambda yv: (yv[0] * (1 - yv[0]),)
+    res = {}
+    for rtol in (1e-4, 1e-7):
+        counts = []
+        with o.use_solver(name, adaptive=dict(rtol=rtol, atol=rtol * 1e-2)):
+            (yv,) = o.diffeqsolve(rhs, np.zeros(1), np.full(1, 3.0), (np.full((1, 1), 0.2),), dt0=0.05, count_steps=counts)
+        res[rtol] = (abs(yv[0, 0] - exact(3.0)), int(counts[0][0]))
+    assert res[1e-4][0] < 1e-3 and res[1e-7][0] < 1e-6 and res[1e-7][0] < res[1e-4][0]
+    assert res[1e-7][1] > res[1e-4][1]
+    counts = []
+    with o.use_solver(name, adaptive=dict(rtol=1e-6, atol=1e-8)):
+        o.diffeqsolve(rhs, np.zeros(1), np.full(1, 3.0), (np.full((1, 1), 0.2),), dt0=3.0, count_steps=counts)   # far too large
+        o.diffeqsolve(rhs, np.zeros(1), np.full(1, 3.0), (np.full((1, 1), 0.2),), dt0=0.01, count_steps=counts)
+    assert counts[0][0] >= 2
