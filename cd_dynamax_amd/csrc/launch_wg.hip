@@ -340,6 +340,26 @@ struct AdjWorkspace {
 static AdjWorkspace g_adj_ws;
 static std::mutex g_adj_mutex;
 
+// grow (never shrink) the workspace to `bytes` on the current device; a buffer still in use by an earlier launch is waited for
+// on the device (same size) or on the host (before it is replaced).  Call with g_adj_mutex held.
+static int workspace_reserve(AdjWorkspace& ws, size_t bytes, hipStream_t stream) {
+  int dev = 0;
+  CDKF_HIP_CHECK(hipGetDevice(&dev));
+  if (ws.cap < bytes || ws.device != dev) {
+    if (ws.in_flight) CDKF_HIP_CHECK(hipEventSynchronize(ws.done));
+    if (ws.p) (void)hipFree(ws.p);
+    if (ws.done) (void)hipEventDestroy(ws.done);
+    ws = AdjWorkspace();
+    CDKF_HIP_CHECK(hipMalloc(&ws.p, bytes));
+    CDKF_HIP_CHECK(hipEventCreateWithFlags(&ws.done, hipEventDisableTiming));
+    ws.cap = bytes;
+    ws.device = dev;
+  } else if (ws.in_flight) {
+    CDKF_HIP_CHECK(hipStreamWaitEvent(stream, ws.done, 0));
+  }
+  return CDKF_OK;
+}
+
 bool adjoint_shape_available(const cdkf_model* mdl, const cdkf_opts* o) {
   if (o->solver != CDKF_SOLVER_DOPRI5 || o->adaptive) return false;
   if (!wave8_shape(mdl) || !wg_shape_available(mdl, 8) || o->num_iter != 1 || o->forecast) return false;
@@ -372,21 +392,8 @@ int launch_ekf_grad_adjoint(const cdkf_model* mdl, const cdkf_opts* o, int64_t N
   if (rc) return rc;
   const size_t nm = (size_t)N * T * mdl->state_dim, nP = nm * mdl->state_dim, bytes = 2 * (nm + nP) * sizeof(R);
   std::lock_guard<std::mutex> lock(g_adj_mutex);
-  int dev = 0;
-  CDKF_HIP_CHECK(hipGetDevice(&dev));
   AdjWorkspace& ws = g_adj_ws;
-  if (ws.cap < bytes || ws.device != dev) {
-    if (ws.in_flight) CDKF_HIP_CHECK(hipEventSynchronize(ws.done));
-    if (ws.p) (void)hipFree(ws.p);
-    if (ws.done) (void)hipEventDestroy(ws.done);
-    ws = AdjWorkspace();
-    CDKF_HIP_CHECK(hipMalloc(&ws.p, bytes));
-    CDKF_HIP_CHECK(hipEventCreateWithFlags(&ws.done, hipEventDisableTiming));
-    ws.cap = bytes;
-    ws.device = dev;
-  } else if (ws.in_flight) {
-    CDKF_HIP_CHECK(hipStreamWaitEvent(stream, ws.done, 0));
-  }
+  if (int wrc = workspace_reserve(ws, bytes, stream)) return wrc;
   R* w = (R*)ws.p;
   a.t = t; a.y = y; a.ll = ll; a.status = status;
   a.fm = w; a.fP = w + nm; a.pm = w + nm + nP; a.pP = w + 2 * nm + nP;
@@ -441,21 +448,8 @@ int launch_kf_smoother1(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, in
   a.t = t; a.y = y; a.ll = ll; a.fm = fm; a.fP = fP; a.sm = sm; a.sP = sP; a.status = status;
   const size_t d = mdl->state_dim, items = (size_t)N * (size_t)(T - 1), bytes = (items ? items : 1) * 2 * d * d * sizeof(R);
   std::lock_guard<std::mutex> lock(g_adj_mutex);
-  int dev = 0;
-  CDKF_HIP_CHECK(hipGetDevice(&dev));
   AdjWorkspace& ws = g_adj_ws;
-  if (ws.cap < bytes || ws.device != dev) {
-    if (ws.in_flight) CDKF_HIP_CHECK(hipEventSynchronize(ws.done));
-    if (ws.p) (void)hipFree(ws.p);
-    if (ws.done) (void)hipEventDestroy(ws.done);
-    ws = AdjWorkspace();
-    CDKF_HIP_CHECK(hipMalloc(&ws.p, bytes));
-    CDKF_HIP_CHECK(hipEventCreateWithFlags(&ws.done, hipEventDisableTiming));
-    ws.cap = bytes;
-    ws.device = dev;
-  } else if (ws.in_flight) {
-    CDKF_HIP_CHECK(hipStreamWaitEvent(stream, ws.done, 0));
-  }
+  if (int wrc = workspace_reserve(ws, bytes, stream)) return wrc;
   const size_t lds = sizeof(R) * (size_t)kRts1Waves * Rts1Off::end + 64;
   if (items) {
     hipLaunchKernelGGL(pushforward_wave8_kernel<R>, dim3((unsigned)((items + kRts1Waves - 1) / kRts1Waves)),
