@@ -21,7 +21,12 @@ static int run_eks_reg(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int
     CDKF_HIP_CHECK(hipGetLastError());
     return CDKF_OK;
   }
-  hipLaunchKernelGGL((filter_reg_kernel<R, D, M, Drift, false, false, false, kOutSome>), dim3(blocks), dim3(64), 0, stream, a);
+  // the smoother's internal filter runs with the caller's state_order (extended_kalman_smoother forwards hyperparams to the
+  // filter, inference_ekf.py:489-495); the backward pass is always smooth_order 'first'
+  if (of.state_order == CDKF_ORDER_ZEROTH)
+    hipLaunchKernelGGL((filter_reg_kernel<R, D, M, Drift, false, true, false, kOutSome>), dim3(blocks), dim3(64), 0, stream, a);
+  else
+    hipLaunchKernelGGL((filter_reg_kernel<R, D, M, Drift, false, false, false, kOutSome>), dim3(blocks), dim3(64), 0, stream, a);
   CDKF_HIP_CHECK(hipGetLastError());
   hipLaunchKernelGGL((ekf_smoother_reg_kernel<R, D, M, Drift>), dim3(blocks), dim3(64), 0, stream, a, sm, sP);
   CDKF_HIP_CHECK(hipGetLastError());
@@ -36,10 +41,6 @@ int launch_ekf_smoother(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, in
     return CDKF_EINVAL;
   }
   if (custom_kind(mdl->drift_kind)) return launch_custom<R>(2, mdl, o, N, T, t, y, ll, fm, fP, sm, sP, status, stream);
-  if (o->state_order == CDKF_ORDER_ZEROTH) {
-    // the reference's filter accepts it; kept for parity with extended_kalman_smoother, which simply
-    // forwards hyperparams to the filter and always smooths with smooth_order = 'first'
-  }
 #define X(KIND, DRIFT, D_, M_)                                                           \
   if (mdl->drift_kind == KIND && mdl->state_dim == D_ && mdl->emission_dim == M_)        \
     return run_eks_reg<R, D_, M_, DRIFT<R, D_>>(mdl, o, N, T, t, y, ll, fm, fP, sm, sP, status, stream);

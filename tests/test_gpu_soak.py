@@ -1,0 +1,89 @@
+"""Randomised parity soak through the C ABI: shapes, layouts, precisions, orders, shared / per-trajectory time grids, edge sizes
+(T = 1, N = 1, N just above a wavefront), every kernel family (register, wavefront, workgroup)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import cd_dynamax_amd as cd
+import cdkf_oracle as o
+from cd_dynamax_amd import _ffi, models
+from helpers import linear_model, lorenz96_model, mlp_model, params_from, relerr
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(algo, mdl, opts, layout, t, y, dtype, want=(True,) * 4):
+    """Call the host entry point in an explicit layout and return arrays in the reference shapes."""
+    N, T, m = y.shape
+    d = mdl.d
+    blk = models._model_block(params_from(mdl))
+    opts.layout = layout
+    tt = np.asarray(t, dtype)
+    if layout == _ffi.LAYOUT_NT:
+        y_l = np.ascontiguousarray(y, dtype)
+        t_l = np.ascontiguousarray(tt)
+        shp = [(N, T, d), (N, T, d, d)] * 2
+        back = lambda a: a
+    elif layout == _ffi.LAYOUT_TN:
+        y_l = np.ascontiguousarray(np.asarray(y, dtype).transpose(1, 0, 2))
+        t_l = np.ascontiguousarray(tt if opts.t_shared else tt.T)
+        shp = [(T, N, d), (T, N, d, d)] * 2
+        back = lambda a: np.swapaxes(a, 0, 1)
+    else:
+        y_l = np.ascontiguousarray(np.asarray(y, dtype).transpose(1, 2, 0))
+        t_l = np.ascontiguousarray(tt if opts.t_shared else tt.T)
+        shp = [(T, d, N), (T, d, d, N)] * 2
+        back = lambda a: np.moveaxis(a, -1, 0)
+    ll = np.empty(N, dtype)
+    st = np.zeros(N, np.int32)
+    outs = [np.full(s, np.nan, dtype) if w else None for s, w in zip(shp, want)]
+    vp = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+    fn = getattr(_ffi.lib(), f"cdkf_{algo}_{'f32' if dtype == np.float32 else 'f64'}")
+    _ffi.check(fn(C.byref(blk.c), C.byref(opts), N, T, vp(t_l), vp(y_l), vp(ll), *[vp(a) for a in outs], vp(st)))
+    return ll, [None if a is None else back(a) for a in outs], st
+
+
+CASES = [
+    # (model factory, N, T)
+    (lambda r: o.lorenz63_model(3), 1, 1), (lambda r: o.lorenz63_model(1), 65, 2), (lambda r: o.lorenz63_model(2), 130, 7),
+    (lambda r: linear_model(r, 2, 6), 3, 9), (lambda r: linear_model(r, 4, 2), 70, 5), (lambda r: linear_model(r, 1, 1), 64, 3),
+    (lambda r: linear_model(r, 5, 3), 5, 6), (lambda r: lorenz96_model(6, 6), 4, 5), (lambda r: lorenz96_model(12, 5), 3, 4),
+    (lambda r: mlp_model(r, 3, 2, (9, 4)), 6, 5), (lambda r: mlp_model(r, 10, 3, (8, 8)), 2, 4), (lambda r: linear_model(r, 17, 20), 2, 3),
+]
+
+
+@pytest.mark.parametrize("case", range(len(CASES)))
+def test_soak_filters_and_smoother(hip_lib, case):
+    rng = np.random.default_rng(1000 + case)
+    factory, N, T = CASES[case]
+    mdl = factory(rng)
+    shared = bool(case % 3 == 1)
+    t = o.irregular_times(rng, 1 if shared else N, T, 0.05)
+    tt = np.broadcast_to(t, (N, T)) if shared else t
+    y = o.simulate(mdl, tt, rng)
+    order = ["second", "first", "zeroth"][case % 3]
+    num_iter = 1 + (case % 2)
+    refs = {"ekf": o.ekf_filter(mdl, tt, y, state_order=order, num_iter=num_iter), "ukf": o.ukf_filter(mdl, tt, y),
+            "eks": o.ekf_smoother(mdl, tt, y, state_order=order)}
+    for layout in (_ffi.LAYOUT_NT, _ffi.LAYOUT_TN, _ffi.LAYOUT_TCN):
+        for dtype, tol in ((np.float64, 2e-9), (np.float32, 3e-3)):
+            opts = _ffi.default_opts()
+            opts.t_shared = 1 if shared else 0
+            opts.state_order = _ffi.ORDER[order]
+            opts.num_iter = num_iter
+            t_in = t[0] if shared else t
+            ll, outs, st = _run("ekf_filter", mdl, opts, layout, t_in, y, dtype)
+            assert not st.any(), (layout, dtype, st)
+            for a, k in zip(outs, ("filtered_means", "filtered_covariances", "predicted_means", "predicted_covariances")):
+                assert relerr(a, refs["ekf"][k]) < tol, (layout, dtype, k)
+            assert relerr(ll, refs["ekf"]["marginal_loglik"]) < tol
+            if dtype == np.float64:      # a subset of outputs: the others must stay untouched (NULL pointers)
+                ll2, outs2, _ = _run("ekf_filter", mdl, opts, layout, t_in, y, dtype, want=(False, True, False, False))
+                assert relerr(outs2[1], refs["ekf"]["filtered_covariances"]) < tol and relerr(ll2, ll) < 1e-13
+                opts.num_iter = 1
+                llu, outsu, _ = _run("ukf_filter", mdl, opts, layout, t_in, y, dtype)
+                assert relerr(outsu[0], refs["ukf"]["filtered_means"]) < 1e-8, layout
+                lls, outss, _ = _run("ekf_smoother", mdl, opts, layout, t_in, y, dtype)
+                assert relerr(outss[2], refs["eks"]["smoothed_means"]) < 1e-8, layout
+                assert relerr(outss[3], refs["eks"]["smoothed_covariances"]) < 1e-8, layout
