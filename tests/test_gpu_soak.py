@@ -87,3 +87,34 @@ def test_soak_filters_and_smoother(hip_lib, case):
                 lls, outss, _ = _run("ekf_smoother", mdl, opts, layout, t_in, y, dtype)
                 assert relerr(outss[2], refs["eks"]["smoothed_means"]) < 1e-8, layout
                 assert relerr(outss[3], refs["eks"]["smoothed_covariances"]) < 1e-8, layout
+
+
+@pytest.mark.parametrize("kind", ["lorenz63", "linear44", "mlp"])
+def test_soak_gradient_layouts(hip_lib, kind):
+    """cdkf_ekf_loglik_grad[_all]_* honour opts.layout for t and y (forward-sensitivity and reverse-sweep kernels), shared and
+    per-trajectory grids; N = 1 and N just above a wavefront."""
+    rng = np.random.default_rng(7)
+    mdl = {"lorenz63": lambda: o.lorenz63_model(3), "linear44": lambda: linear_model(rng, 4, 4),
+           "mlp": lambda: mlp_model(rng, 5, 2, (6, 7))}[kind]()
+    for N, T, shared in ((1, 6, False), (66, 5, True)):
+        t = o.irregular_times(rng, 1 if shared else N, T, 0.04)
+        tt = np.broadcast_to(t, (N, T)) if shared else t
+        y = o.simulate(mdl, tt, rng)
+        ll_ref, g_ref = o.ekf_loglik_grad_adjoint(mdl, tt, y)
+        blk = models._model_block(params_from(mdl))
+        for layout in (_ffi.LAYOUT_NT, _ffi.LAYOUT_TN, _ffi.LAYOUT_TCN):
+            opts = _ffi.default_opts()
+            opts.state_order = _ffi.ORDER["first"]
+            opts.t_shared = 1 if shared else 0
+            opts.layout = layout
+            y_l = {_ffi.LAYOUT_NT: y, _ffi.LAYOUT_TN: y.transpose(1, 0, 2), _ffi.LAYOUT_TCN: y.transpose(1, 2, 0)}[layout]
+            t_l = t[0] if shared else (t if layout == _ffi.LAYOUT_NT else t.T)
+            y_l, t_l = np.ascontiguousarray(y_l), np.ascontiguousarray(t_l)
+            ll, g, st = np.empty(N), np.empty((N, blk.theta.size)), np.zeros(N, np.int32)
+            gm = np.empty((N, _ffi.model_grad_size(mdl.d, mdl.m)))
+            vp = lambda a: a.ctypes.data_as(C.c_void_p)
+            _ffi.check(_ffi.lib().cdkf_ekf_loglik_grad_f64(C.byref(blk.c), C.byref(opts), N, T, vp(t_l), vp(y_l), vp(ll), vp(g), vp(st)))
+            assert relerr(g, g_ref) < 1e-8 and relerr(ll, ll_ref) < 1e-10, (kind, layout, N)
+            _ffi.check(_ffi.lib().cdkf_ekf_loglik_grad_all_f64(C.byref(blk.c), C.byref(opts), N, T, vp(t_l), vp(y_l), vp(ll), vp(g),
+                                                               vp(gm), vp(st)))
+            assert relerr(g, g_ref) < 1e-8 and np.isfinite(gm).all(), (kind, layout, N)
