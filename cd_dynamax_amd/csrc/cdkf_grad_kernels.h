@@ -301,7 +301,8 @@ struct GradArgs {
 };
 
 // ---- log-likelihood + gradient sweep -----------------------------------------------------------------------
-template <typename R, int D, int M, typename Drift>
+// GENERIC: run-time Runge-Kutta tableau / adaptive steps (opts.solver, opts.adaptive) instead of the pinned Dormand-Prince
+template <typename R, int D, int M, typename Drift, bool GENERIC = false>
 __global__ __launch_bounds__(64, 1) void ekf_grad_reg_kernel(const GradArgs<R, D, M, Drift> ga) {
   constexpr int NS = Dims<D>::NS;
   constexpr int NP = Dims<D>::NP;
@@ -328,8 +329,7 @@ __global__ __launch_bounds__(64, 1) void ekf_grad_reg_kernel(const GradArgs<R, D
   LlAcc ll;
   double g = 0.0;
   int st = 0;
-  Dp5V<R> C;
-  C.init();
+  const auto C = TabSel<R, GENERIC>::get(a);
   DriftGrad<R, D, Drift> dg;
   dg.init(p);
   EkfSensRhs<R, D, Drift> rhs{a.drift, dg, a.LQL};
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(64, 1) void ekf_grad_reg_kernel(const GradArgs<R, D
     const R tnn = tp[0];
     // the last predict (over dt_final) does not enter the log-likelihood: skip it
     if (k + 1 < a.T) {
-      const bool capped = integrate<R, 2 * NS>(ys, tcur, t1, a.dt0, a.max_steps, rhs, C);
+      const bool capped = integrate<R, 2 * NS, 0, NS>(ys, tcur, t1, a.dt0, a.max_steps, rhs, C);
       if (capped) st |= kStatusMaxSteps;
     }
     tcur = tnext_obs;

@@ -266,12 +266,16 @@ CDKF_DEV double rmax(double a, double b) { return fmax(a, b); }
 // and the FULL d x d covariance, so the packed off-diagonal entries count twice -- scaled by atol + max(|y|, |y_new|) rtol;
 // accept iff < 1; next size = attempted size * clip(0.9 e^-c1 e1^-c2 e2^-c3, [1 if accepted else 0.2, 10]); a rejected step
 // that would cross the end goes half-way.  max_steps counts attempts.  Each lane adapts on its own.
-template <typename R, int NS, int MEAN_ONLY, typename Rhs>
+// NERR: the leading entries of y that form the reference's state pytree and enter the error norm (all of them for the
+// filters; the primal half for the forward-sensitivity gradient kernels, whose tangents ride along on the primal's steps
+// exactly as JAX differentiates the solve: the controller's factor is under stop_gradient).
+template <typename R, int NS, int MEAN_ONLY, int NERR, typename Rhs>
 CDKF_DEV bool integrate_adaptive(R (&y)[NS], R t0, R t1, R dt0, long max_steps, const Rhs& rhs, const RkTab<R>& tb) {
-  // state dimension behind the packed layout NS = D + D (D + 1) / 2
-  constexpr int D = MEAN_ONLY ? NS : (NS == 2 ? 1 : NS == 5 ? 2 : NS == 9 ? 3 : NS == 14 ? 4 : NS == 20 ? 5 : NS == 27 ? 6 : -1);
+  // state dimension behind the packed layout NERR = D + D (D + 1) / 2
+  constexpr int D =
+      MEAN_ONLY ? NERR : (NERR == 2 ? 1 : NERR == 5 ? 2 : NERR == 9 ? 3 : NERR == 14 ? 4 : NERR == 20 ? 5 : NERR == 27 ? 6 : -1);
   static_assert(D > 0, "integrate_adaptive: unexpected state size");
-  constexpr int COUNT = MEAN_ONLY ? NS : D + D * D;
+  constexpr int COUNT = MEAN_ONLY ? NERR : D + D * D;
   R tprev = t0;
   R tnext = rmin(t0 + dt0, t1);
   R inv1 = R(1), inv2 = R(1);
@@ -316,7 +320,7 @@ CDKF_DEV bool integrate_adaptive(R (&y)[NS], R t0, R t1, R dt0, long max_steps, 
     }
     R sq = R(0);
 #pragma unroll
-    for (int e = 0; e < NS; ++e) {
+    for (int e = 0; e < NERR; ++e) {
       R err = R(0);
 #pragma unroll
       for (int s = 0; s < 7; ++s) err = rfma(tb.berr[s], k[s][e], err);
@@ -357,9 +361,9 @@ CDKF_DEV bool integrate_adaptive(R (&y)[NS], R t0, R t1, R dt0, long max_steps, 
   return capped;
 }
 
-template <typename R, int NS, int MEAN_ONLY = 0, typename Rhs>
+template <typename R, int NS, int MEAN_ONLY = 0, int NERR = NS, typename Rhs>
 CDKF_DEV bool integrate(R (&y)[NS], R t0, R t1, R dt0, long max_steps, const Rhs& rhs, const RkTab<R>& tb) {
-  if (tb.adaptive) return integrate_adaptive<R, NS, MEAN_ONLY>(y, t0, t1, dt0, max_steps, rhs, tb);
+  if (tb.adaptive) return integrate_adaptive<R, NS, MEAN_ONLY, NERR>(y, t0, t1, dt0, max_steps, rhs, tb);
   R tprev = t0;
   R tnext = rmin(t0 + dt0, t1);
   long steps = 0;
@@ -378,7 +382,7 @@ CDKF_DEV bool integrate(R (&y)[NS], R t0, R t1, R dt0, long max_steps, const Rhs
   return capped;
 }
 
-template <typename R, int NS, int MEAN_ONLY = 0, typename Rhs>
+template <typename R, int NS, int MEAN_ONLY = 0, int NERR = NS, typename Rhs>
 CDKF_DEV bool integrate(R (&y)[NS], R t0, R t1, R dt0, long max_steps, const Rhs& rhs, const Dp5V<R>& C) {
   R tprev = t0;
   R tnext = rmin(t0 + dt0, t1);

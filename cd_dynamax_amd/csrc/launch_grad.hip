@@ -15,7 +15,6 @@
 namespace cdkf {
 
 static bool sens_shape_available(const cdkf_model* mdl, const cdkf_opts* o) {
-  if (o->solver != CDKF_SOLVER_DOPRI5 || o->adaptive) return false;
   if (o->state_order == CDKF_ORDER_ZEROTH || o->num_iter != 1 || o->forecast) return false;
 #define X(KIND, DRIFT, D_, M_) \
   if (mdl->drift_kind == KIND && mdl->state_dim == D_ && mdl->emission_dim == M_) return true;
@@ -35,7 +34,11 @@ static int run_grad(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_
   fill_reg_args(ga.a, mdl, o, N, T, t, y, ll, (R*)nullptr, (R*)nullptr, (R*)nullptr, (R*)nullptr, status);
   ga.grad = grad;
   const long lanes = (long)N * DriftGrad<R, D, Drift>::NPAR;
-  hipLaunchKernelGGL((ekf_grad_reg_kernel<R, D, M, Drift>), dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, stream, ga);
+  const dim3 grid((unsigned)((lanes + 63) / 64)), block(64);
+  if (o->solver != CDKF_SOLVER_DOPRI5 || o->adaptive)  // run-time tableau / adaptive steps: the tangents ride on the primal's steps
+    hipLaunchKernelGGL((ekf_grad_reg_kernel<R, D, M, Drift, true>), grid, block, 0, stream, ga);
+  else
+    hipLaunchKernelGGL((ekf_grad_reg_kernel<R, D, M, Drift>), grid, block, 0, stream, ga);
   CDKF_HIP_CHECK(hipGetLastError());
   return CDKF_OK;
 }

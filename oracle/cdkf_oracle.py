@@ -433,7 +433,7 @@ def dopri5_step(rhs, y, dt):
     return _tree_axpy(y, ks, B, dtype)
 
 
-def diffeqsolve(rhs, t0, t1, y0, dt0=0.01, max_steps=100000, count_steps=None):
+def diffeqsolve(rhs, t0, t1, y0, dt0=0.01, max_steps=100000, count_steps=None, err_components=None):
     """Integrate the autonomous ODE y' = rhs(y) from t0 to t1 (both [N]) with fixed-step Dopri5.
 
     Mirrors diffrax 0.4.0: tprev=t0, tnext=min(t0+dt0, t1); while tprev < t1: step(tprev->tnext);
@@ -443,7 +443,7 @@ def diffeqsolve(rhs, t0, t1, y0, dt0=0.01, max_steps=100000, count_steps=None):
     autonomous right-hand sides of this path the caller passes t0=0, t1=t1-t0 and the negated rhs.
     """
     if _ACTIVE[-1][1] is not None:
-        return _diffeqsolve_adaptive(rhs, t0, t1, y0, dt0, max_steps, count_steps)
+        return _diffeqsolve_adaptive(rhs, t0, t1, y0, dt0, max_steps, count_steps, err_components)
     dtype = y0[0].dtype
     tol = dtype.type(1e-10 if dtype == np.float64 else 1e-6)
     t0 = np.asarray(t0, dtype=dtype)
@@ -471,7 +471,7 @@ def diffeqsolve(rhs, t0, t1, y0, dt0=0.01, max_steps=100000, count_steps=None):
     return y
 
 
-def _diffeqsolve_adaptive(rhs, t0, t1, y0, dt0, max_steps, count_steps):
+def _diffeqsolve_adaptive(rhs, t0, t1, y0, dt0, max_steps, count_steps, err_components=None):
     """diffrax.PIDController around the embedded pair (diffrax 0.4.0 is not in the mount; restated from its published
     algorithm -- step_size_controller/adaptive.py and the integrate loop):
       y_error      = dt * sum_i (b_sol - b_hat)_i k_i, the last stage being f(y_candidate) (FSAL methods)
@@ -501,7 +501,10 @@ def _diffeqsolve_adaptive(rhs, t0, t1, y0, dt0, max_steps, count_steps):
     inv2 = np.ones(N, dtype)
     nsteps = np.zeros(N, dtype=np.int64)
     bc = lambda v, c: v.reshape((-1,) + (1,) * (c.ndim - 1))
-    size = sum(int(np.prod(c.shape[1:])) for c in y0)
+    # err_components: how many leading components form the reference's state pytree and enter the error norm (the forward-
+    # sensitivity gradient integrates tangents alongside; JAX differentiates the solve with the controller under stop_gradient)
+    nerr = len(y0) if err_components is None else err_components
+    size = sum(int(np.prod(c.shape[1:])) for c in y0[:nerr])
     for _ in range(int(max_steps)):
         active = tprev < t1
         if not active.any():
@@ -516,7 +519,7 @@ def _diffeqsolve_adaptive(rhs, t0, t1, y0, dt0, max_steps, count_steps):
             ks.append(tuple(bc(dt, c) * c for c in rhs(ynew)))
         yerr = tuple(sum(dtype.type(Berr[i]) * ks[i][c] for i in range(len(ks)) if Berr[i] != 0.0) for c in range(len(y)))
         sq = np.zeros(N, dtype)
-        for c in range(len(y)):
+        for c in range(nerr):
             sc = yerr[c] / (atol + np.maximum(np.abs(y[c]), np.abs(ynew[c])) * rtol)
             sq = sq + np.sum((sc * sc).reshape(N, -1), axis=1)
         scaled = np.sqrt(sq / dtype.type(size))
@@ -955,7 +958,7 @@ def ekf_loglik_grad(mdl: Model, t, y, dt0=0.01, dt_final=1e-10, max_steps=100000
             B = dF @ PP[:, None] + F[:, None] @ dPP
             return dmdt, dPdt, ddm, B + T_(B)
 
-        m, P, dm, dP = diffeqsolve(rhs_all, t0s[:, k], t1s[:, k], (m, P, dm, dP), dt0, max_steps)
+        m, P, dm, dP = diffeqsolve(rhs_all, t0s[:, k], t1s[:, k], (m, P, dm, dP), dt0, max_steps, err_components=2)
     return ll, g
 
 

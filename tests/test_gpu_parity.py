@@ -532,8 +532,8 @@ def test_solver_choice_refusals(hip_lib):
         cd.cdnlgssm_filter(params_from(mdl), y, t[..., None], cd.EKFHyperParams(diffeqsolve_settings={"stepsize_controller": object()}))
     l63 = o.lorenz63_model(3)
     y3 = o.simulate(l63, t, rng)
-    with pytest.raises(NotImplementedError, match="no gradient kernel"):
-        cd.cdnlgssm_loglik_and_grad(params_from(l63), y3, t[..., None], cd.EKFHyperParams(diffeqsolve_settings={"solver": "heun"}))
+    with pytest.raises(NotImplementedError, match="no reverse-sweep kernel"):   # the all-parameter sweep is fixed-step Dopri5 only
+        cd.cdnlgssm_loglik_and_grad_all(params_from(l63), y3, t[..., None], cd.EKFHyperParams(diffeqsolve_settings={"solver": "heun"}))
 
 
 @pytest.mark.parametrize("solver,ctrl", [("tsit5", dict(rtol=1e-6, atol=1e-8)), ("dopri5", dict(rtol=1e-5, atol=1e-7, pcoeff=0.1, icoeff=0.3)),
@@ -591,3 +591,28 @@ def test_adaptive_refusals(hip_lib):
         cd.cdnlgssm_filter(params_from(mdl), y8, t[..., None], cd.EKFHyperParams(diffeqsolve_settings={"stepsize_controller": pid}))
     assert cd.cdnlgssm_filter(params_from(l63), y, t[..., None], cd.EKFHyperParams(
         diffeqsolve_settings={"stepsize_controller": cd.ConstantStepSize(), "tol_vbt": 1e-5})).filtered_means.shape == (2, 5, 3)
+
+
+@pytest.mark.parametrize("settings,ctx", [({"solver": "tsit5"}, ("tsit5", None)), ({"solver": "heun", "dt0": 0.002}, ("heun", None)),
+                                          ({"solver": "tsit5", "dt0": 0.05, "stepsize_controller": ("pid", 1e-6, 1e-8)},
+                                           ("tsit5", dict(rtol=1e-6, atol=1e-8)))])
+def test_loglik_gradient_under_solver_settings(hip_lib, settings, ctx):
+    """The reference's tutorial differentiates the log-likelihood under Tsit5 + PIDController and under cheap fixed-step
+    methods (notebooks/tutorial/diffeqsolve_settings_analysis.ipynb).  Forward sensitivities ride on the primal's steps --
+    with adaptive control the error norm sees the primal state only and the controller's factor carries no derivative, which
+    is how JAX differentiates the solve -- against the oracle doing the same."""
+    rng = np.random.default_rng(33)
+    mdl = o.lorenz63_model(1)
+    N, T = 20, 15
+    t = o.irregular_times(rng, N, T, 0.06)
+    y = o.simulate(mdl, t, rng)
+    st = dict(settings)
+    if "stepsize_controller" in st:
+        st["stepsize_controller"] = cd.PIDController(*st["stepsize_controller"][1:])
+    dt0 = st.get("dt0", 0.01)
+    with o.use_solver(ctx[0], adaptive=ctx[1]):
+        ll_ref, g_ref = o.ekf_loglik_grad(mdl, t, y, dt0=dt0)
+    ll, g = cd.cdnlgssm_loglik_and_grad(params_from(mdl), y, t[..., None], cd.EKFHyperParams(diffeqsolve_settings=st))
+    np.testing.assert_allclose(ll, ll_ref, rtol=1e-10)
+    got = np.stack([g.sigma, g.rho, g.beta], -1)
+    assert relerr(got, g_ref) < 1e-8

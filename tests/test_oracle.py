@@ -380,3 +380,23 @@ def test_adaptive_controller_meets_tolerance_and_adapts(name):
         o.diffeqsolve(rhs, np.zeros(1), np.full(1, 3.0), (np.full((1, 1), 0.2),), dt0=3.0, count_steps=counts)   # far too large
         o.diffeqsolve(rhs, np.zeros(1), np.full(1, 3.0), (np.full((1, 1), 0.2),), dt0=0.01, count_steps=counts)
     assert counts[0][0] >= 2
+
+
+def test_gradient_under_another_fixed_step_method_matches_finite_differences():
+    """Forward sensitivities along the steps of a non-default tableau (Heun) are still the derivative of that discretised
+    log-likelihood."""
+    rng = np.random.default_rng(35)
+    mdl = o.lorenz63_model(2)
+    t = o.irregular_times(rng, 2, 12, 0.1)
+    y = o.simulate(mdl, t, rng)
+    with o.use_solver("heun"):
+        _, g = o.ekf_loglik_grad(mdl, t, y)
+        th0 = mdl.drift.theta()
+        for p_ in range(3):
+            h = 1e-6 * max(1.0, abs(th0[p_]))
+            tp, tm = th0.copy(), th0.copy()
+            tp[p_] += h
+            tm[p_] -= h
+            mk = lambda th: o.Model(o.Lorenz63Drift(*th), mdl.L, mdl.Qc, mdl.H, mdl.bias, mdl.R, mdl.m0, mdl.P0)
+            fd = (o.ekf_filter(mk(tp), t, y)["marginal_loglik"] - o.ekf_filter(mk(tm), t, y)["marginal_loglik"]) / (2 * h)
+            np.testing.assert_allclose(g[:, p_], fd, rtol=2e-6, atol=1e-6)
