@@ -53,7 +53,8 @@ constexpr size_t adj_lds_bytes() {
 // layout of the optional model-gradient block (per trajectory): m0 [d] | P0 [d,d] | LQL [d,d] | H [m,d] | bias [m] | R [m,m]
 __host__ __device__ inline long adj_model_grad_size(int d, int m) { return (long)d + 2L * d * d + (long)m * d + m + (long)m * m; }
 
-template <typename R, bool MLP>
+// SMOOTH: the same wavefront machinery runs the EKF (RTS) smoother's backward sweep instead of the adjoint (see below)
+template <typename R, bool MLP, bool SMOOTH = false>
 __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wave8_kernel(const WgArgs<R> a, R* __restrict__ grad,
                                                                                        R* __restrict__ grad_model) {
   constexpr int WAVES = adj_waves<R, MLP>();
@@ -444,6 +445,135 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
       Pb += yP[s];
     }
   };
+
+  // ---- SMOOTH: EKF (RTS) smoother backward sweep for state_dim <= 8 (inference_ekf.py:363-448, 503-531) -------------------
+  // Per interval the filtered (m_f, P_f) are constants: G = F(m_f) + psd_solve(P_f, L Qc L^T)^T and f(m_f) are formed once,
+  // then  dm = -[f(m_f) + G (m_s - m_f)],  dP = -[G P_s + (G P_s)^T - L Qc L^T]  is integrated over [0, t_{k+1} - t_k].
+  if constexpr (SMOOTH) {
+    const R* tp = a.t + n * a.t_sn;
+    auto mo = [&](long k) { return n * a.m_sn + k * a.m_sk + lane * a.m_si; };
+    auto po = [&](long k) { return n * a.P_sn + k * a.P_sk + (long)(i * d + j) * a.P_si; };
+    R lqlcol[8];  // column j of L Qc L^T, the right-hand side of this lane's column solve
+#pragma unroll
+    for (int r = 0; r < 8; ++r) lqlcol[r] = (r < d && j < d) ? (a.par + a.o_LQL)[r * d + j] : R(0);
+    R ms = (lane < d) ? a.fm[mo(a.T - 1)] : R(0);
+    R Ps = inP ? a.fP[po(a.T - 1)] : R(0);
+    if (lane < d) a.sm[mo(a.T - 1)] = ms;
+    if (inP) a.sP[po(a.T - 1)] = Ps;
+    int st = 0;
+    R t1 = tp[(a.T - 1) * a.t_sk];
+    for (long k = a.T - 2; k >= 0; --k) {
+      const R t0 = tp[k * a.t_sk];
+      const R mf = (lane < d) ? a.fm[mo(k)] : R(0);
+      const R Pf = inP ? a.fP[po(k)] : R(0);
+      // F(m_f), f(m_f)
+      if (lane < 8) W[AdjOff::x + lane] = mf;
+      W[AdjOff::P + lane] = Pf;
+      wave_sync();
+      R Fij;
+      if constexpr (MLP) {
+        R xk[8], a1, d1, a2, d2, Tt[8];
+        mlp_fwd(xk, a1, d1, a2, d2, Tt, Fij);
+      } else {
+        drift_fwd(Fij);
+      }
+      wave_sync();
+      const R fmf = (lane < 8) ? W[AdjOff::f + lane] : R(0);
+      // psd_solve(P_f, LQL): Sb = sym(P_f) + 1e-9 I, padded with the identity
+      R s2 = inP ? R(0.5) * (Pf + W[AdjOff::P + j * 8 + i]) + (i == j ? R(1e-9) : R(0)) : (i == j ? R(1) : R(0));
+      R inv2[8];
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        W[AdjOff::S2 + lane] = s2;
+        wave_sync();
+        const R p2 = W[AdjOff::S2 + p * 8 + p];
+        if (p < d && !(p2 > R(0))) st |= kStatusNotPd;
+        const R r2 = rrsqrt(p2);
+        inv2[p] = r2;
+        const R l2i = W[AdjOff::S2 + i * 8 + p] * r2, l2j = W[AdjOff::S2 + j * 8 + p] * r2;
+        wave_sync();
+        if (j == p && i >= p)
+          s2 = (i == p) ? p2 * r2 : l2i;
+        else if (i > p && j > p && j <= i)
+          s2 = rfma(-l2i, l2j, s2);
+      }
+      W[AdjOff::S2 + lane] = s2;
+      wave_sync();
+      R col[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) col[r] = lqlcol[r];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        R w = col[r];
+#pragma unroll
+        for (int c = 0; c < r; ++c) w = rfma(-W[AdjOff::S2 + r * 8 + c], col[c], w);
+        col[r] = w * inv2[r];
+      }
+#pragma unroll
+      for (int r = 7; r >= 0; --r) {
+        R w = col[r];
+#pragma unroll
+        for (int c = r + 1; c < 8; ++c) w = rfma(-W[AdjOff::S2 + c * 8 + r], col[c], w);
+        col[r] = w * inv2[r];
+      }
+      R xij = 0;  // X[i][j] = (Sb^-1 LQL)[i][j]
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+        if (r == i) xij = col[r];
+      W[AdjOff::X + lane] = inP ? xij : R(0);
+      wave_sync();
+      W[AdjOff::G + lane] = Fij + W[AdjOff::X + j * 8 + i];  // G = F + X^T
+      if (lane < 8) W[AdjOff::mb + lane] = mf;
+      wave_sync();
+      // reverse-time right-hand side at the stage value
+      auto rhs_s = [&](R xs, R Pst, R& kM, R& kP) {
+        W[AdjOff::P + lane] = Pst;
+        if (lane < 8) W[AdjOff::x + lane] = xs;
+        wave_sync();
+        const R acc = mm(AdjOff::G, AdjOff::P);
+        W[AdjOff::A + lane] = acc;
+        if (lane < 8) {
+          R sdot = 0;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) sdot = rfma(W[AdjOff::G + lane * 8 + q], W[AdjOff::x + q] - W[AdjOff::mb + q], sdot);
+          kM = (lane < d) ? -(fmf + sdot) : R(0);
+        }
+        wave_sync();
+        kP = inP ? -((acc + W[AdjOff::A + j * 8 + i]) - lql) : R(0);
+        wave_sync();
+      };
+      const R tend = t1 - t0;
+      R tprev = 0, tnext = rmin(a.dt0, tend);
+      long steps = 0;
+      while (tprev < tend) {  // uniform over the wavefront
+        if (steps >= a.max_steps) {
+          st |= kStatusMaxSteps;
+          break;
+        }
+        const R dt = tnext - tprev;
+        R kM[6] = {0, 0, 0, 0, 0, 0}, kP[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int sg = 0; sg < 6; ++sg) rhs_s(stage_in(sg, ms, kM, dt), stage_in(sg, Ps, kP, dt), kM[sg], kP[sg]);
+        R sm_ = 0, sp_ = 0;
+#pragma unroll
+        for (int sg = 0; sg < 6; ++sg) {
+          sm_ = rfma(TB::b[sg], kM[sg], sm_);
+          sp_ = rfma(TB::b[sg], kP[sg], sp_);
+        }
+        ms = rfma(dt, sm_, ms);
+        Ps = rfma(dt, sp_, Ps);
+        tprev = rmin(tnext, tend);
+        const R tn = tnext + a.dt0;
+        tnext = (tn > tend - Tol<R>::v) ? tend : tn;
+        ++steps;
+      }
+      if (lane < d) a.sm[mo(k)] = ms;
+      if (inP) a.sP[po(k)] = Ps;
+      t1 = t0;
+    }
+    if (st && lane == 0 && a.status) atomicOr(&a.status[n], st);
+    return;
+  }
 
   // ---- backward sweep ------------------------------------------------------------------------------------------------
   const R* tp = a.t + n * a.t_sn;

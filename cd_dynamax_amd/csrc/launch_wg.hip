@@ -290,6 +290,9 @@ int launch_ekf_filter_wg(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, i
   return rc ? rc : rc2;
 }
 
+template <typename R, bool MLP, bool SMOOTH = false>
+static int launch_adjoint_kernel(const WgArgs<R>& a, R* grad, R* grad_model, hipStream_t stream);  // defined below
+
 template <typename R>
 int launch_ekf_smoother_wg(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y,
                            R* ll, R* fm, R* fP, R* sm, R* sP, int32_t* status, hipStream_t stream) {
@@ -301,9 +304,11 @@ int launch_ekf_smoother_wg(const cdkf_model* mdl, const cdkf_opts* o, int64_t N,
   int rc = wg_prepare(a, &blk, &slot, mdl, &of, N, T, stream);
   if (rc) return rc;
   a.t = t; a.y = y; a.ll = ll; a.fm = fm; a.fP = fP; a.pm = nullptr; a.pP = nullptr; a.sm = sm; a.sP = sP; a.status = status;
-  if (wave8_shape(mdl)) {  // forward pass on the wavefront-per-trajectory filter (4-6x faster at d <= 8), backward pass below
+  if (wave8_shape(mdl)) {  // state_dim <= 8: both passes on the wavefront-per-trajectory kernels
     rc = launch_wave8<R>(a, stream);
-    if (!rc) rc = launch_wg_dispatch<R>(a, mdl, true, stream, /*filter=*/false);
+    if (!rc)
+      rc = (mdl->drift_kind == CDKF_DRIFT_MLP_TANH) ? launch_adjoint_kernel<R, true, true>(a, nullptr, nullptr, stream)
+                                                     : launch_adjoint_kernel<R, false, true>(a, nullptr, nullptr, stream);
   } else {
     rc = launch_wg_dispatch<R>(a, mdl, true, stream);
   }
@@ -374,14 +379,14 @@ bool adjoint_shape_available(const cdkf_model* mdl, const cdkf_opts* o) {
   return true;
 }
 
-template <typename R, bool MLP>
+template <typename R, bool MLP, bool SMOOTH>
 static int launch_adjoint_kernel(const WgArgs<R>& a, R* grad, R* grad_model, hipStream_t stream) {
-  static const int cap_rc = wg_raise_lds_cap(&ekf_adjoint_wave8_kernel<R, MLP>);
+  static const int cap_rc = wg_raise_lds_cap(&ekf_adjoint_wave8_kernel<R, MLP, SMOOTH>);
   if (cap_rc) return CDKF_EHIP;
   constexpr int WAVES = adj_waves<R, MLP>();
   constexpr size_t lds = adj_lds_bytes<R, MLP>();
   const dim3 grid((unsigned)((a.N + WAVES - 1) / WAVES)), block(64 * WAVES);
-  auto kernel = ekf_adjoint_wave8_kernel<R, MLP>;
+  auto kernel = ekf_adjoint_wave8_kernel<R, MLP, SMOOTH>;
   hipLaunchKernelGGL(kernel, grid, block, lds, stream, a, grad, grad_model);
   CDKF_HIP_CHECK(hipGetLastError());
   return CDKF_OK;
