@@ -31,6 +31,7 @@ struct WgArgs {
   R ukf_c, ukf_wm0, ukf_wi;  // sigma scale sqrt(n + lambda), w_mean[0], 1 / (2 (n + lambda))   (inference_ukf.py:63-89)
   long max_steps;
   R dt0, dt_final;
+  RkTab<R> rk;   // Runge-Kutta tableau of the predict step (opts.solver; fixed steps)
   const R* par;  // device block: theta | LQL[d*d] | LQLz[d*d] | H[m*d] | hb[m] | Rm[m*m] | m0[d] | P0[d*d]
   long o_theta, o_LQL, o_LQLz, o_H, o_hb, o_R, o_m0, o_P0;
   long N, T;
@@ -621,8 +622,13 @@ struct Own {
 // inlined right-hand side, the slope arrays were indexed dynamically and moved to scratch memory (5x slower sweeps).
 template <int S, typename R, int EPT, typename RhsFn>
 __device__ __forceinline__ void wg_stage(const WgLds<R>& L, const Own<R, EPT>& own, int d, R dt, bool with_P, RhsFn& rhs,
-                                         R (&kM)[6], R (&kP)[6][EPT]) {
-  using TB = Dp5T<R>;
+                                         R (&kM)[6], R (&kP)[6][EPT], const RkTab<R>& tb) {
+  if (S >= tb.stages) {  // methods with fewer stages (uniform over the workgroup): no slope, no barrier
+    kM[S] = R(0);
+#pragma unroll
+    for (int u = 0; u < EPT; ++u) kP[S][u] = R(0);
+    return;
+  }
   R* mcur = L.vec(0);
   R* Pm = L.mat(0);
   R* ms = L.vec(1);
@@ -631,18 +637,18 @@ __device__ __forceinline__ void wg_stage(const WgLds<R>& L, const Own<R, EPT>& o
     rhs(mcur, Pm, kM[0], kP[0]);
   } else {
     if (threadIdx.x < d) {
-      R acc = TB::a[S][0] * kM[0];
+      R acc = tb.a[S][0] * kM[0];
 #pragma unroll
-      for (int j = 1; j < S; ++j) acc = rfma(TB::a[S][j], kM[j], acc);
+      for (int j = 1; j < S; ++j) acc = rfma(tb.a[S][j], kM[j], acc);
       ms[threadIdx.x] = rfma(dt, acc, mcur[threadIdx.x]);
     }
     if (with_P) {
 #pragma unroll
       for (int u = 0; u < EPT; ++u)
         if (u < own.n) {
-          R acc = TB::a[S][0] * kP[0][u];
+          R acc = tb.a[S][0] * kP[0][u];
 #pragma unroll
-          for (int j = 1; j < S; ++j) acc = rfma(TB::a[S][j], kP[j][u], acc);
+          for (int j = 1; j < S; ++j) acc = rfma(tb.a[S][j], kP[j][u], acc);
           {
             const int o_ = own.off(u);
             Ps[o_] = rfma(dt, acc, Pm[o_]);
@@ -657,28 +663,30 @@ __device__ __forceinline__ void wg_stage(const WgLds<R>& L, const Own<R, EPT>& o
 
 template <typename R, int EPT, typename RhsFn>
 __device__ __forceinline__ void wg_dopri5_step(const WgLds<R>& L, const Own<R, EPT>& own, int d, R dt, bool with_P,
-                                               RhsFn rhs) {
-  using C = Dp5<R>;
+                                               RhsFn rhs, const RkTab<R>& tb) {
   R* mcur = L.vec(0);
   R* Pm = L.mat(0);
   R kM[6];
   R kP[6][EPT];
-  wg_stage<0>(L, own, d, dt, with_P, rhs, kM, kP);
-  wg_stage<1>(L, own, d, dt, with_P, rhs, kM, kP);
-  wg_stage<2>(L, own, d, dt, with_P, rhs, kM, kP);
-  wg_stage<3>(L, own, d, dt, with_P, rhs, kM, kP);
-  wg_stage<4>(L, own, d, dt, with_P, rhs, kM, kP);
-  wg_stage<5>(L, own, d, dt, with_P, rhs, kM, kP);
+  wg_stage<0>(L, own, d, dt, with_P, rhs, kM, kP, tb);
+  wg_stage<1>(L, own, d, dt, with_P, rhs, kM, kP, tb);
+  wg_stage<2>(L, own, d, dt, with_P, rhs, kM, kP, tb);
+  wg_stage<3>(L, own, d, dt, with_P, rhs, kM, kP, tb);
+  wg_stage<4>(L, own, d, dt, with_P, rhs, kM, kP, tb);
+  wg_stage<5>(L, own, d, dt, with_P, rhs, kM, kP, tb);
   if (threadIdx.x < d) {
-    const R acc = rfma(C::b6, kM[5], rfma(C::b5, kM[4], rfma(C::b4, kM[3], rfma(C::b3, kM[2], C::b1 * kM[0]))));
+    R acc = tb.b[0] * kM[0];
+#pragma unroll
+    for (int sg = 1; sg < 6; ++sg) acc = rfma(tb.b[sg], kM[sg], acc);
     mcur[threadIdx.x] = rfma(dt, acc, mcur[threadIdx.x]);
   }
   if (with_P) {
 #pragma unroll
     for (int u = 0; u < EPT; ++u)
       if (u < own.n) {
-        const R acc =
-            rfma(C::b6, kP[5][u], rfma(C::b5, kP[4][u], rfma(C::b4, kP[3][u], rfma(C::b3, kP[2][u], C::b1 * kP[0][u]))));
+        R acc = tb.b[0] * kP[0][u];
+#pragma unroll
+        for (int sg = 1; sg < 6; ++sg) acc = rfma(tb.b[sg], kP[sg][u], acc);
         {
           const int o_ = own.off(u);
           Pm[o_] = rfma(dt, acc, Pm[o_]);
@@ -690,13 +698,13 @@ __device__ __forceinline__ void wg_dopri5_step(const WgLds<R>& L, const Own<R, E
 
 template <typename R, int EPT, typename RhsFn>
 __device__ __forceinline__ bool wg_integrate(const WgLds<R>& L, const Own<R, EPT>& own, int d, R t0, R t1, R dt0,
-                                             long max_steps, bool with_P, RhsFn rhs) {
+                                             long max_steps, bool with_P, RhsFn rhs, const RkTab<R>& tb) {
   R tprev = t0;
   R tnext = rmin(t0 + dt0, t1);
   long steps = 0;
   while (tprev < t1) {  // uniform over the workgroup
     if (steps >= max_steps) return true;
-    wg_dopri5_step<R, EPT>(L, own, d, tnext - tprev, with_P, rhs);
+    wg_dopri5_step<R, EPT>(L, own, d, tnext - tprev, with_P, rhs, tb);
     tprev = rmin(tnext, t1);
     const R tn = tnext + dt0;
     tnext = (tn > t1 - Tol<R>::v) ? t1 : tn;
@@ -1109,7 +1117,7 @@ __global__ __launch_bounds__(512) void ekf_filter_wg_kernel(const WgArgs<R> a_in
     // (re)derive this thread's entry indices here: values that live across the measurement update would be spilled to
     // scratch by its register pressure and re-loaded inside every Runge-Kutta stage (measured: 3.4x on the d = 40 sweep)
     own.init(d, lq, a.par + a.o_LQL);
-    if (wg_integrate<R, EPT>(L, own, d, t0, t1, a.dt0, a.max_steps, !zeroth, rhs)) st |= kStatusMaxSteps;
+    if (wg_integrate<R, EPT>(L, own, d, t0, t1, a.dt0, a.max_steps, !zeroth, rhs, a.rk)) st |= kStatusMaxSteps;
     if (zeroth) {
       const R sq = rsqrt_(t1 - t0);
       const R* Qz = a.par + a.o_LQLz;
@@ -1211,7 +1219,7 @@ __global__ __launch_bounds__(512) void ekf_smoother_wg_kernel(const WgArgs<R> a)
     }
     __syncthreads();
     own.init(d, lq, a.par + a.o_LQL);  // see the filter kernel
-    if (wg_integrate<R, EPT>(L, own, d, R(0), t1 - t0, a.dt0, a.max_steps, true, rhs)) st |= kStatusMaxSteps;
+    if (wg_integrate<R, EPT>(L, own, d, R(0), t1 - t0, a.dt0, a.max_steps, true, rhs, a.rk)) st |= kStatusMaxSteps;
     wg_store(a, L, a.sm, a.sP, n, k);
     __syncthreads();
     t1 = t0;

@@ -89,10 +89,9 @@ template <typename R>
 static int wg_prepare(WgArgs<R>& a, R** dev_block, ParamSlot** slot_out, const cdkf_model* mdl, const cdkf_opts* o,
                       int64_t N, int64_t T, hipStream_t stream) {
   const int d = mdl->state_dim, m = mdl->emission_dim;
-  if (o->solver != CDKF_SOLVER_DOPRI5 || o->adaptive) {
-    set_error("opts.solver = %d, adaptive = %d: the workgroup / wavefront kernels (state_dim %d, emission_dim %d) integrate with Dormand-Prince "
-              "in fixed steps only; the other Runge-Kutta methods and adaptive stepping run on the register-resident shapes", o->solver,
-              o->adaptive, d, m);
+  if (o->adaptive) {
+    set_error("opts.adaptive: the workgroup / wavefront kernels (state_dim %d, emission_dim %d) integrate in fixed steps only; adaptive "
+              "stepping runs on the register-resident shapes", d, m);
     return CDKF_EUNSUPPORTED;
   }
   if (!wg_shape_available(mdl, sizeof(R))) {
@@ -152,6 +151,7 @@ static int wg_prepare(WgArgs<R>& a, R** dev_block, ParamSlot** slot_out, const c
   a.order = o->state_order;
   a.num_iter = o->num_iter;
   a.max_steps = (long)o->max_steps;
+  fill_rk_tab<R>(o, a.rk);
   a.dt0 = R(o->dt0);
   a.dt_final = R(o->dt_final);
   a.N = N;
@@ -285,7 +285,8 @@ int launch_ekf_filter_wg(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, i
   if (rc) return rc;
   a.t = t; a.y = y; a.ll = ll; a.fm = fm; a.fP = fP; a.pm = pm; a.pP = pP; a.status = status;
   if (!y) { a.y = t; a.y_sn = a.y_sk = a.y_si = 0; }  // forecast mode: observations are ignored
-  rc = wave8_shape(mdl) ? launch_wave8<R>(a, stream) : launch_wg_dispatch<R>(a, mdl, false, stream);
+  rc = (wave8_shape(mdl) && o->solver == CDKF_SOLVER_DOPRI5) ? launch_wave8<R>(a, stream)  // (wave8 carries the Dopri5 constants)
+                                                             : launch_wg_dispatch<R>(a, mdl, false, stream);
   const int rc2 = param_pool_release(slot, stream);
   return rc ? rc : rc2;
 }
@@ -304,7 +305,7 @@ int launch_ekf_smoother_wg(const cdkf_model* mdl, const cdkf_opts* o, int64_t N,
   int rc = wg_prepare(a, &blk, &slot, mdl, &of, N, T, stream);
   if (rc) return rc;
   a.t = t; a.y = y; a.ll = ll; a.fm = fm; a.fP = fP; a.pm = nullptr; a.pP = nullptr; a.sm = sm; a.sP = sP; a.status = status;
-  if (wave8_shape(mdl)) {  // state_dim <= 8: both passes on the wavefront-per-trajectory kernels
+  if (wave8_shape(mdl) && o->solver == CDKF_SOLVER_DOPRI5) {  // state_dim <= 8: both passes on the wavefront-per-trajectory kernels
     rc = launch_wave8<R>(a, stream);
     if (!rc)
       rc = (mdl->drift_kind == CDKF_DRIFT_MLP_TANH) ? launch_adjoint_kernel<R, true, true>(a, nullptr, nullptr, stream)
@@ -433,6 +434,10 @@ bool smoother1_shape_available(const cdkf_model* mdl) {
 template <typename R>
 int launch_kf_smoother1(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll,
                         R* fm, R* fP, R* sm, R* sP, R* cross, int32_t* status, hipStream_t stream) {
+  if (o->solver != CDKF_SOLVER_DOPRI5 || o->adaptive) {
+    set_error("kf_smoother1: the pushed-forward (A, Q) are integrated with fixed-step Dormand-Prince only");
+    return CDKF_EUNSUPPORTED;
+  }
   if (!smoother1_shape_available(mdl)) {
     set_error("kf_smoother1: needs a linear drift with zero bias and state_dim <= 8 (got drift_kind=%d state_dim=%d)",
               mdl->drift_kind, mdl->state_dim);

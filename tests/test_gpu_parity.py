@@ -524,8 +524,6 @@ def test_solver_choice_refusals(hip_lib):
     mdl = lorenz96_model(8, 4)
     t = o.irregular_times(rng, 2, 5, 0.1)
     y = o.simulate(mdl, t, rng)
-    with pytest.raises(_ffi.CdkfError, match="fixed steps only"):
-        cd.cdnlgssm_filter(params_from(mdl), y, t[..., None], cd.EKFHyperParams(diffeqsolve_settings={"solver": "tsit5"}))
     with pytest.raises(NotImplementedError, match="choose from"):
         cd.cdnlgssm_filter(params_from(mdl), y, t[..., None], cd.EKFHyperParams(diffeqsolve_settings={"solver": "kvaerno5"}))
     with pytest.raises(NotImplementedError, match="stepsize_controller"):

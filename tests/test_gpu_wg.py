@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 
 import cd_dynamax_amd as cd
+from cd_dynamax_amd import _ffi
 import cdkf_oracle as o
 from helpers import (FILTER_KEYS, GOLDEN_WIDE, linear_model, load_golden, lorenz96_model, mlp_model, model_from_fixture,
                      params_from, relerr)
@@ -216,3 +217,29 @@ def test_loglik_gradient_all_parameters(hip_lib, kind, d, m):
     ll1, g1 = cd.cdnlgssm_loglik_and_grad_all(params_from(mdl), y[2], t[2][:, None], hyp)
     assert np.ndim(ll1) == 0 and g1.emissions.emission_cov.params.shape == (m, m)
     close(g1.emissions.emission_cov.params, ex["R"][2], "R[2]")
+
+
+@pytest.mark.parametrize("solver", ["tsit5", "heun", "euler"])
+def test_workgroup_kernels_other_runge_kutta_methods(hip_lib, solver):
+    """diffeqsolve_settings={'solver': ...} beyond the register-resident shapes: Lorenz-96 d = 12 (workgroup kernels) and
+    d = 6 / an MLP drift at d = 5 (state_dim <= 8 takes the workgroup kernels for non-default methods), EKF / UKF / smoother."""
+    rng = np.random.default_rng(17)
+    settings = {"solver": solver}
+    for mdl in (lorenz96_model(12, 5), lorenz96_model(6, 6), mlp_model(rng, 5, 2, (9, 7))):
+        N, T = 3, 8
+        t = o.irregular_times(rng, N, T, 0.03)
+        y = o.simulate(mdl, t, rng)
+        P = params_from(mdl)
+        with o.use_solver(solver):
+            ref = o.ekf_filter(mdl, t, y, state_order="first")
+            refu = o.ukf_filter(mdl, t, y)
+            refs = o.ekf_smoother(mdl, t, y, state_order="first")
+        post = cd.cdnlgssm_filter(P, y, t[..., None], cd.EKFHyperParams(state_order="first", diffeqsolve_settings=settings))
+        for k in FILTER_KEYS:
+            assert relerr(getattr(post, k), ref[k]) < 1e-10, k
+        postu = cd.cdnlgssm_filter(P, y, t[..., None], cd.UKFHyperParams(diffeqsolve_settings=settings))
+        assert relerr(postu.filtered_covariances, refu["filtered_covariances"]) < 1e-9
+        sm = cd.cdnlgssm_smoother(P, y, t[..., None], cd.EKFHyperParams(state_order="first", diffeqsolve_settings=settings))
+        assert relerr(sm.smoothed_covariances, refs["smoothed_covariances"]) < 1e-9
+    with pytest.raises(_ffi.CdkfError, match="fixed steps only"):
+        cd.cdnlgssm_filter(P, y, t[..., None], cd.EKFHyperParams(diffeqsolve_settings={"stepsize_controller": cd.PIDController(1e-3, 1e-6)}))
