@@ -614,3 +614,31 @@ def test_loglik_gradient_under_solver_settings(hip_lib, settings, ctx):
     np.testing.assert_allclose(ll, ll_ref, rtol=1e-10)
     got = np.stack([g.sigma, g.rho, g.beta], -1)
     assert relerr(got, g_ref) < 1e-8
+
+
+def test_integration_md_binding_stub_runs(hip_lib):
+    """The ctypes stub INTEGRATION.md shows a maintainer (section 2) is executed as written -- only the library path and the
+    posterior class are supplied -- and must agree with the package's own filter: the documented struct layouts and call
+    sequence are the real ones."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    block = re.search(r"```python\nimport ctypes as C, numpy as np\n(.*?)```", text, re.S).group(0)
+    code = block.strip("`").replace("python\n", "", 1)
+    code = code.replace('C.CDLL("libcdkf_hip.so")', f'C.CDLL({_ffi.LIB_PATH!r})')
+    ns = {"PosteriorGSSMFiltered": cd.PosteriorGSSMFiltered}
+    exec(code, ns)
+    ns["_lib"].cdkf_last_error.restype = C.c_char_p
+    rng = np.random.default_rng(5)
+    mdl = o.lorenz63_model(2)
+    T = 30
+    t = o.irregular_times(rng, 1, T, 0.3)
+    y = o.simulate(mdl, t, rng)[0]
+    P = params_from(mdl)
+    hyp = cd.EKFHyperParams()
+    got = ns["_hip_ekf_filter"](P, y, t[0][:, None], hyp, 1)
+    ref = cd.cdnlgssm_filter(P, y, t[0][:, None], hyp)
+    for k in FILTER_KEYS:
+        assert relerr(getattr(got, k), getattr(ref, k)) < 1e-13, k
+    assert abs(got.marginal_loglik - ref.marginal_loglik) < 1e-12 * abs(ref.marginal_loglik)
