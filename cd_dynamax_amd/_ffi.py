@@ -31,6 +31,7 @@ DRIFT_MLP_TANH = 3
 LAYOUT_NT = 0
 LAYOUT_TN = 1
 LAYOUT_TCN = 2
+LAYOUT_SAME = -1
 
 ORDER = {"zeroth": 0, "first": 1, "second": 2}
 
@@ -79,6 +80,8 @@ class CdkfOpts(C.Structure):
         ("pid_p", C.c_double),
         ("pid_i", C.c_double),
         ("pid_d", C.c_double),
+        ("layout_in", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 
@@ -274,20 +277,20 @@ def run_host(algo: str, mdl: ModelBlock, opts: CdkfOpts, t: np.ndarray, y: np.nd
     the four optional output arrays in ABI order.  Returns (ll, [4 arrays or None], status); the
     arrays have the reference shapes [N,T,...].
 
-    The device side runs in the layout the library prefers for this model (cdkf_preferred_layout:
+    The outputs are produced in the layout the library prefers for this model (cdkf_preferred_layout:
     CDKF_LAYOUT_TCN = [T,w,N] for the lane-per-trajectory kernels, CDKF_LAYOUT_TN = [T,N,w] for the
-    workgroup-per-trajectory ones): inputs are transposed on the host before upload and the outputs
-    come back as transposed VIEWS of those buffers (same shapes and values as the reference's arrays).
+    workgroup-per-trajectory ones) and come back as transposed VIEWS of those buffers (same shapes and values as
+    the reference's arrays); the inputs are uploaded untransposed (opts.layout_in = CDKF_LAYOUT_NT).
     """
     dtype = np.dtype(dtype)
     suffix = {np.dtype(np.float32): "f32", np.dtype(np.float64): "f64"}[dtype]
     N, T, m = y.shape
     d = mdl.state_dim
     opts.layout = lib().cdkf_preferred_layout(C.byref(mdl.c))
+    opts.layout_in = LAYOUT_NT  # t and y go over as they are ([N,T], [N,T,m]): no host-side transposition of the inputs
     tcn = opts.layout == LAYOUT_TCN
-    t = np.asarray(t, dtype=dtype)
-    t = np.ascontiguousarray(t if opts.t_shared else t.T)
-    y = np.ascontiguousarray(np.asarray(y, dtype=dtype).transpose((1, 2, 0) if tcn else (1, 0, 2)))
+    t = np.ascontiguousarray(t, dtype=dtype)
+    y = np.ascontiguousarray(y, dtype=dtype)
     ll = np.empty((N,), dtype)
     status = np.zeros((N,), np.int32)
     shapes = [(T, d, N), (T, d, d, N), (T, d, N), (T, d, d, N)] if tcn else [(T, N, d), (T, N, d, d)] * 2
@@ -327,9 +330,9 @@ def kf_smoother1(mdl: ModelBlock, opts: CdkfOpts, t: np.ndarray, y: np.ndarray, 
     N, T, m = y.shape
     d = mdl.state_dim
     opts.layout = LAYOUT_TN
-    t = np.asarray(t, dtype=dtype)
-    t = np.ascontiguousarray(t if opts.t_shared else t.T)
-    y = np.ascontiguousarray(np.asarray(y, dtype=dtype).transpose(1, 0, 2))
+    opts.layout_in = LAYOUT_NT
+    t = np.ascontiguousarray(t, dtype=dtype)
+    y = np.ascontiguousarray(y, dtype=dtype)
     ll = np.empty((N,), dtype)
     status = np.zeros((N,), np.int32)
     fm, sm = (np.empty((T, N, d), dtype) for _ in range(2))
@@ -351,10 +354,10 @@ def loglik_grad(mdl: ModelBlock, opts: CdkfOpts, t: np.ndarray, y: np.ndarray, d
     dtype = np.dtype(dtype)
     suffix = {np.dtype(np.float32): "f32", np.dtype(np.float64): "f64"}[dtype]
     N, T, m = y.shape
-    opts.layout = LAYOUT_TCN  # the gradient kernels are lane-per-(trajectory, parameter): coalesced in [T,w,N]
-    t = np.asarray(t, dtype=dtype)
-    t = np.ascontiguousarray(t if opts.t_shared else t.T)
-    y = np.ascontiguousarray(np.asarray(y, dtype=dtype).transpose(1, 2, 0))
+    opts.layout = LAYOUT_TCN
+    opts.layout_in = LAYOUT_NT  # inputs as they are; only ll [N] and grad [N, n_theta] come back
+    t = np.ascontiguousarray(t, dtype=dtype)
+    y = np.ascontiguousarray(y, dtype=dtype)
     ll = np.empty((N,), dtype)
     grad = np.empty((N, mdl.theta.size), dtype)
     status = np.zeros((N,), np.int32)

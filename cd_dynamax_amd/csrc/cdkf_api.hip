@@ -48,6 +48,11 @@ int check_common(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T
     set_error("opts.layout must be CDKF_LAYOUT_NT, CDKF_LAYOUT_TN or CDKF_LAYOUT_TCN");
     return CDKF_EINVAL;
   }
+  if (o->layout_in != CDKF_LAYOUT_SAME && o->layout_in != CDKF_LAYOUT_NT && o->layout_in != CDKF_LAYOUT_TN &&
+      o->layout_in != CDKF_LAYOUT_TCN) {
+    set_error("opts.layout_in must be CDKF_LAYOUT_SAME or one of the CDKF_LAYOUT_* values");
+    return CDKF_EINVAL;
+  }
   if (o->solver < CDKF_SOLVER_DOPRI5 || o->solver > CDKF_SOLVER_EULER || (o->adaptive != 0 && o->adaptive != 1)) {
     set_error("opts.solver must be one of CDKF_SOLVER_* (got %d) and opts.adaptive 0 or 1 (got %d)", o->solver, o->adaptive);
     return CDKF_EINVAL;
@@ -381,6 +386,8 @@ void cdkf_default_opts(cdkf_opts* o) {
   o->pid_p = 0.0;
   o->pid_i = 1.0;
   o->pid_d = 0.0;
+  o->layout_in = CDKF_LAYOUT_SAME;
+  o->reserved = 0;
   o->max_steps = 100000;
   o->dt0 = 0.01;
   o->dt_final = 1e-10;

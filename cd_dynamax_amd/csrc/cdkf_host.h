@@ -128,6 +128,33 @@ inline bool fill_rk_tab(const cdkf_opts* o, RkTab<R>& tb) {
   return true;
 }
 
+// Element (n, k, i) of an array lives at n * sn + k * sk + i * si.  opts.layout places the OUTPUT arrays (means,
+// covariances); the inputs t and y follow opts.layout_in (CDKF_LAYOUT_SAME = like the outputs).  w = components per row.
+struct ArrayStrides {
+  long sn, sk, si;
+};
+inline ArrayStrides layout_strides(int layout, long N, long T, long w) {
+  if (layout == CDKF_LAYOUT_TCN) return {1, N * w, N};
+  if (layout == CDKF_LAYOUT_TN) return {w, N * w, 1};
+  return {T * w, w, 1};
+}
+struct SweepStrides {
+  long t_sn, t_sk, y_sn, y_sk, y_si, m_sn, m_sk, m_si, P_sn, P_sk, P_si;
+};
+inline SweepStrides sweep_strides(const cdkf_opts* o, long N, long T, long D, long M, bool no_y) {
+  const int lin = (o->layout_in == CDKF_LAYOUT_SAME) ? o->layout : o->layout_in;
+  const ArrayStrides ts = layout_strides(lin, N, T, 1), ys = layout_strides(lin, N, T, M);
+  const ArrayStrides ms = layout_strides(o->layout, N, T, D), Ps = layout_strides(o->layout, N, T, D * D);
+  SweepStrides s;
+  s.t_sn = o->t_shared ? 0 : ts.sn;
+  s.t_sk = o->t_shared ? 1 : ts.sk;
+  s.y_sn = ys.sn; s.y_sk = ys.sk; s.y_si = ys.si;
+  s.m_sn = ms.sn; s.m_sk = ms.sk; s.m_si = ms.si;
+  s.P_sn = Ps.sn; s.P_sk = Ps.sk; s.P_si = Ps.si;
+  if (no_y) s.y_sn = s.y_sk = s.y_si = 0;  // forecast mode: every 'observation' load hits one valid address
+  return s;
+}
+
 template <typename R, int D, int M, typename Drift>
 void fill_reg_args(RegArgs<R, D, M, Drift>& a, const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T,
                    const R* t, const R* y, R* ll, R* fm, R* fP, R* pm, R* pP, int32_t* status) {
@@ -163,36 +190,12 @@ void fill_reg_args(RegArgs<R, D, M, Drift>& a, const cdkf_model* mdl, const cdkf
   fill_rk_tab<R>(o, a.rk);  // opts.solver / adaptive were validated by check_common
   a.N = N;
   a.T = T;
-  a.y_si = a.m_si = a.P_si = 1;
   const bool no_y = (y == nullptr);
-  if (o->layout == CDKF_LAYOUT_TCN) {  // [T,w,N]: component-major inside a time step
-    a.t_sn = o->t_shared ? 0 : 1;
-    a.t_sk = o->t_shared ? 1 : N;
-    a.y_sn = a.m_sn = a.P_sn = 1;
-    a.y_sk = N * M;
-    a.m_sk = N * D;
-    a.P_sk = N * D * D;
-    a.y_si = a.m_si = a.P_si = N;
-  } else if (o->layout == CDKF_LAYOUT_TN) {  // time-major [T,N,w]
-    a.t_sn = o->t_shared ? 0 : 1;
-    a.t_sk = o->t_shared ? 1 : N;
-    a.y_sn = M;
-    a.y_sk = N * M;
-    a.m_sn = D;
-    a.m_sk = N * D;
-    a.P_sn = D * D;
-    a.P_sk = N * D * D;
-  } else {  // reference layout [N,T,w]
-    a.t_sn = o->t_shared ? 0 : T;
-    a.t_sk = 1;
-    a.y_sn = T * M;
-    a.y_sk = M;
-    a.m_sn = T * D;
-    a.m_sk = D;
-    a.P_sn = T * D * D;
-    a.P_sk = D * D;
+  {
+    const SweepStrides st = sweep_strides(o, N, T, D, M, no_y);
+    a.t_sn = st.t_sn; a.t_sk = st.t_sk; a.y_sn = st.y_sn; a.y_sk = st.y_sk; a.y_si = st.y_si;
+    a.m_sn = st.m_sn; a.m_sk = st.m_sk; a.m_si = st.m_si; a.P_sn = st.P_sn; a.P_sk = st.P_sk; a.P_si = st.P_si;
   }
-  if (no_y) a.y_sn = a.y_sk = a.y_si = 0;  // every 'observation' load hits t[0]
   a.t = t;
   a.y = y ? y : t;  // forecast mode ignores the observations; keep the prefetch loads on valid memory
   a.ll = ll;

@@ -338,26 +338,13 @@ int launch_custom(int algo, const cdkf_model* mdl, const cdkf_opts* o, int64_t N
   ip[3] = smoother ? 0 : o->forecast;
   ip[4] = N;
   ip[5] = T;
-  const long M = m, D = d;
-  long* st = ip + 6;  // t_sn t_sk y_sn y_sk y_si m_sn m_sk m_si P_sn P_sk P_si
-  st[4] = st[7] = st[10] = 1;
-  if (o->layout == CDKF_LAYOUT_TCN) {
-    st[0] = o->t_shared ? 0 : 1; st[1] = o->t_shared ? 1 : N;
-    st[2] = st[5] = st[8] = 1;
-    st[3] = N * M; st[6] = N * D; st[9] = N * D * D;
-    st[4] = st[7] = st[10] = N;
-  } else if (o->layout == CDKF_LAYOUT_TN) {
-    st[0] = o->t_shared ? 0 : 1; st[1] = o->t_shared ? 1 : N;
-    st[2] = M; st[3] = N * M; st[5] = D; st[6] = N * D; st[8] = D * D; st[9] = N * D * D;
-  } else {
-    st[0] = o->t_shared ? 0 : T; st[1] = 1;
-    st[2] = T * M; st[3] = M; st[5] = T * D; st[6] = D; st[8] = T * D * D; st[9] = D * D;
+  {
+    const SweepStrides ss = sweep_strides(o, N, T, d, m, !y);
+    long* st = ip + 6;  // t_sn t_sk y_sn y_sk y_si m_sn m_sk m_si P_sn P_sk P_si
+    st[0] = ss.t_sn; st[1] = ss.t_sk; st[2] = ss.y_sn; st[3] = ss.y_sk; st[4] = ss.y_si; st[5] = ss.m_sn; st[6] = ss.m_sk;
+    st[7] = ss.m_si; st[8] = ss.P_sn; st[9] = ss.P_sk; st[10] = ss.P_si;
   }
-  const R* yy = y;
-  if (!y) {  // forecast mode ignores the observations; keep the prefetch loads on valid memory
-    yy = t;
-    st[2] = st[3] = st[4] = 0;
-  }
+  const R* yy = y ? y : t;  // forecast mode ignores the observations; keep the prefetch loads on valid memory
   const size_t par_bytes = par.size() * sizeof(R), blob = ((par_bytes + 15) & ~size_t(15)) + sizeof(ip);
   ParamSlot* slot = nullptr;
   int rc = param_pool_acquire(blob, &slot);

@@ -156,34 +156,10 @@ static int wg_prepare(WgArgs<R>& a, R** dev_block, ParamSlot** slot_out, const c
   a.dt_final = R(o->dt_final);
   a.N = N;
   a.T = T;
-  a.y_si = a.m_si = a.P_si = 1;
-  const long M = m, D = d;
-  if (o->layout == CDKF_LAYOUT_TCN) {
-    a.t_sn = o->t_shared ? 0 : 1;
-    a.t_sk = o->t_shared ? 1 : N;
-    a.y_sn = a.m_sn = a.P_sn = 1;
-    a.y_sk = N * M;
-    a.m_sk = N * D;
-    a.P_sk = N * D * D;
-    a.y_si = a.m_si = a.P_si = N;
-  } else if (o->layout == CDKF_LAYOUT_TN) {
-    a.t_sn = o->t_shared ? 0 : 1;
-    a.t_sk = o->t_shared ? 1 : N;
-    a.y_sn = M;
-    a.y_sk = N * M;
-    a.m_sn = D;
-    a.m_sk = N * D;
-    a.P_sn = D * D;
-    a.P_sk = N * D * D;
-  } else {
-    a.t_sn = o->t_shared ? 0 : T;
-    a.t_sk = 1;
-    a.y_sn = T * M;
-    a.y_sk = M;
-    a.m_sn = T * D;
-    a.m_sk = D;
-    a.P_sn = T * D * D;
-    a.P_sk = D * D;
+  {
+    const SweepStrides st = sweep_strides(o, N, T, d, m, false);
+    a.t_sn = st.t_sn; a.t_sk = st.t_sk; a.y_sn = st.y_sn; a.y_sk = st.y_sk; a.y_si = st.y_si;
+    a.m_sn = st.m_sn; a.m_sk = st.m_sk; a.m_si = st.m_si; a.P_sn = st.P_sn; a.P_sk = st.P_sk; a.P_si = st.P_si;
   }
   return CDKF_OK;
 }

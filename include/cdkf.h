@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define CDKF_VERSION 102 /* 0.1.0 */
+#define CDKF_VERSION 103 /* 0.1.0 */
 
 /* error codes */
 #define CDKF_OK 0
@@ -74,6 +74,7 @@ extern "C" {
 #define CDKF_LAYOUT_TCN 2 /* t [T,N], y [T,m,N], means [T,d,N], covariances [T,d,d,N]: trajectory index
                              fastest, so that lane n of a wavefront touches element n of a contiguous run in
                              EVERY load and store instruction (fully coalesced; the engine's native layout) */
+#define CDKF_LAYOUT_SAME (-1) /* opts.layout_in: the inputs use opts.layout */
 
 /* state_order of EKFHyperParams (inference_ekf.py:40) */
 #define CDKF_ORDER_ZEROTH 0
@@ -135,6 +136,10 @@ typedef struct cdkf_opts {
   double pid_p;         /* PIDController pcoeff / icoeff / dcoeff; defaults 0 / 1 / 0 (an I-controller, diffrax's default) */
   double pid_i;
   double pid_d;
+  int32_t layout_in;    /* layout of the INPUT arrays t and y: CDKF_LAYOUT_SAME (default: like `layout`) or a CDKF_LAYOUT_* value.
+                           E.g. layout = TCN with layout_in = NT lets a host caller hand over the reference's [N,T,m] arrays
+                           untransposed and still get the coalesced native output layout. */
+  int32_t reserved;     /* must be 0 */
 } cdkf_opts;
 
 /* Fill *opts with the reference defaults listed above. */
