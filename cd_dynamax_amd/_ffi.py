@@ -110,6 +110,32 @@ SYMBOLS = (
 _lib: Optional[C.CDLL] = None
 
 
+def _share_torch_hip_runtime() -> None:
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64 and load it by FILE name, this library
+    asks for the SONAME: whichever comes first decides whether the other finds it already loaded.  With torch imported first
+    everything shares torch's copy; with this library first, a later ``import torch`` (bench.py, the device-tensor front-end,
+    torch.distributed) would bring a second runtime into the process and neither sees the GPU any more.  So when torch is
+    installed its runtime libraries are loaded here, before ours, without importing torch itself."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules or os.environ.get("CDKF_SYSTEM_HIP_RUNTIME"):
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    for name in ("libamd_comgr.so", "libamdhip64.so", "libhiprtc.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
 def lib() -> C.CDLL:
     """Load libcdkf_hip.so (once).  Fails loudly when it has not been built."""
     global _lib
@@ -120,6 +146,7 @@ def lib() -> C.CDLL:
             f"HIP library {LIB_PATH} is missing; build it with `make -C cd_dynamax_amd/csrc` "
             "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback."
         )
+    _share_torch_hip_runtime()
     L = C.CDLL(LIB_PATH)
     L.cdkf_last_error.restype = C.c_char_p
     L.cdkf_version.restype = C.c_int

@@ -18,6 +18,7 @@ from typing import List, Optional, Tuple, Union
 import numpy as np
 
 from . import _ffi
+from . import device as _device
 from .params import (EKFHyperParams, EnKFHyperParams, GSSMForecast, LearnableCustomDrift, LearnableCustomEmission, LearnableLinear,
                      LearnableLorenz63,
                      LearnableLorenz96,
@@ -201,10 +202,14 @@ def cdnlgssm_filter(
         raise TypeError(f"unknown filter hyperparams {type(hyperparams).__name__}")
     mdl = _model_block(params)
     opts = _opts(hyperparams, num_iter if algo == "ekf_filter" else 1)
-    y, t, batched, dtype = _prepare(emissions, t_emissions, hyperparams, opts, dtype)
     fields = list(output_fields) if output_fields is not None else []
     want = [f in fields for f in _FILTER_FIELDS]
-    ll, outs, _ = _ffi.run_host(algo, mdl, opts, t, y, want, dtype)
+    if _device.is_device_tensor(emissions):  # data already on the GPU: run in place, return device tensors
+        y, t, batched, _ = _device.prepare(emissions, t_emissions, opts)
+        ll, outs, _ = _device.run_device(algo, mdl, opts, t, y, want)
+    else:
+        y, t, batched, dtype = _prepare(emissions, t_emissions, hyperparams, opts, dtype)
+        ll, outs, _ = _ffi.run_host(algo, mdl, opts, t, y, want, dtype)
     out = {name: _squeeze(arr, batched) for name, arr in zip(_FILTER_FIELDS, outs) if arr is not None}
     return PosteriorGSSMFiltered(marginal_loglik=ll if batched else ll[0], **out)
 
@@ -230,8 +235,12 @@ def cdnlgssm_smoother(
         raise ValueError(f"EKF hyperparams.smooth_order = {hyperparams.smooth_order} not implemented yet")
     mdl = _model_block(params)
     opts = _opts(hyperparams, 1)
-    y, t, batched, dtype = _prepare(emissions, t_emissions, hyperparams, opts, dtype)
-    ll, outs, _ = _ffi.run_host("ekf_smoother", mdl, opts, t, y, [True] * 4, dtype)
+    if _device.is_device_tensor(emissions):
+        y, t, batched, _ = _device.prepare(emissions, t_emissions, opts)
+        ll, outs, _ = _device.run_device("ekf_smoother", mdl, opts, t, y, [True] * 4)
+    else:
+        y, t, batched, dtype = _prepare(emissions, t_emissions, hyperparams, opts, dtype)
+        ll, outs, _ = _ffi.run_host("ekf_smoother", mdl, opts, t, y, [True] * 4, dtype)
     fm, fP, sm, sP = (_squeeze(a, batched) for a in outs)
     return PosteriorGSSMSmoothed(marginal_loglik=ll if batched else ll[0], filtered_means=fm, filtered_covariances=fP,
                                  smoothed_means=sm, smoothed_covariances=sP)
@@ -306,12 +315,19 @@ def cdnlgssm_loglik_and_grad(
         raise NotImplementedError("gradients are provided for the EKF marginal log-likelihood only")
     mdl = _model_block(params)
     opts = _opts(hyperparams, 1)
-    y, t, batched, dtype = _prepare(emissions, t_emissions, hyperparams, opts, dtype)
+    on_device = _device.is_device_tensor(emissions)
+    if on_device:
+        y, t, batched, dtype = _device.prepare(emissions, t_emissions, opts)
+    else:
+        y, t, batched, dtype = _prepare(emissions, t_emissions, hyperparams, opts, dtype)
     if not _ffi.lib().cdkf_grad_supported(_ffi.C.byref(mdl.c), _ffi.C.byref(opts)):
         raise NotImplementedError(
             f"no gradient kernel for drift {type(params.dynamics.drift).__name__} with state_dim={mdl.state_dim}, "
             f"emission_dim={mdl.emission_dim}, state_order={hyperparams.state_order}")
-    ll, grad, _ = _ffi.loglik_grad(mdl, opts, t, y, dtype)
+    if on_device:  # ll and the per-trajectory gradient stay on the device (torch tensors)
+        ll, grad, _ = _device.loglik_grad_device(mdl, opts, t, y, False)
+    else:
+        ll, grad, _ = _ffi.loglik_grad(mdl, opts, t, y, dtype)
     if not batched:
         ll, grad = ll[0], grad[0]
     return ll, _drift_like(params.dynamics.drift, grad)
@@ -337,13 +353,20 @@ def cdnlgssm_loglik_and_grad_all(
         raise NotImplementedError("gradients are provided for the EKF marginal log-likelihood only")
     mdl = _model_block(params)
     opts = _opts(hyperparams, 1)
-    y, t, batched, dtype = _prepare(emissions, t_emissions, hyperparams, opts, dtype)
+    on_device = _device.is_device_tensor(emissions)
+    if on_device:
+        y, t, batched, dtype = _device.prepare(emissions, t_emissions, opts)
+    else:
+        y, t, batched, dtype = _prepare(emissions, t_emissions, hyperparams, opts, dtype)
     if not _ffi.lib().cdkf_grad_all_supported(_ffi.C.byref(mdl.c), _ffi.C.byref(opts)):
         raise NotImplementedError(
             f"no reverse-sweep kernel for drift {type(params.dynamics.drift).__name__} with state_dim={mdl.state_dim}, "
             f"emission_dim={mdl.emission_dim}, state_order={hyperparams.state_order} (needs dimensions <= 8; MLP drift: "
             "state_order='first')")
-    ll, gth, _, gm = _ffi.loglik_grad(mdl, opts, t, y, dtype, with_model=True)
+    if on_device:  # the sweeps run on the device tensors; the (small) gradient blocks are packed on the host
+        ll, gth, _, gm = (x.cpu().numpy() for x in _device.loglik_grad_device(mdl, opts, t, y, True))
+    else:
+        ll, gth, _, gm = _ffi.loglik_grad(mdl, opts, t, y, dtype, with_model=True)
     if not batched:
         ll, gth, gm = ll[0], gth[0], gm[0]
     return ll, _grads_tree(params, mdl, gth, gm)

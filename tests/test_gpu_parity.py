@@ -642,3 +642,41 @@ def test_integration_md_binding_stub_runs(hip_lib):
     for k in FILTER_KEYS:
         assert relerr(getattr(got, k), getattr(ref, k)) < 1e-13, k
     assert abs(got.marginal_loglik - ref.marginal_loglik) < 1e-12 * abs(ref.marginal_loglik)
+
+
+def test_device_resident_torch_tensors(hip_lib):
+    """emissions / t_emissions as torch tensors that already live on the GPU: the sweeps run on them in place (the `_dev` entry
+    points on torch's current stream) and return device tensors equal to the host path's arrays -- filter, smoother,
+    log-likelihood, gradients; fp64 and fp32; register and wavefront kernels; batched and single trajectory."""
+    import torch
+    rng = np.random.default_rng(55)
+    for mdl, order in ((o.lorenz63_model(2), "second"), (lorenz96_model(6, 3), "first")):
+        N, T = 37, 12
+        t = o.irregular_times(rng, N, T, 0.05)
+        y = o.simulate(mdl, t, rng)
+        P = params_from(mdl)
+        hyp = cd.EKFHyperParams(state_order=order)
+        yd, td = torch.from_numpy(y).cuda(), torch.from_numpy(t[..., None]).cuda()
+        host = cd.cdnlgssm_filter(P, y, t[..., None], hyp)
+        dev = cd.cdnlgssm_filter(P, yd, td, hyp)
+        assert dev.filtered_means.is_cuda and tuple(dev.filtered_covariances.shape) == host.filtered_covariances.shape
+        for k in list(FILTER_KEYS) + ["marginal_loglik"]:
+            np.testing.assert_array_equal(getattr(dev, k).cpu().numpy(), getattr(host, k))
+        sm_h = cd.cdnlgssm_smoother(P, y, t[..., None], hyp)
+        sm_d = cd.cdnlgssm_smoother(P, yd, td, hyp)
+        np.testing.assert_array_equal(sm_d.smoothed_covariances.cpu().numpy(), sm_h.smoothed_covariances)
+        ll_d = cd.ContDiscreteNonlinearGaussianSSM(mdl.d, mdl.m).marginal_log_prob(P, yd, td, cd.UKFHyperParams())
+        ll_h = cd.ContDiscreteNonlinearGaussianSSM(mdl.d, mdl.m).marginal_log_prob(P, y, t[..., None], cd.UKFHyperParams())
+        np.testing.assert_array_equal(ll_d.cpu().numpy(), ll_h)
+        one = cd.cdnlgssm_filter(P, yd[3], td[3], hyp)                       # single trajectory
+        assert tuple(one.filtered_means.shape) == (T, mdl.d) and one.marginal_loglik.ndim == 0
+        np.testing.assert_array_equal(one.filtered_means.cpu().numpy(), host.filtered_means[3])
+        f32 = cd.cdnlgssm_filter(P, yd.float(), td.float(), hyp)
+        assert f32.filtered_means.dtype == torch.float32 and relerr(f32.filtered_means.cpu().numpy(), host.filtered_means) < 1e-3
+        gh = cd.cdnlgssm_loglik_and_grad(P, y, t[..., None], cd.EKFHyperParams(state_order="first"))
+        gd = cd.cdnlgssm_loglik_and_grad(P, yd, td, cd.EKFHyperParams(state_order="first"))
+        for a, b in zip(gd[1], gh[1]):
+            np.testing.assert_array_equal(a.cpu().numpy(), b)
+        ga_h = cd.cdnlgssm_loglik_and_grad_all(P, y, t[..., None], cd.EKFHyperParams(state_order="first"))
+        ga_d = cd.cdnlgssm_loglik_and_grad_all(P, yd, td, cd.EKFHyperParams(state_order="first"))
+        np.testing.assert_array_equal(ga_d[1].emissions.emission_cov.params, ga_h[1].emissions.emission_cov.params)
