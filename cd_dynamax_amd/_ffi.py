@@ -95,7 +95,7 @@ class CdkfError(RuntimeError):
 _ALGOS = ("ekf_filter", "ukf_filter", "ekf_smoother")
 SYMBOLS = (
     ["cdkf_default_opts", "cdkf_version", "cdkf_last_error", "cdkf_device_count", "cdkf_supported",
-     "cdkf_preferred_layout", "cdkf_malloc",
+     "cdkf_preferred_layout", "cdkf_trajectories_per_wavefront", "cdkf_malloc",
      "cdkf_free", "cdkf_memcpy_h2d", "cdkf_memcpy_d2h", "cdkf_memset", "cdkf_synchronize", "cdkf_ll_sum_f64_dev",
      "cdkf_ll_sum_f32_dev", "cdkf_emission_moments_f64", "cdkf_emission_moments_f32", "cdkf_emission_moments_f64_dev",
      "cdkf_emission_moments_f32_dev", "cdkf_ekf_loglik_grad_f64", "cdkf_ekf_loglik_grad_f32",
@@ -157,6 +157,8 @@ def lib() -> C.CDLL:
     L.cdkf_supported.restype = C.c_int
     L.cdkf_preferred_layout.argtypes = [C.POINTER(CdkfModel)]
     L.cdkf_preferred_layout.restype = C.c_int
+    L.cdkf_trajectories_per_wavefront.argtypes = [C.c_int64]
+    L.cdkf_trajectories_per_wavefront.restype = C.c_int
     L.cdkf_malloc.argtypes = [C.POINTER(C.c_void_p), C.c_int64]
     L.cdkf_free.argtypes = [C.c_void_p]
     L.cdkf_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]

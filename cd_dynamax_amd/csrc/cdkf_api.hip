@@ -1,4 +1,6 @@
 // cdkf_api.hip -- the C ABI of include/cdkf.h: argument checks, kernel selection, host-buffer wrappers.
+#include <cstdlib>
+
 #include "cdkf_host.h"
 #include "cdkf_launch.h"
 
@@ -76,6 +78,25 @@ int check_common(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T
 int select_device(const cdkf_opts* o) {
   if (o && o->device >= 0) CDKF_HIP_CHECK(hipSetDevice(o->device));
   return CDKF_OK;
+}
+
+// Distinct trajectories per wavefront for the lane-per-trajectory sweeps (cdkf_filter_reg_body.inc): the largest power of two
+// that still yields two wavefronts per CU of the current device, 64 once the batch is that large.  CDKF_LANES_PER_WAVE
+// overrides (tuning / tests).
+int reg_lanes_per_wave(int64_t N) {
+  static const int forced = [] {
+    const char* e = std::getenv("CDKF_LANES_PER_WAVE");
+    const int v = e ? std::atoi(e) : 0;
+    return (v >= 1 && v <= 64 && (v & (v - 1)) == 0) ? v : 0;
+  }();
+  if (forced) return forced;
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+    cus = 256;
+  const int64_t waves = 2 * (int64_t)cus;
+  int lanes = 64;
+  while (lanes > 1 && (N + lanes - 1) / lanes < waves) lanes >>= 1;
+  return lanes;
 }
 
 // ---- host-buffer wrapper: allocate, upload, run the _dev path, download -------------------------
@@ -414,6 +435,8 @@ int cdkf_supported(const cdkf_model* mdl, const cdkf_opts* o, int algo, int byte
   if (!mdl || !o || (bytes_per_real != 4 && bytes_per_real != 8) || algo < 0 || algo > 2) return 0;
   return kernel_available(mdl, o, algo, bytes_per_real) ? 1 : 0;
 }
+
+int cdkf_trajectories_per_wavefront(int64_t N) { return cdkf::reg_lanes_per_wave(N < 1 ? 1 : N); }
 
 int cdkf_preferred_layout(const cdkf_model* mdl) {
   return (mdl && (reg_shape_available(mdl) || custom_kind(mdl->drift_kind))) ? CDKF_LAYOUT_TCN : CDKF_LAYOUT_TN;

@@ -309,7 +309,7 @@ __global__ __launch_bounds__(64, 1) void ekf_grad_reg_kernel(const GradArgs<R, D
   constexpr int NPAR = DriftGrad<R, D, Drift>::NPAR;
   const RegArgs<R, D, M, Drift>& a = ga.a;
   const long total = a.N * NPAR;
-  const long gid0 = (long)blockIdx.x * 64 + threadIdx.x;
+  const long gid0 = reg_unit_index(ga.a.lanes, ga.a.xcd_shift);
   const bool live = gid0 < total;
   const long gid = live ? gid0 : total - 1;  // idle lanes shadow the last (trajectory, parameter) pair
   const long n = gid / NPAR;

@@ -155,6 +155,23 @@ inline SweepStrides sweep_strides(const cdkf_opts* o, long N, long T, long D, lo
   return s;
 }
 
+int reg_lanes_per_wave(int64_t N);
+// wavefront grouping of `units` lanes-worth of work (reg_unit_index): lanes per wavefront, log2 of the groups per 128-byte
+// line of `bytes_per_real`-sized components, number of blocks (a multiple of 8 << xcd_shift; surplus blocks idle)
+struct RegGrouping {
+  int lanes, xcd_shift;
+  unsigned blocks;
+};
+inline RegGrouping reg_grouping(int64_t units, int bytes_per_real) {
+  RegGrouping g;
+  g.lanes = reg_lanes_per_wave(units);
+  g.xcd_shift = 0;
+  while ((g.lanes << g.xcd_shift) * bytes_per_real < 128) ++g.xcd_shift;
+  const int64_t groups = (units + g.lanes - 1) / g.lanes, round = (int64_t)8 << g.xcd_shift;
+  g.blocks = (unsigned)(g.xcd_shift ? (groups + round - 1) / round * round : groups);
+  return g;
+}
+
 template <typename R, int D, int M, typename Drift>
 void fill_reg_args(RegArgs<R, D, M, Drift>& a, const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T,
                    const R* t, const R* y, R* ll, R* fm, R* fP, R* pm, R* pP, int32_t* status) {
@@ -187,6 +204,11 @@ void fill_reg_args(RegArgs<R, D, M, Drift>& a, const cdkf_model* mdl, const cdkf
   a.num_iter = o->num_iter;
   a.forecast = o->forecast;
   a.solver = o->solver;
+  {
+    const RegGrouping g = reg_grouping(N, (int)sizeof(R));
+    a.lanes = g.lanes;
+    a.xcd_shift = g.xcd_shift;
+  }
   fill_rk_tab<R>(o, a.rk);  // opts.solver / adaptive were validated by check_common
   a.N = N;
   a.T = T;

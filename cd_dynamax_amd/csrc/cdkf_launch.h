@@ -2,6 +2,7 @@
 // (drift, state_dim, emission_dim) shapes listed in CDKF_REG_SHAPES; every other shape goes to the
 // LDS-resident wave-per-trajectory kernels (cdkf_wave_kernels.h).
 #pragma once
+#include <cstdlib>
 #include "cdkf_host.h"
 
 // X(drift_kind, DriftTemplate, D, M)
@@ -100,7 +101,7 @@ inline bool emission_is_selection(const cdkf_model* mdl) {
 // launch filter_reg_kernel with the OUT specialisation matching the requested output pointers
 template <typename R, int D, int M, typename Drift, bool UKF, bool ZEROTH, bool HSEL>
 inline void launch_filter_reg(const RegArgs<R, D, M, Drift>& a, hipStream_t stream) {
-  const dim3 grid((unsigned)((a.N + 63) / 64)), block(64);
+  const dim3 grid(reg_grouping(a.N, (int)sizeof(R)).blocks), block(64);
   const bool all = a.fm && a.fP && a.pm && a.pP, none = !a.fm && !a.fP && !a.pm && !a.pP;
   if (a.rk.stages && (a.solver != CDKF_SOLVER_DOPRI5 || a.rk.adaptive)) {  // non-default method or adaptive steps: run-time tableau
     if (a.forecast)

@@ -34,6 +34,8 @@ struct RegArgs {
   long max_steps;
   int order, num_iter, forecast;
   int solver;   // CDKF_SOLVER_*
+  int lanes;      // distinct trajectories per wavefront (power of two <= 64; the other lanes repeat them)
+  int xcd_shift;  // log2 of the wavefront groups that share a 128-byte line (reg_unit_index)
   RkTab<R> rk;  // used by the GENERIC instantiations only (solver != CDKF_SOLVER_DOPRI5)
   long N, T;
   // element (n, k, i) of an array lives at  n * sn + k * sk + i.  Reference layout [N,T,w]:
@@ -49,6 +51,17 @@ struct RegArgs {
   R* pP;
   int* status;
 };
+
+// Unit (trajectory; (trajectory, parameter) pair in the gradient sweep) of this lane.  `lanes` consecutive units per
+// wavefront, repeated over its 64 lanes (cdkf_filter_reg_body.inc).  Below 16 units a wavefront touches only part of each
+// 128-byte line of the [T,comp,N] arrays, and workgroups are dealt to the 8 XCDs round-robin: the 2^xcd_shift groups that
+// share a line are renumbered onto ONE XCD (blocks b, b + 8, ...), whose L2 then fetches the line once and writes it whole.
+CDKF_DEV long reg_unit_index(int lanes, int xcd_shift) {
+  const long b = blockIdx.x;
+  const int sh = xcd_shift;
+  const long grp = ((b >> (3 + sh)) << (3 + sh)) + ((b & 7) << sh) + ((b >> 3) & ((1 << sh) - 1));
+  return grp * lanes + (threadIdx.x & (lanes - 1));
+}
 
 // tableau the sweep integrates with: the VGPR-pinned Dormand-Prince constants, or the run-time tableau of the arguments
 template <typename R, bool GENERIC>
@@ -729,7 +742,7 @@ struct SmoothRhs {
 template <typename R, int D, int M, typename Drift, bool GENERIC = false>
 CDKF_DEV void ekf_smoother_reg_body(const RegArgs<R, D, M, Drift>& a, R* __restrict__ sm, R* __restrict__ sP) {
   constexpr int NS = Dims<D>::NS;
-  const long gid = (long)blockIdx.x * 64 + threadIdx.x;
+  const long gid = reg_unit_index(a.lanes, a.xcd_shift);
   const bool live = gid < a.N;
   const long n = live ? gid : a.N - 1;
   const R* __restrict__ tp = a.t + n * a.t_sn;

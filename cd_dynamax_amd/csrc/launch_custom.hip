@@ -125,7 +125,7 @@ __device__ __forceinline__ void unpack(Args& a, const R* __restrict__ par, const
   for (int s = 0; s < 7; ++s) a.rk.berr[s] = par[o + s];
   o += 7;
   a.rk.rtol = par[o]; a.rk.atol = par[o + 1]; a.rk.c1 = par[o + 2]; a.rk.c2 = par[o + 3]; a.rk.c3 = par[o + 4];
-  a.rk.stages = (int)ip[17]; a.solver = (int)ip[18]; a.rk.adaptive = (int)ip[19]; a.rk.fsal = (int)ip[20];
+  a.rk.stages = (int)ip[17]; a.solver = (int)ip[18]; a.rk.adaptive = (int)ip[19]; a.rk.fsal = (int)ip[20]; a.lanes = (int)ip[21]; a.xcd_shift = (int)ip[22];
   a.max_steps = ip[0]; a.order = (int)ip[1]; a.num_iter = (int)ip[2]; a.forecast = (int)ip[3]; a.N = ip[4]; a.T = ip[5];
   a.t_sn = ip[6]; a.t_sk = ip[7]; a.y_sn = ip[8]; a.y_sk = ip[9]; a.y_si = ip[10]; a.m_sn = ip[11]; a.m_sk = ip[12];
   a.m_si = ip[13]; a.P_sn = ip[14]; a.P_sk = ip[15]; a.P_si = ip[16];
@@ -327,7 +327,10 @@ int launch_custom(int algo, const cdkf_model* mdl, const cdkf_opts* o, int64_t N
   for (int s = 0; s < 7; ++s) par.push_back(tb.berr[s]);
   par.push_back(tb.rtol); par.push_back(tb.atol); par.push_back(tb.c1); par.push_back(tb.c2); par.push_back(tb.c3);
   const int generic = o->solver != CDKF_SOLVER_DOPRI5 || o->adaptive;
-  long ip[21];
+  long ip[23];
+  const RegGrouping grouping = reg_grouping(N, (int)sizeof(R));
+  ip[21] = grouping.lanes;
+  ip[22] = grouping.xcd_shift;
   ip[17] = tb.stages;
   ip[18] = o->solver;
   ip[19] = tb.adaptive;
@@ -356,7 +359,7 @@ int launch_custom(int algo, const cdkf_model* mdl, const cdkf_opts* o, int64_t N
   const long* dip = (const long*)((char*)slot->dev + ((par_bytes + 15) & ~size_t(15)));
 
   // ---- kernels ---------------------------------------------------------------------------------------------------------
-  const unsigned blocks = (unsigned)((N + 63) / 64);
+  const unsigned blocks = grouping.blocks;
   R* null_r = nullptr;
   auto run = [&](const Key& key, R* o1, R* o2, R* o3, R* o4, R* sm, R* sP) -> int {
     hipFunction_t fn = nullptr;

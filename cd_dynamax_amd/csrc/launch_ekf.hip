@@ -11,7 +11,7 @@ static int run_ekf_reg(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int
   if (o->state_order == CDKF_ORDER_ZEROTH && (o->solver != CDKF_SOLVER_DOPRI5 || o->adaptive)) {
     launch_filter_reg<R, D, M, Drift, false, true, false>(a, stream);
   } else if (o->state_order == CDKF_ORDER_ZEROTH) {
-    const dim3 grid((unsigned)((N + 63) / 64)), block(64);
+    const dim3 grid(reg_grouping(N, (int)sizeof(R)).blocks), block(64);
     if (o->forecast)
       hipLaunchKernelGGL((filter_reg_kernel<R, D, M, Drift, false, true, false, kOutSome, true>), grid, block, 0, stream, a);
     else

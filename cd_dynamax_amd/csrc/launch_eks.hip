@@ -10,7 +10,7 @@ static int run_eks_reg(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int
   of.num_iter = 1;  // the smoother's internal filter call uses the default (inference_ekf.py:489-495)
   RegArgs<R, D, M, Drift> a;
   fill_reg_args(a, mdl, &of, N, T, t, y, ll, fm, fP, (R*)nullptr, (R*)nullptr, status);
-  const unsigned blocks = (unsigned)((N + 63) / 64);
+  const unsigned blocks = reg_grouping(N, (int)sizeof(R)).blocks;
   if (of.solver != CDKF_SOLVER_DOPRI5 || of.adaptive) {
     if (of.state_order == CDKF_ORDER_ZEROTH)
       hipLaunchKernelGGL((filter_reg_kernel<R, D, M, Drift, false, true, false, kOutSome, false, true>), dim3(blocks), dim3(64), 0, stream, a);

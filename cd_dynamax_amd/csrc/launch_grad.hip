@@ -34,7 +34,10 @@ static int run_grad(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_
   fill_reg_args(ga.a, mdl, o, N, T, t, y, ll, (R*)nullptr, (R*)nullptr, (R*)nullptr, (R*)nullptr, status);
   ga.grad = grad;
   const long lanes = (long)N * DriftGrad<R, D, Drift>::NPAR;
-  const dim3 grid((unsigned)((lanes + 63) / 64)), block(64);
+  const RegGrouping g = reg_grouping(lanes, (int)sizeof(R));
+  ga.a.lanes = g.lanes;
+  ga.a.xcd_shift = g.xcd_shift;
+  const dim3 grid(g.blocks), block(64);
   if (o->solver != CDKF_SOLVER_DOPRI5 || o->adaptive)  // run-time tableau / adaptive steps: the tangents ride on the primal's steps
     hipLaunchKernelGGL((ekf_grad_reg_kernel<R, D, M, Drift, true>), grid, block, 0, stream, ga);
   else

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define CDKF_VERSION 103 /* 0.1.0 */
+#define CDKF_VERSION 104 /* 0.1.0 */
 
 /* error codes */
 #define CDKF_OK 0
@@ -156,6 +156,12 @@ int cdkf_supported(const cdkf_model* mdl, const cdkf_opts* opts, int algo, int b
 /* The layout (CDKF_LAYOUT_*) in which this model's kernels move data fastest: _TCN for the lane-per-trajectory
  * kernels (small state_dim), _TN for the workgroup-per-trajectory kernels (a trajectory's d x d block contiguous). */
 int cdkf_preferred_layout(const cdkf_model* mdl);
+
+/* Informational: how many distinct trajectories the lane-per-trajectory sweeps (state_dim <= 4) put on one 64-lane
+ * wavefront for a batch of N on the current device -- 64 once N fills the chip, fewer (a power of two; the remaining
+ * lanes repeat them) for small batches, so that a long interval of one trajectory delays fewer others.  Results do not
+ * depend on it.  The environment variable CDKF_LANES_PER_WAVE (1 ... 64, power of two) overrides the choice. */
+int cdkf_trajectories_per_wavefront(int64_t N);
 
 /* ---- device memory helpers (so that host code needs no other GPU runtime) ------------------- */
 int cdkf_malloc(void** dev_ptr, int64_t bytes);

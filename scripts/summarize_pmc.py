@@ -13,11 +13,12 @@ out = {"round": 1, "tag": tag,
        "workload": "N=4096, T=1000, fp64, 4 outputs, native [T,comp,N] layout"}
 for kind, name in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
     f = glob.glob(f"gpurun_out/prof_{tag}/pmc_{kind}/runc/*_counter_collection.csv")[0]
-    rows = [r for r in csv.DictReader(open(f)) if kernel_sub in r["Kernel_Name"] and int(r["Grid_Size"]) == N]
+    rows = [r for r in csv.DictReader(open(f)) if kernel_sub in r["Kernel_Name"]]  # bench.py --no-saturation: every launch is the N x T batch
     out["kernel"] = rows[0]["Kernel_Name"][:120]
     vals = [float(r["Counter_Value"]) for r in rows][1:]
     out[name + "_KB_per_launch_raw"] = sum(vals) / len(vals)
     out["vgpr_count"], out["sgpr_count"] = int(rows[0]["VGPR_Count"]), int(rows[0]["SGPR_Count"])
+    out["grid_size_lanes"] = int(rows[0]["Grid_Size"])
 out["hbm_read_bytes_per_launch"] = out["FETCH_SIZE_KB_per_launch_raw"] * 1024 * 2
 out["hbm_write_bytes_per_launch"] = out["WRITE_SIZE_KB_per_launch_raw"] * 1024
 out["hbm_traffic_bytes_per_launch"] = out["hbm_read_bytes_per_launch"] + out["hbm_write_bytes_per_launch"]

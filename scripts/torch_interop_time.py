@@ -16,3 +16,22 @@ import torch; print("import torch", round(time.time() - t0, 1), flush=True)
 yd = torch.from_numpy(y).cuda(); td = torch.from_numpy(t[..., None]).cuda(); torch.cuda.synchronize(); print("tensors on device", round(time.time() - t0, 1), flush=True)
 dev = cd.cdnlgssm_filter(P, yd, td); torch.cuda.synchronize(); print("device filter", round(time.time() - t0, 1), flush=True)
 print(np.abs(dev.filtered_means.cpu().numpy() - host.filtered_means).max())
+
+# BASELINE config 2 from device tensors: wall time per call (torch caching allocator warm), all four moment arrays / ll only
+mdl = o.lorenz63_model(3)
+P = params_from(mdl)
+N, T = 4096, 1000
+t = o.irregular_times(rng, N, T, 0.01)
+y = rng.standard_normal((N, T, 3))
+yd = torch.from_numpy(y).cuda(); td = torch.from_numpy(t[..., None]).cuda()
+model = cd.ContDiscreteNonlinearGaussianSSM(3, 3)
+for name, fn in (("filter, 4 outputs", lambda: cd.cdnlgssm_filter(P, yd, td)),
+                 ("marginal_log_prob", lambda: model.marginal_log_prob(P, yd, td)),
+                 ("loglik_and_grad", lambda: cd.cdnlgssm_loglik_and_grad(P, yd, td))):
+    for _ in range(3):
+        r = fn()
+    torch.cuda.synchronize(); t1 = time.time()
+    for _ in range(10):
+        r = fn()
+    torch.cuda.synchronize()
+    print(f"C2 device-resident {name}: {(time.time() - t1) * 100:.2f} ms per call", flush=True)

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol(hip_lib):
 
 
 def test_version_and_default_opts(hip_lib):
-    assert hip_lib.cdkf_version() == 103
+    assert hip_lib.cdkf_version() == 104
     o = _ffi.default_opts()
     assert (o.state_order, o.num_iter, o.t_shared, o.device, o.layout) == (2, 1, 0, -1, 0)
     assert o.max_steps == 100000 and o.dt0 == 0.01 and o.dt_final == 1e-10 and o.cov_rescaling == 1.0
@@ -35,6 +35,17 @@ def test_version_and_default_opts(hip_lib):
     # struct sizes the header implies (LP64): guards against silent ABI drift
     assert C.sizeof(_ffi.CdkfOpts) == 8 * 4 + 8 + 11 * 8 + 2 * 4
     assert C.sizeof(_ffi.CdkfModel) == 6 * 4 + 8 + 8 * 8
+
+
+def test_trajectories_per_wavefront_rule(hip_lib):
+    """Without a GPU the rule assumes 256 CUs: at least 512 wavefronts while the batch allows, never more than 1023."""
+    if os.environ.get("CDKF_LANES_PER_WAVE"):
+        pytest.skip("grouping forced through the environment")
+    f = hip_lib.cdkf_trajectories_per_wavefront
+    assert [f(n) for n in (1, 8, 512, 1024, 1100, 4096, 5000, 16384, 32768, 40000, 10**6)] == [1, 1, 1, 2, 2, 8, 8, 32, 64, 64, 64]
+    for n in (700, 3000, 12288, 30000):
+        w = f(n)
+        assert w & (w - 1) == 0 and 512 <= -(-n // w) < 1024
 
 
 def _l63_block():

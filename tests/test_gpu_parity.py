@@ -205,6 +205,33 @@ def test_layouts_are_bitwise_identical_and_ll_sum(hip_lib):
             assert (a[2] == 0).all()
 
 
+@pytest.mark.parametrize("N,T", [(1100, 24), (5000, 12), (40000, 6)])
+def test_results_do_not_depend_on_the_wavefront_grouping(hip_lib, N, T):
+    """The launch groups 1 ... 64 distinct trajectories per wavefront depending on the batch size (reg_lanes_per_wave,
+    cdkf_api.hip): a trajectory's results must be BITWISE the same inside a large batch (2, 8 and 64 per wavefront here)
+    and in a batch of five (one per wavefront), for every lane-per-trajectory sweep."""
+    rng = np.random.default_rng(N)
+    mdl = o.lorenz63_model(3)
+    t = o.irregular_times(rng, N, T, 0.012 * T)  # intervals on both sides of dt0: the RK pass count differs between lanes
+    y = rng.standard_normal((N, T, 3)) * 3.0
+    sub = np.sort(rng.choice(N, size=5, replace=False))
+    P = params_from(mdl)
+    for hyper in (cd.EKFHyperParams(), cd.UKFHyperParams()):
+        big = cd.cdnlgssm_filter(P, y, t[..., None], hyperparams=hyper)
+        small = cd.cdnlgssm_filter(P, y[sub], t[sub][..., None], hyperparams=hyper)
+        for k in FILTER_KEYS + ["marginal_loglik"]:
+            np.testing.assert_array_equal(np.asarray(getattr(big, k))[sub], np.asarray(getattr(small, k)), err_msg=k)
+    big = cd.cdnlgssm_smoother(P, y, t[..., None])
+    small = cd.cdnlgssm_smoother(P, y[sub], t[sub][..., None])
+    for k in ("smoothed_means", "smoothed_covariances", "filtered_means"):
+        np.testing.assert_array_equal(np.asarray(getattr(big, k))[sub], np.asarray(getattr(small, k)), err_msg=k)
+    ll_b, g_b = cd.cdnlgssm_loglik_and_grad(P, y, t[..., None])
+    ll_s, g_s = cd.cdnlgssm_loglik_and_grad(P, y[sub], t[sub][..., None])
+    np.testing.assert_array_equal(ll_b[sub], ll_s)
+    for name in ("sigma", "rho", "beta"):
+        np.testing.assert_array_equal(getattr(g_b, name)[sub], getattr(g_s, name))
+
+
 def test_status_flags_and_nan_propagation(hip_lib):
     rng = np.random.default_rng(8)
     mdl = o.lorenz63_model(3)
