@@ -203,11 +203,13 @@ CDKF_DEV void ekf_update(const Args& a, R (&ys)[Dims<D>::NS], const R (&yobs)[M]
         v[r] = yobs[r] - (s + a.hb[r]);
       }
     }
+    R q = R(0), pinv = R(1);
     if (it == 0) {
-      // TFP log_prob: Cholesky of S as given (lower triangle, no jitter)
+      // TFP log_prob: Cholesky of S as given (lower triangle, no jitter).  The accumulator call (a data-dependent branch
+      // around the occasional log) comes after the update so that this factorisation and psd_solve's -- two independent
+      // chains of dependent fp64 operations -- share one basic block and are interleaved by the scheduler.
       R Lc[M][M], inv[M];
       chol_lower<R, M>(S, Lc, inv, bad);
-      R q = R(0), pinv = R(1);
       R z[M];
 #pragma unroll
       for (int i = 0; i < M; ++i) {
@@ -218,7 +220,6 @@ CDKF_DEV void ekf_update(const Args& a, R (&ys)[Dims<D>::NS], const R (&yobs)[M]
         q = rfma(z[i], z[i], q);
         pinv *= inv[i];
       }
-      ll.add((double)q, (double)pinv, M);
     }
     // psd_solve: symmetrize + 1e-9 I, Cholesky, cho_solve           dynamax/utils/utils.py:202-207
     R Sb[M][M];
@@ -277,6 +278,10 @@ CDKF_DEV void ekf_update(const Args& a, R (&ys)[Dims<D>::NS], const R (&yobs)[M]
     }
 #pragma unroll
     for (int e = 0; e < Dims<D>::NP; ++e) ys[D + e] = Pn[e];
+    if (it == 0) {
+      asm volatile("" : "+v"(q), "+v"(pinv) : "v"(ys[D]), "v"(ys[0]));  // pin the accumulator call below the update (see above)
+      ll.add((double)q, (double)pinv, M);
+    }
   }
   if (bad) st |= kStatusNotPd;
 }

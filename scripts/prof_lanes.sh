@@ -4,7 +4,7 @@ set -u
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_lanes
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-for W in 64 32 16; do
+for W in ${LANES_LIST:-64 32 16}; do
   export CDKF_LANES_PER_WAVE=$W
   i=0
   for PMC in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAVES" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY" "SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_INSTS_SMEM" "SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA"; do
@@ -14,7 +14,7 @@ for W in 64 32 16; do
 done
 python3 - <<PY
 import csv, glob, collections
-for W in (64, 32, 16):
+for W in [int(w) for w in "${LANES_LIST:-64 32 16}".split()]:
     agg = collections.OrderedDict()
     for f in sorted(glob.glob("$OUT/w%d_p*/*/*_counter_collection.csv" % W)):
         for r in csv.DictReader(open(f)):
