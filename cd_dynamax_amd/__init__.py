@@ -5,6 +5,7 @@ filtering / smoothing hot path; the arithmetic lives in hand-written HIP kernels
 ``include/cdkf.h``.
 """
 from . import fit
+from . import mcmc
 from .linear import (ContDiscreteLinearGaussianSSM, KFHyperParams, ParamsCDLGSSM, ParamsCDLGSSMDynamics,
                      ParamsLGSSMEmissions, cdlgssm_filter, cdlgssm_smoother)
 from .models import (ContDiscreteNonlinearGaussianSSM, cdnlgssm_emissions, cdnlgssm_filter, cdnlgssm_forecast,

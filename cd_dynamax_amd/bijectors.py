@@ -65,3 +65,16 @@ class RealToPSDBijector:
         gL = np.tril((g + np.swapaxes(g, -1, -2)) @ L)
         gL[..., di, di] *= L[..., di, di]
         return fill_triangular_inverse(gL)
+
+    def forward_log_det_jacobian_and_grad(self, x):
+        """log |det d vech(forward(x)) / dx| and its gradient: TFP's FillScaleTriL(Exp) contributes sum_j x_jj (the
+        diagonal entries of fill_triangular(x), i.e. log L_jj) and CholeskyOuterProduct n log 2 + sum_j (n - j) log L_jj,
+        j = 0..n-1 -- what ``prop.constrainer.forward_log_det_jacobian(unc_value)`` returns in dynamax/parameters.py:118-121."""
+        x = np.asarray(x, np.float64)
+        m = x.shape[-1]
+        n = int(round(np.sqrt(0.25 + 2 * m) - 0.5))
+        idx = _tri_index(n)[np.arange(n), np.arange(n)]
+        w = n - np.arange(n) + 1.0
+        grad = np.zeros(m)
+        grad[idx] = w
+        return n * np.log(2.0) + float(np.dot(w, x[idx])), grad

@@ -228,6 +228,29 @@ class ContDiscreteLinearGaussianSSM:
             out[2] = [_from_nonlinear(p, params) for p in out[2]]
         return tuple(out)
 
+    def log_prior(self, params) -> float:
+        return 0.0
+
+    def fit_mcmc(self, initial_params, props, emissions, t_emissions=None, filter_hyperparams=None, inputs=None,
+                 n_mcmc_samples: int = 500, mcmc_algorithm=None, verbose: bool = True, key=0, dtype=None,
+                 return_info: bool = False):
+        """``SSM.fit_mcmc`` (ssm_temissions.py:601-777) for the linear model (``cd_dynamax_amd.mcmc.fit_mcmc``); the sample
+        sets come back in this model's parameter structure, every leaf with a leading sample axis."""
+        from .mcmc import fit_mcmc
+        nl = ContDiscreteNonlinearGaussianSSM(self.state_dim, self.emission_dim)
+        out = list(fit_mcmc(nl, _as_nonlinear(initial_params, inputs), _props_as_nonlinear(props, initial_params), emissions,
+                            t_emissions, _hyper(filter_hyperparams), None, n_mcmc_samples, mcmc_algorithm, verbose, key, dtype,
+                            return_info))
+        for i in (0, 1):
+            count = out[i].initial.mean.params.shape[0]
+            rep = lambda v: None if v is None else np.broadcast_to(np.asarray(v), (count,) + np.shape(v)).copy()
+            like = initial_params._replace(
+                dynamics=initial_params.dynamics._replace(bias=rep(initial_params.dynamics.bias),
+                                                          input_weights=rep(initial_params.dynamics.input_weights)),
+                emissions=initial_params.emissions._replace(input_weights=rep(initial_params.emissions.input_weights)))
+            out[i] = _from_nonlinear(out[i], like)
+        return tuple(out)
+
     def filter(self, params, emissions, t_emissions=None, filter_hyperparams=None, inputs=None, dtype=None):
         return cdlgssm_filter(params, emissions, t_emissions, filter_hyperparams, inputs, dtype=dtype)
 

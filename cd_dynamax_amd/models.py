@@ -544,6 +544,18 @@ class ContDiscreteNonlinearGaussianSSM:
         return fit_sgd(self, params, props, emissions, t_emissions, filter_hyperparams, inputs, optimizer, batch_size,
                        num_epochs, shuffle, return_param_history, return_grad_history, key, dtype, allreduce)
 
+    def log_prior(self, params) -> float:
+        """SSM.log_prior (ssm_temissions.py:152-161): the reference's models define no prior."""
+        return 0.0
+
+    def fit_mcmc(self, initial_params, props, emissions, t_emissions=None, filter_hyperparams=None, inputs=None,
+                 n_mcmc_samples: int = 500, mcmc_algorithm=None, verbose: bool = True, key=0, dtype=None,
+                 return_info: bool = False):
+        """ssm_temissions.py:601-777 (HMC / NUTS with window adaptation); see ``cd_dynamax_amd.mcmc.fit_mcmc``."""
+        from .mcmc import fit_mcmc
+        return fit_mcmc(self, initial_params, props, emissions, t_emissions, filter_hyperparams, inputs, n_mcmc_samples,
+                        mcmc_algorithm, verbose, key, dtype, return_info)
+
     def filter(self, params, emissions, t_emissions=None, filter_hyperparams=EKFHyperParams(), inputs=None,
                dtype=None) -> PosteriorGSSMFiltered:
         return cdnlgssm_filter(params, emissions, t_emissions, filter_hyperparams, inputs, dtype=dtype)
