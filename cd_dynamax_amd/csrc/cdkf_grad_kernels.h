@@ -341,16 +341,18 @@ __global__ __launch_bounds__(64, 1) void ekf_grad_reg_kernel(const GradArgs<R, D
 #pragma unroll
   for (int r = 0; r < M; ++r) ycur[r] = yp[r * a.y_si];
 
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see cdkf_filter_reg_body.inc
   for (long k = 0; k < a.T; ++k) {
-    ekf_update_sens<R, D, M>(a, ys, ycur, ll, g, st);
-    if (ys[0] != ys[0]) st |= kStatusNan;
-    const R t1 = (k + 1 < a.T) ? tnext_obs : tcur + a.dt_final;
+    // prefetch of y_{k+1}, t_{k+2} a whole step ahead (cdkf_filter_reg_body.inc)
     if (k + 1 < a.T) yp += a.y_sk;
     if (k + 2 < a.T) tp += a.t_sk;
     R ynext[M];
 #pragma unroll
     for (int r = 0; r < M; ++r) ynext[r] = yp[r * a.y_si];
     const R tnn = tp[0];
+    ekf_update_sens<R, D, M>(a, ys, ycur, ll, g, st);
+    if (ys[0] != ys[0]) st |= kStatusNan;
+    const R t1 = (k + 1 < a.T) ? tnext_obs : tcur + a.dt_final;
     // the last predict (over dt_final) does not enter the log-likelihood: skip it
     if (k + 1 < a.T) {
       const bool capped = integrate<R, 2 * NS, 0, NS>(ys, tcur, t1, a.dt0, a.max_steps, rhs, C);
