@@ -757,6 +757,9 @@ CDKF_DEV void ekf_smoother_reg_body(const RegArgs<R, D, M, Drift>& a, R* __restr
   bool bad = false;
   const auto C = TabSel<R, GENERIC>::get(a);
 
+  constexpr int NP = Dims<D>::NP;
+  // idle / repeating lanes shadow a live trajectory and store the same values: the stores are unconditional (exact vmcnt
+  // accounting, see filter_reg_kernel) and the outputs are never NULL here
   R ys[NS];  // smoothed moments at t_{k+1}
   {
     const long k = a.T - 1;
@@ -766,20 +769,44 @@ CDKF_DEV void ekf_smoother_reg_body(const RegArgs<R, D, M, Drift>& a, R* __restr
     for (int i = 0; i < D; ++i)
 #pragma unroll
       for (int j = i; j < D; ++j) ys[D + sidx<D>(i, j)] = fP[k * a.P_sk + (i * D + j) * a.P_si];
-    if (live) store_moments<R, D>(sm, sP, n * a.m_sn + k * a.m_sk, n * a.P_sn + k * a.P_sk, a.m_si, a.P_si, ys);
+    store_moments_all<R, D>(sm, sP, n * a.m_sn + k * a.m_sk, n * a.P_sn + k * a.P_sk, a.m_si, a.P_si, ys);
   }
   R t1 = tp[(a.T - 1) * a.t_sk];
+  // filtered moments of step k are loaded one step ahead (during the integration of step k + 1): every step reads fresh
+  // lines, and used on arrival they exposed a full memory round trip per step
+  R mf_n[D], Pf_n[NP], t0_n;
+  {
+    const long k = a.T >= 2 ? a.T - 2 : 0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) mf_n[i] = fm[k * a.m_sk + i * a.m_si];
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int j = i; j < D; ++j) Pf_n[sidx<D>(i, j)] = fP[k * a.P_sk + (i * D + j) * a.P_si];
+    t0_n = tp[k * a.t_sk];
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) before the loop: see cdkf_filter_reg_body.inc
   for (long k = a.T - 2; k >= 0; --k) {
     SmoothRhs<R, D> rhs;
     rhs.LQL = a.LQL;
     R Pf[D][D];
 #pragma unroll
-    for (int i = 0; i < D; ++i) rhs.mf[i] = fm[k * a.m_sk + i * a.m_si];
+    for (int i = 0; i < D; ++i) rhs.mf[i] = mf_n[i];
 #pragma unroll
     for (int i = 0; i < D; ++i)
 #pragma unroll
-      for (int j = 0; j < D; ++j) Pf[i][j] = fP[k * a.P_sk + (i * D + j) * a.P_si];
-    const R t0 = tp[k * a.t_sk];
+      for (int j = 0; j < D; ++j) Pf[i][j] = Pf_n[sidx<D>(i, j)];  // the filter stored a symmetric matrix
+    const R t0 = t0_n;
+    {
+      const long kn = k >= 1 ? k - 1 : 0;
+#pragma unroll
+      for (int i = 0; i < D; ++i) mf_n[i] = fm[kn * a.m_sk + i * a.m_si];
+#pragma unroll
+      for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = i; j < D; ++j) Pf_n[sidx<D>(i, j)] = fP[kn * a.P_sk + (i * D + j) * a.P_si];
+      t0_n = tp[kn * a.t_sk];
+    }
     a.drift.f(rhs.mf, rhs.fmf);
     a.drift.jac(rhs.mf, rhs.G);
     // aux = psd_solve(P_f, LQL)^T
@@ -803,7 +830,7 @@ CDKF_DEV void ekf_smoother_reg_body(const RegArgs<R, D, M, Drift>& a, R* __restr
 #pragma unroll
       for (int j = 0; j < D; ++j) rhs.G[i][j] += X[j][i];
     if (integrate<R, NS>(ys, R(0), t1 - t0, a.dt0, a.max_steps, rhs, C)) st |= kStatusMaxSteps;
-    if (live) store_moments<R, D>(sm, sP, n * a.m_sn + k * a.m_sk, n * a.P_sn + k * a.P_sk, a.m_si, a.P_si, ys);
+    store_moments_all<R, D>(sm, sP, n * a.m_sn + k * a.m_sk, n * a.P_sn + k * a.P_sk, a.m_si, a.P_si, ys);
     t1 = t0;
   }
   if (bad) st |= kStatusNotPd;

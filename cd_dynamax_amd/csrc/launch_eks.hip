@@ -25,6 +25,8 @@ static int run_eks_reg(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int
   // filter, inference_ekf.py:489-495); the backward pass is always smooth_order 'first'
   if (of.state_order == CDKF_ORDER_ZEROTH)
     hipLaunchKernelGGL((filter_reg_kernel<R, D, M, Drift, false, true, false, kOutSome>), dim3(blocks), dim3(64), 0, stream, a);
+  else if (M <= D && emission_is_selection(mdl))  // H = I[:M], no bias: the products with H disappear (as in launch_ekf.hip)
+    hipLaunchKernelGGL((filter_reg_kernel<R, D, M, Drift, false, false, (M <= D), kOutSome>), dim3(blocks), dim3(64), 0, stream, a);
   else
     hipLaunchKernelGGL((filter_reg_kernel<R, D, M, Drift, false, false, false, kOutSome>), dim3(blocks), dim3(64), 0, stream, a);
   CDKF_HIP_CHECK(hipGetLastError());

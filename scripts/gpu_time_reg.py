@@ -47,4 +47,11 @@ for dtype, sfx in ((np.float64, "f64"), (np.float32, "f32")):
             for _ in range(10): run0()
             _ffi.check(L.cdkf_synchronize(None))
             print(f"{algo} {sfx}, log-likelihood only: {(time.perf_counter() - t0) * 100:.3f} ms")
+            run1 = lambda: _ffi.check(fn(C.byref(blk.c), C.byref(opts), N, T, td, yd, ll, bufs[0], bufs[1], None, None, st, None))
+            for _ in range(3): run1()
+            _ffi.check(L.cdkf_synchronize(None))
+            t0 = time.perf_counter()
+            for _ in range(10): run1()
+            _ffi.check(L.cdkf_synchronize(None))
+            print(f"{algo} {sfx}, filtered moments only (the smoother's forward sweep): {(time.perf_counter() - t0) * 100:.3f} ms")
     for p in [yd, td, ll, st] + bufs: L.cdkf_free(p)
