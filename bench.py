@@ -166,6 +166,8 @@ def main():
             out["value_and_grad"] = value_and_grad(lib, blk, opts, N, T, t_d, y_d, ll, dev, torch, stream)
             del fm, fP, pm, pP
             out["saturated_regime"] = saturated(lib, blk, opts, dev, torch)
+            torch.cuda.empty_cache()
+            out["other_configs"] = other_configs(lib, dev, torch, t_h, y_h)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
@@ -243,6 +245,95 @@ def saturated(lib, blk, opts, dev, torch, n=65536, reps=5):
     gbs = n * T * 224 / (ms * 1e-3) / 1e9
     return {"trajectories": n, "num_timesteps": T, "kernel_ms": ms, "trajectories_per_sec": n / (ms * 1e-3),
             "achieved_GBps": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS}
+
+
+def other_configs(lib, dev, torch, t_h, y_h):
+    """Informational: the other BASELINE.json configurations (their per-GPU slices where the config spans 8 GPUs) through
+    the same C ABI, timed with HIP events on the launch stream -- device-resident inputs, native layouts, synthetic data
+    of SURVEY.md section 8d.  Not part of the headline metric."""
+    import cd_dynamax_amd as cd
+    from cd_dynamax_amd import _ffi
+    from cd_dynamax_amd.models import _model_block
+    p = lambda x: None if x is None else C.c_void_p(x.data_ptr())
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def timed(run, reps=3):
+        run()
+        torch.cuda.synchronize()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for a, b in evs:
+            a.record()
+            run()
+            b.record()
+        torch.cuda.synchronize()
+        return float(np.mean([a.elapsed_time(b) for a, b in evs]))
+
+    def grids(rng, n, T):
+        u = rng.uniform(0.0, 1.0, size=(n, T))
+        s = np.cumsum(u, axis=1)
+        return s / s[:, -1:] * (0.005 * T)
+
+    def case(params, t, y, dtype, layout, algos, outputs=True, grad=False, state_order=2):
+        blk = _model_block(params)
+        opts = _ffi.default_opts()
+        opts.layout = layout
+        opts.state_order = state_order
+        n, T, m = y.shape
+        d = blk.state_dim
+        tdt = torch.float64 if dtype == "f64" else torch.float32
+        t_d = torch.from_numpy(np.ascontiguousarray(t.T)).to(dev, tdt)
+        y_d = torch.from_numpy(np.ascontiguousarray(y.transpose(1, 2, 0) if layout == _ffi.LAYOUT_TCN else y.transpose(1, 0, 2))).to(dev, tdt)
+        ll = torch.empty(n, dtype=tdt, device=dev)
+        st = torch.zeros(n, dtype=torch.int32, device=dev)
+        bufs = [torch.empty(n * T * w, dtype=tdt, device=dev) if outputs else None for w in (d, d * d, d, d * d)]
+        res = {}
+        for algo in algos:
+            fn = getattr(lib, f"cdkf_{algo}_{dtype}_dev")
+            res[algo + "_ms"] = timed(lambda: _ffi.check(fn(C.byref(blk.c), C.byref(opts), n, T, p(t_d), p(y_d), p(ll),
+                                                            *[p(b) for b in bufs], p(st), stream)))
+        if grad:
+            del bufs
+            g = torch.empty(n, blk.theta.size, dtype=tdt, device=dev)
+            gm = torch.empty(n, _ffi.model_grad_size(d, m), dtype=tdt, device=dev)
+            fn = getattr(lib, f"cdkf_ekf_loglik_grad_all_{dtype}_dev")
+            opts.layout = _ffi.LAYOUT_TCN
+            y_g = torch.from_numpy(np.ascontiguousarray(y.transpose(1, 2, 0))).to(dev, tdt)
+            res["loglik_and_grad_all_ms"] = timed(lambda: _ffi.check(fn(C.byref(blk.c), C.byref(opts), n, T, p(t_d), p(y_g), p(ll),
+                                                                        p(g), p(gm), p(st), stream)))
+        res["status_flags_raised"] = int((st != 0).sum().item())
+        return res
+
+    eye = np.eye
+    out = {}
+    l63 = cd.ParamsCDNLGSSM(
+        initial=cd.ParamsLGSSMInitial(cd.LearnableVector(np.zeros(3)), cd.LearnableMatrix(5.0 * eye(3))),
+        dynamics=cd.ParamsCDNLGSSMDynamics(cd.LearnableLorenz63(10.0, 28.0, 8.0 / 3.0), cd.LearnableMatrix(eye(3)), cd.LearnableMatrix(eye(3)), 2.0),
+        emissions=cd.ParamsCDNLGSSMEmissions(cd.LearnableLinear(eye(3), np.zeros(3)), cd.LearnableMatrix(eye(3))))
+    out["config3_lorenz63_ukf_fp32_4096x1000"] = case(l63, t_h, y_h, "f32", _ffi.LAYOUT_TCN, ["ukf_filter"])
+    out["config2_with_smoother_fp64_4096x1000"] = case(l63, t_h, y_h, "f64", _ffi.LAYOUT_TCN, ["ekf_smoother"])
+    rng = np.random.default_rng(1)
+    d = 40
+    l96 = cd.ParamsCDNLGSSM(
+        initial=cd.ParamsLGSSMInitial(cd.LearnableVector(8.0 * np.ones(d)), cd.LearnableMatrix(eye(d))),
+        dynamics=cd.ParamsCDNLGSSMDynamics(cd.LearnableLorenz96(8.0), cd.LearnableMatrix(eye(d)), cd.LearnableMatrix(eye(d)), 2.0),
+        emissions=cd.ParamsCDNLGSSMEmissions(cd.LearnableLinear(eye(d), np.zeros(d)), cd.LearnableMatrix(eye(d))))
+    n, T = 2048, 500
+    out["config4_slice_lorenz96_d40_fp64_2048x500"] = case(l96, grids(rng, n, T), 8.0 + rng.standard_normal((n, T, d)), "f64",
+                                                          _ffi.LAYOUT_TN, ["ekf_filter", "ekf_smoother"])
+    rng = np.random.default_rng(2)
+    d, m, h = 8, 4, 64
+    mlp = cd.LearnableMLP(rng.standard_normal((h, d)) / np.sqrt(d), 0.1 * rng.standard_normal(h),
+                          rng.standard_normal((h, h)) / np.sqrt(h), 0.1 * rng.standard_normal(h),
+                          rng.standard_normal((d, h)) / np.sqrt(h), 0.1 * rng.standard_normal(d))
+    c5 = cd.ParamsCDNLGSSM(
+        initial=cd.ParamsLGSSMInitial(cd.LearnableVector(np.zeros(d)), cd.LearnableMatrix(eye(d))),
+        dynamics=cd.ParamsCDNLGSSMDynamics(mlp, cd.LearnableMatrix(eye(d)), cd.LearnableMatrix(0.5 * eye(d)), 1.0),
+        emissions=cd.ParamsCDNLGSSMEmissions(cd.LearnableLinear(eye(d)[:m], np.zeros(m)), cd.LearnableMatrix(0.5 * eye(m))))
+    n, T = 1024, 1000
+    # state_order 'first': the order the reverse (gradient) sweep supports for the MLP drift
+    out["config5_slice_mlp_d8_fp64_1024x1000_first_order"] = case(c5, grids(rng, n, T), rng.standard_normal((n, T, m)), "f64",
+                                                                 _ffi.LAYOUT_TN, ["ekf_filter"], outputs=False, grad=True, state_order=1)
+    return out
 
 
 def cpu_baseline_and_error(t_h, y_h, ll_dev, fm_dev):
