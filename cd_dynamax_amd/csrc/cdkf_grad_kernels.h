@@ -310,6 +310,7 @@ __global__ __launch_bounds__(64, 1) void ekf_grad_reg_kernel(const GradArgs<R, D
   const RegArgs<R, D, M, Drift>& a = ga.a;
   const long total = a.N * NPAR;
   const long gid0 = reg_unit_index(ga.a.lanes, ga.a.xcd_shift);
+  if (reg_group_is_surplus(gid0, ga.a.lanes, total)) return;
   const bool live = gid0 < total;
   const long gid = live ? gid0 : total - 1;  // idle lanes shadow the last (trajectory, parameter) pair
   const long n = gid / NPAR;

@@ -62,6 +62,8 @@ CDKF_DEV long reg_unit_index(int lanes, int xcd_shift) {
   const long grp = ((b >> (3 + sh)) << (3 + sh)) + ((b & 7) << sh) + ((b >> 3) & ((1 << sh) - 1));
   return grp * lanes + (threadIdx.x & (lanes - 1));
 }
+// true for the surplus wavefronts of the rounded-up grid (their whole group lies beyond the batch): they leave at once
+CDKF_DEV bool reg_group_is_surplus(long unit, int lanes, long units) { return unit - (threadIdx.x & (lanes - 1)) >= units; }
 
 // tableau the sweep integrates with: the VGPR-pinned Dormand-Prince constants, or the run-time tableau of the arguments
 template <typename R, bool GENERIC>
@@ -748,6 +750,7 @@ template <typename R, int D, int M, typename Drift, bool GENERIC = false>
 CDKF_DEV void ekf_smoother_reg_body(const RegArgs<R, D, M, Drift>& a, R* __restrict__ sm, R* __restrict__ sP) {
   constexpr int NS = Dims<D>::NS;
   const long gid = reg_unit_index(a.lanes, a.xcd_shift);
+  if (reg_group_is_surplus(gid, a.lanes, a.N)) return;
   const bool live = gid < a.N;
   const long n = live ? gid : a.N - 1;
   const R* __restrict__ tp = a.t + n * a.t_sn;
