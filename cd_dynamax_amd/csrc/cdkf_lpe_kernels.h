@@ -1,0 +1,212 @@
+// cdkf_lpe_kernels.h -- Lorenz-63 EKF filter sweep with SIXTEEN LANES PER TRAJECTORY, for batches too small to fill the chip
+// with the lane-per-trajectory kernel (4096 trajectories: 64 wavefronts' worth of lanes on 1024 SIMDs).
+//
+// A lone wavefront pays one 4-cycle issue slot per instruction whatever the lane count, so with SIMDs to spare the sweep
+// gets faster only by issuing fewer instructions per observation step.  Here a trajectory occupies one 16-lane DPP row as a
+// 4 x 4 grid, lane (i, j) = 4 i + j:
+//
+//      (i, j), i, j < 3 : P_ij          (i, 3), i < 3 : m_i          (3, j), j < 3 : y_j (observation stream)     (3, 3) : t
+//
+// * predict: every lane integrates ITS entry -- 20 tableau FMAs per Runge-Kutta step instead of 180, and the right-hand
+//   side F P + P F^T + L Qc L^T as two 4-term dot products whose operands arrive by full-rate DPP moves (row_ror by 4 s: the
+//   entry s rows below in the same column; quad_perm rotation: s columns to the right in the same row); the Jacobian
+//   entries a lane needs, F_{i,(i+s)%4} and F_{j,(j+s)%4}, are affine in the mean with per-lane constants (at most two of
+//   the three mean components per slot), the mean itself arrives through row_newbcast operands of the fp64 ALU;
+// * update: the twelve moments are broadcast to every lane of the row (row_newbcast), each lane runs the SAME update code as
+//   the lane-per-trajectory kernel (ekf_update) redundantly and keeps its own entry -- one source for the arithmetic;
+// * stores: lane (i, j) writes its own entry -- ONE store instruction per moment set (mean and covariance together, per-lane
+//   pointers) instead of twelve; the row-3 lanes stream the observations and times in, one load per step.
+//
+// Per observation step ~600 issue slots instead of ~830 (+ 24 stores at ~19 cycles): 4096 x 1000, fp64: 1.77 -> see DESIGN.md.
+// Scope: drift Lorenz-63, emission = the three state coordinates (H = I, no bias), num_iter 1, state_order first / second
+// (identical for this drift), fixed-step Dormand-Prince, all four outputs or none.  Everything else runs on filter_reg_kernel.
+#pragma once
+#include "cdkf_reg_kernels.h"
+
+namespace cdkf {
+
+template <int CTRL>
+CDKF_DEV double lpe_dpp(double v) {
+  const long long old = 0, src = __builtin_bit_cast(long long, v);
+  const long long r = __builtin_amdgcn_update_dpp(old, src, CTRL, 0xF, 0xF, true);  // every source lane is valid: no merge with `old`
+  return __builtin_bit_cast(double, r);
+}
+template <int CTRL>
+CDKF_DEV float lpe_dpp(float v) {
+  const int old = 0, src = __builtin_bit_cast(int, v);
+  const int r = __builtin_amdgcn_update_dpp(old, src, CTRL, 0xF, 0xF, true);
+  return __builtin_bit_cast(float, r);
+}
+// value of lane L of this 16-lane row (folds into the consuming fp64 instruction as a row_newbcast operand)
+template <int L, typename R>
+CDKF_DEV R lpe_bcast(R v) { return lpe_dpp<0x150 + L>(v); }
+
+// Right-hand side of the moment ODEs for the entry this lane owns (see the header comment for the grid).
+template <typename R>
+struct LpeRhs {
+  // Jacobian slots relative to the lane's row i and column j: F_{q,(q+1)%4} = c1 + gx1 x, F_{q,(q+2)%4} = gy2 y,
+  // F_{q,(q+3)%4} = c3 + gz3 z + gx3 x (row / column 3 of the grid is not part of P: all zero)
+  R c1i, gx1i, gy2i, c3i, gz3i, gx3i, c1j, gx1j, gy2j, c3j, gz3j, gx3j;
+  R g0, q;                  // F_ii + F_jj and (L Qc L^T)_ij for the covariance lanes, 0 elsewhere
+  R ax, ay, az, axz, axy;   // drift of the mean lanes: f_i = (ax + axz z + axy y) x + ay y + az z, 0 elsewhere
+  CDKF_DEV void init(int i, int j, R sigma, R rho, R beta, const R* LQL) {
+    auto slot = [&](int r, R& c1, R& gx1, R& gy2, R& c3, R& gz3, R& gx3) {
+      c1 = (r == 0) ? sigma : R(0);
+      gx1 = (r == 1) ? R(-1) : R(0);
+      gy2 = (r == 2) ? R(1) : R(0);
+      c3 = (r == 1) ? rho : R(0);
+      gz3 = (r == 1) ? R(-1) : R(0);
+      gx3 = (r == 2) ? R(1) : R(0);
+    };
+    const bool cov = i < 3 && j < 3, mean = i < 3 && j == 3;
+    slot(cov ? i : 3, c1i, gx1i, gy2i, c3i, gz3i, gx3i);
+    slot(cov ? j : 3, c1j, gx1j, gy2j, c3j, gz3j, gx3j);
+    const R diag[4] = {-sigma, R(-1), -beta, R(0)};
+    g0 = cov ? diag[i] + diag[j] : R(0);
+    q = cov ? LQL[sidx<3>(i, j)] : R(0);
+    ax = mean ? (i == 0 ? -sigma : (i == 1 ? rho : R(0))) : R(0);
+    ay = mean ? (i == 0 ? sigma : (i == 1 ? R(-1) : R(0))) : R(0);
+    az = (mean && i == 2) ? -beta : R(0);
+    axz = (mean && i == 1) ? R(-1) : R(0);
+    axy = (mean && i == 2) ? R(1) : R(0);
+  }
+  CDKF_DEV void operator()(const R (&s)[1], R (&k)[1]) const {
+    const R v = s[0];
+    const R x = lpe_bcast<3>(v), y = lpe_bcast<7>(v), z = lpe_bcast<11>(v);
+    const R d1 = lpe_dpp<0x120 + 12>(v), d2 = lpe_dpp<0x120 + 8>(v), d3 = lpe_dpp<0x120 + 4>(v);  // rows i+1, i+2, i+3
+    const R r1 = lpe_dpp<0x39>(v), r2 = lpe_dpp<0x4E>(v), r3 = lpe_dpp<0x93>(v);                  // columns j+1, j+2, j+3
+    const R fi1 = rfma(gx1i, x, c1i), fi2 = gy2i * y, fi3 = rfma(gz3i, z, rfma(gx3i, x, c3i));
+    const R fj1 = rfma(gx1j, x, c1j), fj2 = gy2j * y, fj3 = rfma(gz3j, z, rfma(gx3j, x, c3j));
+    const R dm = rfma(rfma(axy, y, rfma(axz, z, ax)), x, rfma(ay, y, az * z));
+    R acc = rfma(g0, v, q + dm);
+    acc = rfma(fi1, d1, acc);
+    acc = rfma(fi2, d2, acc);
+    acc = rfma(fi3, d3, acc);
+    acc = rfma(fj1, r1, acc);
+    acc = rfma(fj2, r2, acc);
+    acc = rfma(fj3, r3, acc);
+    k[0] = acc;
+  }
+};
+
+// groups of four trajectories per wavefront; the four wavefronts that share a 128-byte line of the [T,comp,N] arrays sit on
+// one XCD (same renumbering as reg_unit_index with xcd_shift = 2 for fp64, 3 for fp32)
+template <typename R>
+constexpr int lpe_xcd_shift() { return sizeof(R) == 8 ? 2 : 3; }
+template <typename R>
+inline unsigned lpe_blocks(int64_t N) {
+  const int64_t groups = (N + 3) / 4, round = (int64_t)8 << lpe_xcd_shift<R>();
+  return (unsigned)((groups + round - 1) / round * round);
+}
+
+template <typename R, bool OUT>
+__global__ __launch_bounds__(64) void filter_lpe_l63_kernel(const RegArgs<R, 3, 3, DriftLorenz63<R, 3>> a) {
+  constexpr int D = 3, NS = Dims<D>::NS;
+  const int lane = threadIdx.x, l = lane & 15, i = l >> 2, j = l & 3;
+  constexpr int sh = lpe_xcd_shift<R>();
+  const long b = blockIdx.x;
+  const long grp = ((b >> (3 + sh)) << (3 + sh)) + ((b & 7) << sh) + ((b >> 3) & ((1 << sh) - 1));
+  if (grp * 4 >= a.N) return;  // surplus wavefront of the rounded-up grid
+  const long n_raw = grp * 4 + (lane >> 4);
+  const bool live = n_raw < a.N;
+  const long n = live ? n_raw : a.N - 1;  // an idle row shadows the last trajectory (same values to the same addresses)
+  const bool cov = i < 3 && j < 3, mean = i < 3 && j == 3;
+
+  LpeRhs<R> rhs;
+  rhs.init(i, j, a.drift.sigma, a.drift.rho, a.drift.beta, a.LQL);
+  const auto C = TabSel<R, false>::get(a);
+
+  // own entry; index of that entry in the gathered state [m_0..m_2, P_00, P_01, P_02, P_11, P_12, P_22] (-1: none)
+  const int own = cov ? D + sidx<D>(i, j) : (mean ? i : -1);
+  R v = cov ? a.P0[sidx<D>(i, j)] : (mean ? a.m0[i] : R(0));
+
+  // input stream of the row-3 lanes: (3, j < 3) reads y_j, (3, 3) reads t one step further ahead; the other lanes re-read t_0
+  const R* __restrict__ tp0 = a.t + n * a.t_sn;
+  const R* ldp = tp0;
+  long ld_stride = 0, ld_ahead = a.T;  // advance while k + ld_ahead < T
+  if (i == 3 && j < 3) {
+    ldp = a.y + n * a.y_sn + j * a.y_si;
+    ld_stride = a.y_sk;
+    ld_ahead = 1;
+  } else if (l == 15) {
+    ld_stride = a.t_sk;
+    ld_ahead = 2;
+    if (a.T > 1) ldp += a.t_sk;
+  }
+  R tcur = tp0[0];
+  R cur = ldp[0];  // y_0 / t_1
+  // output pointers of this lane (filtered and predicted arrays share the geometry)
+  R* fout = nullptr;
+  R* pout = nullptr;
+  long out_stride = 0;
+  if constexpr (OUT) {
+    if (cov) {
+      fout = a.fP + n * a.P_sn + (i * D + j) * a.P_si;
+      pout = a.pP + n * a.P_sn + (i * D + j) * a.P_si;
+      out_stride = a.P_sk;
+    } else if (mean) {
+      fout = a.fm + n * a.m_sn + i * a.m_si;
+      pout = a.pm + n * a.m_sn + i * a.m_si;
+      out_stride = a.m_sk;
+    }
+  }
+
+  LlAcc ll;
+  int st = 0;
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see cdkf_filter_reg_body.inc
+  for (long k = 0; k < a.T; ++k) {
+    if (k + ld_ahead < a.T) ldp += ld_stride;
+    const R nxt = ldp[0];  // y_{k+1} / t_{k+2}, a whole step ahead
+
+    // ---- measurement update, redundantly in every lane of the row, on the gathered moments -------------------------
+    R ys[NS], yobs[D];
+    ys[0] = lpe_bcast<3>(v);
+    ys[1] = lpe_bcast<7>(v);
+    ys[2] = lpe_bcast<11>(v);
+    ys[3] = lpe_bcast<0>(v);
+    ys[4] = lpe_bcast<1>(v);
+    ys[5] = lpe_bcast<2>(v);
+    ys[6] = lpe_bcast<5>(v);
+    ys[7] = lpe_bcast<6>(v);
+    ys[8] = lpe_bcast<10>(v);
+    yobs[0] = lpe_bcast<12>(cur);
+    yobs[1] = lpe_bcast<13>(cur);
+    yobs[2] = lpe_bcast<14>(cur);
+    const R tnext_obs = lpe_bcast<15>(cur);
+    ekf_update<R, D, D, true>(a, ys, yobs, ll, st);
+    if (ys[0] != ys[0]) st |= kStatusNan;
+    R upd = R(0);
+#pragma unroll
+    for (int e = 0; e < NS; ++e) upd = (own == e) ? ys[e] : upd;
+    v = upd;
+    if constexpr (OUT) {
+      if (own >= 0) *fout = v;
+    }
+
+    // ---- predict to t_{k+1} (to t_k + dt_final after the last observation) -----------------------------------------
+    const R t1 = (k + 1 < a.T) ? tnext_obs : tcur + a.dt_final;
+    R y1[1] = {v};
+    if (integrate<R, 1>(y1, tcur, t1, a.dt0, a.max_steps, rhs, C)) st |= kStatusMaxSteps;
+    v = y1[0];
+    if constexpr (OUT) {
+      if (own >= 0) *pout = v;
+      fout += out_stride;
+      pout += out_stride;
+    }
+    tcur = tnext_obs;
+    cur = nxt;
+  }
+  ll.flush();
+  if (live && l == 0) {
+    a.ll[n] = (R)ll.ll;
+    if (a.status) a.status[n] = st;
+  }
+}
+
+// launch conditions beyond the shape (checked by the caller): see the header comment
+inline bool lpe_batch_is_small(int64_t N) {
+  // 4 trajectories per wavefront: worthwhile while that still leaves no more than ~2 wavefronts per SIMD
+  return N <= 8192;
+}
+
+}  // namespace cdkf

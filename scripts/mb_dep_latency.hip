@@ -60,6 +60,36 @@ __global__ void store_burst(double* out, long* cyc, int iters, double* buf, long
   if (lane == 0) *cyc = t1 - t0;
 }
 
+// The same 12 doubles per iteration written component-contiguous ([T,N,w] layout): per lane 3 + 9 adjacent doubles at a lane
+// stride of 24 / 72 bytes -- 2 + 5 wide stores with immediate offsets and two address computations.
+typedef double double2a __attribute__((ext_vector_type(2), aligned(8)));
+template <int FILL>
+__global__ void store_tn(double* out, long* cyc, int iters, double* buf, long row, int mode) {
+  const int lane = threadIdx.x;
+  const int col = mode == 1 ? (lane & 7) : lane;
+  double x = lane * 1e-3, y = 1.0;
+  long t0 = __builtin_readcyclecounter();
+  for (int i = 0; i < iters; ++i) {
+    double* m = buf + (long)(i & 63) * 12 * row + col * 3;
+    double* P = buf + (long)(i & 63) * 12 * row + 3 * row + col * 9;
+    *(double2a*)(m) = double2a{x, x};
+    m[2] = x;
+#pragma unroll
+    for (int f = 0; f < 2 * FILL; ++f) y = __builtin_fma(y, 1.0000001, 1e-9);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      *(double2a*)(P + 2 * r) = double2a{x, x};
+#pragma unroll
+      for (int f = 0; f < FILL; ++f) y = __builtin_fma(y, 1.0000001, 1e-9);
+    }
+    P[8] = x;
+    x += 1.0;
+  }
+  long t1 = __builtin_readcyclecounter();
+  out[lane] = y;
+  if (lane == 0) *cyc = t1 - t0;
+}
+
 __global__ void add64_chain(double* out, long* cyc, int iters, long stride) {
   long a = threadIdx.x;
   long t0 = __builtin_readcyclecounter();
@@ -113,6 +143,13 @@ int main() {
     run(nm, 12, store_burst<4>, buf, row, mode);
     snprintf(nm, sizeof nm, "store + 16 fma, %s", names[mode]);
     run(nm, 12, store_burst<16>, buf, row, mode);
+  }
+  for (int mode = 0; mode < 2; ++mode) {
+    char nm[96];
+    snprintf(nm, sizeof nm, "[T,N,w] 7 wide stores (ticks per 12 doubles / 12), %s", names[mode]);
+    run(nm, 12, store_tn<0>, buf, row, mode);
+    snprintf(nm, sizeof nm, "[T,N,w] 7 wide stores + 6x4 fma (per 12 doubles / 12), %s", names[mode]);
+    run(nm, 12, store_tn<4>, buf, row, mode);
   }
   return 0;
 }
