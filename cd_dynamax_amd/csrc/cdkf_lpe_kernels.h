@@ -135,9 +135,11 @@ __global__ __launch_bounds__(64) void filter_lpe_l63_kernel(const RegArgs<R, 3, 
   }
   R tcur = tp0[0];
   R cur = ldp[0];  // y_0 / t_1
-  // output pointers of this lane (filtered and predicted arrays share the geometry)
-  R* fout = nullptr;
-  R* pout = nullptr;
+  // output pointers of this lane (filtered and predicted arrays share the geometry).  The row-3 lanes own no moment; so that
+  // the stores stay unconditional (exact vmcnt accounting: behind a branch the compiler drains every store before the next
+  // step's load, ~600 cycles per step) they write their zero to ll[n], which lane 0 overwrites after the sweep.
+  R* fout = a.ll + n;
+  R* pout = a.ll + n;
   long out_stride = 0;
   if constexpr (OUT) {
     if (cov) {
@@ -179,9 +181,7 @@ __global__ __launch_bounds__(64) void filter_lpe_l63_kernel(const RegArgs<R, 3, 
 #pragma unroll
     for (int e = 0; e < NS; ++e) upd = (own == e) ? ys[e] : upd;
     v = upd;
-    if constexpr (OUT) {
-      if (own >= 0) *fout = v;
-    }
+    if constexpr (OUT) *fout = v;
 
     // ---- predict to t_{k+1} (to t_k + dt_final after the last observation) -----------------------------------------
     const R t1 = (k + 1 < a.T) ? tnext_obs : tcur + a.dt_final;
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(64) void filter_lpe_l63_kernel(const RegArgs<R, 3, 
     if (integrate<R, 1>(y1, tcur, t1, a.dt0, a.max_steps, rhs, C)) st |= kStatusMaxSteps;
     v = y1[0];
     if constexpr (OUT) {
-      if (own >= 0) *pout = v;
+      *pout = v;
       fout += out_stride;
       pout += out_stride;
     }
