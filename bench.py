@@ -156,7 +156,7 @@ def main():
                        "trajectories_per_gpu": N, "num_timesteps": T, "parallelism": f"dp{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "filter_reg_kernel<double,3,3,DriftLorenz63,UKF=0,ZEROTH=0,HSEL=1,OUT=all>",
+                         "kernel": "filter_lpe_l63_kernel<double,OUT=all> (sixteen lanes per trajectory; the N=65536 line below runs filter_reg_kernel)",
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_per_launch},
             "marginal_loglik_sum": total_ll, "status_flags_raised": n_bad,
         }

@@ -6,7 +6,7 @@ import json
 import sys
 
 tag = sys.argv[1]
-kernel_sub = sys.argv[2] if len(sys.argv) > 2 else "ekf_filter"
+kernel_sub = sys.argv[2] if len(sys.argv) > 2 else "filter_"
 N, T, bytes_per_step = 4096, 1000, 224
 out = {"round": 1, "tag": tag,
        "command": "rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-saturation",
