@@ -21,6 +21,12 @@
 // Scope: drift Lorenz-63, emission = the three state coordinates (H = I, no bias), num_iter 1, state_order first / second
 // (identical for this drift), fixed-step Dormand-Prince, all four outputs or none.  Everything else runs on filter_reg_kernel.
 #pragma once
+#ifndef __HIPCC_RTC__
+#include <cstdlib>
+#include <type_traits>
+
+#include "cdkf_launch.h"
+#endif
 #include "cdkf_reg_kernels.h"
 
 namespace cdkf {
@@ -99,7 +105,8 @@ inline unsigned lpe_blocks(int64_t N) {
   return (unsigned)((groups + round - 1) / round * round);
 }
 
-template <typename R, bool OUT>
+// OUT: 0 log-likelihood only, 1 all four moment arrays, 2 filtered moments only (the smoother's forward sweep)
+template <typename R, int OUT>
 __global__ __launch_bounds__(64) void filter_lpe_l63_kernel(const RegArgs<R, 3, 3, DriftLorenz63<R, 3>> a) {
   constexpr int D = 3, NS = Dims<D>::NS;
   const int lane = threadIdx.x, l = lane & 15, i = l >> 2, j = l & 3;
@@ -144,11 +151,11 @@ __global__ __launch_bounds__(64) void filter_lpe_l63_kernel(const RegArgs<R, 3, 
   if constexpr (OUT) {
     if (cov) {
       fout = a.fP + n * a.P_sn + (i * D + j) * a.P_si;
-      pout = a.pP + n * a.P_sn + (i * D + j) * a.P_si;
+      if constexpr (OUT == 1) pout = a.pP + n * a.P_sn + (i * D + j) * a.P_si;
       out_stride = a.P_sk;
     } else if (mean) {
       fout = a.fm + n * a.m_sn + i * a.m_si;
-      pout = a.pm + n * a.m_sn + i * a.m_si;
+      if constexpr (OUT == 1) pout = a.pm + n * a.m_sn + i * a.m_si;
       out_stride = a.m_sk;
     }
   }
@@ -188,11 +195,11 @@ __global__ __launch_bounds__(64) void filter_lpe_l63_kernel(const RegArgs<R, 3, 
     R y1[1] = {v};
     if (integrate<R, 1>(y1, tcur, t1, a.dt0, a.max_steps, rhs, C)) st |= kStatusMaxSteps;
     v = y1[0];
-    if constexpr (OUT) {
+    if constexpr (OUT == 1) {
       *pout = v;
-      fout += out_stride;
       pout += out_stride;
     }
+    if constexpr (OUT) fout += out_stride;
     tcur = tnext_obs;
     cur = nxt;
   }
@@ -203,10 +210,36 @@ __global__ __launch_bounds__(64) void filter_lpe_l63_kernel(const RegArgs<R, 3, 
   }
 }
 
-// launch conditions beyond the shape (checked by the caller): see the header comment
 inline bool lpe_batch_is_small(int64_t N) {
   // 4 trajectories per wavefront: worthwhile while that still leaves no more than ~2 wavefronts per SIMD
   return N <= 8192;
 }
+
+#ifndef __HIPCC_RTC__
+// Small Lorenz-63 batches (H = I): sixteen lanes per trajectory (cdkf_lpe_kernels.h).  CDKF_NO_LPE=1 keeps the
+// lane-per-trajectory kernel (A/B timing, tests of the latter at small N).
+template <typename R, int D, int M, typename Drift>
+inline bool try_lpe(const RegArgs<R, D, M, Drift>& a, const cdkf_model* mdl, const cdkf_opts* o, hipStream_t stream) {
+  if constexpr (std::is_same<Drift, DriftLorenz63<R, 3>>::value && D == 3 && M == 3) {
+    static const bool off = [] { const char* e = std::getenv("CDKF_NO_LPE"); return e && e[0] == '1'; }();
+    const bool all = a.fm && a.fP && a.pm && a.pP, none = !a.fm && !a.fP && !a.pm && !a.pP;
+    const bool filt = a.fm && a.fP && !a.pm && !a.pP;
+    if (off || !lpe_batch_is_small(a.N) || !(all || none || filt) || !emission_is_selection(mdl) || o->forecast ||
+        o->state_order == CDKF_ORDER_ZEROTH || o->solver != CDKF_SOLVER_DOPRI5 || o->adaptive)
+      return false;
+    const dim3 grid(lpe_blocks<R>(a.N)), block(64);
+    if (all)
+      hipLaunchKernelGGL((filter_lpe_l63_kernel<R, 1>), grid, block, 0, stream, a);
+    else if (filt)
+      hipLaunchKernelGGL((filter_lpe_l63_kernel<R, 2>), grid, block, 0, stream, a);
+    else
+      hipLaunchKernelGGL((filter_lpe_l63_kernel<R, 0>), grid, block, 0, stream, a);
+    return true;
+  } else {
+    return false;
+  }
+}
+
+#endif
 
 }  // namespace cdkf

@@ -1,32 +1,8 @@
 // launch_ekf.hip -- EKF filter sweep: kernel selection and launch.
-#include <cstdlib>
-#include <type_traits>
-
 #include "cdkf_launch.h"
 #include "cdkf_lpe_kernels.h"
 
 namespace cdkf {
-
-// Small Lorenz-63 batches (H = I): sixteen lanes per trajectory (cdkf_lpe_kernels.h).  CDKF_NO_LPE=1 keeps the
-// lane-per-trajectory kernel (A/B timing, tests of the latter at small N).
-template <typename R, int D, int M, typename Drift>
-static bool try_lpe(const RegArgs<R, D, M, Drift>& a, const cdkf_model* mdl, const cdkf_opts* o, hipStream_t stream) {
-  if constexpr (std::is_same<Drift, DriftLorenz63<R, 3>>::value && D == 3 && M == 3) {
-    static const bool off = [] { const char* e = std::getenv("CDKF_NO_LPE"); return e && e[0] == '1'; }();
-    const bool all = a.fm && a.fP && a.pm && a.pP, none = !a.fm && !a.fP && !a.pm && !a.pP;
-    if (off || !lpe_batch_is_small(a.N) || !(all || none) || !emission_is_selection(mdl) || o->forecast ||
-        o->state_order == CDKF_ORDER_ZEROTH || o->solver != CDKF_SOLVER_DOPRI5 || o->adaptive)
-      return false;
-    const dim3 grid(lpe_blocks<R>(a.N)), block(64);
-    if (all)
-      hipLaunchKernelGGL((filter_lpe_l63_kernel<R, true>), grid, block, 0, stream, a);
-    else
-      hipLaunchKernelGGL((filter_lpe_l63_kernel<R, false>), grid, block, 0, stream, a);
-    return true;
-  } else {
-    return false;
-  }
-}
 
 template <typename R, int D, int M, typename Drift>
 static int run_ekf_reg(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll,

@@ -1,5 +1,6 @@
 // launch_eks.hip -- EKF smoother: forward filter sweep (num_iter = 1) then the backward sweep.
 #include "cdkf_launch.h"
+#include "cdkf_lpe_kernels.h"
 
 namespace cdkf {
 
@@ -23,7 +24,8 @@ static int run_eks_reg(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int
   }
   // the smoother's internal filter runs with the caller's state_order (extended_kalman_smoother forwards hyperparams to the
   // filter, inference_ekf.py:489-495); the backward pass is always smooth_order 'first'
-  if (of.state_order == CDKF_ORDER_ZEROTH)
+  if (try_lpe(a, mdl, &of, stream)) {  // small Lorenz-63 batch: sixteen lanes per trajectory, filtered moments only
+  } else if (of.state_order == CDKF_ORDER_ZEROTH)
     hipLaunchKernelGGL((filter_reg_kernel<R, D, M, Drift, false, true, false, kOutSome>), dim3(blocks), dim3(64), 0, stream, a);
   else if (M <= D && emission_is_selection(mdl))  // H = I[:M], no bias: the products with H disappear (as in launch_ekf.hip)
     hipLaunchKernelGGL((filter_reg_kernel<R, D, M, Drift, false, false, (M <= D), kOutSome>), dim3(blocks), dim3(64), 0, stream, a);

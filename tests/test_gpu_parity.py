@@ -232,7 +232,11 @@ def test_results_do_not_depend_on_the_wavefront_grouping(hip_lib, N, T):
     big = cd.cdnlgssm_smoother(P, y, t[..., None])
     small = cd.cdnlgssm_smoother(P, y[sub], t[sub][..., None])
     for k in ("smoothed_means", "smoothed_covariances", "filtered_means"):
-        np.testing.assert_array_equal(np.asarray(getattr(big, k))[sub], np.asarray(getattr(small, k)), err_msg=k)
+        a, b = np.asarray(getattr(big, k))[sub], np.asarray(getattr(small, k))
+        if N <= 8192:  # the smoother's forward sweep follows the same kernel choice as the EKF filter above
+            np.testing.assert_array_equal(a, b, err_msg=k)
+        else:
+            np.testing.assert_allclose(a, b, rtol=1e-10, atol=1e-12, err_msg=k)
     ll_b, g_b = cd.cdnlgssm_loglik_and_grad(P, y, t[..., None])
     ll_s, g_s = cd.cdnlgssm_loglik_and_grad(P, y[sub], t[sub][..., None])
     np.testing.assert_array_equal(ll_b[sub], ll_s)
