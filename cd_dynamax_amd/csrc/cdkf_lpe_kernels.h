@@ -95,6 +95,70 @@ struct LpeRhs {
   }
 };
 
+// Measurement update in the same grid (num_iter = 1, symmetric R): the four rows of a trajectory's grid factorise and solve
+// DIFFERENT systems with ONE instruction stream -- rows i < 3: psd_solve's S + 1e-9 I against column i of H P = P (which,
+// P being symmetric, is the row's own three covariance lanes: quad broadcasts), i.e. row i of the gain K; row 3: the
+// log-likelihood's S against the innovation.  A lane then holds K_i. ; the rows K_j. it needs for P+_ij = P_ij - (K S K^T)_ij
+// come from a broadcast of the three gain rows and a two-level select on j.  ~140 instructions instead of the ~270 of
+// the redundant per-lane update, the same operations on each number (chol_lower / substitution order of ekf_update).
+template <typename R, typename Args>
+CDKF_DEV void lpe_update(const Args& a, R& v, R cur, int i, int j, LlAcc& ll, bool& bad) {
+  constexpr int D = 3;
+  const bool row3 = i == 3, cov = i < 3 && j < 3, mean = i < 3 && j == 3;
+  const R Pg[6] = {lpe_bcast<0>(v), lpe_bcast<1>(v), lpe_bcast<2>(v), lpe_bcast<5>(v), lpe_bcast<6>(v), lpe_bcast<10>(v)};
+  const R m0 = lpe_bcast<3>(v), m1 = lpe_bcast<7>(v), m2 = lpe_bcast<11>(v);
+  const R inn[D] = {lpe_bcast<12>(cur) - m0, lpe_bcast<13>(cur) - m1, lpe_bcast<14>(cur) - m2};
+  R S[D][D];
+#pragma unroll
+  for (int r = 0; r < D; ++r)
+#pragma unroll
+    for (int c = 0; c < D; ++c) S[r][c] = Pg[sidx<D>(r, c)] + a.Rm[r][c];
+  const R eps = row3 ? R(0) : R(1e-9);
+  R A[D][D], L[D][D], inv[D];
+#pragma unroll
+  for (int r = 0; r < D; ++r)
+#pragma unroll
+    for (int c = 0; c <= r; ++c) A[r][c] = (r == c) ? S[r][c] + eps : S[r][c];
+  chol_lower<R, D>(A, L, inv, bad);
+  // right-hand side: row i of P (= column i) for the gain rows, the innovation for row 3
+  const R q0 = lpe_dpp<0x00>(v), q1 = lpe_dpp<0x55>(v), q2 = lpe_dpp<0xAA>(v);
+  const R b0 = row3 ? inn[0] : q0, b1 = row3 ? inn[1] : q1, b2 = row3 ? inn[2] : q2;
+  const R w0 = b0 * inv[0];
+  const R w1 = rfma(-L[1][0], w0, b1) * inv[1];
+  const R w2 = rfma(-L[2][1], w1, rfma(-L[2][0], w0, b2)) * inv[2];
+  const R quad = rfma(w2, w2, rfma(w1, w1, w0 * w0));
+  const R pinv = (inv[0] * inv[1]) * inv[2];
+  ll.add((double)lpe_bcast<12>(quad), (double)lpe_bcast<12>(pinv), D);
+  R x[D];  // K_i.
+  x[2] = w2 * inv[2];
+  x[1] = rfma(-L[2][1], x[2], w1) * inv[1];
+  x[0] = rfma(-L[2][0], x[2], rfma(-L[1][0], x[1], w0)) * inv[0];
+  R Kj[D];
+#pragma unroll
+  for (int c = 0; c < D; ++c) {
+    const R k0 = lpe_bcast<0>(x[c]), k1 = lpe_bcast<4>(x[c]), k2 = lpe_bcast<8>(x[c]);
+    Kj[c] = (j == 0) ? k0 : ((j == 1) ? k1 : k2);
+  }
+  R KSi[D], KSj[D];
+#pragma unroll
+  for (int c = 0; c < D; ++c) {
+    KSi[c] = rfma(x[2], S[2][c], rfma(x[1], S[1][c], x[0] * S[0][c]));
+    KSj[c] = rfma(Kj[2], S[2][c], rfma(Kj[1], S[1][c], Kj[0] * S[0][c]));
+  }
+  const R tij = rfma(KSi[2], Kj[2], rfma(KSi[1], Kj[1], KSi[0] * Kj[0]));
+  const R tji = rfma(KSj[2], x[2], rfma(KSj[1], x[1], KSj[0] * x[0]));
+  const R pn = R(0.5) * ((v - tij) + (v - tji));
+  const R mn = rfma(x[2], inn[2], rfma(x[1], inn[1], rfma(x[0], inn[0], v)));
+  v = cov ? pn : (mean ? mn : R(0));
+  // The lanes below the diagonal adopt the value of their transpose partner (lanes 4 <- 1, 9 <- 6: row_shr:3; 8 <- 2:
+  // row_shr:6).  Each lane integrates its own entry, so P_ij and P_ji differ by rounding after a predict, and the
+  // antisymmetric part is amplified by the (chaotic) flow -- left alone it reached 1e-8 relative within 300 steps and
+  // destroyed the filter within 1000; the packed-symmetric kernels cannot develop it.
+  const R s3 = lpe_dpp<0x110 + 3>(v), s6 = lpe_dpp<0x110 + 6>(v);
+  v = ((i == 1 && j == 0) || (i == 2 && j == 1)) ? s3 : v;
+  v = (i == 2 && j == 0) ? s6 : v;
+}
+
 // groups of four trajectories per wavefront; the four wavefronts that share a 128-byte line of the [T,comp,N] arrays sit on
 // one XCD (same renumbering as reg_unit_index with xcd_shift = 2 for fp64, 3 for fp32)
 template <typename R>
@@ -162,12 +226,18 @@ __global__ __launch_bounds__(64) void filter_lpe_l63_kernel(const RegArgs<R, 3, 
 
   LlAcc ll;
   int st = 0;
+  bool bad = false;  // a non-positive pivot in this row's factorisations (lpe_update)
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see cdkf_filter_reg_body.inc
   for (long k = 0; k < a.T; ++k) {
     if (k + ld_ahead < a.T) ldp += ld_stride;
     const R nxt = ldp[0];  // y_{k+1} / t_{k+2}, a whole step ahead
 
-    // ---- measurement update, redundantly in every lane of the row, on the gathered moments -------------------------
+    const R tnext_obs = lpe_bcast<15>(cur);
+    if (a.lpe_fast) {
+      lpe_update(a, v, cur, i, j, ll, bad);
+    } else {
+    // ---- measurement update, redundantly in every lane of the row, on the gathered moments (iterated updates, an
+    // emission covariance that is not exactly symmetric) ---------------------------------------------------------------
     R ys[NS], yobs[D];
     ys[0] = lpe_bcast<3>(v);
     ys[1] = lpe_bcast<7>(v);
@@ -181,13 +251,13 @@ __global__ __launch_bounds__(64) void filter_lpe_l63_kernel(const RegArgs<R, 3, 
     yobs[0] = lpe_bcast<12>(cur);
     yobs[1] = lpe_bcast<13>(cur);
     yobs[2] = lpe_bcast<14>(cur);
-    const R tnext_obs = lpe_bcast<15>(cur);
     ekf_update<R, D, D, true>(a, ys, yobs, ll, st);
     if (ys[0] != ys[0]) st |= kStatusNan;
     R upd = R(0);
 #pragma unroll
     for (int e = 0; e < NS; ++e) upd = (own == e) ? ys[e] : upd;
     v = upd;
+    }
     if constexpr (OUT) *fout = v;
 
     // ---- predict to t_{k+1} (to t_k + dt_final after the last observation) -----------------------------------------
@@ -204,6 +274,12 @@ __global__ __launch_bounds__(64) void filter_lpe_l63_kernel(const RegArgs<R, 3, 
     cur = nxt;
   }
   ll.flush();
+  if (a.lpe_fast) {  // flags of the in-grid update: either factorisation (gain rows, log-likelihood row) failed; NaN is sticky
+    const R bf = bad ? R(1) : R(0);
+    if (lpe_bcast<0>(bf) + lpe_bcast<12>(bf) > R(0)) st |= kStatusNotPd;
+    const R m_last = lpe_bcast<3>(v);
+    if (m_last != m_last) st |= kStatusNan;
+  }
   if (live && l == 0) {
     a.ll[n] = (R)ll.ll;
     if (a.status) a.status[n] = st;
@@ -228,12 +304,17 @@ inline bool try_lpe(const RegArgs<R, D, M, Drift>& a, const cdkf_model* mdl, con
         o->state_order == CDKF_ORDER_ZEROTH || o->solver != CDKF_SOLVER_DOPRI5 || o->adaptive)
       return false;
     const dim3 grid(lpe_blocks<R>(a.N)), block(64);
+    RegArgs<R, D, M, Drift> b = a;
+    bool sym = true;
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < r; ++c) sym = sym && b.Rm[r][c] == b.Rm[c][r];
+    b.lpe_fast = (o->num_iter == 1 && sym) ? 1 : 0;
     if (all)
-      hipLaunchKernelGGL((filter_lpe_l63_kernel<R, 1>), grid, block, 0, stream, a);
+      hipLaunchKernelGGL((filter_lpe_l63_kernel<R, 1>), grid, block, 0, stream, b);
     else if (filt)
-      hipLaunchKernelGGL((filter_lpe_l63_kernel<R, 2>), grid, block, 0, stream, a);
+      hipLaunchKernelGGL((filter_lpe_l63_kernel<R, 2>), grid, block, 0, stream, b);
     else
-      hipLaunchKernelGGL((filter_lpe_l63_kernel<R, 0>), grid, block, 0, stream, a);
+      hipLaunchKernelGGL((filter_lpe_l63_kernel<R, 0>), grid, block, 0, stream, b);
     return true;
   } else {
     return false;
