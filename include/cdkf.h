@@ -161,7 +161,7 @@ int cdkf_preferred_layout(const cdkf_model* mdl);
  * wavefront for a batch of N on the current device -- 64 once N fills the chip, fewer (a power of two; the remaining
  * lanes repeat them) for small batches, so that a long interval of one trajectory delays fewer others.  Results do not
  * depend on it.  The environment variable CDKF_LANES_PER_WAVE (1 ... 64, power of two) overrides the choice.
- * (Lorenz-63 EKF batches of at most 8192 trajectories with H = I run on a third mapping, sixteen lanes per trajectory,
+ * (Lorenz-63 EKF batches of at most 4096 trajectories (16 per CU) with H = I run on a third mapping, sixteen lanes per trajectory,
  * which agrees with the others to rounding; CDKF_NO_LPE=1 disables it.) */
 int cdkf_trajectories_per_wavefront(int64_t N);
 

@@ -219,10 +219,10 @@ def test_results_do_not_depend_on_the_wavefront_grouping(hip_lib, N, T):
     for hyper in (cd.EKFHyperParams(), cd.UKFHyperParams()):
         big = cd.cdnlgssm_filter(P, y, t[..., None], hyperparams=hyper)
         small = cd.cdnlgssm_filter(P, y[sub], t[sub][..., None], hyperparams=hyper)
-        # the EKF sweep of this model switches to the sixteen-lanes-per-trajectory kernel below 8193 trajectories
+        # the EKF sweep of this model runs on the sixteen-lanes-per-trajectory kernel up to 4096 trajectories (16 per CU)
         # (cdkf_lpe_kernels.h: same update code, the predict sums in a different order): bitwise on one side of that
         # threshold, rounding-level across it
-        same_kernel = isinstance(hyper, cd.UKFHyperParams) or N <= 8192
+        same_kernel = isinstance(hyper, cd.UKFHyperParams) or N <= 4096
         for k in FILTER_KEYS + ["marginal_loglik"]:
             a, b = np.asarray(getattr(big, k))[sub], np.asarray(getattr(small, k))
             if same_kernel:
@@ -233,7 +233,7 @@ def test_results_do_not_depend_on_the_wavefront_grouping(hip_lib, N, T):
     small = cd.cdnlgssm_smoother(P, y[sub], t[sub][..., None])
     for k in ("smoothed_means", "smoothed_covariances", "filtered_means"):
         a, b = np.asarray(getattr(big, k))[sub], np.asarray(getattr(small, k))
-        if N <= 8192:  # the smoother's forward sweep follows the same kernel choice as the EKF filter above
+        if N <= 4096:  # the smoother's forward sweep follows the same kernel choice as the EKF filter above
             np.testing.assert_array_equal(a, b, err_msg=k)
         else:
             np.testing.assert_allclose(a, b, rtol=1e-10, atol=1e-12, err_msg=k)
