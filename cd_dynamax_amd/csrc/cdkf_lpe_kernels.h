@@ -50,31 +50,28 @@ CDKF_DEV R lpe_bcast(R v) { return lpe_dpp<0x150 + L>(v); }
 // Right-hand side of the moment ODEs for the entry this lane owns (see the header comment for the grid).
 template <typename R>
 struct LpeRhs {
-  // Jacobian slots relative to the lane's row i and column j: F_{q,(q+1)%4} = c1 + gx1 x, F_{q,(q+2)%4} = gy2 y,
-  // F_{q,(q+3)%4} = c3 + gz3 z + gx3 x (row / column 3 of the grid is not part of P: all zero)
+  // Slots relative to the lane's row i and column j: F_{q,(q+1)%4} = c1 + gx1 x, F_{q,(q+2)%4} = gy2 y,
+  // F_{q,(q+3)%4} = c3 + gz3 z + gx3 x (row / column 3 of the grid is not part of P: all zero).  The mean lanes (column 3)
+  // ride on the SAME instructions: the drift is f(m) = M(m) m with M = [[-s, s, 0], [rho, -1, -x], [0, x, -b]], which differs
+  // from the Jacobian F only in the (1,0) and (2,0) entries, so a mean lane carries M's constants in its row slots and zeros in
+  // its column slots and its slope is the row dot product alone.
   R c1i, gx1i, gy2i, c3i, gz3i, gx3i, c1j, gx1j, gy2j, c3j, gz3j, gx3j;
-  R g0, q;                  // F_ii + F_jj and (L Qc L^T)_ij for the covariance lanes, 0 elsewhere
-  R ax, ay, az, axz, axy;   // drift of the mean lanes: f_i = (ax + axz z + axy y) x + ay y + az z, 0 elsewhere
+  R g0, q;  // diagonal slot(s): F_ii + F_jj (covariance lanes) / M_ii (mean lanes); (L Qc L^T)_ij for the covariance lanes
   CDKF_DEV void init(int i, int j, R sigma, R rho, R beta, const R* LQL) {
-    auto slot = [&](int r, R& c1, R& gx1, R& gy2, R& c3, R& gz3, R& gx3) {
+    auto slot = [&](int r, bool jac, R& c1, R& gx1, R& gy2, R& c3, R& gz3, R& gx3) {
       c1 = (r == 0) ? sigma : R(0);
       gx1 = (r == 1) ? R(-1) : R(0);
-      gy2 = (r == 2) ? R(1) : R(0);
+      gy2 = (r == 2 && jac) ? R(1) : R(0);  // F_20 = y, M_20 = 0
       c3 = (r == 1) ? rho : R(0);
-      gz3 = (r == 1) ? R(-1) : R(0);
+      gz3 = (r == 1 && jac) ? R(-1) : R(0);  // F_10 = rho - z, M_10 = rho
       gx3 = (r == 2) ? R(1) : R(0);
     };
     const bool cov = i < 3 && j < 3, mean = i < 3 && j == 3;
-    slot(cov ? i : 3, c1i, gx1i, gy2i, c3i, gz3i, gx3i);
-    slot(cov ? j : 3, c1j, gx1j, gy2j, c3j, gz3j, gx3j);
+    slot((cov || mean) ? i : 3, cov, c1i, gx1i, gy2i, c3i, gz3i, gx3i);
+    slot(cov ? j : 3, true, c1j, gx1j, gy2j, c3j, gz3j, gx3j);
     const R diag[4] = {-sigma, R(-1), -beta, R(0)};
-    g0 = cov ? diag[i] + diag[j] : R(0);
+    g0 = cov ? diag[i] + diag[j] : (mean ? diag[i] : R(0));
     q = cov ? LQL[sidx<3>(i, j)] : R(0);
-    ax = mean ? (i == 0 ? -sigma : (i == 1 ? rho : R(0))) : R(0);
-    ay = mean ? (i == 0 ? sigma : (i == 1 ? R(-1) : R(0))) : R(0);
-    az = (mean && i == 2) ? -beta : R(0);
-    axz = (mean && i == 1) ? R(-1) : R(0);
-    axy = (mean && i == 2) ? R(1) : R(0);
   }
   CDKF_DEV void operator()(const R (&s)[1], R (&k)[1]) const {
     const R v = s[0];
@@ -83,8 +80,7 @@ struct LpeRhs {
     const R r1 = lpe_dpp<0x39>(v), r2 = lpe_dpp<0x4E>(v), r3 = lpe_dpp<0x93>(v);                  // columns j+1, j+2, j+3
     const R fi1 = rfma(gx1i, x, c1i), fi2 = gy2i * y, fi3 = rfma(gz3i, z, rfma(gx3i, x, c3i));
     const R fj1 = rfma(gx1j, x, c1j), fj2 = gy2j * y, fj3 = rfma(gz3j, z, rfma(gx3j, x, c3j));
-    const R dm = rfma(rfma(axy, y, rfma(axz, z, ax)), x, rfma(ay, y, az * z));
-    R acc = rfma(g0, v, q + dm);
+    R acc = rfma(g0, v, q);
     acc = rfma(fi1, d1, acc);
     acc = rfma(fi2, d2, acc);
     acc = rfma(fi3, d3, acc);
