@@ -187,21 +187,26 @@ __global__ __launch_bounds__(64) void filter_lpe_l63_kernel(const RegArgs<R, 3, 
   const int own = cov ? D + sidx<D>(i, j) : (mean ? i : -1);
   R v = cov ? a.P0[sidx<D>(i, j)] : (mean ? a.m0[i] : R(0));
 
-  // input stream of the row-3 lanes: (3, j < 3) reads y_j, (3, 3) reads t one step further ahead; the other lanes re-read t_0
+  // Input stream of the row-3 lanes: (3, j < 3) reads y_j, (3, 3) reads t one row further on (t_{k+1} for step k); the other
+  // lanes re-read t_0.  TWO buffers in static registers (the time loop is unrolled by two): a buffer is consumed by the
+  // update at the start of its step and reloaded right after it for the step after next, ~1.6 steps (~1.6 us) before it is
+  // read again -- a single buffer loaded one step ahead left the load latency partly exposed once a step took ~1 us.
   const R* __restrict__ tp0 = a.t + n * a.t_sn;
-  const R* ldp = tp0;
-  long ld_stride = 0, ld_ahead = a.T;  // advance while k + ld_ahead < T
+  const R* ldbase = tp0;
+  long ld_stride = 0, ld_off = 0;
   if (i == 3 && j < 3) {
-    ldp = a.y + n * a.y_sn + j * a.y_si;
+    ldbase = a.y + n * a.y_sn + j * a.y_si;
     ld_stride = a.y_sk;
-    ld_ahead = 1;
   } else if (l == 15) {
     ld_stride = a.t_sk;
-    ld_ahead = 2;
-    if (a.T > 1) ldp += a.t_sk;
+    ld_off = 1;
   }
+  const long last = a.T - 1;
+  const R* pA = ldbase + (ld_off < last ? ld_off : last) * ld_stride;
+  const R* pB = ldbase + (ld_off + 1 < last ? ld_off + 1 : last) * ld_stride;
+  const long ld_stride2 = 2 * ld_stride;
   R tcur = tp0[0];
-  R cur = ldp[0];  // y_0 / t_1
+  R bufA = pA[0], bufB = pB[0];
   // output pointers of this lane (filtered and predicted arrays share the geometry).  The row-3 lanes own no moment; so that
   // the stores stay unconditional (exact vmcnt accounting: behind a branch the compiler drains every store before the next
   // step's load, ~600 cycles per step) they write their zero to ll[n], which lane 0 overwrites after the sweep.
@@ -224,39 +229,38 @@ __global__ __launch_bounds__(64) void filter_lpe_l63_kernel(const RegArgs<R, 3, 
   int st = 0;
   bool bad = false;  // a non-positive pivot in this row's factorisations (lpe_update)
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see cdkf_filter_reg_body.inc
-  for (long k = 0; k < a.T; ++k) {
-    if (k + ld_ahead < a.T) ldp += ld_stride;
-    const R nxt = ldp[0];  // y_{k+1} / t_{k+2}, a whole step ahead
-
+  auto step = [&](const long k, R& cur, const R*& ldp) {
     const R tnext_obs = lpe_bcast<15>(cur);
     if (a.lpe_fast) {
       lpe_update(a, v, cur, i, j, ll, bad);
     } else {
-    // ---- measurement update, redundantly in every lane of the row, on the gathered moments (iterated updates, an
-    // emission covariance that is not exactly symmetric) ---------------------------------------------------------------
-    R ys[NS], yobs[D];
-    ys[0] = lpe_bcast<3>(v);
-    ys[1] = lpe_bcast<7>(v);
-    ys[2] = lpe_bcast<11>(v);
-    ys[3] = lpe_bcast<0>(v);
-    ys[4] = lpe_bcast<1>(v);
-    ys[5] = lpe_bcast<2>(v);
-    ys[6] = lpe_bcast<5>(v);
-    ys[7] = lpe_bcast<6>(v);
-    ys[8] = lpe_bcast<10>(v);
-    yobs[0] = lpe_bcast<12>(cur);
-    yobs[1] = lpe_bcast<13>(cur);
-    yobs[2] = lpe_bcast<14>(cur);
-    ekf_update<R, D, D, true>(a, ys, yobs, ll, st);
-    if (ys[0] != ys[0]) st |= kStatusNan;
-    R upd = R(0);
+      // measurement update, redundantly in every lane of the row, on the gathered moments (iterated updates, an emission
+      // covariance that is not exactly symmetric)
+      R ys[NS], yobs[D];
+      ys[0] = lpe_bcast<3>(v);
+      ys[1] = lpe_bcast<7>(v);
+      ys[2] = lpe_bcast<11>(v);
+      ys[3] = lpe_bcast<0>(v);
+      ys[4] = lpe_bcast<1>(v);
+      ys[5] = lpe_bcast<2>(v);
+      ys[6] = lpe_bcast<5>(v);
+      ys[7] = lpe_bcast<6>(v);
+      ys[8] = lpe_bcast<10>(v);
+      yobs[0] = lpe_bcast<12>(cur);
+      yobs[1] = lpe_bcast<13>(cur);
+      yobs[2] = lpe_bcast<14>(cur);
+      ekf_update<R, D, D, true>(a, ys, yobs, ll, st);
+      if (ys[0] != ys[0]) st |= kStatusNan;
+      R upd = R(0);
 #pragma unroll
-    for (int e = 0; e < NS; ++e) upd = (own == e) ? ys[e] : upd;
-    v = upd;
+      for (int e = 0; e < NS; ++e) upd = (own == e) ? ys[e] : upd;
+      v = upd;
     }
+    if (k + 2 + ld_off < a.T) ldp += ld_stride2;
+    cur = ldp[0];  // this buffer's next row: y_{k+2} / t_{k+3}
     if constexpr (OUT) *fout = v;
 
-    // ---- predict to t_{k+1} (to t_k + dt_final after the last observation) -----------------------------------------
+    // predict to t_{k+1} (to t_k + dt_final after the last observation)
     const R t1 = (k + 1 < a.T) ? tnext_obs : tcur + a.dt_final;
     R y1[1] = {v};
     if (integrate<R, 1>(y1, tcur, t1, a.dt0, a.max_steps, rhs, C)) st |= kStatusMaxSteps;
@@ -267,8 +271,13 @@ __global__ __launch_bounds__(64) void filter_lpe_l63_kernel(const RegArgs<R, 3, 
     }
     if constexpr (OUT) fout += out_stride;
     tcur = tnext_obs;
-    cur = nxt;
+  };
+  long k = 0;
+  for (; k + 1 < a.T; k += 2) {  // straight-line pair of steps: the vmcnt accounting stays exact (no branch between the loads)
+    step(k, bufA, pA);
+    step(k + 1, bufB, pB);
   }
+  if (k < a.T) step(k, bufA, pA);
   ll.flush();
   if (a.lpe_fast) {  // flags of the in-grid update: either factorisation (gain rows, log-likelihood row) failed; NaN is sticky
     const R bf = bad ? R(1) : R(0);
