@@ -119,6 +119,31 @@ def test_options_num_iter_zeroth_order_subsets(hip_lib):
     _check_filter(cd.cdnlgssm_filter(P, y, t[..., None], cd.UKFHyperParams(alpha=1.2, beta=1.5, kappa=0.5)), ref, 1e-8)
 
 
+def test_sixteen_lane_kernel_paths(hip_lib):
+    """Small Lorenz-63 batches with H = I run on filter_lpe_l63_kernel (cdkf_lpe_kernels.h).  Its update has two forms:
+    inside the lane grid (num_iter = 1, symmetric R) and the per-lane fallback (iterated updates; an emission covariance
+    that is not exactly symmetric).  Both against the oracle, odd and even T (the time loop is unrolled by two), N not a
+    multiple of the four trajectories per wavefront, all three output modes."""
+    rng = np.random.default_rng(12)
+    mdl = o.lorenz63_model(3)
+    P = params_from(mdl)
+    for N, T in ((7, 31), (6, 30), (1, 2), (3, 1)):
+        t = o.irregular_times(rng, N, T, 0.008 * T)
+        y = o.simulate(mdl, t, rng)
+        _check_filter(cd.cdnlgssm_filter(P, y, t[..., None]), o.ekf_filter(mdl, t, y), 1e-9)
+        ref2 = o.ekf_filter(mdl, t, y, num_iter=2)
+        _check_filter(cd.cdnlgssm_filter(P, y, t[..., None], num_iter=2), ref2, 1e-9)
+        post = cd.cdnlgssm_filter(P, y, t[..., None], output_fields=[])                        # log-likelihood only
+        assert relerr(post.marginal_loglik, o.ekf_filter(mdl, t, y)["marginal_loglik"]) < 1e-9
+        sm = cd.cdnlgssm_smoother(P, y, t[..., None])                                           # filtered moments only
+        assert relerr(sm.smoothed_covariances, o.ekf_smoother(mdl, t, y)["smoothed_covariances"]) < 1e-9
+    Rn = np.eye(3) + 0.05 * np.triu(np.ones((3, 3)), 1)                                         # not symmetric
+    skew = o.Model(mdl.drift, mdl.L, mdl.Qc, mdl.H, mdl.bias, Rn, mdl.m0, mdl.P0)
+    t = o.irregular_times(rng, 5, 20, 0.15)
+    y = o.simulate(mdl, t, rng)
+    _check_filter(cd.cdnlgssm_filter(params_from(skew), y, t[..., None]), o.ekf_filter(skew, t, y), 1e-9)
+
+
 def test_edge_cases_T1_N1_duplicates_long_gaps(hip_lib):
     rng = np.random.default_rng(6)
     mdl = o.lorenz63_model(3)
