@@ -65,7 +65,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-saturation", action="store_true", help="skip the extra N=65536 (HBM-bound regime) measurement")
+    ap.add_argument("--no-saturation", action="store_true", help="skip the extra N=131072 (HBM-bound regime) measurement")
     args = ap.parse_args()
 
     import torch
@@ -156,7 +156,7 @@ def main():
                        "trajectories_per_gpu": N, "num_timesteps": T, "parallelism": f"dp{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "filter_lpe_l63_kernel<double,OUT=all> (sixteen lanes per trajectory; the N=65536 line below runs filter_reg_kernel)",
+                         "kernel": "filter_lpe_l63_kernel<double,OUT=all> (sixteen lanes per trajectory; the N=131072 line below runs filter_reg_kernel)",
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_per_launch},
             "marginal_loglik_sum": total_ll, "status_flags_raised": n_bad,
         }
@@ -215,10 +215,10 @@ def value_and_grad(lib, blk, opts, N, T, t_d, y_d, ll, dev, torch, stream, reps=
             "trajectories_per_sec": N / (ms * 1e-3), "grad_sum": [float(v) for v in grad.sum(0).tolist()]}
 
 
-def saturated(lib, blk, opts, dev, torch, n=65536, reps=5):
-    """Same kernel, same per-trajectory workload, 16x the trajectories (1024 wavefronts = one per SIMD): the
-    regime where the sweep is bounded by HBM rather than by the T-long dependency chain of 64 wavefronts.
-    Reported beside the headline number, never instead of it."""
+def saturated(lib, blk, opts, dev, torch, n=131072, reps=5):
+    """Same per-trajectory workload, 32x the trajectories (lane-per-trajectory kernel, two wavefronts per SIMD; 29 GB
+    per sweep): the regime where the sweep is bounded by HBM rather than by the T-long dependency chain per wavefront
+    (scripts/n_sweep.py: 65 536: 4.9 TB/s, 131 072: 5.2 TB/s, 262 144: 4.8 TB/s).  Reported beside the headline number, never instead of it."""
     from cd_dynamax_amd import _ffi
     T = T_STEPS
     t_h, y_h = make_batch(99, 4096, T)
