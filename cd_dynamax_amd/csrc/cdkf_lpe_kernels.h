@@ -291,6 +291,151 @@ __global__ __launch_bounds__(64) void filter_lpe_l63_kernel(const RegArgs<R, 3, 
   }
 }
 
+// ---- EKF smoother backward sweep in the same grid (extended_kalman_smoother's reverse scan, inference_ekf.py:363-448) -----------
+// Per interval the right-hand side is LINEAR with coefficients that are constant over the interval (G = F(m_f) + psd_solve(P_f,
+// L Qc L^T)^T and f(m_f) are evaluated at the filtered moments): row i of the grid solves (P_f + 1e-9 I) x = (L Qc L^T)[:, i], which is
+// row i of psd_solve(...)^T, so G_i. is local to the row; the rows G_j. a covariance lane also needs come from a broadcast and a
+// masked sum.  The slots are then put into the rotated order of the DPP fetches once per interval, and a Runge-Kutta stage is 12
+// moves + 7 FMAs (the lane-per-trajectory sweep: ~88 instructions per stage).  Lanes below the diagonal re-adopt their transpose
+// partner every step (see lpe_update).  Inputs: the filtered moments the forward sweep just wrote; each lane loads its own entry.
+template <typename R>
+struct LpeLinRhs {
+  R g0, q, ci1, ci2, ci3, cj1, cj2, cj3;
+  CDKF_DEV void operator()(const R (&s)[1], R (&k)[1]) const {
+    const R v = s[0];
+    const R d1 = lpe_dpp<0x120 + 12>(v), d2 = lpe_dpp<0x120 + 8>(v), d3 = lpe_dpp<0x120 + 4>(v);
+    const R r1 = lpe_dpp<0x39>(v), r2 = lpe_dpp<0x4E>(v), r3 = lpe_dpp<0x93>(v);
+    R acc = rfma(g0, v, q);
+    acc = rfma(ci1, d1, acc);
+    acc = rfma(ci2, d2, acc);
+    acc = rfma(ci3, d3, acc);
+    acc = rfma(cj1, r1, acc);
+    acc = rfma(cj2, r2, acc);
+    acc = rfma(cj3, r3, acc);
+    k[0] = acc;
+  }
+};
+
+template <typename R>
+__global__ __launch_bounds__(64) void smoother_lpe_l63_kernel(const RegArgs<R, 3, 3, DriftLorenz63<R, 3>> a, R* __restrict__ sm,
+                                                              R* __restrict__ sP) {
+  constexpr int D = 3;
+  const int lane = threadIdx.x, l = lane & 15, i = l >> 2, j = l & 3;
+  constexpr int sh = lpe_xcd_shift<R>();
+  const long b = blockIdx.x;
+  const long grp = ((b >> (3 + sh)) << (3 + sh)) + ((b & 7) << sh) + ((b >> 3) & ((1 << sh) - 1));
+  if (grp * 4 >= a.N) return;
+  const long n_raw = grp * 4 + (lane >> 4);
+  const bool live = n_raw < a.N;
+  const long n = live ? n_raw : a.N - 1;
+  const bool cov = i < 3 && j < 3, mean = i < 3 && j == 3;
+  const auto C = TabSel<R, false>::get(a);
+  const R sigma = a.drift.sigma, rho = a.drift.rho, beta = a.drift.beta;
+
+  // per-lane constants: row / column indicator masks (negated: the right-hand side is -(...)), Jacobian row i in absolute columns
+  // F_i0 = a0 + bz0 z + by0 y, F_i1 = a1 + bx1 x, F_i2 = a2 + bx2 x, this row's right-hand side of psd_solve, L Qc L^T entry
+  const R e0 = (i == 0) ? R(-1) : R(0), e1 = (i == 1) ? R(-1) : R(0), e2 = (i == 2) ? R(-1) : R(0);
+  const R f0 = (cov && j == 0) ? R(1) : R(0), f1 = (cov && j == 1) ? R(1) : R(0), f2 = (cov && j == 2) ? R(1) : R(0);
+  const R a0 = (i == 0) ? -sigma : ((i == 1) ? rho : R(0)), bz0 = (i == 1) ? R(-1) : R(0), by0 = (i == 2) ? R(1) : R(0);
+  const R a1 = (i == 0) ? sigma : ((i == 1) ? R(-1) : R(0)), bx1 = (i == 2) ? R(1) : R(0);
+  const R a2 = (i == 2) ? -beta : R(0), bx2 = (i == 1) ? R(-1) : R(0);
+  R bq[D];
+#pragma unroll
+  for (int c = 0; c < D; ++c) bq[c] = (i < 3) ? a.LQL[sidx<D>(c, i < 3 ? i : 0)] : R(0);
+  const R qc = cov ? a.LQL[sidx<D>(i, j < 3 ? j : 0)] : R(0);
+  const R mmask = mean ? R(1) : R(0);
+
+  // this lane's entry of the filtered moments (input) and of the smoothed moments (output).  The row-3 lanes own no moment:
+  // lane 15 streams t in; on the output side all four mirror the row above them (same address, same value), which keeps the
+  // stores unconditional without a scratch target
+  const int io = (i == 3) ? 2 : i;
+  const R* in = (j == 3) ? a.fm + n * a.m_sn + io * a.m_si : a.fP + n * a.P_sn + (io * D + j) * a.P_si;
+  R* out = (j == 3) ? sm + n * a.m_sn + io * a.m_si : sP + n * a.P_sn + (io * D + j) * a.P_si;
+  const long out_stride = (j == 3) ? a.m_sk : a.P_sk;
+  long in_stride = out_stride;
+  if (l == 15) {
+    in = a.t + n * a.t_sn;
+    in_stride = a.t_sk;
+  }
+  const long last = a.T - 1;
+  R v = in[last * in_stride];  // smoothed = filtered at the last time (lane 15: t_{T-1})
+  R t1 = lpe_bcast<15>(v);
+  if (i == 3) v = R(0);
+  {
+    const R up = lpe_dpp<0x120 + 4>(v);  // row (i + 3) % 4: for the row-3 lanes the row above
+    out[last * out_stride] = (i == 3) ? up : v;
+  }
+  const long rowA = last - 1 > 0 ? last - 1 : 0, rowB = last - 2 > 0 ? last - 2 : 0;
+  const R* pA = in + rowA * in_stride;
+  const R* pB = in + rowB * in_stride;
+  R bufA = pA[0], bufB = pB[0];
+  const long stride2 = 2 * in_stride;
+  R* op = out + (last - 1) * out_stride;
+  int st = 0;
+  bool bad = false;
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  auto step = [&](const long k, R& fb, const R*& ldp) {
+    const R t0 = lpe_bcast<15>(fb);
+    const R mx = lpe_bcast<3>(fb), my = lpe_bcast<7>(fb), mz = lpe_bcast<11>(fb);
+    const R Pg[6] = {lpe_bcast<0>(fb), lpe_bcast<1>(fb), lpe_bcast<2>(fb), lpe_bcast<5>(fb), lpe_bcast<6>(fb), lpe_bcast<10>(fb)};
+    if (k - 2 >= 0) ldp -= stride2;
+    fb = ldp[0];  // this buffer's next row (k - 2), ~1.6 steps before it is read
+    R A[D][D], L[D][D], inv[D];
+#pragma unroll
+    for (int r = 0; r < D; ++r)
+#pragma unroll
+      for (int c = 0; c <= r; ++c) A[r][c] = (r == c) ? Pg[sidx<D>(r, c)] + R(1e-9) : Pg[sidx<D>(r, c)];
+    chol_lower<R, D>(A, L, inv, bad);
+    const R w0 = bq[0] * inv[0];
+    const R w1 = rfma(-L[1][0], w0, bq[1]) * inv[1];
+    const R w2 = rfma(-L[2][1], w1, rfma(-L[2][0], w0, bq[2])) * inv[2];
+    R x[D];
+    x[2] = w2 * inv[2];
+    x[1] = rfma(-L[2][1], x[2], w1) * inv[1];
+    x[0] = rfma(-L[2][0], x[2], rfma(-L[1][0], x[1], w0)) * inv[0];
+    // G_i. = F_i.(m_f) + x
+    const R Gi0 = rfma(by0, my, rfma(bz0, mz, a0)) + x[0], Gi1 = rfma(bx1, mx, a1) + x[1], Gi2 = rfma(bx2, mx, a2) + x[2];
+    const R Gi[D] = {Gi0, Gi1, Gi2};
+    R Gj[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c)
+      Gj[c] = rfma(f2, lpe_bcast<8>(Gi[c]), rfma(f1, lpe_bcast<4>(Gi[c]), f0 * lpe_bcast<0>(Gi[c])));
+    LpeLinRhs<R> rhs;
+    // slots in the rotated order of the fetches, negated (e* are -1 on their row): -G_{i,(i+s)%4}, -G_{j,(j+s)%4}
+    rhs.ci1 = rfma(e1, Gi[2], e0 * Gi[1]);
+    rhs.ci2 = rfma(e2, Gi[0], e0 * Gi[2]);
+    rhs.ci3 = rfma(e2, Gi[1], e1 * Gi[0]);
+    rhs.cj1 = -rfma(f1, Gj[2], f0 * Gj[1]);
+    rhs.cj2 = -rfma(f2, Gj[0], f0 * Gj[2]);
+    rhs.cj3 = -rfma(f2, Gj[1], f1 * Gj[0]);
+    const R gii = rfma(e2, Gi[2], rfma(e1, Gi[1], e0 * Gi[0]));          // -G_ii
+    const R gjj = rfma(f2, Gj[2], rfma(f1, Gj[1], f0 * Gj[0]));          // +G_jj (covariance lanes), 0 elsewhere
+    rhs.g0 = gii - gjj;
+    // mean lanes: -(f_i(m_f) - sum_c G_ic m_f,c) = x . m_f - corr_i, corr = z x (row 1), -y x (row 2): f = M(m) m, M - F = corr
+    const R xm = rfma(x[2], mz, rfma(x[1], my, x[0] * mx));
+    const R corr = rfma(e1, mz, -(e2 * my)) * mx;  // e1 = -1 on row 1: -z x; e2 = -1 on row 2: +y x  => this is -corr_i
+    rhs.q = rfma(mmask, xm + corr, qc);
+    R y1[1] = {v};
+    if (integrate<R, 1>(y1, R(0), t1 - t0, a.dt0, a.max_steps, rhs, C)) st |= kStatusMaxSteps;
+    v = y1[0];
+    const R s3 = lpe_dpp<0x110 + 3>(v), s6 = lpe_dpp<0x110 + 6>(v);
+    v = ((i == 1 && j == 0) || (i == 2 && j == 1)) ? s3 : v;
+    v = (i == 2 && j == 0) ? s6 : v;
+    const R up = lpe_dpp<0x120 + 4>(v);
+    *op = (i == 3) ? up : v;
+    op -= out_stride;
+    t1 = t0;
+  };
+  long k = a.T - 2;
+  for (; k - 1 >= 0; k -= 2) {
+    step(k, bufA, pA);
+    step(k - 1, bufB, pB);
+  }
+  if (k >= 0) step(k, bufA, pA);
+  if (bad) st |= kStatusNotPd;
+  if (live && l == 0 && a.status && st) atomicOr(&a.status[n], st);
+}
+
 inline bool lpe_batch_is_small(int64_t N) {
   // 4 trajectories per wavefront: faster than the lane-per-trajectory sweep while every wavefront has a SIMD to itself
   // (MI355X: 1024 SIMDs -> 4096 trajectories: 1.19 against 1.78 ms; 5120: 1.90 against 1.79 ms)
@@ -330,6 +475,18 @@ inline bool try_lpe(const RegArgs<R, D, M, Drift>& a, const cdkf_model* mdl, con
   }
 }
 
+// backward sweep of the smoother on the same grid (launch_eks.hip, after the forward sweep)
+template <typename R, int D, int M, typename Drift>
+inline bool try_lpe_smoother(const RegArgs<R, D, M, Drift>& a, const cdkf_opts* o, R* sm, R* sP, hipStream_t stream) {
+  if constexpr (std::is_same<Drift, DriftLorenz63<R, 3>>::value && D == 3 && M == 3) {
+    static const bool off = [] { const char* e = std::getenv("CDKF_NO_LPE"); return e && e[0] == '1'; }();
+    if (off || !lpe_batch_is_small(a.N) || o->solver != CDKF_SOLVER_DOPRI5 || o->adaptive) return false;
+    hipLaunchKernelGGL((smoother_lpe_l63_kernel<R>), dim3(lpe_blocks<R>(a.N)), dim3(64), 0, stream, a, sm, sP);
+    return true;
+  } else {
+    return false;
+  }
+}
 #endif
 
 }  // namespace cdkf
