@@ -390,9 +390,14 @@ def test_baseline_config1_linear_tracking_front_end(hip_lib):
     ll = model.marginal_log_prob(params, y, t[:, None], cd.KFHyperParams(dt_final=1.0))
     assert abs(ll - post.marginal_loglik) < 1e-10 * abs(ll)
     sm = model.smoother(params, y, t[:, None], smoother_type="cd_smoother_2")
-    oref = o.ekf_smoother(mdl, t[None], y[None], state_order="first")
-    assert relerr(sm.smoothed_means, oref["smoothed_means"][0]) < 1e-9
-    assert relerr(sm.smoothed_covariances, oref["smoothed_covariances"][0]) < 1e-9
+    assert np.isfinite(sm.smoothed_covariances).all() and relerr(sm.smoothed_means[-1], post.filtered_means[-1]) < 1e-12
+    # the NumPy oracle needs 100 Dormand-Prince steps per interval and sweep: pinned on the first 60 observations (the CPU
+    # share of this test was 25 s, several minutes on a loaded GPU box)
+    W = 60
+    smw = model.smoother(params, y[:W], t[:W, None], smoother_type="cd_smoother_2")
+    oref = o.ekf_smoother(mdl, t[None, :W], y[None, :W], state_order="first")
+    assert relerr(smw.smoothed_means, oref["smoothed_means"][0]) < 1e-9
+    assert relerr(smw.smoothed_covariances, oref["smoothed_covariances"][0]) < 1e-9
     post32 = model.filter(params, y.astype(np.float32), filter_hyperparams=cd.KFHyperParams(dt_final=1.0))
     assert relerr(post32.filtered_means, ref["filtered_means"]) < 1e-4
 
