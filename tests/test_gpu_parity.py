@@ -137,6 +137,17 @@ def test_sixteen_lane_kernel_paths(hip_lib):
         assert relerr(post.marginal_loglik, o.ekf_filter(mdl, t, y)["marginal_loglik"]) < 1e-9
         sm = cd.cdnlgssm_smoother(P, y, t[..., None])                                           # filtered moments only
         assert relerr(sm.smoothed_covariances, o.ekf_smoother(mdl, t, y)["smoothed_covariances"]) < 1e-9
+    # long gaps (up to ~12 Dormand-Prince steps per interval, different per trajectory), a non-default step, fp32, shared grid
+    t = o.irregular_times(rng, 9, 25, 1.5)
+    y = o.simulate(mdl, t, rng)
+    hyp = cd.EKFHyperParams(diffeqsolve_settings={"dt0": 0.007})
+    _check_filter(cd.cdnlgssm_filter(P, y, t[..., None], hyp), o.ekf_filter(mdl, t, y, dt0=0.007), 1e-9)
+    _check_filter(cd.cdnlgssm_filter(P, y.astype(np.float32), t[..., None]), o.ekf_filter(mdl, t, y), 3e-5)
+    ts = np.broadcast_to(t[0], t.shape)
+    _check_filter(cd.cdnlgssm_filter(P, y, t[0][:, None]), o.ekf_filter(mdl, ts, y), 1e-9)
+    sm = cd.cdnlgssm_smoother(P, y, t[..., None], hyp)
+    ref = o.ekf_smoother(mdl, t, y, dt0=0.007)
+    assert relerr(sm.smoothed_means, ref["smoothed_means"]) < 1e-9 and relerr(sm.smoothed_covariances, ref["smoothed_covariances"]) < 1e-9
     Rn = np.eye(3) + 0.05 * np.triu(np.ones((3, 3)), 1)                                         # not symmetric
     skew = o.Model(mdl.drift, mdl.L, mdl.Qc, mdl.H, mdl.bias, Rn, mdl.m0, mdl.P0)
     t = o.irregular_times(rng, 5, 20, 0.15)
