@@ -18,8 +18,9 @@
 //   pointers) instead of twelve; the row-3 lanes stream the observations and times in, one load per step.
 //
 // Per observation step ~600 issue slots instead of ~830 (+ 24 stores at ~19 cycles): 4096 x 1000, fp64: 1.77 -> see DESIGN.md.
-// Scope: drift Lorenz-63, emission = the three state coordinates (H = I, no bias), num_iter 1, state_order first / second
-// (identical for this drift), fixed-step Dormand-Prince, all four outputs or none.  Everything else runs on filter_reg_kernel.
+// Scope: drift Lorenz-63, emission H = I (update inside the lane grid; num_iter 1, symmetric R) or any linear emission with
+// m < 3 / iterated updates (per-lane update code), state_order first / second (identical for this drift), fixed-step
+// Dormand-Prince, outputs: all four, none, or the filtered pair.  Everything else runs on filter_reg_kernel.
 #pragma once
 #ifndef __HIPCC_RTC__
 #include <cstdlib>
@@ -166,8 +167,10 @@ inline unsigned lpe_blocks(int64_t N) {
 }
 
 // OUT: 0 log-likelihood only, 1 all four moment arrays, 2 filtered moments only (the smoother's forward sweep)
-template <typename R, int OUT>
-__global__ __launch_bounds__(64) void filter_lpe_l63_kernel(const RegArgs<R, 3, 3, DriftLorenz63<R, 3>> a) {
+// M: emission dimension (1..3).  M == 3 is launched for H = I (HSEL update code, in-grid update when a.lpe_fast); M < 3 takes any
+// linear emission through the per-lane update.
+template <typename R, int M, int OUT>
+__global__ __launch_bounds__(64) void filter_lpe_l63_kernel(const RegArgs<R, 3, M, DriftLorenz63<R, 3>> a) {
   constexpr int D = 3, NS = Dims<D>::NS;
   const int lane = threadIdx.x, l = lane & 15, i = l >> 2, j = l & 3;
   constexpr int sh = lpe_xcd_shift<R>();
@@ -194,7 +197,7 @@ __global__ __launch_bounds__(64) void filter_lpe_l63_kernel(const RegArgs<R, 3, 
   const R* __restrict__ tp0 = a.t + n * a.t_sn;
   const R* ldbase = tp0;
   long ld_stride = 0, ld_off = 0;
-  if (i == 3 && j < 3) {
+  if (i == 3 && j < M) {
     ldbase = a.y + n * a.y_sn + j * a.y_si;
     ld_stride = a.y_sk;
   } else if (l == 15) {
@@ -231,12 +234,17 @@ __global__ __launch_bounds__(64) void filter_lpe_l63_kernel(const RegArgs<R, 3, 
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see cdkf_filter_reg_body.inc
   auto step = [&](const long k, R& cur, const R*& ldp) {
     const R tnext_obs = lpe_bcast<15>(cur);
-    if (a.lpe_fast) {
-      lpe_update(a, v, cur, i, j, ll, bad);
-    } else {
+    bool in_grid = false;
+    if constexpr (M == 3) {
+      if (a.lpe_fast) {
+        lpe_update(a, v, cur, i, j, ll, bad);
+        in_grid = true;
+      }
+    }
+    if (!in_grid) {
       // measurement update, redundantly in every lane of the row, on the gathered moments (iterated updates, an emission
       // covariance that is not exactly symmetric)
-      R ys[NS], yobs[D];
+      R ys[NS], yobs[M];
       ys[0] = lpe_bcast<3>(v);
       ys[1] = lpe_bcast<7>(v);
       ys[2] = lpe_bcast<11>(v);
@@ -247,9 +255,9 @@ __global__ __launch_bounds__(64) void filter_lpe_l63_kernel(const RegArgs<R, 3, 
       ys[7] = lpe_bcast<6>(v);
       ys[8] = lpe_bcast<10>(v);
       yobs[0] = lpe_bcast<12>(cur);
-      yobs[1] = lpe_bcast<13>(cur);
-      yobs[2] = lpe_bcast<14>(cur);
-      ekf_update<R, D, D, true>(a, ys, yobs, ll, st);
+      if constexpr (M > 1) yobs[1] = lpe_bcast<13>(cur);
+      if constexpr (M > 2) yobs[2] = lpe_bcast<14>(cur);
+      ekf_update<R, D, M, (M == 3)>(a, ys, yobs, ll, st);
       if (ys[0] != ys[0]) st |= kStatusNan;
       R upd = R(0);
 #pragma unroll
@@ -316,8 +324,8 @@ struct LpeLinRhs {
   }
 };
 
-template <typename R>
-__global__ __launch_bounds__(64) void smoother_lpe_l63_kernel(const RegArgs<R, 3, 3, DriftLorenz63<R, 3>> a, R* __restrict__ sm,
+template <typename R, int M>
+__global__ __launch_bounds__(64) void smoother_lpe_l63_kernel(const RegArgs<R, 3, M, DriftLorenz63<R, 3>> a, R* __restrict__ sm,
                                                               R* __restrict__ sP) {
   constexpr int D = 3;
   const int lane = threadIdx.x, l = lane & 15, i = l >> 2, j = l & 3;
@@ -450,25 +458,25 @@ inline bool lpe_batch_is_small(int64_t N) {
 // lane-per-trajectory kernel (A/B timing, tests of the latter at small N).
 template <typename R, int D, int M, typename Drift>
 inline bool try_lpe(const RegArgs<R, D, M, Drift>& a, const cdkf_model* mdl, const cdkf_opts* o, hipStream_t stream) {
-  if constexpr (std::is_same<Drift, DriftLorenz63<R, 3>>::value && D == 3 && M == 3) {
+  if constexpr (std::is_same<Drift, DriftLorenz63<R, 3>>::value && D == 3 && M <= 3) {
     static const bool off = [] { const char* e = std::getenv("CDKF_NO_LPE"); return e && e[0] == '1'; }();
     const bool all = a.fm && a.fP && a.pm && a.pP, none = !a.fm && !a.fP && !a.pm && !a.pP;
     const bool filt = a.fm && a.fP && !a.pm && !a.pP;
-    if (off || !lpe_batch_is_small(a.N) || !(all || none || filt) || !emission_is_selection(mdl) || o->forecast ||
+    if (off || !lpe_batch_is_small(a.N) || !(all || none || filt) || (M == 3 && !emission_is_selection(mdl)) || o->forecast ||
         o->state_order == CDKF_ORDER_ZEROTH || o->solver != CDKF_SOLVER_DOPRI5 || o->adaptive)
       return false;
     const dim3 grid(lpe_blocks<R>(a.N)), block(64);
     RegArgs<R, D, M, Drift> b = a;
     bool sym = true;
-    for (int r = 0; r < 3; ++r)
+    for (int r = 0; r < M; ++r)
       for (int c = 0; c < r; ++c) sym = sym && b.Rm[r][c] == b.Rm[c][r];
-    b.lpe_fast = (o->num_iter == 1 && sym) ? 1 : 0;
+    b.lpe_fast = (M == 3 && o->num_iter == 1 && sym) ? 1 : 0;
     if (all)
-      hipLaunchKernelGGL((filter_lpe_l63_kernel<R, 1>), grid, block, 0, stream, b);
+      hipLaunchKernelGGL((filter_lpe_l63_kernel<R, M, 1>), grid, block, 0, stream, b);
     else if (filt)
-      hipLaunchKernelGGL((filter_lpe_l63_kernel<R, 2>), grid, block, 0, stream, b);
+      hipLaunchKernelGGL((filter_lpe_l63_kernel<R, M, 2>), grid, block, 0, stream, b);
     else
-      hipLaunchKernelGGL((filter_lpe_l63_kernel<R, 0>), grid, block, 0, stream, b);
+      hipLaunchKernelGGL((filter_lpe_l63_kernel<R, M, 0>), grid, block, 0, stream, b);
     return true;
   } else {
     return false;
@@ -478,10 +486,10 @@ inline bool try_lpe(const RegArgs<R, D, M, Drift>& a, const cdkf_model* mdl, con
 // backward sweep of the smoother on the same grid (launch_eks.hip, after the forward sweep)
 template <typename R, int D, int M, typename Drift>
 inline bool try_lpe_smoother(const RegArgs<R, D, M, Drift>& a, const cdkf_opts* o, R* sm, R* sP, hipStream_t stream) {
-  if constexpr (std::is_same<Drift, DriftLorenz63<R, 3>>::value && D == 3 && M == 3) {
+  if constexpr (std::is_same<Drift, DriftLorenz63<R, 3>>::value && D == 3 && M <= 3) {
     static const bool off = [] { const char* e = std::getenv("CDKF_NO_LPE"); return e && e[0] == '1'; }();
     if (off || !lpe_batch_is_small(a.N) || o->solver != CDKF_SOLVER_DOPRI5 || o->adaptive) return false;
-    hipLaunchKernelGGL((smoother_lpe_l63_kernel<R>), dim3(lpe_blocks<R>(a.N)), dim3(64), 0, stream, a, sm, sP);
+    hipLaunchKernelGGL((smoother_lpe_l63_kernel<R, M>), dim3(lpe_blocks<R>(a.N)), dim3(64), 0, stream, a, sm, sP);
     return true;
   } else {
     return false;
