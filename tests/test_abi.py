@@ -95,3 +95,13 @@ def test_no_gpu_means_loud_failure(hip_lib):
     with pytest.raises(_ffi.CdkfError) as ei:
         cd.cdnlgssm_filter(params_from(orc.lorenz63_model(3)), np.zeros((5, 3)), np.arange(5.0)[:, None])
     assert ei.value.code == _ffi.CDKF_EHIP
+
+
+def test_graft_entry_build_passes(hip_lib):
+    """The driver's build check: __graft_entry__.build() (make is a no-op once the library is built) must succeed, including
+    its own consistency checks (exported symbols, library version == header version)."""
+    import importlib
+    import sys
+    sys.path.insert(0, ROOT)
+    entry = importlib.import_module("__graft_entry__")
+    entry.build()
