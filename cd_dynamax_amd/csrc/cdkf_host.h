@@ -209,7 +209,6 @@ void fill_reg_args(RegArgs<R, D, M, Drift>& a, const cdkf_model* mdl, const cdkf
     a.lanes = g.lanes;
     a.xcd_shift = g.xcd_shift;
   }
-  a.lpe_fast = 0;
   fill_rk_tab<R>(o, a.rk);  // opts.solver / adaptive were validated by check_common
   a.N = N;
   a.T = T;

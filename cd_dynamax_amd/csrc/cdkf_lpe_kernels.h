@@ -48,105 +48,212 @@ CDKF_DEV float lpe_dpp(float v) {
 template <int L, typename R>
 CDKF_DEV R lpe_bcast(R v) { return lpe_dpp<0x150 + L>(v); }
 
+// the same move that leaves the lanes of the banks (= grid rows) outside BANKS with `keep` instead of the fetched value
+template <int CTRL, int BANKS>
+CDKF_DEV double lpe_dpp_keep(double keep, double v) {
+  const long long r = __builtin_amdgcn_update_dpp(__builtin_bit_cast(long long, keep), __builtin_bit_cast(long long, v), CTRL, 0xF,
+                                                  BANKS, false);
+  return __builtin_bit_cast(double, r);
+}
+template <int CTRL, int BANKS>
+CDKF_DEV float lpe_dpp_keep(float keep, float v) {
+  const int r = __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, keep), __builtin_bit_cast(int, v), CTRL, 0xF, BANKS, false);
+  return __builtin_bit_cast(float, r);
+}
+
+// acc + (lane L of this row's value of src) * mult as ONE instruction: the row_newbcast operand of v_fmac_f64 (the compiler keeps
+// a separate v_mov_b64_dpp in front of the 64-bit multiply-add; 32-bit it folds the move by itself).  The statement is opaque to
+// the hazard recogniser: `src` must have been written at least two instructions earlier (VALU write -> DPP read, 2 wait states) --
+// every caller passes a `mult` that is itself computed from values fetched from `src`, which puts those instructions in between.
+template <int L>
+CDKF_DEV double lpe_fmac_bcast(double acc, double src, double mult) {
+  asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mult), "n"(L));
+  return acc;
+}
+template <int L>
+CDKF_DEV float lpe_fmac_bcast(float acc, float src, float mult) { return rfma(lpe_bcast<L>(src), mult, acc); }
+
 // Right-hand side of the moment ODEs for the entry this lane owns (see the header comment for the grid).
+//
+// d P_ij = sum_k F_ik P_kj + sum_k P_ik F_jk + (L Qc L^T)_ij.  The row side fetches the entries of the lane's COLUMN from the rows
+// i+1, i+2, i+3 (mod 4; row_ror), the column side the entries of the lane's ROW from the columns (j+1) % 3, (j+2) % 3 -- a quad
+// permutation may be any map, so the rotation runs over the three covariance columns only: two fetches instead of three.  The
+// Jacobian entries are affine in the mean with per-lane constants; the sum is grouped by mean component,
+//      k = [g0 v + q + c1i d1 + c3i d3 + cAj r1 + cBj r2] + x [gx1i d1 + gx3i d3 + gxAj r1 + gxBj r2] + y [gy2i d2 + gyAj r1]
+//          + z [gz3i d3 + gzBj r2],
+// so that x, y, z enter as the row_newbcast operand of one accumulating instruction each (no separate broadcast moves):
+// 16 fp64 instructions + 10 32-bit moves per stage (was 15 + 3 + 12).
+// The mean lanes (column 3) ride on the SAME instructions: the drift is f(m) = M(m) m with M = [[-s, s, 0], [rho, -1, -x],
+// [0, x, -b]], which differs from the Jacobian F only in the (1,0) and (2,0) entries, so a mean lane carries M's constants in its
+// row slots and zeros in its column slots and its slope is the row dot product alone.
 template <typename R>
 struct LpeRhs {
-  // Slots relative to the lane's row i and column j: F_{q,(q+1)%4} = c1 + gx1 x, F_{q,(q+2)%4} = gy2 y,
-  // F_{q,(q+3)%4} = c3 + gz3 z + gx3 x (row / column 3 of the grid is not part of P: all zero).  The mean lanes (column 3)
-  // ride on the SAME instructions: the drift is f(m) = M(m) m with M = [[-s, s, 0], [rho, -1, -x], [0, x, -b]], which differs
-  // from the Jacobian F only in the (1,0) and (2,0) entries, so a mean lane carries M's constants in its row slots and zeros in
-  // its column slots and its slope is the row dot product alone.
-  R c1i, gx1i, gy2i, c3i, gz3i, gx3i, c1j, gx1j, gy2j, c3j, gz3j, gx3j;
-  R g0, q;  // diagonal slot(s): F_ii + F_jj (covariance lanes) / M_ii (mean lanes); (L Qc L^T)_ij for the covariance lanes
+  R g0, q;                   // F_ii + F_jj (covariance lanes) / M_ii (mean lanes); (L Qc L^T)_ij
+  R c1i, c3i, cAj, cBj;      // constant parts: F_{i,i+1}, F_{i,i+3} (mod 4), F_{j,(j+1)%3}, F_{j,(j+2)%3}
+  R gx1i, gx3i, gxAj, gxBj;  // their coefficients of x
+  R gy2i, gyAj;              // of y (row slot i+2, column slot A)
+  R gz3i, gzBj;              // of z (row slot i+3, column slot B)
   CDKF_DEV void init(int i, int j, R sigma, R rho, R beta, const R* LQL) {
-    auto slot = [&](int r, bool jac, R& c1, R& gx1, R& gy2, R& c3, R& gz3, R& gx3) {
-      c1 = (r == 0) ? sigma : R(0);
-      gx1 = (r == 1) ? R(-1) : R(0);
-      gy2 = (r == 2 && jac) ? R(1) : R(0);  // F_20 = y, M_20 = 0
-      c3 = (r == 1) ? rho : R(0);
-      gz3 = (r == 1 && jac) ? R(-1) : R(0);  // F_10 = rho - z, M_10 = rho
-      gx3 = (r == 2) ? R(1) : R(0);
-    };
     const bool cov = i < 3 && j < 3, mean = i < 3 && j == 3;
-    slot((cov || mean) ? i : 3, cov, c1i, gx1i, gy2i, c3i, gz3i, gx3i);
-    slot(cov ? j : 3, true, c1j, gx1j, gy2j, c3j, gz3j, gx3j);
+    const int r = (cov || mean) ? i : 3, c = cov ? j : 3;
+    // row slots of row r: (r, r+1): F01 = s, F12 = -x; (r, r+2): F20 = y (M20 = 0); (r, r+3): F10 = rho - z (M10 = rho), F21 = x
+    c1i = (r == 0) ? sigma : R(0);
+    gx1i = (r == 1) ? R(-1) : R(0);
+    gy2i = (r == 2 && cov) ? R(1) : R(0);
+    c3i = (r == 1) ? rho : R(0);
+    gz3i = (r == 1 && cov) ? R(-1) : R(0);
+    gx3i = (r == 2) ? R(1) : R(0);
+    // column slots of column c: A = F_{c,(c+1)%3}: F01 = s, F12 = -x, F20 = y;  B = F_{c,(c+2)%3}: F02 = 0, F10 = rho - z, F21 = x
+    cAj = (c == 0) ? sigma : R(0);
+    gxAj = (c == 1) ? R(-1) : R(0);
+    gyAj = (c == 2) ? R(1) : R(0);
+    cBj = (c == 1) ? rho : R(0);
+    gzBj = (c == 1) ? R(-1) : R(0);
+    gxBj = (c == 2) ? R(1) : R(0);
     const R diag[4] = {-sigma, R(-1), -beta, R(0)};
     g0 = cov ? diag[i] + diag[j] : (mean ? diag[i] : R(0));
     q = cov ? LQL[sidx<3>(i, j)] : R(0);
   }
-  CDKF_DEV void operator()(const R (&s)[1], R (&k)[1]) const {
-    const R v = s[0];
-    const R x = lpe_bcast<3>(v), y = lpe_bcast<7>(v), z = lpe_bcast<11>(v);
+  CDKF_DEV R eval(const R v) const {
     const R d1 = lpe_dpp<0x120 + 12>(v), d2 = lpe_dpp<0x120 + 8>(v), d3 = lpe_dpp<0x120 + 4>(v);  // rows i+1, i+2, i+3
-    const R r1 = lpe_dpp<0x39>(v), r2 = lpe_dpp<0x4E>(v), r3 = lpe_dpp<0x93>(v);                  // columns j+1, j+2, j+3
-    const R fi1 = rfma(gx1i, x, c1i), fi2 = gy2i * y, fi3 = rfma(gz3i, z, rfma(gx3i, x, c3i));
-    const R fj1 = rfma(gx1j, x, c1j), fj2 = gy2j * y, fj3 = rfma(gz3j, z, rfma(gx3j, x, c3j));
+    const R r1 = lpe_dpp<0xC9>(v), r2 = lpe_dpp<0xD2>(v);  // quad_perm [1,2,0,3], [2,0,1,3]: columns (j+1) % 3, (j+2) % 3
     R acc = rfma(g0, v, q);
-    acc = rfma(fi1, d1, acc);
-    acc = rfma(fi2, d2, acc);
-    acc = rfma(fi3, d3, acc);
-    acc = rfma(fj1, r1, acc);
-    acc = rfma(fj2, r2, acc);
-    acc = rfma(fj3, r3, acc);
-    k[0] = acc;
+    acc = rfma(c1i, d1, acc);
+    acc = rfma(c3i, d3, acc);
+    acc = rfma(cAj, r1, acc);
+    acc = rfma(cBj, r2, acc);
+    const R X = rfma(gxBj, r2, rfma(gxAj, r1, rfma(gx3i, d3, gx1i * d1)));
+    const R Y = rfma(gyAj, r1, gy2i * d2);
+    const R Z = rfma(gzBj, r2, gz3i * d3);
+    acc = lpe_fmac_bcast<3>(acc, v, X);
+    acc = lpe_fmac_bcast<7>(acc, v, Y);
+    acc = lpe_fmac_bcast<11>(acc, v, Z);
+    return acc;
   }
+  CDKF_DEV void operator()(const R (&s)[1], R (&k)[1]) const { k[0] = eval(s[0]); }
 };
+
+// One Dormand-Prince step of the lane's entry.  fp64: slopes scaled by the step once (k_s = dt f_s: six products) and combined
+// with the tableau constants from registers -- 26 instructions beside the right-hand sides; dopri5_step's fp64 form (c_sj = dt a_sj
+// formed per step) is laid out for nine entries per lane and costs 40 for one.  fp32 keeps dopri5_step's association, which is the
+// reference's (`y0 + dt (a_lower[i] @ ks)`).
+template <typename R>
+CDKF_DEV void lpe_step(R& y, R dt, const LpeRhs<R>& rhs, const Dp5V<R>& C) {
+  if constexpr (sizeof(R) == 8) {
+    const R k1 = dt * rhs.eval(y);
+    const R k2 = dt * rhs.eval(rfma(C.a21, k1, y));
+    const R k3 = dt * rhs.eval(rfma(C.a32, k2, rfma(C.a31, k1, y)));
+    const R k4 = dt * rhs.eval(rfma(C.a43, k3, rfma(C.a42, k2, rfma(C.a41, k1, y))));
+    const R k5 = dt * rhs.eval(rfma(C.a54, k4, rfma(C.a53, k3, rfma(C.a52, k2, rfma(C.a51, k1, y)))));
+    const R k6 = dt * rhs.eval(rfma(C.a65, k5, rfma(C.a64, k4, rfma(C.a63, k3, rfma(C.a62, k2, rfma(C.a61, k1, y))))));
+    y = rfma(C.b6, k6, rfma(C.b5, k5, rfma(C.b4, k4, rfma(C.b3, k3, rfma(C.b1, k1, y)))));
+  } else {
+    R ys[1] = {y};
+    dopri5_step<R, 1>(ys, dt, rhs, C);
+    y = ys[0];
+  }
+}
+
+// diffrax's loop (see integrate in cdkf_math.h) around lpe_step; true when max_steps was hit
+template <typename R>
+CDKF_DEV bool lpe_integrate(R& y, R t0, R t1, R dt0, long max_steps, const LpeRhs<R>& rhs, const Dp5V<R>& C) {
+  R tprev = t0;
+  R tnext = rmin(t0 + dt0, t1);
+  long steps = 0;
+  bool capped = false;
+  while (tprev < t1) {
+    if (steps >= max_steps) {
+      capped = true;
+      break;
+    }
+    lpe_step<R>(y, tnext - tprev, rhs, C);
+    tprev = rmin(tnext, t1);
+    const R tn = tnext + dt0;
+    tnext = (tn > t1 - Tol<R>::v) ? t1 : tn;
+    ++steps;
+  }
+  return capped;
+}
+
+// 1 / sqrt(x) for the factorisations of the in-grid update: v_rsq_f64 and one third-order correction (the library routine's own
+// arithmetic without its special-casing of 0 and +inf; a non-positive pivot still gives NaN, which is what is wanted of it).
+CDKF_DEV double lpe_rsqrt(double x) {
+  const double y0 = __builtin_amdgcn_rsq(x);
+  const double e = rfma(-(x * y0), y0, 1.0);
+  return rfma(y0 * e, rfma(e, 0.375, 0.5), y0);
+}
+CDKF_DEV float lpe_rsqrt(float x) { return rrsqrt(x); }
 
 // Measurement update in the same grid (num_iter = 1, symmetric R): the four rows of a trajectory's grid factorise and solve
 // DIFFERENT systems with ONE instruction stream -- rows i < 3: psd_solve's S + 1e-9 I against column i of H P = P (which,
 // P being symmetric, is the row's own three covariance lanes: quad broadcasts), i.e. row i of the gain K; row 3: the
-// log-likelihood's S against the innovation.  A lane then holds K_i. ; the rows K_j. it needs for P+_ij = P_ij - (K S K^T)_ij
-// come from a broadcast of the three gain rows and a two-level select on j.  ~140 instructions instead of the ~270 of
-// the redundant per-lane update, the same operations on each number (chol_lower / substitution order of ekf_update).
+// log-likelihood's S against the innovation (the quad broadcast writes banks 0..2 only and leaves bank 3 the innovation it held).
+// A lane then holds K_i. and (K S)_i. ; what it subtracts from its entry is (K S)_i. K_j.^T for a covariance lane and -K_i. (y - m)
+// for a mean lane.  K_j. belongs to another row: the three candidates j = 0, 1, 2 are formed with the gain rows as row_newbcast
+// operands and the lane picks its own.  Lanes on and above the diagonal keep P_ij - (K S K^T)_ij as computed (the reference
+// averages it with the (j, i) value, which differs by rounding only), lanes below adopt their transpose partner's value.
+// Every lane accumulates the log-likelihood terms of ITS row's system; the row-3 lanes hold the trajectory's.
 template <typename R, typename Args>
 CDKF_DEV void lpe_update(const Args& a, R& v, R cur, int i, int j, LlAcc& ll, bool& bad) {
   constexpr int D = 3;
-  const bool row3 = i == 3, cov = i < 3 && j < 3, mean = i < 3 && j == 3;
+  const bool row3 = i == 3;
   const R Pg[6] = {lpe_bcast<0>(v), lpe_bcast<1>(v), lpe_bcast<2>(v), lpe_bcast<5>(v), lpe_bcast<6>(v), lpe_bcast<10>(v)};
-  const R m0 = lpe_bcast<3>(v), m1 = lpe_bcast<7>(v), m2 = lpe_bcast<11>(v);
-  const R inn[D] = {lpe_bcast<12>(cur) - m0, lpe_bcast<13>(cur) - m1, lpe_bcast<14>(cur) - m2};
   R S[D][D];
 #pragma unroll
   for (int r = 0; r < D; ++r)
 #pragma unroll
     for (int c = 0; c < D; ++c) S[r][c] = Pg[sidx<D>(r, c)] + a.Rm[r][c];
+  // innovation y_c - m_c: the observation's broadcast, then one multiply-add with the mean's broadcast as its operand.  neg1 is
+  // tied to a value the compiler fetched from v with a move of its own, which keeps the statements behind v's hazard window.
+  R neg1 = R(-1);
+  asm volatile("" : "+v"(neg1) : "v"(Pg[5]));
+  R b0 = lpe_fmac_bcast<3>(lpe_bcast<12>(cur), v, neg1);
+  R b1 = lpe_fmac_bcast<7>(lpe_bcast<13>(cur), v, neg1);
+  R b2 = lpe_fmac_bcast<11>(lpe_bcast<14>(cur), v, neg1);
+  // right-hand sides: row i of P (= column i) for the gain rows; the innovation stays where it is in row 3
+  b0 = lpe_dpp_keep<0x00, 0x7>(b0, v);
+  b1 = lpe_dpp_keep<0x55, 0x7>(b1, v);
+  b2 = lpe_dpp_keep<0xAA, 0x7>(b2, v);
   const R eps = row3 ? R(0) : R(1e-9);
-  R A[D][D], L[D][D], inv[D];
-#pragma unroll
-  for (int r = 0; r < D; ++r)
-#pragma unroll
-    for (int c = 0; c <= r; ++c) A[r][c] = (r == c) ? S[r][c] + eps : S[r][c];
-  chol_lower<R, D>(A, L, inv, bad);
-  // right-hand side: row i of P (= column i) for the gain rows, the innovation for row 3
-  const R q0 = lpe_dpp<0x00>(v), q1 = lpe_dpp<0x55>(v), q2 = lpe_dpp<0xAA>(v);
-  const R b0 = row3 ? inn[0] : q0, b1 = row3 ? inn[1] : q1, b2 = row3 ? inn[2] : q2;
-  const R w0 = b0 * inv[0];
-  const R w1 = rfma(-L[1][0], w0, b1) * inv[1];
-  const R w2 = rfma(-L[2][1], w1, rfma(-L[2][0], w0, b2)) * inv[2];
+  // Cholesky factor of S (+ eps I), chol_lower's operations with lpe_rsqrt
+  const R d0 = S[0][0] + eps;
+  bad = bad || !(d0 > R(0));
+  const R i0 = lpe_rsqrt(d0);
+  const R L10 = S[1][0] * i0, L20 = S[2][0] * i0;
+  const R d1 = rfma(-L10, L10, S[1][1] + eps);
+  bad = bad || !(d1 > R(0));
+  const R i1 = lpe_rsqrt(d1);
+  const R L21 = rfma(-L20, L10, S[2][1]) * i1;
+  const R d2 = rfma(-L21, L21, rfma(-L20, L20, S[2][2] + eps));
+  bad = bad || !(d2 > R(0));
+  const R i2 = lpe_rsqrt(d2);
+  const R w0 = b0 * i0;
+  const R w1 = rfma(-L10, w0, b1) * i1;
+  const R w2 = rfma(-L21, w1, rfma(-L20, w0, b2)) * i2;
   const R quad = rfma(w2, w2, rfma(w1, w1, w0 * w0));
-  const R pinv = (inv[0] * inv[1]) * inv[2];
-  ll.add((double)lpe_bcast<12>(quad), (double)lpe_bcast<12>(pinv), D);
+  const R pinv = (i0 * i1) * i2;
+  ll.add((double)quad, (double)pinv, D);
   R x[D];  // K_i.
-  x[2] = w2 * inv[2];
-  x[1] = rfma(-L[2][1], x[2], w1) * inv[1];
-  x[0] = rfma(-L[2][0], x[2], rfma(-L[1][0], x[1], w0)) * inv[0];
-  R Kj[D];
+  x[2] = w2 * i2;
+  x[1] = rfma(-L21, x[2], w1) * i1;
+  x[0] = rfma(-L20, x[2], rfma(-L10, x[1], w0)) * i0;
+  R KS[D];  // -(K S)_i.
+#pragma unroll
+  for (int c = 0; c < D; ++c) KS[c] = rfma(-x[2], S[2][c], rfma(-x[1], S[1][c], -x[0] * S[0][c]));
+  // candidates P_ij - (K S)_i. K_j.^T for j = 0, 1, 2 (gain row j = lanes 4 j .. of this grid) and m_i + K_i. (y - m) for the mean
+  // lanes (the innovation: row 3's right-hand sides)
+  R n0 = v, n1 = v, n2 = v, n3 = v;
 #pragma unroll
   for (int c = 0; c < D; ++c) {
-    const R k0 = lpe_bcast<0>(x[c]), k1 = lpe_bcast<4>(x[c]), k2 = lpe_bcast<8>(x[c]);
-    Kj[c] = (j == 0) ? k0 : ((j == 1) ? k1 : k2);
+    n0 = lpe_fmac_bcast<0>(n0, x[c], KS[c]);
+    n1 = lpe_fmac_bcast<4>(n1, x[c], KS[c]);
+    n2 = lpe_fmac_bcast<8>(n2, x[c], KS[c]);
   }
-  R KSi[D], KSj[D];
-#pragma unroll
-  for (int c = 0; c < D; ++c) {
-    KSi[c] = rfma(x[2], S[2][c], rfma(x[1], S[1][c], x[0] * S[0][c]));
-    KSj[c] = rfma(Kj[2], S[2][c], rfma(Kj[1], S[1][c], Kj[0] * S[0][c]));
-  }
-  const R tij = rfma(KSi[2], Kj[2], rfma(KSi[1], Kj[1], KSi[0] * Kj[0]));
-  const R tji = rfma(KSj[2], x[2], rfma(KSj[1], x[1], KSj[0] * x[0]));
-  const R pn = R(0.5) * ((v - tij) + (v - tji));
-  const R mn = rfma(x[2], inn[2], rfma(x[1], inn[1], rfma(x[0], inn[0], v)));
-  v = cov ? pn : (mean ? mn : R(0));
+  n3 = lpe_fmac_bcast<12>(n3, b0, x[0]);
+  n3 = lpe_fmac_bcast<12>(n3, b1, x[1]);
+  n3 = lpe_fmac_bcast<12>(n3, b2, x[2]);
+  const R nv = (j == 0) ? n0 : ((j == 1) ? n1 : ((j == 2) ? n2 : n3));
+  v = row3 ? R(0) : nv;
   // The lanes below the diagonal adopt the value of their transpose partner (lanes 4 <- 1, 9 <- 6: row_shr:3; 8 <- 2:
   // row_shr:6).  Each lane integrates its own entry, so P_ij and P_ji differ by rounding after a predict, and the
   // antisymmetric part is amplified by the (chaotic) flow -- left alone it reached 1e-8 relative within 300 steps and
@@ -167,10 +274,11 @@ inline unsigned lpe_blocks(int64_t N) {
 }
 
 // OUT: 0 log-likelihood only, 1 all four moment arrays, 2 filtered moments only (the smoother's forward sweep)
-// M: emission dimension (1..3).  M == 3 is launched for H = I (HSEL update code, in-grid update when a.lpe_fast); M < 3 takes any
-// linear emission through the per-lane update.
-template <typename R, int M, int OUT>
+// M: emission dimension (1..3).  M == 3 is launched for H = I (HSEL update code); FAST: the in-grid update (lpe_update: one update
+// iteration, symmetric R); otherwise -- M < 3 with any linear emission, iterated updates -- the per-lane update.
+template <typename R, int M, int OUT, bool FAST>
 __global__ __launch_bounds__(64) void filter_lpe_l63_kernel(const RegArgs<R, 3, M, DriftLorenz63<R, 3>> a) {
+  static_assert(!FAST || M == 3, "the in-grid update is written for H = I");
   constexpr int D = 3, NS = Dims<D>::NS;
   const int lane = threadIdx.x, l = lane & 15, i = l >> 2, j = l & 3;
   constexpr int sh = lpe_xcd_shift<R>();
@@ -212,7 +320,7 @@ __global__ __launch_bounds__(64) void filter_lpe_l63_kernel(const RegArgs<R, 3, 
   R bufA = pA[0], bufB = pB[0];
   // output pointers of this lane (filtered and predicted arrays share the geometry).  The row-3 lanes own no moment; so that
   // the stores stay unconditional (exact vmcnt accounting: behind a branch the compiler drains every store before the next
-  // step's load, ~600 cycles per step) they write their zero to ll[n], which lane 0 overwrites after the sweep.
+  // step's load, ~600 cycles per step) they write their zero to ll[n], which is overwritten after the sweep.
   R* fout = a.ll + n;
   R* pout = a.ll + n;
   long out_stride = 0;
@@ -232,16 +340,14 @@ __global__ __launch_bounds__(64) void filter_lpe_l63_kernel(const RegArgs<R, 3, 
   int st = 0;
   bool bad = false;  // a non-positive pivot in this row's factorisations (lpe_update)
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see cdkf_filter_reg_body.inc
-  auto step = [&](const long k, R& cur, const R*& ldp) {
+  // One observation step.  TAIL = false: a step of the main loop, at least four rows before the end of the arrays -- the
+  // reload's row exists for every lane and the predict ends at the next observation, so neither is tested.
+  auto step = [&](auto tail, const long k, R& cur, const R*& ldp) {
+    constexpr bool TAIL = decltype(tail)::value;
     const R tnext_obs = lpe_bcast<15>(cur);
-    bool in_grid = false;
-    if constexpr (M == 3) {
-      if (a.lpe_fast) {
-        lpe_update(a, v, cur, i, j, ll, bad);
-        in_grid = true;
-      }
-    }
-    if (!in_grid) {
+    if constexpr (FAST) {
+      lpe_update(a, v, cur, i, j, ll, bad);
+    } else {
       // measurement update, redundantly in every lane of the row, on the gathered moments (iterated updates, an emission
       // covariance that is not exactly symmetric)
       R ys[NS], yobs[M];
@@ -264,15 +370,13 @@ __global__ __launch_bounds__(64) void filter_lpe_l63_kernel(const RegArgs<R, 3, 
       for (int e = 0; e < NS; ++e) upd = (own == e) ? ys[e] : upd;
       v = upd;
     }
-    if (k + 2 + ld_off < a.T) ldp += ld_stride2;
+    if (!TAIL || k + 2 + ld_off < a.T) ldp += ld_stride2;
     cur = ldp[0];  // this buffer's next row: y_{k+2} / t_{k+3}
     if constexpr (OUT) *fout = v;
 
     // predict to t_{k+1} (to t_k + dt_final after the last observation)
-    const R t1 = (k + 1 < a.T) ? tnext_obs : tcur + a.dt_final;
-    R y1[1] = {v};
-    if (integrate<R, 1>(y1, tcur, t1, a.dt0, a.max_steps, rhs, C)) st |= kStatusMaxSteps;
-    v = y1[0];
+    const R t1 = (!TAIL || k + 1 < a.T) ? tnext_obs : tcur + a.dt_final;
+    if (lpe_integrate<R>(v, tcur, t1, a.dt0, a.max_steps, rhs, C)) st |= kStatusMaxSteps;
     if constexpr (OUT == 1) {
       *pout = v;
       pout += out_stride;
@@ -280,20 +384,26 @@ __global__ __launch_bounds__(64) void filter_lpe_l63_kernel(const RegArgs<R, 3, 
     if constexpr (OUT) fout += out_stride;
     tcur = tnext_obs;
   };
+  // straight-line pairs of steps: the vmcnt accounting stays exact (no branch between the loads)
   long k = 0;
-  for (; k + 1 < a.T; k += 2) {  // straight-line pair of steps: the vmcnt accounting stays exact (no branch between the loads)
-    step(k, bufA, pA);
-    step(k + 1, bufB, pB);
+  for (; k + 5 <= a.T; k += 2) {  // rows k + 3 and k + 4 exist
+    step(std::false_type{}, k, bufA, pA);
+    step(std::false_type{}, k + 1, bufB, pB);
   }
-  if (k < a.T) step(k, bufA, pA);
+  for (; k + 1 < a.T; k += 2) {
+    step(std::true_type{}, k, bufA, pA);
+    step(std::true_type{}, k + 1, bufB, pB);
+  }
+  if (k < a.T) step(std::true_type{}, k, bufA, pA);
   ll.flush();
-  if (a.lpe_fast) {  // flags of the in-grid update: either factorisation (gain rows, log-likelihood row) failed; NaN is sticky
+  if constexpr (FAST) {  // flags of the in-grid update: either factorisation (gain rows, log-likelihood row) failed; NaN is sticky
     const R bf = bad ? R(1) : R(0);
     if (lpe_bcast<0>(bf) + lpe_bcast<12>(bf) > R(0)) st |= kStatusNotPd;
     const R m_last = lpe_bcast<3>(v);
     if (m_last != m_last) st |= kStatusNan;
   }
-  if (live && l == 0) {
+  // the trajectory's log-likelihood: every lane's with the per-lane update, the row-3 lanes' with the in-grid update
+  if (live && l == (FAST ? 12 : 0)) {
     a.ll[n] = (R)ll.ll;
     if (a.status) a.status[n] = st;
   }
@@ -466,17 +576,26 @@ inline bool try_lpe(const RegArgs<R, D, M, Drift>& a, const cdkf_model* mdl, con
         o->state_order == CDKF_ORDER_ZEROTH || o->solver != CDKF_SOLVER_DOPRI5 || o->adaptive)
       return false;
     const dim3 grid(lpe_blocks<R>(a.N)), block(64);
-    RegArgs<R, D, M, Drift> b = a;
     bool sym = true;
     for (int r = 0; r < M; ++r)
-      for (int c = 0; c < r; ++c) sym = sym && b.Rm[r][c] == b.Rm[c][r];
-    b.lpe_fast = (M == 3 && o->num_iter == 1 && sym) ? 1 : 0;
+      for (int c = 0; c < r; ++c) sym = sym && a.Rm[r][c] == a.Rm[c][r];
+    const bool fast = M == 3 && o->num_iter == 1 && sym;  // the in-grid update (lpe_update)
+    auto launch = [&](auto out) {
+      constexpr int OUT = decltype(out)::value;
+      if constexpr (M == 3) {
+        if (fast) {
+          hipLaunchKernelGGL((filter_lpe_l63_kernel<R, M, OUT, true>), grid, block, 0, stream, a);
+          return;
+        }
+      }
+      hipLaunchKernelGGL((filter_lpe_l63_kernel<R, M, OUT, false>), grid, block, 0, stream, a);
+    };
     if (all)
-      hipLaunchKernelGGL((filter_lpe_l63_kernel<R, M, 1>), grid, block, 0, stream, b);
+      launch(std::integral_constant<int, 1>{});
     else if (filt)
-      hipLaunchKernelGGL((filter_lpe_l63_kernel<R, M, 2>), grid, block, 0, stream, b);
+      launch(std::integral_constant<int, 2>{});
     else
-      hipLaunchKernelGGL((filter_lpe_l63_kernel<R, M, 0>), grid, block, 0, stream, b);
+      launch(std::integral_constant<int, 0>{});
     return true;
   } else {
     return false;

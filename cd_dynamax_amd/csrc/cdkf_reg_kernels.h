@@ -36,7 +36,6 @@ struct RegArgs {
   int solver;   // CDKF_SOLVER_*
   int lanes;      // distinct trajectories per wavefront (power of two <= 64; the other lanes repeat them)
   int xcd_shift;  // log2 of the wavefront groups that share a 128-byte line (reg_unit_index)
-  int lpe_fast;   // filter_lpe_l63_kernel: num_iter == 1 and R exactly symmetric -> update inside the lane grid (lpe_update)
   RkTab<R> rk;  // used by the GENERIC instantiations only (solver != CDKF_SOLVER_DOPRI5)
   long N, T;
   // element (n, k, i) of an array lives at  n * sn + k * sk + i.  Reference layout [N,T,w]:

@@ -189,8 +189,9 @@ def fit_sgd(model, params, props, emissions, t_emissions=None, filter_hyperparam
 
     ``key``: seed of the NumPy generator that permutes the sequences when ``shuffle`` (JAX's PRNG stream is not
     reproduced).  ``allreduce``: optional callable summing a float64 array over data-parallel ranks
-    (``distributed.allreduce_sum_array``) -- each rank then passes its own block of sequences and every rank applies the
-    same update."""
+    (``distributed.allreduce_sum_array``) -- each rank then passes its own block of sequences (blocks may differ in size or be
+    empty) and every rank applies the same update: the single-process fit of the concatenated data, with step b's minibatch
+    made of every rank's b-th piece."""
     from .models import _grads_tree, _model_block, _opts, _prepare
     hyper = EKFHyperParams() if filter_hyperparams is None else filter_hyperparams
     if not isinstance(hyper, EKFHyperParams):
@@ -214,18 +215,35 @@ def fit_sgd(model, params, props, emissions, t_emissions=None, filter_hyperparam
     n_theta = mdl0.theta.size
     n_model = 0 if tr.drift_only else _ffi.model_grad_size(mdl0.state_dim, mdl0.emission_dim)
     t_shared = bool(opts.t_shared)
-    num_batches = -(-N // batch_size)
-    if batch_size >= N:
-        shuffle = False
+    if allreduce is not None:
+        # Data-parallel: this rank holds its block of the N_total sequences.  The loss is the single-process one,
+        # -(sum over the GLOBAL minibatch of ll * N_total / B_global) / emissions.size of the whole data set, so N and size are
+        # summed once here, every rank takes the same number of optimiser steps per epoch (ceil(N_total / batch_size): the
+        # collective is called the same number of times everywhere), a rank's share of a step is the b-th of that many nearly equal
+        # pieces of its block (possibly empty: it then contributes zeros), and the minibatch size travels with the sums.
+        tot = np.asarray(allreduce(np.array([float(N), size])), np.float64)
+        N_total, size = int(round(tot[0])), float(tot[1])
+        num_batches = -(-N_total // batch_size)
+        if batch_size >= N_total:
+            shuffle = False
+        pieces = lambda idx: np.array_split(idx, num_batches)
+    else:
+        N_total = N
+        num_batches = -(-N // batch_size)
+        if batch_size >= N:
+            shuffle = False
+        pieces = lambda idx: [idx[b * batch_size:(b + 1) * batch_size] for b in range(num_batches)]
     rng = np.random.default_rng(key if isinstance(key, (int, np.integer)) else 0)
 
     def build(idx):
+        if len(idx) == 0:
+            return None  # this rank has no sequence in that step
         return _ResidentBatch(y[idx], t if t_shared else t[idx], t_shared, n_theta, n_model, dtype)
 
     order = np.arange(N)
-    resident: List[_ResidentBatch] = []
+    resident: List[Optional[_ResidentBatch]] = []
     if not shuffle:
-        resident = [build(order[b * batch_size:(b + 1) * batch_size]) for b in range(num_batches)]
+        resident = [build(idx) for idx in pieces(order)]
 
     u = tr.to_unconstrained(params)
     state = optimizer.init(u)
@@ -236,24 +254,32 @@ def fit_sgd(model, params, props, emissions, t_emissions=None, filter_hyperparam
             if shuffle:
                 perm = rng.permutation(N)
                 for b in resident:
-                    b.free()
-                resident = [build(perm[b * batch_size:(b + 1) * batch_size]) for b in range(num_batches)]
-            avg = 0.0
+                    if b is not None:
+                        b.free()
+                resident = [build(idx) for idx in pieces(perm)]
+            avg, itr = 0.0, 0
             g_u = np.zeros(tr.size)
-            for itr, batch in enumerate(resident):
+            for batch in resident:
                 cur = tr.from_unconstrained(params, u)
                 mdl = _model_block(cur)
-                ll_sum, g_th, g_md = batch.value_and_grad(mdl, opts, suffix)
+                if batch is None:
+                    ll_sum, g_th, g_md, B = 0.0, np.zeros(n_theta), np.zeros(n_model), 0
+                else:
+                    ll_sum, g_th, g_md = batch.value_and_grad(mdl, opts, suffix)
+                    B = batch.B
                 if allreduce is not None:
-                    red = allreduce(np.concatenate([[ll_sum], g_th, g_md]))
-                    ll_sum, g_th, g_md = float(red[0]), red[1:1 + n_theta], red[1 + n_theta:]
+                    red = np.asarray(allreduce(np.concatenate([[ll_sum, float(B)], g_th, g_md])), np.float64)
+                    ll_sum, B, g_th, g_md = float(red[0]), int(round(red[1])), red[2:2 + n_theta], red[2 + n_theta:]
+                    if B == 0:  # no rank had a sequence left for this step (more steps than sequences per rank): nothing to do
+                        continue
                 grads = _grads_tree(cur, mdl, g_th, g_md if n_model else None)
-                scale = N / batch.B
+                scale = N_total / B
                 loss = -(ll_sum * scale) / size
                 g_u = -(tr.pull_back(grads, u) * scale) / size
                 upd, state = optimizer.update(g_u, state)
                 u = u + upd
                 avg = (avg * itr + loss) / (itr + 1)
+                itr += 1
             losses.append(avg)
             if return_param_history:
                 param_hist.append(tr.from_unconstrained(params, u))
@@ -261,7 +287,8 @@ def fit_sgd(model, params, props, emissions, t_emissions=None, filter_hyperparam
                 grad_hist.append(g_u.copy())
     finally:
         for b in resident:
-            b.free()
+            if b is not None:
+                b.free()
     out = [tr.from_unconstrained(params, u), np.asarray(losses)]
     if return_param_history:
         out.append(param_hist)

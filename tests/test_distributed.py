@@ -71,3 +71,105 @@ def test_two_process_gloo_loglik_allreduce(tmp_path):
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count("RANK_OK_") == 2, out.stdout
+
+
+FIT_WORKER = r'''
+import os, sys
+sys.path[:0] = [os.environ["CDKF_ROOT"], os.path.join(os.environ["CDKF_ROOT"], "oracle"), os.path.join(os.environ["CDKF_ROOT"], "tests")]
+import numpy as np
+import torch.distributed as dist
+import cdkf_oracle as o
+import cd_dynamax_amd as cd
+from cd_dynamax_amd import distributed as D, fit
+from test_fit import _l63_problem
+
+rank, local_rank, world = D.init_process_group("gloo")
+assert world == 2
+
+class OracleBatch:
+    """Stands in for fit._ResidentBatch (the GPU sweep) on CPU: same interface, value and gradient from the oracle."""
+    def __init__(self, y, t, t_shared, n_theta, n_model, dtype):
+        self.y, self.t, self.B = np.asarray(y, np.float64), np.asarray(t, np.float64), y.shape[0]
+    def value_and_grad(self, mdl, opts, suffix):
+        m = o.lorenz63_model(1)
+        cur = o.Model(o.Lorenz63Drift(*mdl.theta), m.L, m.Qc, m.H, m.bias, m.R, m.m0, 100 * np.eye(3))
+        ll, g = o.ekf_loglik_grad(cur, self.t, self.y)
+        return float(ll.sum()), g.sum(0), np.zeros(0)
+    def free(self):
+        pass
+fit._ResidentBatch = OracleBatch
+
+model, params, props = _l63_problem(m=1)
+rng = np.random.default_rng(5)              # every rank builds the same global data and takes its (unequal) block
+mdl = o.lorenz63_model(1)
+mdl = o.Model(mdl.drift, mdl.L, mdl.Qc, mdl.H, mdl.bias, mdl.R, mdl.m0, 100 * np.eye(3))
+N, T, lr = 7, 12, 0.05
+t = o.irregular_times(rng, N, T, 0.05)
+y = o.simulate(mdl, t, rng)
+lo, hi = D.shard_bounds(N, rank, world)      # 4 and 3 sequences
+calls = []
+def allreduce(x):
+    calls.append(len(x))
+    return D.allreduce_sum_array(x)
+
+def expected(batches):
+    """The single-process loop of fit_sgd over the given global minibatches (index arrays), written out with the oracle."""
+    th, losses = mdl.drift.theta().copy(), []
+    for idx in batches:
+        cur = o.Model(o.Lorenz63Drift(*th), mdl.L, mdl.Qc, mdl.H, mdl.bias, mdl.R, mdl.m0, mdl.P0)
+        ll, g = o.ekf_loglik_grad(cur, t[idx], y[idx])
+        scale = N / len(idx)
+        losses.append(-(ll.sum() * scale) / y.size)
+        th = th - lr * (-(g.sum(0) * scale) / y.size)
+    return th, float(np.mean(losses))
+
+# (a) full batch: identical to the single-process fit of all seven sequences
+new, losses = model.fit_sgd(params, props, y[lo:hi], t[lo:hi, :, None], cd.EKFHyperParams(), optimizer=fit.SGD(lr), batch_size=N,
+                            num_epochs=1, allreduce=allreduce)
+th, loss = expected([np.arange(N)])
+got = np.array([new.dynamics.drift.sigma, new.dynamics.drift.rho, new.dynamics.drift.beta])
+assert np.allclose(got, th, rtol=1e-10), (got, th)
+assert abs(losses[0] - loss) < 1e-10 * abs(loss), (losses, loss)
+assert calls == [2, 2 + 3], calls            # one set-up reduction, one per step
+
+# (b) minibatches of 3 out of 7 with blocks of 4 and 3: three steps on BOTH ranks (no rank runs out of collectives), step b made
+# of every rank's b-th piece
+calls.clear()
+new, losses = model.fit_sgd(params, props, y[lo:hi], t[lo:hi, :, None], cd.EKFHyperParams(), optimizer=fit.SGD(lr), batch_size=3,
+                            num_epochs=1, allreduce=allreduce)
+assert calls == [2, 5, 5, 5], calls
+pieces = [np.array_split(np.arange(*D.shard_bounds(N, r, world)), 3) for r in range(world)]
+th, loss = expected([np.concatenate([pieces[0][b], pieces[1][b]]) for b in range(3)])
+got = np.array([new.dynamics.drift.sigma, new.dynamics.drift.rho, new.dynamics.drift.beta])
+assert np.allclose(got, th, rtol=1e-10), (got, th)
+assert abs(losses[0] - loss) < 1e-10 * abs(loss), (losses, loss)
+
+# (c) more steps than a rank has sequences: its empty pieces contribute zeros, globally empty steps are skipped
+new, losses = model.fit_sgd(params, props, y[lo:hi], t[lo:hi, :, None], cd.EKFHyperParams(), optimizer=fit.SGD(lr), batch_size=1,
+                            num_epochs=1, allreduce=allreduce)
+pieces = [np.array_split(np.arange(*D.shard_bounds(N, r, world)), 7) for r in range(world)]
+steps = [np.concatenate([pieces[0][b], pieces[1][b]]) for b in range(7)]
+assert [len(b) for b in steps] == [2, 2, 2, 1, 0, 0, 0]          # steps that no rank has a sequence for are skipped everywhere
+th, loss = expected([b for b in steps if len(b)])
+got = np.array([new.dynamics.drift.sigma, new.dynamics.drift.rho, new.dynamics.drift.beta])
+assert np.allclose(got, th, rtol=1e-10), (got, th)
+dist.barrier()
+dist.destroy_process_group()
+sys.stdout.write("RANK_OK_%d\n" % rank); sys.stdout.flush()
+'''
+
+
+def test_two_process_gloo_fit_sgd_matches_single_process(tmp_path):
+    """fit_sgd(allreduce=...) on two ranks with unequal blocks: the global loss scaling (N_total / B_global, emissions.size of
+    the whole data set), the same number of collectives on every rank, empty pieces (round-1 advisor finding)."""
+    script = tmp_path / "fit_worker.py"
+    script.write_text(FIT_WORKER)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, CDKF_ROOT=ROOT, OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), str(script)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count("RANK_OK_") == 2, out.stdout
