@@ -103,7 +103,11 @@ SYMBOLS = (
      "cdkf_kf_smoother1_f64", "cdkf_kf_smoother1_f32", "cdkf_kf_smoother1_f64_dev", "cdkf_kf_smoother1_f32_dev",
      "cdkf_kf_smoother1_supported", "cdkf_grad_supported", "cdkf_grad_all_supported", "cdkf_ekf_loglik_grad_all_f64",
      "cdkf_ekf_loglik_grad_all_f32", "cdkf_ekf_loglik_grad_all_f64_dev", "cdkf_ekf_loglik_grad_all_f32_dev", "cdkf_grad_sum_f64_dev",
-     "cdkf_grad_sum_f32_dev"]
+     "cdkf_grad_sum_f32_dev", "cdkf_comm_unique_id", "cdkf_comm_init_rank", "cdkf_comm_init_all", "cdkf_comm_rank", "cdkf_comm_world",
+     "cdkf_ll_allreduce", "cdkf_comm_allreduce_max", "cdkf_ll_allreduce_all", "cdkf_comm_destroy", "cdkf_rdv_create",
+     "cdkf_rdv_broadcast", "cdkf_rdv_allreduce", "cdkf_rdv_barrier", "cdkf_rdv_destroy", "cdkf_last_kernel", "cdkf_event_create",
+     "cdkf_event_record", "cdkf_event_elapsed_ms", "cdkf_event_destroy", "cdkf_stream_create", "cdkf_stream_destroy",
+     "cdkf_set_device"]
     + [f"cdkf_{a}_{p}{s}" for a in _ALGOS for p in ("f64", "f32") for s in ("", "_dev")]
 )
 
@@ -118,7 +122,7 @@ def _share_torch_hip_runtime() -> None:
     installed its runtime libraries are loaded here, before ours, without importing torch itself."""
     import importlib.util
     import sys
-    if "torch" in sys.modules or os.environ.get("CDKF_SYSTEM_HIP_RUNTIME"):
+    if os.environ.get("CDKF_SYSTEM_HIP_RUNTIME"):
         return
     try:
         spec = importlib.util.find_spec("torch")
@@ -127,6 +131,12 @@ def _share_torch_hip_runtime() -> None:
     if spec is None or not spec.submodule_search_locations:
         return
     libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    # RCCL belongs to the HIP runtime it was built with: when the process runs on torch's runtime, the collective
+    # (cdkf_comm_*, loaded on first use) takes torch's copy too
+    if not os.environ.get("CDKF_RCCL_PATH") and os.path.exists(os.path.join(libdir, "librccl.so")):
+        os.environ["CDKF_RCCL_PATH"] = os.path.join(libdir, "librccl.so")
+    if "torch" in sys.modules:
+        return  # torch's runtime is already in the process
     for name in ("libamd_comgr.so", "libamdhip64.so", "libhiprtc.so"):
         path = os.path.join(libdir, name)
         if os.path.exists(path):
@@ -226,6 +236,28 @@ def lib() -> C.CDLL:
             f = getattr(L, f"cdkf_{a}_{p}_dev")
             f.argtypes = base + [C.c_void_p]
             f.restype = C.c_int
+    L.cdkf_comm_unique_id.argtypes = [C.c_void_p]
+    L.cdkf_comm_init_rank.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int, C.c_int]
+    L.cdkf_comm_init_all.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int)]
+    L.cdkf_comm_rank.argtypes = [C.c_void_p]
+    L.cdkf_comm_world.argtypes = [C.c_void_p]
+    L.cdkf_ll_allreduce.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    L.cdkf_comm_allreduce_max.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    L.cdkf_ll_allreduce_all.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p), C.c_int64, C.POINTER(C.c_void_p)]
+    L.cdkf_comm_destroy.argtypes = [C.c_void_p]
+    L.cdkf_rdv_create.argtypes = [C.POINTER(C.c_void_p), C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.cdkf_rdv_broadcast.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    L.cdkf_rdv_allreduce.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int]
+    L.cdkf_rdv_barrier.argtypes = [C.c_void_p]
+    L.cdkf_rdv_destroy.argtypes = [C.c_void_p]
+    L.cdkf_last_kernel.restype = C.c_char_p
+    L.cdkf_event_create.argtypes = [C.POINTER(C.c_void_p)]
+    L.cdkf_event_record.argtypes = [C.c_void_p, C.c_void_p]
+    L.cdkf_event_elapsed_ms.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
+    L.cdkf_event_destroy.argtypes = [C.c_void_p]
+    L.cdkf_stream_create.argtypes = [C.POINTER(C.c_void_p)]
+    L.cdkf_stream_destroy.argtypes = [C.c_void_p]
+    L.cdkf_set_device.argtypes = [C.c_int]
     _lib = L
     return L
 

@@ -15,6 +15,15 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+static thread_local char g_kernel[192] = "";
+
+void note_kernel(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_kernel, sizeof(g_kernel), fmt, ap);
+  va_end(ap);
+}
+
 int check_common(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const void* t, const void* y,
                  const void* ll) {
   if (!mdl || !o) {
@@ -36,6 +45,26 @@ int check_common(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T
   if (!mdl->theta || !mdl->L || !mdl->Qc || !mdl->H || !mdl->h_bias || !mdl->R || !mdl->m0 || !mdl->P0) {
     set_error("model parameter pointers must not be NULL");
     return CDKF_EINVAL;
+  }
+  {  // the drift's parameter block is read with the size the drift implies: a short block from a C caller must not be read past
+    const long d = mdl->state_dim, h1 = mdl->hidden1, h2 = mdl->hidden2;
+    long want = -1;
+    switch (mdl->drift_kind) {
+      case CDKF_DRIFT_LINEAR: want = d * d + d; break;
+      case CDKF_DRIFT_LORENZ63: want = 3; break;
+      case CDKF_DRIFT_LORENZ96: want = 1; break;
+      case CDKF_DRIFT_MLP_TANH: want = (h1 >= 1 && h2 >= 1) ? h1 * d + h1 + h2 * h1 + h2 + d * h2 + d : -2; break;
+      default: break;  // custom drifts: checked against the registered size where they are looked up
+    }
+    if (want == -2) {
+      set_error("drift MLP_TANH needs hidden1, hidden2 >= 1 (got %d, %d)", mdl->hidden1, mdl->hidden2);
+      return CDKF_EINVAL;
+    }
+    if (want >= 0 && mdl->n_theta != want) {
+      set_error("drift_kind %d with state_dim %d takes n_theta = %ld parameters (got %lld)", mdl->drift_kind, mdl->state_dim, want,
+                (long long)mdl->n_theta);
+      return CDKF_EINVAL;
+    }
   }
   if (mdl->emission_kind != 0 && !custom_kind(mdl->drift_kind)) {
     set_error("emission_kind %d: a custom emission runs on the run-time compiled kernels, which need the drift as source too "
@@ -75,10 +104,6 @@ int check_common(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T
   return CDKF_OK;
 }
 
-int select_device(const cdkf_opts* o) {
-  if (o && o->device >= 0) CDKF_HIP_CHECK(hipSetDevice(o->device));
-  return CDKF_OK;
-}
 
 // Distinct trajectories per wavefront for the lane-per-trajectory sweeps (cdkf_filter_reg_body.inc): the largest power of two
 // that still yields two wavefronts per CU of the current device, 64 once the batch is that large.  CDKF_LANES_PER_WAVE
@@ -106,8 +131,7 @@ int run_with_host_buffers(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, 
   int rc = check_common(mdl, o, N, T, t, y, ll);
   if (rc) return rc;
   if (N == 0) return CDKF_OK;
-  rc = select_device(o);
-  if (rc) return rc;
+  CDKF_SELECT_DEVICE(o);
   const int d = mdl->state_dim, m = mdl->emission_dim;
   const size_t nt = (size_t)(o->t_shared ? T : N * T);
   const size_t nm = (size_t)N * T * d, nP = nm * d;
@@ -193,7 +217,7 @@ int loglik_grad_dev(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_
     return CDKF_EINVAL;
   }
   if (N == 0) return CDKF_OK;
-  if ((rc = select_device(o))) return rc;
+  CDKF_SELECT_DEVICE(o);
   return launch_ekf_grad<R>(mdl, o, N, T, t, y, ll, grad, grad_model, status, (hipStream_t)stream);
 }
 
@@ -207,7 +231,7 @@ int loglik_grad_host(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64
     return CDKF_EINVAL;
   }
   if (N == 0) return CDKF_OK;
-  if ((rc = select_device(o))) return rc;
+  CDKF_SELECT_DEVICE(o);
   const size_t nt = (size_t)(o->t_shared ? T : N * T), ny = (size_t)N * T * mdl->emission_dim;
   const size_t ng = (size_t)N * (size_t)mdl->n_theta;
   const size_t dd = mdl->state_dim, mm = mdl->emission_dim;
@@ -237,7 +261,7 @@ int kf_smoother1_dev(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64
   int rc = check_common(mdl, o, N, T, t, y, ll);
   if (rc) return rc;
   if (N == 0) return CDKF_OK;
-  if ((rc = select_device(o))) return rc;
+  CDKF_SELECT_DEVICE(o);
   return launch_kf_smoother1<R>(mdl, o, N, T, t, y, ll, fm, fP, sm, sP, cross, status, (hipStream_t)stream);
 }
 
@@ -251,7 +275,7 @@ int kf_smoother1_host(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int6
     return CDKF_EINVAL;
   }
   if (N == 0) return CDKF_OK;
-  if ((rc = select_device(o))) return rc;
+  CDKF_SELECT_DEVICE(o);
   const size_t d = mdl->state_dim, m = mdl->emission_dim;
   const size_t nt = (size_t)(o->t_shared ? T : N * T), ny = (size_t)N * T * m, nm = (size_t)N * T * d, nP = nm * d;
   DevBuf dt, dy, dll, dst, dfm, dfP, dsm, dsP, dcr;
@@ -494,6 +518,52 @@ int cdkf_synchronize(void* stream) {
   CDKF_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
   return CDKF_OK;
 }
+const char* cdkf_last_kernel(void) { return g_kernel; }
+int cdkf_event_create(void** event) {
+  if (!event) {
+    set_error("cdkf_event_create: NULL argument");
+    return CDKF_EINVAL;
+  }
+  hipEvent_t e = nullptr;
+  CDKF_HIP_CHECK(hipEventCreate(&e));
+  *event = e;
+  return CDKF_OK;
+}
+int cdkf_event_record(void* event, void* stream) {
+  CDKF_HIP_CHECK(hipEventRecord((hipEvent_t)event, (hipStream_t)stream));
+  return CDKF_OK;
+}
+int cdkf_event_elapsed_ms(void* start, void* stop, float* ms) {
+  if (!ms) {
+    set_error("cdkf_event_elapsed_ms: NULL argument");
+    return CDKF_EINVAL;
+  }
+  CDKF_HIP_CHECK(hipEventSynchronize((hipEvent_t)stop));
+  CDKF_HIP_CHECK(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+  return CDKF_OK;
+}
+int cdkf_event_destroy(void* event) {
+  if (event) CDKF_HIP_CHECK(hipEventDestroy((hipEvent_t)event));
+  return CDKF_OK;
+}
+int cdkf_stream_create(void** stream) {
+  if (!stream) {
+    set_error("cdkf_stream_create: NULL argument");
+    return CDKF_EINVAL;
+  }
+  hipStream_t s = nullptr;
+  CDKF_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  *stream = s;
+  return CDKF_OK;
+}
+int cdkf_stream_destroy(void* stream) {
+  if (stream) CDKF_HIP_CHECK(hipStreamDestroy((hipStream_t)stream));
+  return CDKF_OK;
+}
+int cdkf_set_device(int device) {
+  CDKF_HIP_CHECK(hipSetDevice(device));
+  return CDKF_OK;
+}
 
 #define CDKF_DEFINE_ALGO(NAME, SUFFIX, RTYPE, LAUNCH)                                                              \
   int cdkf_##NAME##_##SUFFIX##_dev(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const RTYPE* t, \
@@ -502,7 +572,7 @@ int cdkf_synchronize(void* stream) {
     int rc = check_common(mdl, o, N, T, t, y, ll);                                                                 \
     if (rc) return rc;                                                                                             \
     if (N == 0) return CDKF_OK;                                                                                    \
-    if ((rc = select_device(o))) return rc;                                                                        \
+    CDKF_SELECT_DEVICE(o);                                                                        \
     return LAUNCH<RTYPE>(mdl, o, N, T, t, y, ll, a1, a2, a3, a4, status, (hipStream_t)stream);                     \
   }                                                                                                                \
   int cdkf_##NAME##_##SUFFIX(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const RTYPE* t,      \

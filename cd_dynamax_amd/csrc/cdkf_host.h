@@ -15,6 +15,10 @@
 namespace cdkf {
 
 void set_error(const char* fmt, ...);
+// records the sweep kernel a call is about to launch (cdkf_last_kernel): the name as a profile prints it, up to where it is known
+void note_kernel(const char* fmt, ...);
+template <typename R>
+inline const char* real_name() { return sizeof(R) == 8 ? "double" : "float"; }
 int check_common(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T, const void* t, const void* y,
                  const void* ll);
 
@@ -26,6 +30,34 @@ int check_common(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_
       return CDKF_EHIP;                                                                   \
     }                                                                                     \
   } while (0)
+
+// opts.device >= 0 runs the call on that device; the caller's current device is put back on every way out (a call on a cuda:1
+// tensor must not move the process's -- PyTorch's -- current device under the caller's feet)
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false, good = true;
+  explicit DeviceGuard(int device) {
+    if (device < 0) return;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev == device) return;
+    const hipError_t err = hipSetDevice(device);
+    if (err != hipSuccess) {
+      set_error("hipSetDevice(%d) failed: %s", device, hipGetErrorString(err));
+      good = false;
+      return;
+    }
+    switched = true;
+  }
+  ~DeviceGuard() {
+    if (switched && prev >= 0) (void)hipSetDevice(prev);
+  }
+  DeviceGuard(const DeviceGuard&) = delete;
+  DeviceGuard& operator=(const DeviceGuard&) = delete;
+  bool ok() const { return good; }
+};
+#define CDKF_SELECT_DEVICE(o)                                      \
+  ::cdkf::DeviceGuard device_guard__((o) ? (o)->device : -1);      \
+  if (!device_guard__.ok()) return CDKF_EHIP
 
 // RAII device buffer for the host-pointer entry points
 struct DevBuf {
@@ -228,6 +260,5 @@ void fill_reg_args(RegArgs<R, D, M, Drift>& a, const cdkf_model* mdl, const cdkf
   a.status = status;
 }
 
-int select_device(const cdkf_opts* o);
 
 }  // namespace cdkf

@@ -59,6 +59,21 @@ struct ParamSlot {
 };
 int param_pool_acquire(size_t bytes, ParamSlot** out);
 int param_pool_release(ParamSlot* s, hipStream_t stream);
+// A slot on loan: whatever way the launcher leaves, the slot's event is recorded behind the work enqueued so far, so the ring
+// cannot hand the pinned staging buffer to the next call while this call's copy is still pending.
+struct ParamLease {
+  ParamSlot* slot = nullptr;
+  hipStream_t stream = nullptr;
+  explicit ParamLease(hipStream_t s) : stream(s) {}
+  ParamLease(const ParamLease&) = delete;
+  ParamLease& operator=(const ParamLease&) = delete;
+  int release() {
+    ParamSlot* s = slot;
+    slot = nullptr;
+    return s ? param_pool_release(s, stream) : CDKF_OK;
+  }
+  ~ParamLease() { (void)release(); }
+};
 
 // user-supplied drifts compiled at run time (launch_custom.hip); algo: 0 EKF filter, 1 UKF filter, 2 EKF smoother
 bool custom_kind(int kind);
@@ -103,6 +118,7 @@ template <typename R, int D, int M, typename Drift, bool UKF, bool ZEROTH, bool 
 inline void launch_filter_reg(const RegArgs<R, D, M, Drift>& a, hipStream_t stream) {
   const dim3 grid(reg_grouping(a.N, (int)sizeof(R)).blocks), block(64);
   const bool all = a.fm && a.fP && a.pm && a.pP, none = !a.fm && !a.fP && !a.pm && !a.pP;
+  note_kernel("filter_reg_kernel<%s, %d, %d, ", real_name<R>(), D, M);
   if (a.rk.stages && (a.solver != CDKF_SOLVER_DOPRI5 || a.rk.adaptive)) {  // non-default method or adaptive steps: run-time tableau
     if (a.forecast)
       hipLaunchKernelGGL((filter_reg_kernel<R, D, M, Drift, UKF, ZEROTH, false, kOutSome, true, true>), grid, block, 0, stream, a);

@@ -86,9 +86,20 @@ CDKF_DEV float lpe_fmac_bcast(float acc, float src, float mult) { return rfma(lp
 // The mean lanes (column 3) ride on the SAME instructions: the drift is f(m) = M(m) m with M = [[-s, s, 0], [rho, -1, -x],
 // [0, x, -b]], which differs from the Jacobian F only in the (1,0) and (2,0) entries, so a mean lane carries M's constants in its
 // row slots and zeros in its column slots and its slope is the row dot product alone.
-template <typename R>
+//
+// UKF = true: the unscented filter's moment equations for THIS drift.  Lorenz-63 is quadratic, f(m + o) = f(m) + F(m) o + b(o, o) with
+// b(o, o) = (0, -o_x o_z, o_x o_y), and the sigma points are symmetric about the mean (m, m +- c chol(P)_{:,i}, inference_ukf.py:45-60), so
+// the weighted sums of _predict (inference_ukf.py:124-143) collapse exactly, for every alpha, beta, kappa:
+//     dm/dt = f_X^T w_mean              = f(m) + 2 w_i c^2 b(P) = f(m) + (0, -P_02, P_01)      (2 w_i c^2 = 1, sum_i o_i o_i^T = c^2 P)
+//     f_X^T W X = w_i sum_i (f(X_i+) - f(X_i-)) o_i^T = 2 w_i c^2 F(m) P = F(m) P             (the centre point's term carries X_0 - m = 0)
+// i.e. the EKF's covariance equation and a mean equation with the TRUE second-order term (which the reference's EKF 'second' order
+// lacks for this drift).  No Cholesky factor and no sigma point is formed: two more multiply-adds on the mean lanes.  What is NOT
+// reproduced: the reference turns a trajectory into NaN when a Runge-Kutta STAGE covariance loses positive definiteness
+// (jnp.linalg.cholesky); here positive definiteness is tested where the update forms its sigma points (lpe_pd_check), once per step.
+template <typename R, bool UKF = false>
 struct LpeRhs {
   R g0, q;                   // F_ii + F_jj (covariance lanes) / M_ii (mean lanes); (L Qc L^T)_ij
+  R u1, u2;                  // UKF: coefficients of P_01 (lane (2,3): +1) and P_02 (lane (1,3): -1) in the mean equation
   R c1i, c3i, cAj, cBj;      // constant parts: F_{i,i+1}, F_{i,i+3} (mod 4), F_{j,(j+1)%3}, F_{j,(j+2)%3}
   R gx1i, gx3i, gxAj, gxBj;  // their coefficients of x
   R gy2i, gyAj;              // of y (row slot i+2, column slot A)
@@ -113,6 +124,8 @@ struct LpeRhs {
     const R diag[4] = {-sigma, R(-1), -beta, R(0)};
     g0 = cov ? diag[i] + diag[j] : (mean ? diag[i] : R(0));
     q = cov ? LQL[sidx<3>(i, j)] : R(0);
+    u1 = (mean && i == 2) ? R(1) : R(0);
+    u2 = (mean && i == 1) ? R(-1) : R(0);
   }
   CDKF_DEV R eval(const R v) const {
     const R d1 = lpe_dpp<0x120 + 12>(v), d2 = lpe_dpp<0x120 + 8>(v), d3 = lpe_dpp<0x120 + 4>(v);  // rows i+1, i+2, i+3
@@ -128,17 +141,34 @@ struct LpeRhs {
     acc = lpe_fmac_bcast<3>(acc, v, X);
     acc = lpe_fmac_bcast<7>(acc, v, Y);
     acc = lpe_fmac_bcast<11>(acc, v, Z);
+    if constexpr (UKF) {  // chained on acc: behind the statements above, hence behind v's hazard window
+      acc = lpe_fmac_bcast<1>(acc, v, u1);
+      acc = lpe_fmac_bcast<2>(acc, v, u2);
+    }
     return acc;
   }
   CDKF_DEV void operator()(const R (&s)[1], R (&k)[1]) const { k[0] = eval(s[0]); }
 };
 
+// The unscented update draws its sigma points from chol(P) (inference_ukf.py:184, 57): a covariance that is not positive definite
+// makes the reference's factor -- and from there the whole trajectory -- NaN.  Same test without the factor: the three leading
+// principal minors (Sylvester), from broadcasts of the grid; every lane of the row gets the same answer.
+template <typename R>
+CDKF_DEV bool lpe_pd_check(const R v) {
+  const R p00 = lpe_bcast<0>(v), p01 = lpe_bcast<1>(v), p02 = lpe_bcast<2>(v), p11 = lpe_bcast<5>(v), p12 = lpe_bcast<6>(v),
+          p22 = lpe_bcast<10>(v);
+  const R m2 = rfma(p00, p11, -(p01 * p01));
+  const R c0 = rfma(p11, p22, -(p12 * p12)), c1 = rfma(p01, p22, -(p12 * p02)), c2 = rfma(p01, p12, -(p11 * p02));
+  const R m3 = rfma(p02, c2, rfma(p00, c0, -(p01 * c1)));
+  return (p00 > R(0)) && (m2 > R(0)) && (m3 > R(0));
+}
+
 // One Dormand-Prince step of the lane's entry.  fp64: slopes scaled by the step once (k_s = dt f_s: six products) and combined
 // with the tableau constants from registers -- 26 instructions beside the right-hand sides; dopri5_step's fp64 form (c_sj = dt a_sj
 // formed per step) is laid out for nine entries per lane and costs 40 for one.  fp32 keeps dopri5_step's association, which is the
 // reference's (`y0 + dt (a_lower[i] @ ks)`).
-template <typename R>
-CDKF_DEV void lpe_step(R& y, R dt, const LpeRhs<R>& rhs, const Dp5V<R>& C) {
+template <typename R, typename Rhs>
+CDKF_DEV void lpe_step(R& y, R dt, const Rhs& rhs, const Dp5V<R>& C) {
   if constexpr (sizeof(R) == 8) {
     const R k1 = dt * rhs.eval(y);
     const R k2 = dt * rhs.eval(rfma(C.a21, k1, y));
@@ -155,8 +185,8 @@ CDKF_DEV void lpe_step(R& y, R dt, const LpeRhs<R>& rhs, const Dp5V<R>& C) {
 }
 
 // diffrax's loop (see integrate in cdkf_math.h) around lpe_step; true when max_steps was hit
-template <typename R>
-CDKF_DEV bool lpe_integrate(R& y, R t0, R t1, R dt0, long max_steps, const LpeRhs<R>& rhs, const Dp5V<R>& C) {
+template <typename R, typename Rhs>
+CDKF_DEV bool lpe_integrate(R& y, R t0, R t1, R dt0, long max_steps, const Rhs& rhs, const Dp5V<R>& C) {
   R tprev = t0;
   R tnext = rmin(t0 + dt0, t1);
   long steps = 0;
@@ -276,9 +306,13 @@ inline unsigned lpe_blocks(int64_t N) {
 // OUT: 0 log-likelihood only, 1 all four moment arrays, 2 filtered moments only (the smoother's forward sweep)
 // M: emission dimension (1..3).  M == 3 is launched for H = I (HSEL update code); FAST: the in-grid update (lpe_update: one update
 // iteration, symmetric R); otherwise -- M < 3 with any linear emission, iterated updates -- the per-lane update.
-template <typename R, int M, int OUT, bool FAST>
+// UKF: the unscented filter (LpeRhs<R, true>; its update with a linear emission is the same algebra as the EKF's -- the sigma points
+// pass through h(x) = x exactly: pred_mean = m, pred_cov = P + R, pred_cross = P, inference_ukf.py:186-203 -- plus the
+// positive-definiteness test the reference's Cholesky of P implies).
+template <typename R, int M, int OUT, bool FAST, bool UKF = false>
 __global__ __launch_bounds__(64) void filter_lpe_l63_kernel(const RegArgs<R, 3, M, DriftLorenz63<R, 3>> a) {
   static_assert(!FAST || M == 3, "the in-grid update is written for H = I");
+  static_assert(!UKF || FAST, "the unscented filter runs with the in-grid update");
   constexpr int D = 3, NS = Dims<D>::NS;
   const int lane = threadIdx.x, l = lane & 15, i = l >> 2, j = l & 3;
   constexpr int sh = lpe_xcd_shift<R>();
@@ -290,7 +324,7 @@ __global__ __launch_bounds__(64) void filter_lpe_l63_kernel(const RegArgs<R, 3, 
   const long n = live ? n_raw : a.N - 1;  // an idle row shadows the last trajectory (same values to the same addresses)
   const bool cov = i < 3 && j < 3, mean = i < 3 && j == 3;
 
-  LpeRhs<R> rhs;
+  LpeRhs<R, UKF> rhs;
   rhs.init(i, j, a.drift.sigma, a.drift.rho, a.drift.beta, a.LQL);
   const auto C = TabSel<R, false>::get(a);
 
@@ -345,6 +379,12 @@ __global__ __launch_bounds__(64) void filter_lpe_l63_kernel(const RegArgs<R, 3, 
   auto step = [&](auto tail, const long k, R& cur, const R*& ldp) {
     constexpr bool TAIL = decltype(tail)::value;
     const R tnext_obs = lpe_bcast<15>(cur);
+    if constexpr (UKF) {
+      if (!lpe_pd_check(v)) {  // chol(P) of the update's sigma points fails: NaN from here on, as in the reference
+        bad = true;
+        v = (i < 3) ? R(__builtin_nan("")) : v;
+      }
+    }
     if constexpr (FAST) {
       lpe_update(a, v, cur, i, j, ll, bad);
     } else {
@@ -413,25 +453,24 @@ __global__ __launch_bounds__(64) void filter_lpe_l63_kernel(const RegArgs<R, 3, 
 // Per interval the right-hand side is LINEAR with coefficients that are constant over the interval (G = F(m_f) + psd_solve(P_f,
 // L Qc L^T)^T and f(m_f) are evaluated at the filtered moments): row i of the grid solves (P_f + 1e-9 I) x = (L Qc L^T)[:, i], which is
 // row i of psd_solve(...)^T, so G_i. is local to the row; the rows G_j. a covariance lane also needs come from a broadcast and a
-// masked sum.  The slots are then put into the rotated order of the DPP fetches once per interval, and a Runge-Kutta stage is 12
-// moves + 7 FMAs (the lane-per-trajectory sweep: ~88 instructions per stage).  Lanes below the diagonal re-adopt their transpose
+// masked sum.  The slots are then put into the rotated order of the DPP fetches once per interval, and a Runge-Kutta stage is 10
+// moves + 6 FMAs (the lane-per-trajectory sweep: ~88 instructions per stage).  Lanes below the diagonal re-adopt their transpose
 // partner every step (see lpe_update).  Inputs: the filtered moments the forward sweep just wrote; each lane loads its own entry.
 template <typename R>
 struct LpeLinRhs {
-  R g0, q, ci1, ci2, ci3, cj1, cj2, cj3;
-  CDKF_DEV void operator()(const R (&s)[1], R (&k)[1]) const {
-    const R v = s[0];
-    const R d1 = lpe_dpp<0x120 + 12>(v), d2 = lpe_dpp<0x120 + 8>(v), d3 = lpe_dpp<0x120 + 4>(v);
-    const R r1 = lpe_dpp<0x39>(v), r2 = lpe_dpp<0x4E>(v), r3 = lpe_dpp<0x93>(v);
+  R g0, q, ci1, ci2, ci3, cjA, cjB;
+  CDKF_DEV R eval(const R v) const {
+    const R d1 = lpe_dpp<0x120 + 12>(v), d2 = lpe_dpp<0x120 + 8>(v), d3 = lpe_dpp<0x120 + 4>(v);  // rows i+1, i+2, i+3
+    const R r1 = lpe_dpp<0xC9>(v), r2 = lpe_dpp<0xD2>(v);                                          // columns (j+1) % 3, (j+2) % 3
     R acc = rfma(g0, v, q);
     acc = rfma(ci1, d1, acc);
     acc = rfma(ci2, d2, acc);
     acc = rfma(ci3, d3, acc);
-    acc = rfma(cj1, r1, acc);
-    acc = rfma(cj2, r2, acc);
-    acc = rfma(cj3, r3, acc);
-    k[0] = acc;
+    acc = rfma(cjA, r1, acc);
+    acc = rfma(cjB, r2, acc);
+    return acc;
   }
+  CDKF_DEV void operator()(const R (&s)[1], R (&k)[1]) const { k[0] = eval(s[0]); }
 };
 
 template <typename R, int M>
@@ -523,9 +562,8 @@ __global__ __launch_bounds__(64) void smoother_lpe_l63_kernel(const RegArgs<R, 3
     rhs.ci1 = rfma(e1, Gi[2], e0 * Gi[1]);
     rhs.ci2 = rfma(e2, Gi[0], e0 * Gi[2]);
     rhs.ci3 = rfma(e2, Gi[1], e1 * Gi[0]);
-    rhs.cj1 = -rfma(f1, Gj[2], f0 * Gj[1]);
-    rhs.cj2 = -rfma(f2, Gj[0], f0 * Gj[2]);
-    rhs.cj3 = -rfma(f2, Gj[1], f1 * Gj[0]);
+    rhs.cjA = -rfma(f2, Gj[0], rfma(f1, Gj[2], f0 * Gj[1]));  // -G_{j,(j+1)%3}
+    rhs.cjB = -rfma(f2, Gj[1], rfma(f1, Gj[0], f0 * Gj[2]));  // -G_{j,(j+2)%3}
     const R gii = rfma(e2, Gi[2], rfma(e1, Gi[1], e0 * Gi[0]));          // -G_ii
     const R gjj = rfma(f2, Gj[2], rfma(f1, Gj[1], f0 * Gj[0]));          // +G_jj (covariance lanes), 0 elsewhere
     rhs.g0 = gii - gjj;
@@ -533,9 +571,7 @@ __global__ __launch_bounds__(64) void smoother_lpe_l63_kernel(const RegArgs<R, 3
     const R xm = rfma(x[2], mz, rfma(x[1], my, x[0] * mx));
     const R corr = rfma(e1, mz, -(e2 * my)) * mx;  // e1 = -1 on row 1: -z x; e2 = -1 on row 2: +y x  => this is -corr_i
     rhs.q = rfma(mmask, xm + corr, qc);
-    R y1[1] = {v};
-    if (integrate<R, 1>(y1, R(0), t1 - t0, a.dt0, a.max_steps, rhs, C)) st |= kStatusMaxSteps;
-    v = y1[0];
+    if (lpe_integrate<R>(v, R(0), t1 - t0, a.dt0, a.max_steps, rhs, C)) st |= kStatusMaxSteps;
     const R s3 = lpe_dpp<0x110 + 3>(v), s6 = lpe_dpp<0x110 + 6>(v);
     v = ((i == 1 && j == 0) || (i == 2 && j == 1)) ? s3 : v;
     v = (i == 2 && j == 0) ? s6 : v;
@@ -567,28 +603,37 @@ inline bool lpe_batch_is_small(int64_t N) {
 // Small Lorenz-63 batches (H = I): sixteen lanes per trajectory (cdkf_lpe_kernels.h).  CDKF_NO_LPE=1 keeps the
 // lane-per-trajectory kernel (A/B timing, tests of the latter at small N).
 template <typename R, int D, int M, typename Drift>
-inline bool try_lpe(const RegArgs<R, D, M, Drift>& a, const cdkf_model* mdl, const cdkf_opts* o, hipStream_t stream) {
+inline bool try_lpe(const RegArgs<R, D, M, Drift>& a, const cdkf_model* mdl, const cdkf_opts* o, hipStream_t stream, bool ukf = false) {
   if constexpr (std::is_same<Drift, DriftLorenz63<R, 3>>::value && D == 3 && M <= 3) {
     static const bool off = [] { const char* e = std::getenv("CDKF_NO_LPE"); return e && e[0] == '1'; }();
+    // CDKF_UKF_SIGMA_POINTS=1: the unscented filter on the lane-per-trajectory kernel, which forms the sigma points (A/B, tests)
+    static const bool ukf_off = [] { const char* e = std::getenv("CDKF_UKF_SIGMA_POINTS"); return e && e[0] == '1'; }();
     const bool all = a.fm && a.fP && a.pm && a.pP, none = !a.fm && !a.fP && !a.pm && !a.pP;
     const bool filt = a.fm && a.fP && !a.pm && !a.pP;
     if (off || !lpe_batch_is_small(a.N) || !(all || none || filt) || (M == 3 && !emission_is_selection(mdl)) || o->forecast ||
-        o->state_order == CDKF_ORDER_ZEROTH || o->solver != CDKF_SOLVER_DOPRI5 || o->adaptive)
+        o->solver != CDKF_SOLVER_DOPRI5 || o->adaptive)
       return false;
+    if (!ukf && o->state_order == CDKF_ORDER_ZEROTH) return false;
     const dim3 grid(lpe_blocks<R>(a.N)), block(64);
     bool sym = true;
     for (int r = 0; r < M; ++r)
       for (int c = 0; c < r; ++c) sym = sym && a.Rm[r][c] == a.Rm[c][r];
-    const bool fast = M == 3 && o->num_iter == 1 && sym;  // the in-grid update (lpe_update)
+    const bool fast = M == 3 && (ukf || o->num_iter == 1) && sym;  // the in-grid update (lpe_update)
+    if (ukf && (ukf_off || !fast || !(a.ukf_c > R(0)))) return false;  // (n + lambda <= 0: the reference's NaNs come from the other kernel)
     auto launch = [&](auto out) {
       constexpr int OUT = decltype(out)::value;
+      note_kernel("filter_lpe_l63_kernel<%s, %d, %d, %s, %s>", real_name<R>(), M, OUT, fast ? "true" : "false", ukf ? "true" : "false");
       if constexpr (M == 3) {
+        if (ukf) {
+          hipLaunchKernelGGL((filter_lpe_l63_kernel<R, M, OUT, true, true>), grid, block, 0, stream, a);
+          return;
+        }
         if (fast) {
-          hipLaunchKernelGGL((filter_lpe_l63_kernel<R, M, OUT, true>), grid, block, 0, stream, a);
+          hipLaunchKernelGGL((filter_lpe_l63_kernel<R, M, OUT, true, false>), grid, block, 0, stream, a);
           return;
         }
       }
-      hipLaunchKernelGGL((filter_lpe_l63_kernel<R, M, OUT, false>), grid, block, 0, stream, a);
+      hipLaunchKernelGGL((filter_lpe_l63_kernel<R, M, OUT, false, false>), grid, block, 0, stream, a);
     };
     if (all)
       launch(std::integral_constant<int, 1>{});
@@ -608,6 +653,7 @@ inline bool try_lpe_smoother(const RegArgs<R, D, M, Drift>& a, const cdkf_opts* 
   if constexpr (std::is_same<Drift, DriftLorenz63<R, 3>>::value && D == 3 && M <= 3) {
     static const bool off = [] { const char* e = std::getenv("CDKF_NO_LPE"); return e && e[0] == '1'; }();
     if (off || !lpe_batch_is_small(a.N) || o->solver != CDKF_SOLVER_DOPRI5 || o->adaptive) return false;
+    note_kernel("smoother_lpe_l63_kernel<%s, %d>", real_name<R>(), M);
     hipLaunchKernelGGL((smoother_lpe_l63_kernel<R, M>), dim3(lpe_blocks<R>(a.N)), dim3(64), 0, stream, a, sm, sP);
     return true;
   } else {

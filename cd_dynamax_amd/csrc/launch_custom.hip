@@ -38,14 +38,20 @@ struct Compiled {
   hipModule_t module = nullptr;
   hipFunction_t fn = nullptr;
 };
-std::map<Key, Compiled> g_modules;
+std::map<std::pair<int, Key>, Compiled> g_modules;  // per device: a hipModule / hipFunction belongs to the device it was loaded on
 
 std::mutex& g_mutex_emis() {
   static std::mutex m;
   return m;
 }
 
+std::mutex& g_mutex_srcdir() {
+  static std::mutex m;
+  return m;
+}
+
 std::string source_dir() {
+  std::lock_guard<std::mutex> lock(g_mutex_srcdir());
   if (!g_src_dir.empty()) return g_src_dir;
   Dl_info info;
   if (dladdr((const void*)&source_dir, &info) && info.dli_fname) {
@@ -194,14 +200,14 @@ int compile_variant(const CustomDrift& c, const Key& key, const std::string& arc
 
 int get_function(int kind, const Key& key, hipFunction_t* fn) {
   std::lock_guard<std::mutex> lock(g_mutex);
-  auto it = g_modules.find(key);
+  int dev = 0;
+  CDKF_HIP_CHECK(hipGetDevice(&dev));
+  auto it = g_modules.find({dev, key});
   if (it != g_modules.end()) {
     *fn = it->second.fn;
     return CDKF_OK;
   }
   const CustomDrift& c = g_drifts[kind - CDKF_DRIFT_CUSTOM_BASE];
-  int dev = 0;
-  CDKF_HIP_CHECK(hipGetDevice(&dev));
   hipDeviceProp_t prop;
   CDKF_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
   std::vector<char> code;
@@ -210,7 +216,7 @@ int get_function(int kind, const Key& key, hipFunction_t* fn) {
   Compiled m;
   CDKF_HIP_CHECK(hipModuleLoadData(&m.module, code.data()));
   CDKF_HIP_CHECK(hipModuleGetFunction(&m.fn, m.module, "cdkf_custom_kernel"));
-  g_modules[key] = m;
+  g_modules[{dev, key}] = m;
   *fn = m.fn;
   return CDKF_OK;
 }
@@ -349,9 +355,10 @@ int launch_custom(int algo, const cdkf_model* mdl, const cdkf_opts* o, int64_t N
   }
   const R* yy = y ? y : t;  // forecast mode ignores the observations; keep the prefetch loads on valid memory
   const size_t par_bytes = par.size() * sizeof(R), blob = ((par_bytes + 15) & ~size_t(15)) + sizeof(ip);
-  ParamSlot* slot = nullptr;
-  int rc = param_pool_acquire(blob, &slot);
+  ParamLease lease(stream);
+  int rc = param_pool_acquire(blob, &lease.slot);
   if (rc) return rc;
+  ParamSlot* slot = lease.slot;
   std::memcpy(slot->host, par.data(), par_bytes);
   std::memcpy((char*)slot->host + ((par_bytes + 15) & ~size_t(15)), ip, sizeof(ip));
   CDKF_HIP_CHECK(hipMemcpyAsync(slot->dev, slot->host, blob, hipMemcpyHostToDevice, stream));
@@ -377,7 +384,7 @@ int launch_custom(int algo, const cdkf_model* mdl, const cdkf_opts* o, int64_t N
     rc = run(Key(mdl->drift_kind, (int)sizeof(R), m, 0, zeroth, 0, 0, generic, ek), a1, a2, null_r, null_r, null_r, null_r);
     if (!rc) rc = run(Key(mdl->drift_kind, (int)sizeof(R), m, 0, 0, 0, 1, generic, 0), a1, a2, null_r, null_r, a3, a4);
   }
-  const int rc2 = param_pool_release(slot, stream);
+  const int rc2 = lease.release();
   return rc ? rc : rc2;
 }
 
@@ -426,7 +433,7 @@ int custom_compile_check(int kind, int bytes_per_real, int emission_dim, int alg
 }
 
 void custom_set_source_dir(const char* dir) {
-  std::lock_guard<std::mutex> lock(g_mutex);
+  std::lock_guard<std::mutex> lock(g_mutex_srcdir());
   g_src_dir = dir ? dir : "";
 }
 

@@ -18,6 +18,7 @@ static int run_eks_reg(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int
     else
       hipLaunchKernelGGL((filter_reg_kernel<R, D, M, Drift, false, false, false, kOutSome, false, true>), dim3(blocks), dim3(64), 0, stream, a);
     CDKF_HIP_CHECK(hipGetLastError());
+    note_kernel("ekf_smoother_reg_kernel<%s, %d, %d, ", real_name<R>(), D, M);
     hipLaunchKernelGGL((ekf_smoother_reg_kernel<R, D, M, Drift, true>), dim3(blocks), dim3(64), 0, stream, a, sm, sP);
     CDKF_HIP_CHECK(hipGetLastError());
     return CDKF_OK;
@@ -32,8 +33,10 @@ static int run_eks_reg(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int
   else
     hipLaunchKernelGGL((filter_reg_kernel<R, D, M, Drift, false, false, false, kOutSome>), dim3(blocks), dim3(64), 0, stream, a);
   CDKF_HIP_CHECK(hipGetLastError());
-  if (!try_lpe_smoother(a, &of, sm, sP, stream))
+  if (!try_lpe_smoother(a, &of, sm, sP, stream)) {
+    note_kernel("ekf_smoother_reg_kernel<%s, %d, %d, ", real_name<R>(), D, M);
     hipLaunchKernelGGL((ekf_smoother_reg_kernel<R, D, M, Drift>), dim3(blocks), dim3(64), 0, stream, a, sm, sP);
+  }
   CDKF_HIP_CHECK(hipGetLastError());
   return CDKF_OK;
 }

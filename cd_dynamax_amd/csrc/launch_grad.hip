@@ -38,6 +38,7 @@ static int run_grad(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_
   ga.a.lanes = g.lanes;
   ga.a.xcd_shift = g.xcd_shift;
   const dim3 grid(g.blocks), block(64);
+  note_kernel("ekf_grad_reg_kernel<%s, %d, %d, ", real_name<R>(), D, M);
   if (o->solver != CDKF_SOLVER_DOPRI5 || o->adaptive)  // run-time tableau / adaptive steps: the tangents ride on the primal's steps
     hipLaunchKernelGGL((ekf_grad_reg_kernel<R, D, M, Drift, true>), grid, block, 0, stream, ga);
   else

@@ -1,5 +1,6 @@
 // launch_ukf.hip -- UKF filter sweep: kernel selection and launch.
 #include "cdkf_launch.h"
+#include "cdkf_lpe_kernels.h"
 
 namespace cdkf {
 
@@ -8,7 +9,8 @@ static int run_ukf_reg(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int
                        R* fm, R* fP, R* pm, R* pP, int32_t* status, hipStream_t stream) {
   RegArgs<R, D, M, Drift> a;
   fill_reg_args(a, mdl, o, N, T, t, y, ll, fm, fP, pm, pP, status);
-  launch_filter_reg<R, D, M, Drift, true, false, false>(a, stream);
+  // small Lorenz-63 batches with H = I: sixteen lanes per trajectory, the unscented moment equations in closed form (LpeRhs<R, true>)
+  if (!try_lpe(a, mdl, o, stream, true)) launch_filter_reg<R, D, M, Drift, true, false, false>(a, stream);
   CDKF_HIP_CHECK(hipGetLastError());
   return CDKF_OK;
 }

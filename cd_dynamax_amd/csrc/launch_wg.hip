@@ -126,6 +126,7 @@ static int wg_prepare(WgArgs<R>& a, R** dev_block, ParamSlot** slot_out, const c
   ParamSlot* slot = nullptr;
   int prc = param_pool_acquire(h.size() * sizeof(R), &slot);
   if (prc) return prc;
+  *slot_out = slot;  // the caller's lease covers every exit from here on
   std::memcpy(slot->host, h.data(), h.size() * sizeof(R));
   CDKF_HIP_CHECK(hipMemcpyAsync(slot->dev, slot->host, h.size() * sizeof(R), hipMemcpyHostToDevice, stream));
   *dev_block = (R*)slot->dev;
@@ -172,6 +173,22 @@ static int wg_raise_lds_cap(K kernel) {
   CDKF_HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLdsLimit - 256)));
   return CDKF_OK;
 }
+// The attribute belongs to the (kernel, device) pair: raise it once per device the process launches on, not once per process.
+// F is a distinct lambda type per call site and template instantiation, so each has its own record.
+template <typename F>
+static int once_per_device(F&& raise) {
+  static std::mutex m;
+  static std::vector<char> done;
+  int dev = 0;
+  CDKF_HIP_CHECK(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(m);
+  if ((size_t)dev >= done.size()) done.resize(dev + 1, 0);
+  if (!done[dev]) {
+    if (raise()) return CDKF_EHIP;
+    done[dev] = 1;
+  }
+  return CDKF_OK;
+}
 
 static int wg_threads(int d) {
   if (const char* e = getenv("CDKF_WG_THREADS")) return atoi(e);  // debugging aid
@@ -196,13 +213,14 @@ static int wg_ept(int d, int threads) {
 template <typename R, int EPT>
 static int launch_wg_pair(const WgArgs<R>& a, bool filter, bool smoother, int threads, size_t lds_f, size_t lds_s,
                           hipStream_t stream) {
-  static const int cap_rc = wg_raise_lds_cap(ekf_filter_wg_kernel<R, EPT, false, kDriftAny>) |
-                            wg_raise_lds_cap(ekf_filter_wg_kernel<R, EPT, true, kDriftAny>) |
-                            wg_raise_lds_cap(ekf_filter_wg_kernel<R, EPT, false, kDriftLorenz96>) |
-                            wg_raise_lds_cap(ekf_smoother_wg_kernel<R, EPT>);
-  if (cap_rc) return CDKF_EHIP;
+  if (once_per_device([] {
+        return wg_raise_lds_cap(ekf_filter_wg_kernel<R, EPT, false, kDriftAny>) | wg_raise_lds_cap(ekf_filter_wg_kernel<R, EPT, true, kDriftAny>) |
+               wg_raise_lds_cap(ekf_filter_wg_kernel<R, EPT, false, kDriftLorenz96>) | wg_raise_lds_cap(ekf_smoother_wg_kernel<R, EPT>);
+      }))
+    return CDKF_EHIP;
   if (filter) {
     const dim3 grid((unsigned)a.N), block(threads);
+    note_kernel("ekf_filter_wg_kernel<%s, %d, %s, ", real_name<R>(), EPT, a.ukf ? "true" : "false");
     if (a.ukf)
       hipLaunchKernelGGL((ekf_filter_wg_kernel<R, EPT, true, kDriftAny>), grid, block, lds_f, stream, a);
     else if (a.kind == kDriftLorenz96)
@@ -212,6 +230,7 @@ static int launch_wg_pair(const WgArgs<R>& a, bool filter, bool smoother, int th
     CDKF_HIP_CHECK(hipGetLastError());
   }
   if (smoother) {
+    note_kernel("ekf_smoother_wg_kernel<%s, %d>", real_name<R>(), EPT);
     hipLaunchKernelGGL((ekf_smoother_wg_kernel<R, EPT>), dim3((unsigned)a.N), dim3(threads), lds_s, stream, a);
     CDKF_HIP_CHECK(hipGetLastError());
   }
@@ -242,10 +261,10 @@ static bool wave8_shape(const cdkf_model* mdl) {
 
 template <typename R>
 static int launch_wave8(const WgArgs<R>& a, hipStream_t stream) {
-  static const int cap_rc = wg_raise_lds_cap(ekf_filter_wave8_kernel<R>);
-  if (cap_rc) return CDKF_EHIP;
+  if (once_per_device([] { return wg_raise_lds_cap(ekf_filter_wave8_kernel<R>); })) return CDKF_EHIP;
   const size_t lds = sizeof(R) * (size_t)wave8_lds_reals(a.kind) + 64;
   const unsigned blocks = (unsigned)((a.N + kW8Waves - 1) / kW8Waves);
+  note_kernel("ekf_filter_wave8_kernel<%s>", real_name<R>());
   hipLaunchKernelGGL(ekf_filter_wave8_kernel<R>, dim3(blocks), dim3(64 * kW8Waves), lds, stream, a);
   CDKF_HIP_CHECK(hipGetLastError());
   return CDKF_OK;
@@ -256,14 +275,14 @@ int launch_ekf_filter_wg(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, i
                          R* fm, R* fP, R* pm, R* pP, int32_t* status, hipStream_t stream) {
   WgArgs<R> a{};
   R* blk = nullptr;
-  ParamSlot* slot = nullptr;
-  int rc = wg_prepare(a, &blk, &slot, mdl, o, N, T, stream);
+  ParamLease lease(stream);
+  int rc = wg_prepare(a, &blk, &lease.slot, mdl, o, N, T, stream);
   if (rc) return rc;
   a.t = t; a.y = y; a.ll = ll; a.fm = fm; a.fP = fP; a.pm = pm; a.pP = pP; a.status = status;
   if (!y) { a.y = t; a.y_sn = a.y_sk = a.y_si = 0; }  // forecast mode: observations are ignored
   rc = (wave8_shape(mdl) && o->solver == CDKF_SOLVER_DOPRI5) ? launch_wave8<R>(a, stream)  // (wave8 carries the Dopri5 constants)
                                                              : launch_wg_dispatch<R>(a, mdl, false, stream);
-  const int rc2 = param_pool_release(slot, stream);
+  const int rc2 = lease.release();
   return rc ? rc : rc2;
 }
 
@@ -277,8 +296,8 @@ int launch_ekf_smoother_wg(const cdkf_model* mdl, const cdkf_opts* o, int64_t N,
   of.num_iter = 1;
   WgArgs<R> a{};
   R* blk = nullptr;
-  ParamSlot* slot = nullptr;
-  int rc = wg_prepare(a, &blk, &slot, mdl, &of, N, T, stream);
+  ParamLease lease(stream);
+  int rc = wg_prepare(a, &blk, &lease.slot, mdl, &of, N, T, stream);
   if (rc) return rc;
   a.t = t; a.y = y; a.ll = ll; a.fm = fm; a.fP = fP; a.pm = nullptr; a.pP = nullptr; a.sm = sm; a.sP = sP; a.status = status;
   if (wave8_shape(mdl) && o->solver == CDKF_SOLVER_DOPRI5) {  // state_dim <= 8: both passes on the wavefront-per-trajectory kernels
@@ -289,7 +308,7 @@ int launch_ekf_smoother_wg(const cdkf_model* mdl, const cdkf_opts* o, int64_t N,
   } else {
     rc = launch_wg_dispatch<R>(a, mdl, true, stream);
   }
-  const int rc2 = param_pool_release(slot, stream);
+  const int rc2 = lease.release();
   return rc ? rc : rc2;
 }
 
@@ -302,15 +321,15 @@ int launch_ukf_filter_wg(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, i
   }
   WgArgs<R> a{};
   R* blk = nullptr;
-  ParamSlot* slot = nullptr;
-  int rc = wg_prepare(a, &blk, &slot, mdl, o, N, T, stream);
+  ParamLease lease(stream);
+  int rc = wg_prepare(a, &blk, &lease.slot, mdl, o, N, T, stream);
   if (rc) return rc;
   a.ukf = 1;
   a.num_iter = 1;
   a.t = t; a.y = y; a.ll = ll; a.fm = fm; a.fP = fP; a.pm = pm; a.pP = pP; a.status = status;
   if (!y) { a.y = t; a.y_sn = a.y_sk = a.y_si = 0; }
   rc = launch_wg_dispatch<R>(a, mdl, false, stream);
-  const int rc2 = param_pool_release(slot, stream);
+  const int rc2 = lease.release();
   return rc ? rc : rc2;
 }
 
@@ -358,12 +377,12 @@ bool adjoint_shape_available(const cdkf_model* mdl, const cdkf_opts* o) {
 
 template <typename R, bool MLP, bool SMOOTH>
 static int launch_adjoint_kernel(const WgArgs<R>& a, R* grad, R* grad_model, hipStream_t stream) {
-  static const int cap_rc = wg_raise_lds_cap(&ekf_adjoint_wave8_kernel<R, MLP, SMOOTH>);
-  if (cap_rc) return CDKF_EHIP;
+  if (once_per_device([] { return wg_raise_lds_cap(&ekf_adjoint_wave8_kernel<R, MLP, SMOOTH>); })) return CDKF_EHIP;
   constexpr int WAVES = adj_waves<R, MLP>();
   constexpr size_t lds = adj_lds_bytes<R, MLP>();
   const dim3 grid((unsigned)((a.N + WAVES - 1) / WAVES)), block(64 * WAVES);
   auto kernel = ekf_adjoint_wave8_kernel<R, MLP, SMOOTH>;
+  note_kernel("ekf_adjoint_wave8_kernel<%s, %s, %s>", real_name<R>(), MLP ? "true" : "false", SMOOTH ? "true" : "false");
   hipLaunchKernelGGL(kernel, grid, block, lds, stream, a, grad, grad_model);
   CDKF_HIP_CHECK(hipGetLastError());
   return CDKF_OK;
@@ -374,11 +393,12 @@ int launch_ekf_grad_adjoint(const cdkf_model* mdl, const cdkf_opts* o, int64_t N
                             R* grad, R* grad_model, int32_t* status, hipStream_t stream) {
   WgArgs<R> a{};
   R* blk = nullptr;
-  ParamSlot* slot = nullptr;
-  int rc = wg_prepare(a, &blk, &slot, mdl, o, N, T, stream);
+  // the workspace lock first, the parameter slot second: a caller waiting for the workspace holds no slot of the ring
+  std::lock_guard<std::mutex> lock(g_adj_mutex);
+  ParamLease lease(stream);
+  int rc = wg_prepare(a, &blk, &lease.slot, mdl, o, N, T, stream);
   if (rc) return rc;
   const size_t nm = (size_t)N * T * mdl->state_dim, nP = nm * mdl->state_dim, bytes = 2 * (nm + nP) * sizeof(R);
-  std::lock_guard<std::mutex> lock(g_adj_mutex);
   AdjWorkspace& ws = g_adj_ws;
   if (int wrc = workspace_reserve(ws, bytes, stream)) return wrc;
   R* w = (R*)ws.p;
@@ -390,7 +410,7 @@ int launch_ekf_grad_adjoint(const cdkf_model* mdl, const cdkf_opts* o, int64_t N
                                                    : launch_adjoint_kernel<R, false>(a, grad, grad_model, stream);
   CDKF_HIP_CHECK(hipEventRecord(ws.done, stream));
   ws.in_flight = true;
-  const int rc2 = param_pool_release(slot, stream);
+  const int rc2 = lease.release();
   return rc ? rc : rc2;
 }
 template int launch_ekf_grad_adjoint<float>(const cdkf_model*, const cdkf_opts*, int64_t, int64_t, const float*, const float*,
@@ -429,16 +449,16 @@ int launch_kf_smoother1(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, in
   of.forecast = 0;
   int rc = launch_ekf_filter<R>(mdl, &of, N, T, t, y, ll, fm, fP, nullptr, nullptr, status, stream);
   if (rc) return rc;
-  static const int cap_rc = wg_raise_lds_cap(pushforward_wave8_kernel<R>) | wg_raise_lds_cap(rts1_wave8_kernel<R>);
-  if (cap_rc) return CDKF_EHIP;
+  if (once_per_device([] { return wg_raise_lds_cap(pushforward_wave8_kernel<R>) | wg_raise_lds_cap(rts1_wave8_kernel<R>); }))
+    return CDKF_EHIP;
   WgArgs<R> a{};
   R* blk = nullptr;
-  ParamSlot* slot = nullptr;
-  rc = wg_prepare(a, &blk, &slot, mdl, &of, N, T, stream);
+  std::lock_guard<std::mutex> lock(g_adj_mutex);
+  ParamLease lease(stream);
+  rc = wg_prepare(a, &blk, &lease.slot, mdl, &of, N, T, stream);
   if (rc) return rc;
   a.t = t; a.y = y; a.ll = ll; a.fm = fm; a.fP = fP; a.sm = sm; a.sP = sP; a.status = status;
   const size_t d = mdl->state_dim, items = (size_t)N * (size_t)(T - 1), bytes = (items ? items : 1) * 2 * d * d * sizeof(R);
-  std::lock_guard<std::mutex> lock(g_adj_mutex);
   AdjWorkspace& ws = g_adj_ws;
   if (int wrc = workspace_reserve(ws, bytes, stream)) return wrc;
   const size_t lds = sizeof(R) * (size_t)kRts1Waves * Rts1Off::end + 64;
@@ -452,7 +472,7 @@ int launch_kf_smoother1(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, in
   CDKF_HIP_CHECK(hipGetLastError());
   CDKF_HIP_CHECK(hipEventRecord(ws.done, stream));
   ws.in_flight = true;
-  return param_pool_release(slot, stream);
+  return lease.release();
 }
 template int launch_kf_smoother1<float>(const cdkf_model*, const cdkf_opts*, int64_t, int64_t, const float*, const float*,
                                         float*, float*, float*, float*, float*, float*, int32_t*, hipStream_t);

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define CDKF_VERSION 104 /* 0.1.0 */
+#define CDKF_VERSION 105 /* 0.2.0 */
 
 /* error codes */
 #define CDKF_OK 0
@@ -343,6 +343,54 @@ int cdkf_grad_sum_f32_dev(const float* grad, int64_t N, int64_t n_theta, double*
  *      the device so that the multi-GPU caller can all-reduce ONE scalar over RCCL. ------------- */
 int cdkf_ll_sum_f64_dev(const double* ll, int64_t N, double* out_sum, void* stream);
 int cdkf_ll_sum_f32_dev(const float* ll, int64_t N, double* out_sum, void* stream);
+
+/* ---- data-parallel reduction: the ONE collective of the path -------------------------------------------------------------------
+ * Trajectories share the parameters and nothing else, so the reference's training losses are `vmap(...)(...).sum()` over the batch
+ * (src/ssm_temissions.py:555-568 for fit_sgd, :665-679 for fit_mcmc).  Sharded over GPUs, each rank sweeps its block, reduces on
+ * the device (cdkf_ll_sum_*_dev, cdkf_grad_sum_*_dev) and the 1 (+ n_theta) doubles are summed in place over RCCL / xGMI
+ * (ncclAllReduce, double, sum) on the same stream -- no host round trip between the sweep and the reduced sum.  RCCL is loaded at
+ * first use; without it these return CDKF_EUNSUPPORTED and everything else works. */
+typedef struct cdkf_comm cdkf_comm;
+#define CDKF_COMM_ID_BYTES 128 /* sizeof(ncclUniqueId) */
+/* one process per GPU: rank 0 makes the id, the ranks exchange it (cdkf_rdv_broadcast below, or any channel of the caller's),
+ * every rank joins with the device it sweeps on */
+int cdkf_comm_unique_id(void* id /* [CDKF_COMM_ID_BYTES] */);
+int cdkf_comm_init_rank(cdkf_comm** comm, const void* id, int rank, int world, int device);
+/* one process driving ndev GPUs: comms[i] lives on devices[i] (NULL: 0 .. ndev-1) */
+int cdkf_comm_init_all(cdkf_comm** comms /* [ndev] */, int ndev, const int* devices);
+int cdkf_comm_rank(const cdkf_comm* comm);
+int cdkf_comm_world(const cdkf_comm* comm);
+/* sums[0 .. count) (device memory) <- the sum over all ranks, in place, enqueued on `stream` */
+int cdkf_ll_allreduce(const cdkf_comm* comm, double* sums, int64_t count, void* stream);
+/* the same with max (the wall-clock maximum over ranks that a benchmark reports) */
+int cdkf_comm_allreduce_max(const cdkf_comm* comm, double* values, int64_t count, void* stream);
+/* single-process form: one grouped call for the ndev communicators of cdkf_comm_init_all */
+int cdkf_ll_allreduce_all(cdkf_comm* const* comms, int ndev, double* const* sums, int64_t count, void* const* streams);
+int cdkf_comm_destroy(cdkf_comm* comm);
+
+/* Host-only rendezvous for process-per-GPU launches (a star over TCP, rank 0 listening on addr:port): hands the RCCL id around
+ * and sums / maximises a few host doubles (rank order: deterministic).  Needs no GPU. */
+typedef struct cdkf_rdv cdkf_rdv;
+int cdkf_rdv_create(cdkf_rdv** rdv, const char* addr, int port, int rank, int world, int timeout_ms);
+int cdkf_rdv_broadcast(cdkf_rdv* rdv, void* buf, int64_t bytes); /* from rank 0 */
+int cdkf_rdv_allreduce(cdkf_rdv* rdv, double* values, int64_t count, int op /* 0 sum, 1 max */);
+int cdkf_rdv_barrier(cdkf_rdv* rdv);
+int cdkf_rdv_destroy(cdkf_rdv* rdv);
+
+/* ---- measurement plumbing ------------------------------------------------------------------------------------------------------
+ * Name of the sweep kernel the calling thread's last filter / smoother / gradient call launched (the one a profile of that call is
+ * dominated by), e.g. "filter_lpe_l63_kernel<double, 3, 1, true>"; "" before the first call.  bench.py matches it against the
+ * kernel names of the committed rocprofv3 summaries. */
+const char* cdkf_last_kernel(void);
+/* HIP events for timing on a stream of the caller's: create, record on `stream`, elapsed milliseconds between two recorded events
+ * (synchronises on the second), destroy.  Streams: create / destroy a non-blocking stream. */
+int cdkf_event_create(void** event);
+int cdkf_event_record(void* event, void* stream);
+int cdkf_event_elapsed_ms(void* start, void* stop, float* ms);
+int cdkf_event_destroy(void* event);
+int cdkf_stream_create(void** stream);
+int cdkf_stream_destroy(void* stream);
+int cdkf_set_device(int device);
 
 #ifdef __cplusplus
 }

@@ -12,11 +12,31 @@ _KIND = {"linear": 0, "lorenz63": 1, "lorenz96": 2}
 _ORDER = {"zeroth": 0, "first": 1, "second": 2}
 
 
+_native = None  # set by build_native(): the library compiled on (and for) this machine
+
+
 def build():
     subprocess.check_call(["make", "-C", _HERE, "-s"])
 
 
+def build_native():
+    """Compile the restatement with -march=native on the machine that is going to time it (the shipped library is built elsewhere
+    for a portable ISA level).  Returns True when that build is now in use; on any failure the portable library stays."""
+    global _native
+    out = os.path.join(_HERE, "_build", "native")
+    try:
+        subprocess.check_call(["make", "-C", _HERE, "-s", "ARCH=native", "OUT=_build/native"], stdout=subprocess.DEVNULL,
+                              stderr=subprocess.DEVNULL)
+        _native = C.CDLL(os.path.join(out, "libcdkf_oracle.so"))
+        return True
+    except Exception:
+        _native = None
+        return False
+
+
 def _lib():
+    if _native is not None:
+        return _native
     if not os.path.exists(_SO):
         build()
     return C.CDLL(_SO)

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol(hip_lib):
 
 
 def test_version_and_default_opts(hip_lib):
-    assert hip_lib.cdkf_version() == 104
+    assert hip_lib.cdkf_version() == 105
     o = _ffi.default_opts()
     assert (o.state_order, o.num_iter, o.t_shared, o.device, o.layout) == (2, 1, 0, -1, 0)
     assert o.max_steps == 100000 and o.dt0 == 0.01 and o.dt_final == 1e-10 and o.cov_rescaling == 1.0
@@ -83,6 +83,24 @@ def test_argument_errors_are_reported(hip_lib):
     # N = 0 is a valid empty batch
     o = _ffi.default_opts()
     assert f(C.byref(blk.c), C.byref(o), 0, 4, vp(t), vp(y), vp(ll), None, None, None, None, None) == _ffi.CDKF_OK
+    # a drift parameter block of the wrong length is refused before anything reads it (a C caller's short theta)
+    for kind, d, good in ((_ffi.DRIFT_LORENZ63, 3, 3), (_ffi.DRIFT_LINEAR, 3, 12)):
+        for bad in (good - 1, good + 1, 0):
+            short = _ffi.ModelBlock(kind, np.ones(max(bad, 1)), np.eye(d), np.eye(d), np.eye(d), np.zeros(d), np.eye(d), np.zeros(d), np.eye(d))
+            short.c.n_theta = bad
+            for fn in (hip_lib.cdkf_ekf_filter_f64, hip_lib.cdkf_ukf_filter_f64):
+                assert fn(C.byref(short.c), C.byref(o), 2, 4, vp(t), vp(y), vp(ll), None, None, None, None, None) == _ffi.CDKF_EINVAL
+            assert b"n_theta" in hip_lib.cdkf_last_error()
+            g = np.zeros((2, 16))
+            assert hip_lib.cdkf_ekf_loglik_grad_f64(C.byref(short.c), C.byref(o), 2, 4, vp(t), vp(y), vp(ll), vp(g), None) == _ffi.CDKF_EINVAL
+
+
+def test_last_kernel_and_plumbing_symbols(hip_lib):
+    assert hip_lib.cdkf_last_kernel() == b"" or isinstance(hip_lib.cdkf_last_kernel(), bytes)
+    ev = C.c_void_p()
+    assert hip_lib.cdkf_event_create(None) == _ffi.CDKF_EINVAL
+    assert hip_lib.cdkf_stream_create(None) == _ffi.CDKF_EINVAL
+    assert hip_lib.cdkf_event_destroy(None) == _ffi.CDKF_OK and hip_lib.cdkf_stream_destroy(None) == _ffi.CDKF_OK
 
 
 def test_no_gpu_means_loud_failure(hip_lib):

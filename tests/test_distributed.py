@@ -173,3 +173,86 @@ def test_two_process_gloo_fit_sgd_matches_single_process(tmp_path):
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count("RANK_OK_") == 2, out.stdout
+
+
+COMM_WORKER = r'''
+import os, sys
+sys.path[:0] = [os.environ["CDKF_ROOT"], os.path.join(os.environ["CDKF_ROOT"], "oracle")]
+import numpy as np
+import cdkf_oracle as o
+from cd_dynamax_amd import distributed as D
+
+rank, world, port = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+comm = D.Comm(rank, world, "127.0.0.1", port, device=None)     # host-only: the library's rendezvous, no RCCL, no torch
+assert "torch" not in sys.modules
+rng = np.random.default_rng(0)
+mdl = o.lorenz63_model(3)
+N, T = 7, 15
+t = o.irregular_times(rng, N, T, 0.1)
+y = o.simulate(mdl, t, rng)
+full = o.ekf_filter(mdl, t, y)["marginal_loglik"]
+# shard -> local log-likelihoods -> the library's all-reduce
+calls = []
+def local(lo, hi):
+    calls.append((lo, hi))
+    return o.ekf_filter(mdl, t[lo:hi], y[lo:hi])["marginal_loglik"]
+total = D.sharded_marginal_log_prob(local, N, comm=comm)
+assert calls == [D.shard_bounds(N, rank, world)], calls
+# rank 0 adds in rank order: the same bits on every rank, equal to the sequential sum of the block sums
+blocks = [full[slice(*D.shard_bounds(N, r, world))].sum() for r in range(world)]
+seq = blocks[0]
+for b in blocks[1:]:
+    seq = seq + b
+assert total == seq, (total, seq)
+assert np.array_equal(comm.allreduce_sum_host(np.arange(5.0) * (rank + 1)), np.arange(5.0) * sum(range(1, world + 1)))
+assert np.array_equal(comm.allreduce_max_host([float(rank), -float(rank)]), [world - 1.0, 0.0])
+tot, g = D.sharded_loglik_and_grad(lambda lo, hi: o.ekf_loglik_grad(mdl, t[lo:hi], y[lo:hi]), N, 3, comm=comm)
+ll_full, g_full = o.ekf_loglik_grad(mdl, t, y)
+assert abs(tot - ll_full.sum()) < 1e-12 * abs(ll_full.sum())
+assert np.allclose(g, g_full.sum(axis=0), rtol=1e-12, atol=1e-12)
+try:
+    comm.allreduce_sum_dev(None, 1)
+    raise SystemExit("a host-only communicator must refuse the device collective")
+except RuntimeError:
+    pass
+comm.barrier()
+comm.close()
+sys.stdout.write("RANK_OK_%d\n" % rank); sys.stdout.flush()
+'''
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_library_rendezvous_allreduce_across_processes(tmp_path, world):
+    """The N > 1 composition through the library's OWN collective entry points (cdkf_rdv_*; the RCCL leg needs GPUs): plain
+    processes, no torch, shard -> local sums -> all-reduce."""
+    script = tmp_path / "comm_worker.py"
+    script.write_text(COMM_WORKER)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, CDKF_ROOT=ROOT, OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(world), str(port)], env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, so + se
+    assert sum(so.count("RANK_OK_") for so, _ in outs) == world
+
+
+def test_rendezvous_argument_and_timeout_errors():
+    import ctypes as C
+    from cd_dynamax_amd import _ffi
+    L = _ffi.lib()
+    h = C.c_void_p()
+    assert L.cdkf_rdv_create(C.byref(h), b"127.0.0.1", 0, 0, 2, 100) == _ffi.CDKF_EINVAL
+    assert L.cdkf_rdv_create(C.byref(h), b"127.0.0.1", 1234, 2, 2, 100) == _ffi.CDKF_EINVAL
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    # nobody listens: rank 1 gives up after the timeout with a message, no hang
+    rc = L.cdkf_rdv_create(C.byref(h), b"127.0.0.1", port, 1, 2, 300)
+    assert rc != 0 and b"cannot reach rank 0" in L.cdkf_last_error()
+    # rank 0 alone: the others never arrive
+    rc = L.cdkf_rdv_create(C.byref(h), b"127.0.0.1", port, 0, 2, 300)
+    assert rc != 0 and b"ranks arrived" in L.cdkf_last_error()
+    assert L.cdkf_ll_allreduce(None, None, 1, None) == _ffi.CDKF_EINVAL

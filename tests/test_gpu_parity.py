@@ -326,6 +326,85 @@ def test_c2_full_size_properties(hip_lib):
     assert relerr(outs32[0][sub], ref["filtered_means"]) < 1e-4
 
 
+def test_unscented_filter_on_the_lane_grid(hip_lib, tmp_path):
+    """Small Lorenz-63 batches with H = I run the unscented filter on filter_lpe_l63_kernel<..., UKF = true>, whose moment
+    equations are the sigma-point sums of inference_ukf.py:124-143 collapsed for this (quadratic) drift.  Against the oracle,
+    which forms the sigma points literally: default and non-default (alpha, beta, kappa), odd / even T, N not a multiple of
+    four, every output mode, long gaps, fp32; against the lane-per-trajectory kernel, which also forms them
+    (CDKF_UKF_SIGMA_POINTS=1, read once per process: a child process); and the reference's NaN when the covariance the update
+    draws its sigma points from is not positive definite."""
+    import os, subprocess, sys
+    rng = np.random.default_rng(21)
+    mdl = o.lorenz63_model(3)
+    P = params_from(mdl)
+    for (N, T), hyp, kw in (((7, 31), cd.UKFHyperParams(), {}), ((6, 30), cd.UKFHyperParams(alpha=0.7, beta=1.5, kappa=0.5),
+                                                                  dict(alpha=0.7, beta=1.5, kappa=0.5)),
+                            ((1, 2), cd.UKFHyperParams(), {}), ((3, 1), cd.UKFHyperParams(), {})):
+        t = o.irregular_times(rng, N, T, 0.008 * T)
+        y = o.simulate(mdl, t, rng)
+        ref = o.ukf_filter(mdl, t, y, **kw)
+        _check_filter(cd.cdnlgssm_filter(P, y, t[..., None], hyp), ref, 1e-9)
+        post = cd.cdnlgssm_filter(P, y, t[..., None], hyp, output_fields=[])
+        assert relerr(post.marginal_loglik, ref["marginal_loglik"]) < 1e-9
+        post = cd.cdnlgssm_filter(P, y, t[..., None], hyp, output_fields=["filtered_means", "filtered_covariances"])
+        assert relerr(post.filtered_covariances, ref["filtered_covariances"]) < 1e-9
+    assert hip_lib.cdkf_last_kernel().startswith(b"filter_lpe_l63_kernel<double, 3, 2, true, true>")
+    t = o.irregular_times(rng, 9, 25, 1.5)  # up to ~12 Dormand-Prince steps per interval
+    y = o.simulate(mdl, t, rng)
+    ref = o.ukf_filter(mdl, t, y)
+    _check_filter(cd.cdnlgssm_filter(P, y, t[..., None], cd.UKFHyperParams()), ref, 1e-9)
+    _check_filter(cd.cdnlgssm_filter(P, y.astype(np.float32), t[..., None], cd.UKFHyperParams()), ref, 3e-5)
+    # the same call in a process that keeps the sigma-point kernel
+    np.savez(tmp_path / "in.npz", t=t, y=y)
+    code = ("import sys, numpy as np; sys.path[:0] = [%r, %r, %r]\n"
+            "import cd_dynamax_amd as cd, cdkf_oracle as o\nfrom cd_dynamax_amd import _ffi\nfrom helpers import params_from\n"
+            "d = np.load(%r); post = cd.cdnlgssm_filter(params_from(o.lorenz63_model(3)), d['y'], d['t'][..., None], cd.UKFHyperParams())\n"
+            "assert _ffi.lib().cdkf_last_kernel().startswith(b'filter_reg_kernel'), _ffi.lib().cdkf_last_kernel()\n"
+            "np.savez(%r, ll=post.marginal_loglik, fm=post.filtered_means, pP=post.predicted_covariances)\n"
+            % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(o.__file__)),
+               os.path.dirname(os.path.abspath(__file__)), str(tmp_path / "in.npz"), str(tmp_path / "out.npz")))
+    subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CDKF_UKF_SIGMA_POINTS="1"), check=True, timeout=600)
+    other = np.load(tmp_path / "out.npz")
+    post = cd.cdnlgssm_filter(P, y, t[..., None], cd.UKFHyperParams())
+    assert relerr(post.marginal_loglik, other["ll"]) < 1e-11 and relerr(post.filtered_means, other["fm"]) < 1e-11
+    assert relerr(post.predicted_covariances, other["pP"]) < 1e-11
+    # an indefinite initial covariance: chol(P) of the first update's sigma points is NaN in the reference (S = P + R is fine)
+    Pbad = np.array([[1.0, 2.0, 0.0], [2.0, 1.0, 0.0], [0.0, 0.0, 1.0]])
+    bad = o.Model(mdl.drift, mdl.L, mdl.Qc, mdl.H, mdl.bias, 5.0 * np.eye(3), mdl.m0, Pbad)
+    assert np.isnan(o.ukf_filter(bad, t[:2], y[:2])["marginal_loglik"]).all()
+    opts = _ffi.default_opts()
+    ll, outs, st, _ = _run_dev(hip_lib, "ukf_filter", models._model_block(params_from(bad)), opts, t[:2], y[:2], np.float64, _ffi.LAYOUT_TCN)
+    assert np.isnan(ll).all() and (st & _ffi.STATUS_NOT_PD).all() and np.isnan(outs[0]).all()
+
+
+def test_c3_full_size_properties(hip_lib):
+    """BASELINE config 3 (Lorenz-63 UKF, 4096 x 1000, fp32) through size-independent properties: a random subset re-run alone
+    through the fp64 ORACLE (literal sigma points) matches the fp32 sweep -- filtered means within 1e-5 (the north-star bar; the
+    reference itself computes in float32), log-likelihoods within 1e-5 --, no flag is raised, and the fp64 sweep of the same
+    batch matches the oracle to 1e-9."""
+    rng = np.random.default_rng(3)
+    mdl = o.lorenz63_model(3)
+    N, T = 4096, 1000
+    t = o.irregular_times(rng, N, T, 0.005 * T)
+    y = (rng.standard_normal((N, T, 3)) * 3.0)
+    sub = rng.choice(N, size=5, replace=False)
+    y[sub] = o.simulate(mdl, t[sub], rng)
+    blk = models._model_block(params_from(mdl))
+    ref = o.ukf_filter(mdl, t[sub], y[sub])
+    ll, outs, st, llsum = _run_dev(hip_lib, "ukf_filter", blk, _ffi.default_opts(), t, y, np.float32, _ffi.LAYOUT_TCN)
+    assert hip_lib.cdkf_last_kernel().startswith(b"filter_lpe_l63_kernel<float, 3, 1, true, true>")
+    assert (st == 0).all() and np.isfinite(ll).all()
+    assert abs(llsum - ll.astype(np.float64).sum()) < 1e-6 * abs(llsum)
+    assert relerr(ll[sub], ref["marginal_loglik"]) < 1e-5
+    assert relerr(outs[0][sub], ref["filtered_means"]) < 1e-5
+    assert relerr(outs[1][sub], ref["filtered_covariances"]) < 3e-5
+    ll, outs, st, _ = _run_dev(hip_lib, "ukf_filter", blk, _ffi.default_opts(), t, y, np.float64, _ffi.LAYOUT_TCN)
+    assert (st == 0).all()
+    assert relerr(ll[sub], ref["marginal_loglik"]) < 1e-9
+    for a, k in zip(outs, FILTER_KEYS):
+        assert relerr(a[sub], ref[k]) < 1e-9, k
+
+
 def test_reference_known_answer_constants_through_the_hip_kernels(hip_lib):
     """The reference's Dopri5 push-forward constants (src/test_scripts/cdlgssm_test_filter_TRegular.py:59-60) through
     the fp32 HIP EKF itself: F = -0.1 I, L = Qc = 0.5 I, unit interval, R huge so that the update is a no-op; the
