@@ -4,6 +4,7 @@
 #include "cdkf_wave8_kernels.h"
 #include "cdkf_adjoint_kernels.h"
 #include "cdkf_rts1_kernels.h"
+#include "cdkf_wave40_kernels.h"
 
 #include <mutex>
 
@@ -270,6 +271,34 @@ static int launch_wave8(const WgArgs<R>& a, hipStream_t stream) {
   return CDKF_OK;
 }
 
+// Lorenz-96 with H = I at state_dim 40 (BASELINE config 4): wavefront-per-trajectory sweep (cdkf_wave40_kernels.h)
+static bool wave40_shape(const cdkf_model* mdl, const cdkf_opts* o) {
+  if (getenv("CDKF_NO_WAVE40")) return false;  // A/B and tests: keep the workgroup kernels
+  const int d = mdl->state_dim;
+  if (mdl->drift_kind != CDKF_DRIFT_LORENZ96 || d != 40 || mdl->emission_dim != d || !emission_is_selection(mdl)) return false;
+  if (o->num_iter != 1 || o->forecast || o->state_order == CDKF_ORDER_ZEROTH || o->solver != CDKF_SOLVER_DOPRI5 || o->adaptive)
+    return false;
+  for (int r = 0; r < d; ++r)
+    for (int c = 0; c < r; ++c)
+      if (mdl->R[r * d + c] != mdl->R[c * d + r]) return false;  // P - X^T S X is formed as P - Y^T Y + 1e-9 X^T X
+  return true;
+}
+
+template <typename R>
+static int launch_wave40(const WgArgs<R>& a, hipStream_t stream) {
+  constexpr int D = 40;
+  if (once_per_device([] { return wg_raise_lds_cap(ekf_filter_wave_l96_kernel<R, D>); })) return CDKF_EHIP;
+  const size_t lds = sizeof(R) * (size_t)wave40_lds_reals<D>() + 64;
+  const unsigned blocks = (unsigned)((a.N + W40<D>::kWaves - 1) / W40<D>::kWaves);
+  note_kernel("ekf_filter_wave_l96_kernel<%s, %d>", real_name<R>(), D);
+  WgArgs<R> b = a;
+  const char* ab = getenv("CDKF_W40_ABLATE");  // diagnostic: mask of phases to skip (see the kernel); never set in production
+  b.forecast = ab ? atoi(ab) : 0;
+  hipLaunchKernelGGL((ekf_filter_wave_l96_kernel<R, D>), dim3(blocks), dim3(64 * W40<D>::kWaves), lds, stream, b);
+  CDKF_HIP_CHECK(hipGetLastError());
+  return CDKF_OK;
+}
+
 template <typename R>
 int launch_ekf_filter_wg(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll,
                          R* fm, R* fP, R* pm, R* pP, int32_t* status, hipStream_t stream) {
@@ -280,8 +309,11 @@ int launch_ekf_filter_wg(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, i
   if (rc) return rc;
   a.t = t; a.y = y; a.ll = ll; a.fm = fm; a.fP = fP; a.pm = pm; a.pP = pP; a.status = status;
   if (!y) { a.y = t; a.y_sn = a.y_sk = a.y_si = 0; }  // forecast mode: observations are ignored
-  rc = (wave8_shape(mdl) && o->solver == CDKF_SOLVER_DOPRI5) ? launch_wave8<R>(a, stream)  // (wave8 carries the Dopri5 constants)
-                                                             : launch_wg_dispatch<R>(a, mdl, false, stream);
+  if (wave40_shape(mdl, o) && y)
+    rc = launch_wave40<R>(a, stream);
+  else
+    rc = (wave8_shape(mdl) && o->solver == CDKF_SOLVER_DOPRI5) ? launch_wave8<R>(a, stream)  // (wave8 carries the Dopri5 constants)
+                                                               : launch_wg_dispatch<R>(a, mdl, false, stream);
   const int rc2 = lease.release();
   return rc ? rc : rc2;
 }
@@ -305,6 +337,9 @@ int launch_ekf_smoother_wg(const cdkf_model* mdl, const cdkf_opts* o, int64_t N,
     if (!rc)
       rc = (mdl->drift_kind == CDKF_DRIFT_MLP_TANH) ? launch_adjoint_kernel<R, true, true>(a, nullptr, nullptr, stream)
                                                      : launch_adjoint_kernel<R, false, true>(a, nullptr, nullptr, stream);
+  } else if (wave40_shape(mdl, &of)) {  // d = 40: forward pass on the wavefront-per-trajectory sweep, backward on the workgroup kernel
+    rc = launch_wave40<R>(a, stream);
+    if (!rc) rc = launch_wg_dispatch<R>(a, mdl, true, stream, false);
   } else {
     rc = launch_wg_dispatch<R>(a, mdl, true, stream);
   }
