@@ -20,6 +20,20 @@ constexpr int kW8 = 8;        // lane grid is 8 x 8
 constexpr int kHid = 64;      // hidden units padded to the wavefront width
 constexpr int kW8Waves = 4;   // trajectories per workgroup
 
+// accumulator row of register r in lane group g = lane >> 4 (C/D layout of v_mfma_f64_16x16x4 / v_mfma_f32_16x16x4)
+template <typename R>
+struct W8Tile;
+template <>
+struct W8Tile<double> {
+  using V4 = wg_f64x4;
+  static CDKF_DEV int row(int g, int r) { return g + 4 * r; }
+};
+template <>
+struct W8Tile<float> {
+  using V4 = wg_f32x4;
+  static CDKF_DEV int row(int g, int r) { return 4 * g + r; }
+};
+
 CDKF_DEV void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
@@ -96,20 +110,37 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave8_kernel(const WgArgs<R
   const R hbj = (lane < m) ? (a.par + a.o_hb)[lane] : R(0);
   const R Wlin = (a.kind == kDriftLinear && inP) ? th[i * d + j] : R(0);    // linear drift: lane (i,k) holds W[i][k]
   const R blin = (a.kind == kDriftLinear && lane < d) ? th[d * d + lane] : R(0);
-  R w1row[kW8], w2row[kHid], gmrow[kHid];
+  // MLP: the layer products run on the matrix cores (v_mfma_*_16x16x4: A[m = lane & 15][k = lane >> 4], B[k][n = lane & 15]).
+  // Operands that are weights stay in registers for the whole sweep, in the layout the instruction wants:
+  //   w2A[mt][ks] = W2[16 mt + lm][4 ks + lg]                     A operand of  [T | z2] = W2 [D1 W1 | a1]      (64 x 64 x 9)
+  //   w1B[ks]     = W1[4 ks + lg][lm] (lm < 8)                    weight part of that product's B operand
+  //   w3A[mt][r]  = W3[lm][16 mt + row(lg, r)] (lm < 8)           A operand of  [F | f] = W3 [D2 T | a2]        (8 x 64 x 9):
+  //                 its k-steps are taken in the order in which the first product's accumulator holds the rows of T, so the
+  //                 accumulator registers ARE the B operand (scaled by d2): no data movement between the two products.
+  // (the rows of W2 / G that the scalar code kept pinned -- 128 registers each -- are gone; grad(div f) uses
+  //  s_p = sum_i W3[i][p] T[p][i] instead of sum_q G[p][q] d1_q: the same number, from the tangent that is already there)
+  using MTile = W8Tile<R>;
+  const int lm = lane & 15, lg = lane >> 4;
+  R w1row[kW8], w3col[kW8], w2A[4][16], w1B[16], w3A[4][4];
   R b1l = 0, b2l = 0;
+  const R e8 = (lm == 8) ? R(1) : R(0), ne8 = (lm == 8) ? R(0) : R(1);
+  const int sc_off = (lm == 8) ? W8Off::a2 : W8Off::d2;  // column 8 of the second product carries a2 (the drift itself)
   const bool second = (a.order == 2) && mlp;
   if (mlp) {
 #pragma unroll
-    for (int jj = 0; jj < kW8; ++jj) w1row[jj] = pin(Sh[W8Sh::W1 + lane * kW8 + jj]);
-    // pin(): the rows must stay in VGPRs -- re-reading them from LDS inside the loops would be a 64-way bank
-    // conflict (lane p reads row p: stride 64 elements)
-#pragma unroll
-    for (int q = 0; q < kHid; ++q) w2row[q] = pin(Sh[W8Sh::W2 + lane * kHid + q]);
-    if (second) {
-#pragma unroll
-      for (int q = 0; q < kHid; ++q) gmrow[q] = pin(Sh[W8Sh::Gm + lane * kHid + q]);
+    for (int jj = 0; jj < kW8; ++jj) {
+      w1row[jj] = pin(Sh[W8Sh::W1 + lane * kW8 + jj]);
+      w3col[jj] = pin(Sh[W8Sh::W3 + jj * 65 + lane]);
     }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) w2A[mt][ks] = pin(Sh[W8Sh::W2 + (16 * mt + lm) * kHid + 4 * ks + lg]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) w3A[mt][r] = pin(lm < kW8 ? Sh[W8Sh::W3 + lm * 65 + 16 * mt + MTile::row(lg, r)] : R(0));
+    }
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) w1B[ks] = pin(lm < kW8 ? Sh[W8Sh::W1 + (4 * ks + lg) * kW8 + lm] : R(0));
     b1l = Sh[W8Sh::b1 + lane];
     b2l = Sh[W8Sh::b2 + lane];
   }
@@ -121,9 +152,6 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave8_kernel(const WgArgs<R
   int st = 0;
   bool bad = false;
   const bool zeroth = a.order == 0;
-  // explicit double-buffering of LDS reads pays in fp32; in fp64 the pinned weight rows already fill the register
-  // file and a second buffer spills to scratch (measured 2.7x slower), so fp64 loads each chunk right before use
-  constexpr bool kPrefetch = sizeof(R) == 4;
 
   // right-hand side of the moment ODEs for the stage value (xs: mean on lanes < d, Ps: this lane's covariance entry)
   auto rhs = [&](R xs, R Ps, R& kM, R& kP) {
@@ -171,7 +199,6 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave8_kernel(const WgArgs<R
         fi = rfma(X(lp1) - X(lm2), X(lm1), th[0] - X(l));
       }
     } else {  // MLP
-      if constexpr (kPrefetch) {  // fp32: explicitly double-buffered LDS reads
       // layer 1: lane = hidden unit q
       R z1 = b1l;
 #pragma unroll
@@ -180,251 +207,62 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave8_kernel(const WgArgs<R
       const R d1 = R(1) - a1 * a1;
       W[W8Off::a1 + lane] = a1;
       W[W8Off::d1 + lane] = d1;
-      if (!zeroth) {
+      wave_sync();
+      // layer 2 on the matrix cores: acc[mt][r] = [T | z2 - b2][16 mt + row(lg, r)][lm],  T = W2 D1 W1 (tangent), column 8: W2 a1
+      typename MTile::V4 acc[4];
 #pragma unroll
-        for (int k = 0; k < kW8; ++k) W[W8Off::U + lane * kW8 + k] = d1 * w1row[k];
+      for (int mt = 0; mt < 4; ++mt) acc[mt] = typename MTile::V4{0, 0, 0, 0};
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        const R dq = W[W8Off::d1 + 4 * ks + lg], aq = W[W8Off::a1 + 4 * ks + lg];
+        const R bv = rfma(dq, w1B[ks], aq * e8);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[mt] = wg_mfma(w2A[mt][ks], bv, acc[mt]);
+      }
+      if (lm == 8) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) W[W8Off::s2 + 16 * mt + MTile::row(lg, r)] = acc[mt][r];
+      }
+      if (second && lm < kW8) {  // rows of T for grad(div f): s_p = sum_i W3[i][p] T[p][i]
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) W[W8Off::U + (16 * mt + MTile::row(lg, r)) * 9 + lm] = acc[mt][r];
       }
       wave_sync();
-      // layer 2: lane = hidden unit p; z2 and the tangent T[p][:] = sum_q W2[p][q] U[q][:]
-      R z2 = b2l;
-      R T[kW8];
-#pragma unroll
-      for (int k = 0; k < kW8; ++k) T[k] = 0;
-      // (explicitly double-buffered in chunks of 4 hidden units: a lone wavefront has no other wave to hide the
-      //  ~100-cycle LDS round trip, so the next chunk's loads are in flight while this chunk's FMAs issue)
-      if (!zeroth) {
-        constexpr int CQ = (sizeof(R) == 8) ? 2 : 4;  // fp64: the pinned rows already fill the register file
-        R ub[2][CQ][kW8], ab[2][CQ];
-        auto ld = [&](int b, int q0) {
-#pragma unroll
-          for (int qq = 0; qq < CQ; ++qq) {
-            ab[b][qq] = W[W8Off::a1 + q0 + qq];
-#pragma unroll
-            for (int k = 0; k < kW8; ++k) ub[b][qq][k] = W[W8Off::U + (q0 + qq) * kW8 + k];
-          }
-        };
-        if (kPrefetch) ld(0, 0);
-#pragma unroll
-        for (int c = 0; c < kHid / CQ; ++c) {
-          const int b = kPrefetch ? (c & 1) : 0;
-          if (kPrefetch) {
-            if (c + 1 < kHid / CQ) ld(b ^ 1, CQ * (c + 1));
-          } else {
-            __builtin_amdgcn_sched_barrier(0);  // keep this chunk's loads behind the previous chunk's FMAs
-            ld(0, CQ * c);
-          }
-#pragma unroll
-          for (int qq = 0; qq < CQ; ++qq) {
-            const R w = w2row[CQ * c + qq];
-            z2 = rfma(w, ab[b][qq], z2);
-#pragma unroll
-            for (int k = 0; k < kW8; ++k) T[k] = rfma(w, ub[b][qq][k], T[k]);
-          }
-        }
-      } else {
-        R ab[2][16];
-        auto ld = [&](int b, int q0) {
-#pragma unroll
-          for (int qq = 0; qq < 16; ++qq) ab[b][qq] = W[W8Off::a1 + q0 + qq];
-        };
-        if (kPrefetch) ld(0, 0);
-#pragma unroll
-        for (int c = 0; c < kHid / 16; ++c) {
-          const int b = kPrefetch ? (c & 1) : 0;
-          if (kPrefetch) {
-            if (c + 1 < kHid / 16) ld(b ^ 1, 16 * (c + 1));
-          } else {
-            __builtin_amdgcn_sched_barrier(0);  // keep this chunk's loads behind the previous chunk's FMAs
-            ld(0, 16 * c);
-          }
-#pragma unroll
-          for (int qq = 0; qq < 16; ++qq) z2 = rfma(w2row[16 * c + qq], ab[b][qq], z2);
-        }
-      }
+      const R z2 = W[W8Off::s2 + lane] + b2l;  // lane = hidden unit p
       const R a2 = rtanh(z2);
       const R d2 = R(1) - a2 * a2;
       W[W8Off::a2 + lane] = a2;
       W[W8Off::d2 + lane] = d2;
-      if (!zeroth) {
+      R sdiv = 0;
+      if (second) {
 #pragma unroll
-        for (int k = 0; k < kW8; ++k) W[W8Off::V + lane * kW8 + k] = d2 * T[k];
+        for (int k = 0; k < kW8; ++k) sdiv = rfma(w3col[k], W[W8Off::U + lane * 9 + k], sdiv);
       }
       wave_sync();
-      // layer 3: lane (i, j): F[i][j] = sum_p W3[i][p] V[p][j]; row sums of W3 a2 give f_i (kept by lanes with j == 0)
-      R fs = 0;
-      {
-        constexpr int CP = (sizeof(R) == 8) ? 4 : 8;
-        R w3b[2][CP], vb[2][CP], a2b[2][CP];
-        auto ld = [&](int b, int p0) {
+      // layer 3 on the matrix cores: the accumulator rows are this product's k index, scaled by d2 (column 8: a2 itself)
+      typename MTile::V4 acc3{0, 0, 0, 0};
 #pragma unroll
-          for (int pp = 0; pp < CP; ++pp) {
-            w3b[b][pp] = Sh[W8Sh::W3 + i * 65 + p0 + pp];
-            a2b[b][pp] = W[W8Off::a2 + p0 + pp];
-            if (!zeroth) vb[b][pp] = W[W8Off::V + (p0 + pp) * kW8 + j];
-          }
-        };
-        if (kPrefetch) ld(0, 0);
+      for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int c = 0; c < kHid / CP; ++c) {
-          const int b = kPrefetch ? (c & 1) : 0;
-          if (kPrefetch) {
-            if (c + 1 < kHid / CP) ld(b ^ 1, CP * (c + 1));
-          } else {
-            __builtin_amdgcn_sched_barrier(0);  // keep this chunk's loads behind the previous chunk's FMAs
-            ld(0, CP * c);
-          }
-#pragma unroll
-          for (int pp = 0; pp < CP; ++pp) {
-            fs = rfma(w3b[b][pp], a2b[b][pp], fs);
-            if (!zeroth) Fij = rfma(w3b[b][pp], vb[b][pp], Fij);
-          }
+        for (int r = 0; r < 4; ++r) {
+          const R sc = W[sc_off + 16 * mt + MTile::row(lg, r)];
+          const R bv = sc * rfma(acc[mt][r], ne8, e8);
+          acc3 = wg_mfma(w3A[mt][r], bv, acc3);
         }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = MTile::row(lg, r);
+        if (row < kW8 && lm < kW8) W[W8Off::A + row * kW8 + lm] = acc3[r];       // F[row][lm]
+        if (row < kW8 && lm == 8) W[W8Off::f + row] = acc3[r] + Sh[W8Sh::b3 + row];
       }
-      if (!inP) Fij = 0;
-      // f_i sits on lanes (i, *); move it to lane i
-      if (j == 0) W[W8Off::f + i] = fs + Sh[W8Sh::b3 + i];
       R gl = 0;
       if (second) {
-        // g = grad(div f):  s2_p = dd2_p sum_q G[p][q] d1_q ;  tq_q = dd1_q sum_p d2_p G[p][q] + d1_q sum_p s2_p W2[p][q]
-        R s = 0;
-        {
-          constexpr int CD = (sizeof(R) == 8) ? 8 : 16;
-          R db[2][CD];
-          auto ld = [&](int b, int q0) {
-#pragma unroll
-            for (int qq = 0; qq < CD; ++qq) db[b][qq] = W[W8Off::d1 + q0 + qq];
-          };
-          if (kPrefetch) ld(0, 0);
-#pragma unroll
-          for (int c = 0; c < kHid / CD; ++c) {
-            const int b = kPrefetch ? (c & 1) : 0;
-            if (kPrefetch) {
-              if (c + 1 < kHid / CD) ld(b ^ 1, CD * (c + 1));
-            } else {
-              __builtin_amdgcn_sched_barrier(0);  // keep this chunk's loads behind the previous chunk's FMAs
-              ld(0, CD * c);
-            }
-#pragma unroll
-            for (int qq = 0; qq < CD; ++qq) s = rfma(gmrow[CD * c + qq], db[b][qq], s);
-          }
-        }
-        W[W8Off::s2 + lane] = R(-2) * a2 * d2 * s;
-        wave_sync();
-        R td = 0, tc = 0;
-        {
-          constexpr int CT = (sizeof(R) == 8) ? 4 : 8;
-          R d2b[2][CT], gb[2][CT], s2b[2][CT], wb[2][CT];
-          auto ld = [&](int b, int p0) {
-#pragma unroll
-            for (int pp = 0; pp < CT; ++pp) {
-              d2b[b][pp] = W[W8Off::d2 + p0 + pp];
-              gb[b][pp] = Sh[W8Sh::Gm + (p0 + pp) * kHid + lane];
-              s2b[b][pp] = W[W8Off::s2 + p0 + pp];
-              wb[b][pp] = Sh[W8Sh::W2 + (p0 + pp) * kHid + lane];
-            }
-          };
-          if (kPrefetch) ld(0, 0);
-#pragma unroll
-          for (int c = 0; c < kHid / CT; ++c) {
-            const int b = kPrefetch ? (c & 1) : 0;
-            if (kPrefetch) {
-              if (c + 1 < kHid / CT) ld(b ^ 1, CT * (c + 1));
-            } else {
-              __builtin_amdgcn_sched_barrier(0);  // keep this chunk's loads behind the previous chunk's FMAs
-              ld(0, CT * c);
-            }
-#pragma unroll
-            for (int pp = 0; pp < CT; ++pp) {
-              td = rfma(d2b[b][pp], gb[b][pp], td);
-              tc = rfma(s2b[b][pp], wb[b][pp], tc);
-            }
-          }
-        }
-        W[W8Off::tq + lane] = td * (R(-2) * a1 * d1) + tc * d1;
-        wave_sync();
-        {
-          // g_l = sum_q tq[q] W1[q][l] for l < 8: every lane (i, j) sums the 8 hidden units q = 8 c + i of column j,
-          // the 8 partial sums of a column meet in the tile
-          R part = 0;
-#pragma unroll
-          for (int c = 0; c < kHid / 8; ++c) part = rfma(W[W8Off::tq + 8 * c + i], Sh[W8Sh::W1 + (8 * c + i) * kW8 + j], part);
-          W[W8Off::A + lane] = part;
-          wave_sync();
-          if (lane < kW8) {
-#pragma unroll
-            for (int r = 0; r < kW8; ++r) gl += W[W8Off::A + r * kW8 + lane];
-          }
-        }
-      }
-      wave_sync();
-      if (lane < kW8) {
-        fi = W[W8Off::f + lane];
-        if (second) W[W8Off::g + lane] = gl;
-      }
-      wave_sync();
-      } else {  // fp64: plain loops (a second buffer would spill the pinned weight rows)
-      // layer 1: lane = hidden unit q
-      R z1 = b1l;
-#pragma unroll
-      for (int k = 0; k < kW8; ++k) z1 = rfma(w1row[k], xk[k], z1);
-      const R a1 = rtanh(z1);
-      const R d1 = R(1) - a1 * a1;
-      W[W8Off::a1 + lane] = a1;
-      W[W8Off::d1 + lane] = d1;
-      if (!zeroth) {
-#pragma unroll
-        for (int k = 0; k < kW8; ++k) W[W8Off::U + lane * kW8 + k] = d1 * w1row[k];
-      }
-      wave_sync();
-      // layer 2: lane = hidden unit p; z2 and the tangent T[p][:] = sum_q W2[p][q] U[q][:]
-      R z2 = b2l;
-      R T[kW8];
-#pragma unroll
-      for (int k = 0; k < kW8; ++k) T[k] = 0;
-      if (!zeroth) {
-#pragma unroll
-        for (int q = 0; q < kHid; ++q) {
-          const R w = w2row[q];
-          z2 = rfma(w, W[W8Off::a1 + q], z2);
-#pragma unroll
-          for (int k = 0; k < kW8; ++k) T[k] = rfma(w, W[W8Off::U + q * kW8 + k], T[k]);
-        }
-      } else {
-#pragma unroll
-        for (int q = 0; q < kHid; ++q) z2 = rfma(w2row[q], W[W8Off::a1 + q], z2);
-      }
-      const R a2 = rtanh(z2);
-      const R d2 = R(1) - a2 * a2;
-      W[W8Off::a2 + lane] = a2;
-      W[W8Off::d2 + lane] = d2;
-      if (!zeroth) {
-#pragma unroll
-        for (int k = 0; k < kW8; ++k) W[W8Off::V + lane * kW8 + k] = d2 * T[k];
-      }
-      wave_sync();
-      // layer 3: lane (i, j): F[i][j] = sum_p W3[i][p] V[p][j]; row sums of W3 a2 give f_i (kept by lanes with j == 0)
-      R fs = 0;
-      if (!zeroth) {
-#pragma unroll 8
-        for (int p = 0; p < kHid; ++p) {
-          const R w3 = Sh[W8Sh::W3 + i * 65 + p];
-          Fij = rfma(w3, W[W8Off::V + p * kW8 + j], Fij);
-          fs = rfma(w3, W[W8Off::a2 + p], fs);
-        }
-      } else {
-#pragma unroll 8
-        for (int p = 0; p < kHid; ++p) fs = rfma(Sh[W8Sh::W3 + i * 65 + p], W[W8Off::a2 + p], fs);
-      }
-      if (!inP) Fij = 0;
-      // f_i sits on lanes (i, *); move it to lane i
-      if (j == 0) W[W8Off::f + i] = fs + Sh[W8Sh::b3 + i];
-      R gl = 0;
-      if (second) {
-        // g = grad(div f):  s2_p = dd2_p sum_q G[p][q] d1_q ;  tq_q = dd1_q sum_p d2_p G[p][q] + d1_q sum_p s2_p W2[p][q]
-        R s = 0;
-#pragma unroll
-        for (int q = 0; q < kHid; ++q) s = rfma(gmrow[q], W[W8Off::d1 + q], s);
-        W[W8Off::s2 + lane] = R(-2) * a2 * d2 * s;
+        // g = grad(div f):  s2_p = dd2_p s_p ;  tq_q = dd1_q sum_p d2_p G[p][q] + d1_q sum_p s2_p W2[p][q]
+        W[W8Off::s2 + lane] = R(-2) * a2 * d2 * sdiv;
         wave_sync();
         R td = 0, tc = 0;
 #pragma unroll 8
@@ -440,12 +278,12 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave8_kernel(const WgArgs<R
         }
       }
       wave_sync();
+      Fij = inP ? W[W8Off::A + lane] : R(0);
       if (lane < kW8) {
         fi = W[W8Off::f + lane];
         if (second) W[W8Off::g + lane] = gl;
       }
       wave_sync();
-      }
     }
     if (lane < kW8) kM = (lane < d) ? fi : R(0);
     if (zeroth) return;
