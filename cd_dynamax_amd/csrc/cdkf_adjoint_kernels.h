@@ -15,9 +15,11 @@
 //
 // Mapping: one wavefront per trajectory as in cdkf_wave8_kernels.h -- lane (i, j) owns entry (i, j) of every 8 x 8 tile
 // (P, its adjoint, the stage slopes and their adjoints stay in registers), lane p is hidden unit p in the MLP passes and
-// accumulates row p of dW2 (64 registers), row p of dW1, column p of dW3 and its bias entries for the whole sweep: the
-// parameter gradient never leaves registers until the final store.  W2 is read from LDS in both orientations
-// (W2T[q][p] for the forward matvec, W2[p][q] for the transposed one) so that lanes always hit consecutive banks.
+// accumulates row p of dW1, column p of dW3 and its bias entries for the whole sweep, dW2 lives in sixteen matrix-core
+// accumulator tiles: the parameter gradient never leaves registers until the final store.  The three 64 x 64 x 9 products of a
+// right-hand-side adjoint (tangent W2 [D1 W1 | a1], weight update [zt2 | z2b] [D1 W1 | a1]^T, transposed [zt2 | z2b]^T W2) run as
+// v_mfma_*_16x16x4; W2 sits in LDS once with rows padded to 65, which serves it along p (A operand of the first) and along q (B
+// operand of the last) without bank conflicts.
 #pragma once
 #include "cdkf_wave8_kernels.h"
 
@@ -26,25 +28,29 @@ namespace cdkf {
 struct AdjSh {  // per workgroup, in reals; hidden sizes padded to 64, state to 8
   static constexpr int W1 = 0;             // [64][8]
   static constexpr int b1 = 512;           // [64]
-  static constexpr int W2 = 576;           // [64][64]   W2[p][q]
-  static constexpr int W2T = 576 + 4096;   // [64][64]   W2T[q][p] = W2[p][q]
-  static constexpr int b2 = 576 + 8192;    // [64]
-  static constexpr int W3 = 8832;          // [8][65]
-  static constexpr int b3 = 8832 + 520;    // [8]
-  static constexpr int end = 9360;
+  static constexpr int W2 = 576;           // [64][65]   W2[p][q], rows padded to 65: as a matrix-core operand it is read along p (A of
+                                           //            the tangent product) AND along q (B of the transposed one), conflict-free both ways
+  static constexpr int b2 = 576 + 64 * 65; // [64]
+  static constexpr int W3 = b2 + 64;       // [8][65]
+  static constexpr int b3 = W3 + 520;      // [8]
+  static constexpr int end = b3 + 8;
 };
-constexpr int kAdjCk = 8;  // Dormand-Prince step starts kept per replay chunk
+constexpr int kAdjCk = 4;  // Dormand-Prince step starts kept per replay chunk
 struct AdjOff {  // per wavefront, in reals
   static constexpr int P = 0, F = 64, Lam = 128, G = 192, A = 256, B = 320, X = 384, S = 448, S1 = 512, S2 = 576, HP = 640,
                        H = 704, Pb = 768, Kb = 832, Ub = 896, Si = 960, XP = 1024;
   static constexpr int x = 1088, lam = 1096, f = 1104, v = 1112, w = 1120, mb = 1128, vb = 1136;
-  static constexpr int a1 = 1168, a2 = 1232, zb2 = 1296, U = 1360, V = 1872, ZT2 = 2384, RED = 2896;
-  static constexpr int ck = 3408;  // kAdjCk x (64 P + 8 m), then kAdjCk step sizes
-  static constexpr int end = 3408 + kAdjCk * 72 + kAdjCk;
+  // MLP passes: three [64][9] images (stride 9: a lane's row is conflict-free) that are the matrix-core operands / results --
+  //   UC = [D1 W1 | a1]  (B of the tangent product, B of the dW2 update),   ZC = [zt2 | z2b]  (A of the dW2 update and of the
+  //   transposed product),   TC = [T | z2 - b2] (result of the tangent product, a row per hidden unit); once its rows are in
+  //   registers the same image takes CC = [c1 | s1] (result of the transposed product) and then the partial sums RED
+  static constexpr int a1 = 1168, a2 = 1232, d2 = 1296, UC = 1360, ZC = 1936, TC = 2512, CC = 2512, RED = 2512;
+  static constexpr int ck = 3088;  // kAdjCk x (64 P + 8 m), then kAdjCk step sizes
+  static constexpr int end = 3088 + kAdjCk * 72 + kAdjCk;
 };
 template <typename R, bool MLP>
 constexpr int adj_waves() {
-  return (MLP && sizeof(R) == 8) ? 2 : 4;
+  return 4;  // one wavefront per SIMD (150 KB of LDS per workgroup in fp64 with the MLP's weights)
 }
 template <typename R, bool MLP>
 constexpr size_t adj_lds_bytes() {
@@ -78,9 +84,7 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
   for (int e = threadIdx.x; e < h1; e += blockDim.x) Sh[AdjSh::b1 + e] = th[ob1 + e];
   for (int e = threadIdx.x; e < h2 * h1; e += blockDim.x) {
     const int p = fdiv(e, h1), q = e - p * h1;
-    const R w = th[oW2 + e];
-    Sh[AdjSh::W2 + p * 64 + q] = w;
-    Sh[AdjSh::W2T + q * 64 + p] = w;
+    Sh[AdjSh::W2 + p * 65 + q] = th[oW2 + e];
   }
   for (int e = threadIdx.x; e < h2; e += blockDim.x) Sh[AdjSh::b2 + e] = th[ob2 + e];
   for (int e = threadIdx.x; e < d * h2; e += blockDim.x) {
@@ -114,10 +118,19 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
   const R blin = (a.kind == kDriftLinear && lane < d) ? th[d * d + lane] : R(0);
 
   // ---- parameter-gradient accumulators (registers for the whole sweep) -------------------------------------------
-  R gW2[MLP ? 64 : 1], gW1[8], gW3[8];
+  // d ll / d W2 accumulates in matrix-core accumulator tiles for the whole sweep: gW2t[mt][nt][r] is entry
+  // (16 mt + row(lg, r), 16 nt + lm) -- the rank-9 update of every right-hand-side adjoint is 48 v_mfma_*_16x16x4
+  using MTile = W8Tile<R>;
+  const int lm = lane & 15, lg = lane >> 4;
+  const R e8 = (lm == 8) ? R(1) : R(0), ne8 = (lm == 8) ? R(0) : R(1);
+  const int sc_off = (lm == 8) ? AdjOff::a2 : AdjOff::d2;
+  typename MTile::V4 gW2t[MLP ? 4 : 1][MLP ? 4 : 1];
+  R gW1[8], gW3[8];
   R gb1 = 0, gb2 = 0, gb3 = 0;
 #pragma unroll
-  for (int q = 0; q < (MLP ? 64 : 1); ++q) gW2[q] = 0;
+  for (int mt = 0; mt < (MLP ? 4 : 1); ++mt)
+#pragma unroll
+    for (int nt = 0; nt < (MLP ? 4 : 1); ++nt) gW2t[mt][nt] = typename MTile::V4{0, 0, 0, 0};
 #pragma unroll
   for (int k = 0; k < 8; ++k) gW1[k] = gW3[k] = 0;
   R gTile = 0, gVec = 0;                 // non-MLP drifts: linear dW[i][j] on lane (i, j); bias / Lorenz parameters on lanes < 8
@@ -146,44 +159,65 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
   // ---- MLP forward with the tangent of the 8 unit directions; needs W[x] = stage mean (synced) ---------------------
   // lane = hidden unit: returns a1, d1 (layer 1), a2, d2, T = W2 (D1 W1) row (layer 2); leaves a1, U = D1 W1, a2,
   // V = D2 T in LDS and the Jacobian entry F_ij / the drift f in registers of lane (i, j) / LDS vector f.
-  auto mlp_fwd = [&](R (&xk)[8], R& a1, R& d1, R& a2, R& d2, R (&T)[8], R& Fij) {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) xk[k] = W[AdjOff::x + k];
+  auto mlp_fwd = [&](R& a1, R& d1, R& a2, R& d2, R (&T)[8], R& Fij) {
     R z1 = b1l;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) z1 = rfma(w1row[k], xk[k], z1);
+    for (int k = 0; k < 8; ++k) z1 = rfma(w1row[k], W[AdjOff::x + k], z1);
     a1 = rtanh(z1);
     d1 = R(1) - a1 * a1;
     W[AdjOff::a1 + lane] = a1;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) W[AdjOff::U + lane * 8 + k] = d1 * w1row[k];
+    for (int k = 0; k < 8; ++k) W[AdjOff::UC + lane * 9 + k] = d1 * w1row[k];
+    W[AdjOff::UC + lane * 9 + 8] = a1;
     wave_sync();
-    R z2 = b2l;
+    // [T | z2 - b2] = W2 [D1 W1 | a1] on the matrix cores (A operand: W2T rows, lanes along p; B operand: UC rows)
+    typename MTile::V4 acc[4];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) T[k] = 0;
-#pragma unroll 8
-    for (int q = 0; q < 64; ++q) {
-      const R w = Sh[AdjSh::W2T + q * 64 + lane];
-      z2 = rfma(w, W[AdjOff::a1 + q], z2);
+    for (int mt = 0; mt < 4; ++mt) acc[mt] = typename MTile::V4{0, 0, 0, 0};
 #pragma unroll
-      for (int k = 0; k < 8; ++k) T[k] = rfma(w, W[AdjOff::U + q * 8 + k], T[k]);
+    for (int ks = 0; ks < 16; ++ks) {
+      const R bv = (lm < 9) ? W[AdjOff::UC + (4 * ks + lg) * 9 + lm] : R(0);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) acc[mt] = wg_mfma(Sh[AdjSh::W2 + (16 * mt + lm) * 65 + 4 * ks + lg], bv, acc[mt]);
+      if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // operands of four k-steps in flight, not of all sixteen (registers)
     }
-    a2 = rtanh(z2);
+    if (lm < 9) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) W[AdjOff::TC + (16 * mt + MTile::row(lg, r)) * 9 + lm] = acc[mt][r];
+    }
+    wave_sync();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) T[k] = W[AdjOff::TC + lane * 9 + k];
+    a2 = rtanh(W[AdjOff::TC + lane * 9 + 8] + b2l);
     d2 = R(1) - a2 * a2;
     W[AdjOff::a2 + lane] = a2;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) W[AdjOff::V + lane * 8 + k] = d2 * T[k];
+    W[AdjOff::d2 + lane] = d2;
     wave_sync();
-    R fs = 0;
-    Fij = 0;
-#pragma unroll 8
-    for (int p = 0; p < 64; ++p) {
-      const R w3 = Sh[AdjSh::W3 + i * 65 + p];
-      Fij = rfma(w3, W[AdjOff::V + p * 8 + j], Fij);
-      fs = rfma(w3, W[AdjOff::a2 + p], fs);
+    // [F | f - b3] = W3 [D2 T | a2]: the accumulator rows of the first product are this one's k index
+    typename MTile::V4 acc3{0, 0, 0, 0};
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        // (the tangent comes back from its image rather than from the live accumulators: registers are what this kernel is
+        //  short of -- every value kept across the tanh evaluations above was a spill)
+        const int pr = 16 * mt + MTile::row(lg, r);
+        const R sc = W[sc_off + pr];
+        const R w3 = (lm < 8) ? Sh[AdjSh::W3 + lm * 65 + pr] : R(0);
+        const R tv = (lm < 8) ? W[AdjOff::TC + pr * 9 + lm] : e8;
+        acc3 = wg_mfma(w3, sc * tv, acc3);
+      }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = MTile::row(lg, r);
+      if (row < 8 && lm < 8) W[AdjOff::F + row * 8 + lm] = acc3[r];
+      if (row < 8 && lm == 8) W[AdjOff::f + row] = (row < d) ? acc3[r] + Sh[AdjSh::b3 + row] : R(0);
     }
-    if (!inP) Fij = 0;
-    if (j == 0) W[AdjOff::f + i] = (i < d) ? fs + Sh[AdjSh::b3 + i] : R(0);
+    wave_sync();
+    Fij = inP ? W[AdjOff::F + lane] : R(0);
+    wave_sync();  // (the callers overwrite the F tile)
   };
 
   // ---- registry drifts other than the MLP: Jacobian entry on lane (i, j), f in the LDS vector; needs W[x] (synced) ----
@@ -235,8 +269,8 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
     wave_sync();
     R Fij;
     if constexpr (MLP) {
-      R xk[8], a1, d1, a2, d2, T[8];
-      mlp_fwd(xk, a1, d1, a2, d2, T, Fij);
+      R a1, d1, a2, d2, T[8];
+      mlp_fwd(a1, d1, a2, d2, T, Fij);
     } else {
       drift_fwd(Fij);
     }
@@ -308,19 +342,16 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
       wave_sync();
       return;
     } else {
-    R xk[8], a1, d1, a2, d2, T[8], Fij;
-    mlp_fwd(xk, a1, d1, a2, d2, T, Fij);
+    R a1, d1, a2, d2, T[8], Fij;
+    mlp_fwd(a1, d1, a2, d2, T, Fij);
     W[AdjOff::F + lane] = Fij;
     W[AdjOff::G + lane] = R(2) * mm(AdjOff::Lam, AdjOff::P);
     wave_sync();
     YP = mm_tn(AdjOff::F, AdjOff::Lam) + mm(AdjOff::Lam, AdjOff::F);
     // layer 3, lane p: c2_j = sum_i W3[i][p] G[i][j] is the cotangent of V[p][j]
-    R c2[8], lamv[8];
+    R c2[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      c2[k] = 0;
-      lamv[k] = W[AdjOff::lam + k];
-    }
+    for (int k = 0; k < 8; ++k) c2[k] = 0;
     R a2b = 0;
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
@@ -331,8 +362,9 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
         c2[k] = rfma(w3col[r], g, c2[k]);
         gv = rfma(g, T[k], gv);
       }
-      gW3[r] = rfma(lamv[r], a2, rfma(d2, gv, gW3[r]));
-      a2b = rfma(w3col[r], lamv[r], a2b);
+      const R lamr = W[AdjOff::lam + r];
+      gW3[r] = rfma(lamr, a2, rfma(d2, gv, gW3[r]));
+      a2b = rfma(w3col[r], lamr, a2b);
     }
     R zt2[8];
     {
@@ -345,29 +377,51 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
     }
     const R z2b = d2 * a2b;
     gb2 += z2b;
-    W[AdjOff::zb2 + lane] = z2b;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) W[AdjOff::ZT2 + lane * 8 + k] = zt2[k];
-    // layer 2 weights: dW2[p][q] += z2b a1[q] + sum_j zt2[j] U[q][j]
+    for (int k = 0; k < 8; ++k) W[AdjOff::ZC + lane * 9 + k] = zt2[k];
+    W[AdjOff::ZC + lane * 9 + 8] = z2b;
+    wave_sync();
+    // layer 2 weights: dW2 += [zt2 | z2b] [D1 W1 | a1]^T -- a 64 x 64 x 9 product accumulated in the tiles (three k-steps)
 #pragma unroll
-    for (int q = 0; q < 64; ++q) {
-      R s = rfma(z2b, W[AdjOff::a1 + q], gW2[q]);
+    for (int ks = 0; ks < 3; ++ks) {
+      const int jj = 4 * ks + lg;
+      const bool jin = jj < 9;
+      R av[4], bv[4];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) s = rfma(zt2[k], W[AdjOff::U + q * 8 + k], s);
-      gW2[q] = s;
+      for (int t4 = 0; t4 < 4; ++t4) {
+        av[t4] = jin ? W[AdjOff::ZC + (16 * t4 + lm) * 9 + jj] : R(0);
+        bv[t4] = jin ? W[AdjOff::UC + (16 * t4 + lm) * 9 + jj] : R(0);
+      }
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) gW2t[mt][nt] = wg_mfma(av[mt], bv[nt], gW2t[mt][nt]);
+    }
+    // layer 1: [c1 | s1]^T = [zt2 | z2b]^T W2 (cotangents of U and a1): rows j = 0 .. 8, columns q
+    {
+      typename MTile::V4 cacc[4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) cacc[nt] = typename MTile::V4{0, 0, 0, 0};
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        const R av = (lm < 9) ? W[AdjOff::ZC + (4 * ks + lg) * 9 + lm] : R(0);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) cacc[nt] = wg_mfma(av, Sh[AdjSh::W2 + (4 * ks + lg) * 65 + 16 * nt + lm], cacc[nt]);
+        if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = MTile::row(lg, r);
+          if (row < 9) W[AdjOff::CC + (16 * nt + lm) * 9 + row] = cacc[nt][r];
+        }
     }
     wave_sync();
-    // layer 1, lane q: c1_j = sum_p W2[p][q] zt2_p[j] is the cotangent of U[q][j]
-    R c1[8], s1 = 0;
+    R c1[8], s1 = W[AdjOff::CC + lane * 9 + 8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) c1[k] = 0;
-#pragma unroll 8
-    for (int p = 0; p < 64; ++p) {
-      const R w = Sh[AdjSh::W2 + p * 64 + lane];
-      s1 = rfma(w, W[AdjOff::zb2 + p], s1);
-#pragma unroll
-      for (int k = 0; k < 8; ++k) c1[k] = rfma(w, W[AdjOff::ZT2 + p * 8 + k], c1[k]);
-    }
+    for (int k = 0; k < 8; ++k) c1[k] = W[AdjOff::CC + lane * 9 + k];
+    wave_sync();  // (RED below shares the CC image)
     {
       R s = 0;
 #pragma unroll
@@ -378,7 +432,7 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
     gb1 += z1b;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      gW1[k] = rfma(z1b, xk[k], rfma(d1, c1[k], gW1[k]));
+      gW1[k] = rfma(z1b, W[AdjOff::x + k], rfma(d1, c1[k], gW1[k]));
       W[AdjOff::RED + lane * 8 + k] = w1row[k] * z1b;
     }
     if (lane < 8) gb3 += lam;
@@ -472,8 +526,8 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
       wave_sync();
       R Fij;
       if constexpr (MLP) {
-        R xk[8], a1, d1, a2, d2, Tt[8];
-        mlp_fwd(xk, a1, d1, a2, d2, Tt, Fij);
+        R a1, d1, a2, d2, Tt[8];
+        mlp_fwd(a1, d1, a2, d2, Tt, Fij);
       } else {
         drift_fwd(Fij);
       }
@@ -821,10 +875,16 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
       if (k < d) g[oW1 + (long)lane * d + k] = gW1[k];
     g[ob1 + lane] = gb1;
   }
-  if (lane < h2) {
 #pragma unroll
-    for (int q = 0; q < 64; ++q)
-      if (q < h1) g[oW2 + (long)lane * h1 + q] = gW2[q];
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int pr = 16 * mt + MTile::row(lg, r), qc = 16 * nt + lm;
+        if (pr < h2 && qc < h1) g[oW2 + (long)pr * h1 + qc] = gW2t[mt][nt][r];
+      }
+  if (lane < h2) {
     g[ob2 + lane] = gb2;
 #pragma unroll
     for (int r = 0; r < 8; ++r)

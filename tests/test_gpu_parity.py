@@ -255,10 +255,10 @@ def test_results_do_not_depend_on_the_wavefront_grouping(hip_lib, N, T):
     for hyper in (cd.EKFHyperParams(), cd.UKFHyperParams()):
         big = cd.cdnlgssm_filter(P, y, t[..., None], hyperparams=hyper)
         small = cd.cdnlgssm_filter(P, y[sub], t[sub][..., None], hyperparams=hyper)
-        # the EKF sweep of this model runs on the sixteen-lanes-per-trajectory kernel up to 4096 trajectories (16 per CU)
-        # (cdkf_lpe_kernels.h: same update code, the predict sums in a different order): bitwise on one side of that
-        # threshold, rounding-level across it
-        same_kernel = isinstance(hyper, cd.UKFHyperParams) or N <= 4096
+        # both sweeps of this model run on the sixteen-lanes-per-trajectory kernel up to 4096 trajectories (16 per CU)
+        # (cdkf_lpe_kernels.h: the predict sums in a different order; the unscented filter there uses the collapsed moment
+        # equations instead of forming the sigma points): bitwise on one side of that threshold, rounding-level across it
+        same_kernel = N <= 4096
         for k in FILTER_KEYS + ["marginal_loglik"]:
             a, b = np.asarray(getattr(big, k))[sub], np.asarray(getattr(small, k))
             if same_kernel:
