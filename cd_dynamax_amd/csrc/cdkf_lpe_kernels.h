@@ -1,4 +1,4 @@
-// cdkf_lpe_kernels.h -- Lorenz-63 EKF filter sweep with SIXTEEN LANES PER TRAJECTORY, for batches too small to fill the chip
+// cdkf_lpe_kernels.h -- EKF / UKF filter sweep for three-dimensional states (Lorenz-63, linear drift) with SIXTEEN LANES PER TRAJECTORY, for batches too small to fill the chip
 // with the lane-per-trajectory kernel (4096 trajectories: 64 wavefronts' worth of lanes on 1024 SIMDs).
 //
 // A lone wavefront pays one 4-cycle issue slot per instruction whatever the lane count, so with SIMDs to spare the sweep
@@ -148,6 +148,56 @@ struct LpeRhs {
     return acc;
   }
   CDKF_DEV void operator()(const R (&s)[1], R (&k)[1]) const { k[0] = eval(s[0]); }
+};
+
+// A right-hand side that is LINEAR in the lane's grid with per-lane constant coefficients: the smoother's backward equations
+// (coefficients rebuilt per interval) and a linear drift f = W x + b (coefficients fixed for the whole sweep).
+template <typename R>
+struct LpeLinRhs {
+  R g0, q, ci1, ci2, ci3, cjA, cjB;
+  CDKF_DEV R eval(const R v) const {
+    const R d1 = lpe_dpp<0x120 + 12>(v), d2 = lpe_dpp<0x120 + 8>(v), d3 = lpe_dpp<0x120 + 4>(v);  // rows i+1, i+2, i+3
+    const R r1 = lpe_dpp<0xC9>(v), r2 = lpe_dpp<0xD2>(v);                                          // columns (j+1) % 3, (j+2) % 3
+    R acc = rfma(g0, v, q);
+    acc = rfma(ci1, d1, acc);
+    acc = rfma(ci2, d2, acc);
+    acc = rfma(ci3, d3, acc);
+    acc = rfma(cjA, r1, acc);
+    acc = rfma(cjB, r2, acc);
+    return acc;
+  }
+  CDKF_DEV void operator()(const R (&s)[1], R (&k)[1]) const { k[0] = eval(s[0]); }
+};
+
+// Right-hand side of the sweep for a drift: Lorenz-63 (affine Jacobian) or linear (constant coefficients: covariance lanes
+// d P_ij = sum_k W_ik P_kj + sum_k P_ik W_jk + (L Qc L^T)_ij, mean lanes d m_i = sum_k W_ik m_k + b_i on the same row fetches).  A
+// linear drift has no curvature: its unscented moment equations ARE these (the sigma-point sums collapse with b(o, o) = 0).
+template <typename R, typename Drift, bool UKF>
+struct LpeRhsOf;
+template <typename R, bool UKF>
+struct LpeRhsOf<R, DriftLorenz63<R, 3>, UKF> {
+  using type = LpeRhs<R, UKF>;
+  template <typename Args>
+  static CDKF_DEV void init(type& rhs, int i, int j, const Args& a) {
+    rhs.init(i, j, a.drift.sigma, a.drift.rho, a.drift.beta, a.LQL);
+  }
+};
+template <typename R, bool UKF>
+struct LpeRhsOf<R, DriftLinear<R, 3>, UKF> {
+  using type = LpeLinRhs<R>;
+  template <typename Args>
+  static CDKF_DEV void init(type& rhs, int i, int j, const Args& a) {
+    const bool cov = i < 3 && j < 3, mean = i < 3 && j == 3;
+    auto Wm = [&](int r, int c) { return (r < 3 && c < 3) ? a.drift.W[r][c] : R(0); };
+    const int r = (cov || mean) ? i : 3, c = cov ? j : 3;
+    rhs.ci1 = Wm(r, (r + 1) & 3);
+    rhs.ci2 = Wm(r, (r + 2) & 3);
+    rhs.ci3 = Wm(r, (r + 3) & 3);
+    rhs.cjA = (c < 3) ? Wm(c, (c + 1) % 3) : R(0);
+    rhs.cjB = (c < 3) ? Wm(c, (c + 2) % 3) : R(0);
+    rhs.g0 = cov ? Wm(i, i) + Wm(j, j) : (mean ? Wm(i, i) : R(0));
+    rhs.q = cov ? a.LQL[sidx<3>(i, j)] : (mean ? a.drift.b[i] : R(0));
+  }
 };
 
 // The unscented update draws its sigma points from chol(P) (inference_ukf.py:184, 57): a covariance that is not positive definite
@@ -309,8 +359,8 @@ inline unsigned lpe_blocks(int64_t N) {
 // UKF: the unscented filter (LpeRhs<R, true>; its update with a linear emission is the same algebra as the EKF's -- the sigma points
 // pass through h(x) = x exactly: pred_mean = m, pred_cov = P + R, pred_cross = P, inference_ukf.py:186-203 -- plus the
 // positive-definiteness test the reference's Cholesky of P implies).
-template <typename R, int M, int OUT, bool FAST, bool UKF = false>
-__global__ __launch_bounds__(64) void filter_lpe_l63_kernel(const RegArgs<R, 3, M, DriftLorenz63<R, 3>> a) {
+template <typename R, typename Drift, int M, int OUT, bool FAST, bool UKF = false>
+__global__ __launch_bounds__(64) void filter_lpe_kernel(const RegArgs<R, 3, M, Drift> a) {
   static_assert(!FAST || M == 3, "the in-grid update is written for H = I");
   static_assert(!UKF || FAST, "the unscented filter runs with the in-grid update");
   constexpr int D = 3, NS = Dims<D>::NS;
@@ -324,8 +374,8 @@ __global__ __launch_bounds__(64) void filter_lpe_l63_kernel(const RegArgs<R, 3, 
   const long n = live ? n_raw : a.N - 1;  // an idle row shadows the last trajectory (same values to the same addresses)
   const bool cov = i < 3 && j < 3, mean = i < 3 && j == 3;
 
-  LpeRhs<R, UKF> rhs;
-  rhs.init(i, j, a.drift.sigma, a.drift.rho, a.drift.beta, a.LQL);
+  typename LpeRhsOf<R, Drift, UKF>::type rhs;
+  LpeRhsOf<R, Drift, UKF>::init(rhs, i, j, a);
   const auto C = TabSel<R, false>::get(a);
 
   // own entry; index of that entry in the gathered state [m_0..m_2, P_00, P_01, P_02, P_11, P_12, P_22] (-1: none)
@@ -456,23 +506,6 @@ __global__ __launch_bounds__(64) void filter_lpe_l63_kernel(const RegArgs<R, 3, 
 // masked sum.  The slots are then put into the rotated order of the DPP fetches once per interval, and a Runge-Kutta stage is 10
 // moves + 6 FMAs (the lane-per-trajectory sweep: ~88 instructions per stage).  Lanes below the diagonal re-adopt their transpose
 // partner every step (see lpe_update).  Inputs: the filtered moments the forward sweep just wrote; each lane loads its own entry.
-template <typename R>
-struct LpeLinRhs {
-  R g0, q, ci1, ci2, ci3, cjA, cjB;
-  CDKF_DEV R eval(const R v) const {
-    const R d1 = lpe_dpp<0x120 + 12>(v), d2 = lpe_dpp<0x120 + 8>(v), d3 = lpe_dpp<0x120 + 4>(v);  // rows i+1, i+2, i+3
-    const R r1 = lpe_dpp<0xC9>(v), r2 = lpe_dpp<0xD2>(v);                                          // columns (j+1) % 3, (j+2) % 3
-    R acc = rfma(g0, v, q);
-    acc = rfma(ci1, d1, acc);
-    acc = rfma(ci2, d2, acc);
-    acc = rfma(ci3, d3, acc);
-    acc = rfma(cjA, r1, acc);
-    acc = rfma(cjB, r2, acc);
-    return acc;
-  }
-  CDKF_DEV void operator()(const R (&s)[1], R (&k)[1]) const { k[0] = eval(s[0]); }
-};
-
 template <typename R, int M>
 __global__ __launch_bounds__(64) void smoother_lpe_l63_kernel(const RegArgs<R, 3, M, DriftLorenz63<R, 3>> a, R* __restrict__ sm,
                                                               R* __restrict__ sP) {
@@ -604,7 +637,7 @@ inline bool lpe_batch_is_small(int64_t N) {
 // lane-per-trajectory kernel (A/B timing, tests of the latter at small N).
 template <typename R, int D, int M, typename Drift>
 inline bool try_lpe(const RegArgs<R, D, M, Drift>& a, const cdkf_model* mdl, const cdkf_opts* o, hipStream_t stream, bool ukf = false) {
-  if constexpr (std::is_same<Drift, DriftLorenz63<R, 3>>::value && D == 3 && M <= 3) {
+  if constexpr ((std::is_same<Drift, DriftLorenz63<R, 3>>::value || std::is_same<Drift, DriftLinear<R, 3>>::value) && D == 3 && M <= 3) {
     static const bool off = [] { const char* e = std::getenv("CDKF_NO_LPE"); return e && e[0] == '1'; }();
     // CDKF_UKF_SIGMA_POINTS=1: the unscented filter on the lane-per-trajectory kernel, which forms the sigma points (A/B, tests)
     static const bool ukf_off = [] { const char* e = std::getenv("CDKF_UKF_SIGMA_POINTS"); return e && e[0] == '1'; }();
@@ -622,18 +655,20 @@ inline bool try_lpe(const RegArgs<R, D, M, Drift>& a, const cdkf_model* mdl, con
     if (ukf && (ukf_off || !fast || !(a.ukf_c > R(0)))) return false;  // (n + lambda <= 0: the reference's NaNs come from the other kernel)
     auto launch = [&](auto out) {
       constexpr int OUT = decltype(out)::value;
-      note_kernel("filter_lpe_l63_kernel<%s, %d, %d, %s, %s>", real_name<R>(), M, OUT, fast ? "true" : "false", ukf ? "true" : "false");
+      note_kernel("filter_lpe_kernel<%s, cdkf::%s<%s, 3>, %d, %d, %s, %s>", real_name<R>(),
+                  std::is_same<Drift, DriftLinear<R, 3>>::value ? "DriftLinear" : "DriftLorenz63", real_name<R>(), M, OUT,
+                  fast ? "true" : "false", ukf ? "true" : "false");
       if constexpr (M == 3) {
         if (ukf) {
-          hipLaunchKernelGGL((filter_lpe_l63_kernel<R, M, OUT, true, true>), grid, block, 0, stream, a);
+          hipLaunchKernelGGL((filter_lpe_kernel<R, Drift, M, OUT, true, true>), grid, block, 0, stream, a);
           return;
         }
         if (fast) {
-          hipLaunchKernelGGL((filter_lpe_l63_kernel<R, M, OUT, true, false>), grid, block, 0, stream, a);
+          hipLaunchKernelGGL((filter_lpe_kernel<R, Drift, M, OUT, true, false>), grid, block, 0, stream, a);
           return;
         }
       }
-      hipLaunchKernelGGL((filter_lpe_l63_kernel<R, M, OUT, false, false>), grid, block, 0, stream, a);
+      hipLaunchKernelGGL((filter_lpe_kernel<R, Drift, M, OUT, false, false>), grid, block, 0, stream, a);
     };
     if (all)
       launch(std::integral_constant<int, 1>{});

@@ -120,7 +120,7 @@ def test_options_num_iter_zeroth_order_subsets(hip_lib):
 
 
 def test_sixteen_lane_kernel_paths(hip_lib):
-    """Small Lorenz-63 batches with H = I run on filter_lpe_l63_kernel (cdkf_lpe_kernels.h).  Its update has two forms:
+    """Small Lorenz-63 batches with H = I run on filter_lpe_kernel (cdkf_lpe_kernels.h).  Its update has two forms:
     inside the lane grid (num_iter = 1, symmetric R) and the per-lane fallback (iterated updates; an emission covariance
     that is not exactly symmetric).  Both against the oracle, odd and even T (the time loop is unrolled by two), N not a
     multiple of the four trajectories per wavefront, all three output modes."""
@@ -327,7 +327,7 @@ def test_c2_full_size_properties(hip_lib):
 
 
 def test_unscented_filter_on_the_lane_grid(hip_lib, tmp_path):
-    """Small Lorenz-63 batches with H = I run the unscented filter on filter_lpe_l63_kernel<..., UKF = true>, whose moment
+    """Small Lorenz-63 batches with H = I run the unscented filter on filter_lpe_kernel<..., UKF = true>, whose moment
     equations are the sigma-point sums of inference_ukf.py:124-143 collapsed for this (quadratic) drift.  Against the oracle,
     which forms the sigma points literally: default and non-default (alpha, beta, kappa), odd / even T, N not a multiple of
     four, every output mode, long gaps, fp32; against the lane-per-trajectory kernel, which also forms them
@@ -348,7 +348,7 @@ def test_unscented_filter_on_the_lane_grid(hip_lib, tmp_path):
         assert relerr(post.marginal_loglik, ref["marginal_loglik"]) < 1e-9
         post = cd.cdnlgssm_filter(P, y, t[..., None], hyp, output_fields=["filtered_means", "filtered_covariances"])
         assert relerr(post.filtered_covariances, ref["filtered_covariances"]) < 1e-9
-    assert hip_lib.cdkf_last_kernel().startswith(b"filter_lpe_l63_kernel<double, 3, 2, true, true>")
+    assert hip_lib.cdkf_last_kernel().startswith(b"filter_lpe_kernel<double, cdkf::DriftLorenz63<double, 3>, 3, 2, true, true>")
     t = o.irregular_times(rng, 9, 25, 1.5)  # up to ~12 Dormand-Prince steps per interval
     y = o.simulate(mdl, t, rng)
     ref = o.ukf_filter(mdl, t, y)
@@ -377,6 +377,37 @@ def test_unscented_filter_on_the_lane_grid(hip_lib, tmp_path):
     assert np.isnan(ll).all() and (st & _ffi.STATUS_NOT_PD).all() and np.isnan(outs[0]).all()
 
 
+def test_linear_drift_on_the_lane_grid(hip_lib):
+    """The sixteen-lane sweep also carries linear drifts at state_dim 3 (constant per-lane coefficients): EKF orders, UKF (for a
+    linear drift the unscented moment equations are the EKF's), full and partial observation, against the oracle and against
+    the closed-form (matrix-exponential) Kalman filter; larger batches fall back to the lane-per-trajectory kernel and agree."""
+    from helpers import closed_form_kf
+    rng = np.random.default_rng(33)
+    for m in (3, 1):
+        mdl = linear_model(rng, 3, m)
+        if m == 3:
+            mdl = o.Model(mdl.drift, mdl.L, mdl.Qc, np.eye(3), np.zeros(3), mdl.R, mdl.m0, mdl.P0)  # H = I: the in-grid update
+        P = params_from(mdl)
+        N, T = 9, 40
+        t = o.irregular_times(rng, N, T, 0.012 * T)
+        y = o.simulate(mdl, t, rng)
+        for order in ("first", "second"):
+            _check_filter(cd.cdnlgssm_filter(P, y, t[..., None], cd.EKFHyperParams(state_order=order)), o.ekf_filter(mdl, t, y, state_order=order), 1e-9)
+        assert hip_lib.cdkf_last_kernel().startswith(b"filter_lpe_kernel<double, cdkf::DriftLinear<double, 3>, %d, 1, " % m)
+        if m == 3:
+            _check_filter(cd.cdnlgssm_filter(P, y, t[..., None], cd.UKFHyperParams()), o.ukf_filter(mdl, t, y), 1e-9)
+            assert hip_lib.cdkf_last_kernel().startswith(b"filter_lpe_kernel<double, cdkf::DriftLinear<double, 3>, 3, 1, true, true>")
+        _check_filter(cd.cdnlgssm_filter(P, y.astype(np.float32), t[..., None]), o.ekf_filter(mdl, t, y), 3e-5)
+        ex = closed_form_kf(mdl, t[0], y[0])
+        post = cd.cdnlgssm_filter(P, y[0], t[0][:, None])
+        assert relerr(post.filtered_means, ex["filtered_means"]) < 1e-7 and abs(post.marginal_loglik - ex["marginal_loglik"]) < 1e-6 * abs(ex["marginal_loglik"])
+        big_t, big_y = np.tile(t, (460, 1))[:4100], np.tile(y, (460, 1, 1))[:4100]  # > 4096: lane-per-trajectory kernel
+        big = cd.cdnlgssm_filter(P, big_y, big_t[..., None])
+        assert hip_lib.cdkf_last_kernel().startswith(b"filter_reg_kernel")
+        small = cd.cdnlgssm_filter(P, y, t[..., None])
+        assert relerr(np.asarray(big.filtered_covariances)[:N], small.filtered_covariances) < 1e-11
+
+
 def test_c3_full_size_properties(hip_lib):
     """BASELINE config 3 (Lorenz-63 UKF, 4096 x 1000, fp32) through size-independent properties: a random subset re-run alone
     through the fp64 ORACLE (literal sigma points) matches the fp32 sweep -- filtered means within 1e-5 (the north-star bar; the
@@ -392,7 +423,7 @@ def test_c3_full_size_properties(hip_lib):
     blk = models._model_block(params_from(mdl))
     ref = o.ukf_filter(mdl, t[sub], y[sub])
     ll, outs, st, llsum = _run_dev(hip_lib, "ukf_filter", blk, _ffi.default_opts(), t, y, np.float32, _ffi.LAYOUT_TCN)
-    assert hip_lib.cdkf_last_kernel().startswith(b"filter_lpe_l63_kernel<float, 3, 1, true, true>")
+    assert hip_lib.cdkf_last_kernel().startswith(b"filter_lpe_kernel<float, cdkf::DriftLorenz63<float, 3>, 3, 1, true, true>")
     assert (st == 0).all() and np.isfinite(ll).all()
     assert abs(llsum - ll.astype(np.float64).sum()) < 1e-6 * abs(llsum)
     assert relerr(ll[sub], ref["marginal_loglik"]) < 1e-5
