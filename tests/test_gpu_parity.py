@@ -765,6 +765,38 @@ def test_adaptive_step_size_control(hip_lib, solver, ctrl):
     assert (status & 4).any()
 
 
+def test_notebook_pin_default_vs_tsit5_pid_loglik(hip_lib):
+    """The reference-recorded statement about the adaptive path (tutorial diffeqsolve_settings_analysis.ipynb:385-386; see
+    tests/test_oracle.py::test_notebook_pin_default_vs_tsit5_pid_loglik): default Dopri5 and Tsit5 + PIDController(1e-9, 1e-9)
+    give the same marginal log-likelihood to float32 resolution.  The HIP path on the notebook's model at its time density:
+    fp64 within 6.7e-8 relative (one float32 ulp of the notebook's value); fp32, the reference's precision, within 16 ulps
+    (the notebook saw 0 at 10 000 steps; rounding accumulates differently here) with the adaptive solve under a tolerance
+    BELOW float32 resolution still terminating; each against the oracle under the same settings."""
+    rng = np.random.default_rng(2024)
+    mdl = o.lorenz63_model(1)
+    P = params_from(mdl)
+    N, T = 6, 2000
+    t = o.irregular_times(rng, N, T, 0.005 * T)
+    y = o.simulate(mdl, t, rng)
+    hifi_settings = {"solver": "tsit5", "stepsize_controller": cd.PIDController(rtol=1e-9, atol=1e-9), "max_steps": 10 ** 7}
+    d64 = cd.cdnlgssm_filter(P, y, t[..., None], cd.EKFHyperParams(), output_fields=[]).marginal_loglik
+    h64 = cd.cdnlgssm_filter(P, y, t[..., None], cd.EKFHyperParams(diffeqsolve_settings=hifi_settings), output_fields=[]).marginal_loglik
+    assert np.all(np.abs(d64 - h64) <= 6.7e-8 * np.abs(h64)), (d64, h64)
+    y32 = y.astype(np.float32)
+    d32 = np.asarray(cd.cdnlgssm_filter(P, y32, t[..., None], cd.EKFHyperParams(), output_fields=[]).marginal_loglik, np.float64)
+    h32 = np.asarray(cd.cdnlgssm_filter(P, y32, t[..., None], cd.EKFHyperParams(diffeqsolve_settings=hifi_settings), output_fields=[]).marginal_loglik,
+                     np.float64)
+    assert np.all(np.isfinite(h32))
+    assert np.all(np.abs(d32 - h32) <= 16 * 6.0e-8 * np.abs(h64)), (d32, h32)
+    assert np.all(np.abs(d32 - d64) <= 3e-5 * np.abs(d64))
+    # the oracle under the same two settings (a short prefix: the adaptive NumPy loop is slow)
+    Ts = 150
+    with o.use_solver("tsit5", adaptive=dict(rtol=1e-9, atol=1e-9)):
+        ref_h = o.ekf_filter(mdl, t[:2, :Ts], y[:2, :Ts])["marginal_loglik"]
+    got_h = cd.cdnlgssm_filter(P, y[:2, :Ts], t[:2, :Ts, None], cd.EKFHyperParams(diffeqsolve_settings=hifi_settings), output_fields=[]).marginal_loglik
+    assert relerr(got_h, ref_h) < 1e-9
+
+
 def test_adaptive_refusals(hip_lib):
     rng = np.random.default_rng(1)
     l63 = o.lorenz63_model(3)

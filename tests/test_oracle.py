@@ -400,3 +400,21 @@ def test_gradient_under_another_fixed_step_method_matches_finite_differences():
             mk = lambda th: o.Model(o.Lorenz63Drift(*th), mdl.L, mdl.Qc, mdl.H, mdl.bias, mdl.R, mdl.m0, mdl.P0)
             fd = (o.ekf_filter(mk(tp), t, y)["marginal_loglik"] - o.ekf_filter(mk(tm), t, y)["marginal_loglik"]) / (2 * h)
             np.testing.assert_allclose(g[:, p_], fd, rtol=2e-6, atol=1e-6)
+
+
+def test_notebook_pin_default_vs_tsit5_pid_loglik():
+    """The reference's tutorial prints the same float32 marginal log-likelihood under the default settings (Dopri5, dt0 = 0.01)
+    and under Tsit5 + PIDController(atol=1e-9, rtol=1e-9) (src/notebooks/tutorial/diffeqsolve_settings_analysis.ipynb:385-386:
+    -14591.8759765625 both; Lorenz-63, H = [1, 0, 0], R = 1, Q = I, P0 = 5 I, mean gap 0.005): agreement below one float32 ulp,
+    6.7e-8 relative.  The same model and time density on seeded synthetic data: the fp64 oracle's two solves must agree to that
+    bound -- the only statement of the reference that reaches the restated Tsit5 tableau and PID controller."""
+    rng = np.random.default_rng(2024)
+    mdl = o.lorenz63_model(1)  # H = [1, 0, 0], R = 1, L = Qc = I, m0 = 0, P0 = 5 I: the notebook's model
+    N, T = 2, 260
+    t = o.irregular_times(rng, N, T, 0.005 * T)
+    y = o.simulate(mdl, t, rng)
+    default = o.ekf_filter(mdl, t, y)["marginal_loglik"]
+    with o.use_solver("tsit5", adaptive=dict(rtol=1e-9, atol=1e-9)):
+        hifi = o.ekf_filter(mdl, t, y)["marginal_loglik"]
+    assert np.all(np.abs(default - hifi) <= 6.7e-8 * np.abs(hifi)), (default, hifi)
+    assert np.all(default != hifi)  # two different integrators: not the same numbers by construction
