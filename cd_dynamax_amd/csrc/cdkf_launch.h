@@ -3,6 +3,8 @@
 // LDS-resident wave-per-trajectory kernels (cdkf_wave_kernels.h).
 #pragma once
 #include <cstdlib>
+#include <mutex>
+#include <vector>
 #include "cdkf_host.h"
 
 // X(drift_kind, DriftTemplate, D, M)
@@ -143,5 +145,41 @@ inline bool reg_shape_available(const cdkf_model* mdl) {
 #undef X
   return false;
 }
+
+// ---- shared by the translation units that launch LDS-heavy kernels (launch_wg.hip, launch_w40.hip) ------------------------
+static constexpr size_t kLdsLimit = 160 * 1024;
+
+// Raise the dynamic-LDS cap of a kernel ONCE to the whole CU (minus the kernels' few static bytes).  Re-setting the
+// attribute to the exact size before every launch misbehaved on ROCm 7.2: the first launch after the size grew
+// ran with the stale, smaller cap and produced garbage.
+template <typename K>
+static int wg_raise_lds_cap(K kernel) {
+  CDKF_HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLdsLimit - 256)));
+  return CDKF_OK;
+}
+// The attribute belongs to the (kernel, device) pair: raise it once per device the process launches on, not once per process.
+// F is a distinct lambda type per call site and template instantiation, so each has its own record.
+template <typename F>
+static int once_per_device(F&& raise) {
+  static std::mutex m;
+  static std::vector<char> done;
+  int dev = 0;
+  CDKF_HIP_CHECK(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(m);
+  if ((size_t)dev >= done.size()) done.resize(dev + 1, 0);
+  if (!done[dev]) {
+    if (raise()) return CDKF_EHIP;
+    done[dev] = 1;
+  }
+  return CDKF_OK;
+}
+
+// Lorenz-96 with H = I at state_dim 40 (BASELINE config 4): wavefront-per-trajectory sweeps (launch_w40.hip,
+// cdkf_wave40_kernels.h).  backward = false: the filter sweep; true: the smoother's backward sweep over the filtered moments.
+template <typename R>
+struct WgArgs;
+bool wave40_shape(const cdkf_model* mdl, const cdkf_opts* o);
+template <typename R>
+int launch_wave40(const WgArgs<R>& a, hipStream_t stream, bool backward = false);
 
 }  // namespace cdkf

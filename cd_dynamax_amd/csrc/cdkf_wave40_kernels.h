@@ -51,7 +51,12 @@ struct W40 {
   static constexpr int o_buf = 0, o_L1 = BUF, o_L2 = o_L1 + LPK, o_xs = o_L2 + LPK, o_ca = o_xs + VEC, o_cb = o_ca + VEC,
                        o_i2 = o_cb + VEC, o_v = o_i2 + VEC, o_end = o_v + VEC;
   static constexpr int kWaves = 4;
-  static constexpr int SH = 2 * 64 * EPL;  // per workgroup: (L Qc L^T) and R entries in ownership order [s][lane]
+  // per workgroup: (L Qc L^T) and R entries in ownership order [s][lane], then the index table of the owned entries (two 32-bit
+  // words per entry: (i, j), and the entry's three offsets in the update's images), sized for 4-byte reals
+  static constexpr int SHQ = 2 * 64 * EPL, SH = SHQ + 2 * 64 * EPL;
+  // table word A: i | j << 8; word B: (i LDY + j) | (j LDY + i) << 11 | (rs(j) + i) << 22
+  static_assert(48 * (D + 2) < 2048 && 2 * ((D + 2) / 2) * ((D + 1) / 2 + 1) < 1024, "offsets fit their fields");
+  __host__ __device__ static constexpr bool owned(int s, int lane) { return lane + 64 * s < NP; }
 };
 template <int D>
 __host__ __device__ constexpr long wave40_lds_reals() { return (long)W40<D>::SH + (long)W40<D>::kWaves * W40<D>::o_end; }
@@ -82,10 +87,283 @@ CDKF_DEV double w40_readlane(double v, int l) {
 }
 CDKF_DEV float w40_readlane(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
 
+// ---- dense linear algebra of one wavefront on LDS-resident operands ------------------------------------------------------------
+// A symmetric positive-definite system of order D (+ one augmented row) in packed lower storage (row i at W40<D>::rs(i)), its
+// right-hand sides as the ROWS of an image with leading dimension LDY (lane c owns row c = right-hand side c).  Everything that is
+// a matrix product -- the contributions of the finished columns to a panel of the factorisation, of the solved blocks to the next
+// block of a triangular solve -- runs on the matrix cores in 16 x 16 tiles (v_mfma_*_16x16x4: A[m = lane & 15][k = lane >> 4],
+// B[k = lane >> 4][n = lane & 15]); only the 16-wide triangles on the diagonal are scalar recurrences (lane = row, the panel in
+// registers, multipliers through v_readlane / LDS broadcasts).  Callers synchronise the wavefront before the first call.
+#ifdef CDKF_W40_PROFILE  // local diagnostic build: cycles per phase (s_memtime), printed by trajectory 0
+__device__ long long w40_prof[16];
+#define W40_TICK(i)                                 \
+  {                                                 \
+    const long long w40_now = clock64();            \
+    if (threadIdx.x == 0 && blockIdx.x == 0) w40_prof[i] += w40_now - w40_last; \
+    w40_last = clock64();                            \
+  }
+#define W40_TICK_DECL long long w40_last = clock64();
+#define W40_TICK_ARG , long long& w40_last
+#define W40_TICK_PASS , w40_last
+#else
+#define W40_TICK(i)
+#define W40_TICK_DECL
+#define W40_TICK_ARG
+#define W40_TICK_PASS
+#endif
+
+template <typename R, int D>
+struct W40Lin {
+  using W = W40<D>;
+  using Tile = W40Tile<R>;
+  using V4 = typename Tile::V4;
+  static constexpr int LDY = W::LDY;
+  static constexpr int NB = (D + 15) / 16;  // blocks of sixteen rows / columns
+  static_assert(D % 8 == 0, "panels of eight or sixteen columns");
+
+  // L[i][c0 + c] -= sum_{k < c0} L[i][k] L[c0 + c][k]  for the rows i >= c0 (the augmented row D included), c < 16: the left-looking
+  // update of the panel of columns from c0 (a multiple of sixteen), for NS systems at once (independent accumulator chains)
+  template <int NS, int P>
+  static CDKF_DEV void chol_gemm(R* const (&L)[NS], const int lane) {
+    constexpr int c0 = 16 * P;
+    const int lm = lane & 15, lg = lane >> 4;
+    const int brow = c0 + lm;
+    const bool bin = brow <= D;
+    const int boff = W::rs(bin ? brow : D);
+    V4 acc[NS][NB];
+#pragma unroll
+    for (int it = 0; it < NB; ++it)
+      if (it >= P) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * it + Tile::row(lg, r);
+          const bool ok = row <= D && brow <= row;
+          const int o = W::rs(ok ? row : D) + brow;
+#pragma unroll
+          for (int s = 0; s < NS; ++s) acc[s][it][r] = ok ? L[s][o] : R(0);
+        }
+      }
+#pragma unroll
+    for (int k0 = 0; k0 < c0; k0 += 4) {
+      const int kk = k0 + lg;
+      R bv[NS], av[NS][NB];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) bv[s] = bin ? L[s][boff + kk] : R(0);
+#pragma unroll
+      for (int it = 0; it < NB; ++it)
+        if (it >= P) {
+          const int arow = 16 * it + lm;
+          const int ao = W::rs(arow <= D ? arow : D) + kk;
+#pragma unroll
+          for (int s = 0; s < NS; ++s) av[s][it] = arow <= D ? -L[s][ao] : R(0);
+        }
+#pragma unroll
+      for (int it = 0; it < NB; ++it)
+        if (it >= P) {
+#pragma unroll
+          for (int s = 0; s < NS; ++s) acc[s][it] = wg_mfma(av[s][it], bv[s], acc[s][it]);
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < NB; ++it)
+      if (it >= P) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * it + Tile::row(lg, r);
+          if (row <= D && brow <= row) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) L[s][W::rs(row) + brow] = acc[s][it][r];
+          }
+        }
+      }
+  }
+
+  // the W_ columns from c0 of the rows from c0, lane = row, the panel's entries in registers.  A finished column goes to a 64-entry
+  // LDS scratch indexed by row (col[s]); the multipliers L[c0 + q][c] of the columns still to update come back from there as
+  // broadcast reads, two per instruction (LDS executes a wavefront's accesses in order: no synchronisation in between).  Only the
+  // pivot travels through v_readlane.
+  template <int NS, int W_>
+  static CDKF_DEV void chol_panel(R* const (&L)[NS], R* const (&col)[NS], R* inv, const int c0, const int rowi, const int ri,
+                                  const int lane, R& quad, R& pinv, bool& bad) {
+    R u[NS][W_];
+#pragma unroll
+    for (int r = 0; r < W_; ++r)
+#pragma unroll
+      for (int s = 0; s < NS; ++s) u[s][r] = L[s][ri + c0 + r];
+#pragma unroll
+    for (int r = 0; r < W_; ++r) {
+      const int c = c0 + r;
+      R rr[NS];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const R p = w40_readlane(u[s][r], c);
+        bad = bad || !(p > R(0));
+        rr[s] = w40_rsqrt(p);
+        u[s][r] *= rr[s];  // L[i][c] for the rows below the pivot
+        if (r + 1 < W_) col[s][lane] = u[s][r];
+      }
+      if (lane == D) quad = rfma(u[0][r], u[0][r], quad);
+      if (lane == 0) inv[c] = rr[NS - 1];
+      pinv *= rr[0];
+      R mult[NS][W_];
+#pragma unroll
+      for (int q = r + 1; q < W_; ++q)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) mult[s][q] = col[s][c0 + q];  // L[c0 + q][c]
+#pragma unroll
+      for (int q = r + 1; q < W_; ++q)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) u[s][q] = rfma(-u[s][r], mult[s][q], u[s][q]);
+    }
+#pragma unroll
+    for (int r = 0; r < W_; ++r)
+      if (rowi > c0 + r) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) L[s][ri + c0 + r] = u[s][r];
+      }
+  }
+
+  // Cholesky factorisation of NS systems in lockstep, lane = row (rowi; lanes above D shadow row D, ri = rs(rowi)).  System 0's
+  // augmented row is forward-substituted along the way: quad accumulates its squares on lane D; logdet the logs of system 0's
+  // reciprocal pivots; inv[] (LDS) the reciprocal pivots of the LAST system (the one the solves use); col[s]: 64 reals of LDS
+  // scratch per system.  bad: a pivot was not positive.
+  template <int NS>
+  static CDKF_DEV void cholesky(R* const (&L)[NS], R* const (&col)[NS], R* inv, const int rowi, const int ri, const int lane,
+                                R& quad, double& logdet, bool& bad W40_TICK_ARG) {
+    static_assert(NB <= 3, "panels beyond the third: add a case");
+    for (int P = 0; P < NB; ++P) {
+      const int c0 = 16 * P;
+      if (P == 1) chol_gemm<NS, 1>(L, lane);
+      if (P == 2) chol_gemm<NS, 2>(L, lane);
+      if (P) wave_sync();
+      W40_TICK(1)
+      R pinv = R(1);
+      if (D - c0 >= 16)
+        chol_panel<NS, 16>(L, col, inv, c0, rowi, ri, lane, quad, pinv, bad);
+      else
+        chol_panel<NS, (D % 16 ? D % 16 : 16)>(L, col, inv, c0, rowi, ri, lane, quad, pinv, bad);
+      W40_TICK(2)
+      logdet += log((double)pinv);
+      wave_sync();
+      W40_TICK(4)
+    }
+  }
+
+  // img[c][16 b + r] -= sum_k img[c][k] Lf(16 b + r, k) over the unknowns k already solved: k < 16 b going forward (Lf(i, k) = L[i][k]),
+  // k >= 16 (b + 1) going backward (Lf(i, k) = L[k][i], the transposed factor); all D right-hand sides c, r < 16
+  template <bool FWD, int b>
+  static CDKF_DEV void solve_gemm(R* img, const R* L, const int lane) {
+    const int lm = lane & 15, lg = lane >> 4;
+    const int ucol = 16 * b + lm;  // the unknown this lane's B operand / accumulator column stands for
+    const bool uin = ucol < D;
+    V4 acc[NB];
+#pragma unroll
+    for (int ct = 0; ct < NB; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * ct + Tile::row(lg, r);
+        acc[ct][r] = (row < D && uin) ? img[row * LDY + ucol] : R(0);
+      }
+    constexpr int kbeg = FWD ? 0 : 16 * (b + 1), kend = FWD ? 16 * b : D;
+    const int boff = W::rs(uin ? ucol : 0);
+#pragma unroll
+    for (int k0 = kbeg; k0 < kend; k0 += 4) {
+      const int kk = k0 + lg;
+      const R bv = uin ? (FWD ? L[boff + kk] : L[W::rs(kk) + ucol]) : R(0);
+      R av[NB];
+#pragma unroll
+      for (int ct = 0; ct < NB; ++ct) av[ct] = (16 * ct + lm < D) ? -img[(16 * ct + lm) * LDY + kk] : R(0);
+#pragma unroll
+      for (int ct = 0; ct < NB; ++ct) acc[ct] = wg_mfma(av[ct], bv, acc[ct]);
+    }
+#pragma unroll
+    for (int ct = 0; ct < NB; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * ct + Tile::row(lg, r);
+        if (row < D && uin) img[row * LDY + ucol] = acc[ct][r];
+      }
+  }
+
+  // the W_ unknowns from c0 of this lane's right-hand side: the triangle on the diagonal (factor entries as LDS broadcasts)
+  template <bool FWD, int W_>
+  static CDKF_DEV void sub_block(R* mine, const R* L, const R* inv, const R* dotw, const int c0, const bool isrow, R& dot) {
+    R u[W_];
+#pragma unroll
+    for (int r = 0; r < W_; ++r) u[r] = mine[c0 + r];
+    if constexpr (FWD) {
+#pragma unroll
+      for (int r = 0; r < W_; ++r) {
+        const R* Lr = L + W::rs(c0 + r) + c0;
+#pragma unroll
+        for (int q = 0; q < r; ++q) u[r] = rfma(-Lr[q], u[q], u[r]);
+        u[r] *= inv[c0 + r];
+      }
+    } else {
+      const R* Lq[W_];
+#pragma unroll
+      for (int q = 0; q < W_; ++q) Lq[q] = L + W::rs(c0 + q) + c0;
+#pragma unroll
+      for (int r = W_ - 1; r >= 0; --r) {
+#pragma unroll
+        for (int q = r + 1; q < W_; ++q) u[r] = rfma(-Lq[q][r], u[q], u[r]);
+        u[r] *= inv[c0 + r];
+      }
+      if (dotw) {
+#pragma unroll
+        for (int r = 0; r < W_; ++r) dot = rfma(u[r], dotw[c0 + r], dot);
+      }
+    }
+    if (isrow) {
+#pragma unroll
+      for (int r = 0; r < W_; ++r) mine[c0 + r] = u[r];
+    }
+  }
+
+  // (L L^T) x = b for the D right-hand sides held as the rows of img (lane c < D: row c, in place).  After the forward pass the image
+  // holds Y = L^-1 B (by rows: Y^T), handed to `between` (the filter's rank-d product reads it there); returns this lane's
+  // x . dotw (dotw: a D-vector in LDS, or nullptr).
+  template <typename Between>
+  static CDKF_DEV R solve(R* img, const R* L, const R* inv, const R* dotw, const int lane, Between&& between W40_TICK_ARG) {
+    constexpr int WL = D % 16 ? D % 16 : 16;  // width of the last block
+    const bool isrow = lane < D;
+    R* mine = img + (isrow ? lane : 0) * LDY;
+    R dot = R(0);
+    for (int b = 0; b < NB; ++b) {  // forward
+      if (b == 1) solve_gemm<true, 1>(img, L, lane);
+      if (b == 2) solve_gemm<true, 2>(img, L, lane);
+      if (b) wave_sync();
+      W40_TICK(5)
+      if (b < NB - 1)
+        sub_block<true, 16>(mine, L, inv, dotw, 16 * b, isrow, dot);
+      else
+        sub_block<true, WL>(mine, L, inv, dotw, 16 * b, isrow, dot);
+      wave_sync();
+      W40_TICK(6)
+    }
+    between();
+    W40_TICK(7)
+    for (int b = NB - 1; b >= 0; --b) {  // backward
+      if (b == 0 && NB > 1) solve_gemm<false, 0>(img, L, lane);
+      if (b == 1 && NB > 2) solve_gemm<false, 1>(img, L, lane);
+      if (b < NB - 1) wave_sync();
+      W40_TICK(8)
+      if (b < NB - 1)
+        sub_block<false, 16>(mine, L, inv, dotw, 16 * b, isrow, dot);
+      else
+        sub_block<false, WL>(mine, L, inv, dotw, 16 * b, isrow, dot);
+      wave_sync();
+      W40_TICK(9)
+    }
+    return dot;
+  }
+};
+
 template <typename R, int D>
 __global__ __launch_bounds__(256, 1) void ekf_filter_wave_l96_kernel(const WgArgs<R> a) {
   using W = W40<D>;
   using Tile = W40Tile<R>;
+  using Lin = W40Lin<R, D>;
   constexpr int EPL = W::EPL, LDP = W::LDP, LDY = W::LDY;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -107,8 +385,8 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave_l96_kernel(const WgArg
   // (the entry's constants (L Qc L^T)_ij and R_ij live once per workgroup in LDS, slot-major so that a wavefront reads a
   //  contiguous run; the per-entry addresses other than the stage image's are recomputed from (i, j) where they are used --
   //  registers are what the scheduler needs to keep LDS reads in flight)
-  int offP[EPL], ei[EPL], ej[EPL];
-  bool own[EPL];
+  unsigned* tabA = reinterpret_cast<unsigned*>(shQ + W::SHQ);
+  unsigned* tabB = tabA + 64 * EPL;
   R Pe[EPL];
   {
     const R* P0 = a.par + a.o_P0;
@@ -117,29 +395,29 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave_l96_kernel(const WgArg
 #pragma unroll
     for (int s = 0; s < EPL; ++s) {
       const int e = lane + 64 * s;
-      own[s] = e < W::NP;
+      const bool own = e < W::NP;
       int i = 0, rs = 0;  // row i starts at rs = i D - i (i - 1) / 2
       while (i + 1 < D && e >= rs + (D - i)) {
         rs += D - i;
         ++i;
       }
-      const int j = own[s] ? i + (e - rs) : i;
-      ei[s] = i;
-      ej[s] = j;
-      offP[s] = (i + 2) * LDP + (j + 2);
-      Pe[s] = own[s] ? R(0.5) * (P0[i * D + j] + P0[j * D + i]) : R(0);
+      const int j = own ? i + (e - rs) : i;
+      Pe[s] = own ? R(0.5) * (P0[i * D + j] + P0[j * D + i]) : R(0);
       if (wave == 0) {
-        shQ[64 * s + lane] = own[s] ? LQL[i * D + j] : R(0);
-        shR[64 * s + lane] = own[s] ? Rm[i * D + j] : R(0);
+        shQ[64 * s + lane] = own ? LQL[i * D + j] : R(0);
+        shR[64 * s + lane] = own ? Rm[i * D + j] : R(0);
+        tabA[64 * s + lane] = (unsigned)i | (unsigned)j << 8;
+        tabB[64 * s + lane] = (unsigned)(i * LDY + j) | (unsigned)(j * LDY + i) << 11 | (unsigned)(W::rs(j) + i) << 22;
       }
     }
   }
   __syncthreads();
   if (n >= a.N) return;  // whole wavefront; no workgroup barrier anywhere below
-  auto offT = [&](int s) { return (ej[s] + 2) * LDP + (ei[s] + 2); };   // transposed position in the stage image
-  auto offY = [&](int s) { return ei[s] * LDY + ej[s]; };               // update image, row-major
-  auto offYT = [&](int s) { return ej[s] * LDY + ei[s]; };
-  auto offL = [&](int s) { return W::rs(ej[s]) + ei[s]; };              // packed lower: row j, column i (i <= j)
+  // the owned entries' indices come from the table where they are used (registers are for the Runge-Kutta slopes and the panels)
+  struct Ent { int i, j; };
+  auto entry = [&](int s) { const unsigned w = tabA[64 * s + lane]; return Ent{(int)(w & 255u), (int)(w >> 8)}; };
+  struct Off { int y, yt, l; };
+  auto offsets = [&](int s) { const unsigned w = tabB[64 * s + lane]; return Off{(int)(w & 2047u), (int)((w >> 11) & 2047u), (int)(w >> 22)}; };
   const bool isrow = lane < D;
   const int lp1 = (lane + 1 >= D) ? lane + 1 - D : lane + 1, lm1 = (lane == 0) ? D - 1 : lane - 1,
             lm2 = (lane <= 1) ? lane + D - 2 : lane - 2;
@@ -163,12 +441,18 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave_l96_kernel(const WgArg
 
   // stage image of (mean, covariance) in LDS; returns the slopes of the owned entries and of the lane's mean component
   auto rhs = [&](const R (&Ps)[EPL], const R xm, R (&kP)[EPL], R& kM) {
+    int ei[EPL], ej[EPL], offP[EPL];
 #pragma unroll
-    for (int s = 0; s < EPL; ++s)
-      if (own[s]) {
+    for (int s = 0; s < EPL; ++s) {
+      const Ent e = entry(s);
+      ei[s] = e.i;
+      ej[s] = e.j;
+      offP[s] = (e.i + 2) * LDP + (e.j + 2);
+      if (W::owned(s, lane)) {
         buf[offP[s]] = Ps[s];
-        buf[offT(s)] = Ps[s];
+        buf[(e.j + 2) * LDP + (e.i + 2)] = Ps[s];
       }
+    }
     if (isrow) xs[lane] = xm;
     wave_sync();
     // halo of the image: rows -2, -1 <- D-2, D-1; row D <- 0; the same for the columns (corners are never read)
@@ -219,7 +503,7 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave_l96_kernel(const WgArg
           k = rfma(c4[u][1], o6[u][1], k);
           k = rfma(c4[u][2], o6[u][5] - o6[u][3], k);
           k = rfma(c4[u][3], o6[u][4], k);
-          kP[s] = own[s] ? k : R(0);
+          kP[s] = W::owned(s, lane) ? k : R(0);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -231,12 +515,21 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave_l96_kernel(const WgArg
   auto store_cov = [&](R* dst, long k, const R* img, int ld, int) {
     if (!dst || (skip & 16)) return;
     R* o = dst + n * a.P_sn + k * a.P_sk;
-    for (int e = lane; e < D * D; e += 64) {
-      const int r = fdiv(e, D), c = e - r * D;
-      o[(long)e * a.P_si] = img[r * ld + c];
+    constexpr int NE = (D * D + 63) / 64;
+    R v[NE];
+#pragma unroll
+    for (int q = 0; q < NE; ++q) {  // all reads in flight, then the stores
+      const int e = lane + 64 * q, r = e / D, c = e - r * D;
+      v[q] = (e < D * D) ? img[r * ld + c] : R(0);
+    }
+#pragma unroll
+    for (int q = 0; q < NE; ++q) {
+      const int e = lane + 64 * q;
+      if (e < D * D) o[(long)e * a.P_si] = v[q];
     }
   };
 
+  W40_TICK_DECL
   for (long k = 0; k < a.T; ++k) {
     const R yk = ynext;
     const R tnext_obs = (k + 1 < a.T) ? tp[(k + 1) * a.t_sk] : tcur;
@@ -244,15 +537,20 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave_l96_kernel(const WgArg
 
     // =================================== update ===================================================================================
     // S = P + R into both packed systems (row d: the innovation), P itself into the image (rows = columns of the solves)
+    int oY[EPL], oYT[EPL];  // the owned entries' two positions in the (symmetric) image, kept for the whole update
 #pragma unroll
-    for (int s = 0; s < EPL; ++s)
-      if (own[s]) {
+    for (int s = 0; s < EPL; ++s) {
+      const Off f = offsets(s);
+      oY[s] = f.y;
+      oYT[s] = f.yt;
+      if (W::owned(s, lane)) {
         const R sv = Pe[s] + shR[64 * s + lane];
-        L1[offL(s)] = sv;
-        L2[offL(s)] = (ei[s] == ej[s]) ? sv + R(1e-9) : sv;
-        buf[offY(s)] = Pe[s];
-        buf[offYT(s)] = Pe[s];
+        L1[f.l] = sv;
+        L2[f.l] = (f.y == f.yt) ? sv + R(1e-9) : sv;
+        buf[f.y] = Pe[s];
+        buf[f.yt] = Pe[s];
       }
+    }
     if (isrow) {
       const R v = yk - mj;
       L1[W::rs(D) + lane] = v;
@@ -261,79 +559,21 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave_l96_kernel(const WgArg
     }
     for (int e = lane; e < (48 - D) * LDY; e += 64) buf[D * LDY + e] = R(0);  // rows d .. 47 of the image: zero operands of the tiles
     wave_sync();
-    // left-looking factorisation of both systems by panels of eight columns, lane i = row i (row d: forward substitution of the
-    // innovation).  A panel's eight entries of the lane's row sit in registers for both systems (sixteen independent chains): the
-    // contributions of the finished columns stream in from LDS (the lane's own row + broadcasts of the panel's rows), inside the
-    // panel the multipliers L[8p+q][c] are other lanes' registers and arrive through v_readlane -- no LDS round trip, one
-    // wavefront synchronisation per panel.
+    // both factorisations in lockstep (W40Lin::cholesky): system 0 = S with the innovation as its augmented row (TFP's factor: the
+    // log-likelihood's log-determinant and quadratic form), system 1 = S + 1e-9 I (psd_solve's factor: the gain)
     R quad = R(0);
-    for (int p = 0; p < ((skip & 1) ? 0 : D / 8); ++p) {
-      const int c0 = 8 * p;
-      R u1[8], u2[8];
-#pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        u1[r] = L1[ri + c0 + r];
-        u2[r] = L2[ri + c0 + r];
-      }
-      for (int t0 = 0; t0 < c0; t0 += 2) {  // two finished columns at a time: 36 LDS reads in flight, then 32 multiply-adds
-        R a1[2], a2[2], b1[2][8], b2[2][8];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          a1[q] = L1[ri + t0 + q];
-          a2[q] = L2[ri + t0 + q];
-#pragma unroll
-          for (int r = 0; r < 8; ++r) {
-            const int rr = W::rs(c0 + r) + t0 + q;
-            b1[q][r] = L1[rr];
-            b2[q][r] = L2[rr];
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-          for (int r = 0; r < 8; ++r) {
-            u1[r] = rfma(-a1[q], b1[q][r], u1[r]);
-            u2[r] = rfma(-a2[q], b2[q][r], u2[r]);
-          }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      R pinv = R(1);
-#pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const int c = c0 + r;
-        const R p1 = w40_readlane(u1[r], c), p2 = w40_readlane(u2[r], c);
-        bad = bad || !(p1 > R(0)) || !(p2 > R(0));
-        const R r1 = w40_rsqrt(p1), r2 = w40_rsqrt(p2);
-        u1[r] *= r1;  // L[i][c] for the rows below the pivot
-        u2[r] *= r2;
-        if (lane == D) quad = rfma(u1[r], u1[r], quad);  // z_c of the log-likelihood's forward substitution
-        if (lane == 0) inv2[c] = r2;
-        pinv *= r1;
-#pragma unroll
-        for (int q = r + 1; q < 8; ++q) {
-          const R b1 = w40_readlane(u1[r], c0 + q), b2 = w40_readlane(u2[r], c0 + q);  // L[c0+q][c]
-          u1[q] = rfma(-u1[r], b1, u1[q]);
-          u2[q] = rfma(-u2[r], b2, u2[q]);
-        }
-      }
-      ll.ll += log((double)pinv);  // sum of the logs of the reciprocal pivots, eight at a time
-#pragma unroll
-      for (int r = 0; r < 8; ++r)
-        if (rowi > c0 + r) {
-          L1[ri + c0 + r] = u1[r];
-          L2[ri + c0 + r] = u2[r];
-        }
-      wave_sync();
+    if (!(skip & 1)) {
+      R* const sys[2] = {L1, L2};
+      R* const scr[2] = {ca, cb};  // (the predict step's coefficient vectors: free during the update)
+      W40_TICK(0)
+      Lin::template cholesky<2>(sys, scr, inv2, rowi, ri, lane, quad, ll.ll, bad W40_TICK_PASS);
     }
     ll.ll += -0.5 * (double)w40_readlane(quad, D) - 0.5 * D * 1.8378770664093454835606594728112;
 
-    // gain: lane c < D solves (L2 L2^T) x = P[:, c] in place in its row of the image, eight unknowns at a time in registers: the
-    // contributions of the rows already solved stream through (their unknowns from the lane's own row, the factor's entries as
-    // broadcasts), the 8 x 8 triangle inside a block is unrolled.  After the forward pass the image holds Y (row c = column c of
-    // Y = L_b^-1 P), after the backward pass X: each is consumed by a rank-d product on the matrix cores where it stands --
-    // T = Y^T Y - 1e-9 X^T X; the A- and B-operand layouts of v_mfma_*_16x16x4 coincide, so one read serves both sides.
-    static_assert(D % 8 == 0, "blocks of eight unknowns");
+    // gain: lane c < D solves (L2 L2^T) x = P[:, c] in place in its row of the image (W40Lin::solve).  After the forward pass the
+    // image holds Y (row c = column c of Y = L_b^-1 P), after the backward pass X: each is consumed by a rank-d product on the
+    // matrix cores where it stands -- T = Y^T Y - 1e-9 X^T X; the A- and B-operand layouts of v_mfma_*_16x16x4 coincide, so one
+    // read serves both sides.
     typename Tile::V4 acc[6];
 #pragma unroll
     for (int q = 0; q < 6; ++q) acc[q] = typename Tile::V4{0, 0, 0, 0};
@@ -356,80 +596,17 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave_l96_kernel(const WgArg
           }
       }
     };
-    R* mine = buf + (isrow ? lane : 0) * LDY;
-    for (int b = 0; b < ((skip & 2) ? 0 : D / 8); ++b) {  // forward: L2 y = p
-      R u[8];
-#pragma unroll
-      for (int r = 0; r < 8; ++r) u[r] = mine[8 * b + r];
-      for (int t0 = 0; t0 < 8 * b; t0 += 4) {  // four solved unknowns at a time: 36 LDS reads in flight, then 32 multiply-adds
-        R yt[4], lv[4][8];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          yt[q] = mine[t0 + q];
-#pragma unroll
-          for (int r = 0; r < 8; ++r) lv[q][r] = L2[W::rs(8 * b + r) + t0 + q];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-          for (int r = 0; r < 8; ++r) u[r] = rfma(-lv[q][r], yt[q], u[r]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-#pragma unroll
-      for (int r = 0; r < 8; ++r) {
-#pragma unroll
-        for (int q = 0; q < r; ++q) u[r] = rfma(-L2[W::rs(8 * b + r) + 8 * b + q], u[q], u[r]);
-        u[r] *= inv2[8 * b + r];
-      }
-      if (isrow) {
-#pragma unroll
-        for (int r = 0; r < 8; ++r) mine[8 * b + r] = u[r];
-      }
-    }
-    wave_sync();
-    if (!(skip & 4)) rank_update(R(1));
-    wave_sync();
     R dotv = R(0);  // X^T v of this lane's column
-    for (int b = ((skip & 2) ? -1 : D / 8 - 1); b >= 0; --b) {  // backward: L2^T x = y
-      R u[8];
-#pragma unroll
-      for (int r = 0; r < 8; ++r) u[r] = mine[8 * b + r];
-      for (int t0 = D - 4; t0 >= 8 * b + 8; t0 -= 4) {
-        R xt[4], lv[4][8];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          xt[q] = mine[t0 + q];
-          const R* Lt = L2 + W::rs(t0 + q) + 8 * b;
-#pragma unroll
-          for (int r = 0; r < 8; ++r) lv[q][r] = Lt[r];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-          for (int r = 0; r < 8; ++r) u[r] = rfma(-lv[q][r], xt[q], u[r]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-#pragma unroll
-      for (int r = 7; r >= 0; --r) {
-#pragma unroll
-        for (int q = r + 1; q < 8; ++q) u[r] = rfma(-L2[W::rs(8 * b + q) + 8 * b + r], u[q], u[r]);
-        u[r] *= inv2[8 * b + r];
-      }
-#pragma unroll
-      for (int r = 0; r < 8; ++r) dotv = rfma(u[r], vv[8 * b + r], dotv);
-      if (isrow) {
-#pragma unroll
-        for (int r = 0; r < 8; ++r) mine[8 * b + r] = u[r];
-      }
-    }
+    if (!(skip & 2))
+      dotv = Lin::solve(buf, L2, inv2, vv, lane, [&] {
+        if (!(skip & 4)) rank_update(R(1));
+        wave_sync();
+      } W40_TICK_PASS);
     // m+ = m + X^T v
     if (isrow) {
       mj += dotv;
       if (mj != mj) st |= kStatusNan;
     }
-    wave_sync();
     if (!(skip & 4)) rank_update(R(-1e-9));
     wave_sync();
     // tiles -> image (row-major, leading dimension LDY) -> owners
@@ -450,20 +627,21 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave_l96_kernel(const WgArg
     wave_sync();
 #pragma unroll
     for (int s = 0; s < EPL; ++s)
-      if (own[s]) Pe[s] -= buf[offY(s)];
+      if (W::owned(s, lane)) Pe[s] -= buf[oY[s]];
     wave_sync();
     // filtered moments out: full symmetric image first
 #pragma unroll
     for (int s = 0; s < EPL; ++s)
-      if (own[s]) {
-        buf[offY(s)] = Pe[s];
-        buf[offYT(s)] = Pe[s];
+      if (W::owned(s, lane)) {
+        buf[oY[s]] = Pe[s];
+        buf[oYT[s]] = Pe[s];
       }
     if (a.fm && isrow) a.fm[n * a.m_sn + k * a.m_sk + lane * a.m_si] = mj;
     wave_sync();
     store_cov(a.fP, k, buf, LDY, 0);
     wave_sync();
 
+    W40_TICK(10)
     // =================================== predict ==================================================================================
     const R t1 = (k + 1 < a.T) ? tnext_obs : tcur + a.dt_final;
     {
@@ -528,14 +706,16 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave_l96_kernel(const WgArg
         ++steps;
       }
     }
+    W40_TICK(11)
     // predicted moments out
     if (a.pm && isrow) a.pm[n * a.m_sn + k * a.m_sk + lane * a.m_si] = mj;
     if (a.pP) {
 #pragma unroll
       for (int s = 0; s < EPL; ++s)
-        if (own[s]) {
-          buf[offY(s)] = Pe[s];
-          buf[offYT(s)] = Pe[s];
+        if (W::owned(s, lane)) {
+          const Off f = offsets(s);
+          buf[f.y] = Pe[s];
+          buf[f.yt] = Pe[s];
         }
       wave_sync();
       store_cov(a.pP, k, buf, LDY, 0);
@@ -548,6 +728,13 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave_l96_kernel(const WgArg
     a.ll[n] = (R)ll.ll;
     if (a.status) a.status[n] = st;
   }
+#ifdef CDKF_W40_PROFILE
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    printf("w40 cycles/step:");
+    for (int i = 0; i < 12; ++i) printf(" [%d] %lld", i, w40_prof[i] / a.T);
+    printf("\n");
+  }
+#endif
 }
 
 }  // namespace cdkf

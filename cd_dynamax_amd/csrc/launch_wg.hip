@@ -4,13 +4,8 @@
 #include "cdkf_wave8_kernels.h"
 #include "cdkf_adjoint_kernels.h"
 #include "cdkf_rts1_kernels.h"
-#include "cdkf_wave40_kernels.h"
-
-#include <mutex>
 
 namespace cdkf {
-
-static constexpr size_t kLdsLimit = 160 * 1024;
 
 static int wg_hsel(const cdkf_model* mdl) { return emission_is_selection(mdl) ? 1 : 0; }
 
@@ -166,31 +161,6 @@ static int wg_prepare(WgArgs<R>& a, R** dev_block, ParamSlot** slot_out, const c
   return CDKF_OK;
 }
 
-// Raise the dynamic-LDS cap of a kernel ONCE to the whole CU (minus the kernels' few static bytes).  Re-setting the
-// attribute to the exact size before every launch misbehaved on ROCm 7.2: the first launch after the size grew
-// ran with the stale, smaller cap and produced garbage.
-template <typename K>
-static int wg_raise_lds_cap(K kernel) {
-  CDKF_HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLdsLimit - 256)));
-  return CDKF_OK;
-}
-// The attribute belongs to the (kernel, device) pair: raise it once per device the process launches on, not once per process.
-// F is a distinct lambda type per call site and template instantiation, so each has its own record.
-template <typename F>
-static int once_per_device(F&& raise) {
-  static std::mutex m;
-  static std::vector<char> done;
-  int dev = 0;
-  CDKF_HIP_CHECK(hipGetDevice(&dev));
-  std::lock_guard<std::mutex> lock(m);
-  if ((size_t)dev >= done.size()) done.resize(dev + 1, 0);
-  if (!done[dev]) {
-    if (raise()) return CDKF_EHIP;
-    done[dev] = 1;
-  }
-  return CDKF_OK;
-}
-
 static int wg_threads(int d) {
   if (const char* e = getenv("CDKF_WG_THREADS")) return atoi(e);  // debugging aid
   // d >= 32: 512 threads (two wavefronts per SIMD hide each other's LDS latency, and 4 owned entries per thread
@@ -267,34 +237,6 @@ static int launch_wave8(const WgArgs<R>& a, hipStream_t stream) {
   const unsigned blocks = (unsigned)((a.N + kW8Waves - 1) / kW8Waves);
   note_kernel("ekf_filter_wave8_kernel<%s>", real_name<R>());
   hipLaunchKernelGGL(ekf_filter_wave8_kernel<R>, dim3(blocks), dim3(64 * kW8Waves), lds, stream, a);
-  CDKF_HIP_CHECK(hipGetLastError());
-  return CDKF_OK;
-}
-
-// Lorenz-96 with H = I at state_dim 40 (BASELINE config 4): wavefront-per-trajectory sweep (cdkf_wave40_kernels.h)
-static bool wave40_shape(const cdkf_model* mdl, const cdkf_opts* o) {
-  if (getenv("CDKF_NO_WAVE40")) return false;  // A/B and tests: keep the workgroup kernels
-  const int d = mdl->state_dim;
-  if (mdl->drift_kind != CDKF_DRIFT_LORENZ96 || d != 40 || mdl->emission_dim != d || !emission_is_selection(mdl)) return false;
-  if (o->num_iter != 1 || o->forecast || o->state_order == CDKF_ORDER_ZEROTH || o->solver != CDKF_SOLVER_DOPRI5 || o->adaptive)
-    return false;
-  for (int r = 0; r < d; ++r)
-    for (int c = 0; c < r; ++c)
-      if (mdl->R[r * d + c] != mdl->R[c * d + r]) return false;  // P - X^T S X is formed as P - Y^T Y + 1e-9 X^T X
-  return true;
-}
-
-template <typename R>
-static int launch_wave40(const WgArgs<R>& a, hipStream_t stream) {
-  constexpr int D = 40;
-  if (once_per_device([] { return wg_raise_lds_cap(ekf_filter_wave_l96_kernel<R, D>); })) return CDKF_EHIP;
-  const size_t lds = sizeof(R) * (size_t)wave40_lds_reals<D>() + 64;
-  const unsigned blocks = (unsigned)((a.N + W40<D>::kWaves - 1) / W40<D>::kWaves);
-  note_kernel("ekf_filter_wave_l96_kernel<%s, %d>", real_name<R>(), D);
-  WgArgs<R> b = a;
-  const char* ab = getenv("CDKF_W40_ABLATE");  // diagnostic: mask of phases to skip (see the kernel); never set in production
-  b.forecast = ab ? atoi(ab) : 0;
-  hipLaunchKernelGGL((ekf_filter_wave_l96_kernel<R, D>), dim3(blocks), dim3(64 * W40<D>::kWaves), lds, stream, b);
   CDKF_HIP_CHECK(hipGetLastError());
   return CDKF_OK;
 }
