@@ -359,6 +359,57 @@ struct W40Lin {
   }
 };
 
+// One Dormand-Prince step of the owned covariance entries and the lane's mean component (slopes scaled by dt as they are formed).
+template <typename R, int EPL, typename Rhs>
+CDKF_DEV void w40_dopri5(Rhs&& rhs, R (&Pe)[EPL], R& mj, const R dt) {
+  using C = Dp5<R>;
+  R k1[EPL], k2[EPL], k3[EPL], k4[EPL], k5[EPL], k6[EPL], ys[EPL];
+  R m1, m2, m3, m4, m5, m6;
+  rhs(Pe, mj, k1, m1);
+#pragma unroll
+  for (int s = 0; s < EPL; ++s) {
+    k1[s] *= dt;
+    ys[s] = rfma(C::a21, k1[s], Pe[s]);
+  }
+  m1 *= dt;
+  rhs(ys, rfma(C::a21, m1, mj), k2, m2);
+#pragma unroll
+  for (int s = 0; s < EPL; ++s) {
+    k2[s] *= dt;
+    ys[s] = rfma(C::a32, k2[s], rfma(C::a31, k1[s], Pe[s]));
+  }
+  m2 *= dt;
+  rhs(ys, rfma(C::a32, m2, rfma(C::a31, m1, mj)), k3, m3);
+#pragma unroll
+  for (int s = 0; s < EPL; ++s) {
+    k3[s] *= dt;
+    ys[s] = rfma(C::a43, k3[s], rfma(C::a42, k2[s], rfma(C::a41, k1[s], Pe[s])));
+  }
+  m3 *= dt;
+  rhs(ys, rfma(C::a43, m3, rfma(C::a42, m2, rfma(C::a41, m1, mj))), k4, m4);
+#pragma unroll
+  for (int s = 0; s < EPL; ++s) {
+    k4[s] *= dt;
+    ys[s] = rfma(C::a54, k4[s], rfma(C::a53, k3[s], rfma(C::a52, k2[s], rfma(C::a51, k1[s], Pe[s]))));
+  }
+  m4 *= dt;
+  rhs(ys, rfma(C::a54, m4, rfma(C::a53, m3, rfma(C::a52, m2, rfma(C::a51, m1, mj)))), k5, m5);
+#pragma unroll
+  for (int s = 0; s < EPL; ++s) {
+    k5[s] *= dt;
+    ys[s] = rfma(C::a65, k5[s], rfma(C::a64, k4[s], rfma(C::a63, k3[s], rfma(C::a62, k2[s], rfma(C::a61, k1[s], Pe[s])))));
+  }
+  m5 *= dt;
+  rhs(ys, rfma(C::a65, m5, rfma(C::a64, m4, rfma(C::a63, m3, rfma(C::a62, m2, rfma(C::a61, m1, mj))))), k6, m6);
+#pragma unroll
+  for (int s = 0; s < EPL; ++s) {
+    k6[s] *= dt;
+    Pe[s] = rfma(C::b6, k6[s], rfma(C::b5, k5[s], rfma(C::b4, k4[s], rfma(C::b3, k3[s], rfma(C::b1, k1[s], Pe[s])))));
+  }
+  m6 *= dt;
+  mj = rfma(C::b6, m6, rfma(C::b5, m5, rfma(C::b4, m4, rfma(C::b3, m3, rfma(C::b1, m1, mj)))));
+}
+
 template <typename R, int D>
 __global__ __launch_bounds__(256, 1) void ekf_filter_wave_l96_kernel(const WgArgs<R> a) {
   using W = W40<D>;
@@ -654,52 +705,7 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave_l96_kernel(const WgArg
           break;
         }
         const R dt = tnx - tprev;
-        using C = Dp5<R>;
-        R k1[EPL], k2[EPL], k3[EPL], k4[EPL], k5[EPL], k6[EPL], ys[EPL];
-        R m1, m2, m3, m4, m5, m6;
-        rhs(Pe, mj, k1, m1);
-#pragma unroll
-        for (int s = 0; s < EPL; ++s) {
-          k1[s] *= dt;
-          ys[s] = rfma(C::a21, k1[s], Pe[s]);
-        }
-        m1 *= dt;
-        rhs(ys, rfma(C::a21, m1, mj), k2, m2);
-#pragma unroll
-        for (int s = 0; s < EPL; ++s) {
-          k2[s] *= dt;
-          ys[s] = rfma(C::a32, k2[s], rfma(C::a31, k1[s], Pe[s]));
-        }
-        m2 *= dt;
-        rhs(ys, rfma(C::a32, m2, rfma(C::a31, m1, mj)), k3, m3);
-#pragma unroll
-        for (int s = 0; s < EPL; ++s) {
-          k3[s] *= dt;
-          ys[s] = rfma(C::a43, k3[s], rfma(C::a42, k2[s], rfma(C::a41, k1[s], Pe[s])));
-        }
-        m3 *= dt;
-        rhs(ys, rfma(C::a43, m3, rfma(C::a42, m2, rfma(C::a41, m1, mj))), k4, m4);
-#pragma unroll
-        for (int s = 0; s < EPL; ++s) {
-          k4[s] *= dt;
-          ys[s] = rfma(C::a54, k4[s], rfma(C::a53, k3[s], rfma(C::a52, k2[s], rfma(C::a51, k1[s], Pe[s]))));
-        }
-        m4 *= dt;
-        rhs(ys, rfma(C::a54, m4, rfma(C::a53, m3, rfma(C::a52, m2, rfma(C::a51, m1, mj)))), k5, m5);
-#pragma unroll
-        for (int s = 0; s < EPL; ++s) {
-          k5[s] *= dt;
-          ys[s] = rfma(C::a65, k5[s], rfma(C::a64, k4[s], rfma(C::a63, k3[s], rfma(C::a62, k2[s], rfma(C::a61, k1[s], Pe[s])))));
-        }
-        m5 *= dt;
-        rhs(ys, rfma(C::a65, m5, rfma(C::a64, m4, rfma(C::a63, m3, rfma(C::a62, m2, rfma(C::a61, m1, mj))))), k6, m6);
-#pragma unroll
-        for (int s = 0; s < EPL; ++s) {
-          k6[s] *= dt;
-          Pe[s] = rfma(C::b6, k6[s], rfma(C::b5, k5[s], rfma(C::b4, k4[s], rfma(C::b3, k3[s], rfma(C::b1, k1[s], Pe[s])))));
-        }
-        m6 *= dt;
-        mj = rfma(C::b6, m6, rfma(C::b5, m5, rfma(C::b4, m4, rfma(C::b3, m3, rfma(C::b1, m1, mj)))));
+        w40_dopri5<R, EPL>(rhs, Pe, mj, dt);
         tprev = rmin(tnx, t1);
         const R tn = tnx + a.dt0;
         tnx = (tn > t1 - Tol<R>::v) ? t1 : tn;
@@ -735,6 +741,271 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave_l96_kernel(const WgArg
     printf("\n");
   }
 #endif
+}
+
+// ---- backward sweep of the EKF (RTS) smoother, same model and ownership (inference_ekf.py:363-448, 503-531) ------------------------
+// Per interval [t_k, t_k+1] the filtered (m_f, P_f) at t_k are constants: G = F(m_f) + psd_solve(P_f, L Qc L^T)^T and f(m_f) are
+// formed once, then  dm = -[f(m_f) + G (m_s - m_f)],  dP = -[G P_s + (G P_s)^T - L Qc L^T]  is integrated over [0, t_k+1 - t_k]
+// from the smoothed moments at t_k+1.  One wavefront per trajectory:
+//  * P_f streams from HBM into an LDS image; sym(P_f) + 1e-9 I is factored and (L L^T) X = L Qc L^T solved by W40Lin (16-wide blocks,
+//    the products on the matrix cores); the solve leaves X^T where G is wanted, the four non-zeros of F's row i are added by lane i;
+//  * a stage writes the symmetric image of P_s with (m_s - m_f) as row D, multiplies G by it on the matrix cores (3 x 3 tiles of
+//    16 x 16, ten steps of four: 90 v_mfma_*_16x16x4 -- the mean's G (m_s - m_f) is column D of the same product), sends the tiles
+//    back through LDS and the owners pick up A_ij + A_ji.  G is dense (the solve fills it), so this is 2 D^3 flops per stage: the
+//    matrix cores' time (90 x 64 cycles) is the floor of a stage.
+template <int D>
+struct W40S {
+  using W = W40<D>;
+  static constexpr int IMG = ((D + 1) * W::LDY + 1) & ~1;  // rows 0 .. D (row D: the mean's column of the stage product)
+  static_assert(IMG >= W::LPK && IMG >= D * W::LDY, "the second region also holds the packed system and the staged P_f");
+  static constexpr int o_G = 0, o_B = IMG, o_inv = 2 * IMG, o_xs = o_inv + 64, o_col = o_xs + 64, o_end = o_col + 64;
+  static constexpr int SHQ = 64 * W::EPL, SH = SHQ + 2 * 64 * W::EPL;  // L Qc L^T in ownership order, then the index table
+  static constexpr int kWaves = 4;
+};
+template <int D>
+__host__ __device__ constexpr long wave40_smoother_lds_reals() { return (long)W40S<D>::SH + (long)W40S<D>::kWaves * W40S<D>::o_end; }
+
+template <typename R, int D>
+__global__ __launch_bounds__(256, 1) void ekf_smoother_wave_l96_kernel(const WgArgs<R> a) {
+  using W = W40<D>;
+  using S = W40S<D>;
+  using Tile = W40Tile<R>;
+  using Lin = W40Lin<R, D>;
+  using V4 = typename Tile::V4;
+  constexpr int EPL = W::EPL, LDY = W::LDY;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  R* shQ = reinterpret_cast<R*>(smem_raw);
+  unsigned* tabA = reinterpret_cast<unsigned*>(shQ + S::SHQ);
+  unsigned* tabB = tabA + 64 * EPL;
+  R* Wb = shQ + S::SH + (long)wave * S::o_end;
+  static_assert(S::SH % 2 == 0 && S::o_end % 2 == 0 && S::o_B % 2 == 0, "16-byte aligned regions");
+  R* Gm = static_cast<R*>(__builtin_assume_aligned(Wb + S::o_G, 16));  // staged P_f -> right-hand sides -> X^T -> G
+  R* Bm = static_cast<R*>(__builtin_assume_aligned(Wb + S::o_B, 16));  // packed system / stage image / product
+  R* inv = Wb + S::o_inv;
+  R* xs = Wb + S::o_xs;
+  R* col = Wb + S::o_col;
+  const long n = (long)blockIdx.x * S::kWaves + wave;
+  if (wave == 0) {
+    const R* LQL = a.par + a.o_LQL;
+#pragma unroll
+    for (int s = 0; s < EPL; ++s) {
+      const int e = lane + 64 * s;
+      const bool own = e < W::NP;
+      int i = 0, rs = 0;
+      while (i + 1 < D && e >= rs + (D - i)) {
+        rs += D - i;
+        ++i;
+      }
+      const int j = own ? i + (e - rs) : i;
+      shQ[64 * s + lane] = own ? LQL[i * D + j] : R(0);
+      tabA[64 * s + lane] = (unsigned)i | (unsigned)j << 8;
+      tabB[64 * s + lane] = (unsigned)(i * LDY + j) | (unsigned)(j * LDY + i) << 11 | (unsigned)(W::rs(j) + i) << 22;
+    }
+  }
+  __syncthreads();
+  if (n >= a.N) return;
+  const bool isrow = lane < D;
+  const int lp1 = (lane + 1 >= D) ? lane + 1 - D : lane + 1, lm1 = (lane == 0) ? D - 1 : lane - 1,
+            lm2 = (lane <= 1) ? lane + D - 2 : lane - 2;
+  const R forcing = (a.par + a.o_theta)[0];
+  const int rowi = (lane <= D) ? lane : D, ri = W::rs(rowi);
+  const int lm = lane & 15, lg = lane >> 4;
+  const R* tp = a.t + n * a.t_sn;
+  const long mo = n * a.m_sn + (isrow ? lane : 0) * a.m_si;
+  const R* fPn = a.fP + n * a.P_sn;
+  int st = 0;
+  bool bad = false;
+
+  int oY[EPL], oYT[EPL];  // the owned entries' two positions in a symmetric image
+#pragma unroll
+  for (int s = 0; s < EPL; ++s) {
+    const unsigned w = tabB[64 * s + lane];
+    oY[s] = (int)(w & 2047u);
+    oYT[s] = (int)((w >> 11) & 2047u);
+  }
+  auto store_cov = [&](long k) {  // the symmetric image in Bm -> sP[k]
+    R* o = a.sP + n * a.P_sn + k * a.P_sk;
+    constexpr int NE = (D * D + 63) / 64;
+    R v[NE];
+#pragma unroll
+    for (int q = 0; q < NE; ++q) {
+      const int e = lane + 64 * q, r = e / D, c = e - r * D;
+      v[q] = (e < D * D) ? Bm[r * LDY + c] : R(0);
+    }
+#pragma unroll
+    for (int q = 0; q < NE; ++q) {
+      const int e = lane + 64 * q;
+      if (e < D * D) o[(long)e * a.P_si] = v[q];
+    }
+  };
+
+  // smoothed moments at the last time = the filtered ones
+  R Ps[EPL];
+  R ms = isrow ? a.fm[mo + (a.T - 1) * a.m_sk] : R(0);
+  {
+    const R* src = fPn + (a.T - 1) * a.P_sk;
+#pragma unroll
+    for (int s = 0; s < EPL; ++s) {
+      const unsigned w = tabA[64 * s + lane];
+      const int i = (int)(w & 255u), j = (int)(w >> 8);
+      Ps[s] = W::owned(s, lane) ? src[(long)(i * D + j) * a.P_si] : R(0);
+      if (W::owned(s, lane)) {
+        Bm[oY[s]] = Ps[s];
+        Bm[oYT[s]] = Ps[s];
+      }
+    }
+    if (isrow) a.sm[mo + (a.T - 1) * a.m_sk] = ms;
+    wave_sync();
+    store_cov(a.T - 1);
+    wave_sync();
+  }
+
+  R t1 = tp[(a.T - 1) * a.t_sk];
+  for (long k = a.T - 2; k >= 0; --k) {
+    const R t0 = tp[k * a.t_sk];
+    const R mf = isrow ? a.fm[mo + k * a.m_sk] : R(0);
+    {  // P_f -> image (row-major)
+      const R* src = fPn + k * a.P_sk;
+      constexpr int NE = (D * D + 63) / 64;
+      R v[NE];
+#pragma unroll
+      for (int q = 0; q < NE; ++q) {
+        const int e = lane + 64 * q;
+        v[q] = (e < D * D) ? src[(long)e * a.P_si] : R(0);
+      }
+#pragma unroll
+      for (int q = 0; q < NE; ++q) {
+        const int e = lane + 64 * q, r = e / D, c = e - r * D;
+        if (e < D * D) Gm[r * LDY + c] = v[q];
+      }
+    }
+    if (isrow) xs[lane] = mf;
+    wave_sync();
+    // S = sym(P_f) + 1e-9 I in packed lower storage (row D: zeros -- W40Lin factors D + 1 rows); f(m_f) and the Jacobian's row
+#pragma unroll
+    for (int s = 0; s < EPL; ++s)
+      if (W::owned(s, lane)) {
+        const unsigned w = tabB[64 * s + lane];
+        const R sv = R(0.5) * (Gm[oY[s]] + Gm[oYT[s]]);
+        Bm[(int)(w >> 22)] = (oY[s] == oYT[s]) ? sv + R(1e-9) : sv;
+      }
+    if (isrow) Bm[W::rs(D) + lane] = R(0);
+    R fa = R(0), fb = R(0), fmf = R(0);  // a_i = x_{i-1}, b_i = x_{i+1} - x_{i-2}: F_i,i-2 = -a_i, F_i,i-1 = b_i, F_ii = -1, F_i,i+1 = a_i
+    if (isrow) {
+      const R xp1 = xs[lp1], xm1 = xs[lm1], xm2 = xs[lm2];
+      fa = xm1;
+      fb = xp1 - xm2;
+      fmf = rfma(fb, fa, forcing - mf);
+    }
+    wave_sync();
+    // right-hand sides L Qc L^T (row c of the image = column c)
+#pragma unroll
+    for (int s = 0; s < EPL; ++s)
+      if (W::owned(s, lane)) {
+        const R q = shQ[64 * s + lane];
+        Gm[oY[s]] = q;
+        Gm[oYT[s]] = q;
+      }
+    wave_sync();
+    {
+      R* const sys[1] = {Bm};
+      R* const scr[1] = {col};
+      R quad = R(0);
+      double logdet = 0.0;
+      long long w40_last = 0;
+      (void)w40_last;
+      Lin::template cholesky<1>(sys, scr, inv, rowi, ri, lane, quad, logdet, bad W40_TICK_PASS);
+      Lin::solve(Gm, Bm, inv, (const R*)nullptr, lane, [] {} W40_TICK_PASS);
+    }
+    // G = F(m_f) + X^T: the image holds X^T already
+    if (isrow) {
+      R* g = Gm + lane * LDY;
+      g[lm2] -= fa;
+      g[lm1] += fb;
+      g[lane] -= R(1);
+      g[lp1] += fa;
+    }
+    wave_sync();
+
+    auto rhs = [&](const R (&Pst)[EPL], const R xm, R (&kP)[EPL], R& kM) {
+#pragma unroll
+      for (int s = 0; s < EPL; ++s)
+        if (W::owned(s, lane)) {
+          Bm[oY[s]] = Pst[s];
+          Bm[oYT[s]] = Pst[s];
+        }
+      if (isrow) Bm[D * LDY + lane] = xm - mf;
+      wave_sync();
+      V4 acc[9];
+#pragma unroll
+      for (int q = 0; q < 9; ++q) acc[q] = V4{0, 0, 0, 0};
+#pragma unroll
+      for (int ks = 0; ks < D / 4; ++ks) {
+        const int kk = 4 * ks + lg;
+        R og[3], op[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          const int row = 16 * t + lm;
+          og[t] = (row < D) ? Gm[(row < D ? row : 0) * LDY + kk] : R(0);
+          op[t] = (row <= D) ? Bm[(row <= D ? row : 0) * LDY + kk] : R(0);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 3; ++nt) acc[3 * mt + nt] = wg_mfma(og[mt], op[nt], acc[3 * mt + nt]);
+      }
+      wave_sync();
+#pragma unroll
+      for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * mt + Tile::row(lg, r), colx = 16 * nt + lm;
+            if (row < D && colx <= D) Bm[row * LDY + colx] = acc[3 * mt + nt][r];
+          }
+      wave_sync();
+#pragma unroll
+      for (int s = 0; s < EPL; ++s)
+        kP[s] = W::owned(s, lane) ? shQ[64 * s + lane] - (Bm[oY[s]] + Bm[oYT[s]]) : R(0);
+      kM = isrow ? -(fmf + Bm[lane * LDY + D]) : R(0);
+      wave_sync();
+    };
+    {
+      const R tend = t1 - t0;
+      R tprev = R(0);
+      R tnx = rmin(a.dt0, tend);
+      long steps = 0;
+      while (tprev < tend) {
+        if (steps >= a.max_steps) {
+          st |= kStatusMaxSteps;
+          break;
+        }
+        w40_dopri5<R, EPL>(rhs, Ps, ms, tnx - tprev);
+        tprev = rmin(tnx, tend);
+        const R tn = tnx + a.dt0;
+        tnx = (tn > tend - Tol<R>::v) ? tend : tn;
+        ++steps;
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < EPL; ++s)
+      if (W::owned(s, lane)) {
+        Bm[oY[s]] = Ps[s];
+        Bm[oYT[s]] = Ps[s];
+      }
+    if (isrow) {
+      a.sm[mo + k * a.m_sk] = ms;
+      if (ms != ms) st |= kStatusNan;
+    }
+    wave_sync();
+    store_cov(k);
+    wave_sync();
+    t1 = t0;
+  }
+  if (bad) st |= kStatusNotPd;
+  if (lane == 0 && a.status && st) atomicOr(&a.status[n], st);
 }
 
 }  // namespace cdkf

@@ -21,6 +21,15 @@ bool wave40_shape(const cdkf_model* mdl, const cdkf_opts* o) {
 template <typename R>
 int launch_wave40(const WgArgs<R>& a, hipStream_t stream, bool backward) {
   constexpr int D = 40;
+  if (backward) {
+    if (once_per_device([] { return wg_raise_lds_cap(ekf_smoother_wave_l96_kernel<R, D>); })) return CDKF_EHIP;
+    const size_t lds = sizeof(R) * (size_t)wave40_smoother_lds_reals<D>() + 64;
+    const unsigned blocks = (unsigned)((a.N + W40S<D>::kWaves - 1) / W40S<D>::kWaves);
+    note_kernel("ekf_smoother_wave_l96_kernel<%s, %d>", real_name<R>(), D);
+    hipLaunchKernelGGL((ekf_smoother_wave_l96_kernel<R, D>), dim3(blocks), dim3(64 * W40S<D>::kWaves), lds, stream, a);
+    CDKF_HIP_CHECK(hipGetLastError());
+    return CDKF_OK;
+  }
   if (once_per_device([] { return wg_raise_lds_cap(ekf_filter_wave_l96_kernel<R, D>); })) return CDKF_EHIP;
   const size_t lds = sizeof(R) * (size_t)wave40_lds_reals<D>() + 64;
   const unsigned blocks = (unsigned)((a.N + W40<D>::kWaves - 1) / W40<D>::kWaves);

@@ -279,9 +279,11 @@ int launch_ekf_smoother_wg(const cdkf_model* mdl, const cdkf_opts* o, int64_t N,
     if (!rc)
       rc = (mdl->drift_kind == CDKF_DRIFT_MLP_TANH) ? launch_adjoint_kernel<R, true, true>(a, nullptr, nullptr, stream)
                                                      : launch_adjoint_kernel<R, false, true>(a, nullptr, nullptr, stream);
-  } else if (wave40_shape(mdl, &of)) {  // d = 40: forward pass on the wavefront-per-trajectory sweep, backward on the workgroup kernel
+  } else if (wave40_shape(mdl, &of)) {  // d = 40: both passes on the wavefront-per-trajectory sweeps
     rc = launch_wave40<R>(a, stream);
-    if (!rc) rc = launch_wg_dispatch<R>(a, mdl, true, stream, false);
+    if (!rc)
+      rc = getenv("CDKF_WG_BACKWARD") ? launch_wg_dispatch<R>(a, mdl, true, stream, false)  // (A/B and tests: the workgroup kernel)
+                                      : launch_wave40<R>(a, stream, true);
   } else {
     rc = launch_wg_dispatch<R>(a, mdl, true, stream);
   }
