@@ -46,7 +46,8 @@ struct AdjOff {  // per wavefront, in reals
   //   registers the same image takes CC = [c1 | s1] (result of the transposed product) and then the partial sums RED
   static constexpr int a1 = 1168, a2 = 1232, d2 = 1296, UC = 1360, ZC = 1936, TC = 2512, CC = 2512, RED = 2512;
   static constexpr int ck = 3088;  // kAdjCk x (64 P + 8 m), then kAdjCk step sizes
-  static constexpr int end = 3088 + kAdjCk * 72 + kAdjCk;
+  static constexpr int km = 3088 + kAdjCk * 72 + kAdjCk, ym = km + 48;  // mean parts of the step's slopes / stage cotangents [6][8]
+  static constexpr int end = ym + 48;
 };
 template <typename R, bool MLP>
 constexpr int adj_waves() {
@@ -66,8 +67,9 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
   constexpr int WAVES = adj_waves<R, MLP>();
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   R* Sh = reinterpret_cast<R*>(smem_raw);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int i = lane >> 3, j = lane & 7;
+  const int wave = threadIdx.x >> 6;
+  int lane = threadIdx.x & 63;
+  int i = lane >> 3, j = lane & 7;
   const int d = a.d, m = a.m, h1 = a.h1, h2 = a.h2;
   R* W = Sh + (MLP ? AdjSh::end : 0) + wave * AdjOff::end;
   const R* th = a.par + a.o_theta;
@@ -103,17 +105,12 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
   const R Hij = (i < m && j < d) ? (a.par + a.o_H)[i * d + j] : R(0);  // lane (r=i, k=j) holds H[r][k]
   const R Rij = (i < m && j < m) ? (a.par + a.o_R)[i * m + j] : R(0);
   const R hbj = (lane < m) ? (a.par + a.o_hb)[lane] : R(0);
-  R w1row[8], w3col[8];
-  R b1l = 0, b2l = 0;
-  if constexpr (MLP) {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      w1row[k] = Sh[AdjSh::W1 + lane * 8 + k];
-      w3col[k] = Sh[AdjSh::W3 + k * 65 + lane];
-    }
-    b1l = Sh[AdjSh::b1 + lane];
-    b2l = Sh[AdjSh::b2 + lane];
-  }
+  // this lane's row of W1 / column of W3 / biases come from the shared LDS copy where they are used: held in registers for the whole
+  // sweep they were the first thing the allocator parked in scratch (30 reloads each per step)
+  auto w1row = [&](int k) __attribute__((always_inline)) { return Sh[AdjSh::W1 + lane * 8 + k]; };
+  auto w3col = [&](int k) __attribute__((always_inline)) { return Sh[AdjSh::W3 + k * 65 + lane]; };
+  auto b1l = [&]() __attribute__((always_inline)) { return Sh[AdjSh::b1 + lane]; };
+  auto b2l = [&]() __attribute__((always_inline)) { return Sh[AdjSh::b2 + lane]; };
   const R Wlin = (a.kind == kDriftLinear && inP) ? th[i * d + j] : R(0);  // linear drift: lane (i,k) holds W[i][k]
   const R blin = (a.kind == kDriftLinear && lane < d) ? th[d * d + lane] : R(0);
 
@@ -121,9 +118,19 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
   // d ll / d W2 accumulates in matrix-core accumulator tiles for the whole sweep: gW2t[mt][nt][r] is entry
   // (16 mt + row(lg, r), 16 nt + lm) -- the rank-9 update of every right-hand-side adjoint is 48 v_mfma_*_16x16x4
   using MTile = W8Tile<R>;
-  const int lm = lane & 15, lg = lane >> 4;
-  const R e8 = (lm == 8) ? R(1) : R(0), ne8 = (lm == 8) ? R(0) : R(1);
-  const int sc_off = (lm == 8) ? AdjOff::a2 : AdjOff::d2;
+  int lm = lane & 15, lg = lane >> 4;
+  const R e8 = (lm == 8) ? R(1) : R(0);
+  int sc_off = (lm == 8) ? AdjOff::a2 : AdjOff::d2;
+  // The lane index is laundered through an empty asm at the top of every right-hand side: what is derived from it (LDS addresses of
+  // the tiles and images) is then recomputed where it is used instead of being hoisted out of the sweep's loops and parked in scratch
+  auto fresh = [&]() __attribute__((always_inline)) {
+    asm volatile("" : "+v"(lane));
+    i = lane >> 3;
+    j = lane & 7;
+    lm = lane & 15;
+    lg = lane >> 4;
+    sc_off = (lm == 8) ? AdjOff::a2 : AdjOff::d2;
+  };
   typename MTile::V4 gW2t[MLP ? 4 : 1][MLP ? 4 : 1];
   R gW1[8], gW3[8];
   R gb1 = 0, gb2 = 0, gb3 = 0;
@@ -137,19 +144,19 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
   R gQ = 0, gR = 0, gH = 0, gBias = 0;   // model block: d/d(L Qc L^T), d/dR, d/dH on lane (i, j); d/d bias on lanes < 8
 
   // ---- 8 x 8 tile products: lane (i, j) gets one entry ----------------------------------------------------------
-  auto mm = [&](int TA, int TB) {  // (A B)_ij
+  auto mm = [&](int TA, int TB) __attribute__((always_inline)) {  // (A B)_ij
     R s = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) s = rfma(W[TA + i * 8 + k], W[TB + k * 8 + j], s);
     return s;
   };
-  auto mm_tn = [&](int TA, int TB) {  // (A^T B)_ij
+  auto mm_tn = [&](int TA, int TB) __attribute__((always_inline)) {  // (A^T B)_ij
     R s = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) s = rfma(W[TA + k * 8 + i], W[TB + k * 8 + j], s);
     return s;
   };
-  auto mm_nt = [&](int TA, int TB) {  // (A B^T)_ij
+  auto mm_nt = [&](int TA, int TB) __attribute__((always_inline)) {  // (A B^T)_ij
     R s = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) s = rfma(W[TA + i * 8 + k], W[TB + j * 8 + k], s);
@@ -159,15 +166,15 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
   // ---- MLP forward with the tangent of the 8 unit directions; needs W[x] = stage mean (synced) ---------------------
   // lane = hidden unit: returns a1, d1 (layer 1), a2, d2, T = W2 (D1 W1) row (layer 2); leaves a1, U = D1 W1, a2,
   // V = D2 T in LDS and the Jacobian entry F_ij / the drift f in registers of lane (i, j) / LDS vector f.
-  auto mlp_fwd = [&](R& a1, R& d1, R& a2, R& d2, R (&T)[8], R& Fij) {
-    R z1 = b1l;
+  auto mlp_fwd = [&](R& a1, R& d1, R& a2, R& d2, R (&T)[8], R& Fij) __attribute__((always_inline)) {
+    R z1 = b1l();
 #pragma unroll
-    for (int k = 0; k < 8; ++k) z1 = rfma(w1row[k], W[AdjOff::x + k], z1);
+    for (int k = 0; k < 8; ++k) z1 = rfma(w1row(k), W[AdjOff::x + k], z1);
     a1 = rtanh(z1);
     d1 = R(1) - a1 * a1;
     W[AdjOff::a1 + lane] = a1;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) W[AdjOff::UC + lane * 9 + k] = d1 * w1row[k];
+    for (int k = 0; k < 8; ++k) W[AdjOff::UC + lane * 9 + k] = d1 * w1row(k);
     W[AdjOff::UC + lane * 9 + 8] = a1;
     wave_sync();
     // [T | z2 - b2] = W2 [D1 W1 | a1] on the matrix cores (A operand: W2T rows, lanes along p; B operand: UC rows)
@@ -190,7 +197,7 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
     wave_sync();
 #pragma unroll
     for (int k = 0; k < 8; ++k) T[k] = W[AdjOff::TC + lane * 9 + k];
-    a2 = rtanh(W[AdjOff::TC + lane * 9 + 8] + b2l);
+    a2 = rtanh(W[AdjOff::TC + lane * 9 + 8] + b2l());
     d2 = R(1) - a2 * a2;
     W[AdjOff::a2 + lane] = a2;
     W[AdjOff::d2 + lane] = d2;
@@ -221,7 +228,7 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
   };
 
   // ---- registry drifts other than the MLP: Jacobian entry on lane (i, j), f in the LDS vector; needs W[x] (synced) ----
-  auto drift_fwd = [&](R& Fij) {
+  auto drift_fwd = [&](R& Fij) __attribute__((always_inline)) {
     R xk[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) xk[k] = W[AdjOff::x + k];
@@ -244,7 +251,7 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
       if (lane == 1) fi = xk[0] * (rho - xk[2]) - xk[1];
       if (lane == 2) fi = xk[0] * xk[1] - bt * xk[2];
     } else {  // Lorenz-96
-      auto X = [&](int q) { return W[AdjOff::x + q]; };
+      auto X = [&](int q) __attribute__((always_inline)) { return W[AdjOff::x + q]; };
       const int ip1 = (i + 1 >= d) ? 0 : i + 1, im1 = (i == 0) ? d - 1 : i - 1, im2 = (im1 == 0) ? d - 1 : im1 - 1;
       if (inP) {
         if (j == ip1) Fij = X(im1);
@@ -263,7 +270,8 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
   };
 
   // ---- right-hand side of the moment ODEs (state_order 'first') --------------------------------------------------
-  auto rhs_fwd = [&](R xs, R Ps, R& kM, R& kP) {
+  auto rhs_fwd = [&](R xs, R Ps, R& kM, R& kP) __attribute__((always_inline)) {
+    fresh();
     W[AdjOff::P + lane] = Ps;
     if (lane < 8) W[AdjOff::x + lane] = xs;
     wave_sync();
@@ -286,7 +294,8 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
 
   // ---- its adjoint: given the cotangent (lam, Lam) of the slope at the stage value (xs, Ps) -----------------------
   //   Ybar_P = F^T Lam + Lam F;   Ybar_m, dtheta += gradient of  lam . f(x) + <G, F(x)>,  G = 2 Lam P
-  auto rhs_adj = [&](R xs, R Ps, R lam, R Lam, R& YM, R& YP) {
+  auto rhs_adj = [&](R xs, R Ps, R lam, R Lam, R& YM, R& YP) __attribute__((always_inline)) {
+    fresh();
     W[AdjOff::P + lane] = Ps;
     W[AdjOff::Lam + lane] = Lam;
     if (lane < 8) {
@@ -303,7 +312,7 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
       W[AdjOff::G + lane] = Gij;
       wave_sync();
       YP = mm_tn(AdjOff::F, AdjOff::Lam) + mm(AdjOff::Lam, AdjOff::F);
-      auto G = [&](int r, int c) { return W[AdjOff::G + r * 8 + c]; };
+      auto G = [&](int r, int c) __attribute__((always_inline)) { return W[AdjOff::G + r * 8 + c]; };
       if (a.kind == kDriftLinear) gTile = rfma(W[AdjOff::lam + i], W[AdjOff::x + j], gTile + Gij);
       if (lane < 8) {
         R s = 0;  // (F^T lam)_lane
@@ -325,7 +334,7 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
           }
         } else {  // Lorenz-96: dF[i][i+1]/dx_{i-1} = 1, dF[i][i-2]/dx_{i-1} = -1, dF[i][i-1]/dx_{i+1} = 1, dF[i][i-1]/dx_{i-2} = -1
           if (lane < d) {
-            auto wrap = [&](int q) { return q < 0 ? q + d : (q >= d ? q - d : q); };
+            auto wrap = [&](int q) __attribute__((always_inline)) { return q < 0 ? q + d : (q >= d ? q - d : q); };
             const int c = lane;
             const int c1 = wrap(c + 1), c2 = wrap(c + 2), cm1 = wrap(c - 1), cm2 = wrap(c - 2);
             s += G(c1, c2) - G(c1, cm1) + G(cm1, cm2) - G(c2, c1);
@@ -359,12 +368,12 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const R g = W[AdjOff::G + r * 8 + k];
-        c2[k] = rfma(w3col[r], g, c2[k]);
+        c2[k] = rfma(w3col(r), g, c2[k]);
         gv = rfma(g, T[k], gv);
       }
       const R lamr = W[AdjOff::lam + r];
       gW3[r] = rfma(lamr, a2, rfma(d2, gv, gW3[r]));
-      a2b = rfma(w3col[r], lamr, a2b);
+      a2b = rfma(w3col(r), lamr, a2b);
     }
     R zt2[8];
     {
@@ -425,7 +434,7 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
     {
       R s = 0;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) s = rfma(w1row[k], c1[k], s);
+      for (int k = 0; k < 8; ++k) s = rfma(w1row(k), c1[k], s);
       s1 = rfma(R(-2) * a1, s, s1);
     }
     const R z1b = d1 * s1;
@@ -433,7 +442,7 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       gW1[k] = rfma(z1b, W[AdjOff::x + k], rfma(d1, c1[k], gW1[k]));
-      W[AdjOff::RED + lane * 8 + k] = w1row[k] * z1b;
+      W[AdjOff::RED + lane * 8 + k] = w1row(k) * z1b;
     }
     if (lane < 8) gb3 += lam;
     wave_sync();
@@ -455,48 +464,77 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
 
   using TB = Dp5T<R>;
   // stage value i from the step start and the slopes k_0 .. k_{i-1}
-  auto stage_in = [&](int si, R y0, const R (&ks)[6], R dt) {
+  auto stage_in = [&](int si, R y0, const R (&ks)[6], R dt) __attribute__((always_inline)) {
     R s = 0;
 #pragma unroll
     for (int jj = 0; jj < 5; ++jj)
       if (jj < si) s = rfma(TB::a[si][jj], ks[jj], s);
     return rfma(dt, s, y0);
   };
-  // one Dormand-Prince step forward (as the filter takes it)
-  auto step_fwd = [&](R& mj, R& Pij, R dt) {
-    R kM[6] = {0, 0, 0, 0, 0, 0}, kP[6] = {0, 0, 0, 0, 0, 0};
+  // The slopes of the step in hand and the cotangents of its stage values live in LDS, in the twelve tiles that only the measurement
+  // update's adjoint uses (B .. XP) plus two small vectors: the stage loops stay ROLLED -- one inlined copy of each right-hand side
+  // instead of six (the unrolled sweep was ~30 k instructions, several times the instruction cache, with ~800 registers parked in
+  // scratch), and the stage index may be a run-time value.  A lane reads back only what it wrote itself: no synchronisation.
+  constexpr int KPo = AdjOff::B, YPo = AdjOff::B + 6 * 64, KMo = AdjOff::km, YMo = AdjOff::ym;
+  static_assert(AdjOff::B + 12 * 64 == AdjOff::x, "twelve contiguous tiles B .. XP");
+  const int l8 = lane & 7;
+  auto stage_val = [&](int sg, R mj, R Pij, R dt, R& xm, R& Pst) __attribute__((always_inline)) {
+    R sm_ = 0, sp_ = 0;
 #pragma unroll
-    for (int s = 0; s < 6; ++s) rhs_fwd(stage_in(s, mj, kM, dt), stage_in(s, Pij, kP, dt), kM[s], kP[s]);
-    R sm = 0, sp = 0;
-#pragma unroll
-    for (int s = 0; s < 6; ++s) {
-      sm = rfma(TB::b[s], kM[s], sm);
-      sp = rfma(TB::b[s], kP[s], sp);
+    for (int jj = 0; jj < 5; ++jj)
+      if (jj < sg) {  // uniform
+        const R c = TB::a[sg][jj];
+        sp_ = rfma(c, W[KPo + 64 * jj + lane], sp_);
+        sm_ = rfma(c, W[KMo + 8 * jj + l8], sm_);
+      }
+    xm = rfma(dt, sm_, mj);
+    Pst = rfma(dt, sp_, Pij);
+  };
+  auto stages_fwd = [&](R mj, R Pij, R dt) __attribute__((always_inline)) {
+#pragma unroll 1
+    for (int sg = 0; sg < 6; ++sg) {
+      R xm, Pst, kM = 0, kP = 0;
+      stage_val(sg, mj, Pij, dt, xm, Pst);
+      rhs_fwd(xm, Pst, kM, kP);
+      W[KPo + 64 * sg + lane] = kP;
+      if (lane < 8) W[KMo + 8 * sg + lane] = kM;
     }
-    mj = rfma(dt, sm, mj);
-    Pij = rfma(dt, sp, Pij);
+  };
+  // one Dormand-Prince step forward (as the filter takes it)
+  auto step_fwd = [&](R& mj, R& Pij, R dt) __attribute__((always_inline)) {
+    stages_fwd(mj, Pij, dt);
+    R sm_ = 0, sp_ = 0;
+#pragma unroll
+    for (int sg = 0; sg < 6; ++sg) {
+      sm_ = rfma(TB::b[sg], W[KMo + 8 * sg + l8], sm_);
+      sp_ = rfma(TB::b[sg], W[KPo + 64 * sg + lane], sp_);
+    }
+    mj = rfma(dt, sm_, mj);
+    Pij = rfma(dt, sp_, Pij);
   };
   // ... and its adjoint: (mb, Pb) cotangent of the step's result -> cotangent of its start; dtheta accumulated
-  auto step_adj = [&](R mj, R Pij, R dt, R& mb, R& Pb) {
-    R kM[6] = {0, 0, 0, 0, 0, 0}, kP[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int s = 0; s < 6; ++s) rhs_fwd(stage_in(s, mj, kM, dt), stage_in(s, Pij, kP, dt), kM[s], kP[s]);
-    R yM[6] = {0, 0, 0, 0, 0, 0}, yP[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int s = 5; s >= 0; --s) {
-      R lm = TB::b[s] * mb, lp = TB::b[s] * Pb;
+  auto step_adj = [&](R mj, R Pij, R dt, R& mb, R& Pb) __attribute__((always_inline)) {
+    stages_fwd(mj, Pij, dt);
+#pragma unroll 1
+    for (int sg = 5; sg >= 0; --sg) {
+      R lm_ = TB::b[sg] * mb, lp = TB::b[sg] * Pb;
 #pragma unroll
       for (int r = 5; r > 0; --r)
-        if (r > s) {
-          lm = rfma(TB::a[r][s], yM[r], lm);
-          lp = rfma(TB::a[r][s], yP[r], lp);
+        if (r > sg) {  // uniform
+          const R c = TB::a[r][sg];
+          lm_ = rfma(c, W[YMo + 8 * r + l8], lm_);
+          lp = rfma(c, W[YPo + 64 * r + lane], lp);
         }
-      rhs_adj(stage_in(s, mj, kM, dt), stage_in(s, Pij, kP, dt), dt * lm, dt * lp, yM[s], yP[s]);
+      R xm, Pst, yM = 0, yP = 0;
+      stage_val(sg, mj, Pij, dt, xm, Pst);
+      rhs_adj(xm, Pst, dt * lm_, dt * lp, yM, yP);
+      W[YPo + 64 * sg + lane] = yP;
+      if (lane < 8) W[YMo + 8 * sg + lane] = yM;
     }
 #pragma unroll
-    for (int s = 0; s < 6; ++s) {
-      mb += yM[s];
-      Pb += yP[s];
+    for (int sg = 0; sg < 6; ++sg) {
+      if (lane < 8) mb += W[YMo + 8 * sg + lane];
+      Pb += W[YPo + 64 * sg + lane];
     }
   };
 
@@ -505,8 +543,8 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
   // then  dm = -[f(m_f) + G (m_s - m_f)],  dP = -[G P_s + (G P_s)^T - L Qc L^T]  is integrated over [0, t_{k+1} - t_k].
   if constexpr (SMOOTH) {
     const R* tp = a.t + n * a.t_sn;
-    auto mo = [&](long k) { return n * a.m_sn + k * a.m_sk + lane * a.m_si; };
-    auto po = [&](long k) { return n * a.P_sn + k * a.P_sk + (long)(i * d + j) * a.P_si; };
+    auto mo = [&](long k) __attribute__((always_inline)) { return n * a.m_sn + k * a.m_sk + lane * a.m_si; };
+    auto po = [&](long k) __attribute__((always_inline)) { return n * a.P_sn + k * a.P_sk + (long)(i * d + j) * a.P_si; };
     R lqlcol[8];  // column j of L Qc L^T, the right-hand side of this lane's column solve
 #pragma unroll
     for (int r = 0; r < 8; ++r) lqlcol[r] = (r < d && j < d) ? (a.par + a.o_LQL)[r * d + j] : R(0);
@@ -580,7 +618,7 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
       if (lane < 8) W[AdjOff::mb + lane] = mf;
       wave_sync();
       // reverse-time right-hand side at the stage value
-      auto rhs_s = [&](R xs, R Pst, R& kM, R& kP) {
+      auto rhs_s = [&](R xs, R Pst, R& kM, R& kP) __attribute__((always_inline)) {
         W[AdjOff::P + lane] = Pst;
         if (lane < 8) W[AdjOff::x + lane] = xs;
         wave_sync();
@@ -696,7 +734,7 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
     W[AdjOff::S2 + lane] = s2;
     wave_sync();
     // column solves with a factor tile: col <- (L L^T)^-1 col
-    auto chol_solve_col = [&](int TL, const R (&inv)[8], R (&col)[8]) {
+    auto chol_solve_col = [&](int TL, const R (&inv)[8], R (&col)[8]) __attribute__((always_inline)) {
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
         R w = col[r];
@@ -712,7 +750,7 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
         col[r] = w * inv[r];
       }
     };
-    auto pick = [&](const R (&col)[8]) {  // col[i] without a run-time register index
+    auto pick = [&](const R (&col)[8]) __attribute__((always_inline)) {  // col[i] without a run-time register index
       R out = 0;
 #pragma unroll
       for (int r = 0; r < 8; ++r)

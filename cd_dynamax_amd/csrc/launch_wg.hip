@@ -2,7 +2,6 @@
 #include "cdkf_launch.h"
 #include "cdkf_wg2_kernels.h"
 #include "cdkf_wave8_kernels.h"
-#include "cdkf_adjoint_kernels.h"
 #include "cdkf_rts1_kernels.h"
 
 namespace cdkf {
@@ -260,9 +259,6 @@ int launch_ekf_filter_wg(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, i
   return rc ? rc : rc2;
 }
 
-template <typename R, bool MLP, bool SMOOTH = false>
-static int launch_adjoint_kernel(const WgArgs<R>& a, R* grad, R* grad_model, hipStream_t stream);  // defined below
-
 template <typename R>
 int launch_ekf_smoother_wg(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y,
                            R* ll, R* fm, R* fP, R* sm, R* sP, int32_t* status, hipStream_t stream) {
@@ -352,19 +348,6 @@ bool adjoint_shape_available(const cdkf_model* mdl, const cdkf_opts* o) {
   // the MLP has a non-zero grad(div f): its 'second' mean term would need third derivatives of the drift
   if (mdl->drift_kind == CDKF_DRIFT_MLP_TANH && o->state_order != CDKF_ORDER_FIRST) return false;
   return true;
-}
-
-template <typename R, bool MLP, bool SMOOTH>
-static int launch_adjoint_kernel(const WgArgs<R>& a, R* grad, R* grad_model, hipStream_t stream) {
-  if (once_per_device([] { return wg_raise_lds_cap(&ekf_adjoint_wave8_kernel<R, MLP, SMOOTH>); })) return CDKF_EHIP;
-  constexpr int WAVES = adj_waves<R, MLP>();
-  constexpr size_t lds = adj_lds_bytes<R, MLP>();
-  const dim3 grid((unsigned)((a.N + WAVES - 1) / WAVES)), block(64 * WAVES);
-  auto kernel = ekf_adjoint_wave8_kernel<R, MLP, SMOOTH>;
-  note_kernel("ekf_adjoint_wave8_kernel<%s, %s, %s>", real_name<R>(), MLP ? "true" : "false", SMOOTH ? "true" : "false");
-  hipLaunchKernelGGL(kernel, grid, block, lds, stream, a, grad, grad_model);
-  CDKF_HIP_CHECK(hipGetLastError());
-  return CDKF_OK;
 }
 
 template <typename R>
