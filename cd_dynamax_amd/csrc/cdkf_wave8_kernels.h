@@ -44,10 +44,12 @@ CDKF_DEV void wave_sync() {
 struct W8Off {
   static constexpr int P = 0, A = 64, F = 128, X = 192, SX = 256, S1 = 320, S2 = 384, HP = 448;
   static constexpr int x = 512, f = 520, g = 528, v = 536, z = 544, y = 552, tmp = 560;
-  static constexpr int base_end = 568;
+  static constexpr int km = 568;  // mean parts of the Dormand-Prince slopes k1 .. k5 of the step in hand [5][8]; their covariance
+                                  // parts take the five tiles X .. HP, which only the measurement update uses
+  static constexpr int base_end = 608;
   // MLP only
-  static constexpr int a1 = 568, d1 = 632, a2 = 696, d2 = 760, s2 = 824, tq = 888, U = 952, V = 952 + 512;
-  static constexpr int mlp_end = 952 + 1024;
+  static constexpr int a1 = 608, d1 = 672, a2 = 736, d2 = 800, s2 = 864, tq = 928, U = 992, V = 992 + 512;
+  static constexpr int mlp_end = 992 + 1024;
 };
 // shared (per workgroup) MLP weights, all padded to kHid: W1[64][8] b1[64] W2[64][64] b2[64] W3[8][65] b3[8] Gm[64][64]
 struct W8Sh {
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave8_kernel(const WgArgs<R
   const bool zeroth = a.order == 0;
 
   // right-hand side of the moment ODEs for the stage value (xs: mean on lanes < d, Ps: this lane's covariance entry)
-  auto rhs = [&](R xs, R Ps, R& kM, R& kP) {
+  auto rhs = [&](R xs, R Ps, R& kM, R& kP) __attribute__((always_inline)) {
     W[W8Off::P + lane] = Ps;
     if (lane < kW8) W[W8Off::x + lane] = xs;
     wave_sync();
@@ -468,20 +470,38 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave8_kernel(const WgArgs<R
           break;
         }
         const R dt = tnext - tprev;
-        R kM1 = 0, kM2 = 0, kM3 = 0, kM4 = 0, kM5 = 0, kM6 = 0, kP1 = 0, kP2 = 0, kP3 = 0, kP4 = 0, kP5 = 0, kP6 = 0;
-        rhs(mj, Pij, kM1, kP1);
-        rhs(rfma(dt, C::a21 * kM1, mj), rfma(dt, C::a21 * kP1, Pij), kM2, kP2);
-        rhs(rfma(dt, rfma(C::a32, kM2, C::a31 * kM1), mj), rfma(dt, rfma(C::a32, kP2, C::a31 * kP1), Pij), kM3, kP3);
-        rhs(rfma(dt, rfma(C::a43, kM3, rfma(C::a42, kM2, C::a41 * kM1)), mj),
-            rfma(dt, rfma(C::a43, kP3, rfma(C::a42, kP2, C::a41 * kP1)), Pij), kM4, kP4);
-        rhs(rfma(dt, rfma(C::a54, kM4, rfma(C::a53, kM3, rfma(C::a52, kM2, C::a51 * kM1))), mj),
-            rfma(dt, rfma(C::a54, kP4, rfma(C::a53, kP3, rfma(C::a52, kP2, C::a51 * kP1))), Pij), kM5, kP5);
-        rhs(rfma(dt, rfma(C::a65, kM5, rfma(C::a64, kM4, rfma(C::a63, kM3, rfma(C::a62, kM2, C::a61 * kM1)))), mj),
-            rfma(dt, rfma(C::a65, kP5, rfma(C::a64, kP4, rfma(C::a63, kP3, rfma(C::a62, kP2, C::a61 * kP1)))), Pij), kM6,
-            kP6);
-        mj = rfma(dt, rfma(C::b6, kM6, rfma(C::b5, kM5, rfma(C::b4, kM4, rfma(C::b3, kM3, C::b1 * kM1)))), mj);
-        if (!zeroth)
-          Pij = rfma(dt, rfma(C::b6, kP6, rfma(C::b5, kP5, rfma(C::b4, kP4, rfma(C::b3, kP3, C::b1 * kP1)))), Pij);
+        // The stage loop stays ROLLED (one inlined copy of the right-hand side instead of six: the unrolled sweep was several
+        // times the instruction cache): the slopes k1 .. k5 wait in LDS -- a lane reads back only what it wrote itself, no
+        // synchronisation -- and the stage index may be a run-time value.  Same sums in the same order as the unrolled form.
+        using TB = Dp5T<R>;
+        R kM6 = 0, kP6 = 0;
+#pragma unroll 1
+        for (int sg = 0; sg < 6; ++sg) {
+          R sm = 0, sp = 0;
+#pragma unroll
+          for (int jj = 0; jj < 5; ++jj)
+            if (jj < sg) {  // uniform
+              const R c = TB::a[sg][jj];
+              sm = rfma(c, W[W8Off::km + 8 * jj + (lane & 7)], sm);
+              sp = rfma(c, W[W8Off::X + 64 * jj + lane], sp);
+            }
+          R kM = 0, kP = 0;
+          rhs(rfma(dt, sm, mj), rfma(dt, sp, Pij), kM, kP);
+          if (sg < 5) {
+            W[W8Off::X + 64 * sg + lane] = kP;
+            if (lane < kW8) W[W8Off::km + 8 * sg + lane] = kM;
+          } else {
+            kM6 = kM;
+            kP6 = kP;
+          }
+        }
+        {
+          auto KM = [&](int q) __attribute__((always_inline)) { return W[W8Off::km + 8 * q + (lane & 7)]; };
+          auto KP = [&](int q) __attribute__((always_inline)) { return W[W8Off::X + 64 * q + lane]; };
+          const R sm = rfma(C::b6, kM6, rfma(C::b5, KM(4), rfma(C::b4, KM(3), rfma(C::b3, KM(2), C::b1 * KM(0)))));
+          mj = (lane < kW8) ? rfma(dt, sm, mj) : mj;
+          if (!zeroth) Pij = rfma(dt, rfma(C::b6, kP6, rfma(C::b5, KP(4), rfma(C::b4, KP(3), rfma(C::b3, KP(2), C::b1 * KP(0))))), Pij);
+        }
         tprev = rmin(tnext, t1);
         const R tn = tnext + a.dt0;
         tnext = (tn > t1 - Tol<R>::v) ? t1 : tn;
