@@ -1045,6 +1045,52 @@ def drift_vjp(drift, x, lam, G):
     raise NotImplementedError(drift.kind)
 
 
+def divgrad_vjp(drift, x, u):
+    """Gradient of  s(x, theta) = u . g(x),  g = grad(div f) = drift.divgrad,  w.r.t. (x, theta);  x [d], u [d].
+
+    The reverse pass of the EKF's state_order='second' mean term 0.5 P g(m) (inference_ekf.py:108-116 as SURVEY.md
+    section 0.5 reads it): with lam the cotangent of the mean's slope, u = 0.5 P lam.  Only the MLP has g != 0 among the
+    registry drifts.  Reverse mode through MLPDrift.divgrad, line by line (same intermediate names):
+        M = (W1 W3)^T, G = M * W2, td = d2 G, s = G d1, s2 = dd2 s, tc = s2 W2, tq = dd1 td + d1 tc, g = W1^T tq."""
+    if drift.kind != "mlp":
+        return np.zeros_like(x), np.zeros(drift.theta().size)
+    W1, W2, W3 = drift.W1, drift.W2, drift.W3
+    a1 = np.tanh(W1 @ x + drift.b1)
+    d1 = 1 - a1 * a1
+    a2 = np.tanh(W2 @ a1 + drift.b2)
+    d2 = 1 - a2 * a2
+    M = (W1 @ W3).T                                # [h2,h1]
+    G = M * W2
+    td = d2 @ G                                    # [h1]
+    s = G @ d1                                     # [h2]
+    s2 = -2 * a2 * d2 * s
+    tc = s2 @ W2                                   # [h1]
+    tq = -2 * a1 * d1 * td + d1 * tc
+    # reverse
+    r = W1 @ u                                     # cotangent of tq
+    gW1 = np.outer(tq, u)
+    td_b = -2 * a1 * d1 * r
+    tc_b = d1 * r
+    z1_b = r * (-2 * a1 * tq - 2 * d1 * d1 * td)   # through a1, d1 inside tq
+    d2_b = G @ td_b
+    G_b = np.outer(d2, td_b)
+    s2_b = W2 @ tc_b
+    gW2 = np.outer(s2, tc_b)
+    s_b = -2 * a2 * d2 * s2_b
+    z2_b = s2_b * (-2 * s) * d2 * (1 - 3 * a2 * a2) + d2_b * (-2 * a2 * d2)
+    G_b = G_b + np.outer(s_b, d1)
+    z1_b = z1_b + (s_b @ G) * (-2 * a1 * d1)
+    gW2 = gW2 + G_b * M
+    M_b = G_b * W2                                 # M_pq = sum_i W3_ip W1_qi
+    gW1 = gW1 + M_b.T @ W3.T
+    gW3 = W1.T @ M_b.T
+    gW2 = gW2 + np.outer(z2_b, a1)
+    z1_b = z1_b + (W2.T @ z2_b) * d1
+    gW1 = gW1 + np.outer(z1_b, x)
+    xb = W1.T @ z1_b
+    return xb, np.concatenate([g_.ravel() for g_ in (gW1, z1_b, gW2, z2_b, gW3, np.zeros_like(drift.b3))])
+
+
 def _step_sizes(t0, t1, dt0, tol, max_steps):
     """The dt sequence of the diffeqsolve loop above for one interval."""
     out = []
@@ -1057,8 +1103,9 @@ def _step_sizes(t0, t1, dt0, tol, max_steps):
     return out
 
 
-def ekf_loglik_grad_adjoint(mdl: Model, t, y, dt0=0.01, dt_final=1e-10, max_steps=100000, full=False):
-    """Returns (ll [N], grad [N, n_theta]): EKF, state_order 'first', num_iter 1; float64.
+def ekf_loglik_grad_adjoint(mdl: Model, t, y, dt0=0.01, dt_final=1e-10, max_steps=100000, full=False, state_order="first"):
+    """Returns (ll [N], grad [N, n_theta]): EKF, state_order 'first' or 'second' (the mean term 0.5 P grad(div f), reversed by
+    divgrad_vjp), num_iter 1; float64.
 
     ``full=True`` adds a dict with the gradients w.r.t. every other parameter of the model, each with a leading [N]:
     m0, P0, L, Qc, H, bias, R and LQL (= the cotangent of L Qc L^T the first two are chained from).  Cotangents of the
@@ -1078,10 +1125,14 @@ def ekf_loglik_grad_adjoint(mdl: Model, t, y, dt0=0.01, dt_final=1e-10, max_step
     f = lambda x: drift.f(x[None])[0]
     jac = lambda x: drift.jac(x[None])[0]
 
+    second = state_order == "second"
+    assert state_order in ("first", "second")
+    divgrad = lambda x: drift.divgrad(x[None])[0]
+
     def rhs(x, P):
         F = jac(x)
         A = F @ P
-        return f(x), A + A.T + LQL
+        return (f(x) + 0.5 * P @ divgrad(x) if second else f(x)), A + A.T + LQL
 
     def stages(x, P, dt):
         ks = []
@@ -1166,9 +1217,14 @@ def ekf_loglik_grad_adjoint(mdl: Model, t, y, dt0=0.01, dt_final=1e-10, max_step
                     xs, Ps = stage_in(x, P, dt, ks, i)
                     F = jac(xs)
                     xb, tb = drift_vjp(drift, xs, lam, 2 * Lam @ Ps)
+                    Pbar = F.T @ Lam + Lam @ F
+                    if second:  # dm/dt also carries 0.5 Ps g(xs)
+                        xb2, tb2 = divgrad_vjp(drift, xs, 0.5 * Ps.T @ lam)
+                        xb, tb = xb + xb2, tb + tb2
+                        Pbar = Pbar + sym(0.5 * np.outer(lam, divgrad(xs)))
                     thb += tb
                     extra["LQL"][n] += Lam
-                    Yb[i] = (xb, F.T @ Lam + Lam @ F)
+                    Yb[i] = (xb, Pbar)
                 mb = mb + sum(Yb[i][0] for i in range(6))
                 Pb = sym(Pb + sum(Yb[i][1] for i in range(6)))
         ll_out[n] = ll

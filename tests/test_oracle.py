@@ -275,6 +275,67 @@ def test_adjoint_gradient_matches_finite_differences(kind):
         np.testing.assert_allclose(g @ u, fd, rtol=1e-5, atol=1e-8)
 
 
+def test_divgrad_vjp_matches_finite_differences():
+    """divgrad_vjp = gradient of u . grad(div f)(x; theta) w.r.t. x and every MLP weight (the reverse of the 'second'-order
+    mean term), against central differences of MLPDrift.divgrad."""
+    rng = np.random.default_rng(5)
+    d, h1, h2 = 3, 6, 5
+    sizes = [h1 * d, h1, h2 * h1, h2, d * h2, d]
+
+    def build(th):
+        p_ = np.split(th, np.cumsum(sizes)[:-1])
+        return o.MLPDrift(p_[0].reshape(h1, d), p_[1], p_[2].reshape(h2, h1), p_[3], p_[4].reshape(d, h2), p_[5])
+
+    th0 = np.concatenate([rng.standard_normal(k) / 2 for k in sizes])
+    x, u = rng.standard_normal(d), rng.standard_normal(d)
+    xb, tb = o.divgrad_vjp(build(th0), x, u)
+    phi = lambda th, xx: float(u @ build(th).divgrad(xx[None])[0])
+    e = 1e-6
+    fd_t = np.array([(phi(th0 + e * v, x) - phi(th0 - e * v, x)) / (2 * e) for v in np.eye(th0.size)])
+    fd_x = np.array([(phi(th0, x + e * v) - phi(th0, x - e * v)) / (2 * e) for v in np.eye(d)])
+    assert np.abs(fd_t - tb).max() < 1e-8 * np.abs(fd_t).max()
+    assert np.abs(fd_x - xb).max() < 1e-8 * np.abs(fd_x).max()
+
+
+def test_adjoint_gradient_second_order_matches_finite_differences():
+    """state_order='second' (the reference's default, inference_ekf.py:108-116): drift AND model-block gradients of the reverse
+    sweep against central differences of ekf_filter(state_order='second'); the term must matter for the test to mean anything."""
+    from helpers import mlp_model
+    rng = np.random.default_rng(6)
+    mdl = mlp_model(rng, 4, 2, (7, 5))
+    N, T = 2, 10
+    t = o.irregular_times(rng, N, T, 0.04)
+    y = o.simulate(mdl, t, rng)
+    ll, g, ex = o.ekf_loglik_grad_adjoint(mdl, t, y, full=True, state_order="second")
+    np.testing.assert_allclose(ll, o.ekf_filter(mdl, t, y, state_order="second")["marginal_loglik"], rtol=1e-12)
+    _, g1 = o.ekf_loglik_grad_adjoint(mdl, t, y)
+    assert np.abs(g - g1).max() > 1e-4 * np.abs(g).max()
+    th0 = mdl.drift.theta()
+    h = 1e-5
+    for _ in range(3):
+        u = rng.standard_normal(th0.size)
+        u /= np.linalg.norm(u)
+        fd = (o.ekf_filter(_rebuild_drift(mdl, th0 + h * u), t, y, state_order="second")["marginal_loglik"]
+              - o.ekf_filter(_rebuild_drift(mdl, th0 - h * u), t, y, state_order="second")["marginal_loglik"]) / (2 * h)
+        np.testing.assert_allclose(g @ u, fd, rtol=1e-5, atol=1e-8)
+
+    def LL(**kw):
+        a = dict(L=mdl.L, Qc=mdl.Qc, H=mdl.H, bias=mdl.bias, R=mdl.R, m0=mdl.m0, P0=mdl.P0)
+        a.update(kw)
+        return o.ekf_filter(o.Model(mdl.drift, a["L"], a["Qc"], a["H"], a["bias"], a["R"], a["m0"], a["P0"]), t, y,
+                            state_order="second")["marginal_loglik"]
+
+    h = 1e-6
+    for name, symmetric in (("m0", False), ("P0", True), ("Qc", True), ("R", True)):
+        base = getattr(mdl, name)
+        u = rng.standard_normal(base.shape)
+        if symmetric:
+            u = 0.5 * (u + u.T)
+        fd = (LL(**{name: base + h * u}) - LL(**{name: base - h * u})) / (2 * h)
+        an = (ex[name] * u).reshape(N, -1).sum(1)
+        assert np.abs(fd - an).max() < 2e-5 * np.abs(fd).max(), name
+
+
 def test_adjoint_gradient_all_parameters_matches_finite_differences():
     """full=True: gradients w.r.t. m0, P0, L, Qc, H, bias, R (general, non-diagonal values) along random directions."""
     from helpers import mlp_model
