@@ -11,7 +11,9 @@
 //                                 from the filtered moments at k-1 (step starts kept in LDS, stages recomputed),
 //              each right-hand-side adjoint back-propagates through f AND through the Jacobian F = W3 D2 W2 D1 W1
 //              (second-order backprop: reverse over the forward tangent pass).
-// state_order 'first' only: the reference's 'second' mean term 0.5 P grad(div f) would need third derivatives.
+// state_order 'second' (the reference's default): the MLP's mean term 0.5 P grad(div f) (inference_ekf.py:108-116) is evaluated
+// and reversed too -- third derivatives of the drift, two more 64 x 64 x 9 products and one more rank-9 weight update per
+// right-hand-side adjoint (mlp_second_fwd and the block after it in rhs_adj; oracle: divgrad_vjp).
 //
 // Mapping: one wavefront per trajectory as in cdkf_wave8_kernels.h -- lane (i, j) owns entry (i, j) of every 8 x 8 tile
 // (P, its adjoint, the stage slopes and their adjoints stay in registers), lane p is hidden unit p in the MLP passes and
@@ -227,6 +229,109 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
     wave_sync();  // (the callers overwrite the F tile)
   };
 
+  // ---- state_order 'second' for the MLP: the mean also moves with 0.5 P g,  g = grad(div f)  (inference_ekf.py:108-116) -------------
+  // With M = (W1 W3)^T and G = M * W2 (oracle/cdkf_oracle.py MLPDrift.divgrad):  g = W1^T tq,  tq = d1 (-2 a1 td + tc),
+  //   td_q = sum_p d2_p G_pq = sum_i W1[q][i] E1[q][i],   E1 = W2^T A1,  A1 = diag(d2) W3^T           (G never formed: rank 8 through W3, W1)
+  //   tc   = W2^T s2,   s2 = -2 a2 d2 s,   s_p = sum_q G_pq d1_q = sum_i W3[i][p] T[p][i]               (T: the tangent mlp_fwd leaves)
+  // so [E1 | tc] = W2^T [A1 | s2] is ONE more 64 x 64 x 9 product on the matrix cores per right-hand side.
+  const bool second = MLP && a.order == 2;
+  // OUT[p][c] = sum_q W2[p][q] IN[q][c]  (images [64][9]; the caller synchronises before; OUT may be IN)
+  auto w2_times = [&](int IN, int OUT) __attribute__((always_inline)) {
+    typename MTile::V4 acc[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) acc[mt] = typename MTile::V4{0, 0, 0, 0};
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const R bv = (lm < 9) ? W[IN + (4 * ks + lg) * 9 + lm] : R(0);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) acc[mt] = wg_mfma(Sh[AdjSh::W2 + (16 * mt + lm) * 65 + 4 * ks + lg], bv, acc[mt]);
+      if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+    wave_sync();
+    if (lm < 9) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) W[OUT + (16 * mt + MTile::row(lg, r)) * 9 + lm] = acc[mt][r];
+    }
+    wave_sync();
+  };
+  // OUT[q][c] = sum_p IN[p][c] W2[p][q]
+  auto w2t_times = [&](int IN, int OUT) __attribute__((always_inline)) {
+    typename MTile::V4 cacc[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) cacc[nt] = typename MTile::V4{0, 0, 0, 0};
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const R av = (lm < 9) ? W[IN + (4 * ks + lg) * 9 + lm] : R(0);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) cacc[nt] = wg_mfma(av, Sh[AdjSh::W2 + (4 * ks + lg) * 65 + 16 * nt + lm], cacc[nt]);
+      if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+    wave_sync();
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = MTile::row(lg, r);
+        if (row < 9) W[OUT + (16 * nt + lm) * 9 + row] = cacc[nt][r];
+      }
+    wave_sync();
+  };
+  // dW2 += A B^T for two [64][9] images (three k-steps into the sixteen accumulator tiles)
+  auto dw2_update = [&](int AI, int BI) __attribute__((always_inline)) {
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) {
+      const int jj = 4 * ks + lg;
+      const bool jin = jj < 9;
+      R av[4], bv[4];
+#pragma unroll
+      for (int t4 = 0; t4 < 4; ++t4) {
+        av[t4] = jin ? W[AI + (16 * t4 + lm) * 9 + jj] : R(0);
+        bv[t4] = jin ? W[BI + (16 * t4 + lm) * 9 + jj] : R(0);
+      }
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) gW2t[mt][nt] = wg_mfma(av[mt], bv[nt], gW2t[mt][nt]);
+    }
+  };
+  // g into the LDS vector AdjOff::v (lanes < 8); leaves [A1 | s2] in the ZC image; returns what the reverse pass needs
+  auto mlp_second_fwd = [&](R a1, R d1, R a2, R d2, const R (&T)[8], R (&E1)[8], R& sdiv, R& s2, R& td, R& tq) __attribute__((always_inline)) {
+    sdiv = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sdiv = rfma(w3col(k), T[k], sdiv);
+    s2 = R(-2) * a2 * d2 * sdiv;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) W[AdjOff::ZC + lane * 9 + k] = d2 * w3col(k);
+    W[AdjOff::ZC + lane * 9 + 8] = s2;
+    wave_sync();
+    w2t_times(AdjOff::ZC, AdjOff::CC);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) E1[k] = W[AdjOff::CC + lane * 9 + k];
+    const R tc = W[AdjOff::CC + lane * 9 + 8];
+    wave_sync();  // (RED below shares the CC image)
+    td = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) td = rfma(w1row(k), E1[k], td);
+    tq = d1 * rfma(R(-2) * a1, td, tc);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) W[AdjOff::RED + lane * 8 + k] = w1row(k) * tq;
+    wave_sync();
+    R part = 0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) part += W[AdjOff::RED + (8 * c + i) * 8 + j];
+    W[AdjOff::A + lane] = part;
+    wave_sync();
+    if (lane < 8) {
+      R sg = 0;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) sg += W[AdjOff::A + r * 8 + lane];
+      W[AdjOff::v + lane] = (lane < d) ? sg : R(0);
+    }
+    wave_sync();
+  };
+
   // ---- registry drifts other than the MLP: Jacobian entry on lane (i, j), f in the LDS vector; needs W[x] (synced) ----
   auto drift_fwd = [&](R& Fij) __attribute__((always_inline)) {
     R xk[8];
@@ -279,6 +384,10 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
     if constexpr (MLP) {
       R a1, d1, a2, d2, T[8];
       mlp_fwd(a1, d1, a2, d2, T, Fij);
+      if (second) {
+        R E1[8], sdiv, s2, td, tq;
+        mlp_second_fwd(a1, d1, a2, d2, T, E1, sdiv, s2, td, tq);
+      }
     } else {
       drift_fwd(Fij);
     }
@@ -288,7 +397,15 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
     W[AdjOff::A + lane] = acc;
     wave_sync();
     kP = (acc + W[AdjOff::A + j * 8 + i]) + lql;
-    if (lane < 8) kM = W[AdjOff::f + lane];
+    if (lane < 8) {
+      kM = W[AdjOff::f + lane];
+      if (second) {  // + 0.5 (P g)_lane
+        R hg = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) hg = rfma(W[AdjOff::P + lane * 8 + k], W[AdjOff::v + k], hg);
+        kM = rfma(R(0.5), hg, kM);
+      }
+    }
     wave_sync();
   };
 
@@ -353,10 +470,58 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
     } else {
     R a1, d1, a2, d2, T[8], Fij;
     mlp_fwd(a1, d1, a2, d2, T, Fij);
+    // reverse of the 'second'-order mean term 0.5 P g (oracle/cdkf_oracle.py divgrad_vjp, same names): with u = 0.5 P lam,
+    //   r = W1 u,  td_b = -2 a1 d1 r,  tc_b = d1 r,  [F1 | s2_b] = W2 [diag(td_b) W1 | tc_b]  (cotangents of A1 and s2),
+    //   d2_b = sum_i W3[i][p] F1[p][i],  s_b = -2 a2 d2 s2_b;  A2 = diag(s_b) W3^T is a cotangent of the tangent T and simply joins zt2,
+    //   so the first-order pipeline below carries it to dW2, dW1, db1, the state; what is new on the matrix cores is E1, F1 and
+    //   the rank-9 update dW2 += [A1 | s2] [diag(td_b) W1 | tc_b]^T.
+    R sb_ = 0, z2x = 0, z1x = 0;
+    if (second) {
+      R E1[8], sdiv, s2, td, tq;
+      mlp_second_fwd(a1, d1, a2, d2, T, E1, sdiv, s2, td, tq);
+      if (lane < 8) {
+        R hu = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) hu = rfma(W[AdjOff::P + lane * 8 + k], W[AdjOff::lam + k], hu);
+        W[AdjOff::w + lane] = R(0.5) * hu;
+      }
+      wave_sync();
+      R rr = 0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) rr = rfma(w1row(k), W[AdjOff::w + k], rr);
+      const R td_b = R(-2) * a1 * d1 * rr, tc_b = d1 * rr;
+      z1x = rr * (R(-2) * a1 * tq - R(2) * d1 * d1 * td);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        gW1[k] = rfma(tq, W[AdjOff::w + k], rfma(td_b, E1[k], gW1[k]));
+        W[AdjOff::TC + lane * 9 + k] = td_b * w1row(k);
+      }
+      W[AdjOff::TC + lane * 9 + 8] = tc_b;
+      wave_sync();
+      w2_times(AdjOff::TC, AdjOff::TC);
+      R d2_b = 0;
+      const R s2_b = W[AdjOff::TC + lane * 9 + 8];
+      sb_ = R(-2) * a2 * d2 * s2_b;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const R f1 = W[AdjOff::TC + lane * 9 + k];
+        d2_b = rfma(w3col(k), f1, d2_b);
+        gW3[k] = rfma(d2, f1, rfma(sb_, T[k], gW3[k]));
+      }
+      z2x = s2_b * (R(-2) * sdiv) * d2 * (R(1) - R(3) * a2 * a2) + d2_b * (R(-2) * a2 * d2);
+      wave_sync();
+#pragma unroll
+      for (int k = 0; k < 8; ++k) W[AdjOff::TC + lane * 9 + k] = td_b * w1row(k);
+      W[AdjOff::TC + lane * 9 + 8] = tc_b;
+      wave_sync();
+      dw2_update(AdjOff::ZC, AdjOff::TC);
+      wave_sync();  // (ZC is rewritten below)
+    }
     W[AdjOff::F + lane] = Fij;
     W[AdjOff::G + lane] = R(2) * mm(AdjOff::Lam, AdjOff::P);
     wave_sync();
     YP = mm_tn(AdjOff::F, AdjOff::Lam) + mm(AdjOff::Lam, AdjOff::F);
+    if (second) YP += R(0.25) * (W[AdjOff::lam + i] * W[AdjOff::v + j] + W[AdjOff::v + i] * W[AdjOff::lam + j]);
     // layer 3, lane p: c2_j = sum_i W3[i][p] G[i][j] is the cotangent of V[p][j]
     R c2[8];
 #pragma unroll
@@ -382,9 +547,9 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
       for (int k = 0; k < 8; ++k) s = rfma(T[k], c2[k], s);
       a2b = rfma(R(-2) * a2, s, a2b);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) zt2[k] = d2 * c2[k];
+      for (int k = 0; k < 8; ++k) zt2[k] = rfma(d2, c2[k], sb_ * w3col(k));
     }
-    const R z2b = d2 * a2b;
+    const R z2b = rfma(d2, a2b, z2x);
     gb2 += z2b;
 #pragma unroll
     for (int k = 0; k < 8; ++k) W[AdjOff::ZC + lane * 9 + k] = zt2[k];
@@ -437,7 +602,7 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
       for (int k = 0; k < 8; ++k) s = rfma(w1row(k), c1[k], s);
       s1 = rfma(R(-2) * a1, s, s1);
     }
-    const R z1b = d1 * s1;
+    const R z1b = rfma(d1, s1, z1x);
     gb1 += z1b;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {

@@ -345,8 +345,6 @@ bool adjoint_shape_available(const cdkf_model* mdl, const cdkf_opts* o) {
   if (o->solver != CDKF_SOLVER_DOPRI5 || o->adaptive) return false;
   if (!wave8_shape(mdl) || !wg_shape_available(mdl, 8) || o->num_iter != 1 || o->forecast) return false;
   if (o->state_order == CDKF_ORDER_ZEROTH) return false;
-  // the MLP has a non-zero grad(div f): its 'second' mean term would need third derivatives of the drift
-  if (mdl->drift_kind == CDKF_DRIFT_MLP_TANH && o->state_order != CDKF_ORDER_FIRST) return false;
   return true;
 }
 

@@ -308,8 +308,8 @@ def cdnlgssm_loglik_and_grad(
     ``grad`` an instance of the drift's class whose fields hold d ll / d field (leading ``[N]`` when batched).
 
     LearnableLorenz63 / LearnableLinear at the register-resident shapes: forward sensitivities inside the sweep,
-    ``state_order`` first or second.  Any registry drift with state_dim, emission_dim <= 8 (LearnableMLP: hidden <= 64 and
-    ``state_order='first'``): forward + reverse sweep (discrete adjoint).  Anything else raises (no finite-difference
+    ``state_order`` first or second.  Any registry drift with state_dim, emission_dim <= 8 (LearnableMLP: hidden <= 64; its
+    ``state_order='second'`` mean term 0.5 P grad(div f) is reversed too): forward + reverse sweep (discrete adjoint).  Anything else raises (no finite-difference
     fallback)."""
     if not isinstance(hyperparams, EKFHyperParams):
         raise NotImplementedError("gradients are provided for the EKF marginal log-likelihood only")
@@ -346,7 +346,7 @@ def cdnlgssm_loglik_and_grad_all(
     reference, ssm_temissions.py:550-568), leaves carrying a leading ``[N]`` for batched emissions.
 
     One forward and one reverse sweep on the device (cdkf_ekf_loglik_grad_all_*): state and emission dimension <= 8, any
-    registry drift (MLP: ``state_order='first'``).  Gradients of the symmetric matrices (initial covariance, diffusion
+    registry drift, ``state_order`` first or second.  Gradients of the symmetric matrices (initial covariance, diffusion
     covariance, emission covariance) are symmetric cotangents: exact for symmetric perturbations, i.e. for any symmetric
     parametrisation such as the reference's ``RealToPSDBijector``."""
     if not isinstance(hyperparams, EKFHyperParams):

@@ -303,7 +303,7 @@ int cdkf_kf_smoother1_supported(const cdkf_model* mdl);
 /* ---- marginal log-likelihood AND its gradient w.r.t. the drift parameters theta (ordering of cdkf_model.theta):
  *      replaces jax.value_and_grad of the fit_sgd loss, src/ssm_temissions.py:550-568, for the drift block of
  *      the parameters (what the Lorenz-63 parameter-estimation tutorials learn).  EKF, num_iter 1; state_order
- *      first/second (MLP drift: first only -- its 'second' mean term needs third derivatives); shapes:
+ *      first/second (MLP drift, 'second': the mean term 0.5 P grad(div f) is differentiated too); shapes:
  *      cdkf_grad_supported().  ll [N], grad [N, n_theta] row-major whatever opts.layout is
  *      (t and y follow opts.layout).  Exact derivative of the discretised recursion (forward sensitivities). -- */
 int cdkf_ekf_loglik_grad_f64(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T, const double* t,

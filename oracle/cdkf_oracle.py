@@ -991,8 +991,8 @@ def ekf_loglik_grad(mdl: Model, t, y, dt0=0.01, dt_final=1e-10, max_steps=100000
 # --------------------------------------------------------------------------------------
 # What jax.value_and_grad does in the reference (reverse mode through update + Dormand-Prince steps,
 # diffrax_utils.py:49 RecursiveCheckpointAdjoint), written out: checker for the reverse-sweep HIP kernel
-# (cdkf_ekf_loglik_grad_* with the MLP drift).  state_order 'first' (for drifts with a non-zero grad(div f) the
-# 'second' mean term would need third derivatives of the drift); one trajectory at a time, plain loops.
+# (cdkf_ekf_loglik_grad_* with the MLP drift).  state_order 'first' or 'second' (the mean term 0.5 P grad(div f) of a drift
+# with a non-zero grad(div f) -- the MLP -- is reversed by divgrad_vjp: third derivatives); one trajectory at a time, plain loops.
 _DP_A = [[], [1 / 5], [3 / 40, 9 / 40], [44 / 45, -56 / 15, 32 / 9], [19372 / 6561, -25360 / 2187, 64448 / 6561, -212 / 729],
          [9017 / 3168, -355 / 33, 46732 / 5247, 49 / 176, -5103 / 18656]]
 _DP_B = [35 / 384, 0.0, 500 / 1113, 125 / 192, -2187 / 6784, 11 / 84]

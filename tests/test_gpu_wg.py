@@ -162,9 +162,18 @@ def test_mlp_loglik_gradient_reverse_sweep(hip_lib, d, m, h):
     ll32, g32 = cd.cdnlgssm_loglik_and_grad(P, y.astype(np.float32), t[..., None].astype(np.float32), hyp)
     flat32 = np.concatenate([np.asarray(a).reshape(N, -1) for a in g32], axis=-1)
     assert flat32.dtype == np.float32 and np.abs(flat32 - g_ref).max() < 2e-2 * scale
-    # the default state_order='second' needs third derivatives of the drift: refused, not approximated
-    with pytest.raises(NotImplementedError, match="no gradient kernel"):
-        cd.cdnlgssm_loglik_and_grad(P, y, t[..., None])
+    # the reference's default, state_order='second': the mean also moves with 0.5 P grad(div f), whose reverse needs third
+    # derivatives of the drift (oracle: divgrad_vjp, FD-pinned in tests/test_oracle.py)
+    ll_ref2, g_ref2 = o.ekf_loglik_grad_adjoint(mdl, t, y, state_order="second")
+    ll2, g2 = cd.cdnlgssm_loglik_and_grad(P, y, t[..., None])
+    np.testing.assert_allclose(ll2, ll_ref2, rtol=1e-10)
+    flat2 = np.concatenate([np.asarray(a).reshape(N, -1) for a in g2], axis=-1)
+    scale2 = np.abs(g_ref2).max()
+    assert np.abs(flat2 - g_ref2).max() < 1e-8 * scale2, np.abs(flat2 - g_ref2).max() / scale2
+    assert np.abs(g_ref2 - g_ref).max() > 1e-6 * scale2  # the term is really there
+    ll32b, g32b = cd.cdnlgssm_loglik_and_grad(P, y.astype(np.float32), t[..., None].astype(np.float32))
+    flat32b = np.concatenate([np.asarray(a).reshape(N, -1) for a in g32b], axis=-1)
+    assert np.abs(flat32b - g_ref2).max() < 2e-2 * scale2
 
 
 def _general_model(rng, drift, d, m):
@@ -217,6 +226,16 @@ def test_loglik_gradient_all_parameters(hip_lib, kind, d, m):
     ll1, g1 = cd.cdnlgssm_loglik_and_grad_all(params_from(mdl), y[2], t[2][:, None], hyp)
     assert np.ndim(ll1) == 0 and g1.emissions.emission_cov.params.shape == (m, m)
     close(g1.emissions.emission_cov.params, ex["R"][2], "R[2]")
+    if kind == "mlp":  # default hyper-parameters = state_order 'second': every leaf again
+        ll_ref, g_ref, ex = o.ekf_loglik_grad_adjoint(mdl, t, y, full=True, state_order="second")
+        ll, g = cd.cdnlgssm_loglik_and_grad_all(params_from(mdl), y, t[..., None])
+        np.testing.assert_allclose(ll, ll_ref, rtol=1e-10)
+        close(np.concatenate([np.asarray(a).reshape(N, -1) for a in g.dynamics.drift], axis=-1), g_ref, "drift (second)")
+        close(g.initial.mean.params, ex["m0"], "m0 (second)")
+        close(g.initial.cov.params, ex["P0"], "P0 (second)")
+        close(g.dynamics.diffusion_cov.params, ex["Qc"], "Qc (second)")
+        close(g.emissions.emission_function.weights, ex["H"], "H (second)")
+        close(g.emissions.emission_cov.params, ex["R"], "R (second)")
 
 
 @pytest.mark.parametrize("solver", ["tsit5", "heun", "euler"])
