@@ -48,13 +48,14 @@ struct W8Off {
                                   // parts take the five tiles X .. HP, which only the measurement update uses
   static constexpr int base_end = 608;
   // MLP only
-  static constexpr int a1 = 608, d1 = 672, a2 = 736, d2 = 800, s2 = 864, tq = 928, U = 992, V = 992 + 512;
-  static constexpr int mlp_end = 992 + 1024;
+  static constexpr int a1 = 608, d1 = 672, a2 = 736, d2 = 800, s2 = 864, tq = 928;
+  static constexpr int U = 992, Z = 992 + 576;  // two [64][9] images (stride 9: a lane's row is conflict-free), state_order 'second'
+  static constexpr int mlp_end = 992 + 2 * 576;
 };
-// shared (per workgroup) MLP weights, all padded to kHid: W1[64][8] b1[64] W2[64][64] b2[64] W3[8][65] b3[8] Gm[64][64]
-struct W8Sh {
-  static constexpr int W1 = 0, b1 = 512, W2 = 576, b2 = 576 + 4096, W3 = 4736, b3 = 4736 + 8 * 65, Gm = 5264;
-  static constexpr int end = 5264 + 4096;
+struct W8Sh {  // per workgroup: the MLP's weights, hidden sizes padded to 64, state to 8; W2 rows padded to 65 (read along p as the
+                // A operand of the tangent product and along q as the B operand of the transposed one, conflict-free both ways)
+  static constexpr int W1 = 0, b1 = 512, W2 = 576, b2 = 576 + 64 * 65, W3 = b2 + 64, b3 = W3 + 8 * 65;
+  static constexpr int end = b3 + 8;
 };
 __host__ __device__ inline long wave8_lds_reals(int kind) {
   return (kind == kDriftMlp) ? (long)W8Sh::end + kW8Waves * W8Off::mlp_end : (long)kW8Waves * W8Off::base_end;
@@ -85,18 +86,10 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave8_kernel(const WgArgs<R
     const R* gb3 = gW3 + d * h2;
     for (int e = threadIdx.x; e < h1 * d; e += blockDim.x) Sh[W8Sh::W1 + fdiv(e, d) * kW8 + (e - fdiv(e, d) * d)] = gW1[e];
     for (int e = threadIdx.x; e < h1; e += blockDim.x) Sh[W8Sh::b1 + e] = gb1[e];
-    for (int e = threadIdx.x; e < h2 * h1; e += blockDim.x) Sh[W8Sh::W2 + fdiv(e, h1) * kHid + (e - fdiv(e, h1) * h1)] = gW2[e];
+    for (int e = threadIdx.x; e < h2 * h1; e += blockDim.x) Sh[W8Sh::W2 + fdiv(e, h1) * 65 + (e - fdiv(e, h1) * h1)] = gW2[e];
     for (int e = threadIdx.x; e < h2; e += blockDim.x) Sh[W8Sh::b2 + e] = gb2[e];
     for (int e = threadIdx.x; e < d * h2; e += blockDim.x) Sh[W8Sh::W3 + fdiv(e, h2) * 65 + (e - fdiv(e, h2) * h2)] = gW3[e];
     for (int e = threadIdx.x; e < d; e += blockDim.x) Sh[W8Sh::b3 + e] = gb3[e];
-    __syncthreads();
-    // Gm[p][q] = (sum_i W3[i][p] W1[q][i]) * W2[p][q]
-    for (int e = threadIdx.x; e < kHid * kHid; e += blockDim.x) {
-      const int p = e >> 6, q = e & 63;
-      R s = 0;
-      for (int ii = 0; ii < d; ++ii) s = rfma(Sh[W8Sh::W3 + ii * 65 + p], Sh[W8Sh::W1 + q * kW8 + ii], s);
-      Sh[W8Sh::Gm + e] = s * Sh[W8Sh::W2 + e];
-    }
     __syncthreads();
   }
   const long n = (long)blockIdx.x * kW8Waves + wave;
@@ -137,7 +130,7 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave8_kernel(const WgArgs<R
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
 #pragma unroll
-      for (int ks = 0; ks < 16; ++ks) w2A[mt][ks] = pin(Sh[W8Sh::W2 + (16 * mt + lm) * kHid + 4 * ks + lg]);
+      for (int ks = 0; ks < 16; ++ks) w2A[mt][ks] = pin(Sh[W8Sh::W2 + (16 * mt + lm) * 65 + 4 * ks + lg]);
 #pragma unroll
       for (int r = 0; r < 4; ++r) w3A[mt][r] = pin(lm < kW8 ? Sh[W8Sh::W3 + lm * 65 + 16 * mt + MTile::row(lg, r)] : R(0));
     }
@@ -263,20 +256,48 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave8_kernel(const WgArgs<R
       }
       R gl = 0;
       if (second) {
-        // g = grad(div f):  s2_p = dd2_p s_p ;  tq_q = dd1_q sum_p d2_p G[p][q] + d1_q sum_p s2_p W2[p][q]
-        W[W8Off::s2 + lane] = R(-2) * a2 * d2 * sdiv;
+        // g = grad(div f) = W1^T tq (oracle/cdkf_oracle.py MLPDrift.divgrad, G = (W1 W3)^T * W2 never formed):
+        //   tq = d1 (-2 a1 td + tc),  td_q = sum_i W1[q][i] E1[q][i],  [E1 | tc] = W2^T [diag(d2) W3^T | s2],  s2 = -2 a2 d2 s
+        // -- one 64 x 64 x 9 product on the matrix cores (the scalar form walked 64 rows of G and of W2 per lane)
+        const R s2v = R(-2) * a2 * d2 * sdiv;
+#pragma unroll
+        for (int k = 0; k < kW8; ++k) W[W8Off::Z + lane * 9 + k] = d2 * w3col[k];
+        W[W8Off::Z + lane * 9 + 8] = s2v;
         wave_sync();
-        R td = 0, tc = 0;
-#pragma unroll 8
-        for (int p = 0; p < kHid; ++p) {
-          td = rfma(W[W8Off::d2 + p], Sh[W8Sh::Gm + p * kHid + lane], td);
-          tc = rfma(W[W8Off::s2 + p], Sh[W8Sh::W2 + p * kHid + lane], tc);
+        typename MTile::V4 cacc[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) cacc[nt] = typename MTile::V4{0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+          const R av = (lm < 9) ? W[W8Off::Z + (4 * ks + lg) * 9 + lm] : R(0);
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) cacc[nt] = wg_mfma(av, Sh[W8Sh::W2 + (4 * ks + lg) * 65 + 16 * nt + lm], cacc[nt]);
+          if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
-        W[W8Off::tq + lane] = td * (R(-2) * a1 * d1) + tc * d1;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = MTile::row(lg, r);
+            if (row < 9) W[W8Off::U + (16 * nt + lm) * 9 + row] = cacc[nt][r];  // (the rows of T were consumed by sdiv above)
+          }
+        wave_sync();
+        R td = 0;
+#pragma unroll
+        for (int k = 0; k < kW8; ++k) td = rfma(w1row[k], W[W8Off::U + lane * 9 + k], td);
+        const R tqv = d1 * rfma(R(-2) * a1, td, W[W8Off::U + lane * 9 + 8]);
+#pragma unroll
+        for (int k = 0; k < kW8; ++k) W[W8Off::Z + lane * 8 + k] = w1row[k] * tqv;  // (Z: all its reads are behind the product)
+        wave_sync();
+        // g_j = sum_q W1[q][j] tq_q: lane (i, j) sums the hidden units q = 8 c + i, the eight partial sums meet in a tile
+        R part = 0;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) part += W[W8Off::Z + (8 * c + i) * 8 + j];
+        W[W8Off::tq + lane] = part;
         wave_sync();
         if (lane < kW8) {
-#pragma unroll 8
-          for (int q = 0; q < kHid; ++q) gl = rfma(W[W8Off::tq + q], Sh[W8Sh::W1 + q * kW8 + lane], gl);
+#pragma unroll
+          for (int r = 0; r < 8; ++r) gl += W[W8Off::tq + r * 8 + lane];
         }
       }
       wave_sync();
