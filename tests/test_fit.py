@@ -176,8 +176,12 @@ def test_fit_sgd_mlp_drift(hip_lib):
     new, losses = model.fit_sgd(P0, props, y, t[..., None], hyp, optimizer=fit.Adam(0.01), batch_size=4, num_epochs=25,
                                 shuffle=True, key=1)
     assert np.all(np.isfinite(losses)) and losses[-1] < losses[0] and losses[-5:].mean() < losses[:5].mean()
-    with pytest.raises(NotImplementedError, match="no drift gradient kernel"):
-        model.fit_sgd(P0, props, y, t[..., None], cd.EKFHyperParams(), num_epochs=1)   # state_order='second'
+    # the reference's default hyper-parameters (state_order='second': the mean also moves with 0.5 P grad(div f))
+    new2, losses2 = model.fit_sgd(P0, props, y, t[..., None], cd.EKFHyperParams(), optimizer=fit.SGD(lr), batch_size=N, num_epochs=1)
+    ll2, g2 = o.ekf_loglik_grad_adjoint(start, t, y, state_order="second")
+    np.testing.assert_allclose(losses2[0], -ll2.sum() / y.size, rtol=1e-10)
+    got2 = np.concatenate([np.asarray(a).ravel() for a in new2.dynamics.drift])
+    np.testing.assert_allclose(got2, start.drift.theta() + lr * g2.sum(0) / y.size, rtol=1e-8, atol=1e-10)
 
 
 @pytest.mark.gpu
