@@ -39,6 +39,37 @@ def test_lorenz96_filter_and_smoother(hip_lib, d, m):
     assert relerr(post32.filtered_means, ref["filtered_means"]) < 2e-4
 
 
+def test_lorenz96_d40_backward_sweep_kernels_agree(hip_lib, monkeypatch):
+    """Config 4's smoother: the wavefront-per-trajectory backward sweep (ekf_smoother_wave_l96_kernel) against the oracle at a
+    batch that does not fill its last workgroup, against the workgroup kernel it replaced (CDKF_WG_BACKWARD=1), in fp32, and at
+    the degenerate lengths T = 1 (nothing to integrate) and T = 2."""
+    rng = np.random.default_rng(40)
+    mdl = lorenz96_model(40, 40)
+    P = params_from(mdl)
+    N, T = 6, 12
+    t = o.irregular_times(rng, N, T, 0.02 * T)  # some intervals take two or three Dormand-Prince steps
+    y = o.simulate(mdl, t, rng)
+    ref = o.ekf_smoother(mdl, t, y)
+    post = cd.cdnlgssm_smoother(P, y, t[..., None])
+    assert _ffi.lib().cdkf_last_kernel().decode().startswith("ekf_smoother_wave_l96_kernel<double")
+    assert relerr(post.smoothed_means, ref["smoothed_means"]) < 1e-8
+    assert relerr(post.smoothed_covariances, ref["smoothed_covariances"]) < 1e-8
+    assert np.array_equal(post.smoothed_covariances, np.swapaxes(post.smoothed_covariances, -1, -2))
+    monkeypatch.setenv("CDKF_WG_BACKWARD", "1")
+    wg = cd.cdnlgssm_smoother(P, y, t[..., None])
+    assert _ffi.lib().cdkf_last_kernel().decode().startswith("ekf_smoother_wg_kernel")
+    monkeypatch.delenv("CDKF_WG_BACKWARD")
+    assert relerr(post.smoothed_covariances, wg.smoothed_covariances) < 1e-9
+    post32 = cd.cdnlgssm_smoother(P, y.astype(np.float32), t[..., None])
+    assert post32.smoothed_means.dtype == np.float32
+    assert relerr(post32.smoothed_means, ref["smoothed_means"]) < 5e-4
+    for T_short in (1, 2):
+        ps = cd.cdnlgssm_smoother(P, y[:2, :T_short], t[:2, :T_short, None])
+        rs = o.ekf_smoother(mdl, t[:2, :T_short], y[:2, :T_short])
+        assert relerr(ps.smoothed_covariances, rs["smoothed_covariances"]) < 1e-9
+        assert relerr(ps.smoothed_means, rs["smoothed_means"]) < 1e-9
+
+
 @pytest.mark.parametrize("order", ["first", "second", "zeroth"])
 def test_mlp_drift_orders(hip_lib, order):
     """Config C5 shape (d=8, m=4, 2x64 tanh MLP).  'second' exercises the reference's 0.5*trace(H_t @ P) quirk,
