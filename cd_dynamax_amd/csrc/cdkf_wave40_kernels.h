@@ -566,17 +566,21 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave_l96_kernel(const WgArg
   auto store_cov = [&](R* dst, long k, const R* img, int ld, int) {
     if (!dst || (skip & 16)) return;
     R* o = dst + n * a.P_sn + k * a.P_sk;
-    constexpr int NE = (D * D + 63) / 64;
-    R v[NE];
+    // five reads in flight, then their stores (all twenty-five at once cost registers the sweep does not have: 57 -> 48 ms)
+    constexpr int NE = (D * D + 63) / 64, CHK = 5;
+#pragma unroll 1
+    for (int q0 = 0; q0 < NE; q0 += CHK) {
+      R v[CHK];
 #pragma unroll
-    for (int q = 0; q < NE; ++q) {  // all reads in flight, then the stores
-      const int e = lane + 64 * q, r = e / D, c = e - r * D;
-      v[q] = (e < D * D) ? img[r * ld + c] : R(0);
-    }
+      for (int u = 0; u < CHK; ++u) {
+        const int e = lane + 64 * (q0 + u), r = e / D, c = e - r * D;
+        v[u] = (e < D * D) ? img[r * ld + c] : R(0);
+      }
 #pragma unroll
-    for (int q = 0; q < NE; ++q) {
-      const int e = lane + 64 * q;
-      if (e < D * D) o[(long)e * a.P_si] = v[q];
+      for (int u = 0; u < CHK; ++u) {
+        const int e = lane + 64 * (q0 + u);
+        if (e < D * D) o[(long)e * a.P_si] = v[u];
+      }
     }
   };
 
@@ -826,17 +830,20 @@ __global__ __launch_bounds__(256, 1) void ekf_smoother_wave_l96_kernel(const WgA
   }
   auto store_cov = [&](long k) {  // the symmetric image in Bm -> sP[k]
     R* o = a.sP + n * a.P_sn + k * a.P_sk;
-    constexpr int NE = (D * D + 63) / 64;
-    R v[NE];
+    constexpr int NE = (D * D + 63) / 64, CHK = 5;
+#pragma unroll 1
+    for (int q0 = 0; q0 < NE; q0 += CHK) {
+      R v[CHK];
 #pragma unroll
-    for (int q = 0; q < NE; ++q) {
-      const int e = lane + 64 * q, r = e / D, c = e - r * D;
-      v[q] = (e < D * D) ? Bm[r * LDY + c] : R(0);
-    }
+      for (int u = 0; u < CHK; ++u) {
+        const int e = lane + 64 * (q0 + u), r = e / D, c = e - r * D;
+        v[u] = (e < D * D) ? Bm[r * LDY + c] : R(0);
+      }
 #pragma unroll
-    for (int q = 0; q < NE; ++q) {
-      const int e = lane + 64 * q;
-      if (e < D * D) o[(long)e * a.P_si] = v[q];
+      for (int u = 0; u < CHK; ++u) {
+        const int e = lane + 64 * (q0 + u);
+        if (e < D * D) o[(long)e * a.P_si] = v[u];
+      }
     }
   };
 
