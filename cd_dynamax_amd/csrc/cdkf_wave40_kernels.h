@@ -180,8 +180,8 @@ struct W40Lin {
 
   // the W_ columns from c0 of the rows from c0, lane = row, the panel's entries in registers.  A finished column goes to a 64-entry
   // LDS scratch indexed by row (col[s]); the multipliers L[c0 + q][c] of the columns still to update come back from there as
-  // broadcast reads, two per instruction (LDS executes a wavefront's accesses in order: no synchronisation in between).  Only the
-  // pivot travels through v_readlane.
+  // broadcast reads, two per instruction (LDS executes a wavefront's accesses in order: no synchronisation in between).  The
+  // pivot and the next column's multiplier travel through v_readlane (the dependency chain then skips the LDS round trip).
   template <int NS, int W_>
   static CDKF_DEV void chol_panel(R* const (&L)[NS], R* const (&col)[NS], R* inv, const int c0, const int rowi, const int ri,
                                   const int lane, R& quad, R& pinv, bool& bad) {
@@ -206,12 +206,25 @@ struct W40Lin {
       if (lane == 0) inv[c] = rr[NS - 1];
       pinv *= rr[0];
       R mult[NS][W_];
+      // (16-byte reads at immediate offsets from ONE address: c0 is a multiple of sixteen and the scratch is 16-byte aligned)
+      typedef R Pair __attribute__((ext_vector_type(2)));
 #pragma unroll
-      for (int q = r + 1; q < W_; ++q)
+      for (int s = 0; s < NS; ++s) {
+        const Pair* cp = reinterpret_cast<const Pair*>(__builtin_assume_aligned(col[s] + c0, 16));
 #pragma unroll
-        for (int s = 0; s < NS; ++s) mult[s][q] = col[s][c0 + q];  // L[c0 + q][c]
+        for (int h = (r + 1) / 2; h < W_ / 2; ++h) {
+          const Pair pr = cp[h];
+          mult[s][2 * h] = pr[0];
+          mult[s][2 * h + 1] = pr[1];
+        }
+      }
+      // the NEXT column's multiplier through v_readlane: the next pivot then does not wait for the LDS round trip of the scratch
+      if (r + 1 < W_) {
 #pragma unroll
-      for (int q = r + 1; q < W_; ++q)
+        for (int s = 0; s < NS; ++s) u[s][r + 1] = rfma(-u[s][r], w40_readlane(u[s][r], c0 + r + 1), u[s][r + 1]);
+      }
+#pragma unroll
+      for (int q = r + 2; q < W_; ++q)
 #pragma unroll
         for (int s = 0; s < NS; ++s) u[s][q] = rfma(-u[s][r], mult[s][q], u[s][q]);
     }
@@ -820,6 +833,7 @@ __global__ __launch_bounds__(256, 1) void ekf_smoother_wave_l96_kernel(const WgA
   const R* fPn = a.fP + n * a.P_sn;
   int st = 0;
   bool bad = false;
+  const int skip = a.forecast;  // diagnostic mask of phases to skip (scripts/prof_w40.sh; 0 unless CDKF_W40_ABLATE is set)
 
   int oY[EPL], oYT[EPL];  // the owned entries' two positions in a symmetric image
 #pragma unroll
@@ -922,8 +936,8 @@ __global__ __launch_bounds__(256, 1) void ekf_smoother_wave_l96_kernel(const WgA
       double logdet = 0.0;
       long long w40_last = 0;
       (void)w40_last;
-      Lin::template cholesky<1>(sys, scr, inv, rowi, ri, lane, quad, logdet, bad W40_TICK_PASS);
-      Lin::solve(Gm, Bm, inv, (const R*)nullptr, lane, [] {} W40_TICK_PASS);
+      if (!(skip & 1)) Lin::template cholesky<1>(sys, scr, inv, rowi, ri, lane, quad, logdet, bad W40_TICK_PASS);
+      if (!(skip & 2)) Lin::solve(Gm, Bm, inv, (const R*)nullptr, lane, [] {} W40_TICK_PASS);
     }
     // G = F(m_f) + X^T: the image holds X^T already
     if (isrow) {
@@ -984,7 +998,7 @@ __global__ __launch_bounds__(256, 1) void ekf_smoother_wave_l96_kernel(const WgA
       R tprev = R(0);
       R tnx = rmin(a.dt0, tend);
       long steps = 0;
-      while (tprev < tend) {
+      while (tprev < tend && !(skip & 8)) {
         if (steps >= a.max_steps) {
           st |= kStatusMaxSteps;
           break;
@@ -1007,7 +1021,7 @@ __global__ __launch_bounds__(256, 1) void ekf_smoother_wave_l96_kernel(const WgA
       if (ms != ms) st |= kStatusNan;
     }
     wave_sync();
-    store_cov(k);
+    if (!(skip & 16)) store_cov(k);
     wave_sync();
     t1 = t0;
   }

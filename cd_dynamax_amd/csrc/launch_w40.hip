@@ -26,7 +26,10 @@ int launch_wave40(const WgArgs<R>& a, hipStream_t stream, bool backward) {
     const size_t lds = sizeof(R) * (size_t)wave40_smoother_lds_reals<D>() + 64;
     const unsigned blocks = (unsigned)((a.N + W40S<D>::kWaves - 1) / W40S<D>::kWaves);
     note_kernel("ekf_smoother_wave_l96_kernel<%s, %d>", real_name<R>(), D);
-    hipLaunchKernelGGL((ekf_smoother_wave_l96_kernel<R, D>), dim3(blocks), dim3(64 * W40S<D>::kWaves), lds, stream, a);
+    WgArgs<R> b = a;
+    const char* ab = getenv("CDKF_W40_ABLATE_BWD");  // diagnostic: mask of phases to skip; never set in production
+    b.forecast = ab ? atoi(ab) : 0;
+    hipLaunchKernelGGL((ekf_smoother_wave_l96_kernel<R, D>), dim3(blocks), dim3(64 * W40S<D>::kWaves), lds, stream, b);
     CDKF_HIP_CHECK(hipGetLastError());
     return CDKF_OK;
   }
