@@ -526,10 +526,11 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave_l96_kernel(const WgArg
       buf[(dst + 2) * LDP + (c + 2)] = buf[(src + 2) * LDP + (c + 2)];
       buf[(c + 2) * LDP + (dst + 2)] = buf[(c + 2) * LDP + (src + 2)];
     }
+    typedef R Pair __attribute__((ext_vector_type(2)));
+    Pair* cab = reinterpret_cast<Pair*>(__builtin_assume_aligned(ca, 16));  // (a_i, b_i) side by side: one 16-byte read per index
     if (isrow) {
       const R xp1 = xs[lp1], xm1 = xs[lm1], xm2 = xs[lm2];
-      ca[lane] = xm1;
-      cb[lane] = xp1 - xm2;
+      cab[lane] = Pair{xm1, xp1 - xm2};
       kM = rfma(xp1 - xm2, xm1, forcing - xm);
     } else {
       kM = R(0);
@@ -551,10 +552,11 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave_l96_kernel(const WgArg
         o6[u][3] = c[-2];
         o6[u][4] = c[-1];
         o6[u][5] = c[1];
-        c4[u][0] = ca[ei[s]];
-        c4[u][1] = cb[ei[s]];
-        c4[u][2] = ca[ej[s]];
-        c4[u][3] = cb[ej[s]];
+        const Pair ci = cab[ei[s]], cj = cab[ej[s]];
+        c4[u][0] = ci[0];
+        c4[u][1] = ci[1];
+        c4[u][2] = cj[0];
+        c4[u][3] = cj[1];
         qv[u] = shQ[64 * s + lane];
       }
       __builtin_amdgcn_sched_barrier(0);
