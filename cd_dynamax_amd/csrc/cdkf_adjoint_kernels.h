@@ -37,7 +37,6 @@ struct AdjSh {  // per workgroup, in reals; hidden sizes padded to 64, state to 
   static constexpr int b3 = W3 + 520;      // [8]
   static constexpr int end = b3 + 8;
 };
-constexpr int kAdjCk = 4;  // Dormand-Prince step starts kept per replay chunk
 struct AdjOff {  // per wavefront, in reals
   static constexpr int P = 0, F = 64, Lam = 128, G = 192, A = 256, B = 320, X = 384, S = 448, S1 = 512, S2 = 576, HP = 640,
                        H = 704, Pb = 768, Kb = 832, Ub = 896, Si = 960, XP = 1024;
@@ -678,8 +677,9 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
     Pij = rfma(dt, sp_, Pij);
   };
   // ... and its adjoint: (mb, Pb) cotangent of the step's result -> cotangent of its start; dtheta accumulated
-  auto step_adj = [&](R mj, R Pij, R dt, R& mb, R& Pb) __attribute__((always_inline)) {
-    stages_fwd(mj, Pij, dt);
+  // (slopes: the step's six slopes are already in the tiles -- read back from the forward sweep's checkpoints)
+  auto step_adj = [&](R mj, R Pij, R dt, R& mb, R& Pb, bool slopes) __attribute__((always_inline)) {
+    if (!slopes) stages_fwd(mj, Pij, dt);
 #pragma unroll 1
     for (int sg = 5; sg >= 0; --sg) {
       R lm_ = TB::b[sg] * mb, lp = TB::b[sg] * Pb;
@@ -1016,6 +1016,19 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
     }
     const R mf = (lane < d) ? a.fm[n * a.m_sn + (k - 1) * a.m_sk + lane * a.m_si] : R(0);
     const R Pf = inP ? a.fP[n * a.P_sn + (k - 1) * a.P_sk + (i * d + j) * a.P_si] : R(0);
+    // The forward sweep kept the slopes of this interval's steps when there are at most ck_smax of them (288 GB of HBM: 3.5 KB per
+    // step and trajectory is cheaper than six right-hand sides): the step starts then follow from the slopes and nothing is
+    // re-integrated.  Same loops either way (ONE inlined copy of step_adj): with the slopes S <= kAdjCk is a single chunk.
+    const bool have = a.ck && S <= a.ck_smax && S <= kAdjCk;
+    const R* ckb = have ? a.ck + ((n * (a.T - 1) + (k - 1)) * a.ck_smax) * kCkStep : nullptr;
+    auto load_slopes = [&](long s) __attribute__((always_inline)) {
+      const R* c = ckb + s * kCkStep;
+#pragma unroll
+      for (int sg = 0; sg < 6; ++sg) {
+        W[KPo + 64 * sg + lane] = c[sg * 72 + lane];
+        if (lane < 8) W[KMo + 8 * sg + lane] = c[sg * 72 + 64 + lane];
+      }
+    };
     for (long cs = ((S - 1) / kAdjCk) * kAdjCk; cs >= 0; cs -= kAdjCk) {
       const long ce = (cs + kAdjCk < S) ? cs + kAdjCk : S;
       R mj = mf, Pij = Pf;
@@ -1028,7 +1041,21 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
           if (lane < 8) W[AdjOff::ck + slot * 72 + 64 + lane] = mj;
           if (lane == 0) W[AdjOff::ck + kAdjCk * 72 + slot] = dt;
         }
-        if (s + 1 < ce) step_fwd(mj, Pij, dt);
+        if (s + 1 < ce) {
+          if (have) {
+            load_slopes(s);
+            R sm_ = 0, sp_ = 0;
+#pragma unroll
+            for (int sg = 0; sg < 6; ++sg) {
+              sm_ = rfma(TB::b[sg], W[KMo + 8 * sg + l8], sm_);
+              sp_ = rfma(TB::b[sg], W[KPo + 64 * sg + lane], sp_);
+            }
+            mj = rfma(dt, sm_, mj);
+            Pij = rfma(dt, sp_, Pij);
+          } else {
+            step_fwd(mj, Pij, dt);
+          }
+        }
         tprev = rmin(tnext, t1);
         const R tn = tnext + a.dt0;
         tnext = (tn > t1 - Tol<R>::v) ? t1 : tn;
@@ -1039,7 +1066,8 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
         const R Ps = W[AdjOff::ck + slot * 72 + lane];
         const R ms = (lane < 8) ? W[AdjOff::ck + slot * 72 + 64 + lane] : R(0);
         const R dt = W[AdjOff::ck + kAdjCk * 72 + slot];
-        step_adj(ms, Ps, dt, mb, Pb);
+        if (have) load_slopes(s);
+        step_adj(ms, Ps, dt, mb, Pb, have);
       }
       wave_sync();
     }

@@ -491,6 +491,7 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave8_kernel(const WgArgs<R
           break;
         }
         const R dt = tnext - tprev;
+        R* ckp = (a.ck && k + 1 < a.T && steps < a.ck_smax) ? a.ck + ((n * (a.T - 1) + k) * a.ck_smax + steps) * kCkStep : nullptr;
         // The stage loop stays ROLLED (one inlined copy of the right-hand side instead of six: the unrolled sweep was several
         // times the instruction cache): the slopes k1 .. k5 wait in LDS -- a lane reads back only what it wrote itself, no
         // synchronisation -- and the stage index may be a run-time value.  Same sums in the same order as the unrolled form.
@@ -508,6 +509,10 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave8_kernel(const WgArgs<R
             }
           R kM = 0, kP = 0;
           rhs(rfma(dt, sm, mj), rfma(dt, sp, Pij), kM, kP);
+          if (ckp) {  // slopes for the reverse sweep (uniform branch; nullptr outside cdkf_ekf_loglik_grad_all)
+            ckp[sg * 72 + lane] = kP;
+            if (lane < kW8) ckp[sg * 72 + 64 + lane] = kM;
+          }
           if (sg < 5) {
             W[W8Off::X + 64 * sg + lane] = kP;
             if (lane < kW8) W[W8Off::km + 8 * sg + lane] = kM;

@@ -46,7 +46,13 @@ struct WgArgs {
   R* sm;
   R* sP;
   int* status;
+  // reverse sweep only: the forward sweep leaves the six Dormand-Prince slopes of the first ck_smax steps of every interval here
+  // ([N][T-1][ck_smax][6][64 P + 8 m]) and the reverse sweep reads them back instead of re-integrating the interval
+  R* ck;
+  int ck_smax;
 };
+constexpr int kCkStep = 6 * 72;  // reals per checkpointed step
+constexpr int kAdjCk = 4;         // Dormand-Prince step starts the reverse sweep keeps in LDS per replay chunk
 
 // Integer division by a run-time divisor costs ~40 instructions on CDNA: float reciprocal with +-1 correction
 // (exact for 0 <= e < 2^23, 0 < n < 2^12).

@@ -358,12 +358,25 @@ int launch_ekf_grad_adjoint(const cdkf_model* mdl, const cdkf_opts* o, int64_t N
   ParamLease lease(stream);
   int rc = wg_prepare(a, &blk, &lease.slot, mdl, o, N, T, stream);
   if (rc) return rc;
-  const size_t nm = (size_t)N * T * mdl->state_dim, nP = nm * mdl->state_dim, bytes = 2 * (nm + nP) * sizeof(R);
+  const size_t nm = (size_t)N * T * mdl->state_dim, nP = nm * mdl->state_dim;
+  // stage-slope checkpoints of the first smax steps of every interval (0 = re-integrate everything): two steps cover every
+  // interval up to 2 dt0; CDKF_ADJ_CKPT_STEPS overrides, and a workspace beyond CDKF_ADJ_CKPT_GB (default 64) turns them off
+  int smax = 2;
+  if (const char* e = getenv("CDKF_ADJ_CKPT_STEPS")) smax = atoi(e);
+  if (smax < 0) smax = 0;
+  if (smax > kAdjCk) smax = kAdjCk;
+  double cap_gb = 64.0;
+  if (const char* e = getenv("CDKF_ADJ_CKPT_GB")) cap_gb = atof(e);
+  size_t nck = (T > 1) ? (size_t)N * (size_t)(T - 1) * (size_t)smax * kCkStep : 0;
+  if ((double)nck * sizeof(R) > cap_gb * 1e9) nck = 0;
+  const size_t bytes = (2 * (nm + nP) + nck) * sizeof(R);
   AdjWorkspace& ws = g_adj_ws;
   if (int wrc = workspace_reserve(ws, bytes, stream)) return wrc;
   R* w = (R*)ws.p;
   a.t = t; a.y = y; a.ll = ll; a.status = status;
   a.fm = w; a.fP = w + nm; a.pm = w + nm + nP; a.pP = w + 2 * nm + nP;
+  a.ck = nck ? w + 2 * (nm + nP) : nullptr;
+  a.ck_smax = nck ? smax : 0;
   rc = launch_wave8<R>(a, stream);
   if (!rc)
     rc = (mdl->drift_kind == CDKF_DRIFT_MLP_TANH) ? launch_adjoint_kernel<R, true>(a, grad, grad_model, stream)
