@@ -369,9 +369,13 @@ int launch_ekf_grad_adjoint(const cdkf_model* mdl, const cdkf_opts* o, int64_t N
   if (const char* e = getenv("CDKF_ADJ_CKPT_GB")) cap_gb = atof(e);
   size_t nck = (T > 1) ? (size_t)N * (size_t)(T - 1) * (size_t)smax * kCkStep : 0;
   if ((double)nck * sizeof(R) > cap_gb * 1e9) nck = 0;
-  const size_t bytes = (2 * (nm + nP) + nck) * sizeof(R);
   AdjWorkspace& ws = g_adj_ws;
-  if (int wrc = workspace_reserve(ws, bytes, stream)) return wrc;
+  if (int wrc = workspace_reserve(ws, (2 * (nm + nP) + nck) * sizeof(R), stream)) {
+    if (!nck) return wrc;
+    (void)hipGetLastError();  // no room for the slope checkpoints: the sweep re-integrates instead
+    nck = 0;
+    if (int wrc2 = workspace_reserve(ws, 2 * (nm + nP) * sizeof(R), stream)) return wrc2;
+  }
   R* w = (R*)ws.p;
   a.t = t; a.y = y; a.ll = ll; a.status = status;
   a.fm = w; a.fP = w + nm; a.pm = w + nm + nP; a.pP = w + 2 * nm + nP;

@@ -207,6 +207,30 @@ def test_mlp_loglik_gradient_reverse_sweep(hip_lib, d, m, h):
     assert np.abs(flat32b - g_ref2).max() < 2e-2 * scale2
 
 
+def test_reverse_sweep_slope_checkpoints_do_not_change_the_gradient(hip_lib, monkeypatch):
+    """The forward sweep's stage-slope checkpoints (first two steps of every interval) against re-integration
+    (CDKF_ADJ_CKPT_STEPS=0) and against four checkpointed steps: same gradient to rounding, on intervals of 1, 2, 3 and more
+    steps (both paths in one sweep)."""
+    rng = np.random.default_rng(21)
+    mdl = mlp_model(rng, 6, 3, (20, 12))
+    N, T = 5, 14
+    t = o.irregular_times(rng, N, T, 0.012 * T)   # gaps around dt0 = 0.01: one to three steps
+    t[:, 9:] += 0.07                              # and one of eight
+    y = o.simulate(mdl, t, rng)
+    P = params_from(mdl)
+    out = {}
+    for steps in ("2", "0", "4"):
+        monkeypatch.setenv("CDKF_ADJ_CKPT_STEPS", steps)
+        ll, g = cd.cdnlgssm_loglik_and_grad(P, y, t[..., None])
+        out[steps] = np.concatenate([np.asarray(a).reshape(N, -1) for a in g], axis=-1)
+    monkeypatch.delenv("CDKF_ADJ_CKPT_STEPS")
+    scale = np.abs(out["0"]).max()
+    assert np.abs(out["2"] - out["0"]).max() < 1e-11 * scale
+    assert np.abs(out["4"] - out["0"]).max() < 1e-11 * scale
+    _, g_ref = o.ekf_loglik_grad_adjoint(mdl, t, y, state_order="second")
+    assert np.abs(out["2"] - g_ref).max() < 1e-8 * scale
+
+
 def _general_model(rng, drift, d, m):
     """Non-diagonal L, Qc, R, P0, a dense H with bias: every parameter of the model carries a non-trivial gradient."""
     A, B, C = rng.standard_normal((d, d)), rng.standard_normal((m, m)), rng.standard_normal((d, d))
