@@ -71,7 +71,42 @@ CDKF_DEV double lpe_fmac_bcast(double acc, double src, double mult) {
   return acc;
 }
 template <int L>
-CDKF_DEV float lpe_fmac_bcast(float acc, float src, float mult) { return rfma(lpe_bcast<L>(src), mult, acc); }
+CDKF_DEV float lpe_fmac_bcast(float acc, float src, float mult) {
+  asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mult), "n"(L));
+  return acc;
+}
+// 32-bit: EVERY DPP control folds into the multiply-add (acc + dpp(src) * mult), so the sixteen-lane right-hand side needs no
+// separate fetches at all.  Same hazard rule as above; lpe_dpp_fence(v) puts the two wait states behind v's producer.
+#define CDKF_LPE_FMAC32(NAME, CTRL)                                                                                       \
+  CDKF_DEV float NAME(float acc, float src, float mult) {                                                                 \
+    asm volatile("v_fmac_f32_dpp %0, %1, %2 " CTRL " row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mult));      \
+    return acc;                                                                                                           \
+  }
+#define CDKF_LPE_MUL32(NAME, CTRL)                                                                       \
+  CDKF_DEV float NAME(float src, float mult) {                                                           \
+    float out;                                                                                           \
+    asm volatile("v_mul_f32_dpp %0, %1, %2 " CTRL " row_mask:0xf bank_mask:0xf" : "=v"(out) : "v"(src), "v"(mult)); \
+    return out;                                                                                          \
+  }
+CDKF_LPE_MUL32(lpe_mul_ror12, "row_ror:12")
+CDKF_LPE_MUL32(lpe_mul_ror8, "row_ror:8")
+CDKF_LPE_MUL32(lpe_mul_ror4, "row_ror:4")
+CDKF_LPE_MUL32(lpe_mul_bcast7, "row_newbcast:7")
+#undef CDKF_LPE_MUL32
+CDKF_LPE_FMAC32(lpe_fmac_ror12, "row_ror:12")
+CDKF_LPE_FMAC32(lpe_fmac_ror8, "row_ror:8")
+CDKF_LPE_FMAC32(lpe_fmac_ror4, "row_ror:4")
+CDKF_LPE_FMAC32(lpe_fmac_qA, "quad_perm:[1,2,0,3]")
+CDKF_LPE_FMAC32(lpe_fmac_qB, "quad_perm:[2,0,1,3]")
+CDKF_LPE_FMAC32(lpe_fmac_b1, "row_newbcast:1")
+CDKF_LPE_FMAC32(lpe_fmac_b2, "row_newbcast:2")
+CDKF_LPE_FMAC32(lpe_fmac_b3, "row_newbcast:3")
+CDKF_LPE_FMAC32(lpe_fmac_b11, "row_newbcast:11")
+#undef CDKF_LPE_FMAC32
+CDKF_DEV float lpe_dpp_fence(float v) {
+  asm volatile("s_nop 1" : "+v"(v));
+  return v;
+}
 
 // Right-hand side of the moment ODEs for the entry this lane owns (see the header comment for the grid).
 //
@@ -127,7 +162,32 @@ struct LpeRhs {
     u1 = (mean && i == 2) ? R(1) : R(0);
     u2 = (mean && i == 1) ? R(-1) : R(0);
   }
-  CDKF_DEV R eval(const R v) const {
+  CDKF_DEV R eval(const R vin) const {
+    if constexpr (sizeof(R) == 4) {  // every fetch is the DPP operand of the multiply-add that consumes it: 16 (+2) instructions
+      const float v = lpe_dpp_fence(vin);
+      // independent chains, interleaved and pinned in this order (volatile): a lone wavefront issues in order, and the assembler's
+      // hazard pass puts a wait state between two of these statements that touch the same register within two instructions
+      float acc = rfma(g0, v, q);
+      float X = lpe_mul_ror12(v, gx1i);
+      float Y = lpe_mul_ror8(v, gy2i);
+      float Z = lpe_mul_ror4(v, gz3i);
+      acc = lpe_fmac_ror12(acc, v, c1i);
+      X = lpe_fmac_ror4(X, v, gx3i);
+      Y = lpe_fmac_qA(Y, v, gyAj);
+      Z = lpe_fmac_qB(Z, v, gzBj);
+      acc = lpe_fmac_ror4(acc, v, c3i);
+      X = lpe_fmac_qA(X, v, gxAj);
+      float B = lpe_mul_bcast7(v, Y);  // second accumulator for the mean-weighted sums: y Y + z Z (+ the unscented terms)
+      acc = lpe_fmac_qA(acc, v, cAj);
+      X = lpe_fmac_qB(X, v, gxBj);
+      B = lpe_fmac_b11(B, v, Z);
+      acc = lpe_fmac_qB(acc, v, cBj);
+      if constexpr (UKF) B = lpe_fmac_b1(B, v, u1);
+      acc = lpe_fmac_b3(acc, v, X);
+      if constexpr (UKF) B = lpe_fmac_b2(B, v, u2);
+      return acc + B;
+    }
+    const R v = vin;
     const R d1 = lpe_dpp<0x120 + 12>(v), d2 = lpe_dpp<0x120 + 8>(v), d3 = lpe_dpp<0x120 + 4>(v);  // rows i+1, i+2, i+3
     const R r1 = lpe_dpp<0xC9>(v), r2 = lpe_dpp<0xD2>(v);  // quad_perm [1,2,0,3], [2,0,1,3]: columns (j+1) % 3, (j+2) % 3
     R acc = rfma(g0, v, q);
