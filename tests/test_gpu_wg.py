@@ -39,6 +39,33 @@ def test_lorenz96_filter_and_smoother(hip_lib, d, m):
     assert relerr(post32.filtered_means, ref["filtered_means"]) < 2e-4
 
 
+def test_lorenz96_d40_dense_noise_matrices(hip_lib):
+    """Config 4's kernels own the packed upper triangle and use symmetric images throughout: dense (non-diagonal) L, Qc, R, P0 and a
+    non-zero initial mean must still reproduce the oracle (filter: all four moment arrays; smoother)."""
+    rng = np.random.default_rng(123)
+    d = 40
+
+    def spd(n, s):
+        A = rng.standard_normal((n, n))
+        return A @ A.T / n * s + 0.3 * np.eye(n)
+
+    mdl = o.Model(o.Lorenz96Drift(8.0), np.eye(d) + 0.1 * rng.standard_normal((d, d)), spd(d, 0.5), np.eye(d), np.zeros(d), spd(d, 0.7),
+                  8.0 + rng.standard_normal(d), spd(d, 1.0))
+    N, T = 5, 10
+    t = o.irregular_times(rng, N, T, 0.015 * T)
+    y = o.simulate(mdl, t, rng)
+    P = params_from(mdl)
+    ref = o.ekf_smoother(mdl, t, y)
+    post = cd.cdnlgssm_smoother(P, y, t[..., None])
+    assert _ffi.lib().cdkf_last_kernel().decode().startswith("ekf_smoother_wave_l96_kernel<double")
+    for k in ("filtered_means", "filtered_covariances", "smoothed_means", "smoothed_covariances"):
+        assert relerr(getattr(post, k), ref[k]) < 1e-10, k
+    assert relerr(post.marginal_loglik, ref["marginal_loglik"]) < 1e-11
+    flt = cd.cdnlgssm_filter(P, y, t[..., None])
+    assert _ffi.lib().cdkf_last_kernel().decode().startswith("ekf_filter_wave_l96_kernel<double")
+    _check(flt, o.ekf_filter(mdl, t, y), 1e-10)
+
+
 def test_lorenz96_d40_backward_sweep_kernels_agree(hip_lib, monkeypatch):
     """Config 4's smoother: the wavefront-per-trajectory backward sweep (ekf_smoother_wave_l96_kernel) against the oracle at a
     batch that does not fill its last workgroup, against the workgroup kernel it replaced (CDKF_WG_BACKWARD=1), in fp32, and at
