@@ -400,6 +400,9 @@ def other_configs(lib, timer, stream, t_h, y_h, only=None):
     if want("config5_slice_mlp_d8_fp64_1024x1000"):
         out["config5_slice_mlp_d8_fp64_1024x1000"] = case(
             c5, t5, y5, "f64", _ffi.LAYOUT_TN, ["ekf_filter"], "mfma", {"ekf_filter": mlp_flops}, outputs=False, grad=True, state_order=2)
+    if want("config5_slice_mlp_d8_fp32_1024x1000"):  # the reference's own precision (fp32), its default state_order
+        out["config5_slice_mlp_d8_fp32_1024x1000"] = case(
+            c5, t5, y5, "f32", _ffi.LAYOUT_TN, ["ekf_filter"], "mfma", {"ekf_filter": mlp_flops}, outputs=False, grad=True, state_order=2)
     if want("config5_slice_mlp_d8_fp64_1024x1000_first_order"):
         out["config5_slice_mlp_d8_fp64_1024x1000_first_order"] = case(
             c5, t5, y5, "f64", _ffi.LAYOUT_TN, ["ekf_filter"], "mfma", {"ekf_filter": mlp_flops}, outputs=False, grad=True, state_order=1)
