@@ -235,7 +235,8 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
   // so [E1 | tc] = W2^T [A1 | s2] is ONE more 64 x 64 x 9 product on the matrix cores per right-hand side.
   const bool second = MLP && a.order == 2;
   // OUT[p][c] = sum_q W2[p][q] IN[q][c]  (images [64][9]; the caller synchronises before; OUT may be IN)
-  auto w2_times = [&](int IN, int OUT) __attribute__((always_inline)) {
+  // (between: runs after the product's operands have been read and before its result overwrites OUT -- work that still needs IN)
+  auto w2_times = [&](int IN, int OUT, auto&& between) __attribute__((always_inline)) {
     typename MTile::V4 acc[4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) acc[mt] = typename MTile::V4{0, 0, 0, 0};
@@ -246,6 +247,7 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
       for (int mt = 0; mt < 4; ++mt) acc[mt] = wg_mfma(Sh[AdjSh::W2 + (16 * mt + lm) * 65 + 4 * ks + lg], bv, acc[mt]);
       if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
+    between();
     wave_sync();
     if (lm < 9) {
 #pragma unroll
@@ -497,7 +499,8 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
       }
       W[AdjOff::TC + lane * 9 + 8] = tc_b;
       wave_sync();
-      w2_times(AdjOff::TC, AdjOff::TC);
+      // F1 = W2 [B1 | tc_b] in place; the rank-9 update dW2 += [A1 | s2] [B1 | tc_b]^T reads the same image before it is overwritten
+      w2_times(AdjOff::TC, AdjOff::TC, [&]() __attribute__((always_inline)) { dw2_update(AdjOff::ZC, AdjOff::TC); });
       R d2_b = 0;
       const R s2_b = W[AdjOff::TC + lane * 9 + 8];
       sb_ = R(-2) * a2 * d2 * s2_b;
@@ -508,12 +511,6 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
         gW3[k] = rfma(d2, f1, rfma(sb_, T[k], gW3[k]));
       }
       z2x = s2_b * (R(-2) * sdiv) * d2 * (R(1) - R(3) * a2 * a2) + d2_b * (R(-2) * a2 * d2);
-      wave_sync();
-#pragma unroll
-      for (int k = 0; k < 8; ++k) W[AdjOff::TC + lane * 9 + k] = td_b * w1row(k);
-      W[AdjOff::TC + lane * 9 + 8] = tc_b;
-      wave_sync();
-      dw2_update(AdjOff::ZC, AdjOff::TC);
       wave_sync();  // (ZC is rewritten below)
     }
     W[AdjOff::F + lane] = Fij;
