@@ -264,7 +264,8 @@ struct W40Lin {
 
   // img[c][16 b + r] -= sum_k img[c][k] Lf(16 b + r, k) over the unknowns k already solved: k < 16 b going forward (Lf(i, k) = L[i][k]),
   // k >= 16 (b + 1) going backward (Lf(i, k) = L[k][i], the transposed factor); all D right-hand sides c, r < 16
-  template <bool FWD, int b>
+  // (CTM: mask of the sixteen-row groups of right-hand sides this call updates -- two wavefronts can share one product)
+  template <bool FWD, int b, int CTM = (1 << NB) - 1>
   static CDKF_DEV void solve_gemm(R* img, const R* L, const int lane) {
     const int lm = lane & 15, lg = lane >> 4;
     const int ucol = 16 * b + lm;  // the unknown this lane's B operand / accumulator column stands for
@@ -272,10 +273,12 @@ struct W40Lin {
     V4 acc[NB];
 #pragma unroll
     for (int ct = 0; ct < NB; ++ct)
+      if ((CTM >> ct) & 1) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 16 * ct + Tile::row(lg, r);
-        acc[ct][r] = (row < D && uin) ? img[row * LDY + ucol] : R(0);
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * ct + Tile::row(lg, r);
+          acc[ct][r] = (row < D && uin) ? img[row * LDY + ucol] : R(0);
+        }
       }
     constexpr int kbeg = FWD ? 0 : 16 * (b + 1), kend = FWD ? 16 * b : D;
     const int boff = W::rs(uin ? ucol : 0);
@@ -285,16 +288,20 @@ struct W40Lin {
       const R bv = uin ? (FWD ? L[boff + kk] : L[W::rs(kk) + ucol]) : R(0);
       R av[NB];
 #pragma unroll
-      for (int ct = 0; ct < NB; ++ct) av[ct] = (16 * ct + lm < D) ? -img[(16 * ct + lm) * LDY + kk] : R(0);
+      for (int ct = 0; ct < NB; ++ct)
+        if ((CTM >> ct) & 1) av[ct] = (16 * ct + lm < D) ? -img[(16 * ct + lm) * LDY + kk] : R(0);
 #pragma unroll
-      for (int ct = 0; ct < NB; ++ct) acc[ct] = wg_mfma(av[ct], bv, acc[ct]);
+      for (int ct = 0; ct < NB; ++ct)
+        if ((CTM >> ct) & 1) acc[ct] = wg_mfma(av[ct], bv, acc[ct]);
     }
 #pragma unroll
     for (int ct = 0; ct < NB; ++ct)
+      if ((CTM >> ct) & 1) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 16 * ct + Tile::row(lg, r);
-        if (row < D && uin) img[row * LDY + ucol] = acc[ct][r];
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * ct + Tile::row(lg, r);
+          if (row < D && uin) img[row * LDY + ucol] = acc[ct][r];
+        }
       }
   }
 
