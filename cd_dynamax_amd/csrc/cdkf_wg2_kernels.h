@@ -702,9 +702,125 @@ __device__ __forceinline__ void wg_dopri5_step(const WgLds<R>& L, const Own<R, E
   __syncthreads();
 }
 
+// Adaptive steps for the workgroup kernels: diffrax.PIDController around the embedded pair, as integrate_adaptive (cdkf_math.h) does
+// it per lane -- here the error estimate's RMS runs over the mean and the FULL d x d covariance the workgroup's threads own between
+// them (wavefront sums through __shfl_xor, their partial sums through LDS in a fixed order: every thread then holds the same number
+// and takes the same accept / reject decision).  A rejected step leaves the state where it was: the candidate lives in registers
+// until it is accepted.  max_steps counts attempts.
+template <typename R, int EPT, typename RhsFn>
+__device__ __forceinline__ bool wg_integrate_adaptive(const WgLds<R>& L, const Own<R, EPT>& own, int d, R t0, R t1, R dt0,
+                                                      long max_steps, bool with_P, RhsFn rhs, const RkTab<R>& tb) {
+  __shared__ double red[16];
+  R* mcur = L.vec(0);
+  R* Pm = L.mat(0);
+  R* ms = L.vec(1);
+  R* Ps = L.mat(1);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  const R count = with_P ? R(d) + R(d) * R(d) : R(d);
+  R tprev = t0;
+  R tnext = rmin(t0 + dt0, t1);
+  R inv1 = R(1), inv2 = R(1);
+  long steps = 0;
+  while (tprev < t1) {  // uniform over the workgroup
+    if (steps >= max_steps) return true;
+    const R dt = tnext - tprev;
+    R kM[6];
+    R kP[6][EPT];
+    wg_stage<0>(L, own, d, dt, with_P, rhs, kM, kP, tb);
+    wg_stage<1>(L, own, d, dt, with_P, rhs, kM, kP, tb);
+    wg_stage<2>(L, own, d, dt, with_P, rhs, kM, kP, tb);
+    wg_stage<3>(L, own, d, dt, with_P, rhs, kM, kP, tb);
+    wg_stage<4>(L, own, d, dt, with_P, rhs, kM, kP, tb);
+    wg_stage<5>(L, own, d, dt, with_P, rhs, kM, kP, tb);
+    // the candidate
+    R ynM = R(0), ynP[EPT];
+    if (threadIdx.x < d) {
+      R acc = tb.b[0] * kM[0];
+#pragma unroll
+      for (int sg = 1; sg < 6; ++sg) acc = rfma(tb.b[sg], kM[sg], acc);
+      ynM = rfma(dt, acc, mcur[threadIdx.x]);
+    }
+#pragma unroll
+    for (int u = 0; u < EPT; ++u) {
+      ynP[u] = R(0);
+      if (with_P && u < own.n) {
+        R acc = tb.b[0] * kP[0][u];
+#pragma unroll
+        for (int sg = 1; sg < 6; ++sg) acc = rfma(tb.b[sg], kP[sg][u], acc);
+        ynP[u] = rfma(dt, acc, Pm[own.off(u)]);
+      }
+    }
+    // first-same-as-last stage f(y_new) of the embedded estimate
+    R k7M = R(0), k7P[EPT];
+#pragma unroll
+    for (int u = 0; u < EPT; ++u) k7P[u] = R(0);
+    if (tb.fsal) {
+      if (threadIdx.x < d) ms[threadIdx.x] = ynM;
+      if (with_P) {
+#pragma unroll
+        for (int u = 0; u < EPT; ++u)
+          if (u < own.n) Ps[own.off(u)] = ynP[u];
+      }
+      __syncthreads();
+      rhs(ms, Ps, k7M, k7P);
+      __syncthreads();
+    }
+    double sq = 0.0;
+    if (threadIdx.x < d) {
+      R err = tb.berr[6] * k7M;
+#pragma unroll
+      for (int sg = 0; sg < 6; ++sg) err = rfma(tb.berr[sg], kM[sg], err);
+      const R sc = (dt * err) / rfma(rmax(rabs(mcur[threadIdx.x]), rabs(ynM)), tb.rtol, tb.atol);
+      sq += (double)(sc * sc);
+    }
+    if (with_P) {
+#pragma unroll
+      for (int u = 0; u < EPT; ++u)
+        if (u < own.n) {
+          R err = tb.berr[6] * k7P[u];
+#pragma unroll
+          for (int sg = 0; sg < 6; ++sg) err = rfma(tb.berr[sg], kP[sg][u], err);
+          const R sc = (dt * err) / rfma(rmax(rabs(Pm[own.off(u)]), rabs(ynP[u])), tb.rtol, tb.atol);
+          sq += (double)(sc * sc);
+        }
+    }
+#pragma unroll
+    for (int o_ = 32; o_ >= 1; o_ >>= 1) sq += __shfl_xor(sq, o_);
+    if (lane == 0) red[wv] = sq;
+    __syncthreads();
+    double tot = 0.0;
+    for (int w = 0; w < nw; ++w) tot += red[w];
+    const R scaled = rsqrt_((R)tot / count);
+    const bool keep = scaled < R(1);
+    const R inv = (scaled == R(0)) ? R(__builtin_huge_val()) : R(1) / scaled;
+    R factor = R(0.9) * rpow(inv, tb.c1);
+    if (tb.c2 != R(0)) factor *= rpow(inv1, tb.c2);
+    if (tb.c3 != R(0)) factor *= rpow(inv2, tb.c3);
+    factor = rmin(rmax(factor, keep ? R(1) : R(0.2)), R(10));  // (fmax / fmin: a NaN estimate rejects and shrinks, cdkf_math.h)
+    const R nt0 = keep ? tnext : tprev;
+    const R nt1 = nt0 + dt * factor;
+    if (keep) {
+      if (threadIdx.x < d) mcur[threadIdx.x] = ynM;
+      if (with_P) {
+#pragma unroll
+        for (int u = 0; u < EPT; ++u)
+          if (u < own.n) Pm[own.off(u)] = ynP[u];
+      }
+      inv2 = inv1;
+      inv1 = inv;
+    }
+    __syncthreads();  // the state is complete (and `red` free) before the next attempt
+    tprev = rmin(nt0, t1);
+    tnext = (nt1 > t1 - Tol<R>::v) ? (keep ? t1 : rfma(R(0.5), t1 - tprev, tprev)) : nt1;
+    ++steps;
+  }
+  return false;
+}
+
 template <typename R, int EPT, typename RhsFn>
 __device__ __forceinline__ bool wg_integrate(const WgLds<R>& L, const Own<R, EPT>& own, int d, R t0, R t1, R dt0,
                                              long max_steps, bool with_P, RhsFn rhs, const RkTab<R>& tb) {
+  if (tb.adaptive) return wg_integrate_adaptive<R, EPT>(L, own, d, t0, t1, dt0, max_steps, with_P, rhs, tb);
   R tprev = t0;
   R tnext = rmin(t0 + dt0, t1);
   long steps = 0;

@@ -84,11 +84,6 @@ template <typename R>
 static int wg_prepare(WgArgs<R>& a, R** dev_block, ParamSlot** slot_out, const cdkf_model* mdl, const cdkf_opts* o,
                       int64_t N, int64_t T, hipStream_t stream) {
   const int d = mdl->state_dim, m = mdl->emission_dim;
-  if (o->adaptive) {
-    set_error("opts.adaptive: the workgroup / wavefront kernels (state_dim %d, emission_dim %d) integrate in fixed steps only; adaptive "
-              "stepping runs on the register-resident shapes", d, m);
-    return CDKF_EUNSUPPORTED;
-  }
   if (!wg_shape_available(mdl, sizeof(R))) {
     set_error("no kernel for drift_kind=%d state_dim=%d emission_dim=%d n_theta=%lld (fp%d)", mdl->drift_kind, d, m,
               (long long)mdl->n_theta, (int)sizeof(R) * 8);
@@ -253,7 +248,7 @@ int launch_ekf_filter_wg(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, i
   if (wave40_shape(mdl, o) && y)
     rc = launch_wave40<R>(a, stream);
   else
-    rc = (wave8_shape(mdl) && o->solver == CDKF_SOLVER_DOPRI5) ? launch_wave8<R>(a, stream)  // (wave8 carries the Dopri5 constants)
+    rc = (wave8_shape(mdl) && o->solver == CDKF_SOLVER_DOPRI5 && !o->adaptive) ? launch_wave8<R>(a, stream)  // (wave8: fixed-step Dopri5)
                                                                : launch_wg_dispatch<R>(a, mdl, false, stream);
   const int rc2 = lease.release();
   return rc ? rc : rc2;
@@ -270,7 +265,7 @@ int launch_ekf_smoother_wg(const cdkf_model* mdl, const cdkf_opts* o, int64_t N,
   int rc = wg_prepare(a, &blk, &lease.slot, mdl, &of, N, T, stream);
   if (rc) return rc;
   a.t = t; a.y = y; a.ll = ll; a.fm = fm; a.fP = fP; a.pm = nullptr; a.pP = nullptr; a.sm = sm; a.sP = sP; a.status = status;
-  if (wave8_shape(mdl) && o->solver == CDKF_SOLVER_DOPRI5) {  // state_dim <= 8: both passes on the wavefront-per-trajectory kernels
+  if (wave8_shape(mdl) && o->solver == CDKF_SOLVER_DOPRI5 && !o->adaptive) {  // state_dim <= 8: both passes on the wavefront-per-trajectory kernels
     rc = launch_wave8<R>(a, stream);
     if (!rc)
       rc = (mdl->drift_kind == CDKF_DRIFT_MLP_TANH) ? launch_adjoint_kernel<R, true, true>(a, nullptr, nullptr, stream)

@@ -342,5 +342,39 @@ def test_workgroup_kernels_other_runge_kutta_methods(hip_lib, solver):
         assert relerr(postu.filtered_covariances, refu["filtered_covariances"]) < 1e-9
         sm = cd.cdnlgssm_smoother(P, y, t[..., None], cd.EKFHyperParams(state_order="first", diffeqsolve_settings=settings))
         assert relerr(sm.smoothed_covariances, refs["smoothed_covariances"]) < 1e-9
-    with pytest.raises(_ffi.CdkfError, match="fixed steps only"):
-        cd.cdnlgssm_filter(P, y, t[..., None], cd.EKFHyperParams(diffeqsolve_settings={"stepsize_controller": cd.PIDController(1e-3, 1e-6)}))
+
+
+@pytest.mark.parametrize("solver,ctrl", [("dopri5", dict(rtol=1e-6, atol=1e-8)), ("tsit5", dict(rtol=1e-5, atol=1e-7, pcoeff=0.3, icoeff=0.4)),
+                                          ("bosh3", dict(rtol=1e-4, atol=1e-6))])
+def test_workgroup_kernels_adaptive_steps(hip_lib, solver, ctrl):
+    """diffeqsolve_settings={'stepsize_controller': PIDController(...)} beyond the register-resident shapes: the workgroup kernels
+    form the embedded error estimate's RMS over the mean and the full covariance across the workgroup, so every thread takes the
+    same accept / reject decision.  Lorenz-96 d = 12 and d = 40 (the wavefront kernels hand adaptive solves over), an MLP at d = 5:
+    EKF, UKF and smoother against the oracle's restatement of the controller; dt0 far above what the tolerance allows."""
+    rng = np.random.default_rng(31)
+    settings = {"solver": solver, "dt0": 0.05, "stepsize_controller": cd.PIDController(**ctrl)}
+    for mdl, (N, T) in ((lorenz96_model(12, 5), (3, 8)), (mlp_model(rng, 5, 2, (9, 7)), (3, 8)), (lorenz96_model(40, 40), (2, 4))):
+        t = o.irregular_times(rng, N, T, 0.04)
+        t[:, T // 2:] += 0.15
+        y = o.simulate(mdl, t, rng)
+        P = params_from(mdl)
+        with o.use_solver(solver, adaptive=ctrl):
+            ref = o.ekf_filter(mdl, t, y, dt0=0.05, state_order="first")
+            refs = o.ekf_smoother(mdl, t, y, dt0=0.05, state_order="first")
+            refu = o.ukf_filter(mdl, t, y, dt0=0.05) if mdl.d < 40 else None
+        post = cd.cdnlgssm_filter(P, y, t[..., None], cd.EKFHyperParams(state_order="first", diffeqsolve_settings=settings))
+        assert _ffi.lib().cdkf_last_kernel().decode().startswith("ekf_filter_wg_kernel")
+        for k in FILTER_KEYS:
+            assert relerr(getattr(post, k), ref[k]) < 1e-9, k
+        np.testing.assert_allclose(post.marginal_loglik, ref["marginal_loglik"], rtol=1e-9)
+        sm = cd.cdnlgssm_smoother(P, y, t[..., None], cd.EKFHyperParams(state_order="first", diffeqsolve_settings=settings))
+        assert relerr(sm.smoothed_covariances, refs["smoothed_covariances"]) < 1e-8
+        if refu is not None:
+            postu = cd.cdnlgssm_filter(P, y, t[..., None], cd.UKFHyperParams(diffeqsolve_settings=settings))
+            assert relerr(postu.filtered_covariances, refu["filtered_covariances"]) < 1e-8
+    # a step budget that cannot be met raises the MAX_STEPS status
+    from cd_dynamax_amd import models
+    mb = models._model_block(P)
+    op = models._opts(cd.EKFHyperParams(diffeqsolve_settings=dict(settings, max_steps=2)), 1)
+    _, _, status = _ffi.run_host("ekf_filter", mb, op, t, y, [False] * 4, np.float64)
+    assert (status & 4).any()
