@@ -639,12 +639,14 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
   constexpr int KPo = AdjOff::B, YPo = AdjOff::B + 6 * 64, KMo = AdjOff::km, YMo = AdjOff::ym;
   static_assert(AdjOff::B + 12 * 64 == AdjOff::x, "twelve contiguous tiles B .. XP");
   const int l8 = lane & 7;
+  // (the tableau of the step is the one the forward sweep used: a.rk, opts.solver -- fixed steps; nst stages)
+  const int nst = SMOOTH ? 6 : a.rk.stages;
   auto stage_val = [&](int sg, R mj, R Pij, R dt, R& xm, R& Pst) __attribute__((always_inline)) {
     R sm_ = 0, sp_ = 0;
 #pragma unroll
     for (int jj = 0; jj < 5; ++jj)
       if (jj < sg) {  // uniform
-        const R c = TB::a[sg][jj];
+        const R c = a.rk.a[sg][jj];
         sp_ = rfma(c, W[KPo + 64 * jj + lane], sp_);
         sm_ = rfma(c, W[KMo + 8 * jj + l8], sm_);
       }
@@ -653,7 +655,7 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
   };
   auto stages_fwd = [&](R mj, R Pij, R dt) __attribute__((always_inline)) {
 #pragma unroll 1
-    for (int sg = 0; sg < 6; ++sg) {
+    for (int sg = 0; sg < nst; ++sg) {
       R xm, Pst, kM = 0, kP = 0;
       stage_val(sg, mj, Pij, dt, xm, Pst);
       rhs_fwd(xm, Pst, kM, kP);
@@ -661,29 +663,34 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
       if (lane < 8) W[KMo + 8 * sg + lane] = kM;
     }
   };
-  // one Dormand-Prince step forward (as the filter takes it)
-  auto step_fwd = [&](R& mj, R& Pij, R dt) __attribute__((always_inline)) {
-    stages_fwd(mj, Pij, dt);
+  // y + dt sum_s b_s k_s from the slopes in the tiles
+  auto step_end = [&](R& mj, R& Pij, R dt) __attribute__((always_inline)) {
     R sm_ = 0, sp_ = 0;
 #pragma unroll
-    for (int sg = 0; sg < 6; ++sg) {
-      sm_ = rfma(TB::b[sg], W[KMo + 8 * sg + l8], sm_);
-      sp_ = rfma(TB::b[sg], W[KPo + 64 * sg + lane], sp_);
-    }
+    for (int sg = 0; sg < 6; ++sg)
+      if (sg < nst) {  // uniform (the tiles of stages the method does not have hold stale values)
+        sm_ = rfma(a.rk.b[sg], W[KMo + 8 * sg + l8], sm_);
+        sp_ = rfma(a.rk.b[sg], W[KPo + 64 * sg + lane], sp_);
+      }
     mj = rfma(dt, sm_, mj);
     Pij = rfma(dt, sp_, Pij);
   };
+  // one Runge-Kutta step forward (as the filter takes it)
+  auto step_fwd = [&](R& mj, R& Pij, R dt) __attribute__((always_inline)) {
+    stages_fwd(mj, Pij, dt);
+    step_end(mj, Pij, dt);
+  };
   // ... and its adjoint: (mb, Pb) cotangent of the step's result -> cotangent of its start; dtheta accumulated
-  // (slopes: the step's six slopes are already in the tiles -- read back from the forward sweep's checkpoints)
+  // (slopes: the step's slopes are already in the tiles -- read back from the forward sweep's checkpoints)
   auto step_adj = [&](R mj, R Pij, R dt, R& mb, R& Pb, bool slopes) __attribute__((always_inline)) {
     if (!slopes) stages_fwd(mj, Pij, dt);
 #pragma unroll 1
-    for (int sg = 5; sg >= 0; --sg) {
-      R lm_ = TB::b[sg] * mb, lp = TB::b[sg] * Pb;
+    for (int sg = nst - 1; sg >= 0; --sg) {
+      R lm_ = a.rk.b[sg] * mb, lp = a.rk.b[sg] * Pb;
 #pragma unroll
       for (int r = 5; r > 0; --r)
-        if (r > sg) {  // uniform
-          const R c = TB::a[r][sg];
+        if (r > sg && r < nst) {  // uniform
+          const R c = a.rk.a[r][sg];
           lm_ = rfma(c, W[YMo + 8 * r + l8], lm_);
           lp = rfma(c, W[YPo + 64 * r + lane], lp);
         }
@@ -694,10 +701,11 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
       if (lane < 8) W[YMo + 8 * sg + lane] = yM;
     }
 #pragma unroll
-    for (int sg = 0; sg < 6; ++sg) {
-      if (lane < 8) mb += W[YMo + 8 * sg + lane];
-      Pb += W[YPo + 64 * sg + lane];
-    }
+    for (int sg = 0; sg < 6; ++sg)
+      if (sg < nst) {
+        if (lane < 8) mb += W[YMo + 8 * sg + lane];
+        Pb += W[YPo + 64 * sg + lane];
+      }
   };
 
   // ---- SMOOTH: EKF (RTS) smoother backward sweep for state_dim <= 8 (inference_ekf.py:363-448, 503-531) -------------------
@@ -1041,14 +1049,7 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
         if (s + 1 < ce) {
           if (have) {
             load_slopes(s);
-            R sm_ = 0, sp_ = 0;
-#pragma unroll
-            for (int sg = 0; sg < 6; ++sg) {
-              sm_ = rfma(TB::b[sg], W[KMo + 8 * sg + l8], sm_);
-              sp_ = rfma(TB::b[sg], W[KPo + 64 * sg + lane], sp_);
-            }
-            mj = rfma(dt, sm_, mj);
-            Pij = rfma(dt, sp_, Pij);
+            step_end(mj, Pij, dt);
           } else {
             step_fwd(mj, Pij, dt);
           }

@@ -337,7 +337,7 @@ static int workspace_reserve(AdjWorkspace& ws, size_t bytes, hipStream_t stream)
 }
 
 bool adjoint_shape_available(const cdkf_model* mdl, const cdkf_opts* o) {
-  if (o->solver != CDKF_SOLVER_DOPRI5 || o->adaptive) return false;
+  if (o->adaptive) return false;  // (the reverse of an adaptive solve needs the accepted step sizes: not kept)
   if (!wave8_shape(mdl) || !wg_shape_available(mdl, 8) || o->num_iter != 1 || o->forecast) return false;
   if (o->state_order == CDKF_ORDER_ZEROTH) return false;
   return true;
@@ -374,9 +374,10 @@ int launch_ekf_grad_adjoint(const cdkf_model* mdl, const cdkf_opts* o, int64_t N
   R* w = (R*)ws.p;
   a.t = t; a.y = y; a.ll = ll; a.status = status;
   a.fm = w; a.fP = w + nm; a.pm = w + nm + nP; a.pP = w + 2 * nm + nP;
-  a.ck = nck ? w + 2 * (nm + nP) : nullptr;
-  a.ck_smax = nck ? smax : 0;
-  rc = launch_wave8<R>(a, stream);
+  const bool dp5 = o->solver == CDKF_SOLVER_DOPRI5;  // other methods: forward pass on the workgroup kernel (run-time tableau), no slopes kept
+  a.ck = (nck && dp5) ? w + 2 * (nm + nP) : nullptr;
+  a.ck_smax = (nck && dp5) ? smax : 0;
+  rc = dp5 ? launch_wave8<R>(a, stream) : launch_wg_dispatch<R>(a, mdl, false, stream);
   if (!rc)
     rc = (mdl->drift_kind == CDKF_DRIFT_MLP_TANH) ? launch_adjoint_kernel<R, true>(a, grad, grad_model, stream)
                                                    : launch_adjoint_kernel<R, false>(a, grad, grad_model, stream);

@@ -1125,6 +1125,10 @@ def ekf_loglik_grad_adjoint(mdl: Model, t, y, dt0=0.01, dt_final=1e-10, max_step
     f = lambda x: drift.f(x[None])[0]
     jac = lambda x: drift.jac(x[None])[0]
 
+    _A, _B = TABLEAUS[_ACTIVE[-1][0]]  # the Runge-Kutta method of the enclosing use_solver (fixed steps)
+    _DP_A, _DP_B, NST = [list(r) for r in _A], list(_B), len(_B)
+    if _ACTIVE[-1][1] is not None:
+        raise NotImplementedError("reverse sweep: fixed steps only")
     second = state_order == "second"
     assert state_order in ("first", "second")
     divgrad = lambda x: drift.divgrad(x[None])[0]
@@ -1136,7 +1140,7 @@ def ekf_loglik_grad_adjoint(mdl: Model, t, y, dt0=0.01, dt_final=1e-10, max_step
 
     def stages(x, P, dt):
         ks = []
-        for i in range(6):
+        for i in range(NST):
             xs = x + dt * sum((_DP_A[i][j] * ks[j][0] for j in range(i)), np.zeros(d))
             Ps = P + dt * sum((_DP_A[i][j] * ks[j][1] for j in range(i)), np.zeros((d, d)))
             ks.append(rhs(xs, Ps))
@@ -1169,8 +1173,8 @@ def ekf_loglik_grad_adjoint(mdl: Model, t, y, dt0=0.01, dt_final=1e-10, max_step
                 x, P = mf[k], Pf[k]
                 for dt in _step_sizes(tn[k], tn[k + 1], dt0, 1e-10, max_steps):
                     ks = stages(x, P, dt)
-                    x = x + dt * sum(_DP_B[i] * ks[i][0] for i in range(6))
-                    P = P + dt * sum(_DP_B[i] * ks[i][1] for i in range(6))
+                    x = x + dt * sum(_DP_B[i] * ks[i][0] for i in range(NST))
+                    P = P + dt * sum(_DP_B[i] * ks[i][1] for i in range(NST))
                 mp.append(x)
                 Pp.append(P)
         # ---- backward sweep ----
@@ -1205,14 +1209,14 @@ def ekf_loglik_grad_adjoint(mdl: Model, t, y, dt0=0.01, dt_final=1e-10, max_step
             for dt in dts[:-1]:
                 x, P = starts[-1]
                 ks = stages(x, P, dt)
-                starts.append((x + dt * sum(_DP_B[i] * ks[i][0] for i in range(6)),
-                               P + dt * sum(_DP_B[i] * ks[i][1] for i in range(6))))
+                starts.append((x + dt * sum(_DP_B[i] * ks[i][0] for i in range(NST)),
+                               P + dt * sum(_DP_B[i] * ks[i][1] for i in range(NST))))
             for (x, P), dt in zip(reversed(starts), reversed(dts)):
                 ks = stages(x, P, dt)
-                Yb = [None] * 6
-                for i in range(5, -1, -1):
-                    lam = dt * (_DP_B[i] * mb + sum((_DP_A[j][i] * Yb[j][0] for j in range(i + 1, 6)), np.zeros(d)))
-                    Lam = dt * (_DP_B[i] * Pb + sum((_DP_A[j][i] * Yb[j][1] for j in range(i + 1, 6)), np.zeros((d, d))))
+                Yb = [None] * NST
+                for i in range(NST - 1, -1, -1):
+                    lam = dt * (_DP_B[i] * mb + sum((_DP_A[j][i] * Yb[j][0] for j in range(i + 1, NST)), np.zeros(d)))
+                    Lam = dt * (_DP_B[i] * Pb + sum((_DP_A[j][i] * Yb[j][1] for j in range(i + 1, NST)), np.zeros((d, d))))
                     Lam = sym(Lam)
                     xs, Ps = stage_in(x, P, dt, ks, i)
                     F = jac(xs)
@@ -1225,8 +1229,8 @@ def ekf_loglik_grad_adjoint(mdl: Model, t, y, dt0=0.01, dt_final=1e-10, max_step
                     thb += tb
                     extra["LQL"][n] += Lam
                     Yb[i] = (xb, Pbar)
-                mb = mb + sum(Yb[i][0] for i in range(6))
-                Pb = sym(Pb + sum(Yb[i][1] for i in range(6)))
+                mb = mb + sum(Yb[i][0] for i in range(NST))
+                Pb = sym(Pb + sum(Yb[i][1] for i in range(NST)))
         ll_out[n] = ll
         g_out[n] = thb
     if not full:

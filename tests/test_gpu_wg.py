@@ -258,6 +258,33 @@ def test_reverse_sweep_slope_checkpoints_do_not_change_the_gradient(hip_lib, mon
     assert np.abs(out["2"] - g_ref).max() < 1e-8 * scale
 
 
+@pytest.mark.parametrize("solver", ["tsit5", "bosh3", "euler"])
+def test_reverse_sweep_other_runge_kutta_methods(hip_lib, solver):
+    """cdnlgssm_loglik_and_grad[_all] with diffeqsolve_settings={'solver': ...}: the reverse sweep reads the tableau the forward sweep
+    (the workgroup kernel for non-default methods) integrated with -- MLP d = 5 (both state orders) and Lorenz-96 d = 6."""
+    rng = np.random.default_rng(41)
+    settings = {"solver": solver}
+    for mdl, orders in ((mlp_model(rng, 5, 2, (9, 7)), ("first", "second")), (lorenz96_model(6, 3), ("second",))):
+        N, T = 4, 9
+        t = o.irregular_times(rng, N, T, 0.025)
+        t[:, 5:] += 0.06
+        y = o.simulate(mdl, t, rng)
+        P = params_from(mdl)
+        for order in orders:
+            with o.use_solver(solver):
+                ll_ref, g_ref, ex = o.ekf_loglik_grad_adjoint(mdl, t, y, full=True, state_order=order)
+            hyp = cd.EKFHyperParams(state_order=order, diffeqsolve_settings=settings)
+            ll, g = cd.cdnlgssm_loglik_and_grad_all(P, y, t[..., None], hyp)
+            np.testing.assert_allclose(ll, ll_ref, rtol=1e-10)
+            flat = np.concatenate([np.asarray(a_).reshape(N, -1) for a_ in g.dynamics.drift], axis=-1)
+            scale = np.abs(g_ref).max()
+            assert np.abs(flat - g_ref).max() < 1e-8 * scale, (order, np.abs(flat - g_ref).max() / scale)
+            assert np.abs(np.asarray(g.emissions.emission_cov.params) - ex["R"]).max() < 1e-8 * np.abs(ex["R"]).max()
+    with pytest.raises(NotImplementedError, match="no gradient kernel"):  # adaptive steps: the reverse sweep would need the accepted sizes
+        cd.cdnlgssm_loglik_and_grad(P, y, t[..., None], cd.EKFHyperParams(
+            diffeqsolve_settings={"stepsize_controller": cd.PIDController(1e-4, 1e-6)}))
+
+
 def _general_model(rng, drift, d, m):
     """Non-diagonal L, Qc, R, P0, a dense H with bias: every parameter of the model carries a non-trivial gradient."""
     A, B, C = rng.standard_normal((d, d)), rng.standard_normal((m, m)), rng.standard_normal((d, d))

@@ -336,6 +336,27 @@ def test_adjoint_gradient_second_order_matches_finite_differences():
         assert np.abs(fd - an).max() < 2e-5 * np.abs(fd).max(), name
 
 
+@pytest.mark.parametrize("solver", ["tsit5", "bosh3", "heun"])
+def test_adjoint_gradient_other_runge_kutta_methods_matches_finite_differences(solver):
+    """The reverse sweep under another fixed-step method (use_solver): its discrete adjoint is that method's, stage count included."""
+    from helpers import mlp_model
+    rng = np.random.default_rng(12)
+    mdl = mlp_model(rng, 3, 2, (5, 4))
+    t = o.irregular_times(rng, 2, 6, 0.03)
+    y = o.simulate(mdl, t, rng)
+    th0 = mdl.drift.theta()
+    with o.use_solver(solver):
+        for order in ("first", "second"):
+            ll, g = o.ekf_loglik_grad_adjoint(mdl, t, y, state_order=order)
+            np.testing.assert_allclose(ll, o.ekf_filter(mdl, t, y, state_order=order)["marginal_loglik"], rtol=1e-12)
+            u = rng.standard_normal(th0.size)
+            u /= np.linalg.norm(u)
+            h = 1e-5
+            fd = (o.ekf_filter(_rebuild_drift(mdl, th0 + h * u), t, y, state_order=order)["marginal_loglik"]
+                  - o.ekf_filter(_rebuild_drift(mdl, th0 - h * u), t, y, state_order=order)["marginal_loglik"]) / (2 * h)
+            np.testing.assert_allclose(g @ u, fd, rtol=1e-5, atol=1e-8)
+
+
 def test_adjoint_gradient_all_parameters_matches_finite_differences():
     """full=True: gradients w.r.t. m0, P0, L, Qc, H, bias, R (general, non-diagonal values) along random directions."""
     from helpers import mlp_model
