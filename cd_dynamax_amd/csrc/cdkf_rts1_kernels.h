@@ -55,37 +55,76 @@ __global__ __launch_bounds__(64 * kRts1Waves) void pushforward_wave8_kernel(cons
     kQ = (fq + W[Rts1Off::T0 + j * 8 + i]) + lql;
     wave_sync();
   };
-  using TB = Dp5T<R>;
+  // the Runge-Kutta method of opts.solver (a.rk, run-time tableau in the kernel arguments; static stage indices after unrolling),
+  // fixed steps of dt0 or diffrax.PIDController around the embedded pair -- the error norm then runs over the (A, Q) pytree
+  const RkTab<R>& tb = a.rk;
   auto stage_in = [&](int si, R y0, const R (&ks)[6], R dt) {
     R s = 0;
 #pragma unroll
     for (int jj = 0; jj < 5; ++jj)
-      if (jj < si) s = rfma(TB::a[si][jj], ks[jj], s);
+      if (jj < si) s = rfma(tb.a[si][jj], ks[jj], s);
     return rfma(dt, s, y0);
   };
   const R* tp = a.t + n * a.t_sn;
   const R t0 = tp[k * a.t_sk], t1 = tp[(k + 1) * a.t_sk];
   R Aij = (in && i == j) ? R(1) : R(0), Qij = 0;
   R tprev = t0, tnext = rmin(t0 + a.dt0, t1);
+  R inv1 = R(1), inv2 = R(1);
   long steps = 0;
   while (tprev < t1 && steps < a.max_steps) {
     const R dt = tnext - tprev;
     R kA[6] = {0, 0, 0, 0, 0, 0}, kQ[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (int s = 0; s < 6; ++s) rhs(stage_in(s, Aij, kA, dt), stage_in(s, Qij, kQ, dt), kA[s], kQ[s]);
+    for (int s = 0; s < 6; ++s)
+      if (s < tb.stages) rhs(stage_in(s, Aij, kA, dt), stage_in(s, Qij, kQ, dt), kA[s], kQ[s]);  // uniform
     R sa = 0, sq = 0;
 #pragma unroll
     for (int s = 0; s < 6; ++s) {
-      sa = rfma(TB::b[s], kA[s], sa);
-      sq = rfma(TB::b[s], kQ[s], sq);
+      sa = rfma(tb.b[s], kA[s], sa);
+      sq = rfma(tb.b[s], kQ[s], sq);
     }
-    Aij = rfma(dt, sa, Aij);
-    Qij = rfma(dt, sq, Qij);
-    tprev = rmin(tnext, t1);
-    const R tn = tnext + a.dt0;
-    tnext = (tn > t1 - Tol<R>::v) ? t1 : tn;
+    const R An = rfma(dt, sa, Aij), Qn = rfma(dt, sq, Qij);
+    if (!tb.adaptive) {
+      Aij = An;
+      Qij = Qn;
+      tprev = rmin(tnext, t1);
+      const R tn = tnext + a.dt0;
+      tnext = (tn > t1 - Tol<R>::v) ? t1 : tn;
+    } else {  // integrate_adaptive (cdkf_math.h), the RMS over the 2 d^2 entries this wavefront holds
+      R k7A = 0, k7Q = 0;
+      if (tb.fsal) rhs(An, Qn, k7A, k7Q);
+      R eA = tb.berr[6] * k7A, eQ = tb.berr[6] * k7Q;
+#pragma unroll
+      for (int s = 0; s < 6; ++s) {
+        eA = rfma(tb.berr[s], kA[s], eA);
+        eQ = rfma(tb.berr[s], kQ[s], eQ);
+      }
+      const R sA = (dt * eA) / rfma(rmax(rabs(Aij), rabs(An)), tb.rtol, tb.atol);
+      const R sQ = (dt * eQ) / rfma(rmax(rabs(Qij), rabs(Qn)), tb.rtol, tb.atol);
+      double ssum = in ? (double)(sA * sA) + (double)(sQ * sQ) : 0.0;
+#pragma unroll
+      for (int o_ = 32; o_ >= 1; o_ >>= 1) ssum += __shfl_xor(ssum, o_);
+      const R scaled = rsqrt_((R)ssum / R(2 * d * d));
+      const bool keep = scaled < R(1);
+      const R inv = (scaled == R(0)) ? R(__builtin_huge_val()) : R(1) / scaled;
+      R factor = R(0.9) * rpow(inv, tb.c1);
+      if (tb.c2 != R(0)) factor *= rpow(inv1, tb.c2);
+      if (tb.c3 != R(0)) factor *= rpow(inv2, tb.c3);
+      factor = rmin(rmax(factor, keep ? R(1) : R(0.2)), R(10));
+      const R nt0 = keep ? tnext : tprev;
+      const R nt1 = nt0 + dt * factor;
+      if (keep) {
+        Aij = An;
+        Qij = Qn;
+        inv2 = inv1;
+        inv1 = inv;
+      }
+      tprev = rmin(nt0, t1);
+      tnext = (nt1 > t1 - Tol<R>::v) ? (keep ? t1 : rfma(R(0.5), t1 - tprev, tprev)) : nt1;
+    }
     ++steps;
   }
+  if (tprev < t1 && a.status) atomicOr(&a.status[n], kStatusMaxSteps);
   if (in) {
     R* o = AQ + item * 2 * d * d;
     o[i * d + j] = Aij;

@@ -403,10 +403,6 @@ bool smoother1_shape_available(const cdkf_model* mdl) {
 template <typename R>
 int launch_kf_smoother1(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll,
                         R* fm, R* fP, R* sm, R* sP, R* cross, int32_t* status, hipStream_t stream) {
-  if (o->solver != CDKF_SOLVER_DOPRI5 || o->adaptive) {
-    set_error("kf_smoother1: the pushed-forward (A, Q) are integrated with fixed-step Dormand-Prince only");
-    return CDKF_EUNSUPPORTED;
-  }
   if (!smoother1_shape_available(mdl)) {
     set_error("kf_smoother1: needs a linear drift with zero bias and state_dim <= 8 (got drift_kind=%d state_dim=%d)",
               mdl->drift_kind, mdl->state_dim);

@@ -119,13 +119,13 @@ typedef struct cdkf_opts {
   int32_t solver;       /* CDKF_SOLVER_*: the explicit Runge-Kutta method of the predict step, fixed steps of dt0 (the
                            reference forwards diffeqsolve_settings['solver'] to diffrax, src/utils/diffrax_utils.py:40-57).
                            Default DOPRI5 (diffrax_utils.py:120-123).  The other methods run on the register-resident and the
-                           workgroup kernels (incl. custom drifts) and through both gradient paths; the type-1 smoother takes
-                           DOPRI5 only. */
+                           workgroup kernels (incl. custom drifts), through both gradient paths and in the type-1 smoother. */
   int32_t adaptive;     /* 0 (default): fixed steps of dt0 (diffrax.ConstantStepSize).  1: diffrax.PIDController(rtol, atol, pcoeff,
                            icoeff, dcoeff) around the method's embedded error estimate (DOPRI5, TSIT5, BOSH3, HEUN), first step
                            dt0, every trajectory adapting on its own; max_steps then counts accepted and rejected steps.
                            Filters and smoothers of every shape (larger models on the workgroup kernels) and custom drifts;
-                           the reverse-sweep gradient (any method) and the type-1 smoother (DOPRI5) take fixed steps only. */
+                           the type-1 smoother's pushed-forward (A, Q) adapt as well; the reverse-sweep gradient (any method) takes fixed
+                           steps only. */
   int64_t max_steps;    /* RK steps per observation interval; default 100000 */
   double dt0;           /* default 0.01 */
   double dt_final;      /* default 1e-10 (inference_ekf.py:39) */

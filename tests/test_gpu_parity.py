@@ -654,6 +654,36 @@ def test_linear_smoother_type1(hip_lib, d, m):
     assert p32.smoothed_means.dtype == np.float32 and relerr(p32.smoothed_means, ref1["smoothed_means"][0]) < 2e-3
 
 
+@pytest.mark.parametrize("d,m,solver,ctrl", [(3, 2, "tsit5", None), (6, 3, "bosh3", None), (3, 2, "dopri5", dict(rtol=1e-6, atol=1e-8)),
+                                             (6, 3, "tsit5", dict(rtol=1e-5, atol=1e-7))])
+def test_linear_smoother_type1_solver_settings(hip_lib, d, m, solver, ctrl):
+    """cd_smoother_1 with diffeqsolve_settings: the pushed-forward (A, Q) integrate with the chosen method, with fixed steps or
+    under diffrax.PIDController (error norm over the (A, Q) pytree), the forward pass likewise -- against the oracle under use_solver."""
+    rng = np.random.default_rng(70 + d)
+    base = linear_model(rng, d, m)
+    mdl = o.Model(o.LinearDrift(base.drift.W, np.zeros(d)), base.L, base.Qc, base.H, base.bias, base.R, base.m0, base.P0)
+    N, T = 4, 12
+    t = o.irregular_times(rng, N, T, 0.3)
+    t[:, 6:] += 0.2
+    y = o.simulate(mdl, t, rng)
+    model = cd.ContDiscreteLinearGaussianSSM(state_dim=d, emission_dim=m, has_emissions_bias=True)
+    pp = cd.ParameterProperties()
+    params, _ = model.initialize(
+        initial_mean={"params": mdl.m0, "props": pp}, initial_cov={"params": mdl.P0, "props": pp},
+        dynamics_weights={"params": mdl.drift.W, "props": pp}, dynamics_diffusion_coefficient={"params": mdl.L, "props": pp},
+        dynamics_diffusion_cov={"params": mdl.Qc, "props": pp}, emission_weights={"params": mdl.H, "props": pp},
+        emission_bias={"params": mdl.bias, "props": pp}, emission_cov={"params": mdl.R, "props": pp})
+    settings = {"solver": solver, "dt0": 0.05}
+    if ctrl is not None:
+        settings["stepsize_controller"] = cd.PIDController(**ctrl)
+    with o.use_solver(solver, adaptive=ctrl):
+        ref = o.kf_smoother_type1(mdl, t, y, dt0=0.05)
+    post = model.smoother(params, y, t[..., None], filter_hyperparams=cd.KFHyperParams(diffeqsolve_settings=settings))
+    for k in ("filtered_covariances", "smoothed_means", "smoothed_covariances", "smoothed_cross_covariances"):
+        assert relerr(getattr(post, k), ref[k]) < 1e-9, k
+    np.testing.assert_allclose(post.marginal_loglik, ref["marginal_loglik"], rtol=1e-10)
+
+
 def test_linear_smoother_type1_refusals(hip_lib):
     rng = np.random.default_rng(3)
     mdl = linear_model(rng, 12, 3)
