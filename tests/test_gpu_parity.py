@@ -750,8 +750,15 @@ def test_solver_choice_refusals(hip_lib):
         cd.cdnlgssm_filter(params_from(mdl), y, t[..., None], cd.EKFHyperParams(diffeqsolve_settings={"stepsize_controller": object()}))
     l63 = o.lorenz63_model(3)
     y3 = o.simulate(l63, t, rng)
-    with pytest.raises(NotImplementedError, match="no reverse-sweep kernel"):   # the all-parameter sweep is fixed-step Dopri5 only
-        cd.cdnlgssm_loglik_and_grad_all(params_from(l63), y3, t[..., None], cd.EKFHyperParams(diffeqsolve_settings={"solver": "heun"}))
+    with pytest.raises(NotImplementedError, match="no reverse-sweep kernel"):   # the all-parameter sweep takes fixed steps only
+        cd.cdnlgssm_loglik_and_grad_all(params_from(l63), y3, t[..., None], cd.EKFHyperParams(
+            diffeqsolve_settings={"solver": "heun", "stepsize_controller": cd.PIDController(1e-3, 1e-6)}))
+    with o.use_solver("heun"):                                                  # ... with any of the methods
+        ll_ref, g_ref = o.ekf_loglik_grad_adjoint(l63, t, y3)
+    ll, g = cd.cdnlgssm_loglik_and_grad_all(params_from(l63), y3, t[..., None], cd.EKFHyperParams(diffeqsolve_settings={"solver": "heun"}))
+    np.testing.assert_allclose(ll, ll_ref, rtol=1e-10)
+    flat = np.concatenate([np.asarray(a).reshape(2, -1) for a in g.dynamics.drift], axis=-1)
+    assert np.abs(flat - g_ref).max() < 1e-8 * np.abs(g_ref).max()
 
 
 @pytest.mark.parametrize("solver,ctrl", [("tsit5", dict(rtol=1e-6, atol=1e-8)), ("dopri5", dict(rtol=1e-5, atol=1e-7, pcoeff=0.1, icoeff=0.3)),
@@ -835,10 +842,12 @@ def test_adaptive_refusals(hip_lib):
     pid = cd.PIDController(1e-3, 1e-6)
     with pytest.raises(NotImplementedError, match="embedded error estimate"):
         cd.cdnlgssm_filter(params_from(l63), y, t[..., None], cd.EKFHyperParams(diffeqsolve_settings={"solver": "euler", "stepsize_controller": pid}))
-    mdl = lorenz96_model(8, 4)
+    mdl = lorenz96_model(8, 4)   # beyond the register-resident shapes: the workgroup kernels adapt too (tests/test_gpu_wg.py)
     y8 = o.simulate(mdl, t, rng)
-    with pytest.raises(_ffi.CdkfError, match="fixed steps only"):
-        cd.cdnlgssm_filter(params_from(mdl), y8, t[..., None], cd.EKFHyperParams(diffeqsolve_settings={"stepsize_controller": pid}))
+    with o.use_solver("dopri5", adaptive=dict(rtol=1e-3, atol=1e-6)):
+        ref8 = o.ekf_filter(mdl, t, y8)
+    post8 = cd.cdnlgssm_filter(params_from(mdl), y8, t[..., None], cd.EKFHyperParams(diffeqsolve_settings={"stepsize_controller": pid}))
+    assert relerr(post8.filtered_covariances, ref8["filtered_covariances"]) < 1e-9
     assert cd.cdnlgssm_filter(params_from(l63), y, t[..., None], cd.EKFHyperParams(
         diffeqsolve_settings={"stepsize_controller": cd.ConstantStepSize(), "tol_vbt": 1e-5})).filtered_means.shape == (2, 5, 3)
 
