@@ -101,7 +101,7 @@ SYMBOLS = (
      "cdkf_emission_moments_f32_dev", "cdkf_ekf_loglik_grad_f64", "cdkf_ekf_loglik_grad_f32",
      "cdkf_ekf_loglik_grad_f64_dev", "cdkf_ekf_loglik_grad_f32_dev", "cdkf_custom_drift_register", "cdkf_custom_drift_compile", "cdkf_custom_emission_register", "cdkf_set_kernel_source_dir",
      "cdkf_kf_smoother1_f64", "cdkf_kf_smoother1_f32", "cdkf_kf_smoother1_f64_dev", "cdkf_kf_smoother1_f32_dev",
-     "cdkf_kf_smoother1_supported", "cdkf_grad_supported", "cdkf_grad_all_supported", "cdkf_ekf_loglik_grad_all_f64",
+     "cdkf_kf_smoother1_supported", "cdkf_kf_pushforward_f64", "cdkf_kf_pushforward_f32", "cdkf_grad_supported", "cdkf_grad_all_supported", "cdkf_ekf_loglik_grad_all_f64",
      "cdkf_ekf_loglik_grad_all_f32", "cdkf_ekf_loglik_grad_all_f64_dev", "cdkf_ekf_loglik_grad_all_f32_dev", "cdkf_grad_sum_f64_dev",
      "cdkf_grad_sum_f32_dev", "cdkf_comm_unique_id", "cdkf_comm_init_rank", "cdkf_comm_init_all", "cdkf_comm_rank", "cdkf_comm_world",
      "cdkf_ll_allreduce", "cdkf_comm_allreduce_max", "cdkf_ll_allreduce_all", "cdkf_comm_destroy", "cdkf_rdv_create",
@@ -196,6 +196,10 @@ def lib() -> C.CDLL:
     L.cdkf_set_kernel_source_dir(os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc").encode())
     L.cdkf_kf_smoother1_supported.argtypes = [C.POINTER(CdkfModel)]
     L.cdkf_kf_smoother1_supported.restype = C.c_int
+    for p in ("f64", "f32"):
+        f = getattr(L, f"cdkf_kf_pushforward_{p}")
+        f.argtypes = [C.POINTER(CdkfModel), C.POINTER(CdkfOpts), C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
+        f.restype = C.c_int
     for p in ("f64", "f32"):
         base = [C.POINTER(CdkfModel), C.POINTER(CdkfOpts), C.c_int64, C.c_int64] + [C.c_void_p] * 9
         f = getattr(L, f"cdkf_kf_smoother1_{p}")
@@ -403,6 +407,20 @@ def kf_smoother1(mdl: ModelBlock, opts: CdkfOpts, t: np.ndarray, y: np.ndarray, 
              _vp(status)))
     sw = lambda a: np.swapaxes(a, 0, 1)
     return ll, sw(fm), sw(fP), sw(sm), sw(sP), sw(cr)[:, :T - 1], status
+
+
+def kf_pushforward(mdl: ModelBlock, opts: CdkfOpts, t: np.ndarray, dtype):
+    """cdkf_kf_pushforward_<f32|f64>: the pushed-forward (A, Q) of every observation interval, each [N, T-1, d, d]; t [N,T]."""
+    dtype = np.dtype(dtype)
+    suffix = {np.dtype(np.float32): "f32", np.dtype(np.float64): "f64"}[dtype]
+    t = np.ascontiguousarray(t, dtype=dtype)
+    N, T = t.shape
+    d = mdl.state_dim
+    opts.layout_in = LAYOUT_NT
+    opts.t_shared = 0
+    AQ = np.zeros((N, max(T - 1, 0), 2, d, d), dtype)
+    check(getattr(lib(), f"cdkf_kf_pushforward_{suffix}")(C.byref(mdl.c), C.byref(opts), N, T, _vp(t), _vp(AQ)))
+    return AQ[:, :, 0], AQ[:, :, 1]
 
 
 def model_grad_size(d: int, m: int) -> int:

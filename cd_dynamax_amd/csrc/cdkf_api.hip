@@ -301,6 +301,30 @@ int kf_smoother1_host(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int6
   return CDKF_OK;
 }
 
+// ---- linear model: the pushed-forward (A, Q) of every observation interval ------------------------------------------------
+template <typename R>
+int kf_pushforward_host(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, R* AQ) {
+  R dummy = 0;
+  int rc = check_common(mdl, o, N, T, t, &dummy, &dummy);
+  if (rc) return rc;
+  if (!AQ) {
+    set_error("kf_pushforward: the output array must not be NULL");
+    return CDKF_EINVAL;
+  }
+  if (N == 0 || T < 2) return CDKF_OK;
+  CDKF_SELECT_DEVICE(o);
+  const size_t d = mdl->state_dim, nt = (size_t)(o->t_shared ? T : N * T), nA = (size_t)N * (size_t)(T - 1) * 2 * d * d;
+  DevBuf dt, dA, dst;
+  if ((rc = dt.alloc(nt * sizeof(R))) || (rc = dA.alloc(nA * sizeof(R))) || (rc = dst.alloc(N * sizeof(int32_t)))) return rc;
+  CDKF_HIP_CHECK(hipMemcpy(dt.p, t, nt * sizeof(R), hipMemcpyHostToDevice));
+  CDKF_HIP_CHECK(hipMemset(dst.p, 0, N * sizeof(int32_t)));
+  rc = launch_kf_pushforward<R>(mdl, o, N, T, (const R*)dt.p, (R*)dA.p, (int32_t*)dst.p, nullptr);
+  if (rc) return rc;
+  CDKF_HIP_CHECK(hipDeviceSynchronize());
+  CDKF_HIP_CHECK(hipMemcpy(AQ, dA.p, nA * sizeof(R), hipMemcpyDeviceToHost));
+  return CDKF_OK;
+}
+
 // ---- emission moments: one workgroup (64 threads) per state marginal, H and the d x d covariance staged in LDS ----
 template <typename R>
 __global__ __launch_bounds__(64) void emission_moments_kernel(int d, int m, const R* __restrict__ par, long rows,
@@ -641,6 +665,12 @@ int cdkf_kf_smoother1_f32_dev(const cdkf_model* mdl, const cdkf_opts* o, int64_t
   return kf_smoother1_dev<float>(mdl, o, N, T, t, y, ll, fm, fP, sm, sP, cross, status, stream);
 }
 int cdkf_kf_smoother1_supported(const cdkf_model* mdl) { return (mdl && smoother1_shape_available(mdl)) ? 1 : 0; }
+int cdkf_kf_pushforward_f64(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const double* t, double* AQ) {
+  return kf_pushforward_host<double>(mdl, o, N, T, t, AQ);
+}
+int cdkf_kf_pushforward_f32(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const float* t, float* AQ) {
+  return kf_pushforward_host<float>(mdl, o, N, T, t, AQ);
+}
 
 static int need_model_grad(const void* gm) {
   if (gm) return CDKF_OK;

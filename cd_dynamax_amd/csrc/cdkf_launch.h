@@ -49,6 +49,10 @@ template <typename R>
 int launch_kf_smoother1(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll,
                         R* fm, R* fP, R* sm, R* sP, R* cross, int32_t* status, hipStream_t stream);
 bool smoother1_shape_available(const cdkf_model* mdl);
+// the pushed-forward (A, Q) of every interval, AQ [N, T-1, 2, d, d] (same kernel, same shapes as the type-1 smoother)
+template <typename R>
+int launch_kf_pushforward(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, R* AQ, int32_t* status,
+                          hipStream_t stream);
 
 // ring of persistent parameter buffers (launch_wg.hip): device block + pinned staging + an event behind the readers
 struct ParamSlot {

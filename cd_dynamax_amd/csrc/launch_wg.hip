@@ -448,6 +448,38 @@ template int launch_kf_smoother1<float>(const cdkf_model*, const cdkf_opts*, int
 template int launch_kf_smoother1<double>(const cdkf_model*, const cdkf_opts*, int64_t, int64_t, const double*, const double*,
                                          double*, double*, double*, double*, double*, double*, int32_t*, hipStream_t);
 
+// (A, Q) of every observation interval by themselves (cdkf_kf_pushforward_*): AQ [N, T-1, 2, d, d] on the device
+template <typename R>
+int launch_kf_pushforward(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, R* AQ, int32_t* status,
+                          hipStream_t stream) {
+  if (!smoother1_shape_available(mdl)) {
+    set_error("kf_pushforward: needs a linear drift with zero bias and state_dim <= 8 (got drift_kind=%d state_dim=%d)",
+              mdl->drift_kind, mdl->state_dim);
+    return CDKF_EUNSUPPORTED;
+  }
+  if (T < 2 || N < 1) return CDKF_OK;
+  if (once_per_device([] { return wg_raise_lds_cap(pushforward_wave8_kernel<R>) | wg_raise_lds_cap(rts1_wave8_kernel<R>); }))
+    return CDKF_EHIP;
+  WgArgs<R> a{};
+  R* blk = nullptr;
+  ParamLease lease(stream);
+  int rc = wg_prepare(a, &blk, &lease.slot, mdl, o, N, T, stream);
+  if (rc) return rc;
+  a.t = t;
+  a.status = status;
+  const size_t items = (size_t)N * (size_t)(T - 1);
+  const size_t lds = sizeof(R) * (size_t)kRts1Waves * Rts1Off::end + 64;
+  note_kernel("pushforward_wave8_kernel<%s>", real_name<R>());
+  hipLaunchKernelGGL(pushforward_wave8_kernel<R>, dim3((unsigned)((items + kRts1Waves - 1) / kRts1Waves)), dim3(64 * kRts1Waves), lds,
+                     stream, a, AQ);
+  CDKF_HIP_CHECK(hipGetLastError());
+  return lease.release();
+}
+template int launch_kf_pushforward<float>(const cdkf_model*, const cdkf_opts*, int64_t, int64_t, const float*, float*, int32_t*,
+                                          hipStream_t);
+template int launch_kf_pushforward<double>(const cdkf_model*, const cdkf_opts*, int64_t, int64_t, const double*, double*, int32_t*,
+                                           hipStream_t);
+
 #define INST(R)                                                                                                        \
   template int launch_ekf_filter_wg<R>(const cdkf_model*, const cdkf_opts*, int64_t, int64_t, const R*, const R*, R*,  \
                                        R*, R*, R*, R*, int32_t*, hipStream_t);                                         \

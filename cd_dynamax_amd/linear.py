@@ -8,9 +8,13 @@ Mirrors /root/reference/src/continuous_discrete_linear_gaussian_ssm/:
   ``cdlgssm_filter`` inference.py:555-632, ``cdlgssm_smoother`` inference.py:694-800,
   ``ContDiscreteLinearGaussianSSM.{initialize, filter, smoother, marginal_log_prob}`` models.py:42-365.
 
-Differences, all refused loudly rather than approximated:
-  * dynamics bias / inputs: the reference adds ``B u + b`` to the pushed-forward mean WITHOUT integrating it
-    (inference.py ``_predict``); only ``b = 0`` and ``inputs = None`` are supported here.
+Differences (what cannot be reproduced is refused loudly rather than approximated):
+  * dynamics bias / inputs: the reference adds ``B u + b`` to the pushed-forward mean WITHOUT integrating it (inference.py
+    ``_predict``: mu = F m + B u + b) and ``D u + d`` to the emission mean.  The filter (and ``marginal_log_prob``) reproduce
+    that through offsets: with s_0 = 0, s_k+1 = A_k s_k + B u_k + b (A_k = the pushed-forward matrix of interval k, from
+    cdkf_kf_pushforward_*; state_dim <= 8) the state is x = z + s where z runs the bias-free filter on y - H s - D u, so the
+    covariances and the log-likelihood are untouched and s is added back to the means.  The smoothers take no inputs (the
+    reference's own do not either: inference.py:635 "TODO: incorporate inputs!"), and these leaves cannot be trained.
   * the moments are integrated directly (dP/dt = F P + P F^T + L Qc L^T) instead of pushing (A, Q) forward and
     forming A P A^T + Q: identical up to the O(dt0^6) difference of two 5th-order solutions (~1e-12 relative).
   * ``smoother_type='cd_smoother_2'`` (Sarkka Alg. 3.18, inference.py:636-690) is the EKF smoother of the hot path;
@@ -55,16 +59,19 @@ class ParamsCDLGSSM(NamedTuple):
     emissions: ParamsLGSSMEmissions
 
 
-def _as_nonlinear(params: ParamsCDLGSSM, inputs) -> ParamsCDNLGSSM:
-    if inputs is not None and np.asarray(inputs).size:
-        raise NotImplementedError("inputs are not supported by the HIP path (the reference adds B u un-integrated)")
+def _has_offsets(params: ParamsCDLGSSM, inputs) -> bool:
+    b = params.dynamics.bias
+    return (inputs is not None and np.asarray(inputs).size > 0) or (b is not None and bool(np.any(np.asarray(b) != 0)))
+
+
+def _as_nonlinear(params: ParamsCDLGSSM, inputs, offsets_handled: bool = False) -> ParamsCDNLGSSM:
+    if not offsets_handled and _has_offsets(params, inputs):
+        raise NotImplementedError(
+            "dynamics bias / inputs: the reference adds B u + b to the pushed-forward mean without integrating it "
+            "(continuous_discrete_linear_gaussian_ssm/inference.py, _predict); the HIP path reproduces that in cdlgssm_filter / "
+            "marginal_log_prob only (the reference's smoothers take no inputs either)")
     F = np.asarray(params.dynamics.weights, dtype=np.float64)
     d = F.shape[0]
-    b = params.dynamics.bias
-    if b is not None and np.any(np.asarray(b) != 0):
-        raise NotImplementedError(
-            "a non-zero dynamics bias is not supported: the reference adds it to the pushed-forward mean without "
-            "integrating it (continuous_discrete_linear_gaussian_ssm/inference.py, _predict)")
     H = np.asarray(params.emissions.weights, dtype=np.float64)
     hb = params.emissions.bias
     hb = np.zeros(H.shape[0]) if hb is None else np.asarray(hb, dtype=np.float64)
@@ -97,7 +104,7 @@ def _props_as_nonlinear(props: ParamsCDLGSSM, params: ParamsCDLGSSM) -> ParamsCD
             or is_on(props.emissions.input_weights, params.emissions.input_weights)):
         raise NotImplementedError(
             "fit_sgd: the dynamics bias and the input weights cannot be trained on the HIP path (the reference adds "
-            "B u + b un-integrated; only b = 0, no inputs are supported)")
+            "B u + b un-integrated; the filter reproduces that through offsets, their gradient is not formed)")
     pp = lambda p: p if isinstance(p, ParameterProperties) else frozen
     return ParamsCDNLGSSM(
         initial=ParamsLGSSMInitial(LearnableVector(pp(props.initial.mean)), LearnableMatrix(pp(props.initial.cov))),
@@ -114,9 +121,50 @@ def _hyper(filter_hyperparams: Optional[KFHyperParams]) -> EKFHyperParams:
     return EKFHyperParams(dt_final=hp.dt_final, state_order="first", diffeqsolve_settings=hp.diffeqsolve_settings)
 
 
+def _filter_with_offsets(params: ParamsCDLGSSM, emissions, t_emissions, filter_hyperparams, inputs, dtype) -> PosteriorGSSMFiltered:
+    """cdlgssm_filter with a dynamics bias and / or inputs (inference.py:596-620: u_k enters the emission at k and the predict from
+    k to k+1, both un-integrated): the bias-free filter in the offset coordinates described in the module docstring."""
+    from . import _ffi
+    from .models import _model_block, _opts, _prepare
+    nl = _as_nonlinear(params, inputs, offsets_handled=True)
+    mdl = _model_block(nl)
+    hyper = _hyper(filter_hyperparams)
+    opts = _opts(hyper, 1)
+    y, t, batched, dtype = _prepare(emissions, t_emissions, hyper, opts, dtype)
+    if not _ffi.lib().cdkf_kf_smoother1_supported(_ffi.C.byref(mdl.c)):
+        raise NotImplementedError(f"a dynamics bias / inputs run on the HIP path for state_dim <= 8 (got {mdl.state_dim})")
+    N, T, m = y.shape
+    d = mdl.state_dim
+    tt = np.broadcast_to(t, (N, T)) if t.ndim == 1 else t
+    # one more interval: the last predict runs over dt_final (1 on the regular grid of t_emissions=None)
+    t_ext = np.concatenate([tt, tt[:, -1:] + opts.dt_final], axis=1).astype(np.float64)
+    A, _ = _ffi.kf_pushforward(mdl, opts, t_ext, np.float64)                       # [N, T, d, d]
+    H = np.asarray(params.emissions.weights, dtype=np.float64)
+    b = params.dynamics.bias
+    c = np.zeros((N, T, d)) + (0.0 if b is None else np.asarray(b, dtype=np.float64))
+    yy = y.astype(np.float64)
+    if inputs is not None and np.asarray(inputs).size:
+        u = np.asarray(inputs, dtype=np.float64)
+        u = np.broadcast_to(u if u.ndim == 3 else u[None], (N, T, u.shape[-1]))
+        B, Dm = params.dynamics.input_weights, params.emissions.input_weights
+        if B is not None and np.size(B):
+            c = c + u @ np.asarray(B, dtype=np.float64).T
+        if Dm is not None and np.size(Dm):
+            yy = yy - u @ np.asarray(Dm, dtype=np.float64).T
+    s = np.zeros((N, T + 1, d))
+    for k in range(T):
+        s[:, k + 1] = np.einsum("nij,nj->ni", A[:, k], s[:, k]) + c[:, k]
+    yy = yy - s[:, :T] @ H.T
+    post = cdnlgssm_filter(nl, yy.astype(dtype) if batched else yy[0].astype(dtype), t_emissions, hyper, dtype=dtype)
+    sh = lambda a, off: None if a is None else (np.asarray(a) + (off if batched else off[0]).astype(np.asarray(a).dtype))
+    return post._replace(filtered_means=sh(post.filtered_means, s[:, :T]), predicted_means=sh(post.predicted_means, s[:, 1:]))
+
+
 def cdlgssm_filter(params: ParamsCDLGSSM, emissions, t_emissions=None, filter_hyperparams: Optional[KFHyperParams] = None,
                    inputs=None, dtype=None) -> PosteriorGSSMFiltered:
     """Continuous-discrete Kalman filter (reference: inference.py:555-632)."""
+    if _has_offsets(params, inputs):
+        return _filter_with_offsets(params, emissions, t_emissions, filter_hyperparams, inputs, dtype)
     return cdnlgssm_filter(_as_nonlinear(params, inputs), emissions, t_emissions, _hyper(filter_hyperparams), dtype=dtype)
 
 
@@ -200,6 +248,8 @@ class ContDiscreteLinearGaussianSSM:
         return out[0], out[1]
 
     def marginal_log_prob(self, params, emissions, t_emissions=None, filter_hyperparams=None, inputs=None, dtype=None):
+        if _has_offsets(params, inputs):
+            return cdlgssm_filter(params, emissions, t_emissions, filter_hyperparams, inputs, dtype=dtype).marginal_loglik
         return cdnlgssm_filter(_as_nonlinear(params, inputs), emissions, t_emissions, _hyper(filter_hyperparams),
                                output_fields=[], dtype=dtype).marginal_loglik
 

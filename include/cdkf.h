@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define CDKF_VERSION 105 /* 0.2.0 */
+#define CDKF_VERSION 106 /* 0.2.0 */
 
 /* error codes */
 #define CDKF_OK 0
@@ -301,6 +301,13 @@ int cdkf_kf_smoother1_f32_dev(const cdkf_model* mdl, const cdkf_opts* opts, int6
                               const float* y, float* ll, float* filtered_means, float* filtered_covs, float* smoothed_means,
                               float* smoothed_covs, float* smoothed_cross, int32_t* status, void* stream);
 int cdkf_kf_smoother1_supported(const cdkf_model* mdl);
+/* The pushed-forward (A, Q) of every observation interval by themselves -- compute_pushforward, inference.py:105-143 -- for the
+ * same shapes (cdkf_kf_smoother1_supported): AQ [N, T-1, 2, d, d] row-major (A then Q per interval), host arrays; t follows
+ * opts.layout_in / opts.t_shared.  The host side uses it for what the reference adds to the pushed-forward mean WITHOUT
+ * integrating it (dynamics bias and inputs, inference.py:185-205 _predict: mu = F m + B u + b): the offsets s_k+1 = A_k s_k + B u_k + b
+ * are formed from these A_k, the filter runs on y - H s - D u - d, and s is added back to the means. */
+int cdkf_kf_pushforward_f64(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T, const double* t, double* AQ);
+int cdkf_kf_pushforward_f32(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T, const float* t, float* AQ);
 
 /* ---- marginal log-likelihood AND its gradient w.r.t. the drift parameters theta (ordering of cdkf_model.theta):
  *      replaces jax.value_and_grad of the fit_sgd loss, src/ssm_temissions.py:550-568, for the drift block of

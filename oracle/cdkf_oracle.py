@@ -847,6 +847,51 @@ def kf_pushforward(mdl: Model, t0, t1, dt0=0.01, max_steps=100000, dtype=np.floa
     return diffeqsolve(rhs, np.asarray(t0, dtype), np.asarray(t1, dtype), (A0, Q0), dt0, max_steps)
 
 
+def kf_filter_inputs(mdl: Model, t, y, dyn_bias=None, B=None, D=None, inputs=None, dt0=0.01, dt_final=1e-10, max_steps=100000):
+    """cdlgssm_filter with a dynamics bias and inputs, as the reference runs it (continuous_discrete_linear_gaussian_ssm/
+    inference.py:555-632): per step k, with u = inputs[k]:  ll += N(y_k; H m + D u + d, H P H^T + R);  condition (psd_solve);
+    (A, Q) = compute_pushforward(t_k, t_k+1);  m <- A m + B u + b (added WITHOUT being integrated, _predict :185-205),
+    P <- A P A^T + Q.  The drift's own bias must be zero (it would be integrated).  float64; t [N,T] or [T], y [N,T,m],
+    inputs [N,T,nu] or [T,nu]."""
+    mdl = mdl.cast(np.float64)
+    if mdl.drift.kind != "linear" or np.any(mdl.drift.b != 0):
+        raise NotImplementedError("kf_filter_inputs: linear drift with zero (integrated) bias")
+    y = np.asarray(y, np.float64)
+    N, T, mm = y.shape
+    d = mdl.d
+    tt = np.broadcast_to(np.asarray(t, np.float64), (N, T)) if np.ndim(t) == 1 else np.asarray(t, np.float64)
+    b = np.zeros(d) if dyn_bias is None else np.asarray(dyn_bias, np.float64)
+    u = np.zeros((N, T, 0)) if inputs is None else np.broadcast_to(np.asarray(inputs, np.float64), (N, T, np.shape(inputs)[-1]))
+    Bm = np.zeros((d, u.shape[-1])) if B is None else np.asarray(B, np.float64)
+    Dm = np.zeros((mm, u.shape[-1])) if D is None else np.asarray(D, np.float64)
+    H, R, hb = mdl.H, mdl.R, mdl.bias
+    m = np.broadcast_to(mdl.m0, (N, d)).copy()
+    P = np.broadcast_to(mdl.P0, (N, d, d)).copy()
+    ll = np.zeros(N)
+    out = {k: [] for k in ("filtered_means", "filtered_covariances", "predicted_means", "predicted_covariances")}
+    eye = np.eye(mm)
+    for k in range(T):
+        S = H @ P @ H.T + R
+        v = y[:, k] - (m @ H.T + u[:, k] @ Dm.T + hb)
+        Lc = cholesky_lower(S)
+        z = solve_lower(Lc, v[..., None])[..., 0]
+        ll += -0.5 * np.einsum("ni,ni->n", z, z) - np.sum(np.log(np.diagonal(Lc, axis1=-2, axis2=-1)), -1) - 0.5 * mm * math.log(2 * math.pi)
+        X = psd_solve(S, H @ P)                                          # K^T
+        m = m + np.einsum("nri,nr->ni", X, v)
+        P = symmetrize(P - np.swapaxes(X, -1, -2) @ S @ X)
+        out["filtered_means"].append(m)
+        out["filtered_covariances"].append(P)
+        t1 = tt[:, k + 1] if k + 1 < T else tt[:, k] + dt_final
+        A, Q = kf_pushforward(mdl, tt[:, k], t1, dt0, max_steps)
+        m = np.einsum("nij,nj->ni", A, m) + u[:, k] @ Bm.T + b
+        P = A @ P @ np.swapaxes(A, -1, -2) + Q
+        out["predicted_means"].append(m)
+        out["predicted_covariances"].append(P)
+    res = {k: np.stack(v_, axis=1) for k, v_ in out.items()}
+    res["marginal_loglik"] = ll
+    return res
+
+
 def kf_smoother_type1(mdl: Model, t, y, dt0=0.01, dt_final=1e-10, max_steps=100000, dtype=np.float64,
                       filtered: Optional[dict] = None):
     """cdlgssm_smoother(..., smoother_type='cd_smoother_1') (inference.py:694-823, _step_1 :746-773; Sarkka Alg. 3.17):

@@ -654,6 +654,51 @@ def test_linear_smoother_type1(hip_lib, d, m):
     assert p32.smoothed_means.dtype == np.float32 and relerr(p32.smoothed_means, ref1["smoothed_means"][0]) < 2e-3
 
 
+@pytest.mark.parametrize("d,m", [(3, 2), (4, 2), (6, 3)])
+def test_linear_front_end_dynamics_bias_and_inputs(hip_lib, d, m):
+    """ContDiscreteLinearGaussianSSM.filter / marginal_log_prob with a dynamics bias, dynamics and emission input weights and an
+    input series: the reference adds B u_k + b to the pushed-forward mean WITHOUT integrating it and D u_k + d to the emission mean
+    (inference.py:185-205, 596-620).  Against the oracle running exactly that recursion (kf_filter_inputs); batched irregular
+    times with per-trajectory inputs, then one trajectory on the regular grid (the last predict over dt_final = 1) with a shared
+    input series, single precision, and the shapes that stay refused."""
+    rng = np.random.default_rng(80 + d)
+    base = linear_model(rng, d, m)
+    mdl = o.Model(o.LinearDrift(base.drift.W, np.zeros(d)), base.L, base.Qc, base.H, base.bias, base.R, base.m0, base.P0)
+    nu = 2
+    b, B, D = 0.3 * rng.standard_normal(d), rng.standard_normal((d, nu)), rng.standard_normal((m, nu))
+    N, T = 5, 14
+    t = o.irregular_times(rng, N, T, 0.2)
+    u = rng.standard_normal((N, T, nu))
+    y = o.simulate(mdl, t, rng) + u @ D.T
+    model = cd.ContDiscreteLinearGaussianSSM(state_dim=d, emission_dim=m, input_dim=nu, has_dynamics_bias=True, has_emissions_bias=True)
+    pp = cd.ParameterProperties()
+    params, _ = model.initialize(
+        initial_mean={"params": mdl.m0, "props": pp}, initial_cov={"params": mdl.P0, "props": pp},
+        dynamics_weights={"params": mdl.drift.W, "props": pp}, dynamics_bias={"params": b, "props": pp},
+        dynamics_input_weights={"params": B, "props": pp}, dynamics_diffusion_coefficient={"params": mdl.L, "props": pp},
+        dynamics_diffusion_cov={"params": mdl.Qc, "props": pp}, emission_weights={"params": mdl.H, "props": pp},
+        emission_bias={"params": mdl.bias, "props": pp}, emission_input_weights={"params": D, "props": pp},
+        emission_cov={"params": mdl.R, "props": pp})
+    ref = o.kf_filter_inputs(mdl, t, y, b, B, D, u)
+    post = model.filter(params, y, t[..., None], inputs=u)
+    for k in FILTER_KEYS:
+        assert relerr(getattr(post, k), ref[k]) < 1e-9, k
+    np.testing.assert_allclose(post.marginal_loglik, ref["marginal_loglik"], rtol=1e-10)
+    np.testing.assert_allclose(model.marginal_log_prob(params, y, t[..., None], inputs=u), ref["marginal_loglik"], rtol=1e-10)
+    # the offsets matter: without them the means are elsewhere
+    plain = o.ekf_filter(mdl, t, y, state_order="first")
+    assert relerr(plain["filtered_means"], ref["filtered_means"]) > 1e-3
+    # bias only, one trajectory, regular grid, shared (unbatched) inputs, fp32
+    y1, u1 = y[0], u[0]
+    ref1 = o.kf_filter_inputs(mdl, np.arange(T, dtype=float)[None], y1[None], b, B, D, u1[None], dt_final=1.0)
+    p1 = model.filter(params, y1, inputs=u1, filter_hyperparams=cd.KFHyperParams(dt_final=1.0))
+    assert p1.filtered_means.shape == (T, d) and relerr(p1.predicted_means, ref1["predicted_means"][0]) < 1e-9
+    p32 = model.filter(params, y1.astype(np.float32), inputs=u1, filter_hyperparams=cd.KFHyperParams(dt_final=1.0))
+    assert p32.filtered_means.dtype == np.float32 and relerr(p32.filtered_means, ref1["filtered_means"][0]) < 2e-3
+    with pytest.raises(NotImplementedError, match="smoothers take no inputs|_predict"):
+        model.smoother(params, y1, inputs=u1)
+
+
 @pytest.mark.parametrize("d,m,solver,ctrl", [(3, 2, "tsit5", None), (6, 3, "bosh3", None), (3, 2, "dopri5", dict(rtol=1e-6, atol=1e-8)),
                                              (6, 3, "tsit5", dict(rtol=1e-5, atol=1e-7))])
 def test_linear_smoother_type1_solver_settings(hip_lib, d, m, solver, ctrl):
