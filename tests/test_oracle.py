@@ -389,6 +389,33 @@ def test_adjoint_gradient_all_parameters_matches_finite_differences():
             assert np.abs(fd - an).max() < 2e-5 * np.abs(fd).max(), name
 
 
+def test_kf_filter_inputs_reduces_to_the_filter_and_shifts_by_the_offsets():
+    """kf_filter_inputs (the reference's linear filter with un-integrated B u + b and D u + d): without bias and inputs it is the
+    Kalman filter (= the EKF on a linear drift, to the 1e-12 of pushing (A, Q) forward instead of the moments); with them the
+    covariances and the log-likelihood of the SHIFTED data are unchanged and the means move by s_k+1 = A_k s_k + B u_k + b."""
+    from helpers import linear_model
+    rng = np.random.default_rng(21)
+    base = linear_model(rng, 3, 2)
+    mdl = o.Model(o.LinearDrift(base.drift.W, np.zeros(3)), base.L, base.Qc, base.H, base.bias, base.R, base.m0, base.P0)
+    N, T, nu = 2, 7, 2
+    t = o.irregular_times(rng, N, T, 0.3)
+    y = o.simulate(mdl, t, rng)
+    r0, r1 = o.kf_filter_inputs(mdl, t, y), o.ekf_filter(mdl, t, y, state_order="first")
+    for k in ("filtered_means", "filtered_covariances", "predicted_means", "predicted_covariances", "marginal_loglik"):
+        assert np.abs(r0[k] - r1[k]).max() < 1e-11 * np.abs(r1[k]).max(), k
+    b, B, D, u = 0.2 * rng.standard_normal(3), rng.standard_normal((3, nu)), rng.standard_normal((2, nu)), rng.standard_normal((N, T, nu))
+    s = np.zeros((N, T + 1, 3))
+    for k in range(T):
+        t1 = t[:, k + 1] if k + 1 < T else t[:, k] + 1e-10
+        A, _ = o.kf_pushforward(mdl, t[:, k], t1)
+        s[:, k + 1] = np.einsum("nij,nj->ni", A, s[:, k]) + u[:, k] @ B.T + b
+    r2 = o.kf_filter_inputs(mdl, t, y + s[:, :T] @ mdl.H.T + u @ D.T, b, B, D, u)
+    np.testing.assert_allclose(r2["marginal_loglik"], r0["marginal_loglik"], rtol=1e-11)
+    assert np.abs(r2["filtered_covariances"] - r0["filtered_covariances"]).max() < 1e-12
+    assert np.abs(r2["filtered_means"] - (r0["filtered_means"] + s[:, :T])).max() < 1e-10
+    assert np.abs(r2["predicted_means"] - (r0["predicted_means"] + s[:, 1:])).max() < 1e-10
+
+
 def test_type1_smoother_matches_exact_rts():
     """kf_smoother_type1 (reference cd_smoother_1: discrete RTS on the Dopri5-pushed-forward (A, Q)) against the exact
     matrix-exponential RTS smoother; the cross term against its definition with the exact gain."""
