@@ -882,6 +882,10 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
     R inv1[8], inv2[8];
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
+      if (p >= m) {  // (uniform) identity padding: pivot 1, nothing below it
+        inv1[p] = inv2[p] = R(1);
+        continue;
+      }
       W[AdjOff::S1 + lane] = s1;
       W[AdjOff::S2 + lane] = s2;
       wave_sync();

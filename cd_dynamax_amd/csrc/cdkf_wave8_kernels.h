@@ -383,6 +383,10 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave8_kernel(const WgArgs<R
       R inv1[kW8], inv2[kW8];
 #pragma unroll
       for (int p = 0; p < kW8; ++p) {
+        if (p >= m) {  // (uniform) identity padding: pivot 1, nothing below it -- two synchronisations saved per padded column
+          inv1[p] = inv2[p] = R(1);
+          continue;
+        }
         W[W8Off::S1 + lane] = s1;
         W[W8Off::S2 + lane] = s2v;
         wave_sync();
