@@ -1,5 +1,5 @@
-// cdkf_wave40_kernels.h -- wavefront-per-trajectory EKF filter sweep for the Lorenz-96 model at state dimensions 9 .. 48
-// (BASELINE config 4: d = m = 40), emission = the identity on the state (H = I, any symmetric R).
+// cdkf_wave40_kernels.h -- wavefront-per-trajectory EKF filter sweep AND smoother backward sweep for the Lorenz-96 model at state
+// dimensions 9 .. 48 (BASELINE config 4: d = m = 40), emission = the identity on the state (H = I, any symmetric R).
 //
 // The workgroup-per-trajectory kernel (cdkf_wg2_kernels.h) spends a d = 40 observation step in ~35 barrier-separated phases with a
 // few dozen flops per thread in each: 512 threads wait on each other most of the time (SQ_WAIT_ANY 69 % of the wave cycles,
@@ -7,24 +7,26 @@
 // waits on another wavefront; four wavefronts (four trajectories) share a workgroup only to fill the CU's four SIMDs.
 //
 //  * State: the packed upper triangle of P (820 entries at d = 40) dealt round-robin to the 64 lanes -- 13 entries per lane, with
-//    their six Dormand-Prince slopes, in registers; lanes < d own the mean.
+//    their six Dormand-Prince slopes, in registers; lanes < d own the mean.  The entries' indices live in an LDS table (two words
+//    per entry) and are fetched where they are used.
 //  * Predict (inference_ekf.py:76-123): the stage covariance is written to an LDS image with a two-element halo (the Lorenz-96
 //    neighbourhood i-2, i-1, i+1 wraps around), so an entry's right-hand side
 //        dP_ij = a_i (P_{i+1,j} - P_{i-2,j}) + b_i P_{i-1,j} + a_j (P_{i,j+1} - P_{i,j-2}) + b_j P_{i,j-1} - 2 P_ij + (L Qc L^T)_ij,
 //        a_i = x_{i-1},  b_i = x_{i+1} - x_{i-2}                      (the four non-zeros of the Jacobian's row i)
-//    is six LDS reads at constant offsets from ONE per-entry address, four coefficient reads and eight flops; two wavefront-scope
-//    synchronisations per stage.
+//    is six LDS reads at constant offsets from ONE per-entry address, two 16-byte coefficient reads and eight flops; two
+//    wavefront-scope synchronisations per stage.
+//  * Dense linear algebra (W40Lin below): Cholesky factorisation and triangular solves in 16-wide blocks -- every matrix product
+//    among them on the matrix cores, only the 16 x 16 triangles on the diagonal as scalar recurrences.
 //  * Update (inference_ekf.py:153-199, 285-286; H = I so H P = P, S = P + R):
-//      - both Cholesky factors (TFP's of S for the log-likelihood, psd_solve's of S + 1e-9 I for the gain) left-looking in packed
-//        lower storage by panels of eight columns, lane i = row i, the two recurrences in lockstep; the innovation rides along as
-//        row d of the un-jittered system, which makes its forward substitution (the log-likelihood's quadratic form) part of the
-//        factorisation;
-//      - X = (S + 1e-9 I)^-1 P by forward and backward substitution with lane c = right-hand side c, the forty unknowns of a column in
-//        registers (fully unrolled; the factor's entries arrive as LDS broadcasts at compile-time offsets);
-//      - m+ = m + X^T (y - m) (lane c: its own column against the broadcast innovation);
+//      - both Cholesky factors (TFP's of S for the log-likelihood, psd_solve's of S + 1e-9 I for the gain) in lockstep; the
+//        innovation rides along as row d of the un-jittered system, which makes its forward substitution (the log-likelihood's
+//        quadratic form) part of the factorisation;
+//      - X = (S + 1e-9 I)^-1 P with lane c = right-hand side c;  m+ = m + X^T (y - m);
 //      - P+ = P - X^T S X as P - Y^T Y + 1e-9 X^T X with Y = L_b^-1 P the forward solve's result (S = L_b L_b^T - 1e-9 I): two
 //        symmetric rank-d products on the matrix cores (v_mfma_*_16x16x4, six upper 16 x 16 tiles, operands straight from the LDS
 //        image of Y / X, whose A- and B-operand layouts coincide), the -1e-9 folded into the A operand.  Needs R symmetric.
+//  * Backward sweep (ekf_smoother_wave_l96_kernel, further down): G = F(m_f) + psd_solve(P_f, L Qc L^T)^T per interval from the same
+//    W40Lin, G P_s per Runge-Kutta stage as 3 x 3 tiles on the matrix cores.
 //  * Outputs stream from the LDS images (full d x d rows, coalesced).
 //
 // Scope: drift Lorenz-96, H = I (m = d), num_iter = 1, state_order first / second (the same for this drift: grad(div f) = 0), fixed-
