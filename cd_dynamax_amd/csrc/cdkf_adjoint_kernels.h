@@ -841,6 +841,7 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
   const R* tp = a.t + n * a.t_sn;
   const R* yp = a.y + n * a.y_sn;
   R mb = 0, Pb = 0;  // cotangent of the filtered moments at k (mean on lanes < 8)
+  int adj_st = 0;
   for (long k = a.T - 1; k >= 0; --k) {
     // (1) measurement update + log-likelihood term at k, from the predicted moments
     R mp, Pp;
@@ -1013,8 +1014,17 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
 
     // (2) predict k-1 -> k: reverse the Dormand-Prince steps, replaying the interval in chunks of kAdjCk steps
     const R t0 = tp[(k - 1) * a.t_sk], t1 = tp[k * a.t_sk];
+    // an adaptive solve: the forward sweep logged the step sizes it accepted in this interval (the reverse of the solve treats them
+    // as constants -- the controller's factor carries no derivative, as in the reference's reverse mode through diffrax)
+    const R* dtl = a.dtlog ? a.dtlog + (n * (a.T - 1) + (k - 1)) * (1 + a.dtlog_cap) : nullptr;
     long S = 0;
-    {
+    if (dtl) {
+      S = (long)dtl[0];
+      if (S > a.dtlog_cap) {  // more accepted steps than the log holds: the gradient of this trajectory is not valid
+        S = a.dtlog_cap;
+        adj_st |= kStatusMaxSteps;
+      }
+    } else {
       R tprev = t0, tnext = rmin(t0 + a.dt0, t1);
       while (tprev < t1 && S < a.max_steps) {
         tprev = rmin(tnext, t1);
@@ -1043,7 +1053,7 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
       R mj = mf, Pij = Pf;
       R tprev = t0, tnext = rmin(t0 + a.dt0, t1);
       for (long s = 0; s < ce; ++s) {
-        const R dt = tnext - tprev;
+        const R dt = dtl ? dtl[1 + s] : tnext - tprev;
         if (s >= cs) {
           const int slot = (int)(s - cs);
           W[AdjOff::ck + slot * 72 + lane] = Pij;
@@ -1075,6 +1085,7 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
     }
   }
 
+  if (adj_st && lane == 0 && a.status) atomicOr(&a.status[n], adj_st);
   // ---- model block: m0 | P0 | LQL | H | bias | R ------------------------------------------------------------------------
   if (grad_model) {
     R* gm = grad_model + n * adj_model_grad_size(d, m);

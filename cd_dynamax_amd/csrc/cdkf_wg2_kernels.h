@@ -50,6 +50,10 @@ struct WgArgs {
   // ([N][T-1][ck_smax][6][64 P + 8 m]) and the reverse sweep reads them back instead of re-integrating the interval
   R* ck;
   int ck_smax;
+  // adaptive solves under the reverse sweep: the forward (workgroup) sweep logs the accepted step sizes of every interval here
+  // ([N][T-1][1 + dtlog_cap]: their number, then the sizes) and the reverse sweep replays exactly those steps
+  R* dtlog;
+  int dtlog_cap;
 };
 constexpr int kCkStep = 6 * 72;  // reals per checkpointed step
 constexpr int kAdjCk = 4;         // Dormand-Prince step starts the reverse sweep keeps in LDS per replay chunk
@@ -709,7 +713,8 @@ __device__ __forceinline__ void wg_dopri5_step(const WgLds<R>& L, const Own<R, E
 // until it is accepted.  max_steps counts attempts.
 template <typename R, int EPT, typename RhsFn>
 __device__ __forceinline__ bool wg_integrate_adaptive(const WgLds<R>& L, const Own<R, EPT>& own, int d, R t0, R t1, R dt0,
-                                                      long max_steps, bool with_P, RhsFn rhs, const RkTab<R>& tb) {
+                                                      long max_steps, bool with_P, RhsFn rhs, const RkTab<R>& tb, R* dtlog = nullptr,
+                                                      int dtlog_cap = 0) {
   __shared__ double red[16];
   R* mcur = L.vec(0);
   R* Pm = L.mat(0);
@@ -721,8 +726,12 @@ __device__ __forceinline__ bool wg_integrate_adaptive(const WgLds<R>& L, const O
   R tnext = rmin(t0 + dt0, t1);
   R inv1 = R(1), inv2 = R(1);
   long steps = 0;
+  int nacc = 0;  // accepted steps (logged for the reverse sweep)
   while (tprev < t1) {  // uniform over the workgroup
-    if (steps >= max_steps) return true;
+    if (steps >= max_steps) {
+      if (dtlog && threadIdx.x == 0) dtlog[0] = R(nacc);
+      return true;
+    }
     const R dt = tnext - tprev;
     R kM[6];
     R kP[6][EPT];
@@ -808,19 +817,23 @@ __device__ __forceinline__ bool wg_integrate_adaptive(const WgLds<R>& L, const O
       }
       inv2 = inv1;
       inv1 = inv;
+      if (dtlog && threadIdx.x == 0 && nacc < dtlog_cap) dtlog[1 + nacc] = dt;
+      ++nacc;
     }
     __syncthreads();  // the state is complete (and `red` free) before the next attempt
     tprev = rmin(nt0, t1);
     tnext = (nt1 > t1 - Tol<R>::v) ? (keep ? t1 : rfma(R(0.5), t1 - tprev, tprev)) : nt1;
     ++steps;
   }
+  if (dtlog && threadIdx.x == 0) dtlog[0] = R(nacc);
   return false;
 }
 
 template <typename R, int EPT, typename RhsFn>
 __device__ __forceinline__ bool wg_integrate(const WgLds<R>& L, const Own<R, EPT>& own, int d, R t0, R t1, R dt0,
-                                             long max_steps, bool with_P, RhsFn rhs, const RkTab<R>& tb) {
-  if (tb.adaptive) return wg_integrate_adaptive<R, EPT>(L, own, d, t0, t1, dt0, max_steps, with_P, rhs, tb);
+                                             long max_steps, bool with_P, RhsFn rhs, const RkTab<R>& tb, R* dtlog = nullptr,
+                                             int dtlog_cap = 0) {
+  if (tb.adaptive) return wg_integrate_adaptive<R, EPT>(L, own, d, t0, t1, dt0, max_steps, with_P, rhs, tb, dtlog, dtlog_cap);
   R tprev = t0;
   R tnext = rmin(t0 + dt0, t1);
   long steps = 0;
@@ -1239,7 +1252,9 @@ __global__ __launch_bounds__(512) void ekf_filter_wg_kernel(const WgArgs<R> a_in
     // (re)derive this thread's entry indices here: values that live across the measurement update would be spilled to
     // scratch by its register pressure and re-loaded inside every Runge-Kutta stage (measured: 3.4x on the d = 40 sweep)
     own.init(d, lq, a.par + a.o_LQL);
-    if (wg_integrate<R, EPT>(L, own, d, t0, t1, a.dt0, a.max_steps, !zeroth, rhs, a.rk)) st |= kStatusMaxSteps;
+    if (wg_integrate<R, EPT>(L, own, d, t0, t1, a.dt0, a.max_steps, !zeroth, rhs, a.rk,
+                             (a.dtlog && k + 1 < a.T) ? a.dtlog + (n * (a.T - 1) + k) * (1 + a.dtlog_cap) : (R*)nullptr, a.dtlog_cap))
+      st |= kStatusMaxSteps;
     if (zeroth) {
       const R sq = rsqrt_(t1 - t0);
       const R* Qz = a.par + a.o_LQLz;

@@ -337,7 +337,6 @@ static int workspace_reserve(AdjWorkspace& ws, size_t bytes, hipStream_t stream)
 }
 
 bool adjoint_shape_available(const cdkf_model* mdl, const cdkf_opts* o) {
-  if (o->adaptive) return false;  // (the reverse of an adaptive solve needs the accepted step sizes: not kept)
   if (!wave8_shape(mdl) || !wg_shape_available(mdl, 8) || o->num_iter != 1 || o->forecast) return false;
   if (o->state_order == CDKF_ORDER_ZEROTH) return false;
   return true;
@@ -364,17 +363,26 @@ int launch_ekf_grad_adjoint(const cdkf_model* mdl, const cdkf_opts* o, int64_t N
   if (const char* e = getenv("CDKF_ADJ_CKPT_GB")) cap_gb = atof(e);
   size_t nck = (T > 1) ? (size_t)N * (size_t)(T - 1) * (size_t)smax * kCkStep : 0;
   if ((double)nck * sizeof(R) > cap_gb * 1e9) nck = 0;
+  // an adaptive solve: the forward (workgroup) sweep logs the accepted step sizes of every interval (up to CDKF_ADJ_DT_CAP, default
+  // 64; a longer interval raises MAX_STEPS on that trajectory) and the reverse sweep replays them
+  int dtcap = 64;
+  if (const char* e = getenv("CDKF_ADJ_DT_CAP")) dtcap = atoi(e) > 0 ? atoi(e) : 64;
+  const size_t ndt = (o->adaptive && T > 1) ? (size_t)N * (size_t)(T - 1) * (size_t)(1 + dtcap) : 0;
+  if (o->adaptive) nck = 0;
   AdjWorkspace& ws = g_adj_ws;
-  if (int wrc = workspace_reserve(ws, (2 * (nm + nP) + nck) * sizeof(R), stream)) {
+  if (int wrc = workspace_reserve(ws, (2 * (nm + nP) + nck + ndt) * sizeof(R), stream)) {
     if (!nck) return wrc;
     (void)hipGetLastError();  // no room for the slope checkpoints: the sweep re-integrates instead
     nck = 0;
-    if (int wrc2 = workspace_reserve(ws, 2 * (nm + nP) * sizeof(R), stream)) return wrc2;
+    if (int wrc2 = workspace_reserve(ws, (2 * (nm + nP) + ndt) * sizeof(R), stream)) return wrc2;
   }
   R* w = (R*)ws.p;
   a.t = t; a.y = y; a.ll = ll; a.status = status;
   a.fm = w; a.fP = w + nm; a.pm = w + nm + nP; a.pP = w + 2 * nm + nP;
-  const bool dp5 = o->solver == CDKF_SOLVER_DOPRI5;  // other methods: forward pass on the workgroup kernel (run-time tableau), no slopes kept
+  // other methods / adaptive steps: forward pass on the workgroup kernel (run-time tableau), no slopes kept
+  const bool dp5 = o->solver == CDKF_SOLVER_DOPRI5 && !o->adaptive;
+  a.dtlog = ndt ? w + 2 * (nm + nP) + nck : nullptr;
+  a.dtlog_cap = ndt ? dtcap : 0;
   a.ck = (nck && dp5) ? w + 2 * (nm + nP) : nullptr;
   a.ck_smax = (nck && dp5) ? smax : 0;
   rc = dp5 ? launch_wave8<R>(a, stream) : launch_wg_dispatch<R>(a, mdl, false, stream);

@@ -124,8 +124,9 @@ typedef struct cdkf_opts {
                            icoeff, dcoeff) around the method's embedded error estimate (DOPRI5, TSIT5, BOSH3, HEUN), first step
                            dt0, every trajectory adapting on its own; max_steps then counts accepted and rejected steps.
                            Filters and smoothers of every shape (larger models on the workgroup kernels) and custom drifts;
-                           the type-1 smoother's pushed-forward (A, Q) adapt as well; the reverse-sweep gradient (any method) takes fixed
-                           steps only. */
+                           the type-1 smoother's pushed-forward (A, Q) adapt as well; so does the reverse-sweep gradient: its forward
+                           sweep logs the accepted step sizes (up to CDKF_ADJ_DT_CAP = 64 per interval, MAX_STEPS status beyond) and
+                           the reverse sweep replays them as constants (the controller's factor carries no derivative). */
   int64_t max_steps;    /* RK steps per observation interval; default 100000 */
   double dt0;           /* default 0.01 */
   double dt_final;      /* default 1e-10 (inference_ekf.py:39) */

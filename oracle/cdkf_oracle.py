@@ -457,7 +457,7 @@ def dopri5_step(rhs, y, dt):
     return _tree_axpy(y, ks, B, dtype)
 
 
-def diffeqsolve(rhs, t0, t1, y0, dt0=0.01, max_steps=100000, count_steps=None, err_components=None):
+def diffeqsolve(rhs, t0, t1, y0, dt0=0.01, max_steps=100000, count_steps=None, err_components=None, dt_log=None):
     """Integrate the autonomous ODE y' = rhs(y) from t0 to t1 (both [N]) with fixed-step Dopri5.
 
     Mirrors diffrax 0.4.0: tprev=t0, tnext=min(t0+dt0, t1); while tprev < t1: step(tprev->tnext);
@@ -467,7 +467,7 @@ def diffeqsolve(rhs, t0, t1, y0, dt0=0.01, max_steps=100000, count_steps=None, e
     autonomous right-hand sides of this path the caller passes t0=0, t1=t1-t0 and the negated rhs.
     """
     if _ACTIVE[-1][1] is not None:
-        return _diffeqsolve_adaptive(rhs, t0, t1, y0, dt0, max_steps, count_steps, err_components)
+        return _diffeqsolve_adaptive(rhs, t0, t1, y0, dt0, max_steps, count_steps, err_components, dt_log)
     dtype = y0[0].dtype
     tol = dtype.type(1e-10 if dtype == np.float64 else 1e-6)
     t0 = np.asarray(t0, dtype=dtype)
@@ -495,7 +495,7 @@ def diffeqsolve(rhs, t0, t1, y0, dt0=0.01, max_steps=100000, count_steps=None, e
     return y
 
 
-def _diffeqsolve_adaptive(rhs, t0, t1, y0, dt0, max_steps, count_steps, err_components=None):
+def _diffeqsolve_adaptive(rhs, t0, t1, y0, dt0, max_steps, count_steps, err_components=None, dt_log=None):
     """diffrax.PIDController around the embedded pair (diffrax 0.4.0 is not in the mount; restated from its published
     algorithm -- step_size_controller/adaptive.py and the integrate loop):
       y_error      = dt * sum_i (b_sol - b_hat)_i k_i, the last stage being f(y_candidate) (FSAL methods)
@@ -563,6 +563,8 @@ def _diffeqsolve_adaptive(rhs, t0, t1, y0, dt0, max_steps, count_steps, err_comp
         nt0 = np.where(keep, tnext, tprev)
         nt1 = nt0 + dtn
         upd = active & keep
+        if dt_log is not None and upd[0]:  # (batch of one: the accepted step sizes, for the reverse sweep's oracle)
+            dt_log.append(float(dt[0]))
         y = tuple(np.where(bc(upd, c), cn, c) for cn, c in zip(ynew, y))
         inv2 = np.where(upd, inv1, inv2)
         inv1 = np.where(upd, inv, inv1)
@@ -1172,8 +1174,7 @@ def ekf_loglik_grad_adjoint(mdl: Model, t, y, dt0=0.01, dt_final=1e-10, max_step
 
     _A, _B = TABLEAUS[_ACTIVE[-1][0]]  # the Runge-Kutta method of the enclosing use_solver (fixed steps)
     _DP_A, _DP_B, NST = [list(r) for r in _A], list(_B), len(_B)
-    if _ACTIVE[-1][1] is not None:
-        raise NotImplementedError("reverse sweep: fixed steps only")
+    adaptive = _ACTIVE[-1][1] is not None  # the accepted step sizes are constants of the reverse sweep (controller under stop_gradient)
     second = state_order == "second"
     assert state_order in ("first", "second")
     divgrad = lambda x: drift.divgrad(x[None])[0]
@@ -1182,6 +1183,19 @@ def ekf_loglik_grad_adjoint(mdl: Model, t, y, dt0=0.01, dt_final=1e-10, max_step
         F = jac(x)
         A = F @ P
         return (f(x) + 0.5 * P @ divgrad(x) if second else f(x)), A + A.T + LQL
+
+    def step_sizes(x, P, ta, tb):
+        """The dt sequence of the solve over [ta, tb] from (x, P): the fixed-step loop's, or the sizes the controller accepts."""
+        if not adaptive:
+            return _step_sizes(ta, tb, dt0, 1e-10, max_steps)
+        log = []
+
+        def rhs_b(yv):
+            km, kp = rhs(yv[0][0], yv[1][0])
+            return km[None], kp[None]
+
+        diffeqsolve(rhs_b, np.array([ta]), np.array([tb]), (x[None].copy(), P[None].copy()), dt0, max_steps, dt_log=log)
+        return log
 
     def stages(x, P, dt):
         ks = []
@@ -1202,6 +1216,7 @@ def ekf_loglik_grad_adjoint(mdl: Model, t, y, dt0=0.01, dt_final=1e-10, max_step
         tn = t if t.ndim == 1 else t[n]
         # ---- forward sweep, keeping predicted and filtered moments ----
         mp, Pp, mf, Pf = [mdl.m0.copy()], [sym(mdl.P0)], [], []
+        dts_fwd = {}
         ll = 0.0
         for k in range(T):
             m_, P_ = mp[k], Pp[k]
@@ -1216,7 +1231,8 @@ def ekf_loglik_grad_adjoint(mdl: Model, t, y, dt0=0.01, dt_final=1e-10, max_step
             Pf.append(sym(P_ - X.T @ S @ X))
             if k + 1 < T:
                 x, P = mf[k], Pf[k]
-                for dt in _step_sizes(tn[k], tn[k + 1], dt0, 1e-10, max_steps):
+                dts_fwd[k] = step_sizes(x, P, tn[k], tn[k + 1])
+                for dt in dts_fwd[k]:
                     ks = stages(x, P, dt)
                     x = x + dt * sum(_DP_B[i] * ks[i][0] for i in range(NST))
                     P = P + dt * sum(_DP_B[i] * ks[i][1] for i in range(NST))
@@ -1249,7 +1265,7 @@ def ekf_loglik_grad_adjoint(mdl: Model, t, y, dt0=0.01, dt_final=1e-10, max_step
                 extra["m0"][n], extra["P0"][n] = mb, sym(Pb)
                 break
             # predict k-1 -> k: reverse the Dormand-Prince steps
-            dts = _step_sizes(tn[k - 1], tn[k], dt0, 1e-10, max_steps)
+            dts = dts_fwd[k - 1]
             starts = [(mf[k - 1], Pf[k - 1])]
             for dt in dts[:-1]:
                 x, P = starts[-1]

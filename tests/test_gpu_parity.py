@@ -795,10 +795,7 @@ def test_solver_choice_refusals(hip_lib):
         cd.cdnlgssm_filter(params_from(mdl), y, t[..., None], cd.EKFHyperParams(diffeqsolve_settings={"stepsize_controller": object()}))
     l63 = o.lorenz63_model(3)
     y3 = o.simulate(l63, t, rng)
-    with pytest.raises(NotImplementedError, match="no reverse-sweep kernel"):   # the all-parameter sweep takes fixed steps only
-        cd.cdnlgssm_loglik_and_grad_all(params_from(l63), y3, t[..., None], cd.EKFHyperParams(
-            diffeqsolve_settings={"solver": "heun", "stepsize_controller": cd.PIDController(1e-3, 1e-6)}))
-    with o.use_solver("heun"):                                                  # ... with any of the methods
+    with o.use_solver("heun"):                                                  # the all-parameter sweep: any of the methods
         ll_ref, g_ref = o.ekf_loglik_grad_adjoint(l63, t, y3)
     ll, g = cd.cdnlgssm_loglik_and_grad_all(params_from(l63), y3, t[..., None], cd.EKFHyperParams(diffeqsolve_settings={"solver": "heun"}))
     np.testing.assert_allclose(ll, ll_ref, rtol=1e-10)

@@ -280,9 +280,36 @@ def test_reverse_sweep_other_runge_kutta_methods(hip_lib, solver):
             scale = np.abs(g_ref).max()
             assert np.abs(flat - g_ref).max() < 1e-8 * scale, (order, np.abs(flat - g_ref).max() / scale)
             assert np.abs(np.asarray(g.emissions.emission_cov.params) - ex["R"]).max() < 1e-8 * np.abs(ex["R"]).max()
-    with pytest.raises(NotImplementedError, match="no gradient kernel"):  # adaptive steps: the reverse sweep would need the accepted sizes
-        cd.cdnlgssm_loglik_and_grad(P, y, t[..., None], cd.EKFHyperParams(
-            diffeqsolve_settings={"stepsize_controller": cd.PIDController(1e-4, 1e-6)}))
+
+
+@pytest.mark.parametrize("solver,ctrl", [("tsit5", dict(rtol=1e-5, atol=1e-7)), ("dopri5", dict(rtol=1e-4, atol=1e-6, pcoeff=0.2, icoeff=0.5))])
+def test_reverse_sweep_under_adaptive_steps(hip_lib, solver, ctrl, monkeypatch):
+    """value-and-gradient under diffrax.PIDController on the reverse sweep: the forward (workgroup) sweep logs the step sizes it
+    accepts, the reverse sweep replays them as constants.  MLP d = 5 (second order) and Lorenz-96 d = 6 against the oracle doing the
+    same (itself equal to the forward-sensitivity oracle, tests/test_oracle.py); a log too short for an interval raises MAX_STEPS."""
+    rng = np.random.default_rng(51)
+    settings = {"solver": solver, "dt0": 0.05, "stepsize_controller": cd.PIDController(**ctrl)}
+    for mdl, order in ((mlp_model(rng, 5, 2, (9, 7)), "second"), (lorenz96_model(6, 3), "first")):
+        N, T = 4, 8
+        t = o.irregular_times(rng, N, T, 0.05)
+        t[:, 4:] += 0.15
+        y = o.simulate(mdl, t, rng)
+        P = params_from(mdl)
+        with o.use_solver(solver, adaptive=ctrl):
+            ll_ref, g_ref, ex = o.ekf_loglik_grad_adjoint(mdl, t, y, dt0=0.05, full=True, state_order=order)
+        hyp = cd.EKFHyperParams(state_order=order, diffeqsolve_settings=settings)
+        ll, g = cd.cdnlgssm_loglik_and_grad_all(P, y, t[..., None], hyp)
+        np.testing.assert_allclose(ll, ll_ref, rtol=1e-9)
+        flat = np.concatenate([np.asarray(a_).reshape(N, -1) for a_ in g.dynamics.drift], axis=-1)
+        scale = np.abs(g_ref).max()
+        assert np.abs(flat - g_ref).max() < 1e-7 * scale, np.abs(flat - g_ref).max() / scale
+        assert np.abs(np.asarray(g.initial.mean.params) - ex["m0"]).max() < 1e-7 * np.abs(ex["m0"]).max()
+    from cd_dynamax_amd import models
+    monkeypatch.setenv("CDKF_ADJ_DT_CAP", "1")
+    mb = models._model_block(P)
+    op = models._opts(hyp, 1)
+    _, _, status = _ffi.loglik_grad(mb, op, t, y, np.float64)[:3]
+    assert (status & 4).any()
 
 
 def _general_model(rng, drift, d, m):

@@ -357,6 +357,23 @@ def test_adjoint_gradient_other_runge_kutta_methods_matches_finite_differences(s
             np.testing.assert_allclose(g @ u, fd, rtol=1e-5, atol=1e-8)
 
 
+@pytest.mark.parametrize("solver", ["tsit5", "dopri5"])
+def test_adjoint_gradient_under_adaptive_steps_equals_forward_sensitivities(solver):
+    """The reverse sweep of an ADAPTIVE solve takes the accepted step sizes as constants (the controller's factor carries no
+    derivative: that is how the reference's reverse mode through diffrax differentiates it) -- exactly what the forward
+    sensitivities riding on the primal's steps compute (ekf_loglik_grad).  Two derivations, one number."""
+    rng = np.random.default_rng(5)
+    mdl = o.lorenz63_model(2)
+    t = o.irregular_times(rng, 3, 8, 0.06)
+    t[:, 4:] += 0.2
+    y = o.simulate(mdl, t, rng)
+    with o.use_solver(solver, adaptive=dict(rtol=1e-5, atol=1e-7)):
+        ll1, g1 = o.ekf_loglik_grad(mdl, t, y, dt0=0.05)
+        ll2, g2 = o.ekf_loglik_grad_adjoint(mdl, t, y, dt0=0.05, state_order="second")
+    np.testing.assert_allclose(ll2, ll1, rtol=1e-12)
+    assert np.abs(g1 - g2).max() < 1e-11 * np.abs(g1).max()
+
+
 def test_adjoint_gradient_all_parameters_matches_finite_differences():
     """full=True: gradients w.r.t. m0, P0, L, Qc, H, bias, R (general, non-diagonal values) along random directions."""
     from helpers import mlp_model
