@@ -51,8 +51,19 @@ def oracle_backend(monkeypatch):
         return (r["marginal_loglik"], r["filtered_means"], r["filtered_covariances"], r["smoothed_means"],
                 r["smoothed_covariances"], r["smoothed_cross_covariances"], np.zeros(N, np.int32))
 
+    def fake_pushforward(blk, opts, t, dtype):
+        calls.append(("kf_pushforward", 0, opts.dt_final, opts.num_iter, (), np.dtype(dtype)))
+        mdl = _mdl_from_block(blk)
+        N, T = t.shape
+        A = np.zeros((N, T - 1, mdl.d, mdl.d))
+        Q = np.zeros_like(A)
+        for k in range(T - 1):
+            A[:, k], Q[:, k] = o.kf_pushforward(mdl, t[:, k], t[:, k + 1], opts.dt0, opts.max_steps)
+        return A, Q
+
     monkeypatch.setattr(_ffi, "run_host", fake)
     monkeypatch.setattr(_ffi, "kf_smoother1", fake_smoother1)
+    monkeypatch.setattr(_ffi, "kf_pushforward", fake_pushforward)
     monkeypatch.setattr(_ffi, "default_opts", lambda: _default())
     return calls
 
@@ -257,7 +268,15 @@ def test_linear_model_front_end(oracle_backend):
     sm1 = model.smoother(params, y)  # the reference's default: smoother type 1 (discrete RTS on the pushed-forward (A, Q))
     assert oracle_backend[-1][0] == "kf_smoother1" and sm1.smoothed_cross_covariances.shape == (T - 1, 4, 4)
     assert sm1.smoothed_means.shape == (T, 4) and np.ndim(sm1.marginal_loglik) == 0
-    with pytest.raises(NotImplementedError, match="bias"):
-        cd.cdlgssm_filter(params._replace(dynamics=params.dynamics._replace(bias=np.ones(4))), y)
-    with pytest.raises(NotImplementedError, match="inputs"):
-        cd.cdlgssm_filter(params, y, inputs=np.ones((T, 1)))
+    # a dynamics bias and inputs (un-integrated in the reference): offsets from the pushed-forward matrices, host logic of linear.py
+    b, B, D, u = 0.1 * np.ones(4), rng.standard_normal((4, 1)), rng.standard_normal((2, 1)), rng.standard_normal((T, 1))
+    pb = params._replace(dynamics=params.dynamics._replace(bias=b, input_weights=B),
+                         emissions=params.emissions._replace(input_weights=D))
+    pin = cd.cdlgssm_filter(pb, y, inputs=u, filter_hyperparams=cd.KFHyperParams(dt_final=1.0))
+    assert any(c[0] == "kf_pushforward" for c in oracle_backend)
+    rin = o.kf_filter_inputs(mdl, np.arange(T, dtype=float)[None], y[None], b, B, D, u[None], dt_final=1.0)
+    for k in ("filtered_means", "predicted_means", "filtered_covariances"):
+        np.testing.assert_allclose(getattr(pin, k), rin[k][0], rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(pin.marginal_loglik, rin["marginal_loglik"][0], rtol=1e-9)
+    with pytest.raises(NotImplementedError, match="smoothers take no inputs"):
+        model.smoother(pb, y, inputs=u)
