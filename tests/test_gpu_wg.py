@@ -66,6 +66,26 @@ def test_lorenz96_d40_dense_noise_matrices(hip_lib):
     _check(flt, o.ekf_filter(mdl, t, y), 1e-10)
 
 
+def test_c4_full_length_against_the_oracle(hip_lib):
+    """BASELINE config 4 at its full length (500 irregular observations at the benchmark's time density, d = m = 40): both
+    wavefront-per-trajectory sweeps against the oracle on the first two of eight trajectories, every step -- rounding must not
+    accumulate over the scan (filtered / smoothed moments 1e-9, log-likelihood 1e-11)."""
+    rng = np.random.default_rng(4)
+    mdl = lorenz96_model(40, 40)
+    N, T = 8, 500
+    u = rng.uniform(0.0, 1.0, size=(N, T))
+    cs = np.cumsum(u, axis=1)
+    t = cs / cs[:, -1:] * (0.005 * T)
+    y = 8.0 + rng.standard_normal((N, T, 40))
+    post = cd.cdnlgssm_smoother(params_from(mdl), y, t[..., None])
+    assert _ffi.lib().cdkf_last_kernel().decode().startswith("ekf_smoother_wave_l96_kernel<double")
+    ref = o.ekf_smoother(mdl, t[:2], y[:2])
+    for k in ("filtered_means", "filtered_covariances", "smoothed_means", "smoothed_covariances"):
+        assert relerr(getattr(post, k)[:2], ref[k]) < 1e-9, k
+    np.testing.assert_allclose(post.marginal_loglik[:2], ref["marginal_loglik"], rtol=1e-11)
+    assert np.all(np.isfinite(post.smoothed_covariances))
+
+
 def test_lorenz96_d40_backward_sweep_kernels_agree(hip_lib, monkeypatch):
     """Config 4's smoother: the wavefront-per-trajectory backward sweep (ekf_smoother_wave_l96_kernel) against the oracle at a
     batch that does not fill its last workgroup, against the workgroup kernel it replaced (CDKF_WG_BACKWARD=1), in fp32, and at
