@@ -254,6 +254,24 @@ def test_mlp_loglik_gradient_reverse_sweep(hip_lib, d, m, h):
     assert np.abs(flat32b - g_ref2).max() < 2e-2 * scale2
 
 
+def test_c5_long_scan_value_and_gradient_against_the_oracle(hip_lib):
+    """BASELINE config 5's shape (d = 8, m = 4, 2 x 64 tanh MLP, the reference's default state_order='second') over a long scan:
+    log-likelihood and all 5 256 weight gradients of the first of four trajectories against the oracle's discrete adjoint, 400
+    irregular observations at the benchmark's time density -- the reverse sweep's accumulators must not lose digits over the scan."""
+    rng = np.random.default_rng(55)
+    mdl = mlp_model(rng)
+    N, T = 4, 400
+    u = rng.uniform(0.0, 1.0, size=(N, T))
+    cs = np.cumsum(u, axis=1)
+    t = cs / cs[:, -1:] * (0.005 * T)
+    y = rng.standard_normal((N, T, 4))
+    ll, g = cd.cdnlgssm_loglik_and_grad(params_from(mdl), y, t[..., None])
+    ll_ref, g_ref = o.ekf_loglik_grad_adjoint(mdl, t[:1], y[:1], state_order="second")
+    np.testing.assert_allclose(ll[:1], ll_ref, rtol=1e-11)
+    flat = np.concatenate([np.asarray(a).reshape(N, -1) for a in g], axis=-1)[:1]
+    assert np.abs(flat - g_ref).max() < 1e-9 * np.abs(g_ref).max()
+
+
 def test_reverse_sweep_slope_checkpoints_do_not_change_the_gradient(hip_lib, monkeypatch):
     """The forward sweep's stage-slope checkpoints (first two steps of every interval) against re-integration
     (CDKF_ADJ_CKPT_STEPS=0) and against four checkpointed steps: same gradient to rounding, on intervals of 1, 2, 3 and more
