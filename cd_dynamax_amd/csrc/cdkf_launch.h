@@ -43,6 +43,15 @@ template <typename R>
 int launch_ekf_grad_adjoint(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll,
                             R* grad, R* grad_model, int32_t* status, hipStream_t stream);
 bool adjoint_shape_available(const cdkf_model* mdl, const cdkf_opts* o);
+// lease of the per-process reverse-sweep workspace (launch_wg.hip): holds its lock from construction to destruction
+struct GradWorkspaceLease {
+  GradWorkspaceLease();
+  ~GradWorkspaceLease();
+  GradWorkspaceLease(const GradWorkspaceLease&) = delete;
+  GradWorkspaceLease& operator=(const GradWorkspaceLease&) = delete;
+  int reserve(size_t bytes, hipStream_t stream, void** p);  // grow-only; waits for an earlier launch that still uses it
+  int done(hipStream_t stream);                             // behind the last kernel that reads the workspace
+};
 
 // linear model, smoother type 1 (launch_wg.hip, cdkf_rts1_kernels.h); cross (optional) has the strides of sP, entries 0..T-2
 template <typename R>

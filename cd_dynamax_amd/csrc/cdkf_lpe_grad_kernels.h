@@ -1,0 +1,373 @@
+// cdkf_lpe_grad_kernels.h -- reverse sweep of the Lorenz-63 log-likelihood gradient (d ll / d (sigma, rho, beta), the drift block
+// of jax.value_and_grad(_loss_fn), ssm_temissions.py:550-568) on the sixteen-lanes-per-trajectory grid of cdkf_lpe_kernels.h.
+//
+// The forward-sensitivity kernel (ekf_grad_reg_kernel) carries a lane per (trajectory, parameter): 4096 x 3 lanes are 192
+// wavefronts on 1024 SIMDs.  Here the forward sweep is filter_lpe_kernel itself (all four moment arrays into the reverse sweep's
+// workspace) and the backward sweep keeps the same grid -- lane (i, j) of a 16-lane row owns the cotangent of P_ij, column 3 the
+// cotangent of the mean:
+//
+// * predict, reversed: the interval is re-integrated from the filtered moments at k-1 (the start of every Runge-Kutta step is parked
+//   in LDS, one value per lane); per step the six stage values are replayed and the stages reversed.  The cotangent of a slope
+//   (lam, Lam) gives  Pbar = F^T Lam + Lam F,  xbar = F^T lam + dF/dm : 2 Lam P,  thetabar += df/dtheta . lam + dF/dtheta : 2 Lam P.
+//   The first two terms are the forward right-hand side with F transposed: the SAME fetch pattern (column entries from the rows
+//   i+1, i+2, i+3; row entries from the columns (j+1) % 3, (j+2) % 3) with the per-lane constants of F^T.  F is affine in the mean
+//   with five non-constant entries, so the contractions with 2 Lam P need only a handful of products Lam_kj P_lj: a covariance lane
+//   forms the one its ROW contributes from the row fetches it already holds and the three lanes of the row add up in the row's mean
+//   lane (quad permutations); the parameter sums stay distributed over the lanes -- row 0 collects
+//   d/d sigma, row 1 d/d rho, row 2 d/d beta -- and are added up once, after the sweep.
+// * update, reversed: every lane gathers the predicted moments, the observation and the cotangents (row_newbcast) and evaluates the
+//   3 x 3 algebra of the reverse update redundantly, then keeps its own entry.
+//
+// The arithmetic follows oracle/cdkf_oracle.py::ekf_loglik_grad_adjoint (H = I, symmetric R, num_iter 1); grad(div f) = 0 for this
+// drift, so state_order 'first' and 'second' coincide.
+#pragma once
+#include "cdkf_lpe_kernels.h"
+
+namespace cdkf {
+
+constexpr int kLpeGradCap = 64;  // step starts of one interval kept in LDS (longer intervals re-integrate from the last one kept)
+
+// per-lane constants of the reversed right-hand side
+template <typename R>
+struct LpeAdjRhs {
+  R g0;                      // F_ii + F_jj (covariance lanes) / F_ii (mean lanes)
+  R c1, c3, cA, cB;          // constant parts of F_{i+1,i}, F_{i+3,i} (rows mod 4), F_{(j+1)%3,j}, F_{(j+2)%3,j}
+  R gx1, gx3, gxA, gxB;      // their coefficients of x
+  R gy2, gyB;                // of y
+  R gz1, gzA;                // of z
+  R k12, k13, k21, k32;      // the row's share of dF/dm : 2 Lam P (see stage())
+  R t0, t1, t3;              // the lane's share of the parameter contraction
+  R mm;                      // 1 on the mean lanes
+  CDKF_DEV void init(int i, int j, R sigma, R rho, R beta) {
+    const bool cov = i < 3 && j < 3, mean = i < 3 && j == 3;
+    const int r = (cov || mean) ? i : 3, c = cov ? j : 3;
+    // F = [[-s, s, 0], [rho - z, -1, -x], [y, x, -b]].  Row slots of row r hold F_{(r+s)%4, r}:
+    //   r = 0: F10 = rho - z, F20 = y;  r = 1: F21 = x, F01 = s (slot 3);  r = 2: F12 = -x (slot 3)
+    c1 = (r == 0) ? rho : R(0);
+    gz1 = (r == 0) ? R(-1) : R(0);
+    gx1 = (r == 1) ? R(1) : R(0);
+    gy2 = (r == 0) ? R(1) : R(0);
+    c3 = (r == 1) ? sigma : R(0);
+    gx3 = (r == 2) ? R(-1) : R(0);
+    // column slots of column c: A = F_{(c+1)%3, c}: F10 = rho - z, F21 = x, F02 = 0;  B = F_{(c+2)%3, c}: F20 = y, F01 = s, F12 = -x
+    cA = (c == 0) ? rho : R(0);
+    gzA = (c == 0) ? R(-1) : R(0);
+    gxA = (c == 1) ? R(1) : R(0);
+    gyB = (c == 0) ? R(1) : R(0);
+    cB = (c == 1) ? sigma : R(0);
+    gxB = (c == 2) ? R(-1) : R(0);
+    const R diag[4] = {-sigma, R(-1), -beta, R(0)};
+    g0 = cov ? diag[i] + diag[j] : (mean ? diag[i] : R(0));
+    // dF/dx : G = G21 - G12, dF/dy : G = G20, dF/dz : G = -G10 with G = 2 Lam P, G_ab = 2 sum_j Lam_aj P_bj:
+    //   row 0 forms 2 (Lam_2j P_1j - Lam_1j P_2j), row 1  2 Lam_2j P_0j, row 2  -2 Lam_1j P_0j  (column j = the lane's)
+    k12 = (cov && i == 0) ? R(-2) : R(0);
+    k21 = (cov && i == 0) ? R(2) : R(0);
+    k13 = (cov && i == 1) ? R(2) : R(0);
+    k32 = (cov && i == 2) ? R(-2) : R(0);
+    // d/d sigma: lam_0 (y - x) + G01 - G00 (row 0); d/d rho: lam_1 x + G10 (row 1); d/d beta: -lam_2 z - G22 (row 2)
+    const R w = cov ? R(2) : (mean ? R(1) : R(0));
+    t0 = (r == 0 || r == 2) ? -w : R(0);
+    t1 = (r == 0) ? w : R(0);
+    t3 = (r == 1) ? w : R(0);
+    mm = mean ? R(1) : R(0);
+  }
+  // cotangent of the stage VALUE (this lane's entry) from the cotangent L of the stage SLOPE; Ys: the stage value, p1..p3 its entries
+  // in the rows i+1, i+2, i+3 (the fetches the replayed forward right-hand side made).  th accumulates the lane's share of the
+  // parameter gradient.
+  CDKF_DEV R stage(const R L, const R Ys, const R p1, const R p2, const R p3, R& th) const {
+    const R d1 = lpe_dpp<0x120 + 12>(L), d2 = lpe_dpp<0x120 + 8>(L), d3 = lpe_dpp<0x120 + 4>(L);  // rows i+1, i+2, i+3
+    const R r1 = lpe_dpp<0xC9>(L), r2 = lpe_dpp<0xD2>(L);                                          // columns (j+1) % 3, (j+2) % 3
+    R acc = g0 * L;
+    acc = rfma(c1, d1, acc);
+    acc = rfma(c3, d3, acc);
+    acc = rfma(cA, r1, acc);
+    acc = rfma(cB, r2, acc);
+    const R X = rfma(gxB, r2, rfma(gxA, r1, rfma(gx3, d3, gx1 * d1)));
+    const R Y = rfma(gyB, r2, gy2 * d2);
+    const R Z = rfma(gzA, r1, gz1 * d1);
+    // the row's three products (zero on the mean lane), added up over the quad and kept by the mean lane (mm: 1 there, 0 elsewhere)
+    const R msg = rfma(d3, k32 * p2, rfma(d2, k21 * p1, d1 * rfma(k13, p3, k12 * p2)));
+    const R h = msg + lpe_dpp<0xB1>(msg);  // quad_perm [1,0,3,2]
+    const R q4 = h + lpe_dpp<0x4E>(h);     // quad_perm [2,3,0,1]
+    acc = lpe_fmac_bcast<3>(acc, Ys, X);   // (Ys was written by the replay, long before: see lpe_fmac_bcast)
+    acc = lpe_fmac_bcast<7>(acc, Ys, Y);
+    acc = lpe_fmac_bcast<11>(acc, Ys, Z);
+    acc = rfma(mm, q4, acc);
+    th = rfma(L, rfma(t3, p3, rfma(t1, p1, t0 * Ys)), th);
+    return acc;
+  }
+};
+
+// The forward right-hand side (LpeRhs::eval) that also hands out its row fetches of v
+template <typename R>
+CDKF_DEV R lpe_eval_keep(const LpeRhs<R, false>& c, const R v, R& d1, R& d2, R& d3) {
+  d1 = lpe_dpp<0x120 + 12>(v);
+  d2 = lpe_dpp<0x120 + 8>(v);
+  d3 = lpe_dpp<0x120 + 4>(v);
+  if constexpr (sizeof(R) == 4) {
+    return c.eval(v);  // (32-bit: the fetches are operands of the multiply-adds there)
+  } else {
+    const R r1 = lpe_dpp<0xC9>(v), r2 = lpe_dpp<0xD2>(v);
+    R acc = rfma(c.g0, v, c.q);
+    acc = rfma(c.c1i, d1, acc);
+    acc = rfma(c.c3i, d3, acc);
+    acc = rfma(c.cAj, r1, acc);
+    acc = rfma(c.cBj, r2, acc);
+    const R X = rfma(c.gxBj, r2, rfma(c.gxAj, r1, rfma(c.gx3i, d3, c.gx1i * d1)));
+    const R Y = rfma(c.gyAj, r1, c.gy2i * d2);
+    const R Z = rfma(c.gzBj, r2, c.gz3i * d3);
+    acc = lpe_fmac_bcast<3>(acc, v, X);
+    acc = lpe_fmac_bcast<7>(acc, v, Y);
+    acc = lpe_fmac_bcast<11>(acc, v, Z);
+    return acc;
+  }
+}
+
+// One Dormand-Prince step from y over dt, reversed: vb (cotangent of the step's result) becomes the cotangent of y.
+template <typename R>
+CDKF_DEV void lpe_step_adj(const LpeRhs<R, false>& rhs, const LpeAdjRhs<R>& adj, const Dp5V<R>& C, const R y, const R dt, R& vb,
+                           R& th) {
+  R p[6][3];  // row fetches of the six stage values
+  const R k1 = dt * lpe_eval_keep(rhs, y, p[0][0], p[0][1], p[0][2]);
+  const R Y2 = rfma(C.a21, k1, y);
+  const R k2 = dt * lpe_eval_keep(rhs, Y2, p[1][0], p[1][1], p[1][2]);
+  const R Y3 = rfma(C.a32, k2, rfma(C.a31, k1, y));
+  const R k3 = dt * lpe_eval_keep(rhs, Y3, p[2][0], p[2][1], p[2][2]);
+  const R Y4 = rfma(C.a43, k3, rfma(C.a42, k2, rfma(C.a41, k1, y)));
+  const R k4 = dt * lpe_eval_keep(rhs, Y4, p[3][0], p[3][1], p[3][2]);
+  const R Y5 = rfma(C.a54, k4, rfma(C.a53, k3, rfma(C.a52, k2, rfma(C.a51, k1, y))));
+  const R k5 = dt * lpe_eval_keep(rhs, Y5, p[4][0], p[4][1], p[4][2]);
+  const R Y6 = rfma(C.a65, k5, rfma(C.a64, k4, rfma(C.a63, k3, rfma(C.a62, k2, rfma(C.a61, k1, y)))));
+  p[5][0] = lpe_dpp<0x120 + 12>(Y6);
+  p[5][1] = lpe_dpp<0x120 + 8>(Y6);
+  p[5][2] = lpe_dpp<0x120 + 4>(Y6);
+  // cotangent of slope s: dt (b_s vb + sum_{q > s} a_qs Yb_q)
+  const R Yb6 = adj.stage(dt * (C.b6 * vb), Y6, p[5][0], p[5][1], p[5][2], th);
+  const R Yb5 = adj.stage(dt * rfma(C.a65, Yb6, C.b5 * vb), Y5, p[4][0], p[4][1], p[4][2], th);
+  const R Yb4 = adj.stage(dt * rfma(C.a64, Yb6, rfma(C.a54, Yb5, C.b4 * vb)), Y4, p[3][0], p[3][1], p[3][2], th);
+  const R Yb3 = adj.stage(dt * rfma(C.a63, Yb6, rfma(C.a53, Yb5, rfma(C.a43, Yb4, C.b3 * vb))), Y3, p[2][0], p[2][1], p[2][2], th);
+  const R Yb2 =
+      adj.stage(dt * rfma(C.a62, Yb6, rfma(C.a52, Yb5, rfma(C.a42, Yb4, C.a32 * Yb3))), Y2, p[1][0], p[1][1], p[1][2], th);
+  const R Yb1 = adj.stage(dt * rfma(C.a61, Yb6, rfma(C.a51, Yb5, rfma(C.a41, Yb4, rfma(C.a31, Yb3, rfma(C.a21, Yb2, C.b1 * vb))))), y,
+                          p[0][0], p[0][1], p[0][2], th);
+  vb += ((Yb1 + Yb2) + (Yb3 + Yb4)) + (Yb5 + Yb6);
+}
+
+// two wait states behind the producers of a, b, c: what a row_newbcast read of them by lpe_fmac_bcast needs (see there)
+template <typename R>
+CDKF_DEV void lpe_fence3(R& a, R& b, R& c) {
+  asm volatile("s_nop 1" : "+v"(a), "+v"(b), "+v"(c));
+}
+// (j == 0) ? a0 : (j == 1) ? a1 : a2
+template <typename R>
+CDKF_DEV R lpe_sel3(int j, R a0, R a1, R a2) {
+  return (j == 0) ? a0 : ((j == 1) ? a1 : a2);
+}
+
+// The measurement update at one observation, reversed (H = I, symmetric R, one iteration): vp = the grid of the PREDICTED moments
+// with the observation in row 3, vb = the cotangents of the filtered moments; returns this lane's cotangent of the predicted
+// moments (the log-likelihood term of the observation included).
+//
+// The oracle's reverse update (ekf_loglik_grad_adjoint: vbar, Kbar, Sbar, Ubar) collapses, for H = I, to the Joseph form: with
+// A = (S + eps I)^-1, X = A P (the transposed gain), J = I - X = A (R + eps I), u = A v, w = S^-1 v and S A = I - eps A,
+//     Pbar <- J Pbar J^T + sym((J mbar) u^T) + 2 eps sym(J Pbar X^T A) + w w^T / 2 - S^-1 / 2,      mbar <- J mbar + w
+// -- the same numbers to rounding (the eps term is kept: it is 1e-9 of the first, which is the tolerance of the parity tests;
+// S^-1 = A + eps A^2 up to eps^2 = 1e-18).  As in lpe_update the rows of the grid work on DIFFERENT rows of these matrices with one
+// instruction stream: row i solves (S + eps I) x = e_i (one factorisation, per-lane right-hand sides) and carries row i of A, J,
+// J Pbar, ...; the rows of another grid row arrive as row_newbcast operands, entries of the lane's own column by selection, and the
+// transposed entries of the two non-symmetric terms by the fetches of lpe_update's symmetrisation in both directions.
+template <typename R, typename Args>
+CDKF_DEV R lpe_update_adj(const Args& a, const R vp, const R vb, const int i, const int j) {
+  const int l = 4 * i + j;
+  const R Pg[6] = {lpe_bcast<0>(vp), lpe_bcast<1>(vp), lpe_bcast<2>(vp), lpe_bcast<5>(vp), lpe_bcast<6>(vp), lpe_bcast<10>(vp)};
+  const R m[3] = {lpe_bcast<3>(vp), lpe_bcast<7>(vp), lpe_bcast<11>(vp)};
+  const R yo[3] = {lpe_bcast<12>(vp), lpe_bcast<13>(vp), lpe_bcast<14>(vp)};
+  // the cotangent of the filtered covariance: its upper triangle (symmetric up to rounding; the oracle averages the two)
+  const R Bg[6] = {lpe_bcast<0>(vb), lpe_bcast<1>(vb), lpe_bcast<2>(vb), lpe_bcast<5>(vb), lpe_bcast<6>(vb), lpe_bcast<10>(vb)};
+  const R mb[3] = {lpe_bcast<3>(vb), lpe_bcast<7>(vb), lpe_bcast<11>(vb)};
+  constexpr R eps = R(1e-9);
+  R S[3][3], v[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+#pragma unroll
+    for (int c = 0; c <= r; ++c) S[r][c] = Pg[sidx<3>(r, c)] + a.Rm[r][c];
+    v[r] = yo[r] - m[r];
+  }
+  // Cholesky factor of S + eps I (chol_lower's operations with lpe_rsqrt), then row i of its inverse
+  const R i0 = lpe_rsqrt(S[0][0] + eps);
+  const R L10 = S[1][0] * i0, L20 = S[2][0] * i0;
+  const R i1 = lpe_rsqrt(rfma(-L10, L10, S[1][1] + eps));
+  const R L21 = rfma(-L20, L10, S[2][1]) * i1;
+  const R i2 = lpe_rsqrt(rfma(-L21, L21, rfma(-L20, L20, S[2][2] + eps)));
+  const R b0 = (i == 0) ? R(1) : R(0), b1 = (i == 1) ? R(1) : R(0), b2 = (i == 2) ? R(1) : R(0);
+  const R f0 = b0 * i0;
+  const R f1 = rfma(-L10, f0, b1) * i1;
+  const R f2 = rfma(-L21, f1, rfma(-L20, f0, b2)) * i2;
+  R Ai[3];
+  Ai[2] = f2 * i2;
+  Ai[1] = rfma(-L21, Ai[2], f1) * i1;
+  Ai[0] = rfma(-L20, Ai[2], rfma(-L10, Ai[1], f0)) * i0;
+  // row i of J = A (R + eps I), J mbar, J Pbar
+  R Ji[3], JPi[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    Ji[k] = rfma(Ai[2], (k == 2) ? a.Rm[2][k] + eps : a.Rm[2][k],
+                 rfma(Ai[1], (k == 1) ? a.Rm[1][k] + eps : a.Rm[1][k], Ai[0] * ((k == 0) ? a.Rm[0][k] + eps : a.Rm[0][k])));
+  }
+  const R ui = rfma(Ai[2], v[2], rfma(Ai[1], v[1], Ai[0] * v[0]));
+  const R Jmi = rfma(Ji[2], mb[2], rfma(Ji[1], mb[1], Ji[0] * mb[0]));
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+    JPi[k] = rfma(Ji[2], Bg[sidx<3>(2, k)], rfma(Ji[1], Bg[sidx<3>(1, k)], Ji[0] * Bg[sidx<3>(0, k)]));
+  // row i of A^2 (for S^-1 = A + eps A^2) and of J Pbar J^T: the rows c = 0, 1, 2 of A / J from the lanes 4 c
+  lpe_fence3(Ji[0], Ji[1], Ji[2]);
+  R A2[3] = {R(0), R(0), R(0)}, n[3] = {R(0), R(0), R(0)};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    A2[k] = lpe_fmac_bcast<0>(A2[k], Ai[k], Ai[0]);
+    A2[k] = lpe_fmac_bcast<4>(A2[k], Ai[k], Ai[1]);
+    A2[k] = lpe_fmac_bcast<8>(A2[k], Ai[k], Ai[2]);
+    n[0] = lpe_fmac_bcast<0>(n[0], Ji[k], JPi[k]);
+    n[1] = lpe_fmac_bcast<4>(n[1], Ji[k], JPi[k]);
+    n[2] = lpe_fmac_bcast<8>(n[2], Ji[k], JPi[k]);
+  }
+  R Si[3], Wi[3] = {R(0), R(0), R(0)};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) Si[k] = rfma(eps, A2[k], Ai[k]);
+  const R wi = rfma(Si[2], v[2], rfma(Si[1], v[1], Si[0] * v[0]));
+  // E = J Pbar X^T = J Pbar - J Pbar J^T (row i), W = E A
+  const R E0 = JPi[0] - n[0], E1 = JPi[1] - n[1], E2 = JPi[2] - n[2];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    Wi[k] = lpe_fmac_bcast<0>(Wi[k], Ai[k], E0);
+    Wi[k] = lpe_fmac_bcast<4>(Wi[k], Ai[k], E1);
+    Wi[k] = lpe_fmac_bcast<8>(Wi[k], Ai[k], E2);
+  }
+  // the entries of the lane's column j; u_j and w_j belong to grid row j
+  const R nj = lpe_sel3(j, n[0], n[1], n[2]), Wij = lpe_sel3(j, Wi[0], Wi[1], Wi[2]), Sij = lpe_sel3(j, Si[0], Si[1], Si[2]);
+  const R uj = lpe_sel3(j, lpe_bcast<0>(ui), lpe_bcast<4>(ui), lpe_bcast<8>(ui));
+  const R wj = lpe_sel3(j, lpe_bcast<0>(wi), lpe_bcast<4>(wi), lpe_bcast<8>(wi));
+  // Z_ij = (J mbar)_i u_j / 2 + eps W_ij and its transpose partner's (lanes 4 <-> 1, 9 <-> 6: three apart; 8 <-> 2: six apart)
+  const R Z = rfma(eps, Wij, R(0.5) * (Jmi * uj));
+  const R up3 = lpe_dpp<0x110 + 3>(Z), up6 = lpe_dpp<0x110 + 6>(Z);  // row_shr: from the lane 3 / 6 below
+  const R dn3 = lpe_dpp<0x100 + 3>(Z), dn6 = lpe_dpp<0x100 + 6>(Z);  // row_shl: from the lane 3 / 6 above
+  R Zt = Z;
+  Zt = (l == 4 || l == 9) ? up3 : Zt;
+  Zt = (l == 8) ? up6 : Zt;
+  Zt = (l == 1 || l == 6) ? dn3 : Zt;
+  Zt = (l == 2) ? dn6 : Zt;
+  const R pn = nj + ((Z + Zt) + R(0.5) * rfma(wi, wj, -Sij));
+  return (j == 3) ? Jmi + wi : pn;
+}
+
+// grad [N, 3].  The forward sweep (filter_lpe_kernel, OUT = 1) has written fm, fP, pm, pP with the strides of `a`.
+template <typename R>
+__global__ __launch_bounds__(64) void grad_lpe_l63_kernel(const RegArgs<R, 3, 3, DriftLorenz63<R, 3>> a, R* __restrict__ grad) {
+  constexpr int D = 3;
+  __shared__ R starts[kLpeGradCap][64];
+  const int lane = threadIdx.x, l = lane & 15, i = l >> 2, j = l & 3;
+  constexpr int sh = lpe_xcd_shift<R>();
+  const long b = blockIdx.x;
+  const long grp = ((b >> (3 + sh)) << (3 + sh)) + ((b & 7) << sh) + ((b >> 3) & ((1 << sh) - 1));
+  if (grp * 4 >= a.N) return;
+  const long n_raw = grp * 4 + (lane >> 4);
+  const bool live = n_raw < a.N;
+  const long n = live ? n_raw : a.N - 1;
+  const bool cov = i < 3 && j < 3, mean = i < 3 && j == 3;
+
+  LpeRhs<R, false> rhs;
+  rhs.init(i, j, a.drift.sigma, a.drift.rho, a.drift.beta, a.LQL);
+  LpeAdjRhs<R> adj;
+  adj.init(i, j, a.drift.sigma, a.drift.rho, a.drift.beta);
+  const auto C = TabSel<R, false>::get(a);
+
+  // per-lane input streams.  `pin` row k: the predicted moments at observation k (array row k - 1), y_k (row 3), t_k (lane 15);
+  // `fin` row k: the filtered moments at k - 1, t_{k-1} (lane 15)
+  const R* pin;
+  const R* fin;
+  long stride, poff;  // poff: array row of `pin` for observation k is k - poff
+  if (cov) {
+    pin = a.pP + n * a.P_sn + (i * D + j) * a.P_si;
+    fin = a.fP + n * a.P_sn + (i * D + j) * a.P_si;
+    stride = a.P_sk;
+    poff = 1;
+  } else if (mean) {
+    pin = a.pm + n * a.m_sn + i * a.m_si;
+    fin = a.fm + n * a.m_sn + i * a.m_si;
+    stride = a.m_sk;
+    poff = 1;
+  } else if (j < 3) {
+    pin = a.y + n * a.y_sn + j * a.y_si;
+    fin = pin;
+    stride = a.y_sk;
+    poff = 0;
+  } else {
+    pin = a.t + n * a.t_sn;
+    fin = pin;
+    stride = a.t_sk;
+    poff = 0;
+  }
+  auto prow = [&](long k) { const long r = k - poff; return pin[(r > 0 ? r : 0) * stride]; };
+  auto frow = [&](long k) { const long r = k - 1; return fin[(r > 0 ? r : 0) * stride]; };
+  const R own0 = cov ? a.P0[sidx<D>(i, j < 3 ? j : 0)] : (mean ? a.m0[i < 3 ? i : 0] : R(0));
+
+  R vb = R(0), th = R(0);
+  R pv = prow(a.T - 1), fv = frow(a.T - 1);
+  for (long k = a.T - 1; k >= 0; --k) {
+    R vp = pv;
+    const R vf = fv;
+    if (k >= 1) {  // next observation's rows, a step ahead of their use
+      pv = prow(k - 1);
+      fv = frow(k - 1);
+    }
+    if (k == 0 && i < 3) vp = own0;
+    vb = lpe_update_adj(a, vp, vb, i, j);
+    if (k == 0) break;
+    // ---- the predict from k-1 to k, reversed ----
+    const R t1 = lpe_bcast<15>(vp), t0 = lpe_bcast<15>(vf);
+    R y = (i == 3) ? R(0) : vf;
+    // forward: the start of every step (and its size, in lane 15's slot)
+    R tprev = t0, tnext = rmin(t0 + a.dt0, t1);
+    int S = 0;
+    while (tprev < t1) {
+      const R dt = tnext - tprev;
+      if (S < kLpeGradCap) starts[S][lane] = (l == 15) ? dt : y;
+      tprev = rmin(tnext, t1);
+      const R tn = tnext + a.dt0;
+      tnext = (tn > t1 - Tol<R>::v) ? t1 : tn;
+      ++S;
+      if (tprev < t1 && S < kLpeGradCap) lpe_step<R>(y, dt, rhs, C);
+    }
+    for (int s = S - 1; s >= 0; --s) {
+      R ys, dt;
+      if (s < kLpeGradCap) {
+        const R raw = starts[s][lane];
+        dt = lpe_bcast<15>(raw);
+        ys = (i == 3) ? R(0) : raw;
+      } else {  // beyond the window: from the last start kept
+        R tp = t0, tq = rmin(t0 + a.dt0, t1);
+        auto advance = [&] {
+          tp = rmin(tq, t1);
+          const R tn = tq + a.dt0;
+          tq = (tn > t1 - Tol<R>::v) ? t1 : tn;
+        };
+        for (int q = 0; q < kLpeGradCap - 1; ++q) advance();
+        const R raw = starts[kLpeGradCap - 1][lane];
+        ys = (i == 3) ? R(0) : raw;
+        for (int q = kLpeGradCap - 1; q < s; ++q) {
+          lpe_step<R>(ys, tq - tp, rhs, C);
+          advance();
+        }
+        dt = tq - tp;
+      }
+      lpe_step_adj<R>(rhs, adj, C, ys, dt, vb, th);
+    }
+  }
+  // row p holds the shares of parameter p
+  const R g0 = (lpe_bcast<0>(th) + lpe_bcast<1>(th)) + (lpe_bcast<2>(th) + lpe_bcast<3>(th));
+  const R g1 = (lpe_bcast<4>(th) + lpe_bcast<5>(th)) + (lpe_bcast<6>(th) + lpe_bcast<7>(th));
+  const R g2 = (lpe_bcast<8>(th) + lpe_bcast<9>(th)) + (lpe_bcast<10>(th) + lpe_bcast<11>(th));
+  if (live && l < 3) grad[n * 3 + l] = (l == 0) ? g0 : ((l == 1) ? g1 : g2);
+}
+
+}  // namespace cdkf

@@ -1,6 +1,7 @@
 // launch_grad.hip -- log-likelihood + gradient w.r.t. the drift parameters (cdkf_grad_kernels.h): shape registry and launch.
 #include "cdkf_grad_kernels.h"
 #include "cdkf_launch.h"
+#include "cdkf_lpe_grad_kernels.h"
 
 // X(drift_kind, DriftTemplate, D, M)
 #define CDKF_GRAD_SHAPES(X)                   \
@@ -47,12 +48,51 @@ static int run_grad(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_
   return CDKF_OK;
 }
 
+// Small Lorenz-63 batches, H = I: forward sweep + reverse sweep on the sixteen-lanes-per-trajectory grid (cdkf_lpe_grad_kernels.h).
+// CDKF_NO_LPE_GRAD=1 keeps the forward-sensitivity kernel (A/B timing, tests).  handled = false: not this kernel's case.
+template <typename R>
+static int try_lpe_grad(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll, R* grad,
+                        int32_t* status, hipStream_t stream, bool* handled) {
+  *handled = false;
+  static const bool off = [] { const char* e = std::getenv("CDKF_NO_LPE_GRAD"); return e && e[0] == '1'; }();
+  if (off || mdl->drift_kind != CDKF_DRIFT_LORENZ63 || mdl->state_dim != 3 || mdl->emission_dim != 3 || !emission_is_selection(mdl) ||
+      o->num_iter != 1 || o->forecast || o->solver != CDKF_SOLVER_DOPRI5 || o->adaptive || o->state_order == CDKF_ORDER_ZEROTH ||
+      !lpe_batch_is_small(N) || N < 1 || T < 1 || !y)
+    return CDKF_OK;
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < r; ++c)
+      if (R(mdl->R[r * 3 + c]) != R(mdl->R[c * 3 + r])) return CDKF_OK;
+  // the forward sweep's four moment arrays, [T, N, comp] (a wavefront's stores and loads are contiguous pieces)
+  cdkf_opts of = *o;
+  of.layout_in = (o->layout_in == CDKF_LAYOUT_SAME) ? o->layout : o->layout_in;
+  of.layout = CDKF_LAYOUT_TN;
+  const size_t nm = (size_t)N * T * 3, nP = nm * 3;
+  GradWorkspaceLease ws;
+  void* wp = nullptr;
+  if (int rc = ws.reserve(2 * (nm + nP) * sizeof(R), stream, &wp)) return rc;
+  R* w = (R*)wp;
+  RegArgs<R, 3, 3, DriftLorenz63<R, 3>> a;
+  fill_reg_args(a, mdl, &of, N, T, t, y, ll, w, w + nm, w + nm + nP, w + 2 * nm + nP, status);
+  if (!try_lpe(a, mdl, &of, stream)) return CDKF_OK;
+  CDKF_HIP_CHECK(hipGetLastError());
+  *handled = true;
+  note_kernel("grad_lpe_l63_kernel<%s>", real_name<R>());
+  hipLaunchKernelGGL((grad_lpe_l63_kernel<R>), dim3(lpe_blocks<R>(N)), dim3(64), 0, stream, a, grad);
+  CDKF_HIP_CHECK(hipGetLastError());
+  return ws.done(stream);
+}
+
 template <typename R>
 int launch_ekf_grad(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll,
                     R* grad, R* grad_model, int32_t* status, hipStream_t stream) {
   // drift parameters only: forward sensitivities where a register-resident kernel exists (one sweep, no workspace);
   // otherwise, and whenever the model block is requested, the forward + reverse sweep pair
   const bool sens = !grad_model && sens_shape_available(mdl, o);
+  if (sens) {
+    bool handled = false;
+    const int rc = try_lpe_grad<R>(mdl, o, N, T, t, y, ll, grad, status, stream, &handled);
+    if (rc || handled) return rc;
+  }
   if (!sens && adjoint_shape_available(mdl, o))
     return launch_ekf_grad_adjoint<R>(mdl, o, N, T, t, y, ll, grad, grad_model, status, stream);
   if (!sens) {

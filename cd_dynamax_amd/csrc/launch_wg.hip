@@ -336,6 +336,19 @@ static int workspace_reserve(AdjWorkspace& ws, size_t bytes, hipStream_t stream)
   return CDKF_OK;
 }
 
+GradWorkspaceLease::GradWorkspaceLease() { g_adj_mutex.lock(); }
+GradWorkspaceLease::~GradWorkspaceLease() { g_adj_mutex.unlock(); }
+int GradWorkspaceLease::reserve(size_t bytes, hipStream_t stream, void** p) {
+  if (int rc = workspace_reserve(g_adj_ws, bytes, stream)) return rc;
+  *p = g_adj_ws.p;
+  return CDKF_OK;
+}
+int GradWorkspaceLease::done(hipStream_t stream) {
+  CDKF_HIP_CHECK(hipEventRecord(g_adj_ws.done, stream));
+  g_adj_ws.in_flight = true;
+  return CDKF_OK;
+}
+
 bool adjoint_shape_available(const cdkf_model* mdl, const cdkf_opts* o) {
   if (!wave8_shape(mdl) || !wg_shape_available(mdl, 8) || o->num_iter != 1 || o->forecast) return false;
   if (o->state_order == CDKF_ORDER_ZEROTH) return false;

@@ -15,8 +15,13 @@ for dtype, sfx in ((np.float64, "f64"), (np.float32, "f32")):
     rng = np.random.default_rng(0)
     N, T = 4096, 1000
     mdl = o.lorenz63_model(3)
-    t = o.irregular_times(rng, N, T, 0.01).astype(dtype)
-    y = rng.standard_normal((N, T, 3)).astype(dtype) * 5
+    if len(sys.argv) > 1 and sys.argv[1] == "bench":  # the benchmark's batch (every gap <= dt0: one step per interval)
+        import bench
+        t, y = bench.make_batch(7, N, T)
+        t, y = t.astype(dtype), y.astype(dtype)
+    else:
+        t = o.irregular_times(rng, N, T, 0.01).astype(dtype)
+        y = rng.standard_normal((N, T, 3)).astype(dtype) * 5
     mb = _model_block(params_from(mdl)); opts = _opts(cd.EKFHyperParams(), 1); opts.layout = _ffi.LAYOUT_TCN
     tt = np.ascontiguousarray(t.T); yy = np.ascontiguousarray(y.transpose(1, 2, 0))
     def dev(a):
