@@ -281,87 +281,90 @@ __global__ __launch_bounds__(64) void grad_lpe_l63_kernel(const RegArgs<R, 3, 3,
   adj.init(i, j, a.drift.sigma, a.drift.rho, a.drift.beta);
   const auto C = TabSel<R, false>::get(a);
 
-  // per-lane input streams.  `pin` row k: the predicted moments at observation k (array row k - 1), y_k (row 3), t_k (lane 15);
-  // `fin` row k: the filtered moments at k - 1, t_{k-1} (lane 15)
-  const R* pin;
-  const R* fin;
-  long stride, poff;  // poff: array row of `pin` for observation k is k - poff
+  // per-lane input streams, read backwards with running pointers.  `pp`: the predicted moments at observation k (array row k - 1),
+  // y_k (row 3), t_k (lane 15); `fp`: the filtered moments at k - 1, t_{k-1} (lane 15).  Both are loaded a whole step ahead.
+  const R* pp;
+  const R* fp;
+  long stride;
+  const long last = a.T - 1, lastm = last > 0 ? last - 1 : 0;
   if (cov) {
-    pin = a.pP + n * a.P_sn + (i * D + j) * a.P_si;
-    fin = a.fP + n * a.P_sn + (i * D + j) * a.P_si;
     stride = a.P_sk;
-    poff = 1;
+    pp = a.pP + n * a.P_sn + (i * D + j) * a.P_si + lastm * stride;
+    fp = a.fP + n * a.P_sn + (i * D + j) * a.P_si + lastm * stride;
   } else if (mean) {
-    pin = a.pm + n * a.m_sn + i * a.m_si;
-    fin = a.fm + n * a.m_sn + i * a.m_si;
     stride = a.m_sk;
-    poff = 1;
+    pp = a.pm + n * a.m_sn + i * a.m_si + lastm * stride;
+    fp = a.fm + n * a.m_sn + i * a.m_si + lastm * stride;
   } else if (j < 3) {
-    pin = a.y + n * a.y_sn + j * a.y_si;
-    fin = pin;
     stride = a.y_sk;
-    poff = 0;
+    pp = a.y + n * a.y_sn + j * a.y_si + last * stride;
+    fp = pp;
   } else {
-    pin = a.t + n * a.t_sn;
-    fin = pin;
     stride = a.t_sk;
-    poff = 0;
+    pp = a.t + n * a.t_sn + last * stride;
+    fp = a.t + n * a.t_sn + lastm * stride;
   }
-  auto prow = [&](long k) { const long r = k - poff; return pin[(r > 0 ? r : 0) * stride]; };
-  auto frow = [&](long k) { const long r = k - 1; return fin[(r > 0 ? r : 0) * stride]; };
+  const long stride3 = (i == 3) ? stride : 0;
   const R own0 = cov ? a.P0[sidx<D>(i, j < 3 ? j : 0)] : (mean ? a.m0[i < 3 ? i : 0] : R(0));
+  auto advance = [&](R& tp, R& tq, const R t1) {  // the fixed-step loop's next interval (lpe_integrate)
+    tp = rmin(tq, t1);
+    const R tn = tq + a.dt0;
+    tq = (tn > t1 - Tol<R>::v) ? t1 : tn;
+  };
 
   R vb = R(0), th = R(0);
-  R pv = prow(a.T - 1), fv = frow(a.T - 1);
-  for (long k = a.T - 1; k >= 0; --k) {
+  R pv = pp[0], fv = fp[0];
+  for (long k = last; k >= 0; --k) {
     R vp = pv;
     const R vf = fv;
-    if (k >= 1) {  // next observation's rows, a step ahead of their use
-      pv = prow(k - 1);
-      fv = frow(k - 1);
+    if (k >= 1) {  // the rows of observation k - 1 (array rows k - 2 of the moments: none for k = 1, the prior is an argument)
+      pp -= (k >= 2) ? stride : stride3;
+      if (k >= 2) fp -= stride;
+      pv = pp[0];
+      fv = fp[0];
     }
     if (k == 0 && i < 3) vp = own0;
     vb = lpe_update_adj(a, vp, vb, i, j);
     if (k == 0) break;
     // ---- the predict from k-1 to k, reversed ----
     const R t1 = lpe_bcast<15>(vp), t0 = lpe_bcast<15>(vf);
-    R y = (i == 3) ? R(0) : vf;
-    // forward: the start of every step (and its size, in lane 15's slot)
-    R tprev = t0, tnext = rmin(t0 + a.dt0, t1);
-    int S = 0;
-    while (tprev < t1) {
-      const R dt = tnext - tprev;
-      if (S < kLpeGradCap) starts[S][lane] = (l == 15) ? dt : y;
-      tprev = rmin(tnext, t1);
-      const R tn = tnext + a.dt0;
-      tnext = (tn > t1 - Tol<R>::v) ? t1 : tn;
-      ++S;
-      if (tprev < t1 && S < kLpeGradCap) lpe_step<R>(y, dt, rhs, C);
-    }
-    for (int s = S - 1; s >= 0; --s) {
-      R ys, dt;
-      if (s < kLpeGradCap) {
-        const R raw = starts[s][lane];
-        dt = lpe_bcast<15>(raw);
-        ys = (i == 3) ? R(0) : raw;
-      } else {  // beyond the window: from the last start kept
-        R tp = t0, tq = rmin(t0 + a.dt0, t1);
-        auto advance = [&] {
-          tp = rmin(tq, t1);
-          const R tn = tq + a.dt0;
-          tq = (tn > t1 - Tol<R>::v) ? t1 : tn;
-        };
-        for (int q = 0; q < kLpeGradCap - 1; ++q) advance();
-        const R raw = starts[kLpeGradCap - 1][lane];
-        ys = (i == 3) ? R(0) : raw;
-        for (int q = kLpeGradCap - 1; q < s; ++q) {
-          lpe_step<R>(ys, tq - tp, rhs, C);
-          advance();
-        }
-        dt = tq - tp;
+    const R y0 = (i == 3) ? R(0) : vf;
+    R tp = t0, tq = rmin(t0 + a.dt0, t1);
+    const R dt_0 = tq - tp;
+    advance(tp, tq, t1);
+    if (tp < t1) {  // more than one Runge-Kutta step in this interval: the starts of the steps 1, 2, ... (and their sizes, in lane
+                    // 15's slot) are parked in LDS on the way forward
+      R y = y0;
+      lpe_step<R>(y, dt_0, rhs, C);
+      int S = 1;
+      while (tp < t1) {
+        const R dt = tq - tp;
+        if (S <= kLpeGradCap) starts[S - 1][lane] = (l == 15) ? dt : y;
+        advance(tp, tq, t1);
+        ++S;
+        if (tp < t1 && S <= kLpeGradCap) lpe_step<R>(y, dt, rhs, C);
       }
-      lpe_step_adj<R>(rhs, adj, C, ys, dt, vb, th);
+      for (int s = S - 1; s >= 1; --s) {
+        R ys, dt;
+        if (s <= kLpeGradCap) {
+          const R raw = starts[s - 1][lane];
+          dt = lpe_bcast<15>(raw);
+          ys = (i == 3) ? R(0) : raw;
+        } else {  // beyond the window: from the last start kept (step kLpeGradCap)
+          R up = t0, uq = rmin(t0 + a.dt0, t1);
+          for (int q = 0; q < kLpeGradCap; ++q) advance(up, uq, t1);
+          const R raw = starts[kLpeGradCap - 1][lane];
+          ys = (i == 3) ? R(0) : raw;
+          for (int q = kLpeGradCap; q < s; ++q) {
+            lpe_step<R>(ys, uq - up, rhs, C);
+            advance(up, uq, t1);
+          }
+          dt = uq - up;
+        }
+        lpe_step_adj<R>(rhs, adj, C, ys, dt, vb, th);
+      }
     }
+    lpe_step_adj<R>(rhs, adj, C, y0, dt_0, vb, th);
   }
   // row p holds the shares of parameter p
   const R g0 = (lpe_bcast<0>(th) + lpe_bcast<1>(th)) + (lpe_bcast<2>(th) + lpe_bcast<3>(th));
