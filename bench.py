@@ -235,7 +235,8 @@ def pmc_traffic(algorithmic_bytes, kernel_name):
 
 def value_and_grad(lib, blk, opts, N, T, t_d, y_d, ll, timer, stream, reps=5):
     """The SGD objective on the same resident batch: log-likelihood and its gradient w.r.t. (sigma, rho, beta) in one
-    sweep (cdkf_ekf_loglik_grad_f64_dev: forward sensitivities, a lane per (trajectory, parameter)).  Informational --
+    call (cdkf_ekf_loglik_grad_f64_dev: the forward sweep and a reverse sweep on the sixteen-lane grid; forward sensitivities,
+    a lane per (trajectory, parameter), with CDKF_NO_LPE_GRAD=1).  Informational --
     the headline metric stays the filter sweep."""
     from cd_dynamax_amd import _ffi
     from cd_dynamax_amd._ffi import DeviceArray

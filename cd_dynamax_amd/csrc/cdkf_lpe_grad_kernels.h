@@ -177,22 +177,21 @@ CDKF_DEV R lpe_sel3(int j, R a0, R a1, R a2) {
 // J Pbar, ...; the rows of another grid row arrive as row_newbcast operands, entries of the lane's own column by selection, and the
 // transposed entries of the two non-symmetric terms by the fetches of lpe_update's symmetrisation in both directions.
 template <typename R, typename Args>
-CDKF_DEV R lpe_update_adj(const Args& a, const R vp, const R vb, const int i, const int j) {
+CDKF_DEV R lpe_update_adj(const Args& a, R vp, R vb, const int i, const int j) {
   const int l = 4 * i + j;
-  const R Pg[6] = {lpe_bcast<0>(vp), lpe_bcast<1>(vp), lpe_bcast<2>(vp), lpe_bcast<5>(vp), lpe_bcast<6>(vp), lpe_bcast<10>(vp)};
-  const R m[3] = {lpe_bcast<3>(vp), lpe_bcast<7>(vp), lpe_bcast<11>(vp)};
-  const R yo[3] = {lpe_bcast<12>(vp), lpe_bcast<13>(vp), lpe_bcast<14>(vp)};
-  // the cotangent of the filtered covariance: its upper triangle (symmetric up to rounding; the oracle averages the two)
-  const R Bg[6] = {lpe_bcast<0>(vb), lpe_bcast<1>(vb), lpe_bcast<2>(vb), lpe_bcast<5>(vb), lpe_bcast<6>(vb), lpe_bcast<10>(vb)};
-  const R mb[3] = {lpe_bcast<3>(vb), lpe_bcast<7>(vb), lpe_bcast<11>(vb)};
   constexpr R eps = R(1e-9);
+  R neg1 = R(-1);
+  lpe_fence3(vp, vb, neg1);  // vp, vb are row_newbcast operands below
+  const R Pg[6] = {lpe_bcast<0>(vp), lpe_bcast<1>(vp), lpe_bcast<2>(vp), lpe_bcast<5>(vp), lpe_bcast<6>(vp), lpe_bcast<10>(vp)};
   R S[3][3], v[3];
 #pragma unroll
-  for (int r = 0; r < 3; ++r) {
+  for (int r = 0; r < 3; ++r)
 #pragma unroll
     for (int c = 0; c <= r; ++c) S[r][c] = Pg[sidx<3>(r, c)] + a.Rm[r][c];
-    v[r] = yo[r] - m[r];
-  }
+  // innovation y - m: the observation's broadcast, then one multiply-add with the mean's broadcast as its operand
+  v[0] = lpe_fmac_bcast<3>(lpe_bcast<12>(vp), vp, neg1);
+  v[1] = lpe_fmac_bcast<7>(lpe_bcast<13>(vp), vp, neg1);
+  v[2] = lpe_fmac_bcast<11>(lpe_bcast<14>(vp), vp, neg1);
   // Cholesky factor of S + eps I (chol_lower's operations with lpe_rsqrt), then row i of its inverse
   const R i0 = lpe_rsqrt(S[0][0] + eps);
   const R L10 = S[1][0] * i0, L20 = S[2][0] * i0;
@@ -207,48 +206,70 @@ CDKF_DEV R lpe_update_adj(const Args& a, const R vp, const R vb, const int i, co
   Ai[2] = f2 * i2;
   Ai[1] = rfma(-L21, Ai[2], f1) * i1;
   Ai[0] = rfma(-L20, Ai[2], rfma(-L10, Ai[1], f0)) * i0;
-  // row i of J = A (R + eps I), J mbar, J Pbar
+  lpe_fence3(Ai[0], Ai[1], Ai[2]);  // (row_newbcast operands below)
+  // row i of J = A (R + eps I), J mbar, J Pbar (the cotangents as broadcast operands: lane 4 c + k holds Pbar_ck, 4 c + 3 mbar_c)
   R Ji[3], JPi[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     Ji[k] = rfma(Ai[2], (k == 2) ? a.Rm[2][k] + eps : a.Rm[2][k],
                  rfma(Ai[1], (k == 1) ? a.Rm[1][k] + eps : a.Rm[1][k], Ai[0] * ((k == 0) ? a.Rm[0][k] + eps : a.Rm[0][k])));
   }
-  const R ui = rfma(Ai[2], v[2], rfma(Ai[1], v[1], Ai[0] * v[0]));
-  const R Jmi = rfma(Ji[2], mb[2], rfma(Ji[1], mb[1], Ji[0] * mb[0]));
-#pragma unroll
-  for (int k = 0; k < 3; ++k)
-    JPi[k] = rfma(Ji[2], Bg[sidx<3>(2, k)], rfma(Ji[1], Bg[sidx<3>(1, k)], Ji[0] * Bg[sidx<3>(0, k)]));
-  // row i of A^2 (for S^-1 = A + eps A^2) and of J Pbar J^T: the rows c = 0, 1, 2 of A / J from the lanes 4 c
+  R ui = rfma(Ai[2], v[2], rfma(Ai[1], v[1], Ai[0] * v[0]));
+  R Jmi = lpe_bcast<3>(vb) * Ji[0];
+  Jmi = lpe_fmac_bcast<7>(Jmi, vb, Ji[1]);
+  Jmi = lpe_fmac_bcast<11>(Jmi, vb, Ji[2]);
+  JPi[0] = lpe_bcast<0>(vb) * Ji[0];
+  JPi[1] = lpe_bcast<1>(vb) * Ji[0];
+  JPi[2] = lpe_bcast<2>(vb) * Ji[0];
+  JPi[0] = lpe_fmac_bcast<4>(JPi[0], vb, Ji[1]);
+  JPi[1] = lpe_fmac_bcast<5>(JPi[1], vb, Ji[1]);
+  JPi[2] = lpe_fmac_bcast<6>(JPi[2], vb, Ji[1]);
+  JPi[0] = lpe_fmac_bcast<8>(JPi[0], vb, Ji[2]);
+  JPi[1] = lpe_fmac_bcast<9>(JPi[1], vb, Ji[2]);
+  JPi[2] = lpe_fmac_bcast<10>(JPi[2], vb, Ji[2]);
+  // row i of S^-1 = A + eps A^2 and of J Pbar J^T: the rows c = 0, 1, 2 of A / J from the lanes 4 c
   lpe_fence3(Ji[0], Ji[1], Ji[2]);
-  R A2[3] = {R(0), R(0), R(0)}, n[3] = {R(0), R(0), R(0)};
+  const R eA0 = eps * Ai[0], eA1 = eps * Ai[1], eA2 = eps * Ai[2];
+  R Si[3], n[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) Si[c] = Ai[c];
+  n[0] = lpe_bcast<0>(Ji[0]) * JPi[0];
+  n[1] = lpe_bcast<4>(Ji[0]) * JPi[0];
+  n[2] = lpe_bcast<8>(Ji[0]) * JPi[0];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    A2[k] = lpe_fmac_bcast<0>(A2[k], Ai[k], Ai[0]);
-    A2[k] = lpe_fmac_bcast<4>(A2[k], Ai[k], Ai[1]);
-    A2[k] = lpe_fmac_bcast<8>(A2[k], Ai[k], Ai[2]);
-    n[0] = lpe_fmac_bcast<0>(n[0], Ji[k], JPi[k]);
-    n[1] = lpe_fmac_bcast<4>(n[1], Ji[k], JPi[k]);
-    n[2] = lpe_fmac_bcast<8>(n[2], Ji[k], JPi[k]);
+    Si[k] = lpe_fmac_bcast<0>(Si[k], Ai[k], eA0);
+    Si[k] = lpe_fmac_bcast<4>(Si[k], Ai[k], eA1);
+    Si[k] = lpe_fmac_bcast<8>(Si[k], Ai[k], eA2);
+    if (k > 0) {
+      n[0] = lpe_fmac_bcast<0>(n[0], Ji[k], JPi[k]);
+      n[1] = lpe_fmac_bcast<4>(n[1], Ji[k], JPi[k]);
+      n[2] = lpe_fmac_bcast<8>(n[2], Ji[k], JPi[k]);
+    }
   }
-  R Si[3], Wi[3] = {R(0), R(0), R(0)};
-#pragma unroll
-  for (int k = 0; k < 3; ++k) Si[k] = rfma(eps, A2[k], Ai[k]);
-  const R wi = rfma(Si[2], v[2], rfma(Si[1], v[1], Si[0] * v[0]));
-  // E = J Pbar X^T = J Pbar - J Pbar J^T (row i), W = E A
-  const R E0 = JPi[0] - n[0], E1 = JPi[1] - n[1], E2 = JPi[2] - n[2];
+  R wi = rfma(Si[2], v[2], rfma(Si[1], v[1], Si[0] * v[0]));
+  // E = J Pbar X^T = J Pbar - J Pbar J^T (row i), eps W = eps E A
+  const R E0 = eps * (JPi[0] - n[0]), E1 = eps * (JPi[1] - n[1]), E2 = eps * (JPi[2] - n[2]);
+  R hJm = R(0.5) * Jmi, hw = R(0.5) * wi;
+  lpe_fence3(ui, wi, hJm);
+  // candidates for the lane's column k:  Z_ik = (J mbar)_i u_k / 2 + eps W_ik  and  Q_ik = n_ik + (w_i w_k - (S^-1)_ik) / 2;
+  // u_k, w_k belong to grid row k
+  R Zc[3], Qc[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    Wi[k] = lpe_fmac_bcast<0>(Wi[k], Ai[k], E0);
-    Wi[k] = lpe_fmac_bcast<4>(Wi[k], Ai[k], E1);
-    Wi[k] = lpe_fmac_bcast<8>(Wi[k], Ai[k], E2);
+    Zc[k] = lpe_bcast<0>(Ai[k]) * E0;
+    Zc[k] = lpe_fmac_bcast<4>(Zc[k], Ai[k], E1);
+    Zc[k] = lpe_fmac_bcast<8>(Zc[k], Ai[k], E2);
+    Qc[k] = rfma(R(-0.5), Si[k], n[k]);
   }
-  // the entries of the lane's column j; u_j and w_j belong to grid row j
-  const R nj = lpe_sel3(j, n[0], n[1], n[2]), Wij = lpe_sel3(j, Wi[0], Wi[1], Wi[2]), Sij = lpe_sel3(j, Si[0], Si[1], Si[2]);
-  const R uj = lpe_sel3(j, lpe_bcast<0>(ui), lpe_bcast<4>(ui), lpe_bcast<8>(ui));
-  const R wj = lpe_sel3(j, lpe_bcast<0>(wi), lpe_bcast<4>(wi), lpe_bcast<8>(wi));
-  // Z_ij = (J mbar)_i u_j / 2 + eps W_ij and its transpose partner's (lanes 4 <-> 1, 9 <-> 6: three apart; 8 <-> 2: six apart)
-  const R Z = rfma(eps, Wij, R(0.5) * (Jmi * uj));
+  Zc[0] = lpe_fmac_bcast<0>(Zc[0], ui, hJm);
+  Zc[1] = lpe_fmac_bcast<4>(Zc[1], ui, hJm);
+  Zc[2] = lpe_fmac_bcast<8>(Zc[2], ui, hJm);
+  Qc[0] = lpe_fmac_bcast<0>(Qc[0], wi, hw);
+  Qc[1] = lpe_fmac_bcast<4>(Qc[1], wi, hw);
+  Qc[2] = lpe_fmac_bcast<8>(Qc[2], wi, hw);
+  const R Z = lpe_sel3(j, Zc[0], Zc[1], Zc[2]), Q = lpe_sel3(j, Qc[0], Qc[1], Qc[2]);
+  // Z's transpose partner (lanes 4 <-> 1, 9 <-> 6: three apart; 8 <-> 2: six apart)
   const R up3 = lpe_dpp<0x110 + 3>(Z), up6 = lpe_dpp<0x110 + 6>(Z);  // row_shr: from the lane 3 / 6 below
   const R dn3 = lpe_dpp<0x100 + 3>(Z), dn6 = lpe_dpp<0x100 + 6>(Z);  // row_shl: from the lane 3 / 6 above
   R Zt = Z;
@@ -256,8 +277,7 @@ CDKF_DEV R lpe_update_adj(const Args& a, const R vp, const R vb, const int i, co
   Zt = (l == 8) ? up6 : Zt;
   Zt = (l == 1 || l == 6) ? dn3 : Zt;
   Zt = (l == 2) ? dn6 : Zt;
-  const R pn = nj + ((Z + Zt) + R(0.5) * rfma(wi, wj, -Sij));
-  return (j == 3) ? Jmi + wi : pn;
+  return (j == 3) ? Jmi + wi : Q + (Z + Zt);
 }
 
 // grad [N, 3].  The forward sweep (filter_lpe_kernel, OUT = 1) has written fm, fP, pm, pP with the strides of `a`.
@@ -324,7 +344,7 @@ __global__ __launch_bounds__(64) void grad_lpe_l63_kernel(const RegArgs<R, 3, 3,
       fv = fp[0];
     }
     if (k == 0 && i < 3) vp = own0;
-    vb = lpe_update_adj(a, vp, vb, i, j);
+    vb = lpe_update_adj<R>(a, vp, vb, i, j);
     if (k == 0) break;
     // ---- the predict from k-1 to k, reversed ----
     const R t1 = lpe_bcast<15>(vp), t0 = lpe_bcast<15>(vf);

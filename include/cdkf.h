@@ -315,7 +315,8 @@ int cdkf_kf_pushforward_f32(const cdkf_model* mdl, const cdkf_opts* opts, int64_
  *      the parameters (what the Lorenz-63 parameter-estimation tutorials learn).  EKF, num_iter 1; state_order
  *      first/second (MLP drift, 'second': the mean term 0.5 P grad(div f) is differentiated too); shapes:
  *      cdkf_grad_supported().  ll [N], grad [N, n_theta] row-major whatever opts.layout is
- *      (t and y follow opts.layout).  Exact derivative of the discretised recursion (forward sensitivities). -- */
+ *      (t and y follow opts.layout).  Exact derivative of the discretised recursion (forward sensitivities; small
+ *      Lorenz-63 batches with H = I: a forward and a reverse sweep, moments in a grow-only device workspace). -- */
 int cdkf_ekf_loglik_grad_f64(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T, const double* t,
                              const double* y, double* ll, double* grad, int32_t* status);
 int cdkf_ekf_loglik_grad_f32(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T, const float* t,

@@ -275,9 +275,18 @@ def test_results_do_not_depend_on_the_wavefront_grouping(hip_lib, N, T):
             np.testing.assert_allclose(a, b, rtol=1e-10, atol=1e-12, err_msg=k)
     ll_b, g_b = cd.cdnlgssm_loglik_and_grad(P, y, t[..., None])
     ll_s, g_s = cd.cdnlgssm_loglik_and_grad(P, y[sub], t[sub][..., None])
-    np.testing.assert_array_equal(ll_b[sub], ll_s)
+    # (the gradient follows the same threshold: forward + reverse sweep on the sixteen-lane grid up to 4096 trajectories,
+    # forward sensitivities with a lane per (trajectory, parameter) above)
+    if N <= 4096:
+        np.testing.assert_array_equal(ll_b[sub], ll_s)
+    else:
+        np.testing.assert_allclose(ll_b[sub], ll_s, rtol=1e-11)
     for name in ("sigma", "rho", "beta"):
-        np.testing.assert_array_equal(getattr(g_b, name)[sub], getattr(g_s, name))
+        a, b = getattr(g_b, name)[sub], getattr(g_s, name)
+        if N <= 4096:
+            np.testing.assert_array_equal(a, b)
+        else:
+            np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-10 * np.abs(b).max())
 
 
 def test_status_flags_and_nan_propagation(hip_lib):
@@ -603,6 +612,62 @@ def test_loglik_gradient(hip_lib, kind, d, m):
         [g32.weights.reshape(N, -1), g32.bias], -1)
     assert g32.dtype == np.float32
     assert np.max(np.abs(g32 - g_ref) / scale) < 5e-3
+
+
+def test_loglik_gradient_reverse_sweep_on_the_lane_grid(hip_lib, tmp_path):
+    """Small Lorenz-63 batches with H = I take the gradient w.r.t. (sigma, rho, beta) from the forward sweep on the sixteen-lane
+    grid plus grad_lpe_l63_kernel, the reverse sweep on the same grid (ssm_temissions.py:550-568: jax.value_and_grad is reverse
+    mode too).  Against the oracle's forward-sensitivity gradient: one Runge-Kutta step per interval, several, more than the 64
+    step starts the kernel parks in LDS, N not a multiple of four, T = 1 and 2, shared times, a dense symmetric R, another
+    (L, Qc), fp32; and against the forward-sensitivity kernel (CDKF_NO_LPE_GRAD=1, read once per process: a child process)."""
+    import os, subprocess, sys
+    rng = np.random.default_rng(314)
+    mdl = o.lorenz63_model(3)
+    P = params_from(mdl)
+
+    def flat(g):
+        return np.stack([g.sigma, g.rho, g.beta], -1)
+
+    def check(mdl_, t, y, tol=1e-9, dtype=np.float64):
+        ll_ref, g_ref = o.ekf_loglik_grad(mdl_, t, y)
+        ll, g = cd.cdnlgssm_loglik_and_grad(params_from(mdl_), y.astype(dtype), t[..., None].astype(dtype))
+        assert hip_lib.cdkf_last_kernel().startswith(b"grad_lpe_l63_kernel<" + (b"double" if dtype == np.float64 else b"float"))
+        scale = np.abs(g_ref).max(axis=0, keepdims=True) + 1e-30
+        assert np.max(np.abs(ll - ll_ref) / np.abs(ll_ref)) < max(tol * 1e-2, 3e-6 if dtype == np.float32 else 0)
+        assert np.max(np.abs(flat(g) - g_ref) / scale) < tol
+        return ll, flat(g)
+
+    for N, T, gap in ((13, 50, 0.008), (6, 12, 0.05), (5, 6, 0.9), (3, 1, 0.01), (2, 2, 0.3), (1, 9, 0.02)):
+        t = o.irregular_times(rng, N, T, gap)
+        check(mdl, t, o.simulate(mdl, t, rng))
+    t = o.irregular_times(rng, 9, 30, 0.02)
+    y = o.simulate(mdl, t, rng)
+    check(mdl, t, y, tol=5e-3, dtype=np.float32)
+    # one time grid shared by the batch
+    ts = t[0]
+    ll_s, g_s = cd.cdnlgssm_loglik_and_grad(P, y, ts[:, None])
+    assert hip_lib.cdkf_last_kernel().startswith(b"grad_lpe_l63_kernel<double")
+    _, g_ref = o.ekf_loglik_grad(mdl, np.broadcast_to(ts, t.shape), y)
+    assert np.max(np.abs(flat(g_s) - g_ref) / (np.abs(g_ref).max(axis=0, keepdims=True) + 1e-30)) < 1e-9
+    # dense symmetric R, non-trivial diffusion, off-centre prior
+    A = rng.standard_normal((3, 3))
+    mdl2 = o.Model(mdl.drift, np.eye(3) + 0.2 * rng.standard_normal((3, 3)), np.diag([0.5, 1.5, 1.0]), mdl.H, mdl.bias,
+                   0.3 * np.eye(3) + 0.1 * A @ A.T, np.array([1.0, -2.0, 20.0]), 2.0 * np.eye(3) + 0.3 * A.T @ A)
+    check(mdl2, t, o.simulate(mdl2, t, rng))
+    # the same call in a process that keeps the forward-sensitivity kernel
+    ll, g = check(mdl, t, y)
+    np.savez(tmp_path / "in.npz", t=t, y=y)
+    code = ("import sys, numpy as np; sys.path[:0] = [%r, %r, %r]\n"
+            "import cd_dynamax_amd as cd, cdkf_oracle as o\nfrom cd_dynamax_amd import _ffi\nfrom helpers import params_from\n"
+            "d = np.load(%r); ll, g = cd.cdnlgssm_loglik_and_grad(params_from(o.lorenz63_model(3)), d['y'], d['t'][..., None])\n"
+            "assert _ffi.lib().cdkf_last_kernel().startswith(b'ekf_grad_reg_kernel'), _ffi.lib().cdkf_last_kernel()\n"
+            "np.savez(%r, ll=ll, g=np.stack([g.sigma, g.rho, g.beta], -1))\n"
+            % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(o.__file__)),
+               os.path.dirname(os.path.abspath(__file__)), str(tmp_path / "in.npz"), str(tmp_path / "out.npz")))
+    subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CDKF_NO_LPE_GRAD="1"), check=True, timeout=600)
+    other = np.load(tmp_path / "out.npz")
+    assert relerr(ll, other["ll"]) < 1e-12
+    assert np.max(np.abs(g - other["g"]) / np.abs(other["g"]).max(axis=0, keepdims=True)) < 1e-10
 
 
 def test_loglik_gradient_unsupported_raises(hip_lib):
