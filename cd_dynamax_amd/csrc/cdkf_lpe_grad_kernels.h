@@ -25,7 +25,10 @@
 
 namespace cdkf {
 
-constexpr int kLpeGradCap = 64;  // step starts of one interval kept in LDS (longer intervals re-integrate from the last one kept)
+#ifndef CDKF_LPE_GRAD_CAP
+#define CDKF_LPE_GRAD_CAP 64
+#endif
+constexpr int kLpeGradCap = CDKF_LPE_GRAD_CAP;  // step starts of one interval kept in LDS (longer intervals re-integrate from the last one kept)
 
 // per-lane constants of the reversed right-hand side
 template <typename R>
