@@ -77,7 +77,9 @@ struct LpeAdjRhs {
   // cotangent of the stage VALUE (this lane's entry) from the cotangent L of the stage SLOPE; Ys: the stage value, p1..p3 its entries
   // in the rows i+1, i+2, i+3 (the fetches the replayed forward right-hand side made).  th accumulates the lane's share of the
   // parameter gradient.
-  CDKF_DEV R stage(const R L, const R Ys, const R p1, const R p2, const R p3, R& th) const {
+  template <bool ALL>
+  CDKF_DEV R stage(const R L, const R Ys, const R p1, const R p2, const R p3, R& th, R& lql) const {
+    if constexpr (ALL) lql += L;  // cotangent of L Qc L^T: the slope of P carries it as a constant term
     const R d1 = lpe_dpp<0x120 + 12>(L), d2 = lpe_dpp<0x120 + 8>(L), d3 = lpe_dpp<0x120 + 4>(L);  // rows i+1, i+2, i+3
     const R r1 = lpe_dpp<0xC9>(L), r2 = lpe_dpp<0xD2>(L);                                          // columns (j+1) % 3, (j+2) % 3
     R acc = g0 * L;
@@ -127,9 +129,9 @@ CDKF_DEV R lpe_eval_keep(const LpeRhs<R, false>& c, const R v, R& d1, R& d2, R& 
 }
 
 // One Dormand-Prince step from y over dt, reversed: vb (cotangent of the step's result) becomes the cotangent of y.
-template <typename R>
+template <bool ALL, typename R>
 CDKF_DEV void lpe_step_adj(const LpeRhs<R, false>& rhs, const LpeAdjRhs<R>& adj, const Dp5V<R>& C, const R y, const R dt, R& vb,
-                           R& th) {
+                           R& th, R& lql) {
   R p[6][3];  // row fetches of the six stage values
   const R k1 = dt * lpe_eval_keep(rhs, y, p[0][0], p[0][1], p[0][2]);
   const R Y2 = rfma(C.a21, k1, y);
@@ -145,14 +147,14 @@ CDKF_DEV void lpe_step_adj(const LpeRhs<R, false>& rhs, const LpeAdjRhs<R>& adj,
   p[5][1] = lpe_dpp<0x120 + 8>(Y6);
   p[5][2] = lpe_dpp<0x120 + 4>(Y6);
   // cotangent of slope s: dt (b_s vb + sum_{q > s} a_qs Yb_q)
-  const R Yb6 = adj.stage(dt * (C.b6 * vb), Y6, p[5][0], p[5][1], p[5][2], th);
-  const R Yb5 = adj.stage(dt * rfma(C.a65, Yb6, C.b5 * vb), Y5, p[4][0], p[4][1], p[4][2], th);
-  const R Yb4 = adj.stage(dt * rfma(C.a64, Yb6, rfma(C.a54, Yb5, C.b4 * vb)), Y4, p[3][0], p[3][1], p[3][2], th);
-  const R Yb3 = adj.stage(dt * rfma(C.a63, Yb6, rfma(C.a53, Yb5, rfma(C.a43, Yb4, C.b3 * vb))), Y3, p[2][0], p[2][1], p[2][2], th);
+  const R Yb6 = adj.template stage<ALL>(dt * (C.b6 * vb), Y6, p[5][0], p[5][1], p[5][2], th, lql);
+  const R Yb5 = adj.template stage<ALL>(dt * rfma(C.a65, Yb6, C.b5 * vb), Y5, p[4][0], p[4][1], p[4][2], th, lql);
+  const R Yb4 = adj.template stage<ALL>(dt * rfma(C.a64, Yb6, rfma(C.a54, Yb5, C.b4 * vb)), Y4, p[3][0], p[3][1], p[3][2], th, lql);
+  const R Yb3 = adj.template stage<ALL>(dt * rfma(C.a63, Yb6, rfma(C.a53, Yb5, rfma(C.a43, Yb4, C.b3 * vb))), Y3, p[2][0], p[2][1], p[2][2], th, lql);
   const R Yb2 =
-      adj.stage(dt * rfma(C.a62, Yb6, rfma(C.a52, Yb5, rfma(C.a42, Yb4, C.a32 * Yb3))), Y2, p[1][0], p[1][1], p[1][2], th);
-  const R Yb1 = adj.stage(dt * rfma(C.a61, Yb6, rfma(C.a51, Yb5, rfma(C.a41, Yb4, rfma(C.a31, Yb3, rfma(C.a21, Yb2, C.b1 * vb))))), y,
-                          p[0][0], p[0][1], p[0][2], th);
+      adj.template stage<ALL>(dt * rfma(C.a62, Yb6, rfma(C.a52, Yb5, rfma(C.a42, Yb4, C.a32 * Yb3))), Y2, p[1][0], p[1][1], p[1][2], th, lql);
+  const R Yb1 = adj.template stage<ALL>(dt * rfma(C.a61, Yb6, rfma(C.a51, Yb5, rfma(C.a41, Yb4, rfma(C.a31, Yb3, rfma(C.a21, Yb2, C.b1 * vb))))), y,
+                          p[0][0], p[0][1], p[0][2], th, lql);
   vb += ((Yb1 + Yb2) + (Yb3 + Yb4)) + (Yb5 + Yb6);
 }
 
@@ -179,8 +181,27 @@ CDKF_DEV R lpe_sel3(int j, R a0, R a1, R a2) {
 // instruction stream: row i solves (S + eps I) x = e_i (one factorisation, per-lane right-hand sides) and carries row i of A, J,
 // J Pbar, ...; the rows of another grid row arrive as row_newbcast operands, entries of the lane's own column by selection, and the
 // transposed entries of the two non-symmetric terms by the fetches of lpe_update's symmetrisation in both directions.
-template <typename R, typename Args>
-CDKF_DEV R lpe_update_adj(const Args& a, R vp, R vb, const int i, const int j) {
+// accumulators of the model block (ALL): this lane's entry of the cotangents of R, H (covariance lanes) and of the emission bias (row i's,
+// in every lane of the row)
+template <typename R>
+struct LpeModelAcc {
+  R r = R(0), h = R(0), b = R(0), lql = R(0);
+};
+// lanes 4 <-> 1, 9 <-> 6 (three apart), 8 <-> 2 (six apart) exchange values; every other lane keeps its own
+template <typename R>
+CDKF_DEV R lpe_transpose(const R Z, const int l) {
+  const R up3 = lpe_dpp<0x110 + 3>(Z), up6 = lpe_dpp<0x110 + 6>(Z);  // row_shr: from the lane 3 / 6 below
+  const R dn3 = lpe_dpp<0x100 + 3>(Z), dn6 = lpe_dpp<0x100 + 6>(Z);  // row_shl: from the lane 3 / 6 above
+  R Zt = Z;
+  Zt = (l == 4 || l == 9) ? up3 : Zt;
+  Zt = (l == 8) ? up6 : Zt;
+  Zt = (l == 1 || l == 6) ? dn3 : Zt;
+  Zt = (l == 2) ? dn6 : Zt;
+  return Zt;
+}
+
+template <bool ALL, typename R, typename Args>
+CDKF_DEV R lpe_update_adj(const Args& a, R vp, R vb, const int i, const int j, LpeModelAcc<R>& acc) {
   const int l = 4 * i + j;
   constexpr R eps = R(1e-9);
   R neg1 = R(-1);
@@ -272,20 +293,53 @@ CDKF_DEV R lpe_update_adj(const Args& a, R vp, R vb, const int i, const int j) {
   Qc[1] = lpe_fmac_bcast<4>(Qc[1], wi, hw);
   Qc[2] = lpe_fmac_bcast<8>(Qc[2], wi, hw);
   const R Z = lpe_sel3(j, Zc[0], Zc[1], Zc[2]), Q = lpe_sel3(j, Qc[0], Qc[1], Qc[2]);
-  // Z's transpose partner (lanes 4 <-> 1, 9 <-> 6: three apart; 8 <-> 2: six apart)
-  const R up3 = lpe_dpp<0x110 + 3>(Z), up6 = lpe_dpp<0x110 + 6>(Z);  // row_shr: from the lane 3 / 6 below
-  const R dn3 = lpe_dpp<0x100 + 3>(Z), dn6 = lpe_dpp<0x100 + 6>(Z);  // row_shl: from the lane 3 / 6 above
-  R Zt = Z;
-  Zt = (l == 4 || l == 9) ? up3 : Zt;
-  Zt = (l == 8) ? up6 : Zt;
-  Zt = (l == 1 || l == 6) ? dn3 : Zt;
-  Zt = (l == 2) ? dn6 : Zt;
-  return (j == 3) ? Jmi + wi : Q + (Z + Zt);
+  const R Zt = lpe_transpose(Z, l);
+  const R pn = Q + (Z + Zt);
+  if constexpr (ALL) {
+    // The oracle's intermediate cotangents in these terms: vbar = mbar - J mbar - w;  Ubar = u mbar^T - 2 X Pbar + 2 eps A X Pbar
+    // (X Pbar = Pbar - J Pbar);  Sbar = Pbar_new - Pbar - sym(Ubar^T).  Then  Rbar += Sbar,  biasbar -= vbar,
+    // Hbar += (2 Sbar + Ubar) P - vbar m^T   (H = I: H P = P).
+    const R mbi = lpe_dpp<0xFF>(vb);  // quad_perm [3,3,3,3]: the row's mean lane
+    const R vbar = (mbi - Jmi) - wi;
+    R XP[3] = {lpe_dpp<0x00>(vb) - JPi[0], lpe_dpp<0x55>(vb) - JPi[1], lpe_dpp<0xAA>(vb) - JPi[2]};  // row i of Pbar, minus J Pbar's
+    lpe_fence3(XP[0], XP[1], XP[2]);
+    R Ub[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      R axp = lpe_bcast<0>(XP[k]) * Ai[0];
+      axp = lpe_fmac_bcast<4>(axp, XP[k], Ai[1]);
+      axp = lpe_fmac_bcast<8>(axp, XP[k], Ai[2]);
+      Ub[k] = rfma(R(2) * eps, axp, R(-2) * XP[k]);
+    }
+    Ub[0] = lpe_fmac_bcast<3>(Ub[0], vb, ui);
+    Ub[1] = lpe_fmac_bcast<7>(Ub[1], vb, ui);
+    Ub[2] = lpe_fmac_bcast<11>(Ub[2], vb, ui);
+    const R Uij = lpe_sel3(j, Ub[0], Ub[1], Ub[2]);
+    const R Uji = lpe_transpose(Uij, l);
+    const R Sbar = (pn - vb) - R(0.5) * (Uij + Uji);  // (covariance lanes; the others are not stored)
+    acc.r += Sbar;
+    acc.b -= vbar;
+    // row i of 2 Sbar + Ubar, times P (every lane holds P), minus vbar m^T: the candidates for the columns 0, 1, 2
+    const R T0 = rfma(R(2), lpe_dpp<0x00>(Sbar), Ub[0]), T1 = rfma(R(2), lpe_dpp<0x55>(Sbar), Ub[1]),
+            T2 = rfma(R(2), lpe_dpp<0xAA>(Sbar), Ub[2]);
+    R nv = -vbar;
+    lpe_fence3(nv, vp, vb);
+    R Hc[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) Hc[c] = rfma(T2, Pg[sidx<3>(2, c)], rfma(T1, Pg[sidx<3>(1, c)], T0 * Pg[sidx<3>(0, c)]));
+    Hc[0] = lpe_fmac_bcast<3>(Hc[0], vp, nv);
+    Hc[1] = lpe_fmac_bcast<7>(Hc[1], vp, nv);
+    Hc[2] = lpe_fmac_bcast<11>(Hc[2], vp, nv);
+    acc.h += lpe_sel3(j, Hc[0], Hc[1], Hc[2]);
+  }
+  return (j == 3) ? Jmi + wi : pn;
 }
 
 // grad [N, 3].  The forward sweep (filter_lpe_kernel, OUT = 1) has written fm, fP, pm, pP with the strides of `a`.
-template <typename R>
-__global__ __launch_bounds__(64) void grad_lpe_l63_kernel(const RegArgs<R, 3, 3, DriftLorenz63<R, 3>> a, R* __restrict__ grad) {
+// ALL: also grad_model [N, 42] = m0 [3] | P0 [3,3] | LQL [3,3] | H [3,3] | h_bias [3] | R [3,3] (include/cdkf.h, cdkf_ekf_loglik_grad_all_*)
+template <typename R, bool ALL>
+__global__ __launch_bounds__(64) void grad_lpe_l63_kernel(const RegArgs<R, 3, 3, DriftLorenz63<R, 3>> a, R* __restrict__ grad,
+                                                          R* __restrict__ grad_model) {
   constexpr int D = 3;
   __shared__ R starts[kLpeGradCap][64];
   const int lane = threadIdx.x, l = lane & 15, i = l >> 2, j = l & 3;
@@ -336,6 +390,7 @@ __global__ __launch_bounds__(64) void grad_lpe_l63_kernel(const RegArgs<R, 3, 3,
   };
 
   R vb = R(0), th = R(0);
+  LpeModelAcc<R> acc;
   R pv = pp[0], fv = fp[0];
   for (long k = last; k >= 0; --k) {
     R vp = pv;
@@ -347,7 +402,7 @@ __global__ __launch_bounds__(64) void grad_lpe_l63_kernel(const RegArgs<R, 3, 3,
       fv = fp[0];
     }
     if (k == 0 && i < 3) vp = own0;
-    vb = lpe_update_adj<R>(a, vp, vb, i, j);
+    vb = lpe_update_adj<ALL, R>(a, vp, vb, i, j, acc);
     if (k == 0) break;
     // ---- the predict from k-1 to k, reversed ----
     const R t1 = lpe_bcast<15>(vp), t0 = lpe_bcast<15>(vf);
@@ -384,16 +439,32 @@ __global__ __launch_bounds__(64) void grad_lpe_l63_kernel(const RegArgs<R, 3, 3,
           }
           dt = uq - up;
         }
-        lpe_step_adj<R>(rhs, adj, C, ys, dt, vb, th);
+        lpe_step_adj<ALL, R>(rhs, adj, C, ys, dt, vb, th, acc.lql);
       }
     }
-    lpe_step_adj<R>(rhs, adj, C, y0, dt_0, vb, th);
+    lpe_step_adj<ALL, R>(rhs, adj, C, y0, dt_0, vb, th, acc.lql);
   }
   // row p holds the shares of parameter p
   const R g0 = (lpe_bcast<0>(th) + lpe_bcast<1>(th)) + (lpe_bcast<2>(th) + lpe_bcast<3>(th));
   const R g1 = (lpe_bcast<4>(th) + lpe_bcast<5>(th)) + (lpe_bcast<6>(th) + lpe_bcast<7>(th));
   const R g2 = (lpe_bcast<8>(th) + lpe_bcast<9>(th)) + (lpe_bcast<10>(th) + lpe_bcast<11>(th));
   if (live && l < 3) grad[n * 3 + l] = (l == 0) ? g0 : ((l == 1) ? g1 : g2);
+  if constexpr (ALL) {
+    // the symmetric blocks as the oracle returns them: averaged with the transpose partner
+    const R P0b = R(0.5) * (vb + lpe_transpose(vb, l)), Lb = R(0.5) * (acc.lql + lpe_transpose(acc.lql, l)),
+            Rb = R(0.5) * (acc.r + lpe_transpose(acc.r, l));
+    R* gm = grad_model + n * 42;
+    if (live && cov) {
+      gm[3 + i * 3 + j] = P0b;
+      gm[12 + i * 3 + j] = Lb;
+      gm[21 + i * 3 + j] = acc.h;
+      gm[33 + i * 3 + j] = Rb;
+    }
+    if (live && mean) {
+      gm[i] = vb;
+      gm[30 + i] = acc.b;
+    }
+  }
 }
 
 }  // namespace cdkf

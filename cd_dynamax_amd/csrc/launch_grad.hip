@@ -52,7 +52,7 @@ static int run_grad(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_
 // CDKF_NO_LPE_GRAD=1 keeps the forward-sensitivity kernel (A/B timing, tests).  handled = false: not this kernel's case.
 template <typename R>
 static int try_lpe_grad(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll, R* grad,
-                        int32_t* status, hipStream_t stream, bool* handled) {
+                        R* grad_model, int32_t* status, hipStream_t stream, bool* handled) {
   *handled = false;
   static const bool off = [] { const char* e = std::getenv("CDKF_NO_LPE_GRAD"); return e && e[0] == '1'; }();
   if (off || mdl->drift_kind != CDKF_DRIFT_LORENZ63 || mdl->state_dim != 3 || mdl->emission_dim != 3 || !emission_is_selection(mdl) ||
@@ -76,8 +76,11 @@ static int try_lpe_grad(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, in
   if (!try_lpe(a, mdl, &of, stream)) return CDKF_OK;
   CDKF_HIP_CHECK(hipGetLastError());
   *handled = true;
-  note_kernel("grad_lpe_l63_kernel<%s>", real_name<R>());
-  hipLaunchKernelGGL((grad_lpe_l63_kernel<R>), dim3(lpe_blocks<R>(N)), dim3(64), 0, stream, a, grad);
+  note_kernel("grad_lpe_l63_kernel<%s, %s>", real_name<R>(), grad_model ? "true" : "false");
+  if (grad_model)
+    hipLaunchKernelGGL((grad_lpe_l63_kernel<R, true>), dim3(lpe_blocks<R>(N)), dim3(64), 0, stream, a, grad, grad_model);
+  else
+    hipLaunchKernelGGL((grad_lpe_l63_kernel<R, false>), dim3(lpe_blocks<R>(N)), dim3(64), 0, stream, a, grad, grad_model);
   CDKF_HIP_CHECK(hipGetLastError());
   return ws.done(stream);
 }
@@ -88,9 +91,9 @@ int launch_ekf_grad(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_
   // drift parameters only: forward sensitivities where a register-resident kernel exists (one sweep, no workspace);
   // otherwise, and whenever the model block is requested, the forward + reverse sweep pair
   const bool sens = !grad_model && sens_shape_available(mdl, o);
-  if (sens) {
+  if (sens || grad_model) {  // (the model block as well: m0, P0, L Qc L^T, H, bias, R)
     bool handled = false;
-    const int rc = try_lpe_grad<R>(mdl, o, N, T, t, y, ll, grad, status, stream, &handled);
+    const int rc = try_lpe_grad<R>(mdl, o, N, T, t, y, ll, grad, grad_model, status, stream, &handled);
     if (rc || handled) return rc;
   }
   if (!sens && adjoint_shape_available(mdl, o))

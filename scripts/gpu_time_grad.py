@@ -34,3 +34,11 @@ for dtype, sfx in ((np.float64, "f64"), (np.float32, "f32")):
         _ffi.check(fn(C.byref(mb.c), C.byref(opts), N, T, dt_, dy_, dll, dg, dst, None)); _ffi.check(L.cdkf_synchronize(None))
         el = time.perf_counter() - t0
     print(f"grad {sfx} N={N} T={T}: {el*1e3:.2f} ms")
+    if "all" in sys.argv[1:]:  # every parameter of the model (the reverse sweep of cdkf_adjoint_kernels.h)
+        dgm = dev(np.zeros((N, _ffi.model_grad_size(3, 3)), dtype))
+        fa = getattr(L, f"cdkf_ekf_loglik_grad_all_{sfx}_dev")
+        for rep in range(3):
+            t0 = time.perf_counter()
+            _ffi.check(fa(C.byref(mb.c), C.byref(opts), N, T, dt_, dy_, dll, dg, dgm, dst, None)); _ffi.check(L.cdkf_synchronize(None))
+            el = time.perf_counter() - t0
+        print(f"grad_all {sfx} N={N} T={T}: {el*1e3:.2f} ms  ({L.cdkf_last_kernel().decode()[:60]})")

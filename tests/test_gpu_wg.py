@@ -412,6 +412,68 @@ def test_loglik_gradient_all_parameters(hip_lib, kind, d, m):
         close(g.emissions.emission_cov.params, ex["R"], "R (second)")
 
 
+def test_lorenz63_gradient_all_parameters_on_the_lane_grid(hip_lib, tmp_path):
+    """Small Lorenz-63 batches with H = I: the reverse sweep on the sixteen-lane grid (grad_lpe_l63_kernel<..., true>) also returns
+    the model block -- m0, P0, L, Qc, H, bias, R -- of jax.grad(marginal_log_prob) (ssm_temissions.py:550-568 differentiates every
+    trainable leaf).  Against the oracle's discrete adjoint (FD-pinned) with dense L, Qc, R, P0: one and several Runge-Kutta steps
+    per interval, N not a multiple of four, T = 1; and against the wavefront-per-trajectory reverse sweep (CDKF_NO_LPE_GRAD=1 in a
+    child process)."""
+    import os, subprocess, sys
+    rng = np.random.default_rng(2718)
+    base = o.lorenz63_model(3)
+    A, B, C = rng.standard_normal((3, 3)), rng.standard_normal((3, 3)), rng.standard_normal((3, 3))
+    mdl = o.Model(base.drift, np.eye(3) + 0.2 * rng.standard_normal((3, 3)), A @ A.T / 3 + 0.3 * np.eye(3), np.eye(3), np.zeros(3),
+                  B @ B.T / 3 + 0.4 * np.eye(3), np.array([1.0, -1.5, 18.0]), C @ C.T / 3 + 0.5 * np.eye(3))
+    P = params_from(mdl)
+    hyp = cd.EKFHyperParams(state_order="first")
+
+    def leaves(g, N):
+        return {"drift": np.concatenate([np.asarray(a).reshape(N, -1) for a in g.dynamics.drift], axis=-1),
+                "m0": g.initial.mean.params, "P0": g.initial.cov.params, "L": g.dynamics.diffusion_coefficient.params,
+                "Qc": g.dynamics.diffusion_cov.params, "H": g.emissions.emission_function.weights,
+                "bias": g.emissions.emission_function.bias, "R": g.emissions.emission_cov.params}
+
+    for N, T, gap in ((6, 14, 0.008), (5, 9, 0.06), (3, 1, 0.01), (2, 5, 0.9)):
+        t = o.irregular_times(rng, N, T, gap)
+        y = o.simulate(mdl, t, rng)
+        ll_ref, g_ref, ex = o.ekf_loglik_grad_adjoint(mdl, t, y, full=True)
+        ll, g = cd.cdnlgssm_loglik_and_grad_all(P, y, t[..., None], hyp)
+        assert hip_lib.cdkf_last_kernel().startswith(b"grad_lpe_l63_kernel<double, true>"), hip_lib.cdkf_last_kernel()
+        np.testing.assert_allclose(ll, ll_ref, rtol=1e-11)
+        got = leaves(g, N)
+        ex = dict(ex, drift=g_ref)
+        for name in ("drift", "m0", "P0", "L", "Qc", "H", "bias", "R"):
+            scale = np.abs(ex[name]).max() + 1e-300
+            assert np.abs(np.asarray(got[name]) - ex[name]).max() < 1e-9 * scale, (name, N, T)
+    # fp32 and the other kernel on the last batch but one
+    t = o.irregular_times(rng, 7, 20, 0.02)
+    y = o.simulate(mdl, t, rng)
+    ll_ref, g_ref, ex = o.ekf_loglik_grad_adjoint(mdl, t, y, full=True)
+    ll32, g32 = cd.cdnlgssm_loglik_and_grad_all(P, y.astype(np.float32), t[..., None].astype(np.float32), hyp)
+    assert hip_lib.cdkf_last_kernel().startswith(b"grad_lpe_l63_kernel<float, true>")
+    got32 = leaves(g32, 7)
+    for name in ("m0", "P0", "Qc", "H", "bias", "R"):
+        assert np.abs(np.asarray(got32[name]) - ex[name]).max() < 2e-2 * np.abs(ex[name]).max(), name
+    ll, g = cd.cdnlgssm_loglik_and_grad_all(P, y, t[..., None], hyp)
+    got = leaves(g, 7)
+    np.savez(tmp_path / "in.npz", t=t, y=y, L=mdl.L, Qc=mdl.Qc, R=mdl.R, m0=mdl.m0, P0=mdl.P0)
+    code = ("import sys, numpy as np; sys.path[:0] = [%r, %r, %r]\n"
+            "import cd_dynamax_amd as cd, cdkf_oracle as o\nfrom cd_dynamax_amd import _ffi\nfrom helpers import params_from\n"
+            "d = np.load(%r); mdl = o.Model(o.lorenz63_model(3).drift, d['L'], d['Qc'], np.eye(3), np.zeros(3), d['R'], d['m0'], d['P0'])\n"
+            "ll, g = cd.cdnlgssm_loglik_and_grad_all(params_from(mdl), d['y'], d['t'][..., None], cd.EKFHyperParams(state_order='first'))\n"
+            "assert _ffi.lib().cdkf_last_kernel().startswith(b'ekf_adjoint_wave8_kernel'), _ffi.lib().cdkf_last_kernel()\n"
+            "np.savez(%r, ll=ll, H=g.emissions.emission_function.weights, R=g.emissions.emission_cov.params, P0=g.initial.cov.params,\n"
+            "         L=g.dynamics.diffusion_coefficient.params, rho=g.dynamics.drift.rho)\n"
+            % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(o.__file__)),
+               os.path.dirname(os.path.abspath(__file__)), str(tmp_path / "in.npz"), str(tmp_path / "out.npz")))
+    subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CDKF_NO_LPE_GRAD="1"), check=True, timeout=600)
+    other = np.load(tmp_path / "out.npz")
+    assert relerr(ll, other["ll"]) < 1e-12
+    for name in ("H", "R", "P0", "L"):
+        assert np.abs(np.asarray(got[name]) - other[name]).max() < 1e-9 * np.abs(other[name]).max(), name
+    assert np.abs(np.asarray(g.dynamics.drift.rho) - other["rho"]).max() < 1e-9 * np.abs(other["rho"]).max()
+
+
 @pytest.mark.parametrize("solver", ["tsit5", "heun", "euler"])
 def test_workgroup_kernels_other_runge_kutta_methods(hip_lib, solver):
     """diffeqsolve_settings={'solver': ...} beyond the register-resident shapes: Lorenz-96 d = 12 (workgroup kernels) and
