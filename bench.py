@@ -245,9 +245,17 @@ def value_and_grad(lib, blk, opts, N, T, t_d, y_d, ll, timer, stream, reps=5):
     run = lambda: _ffi.check(lib.cdkf_ekf_loglik_grad_f64_dev(C.byref(blk.c), C.byref(opts), N, T, t_d.ptr, y_d.ptr, ll.ptr,
                                                               grad.ptr, st.ptr, stream))
     ms = timer.ms_per_call(run, reps)
-    return {"workload": "same batch: marginal log-likelihood + d/d(sigma, rho, beta) per trajectory, fp64",
-            "kernel": lib.cdkf_last_kernel().decode(), "kernel_ms": ms,
-            "trajectories_per_sec": N / (ms * 1e-3), "grad_sum": [float(v) for v in grad.numpy().sum(0)]}
+    out = {"workload": "same batch: marginal log-likelihood + d/d(sigma, rho, beta) per trajectory, fp64",
+           "kernel": lib.cdkf_last_kernel().decode(), "kernel_ms": ms,
+           "trajectories_per_sec": N / (ms * 1e-3), "grad_sum": [float(v) for v in grad.numpy().sum(0)]}
+    # every trainable leaf (what fit_sgd differentiates): + m0, P0, L Qc L^T, H, bias, R per trajectory
+    gm = DeviceArray((N, _ffi.model_grad_size(3, 3)), np.float64)
+    run_all = lambda: _ffi.check(lib.cdkf_ekf_loglik_grad_all_f64_dev(C.byref(blk.c), C.byref(opts), N, T, t_d.ptr, y_d.ptr, ll.ptr,
+                                                                      grad.ptr, gm.ptr, st.ptr, stream))
+    out["all_parameters_ms"] = timer.ms_per_call(run_all, reps)
+    out["all_parameters_kernel"] = lib.cdkf_last_kernel().decode()
+    gm.free()
+    return out
 
 
 def saturated(lib, blk, opts, timer, stream, n=131072, reps=5):

@@ -696,14 +696,15 @@ inline bool lpe_batch_is_small(int64_t N) {
 // Small Lorenz-63 batches (H = I): sixteen lanes per trajectory (cdkf_lpe_kernels.h).  CDKF_NO_LPE=1 keeps the
 // lane-per-trajectory kernel (A/B timing, tests of the latter at small N).
 template <typename R, int D, int M, typename Drift>
-inline bool try_lpe(const RegArgs<R, D, M, Drift>& a, const cdkf_model* mdl, const cdkf_opts* o, hipStream_t stream, bool ukf = false) {
+inline bool try_lpe(const RegArgs<R, D, M, Drift>& a, const cdkf_model* mdl, const cdkf_opts* o, hipStream_t stream, bool ukf = false,
+                    bool any_batch = false) {  // any_batch: also beyond one wavefront per SIMD (the reverse sweep's forward pass)
   if constexpr ((std::is_same<Drift, DriftLorenz63<R, 3>>::value || std::is_same<Drift, DriftLinear<R, 3>>::value) && D == 3 && M <= 3) {
     static const bool off = [] { const char* e = std::getenv("CDKF_NO_LPE"); return e && e[0] == '1'; }();
     // CDKF_UKF_SIGMA_POINTS=1: the unscented filter on the lane-per-trajectory kernel, which forms the sigma points (A/B, tests)
     static const bool ukf_off = [] { const char* e = std::getenv("CDKF_UKF_SIGMA_POINTS"); return e && e[0] == '1'; }();
     const bool all = a.fm && a.fP && a.pm && a.pP, none = !a.fm && !a.fP && !a.pm && !a.pP;
     const bool filt = a.fm && a.fP && !a.pm && !a.pP;
-    if (off || !lpe_batch_is_small(a.N) || !(all || none || filt) || (M == 3 && !emission_is_selection(mdl)) || o->forecast ||
+    if (off || (!any_batch && !lpe_batch_is_small(a.N)) || !(all || none || filt) || (M == 3 && !emission_is_selection(mdl)) || o->forecast ||
         o->solver != CDKF_SOLVER_DOPRI5 || o->adaptive)
       return false;
     if (!ukf && o->state_order == CDKF_ORDER_ZEROTH) return false;

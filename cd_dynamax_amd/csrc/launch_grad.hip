@@ -57,8 +57,11 @@ static int try_lpe_grad(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, in
   static const bool off = [] { const char* e = std::getenv("CDKF_NO_LPE_GRAD"); return e && e[0] == '1'; }();
   if (off || mdl->drift_kind != CDKF_DRIFT_LORENZ63 || mdl->state_dim != 3 || mdl->emission_dim != 3 || !emission_is_selection(mdl) ||
       o->num_iter != 1 || o->forecast || o->solver != CDKF_SOLVER_DOPRI5 || o->adaptive || o->state_order == CDKF_ORDER_ZEROTH ||
-      !lpe_batch_is_small(N) || N < 1 || T < 1 || !y)
+      N < 1 || T < 1 || !y)
     return CDKF_OK;
+  // drift block only: the forward-sensitivity kernel catches up once the grid has more than a wavefront per SIMD; with the model block
+  // the alternative is the wavefront-per-trajectory reverse sweep (40x slower at this state dimension), whatever the batch size
+  if (!grad_model && !lpe_batch_is_small(N)) return CDKF_OK;
   for (int r = 0; r < 3; ++r)
     for (int c = 0; c < r; ++c)
       if (R(mdl->R[r * 3 + c]) != R(mdl->R[c * 3 + r])) return CDKF_OK;
@@ -69,11 +72,14 @@ static int try_lpe_grad(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, in
   const size_t nm = (size_t)N * T * 3, nP = nm * 3;
   GradWorkspaceLease ws;
   void* wp = nullptr;
-  if (int rc = ws.reserve(2 * (nm + nP) * sizeof(R), stream, &wp)) return rc;
+  if (ws.reserve(2 * (nm + nP) * sizeof(R), stream, &wp)) {  // no room for the moments: the caller's other kernel (the forward
+    (void)hipGetLastError();                                  // sensitivities need no workspace)
+    return CDKF_OK;
+  }
   R* w = (R*)wp;
   RegArgs<R, 3, 3, DriftLorenz63<R, 3>> a;
   fill_reg_args(a, mdl, &of, N, T, t, y, ll, w, w + nm, w + nm + nP, w + 2 * nm + nP, status);
-  if (!try_lpe(a, mdl, &of, stream)) return CDKF_OK;
+  if (!try_lpe(a, mdl, &of, stream, false, grad_model != nullptr)) return CDKF_OK;
   CDKF_HIP_CHECK(hipGetLastError());
   *handled = true;
   note_kernel("grad_lpe_l63_kernel<%s, %s>", real_name<R>(), grad_model ? "true" : "false");

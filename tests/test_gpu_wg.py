@@ -445,6 +445,19 @@ def test_lorenz63_gradient_all_parameters_on_the_lane_grid(hip_lib, tmp_path):
         for name in ("drift", "m0", "P0", "L", "Qc", "H", "bias", "R"):
             scale = np.abs(ex[name]).max() + 1e-300
             assert np.abs(np.asarray(got[name]) - ex[name]).max() < 1e-9 * scale, (name, N, T)
+    # more trajectories than one wavefront per SIMD: still this kernel for the model block (the alternative is 40x slower)
+    N, T = 4400, 4
+    t = o.irregular_times(rng, N, T, 0.02)
+    y = o.simulate(mdl, t, rng)
+    ll, g = cd.cdnlgssm_loglik_and_grad_all(P, y, t[..., None], hyp)
+    assert hip_lib.cdkf_last_kernel().startswith(b"grad_lpe_l63_kernel<double, true>"), hip_lib.cdkf_last_kernel()
+    sub = np.array([0, 1234, 4097, 4399])
+    ll_ref, g_ref, ex = o.ekf_loglik_grad_adjoint(mdl, t[sub], y[sub], full=True)
+    got = leaves(g, N)
+    np.testing.assert_allclose(ll[sub], ll_ref, rtol=1e-11)
+    for name in ("m0", "P0", "L", "Qc", "H", "bias", "R"):
+        assert np.abs(np.asarray(got[name])[sub] - ex[name]).max() < 1e-9 * (np.abs(ex[name]).max() + 1e-300), name
+    assert np.abs(got["drift"][sub] - g_ref).max() < 1e-9 * np.abs(g_ref).max()
     # fp32 and the other kernel on the last batch but one
     t = o.irregular_times(rng, 7, 20, 0.02)
     y = o.simulate(mdl, t, rng)
