@@ -410,12 +410,13 @@ __global__ __launch_bounds__(64) void grad_lpe_l63_kernel(const RegArgs<R, 3, 3,
     R tp = t0, tq = rmin(t0 + a.dt0, t1);
     const R dt_0 = tq - tp;
     advance(tp, tq, t1);
-    if (tp < t1) {  // more than one Runge-Kutta step in this interval: the starts of the steps 1, 2, ... (and their sizes, in lane
-                    // 15's slot) are parked in LDS on the way forward
+    // more than one Runge-Kutta step in this interval: the starts of the steps 1, 2, ... (and their sizes, in lane 15's slot) are parked
+    // in LDS on the way forward
+    if (tp < t1 && a.max_steps > 1) {
       R y = y0;
       lpe_step<R>(y, dt_0, rhs, C);
       int S = 1;
-      while (tp < t1) {
+      while (tp < t1 && S < a.max_steps) {  // (the forward sweep stops at max_steps as well, and raises the flag)
         const R dt = tq - tp;
         if (S <= kLpeGradCap) starts[S - 1][lane] = (l == 15) ? dt : y;
         advance(tp, tq, t1);

@@ -10,7 +10,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     rng = np.random.default_rng(77)
     mdl = o.lorenz63_model(3)
     out = {}
-    for name, N, T, gap in (("a", 70, 40, 0.2), ("b", 9, 30, 0.008), ("c", 5, 6, 0.9)):
+    for name, N, T, gap in (("a", 70, 40, 0.2), ("b", 9, 30, 0.008), ("c", 5, 4, 2.4)):  # (total spans)
         t = o.irregular_times(rng, N, T, gap)
         y = o.simulate(mdl, t, rng)
         ll, g = cd.cdnlgssm_loglik_and_grad(params_from(mdl), y, t[..., None])

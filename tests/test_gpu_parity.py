@@ -637,10 +637,12 @@ def test_loglik_gradient_reverse_sweep_on_the_lane_grid(hip_lib, tmp_path):
         assert np.max(np.abs(flat(g) - g_ref) / scale) < tol
         return ll, flat(g)
 
-    for N, T, gap in ((13, 50, 0.008), (6, 12, 0.05), (5, 6, 0.9), (3, 1, 0.01), (2, 2, 0.3), (1, 9, 0.02)):
-        t = o.irregular_times(rng, N, T, gap)
+    # (total time spans: mean gaps of 0.006, 0.05 and 0.8 = one, about five and about eighty steps of dt0 = 0.01 per interval)
+    for N, T, span in ((13, 50, 0.3), (6, 12, 0.6), (5, 4, 2.4), (3, 1, 0.01), (2, 2, 0.3), (1, 9, 0.2)):
+        t = o.irregular_times(rng, N, T, span)
         check(mdl, t, o.simulate(mdl, t, rng))
-    t = o.irregular_times(rng, 9, 30, 0.02)
+    t = o.irregular_times(rng, 9, 30, 0.9)
+    assert np.diff(t, axis=1).max() > 0.05
     y = o.simulate(mdl, t, rng)
     check(mdl, t, y, tol=5e-3, dtype=np.float32)
     # one time grid shared by the batch
@@ -651,23 +653,33 @@ def test_loglik_gradient_reverse_sweep_on_the_lane_grid(hip_lib, tmp_path):
     assert np.max(np.abs(flat(g_s) - g_ref) / (np.abs(g_ref).max(axis=0, keepdims=True) + 1e-30)) < 1e-9
     # dense symmetric R, non-trivial diffusion, off-centre prior
     A = rng.standard_normal((3, 3))
+    R2 = 0.3 * np.eye(3) + 0.1 * A @ A.T
+    R2 = 0.5 * (R2 + R2.T)  # bitwise symmetric (the in-grid update's condition; anything else takes the per-lane kernels)
     mdl2 = o.Model(mdl.drift, np.eye(3) + 0.2 * rng.standard_normal((3, 3)), np.diag([0.5, 1.5, 1.0]), mdl.H, mdl.bias,
-                   0.3 * np.eye(3) + 0.1 * A @ A.T, np.array([1.0, -2.0, 20.0]), 2.0 * np.eye(3) + 0.3 * A.T @ A)
+                   R2, np.array([1.0, -2.0, 20.0]), 2.0 * np.eye(3) + 0.3 * A.T @ A)
     check(mdl2, t, o.simulate(mdl2, t, rng))
     # the same call in a process that keeps the forward-sensitivity kernel
     ll, g = check(mdl, t, y)
+    # (and with the step count capped below what the longer intervals need: both sweeps stop there, the flag is the forward sweep's)
+    capped = cd.EKFHyperParams(diffeqsolve_settings={"max_steps": 1})
+    ll_c, g_c = cd.cdnlgssm_loglik_and_grad(P, y, t[..., None], capped)
+    assert hip_lib.cdkf_last_kernel().startswith(b"grad_lpe_l63_kernel<double")
     np.savez(tmp_path / "in.npz", t=t, y=y)
     code = ("import sys, numpy as np; sys.path[:0] = [%r, %r, %r]\n"
             "import cd_dynamax_amd as cd, cdkf_oracle as o\nfrom cd_dynamax_amd import _ffi\nfrom helpers import params_from\n"
             "d = np.load(%r); ll, g = cd.cdnlgssm_loglik_and_grad(params_from(o.lorenz63_model(3)), d['y'], d['t'][..., None])\n"
             "assert _ffi.lib().cdkf_last_kernel().startswith(b'ekf_grad_reg_kernel'), _ffi.lib().cdkf_last_kernel()\n"
-            "np.savez(%r, ll=ll, g=np.stack([g.sigma, g.rho, g.beta], -1))\n"
+            "llc, gc = cd.cdnlgssm_loglik_and_grad(params_from(o.lorenz63_model(3)), d['y'], d['t'][..., None],\n"
+            "                                      cd.EKFHyperParams(diffeqsolve_settings={'max_steps': 1}))\n"
+            "np.savez(%r, ll=ll, g=np.stack([g.sigma, g.rho, g.beta], -1), llc=llc, gc=np.stack([gc.sigma, gc.rho, gc.beta], -1))\n"
             % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(o.__file__)),
                os.path.dirname(os.path.abspath(__file__)), str(tmp_path / "in.npz"), str(tmp_path / "out.npz")))
     subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CDKF_NO_LPE_GRAD="1"), check=True, timeout=600)
     other = np.load(tmp_path / "out.npz")
     assert relerr(ll, other["ll"]) < 1e-12
     assert np.max(np.abs(g - other["g"]) / np.abs(other["g"]).max(axis=0, keepdims=True)) < 1e-10
+    assert relerr(ll_c, other["llc"]) < 1e-12 and relerr(ll_c, ll) > 1e-6
+    assert np.max(np.abs(flat(g_c) - other["gc"]) / np.abs(other["gc"]).max(axis=0, keepdims=True)) < 1e-10
 
 
 def test_loglik_gradient_unsupported_raises(hip_lib):

@@ -422,8 +422,10 @@ def test_lorenz63_gradient_all_parameters_on_the_lane_grid(hip_lib, tmp_path):
     rng = np.random.default_rng(2718)
     base = o.lorenz63_model(3)
     A, B, C = rng.standard_normal((3, 3)), rng.standard_normal((3, 3)), rng.standard_normal((3, 3))
+    Rm = B @ B.T / 3 + 0.4 * np.eye(3)
+    Rm = 0.5 * (Rm + Rm.T)  # bitwise symmetric: the in-grid update's condition
     mdl = o.Model(base.drift, np.eye(3) + 0.2 * rng.standard_normal((3, 3)), A @ A.T / 3 + 0.3 * np.eye(3), np.eye(3), np.zeros(3),
-                  B @ B.T / 3 + 0.4 * np.eye(3), np.array([1.0, -1.5, 18.0]), C @ C.T / 3 + 0.5 * np.eye(3))
+                  Rm, np.array([1.0, -1.5, 18.0]), C @ C.T / 3 + 0.5 * np.eye(3))
     P = params_from(mdl)
     hyp = cd.EKFHyperParams(state_order="first")
 
@@ -433,8 +435,9 @@ def test_lorenz63_gradient_all_parameters_on_the_lane_grid(hip_lib, tmp_path):
                 "Qc": g.dynamics.diffusion_cov.params, "H": g.emissions.emission_function.weights,
                 "bias": g.emissions.emission_function.bias, "R": g.emissions.emission_cov.params}
 
-    for N, T, gap in ((6, 14, 0.008), (5, 9, 0.06), (3, 1, 0.01), (2, 5, 0.9)):
-        t = o.irregular_times(rng, N, T, gap)
+    # (total time spans: about one, seven and eighty steps of dt0 = 0.01 per interval -- the last beyond the 64 step starts kept in LDS)
+    for N, T, span in ((6, 14, 0.1), (5, 9, 0.6), (3, 1, 0.01), (2, 4, 2.4)):
+        t = o.irregular_times(rng, N, T, span)
         y = o.simulate(mdl, t, rng)
         ll_ref, g_ref, ex = o.ekf_loglik_grad_adjoint(mdl, t, y, full=True)
         ll, g = cd.cdnlgssm_loglik_and_grad_all(P, y, t[..., None], hyp)
@@ -459,7 +462,7 @@ def test_lorenz63_gradient_all_parameters_on_the_lane_grid(hip_lib, tmp_path):
         assert np.abs(np.asarray(got[name])[sub] - ex[name]).max() < 1e-9 * (np.abs(ex[name]).max() + 1e-300), name
     assert np.abs(got["drift"][sub] - g_ref).max() < 1e-9 * np.abs(g_ref).max()
     # fp32 and the other kernel on the last batch but one
-    t = o.irregular_times(rng, 7, 20, 0.02)
+    t = o.irregular_times(rng, 7, 20, 0.5)
     y = o.simulate(mdl, t, rng)
     ll_ref, g_ref, ex = o.ekf_loglik_grad_adjoint(mdl, t, y, full=True)
     ll32, g32 = cd.cdnlgssm_loglik_and_grad_all(P, y.astype(np.float32), t[..., None].astype(np.float32), hyp)
