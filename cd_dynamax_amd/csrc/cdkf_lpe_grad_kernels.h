@@ -15,11 +15,15 @@
 //   forms the one its ROW contributes from the row fetches it already holds and the three lanes of the row add up in the row's mean
 //   lane (quad permutations); the parameter sums stay distributed over the lanes -- row 0 collects
 //   d/d sigma, row 1 d/d rho, row 2 d/d beta -- and are added up once, after the sweep.
-// * update, reversed: every lane gathers the predicted moments, the observation and the cotangents (row_newbcast) and evaluates the
-//   3 x 3 algebra of the reverse update redundantly, then keeps its own entry.
+// * update, reversed (lpe_update_adj): the update's reverse in Joseph form, the rows of the grid carrying different rows of the
+//   3 x 3 matrices with one instruction stream, as lpe_update does for the forward update;
+// * ALL: the model block as well -- m0, P0 (what is left after the first update), L Qc L^T (the sum of the slope cotangents), H, bias,
+//   R (from the reverse update's intermediate cotangents) -- for cdkf_ekf_loglik_grad_all_*.
 //
-// The arithmetic follows oracle/cdkf_oracle.py::ekf_loglik_grad_adjoint (H = I, symmetric R, num_iter 1); grad(div f) = 0 for this
-// drift, so state_order 'first' and 'second' coincide.
+// What is reversed: _predict's moment equations (inference_ekf.py:76-123) under diffeqsolve's fixed-step Dopri5 (diffrax_utils.py:40-165)
+// and _condition_on + the log-likelihood term (inference_ekf.py:153-199, 285-286), for H = I, symmetric R, num_iter 1 -- the numbers JAX's
+// reverse mode gives for the discretised recursion (the tests hold them to a NumPy restatement of that adjoint, itself pinned by finite
+// differences).  grad(div f) = 0 for this drift, so state_order 'first' and 'second' coincide.
 #pragma once
 #include "cdkf_lpe_kernels.h"
 
@@ -173,7 +177,8 @@ CDKF_DEV R lpe_sel3(int j, R a0, R a1, R a2) {
 // with the observation in row 3, vb = the cotangents of the filtered moments; returns this lane's cotangent of the predicted
 // moments (the log-likelihood term of the observation included).
 //
-// The oracle's reverse update (ekf_loglik_grad_adjoint: vbar, Kbar, Sbar, Ubar) collapses, for H = I, to the Joseph form: with
+// The reverse of the update (cotangents vbar, Kbar, Sbar, Ubar of the innovation, the gain, S and the solve) collapses, for H = I, to the
+// Joseph form: with
 // A = (S + eps I)^-1, X = A P (the transposed gain), J = I - X = A (R + eps I), u = A v, w = S^-1 v and S A = I - eps A,
 //     Pbar <- J Pbar J^T + sym((J mbar) u^T) + 2 eps sym(J Pbar X^T A) + w w^T / 2 - S^-1 / 2,      mbar <- J mbar + w
 // -- the same numbers to rounding (the eps term is kept: it is 1e-9 of the first, which is the tolerance of the parity tests;
@@ -296,7 +301,7 @@ CDKF_DEV R lpe_update_adj(const Args& a, R vp, R vb, const int i, const int j, L
   const R Zt = lpe_transpose(Z, l);
   const R pn = Q + (Z + Zt);
   if constexpr (ALL) {
-    // The oracle's intermediate cotangents in these terms: vbar = mbar - J mbar - w;  Ubar = u mbar^T - 2 X Pbar + 2 eps A X Pbar
+    // The intermediate cotangents in these terms: vbar = mbar - J mbar - w;  Ubar = u mbar^T - 2 X Pbar + 2 eps A X Pbar
     // (X Pbar = Pbar - J Pbar);  Sbar = Pbar_new - Pbar - sym(Ubar^T).  Then  Rbar += Sbar,  biasbar -= vbar,
     // Hbar += (2 Sbar + Ubar) P - vbar m^T   (H = I: H P = P).
     const R mbi = lpe_dpp<0xFF>(vb);  // quad_perm [3,3,3,3]: the row's mean lane
@@ -451,7 +456,7 @@ __global__ __launch_bounds__(64) void grad_lpe_l63_kernel(const RegArgs<R, 3, 3,
   const R g2 = (lpe_bcast<8>(th) + lpe_bcast<9>(th)) + (lpe_bcast<10>(th) + lpe_bcast<11>(th));
   if (live && l < 3) grad[n * 3 + l] = (l == 0) ? g0 : ((l == 1) ? g1 : g2);
   if constexpr (ALL) {
-    // the symmetric blocks as the oracle returns them: averaged with the transpose partner
+    // the symmetric blocks as a symmetric parametrisation pairs with them: averaged with the transpose partner
     const R P0b = R(0.5) * (vb + lpe_transpose(vb, l)), Lb = R(0.5) * (acc.lql + lpe_transpose(acc.lql, l)),
             Rb = R(0.5) * (acc.r + lpe_transpose(acc.r, l));
     R* gm = grad_model + n * 42;
