@@ -341,10 +341,168 @@ CDKF_DEV R lpe_update_adj(const Args& a, R vp, R vb, const int i, const int j, L
 }
 
 // grad [N, 3].  The forward sweep (filter_lpe_kernel, OUT = 1) has written fm, fP, pm, pP with the strides of `a`.
-// ALL: also grad_model [N, 42] = m0 [3] | P0 [3,3] | LQL [3,3] | H [3,3] | h_bias [3] | R [3,3] (include/cdkf.h, cdkf_ekf_loglik_grad_all_*)
-template <typename R, bool ALL>
-__global__ __launch_bounds__(64) void grad_lpe_l63_kernel(const RegArgs<R, 3, 3, DriftLorenz63<R, 3>> a, R* __restrict__ grad,
+// inverse of a general M x M matrix, M <= 3 (adjugate / determinant)
+template <typename R, int M>
+CDKF_DEV void lpe_invm(const R (&A)[M][M], R (&inv)[M][M]) {
+  if constexpr (M == 1) {
+    inv[0][0] = R(1) / A[0][0];
+  } else if constexpr (M == 2) {
+    const R id = R(1) / rfma(A[0][0], A[1][1], -(A[0][1] * A[1][0]));
+    inv[0][0] = A[1][1] * id;
+    inv[0][1] = -A[0][1] * id;
+    inv[1][0] = -A[1][0] * id;
+    inv[1][1] = A[0][0] * id;
+  } else {
+    const R c00 = rfma(A[1][1], A[2][2], -(A[1][2] * A[2][1]));
+    const R c01 = rfma(A[1][2], A[2][0], -(A[1][0] * A[2][2]));
+    const R c02 = rfma(A[1][0], A[2][1], -(A[1][1] * A[2][0]));
+    const R id = R(1) / rfma(A[0][2], c02, rfma(A[0][1], c01, A[0][0] * c00));
+    inv[0][0] = c00 * id;
+    inv[1][0] = c01 * id;
+    inv[2][0] = c02 * id;
+    inv[0][1] = rfma(A[0][2], A[2][1], -(A[0][1] * A[2][2])) * id;
+    inv[1][1] = rfma(A[0][0], A[2][2], -(A[0][2] * A[2][0])) * id;
+    inv[2][1] = rfma(A[0][1], A[2][0], -(A[0][0] * A[2][1])) * id;
+    inv[0][2] = rfma(A[0][1], A[1][2], -(A[0][2] * A[1][1])) * id;
+    inv[1][2] = rfma(A[0][2], A[1][0], -(A[0][0] * A[1][2])) * id;
+    inv[2][2] = rfma(A[0][0], A[1][1], -(A[0][1] * A[1][0])) * id;
+  }
+}
+
+// The reverse update for the emissions the in-grid form does not cover -- H = I[:M] with M < 3 (the forward sweep then runs
+// filter_lpe_kernel<..., FAST = false>; R symmetric as there): every lane gathers the twelve moments, the observation and the
+// cotangents and evaluates the reverse of _condition_on + the log-likelihood term (inference_ekf.py:153-199, 285-286) redundantly, in the
+// literal order of the update: S = H P H^T + R, v = y - H m, w = S^-1 v, X = (sym(S) + eps I)^-1 H P (the transposed gain), then
+//     vbar = X mbar - w,  Kbar = v mbar^T - 2 S X Pbar,  Ubar = (sym(S) + eps I)^-1 Kbar,
+//     Sbar = -X Pbar X^T + w w^T / 2 - S^-1 / 2 - sym(X Ubar^T),
+//     Pbar <- Pbar + sym(Ubar^T H) + H^T Sbar H,  mbar <- mbar - H^T vbar;   Rbar += Sbar,  biasbar -= vbar,  Hbar += 2 Sbar H P - vbar m^T + Ubar P.
+template <bool ALL, int M, typename R, typename Args>
+CDKF_DEV R lpe_update_adj_gen(const Args& a, const R vp, const R vb, const int i, const int j, LpeModelAcc<R>& acc) {
+  const R Pg[6] = {lpe_bcast<0>(vp), lpe_bcast<1>(vp), lpe_bcast<2>(vp), lpe_bcast<5>(vp), lpe_bcast<6>(vp), lpe_bcast<10>(vp)};
+  const R m[3] = {lpe_bcast<3>(vp), lpe_bcast<7>(vp), lpe_bcast<11>(vp)};
+  const R yo[3] = {lpe_bcast<12>(vp), lpe_bcast<13>(vp), lpe_bcast<14>(vp)};
+  const R B[9] = {lpe_bcast<0>(vb), lpe_bcast<1>(vb), lpe_bcast<2>(vb), lpe_bcast<4>(vb), lpe_bcast<5>(vb),
+                  lpe_bcast<6>(vb), lpe_bcast<8>(vb), lpe_bcast<9>(vb), lpe_bcast<10>(vb)};
+  const R mb[3] = {lpe_bcast<3>(vb), lpe_bcast<7>(vb), lpe_bcast<11>(vb)};
+  R P[3][3], Pb[3][3], S[M][M], Sb[M][M], Sinv[M][M], Sbinv[M][M], v[M], w[M], vbar[M];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      P[r][c] = Pg[sidx<3>(r, c)];
+      Pb[r][c] = R(0.5) * (B[3 * r + c] + B[3 * c + r]);
+    }
+#pragma unroll
+  for (int r = 0; r < M; ++r) {
+#pragma unroll
+    for (int c = 0; c < M; ++c) S[r][c] = P[r][c] + a.Rm[r][c];
+    v[r] = yo[r] - m[r];
+  }
+#pragma unroll
+  for (int r = 0; r < M; ++r)
+#pragma unroll
+    for (int c = 0; c < M; ++c) Sb[r][c] = R(0.5) * (S[r][c] + S[c][r]) + ((r == c) ? R(1e-9) : R(0));
+  lpe_invm<R, M>(S, Sinv);
+  lpe_invm<R, M>(Sb, Sbinv);
+  R X[M][3], SX[M][3], Kb[M][3], Ub[M][3], XP[M][3], Sbar[M][M];
+#pragma unroll
+  for (int r = 0; r < M; ++r) {
+    R acc_w = R(0), acc_v = R(0);
+#pragma unroll
+    for (int c = 0; c < M; ++c) acc_w = rfma(Sinv[r][c], v[c], acc_w);
+    w[r] = acc_w;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      R x = R(0);
+#pragma unroll
+      for (int k = 0; k < M; ++k) x = rfma(Sbinv[r][k], P[k][c], x);  // H P = the first M rows of P
+      X[r][c] = x;
+      acc_v = rfma(x, mb[c], acc_v);
+    }
+    vbar[r] = acc_v - w[r];
+  }
+#pragma unroll
+  for (int r = 0; r < M; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      R sx = R(0), xp = R(0);
+#pragma unroll
+      for (int k = 0; k < M; ++k) sx = rfma(S[r][k], X[k][c], sx);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) xp = rfma(X[r][k], Pb[k][c], xp);
+      SX[r][c] = sx;
+      XP[r][c] = xp;
+    }
+#pragma unroll
+  for (int r = 0; r < M; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      R t1 = R(0);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) t1 = rfma(SX[r][k], Pb[k][c], t1);
+      Kb[r][c] = rfma(R(-2), t1, v[r] * mb[c]);
+    }
+#pragma unroll
+  for (int r = 0; r < M; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      R u = R(0);
+#pragma unroll
+      for (int k = 0; k < M; ++k) u = rfma(Sbinv[r][k], Kb[k][c], u);
+      Ub[r][c] = u;
+    }
+#pragma unroll
+  for (int r = 0; r < M; ++r)
+#pragma unroll
+    for (int c = 0; c < M; ++c) {
+      R q = R(0), xu = R(0), ux = R(0);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        q = rfma(XP[r][k], X[c][k], q);
+        xu = rfma(X[r][k], Ub[c][k], xu);
+        ux = rfma(X[c][k], Ub[r][k], ux);
+      }
+      Sbar[r][c] = rfma(R(-0.5), xu + ux, rfma(R(0.5), rfma(w[r], w[c], -Sinv[r][c]), -q));
+    }
+  R out = R(0);
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      R pn = Pb[r][c];
+      if (c < M) pn = rfma(R(0.5), Ub[c < M ? c : 0][r], pn);  // sym(Ubar^T H): (Ubar^T H)_rc = Ubar_cr for c < M
+      if (r < M) pn = rfma(R(0.5), Ub[r < M ? r : 0][c], pn);
+      if (r < M && c < M) pn += Sbar[r < M ? r : 0][c < M ? c : 0];
+      out = (i == r && j == c) ? pn : out;
+    }
+    out = (i == r && j == 3) ? ((r < M) ? mb[r] - vbar[r < M ? r : 0] : mb[r]) : out;
+  }
+  if constexpr (ALL) {
+#pragma unroll
+    for (int r = 0; r < M; ++r) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        R h = -(vbar[r] * m[c]);
+#pragma unroll
+        for (int k = 0; k < M; ++k) h = rfma(R(2) * Sbar[r][k], P[k][c], h);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) h = rfma(Ub[r][k], P[k][c], h);
+        acc.h += (i == r && j == c) ? h : R(0);
+        if (c < M) acc.r += (i == r && j == c) ? Sbar[r][c < M ? c : 0] : R(0);
+      }
+      acc.b -= (i == r) ? vbar[r] : R(0);
+    }
+  }
+  return out;
+}
+
+// M: emission dimension (H = I[:M], symmetric R).  GRID: the reverse update in the grid (lpe_update_adj: M = 3); otherwise per lane.
+// ALL: also grad_model [N, 21 + 3 M + M + M^2] = m0 [3] | P0 [3,3] | LQL [3,3] | H [M,3] | h_bias [M] | R [M,M] (include/cdkf.h,
+// cdkf_ekf_loglik_grad_all_*)
+template <typename R, int M, bool GRID, bool ALL>
+__global__ __launch_bounds__(64) void grad_lpe_l63_kernel(const RegArgs<R, 3, M, DriftLorenz63<R, 3>> a, R* __restrict__ grad,
                                                           R* __restrict__ grad_model) {
+  static_assert(!GRID || M == 3, "the in-grid reverse update is written for H = I");
   constexpr int D = 3;
   __shared__ R starts[kLpeGradCap][64];
   const int lane = threadIdx.x, l = lane & 15, i = l >> 2, j = l & 3;
@@ -377,9 +535,9 @@ __global__ __launch_bounds__(64) void grad_lpe_l63_kernel(const RegArgs<R, 3, 3,
     stride = a.m_sk;
     pp = a.pm + n * a.m_sn + i * a.m_si + lastm * stride;
     fp = a.fm + n * a.m_sn + i * a.m_si + lastm * stride;
-  } else if (j < 3) {
+  } else if (j < 3) {  // (a lane without an observation component mirrors component 0)
     stride = a.y_sk;
-    pp = a.y + n * a.y_sn + j * a.y_si + last * stride;
+    pp = a.y + n * a.y_sn + (j < M ? j : 0) * a.y_si + last * stride;
     fp = pp;
   } else {
     stride = a.t_sk;
@@ -407,7 +565,10 @@ __global__ __launch_bounds__(64) void grad_lpe_l63_kernel(const RegArgs<R, 3, 3,
       fv = fp[0];
     }
     if (k == 0 && i < 3) vp = own0;
-    vb = lpe_update_adj<ALL, R>(a, vp, vb, i, j, acc);
+    if constexpr (GRID)
+      vb = lpe_update_adj<ALL, R>(a, vp, vb, i, j, acc);
+    else
+      vb = lpe_update_adj_gen<ALL, M, R>(a, vp, vb, i, j, acc);
     if (k == 0) break;
     // ---- the predict from k-1 to k, reversed ----
     const R t1 = lpe_bcast<15>(vp), t0 = lpe_bcast<15>(vf);
@@ -459,16 +620,16 @@ __global__ __launch_bounds__(64) void grad_lpe_l63_kernel(const RegArgs<R, 3, 3,
     // the symmetric blocks as a symmetric parametrisation pairs with them: averaged with the transpose partner
     const R P0b = R(0.5) * (vb + lpe_transpose(vb, l)), Lb = R(0.5) * (acc.lql + lpe_transpose(acc.lql, l)),
             Rb = R(0.5) * (acc.r + lpe_transpose(acc.r, l));
-    R* gm = grad_model + n * 42;
+    R* gm = grad_model + n * (21 + 4 * M + M * M);
     if (live && cov) {
       gm[3 + i * 3 + j] = P0b;
       gm[12 + i * 3 + j] = Lb;
-      gm[21 + i * 3 + j] = acc.h;
-      gm[33 + i * 3 + j] = Rb;
+      if (i < M) gm[21 + i * 3 + j] = acc.h;
+      if (i < M && j < M) gm[21 + 4 * M + i * M + j] = Rb;
     }
     if (live && mean) {
       gm[i] = vb;
-      gm[30 + i] = acc.b;
+      if (i < M) gm[21 + 3 * M + i] = acc.b;
     }
   }
 }

@@ -48,23 +48,15 @@ static int run_grad(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_
   return CDKF_OK;
 }
 
-// Small Lorenz-63 batches, H = I: forward sweep + reverse sweep on the sixteen-lanes-per-trajectory grid (cdkf_lpe_grad_kernels.h).
-// CDKF_NO_LPE_GRAD=1 keeps the forward-sensitivity kernel (A/B timing, tests).  handled = false: not this kernel's case.
-template <typename R>
-static int try_lpe_grad(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll, R* grad,
+// Small Lorenz-63 batches, H = I[:m]: forward sweep + reverse sweep on the sixteen-lanes-per-trajectory grid (cdkf_lpe_grad_kernels.h).
+// CDKF_NO_LPE_GRAD=1 keeps the other kernels (A/B timing, tests).  handled = false: not this kernel's case.
+template <typename R, int M>
+static int run_lpe_grad(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll, R* grad,
                         R* grad_model, int32_t* status, hipStream_t stream, bool* handled) {
-  *handled = false;
-  static const bool off = [] { const char* e = std::getenv("CDKF_NO_LPE_GRAD"); return e && e[0] == '1'; }();
-  if (off || mdl->drift_kind != CDKF_DRIFT_LORENZ63 || mdl->state_dim != 3 || mdl->emission_dim != 3 || !emission_is_selection(mdl) ||
-      o->num_iter != 1 || o->forecast || o->solver != CDKF_SOLVER_DOPRI5 || o->adaptive || o->state_order == CDKF_ORDER_ZEROTH ||
-      N < 1 || T < 1 || !y)
-    return CDKF_OK;
-  // drift block only: the forward-sensitivity kernel catches up once the grid has more than a wavefront per SIMD; with the model block
-  // the alternative is the wavefront-per-trajectory reverse sweep (40x slower at this state dimension), whatever the batch size
-  if (!grad_model && !lpe_batch_is_small(N)) return CDKF_OK;
-  for (int r = 0; r < 3; ++r)
-    for (int c = 0; c < r; ++c)
-      if (R(mdl->R[r * 3 + c]) != R(mdl->R[c * 3 + r])) return CDKF_OK;
+  bool sym = true;
+  for (int r = 0; r < M; ++r)
+    for (int c = 0; c < r; ++c) sym = sym && R(mdl->R[r * M + c]) == R(mdl->R[c * M + r]);
+  if (!sym) return CDKF_OK;  // (the reverse update is written for a symmetric S = H P H^T + R)
   // the forward sweep's four moment arrays, [T, N, comp] (a wavefront's stores and loads are contiguous pieces)
   cdkf_opts of = *o;
   of.layout_in = (o->layout_in == CDKF_LAYOUT_SAME) ? o->layout : o->layout_in;
@@ -77,18 +69,49 @@ static int try_lpe_grad(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, in
     return CDKF_OK;
   }
   R* w = (R*)wp;
-  RegArgs<R, 3, 3, DriftLorenz63<R, 3>> a;
+  RegArgs<R, 3, M, DriftLorenz63<R, 3>> a;
   fill_reg_args(a, mdl, &of, N, T, t, y, ll, w, w + nm, w + nm + nP, w + 2 * nm + nP, status);
   if (!try_lpe(a, mdl, &of, stream, false, grad_model != nullptr)) return CDKF_OK;
   CDKF_HIP_CHECK(hipGetLastError());
   *handled = true;
-  note_kernel("grad_lpe_l63_kernel<%s, %s>", real_name<R>(), grad_model ? "true" : "false");
+  const bool grid = M == 3;  // the reverse update inside the grid (the forward sweep made the same choice: lpe_update)
+  note_kernel("grad_lpe_l63_kernel<%s, %d, %s, %s>", real_name<R>(), M, grid ? "true" : "false", grad_model ? "true" : "false");
+  const dim3 g(lpe_blocks<R>(N)), b(64);
+  if constexpr (M == 3) {
+    if (grid) {
+      if (grad_model)
+        hipLaunchKernelGGL((grad_lpe_l63_kernel<R, 3, true, true>), g, b, 0, stream, a, grad, grad_model);
+      else
+        hipLaunchKernelGGL((grad_lpe_l63_kernel<R, 3, true, false>), g, b, 0, stream, a, grad, grad_model);
+      CDKF_HIP_CHECK(hipGetLastError());
+      return ws.done(stream);
+    }
+  }
   if (grad_model)
-    hipLaunchKernelGGL((grad_lpe_l63_kernel<R, true>), dim3(lpe_blocks<R>(N)), dim3(64), 0, stream, a, grad, grad_model);
+    hipLaunchKernelGGL((grad_lpe_l63_kernel<R, M, false, true>), g, b, 0, stream, a, grad, grad_model);
   else
-    hipLaunchKernelGGL((grad_lpe_l63_kernel<R, false>), dim3(lpe_blocks<R>(N)), dim3(64), 0, stream, a, grad, grad_model);
+    hipLaunchKernelGGL((grad_lpe_l63_kernel<R, M, false, false>), g, b, 0, stream, a, grad, grad_model);
   CDKF_HIP_CHECK(hipGetLastError());
   return ws.done(stream);
+}
+
+template <typename R>
+static int try_lpe_grad(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll, R* grad,
+                        R* grad_model, int32_t* status, hipStream_t stream, bool* handled) {
+  *handled = false;
+  static const bool off = [] { const char* e = std::getenv("CDKF_NO_LPE_GRAD"); return e && e[0] == '1'; }();
+  if (off || mdl->drift_kind != CDKF_DRIFT_LORENZ63 || mdl->state_dim != 3 || mdl->emission_dim > 3 || !emission_is_selection(mdl) ||
+      o->num_iter != 1 || o->forecast || o->solver != CDKF_SOLVER_DOPRI5 || o->adaptive || o->state_order == CDKF_ORDER_ZEROTH ||
+      N < 1 || T < 1 || !y)
+    return CDKF_OK;
+  // drift block only: the forward-sensitivity kernel catches up once the grid has more than a wavefront per SIMD; with the model block
+  // the alternative is the wavefront-per-trajectory reverse sweep (40x slower at this state dimension), whatever the batch size
+  if (!grad_model && !lpe_batch_is_small(N)) return CDKF_OK;
+  switch (mdl->emission_dim) {
+    case 1: return run_lpe_grad<R, 1>(mdl, o, N, T, t, y, ll, grad, grad_model, status, stream, handled);
+    case 2: return run_lpe_grad<R, 2>(mdl, o, N, T, t, y, ll, grad, grad_model, status, stream, handled);
+    default: return run_lpe_grad<R, 3>(mdl, o, N, T, t, y, ll, grad, grad_model, status, stream, handled);
+  }
 }
 
 template <typename R>

@@ -11,17 +11,18 @@ import cd_dynamax_amd as cd
 from helpers import params_from
 
 L = _ffi.lib()
+M = next((int(a[2:]) for a in sys.argv[1:] if a.startswith("m=")), 3)  # emission dimension (H = I[:M])
 for dtype, sfx in ((np.float64, "f64"), (np.float32, "f32")):
     rng = np.random.default_rng(0)
     N, T = 4096, 1000
-    mdl = o.lorenz63_model(3)
-    if len(sys.argv) > 1 and sys.argv[1] == "bench":  # the benchmark's batch (every gap <= dt0: one step per interval)
+    mdl = o.lorenz63_model(M)
+    if "bench" in sys.argv[1:]:  # the benchmark's batch (every gap <= dt0: one step per interval)
         import bench
         t, y = bench.make_batch(7, N, T)
-        t, y = t.astype(dtype), y.astype(dtype)
+        t, y = t.astype(dtype), y[..., :M].astype(dtype)
     else:
         t = o.irregular_times(rng, N, T, 0.01).astype(dtype)
-        y = rng.standard_normal((N, T, 3)).astype(dtype) * 5
+        y = rng.standard_normal((N, T, M)).astype(dtype) * 5
     mb = _model_block(params_from(mdl)); opts = _opts(cd.EKFHyperParams(), 1); opts.layout = _ffi.LAYOUT_TCN
     tt = np.ascontiguousarray(t.T); yy = np.ascontiguousarray(y.transpose(1, 2, 0))
     def dev(a):
@@ -33,9 +34,9 @@ for dtype, sfx in ((np.float64, "f64"), (np.float32, "f32")):
         t0 = time.perf_counter()
         _ffi.check(fn(C.byref(mb.c), C.byref(opts), N, T, dt_, dy_, dll, dg, dst, None)); _ffi.check(L.cdkf_synchronize(None))
         el = time.perf_counter() - t0
-    print(f"grad {sfx} N={N} T={T}: {el*1e3:.2f} ms")
+    print(f"grad {sfx} N={N} T={T} m={M}: {el*1e3:.2f} ms  ({L.cdkf_last_kernel().decode()[:50]})")
     if "all" in sys.argv[1:]:  # every parameter of the model (the reverse sweep of cdkf_adjoint_kernels.h)
-        dgm = dev(np.zeros((N, _ffi.model_grad_size(3, 3)), dtype))
+        dgm = dev(np.zeros((N, _ffi.model_grad_size(3, M)), dtype))
         fa = getattr(L, f"cdkf_ekf_loglik_grad_all_{sfx}_dev")
         for rep in range(3):
             t0 = time.perf_counter()

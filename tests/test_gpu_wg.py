@@ -441,7 +441,7 @@ def test_lorenz63_gradient_all_parameters_on_the_lane_grid(hip_lib, tmp_path):
         y = o.simulate(mdl, t, rng)
         ll_ref, g_ref, ex = o.ekf_loglik_grad_adjoint(mdl, t, y, full=True)
         ll, g = cd.cdnlgssm_loglik_and_grad_all(P, y, t[..., None], hyp)
-        assert hip_lib.cdkf_last_kernel().startswith(b"grad_lpe_l63_kernel<double, true>"), hip_lib.cdkf_last_kernel()
+        assert hip_lib.cdkf_last_kernel().startswith(b"grad_lpe_l63_kernel<double, 3, true, true>"), hip_lib.cdkf_last_kernel()
         np.testing.assert_allclose(ll, ll_ref, rtol=1e-11)
         got = leaves(g, N)
         ex = dict(ex, drift=g_ref)
@@ -453,7 +453,7 @@ def test_lorenz63_gradient_all_parameters_on_the_lane_grid(hip_lib, tmp_path):
     t = o.irregular_times(rng, N, T, 0.02)
     y = o.simulate(mdl, t, rng)
     ll, g = cd.cdnlgssm_loglik_and_grad_all(P, y, t[..., None], hyp)
-    assert hip_lib.cdkf_last_kernel().startswith(b"grad_lpe_l63_kernel<double, true>"), hip_lib.cdkf_last_kernel()
+    assert hip_lib.cdkf_last_kernel().startswith(b"grad_lpe_l63_kernel<double, 3, true, true>"), hip_lib.cdkf_last_kernel()
     sub = np.array([0, 1234, 4097, 4399])
     ll_ref, g_ref, ex = o.ekf_loglik_grad_adjoint(mdl, t[sub], y[sub], full=True)
     got = leaves(g, N)
@@ -466,7 +466,7 @@ def test_lorenz63_gradient_all_parameters_on_the_lane_grid(hip_lib, tmp_path):
     y = o.simulate(mdl, t, rng)
     ll_ref, g_ref, ex = o.ekf_loglik_grad_adjoint(mdl, t, y, full=True)
     ll32, g32 = cd.cdnlgssm_loglik_and_grad_all(P, y.astype(np.float32), t[..., None].astype(np.float32), hyp)
-    assert hip_lib.cdkf_last_kernel().startswith(b"grad_lpe_l63_kernel<float, true>")
+    assert hip_lib.cdkf_last_kernel().startswith(b"grad_lpe_l63_kernel<float, 3, true, true>")
     got32 = leaves(g32, 7)
     for name in ("m0", "P0", "Qc", "H", "bias", "R"):
         assert np.abs(np.asarray(got32[name]) - ex[name]).max() < 2e-2 * np.abs(ex[name]).max(), name
@@ -488,6 +488,41 @@ def test_lorenz63_gradient_all_parameters_on_the_lane_grid(hip_lib, tmp_path):
     for name in ("H", "R", "P0", "L"):
         assert np.abs(np.asarray(got[name]) - other[name]).max() < 1e-9 * np.abs(other[name]).max(), name
     assert np.abs(np.asarray(g.dynamics.drift.rho) - other["rho"]).max() < 1e-9 * np.abs(other["rho"]).max()
+
+
+@pytest.mark.parametrize("m", [1, 2])
+def test_lorenz63_gradient_on_the_lane_grid_partial_observations(hip_lib, m):
+    """The same reverse sweep with H = I[:m], m < 3 (SURVEY section 8d's H = [1, 0, 0] case): the reverse update then runs per lane
+    (lpe_update_adj_gen).  Drift block against the oracle's forward sensitivities, every leaf against its discrete adjoint."""
+    rng = np.random.default_rng(100 + m)
+    base = o.lorenz63_model(m)
+    A, B, C = rng.standard_normal((3, 3)), rng.standard_normal((m, m)), rng.standard_normal((3, 3))
+    Rm = B @ B.T / m + 0.5 * np.eye(m)
+    Rm = 0.5 * (Rm + Rm.T)
+    mdl = o.Model(base.drift, np.eye(3) + 0.2 * rng.standard_normal((3, 3)), A @ A.T / 3 + 0.3 * np.eye(3), np.eye(3)[:m], np.zeros(m),
+                  Rm, np.array([1.0, -1.5, 18.0]), C @ C.T / 3 + 0.5 * np.eye(3))
+    P = params_from(mdl)
+    hyp = cd.EKFHyperParams(state_order="first")
+    name = b"grad_lpe_l63_kernel<double, %d, false, " % m
+    for N, T, span in ((7, 25, 0.2), (5, 8, 0.8), (2, 1, 0.1)):
+        t = o.irregular_times(rng, N, T, span)
+        y = o.simulate(mdl, t, rng)
+        ll_ref, g_ref = o.ekf_loglik_grad(mdl, t, y)
+        ll, g = cd.cdnlgssm_loglik_and_grad(P, y, t[..., None])
+        assert hip_lib.cdkf_last_kernel().startswith(name + b"false>"), hip_lib.cdkf_last_kernel()
+        np.testing.assert_allclose(ll, ll_ref, rtol=1e-11)
+        gd = np.stack([g.sigma, g.rho, g.beta], -1)
+        assert np.abs(gd - g_ref).max() <= 1e-9 * np.abs(g_ref).max()  # (T = 1: no predict, the drift block is exactly zero)
+        ll_ref, g_ref, ex = o.ekf_loglik_grad_adjoint(mdl, t, y, full=True)
+        ll, g = cd.cdnlgssm_loglik_and_grad_all(P, y, t[..., None], hyp)
+        assert hip_lib.cdkf_last_kernel().startswith(name + b"true>"), hip_lib.cdkf_last_kernel()
+        got = {"drift": np.concatenate([np.asarray(a).reshape(N, -1) for a in g.dynamics.drift], axis=-1),
+               "m0": g.initial.mean.params, "P0": g.initial.cov.params, "L": g.dynamics.diffusion_coefficient.params,
+               "Qc": g.dynamics.diffusion_cov.params, "H": g.emissions.emission_function.weights,
+               "bias": g.emissions.emission_function.bias, "R": g.emissions.emission_cov.params}
+        ex = dict(ex, drift=g_ref)
+        for key in got:
+            assert np.abs(np.asarray(got[key]) - ex[key]).max() <= 1e-9 * np.abs(ex[key]).max(), (key, N, T)
 
 
 @pytest.mark.parametrize("solver", ["tsit5", "heun", "euler"])
