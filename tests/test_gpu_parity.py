@@ -335,6 +335,46 @@ def test_c2_full_size_properties(hip_lib):
     assert relerr(outs32[0][sub], ref["filtered_means"]) < 1e-4
 
 
+def test_c2_full_size_gradient_properties(hip_lib):
+    """The SGD objective at BASELINE config 2's size (4096 x 1000, fp64), value and gradient w.r.t. every leaf by the forward +
+    reverse sweep on the sixteen-lane grid: trajectories are independent (a subset, re-run alone through the ORACLE's forward
+    sensitivities / discrete adjoint, matches), the log-likelihood is the filter's, the drift block of the all-leaf call equals the
+    drift-only call, and a trajectory's numbers do not depend on the batch it is in."""
+    rng = np.random.default_rng(5)
+    mdl = o.lorenz63_model(3)
+    N, T = 4096, 1000
+    t = o.irregular_times(rng, N, T, 0.005 * T)
+    y = (rng.standard_normal((N, T, 3)) * 3.0)
+    sub = np.sort(rng.choice(N, size=3, replace=False))
+    y[sub] = o.simulate(mdl, t[sub], rng)
+    P = params_from(mdl)
+    hyp = cd.EKFHyperParams(state_order="first")
+    ll, g = cd.cdnlgssm_loglik_and_grad(P, y, t[..., None], hyp)
+    assert hip_lib.cdkf_last_kernel().startswith(b"grad_lpe_l63_kernel<double, 3, true, false>")
+    gd = np.stack([g.sigma, g.rho, g.beta], -1)
+    assert np.isfinite(gd).all() and np.isfinite(ll).all()
+    post = cd.cdnlgssm_filter(P, y, t[..., None], hyp)
+    np.testing.assert_allclose(ll, post.marginal_loglik, rtol=1e-12)
+    ll_ref, g_ref = o.ekf_loglik_grad(mdl, t[sub], y[sub])
+    np.testing.assert_allclose(ll[sub], ll_ref, rtol=1e-10)
+    assert np.abs(gd[sub] - g_ref).max() < 1e-8 * np.abs(g_ref).max()   # (a thousand steps of a chaotic flow amplify rounding)
+    ll2, ga = cd.cdnlgssm_loglik_and_grad_all(P, y, t[..., None], hyp)
+    assert hip_lib.cdkf_last_kernel().startswith(b"grad_lpe_l63_kernel<double, 3, true, true>")
+    np.testing.assert_array_equal(ll2, ll)
+    gda = np.stack([ga.dynamics.drift.sigma, ga.dynamics.drift.rho, ga.dynamics.drift.beta], -1)
+    assert np.abs(gda - gd).max() <= 1e-12 * np.abs(gd).max()
+    _, _, ex = o.ekf_loglik_grad_adjoint(mdl, t[sub], y[sub], full=True)
+    for name, got in (("m0", ga.initial.mean.params), ("P0", ga.initial.cov.params), ("R", ga.emissions.emission_cov.params),
+                      ("H", ga.emissions.emission_function.weights), ("bias", ga.emissions.emission_function.bias),
+                      ("Qc", ga.dynamics.diffusion_cov.params)):
+        assert np.abs(np.asarray(got)[sub] - ex[name]).max() < 1e-8 * np.abs(ex[name]).max(), name
+    # the same trajectories as a batch of their own: bitwise the same numbers (one kernel, four trajectories per wavefront either way)
+    ll3, g3 = cd.cdnlgssm_loglik_and_grad_all(P, y[sub], t[sub][..., None], hyp)
+    np.testing.assert_array_equal(ll3, ll[sub])
+    np.testing.assert_array_equal(np.asarray(g3.emissions.emission_cov.params), np.asarray(ga.emissions.emission_cov.params)[sub])
+    np.testing.assert_array_equal(np.asarray(g3.dynamics.drift.rho), np.asarray(ga.dynamics.drift.rho)[sub])
+
+
 def test_unscented_filter_on_the_lane_grid(hip_lib, tmp_path):
     """Small Lorenz-63 batches with H = I run the unscented filter on filter_lpe_kernel<..., UKF = true>, whose moment
     equations are the sigma-point sums of inference_ukf.py:124-143 collapsed for this (quadratic) drift.  Against the oracle,
