@@ -146,7 +146,10 @@ CDKF_DEV void lpe_step_adj(const LpeRhs<R, false>& rhs, const LpeAdjRhs<R>& adj,
   const R k4 = dt * lpe_eval_keep(rhs, Y4, p[3][0], p[3][1], p[3][2]);
   const R Y5 = rfma(C.a54, k4, rfma(C.a53, k3, rfma(C.a52, k2, rfma(C.a51, k1, y))));
   const R k5 = dt * lpe_eval_keep(rhs, Y5, p[4][0], p[4][1], p[4][2]);
-  const R Y6 = rfma(C.a65, k5, rfma(C.a64, k4, rfma(C.a63, k3, rfma(C.a62, k2, rfma(C.a61, k1, y)))));
+  R Y6 = rfma(C.a65, k5, rfma(C.a64, k4, rfma(C.a63, k3, rfma(C.a62, k2, rfma(C.a61, k1, y)))));
+  // Y6 is a row_newbcast operand of the first stage reversed, whose other inputs do not depend on it: two wait states by hand (the
+  // earlier stage values are behind whole right-hand sides)
+  asm volatile("s_nop 1" : "+v"(Y6));
   p[5][0] = lpe_dpp<0x120 + 12>(Y6);
   p[5][1] = lpe_dpp<0x120 + 8>(Y6);
   p[5][2] = lpe_dpp<0x120 + 4>(Y6);
