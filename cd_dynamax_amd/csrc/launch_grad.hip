@@ -74,23 +74,13 @@ static int run_lpe_grad(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, in
   if (!try_lpe(a, mdl, &of, stream, false, grad_model != nullptr)) return CDKF_OK;
   CDKF_HIP_CHECK(hipGetLastError());
   *handled = true;
-  const bool grid = M == 3;  // the reverse update inside the grid (the forward sweep made the same choice: lpe_update)
-  note_kernel("grad_lpe_l63_kernel<%s, %d, %s, %s>", real_name<R>(), M, grid ? "true" : "false", grad_model ? "true" : "false");
+  constexpr bool kGrid = M == 3;  // the reverse update inside the grid (the forward sweep made the same choice: lpe_update)
+  note_kernel("grad_lpe_l63_kernel<%s, %d, %s, %s>", real_name<R>(), M, kGrid ? "true" : "false", grad_model ? "true" : "false");
   const dim3 g(lpe_blocks<R>(N)), b(64);
-  if constexpr (M == 3) {
-    if (grid) {
-      if (grad_model)
-        hipLaunchKernelGGL((grad_lpe_l63_kernel<R, 3, true, true>), g, b, 0, stream, a, grad, grad_model);
-      else
-        hipLaunchKernelGGL((grad_lpe_l63_kernel<R, 3, true, false>), g, b, 0, stream, a, grad, grad_model);
-      CDKF_HIP_CHECK(hipGetLastError());
-      return ws.done(stream);
-    }
-  }
   if (grad_model)
-    hipLaunchKernelGGL((grad_lpe_l63_kernel<R, M, false, true>), g, b, 0, stream, a, grad, grad_model);
+    hipLaunchKernelGGL((grad_lpe_l63_kernel<R, M, kGrid, true>), g, b, 0, stream, a, grad, grad_model);
   else
-    hipLaunchKernelGGL((grad_lpe_l63_kernel<R, M, false, false>), g, b, 0, stream, a, grad, grad_model);
+    hipLaunchKernelGGL((grad_lpe_l63_kernel<R, M, kGrid, false>), g, b, 0, stream, a, grad, grad_model);
   CDKF_HIP_CHECK(hipGetLastError());
   return ws.done(stream);
 }
