@@ -577,7 +577,7 @@ __global__ __launch_bounds__(64) void grad_lpe_l63_kernel(const RegArgs<R, 3, M,
     const R t1 = lpe_bcast<15>(vp), t0 = lpe_bcast<15>(vf);
     const R y0 = (i == 3) ? R(0) : vf;
     R tp = t0, tq = rmin(t0 + a.dt0, t1);
-    const R dt_0 = tq - tp;
+    const R dt_0 = (t0 < t1) ? tq - tp : R(0);  // (no step where the forward sweep took none: t_k <= t_{k-1})
     advance(tp, tq, t1);
     // more than one Runge-Kutta step in this interval: the starts of the steps 1, 2, ... (and their sizes, in lane 15's slot) are parked
     // in LDS on the way forward

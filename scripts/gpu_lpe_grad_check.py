@@ -37,3 +37,14 @@ for name in "abc":
         print(name, "grid vs oracle:", np.max(np.abs(a[name + "_g"] - g_ref) / scale), " sens vs oracle:", np.max(np.abs(b[name + "_g"] - g_ref) / scale))
         if name == "c":
             print(a[name + "_g"][:2], g_ref[:2])
+# repeated observation times (two observations at one instant): no predict between them, in either sweep
+import cd_dynamax_amd as cd
+from helpers import params_from
+rng = np.random.default_rng(4)
+t = o.irregular_times(rng, 5, 12, 0.3)
+t[:, 6] = t[:, 5]
+y = o.simulate(mdl, t, rng)
+ll_ref, g_ref = o.ekf_loglik_grad(mdl, t, y)
+ll, g = cd.cdnlgssm_loglik_and_grad(params_from(mdl), y, t[..., None])
+gd = np.stack([g.sigma, g.rho, g.beta], -1)
+print("repeated times: ll", np.max(np.abs(ll - ll_ref) / np.abs(ll_ref)), "grad", np.max(np.abs(gd - g_ref)) / np.abs(g_ref).max())

@@ -685,6 +685,10 @@ def test_loglik_gradient_reverse_sweep_on_the_lane_grid(hip_lib, tmp_path):
     assert np.diff(t, axis=1).max() > 0.05
     y = o.simulate(mdl, t, rng)
     check(mdl, t, y, tol=5e-3, dtype=np.float32)
+    # two observations at one instant: no predict between them, in either sweep
+    t2 = t.copy()
+    t2[:, 6] = t2[:, 5]
+    check(mdl, t2, y)
     # one time grid shared by the batch
     ts = t[0]
     ll_s, g_s = cd.cdnlgssm_loglik_and_grad(P, y, ts[:, None])
