@@ -118,3 +118,18 @@ def test_soak_gradient_layouts(hip_lib, kind):
             _ffi.check(_ffi.lib().cdkf_ekf_loglik_grad_all_f64(C.byref(blk.c), C.byref(opts), N, T, vp(t_l), vp(y_l), vp(ll), vp(g),
                                                                vp(gm), vp(st)))
             assert relerr(g, g_ref) < 1e-8 and np.isfinite(gm).all(), (kind, layout, N)
+
+
+def test_soak_gradient_on_the_lane_grid_against_the_other_kernels(hip_lib):
+    """Forty random Lorenz-63 problems (emission dimension 1-3, dense L / Qc / R / P0, 1-44 trajectories, 1-39 observations, one to a few
+    hundred Runge-Kutta steps per interval): the drift block and the model block from the forward + reverse sweep on the sixteen-lane grid
+    against the forward-sensitivity kernel / the wavefront-per-trajectory reverse sweep (scripts/gpu_lpe_grad_soak.py runs the cases in
+    two processes, the second with CDKF_NO_LPE_GRAD=1)."""
+    import os, re, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "scripts", "gpu_lpe_grad_soak.py")], capture_output=True, text=True,
+                         timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert "MISMATCH" not in res.stdout, res.stdout[-2000:]
+    worst = [float(v) for v in re.findall(r": ([0-9.e+-]+)[,}]", res.stdout.splitlines()[-1])]
+    assert len(worst) == 6 and max(worst) < 1e-9, res.stdout[-500:]
