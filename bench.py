@@ -45,22 +45,23 @@ FP64_PEAK_TF = 78.6     # fp64 vector / matrix FMA peak: half the 157.3 TF fp32 
 FP32_PEAK_TF = 157.3
 
 
-def make_batch(rank, n, T):
+def make_batch(rank, n, T, mean_gap=0.005, substeps=1):
     """Synthetic Lorenz-63 batch: per-trajectory irregular grids with mean gap 0.005
     (recipe of the reference's simulation_utils.py:46-49), observations y = x + N(0, I) around a noisy
-    Lorenz-63 path integrated with Euler-Maruyama.  Seeded per rank."""
+    Lorenz-63 path integrated with Euler-Maruyama (`substeps` per observation interval).  Seeded per rank."""
     rng = np.random.default_rng(1234 + rank)
     u = rng.uniform(0.0, 1.0, size=(n, T))
     s = np.cumsum(u, axis=1)
-    t = s / s[:, -1:] * (0.005 * T)
+    t = s / s[:, -1:] * (mean_gap * T)
     x = rng.standard_normal((n, 3)) * np.sqrt(5.0)
     y = np.empty((n, T, 3))
     tc = t[:, 0].copy()
     sig, rho, beta = 10.0, 28.0, 8.0 / 3.0
     for k in range(T):
-        h = (t[:, k] - tc)[:, None]
-        f = np.stack([sig * (x[:, 1] - x[:, 0]), x[:, 0] * (rho - x[:, 2]) - x[:, 1], x[:, 0] * x[:, 1] - beta * x[:, 2]], 1)
-        x = x + h * f + np.sqrt(h) * rng.standard_normal((n, 3))
+        h = (t[:, k] - tc)[:, None] / substeps
+        for _ in range(substeps):
+            f = np.stack([sig * (x[:, 1] - x[:, 0]), x[:, 0] * (rho - x[:, 2]) - x[:, 1], x[:, 0] * x[:, 1] - beta * x[:, 2]], 1)
+            x = x + h * f + np.sqrt(h) * rng.standard_normal((n, 3))
         tc = t[:, k]
         y[:, k] = x + rng.standard_normal((n, 3))
     return t, y
@@ -379,6 +380,13 @@ def other_configs(lib, timer, stream, t_h, y_h, only=None):
     if want("config2_with_smoother_fp64_4096x1000"):
         out["config2_with_smoother_fp64_4096x1000"] = case(l63, t_h, y_h, "f64", _ffi.LAYOUT_TCN, ["ekf_smoother"], "hbm",
                                                           {"ekf_smoother": 8 * ((1 + 3) + 2 * (3 + 9)) + 8 * (1 + 2 * (3 + 9))})
+    if want("config2_long_gap_grid_fp64_4096x1000"):
+        # SURVEY.md section 8d's secondary grid: T_total = 0.05 T, about five Dormand-Prince steps of dt0 = 0.01 per interval (max 10)
+        tl, yl = make_batch(77, 4096, 1000, mean_gap=0.05, substeps=20)
+        out["config2_long_gap_grid_fp64_4096x1000"] = case(l63, tl, yl, "f64", _ffi.LAYOUT_TCN, ["ekf_filter", "ekf_smoother"], "hbm",
+                                                          {"ekf_filter": 8 * ((1 + 3) + 2 * (3 + 9)),
+                                                           "ekf_smoother": 8 * ((1 + 3) + 2 * (3 + 9)) + 8 * (1 + 2 * (3 + 9))},
+                                                          grad=True, state_order=1)
     rng = np.random.default_rng(1)
     d = 40
     l96 = cd.ParamsCDNLGSSM(
