@@ -14,7 +14,7 @@ L = _ffi.lib()
 M = next((int(a[2:]) for a in sys.argv[1:] if a.startswith("m=")), 3)  # emission dimension (H = I[:M])
 for dtype, sfx in ((np.float64, "f64"), (np.float32, "f32")):
     rng = np.random.default_rng(0)
-    N, T = 4096, 1000
+    N, T = next((int(a[2:]) for a in sys.argv[1:] if a.startswith("n=")), 4096), 1000
     mdl = o.lorenz63_model(M)
     if "bench" in sys.argv[1:]:  # the benchmark's batch (every gap <= dt0: one step per interval)
         import bench
