@@ -202,10 +202,30 @@ def main():
         if not args.no_saturation and world == 1:
             opts.layout, opts.layout_in = _ffi.LAYOUT_TCN, _ffi.LAYOUT_SAME  # the lane-per-trajectory kernels' native layout
             out["value_and_grad"] = value_and_grad(lib, blk, opts, N, T, t_d, y_d, ll, timer, stream)
-            for a in (fm, fP, pm, pP):
-                a.free()
-            out["saturated_regime"] = saturated(lib, blk, opts, timer, stream)
-            out["other_configs"] = other_configs(lib, timer, stream, t_h, y_h)
+    for a in (fm, fP, pm, pP):
+        a.free()
+    if not args.no_saturation:
+        # The configurations BASELINE.json defines on 8 GPUs (4: Lorenz-96 filter + smoother with the log-likelihood all-reduce;
+        # 5: the MLP model's SGD objective with the all-reduce of 1 + n_theta + n_model sums) run at EVERY world size, each rank on
+        # its slice, with the collective behind the sweeps on the same stream -- at world 1 through a one-rank RCCL communicator, so
+        # that the 1-GPU point of the curve pays the same calls.  Times are the max over ranks.
+        comm1 = comm
+        if comm1 is None:
+            try:
+                comm1 = D_.Comm.from_env(gpu=True)
+            except Exception as e:  # (no RCCL on this box: the entries then say so; the headline above does not depend on it)
+                sys.stderr.write(f"bench: no one-rank communicator ({e}); other_configs run without the collective\n")
+        others = other_configs(lib, timer, stream, t_h, y_h, comm=comm1, world=world, rank=rank,
+                               only=None if world == 1 else "8gpu")
+        if rank == 0:
+            out["other_configs"] = others
+            if world == 1:
+                opts.layout, opts.layout_in = _ffi.LAYOUT_TCN, _ffi.LAYOUT_SAME
+                out["n_sweep"] = n_sweep(lib, blk, opts, timer, stream)
+                out["saturated_regime"] = out["n_sweep"]["rows"][-1]
+        if comm1 is not None and comm1 is not comm:
+            comm1.close()
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if comm is not None:
         comm.barrier()
@@ -259,28 +279,34 @@ def value_and_grad(lib, blk, opts, N, T, t_d, y_d, ll, timer, stream, reps=5):
     return out
 
 
-def saturated(lib, blk, opts, timer, stream, n=131072, reps=5):
-    """Same per-trajectory workload, 32x the trajectories (lane-per-trajectory kernel, two wavefronts per SIMD; 29 GB
-    per sweep): the regime where the sweep is bounded by HBM rather than by the T-long dependency chain per wavefront
-    (scripts/n_sweep.py: 65 536: 4.9 TB/s, 131 072: 5.2 TB/s, 262 144: 4.8 TB/s).  Reported beside the headline number, never instead of it."""
+def n_sweep(lib, blk, opts, timer, stream, sizes=(4096, 8192, 16384, 32768, 65536, 131072)):
+    """The headline sweep against the batch size, same per-trajectory workload, the dispatcher's own choice of kernel at each N
+    (sixteen lanes per trajectory while every wavefront has a SIMD to itself, one lane per trajectory beyond; the A/B of the two
+    mappings per N is scripts/n_sweep_table.py -> profiles/r03_*_n_sweep.json).  The last row (131 072 trajectories, 29 GB per
+    sweep, two wavefronts per SIMD) is the regime where the sweep is bounded by HBM rather than by the T-long dependency chain
+    of a wavefront; it is also reported as `saturated_regime`.  Informational, never instead of the headline."""
     from cd_dynamax_amd import _ffi
     from cd_dynamax_amd._ffi import DeviceArray
     T = T_STEPS
     t_h, y_h = make_batch(99, 4096, T)
-    reps_n = n // 4096
-    t_d = DeviceArray.from_numpy(np.tile(np.ascontiguousarray(t_h.T), (1, reps_n)))
-    y_d = DeviceArray.from_numpy(np.tile(np.ascontiguousarray(y_h.transpose(1, 2, 0)), (1, 1, reps_n)))
-    ll, st = DeviceArray((n,), np.float64), DeviceArray.from_numpy(np.zeros(n, np.int32))
-    bufs = [DeviceArray((T, w, n), np.float64) for w in (D, D * D, D, D * D)]
-    run = lambda: _ffi.check(lib.cdkf_ekf_filter_f64_dev(C.byref(blk.c), C.byref(opts), n, T, t_d.ptr, y_d.ptr, ll.ptr,
-                                                         *[b.ptr for b in bufs], st.ptr, stream))
-    ms = timer.ms_per_call(run, reps)
-    kernel = lib.cdkf_last_kernel().decode()
-    for a in [t_d, y_d, ll, st] + bufs:
-        a.free()
-    gbs = n * T * 224 / (ms * 1e-3) / 1e9
-    return {"trajectories": n, "num_timesteps": T, "kernel": kernel, "kernel_ms": ms, "trajectories_per_sec": n / (ms * 1e-3),
-            "achieved_GBps": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS}
+    tT, yT = np.ascontiguousarray(t_h.T), np.ascontiguousarray(y_h.transpose(1, 2, 0))
+    rows = []
+    for n in sizes:
+        reps_n = n // 4096
+        t_d = DeviceArray.from_numpy(np.tile(tT, (1, reps_n)))
+        y_d = DeviceArray.from_numpy(np.tile(yT, (1, 1, reps_n)))
+        ll, st = DeviceArray((n,), np.float64), DeviceArray.from_numpy(np.zeros(n, np.int32))
+        bufs = [DeviceArray((T, w, n), np.float64) for w in (D, D * D, D, D * D)]
+        run = lambda: _ffi.check(lib.cdkf_ekf_filter_f64_dev(C.byref(blk.c), C.byref(opts), n, T, t_d.ptr, y_d.ptr, ll.ptr,
+                                                             *[b.ptr for b in bufs], st.ptr, stream))
+        ms = timer.ms_per_call(run, 10 if n <= 16384 else 5)
+        kernel = lib.cdkf_last_kernel().decode()
+        for a in [t_d, y_d, ll, st] + bufs:
+            a.free()
+        gbs = n * T * 224 / (ms * 1e-3) / 1e9
+        rows.append({"trajectories": n, "num_timesteps": T, "kernel": kernel, "kernel_ms": ms, "trajectories_per_sec": n / (ms * 1e-3),
+                     "achieved_GBps": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS})
+    return {"workload": "config 2's sweep (Lorenz-63 EKF, fp64, four output fields, layout [T,comp,N]) at other batch sizes", "rows": rows}
 
 
 def flops_per_step(d, m, c_drift, smoother=False):
@@ -297,15 +323,21 @@ def flops_per_step(d, m, c_drift, smoother=False):
     return total
 
 
-def other_configs(lib, timer, stream, t_h, y_h, only=None):
+def other_configs(lib, timer, stream, t_h, y_h, only=None, comm=None, world=1, rank=0):
     """Informational: the other BASELINE.json configurations (their per-GPU slices where the config spans 8 GPUs) through
     the same C ABI, device-resident inputs, native layouts, synthetic data of SURVEY.md section 8d; each with the roofline that
     bounds it (configs 2 / 3 HBM, 4 / 5 fp64 compute) from the algorithmic bytes / flops and the kernel
-    time (one event pair around back-to-back launches).  Not part of the headline metric."""
+    time (one event pair around back-to-back launches).  Not part of the headline metric.
+
+    With a communicator every timed call is the data-parallel step BASELINE defines: sweeps -> cdkf_ll_sum (+ cdkf_grad_sum for the
+    SGD objective) -> ONE in-place ncclAllReduce of the block sums on the same stream (the `vmap(...).sum()` of
+    ssm_temissions.py:555-568, 665-679); every rank runs its own slice (weak scaling), times are the max over ranks.
+    only = "8gpu": the two configurations BASELINE quotes on 8 GPUs (what `bench.py --gpus N` runs for N > 1)."""
     import cd_dynamax_amd as cd
     from cd_dynamax_amd import _ffi
     from cd_dynamax_amd._ffi import DeviceArray
     from cd_dynamax_amd.models import _model_block
+    has_coll = comm is not None and bool(getattr(comm, "_comm", None))
 
     def grids(rng, n, T):
         u = rng.uniform(0.0, 1.0, size=(n, T))
@@ -322,11 +354,16 @@ def other_configs(lib, timer, stream, t_h, y_h, only=None):
         return {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                 "algorithmic_flops_per_trajectory_step": per_step}
 
-    def case(params, t, y, dtype, layout, algos, bound, per_step, outputs=True, grad=False, state_order=2, keep=None):
+    def over_ranks(ms):
+        return float(comm.allreduce_max_host([ms])[0]) if (comm is not None and world > 1) else ms
+
+    def case(params, t, y, dtype, layout, algos, bound, per_step, outputs=True, grad=False, state_order=2, keep=None, flags=0,
+             suffix=""):
         blk = _model_block(params)
         opts = _ffi.default_opts()
         opts.layout = layout
         opts.state_order = state_order
+        opts.flags = flags
         n, T, m = y.shape
         d = blk.state_dim
         npd = np.float64 if dtype == "f64" else np.float32
@@ -334,17 +371,26 @@ def other_configs(lib, timer, stream, t_h, y_h, only=None):
         y_d = DeviceArray.from_numpy(np.ascontiguousarray(y.transpose(1, 2, 0) if layout == _ffi.LAYOUT_TCN else y.transpose(1, 0, 2), dtype=npd))
         ll = DeviceArray((n,), npd)
         st = DeviceArray.from_numpy(np.zeros(n, np.int32))
+        n_th, n_md = blk.theta.size, _ffi.model_grad_size(d, m)
+        sums = DeviceArray((1 + n_th + n_md,), np.float64)
+        ll_sum = getattr(lib, f"cdkf_ll_sum_{dtype}_dev")
+        grad_sum = getattr(lib, f"cdkf_grad_sum_{dtype}_dev")
         bufs = [DeviceArray((n * T * w,), npd) if outputs else None for w in (d, d * d, d, d * d)]
         p = lambda a: None if a is None else a.ptr
-        res = {}
+        res = {"n_gpus": world, "trajectories_per_gpu": n}
         for algo in algos:
             fn = getattr(lib, f"cdkf_{algo}_{dtype}_dev")
-            run = lambda: _ffi.check(fn(C.byref(blk.c), C.byref(opts), n, T, t_d.ptr, y_d.ptr, ll.ptr, *[p(b) for b in bufs], st.ptr,
-                                        stream))
-            ms = timer.ms_per_call(run, 3)
-            res[algo + "_ms"] = ms
-            res[algo + "_kernel"] = lib.cdkf_last_kernel().decode()
-            res[algo + "_roofline"] = roof(bound, per_step[algo], n, T, ms, dtype)
+
+            def run():
+                _ffi.check(fn(C.byref(blk.c), C.byref(opts), n, T, t_d.ptr, y_d.ptr, ll.ptr, *[p(b) for b in bufs], st.ptr, stream))
+                _ffi.check(ll_sum(ll.ptr, n, sums.ptr, stream))
+                if has_coll:
+                    comm.allreduce_sum_dev(sums.ptr, 1, stream)
+            ms = over_ranks(timer.ms_per_call(run, 3))
+            res[algo + suffix + "_ms"] = ms
+            res[algo + suffix + "_kernel"] = lib.cdkf_last_kernel().decode()
+            res[algo + suffix + "_roofline"] = roof(bound, per_step[algo], n, T, ms, dtype)
+            res[algo + suffix + "_trajectories_per_sec"] = world * n / (ms * 1e-3)
         if keep is not None:
             keep["fm"] = bufs[0].numpy().reshape(T, d, n) if layout == _ffi.LAYOUT_TCN else None
             keep["ll"] = ll.numpy()
@@ -353,29 +399,49 @@ def other_configs(lib, timer, stream, t_h, y_h, only=None):
                 if b is not None:
                     b.free()
             bufs = []
-            g = DeviceArray((n, blk.theta.size), npd)
-            gm = DeviceArray((n, _ffi.model_grad_size(d, m)), npd)
+            g = DeviceArray((n, n_th), npd)
+            gm = DeviceArray((n, n_md), npd)
             fn = getattr(lib, f"cdkf_ekf_loglik_grad_all_{dtype}_dev")
             opts.layout = _ffi.LAYOUT_TCN
             y_g = DeviceArray.from_numpy(np.ascontiguousarray(y.transpose(1, 2, 0), dtype=npd))
-            run = lambda: _ffi.check(fn(C.byref(blk.c), C.byref(opts), n, T, t_d.ptr, y_g.ptr, ll.ptr, g.ptr, gm.ptr, st.ptr, stream))
-            res["loglik_and_grad_all_ms"] = timer.ms_per_call(run, 3)
+            base = sums.ptr.value
+
+            def run():  # one SGD step's objective: value + every gradient, reduced over the batch and over the ranks
+                _ffi.check(fn(C.byref(blk.c), C.byref(opts), n, T, t_d.ptr, y_g.ptr, ll.ptr, g.ptr, gm.ptr, st.ptr, stream))
+                _ffi.check(ll_sum(ll.ptr, n, sums.ptr, stream))
+                _ffi.check(grad_sum(g.ptr, n, n_th, C.c_void_p(base + 8), stream))
+                _ffi.check(grad_sum(gm.ptr, n, n_md, C.c_void_p(base + 8 * (1 + n_th)), stream))
+                if has_coll:
+                    comm.allreduce_sum_dev(sums.ptr, 1 + n_th + n_md, stream)
+            ms = over_ranks(timer.ms_per_call(run, 3))
+            res["loglik_and_grad_all_ms"] = ms
             res["loglik_and_grad_all_kernel"] = lib.cdkf_last_kernel().decode()
+            res["loglik_and_grad_all_trajectories_per_sec"] = world * n / (ms * 1e-3)
+            res["reduced_doubles_per_step"] = 1 + n_th + n_md
             bufs = [g, gm, y_g]
+        res["collective"] = ("cdkf_ll_allreduce (ncclAllReduce, in place, on the sweeps' stream) behind cdkf_ll_sum / cdkf_grad_sum"
+                             if has_coll else None)
         res["status_flags_raised"] = int(np.count_nonzero(st.numpy()))
-        for a in [t_d, y_d, ll, st] + [b for b in bufs if b is not None]:
+        for a in [t_d, y_d, ll, st, sums] + [b for b in bufs if b is not None]:
             a.free()
         return res
 
     eye = np.eye
     out = {}
-    want = lambda name: only is None or only in name  # scripts/run_config.py profiles one configuration at a time
+    multi = only == "8gpu"
+    want = lambda name: only is None or (multi and name.startswith(("config4", "config5_slice_mlp_d8_fp64_1024x1000", "config5_slice_mlp_d8_fp32"))
+                                        and "first_order" not in name) or (not multi and only in name)
     l63 = l63_params(cd)
     if want("config3_lorenz63_ukf_fp32_4096x1000"):
         keep = {}
-        c3 = case(l63, t_h, y_h, "f32", _ffi.LAYOUT_TCN, ["ukf_filter"], "hbm", {"ukf_filter": 4 * ((1 + 3) + 2 * (3 + 9))}, keep=keep)
+        b3 = {"ukf_filter": 4 * ((1 + 3) + 2 * (3 + 9))}
+        c3 = case(l63, t_h, y_h, "f32", _ffi.LAYOUT_TCN, ["ukf_filter"], "hbm", b3, keep=keep)
         if only is None:
             c3.update(ukf_fp32_error(t_h, y_h, keep))
+        # BASELINE says "(sigma-point predict)": the closed form above is exact for this drift; beside it the kernel
+        # that forms the 2 d + 1 sigma points and factorises the covariance in every stage (opts.flags & CDKF_FLAG_UKF_SIGMA_POINTS)
+        lit = case(l63, t_h, y_h, "f32", _ffi.LAYOUT_TCN, ["ukf_filter"], "hbm", b3, flags=_ffi.FLAG_UKF_SIGMA_POINTS, suffix="_sigma_points")
+        c3.update({k: v for k, v in lit.items() if "sigma_points" in k})
         out["config3_lorenz63_ukf_fp32_4096x1000"] = c3
     if want("config2_with_smoother_fp64_4096x1000"):
         out["config2_with_smoother_fp64_4096x1000"] = case(l63, t_h, y_h, "f64", _ffi.LAYOUT_TCN, ["ekf_smoother"], "hbm",
@@ -387,7 +453,7 @@ def other_configs(lib, timer, stream, t_h, y_h, only=None):
                                                           {"ekf_filter": 8 * ((1 + 3) + 2 * (3 + 9)),
                                                            "ekf_smoother": 8 * ((1 + 3) + 2 * (3 + 9)) + 8 * (1 + 2 * (3 + 9))},
                                                           grad=True, state_order=1)
-    rng = np.random.default_rng(1)
+    rng = np.random.default_rng(1 + 1000 * rank)
     d = 40
     l96 = cd.ParamsCDNLGSSM(
         initial=cd.ParamsLGSSMInitial(cd.LearnableVector(8.0 * np.ones(d)), cd.LearnableMatrix(eye(d))),
@@ -413,6 +479,7 @@ def other_configs(lib, timer, stream, t_h, y_h, only=None):
     # state_order 'second' is the reference's default (EKFHyperParams, inference_ekf.py:108-116): for the MLP the mean also moves
     # with 0.5 P grad(div f) -- one more 64 x 64 x 9 product per right-hand side, two more in its reverse (not in the flop model);
     # 'first' is kept beside it (rounds 1 and 2 quoted that one: the reverse sweep could not do 'second' before)
+    rng = np.random.default_rng(3 + 1000 * rank)  # (the weights above are the same on every rank; the data are the rank's own)
     t5, y5 = grids(rng, n, T), rng.standard_normal((n, T, m))
     if want("config5_slice_mlp_d8_fp64_1024x1000"):
         out["config5_slice_mlp_d8_fp64_1024x1000"] = case(

@@ -32,6 +32,7 @@ LAYOUT_NT = 0
 LAYOUT_TN = 1
 LAYOUT_TCN = 2
 LAYOUT_SAME = -1
+FLAG_UKF_SIGMA_POINTS = 1  # cdkf_opts.flags (include/cdkf.h)
 
 ORDER = {"zeroth": 0, "first": 1, "second": 2}
 
@@ -81,7 +82,7 @@ class CdkfOpts(C.Structure):
         ("pid_i", C.c_double),
         ("pid_d", C.c_double),
         ("layout_in", C.c_int32),
-        ("reserved", C.c_int32),
+        ("flags", C.c_int32),
     ]
 
 

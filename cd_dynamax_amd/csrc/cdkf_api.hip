@@ -97,6 +97,10 @@ int check_common(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T
       return CDKF_EINVAL;
     }
   }
+  if (o->flags & ~CDKF_FLAG_UKF_SIGMA_POINTS) {
+    set_error("opts.flags = 0x%x has bits this library version does not know (CDKF_FLAG_*)", (unsigned)o->flags);
+    return CDKF_EINVAL;
+  }
   if (o->num_iter < 1 || !(o->dt0 > 0) || o->max_steps < 1) {
     set_error("need num_iter >= 1, dt0 > 0, max_steps >= 1");
     return CDKF_EINVAL;
@@ -456,7 +460,7 @@ void cdkf_default_opts(cdkf_opts* o) {
   o->pid_i = 1.0;
   o->pid_d = 0.0;
   o->layout_in = CDKF_LAYOUT_SAME;
-  o->reserved = 0;
+  o->flags = 0;
   o->max_steps = 100000;
   o->dt0 = 0.01;
   o->dt_final = 1e-10;

@@ -194,6 +194,9 @@ struct WgArgs;
 bool wave40_shape(const cdkf_model* mdl, const cdkf_opts* o);
 template <typename R>
 int launch_wave40(const WgArgs<R>& a, hipStream_t stream, bool backward = false);
+// filter sweep for state_dim <= 8, one wavefront per trajectory (launch_w8.hip, cdkf_wave8_kernels.h)
+template <typename R>
+int launch_wave8(const WgArgs<R>& a, hipStream_t stream);
 // reverse sweep (gradient) / smoother backward sweep for state_dim <= 8 (launch_adj.hip, cdkf_adjoint_kernels.h)
 template <typename R, bool MLP, bool SMOOTH = false>
 int launch_adjoint_kernel(const WgArgs<R>& a, R* grad, R* grad_model, hipStream_t stream);

@@ -683,13 +683,17 @@ __global__ __launch_bounds__(64) void smoother_lpe_l63_kernel(const RegArgs<R, 3
   if (live && l == 0 && a.status && st) atomicOr(&a.status[n], st);
 }
 
-inline bool lpe_batch_is_small(int64_t N) {
-  // 4 trajectories per wavefront: faster than the lane-per-trajectory sweep while every wavefront has a SIMD to itself
-  // (MI355X: 1024 SIMDs -> 4096 trajectories: 1.19 against 1.78 ms; 5120: 1.90 against 1.79 ms)
+// Which batches take the sixteen-lane grid (4 trajectories per wavefront) instead of the lane-per-trajectory sweep.  `per_simd`:
+// wavefronts per SIMD up to which the grid is the faster one for that sweep (measured: profiles/r03_*_n_sweep.json).
+// CDKF_LPE_MAX_N=<n> overrides the threshold (scripts/n_sweep_table.py: 0 = never, a huge value = always).
+enum LpeSweep { kLpeFilter = 0, kLpeUkf = 1, kLpeSmoother = 2, kLpeGrad = 3 };
+inline bool lpe_batch_is_small(int64_t N, LpeSweep which = kLpeFilter) {
+  if (const char* e = std::getenv("CDKF_LPE_MAX_N")) return N <= std::atoll(e);
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
     cus = 256;
-  return (N + 3) / 4 <= 4 * (int64_t)cus;
+  static constexpr int per_simd[4] = {1, 1, 1, 1};
+  return (N + 3) / 4 <= (int64_t)per_simd[which] * 4 * cus;
 }
 
 #ifndef __HIPCC_RTC__
@@ -700,11 +704,13 @@ inline bool try_lpe(const RegArgs<R, D, M, Drift>& a, const cdkf_model* mdl, con
                     bool any_batch = false) {  // any_batch: also beyond one wavefront per SIMD (the reverse sweep's forward pass)
   if constexpr ((std::is_same<Drift, DriftLorenz63<R, 3>>::value || std::is_same<Drift, DriftLinear<R, 3>>::value) && D == 3 && M <= 3) {
     static const bool off = [] { const char* e = std::getenv("CDKF_NO_LPE"); return e && e[0] == '1'; }();
-    // CDKF_UKF_SIGMA_POINTS=1: the unscented filter on the lane-per-trajectory kernel, which forms the sigma points (A/B, tests)
-    static const bool ukf_off = [] { const char* e = std::getenv("CDKF_UKF_SIGMA_POINTS"); return e && e[0] == '1'; }();
+    // opts.flags & CDKF_FLAG_UKF_SIGMA_POINTS (or CDKF_UKF_SIGMA_POINTS=1 in the environment): the unscented filter on the
+    // lane-per-trajectory kernel, which forms the sigma points and factorises every stage covariance as the reference does
+    static const bool ukf_env = [] { const char* e = std::getenv("CDKF_UKF_SIGMA_POINTS"); return e && e[0] == '1'; }();
+    const bool ukf_off = ukf_env || (o->flags & CDKF_FLAG_UKF_SIGMA_POINTS);
     const bool all = a.fm && a.fP && a.pm && a.pP, none = !a.fm && !a.fP && !a.pm && !a.pP;
     const bool filt = a.fm && a.fP && !a.pm && !a.pP;
-    if (off || (!any_batch && !lpe_batch_is_small(a.N)) || !(all || none || filt) || (M == 3 && !emission_is_selection(mdl)) || o->forecast ||
+    if (off || (!any_batch && !lpe_batch_is_small(a.N, ukf ? kLpeUkf : kLpeFilter)) || !(all || none || filt) || (M == 3 && !emission_is_selection(mdl)) || o->forecast ||
         o->solver != CDKF_SOLVER_DOPRI5 || o->adaptive)
       return false;
     if (!ukf && o->state_order == CDKF_ORDER_ZEROTH) return false;
@@ -748,7 +754,7 @@ template <typename R, int D, int M, typename Drift>
 inline bool try_lpe_smoother(const RegArgs<R, D, M, Drift>& a, const cdkf_opts* o, R* sm, R* sP, hipStream_t stream) {
   if constexpr (std::is_same<Drift, DriftLorenz63<R, 3>>::value && D == 3 && M <= 3) {
     static const bool off = [] { const char* e = std::getenv("CDKF_NO_LPE"); return e && e[0] == '1'; }();
-    if (off || !lpe_batch_is_small(a.N) || o->solver != CDKF_SOLVER_DOPRI5 || o->adaptive) return false;
+    if (off || !lpe_batch_is_small(a.N, kLpeSmoother) || o->solver != CDKF_SOLVER_DOPRI5 || o->adaptive) return false;
     note_kernel("smoother_lpe_l63_kernel<%s, %d>", real_name<R>(), M);
     hipLaunchKernelGGL((smoother_lpe_l63_kernel<R, M>), dim3(lpe_blocks<R>(a.N)), dim3(64), 0, stream, a, sm, sP);
     return true;

@@ -501,9 +501,14 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave_l96_kernel(const WgArg
   LlAcc ll;
   int st = 0;
   bool bad = false;
-  // diagnostic build aid (scripts/prof_w40.sh): a.forecast carries a mask of phases to SKIP (results are then meaningless); the
-  // launcher passes 0 unless CDKF_W40_ABLATE is set.  Uniform run-time branches: the shipped path pays nothing for them.
+  // diagnostic build aid (scripts/prof_w40.sh, -DCDKF_W40_PROFILE builds ONLY): a.forecast carries a mask of phases to SKIP
+  // (results are then meaningless).  The shipped library compiles the mask to a constant zero: no environment variable can
+  // switch a phase off.
+#ifdef CDKF_W40_PROFILE
   const int skip = a.forecast;
+#else
+  constexpr int skip = 0;
+#endif
   if ((skip & 32) && wave) return;  // (one wavefront per CU: how much do the four of a workgroup cost each other?)
 
   // ---- streams -----------------------------------------------------------------------------------------------------------
@@ -844,7 +849,11 @@ __global__ __launch_bounds__(256, 1) void ekf_smoother_wave_l96_kernel(const WgA
   const R* fPn = a.fP + n * a.P_sn;
   int st = 0;
   bool bad = false;
-  const int skip = a.forecast;  // diagnostic mask of phases to skip (scripts/prof_w40.sh; 0 unless CDKF_W40_ABLATE is set)
+#ifdef CDKF_W40_PROFILE
+  const int skip = a.forecast;  // diagnostic mask of phases to skip (scripts/prof_w40.sh; profiling builds only)
+#else
+  constexpr int skip = 0;
+#endif
 
   int oY[EPL], oYT[EPL];  // the owned entries' two positions in a symmetric image
 #pragma unroll

@@ -34,6 +34,20 @@ struct W8Tile<float> {
   static CDKF_DEV int row(int g, int r) { return 4 * g + r; }
 };
 
+#ifdef CDKF_W8_PROFILE  // local diagnostic build (scripts/w8_prof_build.sh): cycles per phase (s_memtime), printed by trajectory 0
+__device__ long long w8_prof[24];
+#define W8_TICK(i)                                                              \
+  {                                                                             \
+    const long long w8_now = clock64();                                         \
+    if (threadIdx.x == 0 && blockIdx.x == 0) w8_prof[i] += w8_now - w8_last;   \
+    w8_last = clock64();                                                        \
+  }
+#define W8_TICK_DECL long long w8_last = clock64();
+#else
+#define W8_TICK(i)
+#define W8_TICK_DECL
+#endif
+
 CDKF_DEV void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
@@ -149,7 +163,9 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave8_kernel(const WgArgs<R
   const bool zeroth = a.order == 0;
 
   // right-hand side of the moment ODEs for the stage value (xs: mean on lanes < d, Ps: this lane's covariance entry)
+  W8_TICK_DECL
   auto rhs = [&](R xs, R Ps, R& kM, R& kP) __attribute__((always_inline)) {
+    W8_TICK(0)  // stage combination (outside the right-hand side)
     W[W8Off::P + lane] = Ps;
     if (lane < kW8) W[W8Off::x + lane] = xs;
     wave_sync();
@@ -203,6 +219,7 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave8_kernel(const WgArgs<R
       W[W8Off::a1 + lane] = a1;
       W[W8Off::d1 + lane] = d1;
       wave_sync();
+      W8_TICK(1)  // state broadcast, layer 1, tanh
       // layer 2 on the matrix cores: acc[mt][r] = [T | z2 - b2][16 mt + row(lg, r)][lm],  T = W2 D1 W1 (tangent), column 8: W2 a1
       typename MTile::V4 acc[4];
 #pragma unroll
@@ -227,6 +244,7 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave8_kernel(const WgArgs<R
           for (int r = 0; r < 4; ++r) W[W8Off::U + (16 * mt + MTile::row(lg, r)) * 9 + lm] = acc[mt][r];
       }
       wave_sync();
+      W8_TICK(2)  // tangent product (64 MFMA) + its images
       const R z2 = W[W8Off::s2 + lane] + b2l;  // lane = hidden unit p
       const R a2 = rtanh(z2);
       const R d2 = R(1) - a2 * a2;
@@ -238,6 +256,7 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave8_kernel(const WgArgs<R
         for (int k = 0; k < kW8; ++k) sdiv = rfma(w3col[k], W[W8Off::U + lane * 9 + k], sdiv);
       }
       wave_sync();
+      W8_TICK(3)  // tanh of layer 2, sdiv
       // layer 3 on the matrix cores: the accumulator rows are this product's k index, scaled by d2 (column 8: a2 itself)
       typename MTile::V4 acc3{0, 0, 0, 0};
 #pragma unroll
@@ -254,6 +273,7 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave8_kernel(const WgArgs<R
         if (row < kW8 && lm < kW8) W[W8Off::A + row * kW8 + lm] = acc3[r];       // F[row][lm]
         if (row < kW8 && lm == 8) W[W8Off::f + row] = acc3[r] + Sh[W8Sh::b3 + row];
       }
+      W8_TICK(4)  // layer 3 (16 chained MFMA), F and f to LDS
       R gl = 0;
       if (second) {
         // g = grad(div f) = W1^T tq (oracle/cdkf_oracle.py MLPDrift.divgrad, G = (W1 W3)^T * W2 never formed):
@@ -282,6 +302,7 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave8_kernel(const WgArgs<R
             if (row < 9) W[W8Off::U + (16 * nt + lm) * 9 + row] = cacc[nt][r];  // (the rows of T were consumed by sdiv above)
           }
         wave_sync();
+        W8_TICK(5)  // 'second': Z image + transposed product (64 MFMA)
         R td = 0;
 #pragma unroll
         for (int k = 0; k < kW8; ++k) td = rfma(w1row[k], W[W8Off::U + lane * 9 + k], td);
@@ -301,6 +322,7 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave8_kernel(const WgArgs<R
         }
       }
       wave_sync();
+      W8_TICK(6)  // 'second': td, tq, g reductions
       Fij = inP ? W[W8Off::A + lane] : R(0);
       if (lane < kW8) {
         fi = W[W8Off::f + lane];
@@ -326,12 +348,14 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave8_kernel(const WgArgs<R
       kM = rfma(R(0.5), s, kM);
     }
     wave_sync();
+    W8_TICK(7)  // F P, k_P, 0.5 P g
   };
 
   const R* tp = a.t + n * a.t_sn;
   const R* yp = a.y + n * a.y_sn;
   using C = Dp5<R>;
   for (long k = 0; k < a.T; ++k) {
+    W8_TICK(8)  // end of step: combination, stores
     // ---------------- update (inference_ekf.py:153-199, 285-286) ----------------
     const R yl = (lane < m) ? yp[k * a.y_sk + lane * a.y_si] : R(0);
     for (int it = 0; it < (a.forecast ? 0 : a.num_iter); ++it) {
@@ -482,6 +506,7 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave8_kernel(const WgArgs<R
     // ---------------- store filtered ----------------
     if (a.fm && lane < d) a.fm[n * a.m_sn + k * a.m_sk + lane * a.m_si] = mj;
     if (a.fP && inP) a.fP[n * a.P_sn + k * a.P_sk + (i * d + j) * a.P_si] = Pij;
+    W8_TICK(9)  // measurement update, symmetrise, filtered stores
     // ---------------- predict ----------------
     const R t0 = tp[k * a.t_sk];
     const R t1 = (k + 1 < a.T) ? tp[(k + 1) * a.t_sk] : t0 + a.dt_final;
@@ -548,6 +573,14 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave8_kernel(const WgArgs<R
     a.ll[n] = (R)ll;
     if (a.status) a.status[n] = st;
   }
+#ifdef CDKF_W8_PROFILE
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    printf("w8 cycles/obs-step (sizeof real %d, order %d):", (int)sizeof(R), a.order);
+    for (int q = 0; q < 10; ++q) printf(" [%d] %lld", q, w8_prof[q] / a.T);
+    printf("\n");
+    for (int q = 0; q < 10; ++q) w8_prof[q] = 0;
+  }
+#endif
 }
 
 }  // namespace cdkf

@@ -96,7 +96,7 @@ static int try_lpe_grad(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, in
     return CDKF_OK;
   // drift block only: the forward-sensitivity kernel catches up once the grid has more than a wavefront per SIMD; with the model block
   // the alternative is the wavefront-per-trajectory reverse sweep (40x slower at this state dimension), whatever the batch size
-  if (!grad_model && !lpe_batch_is_small(N)) return CDKF_OK;
+  if (!grad_model && !lpe_batch_is_small(N, kLpeGrad)) return CDKF_OK;
   switch (mdl->emission_dim) {
     case 1: return run_lpe_grad<R, 1>(mdl, o, N, T, t, y, ll, grad, grad_model, status, stream, handled);
     case 2: return run_lpe_grad<R, 2>(mdl, o, N, T, t, y, ll, grad, grad_model, status, stream, handled);
@@ -120,7 +120,7 @@ int launch_ekf_grad(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_
   if (!sens) {
     set_error("loglik_grad: no kernel for drift_kind=%d state_dim=%d emission_dim=%d state_order=%d num_iter=%d "
               "(forward sensitivities: register-resident Lorenz-63 / linear shapes; reverse sweep: state_dim, emission_dim "
-              "<= 8, MLP hidden <= 64 with state_order first; num_iter 1, state_order first|second)",
+              "<= 8, MLP hidden <= 64; num_iter 1, state_order first|second)",
               mdl->drift_kind, mdl->state_dim, mdl->emission_dim, o->state_order, o->num_iter);
     return CDKF_EUNSUPPORTED;
   }

@@ -27,8 +27,10 @@ int launch_wave40(const WgArgs<R>& a, hipStream_t stream, bool backward) {
     const unsigned blocks = (unsigned)((a.N + W40S<D>::kWaves - 1) / W40S<D>::kWaves);
     note_kernel("ekf_smoother_wave_l96_kernel<%s, %d>", real_name<R>(), D);
     WgArgs<R> b = a;
-    const char* ab = getenv("CDKF_W40_ABLATE_BWD");  // diagnostic: mask of phases to skip; never set in production
-    b.forecast = ab ? atoi(ab) : 0;
+    b.forecast = 0;
+#ifdef CDKF_W40_PROFILE  // scripts/w40_prof_build.sh: mask of phases to skip (the shipped library has no such switch)
+    if (const char* ab = getenv("CDKF_W40_ABLATE_BWD")) b.forecast = atoi(ab);
+#endif
     hipLaunchKernelGGL((ekf_smoother_wave_l96_kernel<R, D>), dim3(blocks), dim3(64 * W40S<D>::kWaves), lds, stream, b);
     CDKF_HIP_CHECK(hipGetLastError());
     return CDKF_OK;
@@ -38,8 +40,10 @@ int launch_wave40(const WgArgs<R>& a, hipStream_t stream, bool backward) {
   const unsigned blocks = (unsigned)((a.N + W40<D>::kWaves - 1) / W40<D>::kWaves);
   note_kernel("ekf_filter_wave_l96_kernel<%s, %d>", real_name<R>(), D);
   WgArgs<R> b = a;
-  const char* ab = getenv("CDKF_W40_ABLATE");  // diagnostic: mask of phases to skip (see the kernel); never set in production
-  b.forecast = ab ? atoi(ab) : 0;
+  b.forecast = 0;
+#ifdef CDKF_W40_PROFILE  // scripts/w40_prof_build.sh: mask of phases to skip (the shipped library has no such switch)
+  if (const char* ab = getenv("CDKF_W40_ABLATE")) b.forecast = atoi(ab);
+#endif
   hipLaunchKernelGGL((ekf_filter_wave_l96_kernel<R, D>), dim3(blocks), dim3(64 * W40<D>::kWaves), lds, stream, b);
   CDKF_HIP_CHECK(hipGetLastError());
   return CDKF_OK;

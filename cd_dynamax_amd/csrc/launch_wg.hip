@@ -1,7 +1,7 @@
 // launch_wg.hip -- workgroup-per-trajectory kernels: parameter block upload, LDS sizing, launch.
 #include "cdkf_launch.h"
 #include "cdkf_wg2_kernels.h"
-#include "cdkf_wave8_kernels.h"
+#include "cdkf_wave8_kernels.h"  // (W8Off / kCkStep for the workspace sizes; the kernel itself is built in launch_w8.hip)
 #include "cdkf_rts1_kernels.h"
 
 namespace cdkf {
@@ -222,17 +222,6 @@ static bool wave8_shape(const cdkf_model* mdl) {
   if (mdl->state_dim > 8 || mdl->emission_dim > 8) return false;
   if (mdl->drift_kind == CDKF_DRIFT_MLP_TANH && (mdl->hidden1 > 64 || mdl->hidden2 > 64)) return false;
   return true;
-}
-
-template <typename R>
-static int launch_wave8(const WgArgs<R>& a, hipStream_t stream) {
-  if (once_per_device([] { return wg_raise_lds_cap(ekf_filter_wave8_kernel<R>); })) return CDKF_EHIP;
-  const size_t lds = sizeof(R) * (size_t)wave8_lds_reals(a.kind) + 64;
-  const unsigned blocks = (unsigned)((a.N + kW8Waves - 1) / kW8Waves);
-  note_kernel("ekf_filter_wave8_kernel<%s>", real_name<R>());
-  hipLaunchKernelGGL(ekf_filter_wave8_kernel<R>, dim3(blocks), dim3(64 * kW8Waves), lds, stream, a);
-  CDKF_HIP_CHECK(hipGetLastError());
-  return CDKF_OK;
 }
 
 template <typename R>

@@ -149,10 +149,12 @@ class _ResidentBatch:
         self.grad = _ffi.DeviceArray((B, n_theta), dtype)
         self.gmodel = _ffi.DeviceArray((B, n_model), dtype) if n_model else None
         self.status = _ffi.DeviceArray((B,), np.int32)
-        self.sums = _ffi.DeviceArray((1 + n_theta + n_model,), np.float64)
+        # [sum ll | sum d ll/d theta | sum d ll/d model block | B]: the block a data-parallel step all-reduces in ONE collective
+        self.sums = _ffi.DeviceArray((2 + n_theta + n_model,), np.float64)
+        self.ones = _ffi.DeviceArray.from_numpy(np.ones(B, dtype))  # the minibatch size reaches slot -1 as a device-side sum
 
-    def value_and_grad(self, mdl: _ffi.ModelBlock, opts, suffix: str):
-        """(sum ll, sum d ll/d theta [n_theta], sum d ll/d model block [n_model]) over the minibatch, reduced on the device."""
+    def _launch(self, mdl: _ffi.ModelBlock, opts, suffix: str):
+        """Sweeps + device-side sums of this minibatch into ``self.sums`` (asynchronous, default stream)."""
         L = _ffi.lib()
         if self.n_model:
             _ffi.check(getattr(L, f"cdkf_ekf_loglik_grad_all_{suffix}_dev")(
@@ -168,20 +170,56 @@ class _ResidentBatch:
         if self.n_model:
             _ffi.check(getattr(L, f"cdkf_grad_sum_{suffix}_dev")(self.gmodel.ptr, self.B, self.n_model,
                                                                 C.c_void_p(sums + 8 * (1 + self.n_theta)), None))
-        _ffi.check(L.cdkf_synchronize(None))
+        _ffi.check(getattr(L, f"cdkf_ll_sum_{suffix}_dev")(self.ones.ptr, self.B,
+                                                         C.c_void_p(sums + 8 * (1 + self.n_theta + self.n_model)), None))
+
+    def value_and_grad(self, mdl: _ffi.ModelBlock, opts, suffix: str):
+        """(sum ll, sum d ll/d theta [n_theta], sum d ll/d model block [n_model]) over the minibatch, reduced on the device."""
+        self._launch(mdl, opts, suffix)
+        _ffi.check(_ffi.lib().cdkf_synchronize(None))
         out = self.sums.numpy()
-        return float(out[0]), out[1:1 + self.n_theta], out[1 + self.n_theta:]
+        return float(out[0]), out[1:1 + self.n_theta], out[1 + self.n_theta:-1]
+
+    def value_and_grad_allreduced(self, mdl: _ffi.ModelBlock, opts, suffix: str, comm):
+        """The data-parallel SGD objective with nothing returning to the host between the sweep and the reduced sums
+        (ssm_temissions.py:555-568: ``vmap(...).sum()`` over ALL sequences): sweeps -> cdkf_ll_sum / cdkf_grad_sum -> ONE in-place
+        ``ncclAllReduce`` of 2 + n_theta + n_model doubles over RCCL, all on one stream; then a single copy of the reduced block.
+        Returns (sum ll, grad theta, grad model, global minibatch size)."""
+        self._launch(mdl, opts, suffix)
+        return _allreduce_block(self.sums, self.n_theta, comm)
 
     def free(self):
-        for a in (self.t, self.y, self.ll, self.grad, self.gmodel, self.status, self.sums):
+        for a in (self.t, self.y, self.ll, self.grad, self.gmodel, self.status, self.sums, self.ones):
             if a is not None:
                 a.free()
+
+
+def _allreduce_block(sums: "_ffi.DeviceArray", n_theta: int, comm):
+    comm.allreduce_sum_dev(sums.ptr, int(np.prod(sums.shape)), None)
+    _ffi.check(_ffi.lib().cdkf_synchronize(None))
+    out = sums.numpy()
+    return float(out[0]), out[1:1 + n_theta], out[1 + n_theta:-1], int(round(out[-1]))
+
+
+class _EmptyPiece:
+    """A rank's share of a data-parallel step in which it has no sequence: zeros, through the same device collective."""
+
+    def __init__(self, n_theta: int, n_model: int):
+        self.B, self.n_theta = 0, n_theta
+        self.sums = _ffi.DeviceArray((2 + n_theta + n_model,), np.float64)
+
+    def value_and_grad_allreduced(self, mdl, opts, suffix, comm):
+        _ffi.check(_ffi.lib().cdkf_memset(self.sums.ptr, 0, self.sums.nbytes))
+        return _allreduce_block(self.sums, self.n_theta, comm)
+
+    def free(self):
+        self.sums.free()
 
 
 def fit_sgd(model, params, props, emissions, t_emissions=None, filter_hyperparams: Optional[Any] = None, inputs=None,
             optimizer=None, batch_size: int = 1, num_epochs: int = 50, shuffle: bool = False,
             return_param_history: bool = False, return_grad_history: bool = False, key=0, dtype=None,
-            allreduce=None):
+            allreduce=None, comm=None):
     """Minimise ``-(log_prior + sum_n ll_n * scale) / emissions.size`` over the trainable parameters, in the unconstrained
     space (ssm_temissions.py:548-583).  Returns ``(params, losses)`` (+ parameter / gradient histories when requested, one
     entry per epoch as the reference's scan returns them, optimize_utils.py:128-131; gradients are those of the loss
@@ -190,8 +228,14 @@ def fit_sgd(model, params, props, emissions, t_emissions=None, filter_hyperparam
     ``key``: seed of the NumPy generator that permutes the sequences when ``shuffle`` (JAX's PRNG stream is not
     reproduced).  ``allreduce``: optional callable summing a float64 array over data-parallel ranks
     (``distributed.allreduce_sum_array``) -- each rank then passes its own block of sequences (blocks may differ in size or be
-    empty) and every rank applies the same update: the single-process fit of the concatenated data, with step b's minibatch
-    made of every rank's b-th piece."""
+    empty) and every rank applies the same update: that of ONE process holding the concatenated data whose step-b minibatch is the
+    union of every rank's b-th piece (``np.array_split`` of the rank's block into ceil(N_total / batch_size) pieces; with
+    ``batch_size >= N_total`` that is the plain single-process full-batch fit, otherwise the minibatch composition differs from
+    ``batch_size`` consecutive slices of the concatenation).
+    ``comm``: a ``distributed.Comm`` instead of the callable.  With an RCCL communicator (``Comm(..., device=d)``) a step's reduction
+    stays on the device: sweeps -> ``cdkf_ll_sum`` / ``cdkf_grad_sum`` -> one in-place ``cdkf_ll_allreduce`` of 2 + n_theta + n_model
+    doubles on the same stream, and only the reduced block is copied back; a host-only ``Comm`` sums the
+    copied-back block over the library's TCP rendezvous (CPU tests)."""
     from .models import _grads_tree, _model_block, _opts, _prepare
     hyper = EKFHyperParams() if filter_hyperparams is None else filter_hyperparams
     if not isinstance(hyper, EKFHyperParams):
@@ -215,6 +259,11 @@ def fit_sgd(model, params, props, emissions, t_emissions=None, filter_hyperparam
     n_theta = mdl0.theta.size
     n_model = 0 if tr.drift_only else _ffi.model_grad_size(mdl0.state_dim, mdl0.emission_dim)
     t_shared = bool(opts.t_shared)
+    if comm is not None:
+        if allreduce is not None:
+            raise ValueError("fit_sgd: pass either allreduce= (a host callable) or comm= (a distributed.Comm), not both")
+        allreduce = comm.allreduce_sum_host
+    on_device = comm is not None and bool(getattr(comm, "_comm", None))  # the step's reduction runs over RCCL, in place
     if allreduce is not None:
         # Data-parallel: this rank holds its block of the N_total sequences.  The loss is the single-process one,
         # -(sum over the GLOBAL minibatch of ll * N_total / B_global) / emissions.size of the whole data set, so N and size are
@@ -236,8 +285,8 @@ def fit_sgd(model, params, props, emissions, t_emissions=None, filter_hyperparam
     rng = np.random.default_rng(key if isinstance(key, (int, np.integer)) else 0)
 
     def build(idx):
-        if len(idx) == 0:
-            return None  # this rank has no sequence in that step
+        if len(idx) == 0:  # this rank has no sequence in that step
+            return _EmptyPiece(n_theta, n_model) if on_device else None
         return _ResidentBatch(y[idx], t if t_shared else t[idx], t_shared, n_theta, n_model, dtype)
 
     order = np.arange(N)
@@ -262,12 +311,16 @@ def fit_sgd(model, params, props, emissions, t_emissions=None, filter_hyperparam
             for batch in resident:
                 cur = tr.from_unconstrained(params, u)
                 mdl = _model_block(cur)
-                if batch is None:
+                if on_device:
+                    ll_sum, g_th, g_md, B = batch.value_and_grad_allreduced(mdl, opts, suffix, comm)
+                    if B == 0:
+                        continue
+                elif batch is None:
                     ll_sum, g_th, g_md, B = 0.0, np.zeros(n_theta), np.zeros(n_model), 0
                 else:
                     ll_sum, g_th, g_md = batch.value_and_grad(mdl, opts, suffix)
                     B = batch.B
-                if allreduce is not None:
+                if allreduce is not None and not on_device:
                     red = np.asarray(allreduce(np.concatenate([[ll_sum, float(B)], g_th, g_md])), np.float64)
                     ll_sum, B, g_th, g_md = float(red[0]), int(round(red[1])), red[2:2 + n_theta], red[2 + n_theta:]
                     if B == 0:  # no rank had a sequence left for this step (more steps than sequences per rank): nothing to do

@@ -264,14 +264,14 @@ class ContDiscreteLinearGaussianSSM:
 
     def fit_sgd(self, params, props, emissions, t_emissions=None, filter_hyperparams=None, inputs=None, optimizer=None,
                 batch_size: int = 1, num_epochs: int = 50, shuffle: bool = False, return_param_history: bool = False,
-                return_grad_history: bool = False, key=0, dtype=None, allreduce=None):
+                return_grad_history: bool = False, key=0, dtype=None, allreduce=None, comm=None):
         """``SSM.fit_sgd`` (ssm_temissions.py:492-600) for the linear model: any of initial mean / cov, dynamics weights,
         diffusion coefficient / cov, emission weights / bias / cov may be trainable (``cd_dynamax_amd.fit.fit_sgd``)."""
         from .fit import fit_sgd
         nl = ContDiscreteNonlinearGaussianSSM(self.state_dim, self.emission_dim)
         out = fit_sgd(nl, _as_nonlinear(params, inputs), _props_as_nonlinear(props, params), emissions, t_emissions,
                       _hyper(filter_hyperparams), None, optimizer, batch_size, num_epochs, shuffle, return_param_history,
-                      return_grad_history, key, dtype, allreduce)
+                      return_grad_history, key, dtype, allreduce, comm)
         out = list(out)
         out[0] = _from_nonlinear(out[0], params)
         if return_param_history:

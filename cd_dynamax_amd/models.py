@@ -142,6 +142,8 @@ def _opts(hyperparams, num_iter: int = 1):
         o.cov_rescaling = float(hyperparams.cov_rescaling)
     else:
         o.ukf_alpha, o.ukf_beta, o.ukf_kappa = float(hyperparams.alpha), float(hyperparams.beta), float(hyperparams.kappa)
+        if getattr(hyperparams, "sigma_points", False):
+            o.flags |= _ffi.FLAG_UKF_SIGMA_POINTS
     return o
 
 
@@ -361,8 +363,8 @@ def cdnlgssm_loglik_and_grad_all(
     if not _ffi.lib().cdkf_grad_all_supported(_ffi.C.byref(mdl.c), _ffi.C.byref(opts)):
         raise NotImplementedError(
             f"no reverse-sweep kernel for drift {type(params.dynamics.drift).__name__} with state_dim={mdl.state_dim}, "
-            f"emission_dim={mdl.emission_dim}, state_order={hyperparams.state_order} (needs dimensions <= 8; MLP drift: "
-            "state_order='first')")
+            f"emission_dim={mdl.emission_dim}, state_order={hyperparams.state_order} (needs state and emission dimensions <= 8, "
+            "MLP hidden layers <= 64, num_iter 1, state_order 'first' or 'second')")
     if on_device:  # the sweeps run on the device tensors; the (small) gradient blocks are packed on the host
         ll, gth, _, gm = (x.cpu().numpy() for x in _device.loglik_grad_device(mdl, opts, t, y, True))
     else:
@@ -538,11 +540,11 @@ class ContDiscreteNonlinearGaussianSSM:
 
     def fit_sgd(self, params, props, emissions, t_emissions=None, filter_hyperparams=None, inputs=None, optimizer=None,
                 batch_size: int = 1, num_epochs: int = 50, shuffle: bool = False, return_param_history: bool = False,
-                return_grad_history: bool = False, key=0, dtype=None, allreduce=None):
+                return_grad_history: bool = False, key=0, dtype=None, allreduce=None, comm=None):
         """ssm_temissions.py:492-600 for the trainable drift parameters; see ``cd_dynamax_amd.fit.fit_sgd``."""
         from .fit import fit_sgd
         return fit_sgd(self, params, props, emissions, t_emissions, filter_hyperparams, inputs, optimizer, batch_size,
-                       num_epochs, shuffle, return_param_history, return_grad_history, key, dtype, allreduce)
+                       num_epochs, shuffle, return_param_history, return_grad_history, key, dtype, allreduce, comm)
 
     def log_prior(self, params) -> float:
         """SSM.log_prior (ssm_temissions.py:152-161): the reference's models define no prior."""

@@ -207,11 +207,16 @@ class EKFHyperParams(NamedTuple):
 
 
 class UKFHyperParams(NamedTuple):
+    """inference_ukf.py:25-33.  ``sigma_points`` is not in the reference: True makes every drift take the kernels that form the
+    2 d + 1 sigma points and factorise the covariance in every Runge-Kutta stage (``CDKF_FLAG_UKF_SIGMA_POINTS``) -- the
+    reference's literal arithmetic, including its NaN when a STAGE covariance loses positive definiteness
+    (inference_ukf.py:57, :138); by default Lorenz-63 / linear drifts use the exact closed form of the weighted sums."""
     dt_final: float = 1e-10
     alpha: float = math.sqrt(3)
     beta: int = 2
     kappa: int = 1
     diffeqsolve_settings: dict = {}
+    sigma_points: bool = False
 
 
 class EnKFHyperParams(NamedTuple):

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define CDKF_VERSION 106 /* 0.2.0 */
+#define CDKF_VERSION 107 /* 0.3.0 */
 
 /* error codes */
 #define CDKF_OK 0
@@ -104,6 +104,15 @@ typedef struct cdkf_model {
 
 /* EKFHyperParams / UKFHyperParams (inference_ekf.py:34-44, inference_ukf.py:25-33) and the
  * defaults of src/utils/diffrax_utils.py:40-52 (Dopri5, ConstantStepSize, dt0 = 0.01). */
+/* cdkf_opts.flags */
+#define CDKF_FLAG_UKF_SIGMA_POINTS 1 /* unscented filter: form the 2 d + 1 sigma points and factorise the covariance in EVERY Runge-Kutta
+                                        stage, literally as inference_ukf.py:45-60, 93-159 do -- also for the drifts whose weighted sums
+                                        this library otherwise evaluates in closed form (Lorenz-63 / linear on the sixteen-lane grid,
+                                        DESIGN.md 3.2b: same numbers to rounding, 3.5x faster).  With the flag a trajectory turns NaN
+                                        exactly where the reference's does: when a STAGE covariance inside an interval loses positive
+                                        definiteness (jnp.linalg.cholesky, inference_ukf.py:57 called from :138), not only when the
+                                        covariance at an observation does. */
+
 typedef struct cdkf_opts {
   int32_t state_order;  /* CDKF_ORDER_*; default SECOND */
   int32_t num_iter;     /* EKF update re-linearisations; default 1 */
@@ -142,7 +151,7 @@ typedef struct cdkf_opts {
   int32_t layout_in;    /* layout of the INPUT arrays t and y: CDKF_LAYOUT_SAME (default: like `layout`) or a CDKF_LAYOUT_* value.
                            E.g. layout = TCN with layout_in = NT lets a host caller hand over the reference's [N,T,m] arrays
                            untransposed and still get the coalesced native output layout. */
-  int32_t reserved;     /* must be 0 */
+  int32_t flags;        /* bit mask of CDKF_FLAG_*; default 0; unknown bits are refused (CDKF_EINVAL) */
 } cdkf_opts;
 
 /* Fill *opts with the reference defaults listed above. */

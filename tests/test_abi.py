@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol(hip_lib):
 
 
 def test_version_and_default_opts(hip_lib):
-    assert hip_lib.cdkf_version() == 106
+    assert hip_lib.cdkf_version() == 107
     o = _ffi.default_opts()
     assert (o.state_order, o.num_iter, o.t_shared, o.device, o.layout) == (2, 1, 0, -1, 0)
     assert o.max_steps == 100000 and o.dt0 == 0.01 and o.dt_final == 1e-10 and o.cov_rescaling == 1.0
@@ -80,6 +80,14 @@ def test_argument_errors_are_reported(hip_lib):
     o = _ffi.default_opts()
     o.layout = 5
     assert f(C.byref(blk.c), C.byref(o), 2, 4, vp(t), vp(y), vp(ll), None, None, None, None, None) == _ffi.CDKF_EINVAL
+    # opts.flags: bits this library version does not define are refused, the defined one is accepted
+    o = _ffi.default_opts()
+    assert o.flags == 0
+    o.flags = 6
+    assert hip_lib.cdkf_ukf_filter_f64(C.byref(blk.c), C.byref(o), 2, 4, vp(t), vp(y), vp(ll), None, None, None, None, None) == _ffi.CDKF_EINVAL
+    assert b"flags" in hip_lib.cdkf_last_error()
+    o.flags = _ffi.FLAG_UKF_SIGMA_POINTS
+    assert hip_lib.cdkf_ukf_filter_f64(C.byref(blk.c), C.byref(o), 0, 4, vp(t), vp(y), vp(ll), None, None, None, None, None) == _ffi.CDKF_OK
     # N = 0 is a valid empty batch
     o = _ffi.default_opts()
     assert f(C.byref(blk.c), C.byref(o), 0, 4, vp(t), vp(y), vp(ll), None, None, None, None, None) == _ffi.CDKF_OK

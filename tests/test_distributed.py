@@ -239,6 +239,91 @@ def test_library_rendezvous_allreduce_across_processes(tmp_path, world):
     assert sum(so.count("RANK_OK_") for so, _ in outs) == world
 
 
+FIT_COMM_WORKER = r'''
+import os, sys
+sys.path[:0] = [os.environ["CDKF_ROOT"], os.path.join(os.environ["CDKF_ROOT"], "oracle"), os.path.join(os.environ["CDKF_ROOT"], "tests")]
+import numpy as np
+import cdkf_oracle as o
+import cd_dynamax_amd as cd
+from cd_dynamax_amd import distributed as D, fit
+from test_fit import _l63_problem
+
+rank, world, port = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+comm = D.Comm(rank, world, "127.0.0.1", port, device=None)   # host-only: fit_sgd(comm=...) then sums over the library's rendezvous
+assert "torch" not in sys.modules
+
+class OracleBatch:
+    """Stands in for fit._ResidentBatch (the GPU sweep) on CPU: same interface, value and gradient from the oracle."""
+    def __init__(self, y, t, t_shared, n_theta, n_model, dtype):
+        self.y, self.t, self.B = np.asarray(y, np.float64), np.asarray(t, np.float64), y.shape[0]
+    def value_and_grad(self, mdl, opts, suffix):
+        m = o.lorenz63_model(1)
+        cur = o.Model(o.Lorenz63Drift(*mdl.theta), m.L, m.Qc, m.H, m.bias, m.R, m.m0, 100 * np.eye(3))
+        ll, g = o.ekf_loglik_grad(cur, self.t, self.y)
+        return float(ll.sum()), g.sum(0), np.zeros(0)
+    def free(self):
+        pass
+fit._ResidentBatch = OracleBatch
+
+model, params, props = _l63_problem(m=1)
+rng = np.random.default_rng(5)
+mdl = o.lorenz63_model(1)
+mdl = o.Model(mdl.drift, mdl.L, mdl.Qc, mdl.H, mdl.bias, mdl.R, mdl.m0, 100 * np.eye(3))
+N, T, lr = 7, 12, 0.05
+t = o.irregular_times(rng, N, T, 0.05)
+y = o.simulate(mdl, t, rng)
+lo, hi = D.shard_bounds(N, rank, world)
+
+def expected(batches):
+    th, losses = mdl.drift.theta().copy(), []
+    for idx in batches:
+        cur = o.Model(o.Lorenz63Drift(*th), mdl.L, mdl.Qc, mdl.H, mdl.bias, mdl.R, mdl.m0, mdl.P0)
+        ll, g = o.ekf_loglik_grad(cur, t[idx], y[idx])
+        scale = N / len(idx)
+        losses.append(-(ll.sum() * scale) / y.size)
+        th = th - lr * (-(g.sum(0) * scale) / y.size)
+    return th, float(np.mean(losses))
+
+for bs in (N, 3, 1):   # full batch; minibatches over unequal blocks; more steps than a rank has sequences (empty pieces)
+    nb = -(-N // bs)
+    new, losses = model.fit_sgd(params, props, y[lo:hi], t[lo:hi, :, None], cd.EKFHyperParams(), optimizer=fit.SGD(lr), batch_size=bs,
+                                num_epochs=1, comm=comm)
+    pieces = [np.array_split(np.arange(*D.shard_bounds(N, r, world)), nb) for r in range(world)]
+    steps = [np.concatenate([pieces[r][b] for r in range(world)]) for b in range(nb)]
+    th, loss = expected([b for b in steps if len(b)])
+    got = np.array([new.dynamics.drift.sigma, new.dynamics.drift.rho, new.dynamics.drift.beta])
+    assert np.allclose(got, th, rtol=1e-10), (bs, got, th)
+    assert abs(losses[0] - loss) < 1e-10 * abs(loss), (bs, losses, loss)
+try:
+    model.fit_sgd(params, props, y[lo:hi], t[lo:hi, :, None], cd.EKFHyperParams(), comm=comm, allreduce=lambda x: x)
+    raise SystemExit("comm= and allreduce= together must be refused")
+except ValueError:
+    pass
+comm.barrier()
+comm.close()
+sys.stdout.write("RANK_OK_%d\\n" % rank); sys.stdout.flush()
+'''
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_fit_sgd_through_the_library_communicator(tmp_path, world):
+    """fit_sgd(comm=Comm(...)): the data-parallel SGD step through the library's own communicator object -- host-only here (TCP
+    rendezvous; the RCCL leg of the same call is tests/test_gpu_comm.py::test_fit_sgd_reduces_on_the_device_through_rccl) --
+    with unequal blocks, minibatches and empty pieces; plain processes, no torch."""
+    script = tmp_path / "fit_comm_worker.py"
+    script.write_text(FIT_COMM_WORKER)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, CDKF_ROOT=ROOT, OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(world), str(port)], env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, so + se
+    assert sum(so.count("RANK_OK_") for so, _ in outs) == world
+
+
 def test_rendezvous_argument_and_timeout_errors():
     import ctypes as C
     from cd_dynamax_amd import _ffi

@@ -153,3 +153,51 @@ def test_two_ranks_share_the_one_device_if_rccl_allows(tmp_path, hip_lib):
     if "RCCL_REFUSED" in text:
         pytest.skip("RCCL refuses two ranks on one device here: " + text.strip().splitlines()[0][:200])
     assert text.count("RANK_OK_") == 2, text
+
+
+def test_fit_sgd_reduces_on_the_device_through_rccl(hip_lib):
+    """fit_sgd(comm=Comm(..., device=0)): the SGD step's reduction (ssm_temissions.py:555-568) stays on the device -- sweeps ->
+    cdkf_ll_sum / cdkf_grad_sum -> ONE in-place ncclAllReduce of 2 + n_theta + n_model doubles through a real RCCL communicator
+    (world 1 on this box) -> a single copy of the reduced block.  Same numbers as the plain single-process fit: drift-only
+    (three parameters) and every leaf (the model block as well), minibatches that do not divide the data."""
+    import cd_dynamax_amd as cd
+    from cd_dynamax_amd import fit
+    from cd_dynamax_amd.bijectors import RealToPSDBijector
+    from cd_dynamax_amd.params import ParameterProperties as PP
+    from test_fit import _l63_problem
+    comm = D.Comm(0, 1, "127.0.0.1", _free_port(), device=0)
+    assert comm._comm
+    calls = []
+    orig = comm.allreduce_sum_dev
+    comm.allreduce_sum_dev = lambda ptr, count, stream=None: (calls.append(count), orig(ptr, count, stream))[1]
+    try:
+        model, params, props = _l63_problem(m=3)
+        rng = np.random.default_rng(4)
+        true = o.lorenz63_model(3)
+        N, T = 11, 40
+        t = o.irregular_times(rng, N, T, 0.01 * T)
+        y = o.simulate(true, t, rng)
+        kw = dict(optimizer=fit.SGD(0.05), batch_size=4, num_epochs=2)
+        ref, ref_losses = model.fit_sgd(params, props, y, t[..., None], cd.EKFHyperParams(), **kw)
+        got, losses = model.fit_sgd(params, props, y, t[..., None], cd.EKFHyperParams(), comm=comm, **kw)
+        # data-parallel pieces are np.array_split pieces (4, 4, 3) -- here identical to the consecutive slices of 4, 4, 3
+        np.testing.assert_allclose(losses, ref_losses, rtol=1e-13)
+        np.testing.assert_allclose([got.dynamics.drift.sigma, got.dynamics.drift.rho, got.dynamics.drift.beta],
+                                   [ref.dynamics.drift.sigma, ref.dynamics.drift.rho, ref.dynamics.drift.beta], rtol=1e-13)
+        assert calls == [2 + 3] * 6, calls  # [sum ll | d/d(sigma, rho, beta) | B], one collective per step
+        # every leaf: + m0, P0, L Qc L^T, H, bias, R through the same single collective
+        calls.clear()
+        psd, free = PP(constrainer=RealToPSDBijector()), PP()
+        allp = params._replace(
+            initial=params.initial._replace(mean=cd.LearnableVector(free), cov=cd.LearnableMatrix(psd)),
+            dynamics=params.dynamics._replace(drift=cd.LearnableLorenz63(free, free, free), diffusion_coefficient=cd.LearnableMatrix(free),
+                                              diffusion_cov=cd.LearnableMatrix(psd), approx_order=PP(False)),
+            emissions=params.emissions._replace(emission_function=cd.LearnableLinear(free, free), emission_cov=cd.LearnableMatrix(psd)))
+        ref, ref_losses = model.fit_sgd(params, allp, y, t[..., None], cd.EKFHyperParams(), **kw)
+        got, losses = model.fit_sgd(params, allp, y, t[..., None], cd.EKFHyperParams(), comm=comm, **kw)
+        np.testing.assert_allclose(losses, ref_losses, rtol=1e-13)
+        np.testing.assert_allclose(got.emissions.emission_cov.params, ref.emissions.emission_cov.params, rtol=1e-12)
+        np.testing.assert_allclose(got.initial.mean.params, ref.initial.mean.params, rtol=1e-12, atol=1e-15)
+        assert calls == [2 + 3 + _ffi.model_grad_size(3, 3)] * 6, calls
+    finally:
+        comm.close()

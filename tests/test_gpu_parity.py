@@ -457,6 +457,56 @@ def test_linear_drift_on_the_lane_grid(hip_lib):
         assert relerr(np.asarray(big.filtered_covariances)[:N], small.filtered_covariances) < 1e-11
 
 
+def test_unscented_filter_literal_sigma_points_flag(hip_lib):
+    """UKFHyperParams(sigma_points=True) -> opts.flags & CDKF_FLAG_UKF_SIGMA_POINTS: the kernel that forms the sigma points and
+    factorises the covariance in every Runge-Kutta stage (inference_ukf.py:57 called from :138), also where the closed form of
+    the weighted sums would apply.  (a) same numbers as the closed form to rounding on a well-behaved problem, in one process;
+    (b) the reference's failure path: with dt0 = 0.022 Lorenz-63 stage covariances lose positive definiteness INSIDE the first
+    interval for two thirds of these trajectories -- the oracle (which restates the reference's per-stage cholesky) turns exactly
+    those into NaN, and so does the flagged sweep; the default sweep tests positive definiteness at the observations only (DESIGN
+    3.2b) and keeps some of them finite.  Unknown flag bits are refused."""
+    rng = np.random.default_rng(33)
+    mdl = o.lorenz63_model(3)
+    P = params_from(mdl)
+    t = o.irregular_times(rng, 9, 40, 0.4)
+    y = o.simulate(mdl, t, rng)
+    lit = cd.cdnlgssm_filter(P, y, t[..., None], cd.UKFHyperParams(sigma_points=True))
+    assert hip_lib.cdkf_last_kernel().startswith(b"filter_reg_kernel"), hip_lib.cdkf_last_kernel()
+    closed = cd.cdnlgssm_filter(P, y, t[..., None], cd.UKFHyperParams())
+    assert hip_lib.cdkf_last_kernel().startswith(b"filter_lpe_kernel"), hip_lib.cdkf_last_kernel()
+    for f in ("marginal_loglik", "filtered_means", "filtered_covariances", "predicted_means", "predicted_covariances"):
+        assert relerr(getattr(lit, f), getattr(closed, f)) < 1e-11, f
+    _check_filter(lit, o.ukf_filter(mdl, t, y), 1e-9)
+    # (b)
+    rng = np.random.default_rng(0)
+    N, T = 32, 30
+    t = o.irregular_times(rng, N, T, 0.06 * T)
+    y = o.simulate(mdl, t, rng)
+    with np.errstate(all="ignore"):
+        ref = o.ukf_filter(mdl, t, y, dt0=0.022)
+    bad = np.isnan(ref["marginal_loglik"])
+    assert 8 <= bad.sum() <= N - 4, bad.sum()  # the regime this test is about: some trajectories fail, some do not
+    hyp = cd.UKFHyperParams(diffeqsolve_settings={"dt0": 0.022}, sigma_points=True)
+    post = cd.cdnlgssm_filter(P, y, t[..., None], hyp)
+    np.testing.assert_array_equal(np.isnan(post.marginal_loglik), bad)
+    np.testing.assert_array_equal(np.isnan(post.filtered_means), np.isnan(ref["filtered_means"]))
+    assert relerr(post.marginal_loglik[~bad], ref["marginal_loglik"][~bad]) < 1e-9
+    assert relerr(post.filtered_covariances[~bad], ref["filtered_covariances"][~bad]) < 1e-9
+    default = cd.cdnlgssm_filter(P, y, t[..., None], cd.UKFHyperParams(diffeqsolve_settings={"dt0": 0.022}))
+    assert np.isnan(default.marginal_loglik).sum() < bad.sum()  # the documented difference on the reference's failure path
+    assert relerr(default.marginal_loglik[~bad], ref["marginal_loglik"][~bad]) < 1e-9
+    # unknown bits
+    blk = models._model_block(P)
+    opts = _ffi.default_opts()
+    opts.flags = 2
+    assert hip_lib.cdkf_supported(_ffi.C.byref(blk.c), _ffi.C.byref(opts), 1, 8) in (0, 1)
+    tt, yy = np.ascontiguousarray(t[:1]), np.ascontiguousarray(y[:1])
+    ll, st = np.zeros(1), np.zeros(1, np.int32)
+    dp = lambda a: a.ctypes.data_as(_ffi.C.c_void_p)
+    rc = hip_lib.cdkf_ukf_filter_f64(_ffi.C.byref(blk.c), _ffi.C.byref(opts), 1, T, dp(tt), dp(yy), dp(ll), None, None, None, None, dp(st))
+    assert rc == _ffi.CDKF_EINVAL and b"flags" in hip_lib.cdkf_last_error()
+
+
 def test_c3_full_size_properties(hip_lib):
     """BASELINE config 3 (Lorenz-63 UKF, 4096 x 1000, fp32) through size-independent properties: a random subset re-run alone
     through the fp64 ORACLE (literal sigma points) matches the fp32 sweep -- filtered means within 1e-5 (the north-star bar; the

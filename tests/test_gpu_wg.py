@@ -86,6 +86,127 @@ def test_c4_full_length_against_the_oracle(hip_lib):
     assert np.all(np.isfinite(post.smoothed_covariances))
 
 
+def test_c4_full_slice_properties(hip_lib):
+    """BASELINE config 4's per-GPU slice at FULL size (2048 trajectories x 500 irregular observations, Lorenz-96 d = m = 40, fp64,
+    filter + smoother; extended_kalman_smoother, inference_ekf.py:450-539), device-resident as bench.py runs it: four 13 GB
+    covariance arrays, element offsets beyond 4 GiB.  Checked through size-independent properties: no status flag, the device
+    log-likelihood sum equals the host sum, a random subset (the LAST trajectory included: the largest offsets) re-run through the
+    ORACLE matches on every step (1e-9), the same subset as a batch of its own gives bitwise the same numbers, symmetric outputs."""
+    import ctypes as C
+    from cd_dynamax_amd.models import _model_block
+    from cd_dynamax_amd._ffi import DeviceArray
+    L = hip_lib
+    rng = np.random.default_rng(41)
+    d = 40
+    mdl = lorenz96_model(d, d)
+    N, T = 2048, 500
+    u = rng.uniform(0.0, 1.0, size=(N, T))
+    cs = np.cumsum(u, axis=1)
+    t = cs / cs[:, -1:] * (0.005 * T)
+    y = 8.0 + rng.standard_normal((N, T, d))
+    sub = np.sort(np.concatenate([rng.choice(N - 1, size=2, replace=False), [N - 1]]))
+    y[sub] = o.simulate(mdl, t[sub], rng)
+    blk = _model_block(params_from(mdl))
+    opts = _ffi.default_opts()
+    opts.layout = _ffi.LAYOUT_TN
+
+    def run(tt, yy):
+        n = tt.shape[0]
+        t_d = DeviceArray.from_numpy(np.ascontiguousarray(tt.T))
+        y_d = DeviceArray.from_numpy(np.ascontiguousarray(yy.transpose(1, 0, 2)))
+        ll, st, llsum = DeviceArray((n,), np.float64), DeviceArray.from_numpy(np.zeros(n, np.int32)), DeviceArray((1,), np.float64)
+        bufs = [DeviceArray((T, n) + w, np.float64) for w in ((d,), (d, d), (d,), (d, d))]
+        _ffi.check(L.cdkf_ekf_smoother_f64_dev(C.byref(blk.c), C.byref(opts), n, T, t_d.ptr, y_d.ptr, ll.ptr, *[b.ptr for b in bufs],
+                                               st.ptr, None))
+        kern = L.cdkf_last_kernel().decode()
+        _ffi.check(L.cdkf_ll_sum_f64_dev(ll.ptr, n, llsum.ptr, None))
+        _ffi.check(L.cdkf_synchronize(None))
+
+        def rows(buf, w, which):  # [len(which), T] + w from the [T, n] + w device array: one small copy per (k, trajectory)
+            out = np.empty((len(which), T) + w)
+            e = int(np.prod(w)) * 8
+            for a, n_ in enumerate(which):
+                for k in range(T):
+                    _ffi.check(L.cdkf_memcpy_d2h(out[a, k].ctypes.data_as(C.c_void_p), C.c_void_p(buf.ptr.value + (k * n + int(n_)) * e), e))
+            return out
+        res = dict(ll=ll.numpy(), st=st.numpy(), llsum=float(llsum.numpy()[0]), kern=kern, rows=rows, bufs=bufs)
+        for a in (t_d, y_d, ll, st, llsum):
+            a.free()
+        return res
+
+    full = run(t, y)
+    assert full["kern"].startswith("ekf_smoother_wave_l96_kernel<double"), full["kern"]
+    assert (full["st"] == 0).all() and np.isfinite(full["ll"]).all()
+    assert abs(full["llsum"] - full["ll"].sum()) <= 1e-11 * abs(full["llsum"])
+    got = {k: full["rows"](b, w, sub) for k, b, w in zip(("filtered_means", "filtered_covariances", "smoothed_means", "smoothed_covariances"),
+                                                        full["bufs"], ((d,), (d, d), (d,), (d, d)))}
+    for b in full["bufs"]:
+        b.free()
+    ref = o.ekf_smoother(mdl, t[sub], y[sub])
+    np.testing.assert_allclose(full["ll"][sub], ref["marginal_loglik"], rtol=1e-11)
+    for k, v in got.items():
+        assert relerr(v, ref[k]) < 1e-9, k
+    assert np.array_equal(got["smoothed_covariances"], np.swapaxes(got["smoothed_covariances"], -1, -2))
+    small = run(t[sub], y[sub])
+    np.testing.assert_array_equal(small["ll"], full["ll"][sub])
+    for (k, v), b, w in zip(got.items(), small["bufs"], ((d,), (d, d), (d,), (d, d))):
+        np.testing.assert_array_equal(small["rows"](b, w, range(len(sub))), v, err_msg=k)
+    for b in small["bufs"]:
+        b.free()
+
+
+def test_c5_full_slice_properties(hip_lib):
+    """BASELINE config 5's per-GPU slice at FULL size (1024 trajectories x 1000 irregular observations, 8 -> 64 -> 64 -> 8 tanh MLP,
+    d = 8, m = 4, the reference's default state_order='second', fp64): the SGD objective's value and all 5 256 weight gradients per
+    trajectory (value_and_grad of ssm_temissions.py:550-568) through the forward sweep + reverse sweep with the 8 GB checkpoint
+    workspace.  Properties: no status flag, every value finite, the log-likelihood is the LL-only filter sweep's, a subset (first,
+    last and a random trajectory) re-run through the ORACLE's discrete adjoint matches (1e-8 of the gradient scale over a
+    thousand steps), the subset as a batch of its own gives bitwise the same numbers, the device-side sums equal the host sums."""
+    import ctypes as C
+    from cd_dynamax_amd.models import _model_block
+    from cd_dynamax_amd._ffi import DeviceArray
+    L = hip_lib
+    rng = np.random.default_rng(52)
+    mdl = mlp_model(rng)
+    N, T = 1024, 1000
+    u = rng.uniform(0.0, 1.0, size=(N, T))
+    cs = np.cumsum(u, axis=1)
+    t = cs / cs[:, -1:] * (0.005 * T)
+    y = rng.standard_normal((N, T, 4))
+    sub = np.array([0, int(rng.integers(1, N - 1)), N - 1])
+    P = params_from(mdl)
+    ll, g = cd.cdnlgssm_loglik_and_grad(P, y, t[..., None])
+    assert L.cdkf_last_kernel().decode().startswith("ekf_adjoint_wave8_kernel<double, true, false>")
+    flat = np.concatenate([np.asarray(a).reshape(N, -1) for a in g], axis=-1)
+    assert flat.shape == (N, 5256) and np.isfinite(flat).all() and np.isfinite(ll).all()
+    post = cd.cdnlgssm_filter(P, y, t[..., None], output_fields=[])
+    np.testing.assert_allclose(ll, post.marginal_loglik, rtol=1e-12)
+    ll_ref, g_ref = o.ekf_loglik_grad_adjoint(mdl, t[sub], y[sub], state_order="second")
+    np.testing.assert_allclose(ll[sub], ll_ref, rtol=1e-11)
+    assert np.abs(flat[sub] - g_ref).max() < 1e-8 * np.abs(g_ref).max()
+    ll3, g3 = cd.cdnlgssm_loglik_and_grad(P, y[sub], t[sub][..., None])
+    np.testing.assert_array_equal(ll3, ll[sub])
+    np.testing.assert_array_equal(np.concatenate([np.asarray(a).reshape(3, -1) for a in g3], axis=-1), flat[sub])
+    # the device-resident composition fit_sgd uses: sweeps -> cdkf_ll_sum / cdkf_grad_sum, status flags
+    blk = _model_block(P)
+    opts = _ffi.default_opts()
+    opts.layout = _ffi.LAYOUT_TCN
+    t_d = DeviceArray.from_numpy(np.ascontiguousarray(t.T))
+    y_d = DeviceArray.from_numpy(np.ascontiguousarray(y.transpose(1, 2, 0)))
+    ll_d, st, gd = DeviceArray((N,), np.float64), DeviceArray.from_numpy(np.zeros(N, np.int32)), DeviceArray((N, 5256), np.float64)
+    sums = DeviceArray((1 + 5256,), np.float64)
+    _ffi.check(L.cdkf_ekf_loglik_grad_f64_dev(C.byref(blk.c), C.byref(opts), N, T, t_d.ptr, y_d.ptr, ll_d.ptr, gd.ptr, st.ptr, None))
+    _ffi.check(L.cdkf_ll_sum_f64_dev(ll_d.ptr, N, sums.ptr, None))
+    _ffi.check(L.cdkf_grad_sum_f64_dev(gd.ptr, N, 5256, C.c_void_p(sums.ptr.value + 8), None))
+    _ffi.check(L.cdkf_synchronize(None))
+    s = sums.numpy()
+    assert (st.numpy() == 0).all()
+    assert abs(s[0] - ll.sum()) <= 1e-11 * abs(ll.sum())
+    assert np.abs(s[1:] - flat.sum(0)).max() <= 1e-10 * np.abs(flat.sum(0)).max()
+    for a in (t_d, y_d, ll_d, st, gd, sums):
+        a.free()
+
+
 def test_lorenz96_d40_backward_sweep_kernels_agree(hip_lib, monkeypatch):
     """Config 4's smoother: the wavefront-per-trajectory backward sweep (ekf_smoother_wave_l96_kernel) against the oracle at a
     batch that does not fill its last workgroup, against the workgroup kernel it replaced (CDKF_WG_BACKWARD=1), in fp32, and at
