@@ -67,6 +67,24 @@ def make_batch(rank, n, T, mean_gap=0.005, substeps=1):
     return t, y
 
 
+class quiet_stdout:
+    """RCCL prints a version banner on the C-level stdout when a communicator is made; the contract is ONE JSON line there.
+    Inside this block file descriptor 1 points at stderr (and the C stdio buffer is flushed before it is pointed back)."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        try:
+            C.CDLL(None).fflush(None)
+        finally:
+            os.dup2(self.saved, 1)
+            os.close(self.saved)
+        return False
+
+
 class Timer:
     """HIP events on the launch stream, through the C ABI."""
 
@@ -117,7 +135,10 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     lib = _ffi.lib()  # raises if the HIP library is missing: there is no fallback
     _ffi.check(lib.cdkf_set_device(local_rank))
-    comm = D_.Comm.from_env(gpu=True) if world > 1 else None  # TCP rendezvous + ncclCommInitRank on device local_rank
+    comm = None
+    if world > 1:
+        with quiet_stdout():
+            comm = D_.Comm.from_env(gpu=True)  # TCP rendezvous + ncclCommInitRank on device local_rank
 
     blk = _model_block(l63_params(cd))
     opts = _ffi.default_opts()
@@ -212,7 +233,12 @@ def main():
         comm1 = comm
         if comm1 is None:
             try:
-                comm1 = D_.Comm.from_env(gpu=True)
+                with quiet_stdout():
+                    comm1 = D_.Comm.from_env(gpu=True)
+                    warm = DeviceArray.from_numpy(np.zeros(1))
+                    comm1.allreduce_sum_dev(warm.ptr, 1, stream)
+                    _ffi.check(lib.cdkf_synchronize(stream))
+                    warm.free()
             except Exception as e:  # (no RCCL on this box: the entries then say so; the headline above does not depend on it)
                 sys.stderr.write(f"bench: no one-rank communicator ({e}); other_configs run without the collective\n")
         others = other_configs(lib, timer, stream, t_h, y_h, comm=comm1, world=world, rank=rank,

@@ -5,6 +5,7 @@ filtering / smoothing hot path; the arithmetic lives in hand-written HIP kernels
 ``include/cdkf.h``.
 """
 from . import fit
+from ._ffi import release_workspace
 from . import mcmc
 from .linear import (ContDiscreteLinearGaussianSSM, KFHyperParams, ParamsCDLGSSM, ParamsCDLGSSMDynamics,
                      ParamsLGSSMEmissions, cdlgssm_filter, cdlgssm_smoother)
@@ -23,4 +24,5 @@ __all__ = [
     "ContDiscreteLinearGaussianSSM", "KFHyperParams", "ParamsCDLGSSM", "ParamsCDLGSSMDynamics", "ParamsLGSSMEmissions",
     "cdlgssm_filter", "cdlgssm_smoother", "cdnlgssm_forecast", "cdnlgssm_emissions", "GSSMForecast",
     "cdnlgssm_loglik_and_grad", "cdnlgssm_loglik_and_grad_all", "LearnableCustomDrift", "LearnableCustomEmission", "PIDController", "ConstantStepSize",
+    "release_workspace",
 ]

@@ -100,9 +100,10 @@ SYMBOLS = (
      "cdkf_free", "cdkf_memcpy_h2d", "cdkf_memcpy_d2h", "cdkf_memset", "cdkf_synchronize", "cdkf_ll_sum_f64_dev",
      "cdkf_ll_sum_f32_dev", "cdkf_emission_moments_f64", "cdkf_emission_moments_f32", "cdkf_emission_moments_f64_dev",
      "cdkf_emission_moments_f32_dev", "cdkf_ekf_loglik_grad_f64", "cdkf_ekf_loglik_grad_f32",
-     "cdkf_ekf_loglik_grad_f64_dev", "cdkf_ekf_loglik_grad_f32_dev", "cdkf_custom_drift_register", "cdkf_custom_drift_compile", "cdkf_custom_emission_register", "cdkf_set_kernel_source_dir",
+     "cdkf_ekf_loglik_grad_f64_dev", "cdkf_ekf_loglik_grad_f32_dev", "cdkf_ukf_loglik_grad_f64", "cdkf_ukf_loglik_grad_f32",
+     "cdkf_ukf_loglik_grad_f64_dev", "cdkf_ukf_loglik_grad_f32_dev", "cdkf_ukf_grad_supported", "cdkf_custom_drift_register", "cdkf_custom_drift_compile", "cdkf_custom_emission_register", "cdkf_set_kernel_source_dir",
      "cdkf_kf_smoother1_f64", "cdkf_kf_smoother1_f32", "cdkf_kf_smoother1_f64_dev", "cdkf_kf_smoother1_f32_dev",
-     "cdkf_kf_smoother1_supported", "cdkf_kf_pushforward_f64", "cdkf_kf_pushforward_f32", "cdkf_grad_supported", "cdkf_grad_all_supported", "cdkf_ekf_loglik_grad_all_f64",
+     "cdkf_kf_smoother1_supported", "cdkf_kf_pushforward_f64", "cdkf_kf_pushforward_f32", "cdkf_grad_supported", "cdkf_grad_all_supported", "cdkf_release_workspace", "cdkf_ekf_loglik_grad_all_f64",
      "cdkf_ekf_loglik_grad_all_f32", "cdkf_ekf_loglik_grad_all_f64_dev", "cdkf_ekf_loglik_grad_all_f32_dev", "cdkf_grad_sum_f64_dev",
      "cdkf_grad_sum_f32_dev", "cdkf_comm_unique_id", "cdkf_comm_init_rank", "cdkf_comm_init_all", "cdkf_comm_rank", "cdkf_comm_world",
      "cdkf_ll_allreduce", "cdkf_comm_allreduce_max", "cdkf_ll_allreduce_all", "cdkf_comm_destroy", "cdkf_rdv_create",
@@ -213,6 +214,12 @@ def lib() -> C.CDLL:
     L.cdkf_grad_supported.restype = C.c_int
     L.cdkf_grad_all_supported.argtypes = [C.POINTER(CdkfModel), C.POINTER(CdkfOpts)]
     L.cdkf_grad_all_supported.restype = C.c_int
+    if hasattr(L, "cdkf_ukf_grad_supported"):
+        L.cdkf_ukf_grad_supported.argtypes = [C.POINTER(CdkfModel), C.POINTER(CdkfOpts)]
+        L.cdkf_ukf_grad_supported.restype = C.c_int
+    if hasattr(L, "cdkf_release_workspace"):  # (absent from libraries older than 107: A/B runs through CDKF_LIB_PATH)
+        L.cdkf_release_workspace.argtypes = []
+        L.cdkf_release_workspace.restype = C.c_int
     for p in ("f64", "f32"):
         base = [C.POINTER(CdkfModel), C.POINTER(CdkfOpts), C.c_int64, C.c_int64] + [C.c_void_p] * 6
         f = getattr(L, f"cdkf_ekf_loglik_grad_all_{p}")
@@ -223,12 +230,15 @@ def lib() -> C.CDLL:
         f.restype = C.c_int
     for p in ("f64", "f32"):
         base = [C.POINTER(CdkfModel), C.POINTER(CdkfOpts), C.c_int64, C.c_int64] + [C.c_void_p] * 5
-        f = getattr(L, f"cdkf_ekf_loglik_grad_{p}")
-        f.argtypes = base
-        f.restype = C.c_int
-        f = getattr(L, f"cdkf_ekf_loglik_grad_{p}_dev")
-        f.argtypes = base + [C.c_void_p]
-        f.restype = C.c_int
+        for algo in ("ekf", "ukf"):
+            if not hasattr(L, f"cdkf_{algo}_loglik_grad_{p}"):
+                continue  # (the unscented entry points are absent from libraries older than 107)
+            f = getattr(L, f"cdkf_{algo}_loglik_grad_{p}")
+            f.argtypes = base
+            f.restype = C.c_int
+            f = getattr(L, f"cdkf_{algo}_loglik_grad_{p}_dev")
+            f.argtypes = base + [C.c_void_p]
+            f.restype = C.c_int
         f = getattr(L, f"cdkf_grad_sum_{p}_dev")
         f.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
         f.restype = C.c_int
@@ -424,13 +434,19 @@ def kf_pushforward(mdl: ModelBlock, opts: CdkfOpts, t: np.ndarray, dtype):
     return AQ[:, :, 0], AQ[:, :, 1]
 
 
+def release_workspace() -> None:
+    """Return the reverse sweeps' device workspace (forward moments + stage checkpoints, grow-only, up to CDKF_ADJ_CKPT_GB) to the
+    device once its last user has finished; the next gradient call allocates again."""
+    check(lib().cdkf_release_workspace())
+
+
 def model_grad_size(d: int, m: int) -> int:
     return d + 2 * d * d + m * d + m + m * m
 
 
-def loglik_grad(mdl: ModelBlock, opts: CdkfOpts, t: np.ndarray, y: np.ndarray, dtype, with_model: bool = False):
-    """cdkf_ekf_loglik_grad[_all]_<f32|f64> on host buffers (t [N,T] or [T], y [N,T,m]): returns (ll [N], grad [N, n_theta],
-    status) and, ``with_model``, the model block [N, d + 2 d^2 + m d + m + m^2] as a fourth item."""
+def loglik_grad(mdl: ModelBlock, opts: CdkfOpts, t: np.ndarray, y: np.ndarray, dtype, with_model: bool = False, ukf: bool = False):
+    """cdkf_ekf_loglik_grad[_all]_<f32|f64> (``ukf``: cdkf_ukf_loglik_grad_*) on host buffers (t [N,T] or [T], y [N,T,m]): returns
+    (ll [N], grad [N, n_theta], status) and, ``with_model``, the model block [N, d + 2 d^2 + m d + m + m^2] as a fourth item."""
     dtype = np.dtype(dtype)
     suffix = {np.dtype(np.float32): "f32", np.dtype(np.float64): "f64"}[dtype]
     N, T, m = y.shape
@@ -446,7 +462,7 @@ def loglik_grad(mdl: ModelBlock, opts: CdkfOpts, t: np.ndarray, y: np.ndarray, d
         fn = getattr(lib(), f"cdkf_ekf_loglik_grad_all_{suffix}")
         check(fn(C.byref(mdl.c), C.byref(opts), N, T, _vp(t), _vp(y), _vp(ll), _vp(grad), _vp(gm), _vp(status)))
         return ll, grad, status, gm
-    fn = getattr(lib(), f"cdkf_ekf_loglik_grad_{suffix}")
+    fn = getattr(lib(), f"cdkf_{'ukf' if ukf else 'ekf'}_loglik_grad_{suffix}")
     check(fn(C.byref(mdl.c), C.byref(opts), N, T, _vp(t), _vp(y), _vp(ll), _vp(grad), _vp(status)))
     return ll, grad, status
 

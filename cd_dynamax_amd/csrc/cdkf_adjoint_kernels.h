@@ -48,7 +48,10 @@ struct AdjOff {  // per wavefront, in reals
   static constexpr int a1 = 1168, a2 = 1232, d2 = 1296, UC = 1360, ZC = 1936, TC = 2512, CC = 2512, RED = 2512;
   static constexpr int ck = 3088;  // kAdjCk x (64 P + 8 m), then kAdjCk step sizes
   static constexpr int km = 3088 + kAdjCk * 72 + kAdjCk, ym = km + 48;  // mean parts of the step's slopes / stage cotangents [6][8]
-  static constexpr int end = ym + 48;
+  // the Runge-Kutta tableau as the rolled stage loops want it: rka[r][c] (6 x 6, zero where the method has no entry: c >= r, or a
+  // stage it does not have) and rkb[6] -- uniform LDS reads in ONE basic block instead of a scalar load and a branch per entry
+  static constexpr int rka = ym + 48, rkb = rka + 36;
+  static constexpr int end = rkb + 6;
 };
 template <typename R, bool MLP>
 constexpr int adj_waves() {
@@ -103,6 +106,23 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
   // ---- per-lane constants ---------------------------------------------------------------------------------------
   const bool inP = (i < d) && (j < d);
   const R lql = inP ? (a.par + a.o_LQL)[i * d + j] : R(0);
+  if constexpr (!SMOOTH) {
+    // tableau table (see AdjOff::rka); the slope / cotangent tiles start from zeros: the branch-free combinations below multiply
+    // entries a stage does not use by a zero coefficient, which must not meet the NaN bit patterns uninitialised LDS may hold
+    // (afterwards the tiles only ever hold this trajectory's own finite numbers: slopes, cotangents, the update's intermediates)
+    if (lane < 36) {
+      const int r = fdiv(lane, 6), c = lane - 6 * r;
+      W[AdjOff::rka + lane] = (c < r && r < a.rk.stages && c < 5) ? a.rk.a[r][c] : R(0);
+    }
+    if (lane < 6) W[AdjOff::rkb + lane] = (lane < a.rk.stages) ? a.rk.b[lane] : R(0);
+#pragma unroll
+    for (int q = 0; q < 12; ++q) W[AdjOff::B + 64 * q + lane] = R(0);
+    if (lane < 48) {
+      W[AdjOff::km + lane] = R(0);
+      W[AdjOff::ym + lane] = R(0);
+    }
+    wave_sync();
+  }
   const R Hij = (i < m && j < d) ? (a.par + a.o_H)[i * d + j] : R(0);  // lane (r=i, k=j) holds H[r][k]
   const R Rij = (i < m && j < m) ? (a.par + a.o_R)[i * m + j] : R(0);
   const R hbj = (lane < m) ? (a.par + a.o_hb)[lane] : R(0);
@@ -171,7 +191,7 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
     R z1 = b1l();
 #pragma unroll
     for (int k = 0; k < 8; ++k) z1 = rfma(w1row(k), W[AdjOff::x + k], z1);
-    a1 = rtanh(z1);
+    a1 = rtanh_fast(z1);
     d1 = R(1) - a1 * a1;
     W[AdjOff::a1 + lane] = a1;
 #pragma unroll
@@ -198,7 +218,7 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
     wave_sync();
 #pragma unroll
     for (int k = 0; k < 8; ++k) T[k] = W[AdjOff::TC + lane * 9 + k];
-    a2 = rtanh(W[AdjOff::TC + lane * 9 + 8] + b2l());
+    a2 = rtanh_fast(W[AdjOff::TC + lane * 9 + 8] + b2l());
     d2 = R(1) - a2 * a2;
     W[AdjOff::a2 + lane] = a2;
     W[AdjOff::d2 + lane] = d2;
@@ -240,12 +260,26 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
     typename MTile::V4 acc[4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) acc[mt] = typename MTile::V4{0, 0, 0, 0};
+    {  // software pipeline: the operands of k-step ks + 1 are requested before the four products of k-step ks are issued (the fence the
+       // products' B operand passes through keeps the loads above it and the products below)
+      R bn = (lm < 9) ? W[IN + lg * 9 + lm] : R(0), an[4];
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-      const R bv = (lm < 9) ? W[IN + (4 * ks + lg) * 9 + lm] : R(0);
+      for (int mt = 0; mt < 4; ++mt) an[mt] = Sh[AdjSh::W2 + (16 * mt + lm) * 65 + lg];
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) acc[mt] = wg_mfma(Sh[AdjSh::W2 + (16 * mt + lm) * 65 + 4 * ks + lg], bv, acc[mt]);
-      if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      for (int ks = 0; ks < 16; ++ks) {
+        R bv = bn;
+        const R a0 = an[0], a1_ = an[1], a2_ = an[2], a3_ = an[3];
+        if (ks < 15) {
+          bn = (lm < 9) ? W[IN + (4 * (ks + 1) + lg) * 9 + lm] : R(0);
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) an[mt] = Sh[AdjSh::W2 + (16 * mt + lm) * 65 + 4 * (ks + 1) + lg];
+        }
+        asm volatile("" : "+v"(bv) : : "memory");
+        acc[0] = wg_mfma(a0, bv, acc[0]);
+        acc[1] = wg_mfma(a1_, bv, acc[1]);
+        acc[2] = wg_mfma(a2_, bv, acc[2]);
+        acc[3] = wg_mfma(a3_, bv, acc[3]);
+      }
     }
     between();
     wave_sync();
@@ -257,18 +291,33 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
     }
     wave_sync();
   };
+  // cacc[nt][r] = sum_p IN[p][row(lg, r)] W2[p][16 nt + lm]  (software-pipelined like w2_times)
+  auto w2t_product = [&](int IN, typename MTile::V4 (&cacc)[4]) __attribute__((always_inline)) {
+    R an = (lm < 9) ? W[IN + lg * 9 + lm] : R(0), bn[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) bn[nt] = Sh[AdjSh::W2 + lg * 65 + 16 * nt + lm];
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      R av = an;
+      const R b0 = bn[0], b1_ = bn[1], b2_ = bn[2], b3_ = bn[3];
+      if (ks < 15) {
+        an = (lm < 9) ? W[IN + (4 * (ks + 1) + lg) * 9 + lm] : R(0);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) bn[nt] = Sh[AdjSh::W2 + (4 * (ks + 1) + lg) * 65 + 16 * nt + lm];
+      }
+      asm volatile("" : "+v"(av) : : "memory");
+      cacc[0] = wg_mfma(av, b0, cacc[0]);
+      cacc[1] = wg_mfma(av, b1_, cacc[1]);
+      cacc[2] = wg_mfma(av, b2_, cacc[2]);
+      cacc[3] = wg_mfma(av, b3_, cacc[3]);
+    }
+  };
   // OUT[q][c] = sum_p IN[p][c] W2[p][q]
   auto w2t_times = [&](int IN, int OUT) __attribute__((always_inline)) {
     typename MTile::V4 cacc[4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) cacc[nt] = typename MTile::V4{0, 0, 0, 0};
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-      const R av = (lm < 9) ? W[IN + (4 * ks + lg) * 9 + lm] : R(0);
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) cacc[nt] = wg_mfma(av, Sh[AdjSh::W2 + (4 * ks + lg) * 65 + 16 * nt + lm], cacc[nt]);
-      if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-    }
+    w2t_product(IN, cacc);
     wave_sync();
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
@@ -375,6 +424,7 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
     if (lane < 8) W[AdjOff::f + lane] = (lane < d) ? fi : R(0);
   };
 
+  W8_TICK_DECL
   // ---- right-hand side of the moment ODEs (state_order 'first') --------------------------------------------------
   auto rhs_fwd = [&](R xs, R Ps, R& kM, R& kP) __attribute__((always_inline)) {
     fresh();
@@ -412,8 +462,51 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
 
   // ---- its adjoint: given the cotangent (lam, Lam) of the slope at the stage value (xs, Ps) -----------------------
   //   Ybar_P = F^T Lam + Lam F;   Ybar_m, dtheta += gradient of  lam . f(x) + <G, F(x)>,  G = 2 Lam P
-  auto rhs_adj = [&](R xs, R Ps, R lam, R Lam, R& YM, R& YP) __attribute__((always_inline)) {
+  // fp32: the MLP checkpoint of the stage below the one in hand, requested one right-hand-side adjoint ahead (see rhs_adj)
+  const R* nx_ptr = nullptr;
+  R nx_a1 = 0, nx_a2 = 0, nx_T[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nx_F = 0, nx_s = 0, nx_td = 0, nx_tq = 0, nx_E1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nx_g = 0;
+  // (mck: the forward sweep's MLP checkpoint of this stage, or nullptr -- then the forward pass through the network is repeated here)
+  auto rhs_adj = [&](R xs, R Ps, R lam, R Lam, R& YM, R& YP, const R* mck) __attribute__((always_inline)) {
     fresh();
+    W8_TICK(10)  // between right-hand-side adjoints: stage values, cotangent combinations
+    // The forward sweep's checkpoint of this stage (MLP): every load is issued HERE, before anything else -- the tile traffic and the
+    // products that do not need them run while they are in flight.  fp32 goes one step further and keeps TWO stages in registers: the
+    // stage below this one in memory (stages and intervals are walked downwards) is requested now and consumed at the next call, a whole
+    // right-hand-side adjoint later (22 more registers; the fp64 instantiation has none to spare, and a load that is merely in flight
+    // there would hold back every scratch reload behind it: vector-memory operations return in order).
+    R ck_a1 = 0, ck_a2 = 0, ck_T[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ck_F = 0, ck_s = 0, ck_td = 0, ck_tq = 0, ck_E1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ck_g = 0;
+    if constexpr (MLP) {
+      if (mck) {
+        auto fetch = [&](const R* c, R& a1_, R& a2_, R (&T_)[8], R& F_, R& s_, R& td_, R& tq_, R (&E_)[8], R& g_) __attribute__((always_inline)) {
+          a1_ = c[kMlpCkA1 * 64 + lane];
+          a2_ = c[kMlpCkA2 * 64 + lane];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) T_[k] = c[(kMlpCkT + k) * 64 + lane];
+          F_ = c[kMlpCkF * 64 + lane];
+          if (second) {
+            s_ = c[kMlpCkS * 64 + lane];
+            td_ = c[kMlpCkTd * 64 + lane];
+            tq_ = c[kMlpCkTq * 64 + lane];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) E_[k] = c[(kMlpCkE1 + k) * 64 + lane];
+            g_ = (lane < 8) ? c[kMlpCkG * 64 + lane] : R(0);
+          }
+        };
+        if constexpr (sizeof(R) == 4) {
+          if (nx_ptr == mck) {  // (uniform) requested one call ago
+            ck_a1 = nx_a1, ck_a2 = nx_a2, ck_F = nx_F, ck_s = nx_s, ck_td = nx_td, ck_tq = nx_tq, ck_g = nx_g;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) ck_T[k] = nx_T[k], ck_E1[k] = nx_E1[k];
+          } else {
+            fetch(mck, ck_a1, ck_a2, ck_T, ck_F, ck_s, ck_td, ck_tq, ck_E1, ck_g);
+          }
+          nx_ptr = (mck > a.ckm) ? mck - (long)a.ckm_nf * 64 : nullptr;  // (the very first stage of the buffer has nothing below it)
+          if (nx_ptr) fetch(nx_ptr, nx_a1, nx_a2, nx_T, nx_F, nx_s, nx_td, nx_tq, nx_E1, nx_g);
+        } else {
+          fetch(mck, ck_a1, ck_a2, ck_T, ck_F, ck_s, ck_td, ck_tq, ck_E1, ck_g);
+        }
+      }
+    }
     W[AdjOff::P + lane] = Ps;
     W[AdjOff::Lam + lane] = Lam;
     if (lane < 8) {
@@ -470,7 +563,22 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
       return;
     } else {
     R a1, d1, a2, d2, T[8], Fij;
-    mlp_fwd(a1, d1, a2, d2, T, Fij);
+    if (mck) {  // (uniform) what the forward sweep computed at this very stage value, from HBM: lane p = hidden unit p
+      a1 = ck_a1;
+      a2 = ck_a2;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) T[k] = ck_T[k];
+      Fij = ck_F;
+      d1 = R(1) - a1 * a1;
+      d2 = R(1) - a2 * a2;
+      // the image the weight update reads: UC = [D1 W1 | a1]  (mlp_fwd leaves it as the tangent product's operand)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) W[AdjOff::UC + lane * 9 + k] = d1 * w1row(k);
+      W[AdjOff::UC + lane * 9 + 8] = a1;
+    } else {
+      mlp_fwd(a1, d1, a2, d2, T, Fij);
+    }
+    W8_TICK(11)  // forward pass through the network (or its checkpoint)
     // reverse of the 'second'-order mean term 0.5 P g (oracle/cdkf_oracle.py divgrad_vjp, same names): with u = 0.5 P lam,
     //   r = W1 u,  td_b = -2 a1 d1 r,  tc_b = d1 r,  [F1 | s2_b] = W2 [diag(td_b) W1 | tc_b]  (cotangents of A1 and s2),
     //   d2_b = sum_i W3[i][p] F1[p][i],  s_b = -2 a2 d2 s2_b;  A2 = diag(s_b) W3^T is a cotangent of the tangent T and simply joins zt2,
@@ -479,7 +587,23 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
     R sb_ = 0, z2x = 0, z1x = 0;
     if (second) {
       R E1[8], sdiv, s2, td, tq;
-      mlp_second_fwd(a1, d1, a2, d2, T, E1, sdiv, s2, td, tq);
+      if (mck) {
+        sdiv = ck_s;
+        td = ck_td;
+        tq = ck_tq;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) E1[k] = ck_E1[k];
+        s2 = R(-2) * a2 * d2 * sdiv;
+        // ZC = [A1 | s2] (operand of the rank-9 weight update below) and g, as mlp_second_fwd leaves them
+#pragma unroll
+        for (int k = 0; k < 8; ++k) W[AdjOff::ZC + lane * 9 + k] = d2 * w3col(k);
+        W[AdjOff::ZC + lane * 9 + 8] = s2;
+        if (lane < 8) W[AdjOff::v + lane] = ck_g;
+        wave_sync();
+      } else {
+        mlp_second_fwd(a1, d1, a2, d2, T, E1, sdiv, s2, td, tq);
+      }
+      W8_TICK(12)  // 'second': E1, tc, g (or their checkpoint)
       if (lane < 8) {
         R hu = 0;
 #pragma unroll
@@ -499,6 +623,7 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
       }
       W[AdjOff::TC + lane * 9 + 8] = tc_b;
       wave_sync();
+      W8_TICK(13)  // 'second': u = 0.5 P lam, r, B1 image
       // F1 = W2 [B1 | tc_b] in place; the rank-9 update dW2 += [A1 | s2] [B1 | tc_b]^T reads the same image before it is overwritten
       w2_times(AdjOff::TC, AdjOff::TC, [&]() __attribute__((always_inline)) { dw2_update(AdjOff::ZC, AdjOff::TC); });
       R d2_b = 0;
@@ -512,6 +637,7 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
       }
       z2x = s2_b * (R(-2) * sdiv) * d2 * (R(1) - R(3) * a2 * a2) + d2_b * (R(-2) * a2 * d2);
       wave_sync();  // (ZC is rewritten below)
+      W8_TICK(14)  // 'second': F1 product (64 MFMA) + rank-9 weight update (48 MFMA) + d2_b
     }
     W[AdjOff::F + lane] = Fij;
     W[AdjOff::G + lane] = R(2) * mm(AdjOff::Lam, AdjOff::P);
@@ -551,6 +677,7 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
     for (int k = 0; k < 8; ++k) W[AdjOff::ZC + lane * 9 + k] = zt2[k];
     W[AdjOff::ZC + lane * 9 + 8] = z2b;
     wave_sync();
+    W8_TICK(15)  // G = 2 Lam P, Ybar_P, layer 3 reversed (c2, dW3), zt2 image
     // layer 2 weights: dW2 += [zt2 | z2b] [D1 W1 | a1]^T -- a 64 x 64 x 9 product accumulated in the tiles (three k-steps)
 #pragma unroll
     for (int ks = 0; ks < 3; ++ks) {
@@ -567,18 +694,13 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) gW2t[mt][nt] = wg_mfma(av[mt], bv[nt], gW2t[mt][nt]);
     }
+    W8_TICK(16)  // weight update dW2 (48 MFMA)
     // layer 1: [c1 | s1]^T = [zt2 | z2b]^T W2 (cotangents of U and a1): rows j = 0 .. 8, columns q
     {
       typename MTile::V4 cacc[4];
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) cacc[nt] = typename MTile::V4{0, 0, 0, 0};
-#pragma unroll
-      for (int ks = 0; ks < 16; ++ks) {
-        const R av = (lm < 9) ? W[AdjOff::ZC + (4 * ks + lg) * 9 + lm] : R(0);
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) cacc[nt] = wg_mfma(av, Sh[AdjSh::W2 + (4 * ks + lg) * 65 + 16 * nt + lm], cacc[nt]);
-        if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-      }
+      w2t_product(AdjOff::ZC, cacc);
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -588,6 +710,7 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
         }
     }
     wave_sync();
+    W8_TICK(17)  // transposed product (64 MFMA) + its image
     R c1[8], s1 = W[AdjOff::CC + lane * 9 + 8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) c1[k] = W[AdjOff::CC + lane * 9 + k];
@@ -620,6 +743,7 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
       YM = s;
     }
     wave_sync();
+    W8_TICK(18)  // layer 1 reversed: z1b, dW1, Ybar_m reduction
     }
   };
 
@@ -644,12 +768,11 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
   auto stage_val = [&](int sg, R mj, R Pij, R dt, R& xm, R& Pst) __attribute__((always_inline)) {
     R sm_ = 0, sp_ = 0;
 #pragma unroll
-    for (int jj = 0; jj < 5; ++jj)
-      if (jj < sg) {  // uniform
-        const R c = a.rk.a[sg][jj];
-        sp_ = rfma(c, W[KPo + 64 * jj + lane], sp_);
-        sm_ = rfma(c, W[KMo + 8 * jj + l8], sm_);
-      }
+    for (int jj = 0; jj < 5; ++jj) {  // (entries jj >= sg carry a zero coefficient: same sums as the guarded form)
+      const R c = W[AdjOff::rka + 6 * sg + jj];
+      sp_ = rfma(c, W[KPo + 64 * jj + lane], sp_);
+      sm_ = rfma(c, W[KMo + 8 * jj + l8], sm_);
+    }
     xm = rfma(dt, sm_, mj);
     Pst = rfma(dt, sp_, Pij);
   };
@@ -667,11 +790,11 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
   auto step_end = [&](R& mj, R& Pij, R dt) __attribute__((always_inline)) {
     R sm_ = 0, sp_ = 0;
 #pragma unroll
-    for (int sg = 0; sg < 6; ++sg)
-      if (sg < nst) {  // uniform (the tiles of stages the method does not have hold stale values)
-        sm_ = rfma(a.rk.b[sg], W[KMo + 8 * sg + l8], sm_);
-        sp_ = rfma(a.rk.b[sg], W[KPo + 64 * sg + lane], sp_);
-      }
+    for (int sg = 0; sg < 6; ++sg) {  // (a stage the method does not have: zero weight)
+      const R c = W[AdjOff::rkb + sg];
+      sm_ = rfma(c, W[KMo + 8 * sg + l8], sm_);
+      sp_ = rfma(c, W[KPo + 64 * sg + lane], sp_);
+    }
     mj = rfma(dt, sm_, mj);
     Pij = rfma(dt, sp_, Pij);
   };
@@ -682,21 +805,21 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
   };
   // ... and its adjoint: (mb, Pb) cotangent of the step's result -> cotangent of its start; dtheta accumulated
   // (slopes: the step's slopes are already in the tiles -- read back from the forward sweep's checkpoints)
-  auto step_adj = [&](R mj, R Pij, R dt, R& mb, R& Pb, bool slopes) __attribute__((always_inline)) {
+  auto step_adj = [&](R mj, R Pij, R dt, R& mb, R& Pb, bool slopes, const R* mckp) __attribute__((always_inline)) {
     if (!slopes) stages_fwd(mj, Pij, dt);
 #pragma unroll 1
     for (int sg = nst - 1; sg >= 0; --sg) {
-      R lm_ = a.rk.b[sg] * mb, lp = a.rk.b[sg] * Pb;
+      const R bs = W[AdjOff::rkb + sg];
+      R lm_ = bs * mb, lp = bs * Pb;
 #pragma unroll
-      for (int r = 5; r > 0; --r)
-        if (r > sg && r < nst) {  // uniform
-          const R c = a.rk.a[r][sg];
-          lm_ = rfma(c, W[YMo + 8 * r + l8], lm_);
-          lp = rfma(c, W[YPo + 64 * r + lane], lp);
-        }
+      for (int r = 5; r > 0; --r) {  // (r <= sg or a stage the method does not have: zero coefficient)
+        const R c = W[AdjOff::rka + 6 * r + sg];
+        lm_ = rfma(c, W[YMo + 8 * r + l8], lm_);
+        lp = rfma(c, W[YPo + 64 * r + lane], lp);
+      }
       R xm, Pst, yM = 0, yP = 0;
       stage_val(sg, mj, Pij, dt, xm, Pst);
-      rhs_adj(xm, Pst, dt * lm_, dt * lp, yM, yP);
+      rhs_adj(xm, Pst, dt * lm_, dt * lp, yM, yP, mckp ? mckp + (long)sg * a.ckm_nf * 64 : nullptr);
       W[YPo + 64 * sg + lane] = yP;
       if (lane < 8) W[YMo + 8 * sg + lane] = yM;
     }
@@ -843,6 +966,7 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
   R mb = 0, Pb = 0;  // cotangent of the filtered moments at k (mean on lanes < 8)
   int adj_st = 0;
   for (long k = a.T - 1; k >= 0; --k) {
+    W8_TICK(19)  // interval bookkeeping: slope loads, step starts, chunk loops
     // (1) measurement update + log-likelihood term at k, from the predicted moments
     R mp, Pp;
     if (k == 0) {
@@ -1010,6 +1134,7 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
       mb = (lane < d) ? mb - sacc : R(0);
     }
     wave_sync();
+    W8_TICK(20)  // measurement update reversed
     if (k == 0) break;
 
     // (2) predict k-1 -> k: reverse the Dormand-Prince steps, replaying the interval in chunks of kAdjCk steps
@@ -1079,13 +1204,23 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
         const R ms = (lane < 8) ? W[AdjOff::ck + slot * 72 + 64 + lane] : R(0);
         const R dt = W[AdjOff::ck + kAdjCk * 72 + slot];
         if (have) load_slopes(s);
-        step_adj(ms, Ps, dt, mb, Pb, have);
+        // (the forward sweep kept the network's intermediates of the interval's FIRST step)
+        const R* mckp = (MLP && have && s == 0 && a.ckm) ? a.ckm + (n * (a.T - 1) + (k - 1)) * (6L * a.ckm_nf * 64) : nullptr;
+        step_adj(ms, Ps, dt, mb, Pb, have, mckp);
       }
       wave_sync();
     }
   }
 
   if (adj_st && lane == 0 && a.status) atomicOr(&a.status[n], adj_st);
+#ifdef CDKF_W8_PROFILE
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    printf("adjoint cycles/obs-step (sizeof real %d, order %d, ckm %d):", (int)sizeof(R), a.order, a.ckm ? 1 : 0);
+    for (int q = 10; q < 21; ++q) printf(" [%d] %lld", q, w8_prof[q] / a.T);
+    printf("\n");
+    for (int q = 10; q < 21; ++q) w8_prof[q] = 0;
+  }
+#endif
   // ---- model block: m0 | P0 | LQL | H | bias | R ------------------------------------------------------------------------
   if (grad_model) {
     R* gm = grad_model + n * adj_model_grad_size(d, m);

@@ -213,7 +213,7 @@ int grad_sum_dev(const R* g, int64_t N, int64_t P, double* out, void* stream) {
 
 template <typename R>
 int loglik_grad_dev(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll,
-                    R* grad, R* grad_model, int32_t* status, void* stream) {
+                    R* grad, R* grad_model, int32_t* status, void* stream, bool ukf = false) {
   int rc = check_common(mdl, o, N, T, t, y, ll);
   if (rc) return rc;
   if (!grad) {
@@ -222,12 +222,13 @@ int loglik_grad_dev(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_
   }
   if (N == 0) return CDKF_OK;
   CDKF_SELECT_DEVICE(o);
+  if (ukf) return launch_ukf_grad<R>(mdl, o, N, T, t, y, ll, grad, status, (hipStream_t)stream);
   return launch_ekf_grad<R>(mdl, o, N, T, t, y, ll, grad, grad_model, status, (hipStream_t)stream);
 }
 
 template <typename R>
 int loglik_grad_host(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll,
-                     R* grad, R* grad_model, int32_t* status) {
+                     R* grad, R* grad_model, int32_t* status, bool ukf = false) {
   int rc = check_common(mdl, o, N, T, t, y, ll);
   if (rc) return rc;
   if (!grad) {
@@ -247,8 +248,9 @@ int loglik_grad_host(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64
     return rc;
   CDKF_HIP_CHECK(hipMemcpy(dt.p, t, nt * sizeof(R), hipMemcpyHostToDevice));
   CDKF_HIP_CHECK(hipMemcpy(dy.p, y, ny * sizeof(R), hipMemcpyHostToDevice));
-  rc = launch_ekf_grad<R>(mdl, o, N, T, (const R*)dt.p, (const R*)dy.p, (R*)dll.p, (R*)dg.p, (R*)dgm.p, (int32_t*)dst.p,
-                          nullptr);
+  rc = ukf ? launch_ukf_grad<R>(mdl, o, N, T, (const R*)dt.p, (const R*)dy.p, (R*)dll.p, (R*)dg.p, (int32_t*)dst.p, nullptr)
+           : launch_ekf_grad<R>(mdl, o, N, T, (const R*)dt.p, (const R*)dy.p, (R*)dll.p, (R*)dg.p, (R*)dgm.p, (int32_t*)dst.p,
+                                nullptr);
   if (rc) return rc;
   CDKF_HIP_CHECK(hipDeviceSynchronize());
   CDKF_HIP_CHECK(hipMemcpy(ll, dll.p, N * sizeof(R), hipMemcpyDeviceToHost));
@@ -650,6 +652,23 @@ int cdkf_ekf_loglik_grad_f32_dev(const cdkf_model* mdl, const cdkf_opts* o, int6
                                  const float* y, float* ll, float* grad, int32_t* status, void* stream) {
   return loglik_grad_dev<float>(mdl, o, N, T, t, y, ll, grad, nullptr, status, stream);
 }
+int cdkf_ukf_loglik_grad_f64(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const double* t,
+                             const double* y, double* ll, double* grad, int32_t* status) {
+  return loglik_grad_host<double>(mdl, o, N, T, t, y, ll, grad, nullptr, status, true);
+}
+int cdkf_ukf_loglik_grad_f32(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const float* t,
+                             const float* y, float* ll, float* grad, int32_t* status) {
+  return loglik_grad_host<float>(mdl, o, N, T, t, y, ll, grad, nullptr, status, true);
+}
+int cdkf_ukf_loglik_grad_f64_dev(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const double* t,
+                                 const double* y, double* ll, double* grad, int32_t* status, void* stream) {
+  return loglik_grad_dev<double>(mdl, o, N, T, t, y, ll, grad, nullptr, status, stream, true);
+}
+int cdkf_ukf_loglik_grad_f32_dev(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const float* t,
+                                 const float* y, float* ll, float* grad, int32_t* status, void* stream) {
+  return loglik_grad_dev<float>(mdl, o, N, T, t, y, ll, grad, nullptr, status, stream, true);
+}
+int cdkf_ukf_grad_supported(const cdkf_model* mdl, const cdkf_opts* o) { return (mdl && o && ukf_grad_shape_available(mdl, o)) ? 1 : 0; }
 int cdkf_kf_smoother1_f64(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const double* t, const double* y,
                           double* ll, double* fm, double* fP, double* sm, double* sP, double* cross, int32_t* status) {
   return kf_smoother1_host<double>(mdl, o, N, T, t, y, ll, fm, fP, sm, sP, cross, status);
@@ -703,6 +722,7 @@ int cdkf_ekf_loglik_grad_all_f32_dev(const cdkf_model* mdl, const cdkf_opts* o, 
   if (int rc = need_model_grad(grad_model)) return rc;
   return loglik_grad_dev<float>(mdl, o, N, T, t, y, ll, grad, grad_model, status, stream);
 }
+int cdkf_release_workspace(void) { return release_grad_workspace(); }
 int cdkf_grad_all_supported(const cdkf_model* mdl, const cdkf_opts* o) {
   return (mdl && o && adjoint_shape_available(mdl, o)) ? 1 : 0;
 }

@@ -58,6 +58,13 @@ struct DriftGrad<R, 3, DriftLorenz63<R, 3>> {
     dF[2][0] += dm[1];
     dF[2][1] += dm[0];
   }
+  // the unscented filter's mean equation: f(m) + b(P), b(P) = (0, -P_02, P_01) -- the sigma-point sum f_X^T w_mean of
+  // inference_ukf.py:124-143 collapsed for this quadratic drift (cdkf_lpe_kernels.h, LpeRhs<R, true>; exact for every alpha, beta, kappa)
+  static constexpr bool kCurved = true;
+  static CDKF_DEV void curvature(const R* Ppacked, R* dm) {
+    dm[1] -= Ppacked[sidx<3>(0, 2)];
+    dm[2] += Ppacked[sidx<3>(0, 1)];
+  }
 };
 
 template <typename R, int D>
@@ -79,11 +86,14 @@ struct DriftGrad<R, D, DriftLinear<R, D>> {
     }
   }
   CDKF_DEV void dstate(const R*, R (&)[D][D]) const {}
+  static constexpr bool kCurved = false;  // a linear drift has no curvature: its unscented moment equations are the extended filter's
+  static CDKF_DEV void curvature(const R*, R*) {}
 };
 
 // ---- primal + tangent moment ODE -----------------------------------------------------------------------
 // state vector: [m (D), P packed (NP), m' (D), P' packed (NP)]
-template <typename R, int D, typename Drift>
+// UKF: the unscented filter's moment equations in the closed form of its sigma-point sums (mean: + b(P), tangent: + b(P'))
+template <typename R, int D, typename Drift, bool UKF = false>
 struct EkfSensRhs {
   static constexpr int NS = Dims<D>::NS;
   const Drift& drift;
@@ -120,6 +130,10 @@ struct EkfSensRhs {
 #pragma unroll
       for (int k = 0; k < D; ++k) s = rfma(F[i][k], dm[k], s);
       dy[NS + i] = s;
+    }
+    if constexpr (UKF) {
+      DriftGrad<R, D, Drift>::curvature(P, dy);
+      DriftGrad<R, D, Drift>::curvature(dP, dy + NS);
     }
 #pragma unroll
     for (int i = 0; i < D; ++i)
@@ -302,7 +316,11 @@ struct GradArgs {
 
 // ---- log-likelihood + gradient sweep -----------------------------------------------------------------------
 // GENERIC: run-time Runge-Kutta tableau / adaptive steps (opts.solver, opts.adaptive) instead of the pinned Dormand-Prince
-template <typename R, int D, int M, typename Drift, bool GENERIC = false>
+// UKF: the unscented filter's log-likelihood (cdkf_ukf_loglik_grad_*): predict by the closed form of the sigma-point sums, update =
+// the extended filter's algebra on the packed symmetric covariance (a linear emission passes the sigma points through exactly, and
+// the reference's unscented update has no symmetrisation to lose: inference_ukf.py:162-203); the covariance the update would draw
+// its sigma points from must be positive definite (jnp.linalg.cholesky, inference_ukf.py:57): NaN and the NOT_PD flag otherwise.
+template <typename R, int D, int M, typename Drift, bool GENERIC = false, bool UKF = false>
 __global__ __launch_bounds__(64, 1) void ekf_grad_reg_kernel(const GradArgs<R, D, M, Drift> ga) {
   constexpr int NS = Dims<D>::NS;
   constexpr int NP = Dims<D>::NP;
@@ -333,7 +351,7 @@ __global__ __launch_bounds__(64, 1) void ekf_grad_reg_kernel(const GradArgs<R, D
   const auto C = TabSel<R, GENERIC>::get(a);
   DriftGrad<R, D, Drift> dg;
   dg.init(p);
-  EkfSensRhs<R, D, Drift> rhs{a.drift, dg, a.LQL};
+  EkfSensRhs<R, D, Drift, UKF> rhs{a.drift, dg, a.LQL};
 
   R tcur = tp[0];
   if (a.T > 1) tp += a.t_sk;
@@ -351,6 +369,16 @@ __global__ __launch_bounds__(64, 1) void ekf_grad_reg_kernel(const GradArgs<R, D
 #pragma unroll
     for (int r = 0; r < M; ++r) ynext[r] = yp[r * a.y_si];
     const R tnn = tp[0];
+    if constexpr (UKF && D == 3) {  // leading principal minors of the predicted covariance
+      const R p00 = ys[D + sidx<D>(0, 0)], p01 = ys[D + sidx<D>(0, 1)], p02 = ys[D + sidx<D>(0, 2)], p11 = ys[D + sidx<D>(1, 1)],
+              p12 = ys[D + sidx<D>(1, 2)], p22 = ys[D + sidx<D>(2, 2)];
+      const R m2 = p00 * p11 - p01 * p01;
+      const R m3 = p22 * m2 - p12 * (p00 * p12 - p01 * p02) + p02 * (p01 * p12 - p11 * p02);
+      if (!(p00 > R(0)) || !(m2 > R(0)) || !(m3 > R(0))) {
+        st |= kStatusNotPd;
+        ys[0] = R(0) / R(0);
+      }
+    }
     ekf_update_sens<R, D, M>(a, ys, ycur, ll, g, st);
     if (ys[0] != ys[0]) st |= kStatusNan;
     const R t1 = (k + 1 < a.T) ? tnext_obs : tcur + a.dt_final;

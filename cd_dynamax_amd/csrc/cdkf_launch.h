@@ -38,11 +38,17 @@ template <typename R>
 int launch_ekf_grad(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll,
                     R* grad, R* grad_model, int32_t* status, hipStream_t stream);
 bool grad_shape_available(const cdkf_model* mdl, const cdkf_opts* o);
+// the unscented filter's log-likelihood + gradient w.r.t. the drift parameters (launch_grad.hip)
+template <typename R>
+int launch_ukf_grad(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll, R* grad,
+                    int32_t* status, hipStream_t stream);
+bool ukf_grad_shape_available(const cdkf_model* mdl, const cdkf_opts* o);
 // reverse sweep, state_dim <= 8 (launch_wg.hip, cdkf_adjoint_kernels.h); grad_model (optional): [N, d + 2 d^2 + m d + m + m^2]
 template <typename R>
 int launch_ekf_grad_adjoint(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll,
                             R* grad, R* grad_model, int32_t* status, hipStream_t stream);
 bool adjoint_shape_available(const cdkf_model* mdl, const cdkf_opts* o);
+int release_grad_workspace();  // frees the per-process reverse-sweep workspace once its last user has finished (launch_wg.hip)
 // lease of the per-process reverse-sweep workspace (launch_wg.hip): holds its lock from construction to destruction
 struct GradWorkspaceLease {
   GradWorkspaceLease();

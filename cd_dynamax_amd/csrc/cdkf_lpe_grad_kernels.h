@@ -29,10 +29,15 @@
 
 namespace cdkf {
 
-#ifndef CDKF_LPE_GRAD_CAP
-#define CDKF_LPE_GRAD_CAP 64
+// Step starts of one observation interval, in LDS (one value per lane and step): a WINDOW of kLpeGradWin consecutive starts that the
+// reversed steps read, and kLpeGradCoarse COARSE starts, one per segment of C steps (C = the window while the interval has at most
+// kLpeGradWin * kLpeGradCoarse = 768 steps, else ceil(steps / kLpeGradCoarse)).  Walking backwards the window is refilled from the
+// segment's coarse start: about 2 S forward steps for an interval of S <= 768 steps, S^2 / 1536 beyond (a gap of 100 time units at
+// dt0 = 0.01: 6.5 S) -- never the (S - window)^2 / 2 of re-integrating from one kept start for every reversed step.
+#ifndef CDKF_LPE_GRAD_WIN
+#define CDKF_LPE_GRAD_WIN 48
 #endif
-constexpr int kLpeGradCap = CDKF_LPE_GRAD_CAP;  // step starts of one interval kept in LDS (longer intervals re-integrate from the last one kept)
+constexpr int kLpeGradWin = CDKF_LPE_GRAD_WIN, kLpeGradCoarse = 16;
 
 // per-lane constants of the reversed right-hand side
 template <typename R>
@@ -507,7 +512,8 @@ __global__ __launch_bounds__(64) void grad_lpe_l63_kernel(const RegArgs<R, 3, M,
                                                           R* __restrict__ grad_model) {
   static_assert(!GRID || M == 3, "the in-grid reverse update is written for H = I");
   constexpr int D = 3;
-  __shared__ R starts[kLpeGradCap][64];
+  __shared__ R starts[kLpeGradWin][64];
+  __shared__ R coarse[kLpeGradCoarse][64];
   const int lane = threadIdx.x, l = lane & 15, i = l >> 2, j = l & 3;
   constexpr int sh = lpe_xcd_shift<R>();
   const long b = blockIdx.x;
@@ -579,37 +585,62 @@ __global__ __launch_bounds__(64) void grad_lpe_l63_kernel(const RegArgs<R, 3, M,
     R tp = t0, tq = rmin(t0 + a.dt0, t1);
     const R dt_0 = (t0 < t1) ? tq - tp : R(0);  // (no step where the forward sweep took none: t_k <= t_{k-1})
     advance(tp, tq, t1);
-    // more than one Runge-Kutta step in this interval: the starts of the steps 1, 2, ... (and their sizes, in lane 15's slot) are parked
-    // in LDS on the way forward
+    // more than one Runge-Kutta step in this interval: the starts of the steps 1, 2, ... (lanes of grid row 3 carry no state: lane 15's
+    // slot holds the step size / the time the step starts at, lane 14's the end of that step) are parked in LDS on the way forward
     if (tp < t1 && a.max_steps > 1) {
+      constexpr int W = kLpeGradWin, NC = kLpeGradCoarse;
+      int nrest = 0;  // the steps behind the first one (time arithmetic only; the forward sweep stops at max_steps as well, and raises the flag)
+      {
+        R up = tp, uq = tq;
+        while (up < t1 && nrest + 1 < a.max_steps) {
+          advance(up, uq, t1);
+          ++nrest;
+        }
+      }
+      const int Cs = (nrest <= W * NC) ? W : (nrest + NC - 1) / NC;  // steps per coarse segment
+      const int G = (nrest + Cs - 1) / Cs;                            // segments (<= NC)
+      // the sub-block the window holds after the forward pass: the last one of the last segment
+      const int gl_first = 1 + (G - 1) * Cs, gl_len = nrest - gl_first + 1;
+      const int wl_first = gl_first + ((gl_len - 1) / W) * W;
       R y = y0;
       lpe_step<R>(y, dt_0, rhs, C);
-      int S = 1;
-      while (tp < t1 && S < a.max_steps) {  // (the forward sweep stops at max_steps as well, and raises the flag)
-        const R dt = tq - tp;
-        if (S <= kLpeGradCap) starts[S - 1][lane] = (l == 15) ? dt : y;
-        advance(tp, tq, t1);
-        ++S;
-        if (tp < t1 && S <= kLpeGradCap) lpe_step<R>(y, dt, rhs, C);
-      }
-      for (int s = S - 1; s >= 1; --s) {
-        R ys, dt;
-        if (s <= kLpeGradCap) {
-          const R raw = starts[s - 1][lane];
-          dt = lpe_bcast<15>(raw);
-          ys = (i == 3) ? R(0) : raw;
-        } else {  // beyond the window: from the last start kept (step kLpeGradCap)
-          R up = t0, uq = rmin(t0 + a.dt0, t1);
-          for (int q = 0; q < kLpeGradCap; ++q) advance(up, uq, t1);
-          const R raw = starts[kLpeGradCap - 1][lane];
-          ys = (i == 3) ? R(0) : raw;
-          for (int q = kLpeGradCap; q < s; ++q) {
-            lpe_step<R>(ys, uq - up, rhs, C);
+      {
+        R up = tp, uq = tq;
+        for (int s = 1; s <= nrest; ++s) {  // y: the start of step s; (up, uq): its interval
+          const R dt = uq - up;
+          const int q = s - 1;
+          if (q - (q / Cs) * Cs == 0) coarse[q / Cs][lane] = (l == 15) ? up : ((l == 14) ? uq : y);
+          if (s >= wl_first) starts[s - wl_first][lane] = (l == 15) ? dt : y;
+          if (s < nrest) {
+            lpe_step<R>(y, dt, rhs, C);
             advance(up, uq, t1);
           }
-          dt = uq - up;
         }
-        lpe_step_adj<ALL, R>(rhs, adj, C, ys, dt, vb, th, acc.lql);
+      }
+      for (int g = G - 1; g >= 0; --g) {
+        const int sfirst = 1 + g * Cs, slast = (sfirst + Cs - 1 < nrest) ? sfirst + Cs - 1 : nrest;
+        for (int bfirst = sfirst + ((slast - sfirst) / W) * W; bfirst >= sfirst; bfirst -= W) {
+          const int blast = (bfirst + W - 1 < slast) ? bfirst + W - 1 : slast;
+          if (bfirst != wl_first) {  // refill the window: from the segment's coarse start up to the end of this sub-block
+            const R raw = coarse[g][lane];
+            R up = lpe_bcast<15>(raw), uq = lpe_bcast<14>(raw);
+            R yy = (i == 3) ? R(0) : raw;
+            for (int s = sfirst; s <= blast; ++s) {
+              const R dt = uq - up;
+              if (s >= bfirst) starts[s - bfirst][lane] = (l == 15) ? dt : yy;
+              if (s < blast) {
+                lpe_step<R>(yy, dt, rhs, C);
+                advance(up, uq, t1);
+              }
+            }
+          }
+          for (int s = blast; s >= bfirst; --s) {
+            const R raw = starts[s - bfirst][lane];
+            const R dt = lpe_bcast<15>(raw);
+            const R ys = (i == 3) ? R(0) : raw;
+            lpe_step_adj<ALL, R>(rhs, adj, C, ys, dt, vb, th, acc.lql);
+          }
+        }
       }
     }
     lpe_step_adj<ALL, R>(rhs, adj, C, y0, dt_0, vb, th, acc.lql);

@@ -692,7 +692,10 @@ inline bool lpe_batch_is_small(int64_t N, LpeSweep which = kLpeFilter) {
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
     cus = 256;
-  static constexpr int per_simd[4] = {1, 1, 1, 1};
+  // measured on MI355X, 4096 ... 131072 trajectories x 1000 steps (profiles/r03_a_n_sweep.json): EKF filter grid 1.70 / lane 1.89 ms at
+  // 8192, 2.43 / 2.00 at 12288; unscented filter (fp32; the lane kernel forms the sigma points) 3.59 / 3.69 at 24576, 4.60 / 3.86 at
+  // 32768; smoother 2.78 / 3.59 at 8192, 3.98 / 3.63 at 12288; drift-block gradient 2.34 / 4.02 at 4096, 5.07 / 4.10 at 5120
+  static constexpr int per_simd[4] = {2, 6, 2, 1};
   return (N + 3) / 4 <= (int64_t)per_simd[which] * 4 * cus;
 }
 

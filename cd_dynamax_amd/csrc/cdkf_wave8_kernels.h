@@ -35,7 +35,7 @@ struct W8Tile<float> {
 };
 
 #ifdef CDKF_W8_PROFILE  // local diagnostic build (scripts/w8_prof_build.sh): cycles per phase (s_memtime), printed by trajectory 0
-__device__ long long w8_prof[24];
+static __device__ long long w8_prof[24];
 #define W8_TICK(i)                                                              \
   {                                                                             \
     const long long w8_now = clock64();                                         \
@@ -54,6 +54,55 @@ CDKF_DEV void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// ---- sums over the 8 x 8 lane grid (lane = 8 i + j) without LDS: the result lands in every lane that took part -------------------------
+// over j (lane bits 0 .. 2): quad permutations, then the half-row mirror; over i (bits 3 .. 5): the half-row rotation, then gfx950's
+// v_permlane16_swap / v_permlane32_swap (a register swapped with its own copy: both halves of the pair come back, their sum is the
+// all-reduce over that lane bit).  64-bit values travel as two 32-bit DPP moves; fp32 folds the DPP control into the add.
+template <int CTRL>
+CDKF_DEV float w8_dpp(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+CDKF_DEV double w8_dpp(double x) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+CDKF_DEV float w8_swap_sum16(float x) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, x), false, false);
+  return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+}
+CDKF_DEV float w8_swap_sum32(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, x), false, false);
+  return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+}
+CDKF_DEV double w8_swap_sum16(double x) {
+  const unsigned lo = __double2loint(x), hi = __double2hiint(x);
+  const auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  return __hiloint2double(rh[0], rl[0]) + __hiloint2double(rh[1], rl[1]);
+}
+CDKF_DEV double w8_swap_sum32(double x) {
+  const unsigned lo = __double2loint(x), hi = __double2hiint(x);
+  const auto rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double(rh[0], rl[0]) + __hiloint2double(rh[1], rl[1]);
+}
+template <typename R>
+CDKF_DEV R w8_sum_j(R x) {  // sum over the eight lanes of a grid row
+  x += w8_dpp<0xB1>(x);   // quad_perm [1, 0, 3, 2]
+  x += w8_dpp<0x4E>(x);   // quad_perm [2, 3, 0, 1]
+  x += w8_dpp<0x141>(x);  // row_half_mirror: the other quad of the eight
+  return x;
+}
+template <typename R>
+CDKF_DEV R w8_sum_i(R x) {  // sum over the eight grid rows (same j)
+  x += w8_dpp<0x128>(x);  // row_ror:8: the other half of the sixteen-lane row
+  x = w8_swap_sum16(x);
+  x = w8_swap_sum32(x);
+  return x;
+}
+
 // per-wavefront LDS tile (in reals)
 struct W8Off {
   static constexpr int P = 0, A = 64, F = 128, X = 192, SX = 256, S1 = 320, S2 = 384, HP = 448;
@@ -65,14 +114,19 @@ struct W8Off {
   static constexpr int a1 = 608, d1 = 672, a2 = 736, d2 = 800, s2 = 864, tq = 928;
   static constexpr int U = 992, Z = 992 + 576;  // two [64][9] images (stride 9: a lane's row is conflict-free), state_order 'second'
   static constexpr int mlp_end = 992 + 2 * 576;
+  static constexpr int rk = 36;  // behind either layout: the Dormand-Prince a[sg][jj] as a 6 x 6 table with zeros for jj >= sg (uniform LDS
+                                 // reads in one basic block instead of a constant-memory load and a branch per entry of the rolled stage loop)
 };
-struct W8Sh {  // per workgroup: the MLP's weights, hidden sizes padded to 64, state to 8; W2 rows padded to 65 (read along p as the
-                // A operand of the tangent product and along q as the B operand of the transposed one, conflict-free both ways)
-  static constexpr int W1 = 0, b1 = 512, W2 = 576, b2 = 576 + 64 * 65, W3 = b2 + 64, b3 = W3 + 8 * 65;
+struct W8Sh {  // per workgroup: the MLP's weights, hidden sizes padded to 64, state to 8.  W2 is read from LDS as the B operand of the
+                // transposed product only (lane (lg, lm) takes W2[p0 + lg][16 nt + lm]): with rows of LD2 = 80 (= 16 mod 32 doubles, = 16
+                // mod 64 words) the four rows of a k-step fall into disjoint bank ranges -- no conflicts in either precision (rows of 65
+                // put the lanes with equal lg + lm on one bank: four-way)
+  static constexpr int LD2 = 80;
+  static constexpr int W1 = 0, b1 = 512, W2 = 576, b2 = 576 + 64 * LD2, W3 = b2 + 64, b3 = W3 + 8 * 65;
   static constexpr int end = b3 + 8;
 };
 __host__ __device__ inline long wave8_lds_reals(int kind) {
-  return (kind == kDriftMlp) ? (long)W8Sh::end + kW8Waves * W8Off::mlp_end : (long)kW8Waves * W8Off::base_end;
+  return (kind == kDriftMlp) ? (long)W8Sh::end + kW8Waves * (W8Off::mlp_end + W8Off::rk) : (long)kW8Waves * (W8Off::base_end + W8Off::rk);
 }
 
 template <typename R>
@@ -85,7 +139,8 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave8_kernel(const WgArgs<R
   const bool mlp = a.kind == kDriftMlp;
   const int h1 = a.h1, h2 = a.h2;
   R* Sh = smem;
-  R* W = smem + (mlp ? W8Sh::end : 0) + wave * (mlp ? W8Off::mlp_end : W8Off::base_end);
+  R* W = smem + (mlp ? W8Sh::end : 0) + wave * ((mlp ? W8Off::mlp_end : W8Off::base_end) + W8Off::rk);
+  const int o_rk = mlp ? W8Off::mlp_end : W8Off::base_end;
   const R* th = a.par + a.o_theta;
 
   // ---- shared MLP weights (zero-padded), built by the whole workgroup --------------------------------------------
@@ -100,7 +155,7 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave8_kernel(const WgArgs<R
     const R* gb3 = gW3 + d * h2;
     for (int e = threadIdx.x; e < h1 * d; e += blockDim.x) Sh[W8Sh::W1 + fdiv(e, d) * kW8 + (e - fdiv(e, d) * d)] = gW1[e];
     for (int e = threadIdx.x; e < h1; e += blockDim.x) Sh[W8Sh::b1 + e] = gb1[e];
-    for (int e = threadIdx.x; e < h2 * h1; e += blockDim.x) Sh[W8Sh::W2 + fdiv(e, h1) * 65 + (e - fdiv(e, h1) * h1)] = gW2[e];
+    for (int e = threadIdx.x; e < h2 * h1; e += blockDim.x) Sh[W8Sh::W2 + fdiv(e, h1) * W8Sh::LD2 + (e - fdiv(e, h1) * h1)] = gW2[e];
     for (int e = threadIdx.x; e < h2; e += blockDim.x) Sh[W8Sh::b2 + e] = gb2[e];
     for (int e = threadIdx.x; e < d * h2; e += blockDim.x) Sh[W8Sh::W3 + fdiv(e, h2) * 65 + (e - fdiv(e, h2) * h2)] = gW3[e];
     for (int e = threadIdx.x; e < d; e += blockDim.x) Sh[W8Sh::b3 + e] = gb3[e];
@@ -108,6 +163,24 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave8_kernel(const WgArgs<R
   }
   const long n = (long)blockIdx.x * kW8Waves + wave;
   if (n >= a.N) return;  // whole wavefront; no workgroup barrier follows
+  {  // tableau table; the slope tiles start from zeros (a zero coefficient must not meet the NaN patterns uninitialised LDS may hold;
+     // afterwards the tiles only ever hold this trajectory's own numbers: slopes, or the measurement update's intermediates)
+    using TBi = Dp5T<R>;
+    if (lane < 36) {
+      const int r = lane / 6, c = lane - 6 * r;
+      R v = 0;
+#pragma unroll
+      for (int rr = 1; rr < 6; ++rr)
+#pragma unroll
+        for (int cc = 0; cc < 5; ++cc)
+          if (rr == r && cc == c && cc < rr) v = TBi::a[rr][cc];
+      W[o_rk + lane] = v;
+    }
+#pragma unroll
+    for (int q = 0; q < 5; ++q) W[W8Off::X + 64 * q + lane] = R(0);
+    if (lane < 40) W[W8Off::km + lane] = R(0);
+    wave_sync();
+  }
 
   // ---- per-lane constants ---------------------------------------------------------------------------------------
   const bool inP = (i < d) && (j < d);
@@ -144,7 +217,7 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave8_kernel(const WgArgs<R
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
 #pragma unroll
-      for (int ks = 0; ks < 16; ++ks) w2A[mt][ks] = pin(Sh[W8Sh::W2 + (16 * mt + lm) * 65 + 4 * ks + lg]);
+      for (int ks = 0; ks < 16; ++ks) w2A[mt][ks] = pin(Sh[W8Sh::W2 + (16 * mt + lm) * W8Sh::LD2 + 4 * ks + lg]);
 #pragma unroll
       for (int r = 0; r < 4; ++r) w3A[mt][r] = pin(lm < kW8 ? Sh[W8Sh::W3 + lm * 65 + 16 * mt + MTile::row(lg, r)] : R(0));
     }
@@ -164,6 +237,7 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave8_kernel(const WgArgs<R
 
   // right-hand side of the moment ODEs for the stage value (xs: mean on lanes < d, Ps: this lane's covariance entry)
   W8_TICK_DECL
+  R* mck = nullptr;  // MLP stage checkpoint of the right-hand side in hand (reverse sweep's forward pass only; uniform)
   auto rhs = [&](R xs, R Ps, R& kM, R& kP) __attribute__((always_inline)) {
     W8_TICK(0)  // stage combination (outside the right-hand side)
     W[W8Off::P + lane] = Ps;
@@ -209,27 +283,35 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave8_kernel(const WgArgs<R
         const int lp1 = (l + 1 >= d) ? 0 : l + 1, lm1 = (l == 0) ? d - 1 : l - 1, lm2 = (lm1 == 0) ? d - 1 : lm1 - 1;
         fi = rfma(X(lp1) - X(lm2), X(lm1), th[0] - X(l));
       }
-    } else {  // MLP
-      // layer 1: lane = hidden unit q
+    } else {  // MLP: six synchronisations per right-hand side (state_order 'second'; five otherwise)
+      // ---- layer 1: lane = hidden unit q ----------------------------------------------------------------------------
       R z1 = b1l;
 #pragma unroll
       for (int k = 0; k < kW8; ++k) z1 = rfma(w1row[k], xk[k], z1);
-      const R a1 = rtanh(z1);
+      const R a1 = rtanh_fast(z1);
       const R d1 = R(1) - a1 * a1;
       W[W8Off::a1 + lane] = a1;
       W[W8Off::d1 + lane] = d1;
+      if (mck) mck[kMlpCkA1 * 64 + lane] = a1;
       wave_sync();
       W8_TICK(1)  // state broadcast, layer 1, tanh
-      // layer 2 on the matrix cores: acc[mt][r] = [T | z2 - b2][16 mt + row(lg, r)][lm],  T = W2 D1 W1 (tangent), column 8: W2 a1
+      // ---- layer 2 on the matrix cores: acc[mt][r] = [T | z2 - b2][16 mt + row(lg, r)][lm],  T = W2 D1 W1 (tangent), column 8: W2 a1
       typename MTile::V4 acc[4];
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) acc[mt] = typename MTile::V4{0, 0, 0, 0};
+      {  // (software pipeline as below: the activations of k-step ks + 1 are requested before the products of k-step ks are issued)
+        R dq_n = W[W8Off::d1 + lg], aq_n = W[W8Off::a1 + lg];
 #pragma unroll
-      for (int ks = 0; ks < 16; ++ks) {
-        const R dq = W[W8Off::d1 + 4 * ks + lg], aq = W[W8Off::a1 + 4 * ks + lg];
-        const R bv = rfma(dq, w1B[ks], aq * e8);
+        for (int ks = 0; ks < 16; ++ks) {
+          R bv = rfma(dq_n, w1B[ks], aq_n * e8);
+          if (ks < 15) {
+            dq_n = W[W8Off::d1 + 4 * (ks + 1) + lg];
+            aq_n = W[W8Off::a1 + 4 * (ks + 1) + lg];
+          }
+          asm volatile("" : "+v"(bv) : : "memory");
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) acc[mt] = wg_mfma(w2A[mt][ks], bv, acc[mt]);
+          for (int mt = 0; mt < 4; ++mt) acc[mt] = wg_mfma(w2A[mt][ks], bv, acc[mt]);
+        }
       }
       if (lm == 8) {
 #pragma unroll
@@ -237,7 +319,8 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave8_kernel(const WgArgs<R
 #pragma unroll
           for (int r = 0; r < 4; ++r) W[W8Off::s2 + 16 * mt + MTile::row(lg, r)] = acc[mt][r];
       }
-      if (second && lm < kW8) {  // rows of T for grad(div f): s_p = sum_i W3[i][p] T[p][i]
+      const bool rows = second || mck;  // the rows of T in lane = hidden-unit order: grad(div f) and the checkpoint
+      if (rows && lm < kW8) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -245,90 +328,136 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave8_kernel(const WgArgs<R
       }
       wave_sync();
       W8_TICK(2)  // tangent product (64 MFMA) + its images
+      // ---- layer 2 activations, s_p = sum_i W3[i][p] T[p][i] and s2 = -2 a2 d2 s in one phase: ONE synchronisation serves both products below
       const R z2 = W[W8Off::s2 + lane] + b2l;  // lane = hidden unit p
-      const R a2 = rtanh(z2);
+      const R a2 = rtanh_fast(z2);
       const R d2 = R(1) - a2 * a2;
       W[W8Off::a2 + lane] = a2;
       W[W8Off::d2 + lane] = d2;
-      R sdiv = 0;
-      if (second) {
+      if (rows) {
+        R sdiv = 0;
 #pragma unroll
-        for (int k = 0; k < kW8; ++k) sdiv = rfma(w3col[k], W[W8Off::U + lane * 9 + k], sdiv);
+        for (int k = 0; k < kW8; ++k) {
+          const R tk = W[W8Off::U + lane * 9 + k];
+          sdiv = rfma(w3col[k], tk, sdiv);
+          if (mck) mck[(kMlpCkT + k) * 64 + lane] = tk;
+        }
+        if (second) W[W8Off::s2 + lane] = R(-2) * a2 * d2 * sdiv;  // (this lane's own slot: z2 - b2 has been taken above)
+        if (mck) {
+          mck[kMlpCkA2 * 64 + lane] = a2;
+          if (second) mck[kMlpCkS * 64 + lane] = sdiv;
+        }
       }
       wave_sync();
-      W8_TICK(3)  // tanh of layer 2, sdiv
-      // layer 3 on the matrix cores: the accumulator rows are this product's k index, scaled by d2 (column 8: a2 itself)
+      W8_TICK(3)  // tanh of layer 2, s, s2
+      // ---- layer 3 and, for 'second', the transposed product, k-step by k-step on FIVE independent accumulator chains ----------------
+      //   [F | f - b3] = W3 [D2 T | a2]: its k index runs over the rows the first product's accumulators hold (scaled by d2; column 8: a2);
+      //   [E1 | tc]^T  = [diag(d2) W3^T | s2]^T W2  (g = grad(div f) = W1^T tq, tq = d1 (-2 a1 td + tc), td_q = sum_i W1[q][i] E1[q][i];
+      //                  oracle/cdkf_oracle.py MLPDrift.divgrad; G = (W1 W3)^T * W2 is never formed): the same k order, A operand from the
+      //                  same pinned W3 slice, B operand = W2 rows from LDS.  The sixteen chained products of layer 3 hide behind the 64 here.
       typename MTile::V4 acc3{0, 0, 0, 0};
+      typename MTile::V4 cacc[4];
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
+      for (int nt = 0; nt < 4; ++nt) cacc[nt] = typename MTile::V4{0, 0, 0, 0};
+      const int off2 = (lm == 8) ? W8Off::s2 : W8Off::d2;
+      if (second) {
+        // software pipeline: the LDS operands of k-step it + 1 are requested BEFORE the five products of k-step it are issued (issued
+        // after them they would arrive while the matrix pipe has already drained: a quarter of every k-step idle)
+        auto prow = [&](int it) __attribute__((always_inline)) { return 16 * (it >> 2) + MTile::row(lg, it & 3); };
+        R sc_n = W[sc_off + prow(0)], x2_n = W[off2 + prow(0)], w_n[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const R sc = W[sc_off + 16 * mt + MTile::row(lg, r)];
-          const R bv = sc * rfma(acc[mt][r], ne8, e8);
-          acc3 = wg_mfma(w3A[mt][r], bv, acc3);
+        for (int nt = 0; nt < 4; ++nt) w_n[nt] = Sh[W8Sh::W2 + prow(0) * W8Sh::LD2 + 16 * nt + lm];
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+          const R sc = sc_n, x2 = x2_n, w0 = w_n[0], w1 = w_n[1], w2 = w_n[2], w3 = w_n[3];
+          const R w3a = w3A[it >> 2][it & 3];
+          R av = x2 * (w3a + e8);  // lm < 8: d2_p W3[lm][p];  lm = 8: s2_p;  else 0
+          R b3v = sc * rfma(acc[it >> 2][it & 3], ne8, e8);
+          if (it < 15) {
+            const int pn = prow(it + 1);
+            sc_n = W[sc_off + pn];
+            x2_n = W[off2 + pn];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) w_n[nt] = Sh[W8Sh::W2 + pn * W8Sh::LD2 + 16 * nt + lm];
+          }
+          // (the products' operands pass through this fence: the loads above stay above it, the products below stay below)
+          asm volatile("" : "+v"(av), "+v"(b3v) : : "memory");
+          acc3 = wg_mfma(w3a, b3v, acc3);
+          cacc[0] = wg_mfma(av, w0, cacc[0]);
+          cacc[1] = wg_mfma(av, w1, cacc[1]);
+          cacc[2] = wg_mfma(av, w2, cacc[2]);
+          cacc[3] = wg_mfma(av, w3, cacc[3]);
         }
+      } else {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const R sc = W[sc_off + 16 * mt + MTile::row(lg, r)];
+            acc3 = wg_mfma(w3A[mt][r], sc * rfma(acc[mt][r], ne8, e8), acc3);
+          }
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = MTile::row(lg, r);
-        if (row < kW8 && lm < kW8) W[W8Off::A + row * kW8 + lm] = acc3[r];       // F[row][lm]
+        if (row < kW8 && lm < kW8) W[W8Off::F + row * kW8 + lm] = acc3[r];       // F[row][lm]
         if (row < kW8 && lm == 8) W[W8Off::f + row] = acc3[r] + Sh[W8Sh::b3 + row];
       }
-      W8_TICK(4)  // layer 3 (16 chained MFMA), F and f to LDS
-      R gl = 0;
       if (second) {
-        // g = grad(div f) = W1^T tq (oracle/cdkf_oracle.py MLPDrift.divgrad, G = (W1 W3)^T * W2 never formed):
-        //   tq = d1 (-2 a1 td + tc),  td_q = sum_i W1[q][i] E1[q][i],  [E1 | tc] = W2^T [diag(d2) W3^T | s2],  s2 = -2 a2 d2 s
-        // -- one 64 x 64 x 9 product on the matrix cores (the scalar form walked 64 rows of G and of W2 per lane)
-        const R s2v = R(-2) * a2 * d2 * sdiv;
-#pragma unroll
-        for (int k = 0; k < kW8; ++k) W[W8Off::Z + lane * 9 + k] = d2 * w3col[k];
-        W[W8Off::Z + lane * 9 + 8] = s2v;
-        wave_sync();
-        typename MTile::V4 cacc[4];
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) cacc[nt] = typename MTile::V4{0, 0, 0, 0};
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-          const R av = (lm < 9) ? W[W8Off::Z + (4 * ks + lg) * 9 + lm] : R(0);
-#pragma unroll
-          for (int nt = 0; nt < 4; ++nt) cacc[nt] = wg_mfma(av, Sh[W8Sh::W2 + (4 * ks + lg) * 65 + 16 * nt + lm], cacc[nt]);
-          if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-        }
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int row = MTile::row(lg, r);
-            if (row < 9) W[W8Off::U + (16 * nt + lm) * 9 + row] = cacc[nt][r];  // (the rows of T were consumed by sdiv above)
+            if (row < 9) W[W8Off::U + (16 * nt + lm) * 9 + row] = cacc[nt][r];  // (the rows of T were consumed above)
           }
-        wave_sync();
-        W8_TICK(5)  // 'second': Z image + transposed product (64 MFMA)
+      }
+      wave_sync();
+      W8_TICK(4)  // layer 3 (16 MFMA) + transposed product (64 MFMA), F, f, E1 | tc to LDS
+      // ---- k_P = F P + P F^T + L Qc L^T straight from the two tiles (no transposed partner to wait for) ---------------------------------
+      if (lane < kW8) kM = (lane < d) ? W[W8Off::f + lane] : R(0);
+      if (mck) mck[kMlpCkF * 64 + lane] = inP ? W[W8Off::F + lane] : R(0);
+      if (!zeroth) {
+        // (F P)_ij and (F P)_ji -- the second sum is, term by term and in the same order, what lane (j, i) forms as its first:
+        // k_P stays exactly symmetric without waiting for the partner's value
+        R sa = 0, sb = 0;
+#pragma unroll
+        for (int k = 0; k < kW8; ++k) {
+          sa = rfma(W[W8Off::F + i * kW8 + k], W[W8Off::P + k * kW8 + j], sa);
+          sb = rfma(W[W8Off::F + j * kW8 + k], W[W8Off::P + k * kW8 + i], sb);
+        }
+        kP = (sa + sb) + lql;
+      }
+      if (second) {
+        // tq, then g_i = sum_q W1[q][i] tq_q: lane (i, j) adds the hidden units q = 8 c + j, the eight partial sums of a grid row meet by
+        // DPP; 0.5 (P g)_j = 0.5 sum_i P_ij g_i over the grid rows by the half-row rotation and the two swaps -- no LDS round trip
         R td = 0;
 #pragma unroll
-        for (int k = 0; k < kW8; ++k) td = rfma(w1row[k], W[W8Off::U + lane * 9 + k], td);
+        for (int k = 0; k < kW8; ++k) {
+          const R ek = W[W8Off::U + lane * 9 + k];
+          td = rfma(w1row[k], ek, td);
+          if (mck) mck[(kMlpCkE1 + k) * 64 + lane] = ek;
+        }
         const R tqv = d1 * rfma(R(-2) * a1, td, W[W8Off::U + lane * 9 + 8]);
+        if (mck) {
+          mck[kMlpCkTd * 64 + lane] = td;
+          mck[kMlpCkTq * 64 + lane] = tqv;
+        }
 #pragma unroll
-        for (int k = 0; k < kW8; ++k) W[W8Off::Z + lane * 8 + k] = w1row[k] * tqv;  // (Z: all its reads are behind the product)
+        for (int k = 0; k < kW8; ++k) W[W8Off::Z + lane * 8 + k] = w1row[k] * tqv;
         wave_sync();
-        // g_j = sum_q W1[q][j] tq_q: lane (i, j) sums the hidden units q = 8 c + i, the eight partial sums meet in a tile
         R part = 0;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) part += W[W8Off::Z + (8 * c + i) * 8 + j];
-        W[W8Off::tq + lane] = part;
-        wave_sync();
-        if (lane < kW8) {
-#pragma unroll
-          for (int r = 0; r < 8; ++r) gl += W[W8Off::tq + r * 8 + lane];
+        for (int c = 0; c < 8; ++c) part += W[W8Off::Z + (8 * c + j) * 8 + i];
+        const R gi = w8_sum_j(part);  // g_i in the lanes (i, *)
+        if (mck && j == 0) mck[kMlpCkG * 64 + i] = (i < d) ? gi : R(0);
+        if (!zeroth) {
+          const R pg = w8_sum_i(Ps * gi);  // (P g)_j in the lanes (*, j)
+          if (lane < kW8) kM = rfma(R(0.5), pg, kM);
         }
       }
-      wave_sync();
-      W8_TICK(6)  // 'second': td, tq, g reductions
-      Fij = inP ? W[W8Off::A + lane] : R(0);
-      if (lane < kW8) {
-        fi = W[W8Off::f + lane];
-        if (second) W[W8Off::g + lane] = gl;
-      }
-      wave_sync();
+      W8_TICK(6)  // k_P, td, tq, g, 0.5 P g
+      return;
     }
     if (lane < kW8) kM = (lane < d) ? fi : R(0);
     if (zeroth) return;
@@ -521,6 +650,7 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave8_kernel(const WgArgs<R
         }
         const R dt = tnext - tprev;
         R* ckp = (a.ck && k + 1 < a.T && steps < a.ck_smax) ? a.ck + ((n * (a.T - 1) + k) * a.ck_smax + steps) * kCkStep : nullptr;
+        R* mckp = (a.ckm && k + 1 < a.T && steps == 0) ? a.ckm + (n * (a.T - 1) + k) * (6L * a.ckm_nf * 64) : nullptr;
         // The stage loop stays ROLLED (one inlined copy of the right-hand side instead of six: the unrolled sweep was several
         // times the instruction cache): the slopes k1 .. k5 wait in LDS -- a lane reads back only what it wrote itself, no
         // synchronisation -- and the stage index may be a run-time value.  Same sums in the same order as the unrolled form.
@@ -530,13 +660,13 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave8_kernel(const WgArgs<R
         for (int sg = 0; sg < 6; ++sg) {
           R sm = 0, sp = 0;
 #pragma unroll
-          for (int jj = 0; jj < 5; ++jj)
-            if (jj < sg) {  // uniform
-              const R c = TB::a[sg][jj];
-              sm = rfma(c, W[W8Off::km + 8 * jj + (lane & 7)], sm);
-              sp = rfma(c, W[W8Off::X + 64 * jj + lane], sp);
-            }
+          for (int jj = 0; jj < 5; ++jj) {  // (jj >= sg: zero coefficient -- the same sums as the guarded form, without its branches)
+            const R c = W[o_rk + 6 * sg + jj];
+            sm = rfma(c, W[W8Off::km + 8 * jj + (lane & 7)], sm);
+            sp = rfma(c, W[W8Off::X + 64 * jj + lane], sp);
+          }
           R kM = 0, kP = 0;
+          mck = mckp ? mckp + (long)sg * a.ckm_nf * 64 : nullptr;
           rhs(rfma(dt, sm, mj), rfma(dt, sp, Pij), kM, kP);
           if (ckp) {  // slopes for the reverse sweep (uniform branch; nullptr outside cdkf_ekf_loglik_grad_all)
             ckp[sg * 72 + lane] = kP;

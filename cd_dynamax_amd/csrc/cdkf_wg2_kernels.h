@@ -54,8 +54,17 @@ struct WgArgs {
   // ([N][T-1][1 + dtlog_cap]: their number, then the sizes) and the reverse sweep replays exactly those steps
   R* dtlog;
   int dtlog_cap;
+  // ... and, for the MLP drift, what a right-hand side evaluates between its state and its Jacobian -- per stage of the FIRST step of
+  // every interval ([N][T-1][6][ckm_nf][64], kMlpCk*: lane p = hidden unit p): a1, the tangent row T[p][0..7], a2, the Jacobian tile
+  // entry, and for state_order 'second' s, E1[p][0..7], td, tq, g.  The reverse sweep's right-hand-side adjoint then starts from these
+  // instead of repeating the forward pass (two tanh layers, the 64 x 64 x 9 products): 288 GB of HBM are cheaper than the matrix cores.
+  R* ckm;
+  int ckm_nf;
 };
 constexpr int kCkStep = 6 * 72;  // reals per checkpointed step
+// fields of the MLP stage checkpoint (each 64 reals, lane-major): first order kMlpCkFirst of them, 'second' kMlpCkSecond
+constexpr int kMlpCkA1 = 0, kMlpCkT = 1, kMlpCkA2 = 9, kMlpCkF = 10, kMlpCkFirst = 11;
+constexpr int kMlpCkS = 11, kMlpCkE1 = 12, kMlpCkTd = 20, kMlpCkTq = 21, kMlpCkG = 22, kMlpCkSecond = 23;
 constexpr int kAdjCk = 4;         // Dormand-Prince step starts the reverse sweep keeps in LDS per replay chunk
 
 // Integer division by a run-time divisor costs ~40 instructions on CDNA: float reciprocal with +-1 correction
@@ -414,6 +423,51 @@ __device__ __forceinline__ R rtanh(R x) {
 }
 template <>
 __device__ __forceinline__ float rtanh<float>(float x) {
+  return tanhf(x);
+}
+// fp64 tanh in ~35 instructions (the library routine is ~130, and a right-hand side of the MLP drift evaluates two per hidden unit):
+//   u = expm1(2|x|) = 2^k p + (2^k - 1),  2|x| = k ln 2 + r,  |r| <= ln 2 / 2,  p = expm1(r) by its Taylor sum to r^13 (4e-18 relative),
+//   tanh|x| = u / (u + 2)  -- no cancellation anywhere (k = 0: u = p carries the full relative accuracy of small arguments);
+// the quotient by v_rcp_f64 + two Newton steps + one residual correction.  Measured against tanhl on 2e7 arguments
+// (|x| < 20, 1e-12 .. 1): 2.6 ulp at worst; NaN in, NaN out; +-inf -> +-1; signed zeros and denormals pass through.
+// Used by the wavefront-per-trajectory kernels (cdkf_wave8_kernels.h, cdkf_adjoint_kernels.h), where the whole kernel is ONE inlined
+// function.  The workgroup kernels below keep the library routine (rtanh): they really CALL wg_drift / wg_cholesky2 / wg_chol_solve
+// (s_swappc), and with this routine inlined into wg_drift the EPT = 1 instantiations returned garbage on gfx950 / ROCm 7.2 -- the
+// Lorenz-96 one, which never evaluates a tanh, included (A/B of two libraries differing in this function only, scripts/dbg_wg.py;
+// tests/test_gpu_wg.py::test_workgroup_kernels_other_runge_kutta_methods is the guard).
+template <typename R>
+__device__ __forceinline__ R rtanh_fast(R x) {
+  double ax = __builtin_fabs((double)x);
+  ax = (ax > 20.0) ? 20.0 : ax;  // (tanh 20 = 1 - 8e-18; a NaN fails the comparison and travels on)
+  const double t = ax + ax;
+  const double kf = __builtin_rint(t * 1.4426950408889634);
+  double r = __builtin_fma(kf, -6.93147180369123816490e-01, t);
+  r = __builtin_fma(kf, -1.90821492927058770002e-10, r);
+  double q = 1.0 / 6227020800.0;
+  q = __builtin_fma(q, r, 1.0 / 479001600.0);
+  q = __builtin_fma(q, r, 1.0 / 39916800.0);
+  q = __builtin_fma(q, r, 1.0 / 3628800.0);
+  q = __builtin_fma(q, r, 1.0 / 362880.0);
+  q = __builtin_fma(q, r, 1.0 / 40320.0);
+  q = __builtin_fma(q, r, 1.0 / 5040.0);
+  q = __builtin_fma(q, r, 1.0 / 720.0);
+  q = __builtin_fma(q, r, 1.0 / 120.0);
+  q = __builtin_fma(q, r, 1.0 / 24.0);
+  q = __builtin_fma(q, r, 1.0 / 6.0);
+  q = __builtin_fma(q, r, 0.5);
+  const double p = __builtin_fma(q * r, r, r);
+  const double s = __builtin_ldexp(1.0, (int)kf);
+  const double u = __builtin_fma(s, p, s - 1.0);
+  const double den = u + 2.0;
+  double y = __builtin_amdgcn_rcp(den);
+  y = __builtin_fma(__builtin_fma(-den, y, 1.0), y, y);
+  y = __builtin_fma(__builtin_fma(-den, y, 1.0), y, y);
+  double res = u * y;
+  res = __builtin_fma(__builtin_fma(-den, res, u), y, res);
+  return (R)__builtin_copysign(res, (double)x);
+}
+template <>
+__device__ __forceinline__ float rtanh_fast<float>(float x) {
   return tanhf(x);
 }
 

@@ -30,7 +30,7 @@ bool grad_shape_available(const cdkf_model* mdl, const cdkf_opts* o) {
 
 template <typename R, int D, int M, typename Drift>
 static int run_grad(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll,
-                    R* grad, int32_t* status, hipStream_t stream) {
+                    R* grad, int32_t* status, hipStream_t stream, bool ukf = false) {
   GradArgs<R, D, M, Drift> ga;
   fill_reg_args(ga.a, mdl, o, N, T, t, y, ll, (R*)nullptr, (R*)nullptr, (R*)nullptr, (R*)nullptr, status);
   ga.grad = grad;
@@ -39,8 +39,21 @@ static int run_grad(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_
   ga.a.lanes = g.lanes;
   ga.a.xcd_shift = g.xcd_shift;
   const dim3 grid(g.blocks), block(64);
-  note_kernel("ekf_grad_reg_kernel<%s, %d, %d, ", real_name<R>(), D, M);
-  if (o->solver != CDKF_SOLVER_DOPRI5 || o->adaptive)  // run-time tableau / adaptive steps: the tangents ride on the primal's steps
+  const bool generic = o->solver != CDKF_SOLVER_DOPRI5 || o->adaptive;  // run-time tableau / adaptive steps: the tangents ride on the primal's steps
+  // (the unscented filter of a drift without curvature has the extended filter's moment equations: the same kernel)
+  const bool curved = ukf && DriftGrad<R, D, Drift>::kCurved;
+  note_kernel("ekf_grad_reg_kernel<%s, %d, %d, %s, %s>", real_name<R>(), D, M, generic ? "true" : "false", curved ? "true" : "false");
+  if constexpr (DriftGrad<R, D, Drift>::kCurved) {
+    if (curved) {
+      if (generic)
+        hipLaunchKernelGGL((ekf_grad_reg_kernel<R, D, M, Drift, true, true>), grid, block, 0, stream, ga);
+      else
+        hipLaunchKernelGGL((ekf_grad_reg_kernel<R, D, M, Drift, false, true>), grid, block, 0, stream, ga);
+      CDKF_HIP_CHECK(hipGetLastError());
+      return CDKF_OK;
+    }
+  }
+  if (generic)
     hipLaunchKernelGGL((ekf_grad_reg_kernel<R, D, M, Drift, true>), grid, block, 0, stream, ga);
   else
     hipLaunchKernelGGL((ekf_grad_reg_kernel<R, D, M, Drift>), grid, block, 0, stream, ga);
@@ -131,6 +144,34 @@ int launch_ekf_grad(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_
 #undef X
   return CDKF_EUNSUPPORTED;
 }
+
+// the unscented filter's log-likelihood and its gradient w.r.t. the drift parameters (cdkf_ukf_loglik_grad_*): forward sensitivities
+// through the closed form of the sigma-point sums -- the register-resident Lorenz-63 / linear shapes
+bool ukf_grad_shape_available(const cdkf_model* mdl, const cdkf_opts* o) {
+  cdkf_opts e = *o;
+  e.state_order = CDKF_ORDER_FIRST;  // (the unscented filter has no state_order; the field is ignored)
+  return sens_shape_available(mdl, &e) && mdl->emission_kind == 0;
+}
+template <typename R>
+int launch_ukf_grad(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll, R* grad,
+                    int32_t* status, hipStream_t stream) {
+  if (!ukf_grad_shape_available(mdl, o)) {
+    set_error("ukf_loglik_grad: no kernel for drift_kind=%d state_dim=%d emission_dim=%d (the closed form of the sigma-point sums is "
+              "instantiated for the register-resident Lorenz-63 and linear shapes with a linear emission; num_iter 1)",
+              mdl->drift_kind, mdl->state_dim, mdl->emission_dim);
+    return CDKF_EUNSUPPORTED;
+  }
+#define X(KIND, DRIFT, D_, M_)                                                    \
+  if (mdl->drift_kind == KIND && mdl->state_dim == D_ && mdl->emission_dim == M_) \
+    return run_grad<R, D_, M_, DRIFT<R, D_>>(mdl, o, N, T, t, y, ll, grad, status, stream, true);
+  CDKF_GRAD_SHAPES(X)
+#undef X
+  return CDKF_EUNSUPPORTED;
+}
+template int launch_ukf_grad<float>(const cdkf_model*, const cdkf_opts*, int64_t, int64_t, const float*, const float*, float*, float*,
+                                    int32_t*, hipStream_t);
+template int launch_ukf_grad<double>(const cdkf_model*, const cdkf_opts*, int64_t, int64_t, const double*, const double*, double*,
+                                     double*, int32_t*, hipStream_t);
 
 template int launch_ekf_grad<float>(const cdkf_model*, const cdkf_opts*, int64_t, int64_t, const float*, const float*,
                                     float*, float*, float*, int32_t*, hipStream_t);

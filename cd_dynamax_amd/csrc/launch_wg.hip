@@ -338,6 +338,23 @@ int GradWorkspaceLease::done(hipStream_t stream) {
   return CDKF_OK;
 }
 
+// cdkf_release_workspace: wait for the last launch that uses the reverse sweeps' workspace and give the memory back
+int release_grad_workspace() {
+  std::lock_guard<std::mutex> lock(g_adj_mutex);
+  AdjWorkspace& ws = g_adj_ws;
+  if (ws.in_flight && ws.done) CDKF_HIP_CHECK(hipEventSynchronize(ws.done));
+  if (ws.p) {
+    int dev = 0;
+    CDKF_HIP_CHECK(hipGetDevice(&dev));
+    if (dev != ws.device) CDKF_HIP_CHECK(hipSetDevice(ws.device));
+    (void)hipFree(ws.p);
+    if (ws.done) (void)hipEventDestroy(ws.done);
+    if (dev != ws.device) CDKF_HIP_CHECK(hipSetDevice(dev));
+  }
+  ws = AdjWorkspace();
+  return CDKF_OK;
+}
+
 bool adjoint_shape_available(const cdkf_model* mdl, const cdkf_opts* o) {
   if (!wave8_shape(mdl) || !wg_shape_available(mdl, 8) || o->num_iter != 1 || o->forecast) return false;
   if (o->state_order == CDKF_ORDER_ZEROTH) return false;
@@ -356,27 +373,41 @@ int launch_ekf_grad_adjoint(const cdkf_model* mdl, const cdkf_opts* o, int64_t N
   if (rc) return rc;
   const size_t nm = (size_t)N * T * mdl->state_dim, nP = nm * mdl->state_dim;
   // stage-slope checkpoints of the first smax steps of every interval (0 = re-integrate everything): two steps cover every
-  // interval up to 2 dt0; CDKF_ADJ_CKPT_STEPS overrides, and a workspace beyond CDKF_ADJ_CKPT_GB (default 64) turns them off
+  // interval up to 2 dt0; CDKF_ADJ_CKPT_STEPS overrides.  For the MLP drift the forward sweep also keeps what each right-hand side
+  // of an interval's FIRST step evaluates inside the network (WgArgs::ckm; 11 / 23 fields of 64 reals per stage: 34 / 71 KB per
+  // interval in fp64), so that the reverse sweep's right-hand-side adjoints start from them instead of repeating the forward pass;
+  // CDKF_ADJ_MLP_CKPT=0 turns that off (A/B, tests).  Checkpoints beyond CDKF_ADJ_CKPT_GB (default 128 of the 288 GB) are dropped --
+  // the MLP block first, then the slopes: the sweep then recomputes instead.  cdkf_release_workspace() returns the memory.
   int smax = 2;
   if (const char* e = getenv("CDKF_ADJ_CKPT_STEPS")) smax = atoi(e);
   if (smax < 0) smax = 0;
   if (smax > kAdjCk) smax = kAdjCk;
-  double cap_gb = 64.0;
+  double cap_gb = 128.0;
   if (const char* e = getenv("CDKF_ADJ_CKPT_GB")) cap_gb = atof(e);
   size_t nck = (T > 1) ? (size_t)N * (size_t)(T - 1) * (size_t)smax * kCkStep : 0;
   if ((double)nck * sizeof(R) > cap_gb * 1e9) nck = 0;
+  const int mlp_nf = (o->state_order == CDKF_ORDER_SECOND) ? kMlpCkSecond : kMlpCkFirst;
+  bool mlp_ck = mdl->drift_kind == CDKF_DRIFT_MLP_TANH && nck > 0;
+  if (const char* e = getenv("CDKF_ADJ_MLP_CKPT")) mlp_ck = mlp_ck && atoi(e) != 0;
+  size_t nckm = mlp_ck ? (size_t)N * (size_t)(T - 1) * 6 * (size_t)mlp_nf * 64 : 0;
+  if ((double)(nck + nckm) * sizeof(R) > cap_gb * 1e9) nckm = 0;
   // an adaptive solve: the forward (workgroup) sweep logs the accepted step sizes of every interval (up to CDKF_ADJ_DT_CAP, default
   // 64; a longer interval raises MAX_STEPS on that trajectory) and the reverse sweep replays them
   int dtcap = 64;
   if (const char* e = getenv("CDKF_ADJ_DT_CAP")) dtcap = atoi(e) > 0 ? atoi(e) : 64;
   const size_t ndt = (o->adaptive && T > 1) ? (size_t)N * (size_t)(T - 1) * (size_t)(1 + dtcap) : 0;
-  if (o->adaptive) nck = 0;
+  if (o->adaptive) nck = nckm = 0;
   AdjWorkspace& ws = g_adj_ws;
-  if (int wrc = workspace_reserve(ws, (2 * (nm + nP) + nck + ndt) * sizeof(R), stream)) {
+  if (int wrc = workspace_reserve(ws, (2 * (nm + nP) + nck + nckm + ndt) * sizeof(R), stream)) {
     if (!nck) return wrc;
-    (void)hipGetLastError();  // no room for the slope checkpoints: the sweep re-integrates instead
-    nck = 0;
-    if (int wrc2 = workspace_reserve(ws, (2 * (nm + nP) + ndt) * sizeof(R), stream)) return wrc2;
+    (void)hipGetLastError();  // no room for every checkpoint: first without the network's intermediates, then without the slopes
+    int wrc2 = nckm ? workspace_reserve(ws, (2 * (nm + nP) + nck + ndt) * sizeof(R), stream) : wrc;
+    nckm = 0;
+    if (wrc2) {
+      (void)hipGetLastError();
+      nck = 0;
+      if (int wrc3 = workspace_reserve(ws, (2 * (nm + nP) + ndt) * sizeof(R), stream)) return wrc3;
+    }
   }
   R* w = (R*)ws.p;
   a.t = t; a.y = y; a.ll = ll; a.status = status;
@@ -387,6 +418,8 @@ int launch_ekf_grad_adjoint(const cdkf_model* mdl, const cdkf_opts* o, int64_t N
   a.dtlog_cap = ndt ? dtcap : 0;
   a.ck = (nck && dp5) ? w + 2 * (nm + nP) : nullptr;
   a.ck_smax = (nck && dp5) ? smax : 0;
+  a.ckm = (nckm && dp5 && smax >= 1) ? w + 2 * (nm + nP) + nck + ndt : nullptr;
+  a.ckm_nf = a.ckm ? mlp_nf : 0;
   rc = dp5 ? launch_wave8<R>(a, stream) : launch_wg_dispatch<R>(a, mdl, false, stream);
   if (!rc)
     rc = (mdl->drift_kind == CDKF_DRIFT_MLP_TANH) ? launch_adjoint_kernel<R, true>(a, grad, grad_model, stream)

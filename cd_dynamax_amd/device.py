@@ -79,7 +79,7 @@ def run_device(algo: str, mdl: _ffi.ModelBlock, opts, t, y, want):
     return ll, outs, status
 
 
-def loglik_grad_device(mdl: _ffi.ModelBlock, opts, t, y, with_model: bool):
+def loglik_grad_device(mdl: _ffi.ModelBlock, opts, t, y, with_model: bool, ukf: bool = False):
     """cdkf_ekf_loglik_grad[_all]_<f32|f64>_dev on device tensors: (ll [N], grad [N, n_theta], status[, model block])."""
     import torch
     N = y.shape[0]
@@ -94,5 +94,6 @@ def loglik_grad_device(mdl: _ffi.ModelBlock, opts, t, y, with_model: bool):
         gm = torch.empty(N, _ffi.model_grad_size(mdl.state_dim, mdl.emission_dim), **kw)
         _launch(getattr(_ffi.lib(), f"cdkf_ekf_loglik_grad_all_{suffix}_dev"), mdl, opts, y, _p(t), _p(y), _p(ll), _p(grad), _p(gm), _p(status))
         return ll, grad, status, gm
-    _launch(getattr(_ffi.lib(), f"cdkf_ekf_loglik_grad_{suffix}_dev"), mdl, opts, y, _p(t), _p(y), _p(ll), _p(grad), _p(status))
+    algo = "ukf" if ukf else "ekf"
+    _launch(getattr(_ffi.lib(), f"cdkf_{algo}_loglik_grad_{suffix}_dev"), mdl, opts, y, _p(t), _p(y), _p(ll), _p(grad), _p(status))
     return ll, grad, status

@@ -22,7 +22,7 @@ from typing import Any, List, Optional
 import numpy as np
 
 from . import _ffi
-from .params import EKFHyperParams, ParameterProperties
+from .params import EKFHyperParams, ParameterProperties, UKFHyperParams
 
 
 class Adam:
@@ -153,10 +153,16 @@ class _ResidentBatch:
         self.sums = _ffi.DeviceArray((2 + n_theta + n_model,), np.float64)
         self.ones = _ffi.DeviceArray.from_numpy(np.ones(B, dtype))  # the minibatch size reaches slot -1 as a device-side sum
 
+    ukf = False  # fit_sgd(filter_hyperparams=UKFHyperParams()): the unscented filter's objective (cdkf_ukf_loglik_grad_*)
+
     def _launch(self, mdl: _ffi.ModelBlock, opts, suffix: str):
         """Sweeps + device-side sums of this minibatch into ``self.sums`` (asynchronous, default stream)."""
         L = _ffi.lib()
-        if self.n_model:
+        if self.ukf:
+            _ffi.check(getattr(L, f"cdkf_ukf_loglik_grad_{suffix}_dev")(
+                C.byref(mdl.c), C.byref(opts), self.B, self.T, self.t.ptr, self.y.ptr, self.ll.ptr, self.grad.ptr,
+                self.status.ptr, None))
+        elif self.n_model:
             _ffi.check(getattr(L, f"cdkf_ekf_loglik_grad_all_{suffix}_dev")(
                 C.byref(mdl.c), C.byref(opts), self.B, self.T, self.t.ptr, self.y.ptr, self.ll.ptr, self.grad.ptr,
                 self.gmodel.ptr, self.status.ptr, None))
@@ -238,8 +244,9 @@ def fit_sgd(model, params, props, emissions, t_emissions=None, filter_hyperparam
     copied-back block over the library's TCP rendezvous (CPU tests)."""
     from .models import _grads_tree, _model_block, _opts, _prepare
     hyper = EKFHyperParams() if filter_hyperparams is None else filter_hyperparams
-    if not isinstance(hyper, EKFHyperParams):
-        raise NotImplementedError("fit_sgd: gradients are provided for the EKF marginal log-likelihood only")
+    ukf = isinstance(hyper, UKFHyperParams)
+    if not ukf and not isinstance(hyper, EKFHyperParams):
+        raise NotImplementedError("fit_sgd: gradients are provided for the EKF and the UKF marginal log-likelihood")
     optimizer = Adam(1e-3) if optimizer is None else optimizer
     tr = _Trainable(params, props)
     opts = _opts(hyper, 1)
@@ -247,9 +254,13 @@ def fit_sgd(model, params, props, emissions, t_emissions=None, filter_hyperparam
     opts.layout = _ffi.LAYOUT_TCN
     suffix = "f32" if dtype == np.float32 else "f64"
     mdl0 = _model_block(params)
-    check = _ffi.lib().cdkf_grad_supported if tr.drift_only else _ffi.lib().cdkf_grad_all_supported
+    if ukf and not tr.drift_only:
+        raise NotImplementedError("fit_sgd with UKFHyperParams: the unscented filter's gradient is provided for the drift parameters "
+                                  f"(trainable: {[p for p, _, _, _ in tr.items]})")
+    check = (_ffi.lib().cdkf_ukf_grad_supported if ukf else
+             (_ffi.lib().cdkf_grad_supported if tr.drift_only else _ffi.lib().cdkf_grad_all_supported))
     if not check(C.byref(mdl0.c), C.byref(opts)):
-        what = "drift gradient" if tr.drift_only else "all-parameter reverse-sweep"
+        what = ("unscented-filter drift gradient" if ukf else "drift gradient") if tr.drift_only else "all-parameter reverse-sweep"
         raise NotImplementedError(
             f"fit_sgd: no {what} kernel for drift {type(params.dynamics.drift).__name__} with state_dim={mdl0.state_dim}, "
             f"emission_dim={mdl0.emission_dim}, state_order={hyper.state_order}"
@@ -287,7 +298,10 @@ def fit_sgd(model, params, props, emissions, t_emissions=None, filter_hyperparam
     def build(idx):
         if len(idx) == 0:  # this rank has no sequence in that step
             return _EmptyPiece(n_theta, n_model) if on_device else None
-        return _ResidentBatch(y[idx], t if t_shared else t[idx], t_shared, n_theta, n_model, dtype)
+        rb = _ResidentBatch(y[idx], t if t_shared else t[idx], t_shared, n_theta, n_model, dtype)
+        if ukf:
+            rb.ukf = True
+        return rb
 
     order = np.arange(N)
     resident: List[Optional[_ResidentBatch]] = []

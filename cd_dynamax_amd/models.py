@@ -304,7 +304,7 @@ def cdnlgssm_loglik_and_grad(
     inputs=None,
     dtype=None,
 ):
-    """EKF marginal log-likelihood and its gradient w.r.t. the drift parameters -- the drift block of what
+    """EKF (or, with ``UKFHyperParams``, unscented) marginal log-likelihood and its gradient w.r.t. the drift parameters -- the drift block of what
     ``jax.value_and_grad(_loss_fn)`` returns in the reference's fit_sgd (ssm_temissions.py:550-568), per trajectory and
     un-negated / un-normalised.  Returns ``(ll, grad)``: ``ll`` as ``marginal_log_prob`` (``[N]`` for batched emissions),
     ``grad`` an instance of the drift's class whose fields hold d ll / d field (leading ``[N]`` when batched).
@@ -313,8 +313,9 @@ def cdnlgssm_loglik_and_grad(
     ``state_order`` first or second.  Any registry drift with state_dim, emission_dim <= 8 (LearnableMLP: hidden <= 64; its
     ``state_order='second'`` mean term 0.5 P grad(div f) is reversed too): forward + reverse sweep (discrete adjoint).  Anything else raises (no finite-difference
     fallback)."""
-    if not isinstance(hyperparams, EKFHyperParams):
-        raise NotImplementedError("gradients are provided for the EKF marginal log-likelihood only")
+    ukf = isinstance(hyperparams, UKFHyperParams)
+    if not ukf and not isinstance(hyperparams, EKFHyperParams):
+        raise NotImplementedError("gradients are provided for the EKF and the UKF marginal log-likelihood (the ensemble filter is stochastic)")
     mdl = _model_block(params)
     opts = _opts(hyperparams, 1)
     on_device = _device.is_device_tensor(emissions)
@@ -322,14 +323,17 @@ def cdnlgssm_loglik_and_grad(
         y, t, batched, dtype = _device.prepare(emissions, t_emissions, opts)
     else:
         y, t, batched, dtype = _prepare(emissions, t_emissions, hyperparams, opts, dtype)
-    if not _ffi.lib().cdkf_grad_supported(_ffi.C.byref(mdl.c), _ffi.C.byref(opts)):
+    supported = _ffi.lib().cdkf_ukf_grad_supported if ukf else _ffi.lib().cdkf_grad_supported
+    if not supported(_ffi.C.byref(mdl.c), _ffi.C.byref(opts)):
         raise NotImplementedError(
-            f"no gradient kernel for drift {type(params.dynamics.drift).__name__} with state_dim={mdl.state_dim}, "
-            f"emission_dim={mdl.emission_dim}, state_order={hyperparams.state_order}")
+            f"no {'unscented-filter ' if ukf else ''}gradient kernel for drift {type(params.dynamics.drift).__name__} with "
+            f"state_dim={mdl.state_dim}, emission_dim={mdl.emission_dim}"
+            + ("" if ukf else f", state_order={hyperparams.state_order}")
+            + (" (the closed form of the sigma-point sums: LearnableLorenz63 / LearnableLinear at the register-resident shapes)" if ukf else ""))
     if on_device:  # ll and the per-trajectory gradient stay on the device (torch tensors)
-        ll, grad, _ = _device.loglik_grad_device(mdl, opts, t, y, False)
+        ll, grad, _ = _device.loglik_grad_device(mdl, opts, t, y, False, ukf=ukf)
     else:
-        ll, grad, _ = _ffi.loglik_grad(mdl, opts, t, y, dtype)
+        ll, grad, _ = _ffi.loglik_grad(mdl, opts, t, y, dtype, ukf=ukf)
     if not batched:
         ll, grad = ll[0], grad[0]
     return ll, _drift_like(params.dynamics.drift, grad)

@@ -334,6 +334,21 @@ int cdkf_ekf_loglik_grad_f64_dev(const cdkf_model* mdl, const cdkf_opts* opts, i
                                  const double* y, double* ll, double* grad, int32_t* status, void* stream);
 int cdkf_ekf_loglik_grad_f32_dev(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T, const float* t,
                                  const float* y, float* ll, float* grad, int32_t* status, void* stream);
+/* ---- the same for the UNSCENTED filter's marginal log-likelihood: value_and_grad of the fit_sgd / fit_mcmc objective with
+ *      filter_hyperparams = UKFHyperParams() (src/ssm_temissions.py:500, 555-568 -> models.py:393-408 -> the UKF branch of
+ *      cdnlgssm_filter, models.py:708 -> inference_ukf.py:206-308).  Forward sensitivities through the closed form of the
+ *      sigma-point sums (exact for the Lorenz-63 and linear drifts: the derivative of a function does not depend on how it is
+ *      written down); ll [N] equals cdkf_ukf_filter_*'s to rounding; a predicted covariance that is not positive definite gives
+ *      NaN and the NOT_PD flag as the filter does.  cdkf_ukf_grad_supported(): register-resident Lorenz-63 / linear shapes. */
+int cdkf_ukf_loglik_grad_f64(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T, const double* t,
+                             const double* y, double* ll, double* grad, int32_t* status);
+int cdkf_ukf_loglik_grad_f32(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T, const float* t,
+                             const float* y, float* ll, float* grad, int32_t* status);
+int cdkf_ukf_loglik_grad_f64_dev(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T, const double* t,
+                                 const double* y, double* ll, double* grad, int32_t* status, void* stream);
+int cdkf_ukf_loglik_grad_f32_dev(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T, const float* t,
+                                 const float* y, float* ll, float* grad, int32_t* status, void* stream);
+int cdkf_ukf_grad_supported(const cdkf_model* mdl, const cdkf_opts* opts);
 /* ---- the same plus the gradient w.r.t. every other model parameter (the remaining leaves of the pytree jax.grad returns
  *      for ParamsCDNLGSSM): grad_model [N, d + 2 d^2 + m d + m + m^2] row-major, per trajectory
  *          m0 [d] | P0 [d,d] | LQL [d,d] | H [m,d] | h_bias [m] | R [m,m]
@@ -352,6 +367,12 @@ int cdkf_ekf_loglik_grad_all_f32_dev(const cdkf_model* mdl, const cdkf_opts* opt
                                      const float* y, float* ll, float* grad, float* grad_model, int32_t* status,
                                      void* stream);
 int cdkf_grad_all_supported(const cdkf_model* mdl, const cdkf_opts* opts);
+/* The reverse sweeps behind cdkf_ekf_loglik_grad_* keep the forward sweep's moments -- and, where it pays, stage checkpoints: up to
+ * CDKF_ADJ_CKPT_GB (environment, default 128) GB -- in ONE per-process device workspace that only grows and is reused by every later
+ * call (no allocation inside an SGD / HMC loop).  This call waits for the last launch that uses it and returns the memory to the
+ * device (e.g. before handing the GPU to another library); the next gradient call allocates again.  Counterpart in the reference:
+ * none (XLA owns the buffers of jax.value_and_grad, src/ssm_temissions.py:550-568). */
+int cdkf_release_workspace(void);
 /* 1 if cdkf_ekf_loglik_grad_* has a kernel for this model/options, else 0 */
 int cdkf_grad_supported(const cdkf_model* mdl, const cdkf_opts* opts);
 /* out[p] = sum_n grad[n, p] on the device (the `.sum()` of ssm_temissions.py:567 applied to the gradient), so a

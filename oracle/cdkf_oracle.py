@@ -1033,6 +1033,92 @@ def ekf_loglik_grad(mdl: Model, t, y, dt0=0.01, dt_final=1e-10, max_steps=100000
     return ll, g
 
 
+def ukf_loglik_grad(mdl: Model, t, y, alpha=math.sqrt(3), beta=2, kappa=1, dt0=0.01, dt_final=1e-10, max_steps=100000,
+                    dtype=np.float64):
+    """(ll [N], grad [N, n_theta]) of the UNSCENTED filter's marginal log-likelihood w.r.t. the drift parameters -- what
+    jax.value_and_grad of the fit_sgd loss yields with filter_hyperparams=UKFHyperParams() (ssm_temissions.py:500, 555-568 through
+    models.py:393-408, inference_ukf.py:206-308) -- for the drifts whose sigma-point sums collapse exactly (Lorenz-63: quadratic;
+    linear) and a linear emission: with P_s = sym(P) = chol(P) chol(P)^T the weighted sums of _predict / _condition_on are, for every
+    (alpha, beta, kappa),
+        dm/dt = f(m) + (0, -P_s02, P_s01),   dP/dt = F(m) P_s + P_s F(m)^T + L Qc L^T,   S = H P_s H^T + R,   C = P_s H^T,
+    and this routine carries forward sensitivities through exactly these (the derivative of a function does not depend on how the
+    function is written down).  Pinned in tests/test_oracle.py by central finite differences of ukf_filter -- the routine that forms
+    the sigma points literally."""
+    dtype = np.dtype(dtype)
+    mdl = mdl.cast(dtype)
+    y = np.asarray(y, dtype=dtype)
+    N, T, _ = y.shape
+    d, mm = mdl.d, mdl.m
+    drift = mdl.drift
+    if drift.kind not in ("lorenz63", "linear"):
+        raise NotImplementedError("ukf_loglik_grad: the closed form of the sigma-point sums is written for Lorenz-63 and linear drifts")
+    curved = drift.kind == "lorenz63"
+    npar = drift.theta().size
+    H, R, bias = mdl.H, mdl.R, mdl.bias
+    LQL = _LQL(mdl)
+    t0s, t1s = _t0_t1(t, dt_final, dtype)
+    m = np.broadcast_to(mdl.m0, (N, d)).copy()
+    P = np.broadcast_to(mdl.P0, (N, d, d)).copy()
+    dm = np.zeros((N, npar, d), dtype)
+    dP = np.zeros((N, npar, d, d), dtype)
+    ll = np.zeros(N, dtype)
+    g = np.zeros((N, npar), dtype)
+    eye = np.eye(mm, dtype=dtype)
+    T_ = lambda A: np.swapaxes(A, -1, -2)
+
+    def curv(Ps):  # b(P_s) = (0, -P_s02, P_s01) on the last axis of [..., 3, 3]
+        out = np.zeros(Ps.shape[:-1], Ps.dtype)
+        if curved:
+            out[..., 1] = -Ps[..., 0, 2]
+            out[..., 2] = Ps[..., 0, 1]
+        return out
+
+    for k in range(T):
+        Ps, dPs = symmetrize(P), symmetrize(dP)
+        HP = H @ Ps
+        S = HP @ H.T + R
+        v = y[:, k] - (m @ H.T + bias)
+        dHP = H @ dPs
+        dS = dHP @ H.T
+        dv = -dm @ H.T
+        Lc = cholesky_lower(S)
+        Sinv = solve_upper_from_lower(Lc, solve_lower(Lc, np.broadcast_to(eye, S.shape).copy()))
+        w = np.einsum("nij,nj->ni", Sinv, v)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            logdet_half = np.sum(np.log(np.diagonal(Lc, axis1=-2, axis2=-1)), axis=-1)
+        ll = ll + (-0.5 * np.einsum("ni,ni->n", v, w) - logdet_half - 0.5 * mm * math.log(2 * math.pi))
+        g = g + (-np.einsum("ni,npi->np", w, dv) + 0.5 * np.einsum("ni,npij,nj->np", w, dS, w)
+                 - 0.5 * np.einsum("nij,npji->np", Sinv, dS))
+        Sb = symmetrize(S) + dtype.type(1e-9) * eye
+        Lb = cholesky_lower(Sb)
+        X = solve_upper_from_lower(Lb, solve_lower(Lb, HP))          # K^T
+        dSb = symmetrize(dS)
+        rhs = dHP - dSb @ X[:, None]
+        Lbp = np.broadcast_to(Lb[:, None], dSb.shape).copy().reshape(-1, mm, mm)
+        dX = solve_upper_from_lower(Lbp, solve_lower(Lbp, rhs.reshape(-1, mm, d))).reshape(rhs.shape)
+        m_new = m + np.einsum("nri,nr->ni", X, v)
+        dm_new = dm + np.einsum("npri,nr->npi", dX, v) + np.einsum("nri,npr->npi", X, dv)
+        SX = S @ X
+        P = P - T_(X) @ SX                                            # (no symmetrize in the unscented update)
+        dP = dP - (T_(dX) @ SX[:, None] + T_(X)[:, None] @ (dS @ X[:, None]) + T_(X)[:, None] @ (S[:, None] @ dX))
+        m, dm = m_new, dm_new
+
+        def rhs_all(yv):
+            mm_, PP, dmm, dPP = yv
+            PPs, dPPs = symmetrize(PP), symmetrize(dPP)
+            F = drift.jac(mm_)
+            dfdth, dFdth, dFdx = _drift_param_derivs(drift, mm_)
+            dmdt = drift.f(mm_) + curv(PPs)
+            dPdt = F @ PPs + PPs @ T_(F) + LQL
+            ddm = np.einsum("nij,npj->npi", F, dmm) + dfdth + curv(dPPs)
+            dF = np.einsum("nkij,npk->npij", dFdx, dmm) + dFdth
+            B = dF @ PPs[:, None] + F[:, None] @ dPPs
+            return dmdt, dPdt, ddm, B + T_(B)
+
+        m, P, dm, dP = diffeqsolve(rhs_all, t0s[:, k], t1s[:, k], (m, P, dm, dP), dt0, max_steps, err_components=2)
+    return ll, g
+
+
 # --------------------------------------------------------------------------------------
 # the same gradient by the discrete adjoint (reverse mode) -- all drift parameters, any registry drift
 # --------------------------------------------------------------------------------------

@@ -7,7 +7,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "_build", "libcdkf_oracle.so")
+# CDKF_ORACLE_SO: the sanitizer build of scripts/sanitize_cpu.sh
+_SO = os.environ.get("CDKF_ORACLE_SO") or os.path.join(_HERE, "_build", "libcdkf_oracle.so")
 _KIND = {"linear": 0, "lorenz63": 1, "lorenz96": 2}
 _ORDER = {"zeroth": 0, "first": 1, "second": 2}
 

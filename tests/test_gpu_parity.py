@@ -450,7 +450,7 @@ def test_linear_drift_on_the_lane_grid(hip_lib):
         ex = closed_form_kf(mdl, t[0], y[0])
         post = cd.cdnlgssm_filter(P, y[0], t[0][:, None])
         assert relerr(post.filtered_means, ex["filtered_means"]) < 1e-7 and abs(post.marginal_loglik - ex["marginal_loglik"]) < 1e-6 * abs(ex["marginal_loglik"])
-        big_t, big_y = np.tile(t, (460, 1))[:4100], np.tile(y, (460, 1, 1))[:4100]  # > 4096: lane-per-trajectory kernel
+        big_t, big_y = np.tile(t, (920, 1))[:8200], np.tile(y, (920, 1, 1))[:8200]  # > 8192 (two wavefronts per SIMD): lane-per-trajectory kernel
         big = cd.cdnlgssm_filter(P, big_y, big_t[..., None])
         assert hip_lib.cdkf_last_kernel().startswith(b"filter_reg_kernel")
         small = cd.cdnlgssm_filter(P, y, t[..., None])
@@ -505,6 +505,70 @@ def test_unscented_filter_literal_sigma_points_flag(hip_lib):
     dp = lambda a: a.ctypes.data_as(_ffi.C.c_void_p)
     rc = hip_lib.cdkf_ukf_filter_f64(_ffi.C.byref(blk.c), _ffi.C.byref(opts), 1, T, dp(tt), dp(yy), dp(ll), None, None, None, None, dp(st))
     assert rc == _ffi.CDKF_EINVAL and b"flags" in hip_lib.cdkf_last_error()
+
+
+def test_unscented_loglik_gradient(hip_lib):
+    """cdkf_ukf_loglik_grad_*: the unscented filter's marginal log-likelihood and its gradient w.r.t. the drift parameters --
+    value_and_grad of the fit_sgd loss with filter_hyperparams=UKFHyperParams() (ssm_temissions.py:500, 555-568 -> models.py:393-408,
+    708 -> inference_ukf.py:206-308) -- against the oracle's ukf_loglik_grad (pinned by finite differences of the literal sigma-point
+    filter, tests/test_oracle.py): Lorenz-63 with m = 1, 2, 3 observed coordinates, default and non-default (alpha, beta, kappa),
+    long gaps, fp32, another Runge-Kutta method; a linear drift (no curvature: the extended filter's gradient); fit_sgd's first
+    step; the NaN of a covariance that is not positive definite; refusals."""
+    from cd_dynamax_amd import fit
+    from test_fit import _l63_problem
+    rng = np.random.default_rng(61)
+    for m in (3, 2, 1):
+        mdl = o.lorenz63_model(m)
+        P = params_from(mdl)
+        N, T = 7, 30
+        t = o.irregular_times(rng, N, T, 0.02 * T)
+        y = o.simulate(mdl, t, rng)
+        for hyp, kw in ((cd.UKFHyperParams(), {}), (cd.UKFHyperParams(alpha=0.7, beta=1.5, kappa=0.5), dict(alpha=0.7, beta=1.5, kappa=0.5))):
+            ll_ref, g_ref = o.ukf_loglik_grad(mdl, t, y, **kw)
+            ll, g = cd.cdnlgssm_loglik_and_grad(P, y, t[..., None], hyp)
+            assert hip_lib.cdkf_last_kernel().startswith(b"ekf_grad_reg_kernel<double, 3, %d, false, true>" % m), hip_lib.cdkf_last_kernel()
+            gd = np.stack([g.sigma, g.rho, g.beta], -1)
+            np.testing.assert_allclose(ll, ll_ref, rtol=1e-10)
+            assert np.abs(gd - g_ref).max() < 1e-9 * np.abs(g_ref).max()
+            post = cd.cdnlgssm_filter(P, y, t[..., None], hyp, output_fields=[])
+            np.testing.assert_allclose(ll, post.marginal_loglik, rtol=1e-10)      # the filter's own log-likelihood
+        _, ge = cd.cdnlgssm_loglik_and_grad(P, y, t[..., None], cd.EKFHyperParams())
+        assert np.abs(np.stack([ge.sigma, ge.rho, ge.beta], -1) - gd).max() > 1e-4 * np.abs(gd).max()  # not the extended filter's
+    # fp32; another method with the run-time tableau
+    ll32, g32 = cd.cdnlgssm_loglik_and_grad(P, y.astype(np.float32), t[..., None].astype(np.float32), cd.UKFHyperParams())
+    assert ll32.dtype == np.float32 and np.abs(np.stack([g32.sigma, g32.rho, g32.beta], -1) - g_ref).max() < 5e-3 * np.abs(g_ref).max()
+    with o.use_solver("tsit5"):
+        ll_ref, g_ref = o.ukf_loglik_grad(mdl, t, y)
+    ll, g = cd.cdnlgssm_loglik_and_grad(P, y, t[..., None], cd.UKFHyperParams(diffeqsolve_settings={"solver": "tsit5"}))
+    assert np.abs(np.stack([g.sigma, g.rho, g.beta], -1) - g_ref).max() < 1e-9 * np.abs(g_ref).max()
+    # a linear drift: the unscented moment equations are the extended filter's
+    lin = linear_model(rng, 3, 3)
+    Pl = params_from(lin)
+    tl = o.irregular_times(rng, 4, 20, 0.5)
+    yl = o.simulate(lin, tl, rng)
+    ll_u, g_u = cd.cdnlgssm_loglik_and_grad(Pl, yl, tl[..., None], cd.UKFHyperParams())
+    ll_r, g_r = o.ukf_loglik_grad(lin, tl, yl)
+    np.testing.assert_allclose(ll_u, ll_r, rtol=1e-10)
+    flat = np.concatenate([np.asarray(g_u.weights).reshape(4, -1), np.asarray(g_u.bias).reshape(4, -1)], -1)
+    assert np.abs(flat - g_r).max() < 1e-9 * np.abs(g_r).max()
+    # fit_sgd with the unscented filter: one plain-SGD step from the oracle's gradient
+    model, params, props = _l63_problem(m=3)
+    mdl3 = o.lorenz63_model(3)
+    mdl3 = o.Model(mdl3.drift, mdl3.L, mdl3.Qc, mdl3.H, mdl3.bias, mdl3.R, np.zeros(3), 100 * np.eye(3))
+    t3 = o.irregular_times(rng, 5, 25, 0.4)
+    y3 = o.simulate(mdl3, t3, rng)
+    new, losses = model.fit_sgd(params, props, y3, t3[..., None], cd.UKFHyperParams(), optimizer=fit.SGD(0.05), batch_size=5, num_epochs=1)
+    ll_r, g_r = o.ukf_loglik_grad(mdl3, t3, y3)
+    np.testing.assert_allclose(losses[0], -ll_r.sum() / y3.size, rtol=1e-10)
+    np.testing.assert_allclose([new.dynamics.drift.sigma, new.dynamics.drift.rho, new.dynamics.drift.beta],
+                               mdl3.drift.theta() + 0.05 * g_r.sum(0) / y3.size, rtol=1e-9)
+    # an initial covariance that is not positive definite: NaN as in the filter (chol of the sigma points, inference_ukf.py:57)
+    bad = o.Model(mdl3.drift, mdl3.L, mdl3.Qc, mdl3.H, mdl3.bias, mdl3.R, mdl3.m0, np.diag([1.0, -1.0, 1.0]))
+    ll_b, _ = cd.cdnlgssm_loglik_and_grad(params_from(bad), y3[:2], t3[:2, :, None], cd.UKFHyperParams())
+    assert np.isnan(ll_b).all()
+    # refusals: no closed form for this drift / the model block
+    with pytest.raises(NotImplementedError):
+        cd.cdnlgssm_loglik_and_grad(params_from(lorenz96_model(6, 3)), np.zeros((2, 5, 3)), np.arange(5.0)[None, :, None].repeat(2, 0), cd.UKFHyperParams())
 
 
 def test_c3_full_size_properties(hip_lib):
@@ -1045,6 +1109,41 @@ def test_notebook_pin_default_vs_tsit5_pid_loglik(hip_lib):
         ref_h = o.ekf_filter(mdl, t[:2, :Ts], y[:2, :Ts])["marginal_loglik"]
     got_h = cd.cdnlgssm_filter(P, y[:2, :Ts], t[:2, :Ts, None], cd.EKFHyperParams(diffeqsolve_settings=hifi_settings), output_fields=[]).marginal_loglik
     assert relerr(got_h, ref_h) < 1e-9
+
+
+def test_notebook_pins_lower_fidelity_settings_by_magnitude(hip_lib):
+    """The same notebook's other recorded log-likelihoods (tests/test_oracle.py::test_notebook_pins_lower_fidelity_settings_by_magnitude:
+    Tsit5 + PIDController(1e-3, 1e-6) from dt0 = 0.1 two float32 ulps off the high-fidelity value, Heun dt0 = 1e-3 off by 2.5e-2, Euler
+    dt0 = 1e-4 by 5.3e-1, per 1e4 observations) through the HIP path: on the same seeded problem the fp64 sweeps reproduce the
+    oracle's sums to 1e-9 under each of the four settings -- so they sit at the same magnitudes -- and in fp32, the reference's
+    precision, the loose controller stays within 16 ulps per sequence of the high-fidelity solve, as the notebook saw (2)."""
+    from test_oracle import _notebook_problem
+    mdl, t, y = _notebook_problem()
+    P = params_from(mdl)
+    settings = {
+        "hifi": ({"solver": "tsit5", "stepsize_controller": cd.PIDController(rtol=1e-9, atol=1e-9), "max_steps": 10 ** 7},
+                 dict(solver="tsit5", adaptive=dict(rtol=1e-9, atol=1e-9)), {}),
+        "loose": ({"solver": "tsit5", "dt0": 0.1, "stepsize_controller": cd.PIDController(rtol=1e-3, atol=1e-6), "max_steps": 100},
+                  dict(solver="tsit5", adaptive=dict(rtol=1e-3, atol=1e-6)), dict(dt0=0.1, max_steps=100)),
+        "heun": ({"solver": "heun", "dt0": 1e-3, "max_steps": 10 ** 4}, dict(solver="heun"), dict(dt0=1e-3, max_steps=10 ** 4)),
+        "euler": ({"solver": "euler", "dt0": 1e-4, "max_steps": 10 ** 3}, dict(solver="euler"), dict(dt0=1e-4, max_steps=10 ** 3)),
+    }
+    got, got32 = {}, {}
+    for name, (hip, orc, kw) in settings.items():
+        ll = cd.cdnlgssm_filter(P, y, t[..., None], cd.EKFHyperParams(diffeqsolve_settings=hip), output_fields=[]).marginal_loglik
+        with o.use_solver(orc["solver"], **({"adaptive": orc["adaptive"]} if "adaptive" in orc else {})):
+            ref = o.ekf_filter(mdl, t, y, **kw)["marginal_loglik"]
+        assert relerr(ll, ref) < 1e-9, name
+        got[name] = float(np.sum(ll))
+        if name in ("hifi", "loose"):
+            got32[name] = np.asarray(cd.cdnlgssm_filter(P, y.astype(np.float32), t[..., None], cd.EKFHyperParams(diffeqsolve_settings=hip),
+                                                        output_fields=[]).marginal_loglik, np.float64)
+    ulp32 = float(np.spacing(np.float32(abs(got["hifi"]))))
+    assert abs(got["loose"] - got["hifi"]) < 3 * ulp32
+    assert 2.54e-2 / 5 < abs(got["heun"] - got["hifi"]) < 2.54e-2 * 5
+    assert 5.3e-1 / 5 < abs(got["euler"] - got["hifi"]) < 5.3e-1 * 5
+    per_seq_ulp = np.spacing(np.abs(got32["hifi"]).astype(np.float32)).astype(np.float64)
+    assert np.all(np.abs(got32["loose"] - got32["hifi"]) <= 16 * per_seq_ulp), (got32["loose"] - got32["hifi"]) / per_seq_ulp
 
 
 def test_adaptive_refusals(hip_lib):

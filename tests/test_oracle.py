@@ -227,6 +227,39 @@ def test_loglik_gradient_matches_finite_differences(kind):
         np.testing.assert_allclose(g[:, p], fd, rtol=2e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("kind,mobs", [("lorenz63", 3), ("lorenz63", 1), ("linear", 2)])
+def test_unscented_loglik_gradient_matches_finite_differences(kind, mobs):
+    """ukf_loglik_grad -- forward sensitivities through the CLOSED FORM of the sigma-point sums (exact for these drifts) -- against
+    central finite differences of ukf_filter, which forms the sigma points and factorises the covariance literally as
+    inference_ukf.py:45-60, 93-203 do; default and non-default (alpha, beta, kappa): the derivative does not depend on them, the
+    log-likelihood agrees to rounding.  This is what value_and_grad(_loss_fn) yields with filter_hyperparams=UKFHyperParams()
+    (ssm_temissions.py:500, 555-568)."""
+    rng = np.random.default_rng(32)
+    if kind == "lorenz63":
+        mdl = o.lorenz63_model(mobs)
+        rebuild = lambda th: o.Model(o.Lorenz63Drift(*th), mdl.L, mdl.Qc, mdl.H, mdl.bias, mdl.R, mdl.m0, mdl.P0)
+    else:
+        mdl = linear_model(rng, 3, mobs)
+        rebuild = lambda th: o.Model(o.LinearDrift(th[:9].reshape(3, 3), th[9:]), mdl.L, mdl.Qc, mdl.H, mdl.bias, mdl.R, mdl.m0, mdl.P0)
+    N, T = 3, 20
+    t = o.irregular_times(rng, N, T, 0.03 * T)
+    y = o.simulate(mdl, t, rng)
+    for kw in ({}, dict(alpha=0.7, beta=1.5, kappa=0.5)):
+        ll, g = o.ukf_loglik_grad(mdl, t, y, **kw)
+        np.testing.assert_allclose(ll, o.ukf_filter(mdl, t, y, **kw)["marginal_loglik"], rtol=1e-11)
+        th0 = mdl.drift.theta()
+        for p in range(th0.size):
+            h = 1e-6 * max(1.0, abs(th0[p]))
+            tp, tm = th0.copy(), th0.copy()
+            tp[p] += h
+            tm[p] -= h
+            fd = (o.ukf_filter(rebuild(tp), t, y, **kw)["marginal_loglik"] - o.ukf_filter(rebuild(tm), t, y, **kw)["marginal_loglik"]) / (2 * h)
+            np.testing.assert_allclose(g[:, p], fd, rtol=2e-6, atol=1e-6)
+    # the unscented and the extended filter's gradients differ (the true second-order term of the mean equation) unless the drift is linear
+    _, ge = o.ekf_loglik_grad(mdl, t, y)
+    assert (np.abs(g - ge).max() > 1e-4 * np.abs(ge).max()) == (kind == "lorenz63")
+
+
 def _rebuild_drift(mdl, th):
     dr = mdl.drift
     if dr.kind == "mlp":
@@ -544,3 +577,38 @@ def test_notebook_pin_default_vs_tsit5_pid_loglik():
         hifi = o.ekf_filter(mdl, t, y)["marginal_loglik"]
     assert np.all(np.abs(default - hifi) <= 6.7e-8 * np.abs(hifi)), (default, hifi)
     assert np.all(default != hifi)  # two different integrators: not the same numbers by construction
+
+
+def _notebook_problem(seed=2025, N=8, T=1250):
+    """The tutorial's model (Lorenz-63 through H = [1, 0, 0], R = 1, L = Qc = I, P0 = 5 I) at its time density (mean gap 0.005) with
+    as many observations as its recorded log-likelihood implies (-14591.9 at about -1.46 per observation: 1e4), as N sequences."""
+    rng = np.random.default_rng(seed)
+    mdl = o.lorenz63_model(1)
+    t = o.irregular_times(rng, N, T, 0.005 * T)
+    return mdl, t, o.simulate(mdl, t, rng)
+
+
+def test_notebook_pins_lower_fidelity_settings_by_magnitude():
+    """The other numbers the same notebook records (src/notebooks/tutorial/diffeqsolve_settings_analysis.ipynb, float32, one
+    realisation of 1e4 observations) against the high-fidelity -14591.8759765625:
+        Tsit5 + PIDController(rtol=1e-3, atol=1e-6), dt0 = 0.1, max_steps = 100   -14591.8740234375   (+1.95e-3 = 2 float32 ulps)
+        Heun,  dt0 = 1e-3, max_steps = 1e4                                        -14591.9013671875   (-2.54e-2)
+        Euler, dt0 = 1e-4, max_steps = 1e3                                        -14592.40625        (-5.3e-1)
+    The data are not reproducible (JAX PRNG), and across seeds the SIGN of these differences changes (checked: Heun -1.8e-2 ..
+    +1.9e-2, Euler -1.2e-1 .. +4.5e-1 per 1e4 observations), so the pin is the order of magnitude on seeded data of the same
+    model, density and size: the restated Heun and Euler tableaus within a factor of five of the recorded gaps, and the loose
+    controller within the three float32 ulps the notebook's own numbers resolve (in fp64 it sits at 1e-6)."""
+    mdl, t, y = _notebook_problem()
+    with o.use_solver("tsit5", adaptive=dict(rtol=1e-9, atol=1e-9)):
+        hifi = o.ekf_filter(mdl, t, y)["marginal_loglik"].sum()
+    assert 1.3e4 < -hifi < 1.6e4
+    with o.use_solver("tsit5", adaptive=dict(rtol=1e-3, atol=1e-6)):
+        loose = o.ekf_filter(mdl, t, y, dt0=0.1, max_steps=100)["marginal_loglik"].sum()
+    with o.use_solver("heun"):
+        heun = o.ekf_filter(mdl, t, y, dt0=1e-3, max_steps=10000)["marginal_loglik"].sum()
+    with o.use_solver("euler"):
+        euler = o.ekf_filter(mdl, t, y, dt0=1e-4, max_steps=1000)["marginal_loglik"].sum()
+    ulp32 = float(np.spacing(np.float32(abs(hifi))))
+    assert abs(loose - hifi) < 3 * ulp32 and loose != hifi
+    assert 2.54e-2 / 5 < abs(heun - hifi) < 2.54e-2 * 5, heun - hifi
+    assert 5.3e-1 / 5 < abs(euler - hifi) < 5.3e-1 * 5, euler - hifi
