@@ -328,6 +328,16 @@ int kf_pushforward_host(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, in
   if (rc) return rc;
   CDKF_HIP_CHECK(hipDeviceSynchronize());
   CDKF_HIP_CHECK(hipMemcpy(AQ, dA.p, nA * sizeof(R), hipMemcpyDeviceToHost));
+  // an interval cut off at max_steps leaves a truncated (A, Q) pair: that is an error for this call -- it has no status output, and its
+  // callers (the linear front end's dynamics-bias / input offsets) would build on the pair silently (diffrax raises in the reference)
+  std::vector<int32_t> st((size_t)N);
+  CDKF_HIP_CHECK(hipMemcpy(st.data(), dst.p, N * sizeof(int32_t), hipMemcpyDeviceToHost));
+  for (int64_t n = 0; n < N; ++n)
+    if (st[(size_t)n] & CDKF_STATUS_MAX_STEPS) {
+      set_error("kf_pushforward: an interval of trajectory %lld needs more than max_steps = %lld Runge-Kutta steps of dt0 = %g: the "
+                "pushed-forward (A, Q) would be truncated", (long long)n, (long long)o->max_steps, o->dt0);
+      return CDKF_EINVAL;
+    }
   return CDKF_OK;
 }
 

@@ -284,6 +284,19 @@ void close_all(cdkf_rdv* r) {
 
 constexpr int kIoTimeoutMs = 600000;  // a peer that says nothing for ten minutes is gone
 
+// The hello a rank sends carries a per-job nonce: CDKF_RDV_NONCE from the environment (any 63-bit number the launcher hands to every
+// rank), else one derived from the rendezvous port and the world size -- so that a stray connection, or a rank of ANOTHER job whose
+// store happens to sit on the same port, is turned away with a NACK instead of taking a slot (and the run's sums with it).
+int64_t rdv_nonce(int port, int world) {
+  if (const char* e = std::getenv("CDKF_RDV_NONCE")) return (int64_t)std::strtoll(e, nullptr, 0);
+  return (int64_t)0x63646b66 * 1000003 + (int64_t)port * 4099 + world;
+}
+struct RdvHello {
+  int32_t magic, rank, world, pad;
+  int64_t nonce;
+};
+constexpr int32_t kRdvMagic = 0x43444b52;  // "CDKR"
+
 }  // namespace
 
 extern "C" int cdkf_rdv_create(cdkf_rdv** out, const char* addr, int port, int rank, int world, int timeout_ms) {
@@ -311,9 +324,10 @@ extern "C" int cdkf_rdv_create(cdkf_rdv** out, const char* addr, int port, int r
   }
   const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(timeout_ms);
   const int one = 1;
+  const int64_t nonce = rdv_nonce(port, world);
   if (rank == 0) {
     r->listen_fd = ::socket(AF_INET, SOCK_STREAM, 0);
-    ::setsockopt(r->listen_fd, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
+    if (r->listen_fd >= 0) ::setsockopt(r->listen_fd, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
     if (r->listen_fd < 0 || ::bind(r->listen_fd, res->ai_addr, res->ai_addrlen) != 0 || ::listen(r->listen_fd, world) != 0) {
       set_error("cdkf_rdv_create: rank 0 cannot listen on %s:%d: %s", addr, port, std::strerror(errno));
       freeaddrinfo(res);
@@ -335,13 +349,19 @@ extern "C" int cdkf_rdv_create(cdkf_rdv** out, const char* addr, int port, int r
       const int fd = ::accept(r->listen_fd, nullptr, nullptr);
       if (fd < 0) continue;
       ::setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
-      int32_t hello[2] = {0, 0};
-      if (!recv_all(fd, hello, sizeof(hello), 10000) || hello[1] != world || hello[0] <= 0 || hello[0] >= world ||
-          r->peers[hello[0]] >= 0) {
-        ::close(fd);  // not one of ours (or a duplicate): ignore
+      // the hello must arrive within what is left of the deadline, two seconds at most: an idle stray connection cannot stall the
+      // accept loop for long; whoever it is gets an answer -- ACK (1) or NACK (0) -- so a refused rank fails at once, with a message
+      RdvHello hello{};
+      const int hello_ms = (int)(left < 2000 ? left : 2000);
+      const bool ok = recv_all(fd, &hello, sizeof(hello), hello_ms) && hello.magic == kRdvMagic && hello.nonce == nonce &&
+                      hello.world == world && hello.rank > 0 && hello.rank < world && r->peers[hello.rank] < 0;
+      const int32_t answer = ok ? 1 : 0;
+      (void)send_all(fd, &answer, sizeof(answer));
+      if (!ok) {
+        ::close(fd);  // not one of ours, another job's, or a duplicate rank
         continue;
       }
-      r->peers[hello[0]] = fd;
+      r->peers[hello.rank] = fd;
       ++got;
     }
   } else {
@@ -361,9 +381,15 @@ extern "C" int cdkf_rdv_create(cdkf_rdv** out, const char* addr, int port, int r
       return CDKF_EHIP;
     }
     ::setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
-    const int32_t hello[2] = {rank, world};
-    if (!send_all(fd, hello, sizeof(hello))) {
-      set_error("cdkf_rdv_create: rank %d lost rank 0: %s", rank, std::strerror(errno));
+    const RdvHello hello{kRdvMagic, rank, world, 0, nonce};
+    int32_t answer = -1;
+    const auto left = std::chrono::duration_cast<std::chrono::milliseconds>(deadline - std::chrono::steady_clock::now()).count();
+    if (!send_all(fd, &hello, sizeof(hello)) || !recv_all(fd, &answer, sizeof(answer), (int)(left > 1000 ? left : 1000)) || answer != 1) {
+      if (answer == 0)
+        set_error("cdkf_rdv_create: rank 0 at %s:%d refused rank %d of %d (a duplicate rank, another world size, or another job's "
+                  "rendezvous: CDKF_RDV_NONCE / CDKF_RDV_PORT)", addr, port, rank, world);
+      else
+        set_error("cdkf_rdv_create: rank %d lost rank 0: %s", rank, std::strerror(errno));
       ::close(fd);
       freeaddrinfo(res);
       delete r;

@@ -121,7 +121,7 @@ struct W40Lin {
   using V4 = typename Tile::V4;
   static constexpr int LDY = W::LDY;
   static constexpr int NB = (D + 15) / 16;  // blocks of sixteen rows / columns
-  static_assert(D % 8 == 0, "panels of eight or sixteen columns");
+  static_assert(D % 4 == 0, "panels of four, eight, twelve or sixteen columns");
 
   // L[i][c0 + c] -= sum_{k < c0} L[i][k] L[c0 + c][k]  for the rows i >= c0 (the augmented row D included), c < 16: the left-looking
   // update of the panel of columns from c0 (a multiple of sixteen), for NS systems at once (independent accumulator chains)

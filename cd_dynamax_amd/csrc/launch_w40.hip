@@ -5,11 +5,14 @@
 
 namespace cdkf {
 
-// Lorenz-96 with H = I at state_dim 40 (BASELINE config 4): wavefront-per-trajectory sweep (cdkf_wave40_kernels.h)
+// Lorenz-96 with H = I at state_dim 40 (BASELINE config 4) -- and at the other state dimensions the kernels are instantiated for (every
+// multiple of four from 12 to 40 (the index table's offset fields end there): the 16-wide panels of the factorisation / solves take a last panel of 4, 8 or 12 columns):
+// wavefront-per-trajectory sweep (cdkf_wave40_kernels.h)
+static bool wave40_dim(int d) { return d >= 12 && d <= 40 && d % 4 == 0; }
 bool wave40_shape(const cdkf_model* mdl, const cdkf_opts* o) {
   if (getenv("CDKF_NO_WAVE40")) return false;  // A/B and tests: keep the workgroup kernels
   const int d = mdl->state_dim;
-  if (mdl->drift_kind != CDKF_DRIFT_LORENZ96 || d != 40 || mdl->emission_dim != d || !emission_is_selection(mdl)) return false;
+  if (mdl->drift_kind != CDKF_DRIFT_LORENZ96 || !wave40_dim(d) || mdl->emission_dim != d || !emission_is_selection(mdl)) return false;
   if (o->num_iter != 1 || o->forecast || o->state_order == CDKF_ORDER_ZEROTH || o->solver != CDKF_SOLVER_DOPRI5 || o->adaptive)
     return false;
   for (int r = 0; r < d; ++r)
@@ -18,9 +21,8 @@ bool wave40_shape(const cdkf_model* mdl, const cdkf_opts* o) {
   return true;
 }
 
-template <typename R>
-int launch_wave40(const WgArgs<R>& a, hipStream_t stream, bool backward) {
-  constexpr int D = 40;
+template <typename R, int D>
+static int launch_wave40_d(const WgArgs<R>& a, hipStream_t stream, bool backward) {
   if (backward) {
     if (once_per_device([] { return wg_raise_lds_cap(ekf_smoother_wave_l96_kernel<R, D>); })) return CDKF_EHIP;
     const size_t lds = sizeof(R) * (size_t)wave40_smoother_lds_reals<D>() + 64;
@@ -47,6 +49,18 @@ int launch_wave40(const WgArgs<R>& a, hipStream_t stream, bool backward) {
   hipLaunchKernelGGL((ekf_filter_wave_l96_kernel<R, D>), dim3(blocks), dim3(64 * W40<D>::kWaves), lds, stream, b);
   CDKF_HIP_CHECK(hipGetLastError());
   return CDKF_OK;
+}
+
+template <typename R>
+int launch_wave40(const WgArgs<R>& a, hipStream_t stream, bool backward) {
+  switch (a.d) {
+#define CDKF_W40_CASE(D_) \
+  case D_: return launch_wave40_d<R, D_>(a, stream, backward);
+    CDKF_W40_CASE(12) CDKF_W40_CASE(16) CDKF_W40_CASE(20) CDKF_W40_CASE(24) CDKF_W40_CASE(28) CDKF_W40_CASE(32) CDKF_W40_CASE(36)
+    CDKF_W40_CASE(40)
+#undef CDKF_W40_CASE
+    default: set_error("wavefront-per-trajectory Lorenz-96 sweep: state_dim %d is not instantiated", a.d); return CDKF_EUNSUPPORTED;
+  }
 }
 
 template int launch_wave40<float>(const WgArgs<float>&, hipStream_t, bool);

@@ -158,8 +158,10 @@ static int wg_prepare(WgArgs<R>& a, R** dev_block, ParamSlot** slot_out, const c
 static int wg_threads(int d) {
   if (const char* e = getenv("CDKF_WG_THREADS")) return atoi(e);  // debugging aid
   // d >= 32: 512 threads (two wavefronts per SIMD hide each other's LDS latency, and 4 owned entries per thread
-  // keep the six RK slopes inside the 256 architectural VGPRs)
-  return d * d >= 1024 ? 512 : (d * d >= 256 ? 128 : 64);
+  // keep the six RK slopes inside the 256 architectural VGPRs); d = 23 .. 31: 256 threads for the same reason -- with 128 threads a
+  // thread owned up to 8 entries, and that instantiation (EPT = 8: 48 slopes per thread in fp64) both crawled and returned NaN
+  // (scripts/dbg_wg28.py: Lorenz-96 d = 24, 28)
+  return d * d >= 1024 ? 512 : (d * d >= 512 ? 256 : (d * d >= 256 ? 128 : 64));
 }
 // the MLP's hidden layers give every phase of the right-hand side >= h1*d independent entries
 static int wg_threads(const cdkf_model* mdl) {

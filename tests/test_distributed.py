@@ -341,3 +341,50 @@ def test_rendezvous_argument_and_timeout_errors():
     rc = L.cdkf_rdv_create(C.byref(h), b"127.0.0.1", port, 0, 2, 300)
     assert rc != 0 and b"ranks arrived" in L.cdkf_last_error()
     assert L.cdkf_ll_allreduce(None, None, 1, None) == _ffi.CDKF_EINVAL
+
+
+def test_rendezvous_turns_strangers_and_duplicates_away():
+    """Rank 0 answers every hello: a connection that does not carry this job's nonce (a stray client, another job whose store sits on
+    the same port) and a second process claiming a rank that is taken are NACKed -- they fail at once with a message instead of
+    taking a slot or waiting out the I/O timeout -- and the real ranks still meet (round-2 advisor finding)."""
+    import ctypes as C
+    import struct
+    import threading
+    import time
+    from cd_dynamax_amd import _ffi
+    L = _ffi.lib()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    world = 3
+    res = {}
+
+    def join(name, rank, timeout_ms=8000):
+        h = C.c_void_p()
+        rc = L.cdkf_rdv_create(C.byref(h), b"127.0.0.1", port, rank, world, timeout_ms)
+        res[name] = (rc, L.cdkf_last_error().decode() if rc else "", h)
+
+    t0 = threading.Thread(target=join, args=("r0", 0))
+    t0.start()
+    time.sleep(0.3)
+    # a stranger: right size, wrong nonce -> NACK (0), connection closed, no slot taken
+    with socket.create_connection(("127.0.0.1", port), timeout=5) as c:
+        c.sendall(struct.pack("<iiiiq", 0x43444B52, 1, world, 0, 12345))
+        assert struct.unpack("<i", c.recv(4))[0] == 0
+    # a client that says nothing: dropped after two seconds at most, the accept loop goes on
+    idle = socket.create_connection(("127.0.0.1", port), timeout=5)
+    t1 = threading.Thread(target=join, args=("r1", 1))
+    t1.start()
+    t1.join(timeout=10)
+    assert res["r1"][0] == 0, res["r1"]
+    # a second rank 1: refused, with a message
+    join("dup", 1, 3000)
+    assert res["dup"][0] != 0 and "refused" in res["dup"][1], res["dup"]
+    t2 = threading.Thread(target=join, args=("r2", 2))
+    t2.start()
+    t2.join(timeout=10)
+    t0.join(timeout=10)
+    idle.close()
+    assert res["r0"][0] == 0 and res["r2"][0] == 0, res
+    for k in ("r0", "r1", "r2"):
+        L.cdkf_rdv_destroy(res[k][2])

@@ -795,6 +795,16 @@ def test_loglik_gradient_reverse_sweep_on_the_lane_grid(hip_lib, tmp_path):
     for N, T, span in ((13, 50, 0.3), (6, 12, 0.6), (5, 4, 2.4), (3, 1, 0.01), (2, 2, 0.3), (1, 9, 0.2)):
         t = o.irregular_times(rng, N, T, span)
         check(mdl, t, o.simulate(mdl, t, rng))
+    # intervals of about a thousand steps (dt0 = 1e-3 over gaps around 1): beyond 48 x 16 steps the coarse step starts are spaced wider
+    # than the window, and a segment is walked back in several refills of the window (two-level checkpoints, cdkf_lpe_grad_kernels.h)
+    tl = o.irregular_times(rng, 3, 3, 2.0)
+    assert np.diff(tl, axis=1).max() > 0.8
+    yl = o.simulate(mdl, tl, rng)
+    ll_ref, g_ref = o.ekf_loglik_grad(mdl, tl, yl, dt0=1e-3)
+    ll_l, g_l = cd.cdnlgssm_loglik_and_grad(P, yl, tl[..., None], cd.EKFHyperParams(diffeqsolve_settings={"dt0": 1e-3}))
+    assert hip_lib.cdkf_last_kernel().startswith(b"grad_lpe_l63_kernel<double")
+    np.testing.assert_allclose(ll_l, ll_ref, rtol=1e-10)
+    assert np.max(np.abs(flat(g_l) - g_ref) / (np.abs(g_ref).max(axis=0, keepdims=True) + 1e-30)) < 1e-8
     t = o.irregular_times(rng, 9, 30, 0.9)
     assert np.diff(t, axis=1).max() > 0.05
     y = o.simulate(mdl, t, rng)

@@ -207,6 +207,43 @@ def test_c5_full_slice_properties(hip_lib):
         a.free()
 
 
+@pytest.mark.parametrize("d", [12, 16, 20, 28, 36])
+def test_lorenz96_wavefront_kernels_other_state_dimensions(hip_lib, d, monkeypatch):
+    """The wavefront-per-trajectory Lorenz-96 sweeps (config 4's kernels) at the other state dimensions they are instantiated for --
+    every multiple of four from 12 to 40: the sixteen-wide panels of the factorisation and the triangular solves end in a panel of
+    4, 8 or 12 columns (extended_kalman_filter / _smoother are shape-generic, inference_ekf.py:202-326, 450-539).  Filter (all four
+    moment arrays) and smoother against the oracle, dense noise matrices, intervals of one to three steps; against the workgroup
+    kernels they replace (CDKF_NO_WAVE40=1); fp32."""
+    rng = np.random.default_rng(100 + d)
+
+    def spd(n, s):
+        A = rng.standard_normal((n, n))
+        return A @ A.T / n * s + 0.3 * np.eye(n)
+
+    mdl = o.Model(o.Lorenz96Drift(8.0), np.eye(d) + 0.1 * rng.standard_normal((d, d)), spd(d, 0.5), np.eye(d), np.zeros(d), spd(d, 0.7),
+                  8.0 + rng.standard_normal(d), spd(d, 1.0))
+    N, T = 5, 12
+    t = o.irregular_times(rng, N, T, 0.015 * T)
+    y = o.simulate(mdl, t, rng)
+    P = params_from(mdl)
+    ref = o.ekf_smoother(mdl, t, y)
+    post = cd.cdnlgssm_smoother(P, y, t[..., None])
+    assert _ffi.lib().cdkf_last_kernel().decode().startswith("ekf_smoother_wave_l96_kernel<double, %d>" % d)
+    for k in ("filtered_means", "filtered_covariances", "smoothed_means", "smoothed_covariances"):
+        assert relerr(getattr(post, k), ref[k]) < 1e-9, k
+    assert relerr(post.marginal_loglik, ref["marginal_loglik"]) < 1e-10
+    flt = cd.cdnlgssm_filter(P, y, t[..., None])
+    assert _ffi.lib().cdkf_last_kernel().decode().startswith("ekf_filter_wave_l96_kernel<double, %d>" % d)
+    _check(flt, o.ekf_filter(mdl, t, y), 1e-9)
+    flt32 = cd.cdnlgssm_filter(P, y.astype(np.float32), t[..., None])
+    assert relerr(flt32.filtered_means, ref["filtered_means"]) < 5e-4
+    monkeypatch.setenv("CDKF_NO_WAVE40", "1")
+    wg = cd.cdnlgssm_smoother(P, y, t[..., None])
+    assert _ffi.lib().cdkf_last_kernel().decode().startswith("ekf_smoother_wg_kernel")
+    monkeypatch.delenv("CDKF_NO_WAVE40")
+    assert relerr(post.smoothed_covariances, wg.smoothed_covariances) < 1e-9
+
+
 def test_lorenz96_d40_backward_sweep_kernels_agree(hip_lib, monkeypatch):
     """Config 4's smoother: the wavefront-per-trajectory backward sweep (ekf_smoother_wave_l96_kernel) against the oracle at a
     batch that does not fill its last workgroup, against the workgroup kernel it replaced (CDKF_WG_BACKWARD=1), in fp32, and at
