@@ -1,5 +1,6 @@
 // cdkf_wave40_kernels.h -- wavefront-per-trajectory EKF filter sweep AND smoother backward sweep for the Lorenz-96 model at state
-// dimensions 9 .. 48 (BASELINE config 4: d = m = 40), emission = the identity on the state (H = I, any symmetric R).
+// dimensions 12 .. 40 (BASELINE config 4: d = m = 40), emission = a selection of state components (H = I, or any m <= d rows of it
+// in any order; any symmetric R).
 //
 // The workgroup-per-trajectory kernel (cdkf_wg2_kernels.h) spends a d = 40 observation step in ~35 barrier-separated phases with a
 // few dozen flops per thread in each: 512 threads wait on each other most of the time (SQ_WAIT_ANY 69 % of the wave cycles,
@@ -29,7 +30,7 @@
 //    W40Lin, G P_s per Runge-Kutta stage as 3 x 3 tiles on the matrix cores.
 //  * Outputs stream from the LDS images (full d x d rows, coalesced).
 //
-// Scope: drift Lorenz-96, H = I (m = d), num_iter = 1, state_order first / second (the same for this drift: grad(div f) = 0), fixed-
+// Scope: drift Lorenz-96, H = rows of the identity (m <= d), num_iter = 1, state_order first / second (the same for this drift: grad(div f) = 0), fixed-
 // step Dormand-Prince, no forecast.  Everything else stays on cdkf_wg2_kernels.h; CDKF_NO_WAVE40=1 forces that (A/B, tests).
 #pragma once
 #include "cdkf_wave8_kernels.h"
@@ -55,8 +56,10 @@ struct W40 {
   static constexpr int kWaves = 4;
   // per workgroup: (L Qc L^T) and R entries in ownership order [s][lane], then the index table of the owned entries (two 32-bit
   // words per entry: (i, j), and the entry's three offsets in the update's images), sized for 4-byte reals
-  static constexpr int SHQ = 2 * 64 * EPL, SH = SHQ + 2 * 64 * EPL;
-  // table word A: i | j << 8; word B: (i LDY + j) | (j LDY + i) << 11 | (rs(j) + i) << 22
+  static constexpr int SHQ = 2 * 64 * EPL, SHT = SHQ + 2 * 64 * EPL, SH = SHT + 64;
+  // table word A: i | j << 8 | (state component i observed) << 16 | (j observed) << 17;
+  // word B: (i LDY + j) | (j LDY + i) << 11 | (rs(j) + i) << 22;  behind the tables: obs[i] = the emission row that observes state
+  // component i, or -1 (64 words)
   static_assert(48 * (D + 2) < 2048 && 2 * ((D + 2) / 2) * ((D + 1) / 2 + 1) < 1024, "offsets fit their fields");
   __host__ __device__ static constexpr bool owned(int s, int lane) { return lane + 64 * s < NP; }
 };
@@ -460,11 +463,27 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave_l96_kernel(const WgArg
   //  registers are what the scheduler needs to keep LDS reads in flight)
   unsigned* tabA = reinterpret_cast<unsigned*>(shQ + W::SHQ);
   unsigned* tabB = tabA + 64 * EPL;
+  int* obs = reinterpret_cast<int*>(shQ + W::SHT);
+  const int M = a.m;
   R Pe[EPL];
   {
     const R* P0 = a.par + a.o_P0;
     const R* LQL = a.par + a.o_LQL;
     const R* Rm = a.par + a.o_R;
+    // The emission selects M <= D state components (every row of H a unit vector, no two alike, no bias: wave40_shape).  The update
+    // runs in STATE coordinates on the order-D system  S_full = [P + R on the observed components; the identity on the others]  with
+    // zero innovation and zero right-hand-side rows there: its factor is [chol(S); I], its solution [S^-1 H P; 0] -- the same numbers
+    // as the M x M system of inference_ekf.py:153-199, with M = D and H = I the system this kernel was written for.
+    if (wave == 0) {
+      int r_obs = -1;
+      if (lane < D) {
+        const R* Hm = a.par + a.o_H;
+        for (int r = 0; r < M; ++r)
+          if (Hm[r * D + lane] != R(0)) r_obs = r;
+      }
+      obs[lane] = r_obs;
+      wave_sync();
+    }
 #pragma unroll
     for (int s = 0; s < EPL; ++s) {
       const int e = lane + 64 * s;
@@ -477,9 +496,10 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave_l96_kernel(const WgArg
       const int j = own ? i + (e - rs) : i;
       Pe[s] = own ? R(0.5) * (P0[i * D + j] + P0[j * D + i]) : R(0);
       if (wave == 0) {
+        const int oi = obs[i], oj = obs[j];
         shQ[64 * s + lane] = own ? LQL[i * D + j] : R(0);
-        shR[64 * s + lane] = own ? Rm[i * D + j] : R(0);
-        tabA[64 * s + lane] = (unsigned)i | (unsigned)j << 8;
+        shR[64 * s + lane] = !own ? R(0) : ((oi >= 0 && oj >= 0) ? Rm[oi * M + oj] : (i == j ? R(1) : R(0)));
+        tabA[64 * s + lane] = (unsigned)i | (unsigned)j << 8 | (unsigned)(oi >= 0) << 16 | (unsigned)(oj >= 0) << 17;
         tabB[64 * s + lane] = (unsigned)(i * LDY + j) | (unsigned)(j * LDY + i) << 11 | (unsigned)(W::rs(j) + i) << 22;
       }
     }
@@ -488,7 +508,7 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave_l96_kernel(const WgArg
   if (n >= a.N) return;  // whole wavefront; no workgroup barrier anywhere below
   // the owned entries' indices come from the table where they are used (registers are for the Runge-Kutta slopes and the panels)
   struct Ent { int i, j; };
-  auto entry = [&](int s) { const unsigned w = tabA[64 * s + lane]; return Ent{(int)(w & 255u), (int)(w >> 8)}; };
+  auto entry = [&](int s) { const unsigned w = tabA[64 * s + lane]; return Ent{(int)(w & 255u), (int)((w >> 8) & 255u)}; };
   struct Off { int y, yt, l; };
   auto offsets = [&](int s) { const unsigned w = tabB[64 * s + lane]; return Off{(int)(w & 2047u), (int)((w >> 11) & 2047u), (int)(w >> 22)}; };
   const bool isrow = lane < D;
@@ -513,7 +533,8 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave_l96_kernel(const WgArg
 
   // ---- streams -----------------------------------------------------------------------------------------------------------
   const R* tp = a.t + n * a.t_sn;
-  const R* yp = a.y + n * a.y_sn + (isrow ? lane : 0) * a.y_si;
+  const int myobs = isrow ? obs[lane] : -1;  // the emission row that observes this lane's state component (-1: none)
+  const R* yp = a.y + n * a.y_sn + (myobs >= 0 ? myobs : 0) * a.y_si;
   R tcur = tp[0];
   R ynext = yp[0];
 
@@ -628,15 +649,17 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave_l96_kernel(const WgArg
       oY[s] = f.y;
       oYT[s] = f.yt;
       if (W::owned(s, lane)) {
-        const R sv = Pe[s] + shR[64 * s + lane];
+        const unsigned wA = tabA[64 * s + lane];
+        const bool obs_i = (wA >> 16) & 1u, obs_j = (wA >> 17) & 1u;
+        const R sv = (obs_i && obs_j) ? Pe[s] + shR[64 * s + lane] : shR[64 * s + lane];
         L1[f.l] = sv;
         L2[f.l] = (f.y == f.yt) ? sv + R(1e-9) : sv;
-        buf[f.y] = Pe[s];
-        buf[f.yt] = Pe[s];
+        buf[f.y] = obs_j ? Pe[s] : R(0);   // row i = right-hand side i = column i of H P in state coordinates: component j of it
+        buf[f.yt] = obs_i ? Pe[s] : R(0);
       }
     }
     if (isrow) {
-      const R v = yk - mj;
+      const R v = (myobs >= 0) ? yk - mj : R(0);
       L1[W::rs(D) + lane] = v;
       L2[W::rs(D) + lane] = v;
       vv[lane] = v;
@@ -652,7 +675,7 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave_l96_kernel(const WgArg
       W40_TICK(0)
       Lin::template cholesky<2>(sys, scr, inv2, rowi, ri, lane, quad, ll.ll, bad W40_TICK_PASS);
     }
-    ll.ll += -0.5 * (double)w40_readlane(quad, D) - 0.5 * D * 1.8378770664093454835606594728112;
+    ll.ll += -0.5 * (double)w40_readlane(quad, D) - 0.5 * M * 1.8378770664093454835606594728112;
 
     // gain: lane c < D solves (L2 L2^T) x = P[:, c] in place in its row of the image (W40Lin::solve).  After the forward pass the
     // image holds Y (row c = column c of Y = L_b^-1 P), after the backward pass X: each is consumed by a rank-d product on the

@@ -5,19 +5,40 @@
 
 namespace cdkf {
 
-// Lorenz-96 with H = I at state_dim 40 (BASELINE config 4) -- and at the other state dimensions the kernels are instantiated for (every
-// multiple of four from 12 to 40 (the index table's offset fields end there): the 16-wide panels of the factorisation / solves take a last panel of 4, 8 or 12 columns):
+// Lorenz-96 observed through H = I at state_dim 40 (BASELINE config 4) -- and through any selection of its components, at every state
+// dimension the kernels are instantiated for (the multiples of four from 12 to 40, where the index table's offset fields end; the
+// 16-wide panels of the factorisation / solves take a last panel of 4, 8 or 12 columns):
 // wavefront-per-trajectory sweep (cdkf_wave40_kernels.h)
 static bool wave40_dim(int d) { return d >= 12 && d <= 40 && d % 4 == 0; }
+// the emission picks m <= d state components: every row of H a unit vector, no two rows alike, no bias (H = I, H = I[:m], every
+// other component, ...)
+static bool emission_selects_components(const cdkf_model* mdl) {
+  const int d = mdl->state_dim, m = mdl->emission_dim;
+  if (m < 1 || m > d) return false;
+  bool taken[64] = {false};
+  for (int r = 0; r < m; ++r) {
+    if (mdl->h_bias[r] != 0.0) return false;
+    int col = -1;
+    for (int j = 0; j < d; ++j) {
+      const double h = mdl->H[r * d + j];
+      if (h == 0.0) continue;
+      if (h != 1.0 || col >= 0) return false;
+      col = j;
+    }
+    if (col < 0 || taken[col]) return false;
+    taken[col] = true;
+  }
+  return true;
+}
 bool wave40_shape(const cdkf_model* mdl, const cdkf_opts* o) {
   if (getenv("CDKF_NO_WAVE40")) return false;  // A/B and tests: keep the workgroup kernels
-  const int d = mdl->state_dim;
-  if (mdl->drift_kind != CDKF_DRIFT_LORENZ96 || !wave40_dim(d) || mdl->emission_dim != d || !emission_is_selection(mdl)) return false;
+  const int d = mdl->state_dim, m = mdl->emission_dim;
+  if (mdl->drift_kind != CDKF_DRIFT_LORENZ96 || !wave40_dim(d) || !emission_selects_components(mdl)) return false;
   if (o->num_iter != 1 || o->forecast || o->state_order == CDKF_ORDER_ZEROTH || o->solver != CDKF_SOLVER_DOPRI5 || o->adaptive)
     return false;
-  for (int r = 0; r < d; ++r)
+  for (int r = 0; r < m; ++r)
     for (int c = 0; c < r; ++c)
-      if (mdl->R[r * d + c] != mdl->R[c * d + r]) return false;  // P - X^T S X is formed as P - Y^T Y + 1e-9 X^T X
+      if (mdl->R[r * m + c] != mdl->R[c * m + r]) return false;  // P - X^T S X is formed as P - Y^T Y + 1e-9 X^T X
   return true;
 }
 

@@ -1,6 +1,7 @@
 // launch_wg.hip -- workgroup-per-trajectory kernels: parameter block upload, LDS sizing, launch.
 #include "cdkf_launch.h"
 #include "cdkf_wg2_kernels.h"
+#include "cdkf_wg_launch.h"
 #include "cdkf_wave8_kernels.h"  // (W8Off / kCkStep for the workspace sizes; the kernel itself is built in launch_w8.hip)
 #include "cdkf_rts1_kernels.h"
 
@@ -177,33 +178,6 @@ static int wg_ept(int d, int threads) {
   return -1;
 }
 
-template <typename R, int EPT>
-static int launch_wg_pair(const WgArgs<R>& a, bool filter, bool smoother, int threads, size_t lds_f, size_t lds_s,
-                          hipStream_t stream) {
-  if (once_per_device([] {
-        return wg_raise_lds_cap(ekf_filter_wg_kernel<R, EPT, false, kDriftAny>) | wg_raise_lds_cap(ekf_filter_wg_kernel<R, EPT, true, kDriftAny>) |
-               wg_raise_lds_cap(ekf_filter_wg_kernel<R, EPT, false, kDriftLorenz96>) | wg_raise_lds_cap(ekf_smoother_wg_kernel<R, EPT>);
-      }))
-    return CDKF_EHIP;
-  if (filter) {
-    const dim3 grid((unsigned)a.N), block(threads);
-    note_kernel("ekf_filter_wg_kernel<%s, %d, %s, ", real_name<R>(), EPT, a.ukf ? "true" : "false");
-    if (a.ukf)
-      hipLaunchKernelGGL((ekf_filter_wg_kernel<R, EPT, true, kDriftAny>), grid, block, lds_f, stream, a);
-    else if (a.kind == kDriftLorenz96)
-      hipLaunchKernelGGL((ekf_filter_wg_kernel<R, EPT, false, kDriftLorenz96>), grid, block, lds_f, stream, a);
-    else
-      hipLaunchKernelGGL((ekf_filter_wg_kernel<R, EPT, false, kDriftAny>), grid, block, lds_f, stream, a);
-    CDKF_HIP_CHECK(hipGetLastError());
-  }
-  if (smoother) {
-    note_kernel("ekf_smoother_wg_kernel<%s, %d>", real_name<R>(), EPT);
-    hipLaunchKernelGGL((ekf_smoother_wg_kernel<R, EPT>), dim3((unsigned)a.N), dim3(threads), lds_s, stream, a);
-    CDKF_HIP_CHECK(hipGetLastError());
-  }
-  return CDKF_OK;
-}
-
 template <typename R>
 static int launch_wg_dispatch(const WgArgs<R>& a, const cdkf_model* mdl, bool smoother, hipStream_t stream, bool filter = true) {
   const int threads = wg_threads(mdl);
@@ -212,8 +186,8 @@ static int launch_wg_dispatch(const WgArgs<R>& a, const cdkf_model* mdl, bool sm
     case 1: return launch_wg_pair<R, 1>(a, filter, smoother, threads, lds_f, lds_s, stream);
     case 2: return launch_wg_pair<R, 2>(a, filter, smoother, threads, lds_f, lds_s, stream);
     case 4: return launch_wg_pair<R, 4>(a, filter, smoother, threads, lds_f, lds_s, stream);
-    case 8: return launch_wg_pair<R, 8>(a, filter, smoother, threads, lds_f, lds_s, stream);
-    case 16: return launch_wg_pair<R, 16>(a, filter, smoother, threads, lds_f, lds_s, stream);
+    case 8:
+    case 16: return launch_wg_pair_wide<R>(a, wg_ept(a.d, threads), filter, smoother, threads, lds_f, lds_s, stream);
     default: set_error("state_dim %d too large for the workgroup kernels", a.d); return CDKF_EUNSUPPORTED;
   }
 }

@@ -244,6 +244,79 @@ def test_lorenz96_wavefront_kernels_other_state_dimensions(hip_lib, d, monkeypat
     assert relerr(post.smoothed_covariances, wg.smoothed_covariances) < 1e-9
 
 
+@pytest.mark.parametrize("d", [46, 48])
+def test_workgroup_kernels_eight_entries_per_thread(hip_lib, d, monkeypatch):
+    """State dimensions 46 .. 64: the workgroup kernels own eight covariance entries per thread.  The -O3 build of that fp64
+    instantiation returned NaN from the second observation on (ROCm 7.2; launch_wg8.hip is built at -O1 since): filter and smoother
+    against the oracle, both precisions."""
+    monkeypatch.setenv("CDKF_NO_WAVE40", "1")
+    rng = np.random.default_rng(d)
+    mdl = lorenz96_model(d, d)
+    N, T = 2, 5
+    t = o.irregular_times(rng, N, T, 0.012 * T)
+    y = o.simulate(mdl, t, rng)
+    P = params_from(mdl)
+    ref = o.ekf_smoother(mdl, t, y)
+    post = cd.cdnlgssm_smoother(P, y, t[..., None])
+    assert _ffi.lib().cdkf_last_kernel().decode().startswith("ekf_smoother_wg_kernel<double, 8>")
+    for k in ("filtered_means", "filtered_covariances", "smoothed_means", "smoothed_covariances"):
+        assert relerr(getattr(post, k), ref[k]) < 1e-9, k
+    assert relerr(post.marginal_loglik, ref["marginal_loglik"]) < 1e-10
+    flt32 = cd.cdnlgssm_filter(P, y.astype(np.float32), t[..., None])
+    assert relerr(flt32.filtered_means, ref["filtered_means"]) < 5e-4
+
+
+@pytest.mark.parametrize("d,sel", [(36, "first20"), (40, "every_other"), (12, "shuffled5"), (24, "single")])
+def test_lorenz96_wavefront_kernels_partial_observation(hip_lib, d, sel, monkeypatch):
+    """The wavefront-per-trajectory Lorenz-96 sweeps when the emission observes only SOME state components (_condition_on is shape-
+    generic, inference_ekf.py:153-199): H = I[:m], every other component, a shuffled handful, a single one -- every row of H a unit
+    vector.  The kernel runs the update in state coordinates on the order-d system [P + R on the observed block; identity elsewhere];
+    the numbers must be those of the m x m system: filter (all four moment arrays, log-likelihood) and smoother against the oracle
+    (1e-9) with a dense symmetric R, against the workgroup kernels (CDKF_NO_WAVE40=1), and in fp32."""
+    rng = np.random.default_rng(300 + d)
+    cols = {"first20": np.arange(20), "every_other": np.arange(0, d, 2), "shuffled5": rng.permutation(d)[:5], "single": np.array([7])}[sel]
+    m = len(cols)
+    H = np.eye(d)[cols]
+
+    def spd(n, s):
+        A = rng.standard_normal((n, n))
+        return A @ A.T / n * s + 0.3 * np.eye(n)
+
+    mdl = o.Model(o.Lorenz96Drift(8.0), np.eye(d), spd(d, 0.5), H, np.zeros(m), spd(m, 0.7), 8.0 + rng.standard_normal(d), spd(d, 1.0))
+    N, T = 5, 14
+    t = o.irregular_times(rng, N, T, 0.015 * T)
+    y = o.simulate(mdl, t, rng)
+    P = params_from(mdl)
+    ref = o.ekf_smoother(mdl, t, y)
+    post = cd.cdnlgssm_smoother(P, y, t[..., None])
+    assert _ffi.lib().cdkf_last_kernel().decode().startswith("ekf_smoother_wave_l96_kernel<double, %d>" % d)
+    for k in ("filtered_means", "filtered_covariances", "smoothed_means", "smoothed_covariances"):
+        assert relerr(getattr(post, k), ref[k]) < 1e-9, k
+    assert relerr(post.marginal_loglik, ref["marginal_loglik"]) < 1e-10
+    flt = cd.cdnlgssm_filter(P, y, t[..., None])
+    assert _ffi.lib().cdkf_last_kernel().decode().startswith("ekf_filter_wave_l96_kernel<double, %d>" % d)
+    _check(flt, o.ekf_filter(mdl, t, y), 1e-9)
+    flt32 = cd.cdnlgssm_filter(P, y.astype(np.float32), t[..., None])
+    assert _ffi.lib().cdkf_last_kernel().decode().startswith("ekf_filter_wave_l96_kernel<float, %d>" % d)
+    assert relerr(flt32.filtered_means, ref["filtered_means"]) < 5e-4
+    monkeypatch.setenv("CDKF_NO_WAVE40", "1")
+    wg = cd.cdnlgssm_filter(P, y, t[..., None])
+    assert _ffi.lib().cdkf_last_kernel().decode().startswith("ekf_filter_wg_kernel")
+    monkeypatch.delenv("CDKF_NO_WAVE40")
+    assert relerr(flt.filtered_covariances, wg.filtered_covariances) < 1e-9
+    np.testing.assert_allclose(flt.marginal_loglik, wg.marginal_loglik, rtol=1e-10)
+    # a non-symmetric R, a bias or a row of H that is not a unit vector keep the workgroup kernels
+    Rn = spd(m, 0.7)
+    if m > 1:
+        Rn[0, 1] += 0.05
+        cd.cdnlgssm_filter(params_from(o.Model(mdl.drift, mdl.L, mdl.Qc, H, np.zeros(m), Rn, mdl.m0, mdl.P0)), y, t[..., None])
+        assert _ffi.lib().cdkf_last_kernel().decode().startswith("ekf_filter_wg_kernel")
+    H2 = H.copy()
+    H2[0, cols[0]] = 0.5
+    cd.cdnlgssm_filter(params_from(o.Model(mdl.drift, mdl.L, mdl.Qc, H2, np.zeros(m), mdl.R, mdl.m0, mdl.P0)), y, t[..., None])
+    assert _ffi.lib().cdkf_last_kernel().decode().startswith("ekf_filter_wg_kernel")
+
+
 def test_lorenz96_d40_backward_sweep_kernels_agree(hip_lib, monkeypatch):
     """Config 4's smoother: the wavefront-per-trajectory backward sweep (ekf_smoother_wave_l96_kernel) against the oracle at a
     batch that does not fill its last workgroup, against the workgroup kernel it replaced (CDKF_WG_BACKWARD=1), in fp32, and at
