@@ -206,5 +206,11 @@ int launch_wave8(const WgArgs<R>& a, hipStream_t stream);
 // reverse sweep (gradient) / smoother backward sweep for state_dim <= 8 (launch_adj.hip, cdkf_adjoint_kernels.h)
 template <typename R, bool MLP, bool SMOOTH = false>
 int launch_adjoint_kernel(const WgArgs<R>& a, R* grad, R* grad_model, hipStream_t stream);
+// reverse sweep (gradient) for larger states, one workgroup per trajectory (launch_adjwg.hip, cdkf_adjoint_wg_kernels.h); scratch:
+// N * adjoint_wg_scratch_reals(d, cap) reals
+bool adjoint_wg_fits(int d, int m, int bytes_per_real);
+long adjoint_wg_scratch_reals(int d, int cap);
+template <typename R>
+int launch_adjoint_wg_kernel(const WgArgs<R>& a, R* grad, R* grad_model, R* scratch, int cap, hipStream_t stream);
 
 }  // namespace cdkf

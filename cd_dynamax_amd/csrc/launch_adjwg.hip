@@ -1,0 +1,30 @@
+// launch_adjwg.hip -- the shape-generic reverse sweep (workgroup per trajectory, cdkf_adjoint_wg_kernels.h) in its own translation unit.
+#include "cdkf_launch.h"
+#include "cdkf_adjoint_wg_kernels.h"
+
+namespace cdkf {
+
+bool adjoint_wg_fits(int d, int m, int bytes_per_real) {
+  return d >= 1 && m >= 1 && d <= 64 && m <= 64 && (size_t)awg_lds_reals(d, m) * bytes_per_real + 64 <= kLdsLimit - 256;
+}
+long adjoint_wg_scratch_reals(int d, int cap) { return awg_scratch_reals(d, cap); }
+
+template <typename R>
+int launch_adjoint_wg_kernel(const WgArgs<R>& a, R* grad, R* grad_model, R* scratch, int cap, hipStream_t stream) {
+  if (!adjoint_wg_fits(a.d, a.m, (int)sizeof(R))) {
+    set_error("reverse sweep: state_dim %d / emission_dim %d need %zu bytes of LDS in fp%d (nine q x q matrices; the limit is q = 41 in "
+              "fp64, 58 in fp32)", a.d, a.m, (size_t)awg_lds_reals(a.d, a.m) * sizeof(R), (int)sizeof(R) * 8);
+    return CDKF_EUNSUPPORTED;
+  }
+  if (once_per_device([] { return wg_raise_lds_cap(&ekf_adjoint_wg_kernel<R>); })) return CDKF_EHIP;
+  const size_t lds = (size_t)awg_lds_reals(a.d, a.m) * sizeof(R) + 64;
+  note_kernel("ekf_adjoint_wg_kernel<%s>", real_name<R>());
+  hipLaunchKernelGGL(ekf_adjoint_wg_kernel<R>, dim3((unsigned)a.N), dim3(kAwgThreads), lds, stream, a, grad, grad_model, scratch,
+                     awg_scratch_reals(a.d, cap), cap);
+  CDKF_HIP_CHECK(hipGetLastError());
+  return CDKF_OK;
+}
+template int launch_adjoint_wg_kernel<float>(const WgArgs<float>&, float*, float*, float*, int, hipStream_t);
+template int launch_adjoint_wg_kernel<double>(const WgArgs<double>&, double*, double*, double*, int, hipStream_t);
+
+}  // namespace cdkf

@@ -331,15 +331,51 @@ int release_grad_workspace() {
   return CDKF_OK;
 }
 
+// beyond the wavefront kernel's shapes: the workgroup-per-trajectory reverse sweep -- Lorenz-96 and linear drifts (for both the mean's
+// second-order term vanishes), fixed steps, as far as its LDS plan goes in fp64 (launch_adjwg.hip)
+static bool adjoint_wg_shape(const cdkf_model* mdl, const cdkf_opts* o) {
+  if (mdl->drift_kind != CDKF_DRIFT_LORENZ96 && mdl->drift_kind != CDKF_DRIFT_LINEAR) return false;
+  if (mdl->emission_kind != 0 || o->adaptive) return false;
+  return wg_shape_available(mdl, 8) && adjoint_wg_fits(mdl->state_dim, mdl->emission_dim, 8);
+}
 bool adjoint_shape_available(const cdkf_model* mdl, const cdkf_opts* o) {
-  if (!wave8_shape(mdl) || !wg_shape_available(mdl, 8) || o->num_iter != 1 || o->forecast) return false;
-  if (o->state_order == CDKF_ORDER_ZEROTH) return false;
-  return true;
+  if (o->num_iter != 1 || o->forecast || o->state_order == CDKF_ORDER_ZEROTH) return false;
+  if (wave8_shape(mdl)) return wg_shape_available(mdl, 8);
+  return adjoint_wg_shape(mdl, o);
+}
+
+// state_dim > 8: forward sweep on the wavefront- (Lorenz-96, launch_w40.hip) or workgroup-per-trajectory filter with all four moment
+// arrays into the workspace, reverse sweep on ekf_adjoint_wg_kernel
+template <typename R>
+static int launch_ekf_grad_adjoint_wg(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll,
+                                      R* grad, R* grad_model, int32_t* status, hipStream_t stream) {
+  WgArgs<R> a{};
+  R* blk = nullptr;
+  std::lock_guard<std::mutex> lock(g_adj_mutex);
+  ParamLease lease(stream);
+  int rc = wg_prepare(a, &blk, &lease.slot, mdl, o, N, T, stream);
+  if (rc) return rc;
+  const size_t nm = (size_t)N * T * mdl->state_dim, nP = nm * mdl->state_dim;
+  int cap = 8;  // step starts kept per replay chunk of an interval (CDKF_ADJ_WG_STARTS)
+  if (const char* e = getenv("CDKF_ADJ_WG_STARTS")) cap = atoi(e) > 0 ? atoi(e) : 8;
+  const size_t nscr = (size_t)N * (size_t)adjoint_wg_scratch_reals(mdl->state_dim, cap);
+  AdjWorkspace& ws = g_adj_ws;
+  if (int wrc = workspace_reserve(ws, (2 * (nm + nP) + nscr) * sizeof(R), stream)) return wrc;
+  R* w = (R*)ws.p;
+  a.t = t; a.y = y; a.ll = ll; a.status = status;
+  a.fm = w; a.fP = w + nm; a.pm = w + nm + nP; a.pP = w + 2 * nm + nP;
+  rc = wave40_shape(mdl, o) ? launch_wave40<R>(a, stream) : launch_wg_dispatch<R>(a, mdl, false, stream);
+  if (!rc) rc = launch_adjoint_wg_kernel<R>(a, grad, grad_model, w + 2 * (nm + nP), cap, stream);
+  CDKF_HIP_CHECK(hipEventRecord(ws.done, stream));
+  ws.in_flight = true;
+  const int rc2 = lease.release();
+  return rc ? rc : rc2;
 }
 
 template <typename R>
 int launch_ekf_grad_adjoint(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll,
                             R* grad, R* grad_model, int32_t* status, hipStream_t stream) {
+  if (!wave8_shape(mdl)) return launch_ekf_grad_adjoint_wg<R>(mdl, o, N, T, t, y, ll, grad, grad_model, status, stream);
   WgArgs<R> a{};
   R* blk = nullptr;
   // the workspace lock first, the parameter slot second: a caller waiting for the workspace holds no slot of the ring

@@ -592,10 +592,13 @@ def _general_model(rng, drift, d, m):
 
 
 @pytest.mark.parametrize("kind,d,m", [("mlp", 8, 4), ("mlp", 5, 3), ("linear", 4, 2), ("lorenz63", 3, 2), ("lorenz96", 6, 3),
-                                      ("lorenz96", 8, 8), ("linear", 1, 1)])
+                                      ("lorenz96", 8, 8), ("linear", 1, 1), ("lorenz96", 12, 5), ("linear", 10, 3), ("lorenz96", 20, 20),
+                                      ("linear", 9, 12)])
 def test_loglik_gradient_all_parameters(hip_lib, kind, d, m):
     """cdnlgssm_loglik_and_grad_all: one forward + one reverse sweep gives d ll / d(every parameter) -- the full pytree
-    jax.grad(marginal_log_prob) returns in the reference -- against the oracle's discrete adjoint (FD-pinned)."""
+    jax.grad(marginal_log_prob) returns in the reference -- against the oracle's discrete adjoint (FD-pinned).  State or emission
+    dimension beyond eight: the workgroup-per-trajectory reverse sweep (ekf_adjoint_wg_kernel; one interval of the grid takes more
+    steps than a replay chunk keeps starts for)."""
     rng = np.random.default_rng(13)
     if kind == "mlp":
         drift = mlp_model(rng, d, m, (24, 40)).drift
@@ -614,6 +617,7 @@ def test_loglik_gradient_all_parameters(hip_lib, kind, d, m):
     ll_ref, g_ref, ex = o.ekf_loglik_grad_adjoint(mdl, t, y, full=True)
     ll, g = cd.cdnlgssm_loglik_and_grad_all(params_from(mdl), y, t[..., None], hyp)
     np.testing.assert_allclose(ll, ll_ref, rtol=1e-10)
+    assert _ffi.lib().cdkf_last_kernel().decode().startswith("ekf_adjoint_wg_kernel<double>") == (max(d, m) > 8)
 
     def close(a, b, name):
         scale = np.abs(b).max() + 1e-300
@@ -643,6 +647,42 @@ def test_loglik_gradient_all_parameters(hip_lib, kind, d, m):
         close(g.dynamics.diffusion_cov.params, ex["Qc"], "Qc (second)")
         close(g.emissions.emission_function.weights, ex["H"], "H (second)")
         close(g.emissions.emission_cov.params, ex["R"], "R (second)")
+
+
+def test_lorenz96_d40_value_and_gradient(hip_lib):
+    """BASELINE config 4's model (Lorenz-96, d = m = 40, H = I) can be trained: value and gradient of the EKF log-likelihood w.r.t. the
+    forcing and every other parameter -- forward sweep on the wavefront kernel (ekf_filter_wave_l96_kernel), reverse sweep on
+    ekf_adjoint_wg_kernel -- against the oracle's discrete adjoint (value_and_grad of marginal_log_prob, ssm_temissions.py:550-568);
+    then with half of the components observed (d = 40, m = 20), the drift block alone, and in fp32."""
+    rng = np.random.default_rng(440)
+    for m in (40, 20):
+        mdl = lorenz96_model(40, m)
+        N, T = 3, 6
+        t = o.irregular_times(rng, N, T, 0.012 * T)
+        t[:, 4:] += 0.035
+        y = o.simulate(mdl, t, rng)
+        P = params_from(mdl)
+        ll_ref, g_ref, ex = o.ekf_loglik_grad_adjoint(mdl, t, y, full=True, state_order="second")
+        ll, g = cd.cdnlgssm_loglik_and_grad_all(P, y, t[..., None])
+        assert _ffi.lib().cdkf_last_kernel().decode().startswith("ekf_adjoint_wg_kernel<double>")
+        np.testing.assert_allclose(ll, ll_ref, rtol=1e-10)
+
+        def close(a, b, name, tol=1e-8):
+            scale = np.abs(b).max() + 1e-300
+            assert np.abs(np.asarray(a) - b).max() < tol * scale, (name, m, np.abs(np.asarray(a) - b).max() / scale)
+
+        close(np.asarray(g.dynamics.drift.forcing if hasattr(g.dynamics.drift, "forcing") else g.dynamics.drift[0]).reshape(N, -1), g_ref, "forcing")
+        close(g.initial.mean.params, ex["m0"], "m0")
+        close(g.initial.cov.params, ex["P0"], "P0")
+        close(g.dynamics.diffusion_cov.params, ex["Qc"], "Qc")
+        close(g.emissions.emission_function.weights, ex["H"], "H")
+        close(g.emissions.emission_cov.params, ex["R"], "R")
+        ll2, gd = cd.cdnlgssm_loglik_and_grad(P, y, t[..., None])
+        np.testing.assert_allclose(ll2, ll_ref, rtol=1e-10)
+        close(np.asarray(gd[0]).reshape(N, -1), g_ref, "forcing (drift block)")
+        ll32, g32 = cd.cdnlgssm_loglik_and_grad(P, y.astype(np.float32), t[..., None])
+        assert _ffi.lib().cdkf_last_kernel().decode().startswith("ekf_adjoint_wg_kernel<float>")
+        close(np.asarray(g32[0]).reshape(N, -1), g_ref, "forcing (fp32)", 2e-3)
 
 
 def test_lorenz63_gradient_all_parameters_on_the_lane_grid(hip_lib, tmp_path):
