@@ -38,6 +38,18 @@ __host__ __device__ inline long awg_scratch_reals(int d, int cap) {
   return 12 * sz + (long)cap * sz + cap;
 }
 
+#ifdef CDKF_AWG_PROFILE  // local diagnostic build: cycles per phase (s_memtime), printed by trajectory 0
+static __device__ long long awg_prof[16];
+#define AWG_TICK(i)                                                  \
+  {                                                                  \
+    const long long awg_now = clock64();                             \
+    if (threadIdx.x == 0 && blockIdx.x == 0) awg_prof[i] += awg_now - awg_last; \
+    awg_last = clock64();                                            \
+  }
+#else
+#define AWG_TICK(i)
+#endif
+
 template <typename R>
 __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArgs<R> a, R* __restrict__ grad, R* __restrict__ grad_model,
                                                                     R* __restrict__ ws, long ws_stride, int cap) {
@@ -77,15 +89,105 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
   R* gR = gm ? gBias + m : nullptr;
 
 #define AWG_FOR(e, cnt) for (int e = tid; e < (cnt); e += NT)
+  // Element-wise passes over a rows x cols matrix: thread = (column, row group) with NT / cols row groups taking the rows in turn -- no
+  // index arithmetic per entry (the maps for cols = d and cols = m are formed once) -- in batches of four rows per thread: the new
+  // values of a batch are formed (LDS / global reads in flight together) before any of them is written; a lone wavefront per SIMD has
+  // nothing else to cover the round trips with.  Every pass over a d x d matrix uses the same map, so an entry of the global scratch
+  // is always read back by the thread that wrote it.
+  struct Map {
+    int j, i0, rs;  // column, first row, row stride; i0 >= rs: the thread sits out
+  };
+  auto make_map = [&](int cols) {
+    Map M;
+    M.rs = fdiv(NT, cols);
+    M.i0 = fdiv(tid, cols);
+    M.j = tid - M.i0 * cols;
+    if (M.i0 >= M.rs) M.i0 = 1 << 20;
+    return M;
+  };
+  const Map map_d = make_map(d), map_m = make_map(m);
+  auto map_for = [&](int cols) { return cols == d ? map_d : (cols == m ? map_m : make_map(cols)); };
+  auto rows2d = [&](int rows, int cols, auto&& value, auto&& store) {
+    const Map M = map_for(cols);
+    for (int ib = M.i0; ib < rows; ib += 4 * M.rs) {
+      R v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = ib + u * M.rs;
+        v[u] = (i < rows) ? value(i, M.j) : R(0);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = ib + u * M.rs;
+        if (i < rows) store(i, M.j, v[u]);
+      }
+    }
+  };
+  // Dense product in 2 x 4 register tiles, one tile per thread: out(i, j, sum_k A(i, k) B(k, j)) for i < rows, j < cols.  Twelve LDS
+  // reads per sixteen multiply-adds (a dot product per entry takes two per multiply-add and waits for each).
+  auto gemm = [&](int rows, int cols, int K, auto&& Aat, auto&& Bat, auto&& out) {
+    const int tr = (rows + 1) >> 1, tc = (cols + 3) >> 2;
+    for (int tile = tid; tile < tr * tc; tile += NT) {
+      const int ti = fdiv(tile, tc), tj = tile - ti * tc;
+      const int i0 = 2 * ti, j0 = 4 * tj;
+      const int i1 = (i0 + 1 < rows) ? i0 + 1 : i0;
+      int jj[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) jj[u] = (j0 + u < cols) ? j0 + u : cols - 1;
+      R acc0[4] = {0, 0, 0, 0}, acc1[4] = {0, 0, 0, 0};
+      int k = 0;
+      for (; k + 2 <= K; k += 2) {
+        const R a00 = Aat(i0, k), a01 = Aat(i0, k + 1), a10 = Aat(i1, k), a11 = Aat(i1, k + 1);
+        R b0[4], b1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          b0[u] = Bat(k, jj[u]);
+          b1[u] = Bat(k + 1, jj[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          acc0[u] = rfma(a01, b1[u], rfma(a00, b0[u], acc0[u]));
+          acc1[u] = rfma(a11, b1[u], rfma(a10, b0[u], acc1[u]));
+        }
+      }
+      if (k < K) {
+        const R a00 = Aat(i0, k), a10 = Aat(i1, k);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const R b = Bat(k, jj[u]);
+          acc0[u] = rfma(a00, b, acc0[u]);
+          acc1[u] = rfma(a10, b, acc1[u]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (j0 + u < cols) {
+          out(i0, j0 + u, acc0[u]);
+          if (i0 + 1 < rows) out(i0 + 1, j0 + u, acc1[u]);
+        }
+    }
+  };
+  // sum_k A(k) B(k), four independent chains
+  auto dot = [&](int K, auto&& Aat, auto&& Bat) {
+    R s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    int k = 0;
+    for (; k + 4 <= K; k += 4) {
+      const R a0 = Aat(k), a1 = Aat(k + 1), a2 = Aat(k + 2), a3 = Aat(k + 3);
+      const R b0 = Bat(k), b1 = Bat(k + 1), b2 = Bat(k + 2), b3 = Bat(k + 3);
+      s0 = rfma(a0, b0, s0);
+      s1 = rfma(a1, b1, s1);
+      s2 = rfma(a2, b2, s2);
+      s3 = rfma(a3, b3, s3);
+    }
+    for (; k < K; ++k) s0 = rfma(Aat(k), Bat(k), s0);
+    return (s0 + s1) + (s2 + s3);
+  };
   // ---- start: H into LDS, accumulators to zero -------------------------------------------------------------------------
   AWG_FOR(e, m * d) {
     const int r = fdiv(e, d), c = e - r * d;
     Hs[r * ld + c] = (par + a.o_H)[e];
   }
-  AWG_FOR(e, d * d) {
-    const int i = fdiv(e, d), j = e - i * d;
-    Pb[i * ld + j] = R(0);
-  }
+  rows2d(d, d, [&](int, int) { return R(0); }, [&](int i, int j, R v) { Pb[i * ld + j] = v; });
   if (tid < 64) mb[tid] = R(0);
   AWG_FOR(e, (int)ntheta) g[e] = R(0);
   if (gm) AWG_FOR(e, (int)awg_model_grad_size(d, m)) gm[e] = R(0);
@@ -95,27 +197,24 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
 
   // ---- drift: dense Jacobian F(x) into a slot, f(x) into fv; x in LDS (synchronised by the caller before AND after) ------------
   auto drift_eval = [&](const R* xv, R* F) {
-    AWG_FOR(e, d * d) {
-      const int i = fdiv(e, d), j = e - i * d;
-      R v;
-      if (lin) {
-        v = th[e];
-      } else {  // Lorenz-96: f_i = (x_{i+1} - x_{i-2}) x_{i-1} - x_i + F
-        const int ip1 = (i + 1 >= d) ? 0 : i + 1, im1 = (i == 0) ? d - 1 : i - 1, im2 = (im1 == 0) ? d - 1 : im1 - 1;
-        v = R(0);
-        if (j == ip1) v += xv[im1];
-        if (j == im2) v -= xv[im1];
-        if (j == im1) v += xv[ip1] - xv[im2];
-        if (j == i) v -= R(1);
-      }
-      F[i * ld + j] = v;
-    }
+    rows2d(d, d,
+           [&](int i, int j) {
+             if (lin) return th[i * d + j];
+             // Lorenz-96: f_i = (x_{i+1} - x_{i-2}) x_{i-1} - x_i + F
+             const int ip1 = (i + 1 >= d) ? 0 : i + 1, im1 = (i == 0) ? d - 1 : i - 1, im2 = (im1 == 0) ? d - 1 : im1 - 1;
+             R v = R(0);
+             if (j == ip1) v += xv[im1];
+             if (j == im2) v -= xv[im1];
+             if (j == im1) v += xv[ip1] - xv[im2];
+             if (j == i) v -= R(1);
+             return v;
+           },
+           [&](int i, int j, R v) { F[i * ld + j] = v; });
     if (tid < d) {
       const int i = tid;
       R f;
       if (lin) {
-        f = th[d * d + i];
-        for (int k = 0; k < d; ++k) f = rfma(th[i * d + k], xv[k], f);
+        f = th[d * d + i] + dot(d, [&](int k) { return th[i * d + k]; }, [&](int k) { return xv[k]; });
       } else {
         const int ip1 = (i + 1 >= d) ? 0 : i + 1, im1 = (i == 0) ? d - 1 : i - 1, im2 = (im1 == 0) ? d - 1 : im1 - 1;
         f = rfma(xv[ip1] - xv[im2], xv[im1], th[0] - xv[i]);
@@ -123,234 +222,245 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
       fv[i] = f;
     }
   };
-  // ---- lower Cholesky factor of the n x n matrix in A (in place, lower triangle), then (L L^T) X = B for the columns of B -------
-  auto chol = [&](R* A, int nn) {
+  // ---- lower Cholesky factors of one or two n x n matrices in lockstep (in place, lower triangles), right-looking with ONE barrier per
+  // column: the trailing update works on the unscaled columns (L_ip L_jp = A_ip A_jp / A_pp), a last pass scales column p by
+  // 1 / sqrt(A_pp).  iv0 / iv1 (LDS vectors) receive 1 / L_pp for the substitutions.
+  auto chol2 = [&](R* A0, R* iv0, R* A1, R* iv1, int nn) {
     for (int p = 0; p < nn; ++p) {
       __syncthreads();
-      const R piv = A[p * ld + p];
-      if (!(piv > R(0))) st |= kStatusNotPd;
-      const R r = R(1) / rsqrt_(piv);
-      __syncthreads();
-      for (int i = p + tid; i < nn; i += NT) A[i * ld + p] = (i == p) ? piv * r : A[i * ld + p] * r;
-      __syncthreads();
-      const int w = nn - p - 1;
-      AWG_FOR(e, w * w) {
-        const int ii = fdiv(e, w), i = p + 1 + ii, j = p + 1 + (e - ii * w);
-        if (j <= i) A[i * ld + j] = rfma(-A[i * ld + p], A[j * ld + p], A[i * ld + j]);
-      }
+      const R p0 = A0[p * ld + p], p1 = A1 ? A1[p * ld + p] : R(1);
+      if (!(p0 > R(0)) || !(p1 > R(0))) st |= kStatusNotPd;
+      const R q0 = R(1) / p0, q1 = R(1) / p1;
+      // rows i > p of the columns p < j <= i  (lane = column j: its multiplier A_jp / A_pp once per column)
+      const int lj = map_for(nn).j;
+      const R mj0 = (lj > p) ? A0[lj * ld + p] * q0 : R(0);
+      const R mj1 = (A1 && lj > p) ? A1[lj * ld + p] * q1 : R(0);
+      rows2d(nn - p - 1, nn,
+             [&](int ii, int j) { const int i = p + 1 + ii; return (j > p && j <= i) ? rfma(-A0[i * ld + p], mj0, A0[i * ld + j]) : R(0); },
+             [&](int ii, int j, R v) { const int i = p + 1 + ii; if (j > p && j <= i) A0[i * ld + j] = v; });
+      if (A1)
+        rows2d(nn - p - 1, nn,
+               [&](int ii, int j) { const int i = p + 1 + ii; return (j > p && j <= i) ? rfma(-A1[i * ld + p], mj1, A1[i * ld + j]) : R(0); },
+               [&](int ii, int j, R v) { const int i = p + 1 + ii; if (j > p && j <= i) A1[i * ld + j] = v; });
     }
     __syncthreads();
-  };
-  auto chol_solve = [&](const R* L, int nn, R* B, int ncols) {  // B [nn][ld], in place; one thread per column
-    if (tid < ncols) {
-      const int c = tid;
-      for (int r = 0; r < nn; ++r) {
-        R w = B[r * ld + c];
-        for (int k = 0; k < r; ++k) w = rfma(-L[r * ld + k], B[k * ld + c], w);
-        B[r * ld + c] = w / L[r * ld + r];
-      }
-      for (int r = nn - 1; r >= 0; --r) {
-        R w = B[r * ld + c];
-        for (int k = r + 1; k < nn; ++k) w = rfma(-L[k * ld + r], B[k * ld + c], w);
-        B[r * ld + c] = w / L[r * ld + r];
-      }
+    if (tid < nn) {
+      iv0[tid] = R(1) / rsqrt_(A0[tid * ld + tid]);
+      if (A1) iv1[tid] = R(1) / rsqrt_(A1[tid * ld + tid]);
     }
     __syncthreads();
+    rows2d(nn, nn, [&](int i, int j) { return (j <= i) ? A0[i * ld + j] * iv0[j] : R(0); }, [&](int i, int j, R v) { if (j <= i) A0[i * ld + j] = v; });
+    if (A1) rows2d(nn, nn, [&](int i, int j) { return (j <= i) ? A1[i * ld + j] * iv1[j] : R(0); }, [&](int i, int j, R v) { if (j <= i) A1[i * ld + j] = v; });
+    __syncthreads();
   };
-  // A <- 0.5 (A + A^T) for a d x d matrix, through a scratch slot
+  // (L L^T) X = B in place for the columns of one or two right-hand-side matrices B [nn][ld] (each with its own factor), both sweeps as
+  // rank-one updates with one barrier per unknown: row k stays unscaled (z_k = L_kk x_k) until its sweep ends
+  auto solve2 = [&](const R* La, const R* iva, R* Ba, int nca, const R* Lb, const R* ivb, R* Bb, int ncb, int nn) {
+    auto sweep = [&](const R* Lx, const R* ivx, R* Bx, int nc, int k, bool fwd) {
+      const int w = fwd ? nn - k - 1 : k, r0 = fwd ? k + 1 : 0;
+      const R xk = Bx[k * ld + map_for(nc).j] * ivx[k];  // the unknown just finished, of this thread's column
+      rows2d(w, nc, [&](int rr, int c) { const int r = r0 + rr; return rfma(-(fwd ? Lx[r * ld + k] : Lx[k * ld + r]), xk, Bx[r * ld + c]); },
+             [&](int rr, int c, R v) { Bx[(r0 + rr) * ld + c] = v; });
+    };
+    auto scale = [&](const R* ivx, R* Bx, int nc) {
+      rows2d(nn, nc, [&](int r, int c) { return Bx[r * ld + c] * ivx[r]; }, [&](int r, int c, R v) { Bx[r * ld + c] = v; });
+    };
+    for (int k = 0; k < nn; ++k) {  // forward: L y = b
+      __syncthreads();
+      sweep(La, iva, Ba, nca, k, true);
+      if (Bb) sweep(Lb, ivb, Bb, ncb, k, true);
+    }
+    __syncthreads();
+    scale(iva, Ba, nca);
+    if (Bb) scale(ivb, Bb, ncb);
+    for (int k = nn - 1; k >= 0; --k) {  // backward: L^T x = y
+      __syncthreads();
+      sweep(La, iva, Ba, nca, k, false);
+      if (Bb) sweep(Lb, ivb, Bb, ncb, k, false);
+    }
+    __syncthreads();
+    scale(iva, Ba, nca);
+    if (Bb) scale(ivb, Bb, ncb);
+    __syncthreads();
+  };
+  // A <- A + 0.5 (T + T^T) for d x d matrices (T fully written and synchronised); A == nullptr: T <- 0.5 (T + T^T) is not needed here
+  auto add_sym = [&](R* A, const R* Tm, bool assign) {
+    rows2d(d, d,
+            [&](int i, int j) {
+              const R sy = R(0.5) * (Tm[i * ld + j] + Tm[j * ld + i]);
+              return assign ? sy : A[i * ld + j] + sy;
+            },
+            [&](int i, int j, R v) {
+              A[i * ld + j] = v;
+            });
+    __syncthreads();
+  };
+  // A <- 0.5 (A + A^T) through a scratch slot
   auto symmetrize = [&](R* A, R* tmp) {
-    AWG_FOR(e, d * d) {
-      const int i = fdiv(e, d), j = e - i * d;
-      tmp[i * ld + j] = R(0.5) * (A[i * ld + j] + A[j * ld + i]);
-    }
+    rows2d(d, d, [&](int i, int j) { return A[i * ld + j]; }, [&](int i, int j, R v) { tmp[i * ld + j] = v; });
     __syncthreads();
-    AWG_FOR(e, d * d) {
-      const int i = fdiv(e, d), j = e - i * d;
-      A[i * ld + j] = tmp[i * ld + j];
-    }
-    __syncthreads();
+    add_sym(A, tmp, true);
   };
 
   // ---- Runge-Kutta stages of one step from (x0, P0s): slopes k_i = (km[i], ksP[i]) -----------------------------------------------
   // stage value i into (xs, Ps): y0 + dt sum_{j < i} a_ij k_j   (own entries of the global slopes)
   auto stage_value = [&](int si, const R* P0s, R* Ps, R dt) {
-    AWG_FOR(e, d * d) {
-      const int i = fdiv(e, d), j = e - i * d;
-      R s = R(0);
-      for (int jj = 0; jj < si; ++jj) s = rfma(a.rk.a[si][jj], ksP[(long)jj * d * d + e], s);
-      Ps[i * ld + j] = rfma(dt, s, P0s[i * ld + j]);
-    }
+    rows2d(d, d,
+            [&](int i, int j) {
+              R s2 = R(0);
+              for (int jj = 0; jj < si; ++jj) s2 = rfma(a.rk.a[si][jj], ksP[(long)jj * d * d + i * d + j], s2);
+              return rfma(dt, s2, P0s[i * ld + j]);
+            },
+            [&](int i, int j, R v) {
+              Ps[i * ld + j] = v;
+            });
     if (tid < d) {
-      R s = R(0);
-      for (int jj = 0; jj < si; ++jj) s = rfma(a.rk.a[si][jj], km[64 * jj + tid], s);
-      xs[tid] = rfma(dt, s, x0[tid]);
+      R s2 = R(0);
+      for (int jj = 0; jj < si; ++jj) s2 = rfma(a.rk.a[si][jj], km[64 * jj + tid], s2);
+      xs[tid] = rfma(dt, s2, x0[tid]);
     }
     __syncthreads();
   };
-  auto stages_fwd = [&](const R* P0s, R* Ps, R* F, R dt) {
+  // (A: a free slot for F Ps)
+  auto stages_fwd = [&](const R* P0s, R* Ps, R* F, R* A, R dt) {
     for (int si = 0; si < nst; ++si) {
       stage_value(si, P0s, Ps, dt);
       drift_eval(xs, F);
       __syncthreads();
-      AWG_FOR(e, d * d) {  // k_P = F Ps + (F Ps)^T + L Qc L^T
-        const int i = fdiv(e, d), j = e - i * d;
-        R sa = R(0), sb = R(0);
-        for (int k = 0; k < d; ++k) {
-          sa = rfma(F[i * ld + k], Ps[k * ld + j], sa);
-          sb = rfma(F[j * ld + k], Ps[k * ld + i], sb);
-        }
-        ksP[(long)si * d * d + e] = (sa + sb) + LQL[e];
-      }
+      gemm(d, d, d, [&](int i, int k) { return F[i * ld + k]; }, [&](int k, int j) { return Ps[k * ld + j]; },
+           [&](int i, int j, R v) { A[i * ld + j] = v; });
       if (tid < d) km[64 * si + tid] = fv[tid];
+      __syncthreads();
+      rows2d(d, d,  // k_P = F Ps + (F Ps)^T + L Qc L^T
+              [&](int i, int j) {
+                return (A[i * ld + j] + A[j * ld + i]) + LQL[i * d + j];
+              },
+              [&](int i, int j, R v) { ksP[(long)si * d * d + i * d + j] = v; });
       __syncthreads();
     }
   };
   // y <- y + dt sum_i b_i k_i  (x0 and the matrix in P0s)
   auto step_end = [&](R* P0s, R dt) {
-    AWG_FOR(e, d * d) {
-      const int i = fdiv(e, d), j = e - i * d;
-      R s = R(0);
-      for (int si = 0; si < nst; ++si) s = rfma(a.rk.b[si], ksP[(long)si * d * d + e], s);
-      P0s[i * ld + j] = rfma(dt, s, P0s[i * ld + j]);
-    }
+    rows2d(d, d,
+            [&](int i, int j) {
+              R s2 = R(0);
+              for (int si = 0; si < nst; ++si) s2 = rfma(a.rk.b[si], ksP[(long)si * d * d + i * d + j], s2);
+              return rfma(dt, s2, P0s[i * ld + j]);
+            },
+            [&](int i, int j, R v) {
+              P0s[i * ld + j] = v;
+            });
     if (tid < d) {
-      R s = R(0);
-      for (int si = 0; si < nst; ++si) s = rfma(a.rk.b[si], km[64 * si + tid], s);
-      x0[tid] = rfma(dt, s, x0[tid]);
+      R s2 = R(0);
+      for (int si = 0; si < nst; ++si) s2 = rfma(a.rk.b[si], km[64 * si + tid], s2);
+      x0[tid] = rfma(dt, s2, x0[tid]);
     }
     __syncthreads();
   };
 
   const R* tp = a.t + n * a.t_sn;
   const R* yp = a.y + n * a.y_sn;
+#ifdef CDKF_AWG_PROFILE
+  long long awg_last = clock64();
+#endif
   for (long k = a.T - 1; k >= 0; --k) {
+    AWG_TICK(0)
     // ================= (1) measurement update + log-likelihood term at k, reversed ===============================================
     R* Pp = slot(1);   // predicted covariance
     R* HP = slot(2);   // H P            [m][d]
-    R* S = slot(3);    // H P H^T + R    [m][m]; later Sbar
+    R* S = slot(3);    // H P H^T + R    [m][m]; later (X Pbar) X^T, then Sbar
     R* L1 = slot(4);   // chol(S); later Kb -> Ub [m][d]
     R* Si = slot(5);   // S^-1; later Sbar H [m][d]
     R* L2 = slot(6);   // chol(sym(S) + 1e-9 I)
     R* X = slot(7);    // (sym(S) + 1e-9 I)^-1 H P   [m][d]
-    R* T1 = slot(8);   // X Pbar         [m][d]
-    AWG_FOR(e, d * d) {
-      const int i = fdiv(e, d), j = e - i * d;
-      Pp[i * ld + j] = (k == 0) ? R(0.5) * ((par + a.o_P0)[i * d + j] + (par + a.o_P0)[j * d + i])
-                                : a.pP[n * a.P_sn + (k - 1) * a.P_sk + (long)e * a.P_si];
-    }
+    R* T1 = slot(8);   // X Pbar [m][d]; later X Ub^T [m][m], then Ub^T H [d][d]
+    rows2d(d, d,
+            [&](int i, int j) {
+              return (k == 0) ? R(0.5) * ((par + a.o_P0)[i * d + j] + (par + a.o_P0)[j * d + i])
+                              : a.pP[n * a.P_sn + (k - 1) * a.P_sk + (long)(i * d + j) * a.P_si];
+            },
+            [&](int i, int j, R v) {
+              Pp[i * ld + j] = v;
+            });
     if (tid < d) x0[tid] = (k == 0) ? (par + a.o_m0)[tid] : a.pm[n * a.m_sn + (k - 1) * a.m_sk + tid * a.m_si];
     __syncthreads();
-    AWG_FOR(e, m * d) {
-      const int r = fdiv(e, d), c = e - r * d;
-      R s = R(0);
-      for (int kk = 0; kk < d; ++kk) s = rfma(Hs[r * ld + kk], Pp[kk * ld + c], s);
-      HP[r * ld + c] = s;
-    }
-    if (tid < m) {
-      R s = hb[tid];
-      for (int kk = 0; kk < d; ++kk) s = rfma(Hs[tid * ld + kk], x0[kk], s);
-      vv[tid] = yp[k * a.y_sk + tid * a.y_si] - s;
-    }
+    gemm(m, d, d, [&](int r, int kk) { return Hs[r * ld + kk]; }, [&](int kk, int c) { return Pp[kk * ld + c]; },
+         [&](int r, int c, R v) { HP[r * ld + c] = v; });
+    if (tid < m)
+      vv[tid] = yp[k * a.y_sk + tid * a.y_si] - (hb[tid] + dot(d, [&](int kk) { return Hs[tid * ld + kk]; }, [&](int kk) { return x0[kk]; }));
     __syncthreads();
-    AWG_FOR(e, m * m) {
-      const int r = fdiv(e, m), c = e - r * m;
-      R s = Rm[e];
-      for (int kk = 0; kk < d; ++kk) s = rfma(HP[r * ld + kk], Hs[c * ld + kk], s);
-      S[r * ld + c] = s;
-    }
+    gemm(m, m, d, [&](int r, int kk) { return HP[r * ld + kk]; }, [&](int kk, int c) { return Hs[c * ld + kk]; },
+         [&](int r, int c, R v) { S[r * ld + c] = v + Rm[r * m + c]; });
     __syncthreads();
-    AWG_FOR(e, m * m) {
-      const int r = fdiv(e, m), c = e - r * m;
-      L1[r * ld + c] = S[r * ld + c];
-      L2[r * ld + c] = R(0.5) * (S[r * ld + c] + S[c * ld + r]) + (r == c ? R(1e-9) : R(0));
-      Si[r * ld + c] = (r == c) ? R(1) : R(0);
-    }
-    AWG_FOR(e, m * d) {
-      const int r = fdiv(e, d), c = e - r * d;
-      X[r * ld + c] = HP[r * ld + c];
-    }
-    chol(L1, m);
-    chol(L2, m);
-    chol_solve(L1, m, Si, m);
-    chol_solve(L2, m, X, d);
+    rows2d(m, m, [&](int r, int c) { return R(0.5) * (S[r * ld + c] + S[c * ld + r]) + (r == c ? R(1e-9) : R(0)); },
+           [&](int r, int c, R v) {
+             L1[r * ld + c] = S[r * ld + c];
+             L2[r * ld + c] = v;
+             Si[r * ld + c] = (r == c) ? R(1) : R(0);
+           });
+    rows2d(m, d, [&](int r, int c) { return HP[r * ld + c]; }, [&](int r, int c, R v) { X[r * ld + c] = v; });
+    AWG_TICK(1)  // loads, H P, S
+    chol2(L1, g1, L2, g2, m);               // (g1, g2: the reciprocal diagonals; free vectors during the update)
+    AWG_TICK(2)  // factorisations
+    solve2(L1, g1, Si, m, L2, g2, X, d, m);
+    AWG_TICK(3)  // S^-1, X
     symmetrize(Pb, T1);
-    AWG_FOR(e, m * d) {  // T1 = X Pbar
-      const int r = fdiv(e, d), c = e - r * d;
-      R s = R(0);
-      for (int kk = 0; kk < d; ++kk) s = rfma(X[r * ld + kk], Pb[kk * ld + c], s);
-      T1[r * ld + c] = s;
-    }
+    gemm(m, d, d, [&](int r, int kk) { return X[r * ld + kk]; }, [&](int kk, int c) { return Pb[kk * ld + c]; },
+         [&](int r, int c, R v) { T1[r * ld + c] = v; });
     if (tid < m) {  // w = S^-1 v;  vbar = X mbar - w
-      R w = R(0), s = R(0);
-      for (int c = 0; c < m; ++c) w = rfma(Si[tid * ld + c], vv[c], w);
-      for (int c = 0; c < d; ++c) s = rfma(X[tid * ld + c], mb[c], s);
+      const R w = dot(m, [&](int c) { return Si[tid * ld + c]; }, [&](int c) { return vv[c]; });
+      const R s2 = dot(d, [&](int c) { return X[tid * ld + c]; }, [&](int c) { return mb[c]; });
       wv[tid] = w;
-      vb[tid] = s - w;
+      vb[tid] = s2 - w;
     }
     __syncthreads();
-    AWG_FOR(e, m * d) {  // Kb = v mbar^T - 2 S (X Pbar)   (cotangent of K^T), over the dead factor L1
-      const int r = fdiv(e, d), c = e - r * d;
-      R s = R(0);
-      for (int kk = 0; kk < m; ++kk) s = rfma(S[r * ld + kk], T1[kk * ld + c], s);
-      L1[r * ld + c] = rfma(R(-2), s, vv[r] * mb[c]);
-    }
+    // Kb = v mbar^T - 2 S (X Pbar)   (cotangent of K^T), over the dead factor L1
+    gemm(m, d, m, [&](int r, int kk) { return S[r * ld + kk]; }, [&](int kk, int c) { return T1[kk * ld + c]; },
+         [&](int r, int c, R v) { L1[r * ld + c] = rfma(R(-2), v, vv[r] * mb[c]); });
     __syncthreads();
     R* Ub = L1;
-    chol_solve(L2, m, Ub, d);  // Ub = (sym(S) + 1e-9 I)^-1 Kb
-    AWG_FOR(e, m * m) {  // Sbar = -(X Pbar) X^T + w w^T / 2 - S^-1 / 2 - sym(X Ub^T), over the dead S
-      const int r = fdiv(e, m), c = e - r * m;
-      R s1 = R(0), s2 = R(0), s3 = R(0);
-      for (int kk = 0; kk < d; ++kk) {
-        s1 = rfma(T1[r * ld + kk], X[c * ld + kk], s1);
-        s2 = rfma(X[r * ld + kk], Ub[c * ld + kk], s2);
-        s3 = rfma(X[c * ld + kk], Ub[r * ld + kk], s3);
-      }
-      const R sbar = -s1 + R(0.5) * wv[r] * wv[c] - R(0.5) * Si[r * ld + c] - R(0.5) * (s2 + s3);
-      S[r * ld + c] = sbar;  // (S itself is dead: Kb has been formed, two barriers ago)
-    }
+    AWG_TICK(4)  // X Pbar, w, vbar, Kb
+    solve2(L2, g2, Ub, d, nullptr, nullptr, nullptr, 0, m);  // Ub = (sym(S) + 1e-9 I)^-1 Kb
+    AWG_TICK(5)  // Ub
+    // Sbar = -(X Pbar) X^T + w w^T / 2 - S^-1 / 2 - sym(X Ub^T): the first product over the dead S, the second over the then dead X Pbar
+    gemm(m, m, d, [&](int r, int kk) { return T1[r * ld + kk]; }, [&](int kk, int c) { return X[c * ld + kk]; },
+         [&](int r, int c, R v) { S[r * ld + c] = v; });
+    __syncthreads();
+    gemm(m, m, d, [&](int r, int kk) { return X[r * ld + kk]; }, [&](int kk, int c) { return Ub[c * ld + kk]; },
+         [&](int r, int c, R v) { T1[r * ld + c] = v; });
     __syncthreads();
     R* Sbar = S;
-    if (gm) {  // model block: dR += Sbar; dH += 2 Sbar (H P) - vbar m^T + Ub P; dbias -= vbar
-      AWG_FOR(e, m * m) {
-        const int r = fdiv(e, m), c = e - r * m;
-        gR[e] += Sbar[r * ld + c];
-      }
-      AWG_FOR(e, m * d) {
-        const int r = fdiv(e, d), c = e - r * d;
-        R s1 = R(0), s2 = R(0);
-        for (int kk = 0; kk < m; ++kk) s1 = rfma(Sbar[r * ld + kk], HP[kk * ld + c], s1);
-        for (int kk = 0; kk < d; ++kk) s2 = rfma(Ub[r * ld + kk], Pp[kk * ld + c], s2);
-        gH[e] += R(2) * s1 - vb[r] * x0[c] + s2;
-      }
+    rows2d(m, m,
+            [&](int r, int c) {
+              return -S[r * ld + c] + R(0.5) * wv[r] * wv[c] - R(0.5) * Si[r * ld + c] - R(0.5) * (T1[r * ld + c] + T1[c * ld + r]);
+            },
+            [&](int r, int c, R v) {
+              Sbar[r * ld + c] = v;
+            });
+    __syncthreads();
+    if (gm) {  // model block: dR += Sbar; dH += 2 Sbar (H P) - vbar m^T + Ub P; dbias -= vbar   (a thread owns the same tiles in both products)
+      rows2d(m, m, [&](int r, int c) { return gR[r * m + c] + Sbar[r * ld + c]; }, [&](int r, int c, R v) { gR[r * m + c] = v; });
+      gemm(m, d, m, [&](int r, int kk) { return Sbar[r * ld + kk]; }, [&](int kk, int c) { return HP[kk * ld + c]; },
+           [&](int r, int c, R v) { gH[r * d + c] += R(2) * v - vb[r] * x0[c]; });
+      gemm(m, d, d, [&](int r, int kk) { return Ub[r * ld + kk]; }, [&](int kk, int c) { return Pp[kk * ld + c]; },
+           [&](int r, int c, R v) { gH[r * d + c] += v; });
       if (tid < m) gBias[tid] -= vb[tid];
     }
-    R* SH = Si;  // Sbar H [m][d], over the dead S^-1 (every thread is past its last read of it: the barrier above)
-    AWG_FOR(e, m * d) {
-      const int r = fdiv(e, d), c = e - r * d;
-      R s = R(0);
-      for (int kk = 0; kk < m; ++kk) s = rfma(Sbar[r * ld + kk], Hs[kk * ld + c], s);
-      SH[r * ld + c] = s;
-    }
+    R* SH = Si;  // Sbar H [m][d], over the dead S^-1
+    gemm(m, d, m, [&](int r, int kk) { return Sbar[r * ld + kk]; }, [&](int kk, int c) { return Hs[kk * ld + c]; },
+         [&](int r, int c, R v) { SH[r * ld + c] = v; });
+    // Pbar <- Pbar + sym(Ub^T H) + H^T Sbar H
+    gemm(d, d, m, [&](int i, int kk) { return Ub[kk * ld + i]; }, [&](int kk, int j) { return Hs[kk * ld + j]; },
+         [&](int i, int j, R v) { T1[i * ld + j] = v; });
     __syncthreads();
-    AWG_FOR(e, d * d) {  // Pbar <- Pbar + sym(Ub^T H) + H^T Sbar H
-      const int i = fdiv(e, d), j = e - i * d;
-      R s1 = R(0), s2 = R(0), s3 = R(0);
-      for (int r = 0; r < m; ++r) {
-        s1 = rfma(Ub[r * ld + i], Hs[r * ld + j], s1);
-        s2 = rfma(Ub[r * ld + j], Hs[r * ld + i], s2);
-        s3 = rfma(Hs[r * ld + i], SH[r * ld + j], s3);
-      }
-      Pb[i * ld + j] += R(0.5) * (s1 + s2) + s3;
-    }
+    gemm(d, d, m, [&](int i, int kk) { return Hs[kk * ld + i]; }, [&](int kk, int j) { return SH[kk * ld + j]; },
+         [&](int i, int j, R v) { Pb[i * ld + j] += v; });
     R mbn = R(0);
-    if (tid < d) {  // mbar <- mbar - H^T vbar
-      R s = R(0);
-      for (int r = 0; r < m; ++r) s = rfma(Hs[r * ld + tid], vb[r], s);
-      mbn = mb[tid] - s;
-    }
+    if (tid < d) mbn = mb[tid] - dot(m, [&](int r) { return Hs[r * ld + tid]; }, [&](int r) { return vb[r]; });  // mbar <- mbar - H^T vbar
     __syncthreads();
     if (tid < d) mb[tid] = mbn;
-    __syncthreads();
+    add_sym(Pb, T1, false);
+    AWG_TICK(6)  // Sbar, model block, Pbar, mbar
     if (k == 0) break;
 
     // ================= (2) predict k-1 -> k: the Runge-Kutta steps of the interval, reversed ========================================
@@ -367,17 +477,15 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
     }
     R* P0s = slot(1);  // start of the step in hand
     R* Ps = slot(2);   // stage value
-    R* Lt = slot(3);   // cotangent of the stage slope before / after symmetrisation
-    R* Lam = slot(4);
+    R* Lt = slot(3);   // cotangent of the stage slope before symmetrisation
+    R* Lam = slot(4);  // ... and after
     R* F = slot(5);
-    R* G = slot(6);    // 2 Lam Ps (linear drift: its weight gradient)
+    R* G = slot(6);    // F Ps (forward) / Lam F (reverse)
     for (long cs = ((Ssteps - 1) / cap) * cap; cs >= 0; cs -= cap) {
       const long ce = (cs + cap < Ssteps) ? cs + cap : Ssteps;
       // replay the interval from the filtered moments at k-1 up to the last start of this chunk, keeping the chunk's starts
-      AWG_FOR(e, d * d) {
-        const int i = fdiv(e, d), j = e - i * d;
-        P0s[i * ld + j] = a.fP[n * a.P_sn + (k - 1) * a.P_sk + (long)e * a.P_si];
-      }
+      rows2d(d, d, [&](int i, int j) { return a.fP[n * a.P_sn + (k - 1) * a.P_sk + (long)(i * d + j) * a.P_si]; },
+             [&](int i, int j, R v) { P0s[i * ld + j] = v; });
       if (tid < d) x0[tid] = a.fm[n * a.m_sn + (k - 1) * a.m_sk + tid * a.m_si];
       __syncthreads();
       {
@@ -386,15 +494,12 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
           const R dt = tnext - tprev;
           if (s >= cs) {
             R* sv = starts + (s - cs) * sz;
-            AWG_FOR(e, d * d) {
-              const int i = fdiv(e, d), j = e - i * d;
-              sv[e] = P0s[i * ld + j];
-            }
+            rows2d(d, d, [&](int i, int j) { return P0s[i * ld + j]; }, [&](int i, int j, R v) { sv[i * d + j] = v; });
             if (tid < d) sv[(long)d * d + tid] = x0[tid];
             if (tid == 0) dts[s - cs] = dt;
           }
           if (s + 1 < ce) {
-            stages_fwd(P0s, Ps, F, dt);
+            stages_fwd(P0s, Ps, F, G, dt);
             step_end(P0s, dt);
           }
           tprev = rmin(tnext, t1);
@@ -405,51 +510,42 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
       __syncthreads();
       for (long s = ce - 1; s >= cs; --s) {
         const R* sv = starts + (s - cs) * sz;
-        AWG_FOR(e, d * d) {  // (each thread reads back the entries it wrote)
-          const int i = fdiv(e, d), j = e - i * d;
-          P0s[i * ld + j] = sv[e];
-        }
+        rows2d(d, d, [&](int i, int j) { return sv[i * d + j]; },  // (each thread reads back the entries it wrote)
+               [&](int i, int j, R v) { P0s[i * ld + j] = v; });
         if (tid < d) x0[tid] = sv[(long)d * d + tid];
         __syncthreads();
         const R dt = dts[s - cs];
-        stages_fwd(P0s, Ps, F, dt);
+        AWG_TICK(7)  // replay, step start
+        stages_fwd(P0s, Ps, F, G, dt);
+        AWG_TICK(8)  // the step's stages forward
         for (int si = nst - 1; si >= 0; --si) {
           // cotangent of slope i: dt (b_i ybar + sum_{r > i} a_ri Ybar_r), symmetrised
-          AWG_FOR(e, d * d) {
-            const int i = fdiv(e, d), j = e - i * d;
-            R s2 = a.rk.b[si] * Pb[i * ld + j];
-            for (int r = nst - 1; r > si; --r) s2 = rfma(a.rk.a[r][si], ybP[(long)r * d * d + e], s2);
-            Lt[i * ld + j] = dt * s2;
-          }
+          rows2d(d, d,
+                  [&](int i, int j) {
+                    R s2 = a.rk.b[si] * Pb[i * ld + j];
+                    for (int r = nst - 1; r > si; --r) s2 = rfma(a.rk.a[r][si], ybP[(long)r * d * d + i * d + j], s2);
+                    return dt * s2;
+                  },
+                  [&](int i, int j, R v) {
+                    Lt[i * ld + j] = v;
+                  });
           if (tid < d) {
             R s2 = a.rk.b[si] * mb[tid];
             for (int r = nst - 1; r > si; --r) s2 = rfma(a.rk.a[r][si], ym[64 * r + tid], s2);
             lam[tid] = dt * s2;
           }
           stage_value(si, P0s, Ps, dt);  // (synchronises)
-          AWG_FOR(e, d * d) {
-            const int i = fdiv(e, d), j = e - i * d;
-            Lam[i * ld + j] = R(0.5) * (Lt[i * ld + j] + Lt[j * ld + i]);
-          }
+          add_sym(Lam, Lt, true);        // (synchronises)
           drift_eval(xs, F);
           __syncthreads();
-          // Ybar_P = F^T Lam + Lam F;  G = 2 Lam Ps where the drift's parameters / state derivative want it
-          AWG_FOR(e, d * d) {
-            const int i = fdiv(e, d), j = e - i * d;
-            R sa = R(0), sb = R(0);
-            for (int kk = 0; kk < d; ++kk) {
-              sa = rfma(F[kk * ld + i], Lam[kk * ld + j], sa);
-              sb = rfma(Lam[i * ld + kk], F[kk * ld + j], sb);
-            }
-            ybP[(long)si * d * d + e] = sa + sb;
-            if (gQ) gQ[e] += Lam[i * ld + j];
-            if (lin) {
-              R sg = R(0);
-              for (int kk = 0; kk < d; ++kk) sg = rfma(Lam[i * ld + kk], Ps[kk * ld + j], sg);
-              g[e] += rfma(lam[i], xs[j], R(2) * sg);  // dW += lam x^T + G
-            }
-          }
-          if (!lin && tid < d) {  // Lorenz-96: the three entries of row i of G the state derivative of F touches
+          AWG_TICK(9)  // stage cotangent, stage value, drift
+          // Ybar_P = F^T Lam + Lam F = (Lam F) + (Lam F)^T;  G = 2 Lam Ps where the drift's parameters / state derivative want it
+          gemm(d, d, d, [&](int i, int kk) { return Lam[i * ld + kk]; }, [&](int kk, int j) { return F[kk * ld + j]; },
+               [&](int i, int j, R v) { G[i * ld + j] = v; });
+          if (lin) {
+            gemm(d, d, d, [&](int i, int kk) { return Lam[i * ld + kk]; }, [&](int kk, int j) { return Ps[kk * ld + j]; },
+                 [&](int i, int j, R v) { g[i * d + j] += rfma(lam[i], xs[j], R(2) * v); });  // dW += lam x^T + G
+          } else if (tid < d) {  // Lorenz-96: the three entries of row i of G the state derivative of F touches
             const int i = tid;
             const int ip1 = (i + 1 >= d) ? 0 : i + 1, im1 = (i == 0) ? d - 1 : i - 1, im2 = (im1 == 0) ? d - 1 : im1 - 1;
             R s1 = R(0), s2 = R(0), s3 = R(0);
@@ -464,10 +560,15 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
             g3[i] = R(2) * s3;  // G[i][i-1]
           }
           __syncthreads();
+          rows2d(d, d,
+                  [&](int i, int j) {
+                    return G[i * ld + j] + G[j * ld + i];
+                  },
+                  [&](int i, int j, R v) { ybP[(long)si * d * d + i * d + j] = v; });
+          if (gQ) rows2d(d, d, [&](int i, int j) { return gQ[i * d + j] + Lam[i * ld + j]; }, [&](int i, int j, R v) { gQ[i * d + j] = v; });
           if (tid < d) {  // Ybar_m = F^T lam (+ the Jacobian's own state derivative contracted with G)
             const int c = tid;
-            R s2 = R(0);
-            for (int r = 0; r < d; ++r) s2 = rfma(F[r * ld + c], lam[r], s2);
+            R s2 = dot(d, [&](int r) { return F[r * ld + c]; }, [&](int r) { return lam[r]; });
             if (lin) {
               g[d * d + c] += lam[c];
             } else {
@@ -485,34 +586,44 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
             gForcing += s2;
           }
           __syncthreads();
+          AWG_TICK(10)  // right-hand-side adjoint products
         }
         // cotangent of the step's start
-        AWG_FOR(e, d * d) {
-          const int i = fdiv(e, d), j = e - i * d;
-          R s2 = Pb[i * ld + j];
-          for (int si = 0; si < nst; ++si) s2 += ybP[(long)si * d * d + e];
-          Pb[i * ld + j] = s2;
-        }
+        rows2d(d, d,
+                [&](int i, int j) {
+                  R s2 = Pb[i * ld + j];
+                  for (int si = 0; si < nst; ++si) s2 += ybP[(long)si * d * d + i * d + j];
+                  return s2;
+                },
+                [&](int i, int j, R v) {
+                  Lt[i * ld + j] = v;
+                });
         if (tid < d) {
           R s2 = mb[tid];
           for (int si = 0; si < nst; ++si) s2 += ym[64 * si + tid];
           mb[tid] = s2;
         }
         __syncthreads();
-        symmetrize(Pb, Lt);
+        add_sym(Pb, Lt, true);
+        AWG_TICK(11)  // step end
       }
     }
   }
   // ---- results ------------------------------------------------------------------------------------------------------------------
   if (gm) {
     if (tid < d) gm[tid] = mb[tid];
-    AWG_FOR(e, d * d) {
-      const int i = fdiv(e, d), j = e - i * d;
-      gP0[e] = R(0.5) * (Pb[i * ld + j] + Pb[j * ld + i]);
-    }
+    rows2d(d, d, [&](int i, int j) { return R(0.5) * (Pb[i * ld + j] + Pb[j * ld + i]); }, [&](int i, int j, R v) { gP0[i * d + j] = v; });
   }
   if (!lin && tid == 0) g[0] = gForcing;
   if (st && tid == 0 && a.status) atomicOr(&a.status[n], st);
+#ifdef CDKF_AWG_PROFILE
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    printf("awg cycles/obs-step (sizeof real %d, d %d):", (int)sizeof(R), d);
+    for (int q2 = 0; q2 < 12; ++q2) printf(" [%d] %lld", q2, awg_prof[q2] / a.T);
+    printf("\n");
+    for (int q2 = 0; q2 < 12; ++q2) awg_prof[q2] = 0;
+  }
+#endif
 #undef AWG_FOR
 }
 
