@@ -145,6 +145,53 @@ def test_fit_sgd_recovers_lorenz63_parameters(hip_lib):
 
 
 @pytest.mark.gpu
+def test_fit_sgd_lorenz96_forcing_beyond_eight_state_dimensions(hip_lib):
+    """fit_sgd on a Lorenz-96 model at d = 20 (ten components observed): the forcing is recovered by Adam on the EKF marginal
+    log-likelihood -- value and gradient from the wavefront-per-trajectory forward sweep and the workgroup-per-trajectory reverse
+    sweep (ekf_adjoint_wg_kernel); the reference trains models of any size (ssm_temissions.py:492-600).  Then forcing AND emission
+    covariance: the loss keeps falling and R moves towards the truth."""
+    from cd_dynamax_amd import _ffi
+    from helpers import lorenz96_model
+    d, m = 20, 10
+    true = lorenz96_model(d, m)
+    model = cd.ContDiscreteNonlinearGaussianSSM(d, m)
+    frozen = PP(trainable=False)
+
+    def problem(forcing, r_scale, r_props):
+        return model.initialize(
+            key=0,
+            initial_mean={"params": true.m0, "props": frozen},
+            initial_cov={"params": true.P0, "props": frozen},
+            dynamics_drift={"params": cd.LearnableLorenz96(forcing), "props": cd.LearnableLorenz96(PP())},
+            dynamics_diffusion_coefficient={"params": cd.LearnableMatrix(np.eye(d)), "props": cd.LearnableMatrix(frozen)},
+            dynamics_diffusion_cov={"params": cd.LearnableMatrix(np.eye(d)), "props": cd.LearnableMatrix(frozen)},
+            emission_function={"params": cd.LearnableLinear(true.H, np.zeros(m)), "props": cd.LearnableLinear(frozen, frozen)},
+            emission_cov={"params": cd.LearnableMatrix(r_scale * np.eye(m)), "props": cd.LearnableMatrix(r_props)},
+        )
+
+    rng = np.random.default_rng(96)
+    N, T = 16, 60
+    t = o.irregular_times(rng, N, T, 0.6)
+    y = o.simulate(true, t, rng)
+    start, props = problem(6.5, 1.0, frozen)
+    new, losses = model.fit_sgd(start, props, y, t[..., None], cd.EKFHyperParams(), optimizer=fit.Adam(0.1), batch_size=N, num_epochs=60)
+    assert _ffi.lib().cdkf_last_kernel().decode().startswith("ekf_adjoint_wg_kernel<double>")
+    assert np.all(np.isfinite(losses)) and losses[-1] < losses[0]
+    assert abs(float(new.dynamics.drift.forcing) - 8.0) < 0.5 * abs(6.5 - 8.0), new.dynamics.drift.forcing
+    # the first step's gradient is the oracle's
+    ll, g = o.ekf_loglik_grad_adjoint(o.Model(o.Lorenz96Drift(6.5), true.L, true.Qc, true.H, true.bias, true.R, true.m0, true.P0), t, y)
+    _, _, _, gh = model.fit_sgd(start, props, y, t[..., None], cd.EKFHyperParams(), optimizer=fit.SGD(1e-3), batch_size=N, num_epochs=1,
+                                return_param_history=True, return_grad_history=True)
+    np.testing.assert_allclose(gh[0], -g.sum(0) / y.size, rtol=1e-8)
+    from cd_dynamax_amd.bijectors import RealToPSDBijector
+    start2, props2 = problem(7.0, 2.0, PP(constrainer=RealToPSDBijector()))
+    new2, losses2 = model.fit_sgd(start2, props2, y, t[..., None], cd.EKFHyperParams(), optimizer=fit.Adam(0.05), batch_size=N, num_epochs=40)
+    assert np.all(np.isfinite(losses2)) and losses2[-1] < losses2[0]
+    r_fit = np.asarray(new2.emissions.emission_cov.params)
+    assert np.abs(np.diag(r_fit) - 1.0).mean() < np.abs(2.0 - 1.0) * 0.6, np.diag(r_fit)
+
+
+@pytest.mark.gpu
 def test_fit_sgd_mlp_drift(hip_lib):
     """BASELINE config 5 in miniature: SGD over the marginal log-likelihood of an MLP-drift model (partial observations).
     First step against the oracle's adjoint gradient, then Adam lowers the loss."""
