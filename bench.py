@@ -490,6 +490,12 @@ def other_configs(lib, timer, stream, t_h, y_h, only=None, comm=None, world=1, r
         out["config4_slice_lorenz96_d40_fp64_2048x500"] = case(
             l96, grids(rng, n, T), 8.0 + rng.standard_normal((n, T, d)), "f64", _ffi.LAYOUT_TN, ["ekf_filter", "ekf_smoother"], "mfma",
             {"ekf_filter": flops_per_step(d, d, 6 * d), "ekf_smoother": flops_per_step(d, d, 6 * d, smoother=True)})
+    if want("config4_value_and_grad_lorenz96_d40_fp64_256x100"):
+        # the same model's SGD objective (round 3: the workgroup-per-trajectory reverse sweep, ekf_adjoint_wg_kernel -- the shape-generic
+        # gradient path, one trajectory per CU): value + every gradient on a slice of one trajectory per compute unit
+        ng, Tg = 256, 100
+        out["config4_value_and_grad_lorenz96_d40_fp64_256x100"] = case(
+            l96, grids(rng, ng, Tg), 8.0 + rng.standard_normal((ng, Tg, d)), "f64", _ffi.LAYOUT_TN, [], "mfma", {}, outputs=False, grad=True)
     rng = np.random.default_rng(2)
     d, m, h = 8, 4, 64
     mlp = cd.LearnableMLP(rng.standard_normal((h, d)) / np.sqrt(d), 0.1 * rng.standard_normal(h),

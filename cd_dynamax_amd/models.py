@@ -311,8 +311,9 @@ def cdnlgssm_loglik_and_grad(
 
     LearnableLorenz63 / LearnableLinear at the register-resident shapes: forward sensitivities inside the sweep,
     ``state_order`` first or second.  Any registry drift with state_dim, emission_dim <= 8 (LearnableMLP: hidden <= 64; its
-    ``state_order='second'`` mean term 0.5 P grad(div f) is reversed too): forward + reverse sweep (discrete adjoint).  Anything else raises (no finite-difference
-    fallback)."""
+    ``state_order='second'`` mean term 0.5 P grad(div f) is reversed too): forward + reverse sweep (discrete adjoint).  LearnableLorenz96 /
+    LearnableLinear beyond eight dimensions (up to 41 in float64, 58 in float32): the workgroup-per-trajectory reverse sweep.  Anything
+    else raises (no finite-difference fallback)."""
     ukf = isinstance(hyperparams, UKFHyperParams)
     if not ukf and not isinstance(hyperparams, EKFHyperParams):
         raise NotImplementedError("gradients are provided for the EKF and the UKF marginal log-likelihood (the ensemble filter is stochastic)")
@@ -351,7 +352,7 @@ def cdnlgssm_loglik_and_grad_all(
     ``ParamsCDNLGSSM`` of the same structure as ``params`` (what ``jax.grad`` of ``marginal_log_prob`` returns in the
     reference, ssm_temissions.py:550-568), leaves carrying a leading ``[N]`` for batched emissions.
 
-    One forward and one reverse sweep on the device (cdkf_ekf_loglik_grad_all_*): state and emission dimension <= 8, any
+    One forward and one reverse sweep on the device (cdkf_ekf_loglik_grad_all_*): state and emission dimension <= 8 for any
     registry drift, ``state_order`` first or second.  Gradients of the symmetric matrices (initial covariance, diffusion
     covariance, emission covariance) are symmetric cotangents: exact for symmetric perturbations, i.e. for any symmetric
     parametrisation such as the reference's ``RealToPSDBijector``."""
@@ -367,7 +368,7 @@ def cdnlgssm_loglik_and_grad_all(
     if not _ffi.lib().cdkf_grad_all_supported(_ffi.C.byref(mdl.c), _ffi.C.byref(opts)):
         raise NotImplementedError(
             f"no reverse-sweep kernel for drift {type(params.dynamics.drift).__name__} with state_dim={mdl.state_dim}, "
-            f"emission_dim={mdl.emission_dim}, state_order={hyperparams.state_order} (needs state and emission dimensions <= 8, "
+            f"emission_dim={mdl.emission_dim}, state_order={hyperparams.state_order} (needs state and emission dimensions <= 8 -- LearnableLorenz96 / LearnableLinear: <= 41 in float64, 58 in float32 --, "
             "MLP hidden layers <= 64, num_iter 1, state_order 'first' or 'second')")
     if on_device:  # the sweeps run on the device tensors; the (small) gradient blocks are packed on the host
         ll, gth, _, gm = (x.cpu().numpy() for x in _device.loglik_grad_device(mdl, opts, t, y, True))
