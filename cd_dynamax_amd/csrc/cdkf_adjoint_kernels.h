@@ -260,20 +260,23 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
     typename MTile::V4 acc[4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) acc[mt] = typename MTile::V4{0, 0, 0, 0};
-    {  // software pipeline: the operands of k-step ks + 1 are requested before the four products of k-step ks are issued (the fence the
-       // products' B operand passes through keeps the loads above it and the products below)
-      R bn = (lm < 9) ? W[IN + lg * 9 + lm] : R(0), an[4];
+    {  // software pipeline: the operands of k-step ks + LA are requested before the four products of k-step ks are issued (the fence the
+       // products' B operand passes through keeps the loads above it and the products below).  LA: one k-step in fp64 (four products =
+       // 256 cycles cover an LDS round trip), four in fp32 (128 cycles do not: scripts/mb/mb_mfma16.hip)
+      constexpr int LA = sizeof(R) == 4 ? 4 : 1;
+      R bq[16], aq[16][4];
+      auto request = [&](int ks) __attribute__((always_inline)) {
+        bq[ks] = (lm < 9) ? W[IN + (4 * ks + lg) * 9 + lm] : R(0);
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) an[mt] = Sh[AdjSh::W2 + (16 * mt + lm) * 65 + lg];
+        for (int mt = 0; mt < 4; ++mt) aq[ks][mt] = Sh[AdjSh::W2 + (16 * mt + lm) * 65 + 4 * ks + lg];
+      };
+#pragma unroll
+      for (int ks = 0; ks < LA; ++ks) request(ks);
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) {
-        R bv = bn;
-        const R a0 = an[0], a1_ = an[1], a2_ = an[2], a3_ = an[3];
-        if (ks < 15) {
-          bn = (lm < 9) ? W[IN + (4 * (ks + 1) + lg) * 9 + lm] : R(0);
-#pragma unroll
-          for (int mt = 0; mt < 4; ++mt) an[mt] = Sh[AdjSh::W2 + (16 * mt + lm) * 65 + 4 * (ks + 1) + lg];
-        }
+        R bv = bq[ks];
+        const R a0 = aq[ks][0], a1_ = aq[ks][1], a2_ = aq[ks][2], a3_ = aq[ks][3];
+        if (ks + LA < 16) request(ks + LA);
         asm volatile("" : "+v"(bv) : : "memory");
         acc[0] = wg_mfma(a0, bv, acc[0]);
         acc[1] = wg_mfma(a1_, bv, acc[1]);
@@ -293,18 +296,20 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
   };
   // cacc[nt][r] = sum_p IN[p][row(lg, r)] W2[p][16 nt + lm]  (software-pipelined like w2_times)
   auto w2t_product = [&](int IN, typename MTile::V4 (&cacc)[4]) __attribute__((always_inline)) {
-    R an = (lm < 9) ? W[IN + lg * 9 + lm] : R(0), bn[4];
+    constexpr int LA = sizeof(R) == 4 ? 4 : 1;  // (look-ahead in k-steps, as in w2_times)
+    R aq[16], bq[16][4];
+    auto request = [&](int ks) __attribute__((always_inline)) {
+      aq[ks] = (lm < 9) ? W[IN + (4 * ks + lg) * 9 + lm] : R(0);
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) bn[nt] = Sh[AdjSh::W2 + lg * 65 + 16 * nt + lm];
+      for (int nt = 0; nt < 4; ++nt) bq[ks][nt] = Sh[AdjSh::W2 + (4 * ks + lg) * 65 + 16 * nt + lm];
+    };
+#pragma unroll
+    for (int ks = 0; ks < LA; ++ks) request(ks);
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
-      R av = an;
-      const R b0 = bn[0], b1_ = bn[1], b2_ = bn[2], b3_ = bn[3];
-      if (ks < 15) {
-        an = (lm < 9) ? W[IN + (4 * (ks + 1) + lg) * 9 + lm] : R(0);
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) bn[nt] = Sh[AdjSh::W2 + (4 * (ks + 1) + lg) * 65 + 16 * nt + lm];
-      }
+      R av = aq[ks];
+      const R b0 = bq[ks][0], b1_ = bq[ks][1], b2_ = bq[ks][2], b3_ = bq[ks][3];
+      if (ks + LA < 16) request(ks + LA);
       asm volatile("" : "+v"(av) : : "memory");
       cacc[0] = wg_mfma(av, b0, cacc[0]);
       cacc[1] = wg_mfma(av, b1_, cacc[1]);

@@ -299,7 +299,23 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave8_kernel(const WgArgs<R
       typename MTile::V4 acc[4];
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) acc[mt] = typename MTile::V4{0, 0, 0, 0};
-      {  // (software pipeline as below: the activations of k-step ks + 1 are requested before the products of k-step ks are issued)
+      if constexpr (sizeof(R) == 4) {
+        // fp32: a k-step's four products take 128 cycles, an LDS round trip about as long -- one k-step of look-ahead leaves the
+        // matrix pipe waiting (scripts/mb/mb_mfma16.hip: 2 950 cycles per product against 2 048 for the pipe alone), and there are
+        // registers to spare: every activation of the product is requested up front
+        R dq[16], aq[16];
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+          dq[ks] = W[W8Off::d1 + 4 * ks + lg];
+          aq[ks] = W[W8Off::a1 + 4 * ks + lg];
+        }
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+          const R bv = rfma(dq[ks], w1B[ks], aq[ks] * e8);
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) acc[mt] = wg_mfma(w2A[mt][ks], bv, acc[mt]);
+        }
+      } else {  // (software pipeline as below: the activations of k-step ks + 1 are requested before the products of k-step ks are issued)
         R dq_n = W[W8Off::d1 + lg], aq_n = W[W8Off::a1 + lg];
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
@@ -364,22 +380,25 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave8_kernel(const WgArgs<R
         // software pipeline: the LDS operands of k-step it + 1 are requested BEFORE the five products of k-step it are issued (issued
         // after them they would arrive while the matrix pipe has already drained: a quarter of every k-step idle)
         auto prow = [&](int it) __attribute__((always_inline)) { return 16 * (it >> 2) + MTile::row(lg, it & 3); };
-        R sc_n = W[sc_off + prow(0)], x2_n = W[off2 + prow(0)], w_n[4];
+        // look-ahead in k-steps: one in fp64 (five products = 320 cycles cover an LDS round trip), four in fp32 (160 cycles do not)
+        constexpr int LA = sizeof(R) == 4 ? 4 : 1;
+        R scq[16], x2q[16], wq[16][4];
+        auto request = [&](int it) __attribute__((always_inline)) {
+          const int pn = prow(it);
+          scq[it] = W[sc_off + pn];
+          x2q[it] = W[off2 + pn];
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) w_n[nt] = Sh[W8Sh::W2 + prow(0) * W8Sh::LD2 + 16 * nt + lm];
+          for (int nt = 0; nt < 4; ++nt) wq[it][nt] = Sh[W8Sh::W2 + pn * W8Sh::LD2 + 16 * nt + lm];
+        };
+#pragma unroll
+        for (int it = 0; it < LA; ++it) request(it);
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
-          const R sc = sc_n, x2 = x2_n, w0 = w_n[0], w1 = w_n[1], w2 = w_n[2], w3 = w_n[3];
+          const R sc = scq[it], x2 = x2q[it], w0 = wq[it][0], w1 = wq[it][1], w2 = wq[it][2], w3 = wq[it][3];
           const R w3a = w3A[it >> 2][it & 3];
           R av = x2 * (w3a + e8);  // lm < 8: d2_p W3[lm][p];  lm = 8: s2_p;  else 0
           R b3v = sc * rfma(acc[it >> 2][it & 3], ne8, e8);
-          if (it < 15) {
-            const int pn = prow(it + 1);
-            sc_n = W[sc_off + pn];
-            x2_n = W[off2 + pn];
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) w_n[nt] = Sh[W8Sh::W2 + pn * W8Sh::LD2 + 16 * nt + lm];
-          }
+          if (it + LA < 16) request(it + LA);
           // (the products' operands pass through this fence: the loads above stay above it, the products below stay below)
           asm volatile("" : "+v"(av), "+v"(b3v) : : "memory");
           acc3 = wg_mfma(w3a, b3v, acc3);

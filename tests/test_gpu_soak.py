@@ -89,13 +89,14 @@ def test_soak_filters_and_smoother(hip_lib, case):
                 assert relerr(outss[3], refs["eks"]["smoothed_covariances"]) < 1e-8, layout
 
 
-@pytest.mark.parametrize("kind", ["lorenz63", "linear44", "mlp"])
+@pytest.mark.parametrize("kind", ["lorenz63", "linear44", "mlp", "lorenz96_13", "linear_11_4"])
 def test_soak_gradient_layouts(hip_lib, kind):
     """cdkf_ekf_loglik_grad[_all]_* honour opts.layout for t and y (forward-sensitivity and reverse-sweep kernels), shared and
     per-trajectory grids; N = 1 and N just above a wavefront."""
     rng = np.random.default_rng(7)
     mdl = {"lorenz63": lambda: o.lorenz63_model(3), "linear44": lambda: linear_model(rng, 4, 4),
-           "mlp": lambda: mlp_model(rng, 5, 2, (6, 7))}[kind]()
+           "mlp": lambda: mlp_model(rng, 5, 2, (6, 7)), "lorenz96_13": lambda: lorenz96_model(13, 6),
+           "linear_11_4": lambda: linear_model(rng, 11, 4)}[kind]()
     for N, T, shared in ((1, 6, False), (66, 5, True)):
         t = o.irregular_times(rng, 1 if shared else N, T, 0.04)
         tt = np.broadcast_to(t, (N, T)) if shared else t
@@ -133,3 +134,49 @@ def test_soak_gradient_on_the_lane_grid_against_the_other_kernels(hip_lib):
     assert "MISMATCH" not in res.stdout, res.stdout[-2000:]
     worst = [float(v) for v in re.findall(r": ([0-9.e+-]+)[,}]", res.stdout.splitlines()[-1])]
     assert len(worst) == 6 and max(worst) < 1e-9, res.stdout[-500:]
+
+
+def test_soak_reverse_sweep_beyond_eight_dimensions(hip_lib):
+    """Sixteen random problems for the workgroup-per-trajectory reverse sweep (ekf_adjoint_wg_kernel): Lorenz-96 and linear drifts,
+    state dimension 9 .. 41, emission dimension 1 .. 41 (m > d included), dense non-diagonal L / Qc / R / P0 and a dense H with bias or a
+    selection of components, 1 .. 5 trajectories, 1 .. 7 observations, intervals from zero length (repeated observation times) to a few
+    dozen Runge-Kutta steps (several replay chunks), other fixed-step tableaus -- every leaf against the oracle's discrete adjoint."""
+    rng = np.random.default_rng(4242)
+    worst = 0.0
+    for case in range(16):
+        lin = case % 3 == 1
+        d = int(rng.integers(9, 20)) if lin else int(rng.integers(9, 42))
+        m = int(rng.integers(1, d + 1)) if case % 4 else int(min(41, d + rng.integers(1, 4)))
+        drift = linear_model(rng, d, min(m, d)).drift if lin else o.Lorenz96Drift(8.0 + rng.standard_normal())
+        A, B, Cc = rng.standard_normal((d, d)), rng.standard_normal((m, m)), rng.standard_normal((d, d))
+        if case % 5 == 2 and m <= d:
+            H, bias = np.eye(d)[rng.permutation(d)[:m]], np.zeros(m)
+        else:
+            H, bias = rng.standard_normal((m, d)) / np.sqrt(d), 0.1 * rng.standard_normal(m)
+        mdl = o.Model(drift, np.eye(d) + 0.1 * rng.standard_normal((d, d)), A @ A.T / d + 0.3 * np.eye(d), H, bias,
+                      B @ B.T / m + 0.3 * np.eye(m), (0.0 if lin else 8.0) + rng.standard_normal(d), Cc @ Cc.T / d + 0.5 * np.eye(d))
+        N, T = int(rng.integers(1, 6)), int(rng.integers(1, 8))
+        t = o.irregular_times(rng, N, T, 0.02 * T)
+        solver = [None, None, "heun", "euler", "tsit5"][case % 5]
+        if T > 3:
+            t[:, 3:] += rng.uniform(0.05, 0.3) if solver is None else 0.02   # one long interval: 5 .. 30 steps (Dormand-Prince only)
+            t[0, 2] = t[0, 1]                          # and a repeated observation time
+        y = o.simulate(mdl, t, rng)
+        hyp = cd.EKFHyperParams(state_order="second" if case % 2 else "first", diffeqsolve_settings={"solver": solver} if solver else {})
+        if solver:
+            with o.use_solver(solver):
+                ll_ref, g_ref, ex = o.ekf_loglik_grad_adjoint(mdl, t, y, full=True)
+        else:
+            ll_ref, g_ref, ex = o.ekf_loglik_grad_adjoint(mdl, t, y, full=True)
+        ll, g = cd.cdnlgssm_loglik_and_grad_all(params_from(mdl), y, t[..., None], hyp)
+        assert _ffi.lib().cdkf_last_kernel().decode().startswith("ekf_adjoint_wg_kernel<double>"), case
+        np.testing.assert_allclose(ll, ll_ref, rtol=1e-9, err_msg=str(case))
+        flat = np.concatenate([np.asarray(a_).reshape(N, -1) for a_ in g.dynamics.drift], axis=-1)
+        pairs = [(flat, g_ref), (g.initial.mean.params, ex["m0"]), (g.initial.cov.params, ex["P0"]), (g.dynamics.diffusion_coefficient.params, ex["L"]),
+                 (g.dynamics.diffusion_cov.params, ex["Qc"]), (g.emissions.emission_function.weights, ex["H"]),
+                 (g.emissions.emission_function.bias, ex["bias"]), (g.emissions.emission_cov.params, ex["R"])]
+        for a_, b_ in pairs:
+            err = np.abs(np.asarray(a_) - b_).max() / (np.abs(b_).max() + 1e-300)
+            worst = max(worst, err)
+            assert err < 2e-8, (case, d, m, lin, solver, err)
+    assert worst < 2e-8
