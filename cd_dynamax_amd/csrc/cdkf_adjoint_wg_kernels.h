@@ -22,7 +22,7 @@
 namespace cdkf {
 
 constexpr int kAwgSlots = 9;   // q x ld matrices in LDS
-constexpr int kAwgVecs = 23;   // 64-entry vectors in LDS
+constexpr int kAwgVecs = 24;   // 64-entry vectors in LDS
 constexpr int kAwgThreads = 256;
 __host__ __device__ inline int awg_ld(int q) { return q | 1; }
 __host__ __device__ inline long awg_lds_reals(int d, int m) {
@@ -32,10 +32,15 @@ __host__ __device__ inline long awg_lds_reals(int d, int m) {
 // layout of the optional model-gradient block (per trajectory): m0 [d] | P0 [d,d] | LQL [d,d] | H [m,d] | bias [m] | R [m,m]
 // (the same as adj_model_grad_size of cdkf_adjoint_kernels.h)
 __host__ __device__ inline long awg_model_grad_size(int d, int m) { return (long)d + 2L * d * d + (long)m * d + m + (long)m * m; }
-// per-trajectory global scratch in reals: six slopes, six stage cotangents, `cap` step starts and their step sizes
+// per-trajectory global scratch in reals: `cap` step starts of a replay chunk and their step sizes
 __host__ __device__ inline long awg_scratch_reals(int d, int cap) {
   const long sz = (long)d * d + d;
-  return 12 * sz + (long)cap * sz + cap;
+  return (long)cap * sz + cap;
+}
+// covariance entries per thread on the (column, row group) map of a d x d matrix
+__host__ __device__ inline int awg_entries_per_thread(int d) {
+  const int rs = kAwgThreads / d;
+  return (d + rs - 1) / rs;
 }
 
 #ifdef CDKF_AWG_PROFILE  // local diagnostic build: cycles per phase (s_memtime), printed by trajectory 0
@@ -50,7 +55,8 @@ static __device__ long long awg_prof[16];
 #define AWG_TICK(i)
 #endif
 
-template <typename R>
+// NE: covariance entries a thread owns at most (rows i0, i0 + rs, ... of its column on the d x d map): 8 up to d = 42, else 16
+template <typename R, int NE>
 __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArgs<R> a, R* __restrict__ grad, R* __restrict__ grad_model,
                                                                     R* __restrict__ ws, long ws_stride, int cap) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -66,6 +72,7 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
     *g1 = vec + 512, *g2 = vec + 576, *g3 = vec + 640;
   R* km = vec + 704;  // mean parts of the step's slopes   [6][64]
   R* ym = km + 384;   // mean parts of the stage cotangents [6][64]
+  R* lam2 = ym + 384; // second copy of lam (stages alternate)
   const R* par = a.par;
   const R* th = par + a.o_theta;
   const R* LQL = par + a.o_LQL;
@@ -75,9 +82,7 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
   const int nst = a.rk.stages;
   const long sz = (long)d * d + d;
   R* wsb = ws + n * ws_stride;
-  R* ksP = wsb;               // [6][d*d] then [6][d] unused (the mean parts live in LDS)
-  R* ybP = wsb + 6 * sz;      // [6][d*d]
-  R* starts = wsb + 12 * sz;  // [cap][d*d + d]
+  R* starts = wsb;            // [cap][d*d + d]
   R* dts = starts + (long)cap * sz;
   const long ntheta = lin ? (long)d * d + d : 1;
   R* g = grad + n * ntheta;
@@ -381,18 +386,55 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
     add_sym(A, tmp, true);
   };
 
-  // ---- Runge-Kutta stages of one step from (x0, P0s): slopes k_i = (km[i], ksP[i]) -----------------------------------------------
-  // stage value i into (xs, Ps): y0 + dt sum_{j < i} a_ij k_j   (own entries of the global slopes)
-  auto stage_value = [&](int si, const R* P0s, R* Ps, R dt) {
-    rows2d(d, d,
-            [&](int i, int j) {
-              R s2 = R(0);
-              for (int jj = 0; jj < si; ++jj) s2 = rfma(a.rk.a[si][jj], ksP[(long)jj * d * d + i * d + j], s2);
-              return rfma(dt, s2, P0s[i * ld + j]);
-            },
-            [&](int i, int j, R v) {
-              Ps[i * ld + j] = v;
-            });
+  // ---- Runge-Kutta stages of one step from (x0, P0s) ------------------------------------------------------------------------------
+  // The covariance parts of the six slopes and of the six stage cotangents of the step in hand stay in the REGISTERS of the thread
+  // that owns the entry (NE entries per thread on the d x d map): a stage's combination is a sum over all six with the coefficient
+  // zero where the tableau has none, a stage's result is written through a select -- every register index is a compile-time constant
+  // although the stage loops stay rolled.  (In a global scratch they cost an L2 round trip per batch and pass: ~40 % of a stage.)
+  R kP[6][NE], yP[6][NE], gQacc[NE];  // (gQacc: d ll / d (L Qc L^T) of the owned entries, accumulated over the whole sweep)
+#pragma unroll
+  for (int s6 = 0; s6 < 6; ++s6)
+#pragma unroll
+    for (int u = 0; u < NE; ++u) kP[s6][u] = yP[s6][u] = R(0);
+#pragma unroll
+  for (int u = 0; u < NE; ++u) gQacc[u] = R(0);
+  auto slots = [&](auto&& value, auto&& store) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u0 = 0; u0 < NE; u0 += 4) {
+      R v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = map_d.i0 + (u0 + u) * map_d.rs;
+        v[u] = (i < d) ? value(i, map_d.j, u0 + u) : R(0);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = map_d.i0 + (u0 + u) * map_d.rs;
+        if (i < d) store(i, map_d.j, u0 + u, v[u]);
+      }
+    }
+  };
+  auto rka = [&](int r, int c) { return (c < r && c < 5) ? a.rk.a[r][c] : R(0); };  // (rows / columns the method does not have: zero)
+  // k_P of stage sv from the product A = F Ps left in LDS (pending: the slope is formed where it is first needed -- no barrier of its own)
+  auto take_slope = [&](int sv, const R* A) __attribute__((always_inline)) {
+    slots([&](int i, int j, int) { return (A[i * ld + j] + A[j * ld + i]) + LQL[i * d + j]; },
+          [&](int, int, int u, R v) {
+#pragma unroll
+            for (int s6 = 0; s6 < 6; ++s6) kP[s6][u] = (s6 == sv) ? v : kP[s6][u];
+          });
+  };
+  // stage value si into (xs, Ps): y0 + dt sum_{j < si} a_ij k_j
+  auto stage_value = [&](int si, const R* P0s, R* Ps, R dt) __attribute__((always_inline)) {
+    R cf[6];
+#pragma unroll
+    for (int s6 = 0; s6 < 6; ++s6) cf[s6] = rka(si, s6);
+    slots([&](int i, int j, int u) {
+            R s2 = R(0);
+#pragma unroll
+            for (int s6 = 0; s6 < 5; ++s6) s2 = rfma(cf[s6], kP[s6][u], s2);
+            return rfma(dt, s2, P0s[i * ld + j]);
+          },
+          [&](int i, int j, int, R v) { Ps[i * ld + j] = v; });
     if (tid < d) {
       R s2 = R(0);
       for (int jj = 0; jj < si; ++jj) s2 = rfma(a.rk.a[si][jj], km[64 * jj + tid], s2);
@@ -400,9 +442,10 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
     }
     __syncthreads();
   };
-  // (A: a free slot for F Ps)
+  // (A: a free slot for F Ps; three barriers per stage)
   auto stages_fwd = [&](const R* P0s, R* Ps, R* F, R* A, R dt) {
     for (int si = 0; si < nst; ++si) {
+      if (si) take_slope(si - 1, A);
       stage_value(si, P0s, Ps, dt);
       drift_eval(xs, F);
       __syncthreads();
@@ -410,25 +453,21 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
            [&](int i, int j, R v) { A[i * ld + j] = v; });
       if (tid < d) km[64 * si + tid] = fv[tid];
       __syncthreads();
-      rows2d(d, d,  // k_P = F Ps + (F Ps)^T + L Qc L^T
-              [&](int i, int j) {
-                return (A[i * ld + j] + A[j * ld + i]) + LQL[i * d + j];
-              },
-              [&](int i, int j, R v) { ksP[(long)si * d * d + i * d + j] = v; });
-      __syncthreads();
     }
+    take_slope(nst - 1, A);
   };
   // y <- y + dt sum_i b_i k_i  (x0 and the matrix in P0s)
   auto step_end = [&](R* P0s, R dt) {
-    rows2d(d, d,
-            [&](int i, int j) {
-              R s2 = R(0);
-              for (int si = 0; si < nst; ++si) s2 = rfma(a.rk.b[si], ksP[(long)si * d * d + i * d + j], s2);
-              return rfma(dt, s2, P0s[i * ld + j]);
-            },
-            [&](int i, int j, R v) {
-              P0s[i * ld + j] = v;
-            });
+    R cf[6];
+#pragma unroll
+    for (int s6 = 0; s6 < 6; ++s6) cf[s6] = (s6 < nst) ? a.rk.b[s6] : R(0);
+    slots([&](int i, int j, int u) {
+            R s2 = R(0);
+#pragma unroll
+            for (int s6 = 0; s6 < 6; ++s6) s2 = rfma(cf[s6], kP[s6][u], s2);
+            return rfma(dt, s2, P0s[i * ld + j]);
+          },
+          [&](int i, int j, int, R v) { P0s[i * ld + j] = v; });
     if (tid < d) {
       R s2 = R(0);
       for (int si = 0; si < nst; ++si) s2 = rfma(a.rk.b[si], km[64 * si + tid], s2);
@@ -597,24 +636,38 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
         AWG_TICK(7)  // replay, step start
         stages_fwd(P0s, Ps, F, G, dt);
         AWG_TICK(8)  // the step's stages forward
+        // (lam in two copies by the stage's parity: a stage's last phase still reads it while the next stage's first phase writes)
+        auto take_cotangent = [&](int sv) __attribute__((always_inline)) {  // Ybar_P of stage sv = G + G^T from the product left in LDS
+          slots([&](int i, int j, int) { return G[i * ld + j] + G[j * ld + i]; },
+                [&](int, int, int u, R v) {
+#pragma unroll
+                  for (int s6 = 0; s6 < 6; ++s6) yP[s6][u] = (s6 == sv) ? v : yP[s6][u];
+                });
+        };
         for (int si = nst - 1; si >= 0; --si) {
-          // cotangent of slope i: dt (b_i ybar + sum_{r > i} a_ri Ybar_r), symmetrised
-          rows2d(d, d,
-                  [&](int i, int j) {
-                    R s2 = a.rk.b[si] * Pb[i * ld + j];
-                    for (int r = nst - 1; r > si; --r) s2 = rfma(a.rk.a[r][si], ybP[(long)r * d * d + i * d + j], s2);
+          R* lamv = (si & 1) ? lam2 : lam;
+          if (si + 1 < nst) take_cotangent(si + 1);
+          // cotangent of slope si: dt (b_si ybar + sum_{r > si} a_r,si Ybar_r); the stage value again
+          {
+            R cf[6];
+#pragma unroll
+            for (int s6 = 0; s6 < 6; ++s6) cf[s6] = (s6 > si && s6 < nst) ? rka(s6, si) : R(0);
+            const R bsi = a.rk.b[si];
+            slots([&](int i, int j, int u) {
+                    R s2 = bsi * Pb[i * ld + j];
+#pragma unroll
+                    for (int s6 = 1; s6 < 6; ++s6) s2 = rfma(cf[s6], yP[s6][u], s2);
                     return dt * s2;
                   },
-                  [&](int i, int j, R v) {
-                    Lt[i * ld + j] = v;
-                  });
+                  [&](int i, int j, int, R v) { Lt[i * ld + j] = v; });
+          }
           if (tid < d) {
             R s2 = a.rk.b[si] * mb[tid];
             for (int r = nst - 1; r > si; --r) s2 = rfma(a.rk.a[r][si], ym[64 * r + tid], s2);
-            lam[tid] = dt * s2;
+            lamv[tid] = dt * s2;
           }
           stage_value(si, P0s, Ps, dt);  // (synchronises)
-          add_sym(Lam, Lt, true);        // (synchronises)
+          rows2d(d, d, [&](int i, int j) { return R(0.5) * (Lt[i * ld + j] + Lt[j * ld + i]); }, [&](int i, int j, R v) { Lam[i * ld + j] = v; });
           drift_eval(xs, F);
           __syncthreads();
           AWG_TICK(9)  // stage cotangent, stage value, drift
@@ -623,33 +676,22 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
                [&](int i, int j, R v) { G[i * ld + j] = v; });
           if (lin) {
             gemm(d, d, d, [&](int i, int kk) { return Lam[i * ld + kk]; }, [&](int kk, int j) { return Ps[kk * ld + j]; },
-                 [&](int i, int j, R v) { g[i * d + j] += rfma(lam[i], xs[j], R(2) * v); });  // dW += lam x^T + G
+                 [&](int i, int j, R v) { g[i * d + j] += rfma(lamv[i], xs[j], R(2) * v); });  // dW += lam x^T + G
           } else if (tid < d) {  // Lorenz-96: the three entries of row i of G the state derivative of F touches
             const int i = tid;
             const int ip1 = (i + 1 >= d) ? 0 : i + 1, im1 = (i == 0) ? d - 1 : i - 1, im2 = (im1 == 0) ? d - 1 : im1 - 1;
-            R s1 = R(0), s2 = R(0), s3 = R(0);
-            for (int kk = 0; kk < d; ++kk) {
-              const R l = Lam[i * ld + kk];
-              s1 = rfma(l, Ps[kk * ld + ip1], s1);
-              s2 = rfma(l, Ps[kk * ld + im2], s2);
-              s3 = rfma(l, Ps[kk * ld + im1], s3);
-            }
-            g1[i] = R(2) * s1;  // G[i][i+1]
-            g2[i] = R(2) * s2;  // G[i][i-2]
-            g3[i] = R(2) * s3;  // G[i][i-1]
+            auto lrow = [&](int kk) { return Lam[i * ld + kk]; };
+            g1[i] = R(2) * dot(d, lrow, [&](int kk) { return Ps[kk * ld + ip1]; });  // G[i][i+1]
+            g2[i] = R(2) * dot(d, lrow, [&](int kk) { return Ps[kk * ld + im2]; });  // G[i][i-2]
+            g3[i] = R(2) * dot(d, lrow, [&](int kk) { return Ps[kk * ld + im1]; });  // G[i][i-1]
           }
+          if (gQ) slots([&](int i, int j, int u) { return gQacc[u] + Lam[i * ld + j]; }, [&](int, int, int u, R v) { gQacc[u] = v; });
           __syncthreads();
-          rows2d(d, d,
-                  [&](int i, int j) {
-                    return G[i * ld + j] + G[j * ld + i];
-                  },
-                  [&](int i, int j, R v) { ybP[(long)si * d * d + i * d + j] = v; });
-          if (gQ) rows2d(d, d, [&](int i, int j) { return gQ[i * d + j] + Lam[i * ld + j]; }, [&](int i, int j, R v) { gQ[i * d + j] = v; });
           if (tid < d) {  // Ybar_m = F^T lam (+ the Jacobian's own state derivative contracted with G)
             const int c = tid;
-            R s2 = dot(d, [&](int r) { return F[r * ld + c]; }, [&](int r) { return lam[r]; });
+            R s2 = dot(d, [&](int r) { return F[r * ld + c]; }, [&](int r) { return lamv[r]; });
             if (lin) {
-              g[d * d + c] += lam[c];
+              g[d * d + c] += lamv[c];
             } else {
               // xbar[i-1] += G[i][i+1] - G[i][i-2];  xbar[i+1] += G[i][i-1];  xbar[i-2] -= G[i][i-1]
               const int cp1 = (c + 1 >= d) ? 0 : c + 1, cm1 = (c == 0) ? d - 1 : c - 1, cp2 = (cp1 + 1 >= d) ? 0 : cp1 + 1;
@@ -659,24 +701,24 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
             }
             ym[64 * si + c] = s2;
           }
-          if (!lin && tid == 0) {
-            R s2 = R(0);
-            for (int r = 0; r < d; ++r) s2 += lam[r];
-            gForcing += s2;
-          }
-          __syncthreads();
+          if (!lin && tid == 64) gForcing += dot(d, [&](int r) { return lamv[r]; }, [&](int) { return R(1); });  // (a thread of another wavefront)
           AWG_TICK(10)  // right-hand-side adjoint products
         }
+        take_cotangent(0);
+        __syncthreads();
         // cotangent of the step's start
-        rows2d(d, d,
-                [&](int i, int j) {
+        {
+          R cf[6];
+#pragma unroll
+          for (int s6 = 0; s6 < 6; ++s6) cf[s6] = (s6 < nst) ? R(1) : R(0);
+          slots([&](int i, int j, int u) {
                   R s2 = Pb[i * ld + j];
-                  for (int si = 0; si < nst; ++si) s2 += ybP[(long)si * d * d + i * d + j];
+#pragma unroll
+                  for (int s6 = 0; s6 < 6; ++s6) s2 = rfma(cf[s6], yP[s6][u], s2);
                   return s2;
                 },
-                [&](int i, int j, R v) {
-                  Lt[i * ld + j] = v;
-                });
+                [&](int i, int j, int, R v) { Lt[i * ld + j] = v; });
+        }
         if (tid < d) {
           R s2 = mb[tid];
           for (int si = 0; si < nst; ++si) s2 += ym[64 * si + tid];
@@ -690,10 +732,11 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
   }
   // ---- results ------------------------------------------------------------------------------------------------------------------
   if (gm) {
+    slots([&](int, int, int u) { return gQacc[u]; }, [&](int i, int j, int, R v) { gQ[i * d + j] = v; });
     if (tid < d) gm[tid] = mb[tid];
     rows2d(d, d, [&](int i, int j) { return R(0.5) * (Pb[i * ld + j] + Pb[j * ld + i]); }, [&](int i, int j, R v) { gP0[i * d + j] = v; });
   }
-  if (!lin && tid == 0) g[0] = gForcing;
+  if (!lin && tid == 64) g[0] = gForcing;
   if (st && tid == 0 && a.status) atomicOr(&a.status[n], st);
 #ifdef CDKF_AWG_PROFILE
   if (threadIdx.x == 0 && blockIdx.x == 0) {

@@ -16,11 +16,20 @@ int launch_adjoint_wg_kernel(const WgArgs<R>& a, R* grad, R* grad_model, R* scra
               "fp64, 58 in fp32)", a.d, a.m, (size_t)awg_lds_reals(a.d, a.m) * sizeof(R), (int)sizeof(R) * 8);
     return CDKF_EUNSUPPORTED;
   }
-  if (once_per_device([] { return wg_raise_lds_cap(&ekf_adjoint_wg_kernel<R>); })) return CDKF_EHIP;
   const size_t lds = (size_t)awg_lds_reals(a.d, a.m) * sizeof(R) + 64;
-  note_kernel("ekf_adjoint_wg_kernel<%s>", real_name<R>());
-  hipLaunchKernelGGL(ekf_adjoint_wg_kernel<R>, dim3((unsigned)a.N), dim3(kAwgThreads), lds, stream, a, grad, grad_model, scratch,
-                     awg_scratch_reals(a.d, cap), cap);
+  const long scratch_stride = awg_scratch_reals(a.d, cap);
+  // the slopes and stage cotangents of a thread's covariance entries stay in registers: 8 entries per thread up to d = 42, else 16
+  if (awg_entries_per_thread(a.d) <= 8) {
+    if (once_per_device([] { return wg_raise_lds_cap(&ekf_adjoint_wg_kernel<R, 8>); })) return CDKF_EHIP;
+    note_kernel("ekf_adjoint_wg_kernel<%s, 8>", real_name<R>());
+    hipLaunchKernelGGL((ekf_adjoint_wg_kernel<R, 8>), dim3((unsigned)a.N), dim3(kAwgThreads), lds, stream, a, grad, grad_model, scratch,
+                       scratch_stride, cap);
+  } else {
+    if (once_per_device([] { return wg_raise_lds_cap(&ekf_adjoint_wg_kernel<R, 16>); })) return CDKF_EHIP;
+    note_kernel("ekf_adjoint_wg_kernel<%s, 16>", real_name<R>());
+    hipLaunchKernelGGL((ekf_adjoint_wg_kernel<R, 16>), dim3((unsigned)a.N), dim3(kAwgThreads), lds, stream, a, grad, grad_model, scratch,
+                       scratch_stride, cap);
+  }
   CDKF_HIP_CHECK(hipGetLastError());
   return CDKF_OK;
 }
