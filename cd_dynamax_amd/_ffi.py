@@ -381,9 +381,10 @@ DRIFT_CUSTOM_BASE = 1000
 SOLVERS = {"dopri5": 0, "tsit5": 1, "bosh3": 2, "heun": 3, "midpoint": 4, "ralston": 5, "euler": 6}
 
 
-def register_custom_drift(state_dim: int, n_theta: int, f_src: str, jac_src: str, divgrad_src: Optional[str]) -> int:
-    """cdkf_custom_drift_register: returns the drift_kind (same sources -> same kind)."""
-    kind = lib().cdkf_custom_drift_register(int(state_dim), int(n_theta), f_src.encode(), jac_src.encode(),
+def register_custom_drift(state_dim: int, n_theta: int, f_src: str, jac_src: Optional[str], divgrad_src: Optional[str]) -> int:
+    """cdkf_custom_drift_register: returns the drift_kind (same sources -> same kind).  ``jac_src`` None: the Jacobian is derived
+    from ``f_src`` by dual numbers; ``divgrad_src`` "auto": so is grad(div f)."""
+    kind = lib().cdkf_custom_drift_register(int(state_dim), int(n_theta), f_src.encode(), None if jac_src is None else jac_src.encode(),
                                             None if divgrad_src is None else divgrad_src.encode())
     if kind < 0:
         check(kind)

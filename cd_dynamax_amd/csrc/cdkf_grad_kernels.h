@@ -25,8 +25,10 @@
 namespace cdkf {
 
 // ---- per-drift parameter derivatives ------------------------------------------------------------------
+// init(p), bind(drift): this lane's parameter and the drift whose parameters it differentiates;
 // dtheta(x, dfdth, dFdth): d f / d theta_p and d F / d theta_p at x for this lane's p;
-// dstate(dm, dF): dF += sum_i (dF/dx_i) dm_i.
+// dstate(x, dm, dF): dF += sum_i (dF/dx_i)(x) dm_i.
+// (a run-time compiled drift gets all three from dual numbers: launch_custom.hip, cdkf_dual.h)
 template <typename R, int D, typename Drift>
 struct DriftGrad;
 
@@ -52,7 +54,8 @@ struct DriftGrad<R, 3, DriftLorenz63<R, 3>> {
     dF[1][0] = e1;
     dF[2][2] = -e2;
   }
-  CDKF_DEV void dstate(const R* dm, R (&dF)[3][3]) const {
+  CDKF_DEV void bind(const DriftLorenz63<R, 3>&) {}
+  CDKF_DEV void dstate(const R*, const R* dm, R (&dF)[3][3]) const {
     dF[1][0] -= dm[2];
     dF[1][2] -= dm[0];
     dF[2][0] += dm[1];
@@ -85,7 +88,8 @@ struct DriftGrad<R, D, DriftLinear<R, D>> {
       df[i] = s;
     }
   }
-  CDKF_DEV void dstate(const R*, R (&)[D][D]) const {}
+  CDKF_DEV void bind(const DriftLinear<R, D>&) {}
+  CDKF_DEV void dstate(const R*, const R*, R (&)[D][D]) const {}
   static constexpr bool kCurved = false;  // a linear drift has no curvature: its unscented moment equations are the extended filter's
   static CDKF_DEV void curvature(const R*, R*) {}
 };
@@ -104,7 +108,7 @@ struct EkfSensRhs {
     drift.f(y, f);
     drift.jac(y, F);
     dg.dtheta(y, dfth, dF);
-    dg.dstate(y + NS, dF);
+    dg.dstate(y, y + NS, dF);
     const R* P = y + D;
     const R* dm = y + NS;
     const R* dP = y + NS + D;
@@ -321,7 +325,7 @@ struct GradArgs {
 // the reference's unscented update has no symmetrisation to lose: inference_ukf.py:162-203); the covariance the update would draw
 // its sigma points from must be positive definite (jnp.linalg.cholesky, inference_ukf.py:57): NaN and the NOT_PD flag otherwise.
 template <typename R, int D, int M, typename Drift, bool GENERIC = false, bool UKF = false>
-__global__ __launch_bounds__(64, 1) void ekf_grad_reg_kernel(const GradArgs<R, D, M, Drift> ga) {
+CDKF_DEV void ekf_grad_reg_body(const GradArgs<R, D, M, Drift>& ga) {
   constexpr int NS = Dims<D>::NS;
   constexpr int NP = Dims<D>::NP;
   constexpr int NPAR = DriftGrad<R, D, Drift>::NPAR;
@@ -351,6 +355,7 @@ __global__ __launch_bounds__(64, 1) void ekf_grad_reg_kernel(const GradArgs<R, D
   const auto C = TabSel<R, GENERIC>::get(a);
   DriftGrad<R, D, Drift> dg;
   dg.init(p);
+  dg.bind(a.drift);
   EkfSensRhs<R, D, Drift, UKF> rhs{a.drift, dg, a.LQL};
 
   R tcur = tp[0];
@@ -400,6 +405,10 @@ __global__ __launch_bounds__(64, 1) void ekf_grad_reg_kernel(const GradArgs<R, D
       if (a.status) a.status[n] = st;
     }
   }
+}
+template <typename R, int D, int M, typename Drift, bool GENERIC = false, bool UKF = false>
+__global__ __launch_bounds__(64, 1) void ekf_grad_reg_kernel(const GradArgs<R, D, M, Drift> ga) {
+  ekf_grad_reg_body<R, D, M, Drift, GENERIC, UKF>(ga);
 }
 
 }  // namespace cdkf

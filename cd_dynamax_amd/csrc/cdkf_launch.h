@@ -99,6 +99,7 @@ struct ParamLease {
 // user-supplied drifts compiled at run time (launch_custom.hip); algo: 0 EKF filter, 1 UKF filter, 2 EKF smoother
 bool custom_kind(int kind);
 bool custom_shape_available(const cdkf_model* mdl, const cdkf_opts* o);
+bool custom_grad_available(const cdkf_model* mdl, const cdkf_opts* o);  // algo 3: log-likelihood + gradient w.r.t. theta (a1: grad [N, n_theta])
 template <typename R>
 int launch_custom(int algo, const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll,
                   R* a1, R* a2, R* a3, R* a4, int32_t* status, hipStream_t stream);

@@ -22,6 +22,7 @@ struct CustomDrift {
   int d, n_theta;
   std::string f_src, jac_src, g_src;
   bool has_g;
+  bool auto_jac, auto_g;  // the Jacobian / grad(div f) are derived from f_src by dual numbers (cdkf_dual.h)
 };
 struct CustomEmission {
   int d, m;
@@ -32,7 +33,8 @@ std::vector<CustomEmission> g_emis;  // emission_kind = CDKF_EMISSION_CUSTOM_BAS
 std::mutex g_mutex;
 std::string g_src_dir;
 
-// kind, bytes per real, emission_dim, ukf, zeroth, forecast, smoother, generic Runge-Kutta tableau, emission kind (0: linear)
+// kind, bytes per real, emission_dim, ukf, zeroth, forecast, smoother (2: the log-likelihood gradient sweep), generic Runge-Kutta
+// tableau, emission kind (0: linear)
 using Key = std::tuple<int, int, int, int, int, int, int, int, int>;
 struct Compiled {
   hipModule_t module = nullptr;
@@ -49,6 +51,8 @@ std::mutex& g_mutex_srcdir() {
   static std::mutex m;
   return m;
 }
+
+bool blank(const std::string& t) { return t.find_first_not_of(" \t\r\n;") == std::string::npos; }
 
 std::string source_dir() {
   std::lock_guard<std::mutex> lock(g_mutex_srcdir());
@@ -67,7 +71,10 @@ std::string source_dir() {
 std::string generate_source(const CustomDrift& c, int bytes, int m, int ukf, int zeroth, int forecast, int smoother,
                             int generic, const CustomEmission* em) {
   std::string s;
-  s += "#include \"cdkf_reg_kernels.h\"\n";
+  const bool grad = smoother == 2;
+  const std::string D_ = std::to_string(c.d), NT_ = std::to_string(c.n_theta > 0 ? c.n_theta : 1);
+  s += grad ? "#include \"cdkf_grad_kernels.h\"\n" : "#include \"cdkf_reg_kernels.h\"\n";
+  s += "#include \"cdkf_dual.h\"\n";
   s += "namespace cdkf {\n";
   s += "template <typename R, int D>\nstruct DriftCustom {\n";
   s += "  static constexpr int NTHETA = " + std::to_string(c.n_theta) + ";\n";
@@ -77,12 +84,55 @@ std::string generate_source(const CustomDrift& c, int bytes, int m, int ukf, int
   s += "  static constexpr bool nz(int, int) { return true; }\n";
   s += "  CDKF_DEV void f(const R* x, R (&fx)[D]) const {\n    const R* theta = th; (void)theta;\n";
   s += "#line 1 \"drift_f\"\n" + c.f_src + "\n  }\n";
+  // the same statements with the scalar type T in place of the compute type: T = a dual number differentiates them (cdkf_dual.h)
+  if (c.auto_jac || c.auto_g || grad) {
+    s += "  template <typename T> CDKF_DEV void f_t(const T* x, const T* theta, T (&fx)[D]) const {\n    (void)theta;\n";
+    s += "#line 1 \"drift_f\"\n" + c.f_src + "\n  }\n";
+  }
   s += "  CDKF_DEV void jac(const R* x, R (&F)[D][D]) const {\n    const R* theta = th; (void)theta;\n";
   s += "    for (int i_ = 0; i_ < D; ++i_) for (int j_ = 0; j_ < D; ++j_) F[i_][j_] = R(0);\n";
-  s += "#line 1 \"drift_jacobian\"\n" + c.jac_src + "\n  }\n";
+  if (c.auto_jac) {  // jacfwd(f): D unit directions (inference_ekf.py:95)
+    s += "    typedef Dual<R, D> T;\n    T xt[D], tht[" + NT_ + "], ft[D];\n";
+    s += "    for (int i_ = 0; i_ < D; ++i_) { xt[i_] = T(x[i_]); xt[i_].g[i_] = R(1); }\n";
+    s += "    for (int k_ = 0; k_ < NTHETA; ++k_) tht[k_] = T(th[k_]);\n";
+    s += "    f_t<T>(xt, tht, ft);\n";
+    s += "    for (int i_ = 0; i_ < D; ++i_) for (int j_ = 0; j_ < D; ++j_) F[i_][j_] = ft[i_].g[j_];\n  }\n";
+  } else {
+    s += "#line 1 \"drift_jacobian\"\n" + c.jac_src + "\n  }\n";
+  }
   s += "  CDKF_DEV void divgrad(const R* x, R (&g)[D]) const {\n    const R* theta = th; (void)theta;\n";
   s += "    for (int i_ = 0; i_ < D; ++i_) g[i_] = R(0);\n";
-  s += "#line 1 \"drift_divgrad\"\n" + c.g_src + "\n  }\n};\n}  // namespace cdkf\n";
+  if (c.auto_g) {  // g_i = d/dx_i sum_j d f_j / d x_j: second derivatives from nested dual numbers (inference_ekf.py:108-116)
+    s += "    typedef Dual<R, D> S1;\n    typedef Dual<S1, D> T;\n    T xt[D], tht[" + NT_ + "], ft[D];\n";
+    s += "    for (int i_ = 0; i_ < D; ++i_) { xt[i_] = T(x[i_]); xt[i_].v.g[i_] = R(1); xt[i_].g[i_] = S1(R(1)); }\n";
+    s += "    for (int k_ = 0; k_ < NTHETA; ++k_) tht[k_] = T(th[k_]);\n";
+    s += "    f_t<T>(xt, tht, ft);\n";
+    s += "    for (int i_ = 0; i_ < D; ++i_) for (int j_ = 0; j_ < D; ++j_) g[i_] += ft[j_].g[j_].g[i_];\n  }\n";
+  } else {
+    s += "#line 1 \"drift_divgrad\"\n" + c.g_src + "\n  }\n";
+  }
+  s += "};\n";
+  if (grad) {
+    // what the forward-sensitivity sweep needs of the drift for its parameter p (cdkf_grad_kernels.h): directional derivatives of f and
+    // of its Jacobian along (dx, e_p dth) -- outer dual: that one direction, inner dual: the D unit directions of the Jacobian
+    s += "template <typename R, int D>\nstruct DriftGrad<R, D, DriftCustom<R, D>> {\n";
+    s += "  static constexpr int NPAR = DriftCustom<R, D>::NTHETA;\n  static constexpr bool kCurved = false;\n";
+    s += "  static CDKF_DEV void curvature(const R*, R*) {}\n  int p;\n  const DriftCustom<R, D>* dr;\n";
+    s += "  CDKF_DEV void init(int p_) { p = p_; }\n  CDKF_DEV void bind(const DriftCustom<R, D>& d_) { dr = &d_; }\n";
+    s += "  CDKF_DEV void along(const R* x, const R* dx, R dth, R (&fd)[D], R (&Fd)[D][D], bool add) const {\n";
+    s += "    typedef Dual<R, 1> S1;\n    typedef Dual<S1, D> T;\n    T xt[D], tht[" + NT_ + "], ft[D];\n";
+    s += "    for (int i_ = 0; i_ < D; ++i_) { S1 b(x[i_]); b.g[0] = dx ? dx[i_] : R(0); xt[i_].v = b; "
+         "for (int j_ = 0; j_ < D; ++j_) xt[i_].g[j_] = S1(i_ == j_ ? R(1) : R(0)); }\n";
+    s += "    for (int k_ = 0; k_ < NPAR; ++k_) { S1 b(dr->th[k_]); b.g[0] = (k_ == p) ? dth : R(0); tht[k_].v = b; "
+         "for (int j_ = 0; j_ < D; ++j_) tht[k_].g[j_] = S1(R(0)); }\n";
+    s += "    dr->template f_t<T>(xt, tht, ft);\n";
+    s += "    for (int i_ = 0; i_ < D; ++i_) { fd[i_] = ft[i_].v.g[0]; for (int j_ = 0; j_ < D; ++j_) "
+         "Fd[i_][j_] = (add ? Fd[i_][j_] : R(0)) + ft[i_].g[j_].g[0]; }\n  }\n";
+    s += "  CDKF_DEV void dtheta(const R* x, R (&df)[D], R (&dF)[D][D]) const { along(x, nullptr, R(1), df, dF, false); }\n";
+    s += "  CDKF_DEV void dstate(const R* x, const R* dm, R (&dF)[D][D]) const { R fd[D]; along(x, dm, R(0), fd, dF, true); }\n";
+    s += "};\n";
+  }
+  s += "}  // namespace cdkf\n";
   if (em) {
     // emission parameters eta = [the model's H block (m x d, row-major) | h_bias (m)], read from the argument block
     s += "namespace cdkf {\ntemplate <typename R, int D, int M>\nstruct EmisCustom {\n";
@@ -138,7 +188,12 @@ __device__ __forceinline__ void unpack(Args& a, const R* __restrict__ par, const
   a.t = t; a.y = y; a.ll = ll; a.fm = fm; a.fP = fP; a.pm = pm; a.pP = pP; a.status = status;
 }
 )";
-  if (!smoother) {
+  if (grad) {
+    s += "extern \"C\" __global__ __launch_bounds__(64, 1) void cdkf_custom_kernel(const R* par, const long* ip, const R* t, "
+         "const R* y, R* ll, R* fm, R* fP, R* pm, R* pP, int* status, R* sm, R* sP) {\n  cdkf::GradArgs<R, DD, MM, Drift> ga;\n"
+         "  unpack(ga.a, par, ip, t, y, ll, nullptr, nullptr, nullptr, nullptr, status);\n  ga.grad = fm;\n";
+    s += "  cdkf::ekf_grad_reg_body<R, DD, MM, Drift, " + std::string(generic ? "true" : "false") + ", false>(ga);\n}\n";
+  } else if (!smoother) {
     s += "extern \"C\" __global__ __launch_bounds__(64, 1) void cdkf_custom_kernel(const R* par, const long* ip, const R* t, "
          "const R* y, R* ll, R* fm, R* fP, R* pm, R* pP, int* status, R* sm, R* sP) {\n  Args a;\n"
          "  unpack(a, par, ip, t, y, ll, fm, fP, pm, pP, status);\n";
@@ -262,7 +317,18 @@ bool custom_shape_available(const cdkf_model* mdl, const cdkf_opts* o) {
   return true;
 }
 
-// algo: 0 EKF filter, 1 UKF filter, 2 EKF smoother (filter + backward sweep)
+// the log-likelihood gradient w.r.t. theta (forward sensitivities, a lane per (trajectory, parameter): ekf_grad_reg_body with the
+// drift's parameter derivatives from dual numbers): linear emission, num_iter 1, state_order 'first' -- or 'second' with a grad(div f)
+// that was registered as identically zero (an empty divgrad_src): the sweep does not carry the mean's second-order term
+bool custom_grad_available(const cdkf_model* mdl, const cdkf_opts* o) {
+  if (!custom_shape_available(mdl, o) || mdl->emission_kind != 0 || mdl->n_theta < 1) return false;
+  if (o->num_iter != 1 || o->forecast || o->state_order == CDKF_ORDER_ZEROTH) return false;
+  std::lock_guard<std::mutex> lock(g_mutex);
+  const CustomDrift& c = g_drifts[mdl->drift_kind - CDKF_DRIFT_CUSTOM_BASE];
+  return o->state_order == CDKF_ORDER_FIRST || (c.has_g && !c.auto_g && blank(c.g_src));
+}
+
+// algo: 0 EKF filter, 1 UKF filter, 2 EKF smoother (filter + backward sweep), 3 EKF log-likelihood + gradient (a1: grad [N, n_theta])
 template <typename R>
 int launch_custom(int algo, const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll,
                   R* a1, R* a2, R* a3, R* a4, int32_t* status, hipStream_t stream) {
@@ -295,7 +361,12 @@ int launch_custom(int algo, const cdkf_model* mdl, const cdkf_opts* o, int64_t N
               "drift twice, inference_ekf.py:108-116); register divgrad_src or use state_order 'first'");
     return CDKF_EUNSUPPORTED;
   }
-  const bool smoother = algo == 2;
+  const bool smoother = algo == 2, gradient = algo == 3;
+  if (gradient && (!custom_grad_available(mdl, o) || !a1 || !y)) {
+    set_error("custom drift: the gradient sweep needs a linear emission, n_theta >= 1, num_iter 1 and state_order 'first' (or "
+              "'second' with grad(div f) registered as identically zero)");
+    return CDKF_EUNSUPPORTED;
+  }
   if (smoother && (!a1 || !a2 || !a3 || !a4)) {
     set_error("EKF smoother: filtered and smoothed output pointers must not be NULL");
     return CDKF_EINVAL;
@@ -334,7 +405,7 @@ int launch_custom(int algo, const cdkf_model* mdl, const cdkf_opts* o, int64_t N
   par.push_back(tb.rtol); par.push_back(tb.atol); par.push_back(tb.c1); par.push_back(tb.c2); par.push_back(tb.c3);
   const int generic = o->solver != CDKF_SOLVER_DOPRI5 || o->adaptive;
   long ip[23];
-  const RegGrouping grouping = reg_grouping(N, (int)sizeof(R));
+  const RegGrouping grouping = reg_grouping(gradient ? N * mdl->n_theta : N, (int)sizeof(R));  // (gradient: a lane per (trajectory, parameter))
   ip[21] = grouping.lanes;
   ip[22] = grouping.xcd_shift;
   ip[17] = tb.stages;
@@ -378,7 +449,9 @@ int launch_custom(int algo, const cdkf_model* mdl, const cdkf_opts* o, int64_t N
     return CDKF_OK;
   };
   const int zeroth = (algo != 1 && o->state_order == CDKF_ORDER_ZEROTH) ? 1 : 0;
-  if (!smoother) {
+  if (gradient) {
+    rc = run(Key(mdl->drift_kind, (int)sizeof(R), m, 0, 0, 0, 2, generic, 0), a1, null_r, null_r, null_r, null_r, null_r);
+  } else if (!smoother) {
     rc = run(Key(mdl->drift_kind, (int)sizeof(R), m, algo == 1, zeroth, o->forecast ? 1 : 0, 0, generic, ek), a1, a2, a3, a4, null_r, null_r);
   } else {
     rc = run(Key(mdl->drift_kind, (int)sizeof(R), m, 0, zeroth, 0, 0, generic, ek), a1, a2, null_r, null_r, null_r, null_r);
@@ -394,16 +467,20 @@ template int launch_custom<double>(int, const cdkf_model*, const cdkf_opts*, int
                                    double*, double*, double*, double*, double*, int32_t*, hipStream_t);
 
 int custom_register(int state_dim, int n_theta, const char* f_src, const char* jac_src, const char* divgrad_src) {
-  if (state_dim < 1 || state_dim > 6 || n_theta < 0 || !f_src || !jac_src) {
-    set_error("custom drift: need 1 <= state_dim <= 6, n_theta >= 0 and sources for f and its Jacobian");
+  if (state_dim < 1 || state_dim > 6 || n_theta < 0 || !f_src) {
+    set_error("custom drift: need 1 <= state_dim <= 6, n_theta >= 0 and the source of f (jac_src NULL or empty: the Jacobian is "
+              "derived from f_src by dual numbers; divgrad_src \"auto\": so is grad(div f))");
     return CDKF_EINVAL;
   }
   std::lock_guard<std::mutex> lock(g_mutex);
-  CustomDrift c{state_dim, n_theta, f_src, jac_src, divgrad_src ? divgrad_src : "", divgrad_src != nullptr};
+  const bool auto_jac = !jac_src || blank(jac_src);
+  const bool auto_g = divgrad_src && std::string(divgrad_src) == "auto";
+  CustomDrift c{state_dim, n_theta, f_src, auto_jac ? "" : jac_src, (divgrad_src && !auto_g) ? divgrad_src : "", divgrad_src != nullptr,
+                auto_jac, auto_g};
   for (size_t k = 0; k < g_drifts.size(); ++k) {
     const CustomDrift& e = g_drifts[k];
     if (e.d == c.d && e.n_theta == c.n_theta && e.f_src == c.f_src && e.jac_src == c.jac_src && e.g_src == c.g_src &&
-        e.has_g == c.has_g)
+        e.has_g == c.has_g && e.auto_jac == c.auto_jac && e.auto_g == c.auto_g)
       return CDKF_DRIFT_CUSTOM_BASE + (int)k;
   }
   g_drifts.push_back(c);
@@ -416,7 +493,7 @@ int custom_compile_check(int kind, int bytes_per_real, int emission_dim, int alg
     return CDKF_EINVAL;
   }
   if (!custom_kind(kind) || (bytes_per_real != 4 && bytes_per_real != 8) || emission_dim < 1 || emission_dim > 6 || algo < 0 ||
-      algo > 2) {
+      algo > 3) {
     set_error("custom drift compile check: bad arguments");
     return CDKF_EINVAL;
   }
@@ -427,6 +504,7 @@ int custom_compile_check(int kind, int bytes_per_real, int emission_dim, int alg
   }
   std::vector<char> code;
   const int zeroth = (algo != 1 && state_order == CDKF_ORDER_ZEROTH) ? 1 : 0;
+  if (algo == 3) return compile_variant(c, Key(kind, bytes_per_real, emission_dim, 0, 0, 0, 2, 0, 0), "gfx950", code);
   int rc = compile_variant(c, Key(kind, bytes_per_real, emission_dim, algo == 1, zeroth, 0, 0, 0, emission_kind), "gfx950", code);
   if (!rc && algo == 2) rc = compile_variant(c, Key(kind, bytes_per_real, emission_dim, 0, 0, 0, 1, 0, 0), "gfx950", code);
   return rc;

@@ -17,6 +17,7 @@ namespace cdkf {
 
 static bool sens_shape_available(const cdkf_model* mdl, const cdkf_opts* o) {
   if (o->state_order == CDKF_ORDER_ZEROTH || o->num_iter != 1 || o->forecast) return false;
+  if (custom_kind(mdl->drift_kind)) return custom_grad_available(mdl, o);  // a run-time compiled drift: its derivatives by dual numbers
 #define X(KIND, DRIFT, D_, M_) \
   if (mdl->drift_kind == KIND && mdl->state_dim == D_ && mdl->emission_dim == M_) return true;
   CDKF_GRAD_SHAPES(X)
@@ -123,6 +124,7 @@ int launch_ekf_grad(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_
   // drift parameters only: forward sensitivities where a register-resident kernel exists (one sweep, no workspace);
   // otherwise, and whenever the model block is requested, the forward + reverse sweep pair
   const bool sens = !grad_model && sens_shape_available(mdl, o);
+  if (sens && custom_kind(mdl->drift_kind)) return launch_custom<R>(3, mdl, o, N, T, t, y, ll, grad, nullptr, nullptr, nullptr, status, stream);
   if (sens || grad_model) {  // (the model block as well: m0, P0, L Qc L^T, H, bias, R)
     bool handled = false;
     const int rc = try_lpe_grad<R>(mdl, o, N, T, t, y, ll, grad, grad_model, status, stream, &handled);

@@ -254,6 +254,8 @@ def _drift_like(drift, theta_grad):
         return LearnableLorenz63(sigma=theta_grad[..., 0], rho=theta_grad[..., 1], beta=theta_grad[..., 2])
     if isinstance(drift, LearnableLorenz96):
         return LearnableLorenz96(forcing=theta_grad[..., 0])
+    if isinstance(drift, LearnableCustomDrift):
+        return drift._replace(theta=theta_grad.reshape(theta_grad.shape[:-1] + np.shape(drift.theta)))
     if isinstance(drift, LearnableMLP):
         lead, parts, off = theta_grad.shape[:-1], [], 0
         for a in drift:

@@ -109,14 +109,19 @@ class LearnableCustomDrift(NamedTuple):
 
       f_src        statements computing ``fx[i]`` from ``x[j]`` and ``theta[k]``         e.g. "fx[0] = x[1]; fx[1] = -theta[0]*sin(x[0]);"
       jac_src      statements assigning the non-zero ``F[i][j]`` = d f_i / d x_j        e.g. "F[0][1] = R(1); F[1][0] = -theta[0]*cos(x[0]);"
-      divgrad_src  statements assigning ``g[i]`` = d/dx_i sum_j d f_j / d x_j, or None (EKF ``state_order='second'`` is
-                   then refused -- the reference obtains this term by differentiating the drift twice)
+                   or None: the Jacobian is derived from ``f_src`` by dual numbers (what ``jacfwd`` does in the reference)
+      divgrad_src  statements assigning ``g[i]`` = d/dx_i sum_j d f_j / d x_j; "auto": derived from ``f_src`` (second derivatives by
+                   nested dual numbers); "" : identically zero; None: EKF ``state_order='second'`` is refused
+
+    ``cdnlgssm_loglik_and_grad`` / ``fit_sgd`` differentiate the log-likelihood w.r.t. ``theta`` (dual numbers again: ``state_order``
+    'first', or 'second' with ``divgrad_src=""``).  Wherever derivatives are derived, ``f_src`` is also compiled with a dual-number
+    scalar type ``T`` in place of ``R``: declare temporaries ``auto`` or ``T`` there, not ``R``.
 
     ``R`` is the compute type (float or double); state_dim <= 6.  ``py_f`` (optional) is the same function as a Python
     callable ``f(x, u, t)`` for host-side use; it is never called by the filter."""
     theta: Any
     f_src: str
-    jac_src: str
+    jac_src: Optional[str] = None
     divgrad_src: Optional[str] = None
     py_f: Optional[Any] = None
 

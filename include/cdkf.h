@@ -266,10 +266,17 @@ int cdkf_emission_moments_f32_dev(const cdkf_model* mdl, int64_t rows, const flo
  *                    (the reference's second-order mean term 0.5 P grad(div f), inference_ekf.py:108-116)
  *      e.g. a pendulum:  f_src "fx[0] = x[1]; fx[1] = -theta[0] * sin(x[0]);"
  *                        jac_src "F[0][1] = R(1); F[1][0] = -theta[0] * cos(x[0]);"
+ *      Derivatives by dual numbers (round 3; the reference calls jacfwd / value_and_grad on the callable it is given,
+ *      inference_ekf.py:95, 108-116, ssm_temissions.py:550-568): jac_src NULL or empty -- the Jacobian is derived from f_src;
+ *      divgrad_src "auto" -- so is grad(div f); and cdkf_ekf_loglik_grad_* differentiates the log-likelihood w.r.t. theta
+ *      (forward sensitivities, a lane per (trajectory, parameter); linear emission, num_iter 1, state_order 'first', or 'second'
+ *      with an empty divgrad_src = identically zero).  f_src is then compiled a second time with the scalar type T = a dual
+ *      number in place of R: x, theta and fx are arrays of T there -- declare temporaries `auto` or `T`, not `R`
+ *      (R(...) constants, +, -, *, /, sin, cos, tan, tanh, sinh, cosh, exp, log, sqrt, pow, fabs, atan and comparisons are provided).
  *      state_dim <= 6, emission_dim <= 6.  Returns the drift_kind to put in cdkf_model (>= CDKF_DRIFT_CUSTOM_BASE; the
- *      same sources give the same kind) or a negative CDKF_E* code.  Filters (EKF all orders, UKF), EKF smoother and
- *      forecast mode are available for custom kinds; kernels compile on first use (seconds) and are cached.  Compile
- *      errors in the snippets surface through cdkf_last_error(). */
+ *      same sources give the same kind) or a negative CDKF_E* code.  Filters (EKF all orders, UKF), EKF smoother,
+ *      forecast mode and the drift-parameter gradient are available for custom kinds; kernels compile on first use (seconds)
+ *      and are cached.  Compile errors in the snippets surface through cdkf_last_error(). */
 int cdkf_custom_drift_register(int state_dim, int n_theta, const char* f_src, const char* jac_src,
                                const char* divgrad_src);
 /* A user-supplied EMISSION function (the reference accepts any callable h and linearises it with jacfwd,

@@ -258,3 +258,130 @@ def test_custom_emission_with_builtin_drift(hip_lib):
     assert relerr(postu.filtered_covariances, refu["filtered_covariances"]) < 1e-9
     with pytest.raises(NotImplementedError, match="no gradient kernel"):
         cd.cdnlgssm_loglik_and_grad(P, y, t[..., None])
+
+
+# ---- derivatives by dual numbers (round 3): the Jacobian, grad(div f) and the parameter gradient from f_src alone -----------------------
+# a drift with every provided function in it: damped, driven, saturating
+NL_F = ("auto s = sin(x[0]); auto e = exp(-theta[2] * x[1] * x[1]);"
+        "fx[0] = x[1] + theta[1] * tanh(x[0] * x[1]);"
+        "fx[1] = -theta[0] * s * e - theta[1] * x[1] + R(0.3) * cos(R(2) * x[0]) / (R(1) + x[0] * x[0]) + sqrt(R(1) + x[1] * x[1]) * pow(theta[2], 2);")
+L63_F = "fx[0] = theta[0] * (x[1] - x[0]); fx[1] = x[0] * (theta[1] - x[2]) - x[1]; fx[2] = x[0] * x[1] - theta[2] * x[2];"
+L63_J = ("F[0][0] = -theta[0]; F[0][1] = theta[0]; F[1][0] = theta[1] - x[2]; F[1][1] = -R(1); F[1][2] = -x[0];"
+         "F[2][0] = x[1]; F[2][1] = x[0]; F[2][2] = -theta[2];")
+
+
+def test_dual_number_variants_compile_without_a_gpu():
+    """jac_src None (Jacobian by dual numbers), divgrad_src "auto" (nested), the gradient sweep (algo 3): every variant goes through
+    hipRTC for gfx950 on the CPU box, both precisions; a snippet that pins a temporary to R fails in the dual-number variant only,
+    with the compiler's diagnostic."""
+    L = _ffi.lib()
+    k = _ffi.register_custom_drift(2, 3, NL_F, None, "auto")
+    for nbytes in (8, 4):
+        for algo in (0, 1, 2):
+            assert L.cdkf_custom_drift_compile(k, nbytes, 1, algo, 2, 0) == 0, L.cdkf_last_error().decode()
+        assert L.cdkf_custom_drift_compile(k, nbytes, 2, 3, 1, 0) == 0, L.cdkf_last_error().decode()
+    k3 = _ffi.register_custom_drift(3, 3, L63_F, L63_J, "")
+    assert L.cdkf_custom_drift_compile(k3, 8, 3, 3, 2, 0) == 0, L.cdkf_last_error().decode()
+    pinned = _ffi.register_custom_drift(2, 1, "R s = sin(x[0]); fx[0] = x[1]; fx[1] = -theta[0] * s;", "F[0][1] = R(1); F[1][0] = -theta[0] * cos(x[0]);", None)
+    assert L.cdkf_custom_drift_compile(pinned, 8, 1, 0, 1, 0) == 0                 # plain filter: R temporaries are fine
+    assert L.cdkf_custom_drift_compile(pinned, 8, 1, 3, 1, 0) != 0                 # gradient: f_src is compiled with T = a dual number
+    assert "drift_f:1" in L.cdkf_last_error().decode()
+
+
+@pytest.mark.gpu
+def test_custom_drift_derivatives_by_dual_numbers(hip_lib):
+    """(1) Lorenz-63 written as a snippet: with the Jacobian derived by dual numbers the filter reproduces the built-in drift's
+    numbers (second order too: grad(div f) "auto" = 0), and the log-likelihood gradient w.r.t. (sigma, rho, beta) equals the built-in
+    forward-sensitivity kernel's and the oracle's.  (2) A drift with tanh / exp / sqrt / pow / cos in it: derived Jacobian and
+    grad(div f) against finite differences of the oracle running the same drift, gradient against central differences of the
+    HIP log-likelihood itself."""
+    rng = np.random.default_rng(90)
+    ref_mdl = o.lorenz63_model(2)
+    N, T = 7, 25
+    t = o.irregular_times(rng, N, T, 0.3)
+    y = o.simulate(ref_mdl, t, rng)
+    th = np.array([10.0, 28.0, 8.0 / 3.0])
+    from helpers import params_from
+    P_builtin = params_from(ref_mdl)
+    flt_ref = cd.cdnlgssm_filter(P_builtin, y, t[..., None])
+    ll_ref, g_ref = o.ekf_loglik_grad(ref_mdl, t, y)
+    for jac, dg in ((L63_J, ""), (None, "auto")):
+        P = params_for(ref_mdl, cd.LearnableCustomDrift(th, L63_F, jac, dg))
+        flt = cd.cdnlgssm_filter(P, y, t[..., None])
+        for k in FILTER_KEYS:
+            assert relerr(getattr(flt, k), getattr(flt_ref, k)) < 1e-12, (k, jac is None)
+        if dg == "":      # (the gradient sweep carries no second-order term: grad(div f) must be registered as identically zero)
+            ll, g = cd.cdnlgssm_loglik_and_grad(P, y, t[..., None])
+            np.testing.assert_allclose(ll, ll_ref, rtol=1e-11)
+            assert np.abs(np.asarray(g.theta) - g_ref).max() < 1e-9 * np.abs(g_ref).max()
+    P1 = params_for(ref_mdl, cd.LearnableCustomDrift(th, L63_F, None, None))
+    ll1, g1 = cd.cdnlgssm_loglik_and_grad(P1, y, t[..., None], cd.EKFHyperParams(state_order="first"))   # Jacobian AND gradient from f_src alone
+    assert np.abs(np.asarray(g1.theta) - g_ref).max() < 1e-9 * np.abs(g_ref).max()
+    with pytest.raises(NotImplementedError, match="no gradient kernel"):
+        cd.cdnlgssm_loglik_and_grad(params_for(ref_mdl, cd.LearnableCustomDrift(th, L63_F, None, "auto")), y, t[..., None])
+
+    # (2) a drift that is not in any registry
+    theta = np.array([1.7, 0.25, 0.4])
+
+    def f_np(x, thv):
+        s, e = np.sin(x[..., 0]), np.exp(-thv[2] * x[..., 1] ** 2)
+        return np.stack([x[..., 1] + thv[1] * np.tanh(x[..., 0] * x[..., 1]),
+                         -thv[0] * s * e - thv[1] * x[..., 1] + 0.3 * np.cos(2 * x[..., 0]) / (1 + x[..., 0] ** 2)
+                         + np.sqrt(1 + x[..., 1] ** 2) * thv[2] ** 2], -1)
+
+    def jac_np(x, thv, h=1e-6):
+        cols = [(f_np(x + h * np.eye(2)[j], thv) - f_np(x - h * np.eye(2)[j], thv)) / (2 * h) for j in range(2)]
+        return np.stack(cols, -1)
+
+    def g_np(x, thv, h=1e-4):
+        div = lambda z: np.trace(jac_np(z, thv, 1e-5), axis1=-2, axis2=-1)
+        return np.stack([(div(x + h * np.eye(2)[j]) - div(x - h * np.eye(2)[j])) / (2 * h) for j in range(2)], -1)
+
+    mdl = make_model(o.CallableDrift(theta, f_np, jac_np, g_np), 1)
+    N, T = 6, 30
+    t = o.irregular_times(rng, N, T, 0.4)
+    y = o.simulate(mdl, t, rng)
+    P = params_for(mdl, cd.LearnableCustomDrift(theta, NL_F, None, "auto"))
+    for order, tol in (("first", 1e-7), ("second", 2e-5)):   # (the oracle's own derivatives here are finite differences)
+        ref = o.ekf_filter(mdl, t, y, state_order=order)
+        post = cd.cdnlgssm_filter(P, y, t[..., None], cd.EKFHyperParams(state_order=order))
+        assert relerr(post.filtered_means, ref["filtered_means"]) < tol, order
+        assert relerr(post.marginal_loglik, ref["marginal_loglik"]) < tol, order
+    hyp = cd.EKFHyperParams(state_order="first")
+    Pg = params_for(mdl, cd.LearnableCustomDrift(theta, NL_F, None, None))
+    ll, g = cd.cdnlgssm_loglik_and_grad(Pg, y, t[..., None], hyp)
+    g = np.asarray(g.theta)
+    for p in range(3):
+        h = 1e-5 * max(1.0, abs(theta[p]))
+        lp = cd.cdnlgssm_filter(params_for(mdl, cd.LearnableCustomDrift(theta + h * np.eye(3)[p], NL_F, None, None)), y, t[..., None], hyp).marginal_loglik
+        lm = cd.cdnlgssm_filter(params_for(mdl, cd.LearnableCustomDrift(theta - h * np.eye(3)[p], NL_F, None, None)), y, t[..., None], hyp).marginal_loglik
+        fd = (lp - lm) / (2 * h)
+        assert np.abs(g[:, p] - fd).max() < 1e-6 * max(1.0, np.abs(fd).max()), (p, g[:, p], fd)
+    g32 = np.asarray(cd.cdnlgssm_loglik_and_grad(Pg, y.astype(np.float32), t[..., None].astype(np.float32), hyp)[1].theta)
+    assert np.abs(g32 - g).max() < 5e-3 * np.abs(g).max()
+
+
+@pytest.mark.gpu
+def test_fit_sgd_on_a_custom_drift(hip_lib):
+    """fit_sgd with a run-time compiled drift: the trainable leaf is the drift's theta, value and gradient come from the dual-number
+    sweep; Adam lowers the loss and moves the pendulum's stiffness and damping towards the truth."""
+    from cd_dynamax_amd import fit
+    from cd_dynamax_amd.params import ParameterProperties as PP
+    rng = np.random.default_rng(91)
+    truth = np.array([2.0, 0.3])
+    mdl = make_model(pendulum_oracle(truth), 2)
+    N, T = 24, 60
+    t = o.irregular_times(rng, N, T, 3.0)
+    y = o.simulate(mdl, t, rng)
+    model = cd.ContDiscreteNonlinearGaussianSSM(2, 2)
+    start = params_for(mdl, cd.LearnableCustomDrift(np.array([1.2, 0.8]), PEND_F, None, None))
+    frozen = PP(trainable=False)
+    props = cd.ParamsCDNLGSSM(
+        initial=cd.ParamsLGSSMInitial(cd.LearnableVector(frozen), cd.LearnableMatrix(frozen)),
+        dynamics=cd.ParamsCDNLGSSMDynamics(cd.LearnableCustomDrift(PP(), None, None, None), cd.LearnableMatrix(frozen), cd.LearnableMatrix(frozen), 1.0),
+        emissions=cd.ParamsCDNLGSSMEmissions(cd.LearnableLinear(frozen, frozen), cd.LearnableMatrix(frozen)))
+    hyp = cd.EKFHyperParams(state_order="first")
+    new, losses = model.fit_sgd(start, props, y, t[..., None], hyp, optimizer=fit.Adam(0.05), batch_size=N, num_epochs=80)
+    got = np.asarray(new.dynamics.drift.theta)
+    assert np.all(np.isfinite(losses)) and losses[-1] < losses[0]
+    assert np.all(np.abs(got - truth) < 0.5 * np.abs(np.array([1.2, 0.8]) - truth)), got
