@@ -393,7 +393,7 @@ def register_custom_drift(state_dim: int, n_theta: int, f_src: str, jac_src: Opt
 
 def register_custom_emission(state_dim: int, emission_dim: int, h_src: str, hjac_src: str) -> int:
     """cdkf_custom_emission_register: returns the emission_kind (same sources -> same kind)."""
-    kind = lib().cdkf_custom_emission_register(int(state_dim), int(emission_dim), h_src.encode(), hjac_src.encode())
+    kind = lib().cdkf_custom_emission_register(int(state_dim), int(emission_dim), h_src.encode(), None if hjac_src is None else hjac_src.encode())
     if kind < 0:
         check(kind)
     return kind

@@ -141,9 +141,23 @@ std::string generate_source(const CustomDrift& c, int bytes, int m, int ukf, int
     s += "    for (int r = 0; r < M; ++r) { for (int k = 0; k < D; ++k) eta_[r * D + k] = a.H[r][k]; eta_[M * D + r] = a.hb[r]; }\n  }\n";
     s += "  CDKF_DEV void h(const R* x, R (&hx)[M]) const {\n    const R* eta = eta_; (void)eta;\n";
     s += "#line 1 \"emission_h\"\n" + em->h_src + "\n  }\n";
+    const bool auto_hjac = blank(em->jac_src);  // jacfwd(h) by dual numbers (inference_ekf.py:258-259)
+    if (auto_hjac) {
+      s += "  template <typename T> CDKF_DEV void h_t(const T* x, const T* eta, T (&hx)[M]) const {\n    (void)eta;\n";
+      s += "#line 1 \"emission_h\"\n" + em->h_src + "\n  }\n";
+    }
     s += "  CDKF_DEV void jac(const R* x, R (&H)[M][D]) const {\n    const R* eta = eta_; (void)eta;\n";
     s += "    for (int r_ = 0; r_ < M; ++r_) for (int k_ = 0; k_ < D; ++k_) H[r_][k_] = R(0);\n";
-    s += "#line 1 \"emission_jacobian\"\n" + em->jac_src + "\n  }\n};\n}  // namespace cdkf\n";
+    if (auto_hjac) {
+      s += "    typedef Dual<R, D> T;\n    T xt[D], et[M * D + M], ht[M];\n";
+      s += "    for (int i_ = 0; i_ < D; ++i_) { xt[i_] = T(x[i_]); xt[i_].g[i_] = R(1); }\n";
+      s += "    for (int k_ = 0; k_ < M * D + M; ++k_) et[k_] = T(eta_[k_]);\n";
+      s += "    h_t<T>(xt, et, ht);\n";
+      s += "    for (int r_ = 0; r_ < M; ++r_) for (int k_ = 0; k_ < D; ++k_) H[r_][k_] = ht[r_].g[k_];\n  }\n";
+    } else {
+      s += "#line 1 \"emission_jacobian\"\n" + em->jac_src + "\n  }\n";
+    }
+    s += "};\n}  // namespace cdkf\n";
   }
   s += "using R = " + std::string(bytes == 8 ? "double" : "float") + ";\n";
   s += "constexpr int DD = " + std::to_string(c.d) + ", MM = " + std::to_string(m) + ";\n";
@@ -291,10 +305,12 @@ static int c_dim(int kind) {
 }
 
 int custom_emission_register(int state_dim, int emission_dim, const char* h_src, const char* hjac_src) {
-  if (state_dim < 1 || state_dim > 6 || emission_dim < 1 || emission_dim > 6 || !h_src || !hjac_src) {
-    set_error("custom emission: need 1 <= state_dim, emission_dim <= 6 and sources for h and its Jacobian");
+  if (state_dim < 1 || state_dim > 6 || emission_dim < 1 || emission_dim > 6 || !h_src) {
+    set_error("custom emission: need 1 <= state_dim, emission_dim <= 6 and the source of h (hjac_src NULL or empty: its Jacobian is "
+              "derived from h_src by dual numbers)");
     return CDKF_EINVAL;
   }
+  if (!hjac_src) hjac_src = "";
   std::lock_guard<std::mutex> lock(g_mutex_emis());
   for (size_t k = 0; k < g_emis.size(); ++k)
     if (g_emis[k].d == state_dim && g_emis[k].m == emission_dim && g_emis[k].h_src == h_src && g_emis[k].jac_src == hjac_src)

@@ -138,12 +138,13 @@ class LearnableCustomEmission(NamedTuple):
 
       h_src     statements computing ``hx[r]`` from ``x[k]`` and ``eta[j]``            e.g. "hx[0] = eta[0] * sin(x[0]);"
       hjac_src  statements assigning the non-zero ``H[r][k]`` = d h_r / d x_k          e.g. "H[0][0] = eta[0] * cos(x[0]);"
+                or None: derived from ``h_src`` by dual numbers (the reference's jacfwd; temporaries in ``h_src`` then ``auto`` / ``T``)
 
     ``eta``: the emission's parameter vector, at most emission_dim * (state_dim + 1) entries (it travels in the H / bias
     block of the C model).  state_dim, emission_dim <= 6.  ``py_h`` (optional): the same function as a Python callable."""
     eta: Any
     h_src: str
-    hjac_src: str
+    hjac_src: Optional[str] = None
     py_h: Optional[Any] = None
 
     def f(self, x, u=None, t=None):

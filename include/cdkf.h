@@ -282,7 +282,8 @@ int cdkf_custom_drift_register(int state_dim, int n_theta, const char* f_src, co
 /* A user-supplied EMISSION function (the reference accepts any callable h and linearises it with jacfwd,
  * inference_ekf.py:258-259, or pushes the sigma points through it, inference_ukf.py:162-203):
  *   h_src     body computing  hx[r] = h_r(x, eta)                 (x: const R*, eta: const R*, R = float or double)
- *   hjac_src  body assigning the NON-ZERO entries H[r][k] = d h_r / d x_k   (H is zeroed first)
+ *   hjac_src  body assigning the NON-ZERO entries H[r][k] = d h_r / d x_k   (H is zeroed first); NULL or empty: derived from h_src
+ *             by dual numbers (h_src is then also compiled with T = a dual number in place of R: temporaries `auto` / `T`)
  * eta is the model's emission block read as a flat vector: eta[r*d + k] = cdkf_model.H[r][k], eta[m*d + r] = h_bias[r].
  * e.g. observing the sine of a pendulum angle: h_src "hx[0] = eta[0] * sin(x[0]);"  hjac_src "H[0][0] = eta[0] * cos(x[0]);"
  * Returns the value for cdkf_model.emission_kind (>= CDKF_EMISSION_CUSTOM_BASE) or a negative CDKF_E* code.  Runs on the

@@ -221,6 +221,12 @@ def test_custom_emission_pendulum_sine(hip_lib):
         for k in FILTER_KEYS:
             assert relerr(getattr(post, k), ref[k]) < 1e-11, (num_iter, k)
         np.testing.assert_allclose(post.marginal_loglik, ref["marginal_loglik"], rtol=1e-11)
+        # the emission's Jacobian (and the drift's) derived from h_src / f_src by dual numbers -- jacfwd in the reference
+        Pa = P._replace(dynamics=P.dynamics._replace(drift=cd.LearnableCustomDrift(theta, PEND_F)),
+                        emissions=P.emissions._replace(emission_function=cd.LearnableCustomEmission(eta, SIN_H)))
+        posta = cd.cdnlgssm_filter(Pa, y, t[..., None], cd.EKFHyperParams(state_order="first"), num_iter=num_iter)
+        for k in FILTER_KEYS:
+            assert relerr(getattr(posta, k), getattr(post, k)) < 1e-13, (num_iter, k)
     refu = o.ukf_filter(mdl, t, y)
     postu = cd.cdnlgssm_filter(P, y, t[..., None], cd.UKFHyperParams())
     for k in FILTER_KEYS:
