@@ -583,8 +583,17 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
 
     // ================= (2) predict k-1 -> k: the Runge-Kutta steps of the interval, reversed ========================================
     const R t0 = tp[(k - 1) * a.t_sk], t1 = tp[k * a.t_sk];
+    // an adaptive solve: the forward (workgroup) sweep logged the step sizes it accepted in this interval; the reverse of the solve
+    // treats them as constants -- the controller's factor carries no derivative, as in the reference's reverse mode through diffrax
+    const R* dtl = a.dtlog ? a.dtlog + (n * (a.T - 1) + (k - 1)) * (1 + a.dtlog_cap) : nullptr;
     long Ssteps = 0;
-    {
+    if (dtl) {
+      Ssteps = (long)dtl[0];
+      if (Ssteps > a.dtlog_cap) {  // more accepted steps than the log holds: the gradient of this trajectory is not valid
+        Ssteps = a.dtlog_cap;
+        st |= kStatusMaxSteps;
+      }
+    } else {
       R tprev = t0, tnext = rmin(t0 + a.dt0, t1);
       while (tprev < t1 && Ssteps < a.max_steps) {
         tprev = rmin(tnext, t1);
@@ -609,7 +618,7 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
       {
         R tprev = t0, tnext = rmin(t0 + a.dt0, t1);
         for (long s = 0; s < ce; ++s) {
-          const R dt = tnext - tprev;
+          const R dt = dtl ? dtl[1 + s] : tnext - tprev;
           if (s >= cs) {
             R* sv = starts + (s - cs) * sz;
             rows2d(d, d, [&](int i, int j) { return P0s[i * ld + j]; }, [&](int i, int j, R v) { sv[i * d + j] = v; });

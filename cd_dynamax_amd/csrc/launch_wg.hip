@@ -332,10 +332,10 @@ int release_grad_workspace() {
 }
 
 // beyond the wavefront kernel's shapes: the workgroup-per-trajectory reverse sweep -- Lorenz-96 and linear drifts (for both the mean's
-// second-order term vanishes), fixed steps, as far as its LDS plan goes in fp64 (launch_adjwg.hip)
+// second-order term vanishes), fixed or adaptive steps, as far as its LDS plan goes in fp64 (launch_adjwg.hip)
 static bool adjoint_wg_shape(const cdkf_model* mdl, const cdkf_opts* o) {
   if (mdl->drift_kind != CDKF_DRIFT_LORENZ96 && mdl->drift_kind != CDKF_DRIFT_LINEAR) return false;
-  if (mdl->emission_kind != 0 || o->adaptive) return false;
+  if (mdl->emission_kind != 0) return false;
   return wg_shape_available(mdl, 8) && adjoint_wg_fits(mdl->state_dim, mdl->emission_dim, 8);
 }
 bool adjoint_shape_available(const cdkf_model* mdl, const cdkf_opts* o) {
@@ -359,11 +359,18 @@ static int launch_ekf_grad_adjoint_wg(const cdkf_model* mdl, const cdkf_opts* o,
   int cap = 8;  // step starts kept per replay chunk of an interval (CDKF_ADJ_WG_STARTS)
   if (const char* e = getenv("CDKF_ADJ_WG_STARTS")) cap = atoi(e) > 0 ? atoi(e) : 8;
   const size_t nscr = (size_t)N * (size_t)adjoint_wg_scratch_reals(mdl->state_dim, cap);
+  // an adaptive solve: the forward (workgroup) sweep logs the accepted step sizes of every interval (up to CDKF_ADJ_DT_CAP, default
+  // 64; a longer interval raises MAX_STEPS on that trajectory) and the reverse sweep replays them
+  int dtcap = 64;
+  if (const char* e = getenv("CDKF_ADJ_DT_CAP")) dtcap = atoi(e) > 0 ? atoi(e) : 64;
+  const size_t ndt = (o->adaptive && T > 1) ? (size_t)N * (size_t)(T - 1) * (size_t)(1 + dtcap) : 0;
   AdjWorkspace& ws = g_adj_ws;
-  if (int wrc = workspace_reserve(ws, (2 * (nm + nP) + nscr) * sizeof(R), stream)) return wrc;
+  if (int wrc = workspace_reserve(ws, (2 * (nm + nP) + nscr + ndt) * sizeof(R), stream)) return wrc;
   R* w = (R*)ws.p;
   a.t = t; a.y = y; a.ll = ll; a.status = status;
   a.fm = w; a.fP = w + nm; a.pm = w + nm + nP; a.pP = w + 2 * nm + nP;
+  a.dtlog = ndt ? w + 2 * (nm + nP) + nscr : nullptr;
+  a.dtlog_cap = ndt ? dtcap : 0;
   rc = wave40_shape(mdl, o) ? launch_wave40<R>(a, stream) : launch_wg_dispatch<R>(a, mdl, false, stream);
   if (!rc) rc = launch_adjoint_wg_kernel<R>(a, grad, grad_model, w + 2 * (nm + nP), cap, stream);
   CDKF_HIP_CHECK(hipEventRecord(ws.done, stream));

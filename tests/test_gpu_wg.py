@@ -556,11 +556,11 @@ def test_reverse_sweep_other_runge_kutta_methods(hip_lib, solver):
 @pytest.mark.parametrize("solver,ctrl", [("tsit5", dict(rtol=1e-5, atol=1e-7)), ("dopri5", dict(rtol=1e-4, atol=1e-6, pcoeff=0.2, icoeff=0.5))])
 def test_reverse_sweep_under_adaptive_steps(hip_lib, solver, ctrl, monkeypatch):
     """value-and-gradient under diffrax.PIDController on the reverse sweep: the forward (workgroup) sweep logs the step sizes it
-    accepts, the reverse sweep replays them as constants.  MLP d = 5 (second order) and Lorenz-96 d = 6 against the oracle doing the
-    same (itself equal to the forward-sensitivity oracle, tests/test_oracle.py); a log too short for an interval raises MAX_STEPS."""
+    accepts, the reverse sweep replays them as constants.  MLP d = 5 (second order), Lorenz-96 d = 6 and d = 12 (the workgroup-per-
+    trajectory reverse sweep) against the oracle doing the same (itself equal to the forward-sensitivity oracle, tests/test_oracle.py); a log too short for an interval raises MAX_STEPS."""
     rng = np.random.default_rng(51)
     settings = {"solver": solver, "dt0": 0.05, "stepsize_controller": cd.PIDController(**ctrl)}
-    for mdl, order in ((mlp_model(rng, 5, 2, (9, 7)), "second"), (lorenz96_model(6, 3), "first")):
+    for mdl, order in ((mlp_model(rng, 5, 2, (9, 7)), "second"), (lorenz96_model(6, 3), "first"), (lorenz96_model(12, 5), "second")):
         N, T = 4, 8
         t = o.irregular_times(rng, N, T, 0.05)
         t[:, 4:] += 0.15
