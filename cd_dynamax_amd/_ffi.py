@@ -92,6 +92,11 @@ class CdkfError(RuntimeError):
         self.code = code
 
 
+class CdkfUnsupported(CdkfError, NotImplementedError):
+    """CDKF_EUNSUPPORTED: no kernel for this (drift, shape, precision, option) combination -- the library's counterpart of the
+    NotImplementedError the host layer raises for what it can rule out before the call."""
+
+
 # every symbol include/cdkf.h declares (tests/test_abi.py checks this list against the header)
 _ALGOS = ("ekf_filter", "ukf_filter", "ekf_smoother")
 SYMBOLS = (
@@ -279,7 +284,7 @@ def lib() -> C.CDLL:
 
 def check(rc: int) -> None:
     if rc != CDKF_OK:
-        raise CdkfError(rc, lib().cdkf_last_error().decode("utf-8", "replace"))
+        raise (CdkfUnsupported if rc == CDKF_EUNSUPPORTED else CdkfError)(rc, lib().cdkf_last_error().decode("utf-8", "replace"))
 
 
 def default_opts() -> CdkfOpts:

@@ -1,7 +1,7 @@
 // cdkf_adjoint_wg_kernels.h -- reverse sweep (discrete adjoint) of the EKF log-likelihood for state dimensions beyond the wavefront
 // kernel's eight (cdkf_adjoint_kernels.h): d ll / d theta for the drift parameters (Lorenz-96: the forcing; linear: W and b) and, on
 // request, for every other parameter of the model (m0, P0, L Qc L^T, H, bias, R), state_dim and emission_dim up to what nine q x q
-// matrices of LDS allow (q = max(d, m): 41 in fp64, 58 in fp32) -- BASELINE config 4's Lorenz-96 at d = 40 among them.
+// matrices of LDS allow (q = max(d, m): 43 in fp64, 62 in fp32) -- BASELINE config 4's Lorenz-96 at d = 40 among them.
 //
 // The reference gets this from jax.value_and_grad through the filter (ssm_temissions.py:550-568; reverse mode through diffrax with
 // RecursiveCheckpointAdjoint, diffrax_utils.py:49) for a model of any size; same quantity here, written out

@@ -12,8 +12,8 @@ long adjoint_wg_scratch_reals(int d, int cap) { return awg_scratch_reals(d, cap)
 template <typename R>
 int launch_adjoint_wg_kernel(const WgArgs<R>& a, R* grad, R* grad_model, R* scratch, int cap, hipStream_t stream) {
   if (!adjoint_wg_fits(a.d, a.m, (int)sizeof(R))) {
-    set_error("reverse sweep: state_dim %d / emission_dim %d need %zu bytes of LDS in fp%d (nine q x q matrices; the limit is q = 41 in "
-              "fp64, 58 in fp32)", a.d, a.m, (size_t)awg_lds_reals(a.d, a.m) * sizeof(R), (int)sizeof(R) * 8);
+    set_error("reverse sweep: state_dim %d / emission_dim %d need %zu bytes of LDS in fp%d (nine q x q matrices; the limit is q = 43 in "
+              "fp64, 62 in fp32)", a.d, a.m, (size_t)awg_lds_reals(a.d, a.m) * sizeof(R), (int)sizeof(R) * 8);
     return CDKF_EUNSUPPORTED;
   }
   const size_t lds = (size_t)awg_lds_reals(a.d, a.m) * sizeof(R) + 64;

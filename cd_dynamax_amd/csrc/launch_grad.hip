@@ -135,7 +135,7 @@ int launch_ekf_grad(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_
   if (!sens) {
     set_error("loglik_grad: no kernel for drift_kind=%d state_dim=%d emission_dim=%d state_order=%d num_iter=%d "
               "(forward sensitivities: register-resident Lorenz-63 / linear shapes and run-time compiled drifts; reverse sweep: "
-              "state_dim, emission_dim <= 8, MLP hidden <= 64 -- Lorenz-96 / linear drifts up to 41 (fp64) / 58 (fp32); num_iter 1, "
+              "state_dim, emission_dim <= 8, MLP hidden <= 64 -- Lorenz-96 / linear drifts up to 43 (fp64) / 62 (fp32); num_iter 1, "
               "state_order first|second)",
               mdl->drift_kind, mdl->state_dim, mdl->emission_dim, o->state_order, o->num_iter);
     return CDKF_EUNSUPPORTED;

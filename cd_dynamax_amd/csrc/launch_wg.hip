@@ -336,7 +336,9 @@ int release_grad_workspace() {
 static bool adjoint_wg_shape(const cdkf_model* mdl, const cdkf_opts* o) {
   if (mdl->drift_kind != CDKF_DRIFT_LORENZ96 && mdl->drift_kind != CDKF_DRIFT_LINEAR) return false;
   if (mdl->emission_kind != 0) return false;
-  return wg_shape_available(mdl, 8) && adjoint_wg_fits(mdl->state_dim, mdl->emission_dim, 8);
+  // (the gate is precision-agnostic: what the float32 kernels take; the launch refuses -- CDKF_EUNSUPPORTED, with the numbers -- a
+  //  float64 call whose nine matrices do not fit)
+  return wg_shape_available(mdl, 4) && adjoint_wg_fits(mdl->state_dim, mdl->emission_dim, 4);
 }
 bool adjoint_shape_available(const cdkf_model* mdl, const cdkf_opts* o) {
   if (o->num_iter != 1 || o->forecast || o->state_order == CDKF_ORDER_ZEROTH) return false;
@@ -349,6 +351,11 @@ bool adjoint_shape_available(const cdkf_model* mdl, const cdkf_opts* o) {
 template <typename R>
 static int launch_ekf_grad_adjoint_wg(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll,
                                       R* grad, R* grad_model, int32_t* status, hipStream_t stream) {
+  if (!adjoint_wg_fits(mdl->state_dim, mdl->emission_dim, (int)sizeof(R))) {
+    set_error("reverse sweep: state_dim %d / emission_dim %d do not fit its LDS plan in fp%d (nine q x q matrices, q = max of the two: "
+              "q <= 43 in fp64, 62 in fp32)", mdl->state_dim, mdl->emission_dim, (int)sizeof(R) * 8);
+    return CDKF_EUNSUPPORTED;
+  }
   WgArgs<R> a{};
   R* blk = nullptr;
   std::lock_guard<std::mutex> lock(g_adj_mutex);

@@ -5,7 +5,7 @@ the HIP sweep ``cdkf_ekf_loglik_grad_*`` instead of ``jax.value_and_grad`` throu
 Scope.  Trainable drift leaves only (the set-up of the reference's own SGD timer, test_scripts/timers/timer_sgd.py:38-66):
 the drift-gradient entry point -- forward sensitivities for the register-resident Lorenz-63 / linear shapes, the reverse
 sweep otherwise.  Any other trainable leaf (initial mean / covariance, diffusion coefficient / covariance, emission
-weights / bias / covariance): the all-parameter reverse sweep (state and emission dimension <= 8; Lorenz-96 and linear drifts up to 41).  Constrainers: ``None``
+weights / bias / covariance): the all-parameter reverse sweep (state and emission dimension <= 8; Lorenz-96 and linear drifts up to 43 in float64, 62 in float32).  Constrainers: ``None``
 or ``bijectors.RealToPSDBijector`` (the reference's choice for covariances); optimisation runs in the unconstrained space
 as in the reference (to_unconstrained / from_unconstrained, dynamax/parameters.py:53-90).  What the kernels cannot
 differentiate raises NotImplementedError -- silently freezing a leaf would change the optimisation problem.

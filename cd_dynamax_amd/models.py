@@ -314,7 +314,7 @@ def cdnlgssm_loglik_and_grad(
     LearnableLorenz63 / LearnableLinear at the register-resident shapes: forward sensitivities inside the sweep,
     ``state_order`` first or second.  Any registry drift with state_dim, emission_dim <= 8 (LearnableMLP: hidden <= 64; its
     ``state_order='second'`` mean term 0.5 P grad(div f) is reversed too): forward + reverse sweep (discrete adjoint).  LearnableLorenz96 /
-    LearnableLinear beyond eight dimensions (up to 41 in float64, 58 in float32): the workgroup-per-trajectory reverse sweep.  Anything
+    LearnableLinear beyond eight dimensions (up to 43 in float64, 62 in float32): the workgroup-per-trajectory reverse sweep.  Anything
     else raises (no finite-difference fallback)."""
     ukf = isinstance(hyperparams, UKFHyperParams)
     if not ukf and not isinstance(hyperparams, EKFHyperParams):
@@ -370,7 +370,7 @@ def cdnlgssm_loglik_and_grad_all(
     if not _ffi.lib().cdkf_grad_all_supported(_ffi.C.byref(mdl.c), _ffi.C.byref(opts)):
         raise NotImplementedError(
             f"no reverse-sweep kernel for drift {type(params.dynamics.drift).__name__} with state_dim={mdl.state_dim}, "
-            f"emission_dim={mdl.emission_dim}, state_order={hyperparams.state_order} (needs state and emission dimensions <= 8 -- LearnableLorenz96 / LearnableLinear: <= 41 in float64, 58 in float32 --, "
+            f"emission_dim={mdl.emission_dim}, state_order={hyperparams.state_order} (needs state and emission dimensions <= 8 -- LearnableLorenz96 / LearnableLinear: <= 43 in float64, 62 in float32 --, "
             "MLP hidden layers <= 64, num_iter 1, state_order 'first' or 'second')")
     if on_device:  # the sweeps run on the device tensors; the (small) gradient blocks are packed on the host
         ll, gth, _, gm = (x.cpu().numpy() for x in _device.loglik_grad_device(mdl, opts, t, y, True))

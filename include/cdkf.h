@@ -365,7 +365,7 @@ int cdkf_ukf_grad_supported(const cdkf_model* mdl, const cdkf_opts* opts);
  *      symmetric perturbations, which is what a symmetric parametrisation (dynamax RealToPSDBijector) produces.
  *      Reverse sweep (discrete adjoint): cdkf_grad_all_supported() -- state_dim and emission_dim <= 8 for every registry drift
  *      (wavefront per trajectory); beyond that the Lorenz-96 and linear drifts on the workgroup-per-trajectory reverse sweep, as far as
- *      its LDS plan goes (max(state_dim, emission_dim) <= 41 in fp64, 58 in fp32; fixed steps).  Replaces jax.value_and_grad of
+ *      its LDS plan goes (max(state_dim, emission_dim) <= 43 in fp64, 62 in fp32; fixed steps).  Replaces jax.value_and_grad of
  *      marginal_log_prob, /root/reference/src/ssm_temissions.py:550-568. ---------------------------------------------------- */
 int cdkf_ekf_loglik_grad_all_f64(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T, const double* t,
                                  const double* y, double* ll, double* grad, double* grad_model, int32_t* status);

@@ -180,3 +180,27 @@ def test_soak_reverse_sweep_beyond_eight_dimensions(hip_lib):
             worst = max(worst, err)
             assert err < 2e-8, (case, d, m, lin, solver, err)
     assert worst < 2e-8
+
+
+@pytest.mark.parametrize("d,m,dtype", [(43, 43, np.float64), (50, 12, np.float32), (62, 62, np.float32), (9, 1, np.float64)])
+def test_reverse_sweep_at_the_edges_of_its_lds_plan(hip_lib, d, m, dtype):
+    """ekf_adjoint_wg_kernel at the largest shapes its nine-matrix LDS plan admits (q = 43 in fp64, 62 in fp32; beyond d = 42 a thread owns
+    up to sixteen covariance entries: the NE = 16 instantiation) and at the smallest (d = 9, m = 1), T = 1 and T = 3, N = 1 and 3:
+    log-likelihood and d/dF against the oracle; one state dimension further the library refuses."""
+    rng = np.random.default_rng(d * 100 + m)
+    mdl = lorenz96_model(d, m)
+    P = params_from(mdl)
+    tol_ll, tol_g = (1e-10, 1e-8) if dtype == np.float64 else (2e-5, 5e-3)
+    for N, T in ((1, 1), (3, 3)):
+        t = o.irregular_times(rng, N, T, 0.012 * T)
+        y = o.simulate(mdl, t, rng)
+        ll_ref, g_ref = o.ekf_loglik_grad_adjoint(mdl, t, y)
+        ll, g = cd.cdnlgssm_loglik_and_grad(P, y.astype(dtype), t[..., None].astype(dtype))
+        name = _ffi.lib().cdkf_last_kernel().decode()
+        assert name.startswith("ekf_adjoint_wg_kernel<%s, %d>" % ("double" if dtype == np.float64 else "float", 8 if d <= 42 else 16)), name
+        np.testing.assert_allclose(ll, ll_ref, rtol=tol_ll)
+        assert np.abs(np.asarray(g.forcing).reshape(N, 1) - g_ref).max() < tol_g * max(1.0, np.abs(g_ref).max()), (N, T)
+    if (d, dtype) in ((43, np.float64), (62, np.float32)):  # one state dimension further the nine matrices no longer fit: refused, by the host gate or by the launch
+        big = lorenz96_model(d + 1, d + 1)
+        with pytest.raises(NotImplementedError):
+            cd.cdnlgssm_loglik_and_grad(params_from(big), np.zeros((1, 2, d + 1), dtype), np.arange(2.0, dtype=dtype)[None, :, None])
