@@ -42,7 +42,8 @@ struct W40 {
   static_assert(D > 8 && D <= 48, "three 16-wide tiles");
   static constexpr int NP = D * (D + 1) / 2;        // packed upper triangle
   static constexpr int EPL = (NP + 63) / 64;        // entries per lane
-  static constexpr int LDP = D + 4;                 // stage image: rows / columns -2 .. D (halo), leading dimension
+  static constexpr int LDP = (D + 4) | 1;           // stage image: rows / columns -2 .. D (halo), leading dimension -- odd: the transposed
+                                                    // writes of the symmetric image then spread over the banks (D = 28: 32 put all 64 lanes on one)
   static constexpr int LDY = D + 2;                 // update image: 48 rows (three tiles) x D; even (16-byte rows for ds_read_b128)
   static constexpr int BUF = (((D + 3) * LDP > 48 * LDY) ? (D + 3) * LDP : 48 * LDY) + 1 & ~1;
   // packed lower triangle of the (D + 1)-row augmented system, every row padded to an even length: row i starts at rs(i), an
