@@ -168,7 +168,7 @@ def main():
         sweep()
         _ffi.check(lib.cdkf_ll_sum_f64_dev(ll.ptr, N, ll_sum.ptr, stream))
         if comm is not None:
-            comm.allreduce_sum_dev(ll_sum.ptr, 1, stream)  # ncclAllReduce of ONE double, in place, behind the sweep
+            comm.allreduce_sum_any(ll_sum.ptr, 1, stream)  # ncclAllReduce of ONE double, in place, behind the sweep (host fallback: Comm)
 
     def fence():
         _ffi.check(lib.cdkf_synchronize(stream))
@@ -216,7 +216,9 @@ def main():
                          "kernel": kernel_name, "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
                          "kernel_ms_method": f"one HIP-event pair around {args.steps} back-to-back launches on the launch stream"},
             "marginal_loglik_sum": total_ll, "status_flags_raised": n_bad,
-            "collective": None if comm is None else "cdkf_ll_allreduce (ncclAllReduce, 1 double, in place) on the sweep's stream",
+            "collective": None if comm is None else (
+                "cdkf_ll_allreduce (ncclAllReduce, 1 double, in place) on the sweep's stream" if not comm.rccl_error else
+                f"HOST fallback (D2H + TCP star + H2D per step): no RCCL communicator -- {comm.rccl_error}"),
         }
         if not args.no_cpu_baseline and world == 1:
             out.update(cpu_baseline_and_error(t_h, y_h, ll.numpy(), fm.numpy().transpose(1, 0, 2)))
@@ -363,7 +365,7 @@ def other_configs(lib, timer, stream, t_h, y_h, only=None, comm=None, world=1, r
     from cd_dynamax_amd import _ffi
     from cd_dynamax_amd._ffi import DeviceArray
     from cd_dynamax_amd.models import _model_block
-    has_coll = comm is not None and bool(getattr(comm, "_comm", None))
+    has_coll = comm is not None and (bool(getattr(comm, "_comm", None)) or world > 1)  # (world > 1 without RCCL: Comm's host fallback)
 
     def grids(rng, n, T):
         u = rng.uniform(0.0, 1.0, size=(n, T))
@@ -411,7 +413,7 @@ def other_configs(lib, timer, stream, t_h, y_h, only=None, comm=None, world=1, r
                 _ffi.check(fn(C.byref(blk.c), C.byref(opts), n, T, t_d.ptr, y_d.ptr, ll.ptr, *[p(b) for b in bufs], st.ptr, stream))
                 _ffi.check(ll_sum(ll.ptr, n, sums.ptr, stream))
                 if has_coll:
-                    comm.allreduce_sum_dev(sums.ptr, 1, stream)
+                    comm.allreduce_sum_any(sums.ptr, 1, stream)
             ms = over_ranks(timer.ms_per_call(run, 3))
             res[algo + suffix + "_ms"] = ms
             res[algo + suffix + "_kernel"] = lib.cdkf_last_kernel().decode()
@@ -438,15 +440,16 @@ def other_configs(lib, timer, stream, t_h, y_h, only=None, comm=None, world=1, r
                 _ffi.check(grad_sum(g.ptr, n, n_th, C.c_void_p(base + 8), stream))
                 _ffi.check(grad_sum(gm.ptr, n, n_md, C.c_void_p(base + 8 * (1 + n_th)), stream))
                 if has_coll:
-                    comm.allreduce_sum_dev(sums.ptr, 1 + n_th + n_md, stream)
+                    comm.allreduce_sum_any(sums.ptr, 1 + n_th + n_md, stream)
             ms = over_ranks(timer.ms_per_call(run, 3))
             res["loglik_and_grad_all_ms"] = ms
             res["loglik_and_grad_all_kernel"] = lib.cdkf_last_kernel().decode()
             res["loglik_and_grad_all_trajectories_per_sec"] = world * n / (ms * 1e-3)
             res["reduced_doubles_per_step"] = 1 + n_th + n_md
             bufs = [g, gm, y_g]
-        res["collective"] = ("cdkf_ll_allreduce (ncclAllReduce, in place, on the sweeps' stream) behind cdkf_ll_sum / cdkf_grad_sum"
-                             if has_coll else None)
+        res["collective"] = (None if not has_coll else
+                             "cdkf_ll_allreduce (ncclAllReduce, in place, on the sweeps' stream) behind cdkf_ll_sum / cdkf_grad_sum"
+                             if not getattr(comm, "rccl_error", None) else f"HOST fallback (no RCCL communicator: {comm.rccl_error})")
         res["status_flags_raised"] = int(np.count_nonzero(st.numpy()))
         for a in [t_d, y_d, ll, st, sums] + [b for b in bufs if b is not None]:
             a.free()

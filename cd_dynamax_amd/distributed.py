@@ -31,12 +31,26 @@ class Comm:
         self.rank, self.world, self.device = int(rank), int(world), device
         self._rdv, self._comm = C.c_void_p(), C.c_void_p()
         _ffi.check(self._L.cdkf_rdv_create(C.byref(self._rdv), addr.encode(), int(port), self.rank, self.world, int(timeout_ms)))
+        self.rccl_error = None  # why there is no RCCL communicator although a device was named (every rank then holds the same answer)
         if device is not None:
+            # Joining RCCL is a collective: a rank that cannot (no library, no device) must not leave the others waiting in it.  Every
+            # step of the set-up is therefore taken by ALL ranks, and after each they agree over the rendezvous (a max of failure flags)
+            # whether to go on; if any rank failed, all of them fall back to the host all-reduce of the rendezvous and say so.
             ident = C.create_string_buffer(128)
-            if self.rank == 0:
-                _ffi.check(self._L.cdkf_comm_unique_id(ident))
+            err = ""
+            if self.rank == 0 and self._L.cdkf_comm_unique_id(ident) != 0:
+                err = self._L.cdkf_last_error().decode("utf-8", "replace")
             _ffi.check(self._L.cdkf_rdv_broadcast(self._rdv, ident, 128))
-            _ffi.check(self._L.cdkf_comm_init_rank(C.byref(self._comm), ident, self.rank, self.world, int(device)))
+            failed = bool(self._host([1.0 if err else 0.0], 1)[0])
+            if not failed:
+                if self._L.cdkf_comm_init_rank(C.byref(self._comm), ident, self.rank, self.world, int(device)) != 0:
+                    err = self._L.cdkf_last_error().decode("utf-8", "replace")
+                failed = bool(self._host([1.0 if err else 0.0], 1)[0])
+            if failed:
+                if self._comm:
+                    self._L.cdkf_comm_destroy(self._comm)
+                self._comm = C.c_void_p()
+                self.rccl_error = err or "another rank could not join the RCCL communicator"
 
     @classmethod
     def from_env(cls, gpu: bool = True, timeout_ms: int = 120000) -> "Comm":
@@ -66,6 +80,18 @@ class Comm:
         if not self._comm:
             raise RuntimeError("Comm was created without a device: no RCCL communicator")
         self._ffi.check(self._L.cdkf_ll_allreduce(self._comm, sums_ptr, int(count), stream))
+
+    def allreduce_sum_any(self, sums_ptr, count: int, stream=None) -> None:
+        """``allreduce_sum_dev`` where an RCCL communicator exists; otherwise (``rccl_error``) the same sum through the host: the stream is
+        drained, the doubles cross the rendezvous' TCP star and return to the device buffer -- slower, same result on every rank."""
+        if self._comm:
+            return self.allreduce_sum_dev(sums_ptr, count, stream)
+        C, L = self._C, self._L
+        self._ffi.check(L.cdkf_synchronize(stream))
+        host = np.zeros(int(count))
+        self._ffi.check(L.cdkf_memcpy_d2h(host.ctypes.data_as(C.c_void_p), sums_ptr, host.nbytes))
+        host = self._host(host, 0)
+        self._ffi.check(L.cdkf_memcpy_h2d(sums_ptr, host.ctypes.data_as(C.c_void_p), host.nbytes))
 
     def allreduce_max_dev(self, ptr, count: int, stream=None) -> None:
         if not self._comm:

@@ -388,3 +388,42 @@ def test_rendezvous_turns_strangers_and_duplicates_away():
     assert res["r0"][0] == 0 and res["r2"][0] == 0, res
     for k in ("r0", "r1", "r2"):
         L.cdkf_rdv_destroy(res[k][2])
+
+
+FALLBACK_WORKER = r'''
+import os, sys
+sys.path[:0] = [os.environ["CDKF_ROOT"]]
+import numpy as np
+from cd_dynamax_amd import distributed as D
+
+rank, world, port = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+comm = D.Comm(rank, world, "127.0.0.1", port, device=rank)   # asks for RCCL on a box that has no GPU
+assert not comm._comm and comm.rccl_error, "a communicator cannot exist here"
+s = comm.allreduce_sum_host([rank + 1.0, 10.0 * (rank + 1)])
+assert np.allclose(s, [world * (world + 1) / 2, 10.0 * world * (world + 1) / 2]), s
+comm.barrier()
+comm.close()
+sys.stdout.write("RANK_OK_%d %s\n" % (rank, comm.rccl_error.replace("\n", " ")[:80])); sys.stdout.flush()
+'''
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_comm_without_rccl_falls_back_on_every_rank(tmp_path, world):
+    """Comm(device=...) where RCCL cannot be joined (here: no GPU): no rank is left waiting inside the collective set-up -- every step
+    of it is taken by all ranks and followed by an agreement over the rendezvous -- and all of them end in the host fallback with the
+    reason in ``rccl_error`` (bench.py --gpus N then reports the host path instead of dying)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible: RCCL would join")
+    script = tmp_path / "fallback_worker.py"
+    script.write_text(FALLBACK_WORKER)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, CDKF_ROOT=ROOT, OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(world), str(port)], env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, so + se
+    assert sum(so.count("RANK_OK_") for so, _ in outs) == world
