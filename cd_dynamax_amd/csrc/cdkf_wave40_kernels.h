@@ -125,6 +125,9 @@ struct W40Lin {
   using V4 = typename Tile::V4;
   static constexpr int LDY = W::LDY;
   static constexpr int NB = (D + 15) / 16;  // blocks of sixteen rows / columns
+  static constexpr int NBR = (D + 16) / 16; // ... of the D + 1 rows of the augmented system (D = 32: row 32 is a third block of its own --
+                                            // left out, the factor was right and the log-likelihood's quadratic form wrong: found by
+                                            // scripts/gpu_fuzz_r03.py, no test had run D = 32)
   static_assert(D % 4 == 0, "panels of four, eight, twelve or sixteen columns");
 
   // L[i][c0 + c] -= sum_{k < c0} L[i][k] L[c0 + c][k]  for the rows i >= c0 (the augmented row D included), c < 16: the left-looking
@@ -136,9 +139,9 @@ struct W40Lin {
     const int brow = c0 + lm;
     const bool bin = brow <= D;
     const int boff = W::rs(bin ? brow : D);
-    V4 acc[NS][NB];
+    V4 acc[NS][NBR];
 #pragma unroll
-    for (int it = 0; it < NB; ++it)
+    for (int it = 0; it < NBR; ++it)
       if (it >= P) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -152,11 +155,11 @@ struct W40Lin {
 #pragma unroll
     for (int k0 = 0; k0 < c0; k0 += 4) {
       const int kk = k0 + lg;
-      R bv[NS], av[NS][NB];
+      R bv[NS], av[NS][NBR];
 #pragma unroll
       for (int s = 0; s < NS; ++s) bv[s] = bin ? L[s][boff + kk] : R(0);
 #pragma unroll
-      for (int it = 0; it < NB; ++it)
+      for (int it = 0; it < NBR; ++it)
         if (it >= P) {
           const int arow = 16 * it + lm;
           const int ao = W::rs(arow <= D ? arow : D) + kk;
@@ -164,14 +167,14 @@ struct W40Lin {
           for (int s = 0; s < NS; ++s) av[s][it] = arow <= D ? -L[s][ao] : R(0);
         }
 #pragma unroll
-      for (int it = 0; it < NB; ++it)
+      for (int it = 0; it < NBR; ++it)
         if (it >= P) {
 #pragma unroll
           for (int s = 0; s < NS; ++s) acc[s][it] = wg_mfma(av[s][it], bv[s], acc[s][it]);
         }
     }
 #pragma unroll
-    for (int it = 0; it < NB; ++it)
+    for (int it = 0; it < NBR; ++it)
       if (it >= P) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {

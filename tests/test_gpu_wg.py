@@ -207,7 +207,7 @@ def test_c5_full_slice_properties(hip_lib):
         a.free()
 
 
-@pytest.mark.parametrize("d", [12, 16, 20, 28, 36])
+@pytest.mark.parametrize("d", [12, 16, 20, 24, 28, 32, 36])
 def test_lorenz96_wavefront_kernels_other_state_dimensions(hip_lib, d, monkeypatch):
     """The wavefront-per-trajectory Lorenz-96 sweeps (config 4's kernels) at the other state dimensions they are instantiated for --
     every multiple of four from 12 to 40: the sixteen-wide panels of the factorisation and the triangular solves end in a panel of
@@ -266,7 +266,7 @@ def test_workgroup_kernels_eight_entries_per_thread(hip_lib, d, monkeypatch):
     assert relerr(flt32.filtered_means, ref["filtered_means"]) < 5e-4
 
 
-@pytest.mark.parametrize("d,sel", [(36, "first20"), (40, "every_other"), (12, "shuffled5"), (24, "single")])
+@pytest.mark.parametrize("d,sel", [(36, "first20"), (40, "every_other"), (12, "shuffled5"), (24, "single"), (32, "first20"), (32, "every_other")])
 def test_lorenz96_wavefront_kernels_partial_observation(hip_lib, d, sel, monkeypatch):
     """The wavefront-per-trajectory Lorenz-96 sweeps when the emission observes only SOME state components (_condition_on is shape-
     generic, inference_ekf.py:153-199): H = I[:m], every other component, a shuffled handful, a single one -- every row of H a unit
