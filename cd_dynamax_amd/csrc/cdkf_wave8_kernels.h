@@ -68,25 +68,34 @@ CDKF_DEV double w8_dpp(double x) {
   const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, false);
   return __hiloint2double(hi, lo);
 }
+// The swaps are written as inline assembly with two read-write registers: through __builtin_amdgcn_permlane{16,32}_swap the fp32 sums
+// came out as r0 + r0 (ROCm 7.2 lowers the builtin's second result to the first register when both feed one 32-bit add:
+// "v_permlane16_swap_b32 v4, v0; v_add_f32 v0, v4, v4"), i.e. twice one half of the sum -- 'second'-order fp32 sweeps were off by
+// 1e-2 from this round's restructuring on; found by scripts/gpu_fuzz_filters.py.  (s_nop 1: the two wait states a VALU-written
+// register needs before a lane-permuting instruction reads it, which the compiler cannot insert around inline assembly.)
+CDKF_DEV void w8_swap16(unsigned& a, unsigned& b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+CDKF_DEV void w8_swap32(unsigned& a, unsigned& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
 CDKF_DEV float w8_swap_sum16(float x) {
-  const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, x), false, false);
-  return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+  unsigned a = __builtin_bit_cast(unsigned, x), b = a;
+  w8_swap16(a, b);
+  return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
 }
 CDKF_DEV float w8_swap_sum32(float x) {
-  const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, x), false, false);
-  return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+  unsigned a = __builtin_bit_cast(unsigned, x), b = a;
+  w8_swap32(a, b);
+  return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
 }
 CDKF_DEV double w8_swap_sum16(double x) {
-  const unsigned lo = __double2loint(x), hi = __double2hiint(x);
-  const auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
-  const auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-  return __hiloint2double(rh[0], rl[0]) + __hiloint2double(rh[1], rl[1]);
+  unsigned la = __double2loint(x), lb = la, ha = __double2hiint(x), hb = ha;
+  w8_swap16(la, lb);
+  w8_swap16(ha, hb);
+  return __hiloint2double(ha, la) + __hiloint2double(hb, lb);
 }
 CDKF_DEV double w8_swap_sum32(double x) {
-  const unsigned lo = __double2loint(x), hi = __double2hiint(x);
-  const auto rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-  const auto rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-  return __hiloint2double(rh[0], rl[0]) + __hiloint2double(rh[1], rl[1]);
+  unsigned la = __double2loint(x), lb = la, ha = __double2hiint(x), hb = ha;
+  w8_swap32(la, lb);
+  w8_swap32(ha, hb);
+  return __hiloint2double(ha, la) + __hiloint2double(hb, lb);
 }
 template <typename R>
 CDKF_DEV R w8_sum_j(R x) {  // sum over the eight lanes of a grid row

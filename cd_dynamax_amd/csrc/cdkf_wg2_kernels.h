@@ -86,7 +86,9 @@ struct WgPlan {
   int nmat, nvec, i_F, i_A, i_HP, i_Hl, extra;
 };
 __host__ __device__ inline int wg_mlp_scratch(int kind, int d, int h1, int h2) {
-  return kind == kDriftMlp ? (2 * h1 + 2 * h2 + d * h1 + h2 * h1 + h1 * d + 4) : 0;  // a1 a2 s2 tq T[h2*d] Gm[h2*h1] U[h1*d]
+  // a1[h1] a2[h2] s2[h2] tq[h1] T[h2*d] Gm[h2*h1] U[h1*d]  (T was sized d * h1 until round 3: with h2 > h1 the tail of U ran into the
+  // copy of the weights behind it -- 1-3 % errors in every output; found by scripts/gpu_fuzz_filters.py, every test had h1 >= h2)
+  return kind == kDriftMlp ? (2 * h1 + 2 * h2 + h2 * d + h2 * h1 + h1 * d + 4) : 0;
 }
 __host__ __device__ inline int wg_mlp_theta(int kind, int d, int h1, int h2) {
   return kind == kDriftMlp ? (h1 * d + h1 + h2 * h1 + h2 + d * h2 + d) : 0;

@@ -856,3 +856,48 @@ def test_workgroup_kernels_adaptive_steps(hip_lib, solver, ctrl):
     op = models._opts(cd.EKFHyperParams(diffeqsolve_settings=dict(settings, max_steps=2)), 1)
     _, _, status = _ffi.run_host("ekf_filter", mb, op, t, y, [False] * 4, np.float64)
     assert (status & 4).any()
+
+
+@pytest.mark.parametrize("d,m,h", [(9, 2, (3, 50)), (10, 8, (17, 33)), (6, 9, (20, 64)), (9, 9, (33, 64))])
+def test_mlp_drift_on_the_workgroup_kernels_second_layer_wider_than_the_first(hip_lib, d, m, h):
+    """MLP drift beyond the wavefront kernel's shapes with hidden sizes h1 < h2: the tangent image T [h2 x d] was given d * h1 reals
+    of LDS, and the tail of the arrays behind it overwrote the copy of the weights (1-3 % errors in every output; every earlier
+    test had h1 >= h2; found by scripts/gpu_fuzz_filters.py).  EKF both orders, smoother and UKF against the oracle."""
+    rng = np.random.default_rng(d * 10 + m)
+    mdl = mlp_model(rng, d, min(m, d), h)
+    if m > d:
+        mdl = o.Model(mdl.drift, mdl.L, mdl.Qc, rng.standard_normal((m, d)) / np.sqrt(d), np.zeros(m), 0.5 * np.eye(m), mdl.m0, mdl.P0)
+    N, T = 3, 7
+    t = o.irregular_times(rng, N, T, 0.012 * T)
+    y = o.simulate(mdl, t, rng)
+    P = params_from(mdl)
+    for order in ("first", "second"):
+        ref = o.ekf_smoother(mdl, t, y, state_order=order)
+        post = cd.cdnlgssm_smoother(P, y, t[..., None], cd.EKFHyperParams(state_order=order))
+        assert _ffi.lib().cdkf_last_kernel().decode().startswith("ekf_smoother_wg_kernel<double")
+        for k in ("filtered_means", "filtered_covariances", "smoothed_means", "smoothed_covariances"):
+            assert relerr(getattr(post, k), ref[k]) < 1e-10, (order, k)
+    refu = o.ukf_filter(mdl, t, y)
+    pu = cd.cdnlgssm_filter(P, y, t[..., None], cd.UKFHyperParams())
+    assert relerr(pu.filtered_means, refu["filtered_means"]) < 1e-10
+
+
+@pytest.mark.parametrize("d,m,h", [(5, 2, (9, 7)), (8, 4, (64, 64)), (2, 1, (1, 1))])
+def test_mlp_second_order_in_float32_on_the_wavefront_kernel(hip_lib, d, m, h):
+    """state_order='second' in fp32 on ekf_filter_wave8_kernel<float>: the mean's 0.5 P grad(div f) is summed over the lane grid with
+    v_permlane16_swap / v_permlane32_swap -- through the compiler builtins the fp32 sums came out as twice one half (r0 + r0) and the
+    sweep was off by 1e-2 from the fp64 oracle, where the fp32 oracle is within 2e-7 (found by scripts/gpu_fuzz_filters.py; the
+    swaps are inline assembly since).  Both orders within 5e-6."""
+    rng = np.random.default_rng(d + 70)
+    mdl = mlp_model(rng, d, m, h)
+    N, T = 3, 8
+    t = o.irregular_times(rng, N, T, 0.012 * T)
+    y = o.simulate(mdl, t, rng)
+    P = params_from(mdl)
+    for order in ("first", "second"):
+        ref = o.ekf_filter(mdl, t, y, state_order=order)
+        p32 = cd.cdnlgssm_filter(P, y.astype(np.float32), t[..., None].astype(np.float32), cd.EKFHyperParams(state_order=order))
+        assert _ffi.lib().cdkf_last_kernel().decode().startswith("ekf_filter_wave8_kernel<float>")
+        assert relerr(p32.filtered_means, ref["filtered_means"]) < 5e-6, order
+        assert relerr(p32.predicted_covariances, ref["predicted_covariances"]) < 5e-6, order
+        np.testing.assert_allclose(p32.marginal_loglik, ref["marginal_loglik"], rtol=2e-5)
