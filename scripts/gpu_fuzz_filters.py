@@ -35,9 +35,14 @@ for case in range(cases):
     bias = np.zeros(m) if sel else 0.1 * rng.standard_normal(m)
     scale = {"linear": 0.0, "lorenz63": 1.0, "lorenz96": 8.0, "mlp": 0.0}[kind]
     mdl = o.Model(drift, np.eye(d) + 0.1 * rng.standard_normal((d, d)), spd(d, 0.5), H, bias, spd(m, 0.7), scale + rng.standard_normal(d), spd(d, 1.0))
+    LONG = os.environ.get("CDKF_FUZZ_LONG")  # long scans with a few long intervals
     N, T = int(rng.choice([1, 2, 5, 33, 70])), int(rng.integers(1, 10))
+    if LONG: N, T = int(rng.choice([1, 2, 4])), int(rng.integers(60, 250))
     if d > 20: N = min(N, 5)
     t = o.irregular_times(rng, N, T, 0.012 * T * rng.choice([1, 1, 4]))
+    if LONG:
+        for _ in range(3):
+            t[:, int(rng.integers(1, T)):] += rng.uniform(0.05, 0.8)
     y = o.simulate(mdl, t, rng)
     order = str(rng.choice(["second", "first", "zeroth"]))
     num_iter = int(rng.choice([1, 1, 2]))
@@ -50,11 +55,14 @@ for case in range(cases):
             print("MISMATCH", name, tag, e, L.cdkf_last_kernel().decode()[:50], flush=True)
     try:
         ref = o.ekf_filter(mdl, t, y, state_order=order, num_iter=num_iter)
+        if not np.isfinite(ref["filtered_means"]).all():
+            continue
         post = cd.cdnlgssm_filter(P, y, t[..., None], hyp, num_iter=num_iter)
         k = L.cdkf_last_kernel().decode().split("<")[0]; kernels[k] = kernels.get(k, 0) + 1
         note("ekf", max([relerr(getattr(post, f), ref[f]) for f in FILTER_KEYS] + [relerr(post.marginal_loglik, ref["marginal_loglik"])]), 1e-8)
         p32 = cd.cdnlgssm_filter(P, y.astype(np.float32), t[..., None].astype(np.float32), hyp, num_iter=num_iter)
-        note("ekf32", relerr(p32.filtered_means, ref["filtered_means"]), 5e-3)
+        if not LONG:
+            note("ekf32", relerr(p32.filtered_means, ref["filtered_means"]), 5e-3)
     except NotImplementedError as e:
         unsupported += 1
     try:

@@ -36,15 +36,24 @@ for case in range(cases):
     else:
         mdl = o.Model(drift, np.eye(d) + 0.2 * rng.standard_normal((d, d)), spd(d, 0.5), rng.standard_normal((m, d)), 0.1 * rng.standard_normal(m), spd(m, 0.7),
                       ({"lorenz96": 8.0}.get(kind, 0.0)) + rng.standard_normal(d), spd(d, 1.0))
-    N, T = int(rng.choice([1, 3, 17, 66])), int(rng.integers(1, 9))
+    LONG = os.environ.get("CDKF_FUZZ_LONG")  # long scans and long intervals: checkpoint windows, replay chunks, accumulation
+    N, T = (int(rng.choice([1, 2, 5])), int(rng.integers(40, 160))) if LONG else (int(rng.choice([1, 3, 17, 66])), int(rng.integers(1, 9)))
     t = o.irregular_times(rng, N, T, 0.012 * T * rng.choice([1, 1, 5]))
+    if LONG and T > 10:
+        for _ in range(3):
+            t[:, int(rng.integers(1, T)):] += rng.uniform(0.1, 1.5)   # a few intervals of 10 .. 150 steps
     if T > 3 and rng.random() < 0.3:
         t[0, 2] = t[0, 1]
     y = o.simulate(mdl, t, rng)
     order = str(rng.choice(["second", "first"]))
     tag = f"{kind} d={d} m={m} N={N} T={T} {order} plain={plain}"
     hyp = cd.EKFHyperParams(state_order=order)
-    ll_ref, g_ref, ex = o.ekf_loglik_grad_adjoint(mdl, t, y, full=True, state_order=order)
+    try:
+        ll_ref, g_ref, ex = o.ekf_loglik_grad_adjoint(mdl, t, y, full=True, state_order=order)
+    except np.linalg.LinAlgError:
+        continue  # (the moment equations of this random model blow up over a long interval: nothing to compare)
+    if not (np.isfinite(g_ref).all() and np.isfinite(ll_ref).all()):
+        continue
     P = params_from(mdl)
     def note(name, e, tol):
         worst[name] = max(worst.get(name, 0.0), e)
@@ -57,7 +66,8 @@ for case in range(cases):
         note("drift", max(np.abs(flat - g_ref).max() / (np.abs(g_ref).max() + 1e-300), relerr(ll, ll_ref)), 1e-7)
         ll32, g32 = cd.cdnlgssm_loglik_and_grad(P, y.astype(np.float32), t[..., None].astype(np.float32), hyp)
         flat32 = np.concatenate([np.asarray(a_).reshape(N, -1) for a_ in g32], axis=-1)
-        note("drift32", np.abs(flat32 - g_ref).max() / (np.abs(g_ref).max() + 1e-300), 3e-2)
+        if not LONG:  # (a chaotic flow amplifies fp32 rounding over long scans: no bound to hold it to)
+            note("drift32", np.abs(flat32 - g_ref).max() / (np.abs(g_ref).max() + 1e-300), 3e-2)
     except NotImplementedError:
         pass
     try:

@@ -1,0 +1,3 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+for s in 81 83 84; do CDKF_FUZZ_LONG=1 timeout 2400 python scripts/gpu_fuzz_grads.py $s 12 2>&1 | grep -v amdgpu.ids | tail -8 | cut -c1-300; done
