@@ -183,7 +183,7 @@ def sharded_loglik_sum_dev(comm: "Comm", ll_ptr, n_local: int, sums_ptr, stream=
     L = _ffi.lib()
     _ffi.check(getattr(L, f"cdkf_ll_sum_{suffix}_dev")(ll_ptr, int(n_local), sums_ptr, stream))
     if comm.world > 1 or comm._comm:
-        comm.allreduce_sum_dev(sums_ptr, 1, stream)
+        comm.allreduce_sum_any(sums_ptr, 1, stream)  # RCCL, or -- where it could not be joined (comm.rccl_error) -- through the host
 
 
 def allreduce_sum_array(values, device=None) -> np.ndarray:

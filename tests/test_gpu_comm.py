@@ -105,10 +105,10 @@ from cd_dynamax_amd.models import _model_block
 from helpers import params_from
 rank, world, port = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 L = _ffi.lib()
-try:
-    comm = D.Comm(rank, world, "127.0.0.1", port, device=0, timeout_ms=60000)
-except _ffi.CdkfError as e:
-    sys.stdout.write("RCCL_REFUSED %s\n" % e); sys.exit(0)
+comm = D.Comm(rank, world, "127.0.0.1", port, device=0, timeout_ms=60000)
+if comm.rccl_error:   # both ranks then hold the same answer and go on through the host all-reduce
+    assert not comm._comm
+    sys.stdout.write("RCCL_REFUSED %s\n" % comm.rccl_error.replace("\n", " ")[:160])
 rng = np.random.default_rng(0)
 mdl = o.lorenz63_model(3)
 N, T = 37, 40
@@ -132,7 +132,8 @@ sys.stdout.write("RANK_OK_%d\n" % rank)
 
 def test_two_ranks_share_the_one_device_if_rccl_allows(tmp_path, hip_lib):
     """Two processes, both on device 0, through the whole composition.  RCCL refuses two ranks on one device on most builds
-    ("Duplicate GPU detected"); the refusal must then come back as an error of the library, not a hang."""
+    ("Duplicate GPU detected"): neither rank may hang in the collective set-up -- both must learn of the refusal (Comm's agreement
+    over the rendezvous), fall back to the host all-reduce and still produce the sharded log-likelihood sum."""
     script = tmp_path / "w.py"
     script.write_text(WORKER)
     port = _free_port()
@@ -150,9 +151,8 @@ def test_two_ranks_share_the_one_device_if_rccl_allows(tmp_path, hip_lib):
     text = "".join(so for so, _ in outs)
     for p, (so, se) in zip(procs, outs):
         assert p.returncode == 0, so + se
-    if "RCCL_REFUSED" in text:
-        pytest.skip("RCCL refuses two ranks on one device here: " + text.strip().splitlines()[0][:200])
     assert text.count("RANK_OK_") == 2, text
+    assert text.count("RCCL_REFUSED") in (0, 2), text  # either both joined RCCL or both took the host path
 
 
 def test_fit_sgd_reduces_on_the_device_through_rccl(hip_lib):
