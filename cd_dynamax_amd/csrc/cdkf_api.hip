@@ -503,7 +503,9 @@ int cdkf_supported(const cdkf_model* mdl, const cdkf_opts* o, int algo, int byte
 int cdkf_trajectories_per_wavefront(int64_t N) { return cdkf::reg_lanes_per_wave(N < 1 ? 1 : N); }
 
 int cdkf_preferred_layout(const cdkf_model* mdl) {
-  return (mdl && (reg_shape_available(mdl) || custom_kind(mdl->drift_kind))) ? CDKF_LAYOUT_TCN : CDKF_LAYOUT_TN;
+  // (drifts given as source: the register-resident kernels up to six dimensions, the workgroup kernels beyond)
+  return (mdl && (reg_shape_available(mdl) || (custom_kind(mdl->drift_kind) && mdl->state_dim <= 6 && mdl->emission_dim <= 6))) ? CDKF_LAYOUT_TCN
+                                                                                                                              : CDKF_LAYOUT_TN;
 }
 
 int cdkf_custom_drift_register(int state_dim, int n_theta, const char* f_src, const char* jac_src, const char* divgrad_src) {

@@ -108,6 +108,14 @@ int custom_compile_check(int kind, int bytes_per_real, int emission_dim, int alg
 int custom_emission_register(int state_dim, int emission_dim, const char* h_src, const char* hjac_src);
 bool custom_emission_kind(int emission_kind, int d, int m);
 void custom_set_source_dir(const char* dir);
+// ... beyond six state / emission dimensions: on the workgroup kernels (launch_wg.hip), which are compiled with the drift at run time
+long custom_ntheta(int kind, int state_dim);
+bool custom_wg_fits(const cdkf_model* mdl);  // launch_wg.hip: the workgroup kernels' LDS plan holds this shape (in fp32)
+int custom_wg_geometry(int kind, int d, int m, int bytes_per_real, bool ukf, int* ept, int* threads, size_t* lds_f, size_t* lds_s);
+template <typename R>
+struct WgArgs;
+template <typename R>
+int launch_custom_wg(const WgArgs<R>& a, int ept, bool filter, bool smoother, int threads, size_t lds_f, size_t lds_s, hipStream_t stream);
 
 bool kernel_available(const cdkf_model* mdl, const cdkf_opts* o, int algo, int bytes_per_real);
 

@@ -21,6 +21,7 @@ namespace cdkf {
 #endif
 
 constexpr int kDriftLinear = 0, kDriftLorenz63 = 1, kDriftLorenz96 = 2, kDriftMlp = 3;
+constexpr int kDriftCustomBase = 1000;  // CDKF_DRIFT_CUSTOM_BASE: drifts that arrive as C source (launch_custom.hip)
 constexpr int kWgBlock = 8;  // panel width of the blocked factorisations
 
 template <typename R>
@@ -494,12 +495,30 @@ __device__ void wg_mlp_prepare(const WgArgs<R>& a, const WgLds<R>& L) {
   __syncthreads();
 }
 
-// f(x) -> fv; dense Jacobian -> F (if F != null); g = grad(div f) -> gv (MLP only, if gv != null).  Ends with a
+#ifdef CDKF_WG_CUSTOM
+// A drift given as C source (state dimension above the register-resident kernels' six): this header is then compiled at run time
+// (launch_custom.hip) together with the definitions of these two, which differentiate the source by dual numbers (cdkf_dual.h):
+//   wg_custom_drift: f(x) -> fv, the dense Jacobian -> F (if non-null), grad(div f) -> gv (if non-null); no barrier at the end;
+//   wg_custom_sigma: the drift at the 2 d + 1 sigma points m, m +- O[:, i] -> f0, DF[:, i] = f+ - f-, foo[:, i] = f+ + f-.
+template <typename R>
+__device__ void wg_custom_drift(const WgArgs<R>& a, const WgLds<R>& L, const R* x, R* fv, R* F, R* gv);
+template <typename R>
+__device__ void wg_custom_sigma(const WgArgs<R>& a, const WgLds<R>& L, const R* ms, const R* O, R* f0, R* DF, R* foo);
+#endif
+
+// f(x) -> fv; dense Jacobian -> F (if F != null); g = grad(div f) -> gv (MLP and custom drifts, if gv != null).  Ends with a
 // barrier.  Lorenz-96 callers that only need f and use the banded product pass F = null.
 template <typename R>
 __device__ void wg_drift(const WgArgs<R>& a, const WgLds<R>& L, const R* __restrict__ x, R* __restrict__ fv,
                          R* __restrict__ F, R* __restrict__ gv) {
   const int d = a.d, lq = a.lq;
+#ifdef CDKF_WG_CUSTOM
+  if (a.kind >= kDriftCustomBase) {
+    wg_custom_drift<R>(a, L, x, fv, F, gv);
+    __syncthreads();
+    return;
+  }
+#endif
   if (a.kind == kDriftLinear) {
     const R* th = a.par + a.o_theta;
     CDKF_WG_FOR(i, d) {
@@ -912,7 +931,11 @@ __device__ __forceinline__ void wg_rhs_ekf(const WgArgs<R>& a, const WgLds<R>& L
   const int d = a.d, lq = a.lq;
   R* fv = L.vec(2);
   R* gv = L.vec(3);
+#ifdef CDKF_WG_CUSTOM
+  const bool second = (a.order == 2) && (a.kind == kDriftMlp || (a.kind >= kDriftCustomBase && CDKF_WG_CUSTOM_SECOND));
+#else
   const bool second = (a.order == 2) && (a.kind == kDriftMlp);
+#endif
   if (a.kind == kDriftLorenz96) {
     const R forcing = (a.par + a.o_theta)[0];
     if (threadIdx.x < d) {
@@ -1024,6 +1047,17 @@ __device__ __forceinline__ void wg_rhs_ukf(const WgArgs<R>& a, const WgLds<R>& L
       sum[r] = acc;
     }
     __syncthreads();
+#ifdef CDKF_WG_CUSTOM
+  } else if (a.kind >= kDriftCustomBase) {  // a thread per sigma-point pair
+    wg_custom_sigma<R>(a, L, ms, O, f0, DF, foo);
+    __syncthreads();
+    CDKF_WG_FOR(r, d) {
+      R acc = 0;
+      for (int i = 0; i < d; ++i) acc += foo[r * lq + i];
+      sum[r] = acc;
+    }
+    __syncthreads();
+#endif
   } else {  // generic (Lorenz-63, MLP): one drift evaluation per sigma point
     wg_drift(a, L, ms, f0, (R*)nullptr, (R*)nullptr);
     CDKF_WG_FOR(r, d) sum[r] = 0;
@@ -1264,7 +1298,11 @@ __global__ __launch_bounds__(512) void ekf_filter_wg_kernel(const WgArgs<R> a_in
   WgArgs<R> a = a_in;
   if constexpr (KIND != kDriftAny) a.kind = KIND;
   a.ukf = UKF ? 1 : 0;
+#ifdef CDKF_WG_STATIC_LDS  // run-time compiled for one shape: the carve-up's size is a constant (no dynamic-LDS cap to raise on a module function)
+  __shared__ __attribute__((aligned(16))) unsigned char smem_raw[CDKF_WG_STATIC_LDS];
+#else
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+#endif
   const WgPlan plan = wg_plan(a.kind, a.d, a.h1, a.h2, a.hsel, false, a.ukf != 0);
   WgLds<R> L(reinterpret_cast<R*>(smem_raw), a.q, a.lq, plan);
   __shared__ int bad;
@@ -1336,7 +1374,11 @@ __global__ __launch_bounds__(512) void ekf_filter_wg_kernel(const WgArgs<R> a_in
 // once; the reverse-time right-hand side is  dm = -[f(m_f) + G (m_s - m_f)],  dP = -[G P_s + (G P_s)^T - LQL].
 template <typename R, int EPT>
 __global__ __launch_bounds__(512) void ekf_smoother_wg_kernel(const WgArgs<R> a) {
+#ifdef CDKF_WG_STATIC_LDS  // run-time compiled for one shape: the carve-up's size is a constant (no dynamic-LDS cap to raise on a module function)
+  __shared__ __attribute__((aligned(16))) unsigned char smem_raw[CDKF_WG_STATIC_LDS];
+#else
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+#endif
   const WgPlan plan = wg_plan(a.kind, a.d, a.h1, a.h2, a.hsel, true);
   WgLds<R> L(reinterpret_cast<R*>(smem_raw), a.q, a.lq, plan);
   __shared__ int bad;

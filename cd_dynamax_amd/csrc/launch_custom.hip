@@ -3,7 +3,9 @@
 // a drift given as C source for f(x, theta), its Jacobian and (optionally) grad(div f), compiled at run time with
 // hipRTC into the SAME lane-per-trajectory sweep bodies (filter_reg_body / ekf_smoother_reg_body of
 // cdkf_reg_kernels.h) the built-in drifts use.  One module per (drift, precision, emission_dim, algorithm variant),
-// compiled on first use and cached for the life of the process.
+// compiled on first use and cached for the life of the process.  Above six state or emission dimensions (up to what the workgroup
+// kernels' LDS plan holds, <= 64) the same source is compiled into the workgroup-per-trajectory sweeps of cdkf_wg2_kernels.h instead
+// (launch_custom_wg): Jacobian, grad(div f) and sigma-point evaluations spread over the workgroup's threads, all by dual numbers.
 #include <dlfcn.h>
 #include <hip/hiprtc.h>
 
@@ -13,6 +15,7 @@
 #include <tuple>
 
 #include "cdkf_launch.h"
+#include "cdkf_wg2_kernels.h"  // WgArgs: the argument block of the workgroup kernels (drifts above six state dimensions)
 
 namespace cdkf {
 
@@ -290,7 +293,238 @@ int get_function(int kind, const Key& key, hipFunction_t* fn) {
   return CDKF_OK;
 }
 
+// ---- beyond six dimensions: the workgroup-per-trajectory kernels with the drift compiled in -------------------------------------
+// kind, bytes per real, entries per thread, ukf, smoother, LDS bytes
+using WgKey = std::tuple<int, int, int, int, int, long>;
+std::map<std::pair<int, WgKey>, Compiled> g_wg_modules;
+
+std::string generate_wg_source(const CustomDrift& c, size_t lds) {
+  std::string s;
+  const std::string D_ = std::to_string(c.d), NT_ = std::to_string(c.n_theta > 0 ? c.n_theta : 1), NTH_ = std::to_string(c.n_theta);
+  const bool second = c.has_g && c.auto_g;  // (registered as identically zero: has_g with a blank source -- nothing to add)
+  s += "#define CDKF_WG_CUSTOM 1\n#define CDKF_WG_CUSTOM_SECOND " + std::string(second ? "1" : "0") + "\n";
+  s += "#define CDKF_WG_STATIC_LDS " + std::to_string(lds) + "\n";
+  s += "#include \"cdkf_reg_kernels.h\"\n#include \"cdkf_wg2_kernels.h\"\n#include \"cdkf_dual.h\"\nnamespace cdkf {\n";
+  s += "constexpr int CD = " + D_ + ", CNT = " + NT_ + ", CNTH = " + NTH_ + ";\n";
+  s += "template <typename T> __device__ __forceinline__ void custom_f(const T* x, const T* theta, T (&fx)[CD]) {\n  (void)theta;\n";
+  s += "#line 1 \"drift_f\"\n" + c.f_src + "\n}\n";
+  s += R"(
+template <typename R>
+__device__ void wg_custom_drift(const WgArgs<R>& a, const WgLds<R>& L, const R* x, R* fv, R* F, R* gv) {
+  const R* th = a.par + a.o_theta;
+  const int lq = a.lq;
+  if (!F) {
+    if (threadIdx.x == 0) {
+      R xr[CD], thr[CNT], fr[CD];
+      for (int i = 0; i < CD; ++i) xr[i] = x[i];
+      for (int k = 0; k < CNTH; ++k) thr[k] = th[k];
+      custom_f<R>(xr, thr, fr);
+      for (int i = 0; i < CD; ++i) fv[i] = fr[i];
+    }
+  } else {  // jacfwd(f) (inference_ekf.py:95): thread j carries the unit direction e_j -> column j of the Jacobian
+    CDKF_WG_FOR(j, CD) {
+      typedef Dual<R, 1> T;
+      T xt[CD], tht[CNT], ft[CD];
+      for (int i = 0; i < CD; ++i) {
+        xt[i] = T(x[i]);
+        xt[i].g[0] = (i == j) ? R(1) : R(0);
+      }
+      for (int k = 0; k < CNTH; ++k) tht[k] = T(th[k]);
+      custom_f<T>(xt, tht, ft);
+      for (int i = 0; i < CD; ++i) F[i * lq + j] = ft[i].g[0];
+      if (j == 0)
+        for (int i = 0; i < CD; ++i) fv[i] = ft[i].v;
+    }
+  }
+  if (gv) {
+#if CDKF_WG_CUSTOM_SECOND
+    // g_k = d/dx_k sum_i d f_i / d x_i (inference_ekf.py:108-116): one nested-dual evaluation per pair (i, k), summed over i afterwards
+    R* W = L.mat(L.plan.i_A);  // free until the right-hand side's product F Ps is formed
+    CDKF_WG_FOR(e, CD * CD) {
+      const int i = e / CD, k = e - i * CD;
+      typedef Dual<R, 1> S1;
+      typedef Dual<S1, 1> T;
+      T xt[CD], tht[CNT], ft[CD];
+      for (int l = 0; l < CD; ++l) {
+        S1 b(x[l]);
+        b.g[0] = (l == k) ? R(1) : R(0);
+        xt[l].v = b;
+        xt[l].g[0] = S1(l == i ? R(1) : R(0));
+      }
+      for (int kk = 0; kk < CNTH; ++kk) {
+        tht[kk].v = S1(th[kk]);
+        tht[kk].g[0] = S1(R(0));
+      }
+      custom_f<T>(xt, tht, ft);
+      R v = R(0);
+      for (int l = 0; l < CD; ++l)
+        if (l == i) v = ft[l].g[0].g[0];
+      W[i * lq + k] = v;
+    }
+    __syncthreads();
+    CDKF_WG_FOR(k, CD) {
+      R sum = R(0);
+      for (int i = 0; i < CD; ++i) sum += W[i * lq + k];
+      gv[k] = sum;
+    }
+#else
+    CDKF_WG_FOR(k, CD) gv[k] = R(0);
+#endif
+  }
+}
+
+template <typename R>
+__device__ void wg_custom_sigma(const WgArgs<R>& a, const WgLds<R>& L, const R* ms, const R* O, R* f0, R* DF, R* foo) {
+  const R* th = a.par + a.o_theta;
+  const int lq = a.lq;
+  (void)L;
+  CDKF_WG_FOR(i, CD + 1) {
+    R xr[CD], thr[CNT], fp[CD], fm[CD];
+    for (int k = 0; k < CNTH; ++k) thr[k] = th[k];
+    if (i == CD) {
+      for (int r = 0; r < CD; ++r) xr[r] = ms[r];
+      custom_f<R>(xr, thr, fp);
+      for (int r = 0; r < CD; ++r) f0[r] = fp[r];
+    } else {
+      for (int r = 0; r < CD; ++r) xr[r] = ms[r] + O[r * lq + i];
+      custom_f<R>(xr, thr, fp);
+      for (int r = 0; r < CD; ++r) xr[r] = ms[r] - O[r * lq + i];
+      custom_f<R>(xr, thr, fm);
+      for (int r = 0; r < CD; ++r) {
+        DF[r * lq + i] = fp[r] - fm[r];
+        foo[r * lq + i] = fp[r] + fm[r];
+      }
+    }
+  }
+}
+}  // namespace cdkf
+)";
+  return s;
+}
+
+std::string wg_kernel_expr(int bytes, int ept, int ukf, int smoother) {
+  const std::string R_ = bytes == 8 ? "double" : "float";
+  if (smoother) return "cdkf::ekf_smoother_wg_kernel<" + R_ + ", " + std::to_string(ept) + ">";
+  return "cdkf::ekf_filter_wg_kernel<" + R_ + ", " + std::to_string(ept) + ", " + (ukf ? "true" : "false") + ", cdkf::kDriftAny>";
+}
+
+int compile_wg_variant(const CustomDrift& c, const WgKey& key, const std::string& arch, std::vector<char>& code, std::string& lowered) {
+  const int bytes = std::get<1>(key), ept = std::get<2>(key), ukf = std::get<3>(key), smoother = std::get<4>(key);
+  const std::string src = generate_wg_source(c, (size_t)std::get<5>(key));
+  const std::string expr = wg_kernel_expr(bytes, ept, ukf, smoother);
+  hiprtcProgram prog = nullptr;
+  if (hiprtcCreateProgram(&prog, src.c_str(), "cdkf_custom_drift_wg.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
+    set_error("custom drift: hiprtcCreateProgram failed");
+    return CDKF_EHIP;
+  }
+  if (hiprtcAddNameExpression(prog, expr.c_str()) != HIPRTC_SUCCESS) {
+    set_error("custom drift: hiprtcAddNameExpression failed");
+    hiprtcDestroyProgram(&prog);
+    return CDKF_EHIP;
+  }
+  // (the instantiations with eight or more entries per thread are built at -O1 in the library too: launch_wg8.hip, Makefile)
+  const std::string inc = "-I" + source_dir(), off = "--offload-arch=" + arch;
+  const char* opts[] = {off.c_str(), ept >= 8 ? "-O1" : "-O3", "-std=c++17", inc.c_str(), "-Wno-pass-failed"};
+  const hiprtcResult res = hiprtcCompileProgram(prog, 5, opts);
+  if (res != HIPRTC_SUCCESS) {
+    size_t n = 0;
+    hiprtcGetProgramLogSize(prog, &n);
+    std::string log(n ? n : 1, '\0');
+    if (n) hiprtcGetProgramLog(prog, &log[0]);
+    std::string brief;
+    size_t pos = 0;
+    while (pos < log.size()) {
+      size_t eol = log.find('\n', pos);
+      if (eol == std::string::npos) eol = log.size();
+      if (log.compare(pos, 21, "In file included from") != 0) brief.append(log, pos, eol - pos + 1);
+      pos = eol + 1;
+    }
+    set_error("custom drift: compilation failed (%s): %.400s", hiprtcGetErrorString(res), brief.c_str());
+    hiprtcDestroyProgram(&prog);
+    return CDKF_EINVAL;
+  }
+  const char* name = nullptr;
+  if (hiprtcGetLoweredName(prog, expr.c_str(), &name) != HIPRTC_SUCCESS || !name) {
+    set_error("custom drift: no lowered name for %s", expr.c_str());
+    hiprtcDestroyProgram(&prog);
+    return CDKF_EHIP;
+  }
+  lowered = name;
+  size_t sz = 0;
+  hiprtcGetCodeSize(prog, &sz);
+  code.resize(sz);
+  hiprtcGetCode(prog, code.data());
+  hiprtcDestroyProgram(&prog);
+  if (const char* dir = getenv("CDKF_CUSTOM_DUMP")) {  // debugging aid: the generated source and its code object
+    const std::string base = std::string(dir) + "/cdkf_custom_wg_" + std::to_string(bytes) + "_" + std::to_string(ept) + "_" + std::to_string(ukf) +
+                             "_" + std::to_string(smoother);
+    if (FILE* f = fopen((base + ".hip").c_str(), "w")) {
+      fwrite(src.data(), 1, src.size(), f);
+      fclose(f);
+    }
+    if (FILE* f = fopen((base + ".co").c_str(), "wb")) {
+      fwrite(code.data(), 1, code.size(), f);
+      fclose(f);
+    }
+  }
+  return CDKF_OK;
+}
+
+int get_wg_function(int kind, const WgKey& key, hipFunction_t* fn) {
+  std::lock_guard<std::mutex> lock(g_mutex);
+  int dev = 0;
+  CDKF_HIP_CHECK(hipGetDevice(&dev));
+  auto it = g_wg_modules.find({dev, key});
+  if (it != g_wg_modules.end()) {
+    *fn = it->second.fn;
+    return CDKF_OK;
+  }
+  const CustomDrift& c = g_drifts[kind - CDKF_DRIFT_CUSTOM_BASE];
+  hipDeviceProp_t prop;
+  CDKF_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+  std::vector<char> code;
+  std::string lowered;
+  int rc = compile_wg_variant(c, key, prop.gcnArchName, code, lowered);
+  if (rc) return rc;
+  Compiled m;
+  CDKF_HIP_CHECK(hipModuleLoadData(&m.module, code.data()));
+  CDKF_HIP_CHECK(hipModuleGetFunction(&m.fn, m.module, lowered.c_str()));
+  g_wg_modules[{dev, key}] = m;
+  *fn = m.fn;
+  return CDKF_OK;
+}
+
 }  // namespace
+
+// the registered parameter count of a custom drift of this state dimension (-1: no such drift): what launch_wg.hip checks n_theta against
+long custom_ntheta(int kind, int state_dim) {
+  std::lock_guard<std::mutex> lock(g_mutex);
+  const int idx = kind - CDKF_DRIFT_CUSTOM_BASE;
+  if (idx < 0 || idx >= (int)g_drifts.size() || g_drifts[idx].d != state_dim) return -1;
+  return g_drifts[idx].n_theta;
+}
+
+// launch of the (filter, smoother) pair of launch_wg_dispatch for a drift that was given as source
+template <typename R>
+int launch_custom_wg(const WgArgs<R>& a, int ept, bool filter, bool smoother, int threads, size_t lds_f, size_t lds_s, hipStream_t stream) {
+  auto run = [&](int smooth, size_t lds) -> int {
+    hipFunction_t fn = nullptr;
+    const size_t bytes = (lds + 15) & ~size_t(15);
+    int r = get_wg_function(a.kind, WgKey(a.kind, (int)sizeof(R), ept, smooth ? 0 : a.ukf, smooth, (long)bytes), &fn);
+    if (r) return r;
+    WgArgs<R> arg = a;
+    void* args[] = {(void*)&arg};
+    note_kernel(smooth ? "ekf_smoother_wg_kernel<%s, %d> (custom drift)" : "ekf_filter_wg_kernel<%s, %d, ...> (custom drift)", real_name<R>(), ept);
+    CDKF_HIP_CHECK(hipModuleLaunchKernel(fn, (unsigned)a.N, 1, 1, (unsigned)threads, 1, 1, 0, stream, args, nullptr));
+    return CDKF_OK;
+  };
+  int rc = CDKF_OK;
+  if (filter) rc = run(0, lds_f);
+  if (!rc && smoother) rc = run(1, lds_s);
+  return rc;
+}
+template int launch_custom_wg<float>(const WgArgs<float>&, int, bool, bool, int, size_t, size_t, hipStream_t);
+template int launch_custom_wg<double>(const WgArgs<double>&, int, bool, bool, int, size_t, size_t, hipStream_t);
 
 bool custom_emission_kind(int ek, int d, int m) {
   std::lock_guard<std::mutex> lock(g_mutex_emis());
@@ -326,10 +560,16 @@ bool custom_kind(int kind) {
 
 bool custom_shape_available(const cdkf_model* mdl, const cdkf_opts* o) {
   if (!custom_kind(mdl->drift_kind)) return false;
-  std::lock_guard<std::mutex> lock(g_mutex);
-  const CustomDrift& c = g_drifts[mdl->drift_kind - CDKF_DRIFT_CUSTOM_BASE];
-  if (c.d != mdl->state_dim || c.n_theta != mdl->n_theta || mdl->emission_dim > 6) return false;
-  if (o && o->state_order == CDKF_ORDER_SECOND && !c.has_g) return false;
+  int cd = 0;
+  {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    const CustomDrift& c = g_drifts[mdl->drift_kind - CDKF_DRIFT_CUSTOM_BASE];
+    if (c.d != mdl->state_dim || c.n_theta != mdl->n_theta) return false;
+    if (o && o->state_order == CDKF_ORDER_SECOND && !c.has_g) return false;
+    cd = c.d;
+  }
+  if (cd > 6 || mdl->emission_dim > 6)  // the workgroup kernels: linear emission, their LDS plan (asked in fp32; an fp64 launch that
+    return mdl->emission_kind == 0 && custom_wg_fits(mdl);  // does not fit says so itself)
   return true;
 }
 
@@ -338,6 +578,7 @@ bool custom_shape_available(const cdkf_model* mdl, const cdkf_opts* o) {
 // that was registered as identically zero (an empty divgrad_src): the sweep does not carry the mean's second-order term
 bool custom_grad_available(const cdkf_model* mdl, const cdkf_opts* o) {
   if (!custom_shape_available(mdl, o) || mdl->emission_kind != 0 || mdl->n_theta < 1) return false;
+  if (mdl->state_dim > 6 || mdl->emission_dim > 6) return false;  // (the forward-sensitivity sweep is a register-resident kernel)
   if (o->num_iter != 1 || o->forecast || o->state_order == CDKF_ORDER_ZEROTH) return false;
   std::lock_guard<std::mutex> lock(g_mutex);
   const CustomDrift& c = g_drifts[mdl->drift_kind - CDKF_DRIFT_CUSTOM_BASE];
@@ -363,11 +604,25 @@ int launch_custom(int algo, const cdkf_model* mdl, const cdkf_opts* o, int64_t N
               c.n_theta, d, (long long)mdl->n_theta);
     return CDKF_EINVAL;
   }
-  if (m > 6) {
-    set_error("custom drifts run on the register-resident kernels: emission_dim <= 6 (got %d)", m);
-    return CDKF_EUNSUPPORTED;
-  }
   const int ek = mdl->emission_kind;
+  if (d > 6 || m > 6) {  // beyond the register-resident kernels: the workgroup-per-trajectory sweeps with this drift compiled in
+    if (ek) {
+      set_error("custom emissions run on the register-resident kernels: state_dim, emission_dim <= 6 (got %d, %d)", d, m);
+      return CDKF_EUNSUPPORTED;
+    }
+    if (algo == 3) {
+      set_error("custom drift: the gradient sweep is a register-resident kernel, state_dim, emission_dim <= 6 (got %d, %d)", d, m);
+      return CDKF_EUNSUPPORTED;
+    }
+    if (algo != 1 && o->state_order == CDKF_ORDER_SECOND && !c.has_g) {
+      set_error("custom drift without grad(div f): state_order 'second' needs it (the reference differentiates the drift twice, "
+                "inference_ekf.py:108-116); register divgrad_src \"auto\" or use state_order 'first'");
+      return CDKF_EUNSUPPORTED;
+    }
+    if (algo == 0) return launch_ekf_filter_wg<R>(mdl, o, N, T, t, y, ll, a1, a2, a3, a4, status, stream);
+    if (algo == 1) return launch_ukf_filter_wg<R>(mdl, o, N, T, t, y, ll, a1, a2, a3, a4, status, stream);
+    return launch_ekf_smoother_wg<R>(mdl, o, N, T, t, y, ll, a1, a2, a3, a4, status, stream);
+  }
   if (ek && !custom_emission_kind(ek, d, m)) {
     set_error("emission_kind %d is not a custom emission registered for state_dim=%d, emission_dim=%d", ek, d, m);
     return CDKF_EINVAL;
@@ -483,14 +738,20 @@ template int launch_custom<double>(int, const cdkf_model*, const cdkf_opts*, int
                                    double*, double*, double*, double*, double*, int32_t*, hipStream_t);
 
 int custom_register(int state_dim, int n_theta, const char* f_src, const char* jac_src, const char* divgrad_src) {
-  if (state_dim < 1 || state_dim > 6 || n_theta < 0 || !f_src) {
-    set_error("custom drift: need 1 <= state_dim <= 6, n_theta >= 0 and the source of f (jac_src NULL or empty: the Jacobian is "
+  if (state_dim < 1 || state_dim > 64 || n_theta < 0 || !f_src) {
+    set_error("custom drift: need 1 <= state_dim <= 64, n_theta >= 0 and the source of f (jac_src NULL or empty: the Jacobian is "
               "derived from f_src by dual numbers; divgrad_src \"auto\": so is grad(div f))");
     return CDKF_EINVAL;
   }
-  std::lock_guard<std::mutex> lock(g_mutex);
   const bool auto_jac = !jac_src || blank(jac_src);
   const bool auto_g = divgrad_src && std::string(divgrad_src) == "auto";
+  if (state_dim > 6 && (!auto_jac || (divgrad_src && !auto_g && !blank(divgrad_src)))) {
+    // (a thread of the workgroup kernels evaluates ONE direction of the Jacobian; a source that fills all of F[D][D] has no place there)
+    set_error("custom drift: above state_dim 6 the derivatives come from f_src by dual numbers -- pass jac_src NULL and divgrad_src "
+              "NULL, \"\" (identically zero) or \"auto\" (got state_dim %d)", state_dim);
+    return CDKF_EINVAL;
+  }
+  std::lock_guard<std::mutex> lock(g_mutex);
   CustomDrift c{state_dim, n_theta, f_src, auto_jac ? "" : jac_src, (divgrad_src && !auto_g) ? divgrad_src : "", divgrad_src != nullptr,
                 auto_jac, auto_g};
   for (size_t k = 0; k < g_drifts.size(); ++k) {
@@ -508,7 +769,7 @@ int custom_compile_check(int kind, int bytes_per_real, int emission_dim, int alg
     set_error("custom emission %d is not registered for this state / emission dimension", emission_kind);
     return CDKF_EINVAL;
   }
-  if (!custom_kind(kind) || (bytes_per_real != 4 && bytes_per_real != 8) || emission_dim < 1 || emission_dim > 6 || algo < 0 ||
+  if (!custom_kind(kind) || (bytes_per_real != 4 && bytes_per_real != 8) || emission_dim < 1 || emission_dim > 64 || algo < 0 ||
       algo > 3) {
     set_error("custom drift compile check: bad arguments");
     return CDKF_EINVAL;
@@ -519,6 +780,22 @@ int custom_compile_check(int kind, int bytes_per_real, int emission_dim, int alg
     c = g_drifts[kind - CDKF_DRIFT_CUSTOM_BASE];
   }
   std::vector<char> code;
+  if (c.d > 6 || emission_dim > 6) {  // the workgroup kernels (dense emission matrix assumed: the larger LDS plan)
+    if (algo == 3 || emission_kind) {
+      set_error("custom drift compile check: gradients and custom emissions need state_dim, emission_dim <= 6");
+      return CDKF_EUNSUPPORTED;
+    }
+    int ept = 0, threads = 0;
+    size_t lds_f = 0, lds_s = 0;
+    if (custom_wg_geometry(kind, c.d, emission_dim, bytes_per_real, algo == 1, &ept, &threads, &lds_f, &lds_s)) {
+      set_error("custom drift compile check: state_dim %d, emission_dim %d do not fit the workgroup kernels' LDS plan", c.d, emission_dim);
+      return CDKF_EUNSUPPORTED;
+    }
+    std::string lowered;
+    int rc = compile_wg_variant(c, WgKey(kind, bytes_per_real, ept, algo == 1, 0, (long)((lds_f + 15) & ~size_t(15))), "gfx950", code, lowered);
+    if (!rc && algo == 2) rc = compile_wg_variant(c, WgKey(kind, bytes_per_real, ept, 0, 1, (long)((lds_s + 15) & ~size_t(15))), "gfx950", code, lowered);
+    return rc;
+  }
   const int zeroth = (algo != 1 && state_order == CDKF_ORDER_ZEROTH) ? 1 : 0;
   if (algo == 3) return compile_variant(c, Key(kind, bytes_per_real, emission_dim, 0, 0, 0, 2, 0, 0), "gfx950", code);
   int rc = compile_variant(c, Key(kind, bytes_per_real, emission_dim, algo == 1, zeroth, 0, 0, 0, emission_kind), "gfx950", code);

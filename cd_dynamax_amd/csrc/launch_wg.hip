@@ -24,7 +24,7 @@ static long expected_theta(const cdkf_model* mdl) {
     case CDKF_DRIFT_LORENZ63: return 3;
     case CDKF_DRIFT_LORENZ96: return 1;
     case CDKF_DRIFT_MLP_TANH: return h1 * d + h1 + h2 * h1 + h2 + d * h2 + d;
-    default: return -1;
+    default: return custom_ntheta(mdl->drift_kind, mdl->state_dim);  // a drift given as source (launch_custom.hip), or -1
   }
 }
 
@@ -34,9 +34,11 @@ bool wg_shape_available(const cdkf_model* mdl, int bytes_per_real) {
   if (expected_theta(mdl) < 0 || expected_theta(mdl) != mdl->n_theta) return false;
   if (mdl->drift_kind == CDKF_DRIFT_LORENZ63 && d != 3) return false;
   if (mdl->drift_kind == CDKF_DRIFT_LORENZ96 && d < 4) return false;
+  if (mdl->drift_kind >= CDKF_DRIFT_CUSTOM_BASE && mdl->emission_kind != 0) return false;
   const size_t lds = bytes_per_real == 8 ? wg_lds_bytes<double>(mdl, true) : wg_lds_bytes<float>(mdl, true);
   return lds <= kLdsLimit - 256;
 }
+bool custom_wg_fits(const cdkf_model* mdl) { return wg_shape_available(mdl, 4); }
 
 // Parameter blocks (up to ~70 KB for d = 40) go through a small ring of persistent device buffers, each paired
 // with a pinned host staging buffer and an event recorded behind the kernels that read it.  The asynchronous
@@ -178,10 +180,45 @@ static int wg_ept(int d, int threads) {
   return -1;
 }
 
+// A drift given as source: at most 256 threads.  Under hipRTC (ROCm 7.2) the device FUNCTIONS these kernels call (s_swappc: wg_ekf_update,
+// wg_cholesky2, ...) do not inherit the kernel's __launch_bounds__(512) register budget as they do under hipcc -- the kernel comes out with
+// 256 + 128 registers, a workgroup of eight such wavefronts does not fit a CU and the launch dies with HSA_STATUS_ERROR_INVALID_ISA
+// (-amdgpu-internalize-symbols, --gpu-max-threads-per-block: no difference; -amdgpu-function-calls=false: 256 registers, but the
+// float32 d = 12 instantiation then faulted on memory).  Four wavefronts, one per SIMD, may have them.
+static int wg_threads_custom(int d) {
+  const int t = wg_threads(d);
+  return t > 256 ? 256 : t;
+}
+
+// what launch_custom.hip needs to compile a drift into these kernels ahead of a launch (cdkf_custom_drift_compile): a dense emission
+// matrix is assumed (the larger plan); nonzero: does not fit
+int custom_wg_geometry(int kind, int d, int m, int bytes_per_real, bool ukf, int* ept, int* threads, size_t* lds_f, size_t* lds_s) {
+  cdkf_model mdl{};
+  mdl.drift_kind = kind;
+  mdl.state_dim = d;
+  mdl.emission_dim = m;
+  if (d < 1 || m < 1 || d > 64 || m > 64) return 1;
+  *threads = wg_threads_custom(d);
+  *ept = wg_ept(d, *threads);
+  const int q = d > m ? d : m, lq = ((q + 3) & ~3) + 1;
+  const size_t s = (size_t)bytes_per_real;
+  *lds_f = s * (size_t)wg_lds_reals(wg_plan(kind, d, 0, 0, 0, false, ukf), q, lq) + 64;
+  *lds_s = s * (size_t)wg_lds_reals(wg_plan(kind, d, 0, 0, 0, true, false), q, lq) + 64;
+  return (*ept < 0 || *lds_f > kLdsLimit - 256 || *lds_s > kLdsLimit - 256) ? 1 : 0;
+}
+
 template <typename R>
 static int launch_wg_dispatch(const WgArgs<R>& a, const cdkf_model* mdl, bool smoother, hipStream_t stream, bool filter = true) {
   const int threads = wg_threads(mdl);
   const size_t lds_f = wg_lds_bytes<R>(mdl, false, a.ukf != 0), lds_s = wg_lds_bytes<R>(mdl, true);
+  if (mdl->drift_kind >= CDKF_DRIFT_CUSTOM_BASE) {  // compiled at run time with the drift's source
+    const int tc = wg_threads_custom(a.d), ept = wg_ept(a.d, tc);
+    if (ept < 0) {
+      set_error("state_dim %d too large for the workgroup kernels", a.d);
+      return CDKF_EUNSUPPORTED;
+    }
+    return launch_custom_wg<R>(a, ept, filter, smoother, tc, lds_f, lds_s, stream);
+  }
   switch (wg_ept(a.d, threads)) {
     case 1: return launch_wg_pair<R, 1>(a, filter, smoother, threads, lds_f, lds_s, stream);
     case 2: return launch_wg_pair<R, 2>(a, filter, smoother, threads, lds_f, lds_s, stream);
@@ -195,6 +232,7 @@ static int launch_wg_dispatch(const WgArgs<R>& a, const cdkf_model* mdl, bool sm
 // wavefront-per-trajectory kernel: state and emission dimensions up to 8, MLP hidden layers up to 64
 static bool wave8_shape(const cdkf_model* mdl) {
   if (getenv("CDKF_NO_WAVE8")) return false;  // debugging aid: force the workgroup kernels
+  if (mdl->drift_kind >= CDKF_DRIFT_CUSTOM_BASE) return false;  // (a drift given as source is compiled into the workgroup kernels)
   if (mdl->state_dim > 8 || mdl->emission_dim > 8) return false;
   if (mdl->drift_kind == CDKF_DRIFT_MLP_TANH && (mdl->hidden1 > 64 || mdl->hidden2 > 64)) return false;
   return true;

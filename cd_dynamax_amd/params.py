@@ -117,7 +117,11 @@ class LearnableCustomDrift(NamedTuple):
     'first', or 'second' with ``divgrad_src=""``).  Wherever derivatives are derived, ``f_src`` is also compiled with a dual-number
     scalar type ``T`` in place of ``R``: declare temporaries ``auto`` or ``T`` there, not ``R``.
 
-    ``R`` is the compute type (float or double); state_dim <= 6.  ``py_f`` (optional) is the same function as a Python
+    ``R`` is the compute type (float or double).  state_dim, emission_dim <= 6: the register-resident kernels.  Beyond that
+    (state_dim <= 64, as far as the workgroup kernels' LDS holds the shape: d = m = 40 in float64, 60 in float32) the same ``f_src`` is
+    compiled into the workgroup-per-trajectory kernels -- ``jac_src`` must then be None and ``divgrad_src`` None, "" or "auto" (a thread
+    per direction of the Jacobian, all by dual numbers), the emission linear; filters, smoother and forecast, no gradient; 10 - 20 s of
+    compilation per variant on first use.  ``py_f`` (optional) is the same function as a Python
     callable ``f(x, u, t)`` for host-side use; it is never called by the filter."""
     theta: Any
     f_src: str

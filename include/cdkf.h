@@ -273,10 +273,15 @@ int cdkf_emission_moments_f32_dev(const cdkf_model* mdl, int64_t rows, const flo
  *      with an empty divgrad_src = identically zero).  f_src is then compiled a second time with the scalar type T = a dual
  *      number in place of R: x, theta and fx are arrays of T there -- declare temporaries `auto` or `T`, not `R`
  *      (R(...) constants, +, -, *, /, sin, cos, tan, tanh, sinh, cosh, exp, log, sqrt, pow, fabs, atan and comparisons are provided).
- *      state_dim <= 6, emission_dim <= 6.  Returns the drift_kind to put in cdkf_model (>= CDKF_DRIFT_CUSTOM_BASE; the
+ *      state_dim, emission_dim <= 6: the register-resident kernels.  Beyond that (state_dim <= 64, as far as the workgroup kernels'
+ *      LDS plan holds the shape: e.g. d = m = 40 in fp64, 60 in fp32) the same f_src is compiled into the workgroup-per-trajectory
+ *      sweeps (round 3): jac_src must then be NULL and divgrad_src NULL, "" or "auto" -- a thread of the workgroup evaluates ONE
+ *      direction of the Jacobian / one (i, k) pair of the second derivatives / one pair of sigma points, all by dual numbers; linear
+ *      emission only, no gradient entry point; 10 - 20 s of compilation per variant on first use.
+ *      Returns the drift_kind to put in cdkf_model (>= CDKF_DRIFT_CUSTOM_BASE; the
  *      same sources give the same kind) or a negative CDKF_E* code.  Filters (EKF all orders, UKF), EKF smoother,
- *      forecast mode and the drift-parameter gradient are available for custom kinds; kernels compile on first use (seconds)
- *      and are cached.  Compile errors in the snippets surface through cdkf_last_error(). */
+ *      forecast mode and (state_dim, emission_dim <= 6) the drift-parameter gradient are available for custom kinds; kernels compile
+ *      on first use (seconds) and are cached.  Compile errors in the snippets surface through cdkf_last_error(). */
 int cdkf_custom_drift_register(int state_dim, int n_theta, const char* f_src, const char* jac_src,
                                const char* divgrad_src);
 /* A user-supplied EMISSION function (the reference accepts any callable h and linearises it with jacfwd,

@@ -66,8 +66,10 @@ def test_register_and_compile_all_variants():
             for algo in (0, 1, 2):
                 assert L.cdkf_custom_drift_compile(kind, nbytes, 1, algo, 1, 0) == 0, L.cdkf_last_error().decode()
     assert L.cdkf_custom_drift_compile(k2, 8, 3, 0, 0, 0) == 0                # zeroth order, emission_dim 3
+    with pytest.raises(_ffi.CdkfError, match="dual numbers"):
+        _ffi.register_custom_drift(9, 1, PEND_F, PEND_J, None)             # state_dim > 6: no hand-written Jacobian (see below)
     with pytest.raises(_ffi.CdkfError):
-        _ffi.register_custom_drift(9, 1, PEND_F, PEND_J, None)             # state_dim > 6
+        _ffi.register_custom_drift(65, 1, PEND_F, None, None)
     assert L.cdkf_custom_drift_compile(12345, 8, 1, 0, 1, 0) != 0
 
 
@@ -391,3 +393,122 @@ def test_fit_sgd_on_a_custom_drift(hip_lib):
     got = np.asarray(new.dynamics.drift.theta)
     assert np.all(np.isfinite(losses)) and losses[-1] < losses[0]
     assert np.all(np.abs(got - truth) < 0.5 * np.abs(np.array([1.2, 0.8]) - truth)), got
+
+
+# ---- beyond six dimensions: the same source compiled into the workgroup-per-trajectory kernels -------------------------------------
+def cubic_l96_src(d):
+    """Lorenz-96 with a cubic damping term: f_i = (x_{i+1} - x_{i-2}) x_{i-1} - x_i - theta_1 x_i^3 + theta_0; grad(div f)_k = -6 theta_1 x_k."""
+    return (f"for (int i = 0; i < {d}; ++i) {{ const int ip1 = (i + 1) % {d}, im1 = (i + {d - 1}) % {d}, im2 = (i + {d - 2}) % {d}; "
+            f"fx[i] = (x[ip1] - x[im2]) * x[im1] - x[i] - theta[1] * x[i] * x[i] * x[i] + theta[0]; }}")
+
+
+def cubic_l96_oracle(theta, d):
+    f = lambda x, th: (np.roll(x, -1, -1) - np.roll(x, 2, -1)) * np.roll(x, 1, -1) - x - th[1] * x ** 3 + th[0]
+
+    def jac(x, th):
+        F = np.zeros(x.shape + (d,), x.dtype)
+        for i in range(d):
+            F[..., i, (i + 1) % d] += x[..., (i - 1) % d]
+            F[..., i, (i - 2) % d] += -x[..., (i - 1) % d]
+            F[..., i, (i - 1) % d] += x[..., (i + 1) % d] - x[..., (i - 2) % d]
+            F[..., i, i] += -1 - 3 * th[1] * x[..., i] ** 2
+        return F
+    g = lambda x, th: -6 * th[1] * x
+    return o.CallableDrift(theta, f, jac, g)
+
+
+def wide_model(rng, d, m, theta, selection=False):
+    H = np.eye(d)[:: max(1, d // m)][:m] if selection else rng.standard_normal((m, d)) / np.sqrt(d)
+    A = rng.standard_normal((d, d)) / np.sqrt(d)
+    Rm = rng.standard_normal((m, m)) / np.sqrt(m)
+    return o.Model(cubic_l96_oracle(theta, d), np.eye(d), 0.05 * np.eye(d) + 0.02 * A @ A.T, H, 0.05 * rng.standard_normal(m),
+                   0.3 * np.eye(m) + 0.05 * Rm @ Rm.T, theta[0] + 0.3 * rng.standard_normal(d), 0.2 * np.eye(d))
+
+
+def test_wide_custom_drift_compiles_without_a_gpu():
+    """state_dim 12: the workgroup kernels go through hipRTC with the drift's source for gfx950 on the CPU box (filter with grad(div f)
+    by nested dual numbers, smoother); a hand-written Jacobian is refused at registration."""
+    L = _ffi.lib()
+    k = _ffi.register_custom_drift(12, 2, cubic_l96_src(12), None, "auto")
+    assert L.cdkf_custom_drift_compile(k, 8, 5, 2, 2, 0) == 0, L.cdkf_last_error().decode()       # filter + smoother, fp64
+    assert L.cdkf_custom_drift_compile(k, 4, 12, 1, 1, 0) == 0, L.cdkf_last_error().decode()      # unscented filter, fp32
+    assert L.cdkf_custom_drift_compile(k, 8, 5, 3, 1, 0) != 0                                     # no gradient sweep up there
+    bad = _ffi.register_custom_drift(12, 1, "for (int i = 0; i < 12; ++i) fx[i] = -theta[0] * sine(x[i]);", None, None)
+    assert L.cdkf_custom_drift_compile(bad, 8, 5, 0, 1, 0) != 0 and "drift_f:1" in L.cdkf_last_error().decode()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,m,selection", [(12, 5, False), (9, 9, True), (7, 3, False), (3, 8, False)])
+def test_wide_custom_drift_filters_and_smoother(hip_lib, d, m, selection):
+    """A drift given as source beyond the register-resident kernels' six dimensions (state or emission): Jacobian by dual numbers, a
+    thread per direction; grad(div f) by nested dual numbers, a thread per (i, k) pair; the unscented filter's sigma points a thread
+    per pair -- EKF first / second / zeroth order, UKF, smoother, fp32, forecast, another Runge-Kutta method and the step-size
+    controller, against the oracle evaluating the same drift through NumPy callables."""
+    rng = np.random.default_rng(800 + 10 * d + m)
+    theta = np.array([4.0, 0.05])
+    mdl = wide_model(rng, d, m, theta, selection)
+    N, T = 5, 14
+    t = o.irregular_times(rng, N, T, 0.04)
+    y = o.simulate(mdl, t, rng)
+    P = params_for(mdl, cd.LearnableCustomDrift(theta, cubic_l96_src(d), None, "auto"))
+    for order in ("second", "first", "zeroth"):
+        ref = o.ekf_filter(mdl, t, y, state_order=order)
+        post = cd.cdnlgssm_filter(P, y, t[..., None], cd.EKFHyperParams(state_order=order))
+        for k in FILTER_KEYS:
+            assert relerr(getattr(post, k), ref[k]) < 1e-10, (order, k)
+        np.testing.assert_allclose(post.marginal_loglik, ref["marginal_loglik"], rtol=1e-10)
+        if order == "second":
+            assert "custom drift" in _ffi.lib().cdkf_last_kernel().decode()
+            ref1 = o.ekf_filter(mdl, t, y, state_order="first")
+            assert relerr(ref1["filtered_means"], ref["filtered_means"]) > 1e-7     # the second-order term is not a no-op here
+    ref = o.ukf_filter(mdl, t, y)
+    post = cd.cdnlgssm_filter(P, y, t[..., None], cd.UKFHyperParams())
+    for k in FILTER_KEYS:
+        assert relerr(getattr(post, k), ref[k]) < 1e-9, k
+    ref = o.ekf_smoother(mdl, t, y, state_order="second")
+    sm = cd.cdnlgssm_smoother(P, y, t[..., None])
+    assert relerr(sm.smoothed_means, ref["smoothed_means"]) < 1e-9
+    assert relerr(sm.smoothed_covariances, ref["smoothed_covariances"]) < 1e-9
+    ref = o.ekf_filter(mdl, t, y, state_order="second")
+    p32 = cd.cdnlgssm_filter(P, y.astype(np.float32), t[..., None].astype(np.float32))
+    assert p32.filtered_means.dtype == np.float32 and relerr(p32.filtered_means, ref["filtered_means"]) < 5e-4
+    tf = np.linspace(0.05, 0.4, 5)
+    fc = cd.cdnlgssm_forecast(P, (mdl.m0, mdl.P0), np.array([[0.0]]), tf[:, None], cd.EKFHyperParams(state_order="first"))
+    rm, rP = o.forecast(mdl, mdl.m0[None], mdl.P0[None], np.array([0.0]), tf[None], "ekf", state_order="first")
+    assert relerr(fc.forecasted_state_means, rm[0]) < 1e-10 and relerr(fc.forecasted_state_covariances, rP[0]) < 1e-10
+    hyp = cd.EKFHyperParams(diffeqsolve_settings={"solver": "tsit5"})
+    with o.use_solver("tsit5"):
+        ref = o.ekf_filter(mdl, t, y, state_order="second")
+    post = cd.cdnlgssm_filter(P, y, t[..., None], hyp)
+    assert relerr(post.filtered_covariances, ref["filtered_covariances"]) < 1e-10
+    ctrl = dict(rtol=1e-6, atol=1e-8)
+    hyp = cd.EKFHyperParams(diffeqsolve_settings={"solver": "dopri5", "dt0": 0.02, "stepsize_controller": cd.PIDController(**ctrl)})
+    with o.use_solver("dopri5", adaptive=ctrl):
+        ref = o.ekf_filter(mdl, t, y, state_order="second", dt0=0.02)
+    post = cd.cdnlgssm_filter(P, y, t[..., None], hyp)
+    assert relerr(post.filtered_covariances, ref["filtered_covariances"]) < 1e-9
+    with pytest.raises(NotImplementedError, match="no gradient kernel"):
+        cd.cdnlgssm_loglik_and_grad(P, y, t[..., None], cd.EKFHyperParams(state_order="first"))
+
+
+@pytest.mark.gpu
+def test_lorenz96_as_source_matches_the_built_in_drift_at_forty_dimensions(hip_lib):
+    """Lorenz-96 at d = 40 written as a snippet (theta_1 = 0 removes the cubic term): the run-time compiled workgroup kernels reproduce
+    the built-in drift's filter and smoother (the wavefront kernels of config 4) and the oracle."""
+    rng = np.random.default_rng(840)
+    d, m = 40, 20
+    theta = np.array([8.0, 0.0])
+    mdl = wide_model(rng, d, m, theta, True)
+    builtin = o.Model(o.Lorenz96Drift(8.0), mdl.L, mdl.Qc, mdl.H, mdl.bias, mdl.R, mdl.m0, mdl.P0)
+    N, T = 3, 10
+    t = o.irregular_times(rng, N, T, 0.03)
+    y = o.simulate(builtin, t, rng)
+    Pc = params_for(mdl, cd.LearnableCustomDrift(theta, cubic_l96_src(d), None, ""))
+    Pb = params_for(builtin, cd.LearnableLorenz96(8.0))
+    ref = o.ekf_smoother(builtin, t, y)
+    for P in (Pc, Pb):
+        sm = cd.cdnlgssm_smoother(P, y, t[..., None])
+        assert relerr(sm.filtered_covariances, ref["filtered_covariances"]) < 1e-10
+        assert relerr(sm.smoothed_means, ref["smoothed_means"]) < 1e-9
+        np.testing.assert_allclose(sm.marginal_loglik, ref["marginal_loglik"], rtol=1e-10)
+    assert "custom drift" not in _ffi.lib().cdkf_last_kernel().decode()
