@@ -55,11 +55,27 @@ static __device__ long long awg_prof[16];
 #define AWG_TICK(i)
 #endif
 
+#ifdef CDKF_AWG_CUSTOM
+// A drift given as C source (launch_custom.hip compiles this header at run time together with the definitions of these two, which
+// differentiate the source by dual numbers, cdkf_dual.h; CDKF_AWG_CUSTOM = the drift's number of parameters):
+//   awg_custom_column:   column j of the Jacobian at x into F (leading dimension ld) and, if fv is non-null, f(x) into fv;
+//   awg_custom_contract: sum_i G[i][j] d2 f_i / dx_j dz  (+ sum_i lam_i d f_i / dz if lam is non-null), z < d: the state component z,
+//                        z >= d: the parameter z - d -- what the reverse of F(m, theta) Ps + (F Ps)^T contributes to the cotangent of z.
+template <typename R>
+__device__ void awg_custom_column(const R* th, const R* x, int j, R* F, int ld, R* fv);
+template <typename R>
+__device__ R awg_custom_contract(const R* th, const R* x, const R* G, int ld, int j, int z, const R* lam);
+#endif
+
 // NE: covariance entries a thread owns at most (rows i0, i0 + rs, ... of its column on the d x d map): 8 up to d = 42, else 16
 template <typename R, int NE>
 __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArgs<R> a, R* __restrict__ grad, R* __restrict__ grad_model,
                                                                     R* __restrict__ ws, long ws_stride, int cap) {
+#ifdef CDKF_WG_STATIC_LDS  // run-time compiled for one shape (no dynamic-LDS cap to raise on a module function)
+  __shared__ __attribute__((aligned(16))) unsigned char smem_raw[CDKF_WG_STATIC_LDS];
+#else
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+#endif
   R* sm = reinterpret_cast<R*>(smem_raw);
   const int tid = threadIdx.x, NT = blockDim.x;
   const long n = blockIdx.x;
@@ -84,7 +100,13 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
   R* wsb = ws + n * ws_stride;
   R* starts = wsb;            // [cap][d*d + d]
   R* dts = starts + (long)cap * sz;
+#ifdef CDKF_AWG_CUSTOM
+  const bool custom = a.kind >= kDriftCustomBase;
+  const long ntheta = custom ? (long)CDKF_AWG_CUSTOM : (lin ? (long)d * d + d : 1);
+#else
+  constexpr bool custom = false;
   const long ntheta = lin ? (long)d * d + d : 1;
+#endif
   R* g = grad + n * ntheta;
   R* gm = grad_model ? grad_model + n * awg_model_grad_size(d, m) : nullptr;
   R* gP0 = gm ? gm + d : nullptr;
@@ -196,12 +218,18 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
   if (tid < 64) mb[tid] = R(0);
   AWG_FOR(e, (int)ntheta) g[e] = R(0);
   if (gm) AWG_FOR(e, (int)awg_model_grad_size(d, m)) gm[e] = R(0);
-  R gForcing = R(0);  // Lorenz-96: thread 0 accumulates d ll / d F
+  R gForcing = R(0);  // Lorenz-96: thread 64 accumulates d ll / d F;  a drift given as source: thread d + p accumulates d ll / d theta_p
   int st = 0;
   __syncthreads();
 
   // ---- drift: dense Jacobian F(x) into a slot, f(x) into fv; x in LDS (synchronised by the caller before AND after) ------------
   auto drift_eval = [&](const R* xv, R* F) {
+#ifdef CDKF_AWG_CUSTOM
+    if (custom) {  // jacfwd with the directions spread over the workgroup: thread j carries e_j
+      AWG_FOR(j, d) awg_custom_column<R>(th, xv, j, F, ld, j == 0 ? fv : (R*)nullptr);
+      return;
+    }
+#endif
     rows2d(d, d,
            [&](int i, int j) {
              if (lin) return th[i * d + j];
@@ -686,6 +714,26 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
           if (lin) {
             gemm(d, d, d, [&](int i, int kk) { return Lam[i * ld + kk]; }, [&](int kk, int j) { return Ps[kk * ld + j]; },
                  [&](int i, int j, R v) { g[i * d + j] += rfma(lamv[i], xs[j], R(2) * v); });  // dW += lam x^T + G
+#ifdef CDKF_AWG_CUSTOM
+          } else if (custom) {
+            // G2 = 2 Lam Ps in full; then c_z = sum_ij G2_ij d F_ij / dz (+ lam . df/dz for a parameter) for every state component and
+            // parameter z, one nested-dual evaluation per (column j, z): the workgroup's threads as (group, z), a group takes every
+            // NG-th column, the partial sums meet in a free slot
+            R* G2 = slot(7);
+            R* part = slot(8);
+            gemm(d, d, d, [&](int i, int kk) { return Lam[i * ld + kk]; }, [&](int kk, int j) { return Ps[kk * ld + j]; },
+                 [&](int i, int j, R v) { G2[i * ld + j] = R(2) * v; });
+            __syncthreads();
+            const int Z = d + (int)ntheta;
+            int NG = NT / Z;
+            if (NG > SL / Z) NG = SL / Z;
+            if (tid < NG * Z) {
+              const int grp = tid / Z, z = tid - grp * Z;
+              R s2 = R(0);
+              for (int j = grp; j < d; j += NG) s2 += awg_custom_contract<R>(th, xs, G2, ld, j, z, (j == 0 && z >= d) ? lamv : (const R*)nullptr);
+              part[grp * Z + z] = s2;
+            }
+#endif
           } else if (tid < d) {  // Lorenz-96: the three entries of row i of G the state derivative of F touches
             const int i = tid;
             const int ip1 = (i + 1 >= d) ? 0 : i + 1, im1 = (i == 0) ? d - 1 : i - 1, im2 = (im1 == 0) ? d - 1 : im1 - 1;
@@ -701,6 +749,13 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
             R s2 = dot(d, [&](int r) { return F[r * ld + c]; }, [&](int r) { return lamv[r]; });
             if (lin) {
               g[d * d + c] += lamv[c];
+#ifdef CDKF_AWG_CUSTOM
+            } else if (custom) {
+              const int Z = d + (int)ntheta;
+              int NG = NT / Z;
+              if (NG > SL / Z) NG = SL / Z;
+              for (int grp = 0; grp < NG; ++grp) s2 += slot(8)[grp * Z + c];
+#endif
             } else {
               // xbar[i-1] += G[i][i+1] - G[i][i-2];  xbar[i+1] += G[i][i-1];  xbar[i-2] -= G[i][i-1]
               const int cp1 = (c + 1 >= d) ? 0 : c + 1, cm1 = (c == 0) ? d - 1 : c - 1, cp2 = (cp1 + 1 >= d) ? 0 : cp1 + 1;
@@ -710,6 +765,16 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
             }
             ym[64 * si + c] = s2;
           }
+#ifdef CDKF_AWG_CUSTOM
+          if (custom) {
+            const int Z = d + (int)ntheta;
+            if (tid >= d && tid < Z) {
+              int NG = NT / Z;
+              if (NG > SL / Z) NG = SL / Z;
+              for (int grp = 0; grp < NG; ++grp) gForcing += slot(8)[grp * Z + tid];
+            }
+          } else
+#endif
           if (!lin && tid == 64) gForcing += dot(d, [&](int r) { return lamv[r]; }, [&](int) { return R(1); });  // (a thread of another wavefront)
           AWG_TICK(10)  // right-hand-side adjoint products
         }
@@ -745,6 +810,11 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
     if (tid < d) gm[tid] = mb[tid];
     rows2d(d, d, [&](int i, int j) { return R(0.5) * (Pb[i * ld + j] + Pb[j * ld + i]); }, [&](int i, int j, R v) { gP0[i * d + j] = v; });
   }
+#ifdef CDKF_AWG_CUSTOM
+  if (custom) {
+    if (tid >= d && tid < d + (int)ntheta) g[tid - d] = gForcing;
+  } else
+#endif
   if (!lin && tid == 64) g[0] = gForcing;
   if (st && tid == 0 && a.status) atomicOr(&a.status[n], st);
 #ifdef CDKF_AWG_PROFILE

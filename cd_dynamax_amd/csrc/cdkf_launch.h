@@ -116,6 +116,11 @@ template <typename R>
 struct WgArgs;
 template <typename R>
 int launch_custom_wg(const WgArgs<R>& a, int ept, bool filter, bool smoother, int threads, size_t lds_f, size_t lds_s, hipStream_t stream);
+// ... and the reverse sweep (launch_adjwg.hip)
+bool custom_adjoint_available(const cdkf_model* mdl, const cdkf_opts* o);
+int custom_awg_geometry(int d, int m, int bytes_per_real, int* ne, size_t* lds);  // launch_adjwg.hip; nonzero: does not fit
+template <typename R>
+int launch_custom_awg(const WgArgs<R>& a, R* grad, R* grad_model, R* scratch, long scratch_stride, int cap, int ne, size_t lds, hipStream_t stream);
 
 bool kernel_available(const cdkf_model* mdl, const cdkf_opts* o, int algo, int bytes_per_real);
 

@@ -8,6 +8,12 @@ bool adjoint_wg_fits(int d, int m, int bytes_per_real) {
   return d >= 1 && m >= 1 && d <= 64 && m <= 64 && (size_t)awg_lds_reals(d, m) * bytes_per_real + 64 <= kLdsLimit - 256;
 }
 long adjoint_wg_scratch_reals(int d, int cap) { return awg_scratch_reals(d, cap); }
+int custom_awg_geometry(int d, int m, int bytes_per_real, int* ne, size_t* lds) {
+  if (!adjoint_wg_fits(d, m, bytes_per_real)) return 1;
+  *ne = awg_entries_per_thread(d) <= 8 ? 8 : 16;
+  *lds = (size_t)awg_lds_reals(d, m) * bytes_per_real + 64;
+  return 0;
+}
 
 template <typename R>
 int launch_adjoint_wg_kernel(const WgArgs<R>& a, R* grad, R* grad_model, R* scratch, int cap, hipStream_t stream) {
@@ -19,6 +25,8 @@ int launch_adjoint_wg_kernel(const WgArgs<R>& a, R* grad, R* grad_model, R* scra
   const size_t lds = (size_t)awg_lds_reals(a.d, a.m) * sizeof(R) + 64;
   const long scratch_stride = awg_scratch_reals(a.d, cap);
   // the slopes and stage cotangents of a thread's covariance entries stay in registers: 8 entries per thread up to d = 42, else 16
+  if (a.kind >= CDKF_DRIFT_CUSTOM_BASE)  // a drift given as source: the kernel is compiled with it at run time (launch_custom.hip)
+    return launch_custom_awg<R>(a, grad, grad_model, scratch, scratch_stride, cap, awg_entries_per_thread(a.d) <= 8 ? 8 : 16, lds, stream);
   if (awg_entries_per_thread(a.d) <= 8) {
     if (once_per_device([] { return wg_raise_lds_cap(&ekf_adjoint_wg_kernel<R, 8>); })) return CDKF_EHIP;
     note_kernel("ekf_adjoint_wg_kernel<%s, 8>", real_name<R>());

@@ -402,15 +402,69 @@ __device__ void wg_custom_sigma(const WgArgs<R>& a, const WgLds<R>& L, const R* 
   return s;
 }
 
+// the shape-generic reverse sweep (cdkf_adjoint_wg_kernels.h) with the drift compiled in: d ll / d theta and every other leaf
+std::string generate_awg_source(const CustomDrift& c, size_t lds) {
+  std::string s;
+  const std::string D_ = std::to_string(c.d), NT_ = std::to_string(c.n_theta > 0 ? c.n_theta : 1), NTH_ = std::to_string(c.n_theta);
+  s += "#define CDKF_AWG_CUSTOM " + NTH_ + "\n#define CDKF_WG_STATIC_LDS " + std::to_string(lds) + "\n";
+  s += "#include \"cdkf_reg_kernels.h\"\n#include \"cdkf_adjoint_wg_kernels.h\"\n#include \"cdkf_dual.h\"\nnamespace cdkf {\n";
+  s += "constexpr int CD = " + D_ + ", CNT = " + NT_ + ", CNTH = " + NTH_ + ";\n";
+  s += "template <typename T> __device__ __forceinline__ void custom_f(const T* x, const T* theta, T (&fx)[CD]) {\n  (void)theta;\n";
+  s += "#line 1 \"drift_f\"\n" + c.f_src + "\n}\n";
+  s += R"(
+template <typename R>
+__device__ void awg_custom_column(const R* th, const R* x, int j, R* F, int ld, R* fv) {
+  typedef Dual<R, 1> T;
+  T xt[CD], tht[CNT], ft[CD];
+  for (int i = 0; i < CD; ++i) {
+    xt[i] = T(x[i]);
+    xt[i].g[0] = (i == j) ? R(1) : R(0);
+  }
+  for (int k = 0; k < CNTH; ++k) tht[k] = T(th[k]);
+  custom_f<T>(xt, tht, ft);
+  for (int i = 0; i < CD; ++i) F[i * ld + j] = ft[i].g[0];
+  if (fv)
+    for (int i = 0; i < CD; ++i) fv[i] = ft[i].v;
+}
+
+// inner dual: the direction e_j of the Jacobian's column; outer dual: the state component or parameter z
+template <typename R>
+__device__ R awg_custom_contract(const R* th, const R* x, const R* G, int ld, int j, int z, const R* lam) {
+  typedef Dual<R, 1> S1;
+  typedef Dual<S1, 1> T;
+  T xt[CD], tht[CNT], ft[CD];
+  for (int l = 0; l < CD; ++l) {
+    S1 b(x[l]);
+    b.g[0] = (l == j) ? R(1) : R(0);
+    xt[l].v = b;
+    xt[l].g[0] = S1(l == z ? R(1) : R(0));
+  }
+  for (int k = 0; k < CNTH; ++k) {
+    tht[k].v = S1(th[k]);
+    tht[k].g[0] = S1(k + CD == z ? R(1) : R(0));
+  }
+  custom_f<T>(xt, tht, ft);
+  R s = R(0);
+  for (int i = 0; i < CD; ++i) s += G[i * ld + j] * ft[i].g[0].g[0];
+  if (lam)
+    for (int i = 0; i < CD; ++i) s += lam[i] * ft[i].g[0].v;
+  return s;
+}
+}  // namespace cdkf
+)";
+  return s;
+}
+
 std::string wg_kernel_expr(int bytes, int ept, int ukf, int smoother) {
   const std::string R_ = bytes == 8 ? "double" : "float";
+  if (smoother == 2) return "cdkf::ekf_adjoint_wg_kernel<" + R_ + ", " + std::to_string(ept) + ">";
   if (smoother) return "cdkf::ekf_smoother_wg_kernel<" + R_ + ", " + std::to_string(ept) + ">";
   return "cdkf::ekf_filter_wg_kernel<" + R_ + ", " + std::to_string(ept) + ", " + (ukf ? "true" : "false") + ", cdkf::kDriftAny>";
 }
 
 int compile_wg_variant(const CustomDrift& c, const WgKey& key, const std::string& arch, std::vector<char>& code, std::string& lowered) {
   const int bytes = std::get<1>(key), ept = std::get<2>(key), ukf = std::get<3>(key), smoother = std::get<4>(key);
-  const std::string src = generate_wg_source(c, (size_t)std::get<5>(key));
+  const std::string src = smoother == 2 ? generate_awg_source(c, (size_t)std::get<5>(key)) : generate_wg_source(c, (size_t)std::get<5>(key));
   const std::string expr = wg_kernel_expr(bytes, ept, ukf, smoother);
   hiprtcProgram prog = nullptr;
   if (hiprtcCreateProgram(&prog, src.c_str(), "cdkf_custom_drift_wg.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
@@ -424,7 +478,7 @@ int compile_wg_variant(const CustomDrift& c, const WgKey& key, const std::string
   }
   // (the instantiations with eight or more entries per thread are built at -O1 in the library too: launch_wg8.hip, Makefile)
   const std::string inc = "-I" + source_dir(), off = "--offload-arch=" + arch;
-  const char* opts[] = {off.c_str(), ept >= 8 ? "-O1" : "-O3", "-std=c++17", inc.c_str(), "-Wno-pass-failed"};
+  const char* opts[] = {off.c_str(), (ept >= 8 && smoother != 2) ? "-O1" : "-O3", "-std=c++17", inc.c_str(), "-Wno-pass-failed"};
   const hiprtcResult res = hiprtcCompileProgram(prog, 5, opts);
   if (res != HIPRTC_SUCCESS) {
     size_t n = 0;
@@ -523,6 +577,36 @@ int launch_custom_wg(const WgArgs<R>& a, int ept, bool filter, bool smoother, in
   if (!rc && smoother) rc = run(1, lds_s);
   return rc;
 }
+// ... and of the reverse sweep (launch_adjwg.hip)
+template <typename R>
+int launch_custom_awg(const WgArgs<R>& a, R* grad, R* grad_model, R* scratch, long scratch_stride, int cap, int ne, size_t lds, hipStream_t stream) {
+  hipFunction_t fn = nullptr;
+  const size_t bytes = (lds + 15) & ~size_t(15);
+  int r = get_wg_function(a.kind, WgKey(a.kind, (int)sizeof(R), ne, 0, 2, (long)bytes), &fn);
+  if (r) return r;
+  WgArgs<R> arg = a;
+  void* args[] = {(void*)&arg, (void*)&grad, (void*)&grad_model, (void*)&scratch, (void*)&scratch_stride, (void*)&cap};
+  note_kernel("ekf_adjoint_wg_kernel<%s, %d> (custom drift)", real_name<R>(), ne);
+  CDKF_HIP_CHECK(hipModuleLaunchKernel(fn, (unsigned)a.N, 1, 1, 256, 1, 1, 0, stream, args, nullptr));
+  return CDKF_OK;
+}
+template int launch_custom_awg<float>(const WgArgs<float>&, float*, float*, float*, long, int, int, size_t, hipStream_t);
+template int launch_custom_awg<double>(const WgArgs<double>&, double*, double*, double*, long, int, int, size_t, hipStream_t);
+
+// the reverse sweep takes a drift given as source if: linear emission, state_order 'first' (or 'second' with grad(div f) registered as
+// identically zero), and the (column, direction) tasks of its second-derivative contraction fit the workgroup: state_dim + n_theta <= 256
+// and <= one LDS slot (q x ld reals, q = max(state_dim, emission_dim))
+bool custom_adjoint_available(const cdkf_model* mdl, const cdkf_opts* o) {
+  if (!custom_kind(mdl->drift_kind) || mdl->emission_kind != 0) return false;
+  if (o->num_iter != 1 || o->forecast || o->state_order == CDKF_ORDER_ZEROTH) return false;
+  std::lock_guard<std::mutex> lock(g_mutex);
+  const CustomDrift& c = g_drifts[mdl->drift_kind - CDKF_DRIFT_CUSTOM_BASE];
+  if (c.d != mdl->state_dim || c.n_theta != mdl->n_theta) return false;
+  if (o->state_order == CDKF_ORDER_SECOND && !(c.has_g && !c.auto_g && blank(c.g_src))) return false;
+  const int q = c.d > mdl->emission_dim ? c.d : mdl->emission_dim, Z = c.d + c.n_theta;
+  return Z <= 256 && Z <= q * (q | 1);
+}
+
 template int launch_custom_wg<float>(const WgArgs<float>&, int, bool, bool, int, size_t, size_t, hipStream_t);
 template int launch_custom_wg<double>(const WgArgs<double>&, int, bool, bool, int, size_t, size_t, hipStream_t);
 
@@ -610,8 +694,8 @@ int launch_custom(int algo, const cdkf_model* mdl, const cdkf_opts* o, int64_t N
       set_error("custom emissions run on the register-resident kernels: state_dim, emission_dim <= 6 (got %d, %d)", d, m);
       return CDKF_EUNSUPPORTED;
     }
-    if (algo == 3) {
-      set_error("custom drift: the gradient sweep is a register-resident kernel, state_dim, emission_dim <= 6 (got %d, %d)", d, m);
+    if (algo == 3) {  // (launch_ekf_grad sends these shapes to the reverse sweep, not here)
+      set_error("custom drift: the forward-sensitivity sweep is a register-resident kernel, state_dim, emission_dim <= 6 (got %d, %d)", d, m);
       return CDKF_EUNSUPPORTED;
     }
     if (algo != 1 && o->state_order == CDKF_ORDER_SECOND && !c.has_g) {
@@ -781,9 +865,19 @@ int custom_compile_check(int kind, int bytes_per_real, int emission_dim, int alg
   }
   std::vector<char> code;
   if (c.d > 6 || emission_dim > 6) {  // the workgroup kernels (dense emission matrix assumed: the larger LDS plan)
-    if (algo == 3 || emission_kind) {
-      set_error("custom drift compile check: gradients and custom emissions need state_dim, emission_dim <= 6");
+    if (emission_kind) {
+      set_error("custom drift compile check: custom emissions need state_dim, emission_dim <= 6");
       return CDKF_EUNSUPPORTED;
+    }
+    if (algo == 3) {  // the reverse sweep (the forward sweep is algo 0's kernel)
+      int ne = 0;
+      size_t lds = 0;
+      if (custom_awg_geometry(c.d, emission_dim, bytes_per_real, &ne, &lds)) {
+        set_error("custom drift compile check: state_dim %d, emission_dim %d do not fit the reverse sweep's LDS plan", c.d, emission_dim);
+        return CDKF_EUNSUPPORTED;
+      }
+      std::string lowered;
+      return compile_wg_variant(c, WgKey(kind, bytes_per_real, ne, 0, 2, (long)((lds + 15) & ~size_t(15))), "gfx950", code, lowered);
     }
     int ept = 0, threads = 0;
     size_t lds_f = 0, lds_s = 0;

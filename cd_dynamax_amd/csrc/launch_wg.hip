@@ -372,7 +372,11 @@ int release_grad_workspace() {
 // beyond the wavefront kernel's shapes: the workgroup-per-trajectory reverse sweep -- Lorenz-96 and linear drifts (for both the mean's
 // second-order term vanishes), fixed or adaptive steps, as far as its LDS plan goes in fp64 (launch_adjwg.hip)
 static bool adjoint_wg_shape(const cdkf_model* mdl, const cdkf_opts* o) {
-  if (mdl->drift_kind != CDKF_DRIFT_LORENZ96 && mdl->drift_kind != CDKF_DRIFT_LINEAR) return false;
+  if (mdl->drift_kind >= CDKF_DRIFT_CUSTOM_BASE) {  // a drift given as source: its derivatives by dual numbers inside the sweep
+    if (!custom_adjoint_available(mdl, o)) return false;
+  } else if (mdl->drift_kind != CDKF_DRIFT_LORENZ96 && mdl->drift_kind != CDKF_DRIFT_LINEAR) {
+    return false;
+  }
   if (mdl->emission_kind != 0) return false;
   // (the gate is precision-agnostic: what the float32 kernels take; the launch refuses -- CDKF_EUNSUPPORTED, with the numbers -- a
   //  float64 call whose nine matrices do not fit)

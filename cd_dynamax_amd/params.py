@@ -120,7 +120,8 @@ class LearnableCustomDrift(NamedTuple):
     ``R`` is the compute type (float or double).  state_dim, emission_dim <= 6: the register-resident kernels.  Beyond that
     (state_dim <= 64, as far as the workgroup kernels' LDS holds the shape: d = m = 40 in float64, 60 in float32) the same ``f_src`` is
     compiled into the workgroup-per-trajectory kernels -- ``jac_src`` must then be None and ``divgrad_src`` None, "" or "auto" (a thread
-    per direction of the Jacobian, all by dual numbers), the emission linear; filters, smoother and forecast, no gradient; 10 - 20 s of
+    per direction of the Jacobian, all by dual numbers), the emission linear; filters, smoother, forecast and -- on the shape-generic
+    reverse sweep, up to 43 dimensions in float64 -- the gradients (``cdnlgssm_loglik_and_grad_all`` at any state_dim); 10 - 20 s of
     compilation per variant on first use.  ``py_f`` (optional) is the same function as a Python
     callable ``f(x, u, t)`` for host-side use; it is never called by the filter."""
     theta: Any

@@ -277,10 +277,12 @@ int cdkf_emission_moments_f32_dev(const cdkf_model* mdl, int64_t rows, const flo
  *      LDS plan holds the shape: e.g. d = m = 40 in fp64, 60 in fp32) the same f_src is compiled into the workgroup-per-trajectory
  *      sweeps (round 3): jac_src must then be NULL and divgrad_src NULL, "" or "auto" -- a thread of the workgroup evaluates ONE
  *      direction of the Jacobian / one (i, k) pair of the second derivatives / one pair of sigma points, all by dual numbers; linear
- *      emission only, no gradient entry point; 10 - 20 s of compilation per variant on first use.
+ *      emission only; 10 - 20 s of compilation per variant on first use.  cdkf_ekf_loglik_grad[_all]_* take these drifts on the
+ *      shape-generic reverse sweep compiled with the source (state_order 'first', or 'second' with an empty divgrad_src;
+ *      state_dim + n_theta <= 256; max(state_dim, emission_dim) <= 43 in fp64, 62 in fp32) -- the _all variant at any state_dim.
  *      Returns the drift_kind to put in cdkf_model (>= CDKF_DRIFT_CUSTOM_BASE; the
  *      same sources give the same kind) or a negative CDKF_E* code.  Filters (EKF all orders, UKF), EKF smoother,
- *      forecast mode and (state_dim, emission_dim <= 6) the drift-parameter gradient are available for custom kinds; kernels compile
+ *      forecast mode and the gradients are available for custom kinds; kernels compile
  *      on first use (seconds) and are cached.  Compile errors in the snippets surface through cdkf_last_error(). */
 int cdkf_custom_drift_register(int state_dim, int n_theta, const char* f_src, const char* jac_src,
                                const char* divgrad_src);

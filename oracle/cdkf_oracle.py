@@ -298,13 +298,16 @@ class CallableDrift:
 
     kind = "custom"
 
-    def __init__(self, theta, f, jac, divgrad=None, dtype=np.float64):
+    def __init__(self, theta, f, jac, divgrad=None, dtype=np.float64, vjp=None):
         self.dtype = np.dtype(dtype)
         self.th = np.asarray(theta, dtype=self.dtype)
         self._f, self._jac, self._g = f, jac, divgrad
+        # vjp(x [d], lam [d], G [d,d], theta) -> (xbar [d], thetabar): the gradient of lam . f + <G, F> (drift_vjp) written out by hand --
+        # what ekf_loglik_grad_adjoint needs of a drift it has no formulas for
+        self._vjp = vjp
 
     def cast(self, dtype):
-        return CallableDrift(self.th, self._f, self._jac, self._g, dtype=dtype)
+        return CallableDrift(self.th, self._f, self._jac, self._g, dtype=dtype, vjp=self._vjp)
 
     def f(self, x):
         return np.asarray(self._f(x, self.th), dtype=x.dtype)
@@ -1160,6 +1163,11 @@ def drift_vjp(drift, x, lam, G):
         gb1 = z1b
         xb = W1.T @ z1b
         return xb, np.concatenate([g.ravel() for g in (gW1, gb1, gW2, gb2, gW3, gb3)])
+    if drift.kind == "custom":
+        if drift._vjp is None:
+            raise NotImplementedError("CallableDrift without vjp")
+        xb, tb = drift._vjp(x, lam, G, drift.th)
+        return np.asarray(xb, np.float64), np.asarray(tb, np.float64)
     F = drift.jac(x[None])[0]
     xb = F.T @ lam
     if drift.kind == "lorenz63":

@@ -414,7 +414,17 @@ def cubic_l96_oracle(theta, d):
             F[..., i, i] += -1 - 3 * th[1] * x[..., i] ** 2
         return F
     g = lambda x, th: -6 * th[1] * x
-    return o.CallableDrift(theta, f, jac, g)
+
+    def vjp(x, lam, G, th):   # gradient of lam . f + <G, F> w.r.t. (x, theta), by hand
+        xb = jac(x[None], th)[0].T @ lam
+        for i in range(d):
+            ip1, im1, im2 = (i + 1) % d, (i - 1) % d, (i - 2) % d
+            xb[im1] += G[i, ip1] - G[i, im2]
+            xb[ip1] += G[i, im1]
+            xb[im2] -= G[i, im1]
+        xb = xb - 6 * th[1] * np.diag(G) * x
+        return xb, np.array([lam.sum(), -(lam * x ** 3).sum() - 3 * (np.diag(G) * x ** 2).sum()])
+    return o.CallableDrift(theta, f, jac, g, vjp=vjp)
 
 
 def wide_model(rng, d, m, theta, selection=False):
@@ -427,12 +437,13 @@ def wide_model(rng, d, m, theta, selection=False):
 
 def test_wide_custom_drift_compiles_without_a_gpu():
     """state_dim 12: the workgroup kernels go through hipRTC with the drift's source for gfx950 on the CPU box (filter with grad(div f)
-    by nested dual numbers, smoother); a hand-written Jacobian is refused at registration."""
+    by nested dual numbers, smoother, reverse sweep); a hand-written Jacobian is refused at registration."""
     L = _ffi.lib()
     k = _ffi.register_custom_drift(12, 2, cubic_l96_src(12), None, "auto")
     assert L.cdkf_custom_drift_compile(k, 8, 5, 2, 2, 0) == 0, L.cdkf_last_error().decode()       # filter + smoother, fp64
     assert L.cdkf_custom_drift_compile(k, 4, 12, 1, 1, 0) == 0, L.cdkf_last_error().decode()      # unscented filter, fp32
-    assert L.cdkf_custom_drift_compile(k, 8, 5, 3, 1, 0) != 0                                     # no gradient sweep up there
+    assert L.cdkf_custom_drift_compile(k, 8, 5, 3, 1, 0) == 0, L.cdkf_last_error().decode()       # the reverse sweep with the drift compiled in
+    assert L.cdkf_custom_drift_compile(k, 8, 50, 3, 1, 0) != 0                                    # ... has an LDS plan of its own (q <= 43 in fp64)
     bad = _ffi.register_custom_drift(12, 1, "for (int i = 0; i < 12; ++i) fx[i] = -theta[0] * sine(x[i]);", None, None)
     assert L.cdkf_custom_drift_compile(bad, 8, 5, 0, 1, 0) != 0 and "drift_f:1" in L.cdkf_last_error().decode()
 
@@ -487,8 +498,68 @@ def test_wide_custom_drift_filters_and_smoother(hip_lib, d, m, selection):
         ref = o.ekf_filter(mdl, t, y, state_order="second", dt0=0.02)
     post = cd.cdnlgssm_filter(P, y, t[..., None], hyp)
     assert relerr(post.filtered_covariances, ref["filtered_covariances"]) < 1e-9
-    with pytest.raises(NotImplementedError, match="no gradient kernel"):
-        cd.cdnlgssm_loglik_and_grad(P, y, t[..., None], cd.EKFHyperParams(state_order="first"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,m,selection", [(12, 5, False), (9, 9, True), (7, 10, False), (2, 1, False)])
+def test_wide_custom_drift_loglik_gradient(hip_lib, d, m, selection):
+    """d ll / d theta and every other leaf for a drift given as source, on the shape-generic reverse sweep compiled with it at run time:
+    what the reverse of F(m, theta) Ps + (F Ps)^T needs -- second derivatives of f contracted with G = 2 Lam Ps -- comes from nested dual
+    numbers, one evaluation per (Jacobian column, state component or parameter).  Against the oracle's reverse sweep with the drift's
+    vector-Jacobian products written out by hand, and against central differences of the HIP log-likelihood."""
+    rng = np.random.default_rng(900 + 10 * d + m)
+    theta = np.array([4.0, 0.05])
+    if d < 4:   # (the cubic Lorenz-96 needs four components: a damped oscillator with the same two parameters' roles)
+        src = "fx[0] = x[1] + theta[0]; fx[1] = -x[0] - theta[1] * x[1] * x[1] * x[1];"
+        f = lambda x, th: np.stack([x[..., 1] + th[0], -x[..., 0] - th[1] * x[..., 1] ** 3], -1)
+
+        def jac(x, th):
+            F = np.zeros(x.shape + (2,), x.dtype)
+            F[..., 0, 1] = 1
+            F[..., 1, 0] = -1
+            F[..., 1, 1] = -3 * th[1] * x[..., 1] ** 2
+            return F
+
+        def vjp(x, lam, G, th):
+            xb = jac(x[None], th)[0].T @ lam
+            xb[1] += -6 * th[1] * x[1] * G[1, 1]
+            return xb, np.array([lam[0], -lam[1] * x[1] ** 3 - 3 * G[1, 1] * x[1] ** 2])
+        drift = o.CallableDrift(theta, f, jac, None, vjp=vjp)
+        mdl = wide_model(rng, 4, m, theta, selection)
+        mdl = o.Model(drift, np.eye(2), mdl.Qc[:2, :2], mdl.H[:, :2], mdl.bias, mdl.R, np.array([0.5, -0.2]), 0.3 * np.eye(2))
+    else:
+        src = cubic_l96_src(d)
+        mdl = wide_model(rng, d, m, theta, selection)
+    N, T = 4, 9
+    t = o.irregular_times(rng, N, T, 0.04)
+    y = o.simulate(mdl, t, rng)
+    P = params_for(mdl, cd.LearnableCustomDrift(theta, src, None, None))
+    hyp = cd.EKFHyperParams(state_order="first")
+    ll_ref, g_ref, full = o.ekf_loglik_grad_adjoint(mdl, t, y, full=True, state_order="first")
+    ll, grads = cd.cdnlgssm_loglik_and_grad_all(P, y, t[..., None], hyp)
+    assert "ekf_adjoint_wg_kernel" in _ffi.lib().cdkf_last_kernel().decode() and "custom drift" in _ffi.lib().cdkf_last_kernel().decode()
+    np.testing.assert_allclose(ll, ll_ref, rtol=1e-10)
+    scale = np.abs(g_ref).max()
+    assert np.abs(np.asarray(grads.dynamics.drift.theta) - g_ref).max() < 1e-8 * scale
+    for got, want in ((grads.initial.mean.params, full["m0"]), (grads.initial.cov.params, full["P0"]),
+                      (grads.dynamics.diffusion_coefficient.params, full["L"]), (grads.dynamics.diffusion_cov.params, full["Qc"]),
+                      (grads.emissions.emission_function.weights, full["H"]), (grads.emissions.emission_function.bias, full["bias"]),
+                      (grads.emissions.emission_cov.params, full["R"])):
+        assert np.abs(np.asarray(got) - want).max() < 1e-8 * max(scale, np.abs(want).max())
+    if d > 6 or m > 6:   # the drift block alone takes the same sweep up there (below: the forward-sensitivity kernel)
+        ll2, g2 = cd.cdnlgssm_loglik_and_grad(P, y, t[..., None], hyp)
+        assert np.abs(np.asarray(g2.theta) - g_ref).max() < 1e-8 * scale
+    for p in range(2):   # central differences of the HIP log-likelihood itself
+        h = 1e-5 * max(1.0, abs(theta[p]))
+        lls = []
+        for sgn in (1, -1):
+            th = theta.copy()
+            th[p] += sgn * h
+            lls.append(cd.cdnlgssm_filter(params_for(mdl, cd.LearnableCustomDrift(th, src, None, None)), y, t[..., None], hyp).marginal_loglik)
+        fd = (lls[0] - lls[1]) / (2 * h)
+        assert np.abs(np.asarray(grads.dynamics.drift.theta)[:, p] - fd).max() < 2e-5 * max(1.0, np.abs(fd).max())
+    with pytest.raises(NotImplementedError):   # a non-zero grad(div f): the mean's second-order term is not reversed for custom drifts
+        cd.cdnlgssm_loglik_and_grad_all(params_for(mdl, cd.LearnableCustomDrift(theta, src, None, "auto")), y, t[..., None])
 
 
 @pytest.mark.gpu
