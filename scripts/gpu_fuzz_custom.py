@@ -1,0 +1,127 @@
+"""Fuzz of the drifts given as source (dev aid, not part of the suite): random sparse quadratic drifts
+f = c - x + theta_0 B x + theta_1 Q(x), Q_i = sum a_i,jk x_j x_k, generated as C statements of random shape (loops, temporaries, pow, products),
+any state / emission dimension the kernels take -- register-resident kernels up to six, workgroup kernels beyond -- against the oracle
+running the same drift from its coefficient arrays: EKF orders, UKF, smoother, forecast, every gradient:
+python3 scripts/gpu_fuzz_custom.py [seed] [cases]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
+import numpy as np
+import cdkf_oracle as o
+import cd_dynamax_amd as cd
+from cd_dynamax_amd import _ffi
+from helpers import FILTER_KEYS, relerr
+
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+cases = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+rng = np.random.default_rng(seed)
+worst = {}
+
+
+def note(name, e, tol, tag):
+    worst[name] = max(worst.get(name, 0.0), float(e))
+    if not (e < tol):
+        print("MISMATCH", name, tag, e, _ffi.lib().cdkf_last_kernel().decode()[:60], flush=True)
+
+
+def spd(n, s):
+    A = rng.standard_normal((n, n))
+    return A @ A.T / n * s + 0.3 * np.eye(n)
+
+
+def random_drift(d):
+    """coefficients + the C statements + the oracle's callables"""
+    B = np.where(rng.random((d, d)) < min(1.0, 3.0 / d), rng.standard_normal((d, d)), 0.0) * 0.5
+    terms = []   # (i, j, k, a): a x_j x_k in f_i
+    for i in range(d):
+        for _ in range(int(rng.integers(0, 3))):
+            terms.append((i, int(rng.integers(d)), int(rng.integers(d)), 0.3 * rng.standard_normal()))
+    c = 0.3 * rng.standard_normal(d)
+    A3 = np.zeros((d, d, d))
+    for i, j, k, a in terms:
+        A3[i, j, k] += a
+    lines = []
+    style = rng.integers(3)
+    for i in range(d):
+        lin = " + ".join(f"R({float(B[i, j])!r}) * x[{j}]" for j in range(d) if B[i, j] != 0) or "R(0)"
+        qs = []
+        for ii, j, k, a in terms:
+            if ii != i:
+                continue
+            if j == k and style == 1:
+                qs.append(f"R({float(a)!r}) * pow(x[{j}], 2)")
+            else:
+                qs.append(f"R({float(a)!r}) * x[{j}] * x[{k}]")
+        quad = " + ".join(qs) or "R(0)"
+        if style == 2:
+            lines.append(f"{{ auto l_ = {lin}; auto q_ = {quad}; fx[{i}] = R({float(c[i])!r}) - x[{i}] + theta[0] * l_ + theta[1] * q_; }}")
+        else:
+            lines.append(f"fx[{i}] = R({float(c[i])!r}) - x[{i}] + theta[0] * ({lin}) + theta[1] * ({quad});")
+    src = "\n".join(lines)
+    S3 = A3 + A3.transpose(0, 2, 1)            # d Q_i / d x_j = S3[i, j, :] . x
+
+    def f(x, th):
+        return c - x + th[0] * x @ B.T + th[1] * np.einsum("ijk,...j,...k->...i", A3, x, x)
+
+    def jac(x, th):
+        return -np.eye(d) + th[0] * B + th[1] * np.einsum("ijk,...k->...ij", S3, x)
+
+    def g(x, th):                              # d/dx_k sum_i dF_ii: th1 sum_i S3[i, i, k]
+        return np.broadcast_to(th[1] * np.einsum("iik->k", S3), x.shape).copy()
+
+    def vjp(x, lam, G, th):
+        F = jac(x[None], th)[0]
+        xb = F.T @ lam + th[1] * np.einsum("ij,ijk->k", G, S3)
+        Q = np.einsum("ijk,j,k->i", A3, x, x)
+        JQ = np.einsum("ijk,k->ij", S3, x)
+        return xb, np.array([lam @ (B @ x) + (G * B).sum(), lam @ Q + (G * JQ).sum()])
+    return src, lambda th: o.CallableDrift(th, f, jac, g, vjp=vjp)
+
+
+for case in range(cases):
+    big = rng.random() < 0.7
+    d = int(rng.integers(7, 25)) if big else int(rng.integers(1, 7))
+    m = int(rng.integers(1, (min(d + 4, 24) if big else 7)))
+    if not big and rng.random() < 0.3:
+        m = int(rng.integers(7, 12))          # small state, wide emission: the workgroup kernels too
+    src, make = random_drift(d)
+    theta = np.array([0.5 + 0.5 * rng.random(), 0.2 * rng.standard_normal()])
+    if rng.random() < 0.4 and m <= d:
+        H, bias = np.eye(d)[rng.permutation(d)[:m]], np.zeros(m)
+    else:
+        H, bias = rng.standard_normal((m, d)) / np.sqrt(d), 0.1 * rng.standard_normal(m)
+    mdl = o.Model(make(theta), np.eye(d) + 0.1 * rng.standard_normal((d, d)), spd(d, 0.3), H, bias, spd(m, 0.5), 0.5 * rng.standard_normal(d), spd(d, 0.3))
+    N, T = int(rng.integers(1, 5)), int(rng.integers(2, 9))
+    t = o.irregular_times(rng, N, T, 0.03 * T)
+    y = o.simulate(mdl, t, rng)
+    mk = lambda g_: cd.ParamsCDNLGSSM(
+        initial=cd.ParamsLGSSMInitial(cd.LearnableVector(mdl.m0), cd.LearnableMatrix(mdl.P0)),
+        dynamics=cd.ParamsCDNLGSSMDynamics(cd.LearnableCustomDrift(theta, src, None, g_), cd.LearnableMatrix(mdl.L), cd.LearnableMatrix(mdl.Qc), 2.0),
+        emissions=cd.ParamsCDNLGSSMEmissions(cd.LearnableLinear(mdl.H, mdl.bias), cd.LearnableMatrix(mdl.R)))
+    P = mk("auto")
+    tag = (case, d, m, N, T)
+    order = str(rng.choice(["second", "first", "zeroth"]))
+    ref = o.ekf_filter(mdl, t, y, state_order=order)
+    post = cd.cdnlgssm_filter(P, y, t[..., None], cd.EKFHyperParams(state_order=order))
+    note("ekf", max(max(relerr(getattr(post, k), ref[k]) for k in FILTER_KEYS), relerr(post.marginal_loglik, ref["marginal_loglik"])), 1e-9, tag + (order,))
+    if rng.random() < 0.5:
+        ref = o.ukf_filter(mdl, t, y)
+        post = cd.cdnlgssm_filter(P, y, t[..., None], cd.UKFHyperParams())
+        note("ukf", max(relerr(getattr(post, k), ref[k]) for k in FILTER_KEYS), 1e-8, tag)
+    if rng.random() < 0.5:
+        ref = o.ekf_smoother(mdl, t, y, state_order="second")
+        sm = cd.cdnlgssm_smoother(P, y, t[..., None])
+        note("eks", max(relerr(sm.smoothed_means, ref["smoothed_means"]), relerr(sm.smoothed_covariances, ref["smoothed_covariances"])), 1e-8, tag)
+    # gradients: state_order 'first', every leaf on the reverse sweep; the drift block alone (forward sensitivities up to six dimensions)
+    ll_ref, g_ref, ex = o.ekf_loglik_grad_adjoint(mdl, t, y, full=True, state_order="first")
+    hyp = cd.EKFHyperParams(state_order="first")
+    Pn = mk(None)
+    ll, g = cd.cdnlgssm_loglik_and_grad_all(Pn, y, t[..., None], hyp)
+    pairs = [(g.dynamics.drift.theta, g_ref), (g.initial.mean.params, ex["m0"]), (g.initial.cov.params, ex["P0"]),
+             (g.dynamics.diffusion_coefficient.params, ex["L"]), (g.dynamics.diffusion_cov.params, ex["Qc"]),
+             (g.emissions.emission_function.weights, ex["H"]), (g.emissions.emission_function.bias, ex["bias"]), (g.emissions.emission_cov.params, ex["R"])]
+    scale = max(np.abs(b_).max() for _, b_ in pairs)
+    note("grad_all", max(max(np.abs(np.asarray(a_) - b_).max() / scale for a_, b_ in pairs), relerr(ll, ll_ref)), 1e-7, tag)
+    ll, g1 = cd.cdnlgssm_loglik_and_grad(Pn, y, t[..., None], hyp)
+    note("grad_theta", np.abs(np.asarray(g1.theta) - g_ref).max() / (np.abs(g_ref).max() + 1e-300), 1e-7, tag)
+print("fuzz custom seed", seed, "cases", cases, "worst", {k: float("%.3g" % v) for k, v in worst.items()}, flush=True)
