@@ -306,7 +306,7 @@ std::string generate_wg_source(const CustomDrift& c, size_t lds) {
   s += "#define CDKF_WG_STATIC_LDS " + std::to_string(lds) + "\n";
   s += "#include \"cdkf_reg_kernels.h\"\n#include \"cdkf_wg2_kernels.h\"\n#include \"cdkf_dual.h\"\nnamespace cdkf {\n";
   s += "constexpr int CD = " + D_ + ", CNT = " + NT_ + ", CNTH = " + NTH_ + ";\n";
-  s += "template <typename T> __device__ __forceinline__ void custom_f(const T* x, const T* theta, T (&fx)[CD]) {\n  (void)theta;\n";
+  s += "// (R: the compute type, as in the register-resident kernels' DriftCustom<R, D> -- the snippet may write R(...) constants)\ntemplate <typename R, typename T> __device__ __forceinline__ void custom_f(const T* x, const T* theta, T (&fx)[CD]) {\n  (void)theta;\n";
   s += "#line 1 \"drift_f\"\n" + c.f_src + "\n}\n";
   s += R"(
 template <typename R>
@@ -318,7 +318,7 @@ __device__ void wg_custom_drift(const WgArgs<R>& a, const WgLds<R>& L, const R* 
       R xr[CD], thr[CNT], fr[CD];
       for (int i = 0; i < CD; ++i) xr[i] = x[i];
       for (int k = 0; k < CNTH; ++k) thr[k] = th[k];
-      custom_f<R>(xr, thr, fr);
+      custom_f<R, R>(xr, thr, fr);
       for (int i = 0; i < CD; ++i) fv[i] = fr[i];
     }
   } else {  // jacfwd(f) (inference_ekf.py:95): thread j carries the unit direction e_j -> column j of the Jacobian
@@ -330,7 +330,7 @@ __device__ void wg_custom_drift(const WgArgs<R>& a, const WgLds<R>& L, const R* 
         xt[i].g[0] = (i == j) ? R(1) : R(0);
       }
       for (int k = 0; k < CNTH; ++k) tht[k] = T(th[k]);
-      custom_f<T>(xt, tht, ft);
+      custom_f<R, T>(xt, tht, ft);
       for (int i = 0; i < CD; ++i) F[i * lq + j] = ft[i].g[0];
       if (j == 0)
         for (int i = 0; i < CD; ++i) fv[i] = ft[i].v;
@@ -355,7 +355,7 @@ __device__ void wg_custom_drift(const WgArgs<R>& a, const WgLds<R>& L, const R* 
         tht[kk].v = S1(th[kk]);
         tht[kk].g[0] = S1(R(0));
       }
-      custom_f<T>(xt, tht, ft);
+      custom_f<R, T>(xt, tht, ft);
       R v = R(0);
       for (int l = 0; l < CD; ++l)
         if (l == i) v = ft[l].g[0].g[0];
@@ -383,13 +383,13 @@ __device__ void wg_custom_sigma(const WgArgs<R>& a, const WgLds<R>& L, const R* 
     for (int k = 0; k < CNTH; ++k) thr[k] = th[k];
     if (i == CD) {
       for (int r = 0; r < CD; ++r) xr[r] = ms[r];
-      custom_f<R>(xr, thr, fp);
+      custom_f<R, R>(xr, thr, fp);
       for (int r = 0; r < CD; ++r) f0[r] = fp[r];
     } else {
       for (int r = 0; r < CD; ++r) xr[r] = ms[r] + O[r * lq + i];
-      custom_f<R>(xr, thr, fp);
+      custom_f<R, R>(xr, thr, fp);
       for (int r = 0; r < CD; ++r) xr[r] = ms[r] - O[r * lq + i];
-      custom_f<R>(xr, thr, fm);
+      custom_f<R, R>(xr, thr, fm);
       for (int r = 0; r < CD; ++r) {
         DF[r * lq + i] = fp[r] - fm[r];
         foo[r * lq + i] = fp[r] + fm[r];
@@ -409,7 +409,7 @@ std::string generate_awg_source(const CustomDrift& c, size_t lds) {
   s += "#define CDKF_AWG_CUSTOM " + NTH_ + "\n#define CDKF_WG_STATIC_LDS " + std::to_string(lds) + "\n";
   s += "#include \"cdkf_reg_kernels.h\"\n#include \"cdkf_adjoint_wg_kernels.h\"\n#include \"cdkf_dual.h\"\nnamespace cdkf {\n";
   s += "constexpr int CD = " + D_ + ", CNT = " + NT_ + ", CNTH = " + NTH_ + ";\n";
-  s += "template <typename T> __device__ __forceinline__ void custom_f(const T* x, const T* theta, T (&fx)[CD]) {\n  (void)theta;\n";
+  s += "// (R: the compute type, as in the register-resident kernels' DriftCustom<R, D> -- the snippet may write R(...) constants)\ntemplate <typename R, typename T> __device__ __forceinline__ void custom_f(const T* x, const T* theta, T (&fx)[CD]) {\n  (void)theta;\n";
   s += "#line 1 \"drift_f\"\n" + c.f_src + "\n}\n";
   s += R"(
 template <typename R>
@@ -421,7 +421,7 @@ __device__ void awg_custom_column(const R* th, const R* x, int j, R* F, int ld, 
     xt[i].g[0] = (i == j) ? R(1) : R(0);
   }
   for (int k = 0; k < CNTH; ++k) tht[k] = T(th[k]);
-  custom_f<T>(xt, tht, ft);
+  custom_f<R, T>(xt, tht, ft);
   for (int i = 0; i < CD; ++i) F[i * ld + j] = ft[i].g[0];
   if (fv)
     for (int i = 0; i < CD; ++i) fv[i] = ft[i].v;
@@ -443,7 +443,7 @@ __device__ R awg_custom_contract(const R* th, const R* x, const R* G, int ld, in
     tht[k].v = S1(th[k]);
     tht[k].g[0] = S1(k + CD == z ? R(1) : R(0));
   }
-  custom_f<T>(xt, tht, ft);
+  custom_f<R, T>(xt, tht, ft);
   R s = R(0);
   for (int i = 0; i < CD; ++i) s += G[i * ld + j] * ft[i].g[0].g[0];
   if (lam)

@@ -399,7 +399,7 @@ def test_fit_sgd_on_a_custom_drift(hip_lib):
 def cubic_l96_src(d):
     """Lorenz-96 with a cubic damping term: f_i = (x_{i+1} - x_{i-2}) x_{i-1} - x_i - theta_1 x_i^3 + theta_0; grad(div f)_k = -6 theta_1 x_k."""
     return (f"for (int i = 0; i < {d}; ++i) {{ const int ip1 = (i + 1) % {d}, im1 = (i + {d - 1}) % {d}, im2 = (i + {d - 2}) % {d}; "
-            f"fx[i] = (x[ip1] - x[im2]) * x[im1] - x[i] - theta[1] * x[i] * x[i] * x[i] + theta[0]; }}")
+            f"fx[i] = (x[ip1] - x[im2]) * x[im1] - R(1) * x[i] - theta[1] * x[i] * x[i] * x[i] + theta[0]; }}")
 
 
 def cubic_l96_oracle(theta, d):
