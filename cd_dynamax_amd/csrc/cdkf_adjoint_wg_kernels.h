@@ -153,6 +153,36 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
   // Dense product in 2 x 4 register tiles, one tile per thread: out(i, j, sum_k A(i, k) B(k, j)) for i < rows, j < cols.  Twelve LDS
   // reads per sixteen multiply-adds (a dot product per entry takes two per multiply-add and waits for each).
   auto gemm = [&](int rows, int cols, int K, auto&& Aat, auto&& Bat, auto&& out) {
+#ifndef CDKF_AWG_VECTOR_GEMM
+    // ... on the matrix cores: 16 x 16 output tiles dealt to the four wavefronts, v_mfma_{f64,f32}_16x16x4 (exact arithmetic of the
+    // type; lane l feeds A[l & 15][k0 + (l >> 4)] and B[k0 + (l >> 4)][l & 15]): two LDS reads per lane and 1024 multiply-adds per
+    // k-step where the register tiles below take twelve per sixteen -- those were LDS-bound (6.5 k cycles per d = 40 product, 26
+    // products per observation step).  A thread owns the same output entries in every product of the same shape.
+    {
+      const int wave = tid >> 6, lane = tid & 63, lm = lane & 15, lg = lane >> 4;
+      const int tcn = (cols + 15) >> 4, ntile = ((rows + 15) >> 4) * tcn;
+      for (int tile = wave; tile < ntile; tile += (NT >> 6)) {
+        const int ti = fdiv(tile, tcn), tj = tile - ti * tcn;
+        const int ai = 16 * ti + lm, bj = 16 * tj + lm;
+        const bool aok = ai < rows, bok = bj < cols;
+        const int aic = aok ? ai : 0, bjc = bok ? bj : 0;
+        typename WgAcc<R>::type acc = {0, 0, 0, 0};
+        for (int k0 = 0; k0 < K; k0 += 4) {
+          const int kk = k0 + lg;
+          const bool kok = kk < K;
+          const int kc = kok ? kk : 0;
+          const R av = Aat(aic, kc), bv = Bat(kc, bjc);
+          acc = wg_mfma((aok && kok) ? av : R(0), (bok && kok) ? bv : R(0), acc);
+        }
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const int row = 16 * ti + WgAcc<R>::row(lane, r4);
+          if (row < rows && bok) out(row, bj, acc[r4]);
+        }
+      }
+      return;
+    }
+#endif
     const int tr = (rows + 1) >> 1, tc = (cols + 3) >> 2;
     for (int tile = tid; tile < tr * tc; tile += NT) {
       const int ti = fdiv(tile, tc), tj = tile - ti * tc;

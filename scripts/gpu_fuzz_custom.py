@@ -80,10 +80,14 @@ def random_drift(d):
 
 for case in range(cases):
     big = rng.random() < 0.7
-    d = int(rng.integers(7, 25)) if big else int(rng.integers(1, 7))
-    m = int(rng.integers(1, (min(d + 4, 24) if big else 7)))
+    dmax = int(os.environ.get("CDKF_FUZZ_DMAX", "24"))
+    d = int(rng.integers(7, dmax + 1)) if big else int(rng.integers(1, 7))
+    m = int(rng.integers(1, (min(d + 4, dmax) if big else 7)))
     if not big and rng.random() < 0.3:
         m = int(rng.integers(7, 12))          # small state, wide emission: the workgroup kernels too
+    if os.environ.get("CDKF_FUZZ_D"):
+        d = int(os.environ["CDKF_FUZZ_D"])
+        m = min(m, d + 4)
     src, make = random_drift(d)
     theta = np.array([0.5 + 0.5 * rng.random(), 0.2 * rng.standard_normal()])
     if rng.random() < 0.4 and m <= d:
@@ -124,4 +128,6 @@ for case in range(cases):
     note("grad_all", max(max(np.abs(np.asarray(a_) - b_).max() / scale for a_, b_ in pairs), relerr(ll, ll_ref)), 1e-7, tag)
     ll, g1 = cd.cdnlgssm_loglik_and_grad(Pn, y, t[..., None], hyp)
     note("grad_theta", np.abs(np.asarray(g1.theta) - g_ref).max() / (np.abs(g_ref).max() + 1e-300), 1e-7, tag)
+    if os.environ.get("CDKF_FUZZ_VERBOSE"):
+        print(tag, "theta grad got", np.asarray(g1.theta).ravel(), "all-leaf", np.asarray(g.dynamics.drift.theta).ravel(), "want", g_ref.ravel(), flush=True)
 print("fuzz custom seed", seed, "cases", cases, "worst", {k: float("%.3g" % v) for k, v in worst.items()}, flush=True)
