@@ -153,11 +153,11 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
   // Dense product in 2 x 4 register tiles, one tile per thread: out(i, j, sum_k A(i, k) B(k, j)) for i < rows, j < cols.  Twelve LDS
   // reads per sixteen multiply-adds (a dot product per entry takes two per multiply-add and waits for each).
   auto gemm = [&](int rows, int cols, int K, auto&& Aat, auto&& Bat, auto&& out) {
-#ifndef CDKF_AWG_VECTOR_GEMM
-    // ... on the matrix cores: 16 x 16 output tiles dealt to the four wavefronts, v_mfma_{f64,f32}_16x16x4 (exact arithmetic of the
-    // type; lane l feeds A[l & 15][k0 + (l >> 4)] and B[k0 + (l >> 4)][l & 15]): two LDS reads per lane and 1024 multiply-adds per
-    // k-step where the register tiles below take twelve per sixteen -- those were LDS-bound (6.5 k cycles per d = 40 product, 26
-    // products per observation step).  A thread owns the same output entries in every product of the same shape.
+#ifdef CDKF_AWG_MFMA_GEMM
+    // The same product on the matrix cores (16 x 16 output tiles dealt to the four wavefronts, v_mfma_{f64,f32}_16x16x4, operands of
+    // eight k-steps in flight): measured, not used -- 31.5 ms against the register tiles' 30.3 per 256 x 100 slice at d = 40 in fp64
+    // (33.6 without the operand prefetch; fp32 26.1 against 26.4): nine tiles over four wavefronts are three rounds, 44 % of a
+    // 48 x 48 tile grid is padding, and the f64 matrix rate is the vector rate on this part.  Kept for the record (-DCDKF_AWG_MFMA_GEMM).
     {
       const int wave = tid >> 6, lane = tid & 63, lm = lane & 15, lg = lane >> 4;
       const int tcn = (cols + 15) >> 4, ntile = ((rows + 15) >> 4) * tcn;
@@ -167,12 +167,22 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
         const bool aok = ai < rows, bok = bj < cols;
         const int aic = aok ? ai : 0, bjc = bok ? bj : 0;
         typename WgAcc<R>::type acc = {0, 0, 0, 0};
-        for (int k0 = 0; k0 < K; k0 += 4) {
-          const int kk = k0 + lg;
-          const bool kok = kk < K;
-          const int kc = kok ? kk : 0;
-          const R av = Aat(aic, kc), bv = Bat(kc, bjc);
-          acc = wg_mfma((aok && kok) ? av : R(0), (bok && kok) ? bv : R(0), acc);
+        // the operands of eight k-steps in flight before the first of their products (a lone wavefront per SIMD has nothing else to cover
+        // the LDS round trips with)
+        for (int k0 = 0; k0 < K; k0 += 32) {
+          R av[8], bv[8];
+#pragma unroll
+          for (int s8 = 0; s8 < 8; ++s8) {
+            const int kk = k0 + 4 * s8 + lg;
+            const bool kok = kk < K;
+            const int kc = kok ? kk : 0;
+            const R a_ = Aat(aic, kc), b_ = Bat(kc, bjc);
+            av[s8] = (aok && kok) ? a_ : R(0);
+            bv[s8] = (bok && kok) ? b_ : R(0);
+          }
+#pragma unroll
+          for (int s8 = 0; s8 < 8; ++s8)
+            if (k0 + 4 * s8 < K) acc = wg_mfma(av[s8], bv[s8], acc);
         }
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {

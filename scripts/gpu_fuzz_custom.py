@@ -10,7 +10,7 @@ import numpy as np
 import cdkf_oracle as o
 import cd_dynamax_amd as cd
 from cd_dynamax_amd import _ffi
-from helpers import FILTER_KEYS, relerr
+from helpers import FILTER_KEYS, random_quadratic_drift, relerr
 
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 cases = int(sys.argv[2]) if len(sys.argv) > 2 else 12
@@ -29,55 +29,6 @@ def spd(n, s):
     return A @ A.T / n * s + 0.3 * np.eye(n)
 
 
-def random_drift(d):
-    """coefficients + the C statements + the oracle's callables"""
-    B = np.where(rng.random((d, d)) < min(1.0, 3.0 / d), rng.standard_normal((d, d)), 0.0) * 0.5
-    terms = []   # (i, j, k, a): a x_j x_k in f_i
-    for i in range(d):
-        for _ in range(int(rng.integers(0, 3))):
-            terms.append((i, int(rng.integers(d)), int(rng.integers(d)), 0.3 * rng.standard_normal()))
-    c = 0.3 * rng.standard_normal(d)
-    A3 = np.zeros((d, d, d))
-    for i, j, k, a in terms:
-        A3[i, j, k] += a
-    lines = []
-    style = rng.integers(3)
-    for i in range(d):
-        lin = " + ".join(f"R({float(B[i, j])!r}) * x[{j}]" for j in range(d) if B[i, j] != 0) or "R(0)"
-        qs = []
-        for ii, j, k, a in terms:
-            if ii != i:
-                continue
-            if j == k and style == 1:
-                qs.append(f"R({float(a)!r}) * pow(x[{j}], 2)")
-            else:
-                qs.append(f"R({float(a)!r}) * x[{j}] * x[{k}]")
-        quad = " + ".join(qs) or "R(0)"
-        if style == 2:
-            lines.append(f"{{ auto l_ = {lin}; auto q_ = {quad}; fx[{i}] = R({float(c[i])!r}) - x[{i}] + theta[0] * l_ + theta[1] * q_; }}")
-        else:
-            lines.append(f"fx[{i}] = R({float(c[i])!r}) - x[{i}] + theta[0] * ({lin}) + theta[1] * ({quad});")
-    src = "\n".join(lines)
-    S3 = A3 + A3.transpose(0, 2, 1)            # d Q_i / d x_j = S3[i, j, :] . x
-
-    def f(x, th):
-        return c - x + th[0] * x @ B.T + th[1] * np.einsum("ijk,...j,...k->...i", A3, x, x)
-
-    def jac(x, th):
-        return -np.eye(d) + th[0] * B + th[1] * np.einsum("ijk,...k->...ij", S3, x)
-
-    def g(x, th):                              # d/dx_k sum_i dF_ii: th1 sum_i S3[i, i, k]
-        return np.broadcast_to(th[1] * np.einsum("iik->k", S3), x.shape).copy()
-
-    def vjp(x, lam, G, th):
-        F = jac(x[None], th)[0]
-        xb = F.T @ lam + th[1] * np.einsum("ij,ijk->k", G, S3)
-        Q = np.einsum("ijk,j,k->i", A3, x, x)
-        JQ = np.einsum("ijk,k->ij", S3, x)
-        return xb, np.array([lam @ (B @ x) + (G * B).sum(), lam @ Q + (G * JQ).sum()])
-    return src, lambda th: o.CallableDrift(th, f, jac, g, vjp=vjp)
-
-
 for case in range(cases):
     big = rng.random() < 0.7
     dmax = int(os.environ.get("CDKF_FUZZ_DMAX", "24"))
@@ -88,7 +39,7 @@ for case in range(cases):
     if os.environ.get("CDKF_FUZZ_D"):
         d = int(os.environ["CDKF_FUZZ_D"])
         m = min(m, d + 4)
-    src, make = random_drift(d)
+    src, make = random_quadratic_drift(rng, d)
     theta = np.array([0.5 + 0.5 * rng.random(), 0.2 * rng.standard_normal()])
     if rng.random() < 0.4 and m <= d:
         H, bias = np.eye(d)[rng.permutation(d)[:m]], np.zeros(m)
@@ -105,14 +56,16 @@ for case in range(cases):
     P = mk("auto")
     tag = (case, d, m, N, T)
     order = str(rng.choice(["second", "first", "zeroth"]))
+    only_grad = bool(os.environ.get("CDKF_FUZZ_ONLY_GRAD"))
     ref = o.ekf_filter(mdl, t, y, state_order=order)
-    post = cd.cdnlgssm_filter(P, y, t[..., None], cd.EKFHyperParams(state_order=order))
-    note("ekf", max(max(relerr(getattr(post, k), ref[k]) for k in FILTER_KEYS), relerr(post.marginal_loglik, ref["marginal_loglik"])), 1e-9, tag + (order,))
-    if rng.random() < 0.5:
+    post = cd.cdnlgssm_filter(P, y, t[..., None], cd.EKFHyperParams(state_order=order)) if not only_grad else None
+    if post is not None:
+        note("ekf", max(max(relerr(getattr(post, k), ref[k]) for k in FILTER_KEYS), relerr(post.marginal_loglik, ref["marginal_loglik"])), 1e-9, tag + (order,))
+    if rng.random() < 0.5 and not only_grad:
         ref = o.ukf_filter(mdl, t, y)
         post = cd.cdnlgssm_filter(P, y, t[..., None], cd.UKFHyperParams())
         note("ukf", max(relerr(getattr(post, k), ref[k]) for k in FILTER_KEYS), 1e-8, tag)
-    if rng.random() < 0.5:
+    if rng.random() < 0.5 and not only_grad:
         ref = o.ekf_smoother(mdl, t, y, state_order="second")
         sm = cd.cdnlgssm_smoother(P, y, t[..., None])
         note("eks", max(relerr(sm.smoothed_means, ref["smoothed_means"]), relerr(sm.smoothed_covariances, ref["smoothed_covariances"])), 1e-8, tag)

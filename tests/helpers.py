@@ -156,3 +156,54 @@ def mlp_model(rng, d=8, m_obs=4, h=64):
     b1, b2, b3 = (0.1 * rng.standard_normal(k) for k in (h1, h2, d))
     return o.Model(o.MLPDrift(W1, b1, W2, b2, W3, b3), np.eye(d), 0.5 * np.eye(d), np.eye(d)[:m_obs], np.zeros(m_obs),
                    0.5 * np.eye(m_obs), np.zeros(d), np.eye(d))
+
+
+def random_quadratic_drift(rng, d):
+    """A random sparse quadratic drift f = c - x + theta_0 B x + theta_1 Q(x), Q_i = sum a_i,jk x_j x_k, as C statements of random shape
+    (plain expressions, pow, temporaries) for LearnableCustomDrift and as the oracle's callables (f, Jacobian, grad(div f), and the
+    vector-Jacobian products the reverse sweep needs, from the coefficient arrays): returns (f_src, make) with make(theta) -> o.CallableDrift."""
+    B = np.where(rng.random((d, d)) < min(1.0, 3.0 / d), rng.standard_normal((d, d)), 0.0) * 0.5
+    terms = []   # (i, j, k, a): a x_j x_k in f_i
+    for i in range(d):
+        for _ in range(int(rng.integers(0, 3))):
+            terms.append((i, int(rng.integers(d)), int(rng.integers(d)), 0.3 * rng.standard_normal()))
+    c = 0.3 * rng.standard_normal(d)
+    A3 = np.zeros((d, d, d))
+    for i, j, k, a in terms:
+        A3[i, j, k] += a
+    lines = []
+    style = rng.integers(3)
+    for i in range(d):
+        lin = " + ".join(f"R({float(B[i, j])!r}) * x[{j}]" for j in range(d) if B[i, j] != 0) or "R(0)"
+        qs = []
+        for ii, j, k, a in terms:
+            if ii != i:
+                continue
+            if j == k and style == 1:
+                qs.append(f"R({float(a)!r}) * pow(x[{j}], 2)")
+            else:
+                qs.append(f"R({float(a)!r}) * x[{j}] * x[{k}]")
+        quad = " + ".join(qs) or "R(0)"
+        if style == 2:
+            lines.append(f"{{ auto l_ = {lin}; auto q_ = {quad}; fx[{i}] = R({float(c[i])!r}) - x[{i}] + theta[0] * l_ + theta[1] * q_; }}")
+        else:
+            lines.append(f"fx[{i}] = R({float(c[i])!r}) - x[{i}] + theta[0] * ({lin}) + theta[1] * ({quad});")
+    src = "\n".join(lines)
+    S3 = A3 + A3.transpose(0, 2, 1)            # d Q_i / d x_j = S3[i, j, :] . x
+
+    def f(x, th):
+        return c - x + th[0] * x @ B.T + th[1] * np.einsum("ijk,...j,...k->...i", A3, x, x)
+
+    def jac(x, th):
+        return -np.eye(d) + th[0] * B + th[1] * np.einsum("ijk,...k->...ij", S3, x)
+
+    def g(x, th):                              # d/dx_k sum_i dF_ii: th1 sum_i S3[i, i, k]
+        return np.broadcast_to(th[1] * np.einsum("iik->k", S3), x.shape).copy()
+
+    def vjp(x, lam, G, th):
+        F = jac(x[None], th)[0]
+        xb = F.T @ lam + th[1] * np.einsum("ij,ijk->k", G, S3)
+        Q = np.einsum("ijk,j,k->i", A3, x, x)
+        JQ = np.einsum("ijk,k->ij", S3, x)
+        return xb, np.array([lam @ (B @ x) + (G * B).sum(), lam @ Q + (G * JQ).sum()])
+    return src, lambda th: o.CallableDrift(th, f, jac, g, vjp=vjp)

@@ -7,7 +7,7 @@ import pytest
 import cd_dynamax_amd as cd
 import cdkf_oracle as o
 from cd_dynamax_amd import _ffi
-from helpers import FILTER_KEYS, relerr
+from helpers import FILTER_KEYS, random_quadratic_drift, relerr
 
 PEND_F = "fx[0] = x[1]; fx[1] = -theta[0] * sin(x[0]) - theta[1] * x[1];"
 PEND_J = "F[0][1] = R(1); F[1][0] = -theta[0] * cos(x[0]); F[1][1] = -theta[1];"
@@ -560,6 +560,43 @@ def test_wide_custom_drift_loglik_gradient(hip_lib, d, m, selection):
         assert np.abs(np.asarray(grads.dynamics.drift.theta)[:, p] - fd).max() < 2e-5 * max(1.0, np.abs(fd).max())
     with pytest.raises(NotImplementedError):   # a non-zero grad(div f): the mean's second-order term is not reversed for custom drifts
         cd.cdnlgssm_loglik_and_grad_all(params_for(mdl, cd.LearnableCustomDrift(theta, src, None, "auto")), y, t[..., None])
+
+
+@pytest.mark.gpu
+def test_custom_drift_gradient_with_a_long_snippet(hip_lib):
+    """The case scripts/gpu_fuzz_custom.py (seed 12, case 0) caught: a 24-statement quadratic drift at d = 24, m = 22, intervals of
+    several Runge-Kutta steps -- the run-time compiled reverse sweep returned d ll / d theta = 0.05 where it is 0.22 in three of four
+    variants of the kernel built at -O2 / -O3 and in none at -O1, which it is built at since.  Filter and
+    smoother of the same drift along the way."""
+    rng = np.random.default_rng(12)
+    rng.random()                                   # (the fuzzer's draws, in its order)
+    d = int(rng.integers(7, 25))
+    m = int(rng.integers(1, min(d + 4, 24)))
+    assert (d, m) == (24, 22)
+    src, make = random_quadratic_drift(rng, d)
+    theta = np.array([0.5 + 0.5 * rng.random(), 0.2 * rng.standard_normal()])
+    spd = lambda n, sc: (lambda A: A @ A.T / n * sc + 0.3 * np.eye(n))(rng.standard_normal((n, n)))
+    if rng.random() < 0.4 and m <= d:
+        H, bias = np.eye(d)[rng.permutation(d)[:m]], np.zeros(m)
+    else:
+        H, bias = rng.standard_normal((m, d)) / np.sqrt(d), 0.1 * rng.standard_normal(m)
+    mdl = o.Model(make(theta), np.eye(d) + 0.1 * rng.standard_normal((d, d)), spd(d, 0.3), H, bias, spd(m, 0.5), 0.5 * rng.standard_normal(d), spd(d, 0.3))
+    N, T = int(rng.integers(1, 5)), int(rng.integers(2, 9))
+    assert (N, T) == (2, 8)
+    t = o.irregular_times(rng, N, T, 0.03 * T)
+    y = o.simulate(mdl, t, rng)
+    P = params_for(mdl, cd.LearnableCustomDrift(theta, src, None, "auto"))
+    ref = o.ekf_smoother(mdl, t, y)
+    sm = cd.cdnlgssm_smoother(P, y, t[..., None])
+    assert relerr(sm.filtered_covariances, ref["filtered_covariances"]) < 1e-10 and relerr(sm.smoothed_means, ref["smoothed_means"]) < 1e-9
+    ll_ref, g_ref, full = o.ekf_loglik_grad_adjoint(mdl, t, y, full=True, state_order="first")
+    Pn = params_for(mdl, cd.LearnableCustomDrift(theta, src, None, None))
+    ll, grads = cd.cdnlgssm_loglik_and_grad_all(Pn, y, t[..., None], cd.EKFHyperParams(state_order="first"))
+    np.testing.assert_allclose(ll, ll_ref, rtol=1e-10)
+    scale = np.abs(g_ref).max()
+    assert np.abs(np.asarray(grads.dynamics.drift.theta) - g_ref).max() < 1e-8 * scale
+    assert np.abs(np.asarray(grads.emissions.emission_function.weights) - full["H"]).max() < 1e-8 * np.abs(full["H"]).max()
+    assert np.abs(np.asarray(grads.initial.cov.params) - full["P0"]).max() < 1e-8 * np.abs(full["P0"]).max()
 
 
 @pytest.mark.gpu
