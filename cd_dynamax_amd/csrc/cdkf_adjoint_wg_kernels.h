@@ -258,7 +258,7 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
   if (tid < 64) mb[tid] = R(0);
   AWG_FOR(e, (int)ntheta) g[e] = R(0);
   if (gm) AWG_FOR(e, (int)awg_model_grad_size(d, m)) gm[e] = R(0);
-  R gForcing = R(0);  // Lorenz-96: thread 64 accumulates d ll / d F;  a drift given as source: thread d + p accumulates d ll / d theta_p
+  R gForcing = R(0);  // Lorenz-96: thread 64 accumulates d ll / d F
   int st = 0;
   __syncthreads();
 
@@ -809,9 +809,14 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
           if (custom) {
             const int Z = d + (int)ntheta;
             if (tid >= d && tid < Z) {
+              // (straight into the result: as a register of these few lanes, kept across the steps like the Lorenz-96 forcing's, the
+              //  sum came back holding only the LAST step's share in three of four builds of the run-time compiled kernel at -O2 / -O3
+              //  -- scripts/gpu_fuzz_custom.py)
               int NG = NT / Z;
               if (NG > SL / Z) NG = SL / Z;
-              for (int grp = 0; grp < NG; ++grp) gForcing += slot(8)[grp * Z + tid];
+              R s3 = R(0);
+              for (int grp = 0; grp < NG; ++grp) s3 += slot(8)[grp * Z + tid];
+              g[tid - d] += s3;
             }
           } else
 #endif
@@ -850,12 +855,7 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
     if (tid < d) gm[tid] = mb[tid];
     rows2d(d, d, [&](int i, int j) { return R(0.5) * (Pb[i * ld + j] + Pb[j * ld + i]); }, [&](int i, int j, R v) { gP0[i * d + j] = v; });
   }
-#ifdef CDKF_AWG_CUSTOM
-  if (custom) {
-    if (tid >= d && tid < d + (int)ntheta) g[tid - d] = gForcing;
-  } else
-#endif
-  if (!lin && tid == 64) g[0] = gForcing;
+  if (!custom && !lin && tid == 64) g[0] = gForcing;
   if (st && tid == 0 && a.status) atomicOr(&a.status[n], st);
 #ifdef CDKF_AWG_PROFILE
   if (threadIdx.x == 0 && blockIdx.x == 0) {

@@ -478,10 +478,8 @@ int compile_wg_variant(const CustomDrift& c, const WgKey& key, const std::string
   }
   // (the instantiations with eight or more entries per thread are built at -O1 in the library too: launch_wg8.hip, Makefile)
   const std::string inc = "-I" + source_dir(), off = "--offload-arch=" + arch;
-  // -O1: the wg kernels' instantiations with eight or more entries per thread (as in the library: launch_wg8.hip, Makefile), and the
-  // reverse sweep with a drift compiled in -- at -O2 / -O3 a 24-statement quadratic drift at d = 24 came back with the wrong d ll / d theta
-  // (scripts/gpu_fuzz_custom.py seeds 11, 12; every smaller shape and the same shape at -O1 agree with the oracle to 1e-15)
-  const char* olevel = (ept >= 8 || smoother == 2) ? "-O1" : "-O3";
+  // -O1: the wg kernels' instantiations with eight or more entries per thread, as in the library (launch_wg8.hip, Makefile)
+  const char* olevel = (ept >= 8 && smoother != 2) ? "-O1" : "-O3";
   if (const char* e = getenv("CDKF_CUSTOM_OPT")) olevel = e;  // debugging aid
   const char* opts[] = {off.c_str(), olevel, "-std=c++17", inc.c_str(), "-Wno-pass-failed"};
   const hiprtcResult res = hiprtcCompileProgram(prog, 5, opts);

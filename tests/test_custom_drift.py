@@ -565,9 +565,9 @@ def test_wide_custom_drift_loglik_gradient(hip_lib, d, m, selection):
 @pytest.mark.gpu
 def test_custom_drift_gradient_with_a_long_snippet(hip_lib):
     """The case scripts/gpu_fuzz_custom.py (seed 12, case 0) caught: a 24-statement quadratic drift at d = 24, m = 22, intervals of
-    several Runge-Kutta steps -- the run-time compiled reverse sweep returned d ll / d theta = 0.05 where it is 0.22 in three of four
-    variants of the kernel built at -O2 / -O3 and in none at -O1, which it is built at since.  Filter and
-    smoother of the same drift along the way."""
+    several Runge-Kutta steps -- the run-time compiled reverse sweep returned d ll / d theta = 0.05 where it is 0.22: only the last
+    reversed step's share, the rest lost from a register two lanes kept the sum in across the steps (the sum
+    goes straight into the result array since).  Filter and smoother of the same drift along the way."""
     rng = np.random.default_rng(12)
     rng.random()                                   # (the fuzzer's draws, in its order)
     d = int(rng.integers(7, 25))
