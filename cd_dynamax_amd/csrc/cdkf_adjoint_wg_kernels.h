@@ -270,6 +270,7 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
       return;
     }
 #endif
+    if (lin)  // (Lorenz-96: the four non-zeros of a row of the Jacobian are formed where they are used -- l96_FPs, l96_LamF below)
     rows2d(d, d,
            [&](int i, int j) {
              if (lin) return th[i * d + j];
@@ -294,6 +295,33 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
       }
       fv[i] = f;
     }
+  };
+  // Lorenz-96: F has four entries per row (F_i,i+1 = x_{i-1}, F_i,i-2 = -x_{i-1}, F_i,i-1 = x_{i+1} - x_{i-2}, F_ii = -1) -- the two dense
+  // products of a stage with it are four-term stencils over the LDS image of the other factor (they were 2 x 6.5 k of a stage's ~ 22 k
+  // cycles as d^3 products against a dense copy of F)
+  const bool l96 = !lin && !custom;
+  auto wrap = [&](int i) { return i < 0 ? i + d : (i >= d ? i - d : i); };
+  auto l96_FPs = [&](const R* xv, const R* Ps_, R* A_) {  // A = F(x) Ps
+    rows2d(d, d,
+           [&](int i, int j) {
+             const int ip1 = wrap(i + 1), im1 = wrap(i - 1), im2 = wrap(i - 2);
+             R v = -xv[im1] * Ps_[im2 * ld + j];
+             v = rfma(xv[ip1] - xv[im2], Ps_[im1 * ld + j], v);
+             v -= Ps_[i * ld + j];
+             return rfma(xv[im1], Ps_[ip1 * ld + j], v);
+           },
+           [&](int i, int j, R v) { A_[i * ld + j] = v; });
+  };
+  auto l96_LamF = [&](const R* xv, const R* Lam_, R* G_) {  // G = Lam F(x): column j of F holds rows j-1, j+2, j+1, j
+    rows2d(d, d,
+           [&](int i, int j) {
+             const int jp1 = wrap(j + 1), jp2 = wrap(j + 2), jm1 = wrap(j - 1), jm2 = wrap(j - 2);
+             R v = Lam_[i * ld + jm1] * xv[jm2];
+             v = rfma(-Lam_[i * ld + jp2], xv[jp1], v);
+             v = rfma(Lam_[i * ld + jp1], xv[jp2] - xv[jm1], v);
+             return v - Lam_[i * ld + j];
+           },
+           [&](int i, int j, R v) { G_[i * ld + j] = v; });
   };
   // ---- lower Cholesky factors of one or two n x n matrices in lockstep (in place, lower triangles), right-looking in PANELS of eight
   // columns, two barriers per panel: (A) every thread of the system's wavefront factorises the 8 x 8 block on the diagonal in
@@ -517,8 +545,11 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
       stage_value(si, P0s, Ps, dt);
       drift_eval(xs, F);
       __syncthreads();
-      gemm(d, d, d, [&](int i, int k) { return F[i * ld + k]; }, [&](int k, int j) { return Ps[k * ld + j]; },
-           [&](int i, int j, R v) { A[i * ld + j] = v; });
+      if (l96)
+        l96_FPs(xs, Ps, A);
+      else
+        gemm(d, d, d, [&](int i, int k) { return F[i * ld + k]; }, [&](int k, int j) { return Ps[k * ld + j]; },
+             [&](int i, int j, R v) { A[i * ld + j] = v; });
       if (tid < d) km[64 * si + tid] = fv[tid];
       __syncthreads();
     }
@@ -749,8 +780,11 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
           __syncthreads();
           AWG_TICK(9)  // stage cotangent, stage value, drift
           // Ybar_P = F^T Lam + Lam F = (Lam F) + (Lam F)^T;  G = 2 Lam Ps where the drift's parameters / state derivative want it
-          gemm(d, d, d, [&](int i, int kk) { return Lam[i * ld + kk]; }, [&](int kk, int j) { return F[kk * ld + j]; },
-               [&](int i, int j, R v) { G[i * ld + j] = v; });
+          if (l96)
+            l96_LamF(xs, Lam, G);
+          else
+            gemm(d, d, d, [&](int i, int kk) { return Lam[i * ld + kk]; }, [&](int kk, int j) { return F[kk * ld + j]; },
+                 [&](int i, int j, R v) { G[i * ld + j] = v; });
           if (lin) {
             gemm(d, d, d, [&](int i, int kk) { return Lam[i * ld + kk]; }, [&](int kk, int j) { return Ps[kk * ld + j]; },
                  [&](int i, int j, R v) { g[i * d + j] += rfma(lamv[i], xs[j], R(2) * v); });  // dW += lam x^T + G
@@ -774,7 +808,13 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
               part[grp * Z + z] = s2;
             }
 #endif
-          } else if (tid < d) {  // Lorenz-96: the three entries of row i of G the state derivative of F touches
+          } else if (tid < 3 * d && 3 * d <= NT) {  // Lorenz-96: the three entries of row i of G the state derivative of F touches, a thread each
+            const int which = fdiv(tid, d), i = tid - which * d;
+            const int ip1 = (i + 1 >= d) ? 0 : i + 1, im1 = (i == 0) ? d - 1 : i - 1, im2 = (im1 == 0) ? d - 1 : im1 - 1;
+            const int col = which == 0 ? ip1 : (which == 1 ? im2 : im1);  // G[i][i+1], G[i][i-2], G[i][i-1]
+            R* gw = which == 0 ? g1 : (which == 1 ? g2 : g3);
+            gw[i] = R(2) * dot(d, [&](int kk) { return Lam[i * ld + kk]; }, [&](int kk) { return Ps[kk * ld + col]; });
+          } else if (tid < d && 3 * d > NT) {
             const int i = tid;
             const int ip1 = (i + 1 >= d) ? 0 : i + 1, im1 = (i == 0) ? d - 1 : i - 1, im2 = (im1 == 0) ? d - 1 : im1 - 1;
             auto lrow = [&](int kk) { return Lam[i * ld + kk]; };
@@ -786,7 +826,16 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
           __syncthreads();
           if (tid < d) {  // Ybar_m = F^T lam (+ the Jacobian's own state derivative contracted with G)
             const int c = tid;
-            R s2 = dot(d, [&](int r) { return F[r * ld + c]; }, [&](int r) { return lamv[r]; });
+            R s2;
+            if (l96) {  // column c of F: rows c-1, c+2, c+1, c
+              const int cp1 = wrap(c + 1), cp2 = wrap(c + 2), cm1 = wrap(c - 1), cm2 = wrap(c - 2);
+              s2 = lamv[cm1] * xs[cm2];
+              s2 = rfma(-lamv[cp2], xs[cp1], s2);
+              s2 = rfma(lamv[cp1], xs[cp2] - xs[cm1], s2);
+              s2 -= lamv[c];
+            } else {
+              s2 = dot(d, [&](int r) { return F[r * ld + c]; }, [&](int r) { return lamv[r]; });
+            }
             if (lin) {
               g[d * d + c] += lamv[c];
 #ifdef CDKF_AWG_CUSTOM
