@@ -95,6 +95,7 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
   const R* Rm = par + a.o_R;
   const R* hb = par + a.o_hb;
   const bool lin = a.kind == kDriftLinear;
+  const bool hsel = a.hsel != 0;
   const int nst = a.rk.stages;
   const long sz = (long)d * d + d;
   R* wsb = ws + n * ws_stride;
@@ -601,13 +602,21 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
             });
     if (tid < d) x0[tid] = (k == 0) ? (par + a.o_m0)[tid] : a.pm[n * a.m_sn + (k - 1) * a.m_sk + tid * a.m_si];
     __syncthreads();
-    gemm(m, d, d, [&](int r, int kk) { return Hs[r * ld + kk]; }, [&](int kk, int c) { return Pp[kk * ld + c]; },
-         [&](int r, int c, R v) { HP[r * ld + c] = v; });
-    if (tid < m)
-      vv[tid] = yp[k * a.y_sk + tid * a.y_si] - (hb[tid] + dot(d, [&](int kk) { return Hs[tid * ld + kk]; }, [&](int kk) { return x0[kk]; }));
-    __syncthreads();
-    gemm(m, m, d, [&](int r, int kk) { return HP[r * ld + kk]; }, [&](int kk, int c) { return Hs[c * ld + kk]; },
-         [&](int r, int c, R v) { S[r * ld + c] = v + Rm[r * m + c]; });
+    // (hsel: H = the first m rows of the identity, no bias -- BASELINE config 4's H = I among them: the five products with H as a factor
+    //  are copies of the other factor's rows / columns)
+    if (hsel) {
+      rows2d(m, d, [&](int r, int c) { return Pp[r * ld + c]; }, [&](int r, int c, R v) { HP[r * ld + c] = v; });
+      rows2d(m, m, [&](int r, int c) { return Pp[r * ld + c] + Rm[r * m + c]; }, [&](int r, int c, R v) { S[r * ld + c] = v; });
+      if (tid < m) vv[tid] = yp[k * a.y_sk + tid * a.y_si] - (hb[tid] + x0[tid]);
+    } else {
+      gemm(m, d, d, [&](int r, int kk) { return Hs[r * ld + kk]; }, [&](int kk, int c) { return Pp[kk * ld + c]; },
+           [&](int r, int c, R v) { HP[r * ld + c] = v; });
+      if (tid < m)
+        vv[tid] = yp[k * a.y_sk + tid * a.y_si] - (hb[tid] + dot(d, [&](int kk) { return Hs[tid * ld + kk]; }, [&](int kk) { return x0[kk]; }));
+      __syncthreads();
+      gemm(m, m, d, [&](int r, int kk) { return HP[r * ld + kk]; }, [&](int kk, int c) { return Hs[c * ld + kk]; },
+           [&](int r, int c, R v) { S[r * ld + c] = v + Rm[r * m + c]; });
+    }
     __syncthreads();
     rows2d(m, m, [&](int r, int c) { return R(0.5) * (S[r * ld + c] + S[c * ld + r]) + (r == c ? R(1e-9) : R(0)); },
            [&](int r, int c, R v) {
@@ -663,17 +672,23 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
            [&](int r, int c, R v) { gH[r * d + c] += v; });
       if (tid < m) gBias[tid] -= vb[tid];
     }
-    R* SH = Si;  // Sbar H [m][d], over the dead S^-1
-    gemm(m, d, m, [&](int r, int kk) { return Sbar[r * ld + kk]; }, [&](int kk, int c) { return Hs[kk * ld + c]; },
-         [&](int r, int c, R v) { SH[r * ld + c] = v; });
-    // Pbar <- Pbar + sym(Ub^T H) + H^T Sbar H
-    gemm(d, d, m, [&](int i, int kk) { return Ub[kk * ld + i]; }, [&](int kk, int j) { return Hs[kk * ld + j]; },
-         [&](int i, int j, R v) { T1[i * ld + j] = v; });
-    __syncthreads();
-    gemm(d, d, m, [&](int i, int kk) { return Hs[kk * ld + i]; }, [&](int kk, int j) { return SH[kk * ld + j]; },
-         [&](int i, int j, R v) { Pb[i * ld + j] += v; });
     R mbn = R(0);
-    if (tid < d) mbn = mb[tid] - dot(m, [&](int r) { return Hs[r * ld + tid]; }, [&](int r) { return vb[r]; });  // mbar <- mbar - H^T vbar
+    if (hsel) {  // Pbar <- Pbar + sym(Ub^T H) + H^T Sbar H with H = [I_m 0]: Ub^T H = [Ub^T 0], H^T Sbar H = Sbar in the leading block
+      rows2d(d, d, [&](int i, int j) { return j < m ? Ub[j * ld + i] : R(0); }, [&](int i, int j, R v) { T1[i * ld + j] = v; });
+      rows2d(m, m, [&](int i, int j) { return Pb[i * ld + j] + Sbar[i * ld + j]; }, [&](int i, int j, R v) { Pb[i * ld + j] = v; });
+      if (tid < d) mbn = mb[tid] - (tid < m ? vb[tid] : R(0));
+    } else {
+      R* SH = Si;  // Sbar H [m][d], over the dead S^-1
+      gemm(m, d, m, [&](int r, int kk) { return Sbar[r * ld + kk]; }, [&](int kk, int c) { return Hs[kk * ld + c]; },
+           [&](int r, int c, R v) { SH[r * ld + c] = v; });
+      // Pbar <- Pbar + sym(Ub^T H) + H^T Sbar H
+      gemm(d, d, m, [&](int i, int kk) { return Ub[kk * ld + i]; }, [&](int kk, int j) { return Hs[kk * ld + j]; },
+           [&](int i, int j, R v) { T1[i * ld + j] = v; });
+      __syncthreads();
+      gemm(d, d, m, [&](int i, int kk) { return Hs[kk * ld + i]; }, [&](int kk, int j) { return SH[kk * ld + j]; },
+           [&](int i, int j, R v) { Pb[i * ld + j] += v; });
+      if (tid < d) mbn = mb[tid] - dot(m, [&](int r) { return Hs[r * ld + tid]; }, [&](int r) { return vb[r]; });  // mbar <- mbar - H^T vbar
+    }
     __syncthreads();
     if (tid < d) mb[tid] = mbn;
     add_sym(Pb, T1, false);
