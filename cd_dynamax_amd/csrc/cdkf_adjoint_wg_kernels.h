@@ -43,6 +43,14 @@ __host__ __device__ inline int awg_entries_per_thread(int d) {
   return (d + rs - 1) / rs;
 }
 
+// 1 / sqrt(x): the hardware estimate and one third-order correction (fp64: to the last bit or two, as w40_rsqrt of the wavefront kernels)
+__device__ __forceinline__ double awg_rsqrt(double x) {
+  const double y0 = __builtin_amdgcn_rsq(x);
+  const double e = rfma(-(x * y0), y0, 1.0);
+  return rfma(y0 * e, rfma(e, 0.375, 0.5), y0);
+}
+__device__ __forceinline__ float awg_rsqrt(float x) { return 1.0f / sqrtf(x); }
+
 #ifdef CDKF_AWG_PROFILE  // local diagnostic build: cycles per phase (s_memtime), printed by trajectory 0
 static __device__ long long awg_prof[16];
 #define AWG_TICK(i)                                                  \
@@ -250,6 +258,52 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
     for (; k < K; ++k) s0 = rfma(Aat(k), Bat(k), s0);
     return (s0 + s1) + (s2 + s3);
   };
+  // The same product for TWO operand sets (system 0: cols0 columns, system 1: cols1, zero = absent) with the tiles of both dealt to
+  // the threads in one round -- the factorisations' and substitutions' rank-8 updates of two systems in lockstep are ~ 130 tiles
+  // each: one after the other they left half the workgroup idle twice.  The operand lambdas take the system as their first argument.
+  auto gemm2 = [&](int rows, int cols0, int cols1, int K, auto&& Aat, auto&& Bat, auto&& out) {
+    const int tr = (rows + 1) >> 1, tc0 = (cols0 + 3) >> 2, tcs = tc0 + ((cols1 + 3) >> 2);
+    for (int tile = tid; tile < tr * tcs; tile += NT) {
+      const int ti = fdiv(tile, tcs), tjj = tile - ti * tcs;
+      const int sy = tjj >= tc0 ? 1 : 0, tj = sy ? tjj - tc0 : tjj, cols = sy ? cols1 : cols0;
+      const int i0 = 2 * ti, j0 = 4 * tj;
+      const int i1 = (i0 + 1 < rows) ? i0 + 1 : i0;
+      int jj[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) jj[u] = (j0 + u < cols) ? j0 + u : cols - 1;
+      R acc0[4] = {0, 0, 0, 0}, acc1[4] = {0, 0, 0, 0};
+      int k = 0;
+      for (; k + 2 <= K; k += 2) {
+        const R a00 = Aat(sy, i0, k), a01 = Aat(sy, i0, k + 1), a10 = Aat(sy, i1, k), a11 = Aat(sy, i1, k + 1);
+        R b0[4], b1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          b0[u] = Bat(sy, k, jj[u]);
+          b1[u] = Bat(sy, k + 1, jj[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          acc0[u] = rfma(a01, b1[u], rfma(a00, b0[u], acc0[u]));
+          acc1[u] = rfma(a11, b1[u], rfma(a10, b0[u], acc1[u]));
+        }
+      }
+      if (k < K) {
+        const R a00 = Aat(sy, i0, k), a10 = Aat(sy, i1, k);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const R b = Bat(sy, k, jj[u]);
+          acc0[u] = rfma(a00, b, acc0[u]);
+          acc1[u] = rfma(a10, b, acc1[u]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (j0 + u < cols) {
+          out(sy, i0, j0 + u, acc0[u]);
+          if (i0 + 1 < rows) out(sy, i0 + 1, j0 + u, acc1[u]);
+        }
+    }
+  };
   // ---- start: H into LDS, accumulators to zero -------------------------------------------------------------------------
   AWG_FOR(e, m * d) {
     const int r = fdiv(e, d), c = e - r * d;
@@ -351,7 +405,7 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
 #pragma unroll
           for (int kk = 0; kk < c; ++kk) sd = rfma(-L[c][kk], L[c][kk], sd);
           if (!(sd > R(0))) st |= kStatusNotPd;
-          const R rinv = R(1) / rsqrt_(sd);
+          const R rinv = awg_rsqrt(sd);  // (a square root and a division in fp64 are ~ 100 instructions on the panel's critical path)
           L[c][c] = sd * rinv;
           ivl[c] = rinv;
 #pragma unroll
@@ -390,12 +444,9 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
       __syncthreads();
       const int rem = nn - p0 - NB, q0 = p0 + NB;
       if (rem > 0) {
-        auto trail = [&](R* A) {
-          gemm(rem, rem, NB, [&](int i, int kk) { return A[(q0 + i) * ld + p0 + kk]; }, [&](int kk, int j) { return A[(q0 + j) * ld + p0 + kk]; },
-               [&](int i, int j, R v) { if (j <= i) A[(q0 + i) * ld + q0 + j] -= v; });
-        };
-        trail(A0);
-        if (A1) trail(A1);
+        gemm2(rem, rem, A1 ? rem : 0, NB, [&](int sy, int i, int kk) { return (sy ? A1 : A0)[(q0 + i) * ld + p0 + kk]; },
+              [&](int sy, int kk, int j) { return (sy ? A1 : A0)[(q0 + j) * ld + p0 + kk]; },
+              [&](int sy, int i, int j, R v) { if (j <= i) (sy ? A1 : A0)[(q0 + i) * ld + q0 + j] -= v; });
       }
     }
     __syncthreads();
@@ -428,12 +479,9 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
       __syncthreads();
       const int rem = nn - p0 - NB, q0 = p0 + NB;
       if (rem > 0) {
-        auto below = [&](const R* Lx, R* Bx, int nc) {
-          gemm(rem, nc, NB, [&](int i, int kk) { return Lx[(q0 + i) * ld + p0 + kk]; }, [&](int kk, int j) { return Bx[(p0 + kk) * ld + j]; },
-               [&](int i, int j, R v) { Bx[(q0 + i) * ld + j] -= v; });
-        };
-        below(La, Ba, nca);
-        if (Bb) below(Lb, Bb, ncb);
+        gemm2(rem, nca, Bb ? ncb : 0, NB, [&](int sy, int i, int kk) { return (sy ? Lb : La)[(q0 + i) * ld + p0 + kk]; },
+              [&](int sy, int kk, int j) { return (sy ? Bb : Ba)[(p0 + kk) * ld + j]; },
+              [&](int sy, int i, int j, R v) { (sy ? Bb : Ba)[(q0 + i) * ld + j] -= v; });
       }
     }
     for (int p0 = ((nn - 1) / NB) * NB; p0 >= 0; p0 -= NB) {  // backward: L^T x = y
@@ -454,12 +502,9 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
       }
       __syncthreads();
       if (p0 > 0) {
-        auto above = [&](const R* Lx, R* Bx, int nc) {
-          gemm(p0, nc, wdt, [&](int i, int kk) { return Lx[(p0 + kk) * ld + i]; }, [&](int kk, int j) { return Bx[(p0 + kk) * ld + j]; },
-               [&](int i, int j, R v) { Bx[i * ld + j] -= v; });
-        };
-        above(La, Ba, nca);
-        if (Bb) above(Lb, Bb, ncb);
+        gemm2(p0, nca, Bb ? ncb : 0, wdt, [&](int sy, int i, int kk) { return (sy ? Lb : La)[(p0 + kk) * ld + i]; },
+              [&](int sy, int kk, int j) { return (sy ? Bb : Ba)[(p0 + kk) * ld + j]; },
+              [&](int sy, int i, int j, R v) { (sy ? Bb : Ba)[i * ld + j] -= v; });
       }
     }
     __syncthreads();
