@@ -632,11 +632,10 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
     R* Pp = slot(1);   // predicted covariance
     R* HP = slot(2);   // H P            [m][d]
     R* S = slot(3);    // H P H^T + R    [m][m]; later (X Pbar) X^T, then Sbar
-    R* L1 = slot(4);   // chol(S); later Kb -> Ub [m][d]
+    R* L1 = slot(4);   // chol(S); later Kb [m][d]
     R* Si = slot(5);   // S^-1; later Sbar H [m][d]
-    R* L2 = slot(6);   // chol(sym(S) + 1e-9 I)
-    R* X = slot(7);    // (sym(S) + 1e-9 I)^-1 H P   [m][d]
-    R* T1 = slot(8);   // X Pbar [m][d]; later X Ub^T [m][m], then Ub^T H [d][d]
+    R* L2 = slot(6);   // chol(sym(S) + 1e-9 I); later X = W2 H P [m][d]
+    R* T1 = slot(8);   // X Pbar [m][d]; later Ub = W2 Kb [m][d]
     rows2d(d, d,
             [&](int i, int j) {
               return (k == 0) ? R(0.5) * ((par + a.o_P0)[i * d + j] + (par + a.o_P0)[j * d + i])
@@ -663,19 +662,26 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
            [&](int r, int c, R v) { S[r * ld + c] = v + Rm[r * m + c]; });
     }
     __syncthreads();
+    // psd_solve's matrix is used twice (X = W2 H P, Ub = W2 Kb, W2 = (sym(S) + 1e-9 I)^-1): its inverse is formed ONCE, in lockstep with
+    // S^-1 (which the log-likelihood's gradient needs anyway), and the two applications are dense products -- a third substitution
+    // sweep with one system (49 k cycles at m = 40, half the workgroup idle) against two products of 6.5 k
+    R* W2 = slot(7);   // (sym(S) + 1e-9 I)^-1 [m][m]; later X Ub^T [m][m], then Ub^T H [d][d]
+    R* X = slot(6);    // W2 H P [m][d], over the dead factor L2
     rows2d(m, m, [&](int r, int c) { return R(0.5) * (S[r * ld + c] + S[c * ld + r]) + (r == c ? R(1e-9) : R(0)); },
            [&](int r, int c, R v) {
              L1[r * ld + c] = S[r * ld + c];
              L2[r * ld + c] = v;
              Si[r * ld + c] = (r == c) ? R(1) : R(0);
+             W2[r * ld + c] = (r == c) ? R(1) : R(0);
            });
-    rows2d(m, d, [&](int r, int c) { return HP[r * ld + c]; }, [&](int r, int c, R v) { X[r * ld + c] = v; });
     AWG_TICK(1)  // loads, H P, S
     chol2(L1, g1, L2, g2, m);               // (g1, g2: the reciprocal diagonals; free vectors during the update)
     AWG_TICK(2)  // factorisations
-    solve2(L1, g1, Si, m, L2, g2, X, d, m);
-    AWG_TICK(3)  // S^-1, X
-    symmetrize(Pb, T1);
+    solve2(L1, g1, Si, m, L2, g2, W2, m, m);
+    gemm(m, d, m, [&](int r, int kk) { return W2[r * ld + kk]; }, [&](int kk, int c) { return HP[kk * ld + c]; },
+         [&](int r, int c, R v) { X[r * ld + c] = v; });
+    AWG_TICK(3)  // S^-1, W2, X
+    symmetrize(Pb, T1);  // (synchronises: X is complete behind it)
     gemm(m, d, d, [&](int r, int kk) { return X[r * ld + kk]; }, [&](int kk, int c) { return Pb[kk * ld + c]; },
          [&](int r, int c, R v) { T1[r * ld + c] = v; });
     if (tid < m) {  // w = S^-1 v;  vbar = X mbar - w
@@ -686,24 +692,29 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
     }
     __syncthreads();
     // Kb = v mbar^T - 2 S (X Pbar)   (cotangent of K^T), over the dead factor L1
+    R* Kb = L1;
     gemm(m, d, m, [&](int r, int kk) { return S[r * ld + kk]; }, [&](int kk, int c) { return T1[kk * ld + c]; },
-         [&](int r, int c, R v) { L1[r * ld + c] = rfma(R(-2), v, vv[r] * mb[c]); });
+         [&](int r, int c, R v) { Kb[r * ld + c] = rfma(R(-2), v, vv[r] * mb[c]); });
     __syncthreads();
-    R* Ub = L1;
     AWG_TICK(4)  // X Pbar, w, vbar, Kb
-    solve2(L2, g2, Ub, d, nullptr, nullptr, nullptr, 0, m);  // Ub = (sym(S) + 1e-9 I)^-1 Kb
-    AWG_TICK(5)  // Ub
-    // Sbar = -(X Pbar) X^T + w w^T / 2 - S^-1 / 2 - sym(X Ub^T): the first product over the dead S, the second over the then dead X Pbar
+    // Sbar = -(X Pbar) X^T + w w^T / 2 - S^-1 / 2 - sym(X Ub^T): the first product over the dead S; Ub = W2 Kb over the then dead
+    // X Pbar; X Ub^T over the then dead W2
     gemm(m, m, d, [&](int r, int kk) { return T1[r * ld + kk]; }, [&](int kk, int c) { return X[c * ld + kk]; },
          [&](int r, int c, R v) { S[r * ld + c] = v; });
     __syncthreads();
+    R* Ub = T1;
+    gemm(m, d, m, [&](int r, int kk) { return W2[r * ld + kk]; }, [&](int kk, int c) { return Kb[kk * ld + c]; },
+         [&](int r, int c, R v) { Ub[r * ld + c] = v; });
+    __syncthreads();
+    AWG_TICK(5)  // Ub
+    R* XU = W2;
     gemm(m, m, d, [&](int r, int kk) { return X[r * ld + kk]; }, [&](int kk, int c) { return Ub[c * ld + kk]; },
-         [&](int r, int c, R v) { T1[r * ld + c] = v; });
+         [&](int r, int c, R v) { XU[r * ld + c] = v; });
     __syncthreads();
     R* Sbar = S;
     rows2d(m, m,
             [&](int r, int c) {
-              return -S[r * ld + c] + R(0.5) * wv[r] * wv[c] - R(0.5) * Si[r * ld + c] - R(0.5) * (T1[r * ld + c] + T1[c * ld + r]);
+              return -S[r * ld + c] + R(0.5) * wv[r] * wv[c] - R(0.5) * Si[r * ld + c] - R(0.5) * (XU[r * ld + c] + XU[c * ld + r]);
             },
             [&](int r, int c, R v) {
               Sbar[r * ld + c] = v;
@@ -717,9 +728,10 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
            [&](int r, int c, R v) { gH[r * d + c] += v; });
       if (tid < m) gBias[tid] -= vb[tid];
     }
+    R* UH = XU;  // Ub^T H [d][d], over the dead X Ub^T
     R mbn = R(0);
     if (hsel) {  // Pbar <- Pbar + sym(Ub^T H) + H^T Sbar H with H = [I_m 0]: Ub^T H = [Ub^T 0], H^T Sbar H = Sbar in the leading block
-      rows2d(d, d, [&](int i, int j) { return j < m ? Ub[j * ld + i] : R(0); }, [&](int i, int j, R v) { T1[i * ld + j] = v; });
+      rows2d(d, d, [&](int i, int j) { return j < m ? Ub[j * ld + i] : R(0); }, [&](int i, int j, R v) { UH[i * ld + j] = v; });
       rows2d(m, m, [&](int i, int j) { return Pb[i * ld + j] + Sbar[i * ld + j]; }, [&](int i, int j, R v) { Pb[i * ld + j] = v; });
       if (tid < d) mbn = mb[tid] - (tid < m ? vb[tid] : R(0));
     } else {
@@ -728,7 +740,7 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
            [&](int r, int c, R v) { SH[r * ld + c] = v; });
       // Pbar <- Pbar + sym(Ub^T H) + H^T Sbar H
       gemm(d, d, m, [&](int i, int kk) { return Ub[kk * ld + i]; }, [&](int kk, int j) { return Hs[kk * ld + j]; },
-           [&](int i, int j, R v) { T1[i * ld + j] = v; });
+           [&](int i, int j, R v) { UH[i * ld + j] = v; });
       __syncthreads();
       gemm(d, d, m, [&](int i, int kk) { return Hs[kk * ld + i]; }, [&](int kk, int j) { return SH[kk * ld + j]; },
            [&](int i, int j, R v) { Pb[i * ld + j] += v; });
@@ -736,7 +748,7 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
     }
     __syncthreads();
     if (tid < d) mb[tid] = mbn;
-    add_sym(Pb, T1, false);
+    add_sym(Pb, UH, false);
     AWG_TICK(6)  // Sbar, model block, Pbar, mbar
     if (k == 0) break;
 
