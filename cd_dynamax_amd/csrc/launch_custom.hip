@@ -480,7 +480,6 @@ int compile_wg_variant(const CustomDrift& c, const WgKey& key, const std::string
   const std::string inc = "-I" + source_dir(), off = "--offload-arch=" + arch;
   // -O1: the wg kernels' instantiations with eight or more entries per thread, as in the library (launch_wg8.hip, Makefile)
   const char* olevel = (ept >= 8 && smoother != 2) ? "-O1" : "-O3";
-  if (const char* e = getenv("CDKF_CUSTOM_OPT")) olevel = e;  // debugging aid
   const char* opts[] = {off.c_str(), olevel, "-std=c++17", inc.c_str(), "-Wno-pass-failed"};
   const hiprtcResult res = hiprtcCompileProgram(prog, 5, opts);
   if (res != HIPRTC_SUCCESS) {
