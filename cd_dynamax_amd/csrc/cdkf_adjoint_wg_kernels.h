@@ -59,8 +59,10 @@ static __device__ long long awg_prof[16];
     if (threadIdx.x == 0 && blockIdx.x == 0) awg_prof[i] += awg_now - awg_last; \
     awg_last = clock64();                                            \
   }
+#define AWG_TICK2(i) AWG_TICK(i)
 #else
 #define AWG_TICK(i)
+#define AWG_TICK2(i)
 #endif
 
 #ifdef CDKF_AWG_CUSTOM
@@ -86,6 +88,9 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
 #endif
   R* sm = reinterpret_cast<R*>(smem_raw);
   const int tid = threadIdx.x, NT = blockDim.x;
+#ifdef CDKF_AWG_PROFILE
+  long long awg_last = clock64();
+#endif
   const long n = blockIdx.x;
   const int d = a.d, m = a.m, q = d > m ? d : m, ld = awg_ld(q), SL = q * ld;
   auto slot = [&](int s) { return sm + (long)s * SL; };
@@ -393,6 +398,7 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
     for (int p0 = 0; p0 < nn; p0 += NB) {
       __syncthreads();
       const int wdt = (nn - p0 < NB) ? nn - p0 : NB;
+      AWG_TICK2(12)
       if (act) {
         R L[NB][NB], ivl[NB];
 #pragma unroll
@@ -441,13 +447,16 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
           }
         }
       }
+      AWG_TICK2(13)
       __syncthreads();
+      AWG_TICK2(14)
       const int rem = nn - p0 - NB, q0 = p0 + NB;
       if (rem > 0) {
         gemm2(rem, rem, A1 ? rem : 0, NB, [&](int sy, int i, int kk) { return (sy ? A1 : A0)[(q0 + i) * ld + p0 + kk]; },
               [&](int sy, int kk, int j) { return (sy ? A1 : A0)[(q0 + j) * ld + p0 + kk]; },
               [&](int sy, int i, int j, R v) { if (j <= i) (sy ? A1 : A0)[(q0 + i) * ld + q0 + j] -= v; });
       }
+      AWG_TICK2(15)
     }
     __syncthreads();
   };
@@ -624,7 +633,7 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
   const R* tp = a.t + n * a.t_sn;
   const R* yp = a.y + n * a.y_sn;
 #ifdef CDKF_AWG_PROFILE
-  long long awg_last = clock64();
+  awg_last = clock64();
 #endif
   for (long k = a.T - 1; k >= 0; --k) {
     AWG_TICK(0)
@@ -981,9 +990,9 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
 #ifdef CDKF_AWG_PROFILE
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     printf("awg cycles/obs-step (sizeof real %d, d %d):", (int)sizeof(R), d);
-    for (int q2 = 0; q2 < 12; ++q2) printf(" [%d] %lld", q2, awg_prof[q2] / a.T);
+    for (int q2 = 0; q2 < 16; ++q2) printf(" [%d] %lld", q2, awg_prof[q2] / a.T);
     printf("\n");
-    for (int q2 = 0; q2 < 12; ++q2) awg_prof[q2] = 0;
+    for (int q2 = 0; q2 < 16; ++q2) awg_prof[q2] = 0;
   }
 #endif
 #undef AWG_FOR
