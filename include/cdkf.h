@@ -298,7 +298,8 @@ int cdkf_custom_drift_register(int state_dim, int n_theta, const char* f_src, co
  * filters, EKF smoother; not the gradient or emission-moment entry points. */
 int cdkf_custom_emission_register(int state_dim, int emission_dim, const char* h_src, const char* hjac_src);
 /* compile (without loading: no GPU needed) the kernel for one variant -- algo 0 EKF filter, 1 UKF filter, 2 EKF
- * smoother; emission_kind 0 or a registered custom emission -- to check the snippets early; 0 or a negative CDKF_E* code
+ * smoother, 3 the log-likelihood gradient (the forward-sensitivity sweep up to six dimensions, the reverse sweep beyond);
+ * emission_kind 0 or a registered custom emission -- to check the snippets early; 0 or a negative CDKF_E* code
  * with the compiler log in cdkf_last_error() */
 int cdkf_custom_drift_compile(int drift_kind, int bytes_per_real, int emission_dim, int algo, int state_order,
                               int emission_kind);
