@@ -108,7 +108,6 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
   const R* Rm = par + a.o_R;
   const R* hb = par + a.o_hb;
   const bool lin = a.kind == kDriftLinear;
-  const bool hsel = a.hsel != 0;
   const int nst = a.rk.stages;
   const long sz = (long)d * d + d;
   R* wsb = ws + n * ws_stride;
@@ -316,6 +315,41 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
   }
   rows2d(d, d, [&](int, int) { return R(0); }, [&](int i, int j, R v) { Pb[i * ld + j] = v; });
   if (tid < 64) mb[tid] = R(0);
+  // Does the emission pick state components (every row of H a unit vector, no two alike, no bias -- H = I, H = I[:m], any subset in
+  // any order: BASELINE config 4's H = I among them)?  Then the five products of the update's adjoint with H as a factor are copies
+  // of the other factor's rows / columns: obs_s[r] = the component row r observes, inv_s[c] = the row that observes component c or -1.
+  __shared__ unsigned char obs_s[64];  // (bytes: the launchers raise the dynamic-LDS cap to all but 256 bytes of the CU's 160 KB)
+  __shared__ signed char inv_s[64];
+  __shared__ int sel_s;  // (a flag of our own: __syncthreads_and brings 256 bytes of static LDS with it)
+  if (tid == 0) sel_s = 1;
+  __syncthreads();
+  int sel_ok = 1;
+  if (tid < m) {
+    int col = -1, bad_row = (hb[tid] != R(0)) ? 1 : 0;
+    for (int c = 0; c < d; ++c) {
+      const R h = Hs[tid * ld + c];
+      if (h == R(0)) continue;
+      if (h != R(1) || col >= 0) bad_row = 1;
+      col = c;
+    }
+    if (col < 0) bad_row = 1;
+    obs_s[tid] = (unsigned char)(col < 0 ? 0 : col);
+    sel_ok = !bad_row;
+  }
+  __syncthreads();
+  if (tid < d) {
+    int who = -1, cnt = 0;
+    for (int r = 0; r < m; ++r)
+      if (obs_s[r] == tid) {
+        who = r;
+        ++cnt;
+      }
+    inv_s[tid] = (signed char)who;
+    if (cnt > 1) sel_ok = 0;
+  }
+  if (!sel_ok) sel_s = 0;
+  __syncthreads();
+  const bool hsel = sel_s != 0 && m <= d;
   AWG_FOR(e, (int)ntheta) g[e] = R(0);
   if (gm) AWG_FOR(e, (int)awg_model_grad_size(d, m)) gm[e] = R(0);
   R gForcing = R(0);  // Lorenz-96: thread 64 accumulates d ll / d F
@@ -655,12 +689,10 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
             });
     if (tid < d) x0[tid] = (k == 0) ? (par + a.o_m0)[tid] : a.pm[n * a.m_sn + (k - 1) * a.m_sk + tid * a.m_si];
     __syncthreads();
-    // (hsel: H = the first m rows of the identity, no bias -- BASELINE config 4's H = I among them: the five products with H as a factor
-    //  are copies of the other factor's rows / columns)
     if (hsel) {
-      rows2d(m, d, [&](int r, int c) { return Pp[r * ld + c]; }, [&](int r, int c, R v) { HP[r * ld + c] = v; });
-      rows2d(m, m, [&](int r, int c) { return Pp[r * ld + c] + Rm[r * m + c]; }, [&](int r, int c, R v) { S[r * ld + c] = v; });
-      if (tid < m) vv[tid] = yp[k * a.y_sk + tid * a.y_si] - (hb[tid] + x0[tid]);
+      rows2d(m, d, [&](int r, int c) { return Pp[obs_s[r] * ld + c]; }, [&](int r, int c, R v) { HP[r * ld + c] = v; });
+      rows2d(m, m, [&](int r, int c) { return Pp[obs_s[r] * ld + obs_s[c]] + Rm[r * m + c]; }, [&](int r, int c, R v) { S[r * ld + c] = v; });
+      if (tid < m) vv[tid] = yp[k * a.y_sk + tid * a.y_si] - (hb[tid] + x0[obs_s[tid]]);
     } else {
       gemm(m, d, d, [&](int r, int kk) { return Hs[r * ld + kk]; }, [&](int kk, int c) { return Pp[kk * ld + c]; },
            [&](int r, int c, R v) { HP[r * ld + c] = v; });
@@ -739,10 +771,11 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
     }
     R* UH = XU;  // Ub^T H [d][d], over the dead X Ub^T
     R mbn = R(0);
-    if (hsel) {  // Pbar <- Pbar + sym(Ub^T H) + H^T Sbar H with H = [I_m 0]: Ub^T H = [Ub^T 0], H^T Sbar H = Sbar in the leading block
-      rows2d(d, d, [&](int i, int j) { return j < m ? Ub[j * ld + i] : R(0); }, [&](int i, int j, R v) { UH[i * ld + j] = v; });
-      rows2d(m, m, [&](int i, int j) { return Pb[i * ld + j] + Sbar[i * ld + j]; }, [&](int i, int j, R v) { Pb[i * ld + j] = v; });
-      if (tid < d) mbn = mb[tid] - (tid < m ? vb[tid] : R(0));
+    if (hsel) {  // Pbar <- Pbar + sym(Ub^T H) + H^T Sbar H: column j of Ub^T H is row inv[j] of Ub (or zero), H^T Sbar H scatters Sbar
+      rows2d(d, d, [&](int i, int j) { return inv_s[j] >= 0 ? Ub[inv_s[j] * ld + i] : R(0); }, [&](int i, int j, R v) { UH[i * ld + j] = v; });
+      rows2d(m, m, [&](int r, int c) { return Pb[obs_s[r] * ld + obs_s[c]] + Sbar[r * ld + c]; },
+             [&](int r, int c, R v) { Pb[obs_s[r] * ld + obs_s[c]] = v; });
+      if (tid < d) mbn = mb[tid] - (inv_s[tid] >= 0 ? vb[inv_s[tid]] : R(0));
     } else {
       R* SH = Si;  // Sbar H [m][d], over the dead S^-1
       gemm(m, d, m, [&](int r, int kk) { return Sbar[r * ld + kk]; }, [&](int kk, int c) { return Hs[kk * ld + c]; },
