@@ -685,6 +685,40 @@ def test_lorenz96_d40_value_and_gradient(hip_lib):
         close(np.asarray(g32[0]).reshape(N, -1), g_ref, "forcing (fp32)", 2e-3)
 
 
+@pytest.mark.parametrize("drift", ["lorenz96", "linear"])
+def test_reverse_sweep_with_a_scattered_selection_of_observed_components(hip_lib, drift):
+    """The update's adjoint takes the products with H as copies when the emission picks state components -- any subset, in any order
+    (detected in the kernel): Lorenz-96 d = 16 and a linear drift d = 11 observed through rows 5, 2, 11 (or 9), 0, 7 of the identity, dense R
+    and P0, every leaf against the oracle; a bias or a doubled row sends the same model down the dense products, with the same answer."""
+    rng = np.random.default_rng(661)
+    d = 16 if drift == "lorenz96" else 11
+    rows = [5, 2, 11 if d > 11 else 9, 0, 7]
+    m = len(rows)
+    A = rng.standard_normal((d, d)) / np.sqrt(d)
+    Rm = rng.standard_normal((m, m)) / np.sqrt(m)
+    base = lorenz96_model(d, m) if drift == "lorenz96" else linear_model(rng, d, m)
+    for variant in ("selection", "bias", "dense"):
+        H = np.eye(d)[rows]
+        bias = np.zeros(m)
+        if variant == "bias":
+            bias[2] = 0.3
+        if variant == "dense":
+            H[1, 3] = 0.5
+        mdl = o.Model(base.drift, np.eye(d), 0.4 * np.eye(d) + 0.1 * A @ A.T, H, bias, 0.5 * np.eye(m) + 0.1 * Rm @ Rm.T, base.m0, 0.6 * np.eye(d) + 0.2 * A.T @ A)
+        N, T = 3, 6
+        t = o.irregular_times(rng, N, T, 0.02 * T)
+        y = o.simulate(mdl, t, rng)
+        ll_ref, g_ref, ex = o.ekf_loglik_grad_adjoint(mdl, t, y, full=True, state_order="first")
+        ll, g = cd.cdnlgssm_loglik_and_grad_all(params_from(mdl), y, t[..., None], cd.EKFHyperParams(state_order="first"))
+        assert _ffi.lib().cdkf_last_kernel().decode().startswith("ekf_adjoint_wg_kernel<double")
+        np.testing.assert_allclose(ll, ll_ref, rtol=1e-10)
+        flat = np.concatenate([np.asarray(a_).reshape(N, -1) for a_ in g.dynamics.drift], axis=-1)
+        for got, want in ((flat, g_ref), (g.initial.mean.params, ex["m0"]), (g.initial.cov.params, ex["P0"]), (g.dynamics.diffusion_cov.params, ex["Qc"]),
+                          (g.emissions.emission_function.weights, ex["H"]), (g.emissions.emission_function.bias, ex["bias"]),
+                          (g.emissions.emission_cov.params, ex["R"])):
+            assert np.abs(np.asarray(got) - want).max() < 1e-8 * (np.abs(want).max() + 1e-300), variant
+
+
 def test_lorenz63_gradient_all_parameters_on_the_lane_grid(hip_lib, tmp_path):
     """Small Lorenz-63 batches with H = I: the reverse sweep on the sixteen-lane grid (grad_lpe_l63_kernel<..., true>) also returns
     the model block -- m0, P0, L, Qc, H, bias, R -- of jax.grad(marginal_log_prob) (ssm_temissions.py:550-568 differentiates every
