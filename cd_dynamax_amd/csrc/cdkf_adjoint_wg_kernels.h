@@ -24,6 +24,9 @@ namespace cdkf {
 constexpr int kAwgSlots = 9;   // q x ld matrices in LDS
 constexpr int kAwgVecs = 24;   // 64-entry vectors in LDS
 constexpr int kAwgThreads = 256;
+#ifndef CDKF_AWG_SOLVE_PANEL
+#define CDKF_AWG_SOLVE_PANEL 8  // (16 -- six substitution panel steps per system instead of ten -- measured 20.9 ms against 20.5 at d = 40)
+#endif
 __host__ __device__ inline int awg_ld(int q) { return q | 1; }
 __host__ __device__ inline long awg_lds_reals(int d, int m) {
   const int q = d > m ? d : m, ld = awg_ld(q);
@@ -497,50 +500,51 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
   // (L L^T) X = B in place for the columns of one or two right-hand-side matrices B [nn][ld] (each with its own factor), in blocks of
   // eight unknowns: (A) a thread per column substitutes through the 8 x 8 triangle in registers, (B) the remaining rows take the
   // block's contribution as a tiled product; two barriers per block and direction.
+  constexpr int NBS = CDKF_AWG_SOLVE_PANEL;  // unknowns per substitution panel (the factorisation's panels stay at eight: its diagonal block lives in registers)
   auto solve2 = [&](const R* La, const R* iva, R* Ba, int nca, const R* Lb, const R* ivb, R* Bb, int ncb, int nn) {
     const int sys = tid >> 6, c = tid & 63;
     const R* Ls = sys == 0 ? La : Lb;
     const R* ivs = sys == 0 ? iva : ivb;
     R* Bs = sys == 0 ? Ba : Bb;
     const bool act = (sys == 0 || (sys == 1 && Bb)) && c < (sys == 0 ? nca : ncb);
-    for (int p0 = 0; p0 < nn; p0 += NB) {  // forward: L y = b
+    for (int p0 = 0; p0 < nn; p0 += NBS) {  // forward: L y = b
       __syncthreads();
-      const int wdt = (nn - p0 < NB) ? nn - p0 : NB;
+      const int wdt = (nn - p0 < NBS) ? nn - p0 : NBS;
       if (act) {
-        R x[NB];
+        R x[NBS];
 #pragma unroll
-        for (int r = 0; r < NB; ++r) {
+        for (int r = 0; r < NBS; ++r) {
           R tt = (r < wdt) ? Bs[(p0 + r) * ld + c] : R(0);
 #pragma unroll
           for (int kk = 0; kk < r; ++kk) tt = rfma(-((r < wdt) ? Ls[(p0 + r) * ld + p0 + kk] : R(0)), x[kk], tt);
           x[r] = (r < wdt) ? tt * ivs[p0 + r] : R(0);
         }
 #pragma unroll
-        for (int r = 0; r < NB; ++r)
+        for (int r = 0; r < NBS; ++r)
           if (r < wdt) Bs[(p0 + r) * ld + c] = x[r];
       }
       __syncthreads();
-      const int rem = nn - p0 - NB, q0 = p0 + NB;
+      const int rem = nn - p0 - NBS, q0 = p0 + NBS;
       if (rem > 0) {
-        gemm2(rem, nca, Bb ? ncb : 0, NB, [&](int sy, int i, int kk) { return (sy ? Lb : La)[(q0 + i) * ld + p0 + kk]; },
+        gemm2(rem, nca, Bb ? ncb : 0, NBS, [&](int sy, int i, int kk) { return (sy ? Lb : La)[(q0 + i) * ld + p0 + kk]; },
               [&](int sy, int kk, int j) { return (sy ? Bb : Ba)[(p0 + kk) * ld + j]; },
               [&](int sy, int i, int j, R v) { (sy ? Bb : Ba)[(q0 + i) * ld + j] -= v; });
       }
     }
-    for (int p0 = ((nn - 1) / NB) * NB; p0 >= 0; p0 -= NB) {  // backward: L^T x = y
+    for (int p0 = ((nn - 1) / NBS) * NBS; p0 >= 0; p0 -= NBS) {  // backward: L^T x = y
       __syncthreads();
-      const int wdt = (nn - p0 < NB) ? nn - p0 : NB;
+      const int wdt = (nn - p0 < NBS) ? nn - p0 : NBS;
       if (act) {
-        R x[NB];
+        R x[NBS];
 #pragma unroll
-        for (int r = NB - 1; r >= 0; --r) {
+        for (int r = NBS - 1; r >= 0; --r) {
           R tt = (r < wdt) ? Bs[(p0 + r) * ld + c] : R(0);
 #pragma unroll
-          for (int kk = r + 1; kk < NB; ++kk) tt = rfma(-((kk < wdt) ? Ls[(p0 + kk) * ld + p0 + r] : R(0)), x[kk], tt);
+          for (int kk = r + 1; kk < NBS; ++kk) tt = rfma(-((kk < wdt) ? Ls[(p0 + kk) * ld + p0 + r] : R(0)), x[kk], tt);
           x[r] = (r < wdt) ? tt * ivs[p0 + r] : R(0);
         }
 #pragma unroll
-        for (int r = 0; r < NB; ++r)
+        for (int r = 0; r < NBS; ++r)
           if (r < wdt) Bs[(p0 + r) * ld + c] = x[r];
       }
       __syncthreads();
