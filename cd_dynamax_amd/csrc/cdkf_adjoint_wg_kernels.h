@@ -23,7 +23,7 @@ namespace cdkf {
 
 constexpr int kAwgSlots = 9;   // q x ld matrices in LDS
 constexpr int kAwgVecs = 24;   // 64-entry vectors in LDS
-constexpr int kAwgThreads = 256;
+constexpr int kAwgThreads = 256;  // (512 -- two wavefronts per SIMD at 256 registers each -- spills 266 registers even at four entries per thread: not pursued)
 #ifndef CDKF_AWG_SOLVE_PANEL
 #define CDKF_AWG_SOLVE_PANEL 8  // (16 -- six substitution panel steps per system instead of ten -- measured 20.9 ms against 20.5 at d = 40)
 #endif
