@@ -78,6 +78,17 @@ template <typename R>
 __device__ void awg_custom_column(const R* th, const R* x, int j, R* F, int ld, R* fv);
 template <typename R>
 __device__ R awg_custom_contract(const R* th, const R* x, const R* G, int ld, int j, int z, const R* lam);
+// state_order 'second' (CDKF_AWG_CUSTOM_SECOND: grad(div f) registered as "auto"): the mean's slope carries 0.5 Ps g(x), g = grad(div f)
+//   awg_custom_divpair: d2 f_i / dx_i dx_k  (g_k is its sum over i);
+//   awg_custom_third:   sum_k u_k d3 f_i / dx_i dx_k dz -- what the reverse of u . g(x, theta), u = 0.5 Ps^T lam, contributes to the
+//                       cotangent of the state component / parameter z (its sum over i)
+template <typename R>
+__device__ R awg_custom_divpair(const R* th, const R* x, int i, int k);
+template <typename R>
+__device__ R awg_custom_third(const R* th, const R* x, const R* u, int i, int z);
+#ifndef CDKF_AWG_CUSTOM_SECOND
+#define CDKF_AWG_CUSTOM_SECOND 0
+#endif
 #endif
 
 // NE: covariance entries a thread owns at most (rows i0, i0 + rs, ... of its column on the d x d map): 8 up to d = 42, else 16
@@ -119,8 +130,10 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
 #ifdef CDKF_AWG_CUSTOM
   const bool custom = a.kind >= kDriftCustomBase;
   const long ntheta = custom ? (long)CDKF_AWG_CUSTOM : (lin ? (long)d * d + d : 1);
+  const bool second = custom && CDKF_AWG_CUSTOM_SECOND && a.order == 2;
 #else
   constexpr bool custom = false;
+  constexpr bool second = false;
   const long ntheta = lin ? (long)d * d + d : 1;
 #endif
   R* g = grad + n * ntheta;
@@ -420,6 +433,24 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
            },
            [&](int i, int j, R v) { G_[i * ld + j] = v; });
   };
+#if defined(CDKF_AWG_CUSTOM) && CDKF_AWG_CUSTOM_SECOND
+  // g = grad(div f) at xv into gout (an LDS vector): one nested-dual evaluation per pair (i, k) into a free slot, column sums behind a
+  // barrier (deterministic); synchronises before and after the sums
+  auto custom_g = [&](const R* xv, R* gout) {
+    R* W = slot(7);
+    AWG_FOR(e, d * d) {
+      const int i = fdiv(e, d), kk = e - i * d;
+      W[i * ld + kk] = awg_custom_divpair<R>(th, xv, i, kk);
+    }
+    __syncthreads();
+    if (tid < d) {
+      R sg = R(0);
+      for (int i = 0; i < d; ++i) sg += W[i * ld + tid];
+      gout[tid] = sg;
+    }
+    __syncthreads();
+  };
+#endif
   // ---- lower Cholesky factors of one or two n x n matrices in lockstep (in place, lower triangles), right-looking in PANELS of eight
   // columns, two barriers per panel: (A) every thread of the system's wavefront factorises the 8 x 8 block on the diagonal in
   // registers (redundantly: broadcast reads, no exchange) and solves its own row of the panel against it; (B) the trailing matrix
@@ -643,6 +674,12 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
       else
         gemm(d, d, d, [&](int i, int k) { return F[i * ld + k]; }, [&](int k, int j) { return Ps[k * ld + j]; },
              [&](int i, int j, R v) { A[i * ld + j] = v; });
+#if defined(CDKF_AWG_CUSTOM) && CDKF_AWG_CUSTOM_SECOND
+      if (second) {  // dm/dt = f + 0.5 Ps g  (inference_ekf.py:108-116)
+        custom_g(xs, g1);
+        if (tid < d) km[64 * si + tid] = rfma(R(0.5), dot(d, [&](int kk) { return Ps[tid * ld + kk]; }, [&](int kk) { return g1[kk]; }), fv[tid]);
+      } else
+#endif
       if (tid < d) km[64 * si + tid] = fv[tid];
       __syncthreads();
     }
@@ -896,13 +933,20 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
           rows2d(d, d, [&](int i, int j) { return R(0.5) * (Lt[i * ld + j] + Lt[j * ld + i]); }, [&](int i, int j, R v) { Lam[i * ld + j] = v; });
           drift_eval(xs, F);
           __syncthreads();
+#if defined(CDKF_AWG_CUSTOM) && CDKF_AWG_CUSTOM_SECOND
+          if (second) {  // g(xs) again, and u = 0.5 Ps^T lam: the cotangent of g in the mean's slope
+            custom_g(xs, g1);
+            if (tid < d) g2[tid] = R(0.5) * dot(d, [&](int i) { return Ps[i * ld + tid]; }, [&](int i) { return lamv[i]; });
+            __syncthreads();
+          }
+#endif
           AWG_TICK(9)  // stage cotangent, stage value, drift
           // Ybar_P = F^T Lam + Lam F = (Lam F) + (Lam F)^T;  G = 2 Lam Ps where the drift's parameters / state derivative want it
           if (l96)
             l96_LamF(xs, Lam, G);
           else
             gemm(d, d, d, [&](int i, int kk) { return Lam[i * ld + kk]; }, [&](int kk, int j) { return F[kk * ld + j]; },
-                 [&](int i, int j, R v) { G[i * ld + j] = v; });
+                 [&](int i, int j, R v) { G[i * ld + j] = second ? rfma(R(0.25) * lamv[i], g1[j], v) : v; });  // (Ybar_P = G + G^T gains sym(0.5 lam g^T))
           if (lin) {
             gemm(d, d, d, [&](int i, int kk) { return Lam[i * ld + kk]; }, [&](int kk, int j) { return Ps[kk * ld + j]; },
                  [&](int i, int j, R v) { g[i * d + j] += rfma(lamv[i], xs[j], R(2) * v); });  // dW += lam x^T + G
@@ -922,7 +966,12 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
             if (tid < NG * Z) {
               const int grp = tid / Z, z = tid - grp * Z;
               R s2 = R(0);
-              for (int j = grp; j < d; j += NG) s2 += awg_custom_contract<R>(th, xs, G2, ld, j, z, (j == 0 && z >= d) ? lamv : (const R*)nullptr);
+              for (int j = grp; j < d; j += NG) {
+                s2 += awg_custom_contract<R>(th, xs, G2, ld, j, z, (j == 0 && z >= d) ? lamv : (const R*)nullptr);
+#if CDKF_AWG_CUSTOM_SECOND
+                if (second) s2 += awg_custom_third<R>(th, xs, g2, j, z);  // (j in the role of the divergence's index i)
+#endif
+              }
               part[grp * Z + z] = s2;
             }
 #endif

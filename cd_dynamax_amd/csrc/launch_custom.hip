@@ -407,6 +407,7 @@ std::string generate_awg_source(const CustomDrift& c, size_t lds) {
   std::string s;
   const std::string D_ = std::to_string(c.d), NT_ = std::to_string(c.n_theta > 0 ? c.n_theta : 1), NTH_ = std::to_string(c.n_theta);
   s += "#define CDKF_AWG_CUSTOM " + NTH_ + "\n#define CDKF_WG_STATIC_LDS " + std::to_string(lds) + "\n";
+  s += "#define CDKF_AWG_CUSTOM_SECOND " + std::string((c.has_g && c.auto_g) ? "1" : "0") + "\n";
   s += "#include \"cdkf_reg_kernels.h\"\n#include \"cdkf_adjoint_wg_kernels.h\"\n#include \"cdkf_dual.h\"\nnamespace cdkf {\n";
   s += "constexpr int CD = " + D_ + ", CNT = " + NT_ + ", CNTH = " + NTH_ + ";\n";
   s += "// (R: the compute type, as in the register-resident kernels' DriftCustom<R, D> -- the snippet may write R(...) constants)\ntemplate <typename R, typename T> __device__ __forceinline__ void custom_f(const T* x, const T* theta, T (&fx)[CD]) {\n  (void)theta;\n";
@@ -449,6 +450,55 @@ __device__ __forceinline__ R awg_custom_contract(const R* th, const R* x, const 
   if (lam)
     for (int i = 0; i < CD; ++i) s += lam[i] * ft[i].g[0].v;
   return s;
+}
+
+template <typename R>
+__device__ __forceinline__ R awg_custom_divpair(const R* th, const R* x, int i, int k) {
+  typedef Dual<R, 1> S1;
+  typedef Dual<S1, 1> T;
+  T xt[CD], tht[CNT], ft[CD];
+  for (int l = 0; l < CD; ++l) {
+    S1 b(x[l]);
+    b.g[0] = (l == k) ? R(1) : R(0);
+    xt[l].v = b;
+    xt[l].g[0] = S1(l == i ? R(1) : R(0));
+  }
+  for (int kk = 0; kk < CNTH; ++kk) {
+    tht[kk].v = S1(th[kk]);
+    tht[kk].g[0] = S1(R(0));
+  }
+  custom_f<R, T>(xt, tht, ft);
+  R v = R(0);
+  for (int l = 0; l < CD; ++l)
+    if (l == i) v = ft[l].g[0].g[0];
+  return v;
+}
+
+// innermost dual: the direction u; middle: e_i; outer: the state component or parameter z
+template <typename R>
+__device__ __forceinline__ R awg_custom_third(const R* th, const R* x, const R* u, int i, int z) {
+  typedef Dual<R, 1> S1;
+  typedef Dual<S1, 1> S2;
+  typedef Dual<S2, 1> T;
+  T xt[CD], tht[CNT], ft[CD];
+  for (int l = 0; l < CD; ++l) {
+    S1 a_(x[l]);
+    a_.g[0] = u[l];
+    S2 b;
+    b.v = a_;
+    b.g[0] = S1(l == i ? R(1) : R(0));
+    xt[l].v = b;
+    xt[l].g[0] = S2(l == z ? R(1) : R(0));
+  }
+  for (int kk = 0; kk < CNTH; ++kk) {
+    tht[kk].v = S2(th[kk]);
+    tht[kk].g[0] = S2(kk + CD == z ? R(1) : R(0));
+  }
+  custom_f<R, T>(xt, tht, ft);
+  R v = R(0);
+  for (int l = 0; l < CD; ++l)
+    if (l == i) v = ft[l].g[0].g[0].g[0];
+  return v;
 }
 }  // namespace cdkf
 )";
@@ -595,8 +645,8 @@ int launch_custom_awg(const WgArgs<R>& a, R* grad, R* grad_model, R* scratch, lo
 template int launch_custom_awg<float>(const WgArgs<float>&, float*, float*, float*, long, int, int, size_t, hipStream_t);
 template int launch_custom_awg<double>(const WgArgs<double>&, double*, double*, double*, long, int, int, size_t, hipStream_t);
 
-// the reverse sweep takes a drift given as source if: linear emission, state_order 'first' (or 'second' with grad(div f) registered as
-// identically zero), and the (column, direction) tasks of its second-derivative contraction fit the workgroup: state_dim + n_theta <= 256
+// the reverse sweep takes a drift given as source if: linear emission, state_order 'first' or 'second' (grad(div f) registered as
+// identically zero or as "auto"), and the (column, direction) tasks of its second-derivative contraction fit the workgroup: state_dim + n_theta <= 256
 // and <= one LDS slot (q x ld reals, q = max(state_dim, emission_dim))
 bool custom_adjoint_available(const cdkf_model* mdl, const cdkf_opts* o) {
   if (!custom_kind(mdl->drift_kind) || mdl->emission_kind != 0) return false;
@@ -604,7 +654,8 @@ bool custom_adjoint_available(const cdkf_model* mdl, const cdkf_opts* o) {
   std::lock_guard<std::mutex> lock(g_mutex);
   const CustomDrift& c = g_drifts[mdl->drift_kind - CDKF_DRIFT_CUSTOM_BASE];
   if (c.d != mdl->state_dim || c.n_theta != mdl->n_theta) return false;
-  if (o->state_order == CDKF_ORDER_SECOND && !(c.has_g && !c.auto_g && blank(c.g_src))) return false;
+  // 'second': grad(div f) registered as identically zero, or "auto" (third derivatives by triply nested dual numbers)
+  if (o->state_order == CDKF_ORDER_SECOND && !(c.has_g && (c.auto_g || blank(c.g_src)))) return false;
   const int q = c.d > mdl->emission_dim ? c.d : mdl->emission_dim, Z = c.d + c.n_theta;
   return Z <= 256 && Z <= q * (q | 1);
 }

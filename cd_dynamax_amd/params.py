@@ -114,7 +114,7 @@ class LearnableCustomDrift(NamedTuple):
                    nested dual numbers); "" : identically zero; None: EKF ``state_order='second'`` is refused
 
     ``cdnlgssm_loglik_and_grad`` / ``fit_sgd`` differentiate the log-likelihood w.r.t. ``theta`` (dual numbers again: ``state_order``
-    'first', or 'second' with ``divgrad_src=""``).  Wherever derivatives are derived, ``f_src`` is also compiled with a dual-number
+    'first', or 'second' with ``divgrad_src=""`` or ``"auto"`` -- the latter on the reverse sweep, third derivatives of f).  Wherever derivatives are derived, ``f_src`` is also compiled with a dual-number
     scalar type ``T`` in place of ``R``: declare temporaries ``auto`` or ``T`` there, not ``R``.
 
     ``R`` is the compute type (float or double).  state_dim, emission_dim <= 6: the register-resident kernels.  Beyond that

@@ -278,8 +278,9 @@ int cdkf_emission_moments_f32_dev(const cdkf_model* mdl, int64_t rows, const flo
  *      sweeps (round 3): jac_src must then be NULL and divgrad_src NULL, "" or "auto" -- a thread of the workgroup evaluates ONE
  *      direction of the Jacobian / one (i, k) pair of the second derivatives / one pair of sigma points, all by dual numbers; linear
  *      emission only; 10 - 20 s of compilation per variant on first use.  cdkf_ekf_loglik_grad[_all]_* take these drifts on the
- *      shape-generic reverse sweep compiled with the source (state_order 'first', or 'second' with an empty divgrad_src;
- *      state_dim + n_theta <= 256; max(state_dim, emission_dim) <= 43 in fp64, 62 in fp32) -- the _all variant at any state_dim.
+ *      shape-generic reverse sweep compiled with the source (state_order 'first', or 'second' with divgrad_src "" or "auto" -- third
+ *      derivatives by triply nested dual numbers; state_dim + n_theta <= 256; max(state_dim, emission_dim) <= 43 in fp64, 62 in
+ *      fp32) -- the _all variant at any state_dim.
  *      Returns the drift_kind to put in cdkf_model (>= CDKF_DRIFT_CUSTOM_BASE; the
  *      same sources give the same kind) or a negative CDKF_E* code.  Filters (EKF all orders, UKF), EKF smoother,
  *      forecast mode and the gradients are available for custom kinds; kernels compile

@@ -298,16 +298,17 @@ class CallableDrift:
 
     kind = "custom"
 
-    def __init__(self, theta, f, jac, divgrad=None, dtype=np.float64, vjp=None):
+    def __init__(self, theta, f, jac, divgrad=None, dtype=np.float64, vjp=None, gvjp=None):
         self.dtype = np.dtype(dtype)
         self.th = np.asarray(theta, dtype=self.dtype)
         self._f, self._jac, self._g = f, jac, divgrad
         # vjp(x [d], lam [d], G [d,d], theta) -> (xbar [d], thetabar): the gradient of lam . f + <G, F> (drift_vjp) written out by hand --
-        # what ekf_loglik_grad_adjoint needs of a drift it has no formulas for
-        self._vjp = vjp
+        # what ekf_loglik_grad_adjoint needs of a drift it has no formulas for; gvjp(x, u [d], theta) -> (xbar, thetabar): the gradient
+        # of u . grad(div f) (divgrad_vjp: state_order 'second')
+        self._vjp, self._gvjp = vjp, gvjp
 
     def cast(self, dtype):
-        return CallableDrift(self.th, self._f, self._jac, self._g, dtype=dtype, vjp=self._vjp)
+        return CallableDrift(self.th, self._f, self._jac, self._g, dtype=dtype, vjp=self._vjp, gvjp=self._gvjp)
 
     def f(self, x):
         return np.asarray(self._f(x, self.th), dtype=x.dtype)
@@ -1193,6 +1194,11 @@ def divgrad_vjp(drift, x, u):
     section 0.5 reads it): with lam the cotangent of the mean's slope, u = 0.5 P lam.  Only the MLP has g != 0 among the
     registry drifts.  Reverse mode through MLPDrift.divgrad, line by line (same intermediate names):
         M = (W1 W3)^T, G = M * W2, td = d2 G, s = G d1, s2 = dd2 s, tc = s2 W2, tq = dd1 td + d1 tc, g = W1^T tq."""
+    if drift.kind == "custom":
+        if drift._gvjp is None:
+            raise NotImplementedError("CallableDrift without gvjp")
+        xb, tb = drift._gvjp(x, u, drift.th)
+        return np.asarray(xb, np.float64), np.asarray(tb, np.float64)
     if drift.kind != "mlp":
         return np.zeros_like(x), np.zeros(drift.theta().size)
     W1, W2, W3 = drift.W1, drift.W2, drift.W3

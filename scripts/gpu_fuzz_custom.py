@@ -70,14 +70,16 @@ for case in range(cases):
         sm = cd.cdnlgssm_smoother(P, y, t[..., None])
         note("eks", max(relerr(sm.smoothed_means, ref["smoothed_means"]), relerr(sm.smoothed_covariances, ref["smoothed_covariances"])), 1e-8, tag)
     # gradients: state_order 'first', every leaf on the reverse sweep; the drift block alone (forward sensitivities up to six dimensions)
-    ll_ref, g_ref, ex = o.ekf_loglik_grad_adjoint(mdl, t, y, full=True, state_order="first")
-    hyp = cd.EKFHyperParams(state_order="first")
-    Pn = mk(None)
+    gorder = "second" if rng.random() < 0.5 else "first"     # 'second': grad(div f) "auto" -- third derivatives in the reverse sweep
+    ll_ref, g_ref, ex = o.ekf_loglik_grad_adjoint(mdl, t, y, full=True, state_order=gorder)
+    hyp = cd.EKFHyperParams(state_order=gorder)
+    Pn = mk("auto") if gorder == "second" else mk(None)
     ll, g = cd.cdnlgssm_loglik_and_grad_all(Pn, y, t[..., None], hyp)
     pairs = [(g.dynamics.drift.theta, g_ref), (g.initial.mean.params, ex["m0"]), (g.initial.cov.params, ex["P0"]),
              (g.dynamics.diffusion_coefficient.params, ex["L"]), (g.dynamics.diffusion_cov.params, ex["Qc"]),
              (g.emissions.emission_function.weights, ex["H"]), (g.emissions.emission_function.bias, ex["bias"]), (g.emissions.emission_cov.params, ex["R"])]
     scale = max(np.abs(b_).max() for _, b_ in pairs)
+    tag = tag + (gorder,)
     note("grad_all", max(max(np.abs(np.asarray(a_) - b_).max() / scale for a_, b_ in pairs), relerr(ll, ll_ref)), 1e-7, tag)
     ll, g1 = cd.cdnlgssm_loglik_and_grad(Pn, y, t[..., None], hyp)
     note("grad_theta", np.abs(np.asarray(g1.theta) - g_ref).max() / (np.abs(g_ref).max() + 1e-300), 1e-7, tag)

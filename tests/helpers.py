@@ -206,4 +206,6 @@ def random_quadratic_drift(rng, d):
         Q = np.einsum("ijk,j,k->i", A3, x, x)
         JQ = np.einsum("ijk,k->ij", S3, x)
         return xb, np.array([lam @ (B @ x) + (G * B).sum(), lam @ Q + (G * JQ).sum()])
-    return src, lambda th: o.CallableDrift(th, f, jac, g, vjp=vjp)
+    c3 = np.einsum("iik->k", S3)                 # g = theta_1 c3: gradient of u . g is (0, [0, u . c3])
+    gvjp = lambda x, u, th: (np.zeros_like(x), np.array([0.0, u @ c3]))
+    return src, lambda th: o.CallableDrift(th, f, jac, g, vjp=vjp, gvjp=gvjp)

@@ -325,8 +325,10 @@ def test_custom_drift_derivatives_by_dual_numbers(hip_lib):
     P1 = params_for(ref_mdl, cd.LearnableCustomDrift(th, L63_F, None, None))
     ll1, g1 = cd.cdnlgssm_loglik_and_grad(P1, y, t[..., None], cd.EKFHyperParams(state_order="first"))   # Jacobian AND gradient from f_src alone
     assert np.abs(np.asarray(g1.theta) - g_ref).max() < 1e-9 * np.abs(g_ref).max()
-    with pytest.raises(NotImplementedError, match="no gradient kernel"):
-        cd.cdnlgssm_loglik_and_grad(params_for(ref_mdl, cd.LearnableCustomDrift(th, L63_F, None, "auto")), y, t[..., None])
+    # the reference's default state_order 'second' with grad(div f) "auto" (= 0 for this drift): the reverse sweep with third derivatives
+    ll2, g2 = cd.cdnlgssm_loglik_and_grad(params_for(ref_mdl, cd.LearnableCustomDrift(th, L63_F, None, "auto")), y, t[..., None])
+    assert "ekf_adjoint_wg_kernel" in _ffi.lib().cdkf_last_kernel().decode()
+    assert np.abs(np.asarray(g2.theta) - g_ref).max() < 1e-9 * np.abs(g_ref).max()
 
     # (2) a drift that is not in any registry
     theta = np.array([1.7, 0.25, 0.4])
@@ -424,7 +426,8 @@ def cubic_l96_oracle(theta, d):
             xb[im2] -= G[i, im1]
         xb = xb - 6 * th[1] * np.diag(G) * x
         return xb, np.array([lam.sum(), -(lam * x ** 3).sum() - 3 * (np.diag(G) * x ** 2).sum()])
-    return o.CallableDrift(theta, f, jac, g, vjp=vjp)
+    gvjp = lambda x, u, th: (-6 * th[1] * u, np.array([0.0, -6 * (u * x).sum()]))   # gradient of u . g, g = -6 theta_1 x
+    return o.CallableDrift(theta, f, jac, g, vjp=vjp, gvjp=gvjp)
 
 
 def wide_model(rng, d, m, theta, selection=False):
@@ -558,8 +561,19 @@ def test_wide_custom_drift_loglik_gradient(hip_lib, d, m, selection):
             lls.append(cd.cdnlgssm_filter(params_for(mdl, cd.LearnableCustomDrift(th, src, None, None)), y, t[..., None], hyp).marginal_loglik)
         fd = (lls[0] - lls[1]) / (2 * h)
         assert np.abs(np.asarray(grads.dynamics.drift.theta)[:, p] - fd).max() < 2e-5 * max(1.0, np.abs(fd).max())
-    with pytest.raises(NotImplementedError):   # a non-zero grad(div f): the mean's second-order term is not reversed for custom drifts
-        cd.cdnlgssm_loglik_and_grad_all(params_for(mdl, cd.LearnableCustomDrift(theta, src, None, "auto")), y, t[..., None])
+    if d >= 4:   # the reference's default state_order = 'second' with a non-zero grad(div f) = -6 theta_1 x: third derivatives of f, triply nested duals
+        ll_ref, g_ref, full = o.ekf_loglik_grad_adjoint(mdl, t, y, full=True, state_order="second")
+        ll, grads = cd.cdnlgssm_loglik_and_grad_all(params_for(mdl, cd.LearnableCustomDrift(theta, src, None, "auto")), y, t[..., None])
+        np.testing.assert_allclose(ll, ll_ref, rtol=1e-10)
+        scale = np.abs(g_ref).max()
+        assert np.abs(np.asarray(grads.dynamics.drift.theta) - g_ref).max() < 1e-8 * scale
+        for got, want in ((grads.initial.mean.params, full["m0"]), (grads.initial.cov.params, full["P0"]), (grads.dynamics.diffusion_cov.params, full["Qc"]),
+                          (grads.emissions.emission_function.weights, full["H"]), (grads.emissions.emission_cov.params, full["R"])):
+            assert np.abs(np.asarray(got) - want).max() < 1e-8 * max(scale, np.abs(want).max())
+        ll1, _, _ = o.ekf_loglik_grad_adjoint(mdl, t, y, full=True, state_order="first")
+        assert np.abs(ll1 - ll_ref).max() > 1e-9 * np.abs(ll_ref).max()     # (the second-order term is not a no-op here)
+    with pytest.raises(NotImplementedError):   # without grad(div f) the default order is refused, as for the filter
+        cd.cdnlgssm_loglik_and_grad_all(params_for(mdl, cd.LearnableCustomDrift(theta, src, None, None)), y, t[..., None])
 
 
 @pytest.mark.gpu
