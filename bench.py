@@ -499,6 +499,10 @@ def other_configs(lib, timer, stream, t_h, y_h, only=None, comm=None, world=1, r
         ng, Tg = 256, 100
         out["config4_value_and_grad_lorenz96_d40_fp64_256x100"] = case(
             l96, grids(rng, ng, Tg), 8.0 + rng.standard_normal((ng, Tg, d)), "f64", _ffi.LAYOUT_TN, [], "mfma", {}, outputs=False, grad=True)
+    if want("config4_value_and_grad_lorenz96_d40_fp64_2048x500"):
+        # ... and on config 4's whole per-GPU slice (eight rounds of 256 workgroups; the forward sweep's four moment arrays: 26 GB of workspace)
+        out["config4_value_and_grad_lorenz96_d40_fp64_2048x500"] = case(
+            l96, grids(rng, n, T), 8.0 + rng.standard_normal((n, T, d)), "f64", _ffi.LAYOUT_TN, [], "mfma", {}, outputs=False, grad=True)
     rng = np.random.default_rng(2)
     d, m, h = 8, 4, 64
     mlp = cd.LearnableMLP(rng.standard_normal((h, d)) / np.sqrt(d), 0.1 * rng.standard_normal(h),
