@@ -131,6 +131,12 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
   const bool custom = a.kind >= kDriftCustomBase;
   const long ntheta = custom ? (long)CDKF_AWG_CUSTOM : (lin ? (long)d * d + d : 1);
   const bool second = custom && CDKF_AWG_CUSTOM_SECOND && a.order == 2;
+  // the (group, z) tasks of the second-derivative contraction and where their partial sums meet: a free slot, or -- for the smallest
+  // shapes, whose slots hold less than d + n_theta reals -- a free 64-entry vector
+  const int cZ = d + (int)ntheta;
+  R* const cpart = (SL >= cZ) ? slot(8) : (vec + 640);  // (vec + 640: g3, a Lorenz-96 vector)
+  const int ccap = (SL >= cZ) ? SL : 64;
+  const int cNG = (NT / cZ < ccap / cZ) ? NT / cZ : ccap / cZ;
 #else
   constexpr bool custom = false;
   constexpr bool second = false;
@@ -956,13 +962,11 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
             // parameter z, one nested-dual evaluation per (column j, z): the workgroup's threads as (group, z), a group takes every
             // NG-th column, the partial sums meet in a free slot
             R* G2 = slot(7);
-            R* part = slot(8);
+            R* part = cpart;
             gemm(d, d, d, [&](int i, int kk) { return Lam[i * ld + kk]; }, [&](int kk, int j) { return Ps[kk * ld + j]; },
                  [&](int i, int j, R v) { G2[i * ld + j] = R(2) * v; });
             __syncthreads();
-            const int Z = d + (int)ntheta;
-            int NG = NT / Z;
-            if (NG > SL / Z) NG = SL / Z;
+            const int Z = cZ, NG = cNG;
             if (tid < NG * Z) {
               const int grp = tid / Z, z = tid - grp * Z;
               R s2 = R(0);
@@ -1007,10 +1011,7 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
               g[d * d + c] += lamv[c];
 #ifdef CDKF_AWG_CUSTOM
             } else if (custom) {
-              const int Z = d + (int)ntheta;
-              int NG = NT / Z;
-              if (NG > SL / Z) NG = SL / Z;
-              for (int grp = 0; grp < NG; ++grp) s2 += slot(8)[grp * Z + c];
+              for (int grp = 0; grp < cNG; ++grp) s2 += cpart[grp * cZ + c];
 #endif
             } else {
               // xbar[i-1] += G[i][i+1] - G[i][i-2];  xbar[i+1] += G[i][i-1];  xbar[i-2] -= G[i][i-1]
@@ -1023,15 +1024,13 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
           }
 #ifdef CDKF_AWG_CUSTOM
           if (custom) {
-            const int Z = d + (int)ntheta;
+            const int Z = cZ;
             if (tid >= d && tid < Z) {
               // (straight into the result: as a register of these few lanes, kept across the steps like the Lorenz-96 forcing's, the
               //  sum came back holding only the LAST step's share in three of four builds of the run-time compiled kernel at -O2 / -O3
               //  -- scripts/gpu_fuzz_custom.py)
-              int NG = NT / Z;
-              if (NG > SL / Z) NG = SL / Z;
               R s3 = R(0);
-              for (int grp = 0; grp < NG; ++grp) s3 += slot(8)[grp * Z + tid];
+              for (int grp = 0; grp < cNG; ++grp) s3 += cpart[grp * Z + tid];
               g[tid - d] += s3;
             }
           } else

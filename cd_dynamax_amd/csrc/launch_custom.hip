@@ -647,7 +647,7 @@ template int launch_custom_awg<double>(const WgArgs<double>&, double*, double*, 
 
 // the reverse sweep takes a drift given as source if: linear emission, state_order 'first' or 'second' (grad(div f) registered as
 // identically zero or as "auto"), and the (column, direction) tasks of its second-derivative contraction fit the workgroup: state_dim + n_theta <= 256
-// and <= one LDS slot (q x ld reals, q = max(state_dim, emission_dim))
+// and <= one LDS slot (q x ld reals, q = max(state_dim, emission_dim)) or 64
 bool custom_adjoint_available(const cdkf_model* mdl, const cdkf_opts* o) {
   if (!custom_kind(mdl->drift_kind) || mdl->emission_kind != 0) return false;
   if (o->num_iter != 1 || o->forecast || o->state_order == CDKF_ORDER_ZEROTH) return false;
@@ -657,7 +657,7 @@ bool custom_adjoint_available(const cdkf_model* mdl, const cdkf_opts* o) {
   // 'second': grad(div f) registered as identically zero, or "auto" (third derivatives by triply nested dual numbers)
   if (o->state_order == CDKF_ORDER_SECOND && !(c.has_g && (c.auto_g || blank(c.g_src)))) return false;
   const int q = c.d > mdl->emission_dim ? c.d : mdl->emission_dim, Z = c.d + c.n_theta;
-  return Z <= 256 && Z <= q * (q | 1);
+  return Z <= 256 && (Z <= q * (q | 1) || Z <= 64);  // (the smallest shapes: the partial sums meet in a 64-entry vector instead of a slot)
 }
 
 template int launch_custom_wg<float>(const WgArgs<float>&, int, bool, bool, int, size_t, size_t, hipStream_t);

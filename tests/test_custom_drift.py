@@ -577,6 +577,35 @@ def test_wide_custom_drift_loglik_gradient(hip_lib, d, m, selection):
 
 
 @pytest.mark.gpu
+def test_scalar_custom_drift_gradient_of_every_leaf(hip_lib):
+    """The smallest shape, d = m = 1 (f = theta_0 - theta_1 x^3): a slot of the reverse sweep's LDS plan holds ONE real there, so the
+    partial sums of the second-derivative contraction meet in a vector instead -- scripts/gpu_fuzz_custom.py found the shape refused."""
+    rng = np.random.default_rng(611)
+    theta = np.array([0.4, 0.3])
+    f = lambda x, th: th[0] - th[1] * x ** 3
+    jac = lambda x, th: (-3 * th[1] * x ** 2)[..., None]
+    g = lambda x, th: -6 * th[1] * x
+    vjp = lambda x, lam, G, th: (-3 * th[1] * x ** 2 * lam - 6 * th[1] * x * G[0], np.array([lam[0], -lam[0] * x[0] ** 3 - 3 * G[0, 0] * x[0] ** 2]))
+    gvjp = lambda x, u, th: (-6 * th[1] * u, np.array([0.0, -6 * u[0] * x[0]]))
+    mdl = o.Model(o.CallableDrift(theta, f, jac, g, vjp=vjp, gvjp=gvjp), np.eye(1), 0.2 * np.eye(1), np.array([[0.8]]), np.array([0.1]), 0.3 * np.eye(1),
+                  np.array([0.5]), 0.4 * np.eye(1))
+    N, T = 5, 9
+    t = o.irregular_times(rng, N, T, 0.3)
+    y = o.simulate(mdl, t, rng)
+    for order, gsrc in (("first", None), ("second", "auto")):
+        P = params_for(mdl, cd.LearnableCustomDrift(theta, "fx[0] = theta[0] - theta[1] * x[0] * x[0] * x[0];", None, gsrc))
+        ll_ref, g_ref, full = o.ekf_loglik_grad_adjoint(mdl, t, y, full=True, state_order=order)
+        ll, grads = cd.cdnlgssm_loglik_and_grad_all(P, y, t[..., None], cd.EKFHyperParams(state_order=order))
+        np.testing.assert_allclose(ll, ll_ref, rtol=1e-10)
+        scale = np.abs(g_ref).max()
+        assert np.abs(np.asarray(grads.dynamics.drift.theta) - g_ref).max() < 1e-8 * scale, order
+        for got, want in ((grads.initial.mean.params, full["m0"]), (grads.initial.cov.params, full["P0"]), (grads.dynamics.diffusion_cov.params, full["Qc"]),
+                          (grads.emissions.emission_function.weights, full["H"]), (grads.emissions.emission_function.bias, full["bias"]),
+                          (grads.emissions.emission_cov.params, full["R"])):
+            assert np.abs(np.asarray(got) - want).max() < 1e-8 * max(scale, np.abs(want).max()), order
+
+
+@pytest.mark.gpu
 def test_custom_drift_gradient_with_a_long_snippet(hip_lib):
     """The case scripts/gpu_fuzz_custom.py (seed 12, case 0) caught: a 24-statement quadratic drift at d = 24, m = 22, intervals of
     several Runge-Kutta steps -- the run-time compiled reverse sweep returned d ll / d theta = 0.05 where it is 0.22: only the last
