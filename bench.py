@@ -124,6 +124,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-saturation", action="store_true", help="skip the informational extra measurements")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher set the environment: this process becomes the launcher (it has not touched the GPU and never will)
+        sys.exit(self_launch(args.gpus))
 
     from cd_dynamax_amd import _ffi, distributed as D_
     import cd_dynamax_amd as cd
@@ -260,6 +263,50 @@ def main():
         comm.close()
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` with no launcher: start the N ranks as CHILD processes (one per GPU, LOCAL_RANK = RANK; the environment
+    torch.distributed.run would export), rank 0 on this process's stdout (its ONE JSON line), the others' stdout on stderr.  The parent
+    makes no HIP call -- a process that has initialised the GPU must not exec or be replaced -- it only waits; the first rank that fails
+    takes the others down (by PID) and its exit code is the parent's."""
+    import socket
+    import subprocess
+    port = None
+    for _ in range(64):  # MASTER_PORT is the launcher's, the library's rendezvous listens on MASTER_PORT + 1: find a free pair
+        with socket.socket() as s1:
+            s1.bind(("127.0.0.1", 0))
+            cand = s1.getsockname()[1]
+            try:
+                with socket.socket() as s2:
+                    s2.bind(("127.0.0.1", cand + 1))
+            except OSError:
+                continue
+            port = cand
+            break
+    if port is None:
+        raise SystemExit("bench: no free port pair on 127.0.0.1")
+    env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_WORLD_SIZE=str(n),
+               CDKF_RDV_NONCE=str(int.from_bytes(os.urandom(7), "little")), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    procs = []
+    for r in range(n):
+        procs.append(subprocess.Popen(cmd, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                sys.stderr.write(f"bench: rank {r} exited with {code}; stopping the other ranks\n")
+                for q in live:
+                    procs[q].terminate()
+        time.sleep(0.05)
+    return rc
+
+
 def pmc_traffic(algorithmic_bytes, kernel_name):
     """HBM bytes per launch of the sweep kernel from the committed rocprofv3 PMC passes of THIS command
     (profiles/*_counters.json, written by scripts/summarize_prof.py from scripts/prof_r02.sh <tag> bench: FETCH_SIZE x2 per
@@ -296,13 +343,15 @@ def value_and_grad(lib, blk, opts, N, T, t_d, y_d, ll, timer, stream, reps=5):
     ms = timer.ms_per_call(run, reps)
     out = {"workload": "same batch: marginal log-likelihood + d/d(sigma, rho, beta) per trajectory, fp64",
            "kernel": lib.cdkf_last_kernel().decode(), "kernel_ms": ms,
-           "trajectories_per_sec": N / (ms * 1e-3), "grad_sum": [float(v) for v in grad.numpy().sum(0)]}
+           "trajectories_per_sec": N / (ms * 1e-3), "grad_sum": [float(v) for v in grad.numpy().sum(0)],
+           "roofline": grad_roofline("hbm", 3, 3, 12, N, T, ms, "f64", 3)}
     # every trainable leaf (what fit_sgd differentiates): + m0, P0, L Qc L^T, H, bias, R per trajectory
     gm = DeviceArray((N, _ffi.model_grad_size(3, 3)), np.float64)
     run_all = lambda: _ffi.check(lib.cdkf_ekf_loglik_grad_all_f64_dev(C.byref(blk.c), C.byref(opts), N, T, t_d.ptr, y_d.ptr, ll.ptr,
                                                                       grad.ptr, gm.ptr, st.ptr, stream))
     out["all_parameters_ms"] = timer.ms_per_call(run_all, reps)
     out["all_parameters_kernel"] = lib.cdkf_last_kernel().decode()
+    out["all_parameters_roofline"] = grad_roofline("hbm", 3, 3, 12, N, T, out["all_parameters_ms"], "f64", 3 + _ffi.model_grad_size(3, 3))
     gm.free()
     return out
 
@@ -351,6 +400,27 @@ def flops_per_step(d, m, c_drift, smoother=False):
     return total
 
 
+def grad_roofline(bound, d, m, c_drift, n, T, ms, dtype, n_out, steps_per_interval=1.0):
+    """Roofline of a value-and-gradient call ("what a gradient is priced at").  ALGORITHMIC work of reverse mode:
+    the forward recursion once and its adjoint, in which every product of the forward has two -- 3 x the filter's flops (SURVEY.md
+    section 8d per step, x the mean number of Runge-Kutta steps per interval on grids with several); a replay of stage values the
+    forward sweep did not keep is the implementation's choice and is NOT counted.  Algorithmic bytes: the log-likelihood-only stream
+    B_ll = s (1 + m) per trajectory-step read once (the reverse sweep's second read of it and every checkpoint are implementation
+    traffic) + s (1 + n_out) per trajectory written.  Both fractions are given; `bound` names the one SURVEY 8d assigns the config."""
+    s = 8 if dtype == "f64" else 4
+    rhs = 2 * d ** 3 + 2 * d ** 2 + c_drift
+    fwd = steps_per_interval * (6 * rhs + 54 * (d + d * d)) + 4 * m * d * d + 6 * m * m * d + m ** 3 / 3.0
+    flops, nbytes = 3.0 * fwd * n * T, s * (1 + m) * n * T + s * (1 + n_out) * n
+    peak = FP64_PEAK_TF if dtype == "f64" else FP32_PEAK_TF
+    tf, gbs = flops / (ms * 1e-3) / 1e12, nbytes / (ms * 1e-3) / 1e9
+    r = ({"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak} if bound == "mfma" else
+         {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS})
+    r.update({"algorithmic_flops_per_trajectory_step": 3.0 * fwd, "algorithmic_bytes_per_trajectory_step": s * (1 + m),
+              "flops_frac": tf / peak, "hbm_frac": gbs / HBM_PEAK_GBS,
+              "count": "3 x forward flops (forward + adjoint, no replay); log-likelihood-only bytes"})
+    return r
+
+
 def other_configs(lib, timer, stream, t_h, y_h, only=None, comm=None, world=1, rank=0):
     """Informational: the other BASELINE.json configurations (their per-GPU slices where the config spans 8 GPUs) through
     the same C ABI, device-resident inputs, native layouts, synthetic data of SURVEY.md section 8d; each with the roofline that
@@ -386,7 +456,7 @@ def other_configs(lib, timer, stream, t_h, y_h, only=None, comm=None, world=1, r
         return float(comm.allreduce_max_host([ms])[0]) if (comm is not None and world > 1) else ms
 
     def case(params, t, y, dtype, layout, algos, bound, per_step, outputs=True, grad=False, state_order=2, keep=None, flags=0,
-             suffix=""):
+             suffix="", c_drift=12.0):
         blk = _model_block(params)
         opts = _ffi.default_opts()
         opts.layout = layout
@@ -444,6 +514,9 @@ def other_configs(lib, timer, stream, t_h, y_h, only=None, comm=None, world=1, r
             ms = over_ranks(timer.ms_per_call(run, 3))
             res["loglik_and_grad_all_ms"] = ms
             res["loglik_and_grad_all_kernel"] = lib.cdkf_last_kernel().decode()
+            # (Runge-Kutta steps per interval of THIS grid at dt0 = 0.01: 1 on the headline grids, about 5.5 on the long-gap one)
+            spi = float(np.maximum(1.0, np.ceil(np.diff(t, axis=1) / 0.01 - 1e-9)).mean())
+            res["loglik_and_grad_all_roofline"] = grad_roofline(bound, d, m, c_drift, n, T, ms, dtype, n_th + n_md, spi)
             res["loglik_and_grad_all_trajectories_per_sec"] = world * n / (ms * 1e-3)
             res["reduced_doubles_per_step"] = 1 + n_th + n_md
             bufs = [g, gm, y_g]
@@ -498,11 +571,13 @@ def other_configs(lib, timer, stream, t_h, y_h, only=None, comm=None, world=1, r
         # gradient path, one trajectory per CU): value + every gradient on a slice of one trajectory per compute unit
         ng, Tg = 256, 100
         out["config4_value_and_grad_lorenz96_d40_fp64_256x100"] = case(
-            l96, grids(rng, ng, Tg), 8.0 + rng.standard_normal((ng, Tg, d)), "f64", _ffi.LAYOUT_TN, [], "mfma", {}, outputs=False, grad=True)
+            l96, grids(rng, ng, Tg), 8.0 + rng.standard_normal((ng, Tg, d)), "f64", _ffi.LAYOUT_TN, [], "mfma", {}, outputs=False, grad=True,
+            c_drift=6 * d)
     if want("config4_value_and_grad_lorenz96_d40_fp64_2048x500"):
         # ... and on config 4's whole per-GPU slice (eight rounds of 256 workgroups; the forward sweep's four moment arrays: 26 GB of workspace)
         out["config4_value_and_grad_lorenz96_d40_fp64_2048x500"] = case(
-            l96, grids(rng, n, T), 8.0 + rng.standard_normal((n, T, d)), "f64", _ffi.LAYOUT_TN, [], "mfma", {}, outputs=False, grad=True)
+            l96, grids(rng, n, T), 8.0 + rng.standard_normal((n, T, d)), "f64", _ffi.LAYOUT_TN, [], "mfma", {}, outputs=False, grad=True,
+            c_drift=6 * d)
     rng = np.random.default_rng(2)
     d, m, h = 8, 4, 64
     mlp = cd.LearnableMLP(rng.standard_normal((h, d)) / np.sqrt(d), 0.1 * rng.standard_normal(h),
@@ -522,13 +597,16 @@ def other_configs(lib, timer, stream, t_h, y_h, only=None, comm=None, world=1, r
     t5, y5 = grids(rng, n, T), rng.standard_normal((n, T, m))
     if want("config5_slice_mlp_d8_fp64_1024x1000"):
         out["config5_slice_mlp_d8_fp64_1024x1000"] = case(
-            c5, t5, y5, "f64", _ffi.LAYOUT_TN, ["ekf_filter"], "mfma", {"ekf_filter": mlp_flops}, outputs=False, grad=True, state_order=2)
+            c5, t5, y5, "f64", _ffi.LAYOUT_TN, ["ekf_filter"], "mfma", {"ekf_filter": mlp_flops}, outputs=False, grad=True, state_order=2,
+            c_drift=10.2e3 + 73.7e3)
     if want("config5_slice_mlp_d8_fp32_1024x1000"):  # the reference's own precision (fp32), its default state_order
         out["config5_slice_mlp_d8_fp32_1024x1000"] = case(
-            c5, t5, y5, "f32", _ffi.LAYOUT_TN, ["ekf_filter"], "mfma", {"ekf_filter": mlp_flops}, outputs=False, grad=True, state_order=2)
+            c5, t5, y5, "f32", _ffi.LAYOUT_TN, ["ekf_filter"], "mfma", {"ekf_filter": mlp_flops}, outputs=False, grad=True, state_order=2,
+            c_drift=10.2e3 + 73.7e3)
     if want("config5_slice_mlp_d8_fp64_1024x1000_first_order"):
         out["config5_slice_mlp_d8_fp64_1024x1000_first_order"] = case(
-            c5, t5, y5, "f64", _ffi.LAYOUT_TN, ["ekf_filter"], "mfma", {"ekf_filter": mlp_flops}, outputs=False, grad=True, state_order=1)
+            c5, t5, y5, "f64", _ffi.LAYOUT_TN, ["ekf_filter"], "mfma", {"ekf_filter": mlp_flops}, outputs=False, grad=True, state_order=1,
+            c_drift=10.2e3 + 73.7e3)
     return out
 
 

@@ -110,7 +110,7 @@ SYMBOLS = (
      "cdkf_kf_smoother1_f64", "cdkf_kf_smoother1_f32", "cdkf_kf_smoother1_f64_dev", "cdkf_kf_smoother1_f32_dev",
      "cdkf_kf_smoother1_supported", "cdkf_kf_pushforward_f64", "cdkf_kf_pushforward_f32", "cdkf_grad_supported", "cdkf_grad_all_supported", "cdkf_release_workspace", "cdkf_ekf_loglik_grad_all_f64",
      "cdkf_ekf_loglik_grad_all_f32", "cdkf_ekf_loglik_grad_all_f64_dev", "cdkf_ekf_loglik_grad_all_f32_dev", "cdkf_grad_sum_f64_dev",
-     "cdkf_grad_sum_f32_dev", "cdkf_comm_unique_id", "cdkf_comm_init_rank", "cdkf_comm_init_all", "cdkf_comm_rank", "cdkf_comm_world",
+     "cdkf_grad_sum_f32_dev", "cdkf_comm_preflight", "cdkf_comm_unique_id", "cdkf_comm_init_rank", "cdkf_comm_init_all", "cdkf_comm_rank", "cdkf_comm_world",
      "cdkf_ll_allreduce", "cdkf_comm_allreduce_max", "cdkf_ll_allreduce_all", "cdkf_comm_destroy", "cdkf_rdv_create",
      "cdkf_rdv_broadcast", "cdkf_rdv_allreduce", "cdkf_rdv_barrier", "cdkf_rdv_destroy", "cdkf_last_kernel", "cdkf_event_create",
      "cdkf_event_record", "cdkf_event_elapsed_ms", "cdkf_event_destroy", "cdkf_stream_create", "cdkf_stream_destroy",
@@ -256,6 +256,7 @@ def lib() -> C.CDLL:
             f = getattr(L, f"cdkf_{a}_{p}_dev")
             f.argtypes = base + [C.c_void_p]
             f.restype = C.c_int
+    L.cdkf_comm_preflight.argtypes = [C.c_int]
     L.cdkf_comm_unique_id.argtypes = [C.c_void_p]
     L.cdkf_comm_init_rank.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int, C.c_int]
     L.cdkf_comm_init_all.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int)]

@@ -61,15 +61,24 @@ const Rccl* rccl() {
   std::lock_guard<std::mutex> lock(g_rccl_mutex);
   if (g_rccl.handle) return &g_rccl;
   const char* env = std::getenv("CDKF_RCCL_PATH");
-  const char* names[] = {env && env[0] ? env : "librccl.so.1", "librccl.so.1", "librccl.so"};
   void* h = nullptr;
-  for (const char* nm : names) {
-    h = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
-    if (h) break;
-  }
-  if (!h) {
-    set_error("RCCL is not available: %s", dlerror());
-    return nullptr;
+  if (env && env[0]) {
+    // a library the caller NAMED is the only candidate: falling back to the system's copy would pair this process's HIP runtime with
+    // an RCCL built against another one -- the failure is reported (and agreed on by all ranks, cdkf_comm_preflight) instead
+    h = dlopen(env, RTLD_NOW | RTLD_LOCAL);
+    if (!h) {
+      set_error("RCCL is not available: CDKF_RCCL_PATH=%s: %s", env, dlerror());
+      return nullptr;
+    }
+  } else {
+    for (const char* nm : {"librccl.so.1", "librccl.so"}) {
+      h = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+      if (h) break;
+    }
+    if (!h) {
+      set_error("RCCL is not available: %s", dlerror());
+      return nullptr;
+    }
   }
   Rccl r;
   r.handle = h;
@@ -110,6 +119,29 @@ struct cdkf_comm {
 };
 
 static_assert(sizeof(ncclUniqueId) == CDKF_COMM_ID_BYTES, "include/cdkf.h: CDKF_COMM_ID_BYTES");
+
+// What a rank can find out about its own chances of joining a communicator WITHOUT entering a collective: the library and its symbols
+// (dlopen), the device index against the devices this process sees.  ncclCommInitRank's bootstrap has no timeout, so a rank that fails
+// here while its peers are already inside it strands the job: every rank takes this step first, the ranks agree on the outcome over
+// the rendezvous (a max of failure flags), and only a unanimous pass goes on to ncclCommInitRank (cd_dynamax_amd/distributed.py).
+extern "C" int cdkf_comm_preflight(int device) {
+  if (device < 0) {
+    set_error("cdkf_comm_preflight: bad device %d", device);
+    return CDKF_EINVAL;
+  }
+  if (!rccl()) return CDKF_EUNSUPPORTED;
+  int n = 0;
+  const hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    set_error("cdkf_comm_preflight: hipGetDeviceCount failed: %s", hipGetErrorString(e));
+    return CDKF_EHIP;
+  }
+  if (device >= n) {
+    set_error("cdkf_comm_preflight: device %d of %d visible device(s)", device, n);
+    return CDKF_EHIP;
+  }
+  return CDKF_OK;
+}
 
 extern "C" int cdkf_comm_unique_id(void* id) {
   if (!id) {
@@ -287,9 +319,18 @@ constexpr int kIoTimeoutMs = 600000;  // a peer that says nothing for ten minute
 // The hello a rank sends carries a per-job nonce: CDKF_RDV_NONCE from the environment (any 63-bit number the launcher hands to every
 // rank), else one derived from the rendezvous port and the world size -- so that a stray connection, or a rank of ANOTHER job whose
 // store happens to sit on the same port, is turned away with a NACK instead of taking a slot (and the run's sums with it).
+// The default also folds in whatever job identity the launcher exports to every rank alike (TORCHELASTIC_RUN_ID, SLURM_JOB_ID,
+// MASTER_ADDR -- FNV-1a over their text), so two jobs on the default port and the same world size no longer share a nonce unless
+// the launcher gives them nothing to tell them apart; CDKF_RDV_NONCE is then the way to isolate them.
 int64_t rdv_nonce(int port, int world) {
   if (const char* e = std::getenv("CDKF_RDV_NONCE")) return (int64_t)std::strtoll(e, nullptr, 0);
-  return (int64_t)0x63646b66 * 1000003 + (int64_t)port * 4099 + world;
+  uint64_t h = 1469598103934665603ull;
+  for (const char* name : {"TORCHELASTIC_RUN_ID", "SLURM_JOB_ID", "MASTER_ADDR"})
+    if (const char* v = std::getenv(name)) {
+      for (const char* c = v; *c; ++c) h = (h ^ (unsigned char)*c) * 1099511628211ull;
+      h = (h ^ 0xffu) * 1099511628211ull;
+    }
+  return (int64_t)((h >> 1) ^ ((uint64_t)0x63646b66 * 1000003 + (uint64_t)port * 4099 + (uint64_t)world));
 }
 struct RdvHello {
   int32_t magic, rank, world, pad;

@@ -153,7 +153,9 @@ int launch_ekf_grad(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_
 bool ukf_grad_shape_available(const cdkf_model* mdl, const cdkf_opts* o) {
   cdkf_opts e = *o;
   e.state_order = CDKF_ORDER_FIRST;  // (the unscented filter has no state_order; the field is ignored)
-  return sens_shape_available(mdl, &e) && mdl->emission_kind == 0;
+  // (run-time compiled drifts have forward-sensitivity kernels of their own, but none through the sigma-point closed form: only the
+  // built-in CDKF_GRAD_SHAPES dispatch below -- saying yes here would pass fit_sgd's gate and fail after its batches were uploaded)
+  return !custom_kind(mdl->drift_kind) && sens_shape_available(mdl, &e) && mdl->emission_kind == 0;
 }
 template <typename R>
 int launch_ukf_grad(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll, R* grad,
@@ -169,6 +171,8 @@ int launch_ukf_grad(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_
     return run_grad<R, D_, M_, DRIFT<R, D_>>(mdl, o, N, T, t, y, ll, grad, status, stream, true);
   CDKF_GRAD_SHAPES(X)
 #undef X
+  set_error("ukf_loglik_grad: drift_kind=%d state_dim=%d emission_dim=%d passed the shape gate but has no instantiation", mdl->drift_kind,
+            mdl->state_dim, mdl->emission_dim);
   return CDKF_EUNSUPPORTED;
 }
 template int launch_ukf_grad<float>(const cdkf_model*, const cdkf_opts*, int64_t, int64_t, const float*, const float*, float*, float*,

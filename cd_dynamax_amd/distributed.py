@@ -36,12 +36,19 @@ class Comm:
             # Joining RCCL is a collective: a rank that cannot (no library, no device) must not leave the others waiting in it.  Every
             # step of the set-up is therefore taken by ALL ranks, and after each they agree over the rendezvous (a max of failure flags)
             # whether to go on; if any rank failed, all of them fall back to the host all-reduce of the rendezvous and say so.
+            # First the part a rank can check ALONE (cdkf_comm_preflight: RCCL loads, the device exists): ncclCommInitRank's bootstrap has
+            # no timeout, so a rank that would fail before reaching it -- no librccl on its node, LOCAL_RANK beyond its devices -- must be
+            # found out while nobody is inside the collective yet.
             ident = C.create_string_buffer(128)
             err = ""
-            if self.rank == 0 and self._L.cdkf_comm_unique_id(ident) != 0:
+            if self._L.cdkf_comm_preflight(int(device)) != 0:
                 err = self._L.cdkf_last_error().decode("utf-8", "replace")
-            _ffi.check(self._L.cdkf_rdv_broadcast(self._rdv, ident, 128))
             failed = bool(self._host([1.0 if err else 0.0], 1)[0])
+            if not failed:
+                if self.rank == 0 and self._L.cdkf_comm_unique_id(ident) != 0:
+                    err = self._L.cdkf_last_error().decode("utf-8", "replace")
+                _ffi.check(self._L.cdkf_rdv_broadcast(self._rdv, ident, 128))
+                failed = bool(self._host([1.0 if err else 0.0], 1)[0])
             if not failed:
                 if self._L.cdkf_comm_init_rank(C.byref(self._comm), ident, self.rank, self.world, int(device)) != 0:
                     err = self._L.cdkf_last_error().decode("utf-8", "replace")

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define CDKF_VERSION 107 /* 0.3.0 */
+#define CDKF_VERSION 108 /* 0.4.0 */
 
 /* error codes */
 #define CDKF_OK 0
@@ -415,6 +415,10 @@ typedef struct cdkf_comm cdkf_comm;
 #define CDKF_COMM_ID_BYTES 128 /* sizeof(ncclUniqueId) */
 /* one process per GPU: rank 0 makes the id, the ranks exchange it (cdkf_rdv_broadcast below, or any channel of the caller's),
  * every rank joins with the device it sweeps on */
+/* (before any of it: what this rank can check alone -- RCCL loads and resolves, `device` is one of the visible devices.  No collective
+ * inside; the ranks agree on the outcomes over the rendezvous and enter ncclCommInitRank, whose bootstrap has no timeout, only if all
+ * passed.  Replaces nothing in the reference: it runs one device.) */
+int cdkf_comm_preflight(int device);
 int cdkf_comm_unique_id(void* id /* [CDKF_COMM_ID_BYTES] */);
 int cdkf_comm_init_rank(cdkf_comm** comm, const void* id, int rank, int world, int device);
 /* one process driving ndev GPUs: comms[i] lives on devices[i] (NULL: 0 .. ndev-1) */

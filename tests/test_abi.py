@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol(hip_lib):
 
 
 def test_version_and_default_opts(hip_lib):
-    assert hip_lib.cdkf_version() == 107
+    assert hip_lib.cdkf_version() == 108
     o = _ffi.default_opts()
     assert (o.state_order, o.num_iter, o.t_shared, o.device, o.layout) == (2, 1, 0, -1, 0)
     assert o.max_steps == 100000 and o.dt0 == 0.01 and o.dt_final == 1e-10 and o.cov_rescaling == 1.0

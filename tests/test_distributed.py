@@ -427,3 +427,60 @@ def test_comm_without_rccl_falls_back_on_every_rank(tmp_path, world):
     for p, (so, se) in zip(procs, outs):
         assert p.returncode == 0, so + se
     assert sum(so.count("RANK_OK_") for so, _ in outs) == world
+
+
+def test_bench_gpus_n_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher in the environment starts its own two ranks as child processes: on
+    this GPU-less box both children must get as far as the library's "no HIP device" error -- not a SystemExit in the parent asking
+    for torch.distributed.run -- and the parent's exit code is the failing rank's."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible: the children would run the benchmark")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--no-cpu-baseline", "--no-saturation"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0
+    assert "torch.distributed.run" not in p.stderr, p.stderr
+    assert p.stderr.count("hipSetDevice") + p.stderr.count("no ROCm-capable device") >= 2 or "stopping the other ranks" in p.stderr, p.stderr
+    assert "bench: rank" in p.stderr and p.stdout.strip() == "", (p.stdout, p.stderr)
+
+
+ONE_RANK_FAILS_WORKER = r'''
+import os, sys
+rank, world, port = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+if rank == 1:
+    os.environ["CDKF_RCCL_PATH"] = "/nonexistent/librccl.so"   # this rank alone cannot even load RCCL
+sys.path[:0] = [os.environ["CDKF_ROOT"]]
+import numpy as np
+from cd_dynamax_amd import distributed as D
+comm = D.Comm(rank, world, "127.0.0.1", port, device=rank, timeout_ms=60000)
+assert not comm._comm and comm.rccl_error, "a communicator cannot exist here"
+s = comm.allreduce_sum_host([rank + 1.0])
+assert np.allclose(s, [world * (world + 1) / 2]), s
+comm.barrier()
+comm.close()
+sys.stdout.write("RANK_OK_%d %s\n" % (rank, comm.rccl_error.replace("\n", " ")[:120])); sys.stdout.flush()
+'''
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_comm_preflight_failure_of_one_rank_strands_nobody(tmp_path, world):
+    """ADVICE r3: a rank that fails BEFORE it would reach ncclCommInitRank (no librccl on its node: CDKF_RCCL_PATH names a missing
+    file and is now the only candidate) is found out in the non-collective preflight (cdkf_comm_preflight) that all ranks take first;
+    the ranks agree on it over the rendezvous and nobody enters the collective.  Rank 1's reason names its missing library, the other
+    ranks learn that a peer failed (on this GPU-less box their own preflight fails on the device instead: different reasons on different
+    ranks, one agreement).  The GPU leg -- rank 0 passes, rank 1 names a device that does not exist -- is tests/test_gpu_comm.py."""
+    script = tmp_path / "one_rank_fails_worker.py"
+    script.write_text(ONE_RANK_FAILS_WORKER)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, CDKF_ROOT=ROOT, OMP_NUM_THREADS="1")
+    env.pop("CDKF_RCCL_PATH", None)
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(world), str(port)], env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, so + se
+    assert sum(so.count("RANK_OK_") for so, _ in outs) == world
+    assert "CDKF_RCCL_PATH=/nonexistent/librccl.so" in outs[1][0], outs[1][0]

@@ -155,6 +155,47 @@ def test_two_ranks_share_the_one_device_if_rccl_allows(tmp_path, hip_lib):
     assert text.count("RCCL_REFUSED") in (0, 2), text  # either both joined RCCL or both took the host path
 
 
+PREFLIGHT_WORKER = r'''
+import os, sys
+sys.path[:0] = [os.environ["CDKF_ROOT"]]
+import numpy as np
+from cd_dynamax_amd import _ffi, distributed as D
+rank, world, port = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+n_dev = _ffi.lib().cdkf_device_count()
+device = 0 if rank == 0 else n_dev + 5      # rank 1 alone names a device that does not exist (LOCAL_RANK beyond its node's GPUs)
+comm = D.Comm(rank, world, "127.0.0.1", port, device=device, timeout_ms=60000)
+assert not comm._comm and comm.rccl_error, "rank 1 cannot join: nobody may"
+s = comm.allreduce_sum_host([rank + 1.0])
+assert np.allclose(s, [3.0]), s
+comm.barrier(); comm.close()
+sys.stdout.write("RANK_OK_%d %s\n" % (rank, comm.rccl_error.replace("\n", " ")[:120]))
+'''
+
+
+def test_preflight_failure_of_one_rank_strands_nobody(tmp_path, hip_lib):
+    """ADVICE r3 (medium): rank 0 is healthy (device 0, RCCL loads), rank 1 names a device beyond the visible ones.  Before the
+    preflight rank 1 returned early from cdkf_comm_init_rank while rank 0 sat in ncclCommInitRank's bootstrap (no timeout) for ever;
+    now rank 1 fails cdkf_comm_preflight, the agreement that follows tells rank 0, and both finish on the host all-reduce."""
+    script = tmp_path / "pf.py"
+    script.write_text(PREFLIGHT_WORKER)
+    port = _free_port()
+    env = dict(os.environ, CDKF_ROOT=ROOT)
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", str(port)], env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=180))
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("a rank was left waiting inside the RCCL set-up")
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, so + se
+    assert "RANK_OK_0 another rank could not join" in outs[0][0], outs[0][0]
+    assert "RANK_OK_1 cdkf_comm_preflight: device" in outs[1][0], outs[1][0]
+
+
 def test_fit_sgd_reduces_on_the_device_through_rccl(hip_lib):
     """fit_sgd(comm=Comm(..., device=0)): the SGD step's reduction (ssm_temissions.py:555-568) stays on the device -- sweeps ->
     cdkf_ll_sum / cdkf_grad_sum -> ONE in-place ncclAllReduce of 2 + n_theta + n_model doubles through a real RCCL communicator

@@ -1,7 +1,7 @@
 """Parity of the HIP path (through the C ABI) with the CPU oracle and the golden vectors.  GPU only.
 
 Tolerances: the fp64 engine must agree with the fp64 oracle to 1e-9 max-relative (observed ~1e-14; the
-north-star bar is 1e-5); the fp32 engine is compared with the SAME fp64 oracle at 3e-5 (observed ~1e-6; the
+north-star bar is 1e-5); the fp32 engine is compared with the SAME fp64 oracle at 1e-5 (observed ~1e-6; the
 reference itself runs in float32)."""
 import ctypes as C
 
@@ -15,7 +15,7 @@ from helpers import FILTER_KEYS, GOLDEN, linear_model, load_golden, lorenz96_mod
 
 pytestmark = pytest.mark.gpu
 
-TOL = {np.float64: 1e-9, np.float32: 3e-5}
+TOL = {np.float64: 1e-9, np.float32: 1e-5}  # fp32: the north-star's bar (BASELINE.json), observed ~1e-6
 
 
 def _check_filter(post, ref, tol):
@@ -71,7 +71,7 @@ def test_golden_vectors(hip_lib, name, dtype):
     mdl = model_from_fixture(g)
     P = params_from(mdl)
     s = int(g["stride"])
-    tol = 1e-9 if dtype == np.float64 else 1e-4
+    tol = 1e-9 if dtype == np.float64 else 1e-5
     dtf = float(g["dt_final"])
     y, t = g["y"].astype(dtype), g["t"][..., None]
     for order in ("first", "second"):
@@ -142,7 +142,7 @@ def test_sixteen_lane_kernel_paths(hip_lib):
     y = o.simulate(mdl, t, rng)
     hyp = cd.EKFHyperParams(diffeqsolve_settings={"dt0": 0.007})
     _check_filter(cd.cdnlgssm_filter(P, y, t[..., None], hyp), o.ekf_filter(mdl, t, y, dt0=0.007), 1e-9)
-    _check_filter(cd.cdnlgssm_filter(P, y.astype(np.float32), t[..., None]), o.ekf_filter(mdl, t, y), 3e-5)
+    _check_filter(cd.cdnlgssm_filter(P, y.astype(np.float32), t[..., None]), o.ekf_filter(mdl, t, y), 1e-5)
     ts = np.broadcast_to(t[0], t.shape)
     _check_filter(cd.cdnlgssm_filter(P, y, t[0][:, None]), o.ekf_filter(mdl, ts, y), 1e-9)
     sm = cd.cdnlgssm_smoother(P, y, t[..., None], hyp)
@@ -332,7 +332,7 @@ def test_c2_full_size_properties(hip_lib):
     # fp32 engine on the same batch stays within the north-star 1e-5 of the fp64 engine on the filtered moments
     ll32, outs32, st32, _ = _run_dev(hip_lib, "ekf_filter", blk, _ffi.default_opts(), t, y, np.float32, _ffi.LAYOUT_TCN)
     assert (st32 == 0).all()
-    assert relerr(outs32[0][sub], ref["filtered_means"]) < 1e-4
+    assert relerr(outs32[0][sub], ref["filtered_means"]) < 1e-5
 
 
 def test_c2_full_size_gradient_properties(hip_lib):
@@ -402,7 +402,7 @@ def test_unscented_filter_on_the_lane_grid(hip_lib, tmp_path):
     y = o.simulate(mdl, t, rng)
     ref = o.ukf_filter(mdl, t, y)
     _check_filter(cd.cdnlgssm_filter(P, y, t[..., None], cd.UKFHyperParams()), ref, 1e-9)
-    _check_filter(cd.cdnlgssm_filter(P, y.astype(np.float32), t[..., None], cd.UKFHyperParams()), ref, 3e-5)
+    _check_filter(cd.cdnlgssm_filter(P, y.astype(np.float32), t[..., None], cd.UKFHyperParams()), ref, 1e-5)
     # the same call in a process that keeps the sigma-point kernel
     np.savez(tmp_path / "in.npz", t=t, y=y)
     code = ("import sys, numpy as np; sys.path[:0] = [%r, %r, %r]\n"
@@ -446,7 +446,7 @@ def test_linear_drift_on_the_lane_grid(hip_lib):
         if m == 3:
             _check_filter(cd.cdnlgssm_filter(P, y, t[..., None], cd.UKFHyperParams()), o.ukf_filter(mdl, t, y), 1e-9)
             assert hip_lib.cdkf_last_kernel().startswith(b"filter_lpe_kernel<double, cdkf::DriftLinear<double, 3>, 3, 1, true, true>")
-        _check_filter(cd.cdnlgssm_filter(P, y.astype(np.float32), t[..., None]), o.ekf_filter(mdl, t, y), 3e-5)
+        _check_filter(cd.cdnlgssm_filter(P, y.astype(np.float32), t[..., None]), o.ekf_filter(mdl, t, y), 1e-5)
         ex = closed_form_kf(mdl, t[0], y[0])
         post = cd.cdnlgssm_filter(P, y[0], t[0][:, None])
         assert relerr(post.filtered_means, ex["filtered_means"]) < 1e-7 and abs(post.marginal_loglik - ex["marginal_loglik"]) < 1e-6 * abs(ex["marginal_loglik"])
@@ -591,7 +591,7 @@ def test_c3_full_size_properties(hip_lib):
     assert abs(llsum - ll.astype(np.float64).sum()) < 1e-6 * abs(llsum)
     assert relerr(ll[sub], ref["marginal_loglik"]) < 1e-5
     assert relerr(outs[0][sub], ref["filtered_means"]) < 1e-5
-    assert relerr(outs[1][sub], ref["filtered_covariances"]) < 3e-5
+    assert relerr(outs[1][sub], ref["filtered_covariances"]) < 1e-5
     ll, outs, st, _ = _run_dev(hip_lib, "ukf_filter", blk, _ffi.default_opts(), t, y, np.float64, _ffi.LAYOUT_TCN)
     assert (st == 0).all()
     assert relerr(ll[sub], ref["marginal_loglik"]) < 1e-9
@@ -683,7 +683,7 @@ def test_baseline_config1_linear_tracking_front_end(hip_lib):
     assert relerr(smw.smoothed_means, oref["smoothed_means"][0]) < 1e-9
     assert relerr(smw.smoothed_covariances, oref["smoothed_covariances"][0]) < 1e-9
     post32 = model.filter(params, y.astype(np.float32), filter_hyperparams=cd.KFHyperParams(dt_final=1.0))
-    assert relerr(post32.filtered_means, ref["filtered_means"]) < 1e-4
+    assert relerr(post32.filtered_means, ref["filtered_means"]) < 1e-5
 
 
 def test_forecast_matches_repeated_predict(hip_lib):
