@@ -138,6 +138,159 @@ __host__ __device__ inline long wave8_lds_reals(int kind) {
   return (kind == kDriftMlp) ? (long)W8Sh::end + kW8Waves * (W8Off::mlp_end + W8Off::rk) : (long)kW8Waves * (W8Off::base_end + W8Off::rk);
 }
 
+// ---- the measurement update of one observation on the 8 x 8 lane grid (inference_ekf.py:153-199, 285-286), shared by the sweeps of this
+// file and of cdkf_wave8s_kernels.h: W = the wavefront's tile block (W8Off offsets P .. tmp), lane (i, j) holds P_ij, lanes < d the mean.
+// Two factorisations side by side (TFP's of S for the log-likelihood, psd_solve's of sym(S) + 1e-9 I for the gain), num_iter
+// relinearisations, then symmetrize.  Wavefront-scope synchronisation only.
+template <typename R>
+CDKF_DEV void w8_measurement_update(R* W, int lane, int i, int j, int d, int m, bool inP, bool hsel, R Hij, R Rij, R hbj, R yl, int num_iter,
+                                    int forecast, R& Pij, R& mj, double& ll, bool& bad) {
+  for (int it = 0; it < (forecast ? 0 : num_iter); ++it) {
+    W[W8Off::P + lane] = Pij;
+    if (lane < kW8) W[W8Off::x + lane] = mj;
+    wave_sync();
+    // HP[r][c] (lane (r=i, c=j)) = sum_k H[r][k] P[k][c];  H row r lives on lanes (r, *)
+    R hp;
+    if (hsel) {
+      hp = (i < m) ? Pij : R(0);
+    } else {
+      W[W8Off::F + lane] = Hij;  // borrow the F tile for H
+      wave_sync();
+      hp = 0;
+#pragma unroll
+      for (int kk = 0; kk < kW8; ++kk) hp = rfma(W[W8Off::F + i * kW8 + kk], W[W8Off::P + kk * kW8 + j], hp);
+    }
+    W[W8Off::HP + lane] = hp;
+    wave_sync();
+    // S[r][c] = sum_k HP[r][k] H[c][k] + R[r][c]
+    R s;
+    if (hsel) {
+      s = (i < m && j < m) ? Pij + Rij : R(0);
+    } else {
+      s = 0;
+#pragma unroll
+      for (int kk = 0; kk < kW8; ++kk) s = rfma(W[W8Off::HP + i * kW8 + kk], W[W8Off::F + j * kW8 + kk], s);
+      s = (i < m && j < m) ? s + Rij : R(0);
+    }
+    // innovation on lanes < m
+    R vv = 0;
+    if (lane < kW8) {
+      if (hsel) {
+        vv = (lane < m) ? yl - mj : R(0);
+      } else {
+        R hm = 0;
+#pragma unroll
+        for (int kk = 0; kk < kW8; ++kk) hm = rfma(W[W8Off::F + lane * kW8 + kk], W[W8Off::x + kk], hm);
+        vv = (lane < m) ? yl - (hm + hbj) : R(0);
+      }
+      W[W8Off::v + lane] = vv;
+    }
+    // two factorisations side by side: S1 = S (TFP), S2 = symmetrize(S) + 1e-9 I (psd_solve); pad with identity
+    W[W8Off::S1 + lane] = s;
+    wave_sync();
+    R s1 = (i < m && j < m) ? s : (i == j ? R(1) : R(0));
+    R s2v = (i < m && j < m) ? R(0.5) * (s + W[W8Off::S1 + j * kW8 + i]) + (i == j ? R(1e-9) : R(0)) : (i == j ? R(1) : R(0));
+    wave_sync();
+    R inv1[kW8], inv2[kW8];
+#pragma unroll
+    for (int p = 0; p < kW8; ++p) {
+      if (p >= m) {  // (uniform) identity padding: pivot 1, nothing below it -- two synchronisations saved per padded column
+        inv1[p] = inv2[p] = R(1);
+        continue;
+      }
+      W[W8Off::S1 + lane] = s1;
+      W[W8Off::S2 + lane] = s2v;
+      wave_sync();
+      const R p1 = W[W8Off::S1 + p * kW8 + p], p2 = W[W8Off::S2 + p * kW8 + p];
+      if (p < m && (!(p1 > R(0)) || !(p2 > R(0)))) bad = true;
+      const R r1 = rrsqrt(p1), r2 = rrsqrt(p2);
+      inv1[p] = r1;
+      inv2[p] = r2;
+      // column p below the pivot, scaled; then the trailing update of the lower triangle
+      const R l1i = W[W8Off::S1 + i * kW8 + p] * r1, l1j = W[W8Off::S1 + j * kW8 + p] * r1;
+      const R l2i = W[W8Off::S2 + i * kW8 + p] * r2, l2j = W[W8Off::S2 + j * kW8 + p] * r2;
+      wave_sync();
+      if (j == p && i >= p) {
+        s1 = (i == p) ? p1 * r1 : l1i;
+        s2v = (i == p) ? p2 * r2 : l2i;
+      } else if (i > p && j > p && j <= i) {
+        s1 = rfma(-l1i, l1j, s1);
+        s2v = rfma(-l2i, l2j, s2v);
+      }
+    }
+    // now s1 / s2v hold L1 / L2 (lower triangles)
+    W[W8Off::S1 + lane] = s1;
+    W[W8Off::S2 + lane] = s2v;
+    wave_sync();
+    if (it == 0) {
+      // z = L1^-1 v (forward substitution on every lane redundantly), log-likelihood term
+      R z[kW8];
+      double qd = 0.0, pinv = 1.0;
+#pragma unroll
+      for (int r = 0; r < kW8; ++r) {
+        R w = W[W8Off::v + r];
+#pragma unroll
+        for (int c = 0; c < r; ++c) w = rfma(-W[W8Off::S1 + r * kW8 + c], z[c], w);
+        z[r] = w * inv1[r];
+        if (r < m) {
+          qd += (double)z[r] * (double)z[r];
+          pinv *= (double)inv1[r];
+        }
+      }
+      ll += -0.5 * qd + log(pinv) - 0.5 * m * 1.8378770664093454835606594728112;
+    }
+    // X = Sb^-1 HP : column c = j solved by the 8 lanes (*, j); every lane walks its own column redundantly
+    R xcol[kW8];
+#pragma unroll
+    for (int r = 0; r < kW8; ++r) {
+      R w = W[W8Off::HP + r * kW8 + j];
+#pragma unroll
+      for (int c = 0; c < r; ++c) w = rfma(-W[W8Off::S2 + r * kW8 + c], xcol[c], w);
+      xcol[r] = w * inv2[r];
+    }
+#pragma unroll
+    for (int r = kW8 - 1; r >= 0; --r) {
+      R w = xcol[r];
+#pragma unroll
+      for (int c = r + 1; c < kW8; ++c) w = rfma(-W[W8Off::S2 + c * kW8 + r], xcol[c], w);
+      xcol[r] = w * inv2[r];
+    }
+    R xij = 0;  // X[r=i][c=j] (select instead of a run-time register index)
+#pragma unroll
+    for (int r = 0; r < kW8; ++r)
+      if (r == i && r < m) xij = xcol[r];
+    W[W8Off::X + lane] = xij;
+    wave_sync();
+    // SX[r][c] = sum_q S[r][q] X[q][c]   (S re-read from the original tile: recompute from s saved in HP slot order)
+    // the original S was overwritten by its factor; keep a copy in SX's slot first
+    W[W8Off::SX + lane] = s;
+    wave_sync();
+    R sx = 0;
+#pragma unroll
+    for (int q = 0; q < kW8; ++q) sx = rfma(W[W8Off::SX + i * kW8 + q], xcol[q] * ((q < m) ? R(1) : R(0)), sx);
+    wave_sync();
+    W[W8Off::SX + lane] = (i < m) ? sx : R(0);
+    wave_sync();
+    // T[a][b] = sum_r X[r][a] SX[r][b];  P <- P - T;  m <- m + X^T v
+    R tt = 0;
+#pragma unroll
+    for (int r = 0; r < kW8; ++r) tt = rfma(W[W8Off::X + r * kW8 + i], W[W8Off::SX + r * kW8 + j], tt);
+    if (inP) Pij -= tt;
+    if (lane < kW8) {
+      R dm = 0;
+#pragma unroll
+      for (int r = 0; r < kW8; ++r) dm = rfma(W[W8Off::X + r * kW8 + lane], W[W8Off::v + r], dm);
+      if (lane < d) mj += dm;
+    }
+    wave_sync();
+  }
+  // symmetrize
+  W[W8Off::P + lane] = Pij;
+  wave_sync();
+  Pij = R(0.5) * (Pij + W[W8Off::P + j * kW8 + i]);
+  wave_sync();
+}
+
 template <typename R>
 __global__ __launch_bounds__(256, 1) void ekf_filter_wave8_kernel(const WgArgs<R> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -515,150 +668,7 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave8_kernel(const WgArgs<R
     W8_TICK(8)  // end of step: combination, stores
     // ---------------- update (inference_ekf.py:153-199, 285-286) ----------------
     const R yl = (lane < m) ? yp[k * a.y_sk + lane * a.y_si] : R(0);
-    for (int it = 0; it < (a.forecast ? 0 : a.num_iter); ++it) {
-      W[W8Off::P + lane] = Pij;
-      if (lane < kW8) W[W8Off::x + lane] = mj;
-      wave_sync();
-      // HP[r][c] (lane (r=i, c=j)) = sum_k H[r][k] P[k][c];  H row r lives on lanes (r, *)
-      R hp;
-      if (hsel) {
-        hp = (i < m) ? Pij : R(0);
-      } else {
-        W[W8Off::F + lane] = Hij;  // borrow the F tile for H
-        wave_sync();
-        hp = 0;
-#pragma unroll
-        for (int kk = 0; kk < kW8; ++kk) hp = rfma(W[W8Off::F + i * kW8 + kk], W[W8Off::P + kk * kW8 + j], hp);
-      }
-      W[W8Off::HP + lane] = hp;
-      wave_sync();
-      // S[r][c] = sum_k HP[r][k] H[c][k] + R[r][c]
-      R s;
-      if (hsel) {
-        s = (i < m && j < m) ? Pij + Rij : R(0);
-      } else {
-        s = 0;
-#pragma unroll
-        for (int kk = 0; kk < kW8; ++kk) s = rfma(W[W8Off::HP + i * kW8 + kk], W[W8Off::F + j * kW8 + kk], s);
-        s = (i < m && j < m) ? s + Rij : R(0);
-      }
-      // innovation on lanes < m
-      R vv = 0;
-      if (lane < kW8) {
-        if (hsel) {
-          vv = (lane < m) ? yl - mj : R(0);
-        } else {
-          R hm = 0;
-#pragma unroll
-          for (int kk = 0; kk < kW8; ++kk) hm = rfma(W[W8Off::F + lane * kW8 + kk], W[W8Off::x + kk], hm);
-          vv = (lane < m) ? yl - (hm + hbj) : R(0);
-        }
-        W[W8Off::v + lane] = vv;
-      }
-      // two factorisations side by side: S1 = S (TFP), S2 = symmetrize(S) + 1e-9 I (psd_solve); pad with identity
-      W[W8Off::S1 + lane] = s;
-      wave_sync();
-      R s1 = (i < m && j < m) ? s : (i == j ? R(1) : R(0));
-      R s2v = (i < m && j < m) ? R(0.5) * (s + W[W8Off::S1 + j * kW8 + i]) + (i == j ? R(1e-9) : R(0)) : (i == j ? R(1) : R(0));
-      wave_sync();
-      R inv1[kW8], inv2[kW8];
-#pragma unroll
-      for (int p = 0; p < kW8; ++p) {
-        if (p >= m) {  // (uniform) identity padding: pivot 1, nothing below it -- two synchronisations saved per padded column
-          inv1[p] = inv2[p] = R(1);
-          continue;
-        }
-        W[W8Off::S1 + lane] = s1;
-        W[W8Off::S2 + lane] = s2v;
-        wave_sync();
-        const R p1 = W[W8Off::S1 + p * kW8 + p], p2 = W[W8Off::S2 + p * kW8 + p];
-        if (p < m && (!(p1 > R(0)) || !(p2 > R(0)))) bad = true;
-        const R r1 = rrsqrt(p1), r2 = rrsqrt(p2);
-        inv1[p] = r1;
-        inv2[p] = r2;
-        // column p below the pivot, scaled; then the trailing update of the lower triangle
-        const R l1i = W[W8Off::S1 + i * kW8 + p] * r1, l1j = W[W8Off::S1 + j * kW8 + p] * r1;
-        const R l2i = W[W8Off::S2 + i * kW8 + p] * r2, l2j = W[W8Off::S2 + j * kW8 + p] * r2;
-        wave_sync();
-        if (j == p && i >= p) {
-          s1 = (i == p) ? p1 * r1 : l1i;
-          s2v = (i == p) ? p2 * r2 : l2i;
-        } else if (i > p && j > p && j <= i) {
-          s1 = rfma(-l1i, l1j, s1);
-          s2v = rfma(-l2i, l2j, s2v);
-        }
-      }
-      // now s1 / s2v hold L1 / L2 (lower triangles)
-      W[W8Off::S1 + lane] = s1;
-      W[W8Off::S2 + lane] = s2v;
-      wave_sync();
-      if (it == 0) {
-        // z = L1^-1 v (forward substitution on every lane redundantly), log-likelihood term
-        R z[kW8];
-        double qd = 0.0, pinv = 1.0;
-#pragma unroll
-        for (int r = 0; r < kW8; ++r) {
-          R w = W[W8Off::v + r];
-#pragma unroll
-          for (int c = 0; c < r; ++c) w = rfma(-W[W8Off::S1 + r * kW8 + c], z[c], w);
-          z[r] = w * inv1[r];
-          if (r < m) {
-            qd += (double)z[r] * (double)z[r];
-            pinv *= (double)inv1[r];
-          }
-        }
-        ll += -0.5 * qd + log(pinv) - 0.5 * m * 1.8378770664093454835606594728112;
-      }
-      // X = Sb^-1 HP : column c = j solved by the 8 lanes (*, j); every lane walks its own column redundantly
-      R xcol[kW8];
-#pragma unroll
-      for (int r = 0; r < kW8; ++r) {
-        R w = W[W8Off::HP + r * kW8 + j];
-#pragma unroll
-        for (int c = 0; c < r; ++c) w = rfma(-W[W8Off::S2 + r * kW8 + c], xcol[c], w);
-        xcol[r] = w * inv2[r];
-      }
-#pragma unroll
-      for (int r = kW8 - 1; r >= 0; --r) {
-        R w = xcol[r];
-#pragma unroll
-        for (int c = r + 1; c < kW8; ++c) w = rfma(-W[W8Off::S2 + c * kW8 + r], xcol[c], w);
-        xcol[r] = w * inv2[r];
-      }
-      R xij = 0;  // X[r=i][c=j] (select instead of a run-time register index)
-#pragma unroll
-      for (int r = 0; r < kW8; ++r)
-        if (r == i && r < m) xij = xcol[r];
-      W[W8Off::X + lane] = xij;
-      wave_sync();
-      // SX[r][c] = sum_q S[r][q] X[q][c]   (S re-read from the original tile: recompute from s saved in HP slot order)
-      // the original S was overwritten by its factor; keep a copy in SX's slot first
-      W[W8Off::SX + lane] = s;
-      wave_sync();
-      R sx = 0;
-#pragma unroll
-      for (int q = 0; q < kW8; ++q) sx = rfma(W[W8Off::SX + i * kW8 + q], xcol[q] * ((q < m) ? R(1) : R(0)), sx);
-      wave_sync();
-      W[W8Off::SX + lane] = (i < m) ? sx : R(0);
-      wave_sync();
-      // T[a][b] = sum_r X[r][a] SX[r][b];  P <- P - T;  m <- m + X^T v
-      R tt = 0;
-#pragma unroll
-      for (int r = 0; r < kW8; ++r) tt = rfma(W[W8Off::X + r * kW8 + i], W[W8Off::SX + r * kW8 + j], tt);
-      if (inP) Pij -= tt;
-      if (lane < kW8) {
-        R dm = 0;
-#pragma unroll
-        for (int r = 0; r < kW8; ++r) dm = rfma(W[W8Off::X + r * kW8 + lane], W[W8Off::v + r], dm);
-        if (lane < d) mj += dm;
-      }
-      wave_sync();
-    }
-    // symmetrize
-    W[W8Off::P + lane] = Pij;
-    wave_sync();
-    Pij = R(0.5) * (Pij + W[W8Off::P + j * kW8 + i]);
-    wave_sync();
+    w8_measurement_update<R>(W, lane, i, j, d, m, inP, hsel, Hij, Rij, hbj, yl, a.num_iter, a.forecast, Pij, mj, ll, bad);
     if (mj != mj) st |= kStatusNan;
     // ---------------- store filtered ----------------
     if (a.fm && lane < d) a.fm[n * a.m_sn + k * a.m_sk + lane * a.m_si] = mj;

@@ -61,6 +61,9 @@ struct WgArgs {
   // instead of repeating the forward pass (two tanh layers, the 64 x 64 x 9 products): 288 GB of HBM are cheaper than the matrix cores.
   R* ckm;
   int ckm_nf;
+  // MLP drift: W2 once more in the parameter block, zero-padded to [64][64] (cdkf_wave8s_kernels.h loads its register slices from it with
+  // one lane offset and immediates -- no bounds checks, no clamped addresses); -1: not there
+  long o_w2pad;
 };
 constexpr int kCkStep = 6 * 72;  // reals per checkpointed step
 // fields of the MLP stage checkpoint (each 64 reals, lane-major): first order kMlpCkFirst of them, 'second' kMlpCkSecond

@@ -116,6 +116,15 @@ static int wg_prepare(WgArgs<R>& a, R** dev_block, ParamSlot** slot_out, const c
   a.o_R = push(mdl->R, (long)m * m);
   a.o_m0 = push(mdl->m0, d);
   a.o_P0 = push(mdl->P0, (long)d * d);
+  a.o_w2pad = -1;
+  if (mdl->drift_kind == CDKF_DRIFT_MLP_TANH && mdl->hidden1 <= 64 && mdl->hidden2 <= 64 && d <= 8) {
+    const int h1 = mdl->hidden1, h2 = mdl->hidden2;
+    const double* W2 = mdl->theta + (long)h1 * d + h1;
+    a.o_w2pad = (long)h.size();
+    h.resize(h.size() + 64 * 64, R(0));
+    for (int p = 0; p < h2; ++p)
+      for (int q = 0; q < h1; ++q) h[a.o_w2pad + p * 64 + q] = R(W2[p * h1 + q]);
+  }
   ParamSlot* slot = nullptr;
   int prc = param_pool_acquire(h.size() * sizeof(R), &slot);
   if (prc) return prc;

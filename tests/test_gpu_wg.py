@@ -1,5 +1,6 @@
 """Parity of the workgroup-per-trajectory kernels (state dimensions beyond the register kernels: Lorenz-96,
 MLP drift, larger linear models) with the oracle.  GPU only."""
+import os
 import numpy as np
 import pytest
 
@@ -931,7 +932,65 @@ def test_mlp_second_order_in_float32_on_the_wavefront_kernel(hip_lib, d, m, h):
     for order in ("first", "second"):
         ref = o.ekf_filter(mdl, t, y, state_order=order)
         p32 = cd.cdnlgssm_filter(P, y.astype(np.float32), t[..., None].astype(np.float32), cd.EKFHyperParams(state_order=order))
-        assert _ffi.lib().cdkf_last_kernel().decode().startswith("ekf_filter_wave8_kernel<float>")
+        # (fp32 runs the two-wavefront mapping by default, cdkf_wave8s_kernels.h: the same lane-grid sums)
+        assert _ffi.lib().cdkf_last_kernel().decode().startswith(("ekf_filter_wave8_kernel<float>", "ekf_filter_wave8s_kernel<float"))
         assert relerr(p32.filtered_means, ref["filtered_means"]) < 5e-6, order
         assert relerr(p32.predicted_covariances, ref["predicted_covariances"]) < 5e-6, order
         np.testing.assert_allclose(p32.marginal_loglik, ref["marginal_loglik"], rtol=2e-5)
+
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+W8_SPLIT_WORKER = r'''
+import os, sys
+sys.path[:0] = [os.environ["CDKF_ROOT"], os.path.join(os.environ["CDKF_ROOT"], "oracle"), os.path.join(os.environ["CDKF_ROOT"], "tests")]
+import numpy as np
+import cdkf_oracle as o
+import cd_dynamax_amd as cd
+from cd_dynamax_amd import _ffi
+from helpers import FILTER_KEYS, mlp_model, params_from, relerr
+want = "wave8s" if os.environ["CDKF_W8_SPLIT"] == "2" else "wave8_kernel"
+worst = {}
+for d, m, h in ((8, 4, (64, 64)), (5, 2, (24, 40)), (8, 8, (64, 17))):
+    rng = np.random.default_rng(100 + d + m)
+    mdl = mlp_model(rng, d, m, h)
+    N, T = 6, 40
+    t = o.irregular_times(rng, N, T, 0.006 * T)
+    t[:, 30:] += 0.07          # one interval of eight Dormand-Prince steps
+    y = o.simulate(mdl, t, rng)
+    P = params_from(mdl)
+    for order in ("first", "second"):
+        ref = o.ekf_filter(mdl, t, y, state_order=order)
+        for dtype, tol in ((np.float64, 1e-9), (np.float32, 1e-5)):
+            post = cd.cdnlgssm_filter(P, y.astype(dtype), t[..., None], cd.EKFHyperParams(state_order=order))
+            assert want in _ffi.lib().cdkf_last_kernel().decode(), _ffi.lib().cdkf_last_kernel().decode()
+            errs = [relerr(getattr(post, k), ref[k]) for k in FILTER_KEYS]
+            errs.append(float(np.max(np.abs(np.asarray(post.marginal_loglik, np.float64) - ref["marginal_loglik"]) / np.abs(ref["marginal_loglik"]))))
+            worst[dtype.__name__] = max(worst.get(dtype.__name__, 0.0), max(errs))
+            assert max(errs) < tol, (d, m, h, order, dtype.__name__, errs)
+        # the same sweep as the forward pass of the reverse sweep (it leaves the stage checkpoints the adjoint starts from)
+        ll_ref, g_ref = o.ekf_loglik_grad_adjoint(mdl, t, y, state_order=order)
+        ll, g = cd.cdnlgssm_loglik_and_grad(P, y, t[..., None], cd.EKFHyperParams(state_order=order))
+        flat = np.concatenate([np.asarray(a).reshape(N, -1) for a in g], axis=-1)
+        assert np.abs(flat - g_ref).max() < 1e-8 * np.abs(g_ref).max(), (d, m, h, order)
+        np.testing.assert_allclose(ll, ll_ref, rtol=1e-10)
+        ll32, g32 = cd.cdnlgssm_loglik_and_grad(P, y.astype(np.float32), t[..., None].astype(np.float32), cd.EKFHyperParams(state_order=order))
+        flat32 = np.concatenate([np.asarray(a).reshape(N, -1) for a in g32], axis=-1)
+        assert np.abs(flat32 - g_ref).max() < 2e-2 * np.abs(g_ref).max(), (d, m, h, order)
+sys.stdout.write("SPLIT_OK %s %s\n" % (os.environ["CDKF_W8_SPLIT"], worst))
+'''
+
+
+@pytest.mark.parametrize("split", ["0", "2"])
+def test_mlp_sweep_on_one_and_on_two_wavefronts_per_trajectory(hip_lib, tmp_path, split):
+    """The MLP-drift sweep has two mappings -- one wavefront per trajectory (cdkf_wave8_kernels.h) and one trajectory over two
+    wavefronts (cdkf_wave8s_kernels.h; the default in fp32) -- and the library picks by precision.  Both are held to the oracle in BOTH
+    precisions here (CDKF_W8_SPLIT forces one; the library reads it once, hence the child process): full and ragged hidden sizes, m = d,
+    both state orders, an eight-step interval, and as the forward pass of the reverse sweep (value and every weight gradient).
+    Reference: inference_ekf.py:46-148, 202-326; ssm_temissions.py:550-568."""
+    import subprocess, sys
+    script = tmp_path / "w8_split_worker.py"
+    script.write_text(W8_SPLIT_WORKER)
+    env = dict(os.environ, CDKF_ROOT=ROOT, CDKF_W8_SPLIT=split)
+    p = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and f"SPLIT_OK {split}" in p.stdout, p.stdout + p.stderr
