@@ -6,9 +6,15 @@
 // compiled on first use and cached for the life of the process.  Above six state or emission dimensions (up to what the workgroup
 // kernels' LDS plan holds, <= 64) the same source is compiled into the workgroup-per-trajectory sweeps of cdkf_wg2_kernels.h instead
 // (launch_custom_wg): Jacobian, grad(div f) and sigma-point evaluations spread over the workgroup's threads, all by dual numbers.
+#include <dirent.h>
 #include <dlfcn.h>
 #include <hip/hiprtc.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
 #include <map>
 #include <mutex>
 #include <string>
@@ -69,6 +75,144 @@ std::string source_dir() {
     g_src_dir = ".";
   }
   return g_src_dir;
+}
+
+// ---- code objects on disk ---------------------------------------------------------------------------------------------------------
+// A variant takes hipRTC 0.4 - 20 s (the workgroup kernels with a drift compiled in: 10 - 20 s) and was paid again by every process.  The
+// code object now also goes to a cache directory -- CDKF_RTC_CACHE_DIR, else rtc_cache/ beside the library (in-tree: it travels with the
+// built library), else ~/.cache/cdkf_rtc -- under a key that covers everything the output depends on: the generated source, the
+// compile options (target, optimisation level), the hipRTC version, and the CONTENT of every header the source can include (all *.h /
+// *.inc of the kernel directory: a changed kernel invalidates every entry).  Files are written to a temporary name and renamed, so
+// concurrent processes (ranks, pytest workers) never see a partial entry; a damaged or foreign file fails its header check and is
+// recompiled over.  CDKF_RTC_CACHE=0 turns the cache off.
+struct Fnv128 {  // two independent 64-bit FNV-1a streams (different offsets / an extra rotation): 128 bits of key
+  uint64_t a = 1469598103934665603ull, b = 0x9e3779b97f4a7c15ull;
+  void feed(const void* p, size_t n) {
+    const unsigned char* c = static_cast<const unsigned char*>(p);
+    for (size_t i = 0; i < n; ++i) {
+      a = (a ^ c[i]) * 1099511628211ull;
+      b = ((b << 5) | (b >> 59)) ^ (c[i] + 0x100 * (i & 0xff));
+      b *= 0x100000001b3ull;
+    }
+  }
+  void feed(const std::string& s) {
+    const uint64_t n = s.size();
+    feed(&n, sizeof(n));
+    feed(s.data(), s.size());
+  }
+};
+
+bool rtc_cache_enabled() {
+  const char* e = getenv("CDKF_RTC_CACHE");
+  return !(e && e[0] == '0');
+}
+
+// hash of every header under the kernel directory (once per process)
+const std::string& rtc_headers_digest() {
+  static std::string digest;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    Fnv128 h;
+    const std::string dir = source_dir();
+    std::vector<std::string> names;
+    if (DIR* dp = opendir(dir.c_str())) {
+      while (dirent* e = readdir(dp)) {
+        const std::string nm = e->d_name;
+        const size_t dot = nm.find_last_of('.');
+        if (dot == std::string::npos) continue;
+        const std::string ext = nm.substr(dot);
+        if (ext == ".h" || ext == ".inc") names.push_back(nm);
+      }
+      closedir(dp);
+    }
+    std::sort(names.begin(), names.end());
+    for (const std::string& nm : names) {
+      h.feed(nm);
+      if (FILE* f = fopen((dir + "/" + nm).c_str(), "rb")) {
+        char buf[65536];
+        size_t n;
+        while ((n = fread(buf, 1, sizeof(buf), f)) > 0) h.feed(buf, n);
+        fclose(f);
+      }
+    }
+    char out[40];
+    snprintf(out, sizeof(out), "%016llx%016llx", (unsigned long long)h.a, (unsigned long long)h.b);
+    digest = out;
+  });
+  return digest;
+}
+
+std::string rtc_cache_dir() {
+  static std::string dir;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    auto usable = [](const std::string& d) {
+      if (d.empty()) return false;
+      (void)mkdir(d.c_str(), 0755);
+      return access(d.c_str(), W_OK | X_OK) == 0;
+    };
+    if (const char* e = getenv("CDKF_RTC_CACHE_DIR")) {
+      if (usable(e)) dir = e;
+      return;
+    }
+    const std::string beside = source_dir() + "/../lib/rtc_cache";
+    if (usable(beside)) {
+      dir = beside;
+      return;
+    }
+    std::string home;
+    if (const char* x = getenv("XDG_CACHE_HOME")) home = x;
+    else if (const char* hm = getenv("HOME")) home = std::string(hm) + "/.cache";
+    if (!home.empty()) {
+      (void)mkdir(home.c_str(), 0755);
+      if (usable(home + "/cdkf_rtc")) dir = home + "/cdkf_rtc";
+    }
+  });
+  return dir;
+}
+
+std::string rtc_cache_key(const std::string& src, const std::string& arch, const char* olevel, const std::string& expr) {
+  Fnv128 h;
+  int maj = 0, min = 0;
+  (void)hiprtcVersion(&maj, &min);
+  const std::string meta = "cdkf-rtc-1|" + arch + "|" + olevel + "|hiprtc " + std::to_string(maj) + "." + std::to_string(min) + "|" +
+                           rtc_headers_digest() + "|" + expr;
+  h.feed(meta);
+  h.feed(src);
+  char out[40];
+  snprintf(out, sizeof(out), "%016llx%016llx", (unsigned long long)h.a, (unsigned long long)h.b);
+  return out;
+}
+
+constexpr uint32_t kRtcMagic = 0x43524b43;  // "CKRC"
+bool rtc_cache_load(const std::string& key, std::vector<char>& code, std::string& lowered) {
+  const std::string dir = rtc_cache_dir();
+  if (dir.empty() || !rtc_cache_enabled()) return false;
+  FILE* f = fopen((dir + "/" + key + ".co").c_str(), "rb");
+  if (!f) return false;
+  uint32_t head[4] = {0, 0, 0, 0};  // magic, name bytes, code bytes (low, high)
+  bool ok = fread(head, sizeof(head), 1, f) == 1 && head[0] == kRtcMagic && head[1] < 4096;
+  const uint64_t nbytes = ok ? ((uint64_t)head[3] << 32) | head[2] : 0;
+  ok = ok && nbytes > 0 && nbytes < (1ull << 30);
+  if (ok) {
+    lowered.assign(head[1], '\0');
+    code.resize(nbytes);
+    ok = (head[1] == 0 || fread(&lowered[0], head[1], 1, f) == 1) && fread(code.data(), nbytes, 1, f) == 1 && fgetc(f) == EOF;
+  }
+  fclose(f);
+  if (!ok) code.clear();
+  return ok;
+}
+void rtc_cache_store(const std::string& key, const std::vector<char>& code, const std::string& lowered) {
+  const std::string dir = rtc_cache_dir();
+  if (dir.empty() || !rtc_cache_enabled() || code.empty()) return;
+  const std::string final_name = dir + "/" + key + ".co", tmp = final_name + ".tmp" + std::to_string((long)getpid());
+  FILE* f = fopen(tmp.c_str(), "wb");
+  if (!f) return;
+  const uint32_t head[4] = {kRtcMagic, (uint32_t)lowered.size(), (uint32_t)(code.size() & 0xffffffffu), (uint32_t)((uint64_t)code.size() >> 32)};
+  const bool ok = fwrite(head, sizeof(head), 1, f) == 1 && (lowered.empty() || fwrite(lowered.data(), lowered.size(), 1, f) == 1) &&
+                  fwrite(code.data(), code.size(), 1, f) == 1;
+  if (fclose(f) != 0 || !ok || rename(tmp.c_str(), final_name.c_str()) != 0) (void)unlink(tmp.c_str());
 }
 
 std::string generate_source(const CustomDrift& c, int bytes, int m, int ukf, int zeroth, int forecast, int smoother,
@@ -236,6 +380,11 @@ int compile_variant(const CustomDrift& c, const Key& key, const std::string& arc
   }
   const std::string src = generate_source(c, std::get<1>(key), std::get<2>(key), std::get<3>(key), std::get<4>(key),
                                           std::get<5>(key), std::get<6>(key), std::get<7>(key), ek ? &em : nullptr);
+  const std::string cache_key = rtc_cache_key(src, arch, "-O3", "cdkf_custom_kernel");
+  {
+    std::string unused;
+    if (rtc_cache_load(cache_key, code, unused)) return CDKF_OK;
+  }
   hiprtcProgram prog = nullptr;
   if (hiprtcCreateProgram(&prog, src.c_str(), "cdkf_custom_drift.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
     set_error("custom drift: hiprtcCreateProgram failed");
@@ -267,6 +416,7 @@ int compile_variant(const CustomDrift& c, const Key& key, const std::string& arc
   code.resize(sz);
   hiprtcGetCode(prog, code.data());
   hiprtcDestroyProgram(&prog);
+  rtc_cache_store(cache_key, code, std::string());
   return CDKF_OK;
 }
 
@@ -516,6 +666,9 @@ int compile_wg_variant(const CustomDrift& c, const WgKey& key, const std::string
   const int bytes = std::get<1>(key), ept = std::get<2>(key), ukf = std::get<3>(key), smoother = std::get<4>(key);
   const std::string src = smoother == 2 ? generate_awg_source(c, (size_t)std::get<5>(key)) : generate_wg_source(c, (size_t)std::get<5>(key));
   const std::string expr = wg_kernel_expr(bytes, ept, ukf, smoother);
+  const char* olevel = (ept >= 8 && smoother != 2) ? "-O1" : "-O3";
+  const std::string cache_key = rtc_cache_key(src, arch, olevel, expr);
+  if (!getenv("CDKF_CUSTOM_DUMP") && rtc_cache_load(cache_key, code, lowered) && !lowered.empty()) return CDKF_OK;
   hiprtcProgram prog = nullptr;
   if (hiprtcCreateProgram(&prog, src.c_str(), "cdkf_custom_drift_wg.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
     set_error("custom drift: hiprtcCreateProgram failed");
@@ -529,7 +682,6 @@ int compile_wg_variant(const CustomDrift& c, const WgKey& key, const std::string
   // (the instantiations with eight or more entries per thread are built at -O1 in the library too: launch_wg8.hip, Makefile)
   const std::string inc = "-I" + source_dir(), off = "--offload-arch=" + arch;
   // -O1: the wg kernels' instantiations with eight or more entries per thread, as in the library (launch_wg8.hip, Makefile)
-  const char* olevel = (ept >= 8 && smoother != 2) ? "-O1" : "-O3";
   const char* opts[] = {off.c_str(), olevel, "-std=c++17", inc.c_str(), "-Wno-pass-failed"};
   const hiprtcResult res = hiprtcCompileProgram(prog, 5, opts);
   if (res != HIPRTC_SUCCESS) {
@@ -561,6 +713,7 @@ int compile_wg_variant(const CustomDrift& c, const WgKey& key, const std::string
   code.resize(sz);
   hiprtcGetCode(prog, code.data());
   hiprtcDestroyProgram(&prog);
+  rtc_cache_store(cache_key, code, lowered);
   if (const char* dir = getenv("CDKF_CUSTOM_DUMP")) {  // debugging aid: the generated source and its code object
     const std::string base = std::string(dir) + "/cdkf_custom_wg_" + std::to_string(bytes) + "_" + std::to_string(ept) + "_" + std::to_string(ukf) +
                              "_" + std::to_string(smoother);

@@ -10,6 +10,18 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+def _gpu_visible():
+    """Without touching the GPU (and without importing torch): does this box have an AMD compute device node?"""
+    return os.path.exists("/dev/kfd")
+
+
+# The code objects hipRTC produces are cached on disk (launch_custom.hip; the GPU suite was paying 10 - 20 s per variant and process).  On
+# a box without a GPU -- where the suite's job is to show that the run-time compilation itself works -- the cache is switched off unless a
+# test sets its own directory, so every variant there really goes through hipRTC.
+if not _gpu_visible():
+    os.environ.setdefault("CDKF_RTC_CACHE", "0")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `pytest -m gpu` on the GPU box)")
 

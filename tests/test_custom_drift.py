@@ -1,6 +1,7 @@
 """User-supplied drifts compiled at run time (cdkf_custom_drift_register; reference: any callable as
 ParamsCDNLGSSMDynamics.drift, cdnlgssm_utils.py:38-61).  CPU: registration, hipRTC compilation of every variant (no GPU
 needed), diagnostics for broken snippets.  GPU: parity with the oracle running the same drift as NumPy callables."""
+import os
 import numpy as np
 import pytest
 
@@ -663,3 +664,52 @@ def test_lorenz96_as_source_matches_the_built_in_drift_at_forty_dimensions(hip_l
         assert relerr(sm.smoothed_means, ref["smoothed_means"]) < 1e-9
         np.testing.assert_allclose(sm.marginal_loglik, ref["marginal_loglik"], rtol=1e-10)
     assert "custom drift" not in _ffi.lib().cdkf_last_kernel().decode()
+
+
+RTC_CACHE_WORKER = r'''
+import os, sys, time
+sys.path[:0] = [os.environ["CDKF_ROOT"]]
+from cd_dynamax_amd import _ffi
+L = _ffi.lib()
+k = _ffi.register_custom_drift(2, 2, "fx[0] = x[1];\nfx[1] = -theta[0] * sin(x[0]) - theta[1] * x[1] * R(1.5);", None, None)
+t0 = time.perf_counter()
+assert L.cdkf_custom_drift_compile(k, 8, 1, 0, 1, 0) == 0, L.cdkf_last_error().decode()   # lane-per-trajectory filter, fp64
+k7 = _ffi.register_custom_drift(7, 1, "for (int i = 0; i < 7; ++i) fx[i] = -theta[0] * x[i] * x[(i + 1) % 7];", None, None)
+assert L.cdkf_custom_drift_compile(k7, 8, 3, 0, 1, 0) == 0, L.cdkf_last_error().decode()  # workgroup filter (lowered name kept)
+sys.stdout.write("SECONDS %.3f\n" % (time.perf_counter() - t0))
+'''
+
+
+def test_rtc_code_objects_are_cached_on_disk(tmp_path):
+    """VERDICT r3 item 7a: hipRTC code objects persist (key: generated source + options + target + hipRTC version + the content of every
+    kernel header).  Cold process: entries appear; warm process: the same calls return without compiling; a damaged entry is recompiled
+    over; CDKF_RTC_CACHE=0 writes nothing.  No GPU needed (cdkf_custom_drift_compile names the target itself)."""
+    import subprocess, sys
+    script = tmp_path / "rtc_cache_worker.py"
+    script.write_text(RTC_CACHE_WORKER)
+    cache = tmp_path / "cache"
+    cache.mkdir()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(**extra):
+        env = dict(os.environ, CDKF_ROOT=root, CDKF_RTC_CACHE_DIR=str(cache), CDKF_RTC_CACHE="1")
+        env.update(extra)
+        p = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stdout + p.stderr
+        return float(p.stdout.split("SECONDS")[1])
+
+    cold = run()
+    entries = sorted(os.listdir(cache))
+    assert len(entries) == 2 and all(e.endswith(".co") for e in entries), entries
+    blobs = [open(cache / e, "rb").read() for e in entries]
+    warm = run()
+    assert warm < 0.5 * cold and warm < 2.0, (cold, warm)
+    assert [open(cache / e, "rb").read() for e in entries] == blobs            # untouched by the warm run
+    with open(cache / entries[0], "r+b") as f:                                # a damaged entry: bad magic
+        f.write(b"XXXX")
+    run()
+    assert open(cache / entries[0], "rb").read() == blobs[0]                  # recompiled over, bit-identical code object
+    for e in entries:
+        os.remove(cache / e)
+    run(CDKF_RTC_CACHE="0")
+    assert os.listdir(cache) == []
