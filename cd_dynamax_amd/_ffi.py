@@ -83,6 +83,8 @@ class CdkfOpts(C.Structure):
         ("pid_d", C.c_double),
         ("layout_in", C.c_int32),
         ("flags", C.c_int32),
+        ("dtmin", C.c_double),
+        ("dtmax", C.c_double),
     ]
 
 

@@ -96,6 +96,10 @@ int check_common(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T
                 "not both zero (solver %d, rtol %g, atol %g)", o->solver, o->rtol, o->atol);
       return CDKF_EINVAL;
     }
+    if (!(o->dtmin >= 0) || !(o->dtmax > 0) || !(o->dtmin <= o->dtmax)) {
+      set_error("adaptive stepping: need 0 <= dtmin <= dtmax, dtmax > 0 (got dtmin %g, dtmax %g; defaults 0 and infinity)", o->dtmin, o->dtmax);
+      return CDKF_EINVAL;
+    }
   }
   if (o->flags & ~CDKF_FLAG_UKF_SIGMA_POINTS) {
     set_error("opts.flags = 0x%x has bits this library version does not know (CDKF_FLAG_*)", (unsigned)o->flags);
@@ -473,6 +477,8 @@ void cdkf_default_opts(cdkf_opts* o) {
   o->pid_d = 0.0;
   o->layout_in = CDKF_LAYOUT_SAME;
   o->flags = 0;
+  o->dtmin = 0.0;
+  o->dtmax = HUGE_VAL;
   o->max_steps = 100000;
   o->dt0 = 0.01;
   o->dt_final = 1e-10;

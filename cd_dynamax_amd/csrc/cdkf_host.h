@@ -157,6 +157,8 @@ inline bool fill_rk_tab(const cdkf_opts* o, RkTab<R>& tb) {
   tb.c1 = R((o->pid_i + o->pid_p + o->pid_d) / ord);
   tb.c2 = R(-(o->pid_p + 2 * o->pid_d) / ord);
   tb.c3 = R(o->pid_d / ord);
+  tb.dtmin = R(o->dtmin);
+  tb.dtmax = R(o->dtmax);
   return true;
 }
 

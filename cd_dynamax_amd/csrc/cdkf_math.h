@@ -223,6 +223,7 @@ struct RkTab {
   int adaptive, fsal;
   R berr[7];
   R rtol, atol, c1, c2, c3;
+  R dtmin, dtmax;  // bounds on every proposed step size (0 / +inf: none); a step taken at dtmin is kept (PIDController force_dtmin)
 };
 
 template <typename R, int NS, typename Rhs>
@@ -277,7 +278,9 @@ CDKF_DEV bool integrate_adaptive(R (&y)[NS], R t0, R t1, R dt0, long max_steps, 
   static_assert(D > 0, "integrate_adaptive: unexpected state size");
   constexpr int COUNT = MEAN_ONLY ? NERR : D + D * D;
   R tprev = t0;
-  R tnext = rmin(t0 + dt0, t1);
+  const R dt_first = rmin(dt0, tb.dtmax);
+  bool at_min = dt_first <= tb.dtmin;
+  R tnext = rmin(t0 + rmax(dt_first, tb.dtmin), t1);
   R inv1 = R(1), inv2 = R(1);
   long steps = 0;
   bool capped = false;
@@ -338,7 +341,7 @@ CDKF_DEV bool integrate_adaptive(R (&y)[NS], R t0, R t1, R dt0, long max_steps, 
       sq = rfma(w * sc, sc, sq);
     }
     const R scaled = rsqrt_(sq / R(COUNT));
-    const bool keep = scaled < R(1);
+    const bool keep = scaled < R(1) || at_min;
     const R inv = (scaled == R(0)) ? R(__builtin_huge_val()) : R(1) / scaled;
     R factor = R(0.9) * rpow(inv, tb.c1);
     if (tb.c2 != R(0)) factor *= rpow(inv1, tb.c2);
@@ -347,7 +350,10 @@ CDKF_DEV bool integrate_adaptive(R (&y)[NS], R t0, R t1, R dt0, long max_steps, 
     // rejects the step and shrinks it by factormin; diffrax's clip would propagate the NaN and end in its max_steps error
     factor = rmin(rmax(factor, keep ? R(1) : R(0.2)), R(10));
     const R nt0 = keep ? tnext : tprev;
-    const R nt1 = nt0 + dt * factor;
+    R dtn = rmin(dt * factor, tb.dtmax);
+    at_min = dtn <= tb.dtmin;
+    dtn = rmax(dtn, tb.dtmin);
+    const R nt1 = nt0 + dtn;
     if (keep) {
 #pragma unroll
       for (int e = 0; e < NS; ++e) y[e] = yn[e];

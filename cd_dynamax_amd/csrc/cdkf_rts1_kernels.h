@@ -68,7 +68,10 @@ __global__ __launch_bounds__(64 * kRts1Waves) void pushforward_wave8_kernel(cons
   const R* tp = a.t + n * a.t_sn;
   const R t0 = tp[k * a.t_sk], t1 = tp[(k + 1) * a.t_sk];
   R Aij = (in && i == j) ? R(1) : R(0), Qij = 0;
-  R tprev = t0, tnext = rmin(t0 + a.dt0, t1);
+  // (adaptive: the first size clipped to [dtmin, dtmax], a step at dtmin kept -- integrate_adaptive, cdkf_math.h)
+  const R dt_first = tb.adaptive ? rmin(a.dt0, tb.dtmax) : a.dt0;
+  bool at_min = tb.adaptive && dt_first <= tb.dtmin;
+  R tprev = t0, tnext = rmin(t0 + (tb.adaptive ? rmax(dt_first, tb.dtmin) : a.dt0), t1);
   R inv1 = R(1), inv2 = R(1);
   long steps = 0;
   while (tprev < t1 && steps < a.max_steps) {
@@ -105,14 +108,17 @@ __global__ __launch_bounds__(64 * kRts1Waves) void pushforward_wave8_kernel(cons
 #pragma unroll
       for (int o_ = 32; o_ >= 1; o_ >>= 1) ssum += __shfl_xor(ssum, o_);
       const R scaled = rsqrt_((R)ssum / R(2 * d * d));
-      const bool keep = scaled < R(1);
+      const bool keep = scaled < R(1) || at_min;
       const R inv = (scaled == R(0)) ? R(__builtin_huge_val()) : R(1) / scaled;
       R factor = R(0.9) * rpow(inv, tb.c1);
       if (tb.c2 != R(0)) factor *= rpow(inv1, tb.c2);
       if (tb.c3 != R(0)) factor *= rpow(inv2, tb.c3);
       factor = rmin(rmax(factor, keep ? R(1) : R(0.2)), R(10));
       const R nt0 = keep ? tnext : tprev;
-      const R nt1 = nt0 + dt * factor;
+      R dtn = rmin(dt * factor, tb.dtmax);
+      at_min = dtn <= tb.dtmin;
+      dtn = rmax(dtn, tb.dtmin);
+      const R nt1 = nt0 + dtn;
       if (keep) {
         Aij = An;
         Qij = Qn;

@@ -801,7 +801,9 @@ __device__ __forceinline__ bool wg_integrate_adaptive(const WgLds<R>& L, const O
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
   const R count = with_P ? R(d) + R(d) * R(d) : R(d);
   R tprev = t0;
-  R tnext = rmin(t0 + dt0, t1);
+  const R dt_first = rmin(dt0, tb.dtmax);  // (the first size clipped to [dtmin, dtmax], a step at dtmin kept -- integrate_adaptive, cdkf_math.h)
+  bool at_min = dt_first <= tb.dtmin;
+  R tnext = rmin(t0 + rmax(dt_first, tb.dtmin), t1);
   R inv1 = R(1), inv2 = R(1);
   long steps = 0;
   int nacc = 0;  // accepted steps (logged for the reverse sweep)
@@ -878,14 +880,17 @@ __device__ __forceinline__ bool wg_integrate_adaptive(const WgLds<R>& L, const O
     double tot = 0.0;
     for (int w = 0; w < nw; ++w) tot += red[w];
     const R scaled = rsqrt_((R)tot / count);
-    const bool keep = scaled < R(1);
+    const bool keep = scaled < R(1) || at_min;
     const R inv = (scaled == R(0)) ? R(__builtin_huge_val()) : R(1) / scaled;
     R factor = R(0.9) * rpow(inv, tb.c1);
     if (tb.c2 != R(0)) factor *= rpow(inv1, tb.c2);
     if (tb.c3 != R(0)) factor *= rpow(inv2, tb.c3);
     factor = rmin(rmax(factor, keep ? R(1) : R(0.2)), R(10));  // (fmax / fmin: a NaN estimate rejects and shrinks, cdkf_math.h)
     const R nt0 = keep ? tnext : tprev;
-    const R nt1 = nt0 + dt * factor;
+    R dtn = rmin(dt * factor, tb.dtmax);
+    at_min = dtn <= tb.dtmin;
+    dtn = rmax(dtn, tb.dtmin);
+    const R nt1 = nt0 + dtn;
     if (keep) {
       if (threadIdx.x < d) mcur[threadIdx.x] = ynM;
       if (with_P) {

@@ -116,14 +116,17 @@ def _opts(hyperparams, num_iter: int = 1):
     if ctrl is not None and type(ctrl).__name__ != "ConstantStepSize" and ctrl != "ConstantStepSize":
         if not (hasattr(ctrl, "rtol") and hasattr(ctrl, "atol")):
             raise NotImplementedError(f"diffeqsolve_settings['stepsize_controller'] = {ctrl!r}: ConstantStepSize or PIDController")
-        defaults = dict(dtmin=None, dtmax=None, step_ts=None, jump_ts=None, safety=0.9, factormin=0.2, factormax=10.0,
-                        force_dtmin=True, error_order=None)
+        defaults = dict(step_ts=None, jump_ts=None, safety=0.9, factormin=0.2, factormax=10.0, force_dtmin=True, error_order=None)
         for k, v in defaults.items():
             if hasattr(ctrl, k) and getattr(ctrl, k) is not None and getattr(ctrl, k) != v:
                 raise NotImplementedError(f"PIDController.{k} = {getattr(ctrl, k)!r}: only the default ({v!r}) is implemented")
         o.adaptive = 1
         o.rtol, o.atol = float(ctrl.rtol), float(ctrl.atol)
         o.pid_p, o.pid_i, o.pid_d = (float(getattr(ctrl, k, v)) for k, v in (("pcoeff", 0.0), ("icoeff", 1.0), ("dcoeff", 0.0)))
+        if getattr(ctrl, "dtmin", None) is not None:
+            o.dtmin = float(ctrl.dtmin)
+        if getattr(ctrl, "dtmax", None) is not None:
+            o.dtmax = float(ctrl.dtmax)
     solver = settings.get("solver", "dopri5")
     name = solver.lower() if isinstance(solver, str) else type(solver).__name__.lower()   # 'tsit5' or a diffrax.Tsit5() object
     if name not in _ffi.SOLVERS:

@@ -92,14 +92,16 @@ class ConstantStepSize(NamedTuple):
 
 
 class PIDController(NamedTuple):
-    """diffrax.PIDController(rtol, atol, pcoeff, icoeff, dcoeff) for ``diffeqsolve_settings['stepsize_controller']``; the
-    remaining diffrax options are at their defaults (safety 0.9, factormin 0.2, factormax 10, RMS norm, no dtmin / dtmax).
+    """diffrax.PIDController(rtol, atol, pcoeff, icoeff, dcoeff, dtmin, dtmax) for ``diffeqsolve_settings['stepsize_controller']``;
+    the remaining diffrax options are at their defaults (safety 0.9, factormin 0.2, factormax 10, RMS norm, force_dtmin=True).
     A diffrax controller object with the same attributes is accepted as well."""
     rtol: float
     atol: float
     pcoeff: float = 0.0
     icoeff: float = 1.0
     dcoeff: float = 0.0
+    dtmin: Optional[float] = None
+    dtmax: Optional[float] = None
 
 
 class LearnableCustomDrift(NamedTuple):

@@ -152,6 +152,10 @@ typedef struct cdkf_opts {
                            E.g. layout = TCN with layout_in = NT lets a host caller hand over the reference's [N,T,m] arrays
                            untransposed and still get the coalesced native output layout. */
   int32_t flags;        /* bit mask of CDKF_FLAG_*; default 0; unknown bits are refused (CDKF_EINVAL) */
+  double dtmin;         /* adaptive only: PIDController(dtmin=, dtmax=) with force_dtmin=True (diffrax's default) -- every proposed step size,
+                           the first included, is clipped to [dtmin, dtmax], and a step taken at dtmin is kept whatever its error estimate.
+                           Defaults 0 and +infinity (= no bounds; src/utils/diffrax_utils.py:40-57 forwards the controller object) */
+  double dtmax;
 } cdkf_opts;
 
 /* Fill *opts with the reference defaults listed above. */

@@ -507,8 +507,9 @@ def _diffeqsolve_adaptive(rhs, t0, t1, y0, dt0, max_steps, count_steps, err_comp
                      y_error / (atol + max(|y0|, |y_candidate|) rtol);   keep the step iff scaled_error < 1
       factor       = clip(safety * e^-(i+p+d)/order * e_prev^(p+2d)/order * e_prevprev^-d/order, [1 if kept else factormin, factormax])
                      with e the scaled error (history updated on accepted steps only), safety 0.9, factormin 0.2, factormax 10
-      next step    = previous attempted size * factor, from t1 (kept) or again from t0 (rejected); the end is clipped as in
-                     the fixed-step loop, a REJECTED step that would cross the end is sent half-way there
+      next step    = previous attempted size * factor, clipped to [dtmin, dtmax] when those are given (a size proposed at or below
+                     dtmin flags the step taken with it as kept whatever its error: force_dtmin), from t1 (kept) or again from t0
+                     (rejected); the end is clipped as in the fixed-step loop, a REJECTED step that would cross the end is sent half-way there
     max_steps counts accepted and rejected steps."""
     name, ad = _ACTIVE[-1]
     A, B = TABLEAUS[name]
@@ -519,11 +520,16 @@ def _diffeqsolve_adaptive(rhs, t0, t1, y0, dt0, max_steps, count_steps, err_comp
     pc, ic, dc = (dtype.type(ad.get(k, v)) for k, v in (("pcoeff", 0.0), ("icoeff", 1.0), ("dcoeff", 0.0)))
     c1, c2, c3 = (ic + pc + dc) / order, -(pc + 2 * dc) / order, dc / order
     safety, fmin, fmax = dtype.type(0.9), dtype.type(0.2), dtype.type(10.0)
+    # dtmin / dtmax (PIDController.init and the end of adapt_step_size, force_dtmin=True): every proposed size -- the first one too -- is
+    # clipped to [dtmin, dtmax]; a step proposed at or below dtmin is flagged, and the step taken under that flag is KEPT whatever its error
+    dtmin, dtmax = dtype.type(ad.get("dtmin") or 0.0), dtype.type(ad.get("dtmax") or np.inf)
     t0 = np.asarray(t0, dtype=dtype)
     t1 = np.asarray(t1, dtype=dtype)
     N = t0.shape[0]
     tprev = t0.copy()
-    tnext = np.minimum(t0 + dtype.type(dt0), t1)
+    dt_first = np.minimum(dtype.type(dt0), dtmax)
+    at_min = np.full(N, bool(dt_first <= dtmin))
+    tnext = np.minimum(t0 + np.maximum(dt_first, dtmin), t1)
     y = tuple(c.copy() for c in y0)
     inv1 = np.ones(N, dtype)
     inv2 = np.ones(N, dtype)
@@ -551,7 +557,7 @@ def _diffeqsolve_adaptive(rhs, t0, t1, y0, dt0, max_steps, count_steps, err_comp
             sc = yerr[c] / (atol + np.maximum(np.abs(y[c]), np.abs(ynew[c])) * rtol)
             sq = sq + np.sum((sc * sc).reshape(N, -1), axis=1)
         scaled = np.sqrt(sq / dtype.type(size))
-        keep = scaled < 1
+        keep = (scaled < 1) | at_min
         with np.errstate(divide="ignore", over="ignore", invalid="ignore"):
             inv = np.where(scaled == 0, dtype.type(np.inf), dtype.type(1) / scaled)
             factor = safety * inv ** c1
@@ -563,7 +569,9 @@ def _diffeqsolve_adaptive(rhs, t0, t1, y0, dt0, max_steps, count_steps, err_comp
         # step was far too long) rejects the step with factor = factormin.  diffrax's clip would propagate the NaN into the
         # step size and the solve would end in its max_steps error; the engine retries with a shorter step instead.
         factor = np.fmin(np.fmax(factor, np.where(keep, dtype.type(1), fmin)), fmax)
-        dtn = dt * factor
+        dtn = np.fmin(dt * factor, dtmax)
+        at_min = np.where(active, dtn <= dtmin, at_min)
+        dtn = np.fmax(dtn, dtmin)
         nt0 = np.where(keep, tnext, tprev)
         nt1 = nt0 + dtn
         upd = active & keep

@@ -1092,6 +1092,60 @@ def test_adaptive_step_size_control(hip_lib, solver, ctrl):
     assert (status & 4).any()
 
 
+@pytest.mark.parametrize("ctrl", [dict(rtol=1e-6, atol=1e-8, dtmax=0.004), dict(rtol=1e-12, atol=1e-14, dtmin=0.003),
+                                  dict(rtol=1e-5, atol=1e-7, pcoeff=0.1, icoeff=0.3, dtmin=0.002, dtmax=0.01)])
+def test_adaptive_step_size_bounds(hip_lib, ctrl):
+    """PIDController(dtmin=, dtmax=) (the reference forwards any controller, src/utils/diffrax_utils.py:40-57): the
+    three kernel families that adapt -- register-resident (Lorenz-63), workgroup (Lorenz-96 d = 12), the type-1 smoother's pushed-forward
+    (A, Q) of the linear front-end -- against the oracle's controller with the same bounds: a cap that binds on every step, a floor that
+    forces steps the tolerance would reject (kept by force_dtmin), both at once."""
+    rng = np.random.default_rng(101)
+    settings = {"solver": "dopri5", "dt0": 0.05, "stepsize_controller": cd.PIDController(**ctrl)}
+    for mdl, (N, T) in ((o.lorenz63_model(2), (7, 12)), (lorenz96_model(12, 5), (3, 6))):
+        t = o.irregular_times(rng, N, T, 0.05)
+        t[:, T // 2:] += 0.1
+        y = o.simulate(mdl, t, rng)
+        P = params_from(mdl)
+        with o.use_solver("dopri5", adaptive=ctrl):
+            ref = o.ekf_filter(mdl, t, y, dt0=0.05, state_order="first")
+            refs = o.ekf_smoother(mdl, t, y, dt0=0.05, state_order="first")
+        post = cd.cdnlgssm_filter(P, y, t[..., None], cd.EKFHyperParams(state_order="first", diffeqsolve_settings=settings))
+        for k in FILTER_KEYS:
+            assert relerr(getattr(post, k), ref[k]) < 1e-9, (mdl.d, k)
+        np.testing.assert_allclose(post.marginal_loglik, ref["marginal_loglik"], rtol=1e-9)
+        sm = cd.cdnlgssm_smoother(P, y, t[..., None], cd.EKFHyperParams(state_order="first", diffeqsolve_settings=settings))
+        assert relerr(sm.smoothed_covariances, refs["smoothed_covariances"]) < 1e-8, mdl.d
+    # the bounds really bind: without them the same tolerances give other numbers
+    free = {k: v for k, v in ctrl.items() if k not in ("dtmin", "dtmax")}
+    postf = cd.cdnlgssm_filter(P, y, t[..., None], cd.EKFHyperParams(state_order="first", diffeqsolve_settings=dict(
+        settings, stepsize_controller=cd.PIDController(**free), max_steps=400)))
+    assert not np.array_equal(np.nan_to_num(postf.filtered_means), post.filtered_means)
+    # linear front-end, smoother type 1: the (A, Q) pairs of every interval integrate under the same controller
+    d, m = 4, 2
+    base = linear_model(rng, d, m)
+    lm = o.Model(o.LinearDrift(base.drift.W, np.zeros(d)), base.L, base.Qc, base.H, base.bias, base.R, base.m0, base.P0)
+    Nl, Tl = 3, 10
+    tl = o.irregular_times(rng, Nl, Tl, 0.15)
+    tl[:, 6:] += 0.2
+    yl = o.simulate(lm, tl, rng)
+    model = cd.ContDiscreteLinearGaussianSSM(state_dim=d, emission_dim=m, has_emissions_bias=True)
+    pp = cd.ParameterProperties()
+    lp, _ = model.initialize(
+        initial_mean={"params": lm.m0, "props": pp}, initial_cov={"params": lm.P0, "props": pp},
+        dynamics_weights={"params": lm.drift.W, "props": pp}, dynamics_diffusion_coefficient={"params": lm.L, "props": pp},
+        dynamics_diffusion_cov={"params": lm.Qc, "props": pp}, emission_weights={"params": lm.H, "props": pp},
+        emission_bias={"params": lm.bias, "props": pp}, emission_cov={"params": lm.R, "props": pp})
+    with o.use_solver("dopri5", adaptive=ctrl):
+        ref1 = o.kf_smoother_type1(lm, tl, yl, dt0=0.05)
+    sm1 = model.smoother(lp, yl, tl[..., None], filter_hyperparams=cd.KFHyperParams(diffeqsolve_settings=settings))
+    for k in ("smoothed_means", "smoothed_covariances", "smoothed_cross_covariances"):
+        assert relerr(getattr(sm1, k), ref1[k]) < 1e-9, k
+    # and the library refuses bounds that make no sense
+    op = models._opts(cd.EKFHyperParams(diffeqsolve_settings=dict(settings, stepsize_controller=cd.PIDController(1e-3, 1e-6, dtmin=0.1, dtmax=0.01))), 1)
+    with pytest.raises(_ffi.CdkfError, match="dtmin"):
+        _ffi.run_host("ekf_filter", models._model_block(P), op, t, y, [False] * 4, np.float64)
+
+
 def test_notebook_pin_default_vs_tsit5_pid_loglik(hip_lib):
     """The reference-recorded statement about the adaptive path (tutorial diffeqsolve_settings_analysis.ipynb:385-386; see
     tests/test_oracle.py::test_notebook_pin_default_vs_tsit5_pid_loglik): default Dopri5 and Tsit5 + PIDController(1e-9, 1e-9)

@@ -541,6 +541,34 @@ def test_adaptive_controller_meets_tolerance_and_adapts(name):
     assert counts[0][0] >= 2
 
 
+def test_adaptive_controller_step_size_bounds():
+    """PIDController(dtmin=, dtmax=) (diffrax forwards them from diffeqsolve_settings, src/utils/diffrax_utils.py:40-57): no accepted step
+    is longer than dtmax (the first one, dt0, included) or -- except the one clipped to the end of the interval -- shorter than dtmin; a
+    step taken at dtmin is kept whatever its error (force_dtmin), so a tolerance the method cannot meet costs (t1 - t0) / dtmin steps
+    instead of running into max_steps; bounds that never bind change nothing."""
+    rhs = lambda yv: (yv[0] * (1 - yv[0]),)
+    y0 = (np.full((1, 1), 0.2),)
+    free, log_free = [], []
+    with o.use_solver("dopri5", adaptive=dict(rtol=1e-5, atol=1e-7)):
+        (ya,) = o.diffeqsolve(rhs, np.zeros(1), np.full(1, 3.0), y0, dt0=0.05, count_steps=free, dt_log=log_free)
+    loose, log_loose = [], []
+    with o.use_solver("dopri5", adaptive=dict(rtol=1e-5, atol=1e-7, dtmin=1e-9, dtmax=50.0)):
+        (yb,) = o.diffeqsolve(rhs, np.zeros(1), np.full(1, 3.0), y0, dt0=0.05, count_steps=loose, dt_log=log_loose)
+    assert np.array_equal(ya, yb) and log_free == log_loose
+    capped, log_cap = [], []
+    with o.use_solver("dopri5", adaptive=dict(rtol=1e-5, atol=1e-7, dtmax=0.02)):
+        (yc,) = o.diffeqsolve(rhs, np.zeros(1), np.full(1, 3.0), y0, dt0=0.05, count_steps=capped, dt_log=log_cap)
+    assert max(log_cap) <= 0.02 * (1 + 1e-12) and log_cap[0] <= 0.02 * (1 + 1e-12) and max(log_free) > 0.05
+    assert capped[0][0] >= 150 > free[0][0]
+    floor, log_floor = [], []
+    with o.use_solver("heun", adaptive=dict(rtol=1e-13, atol=1e-15, dtmin=0.01)):   # hopeless for a second-order method
+        (yd,) = o.diffeqsolve(rhs, np.zeros(1), np.full(1, 3.0), y0, dt0=0.05, count_steps=floor, dt_log=log_floor, max_steps=2000)
+    # (about 300 kept steps; an attempt whose size came out one ulp above dtmin is not flagged, fails, and is retried AT dtmin)
+    assert min(log_floor[:-1]) >= 0.01 * (1 - 1e-9) and 290 <= len(log_floor) <= 310 and floor[0][0] <= 700
+    exact = 0.2 * np.exp(3.0) / (1 + 0.2 * (np.exp(3.0) - 1))
+    assert abs(yd[0, 0] - exact) < 1e-4
+
+
 def test_gradient_under_another_fixed_step_method_matches_finite_differences():
     """Forward sensitivities along the steps of a non-default tableau (Heun) are still the derivative of that discretised
     log-likelihood."""
