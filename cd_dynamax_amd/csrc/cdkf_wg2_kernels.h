@@ -756,6 +756,14 @@ __device__ __forceinline__ void wg_dopri5_step(const WgLds<R>& L, const Own<R, E
   R* Pm = L.mat(0);
   R kM[6];
   R kP[6][EPT];
+#ifdef CDKF_WG_ZERO_INIT  // (diagnostic build, scripts/bisect_wg8.sh: does an uninitialised slope slot reach a result?)
+#pragma unroll
+  for (int s_ = 0; s_ < 6; ++s_) {
+    kM[s_] = R(0);
+#pragma unroll
+    for (int u = 0; u < EPT; ++u) kP[s_][u] = R(0);
+  }
+#endif
   wg_stage<0>(L, own, d, dt, with_P, rhs, kM, kP, tb);
   wg_stage<1>(L, own, d, dt, with_P, rhs, kM, kP, tb);
   wg_stage<2>(L, own, d, dt, with_P, rhs, kM, kP, tb);
