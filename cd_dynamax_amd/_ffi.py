@@ -111,7 +111,8 @@ SYMBOLS = (
      "cdkf_ukf_loglik_grad_f64_dev", "cdkf_ukf_loglik_grad_f32_dev", "cdkf_ukf_grad_supported", "cdkf_custom_drift_register", "cdkf_custom_drift_compile", "cdkf_custom_emission_register", "cdkf_set_kernel_source_dir",
      "cdkf_kf_smoother1_f64", "cdkf_kf_smoother1_f32", "cdkf_kf_smoother1_f64_dev", "cdkf_kf_smoother1_f32_dev",
      "cdkf_kf_smoother1_supported", "cdkf_kf_pushforward_f64", "cdkf_kf_pushforward_f32", "cdkf_grad_supported", "cdkf_grad_all_supported", "cdkf_release_workspace", "cdkf_ekf_loglik_grad_all_f64",
-     "cdkf_ekf_loglik_grad_all_f32", "cdkf_ekf_loglik_grad_all_f64_dev", "cdkf_ekf_loglik_grad_all_f32_dev", "cdkf_grad_sum_f64_dev",
+     "cdkf_ekf_loglik_grad_all_f32", "cdkf_ekf_loglik_grad_all_f64_dev", "cdkf_ekf_loglik_grad_all_f32_dev", "cdkf_ekf_loglik_grad_jumps_f64",
+     "cdkf_ekf_loglik_grad_jumps_f32", "cdkf_grad_sum_f64_dev",
      "cdkf_grad_sum_f32_dev", "cdkf_comm_preflight", "cdkf_comm_unique_id", "cdkf_comm_init_rank", "cdkf_comm_init_all", "cdkf_comm_rank", "cdkf_comm_world",
      "cdkf_ll_allreduce", "cdkf_comm_allreduce_max", "cdkf_ll_allreduce_all", "cdkf_comm_destroy", "cdkf_rdv_create",
      "cdkf_rdv_broadcast", "cdkf_rdv_allreduce", "cdkf_rdv_barrier", "cdkf_rdv_destroy", "cdkf_last_kernel", "cdkf_event_create",
@@ -235,6 +236,10 @@ def lib() -> C.CDLL:
         f = getattr(L, f"cdkf_ekf_loglik_grad_all_{p}_dev")
         f.argtypes = base + [C.c_void_p]
         f.restype = C.c_int
+        if hasattr(L, f"cdkf_ekf_loglik_grad_jumps_{p}"):  # (absent from libraries older than 108)
+            f = getattr(L, f"cdkf_ekf_loglik_grad_jumps_{p}")
+            f.argtypes = [C.POINTER(CdkfModel), C.POINTER(CdkfOpts), C.c_int64, C.c_int64] + [C.c_void_p] * 9
+            f.restype = C.c_int
     for p in ("f64", "f32"):
         base = [C.POINTER(CdkfModel), C.POINTER(CdkfOpts), C.c_int64, C.c_int64] + [C.c_void_p] * 5
         for algo in ("ekf", "ukf"):
@@ -474,6 +479,29 @@ def loglik_grad(mdl: ModelBlock, opts: CdkfOpts, t: np.ndarray, y: np.ndarray, d
     fn = getattr(lib(), f"cdkf_{'ukf' if ukf else 'ekf'}_loglik_grad_{suffix}")
     check(fn(C.byref(mdl.c), C.byref(opts), N, T, _vp(t), _vp(y), _vp(ll), _vp(grad), _vp(status)))
     return ll, grad, status
+
+
+def loglik_grad_jumps(mdl: ModelBlock, opts: CdkfOpts, t: np.ndarray, y: np.ndarray, jumps: np.ndarray, dtype):
+    """cdkf_ekf_loglik_grad_jumps_<f32|f64> on host buffers: the reverse sweep of a model whose predicted mean takes the jump
+    ``jumps[n, k]`` behind interval k (the linear front-end's dynamics bias / inputs).  Returns (ll [N], grad [N, n_theta],
+    grad_model [N, ...], grad_jumps [N, T, d], grad_y [N, T, m], status)."""
+    dtype = np.dtype(dtype)
+    suffix = {np.dtype(np.float32): "f32", np.dtype(np.float64): "f64"}[dtype]
+    N, T, m = y.shape
+    d = mdl.state_dim
+    opts.layout = LAYOUT_TCN
+    opts.layout_in = LAYOUT_NT
+    t = np.ascontiguousarray(t, dtype=dtype)
+    y = np.ascontiguousarray(y, dtype=dtype)
+    jumps = np.ascontiguousarray(np.broadcast_to(jumps, (N, T, d)), dtype=dtype)
+    ll = np.empty((N,), dtype)
+    grad = np.empty((N, max(1, mdl.theta.size)), dtype)
+    gm = np.empty((N, model_grad_size(d, m)), dtype)
+    gj, gy = np.empty((N, T, d), dtype), np.empty((N, T, m), dtype)
+    status = np.zeros((N,), np.int32)
+    fn = getattr(lib(), f"cdkf_ekf_loglik_grad_jumps_{suffix}")
+    check(fn(C.byref(mdl.c), C.byref(opts), N, T, _vp(t), _vp(y), _vp(jumps), _vp(ll), _vp(grad), _vp(gm), _vp(gj), _vp(gy), _vp(status)))
+    return ll, grad[:, :mdl.theta.size], gm, gj, gy, status
 
 
 def emission_moments(mdl: ModelBlock, means: np.ndarray, covs: Optional[np.ndarray], dtype):

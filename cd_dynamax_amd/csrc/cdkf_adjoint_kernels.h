@@ -1134,6 +1134,13 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
       mb = (lane < d) ? mb - sacc : R(0);
     }
     wave_sync();
+    // (per-step cotangents for the linear front-end's offsets, WgArgs::gcj / gy: mb is now the cotangent of the mean PREDICTED for t_k,
+    //  i.e. of the jump added at the end of interval k-1; vb that of the innovation = of y_k)
+    if (a.gy && lane < m) a.gy[(n * a.T + k) * m + lane] = vb;
+    if (a.gcj && lane < d) {
+      if (k > 0) a.gcj[(n * a.T + (k - 1)) * d + lane] = mb;
+      if (k == a.T - 1) a.gcj[(n * a.T + k) * d + lane] = R(0);  // (the jump behind the last observation reaches no likelihood term)
+    }
     W8_TICK(20)  // measurement update reversed
     if (k == 0) break;
 

@@ -32,6 +32,12 @@ __host__ __device__ inline long awg_lds_reals(int d, int m) {
   const int q = d > m ? d : m, ld = awg_ld(q);
   return (long)kAwgSlots * q * ld + (long)m * ld + 64L * kAwgVecs;
 }
+// MLP drift (round 4; d -> h1 -> h2 -> d, tanh): behind the vectors the weights W2 [h2][h1 | 1], W1 [h1][d | 1], W3 [d][h2 | 1], twenty
+// 64-entry work vectors and four [64][d | 1] images (the tangent pass U = D1 W1, T = W2 U and the cotangents of the two)
+constexpr int kAwgMlpVecs = 20;
+__host__ __device__ inline long awg_mlp_lds_reals(int d, int h1, int h2) {
+  return (long)h2 * (h1 | 1) + (long)h1 * (d | 1) + (long)d * (h2 | 1) + 64L * kAwgMlpVecs + 4L * 64 * (d | 1);
+}
 // layout of the optional model-gradient block (per trajectory): m0 [d] | P0 [d,d] | LQL [d,d] | H [m,d] | bias [m] | R [m,m]
 // (the same as adj_model_grad_size of cdkf_adjoint_kernels.h)
 __host__ __device__ inline long awg_model_grad_size(int d, int m) { return (long)d + 2L * d * d + (long)m * d + m + (long)m * m; }
@@ -139,8 +145,12 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
   const int cNG = (NT / cZ < ccap / cZ) ? NT / cZ : ccap / cZ;
 #else
   constexpr bool custom = false;
-  constexpr bool second = false;
-  const long ntheta = lin ? (long)d * d + d : 1;
+  // (round 4) the MLP drift beyond eight state dimensions: hidden sizes <= 64, both state orders -- the reverse of a right-hand side
+  // is the oracle's MLP branch of the drift's vector-Jacobian product and divgrad_vjp, line by line, on the workgroup's threads
+  const bool mlp = a.kind == kDriftMlp;
+  const bool second = mlp && a.order == 2;
+  const int h1 = a.h1, h2 = a.h2;
+  const long ntheta = lin ? (long)d * d + d : (mlp ? (long)h1 * d + h1 + (long)h2 * h1 + h2 + (long)d * h2 + d : 1);
 #endif
   R* g = grad + n * ntheta;
   R* gm = grad_model ? grad_model + n * awg_model_grad_size(d, m) : nullptr;
@@ -415,7 +425,10 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
   // Lorenz-96: F has four entries per row (F_i,i+1 = x_{i-1}, F_i,i-2 = -x_{i-1}, F_i,i-1 = x_{i+1} - x_{i-2}, F_ii = -1) -- the two dense
   // products of a stage with it are four-term stencils over the LDS image of the other factor (they were 2 x 6.5 k of a stage's ~ 22 k
   // cycles as d^3 products against a dense copy of F)
-  const bool l96 = !lin && !custom;
+#ifdef CDKF_AWG_CUSTOM
+  constexpr bool mlp = false;
+#endif
+  const bool l96 = !lin && !custom && !mlp;
   auto wrap = [&](int i) { return i < 0 ? i + d : (i >= d ? i - d : i); };
   auto l96_FPs = [&](const R* xv, const R* Ps_, R* A_) {  // A = F(x) Ps
     rows2d(d, d,

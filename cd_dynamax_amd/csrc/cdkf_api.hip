@@ -264,6 +264,42 @@ int loglik_grad_host(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64
   return CDKF_OK;
 }
 
+// ---- value + every gradient with per-step jumps of the predicted mean (host buffers; the linear front-end's bias / inputs) -----------
+template <typename R>
+int loglik_grad_jumps_host(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, const R* jumps,
+                           R* ll, R* grad, R* grad_model, R* grad_jumps, R* grad_y, int32_t* status) {
+  int rc = check_common(mdl, o, N, T, t, y, ll);
+  if (rc) return rc;
+  if (!grad || !grad_model || !jumps || !grad_jumps || !grad_y) {
+    set_error("loglik_grad_jumps: grad, grad_model, jumps, grad_jumps and grad_y must not be NULL");
+    return CDKF_EINVAL;
+  }
+  if (N == 0) return CDKF_OK;
+  CDKF_SELECT_DEVICE(o);
+  const size_t dd = mdl->state_dim, mm = mdl->emission_dim;
+  const size_t nt = (size_t)(o->t_shared ? T : N * T), ny = (size_t)N * T * mm, nj = (size_t)N * T * dd;
+  const size_t ng = (size_t)N * (size_t)(mdl->n_theta > 0 ? mdl->n_theta : 1), ngm = (size_t)N * (dd + 2 * dd * dd + mm * dd + mm + mm * mm);
+  DevBuf dt, dy, dj, dll, dg, dgm, dgj, dgy, dst;
+  if ((rc = dt.alloc(nt * sizeof(R))) || (rc = dy.alloc(ny * sizeof(R))) || (rc = dj.alloc(nj * sizeof(R))) ||
+      (rc = dll.alloc(N * sizeof(R))) || (rc = dg.alloc(ng * sizeof(R))) || (rc = dgm.alloc(ngm * sizeof(R))) ||
+      (rc = dgj.alloc(nj * sizeof(R))) || (rc = dgy.alloc(ny * sizeof(R))) || (rc = dst.alloc(N * sizeof(int32_t))))
+    return rc;
+  CDKF_HIP_CHECK(hipMemcpy(dt.p, t, nt * sizeof(R), hipMemcpyHostToDevice));
+  CDKF_HIP_CHECK(hipMemcpy(dy.p, y, ny * sizeof(R), hipMemcpyHostToDevice));
+  CDKF_HIP_CHECK(hipMemcpy(dj.p, jumps, nj * sizeof(R), hipMemcpyHostToDevice));
+  rc = launch_ekf_grad_adjoint_jumps<R>(mdl, o, N, T, (const R*)dt.p, (const R*)dy.p, (const R*)dj.p, (R*)dll.p, (R*)dg.p, (R*)dgm.p,
+                                        (R*)dgj.p, (R*)dgy.p, (int32_t*)dst.p, nullptr);
+  if (rc) return rc;
+  CDKF_HIP_CHECK(hipDeviceSynchronize());
+  CDKF_HIP_CHECK(hipMemcpy(ll, dll.p, N * sizeof(R), hipMemcpyDeviceToHost));
+  CDKF_HIP_CHECK(hipMemcpy(grad, dg.p, (size_t)N * (size_t)mdl->n_theta * sizeof(R), hipMemcpyDeviceToHost));
+  CDKF_HIP_CHECK(hipMemcpy(grad_model, dgm.p, ngm * sizeof(R), hipMemcpyDeviceToHost));
+  CDKF_HIP_CHECK(hipMemcpy(grad_jumps, dgj.p, nj * sizeof(R), hipMemcpyDeviceToHost));
+  CDKF_HIP_CHECK(hipMemcpy(grad_y, dgy.p, ny * sizeof(R), hipMemcpyDeviceToHost));
+  if (status) CDKF_HIP_CHECK(hipMemcpy(status, dst.p, N * sizeof(int32_t), hipMemcpyDeviceToHost));
+  return CDKF_OK;
+}
+
 // ---- linear model, smoother type 1 -------------------------------------------------------------------------------------
 template <typename R>
 int kf_smoother1_dev(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll, R* fm,
@@ -739,6 +775,16 @@ int cdkf_ekf_loglik_grad_all_f32_dev(const cdkf_model* mdl, const cdkf_opts* o, 
                                      void* stream) {
   if (int rc = need_model_grad(grad_model)) return rc;
   return loglik_grad_dev<float>(mdl, o, N, T, t, y, ll, grad, grad_model, status, stream);
+}
+int cdkf_ekf_loglik_grad_jumps_f64(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const double* t, const double* y,
+                                   const double* jumps, double* ll, double* grad, double* grad_model, double* grad_jumps, double* grad_y,
+                                   int32_t* status) {
+  return loglik_grad_jumps_host<double>(mdl, o, N, T, t, y, jumps, ll, grad, grad_model, grad_jumps, grad_y, status);
+}
+int cdkf_ekf_loglik_grad_jumps_f32(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const float* t, const float* y,
+                                   const float* jumps, float* ll, float* grad, float* grad_model, float* grad_jumps, float* grad_y,
+                                   int32_t* status) {
+  return loglik_grad_jumps_host<float>(mdl, o, N, T, t, y, jumps, ll, grad, grad_model, grad_jumps, grad_y, status);
 }
 int cdkf_release_workspace(void) { return release_grad_workspace(); }
 int cdkf_grad_all_supported(const cdkf_model* mdl, const cdkf_opts* o) {

@@ -47,6 +47,12 @@ bool ukf_grad_shape_available(const cdkf_model* mdl, const cdkf_opts* o);
 template <typename R>
 int launch_ekf_grad_adjoint(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll,
                             R* grad, R* grad_model, int32_t* status, hipStream_t stream);
+// ... with per-step jumps of the predicted mean ([N, T, d]) and the per-step cotangents of the jumps and of the observations
+// ([N, T, d], [N, T, m]; cdkf_ekf_loglik_grad_jumps_*): state_dim, emission_dim <= 8, fixed-step Dormand-Prince
+template <typename R>
+int launch_ekf_grad_adjoint_jumps(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y,
+                                  const R* jumps, R* ll, R* grad, R* grad_model, R* grad_jumps, R* grad_y, int32_t* status,
+                                  hipStream_t stream);
 bool adjoint_shape_available(const cdkf_model* mdl, const cdkf_opts* o);
 int release_grad_workspace();  // frees the per-process reverse-sweep workspace once its last user has finished (launch_wg.hip)
 // lease of the per-process reverse-sweep workspace (launch_wg.hip): holds its lock from construction to destruction

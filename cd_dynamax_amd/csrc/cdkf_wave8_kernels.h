@@ -732,6 +732,7 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave8_kernel(const WgArgs<R
       }
     }
     if (zeroth) Pij = rfma(rsqrt_(t1 - t0), lqlz, Pij);
+    if (a.cj && lane < d) mj += a.cj[(n * a.T + k) * d + lane];  // (a jump of the predicted mean: WgArgs::cj)
     if (a.pm && lane < d) a.pm[n * a.m_sn + k * a.m_sk + lane * a.m_si] = mj;
     if (a.pP && inP) a.pP[n * a.P_sn + k * a.P_sk + (i * d + j) * a.P_si] = Pij;
   }

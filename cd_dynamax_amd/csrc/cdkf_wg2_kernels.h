@@ -64,6 +64,13 @@ struct WgArgs {
   // MLP drift: W2 once more in the parameter block, zero-padded to [64][64] (cdkf_wave8s_kernels.h loads its register slices from it with
   // one lane offset and immediates -- no bounds checks, no clamped addresses); -1: not there
   long o_w2pad;
+  // Per-step jumps of the PREDICTED mean (cdkf_ekf_loglik_grad_jumps_*: the linear front-end's dynamics bias / inputs, which the
+  // reference adds to the pushed-forward mean without integrating them, continuous_discrete_linear_gaussian_ssm/inference.py:185-205):
+  // cj[n][k][:] is added to the mean predicted from t_k to t_{k+1} ([N][T][d], contiguous).  Reverse sweep: gcj[n][k][:] receives the
+  // cotangent of that jump, gy[n][k][:] the cotangent of the observation y_k ([N][T][d], [N][T][m]).  All null elsewhere.
+  const R* cj;
+  R* gcj;
+  R* gy;
 };
 constexpr int kCkStep = 6 * 72;  // reals per checkpointed step
 // fields of the MLP stage checkpoint (each 64 reals, lane-major): first order kMlpCkFirst of them, 'second' kMlpCkSecond

@@ -32,7 +32,7 @@ int launch_wave8s(const WgArgs<R>& a, hipStream_t stream) {
 
 template <typename R>
 int launch_wave8(const WgArgs<R>& a, hipStream_t stream) {
-  if (a.kind == kDriftMlp && a.o_w2pad > 0) {  // (the padded copy of W2: wg_prepare)
+  if (a.kind == kDriftMlp && a.o_w2pad > 0 && !a.cj) {  // (the padded copy of W2: wg_prepare; mean jumps: the one-wavefront sweep)
     static const int env_split = [] {
       const char* e = std::getenv("CDKF_W8_SPLIT");
       return e ? std::atoi(e) : -1;

@@ -438,9 +438,8 @@ static int launch_ekf_grad_adjoint_wg(const cdkf_model* mdl, const cdkf_opts* o,
 }
 
 template <typename R>
-int launch_ekf_grad_adjoint(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll,
-                            R* grad, R* grad_model, int32_t* status, hipStream_t stream) {
-  if (!wave8_shape(mdl)) return launch_ekf_grad_adjoint_wg<R>(mdl, o, N, T, t, y, ll, grad, grad_model, status, stream);
+static int adjoint_wave8_impl(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, const R* jumps,
+                              R* ll, R* grad, R* grad_model, R* grad_jumps, R* grad_y, int32_t* status, hipStream_t stream) {
   WgArgs<R> a{};
   R* blk = nullptr;
   // the workspace lock first, the parameter slot second: a caller waiting for the workspace holds no slot of the ring
@@ -488,6 +487,7 @@ int launch_ekf_grad_adjoint(const cdkf_model* mdl, const cdkf_opts* o, int64_t N
   }
   R* w = (R*)ws.p;
   a.t = t; a.y = y; a.ll = ll; a.status = status;
+  a.cj = jumps; a.gcj = grad_jumps; a.gy = grad_y;
   a.fm = w; a.fP = w + nm; a.pm = w + nm + nP; a.pP = w + 2 * nm + nP;
   // other methods / adaptive steps: forward pass on the workgroup kernel (run-time tableau), no slopes kept
   const bool dp5 = o->solver == CDKF_SOLVER_DOPRI5 && !o->adaptive;
@@ -506,6 +506,30 @@ int launch_ekf_grad_adjoint(const cdkf_model* mdl, const cdkf_opts* o, int64_t N
   const int rc2 = lease.release();
   return rc ? rc : rc2;
 }
+template <typename R>
+int launch_ekf_grad_adjoint(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll,
+                            R* grad, R* grad_model, int32_t* status, hipStream_t stream) {
+  if (!wave8_shape(mdl)) return launch_ekf_grad_adjoint_wg<R>(mdl, o, N, T, t, y, ll, grad, grad_model, status, stream);
+  return adjoint_wave8_impl<R>(mdl, o, N, T, t, y, nullptr, ll, grad, grad_model, nullptr, nullptr, status, stream);
+}
+template <typename R>
+int launch_ekf_grad_adjoint_jumps(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y,
+                                  const R* jumps, R* ll, R* grad, R* grad_model, R* grad_jumps, R* grad_y, int32_t* status,
+                                  hipStream_t stream) {
+  // the jumps live in the wavefront-per-trajectory sweeps only (the forward kernel adds them, the reverse kernel emits their
+  // cotangents): state_dim, emission_dim <= 8, fixed-step Dormand-Prince, what the reverse sweep itself requires
+  if (!wave8_shape(mdl) || !adjoint_shape_available(mdl, o) || o->solver != CDKF_SOLVER_DOPRI5 || o->adaptive) {
+    set_error("loglik_grad_jumps: needs state_dim, emission_dim <= 8, the default solver (fixed-step Dopri5), num_iter 1, state_order "
+              "first or second (drift_kind=%d state_dim=%d emission_dim=%d solver=%d adaptive=%d)", mdl->drift_kind, mdl->state_dim,
+              mdl->emission_dim, o->solver, o->adaptive);
+    return CDKF_EUNSUPPORTED;
+  }
+  return adjoint_wave8_impl<R>(mdl, o, N, T, t, y, jumps, ll, grad, grad_model, grad_jumps, grad_y, status, stream);
+}
+template int launch_ekf_grad_adjoint_jumps<float>(const cdkf_model*, const cdkf_opts*, int64_t, int64_t, const float*, const float*, const float*,
+                                                  float*, float*, float*, float*, float*, int32_t*, hipStream_t);
+template int launch_ekf_grad_adjoint_jumps<double>(const cdkf_model*, const cdkf_opts*, int64_t, int64_t, const double*, const double*,
+                                                   const double*, double*, double*, double*, double*, double*, int32_t*, hipStream_t);
 template int launch_ekf_grad_adjoint<float>(const cdkf_model*, const cdkf_opts*, int64_t, int64_t, const float*, const float*,
                                             float*, float*, float*, int32_t*, hipStream_t);
 template int launch_ekf_grad_adjoint<double>(const cdkf_model*, const cdkf_opts*, int64_t, int64_t, const double*,

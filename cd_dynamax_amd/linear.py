@@ -14,7 +14,8 @@ Differences (what cannot be reproduced is refused loudly rather than approximate
     that through offsets: with s_0 = 0, s_k+1 = A_k s_k + B u_k + b (A_k = the pushed-forward matrix of interval k, from
     cdkf_kf_pushforward_*; state_dim <= 8) the state is x = z + s where z runs the bias-free filter on y - H s - D u, so the
     covariances and the log-likelihood are untouched and s is added back to the means.  The smoothers take no inputs (the
-    reference's own do not either: inference.py:635 "TODO: incorporate inputs!"), and these leaves cannot be trained.
+    reference's own do not either: inference.py:635 "TODO: incorporate inputs!").  Their gradient -- and fit_sgd over them -- comes from
+    the reverse sweep with jumps of the predicted mean (``_loglik_and_grad_with_offsets``, cdkf_ekf_loglik_grad_jumps_*).
   * the moments are integrated directly (dP/dt = F P + P F^T + L Qc L^T) instead of pushing (A, Q) forward and
     forming A P A^T + Q: identical up to the O(dt0^6) difference of two 5th-order solutions (~1e-12 relative).
   * ``smoother_type='cd_smoother_2'`` (Sarkka Alg. 3.18, inference.py:636-690) is the EKF smoother of the hot path;
@@ -103,8 +104,8 @@ def _props_as_nonlinear(props: ParamsCDLGSSM, params: ParamsCDLGSSM) -> ParamsCD
     if (is_on(props.dynamics.bias, params.dynamics.bias) or is_on(props.dynamics.input_weights, params.dynamics.input_weights)
             or is_on(props.emissions.input_weights, params.emissions.input_weights)):
         raise NotImplementedError(
-            "fit_sgd: the dynamics bias and the input weights cannot be trained on the HIP path (the reference adds "
-            "B u + b un-integrated; the filter reproduces that through offsets, their gradient is not formed)")
+            "the dynamics bias and the input weights are trained through ContDiscreteLinearGaussianSSM.fit_sgd "
+            "(_fit_sgd_with_offsets: state_dim, emission_dim <= 8, the default solver); this route has no place for them")
     pp = lambda p: p if isinstance(p, ParameterProperties) else frozen
     return ParamsCDNLGSSM(
         initial=ParamsLGSSMInitial(LearnableVector(pp(props.initial.mean)), LearnableMatrix(pp(props.initial.cov))),
@@ -158,6 +159,118 @@ def _filter_with_offsets(params: ParamsCDLGSSM, emissions, t_emissions, filter_h
     post = cdnlgssm_filter(nl, yy.astype(dtype) if batched else yy[0].astype(dtype), t_emissions, hyper, dtype=dtype)
     sh = lambda a, off: None if a is None else (np.asarray(a) + (off if batched else off[0]).astype(np.asarray(a).dtype))
     return post._replace(filtered_means=sh(post.filtered_means, s[:, :T]), predicted_means=sh(post.predicted_means, s[:, 1:]))
+
+
+def _trains_offsets(props: ParamsCDLGSSM, params: ParamsCDLGSSM) -> bool:
+    is_on = lambda p, v: isinstance(p, ParameterProperties) and p.trainable and v is not None and np.size(v) > 0
+    return (is_on(props.dynamics.bias, params.dynamics.bias) or is_on(props.dynamics.input_weights, params.dynamics.input_weights)
+            or is_on(props.emissions.input_weights, params.emissions.input_weights))
+
+
+def _loglik_and_grad_with_offsets(params: ParamsCDLGSSM, emissions, t_emissions, filter_hyperparams, inputs, dtype):
+    """(marginal log-likelihood, gradient tree) of the linear model WITH a dynamics bias / inputs -- every leaf, the bias and the three
+    input-weight matrices included (the reference: jax.value_and_grad of marginal_log_prob, in which they are ordinary trainable leaves,
+    continuous_discrete_linear_gaussian_ssm/models.py:116-139, 167).  The reference's predict adds B u_k + b to the pushed-forward mean
+    un-integrated (inference.py:185-205): on the device that is a JUMP of the predicted mean behind every interval
+    (cdkf_ekf_loglik_grad_jumps_*), whose reverse sweep hands back the cotangent of every jump and of every observation; the chain to
+    b, B (jump_k = B u_k + b) and D (the filter sees y_k - D u_k) is three small contractions here."""
+    from . import _ffi
+    from .models import _grads_tree, _model_block, _opts, _prepare
+    nl = _as_nonlinear(params, inputs, offsets_handled=True)
+    mdl = _model_block(nl)
+    hyper = _hyper(filter_hyperparams)
+    opts = _opts(hyper, 1)
+    y, t, batched, dtype = _prepare(emissions, t_emissions, hyper, opts, dtype)
+    N, T, m = y.shape
+    d = mdl.state_dim
+    b = params.dynamics.bias
+    jumps = np.zeros((N, T, d)) + (0.0 if b is None else np.asarray(b, dtype=np.float64))
+    yy = y.astype(np.float64)
+    u = None
+    B, Dm = params.dynamics.input_weights, params.emissions.input_weights
+    if inputs is not None and np.asarray(inputs).size:
+        u = np.asarray(inputs, dtype=np.float64)
+        u = np.broadcast_to(u if u.ndim == 3 else u[None], (N, T, u.shape[-1]))
+        if B is not None and np.size(B):
+            jumps = jumps + u @ np.asarray(B, dtype=np.float64).T
+        if Dm is not None and np.size(Dm):
+            yy = yy - u @ np.asarray(Dm, dtype=np.float64).T
+    try:
+        ll, gth, gm, gj, gy, _ = _ffi.loglik_grad_jumps(mdl, opts, t, yy, jumps, dtype)
+    except _ffi.CdkfUnsupported as e:
+        raise NotImplementedError(f"gradient of the linear model with a dynamics bias / inputs: {e}") from e
+    g = _from_nonlinear(_grads_tree(nl, mdl, gth, gm), params)
+    gj, gy = gj.astype(np.float64), gy.astype(np.float64)
+    g_b = None if b is None else gj.sum(axis=1)
+    g_B = None if B is None else (np.einsum("nkd,nku->ndu", gj, u) if (u is not None and np.size(B)) else np.zeros((N,) + np.shape(B)))
+    g_D = None if Dm is None else (-np.einsum("nkm,nku->nmu", gy, u) if (u is not None and np.size(Dm)) else np.zeros((N,) + np.shape(Dm)))
+    pick = (lambda a: a) if batched else (lambda a: None if a is None else a[0])
+    g = g._replace(dynamics=g.dynamics._replace(bias=pick(g_b), input_weights=pick(g_B)),
+                   emissions=g.emissions._replace(input_weights=pick(g_D)))
+    if not batched:
+        ll = ll[0]
+    return ll, g
+
+
+def _fit_sgd_with_offsets(model, params, props, emissions, t_emissions, filter_hyperparams, inputs, optimizer, batch_size, num_epochs,
+                          shuffle, return_param_history, return_grad_history, key, dtype):
+    """``SSM.fit_sgd`` (ssm_temissions.py:492-600) for a linear model with a dynamics bias / inputs, any leaf trainable: the loop of
+    ``cd_dynamax_amd.fit.fit_sgd`` (same loss scaling, unconstrained space, optimiser) around ``_loglik_and_grad_with_offsets``; the
+    sweeps take host arrays per step (this front-end is BASELINE config 1: one or a few trajectories)."""
+    from .fit import Adam, _Trainable
+    optimizer = Adam(1e-3) if optimizer is None else optimizer
+    tr = _Trainable(params, props)
+    y = np.asarray(emissions)
+    batched = y.ndim == 3
+    y3 = y if batched else y[None]
+    N = y3.shape[0]
+    size = float(y3.size)
+    tt = None if t_emissions is None else np.asarray(t_emissions)
+    uu = None if inputs is None else np.asarray(inputs)
+    num_batches = -(-N // batch_size)
+    if batch_size >= N:
+        shuffle = False
+    rng = np.random.default_rng(key if isinstance(key, (int, np.integer)) else 0)
+    per_traj = lambda a, idx: a if a is None else (a[idx] if (batched and a.ndim == y.ndim) else a)
+    u = tr.to_unconstrained(params)
+    state = optimizer.init(u)
+    losses, param_hist, grad_hist = [], [], []
+    for _ in range(num_epochs):
+        order = rng.permutation(N) if shuffle else np.arange(N)
+        avg, itr = 0.0, 0
+        g_u = np.zeros(tr.size)
+        for bi in range(num_batches):
+            idx = order[bi * batch_size:(bi + 1) * batch_size]
+            cur = tr.from_unconstrained(params, u)
+            yb = y3[idx] if batched else y
+            ll, g = _loglik_and_grad_with_offsets(cur, yb, per_traj(tt, idx), filter_hyperparams, per_traj(uu, idx), dtype)
+            if batched:  # sum the per-trajectory leaves over the minibatch
+                g = _tree_map(lambda a: None if a is None else np.asarray(a).sum(axis=0), g)
+                ll = float(np.sum(ll))
+            scale = N / len(idx)
+            loss = -(float(ll) * scale) / size
+            g_u = -(tr.pull_back(g, u) * scale) / size
+            upd, state = optimizer.update(g_u, state)
+            u = u + upd
+            avg = (avg * itr + loss) / (itr + 1)
+            itr += 1
+        losses.append(avg)
+        if return_param_history:
+            param_hist.append(tr.from_unconstrained(params, u))
+        if return_grad_history:
+            grad_hist.append(g_u.copy())
+    out = [tr.from_unconstrained(params, u), np.asarray(losses)]
+    if return_param_history:
+        out.append(param_hist)
+    if return_grad_history:
+        out.append(grad_hist)
+    return tuple(out)
+
+
+def _tree_map(fn, tree):
+    if isinstance(tree, tuple) and hasattr(tree, "_fields"):
+        return type(tree)(*[_tree_map(fn, v) for v in tree])
+    return fn(tree)
 
 
 def cdlgssm_filter(params: ParamsCDLGSSM, emissions, t_emissions=None, filter_hyperparams: Optional[KFHyperParams] = None,
@@ -257,7 +370,14 @@ class ContDiscreteLinearGaussianSSM:
                                    dtype=None):
         """(marginal_log_prob, its gradient as a ParamsCDLGSSM): the pytree ``jax.value_and_grad`` returns in the reference's
         fit_sgd (ssm_temissions.py:550-568); reverse sweep on the device, state and emission dimension <= 8.  The entries of
-        the dynamics bias / input weights (not on the HIP path) are returned as they are in ``params``."""
+        the dynamics bias / input weights come from the reverse sweep with mean jumps (``_loglik_and_grad_with_offsets``) whenever the
+        model has a bias or is given inputs; without either their entries are returned as they are in ``params``."""
+        if _has_offsets(params, inputs) or params.dynamics.bias is not None:
+            try:
+                return _loglik_and_grad_with_offsets(params, emissions, t_emissions, filter_hyperparams, inputs, dtype)
+            except NotImplementedError:
+                if _has_offsets(params, inputs):
+                    raise  # (a zero bias and no inputs: the bias-free reverse sweep below covers larger models and other solvers)
         ll, g = cdnlgssm_loglik_and_grad_all(_as_nonlinear(params, inputs), emissions, t_emissions, _hyper(filter_hyperparams),
                                              dtype=dtype)
         return ll, _from_nonlinear(g, params)
@@ -268,6 +388,11 @@ class ContDiscreteLinearGaussianSSM:
         """``SSM.fit_sgd`` (ssm_temissions.py:492-600) for the linear model: any of initial mean / cov, dynamics weights,
         diffusion coefficient / cov, emission weights / bias / cov may be trainable (``cd_dynamax_amd.fit.fit_sgd``)."""
         from .fit import fit_sgd
+        if _has_offsets(params, inputs) or _trains_offsets(props, params):
+            if allreduce is not None or comm is not None:
+                raise NotImplementedError("fit_sgd of a linear model with a dynamics bias / inputs runs in one process")
+            return _fit_sgd_with_offsets(self, params, props, emissions, t_emissions, filter_hyperparams, inputs, optimizer, batch_size,
+                                         num_epochs, shuffle, return_param_history, return_grad_history, key, dtype)
         nl = ContDiscreteNonlinearGaussianSSM(self.state_dim, self.emission_dim)
         out = fit_sgd(nl, _as_nonlinear(params, inputs), _props_as_nonlinear(props, params), emissions, t_emissions,
                       _hyper(filter_hyperparams), None, optimizer, batch_size, num_epochs, shuffle, return_param_history,

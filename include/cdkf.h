@@ -390,6 +390,19 @@ int cdkf_ekf_loglik_grad_all_f64_dev(const cdkf_model* mdl, const cdkf_opts* opt
 int cdkf_ekf_loglik_grad_all_f32_dev(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T, const float* t,
                                      const float* y, float* ll, float* grad, float* grad_model, int32_t* status,
                                      void* stream);
+/* ... the same for a model whose PREDICTED mean takes a jump behind every interval: jumps[n][k][:] ([N,T,d], contiguous, whatever
+ * opts.layout says about t and y) is added to the mean predicted from t_k to t_{k+1}.  That is how the reference's linear model applies
+ * its dynamics bias and inputs -- `mu_pred = A m + B u + b`, un-integrated
+ * (/root/reference/src/continuous_discrete_linear_gaussian_ssm/inference.py:185-205, 596-620) -- so with jumps = u B^T + b this is
+ * jax.value_and_grad of that model's marginal_log_prob (models.py:116-139, 167: bias and input weights are ordinary trainable leaves):
+ * grad_jumps[n][k][:] = d ll_n / d jumps[n][k][:] (chain to b and B on the host), grad_y[n][k][:] = d ll_n / d y[n][k][:] (chain to the
+ * emission input weights: y enters as y - D u).  state_dim, emission_dim <= 8, fixed-step Dopri5; host buffers. */
+int cdkf_ekf_loglik_grad_jumps_f64(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T, const double* t,
+                                   const double* y, const double* jumps, double* ll, double* grad, double* grad_model,
+                                   double* grad_jumps, double* grad_y, int32_t* status);
+int cdkf_ekf_loglik_grad_jumps_f32(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T, const float* t,
+                                   const float* y, const float* jumps, float* ll, float* grad, float* grad_model,
+                                   float* grad_jumps, float* grad_y, int32_t* status);
 int cdkf_grad_all_supported(const cdkf_model* mdl, const cdkf_opts* opts);
 /* The reverse sweeps behind cdkf_ekf_loglik_grad_* keep the forward sweep's moments -- and, where it pays, stage checkpoints: up to
  * CDKF_ADJ_CKPT_GB (environment, default 128) GB -- in ONE per-process device workspace that only grows and is reused by every later
