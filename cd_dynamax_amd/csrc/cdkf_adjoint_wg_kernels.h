@@ -98,7 +98,9 @@ __device__ R awg_custom_third(const R* th, const R* x, const R* u, int i, int z)
 #endif
 
 // NE: covariance entries a thread owns at most (rows i0, i0 + rs, ... of its column on the d x d map): 8 up to d = 42, else 16
-template <typename R, int NE>
+// MLP: the instantiation that carries the network's forward / reverse passes (a separate one: in the Lorenz-96 / linear / source-drift
+// instantiation that code would only cost registers -- 560 -> 788 B of scratch per lane in fp64 when it was compiled in)
+template <typename R, int NE, bool MLP = false>
 __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArgs<R> a, R* __restrict__ grad, R* __restrict__ grad_model,
                                                                     R* __restrict__ ws, long ws_stride, int cap) {
 #ifdef CDKF_WG_STATIC_LDS  // run-time compiled for one shape (no dynamic-LDS cap to raise on a module function)
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
   constexpr bool custom = false;
   // (round 4) the MLP drift beyond eight state dimensions: hidden sizes <= 64, both state orders -- the reverse of a right-hand side
   // is the oracle's MLP branch of the drift's vector-Jacobian product and divgrad_vjp, line by line, on the workgroup's threads
-  const bool mlp = a.kind == kDriftMlp;
+  constexpr bool mlp = MLP;
   const bool second = mlp && a.order == 2;
   const int h1 = a.h1, h2 = a.h2;
   const long ntheta = lin ? (long)d * d + d : (mlp ? (long)h1 * d + h1 + (long)h2 * h1 + h2 + (long)d * h2 + d : 1);
@@ -388,11 +390,263 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
   int st = 0;
   __syncthreads();
 
+#ifndef CDKF_AWG_CUSTOM
+  // ---- MLP drift (round 4): weights, work vectors and the tangent pass's images behind the vectors (awg_mlp_lds_reals) ---------------
+  const int l1 = h1 | 1, l2 = h2 | 1, ldd = d | 1;
+  R* const mx = lam2 + 64;
+  R* const W2s = mx;                              // [h2][l1]
+  R* const W1s = W2s + (long)h2 * l1;             // [h1][ldd]
+  R* const W3s = W1s + (long)h1 * ldd;            // [d][l2]
+  R* const mv = W3s + (long)d * l2;               // kAwgMlpVecs vectors of 64
+  R *const va1 = mv, *const vd1 = mv + 64, *const va2 = mv + 128, *const vd2 = mv + 192, *const vz2b = mv + 256, *const vz1b = mv + 320,
+    *const vs = mv + 384, *const vs2 = mv + 448, *const vtd = mv + 512, *const vtq = mv + 576, *const vr = mv + 640, *const vtdb = mv + 704,
+    *const vtcb = mv + 768, *const vs2b = mv + 832, *const vsb = mv + 896, *const vd2b = mv + 960, *const vz2c = mv + 1024,
+    *const vz1c = mv + 1088;
+  R* const Ui = mv + 64L * kAwgMlpVecs;           // [h1][ldd]  U = D1 W1
+  R* const Ti = Ui + 64L * ldd;                   // [h2][ldd]  T = W2 U  (tangent of z2)
+  R* const C2 = Ti + 64L * ldd;                   // [h2][ldd]  cotangent of D2 T, then of T
+  R* const C1 = C2 + 64L * ldd;                   // [h1][ldd]  cotangent of U; 'second': E1 = W2^T diag(d2) W3^T on the way
+  const long oW1 = 0, ob1 = oW1 + (long)h1 * d, oW2 = ob1 + h1, ob2 = oW2 + (long)h2 * h1, oW3 = ob2 + h2, ob3 = oW3 + (long)d * h2;
+  if (mlp) {
+    AWG_FOR(e, h2 * h1) { const int p_ = fdiv(e, h1); W2s[p_ * l1 + (e - p_ * h1)] = th[oW2 + e]; }
+    AWG_FOR(e, h1 * d) { const int q_ = fdiv(e, d); W1s[q_ * ldd + (e - q_ * d)] = th[oW1 + e]; }
+    AWG_FOR(e, d * h2) { const int i_ = fdiv(e, h2); W3s[i_ * l2 + (e - i_ * h2)] = th[oW3 + e]; }
+    __syncthreads();
+  }
+  // f(xv) into fv, F(xv) = W3 D2 W2 D1 W1 into F; leaves a1, d1, a2, d2, U, T for mlp_g / mlp_bwd.  Synchronises inside; the caller
+  // synchronises before and after as for the other drifts.
+  auto mlp_fwd = [&](const R* xv, R* F) {
+    AWG_FOR(q_, h1) {
+      R z = th[ob1 + q_];
+      for (int i_ = 0; i_ < d; ++i_) z = rfma(W1s[q_ * ldd + i_], xv[i_], z);
+      const R a1_ = rtanh_fast(z);
+      va1[q_] = a1_;
+      vd1[q_] = R(1) - a1_ * a1_;
+    }
+    __syncthreads();
+    AWG_FOR(e, h1 * d) {
+      const int q_ = fdiv(e, d), i_ = e - q_ * d;
+      Ui[q_ * ldd + i_] = vd1[q_] * W1s[q_ * ldd + i_];
+    }
+    AWG_FOR(p_, h2) {
+      R z = th[ob2 + p_];
+      for (int q_ = 0; q_ < h1; ++q_) z = rfma(W2s[p_ * l1 + q_], va1[q_], z);
+      const R a2_ = rtanh_fast(z);
+      va2[p_] = a2_;
+      vd2[p_] = R(1) - a2_ * a2_;
+    }
+    __syncthreads();
+    AWG_FOR(e, h2 * d) {
+      const int p_ = fdiv(e, d), i_ = e - p_ * d;
+      R s_ = R(0);
+      for (int q_ = 0; q_ < h1; ++q_) s_ = rfma(W2s[p_ * l1 + q_], Ui[q_ * ldd + i_], s_);
+      Ti[p_ * ldd + i_] = s_;
+    }
+    __syncthreads();
+    AWG_FOR(e, d * d) {
+      const int i_ = fdiv(e, d), j_ = e - i_ * d;
+      R s_ = R(0);
+      for (int p_ = 0; p_ < h2; ++p_) s_ = rfma(W3s[i_ * l2 + p_] * vd2[p_], Ti[p_ * ldd + j_], s_);
+      F[i_ * ld + j_] = s_;
+    }
+    if (tid < d) {
+      R s_ = th[ob3 + tid];
+      for (int p_ = 0; p_ < h2; ++p_) s_ = rfma(W3s[tid * l2 + p_], va2[p_], s_);
+      fv[tid] = s_;
+    }
+  };
+  // g = grad(div f) at the point mlp_fwd was last called for, into gout (oracle: MLPDrift.divgrad): td = G^T d2, s = G d1, s2 = -2 a2 d2 s,
+  // tc = W2^T s2, tq = d1 (-2 a1 td + tc), g = W1^T tq with G = ((W1 W3)^T o W2) through its rank-d factors -- E1 = W2^T diag(d2) W3^T
+  // gives td_q = sum_i W1[q][i] E1[q][i], the tangent T gives s_p = sum_i W3[i][p] T[p][i].  Synchronises before it reads and after.
+  auto mlp_g = [&](R* gout) {
+    __syncthreads();
+    AWG_FOR(p_, h2) {
+      R s_ = R(0);
+      for (int i_ = 0; i_ < d; ++i_) s_ = rfma(W3s[i_ * l2 + p_], Ti[p_ * ldd + i_], s_);
+      vs[p_] = s_;
+      vs2[p_] = R(-2) * va2[p_] * vd2[p_] * s_;
+    }
+    AWG_FOR(e, h1 * d) {
+      const int q_ = fdiv(e, d), i_ = e - q_ * d;
+      R s_ = R(0);
+      for (int p_ = 0; p_ < h2; ++p_) s_ = rfma(W2s[p_ * l1 + q_] * vd2[p_], W3s[i_ * l2 + p_], s_);
+      C1[q_ * ldd + i_] = s_;
+    }
+    __syncthreads();
+    AWG_FOR(q_, h1) {
+      R td_ = R(0), tc_ = R(0);
+      for (int i_ = 0; i_ < d; ++i_) td_ = rfma(W1s[q_ * ldd + i_], C1[q_ * ldd + i_], td_);
+      for (int p_ = 0; p_ < h2; ++p_) tc_ = rfma(vs2[p_], W2s[p_ * l1 + q_], tc_);
+      vtd[q_] = td_;
+      vtq[q_] = vd1[q_] * rfma(R(-2) * va1[q_], td_, tc_);
+    }
+    __syncthreads();
+    if (tid < d) {
+      R s_ = R(0);
+      for (int q_ = 0; q_ < h1; ++q_) s_ = rfma(W1s[q_ * ldd + tid], vtq[q_], s_);
+      gout[tid] = s_;
+    }
+    __syncthreads();
+  };
+  // Reverse of a right-hand side through the network: the gradient of  lam . f(x) + <G2, F(x)>  (+ u . g(x) for 'second', u non-null;
+  // mlp_g must have run for this point) with respect to x -- into xb -- and to the weights -- added to the trajectory's gradient g.
+  // oracle/cdkf_oracle.py: the "mlp" branch of the drift's vector-Jacobian product and divgrad_vjp, same intermediate names.  Every
+  // entry of g is always updated by the same thread (one AWG_FOR index space per weight block): program order, no atomics.
+  auto M_of = [&](int p_, int q_) {  // M_pq = sum_i W3[i][p] W1[q][i]  ((W1 W3)^T, never stored)
+    R s_ = R(0);
+    for (int i_ = 0; i_ < d; ++i_) s_ = rfma(W3s[i_ * l2 + p_], W1s[q_ * ldd + i_], s_);
+    return s_;
+  };
+  auto mlp_bwd = [&](const R* xv, const R* lamv, const R* G2, const R* u, R* xb) {
+    __syncthreads();
+    AWG_FOR(e, h2 * d) {  // c2 = W3^T G2
+      const int p_ = fdiv(e, d), j_ = e - p_ * d;
+      R s_ = R(0);
+      for (int i_ = 0; i_ < d; ++i_) s_ = rfma(W3s[i_ * l2 + p_], G2[i_ * ld + j_], s_);
+      C2[p_ * ldd + j_] = s_;
+    }
+    if (tid < d) g[ob3 + tid] += lamv[tid];
+    __syncthreads();
+    AWG_FOR(e, d * h2) {  // dW3 += lam a2^T + G2 (D2 T)^T
+      const int i_ = fdiv(e, h2), p_ = e - i_ * h2;
+      R s_ = R(0);
+      for (int j_ = 0; j_ < d; ++j_) s_ = rfma(G2[i_ * ld + j_], Ti[p_ * ldd + j_], s_);
+      g[oW3 + e] += rfma(lamv[i_], va2[p_], vd2[p_] * s_);
+    }
+    AWG_FOR(p_, h2) {  // a2b, z2b
+      R s_ = R(0), w_ = R(0);
+      for (int i_ = 0; i_ < d; ++i_) s_ = rfma(W3s[i_ * l2 + p_], lamv[i_], s_);
+      for (int j_ = 0; j_ < d; ++j_) w_ = rfma(Ti[p_ * ldd + j_], C2[p_ * ldd + j_], w_);
+      vz2b[p_] = vd2[p_] * rfma(R(-2) * va2[p_], w_, s_);
+    }
+    __syncthreads();
+    AWG_FOR(e, h2 * d) {  // zt2 = D2 c2
+      const int p_ = fdiv(e, d);
+      C2[p_ * ldd + (e - p_ * d)] *= vd2[p_];
+    }
+    __syncthreads();
+    AWG_FOR(e, h2 * h1) {  // dW2 += z2b a1^T + zt2 U^T
+      const int p_ = fdiv(e, h1), q_ = e - p_ * h1;
+      R s_ = vz2b[p_] * va1[q_];
+      for (int j_ = 0; j_ < d; ++j_) s_ = rfma(C2[p_ * ldd + j_], Ui[q_ * ldd + j_], s_);
+      g[oW2 + e] += s_;
+    }
+    AWG_FOR(p_, h2) g[ob2 + p_] += vz2b[p_];
+    AWG_FOR(e, h1 * d) {  // c1 = W2^T zt2
+      const int q_ = fdiv(e, d), j_ = e - q_ * d;
+      R s_ = R(0);
+      for (int p_ = 0; p_ < h2; ++p_) s_ = rfma(W2s[p_ * l1 + q_], C2[p_ * ldd + j_], s_);
+      C1[q_ * ldd + j_] = s_;
+    }
+    __syncthreads();
+    AWG_FOR(q_, h1) {  // a1b, z1b
+      R s_ = R(0), w_ = R(0);
+      for (int p_ = 0; p_ < h2; ++p_) s_ = rfma(W2s[p_ * l1 + q_], vz2b[p_], s_);
+      for (int j_ = 0; j_ < d; ++j_) w_ = rfma(W1s[q_ * ldd + j_], C1[q_ * ldd + j_], w_);
+      const R z_ = vd1[q_] * rfma(R(-2) * va1[q_], w_, s_);
+      vz1b[q_] = z_;
+      g[ob1 + q_] += z_;
+    }
+    __syncthreads();
+    AWG_FOR(e, h1 * d) {  // dW1 += z1b x^T + D1 c1
+      const int q_ = fdiv(e, d), i_ = e - q_ * d;
+      g[oW1 + e] += rfma(vz1b[q_], xv[i_], vd1[q_] * C1[q_ * ldd + i_]);
+    }
+    if (tid < d) {
+      R s_ = R(0);
+      for (int q_ = 0; q_ < h1; ++q_) s_ = rfma(W1s[q_ * ldd + tid], vz1b[q_], s_);
+      xb[tid] = s_;
+    }
+    __syncthreads();
+    if (!u) return;
+    // ---- 'second': the gradient of u . g(x) (divgrad_vjp) --------------------------------------------------------------------------
+    AWG_FOR(q_, h1) {
+      R r_ = R(0);
+      for (int l_ = 0; l_ < d; ++l_) r_ = rfma(W1s[q_ * ldd + l_], u[l_], r_);
+      const R a1_ = va1[q_], d1_ = vd1[q_];
+      vr[q_] = r_;
+      vtdb[q_] = R(-2) * a1_ * d1_ * r_;
+      vtcb[q_] = d1_ * r_;
+      vz1c[q_] = r_ * (R(-2) * a1_ * vtq[q_] - R(2) * d1_ * d1_ * vtd[q_]);
+    }
+    AWG_FOR(e, h1 * d) {
+      const int q_ = fdiv(e, d);
+      g[oW1 + e] += vtq[q_] * u[e - q_ * d];
+    }
+    __syncthreads();
+    AWG_FOR(p_, h2) {
+      R d2b_ = R(0), s2b_ = R(0);
+      for (int q_ = 0; q_ < h1; ++q_) {
+        const R w_ = W2s[p_ * l1 + q_];
+        d2b_ = rfma(w_ * M_of(p_, q_), vtdb[q_], d2b_);
+        s2b_ = rfma(w_, vtcb[q_], s2b_);
+      }
+      const R a2_ = va2[p_], d2_ = vd2[p_];
+      vs2b[p_] = s2b_;
+      vsb[p_] = R(-2) * a2_ * d2_ * s2b_;
+      vd2b[p_] = d2b_;
+      vz2c[p_] = s2b_ * (R(-2) * vs[p_]) * d2_ * (R(1) - R(3) * a2_ * a2_) + d2b_ * (R(-2) * a2_ * d2_);
+    }
+    AWG_FOR(e, h2 * h1) {
+      const int p_ = fdiv(e, h1);
+      g[oW2 + e] += vs2[p_] * vtcb[e - p_ * h1];
+    }
+    __syncthreads();
+    AWG_FOR(q_, h1) {  // z1_b += (s_b G)(-2 a1 d1)
+      R s_ = R(0);
+      for (int p_ = 0; p_ < h2; ++p_) s_ = rfma(vsb[p_] * W2s[p_ * l1 + q_], M_of(p_, q_), s_);
+      vz1c[q_] += s_ * (R(-2) * va1[q_] * vd1[q_]);
+    }
+    AWG_FOR(e, h2 * h1) {  // dW2 += G_b o M + z2_b a1^T,  G_b = d2 td_b^T + s_b d1^T
+      const int p_ = fdiv(e, h1), q_ = e - p_ * h1;
+      const R gb_ = rfma(vd2[p_], vtdb[q_], vsb[p_] * vd1[q_]);
+      g[oW2 + e] += rfma(gb_, M_of(p_, q_), vz2c[p_] * va1[q_]);
+    }
+    AWG_FOR(e, h1 * d) {  // dW1 += (G_b o W2)^T W3^T
+      const int q_ = fdiv(e, d), i_ = e - q_ * d;
+      R s_ = R(0);
+      for (int p_ = 0; p_ < h2; ++p_) s_ = rfma(rfma(vd2[p_], vtdb[q_], vsb[p_] * vd1[q_]) * W2s[p_ * l1 + q_], W3s[i_ * l2 + p_], s_);
+      g[oW1 + e] += s_;
+    }
+    AWG_FOR(e, d * h2) {  // dW3 += W1^T (G_b o W2)^T
+      const int i_ = fdiv(e, h2), p_ = e - i_ * h2;
+      R s_ = R(0);
+      for (int q_ = 0; q_ < h1; ++q_) s_ = rfma(W1s[q_ * ldd + i_], rfma(vd2[p_], vtdb[q_], vsb[p_] * vd1[q_]) * W2s[p_ * l1 + q_], s_);
+      g[oW3 + e] += s_;
+    }
+    AWG_FOR(p_, h2) g[ob2 + p_] += vz2c[p_];
+    __syncthreads();
+    AWG_FOR(q_, h1) {  // z1_b += (W2^T z2_b) d1
+      R s_ = R(0);
+      for (int p_ = 0; p_ < h2; ++p_) s_ = rfma(W2s[p_ * l1 + q_], vz2c[p_], s_);
+      const R z_ = rfma(s_, vd1[q_], vz1c[q_]);
+      vz1c[q_] = z_;
+      g[ob1 + q_] += z_;
+    }
+    __syncthreads();
+    AWG_FOR(e, h1 * d) {
+      const int q_ = fdiv(e, d);
+      g[oW1 + e] += vz1c[q_] * xv[e - q_ * d];
+    }
+    if (tid < d) {
+      R s_ = xb[tid];
+      for (int q_ = 0; q_ < h1; ++q_) s_ = rfma(W1s[q_ * ldd + tid], vz1c[q_], s_);
+      xb[tid] = s_;
+    }
+    __syncthreads();
+  };
+#endif
   // ---- drift: dense Jacobian F(x) into a slot, f(x) into fv; x in LDS (synchronised by the caller before AND after) ------------
   auto drift_eval = [&](const R* xv, R* F) {
 #ifdef CDKF_AWG_CUSTOM
     if (custom) {  // jacfwd with the directions spread over the workgroup: thread j carries e_j
       AWG_FOR(j, d) awg_custom_column<R>(th, xv, j, F, ld, j == 0 ? fv : (R*)nullptr);
+      return;
+    }
+#endif
+#ifndef CDKF_AWG_CUSTOM
+    if (mlp) {
+      mlp_fwd(xv, F);
       return;
     }
 #endif
@@ -698,6 +952,11 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
         custom_g(xs, g1);
         if (tid < d) km[64 * si + tid] = rfma(R(0.5), dot(d, [&](int kk) { return Ps[tid * ld + kk]; }, [&](int kk) { return g1[kk]; }), fv[tid]);
       } else
+#else
+      if (second) {  // (MLP) dm/dt = f + 0.5 Ps g  (inference_ekf.py:108-116)
+        mlp_g(g1);
+        if (tid < d) km[64 * si + tid] = rfma(R(0.5), dot(d, [&](int kk) { return Ps[tid * ld + kk]; }, [&](int kk) { return g1[kk]; }), fv[tid]);
+      } else
 #endif
       if (tid < d) km[64 * si + tid] = fv[tid];
       __syncthreads();
@@ -958,6 +1217,12 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
             if (tid < d) g2[tid] = R(0.5) * dot(d, [&](int i) { return Ps[i * ld + tid]; }, [&](int i) { return lamv[i]; });
             __syncthreads();
           }
+#else
+          if (second) {  // (MLP) g(xs) again, and u = 0.5 Ps^T lam: the cotangent of g in the mean's slope
+            mlp_g(g1);
+            if (tid < d) g2[tid] = R(0.5) * dot(d, [&](int i) { return Ps[i * ld + tid]; }, [&](int i) { return lamv[i]; });
+            __syncthreads();
+          }
 #endif
           AWG_TICK(9)  // stage cotangent, stage value, drift
           // Ybar_P = F^T Lam + Lam F = (Lam F) + (Lam F)^T;  G = 2 Lam Ps where the drift's parameters / state derivative want it
@@ -991,6 +1256,12 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
               }
               part[grp * Z + z] = s2;
             }
+#else
+          } else if (mlp) {  // G2 = 2 Lam Ps in full, then the network's reverse pass (weights' gradient into g, state's into g3)
+            R* G2 = slot(7);
+            gemm(d, d, d, [&](int i, int kk) { return Lam[i * ld + kk]; }, [&](int kk, int j) { return Ps[kk * ld + j]; },
+                 [&](int i, int j, R v) { G2[i * ld + j] = R(2) * v; });
+            mlp_bwd(xs, lamv, G2, second ? g2 : (const R*)nullptr, g3);
 #endif
           } else if (tid < 3 * d && 3 * d <= NT) {  // Lorenz-96: the three entries of row i of G the state derivative of F touches, a thread each
             const int which = fdiv(tid, d), i = tid - which * d;
@@ -1025,6 +1296,9 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
 #ifdef CDKF_AWG_CUSTOM
             } else if (custom) {
               for (int grp = 0; grp < cNG; ++grp) s2 += cpart[grp * cZ + c];
+#else
+            } else if (mlp) {
+              s2 = g3[c];  // (the network's reverse pass returns the whole state gradient, F^T lam included)
 #endif
             } else {
               // xbar[i-1] += G[i][i+1] - G[i][i-2];  xbar[i+1] += G[i][i-1];  xbar[i-2] -= G[i][i-1]
@@ -1048,7 +1322,7 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
             }
           } else
 #endif
-          if (!lin && tid == 64) gForcing += dot(d, [&](int r) { return lamv[r]; }, [&](int) { return R(1); });  // (a thread of another wavefront)
+          if (l96 && tid == 64) gForcing += dot(d, [&](int r) { return lamv[r]; }, [&](int) { return R(1); });  // (a thread of another wavefront)
           AWG_TICK(10)  // right-hand-side adjoint products
         }
         take_cotangent(0);
@@ -1083,7 +1357,7 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
     if (tid < d) gm[tid] = mb[tid];
     rows2d(d, d, [&](int i, int j) { return R(0.5) * (Pb[i * ld + j] + Pb[j * ld + i]); }, [&](int i, int j, R v) { gP0[i * d + j] = v; });
   }
-  if (!custom && !lin && tid == 64) g[0] = gForcing;
+  if (l96 && tid == 64) g[0] = gForcing;
   if (st && tid == 0 && a.status) atomicOr(&a.status[n], st);
 #ifdef CDKF_AWG_PROFILE
   if (threadIdx.x == 0 && blockIdx.x == 0) {

@@ -229,6 +229,7 @@ int launch_adjoint_kernel(const WgArgs<R>& a, R* grad, R* grad_model, hipStream_
 // reverse sweep (gradient) for larger states, one workgroup per trajectory (launch_adjwg.hip, cdkf_adjoint_wg_kernels.h); scratch:
 // N * adjoint_wg_scratch_reals(d, cap) reals
 bool adjoint_wg_fits(int d, int m, int bytes_per_real);
+bool adjoint_wg_fits_mlp(int d, int m, int h1, int h2, int bytes_per_real);  // ... + the MLP drift's LDS region
 long adjoint_wg_scratch_reals(int d, int cap);
 template <typename R>
 int launch_adjoint_wg_kernel(const WgArgs<R>& a, R* grad, R* grad_model, R* scratch, int cap, hipStream_t stream);

@@ -383,6 +383,9 @@ int release_grad_workspace() {
 static bool adjoint_wg_shape(const cdkf_model* mdl, const cdkf_opts* o) {
   if (mdl->drift_kind >= CDKF_DRIFT_CUSTOM_BASE) {  // a drift given as source: its derivatives by dual numbers inside the sweep
     if (!custom_adjoint_available(mdl, o)) return false;
+  } else if (mdl->drift_kind == CDKF_DRIFT_MLP_TANH) {  // (round 4) the network's reverse pass on the workgroup's threads, both state orders
+    return mdl->emission_kind == 0 && wg_shape_available(mdl, 4) && mdl->state_dim <= 42 &&
+           adjoint_wg_fits_mlp(mdl->state_dim, mdl->emission_dim, mdl->hidden1, mdl->hidden2, 4);
   } else if (mdl->drift_kind != CDKF_DRIFT_LORENZ96 && mdl->drift_kind != CDKF_DRIFT_LINEAR) {
     return false;
   }
@@ -402,9 +405,13 @@ bool adjoint_shape_available(const cdkf_model* mdl, const cdkf_opts* o) {
 template <typename R>
 static int launch_ekf_grad_adjoint_wg(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll,
                                       R* grad, R* grad_model, int32_t* status, hipStream_t stream) {
-  if (!adjoint_wg_fits(mdl->state_dim, mdl->emission_dim, (int)sizeof(R))) {
+  const bool fits = mdl->drift_kind == CDKF_DRIFT_MLP_TANH
+                        ? adjoint_wg_fits_mlp(mdl->state_dim, mdl->emission_dim, mdl->hidden1, mdl->hidden2, (int)sizeof(R))
+                        : adjoint_wg_fits(mdl->state_dim, mdl->emission_dim, (int)sizeof(R));
+  if (!fits) {
     set_error("reverse sweep: state_dim %d / emission_dim %d do not fit its LDS plan in fp%d (nine q x q matrices, q = max of the two: "
-              "q <= 43 in fp64, 62 in fp32)", mdl->state_dim, mdl->emission_dim, (int)sizeof(R) * 8);
+              "q <= 43 in fp64, 62 in fp32; with an MLP drift its weights and tangent images as well)", mdl->state_dim, mdl->emission_dim,
+              (int)sizeof(R) * 8);
     return CDKF_EUNSUPPORTED;
   }
   WgArgs<R> a{};

@@ -219,6 +219,10 @@ def _fit_sgd_with_offsets(model, params, props, emissions, t_emissions, filter_h
     sweeps take host arrays per step (this front-end is BASELINE config 1: one or a few trajectories)."""
     from .fit import Adam, _Trainable
     optimizer = Adam(1e-3) if optimizer is None else optimizer
+    # a leaf that is absent (None) or empty (input weights with input_dim = 0) has nothing to train
+    frozen = ParameterProperties(trainable=False)
+    props = _tree_map2(lambda p, v: p if (isinstance(p, ParameterProperties) and v is not None and np.size(v) > 0) else
+                       (frozen if isinstance(p, ParameterProperties) else p), props, params)
     tr = _Trainable(params, props)
     y = np.asarray(emissions)
     batched = y.ndim == 3
@@ -265,6 +269,12 @@ def _fit_sgd_with_offsets(model, params, props, emissions, t_emissions, filter_h
     if return_grad_history:
         out.append(grad_hist)
     return tuple(out)
+
+
+def _tree_map2(fn, tree, other):
+    if isinstance(tree, tuple) and hasattr(tree, "_fields") and not isinstance(tree, ParameterProperties):
+        return type(tree)(*[_tree_map2(fn, v, getattr(other, f)) for f, v in zip(tree._fields, tree)])
+    return fn(tree, other)
 
 
 def _tree_map(fn, tree):
