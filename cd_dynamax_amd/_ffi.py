@@ -112,7 +112,8 @@ SYMBOLS = (
      "cdkf_kf_smoother1_f64", "cdkf_kf_smoother1_f32", "cdkf_kf_smoother1_f64_dev", "cdkf_kf_smoother1_f32_dev",
      "cdkf_kf_smoother1_supported", "cdkf_kf_pushforward_f64", "cdkf_kf_pushforward_f32", "cdkf_grad_supported", "cdkf_grad_all_supported", "cdkf_release_workspace", "cdkf_ekf_loglik_grad_all_f64",
      "cdkf_ekf_loglik_grad_all_f32", "cdkf_ekf_loglik_grad_all_f64_dev", "cdkf_ekf_loglik_grad_all_f32_dev", "cdkf_ekf_loglik_grad_jumps_f64",
-     "cdkf_ekf_loglik_grad_jumps_f32", "cdkf_grad_sum_f64_dev",
+     "cdkf_ekf_loglik_grad_jumps_f32", "cdkf_ukf_loglik_grad_all_f64", "cdkf_ukf_loglik_grad_all_f32", "cdkf_ukf_loglik_grad_all_f64_dev",
+     "cdkf_ukf_loglik_grad_all_f32_dev", "cdkf_ukf_grad_all_supported", "cdkf_grad_sum_f64_dev",
      "cdkf_grad_sum_f32_dev", "cdkf_comm_preflight", "cdkf_comm_unique_id", "cdkf_comm_init_rank", "cdkf_comm_init_all", "cdkf_comm_rank", "cdkf_comm_world",
      "cdkf_ll_allreduce", "cdkf_comm_allreduce_max", "cdkf_ll_allreduce_all", "cdkf_comm_destroy", "cdkf_rdv_create",
      "cdkf_rdv_broadcast", "cdkf_rdv_allreduce", "cdkf_rdv_barrier", "cdkf_rdv_destroy", "cdkf_last_kernel", "cdkf_event_create",
@@ -236,6 +237,15 @@ def lib() -> C.CDLL:
         f = getattr(L, f"cdkf_ekf_loglik_grad_all_{p}_dev")
         f.argtypes = base + [C.c_void_p]
         f.restype = C.c_int
+        if hasattr(L, f"cdkf_ukf_loglik_grad_all_{p}"):  # (absent from libraries older than 108)
+            f = getattr(L, f"cdkf_ukf_loglik_grad_all_{p}")
+            f.argtypes = base
+            f.restype = C.c_int
+            f = getattr(L, f"cdkf_ukf_loglik_grad_all_{p}_dev")
+            f.argtypes = base + [C.c_void_p]
+            f.restype = C.c_int
+            L.cdkf_ukf_grad_all_supported.argtypes = [C.POINTER(CdkfModel), C.POINTER(CdkfOpts)]
+            L.cdkf_ukf_grad_all_supported.restype = C.c_int
         if hasattr(L, f"cdkf_ekf_loglik_grad_jumps_{p}"):  # (absent from libraries older than 108)
             f = getattr(L, f"cdkf_ekf_loglik_grad_jumps_{p}")
             f.argtypes = [C.POINTER(CdkfModel), C.POINTER(CdkfOpts), C.c_int64, C.c_int64] + [C.c_void_p] * 9
@@ -473,7 +483,7 @@ def loglik_grad(mdl: ModelBlock, opts: CdkfOpts, t: np.ndarray, y: np.ndarray, d
     status = np.zeros((N,), np.int32)
     if with_model:
         gm = np.empty((N, model_grad_size(mdl.state_dim, mdl.emission_dim)), dtype)
-        fn = getattr(lib(), f"cdkf_ekf_loglik_grad_all_{suffix}")
+        fn = getattr(lib(), f"cdkf_{'ukf' if ukf else 'ekf'}_loglik_grad_all_{suffix}")
         check(fn(C.byref(mdl.c), C.byref(opts), N, T, _vp(t), _vp(y), _vp(ll), _vp(grad), _vp(gm), _vp(status)))
         return ll, grad, status, gm
     fn = getattr(lib(), f"cdkf_{'ukf' if ukf else 'ekf'}_loglik_grad_{suffix}")

@@ -455,6 +455,19 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
     kP = (acc + W[AdjOff::A + j * 8 + i]) + lql;
     if (lane < 8) {
       kM = W[AdjOff::f + lane];
+      if constexpr (!MLP) {
+        if (a.ukf && lane < d) {  // the unscented filter's curvature term of a quadratic drift (cdkf_wave8_kernels.h, oracle: ukf_curvature)
+          auto Pe = [&](int r, int c) __attribute__((always_inline)) { return W[AdjOff::P + r * 8 + c]; };
+          if (a.kind == kDriftLorenz63) {
+            if (lane == 1) kM -= Pe(0, 2);
+            if (lane == 2) kM += Pe(0, 1);
+          } else if (a.kind == kDriftLorenz96) {
+            const int l = lane;
+            const int lp1 = (l + 1 >= d) ? 0 : l + 1, lm1 = (l == 0) ? d - 1 : l - 1, lm2 = (lm1 == 0) ? d - 1 : lm1 - 1;
+            kM += Pe(lp1, lm1) - Pe(lm2, lm1);
+          }
+        }
+      }
       if (second) {  // + 0.5 (P g)_lane
         R hg = 0;
 #pragma unroll
@@ -523,6 +536,20 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
       W[AdjOff::G + lane] = Gij;
       wave_sync();
       YP = mm_tn(AdjOff::F, AdjOff::Lam) + mm(AdjOff::Lam, AdjOff::F);
+      if (a.ukf && inP) {  // cotangent of Ps through lam . curvature(Ps), symmetric (oracle: ukf_curvature_vjp)
+        auto lm_ = [&](int r) __attribute__((always_inline)) { return W[AdjOff::lam + r]; };
+        if (a.kind == kDriftLorenz63) {
+          if ((i == 0 && j == 2) || (i == 2 && j == 0)) YP -= R(0.5) * lm_(1);
+          if ((i == 0 && j == 1) || (i == 1 && j == 0)) YP += R(0.5) * lm_(2);
+        } else if (a.kind == kDriftLorenz96) {
+          auto wr = [&](int q) __attribute__((always_inline)) { return q < 0 ? q + d : (q >= d ? q - d : q); };
+          // Pb[l+1][l-1] += lam_l, Pb[l-2][l-1] -= lam_l, then 0.5 (Pb + Pb^T): the entries of lane (i, j)
+          if (j == wr(i - 2)) YP += R(0.5) * lm_(wr(i - 1));   // (i, j) = (l+1, l-1)
+          if (i == wr(j - 2)) YP += R(0.5) * lm_(wr(j - 1));   // its transpose
+          if (j == wr(i + 1)) YP -= R(0.5) * lm_(wr(i + 2));   // (i, j) = (l-2, l-1)
+          if (i == wr(j + 1)) YP -= R(0.5) * lm_(wr(j + 2));   // its transpose
+        }
+      }
       auto G = [&](int r, int c) __attribute__((always_inline)) { return W[AdjOff::G + r * 8 + c]; };
       if (a.kind == kDriftLinear) gTile = rfma(W[AdjOff::lam + i], W[AdjOff::x + j], gTile + Gij);
       if (lane < 8) {

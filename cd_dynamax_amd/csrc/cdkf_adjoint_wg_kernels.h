@@ -958,7 +958,12 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
         if (tid < d) km[64 * si + tid] = rfma(R(0.5), dot(d, [&](int kk) { return Ps[tid * ld + kk]; }, [&](int kk) { return g1[kk]; }), fv[tid]);
       } else
 #endif
-      if (tid < d) km[64 * si + tid] = fv[tid];
+      if (tid < d) {
+        R kmv = fv[tid];
+        if (a.ukf && l96)  // the unscented filter's curvature term of the quadratic drift (oracle: ukf_curvature)
+          kmv += Ps[wrap(tid + 1) * ld + wrap(tid - 1)] - Ps[wrap(tid - 2) * ld + wrap(tid - 1)];
+        km[64 * si + tid] = kmv;
+      }
       __syncthreads();
     }
     take_slope(nst - 1, A);
@@ -1323,6 +1328,13 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
           } else
 #endif
           if (l96 && tid == 64) gForcing += dot(d, [&](int r) { return lamv[r]; }, [&](int) { return R(1); });  // (a thread of another wavefront)
+          if (a.ukf && l96) {  // Ybar_P = G + G^T gains the cotangent of Ps through lam . curvature(Ps) (oracle: ukf_curvature_vjp)
+            if (tid < d) {
+              G[wrap(tid + 1) * ld + wrap(tid - 1)] += R(0.5) * lamv[tid];
+              G[wrap(tid - 2) * ld + wrap(tid - 1)] -= R(0.5) * lamv[tid];
+            }
+            __syncthreads();
+          }
           AWG_TICK(10)  // right-hand-side adjoint products
         }
         take_cotangent(0);

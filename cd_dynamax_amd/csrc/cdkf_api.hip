@@ -226,6 +226,7 @@ int loglik_grad_dev(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_
   }
   if (N == 0) return CDKF_OK;
   CDKF_SELECT_DEVICE(o);
+  if (ukf && grad_model) return launch_ukf_grad_all<R>(mdl, o, N, T, t, y, ll, grad, grad_model, status, (hipStream_t)stream);
   if (ukf) return launch_ukf_grad<R>(mdl, o, N, T, t, y, ll, grad, status, (hipStream_t)stream);
   return launch_ekf_grad<R>(mdl, o, N, T, t, y, ll, grad, grad_model, status, (hipStream_t)stream);
 }
@@ -252,7 +253,9 @@ int loglik_grad_host(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64
     return rc;
   CDKF_HIP_CHECK(hipMemcpy(dt.p, t, nt * sizeof(R), hipMemcpyHostToDevice));
   CDKF_HIP_CHECK(hipMemcpy(dy.p, y, ny * sizeof(R), hipMemcpyHostToDevice));
-  rc = ukf ? launch_ukf_grad<R>(mdl, o, N, T, (const R*)dt.p, (const R*)dy.p, (R*)dll.p, (R*)dg.p, (int32_t*)dst.p, nullptr)
+  rc = (ukf && grad_model) ? launch_ukf_grad_all<R>(mdl, o, N, T, (const R*)dt.p, (const R*)dy.p, (R*)dll.p, (R*)dg.p, (R*)dgm.p,
+                                                   (int32_t*)dst.p, nullptr)
+       : ukf ? launch_ukf_grad<R>(mdl, o, N, T, (const R*)dt.p, (const R*)dy.p, (R*)dll.p, (R*)dg.p, (int32_t*)dst.p, nullptr)
            : launch_ekf_grad<R>(mdl, o, N, T, (const R*)dt.p, (const R*)dy.p, (R*)dll.p, (R*)dg.p, (R*)dgm.p, (int32_t*)dst.p,
                                 nullptr);
   if (rc) return rc;
@@ -775,6 +778,29 @@ int cdkf_ekf_loglik_grad_all_f32_dev(const cdkf_model* mdl, const cdkf_opts* o, 
                                      void* stream) {
   if (int rc = need_model_grad(grad_model)) return rc;
   return loglik_grad_dev<float>(mdl, o, N, T, t, y, ll, grad, grad_model, status, stream);
+}
+int cdkf_ukf_loglik_grad_all_f64(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const double* t, const double* y,
+                                 double* ll, double* grad, double* grad_model, int32_t* status) {
+  if (int rc = need_model_grad(grad_model)) return rc;
+  return loglik_grad_host<double>(mdl, o, N, T, t, y, ll, grad, grad_model, status, true);
+}
+int cdkf_ukf_loglik_grad_all_f32(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const float* t, const float* y,
+                                 float* ll, float* grad, float* grad_model, int32_t* status) {
+  if (int rc = need_model_grad(grad_model)) return rc;
+  return loglik_grad_host<float>(mdl, o, N, T, t, y, ll, grad, grad_model, status, true);
+}
+int cdkf_ukf_loglik_grad_all_f64_dev(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const double* t, const double* y,
+                                     double* ll, double* grad, double* grad_model, int32_t* status, void* stream) {
+  if (int rc = need_model_grad(grad_model)) return rc;
+  return loglik_grad_dev<double>(mdl, o, N, T, t, y, ll, grad, grad_model, status, stream, true);
+}
+int cdkf_ukf_loglik_grad_all_f32_dev(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const float* t, const float* y,
+                                     float* ll, float* grad, float* grad_model, int32_t* status, void* stream) {
+  if (int rc = need_model_grad(grad_model)) return rc;
+  return loglik_grad_dev<float>(mdl, o, N, T, t, y, ll, grad, grad_model, status, stream, true);
+}
+int cdkf_ukf_grad_all_supported(const cdkf_model* mdl, const cdkf_opts* o) {
+  return (mdl && o && ukf_grad_all_shape_available(mdl, o)) ? 1 : 0;
 }
 int cdkf_ekf_loglik_grad_jumps_f64(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const double* t, const double* y,
                                    const double* jumps, double* ll, double* grad, double* grad_model, double* grad_jumps, double* grad_y,

@@ -54,6 +54,11 @@ int launch_ekf_grad_adjoint_jumps(const cdkf_model* mdl, const cdkf_opts* o, int
                                   const R* jumps, R* ll, R* grad, R* grad_model, R* grad_jumps, R* grad_y, int32_t* status,
                                   hipStream_t stream);
 bool adjoint_shape_available(const cdkf_model* mdl, const cdkf_opts* o);
+// the unscented filter's reverse-sweep gradient, every leaf (launch_wg.hip): Lorenz-63 / Lorenz-96 / linear drifts, linear emission
+bool ukf_grad_all_shape_available(const cdkf_model* mdl, const cdkf_opts* o);
+template <typename R>
+int launch_ukf_grad_all(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll, R* grad,
+                        R* grad_model, int32_t* status, hipStream_t stream);
 int release_grad_workspace();  // frees the per-process reverse-sweep workspace once its last user has finished (launch_wg.hip)
 // lease of the per-process reverse-sweep workspace (launch_wg.hip): holds its lock from construction to destruction
 struct GradWorkspaceLease {

@@ -640,6 +640,20 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave8_kernel(const WgArgs<R
       W8_TICK(6)  // k_P, td, tq, g, 0.5 P g
       return;
     }
+    if (a.ukf && lane < d) {
+      // The UNSCENTED filter's mean equation for a quadratic drift, in closed form (exact for every alpha, beta, kappa; oracle:
+      // ukf_curvature): f(m) + 0.5 sum_jk (d^2 f / dx_j dx_k) Ps_jk -- the covariance equation is the extended filter's.  Set by the
+      // unscented filter's reverse-sweep gradient only (cdkf_ukf_loglik_grad_all_*), whose forward pass this then is.
+      auto Pe = [&](int r, int c) __attribute__((always_inline)) { return W[W8Off::P + r * kW8 + c]; };
+      if (a.kind == kDriftLorenz63) {
+        if (lane == 1) fi -= Pe(0, 2);
+        if (lane == 2) fi += Pe(0, 1);
+      } else if (a.kind == kDriftLorenz96) {
+        const int l = lane;
+        const int lp1 = (l + 1 >= d) ? 0 : l + 1, lm1 = (l == 0) ? d - 1 : l - 1, lm2 = (lm1 == 0) ? d - 1 : lm1 - 1;
+        fi += Pe(lp1, lm1) - Pe(lm2, lm1);
+      }
+    }
     if (lane < kW8) kM = (lane < d) ? fi : R(0);
     if (zeroth) return;
     // A = F Ps ; kP = A_ij + A_ji + LQL_ij

@@ -404,7 +404,7 @@ bool adjoint_shape_available(const cdkf_model* mdl, const cdkf_opts* o) {
 // arrays into the workspace, reverse sweep on ekf_adjoint_wg_kernel
 template <typename R>
 static int launch_ekf_grad_adjoint_wg(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll,
-                                      R* grad, R* grad_model, int32_t* status, hipStream_t stream) {
+                                      R* grad, R* grad_model, int32_t* status, hipStream_t stream, bool ukf = false) {
   const bool fits = mdl->drift_kind == CDKF_DRIFT_MLP_TANH
                         ? adjoint_wg_fits_mlp(mdl->state_dim, mdl->emission_dim, mdl->hidden1, mdl->hidden2, (int)sizeof(R))
                         : adjoint_wg_fits(mdl->state_dim, mdl->emission_dim, (int)sizeof(R));
@@ -436,7 +436,10 @@ static int launch_ekf_grad_adjoint_wg(const cdkf_model* mdl, const cdkf_opts* o,
   a.fm = w; a.fP = w + nm; a.pm = w + nm + nP; a.pP = w + 2 * nm + nP;
   a.dtlog = ndt ? w + 2 * (nm + nP) + nscr : nullptr;
   a.dtlog_cap = ndt ? dtcap : 0;
-  rc = wave40_shape(mdl, o) ? launch_wave40<R>(a, stream) : launch_wg_dispatch<R>(a, mdl, false, stream);
+  // (unscented: the forward sweep forms the sigma points on the workgroup kernel; the reverse sweep replays the same moment equations in
+  //  closed form -- equal to rounding for the quadratic drift this path admits)
+  a.ukf = ukf ? 1 : 0;
+  rc = (wave40_shape(mdl, o) && !ukf) ? launch_wave40<R>(a, stream) : launch_wg_dispatch<R>(a, mdl, false, stream);
   if (!rc) rc = launch_adjoint_wg_kernel<R>(a, grad, grad_model, w + 2 * (nm + nP), cap, stream);
   CDKF_HIP_CHECK(hipEventRecord(ws.done, stream));
   ws.in_flight = true;
@@ -446,7 +449,8 @@ static int launch_ekf_grad_adjoint_wg(const cdkf_model* mdl, const cdkf_opts* o,
 
 template <typename R>
 static int adjoint_wave8_impl(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, const R* jumps,
-                              R* ll, R* grad, R* grad_model, R* grad_jumps, R* grad_y, int32_t* status, hipStream_t stream) {
+                              R* ll, R* grad, R* grad_model, R* grad_jumps, R* grad_y, int32_t* status, hipStream_t stream,
+                              bool ukf = false) {
   WgArgs<R> a{};
   R* blk = nullptr;
   // the workspace lock first, the parameter slot second: a caller waiting for the workspace holds no slot of the ring
@@ -495,6 +499,7 @@ static int adjoint_wave8_impl(const cdkf_model* mdl, const cdkf_opts* o, int64_t
   R* w = (R*)ws.p;
   a.t = t; a.y = y; a.ll = ll; a.status = status;
   a.cj = jumps; a.gcj = grad_jumps; a.gy = grad_y;
+  a.ukf = ukf ? 1 : 0;  // (the unscented filter's closed-form moment equations in both wavefront sweeps: cdkf_ukf_loglik_grad_all_*)
   a.fm = w; a.fP = w + nm; a.pm = w + nm + nP; a.pP = w + 2 * nm + nP;
   // other methods / adaptive steps: forward pass on the workgroup kernel (run-time tableau), no slopes kept
   const bool dp5 = o->solver == CDKF_SOLVER_DOPRI5 && !o->adaptive;
@@ -533,6 +538,34 @@ int launch_ekf_grad_adjoint_jumps(const cdkf_model* mdl, const cdkf_opts* o, int
   }
   return adjoint_wave8_impl<R>(mdl, o, N, T, t, y, jumps, ll, grad, grad_model, grad_jumps, grad_y, status, stream);
 }
+// The unscented filter's log-likelihood and its gradient w.r.t. EVERY leaf: for the drifts whose sigma-point sums
+// collapse exactly -- Lorenz-63 and Lorenz-96 (quadratic), linear -- with a linear emission, the moment equations are the extended
+// filter's plus a curvature term in the mean (oracle: ukf_curvature), and the reverse sweeps differentiate exactly those.
+bool ukf_grad_all_shape_available(const cdkf_model* mdl, const cdkf_opts* o) {
+  if (mdl->drift_kind != CDKF_DRIFT_LORENZ63 && mdl->drift_kind != CDKF_DRIFT_LORENZ96 && mdl->drift_kind != CDKF_DRIFT_LINEAR) return false;
+  if (mdl->emission_kind != 0 || o->solver != CDKF_SOLVER_DOPRI5 || o->adaptive) return false;
+  cdkf_opts e = *o;
+  e.state_order = CDKF_ORDER_FIRST;  // (the unscented filter has no state_order)
+  return adjoint_shape_available(mdl, &e);
+}
+template <typename R>
+int launch_ukf_grad_all(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll, R* grad,
+                        R* grad_model, int32_t* status, hipStream_t stream) {
+  if (!ukf_grad_all_shape_available(mdl, o)) {
+    set_error("ukf_loglik_grad_all: the unscented filter's reverse-sweep gradient covers the Lorenz-63, Lorenz-96 and linear drifts with a "
+              "linear emission, the default solver, num_iter 1 (drift_kind=%d state_dim=%d emission_dim=%d emission_kind=%d solver=%d)",
+              mdl->drift_kind, mdl->state_dim, mdl->emission_dim, mdl->emission_kind, o->solver);
+    return CDKF_EUNSUPPORTED;
+  }
+  cdkf_opts e = *o;
+  e.state_order = CDKF_ORDER_FIRST;
+  if (wave8_shape(mdl)) return adjoint_wave8_impl<R>(mdl, &e, N, T, t, y, nullptr, ll, grad, grad_model, nullptr, nullptr, status, stream, true);
+  return launch_ekf_grad_adjoint_wg<R>(mdl, &e, N, T, t, y, ll, grad, grad_model, status, stream, true);
+}
+template int launch_ukf_grad_all<float>(const cdkf_model*, const cdkf_opts*, int64_t, int64_t, const float*, const float*, float*, float*,
+                                        float*, int32_t*, hipStream_t);
+template int launch_ukf_grad_all<double>(const cdkf_model*, const cdkf_opts*, int64_t, int64_t, const double*, const double*, double*,
+                                         double*, double*, int32_t*, hipStream_t);
 template int launch_ekf_grad_adjoint_jumps<float>(const cdkf_model*, const cdkf_opts*, int64_t, int64_t, const float*, const float*, const float*,
                                                   float*, float*, float*, float*, float*, int32_t*, hipStream_t);
 template int launch_ekf_grad_adjoint_jumps<double>(const cdkf_model*, const cdkf_opts*, int64_t, int64_t, const double*, const double*,

@@ -92,7 +92,8 @@ def loglik_grad_device(mdl: _ffi.ModelBlock, opts, t, y, with_model: bool, ukf: 
     status = torch.zeros(N, dtype=torch.int32, device=y.device)
     if with_model:
         gm = torch.empty(N, _ffi.model_grad_size(mdl.state_dim, mdl.emission_dim), **kw)
-        _launch(getattr(_ffi.lib(), f"cdkf_ekf_loglik_grad_all_{suffix}_dev"), mdl, opts, y, _p(t), _p(y), _p(ll), _p(grad), _p(gm), _p(status))
+        _launch(getattr(_ffi.lib(), f"cdkf_{'ukf' if ukf else 'ekf'}_loglik_grad_all_{suffix}_dev"), mdl, opts, y, _p(t), _p(y), _p(ll), _p(grad),
+                _p(gm), _p(status))
         return ll, grad, status, gm
     algo = "ukf" if ukf else "ekf"
     _launch(getattr(_ffi.lib(), f"cdkf_{algo}_loglik_grad_{suffix}_dev"), mdl, opts, y, _p(t), _p(y), _p(ll), _p(grad), _p(status))

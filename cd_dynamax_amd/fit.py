@@ -158,7 +158,11 @@ class _ResidentBatch:
     def _launch(self, mdl: _ffi.ModelBlock, opts, suffix: str):
         """Sweeps + device-side sums of this minibatch into ``self.sums`` (asynchronous, default stream)."""
         L = _ffi.lib()
-        if self.ukf:
+        if self.ukf and self.n_model:
+            _ffi.check(getattr(L, f"cdkf_ukf_loglik_grad_all_{suffix}_dev")(
+                C.byref(mdl.c), C.byref(opts), self.B, self.T, self.t.ptr, self.y.ptr, self.ll.ptr, self.grad.ptr,
+                self.gmodel.ptr, self.status.ptr, None))
+        elif self.ukf:
             _ffi.check(getattr(L, f"cdkf_ukf_loglik_grad_{suffix}_dev")(
                 C.byref(mdl.c), C.byref(opts), self.B, self.T, self.t.ptr, self.y.ptr, self.ll.ptr, self.grad.ptr,
                 self.status.ptr, None))
@@ -254,21 +258,21 @@ def fit_sgd(model, params, props, emissions, t_emissions=None, filter_hyperparam
     opts.layout = _ffi.LAYOUT_TCN
     suffix = "f32" if dtype == np.float32 else "f64"
     mdl0 = _model_block(params)
-    if ukf and not tr.drift_only:
-        raise NotImplementedError("fit_sgd with UKFHyperParams: the unscented filter's gradient is provided for the drift parameters "
-                                  f"(trainable: {[p for p, _, _, _ in tr.items]})")
-    check = (_ffi.lib().cdkf_ukf_grad_supported if ukf else
+    ukf_all = False
+    if ukf:  # the forward-sensitivity kernel where it exists and suffices (drift block, register shapes), else the reverse sweeps
+        ukf_all = not tr.drift_only or not _ffi.lib().cdkf_ukf_grad_supported(C.byref(mdl0.c), C.byref(opts))
+    check = ((_ffi.lib().cdkf_ukf_grad_all_supported if ukf_all else _ffi.lib().cdkf_ukf_grad_supported) if ukf else
              (_ffi.lib().cdkf_grad_supported if tr.drift_only else _ffi.lib().cdkf_grad_all_supported))
     if not check(C.byref(mdl0.c), C.byref(opts)):
         what = ("unscented-filter drift gradient" if ukf else "drift gradient") if tr.drift_only else "all-parameter reverse-sweep"
         raise NotImplementedError(
             f"fit_sgd: no {what} kernel for drift {type(params.dynamics.drift).__name__} with state_dim={mdl0.state_dim}, "
-            f"emission_dim={mdl0.emission_dim}, state_order={hyper.state_order}"
+            f"emission_dim={mdl0.emission_dim}, state_order={getattr(hyper, 'state_order', '-')}"
             + ("" if tr.drift_only else f"; trainable: {[p for p, _, _, _ in tr.items]}"))
     N = y.shape[0]
     size = float(y.size)
     n_theta = mdl0.theta.size
-    n_model = 0 if tr.drift_only else _ffi.model_grad_size(mdl0.state_dim, mdl0.emission_dim)
+    n_model = 0 if (tr.drift_only and not ukf_all) else _ffi.model_grad_size(mdl0.state_dim, mdl0.emission_dim)
     t_shared = bool(opts.t_shared)
     if comm is not None:
         if allreduce is not None:

@@ -26,7 +26,7 @@ import numpy as np
 
 from . import _ffi
 from .fit import _Trainable, _ResidentBatch, _get
-from .params import EKFHyperParams
+from .params import EKFHyperParams, UKFHyperParams
 
 LogDensity = Callable[[np.ndarray], Tuple[float, np.ndarray]]
 
@@ -328,8 +328,9 @@ def fit_mcmc(model, initial_params, props, emissions, t_emissions=None, filter_h
     par = dict(mcmc_algorithm.get("parameters", {}))
     num_steps = int(par.pop("num_steps", 1000))
     hyper = EKFHyperParams() if filter_hyperparams is None else filter_hyperparams
-    if not isinstance(hyper, EKFHyperParams):
-        raise NotImplementedError("fit_mcmc: gradients are provided for the EKF marginal log-likelihood only")
+    ukf = isinstance(hyper, UKFHyperParams)
+    if not ukf and not isinstance(hyper, EKFHyperParams):
+        raise NotImplementedError("fit_mcmc: gradients are provided for the EKF and the UKF marginal log-likelihood")
     prior0 = float(model.log_prior(initial_params)) if hasattr(model, "log_prior") else 0.0
     if prior0 != 0.0:
         raise NotImplementedError("fit_mcmc: a model log_prior other than the reference's 0.0 has no gradient here")
@@ -339,15 +340,18 @@ def fit_mcmc(model, initial_params, props, emissions, t_emissions=None, filter_h
     opts.layout = _ffi.LAYOUT_TCN
     suffix = "f32" if dtype == np.float32 else "f64"
     mdl0 = _model_block(initial_params)
-    check = _ffi.lib().cdkf_grad_supported if tr.drift_only else _ffi.lib().cdkf_grad_all_supported
+    # (unscented: the reverse sweeps over the closed-form moment equations, every leaf -- cdkf_ukf_loglik_grad_all_*)
+    check = (_ffi.lib().cdkf_ukf_grad_all_supported if ukf else
+             (_ffi.lib().cdkf_grad_supported if tr.drift_only else _ffi.lib().cdkf_grad_all_supported))
     if not check(C.byref(mdl0.c), C.byref(opts)):
         raise NotImplementedError(
             f"fit_mcmc: no gradient kernel for drift {type(initial_params.dynamics.drift).__name__} with state_dim="
-            f"{mdl0.state_dim}, emission_dim={mdl0.emission_dim}, state_order={hyper.state_order}; trainable: "
+            f"{mdl0.state_dim}, emission_dim={mdl0.emission_dim}, state_order={getattr(hyper, 'state_order', '-')}; trainable: "
             f"{[p for p, _, _, _ in tr.items]}")
     n_theta = mdl0.theta.size
-    n_model = 0 if tr.drift_only else _ffi.model_grad_size(mdl0.state_dim, mdl0.emission_dim)
+    n_model = 0 if (tr.drift_only and not ukf) else _ffi.model_grad_size(mdl0.state_dim, mdl0.emission_dim)
     batch = _ResidentBatch(y, t, bool(opts.t_shared), n_theta, n_model, dtype)
+    batch.ukf = ukf
 
     def logdensity(u):
         try:

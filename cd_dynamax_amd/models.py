@@ -330,6 +330,11 @@ def cdnlgssm_loglik_and_grad(
     else:
         y, t, batched, dtype = _prepare(emissions, t_emissions, hyperparams, opts, dtype)
     supported = _ffi.lib().cdkf_ukf_grad_supported if ukf else _ffi.lib().cdkf_grad_supported
+    if ukf and not supported(_ffi.C.byref(mdl.c), _ffi.C.byref(opts)) and \
+            _ffi.lib().cdkf_ukf_grad_all_supported(_ffi.C.byref(mdl.c), _ffi.C.byref(opts)):
+        # no forward-sensitivity kernel at this shape (Lorenz-96, larger linear models): the drift block of the reverse sweeps' result
+        ll, g = cdnlgssm_loglik_and_grad_all(params, emissions, t_emissions, hyperparams, inputs, dtype)
+        return ll, g.dynamics.drift
     if not supported(_ffi.C.byref(mdl.c), _ffi.C.byref(opts)):
         raise NotImplementedError(
             f"no {'unscented-filter ' if ukf else ''}gradient kernel for drift {type(params.dynamics.drift).__name__} with "
@@ -349,11 +354,11 @@ def cdnlgssm_loglik_and_grad_all(
     params: ParamsCDNLGSSM,
     emissions,
     t_emissions=None,
-    hyperparams: EKFHyperParams = EKFHyperParams(),
+    hyperparams: Union[EKFHyperParams, UKFHyperParams] = EKFHyperParams(),
     inputs=None,
     dtype=None,
 ):
-    """EKF marginal log-likelihood and its gradient w.r.t. EVERY parameter: returns ``(ll, grads)`` with ``grads`` a
+    """EKF (or, with ``UKFHyperParams``, unscented) marginal log-likelihood and its gradient w.r.t. EVERY parameter: returns ``(ll, grads)`` with ``grads`` a
     ``ParamsCDNLGSSM`` of the same structure as ``params`` (what ``jax.grad`` of ``marginal_log_prob`` returns in the
     reference, ssm_temissions.py:550-568), leaves carrying a leading ``[N]`` for batched emissions.
 
@@ -361,8 +366,9 @@ def cdnlgssm_loglik_and_grad_all(
     registry drift, ``state_order`` first or second.  Gradients of the symmetric matrices (initial covariance, diffusion
     covariance, emission covariance) are symmetric cotangents: exact for symmetric perturbations, i.e. for any symmetric
     parametrisation such as the reference's ``RealToPSDBijector``."""
-    if not isinstance(hyperparams, EKFHyperParams):
-        raise NotImplementedError("gradients are provided for the EKF marginal log-likelihood only")
+    ukf = isinstance(hyperparams, UKFHyperParams)
+    if not ukf and not isinstance(hyperparams, EKFHyperParams):
+        raise NotImplementedError("gradients are provided for the EKF and the UKF marginal log-likelihood (the ensemble filter is stochastic)")
     mdl = _model_block(params)
     opts = _opts(hyperparams, 1)
     on_device = _device.is_device_tensor(emissions)
@@ -370,6 +376,21 @@ def cdnlgssm_loglik_and_grad_all(
         y, t, batched, dtype = _device.prepare(emissions, t_emissions, opts)
     else:
         y, t, batched, dtype = _prepare(emissions, t_emissions, hyperparams, opts, dtype)
+    if ukf:
+        # the unscented filter, every leaf (cdkf_ukf_loglik_grad_all_*): the reverse sweeps over its moment equations in closed form --
+        # exact for the quadratic Lorenz-63 / Lorenz-96 drifts and the linear one (inference_ukf.py:93-203 differentiated by JAX)
+        if not _ffi.lib().cdkf_ukf_grad_all_supported(_ffi.C.byref(mdl.c), _ffi.C.byref(opts)):
+            raise NotImplementedError(
+                f"no unscented-filter reverse-sweep kernel for drift {type(params.dynamics.drift).__name__} with state_dim={mdl.state_dim}, "
+                f"emission_dim={mdl.emission_dim} (the sigma-point sums have a closed form for LearnableLorenz63, LearnableLorenz96 and "
+                "LearnableLinear; linear emission, default solver)")
+        if on_device:
+            ll, gth, _, gm = (x.cpu().numpy() for x in _device.loglik_grad_device(mdl, opts, t, y, True, ukf=True))
+        else:
+            ll, gth, _, gm = _ffi.loglik_grad(mdl, opts, t, y, dtype, with_model=True, ukf=True)
+        if not batched:
+            ll, gth, gm = ll[0], gth[0], gm[0]
+        return ll, _grads_tree(params, mdl, gth, gm)
     if not _ffi.lib().cdkf_grad_all_supported(_ffi.C.byref(mdl.c), _ffi.C.byref(opts)):
         raise NotImplementedError(
             f"no reverse-sweep kernel for drift {type(params.dynamics.drift).__name__} with state_dim={mdl.state_dim}, "

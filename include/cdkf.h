@@ -370,6 +370,23 @@ int cdkf_ukf_loglik_grad_f64_dev(const cdkf_model* mdl, const cdkf_opts* opts, i
 int cdkf_ukf_loglik_grad_f32_dev(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T, const float* t,
                                  const float* y, float* ll, float* grad, int32_t* status, void* stream);
 int cdkf_ukf_grad_supported(const cdkf_model* mdl, const cdkf_opts* opts);
+/* ---- ... and w.r.t. EVERY leaf (grad_model as in cdkf_ekf_loglik_grad_all_*): the reverse sweeps over the unscented filter's moment
+ *      equations in closed form -- the extended filter's plus the curvature term 0.5 sum_jk (d^2 f / dx_j dx_k) P_jk in the mean, exact
+ *      for the quadratic Lorenz-63 / Lorenz-96 drifts and (no curvature) the linear one, any shape the reverse sweeps take (state and
+ *      emission dimension <= 8 on the wavefront sweep, Lorenz-96 / linear beyond on the workgroup sweep), linear emission, default
+ *      solver.  What fit_sgd / fit_mcmc differentiate in the reference with filter_hyperparams = UKFHyperParams() when any leaf is
+ *      trainable (src/ssm_temissions.py:500-568, 601-679 -> inference_ukf.py:93-203). */
+int cdkf_ukf_loglik_grad_all_f64(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T, const double* t,
+                                 const double* y, double* ll, double* grad, double* grad_model, int32_t* status);
+int cdkf_ukf_loglik_grad_all_f32(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T, const float* t,
+                                 const float* y, float* ll, float* grad, float* grad_model, int32_t* status);
+int cdkf_ukf_loglik_grad_all_f64_dev(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T, const double* t,
+                                     const double* y, double* ll, double* grad, double* grad_model, int32_t* status,
+                                     void* stream);
+int cdkf_ukf_loglik_grad_all_f32_dev(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T, const float* t,
+                                     const float* y, float* ll, float* grad, float* grad_model, int32_t* status,
+                                     void* stream);
+int cdkf_ukf_grad_all_supported(const cdkf_model* mdl, const cdkf_opts* opts);
 /* ---- the same plus the gradient w.r.t. every other model parameter (the remaining leaves of the pytree jax.grad returns
  *      for ParamsCDNLGSSM): grad_model [N, d + 2 d^2 + m d + m + m^2] row-major, per trajectory
  *          m0 [d] | P0 [d,d] | LQL [d,d] | H [m,d] | h_bias [m] | R [m,m]

@@ -1258,7 +1258,50 @@ def _step_sizes(t0, t1, dt0, tol, max_steps):
     return out
 
 
-def ekf_loglik_grad_adjoint(mdl: Model, t, y, dt0=0.01, dt_final=1e-10, max_steps=100000, full=False, state_order="first"):
+def ukf_curvature(drift, P):
+    """The term the unscented filter's mean equation has beyond f(m) for a QUADRATIC drift (every alpha, beta, kappa): the sigma points
+    are symmetric about the mean, f(m + o) + f(m - o) = 2 f(m) + 2 b(o, o) with b the drift's bilinear part, and sum_i o_i o_i^T = c^2 P,
+    2 w_i c^2 = 1, so the weighted sum of inference_ukf.py:124-143 is f(m) + 0.5 sum_jk (d^2 f / dx_j dx_k) P_jk -- (0, -P_02, P_01) for
+    Lorenz-63, P_{i+1,i-1} - P_{i-2,i-1} for Lorenz-96, nothing for a linear drift; the covariance equation is the extended filter's
+    (f(m + o) - f(m - o) = 2 F(m) o exactly).  P [d,d] symmetric."""
+    d = P.shape[0]
+    if drift.kind == "linear":
+        return np.zeros(d)
+    if drift.kind == "lorenz63":
+        return np.array([0.0, -P[0, 2], P[0, 1]])
+    if drift.kind == "lorenz96":
+        i = np.arange(d)
+        return P[(i + 1) % d, (i - 1) % d] - P[(i - 2) % d, (i - 1) % d]
+    raise NotImplementedError(f"ukf_curvature: drift {drift.kind} is not quadratic (its sigma-point sums have no closed form)")
+
+
+def ukf_curvature_vjp(drift, lam):
+    """Cotangent of P through lam . ukf_curvature(drift, P), as a symmetric matrix."""
+    d = lam.shape[0]
+    Pb = np.zeros((d, d))
+    if drift.kind == "lorenz63":
+        Pb[0, 2] -= lam[1]
+        Pb[0, 1] += lam[2]
+    elif drift.kind == "lorenz96":
+        i = np.arange(d)
+        np.add.at(Pb, ((i + 1) % d, (i - 1) % d), lam)
+        np.add.at(Pb, ((i - 2) % d, (i - 1) % d), -lam)
+    elif drift.kind != "linear":
+        raise NotImplementedError(drift.kind)
+    return 0.5 * (Pb + Pb.T)
+
+
+def ukf_loglik_grad_all(mdl: Model, t, y, dt0=0.01, dt_final=1e-10, max_steps=100000):
+    """(ll [N], grad [N, n_theta], dict of the other leaves' gradients) of the UNSCENTED filter's marginal log-likelihood -- what
+    jax.value_and_grad yields in the reference with filter_hyperparams=UKFHyperParams() (ssm_temissions.py:500, 555-568 -> models.py:
+    393-408, 708 -> inference_ukf.py:206-308) -- for the drifts whose sigma-point sums collapse exactly (Lorenz-63, Lorenz-96: quadratic;
+    linear) and a linear emission: the discrete adjoint of the extended filter's recursion with ukf_curvature in the mean equation (the
+    derivative of a function does not depend on how it is written down).  Pinned by central finite differences of ukf_filter -- the
+    routine that forms the sigma points literally (tests/test_oracle.py)."""
+    return ekf_loglik_grad_adjoint(mdl, t, y, dt0, dt_final, max_steps, full=True, state_order="first", ukf=True)
+
+
+def ekf_loglik_grad_adjoint(mdl: Model, t, y, dt0=0.01, dt_final=1e-10, max_steps=100000, full=False, state_order="first", ukf=False):
     """Returns (ll [N], grad [N, n_theta]): EKF, state_order 'first' or 'second' (the mean term 0.5 P grad(div f), reversed by
     divgrad_vjp), num_iter 1; float64.
 
@@ -1290,7 +1333,10 @@ def ekf_loglik_grad_adjoint(mdl: Model, t, y, dt0=0.01, dt_final=1e-10, max_step
     def rhs(x, P):
         F = jac(x)
         A = F @ P
-        return (f(x) + 0.5 * P @ divgrad(x) if second else f(x)), A + A.T + LQL
+        fm = f(x) + 0.5 * P @ divgrad(x) if second else f(x)
+        if ukf:  # (the unscented filter's moment equations in closed form: ukf_curvature)
+            fm = fm + ukf_curvature(drift, sym(P))
+        return fm, A + A.T + LQL
 
     def step_sizes(x, P, ta, tb):
         """The dt sequence of the solve over [ta, tb] from (x, P): the fixed-step loop's, or the sizes the controller accepts."""
@@ -1395,6 +1441,8 @@ def ekf_loglik_grad_adjoint(mdl: Model, t, y, dt0=0.01, dt_final=1e-10, max_step
                         xb2, tb2 = divgrad_vjp(drift, xs, 0.5 * Ps.T @ lam)
                         xb, tb = xb + xb2, tb + tb2
                         Pbar = Pbar + sym(0.5 * np.outer(lam, divgrad(xs)))
+                    if ukf:
+                        Pbar = Pbar + ukf_curvature_vjp(drift, lam)
                     thb += tb
                     extra["LQL"][n] += Lam
                     Yb[i] = (xb, Pbar)

@@ -566,9 +566,90 @@ def test_unscented_loglik_gradient(hip_lib):
     bad = o.Model(mdl3.drift, mdl3.L, mdl3.Qc, mdl3.H, mdl3.bias, mdl3.R, mdl3.m0, np.diag([1.0, -1.0, 1.0]))
     ll_b, _ = cd.cdnlgssm_loglik_and_grad(params_from(bad), y3[:2], t3[:2, :, None], cd.UKFHyperParams())
     assert np.isnan(ll_b).all()
-    # refusals: no closed form for this drift / the model block
+    # refusals: no closed form for this drift (the MLP is not quadratic)
+    from helpers import mlp_model
     with pytest.raises(NotImplementedError):
-        cd.cdnlgssm_loglik_and_grad(params_from(lorenz96_model(6, 3)), np.zeros((2, 5, 3)), np.arange(5.0)[None, :, None].repeat(2, 0), cd.UKFHyperParams())
+        cd.cdnlgssm_loglik_and_grad(params_from(mlp_model(rng, 4, 2, 8)), np.zeros((2, 5, 2)), np.arange(5.0)[None, :, None].repeat(2, 0), cd.UKFHyperParams())
+
+
+@pytest.mark.parametrize("kind,d,m", [("lorenz63", 3, 1), ("lorenz63", 3, 2), ("lorenz63", 3, 3), ("lorenz96", 6, 3), ("lorenz96", 12, 5),
+                                      ("linear", 4, 2), ("lorenz96", 20, 20)])
+def test_unscented_loglik_gradient_of_every_leaf(hip_lib, kind, d, m):
+    """value_and_grad of the UNSCENTED filter's marginal log-likelihood w.r.t. every leaf (what fit_sgd / fit_mcmc
+    differentiate in the reference with filter_hyperparams=UKFHyperParams(): ssm_temissions.py:500-568, 601-679 -> inference_ukf.py:
+    93-203) -- cdkf_ukf_loglik_grad_all_*: the reverse sweeps over the moment equations in closed form (exact for the quadratic
+    Lorenz-63 / Lorenz-96 drifts and the linear one) -- against the oracle's ukf_loglik_grad_all, which tests/test_oracle.py pins by
+    finite differences of the literal sigma-point filter.  Dense non-diagonal model matrices, an eight-step interval; the value is the
+    sigma-point filter's own log-likelihood; fp32; then fit_sgd's first step over EVERY leaf and a short fit_mcmc with UKFHyperParams."""
+    from cd_dynamax_amd import fit
+    rng = np.random.default_rng(700 + 10 * d + m)
+    if kind == "lorenz63":
+        drift, scale = o.Lorenz63Drift(10.0, 28.0, 8.0 / 3.0), 1.0
+    elif kind == "lorenz96":
+        drift, scale = o.Lorenz96Drift(8.0), 8.0
+    else:
+        drift, scale = linear_model(rng, d, m).drift, 0.0
+    A, B, Cm = rng.standard_normal((d, d)), rng.standard_normal((m, m)), rng.standard_normal((d, d))
+    mdl = o.Model(drift, np.eye(d) + 0.1 * rng.standard_normal((d, d)), A @ A.T / d * 0.3 + 0.3 * np.eye(d), rng.standard_normal((m, d)) / np.sqrt(d),
+                  0.1 * rng.standard_normal(m), B @ B.T / m * 0.5 + 0.3 * np.eye(m), scale + rng.standard_normal(d), Cm @ Cm.T / d * 0.5 + 0.5 * np.eye(d))
+    N, T = 4, 10
+    t = o.irregular_times(rng, N, T, 0.12)
+    t[:, 6:] += 0.07
+    y = o.simulate(mdl, t, rng)
+    P = params_from(mdl)
+    ll_ref, g_ref, ex = o.ukf_loglik_grad_all(mdl, t, y)
+    ll, g = cd.cdnlgssm_loglik_and_grad_all(P, y, t[..., None], cd.UKFHyperParams())
+    kern = _ffi.lib().cdkf_last_kernel().decode()
+    assert kern.startswith("ekf_adjoint_wg_kernel<double" if d > 8 else "ekf_adjoint_wave8_kernel<double"), kern
+    np.testing.assert_allclose(ll, ll_ref, rtol=1e-9)
+    post = cd.cdnlgssm_filter(P, y, t[..., None], cd.UKFHyperParams(), output_fields=[])
+    np.testing.assert_allclose(ll, post.marginal_loglik, rtol=1e-9)          # the sigma-point filter's own log-likelihood
+
+    def close(a, b, name, tol=1e-8):
+        sc = np.abs(b).max() + 1e-300
+        assert np.abs(np.asarray(a) - b).max() < tol * sc, (name, np.abs(np.asarray(a) - b).max() / sc)
+
+    flat = lambda gg: np.concatenate([np.asarray(a).reshape(N, -1) for a in gg.dynamics.drift], axis=-1)
+    close(flat(g), g_ref, "drift")
+    close(g.initial.mean.params, ex["m0"], "m0")
+    close(g.initial.cov.params, ex["P0"], "P0")
+    close(g.dynamics.diffusion_coefficient.params, ex["L"], "L")
+    close(g.dynamics.diffusion_cov.params, ex["Qc"], "Qc")
+    close(g.emissions.emission_function.weights, ex["H"], "H")
+    close(g.emissions.emission_function.bias, ex["bias"], "bias")
+    close(g.emissions.emission_cov.params, ex["R"], "R")
+    if kind != "linear":  # not the extended filter's gradient: the curvature term is there
+        _, ge = cd.cdnlgssm_loglik_and_grad_all(P, y, t[..., None], cd.EKFHyperParams(state_order="first"))
+        assert np.abs(np.asarray(ge.initial.mean.params) - ex["m0"]).max() > 1e-5 * np.abs(ex["m0"]).max()
+    # the drift block alone comes from the same sweeps where no forward-sensitivity kernel exists
+    ll_d, g_d = cd.cdnlgssm_loglik_and_grad(P, y, t[..., None], cd.UKFHyperParams())
+    close(np.concatenate([np.asarray(a).reshape(N, -1) for a in g_d], axis=-1), g_ref, "drift block", 1e-7)
+    ll32, g32 = cd.cdnlgssm_loglik_and_grad_all(P, y.astype(np.float32), t[..., None].astype(np.float32), cd.UKFHyperParams())
+    assert ll32.dtype == np.float32
+    close(g32.emissions.emission_cov.params, ex["R"], "R fp32", 2e-2)
+    if d > 8:
+        return
+    # fit_sgd over every leaf with the unscented objective: first plain-SGD step = the oracle's gradient pulled back
+    free = cd.ParameterProperties()
+    from cd_dynamax_amd.bijectors import RealToPSDBijector
+    psd = cd.ParameterProperties(constrainer=RealToPSDBijector())
+    frozen = cd.ParameterProperties(trainable=False)
+    drift_props = type(P.dynamics.drift)(*([free] * len(P.dynamics.drift)))
+    props = P._replace(
+        initial=P.initial._replace(mean=cd.LearnableVector(free), cov=cd.LearnableMatrix(psd)),
+        dynamics=P.dynamics._replace(drift=drift_props, diffusion_coefficient=cd.LearnableMatrix(frozen), diffusion_cov=cd.LearnableMatrix(psd),
+                                     approx_order=frozen),
+        emissions=P.emissions._replace(emission_function=cd.LearnableLinear(free, free), emission_cov=cd.LearnableMatrix(psd)))
+    model = cd.ContDiscreteNonlinearGaussianSSM(d, m)
+    lr = 1e-3
+    new, losses = model.fit_sgd(P, props, y, t[..., None], cd.UKFHyperParams(), optimizer=fit.SGD(lr), batch_size=N, num_epochs=1)
+    np.testing.assert_allclose(losses[0], -ll_ref.sum() / y.size, rtol=1e-9)
+    np.testing.assert_allclose(np.asarray(new.initial.mean.params), mdl.m0 + lr * ex["m0"].sum(0) / y.size, rtol=1e-7, atol=1e-12)
+    np.testing.assert_allclose(np.asarray(new.emissions.emission_function.weights), mdl.H + lr * ex["H"].sum(0) / y.size, rtol=1e-7, atol=1e-12)
+    if kind == "lorenz63" and m == 2:
+        out = model.fit_mcmc(P, props, y, t[..., None], cd.UKFHyperParams(), n_mcmc_samples=6,
+                             mcmc_algorithm={"type": "hmc", "parameters": {"num_steps": 8, "num_integration_steps": 3}}, verbose=False, key=2)
+        assert np.asarray(out[1].initial.mean.params).shape == (6, d) and np.all(np.isfinite(out[3]))
 
 
 def test_c3_full_size_properties(hip_lib):

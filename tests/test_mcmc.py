@@ -124,8 +124,8 @@ def test_fit_mcmc_refusals_need_no_gpu():
     y, t = np.zeros((5, 3)), np.arange(5.0)[:, None]
     with pytest.raises(NotImplementedError, match="rmhmc"):
         model.fit_mcmc(params, props, y, t, mcmc_algorithm={"type": "rmhmc", "parameters": {"num_steps": 2}})
-    with pytest.raises(NotImplementedError, match="EKF"):
-        model.fit_mcmc(params, props, y, t, cd.UKFHyperParams())
+    with pytest.raises(NotImplementedError, match="EKF"):   # (the unscented filter is served from round 4 on; the ensemble filter is stochastic)
+        model.fit_mcmc(params, props, y, t, cd.EnKFHyperParams())
     assert model.log_prior(params) == 0.0
 
 

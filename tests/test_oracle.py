@@ -640,3 +640,57 @@ def test_notebook_pins_lower_fidelity_settings_by_magnitude():
     assert abs(loose - hifi) < 3 * ulp32 and loose != hifi
     assert 2.54e-2 / 5 < abs(heun - hifi) < 2.54e-2 * 5, heun - hifi
     assert 5.3e-1 / 5 < abs(euler - hifi) < 5.3e-1 * 5, euler - hifi
+
+
+@pytest.mark.parametrize("kind,d,m", [("lorenz63", 3, 2), ("lorenz96", 6, 3), ("linear", 3, 2)])
+def test_unscented_loglik_gradient_of_every_leaf_matches_finite_differences(kind, d, m):
+    """ukf_loglik_grad_all -- the unscented filter's gradient w.r.t. EVERY leaf (the reference gets it from JAX
+    through the sigma points and their Cholesky factor: ssm_temissions.py:500-568 -> inference_ukf.py:93-203) -- is the discrete adjoint
+    of the closed-form moment equations; pinned here by central finite differences of ukf_filter, the routine that forms the sigma
+    points literally: random directions in every leaf (symmetric ones for the covariances), dense non-diagonal model matrices."""
+    rng = np.random.default_rng(500 + d)
+    if kind == "lorenz63":
+        drift = o.Lorenz63Drift(10.0, 28.0, 8.0 / 3.0)
+    elif kind == "lorenz96":
+        drift = o.Lorenz96Drift(8.0)
+    else:
+        W = -0.6 * np.eye(d) + 0.3 * rng.standard_normal((d, d))
+        drift = o.LinearDrift(W, 0.2 * rng.standard_normal(d))
+    A, B, C = rng.standard_normal((d, d)), rng.standard_normal((m, m)), rng.standard_normal((d, d))
+    scale = 8.0 if kind == "lorenz96" else (1.0 if kind == "lorenz63" else 0.0)
+    mdl = o.Model(drift, np.eye(d) + 0.1 * rng.standard_normal((d, d)), A @ A.T / d * 0.3 + 0.3 * np.eye(d), rng.standard_normal((m, d)) / np.sqrt(d),
+                  0.1 * rng.standard_normal(m), B @ B.T / m * 0.5 + 0.3 * np.eye(m), scale + rng.standard_normal(d), C @ C.T / d * 0.5 + 0.5 * np.eye(d))
+    N, T = 2, 8
+    t = o.irregular_times(rng, N, T, 0.15)
+    y = o.simulate(mdl, t, rng)
+    ll, g, ex = o.ukf_loglik_grad_all(mdl, t, y)
+    ref = o.ukf_filter(mdl, t, y)
+    np.testing.assert_allclose(ll, ref["marginal_loglik"], rtol=1e-9)
+    ll_e = o.ekf_filter(mdl, t, y, state_order="first")["marginal_loglik"]
+    if kind != "linear":
+        assert np.abs(ll - ll_e).max() > 1e-6 * np.abs(ll).max()      # the curvature term is really there
+    sym = lambda M: 0.5 * (M + M.T)
+    th0 = drift.theta()
+
+    def with_(**kw):
+        th = kw.get("theta", th0)
+        if kind == "lorenz63":
+            dr = o.Lorenz63Drift(*th)
+        elif kind == "lorenz96":
+            dr = o.Lorenz96Drift(th[0])
+        else:
+            dr = o.LinearDrift(th[:d * d].reshape(d, d), th[d * d:])
+        g_ = lambda k, v: kw.get(k, v)
+        return o.Model(dr, g_("L", mdl.L), g_("Qc", mdl.Qc), g_("H", mdl.H), g_("bias", mdl.bias), g_("R", mdl.R), g_("m0", mdl.m0), g_("P0", mdl.P0))
+
+    h = 1e-6
+    checks = [("theta", th0, g, False), ("m0", mdl.m0, ex["m0"], False), ("P0", mdl.P0, ex["P0"], True), ("L", mdl.L, ex["L"], False),
+              ("Qc", mdl.Qc, ex["Qc"], True), ("H", mdl.H, ex["H"], False), ("bias", mdl.bias, ex["bias"], False), ("R", mdl.R, ex["R"], True)]
+    for name, base, grad, symm in checks:
+        u = rng.standard_normal(np.shape(base))
+        if symm:
+            u = sym(u)
+        fd = (o.ukf_filter(with_(**{name: base + h * u}), t, y)["marginal_loglik"]
+              - o.ukf_filter(with_(**{name: base - h * u}), t, y)["marginal_loglik"]) / (2 * h)
+        an = (np.asarray(grad).reshape(N, -1) * u.reshape(1, -1)).sum(-1)
+        assert np.abs(an - fd).max() < 2e-6 * max(1.0, np.abs(fd).max()), (name, an, fd)
