@@ -1004,6 +1004,40 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
       Pp = inP ? a.pP[n * a.P_sn + (k - 1) * a.P_sk + (i * d + j) * a.P_si] : R(0);
     }
     const R yl = (lane < m) ? yp[k * a.y_sk + lane * a.y_si] : R(0);
+    // num_iter > 1 (inference_ekf.py:153-199: every iteration starts from the previous one's posterior, symmetrize once at the end, the
+    // log-likelihood term on the first one's inputs): the inputs of iterations 1 .. n-1 are recomputed forward from the predicted
+    // moments -- the forward sweep's own update on a scratch block (the MLP passes' images, free here) -- and parked in LDS (72 reals
+    // each); the iterations are then reversed one by one, the last first.
+    const int nit = a.num_iter;
+    R* const itW = W + AdjOff::UC;            // a W8Off-shaped block of 608 reals for w8_measurement_update
+    R* const itS = itW + W8Off::base_end;     // stash: iteration it's inputs at itS + 72 it (P on the lane grid, the mean behind)
+    if (nit > 1) {
+      R Pi = Pp, mi = mp;
+      double ll_unused = 0.0;
+      bool bad_unused = false;
+      for (int it = 1; it < nit; ++it) {
+        w8_measurement_update<R, false>(itW, lane, i, j, d, m, inP, false, Hij, Rij, hbj, yl, 1, 0, Pi, mi, ll_unused, bad_unused);
+        itS[72 * it + lane] = Pi;
+        if (lane < 8) itS[72 * it + 64 + lane] = mi;
+      }
+      wave_sync();
+    }
+    R vb_sum = 0;
+#pragma unroll 1
+    for (int it = nit - 1; it >= 0; --it) {
+    const bool first = it == 0, last = it == nit - 1;
+    if (it > 0) {
+      Pp = itS[72 * it + lane];
+      mp = (lane < 8) ? itS[72 * it + 64 + lane] : R(0);
+    } else if (nit > 1) {  // (back to the predicted moments)
+      if (k == 0) {
+        mp = (lane < d) ? (a.par + a.o_m0)[lane] : R(0);
+        Pp = inP ? R(0.5) * ((a.par + a.o_P0)[i * d + j] + (a.par + a.o_P0)[j * d + i]) : R(0);
+      } else {
+        mp = (lane < d) ? a.pm[n * a.m_sn + (k - 1) * a.m_sk + lane * a.m_si] : R(0);
+        Pp = inP ? a.pP[n * a.P_sn + (k - 1) * a.P_sk + (i * d + j) * a.P_si] : R(0);
+      }
+    }
     W[AdjOff::P + lane] = Pp;
     W[AdjOff::H + lane] = Hij;
     W[AdjOff::Pb + lane] = Pb;
@@ -1013,7 +1047,7 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
     }
     wave_sync();
     const R hp = mm(AdjOff::H, AdjOff::P);
-    const R Pbs = R(0.5) * (Pb + W[AdjOff::Pb + j * 8 + i]);
+    const R Pbs = last ? R(0.5) * (Pb + W[AdjOff::Pb + j * 8 + i]) : Pb;  // (the forward symmetrises once, after the last iteration)
     W[AdjOff::HP + lane] = hp;
     R vv = 0;
     if (lane < 8) {
@@ -1113,8 +1147,9 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
 #pragma unroll
       for (int r = 0; r < 8; ++r)
         if (r == lane) wl = wv[r];
-      vb = (lane < m) ? sacc - wl : R(0);
+      vb = (lane < m) ? (first ? sacc - wl : sacc) : R(0);  // (- w: the log-likelihood term, on the first iteration's inputs only)
       W[AdjOff::vb + lane] = vb;
+      vb_sum += vb;
     }
     wave_sync();
     // Kb = v mbar^T - 2 S (X Pbar)      (cotangent of K^T)
@@ -1137,7 +1172,8 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
     const R xu = mm_nt(AdjOff::X, AdjOff::Ub);
     W[AdjOff::A + lane] = xu;
     wave_sync();
-    R sbar = -mm_nt(AdjOff::XP, AdjOff::X) + R(0.5) * wi * wj - R(0.5) * sinv - R(0.5) * (xu + W[AdjOff::A + j * 8 + i]);
+    R sbar = -mm_nt(AdjOff::XP, AdjOff::X) - R(0.5) * (xu + W[AdjOff::A + j * 8 + i]);
+    if (first) sbar += R(0.5) * wi * wj - R(0.5) * sinv;
     if (!(i < m && j < m)) sbar = 0;
     W[AdjOff::B + lane] = sbar;
     wave_sync();
@@ -1161,9 +1197,10 @@ __global__ __launch_bounds__((64 * adj_waves<R, MLP>()), 1) void ekf_adjoint_wav
       mb = (lane < d) ? mb - sacc : R(0);
     }
     wave_sync();
+    }  // (update iterations)
     // (per-step cotangents for the linear front-end's offsets, WgArgs::gcj / gy: mb is now the cotangent of the mean PREDICTED for t_k,
-    //  i.e. of the jump added at the end of interval k-1; vb that of the innovation = of y_k)
-    if (a.gy && lane < m) a.gy[(n * a.T + k) * m + lane] = vb;
+    //  i.e. of the jump added at the end of interval k-1; the vb of the iterations add up to that of y_k)
+    if (a.gy && lane < m) a.gy[(n * a.T + k) * m + lane] = vb_sum;
     if (a.gcj && lane < d) {
       if (k > 0) a.gcj[(n * a.T + (k - 1)) * d + lane] = mb;
       if (k == a.T - 1) a.gcj[(n * a.T + k) * d + lane] = R(0);  // (the jump behind the last observation reaches no likelihood term)

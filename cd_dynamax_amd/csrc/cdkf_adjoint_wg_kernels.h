@@ -952,7 +952,7 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
         custom_g(xs, g1);
         if (tid < d) km[64 * si + tid] = rfma(R(0.5), dot(d, [&](int kk) { return Ps[tid * ld + kk]; }, [&](int kk) { return g1[kk]; }), fv[tid]);
       } else
-#else
+#elif !defined(CDKF_AWG_CUSTOM)
       if (second) {  // (MLP) dm/dt = f + 0.5 Ps g  (inference_ekf.py:108-116)
         mlp_g(g1);
         if (tid < d) km[64 * si + tid] = rfma(R(0.5), dot(d, [&](int kk) { return Ps[tid * ld + kk]; }, [&](int kk) { return g1[kk]; }), fv[tid]);
@@ -1119,6 +1119,12 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
     if (k == 0) break;
 
     // ================= (2) predict k-1 -> k: the Runge-Kutta steps of the interval, reversed ========================================
+    // (the slope / cotangent registers start every interval at zero: written through selects, they would otherwise count as live
+    //  across the update's adjoint above -- 24 NE registers the products and factorisations there then spill around)
+#pragma unroll
+    for (int s6 = 0; s6 < 6; ++s6)
+#pragma unroll
+      for (int u = 0; u < NE; ++u) kP[s6][u] = yP[s6][u] = R(0);
     const R t0 = tp[(k - 1) * a.t_sk], t1 = tp[k * a.t_sk];
     // an adaptive solve: the forward (workgroup) sweep logged the step sizes it accepted in this interval; the reverse of the solve
     // treats them as constants -- the controller's factor carries no derivative, as in the reference's reverse mode through diffrax
@@ -1222,7 +1228,7 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
             if (tid < d) g2[tid] = R(0.5) * dot(d, [&](int i) { return Ps[i * ld + tid]; }, [&](int i) { return lamv[i]; });
             __syncthreads();
           }
-#else
+#elif !defined(CDKF_AWG_CUSTOM)
           if (second) {  // (MLP) g(xs) again, and u = 0.5 Ps^T lam: the cotangent of g in the mean's slope
             mlp_g(g1);
             if (tid < d) g2[tid] = R(0.5) * dot(d, [&](int i) { return Ps[i * ld + tid]; }, [&](int i) { return lamv[i]; });

@@ -142,7 +142,8 @@ __host__ __device__ inline long wave8_lds_reals(int kind) {
 // file and of cdkf_wave8s_kernels.h: W = the wavefront's tile block (W8Off offsets P .. tmp), lane (i, j) holds P_ij, lanes < d the mean.
 // Two factorisations side by side (TFP's of S for the log-likelihood, psd_solve's of sym(S) + 1e-9 I for the gain), num_iter
 // relinearisations, then symmetrize.  Wavefront-scope synchronisation only.
-template <typename R>
+// SYM = false: without the final symmetrisation (one iteration of several, for the reverse sweep's recomputation of their inputs).
+template <typename R, bool SYM = true>
 CDKF_DEV void w8_measurement_update(R* W, int lane, int i, int j, int d, int m, bool inP, bool hsel, R Hij, R Rij, R hbj, R yl, int num_iter,
                                     int forecast, R& Pij, R& mj, double& ll, bool& bad) {
   for (int it = 0; it < (forecast ? 0 : num_iter); ++it) {
@@ -284,6 +285,7 @@ CDKF_DEV void w8_measurement_update(R* W, int lane, int i, int j, int d, int m, 
     }
     wave_sync();
   }
+  if constexpr (!SYM) return;
   // symmetrize
   W[W8Off::P + lane] = Pij;
   wave_sync();

@@ -395,9 +395,11 @@ static bool adjoint_wg_shape(const cdkf_model* mdl, const cdkf_opts* o) {
   return wg_shape_available(mdl, 4) && adjoint_wg_fits(mdl->state_dim, mdl->emission_dim, 4);
 }
 bool adjoint_shape_available(const cdkf_model* mdl, const cdkf_opts* o) {
-  if (o->num_iter != 1 || o->forecast || o->state_order == CDKF_ORDER_ZEROTH) return false;
+  if (o->num_iter < 1 || o->num_iter > 8 || o->forecast || o->state_order == CDKF_ORDER_ZEROTH) return false;
+  // (num_iter > 1 -- the iterated update of inference_ekf.py:153-199 -- is reversed iteration by iteration in both reverse sweeps,
+  //  the inputs of iterations 1 .. n-1 recomputed from the predicted moments and parked in LDS -- on the wavefront sweep, d, m <= 8)
   if (wave8_shape(mdl)) return wg_shape_available(mdl, 8);
-  return adjoint_wg_shape(mdl, o);
+  return o->num_iter == 1 && adjoint_wg_shape(mdl, o);  // (the workgroup sweep reverses one update iteration)
 }
 
 // state_dim > 8: forward sweep on the wavefront- (Lorenz-96, launch_w40.hip) or workgroup-per-trajectory filter with all four moment
@@ -545,7 +547,8 @@ bool ukf_grad_all_shape_available(const cdkf_model* mdl, const cdkf_opts* o) {
   if (mdl->drift_kind != CDKF_DRIFT_LORENZ63 && mdl->drift_kind != CDKF_DRIFT_LORENZ96 && mdl->drift_kind != CDKF_DRIFT_LINEAR) return false;
   if (mdl->emission_kind != 0 || o->solver != CDKF_SOLVER_DOPRI5 || o->adaptive) return false;
   cdkf_opts e = *o;
-  e.state_order = CDKF_ORDER_FIRST;  // (the unscented filter has no state_order)
+  e.state_order = CDKF_ORDER_FIRST;  // (the unscented filter has no state_order and no update iterations)
+  e.num_iter = 1;
   return adjoint_shape_available(mdl, &e);
 }
 template <typename R>
@@ -559,6 +562,7 @@ int launch_ukf_grad_all(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, in
   }
   cdkf_opts e = *o;
   e.state_order = CDKF_ORDER_FIRST;
+  e.num_iter = 1;
   if (wave8_shape(mdl)) return adjoint_wave8_impl<R>(mdl, &e, N, T, t, y, nullptr, ll, grad, grad_model, nullptr, nullptr, status, stream, true);
   return launch_ekf_grad_adjoint_wg<R>(mdl, &e, N, T, t, y, ll, grad, grad_model, status, stream, true);
 }

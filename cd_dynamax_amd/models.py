@@ -357,6 +357,7 @@ def cdnlgssm_loglik_and_grad_all(
     hyperparams: Union[EKFHyperParams, UKFHyperParams] = EKFHyperParams(),
     inputs=None,
     dtype=None,
+    num_iter: int = 1,
 ):
     """EKF (or, with ``UKFHyperParams``, unscented) marginal log-likelihood and its gradient w.r.t. EVERY parameter: returns ``(ll, grads)`` with ``grads`` a
     ``ParamsCDNLGSSM`` of the same structure as ``params`` (what ``jax.grad`` of ``marginal_log_prob`` returns in the
@@ -370,7 +371,7 @@ def cdnlgssm_loglik_and_grad_all(
     if not ukf and not isinstance(hyperparams, EKFHyperParams):
         raise NotImplementedError("gradients are provided for the EKF and the UKF marginal log-likelihood (the ensemble filter is stochastic)")
     mdl = _model_block(params)
-    opts = _opts(hyperparams, 1)
+    opts = _opts(hyperparams, 1 if ukf else num_iter)  # (num_iter: the EKF's update iterations, as cdnlgssm_filter takes them)
     on_device = _device.is_device_tensor(emissions)
     if on_device:
         y, t, batched, dtype = _device.prepare(emissions, t_emissions, opts)
@@ -395,7 +396,7 @@ def cdnlgssm_loglik_and_grad_all(
         raise NotImplementedError(
             f"no reverse-sweep kernel for drift {type(params.dynamics.drift).__name__} with state_dim={mdl.state_dim}, "
             f"emission_dim={mdl.emission_dim}, state_order={hyperparams.state_order} (needs state and emission dimensions <= 8 -- LearnableLorenz96 / LearnableLinear: <= 43 in float64, 62 in float32 --, "
-            "MLP hidden layers <= 64, num_iter 1, state_order 'first' or 'second')")
+            "MLP hidden layers <= 64, state_order 'first' or 'second'; num_iter > 1 for state and emission dimensions <= 8)")
     if on_device:  # the sweeps run on the device tensors; the (small) gradient blocks are packed on the host
         ll, gth, _, gm = (x.cpu().numpy() for x in _device.loglik_grad_device(mdl, opts, t, y, True))
     else:

@@ -1301,9 +1301,11 @@ def ukf_loglik_grad_all(mdl: Model, t, y, dt0=0.01, dt_final=1e-10, max_steps=10
     return ekf_loglik_grad_adjoint(mdl, t, y, dt0, dt_final, max_steps, full=True, state_order="first", ukf=True)
 
 
-def ekf_loglik_grad_adjoint(mdl: Model, t, y, dt0=0.01, dt_final=1e-10, max_steps=100000, full=False, state_order="first", ukf=False):
+def ekf_loglik_grad_adjoint(mdl: Model, t, y, dt0=0.01, dt_final=1e-10, max_steps=100000, full=False, state_order="first", ukf=False,
+                            num_iter=1):
     """Returns (ll [N], grad [N, n_theta]): EKF, state_order 'first' or 'second' (the mean term 0.5 P grad(div f), reversed by
-    divgrad_vjp), num_iter 1; float64.
+    divgrad_vjp); ``num_iter`` update iterations as inference_ekf.py:153-199 runs them (each from the previous one's posterior, the
+    log-likelihood term from the first one's inputs, symmetrize once at the end); float64.
 
     ``full=True`` adds a dict with the gradients w.r.t. every other parameter of the model, each with a leading [N]:
     m0, P0, L, Qc, H, bias, R and LQL (= the cotangent of L Qc L^T the first two are chained from).  Cotangents of the
@@ -1370,6 +1372,7 @@ def ekf_loglik_grad_adjoint(mdl: Model, t, y, dt0=0.01, dt_final=1e-10, max_step
         tn = t if t.ndim == 1 else t[n]
         # ---- forward sweep, keeping predicted and filtered moments ----
         mp, Pp, mf, Pf = [mdl.m0.copy()], [sym(mdl.P0)], [], []
+        upd_in = []
         dts_fwd = {}
         ll = 0.0
         for k in range(T):
@@ -1379,10 +1382,15 @@ def ekf_loglik_grad_adjoint(mdl: Model, t, y, dt0=0.01, dt_final=1e-10, max_step
             Lc = np.linalg.cholesky(S)
             w = np.linalg.solve(S, v)
             ll += -0.5 * v @ w - np.log(np.diag(Lc)).sum() - 0.5 * mm * math.log(2 * math.pi)
-            Sb = sym(S) + 1e-9 * eye_m
-            X = np.linalg.solve(Sb, H @ P_)
-            mf.append(m_ + X.T @ v)
-            Pf.append(sym(P_ - X.T @ S @ X))
+            its = [(m_, P_)]                                   # inputs of every update iteration
+            for _it in range(num_iter):
+                mi, Pi = its[-1]
+                Si = H @ Pi @ H.T + R
+                Xi = np.linalg.solve(sym(Si) + 1e-9 * eye_m, H @ Pi)
+                its.append((mi + Xi.T @ (y[n, k] - (H @ mi + bias)), Pi - Xi.T @ Si @ Xi))
+            upd_in.append(its[:-1])
+            mf.append(its[-1][0])
+            Pf.append(sym(its[-1][1]))
             if k + 1 < T:
                 x, P = mf[k], Pf[k]
                 dts_fwd[k] = step_sizes(x, P, tn[k], tn[k + 1])
@@ -1396,25 +1404,29 @@ def ekf_loglik_grad_adjoint(mdl: Model, t, y, dt0=0.01, dt_final=1e-10, max_step
         thb = np.zeros(npar)
         mb, Pb = np.zeros(d), np.zeros((d, d))          # adjoint of the filtered moments at k
         for k in range(T - 1, -1, -1):
-            m_, P_ = mp[k], Pp[k]
-            HP = H @ P_
-            S = HP @ H.T + R
-            v = y[n, k] - (H @ m_ + bias)
-            Sinv = np.linalg.inv(S)
-            w = Sinv @ v
-            Sb = sym(S) + 1e-9 * eye_m
-            X = np.linalg.solve(Sb, HP)
             Pb = sym(Pb)
-            vb = X @ mb - w
-            Kb = np.outer(v, mb) - 2 * S @ X @ Pb                  # cotangent of K^T  [m,d]
-            Sbar = -X @ Pb @ X.T + 0.5 * np.outer(w, w) - 0.5 * Sinv
-            Ub = np.linalg.solve(Sb, Kb)                           # [m,d]
-            Sbar = Sbar + sym(-X @ Ub.T)
-            extra["R"][n] += Sbar
-            extra["H"][n] += 2 * Sbar @ HP - np.outer(vb, m_) + Ub @ P_
-            extra["bias"][n] -= vb
-            Pb = Pb + sym(Ub.T @ H) + H.T @ Sbar @ H
-            mb = mb - H.T @ vb
+            for it in range(num_iter - 1, -1, -1):                 # the update iterations reversed; the likelihood term sits on the first
+                m_, P_ = upd_in[k][it]
+                HP = H @ P_
+                S = HP @ H.T + R
+                v = y[n, k] - (H @ m_ + bias)
+                Sb = sym(S) + 1e-9 * eye_m
+                X = np.linalg.solve(Sb, HP)
+                vb = X @ mb
+                Kb = np.outer(v, mb) - 2 * S @ X @ Pb              # cotangent of K^T  [m,d]
+                Sbar = -X @ Pb @ X.T
+                if it == 0:
+                    Sinv = np.linalg.inv(S)
+                    w = Sinv @ v
+                    vb = vb - w
+                    Sbar = Sbar + 0.5 * np.outer(w, w) - 0.5 * Sinv
+                Ub = np.linalg.solve(Sb, Kb)                       # [m,d]
+                Sbar = Sbar + sym(-X @ Ub.T)
+                extra["R"][n] += Sbar
+                extra["H"][n] += 2 * Sbar @ HP - np.outer(vb, m_) + Ub @ P_
+                extra["bias"][n] -= vb
+                Pb = Pb + sym(Ub.T @ H) + H.T @ Sbar @ H
+                mb = mb - H.T @ vb
             if k == 0:
                 extra["m0"][n], extra["P0"][n] = mb, sym(Pb)
                 break

@@ -131,3 +131,21 @@ def test_graft_entry_build_passes(hip_lib):
     sys.path.insert(0, ROOT)
     entry = importlib.import_module("__graft_entry__")
     entry.build()
+
+
+def test_integration_md_structs_have_the_library_layout():
+    """The ctypes structs INTEGRATION.md shows a maintainer are the ones cdkf.h declares: same field names, order and size as the
+    package's own bindings (a struct that lags the header lets cdkf_default_opts write past it)."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    block = re.search(r"```python\nimport ctypes as C, numpy as np\n(.*?)```", text, re.S).group(1)
+    decls = block.split("def _hip_ekf_filter")[0].replace('_lib = C.CDLL("libcdkf_hip.so")', "")
+    ns = {}
+    exec("import ctypes as C, numpy as np\n" + decls, ns)
+    for doc, own in ((ns["cdkf_opts"], _ffi.CdkfOpts), (ns["cdkf_model"], _ffi.CdkfModel)):
+        assert C.sizeof(doc) == C.sizeof(own)
+        assert [f[0] for f in doc._fields_] == [f[0] for f in own._fields_][:len(doc._fields_)]
+        for name, *_ in doc._fields_:
+            assert getattr(doc, name).offset == getattr(own, name).offset, name

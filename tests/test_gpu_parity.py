@@ -939,8 +939,8 @@ def test_loglik_gradient_unsupported_raises(hip_lib):
     with pytest.raises(NotImplementedError, match="LDS plan"):   # (refused by the launch: the host gate is precision-agnostic)
         cd.cdnlgssm_loglik_and_grad(params_from(mdl), y, t[..., None])
     with pytest.raises(NotImplementedError, match="no gradient kernel"):
-        from helpers import mlp_model                                    # an MLP drift beyond eight state dimensions: no reverse sweep
-        cd.cdnlgssm_loglik_and_grad(params_from(mlp_model(rng, 12, 4, (8, 8))), np.zeros((2, 5, 4)), t[..., None])
+        from helpers import mlp_model                                    # an MLP drift with a hidden layer beyond 64: no reverse sweep
+        cd.cdnlgssm_loglik_and_grad(params_from(mlp_model(rng, 12, 4, (80, 8))), np.zeros((2, 5, 4)), t[..., None])
     with pytest.raises(NotImplementedError, match="no gradient kernel"):
         cd.cdnlgssm_loglik_and_grad(params_from(o.lorenz63_model(3)), y[..., :3], t[..., None],
                                     cd.EKFHyperParams(state_order="zeroth"))

