@@ -1,0 +1,711 @@
+// cdkf_adjoint_w40_kernels.h -- reverse sweep (value-and-gradient of the marginal log-likelihood w.r.t. the forcing and every leaf of
+// the model block) of the Lorenz-96 model at state dimensions 12 .. 40 on ONE WAVEFRONT PER TRAJECTORY: the counterpart of
+// ekf_filter_wave_l96_kernel (cdkf_wave40_kernels.h) for the discrete adjoint that ekf_adjoint_wg_kernel runs with a workgroup per
+// trajectory.  Same scope as the forward kernel: emission = a selection of state components (H rows of the identity, no bias), any
+// symmetric R, num_iter = 1, fixed-step Dormand-Prince.  Oracle: cdkf_oracle.ekf_loglik_grad_adjoint, line by line.
+//
+// Why: the workgroup kernel spends a d = 40 observation step in ~60 barrier-separated phases of a few dozen flops per thread (375 k
+// cycles, one trajectory per CU); the factorisation and the substitutions do not parallelise over 256 threads.  Here a wavefront owns
+// the trajectory, nothing inside the time loop waits on another wavefront, and two trajectories share a CU (fp32: four).
+//
+//  * Update, reversed (inference_ekf.py:153-199 backwards), in STATE coordinates as the forward kernel runs it: the order-D system
+//    S_full = [P + R on the observed components; the identity on the others], zero innovation / right-hand-side rows there.
+//      - ONE factorisation and ONE substitution sweep: W2 = (sym S + 1e-9 I)^-1 from the identity (W40Lin); psd_solve's two
+//        applications are products, X = W2 (E P), Ub = W2 Kb, and the log-likelihood's S^-1 = W2 + 1e-9 W2 W2 (+ O(1e-18 |W2|^3))
+//        needs no factor of its own;
+//      - ten dense products on the matrix cores (v_mfma_*_16x16x4, 3 x 3 tiles of 16 x 16, operands straight from four LDS images
+//        that are reused as their contents die): X, W2 W2, X Pb, (E P) Pb, (X Pb) X^T, W2 Kb, X Ub^T, Ub X^T, Sbar (E P), Ub P;
+//        S X Pb is formed as (E P - 1e-9 X) Pb (S X = E P - 1e-9 X by the definition of X), so S itself is never stored;
+//      - Sbar, Kb, Ub stay in accumulator registers between the products that form and consume them.
+//  * Predict, reversed: per Runge-Kutta step the six stages forward (slopes of the owned entries of the packed upper triangle in
+//    registers, as the forward kernel) and backward: the stage cotangent Lam as a symmetric LDS image with a wrap-around halo,
+//    Ybar_P = Lam F + (Lam F)^T as a six-point stencil on it (the Jacobian's four non-zeros per row), the state's cotangent from
+//    three rows of Lam against four rows of the stage covariance, the weighted sums of the stage cotangents in lane-owned LDS arrays.
+//    Intervals of several steps are replayed from the filtered moments in chunks of `cap` step starts (global scratch).
+//  * The model block accumulates in global memory (H, R, bias: read-modify-write by the lane that owns the tile entry in every step;
+//    the first step writes), LQL / P0 / m0 / the forcing in registers until the end.
+#pragma once
+#include "cdkf_wave40_kernels.h"
+
+namespace cdkf {
+
+template <typename R, int D>
+struct W40A {
+  using W = W40<D>;
+  static constexpr int EPL = W::EPL, LDY = W::LDY, LDP = W::LDP;
+  static constexpr int NB = (D + 15) / 16, NT = NB * NB;
+  static constexpr int IMG = D * LDY;          // an update image: D rows, leading dimension LDY (even)
+  static constexpr int SIMG = (D + 4) * LDP;   // a stage image: rows / columns -2 .. D + 1 (wrap-around halo)
+  static constexpr int LPK = W::LPK;
+  static constexpr int ACC = 64 * EPL;         // a lane-owned array of the owned entries
+  static constexpr int NACC = 5;               // weighted sums of the stage cotangents, stages 0 .. 4
+  static constexpr int upd = 4 * IMG + LPK, prd = SIMG + IMG + NACC * ACC;
+  static constexpr int body = ((upd > prd ? upd : prd) + 1) & ~1;
+  static constexpr int NV = 15;
+  static constexpr int o_end = body + NV * 64;
+  static constexpr int kWaves = 2;
+  // per workgroup: (L Qc L^T) and R entries in ownership order, the index tables (two 32-bit words per entry), obs[64]
+  static constexpr int TABW = 2 * 64 * EPL + 64;  // 32-bit words
+  static constexpr int SH = (2 * 64 * EPL + (TABW * 4 + (int)sizeof(R) - 1) / (int)sizeof(R) + 1) & ~1;
+  static constexpr long lds_reals = (long)SH + (long)kWaves * o_end;
+  // global scratch per trajectory: `cap` step starts (owned entries lane-major + the mean)
+  __host__ __device__ static constexpr long start_reals() { return 64L * EPL + 64; }
+};
+
+// acc[mt * NB + nt] += sum_k fa(16 mt + (lane & 15), k) fb(k, 16 nt + (lane & 15)) over k < D (D a multiple of four); the operand
+// functions return zero outside the matrix
+template <typename R, int D, typename Acc, typename FA, typename FB>
+CDKF_DEV void w40a_mm(Acc& acc, const int lane, FA&& fa, FB&& fb) {
+  constexpr int NB = W40A<R, D>::NB;
+  const int lm = lane & 15, lg = lane >> 4;
+#pragma unroll 2
+  for (int ks = 0; ks < D / 4; ++ks) {
+    const int kk = 4 * ks + lg;
+    R av[NB], bv[NB];
+#pragma unroll
+    for (int t = 0; t < NB; ++t) {
+      av[t] = fa(16 * t + lm, kk);
+      bv[t] = fb(kk, 16 * t + lm);
+    }
+#pragma unroll
+    for (int mt = 0; mt < NB; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NB; ++nt) acc[mt * NB + nt] = wg_mfma(av[mt], bv[nt], acc[mt * NB + nt]);
+  }
+}
+
+template <typename R, int D>
+__global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<R> a, R* __restrict__ grad, R* __restrict__ grad_model,
+                                                                    R* __restrict__ ws, const long ws_stride, const int cap) {
+  using W = W40<D>;
+  using A = W40A<R, D>;
+  using Tile = W40Tile<R>;
+  using Lin = W40Lin<R, D>;
+  using V4 = typename Tile::V4;
+  using T = Dp5T<R>;
+  constexpr int EPL = W::EPL, LDP = W::LDP, LDY = W::LDY, IMG = A::IMG, NB = A::NB, NT = A::NT;
+  static_assert(A::SH % 2 == 0 && A::o_end % 2 == 0 && IMG % 2 == 0 && A::SIMG % 2 == 0 && A::LPK % 2 == 0, "16-byte aligned regions");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  R* shQ = reinterpret_cast<R*>(smem_raw);
+  R* shR = shQ + 64 * EPL;
+  unsigned* tabA = reinterpret_cast<unsigned*>(shR + 64 * EPL);
+  unsigned* tabB = tabA + 64 * EPL;
+  int* obs = reinterpret_cast<int*>(tabB + 64 * EPL);
+  R* Wb = shQ + A::SH + (long)wave * A::o_end;
+  // update: four images and the packed factor; predict: the stage image (halo), the stage covariance, the cotangent sums
+  R* I0 = static_cast<R*>(__builtin_assume_aligned(Wb, 16));
+  R* I1 = I0 + IMG;
+  R* I2 = I1 + IMG;
+  R* I3 = I2 + IMG;
+  R* Lp = static_cast<R*>(__builtin_assume_aligned(I3 + IMG, 16));
+  R* S0 = I0;
+  R* PsI = S0 + A::SIMG;
+  R* AccL = PsI + IMG;
+  R* vec = Wb + A::body;
+  R *v_xs = vec, *v_ca = vec + 64 /* pairs: 128 */, *v_c3 = vec + 192 /* triples: 192 */, *v_lam = vec + 384, *v_mb = vec + 448,
+    *v_v = vec + 512, *v_w = vec + 576, *v_vb = vec + 640, *v_u = vec + 704, *v_m = vec + 768, *v_inv = vec + 832, *v_dt = vec + 896;
+  const long n = (long)blockIdx.x * A::kWaves + wave;
+  const int M = a.m;
+
+  // ---- tables: the owned entries e = lane + 64 s of the packed upper triangle (as the forward kernel) ------------------------------
+  {
+    const R* LQL = a.par + a.o_LQL;
+    const R* Rm = a.par + a.o_R;
+    if (wave == 0) {
+      int r_obs = -1;
+      if (lane < D) {
+        const R* Hm = a.par + a.o_H;
+        for (int r = 0; r < M; ++r)
+          if (Hm[r * D + lane] != R(0)) r_obs = r;
+      }
+      obs[lane] = r_obs;
+      wave_sync();
+#pragma unroll
+      for (int s = 0; s < EPL; ++s) {
+        const int e = lane + 64 * s;
+        const bool own = e < W::NP;
+        int i = 0, rs = 0;  // row i starts at rs = i D - i (i - 1) / 2
+        while (i + 1 < D && e >= rs + (D - i)) {
+          rs += D - i;
+          ++i;
+        }
+        const int j = own ? i + (e - rs) : i;
+        const int oi = obs[i], oj = obs[j];
+        shQ[64 * s + lane] = own ? LQL[i * D + j] : R(0);
+        shR[64 * s + lane] = !own ? R(0) : ((oi >= 0 && oj >= 0) ? Rm[oi * M + oj] : (i == j ? R(1) : R(0)));
+        tabA[64 * s + lane] = (unsigned)i | (unsigned)j << 8 | (unsigned)(oi >= 0) << 16 | (unsigned)(oj >= 0) << 17;
+        tabB[64 * s + lane] = (unsigned)(i * LDY + j) | (unsigned)(j * LDY + i) << 11 | (unsigned)(W::rs(j) + i) << 22;
+      }
+    }
+  }
+  __syncthreads();
+  if (n >= a.N) return;  // whole wavefront; no workgroup barrier anywhere below
+  struct Ent { int i, j; };
+  auto entry = [&](int s) { const unsigned w = tabA[64 * s + lane]; return Ent{(int)(w & 255u), (int)((w >> 8) & 255u)}; };
+  struct Off { int y, yt, l; };
+  auto offsets = [&](int s) { const unsigned w = tabB[64 * s + lane]; return Off{(int)(w & 2047u), (int)((w >> 11) & 2047u), (int)(w >> 22)}; };
+  const bool isrow = lane < D;
+  const int lp1 = (lane + 1 >= D) ? lane + 1 - D : lane + 1, lp2 = (lane + 2 >= D) ? lane + 2 - D : lane + 2,
+            lm1 = (lane == 0) ? D - 1 : lane - 1, lm2 = (lane <= 1) ? lane + D - 2 : lane - 2;
+  const int myobs = isrow ? obs[lane] : -1;
+  const unsigned long long obsmask = __ballot(myobs >= 0);
+  auto observed = [&](int i) { return (bool)((obsmask >> i) & 1ull); };
+  const R forcing = (a.par + a.o_theta)[0];
+  const int rowi = (lane <= D) ? lane : D;
+  const int ri = W::rs(rowi);
+  const int lm = lane & 15, lg = lane >> 4;
+  const R* tp = a.t + n * a.t_sn;
+  const R* yp = a.y + n * a.y_sn + (myobs >= 0 ? myobs : 0) * a.y_si;
+  R* g = grad + n;  // (the forcing: one drift parameter)
+  R* gm = grad_model ? grad_model + n * ((long)D + 2L * D * D + (long)M * D + M + (long)M * M) : nullptr;
+  R* gP0 = gm ? gm + D : nullptr;
+  R* gQ = gm ? gm + D + (long)D * D : nullptr;
+  R* gH = gm ? gm + D + 2L * D * D : nullptr;
+  R* gBias = gm ? gH + (long)M * D : nullptr;
+  R* gR = gm ? gBias + M : nullptr;
+  R* wsb = ws + n * ws_stride;
+
+  R Pb[EPL], gQacc[EPL];  // cotangent of the covariance, d ll / d (L Qc L^T): owned entries
+#pragma unroll
+  for (int s = 0; s < EPL; ++s) Pb[s] = gQacc[s] = R(0);
+  R mb = R(0), gF = R(0);
+  int st = 0;
+  bool bad = false;
+
+  // tiles <-> images
+  auto tiles_zero = [&](V4 (&acc)[NT]) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = V4{0, 0, 0, 0};
+  };
+  auto tiles_store = [&](R* img, const V4 (&acc)[NT]) {
+#pragma unroll
+    for (int mt = 0; mt < NB; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NB; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * mt + Tile::row(lg, r), col = 16 * nt + lm;
+          if (row < D && col < D) img[row * LDY + col] = acc[mt * NB + nt][r];
+        }
+  };
+  auto img_at = [&](const R* img, int i, int k) { return i < D ? img[i * LDY + k] : R(0); };  // (k < D by construction)
+
+  // ---- one right-hand side of the moment equations on the stage image (as the forward kernel's) --------------------------------------
+  auto rhs = [&](const R (&Ps)[EPL], const R xm, R (&kP)[EPL], R& kM) {
+    int ei[EPL], ej[EPL], offP[EPL];
+#pragma unroll
+    for (int s = 0; s < EPL; ++s) {
+      const Ent e = entry(s);
+      ei[s] = e.i;
+      ej[s] = e.j;
+      offP[s] = (e.i + 2) * LDP + (e.j + 2);
+      if (W::owned(s, lane)) {
+        S0[offP[s]] = Ps[s];
+        S0[(e.j + 2) * LDP + (e.i + 2)] = Ps[s];
+      }
+    }
+    if (isrow) v_xs[lane] = xm;
+    wave_sync();
+    for (int e = lane; e < 3 * D; e += 64) {  // halo: rows -2, -1 <- D-2, D-1; row D <- 0; the same for the columns
+      const int r = (e >= 2 * D) ? 2 : (e >= D ? 1 : 0), c = e - r * D;
+      const int src = (r == 2) ? 0 : D - 2 + r, dst = (r == 2) ? D : r - 2;
+      S0[(dst + 2) * LDP + (c + 2)] = S0[(src + 2) * LDP + (c + 2)];
+      S0[(c + 2) * LDP + (dst + 2)] = S0[(c + 2) * LDP + (src + 2)];
+    }
+    typedef R Pair __attribute__((ext_vector_type(2)));
+    Pair* cab = reinterpret_cast<Pair*>(__builtin_assume_aligned(v_ca, 16));
+    if (isrow) {
+      const R xp1 = v_xs[lp1], xm1 = v_xs[lm1], xm2 = v_xs[lm2];
+      cab[lane] = Pair{xm1, xp1 - xm2};
+      kM = rfma(xp1 - xm2, xm1, forcing - xm);
+    } else {
+      kM = R(0);
+    }
+    wave_sync();
+    constexpr int CH = 4;
+#pragma unroll
+    for (int s0 = 0; s0 < EPL; s0 += CH) {
+      R o6[CH][6], c4[CH][4], qv[CH];
+#pragma unroll
+      for (int u = 0; u < CH; ++u) {
+        const int s = (s0 + u < EPL) ? s0 + u : EPL - 1;
+        const R* c = S0 + offP[s];
+        o6[u][0] = c[-2 * LDP];
+        o6[u][1] = c[-LDP];
+        o6[u][2] = c[LDP];
+        o6[u][3] = c[-2];
+        o6[u][4] = c[-1];
+        o6[u][5] = c[1];
+        const Pair ci = cab[ei[s]], cj = cab[ej[s]];
+        c4[u][0] = ci[0];
+        c4[u][1] = ci[1];
+        c4[u][2] = cj[0];
+        c4[u][3] = cj[1];
+        qv[u] = shQ[64 * s + lane];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < CH; ++u) {
+        if (s0 + u < EPL) {
+          const int s = s0 + u;
+          R kk = rfma(R(-2), Ps[s], qv[u]);
+          kk = rfma(c4[u][0], o6[u][2] - o6[u][0], kk);
+          kk = rfma(c4[u][1], o6[u][1], kk);
+          kk = rfma(c4[u][2], o6[u][5] - o6[u][3], kk);
+          kk = rfma(c4[u][3], o6[u][4], kk);
+          kP[s] = W::owned(s, lane) ? kk : R(0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    wave_sync();  // the image is rewritten by the next stage
+  };
+
+  for (long k = a.T - 1; k >= 0; --k) {
+    const bool first = (k == a.T - 1);
+    // =================================== (1) the measurement update at k, reversed =====================================================
+    // predicted moments (P0 / m0 at k = 0) into I0, the identity into I2, Pbar into I1
+    {
+      const R* P0p = a.par + a.o_P0;
+      const R* src = a.pP + n * a.P_sn + (k > 0 ? k - 1 : 0) * a.P_sk;
+      constexpr int NE = (D * D + 63) / 64, CHK = 8;
+#pragma unroll 1
+      for (int q0 = 0; q0 < NE; q0 += CHK) {
+        R v[CHK];
+#pragma unroll
+        for (int u = 0; u < CHK; ++u) {
+          const int e = lane + 64 * (q0 + u), r = e / D, c = e - r * D;
+          v[u] = (e < D * D) ? (k == 0 ? R(0.5) * (P0p[r * D + c] + P0p[c * D + r]) : src[(long)e * a.P_si]) : R(0);
+        }
+#pragma unroll
+        for (int u = 0; u < CHK; ++u) {
+          const int e = lane + 64 * (q0 + u), r = e / D, c = e - r * D;
+          if (e < D * D) {
+            I0[r * LDY + c] = v[u];
+            I2[r * LDY + c] = (r == c) ? R(1) : R(0);
+          }
+        }
+      }
+    }
+    R mpred = R(0), vk = R(0);
+    if (isrow) {
+      mpred = (k == 0) ? (a.par + a.o_m0)[lane] : a.pm[n * a.m_sn + (k - 1) * a.m_sk + lane * a.m_si];
+      vk = (myobs >= 0) ? yp[k * a.y_sk] - mpred : R(0);
+    }
+    v_v[lane] = vk;
+    v_mb[lane] = mb;
+    v_m[lane] = mpred;
+#pragma unroll
+    for (int s = 0; s < EPL; ++s)
+      if (W::owned(s, lane)) {
+        const Off f = offsets(s);
+        I1[f.y] = Pb[s];
+        I1[f.yt] = Pb[s];
+      }
+    wave_sync();
+    // sym(S) + 1e-9 I, packed lower (state coordinates: the identity on the unobserved components); the augmented row is not used
+#pragma unroll
+    for (int s = 0; s < EPL; ++s)
+      if (W::owned(s, lane)) {
+        const Off f = offsets(s);
+        const unsigned wA = tabA[64 * s + lane];
+        const bool obs_i = (wA >> 16) & 1u, obs_j = (wA >> 17) & 1u;
+        const R sv = (obs_i && obs_j) ? I0[f.y] + shR[64 * s + lane] : shR[64 * s + lane];
+        Lp[f.l] = (f.y == f.yt) ? sv + R(1e-9) : sv;
+      }
+    if (isrow) Lp[W::rs(D) + lane] = R(0);
+    wave_sync();
+    {
+      R quad = R(0);
+      double logdet = 0.0;
+      R* const sys[1] = {Lp};
+      R* const scr[1] = {v_ca};
+      Lin::template cholesky<1>(sys, scr, v_inv, rowi, ri, lane, quad, logdet, bad);
+    }
+    // W2 = (sym S + 1e-9 I)^-1: the D columns of the identity, in place in I2
+    Lin::solve(I2, Lp, v_inv, (const R*)nullptr, lane, [&] {});
+    // X = W2 (E P) -> I3
+    {
+      V4 acc[NT];
+      tiles_zero(acc);
+      w40a_mm<R, D>(acc, lane, [&](int i, int kk) { return img_at(I2, i, kk); },
+                    [&](int kk, int j) { return (j < D && observed(kk)) ? I0[kk * LDY + j] : R(0); });
+      tiles_store(I3, acc);
+    }
+    wave_sync();
+    // w = S^-1 v = u1 + 1e-9 W2 u1, u1 = W2 v;  vbar = X mbar - w
+    R wv = R(0), vb = R(0);
+    {
+      R u1 = R(0), tx = R(0);
+      if (isrow) {
+        const R* w2r = I2 + lane * LDY;
+        const R* xr = I3 + lane * LDY;
+#pragma unroll 4
+        for (int c = 0; c < D; ++c) {
+          u1 = rfma(w2r[c], v_v[c], u1);
+          tx = rfma(xr[c], v_mb[c], tx);
+        }
+      }
+      v_u[lane] = u1;
+      wave_sync();
+      R u2 = R(0);
+      if (isrow) {
+        const R* w2r = I2 + lane * LDY;
+#pragma unroll 4
+        for (int c = 0; c < D; ++c) u2 = rfma(w2r[c], v_u[c], u2);
+      }
+      wv = rfma(R(1e-9), u2, u1);
+      vb = tx - wv;
+      v_w[lane] = wv;
+      v_vb[lane] = vb;
+    }
+    // X Pb and (E P) Pb;  Kb = v mbar^T - 2 S X Pb,  S X = E P - 1e-9 X
+    V4 accK[NT], accS[NT];
+    {
+      V4 accX[NT];
+      tiles_zero(accX);
+      tiles_zero(accK);
+      w40a_mm<R, D>(accX, lane, [&](int i, int kk) { return img_at(I3, i, kk); }, [&](int kk, int j) { return j < D ? I1[kk * LDY + j] : R(0); });
+      w40a_mm<R, D>(accK, lane, [&](int i, int kk) { return (i < D && observed(i)) ? I0[i * LDY + kk] : R(0); },
+                    [&](int kk, int j) { return j < D ? I1[kk * LDY + j] : R(0); });
+      wave_sync();  // (every read of Pbar's image is done; v_w / v_vb are visible)
+      tiles_store(I1, accX);  // X Pb
+#pragma unroll
+      for (int mt = 0; mt < NB; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NB; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * mt + Tile::row(lg, r), col = 16 * nt + lm;
+            const int t = mt * NB + nt;
+            accK[t][r] = rfma(R(-2), rfma(R(-1e-9), accX[t][r], accK[t][r]), v_v[row] * v_mb[col]);
+          }
+    }
+    // Sbar = -(X Pb) X^T + w w^T / 2 - S^-1 / 2 - sym(X Ub^T);  S^-1 = W2 + 1e-9 W2 W2
+    tiles_zero(accS);
+    w40a_mm<R, D>(accS, lane, [&](int i, int kk) { return img_at(I2, i, kk); }, [&](int kk, int j) { return j < D ? I2[kk * LDY + j] : R(0); });
+#pragma unroll
+    for (int mt = 0; mt < NB; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NB; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * mt + Tile::row(lg, r), col = 16 * nt + lm;
+          const int t = mt * NB + nt;
+          const R w2 = (row < D && col < D) ? I2[row * LDY + col] : R(0);
+          accS[t][r] = R(0.5) * (v_w[row] * v_w[col] - rfma(R(1e-9), accS[t][r], w2));
+        }
+    wave_sync();  // (X Pb is in I1)
+    w40a_mm<R, D>(accS, lane, [&](int i, int kk) { return -img_at(I1, i, kk); }, [&](int kk, int j) { return j < D ? I3[j * LDY + kk] : R(0); });
+    wave_sync();
+    tiles_store(I1, accK);  // Kb
+    wave_sync();
+    // Ub = W2 Kb -> I2 (over the then dead W2)
+    {
+      V4 accU[NT];
+      tiles_zero(accU);
+      w40a_mm<R, D>(accU, lane, [&](int i, int kk) { return img_at(I2, i, kk); }, [&](int kk, int j) { return j < D ? I1[kk * LDY + j] : R(0); });
+      wave_sync();
+      tiles_store(I2, accU);
+    }
+    wave_sync();
+    w40a_mm<R, D>(accS, lane, [&](int i, int kk) { return R(-0.5) * img_at(I3, i, kk); }, [&](int kk, int j) { return j < D ? I2[j * LDY + kk] : R(0); });
+    w40a_mm<R, D>(accS, lane, [&](int i, int kk) { return R(-0.5) * img_at(I2, i, kk); }, [&](int kk, int j) { return j < D ? I3[j * LDY + kk] : R(0); });
+    // model block: dR += Sbar (the observed pairs)
+    if (gm) {
+#pragma unroll
+      for (int mt = 0; mt < NB; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NB; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * mt + Tile::row(lg, r), col = 16 * nt + lm;
+            if (row < D && col < D) {
+              const int orow = obs[row], ocol = obs[col];
+              if (orow >= 0 && ocol >= 0) {
+                R* p = gR + orow * M + ocol;
+                *p = first ? accS[mt * NB + nt][r] : *p + accS[mt * NB + nt][r];
+              }
+            }
+          }
+    }
+    tiles_store(I1, accS);  // Sbar (Kb is dead: Ub was formed behind a synchronisation)
+    wave_sync();
+    if (gm) {  // dH += 2 Sbar (E P) - vbar m^T + Ub P; dbias -= vbar
+      V4 accH[NT];
+      tiles_zero(accH);
+      w40a_mm<R, D>(accH, lane, [&](int i, int kk) { return R(2) * img_at(I1, i, kk); },
+                    [&](int kk, int j) { return (j < D && observed(kk)) ? I0[kk * LDY + j] : R(0); });
+      w40a_mm<R, D>(accH, lane, [&](int i, int kk) { return img_at(I2, i, kk); }, [&](int kk, int j) { return j < D ? I0[kk * LDY + j] : R(0); });
+#pragma unroll
+      for (int mt = 0; mt < NB; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NB; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * mt + Tile::row(lg, r), col = 16 * nt + lm;
+            if (row < D && col < D) {
+              const int orow = obs[row];
+              if (orow >= 0) {
+                R* p = gH + orow * D + col;
+                const R v = rfma(-v_vb[row], v_m[col], accH[mt * NB + nt][r]);
+                *p = first ? v : *p + v;
+              }
+            }
+          }
+      if (myobs >= 0) gBias[myobs] = first ? -vb : gBias[myobs] - vb;
+    }
+    // Pbar <- Pbar + sym(Ub^T H) + H^T Sbar H;  mbar <- mbar - H^T vbar
+#pragma unroll
+    for (int s = 0; s < EPL; ++s)
+      if (W::owned(s, lane)) {
+        const Off f = offsets(s);
+        const unsigned wA = tabA[64 * s + lane];
+        const bool obs_i = (wA >> 16) & 1u, obs_j = (wA >> 17) & 1u;
+        const R uij = obs_j ? I2[f.yt] : R(0), uji = obs_i ? I2[f.y] : R(0);
+        Pb[s] += rfma(R(0.5), uij + uji, (obs_i && obs_j) ? I1[f.y] : R(0));
+      }
+    mb -= vb;
+    wave_sync();
+    if (k == 0) break;
+
+    // =================================== (2) predict k-1 -> k: the Runge-Kutta steps of the interval, reversed =========================
+    const R t0 = tp[(k - 1) * a.t_sk], t1 = tp[k * a.t_sk];
+    long S = 0;
+    {
+      R tprev = t0, tnx = rmin(t0 + a.dt0, t1);
+      while (tprev < t1 && S < a.max_steps) {
+        ++S;
+        tprev = rmin(tnx, t1);
+        const R tn = tnx + a.dt0;
+        tnx = (tn > t1 - Tol<R>::v) ? t1 : tn;
+      }
+      if (tprev < t1) st |= kStatusMaxSteps;
+    }
+    for (long cs = S > 0 ? ((S - 1) / cap) * cap : -1; cs >= 0; cs -= cap) {
+      const long ce = (cs + cap < S) ? cs + cap : S;
+      // replay from the filtered moments at k-1 up to the chunk's last step start, keeping the chunk's starts
+      R P0[EPL], x0;
+#pragma unroll
+      for (int s = 0; s < EPL; ++s) {
+        const Ent e = entry(s);
+        P0[s] = W::owned(s, lane) ? a.fP[n * a.P_sn + (k - 1) * a.P_sk + (long)(e.i * D + e.j) * a.P_si] : R(0);
+      }
+      x0 = isrow ? a.fm[n * a.m_sn + (k - 1) * a.m_sk + lane * a.m_si] : R(0);
+      {
+        R tprev = t0, tnx = rmin(t0 + a.dt0, t1);
+        for (long s = 0; s < ce; ++s) {
+          const R dt = tnx - tprev;
+          if (s >= cs) {
+            if (s + 1 < ce) {  // (the last start of the chunk stays in registers)
+              R* sv = wsb + (s - cs) * A::start_reals();
+#pragma unroll
+              for (int u = 0; u < EPL; ++u) sv[64 * u + lane] = P0[u];
+              sv[64 * EPL + lane] = x0;
+            }
+            v_dt[s - cs] = dt;  // (the step sizes of the chunk: cap <= 64)
+          }
+          if (s + 1 < ce) w40_dopri5<R, EPL>(rhs, P0, x0, dt);
+          tprev = rmin(tnx, t1);
+          const R tn = tnx + a.dt0;
+          tnx = (tn > t1 - Tol<R>::v) ? t1 : tn;
+        }
+      }
+      wave_sync();
+      for (long s = ce - 1; s >= cs; --s) {
+        if (s + 1 < ce) {
+          const R* sv = wsb + (s - cs) * A::start_reals();
+#pragma unroll
+          for (int u = 0; u < EPL; ++u) P0[u] = sv[64 * u + lane];
+          x0 = sv[64 * EPL + lane];
+        }
+        const R dt = v_dt[s - cs];
+        // ---- the step's six stages forward, slopes (times dt) kept ------------------------------------------------------------------
+        R kP[6][EPL], km[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          R Ps[EPL], xs = x0;
+#pragma unroll
+          for (int u = 0; u < EPL; ++u) Ps[u] = P0[u];
+#pragma unroll
+          for (int j = 0; j < 5; ++j)
+            if (j < i) {
+#pragma unroll
+              for (int u = 0; u < EPL; ++u) Ps[u] = rfma(T::a[i][j], kP[j][u], Ps[u]);
+              xs = rfma(T::a[i][j], km[j], xs);
+            }
+          rhs(Ps, xs, kP[i], km[i]);
+#pragma unroll
+          for (int u = 0; u < EPL; ++u) kP[i][u] *= dt;
+          km[i] *= dt;
+        }
+        // ---- ... and backward ----------------------------------------------------------------------------------------------------
+        R Pn[EPL], mn = mb, accm[5];
+#pragma unroll
+        for (int u = 0; u < EPL; ++u) Pn[u] = Pb[u];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) accm[j] = R(0);
+#pragma unroll
+        for (int i = 5; i >= 0; --i) {
+          // stage cotangent  Lam = dt (b_i Pbar + sum_{j > i} a_ji Ybar_j)  and the stage's input
+          R Lam[EPL], Ps[EPL], lam, xs = x0;
+#pragma unroll
+          for (int u = 0; u < EPL; ++u) {
+            const R acc = (i < 5) ? AccL[(i * EPL + u) * 64 + lane] : R(0);
+            Lam[u] = dt * rfma(T::b[i], Pb[u], acc);
+            gQacc[u] += Lam[u];
+            Ps[u] = P0[u];
+          }
+          lam = dt * rfma(T::b[i], mb, (i < 5) ? accm[i < 5 ? i : 0] : R(0));
+          if (isrow) gF += lam;
+#pragma unroll
+          for (int j = 0; j < 5; ++j)
+            if (j < i) {
+#pragma unroll
+              for (int u = 0; u < EPL; ++u) Ps[u] = rfma(T::a[i][j], kP[j][u], Ps[u]);
+              xs = rfma(T::a[i][j], km[j], xs);
+            }
+          int offL[EPL], ei[EPL], ej[EPL];
+#pragma unroll
+          for (int u = 0; u < EPL; ++u) {
+            const Ent e = entry(u);
+            const Off f = offsets(u);
+            ei[u] = e.i;
+            ej[u] = e.j;
+            offL[u] = (e.i + 2) * LDP + (e.j + 2);
+            if (W::owned(u, lane)) {
+              S0[offL[u]] = Lam[u];
+              S0[(e.j + 2) * LDP + (e.i + 2)] = Lam[u];
+              PsI[f.y] = Ps[u];
+              PsI[f.yt] = Ps[u];
+            }
+          }
+          if (isrow) {
+            v_xs[lane] = xs;
+            v_lam[lane] = lam;
+          }
+          wave_sync();
+          for (int e = lane; e < 3 * D; e += 64) {  // halo of Lam: rows / columns -1 <- D-1, D <- 0, D+1 <- 1
+            const int r = (e >= 2 * D) ? 2 : (e >= D ? 1 : 0), c = e - r * D;
+            const int src = (r == 0) ? D - 1 : r - 1, dst = (r == 0) ? -1 : D + r - 1;
+            S0[(dst + 2) * LDP + (c + 2)] = S0[(src + 2) * LDP + (c + 2)];
+            S0[(c + 2) * LDP + (dst + 2)] = S0[(c + 2) * LDP + (src + 2)];
+          }
+          R xbar = R(0);
+          if (isrow) {  // coefficients of column j of the Jacobian: F[j-1][j] = x[j-2], F[j+2][j] = -x[j+1], F[j+1][j] = x[j+2] - x[j-1]
+            const R xm2 = v_xs[lm2], xm1 = v_xs[lm1], xp1 = v_xs[lp1], xp2 = v_xs[lp2];
+            v_c3[3 * lane] = xm2;
+            v_c3[3 * lane + 1] = xp1;
+            v_c3[3 * lane + 2] = xp2 - xm1;
+            // F^T lam
+            xbar = rfma(v_lam[lm1], xm2, rfma(-v_lam[lp2], xp1, rfma(v_lam[lp1], xp2 - xm1, -lam)));
+          }
+          wave_sync();
+          // Ybar_P = Lam F + (Lam F)^T of the owned entries
+          R Yb[EPL];
+          constexpr int CH = 4;
+#pragma unroll
+          for (int s0 = 0; s0 < EPL; s0 += CH) {
+            R o6[CH][6], c6[CH][6];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+              const int s = (s0 + u < EPL) ? s0 + u : EPL - 1;
+              const R* c = S0 + offL[s];
+              o6[u][0] = c[-1];
+              o6[u][1] = c[2];
+              o6[u][2] = c[1];
+              o6[u][3] = c[-LDP];
+              o6[u][4] = c[2 * LDP];
+              o6[u][5] = c[LDP];
+#pragma unroll
+              for (int q = 0; q < 3; ++q) {
+                c6[u][q] = v_c3[3 * ej[s] + q];
+                c6[u][3 + q] = v_c3[3 * ei[s] + q];
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < CH; ++u)
+              if (s0 + u < EPL) {
+                const int s = s0 + u;
+                R y = R(-2) * Lam[s];
+                y = rfma(c6[u][0], o6[u][0], y);
+                y = rfma(-c6[u][1], o6[u][1], y);
+                y = rfma(c6[u][2], o6[u][2], y);
+                y = rfma(c6[u][3], o6[u][3], y);
+                y = rfma(-c6[u][4], o6[u][4], y);
+                y = rfma(c6[u][5], o6[u][5], y);
+                Yb[s] = W::owned(s, lane) ? y : R(0);
+              }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          // the state's cotangent: sum_ij (2 Lam Ps)_ij dF_ij/dx_k = 2 sum_c { Lam[k+1][c] (Ps[c][k+2] - Ps[c][k-1]) + Lam[k-1][c] Ps[c][k-2]
+          //                                                                      - Lam[k+2][c] Ps[c][k+1] }   (both symmetric: rows of the images)
+          if (isrow) {
+            const R* l1 = S0 + (lane + 3) * LDP + 2;  // row k+1 (halo row D at k = D-1)
+            const R* l2 = S0 + (lane + 1) * LDP + 2;  // row k-1 (halo row -1 at k = 0)
+            const R* l3 = S0 + (lane + 4) * LDP + 2;  // row k+2 (halo rows D, D+1)
+            const R* p1 = PsI + lp2 * LDY;
+            const R* p2 = PsI + lm1 * LDY;
+            const R* p3 = PsI + lm2 * LDY;
+            const R* p4 = PsI + lp1 * LDY;
+            R g0 = R(0), g1 = R(0), g2 = R(0), g3 = R(0);
+#pragma unroll 4
+            for (int c = 0; c < D; ++c) {
+              g0 = rfma(l1[c], p1[c] - p2[c], g0);
+              g1 = rfma(l2[c], p3[c], g1);
+              g2 = rfma(l3[c], p4[c], g2);
+            }
+            (void)g3;
+            xbar = rfma(R(2), (g0 + g1) - g2, xbar);
+          }
+          // weighted sums for the earlier stages; the step's input
+#pragma unroll
+          for (int j = 0; j < 5; ++j)
+            if (j < i) {
+#pragma unroll
+              for (int u = 0; u < EPL; ++u) {
+                R* p = AccL + (j * EPL + u) * 64 + lane;
+                *p = (i == 5) ? T::a[i][j] * Yb[u] : rfma(T::a[i][j], Yb[u], *p);
+              }
+              accm[j] = rfma(T::a[i][j], xbar, accm[j]);
+            }
+#pragma unroll
+          for (int u = 0; u < EPL; ++u) Pn[u] += Yb[u];
+          mn += xbar;
+          wave_sync();  // the images are rewritten by the next stage
+        }
+#pragma unroll
+        for (int u = 0; u < EPL; ++u) Pb[u] = Pn[u];
+        mb = mn;
+      }
+    }
+  }
+
+  // ---- results --------------------------------------------------------------------------------------------------------------------
+  if (gm) {
+    if (isrow) gm[lane] = mb;
+#pragma unroll
+    for (int s = 0; s < EPL; ++s)
+      if (W::owned(s, lane)) {
+        const Ent e = entry(s);
+        gP0[e.i * D + e.j] = Pb[s];
+        gP0[e.j * D + e.i] = Pb[s];
+        gQ[e.i * D + e.j] = gQacc[s];
+        gQ[e.j * D + e.i] = gQacc[s];
+      }
+  }
+  wave_sync();
+  v_u[lane] = isrow ? gF : R(0);
+  wave_sync();
+  if (lane == 0) {
+    R sum = R(0);
+    for (int c = 0; c < D; ++c) sum += v_u[c];
+    g[0] = sum;
+  }
+  if (bad) st |= kStatusNotPd;
+  if (st && lane == 0 && a.status) atomicOr(&a.status[n], st);
+}
+
+}  // namespace cdkf

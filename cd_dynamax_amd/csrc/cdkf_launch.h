@@ -232,6 +232,11 @@ int launch_wave8(const WgArgs<R>& a, hipStream_t stream);
 template <typename R, bool MLP, bool SMOOTH = false>
 int launch_adjoint_kernel(const WgArgs<R>& a, R* grad, R* grad_model, hipStream_t stream);
 // reverse sweep (gradient) for larger states, one workgroup per trajectory (launch_adjwg.hip, cdkf_adjoint_wg_kernels.h); scratch:
+// the Lorenz-96 reverse sweep on one wavefront per trajectory (cdkf_adjoint_w40_kernels.h, launch_adjw40.hip): the shapes wave40_shape
+// admits; scratch: N * wave40_adjoint_scratch_reals(d, cap) reals
+long wave40_adjoint_scratch_reals(int d, int cap);
+template <typename R>
+int launch_wave40_adjoint(const WgArgs<R>& a, R* grad, R* grad_model, R* scratch, int cap, hipStream_t stream);
 // N * adjoint_wg_scratch_reals(d, cap) reals
 bool adjoint_wg_fits(int d, int m, int bytes_per_real);
 bool adjoint_wg_fits_mlp(int d, int m, int h1, int h2, int bytes_per_real);  // ... + the MLP drift's LDS region

@@ -425,7 +425,11 @@ static int launch_ekf_grad_adjoint_wg(const cdkf_model* mdl, const cdkf_opts* o,
   const size_t nm = (size_t)N * T * mdl->state_dim, nP = nm * mdl->state_dim;
   int cap = 8;  // step starts kept per replay chunk of an interval (CDKF_ADJ_WG_STARTS)
   if (const char* e = getenv("CDKF_ADJ_WG_STARTS")) cap = atoi(e) > 0 ? atoi(e) : 8;
-  const size_t nscr = (size_t)N * (size_t)adjoint_wg_scratch_reals(mdl->state_dim, cap);
+  // Lorenz-96 through a selection of its components: both sweeps on one wavefront per trajectory (CDKF_NO_WAVE40_ADJ=1 keeps the
+  // workgroup reverse sweep: A/B, tests)
+  const bool w40adj = wave40_shape(mdl, o) && !ukf && !getenv("CDKF_NO_WAVE40_ADJ");
+  if (w40adj && cap > 64) cap = 64;
+  const size_t nscr = (size_t)N * (size_t)(w40adj ? wave40_adjoint_scratch_reals(mdl->state_dim, cap) : adjoint_wg_scratch_reals(mdl->state_dim, cap));
   // an adaptive solve: the forward (workgroup) sweep logs the accepted step sizes of every interval (up to CDKF_ADJ_DT_CAP, default
   // 64; a longer interval raises MAX_STEPS on that trajectory) and the reverse sweep replays them
   int dtcap = 64;
@@ -441,8 +445,15 @@ static int launch_ekf_grad_adjoint_wg(const cdkf_model* mdl, const cdkf_opts* o,
   // (unscented: the forward sweep forms the sigma points on the workgroup kernel; the reverse sweep replays the same moment equations in
   //  closed form -- equal to rounding for the quadratic drift this path admits)
   a.ukf = ukf ? 1 : 0;
+  if (w40adj) {  // the moments between the two sweeps: a trajectory's matrices contiguous, whatever layout the caller's arrays have
+    const long d = mdl->state_dim;
+    a.m_sn = T * d; a.m_sk = d; a.m_si = 1;
+    a.P_sn = T * d * d; a.P_sk = d * d; a.P_si = 1;
+  }
   rc = (wave40_shape(mdl, o) && !ukf) ? launch_wave40<R>(a, stream) : launch_wg_dispatch<R>(a, mdl, false, stream);
-  if (!rc) rc = launch_adjoint_wg_kernel<R>(a, grad, grad_model, w + 2 * (nm + nP), cap, stream);
+  if (!rc)
+    rc = w40adj ? launch_wave40_adjoint<R>(a, grad, grad_model, w + 2 * (nm + nP), cap, stream)
+                : launch_adjoint_wg_kernel<R>(a, grad, grad_model, w + 2 * (nm + nP), cap, stream);
   CDKF_HIP_CHECK(hipEventRecord(ws.done, stream));
   ws.in_flight = true;
   const int rc2 = lease.release();

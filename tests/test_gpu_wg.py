@@ -697,11 +697,15 @@ def test_loglik_gradient_with_iterated_updates(hip_lib, kind, d, m, num_iter):
         cd.cdnlgssm_loglik_and_grad_all(params_from(big), np.zeros((2, 4, 4)), np.arange(4.0)[None, :, None].repeat(2, 0), hyp, num_iter=2)
 
 
-def test_lorenz96_d40_value_and_gradient(hip_lib):
+@pytest.mark.parametrize("sweep", ["ekf_adjoint_wave_l96_kernel", "ekf_adjoint_wg_kernel"])
+def test_lorenz96_d40_value_and_gradient(hip_lib, sweep, monkeypatch):
     """BASELINE config 4's model (Lorenz-96, d = m = 40, H = I) can be trained: value and gradient of the EKF log-likelihood w.r.t. the
-    forcing and every other parameter -- forward sweep on the wavefront kernel (ekf_filter_wave_l96_kernel), reverse sweep on
-    ekf_adjoint_wg_kernel -- against the oracle's discrete adjoint (value_and_grad of marginal_log_prob, ssm_temissions.py:550-568);
-    then with half of the components observed (d = 40, m = 20), the drift block alone, and in fp32."""
+    forcing and every other parameter -- forward sweep on the wavefront kernel (ekf_filter_wave_l96_kernel), reverse sweep on one
+    wavefront per trajectory too (ekf_adjoint_wave_l96_kernel, round 4) or on the workgroup kernel (CDKF_NO_WAVE40_ADJ=1) -- against the
+    oracle's discrete adjoint (value_and_grad of marginal_log_prob, ssm_temissions.py:550-568); then with half of the components
+    observed (d = 40, m = 20), the drift block alone, and in fp32."""
+    if sweep == "ekf_adjoint_wg_kernel":
+        monkeypatch.setenv("CDKF_NO_WAVE40_ADJ", "1")
     rng = np.random.default_rng(440)
     for m in (40, 20):
         mdl = lorenz96_model(40, m)
@@ -712,7 +716,7 @@ def test_lorenz96_d40_value_and_gradient(hip_lib):
         P = params_from(mdl)
         ll_ref, g_ref, ex = o.ekf_loglik_grad_adjoint(mdl, t, y, full=True, state_order="second")
         ll, g = cd.cdnlgssm_loglik_and_grad_all(P, y, t[..., None])
-        assert _ffi.lib().cdkf_last_kernel().decode().startswith("ekf_adjoint_wg_kernel<double")
+        assert _ffi.lib().cdkf_last_kernel().decode().startswith(sweep + "<double")
         np.testing.assert_allclose(ll, ll_ref, rtol=1e-10)
 
         def close(a, b, name, tol=1e-8):
@@ -729,7 +733,7 @@ def test_lorenz96_d40_value_and_gradient(hip_lib):
         np.testing.assert_allclose(ll2, ll_ref, rtol=1e-10)
         close(np.asarray(gd[0]).reshape(N, -1), g_ref, "forcing (drift block)")
         ll32, g32 = cd.cdnlgssm_loglik_and_grad(P, y.astype(np.float32), t[..., None])
-        assert _ffi.lib().cdkf_last_kernel().decode().startswith("ekf_adjoint_wg_kernel<float")
+        assert _ffi.lib().cdkf_last_kernel().decode().startswith(sweep + "<float")
         close(np.asarray(g32[0]).reshape(N, -1), g_ref, "forcing (fp32)", 2e-3)
 
 
@@ -752,13 +756,17 @@ def test_reverse_sweep_with_a_scattered_selection_of_observed_components(hip_lib
             bias[2] = 0.3
         if variant == "dense":
             H[1, 3] = 0.5
-        mdl = o.Model(base.drift, np.eye(d), 0.4 * np.eye(d) + 0.1 * A @ A.T, H, bias, 0.5 * np.eye(m) + 0.1 * Rm @ Rm.T, base.m0, 0.6 * np.eye(d) + 0.2 * A.T @ A)
+        RR = 0.5 * np.eye(m) + 0.1 * Rm @ Rm.T
+        RR = 0.5 * (RR + RR.T)   # (symmetric to the last bit: the wavefront sweeps' gate compares R with its transpose)
+        mdl = o.Model(base.drift, np.eye(d), 0.4 * np.eye(d) + 0.1 * A @ A.T, H, bias, RR, base.m0, 0.6 * np.eye(d) + 0.2 * A.T @ A)
         N, T = 3, 6
         t = o.irregular_times(rng, N, T, 0.02 * T)
         y = o.simulate(mdl, t, rng)
         ll_ref, g_ref, ex = o.ekf_loglik_grad_adjoint(mdl, t, y, full=True, state_order="first")
         ll, g = cd.cdnlgssm_loglik_and_grad_all(params_from(mdl), y, t[..., None], cd.EKFHyperParams(state_order="first"))
-        assert _ffi.lib().cdkf_last_kernel().decode().startswith("ekf_adjoint_wg_kernel<double")
+        # (round 4: Lorenz-96 through a selection of components takes the wavefront-per-trajectory reverse sweep)
+        want_kernel = "ekf_adjoint_wave_l96_kernel<double" if (drift == "lorenz96" and variant == "selection") else "ekf_adjoint_wg_kernel<double"
+        assert _ffi.lib().cdkf_last_kernel().decode().startswith(want_kernel)
         np.testing.assert_allclose(ll, ll_ref, rtol=1e-10)
         flat = np.concatenate([np.asarray(a_).reshape(N, -1) for a_ in g.dynamics.drift], axis=-1)
         for got, want in ((flat, g_ref), (g.initial.mean.params, ex["m0"]), (g.initial.cov.params, ex["P0"]), (g.dynamics.diffusion_cov.params, ex["Qc"]),
