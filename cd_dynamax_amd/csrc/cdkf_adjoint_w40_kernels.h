@@ -29,6 +29,18 @@
 
 namespace cdkf {
 
+#ifdef CDKF_W40A_PROFILE  // local diagnostic build: cycles per phase (s_memtime), printed by trajectory 0 (scripts/prof_w40a.sh)
+__device__ long long w40a_prof[24];
+#define W40A_TICK(i)                                                               \
+  {                                                                                \
+    const long long w40a_now = clock64();                                          \
+    if (threadIdx.x == 0 && blockIdx.x == 0) w40a_prof[i] += w40a_now - w40a_last; \
+    w40a_last = clock64();                                                         \
+  }
+#else
+#define W40A_TICK(i)
+#endif
+
 template <typename R, int D>
 struct W40A {
   using W = W40<D>;
@@ -41,7 +53,7 @@ struct W40A {
   static constexpr int NACC = 5;               // weighted sums of the stage cotangents, stages 0 .. 4
   static constexpr int upd = 4 * IMG + LPK, prd = SIMG + IMG + NACC * ACC;
   static constexpr int body = ((upd > prd ? upd : prd) + 1) & ~1;
-  static constexpr int NV = 15;
+  static constexpr int NV = 17;
   static constexpr int o_end = body + NV * 64;
   static constexpr int kWaves = 2;
   // per workgroup: (L Qc L^T) and R entries in ownership order, the index tables (two 32-bit words per entry), obs[64]
@@ -58,14 +70,60 @@ template <typename R, int D, typename Acc, typename FA, typename FB>
 CDKF_DEV void w40a_mm(Acc& acc, const int lane, FA&& fa, FB&& fb) {
   constexpr int NB = W40A<R, D>::NB;
   const int lm = lane & 15, lg = lane >> 4;
+  R av[NB], bv[NB];
+#pragma unroll
+  for (int t = 0; t < NB; ++t) {
+    av[t] = fa(16 * t + lm, lg);
+    bv[t] = fb(lg, 16 * t + lm);
+  }
 #pragma unroll 2
   for (int ks = 0; ks < D / 4; ++ks) {
-    const int kk = 4 * ks + lg;
+    const int kn = (ks + 1 < D / 4 ? 4 * (ks + 1) : 0) + lg;  // (the last step re-reads the first operands and drops them)
+    R an[NB], bn[NB];
+#pragma unroll
+    for (int t = 0; t < NB; ++t) {
+      an[t] = fa(16 * t + lm, kn);
+      bn[t] = fb(kn, 16 * t + lm);
+    }
+#pragma unroll
+    for (int mt = 0; mt < NB; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NB; ++nt) acc[mt * NB + nt] = wg_mfma(av[mt], bv[nt], acc[mt * NB + nt]);
+#pragma unroll
+    for (int t = 0; t < NB; ++t) {
+      av[t] = an[t];
+      bv[t] = bn[t];
+    }
+  }
+}
+
+// The same product with the operands' addresses formed once: pa[t] walks row 16 t + (lane & 15) of the A image along k (a row that is
+// not there points at a row of zeros); pb[t] walks column 16 t + (lane & 15) of the B image down the rows (BROW = false; a column that
+// is not there is read at column 0 and dropped by blast_ok) or, for a transposed factor, row 16 t + (lane & 15) along k (BROW = true,
+// zeros as for A).  SA: A is scaled by 1, -1, -1/2, 2 (codes 0 .. 3).  MASKK: rows k of B whose state component is not observed
+// count as zero.  k is fully unrolled: every read is an immediate offset from its pointer.
+template <typename R, int D, bool BROW, bool MASKK, int SA, typename Acc>
+CDKF_DEV void w40a_mmp(Acc& acc, const R* const (&pa)[W40A<R, D>::NB], const R* const (&pb)[W40A<R, D>::NB], const bool blast_ok,
+                       const unsigned long long obsmask, const int lg) {
+  constexpr int NB = W40A<R, D>::NB, LDY = W40A<R, D>::LDY;
+  constexpr R sa = SA == 1 ? R(-1) : (SA == 2 ? R(-0.5) : (SA == 3 ? R(2) : R(1)));
+#pragma unroll
+  for (int ks = 0; ks < D / 4; ++ks) {
     R av[NB], bv[NB];
 #pragma unroll
     for (int t = 0; t < NB; ++t) {
-      av[t] = fa(16 * t + lm, kk);
-      bv[t] = fb(kk, 16 * t + lm);
+      av[t] = pa[t][4 * ks];
+      bv[t] = BROW ? pb[t][4 * ks] : pb[t][4 * ks * LDY];
+    }
+    if constexpr (!BROW && D % 16 != 0) bv[NB - 1] = blast_ok ? bv[NB - 1] : R(0);
+    if constexpr (MASKK) {
+      const bool ok = (obsmask >> (4 * ks + lg)) & 1ull;
+#pragma unroll
+      for (int t = 0; t < NB; ++t) bv[t] = ok ? bv[t] : R(0);
+    }
+    if constexpr (SA != 0) {
+#pragma unroll
+      for (int t = 0; t < NB; ++t) av[t] *= sa;
     }
 #pragma unroll
     for (int mt = 0; mt < NB; ++mt)
@@ -86,7 +144,10 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
   constexpr int EPL = W::EPL, LDP = W::LDP, LDY = W::LDY, IMG = A::IMG, NB = A::NB, NT = A::NT;
   static_assert(A::SH % 2 == 0 && A::o_end % 2 == 0 && IMG % 2 == 0 && A::SIMG % 2 == 0 && A::LPK % 2 == 0, "16-byte aligned regions");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  int lane = threadIdx.x & 63;
+  // The lane index is laundered through an empty asm where a phase begins: the index tables are read-only words, so the compiler would
+  // otherwise hoist all 2 EPL table reads -- and the dozens of addresses derived from them -- out of the time loop and spill them
   R* shQ = reinterpret_cast<R*>(smem_raw);
   R* shR = shQ + 64 * EPL;
   unsigned* tabA = reinterpret_cast<unsigned*>(shR + 64 * EPL);
@@ -104,7 +165,7 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
   R* AccL = PsI + IMG;
   R* vec = Wb + A::body;
   R *v_xs = vec, *v_ca = vec + 64 /* pairs: 128 */, *v_c3 = vec + 192 /* triples: 192 */, *v_lam = vec + 384, *v_mb = vec + 448,
-    *v_v = vec + 512, *v_w = vec + 576, *v_vb = vec + 640, *v_u = vec + 704, *v_m = vec + 768, *v_inv = vec + 832, *v_dt = vec + 896;
+    *v_v = vec + 512, *v_w = vec + 576, *v_vb = vec + 640, *v_u = vec + 704, *v_m = vec + 768, *v_inv = vec + 832, *v_dt = vec + 896, *v_dummy = vec + 960, *v_zero = vec + 1024;
   const long n = (long)blockIdx.x * A::kWaves + wave;
   const int M = a.m;
 
@@ -145,16 +206,27 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
   auto entry = [&](int s) { const unsigned w = tabA[64 * s + lane]; return Ent{(int)(w & 255u), (int)((w >> 8) & 255u)}; };
   struct Off { int y, yt, l; };
   auto offsets = [&](int s) { const unsigned w = tabB[64 * s + lane]; return Off{(int)(w & 2047u), (int)((w >> 11) & 2047u), (int)(w >> 22)}; };
-  const bool isrow = lane < D;
-  const int lp1 = (lane + 1 >= D) ? lane + 1 - D : lane + 1, lp2 = (lane + 2 >= D) ? lane + 2 - D : lane + 2,
-            lm1 = (lane == 0) ? D - 1 : lane - 1, lm2 = (lane <= 1) ? lane + D - 2 : lane - 2;
+  bool isrow, blast_ok;
+  int lp1, lp2, lm1, lm2, rowi, ri, lm, lg;
+  auto fresh = [&]() __attribute__((always_inline)) {
+    asm volatile("" : "+v"(lane));
+    __builtin_assume(lane >= 0 && lane < 64);
+    isrow = lane < D;
+    lp1 = (lane + 1 >= D) ? lane + 1 - D : lane + 1;
+    lp2 = (lane + 2 >= D) ? lane + 2 - D : lane + 2;
+    lm1 = (lane == 0) ? D - 1 : lane - 1;
+    lm2 = (lane <= 1) ? lane + D - 2 : lane - 2;
+    rowi = (lane <= D) ? lane : D;  // row of the (augmented) system this lane factors
+    ri = W::rs(rowi);
+    lm = lane & 15;
+    lg = lane >> 4;
+    blast_ok = 16 * (NB - 1) + lm < D;
+  };
+  fresh();
   const int myobs = isrow ? obs[lane] : -1;
   const unsigned long long obsmask = __ballot(myobs >= 0);
   auto observed = [&](int i) { return (bool)((obsmask >> i) & 1ull); };
   const R forcing = (a.par + a.o_theta)[0];
-  const int rowi = (lane <= D) ? lane : D;
-  const int ri = W::rs(rowi);
-  const int lm = lane & 15, lg = lane >> 4;
   const R* tp = a.t + n * a.t_sn;
   const R* yp = a.y + n * a.y_sn + (myobs >= 0 ? myobs : 0) * a.y_si;
   R* g = grad + n;  // (the forcing: one drift parameter)
@@ -186,24 +258,74 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = 16 * mt + Tile::row(lg, r), col = 16 * nt + lm;
-          if (row < D && col < D) img[row * LDY + col] = acc[mt * NB + nt][r];
+          R* p = (row < D && col < D) ? img + row * LDY + col : v_dummy + lane;  // (no predicated stores: a select of the address)
+          *p = acc[mt * NB + nt][r];
         }
   };
   auto img_at = [&](const R* img, int i, int k) { return i < D ? img[i * LDY + k] : R(0); };  // (k < D by construction)
+  // operand walks of the products (w40a_mmp)
+  v_zero[lane] = R(0);
+  struct Ptr3 { const R* p[NB]; };
+  auto rows_of = [&](const R* img, const bool observed_only) {  // row 16 t + lm along k; rows that are not there: zeros
+    Ptr3 q;
+#pragma unroll
+    for (int t = 0; t < NB; ++t) {
+      const int i = 16 * t + lm;
+      q.p[t] = (i < D && (!observed_only || observed(i))) ? img + i * LDY + lg : v_zero + lg;
+    }
+    return q;
+  };
+  auto cols_of = [&](const R* img) {  // column 16 t + lm down the rows
+    Ptr3 q;
+#pragma unroll
+    for (int t = 0; t < NB; ++t) {
+      const int j = 16 * t + lm;
+      q.p[t] = img + lg * LDY + (j < D ? j : 0);
+    }
+    return q;
+  };
+  // acc's entries added to global memory at addr(row, col) (< 0: not there); the old values are all in flight before the first store
+  auto tiles_accumulate = [&](R* base, const V4 (&acc)[NT], const bool first_, auto&& addr) {
+    int off[NT][4];
+    R old[NT][4];
+#pragma unroll
+    for (int mt = 0; mt < NB; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NB; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * mt + Tile::row(lg, r), col = 16 * nt + lm;
+          off[mt * NB + nt][r] = (row < D && col < D) ? addr(row, col) : -1;
+        }
+    if (!first_) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) old[t][r] = base[off[t][r] >= 0 ? off[t][r] : 0];
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {  // (entries that are not there go to a scratch word of this lane: no predicated stores)
+        R* p = off[t][r] >= 0 ? base + off[t][r] : wsb + lane;
+        *p = first_ ? acc[t][r] : old[t][r] + acc[t][r];
+      }
+  };
 
   // ---- one right-hand side of the moment equations on the stage image (as the forward kernel's) --------------------------------------
   auto rhs = [&](const R (&Ps)[EPL], const R xm, R (&kP)[EPL], R& kM) {
-    int ei[EPL], ej[EPL], offP[EPL];
+    fresh();
+    unsigned wa[EPL];  // the owned entries' (i, j): one batch of table reads per right-hand side
+#pragma unroll
+    for (int s = 0; s < EPL; ++s) wa[s] = tabA[64 * s + lane];
 #pragma unroll
     for (int s = 0; s < EPL; ++s) {
-      const Ent e = entry(s);
-      ei[s] = e.i;
-      ej[s] = e.j;
-      offP[s] = (e.i + 2) * LDP + (e.j + 2);
-      if (W::owned(s, lane)) {
-        S0[offP[s]] = Ps[s];
-        S0[(e.j + 2) * LDP + (e.i + 2)] = Ps[s];
-      }
+      const int ei = (int)(wa[s] & 255u), ej = (int)((wa[s] >> 8) & 255u);
+      const bool own = W::owned(s, lane);
+      R* l1 = own ? S0 + (ei + 2) * LDP + (ej + 2) : v_dummy + lane;
+      R* l2 = own ? S0 + (ej + 2) * LDP + (ei + 2) : v_dummy + lane;
+      *l1 = Ps[s];
+      *l2 = Ps[s];
     }
     if (isrow) v_xs[lane] = xm;
     wave_sync();
@@ -230,14 +352,15 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
 #pragma unroll
       for (int u = 0; u < CH; ++u) {
         const int s = (s0 + u < EPL) ? s0 + u : EPL - 1;
-        const R* c = S0 + offP[s];
+        const Ent e{(int)(wa[s] & 255u), (int)((wa[s] >> 8) & 255u)};
+        const R* c = S0 + (e.i + 2) * LDP + (e.j + 2);
         o6[u][0] = c[-2 * LDP];
         o6[u][1] = c[-LDP];
         o6[u][2] = c[LDP];
         o6[u][3] = c[-2];
         o6[u][4] = c[-1];
         o6[u][5] = c[1];
-        const Pair ci = cab[ei[s]], cj = cab[ej[s]];
+        const Pair ci = cab[e.i], cj = cab[e.j];
         c4[u][0] = ci[0];
         c4[u][1] = ci[1];
         c4[u][2] = cj[0];
@@ -262,29 +385,40 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
     wave_sync();  // the image is rewritten by the next stage
   };
 
+#ifdef CDKF_W40A_PROFILE
+  long long w40a_last = clock64();
+#endif
   for (long k = a.T - 1; k >= 0; --k) {
     const bool first = (k == a.T - 1);
+    fresh();
+    W40A_TICK(0)
     // =================================== (1) the measurement update at k, reversed =====================================================
     // predicted moments (P0 / m0 at k = 0) into I0, the identity into I2, Pbar into I1
     {
       const R* P0p = a.par + a.o_P0;
       const R* src = a.pP + n * a.P_sn + (k > 0 ? k - 1 : 0) * a.P_sk;
-      constexpr int NE = (D * D + 63) / 64, CHK = 8;
-#pragma unroll 1
+      constexpr int NE = (D * D + 63) / 64, CHK = (NE + 1) / 2;
+#pragma unroll
       for (int q0 = 0; q0 < NE; q0 += CHK) {
         R v[CHK];
+        if (k > 0) {
 #pragma unroll
-        for (int u = 0; u < CHK; ++u) {
-          const int e = lane + 64 * (q0 + u), r = e / D, c = e - r * D;
-          v[u] = (e < D * D) ? (k == 0 ? R(0.5) * (P0p[r * D + c] + P0p[c * D + r]) : src[(long)e * a.P_si]) : R(0);
+          for (int u = 0; u < CHK; ++u) {
+            const int e = lane + 64 * (q0 + u);
+            v[u] = src[(long)(e < D * D ? e : 0) * a.P_si];
+          }
+        } else {
+#pragma unroll
+          for (int u = 0; u < CHK; ++u) {
+            const int e = lane + 64 * (q0 + u), ec = e < D * D ? e : 0, r = ec / D, c = ec - r * D;
+            v[u] = R(0.5) * (P0p[r * D + c] + P0p[c * D + r]);
+          }
         }
 #pragma unroll
-        for (int u = 0; u < CHK; ++u) {
-          const int e = lane + 64 * (q0 + u), r = e / D, c = e - r * D;
-          if (e < D * D) {
-            I0[r * LDY + c] = v[u];
-            I2[r * LDY + c] = (r == c) ? R(1) : R(0);
-          }
+        for (int u = 0; u < CHK; ++u) {  // (slots past the matrix rewrite entry (0, 0) with its own value: no predicated stores)
+          const int e = lane + 64 * (q0 + u), ec = e < D * D ? e : 0, r = ec / D, c = ec - r * D;
+          I0[r * LDY + c] = v[u];
+          I2[r * LDY + c] = (r == c) ? R(1) : R(0);
         }
       }
     }
@@ -304,6 +438,7 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
         I1[f.yt] = Pb[s];
       }
     wave_sync();
+    fresh();
     // sym(S) + 1e-9 I, packed lower (state coordinates: the identity on the unobserved components); the augmented row is not used
 #pragma unroll
     for (int s = 0; s < EPL; ++s)
@@ -316,6 +451,7 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
       }
     if (isrow) Lp[W::rs(D) + lane] = R(0);
     wave_sync();
+    W40A_TICK(1)  // loads, images, packed system
     {
       R quad = R(0);
       double logdet = 0.0;
@@ -323,17 +459,19 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
       R* const scr[1] = {v_ca};
       Lin::template cholesky<1>(sys, scr, v_inv, rowi, ri, lane, quad, logdet, bad);
     }
+    W40A_TICK(2)  // factorisation
     // W2 = (sym S + 1e-9 I)^-1: the D columns of the identity, in place in I2
     Lin::solve(I2, Lp, v_inv, (const R*)nullptr, lane, [&] {});
+    W40A_TICK(3)  // W2
     // X = W2 (E P) -> I3
     {
       V4 acc[NT];
       tiles_zero(acc);
-      w40a_mm<R, D>(acc, lane, [&](int i, int kk) { return img_at(I2, i, kk); },
-                    [&](int kk, int j) { return (j < D && observed(kk)) ? I0[kk * LDY + j] : R(0); });
+      w40a_mmp<R, D, false, true, 0>(acc, rows_of(I2, false).p, cols_of(I0).p, blast_ok, obsmask, lg);
       tiles_store(I3, acc);
     }
     wave_sync();
+    W40A_TICK(4)  // X
     // w = S^-1 v = u1 + 1e-9 W2 u1, u1 = W2 v;  vbar = X mbar - w
     R wv = R(0), vb = R(0);
     {
@@ -360,15 +498,15 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
       v_w[lane] = wv;
       v_vb[lane] = vb;
     }
+    W40A_TICK(5)  // w, vbar
     // X Pb and (E P) Pb;  Kb = v mbar^T - 2 S X Pb,  S X = E P - 1e-9 X
     V4 accK[NT], accS[NT];
     {
       V4 accX[NT];
       tiles_zero(accX);
       tiles_zero(accK);
-      w40a_mm<R, D>(accX, lane, [&](int i, int kk) { return img_at(I3, i, kk); }, [&](int kk, int j) { return j < D ? I1[kk * LDY + j] : R(0); });
-      w40a_mm<R, D>(accK, lane, [&](int i, int kk) { return (i < D && observed(i)) ? I0[i * LDY + kk] : R(0); },
-                    [&](int kk, int j) { return j < D ? I1[kk * LDY + j] : R(0); });
+      w40a_mmp<R, D, false, false, 0>(accX, rows_of(I3, false).p, cols_of(I1).p, blast_ok, obsmask, lg);
+      w40a_mmp<R, D, false, false, 0>(accK, rows_of(I0, true).p, cols_of(I1).p, blast_ok, obsmask, lg);
       wave_sync();  // (every read of Pbar's image is done; v_w / v_vb are visible)
       tiles_store(I1, accX);  // X Pb
 #pragma unroll
@@ -382,9 +520,10 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
             accK[t][r] = rfma(R(-2), rfma(R(-1e-9), accX[t][r], accK[t][r]), v_v[row] * v_mb[col]);
           }
     }
+    W40A_TICK(6)  // X Pb, (E P) Pb, Kb
     // Sbar = -(X Pb) X^T + w w^T / 2 - S^-1 / 2 - sym(X Ub^T);  S^-1 = W2 + 1e-9 W2 W2
     tiles_zero(accS);
-    w40a_mm<R, D>(accS, lane, [&](int i, int kk) { return img_at(I2, i, kk); }, [&](int kk, int j) { return j < D ? I2[kk * LDY + j] : R(0); });
+    w40a_mmp<R, D, true, false, 0>(accS, rows_of(I2, false).p, rows_of(I2, false).p, blast_ok, obsmask, lg);  // (W2 is symmetric)
 #pragma unroll
     for (int mt = 0; mt < NB; ++mt)
 #pragma unroll
@@ -397,47 +536,37 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
           accS[t][r] = R(0.5) * (v_w[row] * v_w[col] - rfma(R(1e-9), accS[t][r], w2));
         }
     wave_sync();  // (X Pb is in I1)
-    w40a_mm<R, D>(accS, lane, [&](int i, int kk) { return -img_at(I1, i, kk); }, [&](int kk, int j) { return j < D ? I3[j * LDY + kk] : R(0); });
+    w40a_mmp<R, D, true, false, 1>(accS, rows_of(I1, false).p, rows_of(I3, false).p, blast_ok, obsmask, lg);
     wave_sync();
     tiles_store(I1, accK);  // Kb
     wave_sync();
+    W40A_TICK(7)  // W2 W2, (X Pb) X^T
     // Ub = W2 Kb -> I2 (over the then dead W2)
     {
       V4 accU[NT];
       tiles_zero(accU);
-      w40a_mm<R, D>(accU, lane, [&](int i, int kk) { return img_at(I2, i, kk); }, [&](int kk, int j) { return j < D ? I1[kk * LDY + j] : R(0); });
+      w40a_mmp<R, D, false, false, 0>(accU, rows_of(I2, false).p, cols_of(I1).p, blast_ok, obsmask, lg);
       wave_sync();
       tiles_store(I2, accU);
     }
     wave_sync();
-    w40a_mm<R, D>(accS, lane, [&](int i, int kk) { return R(-0.5) * img_at(I3, i, kk); }, [&](int kk, int j) { return j < D ? I2[j * LDY + kk] : R(0); });
-    w40a_mm<R, D>(accS, lane, [&](int i, int kk) { return R(-0.5) * img_at(I2, i, kk); }, [&](int kk, int j) { return j < D ? I3[j * LDY + kk] : R(0); });
+    W40A_TICK(8)  // Ub
+    w40a_mmp<R, D, true, false, 2>(accS, rows_of(I3, false).p, rows_of(I2, false).p, blast_ok, obsmask, lg);
+    w40a_mmp<R, D, true, false, 2>(accS, rows_of(I2, false).p, rows_of(I3, false).p, blast_ok, obsmask, lg);
     // model block: dR += Sbar (the observed pairs)
-    if (gm) {
-#pragma unroll
-      for (int mt = 0; mt < NB; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NB; ++nt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = 16 * mt + Tile::row(lg, r), col = 16 * nt + lm;
-            if (row < D && col < D) {
-              const int orow = obs[row], ocol = obs[col];
-              if (orow >= 0 && ocol >= 0) {
-                R* p = gR + orow * M + ocol;
-                *p = first ? accS[mt * NB + nt][r] : *p + accS[mt * NB + nt][r];
-              }
-            }
-          }
-    }
+    if (gm)
+      tiles_accumulate(gR, accS, first, [&](int row, int col) {
+        const int orow = obs[row], ocol = obs[col];
+        return (orow >= 0 && ocol >= 0) ? orow * M + ocol : -1;
+      });
     tiles_store(I1, accS);  // Sbar (Kb is dead: Ub was formed behind a synchronisation)
     wave_sync();
+    W40A_TICK(9)  // X Ub^T, Ub X^T, dR
     if (gm) {  // dH += 2 Sbar (E P) - vbar m^T + Ub P; dbias -= vbar
       V4 accH[NT];
       tiles_zero(accH);
-      w40a_mm<R, D>(accH, lane, [&](int i, int kk) { return R(2) * img_at(I1, i, kk); },
-                    [&](int kk, int j) { return (j < D && observed(kk)) ? I0[kk * LDY + j] : R(0); });
-      w40a_mm<R, D>(accH, lane, [&](int i, int kk) { return img_at(I2, i, kk); }, [&](int kk, int j) { return j < D ? I0[kk * LDY + j] : R(0); });
+      w40a_mmp<R, D, false, true, 3>(accH, rows_of(I1, false).p, cols_of(I0).p, blast_ok, obsmask, lg);
+      w40a_mmp<R, D, false, false, 0>(accH, rows_of(I2, false).p, cols_of(I0).p, blast_ok, obsmask, lg);
 #pragma unroll
       for (int mt = 0; mt < NB; ++mt)
 #pragma unroll
@@ -445,17 +574,15 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int row = 16 * mt + Tile::row(lg, r), col = 16 * nt + lm;
-            if (row < D && col < D) {
-              const int orow = obs[row];
-              if (orow >= 0) {
-                R* p = gH + orow * D + col;
-                const R v = rfma(-v_vb[row], v_m[col], accH[mt * NB + nt][r]);
-                *p = first ? v : *p + v;
-              }
-            }
+            accH[mt * NB + nt][r] = rfma(-v_vb[row], v_m[col], accH[mt * NB + nt][r]);
           }
+      tiles_accumulate(gH, accH, first, [&](int row, int col) {
+        const int orow = obs[row];
+        return orow >= 0 ? orow * D + col : -1;
+      });
       if (myobs >= 0) gBias[myobs] = first ? -vb : gBias[myobs] - vb;
     }
+    fresh();
     // Pbar <- Pbar + sym(Ub^T H) + H^T Sbar H;  mbar <- mbar - H^T vbar
 #pragma unroll
     for (int s = 0; s < EPL; ++s)
@@ -468,6 +595,7 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
       }
     mb -= vb;
     wave_sync();
+    W40A_TICK(10)  // dH, Pbar
     if (k == 0) break;
 
     // =================================== (2) predict k-1 -> k: the Runge-Kutta steps of the interval, reversed =========================
@@ -485,14 +613,17 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
     }
     for (long cs = S > 0 ? ((S - 1) / cap) * cap : -1; cs >= 0; cs -= cap) {
       const long ce = (cs + cap < S) ? cs + cap : S;
+      fresh();
       // replay from the filtered moments at k-1 up to the chunk's last step start, keeping the chunk's starts
       R P0[EPL], x0;
 #pragma unroll
       for (int s = 0; s < EPL; ++s) {
         const Ent e = entry(s);
-        P0[s] = W::owned(s, lane) ? a.fP[n * a.P_sn + (k - 1) * a.P_sk + (long)(e.i * D + e.j) * a.P_si] : R(0);
+        P0[s] = a.fP[n * a.P_sn + (k - 1) * a.P_sk + (long)(e.i * D + e.j) * a.P_si];  // (slots past the triangle: entry (0, 0), masked below)
       }
       x0 = isrow ? a.fm[n * a.m_sn + (k - 1) * a.m_sk + lane * a.m_si] : R(0);
+#pragma unroll
+      for (int s = 0; s < EPL; ++s) P0[s] = W::owned(s, lane) ? P0[s] : R(0);
       {
         R tprev = t0, tnx = rmin(t0 + a.dt0, t1);
         for (long s = 0; s < ce; ++s) {
@@ -521,6 +652,7 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
           x0 = sv[64 * EPL + lane];
         }
         const R dt = v_dt[s - cs];
+        W40A_TICK(11)  // replay, step start
         // ---- the step's six stages forward, slopes (times dt) kept ------------------------------------------------------------------
         R kP[6][EPL], km[6];
 #pragma unroll
@@ -540,6 +672,7 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
           for (int u = 0; u < EPL; ++u) kP[i][u] *= dt;
           km[i] *= dt;
         }
+        W40A_TICK(12)  // stages forward
         // ---- ... and backward ----------------------------------------------------------------------------------------------------
         R Pn[EPL], mn = mb, accm[5];
 #pragma unroll
@@ -548,43 +681,58 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
         for (int j = 0; j < 5; ++j) accm[j] = R(0);
 #pragma unroll
         for (int i = 5; i >= 0; --i) {
-          // stage cotangent  Lam = dt (b_i Pbar + sum_{j > i} a_ji Ybar_j)  and the stage's input
-          R Lam[EPL], Ps[EPL], lam, xs = x0;
+          fresh();
+          // stage cotangent  Lam = dt (b_i Pbar + sum_{j > i} a_ji Ybar_j)  and the stage's input, entry by entry into the two images
+          // (neither is kept in registers: the stencil reads Lam back from its image)
+          R lam, xs = x0;
+          unsigned wa[EPL];  // the owned entries' (i, j), kept for the stage (one batch of table reads)
 #pragma unroll
-          for (int u = 0; u < EPL; ++u) {
-            const R acc = (i < 5) ? AccL[(i * EPL + u) * 64 + lane] : R(0);
-            Lam[u] = dt * rfma(T::b[i], Pb[u], acc);
-            gQacc[u] += Lam[u];
-            Ps[u] = P0[u];
+          for (int u = 0; u < EPL; ++u) wa[u] = tabA[64 * u + lane];
+          {
+            constexpr int CP = 5;
+#pragma unroll
+            for (int u0 = 0; u0 < EPL; u0 += CP) {
+              R ac[CP];
+#pragma unroll
+              for (int c = 0; c < CP; ++c) {
+                const int u = (u0 + c < EPL) ? u0 + c : EPL - 1;
+                ac[c] = (i < 5) ? AccL[(i * EPL + u) * 64 + lane] : R(0);
+              }
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int c = 0; c < CP; ++c)
+                if (u0 + c < EPL) {
+                  const int u = u0 + c;
+                  const R Lm = dt * rfma(T::b[i], Pb[u], ac[c]);
+                  gQacc[u] += Lm;
+                  R Psu = P0[u];
+#pragma unroll
+                  for (int j = 0; j < 5; ++j)
+                    if (j < i) Psu = rfma(T::a[i][j], kP[j][u], Psu);
+                  const int ei = (int)(wa[u] & 255u), ej = (int)((wa[u] >> 8) & 255u);
+                  const bool own = W::owned(u, lane);  // (the last slot of the upper lanes: a scratch word instead of a predicated store)
+                  R* l1 = own ? S0 + (ei + 2) * LDP + (ej + 2) : v_dummy + lane;
+                  R* l2 = own ? S0 + (ej + 2) * LDP + (ei + 2) : v_dummy + lane;
+                  R* q1 = own ? PsI + ei * LDY + ej : v_dummy + lane;
+                  R* q2 = own ? PsI + ej * LDY + ei : v_dummy + lane;
+                  *l1 = Lm;
+                  *l2 = Lm;
+                  *q1 = Psu;
+                  *q2 = Psu;
+                }
+              __builtin_amdgcn_sched_barrier(0);
+            }
           }
           lam = dt * rfma(T::b[i], mb, (i < 5) ? accm[i < 5 ? i : 0] : R(0));
           if (isrow) gF += lam;
 #pragma unroll
           for (int j = 0; j < 5; ++j)
-            if (j < i) {
-#pragma unroll
-              for (int u = 0; u < EPL; ++u) Ps[u] = rfma(T::a[i][j], kP[j][u], Ps[u]);
-              xs = rfma(T::a[i][j], km[j], xs);
-            }
-          int offL[EPL], ei[EPL], ej[EPL];
-#pragma unroll
-          for (int u = 0; u < EPL; ++u) {
-            const Ent e = entry(u);
-            const Off f = offsets(u);
-            ei[u] = e.i;
-            ej[u] = e.j;
-            offL[u] = (e.i + 2) * LDP + (e.j + 2);
-            if (W::owned(u, lane)) {
-              S0[offL[u]] = Lam[u];
-              S0[(e.j + 2) * LDP + (e.i + 2)] = Lam[u];
-              PsI[f.y] = Ps[u];
-              PsI[f.yt] = Ps[u];
-            }
-          }
+            if (j < i) xs = rfma(T::a[i][j], km[j], xs);
           if (isrow) {
             v_xs[lane] = xs;
             v_lam[lane] = lam;
           }
+          W40A_TICK(18)  // (stage: cotangent, input, images)
           wave_sync();
           for (int e = lane; e < 3 * D; e += 64) {  // halo of Lam: rows / columns -1 <- D-1, D <- 0, D+1 <- 1
             const int r = (e >= 2 * D) ? 2 : (e >= D ? 1 : 0), c = e - r * D;
@@ -602,44 +750,56 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
             xbar = rfma(v_lam[lm1], xm2, rfma(-v_lam[lp2], xp1, rfma(v_lam[lp1], xp2 - xm1, -lam)));
           }
           wave_sync();
-          // Ybar_P = Lam F + (Lam F)^T of the owned entries
-          R Yb[EPL];
+          W40A_TICK(14)  // (stage: halo, coefficients)
+          fresh();
+          // Ybar_P = Lam F + (Lam F)^T of the owned entries, added to the step's input cotangent and to the earlier stages' sums as formed
           constexpr int CH = 4;
 #pragma unroll
           for (int s0 = 0; s0 < EPL; s0 += CH) {
-            R o6[CH][6], c6[CH][6];
+            R o7[CH][7], c6[CH][6], old[CH][5];
 #pragma unroll
             for (int u = 0; u < CH; ++u) {
               const int s = (s0 + u < EPL) ? s0 + u : EPL - 1;
-              const R* c = S0 + offL[s];
-              o6[u][0] = c[-1];
-              o6[u][1] = c[2];
-              o6[u][2] = c[1];
-              o6[u][3] = c[-LDP];
-              o6[u][4] = c[2 * LDP];
-              o6[u][5] = c[LDP];
+              const Ent e{(int)(wa[s] & 255u), (int)((wa[s] >> 8) & 255u)};
+              const R* c = S0 + (e.i + 2) * LDP + (e.j + 2);
+              o7[u][0] = c[-1];
+              o7[u][1] = c[2];
+              o7[u][2] = c[1];
+              o7[u][3] = c[-LDP];
+              o7[u][4] = c[2 * LDP];
+              o7[u][5] = c[LDP];
+              o7[u][6] = c[0];
 #pragma unroll
               for (int q = 0; q < 3; ++q) {
-                c6[u][q] = v_c3[3 * ej[s] + q];
-                c6[u][3 + q] = v_c3[3 * ei[s] + q];
+                c6[u][q] = v_c3[3 * e.j + q];
+                c6[u][3 + q] = v_c3[3 * e.i + q];
               }
+#pragma unroll
+              for (int j = 0; j < 5; ++j) old[u][j] = (j < i && i < 5) ? AccL[(j * EPL + s) * 64 + lane] : R(0);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < CH; ++u)
               if (s0 + u < EPL) {
                 const int s = s0 + u;
-                R y = R(-2) * Lam[s];
-                y = rfma(c6[u][0], o6[u][0], y);
-                y = rfma(-c6[u][1], o6[u][1], y);
-                y = rfma(c6[u][2], o6[u][2], y);
-                y = rfma(c6[u][3], o6[u][3], y);
-                y = rfma(-c6[u][4], o6[u][4], y);
-                y = rfma(c6[u][5], o6[u][5], y);
-                Yb[s] = W::owned(s, lane) ? y : R(0);
+                R y = R(-2) * o7[u][6];
+                y = rfma(c6[u][0], o7[u][0], y);
+                y = rfma(-c6[u][1], o7[u][1], y);
+                y = rfma(c6[u][2], o7[u][2], y);
+                y = rfma(c6[u][3], o7[u][3], y);
+                y = rfma(-c6[u][4], o7[u][4], y);
+                y = rfma(c6[u][5], o7[u][5], y);
+                y = W::owned(s, lane) ? y : R(0);
+                Pn[s] += y;
+#pragma unroll
+                for (int j = 0; j < 5; ++j)
+                  if (j < i) {
+                    AccL[(j * EPL + s) * 64 + lane] = rfma(T::a[i][j], y, old[u][j]);
+                  }
               }
             __builtin_amdgcn_sched_barrier(0);
           }
+          W40A_TICK(15)  // (stage: stencil)
           // the state's cotangent: sum_ij (2 Lam Ps)_ij dF_ij/dx_k = 2 sum_c { Lam[k+1][c] (Ps[c][k+2] - Ps[c][k-1]) + Lam[k-1][c] Ps[c][k-2]
           //                                                                      - Lam[k+2][c] Ps[c][k+1] }   (both symmetric: rows of the images)
           if (isrow) {
@@ -660,29 +820,24 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
             (void)g3;
             xbar = rfma(R(2), (g0 + g1) - g2, xbar);
           }
-          // weighted sums for the earlier stages; the step's input
+          W40A_TICK(16)  // (stage: dot products)
+          // the mean's part of the sums
 #pragma unroll
           for (int j = 0; j < 5; ++j)
-            if (j < i) {
-#pragma unroll
-              for (int u = 0; u < EPL; ++u) {
-                R* p = AccL + (j * EPL + u) * 64 + lane;
-                *p = (i == 5) ? T::a[i][j] * Yb[u] : rfma(T::a[i][j], Yb[u], *p);
-              }
-              accm[j] = rfma(T::a[i][j], xbar, accm[j]);
-            }
-#pragma unroll
-          for (int u = 0; u < EPL; ++u) Pn[u] += Yb[u];
+            if (j < i) accm[j] = rfma(T::a[i][j], xbar, accm[j]);
           mn += xbar;
           wave_sync();  // the images are rewritten by the next stage
+          W40A_TICK(17)  // (stage: sums)
         }
 #pragma unroll
         for (int u = 0; u < EPL; ++u) Pb[u] = Pn[u];
         mb = mn;
+        W40A_TICK(13)  // stages reversed
       }
     }
   }
 
+  fresh();
   // ---- results --------------------------------------------------------------------------------------------------------------------
   if (gm) {
     if (isrow) gm[lane] = mb;
@@ -706,6 +861,14 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
   }
   if (bad) st |= kStatusNotPd;
   if (st && lane == 0 && a.status) atomicOr(&a.status[n], st);
+#ifdef CDKF_W40A_PROFILE
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    printf("w40a cycles/obs-step (sizeof real %d, d %d):", (int)sizeof(R), D);
+    for (int q2 = 0; q2 < 19; ++q2) printf(" [%d] %lld", q2, w40a_prof[q2] / a.T);
+    printf("\n");
+    for (int q2 = 0; q2 < 24; ++q2) w40a_prof[q2] = 0;
+  }
+#endif
 }
 
 }  // namespace cdkf
