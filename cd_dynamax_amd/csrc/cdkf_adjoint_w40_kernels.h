@@ -162,7 +162,7 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
   R* Lp = static_cast<R*>(__builtin_assume_aligned(I3 + IMG, 16));
   R* S0 = I0;
   R* PsI = S0 + A::SIMG;
-  R* AccL = PsI + IMG;
+  R* AccL = PsI + IMG;  // weighted sums of the later stages' cotangents (stages 0 .. 4), lane-major
   R* vec = Wb + A::body;
   R *v_xs = vec, *v_ca = vec + 64 /* pairs: 128 */, *v_c3 = vec + 192 /* triples: 192 */, *v_lam = vec + 384, *v_mb = vec + 448,
     *v_v = vec + 512, *v_w = vec + 576, *v_vb = vec + 640, *v_u = vec + 704, *v_m = vec + 768, *v_inv = vec + 832, *v_dt = vec + 896, *v_dummy = vec + 960, *v_zero = vec + 1024;
@@ -237,6 +237,7 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
   R* gBias = gm ? gH + (long)M * D : nullptr;
   R* gR = gm ? gBias + M : nullptr;
   R* wsb = ws + n * ws_stride;
+  R* PsG = wsb + (long)cap * A::start_reals();  // the step's stage inputs 1 .. 5 of the owned entries, lane-major (L2-resident: rewritten every step)
 
   R Pb[EPL], gQacc[EPL];  // cotangent of the covariance, d ll / d (L Qc L^T): owned entries
 #pragma unroll
@@ -629,12 +630,10 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
         for (long s = 0; s < ce; ++s) {
           const R dt = tnx - tprev;
           if (s >= cs) {
-            if (s + 1 < ce) {  // (the last start of the chunk stays in registers)
-              R* sv = wsb + (s - cs) * A::start_reals();
+            R* sv = wsb + (s - cs) * A::start_reals();  // (the covariance part is read back by the reverse pass's last stage as well)
 #pragma unroll
-              for (int u = 0; u < EPL; ++u) sv[64 * u + lane] = P0[u];
-              sv[64 * EPL + lane] = x0;
-            }
+            for (int u = 0; u < EPL; ++u) sv[64 * u + lane] = P0[u];
+            sv[64 * EPL + lane] = x0;
             v_dt[s - cs] = dt;  // (the step sizes of the chunk: cap <= 64)
           }
           if (s + 1 < ce) w40_dopri5<R, EPL>(rhs, P0, x0, dt);
@@ -653,24 +652,36 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
         }
         const R dt = v_dt[s - cs];
         W40A_TICK(11)  // replay, step start
-        // ---- the step's six stages forward, slopes (times dt) kept ------------------------------------------------------------------
-        R kP[6][EPL], km[6];
+        // ---- the step's stages forward: what the reverse pass needs of them are the stage INPUTS -- the covariance parts go to lane-owned
+        //      arrays in the trajectory's global scratch (stages 1 .. 5; stage 0's is the step's start), the mean's stay in registers; the slopes die with this block
+        //      (the sixth right-hand side is not evaluated: nothing reads its slope)
+        R xin[6];
+        {
+          R kP[5][EPL], km[5];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-          R Ps[EPL], xs = x0;
+          for (int i = 0; i < 6; ++i) {
+            R Ps[EPL], xs = x0;
 #pragma unroll
-          for (int u = 0; u < EPL; ++u) Ps[u] = P0[u];
+            for (int u = 0; u < EPL; ++u) Ps[u] = P0[u];
 #pragma unroll
-          for (int j = 0; j < 5; ++j)
-            if (j < i) {
+            for (int j = 0; j < 5; ++j)
+              if (j < i) {
 #pragma unroll
-              for (int u = 0; u < EPL; ++u) Ps[u] = rfma(T::a[i][j], kP[j][u], Ps[u]);
-              xs = rfma(T::a[i][j], km[j], xs);
+                for (int u = 0; u < EPL; ++u) Ps[u] = rfma(T::a[i][j], kP[j][u], Ps[u]);
+                xs = rfma(T::a[i][j], km[j], xs);
+              }
+            xin[i] = xs;
+            if (i > 0) {
+#pragma unroll
+              for (int u = 0; u < EPL; ++u) PsG[((i - 1) * EPL + u) * 64 + lane] = Ps[u];
             }
-          rhs(Ps, xs, kP[i], km[i]);
+            if (i < 5) {
+              rhs(Ps, xs, kP[i < 5 ? i : 0], km[i < 5 ? i : 0]);
 #pragma unroll
-          for (int u = 0; u < EPL; ++u) kP[i][u] *= dt;
-          km[i] *= dt;
+              for (int u = 0; u < EPL; ++u) kP[i < 5 ? i : 0][u] *= dt;
+              km[i < 5 ? i : 0] *= dt;
+            }
+          }
         }
         W40A_TICK(12)  // stages forward
         // ---- ... and backward ----------------------------------------------------------------------------------------------------
@@ -685,6 +696,10 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
           // stage cotangent  Lam = dt (b_i Pbar + sum_{j > i} a_ji Ybar_j)  and the stage's input, entry by entry into the two images
           // (neither is kept in registers: the stencil reads Lam back from its image)
           R lam, xs = x0;
+          R pin_[EPL];  // the stage's input: in flight from the scratch while the cotangent is formed
+#pragma unroll
+          for (int u = 0; u < EPL; ++u)
+            pin_[u] = (i > 0) ? PsG[((i > 0 ? i - 1 : 0) * EPL + u) * 64 + lane] : (wsb + (s - cs) * A::start_reals())[64 * u + lane];
           unsigned wa[EPL];  // the owned entries' (i, j), kept for the stage (one batch of table reads)
 #pragma unroll
           for (int u = 0; u < EPL; ++u) wa[u] = tabA[64 * u + lane];
@@ -704,11 +719,7 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
                 if (u0 + c < EPL) {
                   const int u = u0 + c;
                   const R Lm = dt * rfma(T::b[i], Pb[u], ac[c]);
-                  gQacc[u] += Lm;
-                  R Psu = P0[u];
-#pragma unroll
-                  for (int j = 0; j < 5; ++j)
-                    if (j < i) Psu = rfma(T::a[i][j], kP[j][u], Psu);
+                  const R Psu = pin_[u];
                   const int ei = (int)(wa[u] & 255u), ej = (int)((wa[u] >> 8) & 255u);
                   const bool own = W::owned(u, lane);  // (the last slot of the upper lanes: a scratch word instead of a predicated store)
                   R* l1 = own ? S0 + (ei + 2) * LDP + (ej + 2) : v_dummy + lane;
@@ -725,9 +736,7 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
           }
           lam = dt * rfma(T::b[i], mb, (i < 5) ? accm[i < 5 ? i : 0] : R(0));
           if (isrow) gF += lam;
-#pragma unroll
-          for (int j = 0; j < 5; ++j)
-            if (j < i) xs = rfma(T::a[i][j], km[j], xs);
+          xs = xin[i];
           if (isrow) {
             v_xs[lane] = xs;
             v_lam[lane] = lam;
@@ -829,8 +838,16 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
           wave_sync();  // the images are rewritten by the next stage
           W40A_TICK(17)  // (stage: sums)
         }
+        // d ll / d (L Qc L^T) += the sum of the six stage cotangents = dt (Pbar + sum_j Acc_j)  (sum_i b_i = 1; the weighted sums are all
+        // complete and still in their arrays)
 #pragma unroll
-        for (int u = 0; u < EPL; ++u) Pb[u] = Pn[u];
+        for (int u = 0; u < EPL; ++u) {
+          R sacc = Pb[u];
+#pragma unroll
+          for (int j = 0; j < 5; ++j) sacc += AccL[(j * EPL + u) * 64 + lane];
+          gQacc[u] = rfma(dt, sacc, gQacc[u]);
+          Pb[u] = Pn[u];
+        }
         mb = mn;
         W40A_TICK(13)  // stages reversed
       }

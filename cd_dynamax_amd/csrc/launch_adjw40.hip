@@ -5,10 +5,11 @@
 
 namespace cdkf {
 
-// per-trajectory global scratch: `cap` step starts of a replay chunk (owned entries lane-major + the mean)
+// per-trajectory global scratch: `cap` step starts of a replay chunk (owned entries lane-major + the mean), then the stage inputs 1 .. 5
+// of the step being reversed (owned entries lane-major)
 long wave40_adjoint_scratch_reals(int d, int cap) {
   const long np = (long)d * (d + 1) / 2, epl = (np + 63) / 64;
-  return (long)cap * (64 * epl + 64);
+  return (long)cap * (64 * epl + 64) + 5 * 64 * epl;  // (+ the stage inputs of the step in hand)
 }
 
 template <typename R, int D>

@@ -701,11 +701,10 @@ def test_loglik_gradient_with_iterated_updates(hip_lib, kind, d, m, num_iter):
 def test_lorenz96_d40_value_and_gradient(hip_lib, sweep, monkeypatch):
     """BASELINE config 4's model (Lorenz-96, d = m = 40, H = I) can be trained: value and gradient of the EKF log-likelihood w.r.t. the
     forcing and every other parameter -- forward sweep on the wavefront kernel (ekf_filter_wave_l96_kernel), reverse sweep on one
-    wavefront per trajectory too (ekf_adjoint_wave_l96_kernel, round 4) or on the workgroup kernel (CDKF_NO_WAVE40_ADJ=1) -- against the
+    wavefront per trajectory too (ekf_adjoint_wave_l96_kernel, round 4: what batches beyond the CU count take) or on the workgroup kernel -- against the
     oracle's discrete adjoint (value_and_grad of marginal_log_prob, ssm_temissions.py:550-568); then with half of the components
     observed (d = 40, m = 20), the drift block alone, and in fp32."""
-    if sweep == "ekf_adjoint_wg_kernel":
-        monkeypatch.setenv("CDKF_NO_WAVE40_ADJ", "1")
+    monkeypatch.setenv("CDKF_WAVE40_ADJ", "0" if sweep == "ekf_adjoint_wg_kernel" else "1")  # (unset: by the number of trajectories)
     rng = np.random.default_rng(440)
     for m in (40, 20):
         mdl = lorenz96_model(40, m)
@@ -738,10 +737,11 @@ def test_lorenz96_d40_value_and_gradient(hip_lib, sweep, monkeypatch):
 
 
 @pytest.mark.parametrize("drift", ["lorenz96", "linear"])
-def test_reverse_sweep_with_a_scattered_selection_of_observed_components(hip_lib, drift):
+def test_reverse_sweep_with_a_scattered_selection_of_observed_components(hip_lib, drift, monkeypatch):
     """The update's adjoint takes the products with H as copies when the emission picks state components -- any subset, in any order
     (detected in the kernel): Lorenz-96 d = 16 and a linear drift d = 11 observed through rows 5, 2, 11 (or 9), 0, 7 of the identity, dense R
     and P0, every leaf against the oracle; a bias or a doubled row sends the same model down the dense products, with the same answer."""
+    monkeypatch.setenv("CDKF_WAVE40_ADJ", "1")  # (the wavefront reverse sweep even for three trajectories)
     rng = np.random.default_rng(661)
     d = 16 if drift == "lorenz96" else 11
     rows = [5, 2, 11 if d > 11 else 9, 0, 7]
@@ -1049,3 +1049,50 @@ def test_mlp_sweep_on_one_and_on_two_wavefronts_per_trajectory(hip_lib, tmp_path
     env = dict(os.environ, CDKF_ROOT=ROOT, CDKF_W8_SPLIT=split)
     p = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and f"SPLIT_OK {split}" in p.stdout, p.stdout + p.stderr
+
+
+@pytest.mark.parametrize("d,rows", [(12, [3, 0, 7]), (20, list(range(20))), (28, [1, 5, 9, 13, 17, 21, 25, 27, 2, 6]), (36, list(range(0, 36, 2)))])
+def test_wavefront_reverse_sweep_of_lorenz96_at_every_instantiated_width(hip_lib, d, rows, monkeypatch):
+    """ekf_adjoint_wave_l96_kernel (round 4: Lorenz-96 through a selection of components, one wavefront per trajectory) at state
+    dimensions whose 16-wide tile grids differ (one, two, three tiles; last tile of 4, 12, 16 columns), with dense L Qc L^T, R, P0, a
+    scattered selection, an interval of 13 Runge-Kutta steps (two replay chunks of eight starts) and one of zero length: every leaf
+    against the oracle's discrete adjoint, and against the workgroup reverse sweep on the same inputs."""
+    monkeypatch.setenv("CDKF_WAVE40_ADJ", "1")
+    rng = np.random.default_rng(900 + d)
+    m = len(rows)
+    A = rng.standard_normal((d, d)) / np.sqrt(d)
+    Rm = rng.standard_normal((m, m)) / np.sqrt(m)
+    RR = 0.5 * np.eye(m) + 0.1 * Rm @ Rm.T
+    RR = 0.5 * (RR + RR.T)
+    base = lorenz96_model(d, m)
+    mdl = o.Model(base.drift, np.eye(d), 0.4 * np.eye(d) + 0.1 * A @ A.T, np.eye(d)[rows], np.zeros(m), RR, base.m0 + 0.1 * rng.standard_normal(d),
+                  0.6 * np.eye(d) + 0.2 * A.T @ A)
+    N, T = 3, 7
+    t = o.irregular_times(rng, N, T, 0.006 * T)
+    t[:, 3:] += 0.125          # thirteen steps of 0.01
+    t[:, 5] = t[:, 4]          # an interval of zero length
+    t[:, 6] = t[:, 5] + 0.004
+    y = o.simulate(mdl, t, rng)
+    hyp = cd.EKFHyperParams(state_order="first")
+    ll_ref, g_ref, ex = o.ekf_loglik_grad_adjoint(mdl, t, y, full=True, state_order="first")
+    got = {}
+    for which in ("1", "0"):
+        monkeypatch.setenv("CDKF_WAVE40_ADJ", which)
+        ll, g = cd.cdnlgssm_loglik_and_grad_all(params_from(mdl), y, t[..., None], hyp)
+        kern = _ffi.lib().cdkf_last_kernel().decode()
+        assert kern.startswith("ekf_adjoint_wave_l96_kernel<double, %d>" % d if which == "1" else "ekf_adjoint_wg_kernel<double"), kern
+        np.testing.assert_allclose(ll, ll_ref, rtol=1e-10)
+        flat = np.concatenate([np.asarray(a_).reshape(N, -1) for a_ in g.dynamics.drift], axis=-1)
+        leaves = [flat, g.initial.mean.params, g.initial.cov.params, g.dynamics.diffusion_cov.params, g.emissions.emission_function.weights,
+                  g.emissions.emission_function.bias, g.emissions.emission_cov.params]
+        for a_, b_, name in zip(leaves, (g_ref, ex["m0"], ex["P0"], ex["Qc"], ex["H"], ex["bias"], ex["R"]), ("forcing", "m0", "P0", "Qc", "H", "bias", "R")):
+            scale = np.abs(b_).max() + 1e-300
+            assert np.abs(np.asarray(a_) - b_).max() < 1e-8 * scale, (which, name, np.abs(np.asarray(a_) - b_).max() / scale)
+        got[which] = [np.asarray(a_) for a_ in leaves]
+    for a_, b_ in zip(got["1"], got["0"]):
+        assert np.abs(a_ - b_).max() <= 1e-9 * (np.abs(b_).max() + 1e-300)
+    # fp32: the forcing's gradient at single-precision accuracy
+    monkeypatch.setenv("CDKF_WAVE40_ADJ", "1")
+    ll32, g32 = cd.cdnlgssm_loglik_and_grad(params_from(mdl), y.astype(np.float32), t[..., None], hyp)
+    assert _ffi.lib().cdkf_last_kernel().decode().startswith("ekf_adjoint_wave_l96_kernel<float, %d>" % d)
+    assert np.abs(np.asarray(g32[0]).reshape(N, -1) - g_ref).max() < 5e-3 * np.abs(g_ref).max()
