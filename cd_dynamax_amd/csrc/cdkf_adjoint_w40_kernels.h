@@ -25,6 +25,9 @@
 //  * The model block accumulates in global memory (H, R, bias: read-modify-write by the lane that owns the tile entry in every step;
 //    the first step writes), LQL / P0 / m0 / the forcing in registers until the end.
 #pragma once
+#ifndef CDKF_W40_LDS_SYNC
+#error "define CDKF_W40_LDS_SYNC before the first include of cdkf_wave40_kernels.h: this sweep keeps global stores in flight across its LDS synchronisations"
+#endif
 #include "cdkf_wave40_kernels.h"
 
 namespace cdkf {
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
           if (Hm[r * D + lane] != R(0)) r_obs = r;
       }
       obs[lane] = r_obs;
-      wave_sync();
+      wave_sync_lds();
 #pragma unroll
       for (int s = 0; s < EPL; ++s) {
         const int e = lane + 64 * s;
@@ -238,10 +241,18 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
   R* gR = gm ? gBias + M : nullptr;
   R* wsb = ws + n * ws_stride;
   R* PsG = wsb + (long)cap * A::start_reals();  // the step's stage inputs 1 .. 5 of the owned entries, lane-major (L2-resident: rewritten every step)
+  // Parked in the same scratch (lane-major, 64 EPL reals each): Pbar while the update's adjoint runs (its registers are then free for the
+  // products' tiles: held across the update it was spilled for the whole sweep, one reload per use), and d ll / d (L Qc L^T), which is
+  // touched once per Runge-Kutta step
+  R* PbG = PsG + 5L * 64 * EPL;
+  R* gQG = PbG + 64L * EPL;
 
-  R Pb[EPL], gQacc[EPL];  // cotangent of the covariance, d ll / d (L Qc L^T): owned entries
+  R Pb[EPL];  // cotangent of the covariance: owned entries
 #pragma unroll
-  for (int s = 0; s < EPL; ++s) Pb[s] = gQacc[s] = R(0);
+  for (int s = 0; s < EPL; ++s) {
+    Pb[s] = R(0);
+    gQG[64 * s + lane] = R(0);
+  }
   R mb = R(0), gF = R(0);
   int st = 0;
   bool bad = false;
@@ -329,7 +340,7 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
       *l2 = Ps[s];
     }
     if (isrow) v_xs[lane] = xm;
-    wave_sync();
+    wave_sync_lds();
     for (int e = lane; e < 3 * D; e += 64) {  // halo: rows -2, -1 <- D-2, D-1; row D <- 0; the same for the columns
       const int r = (e >= 2 * D) ? 2 : (e >= D ? 1 : 0), c = e - r * D;
       const int src = (r == 2) ? 0 : D - 2 + r, dst = (r == 2) ? D : r - 2;
@@ -345,7 +356,7 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
     } else {
       kM = R(0);
     }
-    wave_sync();
+    wave_sync_lds();
     constexpr int CH = 4;
 #pragma unroll
     for (int s0 = 0; s0 < EPL; s0 += CH) {
@@ -383,7 +394,7 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    wave_sync();  // the image is rewritten by the next stage
+    wave_sync_lds();  // the image is rewritten by the next stage
   };
 
 #ifdef CDKF_W40A_PROFILE
@@ -437,8 +448,9 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
         const Off f = offsets(s);
         I1[f.y] = Pb[s];
         I1[f.yt] = Pb[s];
+        PbG[64 * s + lane] = Pb[s];
       }
-    wave_sync();
+    wave_sync_lds();
     fresh();
     // sym(S) + 1e-9 I, packed lower (state coordinates: the identity on the unobserved components); the augmented row is not used
 #pragma unroll
@@ -451,7 +463,7 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
         Lp[f.l] = (f.y == f.yt) ? sv + R(1e-9) : sv;
       }
     if (isrow) Lp[W::rs(D) + lane] = R(0);
-    wave_sync();
+    wave_sync_lds();
     W40A_TICK(1)  // loads, images, packed system
     {
       R quad = R(0);
@@ -471,7 +483,7 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
       w40a_mmp<R, D, false, true, 0>(acc, rows_of(I2, false).p, cols_of(I0).p, blast_ok, obsmask, lg);
       tiles_store(I3, acc);
     }
-    wave_sync();
+    wave_sync_lds();
     W40A_TICK(4)  // X
     // w = S^-1 v = u1 + 1e-9 W2 u1, u1 = W2 v;  vbar = X mbar - w
     R wv = R(0), vb = R(0);
@@ -487,7 +499,7 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
         }
       }
       v_u[lane] = u1;
-      wave_sync();
+      wave_sync_lds();
       R u2 = R(0);
       if (isrow) {
         const R* w2r = I2 + lane * LDY;
@@ -508,7 +520,7 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
       tiles_zero(accK);
       w40a_mmp<R, D, false, false, 0>(accX, rows_of(I3, false).p, cols_of(I1).p, blast_ok, obsmask, lg);
       w40a_mmp<R, D, false, false, 0>(accK, rows_of(I0, true).p, cols_of(I1).p, blast_ok, obsmask, lg);
-      wave_sync();  // (every read of Pbar's image is done; v_w / v_vb are visible)
+      wave_sync_lds();  // (every read of Pbar's image is done; v_w / v_vb are visible)
       tiles_store(I1, accX);  // X Pb
 #pragma unroll
       for (int mt = 0; mt < NB; ++mt)
@@ -536,21 +548,21 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
           const R w2 = (row < D && col < D) ? I2[row * LDY + col] : R(0);
           accS[t][r] = R(0.5) * (v_w[row] * v_w[col] - rfma(R(1e-9), accS[t][r], w2));
         }
-    wave_sync();  // (X Pb is in I1)
+    wave_sync_lds();  // (X Pb is in I1)
     w40a_mmp<R, D, true, false, 1>(accS, rows_of(I1, false).p, rows_of(I3, false).p, blast_ok, obsmask, lg);
-    wave_sync();
+    wave_sync_lds();
     tiles_store(I1, accK);  // Kb
-    wave_sync();
+    wave_sync_lds();
     W40A_TICK(7)  // W2 W2, (X Pb) X^T
     // Ub = W2 Kb -> I2 (over the then dead W2)
     {
       V4 accU[NT];
       tiles_zero(accU);
       w40a_mmp<R, D, false, false, 0>(accU, rows_of(I2, false).p, cols_of(I1).p, blast_ok, obsmask, lg);
-      wave_sync();
+      wave_sync_lds();
       tiles_store(I2, accU);
     }
-    wave_sync();
+    wave_sync_lds();
     W40A_TICK(8)  // Ub
     w40a_mmp<R, D, true, false, 2>(accS, rows_of(I3, false).p, rows_of(I2, false).p, blast_ok, obsmask, lg);
     w40a_mmp<R, D, true, false, 2>(accS, rows_of(I2, false).p, rows_of(I3, false).p, blast_ok, obsmask, lg);
@@ -561,7 +573,7 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
         return (orow >= 0 && ocol >= 0) ? orow * M + ocol : -1;
       });
     tiles_store(I1, accS);  // Sbar (Kb is dead: Ub was formed behind a synchronisation)
-    wave_sync();
+    wave_sync_lds();
     W40A_TICK(9)  // X Ub^T, Ub X^T, dR
     if (gm) {  // dH += 2 Sbar (E P) - vbar m^T + Ub P; dbias -= vbar
       V4 accH[NT];
@@ -592,10 +604,10 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
         const unsigned wA = tabA[64 * s + lane];
         const bool obs_i = (wA >> 16) & 1u, obs_j = (wA >> 17) & 1u;
         const R uij = obs_j ? I2[f.yt] : R(0), uji = obs_i ? I2[f.y] : R(0);
-        Pb[s] += rfma(R(0.5), uij + uji, (obs_i && obs_j) ? I1[f.y] : R(0));
+        Pb[s] = PbG[64 * s + lane] + rfma(R(0.5), uij + uji, (obs_i && obs_j) ? I1[f.y] : R(0));
       }
     mb -= vb;
-    wave_sync();
+    wave_sync_lds();
     W40A_TICK(10)  // dH, Pbar
     if (k == 0) break;
 
@@ -642,7 +654,7 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
           tnx = (tn > t1 - Tol<R>::v) ? t1 : tn;
         }
       }
-      wave_sync();
+      wave_sync_lds();
       for (long s = ce - 1; s >= cs; --s) {
         if (s + 1 < ce) {
           const R* sv = wsb + (s - cs) * A::start_reals();
@@ -742,7 +754,7 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
             v_lam[lane] = lam;
           }
           W40A_TICK(18)  // (stage: cotangent, input, images)
-          wave_sync();
+          wave_sync_lds();
           for (int e = lane; e < 3 * D; e += 64) {  // halo of Lam: rows / columns -1 <- D-1, D <- 0, D+1 <- 1
             const int r = (e >= 2 * D) ? 2 : (e >= D ? 1 : 0), c = e - r * D;
             const int src = (r == 0) ? D - 1 : r - 1, dst = (r == 0) ? -1 : D + r - 1;
@@ -758,7 +770,7 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
             // F^T lam
             xbar = rfma(v_lam[lm1], xm2, rfma(-v_lam[lp2], xp1, rfma(v_lam[lp1], xp2 - xm1, -lam)));
           }
-          wave_sync();
+          wave_sync_lds();
           W40A_TICK(14)  // (stage: halo, coefficients)
           fresh();
           // Ybar_P = Lam F + (Lam F)^T of the owned entries, added to the step's input cotangent and to the earlier stages' sums as formed
@@ -835,7 +847,7 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
           for (int j = 0; j < 5; ++j)
             if (j < i) accm[j] = rfma(T::a[i][j], xbar, accm[j]);
           mn += xbar;
-          wave_sync();  // the images are rewritten by the next stage
+          wave_sync_lds();  // the images are rewritten by the next stage
           W40A_TICK(17)  // (stage: sums)
         }
         // d ll / d (L Qc L^T) += the sum of the six stage cotangents = dt (Pbar + sum_j Acc_j)  (sum_i b_i = 1; the weighted sums are all
@@ -845,7 +857,7 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
           R sacc = Pb[u];
 #pragma unroll
           for (int j = 0; j < 5; ++j) sacc += AccL[(j * EPL + u) * 64 + lane];
-          gQacc[u] = rfma(dt, sacc, gQacc[u]);
+          gQG[64 * u + lane] = rfma(dt, sacc, gQG[64 * u + lane]);
           Pb[u] = Pn[u];
         }
         mb = mn;
@@ -864,13 +876,14 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
         const Ent e = entry(s);
         gP0[e.i * D + e.j] = Pb[s];
         gP0[e.j * D + e.i] = Pb[s];
-        gQ[e.i * D + e.j] = gQacc[s];
-        gQ[e.j * D + e.i] = gQacc[s];
+        const R gq = gQG[64 * s + lane];
+        gQ[e.i * D + e.j] = gq;
+        gQ[e.j * D + e.i] = gq;
       }
   }
-  wave_sync();
+  wave_sync_lds();
   v_u[lane] = isrow ? gF : R(0);
-  wave_sync();
+  wave_sync_lds();
   if (lane == 0) {
     R sum = R(0);
     for (int c = 0; c < D; ++c) sum += v_u[c];

@@ -1,5 +1,6 @@
 // launch_adjw40.hip -- the wavefront-per-trajectory reverse sweep of the Lorenz-96 model (cdkf_adjoint_w40_kernels.h) in its own
 // translation unit.
+#define CDKF_W40_LDS_SYNC 1  // (the factorisation / substitution helpers synchronise LDS only: see wave_sync_lds)
 #include "cdkf_launch.h"
 #include "cdkf_adjoint_w40_kernels.h"
 
@@ -9,7 +10,7 @@ namespace cdkf {
 // of the step being reversed (owned entries lane-major)
 long wave40_adjoint_scratch_reals(int d, int cap) {
   const long np = (long)d * (d + 1) / 2, epl = (np + 63) / 64;
-  return (long)cap * (64 * epl + 64) + 5 * 64 * epl;  // (+ the stage inputs of the step in hand)
+  return (long)cap * (64 * epl + 64) + 7 * 64 * epl;  // (+ the stage inputs of the step in hand, the parked Pbar, d ll / d (L Qc L^T))
 }
 
 template <typename R, int D>

@@ -425,20 +425,11 @@ static int launch_ekf_grad_adjoint_wg(const cdkf_model* mdl, const cdkf_opts* o,
   const size_t nm = (size_t)N * T * mdl->state_dim, nP = nm * mdl->state_dim;
   int cap = 8;  // step starts kept per replay chunk of an interval (CDKF_ADJ_WG_STARTS)
   if (const char* e = getenv("CDKF_ADJ_WG_STARTS")) cap = atoi(e) > 0 ? atoi(e) : 8;
-  // Lorenz-96 through a selection of its components: both sweeps on one wavefront per trajectory
-  // -- when there are more trajectories than CUs: a lone trajectory per CU finishes sooner on the workgroup kernel (165 us against
-  // 290 us per observation step at d = 40), two per CU sooner here.  CDKF_WAVE40_ADJ=0 / 1 forces the choice (A/B, tests).
+  // Lorenz-96 through a selection of its components: both sweeps on one wavefront per trajectory (126 us per observation step and
+  // trajectory at d = 40 against the workgroup kernel's 165, and two trajectories per CU).  CDKF_WAVE40_ADJ=0 keeps the workgroup
+  // reverse sweep (A/B, tests).
   bool w40adj = wave40_shape(mdl, o) && !ukf;
-  if (w40adj) {
-    const char* e = getenv("CDKF_WAVE40_ADJ");
-    if (e) {
-      w40adj = atoi(e) != 0;
-    } else {
-      int dev = 0, cus = 256;
-      if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-      w40adj = N > cus;
-    }
-  }
+  if (const char* e = getenv("CDKF_WAVE40_ADJ")) w40adj = w40adj && atoi(e) != 0;
   if (w40adj && cap > 64) cap = 64;
   const size_t nscr = (size_t)N * (size_t)(w40adj ? wave40_adjoint_scratch_reals(mdl->state_dim, cap) : adjoint_wg_scratch_reals(mdl->state_dim, cap));
   // an adaptive solve: the forward (workgroup) sweep logs the accepted step sizes of every interval (up to CDKF_ADJ_DT_CAP, default

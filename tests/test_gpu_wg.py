@@ -701,10 +701,10 @@ def test_loglik_gradient_with_iterated_updates(hip_lib, kind, d, m, num_iter):
 def test_lorenz96_d40_value_and_gradient(hip_lib, sweep, monkeypatch):
     """BASELINE config 4's model (Lorenz-96, d = m = 40, H = I) can be trained: value and gradient of the EKF log-likelihood w.r.t. the
     forcing and every other parameter -- forward sweep on the wavefront kernel (ekf_filter_wave_l96_kernel), reverse sweep on one
-    wavefront per trajectory too (ekf_adjoint_wave_l96_kernel, round 4: what batches beyond the CU count take) or on the workgroup kernel -- against the
+    wavefront per trajectory too (ekf_adjoint_wave_l96_kernel, round 4: the default) or on the workgroup kernel -- against the
     oracle's discrete adjoint (value_and_grad of marginal_log_prob, ssm_temissions.py:550-568); then with half of the components
     observed (d = 40, m = 20), the drift block alone, and in fp32."""
-    monkeypatch.setenv("CDKF_WAVE40_ADJ", "0" if sweep == "ekf_adjoint_wg_kernel" else "1")  # (unset: by the number of trajectories)
+    monkeypatch.setenv("CDKF_WAVE40_ADJ", "0" if sweep == "ekf_adjoint_wg_kernel" else "1")
     rng = np.random.default_rng(440)
     for m in (40, 20):
         mdl = lorenz96_model(40, m)
@@ -741,7 +741,6 @@ def test_reverse_sweep_with_a_scattered_selection_of_observed_components(hip_lib
     """The update's adjoint takes the products with H as copies when the emission picks state components -- any subset, in any order
     (detected in the kernel): Lorenz-96 d = 16 and a linear drift d = 11 observed through rows 5, 2, 11 (or 9), 0, 7 of the identity, dense R
     and P0, every leaf against the oracle; a bias or a doubled row sends the same model down the dense products, with the same answer."""
-    monkeypatch.setenv("CDKF_WAVE40_ADJ", "1")  # (the wavefront reverse sweep even for three trajectories)
     rng = np.random.default_rng(661)
     d = 16 if drift == "lorenz96" else 11
     rows = [5, 2, 11 if d > 11 else 9, 0, 7]
