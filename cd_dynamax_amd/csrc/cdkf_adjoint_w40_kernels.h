@@ -25,9 +25,6 @@
 //  * The model block accumulates in global memory (H, R, bias: read-modify-write by the lane that owns the tile entry in every step;
 //    the first step writes), LQL / P0 / m0 / the forcing in registers until the end.
 #pragma once
-#ifndef CDKF_W40_LDS_SYNC
-#error "define CDKF_W40_LDS_SYNC before the first include of cdkf_wave40_kernels.h: this sweep keeps global stores in flight across its LDS synchronisations"
-#endif
 #include "cdkf_wave40_kernels.h"
 
 namespace cdkf {
@@ -184,7 +181,7 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
           if (Hm[r * D + lane] != R(0)) r_obs = r;
       }
       obs[lane] = r_obs;
-      wave_sync_lds();
+      wave_sync();
 #pragma unroll
       for (int s = 0; s < EPL; ++s) {
         const int e = lane + 64 * s;
@@ -340,7 +337,7 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
       *l2 = Ps[s];
     }
     if (isrow) v_xs[lane] = xm;
-    wave_sync_lds();
+    wave_sync();
     for (int e = lane; e < 3 * D; e += 64) {  // halo: rows -2, -1 <- D-2, D-1; row D <- 0; the same for the columns
       const int r = (e >= 2 * D) ? 2 : (e >= D ? 1 : 0), c = e - r * D;
       const int src = (r == 2) ? 0 : D - 2 + r, dst = (r == 2) ? D : r - 2;
@@ -356,7 +353,7 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
     } else {
       kM = R(0);
     }
-    wave_sync_lds();
+    wave_sync();
     constexpr int CH = 4;
 #pragma unroll
     for (int s0 = 0; s0 < EPL; s0 += CH) {
@@ -394,7 +391,7 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    wave_sync_lds();  // the image is rewritten by the next stage
+    wave_sync();  // the image is rewritten by the next stage
   };
 
 #ifdef CDKF_W40A_PROFILE
@@ -450,7 +447,7 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
         I1[f.yt] = Pb[s];
         PbG[64 * s + lane] = Pb[s];
       }
-    wave_sync_lds();
+    wave_sync();
     fresh();
     // sym(S) + 1e-9 I, packed lower (state coordinates: the identity on the unobserved components); the augmented row is not used
 #pragma unroll
@@ -463,7 +460,7 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
         Lp[f.l] = (f.y == f.yt) ? sv + R(1e-9) : sv;
       }
     if (isrow) Lp[W::rs(D) + lane] = R(0);
-    wave_sync_lds();
+    wave_sync();
     W40A_TICK(1)  // loads, images, packed system
     {
       R quad = R(0);
@@ -483,7 +480,7 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
       w40a_mmp<R, D, false, true, 0>(acc, rows_of(I2, false).p, cols_of(I0).p, blast_ok, obsmask, lg);
       tiles_store(I3, acc);
     }
-    wave_sync_lds();
+    wave_sync();
     W40A_TICK(4)  // X
     // w = S^-1 v = u1 + 1e-9 W2 u1, u1 = W2 v;  vbar = X mbar - w
     R wv = R(0), vb = R(0);
@@ -499,7 +496,7 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
         }
       }
       v_u[lane] = u1;
-      wave_sync_lds();
+      wave_sync();
       R u2 = R(0);
       if (isrow) {
         const R* w2r = I2 + lane * LDY;
@@ -520,7 +517,7 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
       tiles_zero(accK);
       w40a_mmp<R, D, false, false, 0>(accX, rows_of(I3, false).p, cols_of(I1).p, blast_ok, obsmask, lg);
       w40a_mmp<R, D, false, false, 0>(accK, rows_of(I0, true).p, cols_of(I1).p, blast_ok, obsmask, lg);
-      wave_sync_lds();  // (every read of Pbar's image is done; v_w / v_vb are visible)
+      wave_sync();  // (every read of Pbar's image is done; v_w / v_vb are visible)
       tiles_store(I1, accX);  // X Pb
 #pragma unroll
       for (int mt = 0; mt < NB; ++mt)
@@ -548,21 +545,21 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
           const R w2 = (row < D && col < D) ? I2[row * LDY + col] : R(0);
           accS[t][r] = R(0.5) * (v_w[row] * v_w[col] - rfma(R(1e-9), accS[t][r], w2));
         }
-    wave_sync_lds();  // (X Pb is in I1)
+    wave_sync();  // (X Pb is in I1)
     w40a_mmp<R, D, true, false, 1>(accS, rows_of(I1, false).p, rows_of(I3, false).p, blast_ok, obsmask, lg);
-    wave_sync_lds();
+    wave_sync();
     tiles_store(I1, accK);  // Kb
-    wave_sync_lds();
+    wave_sync();
     W40A_TICK(7)  // W2 W2, (X Pb) X^T
     // Ub = W2 Kb -> I2 (over the then dead W2)
     {
       V4 accU[NT];
       tiles_zero(accU);
       w40a_mmp<R, D, false, false, 0>(accU, rows_of(I2, false).p, cols_of(I1).p, blast_ok, obsmask, lg);
-      wave_sync_lds();
+      wave_sync();
       tiles_store(I2, accU);
     }
-    wave_sync_lds();
+    wave_sync();
     W40A_TICK(8)  // Ub
     w40a_mmp<R, D, true, false, 2>(accS, rows_of(I3, false).p, rows_of(I2, false).p, blast_ok, obsmask, lg);
     w40a_mmp<R, D, true, false, 2>(accS, rows_of(I2, false).p, rows_of(I3, false).p, blast_ok, obsmask, lg);
@@ -573,7 +570,7 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
         return (orow >= 0 && ocol >= 0) ? orow * M + ocol : -1;
       });
     tiles_store(I1, accS);  // Sbar (Kb is dead: Ub was formed behind a synchronisation)
-    wave_sync_lds();
+    wave_sync();
     W40A_TICK(9)  // X Ub^T, Ub X^T, dR
     if (gm) {  // dH += 2 Sbar (E P) - vbar m^T + Ub P; dbias -= vbar
       V4 accH[NT];
@@ -607,7 +604,7 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
         Pb[s] = PbG[64 * s + lane] + rfma(R(0.5), uij + uji, (obs_i && obs_j) ? I1[f.y] : R(0));
       }
     mb -= vb;
-    wave_sync_lds();
+    wave_sync();
     W40A_TICK(10)  // dH, Pbar
     if (k == 0) break;
 
@@ -654,7 +651,7 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
           tnx = (tn > t1 - Tol<R>::v) ? t1 : tn;
         }
       }
-      wave_sync_lds();
+      wave_sync();
       for (long s = ce - 1; s >= cs; --s) {
         if (s + 1 < ce) {
           const R* sv = wsb + (s - cs) * A::start_reals();
@@ -754,7 +751,7 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
             v_lam[lane] = lam;
           }
           W40A_TICK(18)  // (stage: cotangent, input, images)
-          wave_sync_lds();
+          wave_sync();
           for (int e = lane; e < 3 * D; e += 64) {  // halo of Lam: rows / columns -1 <- D-1, D <- 0, D+1 <- 1
             const int r = (e >= 2 * D) ? 2 : (e >= D ? 1 : 0), c = e - r * D;
             const int src = (r == 0) ? D - 1 : r - 1, dst = (r == 0) ? -1 : D + r - 1;
@@ -770,7 +767,7 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
             // F^T lam
             xbar = rfma(v_lam[lm1], xm2, rfma(-v_lam[lp2], xp1, rfma(v_lam[lp1], xp2 - xm1, -lam)));
           }
-          wave_sync_lds();
+          wave_sync();
           W40A_TICK(14)  // (stage: halo, coefficients)
           fresh();
           // Ybar_P = Lam F + (Lam F)^T of the owned entries, added to the step's input cotangent and to the earlier stages' sums as formed
@@ -847,7 +844,7 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
           for (int j = 0; j < 5; ++j)
             if (j < i) accm[j] = rfma(T::a[i][j], xbar, accm[j]);
           mn += xbar;
-          wave_sync_lds();  // the images are rewritten by the next stage
+          wave_sync();  // the images are rewritten by the next stage
           W40A_TICK(17)  // (stage: sums)
         }
         // d ll / d (L Qc L^T) += the sum of the six stage cotangents = dt (Pbar + sum_j Acc_j)  (sum_i b_i = 1; the weighted sums are all
@@ -881,9 +878,9 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
         gQ[e.j * D + e.i] = gq;
       }
   }
-  wave_sync_lds();
+  wave_sync();
   v_u[lane] = isrow ? gF : R(0);
-  wave_sync_lds();
+  wave_sync();
   if (lane == 0) {
     R sum = R(0);
     for (int c = 0; c < D; ++c) sum += v_u[c];

@@ -118,12 +118,6 @@ __device__ long long w40_prof[16];
 #define W40_TICK_PASS
 #endif
 
-// (W40Lin works on LDS only: a translation unit whose kernels keep global stores in flight across it defines CDKF_W40_LDS_SYNC)
-#ifdef CDKF_W40_LDS_SYNC
-#define W40_SYNC wave_sync_lds
-#else
-#define W40_SYNC wave_sync
-#endif
 template <typename R, int D>
 struct W40Lin {
   using W = W40<D>;
@@ -263,7 +257,7 @@ struct W40Lin {
       const int c0 = 16 * P;
       if (P == 1) chol_gemm<NS, 1>(L, lane);
       if (P == 2) chol_gemm<NS, 2>(L, lane);
-      if (P) W40_SYNC();
+      if (P) wave_sync();
       W40_TICK(1)
       R pinv = R(1);
       if (D - c0 >= 16)
@@ -272,7 +266,7 @@ struct W40Lin {
         chol_panel<NS, (D % 16 ? D % 16 : 16)>(L, col, inv, c0, rowi, ri, lane, quad, pinv, bad);
       W40_TICK(2)
       logdet += log((double)pinv);
-      W40_SYNC();
+      wave_sync();
       W40_TICK(4)
     }
   }
@@ -367,13 +361,13 @@ struct W40Lin {
     for (int b = 0; b < NB; ++b) {  // forward
       if (b == 1) solve_gemm<true, 1>(img, L, lane);
       if (b == 2) solve_gemm<true, 2>(img, L, lane);
-      if (b) W40_SYNC();
+      if (b) wave_sync();
       W40_TICK(5)
       if (b < NB - 1)
         sub_block<true, 16>(mine, L, inv, dotw, 16 * b, isrow, dot);
       else
         sub_block<true, WL>(mine, L, inv, dotw, 16 * b, isrow, dot);
-      W40_SYNC();
+      wave_sync();
       W40_TICK(6)
     }
     between();
@@ -381,13 +375,13 @@ struct W40Lin {
     for (int b = NB - 1; b >= 0; --b) {  // backward
       if (b == 0 && NB > 1) solve_gemm<false, 0>(img, L, lane);
       if (b == 1 && NB > 2) solve_gemm<false, 1>(img, L, lane);
-      if (b < NB - 1) W40_SYNC();
+      if (b < NB - 1) wave_sync();
       W40_TICK(8)
       if (b < NB - 1)
         sub_block<false, 16>(mine, L, inv, dotw, 16 * b, isrow, dot);
       else
         sub_block<false, WL>(mine, L, inv, dotw, 16 * b, isrow, dot);
-      W40_SYNC();
+      wave_sync();
       W40_TICK(9)
     }
     return dot;
@@ -492,7 +486,7 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave_l96_kernel(const WgArg
           if (Hm[r * D + lane] != R(0)) r_obs = r;
       }
       obs[lane] = r_obs;
-      W40_SYNC();
+      wave_sync();
     }
 #pragma unroll
     for (int s = 0; s < EPL; ++s) {
@@ -563,7 +557,7 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave_l96_kernel(const WgArg
       }
     }
     if (isrow) xs[lane] = xm;
-    W40_SYNC();
+    wave_sync();
     // halo of the image: rows -2, -1 <- D-2, D-1; row D <- 0; the same for the columns (corners are never read)
     for (int e = lane; e < 3 * D; e += 64) {
       const int r = (e >= 2 * D) ? 2 : (e >= D ? 1 : 0), c = e - r * D;
@@ -580,7 +574,7 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave_l96_kernel(const WgArg
     } else {
       kM = R(0);
     }
-    W40_SYNC();
+    wave_sync();
     // operands of four entries at a time go into registers before any of their arithmetic (forty LDS reads in flight: a lone
     // wavefront has no other wave to cover the ~100-cycle round trip, and the compiler otherwise waits after every read)
     constexpr int CH = 4;
@@ -619,7 +613,7 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave_l96_kernel(const WgArg
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    W40_SYNC();  // the image is rewritten by the next stage
+    wave_sync();  // the image is rewritten by the next stage
   };
 
   // stream a full d x d matrix / d-vector of this step out of LDS images (row-major image with leading dimension ld)
@@ -675,7 +669,7 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave_l96_kernel(const WgArg
       vv[lane] = v;
     }
     for (int e = lane; e < (48 - D) * LDY; e += 64) buf[D * LDY + e] = R(0);  // rows d .. 47 of the image: zero operands of the tiles
-    W40_SYNC();
+    wave_sync();
     // both factorisations in lockstep (W40Lin::cholesky): system 0 = S with the innovation as its augmented row (TFP's factor: the
     // log-likelihood's log-determinant and quadratic form), system 1 = S + 1e-9 I (psd_solve's factor: the gain)
     R quad = R(0);
@@ -717,7 +711,7 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave_l96_kernel(const WgArg
     if (!(skip & 2))
       dotv = Lin::solve(buf, L2, inv2, vv, lane, [&] {
         if (!(skip & 4)) rank_update(R(1));
-        W40_SYNC();
+        wave_sync();
       } W40_TICK_PASS);
     // m+ = m + X^T v
     if (isrow) {
@@ -725,7 +719,7 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave_l96_kernel(const WgArg
       if (mj != mj) st |= kStatusNan;
     }
     if (!(skip & 4)) rank_update(R(-1e-9));
-    W40_SYNC();
+    wave_sync();
     // tiles -> image (row-major, leading dimension LDY) -> owners
     {
       int q = 0;
@@ -741,11 +735,11 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave_l96_kernel(const WgArg
           ++q;
         }
     }
-    W40_SYNC();
+    wave_sync();
 #pragma unroll
     for (int s = 0; s < EPL; ++s)
       if (W::owned(s, lane)) Pe[s] -= buf[oY[s]];
-    W40_SYNC();
+    wave_sync();
     // filtered moments out: full symmetric image first
 #pragma unroll
     for (int s = 0; s < EPL; ++s)
@@ -754,9 +748,9 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave_l96_kernel(const WgArg
         buf[oYT[s]] = Pe[s];
       }
     if (a.fm && isrow) a.fm[n * a.m_sn + k * a.m_sk + lane * a.m_si] = mj;
-    W40_SYNC();
+    wave_sync();
     store_cov(a.fP, k, buf, LDY, 0);
-    W40_SYNC();
+    wave_sync();
 
     W40_TICK(10)
     // =================================== predict ==================================================================================
@@ -789,9 +783,9 @@ __global__ __launch_bounds__(256, 1) void ekf_filter_wave_l96_kernel(const WgArg
           buf[f.y] = Pe[s];
           buf[f.yt] = Pe[s];
         }
-      W40_SYNC();
+      wave_sync();
       store_cov(a.pP, k, buf, LDY, 0);
-      W40_SYNC();
+      wave_sync();
     }
     tcur = tnext_obs;
   }
@@ -930,9 +924,9 @@ __global__ __launch_bounds__(256, 1) void ekf_smoother_wave_l96_kernel(const WgA
       }
     }
     if (isrow) a.sm[mo + (a.T - 1) * a.m_sk] = ms;
-    W40_SYNC();
+    wave_sync();
     store_cov(a.T - 1);
-    W40_SYNC();
+    wave_sync();
   }
 
   R t1 = tp[(a.T - 1) * a.t_sk];
@@ -955,7 +949,7 @@ __global__ __launch_bounds__(256, 1) void ekf_smoother_wave_l96_kernel(const WgA
       }
     }
     if (isrow) xs[lane] = mf;
-    W40_SYNC();
+    wave_sync();
     // S = sym(P_f) + 1e-9 I in packed lower storage (row D: zeros -- W40Lin factors D + 1 rows); f(m_f) and the Jacobian's row
 #pragma unroll
     for (int s = 0; s < EPL; ++s)
@@ -972,7 +966,7 @@ __global__ __launch_bounds__(256, 1) void ekf_smoother_wave_l96_kernel(const WgA
       fb = xp1 - xm2;
       fmf = rfma(fb, fa, forcing - mf);
     }
-    W40_SYNC();
+    wave_sync();
     // right-hand sides L Qc L^T (row c of the image = column c)
 #pragma unroll
     for (int s = 0; s < EPL; ++s)
@@ -981,7 +975,7 @@ __global__ __launch_bounds__(256, 1) void ekf_smoother_wave_l96_kernel(const WgA
         Gm[oY[s]] = q;
         Gm[oYT[s]] = q;
       }
-    W40_SYNC();
+    wave_sync();
     {
       R* const sys[1] = {Bm};
       R* const scr[1] = {col};
@@ -1000,7 +994,7 @@ __global__ __launch_bounds__(256, 1) void ekf_smoother_wave_l96_kernel(const WgA
       g[lane] -= R(1);
       g[lp1] += fa;
     }
-    W40_SYNC();
+    wave_sync();
 
     auto rhs = [&](const R (&Pst)[EPL], const R xm, R (&kP)[EPL], R& kM) {
 #pragma unroll
@@ -1010,7 +1004,7 @@ __global__ __launch_bounds__(256, 1) void ekf_smoother_wave_l96_kernel(const WgA
           Bm[oYT[s]] = Pst[s];
         }
       if (isrow) Bm[D * LDY + lane] = xm - mf;
-      W40_SYNC();
+      wave_sync();
       V4 acc[9];
 #pragma unroll
       for (int q = 0; q < 9; ++q) acc[q] = V4{0, 0, 0, 0};
@@ -1029,7 +1023,7 @@ __global__ __launch_bounds__(256, 1) void ekf_smoother_wave_l96_kernel(const WgA
 #pragma unroll
           for (int nt = 0; nt < 3; ++nt) acc[3 * mt + nt] = wg_mfma(og[mt], op[nt], acc[3 * mt + nt]);
       }
-      W40_SYNC();
+      wave_sync();
 #pragma unroll
       for (int mt = 0; mt < 3; ++mt)
 #pragma unroll
@@ -1039,12 +1033,12 @@ __global__ __launch_bounds__(256, 1) void ekf_smoother_wave_l96_kernel(const WgA
             const int row = 16 * mt + Tile::row(lg, r), colx = 16 * nt + lm;
             if (row < D && colx <= D) Bm[row * LDY + colx] = acc[3 * mt + nt][r];
           }
-      W40_SYNC();
+      wave_sync();
 #pragma unroll
       for (int s = 0; s < EPL; ++s)
         kP[s] = W::owned(s, lane) ? shQ[64 * s + lane] - (Bm[oY[s]] + Bm[oYT[s]]) : R(0);
       kM = isrow ? -(fmf + Bm[lane * LDY + D]) : R(0);
-      W40_SYNC();
+      wave_sync();
     };
     {
       const R tend = t1 - t0;
@@ -1073,9 +1067,9 @@ __global__ __launch_bounds__(256, 1) void ekf_smoother_wave_l96_kernel(const WgA
       a.sm[mo + k * a.m_sk] = ms;
       if (ms != ms) st |= kStatusNan;
     }
-    W40_SYNC();
+    wave_sync();
     if (!(skip & 16)) store_cov(k);
-    W40_SYNC();
+    wave_sync();
     t1 = t0;
   }
   if (bad) st |= kStatusNotPd;

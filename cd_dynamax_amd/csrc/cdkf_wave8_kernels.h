@@ -53,14 +53,6 @@ CDKF_DEV void wave_sync() {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
-// ... for LDS traffic only: the fences name the local address space, so the wait is s_waitcnt lgkmcnt(0) alone -- a wavefront with
-// global stores in flight (outputs, scratch, read-modify-writes of its own lanes' words) does not sit out their round trip at every
-// synchronisation of its LDS images (wave_sync's release fence waits for vmcnt(0) as well)
-CDKF_DEV void wave_sync_lds() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
 
 // ---- sums over the 8 x 8 lane grid (lane = 8 i + j) without LDS: the result lands in every lane that took part -------------------------
 // over j (lane bits 0 .. 2): quad permutations, then the half-row mirror; over i (bits 3 .. 5): the half-row rotation, then gfx950's

@@ -1,6 +1,5 @@
 // launch_adjw40.hip -- the wavefront-per-trajectory reverse sweep of the Lorenz-96 model (cdkf_adjoint_w40_kernels.h) in its own
 // translation unit.
-#define CDKF_W40_LDS_SYNC 1  // (the factorisation / substitution helpers synchronise LDS only: see wave_sync_lds)
 #include "cdkf_launch.h"
 #include "cdkf_adjoint_w40_kernels.h"
 

@@ -1,6 +1,5 @@
 // launch_w40.hip -- Lorenz-96 at state dimension 40 (BASELINE config 4): the wavefront-per-trajectory sweeps of
 // cdkf_wave40_kernels.h, in their own translation unit (they build in seconds; launch_wg.hip's reverse sweep takes minutes).
-#define CDKF_W40_LDS_SYNC 1  // (the sweeps synchronise their LDS images only; their global stores stay in flight: see wave_sync_lds)
 #include "cdkf_launch.h"
 #include "cdkf_wave40_kernels.h"
 
