@@ -828,15 +828,25 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
             const R* p2 = PsI + lm1 * LDY;
             const R* p3 = PsI + lm2 * LDY;
             const R* p4 = PsI + lp1 * LDY;
-            R g0 = R(0), g1 = R(0), g2 = R(0), g3 = R(0);
-#pragma unroll 4
-            for (int c = 0; c < D; ++c) {
-              g0 = rfma(l1[c], p1[c] - p2[c], g0);
-              g1 = rfma(l2[c], p3[c], g1);
-              g2 = rfma(l3[c], p4[c], g2);
+            // (the stage covariance's rows start on 16-byte boundaries -- LDY is even: two columns per read; the cotangent image's
+            //  leading dimension is odd)
+            typedef R Pair __attribute__((ext_vector_type(2)));
+            const Pair* q1 = reinterpret_cast<const Pair*>(__builtin_assume_aligned(p1, 16));
+            const Pair* q2 = reinterpret_cast<const Pair*>(__builtin_assume_aligned(p2, 16));
+            const Pair* q3 = reinterpret_cast<const Pair*>(__builtin_assume_aligned(p3, 16));
+            const Pair* q4 = reinterpret_cast<const Pair*>(__builtin_assume_aligned(p4, 16));
+            R g0 = R(0), g1 = R(0), g2 = R(0), h0 = R(0), h1 = R(0), h2 = R(0);
+#pragma unroll 2
+            for (int c = 0; c < D / 2; ++c) {
+              const Pair a1 = q1[c], a2 = q2[c], a3 = q3[c], a4 = q4[c];
+              g0 = rfma(l1[2 * c], a1[0] - a2[0], g0);
+              h0 = rfma(l1[2 * c + 1], a1[1] - a2[1], h0);
+              g1 = rfma(l2[2 * c], a3[0], g1);
+              h1 = rfma(l2[2 * c + 1], a3[1], h1);
+              g2 = rfma(l3[2 * c], a4[0], g2);
+              h2 = rfma(l3[2 * c + 1], a4[1], h2);
             }
-            (void)g3;
-            xbar = rfma(R(2), (g0 + g1) - g2, xbar);
+            xbar = rfma(R(2), ((g0 + h0) + (g1 + h1)) - (g2 + h2), xbar);
           }
           W40A_TICK(16)  // (stage: dot products)
           // the mean's part of the sums
