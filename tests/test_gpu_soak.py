@@ -182,6 +182,42 @@ def test_soak_reverse_sweep_beyond_eight_dimensions(hip_lib):
     assert worst < 2e-8
 
 
+def test_soak_wavefront_reverse_sweep_of_lorenz96(hip_lib):
+    """Fourteen random problems for ekf_adjoint_wave_l96_kernel (round 4): every instantiated state dimension 12 .. 40, a random
+    selection of 1 .. d observed components in random order, dense symmetric L Qc L^T / R / P0, a random forcing, 1 .. 5 trajectories,
+    1 .. 7 observations, intervals from zero length to thirty Runge-Kutta steps (up to four replay chunks of eight starts), both state
+    orders -- every leaf against the oracle's discrete adjoint."""
+    rng = np.random.default_rng(777)
+    worst = 0.0
+    for case in range(14):
+        d = int(rng.choice([12, 16, 20, 24, 28, 32, 36, 40]))
+        m = d if case % 4 == 0 else int(rng.integers(1, d + 1))
+        A, B, Cc = rng.standard_normal((d, d)), rng.standard_normal((m, m)), rng.standard_normal((d, d))
+        RR = B @ B.T / m + 0.3 * np.eye(m)
+        mdl = o.Model(o.Lorenz96Drift(8.0 + rng.standard_normal()), np.eye(d) + 0.1 * rng.standard_normal((d, d)), A @ A.T / d + 0.3 * np.eye(d),
+                      np.eye(d)[rng.permutation(d)[:m]], np.zeros(m), 0.5 * (RR + RR.T), 8.0 + rng.standard_normal(d), Cc @ Cc.T / d + 0.5 * np.eye(d))
+        N, T = int(rng.integers(1, 6)), int(rng.integers(1, 8))
+        t = o.irregular_times(rng, N, T, 0.02 * T)
+        if T > 3:
+            t[:, 3:] += rng.uniform(0.05, 0.3)   # one long interval: 5 .. 30 steps
+            t[0, 2] = t[0, 1]                    # and a repeated observation time
+        y = o.simulate(mdl, t, rng)
+        order = "second" if case % 2 else "first"
+        ll_ref, g_ref, ex = o.ekf_loglik_grad_adjoint(mdl, t, y, full=True, state_order=order)
+        ll, g = cd.cdnlgssm_loglik_and_grad_all(params_from(mdl), y, t[..., None], cd.EKFHyperParams(state_order=order))
+        assert _ffi.lib().cdkf_last_kernel().decode().startswith("ekf_adjoint_wave_l96_kernel<double, %d>" % d), case
+        np.testing.assert_allclose(ll, ll_ref, rtol=1e-9, err_msg=str(case))
+        flat = np.concatenate([np.asarray(a_).reshape(N, -1) for a_ in g.dynamics.drift], axis=-1)
+        pairs = [(flat, g_ref), (g.initial.mean.params, ex["m0"]), (g.initial.cov.params, ex["P0"]), (g.dynamics.diffusion_coefficient.params, ex["L"]),
+                 (g.dynamics.diffusion_cov.params, ex["Qc"]), (g.emissions.emission_function.weights, ex["H"]),
+                 (g.emissions.emission_function.bias, ex["bias"]), (g.emissions.emission_cov.params, ex["R"])]
+        for a_, b_ in pairs:
+            err = np.abs(np.asarray(a_) - b_).max() / (np.abs(b_).max() + 1e-300)
+            worst = max(worst, err)
+            assert err < 2e-8, (case, d, m, order, err)
+    assert worst < 2e-8
+
+
 @pytest.mark.parametrize("d,m,dtype", [(43, 43, np.float64), (50, 12, np.float32), (62, 62, np.float32), (9, 1, np.float64)])
 def test_reverse_sweep_at_the_edges_of_its_lds_plan(hip_lib, d, m, dtype):
     """ekf_adjoint_wg_kernel at the largest shapes its nine-matrix LDS plan admits (q = 43 in fp64, 62 in fp32; beyond d = 42 a thread owns
