@@ -71,6 +71,10 @@ struct WgArgs {
   const R* cj;
   R* gcj;
   R* gy;
+  // R is diagonal with entries >= 1e-2: the wavefront Lorenz-96 filter then takes the log-likelihood's determinant and quadratic form from
+  // psd_solve's factor of S + 1e-9 I (first-order corrections in 1e-9, the next order below 1e-14 of a step's term) instead of a second
+  // factorisation (cdkf_wave40_kernels.h, ONE = true)
+  int r_diag;
 };
 constexpr int kCkStep = 6 * 72;  // reals per checkpointed step
 // fields of the MLP stage checkpoint (each 64 reals, lane-major): first order kMlpCkFirst of them, 'second' kMlpCkSecond

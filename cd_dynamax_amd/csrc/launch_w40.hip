@@ -58,16 +58,24 @@ static int launch_wave40_d(const WgArgs<R>& a, hipStream_t stream, bool backward
     CDKF_HIP_CHECK(hipGetLastError());
     return CDKF_OK;
   }
-  if (once_per_device([] { return wg_raise_lds_cap(ekf_filter_wave_l96_kernel<R, D>); })) return CDKF_EHIP;
   const size_t lds = sizeof(R) * (size_t)wave40_lds_reals<D>() + 64;
   const unsigned blocks = (unsigned)((a.N + W40<D>::kWaves - 1) / W40<D>::kWaves);
-  note_kernel("ekf_filter_wave_l96_kernel<%s, %d>", real_name<R>(), D);
   WgArgs<R> b = a;
   b.forecast = 0;
 #ifdef CDKF_W40_PROFILE  // scripts/w40_prof_build.sh: mask of phases to skip (the shipped library has no such switch)
   if (const char* ab = getenv("CDKF_W40_ABLATE")) b.forecast = atoi(ab);
 #endif
-  hipLaunchKernelGGL((ekf_filter_wave_l96_kernel<R, D>), dim3(blocks), dim3(64 * W40<D>::kWaves), lds, stream, b);
+  // a diagonal R: one factorisation per update (the log-likelihood's terms by first-order corrections from the gain's factor: kernel
+  // header); CDKF_W40_TWO_FACTORS=1 keeps the two systems in lockstep (A/B, tests)
+  if (a.r_diag && !getenv("CDKF_W40_TWO_FACTORS")) {
+    if (once_per_device([] { return wg_raise_lds_cap(ekf_filter_wave_l96_kernel<R, D, true>); })) return CDKF_EHIP;
+    note_kernel("ekf_filter_wave_l96_kernel<%s, %d, true>", real_name<R>(), D);
+    hipLaunchKernelGGL((ekf_filter_wave_l96_kernel<R, D, true>), dim3(blocks), dim3(64 * W40<D>::kWaves), lds, stream, b);
+  } else {
+    if (once_per_device([] { return wg_raise_lds_cap(ekf_filter_wave_l96_kernel<R, D, false>); })) return CDKF_EHIP;
+    note_kernel("ekf_filter_wave_l96_kernel<%s, %d>", real_name<R>(), D);
+    hipLaunchKernelGGL((ekf_filter_wave_l96_kernel<R, D, false>), dim3(blocks), dim3(64 * W40<D>::kWaves), lds, stream, b);
+  }
   CDKF_HIP_CHECK(hipGetLastError());
   return CDKF_OK;
 }

@@ -117,6 +117,10 @@ static int wg_prepare(WgArgs<R>& a, R** dev_block, ParamSlot** slot_out, const c
   a.o_m0 = push(mdl->m0, d);
   a.o_P0 = push(mdl->P0, (long)d * d);
   a.o_w2pad = -1;
+  a.r_diag = 1;
+  for (int r = 0; r < m; ++r)
+    for (int c = 0; c < m; ++c)
+      if (r == c ? !(mdl->R[r * m + c] >= 1e-2) : mdl->R[r * m + c] != 0.0) a.r_diag = 0;
   if (mdl->drift_kind == CDKF_DRIFT_MLP_TANH && mdl->hidden1 <= 64 && mdl->hidden2 <= 64 && d <= 8) {
     const int h1 = mdl->hidden1, h2 = mdl->hidden2;
     const double* W2 = mdl->theta + (long)h1 * d + h1;

@@ -234,7 +234,7 @@ def test_lorenz96_wavefront_kernels_other_state_dimensions(hip_lib, d, monkeypat
         assert relerr(getattr(post, k), ref[k]) < 1e-9, k
     assert relerr(post.marginal_loglik, ref["marginal_loglik"]) < 1e-10
     flt = cd.cdnlgssm_filter(P, y, t[..., None])
-    assert _ffi.lib().cdkf_last_kernel().decode().startswith("ekf_filter_wave_l96_kernel<double, %d>" % d)
+    assert _ffi.lib().cdkf_last_kernel().decode().startswith("ekf_filter_wave_l96_kernel<double, %d" % d)
     _check(flt, o.ekf_filter(mdl, t, y), 1e-9)
     flt32 = cd.cdnlgssm_filter(P, y.astype(np.float32), t[..., None])
     assert relerr(flt32.filtered_means, ref["filtered_means"]) < 5e-4
@@ -295,10 +295,10 @@ def test_lorenz96_wavefront_kernels_partial_observation(hip_lib, d, sel, monkeyp
         assert relerr(getattr(post, k), ref[k]) < 1e-9, k
     assert relerr(post.marginal_loglik, ref["marginal_loglik"]) < 1e-10
     flt = cd.cdnlgssm_filter(P, y, t[..., None])
-    assert _ffi.lib().cdkf_last_kernel().decode().startswith("ekf_filter_wave_l96_kernel<double, %d>" % d)
+    assert _ffi.lib().cdkf_last_kernel().decode().startswith("ekf_filter_wave_l96_kernel<double, %d" % d)
     _check(flt, o.ekf_filter(mdl, t, y), 1e-9)
     flt32 = cd.cdnlgssm_filter(P, y.astype(np.float32), t[..., None])
-    assert _ffi.lib().cdkf_last_kernel().decode().startswith("ekf_filter_wave_l96_kernel<float, %d>" % d)
+    assert _ffi.lib().cdkf_last_kernel().decode().startswith("ekf_filter_wave_l96_kernel<float, %d" % d)
     assert relerr(flt32.filtered_means, ref["filtered_means"]) < 5e-4
     monkeypatch.setenv("CDKF_NO_WAVE40", "1")
     wg = cd.cdnlgssm_filter(P, y, t[..., None])
@@ -1095,3 +1095,46 @@ def test_wavefront_reverse_sweep_of_lorenz96_at_every_instantiated_width(hip_lib
     ll32, g32 = cd.cdnlgssm_loglik_and_grad(params_from(mdl), y.astype(np.float32), t[..., None], hyp)
     assert _ffi.lib().cdkf_last_kernel().decode().startswith("ekf_adjoint_wave_l96_kernel<float, %d>" % d)
     assert np.abs(np.asarray(g32[0]).reshape(N, -1) - g_ref).max() < 5e-3 * np.abs(g_ref).max()
+
+
+def test_lorenz96_filter_with_one_factorisation_for_a_diagonal_R(hip_lib, monkeypatch):
+    """Round 4: with a diagonal R (entries >= 1e-2) the wavefront Lorenz-96 filter factors S + 1e-9 I only and takes the log-likelihood's
+    log det S and v^T S^-1 v by first-order corrections in 1e-9 (ekf_filter_wave_l96_kernel<R, D, true>): the same log-likelihood as
+    the two factorisations in lockstep to 1e-12, the same moments bitwise (the gain never used the other factor), the oracle's numbers --
+    full and partial observation; a dense or a tiny R keeps the two systems."""
+    rng = np.random.default_rng(31)
+    d = 40
+    for rows, rdiag in ((list(range(d)), None), ([3, 17, 30, 8, 39, 21], np.array([0.5, 2.0, 0.02, 1.0, 0.3, 4.0]))):
+        m = len(rows)
+        base = lorenz96_model(d, m)
+        Rm = np.eye(m) if rdiag is None else np.diag(rdiag)
+        mdl = o.Model(base.drift, base.L, base.Qc, np.eye(d)[rows], np.zeros(m), Rm, base.m0, base.P0)
+        N, T = 3, 12
+        t = o.irregular_times(rng, N, T, 0.01 * T)
+        y = o.simulate(mdl, t, rng)
+        P = params_from(mdl)
+        ref = o.ekf_filter(mdl, t, y)
+        out = {}
+        for two in (False, True):
+            if two:
+                monkeypatch.setenv("CDKF_W40_TWO_FACTORS", "1")
+            else:
+                monkeypatch.delenv("CDKF_W40_TWO_FACTORS", raising=False)
+            post = cd.cdnlgssm_filter(P, y, t[..., None], cd.EKFHyperParams())
+            kern = _ffi.lib().cdkf_last_kernel().decode()
+            assert kern == ("ekf_filter_wave_l96_kernel<double, 40>" if two else "ekf_filter_wave_l96_kernel<double, 40, true>"), kern
+            out[two] = post
+        assert relerr(out[False].marginal_loglik, out[True].marginal_loglik) < 1e-12
+        assert relerr(out[False].marginal_loglik, ref["marginal_loglik"]) < 1e-11
+        for k in ("filtered_means", "filtered_covariances", "predicted_means", "predicted_covariances"):
+            assert np.array_equal(np.asarray(getattr(out[False], k)), np.asarray(getattr(out[True], k))), k
+            assert relerr(getattr(out[False], k), ref[k]) < 1e-9, k
+    monkeypatch.delenv("CDKF_W40_TWO_FACTORS", raising=False)
+    for Rm in (np.diag(np.r_[1e-3, np.ones(d - 1)]), np.eye(d) + 0.01 * (np.eye(d, k=1) + np.eye(d, k=-1))):   # a tiny entry; off-diagonal entries
+        base = lorenz96_model(d, d)
+        mdl = o.Model(base.drift, base.L, base.Qc, np.eye(d), np.zeros(d), Rm, base.m0, base.P0)
+        t = o.irregular_times(rng, 2, 4, 0.04)
+        y = o.simulate(mdl, t, rng)
+        post = cd.cdnlgssm_filter(params_from(mdl), y, t[..., None], cd.EKFHyperParams())
+        assert _ffi.lib().cdkf_last_kernel().decode() == "ekf_filter_wave_l96_kernel<double, 40>"
+        assert relerr(post.marginal_loglik, o.ekf_filter(mdl, t, y)["marginal_loglik"]) < 1e-10
