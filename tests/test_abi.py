@@ -149,3 +149,23 @@ def test_integration_md_structs_have_the_library_layout():
         assert [f[0] for f in doc._fields_] == [f[0] for f in own._fields_][:len(doc._fields_)]
         for name, *_ in doc._fields_:
             assert getattr(doc, name).offset == getattr(own, name).offset, name
+
+
+def test_toolchain_workarounds_cannot_be_switched_off_from_the_command_line():
+    """launch_wg8.hip (the fp64 eight-entries-per-thread workgroup kernels) is built at -O1: at -O3 the instantiation returns NaN on
+    ROCm 7.2 / gfx950 (scripts/bisect_wg8.sh: the result flips at si-shrink-instructions; profiles/r04_d_wg8_bisect.txt).  The
+    Makefile's target-specific `override` must keep -O1 LAST on that object's command line whatever CXXFLAGS a caller passes, and
+    leave every other object at the caller's level."""
+    import os
+    import subprocess
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cd_dynamax_amd", "csrc")
+    flags = "-O3 -std=c++17 -fPIC --offload-arch=gfx950"
+    out = subprocess.run(["make", "-n", "-B", "-C", csrc, "../../build/csrc/launch_wg8.o", "../../build/csrc/launch_w8.o", f"CXXFLAGS={flags}"],
+                         capture_output=True, text=True, check=True).stdout
+    cmds = [ln for ln in out.splitlines() if ln.startswith("hipcc") and " -c " in ln]
+    wg8 = [c for c in cmds if "launch_wg8.hip" in c]
+    w8 = [c for c in cmds if "launch_w8.hip" in c]
+    assert len(wg8) == 1 and len(w8) == 1, out
+    levels = [tok for tok in wg8[0].split() if tok in ("-O0", "-O1", "-O2", "-O3", "-Os", "-Ofast")]
+    assert levels and levels[-1] == "-O1", wg8[0]
+    assert "-O1" not in w8[0].split() and "-O3" in w8[0].split(), w8[0]
