@@ -567,16 +567,21 @@ def other_configs(lib, timer, stream, t_h, y_h, only=None, comm=None, world=1, r
             l96, grids(rng, n, T), 8.0 + rng.standard_normal((n, T, d)), "f64", _ffi.LAYOUT_TN, ["ekf_filter", "ekf_smoother"], "mfma",
             {"ekf_filter": flops_per_step(d, d, 6 * d), "ekf_smoother": flops_per_step(d, d, 6 * d, smoother=True)})
     if want("config4_value_and_grad_lorenz96_d40_fp64_256x100"):
-        # the same model's SGD objective (round 3: the workgroup-per-trajectory reverse sweep, ekf_adjoint_wg_kernel -- the shape-generic
-        # gradient path, one trajectory per CU): value + every gradient on a slice of one trajectory per compute unit
+        # the same model's SGD objective (round 3: the workgroup-per-trajectory reverse sweep, ekf_adjoint_wg_kernel; round 4: one
+        # wavefront per trajectory, ekf_adjoint_wave_l96_kernel): value + every gradient on a slice of one trajectory per compute unit
         ng, Tg = 256, 100
         out["config4_value_and_grad_lorenz96_d40_fp64_256x100"] = case(
             l96, grids(rng, ng, Tg), 8.0 + rng.standard_normal((ng, Tg, d)), "f64", _ffi.LAYOUT_TN, [], "mfma", {}, outputs=False, grad=True,
             c_drift=6 * d)
     if want("config4_value_and_grad_lorenz96_d40_fp64_2048x500"):
-        # ... and on config 4's whole per-GPU slice (eight rounds of 256 workgroups; the forward sweep's four moment arrays: 26 GB of workspace)
+        # ... and on config 4's whole per-GPU slice (two trajectories per CU at a time; the forward sweep's four moment arrays: 26 GB of workspace)
         out["config4_value_and_grad_lorenz96_d40_fp64_2048x500"] = case(
             l96, grids(rng, n, T), 8.0 + rng.standard_normal((n, T, d)), "f64", _ffi.LAYOUT_TN, [], "mfma", {}, outputs=False, grad=True,
+            c_drift=6 * d)
+    if want("config4_value_and_grad_lorenz96_d40_fp32_2048x500"):
+        # ... in float32, the reference's own precision (JAX's default): four trajectories per CU
+        out["config4_value_and_grad_lorenz96_d40_fp32_2048x500"] = case(
+            l96, grids(rng, n, T), 8.0 + rng.standard_normal((n, T, d)), "f32", _ffi.LAYOUT_TN, [], "mfma", {}, outputs=False, grad=True,
             c_drift=6 * d)
     rng = np.random.default_rng(2)
     d, m, h = 8, 4, 64

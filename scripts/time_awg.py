@@ -1,4 +1,4 @@
-"""Times the workgroup reverse sweep on the Lorenz-96 d = m = 40 slice (value + every gradient): python3 scripts/time_awg.py [N] [T] [reps]"""
+"""Times the reverse sweep on the Lorenz-96 d = m = 40 slice (value + every gradient): python3 scripts/time_awg.py [N] [T] [reps] [f64|f32]"""
 import ctypes as C, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT]
@@ -10,6 +10,8 @@ from cd_dynamax_amd._ffi import DeviceArray
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 500
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+suf = sys.argv[4] if len(sys.argv) > 4 else "f64"
+dt = np.float64 if suf == "f64" else np.float32
 d = 40
 eye = np.eye
 l96 = cd.ParamsCDNLGSSM(
@@ -22,14 +24,14 @@ y = 8.0 + rng.standard_normal((N, T, d))
 lib = _ffi.lib()
 blk = _model_block(l96)
 opts = _ffi.default_opts(); opts.layout = _ffi.LAYOUT_TCN
-t_d = DeviceArray.from_numpy(np.ascontiguousarray(t.T)); y_d = DeviceArray.from_numpy(np.ascontiguousarray(y.transpose(1, 2, 0)))
-ll = DeviceArray((N,), np.float64); st = DeviceArray.from_numpy(np.zeros(N, np.int32))
-g = DeviceArray((N, 1), np.float64); gm = DeviceArray((N, _ffi.model_grad_size(d, d)), np.float64)
+t_d = DeviceArray.from_numpy(np.ascontiguousarray(t.T, dt)); y_d = DeviceArray.from_numpy(np.ascontiguousarray(y.transpose(1, 2, 0), dt))
+ll = DeviceArray((N,), dt); st = DeviceArray.from_numpy(np.zeros(N, np.int32))
+g = DeviceArray((N, 1), dt); gm = DeviceArray((N, _ffi.model_grad_size(d, d)), dt)
 def run():
-    _ffi.check(lib.cdkf_ekf_loglik_grad_all_f64_dev(C.byref(blk.c), C.byref(opts), N, T, t_d.ptr, y_d.ptr, ll.ptr, g.ptr, gm.ptr, st.ptr, None))
+    _ffi.check(getattr(lib, f"cdkf_ekf_loglik_grad_all_{suf}_dev")(C.byref(blk.c), C.byref(opts), N, T, t_d.ptr, y_d.ptr, ll.ptr, g.ptr, gm.ptr, st.ptr, None))
 run(); _ffi.check(lib.cdkf_synchronize(None))
 t0 = time.perf_counter()
 for _ in range(reps): run()
 _ffi.check(lib.cdkf_synchronize(None))
 ms = (time.perf_counter() - t0) / reps * 1e3
-print(f"value + every gradient, Lorenz-96 d = m = 40 fp64, {N} x {T}: {ms:.1f} ms  ({lib.cdkf_last_kernel().decode()})  sum g = {float(g.numpy().sum()):.12g}  sum gm = {float(gm.numpy().sum()):.12g}")
+print(f"value + every gradient, Lorenz-96 d = m = 40 {suf}, {N} x {T}: {ms:.1f} ms  ({lib.cdkf_last_kernel().decode()})  sum g = {float(g.numpy().sum()):.12g}  sum gm = {float(gm.numpy().sum()):.12g}")
