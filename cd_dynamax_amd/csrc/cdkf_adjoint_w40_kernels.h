@@ -41,7 +41,11 @@ __device__ long long w40a_prof[24];
 #define W40A_TICK(i)
 #endif
 
-template <typename R, int D>
+// NW: wavefronts per trajectory.  1: a wavefront owns a trajectory, two trajectories per workgroup (they share the index tables and
+// the entry constants in LDS).  2: a workgroup of two wavefronts owns ONE trajectory -- each wavefront takes every other owned slot of
+// the packed triangle and every other 16 x 16 tile of the products; the factorisation, the substitution sweep and the vectors stay on
+// the first wavefront -- and two workgroups share a CU (the entry constants move to registers to make the LDS fit twice).
+template <typename R, int D, int NW = 1>
 struct W40A {
   using W = W40<D>;
   static constexpr int EPL = W::EPL, LDY = W::LDY, LDP = W::LDP;
@@ -55,65 +59,48 @@ struct W40A {
   static constexpr int body = ((upd > prd ? upd : prd) + 1) & ~1;
   static constexpr int NV = 17;
   static constexpr int o_end = body + NV * 64;
-  static constexpr int kWaves = 2;
-  // per workgroup: (L Qc L^T) and R entries in ownership order, the index tables (two 32-bit words per entry), obs[64]
+  static constexpr int kWaves = 2;                 // wavefronts per workgroup
+  static constexpr int kTraj = NW == 1 ? 2 : 1;    // trajectories per workgroup
+  // per workgroup: (NW = 1) the (L Qc L^T) and R entries in ownership order; the index tables (two 32-bit words per entry), obs[64]
   static constexpr int TABW = 2 * 64 * EPL + 64;  // 32-bit words
-  static constexpr int SH = (2 * 64 * EPL + (TABW * 4 + (int)sizeof(R) - 1) / (int)sizeof(R) + 1) & ~1;
-  static constexpr long lds_reals = (long)SH + (long)kWaves * o_end;
+  static constexpr int SHC = NW == 1 ? 2 * 64 * EPL : 0;
+  static constexpr int SH = (SHC + (TABW * 4 + (int)sizeof(R) - 1) / (int)sizeof(R) + 1) & ~1;
+  static constexpr long lds_reals = (long)SH + (long)kTraj * o_end;
   // global scratch per trajectory: `cap` step starts (owned entries lane-major + the mean)
   __host__ __device__ static constexpr long start_reals() { return 64L * EPL + 64; }
 };
 
-// acc[mt * NB + nt] += sum_k fa(16 mt + (lane & 15), k) fb(k, 16 nt + (lane & 15)) over k < D (D a multiple of four); the operand
-// functions return zero outside the matrix
-template <typename R, int D, typename Acc, typename FA, typename FB>
-CDKF_DEV void w40a_mm(Acc& acc, const int lane, FA&& fa, FB&& fb) {
-  constexpr int NB = W40A<R, D>::NB;
-  const int lm = lane & 15, lg = lane >> 4;
-  R av[NB], bv[NB];
-#pragma unroll
-  for (int t = 0; t < NB; ++t) {
-    av[t] = fa(16 * t + lm, lg);
-    bv[t] = fb(lg, 16 * t + lm);
-  }
-#pragma unroll 2
-  for (int ks = 0; ks < D / 4; ++ks) {
-    const int kn = (ks + 1 < D / 4 ? 4 * (ks + 1) : 0) + lg;  // (the last step re-reads the first operands and drops them)
-    R an[NB], bn[NB];
-#pragma unroll
-    for (int t = 0; t < NB; ++t) {
-      an[t] = fa(16 * t + lm, kn);
-      bn[t] = fb(kn, 16 * t + lm);
-    }
-#pragma unroll
-    for (int mt = 0; mt < NB; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < NB; ++nt) acc[mt * NB + nt] = wg_mfma(av[mt], bv[nt], acc[mt * NB + nt]);
-#pragma unroll
-    for (int t = 0; t < NB; ++t) {
-      av[t] = an[t];
-      bv[t] = bn[t];
-    }
-  }
-}
+// which owned slots / product tiles wavefront H of NW takes
+template <int NW, int H>
+__host__ __device__ constexpr bool w40a_mine(int q) { return NW == 1 || (q & 1) == H; }
 
-// The same product with the operands' addresses formed once: pa[t] walks row 16 t + (lane & 15) of the A image along k (a row that is
+// acc[mt * NB + nt] += sum_k A(16 mt + (lane & 15), k) B(k, 16 nt + (lane & 15)) over k < D (a multiple of four), the operands'
+// addresses formed once: pa[t] walks row 16 t + (lane & 15) of the A image along k (a row that is
 // not there points at a row of zeros); pb[t] walks column 16 t + (lane & 15) of the B image down the rows (BROW = false; a column that
 // is not there is read at column 0 and dropped by blast_ok) or, for a transposed factor, row 16 t + (lane & 15) along k (BROW = true,
 // zeros as for A).  SA: A is scaled by 1, -1, -1/2, 2 (codes 0 .. 3).  MASKK: rows k of B whose state component is not observed
 // count as zero.  k is fully unrolled: every read is an immediate offset from its pointer.
-template <typename R, int D, bool BROW, bool MASKK, int SA, typename Acc>
+template <typename R, int D, bool BROW, bool MASKK, int SA, int NW, int H, typename Acc>
 CDKF_DEV void w40a_mmp(Acc& acc, const R* const (&pa)[W40A<R, D>::NB], const R* const (&pb)[W40A<R, D>::NB], const bool blast_ok,
                        const unsigned long long obsmask, const int lg) {
   constexpr int NB = W40A<R, D>::NB, LDY = W40A<R, D>::LDY;
+  // (tiles of the other wavefront: neither their products nor -- where a whole tile row / column is the other's -- their operands)
+  bool need_a[NB], need_b[NB];
+#pragma unroll
+  for (int t = 0; t < NB; ++t) need_a[t] = need_b[t] = false;
+#pragma unroll
+  for (int mt = 0; mt < NB; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NB; ++nt)
+      if (w40a_mine<NW, H>(mt * NB + nt)) need_a[mt] = need_b[nt] = true;
   constexpr R sa = SA == 1 ? R(-1) : (SA == 2 ? R(-0.5) : (SA == 3 ? R(2) : R(1)));
 #pragma unroll
   for (int ks = 0; ks < D / 4; ++ks) {
     R av[NB], bv[NB];
 #pragma unroll
     for (int t = 0; t < NB; ++t) {
-      av[t] = pa[t][4 * ks];
-      bv[t] = BROW ? pb[t][4 * ks] : pb[t][4 * ks * LDY];
+      av[t] = need_a[t] ? pa[t][4 * ks] : R(0);
+      bv[t] = need_b[t] ? (BROW ? pb[t][4 * ks] : pb[t][4 * ks * LDY]) : R(0);
     }
     if constexpr (!BROW && D % 16 != 0) bv[NB - 1] = blast_ok ? bv[NB - 1] : R(0);
     if constexpr (MASKK) {
@@ -128,32 +115,41 @@ CDKF_DEV void w40a_mmp(Acc& acc, const R* const (&pa)[W40A<R, D>::NB], const R* 
 #pragma unroll
     for (int mt = 0; mt < NB; ++mt)
 #pragma unroll
-      for (int nt = 0; nt < NB; ++nt) acc[mt * NB + nt] = wg_mfma(av[mt], bv[nt], acc[mt * NB + nt]);
+      for (int nt = 0; nt < NB; ++nt)
+        if (w40a_mine<NW, H>(mt * NB + nt)) acc[mt * NB + nt] = wg_mfma(av[mt], bv[nt], acc[mt * NB + nt]);
   }
 }
 
-template <typename R, int D>
-__global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<R> a, R* __restrict__ grad, R* __restrict__ grad_model,
-                                                                    R* __restrict__ ws, const long ws_stride, const int cap) {
+template <typename R, int D, int NW, int H>
+CDKF_DEV void w40a_sweep(const WgArgs<R>& a, R* __restrict__ grad, R* __restrict__ grad_model, R* __restrict__ ws, const long ws_stride,
+                         const int cap, unsigned char* smem_raw) {
   using W = W40<D>;
-  using A = W40A<R, D>;
+  using A = W40A<R, D, NW>;
+  constexpr bool LEAD = NW == 1 || H == 0;  // the wavefront that factors, substitutes and owns the vectors (lanes = components)
+  auto mine = [](int q) constexpr { return w40a_mine<NW, H>(q); };
+  // synchronisation of everything that shares the trajectory's LDS: the wavefront itself, or the workgroup's two
+  auto sync = [&]() __attribute__((always_inline)) {
+    if constexpr (NW == 1)
+      wave_sync();
+    else
+      __syncthreads();
+  };
   using Tile = W40Tile<R>;
   using Lin = W40Lin<R, D>;
   using V4 = typename Tile::V4;
   using T = Dp5T<R>;
   constexpr int EPL = W::EPL, LDP = W::LDP, LDY = W::LDY, IMG = A::IMG, NB = A::NB, NT = A::NT;
   static_assert(A::SH % 2 == 0 && A::o_end % 2 == 0 && IMG % 2 == 0 && A::SIMG % 2 == 0 && A::LPK % 2 == 0, "16-byte aligned regions");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int wave = threadIdx.x >> 6;
   int lane = threadIdx.x & 63;
   // The lane index is laundered through an empty asm where a phase begins: the index tables are read-only words, so the compiler would
   // otherwise hoist all 2 EPL table reads -- and the dozens of addresses derived from them -- out of the time loop and spill them
-  R* shQ = reinterpret_cast<R*>(smem_raw);
+  R* shQ = reinterpret_cast<R*>(smem_raw);  // (NW = 1 only: with NW = 2 the entry constants live in registers, Qe / Re below)
   R* shR = shQ + 64 * EPL;
-  unsigned* tabA = reinterpret_cast<unsigned*>(shR + 64 * EPL);
+  unsigned* tabA = reinterpret_cast<unsigned*>(shQ + A::SHC);
   unsigned* tabB = tabA + 64 * EPL;
   int* obs = reinterpret_cast<int*>(tabB + 64 * EPL);
-  R* Wb = shQ + A::SH + (long)wave * A::o_end;
+  R* Wb = shQ + A::SH + (NW == 1 ? (long)wave * A::o_end : 0L);
   // update: four images and the packed factor; predict: the stage image (halo), the stage covariance, the cotangent sums
   R* I0 = static_cast<R*>(__builtin_assume_aligned(Wb, 16));
   R* I1 = I0 + IMG;
@@ -166,7 +162,7 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
   R* vec = Wb + A::body;
   R *v_xs = vec, *v_ca = vec + 64 /* pairs: 128 */, *v_c3 = vec + 192 /* triples: 192 */, *v_lam = vec + 384, *v_mb = vec + 448,
     *v_v = vec + 512, *v_w = vec + 576, *v_vb = vec + 640, *v_u = vec + 704, *v_m = vec + 768, *v_inv = vec + 832, *v_dt = vec + 896, *v_dummy = vec + 960, *v_zero = vec + 1024;
-  const long n = (long)blockIdx.x * A::kWaves + wave;
+  const long n = NW == 1 ? (long)blockIdx.x * A::kWaves + wave : (long)blockIdx.x;
   const int M = a.m;
 
   // ---- tables: the owned entries e = lane + 64 s of the packed upper triangle (as the forward kernel) ------------------------------
@@ -193,15 +189,17 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
         }
         const int j = own ? i + (e - rs) : i;
         const int oi = obs[i], oj = obs[j];
-        shQ[64 * s + lane] = own ? LQL[i * D + j] : R(0);
-        shR[64 * s + lane] = !own ? R(0) : ((oi >= 0 && oj >= 0) ? Rm[oi * M + oj] : (i == j ? R(1) : R(0)));
+        if constexpr (NW == 1) {
+          shQ[64 * s + lane] = own ? LQL[i * D + j] : R(0);
+          shR[64 * s + lane] = !own ? R(0) : ((oi >= 0 && oj >= 0) ? Rm[oi * M + oj] : (i == j ? R(1) : R(0)));
+        }
         tabA[64 * s + lane] = (unsigned)i | (unsigned)j << 8 | (unsigned)(oi >= 0) << 16 | (unsigned)(oj >= 0) << 17;
         tabB[64 * s + lane] = (unsigned)(i * LDY + j) | (unsigned)(j * LDY + i) << 11 | (unsigned)(W::rs(j) + i) << 22;
       }
     }
   }
   __syncthreads();
-  if (n >= a.N) return;  // whole wavefront; no workgroup barrier anywhere below
+  if (n >= a.N) return;  // NW = 1: a whole wavefront, and no workgroup barrier anywhere below; NW = 2: the whole workgroup
   struct Ent { int i, j; };
   auto entry = [&](int s) { const unsigned w = tabA[64 * s + lane]; return Ent{(int)(w & 255u), (int)((w >> 8) & 255u)}; };
   struct Off { int y, yt, l; };
@@ -226,6 +224,34 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
   const int myobs = isrow ? obs[lane] : -1;
   const unsigned long long obsmask = __ballot(myobs >= 0);
   auto observed = [&](int i) { return (bool)((obsmask >> i) & 1ull); };
+  // the owned entries' constants (L Qc L^T)_ij and R_ij in state coordinates: LDS (NW = 1) or registers (NW = 2)
+  R Qe[EPL], Re[EPL];
+  if constexpr (NW != 1) {
+    const R* LQL = a.par + a.o_LQL;
+    const R* Rm = a.par + a.o_R;
+#pragma unroll
+    for (int s = 0; s < EPL; ++s)
+      if (mine(s)) {
+        const unsigned w = tabA[64 * s + lane];
+        const int i = (int)(w & 255u), j = (int)((w >> 8) & 255u);
+        const bool own = W::owned(s, lane);
+        const int oi = obs[i], oj = obs[j];
+        Qe[s] = own ? LQL[i * D + j] : R(0);
+        Re[s] = !own ? R(0) : ((oi >= 0 && oj >= 0) ? Rm[oi * M + oj] : (i == j ? R(1) : R(0)));
+      }
+  }
+  auto q_of = [&](int s) {
+    if constexpr (NW == 1)
+      return shQ[64 * s + lane];
+    else
+      return Qe[s];
+  };
+  auto r_of = [&](int s) {
+    if constexpr (NW == 1)
+      return shR[64 * s + lane];
+    else
+      return Re[s];
+  };
   const R forcing = (a.par + a.o_theta)[0];
   const R* tp = a.t + n * a.t_sn;
   const R* yp = a.y + n * a.y_sn + (myobs >= 0 ? myobs : 0) * a.y_si;
@@ -246,10 +272,11 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
 
   R Pb[EPL];  // cotangent of the covariance: owned entries
 #pragma unroll
-  for (int s = 0; s < EPL; ++s) {
-    Pb[s] = R(0);
-    gQG[64 * s + lane] = R(0);
-  }
+  for (int s = 0; s < EPL; ++s)
+    if (mine(s)) {
+      Pb[s] = R(0);
+      gQG[64 * s + lane] = R(0);
+    }
   R mb = R(0), gF = R(0);
   int st = 0;
   bool bad = false;
@@ -257,18 +284,21 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
   // tiles <-> images
   auto tiles_zero = [&](V4 (&acc)[NT]) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = V4{0, 0, 0, 0};
+    for (int t = 0; t < NT; ++t)
+      if (mine(t)) acc[t] = V4{0, 0, 0, 0};
   };
   auto tiles_store = [&](R* img, const V4 (&acc)[NT]) {
 #pragma unroll
     for (int mt = 0; mt < NB; ++mt)
 #pragma unroll
       for (int nt = 0; nt < NB; ++nt)
+        if (mine(mt * NB + nt)) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = 16 * mt + Tile::row(lg, r), col = 16 * nt + lm;
-          R* p = (row < D && col < D) ? img + row * LDY + col : v_dummy + lane;  // (no predicated stores: a select of the address)
-          *p = acc[mt * NB + nt][r];
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * mt + Tile::row(lg, r), col = 16 * nt + lm;
+            R* p = (row < D && col < D) ? img + row * LDY + col : v_dummy + lane;  // (no predicated stores: a select of the address)
+            *p = acc[mt * NB + nt][r];
+          }
         }
   };
   auto img_at = [&](const R* img, int i, int k) { return i < D ? img[i * LDY + k] : R(0); };  // (k < D by construction)
@@ -301,23 +331,29 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
     for (int mt = 0; mt < NB; ++mt)
 #pragma unroll
       for (int nt = 0; nt < NB; ++nt)
+        if (mine(mt * NB + nt)) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = 16 * mt + Tile::row(lg, r), col = 16 * nt + lm;
-          off[mt * NB + nt][r] = (row < D && col < D) ? addr(row, col) : -1;
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * mt + Tile::row(lg, r), col = 16 * nt + lm;
+            off[mt * NB + nt][r] = (row < D && col < D) ? addr(row, col) : -1;
+          }
         }
     if (!first_) {
 #pragma unroll
       for (int t = 0; t < NT; ++t)
+        if (mine(t)) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) old[t][r] = base[off[t][r] >= 0 ? off[t][r] : 0];
+          for (int r = 0; r < 4; ++r) old[t][r] = base[off[t][r] >= 0 ? off[t][r] : 0];
+        }
     }
 #pragma unroll
     for (int t = 0; t < NT; ++t)
+      if (mine(t)) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {  // (entries that are not there go to a scratch word of this lane: no predicated stores)
-        R* p = off[t][r] >= 0 ? base + off[t][r] : wsb + lane;
-        *p = first_ ? acc[t][r] : old[t][r] + acc[t][r];
+        for (int r = 0; r < 4; ++r) {  // (entries that are not there go to a scratch word of this lane: no predicated stores)
+          R* p = off[t][r] >= 0 ? base + off[t][r] : wsb + 64 * H + lane;
+          *p = first_ ? acc[t][r] : old[t][r] + acc[t][r];
+        }
       }
   };
 
@@ -326,41 +362,45 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
     fresh();
     unsigned wa[EPL];  // the owned entries' (i, j): one batch of table reads per right-hand side
 #pragma unroll
-    for (int s = 0; s < EPL; ++s) wa[s] = tabA[64 * s + lane];
+    for (int s = 0; s < EPL; ++s)
+      if (mine(s)) wa[s] = tabA[64 * s + lane];
 #pragma unroll
-    for (int s = 0; s < EPL; ++s) {
-      const int ei = (int)(wa[s] & 255u), ej = (int)((wa[s] >> 8) & 255u);
-      const bool own = W::owned(s, lane);
-      R* l1 = own ? S0 + (ei + 2) * LDP + (ej + 2) : v_dummy + lane;
-      R* l2 = own ? S0 + (ej + 2) * LDP + (ei + 2) : v_dummy + lane;
-      *l1 = Ps[s];
-      *l2 = Ps[s];
-    }
-    if (isrow) v_xs[lane] = xm;
-    wave_sync();
-    for (int e = lane; e < 3 * D; e += 64) {  // halo: rows -2, -1 <- D-2, D-1; row D <- 0; the same for the columns
-      const int r = (e >= 2 * D) ? 2 : (e >= D ? 1 : 0), c = e - r * D;
-      const int src = (r == 2) ? 0 : D - 2 + r, dst = (r == 2) ? D : r - 2;
-      S0[(dst + 2) * LDP + (c + 2)] = S0[(src + 2) * LDP + (c + 2)];
-      S0[(c + 2) * LDP + (dst + 2)] = S0[(c + 2) * LDP + (src + 2)];
-    }
+    for (int s = 0; s < EPL; ++s)
+      if (mine(s)) {
+        const int ei = (int)(wa[s] & 255u), ej = (int)((wa[s] >> 8) & 255u);
+        const bool own = W::owned(s, lane);
+        R* l1 = own ? S0 + (ei + 2) * LDP + (ej + 2) : v_dummy + lane;
+        R* l2 = own ? S0 + (ej + 2) * LDP + (ei + 2) : v_dummy + lane;
+        *l1 = Ps[s];
+        *l2 = Ps[s];
+      }
+    if (LEAD && isrow) v_xs[lane] = xm;
+    sync();
     typedef R Pair __attribute__((ext_vector_type(2)));
     Pair* cab = reinterpret_cast<Pair*>(__builtin_assume_aligned(v_ca, 16));
-    if (isrow) {
-      const R xp1 = v_xs[lp1], xm1 = v_xs[lm1], xm2 = v_xs[lm2];
-      cab[lane] = Pair{xm1, xp1 - xm2};
-      kM = rfma(xp1 - xm2, xm1, forcing - xm);
-    } else {
-      kM = R(0);
+    kM = R(0);
+    if constexpr (LEAD) {
+      for (int e = lane; e < 3 * D; e += 64) {  // halo: rows -2, -1 <- D-2, D-1; row D <- 0; the same for the columns
+        const int r = (e >= 2 * D) ? 2 : (e >= D ? 1 : 0), c = e - r * D;
+        const int src = (r == 2) ? 0 : D - 2 + r, dst = (r == 2) ? D : r - 2;
+        S0[(dst + 2) * LDP + (c + 2)] = S0[(src + 2) * LDP + (c + 2)];
+        S0[(c + 2) * LDP + (dst + 2)] = S0[(c + 2) * LDP + (src + 2)];
+      }
+      if (isrow) {
+        const R xp1 = v_xs[lp1], xm1 = v_xs[lm1], xm2 = v_xs[lm2];
+        cab[lane] = Pair{xm1, xp1 - xm2};
+        kM = rfma(xp1 - xm2, xm1, forcing - xm);
+      }
     }
-    wave_sync();
-    constexpr int CH = 4;
+    sync();
+    constexpr int CH = NW == 1 ? 4 : 8;  // (slots in flight together: four of this wavefront's)
 #pragma unroll
     for (int s0 = 0; s0 < EPL; s0 += CH) {
       R o6[CH][6], c4[CH][4], qv[CH];
 #pragma unroll
-      for (int u = 0; u < CH; ++u) {
-        const int s = (s0 + u < EPL) ? s0 + u : EPL - 1;
+      for (int u = 0; u < CH; ++u)
+        if (s0 + u < EPL && mine(s0 + u)) {
+        const int s = s0 + u;
         const Ent e{(int)(wa[s] & 255u), (int)((wa[s] >> 8) & 255u)};
         const R* c = S0 + (e.i + 2) * LDP + (e.j + 2);
         o6[u][0] = c[-2 * LDP];
@@ -374,12 +414,12 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
         c4[u][1] = ci[1];
         c4[u][2] = cj[0];
         c4[u][3] = cj[1];
-        qv[u] = shQ[64 * s + lane];
+        qv[u] = q_of(s);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int u = 0; u < CH; ++u) {
-        if (s0 + u < EPL) {
+        if (s0 + u < EPL && mine(s0 + u)) {
           const int s = s0 + u;
           R kk = rfma(R(-2), Ps[s], qv[u]);
           kk = rfma(c4[u][0], o6[u][2] - o6[u][0], kk);
@@ -391,7 +431,57 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    wave_sync();  // the image is rewritten by the next stage
+    sync();  // the image is rewritten by the next stage
+  };
+
+  // One Dormand-Prince step's stages forward from (P0, x0).  keep: what the reverse pass needs of them are the stage INPUTS -- the
+  // covariance parts go to lane-owned arrays in the trajectory's global scratch (stages 1 .. 5; stage 0's is the step's start), the
+  // mean's to xin; the slopes die with the call and the sixth right-hand side is not evaluated (nothing reads its slope).  Otherwise
+  // (the replay of an interval's earlier steps) the step is completed in place.
+  R xin[6];
+  auto stages_forward = [&](R (&P0)[EPL], R& x0, const R dt, auto keep_tag) {
+    constexpr bool KEEP = decltype(keep_tag)::value;
+    R kP[6][EPL], km[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      R Ps[EPL], xs = x0;
+#pragma unroll
+      for (int u = 0; u < EPL; ++u)
+        if (mine(u)) Ps[u] = P0[u];
+#pragma unroll
+      for (int j = 0; j < 5; ++j)
+        if (j < i) {
+#pragma unroll
+          for (int u = 0; u < EPL; ++u)
+            if (mine(u)) Ps[u] = rfma(T::a[i][j], kP[j][u], Ps[u]);
+          xs = rfma(T::a[i][j], km[j], xs);
+        }
+      if constexpr (KEEP) {
+        xin[i] = xs;
+        if (i > 0) {
+#pragma unroll
+          for (int u = 0; u < EPL; ++u)
+            if (mine(u)) PsG[((i - 1) * EPL + u) * 64 + lane] = Ps[u];
+        }
+      }
+      if (!KEEP || i < 5) {
+        rhs(Ps, xs, kP[i], km[i]);
+#pragma unroll
+        for (int u = 0; u < EPL; ++u)
+          if (mine(u)) kP[i][u] *= dt;
+        km[i] *= dt;
+      }
+    }
+    if constexpr (!KEEP) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+        if (T::b[i] != R(0)) {
+#pragma unroll
+          for (int u = 0; u < EPL; ++u)
+            if (mine(u)) P0[u] = rfma(T::b[i], kP[i][u], P0[u]);
+          x0 = rfma(T::b[i], km[i], x0);
+        }
+    }
   };
 
 #ifdef CDKF_W40A_PROFILE
@@ -399,6 +489,7 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
 #endif
   for (long k = a.T - 1; k >= 0; --k) {
     const bool first = (k == a.T - 1);
+    if constexpr (NW != 1) sync();  // (the other wavefront may still be reading the step's cotangent sums, which the images below overwrite)
     fresh();
     W40A_TICK(0)
     // =================================== (1) the measurement update at k, reversed =====================================================
@@ -412,79 +503,87 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
         R v[CHK];
         if (k > 0) {
 #pragma unroll
-          for (int u = 0; u < CHK; ++u) {
-            const int e = lane + 64 * (q0 + u);
-            v[u] = src[(long)(e < D * D ? e : 0) * a.P_si];
-          }
+          for (int u = 0; u < CHK; ++u)
+            if (mine(q0 + u)) {
+              const int e = lane + 64 * (q0 + u);
+              v[u] = src[(long)(e < D * D ? e : 0) * a.P_si];
+            }
         } else {
 #pragma unroll
-          for (int u = 0; u < CHK; ++u) {
-            const int e = lane + 64 * (q0 + u), ec = e < D * D ? e : 0, r = ec / D, c = ec - r * D;
-            v[u] = R(0.5) * (P0p[r * D + c] + P0p[c * D + r]);
-          }
+          for (int u = 0; u < CHK; ++u)
+            if (mine(q0 + u)) {
+              const int e = lane + 64 * (q0 + u), ec = e < D * D ? e : 0, r = ec / D, c = ec - r * D;
+              v[u] = R(0.5) * (P0p[r * D + c] + P0p[c * D + r]);
+            }
         }
 #pragma unroll
-        for (int u = 0; u < CHK; ++u) {  // (slots past the matrix rewrite entry (0, 0) with its own value: no predicated stores)
-          const int e = lane + 64 * (q0 + u), ec = e < D * D ? e : 0, r = ec / D, c = ec - r * D;
-          I0[r * LDY + c] = v[u];
-          I2[r * LDY + c] = (r == c) ? R(1) : R(0);
-        }
+        for (int u = 0; u < CHK; ++u)  // (slots past the matrix rewrite entry (0, 0) with its own value: no predicated stores)
+          if (mine(q0 + u)) {
+            const int e = lane + 64 * (q0 + u), ec = e < D * D ? e : 0, r = ec / D, c = ec - r * D;
+            I0[r * LDY + c] = v[u];
+            I2[r * LDY + c] = (r == c) ? R(1) : R(0);
+          }
       }
     }
-    R mpred = R(0), vk = R(0);
-    if (isrow) {
-      mpred = (k == 0) ? (a.par + a.o_m0)[lane] : a.pm[n * a.m_sn + (k - 1) * a.m_sk + lane * a.m_si];
-      vk = (myobs >= 0) ? yp[k * a.y_sk] - mpred : R(0);
+    if constexpr (LEAD) {
+      R mpred = R(0), vk = R(0);
+      if (isrow) {
+        mpred = (k == 0) ? (a.par + a.o_m0)[lane] : a.pm[n * a.m_sn + (k - 1) * a.m_sk + lane * a.m_si];
+        vk = (myobs >= 0) ? yp[k * a.y_sk] - mpred : R(0);
+      }
+      v_v[lane] = vk;
+      v_mb[lane] = mb;
+      v_m[lane] = mpred;
     }
-    v_v[lane] = vk;
-    v_mb[lane] = mb;
-    v_m[lane] = mpred;
 #pragma unroll
     for (int s = 0; s < EPL; ++s)
-      if (W::owned(s, lane)) {
+      if (mine(s) && W::owned(s, lane)) {
         const Off f = offsets(s);
         I1[f.y] = Pb[s];
         I1[f.yt] = Pb[s];
         PbG[64 * s + lane] = Pb[s];
       }
-    wave_sync();
+    sync();
     fresh();
     // sym(S) + 1e-9 I, packed lower (state coordinates: the identity on the unobserved components); the augmented row is not used
 #pragma unroll
     for (int s = 0; s < EPL; ++s)
-      if (W::owned(s, lane)) {
+      if (mine(s) && W::owned(s, lane)) {
         const Off f = offsets(s);
         const unsigned wA = tabA[64 * s + lane];
         const bool obs_i = (wA >> 16) & 1u, obs_j = (wA >> 17) & 1u;
-        const R sv = (obs_i && obs_j) ? I0[f.y] + shR[64 * s + lane] : shR[64 * s + lane];
+        const R sv = (obs_i && obs_j) ? I0[f.y] + r_of(s) : r_of(s);
         Lp[f.l] = (f.y == f.yt) ? sv + R(1e-9) : sv;
       }
-    if (isrow) Lp[W::rs(D) + lane] = R(0);
-    wave_sync();
+    if (LEAD && isrow) Lp[W::rs(D) + lane] = R(0);
+    sync();
     W40A_TICK(1)  // loads, images, packed system
-    {
-      R quad = R(0);
-      double logdet = 0.0;
-      R* const sys[1] = {Lp};
-      R* const scr[1] = {v_ca};
-      Lin::template cholesky<1>(sys, scr, v_inv, rowi, ri, lane, quad, logdet, bad);
+    if constexpr (LEAD) {
+      {
+        R quad = R(0);
+        double logdet = 0.0;
+        R* const sys[1] = {Lp};
+        R* const scr[1] = {v_ca};
+        Lin::template cholesky<1>(sys, scr, v_inv, rowi, ri, lane, quad, logdet, bad);
+      }
+      W40A_TICK(2)  // factorisation
+      // W2 = (sym S + 1e-9 I)^-1: the D columns of the identity, in place in I2
+      Lin::solve(I2, Lp, v_inv, (const R*)nullptr, lane, [&] {});
     }
-    W40A_TICK(2)  // factorisation
-    // W2 = (sym S + 1e-9 I)^-1: the D columns of the identity, in place in I2
-    Lin::solve(I2, Lp, v_inv, (const R*)nullptr, lane, [&] {});
+    if constexpr (NW != 1) sync();
     W40A_TICK(3)  // W2
     // X = W2 (E P) -> I3
     {
       V4 acc[NT];
       tiles_zero(acc);
-      w40a_mmp<R, D, false, true, 0>(acc, rows_of(I2, false).p, cols_of(I0).p, blast_ok, obsmask, lg);
+      w40a_mmp<R, D, false, true, 0, NW, H>(acc, rows_of(I2, false).p, cols_of(I0).p, blast_ok, obsmask, lg);
       tiles_store(I3, acc);
     }
-    wave_sync();
+    sync();
     W40A_TICK(4)  // X
     // w = S^-1 v = u1 + 1e-9 W2 u1, u1 = W2 v;  vbar = X mbar - w
     R wv = R(0), vb = R(0);
-    {
+    if constexpr (LEAD) {
       R u1 = R(0), tx = R(0);
       if (isrow) {
         const R* w2r = I2 + lane * LDY;
@@ -515,54 +614,58 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
       V4 accX[NT];
       tiles_zero(accX);
       tiles_zero(accK);
-      w40a_mmp<R, D, false, false, 0>(accX, rows_of(I3, false).p, cols_of(I1).p, blast_ok, obsmask, lg);
-      w40a_mmp<R, D, false, false, 0>(accK, rows_of(I0, true).p, cols_of(I1).p, blast_ok, obsmask, lg);
-      wave_sync();  // (every read of Pbar's image is done; v_w / v_vb are visible)
+      w40a_mmp<R, D, false, false, 0, NW, H>(accX, rows_of(I3, false).p, cols_of(I1).p, blast_ok, obsmask, lg);
+      w40a_mmp<R, D, false, false, 0, NW, H>(accK, rows_of(I0, true).p, cols_of(I1).p, blast_ok, obsmask, lg);
+      sync();  // (every read of Pbar's image is done; v_w / v_vb are visible)
       tiles_store(I1, accX);  // X Pb
 #pragma unroll
       for (int mt = 0; mt < NB; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NB; ++nt)
+          if (mine(mt * NB + nt)) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = 16 * mt + Tile::row(lg, r), col = 16 * nt + lm;
-            const int t = mt * NB + nt;
-            accK[t][r] = rfma(R(-2), rfma(R(-1e-9), accX[t][r], accK[t][r]), v_v[row] * v_mb[col]);
+            for (int r = 0; r < 4; ++r) {
+              const int row = 16 * mt + Tile::row(lg, r), col = 16 * nt + lm;
+              const int t = mt * NB + nt;
+              accK[t][r] = rfma(R(-2), rfma(R(-1e-9), accX[t][r], accK[t][r]), v_v[row] * v_mb[col]);
+            }
           }
     }
     W40A_TICK(6)  // X Pb, (E P) Pb, Kb
     // Sbar = -(X Pb) X^T + w w^T / 2 - S^-1 / 2 - sym(X Ub^T);  S^-1 = W2 + 1e-9 W2 W2
     tiles_zero(accS);
-    w40a_mmp<R, D, true, false, 0>(accS, rows_of(I2, false).p, rows_of(I2, false).p, blast_ok, obsmask, lg);  // (W2 is symmetric)
+    w40a_mmp<R, D, true, false, 0, NW, H>(accS, rows_of(I2, false).p, rows_of(I2, false).p, blast_ok, obsmask, lg);  // (W2 is symmetric)
 #pragma unroll
     for (int mt = 0; mt < NB; ++mt)
 #pragma unroll
       for (int nt = 0; nt < NB; ++nt)
+        if (mine(mt * NB + nt)) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = 16 * mt + Tile::row(lg, r), col = 16 * nt + lm;
-          const int t = mt * NB + nt;
-          const R w2 = (row < D && col < D) ? I2[row * LDY + col] : R(0);
-          accS[t][r] = R(0.5) * (v_w[row] * v_w[col] - rfma(R(1e-9), accS[t][r], w2));
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * mt + Tile::row(lg, r), col = 16 * nt + lm;
+            const int t = mt * NB + nt;
+            const R w2 = (row < D && col < D) ? I2[row * LDY + col] : R(0);
+            accS[t][r] = R(0.5) * (v_w[row] * v_w[col] - rfma(R(1e-9), accS[t][r], w2));
+          }
         }
-    wave_sync();  // (X Pb is in I1)
-    w40a_mmp<R, D, true, false, 1>(accS, rows_of(I1, false).p, rows_of(I3, false).p, blast_ok, obsmask, lg);
-    wave_sync();
+    sync();  // (X Pb is in I1)
+    w40a_mmp<R, D, true, false, 1, NW, H>(accS, rows_of(I1, false).p, rows_of(I3, false).p, blast_ok, obsmask, lg);
+    sync();
     tiles_store(I1, accK);  // Kb
-    wave_sync();
+    sync();
     W40A_TICK(7)  // W2 W2, (X Pb) X^T
     // Ub = W2 Kb -> I2 (over the then dead W2)
     {
       V4 accU[NT];
       tiles_zero(accU);
-      w40a_mmp<R, D, false, false, 0>(accU, rows_of(I2, false).p, cols_of(I1).p, blast_ok, obsmask, lg);
-      wave_sync();
+      w40a_mmp<R, D, false, false, 0, NW, H>(accU, rows_of(I2, false).p, cols_of(I1).p, blast_ok, obsmask, lg);
+      sync();
       tiles_store(I2, accU);
     }
-    wave_sync();
+    sync();
     W40A_TICK(8)  // Ub
-    w40a_mmp<R, D, true, false, 2>(accS, rows_of(I3, false).p, rows_of(I2, false).p, blast_ok, obsmask, lg);
-    w40a_mmp<R, D, true, false, 2>(accS, rows_of(I2, false).p, rows_of(I3, false).p, blast_ok, obsmask, lg);
+    w40a_mmp<R, D, true, false, 2, NW, H>(accS, rows_of(I3, false).p, rows_of(I2, false).p, blast_ok, obsmask, lg);
+    w40a_mmp<R, D, true, false, 2, NW, H>(accS, rows_of(I2, false).p, rows_of(I3, false).p, blast_ok, obsmask, lg);
     // model block: dR += Sbar (the observed pairs)
     if (gm)
       tiles_accumulate(gR, accS, first, [&](int row, int col) {
@@ -570,41 +673,43 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
         return (orow >= 0 && ocol >= 0) ? orow * M + ocol : -1;
       });
     tiles_store(I1, accS);  // Sbar (Kb is dead: Ub was formed behind a synchronisation)
-    wave_sync();
+    sync();
     W40A_TICK(9)  // X Ub^T, Ub X^T, dR
     if (gm) {  // dH += 2 Sbar (E P) - vbar m^T + Ub P; dbias -= vbar
       V4 accH[NT];
       tiles_zero(accH);
-      w40a_mmp<R, D, false, true, 3>(accH, rows_of(I1, false).p, cols_of(I0).p, blast_ok, obsmask, lg);
-      w40a_mmp<R, D, false, false, 0>(accH, rows_of(I2, false).p, cols_of(I0).p, blast_ok, obsmask, lg);
+      w40a_mmp<R, D, false, true, 3, NW, H>(accH, rows_of(I1, false).p, cols_of(I0).p, blast_ok, obsmask, lg);
+      w40a_mmp<R, D, false, false, 0, NW, H>(accH, rows_of(I2, false).p, cols_of(I0).p, blast_ok, obsmask, lg);
 #pragma unroll
       for (int mt = 0; mt < NB; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NB; ++nt)
+          if (mine(mt * NB + nt)) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = 16 * mt + Tile::row(lg, r), col = 16 * nt + lm;
-            accH[mt * NB + nt][r] = rfma(-v_vb[row], v_m[col], accH[mt * NB + nt][r]);
+            for (int r = 0; r < 4; ++r) {
+              const int row = 16 * mt + Tile::row(lg, r), col = 16 * nt + lm;
+              accH[mt * NB + nt][r] = rfma(-v_vb[row], v_m[col], accH[mt * NB + nt][r]);
+            }
           }
       tiles_accumulate(gH, accH, first, [&](int row, int col) {
         const int orow = obs[row];
         return orow >= 0 ? orow * D + col : -1;
       });
-      if (myobs >= 0) gBias[myobs] = first ? -vb : gBias[myobs] - vb;
+      if (LEAD && myobs >= 0) gBias[myobs] = first ? -vb : gBias[myobs] - vb;
     }
     fresh();
     // Pbar <- Pbar + sym(Ub^T H) + H^T Sbar H;  mbar <- mbar - H^T vbar
 #pragma unroll
     for (int s = 0; s < EPL; ++s)
-      if (W::owned(s, lane)) {
+      if (mine(s) && W::owned(s, lane)) {
         const Off f = offsets(s);
         const unsigned wA = tabA[64 * s + lane];
         const bool obs_i = (wA >> 16) & 1u, obs_j = (wA >> 17) & 1u;
         const R uij = obs_j ? I2[f.yt] : R(0), uji = obs_i ? I2[f.y] : R(0);
         Pb[s] = PbG[64 * s + lane] + rfma(R(0.5), uij + uji, (obs_i && obs_j) ? I1[f.y] : R(0));
       }
-    mb -= vb;
-    wave_sync();
+    mb -= vb;  // (zero on the second wavefront)
+    sync();
     W40A_TICK(10)  // dH, Pbar
     if (k == 0) break;
 
@@ -627,13 +732,15 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
       // replay from the filtered moments at k-1 up to the chunk's last step start, keeping the chunk's starts
       R P0[EPL], x0;
 #pragma unroll
-      for (int s = 0; s < EPL; ++s) {
-        const Ent e = entry(s);
-        P0[s] = a.fP[n * a.P_sn + (k - 1) * a.P_sk + (long)(e.i * D + e.j) * a.P_si];  // (slots past the triangle: entry (0, 0), masked below)
-      }
-      x0 = isrow ? a.fm[n * a.m_sn + (k - 1) * a.m_sk + lane * a.m_si] : R(0);
+      for (int s = 0; s < EPL; ++s)
+        if (mine(s)) {
+          const Ent e = entry(s);
+          P0[s] = a.fP[n * a.P_sn + (k - 1) * a.P_sk + (long)(e.i * D + e.j) * a.P_si];  // (slots past the triangle: entry (0, 0), masked below)
+        }
+      x0 = (LEAD && isrow) ? a.fm[n * a.m_sn + (k - 1) * a.m_sk + lane * a.m_si] : R(0);
 #pragma unroll
-      for (int s = 0; s < EPL; ++s) P0[s] = W::owned(s, lane) ? P0[s] : R(0);
+      for (int s = 0; s < EPL; ++s)
+        if (mine(s)) P0[s] = W::owned(s, lane) ? P0[s] : R(0);
       {
         R tprev = t0, tnx = rmin(t0 + a.dt0, t1);
         for (long s = 0; s < ce; ++s) {
@@ -641,62 +748,35 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
           if (s >= cs) {
             R* sv = wsb + (s - cs) * A::start_reals();  // (the covariance part is read back by the reverse pass's last stage as well)
 #pragma unroll
-            for (int u = 0; u < EPL; ++u) sv[64 * u + lane] = P0[u];
-            sv[64 * EPL + lane] = x0;
+            for (int u = 0; u < EPL; ++u)
+              if (mine(u)) sv[64 * u + lane] = P0[u];
+            if constexpr (LEAD) sv[64 * EPL + lane] = x0;
             v_dt[s - cs] = dt;  // (the step sizes of the chunk: cap <= 64)
           }
-          if (s + 1 < ce) w40_dopri5<R, EPL>(rhs, P0, x0, dt);
+          if (s + 1 < ce) stages_forward(P0, x0, dt, std::false_type{});
           tprev = rmin(tnx, t1);
           const R tn = tnx + a.dt0;
           tnx = (tn > t1 - Tol<R>::v) ? t1 : tn;
         }
       }
-      wave_sync();
+      sync();
       for (long s = ce - 1; s >= cs; --s) {
         if (s + 1 < ce) {
           const R* sv = wsb + (s - cs) * A::start_reals();
 #pragma unroll
-          for (int u = 0; u < EPL; ++u) P0[u] = sv[64 * u + lane];
-          x0 = sv[64 * EPL + lane];
+          for (int u = 0; u < EPL; ++u)
+            if (mine(u)) P0[u] = sv[64 * u + lane];
+          if constexpr (LEAD) x0 = sv[64 * EPL + lane];
         }
         const R dt = v_dt[s - cs];
         W40A_TICK(11)  // replay, step start
-        // ---- the step's stages forward: what the reverse pass needs of them are the stage INPUTS -- the covariance parts go to lane-owned
-        //      arrays in the trajectory's global scratch (stages 1 .. 5; stage 0's is the step's start), the mean's stay in registers; the slopes die with this block
-        //      (the sixth right-hand side is not evaluated: nothing reads its slope)
-        R xin[6];
-        {
-          R kP[5][EPL], km[5];
-#pragma unroll
-          for (int i = 0; i < 6; ++i) {
-            R Ps[EPL], xs = x0;
-#pragma unroll
-            for (int u = 0; u < EPL; ++u) Ps[u] = P0[u];
-#pragma unroll
-            for (int j = 0; j < 5; ++j)
-              if (j < i) {
-#pragma unroll
-                for (int u = 0; u < EPL; ++u) Ps[u] = rfma(T::a[i][j], kP[j][u], Ps[u]);
-                xs = rfma(T::a[i][j], km[j], xs);
-              }
-            xin[i] = xs;
-            if (i > 0) {
-#pragma unroll
-              for (int u = 0; u < EPL; ++u) PsG[((i - 1) * EPL + u) * 64 + lane] = Ps[u];
-            }
-            if (i < 5) {
-              rhs(Ps, xs, kP[i < 5 ? i : 0], km[i < 5 ? i : 0]);
-#pragma unroll
-              for (int u = 0; u < EPL; ++u) kP[i < 5 ? i : 0][u] *= dt;
-              km[i < 5 ? i : 0] *= dt;
-            }
-          }
-        }
+        stages_forward(P0, x0, dt, std::true_type{});  // (the stage inputs parked for the reverse pass)
         W40A_TICK(12)  // stages forward
         // ---- ... and backward ----------------------------------------------------------------------------------------------------
         R Pn[EPL], mn = mb, accm[5];
 #pragma unroll
-        for (int u = 0; u < EPL; ++u) Pn[u] = Pb[u];
+        for (int u = 0; u < EPL; ++u)
+          if (mine(u)) Pn[u] = Pb[u];
 #pragma unroll
         for (int j = 0; j < 5; ++j) accm[j] = R(0);
 #pragma unroll
@@ -708,24 +788,27 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
           R pin_[EPL];  // the stage's input: in flight from the scratch while the cotangent is formed
 #pragma unroll
           for (int u = 0; u < EPL; ++u)
-            pin_[u] = (i > 0) ? PsG[((i > 0 ? i - 1 : 0) * EPL + u) * 64 + lane] : (wsb + (s - cs) * A::start_reals())[64 * u + lane];
+            if (mine(u))
+              pin_[u] = (i > 0) ? PsG[((i > 0 ? i - 1 : 0) * EPL + u) * 64 + lane] : (wsb + (s - cs) * A::start_reals())[64 * u + lane];
           unsigned wa[EPL];  // the owned entries' (i, j), kept for the stage (one batch of table reads)
 #pragma unroll
-          for (int u = 0; u < EPL; ++u) wa[u] = tabA[64 * u + lane];
+          for (int u = 0; u < EPL; ++u)
+            if (mine(u)) wa[u] = tabA[64 * u + lane];
           {
-            constexpr int CP = 5;
+            constexpr int CP = NW == 1 ? 5 : 10;  // (slots in flight together: five of this wavefront's)
 #pragma unroll
             for (int u0 = 0; u0 < EPL; u0 += CP) {
               R ac[CP];
 #pragma unroll
-              for (int c = 0; c < CP; ++c) {
-                const int u = (u0 + c < EPL) ? u0 + c : EPL - 1;
-                ac[c] = (i < 5) ? AccL[(i * EPL + u) * 64 + lane] : R(0);
-              }
+              for (int c = 0; c < CP; ++c)
+                if (u0 + c < EPL && mine(u0 + c)) {
+                  const int u = u0 + c;
+                  ac[c] = (i < 5) ? AccL[(i * EPL + u) * 64 + lane] : R(0);
+                }
               __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
               for (int c = 0; c < CP; ++c)
-                if (u0 + c < EPL) {
+                if (u0 + c < EPL && mine(u0 + c)) {
                   const int u = u0 + c;
                   const R Lm = dt * rfma(T::b[i], Pb[u], ac[c]);
                   const R Psu = pin_[u];
@@ -744,22 +827,24 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
             }
           }
           lam = dt * rfma(T::b[i], mb, (i < 5) ? accm[i < 5 ? i : 0] : R(0));
-          if (isrow) gF += lam;
+          if (LEAD && isrow) gF += lam;
           xs = xin[i];
-          if (isrow) {
+          if (LEAD && isrow) {
             v_xs[lane] = xs;
             v_lam[lane] = lam;
           }
           W40A_TICK(18)  // (stage: cotangent, input, images)
-          wave_sync();
-          for (int e = lane; e < 3 * D; e += 64) {  // halo of Lam: rows / columns -1 <- D-1, D <- 0, D+1 <- 1
-            const int r = (e >= 2 * D) ? 2 : (e >= D ? 1 : 0), c = e - r * D;
-            const int src = (r == 0) ? D - 1 : r - 1, dst = (r == 0) ? -1 : D + r - 1;
-            S0[(dst + 2) * LDP + (c + 2)] = S0[(src + 2) * LDP + (c + 2)];
-            S0[(c + 2) * LDP + (dst + 2)] = S0[(c + 2) * LDP + (src + 2)];
+          sync();
+          if constexpr (LEAD) {
+            for (int e = lane; e < 3 * D; e += 64) {  // halo of Lam: rows / columns -1 <- D-1, D <- 0, D+1 <- 1
+              const int r = (e >= 2 * D) ? 2 : (e >= D ? 1 : 0), c = e - r * D;
+              const int src = (r == 0) ? D - 1 : r - 1, dst = (r == 0) ? -1 : D + r - 1;
+              S0[(dst + 2) * LDP + (c + 2)] = S0[(src + 2) * LDP + (c + 2)];
+              S0[(c + 2) * LDP + (dst + 2)] = S0[(c + 2) * LDP + (src + 2)];
+            }
           }
           R xbar = R(0);
-          if (isrow) {  // coefficients of column j of the Jacobian: F[j-1][j] = x[j-2], F[j+2][j] = -x[j+1], F[j+1][j] = x[j+2] - x[j-1]
+          if (LEAD && isrow) {  // coefficients of column j of the Jacobian: F[j-1][j] = x[j-2], F[j+2][j] = -x[j+1], F[j+1][j] = x[j+2] - x[j-1]
             const R xm2 = v_xs[lm2], xm1 = v_xs[lm1], xp1 = v_xs[lp1], xp2 = v_xs[lp2];
             v_c3[3 * lane] = xm2;
             v_c3[3 * lane + 1] = xp1;
@@ -767,17 +852,18 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
             // F^T lam
             xbar = rfma(v_lam[lm1], xm2, rfma(-v_lam[lp2], xp1, rfma(v_lam[lp1], xp2 - xm1, -lam)));
           }
-          wave_sync();
+          sync();
           W40A_TICK(14)  // (stage: halo, coefficients)
           fresh();
           // Ybar_P = Lam F + (Lam F)^T of the owned entries, added to the step's input cotangent and to the earlier stages' sums as formed
-          constexpr int CH = 4;
+          constexpr int CH = NW == 1 ? 4 : 8;
 #pragma unroll
           for (int s0 = 0; s0 < EPL; s0 += CH) {
             R o7[CH][7], c6[CH][6], old[CH][5];
 #pragma unroll
-            for (int u = 0; u < CH; ++u) {
-              const int s = (s0 + u < EPL) ? s0 + u : EPL - 1;
+            for (int u = 0; u < CH; ++u)
+              if (s0 + u < EPL && mine(s0 + u)) {
+              const int s = s0 + u;
               const Ent e{(int)(wa[s] & 255u), (int)((wa[s] >> 8) & 255u)};
               const R* c = S0 + (e.i + 2) * LDP + (e.j + 2);
               o7[u][0] = c[-1];
@@ -798,7 +884,7 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < CH; ++u)
-              if (s0 + u < EPL) {
+              if (s0 + u < EPL && mine(s0 + u)) {
                 const int s = s0 + u;
                 R y = R(-2) * o7[u][6];
                 y = rfma(c6[u][0], o7[u][0], y);
@@ -820,6 +906,8 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
           W40A_TICK(15)  // (stage: stencil)
           // the state's cotangent: sum_ij (2 Lam Ps)_ij dF_ij/dx_k = 2 sum_c { Lam[k+1][c] (Ps[c][k+2] - Ps[c][k-1]) + Lam[k-1][c] Ps[c][k-2]
           //                                                                      - Lam[k+2][c] Ps[c][k+1] }   (both symmetric: rows of the images)
+          // (NW = 2: the first wavefront takes the first sum, the second the other two and hands its part over through v_u)
+          R xpart = R(0);
           if (isrow) {
             const R* l1 = S0 + (lane + 3) * LDP + 2;  // row k+1 (halo row D at k = D-1)
             const R* l2 = S0 + (lane + 1) * LDP + 2;  // row k-1 (halo row -1 at k = 0)
@@ -838,35 +926,45 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
             R g0 = R(0), g1 = R(0), g2 = R(0), h0 = R(0), h1 = R(0), h2 = R(0);
 #pragma unroll 2
             for (int c = 0; c < D / 2; ++c) {
-              const Pair a1 = q1[c], a2 = q2[c], a3 = q3[c], a4 = q4[c];
-              g0 = rfma(l1[2 * c], a1[0] - a2[0], g0);
-              h0 = rfma(l1[2 * c + 1], a1[1] - a2[1], h0);
-              g1 = rfma(l2[2 * c], a3[0], g1);
-              h1 = rfma(l2[2 * c + 1], a3[1], h1);
-              g2 = rfma(l3[2 * c], a4[0], g2);
-              h2 = rfma(l3[2 * c + 1], a4[1], h2);
+              if constexpr (NW == 1 || H == 0) {
+                const Pair a1 = q1[c], a2 = q2[c];
+                g0 = rfma(l1[2 * c], a1[0] - a2[0], g0);
+                h0 = rfma(l1[2 * c + 1], a1[1] - a2[1], h0);
+              }
+              if constexpr (NW == 1 || H == 1) {
+                const Pair a3 = q3[c], a4 = q4[c];
+                g1 = rfma(l2[2 * c], a3[0], g1);
+                h1 = rfma(l2[2 * c + 1], a3[1], h1);
+                g2 = rfma(l3[2 * c], a4[0], g2);
+                h2 = rfma(l3[2 * c + 1], a4[1], h2);
+              }
             }
-            xbar = rfma(R(2), ((g0 + h0) + (g1 + h1)) - (g2 + h2), xbar);
+            xpart = R(2) * (((g0 + h0) + (g1 + h1)) - (g2 + h2));
           }
+          if constexpr (NW != 1 && !LEAD) v_u[lane] = xpart;
           W40A_TICK(16)  // (stage: dot products)
-          // the mean's part of the sums
+          sync();  // the images are rewritten by the next stage; the second wavefront's part of the state's cotangent is visible
+          if constexpr (LEAD) {  // the mean's part of the sums
+            xbar += xpart;
+            if constexpr (NW != 1) xbar += v_u[lane];
 #pragma unroll
-          for (int j = 0; j < 5; ++j)
-            if (j < i) accm[j] = rfma(T::a[i][j], xbar, accm[j]);
-          mn += xbar;
-          wave_sync();  // the images are rewritten by the next stage
+            for (int j = 0; j < 5; ++j)
+              if (j < i) accm[j] = rfma(T::a[i][j], xbar, accm[j]);
+            mn += xbar;
+          }
           W40A_TICK(17)  // (stage: sums)
         }
         // d ll / d (L Qc L^T) += the sum of the six stage cotangents = dt (Pbar + sum_j Acc_j)  (sum_i b_i = 1; the weighted sums are all
         // complete and still in their arrays)
 #pragma unroll
-        for (int u = 0; u < EPL; ++u) {
-          R sacc = Pb[u];
+        for (int u = 0; u < EPL; ++u)
+          if (mine(u)) {
+            R sacc = Pb[u];
 #pragma unroll
-          for (int j = 0; j < 5; ++j) sacc += AccL[(j * EPL + u) * 64 + lane];
-          gQG[64 * u + lane] = rfma(dt, sacc, gQG[64 * u + lane]);
-          Pb[u] = Pn[u];
-        }
+            for (int j = 0; j < 5; ++j) sacc += AccL[(j * EPL + u) * 64 + lane];
+            gQG[64 * u + lane] = rfma(dt, sacc, gQG[64 * u + lane]);
+            Pb[u] = Pn[u];
+          }
         mb = mn;
         W40A_TICK(13)  // stages reversed
       }
@@ -876,10 +974,10 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
   fresh();
   // ---- results --------------------------------------------------------------------------------------------------------------------
   if (gm) {
-    if (isrow) gm[lane] = mb;
+    if (LEAD && isrow) gm[lane] = mb;
 #pragma unroll
     for (int s = 0; s < EPL; ++s)
-      if (W::owned(s, lane)) {
+      if (mine(s) && W::owned(s, lane)) {
         const Ent e = entry(s);
         gP0[e.i * D + e.j] = Pb[s];
         gP0[e.j * D + e.i] = Pb[s];
@@ -888,16 +986,18 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
         gQ[e.j * D + e.i] = gq;
       }
   }
-  wave_sync();
-  v_u[lane] = isrow ? gF : R(0);
-  wave_sync();
-  if (lane == 0) {
-    R sum = R(0);
-    for (int c = 0; c < D; ++c) sum += v_u[c];
-    g[0] = sum;
+  if constexpr (LEAD) {
+    wave_sync();
+    v_u[lane] = isrow ? gF : R(0);
+    wave_sync();
+    if (lane == 0) {
+      R sum = R(0);
+      for (int c = 0; c < D; ++c) sum += v_u[c];
+      g[0] = sum;
+    }
+    if (bad) st |= kStatusNotPd;
+    if (st && lane == 0 && a.status) atomicOr(&a.status[n], st);
   }
-  if (bad) st |= kStatusNotPd;
-  if (st && lane == 0 && a.status) atomicOr(&a.status[n], st);
 #ifdef CDKF_W40A_PROFILE
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     printf("w40a cycles/obs-step (sizeof real %d, d %d):", (int)sizeof(R), D);
@@ -906,6 +1006,24 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
     for (int q2 = 0; q2 < 24; ++q2) w40a_prof[q2] = 0;
   }
 #endif
+}
+
+// one wavefront per trajectory, two trajectories per workgroup
+template <typename R, int D>
+__global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<R> a, R* __restrict__ grad, R* __restrict__ grad_model,
+                                                                    R* __restrict__ ws, const long ws_stride, const int cap) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  w40a_sweep<R, D, 1, 0>(a, grad, grad_model, ws, ws_stride, cap, smem_raw);
+}
+// two wavefronts per trajectory, one trajectory per workgroup (two workgroups per CU)
+template <typename R, int D>
+__global__ __launch_bounds__(128) void ekf_adjoint_wave2_l96_kernel(const WgArgs<R> a, R* __restrict__ grad, R* __restrict__ grad_model,
+                                                                     R* __restrict__ ws, const long ws_stride, const int cap) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  if (threadIdx.x < 64)
+    w40a_sweep<R, D, 2, 0>(a, grad, grad_model, ws, ws_stride, cap, smem_raw);
+  else
+    w40a_sweep<R, D, 2, 1>(a, grad, grad_model, ws, ws_stride, cap, smem_raw);
 }
 
 }  // namespace cdkf

@@ -2,6 +2,7 @@
 // translation unit.
 #include "cdkf_launch.h"
 #include "cdkf_adjoint_w40_kernels.h"
+#include <cstdlib>
 
 namespace cdkf {
 
@@ -19,6 +20,21 @@ static int launch_wave40_adjoint_d(const WgArgs<R>& a, R* grad, R* grad_model, R
   if (cap < 1 || cap > 64) {
     set_error("reverse sweep: step starts per replay chunk must be 1 .. 64 (got %d)", cap);
     return CDKF_EINVAL;
+  }
+  // Two wavefronts per trajectory (ekf_adjoint_wave2_l96_kernel: every other owned slot and product tile each, one trajectory per
+  // workgroup, two workgroups per CU -- all four SIMDs at work) or one (two trajectories per workgroup).  CDKF_WAVE40_ADJ_WAVES=1|2.
+  int nw = 2;
+  if (const char* e = getenv("CDKF_WAVE40_ADJ_WAVES")) nw = atoi(e) == 1 ? 1 : 2;
+  if (nw == 2) {
+    using A2 = W40A<R, D, 2>;
+    static_assert(2 * (sizeof(R) * (size_t)A2::lds_reals + 64) <= kLdsLimit - 256, "two one-trajectory workgroups fit the CU's LDS");
+    if (once_per_device([] { return wg_raise_lds_cap(ekf_adjoint_wave2_l96_kernel<R, D>); })) return CDKF_EHIP;
+    const size_t lds2 = sizeof(R) * (size_t)A2::lds_reals + 64;
+    note_kernel("ekf_adjoint_wave2_l96_kernel<%s, %d>", real_name<R>(), D);
+    hipLaunchKernelGGL((ekf_adjoint_wave2_l96_kernel<R, D>), dim3((unsigned)a.N), dim3(128), lds2, stream, a, grad, grad_model, scratch,
+                       wave40_adjoint_scratch_reals(D, cap), cap);
+    CDKF_HIP_CHECK(hipGetLastError());
+    return CDKF_OK;
   }
   if (once_per_device([] { return wg_raise_lds_cap(ekf_adjoint_wave_l96_kernel<R, D>); })) return CDKF_EHIP;
   const size_t lds = sizeof(R) * (size_t)A::lds_reals + 64;

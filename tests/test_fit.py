@@ -175,7 +175,7 @@ def test_fit_sgd_lorenz96_forcing_beyond_eight_state_dimensions(hip_lib):
     y = o.simulate(true, t, rng)
     start, props = problem(6.5, 1.0, frozen)
     new, losses = model.fit_sgd(start, props, y, t[..., None], cd.EKFHyperParams(), optimizer=fit.Adam(0.1), batch_size=N, num_epochs=60)
-    assert _ffi.lib().cdkf_last_kernel().decode().startswith(("ekf_adjoint_wave_l96_kernel<double", "ekf_adjoint_wg_kernel<double"))
+    assert _ffi.lib().cdkf_last_kernel().decode().startswith(("ekf_adjoint_wave2_l96_kernel<double", "ekf_adjoint_wave_l96_kernel<double", "ekf_adjoint_wg_kernel<double"))
     assert np.all(np.isfinite(losses)) and losses[-1] < losses[0]
     assert abs(float(new.dynamics.drift.forcing) - 8.0) < 0.5 * abs(6.5 - 8.0), new.dynamics.drift.forcing
     # the first step's gradient is the oracle's

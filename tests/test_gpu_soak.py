@@ -182,11 +182,14 @@ def test_soak_reverse_sweep_beyond_eight_dimensions(hip_lib):
     assert worst < 2e-8
 
 
-def test_soak_wavefront_reverse_sweep_of_lorenz96(hip_lib):
-    """Fourteen random problems for ekf_adjoint_wave_l96_kernel (round 4): every instantiated state dimension 12 .. 40, a random
+@pytest.mark.parametrize("waves", [1, 2])
+def test_soak_wavefront_reverse_sweep_of_lorenz96(hip_lib, waves, monkeypatch):
+    """Fourteen random problems for ekf_adjoint_wave_l96_kernel / ekf_adjoint_wave2_l96_kernel (round 4: one or two wavefronts per
+    trajectory): every instantiated state dimension 12 .. 40, a random
     selection of 1 .. d observed components in random order, dense symmetric L Qc L^T / R / P0, a random forcing, 1 .. 5 trajectories,
     1 .. 7 observations, intervals from zero length to thirty Runge-Kutta steps (up to four replay chunks of eight starts), both state
     orders -- every leaf against the oracle's discrete adjoint."""
+    monkeypatch.setenv("CDKF_WAVE40_ADJ_WAVES", str(waves))
     rng = np.random.default_rng(777)
     worst = 0.0
     for case in range(14):
@@ -205,7 +208,7 @@ def test_soak_wavefront_reverse_sweep_of_lorenz96(hip_lib):
         order = "second" if case % 2 else "first"
         ll_ref, g_ref, ex = o.ekf_loglik_grad_adjoint(mdl, t, y, full=True, state_order=order)
         ll, g = cd.cdnlgssm_loglik_and_grad_all(params_from(mdl), y, t[..., None], cd.EKFHyperParams(state_order=order))
-        assert _ffi.lib().cdkf_last_kernel().decode().startswith("ekf_adjoint_wave_l96_kernel<double, %d>" % d), case
+        assert _ffi.lib().cdkf_last_kernel().decode().startswith("ekf_adjoint_wave%s_l96_kernel<double, %d>" % ("2" if waves == 2 else "", d)), case
         np.testing.assert_allclose(ll, ll_ref, rtol=1e-9, err_msg=str(case))
         flat = np.concatenate([np.asarray(a_).reshape(N, -1) for a_ in g.dynamics.drift], axis=-1)
         pairs = [(flat, g_ref), (g.initial.mean.params, ex["m0"]), (g.initial.cov.params, ex["P0"]), (g.dynamics.diffusion_coefficient.params, ex["L"]),

@@ -697,14 +697,16 @@ def test_loglik_gradient_with_iterated_updates(hip_lib, kind, d, m, num_iter):
         cd.cdnlgssm_loglik_and_grad_all(params_from(big), np.zeros((2, 4, 4)), np.arange(4.0)[None, :, None].repeat(2, 0), hyp, num_iter=2)
 
 
-@pytest.mark.parametrize("sweep", ["ekf_adjoint_wave_l96_kernel", "ekf_adjoint_wg_kernel"])
+@pytest.mark.parametrize("sweep", ["ekf_adjoint_wave2_l96_kernel", "ekf_adjoint_wave_l96_kernel", "ekf_adjoint_wg_kernel"])
 def test_lorenz96_d40_value_and_gradient(hip_lib, sweep, monkeypatch):
     """BASELINE config 4's model (Lorenz-96, d = m = 40, H = I) can be trained: value and gradient of the EKF log-likelihood w.r.t. the
     forcing and every other parameter -- forward sweep on the wavefront kernel (ekf_filter_wave_l96_kernel), reverse sweep on one
-    wavefront per trajectory too (ekf_adjoint_wave_l96_kernel, round 4: the default) or on the workgroup kernel -- against the
+    or two wavefronts per trajectory (ekf_adjoint_wave_l96_kernel / ekf_adjoint_wave2_l96_kernel, round 4; the latter the default) or on
+    the workgroup kernel -- against the
     oracle's discrete adjoint (value_and_grad of marginal_log_prob, ssm_temissions.py:550-568); then with half of the components
     observed (d = 40, m = 20), the drift block alone, and in fp32."""
     monkeypatch.setenv("CDKF_WAVE40_ADJ", "0" if sweep == "ekf_adjoint_wg_kernel" else "1")
+    monkeypatch.setenv("CDKF_WAVE40_ADJ_WAVES", "1" if sweep == "ekf_adjoint_wave_l96_kernel" else "2")
     rng = np.random.default_rng(440)
     for m in (40, 20):
         mdl = lorenz96_model(40, m)
@@ -764,7 +766,7 @@ def test_reverse_sweep_with_a_scattered_selection_of_observed_components(hip_lib
         ll_ref, g_ref, ex = o.ekf_loglik_grad_adjoint(mdl, t, y, full=True, state_order="first")
         ll, g = cd.cdnlgssm_loglik_and_grad_all(params_from(mdl), y, t[..., None], cd.EKFHyperParams(state_order="first"))
         # (round 4: Lorenz-96 through a selection of components takes the wavefront-per-trajectory reverse sweep)
-        want_kernel = "ekf_adjoint_wave_l96_kernel<double" if (drift == "lorenz96" and variant == "selection") else "ekf_adjoint_wg_kernel<double"
+        want_kernel = "ekf_adjoint_wave2_l96_kernel<double" if (drift == "lorenz96" and variant == "selection") else "ekf_adjoint_wg_kernel<double"
         assert _ffi.lib().cdkf_last_kernel().decode().startswith(want_kernel)
         np.testing.assert_allclose(ll, ll_ref, rtol=1e-10)
         flat = np.concatenate([np.asarray(a_).reshape(N, -1) for a_ in g.dynamics.drift], axis=-1)
@@ -1075,11 +1077,13 @@ def test_wavefront_reverse_sweep_of_lorenz96_at_every_instantiated_width(hip_lib
     hyp = cd.EKFHyperParams(state_order="first")
     ll_ref, g_ref, ex = o.ekf_loglik_grad_adjoint(mdl, t, y, full=True, state_order="first")
     got = {}
-    for which in ("1", "0"):
-        monkeypatch.setenv("CDKF_WAVE40_ADJ", which)
+    for which in ("2", "1", "0"):   # two wavefronts per trajectory (the default), one, the workgroup kernel
+        monkeypatch.setenv("CDKF_WAVE40_ADJ", "0" if which == "0" else "1")
+        monkeypatch.setenv("CDKF_WAVE40_ADJ_WAVES", which if which != "0" else "2")
         ll, g = cd.cdnlgssm_loglik_and_grad_all(params_from(mdl), y, t[..., None], hyp)
         kern = _ffi.lib().cdkf_last_kernel().decode()
-        assert kern.startswith("ekf_adjoint_wave_l96_kernel<double, %d>" % d if which == "1" else "ekf_adjoint_wg_kernel<double"), kern
+        want = {"2": "ekf_adjoint_wave2_l96_kernel<double, %d>" % d, "1": "ekf_adjoint_wave_l96_kernel<double, %d>" % d, "0": "ekf_adjoint_wg_kernel<double"}[which]
+        assert kern.startswith(want), kern
         np.testing.assert_allclose(ll, ll_ref, rtol=1e-10)
         flat = np.concatenate([np.asarray(a_).reshape(N, -1) for a_ in g.dynamics.drift], axis=-1)
         leaves = [flat, g.initial.mean.params, g.initial.cov.params, g.dynamics.diffusion_cov.params, g.emissions.emission_function.weights,
@@ -1088,13 +1092,16 @@ def test_wavefront_reverse_sweep_of_lorenz96_at_every_instantiated_width(hip_lib
             scale = np.abs(b_).max() + 1e-300
             assert np.abs(np.asarray(a_) - b_).max() < 1e-8 * scale, (which, name, np.abs(np.asarray(a_) - b_).max() / scale)
         got[which] = [np.asarray(a_) for a_ in leaves]
-    for a_, b_ in zip(got["1"], got["0"]):
-        assert np.abs(a_ - b_).max() <= 1e-9 * (np.abs(b_).max() + 1e-300)
+    for w_ in ("2", "1"):
+        for a_, b_ in zip(got[w_], got["0"]):
+            assert np.abs(a_ - b_).max() <= 1e-9 * (np.abs(b_).max() + 1e-300)
     # fp32: the forcing's gradient at single-precision accuracy
     monkeypatch.setenv("CDKF_WAVE40_ADJ", "1")
-    ll32, g32 = cd.cdnlgssm_loglik_and_grad(params_from(mdl), y.astype(np.float32), t[..., None], hyp)
-    assert _ffi.lib().cdkf_last_kernel().decode().startswith("ekf_adjoint_wave_l96_kernel<float, %d>" % d)
-    assert np.abs(np.asarray(g32[0]).reshape(N, -1) - g_ref).max() < 5e-3 * np.abs(g_ref).max()
+    for w_ in ("1", "2"):
+        monkeypatch.setenv("CDKF_WAVE40_ADJ_WAVES", w_)
+        ll32, g32 = cd.cdnlgssm_loglik_and_grad(params_from(mdl), y.astype(np.float32), t[..., None], hyp)
+        assert _ffi.lib().cdkf_last_kernel().decode().startswith("ekf_adjoint_wave%s_l96_kernel<float, %d>" % ("2" if w_ == "2" else "", d))
+        assert np.abs(np.asarray(g32[0]).reshape(N, -1) - g_ref).max() < 5e-3 * np.abs(g_ref).max()
 
 
 def test_lorenz96_filter_with_one_factorisation_for_a_diagonal_R(hip_lib, monkeypatch):
