@@ -567,10 +567,42 @@ CDKF_DEV void w40a_sweep(const WgArgs<R>& a, R* __restrict__ grad, R* __restrict
         Lin::template cholesky<1>(sys, scr, v_inv, rowi, ri, lane, quad, logdet, bad);
       }
       W40A_TICK(2)  // factorisation
-      // W2 = (sym S + 1e-9 I)^-1: the D columns of the identity, in place in I2
-      Lin::solve(I2, Lp, v_inv, (const R*)nullptr, lane, [&] {});
+      // W2 = (sym S + 1e-9 I)^-1 = L^-T L^-1: the FORWARD substitution of the D columns of the identity, in place in I2 (row c of the
+      // image = column c of Y = L^-1, which is lower triangular: the blocks' products skip the tiles of right-hand sides that are still
+      // zero) -- the backward substitution is replaced by the product Y^T Y below, which both wavefronts share
+      {
+        constexpr int WL = D % 16 ? D % 16 : 16;
+        R* myrow = I2 + (isrow ? lane : 0) * LDY;
+        R dot = R(0);
+        if constexpr (Lin::NB > 1) {
+          Lin::template sub_block<true, 16>(myrow, Lp, v_inv, (const R*)nullptr, 0, isrow, dot);
+          wave_sync();
+          Lin::template solve_gemm<true, 1, 1>(I2, Lp, lane);
+          wave_sync();
+          if constexpr (Lin::NB > 2) {
+            Lin::template sub_block<true, 16>(myrow, Lp, v_inv, (const R*)nullptr, 16, isrow, dot);
+            wave_sync();
+            Lin::template solve_gemm<true, 2, 3>(I2, Lp, lane);
+            wave_sync();
+            Lin::template sub_block<true, WL>(myrow, Lp, v_inv, (const R*)nullptr, 32, isrow, dot);
+          } else {
+            Lin::template sub_block<true, WL>(myrow, Lp, v_inv, (const R*)nullptr, 16, isrow, dot);
+          }
+        } else {
+          Lin::template sub_block<true, WL>(myrow, Lp, v_inv, (const R*)nullptr, 0, isrow, dot);
+        }
+        wave_sync();
+      }
     }
     if constexpr (NW != 1) sync();
+    {
+      V4 acc[NT];
+      tiles_zero(acc);
+      w40a_mmp<R, D, true, false, 0, NW, H>(acc, rows_of(I2, false).p, rows_of(I2, false).p, blast_ok, obsmask, lg);
+      sync();  // (every read of Y is done)
+      tiles_store(I2, acc);
+    }
+    sync();
     W40A_TICK(3)  // W2
     // X = W2 (E P) -> I3
     {
