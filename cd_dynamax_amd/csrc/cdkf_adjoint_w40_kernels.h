@@ -73,14 +73,19 @@ struct W40A {
 // which owned slots / product tiles wavefront H of NW takes
 template <int NW, int H>
 __host__ __device__ constexpr bool w40a_mine(int q) { return NW == 1 || (q & 1) == H; }
+// ... of a product with a SYMMETRIC result: the tiles on and above the diagonal only (the others are their mirrors), dealt in turn
+template <int NW, int H, int NB>
+__host__ __device__ constexpr bool w40a_mine_sym(int mt, int nt) {
+  return mt <= nt && (NW == 1 || ((mt * NB - mt * (mt - 1) / 2 + (nt - mt)) & 1) == H);
+}
 
 // acc[mt * NB + nt] += sum_k A(16 mt + (lane & 15), k) B(k, 16 nt + (lane & 15)) over k < D (a multiple of four), the operands'
 // addresses formed once: pa[t] walks row 16 t + (lane & 15) of the A image along k (a row that is
 // not there points at a row of zeros); pb[t] walks column 16 t + (lane & 15) of the B image down the rows (BROW = false; a column that
 // is not there is read at column 0 and dropped by blast_ok) or, for a transposed factor, row 16 t + (lane & 15) along k (BROW = true,
-// zeros as for A).  SA: A is scaled by 1, -1, -1/2, 2 (codes 0 .. 3).  MASKK: rows k of B whose state component is not observed
+// zeros as for A).  SYM: the result is symmetric -- only the tiles on and above the diagonal are formed.  SA: A is scaled by 1, -1, -1/2, 2 (codes 0 .. 3).  MASKK: rows k of B whose state component is not observed
 // count as zero.  k is fully unrolled: every read is an immediate offset from its pointer.
-template <typename R, int D, bool BROW, bool MASKK, int SA, int NW, int H, typename Acc>
+template <typename R, int D, bool BROW, bool MASKK, int SA, int NW, int H, bool SYM = false, typename Acc>
 CDKF_DEV void w40a_mmp(Acc& acc, const R* const (&pa)[W40A<R, D>::NB], const R* const (&pb)[W40A<R, D>::NB], const bool blast_ok,
                        const unsigned long long obsmask, const int lg) {
   constexpr int NB = W40A<R, D>::NB, LDY = W40A<R, D>::LDY;
@@ -92,7 +97,7 @@ CDKF_DEV void w40a_mmp(Acc& acc, const R* const (&pa)[W40A<R, D>::NB], const R* 
   for (int mt = 0; mt < NB; ++mt)
 #pragma unroll
     for (int nt = 0; nt < NB; ++nt)
-      if (w40a_mine<NW, H>(mt * NB + nt)) need_a[mt] = need_b[nt] = true;
+      if (SYM ? w40a_mine_sym<NW, H, NB>(mt, nt) : w40a_mine<NW, H>(mt * NB + nt)) need_a[mt] = need_b[nt] = true;
   constexpr R sa = SA == 1 ? R(-1) : (SA == 2 ? R(-0.5) : (SA == 3 ? R(2) : R(1)));
 #pragma unroll
   for (int ks = 0; ks < D / 4; ++ks) {
@@ -116,7 +121,8 @@ CDKF_DEV void w40a_mmp(Acc& acc, const R* const (&pa)[W40A<R, D>::NB], const R* 
     for (int mt = 0; mt < NB; ++mt)
 #pragma unroll
       for (int nt = 0; nt < NB; ++nt)
-        if (w40a_mine<NW, H>(mt * NB + nt)) acc[mt * NB + nt] = wg_mfma(av[mt], bv[nt], acc[mt * NB + nt]);
+        if (SYM ? w40a_mine_sym<NW, H, NB>(mt, nt) : w40a_mine<NW, H>(mt * NB + nt))
+          acc[mt * NB + nt] = wg_mfma(av[mt], bv[nt], acc[mt * NB + nt]);
   }
 }
 
@@ -301,6 +307,34 @@ CDKF_DEV void w40a_sweep(const WgArgs<R>& a, R* __restrict__ grad, R* __restrict
           }
         }
   };
+  // ... of a symmetric matrix held as its tiles on and above the diagonal (w40a_mine_sym): a tile off the diagonal is stored twice
+  auto mineS = [](int mt, int nt) constexpr { return w40a_mine_sym<NW, H, NB>(mt, nt); };
+  auto tilesS_zero = [&](V4 (&acc)[NT]) {
+#pragma unroll
+    for (int mt = 0; mt < NB; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NB; ++nt)
+        if (mineS(mt, nt)) acc[mt * NB + nt] = V4{0, 0, 0, 0};
+  };
+  auto tilesS_store = [&](R* img, const V4 (&acc)[NT]) {
+#pragma unroll
+    for (int mt = 0; mt < NB; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NB; ++nt)
+        if (mineS(mt, nt)) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * mt + Tile::row(lg, r), col = 16 * nt + lm;
+            const bool in = row < D && col < D;
+            R* p = in ? img + row * LDY + col : v_dummy + lane;
+            *p = acc[mt * NB + nt][r];
+            if (mt != nt) {
+              R* q = in ? img + col * LDY + row : v_dummy + lane;
+              *q = acc[mt * NB + nt][r];
+            }
+          }
+        }
+  };
   auto img_at = [&](const R* img, int i, int k) { return i < D ? img[i * LDY + k] : R(0); };  // (k < D by construction)
   // operand walks of the products (w40a_mmp)
   v_zero[lane] = R(0);
@@ -355,6 +389,55 @@ CDKF_DEV void w40a_sweep(const WgArgs<R>& a, R* __restrict__ grad, R* __restrict
           *p = first_ ? acc[t][r] : old[t][r] + acc[t][r];
         }
       }
+  };
+
+  // ... of a symmetric matrix held as its tiles on and above the diagonal: an entry off the diagonal tiles goes to both of its places
+  auto tilesS_accumulate = [&](R* base, const V4 (&acc)[NT], const bool first_, auto&& addr) {
+    int off[NT][4], offm[NT][4];
+    R old[NT][4], oldm[NT][4];
+#pragma unroll
+    for (int mt = 0; mt < NB; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NB; ++nt)
+        if (mineS(mt, nt)) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * mt + Tile::row(lg, r), col = 16 * nt + lm;
+            const bool in = row < D && col < D;
+            off[mt * NB + nt][r] = in ? addr(row, col) : -1;
+            offm[mt * NB + nt][r] = (in && mt != nt) ? addr(col, row) : -1;
+          }
+        }
+    if (!first_) {
+#pragma unroll
+      for (int mt = 0; mt < NB; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NB; ++nt)
+          if (mineS(mt, nt)) {
+            const int t = mt * NB + nt;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              old[t][r] = base[off[t][r] >= 0 ? off[t][r] : 0];
+              if (mt != nt) oldm[t][r] = base[offm[t][r] >= 0 ? offm[t][r] : 0];
+            }
+          }
+    }
+#pragma unroll
+    for (int mt = 0; mt < NB; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NB; ++nt)
+        if (mineS(mt, nt)) {
+          const int t = mt * NB + nt;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            R* p = off[t][r] >= 0 ? base + off[t][r] : wsb + 64 * H + lane;
+            *p = first_ ? acc[t][r] : old[t][r] + acc[t][r];
+            if (mt != nt) {
+              R* q = offm[t][r] >= 0 ? base + offm[t][r] : wsb + 64 * H + lane;
+              *q = first_ ? acc[t][r] : oldm[t][r] + acc[t][r];
+            }
+          }
+        }
   };
 
   // ---- one right-hand side of the moment equations on the stage image (as the forward kernel's) --------------------------------------
@@ -596,11 +679,11 @@ CDKF_DEV void w40a_sweep(const WgArgs<R>& a, R* __restrict__ grad, R* __restrict
     }
     if constexpr (NW != 1) sync();
     {
-      V4 acc[NT];
-      tiles_zero(acc);
-      w40a_mmp<R, D, true, false, 0, NW, H>(acc, rows_of(I2, false).p, rows_of(I2, false).p, blast_ok, obsmask, lg);
+      V4 acc[NT];  // (symmetric: the tiles on and above the diagonal, each stored with its mirror)
+      tilesS_zero(acc);
+      w40a_mmp<R, D, true, false, 0, NW, H, true>(acc, rows_of(I2, false).p, rows_of(I2, false).p, blast_ok, obsmask, lg);
       sync();  // (every read of Y is done)
-      tiles_store(I2, acc);
+      tilesS_store(I2, acc);
     }
     sync();
     W40A_TICK(3)  // W2
@@ -665,13 +748,14 @@ CDKF_DEV void w40a_sweep(const WgArgs<R>& a, R* __restrict__ grad, R* __restrict
     }
     W40A_TICK(6)  // X Pb, (E P) Pb, Kb
     // Sbar = -(X Pb) X^T + w w^T / 2 - S^-1 / 2 - sym(X Ub^T);  S^-1 = W2 + 1e-9 W2 W2
-    tiles_zero(accS);
-    w40a_mmp<R, D, true, false, 0, NW, H>(accS, rows_of(I2, false).p, rows_of(I2, false).p, blast_ok, obsmask, lg);  // (W2 is symmetric)
+    // (Sbar is symmetric, and so is every term of it: its tiles on and above the diagonal only -- w40a_mine_sym)
+    tilesS_zero(accS);
+    w40a_mmp<R, D, true, false, 0, NW, H, true>(accS, rows_of(I2, false).p, rows_of(I2, false).p, blast_ok, obsmask, lg);  // (W2 is symmetric)
 #pragma unroll
     for (int mt = 0; mt < NB; ++mt)
 #pragma unroll
       for (int nt = 0; nt < NB; ++nt)
-        if (mine(mt * NB + nt)) {
+        if (mineS(mt, nt)) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int row = 16 * mt + Tile::row(lg, r), col = 16 * nt + lm;
@@ -681,7 +765,7 @@ CDKF_DEV void w40a_sweep(const WgArgs<R>& a, R* __restrict__ grad, R* __restrict
           }
         }
     sync();  // (X Pb is in I1)
-    w40a_mmp<R, D, true, false, 1, NW, H>(accS, rows_of(I1, false).p, rows_of(I3, false).p, blast_ok, obsmask, lg);
+    w40a_mmp<R, D, true, false, 1, NW, H, true>(accS, rows_of(I1, false).p, rows_of(I3, false).p, blast_ok, obsmask, lg);
     sync();
     tiles_store(I1, accK);  // Kb
     sync();
@@ -696,15 +780,15 @@ CDKF_DEV void w40a_sweep(const WgArgs<R>& a, R* __restrict__ grad, R* __restrict
     }
     sync();
     W40A_TICK(8)  // Ub
-    w40a_mmp<R, D, true, false, 2, NW, H>(accS, rows_of(I3, false).p, rows_of(I2, false).p, blast_ok, obsmask, lg);
-    w40a_mmp<R, D, true, false, 2, NW, H>(accS, rows_of(I2, false).p, rows_of(I3, false).p, blast_ok, obsmask, lg);
+    w40a_mmp<R, D, true, false, 2, NW, H, true>(accS, rows_of(I3, false).p, rows_of(I2, false).p, blast_ok, obsmask, lg);
+    w40a_mmp<R, D, true, false, 2, NW, H, true>(accS, rows_of(I2, false).p, rows_of(I3, false).p, blast_ok, obsmask, lg);
     // model block: dR += Sbar (the observed pairs)
     if (gm)
-      tiles_accumulate(gR, accS, first, [&](int row, int col) {
+      tilesS_accumulate(gR, accS, first, [&](int row, int col) {
         const int orow = obs[row], ocol = obs[col];
         return (orow >= 0 && ocol >= 0) ? orow * M + ocol : -1;
       });
-    tiles_store(I1, accS);  // Sbar (Kb is dead: Ub was formed behind a synchronisation)
+    tilesS_store(I1, accS);  // Sbar (Kb is dead: Ub was formed behind a synchronisation)
     sync();
     W40A_TICK(9)  // X Ub^T, Ub X^T, dR
     if (gm) {  // dH += 2 Sbar (E P) - vbar m^T + Ub P; dbias -= vbar
@@ -1047,9 +1131,10 @@ __global__ __launch_bounds__(128) void ekf_adjoint_wave_l96_kernel(const WgArgs<
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   w40a_sweep<R, D, 1, 0>(a, grad, grad_model, ws, ws_stride, cap, smem_raw);
 }
-// two wavefronts per trajectory, one trajectory per workgroup (two workgroups per CU)
+// two wavefronts per trajectory, one trajectory per workgroup (two workgroups per CU in fp64; fp32: the LDS admits more, and the
+// instantiation is held to 256 registers -- two wavefronts per SIMD -- which it needs by a handful only)
 template <typename R, int D>
-__global__ __launch_bounds__(128) void ekf_adjoint_wave2_l96_kernel(const WgArgs<R> a, R* __restrict__ grad, R* __restrict__ grad_model,
+__global__ __launch_bounds__(128, (sizeof(R) == 4 ? 2 : 1)) void ekf_adjoint_wave2_l96_kernel(const WgArgs<R> a, R* __restrict__ grad, R* __restrict__ grad_model,
                                                                      R* __restrict__ ws, const long ws_stride, const int cap) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   if (threadIdx.x < 64)
