@@ -462,13 +462,15 @@ CDKF_DEV void w40a_sweep(const WgArgs<R>& a, R* __restrict__ grad, R* __restrict
     typedef R Pair __attribute__((ext_vector_type(2)));
     Pair* cab = reinterpret_cast<Pair*>(__builtin_assume_aligned(v_ca, 16));
     kM = R(0);
-    if constexpr (LEAD) {
+    if constexpr (NW == 1 || H == 1) {  // (two wavefronts: the second copies the halo while the first forms the coefficients)
       for (int e = lane; e < 3 * D; e += 64) {  // halo: rows -2, -1 <- D-2, D-1; row D <- 0; the same for the columns
         const int r = (e >= 2 * D) ? 2 : (e >= D ? 1 : 0), c = e - r * D;
         const int src = (r == 2) ? 0 : D - 2 + r, dst = (r == 2) ? D : r - 2;
         S0[(dst + 2) * LDP + (c + 2)] = S0[(src + 2) * LDP + (c + 2)];
         S0[(c + 2) * LDP + (dst + 2)] = S0[(c + 2) * LDP + (src + 2)];
       }
+    }
+    if constexpr (LEAD) {
       if (isrow) {
         const R xp1 = v_xs[lp1], xm1 = v_xs[lm1], xm2 = v_xs[lm2];
         cab[lane] = Pair{xm1, xp1 - xm2};
@@ -951,7 +953,7 @@ CDKF_DEV void w40a_sweep(const WgArgs<R>& a, R* __restrict__ grad, R* __restrict
           }
           W40A_TICK(18)  // (stage: cotangent, input, images)
           sync();
-          if constexpr (LEAD) {
+          if constexpr (NW == 1 || H == 1) {
             for (int e = lane; e < 3 * D; e += 64) {  // halo of Lam: rows / columns -1 <- D-1, D <- 0, D+1 <- 1
               const int r = (e >= 2 * D) ? 2 : (e >= D ? 1 : 0), c = e - r * D;
               const int src = (r == 0) ? D - 1 : r - 1, dst = (r == 0) ? -1 : D + r - 1;
