@@ -1024,7 +1024,7 @@ CDKF_DEV void w40a_sweep(const WgArgs<R>& a, R* __restrict__ grad, R* __restrict
           W40A_TICK(15)  // (stage: stencil)
           // the state's cotangent: sum_ij (2 Lam Ps)_ij dF_ij/dx_k = 2 sum_c { Lam[k+1][c] (Ps[c][k+2] - Ps[c][k-1]) + Lam[k-1][c] Ps[c][k-2]
           //                                                                      - Lam[k+2][c] Ps[c][k+1] }   (both symmetric: rows of the images)
-          // (NW = 2: the first wavefront takes the first sum, the second the other two and hands its part over through v_u)
+          // (NW = 2: each wavefront takes half of the columns of all three sums; the second hands its part over through v_u)
           R xpart = R(0);
           if (isrow) {
             const R* l1 = S0 + (lane + 3) * LDP + 2;  // row k+1 (halo row D at k = D-1)
@@ -1042,20 +1042,16 @@ CDKF_DEV void w40a_sweep(const WgArgs<R>& a, R* __restrict__ grad, R* __restrict
             const Pair* q3 = reinterpret_cast<const Pair*>(__builtin_assume_aligned(p3, 16));
             const Pair* q4 = reinterpret_cast<const Pair*>(__builtin_assume_aligned(p4, 16));
             R g0 = R(0), g1 = R(0), g2 = R(0), h0 = R(0), h1 = R(0), h2 = R(0);
+            constexpr int c_lo = (NW == 1 || H == 0) ? 0 : D / 4, c_hi = (NW == 1 || H == 1) ? D / 2 : D / 4;  // (pairs of columns)
 #pragma unroll 2
-            for (int c = 0; c < D / 2; ++c) {
-              if constexpr (NW == 1 || H == 0) {
-                const Pair a1 = q1[c], a2 = q2[c];
-                g0 = rfma(l1[2 * c], a1[0] - a2[0], g0);
-                h0 = rfma(l1[2 * c + 1], a1[1] - a2[1], h0);
-              }
-              if constexpr (NW == 1 || H == 1) {
-                const Pair a3 = q3[c], a4 = q4[c];
-                g1 = rfma(l2[2 * c], a3[0], g1);
-                h1 = rfma(l2[2 * c + 1], a3[1], h1);
-                g2 = rfma(l3[2 * c], a4[0], g2);
-                h2 = rfma(l3[2 * c + 1], a4[1], h2);
-              }
+            for (int c = c_lo; c < c_hi; ++c) {
+              const Pair a1 = q1[c], a2 = q2[c], a3 = q3[c], a4 = q4[c];
+              g0 = rfma(l1[2 * c], a1[0] - a2[0], g0);
+              h0 = rfma(l1[2 * c + 1], a1[1] - a2[1], h0);
+              g1 = rfma(l2[2 * c], a3[0], g1);
+              h1 = rfma(l2[2 * c + 1], a3[1], h1);
+              g2 = rfma(l3[2 * c], a4[0], g2);
+              h2 = rfma(l3[2 * c + 1], a4[1], h2);
             }
             xpart = R(2) * (((g0 + h0) + (g1 + h1)) - (g2 + h2));
           }
