@@ -307,6 +307,18 @@ CDKF_DEV void w40a_sweep(const WgArgs<R>& a, R* __restrict__ grad, R* __restrict
           }
         }
   };
+  auto tiles_store_all = [&](R* img, const V4 (&acc)[NT]) {  // (every tile: a product one wavefront formed alone)
+#pragma unroll
+    for (int mt = 0; mt < NB; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NB; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * mt + Tile::row(lg, r), col = 16 * nt + lm;
+          R* p = (row < D && col < D) ? img + row * LDY + col : v_dummy + lane;
+          *p = acc[mt * NB + nt][r];
+        }
+  };
   // ... of a symmetric matrix held as its tiles on and above the diagonal (w40a_mine_sym): a tile off the diagonal is stored twice
   auto mineS = [](int mt, int nt) constexpr { return w40a_mine_sym<NW, H, NB>(mt, nt); };
   auto tilesS_zero = [&](V4 (&acc)[NT]) {
@@ -679,7 +691,17 @@ CDKF_DEV void w40a_sweep(const WgArgs<R>& a, R* __restrict__ grad, R* __restrict
         wave_sync();
       }
     }
-    if constexpr (NW != 1) sync();
+    // G = (E P) Pbar -> I3, ALL of it on one wavefront: with two per trajectory the second forms it while the first factors and
+    // substitutes (nothing else is ready for it), and S X Pbar = G - 1e-9 X Pbar with X Pbar = W2 G needs neither X nor Pbar's image
+    // any more -- the product (E P) Pbar leaves the shared part of the step
+    if constexpr (NW == 1 || H == 1) {
+      V4 accG[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) accG[t] = V4{0, 0, 0, 0};
+      w40a_mmp<R, D, false, false, 0, 1, 0>(accG, rows_of(I0, true).p, cols_of(I1).p, blast_ok, obsmask, lg);
+      tiles_store_all(I3, accG);
+    }
+    sync();
     {
       V4 acc[NT];  // (symmetric: the tiles on and above the diagonal, each stored with its mirror)
       tilesS_zero(acc);
@@ -689,12 +711,12 @@ CDKF_DEV void w40a_sweep(const WgArgs<R>& a, R* __restrict__ grad, R* __restrict
     }
     sync();
     W40A_TICK(3)  // W2
-    // X = W2 (E P) -> I3
+    // X = W2 (E P) -> I1 (Pbar's image is dead: G is formed)
     {
       V4 acc[NT];
       tiles_zero(acc);
       w40a_mmp<R, D, false, true, 0, NW, H>(acc, rows_of(I2, false).p, cols_of(I0).p, blast_ok, obsmask, lg);
-      tiles_store(I3, acc);
+      tiles_store(I1, acc);
     }
     sync();
     W40A_TICK(4)  // X
@@ -704,7 +726,7 @@ CDKF_DEV void w40a_sweep(const WgArgs<R>& a, R* __restrict__ grad, R* __restrict
       R u1 = R(0), tx = R(0);
       if (isrow) {
         const R* w2r = I2 + lane * LDY;
-        const R* xr = I3 + lane * LDY;
+        const R* xr = I1 + lane * LDY;
 #pragma unroll 4
         for (int c = 0; c < D; ++c) {
           u1 = rfma(w2r[c], v_v[c], u1);
@@ -725,16 +747,12 @@ CDKF_DEV void w40a_sweep(const WgArgs<R>& a, R* __restrict__ grad, R* __restrict
       v_vb[lane] = vb;
     }
     W40A_TICK(5)  // w, vbar
-    // X Pb and (E P) Pb;  Kb = v mbar^T - 2 S X Pb,  S X = E P - 1e-9 X
+    // X Pb = W2 G;  Kb = v mbar^T - 2 S X Pb,  S X Pb = G - 1e-9 X Pb
     V4 accK[NT], accS[NT];
     {
       V4 accX[NT];
       tiles_zero(accX);
-      tiles_zero(accK);
-      w40a_mmp<R, D, false, false, 0, NW, H>(accX, rows_of(I3, false).p, cols_of(I1).p, blast_ok, obsmask, lg);
-      w40a_mmp<R, D, false, false, 0, NW, H>(accK, rows_of(I0, true).p, cols_of(I1).p, blast_ok, obsmask, lg);
-      sync();  // (every read of Pbar's image is done; v_w / v_vb are visible)
-      tiles_store(I1, accX);  // X Pb
+      w40a_mmp<R, D, false, false, 0, NW, H>(accX, rows_of(I2, false).p, cols_of(I3).p, blast_ok, obsmask, lg);
 #pragma unroll
       for (int mt = 0; mt < NB; ++mt)
 #pragma unroll
@@ -744,9 +762,12 @@ CDKF_DEV void w40a_sweep(const WgArgs<R>& a, R* __restrict__ grad, R* __restrict
             for (int r = 0; r < 4; ++r) {
               const int row = 16 * mt + Tile::row(lg, r), col = 16 * nt + lm;
               const int t = mt * NB + nt;
-              accK[t][r] = rfma(R(-2), rfma(R(-1e-9), accX[t][r], accK[t][r]), v_v[row] * v_mb[col]);
+              const R gel = (row < D && col < D) ? I3[row * LDY + col] : R(0);
+              accK[t][r] = rfma(R(-2), rfma(R(-1e-9), accX[t][r], gel), v_v[row] * v_mb[col]);
             }
           }
+      sync();  // (every read of G is done; v_w / v_vb are visible)
+      tiles_store(I3, accX);  // X Pb
     }
     W40A_TICK(6)  // X Pb, (E P) Pb, Kb
     // Sbar = -(X Pb) X^T + w w^T / 2 - S^-1 / 2 - sym(X Ub^T);  S^-1 = W2 + 1e-9 W2 W2
@@ -766,37 +787,37 @@ CDKF_DEV void w40a_sweep(const WgArgs<R>& a, R* __restrict__ grad, R* __restrict
             accS[t][r] = R(0.5) * (v_w[row] * v_w[col] - rfma(R(1e-9), accS[t][r], w2));
           }
         }
-    sync();  // (X Pb is in I1)
-    w40a_mmp<R, D, true, false, 1, NW, H, true>(accS, rows_of(I1, false).p, rows_of(I3, false).p, blast_ok, obsmask, lg);
+    sync();  // (X Pb is in I3)
+    w40a_mmp<R, D, true, false, 1, NW, H, true>(accS, rows_of(I3, false).p, rows_of(I1, false).p, blast_ok, obsmask, lg);
     sync();
-    tiles_store(I1, accK);  // Kb
+    tiles_store(I3, accK);  // Kb
     sync();
     W40A_TICK(7)  // W2 W2, (X Pb) X^T
     // Ub = W2 Kb -> I2 (over the then dead W2)
     {
       V4 accU[NT];
       tiles_zero(accU);
-      w40a_mmp<R, D, false, false, 0, NW, H>(accU, rows_of(I2, false).p, cols_of(I1).p, blast_ok, obsmask, lg);
+      w40a_mmp<R, D, false, false, 0, NW, H>(accU, rows_of(I2, false).p, cols_of(I3).p, blast_ok, obsmask, lg);
       sync();
       tiles_store(I2, accU);
     }
     sync();
     W40A_TICK(8)  // Ub
-    w40a_mmp<R, D, true, false, 2, NW, H, true>(accS, rows_of(I3, false).p, rows_of(I2, false).p, blast_ok, obsmask, lg);
-    w40a_mmp<R, D, true, false, 2, NW, H, true>(accS, rows_of(I2, false).p, rows_of(I3, false).p, blast_ok, obsmask, lg);
+    w40a_mmp<R, D, true, false, 2, NW, H, true>(accS, rows_of(I1, false).p, rows_of(I2, false).p, blast_ok, obsmask, lg);
+    w40a_mmp<R, D, true, false, 2, NW, H, true>(accS, rows_of(I2, false).p, rows_of(I1, false).p, blast_ok, obsmask, lg);
     // model block: dR += Sbar (the observed pairs)
     if (gm)
       tilesS_accumulate(gR, accS, first, [&](int row, int col) {
         const int orow = obs[row], ocol = obs[col];
         return (orow >= 0 && ocol >= 0) ? orow * M + ocol : -1;
       });
-    tilesS_store(I1, accS);  // Sbar (Kb is dead: Ub was formed behind a synchronisation)
+    tilesS_store(I3, accS);  // Sbar (Kb is dead: Ub was formed behind a synchronisation)
     sync();
     W40A_TICK(9)  // X Ub^T, Ub X^T, dR
     if (gm) {  // dH += 2 Sbar (E P) - vbar m^T + Ub P; dbias -= vbar
       V4 accH[NT];
       tiles_zero(accH);
-      w40a_mmp<R, D, false, true, 3, NW, H>(accH, rows_of(I1, false).p, cols_of(I0).p, blast_ok, obsmask, lg);
+      w40a_mmp<R, D, false, true, 3, NW, H>(accH, rows_of(I3, false).p, cols_of(I0).p, blast_ok, obsmask, lg);
       w40a_mmp<R, D, false, false, 0, NW, H>(accH, rows_of(I2, false).p, cols_of(I0).p, blast_ok, obsmask, lg);
 #pragma unroll
       for (int mt = 0; mt < NB; ++mt)
@@ -824,7 +845,7 @@ CDKF_DEV void w40a_sweep(const WgArgs<R>& a, R* __restrict__ grad, R* __restrict
         const unsigned wA = tabA[64 * s + lane];
         const bool obs_i = (wA >> 16) & 1u, obs_j = (wA >> 17) & 1u;
         const R uij = obs_j ? I2[f.yt] : R(0), uji = obs_i ? I2[f.y] : R(0);
-        Pb[s] = PbG[64 * s + lane] + rfma(R(0.5), uij + uji, (obs_i && obs_j) ? I1[f.y] : R(0));
+        Pb[s] = PbG[64 * s + lane] + rfma(R(0.5), uij + uji, (obs_i && obs_j) ? I3[f.y] : R(0));
       }
     mb -= vb;  // (zero on the second wavefront)
     sync();
