@@ -1043,45 +1043,54 @@ CDKF_DEV void w40a_sweep(const WgArgs<R>& a, R* __restrict__ grad, R* __restrict
             __builtin_amdgcn_sched_barrier(0);
           }
           W40A_TICK(15)  // (stage: stencil)
-          // the state's cotangent: sum_ij (2 Lam Ps)_ij dF_ij/dx_k = 2 sum_c { Lam[k+1][c] (Ps[c][k+2] - Ps[c][k-1]) + Lam[k-1][c] Ps[c][k-2]
-          //                                                                      - Lam[k+2][c] Ps[c][k+1] }   (both symmetric: rows of the images)
-          // (NW = 2: each wavefront takes half of the columns of all three sums; the second hands its part over through v_u)
-          R xpart = R(0);
-          if (isrow) {
-            const R* l1 = S0 + (lane + 3) * LDP + 2;  // row k+1 (halo row D at k = D-1)
-            const R* l2 = S0 + (lane + 1) * LDP + 2;  // row k-1 (halo row -1 at k = 0)
-            const R* l3 = S0 + (lane + 4) * LDP + 2;  // row k+2 (halo rows D, D+1)
-            const R* p1 = PsI + lp2 * LDY;
-            const R* p2 = PsI + lm1 * LDY;
-            const R* p3 = PsI + lm2 * LDY;
-            const R* p4 = PsI + lp1 * LDY;
-            // (the stage covariance's rows start on 16-byte boundaries -- LDY is even: two columns per read; the cotangent image's
-            //  leading dimension is odd)
-            typedef R Pair __attribute__((ext_vector_type(2)));
-            const Pair* q1 = reinterpret_cast<const Pair*>(__builtin_assume_aligned(p1, 16));
-            const Pair* q2 = reinterpret_cast<const Pair*>(__builtin_assume_aligned(p2, 16));
-            const Pair* q3 = reinterpret_cast<const Pair*>(__builtin_assume_aligned(p3, 16));
-            const Pair* q4 = reinterpret_cast<const Pair*>(__builtin_assume_aligned(p4, 16));
-            R g0 = R(0), g1 = R(0), g2 = R(0), h0 = R(0), h1 = R(0), h2 = R(0);
-            constexpr int c_lo = (NW == 1 || H == 0) ? 0 : D / 4, c_hi = (NW == 1 || H == 1) ? D / 2 : D / 4;  // (pairs of columns)
+          // the state's cotangent: sum_ij (2 Lam Ps)_ij dF_ij/dx_k = 2 (M[k+1][k+2] - M[k+1][k-1] + M[k-1][k-2] - M[k+2][k+1]),  M = Lam Ps.
+          // Lane i forms the three entries of ROW i of M that this needs from any lane -- b1 = M[i][i+1], b2 = M[i][i-2], b3 = M[i][i-1]:
+          // one row of Lam against three rows of the (symmetric) stage covariance, 4 D reads per lane where three rows of Lam against
+          // four of Ps for the four entries of lane k's own sum took 7 D; the LDS pipe, which the four wavefronts of a CU share, is what
+          // bounds this phase -- and the lanes exchange the entries through vectors behind the stage's last synchronisation.
+          // (NW = 2: each wavefront takes half of the columns; the partial entries of both meet in the same exchange)
+          {
+            R b1 = R(0), b2 = R(0), b3 = R(0);
+            if (isrow) {
+              const R* lr = S0 + (lane + 2) * LDP + 2;  // row i of Lam (odd leading dimension: one column per read)
+              // (the stage covariance's rows start on 16-byte boundaries -- LDY is even: two columns per read)
+              typedef R Pair __attribute__((ext_vector_type(2)));
+              const Pair* q1 = reinterpret_cast<const Pair*>(__builtin_assume_aligned(PsI + lp1 * LDY, 16));
+              const Pair* q2 = reinterpret_cast<const Pair*>(__builtin_assume_aligned(PsI + lm2 * LDY, 16));
+              const Pair* q3 = reinterpret_cast<const Pair*>(__builtin_assume_aligned(PsI + lm1 * LDY, 16));
+              R e1 = R(0), e2 = R(0), e3 = R(0);
+              constexpr int c_lo = (NW == 1 || H == 0) ? 0 : D / 4, c_hi = (NW == 1 || H == 1) ? D / 2 : D / 4;  // (pairs of columns)
 #pragma unroll 2
-            for (int c = c_lo; c < c_hi; ++c) {
-              const Pair a1 = q1[c], a2 = q2[c], a3 = q3[c], a4 = q4[c];
-              g0 = rfma(l1[2 * c], a1[0] - a2[0], g0);
-              h0 = rfma(l1[2 * c + 1], a1[1] - a2[1], h0);
-              g1 = rfma(l2[2 * c], a3[0], g1);
-              h1 = rfma(l2[2 * c + 1], a3[1], h1);
-              g2 = rfma(l3[2 * c], a4[0], g2);
-              h2 = rfma(l3[2 * c + 1], a4[1], h2);
+              for (int c = c_lo; c < c_hi; ++c) {
+                const Pair a1 = q1[c], a2 = q2[c], a3 = q3[c];
+                const R la = lr[2 * c], lb = lr[2 * c + 1];
+                b1 = rfma(la, a1[0], b1);
+                e1 = rfma(lb, a1[1], e1);
+                b2 = rfma(la, a2[0], b2);
+                e2 = rfma(lb, a2[1], e2);
+                b3 = rfma(la, a3[0], b3);
+                e3 = rfma(lb, a3[1], e3);
+              }
+              b1 += e1;
+              b2 += e2;
+              b3 += e3;
             }
-            xpart = R(2) * (((g0 + h0) + (g1 + h1)) - (g2 + h2));
+            // (vectors of the update, free during the predict: v_v / v_w / v_vb the first wavefront's entries, v_u / v_m / v_inv the second's)
+            (LEAD ? v_v : v_u)[lane] = b1;
+            (LEAD ? v_w : v_m)[lane] = b2;
+            (LEAD ? v_vb : v_inv)[lane] = b3;
           }
-          if constexpr (NW != 1 && !LEAD) v_u[lane] = xpart;
           W40A_TICK(16)  // (stage: dot products)
-          sync();  // the images are rewritten by the next stage; the second wavefront's part of the state's cotangent is visible
+          sync();  // the images are rewritten by the next stage; the entries of M are visible
           if constexpr (LEAD) {  // the mean's part of the sums
-            xbar += xpart;
-            if constexpr (NW != 1) xbar += v_u[lane];
+            if (isrow) {
+              R m12 = v_v[lp1] - v_w[lp1], m3 = v_vb[lm1] - v_vb[lp2];
+              if constexpr (NW != 1) {
+                m12 += v_u[lp1] - v_m[lp1];
+                m3 += v_inv[lm1] - v_inv[lp2];
+              }
+              xbar = rfma(R(2), m12 + m3, xbar);
+            }
 #pragma unroll
             for (int j = 0; j < 5; ++j)
               if (j < i) accm[j] = rfma(T::a[i][j], xbar, accm[j]);
