@@ -159,14 +159,29 @@ template <typename S, int N>
 __device__ inline Dual<S, N> fabs(const Dual<S, N>& a) { return (a.v < S(0.0)) ? -a : a; }
 // a^c for a constant exponent; a^b = exp(b log a) otherwise
 template <typename S, int N>
+__device__ inline Dual<S, N> pow(const Dual<S, N>& a, int c);
+template <typename S, int N>
 __device__ inline Dual<S, N> pow(const Dual<S, N>& a, double c) {
+  if (c >= 0.0 && c <= 16.0 && c == (double)(int)c) return pow(a, (int)c);  // (a whole exponent: by multiplications, below)
   const S pv = S(pow(a.v, c)), dv = S(c) * S(pow(a.v, c - 1.0));  // (pow(float, double) is a double: back to the inner type)
   return dual_chain(a, pv, dv);
 }
 template <typename S, int N>
 __device__ inline Dual<S, N> pow(const Dual<S, N>& a, float c) { return pow(a, (double)c); }
+// a^c for a small whole exponent: by multiplications (exact derivatives of every order the nesting asks for, and no call into the
+// maths library: the library's pow is not inlined into the larger run-time compiled kernels)
 template <typename S, int N>
-__device__ inline Dual<S, N> pow(const Dual<S, N>& a, int c) { return pow(a, (double)c); }
+__device__ inline Dual<S, N> pow(const Dual<S, N>& a, int c) {
+  if (c >= 0 && c <= 16) {
+    Dual<S, N> r(1.0), b = a;
+    for (int e = c; e; e >>= 1) {
+      if (e & 1) r *= b;
+      if (e >> 1) b *= b;
+    }
+    return r;
+  }
+  return pow(a, (double)c);
+}
 template <typename S, int N>
 __device__ inline Dual<S, N> pow(const Dual<S, N>& a, const Dual<S, N>& b) { return exp(b * log(a)); }
 

@@ -171,6 +171,25 @@ std::string rtc_cache_dir() {
   return dir;
 }
 
+// Compiler options every run-time compilation gets beside its optimisation level (part of the cache key).  CDKF_RTC_EXTRA_OPTS
+// (space-separated; a debugging aid) adds to them.
+std::vector<std::string> rtc_extra_options() {
+  std::vector<std::string> v;
+  if (const char* e = getenv("CDKF_RTC_EXTRA_OPTS")) {
+    std::string cur;
+    for (const char* p = e;; ++p) {
+      if (*p == ' ' || *p == '\0') {
+        if (!cur.empty()) v.push_back(cur);
+        cur.clear();
+        if (!*p) break;
+      } else {
+        cur.push_back(*p);
+      }
+    }
+  }
+  return v;
+}
+
 std::string rtc_cache_key(const std::string& src, const std::string& arch, const char* olevel, const std::string& expr) {
   Fnv128 h;
   int maj = 0, min = 0;
@@ -178,6 +197,7 @@ std::string rtc_cache_key(const std::string& src, const std::string& arch, const
   const std::string meta = "cdkf-rtc-1|" + arch + "|" + olevel + "|hiprtc " + std::to_string(maj) + "." + std::to_string(min) + "|" +
                            rtc_headers_digest() + "|" + expr;
   h.feed(meta);
+  for (const std::string& x : rtc_extra_options()) h.feed("|" + x);
   h.feed(src);
   char out[40];
   snprintf(out, sizeof(out), "%016llx%016llx", (unsigned long long)h.a, (unsigned long long)h.b);
@@ -380,10 +400,17 @@ int compile_variant(const CustomDrift& c, const Key& key, const std::string& arc
   }
   const std::string src = generate_source(c, std::get<1>(key), std::get<2>(key), std::get<3>(key), std::get<4>(key),
                                           std::get<5>(key), std::get<6>(key), std::get<7>(key), ek ? &em : nullptr);
-  const std::string cache_key = rtc_cache_key(src, arch, "-O3", "cdkf_custom_kernel");
+  // The forward-sensitivity sweep (algorithm 2) from four state dimensions on is built at -O1: there the kernel sits at all 512 registers
+  // plus 0.6 - 2.6 KB of scratch per lane, and at -O2 / -O3 (ROCm 7.2 hipRTC, gfx950) some builds of the d = 6 instantiation return a wrong
+  // d ll / d theta -- deterministic per build, flipping with spellings of the drift that generate the same arithmetic (`pow(x, 2)` against
+  // `pow(x, 2.0)` against `x * x`), no calls in the code object, not the VGPR-to-AGPR spilling (-amdgpu-spill-vgpr-to-agpr=0: the same
+  // numbers); -O1 is right in every case tried (scripts/dbg_custom_pow.py, NOTES.md R4.7; found by scripts/gpu_fuzz_custom.py seed 40404).
+  // The same family as launch_wg8.hip's -O1 and the lost accumulator of DESIGN.md section 5.1 (ii): large spill-heavy kernels.
+  const char* olevel = (std::get<6>(key) == 2 && c.d >= 4) ? "-O1" : "-O3";
+  const std::string cache_key = rtc_cache_key(src, arch, olevel, "cdkf_custom_kernel");
   {
     std::string unused;
-    if (rtc_cache_load(cache_key, code, unused)) return CDKF_OK;
+    if (!getenv("CDKF_CUSTOM_DUMP") && rtc_cache_load(cache_key, code, unused)) return CDKF_OK;
   }
   hiprtcProgram prog = nullptr;
   if (hiprtcCreateProgram(&prog, src.c_str(), "cdkf_custom_drift.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
@@ -391,8 +418,10 @@ int compile_variant(const CustomDrift& c, const Key& key, const std::string& arc
     return CDKF_EHIP;
   }
   const std::string inc = "-I" + source_dir(), off = "--offload-arch=" + arch;
-  const char* opts[] = {off.c_str(), "-O3", "-std=c++17", inc.c_str(), "-Wno-pass-failed"};
-  const hiprtcResult res = hiprtcCompileProgram(prog, 5, opts);
+  const std::vector<std::string> extra = rtc_extra_options();
+  std::vector<const char*> opts = {off.c_str(), olevel, "-std=c++17", inc.c_str(), "-Wno-pass-failed"};
+  for (const std::string& x : extra) opts.push_back(x.c_str());
+  const hiprtcResult res = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
   if (res != HIPRTC_SUCCESS) {
     size_t n = 0;
     hiprtcGetProgramLogSize(prog, &n);
@@ -417,6 +446,18 @@ int compile_variant(const CustomDrift& c, const Key& key, const std::string& arc
   hiprtcGetCode(prog, code.data());
   hiprtcDestroyProgram(&prog);
   rtc_cache_store(cache_key, code, std::string());
+  if (const char* dir = getenv("CDKF_CUSTOM_DUMP")) {  // debugging aid: the generated source and its code object
+    const std::string base = std::string(dir) + "/cdkf_custom_reg_" + std::to_string(std::get<1>(key)) + "_m" + std::to_string(std::get<2>(key)) + "_" +
+                             std::to_string(std::get<3>(key)) + "_" + std::to_string(std::get<4>(key)) + "_" + std::to_string(std::get<6>(key)) + "_" + cache_key.substr(0, 8);
+    if (FILE* f = fopen((base + ".hip").c_str(), "w")) {
+      fwrite(src.data(), 1, src.size(), f);
+      fclose(f);
+    }
+    if (FILE* f = fopen((base + ".co").c_str(), "wb")) {
+      fwrite(code.data(), 1, code.size(), f);
+      fclose(f);
+    }
+  }
   return CDKF_OK;
 }
 
@@ -682,8 +723,10 @@ int compile_wg_variant(const CustomDrift& c, const WgKey& key, const std::string
   // (the instantiations with eight or more entries per thread are built at -O1 in the library too: launch_wg8.hip, Makefile)
   const std::string inc = "-I" + source_dir(), off = "--offload-arch=" + arch;
   // -O1: the wg kernels' instantiations with eight or more entries per thread, as in the library (launch_wg8.hip, Makefile)
-  const char* opts[] = {off.c_str(), olevel, "-std=c++17", inc.c_str(), "-Wno-pass-failed"};
-  const hiprtcResult res = hiprtcCompileProgram(prog, 5, opts);
+  const std::vector<std::string> extra = rtc_extra_options();
+  std::vector<const char*> opts = {off.c_str(), olevel, "-std=c++17", inc.c_str(), "-Wno-pass-failed"};
+  for (const std::string& x : extra) opts.push_back(x.c_str());
+  const hiprtcResult res = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
   if (res != HIPRTC_SUCCESS) {
     size_t n = 0;
     hiprtcGetProgramLogSize(prog, &n);

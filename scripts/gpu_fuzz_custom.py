@@ -40,6 +40,9 @@ for case in range(cases):
         d = int(os.environ["CDKF_FUZZ_D"])
         m = min(m, d + 4)
     src, make = random_quadratic_drift(rng, d)
+    if os.environ.get("CDKF_FUZZ_NOPOW"):  # (debugging aid: the same drift without pow(), or -- "2.0" -- with the library's pow)
+        import re
+        src = re.sub(r"pow\((x\[\d+\]), 2\)", r"pow(\1, 2.0)" if os.environ["CDKF_FUZZ_NOPOW"] == "2.0" else r"(\1 * \1)", src)
     theta = np.array([0.5 + 0.5 * rng.random(), 0.2 * rng.standard_normal()])
     if rng.random() < 0.4 and m <= d:
         H, bias = np.eye(d)[rng.permutation(d)[:m]], np.zeros(m)
@@ -83,6 +86,10 @@ for case in range(cases):
     note("grad_all", max(max(np.abs(np.asarray(a_) - b_).max() / scale for a_, b_ in pairs), relerr(ll, ll_ref)), 1e-7, tag)
     ll, g1 = cd.cdnlgssm_loglik_and_grad(Pn, y, t[..., None], hyp)
     note("grad_theta", np.abs(np.asarray(g1.theta) - g_ref).max() / (np.abs(g_ref).max() + 1e-300), 1e-7, tag)
+    if os.environ.get("CDKF_FUZZ_VERBOSE") and not (np.abs(np.asarray(g1.theta) - g_ref).max() / (np.abs(g_ref).max() + 1e-300) < 1e-7):
+        print("  source:\n" + src + "\n  theta", theta.tolist(), "H", mdl.H.tolist())
+        print("  drift-only:", np.asarray(g1.theta).tolist(), "\n  all-leaf:  ", np.asarray(g.dynamics.drift.theta).tolist(), "\n  oracle:    ", g_ref.tolist(),
+              "\n  ll", np.asarray(ll).tolist(), ll_ref.tolist(), flush=True)
     if os.environ.get("CDKF_FUZZ_VERBOSE"):
         print(tag, "theta grad got", np.asarray(g1.theta).ravel(), "all-leaf", np.asarray(g.dynamics.drift.theta).ravel(), "want", g_ref.ravel(), flush=True)
 print("fuzz custom seed", seed, "cases", cases, "worst", {k: float("%.3g" % v) for k, v in worst.items()}, flush=True)

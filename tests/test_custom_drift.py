@@ -713,3 +713,42 @@ def test_rtc_code_objects_are_cached_on_disk(tmp_path):
         os.remove(cache / e)
     run(CDKF_RTC_CACHE="0")
     assert os.listdir(cache) == []
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,m", [(6, 1), (4, 3), (3, 2)])
+def test_forward_sensitivities_of_a_source_drift_with_powers(hip_lib, d, m):
+    """What scripts/gpu_fuzz_custom.py (seed 40404, case 7) caught in round 4: `pow(x[j], 2)` in a drift's source and the drift-only
+    gradient on the register-resident forward-sensitivity kernel (d, m <= 6) -- d ll / d theta was wrong by a factor (the all-leaf
+    reverse sweep of the same source, and the same source with `x[j] * x[j]` or `pow(x[j], 2.0)`, were right).  cdkf_dual.h now forms
+    a^c for a small whole c by multiplications (every order of derivative the nested dual numbers ask for, no call into the maths
+    library from the run-time compiled kernel); here the three spellings against the oracle and each other."""
+    import re
+    src = None
+    for seed in range(400):   # a drift whose source squares a component through pow(): the helper's style 1 with a j == k term
+        rng = np.random.default_rng(5000 + seed)
+        s_, make = random_quadratic_drift(rng, d)
+        if "pow(" in s_:
+            src = s_
+            break
+    assert src is not None
+    theta = np.array([0.7, -0.15])
+    A = rng.standard_normal((d, d))
+    B = rng.standard_normal((m, m))
+    mdl = o.Model(make(theta), np.eye(d) + 0.1 * rng.standard_normal((d, d)), A @ A.T / d * 0.3 + 0.3 * np.eye(d),
+                  rng.standard_normal((m, d)) / np.sqrt(d), 0.1 * rng.standard_normal(m), B @ B.T / m * 0.5 + 0.3 * np.eye(m),
+                  0.5 * rng.standard_normal(d), 0.3 * np.eye(d))
+    N, T = 3, 6
+    t = o.irregular_times(rng, N, T, 0.03 * T)
+    y = o.simulate(mdl, t, rng)
+    hyp = cd.EKFHyperParams(state_order="first")
+    ll_ref, g_ref = o.ekf_loglik_grad_adjoint(mdl, t, y, state_order="first")
+    variants = {"pow(x, 2)": src, "pow(x, 2.0)": re.sub(r"pow\((x\[\d+\]), 2\)", r"pow(\1, 2.0)", src),
+                "x * x": re.sub(r"pow\((x\[\d+\]), 2\)", r"(\1 * \1)", src)}
+    for name, s_ in variants.items():
+        P = params_for(mdl, cd.LearnableCustomDrift(theta, s_, None, None))
+        ll, g1 = cd.cdnlgssm_loglik_and_grad(P, y, t[..., None], hyp)
+        np.testing.assert_allclose(ll, ll_ref, rtol=1e-11, err_msg=name)
+        assert np.abs(np.asarray(g1.theta) - g_ref).max() < 1e-9 * np.abs(g_ref).max(), name
+        ll2, g2 = cd.cdnlgssm_loglik_and_grad_all(P, y, t[..., None], hyp)
+        assert np.abs(np.asarray(g2.dynamics.drift.theta) - g_ref).max() < 1e-9 * np.abs(g_ref).max(), name
