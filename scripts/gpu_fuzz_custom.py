@@ -60,6 +60,9 @@ for case in range(cases):
     tag = (case, d, m, N, T)
     order = str(rng.choice(["second", "first", "zeroth"]))
     only_grad = bool(os.environ.get("CDKF_FUZZ_ONLY_GRAD"))
+    if os.environ.get("CDKF_FUZZ_ONLY_CASE") and int(os.environ["CDKF_FUZZ_ONLY_CASE"]) != case:
+        rng.random(); rng.random(); rng.random()   # (the three draws below: which checks run, the gradient's state order)
+        continue
     ref = o.ekf_filter(mdl, t, y, state_order=order)
     post = cd.cdnlgssm_filter(P, y, t[..., None], cd.EKFHyperParams(state_order=order)) if not only_grad else None
     if post is not None:
@@ -68,6 +71,12 @@ for case in range(cases):
         ref = o.ukf_filter(mdl, t, y)
         post = cd.cdnlgssm_filter(P, y, t[..., None], cd.UKFHyperParams())
         note("ukf", max(relerr(getattr(post, k), ref[k]) for k in FILTER_KEYS), 1e-8, tag)
+        if os.environ.get("CDKF_FUZZ_VERBOSE") and not (max(relerr(getattr(post, k), ref[k]) for k in FILTER_KEYS) < 1e-8):
+            print("  ukf per field:", {k: relerr(getattr(post, k), ref[k]) for k in FILTER_KEYS}, "ll", np.asarray(post.marginal_loglik).tolist(), ref["marginal_loglik"].tolist())
+            for n_ in range(N):
+                e_t = [float(np.abs(np.asarray(post.filtered_means)[n_, k_] - ref["filtered_means"][n_, k_]).max()) for k_ in range(T)]
+                print("   trajectory", n_, "per-step mean error", ["%.1e" % v for v in e_t], "min eig filtered cov", ["%.1e" % np.linalg.eigvalsh(ref["filtered_covariances"][n_, k_]).min() for k_ in range(T)])
+            print("  source:\n" + src, flush=True)
     if rng.random() < 0.5 and not only_grad:
         ref = o.ekf_smoother(mdl, t, y, state_order="second")
         sm = cd.cdnlgssm_smoother(P, y, t[..., None])
