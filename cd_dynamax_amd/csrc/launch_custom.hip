@@ -400,13 +400,15 @@ int compile_variant(const CustomDrift& c, const Key& key, const std::string& arc
   }
   const std::string src = generate_source(c, std::get<1>(key), std::get<2>(key), std::get<3>(key), std::get<4>(key),
                                           std::get<5>(key), std::get<6>(key), std::get<7>(key), ek ? &em : nullptr);
-  // The forward-sensitivity sweep (algorithm 2) from four state dimensions on is built at -O1: there the kernel sits at all 512 registers
+  // The forward-sensitivity sweep (algorithm 2) is built at -O1: from four state dimensions on the kernel sits at all 512 registers
   // plus 0.6 - 2.6 KB of scratch per lane, and at -O2 / -O3 (ROCm 7.2 hipRTC, gfx950) some builds of the d = 6 instantiation return a wrong
   // d ll / d theta -- deterministic per build, flipping with spellings of the drift that generate the same arithmetic (`pow(x, 2)` against
   // `pow(x, 2.0)` against `x * x`), no calls in the code object, not the VGPR-to-AGPR spilling (-amdgpu-spill-vgpr-to-agpr=0: the same
   // numbers); -O1 is right in every case tried (scripts/dbg_custom_pow.py, NOTES.md R4.7; found by scripts/gpu_fuzz_custom.py seed 40404).
   // The same family as launch_wg8.hip's -O1 and the lost accumulator of DESIGN.md section 5.1 (ii): large spill-heavy kernels.
-  const char* olevel = (std::get<6>(key) == 2 && c.d >= 4) ? "-O1" : "-O3";
+  // (and below four dimensions too: after cdkf_dual.h changed the way a^2 is formed, the d = 2 instantiation of
+  //  tests/test_custom_drift.py::test_custom_drift_derivatives_by_dual_numbers returned a zero column at -O3 and the right one at -O1)
+  const char* olevel = (std::get<6>(key) == 2) ? "-O1" : "-O3";
   const std::string cache_key = rtc_cache_key(src, arch, olevel, "cdkf_custom_kernel");
   {
     std::string unused;
