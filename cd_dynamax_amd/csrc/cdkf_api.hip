@@ -564,6 +564,14 @@ int cdkf_custom_emission_register(int state_dim, int emission_dim, const char* h
   return custom_emission_register(state_dim, emission_dim, h_src, hjac_src);
 }
 void cdkf_set_kernel_source_dir(const char* dir) { custom_set_source_dir(dir); }
+int cdkf_debug_custom_reg_blob(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T, int algo, int bytes_per_real,
+                               void* par_out, int64_t par_cap_bytes, int64_t* ip_out) {
+  return custom_debug_reg_blob(mdl, opts, N, T, algo, bytes_per_real, par_out, par_cap_bytes, ip_out);
+}
+int cdkf_debug_wg_args(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T, int bytes_per_real, int ukf, int smoother,
+                       void* args_out, int64_t args_cap_bytes, void* blob_out, int64_t blob_cap_bytes, int64_t* geom_out) {
+  return debug_wg_args(mdl, opts, N, T, bytes_per_real, ukf, smoother, args_out, args_cap_bytes, blob_out, blob_cap_bytes, geom_out);
+}
 
 int cdkf_malloc(void** p, int64_t bytes) {
   if (!p || bytes < 0) {

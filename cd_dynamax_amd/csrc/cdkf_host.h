@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -19,6 +20,11 @@ void set_error(const char* fmt, ...);
 void note_kernel(const char* fmt, ...);
 template <typename R>
 inline const char* real_name() { return sizeof(R) == 8 ? "double" : "float"; }
+// a debugging switch of the environment: set AND a non-zero number ("CDKF_X=0" is off, as an unset variable is)
+inline bool env_flag(const char* name) {
+  const char* e = getenv(name);
+  return e && atoi(e) != 0;
+}
 int check_common(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T, const void* t, const void* y,
                  const void* ll);
 

@@ -116,6 +116,8 @@ int launch_custom(int algo, const cdkf_model* mdl, const cdkf_opts* o, int64_t N
                   R* a1, R* a2, R* a3, R* a4, int32_t* status, hipStream_t stream);
 int custom_register(int state_dim, int n_theta, const char* f_src, const char* jac_src, const char* divgrad_src);
 int custom_compile_check(int kind, int bytes_per_real, int emission_dim, int algo, int state_order, int emission_kind);
+int custom_debug_reg_blob(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, int algo, int bytes_per_real, void* par_out,
+                          int64_t par_cap_bytes, int64_t* ip_out);
 int custom_emission_register(int state_dim, int emission_dim, const char* h_src, const char* hjac_src);
 bool custom_emission_kind(int emission_kind, int d, int m);
 void custom_set_source_dir(const char* dir);
@@ -137,6 +139,8 @@ bool kernel_available(const cdkf_model* mdl, const cdkf_opts* o, int algo, int b
 
 // workgroup-per-trajectory kernels (launch_wg.hip): any registry drift, d and m up to what fits 160 KB of LDS
 bool wg_shape_available(const cdkf_model* mdl, int bytes_per_real);
+int debug_wg_args(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, int bytes_per_real, int ukf, int smoother, void* args_out,
+                  int64_t args_cap, void* blob_out, int64_t blob_cap, int64_t* geom);
 template <typename R>
 int launch_ekf_filter_wg(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll,
                          R* fm, R* fP, R* pm, R* pP, int32_t* status, hipStream_t stream);

@@ -7,11 +7,19 @@
 //   MVN(...).log_prob                 inference_ekf.py:286 (TFP MultivariateNormalFullCovariance)
 //   diffeqsolve -> Dopri5, const dt0  src/utils/diffrax_utils.py:40-165 (diffrax 0.4.0)
 #pragma once
-#ifndef __HIPCC_RTC__  // hipRTC (launch_custom.hip) provides the runtime declarations itself
+#if defined(CDKF_HOST_SIM)  // host build of the device templates for the CPU sanitizers (hostsim/cdkf_hostsim.h, tests/test_sanitize.py)
+#include "hostsim/cdkf_hostsim.h"
+#elif !defined(__HIPCC_RTC__)  // hipRTC (launch_custom.hip) provides the runtime declarations itself
 #include <hip/hip_runtime.h>
 #endif
 
 #define CDKF_DEV __device__ __forceinline__
+// an empty asm statement that makes the named vector registers opaque to the optimiser (scheduling / rematerialisation fences)
+#if defined(CDKF_HOST_SIM)
+#define CDKF_OPAQUE(...) ((void)0)
+#else
+#define CDKF_OPAQUE(...) asm volatile("" : __VA_ARGS__)
+#endif
 
 namespace cdkf {
 
@@ -129,7 +137,7 @@ struct Dp5T {
 // per ~4 cycles whatever its type, so those moves cost as much as the fp64 FMAs they feed.
 template <typename R>
 CDKF_DEV R pin(R x) {
-  asm volatile("" : "+v"(x));
+  CDKF_OPAQUE("+v"(x));
   return x;
 }
 template <typename R>

@@ -281,7 +281,7 @@ CDKF_DEV void ekf_update(const Args& a, R (&ys)[Dims<D>::NS], const R (&yobs)[M]
 #pragma unroll
     for (int e = 0; e < Dims<D>::NP; ++e) ys[D + e] = Pn[e];
     if (it == 0) {
-      asm volatile("" : "+v"(q), "+v"(pinv) : "v"(ys[D]), "v"(ys[0]));  // pin the accumulator call below the update (see above)
+      CDKF_OPAQUE("+v"(q), "+v"(pinv) : "v"(ys[D]), "v"(ys[0]));  // pin the accumulator call below the update (see above)
       ll.add((double)q, (double)pinv, M);
     }
   }

@@ -89,7 +89,7 @@ CDKF_DEV float w40_rsqrt(float x) { return rrsqrt(x); }
 CDKF_DEV double w40_readlane(double v, int l) {
   const long long b = __builtin_bit_cast(long long, v);
   const int lo = __builtin_amdgcn_readlane((int)b, l), hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
-  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+  return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
 }
 CDKF_DEV float w40_readlane(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
 

@@ -365,7 +365,7 @@ __device__ __forceinline__ double wave_bcast<double>(double x, int src) {
   const long long b = __double_as_longlong(x);
   const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), src);
   const int hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
-  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+  return __longlong_as_double((long long)(((unsigned long long)(unsigned int)hi << 32) | (unsigned int)lo));  // (unsigned: a left shift of a negative value is undefined before C++20)
 }
 __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -690,7 +690,7 @@ struct Own {
   // they were the values the allocator spilled, and every Runge-Kutta stage re-loaded them from scratch
   __device__ __forceinline__ void at(int u, int& i, int& j) const {
     int t = threadIdx.x;
-    asm volatile("" : "+v"(t));  // opaque: keeps the optimiser from hoisting these few integer ops out of the Runge-Kutta
+    CDKF_OPAQUE("+v"(t));  // opaque: keeps the optimiser from hoisting these few integer ops out of the Runge-Kutta
                                  // loops, where their results (and everything derived from them) were spilled to scratch
     const int e = t + u * blockDim.x;
     i = fdiv(e, d_);

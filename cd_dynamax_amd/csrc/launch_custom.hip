@@ -172,9 +172,13 @@ std::string rtc_cache_dir() {
 }
 
 // Compiler options every run-time compilation gets beside its optimisation level (part of the cache key).  CDKF_RTC_EXTRA_OPTS
-// (space-separated; a debugging aid) adds to them.
-std::vector<std::string> rtc_extra_options() {
+// (space-separated; a debugging aid) adds to them -- to every variant, or with CDKF_RTC_EXTRA_OPTS_ONLY=<text> to the variants whose tag
+// contains <text> (tag: the kernel's name expression for the workgroup variants, "reg ukf=<0|1> algo=<0 filter|1 smoother|2 gradient>"
+// for the register-resident ones), so that a pass bisection of ONE kernel leaves the other kernels of the same run as shipped.
+std::vector<std::string> rtc_extra_options(const std::string& tag) {
   std::vector<std::string> v;
+  if (const char* only = getenv("CDKF_RTC_EXTRA_OPTS_ONLY"))
+    if (*only && tag.find(only) == std::string::npos) return v;
   if (const char* e = getenv("CDKF_RTC_EXTRA_OPTS")) {
     std::string cur;
     for (const char* p = e;; ++p) {
@@ -190,14 +194,33 @@ std::vector<std::string> rtc_extra_options() {
   return v;
 }
 
-std::string rtc_cache_key(const std::string& src, const std::string& arch, const char* olevel, const std::string& expr) {
+// Compiler investigations (scripts/r5_mir_delta.py): CDKF_RTC_OVERRIDE_CO=<file> is loaded IN PLACE of compiling the variant whose tag
+// contains CDKF_RTC_EXTRA_OPTS_ONLY (which must be set) -- a code object built outside the library from the same generated source,
+// e.g. by llc from hand-edited machine IR.  The kernel's name and argument list are the generated source's.
+bool rtc_override_code(const std::string& tag, std::vector<char>& code) {
+  const char* path = getenv("CDKF_RTC_OVERRIDE_CO");
+  const char* only = getenv("CDKF_RTC_EXTRA_OPTS_ONLY");
+  if (!path || !*path || !only || !*only || tag.find(only) == std::string::npos) return false;
+  FILE* f = fopen(path, "rb");
+  if (!f) return false;
+  std::vector<char> buf;
+  char chunk[65536];
+  size_t n;
+  while ((n = fread(chunk, 1, sizeof(chunk), f)) > 0) buf.insert(buf.end(), chunk, chunk + n);
+  fclose(f);
+  if (buf.empty()) return false;
+  code.swap(buf);
+  return true;
+}
+
+std::string rtc_cache_key(const std::string& src, const std::string& arch, const char* olevel, const std::string& expr, const std::string& tag) {
   Fnv128 h;
   int maj = 0, min = 0;
   (void)hiprtcVersion(&maj, &min);
   const std::string meta = "cdkf-rtc-1|" + arch + "|" + olevel + "|hiprtc " + std::to_string(maj) + "." + std::to_string(min) + "|" +
                            rtc_headers_digest() + "|" + expr;
   h.feed(meta);
-  for (const std::string& x : rtc_extra_options()) h.feed("|" + x);
+  for (const std::string& x : rtc_extra_options(tag)) h.feed("|" + x);
   h.feed(src);
   char out[40];
   snprintf(out, sizeof(out), "%016llx%016llx", (unsigned long long)h.a, (unsigned long long)h.b);
@@ -329,7 +352,7 @@ std::string generate_source(const CustomDrift& c, int bytes, int m, int ukf, int
   s += "using R = " + std::string(bytes == 8 ? "double" : "float") + ";\n";
   s += "constexpr int DD = " + std::to_string(c.d) + ", MM = " + std::to_string(m) + ";\n";
   s += "using Drift = cdkf::DriftCustom<R, DD>;\nusing Args = cdkf::RegArgs<R, DD, MM, Drift>;\n";
-  // parameter blob (reals): theta | LQL | LQLz | H | hb | Rm | m0 | P0 | dt0 dt_final ukf_c ukf_wm0 ukf_wc0 ukf_wi | rk.a[30] rk.b[6] rk.berr[7] rtol atol c1 c2 c3
+  // parameter blob (reals): theta | LQL | LQLz | H | hb | Rm | m0 | P0 | dt0 dt_final ukf_c ukf_wm0 ukf_wc0 ukf_wi | rk.a[30] rk.b[6] rk.berr[7] rtol atol c1 c2 c3 | dtmin dtmax
   // integer blob (longs) : max_steps order num_iter forecast N T t_sn t_sk y_sn y_sk y_si m_sn m_sk m_si P_sn P_sk P_si
   s += R"(
 __device__ __forceinline__ void unpack(Args& a, const R* __restrict__ par, const long* __restrict__ ip, const R* t, const R* y,
@@ -362,6 +385,7 @@ __device__ __forceinline__ void unpack(Args& a, const R* __restrict__ par, const
   for (int s = 0; s < 7; ++s) a.rk.berr[s] = par[o + s];
   o += 7;
   a.rk.rtol = par[o]; a.rk.atol = par[o + 1]; a.rk.c1 = par[o + 2]; a.rk.c2 = par[o + 3]; a.rk.c3 = par[o + 4];
+  a.rk.dtmin = par[o + 5]; a.rk.dtmax = par[o + 6];
   a.rk.stages = (int)ip[17]; a.solver = (int)ip[18]; a.rk.adaptive = (int)ip[19]; a.rk.fsal = (int)ip[20]; a.lanes = (int)ip[21]; a.xcd_shift = (int)ip[22];
   a.max_steps = ip[0]; a.order = (int)ip[1]; a.num_iter = (int)ip[2]; a.forecast = (int)ip[3]; a.N = ip[4]; a.T = ip[5];
   a.t_sn = ip[6]; a.t_sk = ip[7]; a.y_sn = ip[8]; a.y_sk = ip[9]; a.y_si = ip[10]; a.m_sn = ip[11]; a.m_sk = ip[12];
@@ -409,7 +433,9 @@ int compile_variant(const CustomDrift& c, const Key& key, const std::string& arc
   // (and below four dimensions too: after cdkf_dual.h changed the way a^2 is formed, the d = 2 instantiation of
   //  tests/test_custom_drift.py::test_custom_drift_derivatives_by_dual_numbers returned a zero column at -O3 and the right one at -O1)
   const char* olevel = (std::get<6>(key) == 2) ? "-O1" : "-O3";
-  const std::string cache_key = rtc_cache_key(src, arch, olevel, "cdkf_custom_kernel");
+  const std::string tag = "reg ukf=" + std::to_string(std::get<3>(key)) + " algo=" + std::to_string(std::get<6>(key));
+  if (rtc_override_code(tag, code)) return CDKF_OK;
+  const std::string cache_key = rtc_cache_key(src, arch, olevel, "cdkf_custom_kernel", tag);
   {
     std::string unused;
     if (!getenv("CDKF_CUSTOM_DUMP") && rtc_cache_load(cache_key, code, unused)) return CDKF_OK;
@@ -420,7 +446,7 @@ int compile_variant(const CustomDrift& c, const Key& key, const std::string& arc
     return CDKF_EHIP;
   }
   const std::string inc = "-I" + source_dir(), off = "--offload-arch=" + arch;
-  const std::vector<std::string> extra = rtc_extra_options();
+  const std::vector<std::string> extra = rtc_extra_options(tag);
   std::vector<const char*> opts = {off.c_str(), olevel, "-std=c++17", inc.c_str(), "-Wno-pass-failed"};
   for (const std::string& x : extra) opts.push_back(x.c_str());
   const hiprtcResult res = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
@@ -716,9 +742,9 @@ int compile_wg_variant(const CustomDrift& c, const WgKey& key, const std::string
   // ... and, after two such finds in one evening of fresh fuzz seeds, every run-time compiled workgroup variant: they are all of this
   // kind (hundreds of KB of code, calls of device functions, scratch), -O1 has no wrong result on record in any of them, and a user's
   // drift is not where 15 - 25 % of speed are worth a wrong filter.  CDKF_RTC_WG_O3=1 brings the -O3 builds back (A/B).
-  const bool o3 = getenv("CDKF_RTC_WG_O3") && !((ept >= 8 && smoother != 2) || ukf);
+  const bool o3 = env_flag("CDKF_RTC_WG_O3") && !((ept >= 8 && smoother != 2) || ukf);
   const char* olevel = o3 ? "-O3" : "-O1";
-  const std::string cache_key = rtc_cache_key(src, arch, olevel, expr);
+  const std::string cache_key = rtc_cache_key(src, arch, olevel, expr, expr);
   if (!getenv("CDKF_CUSTOM_DUMP") && rtc_cache_load(cache_key, code, lowered) && !lowered.empty()) return CDKF_OK;
   hiprtcProgram prog = nullptr;
   if (hiprtcCreateProgram(&prog, src.c_str(), "cdkf_custom_drift_wg.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
@@ -733,7 +759,7 @@ int compile_wg_variant(const CustomDrift& c, const WgKey& key, const std::string
   // (the instantiations with eight or more entries per thread are built at -O1 in the library too: launch_wg8.hip, Makefile)
   const std::string inc = "-I" + source_dir(), off = "--offload-arch=" + arch;
   // -O1: the wg kernels' instantiations with eight or more entries per thread, as in the library (launch_wg8.hip, Makefile)
-  const std::vector<std::string> extra = rtc_extra_options();
+  const std::vector<std::string> extra = rtc_extra_options(expr);
   std::vector<const char*> opts = {off.c_str(), olevel, "-std=c++17", inc.c_str(), "-Wno-pass-failed"};
   for (const std::string& x : extra) opts.push_back(x.c_str());
   const hiprtcResult res = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
@@ -928,6 +954,71 @@ bool custom_grad_available(const cdkf_model* mdl, const cdkf_opts* o) {
   return o->state_order == CDKF_ORDER_FIRST || (c.has_g && !c.auto_g && blank(c.g_src));
 }
 
+// The two argument blocks of a run-time compiled register-resident kernel (the generated `unpack` reads them back):
+//   reals: theta | LQL | LQLz | H | hb | Rm | m0 | P0 | dt0 dt_final ukf_c ukf_wm0 ukf_wc0 ukf_wi | rk.a[30] rk.b[6] rk.berr[7] rtol atol c1 c2 c3
+//          | dtmin dtmax
+//   longs: max_steps order num_iter forecast N T t_sn t_sk y_sn y_sk y_si m_sn m_sk m_si P_sn P_sk P_si stages solver adaptive fsal lanes xcd_shift
+// Host arithmetic only (cdkf_debug_custom_reg_blob hands them to the CPU-sanitizer build of the same kernel, tests/test_hostsim.py).
+// (round 5: dtmin / dtmax were missing -- an adaptive solve of a source drift on these kernels clipped its steps to whatever the
+//  uninitialised fields of the kernel's argument struct held; found by reading the generated source for the MemorySanitizer build)
+template <typename R>
+static RegGrouping custom_reg_blob(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, bool smoother, bool gradient, bool no_y,
+                                   std::vector<R>& par, long (&ip)[23]) {
+  const int d = mdl->state_dim, m = mdl->emission_dim;
+  const int np = d * (d + 1) / 2;
+  par.clear();
+  for (long k = 0; k < mdl->n_theta; ++k) par.push_back(R(mdl->theta[k]));
+  std::vector<R> packed(np);
+  lql_packed<R>(mdl->L, mdl->Qc, d, 1.0, packed.data());
+  par.insert(par.end(), packed.begin(), packed.end());
+  lql_packed<R>(mdl->L, mdl->Qc, d, o->cov_rescaling, packed.data());
+  par.insert(par.end(), packed.begin(), packed.end());
+  for (int k = 0; k < m * d; ++k) par.push_back(R(mdl->H[k]));
+  for (int k = 0; k < m; ++k) par.push_back(R(mdl->h_bias[k]));
+  for (int k = 0; k < m * m; ++k) par.push_back(R(mdl->R[k]));
+  for (int k = 0; k < d; ++k) par.push_back(R(mdl->m0[k]));
+  for (int i = 0; i < d; ++i)
+    for (int j = i; j < d; ++j) par.push_back(R(0.5) * (R(mdl->P0[i * d + j]) + R(mdl->P0[j * d + i])));
+  {
+    const R alpha = R(o->ukf_alpha), n = R(d);
+    const R lamb = alpha * alpha * (n + R(o->ukf_kappa)) - n;
+    par.push_back(R(o->dt0));
+    par.push_back(R(o->dt_final));
+    par.push_back(std::sqrt(n + lamb));
+    par.push_back(lamb / (n + lamb));
+    par.push_back(lamb / (n + lamb) + (R(1) - alpha * alpha + R(o->ukf_beta)));
+    par.push_back(R(1) / (R(2) * (n + lamb)));
+  }
+  RkTab<R> tb;
+  fill_rk_tab<R>(o, tb);
+  for (int s = 0; s < 6; ++s)
+    for (int j = 0; j < 5; ++j) par.push_back(tb.a[s][j]);
+  for (int s = 0; s < 6; ++s) par.push_back(tb.b[s]);
+  for (int s = 0; s < 7; ++s) par.push_back(tb.berr[s]);
+  par.push_back(tb.rtol); par.push_back(tb.atol); par.push_back(tb.c1); par.push_back(tb.c2); par.push_back(tb.c3);
+  par.push_back(tb.dtmin); par.push_back(tb.dtmax);
+  const RegGrouping grouping = reg_grouping(gradient ? N * mdl->n_theta : N, (int)sizeof(R));  // (gradient: a lane per (trajectory, parameter))
+  ip[21] = grouping.lanes;
+  ip[22] = grouping.xcd_shift;
+  ip[17] = tb.stages;
+  ip[18] = o->solver;
+  ip[19] = tb.adaptive;
+  ip[20] = tb.fsal;
+  ip[0] = (long)o->max_steps;
+  ip[1] = o->state_order;
+  ip[2] = smoother ? 1 : o->num_iter;
+  ip[3] = smoother ? 0 : o->forecast;
+  ip[4] = N;
+  ip[5] = T;
+  {
+    const SweepStrides ss = sweep_strides(o, N, T, d, m, no_y);
+    long* st = ip + 6;  // t_sn t_sk y_sn y_sk y_si m_sn m_sk m_si P_sn P_sk P_si
+    st[0] = ss.t_sn; st[1] = ss.t_sk; st[2] = ss.y_sn; st[3] = ss.y_sk; st[4] = ss.y_si; st[5] = ss.m_sn; st[6] = ss.m_sk;
+    st[7] = ss.m_si; st[8] = ss.P_sn; st[9] = ss.P_sk; st[10] = ss.P_si;
+  }
+  return grouping;
+}
+
 // algo: 0 EKF filter, 1 UKF filter, 2 EKF smoother (filter + backward sweep), 3 EKF log-likelihood + gradient (a1: grad [N, n_theta])
 template <typename R>
 int launch_custom(int algo, const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll,
@@ -986,58 +1077,10 @@ int launch_custom(int algo, const cdkf_model* mdl, const cdkf_opts* o, int64_t N
     return CDKF_EINVAL;
   }
   // ---- parameter blobs -----------------------------------------------------------------------------------------------
-  const int np = d * (d + 1) / 2;
   std::vector<R> par;
-  for (long k = 0; k < mdl->n_theta; ++k) par.push_back(R(mdl->theta[k]));
-  std::vector<R> packed(np);
-  lql_packed<R>(mdl->L, mdl->Qc, d, 1.0, packed.data());
-  par.insert(par.end(), packed.begin(), packed.end());
-  lql_packed<R>(mdl->L, mdl->Qc, d, o->cov_rescaling, packed.data());
-  par.insert(par.end(), packed.begin(), packed.end());
-  for (int k = 0; k < m * d; ++k) par.push_back(R(mdl->H[k]));
-  for (int k = 0; k < m; ++k) par.push_back(R(mdl->h_bias[k]));
-  for (int k = 0; k < m * m; ++k) par.push_back(R(mdl->R[k]));
-  for (int k = 0; k < d; ++k) par.push_back(R(mdl->m0[k]));
-  for (int i = 0; i < d; ++i)
-    for (int j = i; j < d; ++j) par.push_back(R(0.5) * (R(mdl->P0[i * d + j]) + R(mdl->P0[j * d + i])));
-  {
-    const R alpha = R(o->ukf_alpha), n = R(d);
-    const R lamb = alpha * alpha * (n + R(o->ukf_kappa)) - n;
-    par.push_back(R(o->dt0));
-    par.push_back(R(o->dt_final));
-    par.push_back(std::sqrt(n + lamb));
-    par.push_back(lamb / (n + lamb));
-    par.push_back(lamb / (n + lamb) + (R(1) - alpha * alpha + R(o->ukf_beta)));
-    par.push_back(R(1) / (R(2) * (n + lamb)));
-  }
-  RkTab<R> tb;
-  fill_rk_tab<R>(o, tb);
-  for (int s = 0; s < 6; ++s)
-    for (int j = 0; j < 5; ++j) par.push_back(tb.a[s][j]);
-  for (int s = 0; s < 6; ++s) par.push_back(tb.b[s]);
-  for (int s = 0; s < 7; ++s) par.push_back(tb.berr[s]);
-  par.push_back(tb.rtol); par.push_back(tb.atol); par.push_back(tb.c1); par.push_back(tb.c2); par.push_back(tb.c3);
-  const int generic = o->solver != CDKF_SOLVER_DOPRI5 || o->adaptive;
   long ip[23];
-  const RegGrouping grouping = reg_grouping(gradient ? N * mdl->n_theta : N, (int)sizeof(R));  // (gradient: a lane per (trajectory, parameter))
-  ip[21] = grouping.lanes;
-  ip[22] = grouping.xcd_shift;
-  ip[17] = tb.stages;
-  ip[18] = o->solver;
-  ip[19] = tb.adaptive;
-  ip[20] = tb.fsal;
-  ip[0] = (long)o->max_steps;
-  ip[1] = o->state_order;
-  ip[2] = smoother ? 1 : o->num_iter;
-  ip[3] = smoother ? 0 : o->forecast;
-  ip[4] = N;
-  ip[5] = T;
-  {
-    const SweepStrides ss = sweep_strides(o, N, T, d, m, !y);
-    long* st = ip + 6;  // t_sn t_sk y_sn y_sk y_si m_sn m_sk m_si P_sn P_sk P_si
-    st[0] = ss.t_sn; st[1] = ss.t_sk; st[2] = ss.y_sn; st[3] = ss.y_sk; st[4] = ss.y_si; st[5] = ss.m_sn; st[6] = ss.m_sk;
-    st[7] = ss.m_si; st[8] = ss.P_sn; st[9] = ss.P_sk; st[10] = ss.P_si;
-  }
+  const RegGrouping grouping = custom_reg_blob<R>(mdl, o, N, T, smoother, gradient, !y, par, ip);
+  const int generic = o->solver != CDKF_SOLVER_DOPRI5 || o->adaptive;
   const R* yy = y ? y : t;  // forecast mode ignores the observations; keep the prefetch loads on valid memory
   const size_t par_bytes = par.size() * sizeof(R), blob = ((par_bytes + 15) & ~size_t(15)) + sizeof(ip);
   ParamLease lease(stream);
@@ -1108,6 +1151,10 @@ int custom_register(int state_dim, int n_theta, const char* f_src, const char* j
 }
 
 int custom_compile_check(int kind, int bytes_per_real, int emission_dim, int algo, int state_order, int emission_kind) {
+  // algo + 16: the register-resident variant that reads its Runge-Kutta tableau / step-size controller from the arguments (what a
+  // launch with opts.solver != Dormand-Prince or opts.adaptive compiles) instead of the pinned Dormand-Prince constants
+  const int generic = (algo >= 16) ? 1 : 0;
+  if (generic) algo -= 16;
   if (emission_kind && !custom_emission_kind(emission_kind, c_dim(kind), emission_dim)) {
     set_error("custom emission %d is not registered for this state / emission dimension", emission_kind);
     return CDKF_EINVAL;
@@ -1150,10 +1197,38 @@ int custom_compile_check(int kind, int bytes_per_real, int emission_dim, int alg
     return rc;
   }
   const int zeroth = (algo != 1 && state_order == CDKF_ORDER_ZEROTH) ? 1 : 0;
-  if (algo == 3) return compile_variant(c, Key(kind, bytes_per_real, emission_dim, 0, 0, 0, 2, 0, 0), "gfx950", code);
-  int rc = compile_variant(c, Key(kind, bytes_per_real, emission_dim, algo == 1, zeroth, 0, 0, 0, emission_kind), "gfx950", code);
-  if (!rc && algo == 2) rc = compile_variant(c, Key(kind, bytes_per_real, emission_dim, 0, 0, 0, 1, 0, 0), "gfx950", code);
+  if (algo == 3) return compile_variant(c, Key(kind, bytes_per_real, emission_dim, 0, 0, 0, 2, generic, 0), "gfx950", code);
+  int rc = compile_variant(c, Key(kind, bytes_per_real, emission_dim, algo == 1, zeroth, 0, 0, generic, emission_kind), "gfx950", code);
+  if (!rc && algo == 2) rc = compile_variant(c, Key(kind, bytes_per_real, emission_dim, 0, 0, 0, 1, generic, 0), "gfx950", code);
   return rc;
+}
+
+// the argument blocks of launch_custom for the CPU-sanitizer build of the generated kernel (cdkf_debug_custom_reg_blob): no HIP call
+int custom_debug_reg_blob(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, int algo, int bytes_per_real, void* par_out,
+                          int64_t par_cap_bytes, int64_t* ip_out) {
+  if (!mdl || !o || !par_out || !ip_out || (bytes_per_real != 4 && bytes_per_real != 8) || algo < 0 || algo > 3) {
+    set_error("cdkf_debug_custom_reg_blob: bad arguments");
+    return CDKF_EINVAL;
+  }
+  long ip[23];
+  int64_t n = 0;
+  unsigned blocks = 0;
+  if (bytes_per_real == 8) {
+    std::vector<double> par;
+    blocks = custom_reg_blob<double>(mdl, o, N, T, algo == 2, algo == 3, false, par, ip).blocks;
+    n = (int64_t)par.size();
+    if (n * 8 > par_cap_bytes) return CDKF_EINVAL;
+    std::memcpy(par_out, par.data(), n * 8);
+  } else {
+    std::vector<float> par;
+    blocks = custom_reg_blob<float>(mdl, o, N, T, algo == 2, algo == 3, false, par, ip).blocks;
+    n = (int64_t)par.size();
+    if (n * 4 > par_cap_bytes) return CDKF_EINVAL;
+    std::memcpy(par_out, par.data(), n * 4);
+  }
+  for (int k = 0; k < 23; ++k) ip_out[k] = ip[k];
+  ip_out[23] = blocks;
+  return (int)n;
 }
 
 void custom_set_source_dir(const char* dir) {

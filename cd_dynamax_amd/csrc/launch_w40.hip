@@ -31,7 +31,7 @@ static bool emission_selects_components(const cdkf_model* mdl) {
   return true;
 }
 bool wave40_shape(const cdkf_model* mdl, const cdkf_opts* o) {
-  if (getenv("CDKF_NO_WAVE40")) return false;  // A/B and tests: keep the workgroup kernels
+  if (env_flag("CDKF_NO_WAVE40")) return false;  // A/B and tests: keep the workgroup kernels
   const int d = mdl->state_dim, m = mdl->emission_dim;
   if (mdl->drift_kind != CDKF_DRIFT_LORENZ96 || !wave40_dim(d) || !emission_selects_components(mdl)) return false;
   if (o->num_iter != 1 || o->forecast || o->state_order == CDKF_ORDER_ZEROTH || o->solver != CDKF_SOLVER_DOPRI5 || o->adaptive)
@@ -67,7 +67,7 @@ static int launch_wave40_d(const WgArgs<R>& a, hipStream_t stream, bool backward
 #endif
   // a diagonal R: one factorisation per update (the log-likelihood's terms by first-order corrections from the gain's factor: kernel
   // header); CDKF_W40_TWO_FACTORS=1 keeps the two systems in lockstep (A/B, tests)
-  if (a.r_diag && !getenv("CDKF_W40_TWO_FACTORS")) {
+  if (a.r_diag && !env_flag("CDKF_W40_TWO_FACTORS")) {
     if (once_per_device([] { return wg_raise_lds_cap(ekf_filter_wave_l96_kernel<R, D, true>); })) return CDKF_EHIP;
     note_kernel("ekf_filter_wave_l96_kernel<%s, %d, true>", real_name<R>(), D);
     hipLaunchKernelGGL((ekf_filter_wave_l96_kernel<R, D, true>), dim3(blocks), dim3(64 * W40<D>::kWaves), lds, stream, b);

@@ -82,17 +82,17 @@ int param_pool_release(ParamSlot* s, hipStream_t stream) {
   return CDKF_OK;
 }
 
-// Builds the parameter block in the compute type and uploads it through the ring above.
+// Builds the parameter block in the compute type (h) and every field of the kernel argument but the pointers: host arithmetic only
+// (cdkf_debug_wg_args hands the result to the CPU-sanitizer build of the same kernels, tests/test_hostsim.py).
 template <typename R>
-static int wg_prepare(WgArgs<R>& a, R** dev_block, ParamSlot** slot_out, const cdkf_model* mdl, const cdkf_opts* o,
-                      int64_t N, int64_t T, hipStream_t stream) {
+static int wg_fill(WgArgs<R>& a, std::vector<R>& h, const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T) {
   const int d = mdl->state_dim, m = mdl->emission_dim;
   if (!wg_shape_available(mdl, sizeof(R))) {
     set_error("no kernel for drift_kind=%d state_dim=%d emission_dim=%d n_theta=%lld (fp%d)", mdl->drift_kind, d, m,
               (long long)mdl->n_theta, (int)sizeof(R) * 8);
     return CDKF_EUNSUPPORTED;
   }
-  std::vector<R> h;
+  h.clear();
   auto push = [&](const double* src, long n) {
     const long off = (long)h.size();
     for (long i = 0; i < n; ++i) h.push_back(R(src[i]));
@@ -129,15 +129,6 @@ static int wg_prepare(WgArgs<R>& a, R** dev_block, ParamSlot** slot_out, const c
     for (int p = 0; p < h2; ++p)
       for (int q = 0; q < h1; ++q) h[a.o_w2pad + p * 64 + q] = R(W2[p * h1 + q]);
   }
-  ParamSlot* slot = nullptr;
-  int prc = param_pool_acquire(h.size() * sizeof(R), &slot);
-  if (prc) return prc;
-  *slot_out = slot;  // the caller's lease covers every exit from here on
-  std::memcpy(slot->host, h.data(), h.size() * sizeof(R));
-  CDKF_HIP_CHECK(hipMemcpyAsync(slot->dev, slot->host, h.size() * sizeof(R), hipMemcpyHostToDevice, stream));
-  *dev_block = (R*)slot->dev;
-  *slot_out = slot;
-  a.par = *dev_block;
   a.kind = mdl->drift_kind;
   a.d = d;
   a.m = m;
@@ -168,6 +159,24 @@ static int wg_prepare(WgArgs<R>& a, R** dev_block, ParamSlot** slot_out, const c
     a.t_sn = st.t_sn; a.t_sk = st.t_sk; a.y_sn = st.y_sn; a.y_sk = st.y_sk; a.y_si = st.y_si;
     a.m_sn = st.m_sn; a.m_sk = st.m_sk; a.m_si = st.m_si; a.P_sn = st.P_sn; a.P_sk = st.P_sk; a.P_si = st.P_si;
   }
+  return CDKF_OK;
+}
+
+// ... and uploads the block through the ring above.
+template <typename R>
+static int wg_prepare(WgArgs<R>& a, R** dev_block, ParamSlot** slot_out, const cdkf_model* mdl, const cdkf_opts* o,
+                      int64_t N, int64_t T, hipStream_t stream) {
+  std::vector<R> h;
+  const int frc = wg_fill(a, h, mdl, o, N, T);
+  if (frc) return frc;
+  ParamSlot* slot = nullptr;
+  int prc = param_pool_acquire(h.size() * sizeof(R), &slot);
+  if (prc) return prc;
+  *slot_out = slot;  // the caller's lease covers every exit from here on
+  std::memcpy(slot->host, h.data(), h.size() * sizeof(R));
+  CDKF_HIP_CHECK(hipMemcpyAsync(slot->dev, slot->host, h.size() * sizeof(R), hipMemcpyHostToDevice, stream));
+  *dev_block = (R*)slot->dev;
+  a.par = *dev_block;
   return CDKF_OK;
 }
 
@@ -242,9 +251,48 @@ static int launch_wg_dispatch(const WgArgs<R>& a, const cdkf_model* mdl, bool sm
   }
 }
 
+// What launch_wg_dispatch would launch for this model -- the argument struct (pointers null), the parameter block, and the geometry
+// {entries per thread, threads, LDS bytes, sizeof(WgArgs<R>)} -- without touching the GPU (cdkf_debug_wg_args).
+template <typename R>
+static int debug_wg_args_t(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, int ukf, int smoother, void* args_out,
+                           int64_t args_cap, void* blob_out, int64_t blob_cap, int64_t* geom) {
+  WgArgs<R> a{};
+  std::vector<R> h;
+  cdkf_opts of = *o;
+  if (smoother) of.num_iter = 1;
+  const int rc = wg_fill(a, h, mdl, &of, N, T);
+  if (rc) return rc;
+  if (ukf) {
+    a.ukf = 1;
+    a.num_iter = 1;
+  }
+  const bool custom = mdl->drift_kind >= CDKF_DRIFT_CUSTOM_BASE;
+  const int threads = custom ? wg_threads_custom(a.d) : wg_threads(mdl);
+  geom[0] = wg_ept(a.d, threads);
+  geom[1] = threads;
+  geom[2] = (int64_t)((wg_lds_bytes<R>(mdl, smoother != 0, ukf != 0) + 15) & ~size_t(15));
+  geom[3] = (int64_t)sizeof(WgArgs<R>);
+  if ((int64_t)sizeof(WgArgs<R>) > args_cap || (int64_t)(h.size() * sizeof(R)) > blob_cap) {
+    set_error("cdkf_debug_wg_args: buffers too small (%lld, %lld bytes needed)", (long long)sizeof(WgArgs<R>), (long long)(h.size() * sizeof(R)));
+    return CDKF_EINVAL;
+  }
+  std::memcpy(args_out, &a, sizeof(WgArgs<R>));
+  std::memcpy(blob_out, h.data(), h.size() * sizeof(R));
+  return (int)h.size();
+}
+int debug_wg_args(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, int bytes_per_real, int ukf, int smoother, void* args_out,
+                  int64_t args_cap, void* blob_out, int64_t blob_cap, int64_t* geom) {
+  if (!mdl || !o || !args_out || !blob_out || !geom || (bytes_per_real != 4 && bytes_per_real != 8)) {
+    set_error("cdkf_debug_wg_args: bad arguments");
+    return CDKF_EINVAL;
+  }
+  return bytes_per_real == 8 ? debug_wg_args_t<double>(mdl, o, N, T, ukf, smoother, args_out, args_cap, blob_out, blob_cap, geom)
+                             : debug_wg_args_t<float>(mdl, o, N, T, ukf, smoother, args_out, args_cap, blob_out, blob_cap, geom);
+}
+
 // wavefront-per-trajectory kernel: state and emission dimensions up to 8, MLP hidden layers up to 64
 static bool wave8_shape(const cdkf_model* mdl) {
-  if (getenv("CDKF_NO_WAVE8")) return false;  // debugging aid: force the workgroup kernels
+  if (env_flag("CDKF_NO_WAVE8")) return false;  // debugging aid: force the workgroup kernels
   if (mdl->drift_kind >= CDKF_DRIFT_CUSTOM_BASE) return false;  // (a drift given as source is compiled into the workgroup kernels)
   if (mdl->state_dim > 8 || mdl->emission_dim > 8) return false;
   if (mdl->drift_kind == CDKF_DRIFT_MLP_TANH && (mdl->hidden1 > 64 || mdl->hidden2 > 64)) return false;
@@ -289,7 +337,7 @@ int launch_ekf_smoother_wg(const cdkf_model* mdl, const cdkf_opts* o, int64_t N,
   } else if (wave40_shape(mdl, &of)) {  // d = 40: both passes on the wavefront-per-trajectory sweeps
     rc = launch_wave40<R>(a, stream);
     if (!rc)
-      rc = getenv("CDKF_WG_BACKWARD") ? launch_wg_dispatch<R>(a, mdl, true, stream, false)  // (A/B and tests: the workgroup kernel)
+      rc = env_flag("CDKF_WG_BACKWARD") ? launch_wg_dispatch<R>(a, mdl, true, stream, false)  // (A/B and tests: the workgroup kernel)
                                       : launch_wave40<R>(a, stream, true);
   } else {
     rc = launch_wg_dispatch<R>(a, mdl, true, stream);

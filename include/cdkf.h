@@ -305,12 +305,29 @@ int cdkf_custom_emission_register(int state_dim, int emission_dim, const char* h
 /* compile (without loading: no GPU needed) the kernel for one variant -- algo 0 EKF filter, 1 UKF filter, 2 EKF
  * smoother, 3 the log-likelihood gradient (the forward-sensitivity sweep up to six dimensions, the reverse sweep beyond);
  * emission_kind 0 or a registered custom emission -- to check the snippets early; 0 or a negative CDKF_E* code
- * with the compiler log in cdkf_last_error() */
+ * with the compiler log in cdkf_last_error().  algo + 16 (state / emission dimension <= 6): the variant that takes its Runge-Kutta
+ * tableau and step-size controller from the arguments (opts.solver other than Dormand-Prince, opts.adaptive). */
 int cdkf_custom_drift_compile(int drift_kind, int bytes_per_real, int emission_dim, int algo, int state_order,
                               int emission_kind);
 /* directory holding the kernel headers (cdkf_reg_kernels.h ...) for run-time compilation; default: <dir of this
  * library>/../csrc */
 void cdkf_set_kernel_source_dir(const char* dir);
+
+/* ---- diagnostics: the argument blocks a launch would hand its kernel, built WITHOUT touching the GPU -- for the CPU-sanitizer
+ *      builds of the same device templates (cd_dynamax_amd/csrc/hostsim/, tests/test_hostsim.py: the kernels of this library compiled
+ *      for the host under ASan / UBSan / MSan / TSan and run on exactly the arguments the launcher forms).  Replaces nothing in the
+ *      reference; not part of the drop-in surface. --------------------------------------------------------------------------- */
+/* run-time compiled register-resident kernel (custom drift, state / emission dimension <= 6): algo as cdkf_custom_drift_compile;
+ * par_out receives the real-valued block (bytes_per_real each), ip_out[24] the integer block followed by the grid size.
+ * Returns the number of reals written or a negative CDKF_E* code. */
+int cdkf_debug_custom_reg_blob(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T, int algo, int bytes_per_real,
+                               void* par_out, int64_t par_cap_bytes, int64_t* ip_out);
+/* workgroup-per-trajectory kernels (cdkf_wg2_kernels.h: any drift, state / emission dimension <= 64): args_out receives the kernel's
+ * argument struct (WgArgs<real>, every pointer null), blob_out its parameter block, geom_out[4] = {covariance entries per thread,
+ * threads per workgroup, LDS bytes, sizeof(WgArgs<real>)}; ukf / smoother select the unscented filter / the backward sweep.
+ * Returns the number of reals in the block or a negative CDKF_E* code. */
+int cdkf_debug_wg_args(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T, int bytes_per_real, int ukf, int smoother,
+                       void* args_out, int64_t args_cap_bytes, void* blob_out, int64_t blob_cap_bytes, int64_t* geom_out);
 
 /* ---- linear model, smoother type 1: replaces cdlgssm_smoother(..., smoother_type='cd_smoother_1') -- the reference's default --
  *      src/continuous_discrete_linear_gaussian_ssm/inference.py:694-823 (_step_1 :746-773, compute_pushforward :105-143):

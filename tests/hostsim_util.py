@@ -1,0 +1,178 @@
+"""Host builds of the device templates under the CPU sanitizers (cd_dynamax_amd/csrc/hostsim/cdkf_hostsim.h): compile a kernel's
+translation unit for x86-64 with -DCDKF_HOST_SIM, run it on the argument blocks the library's launcher forms (cdkf_debug_* entry
+points, no GPU), and hand the outputs back for comparison with the oracle.  Test infrastructure only."""
+import ctypes as C
+import hashlib
+import os
+import shutil
+import subprocess
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "cd_dynamax_amd", "csrc")
+HARNESS = os.path.join(ROOT, "tests", "hostsim")
+BUILD = os.path.join(ROOT, "build", "hostsim")
+
+SANITIZERS = {
+    # -ftrivial-auto-var-init=pattern under ASan: an uninitialised private array reads as 0xAA.. (a huge / NaN real), so a result that
+    # depends on one differs from the oracle instead of happening to be right
+    "asan": ["-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-ftrivial-auto-var-init=pattern"],
+    "msan": ["-fsanitize=memory", "-fsanitize-memory-track-origins=2", "-fno-sanitize-recover=all"],
+    "tsan": ["-fsanitize=thread"],
+    "plain": [],
+}
+
+
+def clang():
+    for c in ("/opt/rocm/lib/llvm/bin/clang++", shutil.which("amdclang++"), shutil.which("clang++")):
+        if c and os.path.exists(c):
+            return c
+    return None
+
+
+def build(harness: str, include_src: str, san: str, opt: str = "-O1", defines=()):
+    """Compile tests/hostsim/<harness> with `include_src` force-included; returns the executable's path (cached by content)."""
+    cc = clang()
+    if cc is None:
+        raise RuntimeError("no clang++ for the host build")
+    os.makedirs(BUILD, exist_ok=True)
+    h = hashlib.sha1()
+    for p in [os.path.join(HARNESS, harness), include_src] + sorted(
+            os.path.join(dp, f) for dp, _, fs in os.walk(CSRC) for f in fs if f.endswith((".h", ".inc"))):
+        h.update(open(p, "rb").read())
+    h.update(" ".join([san, opt] + list(defines)).encode())
+    exe = os.path.join(BUILD, f"{os.path.splitext(harness)[0]}_{san}_{h.hexdigest()[:16]}")
+    if os.path.exists(exe):
+        return exe
+    cmd = [cc, "-x", "c++", "-std=c++17", opt, "-g", "-fno-omit-frame-pointer", "-DCDKF_HOST_SIM=1", "-I", CSRC, "-include", include_src,
+           "-Wno-unused-value", "-Wno-pass-failed", "-Wno-unknown-attributes", "-Wno-unused-function", "-ffp-contract=off",
+           *[f"-D{d}" for d in defines], *SANITIZERS[san], os.path.join(HARNESS, harness), "-o", exe + ".tmp", "-lpthread", "-lm"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=1800)
+    if out.returncode != 0:
+        raise RuntimeError("host build failed:\n" + " ".join(cmd) + "\n" + out.stderr[-6000:])
+    os.replace(exe + ".tmp", exe)
+    return exe
+
+
+def run(exe, infile, outfile, timeout=1800):
+    env = dict(os.environ)
+    env["ASAN_OPTIONS"] = "detect_leaks=0:halt_on_error=1:detect_stack_use_after_return=0"
+    env["UBSAN_OPTIONS"] = "print_stacktrace=1:halt_on_error=1"
+    env["TSAN_OPTIONS"] = "halt_on_error=0:report_signal_unsafe=0:history_size=4"
+    env["MSAN_OPTIONS"] = "halt_on_error=1"
+    return subprocess.run([exe, infile, outfile], capture_output=True, text=True, timeout=timeout, env=env)
+
+
+def sanitizer_reports(stderr: str):
+    keys = ("ERROR: AddressSanitizer", "runtime error:", "WARNING: MemorySanitizer", "WARNING: ThreadSanitizer", "ERROR: ThreadSanitizer")
+    return [ln for ln in stderr.splitlines() if any(k in ln for k in keys)]
+
+
+def dump_custom_source(kind: int, nbytes: int, m: int, algo: int, state_order: int = 2, emission_kind: int = 0):
+    """The translation unit launch_custom.hip generates for this variant (cdkf_custom_drift_compile with CDKF_CUSTOM_DUMP; cross-compiles
+    for gfx950 on the way, no GPU needed).  Returns the path of the .hip file."""
+    from cd_dynamax_amd import _ffi
+    d = tempfile.mkdtemp(prefix="cdkf_dump_")
+    os.environ["CDKF_CUSTOM_DUMP"] = d
+    try:
+        rc = _ffi.lib().cdkf_custom_drift_compile(kind, nbytes, m, algo, state_order, emission_kind)
+        if rc:
+            raise RuntimeError(_ffi.lib().cdkf_last_error().decode())
+    finally:
+        del os.environ["CDKF_CUSTOM_DUMP"]
+    src = [f for f in os.listdir(d) if f.endswith(".hip")]
+    assert src, os.listdir(d)
+    # (algo 2 writes the filter's and the smoother's unit; the caller names the one it wants by suffix)
+    return d, sorted(src)
+
+
+def reg_run(src_path, mdl, opts, t, y, algo, dtype, san, outs, opt="-O1"):
+    """Run a generated register-resident kernel on the host.  t [N,T], y [N,T,m] (layout NT in, `opts.layout` out as set by the
+    caller); outs: lengths (in reals) of (ll, o1, o2, o3, o4, status, sm, sP).  Returns the list of output arrays."""
+    from cd_dynamax_amd import _ffi
+    dtype = np.dtype(dtype)
+    N, T = t.shape
+    par = np.zeros(4096, dtype)
+    ip = np.zeros(24, np.int64)
+    n = _ffi.lib().cdkf_debug_custom_reg_blob(C.byref(mdl.c), C.byref(opts), N, T, algo, dtype.itemsize, par.ctypes.data_as(C.c_void_p),
+                                               par.nbytes, ip.ctypes.data_as(C.POINTER(C.c_int64)))
+    assert n > 0, _ffi.lib().cdkf_last_error().decode()
+    par = par[:n]
+    head = np.zeros(16, np.int64)
+    tt, yy = np.ascontiguousarray(t, dtype), np.ascontiguousarray(y, dtype)
+    head[:5] = [ip[23], n, 23, tt.size, yy.size]
+    head[5:13] = outs
+    exe = build("reg_harness.cpp", src_path, san, opt)
+    with tempfile.TemporaryDirectory() as d:
+        fin, fout = os.path.join(d, "in.bin"), os.path.join(d, "out.bin")
+        with open(fin, "wb") as f:
+            f.write(head.tobytes()); f.write(par.tobytes()); f.write(ip[:23].tobytes()); f.write(tt.tobytes()); f.write(yy.tobytes())
+        res = run(exe, fin, fout)
+        reports = sanitizer_reports(res.stderr)
+        if res.returncode != 0 or reports:
+            raise AssertionError(f"host run ({san}) rc={res.returncode}\n" + res.stderr[-8000:])
+        raw = open(fout, "rb").read()
+    arrs, off = [], 0
+    for k, ln in enumerate(outs):
+        dt = np.dtype(np.int32) if k == 5 else dtype
+        arrs.append(np.frombuffer(raw, dt, ln, off).copy() if ln else None)
+        off += ln * dt.itemsize
+    return arrs
+
+
+def wg_run(include_src, mdl, opts, t, y, dtype, san, *, ukf=False, kind=-1, smoother=False, filtered=None, opt="-O1", timeout=3000):
+    """Run one instantiation of the workgroup-per-trajectory kernels on the host.  include_src: the translation unit
+    (tests/hostsim/wg_builtin_tu.h or a generated custom-drift source).  t [N,T], y [N,T,m]; opts.layout = TN (outputs [T,N,...]) and
+    layout_in = NT are set here.  Returns dict of outputs in the reference shapes [N,T,...]."""
+    from cd_dynamax_amd import _ffi
+    dtype = np.dtype(dtype)
+    N, T = t.shape
+    d, m = mdl.state_dim, mdl.emission_dim
+    opts.layout = _ffi.LAYOUT_TN
+    opts.layout_in = _ffi.LAYOUT_NT
+    opts.t_shared = 0
+    args = np.zeros(8192, np.uint8)
+    blob = np.zeros(1 << 18, dtype)
+    geom = np.zeros(4, np.int64)
+    n = _ffi.lib().cdkf_debug_wg_args(C.byref(mdl.c), C.byref(opts), N, T, dtype.itemsize, int(ukf), int(smoother), args.ctypes.data_as(C.c_void_p),
+                                       args.nbytes, blob.ctypes.data_as(C.c_void_p), blob.nbytes, geom.ctypes.data_as(C.POINTER(C.c_int64)))
+    assert n > 0, _ffi.lib().cdkf_last_error().decode()
+    ept, threads, lds, asz = (int(v) for v in geom)
+    tt, yy = np.ascontiguousarray(t, dtype), np.ascontiguousarray(y, dtype)
+    nm, nP = N * T * d, N * T * d * d
+    head = np.zeros(16, np.int64)
+    head[:6] = [N, threads, asz, n, tt.size, yy.size]
+    head[6:14] = [N, nm, nP, 0 if smoother else nm, 0 if smoother else nP, N, nm if smoother else 0, nP if smoother else 0]
+    defines = [f"HS_REAL={'double' if dtype.itemsize == 8 else 'float'}", f"HS_EPT={ept}", f"HS_UKF={int(ukf)}", f"HS_KIND={kind}",
+               f"HS_SMOOTHER={int(smoother)}"]
+    if not open(include_src).read().count("CDKF_WG_STATIC_LDS"):
+        defines.append(f"CDKF_WG_STATIC_LDS={lds}")
+    exe = build("wg_harness.cpp", include_src, san, opt, defines)
+    with tempfile.TemporaryDirectory() as dd:
+        fin, fout = os.path.join(dd, "in.bin"), os.path.join(dd, "out.bin")
+        with open(fin, "wb") as f:
+            f.write(head.tobytes()); f.write(args[:asz].tobytes()); f.write(blob[:n].tobytes()); f.write(tt.tobytes()); f.write(yy.tobytes())
+            if smoother:   # filtered moments in the sweep's own layout [T,N,...]
+                f.write(np.ascontiguousarray(np.swapaxes(filtered[0], 0, 1), dtype).tobytes())
+                f.write(np.ascontiguousarray(np.swapaxes(filtered[1], 0, 1), dtype).tobytes())
+        res = run(exe, fin, fout, timeout)
+        reports = sanitizer_reports(res.stderr)
+        if res.returncode != 0 or reports:
+            raise AssertionError(f"host run ({san}, ept {ept}, threads {threads}) rc={res.returncode}\n" + res.stderr[-12000:])
+        raw = open(fout, "rb").read()
+    off = 0
+
+    def take(count, dt=dtype):
+        nonlocal off
+        a = np.frombuffer(raw, dt, count, off).copy()
+        off += count * np.dtype(dt).itemsize
+        return a
+    TN = lambda a, shape: np.swapaxes(a.reshape((T, N) + shape), 0, 1)
+    if smoother:
+        sm, sP = take(nm), take(nP)
+        return {"smoothed_means": TN(sm, (d,)), "smoothed_covariances": TN(sP, (d, d)), "status": take(N, np.int32), "geom": (ept, threads, lds)}
+    ll, fm, fP, pm, pP = take(N), take(nm), take(nP), take(nm), take(nP)
+    return {"marginal_loglik": ll, "filtered_means": TN(fm, (d,)), "filtered_covariances": TN(fP, (d, d)), "predicted_means": TN(pm, (d,)),
+            "predicted_covariances": TN(pP, (d, d)), "status": take(N, np.int32), "geom": (ept, threads, lds)}
