@@ -193,8 +193,21 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    per_rank = None
     if comm is not None:
-        elapsed = float(comm.allreduce_max_host([elapsed])[0])
+        # every rank's own clock around the same K steps (the barriers make them nearly equal: a straggler shows as max >> min), and the
+        # collective alone: ONE event pair around 50 back-to-back all-reduces of the one double on the sweep's stream, max over ranks
+        own = elapsed
+        mx = comm.allreduce_max_host([own, -own])
+        elapsed = float(mx[0])
+        coll_timer = Timer(lib, _ffi, stream)
+        coll_ms = coll_timer.ms_per_call(lambda: comm.allreduce_sum_any(ll_sum.ptr, 1, stream), 50)
+        coll_ms = float(comm.allreduce_max_host([coll_ms])[0])
+        per_rank = {"ms_per_step_max": float(mx[0]) / args.steps * 1e3, "ms_per_step_min": -float(mx[1]) / args.steps * 1e3,
+                    "allreduce_us": coll_ms * 1e3,
+                    "allreduce_method": "one HIP-event pair around 50 back-to-back all-reduces of the log-likelihood sum on the sweep's stream, max over ranks"}
+        step()   # (the 50 extra all-reduces multiplied ll_sum by world^50: restore the sum the line reports)
+        fence()
     total_ll = float(ll_sum.numpy()[0])
     n_bad = int(np.count_nonzero(status.numpy()))
     kernel_name = lib.cdkf_last_kernel().decode()
@@ -206,6 +219,7 @@ def main():
     if rank == 0:
         bytes_per_launch = N * T * 8 * ((1 + M) + 2 * (D + D * D))  # 224 B per trajectory-step
         traffic, traffic_src = pmc_traffic(bytes_per_launch, kernel_name)
+        issue = pmc_issue(bytes_per_launch, kernel_name, T)
         achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
         out = {
             "metric": "trajectories_per_sec", "value": world * N * args.steps / elapsed, "unit": "trajectories/s",
@@ -217,8 +231,10 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kernel_name, "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "kernel_ms_method": f"one HIP-event pair around {args.steps} back-to-back launches on the launch stream"},
-            "marginal_loglik_sum": total_ll, "status_flags_raised": n_bad,
+                         "kernel_ms_method": f"one HIP-event pair around {args.steps} back-to-back launches on the launch stream",
+                         # what bounds the sweep at this batch size (one wavefront per SIMD, T sequential steps): instruction issue
+                         "issue": issue},
+            "marginal_loglik_sum": total_ll, "status_flags_raised": n_bad, "per_rank": per_rank,
             "collective": None if comm is None else (
                 "cdkf_ll_allreduce (ncclAllReduce, 1 double, in place) on the sweep's stream" if not comm.rccl_error else
                 f"HOST fallback (D2H + TCP star + H2D per step): no RCCL communicator -- {comm.rccl_error}"),
@@ -305,6 +321,32 @@ def self_launch(n):
                     procs[q].terminate()
         time.sleep(0.05)
     return rc
+
+
+def pmc_issue(algorithmic_bytes, kernel_name, T):
+    """How close the sweep is to the bound that explains it at N = 4096 -- instruction ISSUE of a lone wavefront per SIMD -- from the same
+    committed SQ counter passes as `traffic` (same staleness rule): `frac` = SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES, the share of a
+    wavefront's resident cycles in which it was issuing an instruction (both counters in units of four cycles; 1.0 = an instruction in
+    every slot, the floor of this instruction stream on this mapping); `valu_frac` the vector share of it; instructions per
+    observation step per wavefront."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_counters.json"))):
+        try:
+            rec = json.load(open(path))
+        except Exception:
+            continue
+        if rec.get("algorithmic_bytes_per_launch") != algorithmic_bytes or not kernel_name:
+            continue
+        for k in rec.get("kernels", []):
+            c = {name: v.get("mean_per_launch") for name, v in (k.get("counters") or {}).items()} if isinstance(k.get("counters"), dict) else {}
+            if kernel_name in k.get("kernel", "") and c.get("SQ_WAVE_CYCLES") and c.get("SQ_WAVES"):
+                best = {"frac": c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"], "valu_frac": c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"],
+                        "wait_frac": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"],
+                        "valu_per_step": c["SQ_INSTS_VALU"] / c["SQ_WAVES"] / T, "salu_per_step": c["SQ_INSTS_SALU"] / c["SQ_WAVES"] / T,
+                        "cycles_per_step": 4.0 * c["SQ_WAVE_CYCLES"] / c["SQ_WAVES"] / T, "source": os.path.relpath(path, ROOT),
+                        "definition": "SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES of the sweep kernel (one wavefront per SIMD: no other wavefront fills the rest)"}
+    return best
 
 
 def pmc_traffic(algorithmic_bytes, kernel_name):
