@@ -56,6 +56,8 @@ class CdkfModel(C.Structure):
         ("R", _dp),
         ("m0", _dp),
         ("P0", _dp),
+        ("input_dim", C.c_int32),
+        ("reserved0", C.c_int32),
     ]
 
 
@@ -85,6 +87,7 @@ class CdkfOpts(C.Structure):
         ("flags", C.c_int32),
         ("dtmin", C.c_double),
         ("dtmax", C.c_double),
+        ("inputs", C.c_void_p),
     ]
 
 

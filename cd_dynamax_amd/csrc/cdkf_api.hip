@@ -96,13 +96,17 @@ int check_common(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T
                 "not both zero (solver %d, rtol %g, atol %g)", o->solver, o->rtol, o->atol);
       return CDKF_EINVAL;
     }
-    if (!(o->dtmin >= 0) || !(o->dtmax > 0) || !(o->dtmin <= o->dtmax)) {
-      set_error("adaptive stepping: need 0 <= dtmin <= dtmax, dtmax > 0 (got dtmin %g, dtmax %g; defaults 0 and infinity)", o->dtmin, o->dtmax);
+    if (!(o->dtmin >= 0) || !(o->dtmax >= 0) || (o->dtmax > 0 && !(o->dtmin <= o->dtmax))) {
+      set_error("adaptive stepping: need 0 <= dtmin <= dtmax (got dtmin %g, dtmax %g; defaults 0 and infinity, dtmax 0 = no bound)", o->dtmin, o->dtmax);
       return CDKF_EINVAL;
     }
   }
   if (o->flags & ~CDKF_FLAG_UKF_SIGMA_POINTS) {
     set_error("opts.flags = 0x%x has bits this library version does not know (CDKF_FLAG_*)", (unsigned)o->flags);
+    return CDKF_EINVAL;
+  }
+  if (mdl->input_dim < 0 || mdl->input_dim > 64) {
+    set_error("model.input_dim must be in 0 .. 64 (got %d)", mdl->input_dim);
     return CDKF_EINVAL;
   }
   if (o->num_iter < 1 || !(o->dt0 > 0) || o->max_steps < 1) {
@@ -153,6 +157,16 @@ int run_with_host_buffers(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, 
   if (o2P && (rc = d2P.alloc(nP * sizeof(R)))) return rc;
   CDKF_HIP_CHECK(hipMemcpy(dt.p, t, nt * sizeof(R), hipMemcpyHostToDevice));
   if (y) CDKF_HIP_CHECK(hipMemcpy(dy.p, y, (size_t)N * T * m * sizeof(R), hipMemcpyHostToDevice));
+  // inputs [N,T,d_u]: resident where y is -- uploaded here, the sweep gets the device copy through its own opts
+  DevBuf du_;
+  cdkf_opts od = *o;
+  if (mdl->input_dim > 0 && o->inputs) {
+    const size_t nu = (size_t)N * T * mdl->input_dim * sizeof(R);
+    if ((rc = du_.alloc(nu))) return rc;
+    CDKF_HIP_CHECK(hipMemcpy(du_.p, o->inputs, nu, hipMemcpyHostToDevice));
+    od.inputs = du_.p;
+  }
+  o = &od;
   rc = fn(mdl, o, N, T, (const R*)dt.p, (const R*)dy.p, (R*)dll.p, (R*)d1m.p, (R*)d1P.p, (R*)d2m.p, (R*)d2P.p,
           (int32_t*)dst.p, (void*)nullptr);
   if (rc) return rc;
@@ -253,6 +267,15 @@ int loglik_grad_host(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64
     return rc;
   CDKF_HIP_CHECK(hipMemcpy(dt.p, t, nt * sizeof(R), hipMemcpyHostToDevice));
   CDKF_HIP_CHECK(hipMemcpy(dy.p, y, ny * sizeof(R), hipMemcpyHostToDevice));
+  DevBuf du_;  // inputs [N,T,d_u]: as in run_with_host_buffers
+  cdkf_opts od = *o;
+  if (mdl->input_dim > 0 && o->inputs) {
+    const size_t nu = (size_t)N * T * mdl->input_dim * sizeof(R);
+    if ((rc = du_.alloc(nu))) return rc;
+    CDKF_HIP_CHECK(hipMemcpy(du_.p, o->inputs, nu, hipMemcpyHostToDevice));
+    od.inputs = du_.p;
+  }
+  o = &od;
   rc = (ukf && grad_model) ? launch_ukf_grad_all<R>(mdl, o, N, T, (const R*)dt.p, (const R*)dy.p, (R*)dll.p, (R*)dg.p, (R*)dgm.p,
                                                    (int32_t*)dst.p, nullptr)
        : ukf ? launch_ukf_grad<R>(mdl, o, N, T, (const R*)dt.p, (const R*)dy.p, (R*)dll.p, (R*)dg.p, (int32_t*)dst.p, nullptr)
@@ -518,6 +541,7 @@ void cdkf_default_opts(cdkf_opts* o) {
   o->flags = 0;
   o->dtmin = 0.0;
   o->dtmax = HUGE_VAL;
+  o->inputs = nullptr;
   o->max_steps = 100000;
   o->dt0 = 0.01;
   o->dt_final = 1e-10;

@@ -103,6 +103,10 @@ struct EkfSensRhs {
   const Drift& drift;
   const DriftGrad<R, D, Drift>& dg;
   const R* LQL;
+  static constexpr bool kTime = DriftTime<Drift>::value;
+  CDKF_DEV void set_time(R t) const {
+    if constexpr (kTime) drift.set_time(t);
+  }
   CDKF_DEV void operator()(const R (&y)[2 * NS], R (&dy)[2 * NS]) const {
     R F[D][D], f[D], dfth[D], dF[D][D];
     drift.f(y, f);
@@ -374,6 +378,7 @@ CDKF_DEV void ekf_grad_reg_body(const GradArgs<R, D, M, Drift>& ga) {
 #pragma unroll
     for (int r = 0; r < M; ++r) ynext[r] = yp[r * a.y_si];
     const R tnn = tp[0];
+    if constexpr (DriftInputs<Drift>::value) a.drift.load_inputs(a, n, k);
     if constexpr (UKF && D == 3) {  // leading principal minors of the predicted covariance
       const R p00 = ys[D + sidx<D>(0, 0)], p01 = ys[D + sidx<D>(0, 1)], p02 = ys[D + sidx<D>(0, 2)], p11 = ys[D + sidx<D>(1, 1)],
               p12 = ys[D + sidx<D>(1, 2)], p22 = ys[D + sidx<D>(2, 2)];

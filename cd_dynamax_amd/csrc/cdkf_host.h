@@ -164,7 +164,7 @@ inline bool fill_rk_tab(const cdkf_opts* o, RkTab<R>& tb) {
   tb.c2 = R(-(o->pid_p + 2 * o->pid_d) / ord);
   tb.c3 = R(o->pid_d / ord);
   tb.dtmin = R(o->dtmin);
-  tb.dtmax = R(o->dtmax);
+  tb.dtmax = (o->dtmax == 0.0) ? R(HUGE_VAL) : R(o->dtmax);  // (0: no bound -- a zero-initialised cdkf_opts keeps working)
   return true;
 }
 
@@ -266,6 +266,8 @@ void fill_reg_args(RegArgs<R, D, M, Drift>& a, const cdkf_model* mdl, const cdkf
   a.pm = pm;
   a.pP = pP;
   a.status = status;
+  a.u = nullptr;  // (the registry drifts ignore inputs and time, as the reference's own do: cdnlgssm_utils.py:50-83)
+  a.u_sn = a.u_sk = a.u_si = 0;
 }
 
 

@@ -55,6 +55,42 @@ struct Tol<float> {
   static constexpr float v = 1e-6f;
 };
 
+// ---- right-hand sides that depend on TIME (a drift f(x, u, t) given as source: the reference evaluates f and jacfwd(f) at the
+// solver's stage time, inference_ekf.py:95, 101-114).  A functor with `static constexpr bool kTime = true` gets `set_time(t_stage)`
+// before every evaluation, t_stage = (start of the step) + c_i dt with c_i = sum_j a_ij; everything else (every built-in drift: the
+// reference's own ignore t) compiles to exactly what it did before.  No <type_traits> here: hipRTC compiles this header too.
+template <typename T, typename = void>
+struct RhsTime {
+  static constexpr bool value = false;
+};
+template <typename T>
+struct RhsTime<T, decltype((void)T::kTime)> {
+  static constexpr bool value = T::kTime;
+};
+template <typename R, typename Rhs>
+CDKF_DEV void rhs_at(const Rhs& rhs, R t) {
+  if constexpr (RhsTime<Rhs>::value) rhs.set_time(t);
+}
+// ... and drifts / emissions that say so: `static constexpr bool TIME` (the source mentions t), `static constexpr int DU` (> 0: it reads
+// the inputs u[0 .. DU-1], u = inputs[t0_idx] held over the interval, inference_ekf.py:277-286).  Such a type has set_time(t) const and
+// load_inputs(args, n, k) const writing mutable members (the argument block is handed around by const reference).
+template <typename T, typename = void>
+struct DriftTime {
+  static constexpr bool value = false;
+};
+template <typename T>
+struct DriftTime<T, decltype((void)T::TIME)> {
+  static constexpr bool value = T::TIME;
+};
+template <typename T, typename = void>
+struct DriftInputs {
+  static constexpr bool value = false;
+};
+template <typename T>
+struct DriftInputs<T, decltype((void)T::DU)> {
+  static constexpr bool value = (T::DU > 0);
+};
+
 // ---- Cholesky of an M x M matrix given by its lower triangle (full storage S[a][b], a >= b read) --
 // Returns the factor in Lc (lower) and the reciprocal pivots in inv.  A non-positive pivot gives
 // NaN downstream (rsqrt of a negative), as jnp.linalg.cholesky does; `bad` is set for status.
@@ -160,8 +196,33 @@ struct Dp5V {
 //  * double: ((y0 + c_i1 f_1) + c_i2 f_2) + ...  with c_ij = dt a_ij formed once per step: one FMA per
 //    term (20 per state entry instead of 26).  The extra roundings are at 1e-16 relative.
 template <typename R, int NS, typename Rhs>
-CDKF_DEV void dopri5_step(R (&y)[NS], R dt, const Rhs& rhs, const Dp5V<R>& C) {
+CDKF_DEV void dopri5_step(R (&y)[NS], R dt, const Rhs& rhs, const Dp5V<R>& C, R t = R(0)) {
   R k1[NS], k2[NS], k3[NS], k4[NS], k5[NS], k6[NS], ys[NS];
+  if constexpr (RhsTime<Rhs>::value) {  // (time-dependent right-hand sides: the generic stage loop with the stage times; custom drifts only)
+    R k[6][NS];
+    constexpr R cs[6] = {R(0), R(1.0 / 5.0), R(3.0 / 10.0), R(4.0 / 5.0), R(8.0 / 9.0), R(1)};
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+#pragma unroll
+      for (int e = 0; e < NS; ++e) {
+        R acc = R(0);
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+          if (j < s) acc = rfma(Dp5T<R>::a[s][j], k[j][e], acc);
+        ys[e] = rfma(dt, acc, y[e]);
+      }
+      rhs.set_time(rfma(cs[s], dt, t));
+      rhs(ys, k[s]);
+    }
+#pragma unroll
+    for (int e = 0; e < NS; ++e) {
+      R acc = R(0);
+#pragma unroll
+      for (int s = 0; s < 6; ++s) acc = rfma(Dp5T<R>::b[s], k[s][e], acc);
+      y[e] = rfma(dt, acc, y[e]);
+    }
+    return;
+  }
   if constexpr (sizeof(R) == 8) {
     const R c21 = dt * C.a21, c31 = dt * C.a31, c32 = dt * C.a32, c41 = dt * C.a41, c42 = dt * C.a42,
             c43 = dt * C.a43, c51 = dt * C.a51, c52 = dt * C.a52, c53 = dt * C.a53, c54 = dt * C.a54,
@@ -234,8 +295,18 @@ struct RkTab {
   R dtmin, dtmax;  // bounds on every proposed step size (0 / +inf: none); a step taken at dtmin is kept (PIDController force_dtmin)
 };
 
+// stage time offset c_s = sum_j a_sj of a run-time tableau
+template <typename R>
+CDKF_DEV R rk_stage_c(const RkTab<R>& tb, int s) {
+  R c = R(0);
+#pragma unroll
+  for (int j = 0; j < 5; ++j)
+    if (j < s) c += tb.a[s][j];
+  return c;
+}
+
 template <typename R, int NS, typename Rhs>
-CDKF_DEV void rk_step(R (&y)[NS], R dt, const Rhs& rhs, const RkTab<R>& tb) {
+CDKF_DEV void rk_step(R (&y)[NS], R dt, const Rhs& rhs, const RkTab<R>& tb, R t = R(0)) {
   R k[6][NS], ys[NS];
 #pragma unroll
   for (int s = 0; s < 6; ++s) {
@@ -248,6 +319,7 @@ CDKF_DEV void rk_step(R (&y)[NS], R dt, const Rhs& rhs, const RkTab<R>& tb) {
           if (j < s) acc = rfma(tb.a[s][j], k[j][e], acc);
         ys[e] = rfma(dt, acc, y[e]);
       }
+      if constexpr (RhsTime<Rhs>::value) rhs.set_time(rfma(rk_stage_c(tb, s), dt, t));
       rhs(ys, k[s]);
     } else {
 #pragma unroll
@@ -310,6 +382,7 @@ CDKF_DEV bool integrate_adaptive(R (&y)[NS], R t0, R t1, R dt0, long max_steps, 
             if (j < s) acc = rfma(tb.a[s][j], k[j][e], acc);
           ys[e] = rfma(dt, acc, y[e]);
         }
+        if constexpr (RhsTime<Rhs>::value) rhs.set_time(rfma(rk_stage_c(tb, s), dt, tprev));
         rhs(ys, k[s]);
       } else {
 #pragma unroll
@@ -324,6 +397,7 @@ CDKF_DEV bool integrate_adaptive(R (&y)[NS], R t0, R t1, R dt0, long max_steps, 
       yn[e] = rfma(dt, acc, y[e]);
     }
     if (tb.fsal) {
+      if constexpr (RhsTime<Rhs>::value) rhs.set_time(tprev + dt);
       rhs(yn, k[6]);
     } else {
 #pragma unroll
@@ -387,7 +461,7 @@ CDKF_DEV bool integrate(R (&y)[NS], R t0, R t1, R dt0, long max_steps, const Rhs
       capped = true;
       break;
     }
-    rk_step<R, NS>(y, tnext - tprev, rhs, tb);
+    rk_step<R, NS>(y, tnext - tprev, rhs, tb, tprev);
     tprev = rmin(tnext, t1);
     R tn = tnext + dt0;
     tnext = (tn > t1 - Tol<R>::v) ? t1 : tn;
@@ -407,7 +481,7 @@ CDKF_DEV bool integrate(R (&y)[NS], R t0, R t1, R dt0, long max_steps, const Rhs
       capped = true;
       break;
     }
-    dopri5_step<R, NS>(y, tnext - tprev, rhs, C);
+    dopri5_step<R, NS>(y, tnext - tprev, rhs, C, tprev);
     tprev = rmin(tnext, t1);
     R tn = tnext + dt0;
     tnext = (tn > t1 - Tol<R>::v) ? t1 : tn;

@@ -50,6 +50,10 @@ struct RegArgs {
   R* pm;
   R* pP;
   int* status;
+  // inputs u[n][k][0 .. d_u-1] (element (n, k, i) at n * u_sn + k * u_sk + i * u_si, laid out like y): read only by drifts / emissions
+  // given as source that name them (DriftInputs); null otherwise
+  const R* u;
+  long u_sn, u_sk, u_si;
 };
 
 // Unit (trajectory; (trajectory, parameter) pair in the gradient sweep) of this lane.  `lanes` consecutive units per
@@ -90,6 +94,10 @@ struct EkfRhs {
   const Drift& drift;
   const R* LQL;
   int order;
+  static constexpr bool kTime = DriftTime<Drift>::value;
+  CDKF_DEV void set_time(R t) const {
+    if constexpr (kTime) drift.set_time(t);
+  }
   CDKF_DEV void operator()(const R (&y)[NS], R (&dy)[NS]) const {
     R F[D][D], f[D];
     drift.f(y, f);
@@ -134,6 +142,10 @@ struct EkfRhs {
 template <typename R, int D, typename Drift>
 struct MeanRhs {
   const Drift& drift;
+  static constexpr bool kTime = DriftTime<Drift>::value;
+  CDKF_DEV void set_time(R t) const {
+    if constexpr (kTime) drift.set_time(t);
+  }
   CDKF_DEV void operator()(const R (&y)[D], R (&dy)[D]) const { drift.f(y, dy); }
 };
 
@@ -364,6 +376,10 @@ struct UkfRhs {
   static constexpr int NS = Dims<D>::NS;
   const Args& a;
   bool* bad;
+  static constexpr bool kTime = DriftTime<decltype(Args::drift)>::value;  // (every sigma point's drift at the stage time, inference_ukf.py:142)
+  CDKF_DEV void set_time(R t) const {
+    if constexpr (kTime) a.drift.set_time(t);
+  }
   CDKF_DEV void operator()(const R (&y)[NS], R (&dy)[NS]) const {
     R o[D][D];
     ukf_offsets<R, D>(y, a.ukf_c, o, *bad);
@@ -746,6 +762,52 @@ struct SmoothRhs {
   }
 };
 
+// ... for a drift that depends on time the hoisting is not available: f(m_f, u, t) and jacfwd(f)(m_f, u, t) are evaluated in every
+// stage at t = t1 - s (inference_ekf.py:433-438 under reverse_rhs, diffrax_utils.py:13-25); aux = psd_solve(P_f, L Qc L^T)^T stays
+template <typename R, int D, typename Drift>
+struct SmoothRhsT {
+  static constexpr int NS = Dims<D>::NS;
+  static constexpr bool kTime = true;
+  const Drift& drift;
+  R aux[D][D];
+  R mf[D];
+  R tend;
+  const R* LQL;
+  CDKF_DEV void set_time(R s) const { drift.set_time(tend - s); }
+  CDKF_DEV void operator()(const R (&y)[NS], R (&dy)[NS]) const {
+    R G[D][D], fmf[D], dm[D];
+    drift.f(mf, fmf);
+    drift.jac(mf, G);
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int j = 0; j < D; ++j) G[i][j] += aux[i][j];
+#pragma unroll
+    for (int i = 0; i < D; ++i) dm[i] = y[i] - mf[i];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      R s = G[i][0] * dm[0];
+#pragma unroll
+      for (int k = 1; k < D; ++k) s = rfma(G[i][k], dm[k], s);
+      dy[i] = -(fmf[i] + s);
+    }
+    R A[D][D];
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        R s = G[i][0] * y[D + sidx<D>(0, j)];
+#pragma unroll
+        for (int k = 1; k < D; ++k) s = rfma(G[i][k], y[D + sidx<D>(k, j)], s);
+        A[i][j] = s;
+      }
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int j = i; j < D; ++j) dy[D + sidx<D>(i, j)] = -((A[i][j] + A[j][i]) - LQL[sidx<D>(i, j)]);
+  }
+};
+
 template <typename R, int D, int M, typename Drift, bool GENERIC = false>
 CDKF_DEV void ekf_smoother_reg_body(const RegArgs<R, D, M, Drift>& a, R* __restrict__ sm, R* __restrict__ sP) {
   constexpr int NS = Dims<D>::NS;
@@ -810,8 +872,16 @@ CDKF_DEV void ekf_smoother_reg_body(const RegArgs<R, D, M, Drift>& a, R* __restr
         for (int j = i; j < D; ++j) Pf_n[sidx<D>(i, j)] = fP[kn * a.P_sk + (i * D + j) * a.P_si];
       t0_n = tp[kn * a.t_sk];
     }
-    a.drift.f(rhs.mf, rhs.fmf);
-    a.drift.jac(rhs.mf, rhs.G);
+    if constexpr (DriftInputs<Drift>::value) a.drift.load_inputs(a, n, k);  // u = inputs[t0_idx] of the interval (inference_ekf.py:516)
+    if constexpr (!DriftTime<Drift>::value) {
+      a.drift.f(rhs.mf, rhs.fmf);
+      a.drift.jac(rhs.mf, rhs.G);
+    } else {
+#pragma unroll
+      for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j < D; ++j) rhs.G[i][j] = R(0);
+    }
     // aux = psd_solve(P_f, LQL)^T
     R Sb[D][D], Lb[D][D], invb[D], X[D][D];
 #pragma unroll
@@ -832,7 +902,18 @@ CDKF_DEV void ekf_smoother_reg_body(const RegArgs<R, D, M, Drift>& a, R* __restr
     for (int i = 0; i < D; ++i)
 #pragma unroll
       for (int j = 0; j < D; ++j) rhs.G[i][j] += X[j][i];
-    if (integrate<R, NS>(ys, R(0), t1 - t0, a.dt0, a.max_steps, rhs, C)) st |= kStatusMaxSteps;
+    if constexpr (DriftTime<Drift>::value) {
+      SmoothRhsT<R, D, Drift> rt{a.drift, {}, {}, t1, a.LQL};
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        rt.mf[i] = rhs.mf[i];
+#pragma unroll
+        for (int j = 0; j < D; ++j) rt.aux[i][j] = rhs.G[i][j];
+      }
+      if (integrate<R, NS>(ys, R(0), t1 - t0, a.dt0, a.max_steps, rt, C)) st |= kStatusMaxSteps;
+    } else {
+      if (integrate<R, NS>(ys, R(0), t1 - t0, a.dt0, a.max_steps, rhs, C)) st |= kStatusMaxSteps;
+    }
     store_moments_all<R, D>(sm, sP, n * a.m_sn + k * a.m_sk, n * a.P_sn + k * a.P_sk, a.m_si, a.P_si, ys);
     t1 = t0;
   }

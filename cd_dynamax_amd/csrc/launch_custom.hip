@@ -44,7 +44,8 @@ std::string g_src_dir;
 
 // kind, bytes per real, emission_dim, ukf, zeroth, forecast, smoother (2: the log-likelihood gradient sweep), generic Runge-Kutta
 // tableau, emission kind (0: linear)
-using Key = std::tuple<int, int, int, int, int, int, int, int, int>;
+// kind, bytes per real, m, ukf, zeroth, forecast, smoother (0 filter, 1 smoother, 2 gradient), generic tableau, emission kind, input_dim
+using Key = std::tuple<int, int, int, int, int, int, int, int, int, int>;
 struct Compiled {
   hipModule_t module = nullptr;
   hipFunction_t fn = nullptr;
@@ -258,11 +259,30 @@ void rtc_cache_store(const std::string& key, const std::vector<char>& code, cons
   if (fclose(f) != 0 || !ok || rename(tmp.c_str(), final_name.c_str()) != 0) (void)unlink(tmp.c_str());
 }
 
+// does the snippet name the identifier `w` (a whole word: `t` in "theta" or "tanh" does not count)?
+bool has_word(const std::string& src, const std::string& w) {
+  auto idc = [](char ch) { return (ch >= 'a' && ch <= 'z') || (ch >= 'A' && ch <= 'Z') || (ch >= '0' && ch <= '9') || ch == '_'; };
+  for (size_t p = src.find(w); p != std::string::npos; p = src.find(w, p + 1)) {
+    const bool l = p == 0 || !idc(src[p - 1]), r = p + w.size() >= src.size() || !idc(src[p + w.size()]);
+    if (l && r) return true;
+  }
+  return false;
+}
+// the drift reads the time (f(x, u, t): stage times reach it through set_time) / the emission does
+bool drift_uses_time(const CustomDrift& c) { return has_word(c.f_src, "t") || has_word(c.jac_src, "t") || has_word(c.g_src, "t"); }
+bool drift_reads_context(const CustomDrift& c) {
+  return drift_uses_time(c) || has_word(c.f_src, "u") || has_word(c.jac_src, "u") || has_word(c.g_src, "u");
+}
+
 std::string generate_source(const CustomDrift& c, int bytes, int m, int ukf, int zeroth, int forecast, int smoother,
-                            int generic, const CustomEmission* em) {
+                            int generic, const CustomEmission* em, int du) {
   std::string s;
   const bool grad = smoother == 2;
   const std::string D_ = std::to_string(c.d), NT_ = std::to_string(c.n_theta > 0 ? c.n_theta : 1);
+  const std::string DU_ = std::to_string(du), DU1_ = std::to_string(du > 0 ? du : 1);
+  const bool time_dep = drift_uses_time(c);
+  // what every snippet sees beside x and theta: the inputs row of the interval and the (stage) time -- f(x, u, t), inference_ekf.py:95, 101-114
+  const std::string ctx = "    const R* u = u_; const R t = t_; (void)u; (void)t;\n";
   s += grad ? "#include \"cdkf_grad_kernels.h\"\n" : "#include \"cdkf_reg_kernels.h\"\n";
   s += "#include \"cdkf_dual.h\"\n";
   s += "namespace cdkf {\n";
@@ -270,16 +290,23 @@ std::string generate_source(const CustomDrift& c, int bytes, int m, int ukf, int
   s += "  static constexpr int NTHETA = " + std::to_string(c.n_theta) + ";\n";
   s += "  static constexpr bool HAS_G = " + std::string(c.has_g ? "true" : "false") + ";\n";
   s += "  static constexpr bool CONST_JAC = false;\n";
+  s += "  static constexpr int DU = " + DU_ + ";\n  static constexpr bool TIME = " + std::string(time_dep ? "true" : "false") + ";\n";
   s += "  R th[" + std::to_string(c.n_theta > 0 ? c.n_theta : 1) + "];\n";
+  // inputs of the current interval and the time of the current evaluation: written through const references (the argument block travels
+  // as one), read by the snippets as `u` and `t`; the dual-number evaluations leave both constant
+  s += "  mutable R u_[" + DU1_ + "];\n  mutable R t_;\n";
+  s += "  CDKF_DEV void set_time(R tt) const { t_ = tt; }\n";
+  s += "  template <typename A_> CDKF_DEV void load_inputs(const A_& a, long n, long k) const {\n"
+       "    for (int i_ = 0; i_ < DU; ++i_) u_[i_] = a.u ? a.u[n * a.u_sn + k * a.u_sk + i_ * a.u_si] : R(0);\n  }\n";
   s += "  static constexpr bool nz(int, int) { return true; }\n";
-  s += "  CDKF_DEV void f(const R* x, R (&fx)[D]) const {\n    const R* theta = th; (void)theta;\n";
+  s += "  CDKF_DEV void f(const R* x, R (&fx)[D]) const {\n    const R* theta = th; (void)theta;\n" + ctx;
   s += "#line 1 \"drift_f\"\n" + c.f_src + "\n  }\n";
   // the same statements with the scalar type T in place of the compute type: T = a dual number differentiates them (cdkf_dual.h)
   if (c.auto_jac || c.auto_g || grad) {
-    s += "  template <typename T> CDKF_DEV void f_t(const T* x, const T* theta, T (&fx)[D]) const {\n    (void)theta;\n";
+    s += "  template <typename T> CDKF_DEV void f_t(const T* x, const T* theta, T (&fx)[D]) const {\n    (void)theta;\n" + ctx;
     s += "#line 1 \"drift_f\"\n" + c.f_src + "\n  }\n";
   }
-  s += "  CDKF_DEV void jac(const R* x, R (&F)[D][D]) const {\n    const R* theta = th; (void)theta;\n";
+  s += "  CDKF_DEV void jac(const R* x, R (&F)[D][D]) const {\n    const R* theta = th; (void)theta;\n" + ctx;
   s += "    for (int i_ = 0; i_ < D; ++i_) for (int j_ = 0; j_ < D; ++j_) F[i_][j_] = R(0);\n";
   if (c.auto_jac) {  // jacfwd(f): D unit directions (inference_ekf.py:95)
     s += "    typedef Dual<R, D> T;\n    T xt[D], tht[" + NT_ + "], ft[D];\n";
@@ -290,7 +317,7 @@ std::string generate_source(const CustomDrift& c, int bytes, int m, int ukf, int
   } else {
     s += "#line 1 \"drift_jacobian\"\n" + c.jac_src + "\n  }\n";
   }
-  s += "  CDKF_DEV void divgrad(const R* x, R (&g)[D]) const {\n    const R* theta = th; (void)theta;\n";
+  s += "  CDKF_DEV void divgrad(const R* x, R (&g)[D]) const {\n    const R* theta = th; (void)theta;\n" + ctx;
   s += "    for (int i_ = 0; i_ < D; ++i_) g[i_] = R(0);\n";
   if (c.auto_g) {  // g_i = d/dx_i sum_j d f_j / d x_j: second derivatives from nested dual numbers (inference_ekf.py:108-116)
     s += "    typedef Dual<R, D> S1;\n    typedef Dual<S1, D> T;\n    T xt[D], tht[" + NT_ + "], ft[D];\n";
@@ -326,17 +353,21 @@ std::string generate_source(const CustomDrift& c, int bytes, int m, int ukf, int
   if (em) {
     // emission parameters eta = [the model's H block (m x d, row-major) | h_bias (m)], read from the argument block
     s += "namespace cdkf {\ntemplate <typename R, int D, int M>\nstruct EmisCustom {\n";
-    s += "  static constexpr bool kCustom = true;\n  R eta_[M * D + M];\n";
+    s += "  static constexpr bool kCustom = true;\n  R eta_[M * D + M];\n  R u_[" + DU1_ + "];\n  R t_;\n";
+    // h(x, u, t0), H(x, u, t0): this step's inputs row and observation time (inference_ekf.py:277-286)
+    s += "  template <typename A_> CDKF_DEV void set_ctx(const A_& a, long n, long k, R tt) {\n    t_ = tt;\n"
+         "    for (int i_ = 0; i_ < " + DU_ + "; ++i_) u_[i_] = a.u ? a.u[n * a.u_sn + k * a.u_sk + i_ * a.u_si] : R(0);\n"
+         "    if (" + DU_ + " == 0) u_[0] = R(0);\n  }\n";
     s += "  template <typename Args> CDKF_DEV void load(const Args& a) {\n";
     s += "    for (int r = 0; r < M; ++r) { for (int k = 0; k < D; ++k) eta_[r * D + k] = a.H[r][k]; eta_[M * D + r] = a.hb[r]; }\n  }\n";
-    s += "  CDKF_DEV void h(const R* x, R (&hx)[M]) const {\n    const R* eta = eta_; (void)eta;\n";
+    s += "  CDKF_DEV void h(const R* x, R (&hx)[M]) const {\n    const R* eta = eta_; (void)eta;\n" + ctx;
     s += "#line 1 \"emission_h\"\n" + em->h_src + "\n  }\n";
     const bool auto_hjac = blank(em->jac_src);  // jacfwd(h) by dual numbers (inference_ekf.py:258-259)
     if (auto_hjac) {
-      s += "  template <typename T> CDKF_DEV void h_t(const T* x, const T* eta, T (&hx)[M]) const {\n    (void)eta;\n";
+      s += "  template <typename T> CDKF_DEV void h_t(const T* x, const T* eta, T (&hx)[M]) const {\n    (void)eta;\n" + ctx;
       s += "#line 1 \"emission_h\"\n" + em->h_src + "\n  }\n";
     }
-    s += "  CDKF_DEV void jac(const R* x, R (&H)[M][D]) const {\n    const R* eta = eta_; (void)eta;\n";
+    s += "  CDKF_DEV void jac(const R* x, R (&H)[M][D]) const {\n    const R* eta = eta_; (void)eta;\n" + ctx;
     s += "    for (int r_ = 0; r_ < M; ++r_) for (int k_ = 0; k_ < D; ++k_) H[r_][k_] = R(0);\n";
     if (auto_hjac) {
       s += "    typedef Dual<R, D> T;\n    T xt[D], et[M * D + M], ht[M];\n";
@@ -353,10 +384,11 @@ std::string generate_source(const CustomDrift& c, int bytes, int m, int ukf, int
   s += "constexpr int DD = " + std::to_string(c.d) + ", MM = " + std::to_string(m) + ";\n";
   s += "using Drift = cdkf::DriftCustom<R, DD>;\nusing Args = cdkf::RegArgs<R, DD, MM, Drift>;\n";
   // parameter blob (reals): theta | LQL | LQLz | H | hb | Rm | m0 | P0 | dt0 dt_final ukf_c ukf_wm0 ukf_wc0 ukf_wi | rk.a[30] rk.b[6] rk.berr[7] rtol atol c1 c2 c3 | dtmin dtmax
-  // integer blob (longs) : max_steps order num_iter forecast N T t_sn t_sk y_sn y_sk y_si m_sn m_sk m_si P_sn P_sk P_si
+  // integer blob (longs) : max_steps order num_iter forecast N T t_sn t_sk y_sn y_sk y_si m_sn m_sk m_si P_sn P_sk P_si stages solver
+  //                        adaptive fsal lanes xcd_shift u_sn u_sk u_si
   s += R"(
 __device__ __forceinline__ void unpack(Args& a, const R* __restrict__ par, const long* __restrict__ ip, const R* t, const R* y,
-                                       R* ll, R* fm, R* fP, R* pm, R* pP, int* status) {
+                                       R* ll, R* fm, R* fP, R* pm, R* pP, int* status, const R* u) {
   constexpr int NP = cdkf::Dims<DD>::NP;
   int o = 0;
   for (int k = 0; k < Drift::NTHETA; ++k) a.drift.th[k] = par[o + k];
@@ -391,24 +423,27 @@ __device__ __forceinline__ void unpack(Args& a, const R* __restrict__ par, const
   a.t_sn = ip[6]; a.t_sk = ip[7]; a.y_sn = ip[8]; a.y_sk = ip[9]; a.y_si = ip[10]; a.m_sn = ip[11]; a.m_sk = ip[12];
   a.m_si = ip[13]; a.P_sn = ip[14]; a.P_sk = ip[15]; a.P_si = ip[16];
   a.t = t; a.y = y; a.ll = ll; a.fm = fm; a.fP = fP; a.pm = pm; a.pP = pP; a.status = status;
+  a.u = u; a.u_sn = ip[23]; a.u_sk = ip[24]; a.u_si = ip[25];
+  a.drift.t_ = R(0);
+  for (int k = 0; k < (Drift::DU > 0 ? Drift::DU : 1); ++k) a.drift.u_[k] = R(0);
 }
 )";
   if (grad) {
     s += "extern \"C\" __global__ __launch_bounds__(64, 1) void cdkf_custom_kernel(const R* par, const long* ip, const R* t, "
-         "const R* y, R* ll, R* fm, R* fP, R* pm, R* pP, int* status, R* sm, R* sP) {\n  cdkf::GradArgs<R, DD, MM, Drift> ga;\n"
-         "  unpack(ga.a, par, ip, t, y, ll, nullptr, nullptr, nullptr, nullptr, status);\n  ga.grad = fm;\n";
+         "const R* y, R* ll, R* fm, R* fP, R* pm, R* pP, int* status, R* sm, R* sP, const R* u) {\n  cdkf::GradArgs<R, DD, MM, Drift> ga;\n"
+         "  unpack(ga.a, par, ip, t, y, ll, nullptr, nullptr, nullptr, nullptr, status, u);\n  ga.grad = fm;\n";
     s += "  cdkf::ekf_grad_reg_body<R, DD, MM, Drift, " + std::string(generic ? "true" : "false") + ", false>(ga);\n}\n";
   } else if (!smoother) {
     s += "extern \"C\" __global__ __launch_bounds__(64, 1) void cdkf_custom_kernel(const R* par, const long* ip, const R* t, "
-         "const R* y, R* ll, R* fm, R* fP, R* pm, R* pP, int* status, R* sm, R* sP) {\n  Args a;\n"
-         "  unpack(a, par, ip, t, y, ll, fm, fP, pm, pP, status);\n";
+         "const R* y, R* ll, R* fm, R* fP, R* pm, R* pP, int* status, R* sm, R* sP, const R* u) {\n  Args a;\n"
+         "  unpack(a, par, ip, t, y, ll, fm, fP, pm, pP, status, u);\n";
     s += "  cdkf::filter_reg_body<R, DD, MM, Drift, " + std::string(ukf ? "true" : "false") + ", " +
          std::string(zeroth ? "true" : "false") + ", false, cdkf::kOutSome, " + std::string(forecast ? "true" : "false") + ", " +
          std::string(generic ? "true" : "false") + (em ? ", cdkf::EmisCustom<R, DD, MM>" : "") + ">(a);\n}\n";
   } else {
     s += "extern \"C\" __global__ __launch_bounds__(64) void cdkf_custom_kernel(const R* par, const long* ip, const R* t, "
-         "const R* y, R* ll, R* fm, R* fP, R* pm, R* pP, int* status, R* sm, R* sP) {\n  Args a;\n"
-         "  unpack(a, par, ip, t, y, ll, fm, fP, pm, pP, status);\n"
+         "const R* y, R* ll, R* fm, R* fP, R* pm, R* pP, int* status, R* sm, R* sP, const R* u) {\n  Args a;\n"
+         "  unpack(a, par, ip, t, y, ll, fm, fP, pm, pP, status, u);\n"
          "  cdkf::ekf_smoother_reg_body<R, DD, MM, Drift, " + std::string(generic ? "true" : "false") + ">(a, sm, sP);\n}\n";
   }
   return s;
@@ -423,7 +458,7 @@ int compile_variant(const CustomDrift& c, const Key& key, const std::string& arc
     em = g_emis[ek - CDKF_EMISSION_CUSTOM_BASE];
   }
   const std::string src = generate_source(c, std::get<1>(key), std::get<2>(key), std::get<3>(key), std::get<4>(key),
-                                          std::get<5>(key), std::get<6>(key), std::get<7>(key), ek ? &em : nullptr);
+                                          std::get<5>(key), std::get<6>(key), std::get<7>(key), ek ? &em : nullptr, std::get<9>(key));
   // The forward-sensitivity sweep (algorithm 2) is built at -O1: from four state dimensions on the kernel sits at all 512 registers
   // plus 0.6 - 2.6 KB of scratch per lane, and at -O2 / -O3 (ROCm 7.2 hipRTC, gfx950) some builds of the d = 6 instantiation return a wrong
   // d ll / d theta -- deterministic per build, flipping with spellings of the drift that generate the same arithmetic (`pow(x, 2)` against
@@ -886,6 +921,7 @@ bool custom_adjoint_available(const cdkf_model* mdl, const cdkf_opts* o) {
   std::lock_guard<std::mutex> lock(g_mutex);
   const CustomDrift& c = g_drifts[mdl->drift_kind - CDKF_DRIFT_CUSTOM_BASE];
   if (c.d != mdl->state_dim || c.n_theta != mdl->n_theta) return false;
+  if (drift_reads_context(c)) return false;  // (the reverse sweep does not carry inputs / stage times yet: DESIGN.md section 6)
   // 'second': grad(div f) registered as identically zero, or "auto" (third derivatives by triply nested dual numbers)
   if (o->state_order == CDKF_ORDER_SECOND && !(c.has_g && (c.auto_g || blank(c.g_src)))) return false;
   const int q = c.d > mdl->emission_dim ? c.d : mdl->emission_dim, Z = c.d + c.n_theta;
@@ -936,6 +972,7 @@ bool custom_shape_available(const cdkf_model* mdl, const cdkf_opts* o) {
     if (c.d != mdl->state_dim || c.n_theta != mdl->n_theta) return false;
     if (o && o->state_order == CDKF_ORDER_SECOND && !c.has_g) return false;
     cd = c.d;
+    if ((cd > 6 || mdl->emission_dim > 6) && drift_reads_context(c)) return false;  // (workgroup kernels: no inputs / stage times yet)
   }
   if (cd > 6 || mdl->emission_dim > 6)  // the workgroup kernels: linear emission, their LDS plan (asked in fp32; an fp64 launch that
     return mdl->emission_kind == 0 && custom_wg_fits(mdl);  // does not fit says so itself)
@@ -958,12 +995,13 @@ bool custom_grad_available(const cdkf_model* mdl, const cdkf_opts* o) {
 //   reals: theta | LQL | LQLz | H | hb | Rm | m0 | P0 | dt0 dt_final ukf_c ukf_wm0 ukf_wc0 ukf_wi | rk.a[30] rk.b[6] rk.berr[7] rtol atol c1 c2 c3
 //          | dtmin dtmax
 //   longs: max_steps order num_iter forecast N T t_sn t_sk y_sn y_sk y_si m_sn m_sk m_si P_sn P_sk P_si stages solver adaptive fsal lanes xcd_shift
+//          u_sn u_sk u_si
 // Host arithmetic only (cdkf_debug_custom_reg_blob hands them to the CPU-sanitizer build of the same kernel, tests/test_hostsim.py).
 // (round 5: dtmin / dtmax were missing -- an adaptive solve of a source drift on these kernels clipped its steps to whatever the
 //  uninitialised fields of the kernel's argument struct held; found by reading the generated source for the MemorySanitizer build)
 template <typename R>
 static RegGrouping custom_reg_blob(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, bool smoother, bool gradient, bool no_y,
-                                   std::vector<R>& par, long (&ip)[23]) {
+                                   std::vector<R>& par, long (&ip)[26]) {
   const int d = mdl->state_dim, m = mdl->emission_dim;
   const int np = d * (d + 1) / 2;
   par.clear();
@@ -1015,6 +1053,9 @@ static RegGrouping custom_reg_blob(const cdkf_model* mdl, const cdkf_opts* o, in
     long* st = ip + 6;  // t_sn t_sk y_sn y_sk y_si m_sn m_sk m_si P_sn P_sk P_si
     st[0] = ss.t_sn; st[1] = ss.t_sk; st[2] = ss.y_sn; st[3] = ss.y_sk; st[4] = ss.y_si; st[5] = ss.m_sn; st[6] = ss.m_sk;
     st[7] = ss.m_si; st[8] = ss.P_sn; st[9] = ss.P_sk; st[10] = ss.P_si;
+    const int lin = (o->layout_in == CDKF_LAYOUT_SAME) ? o->layout : o->layout_in;
+    const ArrayStrides us = layout_strides(lin, N, T, mdl->input_dim > 0 ? mdl->input_dim : 1);
+    ip[23] = us.sn; ip[24] = us.sk; ip[25] = us.si;
   }
   return grouping;
 }
@@ -1078,8 +1119,10 @@ int launch_custom(int algo, const cdkf_model* mdl, const cdkf_opts* o, int64_t N
   }
   // ---- parameter blobs -----------------------------------------------------------------------------------------------
   std::vector<R> par;
-  long ip[23];
+  long ip[26];
   const RegGrouping grouping = custom_reg_blob<R>(mdl, o, N, T, smoother, gradient, !y, par, ip);
+  const int du = mdl->input_dim;
+  const R* uu = du > 0 ? (const R*)o->inputs : nullptr;  // (device memory here: the host entry points have uploaded it)
   const int generic = o->solver != CDKF_SOLVER_DOPRI5 || o->adaptive;
   const R* yy = y ? y : t;  // forecast mode ignores the observations; keep the prefetch loads on valid memory
   const size_t par_bytes = par.size() * sizeof(R), blob = ((par_bytes + 15) & ~size_t(15)) + sizeof(ip);
@@ -1101,18 +1144,18 @@ int launch_custom(int algo, const cdkf_model* mdl, const cdkf_opts* o, int64_t N
     int r = get_function(mdl->drift_kind, key, &fn);
     if (r) return r;
     void* args[] = {(void*)&dpar, (void*)&dip, (void*)&t, (void*)&yy, (void*)&ll, (void*)&o1, (void*)&o2,
-                    (void*)&o3,   (void*)&o4,  (void*)&status, (void*)&sm, (void*)&sP};
+                    (void*)&o3,   (void*)&o4,  (void*)&status, (void*)&sm, (void*)&sP, (void*)&uu};
     CDKF_HIP_CHECK(hipModuleLaunchKernel(fn, blocks, 1, 1, 64, 1, 1, 0, stream, args, nullptr));
     return CDKF_OK;
   };
   const int zeroth = (algo != 1 && o->state_order == CDKF_ORDER_ZEROTH) ? 1 : 0;
   if (gradient) {
-    rc = run(Key(mdl->drift_kind, (int)sizeof(R), m, 0, 0, 0, 2, generic, 0), a1, null_r, null_r, null_r, null_r, null_r);
+    rc = run(Key(mdl->drift_kind, (int)sizeof(R), m, 0, 0, 0, 2, generic, 0, du), a1, null_r, null_r, null_r, null_r, null_r);
   } else if (!smoother) {
-    rc = run(Key(mdl->drift_kind, (int)sizeof(R), m, algo == 1, zeroth, o->forecast ? 1 : 0, 0, generic, ek), a1, a2, a3, a4, null_r, null_r);
+    rc = run(Key(mdl->drift_kind, (int)sizeof(R), m, algo == 1, zeroth, o->forecast ? 1 : 0, 0, generic, ek, du), a1, a2, a3, a4, null_r, null_r);
   } else {
-    rc = run(Key(mdl->drift_kind, (int)sizeof(R), m, 0, zeroth, 0, 0, generic, ek), a1, a2, null_r, null_r, null_r, null_r);
-    if (!rc) rc = run(Key(mdl->drift_kind, (int)sizeof(R), m, 0, 0, 0, 1, generic, 0), a1, a2, null_r, null_r, a3, a4);
+    rc = run(Key(mdl->drift_kind, (int)sizeof(R), m, 0, zeroth, 0, 0, generic, ek, du), a1, a2, null_r, null_r, null_r, null_r);
+    if (!rc) rc = run(Key(mdl->drift_kind, (int)sizeof(R), m, 0, 0, 0, 1, generic, 0, du), a1, a2, null_r, null_r, a3, a4);
   }
   const int rc2 = lease.release();
   return rc ? rc : rc2;
@@ -1153,8 +1196,15 @@ int custom_register(int state_dim, int n_theta, const char* f_src, const char* j
 int custom_compile_check(int kind, int bytes_per_real, int emission_dim, int algo, int state_order, int emission_kind) {
   // algo + 16: the register-resident variant that reads its Runge-Kutta tableau / step-size controller from the arguments (what a
   // launch with opts.solver != Dormand-Prince or opts.adaptive compiles) instead of the pinned Dormand-Prince constants
+  // ... + 256 * input_dim: the variant for a model with that many inputs per row (cdkf_model.input_dim; the snippets' `u`)
+  const int du = algo / 256;
+  algo -= 256 * du;
   const int generic = (algo >= 16) ? 1 : 0;
   if (generic) algo -= 16;
+  if (du < 0 || du > 64) {
+    set_error("custom drift compile check: input_dim %d", du);
+    return CDKF_EINVAL;
+  }
   if (emission_kind && !custom_emission_kind(emission_kind, c_dim(kind), emission_dim)) {
     set_error("custom emission %d is not registered for this state / emission dimension", emission_kind);
     return CDKF_EINVAL;
@@ -1197,9 +1247,9 @@ int custom_compile_check(int kind, int bytes_per_real, int emission_dim, int alg
     return rc;
   }
   const int zeroth = (algo != 1 && state_order == CDKF_ORDER_ZEROTH) ? 1 : 0;
-  if (algo == 3) return compile_variant(c, Key(kind, bytes_per_real, emission_dim, 0, 0, 0, 2, generic, 0), "gfx950", code);
-  int rc = compile_variant(c, Key(kind, bytes_per_real, emission_dim, algo == 1, zeroth, 0, 0, generic, emission_kind), "gfx950", code);
-  if (!rc && algo == 2) rc = compile_variant(c, Key(kind, bytes_per_real, emission_dim, 0, 0, 0, 1, generic, 0), "gfx950", code);
+  if (algo == 3) return compile_variant(c, Key(kind, bytes_per_real, emission_dim, 0, 0, 0, 2, generic, 0, du), "gfx950", code);
+  int rc = compile_variant(c, Key(kind, bytes_per_real, emission_dim, algo == 1, zeroth, 0, 0, generic, emission_kind, du), "gfx950", code);
+  if (!rc && algo == 2) rc = compile_variant(c, Key(kind, bytes_per_real, emission_dim, 0, 0, 0, 1, generic, 0, du), "gfx950", code);
   return rc;
 }
 
@@ -1210,7 +1260,7 @@ int custom_debug_reg_blob(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, 
     set_error("cdkf_debug_custom_reg_blob: bad arguments");
     return CDKF_EINVAL;
   }
-  long ip[23];
+  long ip[26];
   int64_t n = 0;
   unsigned blocks = 0;
   if (bytes_per_real == 8) {
@@ -1226,8 +1276,8 @@ int custom_debug_reg_blob(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, 
     if (n * 4 > par_cap_bytes) return CDKF_EINVAL;
     std::memcpy(par_out, par.data(), n * 4);
   }
-  for (int k = 0; k < 23; ++k) ip_out[k] = ip[k];
-  ip_out[23] = blocks;
+  for (int k = 0; k < 26; ++k) ip_out[k] = ip[k];
+  ip_out[26] = blocks;
   return (int)n;
 }
 

@@ -184,6 +184,36 @@ def _squeeze(a, batched):
     return a if (batched or a is None) else a[0]
 
 
+def _attach_inputs(mdl, opts, inputs, y, dtype):
+    """``inputs`` ([T, d_u], shared by the batch, or [N, T, d_u]) -> cdkf_model.input_dim / cdkf_opts.inputs, resident where ``y`` is.
+    The reference hands u = inputs[t0_idx] and the time to the drift and the emission with every call -- f(m, u, t), h(m, u, t)
+    (inference_ekf.py:95, 101-114, 277-286; inference_ukf.py:142, 189): a LearnableCustomDrift / LearnableCustomEmission snippet reads
+    them as ``u[i]`` and ``t``; the registry drifts ignore both, as the reference's own Learnable* classes do (cdnlgssm_utils.py:50-83)."""
+    if inputs is None:
+        return
+    N, T = int(y.shape[0]), int(y.shape[1])
+    if _device.is_device_tensor(y):
+        import torch
+        u = torch.as_tensor(inputs).to(device=y.device, dtype=y.dtype)
+        u = u.reshape(T, -1) if u.ndim <= 2 else u
+        if u.ndim == 2:
+            u = u[None].expand(N, T, u.shape[-1])
+        u = u.contiguous()
+        ptr = u.data_ptr()
+    else:
+        u = np.asarray(inputs, dtype=dtype)
+        u = u.reshape(T, -1) if u.ndim <= 2 else u
+        if u.ndim == 2:
+            u = np.broadcast_to(u, (N,) + u.shape)
+        u = np.ascontiguousarray(u)
+        ptr = u.ctypes.data
+    if tuple(u.shape[:2]) != (N, T):
+        raise ValueError(f"inputs has shape {tuple(u.shape)}; expected [T, d_u] or [N, T, d_u] with N = {N}, T = {T}")
+    mdl.c.input_dim = int(u.shape[-1])
+    opts.inputs = ptr
+    mdl._inputs = u   # (keeps the array alive for the call)
+
+
 def cdnlgssm_filter(
     params: ParamsCDNLGSSM,
     emissions,
@@ -195,8 +225,9 @@ def cdnlgssm_filter(
     dtype=None,
 ) -> PosteriorGSSMFiltered:
     """Continuous-discrete nonlinear filter; EKF or UKF by the class of ``hyperparams``
-    (reference dispatch: models.py:689-716).  ``inputs`` are ignored by every drift in the registry,
-    exactly as the reference's shipped Learnable* classes ignore ``u``."""
+    (reference dispatch: models.py:689-716).  ``inputs`` ([T, d_u] or [N, T, d_u]) reach a drift / emission given as source
+    (``u``, and the time ``t``: _attach_inputs); the registry drifts ignore them exactly as the reference's shipped Learnable*
+    classes ignore ``u``."""
     if isinstance(hyperparams, EKFHyperParams):
         algo = "ekf_filter"
     elif isinstance(hyperparams, UKFHyperParams):
@@ -210,10 +241,12 @@ def cdnlgssm_filter(
     fields = list(output_fields) if output_fields is not None else []
     want = [f in fields for f in _FILTER_FIELDS]
     if _device.is_device_tensor(emissions):  # data already on the GPU: run in place, return device tensors
-        y, t, batched, _ = _device.prepare(emissions, t_emissions, opts)
+        y, t, batched, dtype = _device.prepare(emissions, t_emissions, opts)
+        _attach_inputs(mdl, opts, inputs, y, dtype)
         ll, outs, _ = _device.run_device(algo, mdl, opts, t, y, want)
     else:
         y, t, batched, dtype = _prepare(emissions, t_emissions, hyperparams, opts, dtype)
+        _attach_inputs(mdl, opts, inputs, y, dtype)
         ll, outs, _ = _ffi.run_host(algo, mdl, opts, t, y, want, dtype)
     out = {name: _squeeze(arr, batched) for name, arr in zip(_FILTER_FIELDS, outs) if arr is not None}
     return PosteriorGSSMFiltered(marginal_loglik=ll if batched else ll[0], **out)
@@ -241,10 +274,12 @@ def cdnlgssm_smoother(
     mdl = _model_block(params)
     opts = _opts(hyperparams, 1)
     if _device.is_device_tensor(emissions):
-        y, t, batched, _ = _device.prepare(emissions, t_emissions, opts)
+        y, t, batched, dtype = _device.prepare(emissions, t_emissions, opts)
+        _attach_inputs(mdl, opts, inputs, y, dtype)
         ll, outs, _ = _device.run_device("ekf_smoother", mdl, opts, t, y, [True] * 4)
     else:
         y, t, batched, dtype = _prepare(emissions, t_emissions, hyperparams, opts, dtype)
+        _attach_inputs(mdl, opts, inputs, y, dtype)
         ll, outs, _ = _ffi.run_host("ekf_smoother", mdl, opts, t, y, [True] * 4, dtype)
     fm, fP, sm, sP = (_squeeze(a, batched) for a in outs)
     return PosteriorGSSMSmoothed(marginal_loglik=ll if batched else ll[0], filtered_means=fm, filtered_covariances=fP,
@@ -329,6 +364,7 @@ def cdnlgssm_loglik_and_grad(
         y, t, batched, dtype = _device.prepare(emissions, t_emissions, opts)
     else:
         y, t, batched, dtype = _prepare(emissions, t_emissions, hyperparams, opts, dtype)
+    _attach_inputs(mdl, opts, inputs, y, dtype)
     supported = _ffi.lib().cdkf_ukf_grad_supported if ukf else _ffi.lib().cdkf_grad_supported
     if ukf and not supported(_ffi.C.byref(mdl.c), _ffi.C.byref(opts)) and \
             _ffi.lib().cdkf_ukf_grad_all_supported(_ffi.C.byref(mdl.c), _ffi.C.byref(opts)):
@@ -377,6 +413,7 @@ def cdnlgssm_loglik_and_grad_all(
         y, t, batched, dtype = _device.prepare(emissions, t_emissions, opts)
     else:
         y, t, batched, dtype = _prepare(emissions, t_emissions, hyperparams, opts, dtype)
+    _attach_inputs(mdl, opts, inputs, y, dtype)
     if ukf:
         # the unscented filter, every leaf (cdkf_ukf_loglik_grad_all_*): the reverse sweeps over its moment equations in closed form --
         # exact for the quadratic Lorenz-63 / Lorenz-96 drifts and the linear one (inference_ukf.py:93-203 differentiated by JAX)

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define CDKF_VERSION 108 /* 0.4.0 */
+#define CDKF_VERSION 109 /* 0.5.0 */
 
 /* error codes */
 #define CDKF_OK 0
@@ -100,6 +100,12 @@ typedef struct cdkf_model {
   const double* R;     /* [m,m] emission covariance */
   const double* m0;    /* [d]   initial mean */
   const double* P0;    /* [d,d] initial covariance */
+  int32_t input_dim;   /* (version 109) d_u: length of the inputs row u_k = inputs[t0_idx] the reference hands to the drift and the
+                          emission function with every call, f(x, u, t), h(x, u, t) (inference_ekf.py:95, 101-114, 277-286;
+                          inference_ukf.py:142, 189).  0: none.  Read by drifts / emissions given as source (their snippets see
+                          `u[0 .. d_u-1]` and the time `t`); the registry drifts ignore inputs and time, as the reference's own
+                          LearnableLinear / LearnableLorenz63 do (cdnlgssm_utils.py:50-83).  The array itself: cdkf_opts.inputs. */
+  int32_t reserved0;
 } cdkf_model;
 
 /* EKFHyperParams / UKFHyperParams (inference_ekf.py:34-44, inference_ukf.py:25-33) and the
@@ -155,7 +161,12 @@ typedef struct cdkf_opts {
   double dtmin;         /* adaptive only: PIDController(dtmin=, dtmax=) with force_dtmin=True (diffrax's default) -- every proposed step size,
                            the first included, is clipped to [dtmin, dtmax], and a step taken at dtmin is kept whatever its error estimate.
                            Defaults 0 and +infinity (= no bounds; src/utils/diffrax_utils.py:40-57 forwards the controller object) */
-  double dtmax;
+  double dtmax;          /* (0 is read as "no bound", so that a zero-initialised struct keeps working) */
+  const void* inputs;    /* (version 109) inputs [N,T,d_u] (d_u = cdkf_model.input_dim), laid out like y under opts.layout_in, in the
+                            real type of the entry point called and with the residence of its y (host memory for the host entry
+                            points, device memory for the _dev ones).  NULL with input_dim > 0: zeros (the reference's
+                            _process_input, inference_ekf.py:32, 260).  Clients built against version 108 must be rebuilt: the two
+                            structs grew. */
 } cdkf_opts;
 
 /* Fill *opts with the reference defaults listed above. */
@@ -306,7 +317,8 @@ int cdkf_custom_emission_register(int state_dim, int emission_dim, const char* h
  * smoother, 3 the log-likelihood gradient (the forward-sensitivity sweep up to six dimensions, the reverse sweep beyond);
  * emission_kind 0 or a registered custom emission -- to check the snippets early; 0 or a negative CDKF_E* code
  * with the compiler log in cdkf_last_error().  algo + 16 (state / emission dimension <= 6): the variant that takes its Runge-Kutta
- * tableau and step-size controller from the arguments (opts.solver other than Dormand-Prince, opts.adaptive). */
+ * tableau and step-size controller from the arguments (opts.solver other than Dormand-Prince, opts.adaptive); algo + 256 * d_u:
+ * the variant for a model with cdkf_model.input_dim = d_u. */
 int cdkf_custom_drift_compile(int drift_kind, int bytes_per_real, int emission_dim, int algo, int state_order,
                               int emission_kind);
 /* directory holding the kernel headers (cdkf_reg_kernels.h ...) for run-time compilation; default: <dir of this
@@ -318,7 +330,7 @@ void cdkf_set_kernel_source_dir(const char* dir);
  *      for the host under ASan / UBSan / MSan / TSan and run on exactly the arguments the launcher forms).  Replaces nothing in the
  *      reference; not part of the drop-in surface. --------------------------------------------------------------------------- */
 /* run-time compiled register-resident kernel (custom drift, state / emission dimension <= 6): algo as cdkf_custom_drift_compile;
- * par_out receives the real-valued block (bytes_per_real each), ip_out[24] the integer block followed by the grid size.
+ * par_out receives the real-valued block (bytes_per_real each), ip_out[27] the integer block (26) followed by the grid size.
  * Returns the number of reals written or a negative CDKF_E* code. */
 int cdkf_debug_custom_reg_blob(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T, int algo, int bytes_per_real,
                                void* par_out, int64_t par_cap_bytes, int64_t* ip_out);

@@ -135,6 +135,33 @@ class use_solver:
 
 
 # --------------------------------------------------------------------------------------
+# Inputs and time.  The reference evaluates the drift and the emission as f(m, u, t), h(m, u, t) (and their jacfwd) with
+# u = inputs[t0_idx] held over the interval [t_k, t_{k+1}] and t the solver's stage time (inference_ekf.py:95, 101-114, 277-286;
+# inference_ukf.py:142, 189; cdnlgssm_utils.py:13-61: a LearnableFunction is any callable of (x, u, t)); in the reverse solves of the
+# smoother t = t_{k+1} - s (diffrax_utils.py:13-25).  The registry drifts ignore both, as the reference's own do; a CallableDrift /
+# callable emission built with ut=True receives them.  They travel in this context instead of through every signature: the filters set
+# _CTX["u"] ([N, d_u]) per observation step, the Runge-Kutta steppers set _CTX["t"] ([N]) before every right-hand-side evaluation.
+_CTX = {"u": None, "t": None}
+
+
+def _stage_time(t, dt, c, tmap):
+    if t is None:
+        return
+    ts = t + dt * t.dtype.type(c)
+    _CTX["t"] = ts if tmap is None else tmap(ts)
+
+
+def _ctx_rows(n):
+    """(u, t) of the context broadcast to n rows (n = N, or N * (2 d + 1) when the sigma points of a batch are evaluated at once)."""
+    u, t = _CTX["u"], _CTX["t"]
+    if u is not None and u.shape[0] != n:
+        u = np.repeat(u, n // u.shape[0], axis=0)
+    if t is not None and np.ndim(t) and t.shape[0] != n:
+        t = np.repeat(t, n // t.shape[0], axis=0)
+    return u, t
+
+
+# --------------------------------------------------------------------------------------
 # Drift registry.  f: [N,d] -> [N,d]; jac: [N,d] -> [N,d,d] (dF_i/dx_j);
 # divgrad: [N,d] -> [N,d], the vector  g_l = sum_i d^2 f_i / (dx_i dx_l)  that the reference's
 # "second order" mean term 0.5*jnp.trace(H_t @ P) reduces to (0.5 * P @ g), SURVEY.md section 0.5.
@@ -298,9 +325,12 @@ class CallableDrift:
 
     kind = "custom"
 
-    def __init__(self, theta, f, jac, divgrad=None, dtype=np.float64, vjp=None, gvjp=None):
+    def __init__(self, theta, f, jac, divgrad=None, dtype=np.float64, vjp=None, gvjp=None, ut=False):
+        """ut=True: the callables are f(x, theta, u, t), jac(x, theta, u, t), ... with u [N, d_u] the interval's inputs and t [N] the
+        stage time (module header: _CTX)."""
         self.dtype = np.dtype(dtype)
         self.th = np.asarray(theta, dtype=self.dtype)
+        self.ut = ut
         self._f, self._jac, self._g = f, jac, divgrad
         # vjp(x [d], lam [d], G [d,d], theta) -> (xbar [d], thetabar): the gradient of lam . f + <G, F> (drift_vjp) written out by hand --
         # what ekf_loglik_grad_adjoint needs of a drift it has no formulas for; gvjp(x, u [d], theta) -> (xbar, thetabar): the gradient
@@ -308,18 +338,21 @@ class CallableDrift:
         self._vjp, self._gvjp = vjp, gvjp
 
     def cast(self, dtype):
-        return CallableDrift(self.th, self._f, self._jac, self._g, dtype=dtype, vjp=self._vjp, gvjp=self._gvjp)
+        return CallableDrift(self.th, self._f, self._jac, self._g, dtype=dtype, vjp=self._vjp, gvjp=self._gvjp, ut=self.ut)
+
+    def _extra(self, x):
+        return _ctx_rows(x.shape[0]) if self.ut else ()
 
     def f(self, x):
-        return np.asarray(self._f(x, self.th), dtype=x.dtype)
+        return np.asarray(self._f(x, self.th, *self._extra(x)), dtype=x.dtype)
 
     def jac(self, x):
-        return np.asarray(self._jac(x, self.th), dtype=x.dtype)
+        return np.asarray(self._jac(x, self.th, *self._extra(x)), dtype=x.dtype)
 
     def divgrad(self, x):
         if self._g is None:
             raise NotImplementedError("custom drift without grad(div f): state_order 'second' is unavailable")
-        return np.asarray(self._g(x, self.th), dtype=x.dtype)
+        return np.asarray(self._g(x, self.th, *self._extra(x)), dtype=x.dtype)
 
     def theta(self):
         return self.th.astype(np.float64)
@@ -329,7 +362,7 @@ class Model:
     """The pieces of ParamsCDNLGSSM the hot path touches (cdnlgssm_utils.py:88-209): drift, L, Qc,
     linear emission h(x) = H x + bias (LearnableLinear), R, initial mean / covariance."""
 
-    def __init__(self, drift, L, Qc, H, bias, R, m0, P0, emission=None):
+    def __init__(self, drift, L, Qc, H, bias, R, m0, P0, emission=None, emission_ut=False):
         """``emission``: optional pair of vectorised callables (h(x, eta) -> [N,m], jac(x, eta) -> [N,m,d]) for a
         non-linear emission function (the reference accepts any callable, cdnlgssm_utils.py:38-61, and linearises it with
         jacfwd, inference_ekf.py:258); its parameter vector eta is concat(H.ravel(), bias) -- the storage a run-time
@@ -341,6 +374,7 @@ class Model:
         self.d = self.m0.shape[0]
         self.m = self.H.shape[0]
         self.emission = emission
+        self.emission_ut = emission_ut   # the pair is h(x, eta, u, t), jac(x, eta, u, t): inputs and observation time (module header: _CTX)
 
     def cast(self, dtype):
         mdl = Model.__new__(Model)
@@ -349,6 +383,7 @@ class Model:
             setattr(mdl, k, getattr(self, k).astype(dtype))
         mdl.d, mdl.m = self.d, self.m
         mdl.emission = self.emission
+        mdl.emission_ut = getattr(self, "emission_ut", False)
         return mdl
 
     def h(self, x):
@@ -356,14 +391,16 @@ class Model:
         if self.emission is None:
             return x @ self.H.T + self.bias
         eta = np.concatenate([self.H.ravel(), self.bias])
-        return np.asarray(self.emission[0](x, eta), dtype=x.dtype)
+        extra = _ctx_rows(x.shape[0]) if getattr(self, "emission_ut", False) else ()
+        return np.asarray(self.emission[0](x, eta, *extra), dtype=x.dtype)
 
     def Hjac(self, x):
         """Emission Jacobian at x [N, d] -> [N, m, d]."""
         if self.emission is None:
             return np.broadcast_to(self.H, x.shape[:-1] + self.H.shape)
         eta = np.concatenate([self.H.ravel(), self.bias])
-        return np.asarray(self.emission[1](x, eta), dtype=x.dtype)
+        extra = _ctx_rows(x.shape[0]) if getattr(self, "emission_ut", False) else ()
+        return np.asarray(self.emission[1](x, eta, *extra), dtype=x.dtype)
 
 
 # --------------------------------------------------------------------------------------
@@ -449,19 +486,21 @@ def _tree_axpy(y0, ks, coefs, dtype):
     return tuple(out)
 
 
-def dopri5_step(rhs, y, dt):
-    """One Dopri5 step of size dt (dt: [N]); k_j = dt * f(stage_j) (diffrax ODETerm.vf_prod)."""
+def dopri5_step(rhs, y, dt, t=None, tmap=None):
+    """One Dopri5 step of size dt (dt: [N]); k_j = dt * f(stage_j) (diffrax ODETerm.vf_prod).  t ([N], optional): the step's start --
+    stage i is then evaluated with the context time tmap(t + c_i dt), c_i = sum_j a_ij (module header: _CTX)."""
     dtype = y[0].dtype
     A, B = TABLEAUS[_ACTIVE[-1][0]]
     ks = []
     for i in range(len(B)):
         yi = y if i == 0 else _tree_axpy(y, ks, A[i], dtype)
+        _stage_time(t, dt, sum(A[i]), tmap)
         fi = rhs(yi)
         ks.append(tuple(dt.reshape((-1,) + (1,) * (c.ndim - 1)) * c for c in fi))
     return _tree_axpy(y, ks, B, dtype)
 
 
-def diffeqsolve(rhs, t0, t1, y0, dt0=0.01, max_steps=100000, count_steps=None, err_components=None, dt_log=None):
+def diffeqsolve(rhs, t0, t1, y0, dt0=0.01, max_steps=100000, count_steps=None, err_components=None, dt_log=None, tmap=None):
     """Integrate the autonomous ODE y' = rhs(y) from t0 to t1 (both [N]) with fixed-step Dopri5.
 
     Mirrors diffrax 0.4.0: tprev=t0, tnext=min(t0+dt0, t1); while tprev < t1: step(tprev->tnext);
@@ -471,7 +510,7 @@ def diffeqsolve(rhs, t0, t1, y0, dt0=0.01, max_steps=100000, count_steps=None, e
     autonomous right-hand sides of this path the caller passes t0=0, t1=t1-t0 and the negated rhs.
     """
     if _ACTIVE[-1][1] is not None:
-        return _diffeqsolve_adaptive(rhs, t0, t1, y0, dt0, max_steps, count_steps, err_components, dt_log)
+        return _diffeqsolve_adaptive(rhs, t0, t1, y0, dt0, max_steps, count_steps, err_components, dt_log, tmap)
     dtype = y0[0].dtype
     tol = dtype.type(1e-10 if dtype == np.float64 else 1e-6)
     t0 = np.asarray(t0, dtype=dtype)
@@ -486,7 +525,7 @@ def diffeqsolve(rhs, t0, t1, y0, dt0=0.01, max_steps=100000, count_steps=None, e
         if not active.any():
             break
         dt = np.where(active, tnext - tprev, dtype.type(0))
-        ynew = dopri5_step(rhs, y, dt)
+        ynew = dopri5_step(rhs, y, dt, tprev, tmap)
         y = tuple(np.where(active.reshape((-1,) + (1,) * (c.ndim - 1)), cn, c) for cn, c in zip(ynew, y))
         nsteps += active
         tprev_new = np.minimum(tnext, t1)
@@ -499,7 +538,7 @@ def diffeqsolve(rhs, t0, t1, y0, dt0=0.01, max_steps=100000, count_steps=None, e
     return y
 
 
-def _diffeqsolve_adaptive(rhs, t0, t1, y0, dt0, max_steps, count_steps, err_components=None, dt_log=None):
+def _diffeqsolve_adaptive(rhs, t0, t1, y0, dt0, max_steps, count_steps, err_components=None, dt_log=None, tmap=None):
     """diffrax.PIDController around the embedded pair (diffrax 0.4.0 is not in the mount; restated from its published
     algorithm -- step_size_controller/adaptive.py and the integrate loop):
       y_error      = dt * sum_i (b_sol - b_hat)_i k_i, the last stage being f(y_candidate) (FSAL methods)
@@ -547,9 +586,11 @@ def _diffeqsolve_adaptive(rhs, t0, t1, y0, dt0, max_steps, count_steps, err_comp
         ks = []
         for i in range(len(B)):
             yi = y if i == 0 else _tree_axpy(y, ks, A[i], dtype)
+            _stage_time(tprev, dt, sum(A[i]), tmap)
             ks.append(tuple(bc(dt, c) * c for c in rhs(yi)))
         ynew = _tree_axpy(y, ks, B, dtype)
         if len(Berr) > len(B) and Berr[len(B)] != 0.0:
+            _stage_time(tprev, dt, 1.0, tmap)
             ks.append(tuple(bc(dt, c) * c for c in rhs(ynew)))
         yerr = tuple(sum(dtype.type(Berr[i]) * ks[i][c] for i in range(len(ks)) if Berr[i] != 0.0) for c in range(len(y)))
         sq = np.zeros(N, dtype)
@@ -596,6 +637,21 @@ def _diffeqsolve_adaptive(rhs, t0, t1, y0, dt0, max_steps, count_steps, err_comp
 # --------------------------------------------------------------------------------------
 def _LQL(mdl):
     return mdl.L @ mdl.Qc @ mdl.L.T
+
+
+def _inputs(inputs, N, T, dtype):
+    """inputs [N, T, d_u] in the compute type; None -> zeros [N, T, 1] (_process_input, inference_ekf.py:32, 260)."""
+    if inputs is None:
+        return np.zeros((N, T, 1), dtype)
+    u = np.asarray(inputs, dtype=dtype)
+    return np.broadcast_to(u, (N,) + u.shape).copy() if u.ndim == 2 else u
+
+
+def _set_step(u, t0s, k):
+    """Context of observation step k: u = inputs[k] for the emission and the whole interval that follows, t = t_k for the emission
+    (inference_ekf.py:277-286: h(pred_mean, u, t0), H(pred_mean, u, t0))."""
+    _CTX["u"] = u[:, k]
+    _CTX["t"] = t0s[:, k]
 
 
 def ekf_predict(mdl, m, P, t0, t1, state_order="second", dt0=0.01, max_steps=100000, cov_rescaling=1.0):
@@ -656,14 +712,16 @@ def ekf_filter(
     max_steps: int = 100000,
     cov_rescaling: float = 1.0,
     dtype=np.float64,
+    inputs=None,
 ):
-    """extended_kalman_filter (inference_ekf.py:202-326), batched: t [N,T], y [N,T,m]."""
+    """extended_kalman_filter (inference_ekf.py:202-326), batched: t [N,T], y [N,T,m], inputs [N,T,d_u] or None."""
     dtype = np.dtype(dtype)
     mdl = mdl.cast(dtype)
     y = np.asarray(y, dtype=dtype)
     N, T, _ = y.shape
     d = mdl.d
     t0s, t1s = _t0_t1(t, dt_final, dtype)
+    u = _inputs(inputs, N, T, dtype)
     ll = np.zeros(N, dtype=dtype)
     pm = np.broadcast_to(mdl.m0, (N, d)).copy()
     pP = np.broadcast_to(mdl.P0, (N, d, d)).copy()
@@ -675,6 +733,7 @@ def ekf_filter(
     }
     for k in range(T):
         yk = y[:, k]
+        _set_step(u, t0s, k)
         Hk = mdl.Hjac(pm)
         S = Hk @ pP @ np.swapaxes(Hk, -1, -2) + mdl.R
         ll = ll + mvn_logpdf(yk, mdl.h(pm), S)
@@ -689,18 +748,19 @@ def ekf_filter(
 
 
 def ekf_smoother(mdl: Model, t, y, state_order="second", dt0=0.01, dt_final=1e-10, max_steps=100000, dtype=np.float64,
-                 filtered: Optional[dict] = None):
+                 filtered: Optional[dict] = None, inputs=None):
     """extended_kalman_smoother (inference_ekf.py:450-539) + _smooth (:363-448), smooth_order='first'.
 
     The filter inside the smoother runs with num_iter=1 (inference_ekf.py:489-495).
     """
     dtype = np.dtype(dtype)
     if filtered is None:
-        filtered = ekf_filter(mdl, t, y, state_order, 1, dt0, dt_final, max_steps, dtype=dtype)
+        filtered = ekf_filter(mdl, t, y, state_order, 1, dt0, dt_final, max_steps, dtype=dtype, inputs=inputs)
     mdl = mdl.cast(dtype)
     t = np.asarray(t, dtype=dtype)
     fm, fP = filtered["filtered_means"], filtered["filtered_covariances"]
     N, T, d = fm.shape
+    u = _inputs(inputs, N, T, dtype)
     LQL = _LQL(mdl)
     sm = np.zeros_like(fm)
     sP = np.zeros_like(fP)
@@ -721,7 +781,8 @@ def ekf_smoother(mdl: Model, t, y, state_order="second", dt0=0.01, dt_final=1e-1
             return -dm, -dP  # reverse_rhs (diffrax_utils.py:13-25)
 
         t0, t1 = t[:, k], t[:, k + 1]
-        ms, Ps = diffeqsolve(rhs, np.zeros_like(t0), t1 - t0, (ms, Ps), dt0, max_steps)
+        _CTX["u"] = u[:, k]   # u = inputs[t0_idx] of the interval (inference_ekf.py:516); solver time s -> t1 - s (diffrax_utils.py:13-25)
+        ms, Ps = diffeqsolve(rhs, np.zeros_like(t0), t1 - t0, (ms, Ps), dt0, max_steps, tmap=lambda sv, t1=t1: t1 - sv)
         sm[:, k] = ms
         sP[:, k] = Ps
     return {
@@ -758,12 +819,13 @@ def ukf_sigmas(m, P, lamb):
 
 
 def ukf_filter(mdl: Model, t, y, alpha=math.sqrt(3), beta=2, kappa=1, dt0=0.01, dt_final=1e-10, max_steps=100000,
-               dtype=np.float64):
+               dtype=np.float64, inputs=None):
     """unscented_kalman_filter (inference_ukf.py:206-308), batched."""
     dtype = np.dtype(dtype)
     mdl = mdl.cast(dtype)
     y = np.asarray(y, dtype=dtype)
     N, T, _ = y.shape
+    u = _inputs(inputs, N, T, dtype)
     d = mdl.d
     lamb, w_mean, w_cov, W = ukf_weights(d, alpha, beta, kappa, dtype)
     LQL = _LQL(mdl)
@@ -789,6 +851,7 @@ def ukf_filter(mdl: Model, t, y, alpha=math.sqrt(3), beta=2, kappa=1, dt0=0.01, 
 
     for k in range(T):
         yk = y[:, k]
+        _set_step(u, t0s, k)
         # _condition_on (inference_ukf.py:162-203)
         X = ukf_sigmas(pm, pP, lamb)
         Y = mdl.h(X.reshape(-1, d)).reshape(X.shape[:2] + (mdl.m,))

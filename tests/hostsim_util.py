@@ -88,27 +88,34 @@ def dump_custom_source(kind: int, nbytes: int, m: int, algo: int, state_order: i
     return d, sorted(src)
 
 
-def reg_run(src_path, mdl, opts, t, y, algo, dtype, san, outs, opt="-O1"):
+def reg_run(src_path, mdl, opts, t, y, algo, dtype, san, outs, opt="-O1", inputs=None, preload=None):
     """Run a generated register-resident kernel on the host.  t [N,T], y [N,T,m] (layout NT in, `opts.layout` out as set by the
     caller); outs: lengths (in reals) of (ll, o1, o2, o3, o4, status, sm, sP).  Returns the list of output arrays."""
     from cd_dynamax_amd import _ffi
     dtype = np.dtype(dtype)
     N, T = t.shape
     par = np.zeros(4096, dtype)
-    ip = np.zeros(24, np.int64)
+    ip = np.zeros(27, np.int64)
     n = _ffi.lib().cdkf_debug_custom_reg_blob(C.byref(mdl.c), C.byref(opts), N, T, algo, dtype.itemsize, par.ctypes.data_as(C.c_void_p),
                                                par.nbytes, ip.ctypes.data_as(C.POINTER(C.c_int64)))
     assert n > 0, _ffi.lib().cdkf_last_error().decode()
     par = par[:n]
     head = np.zeros(16, np.int64)
     tt, yy = np.ascontiguousarray(t, dtype), np.ascontiguousarray(y, dtype)
-    head[:5] = [ip[23], n, 23, tt.size, yy.size]
+    head[:5] = [ip[26], n, 26, tt.size, yy.size]
     head[5:13] = outs
+    uu = None if inputs is None else np.ascontiguousarray(inputs, dtype)
+    head[13] = 0 if uu is None else uu.size
+    head[14] = 0 if preload is None else 1   # preload = (fm, fP) flat in the sweep's layout: the smoother's backward kernel reads them
     exe = build("reg_harness.cpp", src_path, san, opt)
     with tempfile.TemporaryDirectory() as d:
         fin, fout = os.path.join(d, "in.bin"), os.path.join(d, "out.bin")
         with open(fin, "wb") as f:
-            f.write(head.tobytes()); f.write(par.tobytes()); f.write(ip[:23].tobytes()); f.write(tt.tobytes()); f.write(yy.tobytes())
+            f.write(head.tobytes()); f.write(par.tobytes()); f.write(ip[:26].tobytes()); f.write(tt.tobytes()); f.write(yy.tobytes())
+            if uu is not None:
+                f.write(uu.tobytes())
+            if preload is not None:
+                f.write(np.ascontiguousarray(preload[0], dtype).tobytes()); f.write(np.ascontiguousarray(preload[1], dtype).tobytes())
         res = run(exe, fin, fout)
         reports = sanitizer_reports(res.stderr)
         if res.returncode != 0 or reports:
@@ -116,6 +123,9 @@ def reg_run(src_path, mdl, opts, t, y, algo, dtype, san, outs, opt="-O1"):
         raw = open(fout, "rb").read()
     arrs, off = [], 0
     for k, ln in enumerate(outs):
+        if k == 0 and preload is not None:
+            arrs.append(None)
+            continue
         dt = np.dtype(np.int32) if k == 5 else dtype
         arrs.append(np.frombuffer(raw, dt, ln, off).copy() if ln else None)
         off += ln * dt.itemsize
