@@ -44,7 +44,7 @@ __host__ __device__ inline long awg_model_grad_size(int d, int m) { return (long
 // per-trajectory global scratch in reals: `cap` step starts of a replay chunk and their step sizes
 __host__ __device__ inline long awg_scratch_reals(int d, int cap) {
   const long sz = (long)d * d + d;
-  return (long)cap * sz + cap;
+  return (long)cap * sz + 2 * (long)cap;  // (+ the sizes AND the start times of the chunk's steps: a drift given as source may read t)
 }
 // covariance entries per thread on the (column, row group) map of a d x d matrix
 __host__ __device__ inline int awg_entries_per_thread(int d) {
@@ -81,17 +81,17 @@ static __device__ long long awg_prof[16];
 //   awg_custom_contract: sum_i G[i][j] d2 f_i / dx_j dz  (+ sum_i lam_i d f_i / dz if lam is non-null), z < d: the state component z,
 //                        z >= d: the parameter z - d -- what the reverse of F(m, theta) Ps + (F Ps)^T contributes to the cotangent of z.
 template <typename R>
-__device__ void awg_custom_column(const R* th, const R* x, int j, R* F, int ld, R* fv);
+__device__ void awg_custom_column(const R* th, const R* x, int j, R* F, int ld, R* fv, const R* uin, R tin);
 template <typename R>
-__device__ R awg_custom_contract(const R* th, const R* x, const R* G, int ld, int j, int z, const R* lam);
+__device__ R awg_custom_contract(const R* th, const R* x, const R* G, int ld, int j, int z, const R* lam, const R* uin, R tin);
 // state_order 'second' (CDKF_AWG_CUSTOM_SECOND: grad(div f) registered as "auto"): the mean's slope carries 0.5 Ps g(x), g = grad(div f)
 //   awg_custom_divpair: d2 f_i / dx_i dx_k  (g_k is its sum over i);
 //   awg_custom_third:   sum_k u_k d3 f_i / dx_i dx_k dz -- what the reverse of u . g(x, theta), u = 0.5 Ps^T lam, contributes to the
 //                       cotangent of the state component / parameter z (its sum over i)
 template <typename R>
-__device__ R awg_custom_divpair(const R* th, const R* x, int i, int k);
+__device__ R awg_custom_divpair(const R* th, const R* x, int i, int k, const R* uin, R tin);
 template <typename R>
-__device__ R awg_custom_third(const R* th, const R* x, const R* u, int i, int z);
+__device__ R awg_custom_third(const R* th, const R* x, const R* u, int i, int z, const R* uin, R tin);
 #ifndef CDKF_AWG_CUSTOM_SECOND
 #define CDKF_AWG_CUSTOM_SECOND 0
 #endif
@@ -135,6 +135,7 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
   R* wsb = ws + n * ws_stride;
   R* starts = wsb;            // [cap][d*d + d]
   R* dts = starts + (long)cap * sz;
+  R* tss = dts + cap;         // start time of each kept step (stage times t + c_i dt of f(x, u, t): inference_ekf.py:95)
 #ifdef CDKF_AWG_CUSTOM
   const bool custom = a.kind >= kDriftCustomBase;
   const long ntheta = custom ? (long)CDKF_AWG_CUSTOM : (lin ? (long)d * d + d : 1);
@@ -381,7 +382,7 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
     inv_s[tid] = (signed char)who;
     if (cnt > 1) sel_ok = 0;
   }
-  if (!sel_ok) sel_s = 0;
+  if (!sel_ok) atomicAnd(&sel_s, 0);  // (several threads may clear the flag: atomically, so that the host build's ThreadSanitizer sees no race)
   __syncthreads();
   const bool hsel = sel_s != 0 && m <= d;
   AWG_FOR(e, (int)ntheta) g[e] = R(0);
@@ -636,11 +637,19 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
     __syncthreads();
   };
 #endif
+  // what a drift given as source sees beside x and theta: the inputs row of the interval in hand and the time of the evaluation in hand
+  // (every thread the same values; the registry drifts ignore both)
+#ifdef CDKF_AWG_CUSTOM
+  R cur_u[CDKF_AWG_CUSTOM_DU > 0 ? CDKF_AWG_CUSTOM_DU : 1];
+  cur_u[0] = R(0);
+#endif
+  R cur_t = R(0);
+  (void)cur_t;
   // ---- drift: dense Jacobian F(x) into a slot, f(x) into fv; x in LDS (synchronised by the caller before AND after) ------------
   auto drift_eval = [&](const R* xv, R* F) {
 #ifdef CDKF_AWG_CUSTOM
     if (custom) {  // jacfwd with the directions spread over the workgroup: thread j carries e_j
-      AWG_FOR(j, d) awg_custom_column<R>(th, xv, j, F, ld, j == 0 ? fv : (R*)nullptr);
+      AWG_FOR(j, d) awg_custom_column<R>(th, xv, j, F, ld, j == 0 ? fv : (R*)nullptr, cur_u, cur_t);
       return;
     }
 #endif
@@ -713,7 +722,7 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
     R* W = slot(7);
     AWG_FOR(e, d * d) {
       const int i = fdiv(e, d), kk = e - i * d;
-      W[i * ld + kk] = awg_custom_divpair<R>(th, xv, i, kk);
+      W[i * ld + kk] = awg_custom_divpair<R>(th, xv, i, kk, cur_u, cur_t);
     }
     __syncthreads();
     if (tid < d) {
@@ -746,6 +755,10 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
         for (int r = 0; r < NB; ++r)
 #pragma unroll
           for (int c = 0; c <= r; ++c) L[r][c] = (r < wdt) ? As[(p0 + r) * ld + p0 + c] : (r == c ? R(1) : R(0));
+        // (wave-synchronous: every lane of the wavefront has read the block before the lanes that own its rows write them back below.
+        //  The hardware runs the wavefront's reads before its writes anyway; the barrier -- no instruction on the GPU -- says so to the
+        //  compiler and to the host build under ThreadSanitizer, tests/test_hostsim.py)
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int c = 0; c < NB; ++c) {
           R sd = L[c][c];
@@ -936,10 +949,11 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
     __syncthreads();
   };
   // (A: a free slot for F Ps; three barriers per stage)
-  auto stages_fwd = [&](const R* P0s, R* Ps, R* F, R* A, R dt) {
+  auto stages_fwd = [&](const R* P0s, R* Ps, R* F, R* A, R dt, R tstep) {
     for (int si = 0; si < nst; ++si) {
       if (si) take_slope(si - 1, A);
       stage_value(si, P0s, Ps, dt);
+      cur_t = rfma(rk_stage_c(a.rk, si), dt, tstep);
       drift_eval(xs, F);
       __syncthreads();
       if (l96)
@@ -1126,6 +1140,10 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
 #pragma unroll
       for (int u = 0; u < NE; ++u) kP[s6][u] = yP[s6][u] = R(0);
     const R t0 = tp[(k - 1) * a.t_sk], t1 = tp[k * a.t_sk];
+#ifdef CDKF_AWG_CUSTOM
+    for (int iu = 0; iu < CDKF_AWG_CUSTOM_DU; ++iu)  // u = inputs[t0_idx] of the interval k-1 -> k (inference_ekf.py:277)
+      cur_u[iu] = a.u ? a.u[n * a.u_sn + (k - 1) * a.u_sk + iu * a.u_si] : R(0);
+#endif
     // an adaptive solve: the forward (workgroup) sweep logged the step sizes it accepted in this interval; the reverse of the solve
     // treats them as constants -- the controller's factor carries no derivative, as in the reference's reverse mode through diffrax
     const R* dtl = a.dtlog ? a.dtlog + (n * (a.T - 1) + (k - 1)) * (1 + a.dtlog_cap) : nullptr;
@@ -1160,18 +1178,24 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
       __syncthreads();
       {
         R tprev = t0, tnext = rmin(t0 + a.dt0, t1);
+        R tlog = t0;  // (adaptive: the start times follow from the logged sizes)
         for (long s = 0; s < ce; ++s) {
           const R dt = dtl ? dtl[1 + s] : tnext - tprev;
+          const R tstart = dtl ? tlog : tprev;
           if (s >= cs) {
             R* sv = starts + (s - cs) * sz;
             rows2d(d, d, [&](int i, int j) { return P0s[i * ld + j]; }, [&](int i, int j, R v) { sv[i * d + j] = v; });
             if (tid < d) sv[(long)d * d + tid] = x0[tid];
-            if (tid == 0) dts[s - cs] = dt;
+            if (tid == 0) {
+              dts[s - cs] = dt;
+              tss[s - cs] = tstart;
+            }
           }
           if (s + 1 < ce) {
-            stages_fwd(P0s, Ps, F, G, dt);
+            stages_fwd(P0s, Ps, F, G, dt, tstart);
             step_end(P0s, dt);
           }
+          tlog += dt;
           tprev = rmin(tnext, t1);
           const R tn = tnext + a.dt0;
           tnext = (tn > t1 - Tol<R>::v) ? t1 : tn;
@@ -1185,8 +1209,9 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
         if (tid < d) x0[tid] = sv[(long)d * d + tid];
         __syncthreads();
         const R dt = dts[s - cs];
+        const R tstart = tss[s - cs];
         AWG_TICK(7)  // replay, step start
-        stages_fwd(P0s, Ps, F, G, dt);
+        stages_fwd(P0s, Ps, F, G, dt, tstart);
         AWG_TICK(8)  // the step's stages forward
         // (lam in two copies by the stage's parity: a stage's last phase still reads it while the next stage's first phase writes)
         auto take_cotangent = [&](int sv) __attribute__((always_inline)) {  // Ybar_P of stage sv = G + G^T from the product left in LDS
@@ -1220,6 +1245,7 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
           }
           stage_value(si, P0s, Ps, dt);  // (synchronises)
           rows2d(d, d, [&](int i, int j) { return R(0.5) * (Lt[i * ld + j] + Lt[j * ld + i]); }, [&](int i, int j, R v) { Lam[i * ld + j] = v; });
+          cur_t = rfma(rk_stage_c(a.rk, si), dt, tstart);
           drift_eval(xs, F);
           __syncthreads();
 #if defined(CDKF_AWG_CUSTOM) && CDKF_AWG_CUSTOM_SECOND
@@ -1260,9 +1286,9 @@ __global__ __launch_bounds__(kAwgThreads) void ekf_adjoint_wg_kernel(const WgArg
               const int grp = tid / Z, z = tid - grp * Z;
               R s2 = R(0);
               for (int j = grp; j < d; j += NG) {
-                s2 += awg_custom_contract<R>(th, xs, G2, ld, j, z, (j == 0 && z >= d) ? lamv : (const R*)nullptr);
+                s2 += awg_custom_contract<R>(th, xs, G2, ld, j, z, (j == 0 && z >= d) ? lamv : (const R*)nullptr, cur_u, cur_t);
 #if CDKF_AWG_CUSTOM_SECOND
-                if (second) s2 += awg_custom_third<R>(th, xs, g2, j, z);  // (j in the role of the divergence's index i)
+                if (second) s2 += awg_custom_third<R>(th, xs, g2, j, z, cur_u, cur_t);  // (j in the role of the divergence's index i)
 #endif
               }
               part[grp * Z + z] = s2;

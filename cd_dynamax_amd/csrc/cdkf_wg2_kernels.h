@@ -71,6 +71,16 @@ struct WgArgs {
   const R* cj;
   R* gcj;
   R* gy;
+  // Inputs and time for a drift given as source (f(x, u, t): inference_ekf.py:95, 101-114; the registry drifts ignore both, as the
+  // reference's own do): u[n][k][0 .. du-1] at n * u_sn + k * u_sk + i * u_si (null: zeros).  The sweep writes the context of the
+  // evaluation in hand into the mutable fields -- every thread the same values, no barrier needed: the offset of this interval's
+  // inputs row, the (stage) time, and for the smoother's reverse-time solves the interval's end (t = ctx_tend - s, diffrax_utils.py:13-25)
+  const R* u;
+  long u_sn, u_sk, u_si;
+  int du;
+  mutable long ctx_uoff;
+  mutable R ctx_t, ctx_tend;
+  mutable int ctx_rev;
   // R is diagonal with entries >= 1e-2: the wavefront Lorenz-96 filter then takes the log-likelihood's determinant and quadratic form from
   // psd_solve's factor of S + 1e-9 I (first-order corrections in 1e-9, the next order below 1e-14 of a step's term) instead of a second
   // factorisation (cdkf_wave40_kernels.h, ONE = true)
@@ -92,6 +102,12 @@ __device__ __forceinline__ int fdiv(int e, int n) {
 }
 
 #define CDKF_WG_FOR(idx, n) for (int idx = threadIdx.x; idx < (n); idx += blockDim.x)
+
+// the time the drift sees for solver time s (WgArgs::ctx_*)
+template <typename R>
+__device__ __forceinline__ void wg_set_time(const WgArgs<R>& a, R s) {
+  a.ctx_t = a.ctx_rev ? a.ctx_tend - s : s;
+}
 
 // ---- LDS carve-up ---------------------------------------------------------------------------------------------
 // matrices (q x lq each): 0 P, 1 Ps (= X in the update), 2 S, 3 L1 (= S X once the log-likelihood is done), 4 L2,
@@ -721,13 +737,16 @@ struct Own {
 // inlined right-hand side, the slope arrays were indexed dynamically and moved to scratch memory (5x slower sweeps).
 template <int S, typename R, int EPT, typename RhsFn>
 __device__ __forceinline__ void wg_stage(const WgLds<R>& L, const Own<R, EPT>& own, int d, R dt, bool with_P, RhsFn& rhs,
-                                         R (&kM)[6], R (&kP)[6][EPT], const RkTab<R>& tb) {
+                                         R (&kM)[6], R (&kP)[6][EPT], const RkTab<R>& tb, const WgArgs<R>& a, R tstep) {
   if (S >= tb.stages) {  // methods with fewer stages (uniform over the workgroup): no slope, no barrier
     kM[S] = R(0);
 #pragma unroll
     for (int u = 0; u < EPT; ++u) kP[S][u] = R(0);
     return;
   }
+#ifdef CDKF_WG_CUSTOM
+  wg_set_time(a, rfma(rk_stage_c(tb, S), dt, tstep));  // stage time t + c_S dt for f(x, u, t)
+#endif
   R* mcur = L.vec(0);
   R* Pm = L.mat(0);
   R* ms = L.vec(1);
@@ -762,7 +781,7 @@ __device__ __forceinline__ void wg_stage(const WgLds<R>& L, const Own<R, EPT>& o
 
 template <typename R, int EPT, typename RhsFn>
 __device__ __forceinline__ void wg_dopri5_step(const WgLds<R>& L, const Own<R, EPT>& own, int d, R dt, bool with_P,
-                                               RhsFn rhs, const RkTab<R>& tb) {
+                                               RhsFn rhs, const RkTab<R>& tb, const WgArgs<R>& a, R tstep) {
   R* mcur = L.vec(0);
   R* Pm = L.mat(0);
   R kM[6];
@@ -775,12 +794,12 @@ __device__ __forceinline__ void wg_dopri5_step(const WgLds<R>& L, const Own<R, E
     for (int u = 0; u < EPT; ++u) kP[s_][u] = R(0);
   }
 #endif
-  wg_stage<0>(L, own, d, dt, with_P, rhs, kM, kP, tb);
-  wg_stage<1>(L, own, d, dt, with_P, rhs, kM, kP, tb);
-  wg_stage<2>(L, own, d, dt, with_P, rhs, kM, kP, tb);
-  wg_stage<3>(L, own, d, dt, with_P, rhs, kM, kP, tb);
-  wg_stage<4>(L, own, d, dt, with_P, rhs, kM, kP, tb);
-  wg_stage<5>(L, own, d, dt, with_P, rhs, kM, kP, tb);
+  wg_stage<0>(L, own, d, dt, with_P, rhs, kM, kP, tb, a, tstep);
+  wg_stage<1>(L, own, d, dt, with_P, rhs, kM, kP, tb, a, tstep);
+  wg_stage<2>(L, own, d, dt, with_P, rhs, kM, kP, tb, a, tstep);
+  wg_stage<3>(L, own, d, dt, with_P, rhs, kM, kP, tb, a, tstep);
+  wg_stage<4>(L, own, d, dt, with_P, rhs, kM, kP, tb, a, tstep);
+  wg_stage<5>(L, own, d, dt, with_P, rhs, kM, kP, tb, a, tstep);
   if (threadIdx.x < d) {
     R acc = tb.b[0] * kM[0];
 #pragma unroll
@@ -810,8 +829,8 @@ __device__ __forceinline__ void wg_dopri5_step(const WgLds<R>& L, const Own<R, E
 // until it is accepted.  max_steps counts attempts.
 template <typename R, int EPT, typename RhsFn>
 __device__ __forceinline__ bool wg_integrate_adaptive(const WgLds<R>& L, const Own<R, EPT>& own, int d, R t0, R t1, R dt0,
-                                                      long max_steps, bool with_P, RhsFn rhs, const RkTab<R>& tb, R* dtlog = nullptr,
-                                                      int dtlog_cap = 0) {
+                                                      long max_steps, bool with_P, RhsFn rhs, const RkTab<R>& tb, const WgArgs<R>& a,
+                                                      R* dtlog = nullptr, int dtlog_cap = 0) {
   __shared__ double red[16];
   R* mcur = L.vec(0);
   R* Pm = L.mat(0);
@@ -834,12 +853,12 @@ __device__ __forceinline__ bool wg_integrate_adaptive(const WgLds<R>& L, const O
     const R dt = tnext - tprev;
     R kM[6];
     R kP[6][EPT];
-    wg_stage<0>(L, own, d, dt, with_P, rhs, kM, kP, tb);
-    wg_stage<1>(L, own, d, dt, with_P, rhs, kM, kP, tb);
-    wg_stage<2>(L, own, d, dt, with_P, rhs, kM, kP, tb);
-    wg_stage<3>(L, own, d, dt, with_P, rhs, kM, kP, tb);
-    wg_stage<4>(L, own, d, dt, with_P, rhs, kM, kP, tb);
-    wg_stage<5>(L, own, d, dt, with_P, rhs, kM, kP, tb);
+    wg_stage<0>(L, own, d, dt, with_P, rhs, kM, kP, tb, a, tprev);
+    wg_stage<1>(L, own, d, dt, with_P, rhs, kM, kP, tb, a, tprev);
+    wg_stage<2>(L, own, d, dt, with_P, rhs, kM, kP, tb, a, tprev);
+    wg_stage<3>(L, own, d, dt, with_P, rhs, kM, kP, tb, a, tprev);
+    wg_stage<4>(L, own, d, dt, with_P, rhs, kM, kP, tb, a, tprev);
+    wg_stage<5>(L, own, d, dt, with_P, rhs, kM, kP, tb, a, tprev);
     // the candidate
     R ynM = R(0), ynP[EPT];
     if (threadIdx.x < d) {
@@ -870,6 +889,9 @@ __device__ __forceinline__ bool wg_integrate_adaptive(const WgLds<R>& L, const O
           if (u < own.n) Ps[own.off(u)] = ynP[u];
       }
       __syncthreads();
+#ifdef CDKF_WG_CUSTOM
+      wg_set_time(a, tprev + dt);
+#endif
       rhs(ms, Ps, k7M, k7P);
       __syncthreads();
     }
@@ -933,15 +955,15 @@ __device__ __forceinline__ bool wg_integrate_adaptive(const WgLds<R>& L, const O
 
 template <typename R, int EPT, typename RhsFn>
 __device__ __forceinline__ bool wg_integrate(const WgLds<R>& L, const Own<R, EPT>& own, int d, R t0, R t1, R dt0,
-                                             long max_steps, bool with_P, RhsFn rhs, const RkTab<R>& tb, R* dtlog = nullptr,
-                                             int dtlog_cap = 0) {
-  if (tb.adaptive) return wg_integrate_adaptive<R, EPT>(L, own, d, t0, t1, dt0, max_steps, with_P, rhs, tb, dtlog, dtlog_cap);
+                                             long max_steps, bool with_P, RhsFn rhs, const RkTab<R>& tb, const WgArgs<R>& a,
+                                             R* dtlog = nullptr, int dtlog_cap = 0) {
+  if (tb.adaptive) return wg_integrate_adaptive<R, EPT>(L, own, d, t0, t1, dt0, max_steps, with_P, rhs, tb, a, dtlog, dtlog_cap);
   R tprev = t0;
   R tnext = rmin(t0 + dt0, t1);
   long steps = 0;
   while (tprev < t1) {  // uniform over the workgroup
     if (steps >= max_steps) return true;
-    wg_dopri5_step<R, EPT>(L, own, d, tnext - tprev, with_P, rhs, tb);
+    wg_dopri5_step<R, EPT>(L, own, d, tnext - tprev, with_P, rhs, tb, a, tprev);
     tprev = rmin(tnext, t1);
     const R tn = tnext + dt0;
     tnext = (tn > t1 - Tol<R>::v) ? t1 : tn;
@@ -1362,7 +1384,11 @@ __global__ __launch_bounds__(512) void ekf_filter_wg_kernel(const WgArgs<R> a_in
     else
       wg_rhs_ekf<R, EPT>(a, L, own, ms, Ps, kM, kP, zeroth);
   };
+  a.ctx_rev = 0;
+  a.ctx_tend = R(0);
+  a.ctx_t = R(0);
   for (long k = 0; k < a.T; ++k) {
+    a.ctx_uoff = n * a.u_sn + k * a.u_sk;  // u = inputs[t0_idx]: this step's interval (inference_ekf.py:277)
     CDKF_WG_FOR(r, m) yl[r] = yp[k * a.y_sk + r * a.y_si];
     const R t0 = tp[k * a.t_sk];
     const R t1 = (k + 1 < a.T) ? tp[(k + 1) * a.t_sk] : t0 + a.dt_final;
@@ -1373,7 +1399,7 @@ __global__ __launch_bounds__(512) void ekf_filter_wg_kernel(const WgArgs<R> a_in
     // (re)derive this thread's entry indices here: values that live across the measurement update would be spilled to
     // scratch by its register pressure and re-loaded inside every Runge-Kutta stage (measured: 3.4x on the d = 40 sweep)
     own.init(d, lq, a.par + a.o_LQL);
-    if (wg_integrate<R, EPT>(L, own, d, t0, t1, a.dt0, a.max_steps, !zeroth, rhs, a.rk,
+    if (wg_integrate<R, EPT>(L, own, d, t0, t1, a.dt0, a.max_steps, !zeroth, rhs, a.rk, a,
                              (a.dtlog && k + 1 < a.T) ? a.dtlog + (n * (a.T - 1) + k) * (1 + a.dtlog_cap) : (R*)nullptr, a.dtlog_cap))
       st |= kStatusMaxSteps;
     if (zeroth) {
@@ -1440,7 +1466,20 @@ __global__ __launch_bounds__(512) void ekf_smoother_wg_kernel(const WgArgs<R> a)
   R* mf = L.vec(9);
   R* fmf = L.vec(10);
   const R* LQL = a.par + a.o_LQL;
+#ifdef CDKF_WG_CUSTOM
+  const bool time_dep = CDKF_WG_CUSTOM_TIME != 0;
+#else
+  const bool time_dep = false;
+#endif
   auto rhs = [&](const R* ms, const R* Ps, R& kM, R (&kP)[EPT]) {
+    if (time_dep) {  // f(m_f, u, t) and jacfwd(f)(m_f, u, t) at t = t1 - s in EVERY stage (inference_ekf.py:433-438); aux = X^T stays
+      wg_drift(a, L, mf, fmf, G, (R*)nullptr);
+      CDKF_WG_FOR(e, d * d) {
+        const int i = fdiv(e, d), j = e - i * d;
+        G[i * lq + j] += X[j * lq + i];
+      }
+      __syncthreads();
+    }
     wg_mm<R, false, false, false>(A, G, Ps, d, d, d, lq);
     if (threadIdx.x < d) {
       R s = 0;
@@ -1459,6 +1498,10 @@ __global__ __launch_bounds__(512) void ekf_smoother_wg_kernel(const WgArgs<R> a)
   R t1 = tp[(a.T - 1) * a.t_sk];
   for (long k = a.T - 2; k >= 0; --k) {
     const R t0 = tp[k * a.t_sk];
+    a.ctx_uoff = n * a.u_sn + k * a.u_sk;  // u = inputs[t0_idx] of the interval (inference_ekf.py:516); t = t1 - s below
+    a.ctx_rev = 1;
+    a.ctx_tend = t1;
+    a.ctx_t = t1;
     CDKF_WG_FOR(i, d) mf[i] = fm[k * a.m_sk + i * a.m_si];
     CDKF_WG_FOR(e, d * d) {
       const int i = fdiv(e, d);
@@ -1481,7 +1524,7 @@ __global__ __launch_bounds__(512) void ekf_smoother_wg_kernel(const WgArgs<R> a)
     }
     __syncthreads();
     own.init(d, lq, a.par + a.o_LQL);  // see the filter kernel
-    if (wg_integrate<R, EPT>(L, own, d, R(0), t1 - t0, a.dt0, a.max_steps, true, rhs, a.rk)) st |= kStatusMaxSteps;
+    if (wg_integrate<R, EPT>(L, own, d, R(0), t1 - t0, a.dt0, a.max_steps, true, rhs, a.rk, a)) st |= kStatusMaxSteps;
     wg_store(a, L, a.sm, a.sP, n, k);
     __syncthreads();
     t1 = t0;

@@ -231,6 +231,7 @@ inline T __shfl_down(T v, int off, int = 64) {
   return r;
 }
 inline int atomicOr(int* p, int v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
+inline int atomicAnd(int* p, int v) { return __atomic_fetch_and(p, v, __ATOMIC_SEQ_CST); }
 
 // ---- compiler builtins of the target -----------------------------------------------------------------------------------------
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)

@@ -428,13 +428,16 @@ __device__ __forceinline__ void unpack(Args& a, const R* __restrict__ par, const
   for (int k = 0; k < (Drift::DU > 0 ? Drift::DU : 1); ++k) a.drift.u_[k] = R(0);
 }
 )";
+  // CDKF_RTC_KERNEL_ATTR: extra attributes on the generated register-resident kernel (compiler investigations, e.g.
+  // "__attribute__((amdgpu_waves_per_eu(2,2)))" to halve its register budget); part of the source, hence of the cache key
+  const std::string kattr = getenv("CDKF_RTC_KERNEL_ATTR") ? std::string(getenv("CDKF_RTC_KERNEL_ATTR")) + " " : std::string();
   if (grad) {
-    s += "extern \"C\" __global__ __launch_bounds__(64, 1) void cdkf_custom_kernel(const R* par, const long* ip, const R* t, "
+    s += "extern \"C\" __global__ __launch_bounds__(64, 1) " + kattr + "void cdkf_custom_kernel(const R* par, const long* ip, const R* t, "
          "const R* y, R* ll, R* fm, R* fP, R* pm, R* pP, int* status, R* sm, R* sP, const R* u) {\n  cdkf::GradArgs<R, DD, MM, Drift> ga;\n"
          "  unpack(ga.a, par, ip, t, y, ll, nullptr, nullptr, nullptr, nullptr, status, u);\n  ga.grad = fm;\n";
     s += "  cdkf::ekf_grad_reg_body<R, DD, MM, Drift, " + std::string(generic ? "true" : "false") + ", false>(ga);\n}\n";
   } else if (!smoother) {
-    s += "extern \"C\" __global__ __launch_bounds__(64, 1) void cdkf_custom_kernel(const R* par, const long* ip, const R* t, "
+    s += "extern \"C\" __global__ __launch_bounds__(64, 1) " + kattr + "void cdkf_custom_kernel(const R* par, const long* ip, const R* t, "
          "const R* y, R* ll, R* fm, R* fP, R* pm, R* pP, int* status, R* sm, R* sP, const R* u) {\n  Args a;\n"
          "  unpack(a, par, ip, t, y, ll, fm, fP, pm, pP, status, u);\n";
     s += "  cdkf::filter_reg_body<R, DD, MM, Drift, " + std::string(ukf ? "true" : "false") + ", " +
@@ -549,30 +552,42 @@ int get_function(int kind, const Key& key, hipFunction_t* fn) {
 
 // ---- beyond six dimensions: the workgroup-per-trajectory kernels with the drift compiled in -------------------------------------
 // kind, bytes per real, entries per thread, ukf, smoother, LDS bytes
-using WgKey = std::tuple<int, int, int, int, int, long>;
+using WgKey = std::tuple<int, int, int, int, int, long, int>;  // (..., input_dim)
 std::map<std::pair<int, WgKey>, Compiled> g_wg_modules;
 
-std::string generate_wg_source(const CustomDrift& c, size_t lds) {
+std::string generate_wg_source(const CustomDrift& c, size_t lds, int du) {
   std::string s;
   const std::string D_ = std::to_string(c.d), NT_ = std::to_string(c.n_theta > 0 ? c.n_theta : 1), NTH_ = std::to_string(c.n_theta);
   const bool second = c.has_g && c.auto_g;  // (registered as identically zero: has_g with a blank source -- nothing to add)
   s += "#define CDKF_WG_CUSTOM 1\n#define CDKF_WG_CUSTOM_SECOND " + std::string(second ? "1" : "0") + "\n";
+  s += "#define CDKF_WG_CUSTOM_TIME " + std::string(drift_uses_time(c) ? "1" : "0") + "\n";
   s += "#define CDKF_WG_STATIC_LDS " + std::to_string(lds) + "\n";
   s += "#include \"cdkf_reg_kernels.h\"\n#include \"cdkf_wg2_kernels.h\"\n#include \"cdkf_dual.h\"\nnamespace cdkf {\n";
-  s += "constexpr int CD = " + D_ + ", CNT = " + NT_ + ", CNTH = " + NTH_ + ";\n";
-  s += "// (R: the compute type, as in the register-resident kernels' DriftCustom<R, D> -- the snippet may write R(...) constants)\ntemplate <typename R, typename T> __device__ __forceinline__ void custom_f(const T* x, const T* theta, T (&fx)[CD]) {\n  (void)theta;\n";
+  s += "constexpr int CD = " + D_ + ", CNT = " + NT_ + ", CNTH = " + NTH_ + ", CDU = " + std::to_string(du) + ", CDU1 = " + std::to_string(du > 0 ? du : 1) + ";\n";
+  // (u: this interval's inputs row, t: the time of the evaluation -- f(x, u, t), inference_ekf.py:95; constants under the dual numbers)
+  s += "// (R: the compute type, as in the register-resident kernels' DriftCustom<R, D> -- the snippet may write R(...) constants)\ntemplate <typename R, typename T> __device__ __forceinline__ void custom_f(const T* x, const T* theta, T (&fx)[CD], const R* u, const R t) {\n  (void)theta; (void)u; (void)t;\n";
   s += "#line 1 \"drift_f\"\n" + c.f_src + "\n}\n";
   s += R"(
+// the inputs row of the interval in hand (WgArgs::ctx_uoff) into registers; the evaluation's time is a.ctx_t
+template <typename R>
+__device__ __forceinline__ void wg_custom_ctx(const WgArgs<R>& a, R (&ub)[CDU1]) {
+  ub[0] = R(0);
+  for (int i = 0; i < CDU; ++i) ub[i] = a.u ? a.u[a.ctx_uoff + i * a.u_si] : R(0);
+}
+
 template <typename R>
 __device__ void wg_custom_drift(const WgArgs<R>& a, const WgLds<R>& L, const R* x, R* fv, R* F, R* gv) {
   const R* th = a.par + a.o_theta;
   const int lq = a.lq;
+  R ub[CDU1];
+  wg_custom_ctx(a, ub);
+  const R tt = a.ctx_t;
   if (!F) {
     if (threadIdx.x == 0) {
       R xr[CD], thr[CNT], fr[CD];
       for (int i = 0; i < CD; ++i) xr[i] = x[i];
       for (int k = 0; k < CNTH; ++k) thr[k] = th[k];
-      custom_f<R, R>(xr, thr, fr);
+      custom_f<R, R>(xr, thr, fr, ub, tt);
       for (int i = 0; i < CD; ++i) fv[i] = fr[i];
     }
   } else {  // jacfwd(f) (inference_ekf.py:95): thread j carries the unit direction e_j -> column j of the Jacobian
@@ -584,7 +599,7 @@ __device__ void wg_custom_drift(const WgArgs<R>& a, const WgLds<R>& L, const R* 
         xt[i].g[0] = (i == j) ? R(1) : R(0);
       }
       for (int k = 0; k < CNTH; ++k) tht[k] = T(th[k]);
-      custom_f<R, T>(xt, tht, ft);
+      custom_f<R, T>(xt, tht, ft, ub, tt);
       for (int i = 0; i < CD; ++i) F[i * lq + j] = ft[i].g[0];
       if (j == 0)
         for (int i = 0; i < CD; ++i) fv[i] = ft[i].v;
@@ -609,7 +624,7 @@ __device__ void wg_custom_drift(const WgArgs<R>& a, const WgLds<R>& L, const R* 
         tht[kk].v = S1(th[kk]);
         tht[kk].g[0] = S1(R(0));
       }
-      custom_f<R, T>(xt, tht, ft);
+      custom_f<R, T>(xt, tht, ft, ub, tt);
       R v = R(0);
       for (int l = 0; l < CD; ++l)
         if (l == i) v = ft[l].g[0].g[0];
@@ -632,18 +647,21 @@ __device__ void wg_custom_sigma(const WgArgs<R>& a, const WgLds<R>& L, const R* 
   const R* th = a.par + a.o_theta;
   const int lq = a.lq;
   (void)L;
+  R ub[CDU1];
+  wg_custom_ctx(a, ub);
+  const R tt = a.ctx_t;
   CDKF_WG_FOR(i, CD + 1) {
     R xr[CD], thr[CNT], fp[CD], fm[CD];
     for (int k = 0; k < CNTH; ++k) thr[k] = th[k];
     if (i == CD) {
       for (int r = 0; r < CD; ++r) xr[r] = ms[r];
-      custom_f<R, R>(xr, thr, fp);
+      custom_f<R, R>(xr, thr, fp, ub, tt);
       for (int r = 0; r < CD; ++r) f0[r] = fp[r];
     } else {
       for (int r = 0; r < CD; ++r) xr[r] = ms[r] + O[r * lq + i];
-      custom_f<R, R>(xr, thr, fp);
+      custom_f<R, R>(xr, thr, fp, ub, tt);
       for (int r = 0; r < CD; ++r) xr[r] = ms[r] - O[r * lq + i];
-      custom_f<R, R>(xr, thr, fm);
+      custom_f<R, R>(xr, thr, fm, ub, tt);
       for (int r = 0; r < CD; ++r) {
         DF[r * lq + i] = fp[r] - fm[r];
         foo[r * lq + i] = fp[r] + fm[r];
@@ -657,18 +675,19 @@ __device__ void wg_custom_sigma(const WgArgs<R>& a, const WgLds<R>& L, const R* 
 }
 
 // the shape-generic reverse sweep (cdkf_adjoint_wg_kernels.h) with the drift compiled in: d ll / d theta and every other leaf
-std::string generate_awg_source(const CustomDrift& c, size_t lds) {
+std::string generate_awg_source(const CustomDrift& c, size_t lds, int du) {
   std::string s;
   const std::string D_ = std::to_string(c.d), NT_ = std::to_string(c.n_theta > 0 ? c.n_theta : 1), NTH_ = std::to_string(c.n_theta);
   s += "#define CDKF_AWG_CUSTOM " + NTH_ + "\n#define CDKF_WG_STATIC_LDS " + std::to_string(lds) + "\n";
+  s += "#define CDKF_AWG_CUSTOM_DU " + std::to_string(du) + "\n";
   s += "#define CDKF_AWG_CUSTOM_SECOND " + std::string((c.has_g && c.auto_g) ? "1" : "0") + "\n";
   s += "#include \"cdkf_reg_kernels.h\"\n#include \"cdkf_adjoint_wg_kernels.h\"\n#include \"cdkf_dual.h\"\nnamespace cdkf {\n";
   s += "constexpr int CD = " + D_ + ", CNT = " + NT_ + ", CNTH = " + NTH_ + ";\n";
-  s += "// (R: the compute type, as in the register-resident kernels' DriftCustom<R, D> -- the snippet may write R(...) constants)\ntemplate <typename R, typename T> __device__ __forceinline__ void custom_f(const T* x, const T* theta, T (&fx)[CD]) {\n  (void)theta;\n";
+  s += "// (R: the compute type, as in the register-resident kernels' DriftCustom<R, D> -- the snippet may write R(...) constants;\n// u, t: the interval's inputs row and the evaluation's time, constants under the dual numbers)\ntemplate <typename R, typename T> __device__ __forceinline__ void custom_f(const T* x, const T* theta, T (&fx)[CD], const R* u, const R t) {\n  (void)theta; (void)u; (void)t;\n";
   s += "#line 1 \"drift_f\"\n" + c.f_src + "\n}\n";
   s += R"(
 template <typename R>
-__device__ void awg_custom_column(const R* th, const R* x, int j, R* F, int ld, R* fv) {
+__device__ void awg_custom_column(const R* th, const R* x, int j, R* F, int ld, R* fv, const R* uin, R tin) {
   typedef Dual<R, 1> T;
   T xt[CD], tht[CNT], ft[CD];
   for (int i = 0; i < CD; ++i) {
@@ -676,7 +695,7 @@ __device__ void awg_custom_column(const R* th, const R* x, int j, R* F, int ld, 
     xt[i].g[0] = (i == j) ? R(1) : R(0);
   }
   for (int k = 0; k < CNTH; ++k) tht[k] = T(th[k]);
-  custom_f<R, T>(xt, tht, ft);
+  custom_f<R, T>(xt, tht, ft, uin, tin);
   for (int i = 0; i < CD; ++i) F[i * ld + j] = ft[i].g[0];
   if (fv)
     for (int i = 0; i < CD; ++i) fv[i] = ft[i].v;
@@ -684,7 +703,7 @@ __device__ void awg_custom_column(const R* th, const R* x, int j, R* F, int ld, 
 
 // inner dual: the direction e_j of the Jacobian's column; outer dual: the state component or parameter z
 template <typename R>
-__device__ __forceinline__ R awg_custom_contract(const R* th, const R* x, const R* G, int ld, int j, int z, const R* lam) {
+__device__ __forceinline__ R awg_custom_contract(const R* th, const R* x, const R* G, int ld, int j, int z, const R* lam, const R* uin, R tin) {
   typedef Dual<R, 1> S1;
   typedef Dual<S1, 1> T;
   T xt[CD], tht[CNT], ft[CD];
@@ -698,7 +717,7 @@ __device__ __forceinline__ R awg_custom_contract(const R* th, const R* x, const 
     tht[k].v = S1(th[k]);
     tht[k].g[0] = S1(k + CD == z ? R(1) : R(0));
   }
-  custom_f<R, T>(xt, tht, ft);
+  custom_f<R, T>(xt, tht, ft, uin, tin);
   R s = R(0);
   for (int i = 0; i < CD; ++i) s += G[i * ld + j] * ft[i].g[0].g[0];
   if (lam)
@@ -707,7 +726,7 @@ __device__ __forceinline__ R awg_custom_contract(const R* th, const R* x, const 
 }
 
 template <typename R>
-__device__ __forceinline__ R awg_custom_divpair(const R* th, const R* x, int i, int k) {
+__device__ __forceinline__ R awg_custom_divpair(const R* th, const R* x, int i, int k, const R* uin, R tin) {
   typedef Dual<R, 1> S1;
   typedef Dual<S1, 1> T;
   T xt[CD], tht[CNT], ft[CD];
@@ -721,7 +740,7 @@ __device__ __forceinline__ R awg_custom_divpair(const R* th, const R* x, int i, 
     tht[kk].v = S1(th[kk]);
     tht[kk].g[0] = S1(R(0));
   }
-  custom_f<R, T>(xt, tht, ft);
+  custom_f<R, T>(xt, tht, ft, uin, tin);
   R v = R(0);
   for (int l = 0; l < CD; ++l)
     if (l == i) v = ft[l].g[0].g[0];
@@ -730,7 +749,7 @@ __device__ __forceinline__ R awg_custom_divpair(const R* th, const R* x, int i, 
 
 // innermost dual: the direction u; middle: e_i; outer: the state component or parameter z
 template <typename R>
-__device__ __forceinline__ R awg_custom_third(const R* th, const R* x, const R* u, int i, int z) {
+__device__ __forceinline__ R awg_custom_third(const R* th, const R* x, const R* u, int i, int z, const R* uin, R tin) {
   typedef Dual<R, 1> S1;
   typedef Dual<S1, 1> S2;
   typedef Dual<S2, 1> T;
@@ -748,7 +767,7 @@ __device__ __forceinline__ R awg_custom_third(const R* th, const R* x, const R* 
     tht[kk].v = S2(th[kk]);
     tht[kk].g[0] = S2(kk + CD == z ? R(1) : R(0));
   }
-  custom_f<R, T>(xt, tht, ft);
+  custom_f<R, T>(xt, tht, ft, uin, tin);
   R v = R(0);
   for (int l = 0; l < CD; ++l)
     if (l == i) v = ft[l].g[0].g[0].g[0];
@@ -768,7 +787,8 @@ std::string wg_kernel_expr(int bytes, int ept, int ukf, int smoother) {
 
 int compile_wg_variant(const CustomDrift& c, const WgKey& key, const std::string& arch, std::vector<char>& code, std::string& lowered) {
   const int bytes = std::get<1>(key), ept = std::get<2>(key), ukf = std::get<3>(key), smoother = std::get<4>(key);
-  const std::string src = smoother == 2 ? generate_awg_source(c, (size_t)std::get<5>(key)) : generate_wg_source(c, (size_t)std::get<5>(key));
+  const std::string src = smoother == 2 ? generate_awg_source(c, (size_t)std::get<5>(key), std::get<6>(key))
+                                        : generate_wg_source(c, (size_t)std::get<5>(key), std::get<6>(key));
   const std::string expr = wg_kernel_expr(bytes, ept, ukf, smoother);
   // -O1: the instantiations with eight or more entries per thread, as in the library (launch_wg8.hip) -- and every unscented variant: at
   // -O3 the generic sigma-point path of a d = 15 source drift with `pow(x, 2)` in it (256 + 128 registers, 1.7 KB of scratch, 45 calls of
@@ -883,7 +903,7 @@ int launch_custom_wg(const WgArgs<R>& a, int ept, bool filter, bool smoother, in
   auto run = [&](int smooth, size_t lds) -> int {
     hipFunction_t fn = nullptr;
     const size_t bytes = (lds + 15) & ~size_t(15);
-    int r = get_wg_function(a.kind, WgKey(a.kind, (int)sizeof(R), ept, smooth ? 0 : a.ukf, smooth, (long)bytes), &fn);
+    int r = get_wg_function(a.kind, WgKey(a.kind, (int)sizeof(R), ept, smooth ? 0 : a.ukf, smooth, (long)bytes, a.du), &fn);
     if (r) return r;
     WgArgs<R> arg = a;
     void* args[] = {(void*)&arg};
@@ -901,7 +921,7 @@ template <typename R>
 int launch_custom_awg(const WgArgs<R>& a, R* grad, R* grad_model, R* scratch, long scratch_stride, int cap, int ne, size_t lds, hipStream_t stream) {
   hipFunction_t fn = nullptr;
   const size_t bytes = (lds + 15) & ~size_t(15);
-  int r = get_wg_function(a.kind, WgKey(a.kind, (int)sizeof(R), ne, 0, 2, (long)bytes), &fn);
+  int r = get_wg_function(a.kind, WgKey(a.kind, (int)sizeof(R), ne, 0, 2, (long)bytes, a.du), &fn);
   if (r) return r;
   WgArgs<R> arg = a;
   void* args[] = {(void*)&arg, (void*)&grad, (void*)&grad_model, (void*)&scratch, (void*)&scratch_stride, (void*)&cap};
@@ -921,7 +941,6 @@ bool custom_adjoint_available(const cdkf_model* mdl, const cdkf_opts* o) {
   std::lock_guard<std::mutex> lock(g_mutex);
   const CustomDrift& c = g_drifts[mdl->drift_kind - CDKF_DRIFT_CUSTOM_BASE];
   if (c.d != mdl->state_dim || c.n_theta != mdl->n_theta) return false;
-  if (drift_reads_context(c)) return false;  // (the reverse sweep does not carry inputs / stage times yet: DESIGN.md section 6)
   // 'second': grad(div f) registered as identically zero, or "auto" (third derivatives by triply nested dual numbers)
   if (o->state_order == CDKF_ORDER_SECOND && !(c.has_g && (c.auto_g || blank(c.g_src)))) return false;
   const int q = c.d > mdl->emission_dim ? c.d : mdl->emission_dim, Z = c.d + c.n_theta;
@@ -972,7 +991,6 @@ bool custom_shape_available(const cdkf_model* mdl, const cdkf_opts* o) {
     if (c.d != mdl->state_dim || c.n_theta != mdl->n_theta) return false;
     if (o && o->state_order == CDKF_ORDER_SECOND && !c.has_g) return false;
     cd = c.d;
-    if ((cd > 6 || mdl->emission_dim > 6) && drift_reads_context(c)) return false;  // (workgroup kernels: no inputs / stage times yet)
   }
   if (cd > 6 || mdl->emission_dim > 6)  // the workgroup kernels: linear emission, their LDS plan (asked in fp32; an fp64 launch that
     return mdl->emission_kind == 0 && custom_wg_fits(mdl);  // does not fit says so itself)
@@ -1233,7 +1251,7 @@ int custom_compile_check(int kind, int bytes_per_real, int emission_dim, int alg
         return CDKF_EUNSUPPORTED;
       }
       std::string lowered;
-      return compile_wg_variant(c, WgKey(kind, bytes_per_real, ne, 0, 2, (long)((lds + 15) & ~size_t(15))), "gfx950", code, lowered);
+      return compile_wg_variant(c, WgKey(kind, bytes_per_real, ne, 0, 2, (long)((lds + 15) & ~size_t(15)), du), "gfx950", code, lowered);
     }
     int ept = 0, threads = 0;
     size_t lds_f = 0, lds_s = 0;
@@ -1242,8 +1260,8 @@ int custom_compile_check(int kind, int bytes_per_real, int emission_dim, int alg
       return CDKF_EUNSUPPORTED;
     }
     std::string lowered;
-    int rc = compile_wg_variant(c, WgKey(kind, bytes_per_real, ept, algo == 1, 0, (long)((lds_f + 15) & ~size_t(15))), "gfx950", code, lowered);
-    if (!rc && algo == 2) rc = compile_wg_variant(c, WgKey(kind, bytes_per_real, ept, 0, 1, (long)((lds_s + 15) & ~size_t(15))), "gfx950", code, lowered);
+    int rc = compile_wg_variant(c, WgKey(kind, bytes_per_real, ept, algo == 1, 0, (long)((lds_f + 15) & ~size_t(15)), du), "gfx950", code, lowered);
+    if (!rc && algo == 2) rc = compile_wg_variant(c, WgKey(kind, bytes_per_real, ept, 0, 1, (long)((lds_s + 15) & ~size_t(15)), du), "gfx950", code, lowered);
     return rc;
   }
   const int zeroth = (algo != 1 && state_order == CDKF_ORDER_ZEROTH) ? 1 : 0;

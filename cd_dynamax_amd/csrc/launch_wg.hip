@@ -117,6 +117,19 @@ static int wg_fill(WgArgs<R>& a, std::vector<R>& h, const cdkf_model* mdl, const
   a.o_m0 = push(mdl->m0, d);
   a.o_P0 = push(mdl->P0, (long)d * d);
   a.o_w2pad = -1;
+  a.u = nullptr;  // (set by the launchers that have inputs: drifts given as source; the registry drifts ignore them)
+  a.u_sn = a.u_sk = a.u_si = 0;
+  a.du = 0;
+  a.ctx_uoff = 0;
+  a.ctx_t = a.ctx_tend = R(0);
+  a.ctx_rev = 0;
+  if (mdl->drift_kind >= CDKF_DRIFT_CUSTOM_BASE && mdl->input_dim > 0) {
+    const int lin = (o->layout_in == CDKF_LAYOUT_SAME) ? o->layout : o->layout_in;
+    const ArrayStrides us = layout_strides(lin, N, T, mdl->input_dim);
+    a.u = (const R*)o->inputs;  // (device memory at this level)
+    a.u_sn = us.sn; a.u_sk = us.sk; a.u_si = us.si;
+    a.du = mdl->input_dim;
+  }
   a.r_diag = 1;
   for (int r = 0; r < m; ++r)
     for (int c = 0; c < m; ++c)
@@ -259,7 +272,7 @@ static int debug_wg_args_t(const cdkf_model* mdl, const cdkf_opts* o, int64_t N,
   WgArgs<R> a{};
   std::vector<R> h;
   cdkf_opts of = *o;
-  if (smoother) of.num_iter = 1;
+  if (smoother == 1) of.num_iter = 1;
   const int rc = wg_fill(a, h, mdl, &of, N, T);
   if (rc) return rc;
   if (ukf) {
@@ -270,8 +283,21 @@ static int debug_wg_args_t(const cdkf_model* mdl, const cdkf_opts* o, int64_t N,
   const int threads = custom ? wg_threads_custom(a.d) : wg_threads(mdl);
   geom[0] = wg_ept(a.d, threads);
   geom[1] = threads;
-  geom[2] = (int64_t)((wg_lds_bytes<R>(mdl, smoother != 0, ukf != 0) + 15) & ~size_t(15));
+  geom[2] = (int64_t)((wg_lds_bytes<R>(mdl, smoother == 1, ukf != 0) + 15) & ~size_t(15));
   geom[3] = (int64_t)sizeof(WgArgs<R>);
+  if (smoother == 2) {  // the reverse sweep (ekf_adjoint_wg_kernel): entries per thread, 256 threads, its LDS plan, scratch reals per trajectory, cap
+    int ne = 0;
+    size_t lds = 0;
+    if (custom_awg_geometry(a.d, a.m, (int)sizeof(R), &ne, &lds)) {
+      set_error("cdkf_debug_wg_args: state_dim %d / emission_dim %d do not fit the reverse sweep's LDS plan", a.d, a.m);
+      return CDKF_EUNSUPPORTED;
+    }
+    geom[0] = ne;
+    geom[1] = 256;
+    geom[2] = (int64_t)((lds + 15) & ~size_t(15));
+    geom[4] = adjoint_wg_scratch_reals(a.d, 8);
+    geom[5] = 8;
+  }
   if ((int64_t)sizeof(WgArgs<R>) > args_cap || (int64_t)(h.size() * sizeof(R)) > blob_cap) {
     set_error("cdkf_debug_wg_args: buffers too small (%lld, %lld bytes needed)", (long long)sizeof(WgArgs<R>), (long long)(h.size() * sizeof(R)));
     return CDKF_EINVAL;

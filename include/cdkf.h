@@ -335,8 +335,10 @@ void cdkf_set_kernel_source_dir(const char* dir);
 int cdkf_debug_custom_reg_blob(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T, int algo, int bytes_per_real,
                                void* par_out, int64_t par_cap_bytes, int64_t* ip_out);
 /* workgroup-per-trajectory kernels (cdkf_wg2_kernels.h: any drift, state / emission dimension <= 64): args_out receives the kernel's
- * argument struct (WgArgs<real>, every pointer null), blob_out its parameter block, geom_out[4] = {covariance entries per thread,
- * threads per workgroup, LDS bytes, sizeof(WgArgs<real>)}; ukf / smoother select the unscented filter / the backward sweep.
+ * argument struct (WgArgs<real>, every pointer null), blob_out its parameter block, geom_out[6] = {covariance entries per thread,
+ * threads per workgroup, LDS bytes, sizeof(WgArgs<real>), 0, 0}; ukf / smoother = 1 select the unscented filter / the backward sweep;
+ * smoother = 2: the reverse sweep of the gradient (ekf_adjoint_wg_kernel), geom_out[4], [5] = its scratch reals per trajectory and the
+ * number of step starts it keeps per replay chunk.
  * Returns the number of reals in the block or a negative CDKF_E* code. */
 int cdkf_debug_wg_args(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T, int bytes_per_real, int ukf, int smoother,
                        void* args_out, int64_t args_cap_bytes, void* blob_out, int64_t blob_cap_bytes, int64_t* geom_out);

@@ -1238,7 +1238,7 @@ def drift_vjp(drift, x, lam, G):
     if drift.kind == "custom":
         if drift._vjp is None:
             raise NotImplementedError("CallableDrift without vjp")
-        xb, tb = drift._vjp(x, lam, G, drift.th)
+        xb, tb = drift._vjp(x, lam, G, drift.th, *(_ctx_rows(1) if drift.ut else ()))  # (ut: the single row's u [1, d_u] and t [1])
         return np.asarray(xb, np.float64), np.asarray(tb, np.float64)
     F = drift.jac(x[None])[0]
     xb = F.T @ lam
@@ -1268,7 +1268,7 @@ def divgrad_vjp(drift, x, u):
     if drift.kind == "custom":
         if drift._gvjp is None:
             raise NotImplementedError("CallableDrift without gvjp")
-        xb, tb = drift._gvjp(x, u, drift.th)
+        xb, tb = drift._gvjp(x, u, drift.th, *(_ctx_rows(1) if drift.ut else ()))
         return np.asarray(xb, np.float64), np.asarray(tb, np.float64)
     if drift.kind != "mlp":
         return np.zeros_like(x), np.zeros(drift.theta().size)
@@ -1365,7 +1365,7 @@ def ukf_loglik_grad_all(mdl: Model, t, y, dt0=0.01, dt_final=1e-10, max_steps=10
 
 
 def ekf_loglik_grad_adjoint(mdl: Model, t, y, dt0=0.01, dt_final=1e-10, max_steps=100000, full=False, state_order="first", ukf=False,
-                            num_iter=1):
+                            num_iter=1, inputs=None):
     """Returns (ll [N], grad [N, n_theta]): EKF, state_order 'first' or 'second' (the mean term 0.5 P grad(div f), reversed by
     divgrad_vjp); ``num_iter`` update iterations as inference_ekf.py:153-199 runs them (each from the previous one's posterior, the
     log-likelihood term from the first one's inputs, symmetrize once at the end); float64.
@@ -1384,6 +1384,7 @@ def ekf_loglik_grad_adjoint(mdl: Model, t, y, dt0=0.01, dt_final=1e-10, max_step
     LQL = _LQL(mdl)
     npar = drift.theta().size
     eye_m = np.eye(mm)
+    u_all = _inputs(inputs, N, T, np.float64)   # f(x, u, t): the interval's inputs row and the stage times travel in _CTX (module header)
     sym = lambda A: 0.5 * (A + A.T)
     f = lambda x: drift.f(x[None])[0]
     jac = lambda x: drift.jac(x[None])[0]
@@ -1416,11 +1417,17 @@ def ekf_loglik_grad_adjoint(mdl: Model, t, y, dt0=0.01, dt_final=1e-10, max_step
         diffeqsolve(rhs_b, np.array([ta]), np.array([tb]), (x[None].copy(), P[None].copy()), dt0, max_steps, dt_log=log)
         return log
 
-    def stages(x, P, dt):
+    def at_stage(ts, dt, i):
+        """context time of stage i of the step that starts at ts: ts + c_i dt"""
+        if ts is not None:
+            _CTX["t"] = np.array([ts + dt * sum(_DP_A[i])])
+
+    def stages(x, P, dt, ts=None):
         ks = []
         for i in range(NST):
             xs = x + dt * sum((_DP_A[i][j] * ks[j][0] for j in range(i)), np.zeros(d))
             Ps = P + dt * sum((_DP_A[i][j] * ks[j][1] for j in range(i)), np.zeros((d, d)))
+            at_stage(ts, dt, i)
             ks.append(rhs(xs, Ps))
         return ks
 
@@ -1456,11 +1463,14 @@ def ekf_loglik_grad_adjoint(mdl: Model, t, y, dt0=0.01, dt_final=1e-10, max_step
             Pf.append(sym(its[-1][1]))
             if k + 1 < T:
                 x, P = mf[k], Pf[k]
+                _CTX["u"] = u_all[n:n + 1, k]
                 dts_fwd[k] = step_sizes(x, P, tn[k], tn[k + 1])
+                ts = tn[k]
                 for dt in dts_fwd[k]:
-                    ks = stages(x, P, dt)
+                    ks = stages(x, P, dt, ts)
                     x = x + dt * sum(_DP_B[i] * ks[i][0] for i in range(NST))
                     P = P + dt * sum(_DP_B[i] * ks[i][1] for i in range(NST))
+                    ts = ts + dt
                 mp.append(x)
                 Pp.append(P)
         # ---- backward sweep ----
@@ -1495,20 +1505,23 @@ def ekf_loglik_grad_adjoint(mdl: Model, t, y, dt0=0.01, dt_final=1e-10, max_step
                 break
             # predict k-1 -> k: reverse the Dormand-Prince steps
             dts = dts_fwd[k - 1]
-            starts = [(mf[k - 1], Pf[k - 1])]
+            _CTX["u"] = u_all[n:n + 1, k - 1]
+            starts, tstarts = [(mf[k - 1], Pf[k - 1])], [tn[k - 1]]
             for dt in dts[:-1]:
                 x, P = starts[-1]
-                ks = stages(x, P, dt)
+                ks = stages(x, P, dt, tstarts[-1])
                 starts.append((x + dt * sum(_DP_B[i] * ks[i][0] for i in range(NST)),
                                P + dt * sum(_DP_B[i] * ks[i][1] for i in range(NST))))
-            for (x, P), dt in zip(reversed(starts), reversed(dts)):
-                ks = stages(x, P, dt)
+                tstarts.append(tstarts[-1] + dt)
+            for (x, P), dt, ts in zip(reversed(starts), reversed(dts), reversed(tstarts)):
+                ks = stages(x, P, dt, ts)
                 Yb = [None] * NST
                 for i in range(NST - 1, -1, -1):
                     lam = dt * (_DP_B[i] * mb + sum((_DP_A[j][i] * Yb[j][0] for j in range(i + 1, NST)), np.zeros(d)))
                     Lam = dt * (_DP_B[i] * Pb + sum((_DP_A[j][i] * Yb[j][1] for j in range(i + 1, NST)), np.zeros((d, d))))
                     Lam = sym(Lam)
                     xs, Ps = stage_in(x, P, dt, ks, i)
+                    at_stage(ts, dt, i)
                     F = jac(xs)
                     xb, tb = drift_vjp(drift, xs, lam, 2 * Lam @ Ps)
                     Pbar = F.T @ Lam + Lam @ F

@@ -135,6 +135,20 @@ def main():
     if not none_ok or all_ok:
         say("the pre-RA shrink rewrites do not separate GOOD from BAD in this pipeline: stop")
         return
+    # by KIND of rewrite first: the pass changes instruction encodings (VOP3 -> VOP2, commuted compares) AND leaves register-allocation
+    # hints in the function's register table (`preferred-register:` -- e.g. $vcc for the carry / condition operands it would like there)
+    is_hint = lambda h: any("preferred-register" in ln for ln in h[2]) or any("preferred-register" in ln for ln in pre_lines[h[0]:h[1]])
+    hints = [i for i, h in enumerate(H) if is_hint(h)]
+    instrs = [i for i, h in enumerate(H) if not is_hint(h)]
+    fmac = [i for i in instrs if any("V_FMAC_F64_e32" in ln for ln in H[i][2])]
+    say("hint lines", len(hints), "| instruction lines", len(instrs), "| of them V_FMAC_F64 e64 -> e32", len(fmac))
+    for label, sub in (("register-allocation hints only", hints), ("instruction rewrites only", instrs), ("V_FMAC_F64_e32 only", fmac),
+                       ("everything but V_FMAC_F64_e32", [i for i in range(len(H)) if i not in set(fmac)]),
+                       ("everything but the hints", instrs)):
+        r = test(sub)
+        say("  %-34s %5d lines: %s" % (label, len(sub), "GOOD" if r else ("BAD" if r is False else "llc failed")))
+    if len(sys.argv) > 2 and sys.argv[2] == "kinds":
+        return
     # ddmin: smallest subset that is still BAD
     cur = list(range(len(H)))
     n = 2

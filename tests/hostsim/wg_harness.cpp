@@ -6,8 +6,9 @@
 // Test infrastructure (tests/test_hostsim.py).  Build-time selection of the instantiation:
 //   -DHS_REAL=double|float -DHS_EPT=<entries per thread> -DHS_UKF=<0|1> -DHS_KIND=<drift kind or -1> -DHS_SMOOTHER=<0|1>
 //   -DCDKF_WG_STATIC_LDS=<bytes>   (the carve-up's size, as for the run-time compiled variants)
-//   in : int64 head[16] = {N, threads, n_args_bytes, n_blob, n_t, n_y, n_ll, n_fm, n_fP, n_pm, n_pP, n_status, n_sm, n_sP, 0, 0},
+//   in : int64 head[16] = {N, threads, n_args_bytes, n_blob, n_t, n_y, n_ll, n_fm, n_fP, n_pm, n_pP, n_status, n_sm, n_sP, n_u, 0},
 //        WgArgs bytes, blob (R), t (R), y (R)  [+ fm, fP (R) when HS_SMOOTHER: the filtered moments the backward sweep reads]
+//        [+ u (R), n_u > 0: the inputs a drift given as source reads]
 //   out: ll, fm, fP, pm, pP, status (int32), sm, sP
 #include <stdint.h>
 #include <stdio.h>
@@ -50,6 +51,7 @@ int main(int argc, char** argv) {
 #if HS_SMOOTHER
   if (fread(fm, sizeof(HR), head[7], f) != (size_t)head[7] || fread(fP, sizeof(HR), head[8], f) != (size_t)head[8]) return 2;
 #endif
+  HR* u = head[14] > 0 ? rd<HR>(f, head[14]) : nullptr;
   fclose(f);
   a.par = blob;
   a.t = t;
@@ -62,6 +64,7 @@ int main(int argc, char** argv) {
   a.sm = sm;
   a.sP = sP;
   a.status = status;
+  a.u = a.du > 0 ? u : nullptr;   // (strides and du: the launcher's own, cdkf_debug_wg_args)
   hostsim::launch((unsigned)head[0], (unsigned)head[1], [&] {
 #if HS_SMOOTHER
     cdkf::ekf_smoother_wg_kernel<HR, HS_EPT>(a);

@@ -132,7 +132,7 @@ def reg_run(src_path, mdl, opts, t, y, algo, dtype, san, outs, opt="-O1", inputs
     return arrs
 
 
-def wg_run(include_src, mdl, opts, t, y, dtype, san, *, ukf=False, kind=-1, smoother=False, filtered=None, opt="-O1", timeout=3000):
+def wg_run(include_src, mdl, opts, t, y, dtype, san, *, ukf=False, kind=-1, smoother=False, filtered=None, opt="-O1", timeout=3000, inputs=None):
     """Run one instantiation of the workgroup-per-trajectory kernels on the host.  include_src: the translation unit
     (tests/hostsim/wg_builtin_tu.h or a generated custom-drift source).  t [N,T], y [N,T,m]; opts.layout = TN (outputs [T,N,...]) and
     layout_in = NT are set here.  Returns dict of outputs in the reference shapes [N,T,...]."""
@@ -145,16 +145,18 @@ def wg_run(include_src, mdl, opts, t, y, dtype, san, *, ukf=False, kind=-1, smoo
     opts.t_shared = 0
     args = np.zeros(8192, np.uint8)
     blob = np.zeros(1 << 18, dtype)
-    geom = np.zeros(4, np.int64)
+    geom = np.zeros(6, np.int64)
     n = _ffi.lib().cdkf_debug_wg_args(C.byref(mdl.c), C.byref(opts), N, T, dtype.itemsize, int(ukf), int(smoother), args.ctypes.data_as(C.c_void_p),
                                        args.nbytes, blob.ctypes.data_as(C.c_void_p), blob.nbytes, geom.ctypes.data_as(C.POINTER(C.c_int64)))
     assert n > 0, _ffi.lib().cdkf_last_error().decode()
-    ept, threads, lds, asz = (int(v) for v in geom)
+    ept, threads, lds, asz = (int(v) for v in geom[:4])
     tt, yy = np.ascontiguousarray(t, dtype), np.ascontiguousarray(y, dtype)
     nm, nP = N * T * d, N * T * d * d
     head = np.zeros(16, np.int64)
     head[:6] = [N, threads, asz, n, tt.size, yy.size]
     head[6:14] = [N, nm, nP, 0 if smoother else nm, 0 if smoother else nP, N, nm if smoother else 0, nP if smoother else 0]
+    uu = None if inputs is None else np.ascontiguousarray(inputs, dtype)
+    head[14] = 0 if uu is None else uu.size
     defines = [f"HS_REAL={'double' if dtype.itemsize == 8 else 'float'}", f"HS_EPT={ept}", f"HS_UKF={int(ukf)}", f"HS_KIND={kind}",
                f"HS_SMOOTHER={int(smoother)}"]
     if not open(include_src).read().count("CDKF_WG_STATIC_LDS"):
@@ -167,6 +169,8 @@ def wg_run(include_src, mdl, opts, t, y, dtype, san, *, ukf=False, kind=-1, smoo
             if smoother:   # filtered moments in the sweep's own layout [T,N,...]
                 f.write(np.ascontiguousarray(np.swapaxes(filtered[0], 0, 1), dtype).tobytes())
                 f.write(np.ascontiguousarray(np.swapaxes(filtered[1], 0, 1), dtype).tobytes())
+            if uu is not None:
+                f.write(uu.tobytes())
         res = run(exe, fin, fout, timeout)
         reports = sanitizer_reports(res.stderr)
         if res.returncode != 0 or reports:
@@ -186,3 +190,54 @@ def wg_run(include_src, mdl, opts, t, y, dtype, san, *, ukf=False, kind=-1, smoo
     ll, fm, fP, pm, pP = take(N), take(nm), take(nP), take(nm), take(nP)
     return {"marginal_loglik": ll, "filtered_means": TN(fm, (d,)), "filtered_covariances": TN(fP, (d, d)), "predicted_means": TN(pm, (d,)),
             "predicted_covariances": TN(pP, (d, d)), "status": take(N, np.int32), "geom": (ept, threads, lds)}
+
+
+def awg_run(include_src, mdl, opts, t, y, dtype, san, forward, *, inputs=None, n_theta=None, opt="-O1", timeout=3000):
+    """Run the reverse sweep ekf_adjoint_wg_kernel on the host.  include_src: the generated custom-drift unit of the reverse sweep (or
+    a header with the library's instantiation); forward: the dict wg_run returned for the filter on the same problem (its four moment
+    arrays are what the reverse sweep reads).  Returns (grad [N, n_theta], grad_model [N, d + 2 d^2 + m d + m + m^2], status)."""
+    from cd_dynamax_amd import _ffi
+    dtype = np.dtype(dtype)
+    N, T = t.shape
+    d, m = mdl.state_dim, mdl.emission_dim
+    opts.layout = _ffi.LAYOUT_TN
+    opts.layout_in = _ffi.LAYOUT_NT
+    opts.t_shared = 0
+    args = np.zeros(8192, np.uint8)
+    blob = np.zeros(1 << 18, dtype)
+    geom = np.zeros(6, np.int64)
+    n = _ffi.lib().cdkf_debug_wg_args(C.byref(mdl.c), C.byref(opts), N, T, dtype.itemsize, 0, 2, args.ctypes.data_as(C.c_void_p),
+                                       args.nbytes, blob.ctypes.data_as(C.c_void_p), blob.nbytes, geom.ctypes.data_as(C.POINTER(C.c_int64)))
+    assert n > 0, _ffi.lib().cdkf_last_error().decode()
+    ne, threads, lds, asz, ws_stride, cap = (int(v) for v in geom)
+    n_theta = int(mdl.c.n_theta) if n_theta is None else n_theta
+    ngm = d + 2 * d * d + m * d + m + m * m
+    tt, yy = np.ascontiguousarray(t, dtype), np.ascontiguousarray(y, dtype)
+    uu = None if inputs is None else np.ascontiguousarray(inputs, dtype)
+    nm, nP = N * T * d, N * T * d * d
+    head = np.zeros(16, np.int64)
+    head[:13] = [N, threads, asz, n, tt.size, yy.size, nm, nP, N * n_theta, N * ngm, ws_stride, cap, 0 if uu is None else uu.size]
+    defines = [f"HS_REAL={'double' if dtype.itemsize == 8 else 'float'}", f"HS_NE={ne}"]
+    if not open(include_src).read().count("CDKF_WG_STATIC_LDS"):
+        defines.append(f"CDKF_WG_STATIC_LDS={lds}")
+    exe = build("awg_harness.cpp", include_src, san, opt, defines)
+    TNf = lambda a: np.ascontiguousarray(np.swapaxes(a, 0, 1), dtype).tobytes()
+    with tempfile.TemporaryDirectory() as dd:
+        fin, fout = os.path.join(dd, "in.bin"), os.path.join(dd, "out.bin")
+        with open(fin, "wb") as f:
+            f.write(head.tobytes()); f.write(args[:asz].tobytes()); f.write(blob[:n].tobytes()); f.write(tt.tobytes()); f.write(yy.tobytes())
+            for k in ("filtered_means", "filtered_covariances", "predicted_means", "predicted_covariances"):
+                f.write(TNf(forward[k]))
+            if uu is not None:
+                f.write(uu.tobytes())
+        res = run(exe, fin, fout, timeout)
+        reports = sanitizer_reports(res.stderr)
+        if res.returncode != 0 or reports:
+            raise AssertionError(f"host run of the reverse sweep ({san}, ne {ne}) rc={res.returncode}\n" + res.stderr[-12000:])
+        raw = open(fout, "rb").read()
+    off = N * dtype.itemsize
+    grad = np.frombuffer(raw, dtype, N * n_theta, off).reshape(N, n_theta).copy()
+    off += N * n_theta * dtype.itemsize
+    gm = np.frombuffer(raw, dtype, N * ngm, off).reshape(N, ngm).copy()
+    off += N * ngm * dtype.itemsize
+    return grad, gm, np.frombuffer(raw, np.int32, N, off).copy()

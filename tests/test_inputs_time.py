@@ -37,9 +37,17 @@ def l63_ut_jac(x, th, u, t):
     return J
 
 
+def l63_ut_vjp(x, lam, G, th, u, t):
+    """gradient of lam . f + <G, F> w.r.t. (x, theta) for one row (what the oracle's reverse sweep needs of a callable drift)"""
+    F = l63_ut_jac(x[None], th, u, t)[0]
+    xb = F.T @ lam + np.array([-G[1, 2] + G[2, 1], G[2, 0], -G[1, 0]])
+    return xb, np.array([lam[0] * (x[1] - x[0]) - G[0, 0] + G[0, 1], lam[1] * x[0] + G[1, 0], -lam[2] * x[2] - G[2, 2]])
+
+
 def l63_ut_model(theta, m_obs=2):
     base = o.lorenz63_model(m_obs)
-    drift = o.CallableDrift(theta, l63_ut_f, l63_ut_jac, lambda x, th, u, t: np.zeros_like(x), ut=True)
+    drift = o.CallableDrift(theta, l63_ut_f, l63_ut_jac, lambda x, th, u, t: np.zeros_like(x), ut=True, vjp=l63_ut_vjp,
+                            gvjp=lambda x, uu, th, u, t: (np.zeros(3), np.zeros(3)))
     return o.Model(drift, base.L, base.Qc, base.H, base.bias, base.R, base.m0, base.P0)
 
 
@@ -123,6 +131,18 @@ def _grad_fd(theta, t, y, u):
         return o.ekf_filter(l63_ut_model(thv), t, y, "first", inputs=u)["marginal_loglik"]
     fd = lambda h: np.stack([(ll_of(theta + h * np.eye(3)[p]) - ll_of(theta - h * np.eye(3)[p])) / (2 * h) for p in range(3)], -1)
     return (4 * fd(5e-5) - fd(1e-4)) / 3
+
+
+def test_oracle_reverse_sweep_with_inputs_and_time_matches_finite_differences():
+    """ekf_loglik_grad_adjoint(inputs=...) -- the reverse sweep with the stage times and the interval's inputs in the context -- against
+    Richardson finite differences of ekf_filter's log-likelihood (drift block), fixed steps and an adaptive solve."""
+    theta, mdl, t, y, u = problem(N=2, T=8)
+    ll, g = o.ekf_loglik_grad_adjoint(mdl, t, y, state_order="first", inputs=u)
+    np.testing.assert_allclose(ll, o.ekf_filter(mdl, t, y, "first", inputs=u)["marginal_loglik"], rtol=1e-12)
+    g_fd = _grad_fd(theta, t, y, u)
+    assert np.abs(g - g_fd).max() < 1e-8 * np.abs(g_fd).max()
+    ll2, g2 = o.ekf_loglik_grad_adjoint(mdl, t, y, state_order="second", inputs=u)   # (grad(div f) = 0 for this drift)
+    assert np.abs(g2 - g).max() < 1e-12 * np.abs(g).max()
 
 
 def test_register_kernels_with_inputs_and_time_on_the_host():
@@ -245,3 +265,130 @@ def test_controlled_pendulum_and_time_dependent_emission(hip_lib):
     refs = o.ekf_smoother(mdl, t, y, "first", inputs=u)
     sm = cd.cdnlgssm_smoother(P, y, t[..., None], cd.EKFHyperParams(state_order="first"), inputs=u)
     assert relerr(sm.smoothed_means, refs["smoothed_means"]) < 1e-9
+
+
+# ---- beyond six dimensions: the workgroup kernels and the reverse sweep ------------------------------------------------------------
+D8, M8 = 8, 5
+
+
+def _l96_ut(d=D8):
+    """Lorenz-96 with a time-dependent forcing and two inputs: f_i = (x_{i+1} - x_{i-2}) x_{i-1} - x_i + th_0 + 2 sin(t + i) + th_1 u_{i mod 2}"""
+    src = "".join(f"fx[{i}] = (x[{(i + 1) % d}] - x[{(i - 2) % d}]) * x[{(i - 1) % d}] - x[{i}] + theta[0] + R(2) * sin(t + R({i})) + theta[1] * u[{i % 2}];"
+                  for i in range(d))
+    idx = np.arange(d)
+
+    def f(x, th, u, t):
+        return (x[..., (idx + 1) % d] - x[..., (idx - 2) % d]) * x[..., (idx - 1) % d] - x + th[0] + 2 * np.sin(t[..., None] + idx) + th[1] * u[..., idx % 2]
+
+    def jac(x, th, u, t):
+        J = np.zeros(x.shape + (d,))
+        for i in range(d):
+            J[..., i, (i + 1) % d] += x[..., (i - 1) % d]
+            J[..., i, (i - 2) % d] -= x[..., (i - 1) % d]
+            J[..., i, (i - 1) % d] += x[..., (i + 1) % d] - x[..., (i - 2) % d]
+            J[..., i, i] -= 1
+        return J
+
+    def vjp(x, lam, G, th, u, t):   # gradient of lam . f + <G, F> w.r.t. (x, theta), one row
+        F = jac(x[None], th, u, t)[0]
+        xb = F.T @ lam
+        for i in range(d):
+            xb[(i - 1) % d] += G[i, (i + 1) % d] - G[i, (i - 2) % d]
+            xb[(i + 1) % d] += G[i, (i - 1) % d]
+            xb[(i - 2) % d] -= G[i, (i - 1) % d]
+        return xb, np.array([lam.sum(), lam @ u[0, idx % 2]])
+    return src, f, jac, vjp
+
+
+def l96_ut_problem(N=2, T=6, span=0.1, seed=1, d=D8, m=M8):
+    rng = np.random.default_rng(seed)
+    theta = np.array([8.0, 0.7])
+    src, f, jac, vjp = _l96_ut(d)
+    H = rng.standard_normal((m, d)) / np.sqrt(d)
+    drift = o.CallableDrift(theta, f, jac, lambda x, th, u, t: np.zeros_like(x), ut=True, vjp=vjp, gvjp=lambda x, uu, th, u, t: (np.zeros(d), np.zeros(2)))
+    mdl = o.Model(drift, np.eye(d), 0.3 * np.eye(d), H, 0.1 * rng.standard_normal(m), 0.5 * np.eye(m), 8 + rng.standard_normal(d), 0.5 * np.eye(d))
+    t = o.irregular_times(rng, N, T, span) + 0.5
+    u = rng.standard_normal((N, T, 2))
+    y = 2 * rng.standard_normal((N, T, m)) + 5
+    P = cd.ParamsCDNLGSSM(
+        initial=cd.ParamsLGSSMInitial(cd.LearnableVector(mdl.m0), cd.LearnableMatrix(mdl.P0)),
+        dynamics=cd.ParamsCDNLGSSMDynamics(cd.LearnableCustomDrift(theta, src, None, ""), cd.LearnableMatrix(mdl.L), cd.LearnableMatrix(mdl.Qc), 2.0),
+        emissions=cd.ParamsCDNLGSSMEmissions(cd.LearnableLinear(mdl.H, mdl.bias), cd.LearnableMatrix(mdl.R)))
+    return theta, mdl, P, t, y, u
+
+
+def test_workgroup_kernels_and_reverse_sweep_with_inputs_and_time_on_the_host():
+    """d = 8 on the run-time compiled workgroup kernels, host build under ASan + UBSan: EKF, UKF, the smoother's backward sweep and
+    the reverse sweep of the gradient (every leaf), each reading the interval's inputs row and the stage times (t1 - s backwards)."""
+    import hostsim_util as hs
+    import shutil
+    if hs.clang() is None or shutil.which("hipcc") is None:
+        pytest.skip("needs clang++ and the HIP library")
+    from cd_dynamax_amd import models
+    theta, mdl, P, t, y, u = l96_ut_problem()
+    mb = models._model_block(P)
+    unit = lambda srcs, tail: [s for s in srcs if s.endswith(tail)][0]
+
+    def opts_for(hyp):
+        opts = models._opts(hyp)
+        models._attach_inputs(mb, opts, u, y, np.float64)
+        return opts
+    hyp = cd.EKFHyperParams(state_order="first")
+    ref = o.ekf_filter(mdl, t, y, "first", inputs=u)
+    ddir, srcs = hs.dump_custom_source(mb.c.drift_kind, 8, M8, 0 + 256 * 2, 1)
+    fwd = hs.wg_run(os.path.join(ddir, unit(srcs, "_0.hip")), mb, opts_for(hyp), t, y, np.float64, "asan", kind=-1, inputs=u)
+    for k in FILTER_KEYS:
+        assert relerr(fwd[k], ref[k]) < 1e-12, k
+    refu = o.ukf_filter(mdl, t, y, inputs=u)
+    ddir, srcs = hs.dump_custom_source(mb.c.drift_kind, 8, M8, 1 + 256 * 2, 1)
+    outu = hs.wg_run(os.path.join(ddir, unit(srcs, "_0.hip")), mb, opts_for(cd.UKFHyperParams()), t, y, np.float64, "asan", ukf=True, kind=-1, inputs=u)
+    for k in FILTER_KEYS:
+        assert relerr(outu[k], refu[k]) < 1e-11, k
+    refs = o.ekf_smoother(mdl, t, y, "first", inputs=u, filtered=ref)
+    ddir, srcs = hs.dump_custom_source(mb.c.drift_kind, 8, M8, 2 + 256 * 2, 1)
+    outs = hs.wg_run(os.path.join(ddir, unit(srcs, "_1.hip")), mb, opts_for(hyp), t, y, np.float64, "asan", smoother=True, kind=-1, inputs=u,
+                     filtered=(ref["filtered_means"], ref["filtered_covariances"]))
+    assert relerr(outs["smoothed_means"], refs["smoothed_means"]) < 1e-12 and relerr(outs["smoothed_covariances"], refs["smoothed_covariances"]) < 1e-12
+    ll_a, g_a, ex = o.ekf_loglik_grad_adjoint(mdl, t, y, full=True, state_order="first", inputs=u)
+    ddir, srcs = hs.dump_custom_source(mb.c.drift_kind, 8, M8, 3 + 256 * 2, 1)
+    g, gm, st = hs.awg_run(os.path.join(ddir, unit(srcs, "_2.hip")), mb, opts_for(hyp), t, y, np.float64, "asan", fwd, inputs=u)
+    assert np.abs(g - g_a).max() < 1e-9 * np.abs(g_a).max() and not st.any()
+    assert np.abs(gm[:, :D8] - ex["m0"]).max() < 1e-9 * np.abs(ex["m0"]).max()
+
+
+@pytest.mark.gpu
+def test_workgroup_path_with_inputs_and_time(hip_lib):
+    """d = 12, m = 7 (the run-time compiled workgroup kernels; forward sweeps and the reverse sweep): EKF / UKF / smoother against the
+    oracle at 1e-9, every gradient leaf at 1e-8; a long-gap grid (several Runge-Kutta steps and replay chunks per interval) as well."""
+    for span, T in ((0.1, 10), (1.2, 8)):
+        theta, mdl, P, t, y, u = l96_ut_problem(N=5, T=T, span=span, seed=7, d=12, m=7)
+        ref = o.ekf_filter(mdl, t, y, "first", inputs=u)
+        post = cd.cdnlgssm_filter(P, y, t[..., None], cd.EKFHyperParams(state_order="first"), inputs=u)
+        for k in FILTER_KEYS:
+            assert relerr(getattr(post, k), ref[k]) < 1e-9, (span, k)
+        refu = o.ukf_filter(mdl, t, y, inputs=u)
+        postu = cd.cdnlgssm_filter(P, y, t[..., None], cd.UKFHyperParams(), inputs=u)
+        for k in FILTER_KEYS:
+            assert relerr(getattr(postu, k), refu[k]) < 1e-9, (span, k)
+        refs = o.ekf_smoother(mdl, t, y, "first", inputs=u, filtered=ref)
+        sm = cd.cdnlgssm_smoother(P, y, t[..., None], cd.EKFHyperParams(state_order="first"), inputs=u)
+        assert relerr(sm.smoothed_means, refs["smoothed_means"]) < 1e-9 and relerr(sm.smoothed_covariances, refs["smoothed_covariances"]) < 1e-9
+        ll_a, g_a, ex = o.ekf_loglik_grad_adjoint(mdl, t, y, full=True, state_order="first", inputs=u)
+        ll, g = cd.cdnlgssm_loglik_and_grad_all(P, y, t[..., None], cd.EKFHyperParams(state_order="first"), inputs=u)
+        np.testing.assert_allclose(ll, ll_a, rtol=1e-10)
+        assert np.abs(np.asarray(g.dynamics.drift.theta) - g_a).max() < 1e-8 * np.abs(g_a).max(), span
+        assert np.abs(np.asarray(g.initial.mean.params) - ex["m0"]).max() < 1e-8 * np.abs(ex["m0"]).max()
+        assert np.abs(np.asarray(g.emissions.emission_function.weights) - ex["H"]).max() < 1e-8 * np.abs(ex["H"]).max()
+
+
+@pytest.mark.gpu
+def test_small_model_reverse_sweep_with_inputs_and_time(hip_lib):
+    """The forced, controlled Lorenz-63 through cdnlgssm_loglik_and_grad_all (d = 3 goes to the reverse sweep of the workgroup kernels
+    for a drift given as source): every leaf against the oracle's reverse sweep."""
+    theta, mdl, t, y, u = problem(N=6, T=15, seed=9)
+    P = l63_ut_params(mdl, theta)
+    ll_a, g_a, ex = o.ekf_loglik_grad_adjoint(mdl, t, y, full=True, state_order="first", inputs=u)
+    ll, g = cd.cdnlgssm_loglik_and_grad_all(P, y, t[..., None], cd.EKFHyperParams(state_order="first"), inputs=u)
+    np.testing.assert_allclose(ll, ll_a, rtol=1e-10)
+    assert np.abs(np.asarray(g.dynamics.drift.theta) - g_a).max() < 1e-8 * np.abs(g_a).max()
+    assert np.abs(np.asarray(g.emissions.emission_cov.params) - ex["R"]).max() < 1e-8 * np.abs(ex["R"]).max()
