@@ -32,38 +32,74 @@ def _disassemble(obj, tmp):
     return subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", co], capture_output=True, text=True, check=True).stdout
 
 
+_BRANCH = re.compile(r"^s_(?:branch|cbranch_\w+)$")
+
+
+def _parse(text):
+    """[(function, [instruction])], an instruction = dict(op, ops, line, addr): addr from objdump's trailing `// ADDR: ENCODING` (None
+    in hand-written listings without one)."""
+    funcs, cur = [], None
+    for raw in text.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(.+)>:$", raw)
+        if m:
+            cur = []
+            funcs.append((m.group(1), cur))
+            continue
+        body, _, tail = raw.partition("//")
+        line = body.strip()
+        if not line or line.endswith(":") or cur is None:
+            continue
+        am = re.match(r"\s*([0-9A-Fa-f]{6,16}):", tail)
+        parts = line.split(None, 1)
+        ops = [t.strip() for t in (parts[1] if len(parts) > 1 else "").replace(" row_", ", row_").replace(" quad_", ", quad_").split(",")]
+        cur.append({"op": parts[0], "ops": ops, "line": line, "addr": int(am.group(1), 16) if am else None})
+    return funcs
+
+
 def _violations(text):
     """(function, instruction, producer) for every DPP source register written by a VALU fewer than two wait states earlier.  A
     virtual clock counts issue slots: one per instruction, N + 1 for `s_nop N`; between a producer issued at tp and a consumer at
-    tc lie tc - tp - 1 wait states."""
-    out, func, recent, clock, n_dpp = [], "?", [], 0, 0  # recent: (issue time, written VGPRs, text) of the latest VALU writers
-    for line in text.splitlines():
-        m = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
-        if m:
-            func, recent = m.group(1), []
-            continue
-        line = line.split("//")[0].strip()
-        if not line:
-            continue
-        if line.endswith(":"):  # a label: predecessors unknown (fall-through and branch targets are the recogniser's business)
-            recent = []
-            continue
-        parts = line.split(None, 1)
-        op, ops = parts[0], [t.strip() for t in (parts[1] if len(parts) > 1 else "").replace(" row_", ", row_").replace(" quad_", ", quad_").split(",")]
-        if op == "s_nop":
-            clock += int(ops[0], 0) + 1
-            continue
-        clock += 1
-        if op.endswith("_dpp"):
-            n_dpp += 1
-            src = _regs(ops[1]) if len(ops) > 1 else set()
-            for tp, written, txt in recent:
-                if written & src and clock - tp - 1 < 2:
-                    out.append((func, line, txt))
-        if op.startswith("v_") and not op.startswith(("v_cmp", "v_readlane", "v_readfirstlane", "v_accvgpr_write")):
-            written = _regs(ops[0]) if ops and ops[0] else set()
-            if written:
-                recent = [(tp, w, t) for tp, w, t in recent if clock - tp < 3] + [(clock, written, line)]
+    tc lie tc - tp - 1 wait states.  CONTROL FLOW (round 5): the producers still inside the window at the end of
+    every predecessor -- the fall-through AND each branch whose target the instruction is, loop back edges included (s_branch /
+    s_cbranch_* carry a dword offset relative to the next instruction) -- enter the window of the block they lead to, as if the
+    consumer issued right after the branch (a taken branch costs more than one slot; counting one is the conservative choice)."""
+    out, n_dpp = [], 0
+    for func, ins in _parse(text):
+        index_of = {i["addr"]: k for k, i in enumerate(ins) if i["addr"] is not None}
+        sources = {}   # target instruction index -> [branch instruction index]
+        for k, i in enumerate(ins):
+            if _BRANCH.match(i["op"]) and i["addr"] is not None and i["ops"] and re.fullmatch(r"\d+", i["ops"][0]):
+                off = int(i["ops"][0])
+                off = off - 65536 if off >= 32768 else off
+                tgt = index_of.get(i["addr"] + 4 + 4 * off)
+                if tgt is not None:
+                    sources.setdefault(tgt, []).append(k)
+        after = [None] * len(ins)   # window after instruction k: [(slots since the producer issued, written VGPRs, text)]
+        for sweep in range(3):      # (a window reaches two slots back: the second sweep sees every back edge's source, the third confirms)
+            found, dpp = [], 0
+            window = []             # producers with their age in slots at the point BEFORE the next instruction issues
+            for k, i in enumerate(ins):
+                for src in sources.get(k, []):
+                    if after[src] is not None:
+                        window = window + [w for w in after[src] if w not in window]
+                op, ops = i["op"], i["ops"]
+                cost = (int(ops[0], 0) + 1) if op == "s_nop" else 1
+                if op.endswith("_dpp"):
+                    dpp += 1
+                    src_regs = _regs(ops[1]) if len(ops) > 1 else set()
+                    for age, written, txt in window:
+                        if written & src_regs and age < 2:   # age = wait states between producer and this consumer
+                            found.append((func, i["line"], txt))
+                window = [(age + cost, w, t) for age, w, t in window if age + cost < 3]
+                if op.startswith("v_") and not op.startswith(("v_cmp", "v_readlane", "v_readfirstlane", "v_accvgpr_write")):
+                    written = _regs(ops[0]) if ops and ops[0] else set()
+                    if written:
+                        window.append((0, written, i["line"]))
+                after[k] = list(window)
+                if op in ("s_branch", "s_endpgm", "s_setpc_b64"):   # no fall-through
+                    window = []
+        out += found
+        n_dpp += dpp
     return out, n_dpp
 
 
@@ -97,3 +133,53 @@ def test_the_checker_flags_a_planted_hazard():
 """
     bad, n = _violations(text)
     assert n == 5 and len(bad) == 3 and "// 11" not in bad[2][1] and "// 3" not in bad[0][1] and bad[0][1].startswith("v_fmac_f64_dpp") and bad[1][1].startswith("v_mul_f32_dpp")
+
+
+def test_the_checker_follows_branches_and_back_edges():
+    """A producer in the last slot of a loop body and a DPP read in the first slot of the loop head (reached by the back edge only), a
+    forward branch over enough instructions, and a clean loop: the first two are reported, the third is not."""
+    text = """0000000000001000 <k>:
+\tv_mov_b32_e32 v1, v0                       // 000000001000: 7E020300
+\ts_nop 2                                    // 000000001004: BF800002
+\tv_mul_f32_dpp v23, v20, v24 row_ror:4 row_mask:0xf bank_mask:0xf // 000000001008: 0A2E30FA FF012414
+\tv_mov_b32_e32 v9, v8                       // 000000001010: 7E120308
+\tv_mul_f32_e32 v20, v21, v22                // 000000001014: 0A282D15
+\ts_cbranch_scc1 65531                       // 000000001018: BF85FFFB
+\tv_mul_f32_e32 v30, v21, v22                // 00000000101C: 0A3C2D15
+\ts_cbranch_vccz 2                           // 000000001020: BF860002
+\tv_mov_b32_e32 v2, v3                       // 000000001024: 7E040303
+\tv_mov_b32_e32 v4, v5                       // 000000001028: 7E080305
+\tv_mul_f32_dpp v23, v30, v24 row_ror:4 row_mask:0xf bank_mask:0xf // 00000000102C: 0A2E30FA FF01241E
+\tv_mul_f32_e32 v40, v21, v22                // 000000001034: 0A502D15
+\ts_nop 1                                    // 000000001038: BF800001
+\ts_cbranch_scc1 65533                       // 00000000103C: BF85FFFD
+\ts_endpgm                                   // 000000001040: BF810000
+"""
+    # back edge 0x1018 -> 0x1008: v20 written at 0x1014, one slot (the branch) before the DPP read at the loop head
+    # forward branch 0x1020 -> 0x102C: v30 written at 0x101C, the branch in between: one wait state
+    bad, n = _violations(text)
+    assert n == 2, n
+    assert len(bad) == 2 and bad[0][2].startswith("v_mul_f32_e32 v20") and bad[1][2].startswith("v_mul_f32_e32 v30"), bad
+
+
+def test_run_time_compiled_code_objects_obey_the_rule_too(tmp_path):
+    """The hipRTC code objects of the in-tree cache (cd_dynamax_amd/lib/rtc_cache/*.co: a 16-byte header, the lowered name, the code
+    object -- launch_custom.hip:rtc_cache_store): whatever DPP instruction the compiler put there is checked against the same rule
+    (their sources hold no hand-written DPP: the count may be zero).  A sample of the cache, newest first; skipped without one."""
+    import struct
+    files = sorted(glob.glob(os.path.join(ROOT, "cd_dynamax_amd", "lib", "rtc_cache", "*.co")), key=os.path.getmtime, reverse=True)[:12]
+    if not files or not os.path.exists(os.path.join(LLVM, "llvm-objdump")):
+        pytest.skip("no run-time compiled code objects in the tree (they are built on first use on a GPU box)")
+    checked = 0
+    for path in files:
+        raw = open(path, "rb").read()
+        magic, nname, lo, hi = struct.unpack("<4I", raw[:16])
+        if magic != 0x43524b43:
+            continue
+        co = tmp_path / "k.co"
+        co.write_bytes(raw[16 + nname:16 + nname + (hi << 32 | lo)])
+        text = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", str(co)], capture_output=True, text=True, check=True).stdout
+        bad, _ = _violations(text)
+        assert not bad, (os.path.basename(path), bad[:3])
+        checked += 1
+    assert checked > 0

@@ -41,7 +41,8 @@ def test_lorenz63_ekf_ukf_eks(hip_lib, dtype, m_obs):
         ref = o.ekf_filter(mdl, t, y, state_order=order)
         _check_filter(cd.cdnlgssm_filter(P, y.astype(dtype), t[..., None], cd.EKFHyperParams(state_order=order)), ref, tol)
     ref = o.ukf_filter(mdl, t, y)
-    _check_filter(cd.cdnlgssm_filter(P, y.astype(dtype), t[..., None], cd.UKFHyperParams()), ref, tol * 10)
+    # (fp64: the UKF's extra Cholesky per stage costs a digit; fp32: the north star's 1e-5 -- observed 3e-7 .. 1.2e-6)
+    _check_filter(cd.cdnlgssm_filter(P, y.astype(dtype), t[..., None], cd.UKFHyperParams()), ref, tol * 10 if dtype == np.float64 else 1e-5)
     ref = o.ekf_smoother(mdl, t, y)
     post = cd.cdnlgssm_smoother(P, y.astype(dtype), t[..., None])
     assert relerr(post.smoothed_means, ref["smoothed_means"]) < tol
@@ -82,9 +83,10 @@ def test_golden_vectors(hip_lib, name, dtype):
         for k in FILTER_KEYS:
             assert relerr(getattr(post, k)[:, ::s], g[f"ekf_{order}_{k}"]) < tol, (order, k)
     post = cd.cdnlgssm_filter(P, y, t, cd.UKFHyperParams(dt_final=dtf))
-    assert relerr(post.marginal_loglik, g["ukf_ll"]) < tol * 10
+    tol_u = tol * 10 if tol < 1e-6 else 1e-5   # (fp32: the north star's bar)
+    assert relerr(post.marginal_loglik, g["ukf_ll"]) < tol_u
     for k in FILTER_KEYS:
-        assert relerr(getattr(post, k)[:, ::s], g[f"ukf_{k}"]) < tol * 10, k
+        assert relerr(getattr(post, k)[:, ::s], g[f"ukf_{k}"]) < tol_u, k
     post = cd.cdnlgssm_smoother(P, y, t, cd.EKFHyperParams(dt_final=dtf))
     assert relerr(post.smoothed_means[:, ::s], g["eks_smoothed_means"]) < tol
     assert relerr(post.smoothed_covariances[:, ::s], g["eks_smoothed_covariances"]) < tol
