@@ -588,6 +588,7 @@ int cdkf_custom_emission_register(int state_dim, int emission_dim, const char* h
   return custom_emission_register(state_dim, emission_dim, h_src, hjac_src);
 }
 void cdkf_set_kernel_source_dir(const char* dir) { custom_set_source_dir(dir); }
+void cdkf_rtc_cache_stats(int64_t* hits, int64_t* misses) { custom_rtc_cache_stats(hits, misses); }
 int cdkf_debug_custom_reg_blob(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T, int algo, int bytes_per_real,
                                void* par_out, int64_t par_cap_bytes, int64_t* ip_out) {
   return custom_debug_reg_blob(mdl, opts, N, T, algo, bytes_per_real, par_out, par_cap_bytes, ip_out);

@@ -319,13 +319,15 @@ constexpr int kIoTimeoutMs = 600000;  // a peer that says nothing for ten minute
 // The hello a rank sends carries a per-job nonce: CDKF_RDV_NONCE from the environment (any 63-bit number the launcher hands to every
 // rank), else one derived from the rendezvous port and the world size -- so that a stray connection, or a rank of ANOTHER job whose
 // store happens to sit on the same port, is turned away with a NACK instead of taking a slot (and the run's sums with it).
-// The default also folds in whatever job identity the launcher exports to every rank alike (TORCHELASTIC_RUN_ID, SLURM_JOB_ID,
-// MASTER_ADDR -- FNV-1a over their text), so two jobs on the default port and the same world size no longer share a nonce unless
-// the launcher gives them nothing to tell them apart; CDKF_RDV_NONCE is then the way to isolate them.
+// The default also folds in the job identities a launcher exports IDENTICALLY to every rank (TORCHELASTIC_RUN_ID, SLURM_JOB_ID -- FNV-1a
+// over their text), so two jobs on the default port and the same world size do not share a nonce when the launcher tells them apart.
+// (Round 4 hashed MASTER_ADDR too: ranks that reach one master under different spellings -- 'localhost' on rank 0, an IP elsewhere --
+//  then computed different nonces and were turned away; ADVICE r4.  An identity only SOME ranks inherit still splits the job: the NACK
+//  names both nonces, and CDKF_RDV_NONCE is the override -- INTEGRATION.md.)
 int64_t rdv_nonce(int port, int world) {
   if (const char* e = std::getenv("CDKF_RDV_NONCE")) return (int64_t)std::strtoll(e, nullptr, 0);
   uint64_t h = 1469598103934665603ull;
-  for (const char* name : {"TORCHELASTIC_RUN_ID", "SLURM_JOB_ID", "MASTER_ADDR"})
+  for (const char* name : {"TORCHELASTIC_RUN_ID", "SLURM_JOB_ID"})
     if (const char* v = std::getenv(name)) {
       for (const char* c = v; *c; ++c) h = (h ^ (unsigned char)*c) * 1099511628211ull;
       h = (h ^ 0xffu) * 1099511628211ull;
@@ -428,7 +430,9 @@ extern "C" int cdkf_rdv_create(cdkf_rdv** out, const char* addr, int port, int r
     if (!send_all(fd, &hello, sizeof(hello)) || !recv_all(fd, &answer, sizeof(answer), (int)(left > 1000 ? left : 1000)) || answer != 1) {
       if (answer == 0)
         set_error("cdkf_rdv_create: rank 0 at %s:%d refused rank %d of %d (a duplicate rank, another world size, or another job's "
-                  "rendezvous: CDKF_RDV_NONCE / CDKF_RDV_PORT)", addr, port, rank, world);
+                  "rendezvous; this rank's job nonce is %lld -- it must equal rank 0's: derived from CDKF_RDV_NONCE, else from the port, "
+                  "the world size and TORCHELASTIC_RUN_ID / SLURM_JOB_ID as THIS rank sees them; set CDKF_RDV_NONCE / CDKF_RDV_PORT)",
+                  addr, port, rank, world, (long long)nonce);
       else
         set_error("cdkf_rdv_create: rank %d lost rank 0: %s", rank, std::strerror(errno));
       ::close(fd);

@@ -116,6 +116,7 @@ int launch_custom(int algo, const cdkf_model* mdl, const cdkf_opts* o, int64_t N
                   R* a1, R* a2, R* a3, R* a4, int32_t* status, hipStream_t stream);
 int custom_register(int state_dim, int n_theta, const char* f_src, const char* jac_src, const char* divgrad_src);
 int custom_compile_check(int kind, int bytes_per_real, int emission_dim, int algo, int state_order, int emission_kind);
+void custom_rtc_cache_stats(int64_t* hits, int64_t* misses);
 int custom_debug_reg_blob(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, int algo, int bytes_per_real, void* par_out,
                           int64_t par_cap_bytes, int64_t* ip_out);
 int custom_emission_register(int state_dim, int emission_dim, const char* h_src, const char* hjac_src);

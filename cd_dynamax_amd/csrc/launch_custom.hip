@@ -6,6 +6,7 @@
 // compiled on first use and cached for the life of the process.  Above six state or emission dimensions (up to what the workgroup
 // kernels' LDS plan holds, <= 64) the same source is compiled into the workgroup-per-trajectory sweeps of cdkf_wg2_kernels.h instead
 // (launch_custom_wg): Jacobian, grad(div f) and sigma-point evaluations spread over the workgroup's threads, all by dual numbers.
+#include <atomic>
 #include <dirent.h>
 #include <dlfcn.h>
 #include <hip/hiprtc.h>
@@ -108,13 +109,20 @@ bool rtc_cache_enabled() {
   return !(e && e[0] == '0');
 }
 
-// hash of every header under the kernel directory (once per process)
-const std::string& rtc_headers_digest() {
-  static std::string digest;
-  static std::once_flag once;
-  std::call_once(once, [] {
+// hash of every header under the kernel directory: computed once per directory (cdkf_set_kernel_source_dir may move it), the
+// directory's path part of it; a header that cannot be read yields an EMPTY digest = "do not use the cache" 
+std::string rtc_headers_digest() {
+  static std::mutex mu;
+  static std::map<std::string, std::string> by_dir;
+  const std::string dir = source_dir();
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = by_dir.find(dir);
+  if (it != by_dir.end()) return it->second;
+  std::string digest;
+  {
     Fnv128 h;
-    const std::string dir = source_dir();
+    bool unreadable = false;
+    h.feed(dir);
     std::vector<std::string> names;
     if (DIR* dp = opendir(dir.c_str())) {
       while (dirent* e = readdir(dp)) {
@@ -134,12 +142,15 @@ const std::string& rtc_headers_digest() {
         size_t n;
         while ((n = fread(buf, 1, sizeof(buf), f)) > 0) h.feed(buf, n);
         fclose(f);
+      } else {
+        unreadable = true;
       }
     }
     char out[40];
     snprintf(out, sizeof(out), "%016llx%016llx", (unsigned long long)h.a, (unsigned long long)h.b);
-    digest = out;
-  });
+    digest = (unreadable || names.empty()) ? std::string() : std::string(out);
+  }
+  by_dir[dir] = digest;
   return digest;
 }
 
@@ -150,6 +161,9 @@ std::string rtc_cache_dir() {
     auto usable = [](const std::string& d) {
       if (d.empty()) return false;
       (void)mkdir(d.c_str(), 0755);
+      struct stat sb;
+      // (what is stored there is loaded as GPU code: a directory others can write to is not a cache; FNV is a key, not a signature)
+      if (stat(d.c_str(), &sb) != 0 || !S_ISDIR(sb.st_mode) || (sb.st_mode & (S_IWGRP | S_IWOTH))) return false;
       return access(d.c_str(), W_OK | X_OK) == 0;
     };
     if (const char* e = getenv("CDKF_RTC_CACHE_DIR")) {
@@ -216,10 +230,11 @@ bool rtc_override_code(const std::string& tag, std::vector<char>& code) {
 
 std::string rtc_cache_key(const std::string& src, const std::string& arch, const char* olevel, const std::string& expr, const std::string& tag) {
   Fnv128 h;
-  int maj = 0, min = 0;
+  int maj = 0, min = 0, rtv = 0;
   (void)hiprtcVersion(&maj, &min);
-  const std::string meta = "cdkf-rtc-1|" + arch + "|" + olevel + "|hiprtc " + std::to_string(maj) + "." + std::to_string(min) + "|" +
-                           rtc_headers_digest() + "|" + expr;
+  (void)hipRuntimeGetVersion(&rtv);  // (major / minor / PATCH of the runtime the compiler ships with: a patch release may change code generation)
+  const std::string meta = "cdkf-rtc-2|" + arch + "|" + olevel + "|hiprtc " + std::to_string(maj) + "." + std::to_string(min) + " rt " +
+                           std::to_string(rtv) + " build " + std::to_string(HIP_VERSION_PATCH) + "|" + rtc_headers_digest() + "|" + expr;
   h.feed(meta);
   for (const std::string& x : rtc_extra_options(tag)) h.feed("|" + x);
   h.feed(src);
@@ -229,11 +244,17 @@ std::string rtc_cache_key(const std::string& src, const std::string& arch, const
 }
 
 constexpr uint32_t kRtcMagic = 0x43524b43;  // "CKRC"
+// how many variants this process took from the disk cache / had to compile (cdkf_rtc_cache_stats: the GPU suite checks the ratio, so
+// that a toolchain bump that invalidates the in-tree cache shows up as a message, not as a 2.4x longer run)
+std::atomic<long> g_rtc_hits{0}, g_rtc_misses{0};
 bool rtc_cache_load(const std::string& key, std::vector<char>& code, std::string& lowered) {
   const std::string dir = rtc_cache_dir();
-  if (dir.empty() || !rtc_cache_enabled()) return false;
+  if (dir.empty() || !rtc_cache_enabled() || rtc_headers_digest().empty()) return false;
   FILE* f = fopen((dir + "/" + key + ".co").c_str(), "rb");
-  if (!f) return false;
+  if (!f) {
+    ++g_rtc_misses;
+    return false;
+  }
   uint32_t head[4] = {0, 0, 0, 0};  // magic, name bytes, code bytes (low, high)
   bool ok = fread(head, sizeof(head), 1, f) == 1 && head[0] == kRtcMagic && head[1] < 4096;
   const uint64_t nbytes = ok ? ((uint64_t)head[3] << 32) | head[2] : 0;
@@ -245,18 +266,30 @@ bool rtc_cache_load(const std::string& key, std::vector<char>& code, std::string
   }
   fclose(f);
   if (!ok) code.clear();
+  ++(ok ? g_rtc_hits : g_rtc_misses);
   return ok;
 }
-void rtc_cache_store(const std::string& key, const std::vector<char>& code, const std::string& lowered) {
+void rtc_cache_store(const std::string& key, const std::vector<char>& code, const std::string& lowered, const std::string& what = std::string()) {
   const std::string dir = rtc_cache_dir();
-  if (dir.empty() || !rtc_cache_enabled() || code.empty()) return;
+  if (dir.empty() || !rtc_cache_enabled() || code.empty() || rtc_headers_digest().empty()) return;
   const std::string final_name = dir + "/" + key + ".co", tmp = final_name + ".tmp" + std::to_string((long)getpid());
   FILE* f = fopen(tmp.c_str(), "wb");
   if (!f) return;
   const uint32_t head[4] = {kRtcMagic, (uint32_t)lowered.size(), (uint32_t)(code.size() & 0xffffffffu), (uint32_t)((uint64_t)code.size() >> 32)};
   const bool ok = fwrite(head, sizeof(head), 1, f) == 1 && (lowered.empty() || fwrite(lowered.data(), lowered.size(), 1, f) == 1) &&
                   fwrite(code.data(), code.size(), 1, f) == 1;
-  if (fclose(f) != 0 || !ok || rename(tmp.c_str(), final_name.c_str()) != 0) (void)unlink(tmp.c_str());
+  if (fclose(f) != 0 || !ok || rename(tmp.c_str(), final_name.c_str()) != 0) {
+    (void)unlink(tmp.c_str());
+    return;
+  }
+  // MANIFEST: one line per stored code object -- key, toolchain, what it is (a text file that can be tracked where the objects are not)
+  if (FILE* m = fopen((dir + "/MANIFEST").c_str(), "a")) {
+    int maj = 0, min = 0, rtv = 0;
+    (void)hiprtcVersion(&maj, &min);
+    (void)hipRuntimeGetVersion(&rtv);
+    fprintf(m, "%s hiprtc %d.%d runtime %d %zu bytes %s\n", key.c_str(), maj, min, rtv, code.size(), what.c_str());
+    fclose(m);
+  }
 }
 
 // does the snippet name the identifier `w` (a whole word: `t` in "theta" or "tanh" does not count)?
@@ -511,7 +544,7 @@ int compile_variant(const CustomDrift& c, const Key& key, const std::string& arc
   code.resize(sz);
   hiprtcGetCode(prog, code.data());
   hiprtcDestroyProgram(&prog);
-  rtc_cache_store(cache_key, code, std::string());
+  rtc_cache_store(cache_key, code, std::string(), tag + " " + olevel);
   if (const char* dir = getenv("CDKF_CUSTOM_DUMP")) {  // debugging aid: the generated source and its code object
     const std::string base = std::string(dir) + "/cdkf_custom_reg_" + std::to_string(std::get<1>(key)) + "_m" + std::to_string(std::get<2>(key)) + "_" +
                              std::to_string(std::get<3>(key)) + "_" + std::to_string(std::get<4>(key)) + "_" + std::to_string(std::get<6>(key)) + "_" + cache_key.substr(0, 8);
@@ -847,7 +880,7 @@ int compile_wg_variant(const CustomDrift& c, const WgKey& key, const std::string
   code.resize(sz);
   hiprtcGetCode(prog, code.data());
   hiprtcDestroyProgram(&prog);
-  rtc_cache_store(cache_key, code, lowered);
+  rtc_cache_store(cache_key, code, lowered, expr + " " + olevel);
   if (const char* dir = getenv("CDKF_CUSTOM_DUMP")) {  // debugging aid: the generated source and its code object
     const std::string base = std::string(dir) + "/cdkf_custom_wg_" + std::to_string(bytes) + "_" + std::to_string(ept) + "_" + std::to_string(ukf) +
                              "_" + std::to_string(smoother);
@@ -1297,6 +1330,11 @@ int custom_debug_reg_blob(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, 
   for (int k = 0; k < 26; ++k) ip_out[k] = ip[k];
   ip_out[26] = blocks;
   return (int)n;
+}
+
+void custom_rtc_cache_stats(int64_t* hits, int64_t* misses) {
+  if (hits) *hits = g_rtc_hits.load();
+  if (misses) *misses = g_rtc_misses.load();
 }
 
 void custom_set_source_dir(const char* dir) {

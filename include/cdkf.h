@@ -324,6 +324,10 @@ int cdkf_custom_drift_compile(int drift_kind, int bytes_per_real, int emission_d
 /* directory holding the kernel headers (cdkf_reg_kernels.h ...) for run-time compilation; default: <dir of this
  * library>/../csrc */
 void cdkf_set_kernel_source_dir(const char* dir);
+/* how many run-time compiled variants THIS process loaded from the on-disk code-object cache (<library dir>/rtc_cache, else
+ * $CDKF_RTC_CACHE_DIR / ~/.cache/cdkf_rtc; key = source + options + target + hipRTC and runtime versions + the kernel headers) and how
+ * many it had to compile.  The cache directory's MANIFEST lists what each stored object is. */
+void cdkf_rtc_cache_stats(int64_t* hits, int64_t* misses);
 
 /* ---- diagnostics: the argument blocks a launch would hand its kernel, built WITHOUT touching the GPU -- for the CPU-sanitizer
  *      builds of the same device templates (cd_dynamax_amd/csrc/hostsim/, tests/test_hostsim.py: the kernels of this library compiled
