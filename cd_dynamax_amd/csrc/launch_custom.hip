@@ -186,6 +186,35 @@ std::string rtc_cache_dir() {
   return dir;
 }
 
+// ---- how the run-time compiled kernels are optimised (round 5: the root cause behind rounds 3 / 4's "-O1 fences") -------------------------
+// ROCm 7.2's compiler (AMD clang 22.0.0git, roc-7.2.0 26014) miscompiles spill-heavy DOUBLE-PRECISION kernels at -O2 / -O3 when the
+// greedy register allocator tracks SUB-REGISTER LIVENESS of the 64-bit VGPR pairs: a gradient that comes back zero (forward-sensitivity
+// sweep, d = 2: 512 registers, 962 spilled, 2.2 KB of scratch), moments 3 % off (unscented workgroup kernel, d = 15), NaN (eight-entries-
+// per-thread workgroup kernels, d = 46).  Established on the GPU (scripts/r5_o3_probe.py, scripts/r5_mir_delta.py, NOTES.md R5.1):
+//   * pass bisection of both run-time compiled cases stops at the pre-RA si-shrink-instructions run, whose rewrites (commuted compares,
+//     VOP3 -> VOP2) only perturb the allocation: applied to the machine IR one kind at a time, no single kind is needed and "any
+//     sufficiently large set" flips the result;
+//   * of fourteen single switches, exactly these turn every wrong build right: -mllvm -enable-subreg-liveness=0, and the basic instead
+//     of the greedy allocator (-vgpr-regalloc=basic); spill placement, stack colouring / slot sharing, AGPR and SGPR spill targets,
+//     hint splitting, DCE inside the allocator, the machine scheduler, forced wait counts change nothing;
+//   * the same sources are clean under ASan / UBSan / MSan / TSan in the host build (tests/test_hostsim.py) and agree with the oracle
+//     there at -O1 and -O3.
+// So every run-time compiled kernel is built at -O3 WITH sub-register liveness off (the allocator then treats a 64-bit pair as one unit:
+// a little more register pressure, never a half that is "dead" and is not).  CDKF_RTC_POLICY = "o1" brings the round-4 fence back,
+// "o3" the plain -O3 that is wrong (the canary of tests/test_gpu_toolchain.py: when a ROCm release passes it, this block can go).
+struct RtcPolicy {
+  const char* olevel;
+  const char* extra1;  // "-mllvm" or null
+  const char* extra2;
+};
+RtcPolicy rtc_policy() {
+  const char* e = getenv("CDKF_RTC_POLICY");
+  const std::string p = e ? e : "";
+  if (p == "o1") return {"-O1", nullptr, nullptr};
+  if (p == "o3") return {"-O3", nullptr, nullptr};
+  return {"-O3", "-mllvm", "-enable-subreg-liveness=0"};
+}
+
 // Compiler options every run-time compilation gets beside its optimisation level (part of the cache key).  CDKF_RTC_EXTRA_OPTS
 // (space-separated; a debugging aid) adds to them -- to every variant, or with CDKF_RTC_EXTRA_OPTS_ONLY=<text> to the variants whose tag
 // contains <text> (tag: the kernel's name expression for the workgroup variants, "reg ukf=<0|1> algo=<0 filter|1 smoother|2 gradient>"
@@ -495,18 +524,12 @@ int compile_variant(const CustomDrift& c, const Key& key, const std::string& arc
   }
   const std::string src = generate_source(c, std::get<1>(key), std::get<2>(key), std::get<3>(key), std::get<4>(key),
                                           std::get<5>(key), std::get<6>(key), std::get<7>(key), ek ? &em : nullptr, std::get<9>(key));
-  // The forward-sensitivity sweep (algorithm 2) is built at -O1: from four state dimensions on the kernel sits at all 512 registers
-  // plus 0.6 - 2.6 KB of scratch per lane, and at -O2 / -O3 (ROCm 7.2 hipRTC, gfx950) some builds of the d = 6 instantiation return a wrong
-  // d ll / d theta -- deterministic per build, flipping with spellings of the drift that generate the same arithmetic (`pow(x, 2)` against
-  // `pow(x, 2.0)` against `x * x`), no calls in the code object, not the VGPR-to-AGPR spilling (-amdgpu-spill-vgpr-to-agpr=0: the same
-  // numbers); -O1 is right in every case tried (scripts/dbg_custom_pow.py, NOTES.md R4.7; found by scripts/gpu_fuzz_custom.py seed 40404).
-  // The same family as launch_wg8.hip's -O1 and the lost accumulator of DESIGN.md section 5.1 (ii): large spill-heavy kernels.
-  // (and below four dimensions too: after cdkf_dual.h changed the way a^2 is formed, the d = 2 instantiation of
-  //  tests/test_custom_drift.py::test_custom_drift_derivatives_by_dual_numbers returned a zero column at -O3 and the right one at -O1)
-  const char* olevel = (std::get<6>(key) == 2) ? "-O1" : "-O3";
+  // (rounds 3 / 4 built the forward-sensitivity sweep at -O1 after wrong gradients at -O2 / -O3: see rtc_policy above for the cause)
+  const RtcPolicy pol = rtc_policy();
+  const char* olevel = pol.olevel;
   const std::string tag = "reg ukf=" + std::to_string(std::get<3>(key)) + " algo=" + std::to_string(std::get<6>(key));
   if (rtc_override_code(tag, code)) return CDKF_OK;
-  const std::string cache_key = rtc_cache_key(src, arch, olevel, "cdkf_custom_kernel", tag);
+  const std::string cache_key = rtc_cache_key(src, arch, (std::string(olevel) + (pol.extra2 ? pol.extra2 : "")).c_str(), "cdkf_custom_kernel", tag);
   {
     std::string unused;
     if (!getenv("CDKF_CUSTOM_DUMP") && rtc_cache_load(cache_key, code, unused)) return CDKF_OK;
@@ -519,6 +542,10 @@ int compile_variant(const CustomDrift& c, const Key& key, const std::string& arc
   const std::string inc = "-I" + source_dir(), off = "--offload-arch=" + arch;
   const std::vector<std::string> extra = rtc_extra_options(tag);
   std::vector<const char*> opts = {off.c_str(), olevel, "-std=c++17", inc.c_str(), "-Wno-pass-failed"};
+  if (pol.extra1) {
+    opts.push_back(pol.extra1);
+    opts.push_back(pol.extra2);
+  }
   for (const std::string& x : extra) opts.push_back(x.c_str());
   const hiprtcResult res = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
   if (res != HIPRTC_SUCCESS) {
@@ -823,16 +850,10 @@ int compile_wg_variant(const CustomDrift& c, const WgKey& key, const std::string
   const std::string src = smoother == 2 ? generate_awg_source(c, (size_t)std::get<5>(key), std::get<6>(key))
                                         : generate_wg_source(c, (size_t)std::get<5>(key), std::get<6>(key));
   const std::string expr = wg_kernel_expr(bytes, ept, ukf, smoother);
-  // -O1: the instantiations with eight or more entries per thread, as in the library (launch_wg8.hip) -- and every unscented variant: at
-  // -O3 the generic sigma-point path of a d = 15 source drift with `pow(x, 2)` in it (256 + 128 registers, 1.7 KB of scratch, 45 calls of
-  // device functions in the code object) filtered 3 % off the oracle, deterministically, and to 1e-15 with `x * x` in the source or at
-  // -O1 (scripts/gpu_fuzz_custom.py seed 62626 case 11; the round-3 library does the same: NOTES.md R4.7)
-  // ... and, after two such finds in one evening of fresh fuzz seeds, every run-time compiled workgroup variant: they are all of this
-  // kind (hundreds of KB of code, calls of device functions, scratch), -O1 has no wrong result on record in any of them, and a user's
-  // drift is not where 15 - 25 % of speed are worth a wrong filter.  CDKF_RTC_WG_O3=1 brings the -O3 builds back (A/B).
-  const bool o3 = env_flag("CDKF_RTC_WG_O3") && !((ept >= 8 && smoother != 2) || ukf);
-  const char* olevel = o3 ? "-O3" : "-O1";
-  const std::string cache_key = rtc_cache_key(src, arch, olevel, expr, expr);
+  // (round 4 built every workgroup variant at -O1 after the unscented d = 15 kernel came out 3 % off at -O3: see rtc_policy for the cause)
+  const RtcPolicy pol = rtc_policy();
+  const char* olevel = pol.olevel;
+  const std::string cache_key = rtc_cache_key(src, arch, (std::string(olevel) + (pol.extra2 ? pol.extra2 : "")).c_str(), expr, expr);
   if (!getenv("CDKF_CUSTOM_DUMP") && rtc_cache_load(cache_key, code, lowered) && !lowered.empty()) return CDKF_OK;
   hiprtcProgram prog = nullptr;
   if (hiprtcCreateProgram(&prog, src.c_str(), "cdkf_custom_drift_wg.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
@@ -849,6 +870,10 @@ int compile_wg_variant(const CustomDrift& c, const WgKey& key, const std::string
   // -O1: the wg kernels' instantiations with eight or more entries per thread, as in the library (launch_wg8.hip, Makefile)
   const std::vector<std::string> extra = rtc_extra_options(expr);
   std::vector<const char*> opts = {off.c_str(), olevel, "-std=c++17", inc.c_str(), "-Wno-pass-failed"};
+  if (pol.extra1) {
+    opts.push_back(pol.extra1);
+    opts.push_back(pol.extra2);
+  }
   for (const std::string& x : extra) opts.push_back(x.c_str());
   const hiprtcResult res = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
   if (res != HIPRTC_SUCCESS) {
