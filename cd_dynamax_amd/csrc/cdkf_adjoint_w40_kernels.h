@@ -584,8 +584,18 @@ CDKF_DEV void w40a_sweep(const WgArgs<R>& a, R* __restrict__ grad, R* __restrict
 #ifdef CDKF_W40A_PROFILE
   long long w40a_last = clock64();
 #endif
+  // The model block's two matrix leaves accumulate in REGISTERS over the sweep (round 5): dR = sum_k Sbar_k and dH = sum_k (2 Sbar (E P) -
+  // vbar m^T + Ub P)_k are formed as accumulator tiles anyway, and the 102 accumulator registers this kernel leaves unused hold the
+  // running sums of the tiles a wavefront owns (3 symmetric + 5 general tiles x 4 values) -- until round 4 every step read-modify-wrote
+  // both matrices in global memory: 2 x (m^2 + m d) reals per trajectory-step, 52 KB at d = m = 40 in fp64, a third of the sweep's HBM
+  // traffic (profiles/r04_o_config4_value_and_grad_2048x500_counters.json: 168 KB per trajectory-step against 26 KB algorithmic).
+  V4 totS[NT], totH[NT];
+  R totB = R(0);
+  if (gm) {
+    tilesS_zero(totS);
+    tiles_zero(totH);
+  }
   for (long k = a.T - 1; k >= 0; --k) {
-    const bool first = (k == a.T - 1);
     if constexpr (NW != 1) sync();  // (the other wavefront may still be reading the step's cotangent sums, which the images below overwrite)
     fresh();
     W40A_TICK(0)
@@ -806,11 +816,13 @@ CDKF_DEV void w40a_sweep(const WgArgs<R>& a, R* __restrict__ grad, R* __restrict
     w40a_mmp<R, D, true, false, 2, NW, H, true>(accS, rows_of(I1, false).p, rows_of(I2, false).p, blast_ok, obsmask, lg);
     w40a_mmp<R, D, true, false, 2, NW, H, true>(accS, rows_of(I2, false).p, rows_of(I1, false).p, blast_ok, obsmask, lg);
     // model block: dR += Sbar (the observed pairs)
-    if (gm)
-      tilesS_accumulate(gR, accS, first, [&](int row, int col) {
-        const int orow = obs[row], ocol = obs[col];
-        return (orow >= 0 && ocol >= 0) ? orow * M + ocol : -1;
-      });
+    if (gm) {
+#pragma unroll
+      for (int mt = 0; mt < NB; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NB; ++nt)
+          if (mineS(mt, nt)) totS[mt * NB + nt] += accS[mt * NB + nt];
+    }
     tilesS_store(I3, accS);  // Sbar (Kb is dead: Ub was formed behind a synchronisation)
     sync();
     W40A_TICK(9)  // X Ub^T, Ub X^T, dR
@@ -830,11 +842,10 @@ CDKF_DEV void w40a_sweep(const WgArgs<R>& a, R* __restrict__ grad, R* __restrict
               accH[mt * NB + nt][r] = rfma(-v_vb[row], v_m[col], accH[mt * NB + nt][r]);
             }
           }
-      tiles_accumulate(gH, accH, first, [&](int row, int col) {
-        const int orow = obs[row];
-        return orow >= 0 ? orow * D + col : -1;
-      });
-      if (LEAD && myobs >= 0) gBias[myobs] = first ? -vb : gBias[myobs] - vb;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+        if (mine(t)) totH[t] += accH[t];
+      if (LEAD && myobs >= 0) totB -= vb;
     }
     fresh();
     // Pbar <- Pbar + sym(Ub^T H) + H^T Sbar H;  mbar <- mbar - H^T vbar
@@ -1118,6 +1129,15 @@ CDKF_DEV void w40a_sweep(const WgArgs<R>& a, R* __restrict__ grad, R* __restrict
   fresh();
   // ---- results --------------------------------------------------------------------------------------------------------------------
   if (gm) {
+    tilesS_accumulate(gR, totS, true, [&](int row, int col) {  // (written once: `first_` = plain stores)
+      const int orow = obs[row], ocol = obs[col];
+      return (orow >= 0 && ocol >= 0) ? orow * M + ocol : -1;
+    });
+    tiles_accumulate(gH, totH, true, [&](int row, int col) {
+      const int orow = obs[row];
+      return orow >= 0 ? orow * D + col : -1;
+    });
+    if (LEAD && myobs >= 0) gBias[myobs] = totB;
     if (LEAD && isrow) gm[lane] = mb;
 #pragma unroll
     for (int s = 0; s < EPL; ++s)

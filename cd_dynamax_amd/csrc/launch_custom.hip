@@ -207,12 +207,16 @@ struct RtcPolicy {
   const char* extra1;  // "-mllvm" or null
   const char* extra2;
 };
-RtcPolicy rtc_policy() {
+RtcPolicy rtc_policy(bool workgroup) {
   const char* e = getenv("CDKF_RTC_POLICY");
   const std::string p = e ? e : "";
   if (p == "o1") return {"-O1", nullptr, nullptr};
   if (p == "o3") return {"-O3", nullptr, nullptr};
-  return {"-O3", "-mllvm", "-enable-subreg-liveness=0"};
+  if (p == "o3basic") return {"-O3", "-mllvm", "-vgpr-regalloc=basic"};
+  if (p == "o1basic") return {"-O1", "-mllvm", "-vgpr-regalloc=basic"};
+  if (p == "o3subreg") return {"-O3", "-mllvm", "-enable-subreg-liveness=0"};
+  if (workgroup) return {"-O1", "-mllvm", "-vgpr-regalloc=basic"};
+  return {"-O3", "-mllvm", "-vgpr-regalloc=basic"};
 }
 
 // Compiler options every run-time compilation gets beside its optimisation level (part of the cache key).  CDKF_RTC_EXTRA_OPTS
@@ -525,7 +529,7 @@ int compile_variant(const CustomDrift& c, const Key& key, const std::string& arc
   const std::string src = generate_source(c, std::get<1>(key), std::get<2>(key), std::get<3>(key), std::get<4>(key),
                                           std::get<5>(key), std::get<6>(key), std::get<7>(key), ek ? &em : nullptr, std::get<9>(key));
   // (rounds 3 / 4 built the forward-sensitivity sweep at -O1 after wrong gradients at -O2 / -O3: see rtc_policy above for the cause)
-  const RtcPolicy pol = rtc_policy();
+  const RtcPolicy pol = rtc_policy(false);
   const char* olevel = pol.olevel;
   const std::string tag = "reg ukf=" + std::to_string(std::get<3>(key)) + " algo=" + std::to_string(std::get<6>(key));
   if (rtc_override_code(tag, code)) return CDKF_OK;
@@ -851,7 +855,7 @@ int compile_wg_variant(const CustomDrift& c, const WgKey& key, const std::string
                                         : generate_wg_source(c, (size_t)std::get<5>(key), std::get<6>(key));
   const std::string expr = wg_kernel_expr(bytes, ept, ukf, smoother);
   // (round 4 built every workgroup variant at -O1 after the unscented d = 15 kernel came out 3 % off at -O3: see rtc_policy for the cause)
-  const RtcPolicy pol = rtc_policy();
+  const RtcPolicy pol = rtc_policy(true);
   const char* olevel = pol.olevel;
   const std::string cache_key = rtc_cache_key(src, arch, (std::string(olevel) + (pol.extra2 ? pol.extra2 : "")).c_str(), expr, expr);
   if (!getenv("CDKF_CUSTOM_DUMP") && rtc_cache_load(cache_key, code, lowered) && !lowered.empty()) return CDKF_OK;

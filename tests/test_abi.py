@@ -154,9 +154,9 @@ def test_integration_md_structs_have_the_library_layout():
 def test_toolchain_workarounds_cannot_be_switched_off_from_the_command_line():
     """launch_wg8.hip (the fp64 eight-entries-per-thread workgroup kernels) returns NaN at plain -O2 / -O3 on ROCm 7.2 / gfx950: the
     greedy register allocator's sub-register liveness tracking of 64-bit VGPR pairs in spill-heavy kernels (round 5: launch_custom.hip
-    rtc_policy, NOTES.md R5.1; rounds 3 / 4 fenced it with -O1).  The Makefile's target-specific `override` must keep
-    `-mllvm -enable-subreg-liveness=0` on that object's command line whatever CXXFLAGS a caller passes, and leave every other object
-    as the caller asked; the run-time compiled kernels get the same switch (CDKF_RTC_POLICY unset)."""
+    rtc_policy, NOTES.md R5.1; rounds 3 / 4 fenced it with -O1).  The Makefile's target-specific `override` must keep the safe build
+    of that object (SUBREG_SAFE) on its command line whatever CXXFLAGS a caller passes, and leave every other object as the caller asked;
+    the run-time compiled kernels are built at -O3 with sub-register liveness off (CDKF_RTC_POLICY unset)."""
     import os
     import subprocess
     csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cd_dynamax_amd", "csrc")
@@ -167,7 +167,10 @@ def test_toolchain_workarounds_cannot_be_switched_off_from_the_command_line():
     wg8 = [c for c in cmds if "launch_wg8.hip" in c]
     w8 = [c for c in cmds if "launch_w8.hip" in c]
     assert len(wg8) == 1 and len(w8) == 1, out
-    assert "-enable-subreg-liveness=0" in wg8[0].split() and "-O3" in wg8[0].split(), wg8[0]
-    assert "-enable-subreg-liveness=0" not in w8[0].split() and "-O3" in w8[0].split(), w8[0]
+    levels = [tok for tok in wg8[0].split() if tok in ("-O0", "-O1", "-O2", "-O3", "-Os", "-Ofast")]
+    # (the offline compiler itself crashes on this translation unit with sub-register liveness off -- a segmentation fault in the greedy
+    #  allocator's spill weights, wg_cholesky2<float> -- so the library's object keeps -O1 or takes the basic allocator, never plain -O3)
+    assert (levels and levels[-1] == "-O1") or "-vgpr-regalloc=basic" in wg8[0].split(), wg8[0]
+    assert "-O1" not in w8[0].split() and "-vgpr-regalloc=basic" not in w8[0].split() and "-O3" in w8[0].split(), w8[0]
     src = open(os.path.join(csrc, "launch_custom.hip")).read()
     assert 'return {"-O3", "-mllvm", "-enable-subreg-liveness=0"};' in src   # the default policy of the run-time compiled kernels

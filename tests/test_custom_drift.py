@@ -699,7 +699,8 @@ def test_rtc_code_objects_are_cached_on_disk(tmp_path):
         return float(p.stdout.split("SECONDS")[1])
 
     cold = run()
-    entries = sorted(os.listdir(cache))
+    assert "MANIFEST" in os.listdir(cache) and len(open(cache / "MANIFEST").read().splitlines()) == 2   # (round 5: what each object is)
+    entries = sorted(e for e in os.listdir(cache) if e != "MANIFEST")
     assert len(entries) == 2 and all(e.endswith(".co") for e in entries), entries
     blobs = [open(cache / e, "rb").read() for e in entries]
     warm = run()
@@ -709,9 +710,12 @@ def test_rtc_code_objects_are_cached_on_disk(tmp_path):
         f.write(b"XXXX")
     run()
     assert open(cache / entries[0], "rb").read() == blobs[0]                  # recompiled over, bit-identical code object
-    for e in entries:
+    for e in entries + ["MANIFEST"]:
         os.remove(cache / e)
     run(CDKF_RTC_CACHE="0")
+    assert os.listdir(cache) == []
+    os.chmod(cache, 0o777)                                                    # a directory others may write to is not a cache
+    run()
     assert os.listdir(cache) == []
 
 

@@ -148,7 +148,8 @@ def test_oracle_reverse_sweep_with_inputs_and_time_matches_finite_differences():
 def test_register_kernels_with_inputs_and_time_on_the_host():
     """The run-time compiled register kernels (EKF, UKF, smoother's two passes, forward-sensitivity gradient) with the forced,
     controlled Lorenz-63 source, compiled for the host and run under ASan + UBSan on the launcher's own argument blocks: 1e-12 of the
-    oracle (the gradient: 1e-8 of Richardson finite differences of the oracle's log-likelihood)."""
+    oracle (the gradient: 1e-8 of Richardson finite differences of the oracle's log-likelihood).  (The EKF leg under the sanitizers, the
+    others as plain host builds: same templates, a third of the compile time.)"""
     import hostsim_util as hs
     import shutil
     if hs.clang() is None or shutil.which("hipcc") is None:
@@ -159,16 +160,16 @@ def test_register_kernels_with_inputs_and_time_on_the_host():
     mb = models._model_block(l63_ut_params(mdl, theta))
     TN = lambda a, shape: np.swapaxes(a.reshape((T, N) + shape), 0, 1)
 
-    def run(algo, hyp, outs, layout=_ffi.LAYOUT_TN, which=0, preload=None):
+    def run(algo, hyp, outs, layout=_ffi.LAYOUT_TN, which=0, preload=None, san="plain"):
         opts = models._opts(hyp)
         opts.layout, opts.layout_in, opts.t_shared = layout, _ffi.LAYOUT_NT, 0
         models._attach_inputs(mb, opts, u, y, np.float64)
         ddir, srcs = hs.dump_custom_source(mb.c.drift_kind, 8, m, algo + 256 * 2, 1)
-        return hs.reg_run(os.path.join(ddir, srcs[which]), mb, opts, t, y, algo, np.float64, "asan", outs, inputs=u, preload=preload)
+        return hs.reg_run(os.path.join(ddir, srcs[which]), mb, opts, t, y, algo, np.float64, san, outs, inputs=u, preload=preload)
     full = (N, N * T * d, N * T * d * d, N * T * d, N * T * d * d, N, 0, 0)
     for algo, hyp, ref in ((0, cd.EKFHyperParams(state_order="first"), o.ekf_filter(mdl, t, y, "first", inputs=u)),
                            (1, cd.UKFHyperParams(), o.ukf_filter(mdl, t, y, inputs=u))):
-        ll, fm, fP, pm, pP, *_ = run(algo, hyp, full)
+        ll, fm, fP, pm, pP, *_ = run(algo, hyp, full, san="asan" if algo == 0 else "plain")   # (one sanitizer build: they take 3 x as long)
         got = dict(marginal_loglik=ll, filtered_means=TN(fm, (d,)), filtered_covariances=TN(fP, (d, d)), predicted_means=TN(pm, (d,)),
                    predicted_covariances=TN(pP, (d, d)))
         for k in FILTER_KEYS:
@@ -318,8 +319,9 @@ def l96_ut_problem(N=2, T=6, span=0.1, seed=1, d=D8, m=M8):
 
 
 def test_workgroup_kernels_and_reverse_sweep_with_inputs_and_time_on_the_host():
-    """d = 8 on the run-time compiled workgroup kernels, host build under ASan + UBSan: EKF, UKF, the smoother's backward sweep and
-    the reverse sweep of the gradient (every leaf), each reading the interval's inputs row and the stage times (t1 - s backwards)."""
+    """d = 8 on the run-time compiled workgroup kernels, host build (the filter and the reverse sweep under ASan + UBSan): EKF, UKF, the
+    smoother's backward sweep and the reverse sweep of the gradient (every leaf), each reading the interval's inputs row and the stage
+    times (t1 - s backwards)."""
     import hostsim_util as hs
     import shutil
     if hs.clang() is None or shutil.which("hipcc") is None:
@@ -341,12 +343,12 @@ def test_workgroup_kernels_and_reverse_sweep_with_inputs_and_time_on_the_host():
         assert relerr(fwd[k], ref[k]) < 1e-12, k
     refu = o.ukf_filter(mdl, t, y, inputs=u)
     ddir, srcs = hs.dump_custom_source(mb.c.drift_kind, 8, M8, 1 + 256 * 2, 1)
-    outu = hs.wg_run(os.path.join(ddir, unit(srcs, "_0.hip")), mb, opts_for(cd.UKFHyperParams()), t, y, np.float64, "asan", ukf=True, kind=-1, inputs=u)
+    outu = hs.wg_run(os.path.join(ddir, unit(srcs, "_0.hip")), mb, opts_for(cd.UKFHyperParams()), t, y, np.float64, "plain", ukf=True, kind=-1, inputs=u)
     for k in FILTER_KEYS:
         assert relerr(outu[k], refu[k]) < 1e-11, k
     refs = o.ekf_smoother(mdl, t, y, "first", inputs=u, filtered=ref)
     ddir, srcs = hs.dump_custom_source(mb.c.drift_kind, 8, M8, 2 + 256 * 2, 1)
-    outs = hs.wg_run(os.path.join(ddir, unit(srcs, "_1.hip")), mb, opts_for(hyp), t, y, np.float64, "asan", smoother=True, kind=-1, inputs=u,
+    outs = hs.wg_run(os.path.join(ddir, unit(srcs, "_1.hip")), mb, opts_for(hyp), t, y, np.float64, "plain", smoother=True, kind=-1, inputs=u,
                      filtered=(ref["filtered_means"], ref["filtered_covariances"]))
     assert relerr(outs["smoothed_means"], refs["smoothed_means"]) < 1e-12 and relerr(outs["smoothed_covariances"], refs["smoothed_covariances"]) < 1e-12
     ll_a, g_a, ex = o.ekf_loglik_grad_adjoint(mdl, t, y, full=True, state_order="first", inputs=u)
