@@ -186,22 +186,24 @@ std::string rtc_cache_dir() {
   return dir;
 }
 
-// ---- how the run-time compiled kernels are optimised (round 5: the root cause behind rounds 3 / 4's "-O1 fences") -------------------------
-// ROCm 7.2's compiler (AMD clang 22.0.0git, roc-7.2.0 26014) miscompiles spill-heavy DOUBLE-PRECISION kernels at -O2 / -O3 when the
-// greedy register allocator tracks SUB-REGISTER LIVENESS of the 64-bit VGPR pairs: a gradient that comes back zero (forward-sensitivity
-// sweep, d = 2: 512 registers, 962 spilled, 2.2 KB of scratch), moments 3 % off (unscented workgroup kernel, d = 15), NaN (eight-entries-
-// per-thread workgroup kernels, d = 46).  Established on the GPU (scripts/r5_o3_probe.py, scripts/r5_mir_delta.py, NOTES.md R5.1):
-//   * pass bisection of both run-time compiled cases stops at the pre-RA si-shrink-instructions run, whose rewrites (commuted compares,
-//     VOP3 -> VOP2) only perturb the allocation: applied to the machine IR one kind at a time, no single kind is needed and "any
-//     sufficiently large set" flips the result;
-//   * of fourteen single switches, exactly these turn every wrong build right: -mllvm -enable-subreg-liveness=0, and the basic instead
-//     of the greedy allocator (-vgpr-regalloc=basic); spill placement, stack colouring / slot sharing, AGPR and SGPR spill targets,
-//     hint splitting, DCE inside the allocator, the machine scheduler, forced wait counts change nothing;
+// ---- how the run-time compiled kernels are optimised (round 5: what is behind rounds 3 / 4's "-O1 fences"; NOTES.md R5.1) -----------------
+// ROCm 7.2's compiler (AMD clang 22.0.0git, roc-7.2.0 26014) miscompiles spill-heavy DOUBLE-PRECISION kernels at -O2 / -O3: a gradient
+// that is never stored (forward-sensitivity sweep, d = 2: all 512 registers, 962 spilled, 2.2 KB of scratch per lane), moments 3 % off
+// (unscented workgroup kernel, d = 15), NaN (eight-entries-per-thread workgroup kernels, d = 46).  Established on the GPU
+// (scripts/r5_o3_probe.py, scripts/r5_mir_delta.py):
+//   * pass bisection stops at the pre-RA si-shrink-instructions run in every case, but its rewrites only perturb the register allocation
+//     that follows: applied to the machine IR one kind at a time none is needed, and no small subset of the 5 760 changed lines flips it;
+//   * of some twenty single switches exactly one turns every wrong build right without breaking a right one: the BASIC instead of the
+//     greedy allocator for the vector registers (-mllvm -vgpr-regalloc=basic).  Spill placement and targets (AGPR, SGPR -> VGPR lanes),
+//     stack colouring / slot sharing, hint splitting, DCE inside the allocator, the machine scheduler, forced wait counts, a 256-register
+//     budget change nothing; -enable-subreg-liveness=0 repairs two kernels and breaks a third;
 //   * the same sources are clean under ASan / UBSan / MSan / TSan in the host build (tests/test_hostsim.py) and agree with the oracle
-//     there at -O1 and -O3.
-// So every run-time compiled kernel is built at -O3 WITH sub-register liveness off (the allocator then treats a 64-bit pair as one unit:
-// a little more register pressure, never a half that is "dead" and is not).  CDKF_RTC_POLICY = "o1" brings the round-4 fence back,
-// "o3" the plain -O3 that is wrong (the canary of tests/test_gpu_toolchain.py: when a ROCm release passes it, this block can go).
+//     there at -O1 and -O3: not an out-of-bounds index, an uninitialised read or a missing barrier of ours.
+// So: the register-resident variants (state / emission dimension <= 6) are built at -O3 WITH THE BASIC VGPR ALLOCATOR -- right in every
+// case on record and 1.1 - 4 x faster than the -O1 fence (gradient sweep d = 4: 26.9 -> 7.2 ms, filter d = 6: 15.3 -> 3.8 ms per 512 x 100);
+// the workgroup variants stay at -O1 with the greedy allocator, which spills far less there and has no wrong result on record in 700 +
+// random problems (the basic allocator costs them 30 - 60 %).  CDKF_RTC_POLICY = o1 | o3 | o3basic | o1basic | o3subreg overrides (A/B;
+// "o3" is the canary of tests/test_gpu_toolchain.py: the day a ROCm release passes it, this block can go).
 struct RtcPolicy {
   const char* olevel;
   const char* extra1;  // "-mllvm" or null
@@ -215,7 +217,7 @@ RtcPolicy rtc_policy(bool workgroup) {
   if (p == "o3basic") return {"-O3", "-mllvm", "-vgpr-regalloc=basic"};
   if (p == "o1basic") return {"-O1", "-mllvm", "-vgpr-regalloc=basic"};
   if (p == "o3subreg") return {"-O3", "-mllvm", "-enable-subreg-liveness=0"};
-  if (workgroup) return {"-O1", "-mllvm", "-vgpr-regalloc=basic"};
+  if (workgroup) return {"-O1", nullptr, nullptr};
   return {"-O3", "-mllvm", "-vgpr-regalloc=basic"};
 }
 

@@ -1,9 +1,8 @@
 """The compiler defect behind rounds 3 / 4's "-O1 fences" (launch_custom.hip: rtc_policy; NOTES.md R5.1), held by a reproducer and a
-canary.  ROCm 7.2's greedy register allocator with sub-register liveness tracking of the 64-bit VGPR pairs miscompiles spill-heavy
-double-precision kernels at -O2 / -O3; the smallest member of the family is the forward-sensitivity sweep of the two-dimensional drift
+canary.  ROCm 7.2's greedy register allocator miscompiles spill-heavy double-precision kernels at the register limit at -O2 / -O3; the smallest member of the family is the forward-sensitivity sweep of the two-dimensional drift
 NL_F of tests/test_custom_drift.py (its generated translation unit is ~90 lines on top of the kernel headers: CDKF_CUSTOM_DUMP writes
 it; scripts/r5_o3_probe.py and scripts/r5_mir_delta.py are the drivers that found the pass and the switch).
-  * under the shipped policy (-O3 with `-mllvm -enable-subreg-liveness=0`) the gradient equals finite differences of the oracle;
+  * under the shipped policy (-O3 with the BASIC allocator for the vector registers) the gradient equals finite differences of the oracle;
   * CANARY: under plain -O3 (CDKF_RTC_POLICY=o3) it is still WRONG on this toolchain -- the day a ROCm release makes this leg pass, the
     test fails with the message to drop the workaround;
   * -O1 (the round-4 fence, CDKF_RTC_POLICY=o1) is right, as it always was."""
@@ -36,6 +35,6 @@ def test_shipped_policy_is_right_and_the_old_fence_too(hip_lib, tmp_path):
 
 def test_canary_plain_o3_is_still_miscompiled_on_this_toolchain(hip_lib, tmp_path):
     ok, line = _case("o3", tmp_path)
-    assert not ok, ("plain -O3 now compiles the forward-sensitivity sweep correctly on this toolchain: the sub-register-liveness workaround "
+    assert not ok, ("plain -O3 now compiles the forward-sensitivity sweep correctly on this toolchain: the basic-allocator workaround "
                     "(launch_custom.hip rtc_policy, csrc/Makefile launch_wg8.o) can be retired -- rerun scripts/r5_o3_probe.py scan ukf15 and "
                     "the d = 46 case first. " + line)
