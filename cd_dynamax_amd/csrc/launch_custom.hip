@@ -192,7 +192,8 @@ std::string rtc_cache_dir() {
 // (unscented workgroup kernel, d = 15), NaN (eight-entries-per-thread workgroup kernels, d = 46).  Established on the GPU
 // (scripts/r5_o3_probe.py, scripts/r5_mir_delta.py):
 //   * pass bisection stops at the pre-RA si-shrink-instructions run in every case, but its rewrites only perturb the register allocation
-//     that follows: applied to the machine IR one kind at a time none is needed, and no small subset of the 5 760 changed lines flips it;
+//     that follows: applied to the machine IR one kind at a time (hints / V_FMAC_F64 e64 -> e32 / the rest) no single instruction is at
+//     fault -- delta debugging over the 5 760 changed lines stays wrong down to 2 520 lines and no chunk alone is wrong;
 //   * of some twenty single switches exactly one turns every wrong build right without breaking a right one: the BASIC instead of the
 //     greedy allocator for the vector registers (-mllvm -vgpr-regalloc=basic).  Spill placement and targets (AGPR, SGPR -> VGPR lanes),
 //     stack colouring / slot sharing, hint splitting, DCE inside the allocator, the machine scheduler, forced wait counts, a 256-register
