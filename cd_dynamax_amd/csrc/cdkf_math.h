@@ -449,6 +449,21 @@ CDKF_DEV bool integrate_adaptive(R (&y)[NS], R t0, R t1, R dt0, long max_steps, 
   return capped;
 }
 
+// CDKF_UNIFORM_INTEGRATE (run-time compiled register-resident kernels, launch_custom.hip): the step loop of the fixed-step solvers runs
+// until EVERY lane of the wavefront has reached its interval's end -- a lane that is there already takes steps of length zero (y + 0 k = y;
+// tnext = tprev = t1 by then) -- so that the loop, whose body is where these kernels spill, runs under a full execution mask.  The wavefront
+// waits for its slowest lane either way.  NOTES.md R5.1.
+#ifndef CDKF_UNIFORM_INTEGRATE
+#define CDKF_UNIFORM_INTEGRATE 0
+#endif
+CDKF_DEV bool wave_any(bool c) {
+#if defined(CDKF_HOST_SIM)
+  return c;  // (the host run takes the lanes of these kernels one at a time)
+#else
+  return __builtin_amdgcn_ballot_w64(c) != 0;
+#endif
+}
+
 template <typename R, int NS, int MEAN_ONLY = 0, int NERR = NS, typename Rhs>
 CDKF_DEV bool integrate(R (&y)[NS], R t0, R t1, R dt0, long max_steps, const Rhs& rhs, const RkTab<R>& tb) {
   if (tb.adaptive) return integrate_adaptive<R, NS, MEAN_ONLY, NERR>(y, t0, t1, dt0, max_steps, rhs, tb);
@@ -456,6 +471,20 @@ CDKF_DEV bool integrate(R (&y)[NS], R t0, R t1, R dt0, long max_steps, const Rhs
   R tnext = rmin(t0 + dt0, t1);
   long steps = 0;
   bool capped = false;
+#if CDKF_UNIFORM_INTEGRATE
+  while (wave_any(tprev < t1 && !capped)) {
+    const bool act = tprev < t1 && !capped;
+    if (act && steps >= max_steps) capped = true;
+    const bool go = act && !capped;
+    rk_step<R, NS>(y, go ? tnext - tprev : R(0), rhs, tb, tprev);
+    if (go) {
+      tprev = rmin(tnext, t1);
+      R tn = tnext + dt0;
+      tnext = (tn > t1 - Tol<R>::v) ? t1 : tn;
+      ++steps;
+    }
+  }
+#else
   while (tprev < t1) {
     if (steps >= max_steps) {
       capped = true;
@@ -467,6 +496,7 @@ CDKF_DEV bool integrate(R (&y)[NS], R t0, R t1, R dt0, long max_steps, const Rhs
     tnext = (tn > t1 - Tol<R>::v) ? t1 : tn;
     ++steps;
   }
+#endif
   return capped;
 }
 
@@ -476,6 +506,20 @@ CDKF_DEV bool integrate(R (&y)[NS], R t0, R t1, R dt0, long max_steps, const Rhs
   R tnext = rmin(t0 + dt0, t1);
   long steps = 0;
   bool capped = false;
+#if CDKF_UNIFORM_INTEGRATE
+  while (wave_any(tprev < t1 && !capped)) {
+    const bool act = tprev < t1 && !capped;
+    if (act && steps >= max_steps) capped = true;
+    const bool go = act && !capped;
+    dopri5_step<R, NS>(y, go ? tnext - tprev : R(0), rhs, C, tprev);
+    if (go) {
+      tprev = rmin(tnext, t1);
+      R tn = tnext + dt0;
+      tnext = (tn > t1 - Tol<R>::v) ? t1 : tn;
+      ++steps;
+    }
+  }
+#else
   while (tprev < t1) {
     if (steps >= max_steps) {
       capped = true;
@@ -487,6 +531,7 @@ CDKF_DEV bool integrate(R (&y)[NS], R t0, R t1, R dt0, long max_steps, const Rhs
     tnext = (tn > t1 - Tol<R>::v) ? t1 : tn;
     ++steps;
   }
+#endif
   return capped;
 }
 

@@ -188,38 +188,72 @@ std::string rtc_cache_dir() {
 
 // ---- how the run-time compiled kernels are optimised (round 5: what is behind rounds 3 / 4's "-O1 fences"; NOTES.md R5.1) -----------------
 // ROCm 7.2's compiler (AMD clang 22.0.0git, roc-7.2.0 26014) miscompiles spill-heavy DOUBLE-PRECISION kernels at -O2 / -O3: a gradient
-// that is never stored (forward-sensitivity sweep, d = 2: all 512 registers, 962 spilled, 2.2 KB of scratch per lane), moments 3 % off
-// (unscented workgroup kernel, d = 15), NaN (eight-entries-per-thread workgroup kernels, d = 46).  Established on the GPU
-// (scripts/r5_o3_probe.py, scripts/r5_mir_delta.py):
-//   * pass bisection stops at the pre-RA si-shrink-instructions run in every case, but its rewrites only perturb the register allocation
-//     that follows: applied to the machine IR one kind at a time (hints / V_FMAC_F64 e64 -> e32 / the rest) no single instruction is at
-//     fault -- delta debugging over the 5 760 changed lines stays wrong down to 2 520 lines and no chunk alone is wrong;
-//   * of some twenty single switches exactly one turns every wrong build right without breaking a right one: the BASIC instead of the
-//     greedy allocator for the vector registers (-mllvm -vgpr-regalloc=basic).  Spill placement and targets (AGPR, SGPR -> VGPR lanes),
-//     stack colouring / slot sharing, hint splitting, DCE inside the allocator, the machine scheduler, forced wait counts, a 256-register
-//     budget change nothing; -enable-subreg-liveness=0 repairs two kernels and breaks a third;
+// that is never stored (forward-sensitivity sweep, d = 2: all 512 registers, 913 spilled, 2.3 KB of scratch per lane), moments 3 % off
+// (unscented workgroup kernel, d = 15), NaN (eight-entries-per-thread workgroup kernels, d = 46: ~1400 spilled).  Established
+// (scripts/r5_o3_probe.py, scripts/r5_mir_delta.py, scripts/r5_spill_table.py; profiles/r05_a_o3_investigation.txt):
 //   * the same sources are clean under ASan / UBSan / MSan / TSan in the host build (tests/test_hostsim.py) and agree with the oracle
-//     there at -O1 and -O3: not an out-of-bounds index, an uninitialised read or a missing barrier of ours.
-// So: the register-resident variants (state / emission dimension <= 6) are built at -O3 WITH THE BASIC VGPR ALLOCATOR -- right in every
-// case on record and 1.1 - 4 x faster than the -O1 fence (gradient sweep d = 4: 26.9 -> 7.2 ms, filter d = 6: 15.3 -> 3.8 ms per 512 x 100);
-// the workgroup variants stay at -O1 with the greedy allocator, which spills far less there and has no wrong result on record in 700 +
-// random problems (the basic allocator costs them 30 - 60 %).  CDKF_RTC_POLICY = o1 | o3 | o3basic | o1basic | o3subreg overrides (A/B;
-// "o3" is the canary of tests/test_gpu_toolchain.py: the day a ROCm release passes it, this block can go).
+//     there at -O1 and -O3: not an out-of-bounds index, an uninitialised read or a missing barrier of ours;
+//   * pass bisection stops at the pre-RA si-shrink-instructions run in every case, but its rewrites only perturb the register allocation
+//     that follows: applied to the machine IR in subsets no single instruction is at fault (delta debugging stays wrong down to 2 520 of
+//     5 760 changed lines and no chunk alone is wrong); -verify-machineinstrs passes on the wrong build;
+//   * every wrong build on record spills >= 700 vector registers to scratch memory; no build with <= 400 has been wrong at any level
+//     (the -O3 filters of d <= 6: 0 - 270, every -O1 build: 0 - 396);
+//   * single -mllvm switches flip individual kernels (the basic VGPR allocator, sub-register liveness off, deferred spilling, wave-uniform
+//     step loops: CDKF_RTC_UNIFORM) but none is right everywhere -- AND NONE CAN BE CHOSEN PER KERNEL: hipRTC parses LLVM's -mllvm options
+//     ONCE PER PROCESS, the first compilation's set (or its absence) is frozen for every later one (measured: the spill count of the same
+//     source under [-O3 basic, -O3, -O3 basic] = 1621, 1621, 1621 and under [-O3, -O3 basic, -O3] = 891, 891, 891).  A policy that
+//     depends on an -mllvm option therefore depends on which kernel a process happens to compile first, and poisons the disk cache.
+// So the shipped policy uses the optimisation LEVEL only, and decides it on the code object it gets: a register-resident variant is
+// built at -O3; if its metadata reports more than CDKF_RTC_SPILL_LIMIT (default 300) spilled vector registers, that build is discarded
+// and the variant rebuilt at -O1 (which spills 2 - 80 x less on these kernels).  The workgroup variants stay at -O1 (no wrong result in
+// 700 + random problems; -O3 is wrong on the d = 15 unscented case).  CDKF_RTC_POLICY = o1 | o3 forces a level (A/B; "o3" is the canary of
+// tests/test_gpu_toolchain.py); o3basic | o1basic | o3subreg add the -mllvm switch named -- meaningful only as the FIRST compilation of
+// a process (scripts/r5_o3_probe.py runs every case in a process of its own).
 struct RtcPolicy {
   const char* olevel;
   const char* extra1;  // "-mllvm" or null
   const char* extra2;
+  long spill_limit;    // > 0: a build that spills more vector registers than this is rebuilt at -O1 (0: keep whatever comes out)
 };
 RtcPolicy rtc_policy(bool workgroup) {
   const char* e = getenv("CDKF_RTC_POLICY");
   const std::string p = e ? e : "";
-  if (p == "o1") return {"-O1", nullptr, nullptr};
-  if (p == "o3") return {"-O3", nullptr, nullptr};
-  if (p == "o3basic") return {"-O3", "-mllvm", "-vgpr-regalloc=basic"};
-  if (p == "o1basic") return {"-O1", "-mllvm", "-vgpr-regalloc=basic"};
-  if (p == "o3subreg") return {"-O3", "-mllvm", "-enable-subreg-liveness=0"};
-  if (workgroup) return {"-O1", nullptr, nullptr};
-  return {"-O3", "-mllvm", "-vgpr-regalloc=basic"};
+  if (p == "o1") return {"-O1", nullptr, nullptr, 0};
+  if (p == "o3") return {"-O3", nullptr, nullptr, 0};
+  if (p == "o3basic") return {"-O3", "-mllvm", "-vgpr-regalloc=basic", 0};
+  if (p == "o1basic") return {"-O1", "-mllvm", "-vgpr-regalloc=basic", 0};
+  if (p == "o3subreg") return {"-O3", "-mllvm", "-enable-subreg-liveness=0", 0};
+  if (workgroup) return {"-O1", nullptr, nullptr, 0};
+  long lim = 300;
+  if (const char* l = getenv("CDKF_RTC_SPILL_LIMIT")) lim = atol(l) > 0 ? atol(l) : 300;
+  return {"-O3", nullptr, nullptr, lim};
+}
+
+// `.vgpr_spill_count` of the (one) kernel of a code object, from its msgpack metadata note: the key is followed by an unsigned integer
+// (positive fixint, 0xcc u8, 0xcd u16, 0xce u32 -- big-endian); -1 when the key is not found.
+long code_object_vgpr_spills(const std::vector<char>& code) {
+  static const char key[] = ".vgpr_spill_count";
+  const size_t kl = sizeof(key) - 1;
+  long worst = -1;
+  for (size_t i = 0; i + kl + 1 < code.size(); ++i) {
+    if (memcmp(code.data() + i, key, kl) != 0) continue;
+    const unsigned char* q = (const unsigned char*)code.data() + i + kl;
+    const size_t left = code.size() - (i + kl);
+    long v = -1;
+    if (q[0] <= 0x7f) v = q[0];
+    else if (q[0] == 0xcc && left > 1) v = q[1];
+    else if (q[0] == 0xcd && left > 2) v = ((long)q[1] << 8) | q[2];
+    else if (q[0] == 0xce && left > 4) v = ((long)q[1] << 24) | ((long)q[2] << 16) | ((long)q[3] << 8) | q[4];
+    if (v > worst) worst = v;
+  }
+  return worst;
+}
+
+// wave-uniform step loops in the register-resident variants (cdkf_math.h: CDKF_UNIFORM_INTEGRATE); CDKF_RTC_UNIFORM = 0 | 1 overrides
+bool rtc_uniform_steps() {
+  const char* e = getenv("CDKF_RTC_UNIFORM");
+  if (e && *e) return e[0] == '1';
+  return false;
 }
 
 // Compiler options every run-time compilation gets beside its optimisation level (part of the cache key).  CDKF_RTC_EXTRA_OPTS
@@ -352,6 +386,7 @@ std::string generate_source(const CustomDrift& c, int bytes, int m, int ukf, int
   const bool time_dep = drift_uses_time(c);
   // what every snippet sees beside x and theta: the inputs row of the interval and the (stage) time -- f(x, u, t), inference_ekf.py:95, 101-114
   const std::string ctx = "    const R* u = u_; const R t = t_; (void)u; (void)t;\n";
+  s += "#define CDKF_UNIFORM_INTEGRATE " + std::string(rtc_uniform_steps() ? "1" : "0") + "\n";
   s += grad ? "#include \"cdkf_grad_kernels.h\"\n" : "#include \"cdkf_reg_kernels.h\"\n";
   s += "#include \"cdkf_dual.h\"\n";
   s += "namespace cdkf {\n";
@@ -531,54 +566,67 @@ int compile_variant(const CustomDrift& c, const Key& key, const std::string& arc
   }
   const std::string src = generate_source(c, std::get<1>(key), std::get<2>(key), std::get<3>(key), std::get<4>(key),
                                           std::get<5>(key), std::get<6>(key), std::get<7>(key), ek ? &em : nullptr, std::get<9>(key));
-  // (rounds 3 / 4 built the forward-sensitivity sweep at -O1 after wrong gradients at -O2 / -O3: see rtc_policy above for the cause)
+  // (rounds 3 / 4 built the forward-sensitivity sweep at -O1 after wrong gradients at -O2 / -O3: see rtc_policy above for the rule now)
   const RtcPolicy pol = rtc_policy(false);
   const char* olevel = pol.olevel;
   const std::string tag = "reg ukf=" + std::to_string(std::get<3>(key)) + " algo=" + std::to_string(std::get<6>(key));
   if (rtc_override_code(tag, code)) return CDKF_OK;
-  const std::string cache_key = rtc_cache_key(src, arch, (std::string(olevel) + (pol.extra2 ? pol.extra2 : "")).c_str(), "cdkf_custom_kernel", tag);
+  const std::string pol_text = std::string(olevel) + (pol.extra2 ? pol.extra2 : "") +
+                               (pol.spill_limit ? "/spills>" + std::to_string(pol.spill_limit) + "->-O1" : std::string());
+  const std::string cache_key = rtc_cache_key(src, arch, pol_text.c_str(), "cdkf_custom_kernel", tag);
   {
     std::string unused;
     if (!getenv("CDKF_CUSTOM_DUMP") && rtc_cache_load(cache_key, code, unused)) return CDKF_OK;
   }
-  hiprtcProgram prog = nullptr;
-  if (hiprtcCreateProgram(&prog, src.c_str(), "cdkf_custom_drift.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
-    set_error("custom drift: hiprtcCreateProgram failed");
-    return CDKF_EHIP;
-  }
-  const std::string inc = "-I" + source_dir(), off = "--offload-arch=" + arch;
-  const std::vector<std::string> extra = rtc_extra_options(tag);
-  std::vector<const char*> opts = {off.c_str(), olevel, "-std=c++17", inc.c_str(), "-Wno-pass-failed"};
-  if (pol.extra1) {
-    opts.push_back(pol.extra1);
-    opts.push_back(pol.extra2);
-  }
-  for (const std::string& x : extra) opts.push_back(x.c_str());
-  const hiprtcResult res = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
-  if (res != HIPRTC_SUCCESS) {
-    size_t n = 0;
-    hiprtcGetProgramLogSize(prog, &n);
-    std::string log(n ? n : 1, '\0');
-    if (n) hiprtcGetProgramLog(prog, &log[0]);
-    // keep the diagnostics, drop the include-chain preamble
-    std::string brief;
-    size_t pos = 0;
-    while (pos < log.size()) {
-      size_t eol = log.find('\n', pos);
-      if (eol == std::string::npos) eol = log.size();
-      if (log.compare(pos, 21, "In file included from") != 0) brief.append(log, pos, eol - pos + 1);
-      pos = eol + 1;
+  long spills = -1;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    hiprtcProgram prog = nullptr;
+    if (hiprtcCreateProgram(&prog, src.c_str(), "cdkf_custom_drift.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
+      set_error("custom drift: hiprtcCreateProgram failed");
+      return CDKF_EHIP;
     }
-    set_error("custom drift: compilation failed (%s): %.400s", hiprtcGetErrorString(res), brief.c_str());
+    const std::string inc = "-I" + source_dir(), off = "--offload-arch=" + arch;
+    const std::vector<std::string> extra = rtc_extra_options(tag);
+    std::vector<const char*> opts = {off.c_str(), olevel, "-std=c++17", inc.c_str(), "-Wno-pass-failed"};
+    if (pol.extra1) {
+      opts.push_back(pol.extra1);
+      opts.push_back(pol.extra2);
+    }
+    for (const std::string& x : extra) opts.push_back(x.c_str());
+    const hiprtcResult res = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
+    if (res != HIPRTC_SUCCESS) {
+      size_t n = 0;
+      hiprtcGetProgramLogSize(prog, &n);
+      std::string log(n ? n : 1, '\0');
+      if (n) hiprtcGetProgramLog(prog, &log[0]);
+      // keep the diagnostics, drop the include-chain preamble
+      std::string brief;
+      size_t pos = 0;
+      while (pos < log.size()) {
+        size_t eol = log.find('\n', pos);
+        if (eol == std::string::npos) eol = log.size();
+        if (log.compare(pos, 21, "In file included from") != 0) brief.append(log, pos, eol - pos + 1);
+        pos = eol + 1;
+      }
+      set_error("custom drift: compilation failed (%s): %.400s", hiprtcGetErrorString(res), brief.c_str());
+      hiprtcDestroyProgram(&prog);
+      return CDKF_EINVAL;
+    }
+    size_t sz = 0;
+    hiprtcGetCodeSize(prog, &sz);
+    code.resize(sz);
+    hiprtcGetCode(prog, code.data());
     hiprtcDestroyProgram(&prog);
-    return CDKF_EINVAL;
+    const long now = code_object_vgpr_spills(code);
+    if (attempt == 0) spills = now;
+    // the rule of rtc_policy: a build past the spill limit is not trusted at this level -- once more at -O1 (unknown count: the same)
+    if (attempt == 0 && pol.spill_limit > 0 && (now < 0 || now > pol.spill_limit) && std::string(olevel) != "-O1") {
+      olevel = "-O1";
+      continue;
+    }
+    break;
   }
-  size_t sz = 0;
-  hiprtcGetCodeSize(prog, &sz);
-  code.resize(sz);
-  hiprtcGetCode(prog, code.data());
-  hiprtcDestroyProgram(&prog);
-  rtc_cache_store(cache_key, code, std::string(), tag + " " + olevel);
+  rtc_cache_store(cache_key, code, std::string(), tag + " " + olevel + " (vgpr spills at " + pol.olevel + ": " + std::to_string(spills) + ")");
   if (const char* dir = getenv("CDKF_CUSTOM_DUMP")) {  // debugging aid: the generated source and its code object
     const std::string base = std::string(dir) + "/cdkf_custom_reg_" + std::to_string(std::get<1>(key)) + "_m" + std::to_string(std::get<2>(key)) + "_" +
                              std::to_string(std::get<3>(key)) + "_" + std::to_string(std::get<4>(key)) + "_" + std::to_string(std::get<6>(key)) + "_" + cache_key.substr(0, 8);
