@@ -593,6 +593,13 @@ int cdkf_debug_custom_reg_blob(const cdkf_model* mdl, const cdkf_opts* opts, int
                                void* par_out, int64_t par_cap_bytes, int64_t* ip_out) {
   return custom_debug_reg_blob(mdl, opts, N, T, algo, bytes_per_real, par_out, par_cap_bytes, ip_out);
 }
+int cdkf_ukf_tangent_compile(const cdkf_model* mdl, const cdkf_opts* opts, int bytes_per_real) {
+  return ukf_tangent_compile_check(mdl, opts, bytes_per_real);
+}
+int cdkf_debug_ukf_tangent_args(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T, int bytes_per_real, int all,
+                                void* args_out, int64_t args_cap_bytes, void* par_out, int64_t par_cap_bytes) {
+  return ukf_tangent_debug_args(mdl, opts, N, T, bytes_per_real, all, args_out, args_cap_bytes, par_out, par_cap_bytes);
+}
 int cdkf_debug_wg_args(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T, int bytes_per_real, int ukf, int smoother,
                        void* args_out, int64_t args_cap_bytes, void* blob_out, int64_t blob_cap_bytes, int64_t* geom_out) {
   return debug_wg_args(mdl, opts, N, T, bytes_per_real, ukf, smoother, args_out, args_cap_bytes, blob_out, blob_cap_bytes, geom_out);

@@ -116,6 +116,15 @@ int launch_custom(int algo, const cdkf_model* mdl, const cdkf_opts* o, int64_t N
                   R* a1, R* a2, R* a3, R* a4, int32_t* status, hipStream_t stream);
 int custom_register(int state_dim, int n_theta, const char* f_src, const char* jac_src, const char* divgrad_src);
 int custom_compile_check(int kind, int bytes_per_real, int emission_dim, int algo, int state_order, int emission_kind);
+// the unscented filter's gradient for any drift / emission: forward mode through the literal sigma-point recursion (launch_custom.hip,
+// cdkf_ukf_tangent_kernels.h); grad_model null: the drift parameters only
+bool ukf_tangent_available(const cdkf_model* mdl, const cdkf_opts* o);
+template <typename R>
+int launch_ukf_tangent(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll, R* grad,
+                       R* grad_model, int32_t* status, hipStream_t stream);
+int ukf_tangent_compile_check(const cdkf_model* mdl, const cdkf_opts* o, int bytes_per_real);
+int ukf_tangent_debug_args(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, int bytes_per_real, int all, void* args_out,
+                           int64_t args_cap, void* par_out, int64_t par_cap);
 void custom_rtc_cache_stats(int64_t* hits, int64_t* misses);
 int custom_debug_reg_blob(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, int algo, int bytes_per_real, void* par_out,
                           int64_t par_cap_bytes, int64_t* ip_out);

@@ -22,6 +22,7 @@
 #include <tuple>
 
 #include "cdkf_launch.h"
+#include "cdkf_ukf_tangent_kernels.h"
 #include "cdkf_wg2_kernels.h"  // WgArgs: the argument block of the workgroup kernels (drifts above six state dimensions)
 
 namespace cdkf {
@@ -1382,6 +1383,288 @@ int custom_compile_check(int kind, int bytes_per_real, int emission_dim, int alg
   int rc = compile_variant(c, Key(kind, bytes_per_real, emission_dim, algo == 1, zeroth, 0, 0, generic, emission_kind, du), "gfx950", code);
   if (!rc && algo == 2) rc = compile_variant(c, Key(kind, bytes_per_real, emission_dim, 0, 0, 0, 1, generic, 0, du), "gfx950", code);
   return rc;
+}
+
+// ---- the unscented filter's gradient for any drift / emission: forward mode through the literal recursion (cdkf_ukf_tangent_kernels.h) ----
+// The drift's statements: the registered source, or -- for a built-in drift -- the same function written out here (theta layouts:
+// cdkf.h).  The emission's: the registered source, or the linear emission h = H x + b over eta = [H | b].
+static std::string ut_builtin_drift(const cdkf_model* mdl) {
+  const int d = mdl->state_dim;
+  const std::string D_ = std::to_string(d);
+  switch (mdl->drift_kind) {
+    case CDKF_DRIFT_LINEAR:
+      return "for (int i_ = 0; i_ < " + D_ + "; ++i_) { T s_ = theta[" + std::to_string(d * d) + " + i_]; for (int k_ = 0; k_ < " + D_ +
+             "; ++k_) s_ += theta[i_ * " + D_ + " + k_] * x[k_]; fx[i_] = s_; }";
+    case CDKF_DRIFT_LORENZ63:
+      return "fx[0] = theta[0] * (x[1] - x[0]); fx[1] = x[0] * (theta[1] - x[2]) - x[1]; fx[2] = x[0] * x[1] - theta[2] * x[2];";
+    case CDKF_DRIFT_LORENZ96:
+      return "for (int i_ = 0; i_ < " + D_ + "; ++i_) fx[i_] = (x[(i_ + 1) % " + D_ + "] - x[(i_ + " + std::to_string(d - 2) + ") % " + D_ +
+             "]) * x[(i_ + " + std::to_string(d - 1) + ") % " + D_ + "] - x[i_] + theta[0];";
+    case CDKF_DRIFT_MLP_TANH: {
+      const int h1 = mdl->hidden1, h2 = mdl->hidden2;
+      const int oW1 = 0, ob1 = oW1 + h1 * d, oW2 = ob1 + h1, ob2 = oW2 + h2 * h1, oW3 = ob2 + h2, ob3 = oW3 + d * h2;
+      auto S = [](int v) { return std::to_string(v); };
+      return "T a1_[" + S(h1) + "], a2_[" + S(h2) + "];\n"
+             "for (int i_ = 0; i_ < " + S(h1) + "; ++i_) { T s_ = theta[" + S(ob1) + " + i_]; for (int k_ = 0; k_ < " + D_ + "; ++k_) s_ += theta[" + S(oW1) +
+             " + i_ * " + D_ + " + k_] * x[k_]; a1_[i_] = tanh(s_); }\n"
+             "for (int i_ = 0; i_ < " + S(h2) + "; ++i_) { T s_ = theta[" + S(ob2) + " + i_]; for (int k_ = 0; k_ < " + S(h1) + "; ++k_) s_ += theta[" + S(oW2) +
+             " + i_ * " + S(h1) + " + k_] * a1_[k_]; a2_[i_] = tanh(s_); }\n"
+             "for (int i_ = 0; i_ < " + D_ + "; ++i_) { T s_ = theta[" + S(ob3) + " + i_]; for (int k_ = 0; k_ < " + S(h2) + "; ++k_) s_ += theta[" + S(oW3) +
+             " + i_ * " + S(h2) + " + k_] * a2_[k_]; fx[i_] = s_; }";
+    }
+    default:
+      return std::string();
+  }
+}
+
+constexpr int kUtMaxDim = 16;  // state / emission dimension of the tangent sweep (private arrays: ~ 6 (d + d (d + 1) / 2) dual numbers per lane)
+
+// is the model one the tangent sweep takes?  (`why`: the refusal's text)
+static bool ut_model_sources(const cdkf_model* mdl, const cdkf_opts* o, std::string& f_src, std::string& h_src, int& nth, std::string* why) {
+  auto no = [&](const char* msg) {
+    if (why) *why = msg;
+    return false;
+  };
+  const int d = mdl->state_dim, m = mdl->emission_dim;
+  if (d < 1 || m < 1 || d > kUtMaxDim || m > kUtMaxDim) return no("state_dim, emission_dim <= 16");
+  if (o->solver != CDKF_SOLVER_DOPRI5 || o->adaptive) return no("the default solver (fixed-step Dormand-Prince)");
+  if (o->forecast) return no("no forecast mode");
+  nth = (int)mdl->n_theta;
+  if (custom_kind(mdl->drift_kind)) {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    const CustomDrift& c = g_drifts[mdl->drift_kind - CDKF_DRIFT_CUSTOM_BASE];
+    if (c.d != d || c.n_theta != mdl->n_theta) return no("the dimensions the drift was registered with");
+    f_src = c.f_src;
+  } else {
+    f_src = ut_builtin_drift(mdl);
+    if (f_src.empty()) return no("a drift whose statements the tangent sweep has (linear, Lorenz-63, Lorenz-96, MLP, or source)");
+    if (mdl->drift_kind == CDKF_DRIFT_LORENZ96 && d < 4) return no("Lorenz-96 from four dimensions");
+  }
+  if (mdl->emission_kind) {
+    if (!custom_emission_kind(mdl->emission_kind, d, m)) return no("an emission registered for these dimensions");
+    std::lock_guard<std::mutex> lock(g_mutex_emis());
+    h_src = g_emis[mdl->emission_kind - CDKF_EMISSION_CUSTOM_BASE].h_src;
+  } else {
+    h_src = "for (int r_ = 0; r_ < " + std::to_string(m) + "; ++r_) { T s_ = eta[" + std::to_string(m * d) + " + r_]; for (int k_ = 0; k_ < " +
+            std::to_string(d) + "; ++k_) s_ += eta[r_ * " + std::to_string(d) + " + k_] * x[k_]; hx[r_] = s_; }";
+  }
+  return true;
+}
+
+bool ukf_tangent_available(const cdkf_model* mdl, const cdkf_opts* o) {
+  std::string f, h;
+  int nth = 0;
+  return ut_model_sources(mdl, o, f, h, nth, nullptr);
+}
+
+static std::string generate_ut_source(const cdkf_model* mdl, const std::string& f_src, const std::string& h_src, int bytes) {
+  const int d = mdl->state_dim, m = mdl->emission_dim, du = mdl->input_dim;
+  std::string s;
+  s += "#include \"cdkf_ukf_tangent_kernels.h\"\nnamespace cdkf {\nstruct UtModel {\n";
+  s += "  static constexpr int D = " + std::to_string(d) + ", M = " + std::to_string(m) + ", NTH = " + std::to_string((int)mdl->n_theta) +
+       ", DU = " + std::to_string(du) + ";\n";
+  // (theta / eta: views whose operator[] hands out the entry as a T -- the snippets index them, as they index the arrays of the filters)
+  s += "  template <typename R, typename T, typename TH> static __device__ void f(const T* x, const TH& theta, T (&fx)[D], const R* u, const R t) {\n"
+       "    (void)theta; (void)u; (void)t;\n#line 1 \"drift_f\"\n" + f_src + "\n  }\n";
+  s += "  template <typename R, typename T, typename EH> static __device__ void h(const T* x, const EH& eta, T (&hx)[M], const R* u, const R t) {\n"
+       "    (void)eta; (void)u; (void)t;\n#line 1 \"emission_h\"\n" + h_src + "\n  }\n};\n}  // namespace cdkf\n";
+  s += "using R = " + std::string(bytes == 8 ? "double" : "float") + ";\n";
+  s += "extern \"C\" __global__ __launch_bounds__(64) void cdkf_ukf_tangent_kernel(const cdkf::UtArgs<R> a) { cdkf::ukf_tangent_body<R, cdkf::UtModel>(a); }\n";
+  return s;
+}
+
+std::map<std::pair<int, std::string>, Compiled> g_ut_modules;  // (device, cache key)
+
+static int ut_get_function(const cdkf_model* mdl, const cdkf_opts* o, int bytes, hipFunction_t* fn, const char* arch_override) {
+  std::string f_src, h_src, why;
+  int nth = 0;
+  if (!ut_model_sources(mdl, o, f_src, h_src, nth, &why)) {
+    set_error("ukf_loglik_grad: the tangent sweep of the literal unscented recursion needs %s (drift_kind=%d state_dim=%d emission_dim=%d "
+              "emission_kind=%d solver=%d)", why.c_str(), mdl->drift_kind, mdl->state_dim, mdl->emission_dim, mdl->emission_kind, o->solver);
+    return CDKF_EUNSUPPORTED;
+  }
+  const std::string src = generate_ut_source(mdl, f_src, h_src, bytes);
+  std::string arch = arch_override ? arch_override : "";
+  int dev = 0;
+  if (!arch_override) {
+    CDKF_HIP_CHECK(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    CDKF_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+    arch = prop.gcnArchName;
+  }
+  // (-O1, as the workgroup variants: a loop-heavy kernel whose state lives in scratch by design; nothing to gain from unrolling it)
+  const char* olevel = "-O1";
+  const std::string tag = "ukf tangent";
+  const std::string cache_key = rtc_cache_key(src, arch, olevel, "cdkf_ukf_tangent_kernel", tag);
+  std::lock_guard<std::mutex> lock(g_mutex);
+  if (!arch_override) {
+    auto it = g_ut_modules.find({dev, cache_key});
+    if (it != g_ut_modules.end()) {
+      *fn = it->second.fn;
+      return CDKF_OK;
+    }
+  }
+  std::vector<char> code;
+  std::string unused;
+  if (getenv("CDKF_CUSTOM_DUMP") || !rtc_cache_load(cache_key, code, unused)) {
+    hiprtcProgram prog = nullptr;
+    if (hiprtcCreateProgram(&prog, src.c_str(), "cdkf_ukf_tangent.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
+      set_error("ukf tangent sweep: hiprtcCreateProgram failed");
+      return CDKF_EHIP;
+    }
+    const std::string inc = "-I" + source_dir(), off = "--offload-arch=" + arch;
+    const std::vector<std::string> extra = rtc_extra_options(tag);
+    std::vector<const char*> opts = {off.c_str(), olevel, "-std=c++17", inc.c_str(), "-Wno-pass-failed"};
+    for (const std::string& x : extra) opts.push_back(x.c_str());
+    const hiprtcResult res = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
+    if (res != HIPRTC_SUCCESS) {
+      size_t n = 0;
+      hiprtcGetProgramLogSize(prog, &n);
+      std::string log(n ? n : 1, '\0');
+      if (n) hiprtcGetProgramLog(prog, &log[0]);
+      std::string brief;
+      size_t pos = 0;
+      while (pos < log.size()) {
+        size_t eol = log.find('\n', pos);
+        if (eol == std::string::npos) eol = log.size();
+        if (log.compare(pos, 21, "In file included from") != 0) brief.append(log, pos, eol - pos + 1);
+        pos = eol + 1;
+      }
+      set_error("ukf tangent sweep: compilation failed (%s): %.600s", hiprtcGetErrorString(res), brief.c_str());
+      hiprtcDestroyProgram(&prog);
+      return CDKF_EINVAL;
+    }
+    size_t sz = 0;
+    hiprtcGetCodeSize(prog, &sz);
+    code.resize(sz);
+    hiprtcGetCode(prog, code.data());
+    hiprtcDestroyProgram(&prog);
+    rtc_cache_store(cache_key, code, std::string(), tag + " d=" + std::to_string(mdl->state_dim) + " m=" + std::to_string(mdl->emission_dim) + " " + olevel);
+    if (const char* dir = getenv("CDKF_CUSTOM_DUMP")) {
+      const std::string base = std::string(dir) + "/cdkf_ukf_tangent_" + std::to_string(bytes) + "_" + cache_key.substr(0, 8);
+      if (FILE* f = fopen((base + ".hip").c_str(), "w")) {
+        fwrite(src.data(), 1, src.size(), f);
+        fclose(f);
+      }
+      if (FILE* f = fopen((base + ".co").c_str(), "wb")) {
+        fwrite(code.data(), 1, code.size(), f);
+        fclose(f);
+      }
+    }
+  }
+  if (arch_override) return CDKF_OK;  // (compile check: no GPU)
+  Compiled m;
+  CDKF_HIP_CHECK(hipModuleLoadData(&m.module, code.data()));
+  CDKF_HIP_CHECK(hipModuleGetFunction(&m.fn, m.module, "cdkf_ukf_tangent_kernel"));
+  g_ut_modules[{dev, cache_key}] = m;
+  *fn = m.fn;
+  return CDKF_OK;
+}
+
+// compile check without a GPU (cdkf_ukf_tangent_compile): the kernel the model would get, built for gfx950
+int ukf_tangent_compile_check(const cdkf_model* mdl, const cdkf_opts* o, int bytes_per_real) {
+  if (!mdl || !o || (bytes_per_real != 4 && bytes_per_real != 8)) return CDKF_EINVAL;
+  hipFunction_t fn;
+  return ut_get_function(mdl, o, bytes_per_real, &fn, "gfx950");
+}
+
+// the argument struct and the parameter block (host copies) of the tangent sweep
+template <typename R>
+static void ut_fill(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, UtArgs<R>& a, std::vector<R>& par) {
+  const int d = mdl->state_dim, m = mdl->emission_dim;
+  par.clear();
+  for (long k = 0; k < mdl->n_theta; ++k) par.push_back(R(mdl->theta[k]));
+  for (int k = 0; k < d; ++k) par.push_back(R(mdl->m0[k]));
+  for (int k = 0; k < d * d; ++k) par.push_back(R(mdl->P0[k]));
+  {
+    std::vector<R> packed(d * (d + 1) / 2);
+    lql_packed<R>(mdl->L, mdl->Qc, d, 1.0, packed.data());  // (pairs i <= j, row-major)
+    std::vector<R> full((size_t)d * d);
+    int e = 0;
+    for (int i = 0; i < d; ++i)
+      for (int j = i; j < d; ++j, ++e) full[i * d + j] = full[j * d + i] = packed[e];
+    par.insert(par.end(), full.begin(), full.end());
+  }
+  for (int k = 0; k < m * d; ++k) par.push_back(R(mdl->H[k]));
+  for (int k = 0; k < m; ++k) par.push_back(R(mdl->h_bias[k]));
+  for (int k = 0; k < m * m; ++k) par.push_back(R(mdl->R[k]));
+  const R alpha = R(o->ukf_alpha), n = R(d);
+  const R lamb = alpha * alpha * (n + R(o->ukf_kappa)) - n;
+  a.dt0 = R(o->dt0);
+  a.dt_final = R(o->dt_final);
+  a.c = std::sqrt(n + lamb);
+  a.wm0 = lamb / (n + lamb);
+  a.wc0 = lamb / (n + lamb) + (R(1) - alpha * alpha + R(o->ukf_beta));
+  a.wi = R(1) / (R(2) * (n + lamb));
+  a.N = N;
+  a.T = T;
+  a.max_steps = (long)o->max_steps;
+  const SweepStrides ss = sweep_strides(o, N, T, d, m, false);
+  a.t_sn = ss.t_sn; a.t_sk = ss.t_sk; a.y_sn = ss.y_sn; a.y_sk = ss.y_sk; a.y_si = ss.y_si;
+  const int lin = (o->layout_in == CDKF_LAYOUT_SAME) ? o->layout : o->layout_in;
+  const ArrayStrides us = layout_strides(lin, N, T, mdl->input_dim > 0 ? mdl->input_dim : 1);
+  a.u_sn = us.sn; a.u_sk = us.sk; a.u_si = us.si;
+}
+
+template <typename R>
+int launch_ukf_tangent(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll, R* grad,
+                       R* grad_model, int32_t* status, hipStream_t stream) {
+  hipFunction_t fn;
+  int rc = ut_get_function(mdl, o, (int)sizeof(R), &fn, nullptr);
+  if (rc) return rc;
+  if (!t || !y || !ll || (!grad && mdl->n_theta > 0)) {
+    set_error("ukf_loglik_grad: t, y, ll and grad must not be NULL");
+    return CDKF_EINVAL;
+  }
+  if (N < 1 || T < 1) return CDKF_OK;
+  UtArgs<R> a{};
+  std::vector<R> par;
+  ut_fill<R>(mdl, o, N, T, a, par);
+  const size_t bytes = par.size() * sizeof(R);
+  ParamLease lease(stream);
+  rc = param_pool_acquire(bytes, &lease.slot);
+  if (rc) return rc;
+  std::memcpy(lease.slot->host, par.data(), bytes);
+  CDKF_HIP_CHECK(hipMemcpyAsync(lease.slot->dev, lease.slot->host, bytes, hipMemcpyHostToDevice, stream));
+  a.par = (const R*)lease.slot->dev;
+  a.t = t; a.y = y; a.ll = ll; a.grad = grad; a.grad_model = grad_model; a.status = status;
+  a.u = mdl->input_dim > 0 ? (const R*)o->inputs : nullptr;  // (device memory here: the host entry points have uploaded it)
+  a.all = grad_model ? 1 : 0;
+  const int d = mdl->state_dim, m = mdl->emission_dim, np = d * (d + 1) / 2, npm = m * (m + 1) / 2;
+  const long nleaf = a.all ? (long)mdl->n_theta + d + 2 * np + m * d + m + npm : (mdl->n_theta > 0 ? (long)mdl->n_theta : 1);
+  const long total = N * nleaf;
+  void* params[] = {(void*)&a};
+  note_kernel("ukf_tangent_kernel<%s> (d=%d m=%d, %ld leaf entries)", real_name<R>(), d, m, nleaf);
+  CDKF_HIP_CHECK(hipModuleLaunchKernel(fn, (unsigned)((total + 63) / 64), 1, 1, 64, 1, 1, 0, stream, params, nullptr));
+  return lease.release();
+}
+template int launch_ukf_tangent<float>(const cdkf_model*, const cdkf_opts*, int64_t, int64_t, const float*, const float*, float*, float*, float*,
+                                       int32_t*, hipStream_t);
+template int launch_ukf_tangent<double>(const cdkf_model*, const cdkf_opts*, int64_t, int64_t, const double*, const double*, double*, double*,
+                                        double*, int32_t*, hipStream_t);
+
+// host copies of the sweep's argument struct and parameter block (cdkf_debug_ukf_tangent_args: the CPU-sanitizer build of the kernel)
+int ukf_tangent_debug_args(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, int bytes_per_real, int all, void* args_out,
+                           int64_t args_cap, void* par_out, int64_t par_cap) {
+  if (!mdl || !o || !args_out || !par_out || (bytes_per_real != 4 && bytes_per_real != 8)) return CDKF_EINVAL;
+  if (bytes_per_real == 8) {
+    UtArgs<double> a{};
+    std::vector<double> par;
+    ut_fill<double>(mdl, o, N, T, a, par);
+    a.all = all;
+    if ((int64_t)sizeof(a) > args_cap || (int64_t)(par.size() * 8) > par_cap) return CDKF_EINVAL;
+    std::memcpy(args_out, &a, sizeof(a));
+    std::memcpy(par_out, par.data(), par.size() * 8);
+    return (int)par.size();
+  }
+  UtArgs<float> a{};
+  std::vector<float> par;
+  ut_fill<float>(mdl, o, N, T, a, par);
+  a.all = all;
+  if ((int64_t)sizeof(a) > args_cap || (int64_t)(par.size() * 4) > par_cap) return CDKF_EINVAL;
+  std::memcpy(args_out, &a, sizeof(a));
+  std::memcpy(par_out, par.data(), par.size() * 4);
+  return (int)par.size();
 }
 
 // the argument blocks of launch_custom for the CPU-sanitizer build of the generated kernel (cdkf_debug_custom_reg_blob): no HIP call

@@ -150,22 +150,20 @@ int launch_ekf_grad(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_
 
 // the unscented filter's log-likelihood and its gradient w.r.t. the drift parameters (cdkf_ukf_loglik_grad_*): forward sensitivities
 // through the closed form of the sigma-point sums -- the register-resident Lorenz-63 / linear shapes
-bool ukf_grad_shape_available(const cdkf_model* mdl, const cdkf_opts* o) {
+static bool ukf_grad_closed_form(const cdkf_model* mdl, const cdkf_opts* o) {
   cdkf_opts e = *o;
   e.state_order = CDKF_ORDER_FIRST;  // (the unscented filter has no state_order; the field is ignored)
-  // (run-time compiled drifts have forward-sensitivity kernels of their own, but none through the sigma-point closed form: only the
-  // built-in CDKF_GRAD_SHAPES dispatch below -- saying yes here would pass fit_sgd's gate and fail after its batches were uploaded)
   return !custom_kind(mdl->drift_kind) && sens_shape_available(mdl, &e) && mdl->emission_kind == 0;
+}
+// every other model (MLP, source drifts / emissions, the built-in drifts at other shapes): the tangent sweep of the literal recursion
+bool ukf_grad_shape_available(const cdkf_model* mdl, const cdkf_opts* o) {
+  return ukf_grad_closed_form(mdl, o) || (mdl->n_theta >= 1 && ukf_tangent_available(mdl, o));
 }
 template <typename R>
 int launch_ukf_grad(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll, R* grad,
                     int32_t* status, hipStream_t stream) {
-  if (!ukf_grad_shape_available(mdl, o)) {
-    set_error("ukf_loglik_grad: no kernel for drift_kind=%d state_dim=%d emission_dim=%d (the closed form of the sigma-point sums is "
-              "instantiated for the register-resident Lorenz-63 and linear shapes with a linear emission; num_iter 1)",
-              mdl->drift_kind, mdl->state_dim, mdl->emission_dim);
-    return CDKF_EUNSUPPORTED;
-  }
+  if (!ukf_grad_closed_form(mdl, o) || env_flag("CDKF_UKF_GRAD_TANGENT"))
+    return launch_ukf_tangent<R>(mdl, o, N, T, t, y, ll, grad, nullptr, status, stream);  // (names what it needs when it refuses)
 #define X(KIND, DRIFT, D_, M_)                                                    \
   if (mdl->drift_kind == KIND && mdl->state_dim == D_ && mdl->emission_dim == M_) \
     return run_grad<R, D_, M_, DRIFT<R, D_>>(mdl, o, N, T, t, y, ll, grad, status, stream, true);

@@ -336,6 +336,10 @@ void cdkf_rtc_cache_stats(int64_t* hits, int64_t* misses);
 /* run-time compiled register-resident kernel (custom drift, state / emission dimension <= 6): algo as cdkf_custom_drift_compile;
  * par_out receives the real-valued block (bytes_per_real each), ip_out[27] the integer block (26) followed by the grid size.
  * Returns the number of reals written or a negative CDKF_E* code. */
+/* the tangent sweep above: args_out receives its argument struct (UtArgs<real>, pointers null), par_out its parameter block; returns the
+ * number of reals in the block or a negative CDKF_E* code */
+int cdkf_debug_ukf_tangent_args(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T, int bytes_per_real, int all,
+                                void* args_out, int64_t args_cap_bytes, void* par_out, int64_t par_cap_bytes);
 int cdkf_debug_custom_reg_blob(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T, int algo, int bytes_per_real,
                                void* par_out, int64_t par_cap_bytes, int64_t* ip_out);
 /* workgroup-per-trajectory kernels (cdkf_wg2_kernels.h: any drift, state / emission dimension <= 64): args_out receives the kernel's
@@ -422,6 +426,15 @@ int cdkf_ukf_loglik_grad_all_f32_dev(const cdkf_model* mdl, const cdkf_opts* opt
                                      const float* y, float* ll, float* grad, float* grad_model, int32_t* status,
                                      void* stream);
 int cdkf_ukf_grad_all_supported(const cdkf_model* mdl, const cdkf_opts* opts);
+/* ... and for every model the closed forms do not cover -- an MLP drift, a drift or an emission given as source, the built-in drifts at
+ *      other shapes -- behind the SAME entry points (cdkf_ukf_loglik_grad_*, cdkf_ukf_loglik_grad_all_*): forward mode through the literal
+ *      sigma-point recursion, the Cholesky factor's derivative included, by dual numbers over the drift's / emission's statements
+ *      (cdkf_ukf_tangent_kernels.h; state_dim, emission_dim <= 16, fixed-step Dormand-Prince, inputs and time-dependent f / h as the
+ *      filters; a lane per (trajectory, leaf entry): a fallback, not a fast path).  With a custom emission the H / h_bias slots of
+ *      grad_model hold the gradient w.r.t. its parameter vector eta = [H | h_bias].  Replaces jax.value_and_grad through
+ *      unscented_kalman_filter, /root/reference/src/ssm_temissions.py:500, 555-568 -> inference_ukf.py:93-203.
+ *      cdkf_ukf_tangent_compile: the kernel a model would get, compiled for gfx950 without a GPU (CDKF_OK or the compiler's message). */
+int cdkf_ukf_tangent_compile(const cdkf_model* mdl, const cdkf_opts* opts, int bytes_per_real);
 /* ---- the same plus the gradient w.r.t. every other model parameter (the remaining leaves of the pytree jax.grad returns
  *      for ParamsCDNLGSSM): grad_model [N, d + 2 d^2 + m d + m + m^2] row-major, per trajectory
  *          m0 [d] | P0 [d,d] | LQL [d,d] | H [m,d] | h_bias [m] | R [m,m]

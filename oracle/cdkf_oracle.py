@@ -325,7 +325,7 @@ class CallableDrift:
 
     kind = "custom"
 
-    def __init__(self, theta, f, jac, divgrad=None, dtype=np.float64, vjp=None, gvjp=None, ut=False):
+    def __init__(self, theta, f, jac, divgrad=None, dtype=np.float64, vjp=None, gvjp=None, ut=False, dtheta=None):
         """ut=True: the callables are f(x, theta, u, t), jac(x, theta, u, t), ... with u [N, d_u] the interval's inputs and t [N] the
         stage time (module header: _CTX)."""
         self.dtype = np.dtype(dtype)
@@ -336,9 +336,10 @@ class CallableDrift:
         # what ekf_loglik_grad_adjoint needs of a drift it has no formulas for; gvjp(x, u [d], theta) -> (xbar, thetabar): the gradient
         # of u . grad(div f) (divgrad_vjp: state_order 'second')
         self._vjp, self._gvjp = vjp, gvjp
+        self._dth = dtheta   # dtheta(x, theta[, u, t]) -> [N, P, d]: d f / d theta (ukf_loglik_grad_all_literal's forward mode)
 
     def cast(self, dtype):
-        return CallableDrift(self.th, self._f, self._jac, self._g, dtype=dtype, vjp=self._vjp, gvjp=self._gvjp, ut=self.ut)
+        return CallableDrift(self.th, self._f, self._jac, self._g, dtype=dtype, vjp=self._vjp, gvjp=self._gvjp, ut=self.ut, dtheta=self._dth)
 
     def _extra(self, x):
         return _ctx_rows(x.shape[0]) if self.ut else ()
@@ -1543,6 +1544,195 @@ def ekf_loglik_grad_adjoint(mdl: Model, t, y, dt0=0.01, dt_final=1e-10, max_step
     extra["L"] = extra["LQL"] @ mdl.L @ mdl.Qc.T + np.swapaxes(extra["LQL"], -1, -2) @ mdl.L @ mdl.Qc
     extra["Qc"] = mdl.L.T @ extra["LQL"] @ mdl.L
     return ll_out, g_out, extra
+
+
+# --------------------------------------------------------------------------------------
+# the unscented filter's gradient for ANY drift / emission: forward mode through the literal sigma-point recursion
+# --------------------------------------------------------------------------------------
+def _drift_dtheta(drift, x):
+    """d f / d theta at x [B, d] -> [B, P, d] (the forward twin of drift_vjp's theta part)."""
+    B, d = x.shape
+    if drift.kind in ("lorenz63", "linear"):
+        return _drift_param_derivs(drift, x)[0]
+    if drift.kind == "lorenz96":
+        return np.ones((B, 1, d), x.dtype)
+    if drift.kind == "mlp":
+        W1, W2, W3 = drift.W1, drift.W2, drift.W3
+        a1, a2 = drift._fwd(x)
+        d1, d2 = 1 - a1 * a1, 1 - a2 * a2
+        A2 = W3[None] * d2[:, None, :]                                 # d f / d z2  [B, d, h2]
+        A1 = np.einsum("bip,pq->biq", A2, W2) * d1[:, None, :]         # d f / d z1  [B, d, h1]
+        eye = np.eye(d, dtype=x.dtype)
+        blocks = [np.einsum("biq,bk->bqki", A1, x).reshape(B, -1, d),                  # W1 [h1, d]
+                  np.swapaxes(A1, 1, 2),                                                   # b1
+                  np.einsum("bip,bq->bpqi", A2, a1).reshape(B, -1, d),                   # W2 [h2, h1]
+                  np.swapaxes(A2, 1, 2),                                                   # b2
+                  np.einsum("ij,bp->bjpi", eye, a2).reshape(B, -1, d),                   # W3 [d, h2]
+                  np.broadcast_to(eye, (B, d, d))]                                         # b3
+        return np.concatenate(blocks, axis=1)
+    if getattr(drift, "_dth", None) is not None:
+        return np.asarray(drift._dth(x, drift.th, *drift._extra(x)), dtype=x.dtype)
+    raise NotImplementedError("d f / d theta of a %s drift: give CallableDrift a dtheta callable" % drift.kind)
+
+
+def ukf_loglik_grad_all_literal(mdl: Model, t, y, alpha=math.sqrt(3), beta=2, kappa=1, dt0=0.01, dt_final=1e-10, max_steps=100000,
+                                inputs=None, h_eta=None):
+    """(ll [N], grad [N, n_theta], dict of the other leaves' gradients) of the UNSCENTED filter's marginal log-likelihood for ANY drift
+    and emission -- jax.value_and_grad through unscented_kalman_filter (ssm_temissions.py:500, 555-568 -> models.py:393-408, 708 ->
+    inference_ukf.py:93-203) -- by forward-mode tangents carried through the literal sigma-point recursion of ukf_filter above: the
+    Cholesky factor's tangent L' = L Phi(L^-1 sym(P') L^-T) (Phi: lower triangle, halved diagonal; jnp.linalg.cholesky symmetrises its
+    input), the sigma points' x' = m' +- c L'_i, the drift's f'(x) = F(x) x' + d f / d theta_p, the Dormand-Prince combination (linear),
+    the update's weighted sums, solves and log-density differentiated term by term.  One tangent per leaf ENTRY; symmetric leaves (P0,
+    L Qc L^T, R) are perturbed symmetrically and their cotangents returned symmetric, as ekf_loglik_grad_adjoint(full=True) does.
+    A non-linear emission (mdl.emission given as callables) uses its Jacobian mdl.Hjac(x) [B, m, d]; its parameters eta = [H | bias]
+    enter through h_eta(x) -> [B, m, m d + m] (d h / d eta) when given, else H and bias are the linear emission's.
+    Pinned by finite differences of ukf_filter (tests/test_oracle.py).  float64, fixed-step solvers."""
+    dtype = np.dtype(np.float64)
+    mdl = mdl.cast(dtype)
+    y = np.asarray(y, dtype)
+    N, T, _ = y.shape
+    d, mm = mdl.d, mdl.m
+    drift = mdl.drift
+    u = _inputs(inputs, N, T, dtype)
+    lamb, w_mean, w_cov, _W = ukf_weights(d, alpha, beta, kappa, dtype)
+    c = np.sqrt(dtype.type(d) + lamb)
+    S_ = 2 * d + 1
+    nth = drift.theta().size
+    iu_d, iu_m = np.triu_indices(d), np.triu_indices(mm)
+    npd, npm = len(iu_d[0]), len(iu_m[0])
+    linear_h = getattr(mdl, "emission", None) is None
+    sizes = [nth, d, npd, npd, mm * d, mm, npm]
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    Q = int(off[-1])
+    T_ = lambda A: np.swapaxes(A, -1, -2)
+    sym = lambda A: 0.5 * (A + T_(A))
+
+    def sym_seed(n, iu):
+        out = np.zeros((len(iu[0]), n, n), dtype)
+        for e, (i, j) in enumerate(zip(*iu)):
+            out[e, i, j] = out[e, j, i] = 1.0
+        return out
+
+    # tangents of the leaves: [Q, ...]
+    dm0 = np.zeros((Q, d), dtype); dm0[off[1]:off[2]] = np.eye(d)
+    dP0 = np.zeros((Q, d, d), dtype); dP0[off[2]:off[3]] = sym_seed(d, iu_d)
+    dLQL = np.zeros((Q, d, d), dtype); dLQL[off[3]:off[4]] = sym_seed(d, iu_d)
+    dH = np.zeros((Q, mm, d), dtype); dH[off[4]:off[5]] = np.eye(mm * d).reshape(mm * d, mm, d)
+    db = np.zeros((Q, mm), dtype); db[off[5]:off[6]] = np.eye(mm)
+    dR = np.zeros((Q, mm, mm), dtype); dR[off[6]:off[7]] = sym_seed(mm, iu_m)
+    LQL = _LQL(mdl)
+    H, bias, R = mdl.H, mdl.bias, mdl.R
+
+    def chol_t(P, dP):
+        """L [N,d,d], L' [N,Q,d,d] of sym(P)."""
+        L = cholesky_lower(sym(P))
+        Li = solve_lower(L, np.broadcast_to(np.eye(d, dtype=dtype), L.shape).copy())          # L^-1
+        M = Li[:, None] @ sym(dP) @ T_(Li)[:, None]
+        Phi = np.tril(M, -1) + 0.5 * M * np.eye(d)
+        return L, L[:, None] @ Phi
+
+    def sigmas_t(m, P, dm, dP):
+        L, dL = chol_t(P, dP)
+        cols, dcols = c * T_(L), c * T_(dL)                                # cols[n, i, :] = c L[:, i]
+        X = np.concatenate([m[:, None], m[:, None] + cols, m[:, None] - cols], axis=1)            # [N, S, d]
+        dX = np.concatenate([dm[:, :, None], dm[:, :, None] + dcols, dm[:, :, None] - dcols], axis=2)   # [N, Q, S, d]
+        return X, dX
+
+    def f_t(X, dX):
+        """f(X) [N,S,d] and its tangent [N,Q,S,d]."""
+        flat = X.reshape(-1, d)
+        fX = drift.f(flat).reshape(X.shape)
+        F = drift.jac(flat).reshape(X.shape + (d,))
+        dfX = np.einsum("nsij,nqsj->nqsi", F, dX)
+        if nth:
+            Jth = _drift_dtheta(drift, flat).reshape(N, S_, nth, d)       # [N, S, P, d]
+            dfX[:, :nth] += np.swapaxes(Jth, 1, 2)
+        return fX, dfX
+
+    def h_t(X, dX):
+        flat = X.reshape(-1, d)
+        if linear_h:
+            Y = X @ H.T + bias
+            dY = dX @ H.T + np.einsum("qij,nsj->nqsi", dH, X) + db[None, :, None, :]
+            return Y, dY
+        Y = mdl.h(flat).reshape(N, S_, mm)
+        Hx = np.asarray(mdl.Hjac(flat), dtype).reshape(N, S_, mm, d)
+        dY = np.einsum("nsij,nqsj->nqsi", Hx, dX)
+        if h_eta is not None:
+            He = np.asarray(h_eta(flat), dtype).reshape(N, S_, mm, mm * d + mm)
+            dY[:, off[4]:off[6]] += np.moveaxis(He, -1, 1)
+        return Y, dY
+
+    def rhs(yv):
+        m_t, P_t, dm_t, dP_t = yv
+        X, dX = sigmas_t(m_t, P_t, dm_t, dP_t)
+        fX, dfX = f_t(X, dX)
+        dm = np.einsum("nsi,s->ni", fX, w_mean)
+        ddm = np.einsum("nqsi,s->nqi", dfX, w_mean)
+        Xc, fc = X - m_t[:, None], fX - dm[:, None]
+        dXc, dfc = dX - dm_t[:, :, None], dfX - ddm[:, :, None]
+        foo = np.einsum("s,nsi,nsj->nij", w_cov, fc, Xc)
+        dfoo = np.einsum("s,nqsi,nsj->nqij", w_cov, dfc, Xc) + np.einsum("s,nsi,nqsj->nqij", w_cov, fc, dXc)
+        return dm, foo + T_(foo) + LQL, ddm, dfoo + T_(dfoo) + dLQL[None]
+
+    t0s, t1s = _t0_t1(t, dt_final, dtype)
+    m = np.broadcast_to(mdl.m0, (N, d)).copy()
+    P = np.broadcast_to(mdl.P0, (N, d, d)).copy()
+    dm = np.broadcast_to(dm0, (N, Q, d)).copy()
+    dP = np.broadcast_to(dP0, (N, Q, d, d)).copy()
+    ll = np.zeros(N, dtype)
+    g = np.zeros((N, Q), dtype)
+    eye_m = np.eye(mm, dtype=dtype)
+    for k in range(T):
+        _set_step(u, t0s, k)
+        X, dX = sigmas_t(m, P, dm, dP)
+        Y, dY = h_t(X, dX)
+        ym = np.einsum("s,nsj->nj", w_mean, Y)
+        dym = np.einsum("s,nqsj->nqj", w_mean, dY)
+        Yc, dYc = Y - ym[:, None], dY - dym[:, :, None]
+        Xc, dXc = X - m[:, None], dX - dm[:, :, None]
+        S = np.einsum("s,nsi,nsj->nij", w_cov, Yc, Yc) + R
+        dS = np.einsum("s,nqsi,nsj->nqij", w_cov, dYc, Yc)
+        dS = dS + T_(dS) + dR[None]
+        C = np.einsum("s,nsi,nsj->nij", w_cov, Xc, Yc)                                   # [N, d, m]
+        dC = np.einsum("s,nqsi,nsj->nqij", w_cov, dXc, Yc) + np.einsum("s,nsi,nqsj->nqij", w_cov, Xc, dYc)
+        v, dv = y[:, k] - ym, -dym
+        # log-density (S as given; its Cholesky factor symmetrises the input) and its tangent
+        Lc = cholesky_lower(sym(S))
+        Sinv = solve_upper_from_lower(Lc, solve_lower(Lc, np.broadcast_to(eye_m, S.shape).copy()))
+        w = np.einsum("nij,nj->ni", Sinv, v)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            ll = ll + (-0.5 * np.einsum("ni,ni->n", v, w) - np.sum(np.log(np.diagonal(Lc, axis1=-2, axis2=-1)), axis=-1)
+                       - 0.5 * mm * math.log(2 * math.pi))
+        dSs = sym(dS)
+        g = g + (-np.einsum("ni,nqi->nq", w, dv) + 0.5 * np.einsum("ni,nqij,nj->nq", w, dSs, w) - 0.5 * np.einsum("nij,nqji->nq", Sinv, dSs))
+        # gain K = psd_solve(S, C^T)^T: Sb = sym(S) + 1e-9 I;  X_ = Sb^-1 C^T  [N, m, d]
+        Sb = sym(S) + dtype.type(1e-9) * eye_m
+        Lb = cholesky_lower(Sb)
+        Xg = solve_upper_from_lower(Lb, solve_lower(Lb, T_(C)))
+        rhs_ = T_(dC) - dSs @ Xg[:, None]
+        Lbq = np.broadcast_to(Lb[:, None], (N, Q, mm, mm)).reshape(-1, mm, mm)
+        dXg = solve_upper_from_lower(Lbq, solve_lower(Lbq, rhs_.reshape(-1, mm, d))).reshape(N, Q, mm, d)
+        K, dK = T_(Xg), T_(dXg)
+        m_new = m + np.einsum("nij,nj->ni", K, v)
+        dm = dm + np.einsum("nqij,nj->nqi", dK, v) + np.einsum("nij,nqj->nqi", K, dv)
+        KS = K @ S
+        dP = dP - (dK @ T_(KS)[:, None] + K[:, None] @ dS @ T_(K)[:, None] + KS[:, None] @ T_(dK))
+        P = P - KS @ T_(K)
+        m = m_new
+        if k + 1 < T:   # (the last predict does not enter the log-likelihood)
+            m, P, dm, dP = diffeqsolve(rhs, t0s[:, k], t1s[:, k], (m, P, dm, dP), dt0, max_steps, err_components=2)
+
+    def unpack_sym(col, n, iu):
+        out = np.zeros((N, n, n), dtype)
+        for e, (i, j) in enumerate(zip(*iu)):
+            out[:, i, j] = out[:, j, i] = col[:, e] if i == j else 0.5 * col[:, e]
+        return out
+    extra = {"m0": g[:, off[1]:off[2]], "P0": unpack_sym(g[:, off[2]:off[3]], d, iu_d), "LQL": unpack_sym(g[:, off[3]:off[4]], d, iu_d),
+             "H": g[:, off[4]:off[5]].reshape(N, mm, d), "bias": g[:, off[5]:off[6]], "R": unpack_sym(g[:, off[6]:off[7]], mm, iu_m)}
+    extra["L"] = extra["LQL"] @ mdl.L @ mdl.Qc.T + T_(extra["LQL"]) @ mdl.L @ mdl.Qc
+    extra["Qc"] = mdl.L.T @ extra["LQL"] @ mdl.L
+    return ll, g[:, :nth], extra
 
 
 # --------------------------------------------------------------------------------------

@@ -241,3 +241,55 @@ def awg_run(include_src, mdl, opts, t, y, dtype, san, forward, *, inputs=None, n
     gm = np.frombuffer(raw, dtype, N * ngm, off).reshape(N, ngm).copy()
     off += N * ngm * dtype.itemsize
     return grad, gm, np.frombuffer(raw, np.int32, N, off).copy()
+
+
+def ut_run(mdl, opts, t, y, dtype, san, *, every_leaf=True, opt="-O1", inputs=None, timeout=3000):
+    """Run the tangent sweep of the literal unscented recursion (cdkf_ukf_tangent_kernels.h) on the host for this model: the
+    translation unit launch_custom.hip generates (cdkf_ukf_tangent_compile with CDKF_CUSTOM_DUMP; cross-compiles for gfx950 on the way).
+    t [N,T], y [N,T,m]; returns (ll [N], grad [N, n_theta], grad_model [N, .] or None, status [N])."""
+    from cd_dynamax_amd import _ffi
+    dtype = np.dtype(dtype)
+    N, T = t.shape
+    d, m, nth = mdl.state_dim, mdl.emission_dim, int(mdl.c.n_theta)
+    dump = tempfile.mkdtemp(prefix="cdkf_dump_")
+    os.environ["CDKF_CUSTOM_DUMP"] = dump
+    try:
+        rc = _ffi.lib().cdkf_ukf_tangent_compile(C.byref(mdl.c), C.byref(opts), dtype.itemsize)
+        if rc:
+            raise RuntimeError(_ffi.lib().cdkf_last_error().decode())
+    finally:
+        del os.environ["CDKF_CUSTOM_DUMP"]
+    src = [os.path.join(dump, f) for f in os.listdir(dump) if f.endswith(".hip")]
+    assert len(src) == 1, os.listdir(dump)
+    args = np.zeros(512, np.uint8)
+    par = np.zeros(65536, dtype)
+    n = _ffi.lib().cdkf_debug_ukf_tangent_args(C.byref(mdl.c), C.byref(opts), N, T, dtype.itemsize, 1 if every_leaf else 0,
+                                                args.ctypes.data_as(C.c_void_p), args.nbytes, par.ctypes.data_as(C.c_void_p), par.nbytes)
+    assert n > 0, _ffi.lib().cdkf_last_error().decode()
+    par = par[:n]
+    nargs = 8 * 8 + 8 * 11 + dtype.itemsize * 6 + 4   # 8 pointers, 11 longs, 6 reals, 1 int ...
+    nargs = (nargs + 7) // 8 * 8                       # ... padded to the struct's alignment
+    npd, npm = d * (d + 1) // 2, m * (m + 1) // 2
+    nleaf = nth + d + 2 * npd + m * d + m + npm if every_leaf else max(nth, 1)
+    gm_len = N * (d + 2 * d * d + m * d + m + m * m) if every_leaf else 0
+    tt, yy = np.ascontiguousarray(t, dtype), np.ascontiguousarray(y, dtype)
+    uu = None if inputs is None else np.ascontiguousarray(inputs, dtype)
+    head = np.array([(N * nleaf + 63) // 64, nargs, n, tt.size, yy.size, 0 if uu is None else uu.size, N * nth, gm_len], np.int64)
+    exe = build("ut_harness.cpp", src[0], san, opt)
+    with tempfile.TemporaryDirectory() as dd:
+        fin, fout = os.path.join(dd, "in.bin"), os.path.join(dd, "out.bin")
+        with open(fin, "wb") as f:
+            f.write(head.tobytes()); f.write(args[:nargs].tobytes()); f.write(par.tobytes()); f.write(tt.tobytes()); f.write(yy.tobytes())
+            if uu is not None:
+                f.write(uu.tobytes())
+        res = run(exe, fin, fout, timeout=timeout)
+        reports = sanitizer_reports(res.stderr)
+        if res.returncode != 0 or reports:
+            raise AssertionError(f"host run ({san}) rc={res.returncode}\n" + res.stderr[-8000:])
+        raw = open(fout, "rb").read()
+    off = 0
+    ll = np.frombuffer(raw, dtype, N, off).copy(); off += N * dtype.itemsize
+    grad = np.frombuffer(raw, dtype, N * nth, off).reshape(N, nth).copy(); off += N * nth * dtype.itemsize
+    gm = np.frombuffer(raw, dtype, gm_len, off).reshape(N, -1).copy() if gm_len else None; off += gm_len * dtype.itemsize
+    status = np.frombuffer(raw, np.int32, N, off).copy()
+    return ll, grad, gm, status
