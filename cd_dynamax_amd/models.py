@@ -332,8 +332,18 @@ def _grads_tree(params: ParamsCDNLGSSM, mdl: _ffi.ModelBlock, g_theta, g_model=N
         dynamics=ParamsCDNLGSSMDynamics(drift=_drift_like(params.dynamics.drift, g_theta),
                                         diffusion_coefficient=LearnableMatrix(g_L), diffusion_cov=LearnableMatrix(g_Qc),
                                         approx_order=0.0),
-        emissions=ParamsCDNLGSSMEmissions(emission_function=LearnableLinear(weights=g_H, bias=g_b),
+        emissions=ParamsCDNLGSSMEmissions(emission_function=_emission_like(params.emissions.emission_function, g_H, g_b),
                                           emission_cov=LearnableMatrix(g_R)))
+
+
+def _emission_like(h, g_H, g_b):
+    """The emission leaf of a gradient tree: LearnableLinear(weights, bias), or -- for a LearnableCustomEmission, whose parameter vector
+    eta travels in the H / bias block of the C model -- the same class with d ll / d eta."""
+    if isinstance(h, LearnableCustomEmission):
+        n = int(np.atleast_1d(np.asarray(h.eta)).size)
+        flat = np.concatenate([g_H.reshape(g_H.shape[:-2] + (-1,)), g_b], axis=-1)
+        return LearnableCustomEmission(eta=flat[..., :n], h_src=h.h_src, hjac_src=h.hjac_src, py_h=h.py_h)
+    return LearnableLinear(weights=g_H, bias=g_b)
 
 
 def cdnlgssm_loglik_and_grad(
@@ -376,7 +386,8 @@ def cdnlgssm_loglik_and_grad(
             f"no {'unscented-filter ' if ukf else ''}gradient kernel for drift {type(params.dynamics.drift).__name__} with "
             f"state_dim={mdl.state_dim}, emission_dim={mdl.emission_dim}"
             + ("" if ukf else f", state_order={hyperparams.state_order}")
-            + (" (the closed form of the sigma-point sums: LearnableLorenz63 / LearnableLinear at the register-resident shapes)" if ukf else ""))
+            + (" (the unscented gradient: closed forms for LearnableLorenz63 / LearnableLorenz96 / LearnableLinear, the tangent sweep of the literal "
+               "recursion for everything else with state_dim, emission_dim <= 16 and the default solver)" if ukf else ""))
     if on_device:  # ll and the per-trajectory gradient stay on the device (torch tensors)
         ll, grad, _ = _device.loglik_grad_device(mdl, opts, t, y, False, ukf=ukf)
     else:
@@ -416,12 +427,13 @@ def cdnlgssm_loglik_and_grad_all(
     _attach_inputs(mdl, opts, inputs, y, dtype)
     if ukf:
         # the unscented filter, every leaf (cdkf_ukf_loglik_grad_all_*): the reverse sweeps over its moment equations in closed form --
-        # exact for the quadratic Lorenz-63 / Lorenz-96 drifts and the linear one (inference_ukf.py:93-203 differentiated by JAX)
+        # exact for the quadratic Lorenz-63 / Lorenz-96 drifts and the linear one -- and, for every other model (an MLP drift, a drift or
+        # an emission given as source), forward mode through the literal sigma-point recursion (inference_ukf.py:93-203 differentiated by JAX)
         if not _ffi.lib().cdkf_ukf_grad_all_supported(_ffi.C.byref(mdl.c), _ffi.C.byref(opts)):
             raise NotImplementedError(
-                f"no unscented-filter reverse-sweep kernel for drift {type(params.dynamics.drift).__name__} with state_dim={mdl.state_dim}, "
-                f"emission_dim={mdl.emission_dim} (the sigma-point sums have a closed form for LearnableLorenz63, LearnableLorenz96 and "
-                "LearnableLinear; linear emission, default solver)")
+                f"no unscented-filter gradient kernel for drift {type(params.dynamics.drift).__name__} with state_dim={mdl.state_dim}, "
+                f"emission_dim={mdl.emission_dim} (closed forms: LearnableLorenz63, LearnableLorenz96, LearnableLinear with a linear emission; "
+                "the tangent sweep of the literal recursion: any drift / emission with state_dim, emission_dim <= 16; default solver)")
         if on_device:
             ll, gth, _, gm = (x.cpu().numpy() for x in _device.loglik_grad_device(mdl, opts, t, y, True, ukf=True))
         else:

@@ -96,8 +96,8 @@ def reg_run(src_path, mdl, opts, t, y, algo, dtype, san, outs, opt="-O1", inputs
     N, T = t.shape
     par = np.zeros(4096, dtype)
     ip = np.zeros(27, np.int64)
-    n = _ffi.lib().cdkf_debug_custom_reg_blob(C.byref(mdl.c), C.byref(opts), N, T, algo, dtype.itemsize, par.ctypes.data_as(C.c_void_p),
-                                               par.nbytes, ip.ctypes.data_as(C.POINTER(C.c_int64)))
+    n = _ffi.lib().cdkf_debug_custom_reg_blob(C.byref(mdl.c), C.byref(opts), C.c_int64(N), C.c_int64(T), algo, dtype.itemsize, par.ctypes.data_as(C.c_void_p),
+                                               C.c_int64(par.nbytes), ip.ctypes.data_as(C.POINTER(C.c_int64)))
     assert n > 0, _ffi.lib().cdkf_last_error().decode()
     par = par[:n]
     head = np.zeros(16, np.int64)
@@ -146,8 +146,8 @@ def wg_run(include_src, mdl, opts, t, y, dtype, san, *, ukf=False, kind=-1, smoo
     args = np.zeros(8192, np.uint8)
     blob = np.zeros(1 << 18, dtype)
     geom = np.zeros(6, np.int64)
-    n = _ffi.lib().cdkf_debug_wg_args(C.byref(mdl.c), C.byref(opts), N, T, dtype.itemsize, int(ukf), int(smoother), args.ctypes.data_as(C.c_void_p),
-                                       args.nbytes, blob.ctypes.data_as(C.c_void_p), blob.nbytes, geom.ctypes.data_as(C.POINTER(C.c_int64)))
+    n = _ffi.lib().cdkf_debug_wg_args(C.byref(mdl.c), C.byref(opts), C.c_int64(N), C.c_int64(T), dtype.itemsize, int(ukf), int(smoother), args.ctypes.data_as(C.c_void_p),
+                                       C.c_int64(args.nbytes), blob.ctypes.data_as(C.c_void_p), C.c_int64(blob.nbytes), geom.ctypes.data_as(C.POINTER(C.c_int64)))
     assert n > 0, _ffi.lib().cdkf_last_error().decode()
     ept, threads, lds, asz = (int(v) for v in geom[:4])
     tt, yy = np.ascontiguousarray(t, dtype), np.ascontiguousarray(y, dtype)
@@ -206,8 +206,8 @@ def awg_run(include_src, mdl, opts, t, y, dtype, san, forward, *, inputs=None, n
     args = np.zeros(8192, np.uint8)
     blob = np.zeros(1 << 18, dtype)
     geom = np.zeros(6, np.int64)
-    n = _ffi.lib().cdkf_debug_wg_args(C.byref(mdl.c), C.byref(opts), N, T, dtype.itemsize, 0, 2, args.ctypes.data_as(C.c_void_p),
-                                       args.nbytes, blob.ctypes.data_as(C.c_void_p), blob.nbytes, geom.ctypes.data_as(C.POINTER(C.c_int64)))
+    n = _ffi.lib().cdkf_debug_wg_args(C.byref(mdl.c), C.byref(opts), C.c_int64(N), C.c_int64(T), dtype.itemsize, 0, 2, args.ctypes.data_as(C.c_void_p),
+                                       C.c_int64(args.nbytes), blob.ctypes.data_as(C.c_void_p), C.c_int64(blob.nbytes), geom.ctypes.data_as(C.POINTER(C.c_int64)))
     assert n > 0, _ffi.lib().cdkf_last_error().decode()
     ne, threads, lds, asz, ws_stride, cap = (int(v) for v in geom)
     n_theta = int(mdl.c.n_theta) if n_theta is None else n_theta
@@ -263,8 +263,8 @@ def ut_run(mdl, opts, t, y, dtype, san, *, every_leaf=True, opt="-O1", inputs=No
     assert len(src) == 1, os.listdir(dump)
     args = np.zeros(512, np.uint8)
     par = np.zeros(65536, dtype)
-    n = _ffi.lib().cdkf_debug_ukf_tangent_args(C.byref(mdl.c), C.byref(opts), N, T, dtype.itemsize, 1 if every_leaf else 0,
-                                                args.ctypes.data_as(C.c_void_p), args.nbytes, par.ctypes.data_as(C.c_void_p), par.nbytes)
+    n = _ffi.lib().cdkf_debug_ukf_tangent_args(C.byref(mdl.c), C.byref(opts), C.c_int64(N), C.c_int64(T), dtype.itemsize, 1 if every_leaf else 0,
+                                                args.ctypes.data_as(C.c_void_p), C.c_int64(args.nbytes), par.ctypes.data_as(C.c_void_p), C.c_int64(par.nbytes))
     assert n > 0, _ffi.lib().cdkf_last_error().decode()
     par = par[:n]
     nargs = 8 * 8 + 8 * 11 + dtype.itemsize * 6 + 4   # 8 pointers, 11 longs, 6 reals, 1 int ...

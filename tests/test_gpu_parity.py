@@ -568,10 +568,10 @@ def test_unscented_loglik_gradient(hip_lib):
     bad = o.Model(mdl3.drift, mdl3.L, mdl3.Qc, mdl3.H, mdl3.bias, mdl3.R, mdl3.m0, np.diag([1.0, -1.0, 1.0]))
     ll_b, _ = cd.cdnlgssm_loglik_and_grad(params_from(bad), y3[:2], t3[:2, :, None], cd.UKFHyperParams())
     assert np.isnan(ll_b).all()
-    # refusals: no closed form for this drift (the MLP is not quadratic)
+    # refusals: no closed form for this drift (the MLP is not quadratic) and beyond the tangent sweep's sixteen dimensions (tests/test_ukf_tangent.py)
     from helpers import mlp_model
     with pytest.raises(NotImplementedError):
-        cd.cdnlgssm_loglik_and_grad(params_from(mlp_model(rng, 4, 2, 8)), np.zeros((2, 5, 2)), np.arange(5.0)[None, :, None].repeat(2, 0), cd.UKFHyperParams())
+        cd.cdnlgssm_loglik_and_grad(params_from(mlp_model(rng, 20, 2, 8)), np.zeros((2, 5, 2)), np.arange(5.0)[None, :, None].repeat(2, 0), cd.UKFHyperParams())
 
 
 @pytest.mark.parametrize("kind,d,m", [("lorenz63", 3, 1), ("lorenz63", 3, 2), ("lorenz63", 3, 3), ("lorenz96", 6, 3), ("lorenz96", 12, 5),

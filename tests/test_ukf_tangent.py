@@ -1,0 +1,319 @@
+"""The unscented filter's gradient for ANY drift / emission: forward mode through the literal sigma-point recursion --
+cdkf_ukf_tangent_kernels.h behind cdkf_ukf_loglik_grad_* / cdkf_ukf_loglik_grad_all_* -- against the oracle's ukf_loglik_grad_all_literal
+(explicit tangent formulas in NumPy: Cholesky tangent, F x' + df/dtheta, differentiated solves), itself pinned by finite differences of
+ukf_filter and by the closed-form adjoint on the drifts that have one.  What the reference computes with jax.value_and_grad through
+unscented_kalman_filter (ssm_temissions.py:500, 555-568 -> models.py:393-408, 708 -> inference_ukf.py:93-203)."""
+import os
+
+import numpy as np
+import pytest
+
+import cdkf_oracle as o
+import cd_dynamax_amd as cd
+from cd_dynamax_amd import _ffi, models
+from helpers import mlp_model, params_from, random_quadratic_drift
+
+LEAVES = ("m0", "P0", "L", "Qc", "H", "bias", "R")
+
+
+def dense_model(rng, drift, d, m, scale=0.0):
+    A, B, Cm = rng.standard_normal((d, d)), rng.standard_normal((m, m)), rng.standard_normal((d, d))
+    return o.Model(drift, np.eye(d) + 0.1 * rng.standard_normal((d, d)), A @ A.T / d * 0.3 + 0.3 * np.eye(d), rng.standard_normal((m, d)) / np.sqrt(d),
+                   0.1 * rng.standard_normal(m), B @ B.T / m * 0.5 + 0.3 * np.eye(m), scale + 0.5 * rng.standard_normal(d), Cm @ Cm.T / d * 0.5 + 0.5 * np.eye(d))
+
+
+def mlp_drift(rng, d, h1, h2):
+    W = lambda a, b: rng.standard_normal((a, b)) / np.sqrt(b)
+    return o.MLPDrift(W(h1, d), 0.1 * rng.standard_normal(h1), W(h2, h1), 0.1 * rng.standard_normal(h2), W(d, h2), 0.1 * rng.standard_normal(d))
+
+
+def with_dtheta(drift):
+    """The oracle-side twin of a random_quadratic_drift (affine in its two parameters): d f / d theta_p = f(theta + e_p) - f(theta)."""
+    f = drift._f
+
+    def dth(x, th, *extra):
+        base = f(x, th, *extra)
+        return np.stack([f(x, th + np.eye(th.size)[p], *extra) - base for p in range(th.size)], axis=1)
+    return o.CallableDrift(drift.th, drift._f, drift._jac, drift._g, vjp=drift._vjp, gvjp=drift._gvjp, ut=drift.ut, dtheta=dth)
+
+
+def close(a, b, name, tol):
+    sc = np.abs(b).max() + 1e-300
+    assert np.abs(np.asarray(a) - b).max() < tol * sc, (name, np.abs(np.asarray(a) - b).max() / sc)
+
+
+def grads_flat(g, N):
+    return np.concatenate([np.asarray(a).reshape(N, -1) for a in g.dynamics.drift], axis=-1)
+
+
+def check_tree(g, g_ref, ex, N, tol):
+    close(grads_flat(g, N), g_ref, "drift", tol)
+    close(g.initial.mean.params, ex["m0"], "m0", tol)
+    close(g.initial.cov.params, ex["P0"], "P0", tol)
+    close(g.dynamics.diffusion_coefficient.params, ex["L"], "L", tol)
+    close(g.dynamics.diffusion_cov.params, ex["Qc"], "Qc", tol)
+    close(g.emissions.emission_cov.params, ex["R"], "R", tol)
+
+
+# ---- the oracle ------------------------------------------------------------------------------------------------------------------
+def test_literal_tangent_oracle_equals_the_closed_form_adjoint_where_there_is_one():
+    """Two derivations of one derivative: forward tangents through the literal sigma-point recursion vs the discrete adjoint of the
+    closed-form moment equations (ukf_loglik_grad_all), Lorenz-63 and Lorenz-96, every leaf, 1e-11."""
+    rng = np.random.default_rng(41)
+    for drift, d, m, scale in ((o.Lorenz63Drift(10.0, 28.0, 8.0 / 3.0), 3, 2, 1.0), (o.Lorenz96Drift(8.0), 5, 3, 8.0)):
+        mdl = dense_model(rng, drift, d, m, scale)
+        t = o.irregular_times(rng, 2, 6, 0.1)
+        y = o.simulate(mdl, t, rng)
+        ll, g, ex = o.ukf_loglik_grad_all_literal(mdl, t, y)
+        ll2, g2, ex2 = o.ukf_loglik_grad_all(mdl, t, y)
+        np.testing.assert_allclose(ll, ll2, rtol=1e-12)
+        np.testing.assert_allclose(ll, o.ukf_filter(mdl, t, y)["marginal_loglik"], rtol=1e-13)
+        close(g, g2, "theta", 1e-11)
+        for k in LEAVES + ("LQL",):
+            close(ex[k], ex2[k], k, 1e-11)
+
+
+def test_literal_tangent_oracle_matches_finite_differences_mlp_and_nonlinear_emission():
+    """... and where there is none: an MLP drift (every weight), and a non-linear emission h = eta_0 sin(x_0) + eta_1 x_1^2 + eta_2 with
+    its parameters, by central finite differences of ukf_filter along random directions (symmetric ones for the covariances)."""
+    rng = np.random.default_rng(42)
+    d, m = 3, 2
+    dr = mlp_drift(rng, d, 4, 3)
+    mdl = dense_model(rng, dr, d, m)
+    N, T = 2, 6
+    t = o.irregular_times(rng, N, T, 0.3)
+    y = o.simulate(mdl, t, rng)
+    ll, g, ex = o.ukf_loglik_grad_all_literal(mdl, t, y)
+    th0 = dr.theta()
+    sizes = np.cumsum([4 * d, 4, 3 * 4, 3, d * 3])
+
+    def with_(**kw):
+        parts = np.split(kw.get("theta", th0), sizes)
+        drift = o.MLPDrift(parts[0].reshape(4, d), parts[1], parts[2].reshape(3, 4), parts[3], parts[4].reshape(d, 3), parts[5])
+        g_ = lambda k, v: kw.get(k, v)
+        return o.Model(drift, g_("L", mdl.L), g_("Qc", mdl.Qc), g_("H", mdl.H), g_("bias", mdl.bias), g_("R", mdl.R), g_("m0", mdl.m0), g_("P0", mdl.P0))
+
+    h = 1e-6
+    sym = lambda M: 0.5 * (M + M.T)
+    for name, base, grad, symm in [("theta", th0, g, False), ("m0", mdl.m0, ex["m0"], False), ("P0", mdl.P0, ex["P0"], True), ("L", mdl.L, ex["L"], False),
+                                   ("Qc", mdl.Qc, ex["Qc"], True), ("H", mdl.H, ex["H"], False), ("bias", mdl.bias, ex["bias"], False), ("R", mdl.R, ex["R"], True)]:
+        for _ in range(2):
+            u = rng.standard_normal(np.shape(base))
+            u = sym(u) if symm else u
+            fd = (o.ukf_filter(with_(**{name: base + h * u}), t, y)["marginal_loglik"] - o.ukf_filter(with_(**{name: base - h * u}), t, y)["marginal_loglik"]) / (2 * h)
+            an = (np.asarray(grad).reshape(N, -1) * u.reshape(1, -1)).sum(-1)
+            assert np.abs(an - fd).max() < 2e-6 * max(1.0, np.abs(fd).max()), (name, an, fd)
+    # a non-linear emission with parameters (eta travels in the H / bias block: eta = [H.ravel() | bias])
+    d, m = 2, 1
+    h_fn = lambda x, eta: (eta[0] * np.sin(x[..., 0]) + eta[1] * x[..., 1] ** 2 + eta[2])[..., None]
+    h_jac = lambda x, eta: np.stack([eta[0] * np.cos(x[..., 0]), 2 * eta[1] * x[..., 1]], -1)[..., None, :]
+    h_eta = lambda x: np.stack([np.sin(x[..., 0]), x[..., 1] ** 2, np.ones(x.shape[0])], -1)[:, None, :]
+    eta0 = np.array([1.3, 0.4, -0.2])
+    mk = lambda eta: o.Model(o.LinearDrift(np.array([[-0.3, 1.0], [-1.0, -0.2]]), np.array([0.1, 0.0])), np.eye(2), 0.2 * np.eye(2), eta[:2].reshape(1, 2),
+                             eta[2:], np.array([[0.3]]), np.array([0.5, -0.4]), 0.4 * np.eye(2) + 0.1, emission=(h_fn, h_jac))
+    t = o.irregular_times(rng, N, T, 0.5)
+    y = o.simulate(mk(eta0), t, rng)
+    ll, g, ex = o.ukf_loglik_grad_all_literal(mk(eta0), t, y, h_eta=h_eta)
+    np.testing.assert_allclose(ll, o.ukf_filter(mk(eta0), t, y)["marginal_loglik"], rtol=1e-12)
+    an = np.concatenate([ex["H"].reshape(N, -1), ex["bias"]], -1)
+    for p in range(3):
+        e = 1e-6 * np.eye(3)[p]
+        fd = (o.ukf_filter(mk(eta0 + e), t, y)["marginal_loglik"] - o.ukf_filter(mk(eta0 - e), t, y)["marginal_loglik"]) / 2e-6
+        assert np.abs(an[:, p] - fd).max() < 2e-6 * max(1.0, np.abs(fd).max()), (p, an[:, p], fd)
+
+
+# ---- the kernel on the host (CPU sanitizers) ---------------------------------------------------------------------------------------
+def test_tangent_sweep_on_the_host_under_asan_equals_the_oracle():
+    """The generated translation unit (an MLP drift, d = 4) compiled for x86-64 with -DCDKF_HOST_SIM under ASan + UBSan
+    (tests/hostsim_util.py: ut_run), every leaf against ukf_loglik_grad_all_literal at 1e-11 -- no GPU involved; the same source the GPU runs."""
+    import hostsim_util as hs
+    if hs.clang() is None:
+        pytest.skip("no clang++ for the host build")
+    rng = np.random.default_rng(43)
+    mdl_o = dense_model(rng, mlp_drift(rng, 4, 5, 3), 4, 2)
+    N, T = 2, 5
+    t = o.irregular_times(rng, N, T, 0.3)
+    y = o.simulate(mdl_o, t, rng)
+    mdl = models._model_block(params_from(mdl_o))
+    opts = models._opts(cd.UKFHyperParams(), 1)
+    ll, g, gm, st = hs.ut_run(mdl, opts, t, y, np.float64, "asan")
+    ll_r, g_r, ex = o.ukf_loglik_grad_all_literal(mdl_o, t, y)
+    assert (st == 0).all()
+    np.testing.assert_allclose(ll, ll_r, rtol=1e-12)
+    close(g, g_r, "theta", 1e-11)
+    d, m, off = 4, 2, 0
+    for k, shape in (("m0", (d,)), ("P0", (d, d)), ("LQL", (d, d)), ("H", (m, d)), ("bias", (m,)), ("R", (m, m))):
+        n = int(np.prod(shape))
+        close(gm[:, off:off + n].reshape((N,) + shape), ex[k], k, 1e-11)
+        off += n
+    # the drift block alone (a lane per drift parameter)
+    ll2, g2, gm2, _ = hs.ut_run(mdl, opts, t, y, np.float64, "plain", every_leaf=False)
+    assert gm2 is None
+    close(g2, g_r, "theta alone", 1e-11)
+
+
+def test_tangent_sweep_cross_compiles_and_gates():
+    """cdkf_ukf_tangent_compile builds the kernel of a d = 12 source drift for gfx950 without a GPU; the gate says yes to what the
+    sweep takes and the launcher names what it needs otherwise."""
+    rng = np.random.default_rng(44)
+    src, make = random_quadratic_drift(rng, 12)
+    mdl_o = dense_model(rng, make(np.array([0.7, 0.1])), 12, 5)
+    P = params_from(o.Model(o.Lorenz96Drift(8.0), mdl_o.L, mdl_o.Qc, mdl_o.H, mdl_o.bias, mdl_o.R, mdl_o.m0, mdl_o.P0))
+    P = P._replace(dynamics=P.dynamics._replace(drift=cd.LearnableCustomDrift(np.array([0.7, 0.1]), src, None, None)))
+    mdl = models._model_block(P)
+    opts = models._opts(cd.UKFHyperParams(), 1)
+    L = _ffi.lib()
+    assert L.cdkf_ukf_tangent_compile(_ffi.C.byref(mdl.c), _ffi.C.byref(opts), 8) == 0, L.cdkf_last_error().decode()
+    assert L.cdkf_ukf_grad_all_supported(_ffi.C.byref(mdl.c), _ffi.C.byref(opts)) == 1
+    assert L.cdkf_ukf_grad_supported(_ffi.C.byref(mdl.c), _ffi.C.byref(opts)) == 1
+    opts.adaptive = 1
+    assert L.cdkf_ukf_grad_all_supported(_ffi.C.byref(mdl.c), _ffi.C.byref(opts)) == 0
+    assert L.cdkf_ukf_tangent_compile(_ffi.C.byref(mdl.c), _ffi.C.byref(opts), 8) != 0
+    assert "fixed-step" in L.cdkf_last_error().decode()
+    big = models._model_block(params_from(mlp_model(rng, 20, 4, 8)))
+    opts.adaptive = 0
+    assert L.cdkf_ukf_grad_all_supported(_ffi.C.byref(big.c), _ffi.C.byref(opts)) == 0   # beyond sixteen dimensions: refused, by name
+    assert L.cdkf_ukf_tangent_compile(_ffi.C.byref(big.c), _ffi.C.byref(opts), 8) != 0 and "<= 16" in L.cdkf_last_error().decode()
+
+
+# ---- the kernel on the GPU ---------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_unscented_gradient_of_an_mlp_model_every_leaf(hip_lib):
+    """MLP drift, d = 8 (config 5's state dimension), ragged hidden sizes: every leaf at 1e-8 of its scale; the value is the sigma-point
+    filter's own log-likelihood; fp32; fit_sgd's first step over every leaf and a short fit_mcmc, both with UKFHyperParams."""
+    from cd_dynamax_amd import fit
+    rng = np.random.default_rng(45)
+    d, m = 8, 4
+    mdl = dense_model(rng, mlp_drift(rng, d, 12, 9), d, m)
+    N, T = 3, 8
+    t = o.irregular_times(rng, N, T, 0.2)
+    y = o.simulate(mdl, t, rng)
+    P = params_from(mdl)
+    ll_r, g_r, ex = o.ukf_loglik_grad_all_literal(mdl, t, y)
+    ll, g = cd.cdnlgssm_loglik_and_grad_all(P, y, t[..., None], cd.UKFHyperParams())
+    assert _ffi.lib().cdkf_last_kernel().decode().startswith("ukf_tangent_kernel<double>")
+    np.testing.assert_allclose(ll, ll_r, rtol=1e-10)
+    np.testing.assert_allclose(ll, cd.cdnlgssm_filter(P, y, t[..., None], cd.UKFHyperParams(), output_fields=[]).marginal_loglik, rtol=1e-9)
+    check_tree(g, g_r, ex, N, 1e-8)
+    close(g.emissions.emission_function.weights, ex["H"], "H", 1e-8)
+    close(g.emissions.emission_function.bias, ex["bias"], "bias", 1e-8)
+    ll_d, g_d = cd.cdnlgssm_loglik_and_grad(P, y, t[..., None], cd.UKFHyperParams())       # the drift block alone
+    close(np.concatenate([np.asarray(a).reshape(N, -1) for a in g_d], axis=-1), g_r, "drift block", 1e-8)
+    ll32, g32 = cd.cdnlgssm_loglik_and_grad_all(P, y.astype(np.float32), t[..., None].astype(np.float32), cd.UKFHyperParams())
+    assert ll32.dtype == np.float32
+    np.testing.assert_allclose(ll32, ll_r, rtol=1e-5)
+    close(grads_flat(g32, N), g_r, "drift fp32", 2e-3)
+    # fit_sgd, every leaf, the unscented objective: the first plain-SGD step on the drift is the oracle's gradient
+    free = cd.ParameterProperties()
+    frozen = cd.ParameterProperties(trainable=False)
+    props = P._replace(
+        initial=P.initial._replace(mean=cd.LearnableVector(free), cov=cd.LearnableMatrix(frozen)),
+        dynamics=P.dynamics._replace(drift=type(P.dynamics.drift)(*([free] * len(P.dynamics.drift))), diffusion_coefficient=cd.LearnableMatrix(frozen),
+                                     diffusion_cov=cd.LearnableMatrix(frozen), approx_order=frozen),
+        emissions=P.emissions._replace(emission_function=cd.LearnableLinear(free, free), emission_cov=cd.LearnableMatrix(frozen)))
+    model = cd.ContDiscreteNonlinearGaussianSSM(d, m)
+    lr = 1e-2
+    new, losses = model.fit_sgd(P, props, y, t[..., None], cd.UKFHyperParams(), optimizer=fit.SGD(lr), batch_size=N, num_epochs=1)
+    np.testing.assert_allclose(losses[0], -ll_r.sum() / y.size, rtol=1e-9)
+    np.testing.assert_allclose(np.asarray(new.dynamics.drift.b3), mdl.drift.b3 + lr * g_r[:, -d:].sum(0) / y.size, rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(np.asarray(new.initial.mean.params), mdl.m0 + lr * ex["m0"].sum(0) / y.size, rtol=1e-7, atol=1e-10)
+    out = model.fit_mcmc(P, props, y, t[..., None], cd.UKFHyperParams(), n_mcmc_samples=4,
+                         mcmc_algorithm={"type": "hmc", "parameters": {"num_steps": 4, "num_integration_steps": 2}}, verbose=False, key=2)
+    assert np.asarray(out[1].initial.mean.params).shape == (4, d) and np.all(np.isfinite(out[3]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,m", [(6, 3), (12, 5)])
+def test_unscented_gradient_of_a_source_drift_every_leaf(hip_lib, d, m):
+    """A drift given as C source (random sparse quadratic, pow / temporaries / loops), d = 6 (the register-resident filters' range) and
+    d = 12 (the workgroup filters'): every leaf at 1e-8; the value is the unscented filter's own."""
+    rng = np.random.default_rng(460 + d)
+    src, make = random_quadratic_drift(rng, d)
+    theta = np.array([0.7, 0.15])
+    mdl = dense_model(rng, with_dtheta(make(theta)), d, m)
+    N, T = 3, 7
+    t = o.irregular_times(rng, N, T, 0.15)
+    y = o.simulate(mdl, t, rng)
+    P0 = params_from(o.Model(o.Lorenz96Drift(8.0) if d >= 4 else o.Lorenz63Drift(), mdl.L, mdl.Qc, mdl.H, mdl.bias, mdl.R, mdl.m0, mdl.P0))
+    P = P0._replace(dynamics=P0.dynamics._replace(drift=cd.LearnableCustomDrift(theta, src, None, None)))
+    ll_r, g_r, ex = o.ukf_loglik_grad_all_literal(mdl, t, y)
+    ll, g = cd.cdnlgssm_loglik_and_grad_all(P, y, t[..., None], cd.UKFHyperParams())
+    assert _ffi.lib().cdkf_last_kernel().decode().startswith("ukf_tangent_kernel<double>")
+    np.testing.assert_allclose(ll, ll_r, rtol=1e-10)
+    np.testing.assert_allclose(ll, cd.cdnlgssm_filter(P, y, t[..., None], cd.UKFHyperParams(), output_fields=[]).marginal_loglik, rtol=1e-9)
+    close(np.asarray(g.dynamics.drift.theta), g_r, "theta", 1e-8)
+    for got, k in ((g.initial.mean.params, "m0"), (g.initial.cov.params, "P0"), (g.dynamics.diffusion_coefficient.params, "L"),
+                   (g.dynamics.diffusion_cov.params, "Qc"), (g.emissions.emission_function.weights, "H"), (g.emissions.emission_function.bias, "bias"),
+                   (g.emissions.emission_cov.params, "R")):
+        close(got, ex[k], k, 1e-8)
+    ll_d, g_d = cd.cdnlgssm_loglik_and_grad(P, y, t[..., None], cd.UKFHyperParams())
+    close(np.asarray(g_d.theta), g_r, "drift block", 1e-8)
+
+
+@pytest.mark.gpu
+def test_unscented_gradient_with_inputs_time_and_a_source_emission(hip_lib):
+    """f(x, u, t) and h(x, eta, u, t) given as source: a driven pendulum (the input enters the drift, the forcing's phase the time) observed
+    through eta_0 sin(x_0) + eta_1 u_0 t: every leaf including the emission's parameters, against the oracle's literal tangents."""
+    rng = np.random.default_rng(47)
+    d, m, N, T = 2, 1, 3, 9
+    f_src = "fx[0] = x[1]; fx[1] = -theta[0] * sin(x[0]) - theta[1] * x[1] + theta[2] * u[0] * cos(t);"
+    h_src = "hx[0] = eta[0] * sin(x[0]) + eta[1] * u[0] * t + eta[2];"
+    theta, eta = np.array([2.0, 0.3, 0.8]), np.array([1.2, 0.05, -0.1])
+    f_np = lambda x, th, u, t: np.stack([x[..., 1], -th[0] * np.sin(x[..., 0]) - th[1] * x[..., 1] + th[2] * u[..., 0] * np.cos(t)], -1)
+
+    def jac_np(x, th, u, t):
+        J = np.zeros(x.shape + (2,))
+        J[..., 0, 1] = 1.0
+        J[..., 1, 0] = -th[0] * np.cos(x[..., 0])
+        J[..., 1, 1] = -th[1]
+        return J
+    dth_np = lambda x, th, u, t: np.stack([np.stack([np.zeros(x.shape[0]), -np.sin(x[..., 0])], -1), np.stack([np.zeros(x.shape[0]), -x[..., 1]], -1),
+                                           np.stack([np.zeros(x.shape[0]), u[..., 0] * np.cos(t)], -1)], axis=1)
+    h_np = lambda x, e, u, t: (e[0] * np.sin(x[..., 0]) + e[1] * u[..., 0] * t + e[2])[..., None]
+    hj_np = lambda x, e, u, t: np.stack([e[0] * np.cos(x[..., 0]), np.zeros(x.shape[0])], -1)[..., None, :]
+    drift = o.CallableDrift(theta, f_np, jac_np, None, ut=True, dtheta=dth_np)
+    mdl = o.Model(drift, np.eye(2), np.array([[0.05, 0.01], [0.01, 0.1]]), eta[:2].reshape(1, 2), eta[2:], np.array([[0.2]]), np.array([0.8, -0.3]),
+                  np.array([[0.3, 0.05], [0.05, 0.4]]), emission=(h_np, hj_np), emission_ut=True)
+    t = o.irregular_times(rng, N, T, 1.5)
+    u = rng.standard_normal((N, T, 1))
+    y = o.simulate(mdl, t, rng)
+
+    def h_eta(x):
+        uu, tt = o._ctx_rows(x.shape[0])
+        return np.stack([np.sin(x[..., 0]), uu[..., 0] * tt, np.ones(x.shape[0])], -1)[:, None, :]
+    ll_r, g_r, ex = o.ukf_loglik_grad_all_literal(mdl, t, y, inputs=u, h_eta=h_eta)
+    np.testing.assert_allclose(ll_r, o.ukf_filter(mdl, t, y, inputs=u)["marginal_loglik"], rtol=1e-12)
+    P = cd.ParamsCDNLGSSM(
+        initial=cd.ParamsLGSSMInitial(cd.LearnableVector(mdl.m0), cd.LearnableMatrix(mdl.P0)),
+        dynamics=cd.ParamsCDNLGSSMDynamics(cd.LearnableCustomDrift(theta, f_src, None, None), cd.LearnableMatrix(mdl.L), cd.LearnableMatrix(mdl.Qc), 2.0),
+        emissions=cd.ParamsCDNLGSSMEmissions(cd.LearnableCustomEmission(eta, h_src, None), cd.LearnableMatrix(mdl.R)))
+    ll, g = cd.cdnlgssm_loglik_and_grad_all(P, y, t[..., None], cd.UKFHyperParams(), inputs=u)
+    assert _ffi.lib().cdkf_last_kernel().decode().startswith("ukf_tangent_kernel<double>")
+    np.testing.assert_allclose(ll, ll_r, rtol=1e-10)
+    close(np.asarray(g.dynamics.drift.theta), g_r, "theta", 1e-8)
+    close(np.asarray(g.emissions.emission_function.eta), np.concatenate([ex["H"].reshape(N, -1), ex["bias"]], -1), "eta", 1e-8)
+    check_tree(g._replace(dynamics=g.dynamics._replace(drift=(np.asarray(g.dynamics.drift.theta),))), g_r, ex, N, 1e-8)
+
+
+@pytest.mark.gpu
+def test_tangent_sweep_equals_the_closed_form_reverse_sweep(hip_lib, monkeypatch):
+    """A/B of the library's two derivations on a model both take (Lorenz-63, m = 2): CDKF_UKF_GRAD_TANGENT=1 sends it through the literal
+    tangent sweep; every leaf agrees with the closed-form reverse sweep at 1e-9."""
+    rng = np.random.default_rng(48)
+    mdl = dense_model(rng, o.Lorenz63Drift(10.0, 28.0, 8.0 / 3.0), 3, 2, 1.0)
+    N, T = 4, 10
+    t = o.irregular_times(rng, N, T, 0.12)
+    y = o.simulate(mdl, t, rng)
+    P = params_from(mdl)
+    ll_a, g_a = cd.cdnlgssm_loglik_and_grad_all(P, y, t[..., None], cd.UKFHyperParams())
+    assert "adjoint" in _ffi.lib().cdkf_last_kernel().decode()
+    monkeypatch.setenv("CDKF_UKF_GRAD_TANGENT", "1")
+    ll_b, g_b = cd.cdnlgssm_loglik_and_grad_all(P, y, t[..., None], cd.UKFHyperParams())
+    assert _ffi.lib().cdkf_last_kernel().decode().startswith("ukf_tangent_kernel<double>")
+    np.testing.assert_allclose(ll_b, ll_a, rtol=1e-11)
+    close(grads_flat(g_b, N), grads_flat(g_a, N), "drift", 1e-9)
+    for a, b, k in ((g_b.initial.mean.params, g_a.initial.mean.params, "m0"), (g_b.initial.cov.params, g_a.initial.cov.params, "P0"),
+                    (g_b.dynamics.diffusion_cov.params, g_a.dynamics.diffusion_cov.params, "Qc"),
+                    (g_b.emissions.emission_function.weights, g_a.emissions.emission_function.weights, "H"),
+                    (g_b.emissions.emission_cov.params, g_a.emissions.emission_cov.params, "R")):
+        close(a, np.asarray(b), k, 1e-9)
