@@ -349,6 +349,39 @@ def pmc_issue(algorithmic_bytes, kernel_name, T):
     return best
 
 
+def pmc_executed(tag_token, kernel_tokens, ms, dtype):
+    """EXECUTED matrix-core work of a config-4 entry beside its dense-count roofline (the kernels use the banded
+    Jacobian, SURVEY 8d's count is dense): SQ_INSTS_VALU_MFMA_F64 / _F32 (wavefront-level instruction count) of the kernels of the timed
+    call x 2048 flop (v_mfma_*_16x16x4) / the time measured NOW, from the latest committed counter passes of the same workload
+    (profiles/*<tag_token>*_counters.json; the instruction count of a kernel is a property of the workload, not of the run).  None when
+    no committed profile names every kernel."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_counters.json"))):
+        if tag_token not in os.path.basename(path):
+            continue
+        try:
+            rec = json.load(open(path))
+        except Exception:
+            continue
+        name = "SQ_INSTS_VALU_MFMA_F64" if dtype == "f64" else "SQ_INSTS_VALU_MFMA_F32"
+        total, found, traffic = 0.0, 0, 0.0
+        for tok in kernel_tokens:
+            for k in rec.get("kernels", []):
+                c = k.get("counters") or {}
+                if tok in k.get("kernel", "") and isinstance(c.get(name), dict) and c[name].get("mean_per_launch") is not None:
+                    total += c[name]["mean_per_launch"]
+                    traffic += k.get("hbm_traffic_bytes_per_launch") or 0.0
+                    found += 1
+                    break
+        if found == len(kernel_tokens):
+            tf = total * 2048.0 / (ms * 1e-3) / 1e12
+            peak = FP64_PEAK_TF if dtype == "f64" else FP32_PEAK_TF
+            best = {"mfma_instructions_per_call": total, "executed_TFLOPs": tf, "executed_mfma_flops_frac": tf / peak,
+                    "hbm_traffic_bytes_per_call": traffic or None, "source": os.path.relpath(path, ROOT)}
+    return best
+
+
 def pmc_traffic(algorithmic_bytes, kernel_name):
     """HBM bytes per launch of the sweep kernel from the committed rocprofv3 PMC passes of THIS command
     (profiles/*_counters.json, written by scripts/summarize_prof.py from scripts/prof_r02.sh <tag> bench: FETCH_SIZE x2 per
@@ -625,6 +658,21 @@ def other_configs(lib, timer, stream, t_h, y_h, only=None, comm=None, world=1, r
         out["config4_value_and_grad_lorenz96_d40_fp32_2048x500"] = case(
             l96, grids(rng, n, T), 8.0 + rng.standard_normal((n, T, d)), "f32", _ffi.LAYOUT_TN, [], "mfma", {}, outputs=False, grad=True,
             c_drift=6 * d)
+    # the executed matrix-core work beside the dense-count rooflines (pmc_executed: committed counter passes of the same workloads)
+    for key, tok, algo, toks in (("config4_slice_lorenz96_d40_fp64_2048x500", "_config4_counters", "ekf_filter", ["ekf_filter_wave_l96_kernel<double, 40"]),
+                                 ("config4_slice_lorenz96_d40_fp64_2048x500", "_config4_counters", "ekf_smoother",
+                                  ["ekf_filter_wave_l96_kernel<double, 40", "ekf_smoother_wave_l96_kernel<double, 40"]),
+                                 ("config4_value_and_grad_lorenz96_d40_fp64_2048x500", "config4_value_and_grad_2048x500", "loglik_and_grad_all",
+                                  ["ekf_filter_wave_l96_kernel<double, 40", "ekf_adjoint_wave2_l96_kernel<double, 40"])):
+        if key in out and algo + "_roofline" in out[key]:
+            ex = pmc_executed(tok, toks, out[key][algo + "_ms"], "f64")
+            if ex:
+                if ex["hbm_traffic_bytes_per_call"]:
+                    nn, TT = 2048, 500
+                    alg = 8.0 * nn * TT * (2 * (40 + 40 * 40)) if algo == "loglik_and_grad_all" else None   # the four moment arrays once
+                    if alg:
+                        ex["hbm_traffic_over_algorithmic"] = ex["hbm_traffic_bytes_per_call"] / alg
+                out[key][algo + "_roofline"]["executed"] = ex
     rng = np.random.default_rng(2)
     d, m, h = 8, 4, 64
     mlp = cd.LearnableMLP(rng.standard_normal((h, d)) / np.sqrt(d), 0.1 * rng.standard_normal(h),
