@@ -341,6 +341,13 @@ def test_workgroup_kernels_and_reverse_sweep_with_inputs_and_time_on_the_host():
     fwd = hs.wg_run(os.path.join(ddir, unit(srcs, "_0.hip")), mb, opts_for(hyp), t, y, np.float64, "asan", kind=-1, inputs=u)
     for k in FILTER_KEYS:
         assert relerr(fwd[k], ref[k]) < 1e-12, k
+    ll_a, g_a, ex = o.ekf_loglik_grad_adjoint(mdl, t, y, full=True, state_order="first", inputs=u)
+    ddir, srcs = hs.dump_custom_source(mb.c.drift_kind, 8, M8, 3 + 256 * 2, 1)
+    g, gm, st = hs.awg_run(os.path.join(ddir, unit(srcs, "_2.hip")), mb, opts_for(hyp), t, y, np.float64, "asan", fwd, inputs=u)
+    assert np.abs(g - g_a).max() < 1e-9 * np.abs(g_a).max() and not st.any()
+    assert np.abs(gm[:, :D8] - ex["m0"]).max() < 1e-9 * np.abs(ex["m0"]).max()
+    if os.environ.get("CDKF_HOSTSIM_FULL") != "1":   # (the unscented filter and the backward sweep: the GPU legs below hold them; a minute of host builds)
+        return
     refu = o.ukf_filter(mdl, t, y, inputs=u)
     ddir, srcs = hs.dump_custom_source(mb.c.drift_kind, 8, M8, 1 + 256 * 2, 1)
     outu = hs.wg_run(os.path.join(ddir, unit(srcs, "_0.hip")), mb, opts_for(cd.UKFHyperParams()), t, y, np.float64, "plain", ukf=True, kind=-1, inputs=u)
@@ -351,11 +358,6 @@ def test_workgroup_kernels_and_reverse_sweep_with_inputs_and_time_on_the_host():
     outs = hs.wg_run(os.path.join(ddir, unit(srcs, "_1.hip")), mb, opts_for(hyp), t, y, np.float64, "plain", smoother=True, kind=-1, inputs=u,
                      filtered=(ref["filtered_means"], ref["filtered_covariances"]))
     assert relerr(outs["smoothed_means"], refs["smoothed_means"]) < 1e-12 and relerr(outs["smoothed_covariances"], refs["smoothed_covariances"]) < 1e-12
-    ll_a, g_a, ex = o.ekf_loglik_grad_adjoint(mdl, t, y, full=True, state_order="first", inputs=u)
-    ddir, srcs = hs.dump_custom_source(mb.c.drift_kind, 8, M8, 3 + 256 * 2, 1)
-    g, gm, st = hs.awg_run(os.path.join(ddir, unit(srcs, "_2.hip")), mb, opts_for(hyp), t, y, np.float64, "asan", fwd, inputs=u)
-    assert np.abs(g - g_a).max() < 1e-9 * np.abs(g_a).max() and not st.any()
-    assert np.abs(gm[:, :D8] - ex["m0"]).max() < 1e-9 * np.abs(ex["m0"]).max()
 
 
 @pytest.mark.gpu
