@@ -274,15 +274,16 @@ CDKF_DEV void w40a_sweep(const WgArgs<R>& a, R* __restrict__ grad, R* __restrict
   // products' tiles: held across the update it was spilled for the whole sweep, one reload per use), and d ll / d (L Qc L^T), which is
   // touched once per Runge-Kutta step
   R* PbG = PsG + 5L * 64 * EPL;
-  R* gQG = PbG + 64L * EPL;
 
   R Pb[EPL];  // cotangent of the covariance: owned entries
 #pragma unroll
   for (int s = 0; s < EPL; ++s)
-    if (mine(s)) {
-      Pb[s] = R(0);
-      gQG[64 * s + lane] = R(0);
-    }
+    if (mine(s)) Pb[s] = R(0);
+  // d ll / d (L Qc L^T): touched once per Runge-Kutta step -- in (accumulator) registers for the whole sweep (round 5: it was parked in the
+  // scratch beside Pbar, one global read-modify-write per step)
+  R gQacc[EPL];
+#pragma unroll
+  for (int s = 0; s < EPL; ++s) gQacc[s] = R(0);
   R mb = R(0), gF = R(0);
   int st = 0;
   bool bad = false;
@@ -648,7 +649,6 @@ CDKF_DEV void w40a_sweep(const WgArgs<R>& a, R* __restrict__ grad, R* __restrict
         const Off f = offsets(s);
         I1[f.y] = Pb[s];
         I1[f.yt] = Pb[s];
-        PbG[64 * s + lane] = Pb[s];
       }
     sync();
     fresh();
@@ -856,7 +856,7 @@ CDKF_DEV void w40a_sweep(const WgArgs<R>& a, R* __restrict__ grad, R* __restrict
         const unsigned wA = tabA[64 * s + lane];
         const bool obs_i = (wA >> 16) & 1u, obs_j = (wA >> 17) & 1u;
         const R uij = obs_j ? I2[f.yt] : R(0), uji = obs_i ? I2[f.y] : R(0);
-        Pb[s] = PbG[64 * s + lane] + rfma(R(0.5), uij + uji, (obs_i && obs_j) ? I3[f.y] : R(0));
+        Pb[s] = Pb[s] + rfma(R(0.5), uij + uji, (obs_i && obs_j) ? I3[f.y] : R(0));
       }
     mb -= vb;  // (zero on the second wavefront)
     sync();
@@ -1117,7 +1117,7 @@ CDKF_DEV void w40a_sweep(const WgArgs<R>& a, R* __restrict__ grad, R* __restrict
             R sacc = Pb[u];
 #pragma unroll
             for (int j = 0; j < 5; ++j) sacc += AccL[(j * EPL + u) * 64 + lane];
-            gQG[64 * u + lane] = rfma(dt, sacc, gQG[64 * u + lane]);
+            gQacc[u] = rfma(dt, sacc, gQacc[u]);
             Pb[u] = Pn[u];
           }
         mb = mn;
@@ -1145,7 +1145,7 @@ CDKF_DEV void w40a_sweep(const WgArgs<R>& a, R* __restrict__ grad, R* __restrict
         const Ent e = entry(s);
         gP0[e.i * D + e.j] = Pb[s];
         gP0[e.j * D + e.i] = Pb[s];
-        const R gq = gQG[64 * s + lane];
+        const R gq = gQacc[s];
         gQ[e.i * D + e.j] = gq;
         gQ[e.j * D + e.i] = gq;
       }

@@ -56,12 +56,12 @@ else:
 '''
 env0 = dict(os.environ, ROOT=ROOT, CDKF_RTC_CACHE_DIR="/tmp/r5_rtc_cache")
 os.makedirs("/tmp/r5_rtc_cache", exist_ok=True)
-for what in ("rtc4", "rtc6", "rtc12", "rtc24"):
+for what in os.environ.get("R5_WHAT", "rtc4,rtc6,rtc12,rtc24").split(","):
     for pol in (os.environ.get("R5_POLICIES", ",o1").split(",")):
         env = dict(env0)
         if pol: env["CDKF_RTC_POLICY"] = pol
         p = subprocess.run([sys.executable, "-c", WORK, what], env=env, capture_output=True, text=True, timeout=3000)
-        print("[policy %s]" % (pol or "O3 + subreg-liveness off"), ([ln for ln in p.stdout.splitlines() if ln.startswith("RESULT")] or [p.stderr[-400:]])[-1], flush=True)
+        print("[policy %s]" % (pol or "shipped: -O3, -O1 past the spill limit"), ([ln for ln in p.stdout.splitlines() if ln.startswith("RESULT")] or [p.stderr[-400:]])[-1], flush=True)
 for lib in ([] if os.environ.get("R5_SKIP_WG8") else ["", os.path.join(ROOT, "build", "alt", "libcdkf_hip_wg8basic.so")]):
     env = dict(env0)
     if lib: env["CDKF_LIB_PATH"] = lib
