@@ -279,11 +279,20 @@ CDKF_DEV void w40a_sweep(const WgArgs<R>& a, R* __restrict__ grad, R* __restrict
 #pragma unroll
   for (int s = 0; s < EPL; ++s)
     if (mine(s)) Pb[s] = R(0);
-  // d ll / d (L Qc L^T): touched once per Runge-Kutta step -- in (accumulator) registers for the whole sweep (round 5: it was parked in the
-  // scratch beside Pbar, one global read-modify-write per step)
+  // Two wavefronts per trajectory (7 owned entries per lane at D = 40): Pbar stays in its registers across the update and d ll / d (L Qc L^T),
+  // touched once per Runge-Kutta step, accumulates in registers for the whole sweep (round 5: 230 of 256 accumulator registers, no spill;
+  // both were parked in the scratch: 26 KB of traffic per trajectory-step).  One wavefront per trajectory (13 entries per lane) has no room:
+  // held there they push the fp64 build from 1 116 to 1 204 B of scratch and 553 spilled registers -- and the -O3 build goes WRONG (one more
+  // member of NOTES R5.1's family, caught by test_lorenz96_d40_value_and_gradient) -- so that mapping keeps the parking.
+  constexpr bool kPark = NW == 1;
+  R* gQG = PbG + 64L * EPL;
   R gQacc[EPL];
 #pragma unroll
-  for (int s = 0; s < EPL; ++s) gQacc[s] = R(0);
+  for (int s = 0; s < EPL; ++s) {
+    gQacc[s] = R(0);
+    if constexpr (kPark)
+      if (mine(s)) gQG[64 * s + lane] = R(0);
+  }
   R mb = R(0), gF = R(0);
   int st = 0;
   bool bad = false;
@@ -649,6 +658,7 @@ CDKF_DEV void w40a_sweep(const WgArgs<R>& a, R* __restrict__ grad, R* __restrict
         const Off f = offsets(s);
         I1[f.y] = Pb[s];
         I1[f.yt] = Pb[s];
+        if constexpr (kPark) PbG[64 * s + lane] = Pb[s];
       }
     sync();
     fresh();
@@ -856,7 +866,8 @@ CDKF_DEV void w40a_sweep(const WgArgs<R>& a, R* __restrict__ grad, R* __restrict
         const unsigned wA = tabA[64 * s + lane];
         const bool obs_i = (wA >> 16) & 1u, obs_j = (wA >> 17) & 1u;
         const R uij = obs_j ? I2[f.yt] : R(0), uji = obs_i ? I2[f.y] : R(0);
-        Pb[s] = Pb[s] + rfma(R(0.5), uij + uji, (obs_i && obs_j) ? I3[f.y] : R(0));
+        const R pb0 = kPark ? PbG[64 * s + lane] : Pb[s];
+        Pb[s] = pb0 + rfma(R(0.5), uij + uji, (obs_i && obs_j) ? I3[f.y] : R(0));
       }
     mb -= vb;  // (zero on the second wavefront)
     sync();
@@ -1117,7 +1128,8 @@ CDKF_DEV void w40a_sweep(const WgArgs<R>& a, R* __restrict__ grad, R* __restrict
             R sacc = Pb[u];
 #pragma unroll
             for (int j = 0; j < 5; ++j) sacc += AccL[(j * EPL + u) * 64 + lane];
-            gQacc[u] = rfma(dt, sacc, gQacc[u]);
+            if constexpr (kPark) gQG[64 * u + lane] = rfma(dt, sacc, gQG[64 * u + lane]);
+            else gQacc[u] = rfma(dt, sacc, gQacc[u]);
             Pb[u] = Pn[u];
           }
         mb = mn;
@@ -1145,7 +1157,7 @@ CDKF_DEV void w40a_sweep(const WgArgs<R>& a, R* __restrict__ grad, R* __restrict
         const Ent e = entry(s);
         gP0[e.i * D + e.j] = Pb[s];
         gP0[e.j * D + e.i] = Pb[s];
-        const R gq = gQacc[s];
+        const R gq = kPark ? gQG[64 * s + lane] : gQacc[s];
         gQ[e.i * D + e.j] = gq;
         gQ[e.j * D + e.i] = gq;
       }
