@@ -116,7 +116,7 @@ SYMBOLS = (
      "cdkf_kf_smoother1_supported", "cdkf_kf_pushforward_f64", "cdkf_kf_pushforward_f32", "cdkf_grad_supported", "cdkf_grad_all_supported", "cdkf_release_workspace", "cdkf_ekf_loglik_grad_all_f64",
      "cdkf_ekf_loglik_grad_all_f32", "cdkf_ekf_loglik_grad_all_f64_dev", "cdkf_ekf_loglik_grad_all_f32_dev", "cdkf_ekf_loglik_grad_jumps_f64",
      "cdkf_ekf_loglik_grad_jumps_f32", "cdkf_ukf_loglik_grad_all_f64", "cdkf_ukf_loglik_grad_all_f32", "cdkf_ukf_loglik_grad_all_f64_dev",
-     "cdkf_ukf_loglik_grad_all_f32_dev", "cdkf_ukf_grad_all_supported", "cdkf_ukf_tangent_compile", "cdkf_debug_ukf_tangent_args", "cdkf_grad_sum_f64_dev",
+     "cdkf_ukf_loglik_grad_all_f32_dev", "cdkf_ukf_grad_all_supported", "cdkf_ukf_tangent_compile", "cdkf_ekf_tangent_compile", "cdkf_debug_ukf_tangent_args", "cdkf_grad_sum_f64_dev",
      "cdkf_grad_sum_f32_dev", "cdkf_comm_preflight", "cdkf_comm_unique_id", "cdkf_comm_init_rank", "cdkf_comm_init_all", "cdkf_comm_rank", "cdkf_comm_world",
      "cdkf_ll_allreduce", "cdkf_comm_allreduce_max", "cdkf_ll_allreduce_all", "cdkf_comm_destroy", "cdkf_rdv_create",
      "cdkf_rdv_broadcast", "cdkf_rdv_allreduce", "cdkf_rdv_barrier", "cdkf_rdv_destroy", "cdkf_last_kernel", "cdkf_event_create",

@@ -594,7 +594,10 @@ int cdkf_debug_custom_reg_blob(const cdkf_model* mdl, const cdkf_opts* opts, int
   return custom_debug_reg_blob(mdl, opts, N, T, algo, bytes_per_real, par_out, par_cap_bytes, ip_out);
 }
 int cdkf_ukf_tangent_compile(const cdkf_model* mdl, const cdkf_opts* opts, int bytes_per_real) {
-  return ukf_tangent_compile_check(mdl, opts, bytes_per_real);
+  return ukf_tangent_compile_check(mdl, opts, bytes_per_real, 0);
+}
+int cdkf_ekf_tangent_compile(const cdkf_model* mdl, const cdkf_opts* opts, int bytes_per_real) {
+  return ukf_tangent_compile_check(mdl, opts, bytes_per_real, 1);
 }
 int cdkf_debug_ukf_tangent_args(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T, int bytes_per_real, int all,
                                 void* args_out, int64_t args_cap_bytes, void* par_out, int64_t par_cap_bytes) {
@@ -854,10 +857,10 @@ int cdkf_ekf_loglik_grad_jumps_f32(const cdkf_model* mdl, const cdkf_opts* o, in
 }
 int cdkf_release_workspace(void) { return release_grad_workspace(); }
 int cdkf_grad_all_supported(const cdkf_model* mdl, const cdkf_opts* o) {
-  return (mdl && o && adjoint_shape_available(mdl, o)) ? 1 : 0;
+  return (mdl && o && (adjoint_shape_available(mdl, o) || ekf_tangent_available(mdl, o))) ? 1 : 0;
 }
 int cdkf_grad_supported(const cdkf_model* mdl, const cdkf_opts* o) {
-  return (mdl && o && grad_shape_available(mdl, o)) ? 1 : 0;
+  return (mdl && o && (grad_shape_available(mdl, o) || (mdl->n_theta >= 1 && ekf_tangent_available(mdl, o)))) ? 1 : 0;
 }
 int cdkf_grad_sum_f64_dev(const double* grad, int64_t N, int64_t n_theta, double* out, void* stream) {
   return grad_sum_dev<double>(grad, N, n_theta, out, stream);

@@ -122,7 +122,12 @@ bool ukf_tangent_available(const cdkf_model* mdl, const cdkf_opts* o);
 template <typename R>
 int launch_ukf_tangent(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll, R* grad,
                        R* grad_model, int32_t* status, hipStream_t stream);
-int ukf_tangent_compile_check(const cdkf_model* mdl, const cdkf_opts* o, int bytes_per_real);
+// ... and the EXTENDED filter's on the same plan (ekf_tangent_body: jacfwd by an outer dual level; any num_iter, emissions given as source)
+bool ekf_tangent_available(const cdkf_model* mdl, const cdkf_opts* o);
+template <typename R>
+int launch_ekf_tangent(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll, R* grad,
+                       R* grad_model, int32_t* status, hipStream_t stream);
+int ukf_tangent_compile_check(const cdkf_model* mdl, const cdkf_opts* o, int bytes_per_real, int ekf);
 int ukf_tangent_debug_args(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, int bytes_per_real, int all, void* args_out,
                            int64_t args_cap, void* par_out, int64_t par_cap);
 void custom_rtc_cache_stats(int64_t* hits, int64_t* misses);

@@ -47,21 +47,40 @@ struct UtArgs {
   R wc0;  // wm0 + 1 - alpha^2 + beta
   R wi;   // 1 / (2 (D + lambda))
   int all;  // 0: the drift parameters only (grad), 1: every leaf (grad and grad_model)
+  int num_iter;  // the EXTENDED filter's update iterations (ekf_tangent_body; inference_ekf.py:153-199)
+  int order;     // the extended filter's state_order: 1 or 2
 };
 
 constexpr int kUtStatusNotPd = 1, kUtStatusNan = 2, kUtStatusMaxSteps = 4;  // (= kStatus* of cdkf_reg_kernels.h)
 
-// entry k of a parameter vector as a T whose tangent is 1 on this lane's entry
+// a real with its parameter tangent lifted into the (possibly nested) dual type T: the innermost Dual<R, 1> carries (v, g), every outer
+// level's directions are zero
+template <typename R, typename T>
+struct UtLift;
+template <typename R>
+struct UtLift<R, Dual<R, 1>> {
+  static __device__ Dual<R, 1> make(R v, R g) {
+    Dual<R, 1> r;
+    r.v = v;
+    r.g[0] = g;
+    return r;
+  }
+};
+template <typename R, typename S, int N>
+struct UtLift<R, Dual<S, N>> {
+  static __device__ Dual<S, N> make(R v, R g) {
+    Dual<S, N> r;
+    r.v = UtLift<R, S>::make(v, g);
+    for (int k = 0; k < N; ++k) r.g[k] = UtLift<R, S>::make(R(0), R(0));
+    return r;
+  }
+};
+// entry k of a parameter vector as a T whose parameter tangent is 1 on this lane's entry
 template <typename R, typename T>
 struct UtView {
   const R* v;
   int seed;  // index (into v) of the entry this lane differentiates, or -1
-  __device__ T operator[](int k) const {
-    T r;
-    r.v = v[k];
-    r.g[0] = (k == seed) ? R(1) : R(0);
-    return r;
-  }
+  __device__ T operator[](int k) const { return UtLift<R, T>::make(v[k], (k == seed) ? R(1) : R(0)); }
 };
 
 __device__ inline int ut_lo(int r, int c) { return r * (r + 1) / 2 + c; }                  // lower-packed (r >= c)
@@ -115,6 +134,40 @@ __device__ void ut_rhs(const UtCtx<R, MD, T>& cx, const T* y, T* dy, R tt, bool&
   for (int j = 0; j < D; ++j) dy[j] = cx.wm0 * f0[j] + cx.wi * sum[j];
   for (int r = 0; r < D; ++r)
     for (int c2 = 0; c2 <= r; ++c2) dy[D + ut_lo(r, c2)] = cx.wi * (foo[r * D + c2] + foo[c2 * D + r]) + cx.q[ut_lo(r, c2)];
+}
+
+// this lane's results: d ll / d (its leaf entry) to its place in grad / grad_model (symmetric leaves: both halves), the value from lane 0
+template <typename R, typename MD>
+__device__ void ut_store(const UtArgs<R>& a, long n, int p, R llv, R g, int st) {
+  constexpr int D = MD::D, M = MD::M, NTH = MD::NTH;
+  constexpr int NPD = D * (D + 1) / 2;
+  constexpr int o_m0 = NTH, o_P0 = o_m0 + D, o_Q = o_P0 + NPD, o_H = o_Q + NPD, o_R = o_H + M * D + M;
+  if (p < NTH) {
+    a.grad[n * NTH + p] = g;
+  } else if (a.all) {
+    constexpr int GM = D + 2 * D * D + M * D + M + M * M;
+    R* gm = a.grad_model + n * GM;
+    auto put_pair = [&](R* base, int e, int dim) {
+      int i = 0, left = e;
+      while (left >= dim - i) {
+        left -= dim - i;
+        ++i;
+      }
+      const int j = i + left;
+      const R val = (i == j) ? g : R(0.5) * g;
+      base[i * dim + j] = val;
+      base[j * dim + i] = val;
+    };
+    if (p < o_P0) gm[p - o_m0] = g;
+    else if (p < o_Q) put_pair(gm + D, p - o_P0, D);
+    else if (p < o_H) put_pair(gm + D + D * D, p - o_Q, D);
+    else if (p < o_R) gm[D + 2 * D * D + (p - o_H)] = g;
+    else put_pair(gm + D + 2 * D * D + M * D + M, p - o_R, M);
+  }
+  if (p == 0) {
+    a.ll[n] = llv;
+    if (a.status) a.status[n] = st;
+  }
 }
 
 template <typename R, typename MD>
@@ -289,33 +342,243 @@ __device__ void ukf_tangent_body(const UtArgs<R>& a) {
   }
   if (bad) st |= kUtStatusNotPd;
   if (!live) return;
-  const R g = (R)llg;
-  if (p < NTH) {
-    a.grad[n * NTH + p] = g;
-  } else if (a.all) {
-    constexpr int GM = D + 2 * D * D + M * D + M + M * M;
-    R* gm = a.grad_model + n * GM;
-    auto put_pair = [&](R* base, int e, int dim) {
-      int i = 0, left = e;
-      while (left >= dim - i) {
-        left -= dim - i;
-        ++i;
+  ut_store<R, MD>(a, n, p, (R)llv, (R)llg, st);
+}
+
+// ---- the EXTENDED filter on the same plan: value and gradient for any drift / emission, any num_iter ----------------------------------
+// What the closed reverse sweeps do not cover (update iterations above eight dimensions, emissions given as source)
+// the literal recursion on dual numbers does: jacfwd(f), jacfwd(h) by an outer Dual<T, D> over the parameter tangent T = Dual<R, 1>
+// (the tangent of the Jacobian falls out with it), the second-order mean term 0.5 P grad(div f) by one more level (D <= 8).
+//   _predict       dm/dt = f(m) [+ 0.5 P grad(div f)(m)],  dP/dt = F P + P F^T + L Qc L^T                  (inference_ekf.py:46-148)
+//   _condition_on  num_iter x { H = jacfwd(h)(m); S = R + H P H^T; K = psd_solve(S, H P)^T; P -= K S K^T; m += K (y - h(m)) }; sym(P)
+//   log-likelihood MVN(h(m_pred), H P H^T + R).log_prob(y) at the predicted moments                         (inference_ekf.py:153-199, 277-286)
+template <typename R, typename MD, typename T>
+__device__ void et_jac_f(const UtCtx<R, MD, T>& cx, const T* m, T* f0, T* F, R tt) {  // F row-major [D][D]
+  constexpr int D = MD::D;
+  typedef Dual<T, D> J;
+  J x[D], fx[D];
+  for (int i = 0; i < D; ++i) {
+    x[i].v = m[i];
+    for (int j = 0; j < D; ++j) x[i].g[j] = UtLift<R, T>::make(i == j ? R(1) : R(0), R(0));
+  }
+  MD::template f<R, J>(x, UtView<R, J>{cx.th.v, cx.th.seed}, fx, cx.ub, tt);
+  for (int i = 0; i < D; ++i) {
+    f0[i] = fx[i].v;
+    for (int j = 0; j < D; ++j) F[i * D + j] = fx[i].g[j];
+  }
+}
+// g_k = d/dx_k sum_i d f_i / d x_i (inference_ekf.py:108-116) with its parameter tangent: two nested direction sets
+template <typename R, typename MD, typename T>
+__device__ void et_divgrad(const UtCtx<R, MD, T>& cx, const T* m, T* g, R tt) {
+  constexpr int D = MD::D;
+  if constexpr (D <= 8) {
+    typedef Dual<T, D> J1;
+    typedef Dual<J1, D> J2;
+    J2 x[D], fx[D];
+    for (int i = 0; i < D; ++i) {
+      x[i].v.v = m[i];
+      for (int j = 0; j < D; ++j) {
+        x[i].v.g[j] = UtLift<R, T>::make(i == j ? R(1) : R(0), R(0));
+        x[i].g[j] = UtLift<R, J1>::make(i == j ? R(1) : R(0), R(0));
       }
-      const int j = i + left;
-      const R val = (i == j) ? g : R(0.5) * g;
-      base[i * dim + j] = val;
-      base[j * dim + i] = val;
-    };
-    if (p < o_P0) gm[p - o_m0] = g;
-    else if (p < o_Q) put_pair(gm + D, p - o_P0, D);
-    else if (p < o_H) put_pair(gm + D + D * D, p - o_Q, D);
-    else if (p < o_R) gm[D + 2 * D * D + (p - o_H)] = g;
-    else put_pair(gm + D + 2 * D * D + M * D + M, p - o_R, M);
+    }
+    MD::template f<R, J2>(x, UtView<R, J2>{cx.th.v, cx.th.seed}, fx, cx.ub, tt);
+    for (int k = 0; k < D; ++k) {
+      T s = UtLift<R, T>::make(R(0), R(0));
+      for (int i = 0; i < D; ++i) s += fx[i].g[i].g[k];
+      g[k] = s;
+    }
+  } else {
+    for (int k = 0; k < D; ++k) g[k] = UtLift<R, T>::make(R(0), R(0));
   }
-  if (p == 0) {
-    a.ll[n] = (R)llv;
-    if (a.status) a.status[n] = st;
+}
+
+template <typename R, typename MD, typename T>
+__device__ void et_rhs(const UtCtx<R, MD, T>& cx, const T* y, T* dy, R tt, bool second) {
+  constexpr int D = MD::D;
+  T f0[D], F[D * D];
+  et_jac_f<R, MD, T>(cx, y, f0, F, tt);
+  auto P = [&](int r, int c) -> const T& { return y[D + (r >= c ? ut_lo(r, c) : ut_lo(c, r))]; };
+  if (second) {
+    T g[D];
+    et_divgrad<R, MD, T>(cx, y, g, tt);
+    for (int l = 0; l < D; ++l) {
+      T s = UtLift<R, T>::make(R(0), R(0));
+      for (int k = 0; k < D; ++k) s += g[k] * P(k, l);
+      f0[l] += R(0.5) * s;
+    }
   }
+  for (int j = 0; j < D; ++j) dy[j] = f0[j];
+  for (int r = 0; r < D; ++r)
+    for (int c = 0; c <= r; ++c) {
+      T s = cx.q[ut_lo(r, c)];
+      for (int k = 0; k < D; ++k) s += F[r * D + k] * P(k, c) + P(r, k) * F[c * D + k];
+      dy[D + ut_lo(r, c)] = s;
+    }
+}
+
+template <typename R, typename MD>
+__device__ void ekf_tangent_body(const UtArgs<R>& a) {
+  constexpr int D = MD::D, M = MD::M, NTH = MD::NTH, DU = MD::DU;
+  constexpr int NPD = D * (D + 1) / 2, NPM = M * (M + 1) / 2, NS = D + NPD;
+  typedef Dual<R, 1> T;
+  typedef Dual<T, D> J;
+  constexpr int o_m0 = NTH, o_P0 = o_m0 + D, o_Q = o_P0 + NPD, o_H = o_Q + NPD, o_R = o_H + M * D + M, n_all = o_R + NPM;
+  const int nleaf = a.all ? n_all : (NTH > 0 ? NTH : 1);
+  const long total = a.N * (long)nleaf;
+  long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = gid < total;
+  if (!live) gid = total - 1;
+  const long n = gid / nleaf;
+  const int p = (int)(gid - n * nleaf);
+  const R* p_m0 = a.par + NTH;
+  const R* p_P0 = p_m0 + D;
+  const R* p_Q = p_P0 + D * D;
+  const R* p_eta = p_Q + D * D;
+  const R* p_R = p_eta + M * D + M;
+  T q[NPD], rm[NPM], y[NS];
+  UtCtx<R, MD, T> cx;
+  cx.th = UtView<R, T>{a.par, (p < NTH) ? p : -1};
+  cx.eta = UtView<R, T>{p_eta, (p >= o_H && p < o_R) ? p - o_H : -1};
+  cx.q = q;
+  cx.c = cx.wm0 = cx.wc0 = cx.wi = R(0);
+  cx.ub[0] = R(0);
+  auto seeded = [&](R v, bool on) { return UtLift<R, T>::make(v, on ? R(1) : R(0)); };
+  for (int i = 0; i < D; ++i) y[i] = seeded(p_m0[i], p == o_m0 + i);
+  for (int r = 0; r < D; ++r)
+    for (int c2 = 0; c2 <= r; ++c2) {
+      y[D + ut_lo(r, c2)] = seeded(R(0.5) * (p_P0[r * D + c2] + p_P0[c2 * D + r]), p == o_P0 + ut_pair(c2, r, D));
+      q[ut_lo(r, c2)] = seeded(R(0.5) * (p_Q[r * D + c2] + p_Q[c2 * D + r]), p == o_Q + ut_pair(c2, r, D));
+    }
+  for (int r = 0; r < M; ++r)
+    for (int c2 = 0; c2 <= r; ++c2) rm[ut_lo(r, c2)] = seeded(R(0.5) * (p_R[r * M + c2] + p_R[c2 * M + r]), p == o_R + ut_pair(c2, r, M));
+  const R* tp = a.t + n * a.t_sn;
+  const R* yp = a.y + n * a.y_sn;
+  double llv = 0.0, llg = 0.0;
+  int st = 0;
+  bool bad = false;
+  constexpr R cs[6] = {R(0), R(1) / R(5), R(3) / R(10), R(4) / R(5), R(8) / R(9), R(1)};
+  const bool second = a.order == 2;
+
+  for (long k = 0; k < a.T; ++k) {
+    const R tcur = tp[k * a.t_sk];
+    for (int i = 0; i < DU; ++i) cx.ub[i] = a.u ? a.u[n * a.u_sn + k * a.u_sk + i * a.u_si] : R(0);
+    for (int it = 0; it < a.num_iter; ++it) {
+      // h(m) and H = jacfwd(h)(m) in one evaluation on Dual<T, D>
+      T hm[M], H[M * D], HP[M * D], S[NPM], v[M];
+      {
+        J x[D], hx[M];
+        for (int i = 0; i < D; ++i) {
+          x[i].v = y[i];
+          for (int j = 0; j < D; ++j) x[i].g[j] = UtLift<R, T>::make(i == j ? R(1) : R(0), R(0));
+        }
+        MD::template h<R, J>(x, UtView<R, J>{cx.eta.v, cx.eta.seed}, hx, cx.ub, tcur);
+        for (int r = 0; r < M; ++r) {
+          hm[r] = hx[r].v;
+          for (int j = 0; j < D; ++j) H[r * D + j] = hx[r].g[j];
+        }
+      }
+      auto P = [&](int r, int c) -> const T& { return y[D + (r >= c ? ut_lo(r, c) : ut_lo(c, r))]; };
+      for (int r = 0; r < M; ++r)
+        for (int j = 0; j < D; ++j) {
+          T s = UtLift<R, T>::make(R(0), R(0));
+          for (int kk = 0; kk < D; ++kk) s += H[r * D + kk] * P(kk, j);
+          HP[r * D + j] = s;
+        }
+      for (int r = 0; r < M; ++r)
+        for (int c2 = 0; c2 <= r; ++c2) {
+          T s = rm[ut_lo(r, c2)];
+          for (int kk = 0; kk < D; ++kk) s += HP[r * D + kk] * H[c2 * D + kk];
+          S[ut_lo(r, c2)] = s;
+        }
+      for (int r = 0; r < M; ++r) v[r] = T(yp[k * a.y_sk + r * a.y_si]) - hm[r];
+      if (it == 0) {  // the log-likelihood term: at the predicted moments, S as given
+        T Lc[NPM], z[M];
+        ut_chol<T, M>(S, Lc, bad);
+        T qf = T(0.0), ld = T(0.0);
+        for (int i = 0; i < M; ++i) {
+          T w = v[i];
+          for (int kk = 0; kk < i; ++kk) w -= Lc[ut_lo(i, kk)] * z[kk];
+          z[i] = w / Lc[ut_lo(i, i)];
+          qf += z[i] * z[i];
+          ld += log(Lc[ut_lo(i, i)]);
+        }
+        const T term = R(-0.5) * qf - ld - R(0.5 * 1.8378770664093453) * R(M);
+        llv += (double)term.v;
+        llg += (double)term.g[0];
+      }
+      T Lb[NPM], Sb[NPM], Kt[M][D];  // Kt = Sb^-1 (H P): K = Kt^T
+      for (int e = 0; e < NPM; ++e) Sb[e] = S[e];
+      for (int r = 0; r < M; ++r) Sb[ut_lo(r, r)] += T(1e-9);
+      ut_chol<T, M>(Sb, Lb, bad);
+      for (int j = 0; j < D; ++j) {
+        T w[M];
+        for (int i = 0; i < M; ++i) {
+          T s = HP[i * D + j];
+          for (int kk = 0; kk < i; ++kk) s -= Lb[ut_lo(i, kk)] * w[kk];
+          w[i] = s / Lb[ut_lo(i, i)];
+        }
+        for (int i = M - 1; i >= 0; --i) {
+          T s = w[i];
+          for (int kk = i + 1; kk < M; ++kk) s -= Lb[ut_lo(kk, i)] * Kt[kk][j];
+          Kt[i][j] = s / Lb[ut_lo(i, i)];
+        }
+      }
+      T KS[D][M];
+      for (int j = 0; j < D; ++j)
+        for (int b = 0; b < M; ++b) {
+          T s = T(0.0);
+          for (int r = 0; r < M; ++r) s += Kt[r][j] * S[r >= b ? ut_lo(r, b) : ut_lo(b, r)];
+          KS[j][b] = s;
+        }
+      for (int r = 0; r < D; ++r)
+        for (int c2 = 0; c2 <= r; ++c2) {
+          T s = T(0.0);
+          for (int b = 0; b < M; ++b) s += KS[r][b] * Kt[b][c2];
+          y[D + ut_lo(r, c2)] -= s;  // (K S K^T is symmetric: the packed triangle IS symmetrize(P - K S K^T))
+        }
+      for (int j = 0; j < D; ++j) {
+        T s = y[j];
+        for (int r = 0; r < M; ++r) s += Kt[r][j] * v[r];
+        y[j] = s;
+      }
+    }
+    if (y[0].v != y[0].v) st |= kUtStatusNan;
+    if (k + 1 < a.T) {
+      const R t1 = tp[(k + 1) * a.t_sk];
+      R tprev = tcur;
+      R tnext = rmin(tcur + a.dt0, t1);
+      long steps = 0;
+      while (tprev < t1) {
+        if (steps >= a.max_steps) {
+          st |= kUtStatusMaxSteps;
+          break;
+        }
+        const R dt = tnext - tprev;
+        T ks[6][NS], ys[NS];
+        for (int s = 0; s < 6; ++s) {
+          for (int e = 0; e < NS; ++e) {
+            T acc = T(0.0);
+            for (int j = 0; j < s; ++j) acc += Dp5T<R>::a[s][j] * ks[j][e];
+            ys[e] = y[e] + dt * acc;
+          }
+          et_rhs<R, MD, T>(cx, ys, ks[s], tprev + cs[s] * dt, second);
+        }
+        for (int e = 0; e < NS; ++e) {
+          T acc = T(0.0);
+          for (int s = 0; s < 6; ++s) acc += Dp5T<R>::b[s] * ks[s][e];
+          y[e] += dt * acc;
+        }
+        tprev = rmin(tnext, t1);
+        const R tn = tnext + a.dt0;
+        tnext = (tn > t1 - Tol<R>::v) ? t1 : tn;
+        ++steps;
+      }
+    }
+  }
+  if (bad) st |= kUtStatusNotPd;
+  if (!live) return;
+  ut_store<R, MD>(a, n, p, (R)llv, (R)llg, st);
 }
 
 }  // namespace cdkf

@@ -1420,7 +1420,7 @@ static std::string ut_builtin_drift(const cdkf_model* mdl) {
 constexpr int kUtMaxDim = 16;  // state / emission dimension of the tangent sweep (private arrays: ~ 6 (d + d (d + 1) / 2) dual numbers per lane)
 
 // is the model one the tangent sweep takes?  (`why`: the refusal's text)
-static bool ut_model_sources(const cdkf_model* mdl, const cdkf_opts* o, std::string& f_src, std::string& h_src, int& nth, std::string* why) {
+static bool ut_model_sources(const cdkf_model* mdl, const cdkf_opts* o, std::string& f_src, std::string& h_src, int& nth, std::string* why, bool ekf = false) {
   auto no = [&](const char* msg) {
     if (why) *why = msg;
     return false;
@@ -1429,11 +1429,17 @@ static bool ut_model_sources(const cdkf_model* mdl, const cdkf_opts* o, std::str
   if (d < 1 || m < 1 || d > kUtMaxDim || m > kUtMaxDim) return no("state_dim, emission_dim <= 16");
   if (o->solver != CDKF_SOLVER_DOPRI5 || o->adaptive) return no("the default solver (fixed-step Dormand-Prince)");
   if (o->forecast) return no("no forecast mode");
+  if (ekf) {  // the extended filter's tangent sweep: jacfwd by an outer dual level, grad(div f) by two (state_dim <= 8)
+    if (o->state_order == CDKF_ORDER_ZEROTH) return no("state_order first or second");
+    if (o->state_order == CDKF_ORDER_SECOND && d > 8) return no("state_order first above eight dimensions (second: state_dim <= 8)");
+    if (o->num_iter < 1 || o->num_iter > 64) return no("1 <= num_iter <= 64");
+  }
   nth = (int)mdl->n_theta;
   if (custom_kind(mdl->drift_kind)) {
     std::lock_guard<std::mutex> lock(g_mutex);
     const CustomDrift& c = g_drifts[mdl->drift_kind - CDKF_DRIFT_CUSTOM_BASE];
     if (c.d != d || c.n_theta != mdl->n_theta) return no("the dimensions the drift was registered with");
+    if (ekf && o->state_order == CDKF_ORDER_SECOND && !c.has_g) return no("grad(div f) registered for state_order second (divgrad_src, as the filter asks)");
     f_src = c.f_src;
   } else {
     f_src = ut_builtin_drift(mdl);
@@ -1456,8 +1462,13 @@ bool ukf_tangent_available(const cdkf_model* mdl, const cdkf_opts* o) {
   int nth = 0;
   return ut_model_sources(mdl, o, f, h, nth, nullptr);
 }
+bool ekf_tangent_available(const cdkf_model* mdl, const cdkf_opts* o) {
+  std::string f, h;
+  int nth = 0;
+  return ut_model_sources(mdl, o, f, h, nth, nullptr, true);
+}
 
-static std::string generate_ut_source(const cdkf_model* mdl, const std::string& f_src, const std::string& h_src, int bytes) {
+static std::string generate_ut_source(const cdkf_model* mdl, const std::string& f_src, const std::string& h_src, int bytes, bool ekf) {
   const int d = mdl->state_dim, m = mdl->emission_dim, du = mdl->input_dim;
   std::string s;
   s += "#include \"cdkf_ukf_tangent_kernels.h\"\nnamespace cdkf {\nstruct UtModel {\n";
@@ -1469,21 +1480,23 @@ static std::string generate_ut_source(const cdkf_model* mdl, const std::string& 
   s += "  template <typename R, typename T, typename EH> static __device__ void h(const T* x, const EH& eta, T (&hx)[M], const R* u, const R t) {\n"
        "    (void)eta; (void)u; (void)t;\n#line 1 \"emission_h\"\n" + h_src + "\n  }\n};\n}  // namespace cdkf\n";
   s += "using R = " + std::string(bytes == 8 ? "double" : "float") + ";\n";
-  s += "extern \"C\" __global__ __launch_bounds__(64) void cdkf_ukf_tangent_kernel(const cdkf::UtArgs<R> a) { cdkf::ukf_tangent_body<R, cdkf::UtModel>(a); }\n";
+  s += "extern \"C\" __global__ __launch_bounds__(64) void cdkf_ukf_tangent_kernel(const cdkf::UtArgs<R> a) { cdkf::" + std::string(ekf ? "ekf" : "ukf") +
+       "_tangent_body<R, cdkf::UtModel>(a); }\n";   // (one entry name for both filters: the harnesses and the launcher call it)
   return s;
 }
 
 std::map<std::pair<int, std::string>, Compiled> g_ut_modules;  // (device, cache key)
 
-static int ut_get_function(const cdkf_model* mdl, const cdkf_opts* o, int bytes, hipFunction_t* fn, const char* arch_override) {
+static int ut_get_function(const cdkf_model* mdl, const cdkf_opts* o, int bytes, hipFunction_t* fn, const char* arch_override, bool ekf = false) {
   std::string f_src, h_src, why;
   int nth = 0;
-  if (!ut_model_sources(mdl, o, f_src, h_src, nth, &why)) {
-    set_error("ukf_loglik_grad: the tangent sweep of the literal unscented recursion needs %s (drift_kind=%d state_dim=%d emission_dim=%d "
-              "emission_kind=%d solver=%d)", why.c_str(), mdl->drift_kind, mdl->state_dim, mdl->emission_dim, mdl->emission_kind, o->solver);
+  if (!ut_model_sources(mdl, o, f_src, h_src, nth, &why, ekf)) {
+    set_error("%s_loglik_grad: the tangent sweep of the literal %s recursion needs %s (drift_kind=%d state_dim=%d emission_dim=%d "
+              "emission_kind=%d solver=%d state_order=%d num_iter=%d)", ekf ? "ekf" : "ukf", ekf ? "extended" : "unscented", why.c_str(), mdl->drift_kind,
+              mdl->state_dim, mdl->emission_dim, mdl->emission_kind, o->solver, o->state_order, o->num_iter);
     return CDKF_EUNSUPPORTED;
   }
-  const std::string src = generate_ut_source(mdl, f_src, h_src, bytes);
+  const std::string src = generate_ut_source(mdl, f_src, h_src, bytes, ekf);
   std::string arch = arch_override ? arch_override : "";
   int dev = 0;
   if (!arch_override) {
@@ -1494,7 +1507,7 @@ static int ut_get_function(const cdkf_model* mdl, const cdkf_opts* o, int bytes,
   }
   // (-O1, as the workgroup variants: a loop-heavy kernel whose state lives in scratch by design; nothing to gain from unrolling it)
   const char* olevel = "-O1";
-  const std::string tag = "ukf tangent";
+  const std::string tag = ekf ? "ekf tangent" : "ukf tangent";
   const std::string cache_key = rtc_cache_key(src, arch, olevel, "cdkf_ukf_tangent_kernel", tag);
   std::lock_guard<std::mutex> lock(g_mutex);
   if (!arch_override) {
@@ -1541,7 +1554,7 @@ static int ut_get_function(const cdkf_model* mdl, const cdkf_opts* o, int bytes,
     hiprtcDestroyProgram(&prog);
     rtc_cache_store(cache_key, code, std::string(), tag + " d=" + std::to_string(mdl->state_dim) + " m=" + std::to_string(mdl->emission_dim) + " " + olevel);
     if (const char* dir = getenv("CDKF_CUSTOM_DUMP")) {
-      const std::string base = std::string(dir) + "/cdkf_ukf_tangent_" + std::to_string(bytes) + "_" + cache_key.substr(0, 8);
+      const std::string base = std::string(dir) + (ekf ? "/cdkf_ekf_tangent_" : "/cdkf_ukf_tangent_") + std::to_string(bytes) + "_" + cache_key.substr(0, 8);
       if (FILE* f = fopen((base + ".hip").c_str(), "w")) {
         fwrite(src.data(), 1, src.size(), f);
         fclose(f);
@@ -1562,10 +1575,10 @@ static int ut_get_function(const cdkf_model* mdl, const cdkf_opts* o, int bytes,
 }
 
 // compile check without a GPU (cdkf_ukf_tangent_compile): the kernel the model would get, built for gfx950
-int ukf_tangent_compile_check(const cdkf_model* mdl, const cdkf_opts* o, int bytes_per_real) {
+int ukf_tangent_compile_check(const cdkf_model* mdl, const cdkf_opts* o, int bytes_per_real, int ekf) {
   if (!mdl || !o || (bytes_per_real != 4 && bytes_per_real != 8)) return CDKF_EINVAL;
   hipFunction_t fn;
-  return ut_get_function(mdl, o, bytes_per_real, &fn, "gfx950");
+  return ut_get_function(mdl, o, bytes_per_real, &fn, "gfx950", ekf != 0);
 }
 
 // the argument struct and the parameter block (host copies) of the tangent sweep
@@ -1599,6 +1612,8 @@ static void ut_fill(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_
   a.N = N;
   a.T = T;
   a.max_steps = (long)o->max_steps;
+  a.num_iter = o->num_iter;
+  a.order = o->state_order == CDKF_ORDER_SECOND ? 2 : 1;
   const SweepStrides ss = sweep_strides(o, N, T, d, m, false);
   a.t_sn = ss.t_sn; a.t_sk = ss.t_sk; a.y_sn = ss.y_sn; a.y_sk = ss.y_sk; a.y_si = ss.y_si;
   const int lin = (o->layout_in == CDKF_LAYOUT_SAME) ? o->layout : o->layout_in;
@@ -1607,10 +1622,10 @@ static void ut_fill(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_
 }
 
 template <typename R>
-int launch_ukf_tangent(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll, R* grad,
-                       R* grad_model, int32_t* status, hipStream_t stream) {
+static int launch_tangent_impl(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll, R* grad,
+                               R* grad_model, int32_t* status, hipStream_t stream, bool ekf) {
   hipFunction_t fn;
-  int rc = ut_get_function(mdl, o, (int)sizeof(R), &fn, nullptr);
+  int rc = ut_get_function(mdl, o, (int)sizeof(R), &fn, nullptr, ekf);
   if (rc) return rc;
   if (!t || !y || !ll || (!grad && mdl->n_theta > 0)) {
     set_error("ukf_loglik_grad: t, y, ll and grad must not be NULL");
@@ -1634,10 +1649,24 @@ int launch_ukf_tangent(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int
   const long nleaf = a.all ? (long)mdl->n_theta + d + 2 * np + m * d + m + npm : (mdl->n_theta > 0 ? (long)mdl->n_theta : 1);
   const long total = N * nleaf;
   void* params[] = {(void*)&a};
-  note_kernel("ukf_tangent_kernel<%s> (d=%d m=%d, %ld leaf entries)", real_name<R>(), d, m, nleaf);
+  note_kernel("%s_tangent_kernel<%s> (d=%d m=%d, %ld leaf entries)", ekf ? "ekf" : "ukf", real_name<R>(), d, m, nleaf);
   CDKF_HIP_CHECK(hipModuleLaunchKernel(fn, (unsigned)((total + 63) / 64), 1, 1, 64, 1, 1, 0, stream, params, nullptr));
   return lease.release();
 }
+template <typename R>
+int launch_ukf_tangent(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll, R* grad,
+                       R* grad_model, int32_t* status, hipStream_t stream) {
+  return launch_tangent_impl<R>(mdl, o, N, T, t, y, ll, grad, grad_model, status, stream, false);
+}
+template <typename R>
+int launch_ekf_tangent(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll, R* grad,
+                       R* grad_model, int32_t* status, hipStream_t stream) {
+  return launch_tangent_impl<R>(mdl, o, N, T, t, y, ll, grad, grad_model, status, stream, true);
+}
+template int launch_ekf_tangent<float>(const cdkf_model*, const cdkf_opts*, int64_t, int64_t, const float*, const float*, float*, float*, float*,
+                                       int32_t*, hipStream_t);
+template int launch_ekf_tangent<double>(const cdkf_model*, const cdkf_opts*, int64_t, int64_t, const double*, const double*, double*, double*,
+                                        double*, int32_t*, hipStream_t);
 template int launch_ukf_tangent<float>(const cdkf_model*, const cdkf_opts*, int64_t, int64_t, const float*, const float*, float*, float*, float*,
                                        int32_t*, hipStream_t);
 template int launch_ukf_tangent<double>(const cdkf_model*, const cdkf_opts*, int64_t, int64_t, const double*, const double*, double*, double*,

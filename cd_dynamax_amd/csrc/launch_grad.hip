@@ -132,6 +132,9 @@ int launch_ekf_grad(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_
   }
   if (!sens && adjoint_shape_available(mdl, o))
     return launch_ekf_grad_adjoint<R>(mdl, o, N, T, t, y, ll, grad, grad_model, status, stream);
+  // what neither covers -- update iterations above eight dimensions, emissions given as source, the MLP beyond its LDS plan (round 5) --
+  // up to sixteen dimensions: forward mode through the literal recursion on dual numbers, a lane per (trajectory, leaf entry)
+  if (!sens && ekf_tangent_available(mdl, o)) return launch_ekf_tangent<R>(mdl, o, N, T, t, y, ll, grad, grad_model, status, stream);
   if (!sens) {
     set_error("loglik_grad: no kernel for drift_kind=%d state_dim=%d emission_dim=%d state_order=%d num_iter=%d "
               "(forward sensitivities: register-resident Lorenz-63 / linear shapes and run-time compiled drifts; reverse sweep: "

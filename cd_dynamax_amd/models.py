@@ -445,7 +445,8 @@ def cdnlgssm_loglik_and_grad_all(
         raise NotImplementedError(
             f"no reverse-sweep kernel for drift {type(params.dynamics.drift).__name__} with state_dim={mdl.state_dim}, "
             f"emission_dim={mdl.emission_dim}, state_order={hyperparams.state_order} (needs state and emission dimensions <= 8 -- LearnableLorenz96 / LearnableLinear: <= 43 in float64, 62 in float32 --, "
-            "MLP hidden layers <= 64, state_order 'first' or 'second'; num_iter > 1 for state and emission dimensions <= 8)")
+            "MLP hidden layers <= 64, state_order 'first' or 'second'; num_iter > 1 for state and emission dimensions <= 8; beyond those, up to "
+            "state / emission dimension 16 with the default solver: the tangent sweep of the literal recursion)")
     if on_device:  # the sweeps run on the device tensors; the (small) gradient blocks are packed on the host
         ll, gth, _, gm = (x.cpu().numpy() for x in _device.loglik_grad_device(mdl, opts, t, y, True))
     else:

@@ -435,6 +435,12 @@ int cdkf_ukf_grad_all_supported(const cdkf_model* mdl, const cdkf_opts* opts);
  *      unscented_kalman_filter, /root/reference/src/ssm_temissions.py:500, 555-568 -> inference_ukf.py:93-203.
  *      cdkf_ukf_tangent_compile: the kernel a model would get, compiled for gfx950 without a GPU (CDKF_OK or the compiler's message). */
 int cdkf_ukf_tangent_compile(const cdkf_model* mdl, const cdkf_opts* opts, int bytes_per_real);
+/* ... and the EXTENDED filter's gradient on the same plan, behind cdkf_ekf_loglik_grad[_all]_* where no forward-sensitivity kernel and no
+ *      reverse sweep exists: num_iter > 1 above eight dimensions, emissions given as source (d ll / d eta in the H / h_bias slots), the
+ *      MLP drift beyond its LDS plan -- state_dim, emission_dim <= 16, state_order first (second: state_dim <= 8), fixed-step
+ *      Dormand-Prince.  jacfwd(f), jacfwd(h) by an outer dual level over the parameter tangent (inference_ekf.py:95, 258), the iterated
+ *      update as inference_ekf.py:153-199 runs it. */
+int cdkf_ekf_tangent_compile(const cdkf_model* mdl, const cdkf_opts* opts, int bytes_per_real);
 /* ---- the same plus the gradient w.r.t. every other model parameter (the remaining leaves of the pytree jax.grad returns
  *      for ParamsCDNLGSSM): grad_model [N, d + 2 d^2 + m d + m + m^2] row-major, per trajectory
  *          m0 [d] | P0 [d,d] | LQL [d,d] | H [m,d] | h_bias [m] | R [m,m]

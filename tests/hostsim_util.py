@@ -243,9 +243,10 @@ def awg_run(include_src, mdl, opts, t, y, dtype, san, forward, *, inputs=None, n
     return grad, gm, np.frombuffer(raw, np.int32, N, off).copy()
 
 
-def ut_run(mdl, opts, t, y, dtype, san, *, every_leaf=True, opt="-O1", inputs=None, timeout=3000):
+def ut_run(mdl, opts, t, y, dtype, san, *, every_leaf=True, opt="-O1", inputs=None, timeout=3000, ekf=False):
     """Run the tangent sweep of the literal unscented recursion (cdkf_ukf_tangent_kernels.h) on the host for this model: the
     translation unit launch_custom.hip generates (cdkf_ukf_tangent_compile with CDKF_CUSTOM_DUMP; cross-compiles for gfx950 on the way).
+    ekf=True: the extended filter's sweep (cdkf_ekf_tangent_compile; opts.state_order / num_iter apply).
     t [N,T], y [N,T,m]; returns (ll [N], grad [N, n_theta], grad_model [N, .] or None, status [N])."""
     from cd_dynamax_amd import _ffi
     dtype = np.dtype(dtype)
@@ -254,7 +255,7 @@ def ut_run(mdl, opts, t, y, dtype, san, *, every_leaf=True, opt="-O1", inputs=No
     dump = tempfile.mkdtemp(prefix="cdkf_dump_")
     os.environ["CDKF_CUSTOM_DUMP"] = dump
     try:
-        rc = _ffi.lib().cdkf_ukf_tangent_compile(C.byref(mdl.c), C.byref(opts), dtype.itemsize)
+        rc = (_ffi.lib().cdkf_ekf_tangent_compile if ekf else _ffi.lib().cdkf_ukf_tangent_compile)(C.byref(mdl.c), C.byref(opts), dtype.itemsize)
         if rc:
             raise RuntimeError(_ffi.lib().cdkf_last_error().decode())
     finally:
@@ -267,7 +268,7 @@ def ut_run(mdl, opts, t, y, dtype, san, *, every_leaf=True, opt="-O1", inputs=No
                                                 args.ctypes.data_as(C.c_void_p), C.c_int64(args.nbytes), par.ctypes.data_as(C.c_void_p), C.c_int64(par.nbytes))
     assert n > 0, _ffi.lib().cdkf_last_error().decode()
     par = par[:n]
-    nargs = 8 * 8 + 8 * 11 + dtype.itemsize * 6 + 4   # 8 pointers, 11 longs, 6 reals, 1 int ...
+    nargs = 8 * 8 + 8 * 11 + dtype.itemsize * 6 + 4 * 3   # 8 pointers, 11 longs, 6 reals, 3 ints ...
     nargs = (nargs + 7) // 8 * 8                       # ... padded to the struct's alignment
     npd, npm = d * (d + 1) // 2, m * (m + 1) // 2
     nleaf = nth + d + 2 * npd + m * d + m + npm if every_leaf else max(nth, 1)

@@ -137,8 +137,15 @@ def test_custom_drift_second_order_with_divgrad(hip_lib):
             assert relerr(getattr(post, k), ref[k]) < 1e-11, k
         ref1 = o.ekf_filter(mdl, t, y, state_order="first")
         assert relerr(ref1["filtered_means"], ref["filtered_means"]) > 1e-6       # the second-order term is not a no-op here
-    with pytest.raises(NotImplementedError, match="no gradient kernel"):
-        cd.cdnlgssm_loglik_and_grad(P, y, t[..., None])
+    # the gradient at the default order (a non-zero grad(div f): no forward-sensitivity kernel) comes from the tangent sweep of the literal
+    # recursion (round 5, cdkf_ukf_tangent_kernels.h: ekf_tangent_body) -- against central differences of the filter's own log-likelihood
+    ll, g = cd.cdnlgssm_loglik_and_grad(P, y, t[..., None])
+    assert _ffi.lib().cdkf_last_kernel().decode().startswith("ekf_tangent_kernel<double>")
+    np.testing.assert_allclose(ll, post.marginal_loglik, rtol=1e-10)
+    e = 1e-6
+    fd = (cd.cdnlgssm_filter(params_for(mdl, cd.LearnableCustomDrift(theta + e, VDP_F, VDP_J, VDP_G)), y, t[..., None]).marginal_loglik
+          - cd.cdnlgssm_filter(params_for(mdl, cd.LearnableCustomDrift(theta - e, VDP_F, VDP_J, VDP_G)), y, t[..., None]).marginal_loglik) / (2 * e)
+    assert np.abs(np.asarray(g.theta)[:, 0] - fd).max() < 1e-6 * max(1.0, np.abs(fd).max())
     # another Runge-Kutta method through the same run-time compiled kernels
     hyp = cd.EKFHyperParams(diffeqsolve_settings={"solver": "tsit5"})
     with o.use_solver("tsit5"):
@@ -265,8 +272,16 @@ def test_custom_emission_with_builtin_drift(hip_lib):
     refu = o.ukf_filter(mdl, t, y)
     postu = cd.cdnlgssm_filter(P, y, t[..., None], cd.UKFHyperParams())
     assert relerr(postu.filtered_covariances, refu["filtered_covariances"]) < 1e-9
-    with pytest.raises(NotImplementedError, match="no gradient kernel"):
-        cd.cdnlgssm_loglik_and_grad(P, y, t[..., None])
+    # the extended filter's gradient under a source emission: the tangent sweep (round 5) against central differences of the filter
+    ll, g = cd.cdnlgssm_loglik_and_grad_all(P, y, t[..., None])
+    assert _ffi.lib().cdkf_last_kernel().decode().startswith("ekf_tangent_kernel<double>")
+    np.testing.assert_allclose(ll, post.marginal_loglik, rtol=1e-10)
+    with_eta = lambda ev: P._replace(emissions=cd.ParamsCDNLGSSMEmissions(cd.LearnableCustomEmission(ev, QUAD_H, QUAD_J), cd.LearnableMatrix(base.R)))
+    for pidx in range(3):
+        e = 1e-6 * np.eye(3)[pidx]
+        fd = (cd.cdnlgssm_filter(with_eta(eta + e), y, t[..., None]).marginal_loglik - cd.cdnlgssm_filter(with_eta(eta - e), y, t[..., None]).marginal_loglik) / 2e-6
+        got = np.asarray(g.emissions.emission_function.eta)[:, pidx]
+        assert np.abs(got - fd).max() < 2e-6 * max(1.0, np.abs(fd).max()), (pidx, got, fd)
 
 
 # ---- derivatives by dual numbers (round 3): the Jacobian, grad(div f) and the parameter gradient from f_src alone -----------------------

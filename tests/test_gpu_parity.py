@@ -942,7 +942,7 @@ def test_loglik_gradient_unsupported_raises(hip_lib):
         cd.cdnlgssm_loglik_and_grad(params_from(mdl), y, t[..., None])
     with pytest.raises(NotImplementedError, match="no gradient kernel"):
         from helpers import mlp_model                                    # an MLP drift with a hidden layer beyond 64: no reverse sweep
-        cd.cdnlgssm_loglik_and_grad(params_from(mlp_model(rng, 12, 4, (80, 8))), np.zeros((2, 5, 4)), t[..., None])
+        cd.cdnlgssm_loglik_and_grad(params_from(mlp_model(rng, 20, 4, (80, 8))), np.zeros((2, 5, 4)), t[..., None])   # (d <= 16: the tangent sweep)
     with pytest.raises(NotImplementedError, match="no gradient kernel"):
         cd.cdnlgssm_loglik_and_grad(params_from(o.lorenz63_model(3)), y[..., :3], t[..., None],
                                     cd.EKFHyperParams(state_order="zeroth"))

@@ -692,7 +692,7 @@ def test_loglik_gradient_with_iterated_updates(hip_lib, kind, d, m, num_iter):
     close(g.emissions.emission_function.weights, ex["H"], "H")
     close(g.emissions.emission_function.bias, ex["bias"], "bias")
     close(g.emissions.emission_cov.params, ex["R"], "R")
-    big = _general_model(rng, lorenz96_model(12, 4).drift, 12, 4)
+    big = _general_model(rng, lorenz96_model(20, 4).drift, 20, 4)   # (up to sixteen dimensions the tangent sweep iterates: tests/test_ukf_tangent.py)
     with pytest.raises(NotImplementedError):
         cd.cdnlgssm_loglik_and_grad_all(params_from(big), np.zeros((2, 4, 4)), np.arange(4.0)[None, :, None].repeat(2, 0), hyp, num_iter=2)
 

