@@ -422,82 +422,6 @@ struct UkfRhs {
   }
 };
 
-// ---- the same right-hand side with the 2 D + 1 sigma points of a trajectory on EIGHT LANES (round 5; D <= 3) ----------------------------
-// With few trajectories (<= 8 per wavefront: cdkf_api.hip reg_lanes_per_wave) the lane-per-trajectory sweep repeats every trajectory on
-// the idle lanes of its wavefront; here the copies share the work of the sigma-point sums instead: a trajectory lives on the eight
-// CONSECUTIVE lanes 8 q .. 8 q + 7 (spl_unit_index), copy c evaluates the drift at ONE sigma point -- c = 0 the mean, 1 .. D: m + c L_i,
-// D + 1 .. 2 D: m - c L_i, the rest: weight zero -- and the weighted sums of inference_ukf.py:128-152 are all-reduced over the eight lanes
-// by three DPP steps (row_half_mirror, quad_perm xor 1, xor 2).  Every step adds the same two values on both lanes of a pair, so the
-// eight copies stay bitwise equal and the update / Runge-Kutta combination they each repeat stays consistent.  Everything else -- the
-// Cholesky factor, the update, the stores -- is the lane-per-trajectory body unchanged (cdkf_filter_reg_body.inc with SPL = true).
-CDKF_DEV long spl_unit_index(int xcd_shift) {
-  const long b = blockIdx.x;
-  const int sh = xcd_shift;
-  const long grp = ((b >> (3 + sh)) << (3 + sh)) + ((b & 7) << sh) + ((b >> 3) & ((1 << sh) - 1));
-  return grp * 8 + (threadIdx.x >> 3);
-}
-CDKF_DEV bool spl_group_is_surplus(long unit, long units) { return unit - (threadIdx.x >> 3) >= units; }
-#if !defined(CDKF_HOST_SIM)
-template <int CTRL>
-CDKF_DEV float spl_dpp(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
-}
-template <int CTRL>
-CDKF_DEV double spl_dpp(double v) {
-  const long long b = __builtin_bit_cast(long long, v);
-  const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), CTRL, 0xf, 0xf, true);
-  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, true);
-  return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
-}
-template <typename R>
-CDKF_DEV R spl_group8_sum(R v) {
-  v += spl_dpp<0x141>(v);  // row_half_mirror: lane i <- lane 7 - i of its group of eight
-  v += spl_dpp<0xB1>(v);   // quad_perm [1, 0, 3, 2]
-  v += spl_dpp<0x4E>(v);   // quad_perm [2, 3, 0, 1]
-  return v;
-}
-#endif
-template <typename R, int D, typename Args>
-struct UkfRhsLanes {
-  static constexpr int NS = Dims<D>::NS;
-  const Args& a;
-  bool* bad;
-  static constexpr bool kTime = false;
-  CDKF_DEV void operator()(const R (&y)[NS], R (&dy)[NS]) const {
-#if !defined(CDKF_HOST_SIM)
-    static_assert(2 * D + 1 <= 8, "UkfRhsLanes: eight lanes per trajectory hold the sigma points of D <= 3");
-    R o[D][D];
-    ukf_offsets<R, D>(y, a.ukf_c, o, *bad);
-    const int c = threadIdx.x & 7;
-    const bool plus = c >= 1 && c <= D, minus = c > D && c <= 2 * D;
-    const int i = plus ? c - 1 : c - 1 - D;
-    const R sgn = plus ? R(1) : (minus ? R(-1) : R(0));
-    R col[D], x[D], f[D];
-#pragma unroll
-    for (int j = 0; j < D; ++j) {
-      R v = R(0);
-#pragma unroll
-      for (int k = 0; k < D; ++k) v = (i == k) ? o[k][j] : v;
-      col[j] = v;
-      x[j] = rfma(sgn, v, y[j]);
-    }
-    a.drift.f(x, f);
-    const R wm = (c == 0) ? a.ukf_wm0 : ((plus || minus) ? a.ukf_wi : R(0));
-#pragma unroll
-    for (int j = 0; j < D; ++j) dy[j] = spl_group8_sum<R>(wm * f[j]);
-    const R ws = sgn * a.ukf_wi;
-#pragma unroll
-    for (int r = 0; r < D; ++r)
-#pragma unroll
-      for (int b = r; b < D; ++b)
-        dy[D + sidx<D>(r, b)] = spl_group8_sum<R>(ws * rfma(f[r], col[b], f[b] * col[r])) + a.LQL[sidx<D>(r, b)];
-#else
-    (void)y;
-    (void)dy;
-#endif
-  }
-};
-
 // Shared tail of the unscented update: log-likelihood term MVN(ybar, S).log_prob(y), gain K = psd_solve(S, C^T)^T,
 // m+ = m + K v, P+ = P - K S K^T  (inference_ukf.py:196-203).  v = y - ybar, Sm = S, C = cross-covariance [D][M].
 template <typename R, int D, int M>
@@ -788,14 +712,6 @@ constexpr int kOutNone = 0, kOutAll = 1, kOutSome = 2;
 template <typename R, int D, int M, typename Drift, bool UKF, bool ZEROTH, bool HSEL, int OUT, bool FORECAST = false,
           bool GENERIC = false, typename Emis = EmisLinearTag>
 __global__ __launch_bounds__(64, 1) void filter_reg_kernel(const RegArgs<R, D, M, Drift> a) {
-  constexpr bool SPL = false;
-#include "cdkf_filter_reg_body.inc"
-}
-// the unscented sweep with a trajectory's sigma points on eight lanes (UkfRhsLanes above): D <= 3, fixed-step Dormand-Prince
-template <typename R, int D, int M, typename Drift, int OUT, typename Emis = EmisLinearTag, bool UKF = true, bool ZEROTH = false,
-          bool HSEL = false, bool FORECAST = false, bool GENERIC = false>
-__global__ __launch_bounds__(64, 1) void filter_reg_spl_kernel(const RegArgs<R, D, M, Drift> a) {
-  constexpr bool SPL = true;  // (the other switches are template parameters so that the body's `if constexpr` discards what it must)
 #include "cdkf_filter_reg_body.inc"
 }
 
@@ -803,7 +719,6 @@ __global__ __launch_bounds__(64, 1) void filter_reg_spl_kernel(const RegArgs<R, 
 template <typename R, int D, int M, typename Drift, bool UKF, bool ZEROTH, bool HSEL, int OUT, bool FORECAST = false,
           bool GENERIC = false, typename Emis = EmisLinearTag>
 CDKF_DEV void filter_reg_body(const RegArgs<R, D, M, Drift>& a) {
-  constexpr bool SPL = false;
 #include "cdkf_filter_reg_body.inc"
 }
 

@@ -10,35 +10,7 @@ static int run_ukf_reg(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int
   RegArgs<R, D, M, Drift> a;
   fill_reg_args(a, mdl, o, N, T, t, y, ll, fm, fP, pm, pP, status);
   // small Lorenz-63 batches with H = I: sixteen lanes per trajectory, the unscented moment equations in closed form (LpeRhs<R, true>)
-  if (try_lpe(a, mdl, o, stream, true)) {
-    CDKF_HIP_CHECK(hipGetLastError());
-    return CDKF_OK;
-  }
-  // literal sigma points, few trajectories (the lane-per-trajectory sweep would repeat each on the idle lanes of its wavefront): the
-  // sigma points of a trajectory on eight lanes instead (round 5, cdkf_reg_kernels.h: UkfRhsLanes).  CDKF_NO_UKF_LANES=1 pins the old mapping.
-  if constexpr (2 * D + 1 <= 8) {
-    const bool generic = a.rk.stages && (a.solver != CDKF_SOLVER_DOPRI5 || a.rk.adaptive);
-    if (!generic && !a.forecast && a.lanes <= 8 && !env_flag("CDKF_NO_UKF_LANES")) {
-      const int bytes = (int)sizeof(R);
-      int sh = 0;
-      while ((8 << sh) * bytes < 128) ++sh;
-      a.lanes = 8;
-      a.xcd_shift = sh;
-      const int64_t groups = (N + 7) / 8, round = (int64_t)8 << sh;
-      const dim3 grid((unsigned)(sh ? (groups + round - 1) / round * round : groups)), block(64);
-      const bool all = a.fm && a.fP && a.pm && a.pP, none = !a.fm && !a.fP && !a.pm && !a.pP;
-      note_kernel("filter_reg_spl_kernel<%s, %d, %d> (sigma points on eight lanes)", real_name<R>(), D, M);
-      if (all)
-        hipLaunchKernelGGL((filter_reg_spl_kernel<R, D, M, Drift, kOutAll>), grid, block, 0, stream, a);
-      else if (none)
-        hipLaunchKernelGGL((filter_reg_spl_kernel<R, D, M, Drift, kOutNone>), grid, block, 0, stream, a);
-      else
-        hipLaunchKernelGGL((filter_reg_spl_kernel<R, D, M, Drift, kOutSome>), grid, block, 0, stream, a);
-      CDKF_HIP_CHECK(hipGetLastError());
-      return CDKF_OK;
-    }
-  }
-  launch_filter_reg<R, D, M, Drift, true, false, false>(a, stream);
+  if (!try_lpe(a, mdl, o, stream, true)) launch_filter_reg<R, D, M, Drift, true, false, false>(a, stream);
   CDKF_HIP_CHECK(hipGetLastError());
   return CDKF_OK;
 }
