@@ -15,9 +15,9 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-# (script, seed, cases): seeds chosen once and kept; together 40 cases
+# (script, seed, cases): seeds chosen once and kept; together 48 cases (round 5: the tangent sweeps' fuzzer)
 SLICE = [("filters", 20261, 9), ("grads", 20262, 6), ("batches", 20263, 6), ("solvers", 20264, 6), ("misc", 20265, 5),
-         ("r03", 20266, 4), ("custom", 20267, 4)]
+         ("r03", 20266, 4), ("custom", 20267, 4), ("tangent", 20268, 8)]
 
 
 # cases the fuzzers caught with run-dependent seeds, replayed alone (the generator's draws in its order, the other cases skipped):
