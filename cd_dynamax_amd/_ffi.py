@@ -121,7 +121,7 @@ SYMBOLS = (
      "cdkf_ll_allreduce", "cdkf_comm_allreduce_max", "cdkf_ll_allreduce_all", "cdkf_comm_destroy", "cdkf_rdv_create",
      "cdkf_rdv_broadcast", "cdkf_rdv_allreduce", "cdkf_rdv_barrier", "cdkf_rdv_destroy", "cdkf_last_kernel", "cdkf_event_create",
      "cdkf_event_record", "cdkf_event_elapsed_ms", "cdkf_event_destroy", "cdkf_stream_create", "cdkf_stream_destroy",
-     "cdkf_set_device", "cdkf_debug_custom_reg_blob", "cdkf_debug_wg_args", "cdkf_rtc_cache_stats"]
+     "cdkf_set_device", "cdkf_struct_sizes", "cdkf_debug_custom_reg_blob", "cdkf_debug_wg_args", "cdkf_rtc_cache_stats"]
     + [f"cdkf_{a}_{p}{s}" for a in _ALGOS for p in ("f64", "f32") for s in ("", "_dev")]
 )
 
@@ -174,6 +174,13 @@ def lib() -> C.CDLL:
     L = C.CDLL(LIB_PATH)
     L.cdkf_last_error.restype = C.c_char_p
     L.cdkf_version.restype = C.c_int
+    if hasattr(L, "cdkf_struct_sizes"):   # the structs this module mirrors have grown (versions 107, 109): never hand a library a shorter one
+        mb, ob = C.c_int64(0), C.c_int64(0)
+        L.cdkf_struct_sizes.restype = None
+        L.cdkf_struct_sizes(C.byref(mb), C.byref(ob))
+        if (mb.value, ob.value) != (C.sizeof(CdkfModel), C.sizeof(CdkfOpts)):
+            raise CdkfError(f"{LIB_PATH} was built for cdkf_model / cdkf_opts of {mb.value} / {ob.value} bytes (version {L.cdkf_version()}); "
+                            f"this binding's structs are {C.sizeof(CdkfModel)} / {C.sizeof(CdkfOpts)}: rebuild the library or update the binding")
     L.cdkf_device_count.restype = C.c_int
     L.cdkf_default_opts.argtypes = [C.POINTER(CdkfOpts)]
     L.cdkf_default_opts.restype = None

@@ -552,6 +552,10 @@ void cdkf_default_opts(cdkf_opts* o) {
 }
 
 int cdkf_version(void) { return CDKF_VERSION; }
+void cdkf_struct_sizes(int64_t* model_bytes, int64_t* opts_bytes) {
+  if (model_bytes) *model_bytes = (int64_t)sizeof(cdkf_model);
+  if (opts_bytes) *opts_bytes = (int64_t)sizeof(cdkf_opts);
+}
 const char* cdkf_last_error(void) { return g_err; }
 
 int cdkf_device_count(void) {

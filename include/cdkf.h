@@ -173,6 +173,10 @@ typedef struct cdkf_opts {
 void cdkf_default_opts(cdkf_opts* opts);
 
 int cdkf_version(void);
+/* sizeof(cdkf_model) and sizeof(cdkf_opts) as THIS library was built.  Both structs have grown (versions 107, 109): a binding that mirrors
+ * them (ctypes, cgo, JNI) compares these with its own sizes before the first call instead of letting the library read past a shorter
+ * struct (cd_dynamax_amd/_ffi.py does, and raises). */
+void cdkf_struct_sizes(int64_t* model_bytes, int64_t* opts_bytes);
 const char* cdkf_last_error(void);
 /* Number of HIP devices visible, or a negative error code. */
 int cdkf_device_count(void);

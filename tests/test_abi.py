@@ -175,3 +175,12 @@ def test_toolchain_workarounds_cannot_be_switched_off_from_the_command_line():
     assert "-O1" not in w8[0].split() and "-vgpr-regalloc=basic" not in w8[0].split() and "-O3" in w8[0].split(), w8[0]
     src = open(os.path.join(csrc, "launch_custom.hip")).read()
     assert 'return {"-O3", nullptr, nullptr, lim};' in src and 'if (workgroup) return {"-O1", nullptr, nullptr, 0};' in src   # the shipped policy
+
+
+def test_struct_sizes_are_checked_at_load(hip_lib):
+    """cdkf_struct_sizes: the library's sizeof(cdkf_model) / sizeof(cdkf_opts) equal the ctypes mirrors' (the structs grew in
+    versions 107 and 109 and nothing told a caller built against an older header); _ffi.lib() compares them at load and raises."""
+    mb, ob = C.c_int64(0), C.c_int64(0)
+    hip_lib.cdkf_struct_sizes(C.byref(mb), C.byref(ob))
+    assert (mb.value, ob.value) == (C.sizeof(_ffi.CdkfModel), C.sizeof(_ffi.CdkfOpts))
+    hip_lib.cdkf_struct_sizes(None, None)   # null outputs are ignored
