@@ -1,4 +1,6 @@
-// cdkf_ukf_tangent_kernels.h -- value and gradient of the UNSCENTED filter's marginal log-likelihood for ANY drift and emission.
+// cdkf_ukf_tangent_kernels.h -- value and gradient of the UNSCENTED filter's marginal log-likelihood for ANY drift and emission
+// (ukf_tangent_body), and of the EXTENDED filter's where no forward-sensitivity kernel and no reverse sweep exists (ekf_tangent_body, at
+// the end of the file): forward mode through the literal recursions on dual numbers.
 //
 // The reference differentiates unscented_kalman_filter with jax.value_and_grad whatever the model is (ssm_temissions.py:500, 555-568 ->
 // models.py:393-408, 708 -> inference_ukf.py:93-203, the Cholesky factor's derivative included).  The closed forms of cdkf_grad_kernels.h /
