@@ -88,6 +88,9 @@ class CdkfOpts(C.Structure):
         ("dtmin", C.c_double),
         ("dtmax", C.c_double),
         ("inputs", C.c_void_p),
+        ("pid_safety", C.c_double),
+        ("pid_factormin", C.c_double),
+        ("pid_factormax", C.c_double),
     ]
 
 

@@ -100,6 +100,12 @@ int check_common(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T
       set_error("adaptive stepping: need 0 <= dtmin <= dtmax (got dtmin %g, dtmax %g; defaults 0 and infinity, dtmax 0 = no bound)", o->dtmin, o->dtmax);
       return CDKF_EINVAL;
     }
+    if (!(o->pid_safety >= 0) || !(o->pid_factormin >= 0) || !(o->pid_factormax >= 0) || (o->pid_factormin > 1) ||
+        (o->pid_factormax > 0 && o->pid_factormax < 1)) {
+      set_error("adaptive stepping: need safety > 0, 0 < factormin <= 1 <= factormax (got %g, %g, %g; 0 = the defaults 0.9, 0.2, 10)",
+                o->pid_safety, o->pid_factormin, o->pid_factormax);
+      return CDKF_EINVAL;
+    }
   }
   if (o->flags & ~CDKF_FLAG_UKF_SIGMA_POINTS) {
     set_error("opts.flags = 0x%x has bits this library version does not know (CDKF_FLAG_*)", (unsigned)o->flags);
@@ -541,6 +547,9 @@ void cdkf_default_opts(cdkf_opts* o) {
   o->flags = 0;
   o->dtmin = 0.0;
   o->dtmax = HUGE_VAL;
+  o->pid_safety = 0.9;
+  o->pid_factormin = 0.2;
+  o->pid_factormax = 10.0;
   o->inputs = nullptr;
   o->max_steps = 100000;
   o->dt0 = 0.01;

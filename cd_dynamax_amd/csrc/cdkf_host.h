@@ -165,6 +165,9 @@ inline bool fill_rk_tab(const cdkf_opts* o, RkTab<R>& tb) {
   tb.c3 = R(o->pid_d / ord);
   tb.dtmin = R(o->dtmin);
   tb.dtmax = (o->dtmax == 0.0) ? R(HUGE_VAL) : R(o->dtmax);  // (0: no bound -- a zero-initialised cdkf_opts keeps working)
+  tb.safety = R(o->pid_safety > 0 ? o->pid_safety : 0.9);  // (0: diffrax's defaults, as for dtmax)
+  tb.fmin = R(o->pid_factormin > 0 ? o->pid_factormin : 0.2);
+  tb.fmax = R(o->pid_factormax > 0 ? o->pid_factormax : 10.0);
   return true;
 }
 

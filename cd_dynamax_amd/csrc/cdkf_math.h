@@ -293,6 +293,7 @@ struct RkTab {
   R berr[7];
   R rtol, atol, c1, c2, c3;
   R dtmin, dtmax;  // bounds on every proposed step size (0 / +inf: none); a step taken at dtmin is kept (PIDController force_dtmin)
+  R safety, fmin, fmax;  // PIDController(safety, factormin, factormax): 0.9, 0.2, 10 unless the caller says otherwise (cdkf_opts, version 110)
 };
 
 // stage time offset c_s = sum_j a_sj of a run-time tableau
@@ -345,7 +346,7 @@ CDKF_DEV double rmax(double a, double b) { return fmax(a, b); }
 // Adaptive solve: the step-size controller of diffrax.PIDController (restated from its published algorithm; oracle:
 // _diffeqsolve_adaptive).  Per step: the embedded error estimate, its RMS over ALL entries of the state pytree -- the mean
 // and the FULL d x d covariance, so the packed off-diagonal entries count twice -- scaled by atol + max(|y|, |y_new|) rtol;
-// accept iff < 1; next size = attempted size * clip(0.9 e^-c1 e1^-c2 e2^-c3, [1 if accepted else 0.2, 10]); a rejected step
+// accept iff < 1; next size = attempted size * clip(safety e^-c1 e1^-c2 e2^-c3, [1 if accepted else factormin, factormax]) (0.9, 0.2, 10 by default); a rejected step
 // that would cross the end goes half-way.  max_steps counts attempts.  Each lane adapts on its own.
 // NERR: the leading entries of y that form the reference's state pytree and enter the error norm (all of them for the
 // filters; the primal half for the forward-sensitivity gradient kernels, whose tangents ride along on the primal's steps
@@ -425,12 +426,12 @@ CDKF_DEV bool integrate_adaptive(R (&y)[NS], R t0, R t1, R dt0, long max_steps, 
     const R scaled = rsqrt_(sq / R(COUNT));
     const bool keep = scaled < R(1) || at_min;
     const R inv = (scaled == R(0)) ? R(__builtin_huge_val()) : R(1) / scaled;
-    R factor = R(0.9) * rpow(inv, tb.c1);
+    R factor = tb.safety * rpow(inv, tb.c1);
     if (tb.c2 != R(0)) factor *= rpow(inv1, tb.c2);
     if (tb.c3 != R(0)) factor *= rpow(inv2, tb.c3);
     // fmax / fmin semantics: a NaN estimate (a stage that left the domain because the attempted step was far too long)
     // rejects the step and shrinks it by factormin; diffrax's clip would propagate the NaN and end in its max_steps error
-    factor = rmin(rmax(factor, keep ? R(1) : R(0.2)), R(10));
+    factor = rmin(rmax(factor, keep ? R(1) : tb.fmin), tb.fmax);
     const R nt0 = keep ? tnext : tprev;
     R dtn = rmin(dt * factor, tb.dtmax);
     at_min = dtn <= tb.dtmin;

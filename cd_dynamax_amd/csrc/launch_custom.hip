@@ -488,7 +488,7 @@ std::string generate_source(const CustomDrift& c, int bytes, int m, int ukf, int
   s += "using R = " + std::string(bytes == 8 ? "double" : "float") + ";\n";
   s += "constexpr int DD = " + std::to_string(c.d) + ", MM = " + std::to_string(m) + ";\n";
   s += "using Drift = cdkf::DriftCustom<R, DD>;\nusing Args = cdkf::RegArgs<R, DD, MM, Drift>;\n";
-  // parameter blob (reals): theta | LQL | LQLz | H | hb | Rm | m0 | P0 | dt0 dt_final ukf_c ukf_wm0 ukf_wc0 ukf_wi | rk.a[30] rk.b[6] rk.berr[7] rtol atol c1 c2 c3 | dtmin dtmax
+  // parameter blob (reals): theta | LQL | LQLz | H | hb | Rm | m0 | P0 | dt0 dt_final ukf_c ukf_wm0 ukf_wc0 ukf_wi | rk.a[30] rk.b[6] rk.berr[7] rtol atol c1 c2 c3 | dtmin dtmax safety factormin factormax
   // integer blob (longs) : max_steps order num_iter forecast N T t_sn t_sk y_sn y_sk y_si m_sn m_sk m_si P_sn P_sk P_si stages solver
   //                        adaptive fsal lanes xcd_shift u_sn u_sk u_si
   s += R"(
@@ -522,7 +522,7 @@ __device__ __forceinline__ void unpack(Args& a, const R* __restrict__ par, const
   for (int s = 0; s < 7; ++s) a.rk.berr[s] = par[o + s];
   o += 7;
   a.rk.rtol = par[o]; a.rk.atol = par[o + 1]; a.rk.c1 = par[o + 2]; a.rk.c2 = par[o + 3]; a.rk.c3 = par[o + 4];
-  a.rk.dtmin = par[o + 5]; a.rk.dtmax = par[o + 6];
+  a.rk.dtmin = par[o + 5]; a.rk.dtmax = par[o + 6]; a.rk.safety = par[o + 7]; a.rk.fmin = par[o + 8]; a.rk.fmax = par[o + 9];
   a.rk.stages = (int)ip[17]; a.solver = (int)ip[18]; a.rk.adaptive = (int)ip[19]; a.rk.fsal = (int)ip[20]; a.lanes = (int)ip[21]; a.xcd_shift = (int)ip[22];
   a.max_steps = ip[0]; a.order = (int)ip[1]; a.num_iter = (int)ip[2]; a.forecast = (int)ip[3]; a.N = ip[4]; a.T = ip[5];
   a.t_sn = ip[6]; a.t_sk = ip[7]; a.y_sn = ip[8]; a.y_sk = ip[9]; a.y_si = ip[10]; a.m_sn = ip[11]; a.m_sk = ip[12];
@@ -1125,7 +1125,7 @@ bool custom_grad_available(const cdkf_model* mdl, const cdkf_opts* o) {
 
 // The two argument blocks of a run-time compiled register-resident kernel (the generated `unpack` reads them back):
 //   reals: theta | LQL | LQLz | H | hb | Rm | m0 | P0 | dt0 dt_final ukf_c ukf_wm0 ukf_wc0 ukf_wi | rk.a[30] rk.b[6] rk.berr[7] rtol atol c1 c2 c3
-//          | dtmin dtmax
+//          | dtmin dtmax safety factormin factormax
 //   longs: max_steps order num_iter forecast N T t_sn t_sk y_sn y_sk y_si m_sn m_sk m_si P_sn P_sk P_si stages solver adaptive fsal lanes xcd_shift
 //          u_sn u_sk u_si
 // Host arithmetic only (cdkf_debug_custom_reg_blob hands them to the CPU-sanitizer build of the same kernel, tests/test_hostsim.py).
@@ -1167,6 +1167,7 @@ static RegGrouping custom_reg_blob(const cdkf_model* mdl, const cdkf_opts* o, in
   for (int s = 0; s < 7; ++s) par.push_back(tb.berr[s]);
   par.push_back(tb.rtol); par.push_back(tb.atol); par.push_back(tb.c1); par.push_back(tb.c2); par.push_back(tb.c3);
   par.push_back(tb.dtmin); par.push_back(tb.dtmax);
+  par.push_back(tb.safety); par.push_back(tb.fmin); par.push_back(tb.fmax);
   const RegGrouping grouping = reg_grouping(gradient ? N * mdl->n_theta : N, (int)sizeof(R));  // (gradient: a lane per (trajectory, parameter))
   ip[21] = grouping.lanes;
   ip[22] = grouping.xcd_shift;

@@ -116,7 +116,7 @@ def _opts(hyperparams, num_iter: int = 1):
     if ctrl is not None and type(ctrl).__name__ != "ConstantStepSize" and ctrl != "ConstantStepSize":
         if not (hasattr(ctrl, "rtol") and hasattr(ctrl, "atol")):
             raise NotImplementedError(f"diffeqsolve_settings['stepsize_controller'] = {ctrl!r}: ConstantStepSize or PIDController")
-        defaults = dict(step_ts=None, jump_ts=None, safety=0.9, factormin=0.2, factormax=10.0, force_dtmin=True, error_order=None)
+        defaults = dict(step_ts=None, jump_ts=None, force_dtmin=True, error_order=None)
         for k, v in defaults.items():
             if hasattr(ctrl, k) and getattr(ctrl, k) is not None and getattr(ctrl, k) != v:
                 raise NotImplementedError(f"PIDController.{k} = {getattr(ctrl, k)!r}: only the default ({v!r}) is implemented")
@@ -127,6 +127,9 @@ def _opts(hyperparams, num_iter: int = 1):
             o.dtmin = float(ctrl.dtmin)
         if getattr(ctrl, "dtmax", None) is not None:
             o.dtmax = float(ctrl.dtmax)
+        for k, field in (("safety", "pid_safety"), ("factormin", "pid_factormin"), ("factormax", "pid_factormax")):   # (ABI 110)
+            if getattr(ctrl, k, None) is not None:
+                setattr(o, field, float(getattr(ctrl, k)))
     solver = settings.get("solver", "dopri5")
     name = solver.lower() if isinstance(solver, str) else type(solver).__name__.lower()   # 'tsit5' or a diffrax.Tsit5() object
     if name not in _ffi.SOLVERS:

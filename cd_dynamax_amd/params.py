@@ -92,9 +92,9 @@ class ConstantStepSize(NamedTuple):
 
 
 class PIDController(NamedTuple):
-    """diffrax.PIDController(rtol, atol, pcoeff, icoeff, dcoeff, dtmin, dtmax) for ``diffeqsolve_settings['stepsize_controller']``;
-    the remaining diffrax options are at their defaults (safety 0.9, factormin 0.2, factormax 10, RMS norm, force_dtmin=True).
-    A diffrax controller object with the same attributes is accepted as well."""
+    """diffrax.PIDController(rtol, atol, pcoeff, icoeff, dcoeff, dtmin, dtmax, safety, factormin, factormax) for
+    ``diffeqsolve_settings['stepsize_controller']``; the remaining diffrax options are at their defaults (RMS norm, force_dtmin=True, no
+    step_ts / jump_ts).  A diffrax controller object with the same attributes is accepted as well."""
     rtol: float
     atol: float
     pcoeff: float = 0.0
@@ -102,6 +102,9 @@ class PIDController(NamedTuple):
     dcoeff: float = 0.0
     dtmin: Optional[float] = None
     dtmax: Optional[float] = None
+    safety: float = 0.9
+    factormin: float = 0.2
+    factormax: float = 10.0
 
 
 class LearnableCustomDrift(NamedTuple):

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define CDKF_VERSION 109 /* 0.5.0 */
+#define CDKF_VERSION 110 /* 0.5.0 */
 
 /* error codes */
 #define CDKF_OK 0
@@ -167,6 +167,10 @@ typedef struct cdkf_opts {
                             points, device memory for the _dev ones).  NULL with input_dim > 0: zeros (the reference's
                             _process_input, inference_ekf.py:32, 260).  Clients built against version 108 must be rebuilt: the two
                             structs grew. */
+  double pid_safety;     /* (version 110) adaptive only: PIDController(safety=, factormin=, factormax=) -- the next step size is the attempted */
+  double pid_factormin;  /* one times clip(safety * e^-c1 e1^-c2 e2^-c3, [1 if the step was kept else factormin, factormax]).  Defaults 0.9, */
+  double pid_factormax;  /* 0.2, 10 (diffrax's); 0 is read as the default, so that a zero-initialised struct keeps working.  cdkf_struct_sizes() */
+                         /* tells a binding whether its mirror of this struct is the library's. */
 } cdkf_opts;
 
 /* Fill *opts with the reference defaults listed above. */

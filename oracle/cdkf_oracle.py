@@ -117,8 +117,8 @@ _ACTIVE = [("dopri5", None)]
 
 class use_solver:
     """``with use_solver('tsit5'): ...`` -- every diffeqsolve call inside integrates with that tableau.  ``adaptive``: None
-    (fixed steps of dt0, diffrax.ConstantStepSize) or a dict(rtol, atol[, pcoeff=0, icoeff=1, dcoeff=0]) for
-    diffrax.PIDController."""
+    (fixed steps of dt0, diffrax.ConstantStepSize) or a dict(rtol, atol[, pcoeff=0, icoeff=1, dcoeff=0, dtmin, dtmax, safety=0.9,
+    factormin=0.2, factormax=10]) for diffrax.PIDController."""
 
     def __init__(self, name, adaptive=None):
         if name not in TABLEAUS:
@@ -559,7 +559,7 @@ def _diffeqsolve_adaptive(rhs, t0, t1, y0, dt0, max_steps, count_steps, err_comp
     rtol, atol = dtype.type(ad["rtol"]), dtype.type(ad["atol"])
     pc, ic, dc = (dtype.type(ad.get(k, v)) for k, v in (("pcoeff", 0.0), ("icoeff", 1.0), ("dcoeff", 0.0)))
     c1, c2, c3 = (ic + pc + dc) / order, -(pc + 2 * dc) / order, dc / order
-    safety, fmin, fmax = dtype.type(0.9), dtype.type(0.2), dtype.type(10.0)
+    safety, fmin, fmax = (dtype.type(ad.get(k) or v) for k, v in (("safety", 0.9), ("factormin", 0.2), ("factormax", 10.0)))
     # dtmin / dtmax (PIDController.init and the end of adapt_step_size, force_dtmin=True): every proposed size -- the first one too -- is
     # clipped to [dtmin, dtmax]; a step proposed at or below dtmin is flagged, and the step taken under that flag is KEPT whatever its error
     dtmin, dtmax = dtype.type(ad.get("dtmin") or 0.0), dtype.type(ad.get("dtmax") or np.inf)

@@ -27,13 +27,14 @@ def test_library_exports_every_declared_symbol(hip_lib):
 
 
 def test_version_and_default_opts(hip_lib):
-    assert hip_lib.cdkf_version() == 109
+    assert hip_lib.cdkf_version() == 110
     o = _ffi.default_opts()
     assert (o.state_order, o.num_iter, o.t_shared, o.device, o.layout) == (2, 1, 0, -1, 0)
     assert o.max_steps == 100000 and o.dt0 == 0.01 and o.dt_final == 1e-10 and o.cov_rescaling == 1.0
     assert abs(o.ukf_alpha - np.sqrt(3)) < 1e-15 and o.ukf_beta == 2 and o.ukf_kappa == 1
     # struct sizes the header implies (LP64): guards against silent ABI drift
-    assert C.sizeof(_ffi.CdkfOpts) == 8 * 4 + 8 + 11 * 8 + 2 * 4 + 2 * 8 + 8  # (v108: + dtmin, dtmax; v109: + inputs)
+    assert C.sizeof(_ffi.CdkfOpts) == 8 * 4 + 8 + 11 * 8 + 2 * 4 + 2 * 8 + 8 + 3 * 8  # (v108: + dtmin, dtmax; v109: + inputs; v110: + safety, factormin, factormax)
+    assert (o.pid_safety, o.pid_factormin, o.pid_factormax) == (0.9, 0.2, 10.0)
     assert C.sizeof(_ffi.CdkfModel) == 6 * 4 + 8 + 8 * 8 + 2 * 4  # (v109: + input_dim, reserved0)
 
 

@@ -1256,9 +1256,12 @@ def test_adaptive_step_size_control(hip_lib, solver, ctrl):
 
 
 @pytest.mark.parametrize("ctrl", [dict(rtol=1e-6, atol=1e-8, dtmax=0.004), dict(rtol=1e-12, atol=1e-14, dtmin=0.003),
-                                  dict(rtol=1e-5, atol=1e-7, pcoeff=0.1, icoeff=0.3, dtmin=0.002, dtmax=0.01)])
+                                  dict(rtol=1e-5, atol=1e-7, pcoeff=0.1, icoeff=0.3, dtmin=0.002, dtmax=0.01),
+                                  dict(rtol=1e-6, atol=1e-8, safety=0.7, factormin=0.5, factormax=1.5),      # (ABI 110: the controller's clip)
+                                  dict(rtol=1e-7, atol=1e-9, pcoeff=0.2, icoeff=0.4, safety=0.95, factormin=0.1, factormax=3.0, dtmax=0.02)])
 def test_adaptive_step_size_bounds(hip_lib, ctrl):
-    """PIDController(dtmin=, dtmax=) (the reference forwards any controller, src/utils/diffrax_utils.py:40-57): the
+    """PIDController(dtmin=, dtmax=) and (round 5, ABI 110) PIDController(safety=, factormin=, factormax=) -- the
+    reference forwards any controller, src/utils/diffrax_utils.py:40-57: the
     three kernel families that adapt -- register-resident (Lorenz-63), workgroup (Lorenz-96 d = 12), the type-1 smoother's pushed-forward
     (A, Q) of the linear front-end -- against the oracle's controller with the same bounds: a cap that binds on every step, a floor that
     forces steps the tolerance would reject (kept by force_dtmin), both at once."""
@@ -1279,7 +1282,7 @@ def test_adaptive_step_size_bounds(hip_lib, ctrl):
         sm = cd.cdnlgssm_smoother(P, y, t[..., None], cd.EKFHyperParams(state_order="first", diffeqsolve_settings=settings))
         assert relerr(sm.smoothed_covariances, refs["smoothed_covariances"]) < 1e-8, mdl.d
     # the bounds really bind: without them the same tolerances give other numbers
-    free = {k: v for k, v in ctrl.items() if k not in ("dtmin", "dtmax")}
+    free = {k: v for k, v in ctrl.items() if k not in ("dtmin", "dtmax", "safety", "factormin", "factormax")}
     postf = cd.cdnlgssm_filter(P, y, t[..., None], cd.EKFHyperParams(state_order="first", diffeqsolve_settings=dict(
         settings, stepsize_controller=cd.PIDController(**free), max_steps=400)))
     assert not np.array_equal(np.nan_to_num(postf.filtered_means), post.filtered_means)

@@ -569,6 +569,28 @@ def test_adaptive_controller_step_size_bounds():
     assert abs(yd[0, 0] - exact) < 1e-4
 
 
+def test_adaptive_controller_safety_and_factor_clip():
+    """PIDController(safety=, factormin=, factormax=): the next size is the attempted one times clip(safety e^-c1 ..., [1 if kept else
+    factormin, factormax]).  The defaults spelled out change nothing; factormax = 1.5 caps the growth of consecutive accepted steps at
+    1.5; a smaller safety takes more steps; the answer stays the ODE's."""
+    rhs = lambda yv: (yv[0] * (1 - yv[0]),)
+    y0 = (np.full((1, 1), 0.2),)
+    runs = {}
+    for name, ad in (("default", dict(rtol=1e-6, atol=1e-8)), ("spelled", dict(rtol=1e-6, atol=1e-8, safety=0.9, factormin=0.2, factormax=10.0)),
+                     ("capped", dict(rtol=1e-6, atol=1e-8, factormax=1.5)), ("timid", dict(rtol=1e-6, atol=1e-8, safety=0.5))):
+        counts, log = [], []
+        with o.use_solver("dopri5", adaptive=ad):
+            (ya,) = o.diffeqsolve(rhs, np.zeros(1), np.full(1, 3.0), y0, dt0=0.001, count_steps=counts, dt_log=log)
+        runs[name] = (ya, counts[0][0], log)
+    assert np.array_equal(runs["default"][0], runs["spelled"][0]) and runs["default"][2] == runs["spelled"][2]
+    growth = lambda log: max(b / a for a, b in zip(log[:-2], log[1:-1]))      # (the last step is clipped to the interval's end)
+    assert growth(runs["default"][2]) > 2.0 and growth(runs["capped"][2]) <= 1.5 * (1 + 1e-12)
+    assert runs["capped"][1] > runs["default"][1] and runs["timid"][1] > runs["default"][1]
+    exact = 0.2 * np.exp(3.0) / (1 + 0.2 * (np.exp(3.0) - 1))
+    for ya, _, _ in runs.values():
+        assert abs(ya[0, 0] - exact) < 1e-6
+
+
 def test_gradient_under_another_fixed_step_method_matches_finite_differences():
     """Forward sensitivities along the steps of a non-default tableau (Heun) are still the derivative of that discretised
     log-likelihood."""
