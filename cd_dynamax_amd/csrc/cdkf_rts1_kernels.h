@@ -110,10 +110,10 @@ __global__ __launch_bounds__(64 * kRts1Waves) void pushforward_wave8_kernel(cons
       const R scaled = rsqrt_((R)ssum / R(2 * d * d));
       const bool keep = scaled < R(1) || at_min;
       const R inv = (scaled == R(0)) ? R(__builtin_huge_val()) : R(1) / scaled;
-      R factor = R(0.9) * rpow(inv, tb.c1);
+      R factor = tb.safety * rpow(inv, tb.c1);
       if (tb.c2 != R(0)) factor *= rpow(inv1, tb.c2);
       if (tb.c3 != R(0)) factor *= rpow(inv2, tb.c3);
-      factor = rmin(rmax(factor, keep ? R(1) : R(0.2)), R(10));
+      factor = rmin(rmax(factor, keep ? R(1) : tb.fmin), tb.fmax);
       const R nt0 = keep ? tnext : tprev;
       R dtn = rmin(dt * factor, tb.dtmax);
       at_min = dtn <= tb.dtmin;
