@@ -124,7 +124,7 @@ SYMBOLS = (
      "cdkf_ll_allreduce", "cdkf_comm_allreduce_max", "cdkf_ll_allreduce_all", "cdkf_comm_destroy", "cdkf_rdv_create",
      "cdkf_rdv_broadcast", "cdkf_rdv_allreduce", "cdkf_rdv_barrier", "cdkf_rdv_destroy", "cdkf_last_kernel", "cdkf_event_create",
      "cdkf_event_record", "cdkf_event_elapsed_ms", "cdkf_event_destroy", "cdkf_stream_create", "cdkf_stream_destroy",
-     "cdkf_set_device", "cdkf_struct_sizes", "cdkf_debug_custom_reg_blob", "cdkf_debug_wg_args", "cdkf_rtc_cache_stats"]
+     "cdkf_set_device", "cdkf_struct_sizes", "cdkf_debug_exec_prologue_check", "cdkf_debug_custom_reg_blob", "cdkf_debug_wg_args", "cdkf_rtc_cache_stats"]
     + [f"cdkf_{a}_{p}{s}" for a in _ALGOS for p in ("f64", "f32") for s in ("", "_dev")]
 )
 

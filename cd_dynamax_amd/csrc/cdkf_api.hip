@@ -616,6 +616,14 @@ int cdkf_debug_ukf_tangent_args(const cdkf_model* mdl, const cdkf_opts* opts, in
                                 void* args_out, int64_t args_cap_bytes, void* par_out, int64_t par_cap_bytes) {
   return ukf_tangent_debug_args(mdl, opts, N, T, bytes_per_real, all, args_out, args_cap_bytes, par_out, par_cap_bytes);
 }
+int cdkf_debug_exec_prologue_check(const void* code, int64_t bytes, const char* arch, char* where, int64_t where_cap) {
+  if (!code || bytes <= 0 || !arch) return -1;
+  std::vector<char> v((const char*)code, (const char*)code + bytes);
+  std::string w;
+  const int rc = rtc_exec_prologue_check(v, arch, &w);
+  if (where && where_cap > 0) snprintf(where, (size_t)where_cap, "%s", w.c_str());
+  return rc;
+}
 int cdkf_debug_wg_args(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T, int bytes_per_real, int ukf, int smoother,
                        void* args_out, int64_t args_cap_bytes, void* blob_out, int64_t blob_cap_bytes, int64_t* geom_out) {
   return debug_wg_args(mdl, opts, N, T, bytes_per_real, ukf, smoother, args_out, args_cap_bytes, blob_out, blob_cap_bytes, geom_out);

@@ -128,6 +128,8 @@ template <typename R>
 int launch_ekf_tangent(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll, R* grad,
                        R* grad_model, int32_t* status, hipStream_t stream);
 int ukf_tangent_compile_check(const cdkf_model* mdl, const cdkf_opts* o, int bytes_per_real, int ekf);
+// 1: the code object shows the ROCm 7.2 spill-placement defect (vector spill code in front of an execution-mask restore), 0: clean, -1: could not look
+int rtc_exec_prologue_check(const std::vector<char>& code, const std::string& arch, std::string* where);
 int ukf_tangent_debug_args(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, int bytes_per_real, int all, void* args_out,
                            int64_t args_cap, void* par_out, int64_t par_cap);
 void custom_rtc_cache_stats(int64_t* hits, int64_t* misses);

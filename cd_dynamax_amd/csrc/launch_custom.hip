@@ -250,6 +250,136 @@ long code_object_vgpr_spills(const std::vector<char>& code) {
   return worst;
 }
 
+// ---- the defect itself, looked for in the machine code (round 5, profiles/r05_j_root_cause.txt) -------------------------------------------
+// What the wrong builds have in common, found with rocgdb and a single-step value trace of the d = 2 sweep: the register allocator's
+// live-range splitting puts spill stores / VGPR -> AGPR copies at the TOP of a structured-control-flow flow (or join) block -- BEFORE the
+// `s_or_saveexec_b64` (`s_or_b64 exec, exec, sX`) that re-enables the lanes of the other arm -- because the scalar allocation that ran
+// first left a rematerialised `s_mov_b32` in front of that restore and the block's prologue is then taken to be empty.  The stores run
+// under the then-arm's mask (an EMPTY one in the reproducer: every lane takes the other arm of an inlined sin()'s range reduction), the
+// loop-carried values they were to save keep stale slots, the Runge-Kutta loop repeats one step until max_steps.  The shape is searched
+// for with comgr's disassembler (the library hipRTC itself sits on; symbols taken from the process):
+//     s_and_saveexec_b64 sX, c ; [s_xor_b64 sY, exec, sX ;] s_cbranch_execz L ; ... ;
+//  L: <lane-masked vector instruction(s)> ; s_or_saveexec_b64 .., sY   |   s_or_b64 exec, exec, sX
+// scripts/check_exec_prologue.py is the same rule over llvm-objdump listings (tests/test_exec_prologue.py: the library's objects, the
+// cache, the -O3 build of launch_wg8.hip as a second positive).  Returns 1 found, 0 clean, -1 could not look (no comgr / no .text).
+struct RtcIns {
+  uint64_t addr;
+  std::string text;
+  uint64_t target;  // branch target, or ~0
+};
+struct RtcDisCtx {
+  const char* base;
+  uint64_t size;
+  std::string text;
+  uint64_t target;
+};
+static uint64_t rtc_dis_read(uint64_t from, char* to, uint64_t size, void* ud) {
+  RtcDisCtx* c = (RtcDisCtx*)ud;
+  if (from >= c->size) return 0;
+  const uint64_t n = std::min(size, c->size - from);
+  std::memcpy(to, c->base + from, n);
+  return n;
+}
+static void rtc_dis_print(const char* ins, void* ud) { ((RtcDisCtx*)ud)->text = ins ? ins : ""; }
+static void rtc_dis_addr(uint64_t a, void* ud) { ((RtcDisCtx*)ud)->target = a; }
+
+int rtc_exec_prologue_defect(const std::vector<char>& code, const std::string& arch, std::string* where) {
+  typedef struct { uint64_t handle; } info_t;
+  typedef int (*create_t)(const char*, uint64_t (*)(uint64_t, char*, uint64_t, void*), void (*)(const char*, void*), void (*)(uint64_t, void*), info_t*);
+  typedef int (*dis_t)(info_t, uint64_t, void*, uint64_t*);
+  typedef int (*destroy_t)(info_t);
+  static create_t create = (create_t)dlsym(RTLD_DEFAULT, "amd_comgr_create_disassembly_info");
+  static dis_t dis = (dis_t)dlsym(RTLD_DEFAULT, "amd_comgr_disassemble_instruction");
+  static destroy_t destroy = (destroy_t)dlsym(RTLD_DEFAULT, "amd_comgr_destroy_disassembly_info");
+  if (!create || !dis || !destroy || code.size() < 64 || std::memcmp(code.data(), "\177ELF", 4) != 0 || code[4] != 2) return -1;
+  // the .text section of the ELF64 code object
+  auto rd = [&](size_t off, int bytes) { uint64_t v = 0; if (off + bytes <= code.size()) std::memcpy(&v, code.data() + off, bytes); return v; };
+  const uint64_t shoff = rd(0x28, 8), shentsize = rd(0x3a, 2), shnum = rd(0x3c, 2), shstrndx = rd(0x3e, 2);
+  if (!shoff || shentsize < 64 || shstrndx >= shnum) return -1;
+  const uint64_t stroff = rd(shoff + shstrndx * shentsize + 0x18, 8);
+  uint64_t toff = 0, tsize = 0;
+  for (uint64_t i = 0; i < shnum; ++i) {
+    const uint64_t sh = shoff + i * shentsize, name = rd(sh, 4);
+    if (stroff + name + 6 <= code.size() && std::memcmp(code.data() + stroff + name, ".text\0", 6) == 0) {
+      toff = rd(sh + 0x18, 8);
+      tsize = rd(sh + 0x20, 8);
+    }
+  }
+  if (!tsize || toff + tsize > code.size()) return -1;
+  RtcDisCtx ctx{code.data() + toff, tsize, std::string(), ~0ull};
+  info_t info{0};
+  const std::string isa = "amdgcn-amd-amdhsa--" + arch.substr(0, arch.find(':'));
+  if (create(isa.c_str(), rtc_dis_read, rtc_dis_print, rtc_dis_addr, &info) != 0) return -1;
+  std::vector<RtcIns> ins;
+  ins.reserve(tsize / 6);
+  for (uint64_t a = 0; a < tsize;) {
+    uint64_t n = 0;
+    ctx.text.clear();
+    ctx.target = ~0ull;
+    if (dis(info, a, &ctx, &n) != 0 || n == 0) n = 4;  // (padding / data: step over a dword)
+    size_t b = ctx.text.find_first_not_of(" \t");
+    ins.push_back({a, b == std::string::npos ? std::string() : ctx.text.substr(b), ctx.target});
+    a += n;
+  }
+  destroy(info);
+  auto op_of = [](const std::string& t) { return t.substr(0, t.find_first_of(" \t")); };
+  auto toks_of = [](const std::string& t) {
+    std::vector<std::string> v;
+    std::string cur;
+    for (char ch : t) {
+      if (ch == ' ' || ch == '\t' || ch == ',') {
+        if (!cur.empty()) v.push_back(cur);
+        cur.clear();
+      } else {
+        cur.push_back(ch);
+      }
+    }
+    if (!cur.empty()) v.push_back(cur);
+    return v;
+  };
+  auto starts = [](const std::string& t, const char* p) { return t.compare(0, std::strlen(p), p) == 0; };
+  auto masked = [&](const std::string& op) {
+    if (starts(op, "scratch_store") || starts(op, "global_store") || starts(op, "buffer_store") || starts(op, "flat_store") || starts(op, "ds_write") ||
+        starts(op, "ds_store") || starts(op, "v_accvgpr_write"))
+      return true;
+    return starts(op, "v_") && !starts(op, "v_readlane") && !starts(op, "v_writelane") && !starts(op, "v_readfirstlane") && !starts(op, "v_cmp");
+  };
+  std::map<uint64_t, size_t> index;
+  for (size_t k = 0; k < ins.size(); ++k) index[ins[k].addr] = k;
+  for (size_t k = 0; k < ins.size(); ++k) {
+    if (op_of(ins[k].text) != "s_cbranch_execz" || ins[k].target == ~0ull || ins[k].target <= ins[k].addr || !index.count(ins[k].target)) continue;
+    std::string sx, sy;
+    for (size_t q = k >= 3 ? k - 3 : 0; q < k; ++q) {
+      const std::vector<std::string> t = toks_of(ins[q].text);
+      if (t.size() >= 4 && t[0] == "s_xor_b64" && t[2] == "exec") sy = t[1];
+      if (t.size() >= 2 && t[0] == "s_and_saveexec_b64") sx = t[1];
+    }
+    const std::string key = !sy.empty() ? sy : sx;
+    if (key.empty()) continue;
+    int bad = 0;
+    for (size_t j = index[ins[k].target]; j < ins.size() && j < index[ins[k].target] + 400; ++j) {
+      const std::vector<std::string> t = toks_of(ins[j].text);
+      if (t.empty()) break;
+      if ((t[0] == "s_or_saveexec_b64" && t.size() >= 3 && t[2] == key) ||
+          (t[0] == "s_or_b64" && t.size() >= 4 && t[1] == "exec" && t[2] == "exec" && t[3] == key)) {
+        if (bad) {
+          if (where) {
+            char buf[160];
+            snprintf(buf, sizeof(buf), "%d lane-masked instruction(s) in front of `%s` at .text+%#llx", bad, ins[j].text.c_str(), (unsigned long long)ins[j].addr);
+            *where = buf;
+          }
+          return 1;
+        }
+        break;
+      }
+      if (starts(t[0], "s_branch") || starts(t[0], "s_cbranch") || starts(t[0], "s_setpc") || starts(t[0], "s_endpgm")) break;
+      if (t.size() >= 2 && t[0][0] == 's' && t[1] == key) break;  // (the saved mask is redefined: not the plain shape)
+      if (masked(t[0])) ++bad;
+    }
+  }
+  return 0;
+}
+
 // wave-uniform step loops in the register-resident variants (cdkf_math.h: CDKF_UNIFORM_INTEGRATE); CDKF_RTC_UNIFORM = 0 | 1 overrides
 bool rtc_uniform_steps() {
   const char* e = getenv("CDKF_RTC_UNIFORM");
@@ -580,6 +710,7 @@ int compile_variant(const CustomDrift& c, const Key& key, const std::string& arc
     if (!getenv("CDKF_CUSTOM_DUMP") && rtc_cache_load(cache_key, code, unused)) return CDKF_OK;
   }
   long spills = -1;
+  std::string defect_note;
   for (int attempt = 0; attempt < 2; ++attempt) {
     hiprtcProgram prog = nullptr;
     if (hiprtcCreateProgram(&prog, src.c_str(), "cdkf_custom_drift.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
@@ -620,14 +751,23 @@ int compile_variant(const CustomDrift& c, const Key& key, const std::string& arc
     hiprtcDestroyProgram(&prog);
     const long now = code_object_vgpr_spills(code);
     if (attempt == 0) spills = now;
-    // the rule of rtc_policy: a build past the spill limit is not trusted at this level -- once more at -O1 (unknown count: the same)
-    if (attempt == 0 && pol.spill_limit > 0 && (now < 0 || now > pol.spill_limit) && std::string(olevel) != "-O1") {
+    std::string where;
+    const int defect = getenv("CDKF_RTC_NO_DEFECT_CHECK") ? 0 : rtc_exec_prologue_defect(code, arch, &where);
+    // the rule of rtc_policy: a build that shows the defect's shape, or is past the spill limit (the regime every wrong build was in),
+    // is not trusted at this level -- once more at -O1 (unknown spill count: the same)
+    if (attempt == 0 && pol.spill_limit > 0 && (defect == 1 || now < 0 || now > pol.spill_limit) && std::string(olevel) != "-O1") {
+      if (defect == 1) defect_note = " exec-prologue defect at " + std::string(olevel) + ": " + where + ";";
       olevel = "-O1";
       continue;
     }
+    if (defect == 1 && pol.spill_limit > 0) {  // (a forced level -- CDKF_RTC_POLICY -- is taken as asked: the canary needs the wrong build)
+      set_error("custom drift: the compiler placed vector spill code in front of an execution-mask restore at -O3 AND at -O1 (%s) -- a known "
+                "ROCm 7.2 register-allocation defect that yields wrong results; refusing to run this kernel", where.c_str());
+      return CDKF_EUNSUPPORTED;
+    }
     break;
   }
-  rtc_cache_store(cache_key, code, std::string(), tag + " " + olevel + " (vgpr spills at " + pol.olevel + ": " + std::to_string(spills) + ")");
+  rtc_cache_store(cache_key, code, std::string(), tag + " " + olevel + " (vgpr spills at " + pol.olevel + ": " + std::to_string(spills) + ";" + defect_note + ")");
   if (const char* dir = getenv("CDKF_CUSTOM_DUMP")) {  // debugging aid: the generated source and its code object
     const std::string base = std::string(dir) + "/cdkf_custom_reg_" + std::to_string(std::get<1>(key)) + "_m" + std::to_string(std::get<2>(key)) + "_" +
                              std::to_string(std::get<3>(key)) + "_" + std::to_string(std::get<4>(key)) + "_" + std::to_string(std::get<6>(key)) + "_" + cache_key.substr(0, 8);
@@ -961,6 +1101,14 @@ int compile_wg_variant(const CustomDrift& c, const WgKey& key, const std::string
   code.resize(sz);
   hiprtcGetCode(prog, code.data());
   hiprtcDestroyProgram(&prog);
+  {
+    std::string where;
+    if (!getenv("CDKF_RTC_NO_DEFECT_CHECK") && !getenv("CDKF_RTC_POLICY") && rtc_exec_prologue_defect(code, arch, &where) == 1) {
+      set_error("custom drift (workgroup kernels): the compiler placed vector spill code in front of an execution-mask restore at %s (%s) -- a "
+                "known ROCm 7.2 register-allocation defect that yields wrong results; refusing to run this kernel", olevel, where.c_str());
+      return CDKF_EUNSUPPORTED;
+    }
+  }
   rtc_cache_store(cache_key, code, lowered, expr + " " + olevel);
   if (const char* dir = getenv("CDKF_CUSTOM_DUMP")) {  // debugging aid: the generated source and its code object
     const std::string base = std::string(dir) + "/cdkf_custom_wg_" + std::to_string(bytes) + "_" + std::to_string(ept) + "_" + std::to_string(ukf) +
@@ -1384,6 +1532,10 @@ int custom_compile_check(int kind, int bytes_per_real, int emission_dim, int alg
   int rc = compile_variant(c, Key(kind, bytes_per_real, emission_dim, algo == 1, zeroth, 0, 0, generic, emission_kind, du), "gfx950", code);
   if (!rc && algo == 2) rc = compile_variant(c, Key(kind, bytes_per_real, emission_dim, 0, 0, 0, 1, generic, 0, du), "gfx950", code);
   return rc;
+}
+
+int rtc_exec_prologue_check(const std::vector<char>& code, const std::string& arch, std::string* where) {
+  return rtc_exec_prologue_defect(code, arch, where);
 }
 
 // ---- the unscented filter's gradient for any drift / emission: forward mode through the literal recursion (cdkf_ukf_tangent_kernels.h) ----

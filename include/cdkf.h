@@ -348,6 +348,10 @@ void cdkf_rtc_cache_stats(int64_t* hits, int64_t* misses);
  * number of reals in the block or a negative CDKF_E* code */
 int cdkf_debug_ukf_tangent_args(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T, int bytes_per_real, int all,
                                 void* args_out, int64_t args_cap_bytes, void* par_out, int64_t par_cap_bytes);
+/* the check the run-time compiled kernels get before they are trusted at -O3 (launch_custom.hip: rtc_exec_prologue_defect): 1 when the
+ * code object (an ELF for `arch`, e.g. "gfx950") shows vector spill code in front of an execution-mask restore -- the ROCm 7.2
+ * register-allocation defect of NOTES.md R5.1 --, 0 clean, -1 could not look (no comgr disassembler in the process) */
+int cdkf_debug_exec_prologue_check(const void* code, int64_t bytes, const char* arch, char* where, int64_t where_cap);
 int cdkf_debug_custom_reg_blob(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T, int algo, int bytes_per_real,
                                void* par_out, int64_t par_cap_bytes, int64_t* ip_out);
 /* workgroup-per-trajectory kernels (cdkf_wg2_kernels.h: any drift, state / emission dimension <= 64): args_out receives the kernel's
