@@ -204,9 +204,12 @@ std::string rtc_cache_dir() {
 //     ONCE PER PROCESS, the first compilation's set (or its absence) is frozen for every later one (measured: the spill count of the same
 //     source under [-O3 basic, -O3, -O3 basic] = 1621, 1621, 1621 and under [-O3, -O3 basic, -O3] = 891, 891, 891).  A policy that
 //     depends on an -mllvm option therefore depends on which kernel a process happens to compile first, and poisons the disk cache.
+//   * LOCATED (rocgdb value trace -> machine IR; rtc_exec_prologue_defect below, profiles/r05_j_root_cause.txt): the vector allocator's
+//     split / spill code is inserted at the top of a flow (join) block IN FRONT of the exec restore; loop-carried spill slots go stale.
 // So the shipped policy uses the optimisation LEVEL only, and decides it on the code object it gets: a register-resident variant is
-// built at -O3; if its metadata reports more than CDKF_RTC_SPILL_LIMIT (default 300) spilled vector registers, that build is discarded
-// and the variant rebuilt at -O1 (which spills 2 - 80 x less on these kernels).  The workgroup variants stay at -O1 (no wrong result in
+// built at -O3; if its machine code shows that shape, or its metadata reports more than CDKF_RTC_SPILL_LIMIT (default 300) spilled
+// vector registers (the regime every wrong build was in), that build is discarded and the variant rebuilt at -O1 (which spills 2 - 80 x
+// less on these kernels), checked again, and refused if the shape is still there.  The workgroup variants stay at -O1 (no wrong result in
 // 700 + random problems; -O3 is wrong on the d = 15 unscented case).  CDKF_RTC_POLICY = o1 | o3 forces a level (A/B; "o3" is the canary of
 // tests/test_gpu_toolchain.py); o3basic | o1basic | o3subreg add the -mllvm switch named -- meaningful only as the FIRST compilation of
 // a process (scripts/r5_o3_probe.py runs every case in a process of its own).
