@@ -154,8 +154,8 @@ def test_integration_md_structs_have_the_library_layout():
 
 def test_toolchain_workarounds_cannot_be_switched_off_from_the_command_line():
     """launch_wg8.hip (the fp64 eight-entries-per-thread workgroup kernels) returns NaN at plain -O2 / -O3 on ROCm 7.2 / gfx950: the
-    greedy register allocator's sub-register liveness tracking of 64-bit VGPR pairs in spill-heavy kernels (round 5: launch_custom.hip
-    rtc_policy, NOTES.md R5.1; rounds 3 / 4 fenced it with -O1).  The Makefile's target-specific `override` must keep the safe build
+    vector register allocator's split code lands in front of an execution-mask restore in two of its instantiations (round 5: located,
+    profiles/r05_j_root_cause.txt; scripts/check_exec_prologue.py flags exactly those two in the -O3 build; rounds 3 / 4 fenced it with -O1).  The Makefile's target-specific `override` must keep the safe build
     of that object (SUBREG_SAFE) on its command line whatever CXXFLAGS a caller passes, and leave every other object as the caller asked;
     the run-time compiled kernels are built at -O3 and rebuilt at -O1 past a spill limit (register-resident) or at -O1 (workgroup variants),
     with no -mllvm option (hipRTC freezes the first compilation's set for the whole process: launch_custom.hip)."""

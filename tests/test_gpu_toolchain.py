@@ -1,9 +1,10 @@
 """The compiler defect behind rounds 3 / 4's "-O1 fences" (launch_custom.hip: rtc_policy; NOTES.md R5.1), held by a reproducer and a
-canary.  ROCm 7.2's compiler miscompiles spill-heavy double-precision kernels at the register limit at -O2 / -O3; the smallest member of
+canary.  ROCm 7.2's compiler miscompiles spill-heavy double-precision kernels at the register limit at -O2 / -O3 (located in round 5:
+vector spill code placed in front of an execution-mask restore, profiles/r05_j_root_cause.txt); the smallest member of
 the family is the forward-sensitivity sweep of NL_F of tests/test_custom_drift.py (its generated translation unit is ~90 lines on top of
 the kernel headers: CDKF_CUSTOM_DUMP writes it; scripts/r5_o3_probe.py and scripts/r5_mir_delta.py are the drivers of the investigation).
-  * under the shipped policy (-O3, rebuilt at -O1 when the code object reports more than 300 spilled vector registers: this kernel's -O3
-    build reports ~900) the gradient equals finite differences of the oracle;
+  * under the shipped policy (-O3, rebuilt at -O1 when the machine code shows the defect's shape or reports more than 300 spilled vector
+    registers: this kernel's -O3 build does both) the gradient equals finite differences of the oracle;
   * CANARY: under plain -O3 (CDKF_RTC_POLICY=o3) it is still WRONG on this toolchain -- the day a ROCm release makes this leg pass, the
     test fails with the message to revisit the rule;
   * -O1 (the round-4 fence, CDKF_RTC_POLICY=o1) is right, as it always was.
