@@ -23,10 +23,31 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 _UNMASKED = ("v_readlane", "v_writelane", "v_readfirstlane")   # do not depend on the execution mask
 
 
+def _listing_dir(obj):
+    """build/disasm/ beside build/csrc/ (listed in .gpurunignore: hundreds of MB of text that the GPU box has no use for)."""
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(obj))), "disasm")
+    os.makedirs(d, exist_ok=True)
+    return d
+
+
 def disassemble(path, tmp):
     raw = open(path, "rb").read()
     if path.endswith(".s"):
         return raw.decode(errors="replace")
+    if path.endswith(".o"):      # (the library's objects are tens of MB of device code: the listing is kept beside the build, keyed by the object's mtime)
+        keep = os.path.join(_listing_dir(path), "%s_%d.s" % (os.path.basename(path), int(os.path.getmtime(path))))
+        if os.path.exists(keep):
+            return open(keep, errors="replace").read()
+        text = _disassemble(path, raw, tmp)
+        try:
+            open(keep, "w").write(text)
+        except OSError:
+            pass
+        return text
+    return _disassemble(path, raw, tmp)
+
+
+def _disassemble(path, raw, tmp):
     co = path
     if raw[:4] == b"CKRC":      # an entry of the library's hipRTC cache: header, name, code object
         magic, nname, lo, hi = struct.unpack("<4I", raw[:16])

@@ -707,7 +707,7 @@ def test_rtc_code_objects_are_cached_on_disk(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
     def run(**extra):
-        env = dict(os.environ, CDKF_ROOT=root, CDKF_RTC_CACHE_DIR=str(cache), CDKF_RTC_CACHE="1")
+        env = dict(os.environ, CDKF_ROOT=root, CDKF_RTC_CACHE_DIR=str(cache), CDKF_RTC_CACHE="1", CDKF_RTC_POLICY="o1")   # (-O1: what is under test is the cache, not the optimiser)
         env.update(extra)
         p = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
         assert p.returncode == 0, p.stdout + p.stderr

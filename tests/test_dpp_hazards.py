@@ -24,7 +24,26 @@ def _regs(tok):
     return {int(m.group(1))} if m else set()
 
 
+def _listing_dir(obj):
+    """build/disasm/ beside build/csrc/ (listed in .gpurunignore: hundreds of MB of text that the GPU box has no use for)."""
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(obj))), "disasm")
+    os.makedirs(d, exist_ok=True)
+    return d
+
+
 def _disassemble(obj, tmp):
+    keep = os.path.join(_listing_dir(obj), "%s_%d.s" % (os.path.basename(obj), int(os.path.getmtime(obj))))   # (shared with
+    if os.path.exists(keep):                                                                                             #  scripts/check_exec_prologue.py)
+        return open(keep, errors="replace").read()
+    text = _disassemble_now(obj, tmp)
+    try:
+        open(keep, "w").write(text)
+    except OSError:
+        pass
+    return text
+
+
+def _disassemble_now(obj, tmp):
     fat, co = os.path.join(tmp, "fat.bin"), os.path.join(tmp, "dev.co")
     subprocess.check_call(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", obj, fat])
     subprocess.check_call([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", f"--input={fat}",
