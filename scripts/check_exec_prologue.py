@@ -12,6 +12,7 @@ The plain `if` is matched the same way: `s_and_saveexec_b64 sX, c; s_cbranch_exe
 
   python scripts/check_exec_prologue.py <code object or .o with a .hip_fatbin or .s listing> [...]      exit code 1 when something is found
 Also used by tests/test_exec_prologue.py over the library's objects and the in-tree hipRTC cache."""
+import gzip
 import os
 import re
 import struct
@@ -24,7 +25,7 @@ _UNMASKED = ("v_readlane", "v_writelane", "v_readfirstlane")   # do not depend o
 
 
 def _listing_dir(obj):
-    """build/disasm/ beside build/csrc/ (listed in .gpurunignore: hundreds of MB of text that the GPU box has no use for)."""
+    """build/disasm/ beside build/csrc/ (listed in .gpurunignore: compressed listings the GPU box has no use for)."""
     d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(obj))), "disasm")
     os.makedirs(d, exist_ok=True)
     return d
@@ -35,12 +36,12 @@ def disassemble(path, tmp):
     if path.endswith(".s"):
         return raw.decode(errors="replace")
     if path.endswith(".o"):      # (the library's objects are tens of MB of device code: the listing is kept beside the build, keyed by the object's mtime)
-        keep = os.path.join(_listing_dir(path), "%s_%d.s" % (os.path.basename(path), int(os.path.getmtime(path))))
+        keep = os.path.join(_listing_dir(path), "%s_%d.s.gz" % (os.path.basename(path), int(os.path.getmtime(path))))
         if os.path.exists(keep):
-            return open(keep, errors="replace").read()
+            return gzip.open(keep, "rt", errors="replace").read()
         text = _disassemble(path, raw, tmp)
         try:
-            open(keep, "w").write(text)
+            gzip.open(keep, "wt", compresslevel=1).write(text)
         except OSError:
             pass
         return text

@@ -4,6 +4,7 @@ gfx9 rule: a VGPR written by a VALU instruction must not be read as a DPP source
 disassembles the gfx950 code objects the library is linked from and checks EVERY DPP instruction against that rule, so a compiler
 release that schedules differently fails here, on the CPU, instead of silently corrupting sweeps on the GPU.  CPU only."""
 import glob
+import gzip
 import os
 import re
 import shutil
@@ -25,19 +26,19 @@ def _regs(tok):
 
 
 def _listing_dir(obj):
-    """build/disasm/ beside build/csrc/ (listed in .gpurunignore: hundreds of MB of text that the GPU box has no use for)."""
+    """build/disasm/ beside build/csrc/ (listed in .gpurunignore: compressed listings the GPU box has no use for)."""
     d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(obj))), "disasm")
     os.makedirs(d, exist_ok=True)
     return d
 
 
 def _disassemble(obj, tmp):
-    keep = os.path.join(_listing_dir(obj), "%s_%d.s" % (os.path.basename(obj), int(os.path.getmtime(obj))))   # (shared with
+    keep = os.path.join(_listing_dir(obj), "%s_%d.s.gz" % (os.path.basename(obj), int(os.path.getmtime(obj))))   # (shared with
     if os.path.exists(keep):                                                                                             #  scripts/check_exec_prologue.py)
-        return open(keep, errors="replace").read()
+        return gzip.open(keep, "rt", errors="replace").read()
     text = _disassemble_now(obj, tmp)
     try:
-        open(keep, "w").write(text)
+        gzip.open(keep, "wt", compresslevel=1).write(text)
     except OSError:
         pass
     return text
