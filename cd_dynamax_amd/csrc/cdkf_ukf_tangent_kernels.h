@@ -51,6 +51,14 @@ struct UtArgs {
   int all;  // 0: the drift parameters only (grad), 1: every leaf (grad and grad_model)
   int num_iter;  // the EXTENDED filter's update iterations (ekf_tangent_body; inference_ekf.py:153-199)
   int order;     // the extended filter's state_order: 1 or 2
+  // VALUE mode (the FILTER of a model only these sweeps take -- an emission given as source above six dimensions): one lane per
+  // trajectory, no seed, the moments written out as the filter entry points deliver them (each pointer nullable)
+  int value_only;
+  R* fm;  // filtered means        (after the update at t_k)
+  R* fc;  // filtered covariances
+  R* pm;  // predicted means       (carried to the next observation time; the last one to t_T + dt_final)
+  R* pc;  // predicted covariances
+  long m_sn, m_sk, m_si, P_sn, P_sk, P_si;
 };
 
 constexpr int kUtStatusNotPd = 1, kUtStatusNan = 2, kUtStatusMaxSteps = 4;  // (= kStatus* of cdkf_reg_kernels.h)
@@ -172,19 +180,30 @@ __device__ void ut_store(const UtArgs<R>& a, long n, int p, R llv, R g, int st) 
   }
 }
 
+// value mode: the moments y = [m | P lower-packed] of trajectory n at observation k to the output arrays (full symmetric matrix)
+template <typename R, typename MD, typename T>
+__device__ void ut_put_moments(const UtArgs<R>& a, long n, long k, const T* y, R* mp, R* Pp) {
+  constexpr int D = MD::D;
+  if (mp)
+    for (int i = 0; i < D; ++i) mp[n * a.m_sn + k * a.m_sk + i * a.m_si] = y[i].v;
+  if (Pp)
+    for (int r = 0; r < D; ++r)
+      for (int c2 = 0; c2 < D; ++c2) Pp[n * a.P_sn + k * a.P_sk + (r * D + c2) * a.P_si] = y[D + (r >= c2 ? ut_lo(r, c2) : ut_lo(c2, r))].v;
+}
 template <typename R, typename MD>
 __device__ void ukf_tangent_body(const UtArgs<R>& a) {
   constexpr int D = MD::D, M = MD::M, NTH = MD::NTH, DU = MD::DU;
   constexpr int NPD = D * (D + 1) / 2, NPM = M * (M + 1) / 2, NS = D + NPD;
   typedef Dual<R, 1> T;
   constexpr int o_m0 = NTH, o_P0 = o_m0 + D, o_Q = o_P0 + NPD, o_H = o_Q + NPD, o_R = o_H + M * D + M, n_all = o_R + NPM;
-  const int nleaf = a.all ? n_all : (NTH > 0 ? NTH : 1);
+  const bool value_only = a.value_only != 0;
+  const int nleaf = value_only ? 1 : (a.all ? n_all : (NTH > 0 ? NTH : 1));
   const long total = a.N * (long)nleaf;
   long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = gid < total;
   if (!live) gid = total - 1;  // idle lanes shadow the last pair; their stores are masked
   const long n = gid / nleaf;
-  const int p = (int)(gid - n * nleaf);
+  const int p = value_only ? -1 : (int)(gid - n * nleaf);  // (-1: no leaf entry is seeded)
 
   const R* p_m0 = a.par + NTH;
   const R* p_P0 = p_m0 + D;
@@ -310,8 +329,10 @@ __device__ void ukf_tangent_body(const UtArgs<R>& a) {
         }
     }
     if (y[0].v != y[0].v) st |= kUtStatusNan;
-    if (k + 1 < a.T) {  // ---- _predict (the last one does not enter the log-likelihood) ----
-      const R t1 = tp[(k + 1) * a.t_sk];
+    if (value_only && live) ut_put_moments<R, MD, T>(a, n, k, y, a.fm, a.fc);
+    const bool last = k + 1 >= a.T;
+    if (!last || value_only) {  // ---- _predict (the last one, to t_T + dt_final, does not enter the log-likelihood: value mode only) ----
+      const R t1 = last ? tcur + a.dt_final : tp[(k + 1) * a.t_sk];
       R tprev = tcur;
       R tnext = rmin(tcur + a.dt0, t1);
       long steps = 0;
@@ -340,10 +361,16 @@ __device__ void ukf_tangent_body(const UtArgs<R>& a) {
         tnext = (tn > t1 - Tol<R>::v) ? t1 : tn;
         ++steps;
       }
+      if (value_only && live) ut_put_moments<R, MD, T>(a, n, k, y, a.pm, a.pc);
     }
   }
   if (bad) st |= kUtStatusNotPd;
   if (!live) return;
+  if (value_only) {
+    a.ll[n] = (R)llv;
+    if (a.status) a.status[n] = st;
+    return;
+  }
   ut_store<R, MD>(a, n, p, (R)llv, (R)llg, st);
 }
 
@@ -369,25 +396,26 @@ __device__ void et_jac_f(const UtCtx<R, MD, T>& cx, const T* m, T* f0, T* F, R t
     for (int j = 0; j < D; ++j) F[i * D + j] = fx[i].g[j];
   }
 }
-// g_k = d/dx_k sum_i d f_i / d x_i (inference_ekf.py:108-116) with its parameter tangent: two nested direction sets
+// g_k = d/dx_k sum_i d f_i / d x_i (inference_ekf.py:108-116) with its parameter tangent: an inner direction set (d f_i / d x_j, all j) under
+// ONE outer direction k at a time -- D evaluations on 2 (D + 1) components each.  (All D outer directions at once is the same work in one
+// evaluation on (D + 1)^2 components: 1.3 KB per intermediate at D = 8, and a drift with a 90-wide hidden layer then asks for more
+// private memory than a lane has -- "stack frame size exceeds limit", fresh-seed fuzz 915020.)
 template <typename R, typename MD, typename T>
 __device__ void et_divgrad(const UtCtx<R, MD, T>& cx, const T* m, T* g, R tt) {
   constexpr int D = MD::D;
   if constexpr (D <= 8) {
     typedef Dual<T, D> J1;
-    typedef Dual<J1, D> J2;
-    J2 x[D], fx[D];
-    for (int i = 0; i < D; ++i) {
-      x[i].v.v = m[i];
-      for (int j = 0; j < D; ++j) {
-        x[i].v.g[j] = UtLift<R, T>::make(i == j ? R(1) : R(0), R(0));
-        x[i].g[j] = UtLift<R, J1>::make(i == j ? R(1) : R(0), R(0));
-      }
-    }
-    MD::template f<R, J2>(x, UtView<R, J2>{cx.th.v, cx.th.seed}, fx, cx.ub, tt);
+    typedef Dual<J1, 1> J2;
     for (int k = 0; k < D; ++k) {
+      J2 x[D], fx[D];
+      for (int i = 0; i < D; ++i) {
+        x[i].v.v = m[i];
+        for (int j = 0; j < D; ++j) x[i].v.g[j] = UtLift<R, T>::make(i == j ? R(1) : R(0), R(0));
+        x[i].g[0] = UtLift<R, J1>::make(i == k ? R(1) : R(0), R(0));
+      }
+      MD::template f<R, J2>(x, UtView<R, J2>{cx.th.v, cx.th.seed}, fx, cx.ub, tt);
       T s = UtLift<R, T>::make(R(0), R(0));
-      for (int i = 0; i < D; ++i) s += fx[i].g[i].g[k];
+      for (int i = 0; i < D; ++i) s += fx[i].g[0].g[i];
       g[k] = s;
     }
   } else {
@@ -426,13 +454,14 @@ __device__ void ekf_tangent_body(const UtArgs<R>& a) {
   typedef Dual<R, 1> T;
   typedef Dual<T, D> J;
   constexpr int o_m0 = NTH, o_P0 = o_m0 + D, o_Q = o_P0 + NPD, o_H = o_Q + NPD, o_R = o_H + M * D + M, n_all = o_R + NPM;
-  const int nleaf = a.all ? n_all : (NTH > 0 ? NTH : 1);
+  const bool value_only = a.value_only != 0;
+  const int nleaf = value_only ? 1 : (a.all ? n_all : (NTH > 0 ? NTH : 1));
   const long total = a.N * (long)nleaf;
   long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = gid < total;
   if (!live) gid = total - 1;
   const long n = gid / nleaf;
-  const int p = (int)(gid - n * nleaf);
+  const int p = value_only ? -1 : (int)(gid - n * nleaf);
   const R* p_m0 = a.par + NTH;
   const R* p_P0 = p_m0 + D;
   const R* p_Q = p_P0 + D * D;
@@ -546,8 +575,10 @@ __device__ void ekf_tangent_body(const UtArgs<R>& a) {
       }
     }
     if (y[0].v != y[0].v) st |= kUtStatusNan;
-    if (k + 1 < a.T) {
-      const R t1 = tp[(k + 1) * a.t_sk];
+    if (value_only && live) ut_put_moments<R, MD, T>(a, n, k, y, a.fm, a.fc);
+    const bool last = k + 1 >= a.T;
+    if (!last || value_only) {
+      const R t1 = last ? tcur + a.dt_final : tp[(k + 1) * a.t_sk];
       R tprev = tcur;
       R tnext = rmin(tcur + a.dt0, t1);
       long steps = 0;
@@ -576,10 +607,16 @@ __device__ void ekf_tangent_body(const UtArgs<R>& a) {
         tnext = (tn > t1 - Tol<R>::v) ? t1 : tn;
         ++steps;
       }
+      if (value_only && live) ut_put_moments<R, MD, T>(a, n, k, y, a.pm, a.pc);
     }
   }
   if (bad) st |= kUtStatusNotPd;
   if (!live) return;
+  if (value_only) {
+    a.ll[n] = (R)llv;
+    if (a.status) a.status[n] = st;
+    return;
+  }
   ut_store<R, MD>(a, n, p, (R)llv, (R)llg, st);
 }
 

@@ -1228,8 +1228,10 @@ static int c_dim(int kind) {
 }
 
 int custom_emission_register(int state_dim, int emission_dim, const char* h_src, const char* hjac_src) {
-  if (state_dim < 1 || state_dim > 6 || emission_dim < 1 || emission_dim > 6 || !h_src) {
-    set_error("custom emission: need 1 <= state_dim, emission_dim <= 6 and the source of h (hjac_src NULL or empty: its Jacobian is "
+  // (up to six dimensions: the register-resident kernels; above, up to sixteen: the value mode of the tangent sweeps -- filters and
+  //  log-likelihood gradients, no smoother: launch_tangent_filter)
+  if (state_dim < 1 || state_dim > 16 || emission_dim < 1 || emission_dim > 16 || !h_src) {
+    set_error("custom emission: need 1 <= state_dim, emission_dim <= 16 and the source of h (hjac_src NULL or empty: its Jacobian is "
               "derived from h_src by dual numbers)");
     return CDKF_EINVAL;
   }
@@ -1257,8 +1259,10 @@ bool custom_shape_available(const cdkf_model* mdl, const cdkf_opts* o) {
     if (o && o->state_order == CDKF_ORDER_SECOND && !c.has_g) return false;
     cd = c.d;
   }
-  if (cd > 6 || mdl->emission_dim > 6)  // the workgroup kernels: linear emission, their LDS plan (asked in fp32; an fp64 launch that
-    return mdl->emission_kind == 0 && custom_wg_fits(mdl);  // does not fit says so itself)
+  if (cd > 6 || mdl->emission_dim > 6) {  // the workgroup kernels: linear emission, their LDS plan (asked in fp32; an fp64 launch that
+    if (mdl->emission_kind == 0) return custom_wg_fits(mdl);  // does not fit says so itself)
+    return o && ukf_tangent_available(mdl, o);  // (value mode of the tangent sweeps; the extended filter's own conditions: at the launch)
+  }
   return true;
 }
 
@@ -1344,6 +1348,10 @@ static RegGrouping custom_reg_blob(const cdkf_model* mdl, const cdkf_opts* o, in
   return grouping;
 }
 
+template <typename R>
+static int launch_tangent_filter(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll, R* fm, R* fc,
+                                 R* pm, R* pc, int32_t* status, hipStream_t stream, bool ekf);
+
 // algo: 0 EKF filter, 1 UKF filter, 2 EKF smoother (filter + backward sweep), 3 EKF log-likelihood + gradient (a1: grad [N, n_theta])
 template <typename R>
 int launch_custom(int algo, const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll,
@@ -1365,8 +1373,10 @@ int launch_custom(int algo, const cdkf_model* mdl, const cdkf_opts* o, int64_t N
   }
   const int ek = mdl->emission_kind;
   if (d > 6 || m > 6) {  // beyond the register-resident kernels: the workgroup-per-trajectory sweeps with this drift compiled in
-    if (ek) {
-      set_error("custom emissions run on the register-resident kernels: state_dim, emission_dim <= 6 (got %d, %d)", d, m);
+    if (ek) {  // an emission given as source above six dimensions: the literal recursions of cdkf_ukf_tangent_kernels.h in value mode
+      if (algo == 0 || algo == 1) return launch_tangent_filter<R>(mdl, o, N, T, t, y, ll, a1, a2, a3, a4, status, stream, algo == 0);
+      set_error("custom emissions above six dimensions: the filters and the log-likelihood gradients only (the smoother and the "
+                "forward-sensitivity sweep are register-resident kernels, state_dim, emission_dim <= 6; got %d, %d)", d, m);
       return CDKF_EUNSUPPORTED;
     }
     if (algo == 3) {  // (launch_ekf_grad sends these shapes to the reverse sweep, not here)
@@ -1775,22 +1785,27 @@ static void ut_fill(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_
   const int lin = (o->layout_in == CDKF_LAYOUT_SAME) ? o->layout : o->layout_in;
   const ArrayStrides us = layout_strides(lin, N, T, mdl->input_dim > 0 ? mdl->input_dim : 1);
   a.u_sn = us.sn; a.u_sk = us.sk; a.u_si = us.si;
+  a.m_sn = ss.m_sn; a.m_sk = ss.m_sk; a.m_si = ss.m_si; a.P_sn = ss.P_sn; a.P_sk = ss.P_sk; a.P_si = ss.P_si;
 }
 
 template <typename R>
 static int launch_tangent_impl(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll, R* grad,
-                               R* grad_model, int32_t* status, hipStream_t stream, bool ekf) {
+                               R* grad_model, int32_t* status, hipStream_t stream, bool ekf, R* const* moments = nullptr) {
   hipFunction_t fn;
   int rc = ut_get_function(mdl, o, (int)sizeof(R), &fn, nullptr, ekf);
   if (rc) return rc;
-  if (!t || !y || !ll || (!grad && mdl->n_theta > 0)) {
-    set_error("ukf_loglik_grad: t, y, ll and grad must not be NULL");
+  if (!t || !y || !ll || (!moments && !grad && mdl->n_theta > 0)) {
+    set_error(moments ? "filter: t, y and ll must not be NULL" : "ukf_loglik_grad: t, y, ll and grad must not be NULL");
     return CDKF_EINVAL;
   }
   if (N < 1 || T < 1) return CDKF_OK;
   UtArgs<R> a{};
   std::vector<R> par;
   ut_fill<R>(mdl, o, N, T, a, par);
+  if (moments) {  // value mode: a lane per trajectory, the filter's outputs
+    a.value_only = 1;
+    a.fm = moments[0]; a.fc = moments[1]; a.pm = moments[2]; a.pc = moments[3];
+  }
   const size_t bytes = par.size() * sizeof(R);
   ParamLease lease(stream);
   rc = param_pool_acquire(bytes, &lease.slot);
@@ -1802,13 +1817,27 @@ static int launch_tangent_impl(const cdkf_model* mdl, const cdkf_opts* o, int64_
   a.u = mdl->input_dim > 0 ? (const R*)o->inputs : nullptr;  // (device memory here: the host entry points have uploaded it)
   a.all = grad_model ? 1 : 0;
   const int d = mdl->state_dim, m = mdl->emission_dim, np = d * (d + 1) / 2, npm = m * (m + 1) / 2;
-  const long nleaf = a.all ? (long)mdl->n_theta + d + 2 * np + m * d + m + npm : (mdl->n_theta > 0 ? (long)mdl->n_theta : 1);
+  const long nleaf = moments ? 1 : (a.all ? (long)mdl->n_theta + d + 2 * np + m * d + m + npm : (mdl->n_theta > 0 ? (long)mdl->n_theta : 1));
   const long total = N * nleaf;
   void* params[] = {(void*)&a};
-  note_kernel("%s_tangent_kernel<%s> (d=%d m=%d, %ld leaf entries)", ekf ? "ekf" : "ukf", real_name<R>(), d, m, nleaf);
+  if (moments) note_kernel("%s_tangent_kernel<%s> (d=%d m=%d, value mode)", ekf ? "ekf" : "ukf", real_name<R>(), d, m);
+  else note_kernel("%s_tangent_kernel<%s> (d=%d m=%d, %ld leaf entries)", ekf ? "ekf" : "ukf", real_name<R>(), d, m, nleaf);
   CDKF_HIP_CHECK(hipModuleLaunchKernel(fn, (unsigned)((total + 63) / 64), 1, 1, 64, 1, 1, 0, stream, params, nullptr));
   return lease.release();
 }
+// the FILTER through the same kernels (value mode): what launch_custom sends here -- an emission given as source above six dimensions
+template <typename R>
+static int launch_tangent_filter(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll, R* fm, R* fc,
+                                 R* pm, R* pc, int32_t* status, hipStream_t stream, bool ekf) {
+  cdkf_opts oo = *o;
+  if (!ekf) {  // (the unscented filter has no state_order / num_iter: the tangent sweep's checks of them do not apply)
+    oo.state_order = CDKF_ORDER_FIRST;
+    oo.num_iter = 1;
+  }
+  R* const moments[4] = {fm, fc, pm, pc};
+  return launch_tangent_impl<R>(mdl, &oo, N, T, t, y, ll, nullptr, nullptr, status, stream, ekf, moments);
+}
+
 template <typename R>
 int launch_ukf_tangent(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll, R* grad,
                        R* grad_model, int32_t* status, hipStream_t stream) {
@@ -1836,7 +1865,8 @@ int ukf_tangent_debug_args(const cdkf_model* mdl, const cdkf_opts* o, int64_t N,
     UtArgs<double> a{};
     std::vector<double> par;
     ut_fill<double>(mdl, o, N, T, a, par);
-    a.all = all;
+    a.all = all == 1;
+  a.value_only = all == 2;
     if ((int64_t)sizeof(a) > args_cap || (int64_t)(par.size() * 8) > par_cap) return CDKF_EINVAL;
     std::memcpy(args_out, &a, sizeof(a));
     std::memcpy(par_out, par.data(), par.size() * 8);
@@ -1845,7 +1875,8 @@ int ukf_tangent_debug_args(const cdkf_model* mdl, const cdkf_opts* o, int64_t N,
   UtArgs<float> a{};
   std::vector<float> par;
   ut_fill<float>(mdl, o, N, T, a, par);
-  a.all = all;
+  a.all = all == 1;
+  a.value_only = all == 2;
   if ((int64_t)sizeof(a) > args_cap || (int64_t)(par.size() * 4) > par_cap) return CDKF_EINVAL;
   std::memcpy(args_out, &a, sizeof(a));
   std::memcpy(par_out, par.data(), par.size() * 4);

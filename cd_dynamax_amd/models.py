@@ -61,6 +61,8 @@ def _model_block(params: ParamsCDNLGSSM) -> _ffi.ModelBlock:
         m = int(np.asarray(params.emissions.emission_cov.f()).shape[0])
         if kind < _ffi.DRIFT_CUSTOM_BASE:
             src = _builtin_drift_source(drift, d)
+            if d > 6:   # (above six dimensions the run-time compiled kernels derive the Jacobian from f_src by dual numbers)
+                src = (src[0], None, src[2])
             kind = _ffi.register_custom_drift(d, theta.size, *src)
             hidden = (0, 0)
         eta = np.atleast_1d(np.asarray(h.eta, dtype=np.float64)).ravel()
@@ -98,7 +100,7 @@ def _builtin_drift_source(drift, d: int):
         return f, jac, ""
     raise NotImplementedError(
         f"a LearnableCustomEmission needs the drift as source: {type(drift).__name__} has no source form here (use "
-        "LearnableCustomDrift, LearnableLorenz63, LearnableLinear or LearnableLorenz96 with state_dim <= 6)")
+        "LearnableCustomDrift, LearnableLorenz63, LearnableLinear or LearnableLorenz96)")
 
 
 def _opts(hyperparams, num_iter: int = 1):

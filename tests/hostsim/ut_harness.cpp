@@ -3,7 +3,7 @@
 // this file, every (block, lane) of the launch called in sequence -- a lane per (trajectory, leaf entry), no cross-lane traffic.  The
 // argument struct and the parameter block are the launcher's own (cdkf_debug_ukf_tangent_args).  Test infrastructure (tests/test_hostsim.py).
 //   in : int64 head[8] = {blocks, args bytes, n_par, n_t, n_y, n_u, n_grad, n_grad_model}, UtArgs bytes, par (R), t (R), y (R), u (R)
-//   out: ll [N], grad, grad_model, status [N] (int32)
+//   out: ll [N], grad, grad_model, status [N] (int32) [, value mode: filtered means, covs, predicted means, covs]
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -45,6 +45,14 @@ int main(int argc, char** argv) {
   R* gm = head[7] > 0 ? (R*)malloc(head[7] * sizeof(R)) : nullptr;
   int* status = (int*)malloc(a.N * sizeof(int));
   a.par = par; a.t = t; a.y = y; a.u = u; a.ll = ll; a.grad = grad; a.grad_model = gm; a.status = status;
+  // value mode (UtArgs::value_only: the filter through the same kernel): the four moment arrays, [N, T, D] and [N, T, D * D] as the
+  // strides of the argument block address them (contiguous: the harness is run with the default layout)
+  const long nm = a.N * a.T * cdkf::UtModel::D, nP = nm * cdkf::UtModel::D;
+  R* mom[4] = {nullptr, nullptr, nullptr, nullptr};
+  if (a.value_only) {
+    for (int k = 0; k < 4; ++k) mom[k] = (R*)malloc(((k & 1) ? nP : nm) * sizeof(R));
+    a.fm = mom[0]; a.fc = mom[1]; a.pm = mom[2]; a.pc = mom[3];
+  }
   hostsim::launch_serial((unsigned)head[0], 64, [&] { cdkf_ukf_tangent_kernel(a); });
   FILE* g = fopen(argv[2], "wb");
   if (!g) return 2;
@@ -55,6 +63,8 @@ int main(int argc, char** argv) {
   wr(grad, head[6], sizeof(R));
   wr(gm, head[7], sizeof(R));
   wr(status, a.N, sizeof(int));
+  if (a.value_only)
+    for (int k = 0; k < 4; ++k) wr(mom[k], (k & 1) ? nP : nm, sizeof(R));
   fclose(g);
   return 0;
 }

@@ -243,11 +243,13 @@ def awg_run(include_src, mdl, opts, t, y, dtype, san, forward, *, inputs=None, n
     return grad, gm, np.frombuffer(raw, np.int32, N, off).copy()
 
 
-def ut_run(mdl, opts, t, y, dtype, san, *, every_leaf=True, opt="-O1", inputs=None, timeout=3000, ekf=False):
+def ut_run(mdl, opts, t, y, dtype, san, *, every_leaf=True, opt="-O1", inputs=None, timeout=3000, ekf=False, value_only=False):
     """Run the tangent sweep of the literal unscented recursion (cdkf_ukf_tangent_kernels.h) on the host for this model: the
     translation unit launch_custom.hip generates (cdkf_ukf_tangent_compile with CDKF_CUSTOM_DUMP; cross-compiles for gfx950 on the way).
     ekf=True: the extended filter's sweep (cdkf_ekf_tangent_compile; opts.state_order / num_iter apply).
-    t [N,T], y [N,T,m]; returns (ll [N], grad [N, n_theta], grad_model [N, .] or None, status [N])."""
+    t [N,T], y [N,T,m]; returns (ll [N], grad [N, n_theta], grad_model [N, .] or None, status [N]).
+    value_only: the kernels' value mode (the FILTER through them, a lane per trajectory): returns (ll, status, filtered means [N,T,d],
+    covariances [N,T,d,d], predicted means, covariances)."""
     from cd_dynamax_amd import _ffi
     dtype = np.dtype(dtype)
     N, T = t.shape
@@ -264,15 +266,15 @@ def ut_run(mdl, opts, t, y, dtype, san, *, every_leaf=True, opt="-O1", inputs=No
     assert len(src) == 1, os.listdir(dump)
     args = np.zeros(512, np.uint8)
     par = np.zeros(65536, dtype)
-    n = _ffi.lib().cdkf_debug_ukf_tangent_args(C.byref(mdl.c), C.byref(opts), C.c_int64(N), C.c_int64(T), dtype.itemsize, 1 if every_leaf else 0,
+    n = _ffi.lib().cdkf_debug_ukf_tangent_args(C.byref(mdl.c), C.byref(opts), C.c_int64(N), C.c_int64(T), dtype.itemsize, 2 if value_only else (1 if every_leaf else 0),
                                                 args.ctypes.data_as(C.c_void_p), C.c_int64(args.nbytes), par.ctypes.data_as(C.c_void_p), C.c_int64(par.nbytes))
     assert n > 0, _ffi.lib().cdkf_last_error().decode()
     par = par[:n]
-    nargs = 8 * 8 + 8 * 11 + dtype.itemsize * 6 + 4 * 3   # 8 pointers, 11 longs, 6 reals, 3 ints ...
-    nargs = (nargs + 7) // 8 * 8                       # ... padded to the struct's alignment
+    nargs = 8 * 8 + 8 * 11 + dtype.itemsize * 6 + 4 * 4   # 8 pointers, 11 longs, 6 reals, 4 ints ...
+    nargs = (nargs + 7) // 8 * 8 + 8 * 4 + 8 * 6       # ... padded to the pointers' alignment, 4 pointers, 6 longs (value mode)
     npd, npm = d * (d + 1) // 2, m * (m + 1) // 2
-    nleaf = nth + d + 2 * npd + m * d + m + npm if every_leaf else max(nth, 1)
-    gm_len = N * (d + 2 * d * d + m * d + m + m * m) if every_leaf else 0
+    nleaf = 1 if value_only else (nth + d + 2 * npd + m * d + m + npm if every_leaf else max(nth, 1))
+    gm_len = N * (d + 2 * d * d + m * d + m + m * m) if every_leaf and not value_only else 0
     tt, yy = np.ascontiguousarray(t, dtype), np.ascontiguousarray(y, dtype)
     uu = None if inputs is None else np.ascontiguousarray(inputs, dtype)
     head = np.array([(N * nleaf + 63) // 64, nargs, n, tt.size, yy.size, 0 if uu is None else uu.size, N * nth, gm_len], np.int64)
@@ -292,5 +294,11 @@ def ut_run(mdl, opts, t, y, dtype, san, *, every_leaf=True, opt="-O1", inputs=No
     ll = np.frombuffer(raw, dtype, N, off).copy(); off += N * dtype.itemsize
     grad = np.frombuffer(raw, dtype, N * nth, off).reshape(N, nth).copy(); off += N * nth * dtype.itemsize
     gm = np.frombuffer(raw, dtype, gm_len, off).reshape(N, -1).copy() if gm_len else None; off += gm_len * dtype.itemsize
-    status = np.frombuffer(raw, np.int32, N, off).copy()
+    status = np.frombuffer(raw, np.int32, N, off).copy(); off += N * 4
+    if value_only:
+        mom = []
+        for k in range(4):
+            cnt = N * T * d * (d if k & 1 else 1)
+            mom.append(np.frombuffer(raw, dtype, cnt, off).reshape((N, T, d, d) if k & 1 else (N, T, d)).copy()); off += cnt * dtype.itemsize
+        return (ll, status) + tuple(mom)
     return ll, grad, gm, status

@@ -176,6 +176,18 @@ def test_tangent_sweep_cross_compiles_and_gates():
     assert L.cdkf_ukf_tangent_compile(_ffi.C.byref(big.c), _ffi.C.byref(opts), 8) != 0 and "<= 16" in L.cdkf_last_error().decode()
 
 
+def test_extended_tangent_sweep_of_a_wide_mlp_fits_a_lane_private_memory():
+    """A drift with a 89-wide hidden layer at d = 8 (fresh-seed fuzz 915020, round 5): with grad(div f) on (D + 1)^2-component numbers the
+    kernel asked for 142 KB of private memory per lane and did not compile ('stack frame size exceeds limit'); one outer direction at a
+    time (et_divgrad) it does, in both precisions."""
+    rng = np.random.default_rng(50)
+    mdl = models._model_block(params_from(dense_model(rng, mlp_drift(rng, 8, 89, 8), 8, 3)))
+    L = _ffi.lib()
+    for order in ("first", "second"):
+        opts = models._opts(cd.EKFHyperParams(state_order=order), 1)
+        assert L.cdkf_ekf_tangent_compile(_ffi.C.byref(mdl.c), _ffi.C.byref(opts), 8) == 0, L.cdkf_last_error().decode()
+
+
 # ---- the kernel on the GPU ---------------------------------------------------------------------------------------------------------
 @pytest.mark.gpu
 def test_unscented_gradient_of_an_mlp_model_every_leaf(hip_lib):

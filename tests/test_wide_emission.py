@@ -1,0 +1,135 @@
+"""Emissions given as source ABOVE the register-resident kernels' six dimensions (VERDICT r4 "missing" 5): the filters run the literal
+recursions of csrc/cdkf_ukf_tangent_kernels.h in VALUE mode (a lane per trajectory, no seed, the moments written as the filter entry
+points deliver them), their gradients come from the same kernels' tangent mode.  The reference takes any callable as emission_function
+(cdnlgssm_utils.py:163-189) and linearises it with jacfwd (inference_ekf.py:258, 277-286) / evaluates it at the sigma points
+(inference_ukf.py:162-203) whatever the dimensions are."""
+import numpy as np
+import pytest
+
+import cdkf_oracle as o
+import cd_dynamax_amd as cd
+from cd_dynamax_amd import _ffi, models
+from helpers import lorenz96_model, relerr
+
+KEYS = ("filtered_means", "filtered_covariances", "predicted_means", "predicted_covariances")
+
+
+def wide_emission(d, m):
+    """h_r(x) = eta_r sin(x_r) + eta_{m + r} x_{r+1} x_{r+2} + x_{r+3} (indices mod d): source (temporaries typed T: the statements are
+    compiled over dual numbers) and the NumPy twin with its Jacobian."""
+    src = " ".join(f"{{ T s_ = eta[{r}] * sin(x[{r % d}]); hx[{r}] = s_ + eta[{m + r}] * x[{(r + 1) % d}] * x[{(r + 2) % d}] + x[{(r + 3) % d}]; }}"
+                   for r in range(m))
+
+    def h(x, eta):
+        return np.stack([eta[r] * np.sin(x[..., r % d]) + eta[m + r] * x[..., (r + 1) % d] * x[..., (r + 2) % d] + x[..., (r + 3) % d]
+                         for r in range(m)], -1)
+
+    def jac(x, eta):
+        H = np.zeros(x.shape[:-1] + (m, d), x.dtype)
+        for r in range(m):
+            H[..., r, r % d] += eta[r] * np.cos(x[..., r % d])
+            H[..., r, (r + 1) % d] += eta[m + r] * x[..., (r + 2) % d]
+            H[..., r, (r + 2) % d] += eta[m + r] * x[..., (r + 1) % d]
+            H[..., r, (r + 3) % d] += 1.0
+        return H
+    return src, (h, jac)
+
+
+def wide_problem(seed, d, m, N, T, span=0.25):
+    rng = np.random.default_rng(seed)
+    src, em = wide_emission(d, m)
+    eta = np.concatenate([0.5 + rng.random(m), 0.05 * rng.standard_normal(m)])
+    base = lorenz96_model(d, m)
+    full = np.concatenate([eta, np.zeros(m * d + m - eta.size)])
+    B = rng.standard_normal((m, m))
+    mdl = o.Model(base.drift, base.L, 0.5 * base.Qc, full[:m * d].reshape(m, d), full[m * d:], B @ B.T / m * 0.3 + 0.5 * np.eye(m),
+                  base.m0 + rng.standard_normal(d), base.P0, emission=em)
+    t = o.irregular_times(rng, N, T, span)
+    y = mdl.h(mdl.m0 + np.cumsum(rng.standard_normal((N, T, d)) * 0.4, axis=1)) + rng.standard_normal((N, T, m))
+    P = cd.ParamsCDNLGSSM(
+        initial=cd.ParamsLGSSMInitial(cd.LearnableVector(mdl.m0), cd.LearnableMatrix(mdl.P0)),
+        dynamics=cd.ParamsCDNLGSSMDynamics(cd.LearnableLorenz96(8.0), cd.LearnableMatrix(mdl.L), cd.LearnableMatrix(mdl.Qc), 2.0),
+        emissions=cd.ParamsCDNLGSSMEmissions(cd.LearnableCustomEmission(eta, src, None), cd.LearnableMatrix(mdl.R)))
+    return mdl, P, t, y, eta
+
+
+@pytest.mark.parametrize("ekf", [True, False])
+def test_value_mode_on_the_host_under_asan_equals_the_oracle_filter(ekf):
+    """The generated translation unit of the d = 8, m = 7 model, host build under AddressSanitizer, value mode: log-likelihood and the
+    four moment arrays against the oracle's filter at 1e-11 (extended: state_order 'second', two update iterations)."""
+    import hostsim_util as hs
+    if hs.clang() is None:
+        pytest.skip("no clang++ for the host build")
+    mdl_o, P, t, y, _ = wide_problem(61, 8, 7, 2, 4)
+    mdl = models._model_block(P)
+    if ekf:
+        opts = models._opts(cd.EKFHyperParams(state_order="second"), 2)
+        ref = o.ekf_filter(mdl_o, t, y, "second", 2)
+    else:
+        opts = models._opts(cd.UKFHyperParams(), 1)
+        ref = o.ukf_filter(mdl_o, t, y)
+    ll, st, fm, fc, pm, pc = hs.ut_run(mdl, opts, t, y, np.float64, "asan", ekf=ekf, value_only=True)
+    assert (st == 0).all()
+    np.testing.assert_allclose(ll, ref["marginal_loglik"], rtol=1e-11)
+    for got, k in zip((fm, fc, pm, pc), KEYS):
+        assert relerr(got, ref[k]) < 1e-11, k
+
+
+def test_wide_emission_registers_and_gates():
+    """Registration up to sixteen dimensions, refusal beyond; the shape query follows; the tangent translation unit cross-compiles."""
+    L = _ffi.lib()
+    src, _ = wide_emission(8, 7)
+    assert _ffi.register_custom_emission(8, 7, src, None) >= 1000
+    with pytest.raises(Exception):
+        _ffi.register_custom_emission(17, 3, "hx[0] = x[0]; hx[1] = x[1]; hx[2] = x[2];", None)
+    _, P, _, _, _ = wide_problem(62, 8, 7, 1, 2)
+    mdl = models._model_block(P)
+    import ctypes as C
+    for ekf in (False, True):
+        opts = models._opts(cd.EKFHyperParams(state_order="first") if ekf else cd.UKFHyperParams(), 1)
+        fn = L.cdkf_ekf_tangent_compile if ekf else L.cdkf_ukf_tangent_compile
+        assert fn(C.byref(mdl.c), C.byref(opts), 8) == 0, L.cdkf_last_error().decode()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,m", [(8, 7), (5, 9), (12, 3)])
+def test_filters_with_a_source_emission_above_six_dimensions(hip_lib, d, m):
+    mdl, P, t, y, _ = wide_problem(63 + d, d, m, 6, 12)
+    for order, num_iter in ((("first", 1), ("second", 2)) if d <= 8 else (("first", 3),)):
+        ref = o.ekf_filter(mdl, t, y, order, num_iter)
+        post = cd.cdnlgssm_filter(P, y, t[..., None], cd.EKFHyperParams(state_order=order), num_iter=num_iter)
+        assert _ffi.lib().cdkf_last_kernel().decode().startswith("ekf_tangent_kernel<double>"), _ffi.lib().cdkf_last_kernel()
+        np.testing.assert_allclose(post.marginal_loglik, ref["marginal_loglik"], rtol=1e-10)
+        for k in KEYS:
+            assert relerr(getattr(post, k), ref[k]) < 1e-9, (order, num_iter, k)
+    refu = o.ukf_filter(mdl, t, y)
+    postu = cd.cdnlgssm_filter(P, y, t[..., None], cd.UKFHyperParams())
+    assert _ffi.lib().cdkf_last_kernel().decode().startswith("ukf_tangent_kernel<double>")
+    np.testing.assert_allclose(postu.marginal_loglik, refu["marginal_loglik"], rtol=1e-10)
+    for k in KEYS:
+        assert relerr(getattr(postu, k), refu[k]) < 1e-9, k
+    # marginal log-likelihood entry point and fp32
+    ll32 = cd.cdnlgssm_filter(P, y, t[..., None], cd.UKFHyperParams(), dtype=np.float32).marginal_loglik
+    assert relerr(ll32, refu["marginal_loglik"]) < 1e-4
+    with pytest.raises(NotImplementedError):
+        cd.cdnlgssm_smoother(P, y, t[..., None], cd.EKFHyperParams(state_order="first"))
+
+
+@pytest.mark.gpu
+def test_gradients_with_a_source_emission_above_six_dimensions(hip_lib):
+    """d ll / d eta and d ll / d F (Lorenz-96's forcing) of both filters at d = 8, m = 7: the tangent mode of the same kernels against
+    central differences of the value mode."""
+    mdl, P, t, y, eta = wide_problem(71, 8, 7, 3, 8)
+    for hyper in (cd.EKFHyperParams(state_order="first"), cd.UKFHyperParams()):
+        ll, g = cd.cdnlgssm_loglik_and_grad_all(P, y, t[..., None], hyper)
+        ll_of = lambda Pv: np.asarray(cd.cdnlgssm_filter(Pv, y, t[..., None], hyper).marginal_loglik)
+        ll0 = ll_of(P)
+        np.testing.assert_allclose(ll, ll0, rtol=1e-12)
+        got = np.asarray(g.emissions.emission_function.eta)
+        for pidx in (0, 3, 9, 13):
+            e = np.zeros_like(eta)
+            e[pidx] = 1e-5
+            w = lambda ev: P._replace(emissions=cd.ParamsCDNLGSSMEmissions(cd.LearnableCustomEmission(ev, P.emissions.emission_function.h_src, None),
+                                                                           P.emissions.emission_cov))
+            fd = (ll_of(w(eta + e)) - ll_of(w(eta - e))) / 2e-5
+            assert np.abs(got[:, pidx] - fd).max() < 1e-6 * max(1.0, np.abs(fd).max()), (type(hyper).__name__, pidx, got[:, pidx], fd)
