@@ -1516,7 +1516,8 @@ int custom_compile_check(int kind, int bytes_per_real, int emission_dim, int alg
   std::vector<char> code;
   if (c.d > 6 || emission_dim > 6) {  // the workgroup kernels (dense emission matrix assumed: the larger LDS plan)
     if (emission_kind) {
-      set_error("custom drift compile check: custom emissions need state_dim, emission_dim <= 6");
+      set_error("custom drift compile check: above six dimensions a custom emission runs on the tangent kernels' value mode -- "
+                "cdkf_ukf_tangent_compile / cdkf_ekf_tangent_compile check those");
       return CDKF_EUNSUPPORTED;
     }
     if (algo == 3) {  // the reverse sweep (the forward sweep is algo 0's kernel)

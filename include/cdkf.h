@@ -318,8 +318,10 @@ int cdkf_custom_drift_register(int state_dim, int n_theta, const char* f_src, co
  * eta is the model's emission block read as a flat vector: eta[r*d + k] = cdkf_model.H[r][k], eta[m*d + r] = h_bias[r].
  * e.g. observing the sine of a pendulum angle: h_src "hx[0] = eta[0] * sin(x[0]);"  hjac_src "H[0][0] = eta[0] * cos(x[0]);"
  * Returns the value for cdkf_model.emission_kind (>= CDKF_EMISSION_CUSTOM_BASE) or a negative CDKF_E* code.  Runs on the
- * run-time compiled kernels: the drift must be a custom kind too.  EKF (re-linearised in every update iteration) and UKF
- * filters, EKF smoother; not the gradient or emission-moment entry points. */
+ * run-time compiled kernels: the drift must be a custom kind too.  state_dim, emission_dim <= 6: EKF (re-linearised in every update
+ * iteration) and UKF filters, EKF smoother, the log-likelihood gradients of both filters (cdkf_*_loglik_grad[_all]_*: every leaf,
+ * eta included, forward mode through the literal recursions).  Up to 16: the filters and those gradients -- h_src is then
+ * always compiled over dual numbers -- not the smoother.  Not the emission-moment entry points. */
 int cdkf_custom_emission_register(int state_dim, int emission_dim, const char* h_src, const char* hjac_src);
 /* compile (without loading: no GPU needed) the kernel for one variant -- algo 0 EKF filter, 1 UKF filter, 2 EKF
  * smoother, 3 the log-likelihood gradient (the forward-sensitivity sweep up to six dimensions, the reverse sweep beyond);
