@@ -1351,6 +1351,9 @@ static RegGrouping custom_reg_blob(const cdkf_model* mdl, const cdkf_opts* o, in
 template <typename R>
 static int launch_tangent_filter(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll, R* fm, R* fc,
                                  R* pm, R* pc, int32_t* status, hipStream_t stream, bool ekf);
+template <typename R>  // (launch_wg.hip)
+int launch_ekf_smoother_backward_wg(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll, R* fm,
+                                    R* fP, R* sm, R* sP, int32_t* status, hipStream_t stream);
 
 // algo: 0 EKF filter, 1 UKF filter, 2 EKF smoother (filter + backward sweep), 3 EKF log-likelihood + gradient (a1: grad [N, n_theta])
 template <typename R>
@@ -1375,8 +1378,25 @@ int launch_custom(int algo, const cdkf_model* mdl, const cdkf_opts* o, int64_t N
   if (d > 6 || m > 6) {  // beyond the register-resident kernels: the workgroup-per-trajectory sweeps with this drift compiled in
     if (ek) {  // an emission given as source above six dimensions: the literal recursions of cdkf_ukf_tangent_kernels.h in value mode
       if (algo == 0 || algo == 1) return launch_tangent_filter<R>(mdl, o, N, T, t, y, ll, a1, a2, a3, a4, status, stream, algo == 0);
-      set_error("custom emissions above six dimensions: the filters and the log-likelihood gradients only (the smoother and the "
-                "forward-sensitivity sweep are register-resident kernels, state_dim, emission_dim <= 6; got %d, %d)", d, m);
+      if (algo == 2) {  // the smoother: that forward pass (num_iter 1, inference_ekf.py:489-495), then the workgroup kernels' backward sweep,
+        if (!a1 || !a2 || !a3 || !a4) {  // which reads the filtered moments and the drift only
+          set_error("EKF smoother: filtered and smoothed output pointers must not be NULL");
+          return CDKF_EINVAL;
+        }
+        cdkf_model lin = *mdl;
+        lin.emission_kind = 0;
+        if (!custom_wg_fits(&lin)) {
+          set_error("EKF smoother with a custom emission above six dimensions: state_dim %d, emission_dim %d do not fit the workgroup "
+                    "kernels' LDS plan (the backward sweep runs there)", d, m);
+          return CDKF_EUNSUPPORTED;
+        }
+        cdkf_opts o1 = *o;
+        o1.num_iter = 1;
+        const int rc = launch_tangent_filter<R>(mdl, &o1, N, T, t, y, ll, a1, a2, nullptr, nullptr, status, stream, true);
+        return rc ? rc : launch_ekf_smoother_backward_wg<R>(&lin, o, N, T, t, y, ll, a1, a2, a3, a4, status, stream);
+      }
+      set_error("custom emissions above six dimensions: filters, smoother and the log-likelihood gradients of the tangent kernels "
+                "(the forward-sensitivity sweep is a register-resident kernel, state_dim, emission_dim <= 6; got %d, %d)", d, m);
       return CDKF_EUNSUPPORTED;
     }
     if (algo == 3) {  // (launch_ekf_grad sends these shapes to the reverse sweep, not here)

@@ -372,6 +372,25 @@ int launch_ekf_smoother_wg(const cdkf_model* mdl, const cdkf_opts* o, int64_t N,
   return rc ? rc : rc2;
 }
 
+// The backward sweep ALONE, over filtered moments already in fm / fP (launch_custom.hip: the forward pass of a model whose EMISSION is
+// given as source above six dimensions runs on the tangent kernels' value mode; the backward sweep never evaluates the emission --
+// inference_ekf.py:363-448 -- so `mdl` arrives with emission_kind 0).  Declared where it is called, not in cdkf_launch.h.
+template <typename R>
+int launch_ekf_smoother_backward_wg(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll, R* fm,
+                                    R* fP, R* sm, R* sP, int32_t* status, hipStream_t stream) {
+  cdkf_opts of = *o;
+  of.num_iter = 1;
+  WgArgs<R> a{};
+  R* blk = nullptr;
+  ParamLease lease(stream);
+  int rc = wg_prepare(a, &blk, &lease.slot, mdl, &of, N, T, stream);
+  if (rc) return rc;
+  a.t = t; a.y = y; a.ll = ll; a.fm = fm; a.fP = fP; a.pm = nullptr; a.pP = nullptr; a.sm = sm; a.sP = sP; a.status = status;
+  rc = launch_wg_dispatch<R>(a, mdl, true, stream, false);
+  const int rc2 = lease.release();
+  return rc ? rc : rc2;
+}
+
 template <typename R>
 int launch_ukf_filter_wg(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll,
                          R* fm, R* fP, R* pm, R* pP, int32_t* status, hipStream_t stream) {
@@ -772,7 +791,9 @@ template int launch_kf_pushforward<double>(const cdkf_model*, const cdkf_opts*, 
   template int launch_ukf_filter_wg<R>(const cdkf_model*, const cdkf_opts*, int64_t, int64_t, const R*, const R*, R*,  \
                                        R*, R*, R*, R*, int32_t*, hipStream_t);                                         \
   template int launch_ekf_smoother_wg<R>(const cdkf_model*, const cdkf_opts*, int64_t, int64_t, const R*, const R*,    \
-                                         R*, R*, R*, R*, R*, int32_t*, hipStream_t);
+                                         R*, R*, R*, R*, R*, int32_t*, hipStream_t);                                   \
+  template int launch_ekf_smoother_backward_wg<R>(const cdkf_model*, const cdkf_opts*, int64_t, int64_t, const R*,     \
+                                                  const R*, R*, R*, R*, R*, R*, int32_t*, hipStream_t);
 INST(float)
 INST(double)
 

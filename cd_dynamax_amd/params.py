@@ -153,7 +153,7 @@ class LearnableCustomEmission(NamedTuple):
     ``eta``: the emission's parameter vector, at most emission_dim * (state_dim + 1) entries (it travels in the H / bias
     block of the C model).  state_dim, emission_dim <= 6: every entry point.  Up to 16: the filters and the log-likelihood gradients
     (the literal recursions on dual numbers, ``csrc/cdkf_ukf_tangent_kernels.h``; ``h_src`` is then compiled over dual numbers whether
-    or not ``hjac_src`` is given: temporaries ``auto`` / ``T``); no smoother.  ``py_h`` (optional): the same function as a Python callable."""
+    or not ``hjac_src`` is given: temporaries ``auto`` / ``T``) and, for the smoother, the workgroup kernels' backward sweep.  ``py_h`` (optional): the same function as a Python callable."""
     eta: Any
     h_src: str
     hjac_src: Optional[str] = None

@@ -320,8 +320,8 @@ int cdkf_custom_drift_register(int state_dim, int n_theta, const char* f_src, co
  * Returns the value for cdkf_model.emission_kind (>= CDKF_EMISSION_CUSTOM_BASE) or a negative CDKF_E* code.  Runs on the
  * run-time compiled kernels: the drift must be a custom kind too.  state_dim, emission_dim <= 6: EKF (re-linearised in every update
  * iteration) and UKF filters, EKF smoother, the log-likelihood gradients of both filters (cdkf_*_loglik_grad[_all]_*: every leaf,
- * eta included, forward mode through the literal recursions).  Up to 16: the filters and those gradients -- h_src is then
- * always compiled over dual numbers -- not the smoother.  Not the emission-moment entry points. */
+ * eta included, forward mode through the literal recursions).  Up to 16: the same entry points on other kernels (the literal recursions
+ * of csrc/cdkf_ukf_tangent_kernels.h; the smoother's backward sweep on the workgroup kernels) -- h_src is then always compiled over dual numbers.  Not the emission-moment entry points. */
 int cdkf_custom_emission_register(int state_dim, int emission_dim, const char* h_src, const char* hjac_src);
 /* compile (without loading: no GPU needed) the kernel for one variant -- algo 0 EKF filter, 1 UKF filter, 2 EKF
  * smoother, 3 the log-likelihood gradient (the forward-sensitivity sweep up to six dimensions, the reverse sweep beyond);

@@ -1,6 +1,7 @@
 """Emissions given as source ABOVE the register-resident kernels' six dimensions (VERDICT r4 "missing" 5): the filters run the literal
 recursions of csrc/cdkf_ukf_tangent_kernels.h in VALUE mode (a lane per trajectory, no seed, the moments written as the filter entry
-points deliver them), their gradients come from the same kernels' tangent mode.  The reference takes any callable as emission_function
+points deliver them), their gradients come from the same kernels' tangent mode, the smoother is that forward pass followed by the
+workgroup kernels' backward sweep (inference_ekf.py:363-448 never evaluates the emission).  The reference takes any callable as emission_function
 (cdnlgssm_utils.py:163-189) and linearises it with jacfwd (inference_ekf.py:258, 277-286) / evaluates it at the sigma points
 (inference_ukf.py:162-203) whatever the dimensions are."""
 import numpy as np
@@ -111,8 +112,14 @@ def test_filters_with_a_source_emission_above_six_dimensions(hip_lib, d, m):
     # marginal log-likelihood entry point and fp32
     ll32 = cd.cdnlgssm_filter(P, y, t[..., None], cd.UKFHyperParams(), dtype=np.float32).marginal_loglik
     assert relerr(ll32, refu["marginal_loglik"]) < 1e-4
-    with pytest.raises(NotImplementedError):
-        cd.cdnlgssm_smoother(P, y, t[..., None], cd.EKFHyperParams(state_order="first"))
+    # the smoother: that forward pass, then the workgroup kernels' backward sweep (which reads filtered moments and the drift only)
+    for order in ("first", "second") if d <= 8 else ("first",):
+        refs = o.ekf_smoother(mdl, t, y, order)
+        posts = cd.cdnlgssm_smoother(P, y, t[..., None], cd.EKFHyperParams(state_order=order))
+        assert "ekf_smoother_wg_kernel" in _ffi.lib().cdkf_last_kernel().decode(), _ffi.lib().cdkf_last_kernel()
+        np.testing.assert_allclose(posts.marginal_loglik, refs["marginal_loglik"], rtol=1e-10)
+        for k in ("filtered_means", "filtered_covariances", "smoothed_means", "smoothed_covariances"):
+            assert relerr(getattr(posts, k), refs[k]) < 1e-9, (order, k)
 
 
 @pytest.mark.gpu
