@@ -15,9 +15,10 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-# (script, seed, cases): seeds chosen once and kept; together 48 cases (round 5: the tangent sweeps' fuzzer)
+# (script, seed, cases): seeds chosen once and kept; together 53 cases (round 5: the tangent sweeps' fuzzer, and the models whose
+# emission is given as source above six dimensions)
 SLICE = [("filters", 20261, 9), ("grads", 20262, 6), ("batches", 20263, 6), ("solvers", 20264, 6), ("misc", 20265, 5),
-         ("r03", 20266, 4), ("custom", 20267, 4), ("tangent", 20268, 8)]
+         ("r03", 20266, 4), ("custom", 20267, 4), ("tangent", 20268, 8), ("wide_emission", 20269, 5)]
 
 
 # cases the fuzzers caught with run-dependent seeds, replayed alone (the generator's draws in its order, the other cases skipped):
