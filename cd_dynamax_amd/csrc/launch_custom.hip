@@ -1261,6 +1261,11 @@ bool custom_shape_available(const cdkf_model* mdl, const cdkf_opts* o) {
   }
   if (cd > 6 || mdl->emission_dim > 6) {  // the workgroup kernels: linear emission, their LDS plan (asked in fp32; an fp64 launch that
     if (mdl->emission_kind == 0) return custom_wg_fits(mdl);  // does not fit says so itself)
+    if (o && o->forecast) {  // (forecasts never evaluate the emission: the workgroup kernels, as if it were linear)
+      cdkf_model lin = *mdl;
+      lin.emission_kind = 0;
+      return custom_wg_fits(&lin);
+    }
     return o && ukf_tangent_available(mdl, o);  // (value mode of the tangent sweeps; the extended filter's own conditions: at the launch)
   }
   return true;
@@ -1377,6 +1382,20 @@ int launch_custom(int algo, const cdkf_model* mdl, const cdkf_opts* o, int64_t N
   const int ek = mdl->emission_kind;
   if (d > 6 || m > 6) {  // beyond the register-resident kernels: the workgroup-per-trajectory sweeps with this drift compiled in
     if (ek) {  // an emission given as source above six dimensions: the literal recursions of cdkf_ukf_tangent_kernels.h in value mode
+      if (o->forecast && (algo == 0 || algo == 1)) {  // repeated _predict (inference_ekf.py:679-766, inference_ukf.py:409-505): no emission in it
+        cdkf_model lin = *mdl;
+        lin.emission_kind = 0;
+        if (!custom_wg_fits(&lin)) {
+          set_error("forecast with a custom emission above six dimensions: state_dim %d, emission_dim %d do not fit the workgroup kernels' LDS plan", d, m);
+          return CDKF_EUNSUPPORTED;
+        }
+        if (algo == 0 && o->state_order == CDKF_ORDER_SECOND && !c.has_g) {
+          set_error("custom drift without grad(div f): state_order 'second' needs it; register divgrad_src \"auto\" or use state_order 'first'");
+          return CDKF_EUNSUPPORTED;
+        }
+        return algo == 0 ? launch_ekf_filter_wg<R>(&lin, o, N, T, t, y, ll, a1, a2, a3, a4, status, stream)
+                         : launch_ukf_filter_wg<R>(&lin, o, N, T, t, y, ll, a1, a2, a3, a4, status, stream);
+      }
       if (algo == 0 || algo == 1) return launch_tangent_filter<R>(mdl, o, N, T, t, y, ll, a1, a2, a3, a4, status, stream, algo == 0);
       if (algo == 2) {  // the smoother: that forward pass (num_iter 1, inference_ekf.py:489-495), then the workgroup kernels' backward sweep,
         if (!a1 || !a2 || !a3 || !a4) {  // which reads the filtered moments and the drift only

@@ -140,3 +140,21 @@ def test_gradients_with_a_source_emission_above_six_dimensions(hip_lib):
                                                                            P.emissions.emission_cov))
             fd = (8 * (ll_of(w(eta + e)) - ll_of(w(eta - e))) - (ll_of(w(eta + 2 * e)) - ll_of(w(eta - 2 * e)))) / 12e-5   # (five-point stencil)
             assert np.abs(got[:, pidx] - fd).max() < 1e-7 * max(1.0, np.abs(fd).max()), (type(hyper).__name__, pidx, got[:, pidx], fd)
+
+
+@pytest.mark.gpu
+def test_forecast_of_a_model_with_a_source_emission_above_six_dimensions(hip_lib):
+    """Forecasts are repeated _predict (inference_ekf.py:679-766, inference_ukf.py:409-505): the emission is never evaluated, so such a
+    model's forecast runs on the workgroup kernels as if its emission were linear."""
+    mdl, P, _, _, _ = wide_problem(81, 8, 7, 1, 2)
+    rng = np.random.default_rng(82)
+    A = rng.standard_normal((8, 8))
+    m_init, P_init = mdl.m0 + rng.standard_normal(8), A @ A.T / 8 + 0.5 * np.eye(8)
+    t_init = 0.2
+    t_forecast = t_init + np.cumsum(rng.uniform(0.001, 0.02, size=12))
+    for method, hyper, tol in (("ekf", cd.EKFHyperParams(state_order="first"), 1e-9), ("ukf", cd.UKFHyperParams(), 1e-8)):
+        ref_m, ref_P = o.forecast(mdl, m_init, P_init, np.array([t_init]), t_forecast[None], method=method, state_order="first")
+        fc = cd.cdnlgssm_forecast(P, (m_init, P_init), np.array([[t_init]]), t_forecast[:, None], hyper)
+        assert "_wg_kernel" in _ffi.lib().cdkf_last_kernel().decode(), _ffi.lib().cdkf_last_kernel()
+        assert relerr(fc.forecasted_state_means, ref_m[0]) < tol, method
+        assert relerr(fc.forecasted_state_covariances, ref_P[0]) < tol, method
