@@ -112,7 +112,8 @@ SYMBOLS = (
      "cdkf_preferred_layout", "cdkf_trajectories_per_wavefront", "cdkf_malloc",
      "cdkf_free", "cdkf_memcpy_h2d", "cdkf_memcpy_d2h", "cdkf_memset", "cdkf_synchronize", "cdkf_ll_sum_f64_dev",
      "cdkf_ll_sum_f32_dev", "cdkf_emission_moments_f64", "cdkf_emission_moments_f32", "cdkf_emission_moments_f64_dev",
-     "cdkf_emission_moments_f32_dev", "cdkf_ekf_loglik_grad_f64", "cdkf_ekf_loglik_grad_f32",
+     "cdkf_emission_moments_f32_dev", "cdkf_custom_emission_moments_f64", "cdkf_custom_emission_moments_f32",
+     "cdkf_custom_emission_moments_compile", "cdkf_ekf_loglik_grad_f64", "cdkf_ekf_loglik_grad_f32",
      "cdkf_ekf_loglik_grad_f64_dev", "cdkf_ekf_loglik_grad_f32_dev", "cdkf_ukf_loglik_grad_f64", "cdkf_ukf_loglik_grad_f32",
      "cdkf_ukf_loglik_grad_f64_dev", "cdkf_ukf_loglik_grad_f32_dev", "cdkf_ukf_grad_supported", "cdkf_custom_drift_register", "cdkf_custom_drift_compile", "cdkf_custom_emission_register", "cdkf_set_kernel_source_dir",
      "cdkf_kf_smoother1_f64", "cdkf_kf_smoother1_f32", "cdkf_kf_smoother1_f64_dev", "cdkf_kf_smoother1_f32_dev",
@@ -209,6 +210,11 @@ def lib() -> C.CDLL:
         f = getattr(L, f"cdkf_emission_moments_{p}_dev")
         f.argtypes = [C.POINTER(CdkfModel), C.c_int64] + [C.c_void_p] * 5
         f.restype = C.c_int
+        f = getattr(L, f"cdkf_custom_emission_moments_{p}")
+        f.argtypes = [C.POINTER(CdkfModel), C.POINTER(CdkfOpts), C.c_int, C.c_int64] + [C.c_void_p] * 6
+        f.restype = C.c_int
+    L.cdkf_custom_emission_moments_compile.argtypes = [C.POINTER(CdkfModel), C.POINTER(CdkfOpts), C.c_int]
+    L.cdkf_custom_emission_moments_compile.restype = C.c_int
     L.cdkf_custom_drift_register.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p]
     L.cdkf_custom_drift_register.restype = C.c_int
     L.cdkf_custom_drift_compile.argtypes = [C.c_int] * 6
@@ -525,6 +531,30 @@ def loglik_grad_jumps(mdl: ModelBlock, opts: CdkfOpts, t: np.ndarray, y: np.ndar
     fn = getattr(lib(), f"cdkf_ekf_loglik_grad_jumps_{suffix}")
     check(fn(C.byref(mdl.c), C.byref(opts), N, T, _vp(t), _vp(y), _vp(jumps), _vp(ll), _vp(grad), _vp(gm), _vp(gj), _vp(gy), _vp(status)))
     return ll, grad[:, :mdl.theta.size], gm, gj, gy, status
+
+
+def custom_emission_moments(mdl: ModelBlock, opts: "CdkfOpts", ukf: bool, t: Optional[np.ndarray], inputs: Optional[np.ndarray], means: np.ndarray,
+                            covs: Optional[np.ndarray], dtype):
+    """cdkf_custom_emission_moments_<f32|f64> on host buffers: means [..., d], covs [..., d, d] or None, t [...] or None,
+    inputs [..., d_u] or None (an emission given as source: the extended and the unscented versions differ)."""
+    dtype = np.dtype(dtype)
+    suffix = {np.dtype(np.float32): "f32", np.dtype(np.float64): "f64"}[dtype]
+    d, m = mdl.state_dim, mdl.emission_dim
+    lead = means.shape[:-1]
+    mu = np.ascontiguousarray(means, dtype).reshape(-1, d)
+    rows = mu.shape[0]
+    P = None if covs is None else np.ascontiguousarray(covs, dtype).reshape(rows, d, d)
+    tt = None if t is None else np.ascontiguousarray(np.broadcast_to(np.asarray(t, dtype), lead), dtype).reshape(rows)
+    uu = None
+    if inputs is not None:
+        u = np.asarray(inputs, dtype)
+        uu = np.ascontiguousarray(np.broadcast_to(u, lead + u.shape[-1:]), dtype).reshape(rows, u.shape[-1])
+        mdl.c.input_dim = int(u.shape[-1])
+    om = np.empty((rows, m), dtype)
+    oc = None if P is None else np.empty((rows, m, m), dtype)
+    check(getattr(lib(), f"cdkf_custom_emission_moments_{suffix}")(C.byref(mdl.c), C.byref(opts), 1 if ukf else 0, rows, _vp(tt), _vp(uu), _vp(mu),
+                                                                     _vp(P), _vp(om), _vp(oc)))
+    return om.reshape(lead + (m,)), None if oc is None else oc.reshape(lead + (m, m))
 
 
 def emission_moments(mdl: ModelBlock, means: np.ndarray, covs: Optional[np.ndarray], dtype):

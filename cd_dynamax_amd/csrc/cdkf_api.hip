@@ -521,6 +521,51 @@ int emission_moments_host(const cdkf_model* mdl, int64_t rows, const R* means, c
   return CDKF_OK;
 }
 
+// (launch_custom.hip)
+template <typename R>
+int launch_custom_emission_moments(const cdkf_model* mdl, const cdkf_opts* o, int ukf, int64_t rows, const R* t, const R* u, const R* means,
+                                   const R* covs, R* out_mean, R* out_cov, hipStream_t stream);
+
+// host buffers in, host buffers out (cdkf_custom_emission_moments_*)
+template <typename R>
+int custom_emission_moments_host(const cdkf_model* mdl, const cdkf_opts* o, int ukf, int64_t rows, const R* t, const R* u, const R* means,
+                                 const R* covs, R* out_mean, R* out_cov) {
+  if (!mdl || !o || rows < 0 || (rows > 0 && (!means || !out_mean))) {
+    set_error("custom_emission_moments: bad arguments");
+    return CDKF_EINVAL;
+  }
+  const size_t d = mdl->state_dim, m = mdl->emission_dim, du = mdl->input_dim > 0 ? mdl->input_dim : 0;
+  if (du > 0 && !u && rows > 0) {
+    set_error("custom_emission_moments: the model has input_dim %d but no inputs were given", mdl->input_dim);
+    return CDKF_EINVAL;
+  }
+  const bool with_cov = covs && out_cov;
+  DevBuf dm, dP, dt, dn, om, oP;
+  int rc;
+  const size_t n = rows > 0 ? (size_t)rows : 0;
+  if ((rc = dm.alloc(n * d * sizeof(R))) || (rc = om.alloc(n * m * sizeof(R)))) return rc;
+  if (n) CDKF_HIP_CHECK(hipMemcpy(dm.p, means, n * d * sizeof(R), hipMemcpyHostToDevice));
+  if (with_cov) {
+    if ((rc = dP.alloc(n * d * d * sizeof(R))) || (rc = oP.alloc(n * m * m * sizeof(R)))) return rc;
+    if (n) CDKF_HIP_CHECK(hipMemcpy(dP.p, covs, n * d * d * sizeof(R), hipMemcpyHostToDevice));
+  }
+  if (t) {
+    if ((rc = dt.alloc(n * sizeof(R)))) return rc;
+    if (n) CDKF_HIP_CHECK(hipMemcpy(dt.p, t, n * sizeof(R), hipMemcpyHostToDevice));
+  }
+  if (du > 0) {
+    if ((rc = dn.alloc(n * du * sizeof(R)))) return rc;
+    if (n) CDKF_HIP_CHECK(hipMemcpy(dn.p, u, n * du * sizeof(R), hipMemcpyHostToDevice));
+  }
+  rc = launch_custom_emission_moments<R>(mdl, o, ukf, rows, t ? (const R*)dt.p : nullptr, du > 0 ? (const R*)dn.p : nullptr, (const R*)dm.p,
+                                         with_cov ? (const R*)dP.p : nullptr, (R*)om.p, with_cov ? (R*)oP.p : nullptr, nullptr);
+  if (rc) return rc;
+  CDKF_HIP_CHECK(hipStreamSynchronize(nullptr));
+  if (n) CDKF_HIP_CHECK(hipMemcpy(out_mean, om.p, n * m * sizeof(R), hipMemcpyDeviceToHost));
+  if (with_cov && n) CDKF_HIP_CHECK(hipMemcpy(out_cov, oP.p, n * m * m * sizeof(R), hipMemcpyDeviceToHost));
+  return CDKF_OK;
+}
+
 }  // namespace cdkf
 
 using namespace cdkf;
@@ -611,6 +656,22 @@ int cdkf_ukf_tangent_compile(const cdkf_model* mdl, const cdkf_opts* opts, int b
 }
 int cdkf_ekf_tangent_compile(const cdkf_model* mdl, const cdkf_opts* opts, int bytes_per_real) {
   return ukf_tangent_compile_check(mdl, opts, bytes_per_real, 1);
+}
+int cdkf_custom_emission_moments_compile(const cdkf_model* mdl, const cdkf_opts* opts, int bytes_per_real) {
+  if (!mdl || !opts) return CDKF_EINVAL;
+  cdkf_opts oo = *opts;  // (the integrator's settings do not matter to this kernel)
+  oo.solver = CDKF_SOLVER_DOPRI5;
+  oo.adaptive = 0;
+  oo.forecast = 0;
+  return ukf_tangent_compile_check(mdl, &oo, bytes_per_real, 2);
+}
+int cdkf_custom_emission_moments_f64(const cdkf_model* mdl, const cdkf_opts* opts, int ukf, int64_t rows, const double* t, const double* inputs,
+                                     const double* means, const double* covs, double* out_mean, double* out_cov) {
+  return custom_emission_moments_host<double>(mdl, opts, ukf, rows, t, inputs, means, covs, out_mean, out_cov);
+}
+int cdkf_custom_emission_moments_f32(const cdkf_model* mdl, const cdkf_opts* opts, int ukf, int64_t rows, const float* t, const float* inputs,
+                                     const float* means, const float* covs, float* out_mean, float* out_cov) {
+  return custom_emission_moments_host<float>(mdl, opts, ukf, rows, t, inputs, means, covs, out_mean, out_cov);
 }
 int cdkf_debug_ukf_tangent_args(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T, int bytes_per_real, int all,
                                 void* args_out, int64_t args_cap_bytes, void* par_out, int64_t par_cap_bytes) {

@@ -1674,7 +1674,112 @@ bool ekf_tangent_available(const cdkf_model* mdl, const cdkf_opts* o) {
   return ut_model_sources(mdl, o, f, h, nth, nullptr, true);
 }
 
-static std::string generate_ut_source(const cdkf_model* mdl, const std::string& f_src, const std::string& h_src, int bytes, bool ekf) {
+// The emission moments of Gaussian state marginals under an emission given as SOURCE (emissions_extended_kalman_filter,
+// inference_ekf.py:768-855: h(m), jacfwd(h) P jacfwd(h)^T + R; emissions_unscented_kalman_filter, inference_ukf.py:507-612: the sigma
+// points of (m, P) through h, weighted mean and covariance + R): a lane per (m, P) row.  Kept as TEXT of the generated translation unit
+// (it is hashed into the code-object cache key with the model's statements), after `using R = ...` and the model struct.
+static const char* kEmissionMomentsKernel = R"EM(
+struct EmArgs {
+  const R* par;  // eta = H [M, D] | h_bias [M], then R [M, M]
+  const R* t;    // [rows] or null
+  const R* u;    // [rows, DU] or null
+  const R* mu;   // [rows, D]
+  const R* P;    // [rows, D, D] or null: point estimates, means only
+  R* ym;         // [rows, M]
+  R* yc;         // [rows, M, M] or null
+  long rows;
+  R c, wm0, wc0, wi;  // sqrt(D + lambda), lambda / (D + lambda), wm0 + 1 - alpha^2 + beta, 1 / (2 (D + lambda))
+  int ukf;
+};
+namespace cdkf {
+template <typename T>
+struct EmEta {
+  const R* v;
+  __device__ T operator[](int k) const { return T(v[k]); }
+};
+}  // namespace cdkf
+extern "C" __global__ __launch_bounds__(64) void cdkf_emission_moments_kernel(const EmArgs a) {
+  using namespace cdkf;
+  typedef UtModel MD;
+  constexpr int D = MD::D, M = MD::M, DU = MD::DU;
+  const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= a.rows) return;
+  const R* eta = a.par;
+  const R* Rm = a.par + M * D + M;
+  R ub[DU > 0 ? DU : 1];
+  ub[0] = R(0);
+  for (int i = 0; i < DU; ++i) ub[i] = a.u ? a.u[r * DU + i] : R(0);
+  const R tt = a.t ? a.t[r] : R(0);
+  const R* m = a.mu + r * D;
+  R* ym = a.ym + r * M;
+  if (!a.P || !a.yc) {  // point estimates: pushed through h
+    R hx[M];
+    MD::template h<R, R>(m, EmEta<R>{eta}, hx, ub, tt);
+    for (int k = 0; k < M; ++k) ym[k] = hx[k];
+    return;
+  }
+  const R* P = a.P + r * D * D;
+  R* yc = a.yc + r * M * M;
+  if (!a.ukf) {
+    typedef Dual<R, D> J;
+    J x[D], hx[M];
+    for (int i = 0; i < D; ++i) {
+      x[i] = J(m[i]);
+      x[i].g[i] = R(1);
+    }
+    MD::template h<R, J>(x, EmEta<J>{eta}, hx, ub, tt);
+    for (int k = 0; k < M; ++k) ym[k] = hx[k].v;
+    for (int p = 0; p < M; ++p)
+      for (int q = 0; q < M; ++q) {
+        R s = Rm[p * M + q];
+        for (int i = 0; i < D; ++i) {
+          R w = R(0);
+          for (int j = 0; j < D; ++j) w += P[i * D + j] * hx[q].g[j];
+          s += hx[p].g[i] * w;
+        }
+        yc[p * M + q] = s;
+      }
+    return;
+  }
+  R L[D * D];  // lower Cholesky factor of sym(P) (jnp.linalg.cholesky symmetrises; a non-positive pivot yields NaN)
+  for (int j = 0; j < D; ++j) {
+    R s = P[j * D + j];
+    for (int k = 0; k < j; ++k) s -= L[j * D + k] * L[j * D + k];
+    const R piv = sqrt(s);
+    L[j * D + j] = piv;
+    for (int i = j + 1; i < D; ++i) {
+      R w = R(0.5) * (P[i * D + j] + P[j * D + i]);
+      for (int k = 0; k < j; ++k) w -= L[i * D + k] * L[j * D + k];
+      L[i * D + j] = w / piv;
+    }
+  }
+  R x[D], Y0[M], Yp[D][M], Ym[D][M];
+  MD::template h<R, R>(m, EmEta<R>{eta}, Y0, ub, tt);
+  for (int i = 0; i < D; ++i) {
+    for (int j = 0; j < D; ++j) x[j] = (j >= i) ? m[j] + a.c * L[j * D + i] : m[j];
+    MD::template h<R, R>(x, EmEta<R>{eta}, Yp[i], ub, tt);
+    for (int j = 0; j < D; ++j) x[j] = (j >= i) ? m[j] - a.c * L[j * D + i] : m[j];
+    MD::template h<R, R>(x, EmEta<R>{eta}, Ym[i], ub, tt);
+  }
+  R yb[M];
+  for (int k = 0; k < M; ++k) {
+    R s = R(0);
+    for (int i = 0; i < D; ++i) s += Yp[i][k] + Ym[i][k];
+    yb[k] = a.wm0 * Y0[k] + a.wi * s;
+    ym[k] = yb[k];
+  }
+  for (int p = 0; p < M; ++p)
+    for (int q = 0; q < M; ++q) {
+      R s = R(0);
+      for (int i = 0; i < D; ++i) s += (Yp[i][p] - yb[p]) * (Yp[i][q] - yb[q]) + (Ym[i][p] - yb[p]) * (Ym[i][q] - yb[q]);
+      yc[p * M + q] = a.wc0 * (Y0[p] - yb[p]) * (Y0[q] - yb[q]) + a.wi * s + Rm[p * M + q];
+    }
+}
+)EM";
+
+// variant: 0 the unscented filter's tangent sweep, 1 the extended filter's, 2 the emission moments kernel above
+static std::string generate_ut_source(const cdkf_model* mdl, const std::string& f_src, const std::string& h_src, int bytes, int variant) {
+  const bool ekf = variant == 1;
   const int d = mdl->state_dim, m = mdl->emission_dim, du = mdl->input_dim;
   std::string s;
   s += "#include \"cdkf_ukf_tangent_kernels.h\"\nnamespace cdkf {\nstruct UtModel {\n";
@@ -1686,6 +1791,7 @@ static std::string generate_ut_source(const cdkf_model* mdl, const std::string& 
   s += "  template <typename R, typename T, typename EH> static __device__ void h(const T* x, const EH& eta, T (&hx)[M], const R* u, const R t) {\n"
        "    (void)eta; (void)u; (void)t;\n#line 1 \"emission_h\"\n" + h_src + "\n  }\n};\n}  // namespace cdkf\n";
   s += "using R = " + std::string(bytes == 8 ? "double" : "float") + ";\n";
+  if (variant == 2) return s + kEmissionMomentsKernel;
   s += "extern \"C\" __global__ __launch_bounds__(64) void cdkf_ukf_tangent_kernel(const cdkf::UtArgs<R> a) { cdkf::" + std::string(ekf ? "ekf" : "ukf") +
        "_tangent_body<R, cdkf::UtModel>(a); }\n";   // (one entry name for both filters: the harnesses and the launcher call it)
   return s;
@@ -1693,16 +1799,23 @@ static std::string generate_ut_source(const cdkf_model* mdl, const std::string& 
 
 std::map<std::pair<int, std::string>, Compiled> g_ut_modules;  // (device, cache key)
 
-static int ut_get_function(const cdkf_model* mdl, const cdkf_opts* o, int bytes, hipFunction_t* fn, const char* arch_override, bool ekf = false) {
+static int ut_get_function(const cdkf_model* mdl, const cdkf_opts* o, int bytes, hipFunction_t* fn, const char* arch_override, int variant = 0) {
   std::string f_src, h_src, why;
   int nth = 0;
+  const bool ekf = variant == 1;
+  const char* entry = variant == 2 ? "cdkf_emission_moments_kernel" : "cdkf_ukf_tangent_kernel";
   if (!ut_model_sources(mdl, o, f_src, h_src, nth, &why, ekf)) {
+    if (variant == 2) {
+      set_error("emission moments of a custom emission: the model must be one the literal recursions take -- %s (drift_kind=%d state_dim=%d "
+                "emission_dim=%d emission_kind=%d)", why.c_str(), mdl->drift_kind, mdl->state_dim, mdl->emission_dim, mdl->emission_kind);
+      return CDKF_EUNSUPPORTED;
+    }
     set_error("%s_loglik_grad: the tangent sweep of the literal %s recursion needs %s (drift_kind=%d state_dim=%d emission_dim=%d "
               "emission_kind=%d solver=%d state_order=%d num_iter=%d)", ekf ? "ekf" : "ukf", ekf ? "extended" : "unscented", why.c_str(), mdl->drift_kind,
               mdl->state_dim, mdl->emission_dim, mdl->emission_kind, o->solver, o->state_order, o->num_iter);
     return CDKF_EUNSUPPORTED;
   }
-  const std::string src = generate_ut_source(mdl, f_src, h_src, bytes, ekf);
+  const std::string src = generate_ut_source(mdl, f_src, h_src, bytes, variant);
   std::string arch = arch_override ? arch_override : "";
   int dev = 0;
   if (!arch_override) {
@@ -1713,8 +1826,8 @@ static int ut_get_function(const cdkf_model* mdl, const cdkf_opts* o, int bytes,
   }
   // (-O1, as the workgroup variants: a loop-heavy kernel whose state lives in scratch by design; nothing to gain from unrolling it)
   const char* olevel = "-O1";
-  const std::string tag = ekf ? "ekf tangent" : "ukf tangent";
-  const std::string cache_key = rtc_cache_key(src, arch, olevel, "cdkf_ukf_tangent_kernel", tag);
+  const std::string tag = variant == 2 ? "emission moments" : ekf ? "ekf tangent" : "ukf tangent";
+  const std::string cache_key = rtc_cache_key(src, arch, olevel, entry, tag);
   std::lock_guard<std::mutex> lock(g_mutex);
   if (!arch_override) {
     auto it = g_ut_modules.find({dev, cache_key});
@@ -1760,7 +1873,7 @@ static int ut_get_function(const cdkf_model* mdl, const cdkf_opts* o, int bytes,
     hiprtcDestroyProgram(&prog);
     rtc_cache_store(cache_key, code, std::string(), tag + " d=" + std::to_string(mdl->state_dim) + " m=" + std::to_string(mdl->emission_dim) + " " + olevel);
     if (const char* dir = getenv("CDKF_CUSTOM_DUMP")) {
-      const std::string base = std::string(dir) + (ekf ? "/cdkf_ekf_tangent_" : "/cdkf_ukf_tangent_") + std::to_string(bytes) + "_" + cache_key.substr(0, 8);
+      const std::string base = std::string(dir) + (variant == 2 ? "/cdkf_emission_moments_" : ekf ? "/cdkf_ekf_tangent_" : "/cdkf_ukf_tangent_") + std::to_string(bytes) + "_" + cache_key.substr(0, 8);
       if (FILE* f = fopen((base + ".hip").c_str(), "w")) {
         fwrite(src.data(), 1, src.size(), f);
         fclose(f);
@@ -1774,7 +1887,7 @@ static int ut_get_function(const cdkf_model* mdl, const cdkf_opts* o, int bytes,
   if (arch_override) return CDKF_OK;  // (compile check: no GPU)
   Compiled m;
   CDKF_HIP_CHECK(hipModuleLoadData(&m.module, code.data()));
-  CDKF_HIP_CHECK(hipModuleGetFunction(&m.fn, m.module, "cdkf_ukf_tangent_kernel"));
+  CDKF_HIP_CHECK(hipModuleGetFunction(&m.fn, m.module, entry));
   g_ut_modules[{dev, cache_key}] = m;
   *fn = m.fn;
   return CDKF_OK;
@@ -1784,8 +1897,60 @@ static int ut_get_function(const cdkf_model* mdl, const cdkf_opts* o, int bytes,
 int ukf_tangent_compile_check(const cdkf_model* mdl, const cdkf_opts* o, int bytes_per_real, int ekf) {
   if (!mdl || !o || (bytes_per_real != 4 && bytes_per_real != 8)) return CDKF_EINVAL;
   hipFunction_t fn;
-  return ut_get_function(mdl, o, bytes_per_real, &fn, "gfx950", ekf != 0);
+  return ut_get_function(mdl, o, bytes_per_real, &fn, "gfx950", ekf);  // (ekf: 0 unscented, 1 extended, 2 the emission-moments kernel)
 }
+
+// emission moments under an emission given as source (cdkf_custom_emission_moments_*): device pointers, rows = number of (m, P) pairs;
+// covs / out_cov null: point estimates.  Declared where it is called (cdkf_api.hip), not in cdkf_launch.h.
+template <typename R>
+int launch_custom_emission_moments(const cdkf_model* mdl, const cdkf_opts* o, int ukf, int64_t rows, const R* t, const R* u, const R* means,
+                                   const R* covs, R* out_mean, R* out_cov, hipStream_t stream) {
+  if (!mdl || !o || rows < 0 || (rows > 0 && (!means || !out_mean))) {
+    set_error("custom_emission_moments: bad arguments");
+    return CDKF_EINVAL;
+  }
+  if (!mdl->emission_kind) {
+    set_error("custom_emission_moments: the model's emission is linear (cdkf_emission_moments_* serves it)");
+    return CDKF_EINVAL;
+  }
+  cdkf_opts oo = *o;  // (the integrator's settings do not matter here: ask for the model alone)
+  oo.solver = CDKF_SOLVER_DOPRI5;
+  oo.adaptive = 0;
+  oo.forecast = 0;
+  hipFunction_t fn;
+  int rc = ut_get_function(mdl, &oo, (int)sizeof(R), &fn, nullptr, 2);
+  if (rc || rows == 0) return rc;
+  const int d = mdl->state_dim, m = mdl->emission_dim;
+  std::vector<R> par;
+  for (int k = 0; k < m * d; ++k) par.push_back(R(mdl->H[k]));
+  for (int k = 0; k < m; ++k) par.push_back(R(mdl->h_bias[k]));
+  for (int k = 0; k < m * m; ++k) par.push_back(R(mdl->R[k]));
+  const size_t bytes = par.size() * sizeof(R);
+  ParamLease lease(stream);
+  rc = param_pool_acquire(bytes, &lease.slot);
+  if (rc) return rc;
+  std::memcpy(lease.slot->host, par.data(), bytes);
+  CDKF_HIP_CHECK(hipMemcpyAsync(lease.slot->dev, lease.slot->host, bytes, hipMemcpyHostToDevice, stream));
+  struct EmArgs {  // (= the struct of kEmissionMomentsKernel)
+    const R* par; const R* t; const R* u; const R* mu; const R* P; R* ym; R* yc; long rows; R c, wm0, wc0, wi; int ukf;
+  } a{};
+  a.par = (const R*)lease.slot->dev;
+  a.t = t; a.u = mdl->input_dim > 0 ? u : nullptr; a.mu = means; a.P = (covs && out_cov) ? covs : nullptr; a.ym = out_mean;
+  a.yc = (covs && out_cov) ? out_cov : nullptr; a.rows = rows; a.ukf = ukf ? 1 : 0;
+  const R alpha = R(o->ukf_alpha), n = R(d), lamb = alpha * alpha * (n + R(o->ukf_kappa)) - n;
+  a.c = std::sqrt(n + lamb);
+  a.wm0 = lamb / (n + lamb);
+  a.wc0 = lamb / (n + lamb) + (R(1) - alpha * alpha + R(o->ukf_beta));
+  a.wi = R(1) / (R(2) * (n + lamb));
+  void* params[] = {(void*)&a};
+  note_kernel("emission_moments_kernel<%s> (custom emission, d=%d m=%d, %s)", real_name<R>(), d, m, ukf ? "unscented" : "extended");
+  CDKF_HIP_CHECK(hipModuleLaunchKernel(fn, (unsigned)((rows + 63) / 64), 1, 1, 64, 1, 1, 0, stream, params, nullptr));
+  return lease.release();
+}
+template int launch_custom_emission_moments<float>(const cdkf_model*, const cdkf_opts*, int, int64_t, const float*, const float*, const float*,
+                                                   const float*, float*, float*, hipStream_t);
+template int launch_custom_emission_moments<double>(const cdkf_model*, const cdkf_opts*, int, int64_t, const double*, const double*,
+                                                    const double*, const double*, double*, double*, hipStream_t);
 
 // the argument struct and the parameter block (host copies) of the tangent sweep
 template <typename R>
@@ -1832,7 +1997,7 @@ template <typename R>
 static int launch_tangent_impl(const cdkf_model* mdl, const cdkf_opts* o, int64_t N, int64_t T, const R* t, const R* y, R* ll, R* grad,
                                R* grad_model, int32_t* status, hipStream_t stream, bool ekf, R* const* moments = nullptr) {
   hipFunction_t fn;
-  int rc = ut_get_function(mdl, o, (int)sizeof(R), &fn, nullptr, ekf);
+  int rc = ut_get_function(mdl, o, (int)sizeof(R), &fn, nullptr, ekf ? 1 : 0);
   if (rc) return rc;
   if (!t || !y || !ll || (!moments && !grad && mdl->n_theta > 0)) {
     set_error(moments ? "filter: t, y and ll must not be NULL" : "ukf_loglik_grad: t, y, ll and grad must not be NULL");

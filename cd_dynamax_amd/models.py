@@ -523,7 +523,9 @@ def cdnlgssm_emissions(params: ParamsCDNLGSSM, t_states, state_means, state_covs
     emissions_extended_kalman_filter inference_ekf.py:768-855 / emissions_unscented_kalman_filter
     inference_ukf.py:507-612): ``(H m + b, H P H^T + R)`` per time point; with ``state_covs=None`` the states are point
     estimates and only the means are returned (second element None).  For the registry's linear emission the EKF and
-    UKF versions coincide, so ``hyperparams`` only selects nothing; ``t_states`` is accepted for signature parity."""
+    UKF versions coincide, so ``hyperparams`` selects nothing and ``t_states`` is accepted for signature parity; for a
+    ``LearnableCustomEmission`` (state / emission dimension <= 16) ``hyperparams`` picks the extended (jacfwd) or the unscented (sigma
+    points) version and ``t_states`` / ``inputs`` reach the statements (a kernel compiled at run time)."""
     if t_states is None:
         raise ValueError("t_states must be provided for forecasting")
     if isinstance(hyperparams, EnKFHyperParams):
@@ -531,9 +533,16 @@ def cdnlgssm_emissions(params: ParamsCDNLGSSM, t_states, state_means, state_covs
     mu = np.asarray(state_means)
     if dtype is None:
         dtype = np.float32 if mu.dtype == np.float32 else np.float64
-    if isinstance(params.emissions.emission_function, LearnableCustomEmission):
-        raise NotImplementedError("emission moments are implemented for the linear emission only")
     mdl = _model_block(params)
+    if isinstance(params.emissions.emission_function, LearnableCustomEmission):
+        # an emission given as source: h(m, u, t) and jacfwd(h) P jacfwd(h)^T + R (extended), or the sigma points of (m, P) through h
+        # (unscented) -- the two reference functions differ here; t_states [T, 1] (or [N, T, 1]) and inputs rows reach the statements
+        ukf = isinstance(hyperparams, UKFHyperParams)
+        opts = _opts(hyperparams if hyperparams is not None else EKFHyperParams(), 1)
+        t = np.asarray(t_states, dtype=np.float64)
+        t = t.reshape(t.shape[:-1]) if t.ndim >= 2 and t.shape[-1] == 1 else t
+        return _ffi.custom_emission_moments(mdl, opts, ukf, t, None if inputs is None else np.asarray(inputs), mu,
+                                            None if state_covs is None else np.asarray(state_covs), dtype)
     return _ffi.emission_moments(mdl, mu, None if state_covs is None else np.asarray(state_covs), dtype)
 
 

@@ -279,6 +279,18 @@ int cdkf_emission_moments_f64_dev(const cdkf_model* mdl, int64_t rows, const dou
                                   double* out_mean, double* out_cov, void* stream);
 int cdkf_emission_moments_f32_dev(const cdkf_model* mdl, int64_t rows, const float* means, const float* covs,
                                   float* out_mean, float* out_cov, void* stream);
+/* The same for an emission given as SOURCE (emission_kind >= CDKF_EMISSION_CUSTOM_BASE; state_dim, emission_dim <= 16), where the two
+ * reference functions differ: ukf = 0 -- emissions_extended_kalman_filter (inference_ekf.py:768-855): h(m, u, t) and
+ * jacfwd(h) P jacfwd(h)^T + R, the Jacobian from h_src by dual numbers; ukf = 1 -- emissions_unscented_kalman_filter
+ * (inference_ukf.py:507-612): the 2 d + 1 sigma points of (m, P) (opts->ukf_alpha / _beta / _kappa) through h, weighted mean and
+ * covariance + R.  Host buffers: t [rows] (NULL: 0), inputs [rows, input_dim] (NULL when input_dim is 0), means, covs (NULL: point
+ * estimates, out_cov not written) and outputs as above.  A kernel compiled at run time around the model's statements
+ * (cdkf_custom_emission_moments_compile: the build check, no GPU needed). */
+int cdkf_custom_emission_moments_f64(const cdkf_model* mdl, const cdkf_opts* opts, int ukf, int64_t rows, const double* t,
+                                     const double* inputs, const double* means, const double* covs, double* out_mean, double* out_cov);
+int cdkf_custom_emission_moments_f32(const cdkf_model* mdl, const cdkf_opts* opts, int ukf, int64_t rows, const float* t,
+                                     const float* inputs, const float* means, const float* covs, float* out_mean, float* out_cov);
+int cdkf_custom_emission_moments_compile(const cdkf_model* mdl, const cdkf_opts* opts, int bytes_per_real);
 
 /* ---- user-supplied drifts.  The reference accepts any Python callable as ParamsCDNLGSSMDynamics.drift
  *      (src/continuous_discrete_nonlinear_gaussian_ssm/cdnlgssm_utils.py:38-61); across a C ABI the drift is C source,
@@ -321,7 +333,7 @@ int cdkf_custom_drift_register(int state_dim, int n_theta, const char* f_src, co
  * run-time compiled kernels: the drift must be a custom kind too.  state_dim, emission_dim <= 6: EKF (re-linearised in every update
  * iteration) and UKF filters, EKF smoother, the log-likelihood gradients of both filters (cdkf_*_loglik_grad[_all]_*: every leaf,
  * eta included, forward mode through the literal recursions).  Up to 16: the same entry points on other kernels (the literal recursions
- * of csrc/cdkf_ukf_tangent_kernels.h; the smoother's backward sweep on the workgroup kernels) -- h_src is then always compiled over dual numbers.  Not the emission-moment entry points. */
+ * of csrc/cdkf_ukf_tangent_kernels.h; the smoother's backward sweep on the workgroup kernels) -- h_src is then always compiled over dual numbers.  Emission moments: cdkf_custom_emission_moments_*. */
 int cdkf_custom_emission_register(int state_dim, int emission_dim, const char* h_src, const char* hjac_src);
 /* compile (without loading: no GPU needed) the kernel for one variant -- algo 0 EKF filter, 1 UKF filter, 2 EKF
  * smoother, 3 the log-likelihood gradient (the forward-sensitivity sweep up to six dimensions, the reverse sweep beyond);

@@ -247,8 +247,11 @@ def test_custom_emission_pendulum_sine(hip_lib):
     assert relerr(sm.smoothed_means, refs["smoothed_means"]) < 1e-10
     p32 = cd.cdnlgssm_filter(P, y.astype(np.float32), t[..., None].astype(np.float32), cd.EKFHyperParams(state_order="first"))
     assert relerr(p32.filtered_means, o.ekf_filter(mdl, t, y, state_order="first")["filtered_means"]) < 5e-4
-    with pytest.raises(NotImplementedError):
-        cd.cdnlgssm_emissions(P, t[0][:, None], post.filtered_means[0], post.filtered_covariances[0])
+    # emission moments of the filtered marginals under the source emission (inference_ekf.py:768-855): h(m), H P H^T + R
+    ym, yc = cd.cdnlgssm_emissions(P, t[0][:, None], post.filtered_means[0], post.filtered_covariances[0])
+    Hm = mdl.Hjac(ref["filtered_means"][0])
+    assert relerr(ym, mdl.h(ref["filtered_means"][0])) < 1e-10
+    assert relerr(yc, Hm @ ref["filtered_covariances"][0] @ np.swapaxes(Hm, -1, -2) + mdl.R) < 1e-10
 
 
 @pytest.mark.gpu

@@ -158,3 +158,53 @@ def test_forecast_of_a_model_with_a_source_emission_above_six_dimensions(hip_lib
         assert "_wg_kernel" in _ffi.lib().cdkf_last_kernel().decode(), _ffi.lib().cdkf_last_kernel()
         assert relerr(fc.forecasted_state_means, ref_m[0]) < tol, method
         assert relerr(fc.forecasted_state_covariances, ref_P[0]) < tol, method
+
+
+def test_emission_moments_kernel_cross_compiles():
+    """cdkf_custom_emission_moments_compile: the kernel generated around the model's statements builds for gfx950 without a GPU, both
+    precisions; a linear emission is sent to the other entry points."""
+    import ctypes as C
+    L = _ffi.lib()
+    _, P, _, _, _ = wide_problem(91, 8, 7, 1, 2)
+    mdl = models._model_block(P)
+    opts = models._opts(cd.UKFHyperParams(), 1)
+    for nbytes in (8, 4):
+        assert L.cdkf_custom_emission_moments_compile(C.byref(mdl.c), C.byref(opts), nbytes) == 0, L.cdkf_last_error().decode()
+
+
+def sigma_point_emission_moments(mdl, m, P, alpha, beta, kappa):
+    """emissions_unscented_kalman_filter (inference_ukf.py:507-612) in NumPy on the oracle's pieces."""
+    d = mdl.d
+    lamb, w_mean, w_cov, _ = o.ukf_weights(d, alpha, beta, kappa, np.float64)
+    X = o.ukf_sigmas(m, P, lamb)                                # [N, 2 d + 1, d]
+    Y = mdl.h(X.reshape(-1, d)).reshape(X.shape[0], X.shape[1], -1)
+    ym = np.einsum("s,nsk->nk", w_mean, Y)
+    dY = Y - ym[:, None]
+    return ym, np.einsum("s,nsp,nsq->npq", w_cov, dY, dY) + mdl.R
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,m", [(8, 7), (3, 2), (16, 16)])
+def test_emission_moments_under_a_source_emission(hip_lib, d, m):
+    """cdnlgssm_emissions for a LearnableCustomEmission: the extended version (h(m), jacfwd(h) P jacfwd(h)^T + R) and the unscented one
+    (sigma points of (m, P) through h) against NumPy on the oracle's emission; point estimates; float32."""
+    mdl, P, _, _, _ = wide_problem(92 + d, d, m, 1, 2)
+    rng = np.random.default_rng(93)
+    rows = 37
+    mu = mdl.m0 + rng.standard_normal((rows, d))
+    A = rng.standard_normal((rows, d, d))
+    Pm = A @ np.swapaxes(A, -1, -2) / d + 0.3 * np.eye(d)
+    t = np.linspace(0.0, 1.0, rows)[:, None]
+    ym, yc = cd.cdnlgssm_emissions(P, t, mu, Pm, hyperparams=cd.EKFHyperParams())
+    assert _ffi.lib().cdkf_last_kernel().decode().startswith("emission_moments_kernel<double>")
+    H = mdl.Hjac(mu)
+    assert relerr(ym, mdl.h(mu)) < 1e-13 and relerr(yc, H @ Pm @ np.swapaxes(H, -1, -2) + mdl.R) < 1e-12
+    for alpha, beta, kappa in ((np.sqrt(3), 2, 1), (1.0, 0.0, 0.5)):
+        ym, yc = cd.cdnlgssm_emissions(P, t, mu, Pm, hyperparams=cd.UKFHyperParams(alpha=alpha, beta=beta, kappa=kappa))
+        rm, rc = sigma_point_emission_moments(mdl, mu, Pm, alpha, beta, kappa)
+        assert relerr(ym, rm) < 1e-11 and relerr(yc, rc) < 1e-10, (alpha, beta, kappa)
+    ym, none = cd.cdnlgssm_emissions(P, t, mu, None)
+    assert none is None and relerr(ym, mdl.h(mu)) < 1e-13
+    ym32, yc32 = cd.cdnlgssm_emissions(P, t, mu.astype(np.float32), Pm.astype(np.float32), hyperparams=cd.UKFHyperParams())
+    rm, rc = sigma_point_emission_moments(mdl, mu, Pm, np.sqrt(3), 2, 1)
+    assert ym32.dtype == np.float32 and relerr(ym32, rm) < 1e-5 and relerr(yc32, rc) < 1e-4
