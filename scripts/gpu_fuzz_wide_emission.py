@@ -1,7 +1,7 @@
 """Fuzz of the filters / smoother / gradients of models whose EMISSION is given as source above the register-resident kernels' six
 dimensions (round 5: the tangent kernels' value mode + the workgroup backward sweep): random (d, m) with max(d, m) in 7 .. 16, Lorenz-96
-or linear drift, random emission parameters, both filters (extended: random state_order / num_iter), the smoother, fp64 against the
-oracle at 1e-9; d ll / d eta against central differences of the value mode.
+or linear drift, random emission parameters, both filters (extended: random state_order / num_iter), the smoother, the emission moments of
+the filtered marginals (both reference versions), fp64 against the oracle at 1e-9; d ll / d eta against central differences of the value mode.
 python3 scripts/gpu_fuzz_wide_emission.py [seed] [cases]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,7 +10,7 @@ import numpy as np
 import cdkf_oracle as o
 import cd_dynamax_amd as cd
 from cd_dynamax_amd import _ffi
-from test_wide_emission import wide_emission, KEYS
+from test_wide_emission import wide_emission, KEYS, sigma_point_emission_moments
 
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 cases = int(sys.argv[2]) if len(sys.argv) > 2 else 10
@@ -87,6 +87,15 @@ for case in range(cases):
     refs = o.ekf_smoother(mdl, t, y, order)
     posts = cd.cdnlgssm_smoother(P, y, t[..., None], hyper)
     note("eks", max(rel(getattr(posts, k), refs[k]) for k in ("filtered_means", "filtered_covariances", "smoothed_means", "smoothed_covariances")), 1e-9, tag)
+    # emission moments of the filtered marginals, both reference versions (cdkf_custom_emission_moments_*)
+    fm, fc = np.asarray(post.filtered_means).reshape(-1, d), np.asarray(post.filtered_covariances).reshape(-1, d, d)
+    ym, yc = cd.cdnlgssm_emissions(P, np.zeros((fm.shape[0], 1)), fm, fc, hyperparams=hyper)
+    Hj = mdl.Hjac(fm)
+    note("emis_ekf", max(rel(ym, mdl.h(fm)), rel(yc, Hj @ fc @ np.swapaxes(Hj, -1, -2) + mdl.R)), 1e-11, tag)
+    if not np.isnan(np.asarray(postu.filtered_covariances)).any():
+        ym, yc = cd.cdnlgssm_emissions(P, np.zeros((fm.shape[0], 1)), fm, fc, hyperparams=cd.UKFHyperParams(alpha=alpha, beta=beta, kappa=kappa))
+        rm, rc = sigma_point_emission_moments(mdl, fm, fc, alpha, beta, kappa)
+        note("emis_ukf", max(rel(ym, rm), rel(yc, rc)), 1e-8, tag + f" a={alpha:.2f} b={beta} k={kappa}")
     if case % 3 == 0:
         ll, g = cd.cdnlgssm_loglik_and_grad_all(P, y, t[..., None], cd.EKFHyperParams(state_order="first"), num_iter=num_iter)
         got = np.asarray(g.emissions.emission_function.eta)
