@@ -208,3 +208,28 @@ def test_emission_moments_under_a_source_emission(hip_lib, d, m):
     ym32, yc32 = cd.cdnlgssm_emissions(P, t, mu.astype(np.float32), Pm.astype(np.float32), hyperparams=cd.UKFHyperParams())
     rm, rc = sigma_point_emission_moments(mdl, mu, Pm, np.sqrt(3), 2, 1)
     assert ym32.dtype == np.float32 and relerr(ym32, rm) < 1e-5 and relerr(yc32, rc) < 1e-4
+
+
+@pytest.mark.gpu
+def test_emission_moments_read_the_inputs_row_and_the_time(hip_lib):
+    """h(x, u, t) = eta_0 sin(x_0) + eta_1 u_0 t + eta_2 (the driven pendulum's emission of tests/test_ukf_tangent.py): t_states and the
+    inputs rows reach the statements (inference_ekf.py:826-845: h(state_mean, inputs[t0_idx], t0))."""
+    rng = np.random.default_rng(97)
+    eta, rows = np.array([1.2, 0.05, -0.1]), 21
+    P = cd.ParamsCDNLGSSM(
+        initial=cd.ParamsLGSSMInitial(cd.LearnableVector(np.zeros(2)), cd.LearnableMatrix(np.eye(2))),
+        dynamics=cd.ParamsCDNLGSSMDynamics(cd.LearnableCustomDrift(np.array([2.0, 0.3, 0.8]),
+                                                                   "fx[0] = x[1]; fx[1] = -theta[0] * sin(x[0]) - theta[1] * x[1] + theta[2] * u[0] * cos(t);", None, None),
+                                           cd.LearnableMatrix(np.eye(2)), cd.LearnableMatrix(0.1 * np.eye(2)), 2.0),
+        emissions=cd.ParamsCDNLGSSMEmissions(cd.LearnableCustomEmission(eta, "hx[0] = eta[0] * sin(x[0]) + eta[1] * u[0] * t + eta[2];", None),
+                                             cd.LearnableMatrix(np.array([[0.2]]))))
+    mu = rng.standard_normal((rows, 2))
+    A = rng.standard_normal((rows, 2, 2))
+    Pm = A @ np.swapaxes(A, -1, -2) + 0.2 * np.eye(2)
+    t = np.cumsum(rng.uniform(0.1, 0.4, rows))
+    u = rng.standard_normal((rows, 1))
+    ym, yc = cd.cdnlgssm_emissions(P, t[:, None], mu, Pm, inputs=u)
+    want = eta[0] * np.sin(mu[:, 0]) + eta[1] * u[:, 0] * t + eta[2]
+    Hrow = np.stack([eta[0] * np.cos(mu[:, 0]), np.zeros(rows)], -1)
+    assert relerr(ym[:, 0], want) < 1e-13
+    assert relerr(yc[:, 0, 0], np.einsum("ni,nij,nj->n", Hrow, Pm, Hrow) + 0.2) < 1e-12
