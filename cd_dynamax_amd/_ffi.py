@@ -113,6 +113,7 @@ SYMBOLS = (
      "cdkf_free", "cdkf_memcpy_h2d", "cdkf_memcpy_d2h", "cdkf_memset", "cdkf_synchronize", "cdkf_ll_sum_f64_dev",
      "cdkf_ll_sum_f32_dev", "cdkf_emission_moments_f64", "cdkf_emission_moments_f32", "cdkf_emission_moments_f64_dev",
      "cdkf_emission_moments_f32_dev", "cdkf_custom_emission_moments_f64", "cdkf_custom_emission_moments_f32",
+     "cdkf_custom_emission_moments_f64_dev", "cdkf_custom_emission_moments_f32_dev",
      "cdkf_custom_emission_moments_compile", "cdkf_ekf_loglik_grad_f64", "cdkf_ekf_loglik_grad_f32",
      "cdkf_ekf_loglik_grad_f64_dev", "cdkf_ekf_loglik_grad_f32_dev", "cdkf_ukf_loglik_grad_f64", "cdkf_ukf_loglik_grad_f32",
      "cdkf_ukf_loglik_grad_f64_dev", "cdkf_ukf_loglik_grad_f32_dev", "cdkf_ukf_grad_supported", "cdkf_custom_drift_register", "cdkf_custom_drift_compile", "cdkf_custom_emission_register", "cdkf_set_kernel_source_dir",
@@ -212,6 +213,9 @@ def lib() -> C.CDLL:
         f.restype = C.c_int
         f = getattr(L, f"cdkf_custom_emission_moments_{p}")
         f.argtypes = [C.POINTER(CdkfModel), C.POINTER(CdkfOpts), C.c_int, C.c_int64] + [C.c_void_p] * 6
+        f.restype = C.c_int
+        f = getattr(L, f"cdkf_custom_emission_moments_{p}_dev")
+        f.argtypes = [C.POINTER(CdkfModel), C.POINTER(CdkfOpts), C.c_int, C.c_int64] + [C.c_void_p] * 7
         f.restype = C.c_int
     L.cdkf_custom_emission_moments_compile.argtypes = [C.POINTER(CdkfModel), C.POINTER(CdkfOpts), C.c_int]
     L.cdkf_custom_emission_moments_compile.restype = C.c_int

@@ -673,6 +673,14 @@ int cdkf_custom_emission_moments_f32(const cdkf_model* mdl, const cdkf_opts* opt
                                      const float* means, const float* covs, float* out_mean, float* out_cov) {
   return custom_emission_moments_host<float>(mdl, opts, ukf, rows, t, inputs, means, covs, out_mean, out_cov);
 }
+int cdkf_custom_emission_moments_f64_dev(const cdkf_model* mdl, const cdkf_opts* opts, int ukf, int64_t rows, const double* t, const double* inputs,
+                                         const double* means, const double* covs, double* out_mean, double* out_cov, void* stream) {
+  return launch_custom_emission_moments<double>(mdl, opts, ukf, rows, t, inputs, means, covs, out_mean, out_cov, (hipStream_t)stream);
+}
+int cdkf_custom_emission_moments_f32_dev(const cdkf_model* mdl, const cdkf_opts* opts, int ukf, int64_t rows, const float* t, const float* inputs,
+                                         const float* means, const float* covs, float* out_mean, float* out_cov, void* stream) {
+  return launch_custom_emission_moments<float>(mdl, opts, ukf, rows, t, inputs, means, covs, out_mean, out_cov, (hipStream_t)stream);
+}
 int cdkf_debug_ukf_tangent_args(const cdkf_model* mdl, const cdkf_opts* opts, int64_t N, int64_t T, int bytes_per_real, int all,
                                 void* args_out, int64_t args_cap_bytes, void* par_out, int64_t par_cap_bytes) {
   return ukf_tangent_debug_args(mdl, opts, N, T, bytes_per_real, all, args_out, args_cap_bytes, par_out, par_cap_bytes);

@@ -290,6 +290,13 @@ int cdkf_custom_emission_moments_f64(const cdkf_model* mdl, const cdkf_opts* opt
                                      const double* inputs, const double* means, const double* covs, double* out_mean, double* out_cov);
 int cdkf_custom_emission_moments_f32(const cdkf_model* mdl, const cdkf_opts* opts, int ukf, int64_t rows, const float* t,
                                      const float* inputs, const float* means, const float* covs, float* out_mean, float* out_cov);
+/* device pointers (same shapes), asynchronous on `stream` (NULL: the default stream) */
+int cdkf_custom_emission_moments_f64_dev(const cdkf_model* mdl, const cdkf_opts* opts, int ukf, int64_t rows, const double* t,
+                                         const double* inputs, const double* means, const double* covs, double* out_mean, double* out_cov,
+                                         void* stream);
+int cdkf_custom_emission_moments_f32_dev(const cdkf_model* mdl, const cdkf_opts* opts, int ukf, int64_t rows, const float* t,
+                                         const float* inputs, const float* means, const float* covs, float* out_mean, float* out_cov,
+                                         void* stream);
 int cdkf_custom_emission_moments_compile(const cdkf_model* mdl, const cdkf_opts* opts, int bytes_per_real);
 
 /* ---- user-supplied drifts.  The reference accepts any Python callable as ParamsCDNLGSSMDynamics.drift

@@ -233,3 +233,40 @@ def test_emission_moments_read_the_inputs_row_and_the_time(hip_lib):
     Hrow = np.stack([eta[0] * np.cos(mu[:, 0]), np.zeros(rows)], -1)
     assert relerr(ym[:, 0], want) < 1e-13
     assert relerr(yc[:, 0, 0], np.einsum("ni,nij,nj->n", Hrow, Pm, Hrow) + 0.2) < 1e-12
+
+
+@pytest.mark.gpu
+def test_emission_moments_on_device_pointers(hip_lib):
+    """cdkf_custom_emission_moments_f64_dev through the library's own memory helpers equals the host-buffer entry point bit for bit."""
+    import ctypes as C
+    L = _ffi.lib()
+    mdl_o, P, _, _, _ = wide_problem(99, 8, 7, 1, 2)
+    rng = np.random.default_rng(98)
+    rows, d, m = 50, 8, 7
+    mu = mdl_o.m0 + rng.standard_normal((rows, d))
+    A = rng.standard_normal((rows, d, d))
+    Pm = A @ np.swapaxes(A, -1, -2) / d + 0.3 * np.eye(d)
+    ym_h, yc_h = cd.cdnlgssm_emissions(P, np.zeros((rows, 1)), mu, Pm, hyperparams=cd.UKFHyperParams())
+    mdl = models._model_block(P)
+    opts = models._opts(cd.UKFHyperParams(), 1)
+    bufs = []
+
+    def dev(a=None, nbytes=0):
+        p = C.c_void_p()
+        _ffi.check(L.cdkf_malloc(C.byref(p), a.nbytes if a is not None else nbytes))
+        bufs.append(p)
+        if a is not None:
+            _ffi.check(L.cdkf_memcpy_h2d(p, a.ctypes.data_as(C.c_void_p), a.nbytes))
+        return p
+    try:
+        d_mu, d_P = dev(np.ascontiguousarray(mu)), dev(np.ascontiguousarray(Pm))
+        d_ym, d_yc = dev(nbytes=rows * m * 8), dev(nbytes=rows * m * m * 8)
+        _ffi.check(L.cdkf_custom_emission_moments_f64_dev(C.byref(mdl.c), C.byref(opts), 1, rows, None, None, d_mu, d_P, d_ym, d_yc, None))
+        _ffi.check(L.cdkf_synchronize(None))
+        ym, yc = np.empty((rows, m)), np.empty((rows, m, m))
+        _ffi.check(L.cdkf_memcpy_d2h(ym.ctypes.data_as(C.c_void_p), d_ym, ym.nbytes))
+        _ffi.check(L.cdkf_memcpy_d2h(yc.ctypes.data_as(C.c_void_p), d_yc, yc.nbytes))
+    finally:
+        for p in bufs:
+            L.cdkf_free(p)
+    assert np.array_equal(ym, ym_h) and np.array_equal(yc, yc_h)
