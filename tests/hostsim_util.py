@@ -302,3 +302,46 @@ def ut_run(mdl, opts, t, y, dtype, san, *, every_leaf=True, opt="-O1", inputs=No
             mom.append(np.frombuffer(raw, dtype, cnt, off).reshape((N, T, d, d) if k & 1 else (N, T, d)).copy()); off += cnt * dtype.itemsize
         return (ll, status) + tuple(mom)
     return ll, grad, gm, status
+
+
+def em_run(mdl, opts, ukf, t, mu, P, dtype, san, *, inputs=None, opt="-O1", timeout=3000):
+    """Run the emission-moments kernel generated around this model's emission statements (launch_custom.hip: kEmissionMomentsKernel) on the
+    host: the translation unit cdkf_custom_emission_moments_compile dumps (it cross-compiles for gfx950 on the way).
+    t [rows], mu [rows, d], P [rows, d, d] or None; returns (ym [rows, m], yc [rows, m, m] or None)."""
+    from cd_dynamax_amd import _ffi
+    dtype = np.dtype(dtype)
+    d, m = mdl.state_dim, mdl.emission_dim
+    rows = mu.shape[0]
+    dump = tempfile.mkdtemp(prefix="cdkf_dump_")
+    os.environ["CDKF_CUSTOM_DUMP"] = dump
+    try:
+        rc = _ffi.lib().cdkf_custom_emission_moments_compile(C.byref(mdl.c), C.byref(opts), dtype.itemsize)
+        if rc:
+            raise RuntimeError(_ffi.lib().cdkf_last_error().decode())
+    finally:
+        del os.environ["CDKF_CUSTOM_DUMP"]
+    src = [os.path.join(dump, f) for f in os.listdir(dump) if f.endswith(".hip")]
+    assert len(src) == 1, os.listdir(dump)
+    par = np.concatenate([np.asarray(mdl.H, np.float64).ravel(), np.asarray(mdl.h_bias, np.float64).ravel(), np.asarray(mdl.R, np.float64).ravel()]).astype(dtype)
+    alpha, n = float(opts.ukf_alpha), float(d)
+    lamb = alpha * alpha * (n + float(opts.ukf_kappa)) - n
+    w = np.array([np.sqrt(n + lamb), lamb / (n + lamb), lamb / (n + lamb) + (1 - alpha * alpha + float(opts.ukf_beta)), 1 / (2 * (n + lamb))], dtype)
+    head = np.array([rows, 1 if ukf else 0, 0 if P is None else 1, par.size], np.int64)
+    exe = build("em_harness.cpp", src[0], san, opt)
+    with tempfile.TemporaryDirectory() as dd:
+        fin, fout = os.path.join(dd, "in.bin"), os.path.join(dd, "out.bin")
+        with open(fin, "wb") as f:
+            f.write(head.tobytes()); f.write(w.tobytes()); f.write(par.tobytes()); f.write(np.ascontiguousarray(t, dtype).tobytes())
+            if inputs is not None:
+                f.write(np.ascontiguousarray(inputs, dtype).tobytes())
+            f.write(np.ascontiguousarray(mu, dtype).tobytes())
+            if P is not None:
+                f.write(np.ascontiguousarray(P, dtype).tobytes())
+        res = run(exe, fin, fout, timeout=timeout)
+        reports = sanitizer_reports(res.stderr)
+        if res.returncode != 0 or reports:
+            raise AssertionError(f"host run ({san}) rc={res.returncode}\n" + res.stderr[-8000:])
+        raw = open(fout, "rb").read()
+    ym = np.frombuffer(raw, dtype, rows * m, 0).reshape(rows, m).copy()
+    yc = None if P is None else np.frombuffer(raw, dtype, rows * m * m, rows * m * dtype.itemsize).reshape(rows, m, m).copy()
+    return ym, yc

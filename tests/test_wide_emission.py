@@ -172,6 +172,33 @@ def test_emission_moments_kernel_cross_compiles():
         assert L.cdkf_custom_emission_moments_compile(C.byref(mdl.c), C.byref(opts), nbytes) == 0, L.cdkf_last_error().decode()
 
 
+@pytest.mark.parametrize("ukf", [False, True])
+def test_emission_moments_kernel_on_the_host_under_asan(ukf):
+    """The generated emission-moments kernel of the d = 8, m = 7 model, host build under AddressSanitizer: both reference versions against
+    NumPy on the oracle's emission (1e-13 / 1e-12), and point estimates."""
+    import hostsim_util as hs
+    if hs.clang() is None:
+        pytest.skip("no clang++ for the host build")
+    mdl_o, P, _, _, _ = wide_problem(94, 8, 7, 1, 2)
+    rng = np.random.default_rng(95)
+    rows, d = 70, 8                      # (two wavefronts' worth of lanes, the second partly idle)
+    mu = mdl_o.m0 + rng.standard_normal((rows, d))
+    A = rng.standard_normal((rows, d, d))
+    Pm = A @ np.swapaxes(A, -1, -2) / d + 0.3 * np.eye(d)
+    blk = models._model_block(P)
+    hyper = cd.UKFHyperParams(alpha=1.0, beta=0.0, kappa=0.5) if ukf else cd.EKFHyperParams()
+    opts = models._opts(hyper, 1)
+    ym, yc = hs.em_run(blk, opts, ukf, np.zeros(rows), mu, Pm, np.float64, "asan")
+    if ukf:
+        rm, rc = sigma_point_emission_moments(mdl_o, mu, Pm, 1.0, 0.0, 0.5)
+    else:
+        H = mdl_o.Hjac(mu)
+        rm, rc = mdl_o.h(mu), H @ Pm @ np.swapaxes(H, -1, -2) + mdl_o.R
+    assert relerr(ym, rm) < 1e-13 and relerr(yc, rc) < 1e-12
+    ym, none = hs.em_run(blk, opts, ukf, np.zeros(rows), mu, None, np.float64, "plain")
+    assert none is None and relerr(ym, mdl_o.h(mu)) < 1e-13
+
+
 def sigma_point_emission_moments(mdl, m, P, alpha, beta, kappa):
     """emissions_unscented_kalman_filter (inference_ukf.py:507-612) in NumPy on the oracle's pieces."""
     d = mdl.d
