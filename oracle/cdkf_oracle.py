@@ -907,6 +907,30 @@ def forecast(mdl: Model, m_init, P_init, t_init, t_forecast, method="ekf", state
     return means, covs
 
 
+def emission_moments(mdl: Model, state_means, state_covs=None, method="ekf", alpha=math.sqrt(3), beta=2, kappa=1, t=None, inputs=None):
+    """emissions_extended_kalman_filter (inference_ekf.py:768-855): (h(m, u, t), H P H^T + R) with H = jacfwd(h)(m, u, t) per row;
+    emissions_unscented_kalman_filter (inference_ukf.py:507-612): the sigma points of (m, P) (_compute_sigmas, :45-60) through h, weighted
+    mean (w_mean) and covariance (w_cov) + R.  state_means [rows, d], state_covs [rows, d, d] or None (point estimates: h(m) alone, second
+    element None); t [rows], inputs [rows, d_u]: this row's time and inputs for an emission that reads them (Model(emission_ut=True))."""
+    m = np.asarray(state_means, np.float64)
+    rows, d = m.shape
+    if getattr(mdl, "emission_ut", False):
+        _CTX["u"] = None if inputs is None else np.asarray(inputs, np.float64)
+        _CTX["t"] = np.zeros(rows) if t is None else np.asarray(t, np.float64).reshape(rows)
+    if state_covs is None:
+        return mdl.h(m), None
+    P = np.asarray(state_covs, np.float64)
+    if method == "ekf":
+        H = mdl.Hjac(m)
+        return mdl.h(m), H @ P @ np.swapaxes(H, -1, -2) + mdl.R
+    lamb, w_mean, w_cov, _ = ukf_weights(d, alpha, beta, kappa, np.float64)
+    X = ukf_sigmas(m, P, lamb)                                   # [rows, 2 d + 1, d]  (every sigma point of a row shares the row's inputs and time: _ctx_rows)
+    Y = mdl.h(X.reshape(-1, d)).reshape(rows, X.shape[1], -1)
+    ym = np.einsum("s,nsk->nk", w_mean, Y)
+    dY = Y - ym[:, None]
+    return ym, np.einsum("s,nsp,nsq->npq", w_cov, dY, dY) + mdl.R
+
+
 # --------------------------------------------------------------------------------------
 # linear model: smoother type 1 (discrete RTS on the pushed-forward (A, Q))
 # --------------------------------------------------------------------------------------

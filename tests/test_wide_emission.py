@@ -200,14 +200,38 @@ def test_emission_moments_kernel_on_the_host_under_asan(ukf):
 
 
 def sigma_point_emission_moments(mdl, m, P, alpha, beta, kappa):
-    """emissions_unscented_kalman_filter (inference_ukf.py:507-612) in NumPy on the oracle's pieces."""
-    d = mdl.d
-    lamb, w_mean, w_cov, _ = o.ukf_weights(d, alpha, beta, kappa, np.float64)
-    X = o.ukf_sigmas(m, P, lamb)                                # [N, 2 d + 1, d]
-    Y = mdl.h(X.reshape(-1, d)).reshape(X.shape[0], X.shape[1], -1)
-    ym = np.einsum("s,nsk->nk", w_mean, Y)
-    dY = Y - ym[:, None]
-    return ym, np.einsum("s,nsp,nsq->npq", w_cov, dY, dY) + mdl.R
+    """emissions_unscented_kalman_filter (inference_ukf.py:507-612): the oracle's restatement."""
+    return o.emission_moments(mdl, m, P, "ukf", alpha, beta, kappa)
+
+
+def test_oracle_emission_moments_against_hand_formulas():
+    """o.emission_moments pinned on a case that can be written out: h(x, u, t) = eta_0 sin(x_0) + eta_1 u_0 t + eta_2 in two dimensions --
+    the extended version is eta_0^2 cos^2(m_0) P_00 + R exactly; for a LINEAR emission both versions are (H m + b, H P H^T + R) (the
+    reference's own statement for its registry emission); point estimates return h(m)."""
+    rng = np.random.default_rng(96)
+    eta, rows = np.array([1.2, 0.05, -0.1]), 9
+    h_np = lambda x, e, u, t: (e[0] * np.sin(x[..., 0]) + e[1] * u[..., 0] * t + e[2])[..., None]
+    hj_np = lambda x, e, u, t: np.stack([e[0] * np.cos(x[..., 0]), np.zeros(x.shape[0])], -1)[..., None, :]
+    mdl = o.Model(o.LinearDrift(-np.eye(2), np.zeros(2)), np.eye(2), 0.1 * np.eye(2), eta[:2].reshape(1, 2), eta[2:], np.array([[0.2]]), np.zeros(2),
+                  np.eye(2), emission=(h_np, hj_np), emission_ut=True)
+    mu = rng.standard_normal((rows, 2))
+    A = rng.standard_normal((rows, 2, 2))
+    Pm = A @ np.swapaxes(A, -1, -2) + 0.2 * np.eye(2)
+    t, u = np.cumsum(rng.uniform(0.1, 0.4, rows)), rng.standard_normal((rows, 1))
+    ym, yc = o.emission_moments(mdl, mu, Pm, "ekf", t=t, inputs=u)
+    np.testing.assert_allclose(ym[:, 0], eta[0] * np.sin(mu[:, 0]) + eta[1] * u[:, 0] * t + eta[2], rtol=1e-14)
+    np.testing.assert_allclose(yc[:, 0, 0], eta[0] ** 2 * np.cos(mu[:, 0]) ** 2 * Pm[:, 0, 0] + 0.2, rtol=1e-13)
+    ymu, ycu = o.emission_moments(mdl, mu, Pm, "ukf", t=t, inputs=u)
+    assert ymu.shape == (rows, 1) and np.all(ycu[:, 0, 0] > 0.2) and np.abs(ymu - ym).max() < 1.5   # (the sigma-point mean: near, not equal)
+    assert o.emission_moments(mdl, mu, None, t=t, inputs=u)[1] is None
+    lin = lorenz96_model(6, 3)
+    mu6 = rng.standard_normal((rows, 6))
+    A6 = rng.standard_normal((rows, 6, 6))
+    P6 = A6 @ np.swapaxes(A6, -1, -2) / 6 + 0.3 * np.eye(6)
+    for method in ("ekf", "ukf"):
+        ym, yc = o.emission_moments(lin, mu6, P6, method)
+        np.testing.assert_allclose(ym, mu6 @ lin.H.T + lin.bias, rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(yc, lin.H @ P6 @ lin.H.T + lin.R, rtol=1e-11, atol=1e-12)
 
 
 @pytest.mark.gpu
@@ -260,6 +284,14 @@ def test_emission_moments_read_the_inputs_row_and_the_time(hip_lib):
     Hrow = np.stack([eta[0] * np.cos(mu[:, 0]), np.zeros(rows)], -1)
     assert relerr(ym[:, 0], want) < 1e-13
     assert relerr(yc[:, 0, 0], np.einsum("ni,nij,nj->n", Hrow, Pm, Hrow) + 0.2) < 1e-12
+    # the unscented version with the row's inputs and time at every sigma point, against the oracle
+    h_np = lambda x, e, uu, tt: (e[0] * np.sin(x[..., 0]) + e[1] * uu[..., 0] * tt + e[2])[..., None]
+    hj_np = lambda x, e, uu, tt: np.stack([e[0] * np.cos(x[..., 0]), np.zeros(x.shape[0])], -1)[..., None, :]
+    mdl_o = o.Model(o.LinearDrift(-np.eye(2), np.zeros(2)), np.eye(2), 0.1 * np.eye(2), eta[:2].reshape(1, 2), eta[2:], np.array([[0.2]]), np.zeros(2),
+                    np.eye(2), emission=(h_np, hj_np), emission_ut=True)
+    ymu, ycu = cd.cdnlgssm_emissions(P, t[:, None], mu, Pm, inputs=u, hyperparams=cd.UKFHyperParams())
+    rm, rc = o.emission_moments(mdl_o, mu, Pm, "ukf", t=t, inputs=u)
+    assert relerr(ymu, rm) < 1e-12 and relerr(ycu, rc) < 1e-11
 
 
 @pytest.mark.gpu
