@@ -1228,8 +1228,8 @@ static int c_dim(int kind) {
 }
 
 int custom_emission_register(int state_dim, int emission_dim, const char* h_src, const char* hjac_src) {
-  // (up to six dimensions: the register-resident kernels; above, up to sixteen: the value mode of the tangent sweeps -- filters and
-  //  log-likelihood gradients, no smoother: launch_tangent_filter)
+  // (up to six dimensions: the register-resident kernels; above, up to sixteen: the value mode of the tangent sweeps -- filters,
+  //  log-likelihood gradients; the smoother's backward sweep and the forecasts on the workgroup kernels: launch_custom's dispatch)
   if (state_dim < 1 || state_dim > 16 || emission_dim < 1 || emission_dim > 16 || !h_src) {
     set_error("custom emission: need 1 <= state_dim, emission_dim <= 16 and the source of h (hjac_src NULL or empty: its Jacobian is "
               "derived from h_src by dual numbers)");
