@@ -534,6 +534,10 @@ int custom_emission_moments_host(const cdkf_model* mdl, const cdkf_opts* o, int 
     set_error("custom_emission_moments: bad arguments");
     return CDKF_EINVAL;
   }
+  if (!mdl->emission_kind) {  // (before anything touches the device: the refusal does not need one)
+    set_error("custom_emission_moments: the model's emission is linear (cdkf_emission_moments_* serves it)");
+    return CDKF_EINVAL;
+  }
   const size_t d = mdl->state_dim, m = mdl->emission_dim, du = mdl->input_dim > 0 ? mdl->input_dim : 0;
   if (du > 0 && !u && rows > 0) {
     set_error("custom_emission_moments: the model has input_dim %d but no inputs were given", mdl->input_dim);

@@ -160,6 +160,24 @@ def test_forecast_of_a_model_with_a_source_emission_above_six_dimensions(hip_lib
         assert relerr(fc.forecasted_state_covariances, ref_P[0]) < tol, method
 
 
+def test_emission_moments_entry_points_refuse_bad_arguments_without_a_gpu():
+    """cdkf_custom_emission_moments_f64: negative row count, missing buffers and a LINEAR emission are refused with a message before any
+    device call (this box has no GPU: a device call would fail differently)."""
+    import ctypes as C
+    from helpers import params_from
+    L = _ffi.lib()
+    _, P, _, _, _ = wide_problem(90, 8, 7, 1, 2)
+    mdl = models._model_block(P)
+    opts = models._opts(cd.EKFHyperParams(), 1)
+    buf = np.zeros(64)
+    vp = buf.ctypes.data_as(C.c_void_p)
+    assert L.cdkf_custom_emission_moments_f64(C.byref(mdl.c), C.byref(opts), 0, -1, None, None, vp, None, vp, None) == _ffi.CDKF_EINVAL
+    assert L.cdkf_custom_emission_moments_f64(C.byref(mdl.c), C.byref(opts), 0, 4, None, None, None, None, vp, None) == _ffi.CDKF_EINVAL
+    lin = models._model_block(params_from(lorenz96_model(6, 3)))
+    assert L.cdkf_custom_emission_moments_f64(C.byref(lin.c), C.byref(opts), 0, 4, None, None, vp, None, vp, None) == _ffi.CDKF_EINVAL
+    assert "linear" in L.cdkf_last_error().decode()
+
+
 def test_emission_moments_kernel_cross_compiles():
     """cdkf_custom_emission_moments_compile: the kernel generated around the model's statements builds for gfx950 without a GPU, both
     precisions; a linear emission is sent to the other entry points."""
